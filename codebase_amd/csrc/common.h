@@ -1,0 +1,70 @@
+// Shared host-side plumbing of libmarlhip.so: error text, launch checks, shape dispatch.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/marlhip.h"
+#include "lbf_core.h"
+
+namespace marl {
+
+void set_error(const char* fmt, ...);
+
+#define MARL_CHECK_LAUNCH(what)                                                   \
+    do {                                                                          \
+        hipError_t e_ = hipGetLastError();                                        \
+        if (e_ != hipSuccess) {                                                   \
+            marl::set_error("%s: %s", what, hipGetErrorString(e_));               \
+            return -2;                                                            \
+        }                                                                         \
+    } while (0)
+
+#define MARL_REQUIRE(cond, ...)              \
+    do {                                     \
+        if (!(cond)) {                       \
+            marl::set_error(__VA_ARGS__);    \
+            return -1;                       \
+        }                                    \
+    } while (0)
+
+inline LbfParams to_params(const marlhip_lbf_config* c) {
+    LbfParams q;
+    q.n_envs = c->n_envs; q.n_agents = c->n_agents; q.n_food = c->n_food;
+    q.rows = c->rows; q.cols = c->cols; q.sight = c->sight;
+    q.max_episode_steps = c->max_episode_steps; q.time_limit = c->time_limit;
+    q.force_coop = c->force_coop; q.min_player_level = c->min_player_level; q.max_player_level = c->max_player_level;
+    q.min_food_level = c->min_food_level; q.max_food_level = c->max_food_level;
+    q.normalize_reward = c->normalize_reward; q.cooperative = c->cooperative;
+    q.penalty = c->penalty; q.seed = c->seed;
+    return q;
+}
+
+// (players, foods) shapes with compiled kernels.  X(P, F)
+#define MARL_LBF_SHAPES(X) X(2, 2) X(2, 3) X(3, 3) X(3, 5) X(4, 3) X(4, 5) X(8, 5)
+
+inline bool lbf_shape_supported(int P, int F) {
+#define X(p, f) if (P == p && F == f) return true;
+    MARL_LBF_SHAPES(X)
+#undef X
+    return false;
+}
+
+inline int lbf_validate(const marlhip_lbf_config* c) {
+    MARL_REQUIRE(c != nullptr, "lbf config is NULL");
+    MARL_REQUIRE(lbf_shape_supported(c->n_agents, c->n_food),
+                 "no LBF kernel for %dp-%df (add it to MARL_LBF_SHAPES in csrc/common.h and rebuild)", c->n_agents, c->n_food);
+    MARL_REQUIRE(c->n_envs > 0, "n_envs must be > 0");
+    MARL_REQUIRE(c->rows >= 3 && c->cols >= 3 && c->rows <= 255 && c->cols <= 255, "field size %dx%d out of range", c->rows, c->cols);
+    MARL_REQUIRE(c->min_player_level >= 1 && c->max_player_level >= c->min_player_level && c->max_player_level <= 20, "player level range");
+    MARL_REQUIRE(c->max_episode_steps > 0 && c->max_episode_steps < 65535, "max_episode_steps");
+    return 0;
+}
+
+// network shapes (D, H, A) with compiled MFMA kernels.  X(D, H, A)
+//   LBF obs dims: 2p2f 12, 2p3f 15, 3p3f 18, 3p5f 24, 4p3f 21, 4p5f 27, 8p5f 39
+#define MARL_NET_SHAPES(X)                                                                         \
+    X(12, 64, 6) X(15, 64, 6) X(18, 64, 6) X(21, 64, 6) X(24, 64, 6) X(27, 64, 6) X(39, 64, 6)     \
+    X(12, 128, 6) X(15, 128, 6) X(18, 128, 6) X(21, 128, 6) X(24, 128, 6) X(27, 128, 6) X(39, 128, 6)
+
+}  // namespace marl

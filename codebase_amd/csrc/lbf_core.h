@@ -1,0 +1,330 @@
+// Level-Based Foraging dynamics on a packed entity list (no dense grid).
+//
+// Replaces the reference's L0 env arithmetic: the third-party
+// lbforaging ForagingEnv.reset/step/_make_gym_obs reached through
+//   marlbase/utils/envs.py:90-97,111  (gym.make -> TimeLimit -> RecordEpisodeStatistics)
+//   marlbase/dqn/train.py:203,217     (env.reset / env.step)
+// plus the per-step wrapper arithmetic marlbase/utils/wrappers.py:31-45,106-108.
+//
+// One env = F food triples (row-major order, level 0 = eaten/absent), P player
+// triples, the step counter and the spawned-food total.  Everything is a pure
+// function of (state, joint action); only reset draws random numbers.  Header is
+// host+device so the integer logic can be exercised by a g++ build in tests/.
+#pragma once
+#include "philox.h"
+
+namespace marl {
+
+enum : int { ACT_NONE = 0, ACT_NORTH = 1, ACT_SOUTH = 2, ACT_WEST = 3, ACT_EAST = 4, ACT_LOAD = 5 };
+
+struct LbfParams {
+    int n_envs, n_agents, n_food, rows, cols, sight;
+    int max_episode_steps;  // upstream registration: 50 -> `done`
+    int time_limit;         // gymnasium TimeLimit (utils/envs.py:96) -> `truncated`; 0 = none
+    int force_coop, min_player_level, max_player_level;
+    int min_food_level, max_food_level;  // max_food_level <= 0: sum of the 3 lowest player levels
+    int normalize_reward;
+    int cooperative;  // CooperativeReward wrapper (utils/wrappers.py:106-108)
+    double penalty;
+    uint64_t seed;
+};
+
+template <int P, int F>
+struct LbfState {
+    int fr[F], fc[F], fl[F];
+    int pr[P], pc[P], pl[P];
+    int step, spawned;
+};
+
+// bytes per env record in HBM: 3F + 3P + 2 (step u16) + 2 (spawned u16), padded to 4
+MARL_HD int lbf_state_stride(int P, int F) { return (3 * F + 3 * P + 4 + 3) & ~3; }
+
+template <int P, int F>
+MARL_HD void lbf_load(const uint8_t* rec, LbfState<P, F>& s) {
+#pragma unroll
+    for (int f = 0; f < F; ++f) { s.fr[f] = rec[3 * f]; s.fc[f] = rec[3 * f + 1]; s.fl[f] = rec[3 * f + 2]; }
+#pragma unroll
+    for (int p = 0; p < P; ++p) { s.pr[p] = rec[3 * F + 3 * p]; s.pc[p] = rec[3 * F + 3 * p + 1]; s.pl[p] = rec[3 * F + 3 * p + 2]; }
+    const uint8_t* t = rec + 3 * F + 3 * P;
+    s.step = t[0] | (t[1] << 8);
+    s.spawned = t[2] | (t[3] << 8);
+}
+
+template <int P, int F>
+MARL_HD void lbf_store(uint8_t* rec, const LbfState<P, F>& s) {
+#pragma unroll
+    for (int f = 0; f < F; ++f) { rec[3 * f] = (uint8_t)s.fr[f]; rec[3 * f + 1] = (uint8_t)s.fc[f]; rec[3 * f + 2] = (uint8_t)s.fl[f]; }
+#pragma unroll
+    for (int p = 0; p < P; ++p) { rec[3 * F + 3 * p] = (uint8_t)s.pr[p]; rec[3 * F + 3 * p + 1] = (uint8_t)s.pc[p]; rec[3 * F + 3 * p + 2] = (uint8_t)s.pl[p]; }
+    uint8_t* t = rec + 3 * F + 3 * P;
+    t[0] = (uint8_t)(s.step & 0xFF); t[1] = (uint8_t)(s.step >> 8);
+    t[2] = (uint8_t)(s.spawned & 0xFF); t[3] = (uint8_t)(s.spawned >> 8);
+}
+
+// level of the food standing on (r,c), 0 if none  (== upstream field[r,c])
+template <int P, int F>
+MARL_HD int lbf_field(const LbfState<P, F>& s, int r, int c) {
+    int v = 0;
+#pragma unroll
+    for (int f = 0; f < F; ++f) v += (s.fl[f] > 0 && s.fr[f] == r && s.fc[f] == c) ? s.fl[f] : 0;
+    return v;
+}
+
+MARL_HD int imin(int a, int b) { return a < b ? a : b; }
+MARL_HD int imax(int a, int b) { return a > b ? a : b; }
+MARL_HD int iabs(int a) { return a < 0 ? -a : a; }
+
+// keep the food list in np.nonzero (row-major) order - the order observations use
+template <int P, int F>
+MARL_HD void lbf_sort_food(LbfState<P, F>& s, int cols) {
+#pragma unroll
+    for (int i = 1; i < F; ++i) {
+#pragma unroll
+        for (int j = F - 1; j >= 1; --j) {
+            if (j <= i) {
+                // absent foods (level 0) sort last
+                const int ka = s.fl[j - 1] > 0 ? s.fr[j - 1] * cols + s.fc[j - 1] : 0x7FFFFFFF;
+                const int kb = s.fl[j] > 0 ? s.fr[j] * cols + s.fc[j] : 0x7FFFFFFF;
+                if (kb < ka) {
+                    int t;
+                    t = s.fr[j]; s.fr[j] = s.fr[j - 1]; s.fr[j - 1] = t;
+                    t = s.fc[j]; s.fc[j] = s.fc[j - 1]; s.fc[j - 1] = t;
+                    t = s.fl[j]; s.fl[j] = s.fl[j - 1]; s.fl[j - 1] = t;
+                }
+            }
+        }
+    }
+}
+
+// ForagingEnv.reset: spawn_players then spawn_food (rejection sampling, <=1000
+// attempts each), draws taken from `rng` in upstream's call order.
+template <int P, int F>
+MARL_HD void lbf_reset(const LbfParams& q, LbfState<P, F>& s, DrawStream& rng) {
+#pragma unroll
+    for (int f = 0; f < F; ++f) { s.fr[f] = 0; s.fc[f] = 0; s.fl[f] = 0; }
+#pragma unroll
+    for (int p = 0; p < P; ++p) { s.pr[p] = 0; s.pc[p] = 0; s.pl[p] = q.min_player_level; }
+    // players: uniform cell until empty (field is still all-zero here)
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        int attempts = 0;
+        while (attempts < 1000) {
+            const int row = rng.integers(0, q.rows);
+            const int col = rng.integers(0, q.cols);
+            bool empty = true;
+#pragma unroll
+            for (int o = 0; o < P; ++o) empty = empty && !(o < p && s.pr[o] == row && s.pc[o] == col);
+            if (empty) {
+                s.pr[p] = row; s.pc[p] = col;
+                s.pl[p] = rng.integers(q.min_player_level, q.max_player_level + 1);
+                break;
+            }
+            ++attempts;
+        }
+    }
+    // max food level: given, or the sum of the (up to) three lowest player levels
+    int max_level = q.max_food_level;
+    if (max_level <= 0) {
+        int lv[P];
+#pragma unroll
+        for (int p = 0; p < P; ++p) lv[p] = s.pl[p];
+#pragma unroll
+        for (int i = 0; i < P; ++i)
+#pragma unroll
+            for (int j = 0; j < P - 1; ++j)
+                if (lv[j + 1] < lv[j]) { const int t = lv[j]; lv[j] = lv[j + 1]; lv[j + 1] = t; }
+        max_level = 0;
+#pragma unroll
+        for (int p = 0; p < P; ++p) max_level += (p < 3) ? lv[p] : 0;
+    }
+    const int min_level = q.force_coop ? max_level : q.min_food_level;
+    int food_count = 0, attempts = 0;
+    while (food_count < F && attempts < 1000) {
+        ++attempts;
+        const int row = rng.integers(1, q.rows - 1);
+        const int col = rng.integers(1, q.cols - 1);
+        bool bad = false;
+        // any food in the 3x3 block, or within 2 cells along the row / column
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            if (f < food_count) {
+                const int dr = iabs(s.fr[f] - row), dc = iabs(s.fc[f] - col);
+                bad = bad || (dr <= 1 && dc <= 1) || (dc == 0 && dr <= 2) || (dr == 0 && dc <= 2);
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < P; ++p) bad = bad || (s.pr[p] == row && s.pc[p] == col);
+        if (bad) continue;
+        const int lvl = (min_level == max_level) ? min_level : rng.integers(min_level, max_level + 1);
+#pragma unroll
+        for (int f = 0; f < F; ++f)
+            if (f == food_count) { s.fr[f] = row; s.fc[f] = col; s.fl[f] = lvl; }
+        ++food_count;
+    }
+    int total = 0;
+#pragma unroll
+    for (int f = 0; f < F; ++f) total += s.fl[f];
+    s.spawned = total;
+    s.step = 0;
+    lbf_sort_food(s, q.cols);
+}
+
+// ForagingEnv.step.  rew[] are the env's own per-agent rewards (fp64, as
+// upstream computes them); `done` = game over (no food left or step limit).
+template <int P, int F>
+MARL_HD void lbf_step(const LbfParams& q, LbfState<P, F>& s, const int* act, double* rew, bool& done) {
+    s.step += 1;
+    int tr[P], tc[P];
+    bool load[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        int a = act[p];
+        const int r = s.pr[p], c = s.pc[p];
+        // valid set of the current state (_gen_valid_moves at the end of the
+        // previous step); an invalid choice silently becomes NONE
+        bool ok;
+        switch (a) {
+            case ACT_NONE: ok = true; break;
+            case ACT_NORTH: ok = r > 0 && lbf_field(s, r - 1, c) == 0; break;
+            case ACT_SOUTH: ok = r < q.rows - 1 && lbf_field(s, r + 1, c) == 0; break;
+            case ACT_WEST: ok = c > 0 && lbf_field(s, r, c - 1) == 0; break;
+            case ACT_EAST: ok = c < q.cols - 1 && lbf_field(s, r, c + 1) == 0; break;
+            case ACT_LOAD:
+                ok = (lbf_field(s, imax(r - 1, 0), c) + lbf_field(s, imin(r + 1, q.rows - 1), c) +
+                      lbf_field(s, r, imax(c - 1, 0)) + lbf_field(s, r, imin(c + 1, q.cols - 1))) > 0;
+                break;
+            default: ok = false; break;
+        }
+        if (!ok) a = ACT_NONE;
+        tr[p] = r + (a == ACT_SOUTH) - (a == ACT_NORTH);
+        tc[p] = c + (a == ACT_EAST) - (a == ACT_WEST);
+        load[p] = (a == ACT_LOAD);
+        rew[p] = 0.0;
+    }
+    // a cell claimed by more than one player is reached by none of them
+    bool sole[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        int n = 0;
+#pragma unroll
+        for (int o = 0; o < P; ++o) n += (tr[o] == tr[p] && tc[o] == tc[p]) ? 1 : 0;
+        sole[p] = (n == 1);
+    }
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+        if (sole[p]) { s.pr[p] = tr[p]; s.pc[p] = tc[p]; }
+
+    // loading, in player order (order-independent on reachable states: the spawn
+    // spacing rule leaves no cell adjacent to two foods)
+    bool pending[P];
+    bool ate = false;
+#pragma unroll
+    for (int p = 0; p < P; ++p) pending[p] = load[p];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        if (!pending[p]) continue;
+        pending[p] = false;
+        const int r = s.pr[p], c = s.pc[p];
+        // adjacent_food_location: N, S, W, E (upstream's `> 1` on N / W kept)
+        int fr_, fc_;
+        if (r > 1 && lbf_field(s, r - 1, c) > 0) { fr_ = r - 1; fc_ = c; }
+        else if (r < q.rows - 1 && lbf_field(s, r + 1, c) > 0) { fr_ = r + 1; fc_ = c; }
+        else if (c > 1 && lbf_field(s, r, c - 1) > 0) { fr_ = r; fc_ = c - 1; }
+        else if (c < q.cols - 1 && lbf_field(s, r, c + 1) > 0) { fr_ = r; fc_ = c + 1; }
+        else continue;
+        const int food = lbf_field(s, fr_, fc_);
+        bool adj[P];
+        int adj_level = 0;
+#pragma unroll
+        for (int o = 0; o < P; ++o) {
+            const bool next_to = (iabs(s.pr[o] - fr_) == 1 && s.pc[o] == fc_) || (iabs(s.pc[o] - fc_) == 1 && s.pr[o] == fr_);
+            adj[o] = next_to && (o == p || pending[o]);
+            adj_level += adj[o] ? s.pl[o] : 0;
+            if (adj[o]) pending[o] = false;
+        }
+        if (adj_level < food) {
+#pragma unroll
+            for (int o = 0; o < P; ++o)
+                if (adj[o]) rew[o] -= q.penalty;
+            continue;
+        }
+#pragma unroll
+        for (int o = 0; o < P; ++o) {
+            if (adj[o]) {
+                double v = (double)(s.pl[o] * food);
+                if (q.normalize_reward) v = v / (double)(adj_level * s.spawned);
+                rew[o] = v;
+            }
+        }
+#pragma unroll
+        for (int f = 0; f < F; ++f)
+            if (s.fl[f] > 0 && s.fr[f] == fr_ && s.fc[f] == fc_) { s.fl[f] = 0; s.fr[f] = 0; s.fc[f] = 0; }
+        ate = true;
+    }
+    // canonical record: live foods first (row-major), eaten slots all-zero at the tail
+    if (ate) lbf_sort_food(s, q.cols);
+    int left = 0;
+#pragma unroll
+    for (int f = 0; f < F; ++f) left += s.fl[f];
+    done = (left == 0) || (q.max_episode_steps <= s.step);
+}
+
+// one element of agent `p`'s observation vector (ForagingEnv._make_gym_obs,
+// vector form): F food triples in row-major order of the visible window, then
+// self, then the other visible players in index order; (-1,-1,0) padding.
+template <int P, int F>
+struct LbfObs {
+    float v[3 * (F + P)];
+};
+
+template <int P, int F>
+MARL_HD void lbf_observe(const LbfParams& q, const LbfState<P, F>& s, int p, LbfObs<P, F>& o) {
+    const int cr = s.pr[p], cc = s.pc[p];
+    const int offr = imin(q.sight, cr) - cr, offc = imin(q.sight, cc) - cc;
+#pragma unroll
+    for (int i = 0; i < F + P; ++i) { o.v[3 * i] = -1.f; o.v[3 * i + 1] = -1.f; o.v[3 * i + 2] = 0.f; }
+    int n = 0;
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+        const bool vis = s.fl[f] > 0 && iabs(s.fr[f] - cr) <= q.sight && iabs(s.fc[f] - cc) <= q.sight;
+        if (vis) {
+#pragma unroll
+            for (int i = 0; i < F; ++i)
+                if (i == n) { o.v[3 * i] = (float)(s.fr[f] + offr); o.v[3 * i + 1] = (float)(s.fc[f] + offc); o.v[3 * i + 2] = (float)s.fl[f]; }
+            ++n;
+        }
+    }
+    // self first
+    o.v[3 * F] = (float)(cr + offr); o.v[3 * F + 1] = (float)(cc + offc); o.v[3 * F + 2] = (float)s.pl[p];
+    int m = 1;
+#pragma unroll
+    for (int a = 0; a < P; ++a) {
+        if (a == p) continue;
+        const int y = s.pr[a] + offr, x = s.pc[a] + offc;
+        const bool vis = imin(y, x) >= 0 && imax(y, x) <= 2 * q.sight;
+        if (vis) {
+#pragma unroll
+            for (int i = 1; i < P; ++i)
+                if (i == m) { o.v[3 * (F + i)] = (float)y; o.v[3 * (F + i) + 1] = (float)x; o.v[3 * (F + i) + 2] = (float)s.pl[a]; }
+            ++m;
+        }
+    }
+}
+
+// wrapper arithmetic applied to the env's rewards before they reach the learner:
+// CooperativeReward = P * [python sum(reward)] in fp64, then one cast to fp32.
+template <int P>
+MARL_HD void lbf_wrap_rewards(const LbfParams& q, const double* raw, float* out) {
+    if (q.cooperative) {
+        double t = 0.0;
+#pragma unroll
+        for (int p = 0; p < P; ++p) t += raw[p];
+#pragma unroll
+        for (int p = 0; p < P; ++p) out[p] = (float)t;
+    } else {
+#pragma unroll
+        for (int p = 0; p < P; ++p) out[p] = (float)raw[p];
+    }
+}
+
+}  // namespace marl

@@ -1,0 +1,190 @@
+// Per-agent 3-layer MLP (Linear-ReLU-Linear-ReLU-Linear) on f32 MFMA for gfx950.
+//
+// Replaces FCNetwork.forward (marlbase/utils/models.py:34-48) as used by
+// MultiAgentIndependentNetwork (utils/models.py:156-170) inside QNetwork.act
+// (dqn/model.py:94-116) and QNetwork._compute_loss (dqn/model.py:127-134).
+//
+// Formulation: activations are kept TRANSPOSED, Y^T[out x 16 rows] = W[out x in] *
+// X^T[in x 16 rows], on v_mfma_f32_16x16x4_f32 (exact f32, == an fmaf chain):
+//   A operand (lane l: A[i=l&15][k=l>>4])  = weights, read from LDS
+//   B operand (lane l: B[k=l>>4][j=l&15])  = activations, one register per k-step
+//   C/D       (lane l: D[row=(l>>4)*4+r][col=l&15], r=0..3)
+// so lane (g=l>>4, j=l&15) holds outputs 16*mt+4g+r of batch row j.  That is
+// exactly the B-operand shape of the next layer if its k-steps are enumerated as
+// (mt, r) with k-index 16*mt+4g+r: layers chain with NO cross-lane movement; only
+// the weight packing knows about the permuted k order.  Per output the f32 sum is
+//   acc = bias; for mt: for r: for g=0..3: acc = fmaf(W[o][16mt+4g+r], x[16mt+4g+r], acc)
+// (layer 1: for ks: for g: k = 4ks+g) - oracle/mlp_exact.c restates this order.
+//
+// Canonical parameters of one agent = torch parameters() order of FCNetwork:
+//   W1[H][D] b1[H] W2[H][H] b2[H] W3[A][H] b3[A]      (row-major, nn.Linear layout)
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace marl {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+#define MARL_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+template <int D_, int H_, int A_>
+struct MlpShape {
+    static constexpr int D = D_, H = H_, A = A_;
+    static constexpr int DP = (D_ + 15) / 16 * 16;  // layer-1 K padded to 16 (float4 of k-steps)
+    static constexpr int KS1 = DP / 4;              // layer-1 k-steps
+    static constexpr int MT = H_ / 16;              // hidden tiles of 16
+    static constexpr int AP = 16;                   // output tile (A <= 16)
+    static_assert(H_ % 16 == 0 && A_ <= 16, "shape");
+    // canonical offsets
+    static constexpr int oW1 = 0, ob1 = H_ * D_, oW2 = ob1 + H_, ob2 = oW2 + H_ * H_, oW3 = ob2 + H_, ob3 = oW3 + A_ * H_;
+    static constexpr int NPARAM = ob3 + A_;
+    // forward pack (floats): A1[MT][KS1/4][64][4] A2[MT][MT][64][4] A3[MT][64][4] b1[H] b2[H] b3[16]
+    static constexpr int pA1 = 0, pA2 = pA1 + MT * KS1 * 64, pA3 = pA2 + MT * MT * 256, pb1 = pA3 + MT * 256, pb2 = pb1 + H_, pb3 = pb2 + H_;
+    static constexpr int NFWD = pb3 + 16;
+    // backward-data pack: T3[MT][64][4] = W3^T tiles (M=h2, K=a), T2[MT][MT][64][4] = W2^T tiles (M=h1, K=h2)
+    static constexpr int pT3 = 0, pT2 = pT3 + MT * 256;
+    static constexpr int NBWD = pT2 + MT * MT * 256;
+};
+
+// value of forward-pack element `idx` taken from the canonical parameter block
+template <class S>
+__device__ __forceinline__ float mlp_fwd_pack_elem(const float* __restrict__ w, int idx) {
+    if (idx < S::pA2) {  // A1[mt][ks4][lane][e]: W1[16mt+i][4(4ks4+e)+g]
+        const int e = idx & 3, lane = (idx >> 2) & 63, rest = idx >> 8;
+        const int ks4 = rest % (S::KS1 / 4), mt = rest / (S::KS1 / 4);
+        const int o = 16 * mt + (lane & 15), k = 4 * (4 * ks4 + e) + (lane >> 4);
+        return k < S::D ? w[S::oW1 + o * S::D + k] : 0.f;
+    } else if (idx < S::pA3) {  // A2[mt2][mt1][lane][r]: W2[16mt2+i][16mt1+4g+r]
+        const int j = idx - S::pA2;
+        const int r = j & 3, lane = (j >> 2) & 63, rest = j >> 8;
+        const int mt1 = rest % S::MT, mt2 = rest / S::MT;
+        return w[S::oW2 + (16 * mt2 + (lane & 15)) * S::H + 16 * mt1 + 4 * (lane >> 4) + r];
+    } else if (idx < S::pb1) {  // A3[mt1][lane][r]: W3[i][16mt1+4g+r]
+        const int j = idx - S::pA3;
+        const int r = j & 3, lane = (j >> 2) & 63, mt1 = j >> 8;
+        const int o = lane & 15;
+        return o < S::A ? w[S::oW3 + o * S::H + 16 * mt1 + 4 * (lane >> 4) + r] : 0.f;
+    } else if (idx < S::pb2) {
+        return w[S::ob1 + idx - S::pb1];
+    } else if (idx < S::pb3) {
+        return w[S::ob2 + idx - S::pb2];
+    } else {
+        const int o = idx - S::pb3;
+        return o < S::A ? w[S::ob3 + o] : 0.f;
+    }
+}
+
+// cooperative (whole workgroup) staging of one network's forward pack into LDS
+template <class S>
+__device__ __forceinline__ void mlp_stage_fwd(const float* __restrict__ w, float* lds, int tid, int nthreads) {
+    for (int idx = tid; idx < S::NFWD; idx += nthreads) lds[idx] = mlp_fwd_pack_elem<S>(w, idx);
+}
+
+template <class S>
+__device__ __forceinline__ void mlp_stage_bwd(const float* __restrict__ w, float* lds, int tid, int nthreads) {
+    for (int idx = tid; idx < S::NBWD; idx += nthreads) {
+        float v;
+        if (idx < S::pT2) {  // T3[mt][lane][r]: A[i=h2 16mt+i][k=a 4g+r] = W3[4g+r][16mt+i]
+            const int r = idx & 3, lane = (idx >> 2) & 63, mt = idx >> 8;
+            const int a = 4 * (lane >> 4) + r;
+            v = a < S::A ? w[S::oW3 + a * S::H + 16 * mt + (lane & 15)] : 0.f;
+        } else {  // T2[mt1][mt2][lane][r]: A[i=h1 16mt1+i][k=h2 16mt2+4g+r] = W2[16mt2+4g+r][16mt1+i]
+            const int j = idx - S::pT2;
+            const int r = j & 3, lane = (j >> 2) & 63, rest = j >> 8;
+            const int mt2 = rest % S::MT, mt1 = rest / S::MT;
+            v = w[S::oW2 + (16 * mt2 + 4 * (lane >> 4) + r) * S::H + 16 * mt1 + (lane & 15)];
+        }
+        lds[idx] = v;
+    }
+}
+
+__device__ __forceinline__ f4 relu4(f4 v) {
+    f4 o;
+    o.x = fmaxf(v.x, 0.f); o.y = fmaxf(v.y, 0.f); o.z = fmaxf(v.z, 0.f); o.w = fmaxf(v.w, 0.f);
+    return o;
+}
+
+// forward of one 16-row block.  x[ks] = X[row j][4ks+g] (zero beyond D).
+// h1/h2 (post-ReLU) and q come back in C layout: [16mt+4g+r][row j].
+template <class S>
+__device__ __forceinline__ void mlp_forward(const float* lds, int lane, const float (&x)[S::KS1], f4 (&h1)[S::MT], f4 (&h2)[S::MT], f4& q) {
+    const int g = lane >> 4;
+    const f4* A1 = reinterpret_cast<const f4*>(lds + S::pA1);
+    const f4* A2 = reinterpret_cast<const f4*>(lds + S::pA2);
+    const f4* A3 = reinterpret_cast<const f4*>(lds + S::pA3);
+    f4 acc[S::MT];
+#pragma unroll
+    for (int mt = 0; mt < S::MT; ++mt) acc[mt] = *reinterpret_cast<const f4*>(lds + S::pb1 + 16 * mt + 4 * g);
+#pragma unroll
+    for (int ks4 = 0; ks4 < S::KS1 / 4; ++ks4) {
+        f4 a[S::MT];
+#pragma unroll
+        for (int mt = 0; mt < S::MT; ++mt) a[mt] = A1[(mt * (S::KS1 / 4) + ks4) * 64 + lane];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int mt = 0; mt < S::MT; ++mt) acc[mt] = MARL_MFMA(a[mt][e], x[4 * ks4 + e], acc[mt]);
+    }
+#pragma unroll
+    for (int mt = 0; mt < S::MT; ++mt) h1[mt] = relu4(acc[mt]);
+
+#pragma unroll
+    for (int mt = 0; mt < S::MT; ++mt) acc[mt] = *reinterpret_cast<const f4*>(lds + S::pb2 + 16 * mt + 4 * g);
+#pragma unroll
+    for (int k1 = 0; k1 < S::MT; ++k1) {
+        f4 a[S::MT];
+#pragma unroll
+        for (int mt = 0; mt < S::MT; ++mt) a[mt] = A2[(mt * S::MT + k1) * 64 + lane];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int mt = 0; mt < S::MT; ++mt) acc[mt] = MARL_MFMA(a[mt][r], h1[k1][r], acc[mt]);
+    }
+#pragma unroll
+    for (int mt = 0; mt < S::MT; ++mt) h2[mt] = relu4(acc[mt]);
+
+    // layer 3: two interleaved partial chains would change the sum order; keep one chain
+    f4 o = *reinterpret_cast<const f4*>(lds + S::pb3 + 4 * g);
+#pragma unroll
+    for (int k1 = 0; k1 < S::MT; ++k1) {
+        const f4 a = A3[k1 * 64 + lane];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o = MARL_MFMA(a[r], h2[k1][r], o);
+    }
+    q = o;
+}
+
+// greedy action of batch row j from q in C layout (lane (g,j) holds Q[4g+r]):
+// first index of the maximum (torch.argmax tie rule), identical in all 4 lanes of j.
+template <int A>
+__device__ __forceinline__ int argmax_rows(const f4& q, int lane, float* best_val = nullptr) {
+    const int g = lane >> 4;
+    float bv = -__builtin_huge_valf();
+    int ba = 0x7FFFFFFF;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int a = 4 * g + r;
+        if (a < A && (q[r] > bv || ba == 0x7FFFFFFF)) { bv = q[r]; ba = a; }
+    }
+#pragma unroll
+    for (int off = 16; off < 64; off <<= 1) {
+        const float ov = __shfl_xor(bv, off);
+        const int oa = __shfl_xor(ba, off);
+        if (oa != 0x7FFFFFFF && (ba == 0x7FFFFFFF || ov > bv || (ov == bv && oa < ba))) { bv = ov; ba = oa; }
+    }
+    if (best_val) *best_val = bv;
+    return ba;
+}
+
+// value Q[a_sel] of batch row j, gathered from the lane that holds it (all 4 lanes of j get it)
+__device__ __forceinline__ float gather_rows(const f4& q, int lane, int a_sel) {
+    const int g = lane >> 4;
+    float v = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v += (4 * g + r == a_sel) ? q[r] : 0.f;
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+
+}  // namespace marl

@@ -1,0 +1,214 @@
+/* marlhip.h - C-ABI of libmarlhip.so, the MI355X (gfx950) implementation of marlbase's
+ * independent-learner hot path.
+ *
+ * The reference (marl-book/codebase) is pure Python: it has no FFI/plugin registry.  Its
+ * extension surface is Hydra `_target_` callables plus duck typing.  Each entry
+ * point below names the reference code it stands in for; the Python adapters in codebase_amd/
+ * re-create the reference objects (make_env, ReplayBuffer, QNetwork, dqn.train.main) on top of
+ * these calls, and INTEGRATION.md shows the ctypes stubs a marlbase maintainer would add.
+ *
+ * Conventions
+ *  - every call returns 0 on success, <0 on error (text: marlhip_last_error()).
+ *  - the CALLER owns all memory: arguments are raw DEVICE pointers (PyTorch-ROCm tensors) plus
+ *    element counts; the library never allocates, never frees, keeps no state between calls.
+ *  - every call takes a hipStream_t (as void*), only enqueues, never synchronises.
+ *  - layouts are agent-major, env-minor: obs[P][N][D] f32, actions[P][N] i32, rewards[P][N] f32,
+ *    done[N] u8.  N = envs, P = agents, D = obs dim, A = actions, T = time_limit, B = batch.
+ *  - integer results (env state, done flags, observations, greedy actions, sampled indices) are
+ *    bit-exact functions of the inputs; fp32 losses/gradients agree with torch fp32 to ~1e-6.
+ */
+#ifndef MARLHIP_H
+#define MARLHIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MARLHIP_VERSION 100
+
+int marlhip_version(void);
+const char* marlhip_last_error(void);
+/* 1 if a HIP device is usable from this process (hipGetDeviceCount > 0), else 0 */
+int marlhip_device_available(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Level-Based Foraging, batched.   Replaces lbforaging's ForagingEnv (third-party; reached via
+ * gym.make at marlbase/utils/envs.py:90-92) under TimeLimit + RecordEpisodeStatistics
+ * (utils/envs.py:96-97, utils/wrappers.py:13-45) and the optional CooperativeReward wrapper
+ * (utils/wrappers.py:106-108).  Field values mirror upstream's registration kwargs.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct marlhip_lbf_config {
+    int32_t n_envs;
+    int32_t n_agents;          /* players */
+    int32_t n_food;            /* max_num_food */
+    int32_t rows, cols;        /* field_size */
+    int32_t sight;             /* == size for full observability, 2 for "-2s" */
+    int32_t max_episode_steps; /* upstream registration: 50 -> `done` */
+    int32_t time_limit;        /* env.time_limit (TimeLimit wrapper) -> `truncated`; 0 = none */
+    int32_t force_coop;
+    int32_t min_player_level, max_player_level;
+    int32_t min_food_level, max_food_level; /* max_food_level <= 0: None (sum of 3 lowest player levels) */
+    int32_t normalize_reward;
+    int32_t cooperative;       /* CooperativeReward wrapper */
+    double penalty;
+    uint64_t seed;             /* Philox key */
+} marlhip_lbf_config;
+
+/* device buffers of a batched env (allocated by the caller) */
+typedef struct marlhip_lbf_buffers {
+    uint8_t* state;     /* [N][marlhip_lbf_state_stride] packed records: F x (row,col,level) u8 in
+                           row-major field order (level 0 = absent), P x (row,col,level) u8,
+                           current_step u16 LE, food_spawned u16 LE, zero pad to 4 B */
+    uint32_t* episode;  /* [N] episodes started so far (index into the Philox reset stream) */
+    float* ep_return;   /* [P][N] running RAW per-agent return (RecordEpisodeStatistics, fp32 adds) */
+    int32_t* ep_length; /* [N] steps taken in the running episode */
+} marlhip_lbf_buffers;
+
+int marlhip_lbf_state_stride(const marlhip_lbf_config* cfg); /* bytes per env record, <0 if unsupported */
+int marlhip_lbf_obs_dim(const marlhip_lbf_config* cfg);      /* 3 * (n_food + n_agents) */
+
+/* env.reset(): re-spawn the envs with mask[n] != 0 (mask NULL = all), episode[n] += 1 for those,
+ * zero their running statistics, write their observations (obs may be NULL).
+ * Call sites replaced: marlbase/dqn/train.py:180,203,246,267; utils/envs.py:111. */
+int marlhip_lbf_reset(const marlhip_lbf_config* cfg, const marlhip_lbf_buffers* buf, const uint8_t* mask,
+                      float* obs /* [P][N][D] */, void* stream);
+
+/* observations of the current state (no transition) */
+int marlhip_lbf_observe(const marlhip_lbf_config* cfg, const marlhip_lbf_buffers* buf, float* obs, void* stream);
+
+/* env.step(actions): one joint transition of every env with active[n] != 0 (NULL = all).
+ * rewards are what the learner sees (fp64 -> fp32 once; summed first if cfg->cooperative).
+ * On done|truncated the finished episode's statistics (info["episode_returns"],
+ * info["episode_length"], wrappers.py:35-41) are latched into fin_return/fin_length.
+ * auto_reset != 0 gives gymnasium(<1.0) AsyncVectorEnv semantics (marlbase/ac/train.py:79):
+ * a finished env is reset inside the call, `obs` holds the reset observation and final_obs
+ * (may be NULL) the terminal one.
+ * Call sites replaced: marlbase/dqn/train.py:191,217,257; marlbase/ac/train.py:79. */
+int marlhip_lbf_step(const marlhip_lbf_config* cfg, const marlhip_lbf_buffers* buf, const uint8_t* active,
+                     const int32_t* actions /* [P][N] */, float* obs /* [P][N][D] */, float* rewards /* [P][N] */,
+                     uint8_t* done /* [N] */, uint8_t* truncated /* [N] */, float* fin_return /* [P][N] */,
+                     int32_t* fin_length /* [N] */, int32_t auto_reset, float* final_obs /* [P][N][D] or NULL */,
+                     void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Per-agent Q-networks.  All agents share one shape (true for every LBF task); parameters of
+ * agent i are one contiguous fp32 block in torch parameters() order of
+ * critic.independent.{i}.network.{0,2,4}.{weight,bias} (marlbase/utils/models.py:34-42,146-154):
+ *     W1[H][D] b1[H] W2[H][H] b2[H] W3[A][H] b3[A]            (nn.Linear row-major)
+ * so state_dict tensors are plain slices of the block (checkpoints: dqn/train.py:340-343).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct marlhip_net_shape {
+    int32_t n_agents; /* P */
+    int32_t obs_dim;  /* D */
+    int32_t hidden;   /* H: two hidden layers of this width (algorithm.model.layers=[H,H]) */
+    int32_t n_actions;/* A */
+} marlhip_net_shape;
+
+int marlhip_net_nparams(const marlhip_net_shape* s); /* per agent; <0 if the shape has no kernel */
+
+/* QNetwork.act (marlbase/dqn/model.py:94-116), batched over N envs: Q = critic_i(obs_i);
+ * ONE uniform per env decides random-vs-greedy for the whole joint action (model.py:105);
+ * greedy = first index of the max (torch.argmax).  Noise: if u != NULL use u[n] and
+ * rand_actions[P][N]; else Philox(seed; env n, episode[n], t = ep_length[n]) as the fused
+ * collector does.  q_out ([P][N][A]) may be NULL. */
+int marlhip_dqn_act(const marlhip_net_shape* s, const float* params /* [P][nparams] */, const float* obs /* [P][N][D] */,
+                    int32_t n_envs, float epsilon, const float* u /* [N] or NULL */,
+                    const int32_t* rand_actions /* [P][N] or NULL */, uint64_t seed, const uint32_t* episode /* [N] */,
+                    const int32_t* ep_length /* [N] */, int32_t* actions /* [P][N] */, float* q_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Episode replay.  Replaces marlbase/dqn/train.py:19-124 (ReplayBuffer).  Storage is
+ * EPISODE-major so a sampled episode is contiguous (the reference's time-major numpy arrays
+ * make every sampled episode 26 strided 60-byte reads per agent):
+ *     obs   f32 [cap][P][T+1][D]     act u8 [cap][P][T]     rew f32 [cap][P][T]
+ *     done  u8  [cap][T+1]           filled u8 [cap][T]
+ * ---------------------------------------------------------------------------------------- */
+typedef struct marlhip_replay_shape {
+    int32_t capacity; /* buffer_size, in episodes */
+    int32_t n_agents, obs_dim, max_len; /* P, D, T */
+} marlhip_replay_shape;
+
+typedef struct marlhip_replay_buffers {
+    float* obs;
+    uint8_t* act;
+    float* rew;
+    uint8_t* done;
+    uint8_t* filled;
+} marlhip_replay_buffers;
+
+/* ReplayBuffer.init_episode (train.py:65-71) for N envs: obs -> row t=0 of slot[n]. */
+int marlhip_replay_init_episode(const marlhip_replay_shape* rs, const marlhip_replay_buffers* rb,
+                                const int32_t* slot /* [N] */, const uint8_t* active /* [N] or NULL */,
+                                const float* obs /* [P][N][D] */, int32_t n_envs, void* stream);
+
+/* ReplayBuffer.add (train.py:73-89) for N envs: obs -> row t[n]+1, action/reward -> t[n],
+ * done -> t[n]+1, filled[t[n]] = 1.  Like the reference it never clears older rows of a
+ * re-used slot (stale tails survive a ring wrap). */
+int marlhip_replay_add(const marlhip_replay_shape* rs, const marlhip_replay_buffers* rb, const int32_t* slot,
+                       const int32_t* t /* [N] */, const uint8_t* active, const float* obs, const int32_t* actions,
+                       const float* rewards, const uint8_t* done, int32_t n_envs, void* stream);
+
+/* ReplayBuffer.sample (train.py:94-124): gather B whole episodes into the reference's Batch
+ * layout: obss f32 [P][T+1][B][D], actions i64 [P][T][B], rewards f32 [P][T][B],
+ * dones f32 [T+1][B], filled f32 [T][B].  idx != NULL: use idx[b] (parity with injected
+ * np.random.randint draws); idx == NULL: idx[b] = Philox(seed; stream 2, counter) mod-free
+ * bounded draw in [0, length), also written to idx_out if non-NULL. */
+int marlhip_replay_sample(const marlhip_replay_shape* rs, const marlhip_replay_buffers* rb, const int32_t* idx,
+                          int32_t batch, int32_t length, uint64_t seed, uint32_t counter, int32_t* idx_out,
+                          float* obss, int64_t* actions, float* rewards, float* dones, float* filled, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Learner step.  Replaces QNetwork._compute_loss + update (marlbase/dqn/model.py:118-174):
+ * critic/target forwards over whole episodes, Double-Q target, masked MSE summed over agents,
+ * backward, global-norm clip, Adam, target update.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct marlhip_batch {
+    const float* obss;      /* [P][T+1][B][D] */
+    const int64_t* actions; /* [P][T][B] */
+    const float* rewards;   /* [P][T][B] */
+    const float* dones;     /* [T+1][B] */
+    const float* filled;    /* [T][B] */
+    int32_t max_len, batch; /* T, B */
+} marlhip_batch;
+
+/* bytes of scratch marlhip_dqn_loss_grad needs for this (shape, T, B) */
+int64_t marlhip_dqn_workspace_bytes(const marlhip_net_shape* s, int32_t max_len, int32_t batch);
+
+/* loss (scalar, model.py:160-163) and its gradient w.r.t. the critic parameters, both written to
+ * device memory: grad[P][nparams] (same layout as params), loss[0] = value, loss[1] = sum(filled).
+ * mode: 0 = IDQN (per-agent targets, model.py:118-163), 1 = VDN (sum over agents, agent-0 reward,
+ * model.py:224-269).  double_q as cfg.double_q (model.py:138-145). */
+int marlhip_dqn_loss_grad(const marlhip_net_shape* s, const float* params, const float* target_params,
+                          const marlhip_batch* batch, float gamma, int32_t double_q, int32_t mode, void* workspace,
+                          int64_t workspace_bytes, float* grad, float* loss, void* stream);
+
+/* clip_grad_norm_(critic.parameters(), max_norm) over ALL agents' parameters (model.py:169-170;
+ * max_norm <= 0: no clipping), torch.optim.Adam single-tensor step (model.py:171; step = 1-based
+ * update count, bias corrections computed in fp64 on the host side of this call), then the
+ * target update (model.py:176-196): hard_update != 0 copies params -> target, else tau > 0
+ * Polyak-averages, else target untouched.  grad_scale multiplies the gradient first (1/world
+ * for an all-reduced SUM).  gnorm_out[0] (may be NULL) receives the pre-clip total norm. */
+int marlhip_dqn_clip_adam(int64_t n, float* params, const float* grad, float* exp_avg, float* exp_avg_sq,
+                          float* target_params, int64_t step, float lr, float beta1, float beta2, float eps,
+                          float max_norm, float grad_scale, int32_t hard_update, float tau, float* gnorm_out,
+                          void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused collector.  Replaces _collect_trajectory (marlbase/dqn/train.py:202-237) for N envs in
+ * ONE launch per round: reset -> T x (act -> step -> replay add), env state in registers, the
+ * critics in LDS, transitions streamed to the replay slots slot_base+n (mod capacity).
+ * Envs whose episode ends early idle for the rest of the round.  Outputs per env: episode
+ * length and RAW per-agent returns (the reference's info["episode_returns"]).
+ * write_replay == 0 gives _evaluate (train.py:177-199).  clear_stale != 0 zeroes filled[t]
+ * beyond the episode end (the reference does not, a7).
+ * ---------------------------------------------------------------------------------------- */
+int marlhip_idqn_collect(const marlhip_lbf_config* cfg, const marlhip_net_shape* s, const float* params, float epsilon,
+                         uint32_t round, const marlhip_replay_shape* rs, const marlhip_replay_buffers* rb,
+                         int32_t slot_base, int32_t write_replay, int32_t clear_stale, int32_t use_proper_termination,
+                         float* fin_return /* [P][N] */, int32_t* fin_length /* [N] */, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MARLHIP_H */

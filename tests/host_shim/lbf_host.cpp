@@ -1,0 +1,97 @@
+// TEST TOOL (not product): g++ build of codebase_amd/csrc/lbf_core.h so the integer env logic
+// that the HIP kernels inline can be checked against oracle/lbf.py on a machine with no GPU.
+#include <stdint.h>
+#include <string.h>
+
+#include "../../codebase_amd/csrc/lbf_core.h"
+
+using namespace marl;
+
+struct HostCfg {
+    int32_t n_envs, n_agents, n_food, rows, cols, sight, max_episode_steps, time_limit;
+    int32_t force_coop, min_player_level, max_player_level, min_food_level, max_food_level;
+    int32_t normalize_reward, cooperative;
+    double penalty;
+    uint64_t seed;
+};
+
+static LbfParams conv(const HostCfg* c) {
+    LbfParams q;
+    q.n_envs = c->n_envs; q.n_agents = c->n_agents; q.n_food = c->n_food; q.rows = c->rows; q.cols = c->cols;
+    q.sight = c->sight; q.max_episode_steps = c->max_episode_steps; q.time_limit = c->time_limit;
+    q.force_coop = c->force_coop; q.min_player_level = c->min_player_level; q.max_player_level = c->max_player_level;
+    q.min_food_level = c->min_food_level; q.max_food_level = c->max_food_level; q.normalize_reward = c->normalize_reward;
+    q.cooperative = c->cooperative; q.penalty = c->penalty; q.seed = c->seed;
+    return q;
+}
+
+template <int P, int F>
+static void run_reset(const LbfParams& q, uint8_t* state, const uint32_t* episode, float* obs) {
+    const int stride = lbf_state_stride(P, F), D = 3 * (P + F);
+    for (int n = 0; n < q.n_envs; ++n) {
+        LbfState<P, F> s;
+        DrawStream rng;
+        rng.init(q.seed, (uint32_t)n, episode[n], STREAM_RESET);
+        lbf_reset(q, s, rng);
+        lbf_store(state + (size_t)n * stride, s);
+        for (int p = 0; p < P; ++p) {
+            LbfObs<P, F> o;
+            lbf_observe(q, s, p, o);
+            for (int d = 0; d < D; ++d) obs[((size_t)p * q.n_envs + n) * D + d] = o.v[d];
+        }
+    }
+}
+
+template <int P, int F>
+static void run_step(const LbfParams& q, uint8_t* state, const int32_t* actions, float* obs, float* rew, double* raw_out,
+                     uint8_t* done, uint8_t* trunc) {
+    const int stride = lbf_state_stride(P, F), D = 3 * (P + F);
+    for (int n = 0; n < q.n_envs; ++n) {
+        LbfState<P, F> s;
+        lbf_load(state + (size_t)n * stride, s);
+        int a[P];
+        double raw[P];
+        float rw[P];
+        bool d = false;
+        for (int p = 0; p < P; ++p) a[p] = actions[(size_t)p * q.n_envs + n];
+        lbf_step(q, s, a, raw, d);
+        lbf_wrap_rewards<P>(q, raw, rw);
+        lbf_store(state + (size_t)n * stride, s);
+        done[n] = d;
+        trunc[n] = q.time_limit > 0 && s.step >= q.time_limit;
+        for (int p = 0; p < P; ++p) {
+            rew[(size_t)p * q.n_envs + n] = rw[p];
+            raw_out[(size_t)p * q.n_envs + n] = raw[p];
+            LbfObs<P, F> o;
+            lbf_observe(q, s, p, o);
+            for (int dd = 0; dd < D; ++dd) obs[((size_t)p * q.n_envs + n) * D + dd] = o.v[dd];
+        }
+    }
+}
+
+#define SHAPES(X) X(2, 2) X(2, 3) X(3, 3) X(3, 5) X(4, 3) X(4, 5) X(8, 5)
+
+extern "C" int host_lbf_stride(int P, int F) { return lbf_state_stride(P, F); }
+
+extern "C" int host_lbf_reset(const HostCfg* c, uint8_t* state, const uint32_t* episode, float* obs) {
+    const LbfParams q = conv(c);
+#define X(p, f) if (c->n_agents == p && c->n_food == f) { run_reset<p, f>(q, state, episode, obs); return 0; }
+    SHAPES(X)
+#undef X
+    return -1;
+}
+
+extern "C" int host_lbf_step(const HostCfg* c, uint8_t* state, const int32_t* actions, float* obs, float* rew, double* raw,
+                             uint8_t* done, uint8_t* trunc) {
+    const LbfParams q = conv(c);
+#define X(p, f) if (c->n_agents == p && c->n_food == f) { run_step<p, f>(q, state, actions, obs, rew, raw, done, trunc); return 0; }
+    SHAPES(X)
+#undef X
+    return -1;
+}
+
+extern "C" void host_philox(const uint32_t* ctr, const uint32_t* key, uint32_t* out) {
+    U4 c; c.x = ctr[0]; c.y = ctr[1]; c.z = ctr[2]; c.w = ctr[3];
+    U4 r = philox4x32_10(c, key[0], key[1]);
+    out[0] = r.x; out[1] = r.y; out[2] = r.z; out[3] = r.w;
+}
