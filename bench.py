@@ -1,0 +1,257 @@
+#!/usr/bin/env python
+"""bench.py - env-steps/s of the IDQN hot path on Foraging-8x8-2p-3f (BASELINE.json metric).
+
+    python bench.py [--gpus N --steps K --warmup W]          (N>1: launched by torch.distributed.run)
+
+One "step" = one ROUND of the hot path on this rank's N_env batched envs:
+    fused collector (reset -> T x (act, env.step, replay add))             1 launch
+    U x ( replay sample-gather of B episodes -> loss/grad -> [RCCL all-reduce] -> clip+Adam+target )
+Cadence (the reference's 1 update of 32 episodes per collected episode cannot be
+kept sequentially at 10M steps/s): the default keeps the reference's REPLAY RATIO - 32 sampled
+episodes per collected episode - but batches the gradient steps: U = 32 updates of B = N_env
+episodes per round.  `--cadence reference` runs the reference's own cadence (N_env sequential
+updates of 32 episodes per round); `--cadence env-only` runs the collector alone.  The timed region
+contains every kernel of the path incl. optimizer and target updates; inputs are resident in HBM.
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel: fused loss/grad, f32 MFMA-bound) and
+`cpu_baseline` (the oracle port of the reference path on the host cores; N=1 only).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+ENV_NAME = "lbforaging:Foraging-8x8-2p-3f-v3"
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense f32-input MFMA peak
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--envs", type=int, default=4096, help="batched envs per GPU")
+    ap.add_argument("--hidden", type=int, default=64)
+    ap.add_argument("--time-limit", type=int, default=25)
+    ap.add_argument("--cadence", default="ratio", choices=["ratio", "reference", "env-only"])
+    ap.add_argument("--update-batch", type=int, default=0, help="episodes per update (default: envs for ratio, 32 for reference)")
+    ap.add_argument("--updates-per-round", type=int, default=0)
+    ap.add_argument("--replay-rounds", type=int, default=4, help="replay capacity in rounds of `envs` episodes")
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(seconds, hidden):
+    """Reference CPU path restated (oracle): python LBF env under the reference wrapper stack +
+    torch-CPU QNetwork/ReplayBuffer port, reference cadence (1 update of 32 episodes per episode once
+    32 episodes are stored), 1 thread as marlbase/run.py:29.  Bounded sample, FPS as loggers.py:70."""
+    import numpy as np
+    import torch
+
+    from oracle import dqn_port as dp
+    from oracle.lbf import MarlbaseEnv
+
+    torch.set_num_threads(1)
+    P, D, A, T = 2, 15, 6, 25
+    env = MarlbaseEnv(ENV_NAME, T, rng=np.random.default_rng(0))
+    learner = dp.Learner(dp.init_params(P, D, hidden, A, seed=0), D, hidden, A)
+    rb = dp.ReplayBuffer(10000, P, D, T)
+    rng = np.random.default_rng(1)
+    eps_sched = dp.epsilon_schedule("linear", 0.5, 1.0, 0.05, 6.5, 100000)
+    steps = updates = 0
+    # fill 32 episodes first (untimed) so the timed window is the steady state after training_start
+    t0 = None
+    while True:
+        if t0 is None and rb.can_sample(32):
+            t0, s0 = time.perf_counter(), steps
+        if t0 is not None and time.perf_counter() - t0 >= seconds:
+            break
+        obs, _ = env.reset()
+        rb.init_episode(obs)
+        done = False
+        eps = eps_sched(steps)
+        while not done:
+            o = torch.tensor(np.stack(obs)).unsqueeze(1)
+            acts, _ = dp.act(learner.flat().detach(), o, eps, torch.tensor([rng.random()], dtype=torch.float32),
+                             torch.tensor(rng.integers(0, A, (P, 1))), D, hidden, A)
+            acts = [int(a) for a in acts[:, 0]]
+            obs, rew, d, tr, info = env.step(acts)
+            done = d or tr
+            rb.add(obs, acts, rew, done)
+            steps += 1
+        if rb.can_sample(32):
+            learner.update(rb.sample(32))
+            updates += 1
+    dt = time.perf_counter() - t0
+    return {"value": (steps - s0) / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
+            "sample": f"{steps - s0} env-steps / {updates} updates of oracle/lbf.py + oracle/dqn_port.py "
+                      f"(python LBF env + torch-CPU IDQN {hidden}-{hidden}, reference cadence: 1 update of 32 episodes "
+                      f"per episode, 1 thread) in {dt:.1f} s; host has {os.cpu_count()} cores"}
+
+
+def main():
+    args = parse()
+    import torch
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an AMD GPU: the marlhip hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
+
+    from codebase_amd import hip as h
+    from codebase_amd._lib import lib
+    from oracle import dqn_port as dp  # parameter init only (orthogonal init, utils/models.py:8-11)
+
+    N, T, H = args.envs, args.time_limit, args.hidden
+    cfg = h.lbf_config(ENV_NAME, N, T, seed=args.seed + 1000003 * rank)
+    P, D, A = cfg.n_agents, 3 * (cfg.n_agents + cfg.n_food), 6
+    spec = h.NetSpec(P, D, H, A)
+    p0 = dp.init_params(P, D, H, A, seed=args.seed)  # identical on every rank
+    params, target = p0.cuda(), p0.clone().cuda()
+    cap = args.replay_rounds * N
+    rb = h.DeviceReplay(cap, P, D, T)
+    finr = torch.zeros(P, N, device="cuda")
+    finl = torch.zeros(N, dtype=torch.int32, device="cuda")
+    up = h.DqnUpdater(spec, params, target, lr=3e-4, gamma=0.99, grad_clip=1.0, double_q=True)
+
+    if args.cadence == "ratio":
+        B = args.update_batch or N
+        U = args.updates_per_round or max(1, (32 * N) // B)
+    elif args.cadence == "reference":
+        B = args.update_batch or 32
+        U = args.updates_per_round or N
+    else:
+        B, U = 0, 0
+    eps_sched = dp.epsilon_schedule("linear", 0.5, 1.0, 0.05, 6.5, 100_000_000)
+    target_interval = 200
+    steps_dev = torch.zeros((), dtype=torch.int64, device="cuda")
+    state = dict(round=0, updates=0, last_target=0)
+
+    def one_round():
+        r = state["round"]
+        h.idqn_collect(cfg, spec, params, eps_sched(r * N * T), r, rb, (r * N) % cap, finr, finl)
+        steps_dev.add_(finl.sum())
+        length = min((r + 1) * N, cap)
+        for _ in range(U):
+            batch = rb.sample(B, length=length, seed=args.seed + rank, counter=state["updates"])
+            up.loss_grad(batch)
+            if dist is not None:
+                dist.all_reduce(up.grad)  # SUM over ranks; clip_adam scales by 1/world
+            state["updates"] += 1
+            hard = (state["updates"] - state["last_target"]) >= target_interval
+            up.apply(hard_update=hard, grad_scale=1.0 / world)
+            if hard:
+                state["last_target"] = state["updates"]
+        state["round"] += 1
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_round()
+    sync()
+    steps_dev.zero_()
+    if not args.no_kernel_timing:
+        lib.marlhip_timing_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_round()
+    sync()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt[0])
+        dist.all_reduce(steps_dev)
+    env_steps = int(steps_dev.item())
+
+    timing = {}
+    if not args.no_kernel_timing:
+        for kid, kname in ((0, "dqn_lossgrad_kernel"), (1, "idqn_collect_kernel"), (2, "replay_sample_kernel")):
+            n, ms = ctypes.c_int64(0), ctypes.c_double(0.0)
+            lib.marlhip_timing_read(kid, ctypes.byref(n), ctypes.byref(ms))
+            if n.value:
+                timing[kname] = {"launches": n.value, "avg_us": 1e3 * ms.value / n.value, "total_ms": ms.value}
+        lib.marlhip_timing_enable(0)
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    fwd_flops_row = 2.0 * (D * H + H * H + H * A)
+    roofline = None
+    if U and "dqn_lossgrad_kernel" in timing:
+        # algorithmic flops per launch: critic fwd on P*B*(T+1) rows, target fwd on P*B*T, backward (2x fwd) on P*B*T
+        flops = fwd_flops_row * P * B * ((T + 1) + T + 2 * T)
+        avg_s = timing["dqn_lossgrad_kernel"]["avg_us"] * 1e-6
+        ach = flops / avg_s / 1e12
+        roofline = {"kernel": "dqn_lossgrad_kernel", "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
+                    "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                    "flops_per_launch": flops, "avg_launch_us": timing["dqn_lossgrad_kernel"]["avg_us"]}
+    elif "idqn_collect_kernel" in timing:
+        # env-only: the collector's HBM traffic is the replay write, 4*P*D + P + 4*P + 2 bytes per env-step (+ row 0)
+        per_step = 4 * P * D + P + 4 * P + 2
+        byts = per_step * env_steps / args.steps + 4 * P * D * N
+        avg_s = timing["idqn_collect_kernel"]["avg_us"] * 1e-6
+        ach = byts / avg_s / 1e9
+        roofline = {"kernel": "idqn_collect_kernel", "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": ach / PEAK_HBM_GBS, "traffic": None, "bytes_per_launch": byts,
+                    "avg_launch_us": timing["idqn_collect_kernel"]["avg_us"]}
+
+    out = {
+        "metric": "env-steps/sec (whole node) IDQN Foraging-8x8-2p-3f",
+        "value": env_steps / dt,
+        "unit": "env-steps/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic (Philox-seeded LBF layouts, orthogonal-init weights)",
+        "config": {
+            "workload": f"IDQN on Foraging-8x8-2p-3f, {N} batched HIP envs per GPU, 2-layer-{H} MLP, time_limit {T}",
+            "cadence": args.cadence,
+            "envs_per_gpu": N,
+            "updates_per_round": U,
+            "update_batch_episodes": B,
+            "sampled_episodes_per_collected_episode": (U * B) / N if N else 0,
+            "replay_capacity_episodes": cap,
+            "parallelism": f"dp{world} (envs + replay sharded per GPU, RCCL grad all-reduce per update)" if world > 1 else "1 GPU",
+            "env_steps_timed": env_steps,
+        },
+        "kernels": timing,
+        "roofline": roofline,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, H)
+    print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

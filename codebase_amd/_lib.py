@@ -1,0 +1,98 @@
+"""ctypes binding of libmarlhip.so (include/marlhip.h).  No fallbacks: if the library is not
+built, importing this module raises; if a call fails, MarlHipError carries marlhip_last_error()."""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int32, c_int64, c_uint8, c_uint32, c_uint64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmarlhip.so")
+
+
+class MarlHipError(RuntimeError):
+    pass
+
+
+class LbfConfig(ctypes.Structure):
+    _fields_ = [
+        ("n_envs", c_int32), ("n_agents", c_int32), ("n_food", c_int32), ("rows", c_int32), ("cols", c_int32),
+        ("sight", c_int32), ("max_episode_steps", c_int32), ("time_limit", c_int32), ("force_coop", c_int32),
+        ("min_player_level", c_int32), ("max_player_level", c_int32), ("min_food_level", c_int32),
+        ("max_food_level", c_int32), ("normalize_reward", c_int32), ("cooperative", c_int32),
+        ("penalty", c_double), ("seed", c_uint64),
+    ]
+
+
+class LbfBuffers(ctypes.Structure):
+    _fields_ = [("state", c_void_p), ("episode", c_void_p), ("ep_return", c_void_p), ("ep_length", c_void_p)]
+
+
+class NetShape(ctypes.Structure):
+    _fields_ = [("n_agents", c_int32), ("obs_dim", c_int32), ("hidden", c_int32), ("n_actions", c_int32)]
+
+
+class ReplayShape(ctypes.Structure):
+    _fields_ = [("capacity", c_int32), ("n_agents", c_int32), ("obs_dim", c_int32), ("max_len", c_int32)]
+
+
+class ReplayBuffers(ctypes.Structure):
+    _fields_ = [("obs", c_void_p), ("act", c_void_p), ("rew", c_void_p), ("done", c_void_p), ("filled", c_void_p)]
+
+
+class BatchStruct(ctypes.Structure):
+    _fields_ = [("obss", c_void_p), ("actions", c_void_p), ("rewards", c_void_p), ("dones", c_void_p),
+                ("filled", c_void_p), ("max_len", c_int32), ("batch", c_int32)]
+
+
+# every symbol include/marlhip.h declares: name -> (restype, argtypes)
+PROTOTYPES = {
+    "marlhip_version": (c_int32, []),
+    "marlhip_last_error": (c_char_p, []),
+    "marlhip_device_available": (c_int32, []),
+    "marlhip_lbf_state_stride": (c_int32, [POINTER(LbfConfig)]),
+    "marlhip_lbf_obs_dim": (c_int32, [POINTER(LbfConfig)]),
+    "marlhip_lbf_reset": (c_int32, [POINTER(LbfConfig), POINTER(LbfBuffers), c_void_p, c_void_p, c_void_p]),
+    "marlhip_lbf_observe": (c_int32, [POINTER(LbfConfig), POINTER(LbfBuffers), c_void_p, c_void_p]),
+    "marlhip_lbf_step": (c_int32, [POINTER(LbfConfig), POINTER(LbfBuffers), c_void_p, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
+    "marlhip_net_nparams": (c_int32, [POINTER(NetShape)]),
+    "marlhip_dqn_act": (c_int32, [POINTER(NetShape), c_void_p, c_void_p, c_int32, c_float, c_void_p, c_void_p, c_uint64,
+                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "marlhip_replay_init_episode": (c_int32, [POINTER(ReplayShape), POINTER(ReplayBuffers), c_void_p, c_void_p, c_void_p,
+                                              c_int32, c_void_p]),
+    "marlhip_replay_add": (c_int32, [POINTER(ReplayShape), POINTER(ReplayBuffers), c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
+    "marlhip_replay_sample": (c_int32, [POINTER(ReplayShape), POINTER(ReplayBuffers), c_void_p, c_int32, c_int32, c_uint64,
+                                        c_uint32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "marlhip_dqn_workspace_bytes": (c_int64, [POINTER(NetShape), c_int32, c_int32]),
+    "marlhip_dqn_loss_grad": (c_int32, [POINTER(NetShape), c_void_p, c_void_p, POINTER(BatchStruct), c_float, c_int32,
+                                        c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "marlhip_dqn_clip_adam": (c_int32, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_double,
+                                        c_double, c_double, c_double, c_float, c_float, c_int32, c_float, c_void_p,
+                                        c_void_p, c_void_p]),
+    "marlhip_timing_enable": (c_int32, [c_int32]),
+    "marlhip_timing_read": (c_int32, [c_int32, POINTER(c_int64), POINTER(c_double)]),
+    "marlhip_idqn_collect": (c_int32, [POINTER(LbfConfig), POINTER(NetShape), c_void_p, c_float, c_uint32,
+                                       POINTER(ReplayShape), POINTER(ReplayBuffers), c_int32, c_int32, c_int32, c_int32,
+                                       c_void_p, c_void_p, c_void_p]),
+}
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: build the HIP library first (python -m codebase_amd.build). "
+        "There is no CPU fallback for the marlhip hot path.")
+
+lib = ctypes.CDLL(LIB_PATH)
+for _name, (_res, _args) in PROTOTYPES.items():
+    _fn = getattr(lib, _name)  # AttributeError here = header and library out of sync
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+def last_error():
+    return lib.marlhip_last_error().decode()
+
+
+def check(rc, what=""):
+    if rc < 0:
+        raise MarlHipError(f"{what}: {last_error()}" if what else last_error())
+    return rc

@@ -1,0 +1,487 @@
+// IDQN learner step on gfx950 (K5-K8): fused critic/target forward + Double-Q TD target + masked
+// MSE + backward on f32 MFMA, deterministic partial-gradient reduction, global-norm clip + Adam +
+// target update.  Replaces QNetwork._compute_loss / update (marlbase/dqn/model.py:118-196).
+//
+// Work decomposition (oracle/mfma_emul.py is the lane-level statement of this file):
+//   wave task = (agent p, group of 16 episodes, chunk [t0,t1) of transitions); a workgroup (4
+//   waves) serves ONE agent whose critic / target / transposed weights sit in LDS as MFMA
+//   A-operand packs.  A task walks time BACKWARDS: at step t it forwards the critic on the 16
+//   rows obs[p][t][b0..b0+15], turns the bootstrap value carried from step t+1 into the TD error
+//   of transition t, back-propagates that row block immediately (activations never leave
+//   registers except for the two LDS transposes the weight-gradient GEMMs need), then forwards
+//   the target net on the same rows to produce the bootstrap value for transition t-1.
+//   Weight gradients accumulate in MFMA accumulators across all tasks of the wave; the 4 waves
+//   fold through LDS and the workgroup writes ONE partial record; a second kernel sums records
+//   in fixed order (bitwise reproducible, no float atomics) and applies 1/sum(filled).
+// MFMA-bound: 360 v_mfma_f32_16x16x4_f32 per 16-row block at H=64 (96 critic fwd, 96 target
+// fwd, 168 backward) = 46.1 kFLOP/row issued vs 43.5 kFLOP/row algorithmic.
+#include "common.h"
+#include "mlp.h"
+
+namespace marl {
+
+constexpr int UPD_BLOCK = 256;
+
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// C-layout registers regs[MT] -> LDS tile[h][16 rows]
+template <int MT>
+__device__ __forceinline__ void tile_write(float* tile, const f4 (&regs)[MT], int g, int j) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tile[(16 * mt + 4 * g + r) * 16 + j] = regs[mt][r];
+}
+
+// lane (g,i) reads tile[16mt+i][4g..4g+3]: operand registers of k-steps ks=0..3 (row 4g+ks)
+__device__ __forceinline__ f4 tile_read(const float* tile, int mt, int g, int i) {
+    return *reinterpret_cast<const f4*>(tile + (16 * mt + i) * 16 + 4 * g);
+}
+
+__device__ __forceinline__ float sum16(float v) {  // over the 16 lanes j of one g
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 8);
+    return v;
+}
+
+template <class S>
+struct UpdLds {
+    static constexpr int TILE = 16 * S::H;                    // one [H][16] transpose tile
+    static constexpr int PER_WAVE = 2 * TILE + 256;           // activation tile, gradient tile, dQ tile
+    static constexpr int oC = 0, oT = S::NFWD, oB = 2 * S::NFWD, oTiles = oB + S::NBWD;
+    static constexpr int TOTAL = oTiles + 4 * PER_WAVE;       // floats
+    static constexpr int REC = S::NPARAM + 2;                 // partial record: grads, loss, n_filled
+    static_assert(2 * S::NFWD >= REC, "fold buffer");
+};
+
+template <class S>
+__global__ __launch_bounds__(UPD_BLOCK) void dqn_lossgrad_kernel(const float* __restrict__ params,
+                                                                 const float* __restrict__ tparams, marlhip_batch bt,
+                                                                 float gamma, int double_q, int n_chunks,
+                                                                 float* __restrict__ partials) {
+    using L = UpdLds<S>;
+    constexpr int MT = S::MT, NT1 = S::DP / 16, D = S::D, H = S::H, A = S::A;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, j = lane & 15;
+    const int p = blockIdx.y;
+    const int T = bt.max_len, B = bt.batch;
+
+    mlp_stage_fwd<S>(params + (size_t)p * S::NPARAM, lds + L::oC, tid, UPD_BLOCK);
+    mlp_stage_fwd<S>(tparams + (size_t)p * S::NPARAM, lds + L::oT, tid, UPD_BLOCK);
+    mlp_stage_bwd<S>(params + (size_t)p * S::NPARAM, lds + L::oB, tid, UPD_BLOCK);
+    __syncthreads();
+
+    const float* cpk = lds + L::oC;
+    const float* tpk = lds + L::oT;
+    const f4* T3 = reinterpret_cast<const f4*>(lds + L::oB + S::pT3);
+    const f4* T2 = reinterpret_cast<const f4*>(lds + L::oB + S::pT2);
+    float* TA = lds + L::oTiles + wave * L::PER_WAVE;
+    float* TG = TA + L::TILE;
+    float* TQ = TG + L::TILE;
+
+    const float* obs_p = bt.obss + (size_t)p * (T + 1) * B * D;
+    const int64_t* act_p = bt.actions + (size_t)p * T * B;
+    const float* rew_p = bt.rewards + (size_t)p * T * B;
+
+    const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f4 dW1[MT][NT1], dW2[MT][MT], dW3[MT], db1[MT], db2[MT], db3 = zero4;
+#pragma unroll
+    for (int a = 0; a < MT; ++a) {
+        dW3[a] = zero4; db1[a] = zero4; db2[a] = zero4;
+#pragma unroll
+        for (int b = 0; b < MT; ++b) dW2[a][b] = zero4;
+#pragma unroll
+        for (int b = 0; b < NT1; ++b) dW1[a][b] = zero4;
+    }
+    float loss_acc = 0.f, nfill_acc = 0.f;
+
+    const int ngroups = (B + 15) >> 4;
+    const int ntasks = ngroups * n_chunks;
+    for (int task = blockIdx.x * 4 + wave; task < ntasks; task += gridDim.x * 4) {
+        const int grp = task / n_chunks, c = task - grp * n_chunks;
+        const int t0 = (c * T) / n_chunks, t1 = ((c + 1) * T) / n_chunks;
+        if (t1 <= t0) continue;
+        const int b0 = grp * 16;
+        const bool rowok = (b0 + j) < B;
+        const int bj = rowok ? b0 + j : B - 1;
+        float tq_next = 0.f;
+        for (int t = t1; t >= t0; --t) {
+            float x[S::KS1];
+            const float* xrow = obs_p + ((size_t)t * B + bj) * D;
+#pragma unroll
+            for (int ks = 0; ks < S::KS1; ++ks) {
+                const int d = 4 * ks + g;
+                x[ks] = (d < D && rowok) ? xrow[d] : 0.f;
+            }
+            f4 h1[MT], h2[MT], q;
+            mlp_forward<S>(cpk, lane, x, h1, h2, q);
+            if (t < t1) {
+                // ---- TD error of transition t (model.py:129,152,160-163)
+                const int a_sel = (int)act_p[(size_t)t * B + bj];
+                const float rw = rew_p[(size_t)t * B + bj];
+                const float dn = bt.dones[(size_t)(t + 1) * B + bj];
+                const float fl = rowok ? bt.filled[(size_t)t * B + bj] : 0.f;
+                const float y = rw + gamma * tq_next * (1.f - dn);
+                const float delta = gather_rows(q, lane, a_sel) - y;
+                if (g == 0) { loss_acc += fl * delta * delta; nfill_acc += fl; }
+                const float dqs = 2.f * fl * delta;
+                f4 dQ[1];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dQ[0][r] = (4 * g + r == a_sel) ? dqs : 0.f;
+                // ---- dW3[a][h2] += dQ^T H2 ; db3
+                wave_lds_fence();
+                tile_write<1>(TQ, dQ, g, j);
+                tile_write<MT>(TA, h2, g, j);
+                wave_lds_fence();
+                {
+                    const f4 aop = tile_read(TQ, 0, g, j);
+#pragma unroll
+                    for (int nt = 0; nt < MT; ++nt) {
+                        const f4 bop = tile_read(TA, nt, g, j);
+#pragma unroll
+                        for (int ks = 0; ks < 4; ++ks) dW3[nt] = MARL_MFMA(aop[ks], bop[ks], dW3[nt]);
+                    }
+                }
+                db3 += dQ[0];
+                // ---- dH2^T = W3^T dQ^T (relu mask)
+                f4 dH2[MT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const f4 a = T3[mt * 64 + lane];
+                    f4 acc = zero4;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc = MARL_MFMA(a[r], dQ[0][r], acc);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[r] = h2[mt][r] > 0.f ? acc[r] : 0.f;
+                    dH2[mt] = acc;
+                    db2[mt] += acc;
+                }
+                // ---- dW2[h2][h1] += dH2^T H1
+                wave_lds_fence();
+                tile_write<MT>(TG, dH2, g, j);
+                tile_write<MT>(TA, h1, g, j);
+                wave_lds_fence();
+                {
+                    f4 bop[MT];
+#pragma unroll
+                    for (int nt = 0; nt < MT; ++nt) bop[nt] = tile_read(TA, nt, g, j);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        const f4 aop = tile_read(TG, mt, g, j);
+#pragma unroll
+                        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                            for (int nt = 0; nt < MT; ++nt) dW2[mt][nt] = MARL_MFMA(aop[ks], bop[nt][ks], dW2[mt][nt]);
+                    }
+                }
+                // ---- dH1^T = W2^T dH2^T (relu mask)
+                f4 dH1[MT];
+#pragma unroll
+                for (int m1 = 0; m1 < MT; ++m1) dH1[m1] = zero4;
+#pragma unroll
+                for (int m2 = 0; m2 < MT; ++m2) {
+                    f4 a[MT];
+#pragma unroll
+                    for (int m1 = 0; m1 < MT; ++m1) a[m1] = T2[(m1 * MT + m2) * 64 + lane];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int m1 = 0; m1 < MT; ++m1) dH1[m1] = MARL_MFMA(a[m1][r], dH2[m2][r], dH1[m1]);
+                }
+#pragma unroll
+                for (int m1 = 0; m1 < MT; ++m1) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dH1[m1][r] = h1[m1][r] > 0.f ? dH1[m1][r] : 0.f;
+                    db1[m1] += dH1[m1];
+                }
+                // ---- dW1[h1][d] += dH1^T X   (B operand straight from global: X[row 4g+ks][d=16nt+j])
+                wave_lds_fence();
+                tile_write<MT>(TG, dH1, g, j);
+                wave_lds_fence();
+#pragma unroll
+                for (int nt = 0; nt < NT1; ++nt) {
+                    float bx[4];
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        const int row = b0 + 4 * g + ks, d = 16 * nt + j;
+                        bx[ks] = (row < B && d < D) ? obs_p[((size_t)t * B + row) * D + d] : 0.f;
+                    }
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        const f4 aop = tile_read(TG, mt, g, j);
+#pragma unroll
+                        for (int ks = 0; ks < 4; ++ks) dW1[mt][nt] = MARL_MFMA(aop[ks], bx[ks], dW1[mt][nt]);
+                    }
+                }
+            }
+            if (t > t0) {
+                // ---- bootstrap value for transition t-1 (model.py:132-145)
+                f4 u1[MT], u2[MT], tq;
+                mlp_forward<S>(tpk, lane, x, u1, u2, tq);
+                const int a_p = double_q ? argmax_rows<A>(q, lane) : argmax_rows<A>(tq, lane);
+                tq_next = gather_rows(tq, lane, a_p);
+            }
+        }
+    }
+
+    // ---- fold the 4 waves through LDS (fixed order), write one partial record per workgroup
+    __syncthreads();
+    float* fold = lds;  // overlays the (now unused) critic/target packs
+    const float lsum = sum16(loss_acc), nsum = sum16(nfill_acc);  // values sit in lanes g==0
+#pragma unroll 1
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+            const bool first = (w == 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int o = 16 * mt + 4 * g + r;
+#pragma unroll
+                    for (int nt = 0; nt < NT1; ++nt) {
+                        const int d = 16 * nt + j;
+                        if (d < D) {
+                            float* dst = fold + S::oW1 + o * D + d;
+                            *dst = first ? dW1[mt][nt][r] : *dst + dW1[mt][nt][r];
+                        }
+                    }
+#pragma unroll
+                    for (int nt = 0; nt < MT; ++nt) {
+                        float* dst = fold + S::oW2 + o * H + 16 * nt + j;
+                        *dst = first ? dW2[mt][nt][r] : *dst + dW2[mt][nt][r];
+                    }
+                    const float s1 = sum16(db1[mt][r]), s2 = sum16(db2[mt][r]);
+                    if (j == 0) {
+                        fold[S::ob1 + o] = first ? s1 : fold[S::ob1 + o] + s1;
+                        fold[S::ob2 + o] = first ? s2 : fold[S::ob2 + o] + s2;
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int a = 4 * g + r;
+#pragma unroll
+                for (int nt = 0; nt < MT; ++nt) {
+                    if (a < A) {
+                        float* dst = fold + S::oW3 + a * H + 16 * nt + j;
+                        *dst = first ? dW3[nt][r] : *dst + dW3[nt][r];
+                    }
+                }
+                const float s3 = sum16(db3[r]);
+                if (j == 0 && a < A) fold[S::ob3 + a] = first ? s3 : fold[S::ob3 + a] + s3;
+            }
+            if (lane == 0) {
+                fold[S::NPARAM] = first ? lsum : fold[S::NPARAM] + lsum;
+                fold[S::NPARAM + 1] = first ? nsum : fold[S::NPARAM + 1] + nsum;
+            }
+        }
+        __syncthreads();
+    }
+    float* rec = partials + ((size_t)p * gridDim.x + blockIdx.x) * L::REC;
+    for (int i = tid; i < L::REC; i += UPD_BLOCK) rec[i] = fold[i];
+}
+
+// grad[p][i] = (sum over the agent's records) / n_filled ; loss = sum of all loss fields / n_filled.
+// n_filled comes from agent 0's records only (every agent sees the same filled mask).
+__global__ __launch_bounds__(256) void dqn_reduce_kernel(const float* __restrict__ partials, int P, int nwg, int nparam,
+                                                         float* __restrict__ grad, float* __restrict__ loss) {
+    __shared__ float s_nf, s_loss;
+    const int rec = nparam + 2;
+    if (threadIdx.x == 0) {
+        float nf = 0.f, ls = 0.f;
+        for (int w = 0; w < nwg; ++w) nf += partials[(size_t)w * rec + nparam + 1];
+        for (int w = 0; w < P * nwg; ++w) ls += partials[(size_t)w * rec + nparam];
+        s_nf = nf;
+        s_loss = ls;
+    }
+    __syncthreads();
+    const float nf = s_nf;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < P * nparam) {
+        const int p = i / nparam, k = i - p * nparam;
+        const float* src = partials + (size_t)p * nwg * rec + k;
+        float acc = 0.f;
+        for (int w = 0; w < nwg; ++w) acc += src[(size_t)w * rec];
+        grad[i] = acc / nf;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        loss[0] = s_loss / nf;
+        loss[1] = nf;
+    }
+}
+
+// ---- clip_grad_norm_ + Adam + target update (model.py:169-196) -----------------------------
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ grad, int64_t n, float scale,
+                                                    float* __restrict__ scratch) {
+    __shared__ float red[4];
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    float v = 0.f;
+    if (i < n) {
+        const float gv = grad[i] * scale;
+        v = gv * gv;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) scratch[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+struct AdamArgs {
+    float lr_step;    // fp32(lr / (1 - beta1^step))
+    float bc2_sqrt;   // fp32(sqrt(1 - beta2^step))
+    float w1;         // fp32(1 - beta1): lerp weight
+    float beta2, w2;  // beta2, fp32(1 - beta2)
+    float eps, max_norm, grad_scale, tau;
+    int hard_update;
+};
+
+__global__ __launch_bounds__(256) void adam_kernel(int64_t n, int nblocks, float* __restrict__ params,
+                                                   const float* __restrict__ grad, float* __restrict__ m,
+                                                   float* __restrict__ v, float* __restrict__ target, AdamArgs a,
+                                                   const float* __restrict__ scratch, float* __restrict__ gnorm_out) {
+    __shared__ float s_coef;
+    if (threadIdx.x == 0) {
+        float ss = 0.f;
+        for (int b = 0; b < nblocks; ++b) ss += scratch[b];
+        const float total = sqrtf(ss);
+        // clip_coef = max_norm / (total_norm + 1e-6), clamped to 1 (torch.nn.utils.clip_grad_norm_)
+        float coef = 1.f;
+        if (a.max_norm > 0.f) coef = fminf(a.max_norm / (total + 1e-6f), 1.f);
+        s_coef = coef;
+        if (gnorm_out != nullptr && blockIdx.x == 0) gnorm_out[0] = total;
+    }
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float gv = (grad[i] * a.grad_scale) * s_coef;
+    // torch.optim.Adam (single-tensor): lerp_, mul_/addcmul_, sqrt/div/add_, addcdiv_
+    float mi = m[i], vi = v[i];
+    mi = mi + a.w1 * (gv - mi);
+    vi = vi * a.beta2 + a.w2 * gv * gv;
+    const float denom = sqrtf(vi) / a.bc2_sqrt + a.eps;
+    float pi = params[i];
+    pi = pi + (-a.lr_step) * (mi / denom);
+    m[i] = mi;
+    v[i] = vi;
+    params[i] = pi;
+    if (target != nullptr) {
+        if (a.hard_update) target[i] = pi;
+        else if (a.tau > 0.f) target[i] = (1.f - a.tau) * target[i] + a.tau * pi;
+    }
+}
+
+struct UpdPlan {
+    int nwg, n_chunks;
+};
+
+inline UpdPlan upd_plan(int P, int T, int B) {
+    const int ngroups = (B + 15) / 16;
+    const int want_waves = 1024 / (P > 0 ? P : 1) > 4 ? 1024 / P : 4;  // ~1 wave per SIMD over the chip
+    int nc = (want_waves + ngroups - 1) / ngroups;
+    if (nc < 1) nc = 1;
+    if (nc > T) nc = T;
+    const int tasks = ngroups * nc;
+    int nwg = (tasks + 3) / 4;
+    const int cap = 256 / P > 1 ? 256 / P : 1;
+    if (nwg > cap) nwg = cap;
+    UpdPlan pl = {nwg, nc};
+    return pl;
+}
+
+template <class S>
+int launch_lossgrad(const marlhip_net_shape* s, const float* params, const float* tparams, const marlhip_batch* bt, float gamma,
+                    int double_q, void* ws, int64_t ws_bytes, float* grad, float* loss, hipStream_t st) {
+    using L = UpdLds<S>;
+    const UpdPlan pl = upd_plan(s->n_agents, bt->max_len, bt->batch);
+    const int64_t need = (int64_t)s->n_agents * pl.nwg * L::REC * sizeof(float);
+    MARL_REQUIRE(ws_bytes >= need, "dqn_loss_grad: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)need);
+    const size_t lds_bytes = (size_t)L::TOTAL * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dqn_lossgrad_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds_bytes);
+        attr_set = true;
+    }
+    timing_begin(TIMER_LOSSGRAD, st);
+    hipLaunchKernelGGL((dqn_lossgrad_kernel<S>), dim3(pl.nwg, s->n_agents), dim3(UPD_BLOCK), lds_bytes, st, params, tparams, *bt,
+                       gamma, double_q, pl.n_chunks, (float*)ws);
+    timing_end(TIMER_LOSSGRAD, st);
+    MARL_CHECK_LAUNCH("dqn_lossgrad_kernel");
+    const int n = s->n_agents * S::NPARAM;
+    hipLaunchKernelGGL(dqn_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)ws, s->n_agents, pl.nwg,
+                       S::NPARAM, grad, loss);
+    MARL_CHECK_LAUNCH("dqn_reduce_kernel");
+    return 0;
+}
+
+}  // namespace marl
+
+using namespace marl;
+
+// shapes with an update kernel (H=64: packs + tiles = 108 KB LDS, dW accumulators in registers)
+#define MARL_UPD_SHAPES(X) X(12, 64, 6) X(15, 64, 6) X(18, 64, 6) X(21, 64, 6) X(24, 64, 6) X(27, 64, 6) X(39, 64, 6)
+
+extern "C" int marlhip_net_nparams(const marlhip_net_shape* s) {
+    MARL_REQUIRE(s != nullptr, "net shape is NULL");
+#define X(d, h, a) if (s->obs_dim == d && s->hidden == h && s->n_actions == a) return MlpShape<d, h, a>::NPARAM;
+    MARL_NET_SHAPES(X)
+#undef X
+    set_error("no MFMA kernel for net shape D=%d H=%d A=%d (add it to MARL_NET_SHAPES)", s->obs_dim, s->hidden, s->n_actions);
+    return -1;
+}
+
+extern "C" int64_t marlhip_dqn_workspace_bytes(const marlhip_net_shape* s, int32_t max_len, int32_t batch) {
+    const int np = marlhip_net_nparams(s);
+    if (np < 0) return -1;
+    const UpdPlan pl = upd_plan(s->n_agents, max_len, batch);
+    return (int64_t)s->n_agents * pl.nwg * (np + 2) * sizeof(float);
+}
+
+extern "C" int marlhip_dqn_loss_grad(const marlhip_net_shape* s, const float* params, const float* target_params,
+                                     const marlhip_batch* batch, float gamma, int32_t double_q, int32_t mode, void* workspace,
+                                     int64_t workspace_bytes, float* grad, float* loss, void* stream) {
+    MARL_REQUIRE(s && params && target_params && batch && workspace && grad && loss, "dqn_loss_grad: NULL pointer");
+    MARL_REQUIRE(batch->obss && batch->actions && batch->rewards && batch->dones && batch->filled, "dqn_loss_grad: NULL batch field");
+    MARL_REQUIRE(batch->max_len > 0 && batch->batch > 0, "dqn_loss_grad: empty batch");
+    MARL_REQUIRE(mode == 0, "dqn_loss_grad: mode %d (VDN) not built yet", mode);
+#define X(d, h, a)                                                                                                         \
+    if (s->obs_dim == d && s->hidden == h && s->n_actions == a)                                                            \
+        return launch_lossgrad<MlpShape<d, h, a>>(s, params, target_params, batch, gamma, double_q, workspace, workspace_bytes, \
+                                                  grad, loss, (hipStream_t)stream);
+    MARL_UPD_SHAPES(X)
+#undef X
+    set_error("no update kernel for net shape D=%d H=%d A=%d", s->obs_dim, s->hidden, s->n_actions);
+    return -1;
+}
+
+extern "C" int marlhip_dqn_clip_adam(int64_t n, float* params, const float* grad, float* exp_avg, float* exp_avg_sq,
+                                     float* target_params, int64_t step, double lr, double beta1, double beta2, double eps,
+                                     float max_norm, float grad_scale, int32_t hard_update, float tau, float* scratch,
+                                     float* gnorm_out, void* stream) {
+    MARL_REQUIRE(n > 0 && params && grad && exp_avg && exp_avg_sq && scratch, "dqn_clip_adam: NULL pointer");
+    MARL_REQUIRE(step >= 1, "dqn_clip_adam: step must be >= 1");
+    const int nblocks = (int)((n + 255) / 256);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(sumsq_kernel, dim3(nblocks), dim3(256), 0, st, grad, n, grad_scale, scratch);
+    MARL_CHECK_LAUNCH("sumsq_kernel");
+    AdamArgs a;
+    // python-float (fp64) scalars exactly as torch.optim.adam._single_tensor_adam forms them
+    const double bc1 = 1.0 - pow(beta1, (double)step);
+    const double bc2 = 1.0 - pow(beta2, (double)step);
+    a.lr_step = (float)(lr / bc1);
+    a.bc2_sqrt = (float)sqrt(bc2);
+    a.w1 = (float)(1.0 - beta1);
+    a.beta2 = (float)beta2;
+    a.w2 = (float)(1.0 - beta2);
+    a.eps = (float)eps; a.max_norm = max_norm; a.grad_scale = grad_scale; a.tau = tau; a.hard_update = hard_update;
+    hipLaunchKernelGGL(adam_kernel, dim3(nblocks), dim3(256), 0, st, n, nblocks, params, grad, exp_avg, exp_avg_sq, target_params,
+                       a, (const float*)scratch, gnorm_out);
+    MARL_CHECK_LAUNCH("adam_kernel");
+    return 0;
+}

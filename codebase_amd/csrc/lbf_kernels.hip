@@ -201,12 +201,14 @@ extern "C" int marlhip_lbf_step(const marlhip_lbf_config* cfg, const marlhip_lbf
     const LbfParams q = to_params(cfg);
     const int grid = (cfg->n_envs + ENV_BLOCK - 1) / ENV_BLOCK;
     const size_t lds = (size_t)ENV_BLOCK * 3 * (cfg->n_agents + cfg->n_food) * sizeof(float);
+    timing_begin(TIMER_ENVSTEP, (hipStream_t)stream);
 #define X(p, f)                                                                                                        \
     if (cfg->n_agents == p && cfg->n_food == f)                                                                        \
         hipLaunchKernelGGL((lbf_step_kernel<p, f>), dim3(grid), dim3(ENV_BLOCK), lds, (hipStream_t)stream, q, *buf, active, \
                            actions, obs, rewards, done, truncated, fin_return, fin_length, (int)auto_reset, final_obs);
     MARL_LBF_SHAPES(X)
 #undef X
+    timing_end(TIMER_ENVSTEP, (hipStream_t)stream);
     MARL_CHECK_LAUNCH("lbf_step");
     return 0;
 }

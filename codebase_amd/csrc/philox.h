@@ -95,4 +95,25 @@ struct DrawStream {
     }
 };
 
+
+// Per-step action noise of env `env` at step `t` of episode `episode` (stream STREAM_ACT):
+// word 0 -> u (ONE uniform decides explore-vs-greedy for the whole joint action,
+// marlbase/dqn/model.py:105), word 1+p -> random action of agent p.  Words beyond the first
+// Philox block come from blocks t | (k << 16).
+template <int P>
+MARL_HD void act_noise(uint64_t seed, uint32_t env, uint32_t episode, uint32_t t, uint32_t n_actions, float& u, int (&ra)[P]) {
+    constexpr int NBLK = (1 + P + 3) / 4;
+    uint32_t w[4 * NBLK];
+#pragma unroll
+    for (int k = 0; k < NBLK; ++k) {
+        U4 c;
+        c.x = env; c.y = episode; c.z = t | ((uint32_t)k << 16); c.w = STREAM_ACT;
+        const U4 o = philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+        w[4 * k] = o.x; w[4 * k + 1] = o.y; w[4 * k + 2] = o.z; w[4 * k + 3] = o.w;
+    }
+    u = u01_f32(w[0]);
+#pragma unroll
+    for (int p = 0; p < P; ++p) ra[p] = (int)bounded_nr(w[1 + p], n_actions);
+}
+
 }  // namespace marl

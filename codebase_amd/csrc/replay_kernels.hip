@@ -1,0 +1,151 @@
+// Episode replay (K3 write, K4 sample-gather) - replaces marlbase/dqn/train.py:19-124.
+// Storage is episode-major (one episode = one contiguous record per array); sampling transposes
+// B whole episodes into the reference's time-major Batch layout.  HBM-bound byte movement:
+// per sampled episode read 4*P*D*(T+1) + P*T*(1+4) + (T+1) + T bytes, write
+// 4*P*D*(T+1) + 8*P*T + 4*P*T + 4*(T+1) + 4*T bytes (3,421 B + 3,924 B for 8x8-2p-3f, T=25).
+#include "common.h"
+
+namespace marl {
+
+__global__ __launch_bounds__(256) void replay_add_kernel(marlhip_replay_shape rs, marlhip_replay_buffers rb,
+                                                         const int32_t* __restrict__ slot, const int32_t* __restrict__ tt,
+                                                         const uint8_t* __restrict__ active, const float* __restrict__ obs,
+                                                         const int32_t* __restrict__ actions, const float* __restrict__ rewards,
+                                                         const uint8_t* __restrict__ done, int N, int init_only) {
+    const int P = rs.n_agents, D = rs.obs_dim, T = rs.max_len;
+    const int64_t total = (int64_t)P * N * D;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int d = (int)(i % D);
+        const int n = (int)((i / D) % N);
+        const int p = (int)(i / ((int64_t)D * N));
+        if (active != nullptr && !active[n]) continue;
+        const int row = init_only ? 0 : tt[n] + 1;
+        if (row > T) continue;  // reference asserts t < max_episode_length (train.py:74)
+        rb.obs[(((size_t)slot[n] * P + p) * (T + 1) + row) * D + d] = obs[i];
+        if (d == 0 && !init_only) {
+            const int t = tt[n];
+            rb.act[((size_t)slot[n] * P + p) * T + t] = (uint8_t)actions[(size_t)p * N + n];
+            rb.rew[((size_t)slot[n] * P + p) * T + t] = rewards[(size_t)p * N + n];
+            if (p == 0) {
+                rb.done[(size_t)slot[n] * (T + 1) + t + 1] = done[n] ? 1 : 0;
+                rb.filled[(size_t)slot[n] * T + t] = 1;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void replay_draw_kernel(int batch, int length, uint64_t seed, uint32_t counter,
+                                                          int32_t* __restrict__ idx_out) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    U4 c;
+    c.x = (uint32_t)(b >> 2); c.y = counter; c.z = 0; c.w = STREAM_SAMPLE;
+    const U4 o = philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    const int s = b & 3;
+    const uint32_t w = s == 0 ? o.x : (s == 1 ? o.y : (s == 2 ? o.z : o.w));
+    idx_out[b] = (int32_t)bounded_nr(w, (uint32_t)length);
+}
+
+// one thread per OUTPUT element: stores are fully coalesced ([p][t][b][d] is contiguous in (b,d));
+// reads are D-float runs of the sampled episodes (L2 / Infinity-Cache resident replay).
+__global__ __launch_bounds__(256) void replay_sample_kernel(marlhip_replay_shape rs, marlhip_replay_buffers rb,
+                                                            const int32_t* __restrict__ idx, int B, float* __restrict__ obss,
+                                                            int64_t* __restrict__ actions, float* __restrict__ rewards,
+                                                            float* __restrict__ dones, float* __restrict__ filled) {
+    const int P = rs.n_agents, D = rs.obs_dim, T = rs.max_len;
+    const int64_t n_obs = (int64_t)P * (T + 1) * B * D;
+    const int64_t n_pt = (int64_t)P * T * B;
+    const int64_t n_d = (int64_t)(T + 1) * B;
+    const int64_t n_f = (int64_t)T * B;
+    const int64_t total = n_obs + n_pt + n_d + n_f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        if (i < n_obs) {
+            const int d = (int)(i % D);
+            const int b = (int)((i / D) % B);
+            const int t = (int)((i / ((int64_t)D * B)) % (T + 1));
+            const int p = (int)(i / ((int64_t)D * B * (T + 1)));
+            obss[i] = rb.obs[(((size_t)idx[b] * P + p) * (T + 1) + t) * D + d];
+        } else if (i < n_obs + n_pt) {
+            const int64_t k = i - n_obs;
+            const int b = (int)(k % B);
+            const int t = (int)((k / B) % T);
+            const int p = (int)(k / ((int64_t)B * T));
+            const size_t src = ((size_t)idx[b] * P + p) * T + t;
+            actions[k] = (int64_t)rb.act[src];
+            rewards[k] = rb.rew[src];
+        } else if (i < n_obs + n_pt + n_d) {
+            const int64_t k = i - n_obs - n_pt;
+            const int b = (int)(k % B), t = (int)(k / B);
+            dones[k] = rb.done[(size_t)idx[b] * (T + 1) + t] ? 1.f : 0.f;
+        } else {
+            const int64_t k = i - n_obs - n_pt - n_d;
+            const int b = (int)(k % B), t = (int)(k / B);
+            filled[k] = rb.filled[(size_t)idx[b] * T + t] ? 1.f : 0.f;
+        }
+    }
+}
+
+inline int check_replay(const marlhip_replay_shape* rs, const marlhip_replay_buffers* rb) {
+    MARL_REQUIRE(rs && rb, "replay: NULL shape/buffers");
+    MARL_REQUIRE(rs->capacity > 0 && rs->n_agents > 0 && rs->obs_dim > 0 && rs->max_len > 0, "replay: bad shape");
+    MARL_REQUIRE(rb->obs && rb->act && rb->rew && rb->done && rb->filled, "replay: NULL buffer");
+    return 0;
+}
+
+inline int grid_for(int64_t total) {
+    int64_t g = (total + 255) / 256;
+    if (g > 8192) g = 8192;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace marl
+
+using namespace marl;
+
+extern "C" int marlhip_replay_init_episode(const marlhip_replay_shape* rs, const marlhip_replay_buffers* rb, const int32_t* slot,
+                                           const uint8_t* active, const float* obs, int32_t n_envs, void* stream) {
+    if (check_replay(rs, rb) != 0) return -1;
+    MARL_REQUIRE(slot && obs && n_envs > 0, "replay_init_episode: NULL pointer");
+    const int64_t total = (int64_t)rs->n_agents * n_envs * rs->obs_dim;
+    hipLaunchKernelGGL(replay_add_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, *rs, *rb, slot,
+                       (const int32_t*)nullptr, active, obs, (const int32_t*)nullptr, (const float*)nullptr,
+                       (const uint8_t*)nullptr, n_envs, 1);
+    MARL_CHECK_LAUNCH("replay_init_episode");
+    return 0;
+}
+
+extern "C" int marlhip_replay_add(const marlhip_replay_shape* rs, const marlhip_replay_buffers* rb, const int32_t* slot,
+                                  const int32_t* t, const uint8_t* active, const float* obs, const int32_t* actions,
+                                  const float* rewards, const uint8_t* done, int32_t n_envs, void* stream) {
+    if (check_replay(rs, rb) != 0) return -1;
+    MARL_REQUIRE(slot && t && obs && actions && rewards && done && n_envs > 0, "replay_add: NULL pointer");
+    const int64_t total = (int64_t)rs->n_agents * n_envs * rs->obs_dim;
+    hipLaunchKernelGGL(replay_add_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, *rs, *rb, slot, t, active, obs,
+                       actions, rewards, done, n_envs, 0);
+    MARL_CHECK_LAUNCH("replay_add");
+    return 0;
+}
+
+extern "C" int marlhip_replay_sample(const marlhip_replay_shape* rs, const marlhip_replay_buffers* rb, const int32_t* idx,
+                                     int32_t batch, int32_t length, uint64_t seed, uint32_t counter, int32_t* idx_out, float* obss,
+                                     int64_t* actions, float* rewards, float* dones, float* filled, void* stream) {
+    if (check_replay(rs, rb) != 0) return -1;
+    MARL_REQUIRE(batch > 0 && obss && actions && rewards && dones && filled, "replay_sample: NULL pointer");
+    if (idx == nullptr) {
+        MARL_REQUIRE(idx_out != nullptr, "replay_sample: idx_out scratch needed when idx is NULL");
+        MARL_REQUIRE(length > 0 && length <= rs->capacity, "replay_sample: length %d out of range", length);
+        hipLaunchKernelGGL(replay_draw_kernel, dim3((batch + 255) / 256), dim3(256), 0, (hipStream_t)stream, batch, length, seed,
+                           counter, idx_out);
+        MARL_CHECK_LAUNCH("replay_draw");
+        idx = idx_out;
+    }
+    const int P = rs->n_agents, D = rs->obs_dim, T = rs->max_len;
+    const int64_t total = (int64_t)P * (T + 1) * batch * D + (int64_t)P * T * batch + (int64_t)(2 * T + 1) * batch;
+    timing_begin(TIMER_SAMPLE, (hipStream_t)stream);
+    hipLaunchKernelGGL(replay_sample_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, *rs, *rb, idx, batch, obss,
+                       actions, rewards, dones, filled);
+    timing_end(TIMER_SAMPLE, (hipStream_t)stream);
+    MARL_CHECK_LAUNCH("replay_sample");
+    return 0;
+}

@@ -1,0 +1,232 @@
+"""Tensor-level Python face of libmarlhip.so: PyTorch-ROCm tensors in, kernels enqueued on the
+current torch stream, nothing copied to the host.  torch is plumbing here (device memory,
+streams); every computation below happens in the HIP library."""
+import ctypes
+from collections import namedtuple
+from dataclasses import dataclass
+
+import torch
+
+from . import _lib
+from ._lib import (BatchStruct, LbfBuffers, LbfConfig, MarlHipError, NetShape, ReplayBuffers, ReplayShape, check, lib)
+
+Batch = namedtuple("Batch", ["obss", "actions", "rewards", "dones", "filled", "action_mask"])  # dqn/train.py:14-16
+
+
+def _require_gpu():
+    if not torch.cuda.is_available() or not lib.marlhip_device_available():
+        raise MarlHipError("marlhip needs an AMD GPU (gfx950): no HIP device is visible and there is no CPU path")
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def parse_lbf_name(name):
+    """'lbforaging:Foraging-8x8-2p-3f[-coop][-2s][-pen]-v3' -> upstream registration kwargs."""
+    base = name.split(":")[-1]
+    parts = base.split("-")
+    if not parts[0].startswith("Foraging"):
+        raise ValueError(f"not a Level-Based Foraging id: {name}")
+    size = next(p for p in parts if "x" in p and p.replace("x", "").isdigit())
+    s = int(size.split("x")[0])
+    p = int(next(q for q in parts if q.endswith("p") and q[:-1].isdigit())[:-1])
+    f = int(next(q for q in parts if q.endswith("f") and q[:-1].isdigit())[:-1])
+    return dict(n_agents=p, n_food=f, rows=s, cols=s, sight=2 if "2s" in parts else s, max_episode_steps=50,
+                force_coop=int("coop" in parts), min_player_level=1, max_player_level=2 if parts[-1] == "v3" else 3,
+                min_food_level=1, max_food_level=0, normalize_reward=1, penalty=0.1 if "pen" in parts else 0.0)
+
+
+def lbf_config(name, n_envs, time_limit, seed=0, cooperative=False, **over):
+    kw = parse_lbf_name(name)
+    kw.update(over)
+    return LbfConfig(n_envs=n_envs, time_limit=int(time_limit or 0), seed=int(seed) & (2**64 - 1),
+                     cooperative=int(cooperative), **kw)
+
+
+class BatchedForaging:
+    """N Level-Based Foraging envs resident in HBM (K1)."""
+
+    def __init__(self, cfg: LbfConfig, device="cuda"):
+        _require_gpu()
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self.N, self.P, self.F = cfg.n_envs, cfg.n_agents, cfg.n_food
+        self.stride = check(lib.marlhip_lbf_state_stride(ctypes.byref(cfg)), "lbf_state_stride")
+        self.D = 3 * (self.P + self.F)
+        dev = self.device
+        self.state = torch.zeros(self.N, self.stride, dtype=torch.uint8, device=dev)
+        self.episode = torch.zeros(self.N, dtype=torch.int32, device=dev)  # u32 bit pattern
+        self.ep_return = torch.zeros(self.P, self.N, dtype=torch.float32, device=dev)
+        self.ep_length = torch.zeros(self.N, dtype=torch.int32, device=dev)
+        self.fin_return = torch.zeros(self.P, self.N, dtype=torch.float32, device=dev)
+        self.fin_length = torch.zeros(self.N, dtype=torch.int32, device=dev)
+        self.obs = torch.zeros(self.P, self.N, self.D, dtype=torch.float32, device=dev)
+        self.rewards = torch.zeros(self.P, self.N, dtype=torch.float32, device=dev)
+        self.done = torch.zeros(self.N, dtype=torch.uint8, device=dev)
+        self.truncated = torch.zeros(self.N, dtype=torch.uint8, device=dev)
+        self.final_obs = torch.zeros(self.P, self.N, self.D, dtype=torch.float32, device=dev)
+        self._buf = LbfBuffers(self.state.data_ptr(), self.episode.data_ptr(), self.ep_return.data_ptr(),
+                               self.ep_length.data_ptr())
+
+    def reset(self, mask=None):
+        check(lib.marlhip_lbf_reset(ctypes.byref(self.cfg), ctypes.byref(self._buf), _ptr(mask), _ptr(self.obs), _stream()),
+              "lbf_reset")
+        return self.obs
+
+    def observe(self):
+        check(lib.marlhip_lbf_observe(ctypes.byref(self.cfg), ctypes.byref(self._buf), _ptr(self.obs), _stream()), "lbf_observe")
+        return self.obs
+
+    def step(self, actions, active=None, auto_reset=False):
+        """actions int32 [P][N] (device).  Returns (obs, rewards, done, truncated) device tensors."""
+        assert actions.dtype == torch.int32 and actions.shape == (self.P, self.N) and actions.is_contiguous()
+        check(lib.marlhip_lbf_step(ctypes.byref(self.cfg), ctypes.byref(self._buf), _ptr(active), _ptr(actions), _ptr(self.obs),
+                                   _ptr(self.rewards), _ptr(self.done), _ptr(self.truncated), _ptr(self.fin_return),
+                                   _ptr(self.fin_length), int(auto_reset), _ptr(self.final_obs) if auto_reset else None,
+                                   _stream()), "lbf_step")
+        return self.obs, self.rewards, self.done, self.truncated
+
+
+@dataclass
+class NetSpec:
+    n_agents: int
+    obs_dim: int
+    hidden: int
+    n_actions: int
+
+    def c(self):
+        return NetShape(self.n_agents, self.obs_dim, self.hidden, self.n_actions)
+
+    def nparams(self):
+        s = self.c()
+        return check(lib.marlhip_net_nparams(ctypes.byref(s)), "net_nparams")
+
+
+def dqn_act(spec: NetSpec, params, obs, epsilon, u=None, rand_actions=None, seed=0, episode=None, ep_length=None,
+            actions=None, q_out=None):
+    """Batched QNetwork.act (K2).  params f32 [P][nparams], obs f32 [P][N][D] -> actions i32 [P][N]."""
+    _require_gpu()
+    P, N, _ = obs.shape
+    if actions is None:
+        actions = torch.empty(P, N, dtype=torch.int32, device=obs.device)
+    s = spec.c()
+    check(lib.marlhip_dqn_act(ctypes.byref(s), _ptr(params), _ptr(obs), N, float(epsilon), _ptr(u), _ptr(rand_actions),
+                              int(seed) & (2**64 - 1), _ptr(episode), _ptr(ep_length), _ptr(actions), _ptr(q_out), _stream()),
+          "dqn_act")
+    return actions
+
+
+class DeviceReplay:
+    """Episode-major replay in HBM (K3/K4) - ReplayBuffer of marlbase/dqn/train.py:19-124."""
+
+    def __init__(self, capacity, n_agents, obs_dim, max_len, device="cuda"):
+        _require_gpu()
+        self.shape = ReplayShape(capacity, n_agents, obs_dim, max_len)
+        self.capacity, self.P, self.D, self.T = capacity, n_agents, obs_dim, max_len
+        dev = torch.device(device)
+        self.device = dev
+        self.obs = torch.zeros(capacity, n_agents, max_len + 1, obs_dim, dtype=torch.float32, device=dev)
+        self.act = torch.zeros(capacity, n_agents, max_len, dtype=torch.uint8, device=dev)
+        self.rew = torch.zeros(capacity, n_agents, max_len, dtype=torch.float32, device=dev)
+        self.done = torch.zeros(capacity, max_len + 1, dtype=torch.uint8, device=dev)
+        self.filled = torch.zeros(capacity, max_len, dtype=torch.uint8, device=dev)
+        self.bufs = ReplayBuffers(self.obs.data_ptr(), self.act.data_ptr(), self.rew.data_ptr(), self.done.data_ptr(),
+                                  self.filled.data_ptr())
+        self._out = {}
+
+    def init_episode(self, slot, obs, active=None):
+        check(lib.marlhip_replay_init_episode(ctypes.byref(self.shape), ctypes.byref(self.bufs), _ptr(slot), _ptr(active),
+                                              _ptr(obs), obs.shape[1], _stream()), "replay_init_episode")
+
+    def add(self, slot, t, obs, actions, rewards, done, active=None):
+        check(lib.marlhip_replay_add(ctypes.byref(self.shape), ctypes.byref(self.bufs), _ptr(slot), _ptr(t), _ptr(active),
+                                     _ptr(obs), _ptr(actions), _ptr(rewards), _ptr(done), obs.shape[1], _stream()), "replay_add")
+
+    def _outputs(self, B):
+        if B not in self._out:
+            dev, P, T, D = self.device, self.P, self.T, self.D
+            self._out[B] = (torch.empty(P, T + 1, B, D, dtype=torch.float32, device=dev),
+                            torch.empty(P, T, B, dtype=torch.int64, device=dev),
+                            torch.empty(P, T, B, dtype=torch.float32, device=dev),
+                            torch.empty(T + 1, B, dtype=torch.float32, device=dev),
+                            torch.empty(T, B, dtype=torch.float32, device=dev),
+                            torch.empty(B, dtype=torch.int32, device=dev))
+        return self._out[B]
+
+    def sample(self, batch_size, length=None, idx=None, seed=0, counter=0, fresh=False):
+        """idx (int32 device tensor) given: gather exactly those episodes; else draw them on the device
+        from Philox(seed, counter) uniformly in [0, length).  Output tensors are re-used per batch size
+        unless fresh=True."""
+        outs = self._outputs(batch_size)
+        if fresh:
+            outs = tuple(torch.empty_like(o) for o in outs)
+        obss, actions, rewards, dones, filled, idx_out = outs
+        check(lib.marlhip_replay_sample(ctypes.byref(self.shape), ctypes.byref(self.bufs), _ptr(idx), batch_size,
+                                        int(length or 0), int(seed) & (2**64 - 1), int(counter) & 0xFFFFFFFF, _ptr(idx_out),
+                                        _ptr(obss), _ptr(actions), _ptr(rewards), _ptr(dones), _ptr(filled), _stream()),
+              "replay_sample")
+        return Batch(obss, actions, rewards, dones, filled, None)
+
+
+class DqnUpdater:
+    """K5-K8: loss + gradient, clip, Adam, target update over flat per-agent parameter blocks."""
+
+    def __init__(self, spec: NetSpec, params, target, lr=3e-4, betas=(0.9, 0.999), eps=1e-8, gamma=0.99, grad_clip=1.0,
+                 double_q=True):
+        _require_gpu()
+        self.spec, self.params, self.target = spec, params, target
+        self.lr, self.betas, self.eps, self.gamma = lr, betas, eps, gamma
+        self.grad_clip = float(grad_clip) if grad_clip else 0.0
+        self.double_q = int(bool(double_q))
+        dev = params.device
+        self.exp_avg = torch.zeros_like(params)
+        self.exp_avg_sq = torch.zeros_like(params)
+        self.grad = torch.zeros_like(params)
+        self.loss = torch.zeros(2, dtype=torch.float32, device=dev)
+        self.gnorm = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.scratch = torch.zeros((params.numel() + 255) // 256 + 1, dtype=torch.float32, device=dev)
+        self.step = 0
+        self._ws = {}
+
+    def _workspace(self, T, B):
+        key = (T, B)
+        if key not in self._ws:
+            s = self.spec.c()
+            n = check(lib.marlhip_dqn_workspace_bytes(ctypes.byref(s), T, B), "dqn_workspace_bytes")
+            self._ws[key] = torch.empty(max(int(n), 4), dtype=torch.uint8, device=self.params.device)
+        return self._ws[key]
+
+    def loss_grad(self, batch, mode=0):
+        T, B = batch.filled.shape
+        ws = self._workspace(T, B)
+        bs = BatchStruct(batch.obss.data_ptr(), batch.actions.data_ptr(), batch.rewards.data_ptr(), batch.dones.data_ptr(),
+                         batch.filled.data_ptr(), T, B)
+        s = self.spec.c()
+        check(lib.marlhip_dqn_loss_grad(ctypes.byref(s), _ptr(self.params), _ptr(self.target), ctypes.byref(bs), float(self.gamma),
+                                        self.double_q, int(mode), _ptr(ws), ws.numel(), _ptr(self.grad), _ptr(self.loss), _stream()),
+              "dqn_loss_grad")
+        return self.loss, self.grad
+
+    def apply(self, hard_update=False, tau=0.0, grad_scale=1.0):
+        self.step += 1
+        check(lib.marlhip_dqn_clip_adam(self.params.numel(), _ptr(self.params), _ptr(self.grad), _ptr(self.exp_avg),
+                                        _ptr(self.exp_avg_sq), _ptr(self.target), self.step, float(self.lr), float(self.betas[0]),
+                                        float(self.betas[1]), float(self.eps), float(self.grad_clip), float(grad_scale),
+                                        int(bool(hard_update)), float(tau), _ptr(self.scratch), _ptr(self.gnorm), _stream()),
+              "dqn_clip_adam")
+
+
+def idqn_collect(cfg: LbfConfig, spec: NetSpec, params, epsilon, round_idx, replay: DeviceReplay, slot_base, fin_return,
+                 fin_length, write_replay=True, clear_stale=False, use_proper_termination=False):
+    """Fused collector: one launch = one round of N episodes (reset -> T x (act, step, add))."""
+    _require_gpu()
+    s = spec.c()
+    check(lib.marlhip_idqn_collect(ctypes.byref(cfg), ctypes.byref(s), _ptr(params), float(epsilon), int(round_idx) & 0xFFFFFFFF,
+                                   ctypes.byref(replay.shape), ctypes.byref(replay.bufs), int(slot_base), int(bool(write_replay)),
+                                   int(bool(clear_stale)), int(bool(use_proper_termination)), _ptr(fin_return), _ptr(fin_length),
+                                   _stream()), "idqn_collect")

@@ -190,9 +190,9 @@ int marlhip_dqn_loss_grad(const marlhip_net_shape* s, const float* params, const
  * Polyak-averages, else target untouched.  grad_scale multiplies the gradient first (1/world
  * for an all-reduced SUM).  gnorm_out[0] (may be NULL) receives the pre-clip total norm. */
 int marlhip_dqn_clip_adam(int64_t n, float* params, const float* grad, float* exp_avg, float* exp_avg_sq,
-                          float* target_params, int64_t step, float lr, float beta1, float beta2, float eps,
-                          float max_norm, float grad_scale, int32_t hard_update, float tau, float* gnorm_out,
-                          void* stream);
+                          float* target_params, int64_t step, double lr, double beta1, double beta2, double eps,
+                          float max_norm, float grad_scale, int32_t hard_update, float tau,
+                          float* scratch /* >= ceil(n/256) floats */, float* gnorm_out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Fused collector.  Replaces _collect_trajectory (marlbase/dqn/train.py:202-237) for N envs in
@@ -207,6 +207,15 @@ int marlhip_idqn_collect(const marlhip_lbf_config* cfg, const marlhip_net_shape*
                          uint32_t round, const marlhip_replay_shape* rs, const marlhip_replay_buffers* rb,
                          int32_t slot_base, int32_t write_replay, int32_t clear_stale, int32_t use_proper_termination,
                          float* fin_return /* [P][N] */, int32_t* fin_length /* [N] */, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Measurement aid (bench.py roofline leg): when enabled, the named kernels are bracketed by HIP
+ * events on the stream they are launched on.  ids: 0 loss/grad kernel, 1 fused collector,
+ * 2 replay sample gather, 3 env step.  marlhip_timing_read waits for the recorded events,
+ * returns launches and summed milliseconds, and clears the slot.
+ * ---------------------------------------------------------------------------------------- */
+int marlhip_timing_enable(int32_t on);
+int marlhip_timing_read(int32_t id, int64_t* launches, double* total_ms);
 
 #ifdef __cplusplus
 }

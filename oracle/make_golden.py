@@ -1,0 +1,181 @@
+"""Generate tests/golden/*.npz from the REFERENCE's own classes.  Runs only in the build
+container (needs /root/reference); the vectors travel, the reference does not.
+
+    PYTHONDONTWRITEBYTECODE=1 python -m oracle.make_golden
+
+The reference's learner imports unmodified once four absent third-party modules are stubbed
+(gymnasium.spaces.flatdim, hydra, omegaconf.DictConfig, imageio) - SURVEY.md 8c.
+Fixtures (all fp32, seeds fixed):
+  learner_H{64,128}.npz : random Batch in the reference layout, critic/target parameter blocks,
+      QNetwork._compute_loss value, its gradient, clip_grad_norm_ total norm, parameters / target /
+      Adam moments after 3 x QNetwork.update (hard target update forced at update 2), plus the
+      critic's Q-values and argmax on 64 observation rows (QNetwork.act's greedy branch).
+  replay.npz : a scripted add/sample trace through the reference ReplayBuffer with a ring wrap
+      and a stale tail, and the Batch it returns for fixed indices.
+  eps.npz : _epsilon_schedule values (linear and exponential).
+"""
+import contextlib
+import io
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+import numpy as np
+import torch
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def import_reference():
+    gym = types.ModuleType("gymnasium")
+    spaces = types.ModuleType("gymnasium.spaces")
+
+    def flatdim(space):
+        return int(space.n) if hasattr(space, "n") else int(np.prod(space.shape))
+
+    spaces.flatdim = flatdim
+    gym.spaces = spaces
+    sys.modules.setdefault("gymnasium", gym)
+    sys.modules.setdefault("gymnasium.spaces", spaces)
+    sys.modules.setdefault("hydra", types.ModuleType("hydra"))
+    oc = types.ModuleType("omegaconf")
+    oc.DictConfig = dict
+    sys.modules.setdefault("omegaconf", oc)
+    sys.modules.setdefault("imageio", types.ModuleType("imageio"))
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    from marlbase.dqn import model as ref_model
+    from marlbase.dqn import train as ref_train
+
+    return ref_model, ref_train
+
+
+class Cfg(dict):
+    __getattr__ = dict.__getitem__
+
+
+class Box:
+    def __init__(self, d):
+        self.shape = (d,)
+
+
+class Discrete:
+    def __init__(self, n):
+        self.n = n
+
+
+def flat_params(net):
+    return torch.stack([torch.cat([p.detach().reshape(-1) for p in m.parameters()]) for m in net.independent])
+
+
+def make_learner(ref_model, P, D, H, A, seed):
+    torch.manual_seed(seed)
+    cfg = Cfg(optimizer="Adam", lr=3e-4, gamma=0.99, grad_clip=1.0, target_update_interval_or_tau=2, double_q=True,
+              standardise_returns=False)
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = ref_model.QNetwork([Box(D)] * P, [Discrete(A)] * P, cfg, [H, H], False, False, True, "cpu")
+    # make biases and the target differ from the critic so nothing is hidden by zeros / equality
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for p in net.critic.parameters():
+            p.add_(0.05 * torch.randn(p.shape, generator=g))
+        for p in net.target.parameters():
+            p.add_(0.08 * torch.randn(p.shape, generator=g))
+    return net
+
+
+def learner_fixture(ref_model, ref_train, H):
+    from oracle.dqn_port import synthetic_batch
+
+    P, T, B, D, A = 2, 25, 32, 15, 6
+    net = make_learner(ref_model, P, D, H, A, seed=10 + H)
+    out = dict(P=P, T=T, B=B, D=D, A=A, H=H, params0=flat_params(net.critic).numpy(), target0=flat_params(net.target).numpy())
+    batches = [synthetic_batch(P, T, B, D, A, seed=100 + i) for i in range(3)]
+    b0 = ref_train.Batch(batches[0]["obss"], batches[0]["actions"], batches[0]["rewards"], batches[0]["dones"],
+                         batches[0]["filled"], None)
+    loss = net._compute_loss(b0)
+    net.optimizer.zero_grad()
+    loss.backward()
+    grads = torch.stack([torch.cat([p.grad.reshape(-1) for p in m.parameters()]) for m in net.independent_critic()]) \
+        if hasattr(net, "independent_critic") else torch.stack(
+            [torch.cat([p.grad.reshape(-1) for p in m.parameters()]) for m in net.critic.independent])
+    out["loss0"] = np.float32(loss.item())
+    out["grad0"] = grads.numpy()
+    out["gnorm0"] = np.float32(torch.sqrt(sum((p.grad ** 2).sum() for p in net.critic.parameters())).item())
+    net.optimizer.zero_grad()
+    # greedy branch of act on 64 rows
+    g = torch.Generator().manual_seed(7)
+    obs = torch.randint(-1, 8, (P, 64, D), generator=g).float()
+    with torch.no_grad():
+        q, _ = net.critic([obs[p].unsqueeze(0) for p in range(P)], None)
+    q = torch.stack(q).squeeze(1)
+    out["act_obs"] = obs.numpy()
+    out["act_q"] = q.numpy()
+    out["act_greedy"] = q.argmax(-1).numpy()
+    losses = []
+    for i, b in enumerate(batches):
+        bb = ref_train.Batch(b["obss"], b["actions"], b["rewards"], b["dones"], b["filled"], None)
+        losses.append(net.update(bb)["loss"])
+        out[f"params{i + 1}"] = flat_params(net.critic).numpy()
+        out[f"target{i + 1}"] = flat_params(net.target).numpy()
+    out["losses"] = np.array(losses, np.float32)
+    st = net.optimizer.state
+    out["exp_avg3"] = torch.stack([torch.cat([st[p]["exp_avg"].reshape(-1) for p in m.parameters()]) for m in net.critic.independent]).numpy()
+    out["exp_avg_sq3"] = torch.stack([torch.cat([st[p]["exp_avg_sq"].reshape(-1) for p in m.parameters()]) for m in net.critic.independent]).numpy()
+    for i, b in enumerate(batches):
+        for k, v in b.items():
+            out[f"batch{i}_{k}"] = v.numpy()
+    np.savez_compressed(os.path.join(OUT, f"learner_H{H}.npz"), **out)
+    print(f"learner_H{H}: loss0={out['loss0']:.6f} gnorm0={out['gnorm0']:.4f} losses={losses}")
+
+
+def replay_fixture(ref_train):
+    P, D, T, CAP = 2, 15, 5, 4
+    rb = ref_train.ReplayBuffer(CAP, P, [Box(D)] * P, [Discrete(6)] * P, T, "cpu")
+    rng = np.random.default_rng(5)
+    trace = []  # (kind, obs[P,D], acts[P], rews[P], done)
+    lens = [5, 3, 5, 4, 2, 5]  # 6 episodes into 4 slots: slots 0,1 are re-used; slot 0: 5 -> 2 (stale tail)
+    for L in lens:
+        o = rng.integers(-1, 8, (P, D)).astype(np.float32)
+        rb.init_episode(list(o))
+        trace.append((0, o, np.zeros(P, np.int64), np.zeros(P, np.float32), 0))
+        for t in range(L):
+            o = rng.integers(-1, 8, (P, D)).astype(np.float32)
+            a = rng.integers(0, 6, P)
+            r = rng.random(P).astype(np.float32)
+            d = int(t == L - 1)
+            rb.add(list(o), a, r, bool(d))
+            trace.append((1, o, a.astype(np.int64), r, d))
+    idx = np.array([0, 1, 2, 3, 1, 0])
+    orig = np.random.randint
+    np.random.randint = lambda lo, hi, size: idx[:size]
+    try:
+        b = rb.sample(len(idx))
+    finally:
+        np.random.randint = orig
+    np.savez_compressed(
+        os.path.join(OUT, "replay.npz"), P=P, D=D, T=T, CAP=CAP, lens=np.array(lens), idx=idx,
+        kind=np.array([t[0] for t in trace]), obs=np.stack([t[1] for t in trace]), acts=np.stack([t[2] for t in trace]),
+        rews=np.stack([t[3] for t in trace]), done=np.array([t[4] for t in trace]), pos=rb.pos, length=len(rb),
+        obss=b.obss.numpy(), actions=b.actions.numpy(), rewards=b.rewards.numpy(), dones=b.dones.numpy(), filled=b.filled.numpy())
+    print("replay: pos", rb.pos, "len", len(rb), "filled", b.filled.numpy().sum(0))
+
+
+def eps_fixture(ref_train):
+    steps = np.array([0, 1, 10, 999, 25000, 50000, 75000, 100000], np.float64)
+    lin = ref_train._epsilon_schedule("linear", 0.5, 1.0, 0.05, 6.5, 100000)
+    ex = ref_train._epsilon_schedule("exponential", 0.5, 1.0, 0.05, 6.5, 100000)
+    np.savez_compressed(os.path.join(OUT, "eps.npz"), steps=steps, linear=np.array([lin(s) for s in steps]),
+                        exponential=np.array([ex(s) for s in steps]))
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(1)
+    ref_model, ref_train = import_reference()
+    for H in (64, 128):
+        learner_fixture(ref_model, ref_train, H)
+    replay_fixture(ref_train)
+    eps_fixture(ref_train)

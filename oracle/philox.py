@@ -94,3 +94,12 @@ class DrawStream:
         foods share one (min,max) level range on the C-ABI, so upstream's
         permutation of the bounds arrays cannot change the outcome."""
         return list(range(n))
+
+
+def act_noise(seed, env, episode, t, n_agents, n_actions):
+    """(u, [random action of agent p]) of one env-step - csrc/philox.h act_noise."""
+    key = (seed & MASK, (seed >> 32) & MASK)
+    words = []
+    for k in range((1 + n_agents + 3) // 4):
+        words += philox4x32_10((env, episode, t | (k << 16), STREAM_ACT), key)
+    return u01_f32(words[0]), [bounded_nr(words[1 + p], n_actions) for p in range(n_agents)]

@@ -1,0 +1,432 @@
+"""GPU parity tests (run with -m gpu on an MI355X).  Everything here goes through the C-ABI of
+libmarlhip.so (codebase_amd.hip -> ctypes) and is checked against the CPU oracle and the golden
+vectors the reference's own classes produced.  Bars: bit-exact for env state / observations /
+done flags / rewards (fp64->fp32 once) / stored replay bytes / greedy actions; fp32 loss within
+1e-5 relative of QNetwork._compute_loss, gradients and post-Adam parameters within fp32 roundoff."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import dqn_port as dp
+from oracle.philox import DrawStream, act_noise, bounded_nr, philox4x32_10, STREAM_SAMPLE
+from tests.helpers import host_cfg, host_shim, lbf_cfg, oracle_env, pack_state, ptr, stride
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+DEV = "cuda"
+
+
+def hip():
+    from codebase_amd import hip as h
+    return h
+
+
+def make_env(name, N, seed=0, coop=False, time_limit=25):
+    h = hip()
+    cfg = h.lbf_config(name, N, time_limit, seed=seed, cooperative=coop)
+    return h.BatchedForaging(cfg), lbf_cfg(name, N, time_limit=time_limit, seed=seed, cooperative=coop)
+
+
+ENVS = [
+    ("lbforaging:Foraging-8x8-2p-3f-v3", False),
+    ("lbforaging:Foraging-8x8-2p-2f-coop-v3", True),
+    ("lbforaging:Foraging-10x10-3p-3f-v3", False),
+    ("lbforaging:Foraging-15x15-4p-5f-v3", True),
+    ("lbforaging:Foraging-15x15-8p-5f-v3", True),
+    ("lbforaging:Foraging-8x8-2p-3f-2s-v3", False),
+    ("lbforaging:Foraging-15x15-4p-3f-pen-v3", False),
+]
+
+
+@pytest.mark.parametrize("name,coop", ENVS)
+def test_env_reset_step_bit_exact_vs_oracle(name, coop):
+    N = 96
+    env, cfg = make_env(name, N, seed=99, coop=coop)
+    P = env.P
+    rng = np.random.default_rng(3)
+    for episode in range(2):
+        obs = env.reset().cpu().numpy()
+        state = env.state.cpu().numpy()
+        orc = []
+        for n in range(N):
+            e = oracle_env(name, cfg)
+            o, _ = e.reset(DrawStream(cfg["seed"], n, episode))
+            orc.append(e)
+            np.testing.assert_array_equal(pack_state(e.env), state[n])
+            for p in range(P):
+                np.testing.assert_array_equal(o[p], obs[p, n])
+        alive = np.ones(N, bool)
+        for t in range(25):
+            acts = rng.choice(6, size=(P, N), p=[0.1, 0.15, 0.15, 0.15, 0.15, 0.3]).astype(np.int32)
+            active = torch.tensor(alive.astype(np.uint8), device=DEV)
+            o_d, r_d, d_d, tr_d = env.step(torch.tensor(acts, device=DEV), active=active)
+            o_d, r_d, d_d, tr_d = o_d.cpu().numpy(), r_d.cpu().numpy(), d_d.cpu().numpy(), tr_d.cpu().numpy()
+            state = env.state.cpu().numpy()
+            finr, finl = env.fin_return.cpu().numpy(), env.fin_length.cpu().numpy()
+            for n in range(N):
+                if not alive[n]:
+                    assert d_d[n] == 0 and tr_d[n] == 0 and (r_d[:, n] == 0).all()
+                    continue
+                o, r, d, tr, info = orc[n].step([int(a) for a in acts[:, n]])
+                np.testing.assert_array_equal(pack_state(orc[n].env), state[n])
+                for p in range(P):
+                    np.testing.assert_array_equal(o[p], o_d[p, n])
+                np.testing.assert_array_equal(np.array(r, dtype=np.float32), r_d[:, n])
+                assert bool(d_d[n]) == d and bool(tr_d[n]) == tr
+                if d or tr:
+                    alive[n] = False
+                    np.testing.assert_array_equal(info["episode_returns"].astype(np.float32), finr[:, n])
+                    assert info["episode_length"] == finl[n]
+            if not alive.any():
+                break
+        assert not alive.any()  # time_limit 25 ends every episode
+
+
+def test_env_million_transitions_vs_host_core():
+    """>= 1e6 (state, joint action) pairs: the kernels against a g++ build of the same env core
+    (which tests/test_lbf_core_host.py pins to the oracle), plus size-independent invariants."""
+    name = "lbforaging:Foraging-8x8-2p-3f-v3"
+    N, T = 40960, 25
+    env, cfg = make_env(name, N, seed=5)
+    lib = host_shim()
+    hc = host_cfg(cfg)
+    P, D, S = env.P, env.D, env.stride
+    obs = env.reset().cpu().numpy()
+    st_h = np.zeros((N, S), np.uint8)
+    obs_h = np.zeros((P, N, D), np.float32)
+    epi = np.zeros(N, np.uint32)
+    assert lib.host_lbf_reset(ctypes.byref(hc), ptr(st_h), ptr(epi), ptr(obs_h)) == 0
+    np.testing.assert_array_equal(env.state.cpu().numpy(), st_h)
+    np.testing.assert_array_equal(obs, obs_h)
+    g = torch.Generator(device="cpu").manual_seed(0)
+    food_prev = st_h[:, 2:9:3].astype(np.int64).sum(1)
+    total_reward = np.zeros((P, N), np.float64)
+    for t in range(T):
+        acts = torch.randint(0, 6, (P, N), generator=g, dtype=torch.int32)
+        o_d, r_d, d_d, tr_d = env.step(acts.to(DEV))
+        rew_h = np.zeros((P, N), np.float32)
+        raw_h = np.zeros((P, N), np.float64)
+        done_h = np.zeros(N, np.uint8)
+        trunc_h = np.zeros(N, np.uint8)
+        a_np = np.ascontiguousarray(acts.numpy())
+        assert lib.host_lbf_step(ctypes.byref(hc), ptr(st_h), ptr(a_np), ptr(obs_h), ptr(rew_h), ptr(raw_h), ptr(done_h), ptr(trunc_h)) == 0
+        st_d = env.state.cpu().numpy()
+        np.testing.assert_array_equal(st_d, st_h)
+        np.testing.assert_array_equal(o_d.cpu().numpy(), obs_h)
+        np.testing.assert_array_equal(r_d.cpu().numpy(), rew_h)
+        np.testing.assert_array_equal(d_d.cpu().numpy(), done_h)
+        np.testing.assert_array_equal(tr_d.cpu().numpy(), trunc_h)
+        food = st_d[:, 2:9:3].astype(np.int64).sum(1)
+        assert (food <= food_prev).all()  # food only ever disappears
+        food_prev = food
+        total_reward += raw_h
+        assert (st_d[:, 15] == t + 1).all()  # step counter (low byte)
+    # normalised rewards: an env can never pay out more than 1 in total
+    assert (total_reward.sum(0) <= 1.0 + 1e-9).all() and (total_reward >= 0).all()
+    assert tr_d.cpu().numpy().all()
+
+
+def test_env_auto_reset_semantics():
+    name = "lbforaging:Foraging-8x8-2p-3f-v3"
+    N = 64
+    env, cfg = make_env(name, N, seed=11, time_limit=5)
+    env.reset()
+    g = torch.Generator().manual_seed(1)
+    for t in range(5):
+        acts = torch.randint(0, 6, (2, N), generator=g, dtype=torch.int32).to(DEV)
+        obs, rew, done, trunc = env.step(acts, auto_reset=True)
+    assert trunc.cpu().numpy().all()
+    assert (env.fin_length.cpu().numpy() == 5).all()
+    assert (env.ep_length.cpu().numpy() == 0).all() and (env.episode.cpu().numpy() == 2).all()
+    # returned obs is the NEW episode's first observation (episode index 1 of the reset stream)
+    o = obs.cpu().numpy()
+    for n in range(0, N, 7):
+        e = oracle_env(name, cfg)
+        ref, _ = e.reset(DrawStream(cfg["seed"], n, 1))
+        for p in range(2):
+            np.testing.assert_array_equal(ref[p], o[p, n])
+    assert (env.final_obs.cpu().numpy()[:, :, -1] > 0).all()  # terminal obs latched (own level > 0)
+
+
+def load(name):
+    return dict(np.load(os.path.join(G, name)))
+
+
+@pytest.mark.parametrize("H", [64, 128])
+def test_act_matches_reference_golden(H):
+    h = hip()
+    g = load(f"learner_H{H}.npz")
+    P, D, A = int(g["P"]), int(g["D"]), int(g["A"])
+    spec = h.NetSpec(P, D, H, A)
+    assert spec.nparams() == g["params0"].shape[1]
+    params = torch.tensor(g["params0"], device=DEV)
+    obs = torch.tensor(g["act_obs"], device=DEV)
+    N = obs.shape[1]
+    q = torch.zeros(P, N, A, device=DEV)
+    u = torch.ones(N, device=DEV)
+    ra = torch.full((P, N), 5, dtype=torch.int32, device=DEV)
+    acts = h.dqn_act(spec, params, obs, 0.0, u=u, rand_actions=ra, q_out=q)
+    np.testing.assert_allclose(q.cpu().numpy(), g["act_q"], rtol=1e-5, atol=1e-5)
+    top2 = np.sort(g["act_q"], -1)
+    clear = (top2[..., -1] - top2[..., -2]) > 1e-4
+    assert clear.mean() > 0.9
+    np.testing.assert_array_equal(acts.cpu().numpy()[clear], g["act_greedy"][clear])
+    # greedy == first index of the max of the kernel's own Q (ties included)
+    np.testing.assert_array_equal(acts.cpu().numpy(), q.cpu().numpy().argmax(-1))
+    # epsilon = 1: every env takes the injected random joint action
+    acts = h.dqn_act(spec, params, obs, 1.0, u=torch.zeros(N, device=DEV), rand_actions=ra)
+    assert (acts.cpu().numpy() == 5).all()
+
+
+def test_act_tie_break_and_philox_noise():
+    h = hip()
+    P, D, H, A, N = 2, 15, 64, 6, 200
+    spec = h.NetSpec(P, D, H, A)
+    # all-zero parameters: every Q is 0 -> argmax must be action 0 (first max, torch rule)
+    params = torch.zeros(P, spec.nparams(), device=DEV)
+    obs = torch.randn(P, N, D, device=DEV)
+    episode = torch.full((N,), 3, dtype=torch.int32, device=DEV)
+    eplen = torch.arange(N, dtype=torch.int32, device=DEV) % 25
+    acts = h.dqn_act(spec, params, obs, 0.0, seed=77, episode=episode, ep_length=eplen).cpu().numpy()
+    assert (acts == 0).all()
+    # bias of the last action largest -> greedy 5; epsilon 0.4 mixes in Philox actions
+    bp = params.clone()
+    bp[:, -1] = 1.0
+    acts = h.dqn_act(spec, bp, obs, 0.4, seed=77, episode=episode, ep_length=eplen).cpu().numpy()
+    n_explore = 0
+    for n in range(N):
+        u, ra = act_noise(77, n, 3, int(eplen[n]), P, A)
+        exp = [ra[p] if 0.4 > u else 5 for p in range(P)]
+        n_explore += 0.4 > u
+        assert list(acts[:, n]) == exp
+    assert 40 < n_explore < 120
+
+
+def test_replay_matches_reference_trace_and_ring_wrap():
+    h = hip()
+    g = load("replay.npz")
+    P, D, T, CAP = int(g["P"]), int(g["D"]), int(g["T"]), int(g["CAP"])
+    rb = h.DeviceReplay(CAP, P, D, T)
+    pos = cur = t = 0
+    for kind, o, a, r, d in zip(g["kind"], g["obs"], g["acts"], g["rews"], g["done"]):
+        obs = torch.tensor(o, device=DEV).reshape(P, 1, D).contiguous()
+        slot = torch.tensor([cur], dtype=torch.int32, device=DEV)
+        if kind == 0:
+            rb.init_episode(slot, obs)
+            t = 0
+        else:
+            rb.add(slot, torch.tensor([t], dtype=torch.int32, device=DEV), obs,
+                   torch.tensor(a, dtype=torch.int32, device=DEV).reshape(P, 1), torch.tensor(r, device=DEV).reshape(P, 1),
+                   torch.tensor([d], dtype=torch.uint8, device=DEV))
+            t += 1
+            if d:  # train.py:86-89
+                pos += 1
+                cur = pos % CAP
+                t = 0
+    idx = torch.tensor(g["idx"], dtype=torch.int32, device=DEV)
+    b = rb.sample(len(g["idx"]), idx=idx)
+    np.testing.assert_array_equal(b.obss.cpu().numpy(), g["obss"])
+    np.testing.assert_array_equal(b.actions.cpu().numpy(), g["actions"])
+    assert b.actions.dtype == torch.int64
+    np.testing.assert_array_equal(b.rewards.cpu().numpy(), g["rewards"])
+    np.testing.assert_array_equal(b.dones.cpu().numpy(), g["dones"])
+    np.testing.assert_array_equal(b.filled.cpu().numpy(), g["filled"])
+    assert g["filled"][:, 0].sum() == 5  # stale tail of the re-used slot survives, as in the reference
+
+
+def test_replay_vectorised_add_and_device_draw():
+    h = hip()
+    P, D, T, CAP, N = 2, 15, 25, 512, 128
+    rb = h.DeviceReplay(CAP, P, D, T)
+    ref = dict(obs=np.zeros((CAP, P, T + 1, D), np.float32), act=np.zeros((CAP, P, T), np.uint8),
+               rew=np.zeros((CAP, P, T), np.float32), done=np.zeros((CAP, T + 1), np.uint8), filled=np.zeros((CAP, T), np.uint8))
+    rng = np.random.default_rng(0)
+    slot = (np.arange(N) * 3 + 7) % CAP
+    o = rng.integers(-1, 8, (P, N, D)).astype(np.float32)
+    rb.init_episode(torch.tensor(slot, dtype=torch.int32, device=DEV), torch.tensor(o, device=DEV))
+    ref["obs"][slot, :, 0] = o.transpose(1, 0, 2)
+    active = np.ones(N, np.uint8)
+    for t in range(T):
+        o = rng.integers(-1, 8, (P, N, D)).astype(np.float32)
+        a = rng.integers(0, 6, (P, N)).astype(np.int32)
+        r = rng.random((P, N)).astype(np.float32)
+        d = (rng.random(N) < 0.1).astype(np.uint8)
+        rb.add(torch.tensor(slot, dtype=torch.int32, device=DEV), torch.full((N,), t, dtype=torch.int32, device=DEV),
+               torch.tensor(o, device=DEV), torch.tensor(a, device=DEV), torch.tensor(r, device=DEV), torch.tensor(d, device=DEV),
+               active=torch.tensor(active, device=DEV))
+        on = active.astype(bool)
+        ref["obs"][slot[on], :, t + 1] = o.transpose(1, 0, 2)[on]
+        ref["act"][slot[on], :, t] = a.T[on]
+        ref["rew"][slot[on], :, t] = r.T[on]
+        ref["done"][slot[on], t + 1] = d[on]
+        ref["filled"][slot[on], t] = 1
+        active = active & (1 - d)
+    for k, ten in (("obs", rb.obs), ("act", rb.act), ("rew", rb.rew), ("done", rb.done), ("filled", rb.filled)):
+        np.testing.assert_array_equal(ten.cpu().numpy(), ref[k])
+    # device-side index draw == oracle Philox stream 2, and the gather matches numpy fancy indexing
+    B, length, seed, counter = 64, 300, 1234, 9
+    b = rb.sample(B, length=length, seed=seed, counter=counter)
+    idx = np.array([bounded_nr(philox4x32_10((i >> 2, counter, 0, STREAM_SAMPLE), (seed, 0))[i & 3], length) for i in range(B)])
+    np.testing.assert_array_equal(rb._out[B][5].cpu().numpy(), idx)
+    np.testing.assert_array_equal(b.obss.cpu().numpy(), ref["obs"][idx].transpose(1, 2, 0, 3))
+    np.testing.assert_array_equal(b.actions.cpu().numpy(), ref["act"][idx].transpose(1, 2, 0).astype(np.int64))
+    np.testing.assert_array_equal(b.rewards.cpu().numpy(), ref["rew"][idx].transpose(1, 2, 0))
+    np.testing.assert_array_equal(b.dones.cpu().numpy(), ref["done"][idx].T.astype(np.float32))
+    np.testing.assert_array_equal(b.filled.cpu().numpy(), ref["filled"][idx].T.astype(np.float32))
+
+
+def dev_batch(h, b):
+    return h.Batch(b["obss"].to(DEV).contiguous(), b["actions"].to(DEV).contiguous(), b["rewards"].to(DEV).contiguous(),
+                   b["dones"].to(DEV).contiguous(), b["filled"].to(DEV).contiguous(), None)
+
+
+def golden_batch(g, i):
+    return {k: torch.tensor(g[f"batch{i}_{k}"]) for k in ("obss", "actions", "rewards", "dones", "filled")}
+
+
+def test_loss_and_grad_match_reference_golden():
+    h = hip()
+    g = load("learner_H64.npz")
+    P, D, H, A = int(g["P"]), int(g["D"]), 64, int(g["A"])
+    spec = h.NetSpec(P, D, H, A)
+    params = torch.tensor(g["params0"], device=DEV)
+    target = torch.tensor(g["target0"], device=DEV)
+    up = h.DqnUpdater(spec, params, target)
+    loss, grad = up.loss_grad(dev_batch(h, golden_batch(g, 0)))
+    loss = loss.cpu().numpy()
+    assert abs(loss[0] - g["loss0"]) <= 1e-5 * abs(g["loss0"]), (loss, g["loss0"])
+    assert loss[1] == g["batch0_filled"].sum()
+    np.testing.assert_allclose(grad.cpu().numpy(), g["grad0"], rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("P,T,B,D,double_q", [(2, 7, 20, 15, True), (2, 25, 32, 15, False), (3, 5, 16, 18, True),
+                                               (4, 25, 100, 27, True), (8, 6, 33, 39, True), (2, 25, 4096, 15, True)])
+def test_loss_and_grad_vs_torch_port(P, T, B, D, double_q):
+    """ragged batches (B not a multiple of 16), other agent counts / obs dims, the bench batch size"""
+    h = hip()
+    H, A = 64, 6
+    spec = h.NetSpec(P, D, H, A)
+    params = dp.init_params(P, D, H, A, seed=1) + 0.05 * torch.randn(P, dp.nparams(D, H, A), generator=torch.Generator().manual_seed(2))
+    target = dp.init_params(P, D, H, A, seed=3) + 0.05 * torch.randn(P, dp.nparams(D, H, A), generator=torch.Generator().manual_seed(4))
+    batch = dp.synthetic_batch(P, T, B, D, A, seed=5)
+    pr = params.clone().requires_grad_(True)
+    ref = dp.compute_loss(pr, target, batch, 0.99, double_q, D, H, A)
+    ref.backward()
+    up = h.DqnUpdater(spec, params.to(DEV), target.to(DEV), double_q=double_q)
+    loss, grad = up.loss_grad(dev_batch(h, batch))
+    assert abs(loss.cpu().numpy()[0] - ref.item()) <= 2e-5 * abs(ref.item())
+    gref = pr.grad.numpy()
+    np.testing.assert_allclose(grad.cpu().numpy(), gref, rtol=2e-4, atol=2e-5 * max(1.0, np.abs(gref).max()))
+    # bitwise reproducible (fixed-order reduction, no float atomics)
+    g1 = grad.clone()
+    _, g2 = up.loss_grad(dev_batch(h, batch))
+    assert torch.equal(g1, g2)
+
+
+def test_update_sequence_matches_reference_golden():
+    """3 x QNetwork.update (clip 1.0, Adam 3e-4, hard target update at update 2)"""
+    h = hip()
+    g = load("learner_H64.npz")
+    P, D, H, A = int(g["P"]), int(g["D"]), 64, int(g["A"])
+    spec = h.NetSpec(P, D, H, A)
+    params = torch.tensor(g["params0"], device=DEV)
+    target = torch.tensor(g["target0"], device=DEV)
+    up = h.DqnUpdater(spec, params, target, lr=3e-4, gamma=0.99, grad_clip=1.0, double_q=True)
+    last_target_update = 0
+    for i in range(3):
+        loss, _ = up.loss_grad(dev_batch(h, golden_batch(g, i)))
+        updates = i + 1
+        hard = (updates - last_target_update) >= 2
+        up.apply(hard_update=hard)
+        if hard:
+            last_target_update = updates
+        assert abs(loss.cpu().numpy()[0] - g["losses"][i]) <= 2e-5 * abs(g["losses"][i])
+        if i == 0:
+            assert abs(up.gnorm.item() - g["gnorm0"]) <= 1e-4 * g["gnorm0"]
+        np.testing.assert_allclose(params.cpu().numpy(), g[f"params{i + 1}"], rtol=0, atol=3e-6)
+        np.testing.assert_allclose(target.cpu().numpy(), g[f"target{i + 1}"], rtol=0, atol=3e-6)
+    np.testing.assert_allclose(up.exp_avg.cpu().numpy(), g["exp_avg3"], rtol=1e-3, atol=1e-7)
+    np.testing.assert_allclose(up.exp_avg_sq.cpu().numpy(), g["exp_avg_sq3"], rtol=1e-3, atol=1e-10)
+
+
+def test_soft_target_update_and_no_clip():
+    h = hip()
+    P, D, H, A = 2, 15, 64, 6
+    spec = h.NetSpec(P, D, H, A)
+    p0 = dp.init_params(P, D, H, A, seed=8)
+    t0 = dp.init_params(P, D, H, A, seed=9)
+    batch = dp.synthetic_batch(P, 25, 32, D, A, seed=1)
+    lr = dp.Learner(p0, D, H, A, grad_clip=0, target_update_interval_or_tau=0.01)
+    lr.target = t0.clone()
+    lr.update(batch)
+    params, target = p0.to(DEV), t0.to(DEV)
+    up = h.DqnUpdater(spec, params, target, grad_clip=0)
+    up.loss_grad(dev_batch(h, batch))
+    up.apply(hard_update=False, tau=0.01)
+    np.testing.assert_allclose(params.cpu().numpy(), lr.flat().detach().numpy(), rtol=0, atol=3e-6)
+    np.testing.assert_allclose(target.cpu().numpy(), lr.target.numpy(), rtol=0, atol=3e-6)
+
+
+@pytest.mark.parametrize("name,H,eps", [("lbforaging:Foraging-8x8-2p-3f-v3", 64, 0.3), ("lbforaging:Foraging-8x8-2p-3f-v3", 128, 0.1),
+                                         ("lbforaging:Foraging-15x15-4p-5f-v3", 64, 0.5)])
+def test_fused_collector_equals_modular_path_and_oracle(name, H, eps):
+    """One round of the fused collector == reset -> T x (dqn_act -> lbf_step -> replay_add) through
+    the modular entry points (bit for bit), and replaying its stored actions through the oracle env
+    reproduces the stored observations / rewards / dones."""
+    h = hip()
+    N, T, seed, rnd = 80, 25, 4242, 3
+    coop = "15x15" in name
+    cfg = h.lbf_config(name, N, T, seed=seed, cooperative=coop)
+    ocfg = lbf_cfg(name, N, time_limit=T, seed=seed, cooperative=coop)
+    P, D = cfg.n_agents, 3 * (cfg.n_agents + cfg.n_food)
+    spec = h.NetSpec(P, D, H, 6)
+    params = (dp.init_params(P, D, H, 6, seed=1) * 3.0).to(DEV)
+    CAP = 256
+    rb_f = h.DeviceReplay(CAP, P, D, T)
+    finr = torch.zeros(P, N, device=DEV)
+    finl = torch.zeros(N, dtype=torch.int32, device=DEV)
+    slot_base = 200  # wraps: slots 200..255, 0..23
+    h.idqn_collect(cfg, spec, params, eps, rnd, rb_f, slot_base, finr, finl)
+    torch.cuda.synchronize()
+    # --- modular path
+    env = h.BatchedForaging(cfg)
+    env.episode.fill_(rnd)  # next reset uses reset-stream index `rnd`
+    rb_m = h.DeviceReplay(CAP, P, D, T)
+    slot = ((torch.arange(N) + slot_base) % CAP).to(torch.int32).to(DEV)
+    obs = env.reset()
+    env.episode.fill_(rnd)  # act noise is keyed by the running episode's index
+    rb_m.init_episode(slot, obs)
+    alive = torch.ones(N, dtype=torch.uint8, device=DEV)
+    for t in range(T):
+        acts = h.dqn_act(spec, params, obs, eps, seed=seed, episode=env.episode, ep_length=env.ep_length)
+        tt = env.ep_length.clone()
+        obs, rew, done, trunc = env.step(acts, active=alive)
+        stored_done = ((done | trunc) > 0).to(torch.uint8)
+        rb_m.add(slot, tt, obs, acts, rew, stored_done, active=alive)
+        alive = alive & (1 - stored_done)
+    for a, b in ((rb_f.obs, rb_m.obs), (rb_f.act, rb_m.act), (rb_f.rew, rb_m.rew), (rb_f.done, rb_m.done), (rb_f.filled, rb_m.filled)):
+        assert torch.equal(a, b)
+    assert torch.equal(finr, env.fin_return) and torch.equal(finl, env.fin_length)
+    # --- oracle replay of the stored actions
+    ro, ra, rr, rd, rf = (x.cpu().numpy() for x in (rb_f.obs, rb_f.act, rb_f.rew, rb_f.done, rb_f.filled))
+    fl, fr = finl.cpu().numpy(), finr.cpu().numpy()
+    for n in range(0, N, 3):
+        s = (slot_base + n) % CAP
+        e = oracle_env(name, ocfg)
+        o, _ = e.reset(DrawStream(seed, n, rnd))
+        for p in range(P):
+            np.testing.assert_array_equal(o[p], ro[s, p, 0])
+        L = int(fl[n])
+        assert rf[s, :L].all() and not rf[s, L:].any()
+        for t in range(L):
+            o, r, d, tr, info = e.step([int(a) for a in ra[s, :, t]])
+            for p in range(P):
+                np.testing.assert_array_equal(o[p], ro[s, p, t + 1])
+            np.testing.assert_array_equal(np.array(r, dtype=np.float32), rr[s, :, t])
+            assert rd[s, t + 1] == int(d or tr)
+        assert d or tr
+        np.testing.assert_array_equal(info["episode_returns"].astype(np.float32), fr[:, n])

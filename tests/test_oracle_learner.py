@@ -1,0 +1,79 @@
+"""CPU: the oracle's learner restatement (oracle/dqn_port.py) against golden vectors produced by
+the REFERENCE's own classes (oracle/make_golden.py -> tests/golden/).  This is what pins the
+learner half of the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import dqn_port as dp
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    return dict(np.load(os.path.join(G, name)))
+
+
+def batch_of(g, i):
+    return {k: torch.tensor(g[f"batch{i}_{k}"]) for k in ("obss", "actions", "rewards", "dones", "filled")}
+
+
+@pytest.mark.parametrize("H", [64, 128])
+def test_loss_grad_and_updates_match_reference(H):
+    g = load(f"learner_H{H}.npz")
+    P, D, A = int(g["P"]), int(g["D"]), int(g["A"])
+    params = torch.tensor(g["params0"]).requires_grad_(True)
+    target = torch.tensor(g["target0"])
+    loss = dp.compute_loss(params, target, batch_of(g, 0), 0.99, True, D, H, A)
+    loss.backward()
+    assert abs(loss.item() - float(g["loss0"])) <= 1e-5 * abs(float(g["loss0"]))
+    np.testing.assert_allclose(params.grad.numpy(), g["grad0"], rtol=1e-4, atol=1e-5)
+    lr = dp.Learner(torch.tensor(g["params0"]), D, H, A, target_update_interval_or_tau=2)
+    lr.target = torch.tensor(g["target0"])
+    for i in range(3):
+        m = lr.update(batch_of(g, i))
+        assert abs(m["loss"] - float(g["losses"][i])) <= 2e-5 * abs(float(g["losses"][i]))
+        np.testing.assert_allclose(lr.flat().detach().numpy(), g[f"params{i + 1}"], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(lr.target.numpy(), g[f"target{i + 1}"], rtol=0, atol=2e-6)
+    # hard update happened exactly at update 2 (interval 2): target2 == params2, target3 == params2
+    np.testing.assert_array_equal(g["target2"], g["params2"])
+    np.testing.assert_array_equal(g["target3"], g["params2"])
+    assert float(g["gnorm0"]) > 1.0  # clipping is active in this fixture
+
+
+@pytest.mark.parametrize("H", [64, 128])
+def test_act_greedy_matches_reference(H):
+    g = load(f"learner_H{H}.npz")
+    D, A = int(g["D"]), int(g["A"])
+    obs = torch.tensor(g["act_obs"])
+    N = obs.shape[1]
+    acts, q = dp.act(torch.tensor(g["params0"]), obs, 0.0, torch.ones(N), torch.zeros(2, N, dtype=torch.int64), D, H, A)
+    np.testing.assert_allclose(q.numpy(), g["act_q"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_array_equal(acts.numpy(), g["act_greedy"])
+
+
+def test_replay_trace_matches_reference():
+    g = load("replay.npz")
+    P, D, T, CAP = int(g["P"]), int(g["D"]), int(g["T"]), int(g["CAP"])
+    rb = dp.ReplayBuffer(CAP, P, D, T)
+    for kind, o, a, r, d in zip(g["kind"], g["obs"], g["acts"], g["rews"], g["done"]):
+        if kind == 0:
+            rb.init_episode(list(o))
+        else:
+            rb.add(list(o), a, r, bool(d))
+    assert rb.pos == int(g["pos"]) and len(rb) == int(g["length"])
+    b = rb.sample_idx(g["idx"])
+    for k in ("obss", "actions", "rewards", "dones", "filled"):
+        np.testing.assert_array_equal(b[k].numpy(), g[k])
+    # the stale tail of the re-used slot 0 (5-step episode overwritten by a 2-step one) survives
+    assert g["filled"][:, 0].sum() == 5
+
+
+def test_epsilon_schedule_matches_reference():
+    g = load("eps.npz")
+    lin = dp.epsilon_schedule("linear", 0.5, 1.0, 0.05, 6.5, 100000)
+    ex = dp.epsilon_schedule("exponential", 0.5, 1.0, 0.05, 6.5, 100000)
+    np.testing.assert_array_equal(np.array([lin(s) for s in g["steps"]]), g["linear"])
+    np.testing.assert_array_equal(np.array([ex(s) for s in g["steps"]]), g["exponential"])
