@@ -118,20 +118,13 @@ def main():
 
     from codebase_amd import hip as h
     from codebase_amd._lib import lib
-    from oracle import dqn_port as dp  # parameter init only (orthogonal init, utils/models.py:8-11)
+    from codebase_amd.dqn.model import QNetwork
+    from codebase_amd.dqn.train import VectorisedIDQN, _epsilon_schedule
+    from codebase_amd.utils.envs import _space_pair
 
     N, T, H = args.envs, args.time_limit, args.hidden
     cfg = h.lbf_config(ENV_NAME, N, T, seed=args.seed + 1000003 * rank)
     P, D, A = cfg.n_agents, 3 * (cfg.n_agents + cfg.n_food), 6
-    spec = h.NetSpec(P, D, H, A)
-    p0 = dp.init_params(P, D, H, A, seed=args.seed)  # identical on every rank
-    params, target = p0.cuda(), p0.clone().cuda()
-    cap = args.replay_rounds * N
-    rb = h.DeviceReplay(cap, P, D, T)
-    finr = torch.zeros(P, N, device="cuda")
-    finl = torch.zeros(N, dtype=torch.int32, device="cuda")
-    up = h.DqnUpdater(spec, params, target, lr=3e-4, gamma=0.99, grad_clip=1.0, double_q=True)
-
     if args.cadence == "ratio":
         B = args.update_batch or N
         U = args.updates_per_round or max(1, (32 * N) // B)
@@ -139,28 +132,19 @@ def main():
         B = args.update_batch or 32
         U = args.updates_per_round or N
     else:
-        B, U = 0, 0
-    eps_sched = dp.epsilon_schedule("linear", 0.5, 1.0, 0.05, 6.5, 100_000_000)
-    target_interval = 200
-    steps_dev = torch.zeros((), dtype=torch.int64, device="cuda")
-    state = dict(round=0, updates=0, last_target=0)
+        B, U = 1, 0
+    torch.manual_seed(args.seed)  # identical initial weights on every rank (orthogonal init, utils/models.py:8-11)
+    obs_space, act_space = _space_pair(cfg)
+    hyper = dict(optimizer="Adam", lr=3e-4, gamma=0.99, grad_clip=1.0, double_q=True, standardise_returns=False,
+                 target_update_interval_or_tau=200)  # marlbase/configs/algorithm/idqn.yaml:16-37
+    model = QNetwork(obs_space, act_space, hyper, [H, H], False, False, True, "cuda")
+    cap = args.replay_rounds * N
+    trainer = VectorisedIDQN(cfg, model, cap, T, B, U, seed=args.seed, dist=dist)
+    eps_sched = _epsilon_schedule("linear", 0.5, 1.0, 0.05, 6.5, 100_000_000)
+    steps_dev = trainer.env_steps
 
     def one_round():
-        r = state["round"]
-        h.idqn_collect(cfg, spec, params, eps_sched(r * N * T), r, rb, (r * N) % cap, finr, finl)
-        steps_dev.add_(finl.sum())
-        length = min((r + 1) * N, cap)
-        for _ in range(U):
-            batch = rb.sample(B, length=length, seed=args.seed + rank, counter=state["updates"])
-            up.loss_grad(batch)
-            if dist is not None:
-                dist.all_reduce(up.grad)  # SUM over ranks; clip_adam scales by 1/world
-            state["updates"] += 1
-            hard = (state["updates"] - state["last_target"]) >= target_interval
-            up.apply(hard_update=hard, grad_scale=1.0 / world)
-            if hard:
-                state["last_target"] = state["updates"]
-        state["round"] += 1
+        trainer.round(eps_sched(trainer.rounds * N * T), train=U > 0)
 
     def sync():
         if dist is not None:

@@ -1,0 +1,152 @@
+"""Configuration surface of the reference, without requiring Hydra.
+
+The reference is driven by Hydra (`python run.py +algorithm=idqn env.name=... env.time_limit=25`,
+marlbase/run.py:14, marlbase/configs/**).  Hydra / OmegaConf are not dependencies of this package;
+this module provides the small part of their behaviour the hot path needs:
+  * the default tree (same keys and values as configs/default.yaml + configs/algorithm/{idqn,vdn}.yaml,
+    with `_target_`s pointing at this package and `device: cuda`),
+  * `+algorithm=<name>` group selection and dotted `key=value` overrides with YAML-typed values,
+  * `instantiate` / `call` on `_target_` strings (module path resolved inside this package first, so
+    the reference's cwd-relative names `dqn.train.main`, `utils.envs.make_env`, `dqn.model.QNetwork`
+    resolve to the HIP implementations unchanged),
+  * a user may also point `--config-dir` at a reference-style YAML tree (read with PyYAML).
+"""
+import copy
+import importlib
+import os
+
+import yaml
+
+
+class Cfg(dict):
+    """dict with attribute access (what the reference expects from DictConfig)."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+
+def to_cfg(x):
+    if isinstance(x, dict):
+        return Cfg({k: to_cfg(v) for k, v in x.items()})
+    if isinstance(x, (list, tuple)):
+        return [to_cfg(v) for v in x]
+    return x
+
+
+DEFAULT = {
+    "seed": None,
+    "algorithm": {"total_steps": 100_000, "log_interval": 10_000, "save_interval": False, "eval_interval": 10_000,
+                  "eval_episodes": 100, "video_interval": False, "video_frames": 500},
+    "env": {"_target_": "utils.envs.make_env", "name": "???", "time_limit": "???", "clear_info": False,
+            "observe_id": False, "standardise_rewards": False, "wrappers": None},
+    "logger": {"_target_": "utils.loggers.FileSystemLogger", "project_name": "marlhip"},
+}
+
+_IDQN = {
+    "algorithm": {
+        "_target_": "dqn.train.main", "name": "idqn",
+        "model": {"_target_": "dqn.model.QNetwork", "layers": [128, 128], "parameter_sharing": False,
+                  "use_orthogonal_init": True, "use_rnn": False, "device": "cuda"},
+        "training_start": 2000, "buffer_size": 10000, "optimizer": "Adam", "lr": 3e-4, "gamma": 0.99,
+        "batch_size": 32, "double_q": True, "grad_clip": 1.0, "use_proper_termination": False,
+        "standardise_returns": False, "eps_decay_style": "linear", "eps_decay_over": 0.5, "eps_start": 1.0,
+        "eps_end": 0.05, "eps_exp_decay_rate": 6.5, "eps_evaluation": 0.05, "target_update_interval_or_tau": 200,
+    }
+}
+
+ALGORITHMS = {
+    "idqn": _IDQN,
+    "vdn": {"env": {"wrappers": ["CooperativeReward"]},
+            "algorithm": dict(copy.deepcopy(_IDQN["algorithm"]), name="vdn",
+                              model=dict(_IDQN["algorithm"]["model"], _target_="dqn.model.VDNetwork"))},
+}
+
+
+def _merge(dst, src):
+    for k, v in src.items():
+        if isinstance(v, dict) and isinstance(dst.get(k), dict):
+            _merge(dst[k], v)
+        else:
+            dst[k] = copy.deepcopy(v)
+    return dst
+
+
+def _set(cfg, dotted, value):
+    cur = cfg
+    parts = dotted.split(".")
+    for p in parts[:-1]:
+        cur = cur.setdefault(p, {})
+    cur[parts[-1]] = value
+
+
+def _load_yaml_tree(config_dir, algorithm):
+    base = yaml.safe_load(open(os.path.join(config_dir, "default.yaml"))) or {}
+    base.pop("defaults", None)
+    base.pop("hydra", None)
+    stack = [algorithm]
+    docs = []
+    while stack:
+        a = stack.pop()
+        d = yaml.safe_load(open(os.path.join(config_dir, "algorithm", f"{a}.yaml"))) or {}
+        for inc in d.pop("defaults", []) or []:
+            if isinstance(inc, str):
+                stack.append(inc)
+        docs.append(d)
+    for d in reversed(docs):
+        _merge(base, d)
+    return base
+
+
+def compose(argv, config_dir=None):
+    """`+algorithm=idqn env.name=... env.time_limit=25 algorithm.model.layers=[64,64]` -> Cfg."""
+    cfg = copy.deepcopy(DEFAULT)
+    algo, overrides = None, []
+    for a in argv:
+        if a.startswith("+algorithm="):
+            algo = a.split("=", 1)[1]
+        elif "=" in a:
+            overrides.append(a.lstrip("+").split("=", 1))
+        else:
+            raise ValueError(f"cannot parse override '{a}'")
+    if algo is None:
+        raise ValueError("select an algorithm with +algorithm=<name>")
+    if config_dir:
+        cfg = _merge(cfg, _load_yaml_tree(config_dir, algo))
+    else:
+        if algo not in ALGORITHMS:
+            raise NotImplementedError(f"+algorithm={algo}: built-in configs cover {sorted(ALGORITHMS)}")
+        _merge(cfg, ALGORITHMS[algo])
+    for k, v in overrides:
+        _set(cfg, k, yaml.safe_load(v))
+    for key in ("name", "time_limit"):
+        if cfg["env"].get(key) == "???":
+            raise ValueError(f"env.{key} must be set (mandatory value, configs/default.yaml:30-31)")
+    return to_cfg(cfg)
+
+
+def resolve(target):
+    """`dqn.train.main` -> codebase_amd.dqn.train.main when such a module exists here, else a normal import."""
+    mod, _, attr = target.rpartition(".")
+    for cand in (f"{__package__}.{mod}", mod):
+        try:
+            return getattr(importlib.import_module(cand), attr)
+        except (ImportError, AttributeError):
+            continue
+    raise ImportError(f"cannot resolve _target_ {target}")
+
+
+def _kwargs(node):
+    return {k: v for k, v in node.items() if k not in ("_target_", "_recursive_")}
+
+
+def instantiate(node, *args, **extra):
+    return resolve(node["_target_"])(*args, **_kwargs(node), **extra)
+
+
+call = instantiate

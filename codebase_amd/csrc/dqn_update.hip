@@ -59,9 +59,24 @@ struct UpdLds {
     static_assert(2 * S::NFWD >= REC, "fold buffer");
 };
 
+// packs of one agent in the workspace: [critic fwd NFWD][target fwd NFWD][critic bwd NBWD]
 template <class S>
-__global__ __launch_bounds__(UPD_BLOCK) void dqn_lossgrad_kernel(const float* __restrict__ params,
-                                                                 const float* __restrict__ tparams, marlhip_batch bt,
+__global__ __launch_bounds__(256) void dqn_pack_kernel(const float* __restrict__ params, const float* __restrict__ tparams,
+                                                       float* __restrict__ packs) {
+    constexpr int TOT = 2 * S::NFWD + S::NBWD;
+    const int p = blockIdx.y;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= TOT) return;
+    const float* w = params + (size_t)p * S::NPARAM;
+    float v;
+    if (idx < S::NFWD) v = mlp_fwd_pack_elem<S>(w, idx);
+    else if (idx < 2 * S::NFWD) v = mlp_fwd_pack_elem<S>(tparams + (size_t)p * S::NPARAM, idx - S::NFWD);
+    else v = mlp_bwd_pack_elem<S>(w, idx - 2 * S::NFWD);
+    packs[(size_t)p * TOT + idx] = v;
+}
+
+template <class S>
+__global__ __launch_bounds__(UPD_BLOCK) void dqn_lossgrad_kernel(const float* __restrict__ packs, marlhip_batch bt,
                                                                  float gamma, int double_q, int n_chunks,
                                                                  float* __restrict__ partials) {
     using L = UpdLds<S>;
@@ -71,9 +86,12 @@ __global__ __launch_bounds__(UPD_BLOCK) void dqn_lossgrad_kernel(const float* __
     const int p = blockIdx.y;
     const int T = bt.max_len, B = bt.batch;
 
-    mlp_stage_fwd<S>(params + (size_t)p * S::NPARAM, lds + L::oC, tid, UPD_BLOCK);
-    mlp_stage_fwd<S>(tparams + (size_t)p * S::NPARAM, lds + L::oT, tid, UPD_BLOCK);
-    mlp_stage_bwd<S>(params + (size_t)p * S::NPARAM, lds + L::oB, tid, UPD_BLOCK);
+    {   // the three packs were laid out by dqn_pack_kernel exactly as LDS wants them: 16-byte linear copy
+        constexpr int TOT4 = (2 * S::NFWD + S::NBWD) / 4;
+        const f4* src = reinterpret_cast<const f4*>(packs + (size_t)p * (2 * S::NFWD + S::NBWD));
+        f4* dst = reinterpret_cast<f4*>(lds);
+        for (int i = tid; i < TOT4; i += UPD_BLOCK) dst[i] = src[i];
+    }
     __syncthreads();
 
     const float* cpk = lds + L::oC;
@@ -290,17 +308,26 @@ __global__ __launch_bounds__(UPD_BLOCK) void dqn_lossgrad_kernel(const float* __
 // n_filled comes from agent 0's records only (every agent sees the same filled mask).
 __global__ __launch_bounds__(256) void dqn_reduce_kernel(const float* __restrict__ partials, int P, int nwg, int nparam,
                                                          float* __restrict__ grad, float* __restrict__ loss) {
-    __shared__ float s_nf, s_loss;
+    __shared__ float s_red[8];
     const int rec = nparam + 2;
-    if (threadIdx.x == 0) {
-        float nf = 0.f, ls = 0.f;
-        for (int w = 0; w < nwg; ++w) nf += partials[(size_t)w * rec + nparam + 1];
-        for (int w = 0; w < P * nwg; ++w) ls += partials[(size_t)w * rec + nparam];
-        s_nf = nf;
-        s_loss = ls;
+    // n_filled (agent 0's records) and the loss sum (all records): strided loads + fixed-order tree
+    float nf = 0.f, ls = 0.f;
+    for (int w = threadIdx.x; w < P * nwg; w += 256) {
+        ls += partials[(size_t)w * rec + nparam];
+        if (w < nwg) nf += partials[(size_t)w * rec + nparam + 1];
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        nf += __shfl_xor(nf, off);
+        ls += __shfl_xor(ls, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        s_red[threadIdx.x >> 6] = nf;
+        s_red[4 + (threadIdx.x >> 6)] = ls;
     }
     __syncthreads();
-    const float nf = s_nf;
+    nf = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+    ls = (s_red[4] + s_red[5]) + (s_red[6] + s_red[7]);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < P * nparam) {
         const int p = i / nparam, k = i - p * nparam;
@@ -310,7 +337,7 @@ __global__ __launch_bounds__(256) void dqn_reduce_kernel(const float* __restrict
         grad[i] = acc / nf;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        loss[0] = s_loss / nf;
+        loss[0] = ls / nf;
         loss[1] = nf;
     }
 }
@@ -399,8 +426,12 @@ int launch_lossgrad(const marlhip_net_shape* s, const float* params, const float
                     int double_q, void* ws, int64_t ws_bytes, float* grad, float* loss, hipStream_t st) {
     using L = UpdLds<S>;
     const UpdPlan pl = upd_plan(s->n_agents, bt->max_len, bt->batch);
-    const int64_t need = (int64_t)s->n_agents * pl.nwg * L::REC * sizeof(float);
+    constexpr int PACK = 2 * S::NFWD + S::NBWD;
+    static_assert(PACK % 4 == 0 && L::oT == S::NFWD && L::oB == 2 * S::NFWD, "pack layout == LDS layout");
+    const int64_t rec_bytes = (int64_t)s->n_agents * pl.nwg * L::REC * sizeof(float);
+    const int64_t need = rec_bytes + (int64_t)s->n_agents * PACK * sizeof(float);
     MARL_REQUIRE(ws_bytes >= need, "dqn_loss_grad: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)need);
+    float* packs = reinterpret_cast<float*>(static_cast<char*>(ws) + ((rec_bytes + 15) & ~(int64_t)15));
     const size_t lds_bytes = (size_t)L::TOTAL * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
@@ -408,8 +439,10 @@ int launch_lossgrad(const marlhip_net_shape* s, const float* params, const float
                             (int)lds_bytes);
         attr_set = true;
     }
+    hipLaunchKernelGGL((dqn_pack_kernel<S>), dim3((PACK + 255) / 256, s->n_agents), dim3(256), 0, st, params, tparams, packs);
+    MARL_CHECK_LAUNCH("dqn_pack_kernel");
     timing_begin(TIMER_LOSSGRAD, st);
-    hipLaunchKernelGGL((dqn_lossgrad_kernel<S>), dim3(pl.nwg, s->n_agents), dim3(UPD_BLOCK), lds_bytes, st, params, tparams, *bt,
+    hipLaunchKernelGGL((dqn_lossgrad_kernel<S>), dim3(pl.nwg, s->n_agents), dim3(UPD_BLOCK), lds_bytes, st, (const float*)packs, *bt,
                        gamma, double_q, pl.n_chunks, (float*)ws);
     timing_end(TIMER_LOSSGRAD, st);
     MARL_CHECK_LAUNCH("dqn_lossgrad_kernel");
@@ -440,7 +473,12 @@ extern "C" int64_t marlhip_dqn_workspace_bytes(const marlhip_net_shape* s, int32
     const int np = marlhip_net_nparams(s);
     if (np < 0) return -1;
     const UpdPlan pl = upd_plan(s->n_agents, max_len, batch);
-    return (int64_t)s->n_agents * pl.nwg * (np + 2) * sizeof(float);
+    // partial records + 16 B alignment slack + weight packs (<= 4 x nparams-padded floats per agent; see launch_lossgrad)
+    int64_t pack = -1;
+#define X(d, h, a) if (s->obs_dim == d && s->hidden == h && s->n_actions == a) pack = 2 * MlpShape<d, h, a>::NFWD + MlpShape<d, h, a>::NBWD;
+    MARL_NET_SHAPES(X)
+#undef X
+    return (int64_t)s->n_agents * pl.nwg * (np + 2) * sizeof(float) + 16 + (int64_t)s->n_agents * pack * sizeof(float);
 }
 
 extern "C" int marlhip_dqn_loss_grad(const marlhip_net_shape* s, const float* params, const float* target_params,

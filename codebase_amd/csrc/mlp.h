@@ -81,6 +81,20 @@ __device__ __forceinline__ void mlp_stage_fwd(const float* __restrict__ w, float
 }
 
 template <class S>
+__device__ __forceinline__ float mlp_bwd_pack_elem(const float* __restrict__ w, int idx) {
+    if (idx < S::pT2) {  // T3[mt][lane][r]: A[i=h2 16mt+i][k=a 4g+r] = W3[4g+r][16mt+i]
+        const int r = idx & 3, lane = (idx >> 2) & 63, mt = idx >> 8;
+        const int a = 4 * (lane >> 4) + r;
+        return a < S::A ? w[S::oW3 + a * S::H + 16 * mt + (lane & 15)] : 0.f;
+    }
+    // T2[mt1][mt2][lane][r]: A[i=h1 16mt1+i][k=h2 16mt2+4g+r] = W2[16mt2+4g+r][16mt1+i]
+    const int j = idx - S::pT2;
+    const int r = j & 3, lane = (j >> 2) & 63, rest = j >> 8;
+    const int mt2 = rest % S::MT, mt1 = rest / S::MT;
+    return w[S::oW2 + (16 * mt2 + 4 * (lane >> 4) + r) * S::H + 16 * mt1 + (lane & 15)];
+}
+
+template <class S>
 __device__ __forceinline__ void mlp_stage_bwd(const float* __restrict__ w, float* lds, int tid, int nthreads) {
     for (int idx = tid; idx < S::NBWD; idx += nthreads) {
         float v;

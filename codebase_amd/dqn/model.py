@@ -1,0 +1,202 @@
+"""`QNetwork` with the reference's duck-typed model interface - drop-in for
+`algorithm.model._target_: dqn.model.QNetwork` (marlbase/configs/algorithm/idqn.yaml:7,
+marlbase/dqn/model.py:14-196) - whose every computation runs in libmarlhip.so.
+
+Interface kept: constructor arguments, `init_hiddens`, `act(inputs, hiddens, epsilon,
+action_masks=None) -> (list[int], hiddens)`, `update(batch) -> {"loss": float}`, `update_target /
+hard_update / soft_update`, `parameters()`, `state_dict()/load_state_dict()` with the reference's key
+names (`critic.independent.{i}.network.{0,2,4}.{weight,bias}`, `target.*`) so checkpoints written by
+either implementation load in the other (marlbase/dqn/train.py:340-343, marlbase/eval.py:42-60).
+
+Storage: one flat fp32 block per agent, `params[P][nparams]`, in torch parameters() order; the
+state_dict tensors are slices of it.
+"""
+import math
+
+import numpy as np
+import random
+from collections import OrderedDict
+
+import torch
+from torch import nn
+
+from .. import hip as _hip
+from ..spaces import flatdim
+
+
+def _fc(dims, use_orthogonal_init):
+    """Linear-ReLU-...-Linear exactly as FCNetwork builds it (utils/models.py:34-42), used only to
+    draw the initial weights from torch's RNG in the reference's order."""
+    mods = []
+    for i in range(len(dims) - 1):
+        lin = nn.Linear(dims[i], dims[i + 1])
+        if use_orthogonal_init:
+            nn.init.orthogonal_(lin.weight.data, gain=np.sqrt(2))  # np.float64 gain, as utils/models.py:9
+            nn.init.constant_(lin.bias.data, 0)
+        mods.append(lin)
+    return mods
+
+
+def init_flat_params(obs_dims, hidden_dims, act_dims, use_orthogonal_init=True):
+    """Initial critic AND target blocks, consuming torch's global RNG like the reference constructor
+    does (critic nets for agents 0..P-1, then target nets; dqn/model.py:36-41) before hard_update
+    overwrites the target.  Returns (critic[P][n], target[P][n]) on the CPU."""
+    blocks = []
+    for _ in range(2):
+        per_agent = []
+        for d, a in zip(obs_dims, act_dims):
+            lins = _fc([d] + list(hidden_dims) + [a], use_orthogonal_init)
+            per_agent.append(torch.cat([t.detach().reshape(-1) for lin in lins for t in (lin.weight, lin.bias)]))
+        blocks.append(torch.stack(per_agent))
+    critic = blocks[0]
+    return critic, critic.clone()  # hard_update (dqn/model.py:60)
+
+
+def _tensor_layout(D, H, A):
+    return [("network.0.weight", (H, D)), ("network.0.bias", (H,)), ("network.2.weight", (H, H)),
+            ("network.2.bias", (H,)), ("network.4.weight", (A, H)), ("network.4.bias", (A,))]
+
+
+class QNetwork:
+    def __init__(self, obs_space, action_space, cfg, layers, parameter_sharing=False, use_rnn=False,
+                 use_orthogonal_init=True, device="cuda"):
+        hidden = [int(h) for h in layers]
+        obs_dims = [flatdim(o) for o in obs_space]
+        act_dims = [flatdim(a) for a in action_space]
+        if parameter_sharing:
+            raise NotImplementedError("parameter_sharing: shared / SePS networks are a 'next' row (DESIGN.md)")
+        if use_rnn:
+            raise NotImplementedError("use_rnn: the GRU path is a 'next' row (DESIGN.md)")
+        if len(hidden) != 2 or hidden[0] != hidden[1]:
+            raise NotImplementedError(f"layers={hidden}: the HIP kernels implement two equal hidden layers (64 or 128)")
+        if len(set(obs_dims)) != 1 or len(set(act_dims)) != 1:
+            raise NotImplementedError("agents with different observation / action sizes")
+        if str(device) == "cpu":
+            raise _hip.MarlHipError("codebase_amd.dqn.model.QNetwork runs on the GPU only: set algorithm.model.device=cuda")
+        get = (lambda k, d=None: cfg[k] if k in cfg else d) if isinstance(cfg, dict) else (lambda k, d=None: getattr(cfg, k, d))
+        opt = get("optimizer", "Adam")
+        if (opt if isinstance(opt, str) else getattr(opt, "__name__", "")) != "Adam":
+            raise NotImplementedError(f"optimizer {opt}: the fused step implements torch.optim.Adam")
+        if get("standardise_returns", False):
+            raise NotImplementedError("standardise_returns is a 'next' row (DESIGN.md)")
+        self.action_space = action_space
+        self.n_agents = len(obs_dims)
+        self.device = torch.device(device)
+        self.spec = _hip.NetSpec(self.n_agents, obs_dims[0], hidden[0], act_dims[0])
+        self.nparams = self.spec.nparams()
+        critic, target = init_flat_params(obs_dims, hidden, act_dims, use_orthogonal_init)
+        assert critic.shape == (self.n_agents, self.nparams)
+        self.params = critic.to(self.device).contiguous()
+        self.target_params = target.to(self.device).contiguous()
+        self.gamma = float(get("gamma", 0.99))
+        self.grad_clip = get("grad_clip", 1.0)
+        self.double_q = bool(get("double_q", True))
+        self.target_update_interval_or_tau = get("target_update_interval_or_tau", 200)
+        self.updater = _hip.DqnUpdater(self.spec, self.params, self.target_params, lr=float(get("lr", 3e-4)),
+                                       gamma=self.gamma, grad_clip=self.grad_clip, double_q=self.double_q)
+        self.updates = 0
+        self.last_target_update = 0
+        self.standardise_returns = False
+        self.mode = 0  # IDQN
+        self._obs1 = torch.zeros(self.n_agents, 1, self.spec.obs_dim, device=self.device)
+        self._u1 = torch.ones(1, device=self.device)
+        self._ra1 = torch.zeros(self.n_agents, 1, dtype=torch.int32, device=self.device)
+
+    # ---- reference interface ---------------------------------------------------------------
+    def forward(self, inputs):
+        raise NotImplementedError("Forward not implemented. Use act or update instead!")
+
+    def init_hiddens(self, batch_size):
+        return [None] * self.n_agents
+
+    def q_values(self, obs):
+        """obs f32 [P][N][D] on the device -> Q [P][N][A] (critic forward, K2)."""
+        q = torch.empty(obs.shape[0], obs.shape[1], self.spec.n_actions, device=obs.device)
+        n = obs.shape[1]
+        _hip.dqn_act(self.spec, self.params, obs, 0.0, u=torch.ones(n, device=obs.device),
+                     rand_actions=torch.zeros(obs.shape[0], n, dtype=torch.int32, device=obs.device), q_out=q)
+        return q
+
+    def act(self, inputs, hiddens, epsilon, action_masks=None):
+        """One env (dqn/model.py:94-116): ONE python `random.random()` draw decides the joint action."""
+        if action_masks is not None:
+            raise NotImplementedError("action masks (SMAClite) are outside this round's hot path")
+        if epsilon > random.random():
+            return list(self.action_space.sample()), hiddens
+        for p, o in enumerate(inputs):
+            self._obs1[p, 0].copy_(torch.as_tensor(o, dtype=torch.float32))
+        acts = _hip.dqn_act(self.spec, self.params, self._obs1, 0.0, u=self._u1, rand_actions=self._ra1)
+        return [int(a) for a in acts[:, 0].tolist()], hiddens
+
+    def act_batched(self, obs, epsilon, seed, episode, ep_length):
+        """N envs on the device, Philox noise keyed like the fused collector."""
+        return _hip.dqn_act(self.spec, self.params, obs, epsilon, seed=seed, episode=episode, ep_length=ep_length)
+
+    def _to_device_batch(self, batch):
+        f = lambda t, dt: t.to(self.device, dt).contiguous()
+        return _hip.Batch(f(batch.obss, torch.float32), f(batch.actions, torch.int64), f(batch.rewards, torch.float32),
+                          f(batch.dones, torch.float32), f(batch.filled, torch.float32), None)
+
+    def update_async(self, batch, grad_sync=None, world=1):
+        """loss/grad -> [grad_sync(grad)] -> clip+Adam -> target update; returns the device loss tensor."""
+        loss, grad = self.updater.loss_grad(self._to_device_batch(batch), mode=self.mode)
+        if grad_sync is not None:
+            grad_sync(grad)
+        self.updates += 1
+        tui = self.target_update_interval_or_tau
+        hard = tui > 1.0 and (self.updates - self.last_target_update) >= tui  # dqn/model.py:176-185
+        tau = float(tui) if tui < 1.0 else 0.0
+        self.updater.apply(hard_update=hard, tau=tau, grad_scale=1.0 / world)
+        if hard:
+            self.last_target_update = self.updates
+        return loss
+
+    def update(self, batch):
+        return {"loss": float(self.update_async(batch)[0].item())}  # .item(): the reference's per-update sync
+
+    def update_target(self):
+        tui = self.target_update_interval_or_tau
+        if tui > 1.0 and (self.updates - self.last_target_update) >= tui:
+            self.hard_update()
+            self.last_target_update = self.updates
+        elif tui < 1.0:
+            self.soft_update(tui)
+
+    def soft_update(self, tau):
+        self.target_params.mul_(1 - tau).add_(self.params, alpha=tau)
+
+    def hard_update(self):
+        self.target_params.copy_(self.params)
+
+    # ---- torch-module-like surface (checkpoints, logger.watch) --------------------------------
+    def _views(self, block, prefix):
+        out = OrderedDict()
+        S = self.spec
+        for i in range(self.n_agents):
+            o = 0
+            for name, shape in _tensor_layout(S.obs_dim, S.hidden, S.n_actions):
+                n = int(torch.tensor(shape).prod())
+                out[f"{prefix}.independent.{i}.{name}"] = block[i, o:o + n].view(shape)
+                o += n
+        return out
+
+    def parameters(self):
+        return list(self._views(self.params, "critic").values())
+
+    def state_dict(self):
+        sd = OrderedDict()
+        for k, v in list(self._views(self.params, "critic").items()) + list(self._views(self.target_params, "target").items()):
+            sd[k] = v.detach().clone()
+        return sd
+
+    def load_state_dict(self, sd):
+        for block, prefix in ((self.params, "critic"), (self.target_params, "target")):
+            for k, view in self._views(block, prefix).items():
+                view.copy_(sd[k].to(self.device))
+
+    def to(self, device):
+        return self
+
+    def __repr__(self):
+        S = self.spec
+        return f"QNetwork[HIP](agents={S.n_agents}, mlp={S.obs_dim}-{S.hidden}-{S.hidden}-{S.n_actions}, params={self.nparams}/agent)"

@@ -1,0 +1,255 @@
+"""IDQN driver with the reference's entry point - drop-in for `algorithm._target_: dqn.train.main`
+(marlbase/configs/algorithm/idqn.yaml:4, marlbase/dqn/train.py:264-345).
+
+Two paths behind the same `main(env, eval_env, logger, time_limit, **cfg)`:
+  * `env` is a single env (make_env without parallel_envs): the reference's loop verbatim in
+    behaviour - collect ONE episode through `model.act`/`env.step`, then at most one update of
+    `batch_size` episodes (train.py:298-312) - every piece executing in the HIP library.
+  * `env` is a HipForagingVecEnv (env.parallel_envs=N): the vectorised loop.  One ROUND = the fused
+    collector gathers one episode from each of the N envs in a single launch, then U updates of B
+    sampled episodes run back to back on the device (no host sync until evaluation).  Cadence is
+    explicit in the config (`algorithm.updates_per_round`, `algorithm.batch_size`); the default
+    keeps the reference's replay ratio: batch_size sampled episodes per collected episode, i.e.
+    U = batch_size * N / B with B = N.
+"""
+import math
+from pathlib import Path
+
+import numpy as np
+import torch
+
+from .. import hip as _hip
+from ..hip import Batch  # noqa: F401  (same field names as dqn/train.py:14-16)
+
+
+class ReplayBuffer:
+    """marlbase/dqn/train.py:19-124 on top of the device-resident episode-major store."""
+
+    def __init__(self, buffer_size, n_agents, observation_space, action_space, max_episode_length, device,
+                 store_action_masks=False):
+        if store_action_masks:
+            raise NotImplementedError("action masks are outside this round's hot path")
+        self.buffer_size, self.n_agents, self.max_episode_length = buffer_size, n_agents, max_episode_length
+        self.device = torch.device(device)
+        D = int(np.prod(observation_space[0].shape))
+        self.store = _hip.DeviceReplay(buffer_size, n_agents, D, max_episode_length, device=device)
+        self.pos = self.cur_pos = self.t = 0
+        self._slot = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._t = torch.zeros(1, dtype=torch.int32, device=self.device)
+
+    def __len__(self):
+        return min(self.pos, self.buffer_size)
+
+    def _obs(self, obss):
+        return torch.as_tensor(np.stack([np.asarray(o, np.float32) for o in obss])).reshape(self.n_agents, 1, -1).to(self.device)
+
+    def init_episode(self, obss, action_masks=None):
+        self.t = 0
+        self._slot.fill_(self.cur_pos)
+        self.store.init_episode(self._slot, self._obs(obss))
+
+    def add(self, obss, acts, rews, done, action_masks=None):
+        assert self.t < self.max_episode_length, "Episode longer than given max length!"
+        self._slot.fill_(self.cur_pos)
+        self._t.fill_(self.t)
+        dev = self.device
+        self.store.add(self._slot, self._t, self._obs(obss),
+                       torch.as_tensor(np.asarray(acts, np.int32).reshape(-1, 1)).to(dev),
+                       torch.as_tensor(np.asarray(rews, np.float32).reshape(-1, 1)).to(dev),
+                       torch.tensor([1 if done else 0], dtype=torch.uint8, device=dev))
+        self.t += 1
+        if done:
+            self.pos += 1
+            self.cur_pos = self.pos % self.buffer_size
+            self.t = 0
+
+    def can_sample(self, batch_size):
+        return self.pos >= batch_size
+
+    def sample(self, batch_size):
+        idx = np.random.randint(0, len(self), size=batch_size)  # legacy global RNG, as train.py:95
+        return self.store.sample(batch_size, idx=torch.as_tensor(idx, dtype=torch.int32).to(self.device), fresh=True)
+
+
+def _epsilon_schedule(decay_style, decay_over, eps_start, eps_end, exp_decay_rate, total_steps):
+    """marlbase/dqn/train.py:127-174 (same checks, same arithmetic)."""
+    styles = {"linear": "lin", "lin": "lin", "exponential": "exp", "exp": "exp"}
+    assert decay_style in styles, "decay_style must be one of 'linear' or 'exponential'"
+    assert 0 <= eps_start <= 1 and 0 <= eps_end <= 1, "eps must be in [0, 1]"
+    assert eps_start >= eps_end, "eps_start must be >= eps_end"
+    assert 0 < decay_over <= 1, "decay_over must be in (0, 1]"
+    assert total_steps > 0, "total_steps must be > 0"
+    assert exp_decay_rate > 0, "eps_decay must be > 0"
+    span = eps_start - eps_end
+    horizon = total_steps * decay_over
+    if styles[decay_style] == "lin":
+        return lambda steps_done: max(eps_end + span * (1 - steps_done / horizon), eps_end)
+    rate = span / horizon * exp_decay_rate
+    return lambda steps_done: max(eps_end + span * math.exp(-rate * steps_done), eps_end)
+
+
+def _episode(env, model, epsilon, rb=None, use_proper_termination=False):
+    """one episode through the scalar API: _collect_trajectory (train.py:202-237) when `rb` is given,
+    else one iteration of _evaluate (train.py:177-199)."""
+    obss, info = env.reset()
+    if rb is not None:
+        rb.init_episode(obss)
+    hiddens = model.init_hiddens(1)
+    done, t = False, 0
+    while not done:
+        actions, hiddens = model.act(obss, hiddens, epsilon)
+        obss, rews, term, truncated, info = env.step(actions)
+        done = term or truncated
+        if rb is not None:
+            rb.add(obss, actions, rews, term if use_proper_termination else done)
+        t += 1
+    return t, info
+
+
+def _collect_trajectory(env, model, rb, epsilon, use_proper_termination):
+    return _episode(env, model, epsilon, rb, use_proper_termination)
+
+
+def _evaluate(env, model, eval_episodes, eval_epsilon):
+    return [_episode(env, model, eval_epsilon)[1] for _ in range(eval_episodes)]
+
+
+class VectorisedIDQN:
+    """Device-resident training state of the vectorised path: N envs, replay shard, learner."""
+
+    def __init__(self, lbf_cfg, model, buffer_episodes, time_limit, batch_size, updates_per_round, seed=0,
+                 use_proper_termination=False, clear_stale=False, dist=None):
+        self.cfg, self.model, self.T = lbf_cfg, model, int(time_limit)
+        self.N = lbf_cfg.n_envs
+        self.capacity = max(int(buffer_episodes) // self.N, 1) * self.N  # whole rounds
+        self.replay = _hip.DeviceReplay(self.capacity, model.n_agents, model.spec.obs_dim, self.T, device=model.device)
+        self.B, self.U = int(batch_size), int(updates_per_round)
+        self.seed = int(seed)
+        self.proper, self.clear_stale = bool(use_proper_termination), bool(clear_stale)
+        self.dist = dist
+        self.world = dist.get_world_size() if dist is not None else 1
+        self.rank = dist.get_rank() if dist is not None else 0
+        dev = model.device
+        self.fin_return = torch.zeros(model.n_agents, self.N, device=dev)
+        self.fin_length = torch.zeros(self.N, dtype=torch.int32, device=dev)
+        self.env_steps = torch.zeros((), dtype=torch.int64, device=dev)  # counted on the device
+        self.rounds = 0
+        self.sample_counter = 0
+        self.last_loss = None
+
+    def _grad_sync(self, grad):
+        self.dist.all_reduce(grad)  # SUM over ranks (RCCL over xGMI); clip+Adam applies 1/world
+
+    def round(self, epsilon, train=True):
+        """collect N episodes (one launch), then U updates; nothing here synchronises with the host."""
+        m = self.model
+        slot_base = (self.rounds * self.N) % self.capacity
+        _hip.idqn_collect(self.cfg, m.spec, m.params, epsilon, self.rounds, self.replay, slot_base, self.fin_return,
+                          self.fin_length, write_replay=True, clear_stale=self.clear_stale,
+                          use_proper_termination=self.proper)
+        self.env_steps += self.fin_length.sum()
+        self.rounds += 1
+        if train:
+            length = min(self.rounds * self.N, self.capacity)
+            sync = self._grad_sync if self.dist is not None else None
+            for _ in range(self.U):
+                batch = self.replay.sample(self.B, length=length, seed=self.seed + 7919 * self.rank, counter=self.sample_counter)
+                self.sample_counter += 1
+                self.last_loss = m.update_async(batch, grad_sync=sync, world=self.world)
+
+    def evaluate(self, episodes, epsilon, round_idx=0):
+        """_evaluate (train.py:177-199) for `episodes` envs in one collector launch (no replay writes);
+        returns per-episode info dicts like RecordEpisodeStatistics emits."""
+        cfg = _hip.LbfConfig.from_buffer_copy(self.cfg)
+        cfg.n_envs = int(episodes)
+        cfg.seed = (self.cfg.seed ^ 0x5DEECE66D) & (2**64 - 1)  # eval env: its own stream
+        dev = self.model.device
+        ret = torch.zeros(self.model.n_agents, episodes, device=dev)
+        ln = torch.zeros(episodes, dtype=torch.int32, device=dev)
+        _hip.idqn_collect(cfg, self.model.spec, self.model.params, epsilon, round_idx, self.replay, 0, ret, ln,
+                          write_replay=False)
+        ret, ln = ret.cpu().numpy(), ln.cpu().numpy()
+        infos = []
+        for i in range(episodes):
+            d = {"episode_returns": ret[:, i].copy(), "episode_length": int(ln[i])}
+            for p in range(ret.shape[0]):
+                d[f"agent{p}/episode_returns"] = ret[p, i]
+            infos.append(d)
+        return infos
+
+
+def _cfg_get(cfg, key, default=None):
+    cur = cfg
+    for part in key.split("."):
+        if isinstance(cur, dict):
+            if part not in cur:
+                return default
+            cur = cur[part]
+        else:
+            if not hasattr(cur, part) and not (hasattr(cur, "__contains__") and part in cur):
+                return default
+            cur = cur[part] if hasattr(cur, "__getitem__") else getattr(cur, part)
+    return cur
+
+
+def _make_model(cfg, env):
+    from ..config import instantiate
+
+    obs_space = getattr(env, "single_observation_space", None) or env.observation_space
+    act_space = getattr(env, "single_action_space", None) or env.action_space
+    return instantiate(_cfg_get(cfg, "model"), obs_space, act_space, cfg)
+
+
+def main(env, eval_env, logger, time_limit, **cfg):
+    model = _make_model(cfg, env)
+    logger.watch(model)
+    g = lambda k, d=None: _cfg_get(cfg, k, d)
+    eps_sched = _epsilon_schedule(g("eps_decay_style"), g("eps_decay_over"), g("eps_start"), g("eps_end"),
+                                  g("eps_exp_decay_rate"), g("total_steps"))
+    total_steps = g("total_steps")
+    vectorised = getattr(env, "n_envs", 1) > 1
+    updates = step = last_eval = last_save = 0
+    metrics = {}
+    if vectorised:
+        N = env.n_envs
+        B = int(g("update_batch_size", 0) or N)
+        U = int(g("updates_per_round", 0) or max(1, (g("batch_size") * N) // B))
+        trainer = VectorisedIDQN(env.cfg, model, max(g("buffer_size"), N), time_limit, B, U, seed=env.cfg.seed,
+                                 use_proper_termination=g("use_proper_termination", False))
+    else:
+        rb = ReplayBuffer(g("buffer_size"), env.unwrapped.n_agents, env.observation_space, env.action_space, time_limit,
+                          _cfg_get(cfg, "model.device", "cuda"))
+    while step < total_steps + 1:
+        if vectorised:
+            train = step > g("training_start") and trainer.rounds * N >= g("batch_size")
+            trainer.round(eps_sched(step), train=train)
+            step = int(trainer.env_steps.item())  # one host sync per round (N episodes)
+            if train:
+                updates += trainer.U
+                metrics = {"loss": float(trainer.last_loss[0].item())}
+        else:
+            t, _ = _collect_trajectory(env, model, rb, eps_sched(step), g("use_proper_termination", False))
+            step += t
+            if step > g("training_start") and rb.can_sample(g("batch_size")):
+                metrics = model.update(rb.sample(g("batch_size")))
+                updates += 1
+            else:
+                metrics = {}
+        if g("eval_interval") and (step - last_eval) >= g("eval_interval"):
+            if vectorised:
+                infos = trainer.evaluate(g("eval_episodes"), g("eps_evaluation"), round_idx=trainer.rounds)
+            else:
+                infos = _evaluate(eval_env, model, g("eval_episodes"), g("eps_evaluation"))
+            if metrics:
+                infos.append(metrics)
+            infos.append({"updates": updates, "environment_steps": step, "epsilon": eps_sched(step)})
+            logger.log_metrics(infos)
+            last_eval = step
+        if g("video_interval"):
+            raise NotImplementedError("video recording is outside the HIP hot path")
+        if g("save_interval") and (step - last_save) >= g("save_interval"):
+            Path("checkpoints").mkdir(exist_ok=True)
+            torch.save(model.state_dict(), f"checkpoints/model_s{step}.pt")
+            last_save = step
+    env.close()
+    return model

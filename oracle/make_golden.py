@@ -163,6 +163,23 @@ def replay_fixture(ref_train):
     print("replay: pos", rb.pos, "len", len(rb), "filled", b.filled.numpy().sum(0))
 
 
+def init_fixture(ref_model):
+    """parameter blocks right after QNetwork.__init__ under torch.manual_seed(123) (orthogonal and
+    default init) - pins codebase_amd.dqn.model.init_flat_params' RNG consumption order."""
+    out = {}
+    for H in (64, 128):
+        for orth in (True, False):
+            torch.manual_seed(123)
+            cfg = Cfg(optimizer="Adam", lr=3e-4, gamma=0.99, grad_clip=1.0, target_update_interval_or_tau=200, double_q=True,
+                      standardise_returns=False)
+            with contextlib.redirect_stdout(io.StringIO()):
+                net = ref_model.QNetwork([Box(15)] * 2, [Discrete(6)] * 2, cfg, [H, H], False, False, orth, "cpu")
+            out[f"critic_H{H}_orth{int(orth)}"] = flat_params(net.critic).numpy()
+            out[f"target_H{H}_orth{int(orth)}"] = flat_params(net.target).numpy()
+            out[f"keys_H{H}"] = np.array(list(net.state_dict().keys()))
+    np.savez_compressed(os.path.join(OUT, "init.npz"), **out)
+
+
 def eps_fixture(ref_train):
     steps = np.array([0, 1, 10, 999, 25000, 50000, 75000, 100000], np.float64)
     lin = ref_train._epsilon_schedule("linear", 0.5, 1.0, 0.05, 6.5, 100000)
@@ -179,3 +196,4 @@ if __name__ == "__main__":
         learner_fixture(ref_model, ref_train, H)
     replay_fixture(ref_train)
     eps_fixture(ref_train)
+    init_fixture(ref_model)
