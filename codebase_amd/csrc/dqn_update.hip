@@ -15,12 +15,14 @@
 //   in fixed order (bitwise reproducible, no float atomics) and applies 1/sum(filled).
 // MFMA-bound: 360 v_mfma_f32_16x16x4_f32 per 16-row block at H=64 (96 critic fwd, 96 target
 // fwd, 168 backward) = 46.1 kFLOP/row issued vs 43.5 kFLOP/row algorithmic.
+#include <stdlib.h>
+
 #include "common.h"
 #include "mlp.h"
 
 namespace marl {
 
-constexpr int UPD_BLOCK = 256;
+constexpr int UPD_MAXWAVES = 8;  // waves per workgroup: 4 (1 per SIMD) or 8 (2 per SIMD)
 
 __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -52,11 +54,12 @@ __device__ __forceinline__ float sum16(float v) {  // over the 16 lanes j of one
 template <class S>
 struct UpdLds {
     static constexpr int TILE = 16 * S::H;                    // one [H][16] transpose tile
-    static constexpr int PER_WAVE = 2 * TILE + 256;           // activation tile, gradient tile, dQ tile
+    static constexpr int PER_WAVE = 4 * TILE + 256;           // h2, h1, dH2, dH1 transpose tiles + dQ tile
     static constexpr int oC = 0, oT = S::NFWD, oB = 2 * S::NFWD, oTiles = oB + S::NBWD;
-    static constexpr int TOTAL = oTiles + 4 * PER_WAVE;       // floats
+    static constexpr int total(int waves) { return oTiles + waves * PER_WAVE; }  // floats
     static constexpr int REC = S::NPARAM + 2;                 // partial record: grads, loss, n_filled
-    static_assert(2 * S::NFWD >= REC, "fold buffer");
+    static constexpr int FOLD = S::NPARAM + (2 * S::H + 18) * 16;  // per-wave fold region (weights + bias/loss strips)
+    static_assert(4 * FOLD <= oTiles + 4 * PER_WAVE, "fold regions overlay packs + tiles");
 };
 
 // packs of one agent in the workspace: [critic fwd NFWD][target fwd NFWD][critic bwd NBWD]
@@ -75,12 +78,13 @@ __global__ __launch_bounds__(256) void dqn_pack_kernel(const float* __restrict__
     packs[(size_t)p * TOT + idx] = v;
 }
 
-template <class S>
-__global__ __launch_bounds__(UPD_BLOCK) void dqn_lossgrad_kernel(const float* __restrict__ packs, marlhip_batch bt,
+template <class S, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dqn_lossgrad_kernel(const float* __restrict__ packs, marlhip_batch bt,
                                                                  float gamma, int double_q, int n_chunks,
-                                                                 float* __restrict__ partials) {
+                                                                 float* __restrict__ partials, unsigned long long* prof) {
     using L = UpdLds<S>;
     constexpr int MT = S::MT, NT1 = S::DP / 16, D = S::D, H = S::H, A = S::A;
+    constexpr int UPD_BLOCK = 64 * WAVES;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, j = lane & 15;
     const int p = blockIdx.y;
@@ -98,9 +102,11 @@ __global__ __launch_bounds__(UPD_BLOCK) void dqn_lossgrad_kernel(const float* __
     const float* tpk = lds + L::oT;
     const f4* T3 = reinterpret_cast<const f4*>(lds + L::oB + S::pT3);
     const f4* T2 = reinterpret_cast<const f4*>(lds + L::oB + S::pT2);
-    float* TA = lds + L::oTiles + wave * L::PER_WAVE;
-    float* TG = TA + L::TILE;
-    float* TQ = TG + L::TILE;
+    float* TH2 = lds + L::oTiles + wave * L::PER_WAVE;
+    float* TH1 = TH2 + L::TILE;
+    float* TG2 = TH1 + L::TILE;
+    float* TG1 = TG2 + L::TILE;
+    float* TQ = TG1 + L::TILE;
 
     const float* obs_p = bt.obss + (size_t)p * (T + 1) * B * D;
     const int64_t* act_p = bt.actions + (size_t)p * T * B;
@@ -117,10 +123,20 @@ __global__ __launch_bounds__(UPD_BLOCK) void dqn_lossgrad_kernel(const float* __
         for (int b = 0; b < NT1; ++b) dW1[a][b] = zero4;
     }
     float loss_acc = 0.f, nfill_acc = 0.f;
+    // optional per-phase cycle accounting (MARLHIP_PROF=1): s_memtime deltas summed per phase
+    unsigned long long pc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pt = 0;
+    const unsigned long long t_begin = prof ? __builtin_readcyclecounter() : 0;
+#define MARL_PHASE(k)                                         \
+    if (prof != nullptr) {                                    \
+        const unsigned long long now_ = __builtin_readcyclecounter(); \
+        pc[k] += now_ - pt;                                   \
+        pt = now_;                                            \
+    }
 
+    const unsigned long long t_loop_begin = prof ? __builtin_readcyclecounter() : 0;
     const int ngroups = (B + 15) >> 4;
     const int ntasks = ngroups * n_chunks;
-    for (int task = blockIdx.x * 4 + wave; task < ntasks; task += gridDim.x * 4) {
+    for (int task = blockIdx.x * WAVES + wave; task < ntasks; task += gridDim.x * WAVES) {
         const int grp = task / n_chunks, c = task - grp * n_chunks;
         const int t0 = (c * T) / n_chunks, t1 = ((c + 1) * T) / n_chunks;
         if (t1 <= t0) continue;
@@ -128,180 +144,263 @@ __global__ __launch_bounds__(UPD_BLOCK) void dqn_lossgrad_kernel(const float* __
         const bool rowok = (b0 + j) < B;
         const int bj = rowok ? b0 + j : B - 1;
         float tq_next = 0.f;
-        for (int t = t1; t >= t0; --t) {
-            float x[S::KS1];
+        // rows of time step t in the two operand shapes the step needs + the transition's scalars;
+        // issued one step ahead so the loads fly under the previous step's MFMAs
+        struct Rows {
+            float x[S::KS1];   // forward B operand: X[row j][4ks+g]
+            float bx[NT1][4];  // dW1 B operand:     X[row 4g+ks][16nt+j]
+            int a_sel;
+            float rw, dn, fl;
+        };
+        // branch-free: every address is clamped in-bounds and loaded unconditionally (a guarded load is
+        // an exec-masked branch + a conservative vmcnt(0) at the join); masks are applied at the point of use
+        auto load_rows = [&](int t, Rows& R) {
             const float* xrow = obs_p + ((size_t)t * B + bj) * D;
 #pragma unroll
             for (int ks = 0; ks < S::KS1; ++ks) {
                 const int d = 4 * ks + g;
-                x[ks] = (d < D && rowok) ? xrow[d] : 0.f;
+                R.x[ks] = xrow[d < D ? d : D - 1];
             }
-            f4 h1[MT], h2[MT], q;
-            mlp_forward<S>(cpk, lane, x, h1, h2, q);
+            const int tt = t < T ? t : T - 1;
+#pragma unroll
+            for (int nt = 0; nt < NT1; ++nt)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int row = b0 + 4 * g + ks, d = 16 * nt + j;
+                    R.bx[nt][ks] = obs_p[((size_t)t * B + (row < B ? row : B - 1)) * D + (d < D ? d : D - 1)];
+                }
+            R.a_sel = (int)act_p[(size_t)tt * B + bj];
+            R.rw = rew_p[(size_t)tt * B + bj];
+            R.dn = bt.dones[(size_t)(tt + 1) * B + bj];
+            R.fl = bt.filled[(size_t)tt * B + bj];
+        };
+        auto mask_rows = [&](Rows& R) {  // zero the padding (obs dims >= D, rows >= B)
+#pragma unroll
+            for (int ks = 0; ks < S::KS1; ++ks) R.x[ks] = (4 * ks + g < D && rowok) ? R.x[ks] : 0.f;
+#pragma unroll
+            for (int nt = 0; nt < NT1; ++nt)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) R.bx[nt][ks] = (b0 + 4 * g + ks < B && 16 * nt + j < D) ? R.bx[nt][ks] : 0.f;
+            R.fl = rowok ? R.fl : 0.f;
+        };
+        Rows cur;
+        load_rows(t1, cur);
+        for (int t = t1; t >= t0; --t) {
+            Rows nxt;
+            if (prof != nullptr) pt = __builtin_readcyclecounter();
+            load_rows(t > t0 ? t - 1 : t0, nxt);  // unconditional (the last step re-reads its own rows)
+            mask_rows(cur);
+            MARL_PHASE(0)
+            f4 h1[MT], h2[MT], q, tq;
+            if (t > t0) mlp_forward_p<S, true>(cpk, tpk, lane, cur.x, h1, h2, q, tq);  // target value feeds transition t-1
+            else mlp_forward_p<S, false>(cpk, tpk, lane, cur.x, h1, h2, q, tq);
+            MARL_PHASE(1)
             if (t < t1) {
                 // ---- TD error of transition t (model.py:129,152,160-163)
-                const int a_sel = (int)act_p[(size_t)t * B + bj];
-                const float rw = rew_p[(size_t)t * B + bj];
-                const float dn = bt.dones[(size_t)(t + 1) * B + bj];
-                const float fl = rowok ? bt.filled[(size_t)t * B + bj] : 0.f;
-                const float y = rw + gamma * tq_next * (1.f - dn);
+                const int a_sel = cur.a_sel;
+                const float fl = cur.fl;
+                const float y = cur.rw + gamma * tq_next * (1.f - cur.dn);
                 const float delta = gather_rows(q, lane, a_sel) - y;
                 if (g == 0) { loss_acc += fl * delta * delta; nfill_acc += fl; }
                 const float dqs = 2.f * fl * delta;
                 f4 dQ[1];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) dQ[0][r] = (4 * g + r == a_sel) ? dqs : 0.f;
-                // ---- dW3[a][h2] += dQ^T H2 ; db3
-                wave_lds_fence();
-                tile_write<1>(TQ, dQ, g, j);
-                tile_write<MT>(TA, h2, g, j);
-                wave_lds_fence();
-                {
-                    const f4 aop = tile_read(TQ, 0, g, j);
-#pragma unroll
-                    for (int nt = 0; nt < MT; ++nt) {
-                        const f4 bop = tile_read(TA, nt, g, j);
-#pragma unroll
-                        for (int ks = 0; ks < 4; ++ks) dW3[nt] = MARL_MFMA(aop[ks], bop[ks], dW3[nt]);
-                    }
-                }
-                db3 += dQ[0];
-                // ---- dH2^T = W3^T dQ^T (relu mask)
-                f4 dH2[MT];
+                MARL_PHASE(2)
+                // ---- backward of row block t.  Phases are fenced with sched_barrier so that every LDS
+                // operand (weight packs, transposed tiles) is requested >= 16 MFMAs before its first use and
+                // every transposed tile is read >= 16 MFMAs after it was written.
+                f4 t3[MT], t2[2][MT];
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
-                    const f4 a = T3[mt * 64 + lane];
-                    f4 acc = zero4;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc = MARL_MFMA(a[r], dQ[0][r], acc);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[r] = h2[mt][r] > 0.f ? acc[r] : 0.f;
-                    dH2[mt] = acc;
-                    db2[mt] += acc;
+                    t3[mt] = T3[mt * 64 + lane];
+                    t2[0][mt] = T2[(mt * MT + 0) * 64 + lane];
                 }
-                // ---- dW2[h2][h1] += dH2^T H1
                 wave_lds_fence();
-                tile_write<MT>(TG, dH2, g, j);
-                tile_write<MT>(TA, h1, g, j);
-                wave_lds_fence();
-                {
-                    f4 bop[MT];
+                tile_write<1>(TQ, dQ, g, j);
+                tile_write<MT>(TH2, h2, g, j);
+                tile_write<MT>(TH1, h1, g, j);
+                db3 += dQ[0];
+                __builtin_amdgcn_sched_barrier(0);
+                // P1: dH2^T = W3^T dQ^T
+                f4 dH2[MT];
 #pragma unroll
-                    for (int nt = 0; nt < MT; ++nt) bop[nt] = tile_read(TA, nt, g, j);
+                for (int mt = 0; mt < MT; ++mt) dH2[mt] = zero4;
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) {
-                        const f4 aop = tile_read(TG, mt, g, j);
+                for (int r = 0; r < 4; ++r)
 #pragma unroll
-                        for (int ks = 0; ks < 4; ++ks)
+                    for (int mt = 0; mt < MT; ++mt) dH2[mt] = MARL_MFMA(t3[mt][r], dQ[0][r], dH2[mt]);
+                __builtin_amdgcn_sched_barrier(0);
+                MARL_PHASE(3)
+                // P2: relu mask, db2, publish dH2 tile; request dW3 operands and the next W2^T step
 #pragma unroll
-                            for (int nt = 0; nt < MT; ++nt) dW2[mt][nt] = MARL_MFMA(aop[ks], bop[nt][ks], dW2[mt][nt]);
-                    }
+                for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dH2[mt][r] = h2[mt][r] > 0.f ? dH2[mt][r] : 0.f;
+                    db2[mt] += dH2[mt];
                 }
-                // ---- dH1^T = W2^T dH2^T (relu mask)
-                f4 dH1[MT];
+                tile_write<MT>(TG2, dH2, g, j);
+                wave_lds_fence();
+                const f4 aQ = tile_read(TQ, 0, g, j);
+                f4 bH2[MT];
+#pragma unroll
+                for (int nt = 0; nt < MT; ++nt) bH2[nt] = tile_read(TH2, nt, g, j);
+#pragma unroll
+                for (int m1 = 0; m1 < MT; ++m1) t2[1][m1] = T2[(m1 * MT + 1) * 64 + lane];
+                __builtin_amdgcn_sched_barrier(0);
+                MARL_PHASE(4)
+                // P3..: dH1^T = W2^T dH2^T in MT steps (m2), dW3 slotted after the first step
+                f4 dH1[MT], bH1[MT], aG2[MT];
 #pragma unroll
                 for (int m1 = 0; m1 < MT; ++m1) dH1[m1] = zero4;
 #pragma unroll
                 for (int m2 = 0; m2 < MT; ++m2) {
-                    f4 a[MT];
-#pragma unroll
-                    for (int m1 = 0; m1 < MT; ++m1) a[m1] = T2[(m1 * MT + m2) * 64 + lane];
+                    const int cb = m2 & 1;
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
 #pragma unroll
-                        for (int m1 = 0; m1 < MT; ++m1) dH1[m1] = MARL_MFMA(a[m1][r], dH2[m2][r], dH1[m1]);
+                        for (int m1 = 0; m1 < MT; ++m1) dH1[m1] = MARL_MFMA(t2[cb][m1][r], dH2[m2][r], dH1[m1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (m2 == 0) {
+                        // dW3[a][h2] += dQ^T H2   (operands requested in P2)
+#pragma unroll
+                        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                            for (int nt = 0; nt < MT; ++nt) dW3[nt] = MARL_MFMA(aQ[ks], bH2[nt][ks], dW3[nt]);
+#pragma unroll
+                        for (int nt = 0; nt < MT; ++nt) bH1[nt] = tile_read(TH1, nt, g, j);
+                    }
+                    if (m2 + 2 < MT) {
+#pragma unroll
+                        for (int m1 = 0; m1 < MT; ++m1) t2[cb][m1] = T2[(m1 * MT + m2 + 2) * 64 + lane];
+                    }
+                    if (m2 == MT - 2) {
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) aG2[mt] = tile_read(TG2, mt, g, j);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
+                MARL_PHASE(5)
+                // relu mask, db1, publish dH1 tile
 #pragma unroll
                 for (int m1 = 0; m1 < MT; ++m1) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) dH1[m1][r] = h1[m1][r] > 0.f ? dH1[m1][r] : 0.f;
                     db1[m1] += dH1[m1];
                 }
-                // ---- dW1[h1][d] += dH1^T X   (B operand straight from global: X[row 4g+ks][d=16nt+j])
+                tile_write<MT>(TG1, dH1, g, j);
                 wave_lds_fence();
-                tile_write<MT>(TG, dH1, g, j);
-                wave_lds_fence();
+                __builtin_amdgcn_sched_barrier(0);
+                // dW2[h2][h1] += dH2^T H1 (first half), request the dH1 tile under it, then the rest + dW1
+                f4 aG1[MT];
 #pragma unroll
-                for (int nt = 0; nt < NT1; ++nt) {
-                    float bx[4];
+                for (int mt = 0; mt < MT / 2; ++mt)
 #pragma unroll
-                    for (int ks = 0; ks < 4; ++ks) {
-                        const int row = b0 + 4 * g + ks, d = 16 * nt + j;
-                        bx[ks] = (row < B && d < D) ? obs_p[((size_t)t * B + row) * D + d] : 0.f;
-                    }
+                    for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) {
-                        const f4 aop = tile_read(TG, mt, g, j);
+                        for (int nt = 0; nt < MT; ++nt) dW2[mt][nt] = MARL_MFMA(aG2[mt][ks], bH1[nt][ks], dW2[mt][nt]);
 #pragma unroll
-                        for (int ks = 0; ks < 4; ++ks) dW1[mt][nt] = MARL_MFMA(aop[ks], bx[ks], dW1[mt][nt]);
-                    }
-                }
+                for (int mt = 0; mt < MT; ++mt) aG1[mt] = tile_read(TG1, mt, g, j);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int mt = MT / 2; mt < MT; ++mt)
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                        for (int nt = 0; nt < MT; ++nt) dW2[mt][nt] = MARL_MFMA(aG2[mt][ks], bH1[nt][ks], dW2[mt][nt]);
+                // dW1[h1][d] += dH1^T X   (B operand prefetched from global one step ahead)
+#pragma unroll
+                for (int nt = 0; nt < NT1; ++nt)
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) dW1[mt][nt] = MARL_MFMA(aG1[mt][ks], cur.bx[nt][ks], dW1[mt][nt]);
+                __builtin_amdgcn_sched_barrier(0);
             }
+            MARL_PHASE(6)
             if (t > t0) {
                 // ---- bootstrap value for transition t-1 (model.py:132-145)
-                f4 u1[MT], u2[MT], tq;
-                mlp_forward<S>(tpk, lane, x, u1, u2, tq);
                 const int a_p = double_q ? argmax_rows<A>(q, lane) : argmax_rows<A>(tq, lane);
                 tq_next = gather_rows(tq, lane, a_p);
             }
+            cur = nxt;
+            MARL_PHASE(7)
         }
     }
 
-    // ---- fold the 4 waves through LDS (fixed order), write one partial record per workgroup
+    const unsigned long long t_loop_end = prof ? __builtin_readcyclecounter() : 0;
+#undef MARL_PHASE
+    // ---- fold the waves through LDS and write ONE partial record per workgroup.  Every wave stores its
+    // accumulators into its own LDS region in parallel (weights at their canonical index, bias / loss
+    // partials as [value][16 lanes] strips), one barrier, then all threads sum the regions in a fixed
+    // order - no cross-lane shuffles, no serialisation between waves, bitwise reproducible.
     __syncthreads();
-    float* fold = lds;  // overlays the (now unused) critic/target packs
-    const float lsum = sum16(loss_acc), nsum = sum16(nfill_acc);  // values sit in lanes g==0
-#pragma unroll 1
-    for (int w = 0; w < 4; ++w) {
-        if (wave == w) {
-            const bool first = (w == 0);
+    {
+        float* mine = lds + (size_t)wave * L::FOLD;
+        float* strips = mine + S::NPARAM;  // [(2H + 16) bias rows + 2 loss rows][16]
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int o = 16 * mt + 4 * g + r;
-#pragma unroll
-                    for (int nt = 0; nt < NT1; ++nt) {
-                        const int d = 16 * nt + j;
-                        if (d < D) {
-                            float* dst = fold + S::oW1 + o * D + d;
-                            *dst = first ? dW1[mt][nt][r] : *dst + dW1[mt][nt][r];
-                        }
-                    }
-#pragma unroll
-                    for (int nt = 0; nt < MT; ++nt) {
-                        float* dst = fold + S::oW2 + o * H + 16 * nt + j;
-                        *dst = first ? dW2[mt][nt][r] : *dst + dW2[mt][nt][r];
-                    }
-                    const float s1 = sum16(db1[mt][r]), s2 = sum16(db2[mt][r]);
-                    if (j == 0) {
-                        fold[S::ob1 + o] = first ? s1 : fold[S::ob1 + o] + s1;
-                        fold[S::ob2 + o] = first ? s2 : fold[S::ob2 + o] + s2;
-                    }
-                }
-            }
+        for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int a = 4 * g + r;
+                const int o = 16 * mt + 4 * g + r;
 #pragma unroll
-                for (int nt = 0; nt < MT; ++nt) {
-                    if (a < A) {
-                        float* dst = fold + S::oW3 + a * H + 16 * nt + j;
-                        *dst = first ? dW3[nt][r] : *dst + dW3[nt][r];
-                    }
+                for (int nt = 0; nt < NT1; ++nt) {
+                    const int d = 16 * nt + j;
+                    if (d < D) mine[S::oW1 + o * D + d] = dW1[mt][nt][r];
                 }
-                const float s3 = sum16(db3[r]);
-                if (j == 0 && a < A) fold[S::ob3 + a] = first ? s3 : fold[S::ob3 + a] + s3;
-            }
-            if (lane == 0) {
-                fold[S::NPARAM] = first ? lsum : fold[S::NPARAM] + lsum;
-                fold[S::NPARAM + 1] = first ? nsum : fold[S::NPARAM + 1] + nsum;
+#pragma unroll
+                for (int nt = 0; nt < MT; ++nt) mine[S::oW2 + o * H + 16 * nt + j] = dW2[mt][nt][r];
+                strips[o * 16 + j] = db1[mt][r];
+                strips[(H + o) * 16 + j] = db2[mt][r];
             }
         }
-        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int a = 4 * g + r;
+#pragma unroll
+            for (int nt = 0; nt < MT; ++nt)
+                if (a < A) mine[S::oW3 + a * H + 16 * nt + j] = dW3[nt][r];
+            strips[(2 * H + a) * 16 + j] = db3[r];
+        }
+        if (g == 0) {
+            strips[(2 * H + 16) * 16 + j] = loss_acc;
+            strips[(2 * H + 17) * 16 + j] = nfill_acc;
+        }
     }
+    __syncthreads();
     float* rec = partials + ((size_t)p * gridDim.x + blockIdx.x) * L::REC;
-    for (int i = tid; i < L::REC; i += UPD_BLOCK) rec[i] = fold[i];
+    for (int i = tid; i < L::REC; i += UPD_BLOCK) {
+        // which strip (if any) holds element i
+        int strip = -1;
+        if (i >= S::ob1 && i < S::ob1 + H) strip = i - S::ob1;
+        else if (i >= S::ob2 && i < S::ob2 + H) strip = H + i - S::ob2;
+        else if (i >= S::ob3 && i < S::ob3 + A) strip = 2 * H + i - S::ob3;
+        else if (i >= S::NPARAM) strip = 2 * H + 16 + (i - S::NPARAM);
+        float acc = 0.f;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) {
+            const float* reg = lds + (size_t)w * L::FOLD;
+            if (strip < 0) {
+                acc += reg[i];
+            } else {
+                const float* sp = reg + S::NPARAM + strip * 16;
+                float t = 0.f;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) t += sp[k];
+                acc += t;
+            }
+        }
+        rec[i] = acc;
+    }
+    if (prof != nullptr && lane == 0) {
+        const unsigned long long t_end = __builtin_readcyclecounter();
+        pc[8] = t_loop_begin - t_begin;   // pack staging
+        pc[9] = t_loop_end - t_loop_begin;  // whole task loop
+        pc[10] = t_end - t_loop_end;      // fold + record write
+        pc[11] = t_end - t_begin;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) atomicAdd(&prof[k], pc[k]);
+    }
 }
 
 // grad[p][i] = (sum over the agent's records) / n_filled ; loss = sum of all loss fields / n_filled.
@@ -407,14 +506,25 @@ struct UpdPlan {
     int nwg, n_chunks;
 };
 
+inline int upd_waves() {  // waves per workgroup (MARLHIP_UPD_WAVES=4|8; default from measurement)
+    static int w = 0;
+    if (w == 0) {
+        const char* e = getenv("MARLHIP_UPD_WAVES");
+        w = 4;  // 8 waves x 5 tiles no longer fit the 160 KiB LDS next to the packs
+        (void)e;
+    }
+    return w;
+}
+
 inline UpdPlan upd_plan(int P, int T, int B) {
     const int ngroups = (B + 15) / 16;
-    const int want_waves = 1024 / (P > 0 ? P : 1) > 4 ? 1024 / P : 4;  // ~1 wave per SIMD over the chip
+    const int W = upd_waves();
+    const int want_waves = 256 * W / (P > 0 ? P : 1) > W ? 256 * W / P : W;  // fill every CU with one workgroup
     int nc = (want_waves + ngroups - 1) / ngroups;
     if (nc < 1) nc = 1;
     if (nc > T) nc = T;
     const int tasks = ngroups * nc;
-    int nwg = (tasks + 3) / 4;
+    int nwg = (tasks + W - 1) / W;
     const int cap = 256 / P > 1 ? 256 / P : 1;
     if (nwg > cap) nwg = cap;
     UpdPlan pl = {nwg, nc};
@@ -430,20 +540,22 @@ int launch_lossgrad(const marlhip_net_shape* s, const float* params, const float
     static_assert(PACK % 4 == 0 && L::oT == S::NFWD && L::oB == 2 * S::NFWD, "pack layout == LDS layout");
     const int64_t rec_bytes = (int64_t)s->n_agents * pl.nwg * L::REC * sizeof(float);
     const int64_t need = rec_bytes + (int64_t)s->n_agents * PACK * sizeof(float);
-    MARL_REQUIRE(ws_bytes >= need, "dqn_loss_grad: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)need);
+    MARL_REQUIRE(ws_bytes >= need + 16 + 128, "dqn_loss_grad: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)need);
     float* packs = reinterpret_cast<float*>(static_cast<char*>(ws) + ((rec_bytes + 15) & ~(int64_t)15));
-    const size_t lds_bytes = (size_t)L::TOTAL * sizeof(float);
+    const int W = upd_waves();
+    const size_t lds_bytes = (size_t)L::total(W) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dqn_lossgrad_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds_bytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dqn_lossgrad_kernel<S, 4>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)(L::total(4) * sizeof(float)));
         attr_set = true;
     }
     hipLaunchKernelGGL((dqn_pack_kernel<S>), dim3((PACK + 255) / 256, s->n_agents), dim3(256), 0, st, params, tparams, packs);
     MARL_CHECK_LAUNCH("dqn_pack_kernel");
     timing_begin(TIMER_LOSSGRAD, st);
-    hipLaunchKernelGGL((dqn_lossgrad_kernel<S>), dim3(pl.nwg, s->n_agents), dim3(UPD_BLOCK), lds_bytes, st, (const float*)packs, *bt,
-                       gamma, double_q, pl.n_chunks, (float*)ws);
+    hipLaunchKernelGGL((dqn_lossgrad_kernel<S, 4>), dim3(pl.nwg, s->n_agents), dim3(256), lds_bytes, st, (const float*)packs, *bt,
+                           gamma, double_q, pl.n_chunks, (float*)ws,
+                           getenv("MARLHIP_PROF") ? reinterpret_cast<unsigned long long*>(static_cast<char*>(ws) + ws_bytes - 128) : nullptr);
     timing_end(TIMER_LOSSGRAD, st);
     MARL_CHECK_LAUNCH("dqn_lossgrad_kernel");
     const int n = s->n_agents * S::NPARAM;
@@ -478,7 +590,8 @@ extern "C" int64_t marlhip_dqn_workspace_bytes(const marlhip_net_shape* s, int32
 #define X(d, h, a) if (s->obs_dim == d && s->hidden == h && s->n_actions == a) pack = 2 * MlpShape<d, h, a>::NFWD + MlpShape<d, h, a>::NBWD;
     MARL_NET_SHAPES(X)
 #undef X
-    return (int64_t)s->n_agents * pl.nwg * (np + 2) * sizeof(float) + 16 + (int64_t)s->n_agents * pack * sizeof(float);
+    // (+ 16 B alignment slack, + 128 B tail used as 12 phase counters when MARLHIP_PROF is set, 8-byte aligned)
+    return (((int64_t)s->n_agents * pl.nwg * (np + 2) * sizeof(float) + 16 + (int64_t)s->n_agents * pack * sizeof(float) + 7) & ~(int64_t)7) + 128;
 }
 
 extern "C" int marlhip_dqn_loss_grad(const marlhip_net_shape* s, const float* params, const float* target_params,

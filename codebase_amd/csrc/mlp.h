@@ -168,6 +168,197 @@ __device__ __forceinline__ void mlp_forward(const float* lds, int lane, const fl
     q = o;
 }
 
+// Two networks (critic pack A, target pack B) on the SAME 16-row block, interleaved layer by
+// layer: 2 x MT independent accumulator chains per layer keep the matrix pipe fed across the
+// dependent-latency gaps and halve the number of layer-boundary drains per row block.  Each
+// network's own summation order is exactly mlp_forward's (bitwise identical results).
+template <class S>
+__device__ __forceinline__ void mlp_forward2(const float* ldsA, const float* ldsB, int lane, const float (&x)[S::KS1],
+                                             f4 (&h1)[S::MT], f4 (&h2)[S::MT], f4& qA, f4& qB) {
+    const int g = lane >> 4;
+    const f4* A1 = reinterpret_cast<const f4*>(ldsA + S::pA1);
+    const f4* A2 = reinterpret_cast<const f4*>(ldsA + S::pA2);
+    const f4* A3 = reinterpret_cast<const f4*>(ldsA + S::pA3);
+    const f4* B1 = reinterpret_cast<const f4*>(ldsB + S::pA1);
+    const f4* B2 = reinterpret_cast<const f4*>(ldsB + S::pA2);
+    const f4* B3 = reinterpret_cast<const f4*>(ldsB + S::pA3);
+    f4 accA[S::MT], accB[S::MT], g1[S::MT], g2[S::MT];
+#pragma unroll
+    for (int mt = 0; mt < S::MT; ++mt) {
+        accA[mt] = *reinterpret_cast<const f4*>(ldsA + S::pb1 + 16 * mt + 4 * g);
+        accB[mt] = *reinterpret_cast<const f4*>(ldsB + S::pb1 + 16 * mt + 4 * g);
+    }
+#pragma unroll
+    for (int ks4 = 0; ks4 < S::KS1 / 4; ++ks4) {
+        f4 a[S::MT], b[S::MT];
+#pragma unroll
+        for (int mt = 0; mt < S::MT; ++mt) {
+            a[mt] = A1[(mt * (S::KS1 / 4) + ks4) * 64 + lane];
+            b[mt] = B1[(mt * (S::KS1 / 4) + ks4) * 64 + lane];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int mt = 0; mt < S::MT; ++mt) {
+                accA[mt] = MARL_MFMA(a[mt][e], x[4 * ks4 + e], accA[mt]);
+                accB[mt] = MARL_MFMA(b[mt][e], x[4 * ks4 + e], accB[mt]);
+            }
+    }
+#pragma unroll
+    for (int mt = 0; mt < S::MT; ++mt) {
+        h1[mt] = relu4(accA[mt]);
+        g1[mt] = relu4(accB[mt]);
+        accA[mt] = *reinterpret_cast<const f4*>(ldsA + S::pb2 + 16 * mt + 4 * g);
+        accB[mt] = *reinterpret_cast<const f4*>(ldsB + S::pb2 + 16 * mt + 4 * g);
+    }
+#pragma unroll
+    for (int k1 = 0; k1 < S::MT; ++k1) {
+        f4 a[S::MT], b[S::MT];
+#pragma unroll
+        for (int mt = 0; mt < S::MT; ++mt) {
+            a[mt] = A2[(mt * S::MT + k1) * 64 + lane];
+            b[mt] = B2[(mt * S::MT + k1) * 64 + lane];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int mt = 0; mt < S::MT; ++mt) {
+                accA[mt] = MARL_MFMA(a[mt][r], h1[k1][r], accA[mt]);
+                accB[mt] = MARL_MFMA(b[mt][r], g1[k1][r], accB[mt]);
+            }
+    }
+#pragma unroll
+    for (int mt = 0; mt < S::MT; ++mt) {
+        h2[mt] = relu4(accA[mt]);
+        g2[mt] = relu4(accB[mt]);
+    }
+    f4 oA = *reinterpret_cast<const f4*>(ldsA + S::pb3 + 4 * g);
+    f4 oB = *reinterpret_cast<const f4*>(ldsB + S::pb3 + 4 * g);
+#pragma unroll
+    for (int k1 = 0; k1 < S::MT; ++k1) {
+        const f4 a = A3[k1 * 64 + lane];
+        const f4 b = B3[k1 * 64 + lane];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            oA = MARL_MFMA(a[r], h2[k1][r], oA);
+            oB = MARL_MFMA(b[r], g2[k1][r], oB);
+        }
+    }
+    qA = oA;
+    qB = oB;
+}
+
+// Software-pipelined forward (one network, or critic+target on the same rows when DUAL): the
+// A-operand fetch (ds_read_b128) of step s+1 is issued BEFORE the MFMAs of step s and pinned there
+// with sched_barrier, so with one wave per SIMD the LDS latency hides under >= 16 MFMAs instead of
+// stalling the matrix pipe in front of every group (hipcc places the reads right before their use).
+// Steps: layer 1 (KS1/4 steps), layer 2 (MT steps), layer 3 (1 step).  Per-output summation order
+// is unchanged (bitwise identical to mlp_forward).
+template <class S, bool DUAL>
+__device__ __forceinline__ void mlp_forward_p(const float* ldsA, const float* ldsB, int lane, const float (&x)[S::KS1],
+                                              f4 (&h1)[S::MT], f4 (&h2)[S::MT], f4& qA, f4& qB) {
+    constexpr int MT = S::MT, N1 = S::KS1 / 4;
+    const int g = lane >> 4;
+    const f4* A1 = reinterpret_cast<const f4*>(ldsA + S::pA1);
+    const f4* A2 = reinterpret_cast<const f4*>(ldsA + S::pA2);
+    const f4* A3 = reinterpret_cast<const f4*>(ldsA + S::pA3);
+    const f4* B1 = reinterpret_cast<const f4*>(ldsB + S::pA1);
+    const f4* B2 = reinterpret_cast<const f4*>(ldsB + S::pA2);
+    const f4* B3 = reinterpret_cast<const f4*>(ldsB + S::pA3);
+    f4 opa[2][MT], opb[2][MT], accA[MT], accB[MT], nbA[MT], nbB[MT], g1[MT], g2[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        opa[0][mt] = A1[(mt * N1 + 0) * 64 + lane];
+        accA[mt] = *reinterpret_cast<const f4*>(ldsA + S::pb1 + 16 * mt + 4 * g);
+        if (DUAL) {
+            opb[0][mt] = B1[(mt * N1 + 0) * 64 + lane];
+            accB[mt] = *reinterpret_cast<const f4*>(ldsB + S::pb1 + 16 * mt + 4 * g);
+        }
+    }
+    // ---- layer 1
+#pragma unroll
+    for (int s = 0; s < N1; ++s) {
+        const int cur = s & 1, nxt = cur ^ 1;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            if (s + 1 < N1) {
+                opa[nxt][mt] = A1[(mt * N1 + s + 1) * 64 + lane];
+                if (DUAL) opb[nxt][mt] = B1[(mt * N1 + s + 1) * 64 + lane];
+            } else {  // first layer-2 step + its bias
+                opa[nxt][mt] = A2[(mt * MT + 0) * 64 + lane];
+                nbA[mt] = *reinterpret_cast<const f4*>(ldsA + S::pb2 + 16 * mt + 4 * g);
+                if (DUAL) {
+                    opb[nxt][mt] = B2[(mt * MT + 0) * 64 + lane];
+                    nbB[mt] = *reinterpret_cast<const f4*>(ldsB + S::pb2 + 16 * mt + 4 * g);
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                accA[mt] = MARL_MFMA(opa[cur][mt][e], x[4 * s + e], accA[mt]);
+                if (DUAL) accB[mt] = MARL_MFMA(opb[cur][mt][e], x[4 * s + e], accB[mt]);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        h1[mt] = relu4(accA[mt]);
+        accA[mt] = nbA[mt];
+        if (DUAL) {
+            g1[mt] = relu4(accB[mt]);
+            accB[mt] = nbB[mt];
+        }
+    }
+    // ---- layer 2
+    f4 o3A, o3B;
+#pragma unroll
+    for (int k1 = 0; k1 < MT; ++k1) {
+        const int cur = (N1 + k1) & 1, nxt = cur ^ 1;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            if (k1 + 1 < MT) {
+                opa[nxt][mt] = A2[(mt * MT + k1 + 1) * 64 + lane];
+                if (DUAL) opb[nxt][mt] = B2[(mt * MT + k1 + 1) * 64 + lane];
+            } else {  // layer-3 operands (MT tiles of K) + bias
+                opa[nxt][mt] = A3[mt * 64 + lane];
+                if (DUAL) opb[nxt][mt] = B3[mt * 64 + lane];
+            }
+        }
+        if (k1 + 1 == MT) {
+            o3A = *reinterpret_cast<const f4*>(ldsA + S::pb3 + 4 * g);
+            if (DUAL) o3B = *reinterpret_cast<const f4*>(ldsB + S::pb3 + 4 * g);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                accA[mt] = MARL_MFMA(opa[cur][mt][r], h1[k1][r], accA[mt]);
+                if (DUAL) accB[mt] = MARL_MFMA(opb[cur][mt][r], g1[k1][r], accB[mt]);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        h2[mt] = relu4(accA[mt]);
+        if (DUAL) g2[mt] = relu4(accB[mt]);
+    }
+    // ---- layer 3 (one chain per network, K order as mlp_forward)
+    constexpr int c3 = (N1 + MT) & 1;
+#pragma unroll
+    for (int k1 = 0; k1 < MT; ++k1)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            o3A = MARL_MFMA(opa[c3][k1][r], h2[k1][r], o3A);
+            if (DUAL) o3B = MARL_MFMA(opb[c3][k1][r], g2[k1][r], o3B);
+        }
+    qA = o3A;
+    if (DUAL) qB = o3B;
+}
+
 // greedy action of batch row j from q in C layout (lane (g,j) holds Q[4g+r]):
 // first index of the maximum (torch.argmax tie rule), identical in all 4 lanes of j.
 template <int A>

@@ -78,7 +78,8 @@ def test_qnetwork_interface_state_dict_and_act():
     torch.set_num_threads(nt)
     sd = m.state_dict()
     assert list(sd.keys()) == list(g["keys_H64"])  # the reference's checkpoint key names, same order
-    np.testing.assert_array_equal(m.params.cpu().numpy(), g["critic_H64_orth1"])
+    # LAPACK's QR rounding differs between host CPUs: bit-exact on the golden's machine (tests/test_host_cpu.py)
+    np.testing.assert_allclose(m.params.cpu().numpy(), g["critic_H64_orth1"], rtol=0, atol=2e-5)
     # act(): greedy branch == torch argmax of a reference-shaped net loaded from the state_dict
     nets = [reference_style_net(sd, i, 15, 64, 6) for i in range(2)]
     rng = np.random.default_rng(0)
@@ -138,10 +139,11 @@ def test_run_entry_point_scalar_and_vectorised(tmp_path, monkeypatch):
     assert df.shape[0] >= 1 and {"updates", "mean_episode_returns", "loss"} <= set(df.columns)
     assert np.isfinite(df["loss"]).all() and any(f.startswith("model_s") for f in os.listdir(tmp_path / "scalar" / "checkpoints"))
     monkeypatch.setenv("MARLHIP_RUN_DIR", str(tmp_path / "vec"))
-    df = run.main(["+algorithm=idqn", f"env.name={NAME}", "env.time_limit=25", "env.parallel_envs=1024",
-                   "algorithm.model.layers=[64,64]", "seed=1", "algorithm.total_steps=400000", "algorithm.eval_interval=100000",
-                   "algorithm.eval_episodes=512", "algorithm.updates_per_round=8"])
-    assert df.shape[0] >= 3 and np.isfinite(df["loss"]).all()
+    # 128 envs, 128 updates of 128 episodes per round (1 update per 25 env-steps, as the reference)
+    df = run.main(["+algorithm=idqn", f"env.name={NAME}", "env.time_limit=25", "env.parallel_envs=128",
+                   "algorithm.model.layers=[64,64]", "seed=1", "algorithm.total_steps=1500000", "algorithm.eval_interval=150000",
+                   "algorithm.eval_episodes=512", "algorithm.updates_per_round=128"])
+    assert df.shape[0] >= 8 and np.isfinite(df["loss"]).all()
     r = df["mean_episode_returns"].to_numpy()
-    print("vectorised IDQN mean eval returns:", r)
-    assert r[-1] > r[0]  # it learns: returns go up over 400k steps
+    print("vectorised IDQN mean eval returns:", r, "updates:", df["updates"].to_numpy())
+    assert r[-3:].mean() > r[:2].mean() + 0.02  # it learns: evaluation returns go up
