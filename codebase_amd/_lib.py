@@ -43,6 +43,17 @@ class BatchStruct(ctypes.Structure):
                 ("filled", c_void_p), ("max_len", c_int32), ("batch", c_int32)]
 
 
+class IdqnLearner(ctypes.Structure):
+    _fields_ = [("net", NetShape), ("rs", ReplayShape), ("rb", ReplayBuffers),
+                ("params", c_void_p), ("target", c_void_p), ("exp_avg", c_void_p), ("exp_avg_sq", c_void_p),
+                ("grad", c_void_p), ("loss", c_void_p), ("scratch", c_void_p), ("gnorm", c_void_p),
+                ("workspace", c_void_p), ("workspace_bytes", c_int64),
+                ("obss", c_void_p), ("actions", c_void_p), ("rewards", c_void_p), ("dones", c_void_p), ("filled", c_void_p),
+                ("idx", c_void_p), ("batch", c_int32), ("double_q", c_int32), ("mode", c_int32), ("materialise_batch", c_int32),
+                ("gamma", c_float), ("max_norm", c_float), ("lr", c_double), ("beta1", c_double), ("beta2", c_double),
+                ("eps", c_double), ("target_update_interval_or_tau", c_double)]
+
+
 # every symbol include/marlhip.h declares: name -> (restype, argtypes)
 PROTOTYPES = {
     "marlhip_version": (c_int32, []),
@@ -66,9 +77,14 @@ PROTOTYPES = {
     "marlhip_dqn_workspace_bytes": (c_int64, [POINTER(NetShape), c_int32, c_int32]),
     "marlhip_dqn_loss_grad": (c_int32, [POINTER(NetShape), c_void_p, c_void_p, POINTER(BatchStruct), c_float, c_int32,
                                         c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "marlhip_dqn_loss_grad_replay": (c_int32, [POINTER(NetShape), c_void_p, c_void_p, POINTER(ReplayShape),
+                                               POINTER(ReplayBuffers), c_void_p, c_int32, c_int32, c_uint64, c_uint32, c_void_p,
+                                               c_float, c_int32, c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "marlhip_dqn_clip_adam": (c_int32, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_double,
                                         c_double, c_double, c_double, c_float, c_float, c_int32, c_float, c_void_p,
                                         c_void_p, c_void_p]),
+    "marlhip_idqn_update_n": (c_int32, [POINTER(IdqnLearner), c_int32, c_int32, c_uint64, c_uint32, POINTER(c_int64),
+                                        POINTER(c_int64), POINTER(c_int64), c_void_p]),
     "marlhip_timing_enable": (c_int32, [c_int32]),
     "marlhip_timing_read": (c_int32, [c_int32, POINTER(c_int64), POINTER(c_double)]),
     "marlhip_idqn_collect": (c_int32, [POINTER(LbfConfig), POINTER(NetShape), c_void_p, c_float, c_uint32,

@@ -78,8 +78,28 @@ __global__ __launch_bounds__(256) void dqn_pack_kernel(const float* __restrict__
     packs[(size_t)p * TOT + idx] = v;
 }
 
-template <class S, int WAVES>
-__global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dqn_lossgrad_kernel(const float* __restrict__ packs, marlhip_batch bt,
+// where the rows come from: a materialised Batch in the reference layout (marlhip_dqn_loss_grad), or the
+// episode-major replay itself, gathered in-kernel through sampled episode indices
+// (marlhip_dqn_loss_grad_replay: no sample kernel, no Batch round trip through HBM)
+struct ReplaySrc {
+    marlhip_replay_buffers rb;
+    const int32_t* idx;  // [B] or nullptr: Philox(seed; stream 2, counter) draw in [0, length)
+    int32_t* idx_out;    // optional record of the indices used
+    uint64_t seed;
+    uint32_t counter;
+    int length;
+};
+
+__device__ __forceinline__ int replay_draw(const ReplaySrc& r, int b) {
+    U4 c;
+    c.x = (uint32_t)(b >> 2); c.y = r.counter; c.z = 0; c.w = STREAM_SAMPLE;
+    const U4 o = philox4x32_10(c, (uint32_t)r.seed, (uint32_t)(r.seed >> 32));
+    const int s = b & 3;
+    return (int)bounded_nr(s == 0 ? o.x : (s == 1 ? o.y : (s == 2 ? o.z : o.w)), (uint32_t)r.length);
+}
+
+template <class S, int WAVES, bool REPLAY>
+__global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dqn_lossgrad_kernel(const float* __restrict__ packs, marlhip_batch bt, ReplaySrc rs,
                                                                  float gamma, int double_q, int n_chunks,
                                                                  float* __restrict__ partials, unsigned long long* prof) {
     using L = UpdLds<S>;
@@ -108,9 +128,10 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dqn_lossgrad_kernel(con
     float* TG1 = TG2 + L::TILE;
     float* TQ = TG1 + L::TILE;
 
-    const float* obs_p = bt.obss + (size_t)p * (T + 1) * B * D;
-    const int64_t* act_p = bt.actions + (size_t)p * T * B;
-    const float* rew_p = bt.rewards + (size_t)p * T * B;
+    const int P = gridDim.y;
+    const float* obs_p = REPLAY ? nullptr : bt.obss + (size_t)p * (T + 1) * B * D;
+    const int64_t* act_p = REPLAY ? nullptr : bt.actions + (size_t)p * T * B;
+    const float* rew_p = REPLAY ? nullptr : bt.rewards + (size_t)p * T * B;
 
     const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
     f4 dW1[MT][NT1], dW2[MT][MT], dW3[MT], db1[MT], db2[MT], db3 = zero4;
@@ -143,6 +164,17 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dqn_lossgrad_kernel(con
         const int b0 = grp * 16;
         const bool rowok = (b0 + j) < B;
         const int bj = rowok ? b0 + j : B - 1;
+        // replay form: episode of batch row j (forward operand / scalars) and of rows 4g..4g+3 (dW1 operand)
+        int ej = 0, eg[4] = {0, 0, 0, 0};
+        if (REPLAY) {
+            ej = rs.idx ? rs.idx[bj] : replay_draw(rs, bj);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int row = b0 + 4 * g + ks, rc = row < B ? row : B - 1;
+                eg[ks] = rs.idx ? rs.idx[rc] : replay_draw(rs, rc);
+            }
+            if (rs.idx_out != nullptr && p == 0 && c == 0 && g == 0 && rowok) rs.idx_out[bj] = ej;
+        }
         float tq_next = 0.f;
         // rows of time step t in the two operand shapes the step needs + the transition's scalars;
         // issued one step ahead so the loads fly under the previous step's MFMAs
@@ -155,24 +187,44 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dqn_lossgrad_kernel(con
         // branch-free: every address is clamped in-bounds and loaded unconditionally (a guarded load is
         // an exec-masked branch + a conservative vmcnt(0) at the join); masks are applied at the point of use
         auto load_rows = [&](int t, Rows& R) {
-            const float* xrow = obs_p + ((size_t)t * B + bj) * D;
-#pragma unroll
-            for (int ks = 0; ks < S::KS1; ++ks) {
-                const int d = 4 * ks + g;
-                R.x[ks] = xrow[d < D ? d : D - 1];
-            }
             const int tt = t < T ? t : T - 1;
+            if (REPLAY) {
+                const float* xrow = rs.rb.obs + (((size_t)ej * P + p) * (T + 1) + t) * D;
 #pragma unroll
-            for (int nt = 0; nt < NT1; ++nt)
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    const int row = b0 + 4 * g + ks, d = 16 * nt + j;
-                    R.bx[nt][ks] = obs_p[((size_t)t * B + (row < B ? row : B - 1)) * D + (d < D ? d : D - 1)];
+                for (int ks = 0; ks < S::KS1; ++ks) {
+                    const int d = 4 * ks + g;
+                    R.x[ks] = xrow[d < D ? d : D - 1];
                 }
-            R.a_sel = (int)act_p[(size_t)tt * B + bj];
-            R.rw = rew_p[(size_t)tt * B + bj];
-            R.dn = bt.dones[(size_t)(tt + 1) * B + bj];
-            R.fl = bt.filled[(size_t)tt * B + bj];
+#pragma unroll
+                for (int nt = 0; nt < NT1; ++nt)
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        const int d = 16 * nt + j;
+                        R.bx[nt][ks] = rs.rb.obs[(((size_t)eg[ks] * P + p) * (T + 1) + t) * D + (d < D ? d : D - 1)];
+                    }
+                R.a_sel = (int)rs.rb.act[((size_t)ej * P + p) * T + tt];
+                R.rw = rs.rb.rew[((size_t)ej * P + p) * T + tt];
+                R.dn = rs.rb.done[(size_t)ej * (T + 1) + tt + 1] ? 1.f : 0.f;
+                R.fl = rs.rb.filled[(size_t)ej * T + tt] ? 1.f : 0.f;
+            } else {
+                const float* xrow = obs_p + ((size_t)t * B + bj) * D;
+#pragma unroll
+                for (int ks = 0; ks < S::KS1; ++ks) {
+                    const int d = 4 * ks + g;
+                    R.x[ks] = xrow[d < D ? d : D - 1];
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT1; ++nt)
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        const int row = b0 + 4 * g + ks, d = 16 * nt + j;
+                        R.bx[nt][ks] = obs_p[((size_t)t * B + (row < B ? row : B - 1)) * D + (d < D ? d : D - 1)];
+                    }
+                R.a_sel = (int)act_p[(size_t)tt * B + bj];
+                R.rw = rew_p[(size_t)tt * B + bj];
+                R.dn = bt.dones[(size_t)(tt + 1) * B + bj];
+                R.fl = bt.filled[(size_t)tt * B + bj];
+            }
         };
         auto mask_rows = [&](Rows& R) {  // zero the padding (obs dims >= D, rows >= B)
 #pragma unroll
@@ -532,8 +584,9 @@ inline UpdPlan upd_plan(int P, int T, int B) {
 }
 
 template <class S>
-int launch_lossgrad(const marlhip_net_shape* s, const float* params, const float* tparams, const marlhip_batch* bt, float gamma,
-                    int double_q, void* ws, int64_t ws_bytes, float* grad, float* loss, hipStream_t st) {
+int launch_lossgrad(const marlhip_net_shape* s, const float* params, const float* tparams, const marlhip_batch* bt,
+                    const ReplaySrc* rsrc, float gamma, int double_q, void* ws, int64_t ws_bytes, float* grad, float* loss,
+                    hipStream_t st) {
     using L = UpdLds<S>;
     const UpdPlan pl = upd_plan(s->n_agents, bt->max_len, bt->batch);
     constexpr int PACK = 2 * S::NFWD + S::NBWD;
@@ -542,20 +595,27 @@ int launch_lossgrad(const marlhip_net_shape* s, const float* params, const float
     const int64_t need = rec_bytes + (int64_t)s->n_agents * PACK * sizeof(float);
     MARL_REQUIRE(ws_bytes >= need + 16 + 128, "dqn_loss_grad: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)need);
     float* packs = reinterpret_cast<float*>(static_cast<char*>(ws) + ((rec_bytes + 15) & ~(int64_t)15));
-    const int W = upd_waves();
-    const size_t lds_bytes = (size_t)L::total(W) * sizeof(float);
+    const size_t lds_bytes = (size_t)L::total(4) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dqn_lossgrad_kernel<S, 4>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)(L::total(4) * sizeof(float)));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dqn_lossgrad_kernel<S, 4, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dqn_lossgrad_kernel<S, 4, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         attr_set = true;
     }
     hipLaunchKernelGGL((dqn_pack_kernel<S>), dim3((PACK + 255) / 256, s->n_agents), dim3(256), 0, st, params, tparams, packs);
     MARL_CHECK_LAUNCH("dqn_pack_kernel");
+    unsigned long long* prof =
+        getenv("MARLHIP_PROF") ? reinterpret_cast<unsigned long long*>(static_cast<char*>(ws) + ws_bytes - 128) : nullptr;
+    ReplaySrc none = {};
     timing_begin(TIMER_LOSSGRAD, st);
-    hipLaunchKernelGGL((dqn_lossgrad_kernel<S, 4>), dim3(pl.nwg, s->n_agents), dim3(256), lds_bytes, st, (const float*)packs, *bt,
-                           gamma, double_q, pl.n_chunks, (float*)ws,
-                           getenv("MARLHIP_PROF") ? reinterpret_cast<unsigned long long*>(static_cast<char*>(ws) + ws_bytes - 128) : nullptr);
+    if (rsrc != nullptr)
+        hipLaunchKernelGGL((dqn_lossgrad_kernel<S, 4, true>), dim3(pl.nwg, s->n_agents), dim3(256), lds_bytes, st,
+                           (const float*)packs, *bt, *rsrc, gamma, double_q, pl.n_chunks, (float*)ws, prof);
+    else
+        hipLaunchKernelGGL((dqn_lossgrad_kernel<S, 4, false>), dim3(pl.nwg, s->n_agents), dim3(256), lds_bytes, st,
+                           (const float*)packs, *bt, none, gamma, double_q, pl.n_chunks, (float*)ws, prof);
     timing_end(TIMER_LOSSGRAD, st);
     MARL_CHECK_LAUNCH("dqn_lossgrad_kernel");
     const int n = s->n_agents * S::NPARAM;
@@ -594,21 +654,46 @@ extern "C" int64_t marlhip_dqn_workspace_bytes(const marlhip_net_shape* s, int32
     return (((int64_t)s->n_agents * pl.nwg * (np + 2) * sizeof(float) + 16 + (int64_t)s->n_agents * pack * sizeof(float) + 7) & ~(int64_t)7) + 128;
 }
 
+static int lossgrad_dispatch(const marlhip_net_shape* s, const float* params, const float* target_params, const marlhip_batch* bt,
+                             const ReplaySrc* rsrc, float gamma, int32_t double_q, int32_t mode, void* workspace,
+                             int64_t workspace_bytes, float* grad, float* loss, void* stream) {
+    MARL_REQUIRE(mode == 0, "dqn_loss_grad: mode %d (VDN) not built yet", mode);
+#define X(d, h, a)                                                                                                          \
+    if (s->obs_dim == d && s->hidden == h && s->n_actions == a)                                                             \
+        return launch_lossgrad<MlpShape<d, h, a>>(s, params, target_params, bt, rsrc, gamma, double_q, workspace,             \
+                                                  workspace_bytes, grad, loss, (hipStream_t)stream);
+    MARL_UPD_SHAPES(X)
+#undef X
+    set_error("no update kernel for net shape D=%d H=%d A=%d", s->obs_dim, s->hidden, s->n_actions);
+    return -1;
+}
+
 extern "C" int marlhip_dqn_loss_grad(const marlhip_net_shape* s, const float* params, const float* target_params,
                                      const marlhip_batch* batch, float gamma, int32_t double_q, int32_t mode, void* workspace,
                                      int64_t workspace_bytes, float* grad, float* loss, void* stream) {
     MARL_REQUIRE(s && params && target_params && batch && workspace && grad && loss, "dqn_loss_grad: NULL pointer");
     MARL_REQUIRE(batch->obss && batch->actions && batch->rewards && batch->dones && batch->filled, "dqn_loss_grad: NULL batch field");
     MARL_REQUIRE(batch->max_len > 0 && batch->batch > 0, "dqn_loss_grad: empty batch");
-    MARL_REQUIRE(mode == 0, "dqn_loss_grad: mode %d (VDN) not built yet", mode);
-#define X(d, h, a)                                                                                                         \
-    if (s->obs_dim == d && s->hidden == h && s->n_actions == a)                                                            \
-        return launch_lossgrad<MlpShape<d, h, a>>(s, params, target_params, batch, gamma, double_q, workspace, workspace_bytes, \
-                                                  grad, loss, (hipStream_t)stream);
-    MARL_UPD_SHAPES(X)
-#undef X
-    set_error("no update kernel for net shape D=%d H=%d A=%d", s->obs_dim, s->hidden, s->n_actions);
-    return -1;
+    return lossgrad_dispatch(s, params, target_params, batch, nullptr, gamma, double_q, mode, workspace, workspace_bytes, grad, loss,
+                             stream);
+}
+
+extern "C" int marlhip_dqn_loss_grad_replay(const marlhip_net_shape* s, const float* params, const float* target_params,
+                                            const marlhip_replay_shape* rs, const marlhip_replay_buffers* rb, const int32_t* idx,
+                                            int32_t batch, int32_t length, uint64_t seed, uint32_t counter, int32_t* idx_out,
+                                            float gamma, int32_t double_q, int32_t mode, void* workspace, int64_t workspace_bytes,
+                                            float* grad, float* loss, void* stream) {
+    MARL_REQUIRE(s && params && target_params && rs && rb && workspace && grad && loss, "dqn_loss_grad_replay: NULL pointer");
+    MARL_REQUIRE(rb->obs && rb->act && rb->rew && rb->done && rb->filled, "dqn_loss_grad_replay: NULL replay buffer");
+    MARL_REQUIRE(rs->n_agents == s->n_agents && rs->obs_dim == s->obs_dim, "dqn_loss_grad_replay: replay / net shape mismatch");
+    MARL_REQUIRE(batch > 0 && rs->max_len > 0, "dqn_loss_grad_replay: empty batch");
+    MARL_REQUIRE(idx != nullptr || (length > 0 && length <= rs->capacity), "dqn_loss_grad_replay: length %d out of range", length);
+    marlhip_batch bt = {};
+    bt.max_len = rs->max_len;
+    bt.batch = batch;
+    ReplaySrc src;
+    src.rb = *rb; src.idx = idx; src.idx_out = idx_out; src.seed = seed; src.counter = counter; src.length = length;
+    return lossgrad_dispatch(s, params, target_params, &bt, &src, gamma, double_q, mode, workspace, workspace_bytes, grad, loss, stream);
 }
 
 extern "C" int marlhip_dqn_clip_adam(int64_t n, float* params, const float* grad, float* exp_avg, float* exp_avg_sq,

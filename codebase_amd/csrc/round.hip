@@ -1,0 +1,44 @@
+// Host-side driver of the learner half of a round: n x (replay sample -> loss/grad -> clip+Adam+target)
+// enqueued from ONE C call.  Same kernels and arithmetic as the individual entry points; this only
+// removes the per-launch cost of crossing the Python/ctypes boundary three times per update (the
+// update is ~150 us of GPU work, so ~20 us of host time per call would otherwise starve the queue).
+// The update / target-update bookkeeping is QNetwork.update + update_target (marlbase/dqn/model.py:165-185).
+#include "common.h"
+
+extern "C" int marlhip_idqn_update_n(const marlhip_idqn_learner* L, int32_t n_updates, int32_t length, uint64_t seed,
+                                     uint32_t counter0, int64_t* adam_step, int64_t* updates, int64_t* last_target_update,
+                                     void* stream) {
+    MARL_REQUIRE(L && adam_step && updates && last_target_update, "idqn_update_n: NULL pointer");
+    MARL_REQUIRE(n_updates >= 0 && L->batch > 0, "idqn_update_n: bad counts");
+    const int np = marlhip_net_nparams(&L->net);
+    if (np < 0) return -1;
+    marlhip_batch bt;
+    bt.obss = L->obss; bt.actions = L->actions; bt.rewards = L->rewards; bt.dones = L->dones; bt.filled = L->filled;
+    bt.max_len = L->rs.max_len; bt.batch = L->batch;
+    const double tui = L->target_update_interval_or_tau;
+    for (int u = 0; u < n_updates; ++u) {
+        int rc;
+        if (L->materialise_batch) {
+            rc = marlhip_replay_sample(&L->rs, &L->rb, nullptr, L->batch, length, seed, counter0 + (uint32_t)u, L->idx, L->obss,
+                                       L->actions, L->rewards, L->dones, L->filled, stream);
+            if (rc < 0) return rc;
+            rc = marlhip_dqn_loss_grad(&L->net, L->params, L->target, &bt, L->gamma, L->double_q, L->mode, L->workspace,
+                                       L->workspace_bytes, L->grad, L->loss, stream);
+        } else {  // gather inside the loss/grad kernel: no sample launch, no Batch round trip
+            rc = marlhip_dqn_loss_grad_replay(&L->net, L->params, L->target, &L->rs, &L->rb, nullptr, L->batch, length, seed,
+                                              counter0 + (uint32_t)u, L->idx, L->gamma, L->double_q, L->mode, L->workspace,
+                                              L->workspace_bytes, L->grad, L->loss, stream);
+        }
+        if (rc < 0) return rc;
+        *updates += 1;
+        *adam_step += 1;
+        const bool hard = tui > 1.0 && (double)(*updates - *last_target_update) >= tui;
+        const float tau = tui < 1.0 ? (float)tui : 0.f;
+        rc = marlhip_dqn_clip_adam((int64_t)L->net.n_agents * np, L->params, L->grad, L->exp_avg, L->exp_avg_sq, L->target,
+                                   *adam_step, L->lr, L->beta1, L->beta2, L->eps, L->max_norm, 1.0f, hard ? 1 : 0, tau,
+                                   L->scratch, L->gnorm, stream);
+        if (rc < 0) return rc;
+        if (hard) *last_target_update = *updates;
+    }
+    return 0;
+}

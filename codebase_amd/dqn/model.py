@@ -137,9 +137,14 @@ class QNetwork:
         return _hip.Batch(f(batch.obss, torch.float32), f(batch.actions, torch.int64), f(batch.rewards, torch.float32),
                           f(batch.dones, torch.float32), f(batch.filled, torch.float32), None)
 
-    def update_async(self, batch, grad_sync=None, world=1):
-        """loss/grad -> [grad_sync(grad)] -> clip+Adam -> target update; returns the device loss tensor."""
-        loss, grad = self.updater.loss_grad(self._to_device_batch(batch), mode=self.mode)
+    def update_async(self, batch, grad_sync=None, world=1, replay=None, **sample_kw):
+        """loss/grad -> [grad_sync(grad)] -> clip+Adam -> target update; returns the device loss tensor.
+        `batch` is a Batch, or (with replay=DeviceReplay) a batch SIZE: the episodes are then gathered
+        inside the loss/grad kernel (sample_kw: length, seed, counter | idx)."""
+        if replay is not None:
+            loss, grad = self.updater.loss_grad_replay(replay, int(batch), mode=self.mode, **sample_kw)
+        else:
+            loss, grad = self.updater.loss_grad(self._to_device_batch(batch), mode=self.mode)
         if grad_sync is not None:
             grad_sync(grad)
         self.updates += 1

@@ -136,6 +136,7 @@ class VectorisedIDQN:
         self.rounds = 0
         self.sample_counter = 0
         self.last_loss = None
+        self._fused = None  # single-GPU: all U updates of a round from one library call
 
     def _grad_sync(self, grad):
         self.dist.all_reduce(grad)  # SUM over ranks (RCCL over xGMI); clip+Adam applies 1/world
@@ -149,13 +150,21 @@ class VectorisedIDQN:
                           use_proper_termination=self.proper)
         self.env_steps += self.fin_length.sum()
         self.rounds += 1
-        if train:
+        if train and self.dist is None and self.U > 0:
+            if self._fused is None:
+                self._fused = _hip.FusedLearner(m.updater, self.replay, self.B, m.target_update_interval_or_tau, mode=m.mode)
+            length = min(self.rounds * self.N, self.capacity)
+            m.updates, m.last_target_update = self._fused.run(self.U, length, self.seed, self.sample_counter, m.updates,
+                                                              m.last_target_update)
+            self.sample_counter += self.U
+            self.last_loss = m.updater.loss
+        elif train:
             length = min(self.rounds * self.N, self.capacity)
             sync = self._grad_sync if self.dist is not None else None
             for _ in range(self.U):
-                batch = self.replay.sample(self.B, length=length, seed=self.seed + 7919 * self.rank, counter=self.sample_counter)
+                self.last_loss = m.update_async(self.B, grad_sync=sync, world=self.world, replay=self.replay, length=length,
+                                                seed=self.seed + 7919 * self.rank, counter=self.sample_counter)
                 self.sample_counter += 1
-                self.last_loss = m.update_async(batch, grad_sync=sync, world=self.world)
 
     def evaluate(self, episodes, epsilon, round_idx=0):
         """_evaluate (train.py:177-199) for `episodes` envs in one collector launch (no replay writes);

@@ -8,7 +8,7 @@ from dataclasses import dataclass
 import torch
 
 from . import _lib
-from ._lib import (BatchStruct, LbfBuffers, LbfConfig, MarlHipError, NetShape, ReplayBuffers, ReplayShape, check, lib)
+from ._lib import (BatchStruct, IdqnLearner, LbfBuffers, LbfConfig, MarlHipError, NetShape, ReplayBuffers, ReplayShape, check, lib)
 
 Batch = namedtuple("Batch", ["obss", "actions", "rewards", "dones", "filled", "action_mask"])  # dqn/train.py:14-16
 
@@ -212,6 +212,17 @@ class DqnUpdater:
               "dqn_loss_grad")
         return self.loss, self.grad
 
+    def loss_grad_replay(self, replay, batch_size, length=None, idx=None, seed=0, counter=0, idx_out=None, mode=0):
+        """Sampling fused into the loss/grad kernel: rows are gathered from the replay in-kernel (no Batch)."""
+        ws = self._workspace(replay.T, batch_size)
+        s = self.spec.c()
+        check(lib.marlhip_dqn_loss_grad_replay(ctypes.byref(s), _ptr(self.params), _ptr(self.target), ctypes.byref(replay.shape),
+                                               ctypes.byref(replay.bufs), _ptr(idx), int(batch_size), int(length or 0),
+                                               int(seed) & (2**64 - 1), int(counter) & 0xFFFFFFFF, _ptr(idx_out),
+                                               float(self.gamma), self.double_q, int(mode), _ptr(ws), ws.numel(), _ptr(self.grad),
+                                               _ptr(self.loss), _stream()), "dqn_loss_grad_replay")
+        return self.loss, self.grad
+
     def apply(self, hard_update=False, tau=0.0, grad_scale=1.0):
         self.step += 1
         check(lib.marlhip_dqn_clip_adam(self.params.numel(), _ptr(self.params), _ptr(self.grad), _ptr(self.exp_avg),
@@ -230,3 +241,37 @@ def idqn_collect(cfg: LbfConfig, spec: NetSpec, params, epsilon, round_idx, repl
                                    ctypes.byref(replay.shape), ctypes.byref(replay.bufs), int(slot_base), int(bool(write_replay)),
                                    int(bool(clear_stale)), int(bool(use_proper_termination)), _ptr(fin_return), _ptr(fin_length),
                                    _stream()), "idqn_collect")
+
+
+class FusedLearner:
+    """n updates per host call (marlhip_idqn_update_n): sample -> loss/grad -> clip+Adam+target, with the
+    reference's update / target-update counters kept in host integers shared with the QNetwork object."""
+
+    def __init__(self, updater: DqnUpdater, replay: DeviceReplay, batch, target_update_interval_or_tau, mode=0,
+                 materialise_batch=False):
+        self.up, self.replay, self.B = updater, replay, int(batch)
+        outs = replay._outputs(self.B)
+        ws = updater._workspace(replay.T, self.B)
+        self.c = IdqnLearner(
+            net=updater.spec.c(), rs=replay.shape, rb=replay.bufs, params=updater.params.data_ptr(),
+            target=updater.target.data_ptr(), exp_avg=updater.exp_avg.data_ptr(), exp_avg_sq=updater.exp_avg_sq.data_ptr(),
+            grad=updater.grad.data_ptr(), loss=updater.loss.data_ptr(), scratch=updater.scratch.data_ptr(),
+            gnorm=updater.gnorm.data_ptr(), workspace=ws.data_ptr(), workspace_bytes=ws.numel(),
+            obss=outs[0].data_ptr(), actions=outs[1].data_ptr(), rewards=outs[2].data_ptr(), dones=outs[3].data_ptr(),
+            filled=outs[4].data_ptr(), idx=outs[5].data_ptr(), batch=self.B, double_q=updater.double_q, mode=int(mode),
+            materialise_batch=int(bool(materialise_batch)),
+            gamma=float(updater.gamma), max_norm=float(updater.grad_clip), lr=float(updater.lr), beta1=float(updater.betas[0]),
+            beta2=float(updater.betas[1]), eps=float(updater.eps),
+            target_update_interval_or_tau=float(target_update_interval_or_tau))
+        self._keep = (outs, ws)
+
+    def run(self, n_updates, length, seed, counter0, updates, last_target_update):
+        """returns the advanced (updates, last_target_update); the Adam step lives in the DqnUpdater"""
+        step = ctypes.c_int64(self.up.step)
+        upd = ctypes.c_int64(int(updates))
+        last = ctypes.c_int64(int(last_target_update))
+        check(lib.marlhip_idqn_update_n(ctypes.byref(self.c), int(n_updates), int(length), int(seed) & (2**64 - 1),
+                                        int(counter0) & 0xFFFFFFFF, ctypes.byref(step), ctypes.byref(upd), ctypes.byref(last),
+                                        _stream()), "idqn_update_n")
+        self.up.step = step.value
+        return upd.value, last.value

@@ -183,6 +183,17 @@ int marlhip_dqn_loss_grad(const marlhip_net_shape* s, const float* params, const
                           const marlhip_batch* batch, float gamma, int32_t double_q, int32_t mode, void* workspace,
                           int64_t workspace_bytes, float* grad, float* loss, void* stream);
 
+/* Same loss and gradient, but the B episodes are gathered INSIDE the kernel straight from the
+ * episode-major replay (ReplayBuffer.sample + _compute_loss fused, train.py:94-124 + model.py:118-163):
+ * no Batch is materialised, each sampled episode is read once.  idx != NULL: episodes idx[b];
+ * idx == NULL: the same Philox draw marlhip_replay_sample makes for (seed, counter, length).
+ * idx_out (may be NULL) records the indices used.  Bitwise identical to sample -> loss_grad. */
+int marlhip_dqn_loss_grad_replay(const marlhip_net_shape* s, const float* params, const float* target_params,
+                                 const marlhip_replay_shape* rs, const marlhip_replay_buffers* rb, const int32_t* idx,
+                                 int32_t batch, int32_t length, uint64_t seed, uint32_t counter, int32_t* idx_out,
+                                 float gamma, int32_t double_q, int32_t mode, void* workspace, int64_t workspace_bytes,
+                                 float* grad, float* loss, void* stream);
+
 /* clip_grad_norm_(critic.parameters(), max_norm) over ALL agents' parameters (model.py:169-170;
  * max_norm <= 0: no clipping), torch.optim.Adam single-tensor step (model.py:171; step = 1-based
  * update count, bias corrections computed in fp64 on the host side of this call), then the
@@ -207,6 +218,38 @@ int marlhip_idqn_collect(const marlhip_lbf_config* cfg, const marlhip_net_shape*
                          uint32_t round, const marlhip_replay_shape* rs, const marlhip_replay_buffers* rb,
                          int32_t slot_base, int32_t write_replay, int32_t clear_stale, int32_t use_proper_termination,
                          float* fin_return /* [P][N] */, int32_t* fin_length /* [N] */, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * n learner updates from one call: n x (marlhip_replay_sample with device-drawn indices ->
+ * marlhip_dqn_loss_grad -> marlhip_dqn_clip_adam), with QNetwork.update's bookkeeping
+ * (marlbase/dqn/model.py:165-185): *updates += 1 per update, hard target copy when
+ * updates - last_target_update >= target_update_interval_or_tau (> 1), Polyak when < 1.
+ * Single-GPU convenience (no hook for a gradient all-reduce): identical kernels, fewer host calls.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct marlhip_idqn_learner {
+    marlhip_net_shape net;
+    marlhip_replay_shape rs;
+    marlhip_replay_buffers rb;
+    float *params, *target, *exp_avg, *exp_avg_sq, *grad, *loss, *scratch, *gnorm;
+    void* workspace;
+    int64_t workspace_bytes;
+    float* obss;      /* sample outputs, shaped for `batch` episodes (marlhip_replay_sample) */
+    int64_t* actions;
+    float* rewards;
+    float* dones;
+    float* filled;
+    int32_t* idx;
+    int32_t batch;
+    int32_t double_q, mode;
+    int32_t materialise_batch; /* 0: gather in the loss/grad kernel (marlhip_dqn_loss_grad_replay); 1: sample -> Batch -> loss_grad */
+    float gamma, max_norm;
+    double lr, beta1, beta2, eps;
+    double target_update_interval_or_tau;
+} marlhip_idqn_learner;
+
+int marlhip_idqn_update_n(const marlhip_idqn_learner* L, int32_t n_updates, int32_t length, uint64_t seed,
+                          uint32_t counter0, int64_t* adam_step, int64_t* updates, int64_t* last_target_update,
+                          void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Measurement aid (bench.py roofline leg): when enabled, the named kernels are bracketed by HIP

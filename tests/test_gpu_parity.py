@@ -327,6 +327,40 @@ def test_loss_and_grad_vs_torch_port(P, T, B, D, double_q):
     assert torch.equal(g1, g2)
 
 
+def test_in_kernel_replay_gather_is_bitwise_the_sample_then_loss_path():
+    """marlhip_dqn_loss_grad_replay == marlhip_replay_sample -> marlhip_dqn_loss_grad (same rows, same order)"""
+    h = hip()
+    P, D, T, H, A, CAP, B = 2, 15, 25, 64, 6, 700, 333
+    spec = h.NetSpec(P, D, H, A)
+    rb = h.DeviceReplay(CAP, P, D, T)
+    g = torch.Generator().manual_seed(0)
+    rb.obs.copy_(torch.randint(-1, 8, rb.obs.shape, generator=g).float())
+    rb.act.copy_(torch.randint(0, A, rb.act.shape, generator=g).to(torch.uint8))
+    rb.rew.copy_(torch.rand(rb.rew.shape, generator=g))
+    lens = torch.randint(1, T + 1, (CAP,), generator=g)
+    rb.filled.copy_((torch.arange(T).unsqueeze(0) < lens.unsqueeze(1)).to(torch.uint8))
+    dn = torch.zeros(CAP, T + 1, dtype=torch.uint8)
+    dn[torch.arange(CAP), lens] = 1
+    rb.done.copy_(dn)
+    params = (dp.init_params(P, D, H, A, seed=1) + 0.05).to(DEV)
+    target = dp.init_params(P, D, H, A, seed=2).to(DEV)
+    up = h.DqnUpdater(spec, params, target)
+    for kw in (dict(length=600, seed=9, counter=4), dict(idx=torch.randint(0, CAP, (B,), generator=g).to(torch.int32).to(DEV))):
+        batch = rb.sample(B, **kw)
+        l1, g1 = up.loss_grad(batch)
+        l1, g1 = l1.clone(), g1.clone()
+        idx_used = rb._out[B][5].clone() if "idx" not in kw else kw["idx"]
+        rec = torch.zeros(B, dtype=torch.int32, device=DEV)
+        l2, g2 = up.loss_grad_replay(rb, B, idx_out=rec, **kw)
+        assert torch.equal(l1, l2) and torch.equal(g1, g2)
+        assert torch.equal(rec, idx_used)
+    # and against the torch restatement
+    pr = params.cpu().clone().requires_grad_(True)
+    ref = dp.compute_loss(pr, target.cpu(), {k: getattr(batch, k).cpu() for k in ("obss", "actions", "rewards", "dones", "filled")},
+                          0.99, True, D, H, A)
+    assert abs(l2.cpu().numpy()[0] - ref.item()) <= 2e-5 * abs(ref.item())
+
+
 def test_update_sequence_matches_reference_golden():
     """3 x QNetwork.update (clip 1.0, Adam 3e-4, hard target update at update 2)"""
     h = hip()
