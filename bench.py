@@ -123,7 +123,9 @@ def main():
     from codebase_amd.utils.envs import _space_pair
 
     N, T, H = args.envs, args.time_limit, args.hidden
-    cfg = h.lbf_config(ENV_NAME, N, T, seed=args.seed + 1000003 * rank)
+    from codebase_amd.parallel import rank_env_seed
+
+    cfg = h.lbf_config(ENV_NAME, N, T, seed=rank_env_seed(args.seed, rank))
     P, D, A = cfg.n_agents, 3 * (cfg.n_agents + cfg.n_food), 6
     if args.cadence == "ratio":
         B = args.update_batch or N

@@ -20,6 +20,7 @@ import torch
 
 from .. import hip as _hip
 from ..hip import Batch  # noqa: F401  (same field names as dqn/train.py:14-16)
+from ..parallel import rank_sample_seed
 
 
 class ReplayBuffer:
@@ -139,7 +140,11 @@ class VectorisedIDQN:
         self._fused = None  # single-GPU: all U updates of a round from one library call
 
     def _grad_sync(self, grad):
-        self.dist.all_reduce(grad)  # SUM over ranks (RCCL over xGMI); clip+Adam applies 1/world
+        from ..parallel import GradSync
+
+        if getattr(self, "_sync", None) is None:
+            self._sync = GradSync(self.dist)  # all-reduce(SUM) over RCCL/xGMI; clip+Adam applies 1/world
+        self._sync(grad)
 
     def round(self, epsilon, train=True):
         """collect N episodes (one launch), then U updates; nothing here synchronises with the host."""
@@ -163,7 +168,7 @@ class VectorisedIDQN:
             sync = self._grad_sync if self.dist is not None else None
             for _ in range(self.U):
                 self.last_loss = m.update_async(self.B, grad_sync=sync, world=self.world, replay=self.replay, length=length,
-                                                seed=self.seed + 7919 * self.rank, counter=self.sample_counter)
+                                                seed=rank_sample_seed(self.seed, self.rank), counter=self.sample_counter)
                 self.sample_counter += 1
 
     def evaluate(self, episodes, epsilon, round_idx=0):
