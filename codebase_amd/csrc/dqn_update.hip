@@ -479,14 +479,22 @@ __global__ __launch_bounds__(256) void dqn_reduce_kernel(const float* __restrict
     __syncthreads();
     nf = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
     ls = (s_red[4] + s_red[5]) + (s_red[6] + s_red[7]);
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    // 64 parameters per block, the record range split over the 4 waves (4x the loads in flight and 4x
+    // the blocks of a thread-per-parameter loop); fixed summation order: slice-local in w order, then
+    // (s0 + s1) + (s2 + s3)
+    __shared__ float s_part[4][64];
+    const int l64 = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + l64;
+    float acc = 0.f;
     if (i < P * nparam) {
         const int p = i / nparam, k = i - p * nparam;
         const float* src = partials + (size_t)p * nwg * rec + k;
-        float acc = 0.f;
-        for (int w = 0; w < nwg; ++w) acc += src[(size_t)w * rec];
-        grad[i] = acc / nf;
+#pragma unroll 8
+        for (int w = slice; w < nwg; w += 4) acc += src[(size_t)w * rec];
     }
+    s_part[slice][l64] = acc;
+    __syncthreads();
+    if (slice == 0 && i < P * nparam) grad[i] = ((s_part[0][l64] + s_part[1][l64]) + (s_part[2][l64] + s_part[3][l64])) / nf;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         loss[0] = ls / nf;
         loss[1] = nf;
@@ -551,6 +559,49 @@ __global__ __launch_bounds__(256) void adam_kernel(int64_t n, int nblocks, float
     if (target != nullptr) {
         if (a.hard_update) target[i] = pi;
         else if (a.tau > 0.f) target[i] = (1.f - a.tau) * target[i] + a.tau * pi;
+    }
+}
+
+// n <= 128k parameters: norm + clip + Adam + target in ONE workgroup (one launch instead of two)
+__global__ __launch_bounds__(1024) void adam_fused_kernel(int64_t n, float* __restrict__ params, const float* __restrict__ grad,
+                                                          float* __restrict__ m, float* __restrict__ v, float* __restrict__ target,
+                                                          AdamArgs a, float* __restrict__ gnorm_out) {
+    __shared__ float red[16];
+    __shared__ float s_coef;
+    float ss = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) {
+        const float gv = grad[i] * a.grad_scale;
+        ss += gv * gv;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) ss += __shfl_xor(ss, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k];
+        const float total = sqrtf(t);
+        s_coef = a.max_norm > 0.f ? fminf(a.max_norm / (total + 1e-6f), 1.f) : 1.f;
+        if (gnorm_out != nullptr) gnorm_out[0] = total;
+    }
+    __syncthreads();
+    const float coef = s_coef;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) {
+        const float gv = (grad[i] * a.grad_scale) * coef;
+        float mi = m[i], vi = v[i];
+        mi = mi + a.w1 * (gv - mi);
+        vi = vi * a.beta2 + a.w2 * gv * gv;
+        const float denom = sqrtf(vi) / a.bc2_sqrt + a.eps;
+        float pi = params[i];
+        pi = pi + (-a.lr_step) * (mi / denom);
+        m[i] = mi;
+        v[i] = vi;
+        params[i] = pi;
+        if (target != nullptr) {
+            if (a.hard_update) target[i] = pi;
+            else if (a.tau > 0.f) target[i] = (1.f - a.tau) * target[i] + a.tau * pi;
+        }
     }
 }
 
@@ -619,7 +670,7 @@ int launch_lossgrad(const marlhip_net_shape* s, const float* params, const float
     timing_end(TIMER_LOSSGRAD, st);
     MARL_CHECK_LAUNCH("dqn_lossgrad_kernel");
     const int n = s->n_agents * S::NPARAM;
-    hipLaunchKernelGGL(dqn_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)ws, s->n_agents, pl.nwg,
+    hipLaunchKernelGGL(dqn_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, st, (const float*)ws, s->n_agents, pl.nwg,
                        S::NPARAM, grad, loss);
     MARL_CHECK_LAUNCH("dqn_reduce_kernel");
     return 0;
@@ -704,8 +755,6 @@ extern "C" int marlhip_dqn_clip_adam(int64_t n, float* params, const float* grad
     MARL_REQUIRE(step >= 1, "dqn_clip_adam: step must be >= 1");
     const int nblocks = (int)((n + 255) / 256);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(sumsq_kernel, dim3(nblocks), dim3(256), 0, st, grad, n, grad_scale, scratch);
-    MARL_CHECK_LAUNCH("sumsq_kernel");
     AdamArgs a;
     // python-float (fp64) scalars exactly as torch.optim.adam._single_tensor_adam forms them
     const double bc1 = 1.0 - pow(beta1, (double)step);
@@ -716,8 +765,16 @@ extern "C" int marlhip_dqn_clip_adam(int64_t n, float* params, const float* grad
     a.beta2 = (float)beta2;
     a.w2 = (float)(1.0 - beta2);
     a.eps = (float)eps; a.max_norm = max_norm; a.grad_scale = grad_scale; a.tau = tau; a.hard_update = hard_update;
-    hipLaunchKernelGGL(adam_kernel, dim3(nblocks), dim3(256), 0, st, n, nblocks, params, grad, exp_avg, exp_avg_sq, target_params,
-                       a, (const float*)scratch, gnorm_out);
-    MARL_CHECK_LAUNCH("adam_kernel");
+    if (n <= 131072) {
+        hipLaunchKernelGGL(adam_fused_kernel, dim3(1), dim3(1024), 0, st, n, params, grad, exp_avg, exp_avg_sq, target_params, a,
+                           gnorm_out);
+        MARL_CHECK_LAUNCH("adam_fused_kernel");
+    } else {
+        hipLaunchKernelGGL(sumsq_kernel, dim3(nblocks), dim3(256), 0, st, grad, n, grad_scale, scratch);
+        MARL_CHECK_LAUNCH("sumsq_kernel");
+        hipLaunchKernelGGL(adam_kernel, dim3(nblocks), dim3(256), 0, st, n, nblocks, params, grad, exp_avg, exp_avg_sq,
+                           target_params, a, (const float*)scratch, gnorm_out);
+        MARL_CHECK_LAUNCH("adam_kernel");
+    }
     return 0;
 }
