@@ -108,13 +108,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an AMD GPU: the marlhip hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # MARLHIP_BENCH_BACKEND=gloo + MARLHIP_BENCH_ONE_DEVICE=1 let the N>1 code path be exercised on a 1-GPU box
+    backend = os.environ.get("MARLHIP_BENCH_BACKEND", "nccl")  # nccl == RCCL on ROCm
+    dev_index = 0 if os.environ.get("MARLHIP_BENCH_ONE_DEVICE") else local_rank
+    torch.cuda.set_device(dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
+        kw = {"device_id": torch.device("cuda", dev_index)} if backend == "nccl" else {}
+        dist.init_process_group(backend, **kw)
 
     from codebase_amd import hip as h
     from codebase_amd._lib import lib
@@ -192,8 +196,17 @@ def main():
         flops = fwd_flops_row * P * B * ((T + 1) + T + 2 * T)
         avg_s = timing["dqn_lossgrad_kernel"]["avg_us"] * 1e-6
         ach = flops / avg_s / 1e12
+        # HBM traffic per launch from the committed rocprofv3 PMC passes (FETCH_SIZE doubled per the gfx950 note,
+        # + WRITE_SIZE), valid for the profiled workload only; bench.py cannot run rocprofv3 on itself
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            if (N, H, B, T) == (4096, 64, 4096, 25):
+                traffic = pmc["kernels"]["dqn_lossgrad_kernel<15,64,6> (replay gather, B=4096)"]["traffic_bytes"]
+        except (OSError, KeyError, ValueError):
+            pass
         roofline = {"kernel": "dqn_lossgrad_kernel", "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                    "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
                     "flops_per_launch": flops, "avg_launch_us": timing["dqn_lossgrad_kernel"]["avg_us"]}
     elif "idqn_collect_kernel" in timing:
         # env-only: the collector's HBM traffic is the replay write, 4*P*D + P + 4*P + 2 bytes per env-step (+ row 0)

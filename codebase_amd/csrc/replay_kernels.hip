@@ -3,6 +3,8 @@
 // B whole episodes into the reference's time-major Batch layout.  HBM-bound byte movement:
 // per sampled episode read 4*P*D*(T+1) + P*T*(1+4) + (T+1) + T bytes, write
 // 4*P*D*(T+1) + 8*P*T + 4*P*T + 4*(T+1) + 4*T bytes (3,421 B + 3,924 B for 8x8-2p-3f, T=25).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace marl {
@@ -85,6 +87,66 @@ __global__ __launch_bounds__(256) void replay_sample_kernel(marlhip_replay_shape
     }
 }
 
+// LDS-staged transposing gather of the observation block (>= 85 % of the sampled bytes).
+// A workgroup owns EB consecutive batch rows: it streams their EB episode records - each one
+// contiguous P*(T+1)*D floats in the episode-major replay - into LDS with fully coalesced loads,
+// then writes, for every (p,t), the EB*D-float run obss[p][t][b0..b0+EB-1][:] with coalesced stores.
+// Both HBM sides move whole lines; the (episode-major -> time-major) transpose happens in LDS.
+__global__ __launch_bounds__(256) void replay_sample_obs_kernel(marlhip_replay_shape rs, const float* __restrict__ robs,
+                                                                const int32_t* __restrict__ idx, int B, int EB,
+                                                                float* __restrict__ obss) {
+    extern __shared__ __attribute__((aligned(16))) float lds_ep[];
+    const int P = rs.n_agents, D = rs.obs_dim, T = rs.max_len;
+    const int E = P * (T + 1) * D;  // floats per episode record
+    const int b0 = blockIdx.x * EB;
+    const int nb = min(EB, B - b0);
+    __shared__ int s_idx[16];
+    if (threadIdx.x < nb) s_idx[threadIdx.x] = idx[b0 + threadIdx.x];
+    __syncthreads();
+    // one flat loop over all EB records (not one loop per record): every thread keeps 8 independent
+    // loads in flight, enough outstanding bytes per CU to cover HBM latency
+    const int all = nb * E;
+#pragma unroll 8
+    for (int i = threadIdx.x; i < all; i += 256) {
+        const int e = i / E, k = i - e * E;
+        lds_ep[i] = robs[(size_t)s_idx[e] * E + k];
+    }
+    __syncthreads();
+    const int run = nb * D;              // contiguous floats per (p,t) in the output
+    const int total = P * (T + 1) * run;
+    for (int o = threadIdx.x; o < total; o += 256) {
+        const int pt = o / run, rem = o - pt * run;
+        const int e = rem / D, d = rem - e * D;
+        obss[((size_t)pt * B + b0) * D + rem] = lds_ep[e * E + pt * D + d];
+    }
+}
+
+// the small per-transition arrays of the Batch (actions i64, rewards, dones, filled)
+__global__ __launch_bounds__(256) void replay_sample_small_kernel(marlhip_replay_shape rs, marlhip_replay_buffers rb,
+                                                                  const int32_t* __restrict__ idx, int B,
+                                                                  int64_t* __restrict__ actions, float* __restrict__ rewards,
+                                                                  float* __restrict__ dones, float* __restrict__ filled) {
+    const int P = rs.n_agents, T = rs.max_len;
+    const int64_t n_pt = (int64_t)P * T * B, n_d = (int64_t)(T + 1) * B, n_f = (int64_t)T * B;
+    const int64_t total = n_pt + n_d + n_f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        if (i < n_pt) {
+            const int b = (int)(i % B), t = (int)((i / B) % T), p = (int)(i / ((int64_t)B * T));
+            const size_t src = ((size_t)idx[b] * P + p) * T + t;
+            actions[i] = (int64_t)rb.act[src];
+            rewards[i] = rb.rew[src];
+        } else if (i < n_pt + n_d) {
+            const int64_t k = i - n_pt;
+            const int b = (int)(k % B), t = (int)(k / B);
+            dones[k] = rb.done[(size_t)idx[b] * (T + 1) + t] ? 1.f : 0.f;
+        } else {
+            const int64_t k = i - n_pt - n_d;
+            const int b = (int)(k % B), t = (int)(k / B);
+            filled[k] = rb.filled[(size_t)idx[b] * T + t] ? 1.f : 0.f;
+        }
+    }
+}
+
 inline int check_replay(const marlhip_replay_shape* rs, const marlhip_replay_buffers* rb) {
     MARL_REQUIRE(rs && rb, "replay: NULL shape/buffers");
     MARL_REQUIRE(rs->capacity > 0 && rs->n_agents > 0 && rs->obs_dim > 0 && rs->max_len > 0, "replay: bad shape");
@@ -141,11 +203,27 @@ extern "C" int marlhip_replay_sample(const marlhip_replay_shape* rs, const marlh
         idx = idx_out;
     }
     const int P = rs->n_agents, D = rs->obs_dim, T = rs->max_len;
-    const int64_t total = (int64_t)P * (T + 1) * batch * D + (int64_t)P * T * batch + (int64_t)(2 * T + 1) * batch;
+    // episodes per workgroup: as many as fit 48 KB of LDS (3 workgroups per CU), at most 16
+    const int ep_bytes = P * (T + 1) * D * (int)sizeof(float);
+    int EB = (48 * 1024) / ep_bytes;
+    if (EB > 16) EB = 16;
+    if (getenv("MARLHIP_SAMPLE_SIMPLE") != nullptr || EB < 1) {  // one-thread-per-element gather (reference variant)
+        const int64_t total = (int64_t)P * (T + 1) * batch * D + (int64_t)P * T * batch + (int64_t)(2 * T + 1) * batch;
+        timing_begin(TIMER_SAMPLE, (hipStream_t)stream);
+        hipLaunchKernelGGL(replay_sample_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, *rs, *rb, idx, batch,
+                           obss, actions, rewards, dones, filled);
+        timing_end(TIMER_SAMPLE, (hipStream_t)stream);
+        MARL_CHECK_LAUNCH("replay_sample");
+        return 0;
+    }
     timing_begin(TIMER_SAMPLE, (hipStream_t)stream);
-    hipLaunchKernelGGL(replay_sample_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, *rs, *rb, idx, batch, obss,
-                       actions, rewards, dones, filled);
+    hipLaunchKernelGGL(replay_sample_obs_kernel, dim3((batch + EB - 1) / EB), dim3(256), (size_t)EB * ep_bytes, (hipStream_t)stream,
+                       *rs, (const float*)rb->obs, idx, batch, EB, obss);
     timing_end(TIMER_SAMPLE, (hipStream_t)stream);
-    MARL_CHECK_LAUNCH("replay_sample");
+    MARL_CHECK_LAUNCH("replay_sample_obs");
+    const int64_t small = (int64_t)P * T * batch + (int64_t)(2 * T + 1) * batch;
+    hipLaunchKernelGGL(replay_sample_small_kernel, dim3(grid_for(small)), dim3(256), 0, (hipStream_t)stream, *rs, *rb, idx, batch,
+                       actions, rewards, dones, filled);
+    MARL_CHECK_LAUNCH("replay_sample_small");
     return 0;
 }
