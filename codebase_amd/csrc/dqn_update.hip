@@ -98,9 +98,25 @@ __device__ __forceinline__ int replay_draw(const ReplaySrc& r, int b) {
     return (int)bounded_nr(s == 0 ? o.x : (s == 1 ? o.y : (s == 2 ? o.z : o.w)), (uint32_t)r.length);
 }
 
-template <class S, int WAVES, bool REPLAY>
+// value-decomposition learners (VDN now, QMIX next) split the step around a MIXER:
+//   MODE 1 "qsel": agent networks forward only -> chosen_p[t][b] = Q_p(o_t)[a_t], tqsel_p[t][b] = bootstrap value
+//   mixer kernel : (chosen, tqsel, r, done, filled) -> dq_p[t][b] = dL/dchosen_p (unnormalised) and per-row loss
+//   MODE 2 "bwd" : agent networks forward (critic only) + backward with the external dq
+// MODE 0 is the fused independent-learner step (IDQN), where the "mixer" is the identity per agent.
+struct MixBufs {
+    float* chosen;   // [P][T][B]
+    float* tqsel;    // [P][T][B]
+    float* r0;       // [T][B] reward of agent 0 (VDNetwork uses batch.rewards[0], dqn/model.py:228)
+    float* dn;       // [T][B] done(t+1)
+    float* fl;       // [T][B] filled(t)
+    float* dq;       // [T][B] (agent stride 0) or [P][T][B]
+    float* lrow;     // [T][B] filled * delta^2
+    int dq_agent_stride;
+};
+
+template <class S, int WAVES, bool REPLAY, int MODE>
 __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dqn_lossgrad_kernel(const float* __restrict__ packs, marlhip_batch bt, ReplaySrc rs,
-                                                                 float gamma, int double_q, int n_chunks,
+                                                                 MixBufs mix, float gamma, int double_q, int n_chunks,
                                                                  float* __restrict__ partials, unsigned long long* prof) {
     using L = UpdLds<S>;
     constexpr int MT = S::MT, NT1 = S::DP / 16, D = S::D, H = S::H, A = S::A;
@@ -183,6 +199,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dqn_lossgrad_kernel(con
             float bx[NT1][4];  // dW1 B operand:     X[row 4g+ks][16nt+j]
             int a_sel;
             float rw, dn, fl;
+            float dq, lr;      // MODE 2: external dL/dchosen and per-row loss
         };
         // branch-free: every address is clamped in-bounds and loaded unconditionally (a guarded load is
         // an exec-masked branch + a conservative vmcnt(0) at the join); masks are applied at the point of use
@@ -225,6 +242,10 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dqn_lossgrad_kernel(con
                 R.dn = bt.dones[(size_t)(tt + 1) * B + bj];
                 R.fl = bt.filled[(size_t)tt * B + bj];
             }
+            if (MODE == 2) {
+                R.dq = mix.dq[(size_t)p * mix.dq_agent_stride + (size_t)tt * B + bj];
+                R.lr = mix.lrow[(size_t)tt * B + bj];
+            }
         };
         auto mask_rows = [&](Rows& R) {  // zero the padding (obs dims >= D, rows >= B)
 #pragma unroll
@@ -244,17 +265,35 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dqn_lossgrad_kernel(con
             mask_rows(cur);
             MARL_PHASE(0)
             f4 h1[MT], h2[MT], q, tq;
-            if (t > t0) mlp_forward_p<S, true>(cpk, tpk, lane, cur.x, h1, h2, q, tq);  // target value feeds transition t-1
+            if (MODE != 2 && t > t0) mlp_forward_p<S, true>(cpk, tpk, lane, cur.x, h1, h2, q, tq);  // target value feeds transition t-1
             else mlp_forward_p<S, false>(cpk, tpk, lane, cur.x, h1, h2, q, tq);
             MARL_PHASE(1)
-            if (t < t1) {
+            if (MODE == 1 && t < t1) {
+                // qsel pass: publish Q_p(o_t)[a_t] and (agent 0) the transition's scalars for the mixer
+                const float ch = gather_rows(q, lane, cur.a_sel);
+                if (g == 0 && rowok) {
+                    mix.chosen[((size_t)p * T + t) * B + bj] = ch;
+                    if (p == 0) {
+                        mix.r0[(size_t)t * B + bj] = cur.rw;
+                        mix.dn[(size_t)t * B + bj] = cur.dn;
+                        mix.fl[(size_t)t * B + bj] = cur.fl;
+                    }
+                }
+            }
+            if (MODE != 1 && t < t1) {
                 // ---- TD error of transition t (model.py:129,152,160-163)
                 const int a_sel = cur.a_sel;
                 const float fl = cur.fl;
-                const float y = cur.rw + gamma * tq_next * (1.f - cur.dn);
-                const float delta = gather_rows(q, lane, a_sel) - y;
-                if (g == 0) { loss_acc += fl * delta * delta; nfill_acc += fl; }
-                const float dqs = 2.f * fl * delta;
+                float dqs;
+                if (MODE == 0) {
+                    const float y = cur.rw + gamma * tq_next * (1.f - cur.dn);
+                    const float delta = gather_rows(q, lane, a_sel) - y;
+                    if (g == 0) { loss_acc += fl * delta * delta; nfill_acc += fl; }
+                    dqs = 2.f * fl * delta;
+                } else {  // the mixer already formed dL/dchosen; agent 0's rows carry the loss bookkeeping
+                    dqs = rowok ? cur.dq : 0.f;
+                    if (g == 0 && p == 0 && rowok) { loss_acc += cur.lr; nfill_acc += fl; }
+                }
                 f4 dQ[1];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) dQ[0][r] = (4 * g + r == a_sel) ? dqs : 0.f;
@@ -370,10 +409,11 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dqn_lossgrad_kernel(con
                 __builtin_amdgcn_sched_barrier(0);
             }
             MARL_PHASE(6)
-            if (t > t0) {
+            if (MODE != 2 && t > t0) {
                 // ---- bootstrap value for transition t-1 (model.py:132-145)
                 const int a_p = double_q ? argmax_rows<A>(q, lane) : argmax_rows<A>(tq, lane);
                 tq_next = gather_rows(tq, lane, a_p);
+                if (MODE == 1 && g == 0 && rowok) mix.tqsel[((size_t)p * T + (t - 1)) * B + bj] = tq_next;
             }
             cur = nxt;
             MARL_PHASE(7)
@@ -382,6 +422,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dqn_lossgrad_kernel(con
 
     const unsigned long long t_loop_end = prof ? __builtin_readcyclecounter() : 0;
 #undef MARL_PHASE
+    if (MODE == 1) return;  // forward-only pass: nothing to fold
     // ---- fold the waves through LDS and write ONE partial record per workgroup.  Every wave stores its
     // accumulators into its own LDS region in parallel (weights at their canonical index, bias / loss
     // partials as [value][16 lanes] strips), one barrier, then all threads sum the regions in a fixed
@@ -634,46 +675,98 @@ inline UpdPlan upd_plan(int P, int T, int B) {
     return pl;
 }
 
-template <class S>
-int launch_lossgrad(const marlhip_net_shape* s, const float* params, const float* tparams, const marlhip_batch* bt,
-                    const ReplaySrc* rsrc, float gamma, int double_q, void* ws, int64_t ws_bytes, float* grad, float* loss,
-                    hipStream_t st) {
+// VDN mixer (VDNetwork._compute_loss, dqn/model.py:237,254-269): chosen_tot = sum_p chosen_p, target_tot = sum_p tq_p,
+// y = r_0 + gamma * target_tot * (1 - done), delta = chosen_tot - y; dL/dchosen_p = 2 * filled * delta for every p.
+__global__ __launch_bounds__(256) void vdn_mix_kernel(MixBufs mix, int P, int T, int B, float gamma) {
+    const int n = T * B;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        float ch = 0.f, tq = 0.f;
+        for (int p = 0; p < P; ++p) {
+            ch += mix.chosen[(size_t)p * n + i];
+            tq += mix.tqsel[(size_t)p * n + i];
+        }
+        const float y = mix.r0[i] + gamma * tq * (1.f - mix.dn[i]);
+        const float delta = ch - y;
+        const float fl = mix.fl[i];
+        mix.dq[i] = 2.f * fl * delta;
+        mix.lrow[i] = fl * delta * delta;
+    }
+}
+
+// workspace layout (floats unless noted): [partial records][pad16][packs][mixer buffers (2P+5) T B][pad8][128 B phase counters]
+struct WsLayout {
+    int64_t rec_bytes, pack_off, mix_off, total;
+};
+
+inline WsLayout ws_layout(int P, int nwg, int rec, int pack, int T, int B) {
+    WsLayout w;
+    w.rec_bytes = (int64_t)P * nwg * rec * sizeof(float);
+    w.pack_off = (w.rec_bytes + 15) & ~(int64_t)15;
+    w.mix_off = w.pack_off + (int64_t)P * pack * sizeof(float);
+    w.total = ((w.mix_off + (int64_t)(2 * P + 5) * T * B * sizeof(float) + 7) & ~(int64_t)7) + 128;
+    return w;
+}
+
+template <class S, bool REPLAY>
+int launch_lossgrad_src(const marlhip_net_shape* s, const float* params, const float* tparams, const marlhip_batch* bt,
+                        const ReplaySrc& src, float gamma, int double_q, int mode, void* ws, int64_t ws_bytes, float* grad,
+                        float* loss, hipStream_t st) {
     using L = UpdLds<S>;
-    const UpdPlan pl = upd_plan(s->n_agents, bt->max_len, bt->batch);
+    const int P = s->n_agents, T = bt->max_len, B = bt->batch;
+    const UpdPlan pl = upd_plan(P, T, B);
     constexpr int PACK = 2 * S::NFWD + S::NBWD;
     static_assert(PACK % 4 == 0 && L::oT == S::NFWD && L::oB == 2 * S::NFWD, "pack layout == LDS layout");
-    const int64_t rec_bytes = (int64_t)s->n_agents * pl.nwg * L::REC * sizeof(float);
-    const int64_t need = rec_bytes + (int64_t)s->n_agents * PACK * sizeof(float);
-    MARL_REQUIRE(ws_bytes >= need + 16 + 128, "dqn_loss_grad: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)need);
-    float* packs = reinterpret_cast<float*>(static_cast<char*>(ws) + ((rec_bytes + 15) & ~(int64_t)15));
+    const WsLayout wl = ws_layout(P, pl.nwg, L::REC, PACK, T, B);
+    MARL_REQUIRE(ws_bytes >= wl.total, "dqn_loss_grad: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)wl.total);
+    float* packs = reinterpret_cast<float*>(static_cast<char*>(ws) + wl.pack_off);
+    float* mixf = reinterpret_cast<float*>(static_cast<char*>(ws) + wl.mix_off);
     const size_t lds_bytes = (size_t)L::total(4) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dqn_lossgrad_kernel<S, 4, false>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dqn_lossgrad_kernel<S, 4, REPLAY, 0>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dqn_lossgrad_kernel<S, 4, true>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dqn_lossgrad_kernel<S, 4, REPLAY, 1>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dqn_lossgrad_kernel<S, 4, REPLAY, 2>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         attr_set = true;
     }
-    hipLaunchKernelGGL((dqn_pack_kernel<S>), dim3((PACK + 255) / 256, s->n_agents), dim3(256), 0, st, params, tparams, packs);
+    hipLaunchKernelGGL((dqn_pack_kernel<S>), dim3((PACK + 255) / 256, P), dim3(256), 0, st, params, tparams, packs);
     MARL_CHECK_LAUNCH("dqn_pack_kernel");
     unsigned long long* prof =
         getenv("MARLHIP_PROF") ? reinterpret_cast<unsigned long long*>(static_cast<char*>(ws) + ws_bytes - 128) : nullptr;
-    ReplaySrc none = {};
+    const size_t tb = (size_t)T * B;
+    MixBufs mix;
+    mix.chosen = mixf; mix.tqsel = mixf + P * tb; mix.r0 = mixf + 2 * P * tb; mix.dn = mix.r0 + tb; mix.fl = mix.dn + tb;
+    mix.dq = mix.fl + tb; mix.lrow = mix.dq + tb; mix.dq_agent_stride = 0;
+    const dim3 grid(pl.nwg, P), block(256);
     timing_begin(TIMER_LOSSGRAD, st);
-    if (rsrc != nullptr)
-        hipLaunchKernelGGL((dqn_lossgrad_kernel<S, 4, true>), dim3(pl.nwg, s->n_agents), dim3(256), lds_bytes, st,
-                           (const float*)packs, *bt, *rsrc, gamma, double_q, pl.n_chunks, (float*)ws, prof);
-    else
-        hipLaunchKernelGGL((dqn_lossgrad_kernel<S, 4, false>), dim3(pl.nwg, s->n_agents), dim3(256), lds_bytes, st,
-                           (const float*)packs, *bt, none, gamma, double_q, pl.n_chunks, (float*)ws, prof);
+    if (mode == 0) {
+        hipLaunchKernelGGL((dqn_lossgrad_kernel<S, 4, REPLAY, 0>), grid, block, lds_bytes, st, (const float*)packs, *bt, src, mix,
+                           gamma, double_q, pl.n_chunks, (float*)ws, prof);
+    } else {
+        hipLaunchKernelGGL((dqn_lossgrad_kernel<S, 4, REPLAY, 1>), grid, block, lds_bytes, st, (const float*)packs, *bt, src, mix,
+                           gamma, double_q, pl.n_chunks, (float*)ws, prof);
+        hipLaunchKernelGGL(vdn_mix_kernel, dim3((unsigned)((tb + 255) / 256 > 1024 ? 1024 : (tb + 255) / 256)), dim3(256), 0, st, mix,
+                           P, T, B, gamma);
+        hipLaunchKernelGGL((dqn_lossgrad_kernel<S, 4, REPLAY, 2>), grid, block, lds_bytes, st, (const float*)packs, *bt, src, mix,
+                           gamma, double_q, pl.n_chunks, (float*)ws, prof);
+    }
     timing_end(TIMER_LOSSGRAD, st);
     MARL_CHECK_LAUNCH("dqn_lossgrad_kernel");
-    const int n = s->n_agents * S::NPARAM;
-    hipLaunchKernelGGL(dqn_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, st, (const float*)ws, s->n_agents, pl.nwg,
-                       S::NPARAM, grad, loss);
+    const int n = P * S::NPARAM;
+    hipLaunchKernelGGL(dqn_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, st, (const float*)ws, P, pl.nwg, S::NPARAM, grad, loss);
     MARL_CHECK_LAUNCH("dqn_reduce_kernel");
     return 0;
+}
+
+template <class S>
+int launch_lossgrad(const marlhip_net_shape* s, const float* params, const float* tparams, const marlhip_batch* bt,
+                    const ReplaySrc* rsrc, float gamma, int double_q, int mode, void* ws, int64_t ws_bytes, float* grad, float* loss,
+                    hipStream_t st) {
+    if (rsrc != nullptr) return launch_lossgrad_src<S, true>(s, params, tparams, bt, *rsrc, gamma, double_q, mode, ws, ws_bytes, grad, loss, st);
+    ReplaySrc none = {};
+    return launch_lossgrad_src<S, false>(s, params, tparams, bt, none, gamma, double_q, mode, ws, ws_bytes, grad, loss, st);
 }
 
 }  // namespace marl
@@ -701,17 +794,16 @@ extern "C" int64_t marlhip_dqn_workspace_bytes(const marlhip_net_shape* s, int32
 #define X(d, h, a) if (s->obs_dim == d && s->hidden == h && s->n_actions == a) pack = 2 * MlpShape<d, h, a>::NFWD + MlpShape<d, h, a>::NBWD;
     MARL_NET_SHAPES(X)
 #undef X
-    // (+ 16 B alignment slack, + 128 B tail used as 12 phase counters when MARLHIP_PROF is set, 8-byte aligned)
-    return (((int64_t)s->n_agents * pl.nwg * (np + 2) * sizeof(float) + 16 + (int64_t)s->n_agents * pack * sizeof(float) + 7) & ~(int64_t)7) + 128;
+    return ws_layout(s->n_agents, pl.nwg, np + 2, (int)pack, max_len, batch).total;
 }
 
 static int lossgrad_dispatch(const marlhip_net_shape* s, const float* params, const float* target_params, const marlhip_batch* bt,
                              const ReplaySrc* rsrc, float gamma, int32_t double_q, int32_t mode, void* workspace,
                              int64_t workspace_bytes, float* grad, float* loss, void* stream) {
-    MARL_REQUIRE(mode == 0, "dqn_loss_grad: mode %d (VDN) not built yet", mode);
+    MARL_REQUIRE(mode == 0 || mode == 1, "dqn_loss_grad: mode %d unknown (0 = IDQN, 1 = VDN)", mode);
 #define X(d, h, a)                                                                                                          \
     if (s->obs_dim == d && s->hidden == h && s->n_actions == a)                                                             \
-        return launch_lossgrad<MlpShape<d, h, a>>(s, params, target_params, bt, rsrc, gamma, double_q, workspace,             \
+        return launch_lossgrad<MlpShape<d, h, a>>(s, params, target_params, bt, rsrc, gamma, double_q, mode, workspace,       \
                                                   workspace_bytes, grad, loss, (hipStream_t)stream);
     MARL_UPD_SHAPES(X)
 #undef X

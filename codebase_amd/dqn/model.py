@@ -205,3 +205,18 @@ class QNetwork:
     def __repr__(self):
         S = self.spec
         return f"QNetwork[HIP](agents={S.n_agents}, mlp={S.obs_dim}-{S.hidden}-{S.hidden}-{S.n_actions}, params={self.nparams}/agent)"
+
+
+class VDNetwork(QNetwork):
+    """Value-decomposition network - drop-in for `dqn.model.VDNetwork` (marlbase/dqn/model.py:199-269,
+    configs/algorithm/vdn.yaml).  Same agent networks and interface as QNetwork; the loss couples the
+    agents through the sum mixer (chosen_tot = sum_p Q_p, target_tot = sum_p target_p, reward of agent 0 -
+    the env is expected to run under CooperativeReward).  On the device the step is
+    agent-forward ("qsel") -> mixer kernel -> agent-backward with the mixer's dL/dchosen."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.mode = 1
+
+    def __repr__(self):
+        return super().__repr__().replace("QNetwork[HIP]", "VDNetwork[HIP]")

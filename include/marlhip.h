@@ -178,7 +178,8 @@ int64_t marlhip_dqn_workspace_bytes(const marlhip_net_shape* s, int32_t max_len,
 /* loss (scalar, model.py:160-163) and its gradient w.r.t. the critic parameters, both written to
  * device memory: grad[P][nparams] (same layout as params), loss[0] = value, loss[1] = sum(filled).
  * mode: 0 = IDQN (per-agent targets, model.py:118-163), 1 = VDN (sum over agents, agent-0 reward,
- * model.py:224-269).  double_q as cfg.double_q (model.py:138-145). */
+ * model.py:224-269; runs as agent-forward -> sum-mixer kernel -> agent-backward).
+ * double_q as cfg.double_q (model.py:138-145). */
 int marlhip_dqn_loss_grad(const marlhip_net_shape* s, const float* params, const float* target_params,
                           const marlhip_batch* batch, float gamma, int32_t double_q, int32_t mode, void* workspace,
                           int64_t workspace_bytes, float* grad, float* loss, void* stream);

@@ -197,3 +197,49 @@ if __name__ == "__main__":
     replay_fixture(ref_train)
     eps_fixture(ref_train)
     init_fixture(ref_model)
+
+
+def vdn_fixture(ref_model, ref_train):
+    """learner_vdn_H64.npz: VDNetwork._compute_loss (marlbase/dqn/model.py:224-269), gradient, 3 updates."""
+    from oracle.dqn_port import synthetic_batch
+
+    P, T, B, D, A, H = 2, 25, 32, 15, 6, 64
+    torch.manual_seed(77)
+    cfg = Cfg(optimizer="Adam", lr=3e-4, gamma=0.99, grad_clip=1.0, target_update_interval_or_tau=2, double_q=True,
+              standardise_returns=False)
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = ref_model.VDNetwork([Box(D)] * P, [Discrete(A)] * P, cfg, [H, H], False, False, True, "cpu")
+    g = torch.Generator().manual_seed(78)
+    with torch.no_grad():
+        for p in net.critic.parameters():
+            p.add_(0.05 * torch.randn(p.shape, generator=g))
+        for p in net.target.parameters():
+            p.add_(0.08 * torch.randn(p.shape, generator=g))
+    out = dict(P=P, T=T, B=B, D=D, A=A, H=H, params0=flat_params(net.critic).numpy(), target0=flat_params(net.target).numpy())
+    batches = [synthetic_batch(P, T, B, D, A, seed=200 + i) for i in range(3)]
+    for b in batches:
+        b["rewards"][1:] = b["rewards"][0]  # CooperativeReward: every agent sees the team reward
+    b0 = ref_train.Batch(batches[0]["obss"], batches[0]["actions"], batches[0]["rewards"], batches[0]["dones"],
+                         batches[0]["filled"], None)
+    loss = net._compute_loss(b0)
+    net.optimizer.zero_grad()
+    loss.backward()
+    out["loss0"] = np.float32(loss.item())
+    out["grad0"] = torch.stack([torch.cat([p.grad.reshape(-1) for p in m.parameters()]) for m in net.critic.independent]).numpy()
+    net.optimizer.zero_grad()
+    losses = []
+    for i, b in enumerate(batches):
+        bb = ref_train.Batch(b["obss"], b["actions"], b["rewards"], b["dones"], b["filled"], None)
+        losses.append(net.update(bb)["loss"])
+        out[f"params{i + 1}"] = flat_params(net.critic).numpy()
+        out[f"target{i + 1}"] = flat_params(net.target).numpy()
+    out["losses"] = np.array(losses, np.float32)
+    for i, b in enumerate(batches):
+        for k, v in b.items():
+            out[f"batch{i}_{k}"] = v.numpy()
+    np.savez_compressed(os.path.join(OUT, "learner_vdn_H64.npz"), **out)
+    print(f"learner_vdn_H64: loss0={out['loss0']:.6f} losses={losses}")
+
+
+if __name__ == "__main__":
+    vdn_fixture(*import_reference())

@@ -77,3 +77,19 @@ def test_epsilon_schedule_matches_reference():
     ex = dp.epsilon_schedule("exponential", 0.5, 1.0, 0.05, 6.5, 100000)
     np.testing.assert_array_equal(np.array([lin(s) for s in g["steps"]]), g["linear"])
     np.testing.assert_array_equal(np.array([ex(s) for s in g["steps"]]), g["exponential"])
+
+
+def test_vdn_loss_grad_and_updates_match_reference():
+    g = load("learner_vdn_H64.npz")
+    D, H, A = int(g["D"]), 64, int(g["A"])
+    params = torch.tensor(g["params0"]).requires_grad_(True)
+    loss = dp.compute_loss(params, torch.tensor(g["target0"]), batch_of(g, 0), 0.99, True, D, H, A, mode="vdn")
+    loss.backward()
+    assert abs(loss.item() - float(g["loss0"])) <= 1e-5 * abs(float(g["loss0"]))
+    np.testing.assert_allclose(params.grad.numpy(), g["grad0"], rtol=1e-4, atol=1e-5)
+    lr = dp.Learner(torch.tensor(g["params0"]), D, H, A, target_update_interval_or_tau=2, mode="vdn")
+    lr.target = torch.tensor(g["target0"])
+    for i in range(3):
+        m = lr.update(batch_of(g, i))
+        assert abs(m["loss"] - float(g["losses"][i])) <= 2e-5 * abs(float(g["losses"][i]))
+        np.testing.assert_allclose(lr.flat().detach().numpy(), g[f"params{i + 1}"], rtol=0, atol=2e-6)
