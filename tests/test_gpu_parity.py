@@ -521,3 +521,49 @@ def test_vdn_other_shapes_vs_torch_port():
         assert abs(loss.cpu().numpy()[0] - ref.item()) <= 3e-5 * abs(ref.item())
         gref = pr.grad.numpy()
         np.testing.assert_allclose(grad.cpu().numpy(), gref, rtol=3e-4, atol=3e-5 * max(1.0, np.abs(gref).max()))
+
+
+def test_edge_cases_tiny_batches_single_env_and_error_paths():
+    """smallest sizes (1 env, 1 episode, T=1), batch sizes around the 16-row tile, and loud failures"""
+    h = hip()
+    from codebase_amd._lib import MarlHipError
+    # one env, time limit 1: every step truncates
+    env, cfg = make_env("lbforaging:Foraging-8x8-2p-3f-v3", 1, seed=3, time_limit=1)
+    env.reset()
+    o, r, d, tr = env.step(torch.zeros(2, 1, dtype=torch.int32, device=DEV))
+    assert tr.item() == 1 and env.fin_length.item() == 1
+    # out-of-range actions behave as NONE (state unchanged except the step counter)
+    env2, _ = make_env("lbforaging:Foraging-8x8-2p-3f-v3", 4, seed=3)
+    env2.reset()
+    s0 = env2.state.clone()
+    env2.step(torch.full((2, 4), 17, dtype=torch.int32, device=DEV))
+    s1 = env2.state.cpu().numpy()
+    assert (s1[:, :15] == s0.cpu().numpy()[:, :15]).all() and (s1[:, 15] == 1).all()
+    # learner: B = 1, 15, 16, 17 episodes and T = 1
+    P, D, H, A = 2, 15, 64, 6
+    spec = h.NetSpec(P, D, H, A)
+    params = dp.init_params(P, D, H, A, seed=1) + 0.03
+    target = dp.init_params(P, D, H, A, seed=2)
+    for T, B in ((1, 1), (1, 17), (3, 15), (2, 16), (25, 1)):
+        batch = dp.synthetic_batch(P, T, B, D, A, seed=T * 100 + B)
+        pr = params.clone().requires_grad_(True)
+        ref = dp.compute_loss(pr, target, batch, 0.99, True, D, H, A)
+        ref.backward()
+        up = h.DqnUpdater(spec, params.to(DEV), target.to(DEV))
+        loss, grad = up.loss_grad(dev_batch(h, batch))
+        assert abs(loss.cpu().numpy()[0] - ref.item()) <= 3e-5 * max(abs(ref.item()), 1e-3), (T, B)
+        gref = pr.grad.numpy()
+        np.testing.assert_allclose(grad.cpu().numpy(), gref, rtol=3e-4, atol=3e-5 * max(1.0, np.abs(gref).max()))
+    # unsupported shapes fail loudly, nothing falls back
+    with pytest.raises(MarlHipError):
+        h.DqnUpdater(h.NetSpec(2, 15, 128, 6), torch.zeros(2, h.NetSpec(2, 15, 128, 6).nparams(), device=DEV),
+                     torch.zeros(2, h.NetSpec(2, 15, 128, 6).nparams(), device=DEV)).loss_grad(
+            dev_batch(h, dp.synthetic_batch(2, 3, 4, 15, 6, seed=0)))
+    with pytest.raises(MarlHipError):
+        h.NetSpec(2, 15, 96, 6).nparams()
+    with pytest.raises(MarlHipError):
+        h.BatchedForaging(h.lbf_config("lbforaging:Foraging-8x8-5p-7f-v3", 4, 25))
+    # replay sample from an empty range is rejected
+    rb = h.DeviceReplay(8, 2, 15, 5)
+    with pytest.raises(MarlHipError):
+        rb.sample(4, length=0)
