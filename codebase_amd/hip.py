@@ -275,3 +275,13 @@ class FusedLearner:
                                         _stream()), "idqn_update_n")
         self.up.step = step.value
         return upd.value, last.value
+
+
+def ac_collect(cfg: LbfConfig, spec: NetSpec, actor_params, round_idx, max_len, use_proper_termination, b_obs, b_act, b_rew,
+               b_done, b_filled, fin_return, fin_length, t_max):
+    """Fused actor-critic rollout collector (marlbase/ac/train.py:24-119): one launch = one collection call."""
+    _require_gpu()
+    s = spec.c()
+    check(lib.marlhip_ac_collect(ctypes.byref(cfg), ctypes.byref(s), _ptr(actor_params), int(round_idx) & 0xFFFFFFFF, int(max_len),
+                                 int(bool(use_proper_termination)), _ptr(b_obs), _ptr(b_act), _ptr(b_rew), _ptr(b_done),
+                                 _ptr(b_filled), _ptr(fin_return), _ptr(fin_length), _ptr(t_max), _stream()), "ac_collect")

@@ -221,6 +221,24 @@ int marlhip_idqn_collect(const marlhip_lbf_config* cfg, const marlhip_net_shape*
                          float* fin_return /* [P][N] */, int32_t* fin_length /* [N] */, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Fused actor-critic rollout collector.  Replaces _collect_trajectories (marlbase/ac/train.py:24-119)
+ * for N vector envs in one launch: envs.reset() -> while running.any(): A2CNetwork.act (actor MLP ->
+ * Categorical sample, ac/model.py:147-153) -> envs.step (auto-reset) -> masked writes of the running envs.
+ * actor_params: [P][nparams] blocks of actor.independent.{i}.network.* (same layout as the Q-networks).
+ * Outputs in the reference's time-major Batch layout (ac/train.py:36-49), fully written (zeros where the
+ * reference leaves its fresh zeros): batch_obs f32 [T+1][N][P*D] (agents concatenated), batch_act i64
+ * [T][N][P], batch_rew f32 [T][N][P], batch_done u8 [T+1][N], batch_filled f32 [T][N]; per-env episode
+ * statistics as info["final_info"][i] carries them; t_max[0] = the reference's returned `t`.
+ * Sampling = inverse CDF of the fp32 softmax with one Philox uniform per (env, step, agent); reset stream
+ * index 2*round, auto-reset observation from 2*round+1.
+ * ---------------------------------------------------------------------------------------- */
+int marlhip_ac_collect(const marlhip_lbf_config* cfg, const marlhip_net_shape* s, const float* actor_params,
+                       uint32_t round, int32_t max_len, int32_t use_proper_termination, float* batch_obs,
+                       int64_t* batch_act, float* batch_rew, uint8_t* batch_done, float* batch_filled,
+                       float* fin_return /* [P][N] */, int32_t* fin_length /* [N] */, int32_t* t_max /* [1] */,
+                       void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * n learner updates from one call: n x (marlhip_replay_sample with device-drawn indices ->
  * marlhip_dqn_loss_grad -> marlhip_dqn_clip_adam), with QNetwork.update's bookkeeping
  * (marlbase/dqn/model.py:165-185): *updates += 1 per update, hard target copy when

@@ -33,6 +33,8 @@ def import_reference():
     spaces = types.ModuleType("gymnasium.spaces")
 
     def flatdim(space):
+        if isinstance(space, (tuple, list)):  # gymnasium flattens a Tuple space to the sum of its parts
+            return sum(flatdim(s) for s in space)
         return int(space.n) if hasattr(space, "n") else int(np.prod(space.shape))
 
     spaces.flatdim = flatdim
@@ -241,5 +243,82 @@ def vdn_fixture(ref_model, ref_train):
     print(f"learner_vdn_H64: loss0={out['loss0']:.6f} losses={losses}")
 
 
+def scripted_policy(obss, t, rng):
+    """walk to the first listed food and load it (with 20 % random actions) - makes some episodes end early"""
+    P, N = len(obss), obss[0].shape[0]
+    acts = np.zeros((N, P), np.int64)
+    for p in range(P):
+        for n in range(N):
+            o = obss[p][n]
+            F = (len(o) - 3 * P) // 3
+            sy, sx = o[3 * F], o[3 * F + 1]
+            a = 0
+            for f in range(F):
+                fy, fx, fl = o[3 * f:3 * f + 3]
+                if fl > 0:
+                    dy, dx = fy - sy, fx - sx
+                    if abs(dy) + abs(dx) == 1:
+                        a = 5
+                    elif dy != 0 and not (abs(dy) == 1 and dx == 0):
+                        a = 2 if dy > 0 else 1
+                    else:
+                        a = 4 if dx > 0 else 3
+                    break
+            if rng.random() < 0.2:
+                a = int(rng.integers(0, 6))
+            acts[n, p] = a
+    return acts
+
+
+def ac_fixture():
+    """ac_collect.npz: the reference's own _collect_trajectories (marlbase/ac/train.py:24-119) driven by
+    oracle.ac_port.OracleVecEnv and a scripted policy; pins oracle.ac_port.collect_trajectories."""
+    import_reference()
+    from marlbase.ac import train as ref_ac
+
+    from oracle.ac_port import OracleVecEnv
+
+    name, N, T, seed = "lbforaging:Foraging-8x8-2p-3f-v3", 12, 25, 31
+    vec = OracleVecEnv(name, N, T, seed)
+    P, D = vec.n_agents, vec.obs_dim
+
+    class SpaceBox:
+        def __init__(self, shape):
+            self.shape = shape
+
+    class VecFacade:  # the gymnasium.vector attributes the reference touches (ac/train.py:32-34)
+        observation_space = [SpaceBox((N, D))] * P
+        single_observation_space = tuple(SpaceBox((D,)) for _ in range(P))
+        single_action_space = tuple(Discrete(6) for _ in range(P))
+
+        def reset(self):
+            return vec.reset()
+
+        def step(self, actions):  # reference passes [P][N] nested lists (ac/train.py:79-81)
+            return vec.step(np.asarray(actions).T)
+
+    rng = np.random.default_rng(9)
+    log = []
+
+    class Model:
+        def init_actor_hiddens(self, n):
+            return None
+
+        def act(self, obss, hiddens, action_mask=None):
+            a = scripted_policy([o.numpy() for o in obss], len(log), rng)
+            log.append(a)
+            return torch.tensor(a.T).unsqueeze(-1), hiddens  # [P][N][1] like torch.stack(dist.sample())
+
+    t, batch, infos = ref_ac._collect_trajectories(VecFacade(), Model(), T, N, P, "cpu", False)
+    lens = batch.filled.sum(0).numpy()
+    np.savez_compressed(os.path.join(OUT, "ac_collect.npz"), name=name, N=N, T=T, seed=seed, t=t, actions_log=np.stack(log),
+                        obss=batch.obss.numpy(), actions=batch.actions.numpy(), rewards=batch.rewards.numpy(),
+                        dones=batch.dones.numpy(), filled=batch.filled.numpy(),
+                        info_returns=np.stack([i["episode_returns"] for i in infos]),
+                        info_lengths=np.array([i["episode_length"] for i in infos]))
+    print("ac_collect: t", t, "episode lengths", lens, "infos", len(infos))
+
+
 if __name__ == "__main__":
     vdn_fixture(*import_reference())
+    ac_fixture()
