@@ -603,6 +603,12 @@ __global__ __launch_bounds__(256) void adam_kernel(int64_t n, int nblocks, float
     }
 }
 
+}  // namespace marl
+
+#include "dqn_update_tp.h"
+
+namespace marl {
+
 // n <= 128k parameters: norm + clip + Adam + target in ONE workgroup (one launch instead of two)
 __global__ __launch_bounds__(1024) void adam_fused_kernel(int64_t n, float* __restrict__ params, const float* __restrict__ grad,
                                                           float* __restrict__ m, float* __restrict__ v, float* __restrict__ target,
@@ -693,7 +699,7 @@ __global__ __launch_bounds__(256) void vdn_mix_kernel(MixBufs mix, int P, int T,
     }
 }
 
-// workspace layout (floats unless noted): [partial records][pad16][packs][mixer buffers (2P+5) T B][pad8][128 B phase counters]
+// workspace layout (floats unless noted): [partial records][pad16][packs][mixer buffers (4P+5) T B][pad8][128 B phase counters]
 struct WsLayout {
     int64_t rec_bytes, pack_off, mix_off, total;
 };
@@ -703,14 +709,69 @@ inline WsLayout ws_layout(int P, int nwg, int rec, int pack, int T, int B) {
     w.rec_bytes = (int64_t)P * nwg * rec * sizeof(float);
     w.pack_off = (w.rec_bytes + 15) & ~(int64_t)15;
     w.mix_off = w.pack_off + (int64_t)P * pack * sizeof(float);
-    w.total = ((w.mix_off + (int64_t)(2 * P + 5) * T * B * sizeof(float) + 7) & ~(int64_t)7) + 128;
+    w.total = ((w.mix_off + (int64_t)(4 * P + 5) * T * B * sizeof(float) + 7) & ~(int64_t)7) + 128;  // mixer buffers of either path
     return w;
+}
+
+// hidden 128: tensor-parallel passes (dqn_update_tp.h) - pass F, mixer, pass B, reduce
+inline UpdPlan upd_plan_tp(int P, int T, int B, int NB) {  // one workgroup per CU, tasks = (block set, time chunk)
+    const int nsets = (B + 16 * NB - 1) / (16 * NB);
+    const int want = 256 / P > 1 ? 256 / P : 1;
+    int nc = (want + nsets - 1) / nsets;
+    if (nc < 1) nc = 1;
+    if (nc > T) nc = T;
+    int nwg = nsets * nc;
+    if (nwg > want) nwg = want;
+    UpdPlan pl = {nwg, nc};
+    return pl;
+}
+
+template <class S, bool REPLAY>
+int launch_lossgrad_tp(const marlhip_net_shape* s, const float* params, const float* tparams, const marlhip_batch* bt,
+                       const ReplaySrc& src, float gamma, int double_q, int mode, void* ws, int64_t ws_bytes, float* grad,
+                       float* loss, hipStream_t st) {
+    constexpr int W = 4, TPW = S::H / 64, NB = 2, NT = W * TPW, REC = S::NPARAM + 2;
+    const int P = s->n_agents, T = bt->max_len, B = bt->batch;
+    const UpdPlan pl = upd_plan_tp(P, T, B, NB);
+    const WsLayout wl = ws_layout(P, pl.nwg, REC, 0, T, B);
+    MARL_REQUIRE(ws_bytes >= wl.total, "dqn_loss_grad: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)wl.total);
+    float* mixf = reinterpret_cast<float*>(static_cast<char*>(ws) + wl.mix_off);
+    const size_t tb = (size_t)T * B;
+    TpMix mix;
+    mix.chosen = mixf; mix.tqsel = mixf + P * tb; mix.rew = mixf + 2 * P * tb; mix.dq = mixf + 3 * P * tb;
+    mix.dn = mixf + 4 * P * tb; mix.fl = mix.dn + tb; mix.lrow = mix.fl + tb;
+    const size_t ldsF = (size_t)(2 * NB * NT + 2 * NB * W) * 256 * sizeof(float);
+    const size_t ldsB = (size_t)(NB * NT * 256 + NB * S::H * 16 + NB * NT * 256 + W * 256 * (1 + 3 * TPW)) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tp_fwd_kernel<S, W, TPW, REPLAY, NB>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsF);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tp_bwd_kernel<S, W, TPW, REPLAY, NB>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsB);
+        attr_set = true;
+    }
+    const dim3 grid(pl.nwg, P), block(64 * W);
+    timing_begin(TIMER_LOSSGRAD, st);
+    hipLaunchKernelGGL((tp_fwd_kernel<S, W, TPW, REPLAY, NB>), grid, block, ldsF, st, params, tparams, *bt, src, mix, double_q,
+                       pl.n_chunks);
+    hipLaunchKernelGGL(tp_mix_kernel, dim3((unsigned)((tb + 255) / 256 > 1024 ? 1024 : (tb + 255) / 256)), dim3(256), 0, st, mix, P, T,
+                       B, gamma, mode == 1 ? 1 : 0);
+    hipLaunchKernelGGL((tp_bwd_kernel<S, W, TPW, REPLAY, NB>), grid, block, ldsB, st, params, *bt, src, mix, pl.n_chunks, (float*)ws);
+    timing_end(TIMER_LOSSGRAD, st);
+    MARL_CHECK_LAUNCH("tp_lossgrad");
+    const int n = P * S::NPARAM;
+    hipLaunchKernelGGL(dqn_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, st, (const float*)ws, P, pl.nwg, S::NPARAM, grad, loss);
+    MARL_CHECK_LAUNCH("dqn_reduce_kernel");
+    return 0;
 }
 
 template <class S, bool REPLAY>
 int launch_lossgrad_src(const marlhip_net_shape* s, const float* params, const float* tparams, const marlhip_batch* bt,
                         const ReplaySrc& src, float gamma, int double_q, int mode, void* ws, int64_t ws_bytes, float* grad,
                         float* loss, hipStream_t st) {
+    if constexpr (S::H > 64) {
+        return launch_lossgrad_tp<S, REPLAY>(s, params, tparams, bt, src, gamma, double_q, mode, ws, ws_bytes, grad, loss, st);
+    } else {
     using L = UpdLds<S>;
     const int P = s->n_agents, T = bt->max_len, B = bt->batch;
     const UpdPlan pl = upd_plan(P, T, B);
@@ -758,6 +819,7 @@ int launch_lossgrad_src(const marlhip_net_shape* s, const float* params, const f
     hipLaunchKernelGGL(dqn_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, st, (const float*)ws, P, pl.nwg, S::NPARAM, grad, loss);
     MARL_CHECK_LAUNCH("dqn_reduce_kernel");
     return 0;
+    }
 }
 
 template <class S>
@@ -774,7 +836,9 @@ int launch_lossgrad(const marlhip_net_shape* s, const float* params, const float
 using namespace marl;
 
 // shapes with an update kernel (H=64: packs + tiles = 108 KB LDS, dW accumulators in registers)
-#define MARL_UPD_SHAPES(X) X(12, 64, 6) X(15, 64, 6) X(18, 64, 6) X(21, 64, 6) X(24, 64, 6) X(27, 64, 6) X(39, 64, 6)
+#define MARL_UPD_SHAPES(X)                                                                                 \
+    X(12, 64, 6) X(15, 64, 6) X(18, 64, 6) X(21, 64, 6) X(24, 64, 6) X(27, 64, 6) X(39, 64, 6)             \
+    X(12, 128, 6) X(15, 128, 6) X(18, 128, 6) X(21, 128, 6) X(24, 128, 6) X(27, 128, 6) X(39, 128, 6)
 
 extern "C" int marlhip_net_nparams(const marlhip_net_shape* s) {
     MARL_REQUIRE(s != nullptr, "net shape is NULL");
@@ -788,7 +852,7 @@ extern "C" int marlhip_net_nparams(const marlhip_net_shape* s) {
 extern "C" int64_t marlhip_dqn_workspace_bytes(const marlhip_net_shape* s, int32_t max_len, int32_t batch) {
     const int np = marlhip_net_nparams(s);
     if (np < 0) return -1;
-    const UpdPlan pl = upd_plan(s->n_agents, max_len, batch);
+    const UpdPlan pl = s->hidden > 64 ? upd_plan_tp(s->n_agents, max_len, batch, 2) : upd_plan(s->n_agents, max_len, batch);
     // partial records + 16 B alignment slack + weight packs (<= 4 x nparams-padded floats per agent; see launch_lossgrad)
     int64_t pack = -1;
 #define X(d, h, a) if (s->obs_dim == d && s->hidden == h && s->n_actions == a) pack = 2 * MlpShape<d, h, a>::NFWD + MlpShape<d, h, a>::NBWD;

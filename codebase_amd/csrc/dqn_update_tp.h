@@ -1,0 +1,560 @@
+// Hidden-dimension tensor-parallel learner kernels (hidden = 16 * W * TPW; built for hidden 128 = 4 waves x 2 tiles).
+// Included by dqn_update.hip after its helpers (tile_write / tile_read / sum16 / ReplaySrc / MixBufs).
+//
+// Why a second formulation: at hidden 128 the single-wave kernel of dqn_update.hip would need 256 accumulator
+// registers for dW2 alone and 240 KB of LDS weight packs.  Here a workgroup of W waves owns a row block
+// together: wave w holds the weights and the gradient accumulators of ITS hidden tiles in REGISTERS (the 512 KB
+// register file of a CU is the only on-chip store large enough), activations are exchanged through LDS:
+//   pass F  : critic + target forward -> chosen_p[t][b], bootstrap value tqsel_p[t][b]       (no accumulators)
+//   mixer   : IDQN (per agent) or VDN (sum) -> dq_p[t][b] = dL/dchosen_p, per-row loss        (tiny kernel)
+//   pass B  : critic forward again (layers 1-2 only) + backward with dq; every wave writes its own gradient slice
+// oracle/mfma_emul_tp.py is the lane-level statement of this file (checked against torch autograd on CPU).
+// Layer 3 is split-K over the waves (each wave multiplies its own h2 tiles, partial Q summed in wave order).
+#pragma once
+
+namespace marl {
+
+struct TpMix {
+    float* chosen;  // [P][T][B]
+    float* tqsel;   // [P][T][B]
+    float* rew;     // [P][T][B]
+    float* dn;      // [T][B]
+    float* fl;      // [T][B]
+    float* dq;      // [P][T][B]
+    float* lrow;    // [T][B]
+};
+
+// register image of the weights of one owned hidden tile
+template <class S, int NT>
+struct TpTileW {
+    float a1[S::KS1];  // W1[16tau+i][4ks+g]
+    f4 a2[NT];         // W2[16tau+i][16kap+4g+r]
+    f4 b1s, b2s;       // b1[16tau+4g+r], b2[...]
+};
+
+template <class S, int NT>
+__device__ __forceinline__ void tp_load_fwd(const float* __restrict__ w, int tau, int lane, TpTileW<S, NT>& t) {
+    const int g = lane >> 4, i = lane & 15;
+#pragma unroll
+    for (int ks = 0; ks < S::KS1; ++ks) {
+        const int k = 4 * ks + g;
+        t.a1[ks] = k < S::D ? w[S::oW1 + (16 * tau + i) * S::D + k] : 0.f;
+    }
+#pragma unroll
+    for (int kap = 0; kap < NT; ++kap)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t.a2[kap][r] = w[S::oW2 + (16 * tau + i) * S::H + 16 * kap + 4 * g + r];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        t.b1s[r] = w[S::ob1 + 16 * tau + 4 * g + r];
+        t.b2s[r] = w[S::ob2 + 16 * tau + 4 * g + r];
+    }
+}
+
+// rows of one 16-episode block at one time step
+template <class S, bool REPLAY>
+struct TpRows {
+    static constexpr int NT1 = S::DP / 16;
+    float x[S::KS1];
+    float bx[NT1][4];
+    int a_sel;
+    float rw, dn, fl, dq, lr;
+};
+
+template <class S, bool REPLAY>
+struct TpSrc {  // everything load_rows needs, per block
+    const float* obs_p;
+    const int64_t* act_p;
+    const float* rew_p;
+    const float* dones;
+    const float* filled;
+    ReplaySrc rs;
+    int P, p, T, B;
+};
+
+template <class S, bool REPLAY, bool BWD>
+__device__ __forceinline__ void tp_load_rows(const TpSrc<S, REPLAY>& s, const TpMix& mix, int t, int b0, int g, int j, int ej,
+                                             const int (&eg)[4], TpRows<S, REPLAY>& R) {
+    constexpr int D = S::D, NT1 = S::DP / 16;
+    const int T = s.T, B = s.B, p = s.p;
+    const int bj = (b0 + j) < B ? b0 + j : B - 1;
+    const int tt = t < T ? t : T - 1;
+    if (REPLAY) {
+        const float* xrow = s.rs.rb.obs + (((size_t)ej * s.P + p) * (T + 1) + t) * D;
+#pragma unroll
+        for (int ks = 0; ks < S::KS1; ++ks) {
+            const int d = 4 * ks + g;
+            R.x[ks] = xrow[d < D ? d : D - 1];
+        }
+        if (BWD) {
+#pragma unroll
+            for (int nt = 0; nt < NT1; ++nt)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int d = 16 * nt + j;
+                    R.bx[nt][ks] = s.rs.rb.obs[(((size_t)eg[ks] * s.P + p) * (T + 1) + t) * D + (d < D ? d : D - 1)];
+                }
+        }
+        R.a_sel = (int)s.rs.rb.act[((size_t)ej * s.P + p) * T + tt];
+        R.rw = s.rs.rb.rew[((size_t)ej * s.P + p) * T + tt];
+        R.dn = s.rs.rb.done[(size_t)ej * (T + 1) + tt + 1] ? 1.f : 0.f;
+        R.fl = s.rs.rb.filled[(size_t)ej * T + tt] ? 1.f : 0.f;
+    } else {
+        const float* xrow = s.obs_p + ((size_t)t * B + bj) * D;
+#pragma unroll
+        for (int ks = 0; ks < S::KS1; ++ks) {
+            const int d = 4 * ks + g;
+            R.x[ks] = xrow[d < D ? d : D - 1];
+        }
+        if (BWD) {
+#pragma unroll
+            for (int nt = 0; nt < NT1; ++nt)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int row = b0 + 4 * g + ks, d = 16 * nt + j;
+                    R.bx[nt][ks] = s.obs_p[((size_t)t * B + (row < B ? row : B - 1)) * D + (d < D ? d : D - 1)];
+                }
+        }
+        R.a_sel = (int)s.act_p[(size_t)tt * B + bj];
+        R.rw = s.rew_p[(size_t)tt * B + bj];
+        R.dn = s.dones[(size_t)(tt + 1) * B + bj];
+        R.fl = s.filled[(size_t)tt * B + bj];
+    }
+    if (BWD) {
+        R.dq = mix.dq[((size_t)p * T + tt) * B + bj];
+        R.lr = mix.lrow[(size_t)tt * B + bj];
+    }
+}
+
+template <class S, bool REPLAY, bool BWD>
+__device__ __forceinline__ void tp_mask_rows(TpRows<S, REPLAY>& R, int b0, int B, int g, int j) {
+    constexpr int D = S::D, NT1 = S::DP / 16;
+    const bool rowok = (b0 + j) < B;
+#pragma unroll
+    for (int ks = 0; ks < S::KS1; ++ks) R.x[ks] = (4 * ks + g < D && rowok) ? R.x[ks] : 0.f;
+    if (BWD) {
+#pragma unroll
+        for (int nt = 0; nt < NT1; ++nt)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) R.bx[nt][ks] = (b0 + 4 * g + ks < B && 16 * nt + j < D) ? R.bx[nt][ks] : 0.f;
+        R.dq = rowok ? R.dq : 0.f;
+        R.lr = rowok ? R.lr : 0.f;
+    }
+    R.fl = rowok ? R.fl : 0.f;
+}
+
+template <bool REPLAY>
+__device__ __forceinline__ void tp_episode_ids(const ReplaySrc& rs, int b0, int B, int g, int j, int& ej, int (&eg)[4]) {
+    ej = 0;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) eg[ks] = 0;
+    if (REPLAY) {
+        const int bj = (b0 + j) < B ? b0 + j : B - 1;
+        ej = rs.idx ? rs.idx[bj] : replay_draw(rs, bj);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int row = b0 + 4 * g + ks, rc = row < B ? row : B - 1;
+            eg[ks] = rs.idx ? rs.idx[rc] : replay_draw(rs, rc);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// pass F: forward of critic and target, workgroup = W waves, NB row blocks per step
+// LDS (floats): Hc[NB][NT][256] | Ht[NB][NT][256] | Qp[NB][W][256] | Tp[NB][W][256]
+// ---------------------------------------------------------------------------------------------------------
+template <class S, int W, int TPW, bool REPLAY, int NB>
+__global__ __launch_bounds__(64 * W, 1) void tp_fwd_kernel(const float* __restrict__ params, const float* __restrict__ tparams,
+                                                           marlhip_batch bt, ReplaySrc rs, TpMix mix, int double_q, int n_chunks) {
+    constexpr int NT = W * TPW, A = S::A;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    f4* Hc = reinterpret_cast<f4*>(lds);
+    f4* Ht = Hc + NB * NT * 64;
+    f4* Qp = Ht + NB * NT * 64;
+    f4* Tp = Qp + NB * W * 64;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, j = lane & 15;
+    const int p = blockIdx.y, P = gridDim.y;
+    const int T = bt.max_len, B = bt.batch;
+
+    TpTileW<S, NT> cw[TPW], tw[TPW];
+    f4 ca3[TPW], ta3[TPW], cb3, tb3;
+    {
+        const float* wc = params + (size_t)p * S::NPARAM;
+        const float* wt = tparams + (size_t)p * S::NPARAM;
+#pragma unroll
+        for (int u = 0; u < TPW; ++u) {
+            const int tau = wave * TPW + u;
+            tp_load_fwd<S, NT>(wc, tau, lane, cw[u]);
+            tp_load_fwd<S, NT>(wt, tau, lane, tw[u]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {  // split-K layer 3: A operand W3[i][16tau+4g+r]
+                ca3[u][r] = j < A ? wc[S::oW3 + j * S::H + 16 * tau + 4 * g + r] : 0.f;
+                ta3[u][r] = j < A ? wt[S::oW3 + j * S::H + 16 * tau + 4 * g + r] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int a = 4 * g + r;
+            cb3[r] = (wave == 0 && a < A) ? wc[S::ob3 + a] : 0.f;
+            tb3[r] = (wave == 0 && a < A) ? wt[S::ob3 + a] : 0.f;
+        }
+    }
+    TpSrc<S, REPLAY> src;
+    src.obs_p = REPLAY ? nullptr : bt.obss + (size_t)p * (T + 1) * B * S::D;
+    src.act_p = REPLAY ? nullptr : bt.actions + (size_t)p * T * B;
+    src.rew_p = REPLAY ? nullptr : bt.rewards + (size_t)p * T * B;
+    src.dones = bt.dones; src.filled = bt.filled; src.rs = rs; src.P = P; src.p = p; src.T = T; src.B = B;
+
+    const int nsets = (B + 16 * NB - 1) / (16 * NB);
+    const int ntasks = nsets * n_chunks;
+    for (int task = blockIdx.x; task < ntasks; task += gridDim.x) {
+        const int set = task / n_chunks, c = task - set * n_chunks;
+        const int t0 = (c * T) / n_chunks, t1 = ((c + 1) * T) / n_chunks;
+        if (t1 <= t0) continue;  // uniform over the workgroup
+        int ej[NB], eg[NB][4];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) tp_episode_ids<REPLAY>(rs, (set * NB + nb) * 16, B, g, j, ej[nb], eg[nb]);
+        if (REPLAY && rs.idx_out != nullptr && p == 0 && c == 0 && wave == 0 && g == 0) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+                if ((set * NB + nb) * 16 + j < B) rs.idx_out[(set * NB + nb) * 16 + j] = ej[nb];
+        }
+        TpRows<S, REPLAY> cur[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) tp_load_rows<S, REPLAY, false>(src, mix, t1, (set * NB + nb) * 16, g, j, ej[nb], eg[nb], cur[nb]);
+        for (int t = t1; t >= t0; --t) {
+            TpRows<S, REPLAY> nxt[NB];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                tp_load_rows<S, REPLAY, false>(src, mix, t > t0 ? t - 1 : t0, (set * NB + nb) * 16, g, j, ej[nb], eg[nb], nxt[nb]);
+                tp_mask_rows<S, REPLAY, false>(cur[nb], (set * NB + nb) * 16, B, g, j);
+            }
+            const bool need_t = t > t0;  // the target value of this step feeds transition t-1
+            // ---- layer 1 of my tiles, dumped for everybody
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int u = 0; u < TPW; ++u) {
+                    f4 acc = cw[u].b1s, acct = tw[u].b1s;
+#pragma unroll
+                    for (int ks = 0; ks < S::KS1; ++ks) {
+                        acc = MARL_MFMA(cw[u].a1[ks], cur[nb].x[ks], acc);
+                        acct = MARL_MFMA(tw[u].a1[ks], cur[nb].x[ks], acct);
+                    }
+                    Hc[(nb * NT + wave * TPW + u) * 64 + lane] = relu4(acc);
+                    Ht[(nb * NT + wave * TPW + u) * 64 + lane] = relu4(acct);
+                }
+            __syncthreads();
+            // ---- layer 2 of my tiles + my split-K share of layer 3
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                f4 q = cb3, tq = tb3;
+#pragma unroll
+                for (int u = 0; u < TPW; ++u) {
+                    f4 acc = cw[u].b2s, acct = tw[u].b2s;
+#pragma unroll
+                    for (int kap = 0; kap < NT; ++kap) {
+                        const f4 hk = Hc[(nb * NT + kap) * 64 + lane];
+                        const f4 gk = Ht[(nb * NT + kap) * 64 + lane];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            acc = MARL_MFMA(cw[u].a2[kap][r], hk[r], acc);
+                            acct = MARL_MFMA(tw[u].a2[kap][r], gk[r], acct);
+                        }
+                    }
+                    acc = relu4(acc);
+                    acct = relu4(acct);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        q = MARL_MFMA(ca3[u][r], acc[r], q);
+                        tq = MARL_MFMA(ta3[u][r], acct[r], tq);
+                    }
+                }
+                Qp[(nb * W + wave) * 64 + lane] = q;
+                Tp[(nb * W + wave) * 64 + lane] = tq;
+            }
+            __syncthreads();
+            // ---- wave 0 finishes Q (partials summed in wave order) and publishes the mixer inputs
+            if (wave == 0) {
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const int b0 = (set * NB + nb) * 16;
+                    const bool rowok = (b0 + j) < B;
+                    const int bj = rowok ? b0 + j : B - 1;
+                    f4 q = Qp[(nb * W + 0) * 64 + lane], tq = Tp[(nb * W + 0) * 64 + lane];
+#pragma unroll
+                    for (int w2 = 1; w2 < W; ++w2) {
+                        q += Qp[(nb * W + w2) * 64 + lane];
+                        tq += Tp[(nb * W + w2) * 64 + lane];
+                    }
+                    if (t < t1) {
+                        const float ch = gather_rows(q, lane, cur[nb].a_sel);
+                        if (g == 0 && rowok) {
+                            mix.chosen[((size_t)p * T + t) * B + bj] = ch;
+                            mix.rew[((size_t)p * T + t) * B + bj] = cur[nb].rw;
+                            if (p == 0) {
+                                mix.dn[(size_t)t * B + bj] = cur[nb].dn;
+                                mix.fl[(size_t)t * B + bj] = cur[nb].fl;
+                            }
+                        }
+                    }
+                    if (need_t) {
+                        const int a_p = double_q ? argmax_rows<A>(q, lane) : argmax_rows<A>(tq, lane);
+                        const float tv = gather_rows(tq, lane, a_p);
+                        if (g == 0 && rowok) mix.tqsel[((size_t)p * T + (t - 1)) * B + bj] = tv;
+                    }
+                }
+            }
+            __syncthreads();  // LDS slots are rewritten by the next step
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) cur[nb] = nxt[nb];
+        }
+    }
+}
+
+// mixers: dq_p[t][b] = dL/dchosen_p (unnormalised), lrow[t][b] = per-row loss (dqn/model.py:152,160-163 / 254-269)
+__global__ __launch_bounds__(256) void tp_mix_kernel(TpMix mix, int P, int T, int B, float gamma, int vdn) {
+    const int n = T * B;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const float fl = mix.fl[i], nd = 1.f - mix.dn[i];
+        if (vdn) {
+            float ch = 0.f, tq = 0.f;
+            for (int p = 0; p < P; ++p) {
+                ch += mix.chosen[(size_t)p * n + i];
+                tq += mix.tqsel[(size_t)p * n + i];
+            }
+            const float delta = ch - (mix.rew[i] + gamma * tq * nd);
+            for (int p = 0; p < P; ++p) mix.dq[(size_t)p * n + i] = 2.f * fl * delta;
+            mix.lrow[i] = fl * delta * delta;
+        } else {
+            float l = 0.f;
+            for (int p = 0; p < P; ++p) {
+                const float delta = mix.chosen[(size_t)p * n + i] - (mix.rew[(size_t)p * n + i] + gamma * mix.tqsel[(size_t)p * n + i] * nd);
+                mix.dq[(size_t)p * n + i] = 2.f * fl * delta;
+                l += delta * delta;  // sum over agents (mse_loss(...).sum(dim=0), model.py:160-162)
+            }
+            mix.lrow[i] = fl * l;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// pass B: critic layers 1-2 forward + backward with the external dq; gradient slices stay with their wave
+// LDS (floats): Hc[NB][NT][256] | HcT[NB][H][16] | G2[NB][NT][256] | per wave: PQ[256] + (P2,PH2,P1)[TPW][256]
+// ---------------------------------------------------------------------------------------------------------
+template <class S, int W, int TPW, bool REPLAY, int NB>
+__global__ __launch_bounds__(64 * W, 1) void tp_bwd_kernel(const float* __restrict__ params, marlhip_batch bt, ReplaySrc rs, TpMix mix,
+                                                           int n_chunks, float* __restrict__ partials) {
+    constexpr int NT = W * TPW, A = S::A, D = S::D, H = S::H, NT1 = S::DP / 16;
+    constexpr int PRIV = 256 * (1 + 3 * TPW);
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    f4* Hc = reinterpret_cast<f4*>(lds);
+    float* HcT = lds + NB * NT * 256;
+    f4* G2 = reinterpret_cast<f4*>(HcT + NB * H * 16);
+    float* priv = HcT + NB * H * 16 + NB * NT * 256;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, j = lane & 15;
+    float* PQ = priv + wave * PRIV;
+    float* P2 = PQ + 256;
+    float* PH2 = P2 + 256 * TPW;
+    float* P1 = PH2 + 256 * TPW;
+    const int p = blockIdx.y, P = gridDim.y;
+    const int T = bt.max_len, B = bt.batch;
+
+    TpTileW<S, NT> cw[TPW];
+    f4 t3[TPW], t2[TPW][NT];
+    {
+        const float* wc = params + (size_t)p * S::NPARAM;
+#pragma unroll
+        for (int u = 0; u < TPW; ++u) {
+            const int tau = wave * TPW + u;
+            tp_load_fwd<S, NT>(wc, tau, lane, cw[u]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int a = 4 * g + r;
+                t3[u][r] = a < A ? wc[S::oW3 + a * H + 16 * tau + j] : 0.f;  // A[i=h2 16tau+i][k=a]
+#pragma unroll
+                for (int kap = 0; kap < NT; ++kap) t2[u][kap][r] = wc[S::oW2 + (16 * kap + 4 * g + r) * H + 16 * tau + j];
+            }
+        }
+    }
+    const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f4 dW2[TPW][NT], dW1[TPW][NT1], dW3[TPW], db1[TPW], db2[TPW], db3 = zero4;
+#pragma unroll
+    for (int u = 0; u < TPW; ++u) {
+        dW3[u] = zero4; db1[u] = zero4; db2[u] = zero4;
+#pragma unroll
+        for (int k = 0; k < NT; ++k) dW2[u][k] = zero4;
+#pragma unroll
+        for (int k = 0; k < NT1; ++k) dW1[u][k] = zero4;
+    }
+    float loss_acc = 0.f, nfill_acc = 0.f;
+
+    TpSrc<S, REPLAY> src;
+    src.obs_p = REPLAY ? nullptr : bt.obss + (size_t)p * (T + 1) * B * D;
+    src.act_p = REPLAY ? nullptr : bt.actions + (size_t)p * T * B;
+    src.rew_p = REPLAY ? nullptr : bt.rewards + (size_t)p * T * B;
+    src.dones = bt.dones; src.filled = bt.filled; src.rs = rs; src.P = P; src.p = p; src.T = T; src.B = B;
+
+    const int nsets = (B + 16 * NB - 1) / (16 * NB);
+    const int ntasks = nsets * n_chunks;
+    for (int task = blockIdx.x; task < ntasks; task += gridDim.x) {
+        const int set = task / n_chunks, c = task - set * n_chunks;
+        const int t0 = (c * T) / n_chunks, t1 = ((c + 1) * T) / n_chunks;
+        if (t1 <= t0) continue;
+        int ej[NB], eg[NB][4];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) tp_episode_ids<REPLAY>(rs, (set * NB + nb) * 16, B, g, j, ej[nb], eg[nb]);
+        TpRows<S, REPLAY> cur[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) tp_load_rows<S, REPLAY, true>(src, mix, t1 - 1, (set * NB + nb) * 16, g, j, ej[nb], eg[nb], cur[nb]);
+        for (int t = t1 - 1; t >= t0; --t) {
+            TpRows<S, REPLAY> nxt[NB];
+            f4 h1[NB][TPW];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                tp_load_rows<S, REPLAY, true>(src, mix, t > t0 ? t - 1 : t0, (set * NB + nb) * 16, g, j, ej[nb], eg[nb], nxt[nb]);
+                tp_mask_rows<S, REPLAY, true>(cur[nb], (set * NB + nb) * 16, B, g, j);
+            }
+            // ---- layer 1 of my tiles: C-layout dump (layer-2 operand) + [h][row] tile (dW2 operand)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int u = 0; u < TPW; ++u) {
+                    f4 acc = cw[u].b1s;
+#pragma unroll
+                    for (int ks = 0; ks < S::KS1; ++ks) acc = MARL_MFMA(cw[u].a1[ks], cur[nb].x[ks], acc);
+                    acc = relu4(acc);
+                    h1[nb][u] = acc;
+                    const int tau = wave * TPW + u;
+                    Hc[(nb * NT + tau) * 64 + lane] = acc;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) HcT[(nb * H + 16 * tau + 4 * g + r) * 16 + j] = acc[r];
+                }
+            __syncthreads();
+            // ---- layer 2, dH2 = W3^T dQ (mask), dW3, dumps of dH2
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const int a_sel = cur[nb].a_sel;
+                f4 dQ[1];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dQ[0][r] = (4 * g + r == a_sel) ? cur[nb].dq : 0.f;
+                if (wave == 0) {
+                    db3 += dQ[0];
+                    if (g == 0 && p == 0) { loss_acc += cur[nb].lr; nfill_acc += cur[nb].fl; }
+                }
+                wave_lds_fence();
+                tile_write<1>(PQ, dQ, g, j);
+#pragma unroll
+                for (int u = 0; u < TPW; ++u) {
+                    f4 acc = cw[u].b2s;
+#pragma unroll
+                    for (int kap = 0; kap < NT; ++kap) {
+                        const f4 hk = Hc[(nb * NT + kap) * 64 + lane];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc = MARL_MFMA(cw[u].a2[kap][r], hk[r], acc);
+                    }
+                    f4 h2[1];
+                    h2[0] = relu4(acc);
+                    f4 d2[1];
+                    d2[0] = zero4;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) d2[0] = MARL_MFMA(t3[u][r], dQ[0][r], d2[0]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) d2[0][r] = h2[0][r] > 0.f ? d2[0][r] : 0.f;
+                    db2[u] += d2[0];
+                    G2[(nb * NT + wave * TPW + u) * 64 + lane] = d2[0];
+                    wave_lds_fence();
+                    tile_write<1>(PH2 + 256 * u, h2, g, j);
+                    wave_lds_fence();
+                    const f4 aQ = tile_read(PQ, 0, g, j);
+                    const f4 bH2 = tile_read(PH2 + 256 * u, 0, g, j);
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) dW3[u] = MARL_MFMA(aQ[ks], bH2[ks], dW3[u]);
+                }
+                wave_lds_fence();  // PQ / PH2 are rewritten by the next block
+            }
+            __syncthreads();
+            // ---- dH1 = W2^T dH2 (mask), dW2, dW1
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+                for (int u = 0; u < TPW; ++u) {
+                    const int tau = wave * TPW + u;
+                    f4 d1[1];
+                    d1[0] = zero4;
+#pragma unroll
+                    for (int kap = 0; kap < NT; ++kap) {
+                        const f4 gk = G2[(nb * NT + kap) * 64 + lane];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) d1[0] = MARL_MFMA(t2[u][kap][r], gk[r], d1[0]);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) d1[0][r] = h1[nb][u][r] > 0.f ? d1[0][r] : 0.f;
+                    db1[u] += d1[0];
+                    // transposed A operands: my dH2 tile (from its C dump) and my dH1 tile
+                    f4 d2[1];
+                    d2[0] = G2[(nb * NT + tau) * 64 + lane];
+                    wave_lds_fence();
+                    tile_write<1>(P2 + 256 * u, d2, g, j);
+                    tile_write<1>(P1 + 256 * u, d1, g, j);
+                    wave_lds_fence();
+                    const f4 aG2 = tile_read(P2 + 256 * u, 0, g, j);
+                    const f4 aG1 = tile_read(P1 + 256 * u, 0, g, j);
+#pragma unroll
+                    for (int nu = 0; nu < NT; ++nu) {
+                        const f4 bH1 = tile_read(HcT + nb * H * 16, nu, g, j);
+#pragma unroll
+                        for (int ks = 0; ks < 4; ++ks) dW2[u][nu] = MARL_MFMA(aG2[ks], bH1[ks], dW2[u][nu]);
+                    }
+#pragma unroll
+                    for (int nt = 0; nt < NT1; ++nt)
+#pragma unroll
+                        for (int ks = 0; ks < 4; ++ks) dW1[u][nt] = MARL_MFMA(aG1[ks], cur[nb].bx[nt][ks], dW1[u][nt]);
+                }
+            }
+            __syncthreads();  // Hc / HcT / G2 are rewritten by the next step
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) cur[nb] = nxt[nb];
+        }
+    }
+
+    // ---- every wave owns disjoint slices of the gradient: straight to the workgroup's partial record
+    float* rec = partials + ((size_t)p * gridDim.x + blockIdx.x) * (S::NPARAM + 2);
+#pragma unroll
+    for (int u = 0; u < TPW; ++u) {
+        const int tau = wave * TPW + u;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int o = 16 * tau + 4 * g + r;
+#pragma unroll
+            for (int nt = 0; nt < NT1; ++nt) {
+                const int d = 16 * nt + j;
+                if (d < D) rec[S::oW1 + o * D + d] = dW1[u][nt][r];
+            }
+#pragma unroll
+            for (int nu = 0; nu < NT; ++nu) rec[S::oW2 + o * H + 16 * nu + j] = dW2[u][nu][r];
+            const int a = 4 * g + r;
+            if (a < A) rec[S::oW3 + a * H + 16 * tau + j] = dW3[u][r];
+            const float s1 = sum16(db1[u][r]), s2 = sum16(db2[u][r]);
+            if (j == 0) {
+                rec[S::ob1 + o] = s1;
+                rec[S::ob2 + o] = s2;
+            }
+        }
+    }
+    if (wave == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int a = 4 * g + r;
+            const float s3 = sum16(db3[r]);
+            if (j == 0 && a < A) rec[S::ob3 + a] = s3;
+        }
+        const float ls = sum16(loss_acc), ns = sum16(nfill_acc);
+        if (lane == 0) {
+            rec[S::NPARAM] = ls;
+            rec[S::NPARAM + 1] = ns;
+        }
+    }
+}
+
+}  // namespace marl

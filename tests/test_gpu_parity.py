@@ -556,10 +556,6 @@ def test_edge_cases_tiny_batches_single_env_and_error_paths():
         np.testing.assert_allclose(grad.cpu().numpy(), gref, rtol=3e-4, atol=3e-5 * max(1.0, np.abs(gref).max()))
     # unsupported shapes fail loudly, nothing falls back
     with pytest.raises(MarlHipError):
-        h.DqnUpdater(h.NetSpec(2, 15, 128, 6), torch.zeros(2, h.NetSpec(2, 15, 128, 6).nparams(), device=DEV),
-                     torch.zeros(2, h.NetSpec(2, 15, 128, 6).nparams(), device=DEV)).loss_grad(
-            dev_batch(h, dp.synthetic_batch(2, 3, 4, 15, 6, seed=0)))
-    with pytest.raises(MarlHipError):
         h.NetSpec(2, 15, 96, 6).nparams()
     with pytest.raises(MarlHipError):
         h.BatchedForaging(h.lbf_config("lbforaging:Foraging-8x8-5p-7f-v3", 4, 25))
@@ -567,3 +563,60 @@ def test_edge_cases_tiny_batches_single_env_and_error_paths():
     rb = h.DeviceReplay(8, 2, 15, 5)
     with pytest.raises(MarlHipError):
         rb.sample(4, length=0)
+
+
+def test_hidden128_learner_matches_reference_golden():
+    """the reference's DEFAULT network (layers [128,128], configs/algorithm/idqn.yaml:8-10) through the
+    tensor-parallel kernels: loss, gradient and 3 updates vs the reference's own QNetwork golden"""
+    h = hip()
+    g = load("learner_H128.npz")
+    P, D, H, A = int(g["P"]), int(g["D"]), 128, int(g["A"])
+    spec = h.NetSpec(P, D, H, A)
+    params = torch.tensor(g["params0"], device=DEV)
+    target = torch.tensor(g["target0"], device=DEV)
+    up = h.DqnUpdater(spec, params, target, lr=3e-4, gamma=0.99, grad_clip=1.0, double_q=True)
+    loss, grad = up.loss_grad(dev_batch(h, golden_batch(g, 0)))
+    assert abs(loss.cpu().numpy()[0] - g["loss0"]) <= 1e-5 * abs(g["loss0"]), (loss, g["loss0"])
+    np.testing.assert_allclose(grad.cpu().numpy(), g["grad0"], rtol=1e-4, atol=2e-5)
+    g1 = grad.clone()
+    _, g2 = up.loss_grad(dev_batch(h, golden_batch(g, 0)))
+    assert torch.equal(g1, g2)  # bitwise reproducible
+    last = 0
+    for i in range(3):
+        loss, _ = up.loss_grad(dev_batch(h, golden_batch(g, i)))
+        hard = (i + 1 - last) >= 2
+        up.apply(hard_update=hard)
+        if hard:
+            last = i + 1
+        assert abs(loss.cpu().numpy()[0] - g["losses"][i]) <= 2e-5 * abs(g["losses"][i])
+        np.testing.assert_allclose(params.cpu().numpy(), g[f"params{i + 1}"], rtol=0, atol=3e-6)
+        np.testing.assert_allclose(target.cpu().numpy(), g[f"target{i + 1}"], rtol=0, atol=3e-6)
+
+
+@pytest.mark.parametrize("P,T,B,D,mode", [(2, 7, 20, 15, "idqn"), (2, 25, 33, 15, "vdn"), (4, 6, 64, 27, "idqn"), (2, 25, 1024, 15, "idqn"),
+                                          (2, 1, 1, 15, "idqn")])
+def test_hidden128_other_shapes_vs_torch_port(P, T, B, D, mode):
+    h = hip()
+    H, A = 128, 6
+    spec = h.NetSpec(P, D, H, A)
+    params = dp.init_params(P, D, H, A, seed=1) + 0.03
+    target = dp.init_params(P, D, H, A, seed=3)
+    batch = dp.synthetic_batch(P, T, B, D, A, seed=5)
+    pr = params.clone().requires_grad_(True)
+    ref = dp.compute_loss(pr, target, batch, 0.99, True, D, H, A, mode=mode)
+    ref.backward()
+    up = h.DqnUpdater(spec, params.to(DEV), target.to(DEV))
+    loss, grad = up.loss_grad(dev_batch(h, batch), mode=1 if mode == "vdn" else 0)
+    assert abs(loss.cpu().numpy()[0] - ref.item()) <= 3e-5 * max(abs(ref.item()), 1e-3)
+    gref = pr.grad.numpy()
+    np.testing.assert_allclose(grad.cpu().numpy(), gref, rtol=3e-4, atol=3e-5 * max(1.0, np.abs(gref).max()))
+    # in-kernel replay gather == Batch path
+    rb = h.DeviceReplay(B, P, D, T)
+    rb.obs.copy_(batch["obss"].permute(2, 0, 1, 3))
+    rb.act.copy_(batch["actions"].permute(2, 0, 1).to(torch.uint8))
+    rb.rew.copy_(batch["rewards"].permute(2, 0, 1))
+    rb.done.copy_(batch["dones"].t().to(torch.uint8))
+    rb.filled.copy_(batch["filled"].t().to(torch.uint8))
+    l1, g1 = loss.clone(), grad.clone()
+    l2, g2 = up.loss_grad_replay(rb, B, idx=torch.arange(B, dtype=torch.int32, device=DEV), mode=1 if mode == "vdn" else 0)
+    assert torch.equal(l1, l2) and torch.equal(g1, g2)
