@@ -93,3 +93,31 @@ def test_vdn_loss_grad_and_updates_match_reference():
         m = lr.update(batch_of(g, i))
         assert abs(m["loss"] - float(g["losses"][i])) <= 2e-5 * abs(float(g["losses"][i]))
         np.testing.assert_allclose(lr.flat().detach().numpy(), g[f"params{i + 1}"], rtol=0, atol=2e-6)
+
+
+@pytest.mark.parametrize("name", ["learner_qmix_H64.npz", "learner_qmix_p4_H64.npz"])
+def test_qmix_loss_grad_and_updates_match_reference(name):
+    """oracle/qmix_port.py against the reference's QMixNetwork (dqn/model.py:272-443): loss, critic and mixer
+    gradients, then 3 updates incl. the clip-critic-only rule and the hard target / target-mixer copy."""
+    from oracle import qmix_port as qp
+
+    g = load(name)
+    P, D, H, A = int(g["P"]), int(g["D"]), 64, int(g["A"])
+    params = torch.tensor(g["params0"]).requires_grad_(True)
+    mixer = torch.tensor(g["mixer0"]).requires_grad_(True)
+    assert mixer.numel() == qp.mixer_nparams(P, P * D)
+    loss = qp.compute_loss(params, torch.tensor(g["target0"]), mixer, torch.tensor(g["tmixer0"]), batch_of(g, 0), 0.99, True, D, H, A)
+    loss.backward()
+    assert abs(loss.item() - float(g["loss0"])) <= 1e-5 * abs(float(g["loss0"]))
+    np.testing.assert_allclose(params.grad.numpy(), g["grad0"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(mixer.grad.numpy(), g["mgrad0"], rtol=1e-4, atol=1e-4)
+    if "losses" not in g:
+        return
+    lr = qp.Learner(torch.tensor(g["params0"]), torch.tensor(g["mixer0"]), D, H, A, target_update_interval_or_tau=2)
+    lr.target, lr.tmixer = torch.tensor(g["target0"]), torch.tensor(g["tmixer0"])
+    for i in range(3):
+        m = lr.update(batch_of(g, i))
+        assert abs(m["loss"] - float(g["losses"][i])) <= 2e-5 * abs(float(g["losses"][i]))
+        np.testing.assert_allclose(lr.flat().detach().numpy(), g[f"params{i + 1}"], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(lr.mflat().detach().numpy(), g[f"mixer{i + 1}"], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(lr.tmixer.numpy(), g[f"tmixer{i + 1}"], rtol=0, atol=2e-6)
