@@ -43,6 +43,11 @@ class BatchStruct(ctypes.Structure):
                 ("filled", c_void_p), ("max_len", c_int32), ("batch", c_int32)]
 
 
+class QmixMixer(ctypes.Structure):
+    _fields_ = [("mixer", c_void_p), ("target_mixer", c_void_p), ("mixer_grad", c_void_p), ("embed_dim", c_int32),
+                ("hypernet_layers", c_int32), ("hypernet_embed", c_int32)]
+
+
 class IdqnLearner(ctypes.Structure):
     _fields_ = [("net", NetShape), ("rs", ReplayShape), ("rb", ReplayBuffers),
                 ("params", c_void_p), ("target", c_void_p), ("exp_avg", c_void_p), ("exp_avg_sq", c_void_p),
@@ -80,6 +85,13 @@ PROTOTYPES = {
     "marlhip_dqn_loss_grad_replay": (c_int32, [POINTER(NetShape), c_void_p, c_void_p, POINTER(ReplayShape),
                                                POINTER(ReplayBuffers), c_void_p, c_int32, c_int32, c_uint64, c_uint32, c_void_p,
                                                c_float, c_int32, c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "marlhip_qmix_nparams": (c_int32, [POINTER(NetShape), c_int32, c_int32, c_int32]),
+    "marlhip_qmix_workspace_bytes": (c_int64, [POINTER(NetShape), c_int32, c_int32]),
+    "marlhip_qmix_loss_grad": (c_int32, [POINTER(NetShape), c_void_p, c_void_p, POINTER(QmixMixer), POINTER(BatchStruct), c_float,
+                                         c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "marlhip_qmix_loss_grad_replay": (c_int32, [POINTER(NetShape), c_void_p, c_void_p, POINTER(QmixMixer), POINTER(ReplayShape),
+                                                POINTER(ReplayBuffers), c_void_p, c_int32, c_int32, c_uint64, c_uint32, c_void_p,
+                                                c_float, c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "marlhip_dqn_clip_adam": (c_int32, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_double,
                                         c_double, c_double, c_double, c_float, c_float, c_int32, c_float, c_void_p,
                                         c_void_p, c_void_p]),

@@ -606,6 +606,7 @@ __global__ __launch_bounds__(256) void adam_kernel(int64_t n, int nblocks, float
 }  // namespace marl
 
 #include "dqn_update_tp.h"
+#include "qmix.h"
 
 namespace marl {
 
@@ -726,10 +727,32 @@ inline UpdPlan upd_plan_tp(int P, int T, int B, int NB) {  // one workgroup per 
     return pl;
 }
 
+// QMIX mixer stage (qmix.h), dispatched on the (agents, obs dim) pair
+template <int D, bool REPLAY>
+int qmix_dispatch_mix(int P, const QmixCtx& qx, const marlhip_batch* bt, const ReplaySrc& src, const QmixIo& io, float gamma,
+                      hipStream_t st) {
+#define X(p, d) \
+    if constexpr (D == d) { if (P == p) return qmix_launch_mix<QmixShape<p, d>, REPLAY>(qx, bt, src, io, gamma, st); }
+    MARL_QMIX_SHAPES(X)
+#undef X
+    set_error("no QMIX mixer kernel for %d agents x %d observations (add it to MARL_QMIX_SHAPES)", P, D);
+    return -1;
+}
+
+template <int D>
+int qmix_dispatch_reduce(int P, const QmixCtx& qx, int T, int B, const float* loss, hipStream_t st) {
+#define X(p, d) \
+    if constexpr (D == d) { if (P == p) return qmix_launch_reduce<QmixShape<p, d>>(qx, T, B, loss, st); }
+    MARL_QMIX_SHAPES(X)
+#undef X
+    set_error("no QMIX mixer kernel for %d agents x %d observations", P, D);
+    return -1;
+}
+
 template <class S, bool REPLAY>
 int launch_lossgrad_tp(const marlhip_net_shape* s, const float* params, const float* tparams, const marlhip_batch* bt,
                        const ReplaySrc& src, float gamma, int double_q, int mode, void* ws, int64_t ws_bytes, float* grad,
-                       float* loss, hipStream_t st) {
+                       float* loss, hipStream_t st, const QmixCtx* qx) {
     constexpr int W = 4, TPW = S::H / 64, NB = 2, NT = W * TPW, REC = S::NPARAM + 2;
     const int P = s->n_agents, T = bt->max_len, B = bt->batch;
     const UpdPlan pl = upd_plan_tp(P, T, B, NB);
@@ -754,23 +777,30 @@ int launch_lossgrad_tp(const marlhip_net_shape* s, const float* params, const fl
     timing_begin(TIMER_LOSSGRAD, st);
     hipLaunchKernelGGL((tp_fwd_kernel<S, W, TPW, REPLAY, NB>), grid, block, ldsF, st, params, tparams, *bt, src, mix, double_q,
                        pl.n_chunks);
-    hipLaunchKernelGGL(tp_mix_kernel, dim3((unsigned)((tb + 255) / 256 > 1024 ? 1024 : (tb + 255) / 256)), dim3(256), 0, st, mix, P, T,
-                       B, gamma, mode == 1 ? 1 : 0);
+    if (mode == 2) {
+        QmixIo io = {mix.chosen, mix.tqsel, mix.rew, mix.dn, mix.fl, mix.dq, mix.lrow, nullptr};
+        const int rc = qmix_dispatch_mix<S::D, REPLAY>(P, *qx, bt, src, io, gamma, st);
+        if (rc != 0) return rc;
+    } else {
+        hipLaunchKernelGGL(tp_mix_kernel, dim3((unsigned)((tb + 255) / 256 > 1024 ? 1024 : (tb + 255) / 256)), dim3(256), 0, st, mix, P,
+                           T, B, gamma, mode == 1 ? 1 : 0);
+    }
     hipLaunchKernelGGL((tp_bwd_kernel<S, W, TPW, REPLAY, NB>), grid, block, ldsB, st, params, *bt, src, mix, pl.n_chunks, (float*)ws);
     timing_end(TIMER_LOSSGRAD, st);
     MARL_CHECK_LAUNCH("tp_lossgrad");
     const int n = P * S::NPARAM;
     hipLaunchKernelGGL(dqn_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, st, (const float*)ws, P, pl.nwg, S::NPARAM, grad, loss);
     MARL_CHECK_LAUNCH("dqn_reduce_kernel");
+    if (mode == 2) return qmix_dispatch_reduce<S::D>(P, *qx, T, B, loss, st);
     return 0;
 }
 
 template <class S, bool REPLAY>
 int launch_lossgrad_src(const marlhip_net_shape* s, const float* params, const float* tparams, const marlhip_batch* bt,
                         const ReplaySrc& src, float gamma, int double_q, int mode, void* ws, int64_t ws_bytes, float* grad,
-                        float* loss, hipStream_t st) {
+                        float* loss, hipStream_t st, const QmixCtx* qx) {
     if constexpr (S::H > 64) {
-        return launch_lossgrad_tp<S, REPLAY>(s, params, tparams, bt, src, gamma, double_q, mode, ws, ws_bytes, grad, loss, st);
+        return launch_lossgrad_tp<S, REPLAY>(s, params, tparams, bt, src, gamma, double_q, mode, ws, ws_bytes, grad, loss, st, qx);
     } else {
     using L = UpdLds<S>;
     const int P = s->n_agents, T = bt->max_len, B = bt->batch;
@@ -800,6 +830,10 @@ int launch_lossgrad_src(const marlhip_net_shape* s, const float* params, const f
     MixBufs mix;
     mix.chosen = mixf; mix.tqsel = mixf + P * tb; mix.r0 = mixf + 2 * P * tb; mix.dn = mix.r0 + tb; mix.fl = mix.dn + tb;
     mix.dq = mix.fl + tb; mix.lrow = mix.dq + tb; mix.dq_agent_stride = 0;
+    if (mode == 2) {  // QMIX: one dq plane per agent
+        mix.lrow = mix.dq + P * tb;
+        mix.dq_agent_stride = (int)tb;
+    }
     const dim3 grid(pl.nwg, P), block(256);
     timing_begin(TIMER_LOSSGRAD, st);
     if (mode == 0) {
@@ -808,8 +842,14 @@ int launch_lossgrad_src(const marlhip_net_shape* s, const float* params, const f
     } else {
         hipLaunchKernelGGL((dqn_lossgrad_kernel<S, 4, REPLAY, 1>), grid, block, lds_bytes, st, (const float*)packs, *bt, src, mix,
                            gamma, double_q, pl.n_chunks, (float*)ws, prof);
-        hipLaunchKernelGGL(vdn_mix_kernel, dim3((unsigned)((tb + 255) / 256 > 1024 ? 1024 : (tb + 255) / 256)), dim3(256), 0, st, mix,
-                           P, T, B, gamma);
+        if (mode == 2) {
+            QmixIo io = {mix.chosen, mix.tqsel, mix.r0, mix.dn, mix.fl, mix.dq, mix.lrow, nullptr};
+            const int rc = qmix_dispatch_mix<S::D, REPLAY>(P, *qx, bt, src, io, gamma, st);
+            if (rc != 0) return rc;
+        } else {
+            hipLaunchKernelGGL(vdn_mix_kernel, dim3((unsigned)((tb + 255) / 256 > 1024 ? 1024 : (tb + 255) / 256)), dim3(256), 0, st,
+                               mix, P, T, B, gamma);
+        }
         hipLaunchKernelGGL((dqn_lossgrad_kernel<S, 4, REPLAY, 2>), grid, block, lds_bytes, st, (const float*)packs, *bt, src, mix,
                            gamma, double_q, pl.n_chunks, (float*)ws, prof);
     }
@@ -818,6 +858,7 @@ int launch_lossgrad_src(const marlhip_net_shape* s, const float* params, const f
     const int n = P * S::NPARAM;
     hipLaunchKernelGGL(dqn_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, st, (const float*)ws, P, pl.nwg, S::NPARAM, grad, loss);
     MARL_CHECK_LAUNCH("dqn_reduce_kernel");
+    if (mode == 2) return qmix_dispatch_reduce<S::D>(P, *qx, T, B, loss, st);
     return 0;
     }
 }
@@ -825,10 +866,11 @@ int launch_lossgrad_src(const marlhip_net_shape* s, const float* params, const f
 template <class S>
 int launch_lossgrad(const marlhip_net_shape* s, const float* params, const float* tparams, const marlhip_batch* bt,
                     const ReplaySrc* rsrc, float gamma, int double_q, int mode, void* ws, int64_t ws_bytes, float* grad, float* loss,
-                    hipStream_t st) {
-    if (rsrc != nullptr) return launch_lossgrad_src<S, true>(s, params, tparams, bt, *rsrc, gamma, double_q, mode, ws, ws_bytes, grad, loss, st);
+                    hipStream_t st, const QmixCtx* qx) {
+    if (rsrc != nullptr)
+        return launch_lossgrad_src<S, true>(s, params, tparams, bt, *rsrc, gamma, double_q, mode, ws, ws_bytes, grad, loss, st, qx);
     ReplaySrc none = {};
-    return launch_lossgrad_src<S, false>(s, params, tparams, bt, none, gamma, double_q, mode, ws, ws_bytes, grad, loss, st);
+    return launch_lossgrad_src<S, false>(s, params, tparams, bt, none, gamma, double_q, mode, ws, ws_bytes, grad, loss, st, qx);
 }
 
 }  // namespace marl
@@ -863,12 +905,12 @@ extern "C" int64_t marlhip_dqn_workspace_bytes(const marlhip_net_shape* s, int32
 
 static int lossgrad_dispatch(const marlhip_net_shape* s, const float* params, const float* target_params, const marlhip_batch* bt,
                              const ReplaySrc* rsrc, float gamma, int32_t double_q, int32_t mode, void* workspace,
-                             int64_t workspace_bytes, float* grad, float* loss, void* stream) {
-    MARL_REQUIRE(mode == 0 || mode == 1, "dqn_loss_grad: mode %d unknown (0 = IDQN, 1 = VDN)", mode);
+                             int64_t workspace_bytes, float* grad, float* loss, void* stream, const QmixCtx* qx = nullptr) {
+    MARL_REQUIRE(mode == 0 || mode == 1 || (mode == 2 && qx != nullptr), "dqn_loss_grad: mode %d unknown (0 = IDQN, 1 = VDN)", mode);
 #define X(d, h, a)                                                                                                          \
     if (s->obs_dim == d && s->hidden == h && s->n_actions == a)                                                             \
         return launch_lossgrad<MlpShape<d, h, a>>(s, params, target_params, bt, rsrc, gamma, double_q, mode, workspace,       \
-                                                  workspace_bytes, grad, loss, (hipStream_t)stream);
+                                                  workspace_bytes, grad, loss, (hipStream_t)stream, qx);
     MARL_UPD_SHAPES(X)
 #undef X
     set_error("no update kernel for net shape D=%d H=%d A=%d", s->obs_dim, s->hidden, s->n_actions);
@@ -901,6 +943,83 @@ extern "C" int marlhip_dqn_loss_grad_replay(const marlhip_net_shape* s, const fl
     ReplaySrc src;
     src.rb = *rb; src.idx = idx; src.idx_out = idx_out; src.seed = seed; src.counter = counter; src.length = length;
     return lossgrad_dispatch(s, params, target_params, &bt, &src, gamma, double_q, mode, workspace, workspace_bytes, grad, loss, stream);
+}
+
+// ---- QMIX (QMixNetwork, marlbase/dqn/model.py:334-443) ------------------------------------------------------
+static int qmix_check(const marlhip_net_shape* s, int32_t embed_dim, int32_t hypernet_layers, int32_t hypernet_embed) {
+    MARL_REQUIRE(s != nullptr, "net shape is NULL");
+    MARL_REQUIRE(embed_dim == 64 && hypernet_layers == 2 && hypernet_embed == 32,
+                 "qmix: only mixing = {embed_dim 64, hypernet_layers 2, hypernet_embed 32} (configs/algorithm/qmix.yaml) is compiled, "
+                 "got {%d, %d, %d}", embed_dim, hypernet_layers, hypernet_embed);
+#define X(p, d) if (s->n_agents == p && s->obs_dim == d) return 0;
+    MARL_QMIX_SHAPES(X)
+#undef X
+    set_error("no QMIX mixer kernel for %d agents x %d observations (add it to MARL_QMIX_SHAPES)", s->n_agents, s->obs_dim);
+    return -1;
+}
+
+extern "C" int marlhip_qmix_nparams(const marlhip_net_shape* s, int32_t embed_dim, int32_t hypernet_layers, int32_t hypernet_embed) {
+    if (qmix_check(s, embed_dim, hypernet_layers, hypernet_embed) != 0) return -1;
+#define X(p, d) if (s->n_agents == p && s->obs_dim == d) return QmixShape<p, d>::NPARAM;
+    MARL_QMIX_SHAPES(X)
+#undef X
+    return -1;
+}
+
+static int64_t qmix_agent_ws(const marlhip_net_shape* s, int32_t max_len, int32_t batch) {
+    const int64_t a = marlhip_dqn_workspace_bytes(s, max_len, batch);
+    return a < 0 ? a : ((a + 255) & ~(int64_t)255);
+}
+
+extern "C" int64_t marlhip_qmix_workspace_bytes(const marlhip_net_shape* s, int32_t max_len, int32_t batch) {
+    if (qmix_check(s, 64, 2, 32) != 0) return -1;
+    const int64_t a = qmix_agent_ws(s, max_len, batch);
+    if (a < 0) return -1;
+#define X(p, d) if (s->n_agents == p && s->obs_dim == d) return a + qmix_ws_layout<QmixShape<p, d>>(max_len, batch).total;
+    MARL_QMIX_SHAPES(X)
+#undef X
+    return -1;
+}
+
+static int qmix_call(const marlhip_net_shape* s, const float* params, const float* target_params, const marlhip_qmix_mixer* mx,
+                     const marlhip_batch* bt, const ReplaySrc* rsrc, float gamma, int32_t double_q, void* workspace,
+                     int64_t workspace_bytes, float* grad, float* loss, void* stream) {
+    MARL_REQUIRE(mx && mx->mixer && mx->target_mixer && mx->mixer_grad, "qmix_loss_grad: NULL mixer pointer");
+    if (qmix_check(s, mx->embed_dim, mx->hypernet_layers, mx->hypernet_embed) != 0) return -1;
+    const int64_t a = qmix_agent_ws(s, bt->max_len, bt->batch);
+    MARL_REQUIRE(a >= 0 && workspace_bytes > a, "qmix_loss_grad: workspace %lld too small", (long long)workspace_bytes);
+    QmixCtx qx;
+    qx.mixer = mx->mixer; qx.tmixer = mx->target_mixer; qx.mgrad = mx->mixer_grad;
+    qx.ws = static_cast<char*>(workspace) + a;
+    qx.ws_bytes = workspace_bytes - a;
+    return lossgrad_dispatch(s, params, target_params, bt, rsrc, gamma, double_q, 2, workspace, a, grad, loss, stream, &qx);
+}
+
+extern "C" int marlhip_qmix_loss_grad(const marlhip_net_shape* s, const float* params, const float* target_params,
+                                      const marlhip_qmix_mixer* mixer, const marlhip_batch* batch, float gamma, int32_t double_q,
+                                      void* workspace, int64_t workspace_bytes, float* grad, float* loss, void* stream) {
+    MARL_REQUIRE(s && params && target_params && batch && workspace && grad && loss, "qmix_loss_grad: NULL pointer");
+    MARL_REQUIRE(batch->obss && batch->actions && batch->rewards && batch->dones && batch->filled, "qmix_loss_grad: NULL batch field");
+    MARL_REQUIRE(batch->max_len > 0 && batch->batch > 0, "qmix_loss_grad: empty batch");
+    return qmix_call(s, params, target_params, mixer, batch, nullptr, gamma, double_q, workspace, workspace_bytes, grad, loss, stream);
+}
+
+extern "C" int marlhip_qmix_loss_grad_replay(const marlhip_net_shape* s, const float* params, const float* target_params,
+                                             const marlhip_qmix_mixer* mixer, const marlhip_replay_shape* rs,
+                                             const marlhip_replay_buffers* rb, const int32_t* idx, int32_t batch, int32_t length,
+                                             uint64_t seed, uint32_t counter, int32_t* idx_out, float gamma, int32_t double_q,
+                                             void* workspace, int64_t workspace_bytes, float* grad, float* loss, void* stream) {
+    MARL_REQUIRE(s && params && target_params && rs && rb && workspace && grad && loss, "qmix_loss_grad_replay: NULL pointer");
+    MARL_REQUIRE(rb->obs && rb->act && rb->rew && rb->done && rb->filled, "qmix_loss_grad_replay: NULL replay buffer");
+    MARL_REQUIRE(rs->n_agents == s->n_agents && rs->obs_dim == s->obs_dim, "qmix_loss_grad_replay: replay / net shape mismatch");
+    MARL_REQUIRE(batch > 0 && rs->max_len > 0, "qmix_loss_grad_replay: empty batch");
+    MARL_REQUIRE(idx != nullptr || (length > 0 && length <= rs->capacity), "qmix_loss_grad_replay: length %d out of range", length);
+    marlhip_batch bt = {};
+    bt.max_len = rs->max_len;
+    bt.batch = batch;
+    ReplaySrc src;
+    src.rb = *rb; src.idx = idx; src.idx_out = idx_out; src.seed = seed; src.counter = counter; src.length = length;
+    return qmix_call(s, params, target_params, mixer, &bt, &src, gamma, double_q, workspace, workspace_bytes, grad, loss, stream);
 }
 
 extern "C" int marlhip_dqn_clip_adam(int64_t n, float* params, const float* grad, float* exp_avg, float* exp_avg_sq,

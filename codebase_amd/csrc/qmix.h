@@ -1,0 +1,662 @@
+// QMIX monotonic mixer (QMixer, marlbase/dqn/model.py:272-331) and its part of QMixNetwork._compute_loss
+// (model.py:374-427) on gfx950.  Included by dqn_update.hip after its helpers; the agent networks run through the
+// same forward-only / backward-with-external-dq passes VDN uses, this file is the stage between them:
+//
+//   chosen_p[t][b], tqsel_p[t][b]  ->  y = mixer(chosen, s_t), y' = target_mixer(tqsel, s_{t+1})
+//   delta = y - (r_0 + gamma y' (1 - done)),  dq_p = dL/dchosen_p,  gradient of the mixer parameters
+//
+// with s = the concatenation of all agents' observations (model.py:389,412; state_dim = P*D, model.py:360).
+// One row = one (t, b) pair, R = T*B rows.  Four kernels, every GEMM on v_mfma_f32_16x16x4_f32 (exact f32):
+//   qmix_l1_kernel    Y1[R][192] = act(S W1cat^T + bias): the four state-fed first layers in ONE GEMM
+//                     (features [0,32) hyper_w_1.0 +ReLU | [32,64) hyper_w_final.0 +ReLU | [64,128) hyper_b_1 |
+//                     [128,192) V.0 +ReLU).  Weights stream through LDS in 64-column K chunks, 32 rows per wave.
+//   qmix_mix_kernel   per 16-row block, wave-independent: w1 = |hyper_w_1.2 h1 + c|, z = sum_p q_p w1_p + b1,
+//                     hidden = elu(z), wf = |hyper_w_final.2 hf + c|, y = hidden.wf + V.2 hv + c.  The online
+//                     instance continues with the TD error and the backward down to the first-layer
+//                     pre-activations; it writes dq_p and the operands of the weight-gradient GEMMs.
+//   qmix_wgrad_kernel split-K (over rows) weight-gradient GEMMs; 8 waves own disjoint accumulator tiles, no LDS.
+//   qmix_reduce_kernel sums the per-workgroup records in fixed order and applies 1/sum(filled).
+// hypernet_layers == 2, embed_dim 64, hypernet_embed 32 (configs/algorithm/qmix.yaml:14-17) are compiled in.
+// d|x|/dx at exactly 0 is taken as -1 (torch: 0): a pre-activation that is exactly 0.0f does not occur with
+// non-degenerate parameters.
+#pragma once
+
+namespace marl {
+
+template <int P_, int D_>
+struct QmixShape {
+    static constexpr int P = P_, D = D_, SD = P_ * D_, E = 64, HE = 32;
+    static constexpr int NF1 = 2 * HE + 2 * E;  // 192 first-layer features
+    static constexpr int MT1 = NF1 / 16;        // 12 feature tiles
+    static constexpr int KS4 = (SD + 15) / 16;  // state columns in groups of 16 (4 k-steps)
+    static constexpr int NCH = (KS4 + 3) / 4;   // LDS chunks of 64 state columns
+    static constexpr int W1T = 4 * P;           // feature tiles of w1 (E*P / 16)
+    // canonical parameter block = mixer.parameters() order
+    static constexpr int oA1 = 0, oa1 = oA1 + HE * SD, oB1 = oa1 + HE, oc1 = oB1 + E * P * HE, oAf = oc1 + E * P,
+                         oaf = oAf + HE * SD, oBf = oaf + HE, ocf = oBf + E * HE, oBb = ocf + E, ocb = oBb + E * SD,
+                         oAv = ocb + E, oav = oAv + E * SD, obv = oav + E, ocv = obv + E;
+    static constexpr int NPARAM = ocv + 1;
+    // first-layer pack: A[ks4][mt][lane][e] = W1cat[16mt+i][16ks4+4e+g], then bias[192]
+    static constexpr int pL1b = KS4 * MT1 * 256, NL1 = pL1b + NF1;
+    // mixing pack: P1[W1T][2][64][4] c1[E*P] PF[4][2][64][4] cf[64] bv[64] cv[4] | T1[2][W1T][64][4] TF[2][4][64][4]
+    static constexpr int mP1 = 0, mc1 = mP1 + W1T * 512, mPF = mc1 + E * P, mcf = mPF + 2048, mbv = mcf + 64, mcv = mbv + 64,
+                         mT1 = mcv + 4, mTF = mT1 + W1T * 512, NMIX = mTF + 2048, NMIX_FWD = mT1;
+    static constexpr int NPACK = 2 * NL1 + NMIX + NMIX_FWD;  // online L1 | target L1 | online mix | target mix (forward part)
+};
+
+template <class Q>
+__host__ __device__ __forceinline__ int qmix_l1_row(int f) {  // canonical offset of row f of the combined first layer
+    return f < 32 ? Q::oA1 + f * Q::SD : f < 64 ? Q::oAf + (f - 32) * Q::SD : f < 128 ? Q::oBb + (f - 64) * Q::SD : Q::oAv + (f - 128) * Q::SD;
+}
+template <class Q>
+__host__ __device__ __forceinline__ int qmix_l1_bias(int f) {
+    return f < 32 ? Q::oa1 + f : f < 64 ? Q::oaf + f - 32 : f < 128 ? Q::ocb + f - 64 : Q::oav + f - 128;
+}
+
+template <class Q>
+__device__ __forceinline__ float qmix_l1_pack_elem(const float* __restrict__ w, int idx) {
+    if (idx >= Q::pL1b) return w[qmix_l1_bias<Q>(idx - Q::pL1b)];
+    const int e = idx & 3, lane = (idx >> 2) & 63, rest = idx >> 8;
+    const int mt = rest % Q::MT1, ks4 = rest / Q::MT1;
+    const int f = 16 * mt + (lane & 15), k = 16 * ks4 + 4 * e + (lane >> 4);
+    return k < Q::SD ? w[qmix_l1_row<Q>(f) + k] : 0.f;
+}
+
+template <class Q>
+__device__ __forceinline__ float qmix_mix_pack_elem(const float* __restrict__ w, int idx) {
+    constexpr int HE = Q::HE;
+    if (idx < Q::mc1) {  // P1[mt2][k1][lane][r] = B1[16mt2+i][16k1+4g+r]
+        const int r = idx & 3, lane = (idx >> 2) & 63, rest = idx >> 8, k1 = rest & 1, mt2 = rest >> 1;
+        return w[Q::oB1 + (16 * mt2 + (lane & 15)) * HE + 16 * k1 + 4 * (lane >> 4) + r];
+    }
+    if (idx < Q::mPF) return w[Q::oc1 + idx - Q::mc1];
+    if (idx < Q::mcf) {  // PF[mt][k1][lane][r] = Bf[16mt+i][16k1+4g+r]
+        const int x = idx - Q::mPF, r = x & 3, lane = (x >> 2) & 63, rest = x >> 8, k1 = rest & 1, mt = rest >> 1;
+        return w[Q::oBf + (16 * mt + (lane & 15)) * HE + 16 * k1 + 4 * (lane >> 4) + r];
+    }
+    if (idx < Q::mbv) return w[Q::ocf + idx - Q::mcf];
+    if (idx < Q::mcv) return w[Q::obv + idx - Q::mbv];
+    if (idx < Q::mT1) return idx == Q::mcv ? w[Q::ocv] : 0.f;
+    if (idx < Q::mTF) {  // T1[m][kt][lane][r]: A[i = h1 feature 16m+i][k = w1 feature 16kt+4g+r] = B1[16kt+4g+r][16m+i]
+        const int x = idx - Q::mT1, r = x & 3, lane = (x >> 2) & 63, rest = x >> 8, kt = rest % Q::W1T, m = rest / Q::W1T;
+        return w[Q::oB1 + (16 * kt + 4 * (lane >> 4) + r) * HE + 16 * m + (lane & 15)];
+    }
+    const int x = idx - Q::mTF, r = x & 3, lane = (x >> 2) & 63, rest = x >> 8, kt = rest & 3, m = rest >> 2;
+    return w[Q::oBf + (16 * kt + 4 * (lane >> 4) + r) * HE + 16 * m + (lane & 15)];
+}
+
+template <class Q>
+__global__ __launch_bounds__(256) void qmix_pack_kernel(const float* __restrict__ mixer, const float* __restrict__ tmixer,
+                                                        float* __restrict__ packs) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= Q::NPACK) return;
+    float v;
+    if (idx < Q::NL1) v = qmix_l1_pack_elem<Q>(mixer, idx);
+    else if (idx < 2 * Q::NL1) v = qmix_l1_pack_elem<Q>(tmixer, idx - Q::NL1);
+    else if (idx < 2 * Q::NL1 + Q::NMIX) v = qmix_mix_pack_elem<Q>(mixer, idx - 2 * Q::NL1);
+    else v = qmix_mix_pack_elem<Q>(tmixer, idx - 2 * Q::NL1 - Q::NMIX);
+    packs[idx] = v;
+}
+
+// where the state rows come from: the reference-layout Batch obss[P][T+1][B][D] or the episode-major replay
+template <class Q, bool REPLAY>
+struct QmixRows {
+    const float* obs;
+    ReplaySrc rs;
+    int T, B;
+    // element (p, d) of the state of (row, time offset) = base(row, toff)[p * pstride() + d]
+    __device__ __forceinline__ const float* base(int row, int toff) const {
+        const int t0 = row / B, b = row - t0 * B, t = t0 + toff;
+        if (REPLAY) {
+            const int e = rs.idx ? rs.idx[b] : replay_draw(rs, b);
+            return rs.rb.obs + ((size_t)e * Q::P * (T + 1) + t) * Q::D;
+        }
+        return obs + ((size_t)t * B + b) * Q::D;
+    }
+    __device__ __forceinline__ size_t pstride() const { return REPLAY ? (size_t)(T + 1) * Q::D : (size_t)(T + 1) * B * Q::D; }
+};
+
+template <class Q>
+__device__ __forceinline__ size_t qmix_state_off(int k, size_t ps) {  // k < SD
+    const int p = k / Q::D, d = k - p * Q::D;
+    return (size_t)p * ps + d;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// first layers: Y1[row][192]
+// ---------------------------------------------------------------------------------------------------------
+template <class Q, bool REPLAY>
+__global__ __launch_bounds__(256) void qmix_l1_kernel(const float* __restrict__ pack, QmixRows<Q, REPLAY> src, int toff, int R,
+                                                      float* __restrict__ Y1) {
+    constexpr int NB = 2, MT1 = Q::MT1, KS4 = Q::KS4, NCH = Q::NCH, SD = Q::SD;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    f4* lds4 = reinterpret_cast<f4*>(lds);
+    const f4* pack4 = reinterpret_cast<const f4*>(pack);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, j = lane & 15;
+    const int ngroups = (R + 64 * NB - 1) / (64 * NB);
+    const size_t ps = src.pstride();
+    if (NCH == 1) {
+        for (int i = tid; i < KS4 * MT1 * 64; i += 256) lds4[i] = pack4[i];
+        __syncthreads();
+    }
+    for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        const float* rb[NB];
+        int row[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            row[nb] = ((grp * 4 + wave) * NB + nb) * 16 + j;
+            rb[nb] = src.base(row[nb] < R ? row[nb] : R - 1, toff);
+        }
+        f4 acc[NB][MT1];
+#pragma unroll
+        for (int mt = 0; mt < MT1; ++mt) {
+            const f4 b = *reinterpret_cast<const f4*>(pack + Q::pL1b + 16 * mt + 4 * g);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[nb][mt] = b;
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            constexpr int full = 4;
+            const int n4 = (KS4 - 4 * c) < full ? (KS4 - 4 * c) : full;
+            if (NCH > 1) {
+                __syncthreads();
+                for (int i = tid; i < n4 * MT1 * 64; i += 256) lds4[i] = pack4[c * 4 * MT1 * 64 + i];
+                __syncthreads();
+            }
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                if (q4 < n4) {
+                    float x[NB][4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int k = 16 * (4 * c + q4) + 4 * e + g;
+                        const size_t off = qmix_state_off<Q>(k < SD ? k : SD - 1, ps);
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) {
+                            const float v = rb[nb][off];
+                            x[nb][e] = k < SD ? v : 0.f;
+                        }
+                    }
+#pragma unroll
+                    for (int mt = 0; mt < MT1; ++mt) {
+                        const f4 a = lds4[(q4 * MT1 + mt) * 64 + lane];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+#pragma unroll
+                            for (int nb = 0; nb < NB; ++nb) acc[nb][mt] = MARL_MFMA(a[e], x[nb][e], acc[nb][mt]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            if (row[nb] < R) {
+                float* y = Y1 + (size_t)row[nb] * Q::NF1 + 4 * g;
+#pragma unroll
+                for (int mt = 0; mt < MT1; ++mt)
+                    *reinterpret_cast<f4*>(y + 16 * mt) = (mt < 4 || mt >= 8) ? relu4(acc[nb][mt]) : acc[nb][mt];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// mixing network on one 16-row block per wave
+// ---------------------------------------------------------------------------------------------------------
+struct QmixIo {
+    const float* chosen;  // [P][R]
+    const float* tqsel;   // [P][R]
+    const float* r0;      // [R] reward of agent 0 (QMixNetwork uses batch.rewards[0], model.py:379)
+    const float* dn;      // [R]
+    const float* fl;      // [R]
+    float* dq;            // [P][R]
+    float* lrow;          // [R]
+    float* ytgt;          // [R] target-mixer output
+};
+
+// backward operands, written by the online instance (Rp = rows padded to whole blocks, nblk = Rp/16):
+//   G1T [nblk][192][16]  d(pre-activation) of the first layers, feature-major inside a block (an MFMA A tile)
+//   DW1T[nblk][E*P][16]  d(pre-abs w1),  DWFT[nblk][64][16]  d(pre-abs w_final),  DY[Rp]  dL/dy
+struct QmixBwd {
+    float* G1T;
+    float* DW1T;
+    float* DWFT;
+    float* DY;
+};
+
+template <int N>
+__device__ __forceinline__ void qmix_store_tiles(float* dst, const f4 (&v)[N], int g, int j) {  // dst[(16mt+4g+r)*16 + j]
+#pragma unroll
+    for (int mt = 0; mt < N; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dst[(16 * mt + 4 * g + r) * 16 + j] = v[mt][r];
+}
+
+template <class Q, bool ONLINE>
+__global__ __launch_bounds__(256, 1) void qmix_mix_kernel(const float* __restrict__ pack, const float* __restrict__ Y1, QmixIo io, int R,
+                                                          float gamma, QmixBwd bw) {
+    constexpr int P = Q::P, W1T = Q::W1T, NPK = ONLINE ? Q::NMIX : Q::NMIX_FWD;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, j = lane & 15;
+    {
+        f4* l4 = reinterpret_cast<f4*>(lds);
+        const f4* p4 = reinterpret_cast<const f4*>(pack);
+        for (int i = tid; i < NPK / 4; i += 256) l4[i] = p4[i];
+        __syncthreads();
+    }
+    const f4* P1 = reinterpret_cast<const f4*>(lds + Q::mP1);
+    const f4* PF = reinterpret_cast<const f4*>(lds + Q::mPF);
+    const f4* T1 = reinterpret_cast<const f4*>(lds + Q::mT1);
+    const f4* TF = reinterpret_cast<const f4*>(lds + Q::mTF);
+    const int nblk = (R + 15) / 16;
+    for (int blk = blockIdx.x * 4 + wave; blk < nblk; blk += gridDim.x * 4) {
+        const int row = blk * 16 + j;
+        const bool ok = row < R;
+        const int rc = ok ? row : R - 1;
+        const float* y1 = Y1 + (size_t)rc * Q::NF1 + 4 * g;
+        f4 h1[2], hf[2], z[4], hv[4];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            h1[k] = *reinterpret_cast<const f4*>(y1 + 16 * k);
+            hf[k] = *reinterpret_cast<const f4*>(y1 + 32 + 16 * k);
+        }
+#pragma unroll
+        for (int et = 0; et < 4; ++et) {
+            z[et] = *reinterpret_cast<const f4*>(y1 + 64 + 16 * et);
+            hv[et] = *reinterpret_cast<const f4*>(y1 + 128 + 16 * et);
+        }
+        float q[P];
+#pragma unroll
+        for (int p = 0; p < P; ++p) q[p] = (ONLINE ? io.chosen : io.tqsel)[(size_t)p * R + rc];
+        // w1 pre-abs = hyper_w_1.2 h1 + c1 ; z += q_p |w1_p|
+        f4 w1[W1T];
+#pragma unroll
+        for (int mt2 = 0; mt2 < W1T; ++mt2) {
+            f4 acc = *reinterpret_cast<const f4*>(lds + Q::mc1 + 16 * mt2 + 4 * g);
+#pragma unroll
+            for (int k1 = 0; k1 < 2; ++k1) {
+                const f4 a = P1[(mt2 * 2 + k1) * 64 + lane];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc = MARL_MFMA(a[r], h1[k1][r], acc);
+            }
+            w1[mt2] = acc;
+        }
+#pragma unroll
+        for (int p = 0; p < P; ++p)
+#pragma unroll
+            for (int et = 0; et < 4; ++et)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) z[et][r] = fmaf(q[p], fabsf(w1[4 * p + et][r]), z[et][r]);
+        f4 ez[4], hid[4], wfp[4];
+#pragma unroll
+        for (int et = 0; et < 4; ++et)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                ez[et][r] = expf(fminf(z[et][r], 0.f));
+                hid[et][r] = z[et][r] > 0.f ? z[et][r] : ez[et][r] - 1.f;
+            }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            f4 acc = *reinterpret_cast<const f4*>(lds + Q::mcf + 16 * mt + 4 * g);
+#pragma unroll
+            for (int k1 = 0; k1 < 2; ++k1) {
+                const f4 a = PF[(mt * 2 + k1) * 64 + lane];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc = MARL_MFMA(a[r], hf[k1][r], acc);
+            }
+            wfp[mt] = acc;
+        }
+        f4 bv[4];
+        float yp = 0.f;
+#pragma unroll
+        for (int et = 0; et < 4; ++et) {
+            bv[et] = *reinterpret_cast<const f4*>(lds + Q::mbv + 16 * et + 4 * g);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                yp = fmaf(hid[et][r], fabsf(wfp[et][r]), yp);
+                yp = fmaf(hv[et][r], bv[et][r], yp);
+            }
+        }
+        yp += __shfl_xor(yp, 16);
+        yp += __shfl_xor(yp, 32);
+        const float y = yp + lds[Q::mcv];
+        if (!ONLINE) {
+            if (g == 0 && ok) io.ytgt[row] = y;
+            continue;
+        }
+        // ---- TD error and backward (model.py:419-427)
+        const float fl = ok ? io.fl[rc] : 0.f;
+        const float delta = y - (io.r0[rc] + gamma * io.ytgt[rc] * (1.f - io.dn[rc]));
+        const float dy = 2.f * fl * delta;
+        if (g == 0) {
+            bw.DY[blk * 16 + j] = dy;
+            if (ok) io.lrow[row] = fl * delta * delta;
+        }
+        f4 dz[4], dwf[4], dhv[4];
+#pragma unroll
+        for (int et = 0; et < 4; ++et)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float dhid = dy * fabsf(wfp[et][r]);
+                dwf[et][r] = wfp[et][r] > 0.f ? dy * hid[et][r] : -(dy * hid[et][r]);
+                dz[et][r] = z[et][r] > 0.f ? dhid : dhid * ez[et][r];
+                dhv[et][r] = hv[et][r] > 0.f ? dy * bv[et][r] : 0.f;
+            }
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            float s = 0.f;
+#pragma unroll
+            for (int et = 0; et < 4; ++et)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float w = w1[4 * p + et][r];
+                    s = fmaf(dz[et][r], fabsf(w), s);
+                    const float dwp = dz[et][r] * q[p];
+                    w1[4 * p + et][r] = w > 0.f ? dwp : -dwp;  // w1 now holds d(pre-abs w1)
+                }
+            s += __shfl_xor(s, 16);
+            s += __shfl_xor(s, 32);
+            if (g == 0 && ok) io.dq[(size_t)p * R + row] = s;
+        }
+        qmix_store_tiles<W1T>(bw.DW1T + (size_t)blk * (Q::E * P * 16), w1, g, j);
+        qmix_store_tiles<4>(bw.DWFT + (size_t)blk * (Q::E * 16), dwf, g, j);
+        f4 dh[4];  // [dh1 (2 tiles) | dhf (2 tiles)]
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            f4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kt = 0; kt < W1T; ++kt) {
+                const f4 a = T1[(m * W1T + kt) * 64 + lane];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc = MARL_MFMA(a[r], w1[kt][r], acc);
+            }
+            f4 accf = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                const f4 a = TF[(m * 4 + kt) * 64 + lane];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) accf = MARL_MFMA(a[r], dwf[kt][r], accf);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                dh[m][r] = h1[m][r] > 0.f ? acc[r] : 0.f;
+                dh[2 + m][r] = hf[m][r] > 0.f ? accf[r] : 0.f;
+            }
+        }
+        float* g1 = bw.G1T + (size_t)blk * (Q::NF1 * 16);
+        qmix_store_tiles<4>(g1, dh, g, j);
+        qmix_store_tiles<4>(g1 + 64 * 16, dz, g, j);
+        qmix_store_tiles<4>(g1 + 128 * 16, dhv, g, j);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// weight gradients: dW1cat[192][SD] = G1^T S, dB1[E*P][32] = DW1^T h1, dBf[64][32] = DWF^T hf, bias gradients = column
+// sums, dV.2 = sum_rows dy hv.  Workgroup = 8 waves over a contiguous range of row blocks; every wave accumulates its
+// own tiles in registers (K order inside a block: row 4g+e at k-step e, the same on both operands).
+// ---------------------------------------------------------------------------------------------------------
+template <class Q, bool REPLAY>
+__global__ __launch_bounds__(512, 1) void qmix_wgrad_kernel(QmixRows<Q, REPLAY> src, const float* __restrict__ Y1, QmixBwd bw, int R,
+                                                            float* __restrict__ partials) {
+    constexpr int P = Q::P, SD = Q::SD, NTS = Q::KS4, W1T = Q::W1T, NF1 = Q::NF1;
+    constexpr int MG = NTS >= 4 ? 2 : 4, NG = 8 / MG, MPW = Q::MT1 / MG, NPW = (NTS + NG - 1) / NG, M2W = (W1T + 7) / 8;
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, g = lane >> 4, j = lane & 15;
+    const int mg = w % MG, ng = w / MG;
+    const size_t ps = src.pstride();
+    f4 accW[MPW][NPW], accB1[M2W][2], accBf = {0.f, 0.f, 0.f, 0.f}, dbv = {0.f, 0.f, 0.f, 0.f};
+    float cs1[MPW], csc1[M2W], cscf = 0.f, dcv = 0.f;
+#pragma unroll
+    for (int m = 0; m < MPW; ++m) {
+        cs1[m] = 0.f;
+#pragma unroll
+        for (int n = 0; n < NPW; ++n) accW[m][n] = accBf;
+    }
+#pragma unroll
+    for (int m = 0; m < M2W; ++m) {
+        csc1[m] = 0.f;
+        accB1[m][0] = accBf;
+        accB1[m][1] = accBf;
+    }
+    size_t soff[NPW];  // state column of this lane in each owned N tile
+    bool sval[NPW];
+#pragma unroll
+    for (int n = 0; n < NPW; ++n) {
+        const int k = 16 * (ng + n * NG) + j;
+        sval[n] = (ng + n * NG) < NTS && k < SD;
+        soff[n] = qmix_state_off<Q>(k < SD ? k : SD - 1, ps);
+    }
+    const int nblk = (R + 15) / 16;
+    const int per = (nblk + gridDim.x - 1) / gridDim.x;
+    const int bA = blockIdx.x * per, bB = (bA + per) < nblk ? bA + per : nblk;
+    for (int blk = bA; blk < bB; ++blk) {
+        const float* rbase[4];
+        const float* yrow[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int row = blk * 16 + 4 * g + e, rc = row < R ? row : R - 1;
+            rbase[e] = src.base(rc, 0);
+            yrow[e] = Y1 + (size_t)rc * NF1;
+        }
+        // (i) first-layer weights
+        f4 a[MPW];
+#pragma unroll
+        for (int m = 0; m < MPW; ++m) {
+            a[m] = *reinterpret_cast<const f4*>(bw.G1T + (size_t)blk * (NF1 * 16) + (16 * (mg * MPW + m) + j) * 16 + 4 * g);
+            if (ng == 0) cs1[m] += (a[m][0] + a[m][1]) + (a[m][2] + a[m][3]);
+        }
+#pragma unroll
+        for (int n = 0; n < NPW; ++n) {
+            float b[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float v = rbase[e][soff[n]];
+                b[e] = sval[n] ? v : 0.f;
+            }
+#pragma unroll
+            for (int m = 0; m < MPW; ++m)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) accW[m][n] = MARL_MFMA(a[m][e], b[e], accW[m][n]);
+        }
+        // (ii) hyper_w_1.2
+        float hb[2][4];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) hb[nt][e] = yrow[e][16 * nt + j];
+#pragma unroll
+        for (int m = 0; m < M2W; ++m) {
+            const int mt2 = w + 8 * m;
+            if (mt2 < W1T) {
+                const f4 a2 = *reinterpret_cast<const f4*>(bw.DW1T + (size_t)blk * (Q::E * P * 16) + (16 * mt2 + j) * 16 + 4 * g);
+                csc1[m] += (a2[0] + a2[1]) + (a2[2] + a2[3]);
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) accB1[m][nt] = MARL_MFMA(a2[e], hb[nt][e], accB1[m][nt]);
+            }
+        }
+        // (iii) hyper_w_final.2: tile (mt = w>>1, nt = w&1)
+        {
+            const f4 a3 = *reinterpret_cast<const f4*>(bw.DWFT + (size_t)blk * (Q::E * 16) + (16 * (w >> 1) + j) * 16 + 4 * g);
+            if ((w & 1) == 0) cscf += (a3[0] + a3[1]) + (a3[2] + a3[3]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) accBf = MARL_MFMA(a3[e], yrow[e][32 + 16 * (w & 1) + j], accBf);
+        }
+        // V.2: wave 7
+        if (w == 7) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float dy = bw.DY[blk * 16 + 4 * g + e];
+                dcv += dy;
+#pragma unroll
+                for (int et = 0; et < 4; ++et) dbv[et] = fmaf(dy, yrow[e][128 + 16 * et + j], dbv[et]);
+            }
+        }
+    }
+    // ---- record of this workgroup, canonical parameter order
+    float* rec = partials + (size_t)blockIdx.x * Q::NPARAM;
+#pragma unroll
+    for (int m = 0; m < MPW; ++m) {
+        const int mt = mg * MPW + m;
+#pragma unroll
+        for (int n = 0; n < NPW; ++n) {
+            const int k = 16 * (ng + n * NG) + j;
+            if ((ng + n * NG) < NTS && k < SD) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rec[qmix_l1_row<Q>(16 * mt + 4 * g + r) + k] = accW[m][n][r];
+            }
+        }
+        if (ng == 0) {
+            float s = cs1[m];
+            s += __shfl_xor(s, 16);
+            s += __shfl_xor(s, 32);
+            if (g == 0) rec[qmix_l1_bias<Q>(16 * mt + j)] = s;
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < M2W; ++m) {
+        const int mt2 = w + 8 * m;
+        if (mt2 < W1T) {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rec[Q::oB1 + (16 * mt2 + 4 * g + r) * Q::HE + 16 * nt + j] = accB1[m][nt][r];
+            float s = csc1[m];
+            s += __shfl_xor(s, 16);
+            s += __shfl_xor(s, 32);
+            if (g == 0) rec[Q::oc1 + 16 * mt2 + j] = s;
+        }
+    }
+    {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rec[Q::oBf + (16 * (w >> 1) + 4 * g + r) * Q::HE + 16 * (w & 1) + j] = accBf[r];
+        if ((w & 1) == 0) {
+            float s = cscf;
+            s += __shfl_xor(s, 16);
+            s += __shfl_xor(s, 32);
+            if (g == 0) rec[Q::ocf + 16 * (w >> 1) + j] = s;
+        }
+    }
+    if (w == 7) {
+#pragma unroll
+        for (int et = 0; et < 4; ++et) {
+            float s = dbv[et];
+            s += __shfl_xor(s, 16);
+            s += __shfl_xor(s, 32);
+            if (g == 0) rec[Q::obv + 16 * et + j] = s;
+        }
+        float s = j == 0 ? dcv : 0.f;
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        if (lane == 0) rec[Q::ocv] = s;
+    }
+}
+
+// mixer_grad[i] = (sum over records, fixed order) / n_filled ; n_filled = nf[1] as written by dqn_reduce_kernel
+__global__ __launch_bounds__(256) void qmix_reduce_kernel(const float* __restrict__ partials, int nwg, int nparam,
+                                                          const float* __restrict__ loss_nf, float* __restrict__ grad) {
+    __shared__ float s_part[4][64];
+    const int l64 = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + l64;
+    float acc = 0.f;
+    if (i < nparam) {
+#pragma unroll 8
+        for (int wg = slice; wg < nwg; wg += 4) acc += partials[(size_t)wg * nparam + i];
+    }
+    s_part[slice][l64] = acc;
+    __syncthreads();
+    if (slice == 0 && i < nparam) grad[i] = ((s_part[0][l64] + s_part[1][l64]) + (s_part[2][l64] + s_part[3][l64])) / loss_nf[1];
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------
+struct QmixCtx {  // what marlhip_qmix_loss_grad adds to the agent-network call
+    const float* mixer;
+    const float* tmixer;
+    float* mgrad;
+    void* ws;  // qmix part of the workspace
+    int64_t ws_bytes;
+};
+
+struct QmixWs {
+    int64_t packs, y1o, y1t, dw1, dwf, dy, ytgt, partials, total;  // byte offsets
+    int nwg3;
+};
+
+template <class Q>
+inline QmixWs qmix_ws_layout(int T, int B) {
+    const int64_t R = (int64_t)T * B, nblk = (R + 15) / 16, Rp = nblk * 16;
+    QmixWs w;
+    auto al = [](int64_t x) { return (x + 255) & ~(int64_t)255; };
+    w.packs = 0;
+    w.y1o = al(w.packs + (int64_t)Q::NPACK * 4);
+    w.y1t = al(w.y1o + Rp * Q::NF1 * 4);  // target first layers, then (dead) reused as G1T
+    w.dw1 = al(w.y1t + Rp * Q::NF1 * 4);
+    w.dwf = al(w.dw1 + Rp * Q::E * Q::P * 4);
+    w.dy = al(w.dwf + Rp * Q::E * 4);
+    w.ytgt = al(w.dy + Rp * 4);
+    w.partials = al(w.ytgt + Rp * 4);
+    w.nwg3 = (int)(nblk < 256 ? nblk : 256);
+    w.total = al(w.partials + (int64_t)w.nwg3 * Q::NPARAM * 4);
+    return w;
+}
+
+// the mixer stage between the agent forward and backward passes
+template <class Q, bool REPLAY>
+int qmix_launch_mix(const QmixCtx& qx, const marlhip_batch* bt, const ReplaySrc& rsrc, const QmixIo& io, float gamma, hipStream_t st) {
+    const int T = bt->max_len, B = bt->batch, R = T * B;
+    const QmixWs wl = qmix_ws_layout<Q>(T, B);
+    MARL_REQUIRE(qx.ws_bytes >= wl.total, "qmix_loss_grad: mixer workspace %lld < %lld bytes", (long long)qx.ws_bytes, (long long)wl.total);
+    char* base = static_cast<char*>(qx.ws);
+    float* packs = reinterpret_cast<float*>(base + wl.packs);
+    float* y1o = reinterpret_cast<float*>(base + wl.y1o);
+    float* y1t = reinterpret_cast<float*>(base + wl.y1t);
+    QmixBwd bw;
+    bw.G1T = y1t;
+    bw.DW1T = reinterpret_cast<float*>(base + wl.dw1);
+    bw.DWFT = reinterpret_cast<float*>(base + wl.dwf);
+    bw.DY = reinterpret_cast<float*>(base + wl.dy);
+    QmixIo io2 = io;
+    io2.ytgt = reinterpret_cast<float*>(base + wl.ytgt);
+    QmixRows<Q, REPLAY> src;
+    src.obs = bt->obss; src.rs = rsrc; src.T = T; src.B = B;
+    constexpr int CH = (Q::NCH == 1 ? Q::KS4 : 4) * Q::MT1 * 256 * (int)sizeof(float);
+    constexpr int LM_ON = Q::NMIX * (int)sizeof(float), LM_TG = Q::NMIX_FWD * (int)sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qmix_l1_kernel<Q, REPLAY>), hipFuncAttributeMaxDynamicSharedMemorySize, CH);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qmix_mix_kernel<Q, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LM_ON);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qmix_mix_kernel<Q, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LM_TG);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((qmix_pack_kernel<Q>), dim3((Q::NPACK + 255) / 256), dim3(256), 0, st, qx.mixer, qx.tmixer, packs);
+    const int ngroups = (R + 127) / 128, nblk = (R + 15) / 16;
+    const int g1 = ngroups < 768 ? ngroups : 768;
+    const int g2 = (nblk + 3) / 4 < 256 ? (nblk + 3) / 4 : 256;
+    timing_begin(TIMER_QMIX, st);
+    hipLaunchKernelGGL((qmix_l1_kernel<Q, REPLAY>), dim3(g1), dim3(256), CH, st, (const float*)(packs + Q::NL1), src, 1, R, y1t);
+    hipLaunchKernelGGL((qmix_mix_kernel<Q, false>), dim3(g2), dim3(256), LM_TG, st, (const float*)(packs + 2 * Q::NL1 + Q::NMIX),
+                       (const float*)y1t, io2, R, gamma, bw);
+    hipLaunchKernelGGL((qmix_l1_kernel<Q, REPLAY>), dim3(g1), dim3(256), CH, st, (const float*)packs, src, 0, R, y1o);
+    hipLaunchKernelGGL((qmix_mix_kernel<Q, true>), dim3(g2), dim3(256), LM_ON, st, (const float*)(packs + 2 * Q::NL1), (const float*)y1o,
+                       io2, R, gamma, bw);
+    hipLaunchKernelGGL((qmix_wgrad_kernel<Q, REPLAY>), dim3(wl.nwg3), dim3(512), 0, st, src, (const float*)y1o, bw, R,
+                       reinterpret_cast<float*>(base + wl.partials));
+    timing_end(TIMER_QMIX, st);
+    MARL_CHECK_LAUNCH("qmix mixer stage");
+    return 0;
+}
+
+// after dqn_reduce_kernel has written loss[1] = sum(filled)
+template <class Q>
+int qmix_launch_reduce(const QmixCtx& qx, int T, int B, const float* loss, hipStream_t st) {
+    const QmixWs wl = qmix_ws_layout<Q>(T, B);
+    hipLaunchKernelGGL(qmix_reduce_kernel, dim3((Q::NPARAM + 63) / 64), dim3(256), 0, st,
+                       (const float*)(static_cast<char*>(qx.ws) + wl.partials), wl.nwg3, Q::NPARAM, loss, qx.mgrad);
+    MARL_CHECK_LAUNCH("qmix_reduce_kernel");
+    return 0;
+}
+
+// (agents, obs dim) pairs with a compiled mixer = the LBF shapes of common.h
+#define MARL_QMIX_SHAPES(X) X(2, 12) X(2, 15) X(3, 18) X(3, 24) X(4, 21) X(4, 27) X(8, 39)
+
+}  // namespace marl

@@ -8,7 +8,7 @@ from dataclasses import dataclass
 import torch
 
 from . import _lib
-from ._lib import (BatchStruct, IdqnLearner, LbfBuffers, LbfConfig, MarlHipError, NetShape, ReplayBuffers, ReplayShape, check, lib)
+from ._lib import (BatchStruct, IdqnLearner, QmixMixer, LbfBuffers, LbfConfig, MarlHipError, NetShape, ReplayBuffers, ReplayShape, check, lib)
 
 Batch = namedtuple("Batch", ["obss", "actions", "rewards", "dones", "filled", "action_mask"])  # dqn/train.py:14-16
 
@@ -230,6 +230,66 @@ class DqnUpdater:
                                         float(self.betas[1]), float(self.eps), float(self.grad_clip), float(grad_scale),
                                         int(bool(hard_update)), float(tau), _ptr(self.scratch), _ptr(self.gnorm), _stream()),
               "dqn_clip_adam")
+
+
+class QmixUpdater(DqnUpdater):
+    """QMixNetwork's learner step (marlbase/dqn/model.py:334-443): agent networks + monotonic mixer.  The mixer block is a
+    second flat parameter vector (mixer.parameters() order) with its own Adam moments; `apply` clips the critic gradient
+    only (QNetwork.update clips critic.parameters(), model.py:169-170) and steps both with the same Adam step count."""
+
+    def __init__(self, spec: NetSpec, params, target, mixer, target_mixer, mixing=None, **kw):
+        super().__init__(spec, params, target, **kw)
+        mixing = dict(mixing or dict(embed_dim=64, hypernet_layers=2, hypernet_embed=32))
+        self.mixing = (int(mixing["embed_dim"]), int(mixing["hypernet_layers"]), int(mixing["hypernet_embed"]))
+        s = spec.c()
+        n = check(lib.marlhip_qmix_nparams(ctypes.byref(s), *self.mixing), "qmix_nparams")
+        if mixer.numel() != n or target_mixer.numel() != n:
+            raise ValueError(f"mixer block has {mixer.numel()} parameters, the QMixer of this shape has {n}")
+        self.mixer, self.target_mixer = mixer, target_mixer
+        self.mixer_grad = torch.zeros_like(mixer)
+        self.mixer_exp_avg = torch.zeros_like(mixer)
+        self.mixer_exp_avg_sq = torch.zeros_like(mixer)
+        self.mixer_scratch = torch.zeros((n + 255) // 256 + 1, dtype=torch.float32, device=mixer.device)
+
+    def _workspace(self, T, B):
+        key = (T, B)
+        if key not in self._ws:
+            s = self.spec.c()
+            n = check(lib.marlhip_qmix_workspace_bytes(ctypes.byref(s), T, B), "qmix_workspace_bytes")
+            self._ws[key] = torch.empty(max(int(n), 4), dtype=torch.uint8, device=self.params.device)
+        return self._ws[key]
+
+    def _mx(self):
+        return QmixMixer(self.mixer.data_ptr(), self.target_mixer.data_ptr(), self.mixer_grad.data_ptr(), *self.mixing)
+
+    def loss_grad(self, batch, mode=2):
+        T, B = batch.filled.shape
+        ws = self._workspace(T, B)
+        bs = BatchStruct(batch.obss.data_ptr(), batch.actions.data_ptr(), batch.rewards.data_ptr(), batch.dones.data_ptr(),
+                         batch.filled.data_ptr(), T, B)
+        s, mx = self.spec.c(), self._mx()
+        check(lib.marlhip_qmix_loss_grad(ctypes.byref(s), _ptr(self.params), _ptr(self.target), ctypes.byref(mx), ctypes.byref(bs),
+                                         float(self.gamma), self.double_q, _ptr(ws), ws.numel(), _ptr(self.grad), _ptr(self.loss),
+                                         _stream()), "qmix_loss_grad")
+        return self.loss, self.grad
+
+    def loss_grad_replay(self, replay, batch_size, length=None, idx=None, seed=0, counter=0, idx_out=None, mode=2):
+        ws = self._workspace(replay.T, batch_size)
+        s, mx = self.spec.c(), self._mx()
+        check(lib.marlhip_qmix_loss_grad_replay(ctypes.byref(s), _ptr(self.params), _ptr(self.target), ctypes.byref(mx),
+                                                ctypes.byref(replay.shape), ctypes.byref(replay.bufs), _ptr(idx), int(batch_size),
+                                                int(length or 0), int(seed) & (2**64 - 1), int(counter) & 0xFFFFFFFF,
+                                                _ptr(idx_out), float(self.gamma), self.double_q, _ptr(ws), ws.numel(),
+                                                _ptr(self.grad), _ptr(self.loss), _stream()), "qmix_loss_grad_replay")
+        return self.loss, self.grad
+
+    def apply(self, hard_update=False, tau=0.0, grad_scale=1.0):
+        super().apply(hard_update, tau, grad_scale)  # critic: clip + Adam + target; advances self.step
+        check(lib.marlhip_dqn_clip_adam(self.mixer.numel(), _ptr(self.mixer), _ptr(self.mixer_grad), _ptr(self.mixer_exp_avg),
+                                        _ptr(self.mixer_exp_avg_sq), _ptr(self.target_mixer), self.step, float(self.lr),
+                                        float(self.betas[0]), float(self.betas[1]), float(self.eps), 0.0, float(grad_scale),
+                                        int(bool(hard_update)), float(tau), _ptr(self.mixer_scratch), None, _stream()),
+              "dqn_clip_adam(mixer)")
 
 
 def idqn_collect(cfg: LbfConfig, spec: NetSpec, params, epsilon, round_idx, replay: DeviceReplay, slot_base, fin_return,

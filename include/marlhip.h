@@ -271,9 +271,41 @@ int marlhip_idqn_update_n(const marlhip_idqn_learner* L, int32_t n_updates, int3
                           void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * QMIX learner.  Replaces QMixNetwork._compute_loss (marlbase/dqn/model.py:374-427) with QMixer.forward
+ * (model.py:313-331) for both the online and the target mixer: state = concatenation of all agents'
+ * observations (model.py:389,412), reward of agent 0 (model.py:379), Double-Q bootstrap mixed by the TARGET
+ * mixer on obs[1:].  Runs as agent-forward -> mixer stage (4 MFMA kernels) -> agent-backward.
+ * Flat mixer block = mixer.parameters() order: hyper_w_1.{0,2}.{weight,bias}, hyper_w_final.{0,2}.{weight,bias},
+ * hyper_b_1.{weight,bias}, V.{0,2}.{weight,bias} (model.py:283-312).  Compiled for mixing = {embed_dim 64,
+ * hypernet_layers 2, hypernet_embed 32} (configs/algorithm/qmix.yaml:14-17); anything else is an error.
+ * QNetwork.update clips the CRITIC gradient only (model.py:169-170): call marlhip_dqn_clip_adam on the critic block
+ * with max_norm and on the mixer block with max_norm = 0 (same step count; one torch Adam over both lists).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct marlhip_qmix_mixer {
+    const float* mixer;        /* [marlhip_qmix_nparams] */
+    const float* target_mixer; /* same layout */
+    float* mixer_grad;         /* out: d loss / d mixer */
+    int32_t embed_dim, hypernet_layers, hypernet_embed;
+} marlhip_qmix_mixer;
+
+int marlhip_qmix_nparams(const marlhip_net_shape* s, int32_t embed_dim, int32_t hypernet_layers, int32_t hypernet_embed);
+/* scratch for marlhip_qmix_loss_grad: the agent-network workspace + first-layer activations and backward operands */
+int64_t marlhip_qmix_workspace_bytes(const marlhip_net_shape* s, int32_t max_len, int32_t batch);
+/* grad[P][nparams], mixer->mixer_grad, loss[0] = value, loss[1] = sum(filled) */
+int marlhip_qmix_loss_grad(const marlhip_net_shape* s, const float* params, const float* target_params,
+                           const marlhip_qmix_mixer* mixer, const marlhip_batch* batch, float gamma, int32_t double_q,
+                           void* workspace, int64_t workspace_bytes, float* grad, float* loss, void* stream);
+/* the same with the B episodes gathered in-kernel from the replay (see marlhip_dqn_loss_grad_replay) */
+int marlhip_qmix_loss_grad_replay(const marlhip_net_shape* s, const float* params, const float* target_params,
+                                  const marlhip_qmix_mixer* mixer, const marlhip_replay_shape* rs,
+                                  const marlhip_replay_buffers* rb, const int32_t* idx, int32_t batch, int32_t length,
+                                  uint64_t seed, uint32_t counter, int32_t* idx_out, float gamma, int32_t double_q,
+                                  void* workspace, int64_t workspace_bytes, float* grad, float* loss, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Measurement aid (bench.py roofline leg): when enabled, the named kernels are bracketed by HIP
  * events on the stream they are launched on.  ids: 0 loss/grad kernel, 1 fused collector,
- * 2 replay sample gather, 3 env step.  marlhip_timing_read waits for the recorded events,
+ * 2 replay sample gather, 3 env step, 4 QMIX mixer stage.  marlhip_timing_read waits for the recorded events,
  * returns launches and summed milliseconds, and clears the slot.
  * ---------------------------------------------------------------------------------------- */
 int marlhip_timing_enable(int32_t on);
