@@ -3,7 +3,7 @@
 The reference is driven by Hydra (`python run.py +algorithm=idqn env.name=... env.time_limit=25`,
 marlbase/run.py:14, marlbase/configs/**).  Hydra / OmegaConf are not dependencies of this package;
 this module provides the small part of their behaviour the hot path needs:
-  * the default tree (same keys and values as configs/default.yaml + configs/algorithm/{idqn,vdn}.yaml,
+  * the default tree (same keys and values as configs/default.yaml + configs/algorithm/{idqn,vdn,qmix}.yaml,
     with `_target_`s pointing at this package and `device: cuda`),
   * `+algorithm=<name>` group selection and dotted `key=value` overrides with YAML-typed values,
   * `instantiate` / `call` on `_target_` strings (module path resolved inside this package first, so
@@ -65,6 +65,11 @@ ALGORITHMS = {
     "vdn": {"env": {"wrappers": ["CooperativeReward"]},
             "algorithm": dict(copy.deepcopy(_IDQN["algorithm"]), name="vdn",
                               model=dict(_IDQN["algorithm"]["model"], _target_="dqn.model.VDNetwork"))},
+    # configs/algorithm/qmix.yaml
+    "qmix": {"env": {"wrappers": ["CooperativeReward"]},
+             "algorithm": dict(copy.deepcopy(_IDQN["algorithm"]), name="qmix",
+                               model=dict(_IDQN["algorithm"]["model"], _target_="dqn.model.QMixNetwork",
+                                          mixing={"embed_dim": 64, "hypernet_layers": 2, "hypernet_embed": 32}))},
 }
 
 

@@ -220,3 +220,92 @@ class VDNetwork(QNetwork):
 
     def __repr__(self):
         return super().__repr__().replace("QNetwork[HIP]", "VDNetwork[HIP]")
+
+
+_MIXER_LAYOUT = ("hyper_w_1.0", "hyper_w_1.2", "hyper_w_final.0", "hyper_w_final.2", "hyper_b_1", "V.0", "V.2")
+
+
+def init_flat_mixer(n_agents, state_dim, embed_dim, hypernet_layers, hypernet_embed):
+    """Initial mixer AND target-mixer blocks in mixer.parameters() order, consuming torch's global RNG like
+    QMixNetwork.__init__ does (mixer, then target mixer, then hard_update; dqn/model.py:283-312, 361-363)."""
+    if hypernet_layers != 2:
+        raise NotImplementedError("QMixer with hypernet_layers != 2: the HIP mixer kernels implement configs/algorithm/qmix.yaml")
+
+    def one():
+        mods = [nn.Linear(state_dim, hypernet_embed), nn.Linear(hypernet_embed, embed_dim * n_agents),
+                nn.Linear(state_dim, hypernet_embed), nn.Linear(hypernet_embed, embed_dim),
+                nn.Linear(state_dim, embed_dim), nn.Linear(state_dim, embed_dim), nn.Linear(embed_dim, 1)]
+        return torch.cat([t.detach().reshape(-1) for m in mods for t in (m.weight, m.bias)]), [m.weight.shape for m in mods]
+
+    mixer, shapes = one()
+    one()  # the target mixer's own draw, overwritten by hard_update
+    return mixer, mixer.clone(), shapes
+
+
+class QMixNetwork(QNetwork):
+    """QMIX - drop-in for `dqn.model.QMixNetwork` (marlbase/dqn/model.py:334-443, configs/algorithm/qmix.yaml).
+    Agent networks as QNetwork; the joint value is the monotonic mixer of the chosen Q-values conditioned on the
+    state (= all agents' observations concatenated).  The mixer lives in a second flat block (`mixer_params`, in
+    mixer.parameters() order) next to the per-agent blocks; on the device the step is agent-forward -> mixer stage
+    (csrc/qmix.h) -> agent-backward; clip_grad_norm_ covers the critic only, Adam steps critic and mixer together."""
+
+    def __init__(self, obs_space, action_space, cfg, layers, parameter_sharing=False, use_rnn=False, use_orthogonal_init=True,
+                 mixing=None, device="cuda"):
+        super().__init__(obs_space, action_space, cfg, layers, parameter_sharing, use_rnn, use_orthogonal_init, device)
+        mixing = dict(mixing or dict(embed_dim=64, hypernet_layers=2, hypernet_embed=32))
+        self.mixing = dict(embed_dim=int(mixing["embed_dim"]), hypernet_layers=int(mixing["hypernet_layers"]),
+                           hypernet_embed=int(mixing["hypernet_embed"]))
+        state_dim = sum(flatdim(o) for o in obs_space)
+        mixer, tmixer, self._mixer_shapes = init_flat_mixer(self.n_agents, state_dim, **self.mixing)
+        self.mixer_params = mixer.to(self.device).contiguous()
+        self.target_mixer_params = tmixer.to(self.device).contiguous()
+        up = self.updater
+        self.updater = _hip.QmixUpdater(self.spec, self.params, self.target_params, self.mixer_params, self.target_mixer_params,
+                                        mixing=self.mixing, lr=up.lr, gamma=self.gamma, grad_clip=self.grad_clip,
+                                        double_q=self.double_q)
+        self.mode = 2
+
+    def update_async(self, batch, grad_sync=None, world=1, replay=None, **sample_kw):
+        sync = None
+        if grad_sync is not None:
+            def sync(grad):  # the mixer gradient rides the same all-reduce cadence
+                grad_sync(grad)
+                grad_sync(self.updater.mixer_grad)
+        return super().update_async(batch, grad_sync=sync, world=world, replay=replay, **sample_kw)
+
+    def soft_update(self, tau):
+        super().soft_update(tau)
+        self.target_mixer_params.mul_(1 - tau).add_(self.mixer_params, alpha=tau)
+
+    def hard_update(self):
+        super().hard_update()
+        self.target_mixer_params.copy_(self.mixer_params)
+
+    def _mixer_views(self, block, prefix):
+        out, o = OrderedDict(), 0
+        for name, wshape in zip(_MIXER_LAYOUT, self._mixer_shapes):
+            for suffix, shape in (("weight", tuple(wshape)), ("bias", (wshape[0],))):
+                n = int(np.prod(shape))
+                out[f"{prefix}.{name}.{suffix}"] = block[o:o + n].view(shape)
+                o += n
+        assert o == block.numel()
+        return out
+
+    def parameters(self):
+        return super().parameters() + list(self._mixer_views(self.mixer_params, "mixer").values())
+
+    def state_dict(self):
+        sd = super().state_dict()
+        for k, v in list(self._mixer_views(self.mixer_params, "mixer").items()) + \
+                list(self._mixer_views(self.target_mixer_params, "target_mixer").items()):
+            sd[k] = v.detach().clone()
+        return sd
+
+    def load_state_dict(self, sd):
+        super().load_state_dict(sd)
+        for block, prefix in ((self.mixer_params, "mixer"), (self.target_mixer_params, "target_mixer")):
+            for k, view in self._mixer_views(block, prefix).items():
+                view.copy_(sd[k].to(self.device))
+
+    def __repr__(self):
+        return super().__repr__().replace("QNetwork[HIP]", "QMixNetwork[HIP]") + f" + mixer({self.mixer_params.numel()} params)"

@@ -91,8 +91,25 @@ def fixture(ref_model, ref_train, name, P, D, B, seed, updates):
           f"losses={losses}")
 
 
+def init_fixture(ref_model):
+    """init_qmix.npz: what QMixNetwork.__init__ leaves in mixer / target_mixer for torch.manual_seed(5), and the
+    state_dict key order a checkpoint written by the reference carries (dqn/train.py:340-343)."""
+    P, D, A, H = 2, 15, 6, 64
+    torch.manual_seed(5)
+    cfg = Cfg(optimizer="Adam", lr=3e-4, gamma=0.99, grad_clip=1.0, target_update_interval_or_tau=200, double_q=True,
+              standardise_returns=False)
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = ref_model.QMixNetwork([Box(D)] * P, [Discrete(A)] * P, cfg, [H, H], False, False, True,
+                                    dict(embed_dim=64, hypernet_layers=2, hypernet_embed=32), "cpu")
+    keys = [k for k in net.state_dict().keys()]
+    np.savez_compressed(os.path.join(OUT, "init_qmix.npz"), mixer=mixer_flat(net.mixer).numpy(),
+                        tmixer=mixer_flat(net.target_mixer).numpy(), keys=np.array(keys))
+    print(f"init_qmix: {len(keys)} state_dict keys, mixer {mixer_flat(net.mixer).numel()} params")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(1)
     rm, rt = import_reference()
+    init_fixture(rm)
     fixture(rm, rt, "learner_qmix_H64.npz", P=2, D=15, B=32, seed=300, updates=3)
     fixture(rm, rt, "learner_qmix_p4_H64.npz", P=4, D=27, B=24, seed=400, updates=0)

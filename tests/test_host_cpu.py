@@ -93,3 +93,26 @@ def test_initial_weights_consume_torch_rng_like_the_reference():
                 np.testing.assert_array_equal(t.numpy(), g[f"target_H{H}_orth{int(orth)}"])
     finally:
         torch.set_num_threads(nt)
+
+
+def test_qmix_mixer_init_consumes_torch_rng_like_the_reference():
+    """same torch.manual_seed -> the mixer block QMixNetwork.__init__ builds after its agent networks
+    (marlbase/dqn/model.py:361-363), bit for bit; qmix.yaml's tree composes with the reference's target string"""
+    from codebase_amd.config import compose
+    from codebase_amd.dqn.model import init_flat_mixer, init_flat_params
+
+    g = np.load(os.path.join(G, "init_qmix.npz"))
+    nt = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        torch.manual_seed(5)
+        init_flat_params([15, 15], [64, 64], [6, 6], True)
+        mixer, tmixer, shapes = init_flat_mixer(2, 30, 64, 2, 32)
+    finally:
+        torch.set_num_threads(nt)
+    np.testing.assert_array_equal(mixer.numpy(), g["mixer"])
+    np.testing.assert_array_equal(tmixer.numpy(), g["tmixer"])
+    assert [tuple(s) for s in shapes] == [(32, 30), (128, 32), (32, 30), (64, 32), (64, 30), (64, 30), (1, 64)]
+    cfg = compose(["+algorithm=qmix", "env.name=lbforaging:Foraging-8x8-2p-3f-v3", "env.time_limit=25"])
+    assert cfg.algorithm.model._target_ == "dqn.model.QMixNetwork" and cfg.env.wrappers == ["CooperativeReward"]
+    assert dict(cfg.algorithm.model.mixing) == {"embed_dim": 64, "hypernet_layers": 2, "hypernet_embed": 32}
