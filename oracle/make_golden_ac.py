@@ -1,0 +1,88 @@
+"""Generate tests/golden/learner_a2c_*.npz and learner_ppo_H64.npz from the REFERENCE's own A2CNetwork / PPONetwork
+(marlbase/ac/model.py:21-352, imported unmodified with the four stubs of oracle/make_golden.py).
+Runs only in the build container (needs /root/reference); the vectors travel, the reference does not.
+
+    PYTHONDONTWRITEBYTECODE=1 python -m oracle.make_golden_ac
+
+Each file: actor / critic / target-critic blocks ([P][n], parameters() order), one rollout Batch per update in the
+ac/train.py layout, the four metrics of update(), the gradient of the first update (recomputed without stepping),
+and the blocks after each of 3 updates at env steps 0, 250, 400 (hard target copy at `step % 200 == 0`: updates 1, 3).
+  learner_a2c_H64.npz       ia2c.yaml defaults (n_steps 5, entropy 0.001, value coef 0.5, no clipping), 2 agents x 15 obs
+  learner_a2c_clip_H128.npz grad_clip 0.5 (clip over actor AND critic), n_steps 3, 3 agents x 18 obs, 128-128
+  learner_ppo_H64.npz       ippo.yaml defaults (4 epochs, clip 0.2)
+"""
+import contextlib
+import io
+import os
+
+import numpy as np
+import torch
+
+from .ac_update_port import synthetic_batch
+from .make_golden import OUT, Box, Cfg, Discrete, flat_params, import_reference
+
+
+def build(cls, P, D, A, H, seed, **over):
+    torch.manual_seed(seed)
+    cfg = Cfg(optimizer="Adam", lr=3e-4, gamma=0.99, grad_clip=False, n_steps=5, entropy_coef=0.001, value_loss_coef=0.5,
+              standardise_returns=False, target_update_interval_or_tau=200, num_epochs=4, ppo_clip=0.2)
+    cfg.update(over)
+    net_cfg = dict(layers=[H, H], parameter_sharing=False, use_orthogonal_init=True, use_rnn=False)
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = cls([Box(D)] * P, [Discrete(A)] * P, cfg, Cfg(net_cfg), Cfg(dict(net_cfg, centralised=False)), "cpu")
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():  # non-zero biases, target != critic
+        for p in list(net.actor.parameters()) + list(net.critic.parameters()):
+            p.add_(0.05 * torch.randn(p.shape, generator=g))
+        for p in net.target_critic.parameters():
+            p.add_(0.08 * torch.randn(p.shape, generator=g))
+    return net, cfg
+
+
+def fixture(ref_ac_model, ref_ac_train, name, cls, P, D, H, N, seed, **over):
+    T, A = 25, 6
+    net, cfg = build(cls, P, D, A, H, seed, **over)
+    out = dict(P=P, T=T, N=N, D=D, A=A, H=H, n_steps=cfg.n_steps, gamma=cfg.gamma, entropy_coef=cfg.entropy_coef,
+               value_loss_coef=cfg.value_loss_coef, grad_clip=float(cfg.grad_clip or 0.0), num_epochs=cfg.num_epochs,
+               ppo_clip=cfg.ppo_clip, actor0=flat_params(net.actor).numpy(), critic0=flat_params(net.critic).numpy(),
+               target0=flat_params(net.target_critic).numpy())
+    steps = [0, 250, 400]
+    batches = [synthetic_batch(P, T, N, D, A, seed=seed + 100 + i) for i in range(3)]
+    mk = lambda b: ref_ac_train.Batch(b["obss"], b["actions"], b["rewards"], b["dones"], b["filled"], None)  # noqa: E731
+    if cls is ref_ac_model.A2CNetwork:  # gradient of the first update, via a throw-away copy stepped with lr = 0
+        probe, _ = build(cls, P, D, A, H, seed, **dict(over, lr=0.0, grad_clip=False))
+        probe.update(mk(batches[0]), 1)
+        out["actor_grad0"] = torch.stack([torch.cat([p.grad.reshape(-1) for p in m.parameters()]) for m in probe.actor.independent]).numpy()
+        out["critic_grad0"] = torch.stack([torch.cat([p.grad.reshape(-1) for p in m.parameters()]) for m in probe.critic.independent]).numpy()
+        with torch.no_grad():  # forward pieces for a forward-only check
+            b = batches[0]
+            nv, _ = probe.get_value(probe.split_obs(b["obss"]), None, target=True)
+            out["next_value0"] = nv.numpy()
+            done = b["dones"].float().unsqueeze(-1).repeat(1, 1, P)
+            from marlbase.utils.utils import compute_nstep_returns
+            out["returns0"] = compute_nstep_returns(b["rewards"], done, nv, cfg.n_steps, cfg.gamma).numpy()
+    metrics = []
+    for i, (b, st) in enumerate(zip(batches, steps)):
+        m = net.update(mk(b), st)
+        metrics.append([m["loss"], m["actor_loss"], m["value_loss"], m["entropy"]])
+        out[f"actor{i + 1}"] = flat_params(net.actor).numpy()
+        out[f"critic{i + 1}"] = flat_params(net.critic).numpy()
+        out[f"target{i + 1}"] = flat_params(net.target_critic).numpy()
+    out["metrics"] = np.array(metrics, np.float64)
+    out["steps"] = np.array(steps)
+    for i, b in enumerate(batches):
+        for k, v in b.items():
+            out[f"batch{i}_{k}"] = v.numpy()
+    np.savez_compressed(os.path.join(OUT, name), **out)
+    print(name, "metrics", np.array(metrics).round(5).tolist())
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(1)
+    import_reference()
+    from marlbase.ac import model as ram
+    from marlbase.ac import train as rat
+
+    fixture(ram, rat, "learner_a2c_H64.npz", ram.A2CNetwork, P=2, D=15, H=64, N=12, seed=500)
+    fixture(ram, rat, "learner_a2c_clip_H128.npz", ram.A2CNetwork, P=3, D=18, H=128, N=9, seed=600, grad_clip=0.5, n_steps=3)
+    fixture(ram, rat, "learner_ppo_H64.npz", ram.PPONetwork, P=2, D=15, H=64, N=12, seed=700)

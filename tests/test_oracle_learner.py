@@ -121,3 +121,45 @@ def test_qmix_loss_grad_and_updates_match_reference(name):
         np.testing.assert_allclose(lr.flat().detach().numpy(), g[f"params{i + 1}"], rtol=0, atol=2e-6)
         np.testing.assert_allclose(lr.mflat().detach().numpy(), g[f"mixer{i + 1}"], rtol=0, atol=2e-6)
         np.testing.assert_allclose(lr.tmixer.numpy(), g[f"tmixer{i + 1}"], rtol=0, atol=2e-6)
+
+
+def ac_batch_of(g, i):
+    return {k: torch.tensor(g[f"batch{i}_{k}"]) for k in ("obss", "actions", "rewards", "dones", "filled")}
+
+
+@pytest.mark.parametrize("name", ["learner_a2c_H64.npz", "learner_a2c_clip_H128.npz", "learner_ppo_H64.npz"])
+def test_actor_critic_update_matches_reference(name):
+    """oracle/ac_update_port.py against the reference's A2CNetwork / PPONetwork (marlbase/ac/model.py:189-352):
+    n-step returns, gradient, metrics and the parameter blocks after 3 updates incl. the step-keyed target copy."""
+    from oracle import ac_update_port as ap
+
+    g = load(name)
+    P, D, H, A = int(g["P"]), int(g["D"]), int(g["H"]), int(g["A"])
+    ppo = "ppo" in name
+    kw = dict(n_steps=int(g["n_steps"]), gamma=float(g["gamma"]), entropy_coef=float(g["entropy_coef"]),
+              value_loss_coef=float(g["value_loss_coef"]))
+    actor, critic, target = (torch.tensor(g[k]) for k in ("actor0", "critic0", "target0"))
+    if not ppo:
+        b = ac_batch_of(g, 0)
+        with torch.no_grad():
+            nv = ap.values(target, b["obss"], D, H)
+            np.testing.assert_allclose(nv.numpy(), g["next_value0"], rtol=1e-5, atol=1e-5)
+            done = b["dones"].float().unsqueeze(-1).repeat(1, 1, P)
+            np.testing.assert_allclose(ap.nstep_returns(b["rewards"], done, nv, kw["n_steps"], kw["gamma"]).numpy(),
+                                       g["returns0"], rtol=1e-5, atol=1e-5)
+        a, c = actor.clone().requires_grad_(True), critic.clone().requires_grad_(True)
+        loss, m = ap.a2c_loss(a, c, target, b, D, H, A, **kw)
+        loss.backward()
+        assert abs(loss.item() - g["metrics"][0][0]) <= 1e-5 * abs(g["metrics"][0][0])
+        np.testing.assert_allclose(a.grad.numpy(), g["actor_grad0"], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(c.grad.numpy(), g["critic_grad0"], rtol=1e-4, atol=1e-6)
+    lr = ap.Learner(actor, critic, D, H, A, grad_clip=float(g["grad_clip"]) or False, num_epochs=int(g["num_epochs"]) if ppo else 0,
+                    ppo_clip=float(g["ppo_clip"]), **kw)
+    lr.target = target
+    for i in range(3):
+        m = lr.update(ac_batch_of(g, i), int(g["steps"][i]))
+        got = [m["loss"], m["actor_loss"], m["value_loss"], m["entropy"]]
+        np.testing.assert_allclose(got, g["metrics"][i], rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(lr.actor().detach().numpy(), g[f"actor{i + 1}"], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(lr.critic().detach().numpy(), g[f"critic{i + 1}"], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(lr.target.numpy(), g[f"target{i + 1}"], rtol=0, atol=2e-6)
