@@ -40,12 +40,19 @@ class ReplayBuffers(ctypes.Structure):
 
 class BatchStruct(ctypes.Structure):
     _fields_ = [("obss", c_void_p), ("actions", c_void_p), ("rewards", c_void_p), ("dones", c_void_p),
-                ("filled", c_void_p), ("max_len", c_int32), ("batch", c_int32)]
+                ("filled", c_void_p), ("max_len", c_int32), ("batch", c_int32),
+                ("obs_agent_stride", c_int64), ("obs_row_stride", c_int64), ("act_agent_stride", c_int64),
+                ("act_row_stride", c_int64)]
 
 
 class QmixMixer(ctypes.Structure):
     _fields_ = [("mixer", c_void_p), ("target_mixer", c_void_p), ("mixer_grad", c_void_p), ("embed_dim", c_int32),
                 ("hypernet_layers", c_int32), ("hypernet_embed", c_int32)]
+
+
+class AcConfig(ctypes.Structure):
+    _fields_ = [("n_steps", c_int32), ("entropy_coef", c_float), ("value_loss_coef", c_float), ("ppo_clip", c_float),
+                ("gamma", c_double)]
 
 
 class IdqnLearner(ctypes.Structure):
@@ -92,6 +99,16 @@ PROTOTYPES = {
     "marlhip_qmix_loss_grad_replay": (c_int32, [POINTER(NetShape), c_void_p, c_void_p, POINTER(QmixMixer), POINTER(ReplayShape),
                                                 POINTER(ReplayBuffers), c_void_p, c_int32, c_int32, c_uint64, c_uint32, c_void_p,
                                                 c_float, c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "marlhip_ac_critic_nparams": (c_int32, [POINTER(NetShape)]),
+    "marlhip_ac_workspace_bytes": (c_int64, [POINTER(NetShape), c_int32, c_int32]),
+    "marlhip_ac_forward_rows": (c_int32, [POINTER(NetShape), c_int32, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_void_p,
+                                          c_void_p]),
+    "marlhip_a2c_loss_grad": (c_int32, [POINTER(NetShape), c_void_p, c_void_p, c_void_p, POINTER(BatchStruct), POINTER(AcConfig),
+                                        c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "marlhip_ppo_prepare": (c_int32, [POINTER(NetShape), c_void_p, c_void_p, c_void_p, POINTER(BatchStruct), POINTER(AcConfig),
+                                      c_void_p, c_int64, c_void_p]),
+    "marlhip_ppo_loss_grad": (c_int32, [POINTER(NetShape), c_void_p, c_void_p, POINTER(BatchStruct), POINTER(AcConfig),
+                                        c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "marlhip_dqn_clip_adam": (c_int32, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_double,
                                         c_double, c_double, c_double, c_float, c_float, c_int32, c_float, c_void_p,
                                         c_void_p, c_void_p]),

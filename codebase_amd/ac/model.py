@@ -1,0 +1,199 @@
+"""`A2CNetwork` / `PPONetwork` with the reference's duck-typed interface - drop-ins for
+`algorithm.model._target_: ac.model.A2CNetwork | ac.model.PPONetwork` (marlbase/configs/algorithm/ia2c.yaml:8,
+ippo.yaml:8; marlbase/ac/model.py:21-352) - whose computations run in libmarlhip.so.
+
+Interface kept: constructor `(obs_space, action_space, cfg, actor, critic, device)`, `init_actor_hiddens`,
+`init_critic_hiddens`, `act(inputs, actor_hiddens, action_mask=None) -> (actions [P,N,1], hiddens)`,
+`get_value(inputs, critic_hiddens, target=False)`, `update(batch, step) -> {"loss", "actor_loss", "value_loss",
+"entropy"}`, `soft_update(t)`, `parameters()`, `state_dict()/load_state_dict()` with the reference's keys
+(`actor.independent.{i}.network.{0,2,4}.{weight,bias}`, `critic.*`, `target_critic.*`).
+
+Storage: ONE flat fp32 block [actor agents | critic agents] (so that clip_grad_norm_(self.parameters()) + Adam is a
+single fused launch) plus the target-critic block; state_dict tensors are slices.
+Built: independent actors and critics (IA2C / IPPO), two equal hidden layers of 64 or 128.  Not built (raise):
+centralised critic (MAA2C / MAPPO), parameter sharing, GRU, action masks, return standardisation.
+"""
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from .. import hip as _hip
+from ..dqn.model import _fc, _tensor_layout
+from ..spaces import flatdim
+
+
+def _get(cfg, k, d=None):
+    if isinstance(cfg, dict):
+        return cfg[k] if k in cfg else d
+    return getattr(cfg, k, d)
+
+
+def _init_blocks(obs_dims, hidden, out_dims, orth):
+    return torch.stack([torch.cat([t.detach().reshape(-1) for lin in _fc([d] + list(hidden) + [a], orth) for t in (lin.weight, lin.bias)])
+                        for d, a in zip(obs_dims, out_dims)])
+
+
+class A2CNetwork:
+    def __init__(self, obs_space, action_space, cfg, actor, critic, device="cuda"):
+        obs_dims = [flatdim(o) for o in obs_space]
+        act_dims = [flatdim(a) for a in action_space]
+        self.n_agents = P = len(obs_dims)
+        for name, net in (("actor", actor), ("critic", critic)):
+            if _get(net, "parameter_sharing", False):
+                raise NotImplementedError(f"{name}.parameter_sharing: shared / SePS networks are a 'next' row (DESIGN.md)")
+            if _get(net, "use_rnn", False):
+                raise NotImplementedError(f"{name}.use_rnn: the GRU path is a 'next' row (DESIGN.md)")
+        if _get(critic, "centralised", False):
+            raise NotImplementedError("critic.centralised (MAA2C / MAPPO) is a 'next' row (DESIGN.md)")
+        if _get(cfg, "standardise_returns", False):
+            raise NotImplementedError("standardise_returns is a 'next' row (DESIGN.md)")
+        ha, hc = [int(h) for h in _get(actor, "layers")], [int(h) for h in _get(critic, "layers")]
+        if ha != hc or len(ha) != 2 or ha[0] != ha[1]:
+            raise NotImplementedError(f"layers actor={ha} critic={hc}: the HIP kernels implement two equal hidden layers (64 or 128), "
+                                      "the same for actor and critic")
+        if len(set(obs_dims)) != 1 or len(set(act_dims)) != 1:
+            raise NotImplementedError("agents with different observation / action sizes")
+        if str(device) == "cpu":
+            raise _hip.MarlHipError("codebase_amd.ac.model.A2CNetwork runs on the GPU only: set algorithm.model.device=cuda")
+        opt = _get(cfg, "optimizer", "Adam")
+        if (opt if isinstance(opt, str) else getattr(opt, "__name__", "")) != "Adam":
+            raise NotImplementedError(f"optimizer {opt}: the fused step implements torch.optim.Adam")
+        self.device = torch.device(device)
+        self.gamma, self.entropy_coef = float(_get(cfg, "gamma", 0.99)), float(_get(cfg, "entropy_coef", 0.001))
+        self.n_steps, self.grad_clip = int(_get(cfg, "n_steps", 5)), _get(cfg, "grad_clip", False)
+        self.value_loss_coef = float(_get(cfg, "value_loss_coef", 0.5))
+        self.target_update_interval_or_tau = _get(cfg, "target_update_interval_or_tau", 200)
+        self.standardise_returns = False
+        self.centralised_critic = False
+        self.spec = _hip.NetSpec(P, obs_dims[0], ha[0], act_dims[0])
+        # torch RNG consumption in the reference's order: actor nets, critic nets, target-critic nets (model.py:44-107)
+        a0 = _init_blocks(obs_dims, ha, act_dims, _get(actor, "use_orthogonal_init", True))
+        c0 = _init_blocks(obs_dims, hc, [1] * P, _get(critic, "use_orthogonal_init", True))
+        _init_blocks(obs_dims, hc, [1] * P, _get(critic, "use_orthogonal_init", True))  # target: drawn, then overwritten (soft_update(1.0))
+        self.block = torch.cat([a0.reshape(-1), c0.reshape(-1)]).to(self.device).contiguous()
+        self.target_critic_params = c0.clone().to(self.device).contiguous()
+        self.updater = _hip.AcUpdater(self.spec, self.block, self.target_critic_params, lr=float(_get(cfg, "lr", 3e-4)),
+                                      gamma=self.gamma, n_steps=self.n_steps, entropy_coef=self.entropy_coef,
+                                      value_loss_coef=self.value_loss_coef, grad_clip=self.grad_clip,
+                                      ppo_clip=float(_get(cfg, "ppo_clip", 0.2)))
+        self.actor_params, self.critic_params = self.updater.actor, self.updater.critic
+
+    # ---- reference interface ---------------------------------------------------------------
+    def init_critic_hiddens(self, batch_size, target=False):
+        return [None] * self.n_agents
+
+    def init_actor_hiddens(self, batch_size):
+        return [None] * self.n_agents
+
+    def forward(self, inputs, rnn_hxs, masks):
+        raise NotImplementedError("Forward not implemented. Use act, get_value, get_target_value or evaluate_actions instead.")
+
+    def _rows(self, inputs):
+        """list of P tensors [..., D] -> contiguous [P][n][D] on the device"""
+        x = torch.stack([torch.as_tensor(i, dtype=torch.float32) for i in inputs]).to(self.device)
+        lead = x.shape[1:-1]
+        return x.reshape(self.n_agents, -1, x.shape[-1]).contiguous(), lead
+
+    def logits(self, inputs):
+        x, lead = self._rows(inputs)
+        n, D = x.shape[1], x.shape[2]
+        out = _hip.ac_forward_rows(self.spec, self.actor_params, x, n * D, D, n)
+        return out.reshape(self.n_agents, *lead, out.shape[-1])
+
+    def act(self, inputs, actor_hiddens, action_mask=None):
+        """model.py:147-153: Categorical(logits).sample() per agent; returns ([P, N, 1] int64, hiddens)"""
+        if action_mask is not None:
+            raise NotImplementedError("action masks (SMAClite) are outside this round's hot path")
+        lg = self.logits(inputs)
+        acts = torch.distributions.Categorical(logits=lg).sample()
+        return acts.unsqueeze(-1), actor_hiddens
+
+    def get_value(self, inputs, critic_hiddens, target=False):
+        """model.py:155-163: [..., P] values of the (target) critic"""
+        x, lead = self._rows(inputs)
+        n, D = x.shape[1], x.shape[2]
+        blk = self.target_critic_params if target else self.critic_params
+        out = _hip.ac_forward_rows(self.spec, blk, x, n * D, D, n, value_net=True)
+        return out.reshape(self.n_agents, *lead).movedim(0, -1).contiguous(), critic_hiddens
+
+    def soft_update(self, t):
+        self.target_critic_params.mul_(1 - t).add_(self.critic_params, alpha=t)
+
+    def _target_update(self, step):
+        tui = self.target_update_interval_or_tau
+        if tui > 1.0 and step % tui == 0:  # model.py:233-239: keyed on the ENV step the driver passes in
+            self.soft_update(1.0)
+        elif tui < 1.0:
+            self.soft_update(tui)
+
+    def update_async(self, batch, step, grad_sync=None, world=1):
+        """loss/grad -> [grad_sync(grad)] -> clip+Adam -> target update; returns the device metrics tensor
+        (loss, actor_loss, value_loss, entropy, sum(filled)) without synchronising."""
+        m = self.updater.a2c_loss_grad(batch)
+        if grad_sync is not None:
+            grad_sync(self.updater.grad)
+        self.updater.apply(grad_scale=1.0 / world)
+        self._target_update(step)
+        return m
+
+    @staticmethod
+    def _metrics(m):
+        m = m.tolist()  # the reference's four .item() syncs
+        return {"loss": m[0], "actor_loss": m[1], "value_loss": m[2], "entropy": m[3]}
+
+    def update(self, batch, step):
+        return self._metrics(self.update_async(batch, step))
+
+    # ---- torch-module-like surface ---------------------------------------------------------------
+    def _views(self):
+        S, P = self.spec, self.n_agents
+        out = OrderedDict()
+        for prefix, block, A in (("actor", self.actor_params, S.n_actions), ("critic", self.critic_params, 1),
+                                 ("target_critic", self.target_critic_params, 1)):
+            for i in range(P):
+                o = 0
+                for name, shape in _tensor_layout(S.obs_dim, S.hidden, A):
+                    n = int(np.prod(shape))
+                    out[f"{prefix}.independent.{i}.{name}"] = block[i, o:o + n].view(shape)
+                    o += n
+        return out
+
+    def parameters(self):
+        return list(self._views().values())
+
+    def state_dict(self):
+        return OrderedDict((k, v.detach().clone()) for k, v in self._views().items())
+
+    def load_state_dict(self, sd):
+        for k, view in self._views().items():
+            view.copy_(sd[k].to(self.device))
+
+    def to(self, device):
+        return self
+
+    def __repr__(self):
+        S = self.spec
+        return (f"{type(self).__name__}[HIP](agents={S.n_agents}, actor={S.obs_dim}-{S.hidden}-{S.hidden}-{S.n_actions}, "
+                f"critic={S.obs_dim}-{S.hidden}-{S.hidden}-1)")
+
+
+class PPONetwork(A2CNetwork):
+    """marlbase/ac/model.py:249-352: returns and old log-probs once per batch, then num_epochs clipped-surrogate steps."""
+
+    def __init__(self, obs_space, action_space, cfg, actor, critic, device="cuda"):
+        super().__init__(obs_space, action_space, cfg, actor, critic, device)
+        self.num_epochs = int(_get(cfg, "num_epochs", 4))
+        self.ppo_clip = float(_get(cfg, "ppo_clip", 0.2))
+
+    def update_async(self, batch, step, grad_sync=None, world=1):
+        up = self.updater
+        up.ppo_prepare(batch)
+        acc = torch.zeros(5, device=self.device)
+        for _ in range(self.num_epochs):
+            acc += up.ppo_loss_grad(batch)
+            if grad_sync is not None:
+                grad_sync(up.grad)
+            up.apply(grad_scale=1.0 / world)
+        self._target_update(step)
+        return acc / self.num_epochs  # model.py:352: mean over epochs

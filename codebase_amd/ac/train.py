@@ -1,6 +1,6 @@
 """Actor-critic rollout collector with the reference's entry point shape - `_collect_trajectories`
-(marlbase/ac/train.py:24-119) - on the fused HIP collector.  The A2C / PPO update itself
-(marlbase/ac/model.py:189-352) is a "next" row; `main` says so instead of falling back."""
+(marlbase/ac/train.py:24-119) - on the fused HIP collector, and the reference's `main` loop (ac/train.py:155-228) around it; the update
+itself is codebase_amd.ac.model.A2CNetwork / PPONetwork (csrc/a2c.hip)."""
 from collections import namedtuple
 
 import numpy as np
@@ -66,6 +66,39 @@ def _collect_trajectories(envs, model, max_ep_length, parallel_envs, n_agents, d
     return t, Batch(b_obs, b_act, b_rew, b_done.bool(), b_fill, None), infos
 
 
+def _log_progress(infos, step, updates, logger):
+    infos.append({"updates": updates, "environment_steps": step})
+    logger.log_metrics(infos)
+
+
 def main(envs, eval_env, logger, time_limit, **cfg):
-    raise NotImplementedError("the A2C/PPO update (marlbase/ac/model.py:189-352) is a 'next' row (DESIGN.md); "
-                              "codebase_amd.ac.train._collect_trajectories (the rollout collector) is built")
+    """marlbase/ac/train.py:155-228: collect one rollout from every env, one update, log at eval_interval.
+    `envs` is a HipForagingVecEnv (env.parallel_envs); the collector and the update are one library call each."""
+    from pathlib import Path
+
+    from ..config import instantiate
+    from ..dqn.train import _cfg_get
+
+    g = lambda k, d=None: _cfg_get(cfg, k, d)  # noqa: E731
+    model = instantiate(g("model"), envs.single_observation_space, envs.single_action_space, cfg)
+    logger.watch(model)
+    parallel_envs = envs.observation_space[0].shape[0]
+    device = g("model.device", "cuda")
+    step = updates = last_eval = last_save = 0
+    while step < g("total_steps") + 1:
+        t, batch, infos = _collect_trajectories(envs, model, time_limit, parallel_envs, model.n_agents, device,
+                                                g("use_proper_termination", False), round_idx=updates)
+        infos.append(model.update(batch, step))
+        if (step - last_eval) >= g("eval_interval"):
+            _log_progress(infos, step, updates, logger)
+            last_eval = step
+        if g("save_interval") and (step - last_save) >= g("save_interval"):
+            Path("checkpoints").mkdir(exist_ok=True)
+            torch.save(model.state_dict(), f"checkpoints/model_s{step}.pt")
+            last_save = step
+        if g("video_interval"):
+            raise NotImplementedError("video recording is outside the HIP hot path")
+        updates += 1
+        step += t * parallel_envs
+    envs.close()
+    return model

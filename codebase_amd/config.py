@@ -72,6 +72,23 @@ ALGORITHMS = {
                                           mixing={"embed_dim": 64, "hypernet_layers": 2, "hypernet_embed": 32}))},
 }
 
+_AC_NET = {"layers": [128, 128], "parameter_sharing": False, "use_orthogonal_init": True, "use_rnn": False}
+_IA2C = {  # configs/algorithm/ia2c.yaml
+    "env": {"parallel_envs": 10},
+    "algorithm": {"_target_": "ac.train.main", "name": "ia2c",
+                  "model": {"_target_": "ac.model.A2CNetwork", "actor": dict(_AC_NET), "critic": dict(_AC_NET, centralised=False),
+                            "device": "cuda"},
+                  "optimizer": "Adam", "lr": 3e-4, "grad_clip": False, "n_steps": 5, "gamma": 0.99, "entropy_coef": 0.001,
+                  "value_loss_coef": 0.5, "use_proper_termination": False, "standardise_returns": False,
+                  "target_update_interval_or_tau": 200},
+}
+ALGORITHMS["ia2c"] = _IA2C
+ALGORITHMS["ippo"] = {  # configs/algorithm/ippo.yaml
+    "env": {"parallel_envs": 10},
+    "algorithm": dict(copy.deepcopy(_IA2C["algorithm"]), name="ippo", num_epochs=4, ppo_clip=0.2,
+                      model=dict(copy.deepcopy(_IA2C["algorithm"]["model"]), _target_="ac.model.PPONetwork")),
+}
+
 
 def _merge(dst, src):
     for k, v in src.items():

@@ -1,0 +1,413 @@
+// Actor-critic learner step (IA2C / IPPO) for gfx950.  Replaces A2CNetwork.update / PPONetwork.update
+// (marlbase/ac/model.py:189-246, 264-352) up to and including loss.backward(); clip + Adam + target update
+// are marlhip_dqn_clip_adam on the joint [actor | critic] block.
+//
+// The step is built from two MFMA primitives shared with the DQN family (dqn_update_kernels.h, mlp.h) and
+// one elementwise kernel between them:
+//   forward rows   mlp_rows_fwd_kernel: out[p][row][:] = MLP_p(obs row) for the target critic (all T+1 rows),
+//                  the critic and the actor (rows t < T).  Weights of one agent sit in LDS as A-operand packs.
+//   ac_elem_kernel one thread per (t, b): n-step returns (marlbase/utils/utils.py:38-63), advantage, Categorical
+//                  log-prob / entropy of the fp32 softmax, the policy-gradient (A2C) or clipped-surrogate (PPO)
+//                  loss row, and dL/dlogits, dL/dvalue for every agent.
+//   backward rows  dqn_lossgrad_kernel MODE 4 (hidden 64) / tp_bwd_kernel FULL (hidden 128): forward again +
+//                  backward with the external output gradient, deterministic partial-record reduction, 1/sum(filled).
+// Rows come straight from the ac/train.py Batch (agents innermost) through marlhip_batch's strides.
+#include "dqn_update_kernels.h"
+
+namespace marl {
+
+// ---- forward rows ------------------------------------------------------------------------------------------
+template <class S>
+__global__ __launch_bounds__(256) void mlp_rows_fwd_kernel(const float* __restrict__ params, const float* __restrict__ obs,
+                                                           size_t agent_stride, size_t row_stride, int n_rows,
+                                                           float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, j = lane & 15;
+    const int p = blockIdx.y;
+    mlp_stage_fwd<S>(params + (size_t)p * S::NPARAM, lds, tid, 256);
+    __syncthreads();
+    const float* obs_p = obs + (size_t)p * agent_stride;
+    const int nblk = (n_rows + 15) >> 4;
+    for (int blk = blockIdx.x * 4 + wave; blk < nblk; blk += gridDim.x * 4) {
+        const int row = blk * 16 + j;
+        const bool ok = row < n_rows;
+        const float* xrow = obs_p + (size_t)(ok ? row : n_rows - 1) * row_stride;
+        float x[S::KS1];
+#pragma unroll
+        for (int ks = 0; ks < S::KS1; ++ks) {
+            const int d = 4 * ks + g;
+            const float v = xrow[d < S::D ? d : S::D - 1];
+            x[ks] = (d < S::D && ok) ? v : 0.f;
+        }
+        f4 h1[S::MT], h2[S::MT], q, unused;
+        mlp_forward_p<S, false>(lds, lds, lane, x, h1, h2, q, unused);
+        if (ok) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (4 * g + r < S::A) out[((size_t)p * n_rows + row) * S::A + 4 * g + r] = q[r];
+        }
+    }
+}
+
+template <class S>
+int launch_forward_rows(int P, const float* params, const marlhip_batch* bt, int n_rows, float* out, hipStream_t st) {
+    const int T = bt->max_len, B = bt->batch;
+    const size_t as = bt->obs_agent_stride ? (size_t)bt->obs_agent_stride : (size_t)(T + 1) * B * S::D;
+    const size_t rs = bt->obs_row_stride ? (size_t)bt->obs_row_stride : (size_t)S::D;
+    constexpr int LDSB = S::NFWD * (int)sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_rows_fwd_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
+        attr_set = true;
+    }
+    const int nblk = (n_rows + 15) / 16;
+    int gx = (nblk + 3) / 4;
+    const int cap = 512 / P > 1 ? 512 / P : 1;
+    if (gx > cap) gx = cap;
+    hipLaunchKernelGGL((mlp_rows_fwd_kernel<S>), dim3(gx, P), dim3(256), LDSB, st, params, bt->obss, as, rs, n_rows, out);
+    MARL_CHECK_LAUNCH("mlp_rows_fwd_kernel");
+    return 0;
+}
+
+// ---- backward rows -----------------------------------------------------------------------------------------
+template <class S>
+int64_t backward_ws_bytes(int P, int T, int B) {
+    if constexpr (S::H > 64) {
+        const UpdPlan pl = upd_plan_tp(P, T, B, 2);
+        return ws_layout(P, pl.nwg, S::NPARAM + 2, 0, T, B).total;
+    } else {
+        const UpdPlan pl = upd_plan(P, T, B);
+        return ws_layout(P, pl.nwg, UpdLds<S>::REC, 2 * S::NFWD + S::NBWD, T, B).total;
+    }
+}
+
+// grad[P][NPARAM] = d(sum_rows lrow-loss)/dparams / sum(filled) from dout[P][T][B][A]; loss[0] = sum(lrow)/sum(filled)
+template <class S>
+int launch_backward_rows(int P, const float* params, const marlhip_batch* bt, const float* dout, float* lrow, void* ws,
+                         int64_t ws_bytes, float* grad, float* loss, hipStream_t st) {
+    const int T = bt->max_len, B = bt->batch;
+    MARL_REQUIRE(ws_bytes >= backward_ws_bytes<S>(P, T, B), "ac backward: workspace %lld too small", (long long)ws_bytes);
+    ReplaySrc none = {};
+    int nwg;
+    if constexpr (S::H > 64) {
+        constexpr int W = 4, TPW = S::H / 64, NB = 2, NT = W * TPW;
+        const UpdPlan pl = upd_plan_tp(P, T, B, NB);
+        nwg = pl.nwg;
+        TpMix mix = {};
+        mix.lrow = lrow;
+        mix.dout = dout;
+        const size_t ldsB = (size_t)(NB * NT * 256 + NB * S::H * 16 + NB * NT * 256 + W * 256 * (1 + 3 * TPW)) * sizeof(float);
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tp_bwd_kernel<S, W, TPW, false, NB, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsB);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((tp_bwd_kernel<S, W, TPW, false, NB, true>), dim3(pl.nwg, P), dim3(64 * W), ldsB, st, params, *bt, none, mix,
+                           pl.n_chunks, (float*)ws);
+        MARL_CHECK_LAUNCH("tp_bwd_kernel<FULL>");
+    } else {
+        using L = UpdLds<S>;
+        constexpr int PACK = 2 * S::NFWD + S::NBWD;
+        const UpdPlan pl = upd_plan(P, T, B);
+        nwg = pl.nwg;
+        const WsLayout wl = ws_layout(P, pl.nwg, L::REC, PACK, T, B);
+        float* packs = reinterpret_cast<float*>(static_cast<char*>(ws) + wl.pack_off);
+        const size_t lds_bytes = (size_t)L::total(4) * sizeof(float);
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dqn_lossgrad_kernel<S, 4, false, 4>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((dqn_pack_kernel<S>), dim3((PACK + 255) / 256, P), dim3(256), 0, st, params, params, packs);
+        MixBufs mix = {};
+        mix.lrow = lrow;
+        mix.dout = dout;
+        hipLaunchKernelGGL((dqn_lossgrad_kernel<S, 4, false, 4>), dim3(pl.nwg, P), dim3(256), lds_bytes, st, (const float*)packs, *bt, none,
+                           mix, 0.f, 0, pl.n_chunks, (float*)ws, (unsigned long long*)nullptr);
+        MARL_CHECK_LAUNCH("dqn_lossgrad_kernel<MODE 4>");
+    }
+    const int n = P * S::NPARAM;
+    hipLaunchKernelGGL(dqn_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, st, (const float*)ws, P, nwg, S::NPARAM, grad, loss);
+    MARL_CHECK_LAUNCH("dqn_reduce_kernel");
+    return 0;
+}
+
+// ---- the elementwise stage ---------------------------------------------------------------------------------
+struct AcArgs {
+    int P, T, B, A, n_steps, mode;  // mode 0: A2C; 1: PPO prepare (returns + old log-probs, no gradients); 2: PPO epoch
+    float gk[18];                   // (float)(gamma ** k), k = 0..n_steps, formed in fp64 like python's gamma**step
+    float ent_coef, vlc, ppo_clip;
+};
+
+struct AcBufs {
+    const float* logits;  // [P][T*B][A]
+    const float* v;       // [P][T*B]
+    const float* vnext;   // [P][(T+1)*B] target-critic values of every observation
+    float* dlogits;       // [P][T*B][A]
+    float* dv;            // [P][T*B]
+    float* lrow_a;        // [T*B] filled * actor-loss row
+    float* lrow_v;        // [T*B] filled * value-loss row
+    float* ent;           // [T*B] filled * sum_p entropy
+    float* ret;           // [P][T*B]  PPO: returns kept across epochs
+    float* oldlogp;       // [P][T*B]  PPO: log-prob under the pre-update policy
+};
+
+static __global__ __launch_bounds__(256) void ac_elem_kernel(AcArgs a, marlhip_batch bt, AcBufs w) {
+    const int TB = a.T * a.B;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= TB) return;
+    const int t = i / a.B, b = i - t * a.B;
+    const size_t aas = bt.act_agent_stride ? (size_t)bt.act_agent_stride : (size_t)TB;
+    const size_t ars = bt.act_row_stride ? (size_t)bt.act_row_stride : 1;
+    const float fl = bt.filled[i];
+    float la = 0.f, lv = 0.f, es = 0.f;
+    for (int p = 0; p < a.P; ++p) {
+        const size_t pi = (size_t)p * TB + i;
+        float ret;
+        if (a.mode == 2) {
+            ret = w.ret[pi];
+        } else {  // compute_nstep_returns (utils/utils.py:38-63)
+            ret = 0.f;
+            for (int k = 0; k <= a.n_steps; ++k) {
+                const int tt = t + k;
+                if (tt >= a.T) break;
+                const float nd = 1.f - bt.dones[(size_t)tt * a.B + b];
+                if (k == a.n_steps) ret += a.gk[k] * w.vnext[(size_t)p * (TB + a.B) + (size_t)tt * a.B + b] * nd;
+                else ret += a.gk[k] * bt.rewards[p * aas + ((size_t)tt * a.B + b) * ars] * nd;
+            }
+            if (a.mode == 1) w.ret[pi] = ret;
+        }
+        const float* l = w.logits + pi * a.A;
+        float m = l[0];
+        for (int k = 1; k < a.A; ++k) m = fmaxf(m, l[k]);
+        float s = 0.f;
+        for (int k = 0; k < a.A; ++k) s += expf(l[k] - m);
+        const float lse = m + logf(s);
+        const int act = (int)bt.actions[p * aas + (size_t)i * ars];
+        const float logp = l[act] - lse;
+        float H = 0.f;
+        for (int k = 0; k < a.A; ++k) H -= expf(l[k] - lse) * (l[k] - lse);
+        if (a.mode == 1) {
+            w.oldlogp[pi] = logp;
+            continue;
+        }
+        const float val = w.v[pi], adv = ret - val;
+        float coef;  // d(actor row loss) / d logp
+        if (a.mode == 0) {
+            la += -logp * adv - a.ent_coef * H;
+            coef = -adv;
+        } else {  // clipped surrogate (model.py:318-327); min() ties split the gradient, clamp passes it inside the range
+            const float ratio = expf(logp - w.oldlogp[pi]);
+            const float rc = fminf(fmaxf(ratio, 1.f - a.ppo_clip), 1.f + a.ppo_clip);
+            const float s1 = ratio * adv, s2 = rc * adv;
+            la += -fminf(s1, s2) - a.ent_coef * H;
+            const bool inside = ratio >= 1.f - a.ppo_clip && ratio <= 1.f + a.ppo_clip;
+            const float share = s1 < s2 ? 1.f : (s1 == s2 ? (inside ? 1.f : 0.5f) : (0.f));
+            coef = -adv * ratio * share;
+        }
+        for (int k = 0; k < a.A; ++k) {
+            const float lp = l[k] - lse, pk = expf(lp);
+            w.dlogits[pi * a.A + k] = fl * (coef * ((k == act ? 1.f : 0.f) - pk) + a.ent_coef * pk * (lp + H));
+        }
+        w.dv[pi] = fl * (-2.f * a.vlc * (ret - val));
+        lv += (ret - val) * (ret - val);
+        es += H;
+    }
+    if (a.mode != 1) {
+        w.lrow_a[i] = fl * la;
+        w.lrow_v[i] = fl * lv;
+        w.ent[i] = fl * es;
+    }
+}
+
+// metrics[0..4] = loss, actor_loss, value_loss, entropy, sum(filled)  (fixed-order tree: reproducible)
+static __global__ __launch_bounds__(1024) void ac_metrics_kernel(int TB, float vlc, const float* __restrict__ lrow_a,
+                                                                 const float* __restrict__ lrow_v, const float* __restrict__ ent,
+                                                                 const float* __restrict__ filled, float* __restrict__ metrics) {
+    __shared__ float sh[4][16];
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i = threadIdx.x; i < TB; i += 1024) {
+        s[0] += lrow_a[i]; s[1] += lrow_v[i]; s[2] += ent[i]; s[3] += filled[i];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) s[k] += __shfl_xor(s[k], off);
+        if ((threadIdx.x & 63) == 0) sh[k][threadIdx.x >> 6] = s[k];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float tot[4];
+        for (int k = 0; k < 4; ++k) {
+            float acc = 0.f;
+            for (int wv = 0; wv < 16; ++wv) acc += sh[k][wv];
+            tot[k] = acc;
+        }
+        const float al = tot[0] / tot[3], vl = tot[1] / tot[3];
+        metrics[0] = al + vlc * vl;
+        metrics[1] = al;
+        metrics[2] = vl;
+        metrics[3] = tot[2] / tot[3];
+        metrics[4] = tot[3];
+    }
+}
+
+// workspace: [vnext | v | logits | dlogits | dv | lrow_a | lrow_v | ent | ret | oldlogp | loss scratch 4][backward workspace]
+struct AcWs {
+    int64_t vnext, v, logits, dlogits, dv, lrow_a, lrow_v, ent, ret, oldlogp, scratch, bwd, total;
+};
+
+template <class SA, class SC>
+AcWs ac_ws_layout(int P, int T, int B) {
+    const int64_t TB = (int64_t)T * B;
+    AcWs w;
+    int64_t o = 0;
+    auto take = [&](int64_t nfloat) { const int64_t at = o; o = (o + nfloat * 4 + 255) & ~(int64_t)255; return at; };
+    w.vnext = take((int64_t)P * (TB + B));
+    w.v = take(P * TB);
+    w.logits = take(P * TB * SA::A);
+    w.dlogits = take(P * TB * SA::A);
+    w.dv = take(P * TB);
+    w.lrow_a = take(TB);
+    w.lrow_v = take(TB);
+    w.ent = take(TB);
+    w.ret = take(P * TB);
+    w.oldlogp = take(P * TB);
+    w.scratch = take(8);
+    w.bwd = o;
+    const int64_t ba = backward_ws_bytes<SA>(P, T, B), bc = backward_ws_bytes<SC>(P, T, B);
+    w.total = o + (ba > bc ? ba : bc);
+    return w;
+}
+
+template <int D, int H, int A>
+int ac_step(int P, const float* actor, const float* critic, const float* target, const marlhip_batch* bt, const marlhip_ac_config* c,
+            int mode, void* ws, int64_t ws_bytes, float* actor_grad, float* critic_grad, float* metrics, hipStream_t st) {
+    using SA = MlpShape<D, H, A>;
+    using SC = MlpShape<D, H, 1>;
+    const int T = bt->max_len, B = bt->batch, TB = T * B;
+    const AcWs wl = ac_ws_layout<SA, SC>(P, T, B);
+    MARL_REQUIRE(ws_bytes >= wl.total, "ac_loss_grad: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)wl.total);
+    char* base = static_cast<char*>(ws);
+    auto f = [&](int64_t off) { return reinterpret_cast<float*>(base + off); };
+    AcBufs w;
+    w.logits = f(wl.logits); w.v = f(wl.v); w.vnext = f(wl.vnext); w.dlogits = f(wl.dlogits); w.dv = f(wl.dv);
+    w.lrow_a = f(wl.lrow_a); w.lrow_v = f(wl.lrow_v); w.ent = f(wl.ent); w.ret = f(wl.ret); w.oldlogp = f(wl.oldlogp);
+    AcArgs a;
+    a.P = P; a.T = T; a.B = B; a.A = A; a.n_steps = c->n_steps; a.mode = mode;
+    for (int k = 0; k <= c->n_steps; ++k) a.gk[k] = (float)pow(c->gamma, (double)k);
+    a.ent_coef = c->entropy_coef; a.vlc = c->value_loss_coef; a.ppo_clip = c->ppo_clip;
+    int rc;
+    if (mode != 2) {  // target-critic values of all T+1 observations (model.py:190-193); PPO reuses the returns across epochs
+        rc = launch_forward_rows<SC>(P, target, bt, TB + B, f(wl.vnext), st);
+        if (rc != 0) return rc;
+    }
+    rc = launch_forward_rows<SA>(P, actor, bt, TB, f(wl.logits), st);
+    if (rc != 0) return rc;
+    if (mode != 1) {
+        rc = launch_forward_rows<SC>(P, critic, bt, TB, f(wl.v), st);
+        if (rc != 0) return rc;
+    }
+    hipLaunchKernelGGL(ac_elem_kernel, dim3((TB + 255) / 256), dim3(256), 0, st, a, *bt, w);
+    MARL_CHECK_LAUNCH("ac_elem_kernel");
+    if (mode == 1) return 0;
+    float* scratch = f(wl.scratch);
+    rc = launch_backward_rows<SA>(P, actor, bt, w.dlogits, w.lrow_a, base + wl.bwd, ws_bytes - wl.bwd, actor_grad, scratch, st);
+    if (rc != 0) return rc;
+    rc = launch_backward_rows<SC>(P, critic, bt, w.dv, w.lrow_v, base + wl.bwd, ws_bytes - wl.bwd, critic_grad, scratch + 2, st);
+    if (rc != 0) return rc;
+    hipLaunchKernelGGL(ac_metrics_kernel, dim3(1), dim3(1024), 0, st, TB, c->value_loss_coef, (const float*)w.lrow_a,
+                       (const float*)w.lrow_v, (const float*)w.ent, bt->filled, metrics);
+    MARL_CHECK_LAUNCH("ac_metrics_kernel");
+    return 0;
+}
+
+}  // namespace marl
+
+using namespace marl;
+
+// (obs dim, hidden) pairs with compiled actor (A = 6) and critic (A = 1) kernels: the LBF shapes of common.h
+#define MARL_AC_SHAPES(X) \
+    X(12, 64) X(15, 64) X(18, 64) X(21, 64) X(24, 64) X(27, 64) X(39, 64) X(12, 128) X(15, 128) X(18, 128) X(21, 128) X(24, 128) X(27, 128) X(39, 128)
+
+static int ac_check(const marlhip_net_shape* s) {
+    MARL_REQUIRE(s != nullptr, "net shape is NULL");
+    MARL_REQUIRE(s->n_agents >= 1 && s->n_actions == 6, "ac: the compiled actors have 6 actions (LBF), got %d", s->n_actions);
+#define X(d, h) if (s->obs_dim == d && s->hidden == h) return 0;
+    MARL_AC_SHAPES(X)
+#undef X
+    set_error("no actor-critic kernels for obs_dim %d hidden %d (add the pair to MARL_AC_SHAPES)", s->obs_dim, s->hidden);
+    return -1;
+}
+
+extern "C" int marlhip_ac_critic_nparams(const marlhip_net_shape* s) {
+    if (ac_check(s) != 0) return -1;
+#define X(d, h) if (s->obs_dim == d && s->hidden == h) return MlpShape<d, h, 1>::NPARAM;
+    MARL_AC_SHAPES(X)
+#undef X
+    return -1;
+}
+
+extern "C" int64_t marlhip_ac_workspace_bytes(const marlhip_net_shape* s, int32_t max_len, int32_t batch) {
+    if (ac_check(s) != 0) return -1;
+#define X(d, h) \
+    if (s->obs_dim == d && s->hidden == h) return ac_ws_layout<MlpShape<d, h, 6>, MlpShape<d, h, 1>>(s->n_agents, max_len, batch).total;
+    MARL_AC_SHAPES(X)
+#undef X
+    return -1;
+}
+
+static int ac_call(const marlhip_net_shape* s, const float* actor, const float* critic, const float* target, const marlhip_batch* bt,
+                   const marlhip_ac_config* c, int mode, void* ws, int64_t ws_bytes, float* actor_grad, float* critic_grad,
+                   float* metrics, void* stream) {
+    if (ac_check(s) != 0) return -1;
+    MARL_REQUIRE(actor && critic && bt && c && ws, "ac_loss_grad: NULL pointer");
+    MARL_REQUIRE(mode == 1 || (actor_grad && critic_grad && metrics), "ac_loss_grad: NULL output");
+    MARL_REQUIRE(mode == 2 || target != nullptr, "ac_loss_grad: NULL target critic");
+    MARL_REQUIRE(bt->obss && bt->actions && bt->rewards && bt->dones && bt->filled, "ac_loss_grad: NULL batch field");
+    MARL_REQUIRE(bt->max_len > 0 && bt->batch > 0, "ac_loss_grad: empty batch");
+    MARL_REQUIRE(c->n_steps >= 1 && c->n_steps <= 16, "ac_loss_grad: n_steps %d outside [1, 16]", c->n_steps);
+#define X(d, h)                                                                                                                  \
+    if (s->obs_dim == d && s->hidden == h)                                                                                        \
+        return ac_step<d, h, 6>(s->n_agents, actor, critic, target, bt, c, mode, ws, ws_bytes, actor_grad, critic_grad, metrics, \
+                                (hipStream_t)stream);
+    MARL_AC_SHAPES(X)
+#undef X
+    return -1;
+}
+
+extern "C" int marlhip_ac_forward_rows(const marlhip_net_shape* s, int32_t value_net, const float* params, const float* obs,
+                                       int64_t agent_stride, int64_t row_stride, int32_t n_rows, float* out, void* stream) {
+    if (ac_check(s) != 0) return -1;
+    MARL_REQUIRE(params && obs && out && n_rows > 0 && agent_stride > 0 && row_stride > 0, "ac_forward_rows: bad argument");
+    marlhip_batch bt = {};
+    bt.obss = obs; bt.max_len = 1; bt.batch = 1;
+    bt.obs_agent_stride = agent_stride; bt.obs_row_stride = row_stride;
+#define X(d, h)                                                                                                            \
+    if (s->obs_dim == d && s->hidden == h)                                                                                  \
+        return value_net ? launch_forward_rows<MlpShape<d, h, 1>>(s->n_agents, params, &bt, n_rows, out, (hipStream_t)stream) \
+                         : launch_forward_rows<MlpShape<d, h, 6>>(s->n_agents, params, &bt, n_rows, out, (hipStream_t)stream);
+    MARL_AC_SHAPES(X)
+#undef X
+    return -1;
+}
+
+extern "C" int marlhip_a2c_loss_grad(const marlhip_net_shape* s, const float* actor, const float* critic, const float* target_critic,
+                                     const marlhip_batch* batch, const marlhip_ac_config* cfg, void* workspace, int64_t workspace_bytes,
+                                     float* actor_grad, float* critic_grad, float* metrics, void* stream) {
+    return ac_call(s, actor, critic, target_critic, batch, cfg, 0, workspace, workspace_bytes, actor_grad, critic_grad, metrics, stream);
+}
+
+extern "C" int marlhip_ppo_prepare(const marlhip_net_shape* s, const float* actor, const float* critic, const float* target_critic,
+                                   const marlhip_batch* batch, const marlhip_ac_config* cfg, void* workspace, int64_t workspace_bytes,
+                                   void* stream) {
+    return ac_call(s, actor, critic, target_critic, batch, cfg, 1, workspace, workspace_bytes, nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int marlhip_ppo_loss_grad(const marlhip_net_shape* s, const float* actor, const float* critic, const marlhip_batch* batch,
+                                     const marlhip_ac_config* cfg, void* workspace, int64_t workspace_bytes, float* actor_grad,
+                                     float* critic_grad, float* metrics, void* stream) {
+    return ac_call(s, actor, critic, nullptr, batch, cfg, 2, workspace, workspace_bytes, actor_grad, critic_grad, metrics, stream);
+}

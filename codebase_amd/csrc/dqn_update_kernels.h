@@ -1,0 +1,894 @@
+// IDQN learner step on gfx950 (K5-K8): fused critic/target forward + Double-Q TD target + masked
+// MSE + backward on f32 MFMA, deterministic partial-gradient reduction, global-norm clip + Adam +
+// target update.  Replaces QNetwork._compute_loss / update (marlbase/dqn/model.py:118-196).
+//
+// Work decomposition (oracle/mfma_emul.py is the lane-level statement of this file):
+//   wave task = (agent p, group of 16 episodes, chunk [t0,t1) of transitions); a workgroup (4
+//   waves) serves ONE agent whose critic / target / transposed weights sit in LDS as MFMA
+//   A-operand packs.  A task walks time BACKWARDS: at step t it forwards the critic on the 16
+//   rows obs[p][t][b0..b0+15], turns the bootstrap value carried from step t+1 into the TD error
+//   of transition t, back-propagates that row block immediately (activations never leave
+//   registers except for the two LDS transposes the weight-gradient GEMMs need), then forwards
+//   the target net on the same rows to produce the bootstrap value for transition t-1.
+//   Weight gradients accumulate in MFMA accumulators across all tasks of the wave; the 4 waves
+//   fold through LDS and the workgroup writes ONE partial record; a second kernel sums records
+//   in fixed order (bitwise reproducible, no float atomics) and applies 1/sum(filled).
+// MFMA-bound: 360 v_mfma_f32_16x16x4_f32 per 16-row block at H=64 (96 critic fwd, 96 target
+// fwd, 168 backward) = 46.1 kFLOP/row issued vs 43.5 kFLOP/row algorithmic.
+#pragma once
+#include <stdlib.h>
+
+#include "common.h"
+#include "mlp.h"
+
+namespace marl {
+
+constexpr int UPD_MAXWAVES = 8;  // waves per workgroup: 4 (1 per SIMD) or 8 (2 per SIMD)
+
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// C-layout registers regs[MT] -> LDS tile[h][16 rows]
+template <int MT>
+__device__ __forceinline__ void tile_write(float* tile, const f4 (&regs)[MT], int g, int j) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tile[(16 * mt + 4 * g + r) * 16 + j] = regs[mt][r];
+}
+
+// lane (g,i) reads tile[16mt+i][4g..4g+3]: operand registers of k-steps ks=0..3 (row 4g+ks)
+__device__ __forceinline__ f4 tile_read(const float* tile, int mt, int g, int i) {
+    return *reinterpret_cast<const f4*>(tile + (16 * mt + i) * 16 + 4 * g);
+}
+
+__device__ __forceinline__ float sum16(float v) {  // over the 16 lanes j of one g
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 8);
+    return v;
+}
+
+template <class S>
+struct UpdLds {
+    static constexpr int TILE = 16 * S::H;                    // one [H][16] transpose tile
+    static constexpr int PER_WAVE = 4 * TILE + 256;           // h2, h1, dH2, dH1 transpose tiles + dQ tile
+    static constexpr int oC = 0, oT = S::NFWD, oB = 2 * S::NFWD, oTiles = oB + S::NBWD;
+    static constexpr int total(int waves) { return oTiles + waves * PER_WAVE; }  // floats
+    static constexpr int REC = S::NPARAM + 2;                 // partial record: grads, loss, n_filled
+    static constexpr int FOLD = S::NPARAM + (2 * S::H + 18) * 16;  // per-wave fold region (weights + bias/loss strips)
+    static_assert(4 * FOLD <= oTiles + 4 * PER_WAVE, "fold regions overlay packs + tiles");
+};
+
+// packs of one agent in the workspace: [critic fwd NFWD][target fwd NFWD][critic bwd NBWD]
+template <class S>
+__global__ __launch_bounds__(256) void dqn_pack_kernel(const float* __restrict__ params, const float* __restrict__ tparams,
+                                                       float* __restrict__ packs) {
+    constexpr int TOT = 2 * S::NFWD + S::NBWD;
+    const int p = blockIdx.y;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= TOT) return;
+    const float* w = params + (size_t)p * S::NPARAM;
+    float v;
+    if (idx < S::NFWD) v = mlp_fwd_pack_elem<S>(w, idx);
+    else if (idx < 2 * S::NFWD) v = mlp_fwd_pack_elem<S>(tparams + (size_t)p * S::NPARAM, idx - S::NFWD);
+    else v = mlp_bwd_pack_elem<S>(w, idx - 2 * S::NFWD);
+    packs[(size_t)p * TOT + idx] = v;
+}
+
+// where the rows come from: a materialised Batch in the reference layout (marlhip_dqn_loss_grad), or the
+// episode-major replay itself, gathered in-kernel through sampled episode indices
+// (marlhip_dqn_loss_grad_replay: no sample kernel, no Batch round trip through HBM)
+struct ReplaySrc {
+    marlhip_replay_buffers rb;
+    const int32_t* idx;  // [B] or nullptr: Philox(seed; stream 2, counter) draw in [0, length)
+    int32_t* idx_out;    // optional record of the indices used
+    uint64_t seed;
+    uint32_t counter;
+    int length;
+};
+
+__device__ __forceinline__ int replay_draw(const ReplaySrc& r, int b) {
+    U4 c;
+    c.x = (uint32_t)(b >> 2); c.y = r.counter; c.z = 0; c.w = STREAM_SAMPLE;
+    const U4 o = philox4x32_10(c, (uint32_t)r.seed, (uint32_t)(r.seed >> 32));
+    const int s = b & 3;
+    return (int)bounded_nr(s == 0 ? o.x : (s == 1 ? o.y : (s == 2 ? o.z : o.w)), (uint32_t)r.length);
+}
+
+// value-decomposition learners (VDN now, QMIX next) split the step around a MIXER:
+//   MODE 1 "qsel": agent networks forward only -> chosen_p[t][b] = Q_p(o_t)[a_t], tqsel_p[t][b] = bootstrap value
+//   mixer kernel : (chosen, tqsel, r, done, filled) -> dq_p[t][b] = dL/dchosen_p (unnormalised) and per-row loss
+//   MODE 2 "bwd" : agent networks forward (critic only) + backward with the external dq
+// MODE 0 is the fused independent-learner step (IDQN), where the "mixer" is the identity per agent.
+struct MixBufs {
+    float* chosen;   // [P][T][B]
+    float* tqsel;    // [P][T][B]
+    float* r0;       // [T][B] reward of agent 0 (VDNetwork uses batch.rewards[0], dqn/model.py:228)
+    float* dn;       // [T][B] done(t+1)
+    float* fl;       // [T][B] filled(t)
+    float* dq;       // [T][B] (agent stride 0) or [P][T][B]
+    float* lrow;     // [T][B] filled * delta^2
+    int dq_agent_stride;
+    const float* dout;  // MODE 4: [P][T][B][A] external gradient w.r.t. EVERY network output (actor-critic learners)
+};
+
+template <class S, int WAVES, bool REPLAY, int MODE>
+__global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dqn_lossgrad_kernel(const float* __restrict__ packs, marlhip_batch bt, ReplaySrc rs,
+                                                                 MixBufs mix, float gamma, int double_q, int n_chunks,
+                                                                 float* __restrict__ partials, unsigned long long* prof) {
+    using L = UpdLds<S>;
+    constexpr int MT = S::MT, NT1 = S::DP / 16, D = S::D, H = S::H, A = S::A;
+    constexpr int UPD_BLOCK = 64 * WAVES;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, j = lane & 15;
+    const int p = blockIdx.y;
+    const int T = bt.max_len, B = bt.batch;
+
+    {   // the three packs were laid out by dqn_pack_kernel exactly as LDS wants them: 16-byte linear copy
+        constexpr int TOT4 = (2 * S::NFWD + S::NBWD) / 4;
+        const f4* src = reinterpret_cast<const f4*>(packs + (size_t)p * (2 * S::NFWD + S::NBWD));
+        f4* dst = reinterpret_cast<f4*>(lds);
+        for (int i = tid; i < TOT4; i += UPD_BLOCK) dst[i] = src[i];
+    }
+    __syncthreads();
+
+    const float* cpk = lds + L::oC;
+    const float* tpk = lds + L::oT;
+    const f4* T3 = reinterpret_cast<const f4*>(lds + L::oB + S::pT3);
+    const f4* T2 = reinterpret_cast<const f4*>(lds + L::oB + S::pT2);
+    float* TH2 = lds + L::oTiles + wave * L::PER_WAVE;
+    float* TH1 = TH2 + L::TILE;
+    float* TG2 = TH1 + L::TILE;
+    float* TG1 = TG2 + L::TILE;
+    float* TQ = TG1 + L::TILE;
+
+    const int P = gridDim.y;
+    // row (t, b) of agent p = obss + p * agent stride + (t * B + b) * row stride (defaults: the dqn/train.py Batch)
+    const size_t obs_as = bt.obs_agent_stride ? (size_t)bt.obs_agent_stride : (size_t)(T + 1) * B * D;
+    const size_t obs_rs = bt.obs_row_stride ? (size_t)bt.obs_row_stride : (size_t)D;
+    const float* obs_p = REPLAY ? nullptr : bt.obss + (size_t)p * obs_as;
+    const int64_t* act_p = (REPLAY || MODE == 4) ? nullptr : bt.actions + (size_t)p * T * B;
+    const float* rew_p = (REPLAY || MODE == 4) ? nullptr : bt.rewards + (size_t)p * T * B;
+
+    const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f4 dW1[MT][NT1], dW2[MT][MT], dW3[MT], db1[MT], db2[MT], db3 = zero4;
+#pragma unroll
+    for (int a = 0; a < MT; ++a) {
+        dW3[a] = zero4; db1[a] = zero4; db2[a] = zero4;
+#pragma unroll
+        for (int b = 0; b < MT; ++b) dW2[a][b] = zero4;
+#pragma unroll
+        for (int b = 0; b < NT1; ++b) dW1[a][b] = zero4;
+    }
+    float loss_acc = 0.f, nfill_acc = 0.f;
+    // optional per-phase cycle accounting (MARLHIP_PROF=1): s_memtime deltas summed per phase
+    unsigned long long pc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pt = 0;
+    const unsigned long long t_begin = prof ? __builtin_readcyclecounter() : 0;
+#define MARL_PHASE(k)                                         \
+    if (prof != nullptr) {                                    \
+        const unsigned long long now_ = __builtin_readcyclecounter(); \
+        pc[k] += now_ - pt;                                   \
+        pt = now_;                                            \
+    }
+
+    const unsigned long long t_loop_begin = prof ? __builtin_readcyclecounter() : 0;
+    const int ngroups = (B + 15) >> 4;
+    const int ntasks = ngroups * n_chunks;
+    for (int task = blockIdx.x * WAVES + wave; task < ntasks; task += gridDim.x * WAVES) {
+        const int grp = task / n_chunks, c = task - grp * n_chunks;
+        const int t0 = (c * T) / n_chunks, t1 = ((c + 1) * T) / n_chunks;
+        if (t1 <= t0) continue;
+        const int b0 = grp * 16;
+        const bool rowok = (b0 + j) < B;
+        const int bj = rowok ? b0 + j : B - 1;
+        // replay form: episode of batch row j (forward operand / scalars) and of rows 4g..4g+3 (dW1 operand)
+        int ej = 0, eg[4] = {0, 0, 0, 0};
+        if (REPLAY) {
+            ej = rs.idx ? rs.idx[bj] : replay_draw(rs, bj);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int row = b0 + 4 * g + ks, rc = row < B ? row : B - 1;
+                eg[ks] = rs.idx ? rs.idx[rc] : replay_draw(rs, rc);
+            }
+            if (rs.idx_out != nullptr && p == 0 && c == 0 && g == 0 && rowok) rs.idx_out[bj] = ej;
+        }
+        float tq_next = 0.f;
+        // rows of time step t in the two operand shapes the step needs + the transition's scalars;
+        // issued one step ahead so the loads fly under the previous step's MFMAs
+        struct Rows {
+            float x[S::KS1];   // forward B operand: X[row j][4ks+g]
+            float bx[NT1][4];  // dW1 B operand:     X[row 4g+ks][16nt+j]
+            int a_sel;
+            float rw, dn, fl;
+            float dq, lr;      // MODE 2: external dL/dchosen and per-row loss
+            float dqv[4];      // MODE 4: external dL/d(output 4g+r)
+        };
+        // branch-free: every address is clamped in-bounds and loaded unconditionally (a guarded load is
+        // an exec-masked branch + a conservative vmcnt(0) at the join); masks are applied at the point of use
+        auto load_rows = [&](int t, Rows& R) {
+            const int tt = t < T ? t : T - 1;
+            if (REPLAY) {
+                const float* xrow = rs.rb.obs + (((size_t)ej * P + p) * (T + 1) + t) * D;
+#pragma unroll
+                for (int ks = 0; ks < S::KS1; ++ks) {
+                    const int d = 4 * ks + g;
+                    R.x[ks] = xrow[d < D ? d : D - 1];
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT1; ++nt)
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        const int d = 16 * nt + j;
+                        R.bx[nt][ks] = rs.rb.obs[(((size_t)eg[ks] * P + p) * (T + 1) + t) * D + (d < D ? d : D - 1)];
+                    }
+                R.a_sel = (int)rs.rb.act[((size_t)ej * P + p) * T + tt];
+                R.rw = rs.rb.rew[((size_t)ej * P + p) * T + tt];
+                R.dn = rs.rb.done[(size_t)ej * (T + 1) + tt + 1] ? 1.f : 0.f;
+                R.fl = rs.rb.filled[(size_t)ej * T + tt] ? 1.f : 0.f;
+            } else {
+                const float* xrow = obs_p + ((size_t)t * B + bj) * obs_rs;
+#pragma unroll
+                for (int ks = 0; ks < S::KS1; ++ks) {
+                    const int d = 4 * ks + g;
+                    R.x[ks] = xrow[d < D ? d : D - 1];
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT1; ++nt)
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        const int row = b0 + 4 * g + ks, d = 16 * nt + j;
+                        R.bx[nt][ks] = obs_p[((size_t)t * B + (row < B ? row : B - 1)) * obs_rs + (d < D ? d : D - 1)];
+                    }
+                if (MODE != 4) {
+                    R.a_sel = (int)act_p[(size_t)tt * B + bj];
+                    R.rw = rew_p[(size_t)tt * B + bj];
+                    R.dn = bt.dones[(size_t)(tt + 1) * B + bj];
+                }
+                R.fl = bt.filled[(size_t)tt * B + bj];
+            }
+            if (MODE == 2) {
+                R.dq = mix.dq[(size_t)p * mix.dq_agent_stride + (size_t)tt * B + bj];
+                R.lr = mix.lrow[(size_t)tt * B + bj];
+            }
+            if (MODE == 4) {
+                const float* drow = mix.dout + (((size_t)p * T + tt) * B + bj) * A;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) R.dqv[r] = drow[4 * g + r < A ? 4 * g + r : A - 1];
+                R.lr = mix.lrow[(size_t)tt * B + bj];
+            }
+        };
+        auto mask_rows = [&](Rows& R) {  // zero the padding (obs dims >= D, rows >= B)
+#pragma unroll
+            for (int ks = 0; ks < S::KS1; ++ks) R.x[ks] = (4 * ks + g < D && rowok) ? R.x[ks] : 0.f;
+#pragma unroll
+            for (int nt = 0; nt < NT1; ++nt)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) R.bx[nt][ks] = (b0 + 4 * g + ks < B && 16 * nt + j < D) ? R.bx[nt][ks] : 0.f;
+            R.fl = rowok ? R.fl : 0.f;
+        };
+        Rows cur;
+        load_rows(t1, cur);
+        for (int t = t1; t >= t0; --t) {
+            Rows nxt;
+            if (prof != nullptr) pt = __builtin_readcyclecounter();
+            load_rows(t > t0 ? t - 1 : t0, nxt);  // unconditional (the last step re-reads its own rows)
+            mask_rows(cur);
+            MARL_PHASE(0)
+            f4 h1[MT], h2[MT], q, tq;
+            if (MODE != 2 && MODE != 4 && t > t0) mlp_forward_p<S, true>(cpk, tpk, lane, cur.x, h1, h2, q, tq);  // target value feeds transition t-1
+            else mlp_forward_p<S, false>(cpk, tpk, lane, cur.x, h1, h2, q, tq);
+            MARL_PHASE(1)
+            if (MODE == 1 && t < t1) {
+                // qsel pass: publish Q_p(o_t)[a_t] and (agent 0) the transition's scalars for the mixer
+                const float ch = gather_rows(q, lane, cur.a_sel);
+                if (g == 0 && rowok) {
+                    mix.chosen[((size_t)p * T + t) * B + bj] = ch;
+                    if (p == 0) {
+                        mix.r0[(size_t)t * B + bj] = cur.rw;
+                        mix.dn[(size_t)t * B + bj] = cur.dn;
+                        mix.fl[(size_t)t * B + bj] = cur.fl;
+                    }
+                }
+            }
+            if (MODE != 1 && t < t1) {
+                // ---- TD error of transition t (model.py:129,152,160-163)
+                const int a_sel = cur.a_sel;
+                const float fl = cur.fl;
+                float dqs;
+                if (MODE == 0) {
+                    const float y = cur.rw + gamma * tq_next * (1.f - cur.dn);
+                    const float delta = gather_rows(q, lane, a_sel) - y;
+                    if (g == 0) { loss_acc += fl * delta * delta; nfill_acc += fl; }
+                    dqs = 2.f * fl * delta;
+                } else {  // the mixer already formed dL/dchosen; agent 0's rows carry the loss bookkeeping
+                    dqs = rowok ? cur.dq : 0.f;
+                    if (g == 0 && p == 0 && rowok) { loss_acc += cur.lr; nfill_acc += fl; }
+                }
+                f4 dQ[1];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (MODE == 4) dQ[0][r] = (rowok && 4 * g + r < A) ? cur.dqv[r] : 0.f;
+                    else dQ[0][r] = (4 * g + r == a_sel) ? dqs : 0.f;
+                }
+                MARL_PHASE(2)
+                // ---- backward of row block t.  Phases are fenced with sched_barrier so that every LDS
+                // operand (weight packs, transposed tiles) is requested >= 16 MFMAs before its first use and
+                // every transposed tile is read >= 16 MFMAs after it was written.
+                f4 t3[MT], t2[2][MT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    t3[mt] = T3[mt * 64 + lane];
+                    t2[0][mt] = T2[(mt * MT + 0) * 64 + lane];
+                }
+                wave_lds_fence();
+                tile_write<1>(TQ, dQ, g, j);
+                tile_write<MT>(TH2, h2, g, j);
+                tile_write<MT>(TH1, h1, g, j);
+                db3 += dQ[0];
+                __builtin_amdgcn_sched_barrier(0);
+                // P1: dH2^T = W3^T dQ^T
+                f4 dH2[MT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) dH2[mt] = zero4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) dH2[mt] = MARL_MFMA(t3[mt][r], dQ[0][r], dH2[mt]);
+                __builtin_amdgcn_sched_barrier(0);
+                MARL_PHASE(3)
+                // P2: relu mask, db2, publish dH2 tile; request dW3 operands and the next W2^T step
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dH2[mt][r] = h2[mt][r] > 0.f ? dH2[mt][r] : 0.f;
+                    db2[mt] += dH2[mt];
+                }
+                tile_write<MT>(TG2, dH2, g, j);
+                wave_lds_fence();
+                const f4 aQ = tile_read(TQ, 0, g, j);
+                f4 bH2[MT];
+#pragma unroll
+                for (int nt = 0; nt < MT; ++nt) bH2[nt] = tile_read(TH2, nt, g, j);
+#pragma unroll
+                for (int m1 = 0; m1 < MT; ++m1) t2[1][m1] = T2[(m1 * MT + 1) * 64 + lane];
+                __builtin_amdgcn_sched_barrier(0);
+                MARL_PHASE(4)
+                // P3..: dH1^T = W2^T dH2^T in MT steps (m2), dW3 slotted after the first step
+                f4 dH1[MT], bH1[MT], aG2[MT];
+#pragma unroll
+                for (int m1 = 0; m1 < MT; ++m1) dH1[m1] = zero4;
+#pragma unroll
+                for (int m2 = 0; m2 < MT; ++m2) {
+                    const int cb = m2 & 1;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int m1 = 0; m1 < MT; ++m1) dH1[m1] = MARL_MFMA(t2[cb][m1][r], dH2[m2][r], dH1[m1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (m2 == 0) {
+                        // dW3[a][h2] += dQ^T H2   (operands requested in P2)
+#pragma unroll
+                        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                            for (int nt = 0; nt < MT; ++nt) dW3[nt] = MARL_MFMA(aQ[ks], bH2[nt][ks], dW3[nt]);
+#pragma unroll
+                        for (int nt = 0; nt < MT; ++nt) bH1[nt] = tile_read(TH1, nt, g, j);
+                    }
+                    if (m2 + 2 < MT) {
+#pragma unroll
+                        for (int m1 = 0; m1 < MT; ++m1) t2[cb][m1] = T2[(m1 * MT + m2 + 2) * 64 + lane];
+                    }
+                    if (m2 == MT - 2) {
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) aG2[mt] = tile_read(TG2, mt, g, j);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                MARL_PHASE(5)
+                // relu mask, db1, publish dH1 tile
+#pragma unroll
+                for (int m1 = 0; m1 < MT; ++m1) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dH1[m1][r] = h1[m1][r] > 0.f ? dH1[m1][r] : 0.f;
+                    db1[m1] += dH1[m1];
+                }
+                tile_write<MT>(TG1, dH1, g, j);
+                wave_lds_fence();
+                __builtin_amdgcn_sched_barrier(0);
+                // dW2[h2][h1] += dH2^T H1 (first half), request the dH1 tile under it, then the rest + dW1
+                f4 aG1[MT];
+#pragma unroll
+                for (int mt = 0; mt < MT / 2; ++mt)
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                        for (int nt = 0; nt < MT; ++nt) dW2[mt][nt] = MARL_MFMA(aG2[mt][ks], bH1[nt][ks], dW2[mt][nt]);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) aG1[mt] = tile_read(TG1, mt, g, j);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int mt = MT / 2; mt < MT; ++mt)
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                        for (int nt = 0; nt < MT; ++nt) dW2[mt][nt] = MARL_MFMA(aG2[mt][ks], bH1[nt][ks], dW2[mt][nt]);
+                // dW1[h1][d] += dH1^T X   (B operand prefetched from global one step ahead)
+#pragma unroll
+                for (int nt = 0; nt < NT1; ++nt)
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) dW1[mt][nt] = MARL_MFMA(aG1[mt][ks], cur.bx[nt][ks], dW1[mt][nt]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            MARL_PHASE(6)
+            if (MODE != 2 && MODE != 4 && t > t0) {
+                // ---- bootstrap value for transition t-1 (model.py:132-145)
+                const int a_p = double_q ? argmax_rows<A>(q, lane) : argmax_rows<A>(tq, lane);
+                tq_next = gather_rows(tq, lane, a_p);
+                if (MODE == 1 && g == 0 && rowok) mix.tqsel[((size_t)p * T + (t - 1)) * B + bj] = tq_next;
+            }
+            cur = nxt;
+            MARL_PHASE(7)
+        }
+    }
+
+    const unsigned long long t_loop_end = prof ? __builtin_readcyclecounter() : 0;
+#undef MARL_PHASE
+    if (MODE == 1) return;  // forward-only pass: nothing to fold
+    // ---- fold the waves through LDS and write ONE partial record per workgroup.  Every wave stores its
+    // accumulators into its own LDS region in parallel (weights at their canonical index, bias / loss
+    // partials as [value][16 lanes] strips), one barrier, then all threads sum the regions in a fixed
+    // order - no cross-lane shuffles, no serialisation between waves, bitwise reproducible.
+    __syncthreads();
+    {
+        float* mine = lds + (size_t)wave * L::FOLD;
+        float* strips = mine + S::NPARAM;  // [(2H + 16) bias rows + 2 loss rows][16]
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = 16 * mt + 4 * g + r;
+#pragma unroll
+                for (int nt = 0; nt < NT1; ++nt) {
+                    const int d = 16 * nt + j;
+                    if (d < D) mine[S::oW1 + o * D + d] = dW1[mt][nt][r];
+                }
+#pragma unroll
+                for (int nt = 0; nt < MT; ++nt) mine[S::oW2 + o * H + 16 * nt + j] = dW2[mt][nt][r];
+                strips[o * 16 + j] = db1[mt][r];
+                strips[(H + o) * 16 + j] = db2[mt][r];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int a = 4 * g + r;
+#pragma unroll
+            for (int nt = 0; nt < MT; ++nt)
+                if (a < A) mine[S::oW3 + a * H + 16 * nt + j] = dW3[nt][r];
+            strips[(2 * H + a) * 16 + j] = db3[r];
+        }
+        if (g == 0) {
+            strips[(2 * H + 16) * 16 + j] = loss_acc;
+            strips[(2 * H + 17) * 16 + j] = nfill_acc;
+        }
+    }
+    __syncthreads();
+    float* rec = partials + ((size_t)p * gridDim.x + blockIdx.x) * L::REC;
+    for (int i = tid; i < L::REC; i += UPD_BLOCK) {
+        // which strip (if any) holds element i
+        int strip = -1;
+        if (i >= S::ob1 && i < S::ob1 + H) strip = i - S::ob1;
+        else if (i >= S::ob2 && i < S::ob2 + H) strip = H + i - S::ob2;
+        else if (i >= S::ob3 && i < S::ob3 + A) strip = 2 * H + i - S::ob3;
+        else if (i >= S::NPARAM) strip = 2 * H + 16 + (i - S::NPARAM);
+        float acc = 0.f;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) {
+            const float* reg = lds + (size_t)w * L::FOLD;
+            if (strip < 0) {
+                acc += reg[i];
+            } else {
+                const float* sp = reg + S::NPARAM + strip * 16;
+                float t = 0.f;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) t += sp[k];
+                acc += t;
+            }
+        }
+        rec[i] = acc;
+    }
+    if (prof != nullptr && lane == 0) {
+        const unsigned long long t_end = __builtin_readcyclecounter();
+        pc[8] = t_loop_begin - t_begin;   // pack staging
+        pc[9] = t_loop_end - t_loop_begin;  // whole task loop
+        pc[10] = t_end - t_loop_end;      // fold + record write
+        pc[11] = t_end - t_begin;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) atomicAdd(&prof[k], pc[k]);
+    }
+}
+
+// grad[p][i] = (sum over the agent's records) / n_filled ; loss = sum of all loss fields / n_filled.
+// n_filled comes from agent 0's records only (every agent sees the same filled mask).
+static __global__ __launch_bounds__(256) void dqn_reduce_kernel(const float* __restrict__ partials, int P, int nwg, int nparam,
+                                                         float* __restrict__ grad, float* __restrict__ loss) {
+    __shared__ float s_red[8];
+    const int rec = nparam + 2;
+    // n_filled (agent 0's records) and the loss sum (all records): strided loads + fixed-order tree
+    float nf = 0.f, ls = 0.f;
+    for (int w = threadIdx.x; w < P * nwg; w += 256) {
+        ls += partials[(size_t)w * rec + nparam];
+        if (w < nwg) nf += partials[(size_t)w * rec + nparam + 1];
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        nf += __shfl_xor(nf, off);
+        ls += __shfl_xor(ls, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        s_red[threadIdx.x >> 6] = nf;
+        s_red[4 + (threadIdx.x >> 6)] = ls;
+    }
+    __syncthreads();
+    nf = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+    ls = (s_red[4] + s_red[5]) + (s_red[6] + s_red[7]);
+    // 64 parameters per block, the record range split over the 4 waves (4x the loads in flight and 4x
+    // the blocks of a thread-per-parameter loop); fixed summation order: slice-local in w order, then
+    // (s0 + s1) + (s2 + s3)
+    __shared__ float s_part[4][64];
+    const int l64 = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + l64;
+    float acc = 0.f;
+    if (i < P * nparam) {
+        const int p = i / nparam, k = i - p * nparam;
+        const float* src = partials + (size_t)p * nwg * rec + k;
+#pragma unroll 8
+        for (int w = slice; w < nwg; w += 4) acc += src[(size_t)w * rec];
+    }
+    s_part[slice][l64] = acc;
+    __syncthreads();
+    if (slice == 0 && i < P * nparam) grad[i] = ((s_part[0][l64] + s_part[1][l64]) + (s_part[2][l64] + s_part[3][l64])) / nf;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        loss[0] = ls / nf;
+        loss[1] = nf;
+    }
+}
+
+// ---- clip_grad_norm_ + Adam + target update (model.py:169-196) -----------------------------
+static __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ grad, int64_t n, float scale,
+                                                    float* __restrict__ scratch) {
+    __shared__ float red[4];
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    float v = 0.f;
+    if (i < n) {
+        const float gv = grad[i] * scale;
+        v = gv * gv;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) scratch[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+struct AdamArgs {
+    float lr_step;    // fp32(lr / (1 - beta1^step))
+    float bc2_sqrt;   // fp32(sqrt(1 - beta2^step))
+    float w1;         // fp32(1 - beta1): lerp weight
+    float beta2, w2;  // beta2, fp32(1 - beta2)
+    float eps, max_norm, grad_scale, tau;
+    int hard_update;
+};
+
+static __global__ __launch_bounds__(256) void adam_kernel(int64_t n, int nblocks, float* __restrict__ params,
+                                                   const float* __restrict__ grad, float* __restrict__ m,
+                                                   float* __restrict__ v, float* __restrict__ target, AdamArgs a,
+                                                   const float* __restrict__ scratch, float* __restrict__ gnorm_out) {
+    __shared__ float s_coef;
+    if (threadIdx.x == 0) {
+        float ss = 0.f;
+        for (int b = 0; b < nblocks; ++b) ss += scratch[b];
+        const float total = sqrtf(ss);
+        // clip_coef = max_norm / (total_norm + 1e-6), clamped to 1 (torch.nn.utils.clip_grad_norm_)
+        float coef = 1.f;
+        if (a.max_norm > 0.f) coef = fminf(a.max_norm / (total + 1e-6f), 1.f);
+        s_coef = coef;
+        if (gnorm_out != nullptr && blockIdx.x == 0) gnorm_out[0] = total;
+    }
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float gv = (grad[i] * a.grad_scale) * s_coef;
+    // torch.optim.Adam (single-tensor): lerp_, mul_/addcmul_, sqrt/div/add_, addcdiv_
+    float mi = m[i], vi = v[i];
+    mi = mi + a.w1 * (gv - mi);
+    vi = vi * a.beta2 + a.w2 * gv * gv;
+    const float denom = sqrtf(vi) / a.bc2_sqrt + a.eps;
+    float pi = params[i];
+    pi = pi + (-a.lr_step) * (mi / denom);
+    m[i] = mi;
+    v[i] = vi;
+    params[i] = pi;
+    if (target != nullptr) {
+        if (a.hard_update) target[i] = pi;
+        else if (a.tau > 0.f) target[i] = (1.f - a.tau) * target[i] + a.tau * pi;
+    }
+}
+
+}  // namespace marl
+
+#include "dqn_update_tp.h"
+#include "qmix.h"
+
+namespace marl {
+
+// n <= 128k parameters: norm + clip + Adam + target in ONE workgroup (one launch instead of two)
+static __global__ __launch_bounds__(1024) void adam_fused_kernel(int64_t n, float* __restrict__ params, const float* __restrict__ grad,
+                                                          float* __restrict__ m, float* __restrict__ v, float* __restrict__ target,
+                                                          AdamArgs a, float* __restrict__ gnorm_out) {
+    __shared__ float red[16];
+    __shared__ float s_coef;
+    float ss = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) {
+        const float gv = grad[i] * a.grad_scale;
+        ss += gv * gv;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) ss += __shfl_xor(ss, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k];
+        const float total = sqrtf(t);
+        s_coef = a.max_norm > 0.f ? fminf(a.max_norm / (total + 1e-6f), 1.f) : 1.f;
+        if (gnorm_out != nullptr) gnorm_out[0] = total;
+    }
+    __syncthreads();
+    const float coef = s_coef;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) {
+        const float gv = (grad[i] * a.grad_scale) * coef;
+        float mi = m[i], vi = v[i];
+        mi = mi + a.w1 * (gv - mi);
+        vi = vi * a.beta2 + a.w2 * gv * gv;
+        const float denom = sqrtf(vi) / a.bc2_sqrt + a.eps;
+        float pi = params[i];
+        pi = pi + (-a.lr_step) * (mi / denom);
+        m[i] = mi;
+        v[i] = vi;
+        params[i] = pi;
+        if (target != nullptr) {
+            if (a.hard_update) target[i] = pi;
+            else if (a.tau > 0.f) target[i] = (1.f - a.tau) * target[i] + a.tau * pi;
+        }
+    }
+}
+
+struct UpdPlan {
+    int nwg, n_chunks;
+};
+
+inline int upd_waves() {  // waves per workgroup (MARLHIP_UPD_WAVES=4|8; default from measurement)
+    static int w = 0;
+    if (w == 0) {
+        const char* e = getenv("MARLHIP_UPD_WAVES");
+        w = 4;  // 8 waves x 5 tiles no longer fit the 160 KiB LDS next to the packs
+        (void)e;
+    }
+    return w;
+}
+
+inline UpdPlan upd_plan(int P, int T, int B) {
+    const int ngroups = (B + 15) / 16;
+    const int W = upd_waves();
+    const int want_waves = 256 * W / (P > 0 ? P : 1) > W ? 256 * W / P : W;  // fill every CU with one workgroup
+    int nc = (want_waves + ngroups - 1) / ngroups;
+    if (nc < 1) nc = 1;
+    if (nc > T) nc = T;
+    const int tasks = ngroups * nc;
+    int nwg = (tasks + W - 1) / W;
+    const int cap = 256 / P > 1 ? 256 / P : 1;
+    if (nwg > cap) nwg = cap;
+    UpdPlan pl = {nwg, nc};
+    return pl;
+}
+
+// VDN mixer (VDNetwork._compute_loss, dqn/model.py:237,254-269): chosen_tot = sum_p chosen_p, target_tot = sum_p tq_p,
+// y = r_0 + gamma * target_tot * (1 - done), delta = chosen_tot - y; dL/dchosen_p = 2 * filled * delta for every p.
+static __global__ __launch_bounds__(256) void vdn_mix_kernel(MixBufs mix, int P, int T, int B, float gamma) {
+    const int n = T * B;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        float ch = 0.f, tq = 0.f;
+        for (int p = 0; p < P; ++p) {
+            ch += mix.chosen[(size_t)p * n + i];
+            tq += mix.tqsel[(size_t)p * n + i];
+        }
+        const float y = mix.r0[i] + gamma * tq * (1.f - mix.dn[i]);
+        const float delta = ch - y;
+        const float fl = mix.fl[i];
+        mix.dq[i] = 2.f * fl * delta;
+        mix.lrow[i] = fl * delta * delta;
+    }
+}
+
+// workspace layout (floats unless noted): [partial records][pad16][packs][mixer buffers (4P+5) T B][pad8][128 B phase counters]
+struct WsLayout {
+    int64_t rec_bytes, pack_off, mix_off, total;
+};
+
+inline WsLayout ws_layout(int P, int nwg, int rec, int pack, int T, int B) {
+    WsLayout w;
+    w.rec_bytes = (int64_t)P * nwg * rec * sizeof(float);
+    w.pack_off = (w.rec_bytes + 15) & ~(int64_t)15;
+    w.mix_off = w.pack_off + (int64_t)P * pack * sizeof(float);
+    w.total = ((w.mix_off + (int64_t)(4 * P + 5) * T * B * sizeof(float) + 7) & ~(int64_t)7) + 128;  // mixer buffers of either path
+    return w;
+}
+
+// hidden 128: tensor-parallel passes (dqn_update_tp.h) - pass F, mixer, pass B, reduce
+inline UpdPlan upd_plan_tp(int P, int T, int B, int NB) {  // one workgroup per CU, tasks = (block set, time chunk)
+    const int nsets = (B + 16 * NB - 1) / (16 * NB);
+    const int want = 256 / P > 1 ? 256 / P : 1;
+    int nc = (want + nsets - 1) / nsets;
+    if (nc < 1) nc = 1;
+    if (nc > T) nc = T;
+    int nwg = nsets * nc;
+    if (nwg > want) nwg = want;
+    UpdPlan pl = {nwg, nc};
+    return pl;
+}
+
+// QMIX mixer stage (qmix.h), dispatched on the (agents, obs dim) pair
+template <int D, bool REPLAY>
+int qmix_dispatch_mix(int P, const QmixCtx& qx, const marlhip_batch* bt, const ReplaySrc& src, const QmixIo& io, float gamma,
+                      hipStream_t st) {
+#define X(p, d) \
+    if constexpr (D == d) { if (P == p) return qmix_launch_mix<QmixShape<p, d>, REPLAY>(qx, bt, src, io, gamma, st); }
+    MARL_QMIX_SHAPES(X)
+#undef X
+    set_error("no QMIX mixer kernel for %d agents x %d observations (add it to MARL_QMIX_SHAPES)", P, D);
+    return -1;
+}
+
+template <int D>
+int qmix_dispatch_reduce(int P, const QmixCtx& qx, int T, int B, const float* loss, hipStream_t st) {
+#define X(p, d) \
+    if constexpr (D == d) { if (P == p) return qmix_launch_reduce<QmixShape<p, d>>(qx, T, B, loss, st); }
+    MARL_QMIX_SHAPES(X)
+#undef X
+    set_error("no QMIX mixer kernel for %d agents x %d observations", P, D);
+    return -1;
+}
+
+template <class S, bool REPLAY>
+int launch_lossgrad_tp(const marlhip_net_shape* s, const float* params, const float* tparams, const marlhip_batch* bt,
+                       const ReplaySrc& src, float gamma, int double_q, int mode, void* ws, int64_t ws_bytes, float* grad,
+                       float* loss, hipStream_t st, const QmixCtx* qx) {
+    constexpr int W = 4, TPW = S::H / 64, NB = 2, NT = W * TPW, REC = S::NPARAM + 2;
+    const int P = s->n_agents, T = bt->max_len, B = bt->batch;
+    const UpdPlan pl = upd_plan_tp(P, T, B, NB);
+    const WsLayout wl = ws_layout(P, pl.nwg, REC, 0, T, B);
+    MARL_REQUIRE(ws_bytes >= wl.total, "dqn_loss_grad: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)wl.total);
+    float* mixf = reinterpret_cast<float*>(static_cast<char*>(ws) + wl.mix_off);
+    const size_t tb = (size_t)T * B;
+    TpMix mix;
+    mix.chosen = mixf; mix.tqsel = mixf + P * tb; mix.rew = mixf + 2 * P * tb; mix.dq = mixf + 3 * P * tb;
+    mix.dn = mixf + 4 * P * tb; mix.fl = mix.dn + tb; mix.lrow = mix.fl + tb;
+    const size_t ldsF = (size_t)(2 * NB * NT + 2 * NB * W) * 256 * sizeof(float);
+    const size_t ldsB = (size_t)(NB * NT * 256 + NB * S::H * 16 + NB * NT * 256 + W * 256 * (1 + 3 * TPW)) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tp_fwd_kernel<S, W, TPW, REPLAY, NB>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsF);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tp_bwd_kernel<S, W, TPW, REPLAY, NB>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsB);
+        attr_set = true;
+    }
+    const dim3 grid(pl.nwg, P), block(64 * W);
+    timing_begin(TIMER_LOSSGRAD, st);
+    hipLaunchKernelGGL((tp_fwd_kernel<S, W, TPW, REPLAY, NB>), grid, block, ldsF, st, params, tparams, *bt, src, mix, double_q,
+                       pl.n_chunks);
+    if (mode == 2) {
+        QmixIo io = {mix.chosen, mix.tqsel, mix.rew, mix.dn, mix.fl, mix.dq, mix.lrow, nullptr};
+        const int rc = qmix_dispatch_mix<S::D, REPLAY>(P, *qx, bt, src, io, gamma, st);
+        if (rc != 0) return rc;
+    } else {
+        hipLaunchKernelGGL(tp_mix_kernel, dim3((unsigned)((tb + 255) / 256 > 1024 ? 1024 : (tb + 255) / 256)), dim3(256), 0, st, mix, P,
+                           T, B, gamma, mode == 1 ? 1 : 0);
+    }
+    hipLaunchKernelGGL((tp_bwd_kernel<S, W, TPW, REPLAY, NB>), grid, block, ldsB, st, params, *bt, src, mix, pl.n_chunks, (float*)ws);
+    timing_end(TIMER_LOSSGRAD, st);
+    MARL_CHECK_LAUNCH("tp_lossgrad");
+    const int n = P * S::NPARAM;
+    hipLaunchKernelGGL(dqn_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, st, (const float*)ws, P, pl.nwg, S::NPARAM, grad, loss);
+    MARL_CHECK_LAUNCH("dqn_reduce_kernel");
+    if (mode == 2) return qmix_dispatch_reduce<S::D>(P, *qx, T, B, loss, st);
+    return 0;
+}
+
+template <class S, bool REPLAY>
+int launch_lossgrad_src(const marlhip_net_shape* s, const float* params, const float* tparams, const marlhip_batch* bt,
+                        const ReplaySrc& src, float gamma, int double_q, int mode, void* ws, int64_t ws_bytes, float* grad,
+                        float* loss, hipStream_t st, const QmixCtx* qx) {
+    if constexpr (S::H > 64) {
+        return launch_lossgrad_tp<S, REPLAY>(s, params, tparams, bt, src, gamma, double_q, mode, ws, ws_bytes, grad, loss, st, qx);
+    } else {
+    using L = UpdLds<S>;
+    const int P = s->n_agents, T = bt->max_len, B = bt->batch;
+    const UpdPlan pl = upd_plan(P, T, B);
+    constexpr int PACK = 2 * S::NFWD + S::NBWD;
+    static_assert(PACK % 4 == 0 && L::oT == S::NFWD && L::oB == 2 * S::NFWD, "pack layout == LDS layout");
+    const WsLayout wl = ws_layout(P, pl.nwg, L::REC, PACK, T, B);
+    MARL_REQUIRE(ws_bytes >= wl.total, "dqn_loss_grad: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)wl.total);
+    float* packs = reinterpret_cast<float*>(static_cast<char*>(ws) + wl.pack_off);
+    float* mixf = reinterpret_cast<float*>(static_cast<char*>(ws) + wl.mix_off);
+    const size_t lds_bytes = (size_t)L::total(4) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dqn_lossgrad_kernel<S, 4, REPLAY, 0>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dqn_lossgrad_kernel<S, 4, REPLAY, 1>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dqn_lossgrad_kernel<S, 4, REPLAY, 2>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((dqn_pack_kernel<S>), dim3((PACK + 255) / 256, P), dim3(256), 0, st, params, tparams, packs);
+    MARL_CHECK_LAUNCH("dqn_pack_kernel");
+    unsigned long long* prof =
+        getenv("MARLHIP_PROF") ? reinterpret_cast<unsigned long long*>(static_cast<char*>(ws) + ws_bytes - 128) : nullptr;
+    const size_t tb = (size_t)T * B;
+    MixBufs mix;
+    mix.chosen = mixf; mix.tqsel = mixf + P * tb; mix.r0 = mixf + 2 * P * tb; mix.dn = mix.r0 + tb; mix.fl = mix.dn + tb;
+    mix.dq = mix.fl + tb; mix.lrow = mix.dq + tb; mix.dq_agent_stride = 0;
+    if (mode == 2) {  // QMIX: one dq plane per agent
+        mix.lrow = mix.dq + P * tb;
+        mix.dq_agent_stride = (int)tb;
+    }
+    const dim3 grid(pl.nwg, P), block(256);
+    timing_begin(TIMER_LOSSGRAD, st);
+    if (mode == 0) {
+        hipLaunchKernelGGL((dqn_lossgrad_kernel<S, 4, REPLAY, 0>), grid, block, lds_bytes, st, (const float*)packs, *bt, src, mix,
+                           gamma, double_q, pl.n_chunks, (float*)ws, prof);
+    } else {
+        hipLaunchKernelGGL((dqn_lossgrad_kernel<S, 4, REPLAY, 1>), grid, block, lds_bytes, st, (const float*)packs, *bt, src, mix,
+                           gamma, double_q, pl.n_chunks, (float*)ws, prof);
+        if (mode == 2) {
+            QmixIo io = {mix.chosen, mix.tqsel, mix.r0, mix.dn, mix.fl, mix.dq, mix.lrow, nullptr};
+            const int rc = qmix_dispatch_mix<S::D, REPLAY>(P, *qx, bt, src, io, gamma, st);
+            if (rc != 0) return rc;
+        } else {
+            hipLaunchKernelGGL(vdn_mix_kernel, dim3((unsigned)((tb + 255) / 256 > 1024 ? 1024 : (tb + 255) / 256)), dim3(256), 0, st,
+                               mix, P, T, B, gamma);
+        }
+        hipLaunchKernelGGL((dqn_lossgrad_kernel<S, 4, REPLAY, 2>), grid, block, lds_bytes, st, (const float*)packs, *bt, src, mix,
+                           gamma, double_q, pl.n_chunks, (float*)ws, prof);
+    }
+    timing_end(TIMER_LOSSGRAD, st);
+    MARL_CHECK_LAUNCH("dqn_lossgrad_kernel");
+    const int n = P * S::NPARAM;
+    hipLaunchKernelGGL(dqn_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, st, (const float*)ws, P, pl.nwg, S::NPARAM, grad, loss);
+    MARL_CHECK_LAUNCH("dqn_reduce_kernel");
+    if (mode == 2) return qmix_dispatch_reduce<S::D>(P, *qx, T, B, loss, st);
+    return 0;
+    }
+}
+
+template <class S>
+int launch_lossgrad(const marlhip_net_shape* s, const float* params, const float* tparams, const marlhip_batch* bt,
+                    const ReplaySrc* rsrc, float gamma, int double_q, int mode, void* ws, int64_t ws_bytes, float* grad, float* loss,
+                    hipStream_t st, const QmixCtx* qx) {
+    if (rsrc != nullptr)
+        return launch_lossgrad_src<S, true>(s, params, tparams, bt, *rsrc, gamma, double_q, mode, ws, ws_bytes, grad, loss, st, qx);
+    ReplaySrc none = {};
+    return launch_lossgrad_src<S, false>(s, params, tparams, bt, none, gamma, double_q, mode, ws, ws_bytes, grad, loss, st, qx);
+}
+
+}  // namespace marl
+

@@ -22,6 +22,7 @@ struct TpMix {
     float* fl;      // [T][B]
     float* dq;      // [P][T][B]
     float* lrow;    // [T][B]
+    const float* dout;  // FULL pass B: [P][T][B][A] external gradient w.r.t. every network output
 };
 
 // register image of the weights of one owned hidden tile
@@ -59,6 +60,7 @@ struct TpRows {
     float bx[NT1][4];
     int a_sel;
     float rw, dn, fl, dq, lr;
+    float dqv[4];  // FULL: dL/d(output 4g+r)
 };
 
 template <class S, bool REPLAY>
@@ -70,9 +72,10 @@ struct TpSrc {  // everything load_rows needs, per block
     const float* filled;
     ReplaySrc rs;
     int P, p, T, B;
+    size_t obs_rs;  // row stride of obs_p (D in the dqn/train.py Batch)
 };
 
-template <class S, bool REPLAY, bool BWD>
+template <class S, bool REPLAY, bool BWD, bool FULL = false>
 __device__ __forceinline__ void tp_load_rows(const TpSrc<S, REPLAY>& s, const TpMix& mix, int t, int b0, int g, int j, int ej,
                                              const int (&eg)[4], TpRows<S, REPLAY>& R) {
     constexpr int D = S::D, NT1 = S::DP / 16;
@@ -100,7 +103,7 @@ __device__ __forceinline__ void tp_load_rows(const TpSrc<S, REPLAY>& s, const Tp
         R.dn = s.rs.rb.done[(size_t)ej * (T + 1) + tt + 1] ? 1.f : 0.f;
         R.fl = s.rs.rb.filled[(size_t)ej * T + tt] ? 1.f : 0.f;
     } else {
-        const float* xrow = s.obs_p + ((size_t)t * B + bj) * D;
+        const float* xrow = s.obs_p + ((size_t)t * B + bj) * s.obs_rs;
 #pragma unroll
         for (int ks = 0; ks < S::KS1; ++ks) {
             const int d = 4 * ks + g;
@@ -112,16 +115,24 @@ __device__ __forceinline__ void tp_load_rows(const TpSrc<S, REPLAY>& s, const Tp
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
                     const int row = b0 + 4 * g + ks, d = 16 * nt + j;
-                    R.bx[nt][ks] = s.obs_p[((size_t)t * B + (row < B ? row : B - 1)) * D + (d < D ? d : D - 1)];
+                    R.bx[nt][ks] = s.obs_p[((size_t)t * B + (row < B ? row : B - 1)) * s.obs_rs + (d < D ? d : D - 1)];
                 }
         }
-        R.a_sel = (int)s.act_p[(size_t)tt * B + bj];
-        R.rw = s.rew_p[(size_t)tt * B + bj];
-        R.dn = s.dones[(size_t)(tt + 1) * B + bj];
+        if (!FULL) {
+            R.a_sel = (int)s.act_p[(size_t)tt * B + bj];
+            R.rw = s.rew_p[(size_t)tt * B + bj];
+            R.dn = s.dones[(size_t)(tt + 1) * B + bj];
+        }
         R.fl = s.filled[(size_t)tt * B + bj];
     }
     if (BWD) {
-        R.dq = mix.dq[((size_t)p * T + tt) * B + bj];
+        if (FULL) {
+            const float* drow = mix.dout + (((size_t)p * T + tt) * B + bj) * S::A;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) R.dqv[r] = drow[4 * g + r < S::A ? 4 * g + r : S::A - 1];
+        } else {
+            R.dq = mix.dq[((size_t)p * T + tt) * B + bj];
+        }
         R.lr = mix.lrow[(size_t)tt * B + bj];
     }
 }
@@ -139,6 +150,8 @@ __device__ __forceinline__ void tp_mask_rows(TpRows<S, REPLAY>& R, int b0, int B
             for (int ks = 0; ks < 4; ++ks) R.bx[nt][ks] = (b0 + 4 * g + ks < B && 16 * nt + j < D) ? R.bx[nt][ks] : 0.f;
         R.dq = rowok ? R.dq : 0.f;
         R.lr = rowok ? R.lr : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) R.dqv[r] = (rowok && 4 * g + r < S::A) ? R.dqv[r] : 0.f;
     }
     R.fl = rowok ? R.fl : 0.f;
 }
@@ -200,7 +213,8 @@ __global__ __launch_bounds__(64 * W, 1) void tp_fwd_kernel(const float* __restri
         }
     }
     TpSrc<S, REPLAY> src;
-    src.obs_p = REPLAY ? nullptr : bt.obss + (size_t)p * (T + 1) * B * S::D;
+    src.obs_p = REPLAY ? nullptr : bt.obss + (size_t)p * (bt.obs_agent_stride ? (size_t)bt.obs_agent_stride : (size_t)(T + 1) * B * S::D);
+    src.obs_rs = bt.obs_row_stride ? (size_t)bt.obs_row_stride : (size_t)S::D;
     src.act_p = REPLAY ? nullptr : bt.actions + (size_t)p * T * B;
     src.rew_p = REPLAY ? nullptr : bt.rewards + (size_t)p * T * B;
     src.dones = bt.dones; src.filled = bt.filled; src.rs = rs; src.P = P; src.p = p; src.T = T; src.B = B;
@@ -313,7 +327,7 @@ __global__ __launch_bounds__(64 * W, 1) void tp_fwd_kernel(const float* __restri
 }
 
 // mixers: dq_p[t][b] = dL/dchosen_p (unnormalised), lrow[t][b] = per-row loss (dqn/model.py:152,160-163 / 254-269)
-__global__ __launch_bounds__(256) void tp_mix_kernel(TpMix mix, int P, int T, int B, float gamma, int vdn) {
+static __global__ __launch_bounds__(256) void tp_mix_kernel(TpMix mix, int P, int T, int B, float gamma, int vdn) {
     const int n = T * B;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         const float fl = mix.fl[i], nd = 1.f - mix.dn[i];
@@ -342,7 +356,7 @@ __global__ __launch_bounds__(256) void tp_mix_kernel(TpMix mix, int P, int T, in
 // pass B: critic layers 1-2 forward + backward with the external dq; gradient slices stay with their wave
 // LDS (floats): Hc[NB][NT][256] | HcT[NB][H][16] | G2[NB][NT][256] | per wave: PQ[256] + (P2,PH2,P1)[TPW][256]
 // ---------------------------------------------------------------------------------------------------------
-template <class S, int W, int TPW, bool REPLAY, int NB>
+template <class S, int W, int TPW, bool REPLAY, int NB, bool FULL = false>
 __global__ __launch_bounds__(64 * W, 1) void tp_bwd_kernel(const float* __restrict__ params, marlhip_batch bt, ReplaySrc rs, TpMix mix,
                                                            int n_chunks, float* __restrict__ partials) {
     constexpr int NT = W * TPW, A = S::A, D = S::D, H = S::H, NT1 = S::DP / 16;
@@ -390,9 +404,10 @@ __global__ __launch_bounds__(64 * W, 1) void tp_bwd_kernel(const float* __restri
     float loss_acc = 0.f, nfill_acc = 0.f;
 
     TpSrc<S, REPLAY> src;
-    src.obs_p = REPLAY ? nullptr : bt.obss + (size_t)p * (T + 1) * B * D;
-    src.act_p = REPLAY ? nullptr : bt.actions + (size_t)p * T * B;
-    src.rew_p = REPLAY ? nullptr : bt.rewards + (size_t)p * T * B;
+    src.obs_p = REPLAY ? nullptr : bt.obss + (size_t)p * (bt.obs_agent_stride ? (size_t)bt.obs_agent_stride : (size_t)(T + 1) * B * D);
+    src.obs_rs = bt.obs_row_stride ? (size_t)bt.obs_row_stride : (size_t)D;
+    src.act_p = (REPLAY || FULL) ? nullptr : bt.actions + (size_t)p * T * B;
+    src.rew_p = (REPLAY || FULL) ? nullptr : bt.rewards + (size_t)p * T * B;
     src.dones = bt.dones; src.filled = bt.filled; src.rs = rs; src.P = P; src.p = p; src.T = T; src.B = B;
 
     const int nsets = (B + 16 * NB - 1) / (16 * NB);
@@ -406,13 +421,14 @@ __global__ __launch_bounds__(64 * W, 1) void tp_bwd_kernel(const float* __restri
         for (int nb = 0; nb < NB; ++nb) tp_episode_ids<REPLAY>(rs, (set * NB + nb) * 16, B, g, j, ej[nb], eg[nb]);
         TpRows<S, REPLAY> cur[NB];
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) tp_load_rows<S, REPLAY, true>(src, mix, t1 - 1, (set * NB + nb) * 16, g, j, ej[nb], eg[nb], cur[nb]);
+        for (int nb = 0; nb < NB; ++nb)
+            tp_load_rows<S, REPLAY, true, FULL>(src, mix, t1 - 1, (set * NB + nb) * 16, g, j, ej[nb], eg[nb], cur[nb]);
         for (int t = t1 - 1; t >= t0; --t) {
             TpRows<S, REPLAY> nxt[NB];
             f4 h1[NB][TPW];
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
-                tp_load_rows<S, REPLAY, true>(src, mix, t > t0 ? t - 1 : t0, (set * NB + nb) * 16, g, j, ej[nb], eg[nb], nxt[nb]);
+                tp_load_rows<S, REPLAY, true, FULL>(src, mix, t > t0 ? t - 1 : t0, (set * NB + nb) * 16, g, j, ej[nb], eg[nb], nxt[nb]);
                 tp_mask_rows<S, REPLAY, true>(cur[nb], (set * NB + nb) * 16, B, g, j);
             }
             // ---- layer 1 of my tiles: C-layout dump (layer-2 operand) + [h][row] tile (dW2 operand)
@@ -437,7 +453,7 @@ __global__ __launch_bounds__(64 * W, 1) void tp_bwd_kernel(const float* __restri
                 const int a_sel = cur[nb].a_sel;
                 f4 dQ[1];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) dQ[0][r] = (4 * g + r == a_sel) ? cur[nb].dq : 0.f;
+                for (int r = 0; r < 4; ++r) dQ[0][r] = FULL ? cur[nb].dqv[r] : ((4 * g + r == a_sel) ? cur[nb].dq : 0.f);
                 if (wave == 0) {
                     db3 += dQ[0];
                     if (g == 0 && p == 0) { loss_acc += cur[nb].lr; nfill_acc += cur[nb].fl; }

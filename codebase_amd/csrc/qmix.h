@@ -553,7 +553,7 @@ __global__ __launch_bounds__(512, 1) void qmix_wgrad_kernel(QmixRows<Q, REPLAY> 
 }
 
 // mixer_grad[i] = (sum over records, fixed order) / n_filled ; n_filled = nf[1] as written by dqn_reduce_kernel
-__global__ __launch_bounds__(256) void qmix_reduce_kernel(const float* __restrict__ partials, int nwg, int nparam,
+static __global__ __launch_bounds__(256) void qmix_reduce_kernel(const float* __restrict__ partials, int nwg, int nparam,
                                                           const float* __restrict__ loss_nf, float* __restrict__ grad) {
     __shared__ float s_part[4][64];
     const int l64 = threadIdx.x & 63, slice = threadIdx.x >> 6;

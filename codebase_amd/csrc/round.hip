@@ -12,7 +12,7 @@ extern "C" int marlhip_idqn_update_n(const marlhip_idqn_learner* L, int32_t n_up
     MARL_REQUIRE(n_updates >= 0 && L->batch > 0, "idqn_update_n: bad counts");
     const int np = marlhip_net_nparams(&L->net);
     if (np < 0) return -1;
-    marlhip_batch bt;
+    marlhip_batch bt = {};
     bt.obss = L->obss; bt.actions = L->actions; bt.rewards = L->rewards; bt.dones = L->dones; bt.filled = L->filled;
     bt.max_len = L->rs.max_len; bt.batch = L->batch;
     const double tui = L->target_update_interval_or_tau;

@@ -8,7 +8,7 @@ from dataclasses import dataclass
 import torch
 
 from . import _lib
-from ._lib import (BatchStruct, IdqnLearner, QmixMixer, LbfBuffers, LbfConfig, MarlHipError, NetShape, ReplayBuffers, ReplayShape, check, lib)
+from ._lib import (AcConfig, BatchStruct, IdqnLearner, QmixMixer, LbfBuffers, LbfConfig, MarlHipError, NetShape, ReplayBuffers, ReplayShape, check, lib)
 
 Batch = namedtuple("Batch", ["obss", "actions", "rewards", "dones", "filled", "action_mask"])  # dqn/train.py:14-16
 
@@ -290,6 +290,96 @@ class QmixUpdater(DqnUpdater):
                                         float(self.betas[0]), float(self.betas[1]), float(self.eps), 0.0, float(grad_scale),
                                         int(bool(hard_update)), float(tau), _ptr(self.mixer_scratch), None, _stream()),
               "dqn_clip_adam(mixer)")
+
+
+def ac_forward_rows(spec: NetSpec, params, obs, agent_stride, row_stride, n_rows, value_net=False):
+    """out[p][row][:] = MLP_p(obs row); value_net: the critic shape (one output)."""
+    _require_gpu()
+    s = spec.c()
+    out = torch.empty(spec.n_agents, n_rows, 1 if value_net else spec.n_actions, device=params.device)
+    check(lib.marlhip_ac_forward_rows(ctypes.byref(s), int(bool(value_net)), _ptr(params), _ptr(obs), int(agent_stride),
+                                      int(row_stride), int(n_rows), _ptr(out), _stream()), "ac_forward_rows")
+    return out
+
+
+class AcUpdater:
+    """A2CNetwork.update / PPONetwork.update on the device (marlbase/ac/model.py:189-352): loss + gradient of actor and
+    critic from one rollout Batch in the ac/train.py layout, then clip over ALL parameters + Adam on the joint block.
+    `block` is ONE flat fp32 tensor [P*n_actor + P*n_critic]: actor blocks first (parameters() order), then critic."""
+
+    def __init__(self, spec: NetSpec, block, target_critic, lr=3e-4, betas=(0.9, 0.999), eps=1e-8, gamma=0.99, n_steps=5,
+                 entropy_coef=0.001, value_loss_coef=0.5, grad_clip=False, ppo_clip=0.2):
+        _require_gpu()
+        s = spec.c()
+        self.spec = spec
+        self.n_actor = spec.nparams()
+        self.n_critic = check(lib.marlhip_ac_critic_nparams(ctypes.byref(s)), "ac_critic_nparams")
+        P = spec.n_agents
+        if block.numel() != P * (self.n_actor + self.n_critic) or target_critic.numel() != P * self.n_critic:
+            raise ValueError("actor-critic parameter block has the wrong size for this shape")
+        self.block, self.target_critic = block, target_critic
+        self.actor = block[:P * self.n_actor].view(P, self.n_actor)
+        self.critic = block[P * self.n_actor:].view(P, self.n_critic)
+        self.grad = torch.zeros_like(block)
+        self.actor_grad = self.grad[:P * self.n_actor].view(P, self.n_actor)
+        self.critic_grad = self.grad[P * self.n_actor:].view(P, self.n_critic)
+        self.exp_avg, self.exp_avg_sq = torch.zeros_like(block), torch.zeros_like(block)
+        self.scratch = torch.zeros((block.numel() + 255) // 256 + 1, dtype=torch.float32, device=block.device)
+        self.gnorm = torch.zeros(1, dtype=torch.float32, device=block.device)
+        self.metrics = torch.zeros(5, dtype=torch.float32, device=block.device)
+        self.cfg = AcConfig(int(n_steps), float(entropy_coef), float(value_loss_coef), float(ppo_clip), float(gamma))
+        self.lr, self.betas, self.eps = lr, betas, eps
+        self.grad_clip = float(grad_clip) if grad_clip else 0.0
+        self.step = 0
+        self._ws = {}
+
+    def _workspace(self, T, B):
+        if (T, B) not in self._ws:
+            s = self.spec.c()
+            n = check(lib.marlhip_ac_workspace_bytes(ctypes.byref(s), T, B), "ac_workspace_bytes")
+            self._ws[(T, B)] = torch.empty(int(n), dtype=torch.uint8, device=self.block.device)
+        return self._ws[(T, B)]
+
+    def _batch(self, batch):
+        """ac/train.py Batch (obss [T+1,N,P*D], actions i64 [T,N,P], rewards [T,N,P], dones [T+1,N], filled [T,N])"""
+        T, N = batch.filled.shape
+        P, D = self.spec.n_agents, self.spec.obs_dim
+        dones = batch.dones if batch.dones.dtype == torch.float32 else batch.dones.float()  # model.py:198
+        keep = (batch.obss.contiguous(), batch.actions.contiguous(), batch.rewards.contiguous(), dones.contiguous(),
+                batch.filled.contiguous())
+        bs = BatchStruct(keep[0].data_ptr(), keep[1].data_ptr(), keep[2].data_ptr(), keep[3].data_ptr(), keep[4].data_ptr(), T, N,
+                         D, P * D, 1, P)
+        return bs, keep, T, N
+
+    def a2c_loss_grad(self, batch):
+        bs, keep, T, N = self._batch(batch)
+        ws, s = self._workspace(T, N), self.spec.c()
+        check(lib.marlhip_a2c_loss_grad(ctypes.byref(s), _ptr(self.actor), _ptr(self.critic), _ptr(self.target_critic),
+                                        ctypes.byref(bs), ctypes.byref(self.cfg), _ptr(ws), ws.numel(), _ptr(self.actor_grad),
+                                        _ptr(self.critic_grad), _ptr(self.metrics), _stream()), "a2c_loss_grad")
+        return self.metrics
+
+    def ppo_prepare(self, batch):
+        bs, keep, T, N = self._batch(batch)
+        ws, s = self._workspace(T, N), self.spec.c()
+        check(lib.marlhip_ppo_prepare(ctypes.byref(s), _ptr(self.actor), _ptr(self.critic), _ptr(self.target_critic),
+                                      ctypes.byref(bs), ctypes.byref(self.cfg), _ptr(ws), ws.numel(), _stream()), "ppo_prepare")
+
+    def ppo_loss_grad(self, batch):
+        bs, keep, T, N = self._batch(batch)
+        ws, s = self._workspace(T, N), self.spec.c()
+        check(lib.marlhip_ppo_loss_grad(ctypes.byref(s), _ptr(self.actor), _ptr(self.critic), ctypes.byref(bs), ctypes.byref(self.cfg),
+                                        _ptr(ws), ws.numel(), _ptr(self.actor_grad), _ptr(self.critic_grad), _ptr(self.metrics),
+                                        _stream()), "ppo_loss_grad")
+        return self.metrics
+
+    def apply(self, grad_scale=1.0):
+        """clip_grad_norm_(self.parameters(), grad_clip) + optimizer.step() (model.py:227-231): one norm over actor + critic"""
+        self.step += 1
+        check(lib.marlhip_dqn_clip_adam(self.block.numel(), _ptr(self.block), _ptr(self.grad), _ptr(self.exp_avg),
+                                        _ptr(self.exp_avg_sq), None, self.step, float(self.lr), float(self.betas[0]),
+                                        float(self.betas[1]), float(self.eps), float(self.grad_clip), float(grad_scale), 0, 0.0,
+                                        _ptr(self.scratch), _ptr(self.gnorm), _stream()), "dqn_clip_adam(actor+critic)")
 
 
 def idqn_collect(cfg: LbfConfig, spec: NetSpec, params, epsilon, round_idx, replay: DeviceReplay, slot_base, fin_return,

@@ -170,6 +170,10 @@ typedef struct marlhip_batch {
     const float* dones;     /* [T+1][B] */
     const float* filled;    /* [T][B] */
     int32_t max_len, batch; /* T, B */
+    /* optional strides in ELEMENTS, 0 = the dqn/train.py layout above.  The ac/train.py Batch (ac/train.py:36-49) keeps the
+     * agents innermost: obss [T+1][B][P*D] -> obs_agent_stride = D, obs_row_stride = P*D; actions / rewards [T][B][P] ->
+     * act_agent_stride = 1, act_row_stride = P.  (obs strides: every learner entry point; act strides: marlhip_ac_* only) */
+    int64_t obs_agent_stride, obs_row_stride, act_agent_stride, act_row_stride;
 } marlhip_batch;
 
 /* bytes of scratch marlhip_dqn_loss_grad needs for this (shape, T, B) */
@@ -237,6 +241,43 @@ int marlhip_ac_collect(const marlhip_lbf_config* cfg, const marlhip_net_shape* s
                        int64_t* batch_act, float* batch_rew, uint8_t* batch_done, float* batch_filled,
                        float* fin_return /* [P][N] */, int32_t* fin_length /* [N] */, int32_t* t_max /* [1] */,
                        void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Actor-critic learner step (IA2C / IPPO).  Replaces A2CNetwork.update / PPONetwork.update
+ * (marlbase/ac/model.py:189-246, 264-352) up to loss.backward(): target-critic values of all T+1 observations,
+ * n-step returns (marlbase/utils/utils.py:38-63), critic values and Categorical log-prob / entropy on obs[:-1],
+ * filled-masked actor + value losses, gradient w.r.t. actor and critic.  Independent networks, no RNN / masks /
+ * return standardisation.  The batch is the ac/train.py Batch (set the marlhip_batch strides; dones as fp32).
+ * actor: [P][marlhip_net_nparams(s)] blocks of actor.independent.{i}.network.*; critic / target_critic:
+ * [P][marlhip_ac_critic_nparams(s)] blocks (same MLP with ONE output).  Afterwards: clip_grad_norm_(self.parameters())
+ * + Adam = ONE marlhip_dqn_clip_adam over the contiguous [actor | critic] block (target = NULL), then the
+ * step-keyed target copy (model.py:233-239) on the critic block.
+ * metrics[5] = loss, actor_loss, value_loss, entropy (model.py:241-246), sum(filled).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct marlhip_ac_config {
+    int32_t n_steps;      /* cfg.n_steps (1..16) */
+    float entropy_coef, value_loss_coef;
+    float ppo_clip;       /* PPO only */
+    double gamma;         /* python float: gamma ** k is formed in fp64 and rounded once, like the reference */
+} marlhip_ac_config;
+
+int marlhip_ac_critic_nparams(const marlhip_net_shape* s);
+int64_t marlhip_ac_workspace_bytes(const marlhip_net_shape* s, int32_t max_len, int32_t batch);
+/* A2CNetwork.get_value / the actor forward of A2CNetwork.act (model.py:147-163) on arbitrary rows:
+ * out[p][row][:] = MLP_p(obs + p * agent_stride + row * row_stride); value_net != 0: the one-output critic shape. */
+int marlhip_ac_forward_rows(const marlhip_net_shape* s, int32_t value_net, const float* params, const float* obs,
+                            int64_t agent_stride, int64_t row_stride, int32_t n_rows, float* out, void* stream);
+int marlhip_a2c_loss_grad(const marlhip_net_shape* s, const float* actor, const float* critic, const float* target_critic,
+                          const marlhip_batch* batch, const marlhip_ac_config* cfg, void* workspace, int64_t workspace_bytes,
+                          float* actor_grad, float* critic_grad, float* metrics, void* stream);
+/* PPONetwork.update: marlhip_ppo_prepare once per batch (returns + old log-probs, kept in the workspace: model.py:266-293),
+ * then per epoch marlhip_ppo_loss_grad + marlhip_dqn_clip_adam (model.py:296-335). */
+int marlhip_ppo_prepare(const marlhip_net_shape* s, const float* actor, const float* critic, const float* target_critic,
+                        const marlhip_batch* batch, const marlhip_ac_config* cfg, void* workspace, int64_t workspace_bytes,
+                        void* stream);
+int marlhip_ppo_loss_grad(const marlhip_net_shape* s, const float* actor, const float* critic, const marlhip_batch* batch,
+                          const marlhip_ac_config* cfg, void* workspace, int64_t workspace_bytes, float* actor_grad,
+                          float* critic_grad, float* metrics, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * n learner updates from one call: n x (marlhip_replay_sample with device-drawn indices ->
