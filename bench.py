@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--replay-rounds", type=int, default=4, help="replay capacity in rounds of `envs` episodes")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--env-name", default=ENV_NAME, help="other BASELINE.json configs, e.g. lbforaging:Foraging-15x15-4p-5f-v3")
-    ap.add_argument("--algo", default="idqn", choices=["idqn", "vdn", "qmix"])
+    ap.add_argument("--algo", default="idqn", choices=["idqn", "vdn", "qmix", "ia2c", "ippo"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -101,6 +101,115 @@ def cpu_baseline(seconds, hidden):
                       f"per episode, 1 thread) in {dt:.1f} s; host has {os.cpu_count()} cores"}
 
 
+def bench_ac(args, rank, world, dist):
+    """IA2C / IPPO (marlbase/ac): one step = one rollout of every env (fused collector, 1 launch) + one update
+    (A2C) or num_epochs updates (PPO) on that rollout.  env-steps = transitions actually stored (sum of `filled`);
+    the reference's own counter advances by t_max * parallel_envs per rollout (ac/train.py:226) - reported next to it."""
+    import torch
+
+    from codebase_amd import hip as h
+    from codebase_amd._lib import lib
+    from codebase_amd.ac.model import A2CNetwork, PPONetwork
+    from codebase_amd.ac.train import Batch
+    from codebase_amd.parallel import GradSync, rank_env_seed
+    from codebase_amd.utils.envs import _space_pair
+
+    N, T, H = args.envs, args.time_limit, args.hidden
+    cfg = h.lbf_config(args.env_name, N, T, seed=rank_env_seed(args.seed, rank))
+    P, D, A = cfg.n_agents, 3 * (cfg.n_agents + cfg.n_food), 6
+    torch.manual_seed(args.seed)
+    obs_space, act_space = _space_pair(cfg)
+    hyper = dict(optimizer="Adam", lr=3e-4, gamma=0.99, grad_clip=False, n_steps=5, entropy_coef=0.001, value_loss_coef=0.5,
+                 standardise_returns=False, target_update_interval_or_tau=200, num_epochs=4, ppo_clip=0.2)  # ia2c.yaml / ippo.yaml
+    net = dict(layers=[H, H], parameter_sharing=False, use_orthogonal_init=True, use_rnn=False)
+    model = (PPONetwork if args.algo == "ippo" else A2CNetwork)(obs_space, act_space, hyper, net, dict(net, centralised=False), "cuda")
+    dev = model.device
+    b_obs = torch.empty(T + 1, N, P * D, device=dev)
+    b_act = torch.empty(T, N, P, dtype=torch.int64, device=dev)
+    b_rew = torch.empty(T, N, P, device=dev)
+    b_done = torch.empty(T + 1, N, dtype=torch.uint8, device=dev)
+    b_donef = torch.empty(T + 1, N, device=dev)
+    b_fill = torch.empty(T, N, device=dev)
+    fin_ret = torch.zeros(P, N, device=dev)
+    fin_len = torch.zeros(N, dtype=torch.int32, device=dev)
+    t_max = torch.zeros(1, dtype=torch.int32, device=dev)
+    steps_dev = torch.zeros((), dtype=torch.int64, device=dev)
+    ref_steps = torch.zeros((), dtype=torch.int64, device=dev)
+    sync_grad = GradSync(dist) if dist is not None else None
+    state = {"round": 0, "step": 0}
+
+    def one_round():
+        h.ac_collect(cfg, model.spec, model.actor_params, state["round"], T, False, b_obs, b_act, b_rew, b_done, b_fill, fin_ret,
+                     fin_len, t_max)
+        b_donef.copy_(b_done)  # batch.dones.float() (ac/model.py:198)
+        model.update_async(Batch(b_obs, b_act, b_rew, b_donef, b_fill, None), state["step"], grad_sync=sync_grad, world=world)
+        steps_dev.add_(b_fill.sum().to(torch.int64))
+        ref_steps.add_(t_max[0].to(torch.int64) * N)
+        state["round"] += 1
+        state["step"] += T * N  # host-side stand-in for the reference's step counter (target update cadence only)
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_round()
+    sync()
+    steps_dev.zero_()
+    ref_steps.zero_()
+    if not args.no_kernel_timing:
+        lib.marlhip_timing_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_round()
+    sync()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt[0])
+        dist.all_reduce(steps_dev)
+        dist.all_reduce(ref_steps)
+    env_steps = int(steps_dev.item())
+    timing = {}
+    if not args.no_kernel_timing:
+        for kid, kname in ((0, "ac_update (fwd rows x3, elementwise, bwd rows x2)"), (1, "ac_collect_kernel")):
+            n, ms = ctypes.c_int64(0), ctypes.c_double(0.0)
+            lib.marlhip_timing_read(kid, ctypes.byref(n), ctypes.byref(ms))
+            if n.value:
+                timing[kname] = {"launches": n.value, "avg_us": 1e3 * ms.value / n.value, "total_ms": ms.value}
+        lib.marlhip_timing_enable(0)
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+    name = args.env_name.split(":")[-1].replace("-v3", "")
+    roofline = None
+    upd = timing.get("ac_update (fwd rows x3, elementwise, bwd rows x2)")
+    if upd:
+        # algorithmic flops per A2C update: target fwd (T+1 rows) + critic fwd+bwd (3x) + actor fwd+bwd (3x) on T rows
+        fa, fc = 2.0 * (D * H + H * H + H * A), 2.0 * (D * H + H * H + H)
+        flops = P * N * (fc * (T + 1) + 3 * fc * T + 3 * fa * T)
+        ach = flops / (upd["avg_us"] * 1e-6) / 1e12
+        roofline = {"kernel": "ac_update", "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None, "flops_per_launch": flops, "avg_launch_us": upd["avg_us"]}
+    out = {
+        "metric": f"env-steps/sec (whole node) {args.algo.upper()} {name}", "value": env_steps / dt, "unit": "env-steps/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic (Philox-seeded LBF layouts, orthogonal-init weights)",
+        "config": {"workload": f"{args.algo.upper()} on {name}, {N} batched HIP envs per GPU, actor/critic 2-layer-{H} MLPs, "
+                               f"time_limit {T}, one update per rollout", "envs_per_gpu": N, "env_steps_timed": env_steps,
+                   "reference_step_counter": int(ref_steps.item()),
+                   "parallelism": f"dp{world} (envs sharded per GPU, RCCL grad all-reduce per update)" if world > 1 else "1 GPU"},
+        "kernels": timing, "roofline": roofline,
+    }
+    print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     import torch
@@ -121,6 +230,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         kw = {"device_id": torch.device("cuda", dev_index)} if backend == "nccl" else {}
         dist.init_process_group(backend, **kw)
+
+    if args.algo in ("ia2c", "ippo"):
+        return bench_ac(args, rank, world, dist)
 
     from codebase_amd import hip as h
     from codebase_amd._lib import lib

@@ -300,6 +300,7 @@ int ac_step(int P, const float* actor, const float* critic, const float* target,
     for (int k = 0; k <= c->n_steps; ++k) a.gk[k] = (float)pow(c->gamma, (double)k);
     a.ent_coef = c->entropy_coef; a.vlc = c->value_loss_coef; a.ppo_clip = c->ppo_clip;
     int rc;
+    timing_begin(TIMER_LOSSGRAD, st);
     if (mode != 2) {  // target-critic values of all T+1 observations (model.py:190-193); PPO reuses the returns across epochs
         rc = launch_forward_rows<SC>(P, target, bt, TB + B, f(wl.vnext), st);
         if (rc != 0) return rc;
@@ -312,7 +313,10 @@ int ac_step(int P, const float* actor, const float* critic, const float* target,
     }
     hipLaunchKernelGGL(ac_elem_kernel, dim3((TB + 255) / 256), dim3(256), 0, st, a, *bt, w);
     MARL_CHECK_LAUNCH("ac_elem_kernel");
-    if (mode == 1) return 0;
+    if (mode == 1) {
+        timing_end(TIMER_LOSSGRAD, st);
+        return 0;
+    }
     float* scratch = f(wl.scratch);
     rc = launch_backward_rows<SA>(P, actor, bt, w.dlogits, w.lrow_a, base + wl.bwd, ws_bytes - wl.bwd, actor_grad, scratch, st);
     if (rc != 0) return rc;
@@ -320,6 +324,7 @@ int ac_step(int P, const float* actor, const float* critic, const float* target,
     if (rc != 0) return rc;
     hipLaunchKernelGGL(ac_metrics_kernel, dim3(1), dim3(1024), 0, st, TB, c->value_loss_coef, (const float*)w.lrow_a,
                        (const float*)w.lrow_v, (const float*)w.ent, bt->filled, metrics);
+    timing_end(TIMER_LOSSGRAD, st);
     MARL_CHECK_LAUNCH("ac_metrics_kernel");
     return 0;
 }

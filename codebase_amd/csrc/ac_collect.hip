@@ -198,8 +198,10 @@ int launch_ac_collect(const LbfParams& q, const float* actor, uint32_t round, in
         attr_set = true;
     }
     (void)hipMemsetAsync(t_max, 0, sizeof(int32_t), st);
+    timing_begin(TIMER_COLLECT, st);
     hipLaunchKernelGGL((ac_collect_kernel<P, F, H>), dim3((q.n_envs + 63) / 64), dim3(ACOL_BLOCK), lds_bytes, st, q, actor, round, T,
                        proper_term, b_obs, b_act, b_rew, b_done, b_filled, fin_return, fin_length, t_max);
+    timing_end(TIMER_COLLECT, st);
     MARL_CHECK_LAUNCH("ac_collect_kernel");
     return 0;
 }
