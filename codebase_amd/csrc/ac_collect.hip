@@ -49,7 +49,7 @@ __device__ __forceinline__ int sample_rows(const f4& logits, int lane, float u) 
 }
 
 template <int P, int F, int H>
-__global__ __launch_bounds__(ACOL_BLOCK) void ac_collect_kernel(LbfParams q, const float* __restrict__ actor, uint32_t round, int T,
+__global__ __launch_bounds__(ACOL_BLOCK) void ac_collect_kernel(LbfParams q, const float* __restrict__ actor /* pre-packed [P][NFWD] */, uint32_t round, int T,
                                                                 int proper_term, float* __restrict__ b_obs,
                                                                 int64_t* __restrict__ b_act, float* __restrict__ b_rew,
                                                                 uint8_t* __restrict__ b_done, float* __restrict__ b_filled,
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(ACOL_BLOCK) void ac_collect_kernel(LbfParams q, con
     const bool valid = n < N;
     const uint32_t env_id = (uint32_t)(valid ? n : N - 1);
     if (RESIDENT) {
-        for (int p = 0; p < P; ++p) mlp_stage_fwd<S>(actor + (size_t)p * S::NPARAM, lds + (size_t)p * S::NFWD, tid, ACOL_BLOCK);
+        for (int p = 0; p < P; ++p) stage_packed<S>(actor + (size_t)p * S::NFWD, lds + (size_t)p * S::NFWD, tid, ACOL_BLOCK);
         __syncthreads();
     }
     LbfState<P, F> s;
@@ -105,12 +105,12 @@ __global__ __launch_bounds__(ACOL_BLOCK) void ac_collect_kernel(LbfParams q, con
                     pack = lds + (size_t)p * S::NFWD;
                 } else {
                     __syncthreads();
-                    mlp_stage_fwd<S>(actor + (size_t)p * S::NPARAM, lds, tid, ACOL_BLOCK);
+                    stage_packed<S>(actor + (size_t)p * S::NFWD, lds, tid, ACOL_BLOCK);
                     __syncthreads();
                     pack = lds;
                 }
-                f4 h1[S::MT], h2[S::MT], logits;
-                mlp_forward<S>(pack, lane, x[p], h1, h2, logits);
+                f4 h1[S::MT], h2[S::MT], logits, unused;
+                mlp_forward_p<S, false>(pack, pack, lane, x[p], h1, h2, logits, unused);
                 const float u = u01_f32(act_noise_word(q.seed, env_id, 2u * round, (uint32_t)t, 1 + p));
                 act[p] = sample_rows<A>(logits, lane, u);
             }
@@ -198,8 +198,10 @@ int launch_ac_collect(const LbfParams& q, const float* actor, uint32_t round, in
         attr_set = true;
     }
     (void)hipMemsetAsync(t_max, 0, sizeof(int32_t), st);
+    float* packs = nullptr;
+    if (launch_fwd_pack<S>(P, actor, &packs, st) != 0) return -1;
     timing_begin(TIMER_COLLECT, st);
-    hipLaunchKernelGGL((ac_collect_kernel<P, F, H>), dim3((q.n_envs + 63) / 64), dim3(ACOL_BLOCK), lds_bytes, st, q, actor, round, T,
+    hipLaunchKernelGGL((ac_collect_kernel<P, F, H>), dim3((q.n_envs + 63) / 64), dim3(ACOL_BLOCK), lds_bytes, st, q, (const float*)packs, round, T,
                        proper_term, b_obs, b_act, b_rew, b_done, b_filled, fin_return, fin_length, t_max);
     timing_end(TIMER_COLLECT, st);
     MARL_CHECK_LAUNCH("ac_collect_kernel");

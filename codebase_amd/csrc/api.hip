@@ -41,6 +41,41 @@ void timing_end(int id, hipStream_t st) {
     ++t.n;
     t.open = false;
 }
+
+struct PackScratch {
+    int dev;
+    hipStream_t st;
+    float* buf;
+    size_t cap;
+};
+static PackScratch g_scratch[16];
+static int g_nscratch = 0;
+
+float* collect_pack_scratch(size_t bytes, hipStream_t st) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    PackScratch* e = nullptr;
+    for (int i = 0; i < g_nscratch; ++i)
+        if (g_scratch[i].dev == dev && g_scratch[i].st == st) e = &g_scratch[i];
+    if (e == nullptr) {
+        if (g_nscratch == 16) return nullptr;
+        e = &g_scratch[g_nscratch++];
+        e->dev = dev; e->st = st; e->buf = nullptr; e->cap = 0;
+    }
+    if (bytes > e->cap) {
+        if (e->buf != nullptr) {
+            (void)hipStreamSynchronize(st);  // a kernel of this stream may still read the old buffer
+            (void)hipFree(e->buf);
+        }
+        const size_t want = bytes < (1u << 20) ? (1u << 20) : bytes;
+        if (hipMalloc(reinterpret_cast<void**>(&e->buf), want) != hipSuccess) {
+            e->buf = nullptr; e->cap = 0;
+            return nullptr;
+        }
+        e->cap = want;
+    }
+    return e->buf;
+}
 }  // namespace marl
 
 extern "C" int marlhip_version(void) { return MARLHIP_VERSION; }

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(COL_BLOCK) void dqn_act_kernel(int P, int N, const 
 }
 
 template <int P, int F, int H>
-__global__ __launch_bounds__(COL_BLOCK) void idqn_collect_kernel(LbfParams q, const float* __restrict__ params, float eps,
+__global__ __launch_bounds__(COL_BLOCK) void idqn_collect_kernel(LbfParams q, const float* __restrict__ packs, float eps,
                                                                  uint32_t round, marlhip_replay_shape rs, marlhip_replay_buffers rb,
                                                                  int slot_base, int write_replay, int clear_stale, int proper_term,
                                                                  float* __restrict__ fin_return, int32_t* __restrict__ fin_length) {
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(COL_BLOCK) void idqn_collect_kernel(LbfParams q, co
     const uint32_t env_id = (uint32_t)(valid ? n : N - 1);
 
     if (RESIDENT) {
-        for (int p = 0; p < P; ++p) mlp_stage_fwd<S>(params + (size_t)p * S::NPARAM, lds + (size_t)p * S::NFWD, tid, COL_BLOCK);
+        for (int p = 0; p < P; ++p) stage_packed<S>(packs + (size_t)p * S::NFWD, lds + (size_t)p * S::NFWD, tid, COL_BLOCK);
         __syncthreads();
     }
 
@@ -135,12 +135,12 @@ __global__ __launch_bounds__(COL_BLOCK) void idqn_collect_kernel(LbfParams q, co
                 pack = lds + (size_t)p * S::NFWD;
             } else {
                 __syncthreads();
-                mlp_stage_fwd<S>(params + (size_t)p * S::NPARAM, lds, tid, COL_BLOCK);
+                stage_packed<S>(packs + (size_t)p * S::NFWD, lds, tid, COL_BLOCK);
                 __syncthreads();
                 pack = lds;
             }
-            f4 h1[S::MT], h2[S::MT], qv;
-            mlp_forward<S>(pack, lane, x[p], h1, h2, qv);
+            f4 h1[S::MT], h2[S::MT], qv, unused;
+            mlp_forward_p<S, false>(pack, pack, lane, x[p], h1, h2, qv, unused);
             const int greedy = argmax_rows<A>(qv, lane);
             act[p] = explore ? rnd[p] : greedy;
         }
@@ -209,8 +209,10 @@ int launch_collect(const LbfParams& q, const float* params, float eps, uint32_t 
         attr_set = true;
     }
     const int grid = (q.n_envs + 63) / 64;
+    float* packs = nullptr;
+    if (launch_fwd_pack<S>(P, params, &packs, st) != 0) return -1;
     timing_begin(TIMER_COLLECT, st);
-    hipLaunchKernelGGL((idqn_collect_kernel<P, F, H>), dim3(grid), dim3(COL_BLOCK), lds_bytes, st, q, params, eps, round, *rs, *rb,
+    hipLaunchKernelGGL((idqn_collect_kernel<P, F, H>), dim3(grid), dim3(COL_BLOCK), lds_bytes, st, q, (const float*)packs, eps, round, *rs, *rb,
                        slot_base, write_replay, clear_stale, proper_term, fin_return, fin_length);
     timing_end(TIMER_COLLECT, st);
     MARL_CHECK_LAUNCH("idqn_collect_kernel");

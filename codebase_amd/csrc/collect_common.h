@@ -27,4 +27,34 @@ __device__ __forceinline__ void pick_obs(const LbfObs<P, F>& o, int g, float (&x
     }
 }
 
+// Pre-packed actor / critic weights for the collectors: one tiny kernel turns the canonical parameter blocks into the
+// MFMA A-operand packs ([P][NFWD], L2-resident), workgroups then stage them with straight 16-byte copies - once when all
+// agents fit in LDS, once per (step, agent) when they do not (hidden 128, > 1 agent).  The scratch is library-owned,
+// grow-only, one per (device, stream) so that collectors on different streams never share it.
+float* collect_pack_scratch(size_t bytes, hipStream_t st);  // api.hip; nullptr on allocation failure
+
+template <class S>
+__global__ __launch_bounds__(256) void fwd_pack_kernel(const float* __restrict__ params, float* __restrict__ packs) {
+    const int p = blockIdx.y, idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx < S::NFWD) packs[(size_t)p * S::NFWD + idx] = mlp_fwd_pack_elem<S>(params + (size_t)p * S::NPARAM, idx);
+}
+
+template <class S>
+__device__ __forceinline__ void stage_packed(const float* __restrict__ pack, float* lds, int tid, int nthreads) {
+    static_assert(S::NFWD % 4 == 0, "pack is a whole number of float4");
+    const f4* src = reinterpret_cast<const f4*>(pack);
+    f4* dst = reinterpret_cast<f4*>(lds);
+    for (int i = tid; i < S::NFWD / 4; i += nthreads) dst[i] = src[i];
+}
+
+template <class S>
+int launch_fwd_pack(int P, const float* params, float** packs_out, hipStream_t st) {
+    float* packs = collect_pack_scratch((size_t)P * S::NFWD * sizeof(float), st);
+    MARL_REQUIRE(packs != nullptr, "collector: cannot allocate %zu bytes of pack scratch", (size_t)P * S::NFWD * sizeof(float));
+    hipLaunchKernelGGL((fwd_pack_kernel<S>), dim3((S::NFWD + 255) / 256, P), dim3(256), 0, st, params, packs);
+    MARL_CHECK_LAUNCH("fwd_pack_kernel");
+    *packs_out = packs;
+    return 0;
+}
+
 }  // namespace marl
