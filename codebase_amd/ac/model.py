@@ -10,8 +10,9 @@ Interface kept: constructor `(obs_space, action_space, cfg, actor, critic, devic
 
 Storage: ONE flat fp32 block [actor agents | critic agents] (so that clip_grad_norm_(self.parameters()) + Adam is a
 single fused launch) plus the target-critic block; state_dict tensors are slices.
-Built: independent actors and critics (IA2C / IPPO), two equal hidden layers of 64 or 128.  Not built (raise):
-centralised critic (MAA2C / MAPPO), parameter sharing, GRU, action masks, return standardisation.
+Built: independent or shared (parameter_sharing True / SePS index list, the same for actor and critic) actors and
+critics (IA2C / IPPO), two equal hidden layers of 64 or 128.  Not built (raise): centralised critic (MAA2C / MAPPO),
+GRU, action masks, return standardisation.
 """
 from collections import OrderedDict
 
@@ -19,7 +20,7 @@ import numpy as np
 import torch
 
 from .. import hip as _hip
-from ..dqn.model import _fc, _tensor_layout
+from ..dqn.model import _fc, _tensor_layout, sharing_indices
 from ..spaces import flatdim
 
 
@@ -39,9 +40,10 @@ class A2CNetwork:
         obs_dims = [flatdim(o) for o in obs_space]
         act_dims = [flatdim(a) for a in action_space]
         self.n_agents = P = len(obs_dims)
+        self.sharing = sharing_indices(_get(actor, "parameter_sharing", False), P)
+        if sharing_indices(_get(critic, "parameter_sharing", False), P) != self.sharing:
+            raise NotImplementedError("actor.parameter_sharing != critic.parameter_sharing: one agent -> network map serves both")
         for name, net in (("actor", actor), ("critic", critic)):
-            if _get(net, "parameter_sharing", False):
-                raise NotImplementedError(f"{name}.parameter_sharing: shared / SePS networks are a 'next' row (DESIGN.md)")
             if _get(net, "use_rnn", False):
                 raise NotImplementedError(f"{name}.use_rnn: the GRU path is a 'next' row (DESIGN.md)")
         if _get(critic, "centralised", False):
@@ -66,11 +68,15 @@ class A2CNetwork:
         self.target_update_interval_or_tau = _get(cfg, "target_update_interval_or_tau", 200)
         self.standardise_returns = False
         self.centralised_critic = False
-        self.spec = _hip.NetSpec(P, obs_dims[0], ha[0], act_dims[0])
+        self.spec = _hip.NetSpec(P, obs_dims[0], ha[0], act_dims[0], self.sharing)
+        if self.sharing is not None:  # one network per distinct index, in order of first appearance (utils/models.py:209-240)
+            first = [self.sharing.index(k) for k in range(max(self.sharing) + 1)]
+            obs_dims, act_dims = [obs_dims[i] for i in first], [act_dims[i] for i in first]
+        K = self.spec.n_blocks
         # torch RNG consumption in the reference's order: actor nets, critic nets, target-critic nets (model.py:44-107)
         a0 = _init_blocks(obs_dims, ha, act_dims, _get(actor, "use_orthogonal_init", True))
-        c0 = _init_blocks(obs_dims, hc, [1] * P, _get(critic, "use_orthogonal_init", True))
-        _init_blocks(obs_dims, hc, [1] * P, _get(critic, "use_orthogonal_init", True))  # target: drawn, then overwritten (soft_update(1.0))
+        c0 = _init_blocks(obs_dims, hc, [1] * K, _get(critic, "use_orthogonal_init", True))
+        _init_blocks(obs_dims, hc, [1] * K, _get(critic, "use_orthogonal_init", True))  # target: drawn, then overwritten (soft_update(1.0))
         self.block = torch.cat([a0.reshape(-1), c0.reshape(-1)]).to(self.device).contiguous()
         self.target_critic_params = c0.clone().to(self.device).contiguous()
         self.updater = _hip.AcUpdater(self.spec, self.block, self.target_critic_params, lr=float(_get(cfg, "lr", 3e-4)),
@@ -147,7 +153,8 @@ class A2CNetwork:
 
     # ---- torch-module-like surface ---------------------------------------------------------------
     def _views(self):
-        S, P = self.spec, self.n_agents
+        S, P = self.spec, self.spec.n_blocks
+        group = "independent" if self.sharing is None else "networks"
         out = OrderedDict()
         for prefix, block, A in (("actor", self.actor_params, S.n_actions), ("critic", self.critic_params, 1),
                                  ("target_critic", self.target_critic_params, 1)):
@@ -155,7 +162,7 @@ class A2CNetwork:
                 o = 0
                 for name, shape in _tensor_layout(S.obs_dim, S.hidden, A):
                     n = int(np.prod(shape))
-                    out[f"{prefix}.independent.{i}.{name}"] = block[i, o:o + n].view(shape)
+                    out[f"{prefix}.{group}.{i}.{name}"] = block[i, o:o + n].view(shape)
                     o += n
         return out
 

@@ -18,13 +18,13 @@ namespace marl {
 
 // ---- forward rows ------------------------------------------------------------------------------------------
 template <class S>
-__global__ __launch_bounds__(256) void mlp_rows_fwd_kernel(const float* __restrict__ params, const float* __restrict__ obs,
+__global__ __launch_bounds__(256) void mlp_rows_fwd_kernel(const float* __restrict__ params, AgentMap am, const float* __restrict__ obs,
                                                            size_t agent_stride, size_t row_stride, int n_rows,
                                                            float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, j = lane & 15;
     const int p = blockIdx.y;
-    mlp_stage_fwd<S>(params + (size_t)p * S::NPARAM, lds, tid, 256);
+    mlp_stage_fwd<S>(params + (size_t)am.net[p] * S::NPARAM, lds, tid, 256);
     __syncthreads();
     const float* obs_p = obs + (size_t)p * agent_stride;
     const int nblk = (n_rows + 15) >> 4;
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void mlp_rows_fwd_kernel(const float* __restri
 }
 
 template <class S>
-int launch_forward_rows(int P, const float* params, const marlhip_batch* bt, int n_rows, float* out, hipStream_t st) {
+int launch_forward_rows(int P, const AgentMap& am, const float* params, const marlhip_batch* bt, int n_rows, float* out, hipStream_t st) {
     const int T = bt->max_len, B = bt->batch;
     const size_t as = bt->obs_agent_stride ? (size_t)bt->obs_agent_stride : (size_t)(T + 1) * B * S::D;
     const size_t rs = bt->obs_row_stride ? (size_t)bt->obs_row_stride : (size_t)S::D;
@@ -64,7 +64,7 @@ int launch_forward_rows(int P, const float* params, const marlhip_batch* bt, int
     int gx = (nblk + 3) / 4;
     const int cap = 512 / P > 1 ? 512 / P : 1;
     if (gx > cap) gx = cap;
-    hipLaunchKernelGGL((mlp_rows_fwd_kernel<S>), dim3(gx, P), dim3(256), LDSB, st, params, bt->obss, as, rs, n_rows, out);
+    hipLaunchKernelGGL((mlp_rows_fwd_kernel<S>), dim3(gx, P), dim3(256), LDSB, st, params, am, bt->obss, as, rs, n_rows, out);
     MARL_CHECK_LAUNCH("mlp_rows_fwd_kernel");
     return 0;
 }
@@ -83,7 +83,7 @@ int64_t backward_ws_bytes(int P, int T, int B) {
 
 // grad[P][NPARAM] = d(sum_rows lrow-loss)/dparams / sum(filled) from dout[P][T][B][A]; loss[0] = sum(lrow)/sum(filled)
 template <class S>
-int launch_backward_rows(int P, const float* params, const marlhip_batch* bt, const float* dout, float* lrow, void* ws,
+int launch_backward_rows(int P, const AgentMap& am, const float* params, const marlhip_batch* bt, const float* dout, float* lrow, void* ws,
                          int64_t ws_bytes, float* grad, float* loss, hipStream_t st) {
     const int T = bt->max_len, B = bt->batch;
     MARL_REQUIRE(ws_bytes >= backward_ws_bytes<S>(P, T, B), "ac backward: workspace %lld too small", (long long)ws_bytes);
@@ -103,7 +103,7 @@ int launch_backward_rows(int P, const float* params, const marlhip_batch* bt, co
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsB);
             attr_set = true;
         }
-        hipLaunchKernelGGL((tp_bwd_kernel<S, W, TPW, false, NB, true>), dim3(pl.nwg, P), dim3(64 * W), ldsB, st, params, *bt, none, mix,
+        hipLaunchKernelGGL((tp_bwd_kernel<S, W, TPW, false, NB, true>), dim3(pl.nwg, P), dim3(64 * W), ldsB, st, params, am, *bt, none, mix,
                            pl.n_chunks, (float*)ws);
         MARL_CHECK_LAUNCH("tp_bwd_kernel<FULL>");
     } else {
@@ -120,7 +120,7 @@ int launch_backward_rows(int P, const float* params, const marlhip_batch* bt, co
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
             attr_set = true;
         }
-        hipLaunchKernelGGL((dqn_pack_kernel<S>), dim3((PACK + 255) / 256, P), dim3(256), 0, st, params, params, packs);
+        hipLaunchKernelGGL((dqn_pack_kernel<S>), dim3((PACK + 255) / 256, P), dim3(256), 0, st, params, params, am, packs);
         MixBufs mix = {};
         mix.lrow = lrow;
         mix.dout = dout;
@@ -128,8 +128,8 @@ int launch_backward_rows(int P, const float* params, const marlhip_batch* bt, co
                            mix, 0.f, 0, pl.n_chunks, (float*)ws, (unsigned long long*)nullptr);
         MARL_CHECK_LAUNCH("dqn_lossgrad_kernel<MODE 4>");
     }
-    const int n = P * S::NPARAM;
-    hipLaunchKernelGGL(dqn_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, st, (const float*)ws, P, nwg, S::NPARAM, grad, loss);
+    const int n = am.nblk * S::NPARAM;
+    hipLaunchKernelGGL(dqn_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, st, (const float*)ws, P, nwg, S::NPARAM, am, grad, loss);
     MARL_CHECK_LAUNCH("dqn_reduce_kernel");
     return 0;
 }
@@ -283,7 +283,7 @@ AcWs ac_ws_layout(int P, int T, int B) {
 }
 
 template <int D, int H, int A>
-int ac_step(int P, const float* actor, const float* critic, const float* target, const marlhip_batch* bt, const marlhip_ac_config* c,
+int ac_step(int P, const AgentMap& am, const float* actor, const float* critic, const float* target, const marlhip_batch* bt, const marlhip_ac_config* c,
             int mode, void* ws, int64_t ws_bytes, float* actor_grad, float* critic_grad, float* metrics, hipStream_t st) {
     using SA = MlpShape<D, H, A>;
     using SC = MlpShape<D, H, 1>;
@@ -302,13 +302,13 @@ int ac_step(int P, const float* actor, const float* critic, const float* target,
     int rc;
     timing_begin(TIMER_LOSSGRAD, st);
     if (mode != 2) {  // target-critic values of all T+1 observations (model.py:190-193); PPO reuses the returns across epochs
-        rc = launch_forward_rows<SC>(P, target, bt, TB + B, f(wl.vnext), st);
+        rc = launch_forward_rows<SC>(P, am, target, bt, TB + B, f(wl.vnext), st);
         if (rc != 0) return rc;
     }
-    rc = launch_forward_rows<SA>(P, actor, bt, TB, f(wl.logits), st);
+    rc = launch_forward_rows<SA>(P, am, actor, bt, TB, f(wl.logits), st);
     if (rc != 0) return rc;
     if (mode != 1) {
-        rc = launch_forward_rows<SC>(P, critic, bt, TB, f(wl.v), st);
+        rc = launch_forward_rows<SC>(P, am, critic, bt, TB, f(wl.v), st);
         if (rc != 0) return rc;
     }
     hipLaunchKernelGGL(ac_elem_kernel, dim3((TB + 255) / 256), dim3(256), 0, st, a, *bt, w);
@@ -318,9 +318,9 @@ int ac_step(int P, const float* actor, const float* critic, const float* target,
         return 0;
     }
     float* scratch = f(wl.scratch);
-    rc = launch_backward_rows<SA>(P, actor, bt, w.dlogits, w.lrow_a, base + wl.bwd, ws_bytes - wl.bwd, actor_grad, scratch, st);
+    rc = launch_backward_rows<SA>(P, am, actor, bt, w.dlogits, w.lrow_a, base + wl.bwd, ws_bytes - wl.bwd, actor_grad, scratch, st);
     if (rc != 0) return rc;
-    rc = launch_backward_rows<SC>(P, critic, bt, w.dv, w.lrow_v, base + wl.bwd, ws_bytes - wl.bwd, critic_grad, scratch + 2, st);
+    rc = launch_backward_rows<SC>(P, am, critic, bt, w.dv, w.lrow_v, base + wl.bwd, ws_bytes - wl.bwd, critic_grad, scratch + 2, st);
     if (rc != 0) return rc;
     hipLaunchKernelGGL(ac_metrics_kernel, dim3(1), dim3(1024), 0, st, TB, c->value_loss_coef, (const float*)w.lrow_a,
                        (const float*)w.lrow_v, (const float*)w.ent, bt->filled, metrics);
@@ -339,6 +339,7 @@ using namespace marl;
 
 static int ac_check(const marlhip_net_shape* s) {
     MARL_REQUIRE(s != nullptr, "net shape is NULL");
+    if (agent_map_validate(s) != 0) return -1;
     MARL_REQUIRE(s->n_agents >= 1 && s->n_actions == 6, "ac: the compiled actors have 6 actions (LBF), got %d", s->n_actions);
 #define X(d, h) if (s->obs_dim == d && s->hidden == h) return 0;
     MARL_AC_SHAPES(X)
@@ -376,7 +377,7 @@ static int ac_call(const marlhip_net_shape* s, const float* actor, const float* 
     MARL_REQUIRE(c->n_steps >= 1 && c->n_steps <= 16, "ac_loss_grad: n_steps %d outside [1, 16]", c->n_steps);
 #define X(d, h)                                                                                                                  \
     if (s->obs_dim == d && s->hidden == h)                                                                                        \
-        return ac_step<d, h, 6>(s->n_agents, actor, critic, target, bt, c, mode, ws, ws_bytes, actor_grad, critic_grad, metrics, \
+        return ac_step<d, h, 6>(s->n_agents, agent_map(s), actor, critic, target, bt, c, mode, ws, ws_bytes, actor_grad, critic_grad, metrics, \
                                 (hipStream_t)stream);
     MARL_AC_SHAPES(X)
 #undef X
@@ -392,8 +393,8 @@ extern "C" int marlhip_ac_forward_rows(const marlhip_net_shape* s, int32_t value
     bt.obs_agent_stride = agent_stride; bt.obs_row_stride = row_stride;
 #define X(d, h)                                                                                                            \
     if (s->obs_dim == d && s->hidden == h)                                                                                  \
-        return value_net ? launch_forward_rows<MlpShape<d, h, 1>>(s->n_agents, params, &bt, n_rows, out, (hipStream_t)stream) \
-                         : launch_forward_rows<MlpShape<d, h, 6>>(s->n_agents, params, &bt, n_rows, out, (hipStream_t)stream);
+        return value_net ? launch_forward_rows<MlpShape<d, h, 1>>(s->n_agents, agent_map(s), params, &bt, n_rows, out, (hipStream_t)stream) \
+                         : launch_forward_rows<MlpShape<d, h, 6>>(s->n_agents, agent_map(s), params, &bt, n_rows, out, (hipStream_t)stream);
     MARL_AC_SHAPES(X)
 #undef X
     return -1;

@@ -184,7 +184,7 @@ __global__ __launch_bounds__(ACOL_BLOCK) void ac_collect_kernel(LbfParams q, con
 }
 
 template <int P, int F, int H>
-int launch_ac_collect(const LbfParams& q, const float* actor, uint32_t round, int T, int proper_term, float* b_obs, int64_t* b_act,
+int launch_ac_collect(const LbfParams& q, const AgentMap& am, const float* actor, uint32_t round, int T, int proper_term, float* b_obs, int64_t* b_act,
                       float* b_rew, uint8_t* b_done, float* b_filled, float* fin_return, int32_t* fin_length, int32_t* t_max,
                       hipStream_t st) {
     constexpr int D = 3 * (P + F);
@@ -199,7 +199,7 @@ int launch_ac_collect(const LbfParams& q, const float* actor, uint32_t round, in
     }
     (void)hipMemsetAsync(t_max, 0, sizeof(int32_t), st);
     float* packs = nullptr;
-    if (launch_fwd_pack<S>(P, actor, &packs, st) != 0) return -1;
+    if (launch_fwd_pack<S>(P, am, actor, &packs, st) != 0) return -1;
     timing_begin(TIMER_COLLECT, st);
     hipLaunchKernelGGL((ac_collect_kernel<P, F, H>), dim3((q.n_envs + 63) / 64), dim3(ACOL_BLOCK), lds_bytes, st, q, (const float*)packs, round, T,
                        proper_term, b_obs, b_act, b_rew, b_done, b_filled, fin_return, fin_length, t_max);
@@ -223,15 +223,16 @@ extern "C" int marlhip_ac_collect(const marlhip_lbf_config* cfg, const marlhip_n
                  "ac_collect: net shape does not match the env (P=%d D=%d A=6 expected)", cfg->n_agents,
                  3 * (cfg->n_agents + cfg->n_food));
     MARL_REQUIRE(max_len > 0, "ac_collect: max_len must be > 0");
+    if (agent_map_validate(s) != 0) return -1;
     const LbfParams q = to_params(cfg);
 #define X(p, f)                                                                                                                  \
     if (cfg->n_agents == p && cfg->n_food == f) {                                                                                \
         if (s->hidden == 64)                                                                                                     \
-            return launch_ac_collect<p, f, 64>(q, actor_params, round, max_len, use_proper_termination, batch_obs, batch_act,     \
+            return launch_ac_collect<p, f, 64>(q, agent_map(s), actor_params, round, max_len, use_proper_termination, batch_obs, batch_act,     \
                                                batch_rew, batch_done, batch_filled, fin_return, fin_length, t_max,               \
                                                (hipStream_t)stream);                                                              \
         if (s->hidden == 128)                                                                                                    \
-            return launch_ac_collect<p, f, 128>(q, actor_params, round, max_len, use_proper_termination, batch_obs, batch_act,    \
+            return launch_ac_collect<p, f, 128>(q, agent_map(s), actor_params, round, max_len, use_proper_termination, batch_obs, batch_act,    \
                                                 batch_rew, batch_done, batch_filled, fin_return, fin_length, t_max,              \
                                                 (hipStream_t)stream);                                                             \
     }

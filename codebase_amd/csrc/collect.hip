@@ -17,7 +17,7 @@ namespace marl {
 constexpr int COL_BLOCK = 256;
 
 template <class S>
-__global__ __launch_bounds__(COL_BLOCK) void dqn_act_kernel(int P, int N, const float* __restrict__ params,
+__global__ __launch_bounds__(COL_BLOCK) void dqn_act_kernel(int P, int N, AgentMap am, const float* __restrict__ params,
                                                             const float* __restrict__ obs, float eps,
                                                             const float* __restrict__ u_in, const int32_t* __restrict__ rand_in,
                                                             uint64_t seed, const uint32_t* __restrict__ episode,
@@ -40,7 +40,7 @@ __global__ __launch_bounds__(COL_BLOCK) void dqn_act_kernel(int P, int N, const 
     const bool explore = eps > u;
     for (int p = 0; p < P; ++p) {
         __syncthreads();
-        mlp_stage_fwd<S>(params + (size_t)p * S::NPARAM, lds, tid, COL_BLOCK);
+        mlp_stage_fwd<S>(params + (size_t)am.net[p] * S::NPARAM, lds, tid, COL_BLOCK);
         __syncthreads();
         float x[S::KS1];
         const float* xrow = obs + ((size_t)p * N + nn) * S::D;
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(COL_BLOCK) void idqn_collect_kernel(LbfParams q, co
 }
 
 template <int P, int F, int H>
-int launch_collect(const LbfParams& q, const float* params, float eps, uint32_t round, const marlhip_replay_shape* rs,
+int launch_collect(const LbfParams& q, const AgentMap& am, const float* params, float eps, uint32_t round, const marlhip_replay_shape* rs,
                    const marlhip_replay_buffers* rb, int slot_base, int write_replay, int clear_stale, int proper_term,
                    float* fin_return, int32_t* fin_length, hipStream_t st) {
     constexpr int D = 3 * (P + F);
@@ -210,7 +210,7 @@ int launch_collect(const LbfParams& q, const float* params, float eps, uint32_t 
     }
     const int grid = (q.n_envs + 63) / 64;
     float* packs = nullptr;
-    if (launch_fwd_pack<S>(P, params, &packs, st) != 0) return -1;
+    if (launch_fwd_pack<S>(P, am, params, &packs, st) != 0) return -1;
     timing_begin(TIMER_COLLECT, st);
     hipLaunchKernelGGL((idqn_collect_kernel<P, F, H>), dim3(grid), dim3(COL_BLOCK), lds_bytes, st, q, (const float*)packs, eps, round, *rs, *rb,
                        slot_base, write_replay, clear_stale, proper_term, fin_return, fin_length);
@@ -227,6 +227,7 @@ extern "C" int marlhip_dqn_act(const marlhip_net_shape* s, const float* params, 
                                const float* u, const int32_t* rand_actions, uint64_t seed, const uint32_t* episode,
                                const int32_t* ep_length, int32_t* actions, float* q_out, void* stream) {
     MARL_REQUIRE(s && params && obs && actions, "dqn_act: NULL pointer");
+    if (agent_map_validate(s) != 0) return -1;
     MARL_REQUIRE(n_envs > 0, "dqn_act: n_envs must be > 0");
     MARL_REQUIRE((u != nullptr) == (rand_actions != nullptr), "dqn_act: u and rand_actions must be given together");
     MARL_REQUIRE(u != nullptr || (episode != nullptr && ep_length != nullptr), "dqn_act: need injected noise or episode/ep_length");
@@ -242,7 +243,7 @@ extern "C" int marlhip_dqn_act(const marlhip_net_shape* s, const float* params, 
             attr_set = true;                                                                                                \
         }                                                                                                                   \
         hipLaunchKernelGGL((dqn_act_kernel<S_>), dim3(grid), dim3(COL_BLOCK), lds_bytes, (hipStream_t)stream, s->n_agents,  \
-                           n_envs, params, obs, epsilon, u, rand_actions, seed, episode, ep_length, actions, q_out);        \
+                           n_envs, agent_map(s), params, obs, epsilon, u, rand_actions, seed, episode, ep_length, actions, q_out);        \
         MARL_CHECK_LAUNCH("dqn_act_kernel");                                                                                \
         return 0;                                                                                                           \
     }
@@ -258,6 +259,7 @@ extern "C" int marlhip_idqn_collect(const marlhip_lbf_config* cfg, const marlhip
                                     float* fin_return, int32_t* fin_length, void* stream) {
     if (lbf_validate(cfg) != 0) return -1;
     MARL_REQUIRE(s && params && rs && rb && fin_return && fin_length, "idqn_collect: NULL pointer");
+    if (agent_map_validate(s) != 0) return -1;
     MARL_REQUIRE(s->n_agents == cfg->n_agents && s->obs_dim == 3 * (cfg->n_agents + cfg->n_food) && s->n_actions == 6,
                  "idqn_collect: net shape does not match the env (P=%d D=%d A=6 expected)", cfg->n_agents,
                  3 * (cfg->n_agents + cfg->n_food));
@@ -269,10 +271,10 @@ extern "C" int marlhip_idqn_collect(const marlhip_lbf_config* cfg, const marlhip
 #define X(p, f)                                                                                                              \
     if (cfg->n_agents == p && cfg->n_food == f) {                                                                            \
         if (s->hidden == 64)                                                                                                 \
-            return launch_collect<p, f, 64>(q, params, epsilon, round, rs, rb, slot_base, write_replay, clear_stale,          \
+            return launch_collect<p, f, 64>(q, agent_map(s), params, epsilon, round, rs, rb, slot_base, write_replay, clear_stale,          \
                                             use_proper_termination, fin_return, fin_length, (hipStream_t)stream);            \
         if (s->hidden == 128)                                                                                                \
-            return launch_collect<p, f, 128>(q, params, epsilon, round, rs, rb, slot_base, write_replay, clear_stale,         \
+            return launch_collect<p, f, 128>(q, agent_map(s), params, epsilon, round, rs, rb, slot_base, write_replay, clear_stale,         \
                                              use_proper_termination, fin_return, fin_length, (hipStream_t)stream);           \
     }
     MARL_LBF_SHAPES(X)

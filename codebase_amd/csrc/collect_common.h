@@ -34,9 +34,9 @@ __device__ __forceinline__ void pick_obs(const LbfObs<P, F>& o, int g, float (&x
 float* collect_pack_scratch(size_t bytes, hipStream_t st);  // api.hip; nullptr on allocation failure
 
 template <class S>
-__global__ __launch_bounds__(256) void fwd_pack_kernel(const float* __restrict__ params, float* __restrict__ packs) {
+__global__ __launch_bounds__(256) void fwd_pack_kernel(const float* __restrict__ params, AgentMap am, float* __restrict__ packs) {
     const int p = blockIdx.y, idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx < S::NFWD) packs[(size_t)p * S::NFWD + idx] = mlp_fwd_pack_elem<S>(params + (size_t)p * S::NPARAM, idx);
+    if (idx < S::NFWD) packs[(size_t)p * S::NFWD + idx] = mlp_fwd_pack_elem<S>(params + (size_t)am.net[p] * S::NPARAM, idx);
 }
 
 template <class S>
@@ -48,10 +48,10 @@ __device__ __forceinline__ void stage_packed(const float* __restrict__ pack, flo
 }
 
 template <class S>
-int launch_fwd_pack(int P, const float* params, float** packs_out, hipStream_t st) {
+int launch_fwd_pack(int P, const AgentMap& am, const float* params, float** packs_out, hipStream_t st) {
     float* packs = collect_pack_scratch((size_t)P * S::NFWD * sizeof(float), st);
     MARL_REQUIRE(packs != nullptr, "collector: cannot allocate %zu bytes of pack scratch", (size_t)P * S::NFWD * sizeof(float));
-    hipLaunchKernelGGL((fwd_pack_kernel<S>), dim3((S::NFWD + 255) / 256, P), dim3(256), 0, st, params, packs);
+    hipLaunchKernelGGL((fwd_pack_kernel<S>), dim3((S::NFWD + 255) / 256, P), dim3(256), 0, st, params, am, packs);
     MARL_CHECK_LAUNCH("fwd_pack_kernel");
     *packs_out = packs;
     return 0;

@@ -66,6 +66,29 @@ inline int lbf_validate(const marlhip_lbf_config* c) {
     return 0;
 }
 
+// agent -> parameter block (identity for independent networks); passed to kernels by value
+struct AgentMap {
+    int nblk;         // number of parameter blocks (networks)
+    int8_t net[16];
+};
+
+inline AgentMap agent_map(const marlhip_net_shape* s) {
+    AgentMap m;
+    m.nblk = s->n_networks > 0 ? s->n_networks : s->n_agents;
+    for (int i = 0; i < 16; ++i) m.net[i] = (int8_t)(s->n_networks > 0 ? (i < s->n_agents ? s->net_of[i] : 0) : i);
+    return m;
+}
+
+inline int agent_map_validate(const marlhip_net_shape* s) {
+    MARL_REQUIRE(s->n_agents >= 1 && s->n_agents <= 16, "net shape: %d agents (1..16 supported)", s->n_agents);
+    if (s->n_networks > 0) {
+        MARL_REQUIRE(s->n_networks <= s->n_agents, "net shape: %d networks for %d agents", s->n_networks, s->n_agents);
+        for (int i = 0; i < s->n_agents; ++i)
+            MARL_REQUIRE(s->net_of[i] >= 0 && s->net_of[i] < s->n_networks, "net shape: net_of[%d] = %d out of range", i, s->net_of[i]);
+    }
+    return 0;
+}
+
 // network shapes (D, H, A) with compiled MFMA kernels.  X(D, H, A)
 //   LBF obs dims: 2p2f 12, 2p3f 15, 3p3f 18, 3p5f 24, 4p3f 21, 4p5f 27, 8p5f 39
 #define MARL_NET_SHAPES(X)                                                                         \

@@ -34,6 +34,8 @@ static int lossgrad_dispatch(const marlhip_net_shape* s, const float* params, co
                              const ReplaySrc* rsrc, float gamma, int32_t double_q, int32_t mode, void* workspace,
                              int64_t workspace_bytes, float* grad, float* loss, void* stream, const QmixCtx* qx = nullptr) {
     MARL_REQUIRE(mode == 0 || mode == 1 || (mode == 2 && qx != nullptr), "dqn_loss_grad: mode %d unknown (0 = IDQN, 1 = VDN)", mode);
+    if (agent_map_validate(s) != 0) return -1;
+    MARL_REQUIRE(bt->act_agent_stride == 0 && bt->act_row_stride == 0, "dqn_loss_grad: action / reward strides are an actor-critic option");
 #define X(d, h, a)                                                                                                          \
     if (s->obs_dim == d && s->hidden == h && s->n_actions == a)                                                             \
         return launch_lossgrad<MlpShape<d, h, a>>(s, params, target_params, bt, rsrc, gamma, double_q, mode, workspace,       \

@@ -66,15 +66,15 @@ struct UpdLds {
 // packs of one agent in the workspace: [critic fwd NFWD][target fwd NFWD][critic bwd NBWD]
 template <class S>
 __global__ __launch_bounds__(256) void dqn_pack_kernel(const float* __restrict__ params, const float* __restrict__ tparams,
-                                                       float* __restrict__ packs) {
+                                                       AgentMap am, float* __restrict__ packs) {
     constexpr int TOT = 2 * S::NFWD + S::NBWD;
     const int p = blockIdx.y;
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= TOT) return;
-    const float* w = params + (size_t)p * S::NPARAM;
+    const float* w = params + (size_t)am.net[p] * S::NPARAM;
     float v;
     if (idx < S::NFWD) v = mlp_fwd_pack_elem<S>(w, idx);
-    else if (idx < 2 * S::NFWD) v = mlp_fwd_pack_elem<S>(tparams + (size_t)p * S::NPARAM, idx - S::NFWD);
+    else if (idx < 2 * S::NFWD) v = mlp_fwd_pack_elem<S>(tparams + (size_t)am.net[p] * S::NPARAM, idx - S::NFWD);
     else v = mlp_bwd_pack_elem<S>(w, idx - 2 * S::NFWD);
     packs[(size_t)p * TOT + idx] = v;
 }
@@ -516,7 +516,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dqn_lossgrad_kernel(con
 // grad[p][i] = (sum over the agent's records) / n_filled ; loss = sum of all loss fields / n_filled.
 // n_filled comes from agent 0's records only (every agent sees the same filled mask).
 static __global__ __launch_bounds__(256) void dqn_reduce_kernel(const float* __restrict__ partials, int P, int nwg, int nparam,
-                                                         float* __restrict__ grad, float* __restrict__ loss) {
+                                                         AgentMap am, float* __restrict__ grad, float* __restrict__ loss) {
     __shared__ float s_red[8];
     const int rec = nparam + 2;
     // n_filled (agent 0's records) and the loss sum (all records): strided loads + fixed-order tree
@@ -544,15 +544,19 @@ static __global__ __launch_bounds__(256) void dqn_reduce_kernel(const float* __r
     const int l64 = threadIdx.x & 63, slice = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + l64;
     float acc = 0.f;
-    if (i < P * nparam) {
-        const int p = i / nparam, k = i - p * nparam;
-        const float* src = partials + (size_t)p * nwg * rec + k;
+    // grad is [am.nblk][nparam]: a shared network's gradient is the sum over its agents, in agent order
+    if (i < am.nblk * nparam) {
+        const int blk = i / nparam, k = i - blk * nparam;
+        for (int p = 0; p < P; ++p) {
+            if (am.net[p] != blk) continue;
+            const float* src = partials + (size_t)p * nwg * rec + k;
 #pragma unroll 8
-        for (int w = slice; w < nwg; w += 4) acc += src[(size_t)w * rec];
+            for (int w = slice; w < nwg; w += 4) acc += src[(size_t)w * rec];
+        }
     }
     s_part[slice][l64] = acc;
     __syncthreads();
-    if (slice == 0 && i < P * nparam) grad[i] = ((s_part[0][l64] + s_part[1][l64]) + (s_part[2][l64] + s_part[3][l64])) / nf;
+    if (slice == 0 && i < am.nblk * nparam) grad[i] = ((s_part[0][l64] + s_part[1][l64]) + (s_part[2][l64] + s_part[3][l64])) / nf;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         loss[0] = ls / nf;
         loss[1] = nf;
@@ -772,6 +776,7 @@ int launch_lossgrad_tp(const marlhip_net_shape* s, const float* params, const fl
                        float* loss, hipStream_t st, const QmixCtx* qx) {
     constexpr int W = 4, TPW = S::H / 64, NB = 2, NT = W * TPW, REC = S::NPARAM + 2;
     const int P = s->n_agents, T = bt->max_len, B = bt->batch;
+    const AgentMap am = agent_map(s);
     const UpdPlan pl = upd_plan_tp(P, T, B, NB);
     const WsLayout wl = ws_layout(P, pl.nwg, REC, 0, T, B);
     MARL_REQUIRE(ws_bytes >= wl.total, "dqn_loss_grad: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)wl.total);
@@ -792,7 +797,7 @@ int launch_lossgrad_tp(const marlhip_net_shape* s, const float* params, const fl
     }
     const dim3 grid(pl.nwg, P), block(64 * W);
     timing_begin(TIMER_LOSSGRAD, st);
-    hipLaunchKernelGGL((tp_fwd_kernel<S, W, TPW, REPLAY, NB>), grid, block, ldsF, st, params, tparams, *bt, src, mix, double_q,
+    hipLaunchKernelGGL((tp_fwd_kernel<S, W, TPW, REPLAY, NB>), grid, block, ldsF, st, params, tparams, am, *bt, src, mix, double_q,
                        pl.n_chunks);
     if (mode == 2) {
         QmixIo io = {mix.chosen, mix.tqsel, mix.rew, mix.dn, mix.fl, mix.dq, mix.lrow, nullptr};
@@ -802,11 +807,11 @@ int launch_lossgrad_tp(const marlhip_net_shape* s, const float* params, const fl
         hipLaunchKernelGGL(tp_mix_kernel, dim3((unsigned)((tb + 255) / 256 > 1024 ? 1024 : (tb + 255) / 256)), dim3(256), 0, st, mix, P,
                            T, B, gamma, mode == 1 ? 1 : 0);
     }
-    hipLaunchKernelGGL((tp_bwd_kernel<S, W, TPW, REPLAY, NB>), grid, block, ldsB, st, params, *bt, src, mix, pl.n_chunks, (float*)ws);
+    hipLaunchKernelGGL((tp_bwd_kernel<S, W, TPW, REPLAY, NB>), grid, block, ldsB, st, params, am, *bt, src, mix, pl.n_chunks, (float*)ws);
     timing_end(TIMER_LOSSGRAD, st);
     MARL_CHECK_LAUNCH("tp_lossgrad");
-    const int n = P * S::NPARAM;
-    hipLaunchKernelGGL(dqn_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, st, (const float*)ws, P, pl.nwg, S::NPARAM, grad, loss);
+    const int n = am.nblk * S::NPARAM;
+    hipLaunchKernelGGL(dqn_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, st, (const float*)ws, P, pl.nwg, S::NPARAM, am, grad, loss);
     MARL_CHECK_LAUNCH("dqn_reduce_kernel");
     if (mode == 2) return qmix_dispatch_reduce<S::D>(P, *qx, T, B, loss, st);
     return 0;
@@ -821,6 +826,7 @@ int launch_lossgrad_src(const marlhip_net_shape* s, const float* params, const f
     } else {
     using L = UpdLds<S>;
     const int P = s->n_agents, T = bt->max_len, B = bt->batch;
+    const AgentMap am = agent_map(s);
     const UpdPlan pl = upd_plan(P, T, B);
     constexpr int PACK = 2 * S::NFWD + S::NBWD;
     static_assert(PACK % 4 == 0 && L::oT == S::NFWD && L::oB == 2 * S::NFWD, "pack layout == LDS layout");
@@ -839,7 +845,7 @@ int launch_lossgrad_src(const marlhip_net_shape* s, const float* params, const f
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         attr_set = true;
     }
-    hipLaunchKernelGGL((dqn_pack_kernel<S>), dim3((PACK + 255) / 256, P), dim3(256), 0, st, params, tparams, packs);
+    hipLaunchKernelGGL((dqn_pack_kernel<S>), dim3((PACK + 255) / 256, P), dim3(256), 0, st, params, tparams, am, packs);
     MARL_CHECK_LAUNCH("dqn_pack_kernel");
     unsigned long long* prof =
         getenv("MARLHIP_PROF") ? reinterpret_cast<unsigned long long*>(static_cast<char*>(ws) + ws_bytes - 128) : nullptr;
@@ -872,8 +878,8 @@ int launch_lossgrad_src(const marlhip_net_shape* s, const float* params, const f
     }
     timing_end(TIMER_LOSSGRAD, st);
     MARL_CHECK_LAUNCH("dqn_lossgrad_kernel");
-    const int n = P * S::NPARAM;
-    hipLaunchKernelGGL(dqn_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, st, (const float*)ws, P, pl.nwg, S::NPARAM, grad, loss);
+    const int n = am.nblk * S::NPARAM;
+    hipLaunchKernelGGL(dqn_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, st, (const float*)ws, P, pl.nwg, S::NPARAM, am, grad, loss);
     MARL_CHECK_LAUNCH("dqn_reduce_kernel");
     if (mode == 2) return qmix_dispatch_reduce<S::D>(P, *qx, T, B, loss, st);
     return 0;

@@ -178,7 +178,7 @@ __device__ __forceinline__ void tp_episode_ids(const ReplaySrc& rs, int b0, int 
 // ---------------------------------------------------------------------------------------------------------
 template <class S, int W, int TPW, bool REPLAY, int NB>
 __global__ __launch_bounds__(64 * W, 1) void tp_fwd_kernel(const float* __restrict__ params, const float* __restrict__ tparams,
-                                                           marlhip_batch bt, ReplaySrc rs, TpMix mix, int double_q, int n_chunks) {
+                                                           AgentMap am, marlhip_batch bt, ReplaySrc rs, TpMix mix, int double_q, int n_chunks) {
     constexpr int NT = W * TPW, A = S::A;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     f4* Hc = reinterpret_cast<f4*>(lds);
@@ -192,8 +192,8 @@ __global__ __launch_bounds__(64 * W, 1) void tp_fwd_kernel(const float* __restri
     TpTileW<S, NT> cw[TPW], tw[TPW];
     f4 ca3[TPW], ta3[TPW], cb3, tb3;
     {
-        const float* wc = params + (size_t)p * S::NPARAM;
-        const float* wt = tparams + (size_t)p * S::NPARAM;
+        const float* wc = params + (size_t)am.net[p] * S::NPARAM;
+        const float* wt = tparams + (size_t)am.net[p] * S::NPARAM;
 #pragma unroll
         for (int u = 0; u < TPW; ++u) {
             const int tau = wave * TPW + u;
@@ -357,7 +357,7 @@ static __global__ __launch_bounds__(256) void tp_mix_kernel(TpMix mix, int P, in
 // LDS (floats): Hc[NB][NT][256] | HcT[NB][H][16] | G2[NB][NT][256] | per wave: PQ[256] + (P2,PH2,P1)[TPW][256]
 // ---------------------------------------------------------------------------------------------------------
 template <class S, int W, int TPW, bool REPLAY, int NB, bool FULL = false>
-__global__ __launch_bounds__(64 * W, 1) void tp_bwd_kernel(const float* __restrict__ params, marlhip_batch bt, ReplaySrc rs, TpMix mix,
+__global__ __launch_bounds__(64 * W, 1) void tp_bwd_kernel(const float* __restrict__ params, AgentMap am, marlhip_batch bt, ReplaySrc rs, TpMix mix,
                                                            int n_chunks, float* __restrict__ partials) {
     constexpr int NT = W * TPW, A = S::A, D = S::D, H = S::H, NT1 = S::DP / 16;
     constexpr int PRIV = 256 * (1 + 3 * TPW);
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(64 * W, 1) void tp_bwd_kernel(const float* __restri
     TpTileW<S, NT> cw[TPW];
     f4 t3[TPW], t2[TPW][NT];
     {
-        const float* wc = params + (size_t)p * S::NPARAM;
+        const float* wc = params + (size_t)am.net[p] * S::NPARAM;
 #pragma unroll
         for (int u = 0; u < TPW; ++u) {
             const int tau = wave * TPW + u;

@@ -34,7 +34,7 @@ extern "C" int marlhip_idqn_update_n(const marlhip_idqn_learner* L, int32_t n_up
         *adam_step += 1;
         const bool hard = tui > 1.0 && (double)(*updates - *last_target_update) >= tui;
         const float tau = tui < 1.0 ? (float)tui : 0.f;
-        rc = marlhip_dqn_clip_adam((int64_t)L->net.n_agents * np, L->params, L->grad, L->exp_avg, L->exp_avg_sq, L->target,
+        rc = marlhip_dqn_clip_adam((int64_t)(L->net.n_networks > 0 ? L->net.n_networks : L->net.n_agents) * np, L->params, L->grad, L->exp_avg, L->exp_avg_sq, L->target,
                                    *adam_step, L->lr, L->beta1, L->beta2, L->eps, L->max_norm, 1.0f, hard ? 1 : 0, tau,
                                    L->scratch, L->gnorm, stream);
         if (rc < 0) return rc;

@@ -37,10 +37,31 @@ def _fc(dims, use_orthogonal_init):
     return mods
 
 
-def init_flat_params(obs_dims, hidden_dims, act_dims, use_orthogonal_init=True):
+def sharing_indices(parameter_sharing, n_agents):
+    """None for independent networks, else the agent -> network map of MultiAgentSharedNetwork
+    (marlbase/utils/models.py:193-202): True -> all agents on network 0; a list -> SePS indices."""
+    if parameter_sharing is False or parameter_sharing is None:
+        return None
+    idx = [0] * n_agents if parameter_sharing is True else [int(i) for i in parameter_sharing]
+    if len(idx) != n_agents:
+        raise ValueError("Expect same number of sharing indices as agents")
+    seen = []
+    for i in idx:
+        if i not in seen:
+            seen.append(i)
+    if seen != list(range(len(seen))):  # the reference indexes its network list with these values (models.py:286-295)
+        raise ValueError(f"sharing indices {idx}: networks must be numbered 0..K-1 in order of first appearance")
+    return tuple(idx)
+
+
+def init_flat_params(obs_dims, hidden_dims, act_dims, use_orthogonal_init=True, sharing=None):
     """Initial critic AND target blocks, consuming torch's global RNG like the reference constructor
-    does (critic nets for agents 0..P-1, then target nets; dqn/model.py:36-41) before hard_update
-    overwrites the target.  Returns (critic[P][n], target[P][n]) on the CPU."""
+    does (critic nets for agents 0..P-1 - or one per shared network in order of first appearance,
+    utils/models.py:209-240 - then target nets; dqn/model.py:36-41) before hard_update
+    overwrites the target.  Returns (critic[K][n], target[K][n]) on the CPU."""
+    if sharing is not None:
+        first = [sharing.index(k) for k in range(max(sharing) + 1)]
+        obs_dims, act_dims = [obs_dims[i] for i in first], [act_dims[i] for i in first]
     blocks = []
     for _ in range(2):
         per_agent = []
@@ -63,8 +84,6 @@ class QNetwork:
         hidden = [int(h) for h in layers]
         obs_dims = [flatdim(o) for o in obs_space]
         act_dims = [flatdim(a) for a in action_space]
-        if parameter_sharing:
-            raise NotImplementedError("parameter_sharing: shared / SePS networks are a 'next' row (DESIGN.md)")
         if use_rnn:
             raise NotImplementedError("use_rnn: the GRU path is a 'next' row (DESIGN.md)")
         if len(hidden) != 2 or hidden[0] != hidden[1]:
@@ -82,10 +101,11 @@ class QNetwork:
         self.action_space = action_space
         self.n_agents = len(obs_dims)
         self.device = torch.device(device)
-        self.spec = _hip.NetSpec(self.n_agents, obs_dims[0], hidden[0], act_dims[0])
+        self.sharing = sharing_indices(parameter_sharing, self.n_agents)
+        self.spec = _hip.NetSpec(self.n_agents, obs_dims[0], hidden[0], act_dims[0], self.sharing)
         self.nparams = self.spec.nparams()
-        critic, target = init_flat_params(obs_dims, hidden, act_dims, use_orthogonal_init)
-        assert critic.shape == (self.n_agents, self.nparams)
+        critic, target = init_flat_params(obs_dims, hidden, act_dims, use_orthogonal_init, self.sharing)
+        assert critic.shape == (self.spec.n_blocks, self.nparams)
         self.params = critic.to(self.device).contiguous()
         self.target_params = target.to(self.device).contiguous()
         self.gamma = float(get("gamma", 0.99))
@@ -177,11 +197,12 @@ class QNetwork:
     def _views(self, block, prefix):
         out = OrderedDict()
         S = self.spec
-        for i in range(self.n_agents):
+        group = "independent" if self.sharing is None else "networks"  # utils/models.py:146 / :204
+        for i in range(S.n_blocks):
             o = 0
             for name, shape in _tensor_layout(S.obs_dim, S.hidden, S.n_actions):
                 n = int(torch.tensor(shape).prod())
-                out[f"{prefix}.independent.{i}.{name}"] = block[i, o:o + n].view(shape)
+                out[f"{prefix}.{group}.{i}.{name}"] = block[i, o:o + n].view(shape)
                 o += n
         return out
 
@@ -204,7 +225,9 @@ class QNetwork:
 
     def __repr__(self):
         S = self.spec
-        return f"QNetwork[HIP](agents={S.n_agents}, mlp={S.obs_dim}-{S.hidden}-{S.hidden}-{S.n_actions}, params={self.nparams}/agent)"
+        share = "" if self.sharing is None else f", sharing={list(self.sharing)}"
+        return (f"QNetwork[HIP](agents={S.n_agents}, mlp={S.obs_dim}-{S.hidden}-{S.hidden}-{S.n_actions}, "
+                f"params={self.nparams}/network{share})")
 
 
 class VDNetwork(QNetwork):

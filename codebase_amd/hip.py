@@ -98,9 +98,21 @@ class NetSpec:
     obs_dim: int
     hidden: int
     n_actions: int
+    sharing: tuple = None  # agent -> network index (parameter sharing / SePS); None = independent networks
 
     def c(self):
-        return NetShape(self.n_agents, self.obs_dim, self.hidden, self.n_actions)
+        s = NetShape(self.n_agents, self.obs_dim, self.hidden, self.n_actions)
+        if self.sharing is not None:
+            if len(self.sharing) != self.n_agents or self.n_agents > 16:
+                raise ValueError("sharing indices: one per agent, at most 16 agents")
+            s.n_networks = max(self.sharing) + 1
+            for i, k in enumerate(self.sharing):
+                s.net_of[i] = int(k)
+        return s
+
+    @property
+    def n_blocks(self):
+        return self.n_agents if self.sharing is None else max(self.sharing) + 1
 
     def nparams(self):
         s = self.c()
@@ -314,7 +326,7 @@ class AcUpdater:
         self.spec = spec
         self.n_actor = spec.nparams()
         self.n_critic = check(lib.marlhip_ac_critic_nparams(ctypes.byref(s)), "ac_critic_nparams")
-        P = spec.n_agents
+        P = spec.n_blocks
         if block.numel() != P * (self.n_actor + self.n_critic) or target_critic.numel() != P * self.n_critic:
             raise ValueError("actor-critic parameter block has the wrong size for this shape")
         self.block, self.target_critic = block, target_critic

@@ -103,9 +103,14 @@ typedef struct marlhip_net_shape {
     int32_t obs_dim;  /* D */
     int32_t hidden;   /* H: two hidden layers of this width (algorithm.model.layers=[H,H]) */
     int32_t n_actions;/* A */
+    /* parameter sharing (MultiAgentSharedNetwork, marlbase/utils/models.py:176-300): n_networks = 0 means independent
+     * networks (one block per agent); otherwise agent i evaluates block net_of[i] (0 <= net_of[i] < n_networks), every
+     * `params` / `target` / `grad` argument is [n_networks][nparams] and a network's gradient is the sum over its agents. */
+    int32_t n_networks;
+    int32_t net_of[16];
 } marlhip_net_shape;
 
-int marlhip_net_nparams(const marlhip_net_shape* s); /* per agent; <0 if the shape has no kernel */
+int marlhip_net_nparams(const marlhip_net_shape* s); /* per network block; <0 if the shape has no kernel */
 
 /* QNetwork.act (marlbase/dqn/model.py:94-116), batched over N envs: Q = critic_i(obs_i);
  * ONE uniform per env decides random-vs-greedy for the whole joint action (model.py:105);

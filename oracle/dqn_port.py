@@ -76,9 +76,12 @@ def act(params, obs, epsilon, u, rand_actions, D, H, A):
     return torch.where(explore, rand_actions, greedy), q
 
 
-def compute_loss(params, tparams, batch, gamma, double_q, D, H, A, mode="idqn"):
+def compute_loss(params, tparams, batch, gamma, double_q, D, H, A, mode="idqn", sharing=None):
     """QNetwork._compute_loss (idqn) / VDNetwork._compute_loss (vdn); batch = dict with
-    obss [P,T+1,B,D], actions i64 [P,T,B], rewards [P,T,B], dones [T+1,B], filled [T,B]."""
+    obss [P,T+1,B,D], actions i64 [P,T,B], rewards [P,T,B], dones [T+1,B], filled [T,B].
+    sharing: agent -> network index (MultiAgentSharedNetwork, utils/models.py:176-300); params are then [K][n]."""
+    if sharing is not None:
+        params, tparams = params[list(sharing)], tparams[list(sharing)]
     obss, actions, rewards = batch["obss"], batch["actions"].unsqueeze(-1), batch["rewards"]
     dones, filled = batch["dones"], batch["filled"]
     P = obss.shape[0]
@@ -107,8 +110,9 @@ class Learner:
     parameters, torch.optim.Adam, hard / soft target update."""
 
     def __init__(self, params, D, H, A, lr=3e-4, gamma=0.99, grad_clip=1.0, double_q=True,
-                 target_update_interval_or_tau=200, mode="idqn"):
+                 target_update_interval_or_tau=200, mode="idqn", sharing=None):
         self.D, self.H, self.A = D, H, A
+        self.sharing = sharing
         P = params.shape[0]
         # one Parameter per tensor, in parameters() order, so clip/Adam see the reference's tensor list
         self.tensors = [torch.nn.Parameter(t.clone()) for p in range(P) for t in split(params[p], D, H, A)]
@@ -126,7 +130,8 @@ class Learner:
         return torch.stack([torch.cat([t.reshape(-1) for t in self.tensors[p * per:(p + 1) * per]]) for p in range(self.P)])
 
     def update(self, batch):
-        loss = compute_loss(self.flat(), self.target, batch, self.gamma, self.double_q, self.D, self.H, self.A, self.mode)
+        loss = compute_loss(self.flat(), self.target, batch, self.gamma, self.double_q, self.D, self.H, self.A, self.mode,
+                            self.sharing)
         self.opt.zero_grad()
         loss.backward()
         gnorm = None

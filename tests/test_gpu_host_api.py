@@ -98,8 +98,10 @@ def test_qnetwork_interface_state_dict_and_act():
     sd2 = {k: v + 1.0 for k, v in sd.items()}
     m.load_state_dict(sd2)
     assert torch.equal(m.state_dict()["target.independent.1.network.4.bias"], sd2["target.independent.1.network.4.bias"])
-    with pytest.raises(NotImplementedError):
-        QNetwork(obs_space, act_space, hyper, [64, 64], True, False, True, "cuda")
+    with pytest.raises(NotImplementedError):  # GRU path: a "next" row
+        QNetwork(obs_space, act_space, hyper, [64, 64], False, True, True, "cuda")
+    shared = QNetwork(obs_space, act_space, hyper, [64, 64], True, False, True, "cuda")  # parameter_sharing=True
+    assert shared.params.shape[0] == 1 and "critic.networks.0.network.0.weight" in shared.state_dict()
 
 
 def test_replay_adapter_follows_reference_trace():

@@ -163,3 +163,23 @@ def test_actor_critic_update_matches_reference(name):
         np.testing.assert_allclose(lr.actor().detach().numpy(), g[f"actor{i + 1}"], rtol=0, atol=2e-6)
         np.testing.assert_allclose(lr.critic().detach().numpy(), g[f"critic{i + 1}"], rtol=0, atol=2e-6)
         np.testing.assert_allclose(lr.target.numpy(), g[f"target{i + 1}"], rtol=0, atol=2e-6)
+
+
+@pytest.mark.parametrize("name,mode", [("learner_shared_H64.npz", "idqn"), ("learner_shared_seps_H64.npz", "vdn")])
+def test_parameter_sharing_matches_reference(name, mode):
+    """MultiAgentSharedNetwork (utils/models.py:176-300): agents mapped onto K shared networks, gradients tied"""
+    g = load(name)
+    D, H, A = int(g["D"]), 64, int(g["A"])
+    sharing = [int(i) for i in g["sharing"]]
+    params = torch.tensor(g["params0"]).requires_grad_(True)
+    loss = dp.compute_loss(params, torch.tensor(g["target0"]), batch_of(g, 0), 0.99, True, D, H, A, mode=mode, sharing=sharing)
+    loss.backward()
+    assert params.shape[0] == len(set(sharing))
+    assert abs(loss.item() - float(g["loss0"])) <= 1e-5 * abs(float(g["loss0"]))
+    np.testing.assert_allclose(params.grad.numpy(), g["grad0"], rtol=1e-4, atol=1e-5)
+    lr = dp.Learner(torch.tensor(g["params0"]), D, H, A, target_update_interval_or_tau=2, mode=mode, sharing=sharing)
+    lr.target = torch.tensor(g["target0"])
+    for i in range(3):
+        m = lr.update(batch_of(g, i))
+        assert abs(m["loss"] - float(g["losses"][i])) <= 2e-5 * abs(float(g["losses"][i]))
+        np.testing.assert_allclose(lr.flat().detach().numpy(), g[f"params{i + 1}"], rtol=0, atol=2e-6)
