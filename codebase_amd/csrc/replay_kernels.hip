@@ -121,6 +121,91 @@ __global__ __launch_bounds__(256) void replay_sample_obs_kernel(marlhip_replay_s
     }
 }
 
+// 16-byte variant: every episode record is a whole number of float4 and every output run starts 16-byte aligned
+// (E % 4 == 0, (B * D) % 4 == 0, (EB * D) % 4 == 0): 4x the bytes in flight per load/store instruction.
+// The same workgroup then transposes the episodes' small per-transition records (actions u8 -> i64, rewards, dones,
+// filled) through the LDS it just drained: coalesced record reads, EB-element runs on the output side.
+__global__ __launch_bounds__(256) void replay_sample_obs4_kernel(marlhip_replay_shape rs, marlhip_replay_buffers rb,
+                                                                 const int32_t* __restrict__ idx, int B, int EB,
+                                                                 float* __restrict__ obss, int64_t* __restrict__ actions,
+                                                                 float* __restrict__ rewards, float* __restrict__ dones,
+                                                                 float* __restrict__ filled) {
+    const float* __restrict__ robs = rb.obs;
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) float lds_ep[];
+    const int P = rs.n_agents, D = rs.obs_dim, T = rs.max_len;
+    const int E = P * (T + 1) * D, E4 = E >> 2;
+    const int b0 = blockIdx.x * EB;
+    const int nb = min(EB, B - b0);
+    __shared__ int s_idx[16];
+    if (threadIdx.x < nb) s_idx[threadIdx.x] = idx[b0 + threadIdx.x];
+    __syncthreads();
+    // small records ([e][PT act | PT rew | T+1 done | T filled], 2 PT + 2 T + 1 <= E values per episode): requested first,
+    // parked in registers until the observation block has left the LDS, so their latency hides under the obs phases
+    constexpr int SMAX = 12;  // register slots per thread; further values (large P*T) are loaded late
+    const int PT = P * T, REC = 2 * PT + 2 * T + 1;
+    auto small_load = [&](int i) -> float {
+        const int e = i / REC, k = i - e * REC;
+        const size_t ep = (size_t)s_idx[e];
+        if (k < PT) return (float)rb.act[ep * PT + k];
+        if (k < 2 * PT) return rb.rew[ep * PT + (k - PT)];
+        if (k < 2 * PT + T + 1) return rb.done[ep * (T + 1) + (k - 2 * PT)] ? 1.f : 0.f;
+        return rb.filled[ep * T + (k - 2 * PT - T - 1)] ? 1.f : 0.f;
+    };
+    float sm[SMAX];
+#pragma unroll
+    for (int c = 0; c < SMAX; ++c) {
+        const int i = threadIdx.x + 256 * c;
+        sm[c] = i < nb * REC ? small_load(i) : 0.f;
+    }
+    const int all4 = nb * E4;
+    f4* l4 = reinterpret_cast<f4*>(lds_ep);
+#pragma unroll 4
+    for (int i = threadIdx.x; i < all4; i += 256) {
+        const int e = i / E4, k = i - e * E4;
+        l4[i] = reinterpret_cast<const f4*>(robs + (size_t)s_idx[e] * E)[k];
+    }
+    __syncthreads();
+    const int run = nb * D;  // contiguous floats per (p,t) in the output
+    if ((run & 3) == 0) {
+        const int run4 = run >> 2, total4 = P * (T + 1) * run4;
+        for (int o = threadIdx.x; o < total4; o += 256) {
+            const int pt = o / run4, rem = (o - pt * run4) << 2;
+            f4 v;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int e = (rem + c) / D, d = (rem + c) - e * D;
+                v[c] = lds_ep[e * E + pt * D + d];
+            }
+            *reinterpret_cast<f4*>(obss + ((size_t)pt * B + b0) * D + rem) = v;
+        }
+    } else {  // ragged last workgroup
+        const int total = P * (T + 1) * run;
+        for (int o = threadIdx.x; o < total; o += 256) {
+            const int pt = o / run, rem = o - pt * run;
+            const int e = rem / D, d = rem - e * D;
+            obss[((size_t)pt * B + b0) * D + rem] = lds_ep[e * E + pt * D + d];
+        }
+    }
+    // ---- small records through the drained LDS
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < SMAX; ++c) {
+        const int i = threadIdx.x + 256 * c;
+        if (i < nb * REC) lds_ep[i] = sm[c];
+    }
+    for (int i = threadIdx.x + 256 * SMAX; i < nb * REC; i += 256) lds_ep[i] = small_load(i);
+    __syncthreads();
+    for (int o = threadIdx.x; o < nb * REC; o += 256) {
+        const int k = o / nb, e = o - k * nb;  // consecutive threads -> consecutive batch rows of one (field, p, t)
+        const float v = lds_ep[e * REC + k];
+        if (k < PT) actions[(size_t)k * B + b0 + e] = (int64_t)v;
+        else if (k < 2 * PT) rewards[(size_t)(k - PT) * B + b0 + e] = v;
+        else if (k < 2 * PT + T + 1) dones[(size_t)(k - 2 * PT) * B + b0 + e] = v;
+        else filled[(size_t)(k - 2 * PT - T - 1) * B + b0 + e] = v;
+    }
+}
+
 // the small per-transition arrays of the Batch (actions i64, rewards, dones, filled)
 __global__ __launch_bounds__(256) void replay_sample_small_kernel(marlhip_replay_shape rs, marlhip_replay_buffers rb,
                                                                   const int32_t* __restrict__ idx, int B,
@@ -203,10 +288,11 @@ extern "C" int marlhip_replay_sample(const marlhip_replay_shape* rs, const marlh
         idx = idx_out;
     }
     const int P = rs->n_agents, D = rs->obs_dim, T = rs->max_len;
-    // episodes per workgroup: as many as fit 48 KB of LDS (3 workgroups per CU), at most 16
+    // episodes per workgroup: as many as fit 52 KB of LDS (3 workgroups per CU), at most 16
     const int ep_bytes = P * (T + 1) * D * (int)sizeof(float);
-    int EB = (48 * 1024) / ep_bytes;
+    int EB = (52 * 1024) / ep_bytes;  // 3 x 52 KB <= 160 KB
     if (EB > 16) EB = 16;
+    if (EB >= 4) EB &= ~3;  // whole float4 runs in the output (16-byte stores)
     if (getenv("MARLHIP_SAMPLE_SIMPLE") != nullptr || EB < 1) {  // one-thread-per-element gather (reference variant)
         const int64_t total = (int64_t)P * (T + 1) * batch * D + (int64_t)P * T * batch + (int64_t)(2 * T + 1) * batch;
         timing_begin(TIMER_SAMPLE, (hipStream_t)stream);
@@ -216,9 +302,18 @@ extern "C" int marlhip_replay_sample(const marlhip_replay_shape* rs, const marlh
         MARL_CHECK_LAUNCH("replay_sample");
         return 0;
     }
+    const bool vec4 = ((P * (T + 1) * D) % 4 == 0) && (((int64_t)batch * D) % 4 == 0) && ((EB * D) % 4 == 0) &&
+                      getenv("MARLHIP_SAMPLE_SCALAR") == nullptr;
     timing_begin(TIMER_SAMPLE, (hipStream_t)stream);
-    hipLaunchKernelGGL(replay_sample_obs_kernel, dim3((batch + EB - 1) / EB), dim3(256), (size_t)EB * ep_bytes, (hipStream_t)stream,
-                       *rs, (const float*)rb->obs, idx, batch, EB, obss);
+    if (vec4) {  // one kernel: observations + the small records
+        hipLaunchKernelGGL(replay_sample_obs4_kernel, dim3((batch + EB - 1) / EB), dim3(256), (size_t)EB * ep_bytes,
+                           (hipStream_t)stream, *rs, *rb, idx, batch, EB, obss, actions, rewards, dones, filled);
+        timing_end(TIMER_SAMPLE, (hipStream_t)stream);
+        MARL_CHECK_LAUNCH("replay_sample_obs4");
+        return 0;
+    } else
+        hipLaunchKernelGGL(replay_sample_obs_kernel, dim3((batch + EB - 1) / EB), dim3(256), (size_t)EB * ep_bytes,
+                           (hipStream_t)stream, *rs, (const float*)rb->obs, idx, batch, EB, obss);
     timing_end(TIMER_SAMPLE, (hipStream_t)stream);
     MARL_CHECK_LAUNCH("replay_sample_obs");
     const int64_t small = (int64_t)P * T * batch + (int64_t)(2 * T + 1) * batch;
