@@ -152,16 +152,18 @@ struct AcBufs {
     float* ent;           // [T*B] filled * sum_p entropy
     float* ret;           // [P][T*B]  PPO: returns kept across epochs
     float* oldlogp;       // [P][T*B]  PPO: log-prob under the pre-update policy
+    float* partial;       // [blocks][4] per-block sums of (actor row, value row, entropy row, filled)
 };
 
 static __global__ __launch_bounds__(256) void ac_elem_kernel(AcArgs a, marlhip_batch bt, AcBufs w) {
     const int TB = a.T * a.B;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= TB) return;
+    const int i0 = blockIdx.x * 256 + threadIdx.x;
+    const bool inside = i0 < TB;
+    const int i = inside ? i0 : TB - 1;  // out-of-range threads shadow the last row and contribute nothing
     const int t = i / a.B, b = i - t * a.B;
     const size_t aas = bt.act_agent_stride ? (size_t)bt.act_agent_stride : (size_t)TB;
     const size_t ars = bt.act_row_stride ? (size_t)bt.act_row_stride : 1;
-    const float fl = bt.filled[i];
+    const float fl = inside ? bt.filled[i] : 0.f;
     float la = 0.f, lv = 0.f, es = 0.f;
     for (int p = 0; p < a.P; ++p) {
         const size_t pi = (size_t)p * TB + i;
@@ -177,7 +179,7 @@ static __global__ __launch_bounds__(256) void ac_elem_kernel(AcArgs a, marlhip_b
                 if (k == a.n_steps) ret += a.gk[k] * w.vnext[(size_t)p * (TB + a.B) + (size_t)tt * a.B + b] * nd;
                 else ret += a.gk[k] * bt.rewards[p * aas + ((size_t)tt * a.B + b) * ars] * nd;
             }
-            if (a.mode == 1) w.ret[pi] = ret;
+            if (a.mode == 1 && inside) w.ret[pi] = ret;
         }
         const float* l = w.logits + pi * a.A;
         float m = l[0];
@@ -190,7 +192,7 @@ static __global__ __launch_bounds__(256) void ac_elem_kernel(AcArgs a, marlhip_b
         float H = 0.f;
         for (int k = 0; k < a.A; ++k) H -= expf(l[k] - lse) * (l[k] - lse);
         if (a.mode == 1) {
-            w.oldlogp[pi] = logp;
+            if (inside) w.oldlogp[pi] = logp;
             continue;
         }
         const float val = w.v[pi], adv = ret - val;
@@ -203,33 +205,46 @@ static __global__ __launch_bounds__(256) void ac_elem_kernel(AcArgs a, marlhip_b
             const float rc = fminf(fmaxf(ratio, 1.f - a.ppo_clip), 1.f + a.ppo_clip);
             const float s1 = ratio * adv, s2 = rc * adv;
             la += -fminf(s1, s2) - a.ent_coef * H;
-            const bool inside = ratio >= 1.f - a.ppo_clip && ratio <= 1.f + a.ppo_clip;
-            const float share = s1 < s2 ? 1.f : (s1 == s2 ? (inside ? 1.f : 0.5f) : (0.f));
+            const bool in_clip = ratio >= 1.f - a.ppo_clip && ratio <= 1.f + a.ppo_clip;
+            const float share = s1 < s2 ? 1.f : (s1 == s2 ? (in_clip ? 1.f : 0.5f) : (0.f));
             coef = -adv * ratio * share;
         }
-        for (int k = 0; k < a.A; ++k) {
-            const float lp = l[k] - lse, pk = expf(lp);
-            w.dlogits[pi * a.A + k] = fl * (coef * ((k == act ? 1.f : 0.f) - pk) + a.ent_coef * pk * (lp + H));
+        if (inside) {
+            for (int k = 0; k < a.A; ++k) {
+                const float lp = l[k] - lse, pk = expf(lp);
+                w.dlogits[pi * a.A + k] = fl * (coef * ((k == act ? 1.f : 0.f) - pk) + a.ent_coef * pk * (lp + H));
+            }
+            w.dv[pi] = fl * (-2.f * a.vlc * (ret - val));
         }
-        w.dv[pi] = fl * (-2.f * a.vlc * (ret - val));
         lv += (ret - val) * (ret - val);
         es += H;
     }
-    if (a.mode != 1) {
+    if (a.mode == 1) return;
+    if (inside) {
         w.lrow_a[i] = fl * la;
         w.lrow_v[i] = fl * lv;
         w.ent[i] = fl * es;
     }
+    // per-block sums for the metrics (fixed order: wave butterfly, then waves 0..3)
+    __shared__ float sh[4][4];
+    float s4[4] = {fl * la, fl * lv, fl * es, fl};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) s4[k] += __shfl_xor(s4[k], off);
+        if ((threadIdx.x & 63) == 0) sh[k][threadIdx.x >> 6] = s4[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) w.partial[blockIdx.x * 4 + threadIdx.x] = (sh[threadIdx.x][0] + sh[threadIdx.x][1]) + (sh[threadIdx.x][2] + sh[threadIdx.x][3]);
 }
 
 // metrics[0..4] = loss, actor_loss, value_loss, entropy, sum(filled)  (fixed-order tree: reproducible)
-static __global__ __launch_bounds__(1024) void ac_metrics_kernel(int TB, float vlc, const float* __restrict__ lrow_a,
-                                                                 const float* __restrict__ lrow_v, const float* __restrict__ ent,
-                                                                 const float* __restrict__ filled, float* __restrict__ metrics) {
+static __global__ __launch_bounds__(1024) void ac_metrics_kernel(int nblocks, float vlc, const float* __restrict__ partial,
+                                                                 float* __restrict__ metrics) {
     __shared__ float sh[4][16];
     float s[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int i = threadIdx.x; i < TB; i += 1024) {
-        s[0] += lrow_a[i]; s[1] += lrow_v[i]; s[2] += ent[i]; s[3] += filled[i];
+    for (int i = threadIdx.x; i < nblocks; i += 1024) {
+        s[0] += partial[4 * i]; s[1] += partial[4 * i + 1]; s[2] += partial[4 * i + 2]; s[3] += partial[4 * i + 3];
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -256,7 +271,7 @@ static __global__ __launch_bounds__(1024) void ac_metrics_kernel(int TB, float v
 
 // workspace: [vnext | v | logits | dlogits | dv | lrow_a | lrow_v | ent | ret | oldlogp | loss scratch 4][backward workspace]
 struct AcWs {
-    int64_t vnext, v, logits, dlogits, dv, lrow_a, lrow_v, ent, ret, oldlogp, scratch, bwd, total;
+    int64_t vnext, v, logits, dlogits, dv, lrow_a, lrow_v, ent, ret, oldlogp, partial, scratch, bwd, total;
 };
 
 template <class SA, class SC>
@@ -275,6 +290,7 @@ AcWs ac_ws_layout(int P, int T, int B) {
     w.ent = take(TB);
     w.ret = take(P * TB);
     w.oldlogp = take(P * TB);
+    w.partial = take(4 * ((TB + 255) / 256));
     w.scratch = take(8);
     w.bwd = o;
     const int64_t ba = backward_ws_bytes<SA>(P, T, B), bc = backward_ws_bytes<SC>(P, T, B);
@@ -295,6 +311,7 @@ int ac_step(int P, const AgentMap& am, const float* actor, const float* critic, 
     AcBufs w;
     w.logits = f(wl.logits); w.v = f(wl.v); w.vnext = f(wl.vnext); w.dlogits = f(wl.dlogits); w.dv = f(wl.dv);
     w.lrow_a = f(wl.lrow_a); w.lrow_v = f(wl.lrow_v); w.ent = f(wl.ent); w.ret = f(wl.ret); w.oldlogp = f(wl.oldlogp);
+    w.partial = f(wl.partial);
     AcArgs a;
     a.P = P; a.T = T; a.B = B; a.A = A; a.n_steps = c->n_steps; a.mode = mode;
     for (int k = 0; k <= c->n_steps; ++k) a.gk[k] = (float)pow(c->gamma, (double)k);
@@ -322,8 +339,8 @@ int ac_step(int P, const AgentMap& am, const float* actor, const float* critic, 
     if (rc != 0) return rc;
     rc = launch_backward_rows<SC>(P, am, critic, bt, w.dv, w.lrow_v, base + wl.bwd, ws_bytes - wl.bwd, critic_grad, scratch + 2, st);
     if (rc != 0) return rc;
-    hipLaunchKernelGGL(ac_metrics_kernel, dim3(1), dim3(1024), 0, st, TB, c->value_loss_coef, (const float*)w.lrow_a,
-                       (const float*)w.lrow_v, (const float*)w.ent, bt->filled, metrics);
+    hipLaunchKernelGGL(ac_metrics_kernel, dim3(1), dim3(1024), 0, st, (TB + 255) / 256, c->value_loss_coef, (const float*)w.partial,
+                       metrics);
     timing_end(TIMER_LOSSGRAD, st);
     MARL_CHECK_LAUNCH("ac_metrics_kernel");
     return 0;
