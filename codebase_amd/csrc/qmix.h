@@ -268,25 +268,28 @@ __global__ __launch_bounds__(256, 1) void qmix_mix_kernel(const float* __restric
         float q[P];
 #pragma unroll
         for (int p = 0; p < P; ++p) q[p] = (ONLINE ? io.chosen : io.tqsel)[(size_t)p * R + rc];
-        // w1 pre-abs = hyper_w_1.2 h1 + c1 ; z += q_p |w1_p|
-        f4 w1[W1T];
+        // w1 pre-abs = hyper_w_1.2 h1 + c1 ; z += q_p |w1_p|, agent by agent (the target instance keeps no w1 tiles)
+        f4 w1[ONLINE ? W1T : 4];
 #pragma unroll
-        for (int mt2 = 0; mt2 < W1T; ++mt2) {
-            f4 acc = *reinterpret_cast<const f4*>(lds + Q::mc1 + 16 * mt2 + 4 * g);
+        for (int p = 0; p < P; ++p) {
 #pragma unroll
-            for (int k1 = 0; k1 < 2; ++k1) {
-                const f4 a = P1[(mt2 * 2 + k1) * 64 + lane];
+            for (int et = 0; et < 4; ++et) {
+                const int mt2 = 4 * p + et;
+                f4 acc = *reinterpret_cast<const f4*>(lds + Q::mc1 + 16 * mt2 + 4 * g);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc = MARL_MFMA(a[r], h1[k1][r], acc);
+                for (int k1 = 0; k1 < 2; ++k1) {
+                    const f4 a = P1[(mt2 * 2 + k1) * 64 + lane];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc = MARL_MFMA(a[r], h1[k1][r], acc);
+                }
+                w1[ONLINE ? mt2 : et] = acc;
             }
-            w1[mt2] = acc;
-        }
-#pragma unroll
-        for (int p = 0; p < P; ++p)
 #pragma unroll
             for (int et = 0; et < 4; ++et)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) z[et][r] = fmaf(q[p], fabsf(w1[4 * p + et][r]), z[et][r]);
+                for (int r = 0; r < 4; ++r) z[et][r] = fmaf(q[p], fabsf(w1[ONLINE ? 4 * p + et : et][r]), z[et][r]);
+            if (!ONLINE) __builtin_amdgcn_sched_barrier(0);  // keep the agents' tile groups from being interleaved (register pressure)
+        }
         f4 ez[4], hid[4], wfp[4];
 #pragma unroll
         for (int et = 0; et < 4; ++et)
@@ -320,10 +323,9 @@ __global__ __launch_bounds__(256, 1) void qmix_mix_kernel(const float* __restric
         yp += __shfl_xor(yp, 16);
         yp += __shfl_xor(yp, 32);
         const float y = yp + lds[Q::mcv];
-        if (!ONLINE) {
+        if constexpr (!ONLINE) {
             if (g == 0 && ok) io.ytgt[row] = y;
-            continue;
-        }
+        } else {
         // ---- TD error and backward (model.py:419-427)
         const float fl = ok ? io.fl[rc] : 0.f;
         const float delta = y - (io.r0[rc] + gamma * io.ytgt[rc] * (1.f - io.dn[rc]));
@@ -387,6 +389,7 @@ __global__ __launch_bounds__(256, 1) void qmix_mix_kernel(const float* __restric
         qmix_store_tiles<4>(g1, dh, g, j);
         qmix_store_tiles<4>(g1 + 64 * 16, dz, g, j);
         qmix_store_tiles<4>(g1 + 128 * 16, dhv, g, j);
+        }
     }
 }
 
@@ -417,13 +420,13 @@ __global__ __launch_bounds__(512, 1) void qmix_wgrad_kernel(QmixRows<Q, REPLAY> 
         accB1[m][0] = accBf;
         accB1[m][1] = accBf;
     }
-    size_t soff[NPW];  // state column of this lane in each owned N tile
+    unsigned soff[NPW];  // state column of this lane in each owned N tile (element offset inside a state row group)
     bool sval[NPW];
 #pragma unroll
     for (int n = 0; n < NPW; ++n) {
         const int k = 16 * (ng + n * NG) + j;
         sval[n] = (ng + n * NG) < NTS && k < SD;
-        soff[n] = qmix_state_off<Q>(k < SD ? k : SD - 1, ps);
+        soff[n] = (unsigned)qmix_state_off<Q>(k < SD ? k : SD - 1, ps);
     }
     const int nblk = (R + 15) / 16;
     const int per = (nblk + gridDim.x - 1) / gridDim.x;
