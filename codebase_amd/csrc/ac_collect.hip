@@ -57,15 +57,25 @@ __global__ __launch_bounds__(ACOL_BLOCK) void ac_collect_kernel(LbfParams q, con
                                                                 int32_t* __restrict__ t_max) {
     constexpr int D = 3 * (P + F), A = 6;
     using S = MlpShape<D, H, A>;
-    constexpr bool RESIDENT = (size_t)P * S::NFWD * sizeof(float) <= 150u * 1024u;
+    using PP = PackPlan<S, P>;
+    constexpr bool RESIDENT = PP::RESIDENT || PP::A3REG;  // no per-step staging
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, j = lane & 15;
     const int n = (blockIdx.x * 4 + wave) * 16 + j;
     const int N = q.n_envs;
     const bool valid = n < N;
     const uint32_t env_id = (uint32_t)(valid ? n : N - 1);
+    f4 a3[PP::A3REG ? P : 1][S::MT];  // output-layer operands, when the full packs do not fit the LDS
     if (RESIDENT) {
-        for (int p = 0; p < P; ++p) stage_packed<S>(actor + (size_t)p * S::NFWD, lds + (size_t)p * S::NFWD, tid, ACOL_BLOCK);
+        for (int p = 0; p < P; ++p)
+            stage_packed_prefix<S>(actor + (size_t)p * S::NFWD, lds + (size_t)p * PP::STRIDE, PP::STRIDE, tid, ACOL_BLOCK);
+        if (PP::A3REG) {
+#pragma unroll
+            for (int p = 0; p < P; ++p)
+#pragma unroll
+                for (int mt = 0; mt < S::MT; ++mt)
+                    a3[p][mt] = reinterpret_cast<const f4*>(actor + (size_t)p * S::NFWD + S::pA3)[mt * 64 + lane];
+        }
         __syncthreads();
     }
     LbfState<P, F> s;
@@ -102,7 +112,7 @@ __global__ __launch_bounds__(ACOL_BLOCK) void ac_collect_kernel(LbfParams q, con
             for (int p = 0; p < P; ++p) {
                 const float* pack;
                 if (RESIDENT) {
-                    pack = lds + (size_t)p * S::NFWD;
+                    pack = lds + (size_t)p * PP::STRIDE;
                 } else {
                     __syncthreads();
                     stage_packed<S>(actor + (size_t)p * S::NFWD, lds, tid, ACOL_BLOCK);
@@ -110,7 +120,7 @@ __global__ __launch_bounds__(ACOL_BLOCK) void ac_collect_kernel(LbfParams q, con
                     pack = lds;
                 }
                 f4 h1[S::MT], h2[S::MT], logits, unused;
-                mlp_forward_p<S, false>(pack, pack, lane, x[p], h1, h2, logits, unused);
+                mlp_forward_p<S, false>(pack, pack, lane, x[p], h1, h2, logits, unused, PP::A3REG ? a3[PP::A3REG ? p : 0] : nullptr);
                 const float u = u01_f32(act_noise_word(q.seed, env_id, 2u * round, (uint32_t)t, 1 + p));
                 act[p] = sample_rows<A>(logits, lane, u);
             }
@@ -189,8 +199,7 @@ int launch_ac_collect(const LbfParams& q, const AgentMap& am, const float* actor
                       hipStream_t st) {
     constexpr int D = 3 * (P + F);
     using S = MlpShape<D, H, 6>;
-    constexpr bool RESIDENT = (size_t)P * S::NFWD * sizeof(float) <= 150u * 1024u;
-    const size_t lds_bytes = (RESIDENT ? (size_t)P : 1) * S::NFWD * sizeof(float);
+    const size_t lds_bytes = PackPlan<S, P>::LDS_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ac_collect_kernel<P, F, H>),

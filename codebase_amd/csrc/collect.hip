@@ -73,7 +73,8 @@ __global__ __launch_bounds__(COL_BLOCK) void idqn_collect_kernel(LbfParams q, co
                                                                  float* __restrict__ fin_return, int32_t* __restrict__ fin_length) {
     constexpr int D = 3 * (P + F), A = 6;
     using S = MlpShape<D, H, A>;
-    constexpr bool RESIDENT = (size_t)P * S::NFWD * sizeof(float) <= 150u * 1024u;
+    using PP = PackPlan<S, P>;
+    constexpr bool RESIDENT = PP::RESIDENT || PP::A3REG;  // no per-step staging
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, j = lane & 15;
     const int n = (blockIdx.x * 4 + wave) * 16 + j;
@@ -81,8 +82,17 @@ __global__ __launch_bounds__(COL_BLOCK) void idqn_collect_kernel(LbfParams q, co
     const bool valid = n < N;
     const uint32_t env_id = (uint32_t)(valid ? n : N - 1);
 
+    f4 a3[PP::A3REG ? P : 1][S::MT];  // output-layer operands of every agent, when the full packs do not fit the LDS
     if (RESIDENT) {
-        for (int p = 0; p < P; ++p) stage_packed<S>(packs + (size_t)p * S::NFWD, lds + (size_t)p * S::NFWD, tid, COL_BLOCK);
+        for (int p = 0; p < P; ++p)
+            stage_packed_prefix<S>(packs + (size_t)p * S::NFWD, lds + (size_t)p * PP::STRIDE, PP::STRIDE, tid, COL_BLOCK);
+        if (PP::A3REG) {
+#pragma unroll
+            for (int p = 0; p < P; ++p)
+#pragma unroll
+                for (int mt = 0; mt < S::MT; ++mt)
+                    a3[p][mt] = reinterpret_cast<const f4*>(packs + (size_t)p * S::NFWD + S::pA3)[mt * 64 + lane];
+        }
         __syncthreads();
     }
 
@@ -132,7 +142,7 @@ __global__ __launch_bounds__(COL_BLOCK) void idqn_collect_kernel(LbfParams q, co
         for (int p = 0; p < P; ++p) {
             const float* pack;
             if (RESIDENT) {
-                pack = lds + (size_t)p * S::NFWD;
+                pack = lds + (size_t)p * PP::STRIDE;
             } else {
                 __syncthreads();
                 stage_packed<S>(packs + (size_t)p * S::NFWD, lds, tid, COL_BLOCK);
@@ -140,7 +150,7 @@ __global__ __launch_bounds__(COL_BLOCK) void idqn_collect_kernel(LbfParams q, co
                 pack = lds;
             }
             f4 h1[S::MT], h2[S::MT], qv, unused;
-            mlp_forward_p<S, false>(pack, pack, lane, x[p], h1, h2, qv, unused);
+            mlp_forward_p<S, false>(pack, pack, lane, x[p], h1, h2, qv, unused, PP::A3REG ? a3[PP::A3REG ? p : 0] : nullptr);
             const int greedy = argmax_rows<A>(qv, lane);
             act[p] = explore ? rnd[p] : greedy;
         }
@@ -200,8 +210,7 @@ int launch_collect(const LbfParams& q, const AgentMap& am, const float* params, 
                    float* fin_return, int32_t* fin_length, hipStream_t st) {
     constexpr int D = 3 * (P + F);
     using S = MlpShape<D, H, 6>;
-    constexpr bool RESIDENT = (size_t)P * S::NFWD * sizeof(float) <= 150u * 1024u;
-    const size_t lds_bytes = (RESIDENT ? (size_t)P : 1) * S::NFWD * sizeof(float);
+    const size_t lds_bytes = PackPlan<S, P>::LDS_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&idqn_collect_kernel<P, F, H>),

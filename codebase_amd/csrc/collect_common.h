@@ -47,6 +47,23 @@ __device__ __forceinline__ void stage_packed(const float* __restrict__ pack, flo
     for (int i = tid; i < S::NFWD / 4; i += nthreads) dst[i] = src[i];
 }
 
+// how a collector keeps P forward packs on chip
+template <class S, int P>
+struct PackPlan {
+    static constexpr size_t LDS_CAP = 150u * 1024u;
+    static constexpr bool RESIDENT = (size_t)P * S::NFWD * sizeof(float) <= LDS_CAP;                 // whole packs in LDS
+    static constexpr bool A3REG = !RESIDENT && (size_t)P * S::NFWD_NOA3 * sizeof(float) <= LDS_CAP;   // output layer in registers
+    static constexpr int STRIDE = RESIDENT ? S::NFWD : S::NFWD_NOA3;                                   // floats per resident agent
+    static constexpr size_t LDS_BYTES = ((RESIDENT || A3REG) ? (size_t)P * STRIDE : (size_t)S::NFWD) * sizeof(float);
+};
+
+template <class S>
+__device__ __forceinline__ void stage_packed_prefix(const float* __restrict__ pack, float* lds, int nfloat, int tid, int nthreads) {
+    const f4* src = reinterpret_cast<const f4*>(pack);
+    f4* dst = reinterpret_cast<f4*>(lds);
+    for (int i = tid; i < nfloat / 4; i += nthreads) dst[i] = src[i];
+}
+
 template <class S>
 int launch_fwd_pack(int P, const AgentMap& am, const float* params, float** packs_out, hipStream_t st) {
     float* packs = collect_pack_scratch((size_t)P * S::NFWD * sizeof(float), st);

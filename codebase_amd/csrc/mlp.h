@@ -38,9 +38,10 @@ struct MlpShape {
     // canonical offsets
     static constexpr int oW1 = 0, ob1 = H_ * D_, oW2 = ob1 + H_, ob2 = oW2 + H_ * H_, oW3 = ob2 + H_, ob3 = oW3 + A_ * H_;
     static constexpr int NPARAM = ob3 + A_;
-    // forward pack (floats): A1[MT][KS1/4][64][4] A2[MT][MT][64][4] A3[MT][64][4] b1[H] b2[H] b3[16]
-    static constexpr int pA1 = 0, pA2 = pA1 + MT * KS1 * 64, pA3 = pA2 + MT * MT * 256, pb1 = pA3 + MT * 256, pb2 = pb1 + H_, pb3 = pb2 + H_;
-    static constexpr int NFWD = pb3 + 16;
+    // forward pack (floats): A1[MT][KS1/4][64][4] A2[MT][MT][64][4] b1[H] b2[H] b3[16] A3[MT][64][4]
+    // (A3 last: the prefix of NFWD_NOA3 floats is a complete pack for callers that keep the output layer in registers)
+    static constexpr int pA1 = 0, pA2 = pA1 + MT * KS1 * 64, pb1 = pA2 + MT * MT * 256, pb2 = pb1 + H_, pb3 = pb2 + H_, pA3 = pb3 + 16;
+    static constexpr int NFWD = pA3 + MT * 256, NFWD_NOA3 = pA3;
     // backward-data pack: T3[MT][64][4] = W3^T tiles (M=h2, K=a), T2[MT][MT][64][4] = W2^T tiles (M=h1, K=h2)
     static constexpr int pT3 = 0, pT2 = pT3 + MT * 256;
     static constexpr int NBWD = pT2 + MT * MT * 256;
@@ -54,23 +55,23 @@ __device__ __forceinline__ float mlp_fwd_pack_elem(const float* __restrict__ w, 
         const int ks4 = rest % (S::KS1 / 4), mt = rest / (S::KS1 / 4);
         const int o = 16 * mt + (lane & 15), k = 4 * (4 * ks4 + e) + (lane >> 4);
         return k < S::D ? w[S::oW1 + o * S::D + k] : 0.f;
-    } else if (idx < S::pA3) {  // A2[mt2][mt1][lane][r]: W2[16mt2+i][16mt1+4g+r]
+    } else if (idx < S::pb1) {  // A2[mt2][mt1][lane][r]: W2[16mt2+i][16mt1+4g+r]
         const int j = idx - S::pA2;
         const int r = j & 3, lane = (j >> 2) & 63, rest = j >> 8;
         const int mt1 = rest % S::MT, mt2 = rest / S::MT;
         return w[S::oW2 + (16 * mt2 + (lane & 15)) * S::H + 16 * mt1 + 4 * (lane >> 4) + r];
-    } else if (idx < S::pb1) {  // A3[mt1][lane][r]: W3[i][16mt1+4g+r]
-        const int j = idx - S::pA3;
-        const int r = j & 3, lane = (j >> 2) & 63, mt1 = j >> 8;
-        const int o = lane & 15;
-        return o < S::A ? w[S::oW3 + o * S::H + 16 * mt1 + 4 * (lane >> 4) + r] : 0.f;
     } else if (idx < S::pb2) {
         return w[S::ob1 + idx - S::pb1];
     } else if (idx < S::pb3) {
         return w[S::ob2 + idx - S::pb2];
-    } else {
+    } else if (idx < S::pA3) {
         const int o = idx - S::pb3;
         return o < S::A ? w[S::ob3 + o] : 0.f;
+    } else {  // A3[mt1][lane][r]: W3[i][16mt1+4g+r]
+        const int j = idx - S::pA3;
+        const int r = j & 3, lane = (j >> 2) & 63, mt1 = j >> 8;
+        const int o = lane & 15;
+        return o < S::A ? w[S::oW3 + o * S::H + 16 * mt1 + 4 * (lane >> 4) + r] : 0.f;
     }
 }
 
@@ -254,9 +255,11 @@ __device__ __forceinline__ void mlp_forward2(const float* ldsA, const float* lds
 // stalling the matrix pipe in front of every group (hipcc places the reads right before their use).
 // Steps: layer 1 (KS1/4 steps), layer 2 (MT steps), layer 3 (1 step).  Per-output summation order
 // is unchanged (bitwise identical to mlp_forward).
+// a3r != nullptr (single network only): the layer-3 operands come from those MT registers instead of the pack's A3 block,
+// so the pack in LDS can be the NFWD_NOA3 prefix.
 template <class S, bool DUAL>
 __device__ __forceinline__ void mlp_forward_p(const float* ldsA, const float* ldsB, int lane, const float (&x)[S::KS1],
-                                              f4 (&h1)[S::MT], f4 (&h2)[S::MT], f4& qA, f4& qB) {
+                                              f4 (&h1)[S::MT], f4 (&h2)[S::MT], f4& qA, f4& qB, const f4* a3r = nullptr) {
     constexpr int MT = S::MT, N1 = S::KS1 / 4;
     const int g = lane >> 4;
     const f4* A1 = reinterpret_cast<const f4*>(ldsA + S::pA1);
@@ -323,7 +326,7 @@ __device__ __forceinline__ void mlp_forward_p(const float* ldsA, const float* ld
                 opa[nxt][mt] = A2[(mt * MT + k1 + 1) * 64 + lane];
                 if (DUAL) opb[nxt][mt] = B2[(mt * MT + k1 + 1) * 64 + lane];
             } else {  // layer-3 operands (MT tiles of K) + bias
-                opa[nxt][mt] = A3[mt * 64 + lane];
+                opa[nxt][mt] = a3r != nullptr ? a3r[mt] : A3[mt * 64 + lane];
                 if (DUAL) opb[nxt][mt] = B3[mt * 64 + lane];
             }
         }
