@@ -735,6 +735,9 @@ inline WsLayout ws_layout(int P, int nwg, int rec, int pack, int T, int B) {
     return w;
 }
 
+#ifndef MARL_TP_NBF
+#define MARL_TP_NBF 2  // row blocks per step of the forward pass
+#endif
 // hidden 128: tensor-parallel passes (dqn_update_tp.h) - pass F, mixer, pass B, reduce
 inline UpdPlan upd_plan_tp(int P, int T, int B, int NB) {  // one workgroup per CU, tasks = (block set, time chunk)
     const int nsets = (B + 16 * NB - 1) / (16 * NB);
@@ -774,10 +777,10 @@ template <class S, bool REPLAY>
 int launch_lossgrad_tp(const marlhip_net_shape* s, const float* params, const float* tparams, const marlhip_batch* bt,
                        const ReplaySrc& src, float gamma, int double_q, int mode, void* ws, int64_t ws_bytes, float* grad,
                        float* loss, hipStream_t st, const QmixCtx* qx) {
-    constexpr int W = 4, TPW = S::H / 64, NB = 2, NT = W * TPW, REC = S::NPARAM + 2;
+    constexpr int W = 4, TPW = S::H / 64, NB = 2, NBF = MARL_TP_NBF, NT = W * TPW, REC = S::NPARAM + 2;
     const int P = s->n_agents, T = bt->max_len, B = bt->batch;
     const AgentMap am = agent_map(s);
-    const UpdPlan pl = upd_plan_tp(P, T, B, NB);
+    const UpdPlan pl = upd_plan_tp(P, T, B, NB), plF = upd_plan_tp(P, T, B, NBF);
     const WsLayout wl = ws_layout(P, pl.nwg, REC, 0, T, B);
     MARL_REQUIRE(ws_bytes >= wl.total, "dqn_loss_grad: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)wl.total);
     float* mixf = reinterpret_cast<float*>(static_cast<char*>(ws) + wl.mix_off);
@@ -785,11 +788,11 @@ int launch_lossgrad_tp(const marlhip_net_shape* s, const float* params, const fl
     TpMix mix;
     mix.chosen = mixf; mix.tqsel = mixf + P * tb; mix.rew = mixf + 2 * P * tb; mix.dq = mixf + 3 * P * tb;
     mix.dn = mixf + 4 * P * tb; mix.fl = mix.dn + tb; mix.lrow = mix.fl + tb;
-    const size_t ldsF = (size_t)(2 * NB * NT + 2 * NB * W) * 256 * sizeof(float);
+    const size_t ldsF = (size_t)(2 * NBF * NT + 2 * NBF * W) * 256 * sizeof(float);
     const size_t ldsB = (size_t)(NB * NT * 256 + NB * S::H * 16 + NB * NT * 256 + W * 256 * (1 + 3 * TPW)) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tp_fwd_kernel<S, W, TPW, REPLAY, NB>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tp_fwd_kernel<S, W, TPW, REPLAY, NBF>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsF);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tp_bwd_kernel<S, W, TPW, REPLAY, NB>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsB);
@@ -797,8 +800,8 @@ int launch_lossgrad_tp(const marlhip_net_shape* s, const float* params, const fl
     }
     const dim3 grid(pl.nwg, P), block(64 * W);
     timing_begin(TIMER_LOSSGRAD, st);
-    hipLaunchKernelGGL((tp_fwd_kernel<S, W, TPW, REPLAY, NB>), grid, block, ldsF, st, params, tparams, am, *bt, src, mix, double_q,
-                       pl.n_chunks);
+    hipLaunchKernelGGL((tp_fwd_kernel<S, W, TPW, REPLAY, NBF>), dim3(plF.nwg, P), block, ldsF, st, params, tparams, am, *bt, src, mix,
+                       double_q, plF.n_chunks);
     if (mode == 2) {
         QmixIo io = {mix.chosen, mix.tqsel, mix.rew, mix.dn, mix.fl, mix.dq, mix.lrow, nullptr};
         const int rc = qmix_dispatch_mix<S::D, REPLAY>(P, *qx, bt, src, io, gamma, st);
