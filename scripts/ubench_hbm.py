@@ -1,5 +1,5 @@
 """HBM-bound kernels at sizes that leave the caches (SURVEY.md 8d "scaled run"): batched env step at
-2^20 envs, replay sample-gather of 65,536 episodes from a 2^20-episode (3.6 GB) replay, replay add.
+2^20 envs, replay sample-gather of 65,536 episodes from a 1.25 x 2^20-episode (4.5 GB) replay, replay add.
 Prints one JSON object: achieved GB/s = algorithmic bytes / measured time, against 8 TB/s."""
 import json
 import os
@@ -40,7 +40,7 @@ per = 2 * env.stride + 4 * P + 4 * P * D + 4 * P + 2
 out["lbf_step_kernel"] = dict(n_envs=N, bytes_per_env_step=per, us=dt * 1e6, env_steps_per_s=N / dt,
                               achieved_GBs=per * N / dt / 1e9, frac_of_8TBs=per * N / dt / 1e9 / PEAK)
 
-T, CAP, B = 25, 1 << 20, 65536
+T, CAP, B = 25, 1310720, 65536  # 1.25 x 2^20 episodes = 4.5 GB of replay (>= 4 GB)
 rb = h.DeviceReplay(CAP, P, D, T)
 rb.obs.uniform_(-1, 7)
 idx = torch.randint(0, CAP, (B,), dtype=torch.int32, device="cuda")
