@@ -14,7 +14,8 @@
 //                     hidden = elu(z), wf = |hyper_w_final.2 hf + c|, y = hidden.wf + V.2 hv + c.  The online
 //                     instance continues with the TD error and the backward down to the first-layer
 //                     pre-activations; it writes dq_p and the operands of the weight-gradient GEMMs.
-//   qmix_wgrad_kernel split-K (over rows) weight-gradient GEMMs; 8 waves own disjoint accumulator tiles, no LDS.
+//   qmix_wgrad1/2_kernel split-K (over rows) weight-gradient GEMMs; 8 waves own disjoint accumulator tiles, no LDS,
+//                     next block's operands prefetched.
 //   qmix_reduce_kernel sums the per-workgroup records in fixed order and applies 1/sum(filled).
 // hypernet_layers == 2, embed_dim 64, hypernet_embed 32 (configs/algorithm/qmix.yaml:14-17) are compiled in.
 // d|x|/dx at exactly 0 is taken as -1 (torch: 0): a pre-activation that is exactly 0.0f does not occur with
@@ -394,31 +395,28 @@ __global__ __launch_bounds__(256, 1) void qmix_mix_kernel(const float* __restric
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// weight gradients: dW1cat[192][SD] = G1^T S, dB1[E*P][32] = DW1^T h1, dBf[64][32] = DWF^T hf, bias gradients = column
-// sums, dV.2 = sum_rows dy hv.  Workgroup = 8 waves over a contiguous range of row blocks; every wave accumulates its
-// own tiles in registers (K order inside a block: row 4g+e at k-step e, the same on both operands).
+// weight gradients: dW1cat[192][SD] = G1^T S (kernel 1), dB1[E*P][32] = DW1^T h1, dBf[64][32] = DWF^T hf, dV.2 =
+// sum_rows dy hv (kernel 2); bias gradients = column sums of the same A operands.  Workgroup = 8 waves over a
+// contiguous range of row blocks; every wave accumulates its own tiles in registers (K order inside a block: row
+// 4g+e at k-step e, the same on both operands).  No LDS: operands come straight from L2 / HBM and the NEXT block's
+// operands are requested before the current block's MFMAs (the loop is latency-bound otherwise: 24-150 MFMAs per wave
+// and block).  Both kernels write disjoint entries of the same per-workgroup record.
 // ---------------------------------------------------------------------------------------------------------
 template <class Q, bool REPLAY>
-__global__ __launch_bounds__(512, 1) void qmix_wgrad_kernel(QmixRows<Q, REPLAY> src, const float* __restrict__ Y1, QmixBwd bw, int R,
-                                                            float* __restrict__ partials) {
-    constexpr int P = Q::P, SD = Q::SD, NTS = Q::KS4, W1T = Q::W1T, NF1 = Q::NF1;
-    constexpr int MG = NTS >= 4 ? 2 : 4, NG = 8 / MG, MPW = Q::MT1 / MG, NPW = (NTS + NG - 1) / NG, M2W = (W1T + 7) / 8;
+__global__ __launch_bounds__(512, 1) void qmix_wgrad1_kernel(QmixRows<Q, REPLAY> src, QmixBwd bw, int R, float* __restrict__ partials) {
+    constexpr int SD = Q::SD, NTS = Q::KS4, NF1 = Q::NF1;
+    constexpr int MG = NTS >= 4 ? 2 : 4, NG = 8 / MG, MPW = Q::MT1 / MG, NPW = (NTS + NG - 1) / NG;
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, g = lane >> 4, j = lane & 15;
     const int mg = w % MG, ng = w / MG;
     const size_t ps = src.pstride();
-    f4 accW[MPW][NPW], accB1[M2W][2], accBf = {0.f, 0.f, 0.f, 0.f}, dbv = {0.f, 0.f, 0.f, 0.f};
-    float cs1[MPW], csc1[M2W], cscf = 0.f, dcv = 0.f;
+    const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f4 accW[MPW][NPW];
+    float cs1[MPW];
 #pragma unroll
     for (int m = 0; m < MPW; ++m) {
         cs1[m] = 0.f;
 #pragma unroll
-        for (int n = 0; n < NPW; ++n) accW[m][n] = accBf;
-    }
-#pragma unroll
-    for (int m = 0; m < M2W; ++m) {
-        csc1[m] = 0.f;
-        accB1[m][0] = accBf;
-        accB1[m][1] = accBf;
+        for (int n = 0; n < NPW; ++n) accW[m][n] = zero4;
     }
     unsigned soff[NPW];  // state column of this lane in each owned N tile (element offset inside a state row group)
     bool sval[NPW];
@@ -428,75 +426,40 @@ __global__ __launch_bounds__(512, 1) void qmix_wgrad_kernel(QmixRows<Q, REPLAY> 
         sval[n] = (ng + n * NG) < NTS && k < SD;
         soff[n] = (unsigned)qmix_state_off<Q>(k < SD ? k : SD - 1, ps);
     }
+    struct Ops {
+        f4 a[MPW];
+        float b[NPW][4];
+    };
+    auto load = [&](int blk, Ops& o) {
+#pragma unroll
+        for (int m = 0; m < MPW; ++m)
+            o.a[m] = *reinterpret_cast<const f4*>(bw.G1T + (size_t)blk * (NF1 * 16) + (16 * (mg * MPW + m) + j) * 16 + 4 * g);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int row = blk * 16 + 4 * g + e;
+            const float* rb = src.base(row < R ? row : R - 1, 0);
+#pragma unroll
+            for (int n = 0; n < NPW; ++n) o.b[n][e] = rb[soff[n]];
+        }
+    };
     const int nblk = (R + 15) / 16;
     const int per = (nblk + gridDim.x - 1) / gridDim.x;
     const int bA = blockIdx.x * per, bB = (bA + per) < nblk ? bA + per : nblk;
+    Ops cur, nxt;
+    if (bA < bB) load(bA, cur);
     for (int blk = bA; blk < bB; ++blk) {
-        const float* rbase[4];
-        const float* yrow[4];
+        load(blk + 1 < bB ? blk + 1 : blk, nxt);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int row = blk * 16 + 4 * g + e, rc = row < R ? row : R - 1;
-            rbase[e] = src.base(rc, 0);
-            yrow[e] = Y1 + (size_t)rc * NF1;
-        }
-        // (i) first-layer weights
-        f4 a[MPW];
+        for (int m = 0; m < MPW; ++m)
+            if (ng == 0) cs1[m] += (cur.a[m][0] + cur.a[m][1]) + (cur.a[m][2] + cur.a[m][3]);
 #pragma unroll
-        for (int m = 0; m < MPW; ++m) {
-            a[m] = *reinterpret_cast<const f4*>(bw.G1T + (size_t)blk * (NF1 * 16) + (16 * (mg * MPW + m) + j) * 16 + 4 * g);
-            if (ng == 0) cs1[m] += (a[m][0] + a[m][1]) + (a[m][2] + a[m][3]);
-        }
-#pragma unroll
-        for (int n = 0; n < NPW; ++n) {
-            float b[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float v = rbase[e][soff[n]];
-                b[e] = sval[n] ? v : 0.f;
-            }
+        for (int n = 0; n < NPW; ++n)
 #pragma unroll
             for (int m = 0; m < MPW; ++m)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) accW[m][n] = MARL_MFMA(a[m][e], b[e], accW[m][n]);
-        }
-        // (ii) hyper_w_1.2
-        float hb[2][4];
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) hb[nt][e] = yrow[e][16 * nt + j];
-#pragma unroll
-        for (int m = 0; m < M2W; ++m) {
-            const int mt2 = w + 8 * m;
-            if (mt2 < W1T) {
-                const f4 a2 = *reinterpret_cast<const f4*>(bw.DW1T + (size_t)blk * (Q::E * P * 16) + (16 * mt2 + j) * 16 + 4 * g);
-                csc1[m] += (a2[0] + a2[1]) + (a2[2] + a2[3]);
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) accB1[m][nt] = MARL_MFMA(a2[e], hb[nt][e], accB1[m][nt]);
-            }
-        }
-        // (iii) hyper_w_final.2: tile (mt = w>>1, nt = w&1)
-        {
-            const f4 a3 = *reinterpret_cast<const f4*>(bw.DWFT + (size_t)blk * (Q::E * 16) + (16 * (w >> 1) + j) * 16 + 4 * g);
-            if ((w & 1) == 0) cscf += (a3[0] + a3[1]) + (a3[2] + a3[3]);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) accBf = MARL_MFMA(a3[e], yrow[e][32 + 16 * (w & 1) + j], accBf);
-        }
-        // V.2: wave 7
-        if (w == 7) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float dy = bw.DY[blk * 16 + 4 * g + e];
-                dcv += dy;
-#pragma unroll
-                for (int et = 0; et < 4; ++et) dbv[et] = fmaf(dy, yrow[e][128 + 16 * et + j], dbv[et]);
-            }
-        }
+                for (int e = 0; e < 4; ++e) accW[m][n] = MARL_MFMA(cur.a[m][e], sval[n] ? cur.b[n][e] : 0.f, accW[m][n]);
+        cur = nxt;
     }
-    // ---- record of this workgroup, canonical parameter order
     float* rec = partials + (size_t)blockIdx.x * Q::NPARAM;
 #pragma unroll
     for (int m = 0; m < MPW; ++m) {
@@ -516,6 +479,75 @@ __global__ __launch_bounds__(512, 1) void qmix_wgrad_kernel(QmixRows<Q, REPLAY> 
             if (g == 0) rec[qmix_l1_bias<Q>(16 * mt + j)] = s;
         }
     }
+}
+
+template <class Q>
+__global__ __launch_bounds__(512, 1) void qmix_wgrad2_kernel(const float* __restrict__ Y1, QmixBwd bw, int R, float* __restrict__ partials) {
+    constexpr int P = Q::P, W1T = Q::W1T, NF1 = Q::NF1, M2W = (W1T + 7) / 8;
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, g = lane >> 4, j = lane & 15;
+    const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f4 accB1[M2W][2], accBf = zero4, dbv = zero4;
+    float csc1[M2W], cscf = 0.f, dcv = 0.f;
+#pragma unroll
+    for (int m = 0; m < M2W; ++m) {
+        csc1[m] = 0.f;
+        accB1[m][0] = zero4;
+        accB1[m][1] = zero4;
+    }
+    struct Ops {
+        f4 a2[M2W], a3;
+        float hb[2][4], hf[4], dy[4], hv[4][4];
+    };
+    auto load = [&](int blk, Ops& o) {
+#pragma unroll
+        for (int m = 0; m < M2W; ++m) {
+            const int mt2 = w + 8 * m;
+            o.a2[m] = mt2 < W1T ? *reinterpret_cast<const f4*>(bw.DW1T + (size_t)blk * (Q::E * P * 16) + (16 * mt2 + j) * 16 + 4 * g) : zero4;
+        }
+        o.a3 = *reinterpret_cast<const f4*>(bw.DWFT + (size_t)blk * (Q::E * 16) + (16 * (w >> 1) + j) * 16 + 4 * g);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int row = blk * 16 + 4 * g + e;
+            const float* y = Y1 + (size_t)(row < R ? row : R - 1) * NF1;
+            o.hb[0][e] = y[j];
+            o.hb[1][e] = y[16 + j];
+            o.hf[e] = y[32 + 16 * (w & 1) + j];
+            if (w == 7) {
+                o.dy[e] = bw.DY[blk * 16 + 4 * g + e];
+#pragma unroll
+                for (int et = 0; et < 4; ++et) o.hv[et][e] = y[128 + 16 * et + j];
+            }
+        }
+    };
+    const int nblk = (R + 15) / 16;
+    const int per = (nblk + gridDim.x - 1) / gridDim.x;
+    const int bA = blockIdx.x * per, bB = (bA + per) < nblk ? bA + per : nblk;
+    Ops cur, nxt;
+    if (bA < bB) load(bA, cur);
+    for (int blk = bA; blk < bB; ++blk) {
+        load(blk + 1 < bB ? blk + 1 : blk, nxt);
+#pragma unroll
+        for (int m = 0; m < M2W; ++m) {
+            csc1[m] += (cur.a2[m][0] + cur.a2[m][1]) + (cur.a2[m][2] + cur.a2[m][3]);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) accB1[m][nt] = MARL_MFMA(cur.a2[m][e], cur.hb[nt][e], accB1[m][nt]);
+        }
+        if ((w & 1) == 0) cscf += (cur.a3[0] + cur.a3[1]) + (cur.a3[2] + cur.a3[3]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) accBf = MARL_MFMA(cur.a3[e], cur.hf[e], accBf);
+        if (w == 7) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                dcv += cur.dy[e];
+#pragma unroll
+                for (int et = 0; et < 4; ++et) dbv[et] = fmaf(cur.dy[e], cur.hv[et][e], dbv[et]);
+            }
+        }
+        cur = nxt;
+    }
+    float* rec = partials + (size_t)blockIdx.x * Q::NPARAM;
 #pragma unroll
     for (int m = 0; m < M2W; ++m) {
         const int mt2 = w + 8 * m;
@@ -530,15 +562,13 @@ __global__ __launch_bounds__(512, 1) void qmix_wgrad_kernel(QmixRows<Q, REPLAY> 
             if (g == 0) rec[Q::oc1 + 16 * mt2 + j] = s;
         }
     }
-    {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) rec[Q::oBf + (16 * (w >> 1) + 4 * g + r) * Q::HE + 16 * (w & 1) + j] = accBf[r];
-        if ((w & 1) == 0) {
-            float s = cscf;
-            s += __shfl_xor(s, 16);
-            s += __shfl_xor(s, 32);
-            if (g == 0) rec[Q::ocf + 16 * (w >> 1) + j] = s;
-        }
+    for (int r = 0; r < 4; ++r) rec[Q::oBf + (16 * (w >> 1) + 4 * g + r) * Q::HE + 16 * (w & 1) + j] = accBf[r];
+    if ((w & 1) == 0) {
+        float s = cscf;
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        if (g == 0) rec[Q::ocf + 16 * (w >> 1) + j] = s;
     }
     if (w == 7) {
 #pragma unroll
@@ -571,6 +601,12 @@ static __global__ __launch_bounds__(256) void qmix_reduce_kernel(const float* __
     if (slice == 0 && i < nparam) grad[i] = ((s_part[0][l64] + s_part[1][l64]) + (s_part[2][l64] + s_part[3][l64])) / loss_nf[1];
 }
 
+// episode index of every batch row, drawn once per update (the mixer kernels then read it instead of re-running Philox)
+static __global__ __launch_bounds__(256) void qmix_draw_kernel(ReplaySrc rs, int B, int32_t* __restrict__ out) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b < B) out[b] = replay_draw(rs, b);
+}
+
 // ---- host side ---------------------------------------------------------------------------------------------
 struct QmixCtx {  // what marlhip_qmix_loss_grad adds to the agent-network call
     const float* mixer;
@@ -581,7 +617,7 @@ struct QmixCtx {  // what marlhip_qmix_loss_grad adds to the agent-network call
 };
 
 struct QmixWs {
-    int64_t packs, y1o, y1t, dw1, dwf, dy, ytgt, partials, total;  // byte offsets
+    int64_t packs, y1o, y1t, dw1, dwf, dy, ytgt, idx, partials, total;  // byte offsets
     int nwg3;
 };
 
@@ -597,8 +633,12 @@ inline QmixWs qmix_ws_layout(int T, int B) {
     w.dwf = al(w.dw1 + Rp * Q::E * Q::P * 4);
     w.dy = al(w.dwf + Rp * Q::E * 4);
     w.ytgt = al(w.dy + Rp * 4);
-    w.partials = al(w.ytgt + Rp * 4);
-    w.nwg3 = (int)(nblk < 256 ? nblk : 256);
+    w.idx = al(w.ytgt + Rp * 4);
+    w.partials = al(w.idx + (int64_t)B * 4);
+    // weight-gradient workgroups: the loop over row blocks is latency-bound when a block carries few MFMAs (small P), so the
+    // light shapes get 3 workgroups per CU; the heavy ones (register-bound, 1 workgroup per CU) one per CU
+    const int64_t cap = Q::P <= 4 ? 768 : 256;
+    w.nwg3 = (int)(nblk < cap ? nblk : cap);
     w.total = al(w.partials + (int64_t)w.nwg3 * Q::NPARAM * 4);
     return w;
 }
@@ -622,6 +662,11 @@ int qmix_launch_mix(const QmixCtx& qx, const marlhip_batch* bt, const ReplaySrc&
     io2.ytgt = reinterpret_cast<float*>(base + wl.ytgt);
     QmixRows<Q, REPLAY> src;
     src.obs = bt->obss; src.rs = rsrc; src.T = T; src.B = B;
+    if (REPLAY && rsrc.idx == nullptr) {
+        int32_t* idxbuf = reinterpret_cast<int32_t*>(base + wl.idx);
+        hipLaunchKernelGGL(qmix_draw_kernel, dim3((B + 255) / 256), dim3(256), 0, st, rsrc, B, idxbuf);
+        src.rs.idx = idxbuf;
+    }
     constexpr int CH = (Q::NCH == 1 ? Q::KS4 : 4) * Q::MT1 * 256 * (int)sizeof(float);
     constexpr int LM_ON = Q::NMIX * (int)sizeof(float), LM_TG = Q::NMIX_FWD * (int)sizeof(float);
     static bool attr_set = false;
@@ -642,7 +687,9 @@ int qmix_launch_mix(const QmixCtx& qx, const marlhip_batch* bt, const ReplaySrc&
     hipLaunchKernelGGL((qmix_l1_kernel<Q, REPLAY>), dim3(g1), dim3(256), CH, st, (const float*)packs, src, 0, R, y1o);
     hipLaunchKernelGGL((qmix_mix_kernel<Q, true>), dim3(g2), dim3(256), LM_ON, st, (const float*)(packs + 2 * Q::NL1), (const float*)y1o,
                        io2, R, gamma, bw);
-    hipLaunchKernelGGL((qmix_wgrad_kernel<Q, REPLAY>), dim3(wl.nwg3), dim3(512), 0, st, src, (const float*)y1o, bw, R,
+    hipLaunchKernelGGL((qmix_wgrad1_kernel<Q, REPLAY>), dim3(wl.nwg3), dim3(512), 0, st, src, bw, R,
+                       reinterpret_cast<float*>(base + wl.partials));
+    hipLaunchKernelGGL((qmix_wgrad2_kernel<Q>), dim3(wl.nwg3), dim3(512), 0, st, (const float*)y1o, bw, R,
                        reinterpret_cast<float*>(base + wl.partials));
     timing_end(TIMER_QMIX, st);
     MARL_CHECK_LAUNCH("qmix mixer stage");
