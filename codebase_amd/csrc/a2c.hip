@@ -13,38 +13,46 @@
 //                  backward with the external output gradient, deterministic partial-record reduction, 1/sum(filled).
 // Rows come straight from the ac/train.py Batch (agents innermost) through marlhip_batch's strides.
 #include "dqn_update_kernels.h"
+#include "collect_common.h"
 
 namespace marl {
 
 // ---- forward rows ------------------------------------------------------------------------------------------
 template <class S>
-__global__ __launch_bounds__(256) void mlp_rows_fwd_kernel(const float* __restrict__ params, AgentMap am, const float* __restrict__ obs,
+__global__ __launch_bounds__(256) void mlp_rows_fwd_kernel(const float* __restrict__ packs /* pre-packed [P][NFWD] */, const float* __restrict__ obs,
                                                            size_t agent_stride, size_t row_stride, int n_rows,
                                                            float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, j = lane & 15;
     const int p = blockIdx.y;
-    mlp_stage_fwd<S>(params + (size_t)am.net[p] * S::NPARAM, lds, tid, 256);
+    stage_packed<S>(packs + (size_t)p * S::NFWD, lds, tid, 256);
     __syncthreads();
     const float* obs_p = obs + (size_t)p * agent_stride;
-    const int nblk = (n_rows + 15) >> 4;
-    for (int blk = blockIdx.x * 4 + wave; blk < nblk; blk += gridDim.x * 4) {
-        const int row = blk * 16 + j;
-        const bool ok = row < n_rows;
-        const float* xrow = obs_p + (size_t)(ok ? row : n_rows - 1) * row_stride;
-        float x[S::KS1];
+    const int nblk = (n_rows + 15) >> 4, npair = (nblk + 1) >> 1;
+    for (int pr = blockIdx.x * 4 + wave; pr < npair; pr += gridDim.x * 4) {  // two row blocks per wave and step
+        float x[2][S::KS1];
+        int row[2];
 #pragma unroll
-        for (int ks = 0; ks < S::KS1; ++ks) {
-            const int d = 4 * ks + g;
-            const float v = xrow[d < S::D ? d : S::D - 1];
-            x[ks] = (d < S::D && ok) ? v : 0.f;
+        for (int h = 0; h < 2; ++h) {
+            row[h] = (2 * pr + h) * 16 + j;
+            const bool ok = row[h] < n_rows;
+            const float* xrow = obs_p + (size_t)(ok ? row[h] : n_rows - 1) * row_stride;
+#pragma unroll
+            for (int ks = 0; ks < S::KS1; ++ks) {
+                const int d = 4 * ks + g;
+                const float v = xrow[d < S::D ? d : S::D - 1];
+                x[h][ks] = (d < S::D && ok) ? v : 0.f;
+            }
         }
-        f4 h1[S::MT], h2[S::MT], q, unused;
-        mlp_forward_p<S, false>(lds, lds, lane, x, h1, h2, q, unused);
-        if (ok) {
+        f4 q[2];
+        mlp_forward_p2<S>(lds, lane, x, q);
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (4 * g + r < S::A) out[((size_t)p * n_rows + row) * S::A + 4 * g + r] = q[r];
+        for (int h = 0; h < 2; ++h) {
+            if (row[h] < n_rows) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (4 * g + r < S::A) out[((size_t)p * n_rows + row[h]) * S::A + 4 * g + r] = q[h][r];
+            }
         }
     }
 }
@@ -60,11 +68,15 @@ int launch_forward_rows(int P, const AgentMap& am, const float* params, const ma
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_rows_fwd_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
         attr_set = true;
     }
-    const int nblk = (n_rows + 15) / 16;
-    int gx = (nblk + 3) / 4;
-    const int cap = 512 / P > 1 ? 512 / P : 1;
+    const int npair = ((n_rows + 15) / 16 + 1) / 2;
+    int gx = (npair + 3) / 4;
+    // one resident workgroup per CU when the pack fills most of the LDS (hidden 128), two otherwise: every workgroup stages once
+    const int per_cu = LDSB > 80 * 1024 ? 1 : 2;
+    const int cap = (256 * per_cu) / P > 1 ? (256 * per_cu) / P : 1;
     if (gx > cap) gx = cap;
-    hipLaunchKernelGGL((mlp_rows_fwd_kernel<S>), dim3(gx, P), dim3(256), LDSB, st, params, am, bt->obss, as, rs, n_rows, out);
+    float* packs = nullptr;
+    if (launch_fwd_pack<S>(P, am, params, &packs, st) != 0) return -1;
+    hipLaunchKernelGGL((mlp_rows_fwd_kernel<S>), dim3(gx, P), dim3(256), LDSB, st, (const float*)packs, bt->obss, as, rs, n_rows, out);
     MARL_CHECK_LAUNCH("mlp_rows_fwd_kernel");
     return 0;
 }

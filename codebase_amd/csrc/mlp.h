@@ -362,6 +362,82 @@ __device__ __forceinline__ void mlp_forward_p(const float* ldsA, const float* ld
     if (DUAL) qB = o3B;
 }
 
+// One network on TWO 16-row blocks at once: every A operand fetched from LDS feeds two MFMAs, which halves the LDS
+// operand traffic per flop (at hidden 128 a single-block forward reads 327 KB of operands per 320 MFMAs - the LDS port
+// and the matrix pipe then run at the same rate).  Same pipelining and per-output summation order as mlp_forward_p.
+template <class S>
+__device__ __forceinline__ void mlp_forward_p2(const float* lds, int lane, const float (&x)[2][S::KS1], f4 (&q)[2]) {
+    constexpr int MT = S::MT, N1 = S::KS1 / 4;
+    const int g = lane >> 4;
+    const f4* A1 = reinterpret_cast<const f4*>(lds + S::pA1);
+    const f4* A2 = reinterpret_cast<const f4*>(lds + S::pA2);
+    const f4* A3 = reinterpret_cast<const f4*>(lds + S::pA3);
+    f4 op[2][MT], acc[2][MT], nb[MT], h1[2][MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        op[0][mt] = A1[(mt * N1 + 0) * 64 + lane];
+        acc[0][mt] = *reinterpret_cast<const f4*>(lds + S::pb1 + 16 * mt + 4 * g);
+        acc[1][mt] = acc[0][mt];
+    }
+#pragma unroll
+    for (int s = 0; s < N1; ++s) {
+        const int cur = s & 1, nxt = cur ^ 1;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            if (s + 1 < N1) {
+                op[nxt][mt] = A1[(mt * N1 + s + 1) * 64 + lane];
+            } else {
+                op[nxt][mt] = A2[(mt * MT + 0) * 64 + lane];
+                nb[mt] = *reinterpret_cast<const f4*>(lds + S::pb2 + 16 * mt + 4 * g);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                acc[0][mt] = MARL_MFMA(op[cur][mt][e], x[0][4 * s + e], acc[0][mt]);
+                acc[1][mt] = MARL_MFMA(op[cur][mt][e], x[1][4 * s + e], acc[1][mt]);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        h1[0][mt] = relu4(acc[0][mt]);
+        h1[1][mt] = relu4(acc[1][mt]);
+        acc[0][mt] = nb[mt];
+        acc[1][mt] = nb[mt];
+    }
+    f4 o3;
+#pragma unroll
+    for (int k1 = 0; k1 < MT; ++k1) {
+        const int cur = (N1 + k1) & 1, nxt = cur ^ 1;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) op[nxt][mt] = (k1 + 1 < MT) ? A2[(mt * MT + k1 + 1) * 64 + lane] : A3[mt * 64 + lane];
+        if (k1 + 1 == MT) o3 = *reinterpret_cast<const f4*>(lds + S::pb3 + 4 * g);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                acc[0][mt] = MARL_MFMA(op[cur][mt][r], h1[0][k1][r], acc[0][mt]);
+                acc[1][mt] = MARL_MFMA(op[cur][mt][r], h1[1][k1][r], acc[1][mt]);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    constexpr int c3 = (N1 + MT) & 1;
+    q[0] = o3;
+    q[1] = o3;
+#pragma unroll
+    for (int k1 = 0; k1 < MT; ++k1)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const f4 h20 = relu4(acc[0][k1]), h21 = relu4(acc[1][k1]);
+            q[0] = MARL_MFMA(op[c3][k1][r], h20[r], q[0]);
+            q[1] = MARL_MFMA(op[c3][k1][r], h21[r], q[1]);
+        }
+}
+
 // greedy action of batch row j from q in C layout (lane (g,j) holds Q[4g+r]):
 // first index of the maximum (torch.argmax tie rule), identical in all 4 lanes of j.
 template <int A>
