@@ -169,7 +169,7 @@ extern "C" int marlhip_dqn_clip_adam(int64_t n, float* params, const float* grad
     a.beta2 = (float)beta2;
     a.w2 = (float)(1.0 - beta2);
     a.eps = (float)eps; a.max_norm = max_norm; a.grad_scale = grad_scale; a.tau = tau; a.hard_update = hard_update;
-    if (n <= 131072) {
+    if (n <= 32768) {  // one workgroup does norm + clip + Adam + target: one launch, best while the block is small
         hipLaunchKernelGGL(adam_fused_kernel, dim3(1), dim3(1024), 0, st, n, params, grad, exp_avg, exp_avg_sq, target_params, a,
                            gnorm_out);
         MARL_CHECK_LAUNCH("adam_fused_kernel");

@@ -594,10 +594,17 @@ static __global__ __launch_bounds__(256) void adam_kernel(int64_t n, int nblocks
                                                    float* __restrict__ v, float* __restrict__ target, AdamArgs a,
                                                    const float* __restrict__ scratch, float* __restrict__ gnorm_out) {
     __shared__ float s_coef;
-    if (threadIdx.x == 0) {
+    __shared__ float s_red[4];
+    {   // every block re-sums the per-block partials of sumsq_kernel: strided loads + fixed-order tree (reproducible)
         float ss = 0.f;
-        for (int b = 0; b < nblocks; ++b) ss += scratch[b];
-        const float total = sqrtf(ss);
+        for (int b = threadIdx.x; b < nblocks; b += 256) ss += scratch[b];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) ss += __shfl_xor(ss, off);
+        if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = ss;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float total = sqrtf((s_red[0] + s_red[1]) + (s_red[2] + s_red[3]));
         // clip_coef = max_norm / (total_norm + 1e-6), clamped to 1 (torch.nn.utils.clip_grad_norm_)
         float coef = 1.f;
         if (a.max_norm > 0.f) coef = fminf(a.max_norm / (total + 1e-6f), 1.f);
@@ -631,7 +638,7 @@ static __global__ __launch_bounds__(256) void adam_kernel(int64_t n, int nblocks
 
 namespace marl {
 
-// n <= 128k parameters: norm + clip + Adam + target in ONE workgroup (one launch instead of two)
+// small blocks (marlhip_dqn_clip_adam: n <= 32k): norm + clip + Adam + target in ONE workgroup (one launch instead of two)
 static __global__ __launch_bounds__(1024) void adam_fused_kernel(int64_t n, float* __restrict__ params, const float* __restrict__ grad,
                                                           float* __restrict__ m, float* __restrict__ v, float* __restrict__ target,
                                                           AdamArgs a, float* __restrict__ gnorm_out) {
