@@ -23,7 +23,6 @@
 
 namespace marl {
 
-constexpr int UPD_MAXWAVES = 8;  // waves per workgroup: 4 (1 per SIMD) or 8 (2 per SIMD)
 
 __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -685,19 +684,12 @@ struct UpdPlan {
     int nwg, n_chunks;
 };
 
-inline int upd_waves() {  // waves per workgroup (MARLHIP_UPD_WAVES=4|8; default from measurement)
-    static int w = 0;
-    if (w == 0) {
-        const char* e = getenv("MARLHIP_UPD_WAVES");
-        w = 4;  // 8 waves x 5 tiles no longer fit the 160 KiB LDS next to the packs
-        (void)e;
-    }
-    return w;
-}
+// 4 waves per workgroup (1 per SIMD): 8 waves x 5 transpose tiles do not fit the 160 KiB LDS next to the packs and spill
+constexpr int UPD_WAVES = 4;
 
 inline UpdPlan upd_plan(int P, int T, int B) {
     const int ngroups = (B + 15) / 16;
-    const int W = upd_waves();
+    constexpr int W = UPD_WAVES;
     const int want_waves = 256 * W / (P > 0 ? P : 1) > W ? 256 * W / P : W;  // fill every CU with one workgroup
     int nc = (want_waves + ngroups - 1) / ngroups;
     if (nc < 1) nc = 1;

@@ -169,86 +169,6 @@ __device__ __forceinline__ void mlp_forward(const float* lds, int lane, const fl
     q = o;
 }
 
-// Two networks (critic pack A, target pack B) on the SAME 16-row block, interleaved layer by
-// layer: 2 x MT independent accumulator chains per layer keep the matrix pipe fed across the
-// dependent-latency gaps and halve the number of layer-boundary drains per row block.  Each
-// network's own summation order is exactly mlp_forward's (bitwise identical results).
-template <class S>
-__device__ __forceinline__ void mlp_forward2(const float* ldsA, const float* ldsB, int lane, const float (&x)[S::KS1],
-                                             f4 (&h1)[S::MT], f4 (&h2)[S::MT], f4& qA, f4& qB) {
-    const int g = lane >> 4;
-    const f4* A1 = reinterpret_cast<const f4*>(ldsA + S::pA1);
-    const f4* A2 = reinterpret_cast<const f4*>(ldsA + S::pA2);
-    const f4* A3 = reinterpret_cast<const f4*>(ldsA + S::pA3);
-    const f4* B1 = reinterpret_cast<const f4*>(ldsB + S::pA1);
-    const f4* B2 = reinterpret_cast<const f4*>(ldsB + S::pA2);
-    const f4* B3 = reinterpret_cast<const f4*>(ldsB + S::pA3);
-    f4 accA[S::MT], accB[S::MT], g1[S::MT], g2[S::MT];
-#pragma unroll
-    for (int mt = 0; mt < S::MT; ++mt) {
-        accA[mt] = *reinterpret_cast<const f4*>(ldsA + S::pb1 + 16 * mt + 4 * g);
-        accB[mt] = *reinterpret_cast<const f4*>(ldsB + S::pb1 + 16 * mt + 4 * g);
-    }
-#pragma unroll
-    for (int ks4 = 0; ks4 < S::KS1 / 4; ++ks4) {
-        f4 a[S::MT], b[S::MT];
-#pragma unroll
-        for (int mt = 0; mt < S::MT; ++mt) {
-            a[mt] = A1[(mt * (S::KS1 / 4) + ks4) * 64 + lane];
-            b[mt] = B1[(mt * (S::KS1 / 4) + ks4) * 64 + lane];
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int mt = 0; mt < S::MT; ++mt) {
-                accA[mt] = MARL_MFMA(a[mt][e], x[4 * ks4 + e], accA[mt]);
-                accB[mt] = MARL_MFMA(b[mt][e], x[4 * ks4 + e], accB[mt]);
-            }
-    }
-#pragma unroll
-    for (int mt = 0; mt < S::MT; ++mt) {
-        h1[mt] = relu4(accA[mt]);
-        g1[mt] = relu4(accB[mt]);
-        accA[mt] = *reinterpret_cast<const f4*>(ldsA + S::pb2 + 16 * mt + 4 * g);
-        accB[mt] = *reinterpret_cast<const f4*>(ldsB + S::pb2 + 16 * mt + 4 * g);
-    }
-#pragma unroll
-    for (int k1 = 0; k1 < S::MT; ++k1) {
-        f4 a[S::MT], b[S::MT];
-#pragma unroll
-        for (int mt = 0; mt < S::MT; ++mt) {
-            a[mt] = A2[(mt * S::MT + k1) * 64 + lane];
-            b[mt] = B2[(mt * S::MT + k1) * 64 + lane];
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int mt = 0; mt < S::MT; ++mt) {
-                accA[mt] = MARL_MFMA(a[mt][r], h1[k1][r], accA[mt]);
-                accB[mt] = MARL_MFMA(b[mt][r], g1[k1][r], accB[mt]);
-            }
-    }
-#pragma unroll
-    for (int mt = 0; mt < S::MT; ++mt) {
-        h2[mt] = relu4(accA[mt]);
-        g2[mt] = relu4(accB[mt]);
-    }
-    f4 oA = *reinterpret_cast<const f4*>(ldsA + S::pb3 + 4 * g);
-    f4 oB = *reinterpret_cast<const f4*>(ldsB + S::pb3 + 4 * g);
-#pragma unroll
-    for (int k1 = 0; k1 < S::MT; ++k1) {
-        const f4 a = A3[k1 * 64 + lane];
-        const f4 b = B3[k1 * 64 + lane];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            oA = MARL_MFMA(a[r], h2[k1][r], oA);
-            oB = MARL_MFMA(b[r], g2[k1][r], oB);
-        }
-    }
-    qA = oA;
-    qB = oB;
-}
-
 // Software-pipelined forward (one network, or critic+target on the same rows when DUAL): the
 // A-operand fetch (ds_read_b128) of step s+1 is issued BEFORE the MFMAs of step s and pinned there
 // with sched_barrier, so with one wave per SIMD the LDS latency hides under >= 16 MFMAs instead of
