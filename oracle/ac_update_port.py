@@ -53,13 +53,18 @@ def logits(block, obss, D, H, A):
     return [dp.mlp(block[p], xs[p], D, H, A) for p in range(P)]
 
 
-def evaluate(actor, critic, target, batch, D, H, A, n_steps, gamma):
+def evaluate(actor, critic, target, batch, D, H, A, n_steps, gamma, ret_ms=None):
     obss, actions = batch["obss"], batch["actions"]
     P = actor.shape[0]
     with torch.no_grad():
         next_value = values(target, obss, D, H)
+    if ret_ms is not None:  # standardise_returns (model.py:195-196)
+        next_value = next_value * torch.sqrt(ret_ms.var) + ret_ms.mean
     done = batch["dones"].float().unsqueeze(-1).repeat(1, 1, P)
     returns = nstep_returns(batch["rewards"], done, next_value, n_steps, gamma)
+    if ret_ms is not None:  # model.py:202-204
+        ret_ms.update(returns)
+        returns = (returns - ret_ms.mean) / torch.sqrt(ret_ms.var)
     v = values(critic, obss[:-1], D, H)
     lg = logits(actor, obss[:-1], D, H, A)
     dists = [torch.distributions.Categorical(logits=l) for l in lg]
@@ -68,8 +73,8 @@ def evaluate(actor, critic, target, batch, D, H, A, n_steps, gamma):
     return returns, v, logp, ent
 
 
-def a2c_loss(actor, critic, target, batch, D, H, A, n_steps=5, gamma=0.99, entropy_coef=0.001, value_loss_coef=0.5):
-    returns, v, logp, ent = evaluate(actor, critic, target, batch, D, H, A, n_steps, gamma)
+def a2c_loss(actor, critic, target, batch, D, H, A, n_steps=5, gamma=0.99, entropy_coef=0.001, value_loss_coef=0.5, ret_ms=None):
+    returns, v, logp, ent = evaluate(actor, critic, target, batch, D, H, A, n_steps, gamma, ret_ms)
     filled = batch["filled"]
     adv = returns - v
     actor_loss = -(logp * adv.detach()).sum(-1) - entropy_coef * ent
@@ -100,7 +105,8 @@ class Learner:
     """A2CNetwork / PPONetwork update: one Adam over actor + critic tensors in parameters() order."""
 
     def __init__(self, actor, critic, D, H, A, lr=3e-4, gamma=0.99, n_steps=5, entropy_coef=0.001, value_loss_coef=0.5,
-                 grad_clip=False, target_update_interval_or_tau=200, num_epochs=0, ppo_clip=0.2):
+                 grad_clip=False, target_update_interval_or_tau=200, num_epochs=0, ppo_clip=0.2, standardise_returns=False):
+        self.ret_ms = dp.RunningMeanStd((actor.shape[0],)) if standardise_returns else None
         self.D, self.H, self.A, self.P = D, H, A, actor.shape[0]
         self.at = [torch.nn.Parameter(t.clone()) for p in range(self.P) for t in dp.split(actor[p], D, H, A)]
         self.ct = [torch.nn.Parameter(t.clone()) for p in range(self.P) for t in dp.split(critic[p], D, H, 1)]
@@ -129,12 +135,14 @@ class Learner:
     def update(self, batch, step):
         D, H, A = self.D, self.H, self.A
         if self.num_epochs == 0:
-            loss, m = a2c_loss(self.actor(), self.critic(), self.target, batch, D, H, A, self.n_steps, self.gamma, self.ec, self.vc)
+            loss, m = a2c_loss(self.actor(), self.critic(), self.target, batch, D, H, A, self.n_steps, self.gamma, self.ec, self.vc,
+                               self.ret_ms)
             self._step(loss)
             metrics = {k: v.item() for k, v in m.items()}
         else:
             with torch.no_grad():
-                returns, _, old_logp, _ = evaluate(self.actor(), self.critic(), self.target, batch, D, H, A, self.n_steps, self.gamma)
+                returns, _, old_logp, _ = evaluate(self.actor(), self.critic(), self.target, batch, D, H, A, self.n_steps, self.gamma,
+                                                   self.ret_ms)
             acc = {}
             for _ in range(self.num_epochs):
                 loss, m = ppo_loss(self.actor(), self.critic(), returns, old_logp, batch, D, H, A, self.ec, self.vc, self.ppo_clip)

@@ -76,7 +76,25 @@ def act(params, obs, epsilon, u, rand_actions, D, H, A):
     return torch.where(explore, rand_actions, greedy), q
 
 
-def compute_loss(params, tparams, batch, gamma, double_q, D, H, A, mode="idqn", sharing=None):
+class RunningMeanStd:
+    """marlbase/utils/standardise_stream.py:6-41 (parallel-variance update; `count` starts at epsilon = 1e-4)."""
+
+    def __init__(self, shape, epsilon=1e-4):
+        self.mean = torch.zeros(shape, dtype=torch.float32)
+        self.var = torch.ones(shape, dtype=torch.float32)
+        self.count = epsilon
+
+    def update(self, arr):
+        arr = arr.reshape(-1, arr.size(-1))
+        bm, bv, bc = torch.mean(arr, dim=0), torch.var(arr, dim=0), arr.shape[0]
+        delta = bm - self.mean
+        tot = self.count + bc
+        new_mean = self.mean + delta * bc / tot
+        m2 = self.var * self.count + bv * bc + torch.square(delta) * self.count * bc / (self.count + bc)
+        self.mean, self.var, self.count = new_mean, m2 / (self.count + bc), bc + self.count
+
+
+def compute_loss(params, tparams, batch, gamma, double_q, D, H, A, mode="idqn", sharing=None, ret_ms=None):
     """QNetwork._compute_loss (idqn) / VDNetwork._compute_loss (vdn); batch = dict with
     obss [P,T+1,B,D], actions i64 [P,T,B], rewards [P,T,B], dones [T+1,B], filled [T,B].
     sharing: agent -> network index (MultiAgentSharedNetwork, utils/models.py:176-300); params are then [K][n]."""
@@ -96,7 +114,13 @@ def compute_loss(params, tparams, batch, gamma, double_q, D, H, A, mode="idqn", 
         target_qs, _ = tq.max(dim=-1)
     if mode == "idqn":
         d = dones[1:].unsqueeze(0).repeat(P, 1, 1)
+        if ret_ms is not None:  # standardise_returns (model.py:146-149): bootstrap values back to the raw scale
+            target_qs = (target_qs.permute(1, 2, 0) * torch.sqrt(ret_ms.var) + ret_ms.mean).permute(2, 0, 1)
         returns = rewards + gamma * target_qs.detach() * (1 - d)
+        if ret_ms is not None:  # model.py:153-158: update with EVERY entry (filled or not), then standardise
+            r = returns.permute(1, 2, 0)
+            ret_ms.update(r)
+            returns = ((r - ret_ms.mean) / torch.sqrt(ret_ms.var)).permute(2, 0, 1)
         loss = torch.nn.functional.mse_loss(chosen, returns.detach(), reduction="none").sum(dim=0)
     else:  # vdn
         chosen = chosen.sum(dim=0)
@@ -110,9 +134,10 @@ class Learner:
     parameters, torch.optim.Adam, hard / soft target update."""
 
     def __init__(self, params, D, H, A, lr=3e-4, gamma=0.99, grad_clip=1.0, double_q=True,
-                 target_update_interval_or_tau=200, mode="idqn", sharing=None):
+                 target_update_interval_or_tau=200, mode="idqn", sharing=None, standardise_returns=False):
         self.D, self.H, self.A = D, H, A
         self.sharing = sharing
+        self.ret_ms = RunningMeanStd((params.shape[0],)) if standardise_returns else None
         P = params.shape[0]
         # one Parameter per tensor, in parameters() order, so clip/Adam see the reference's tensor list
         self.tensors = [torch.nn.Parameter(t.clone()) for p in range(P) for t in split(params[p], D, H, A)]
@@ -131,7 +156,7 @@ class Learner:
 
     def update(self, batch):
         loss = compute_loss(self.flat(), self.target, batch, self.gamma, self.double_q, self.D, self.H, self.A, self.mode,
-                            self.sharing)
+                            self.sharing, self.ret_ms)
         self.opt.zero_grad()
         loss.backward()
         gnorm = None

@@ -1,0 +1,80 @@
+"""tests/golden/learner_std_*.npz: `standardise_returns=True` (RunningMeanStd, marlbase/utils/standardise_stream.py) in the
+reference's own QNetwork (dqn/model.py:146-158) and A2CNetwork (ac/model.py:195-204).  Build container only.
+    PYTHONDONTWRITEBYTECODE=1 python -m oracle.make_golden_std
+Per update: the loss / metrics, the parameter blocks, and the running statistics (mean, var, count) after it."""
+import contextlib
+import io
+import os
+
+import numpy as np
+import torch
+
+from .ac_update_port import synthetic_batch as ac_batch
+from .dqn_port import synthetic_batch
+from .make_golden import OUT, Box, Cfg, Discrete, flat_params, import_reference
+
+
+def idqn(rm, rt):
+    P, T, B, D, A, H = 2, 25, 32, 15, 6, 64
+    torch.manual_seed(1000)
+    cfg = Cfg(optimizer="Adam", lr=3e-4, gamma=0.99, grad_clip=1.0, target_update_interval_or_tau=2, double_q=True,
+              standardise_returns=True)
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = rm.QNetwork([Box(D)] * P, [Discrete(A)] * P, cfg, [H, H], False, False, True, "cpu")
+    g = torch.Generator().manual_seed(1001)
+    with torch.no_grad():
+        for p in net.critic.parameters():
+            p.add_(0.05 * torch.randn(p.shape, generator=g))
+        for p in net.target.parameters():
+            p.add_(0.08 * torch.randn(p.shape, generator=g))
+    out = dict(P=P, T=T, B=B, D=D, A=A, H=H, params0=flat_params(net.critic).numpy(), target0=flat_params(net.target).numpy())
+    batches = [synthetic_batch(P, T, B, D, A, seed=1100 + i) for i in range(3)]
+    losses = []
+    for i, b in enumerate(batches):
+        losses.append(net.update(rt.Batch(b["obss"], b["actions"], b["rewards"], b["dones"], b["filled"], None))["loss"])
+        out[f"params{i + 1}"] = flat_params(net.critic).numpy()
+        out[f"mean{i + 1}"], out[f"var{i + 1}"], out[f"count{i + 1}"] = net.ret_ms.mean.numpy(), net.ret_ms.var.numpy(), np.float64(net.ret_ms.count)
+        for k, v in b.items():
+            out[f"batch{i}_{k}"] = v.numpy()
+    out["losses"] = np.array(losses, np.float32)
+    np.savez_compressed(os.path.join(OUT, "learner_std_idqn_H64.npz"), **out)
+    print("learner_std_idqn_H64", losses, out["mean3"], out["var3"], out["count3"])
+
+
+def a2c(ram, rat):
+    P, T, N, D, A, H = 2, 25, 12, 15, 6, 64
+    torch.manual_seed(1200)
+    cfg = Cfg(optimizer="Adam", lr=3e-4, gamma=0.99, grad_clip=False, n_steps=5, entropy_coef=0.001, value_loss_coef=0.5,
+              standardise_returns=True, target_update_interval_or_tau=200)
+    net_cfg = dict(layers=[H, H], parameter_sharing=False, use_orthogonal_init=True, use_rnn=False)
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = ram.A2CNetwork([Box(D)] * P, [Discrete(A)] * P, cfg, Cfg(net_cfg), Cfg(dict(net_cfg, centralised=False)), "cpu")
+    g = torch.Generator().manual_seed(1201)
+    with torch.no_grad():
+        for p in list(net.actor.parameters()) + list(net.critic.parameters()):
+            p.add_(0.05 * torch.randn(p.shape, generator=g))
+        for p in net.target_critic.parameters():
+            p.add_(0.08 * torch.randn(p.shape, generator=g))
+    out = dict(P=P, T=T, N=N, D=D, A=A, H=H, n_steps=5, gamma=0.99, entropy_coef=0.001, value_loss_coef=0.5,
+               actor0=flat_params(net.actor).numpy(), critic0=flat_params(net.critic).numpy(), target0=flat_params(net.target_critic).numpy())
+    steps, metrics = [0, 250, 400], []
+    for i, st in enumerate(steps):
+        b = ac_batch(P, T, N, D, A, seed=1300 + i)
+        m = net.update(rat.Batch(b["obss"], b["actions"], b["rewards"], b["dones"], b["filled"], None), st)
+        metrics.append([m["loss"], m["actor_loss"], m["value_loss"], m["entropy"]])
+        out[f"actor{i + 1}"], out[f"critic{i + 1}"] = flat_params(net.actor).numpy(), flat_params(net.critic).numpy()
+        out[f"mean{i + 1}"], out[f"var{i + 1}"], out[f"count{i + 1}"] = net.ret_ms.mean.numpy(), net.ret_ms.var.numpy(), np.float64(net.ret_ms.count)
+        for k, v in b.items():
+            out[f"batch{i}_{k}"] = v.numpy()
+    out["metrics"], out["steps"] = np.array(metrics), np.array(steps)
+    np.savez_compressed(os.path.join(OUT, "learner_std_a2c_H64.npz"), **out)
+    print("learner_std_a2c_H64", np.array(metrics).round(5).tolist(), out["mean3"], out["var3"])
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(1)
+    rm, rt = import_reference()
+    from marlbase.ac import model as ram
+    from marlbase.ac import train as rat
+    idqn(rm, rt)
+    a2c(ram, rat)

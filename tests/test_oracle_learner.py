@@ -183,3 +183,30 @@ def test_parameter_sharing_matches_reference(name, mode):
         m = lr.update(batch_of(g, i))
         assert abs(m["loss"] - float(g["losses"][i])) <= 2e-5 * abs(float(g["losses"][i]))
         np.testing.assert_allclose(lr.flat().detach().numpy(), g[f"params{i + 1}"], rtol=0, atol=2e-6)
+
+
+def test_standardise_returns_matches_reference():
+    """RunningMeanStd (utils/standardise_stream.py) inside QNetwork._compute_loss and A2CNetwork.update: losses / metrics,
+    parameters and the running statistics after each of 3 updates"""
+    from oracle import ac_update_port as ap
+
+    g = load("learner_std_idqn_H64.npz")
+    D, H, A = int(g["D"]), 64, int(g["A"])
+    lr = dp.Learner(torch.tensor(g["params0"]), D, H, A, target_update_interval_or_tau=2, standardise_returns=True)
+    lr.target = torch.tensor(g["target0"])
+    for i in range(3):
+        m = lr.update(batch_of(g, i))
+        assert abs(m["loss"] - float(g["losses"][i])) <= 2e-5 * abs(float(g["losses"][i]))
+        np.testing.assert_allclose(lr.flat().detach().numpy(), g[f"params{i + 1}"], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(lr.ret_ms.mean.numpy(), g[f"mean{i + 1}"], rtol=1e-6)
+        np.testing.assert_allclose(lr.ret_ms.var.numpy(), g[f"var{i + 1}"], rtol=1e-6)
+        assert abs(lr.ret_ms.count - float(g[f"count{i + 1}"])) < 1e-6
+    g = load("learner_std_a2c_H64.npz")
+    al = ap.Learner(torch.tensor(g["actor0"]), torch.tensor(g["critic0"]), D, H, A, standardise_returns=True)
+    al.target = torch.tensor(g["target0"])
+    for i in range(3):
+        m = al.update(ac_batch_of(g, i), int(g["steps"][i]))
+        np.testing.assert_allclose([m["loss"], m["actor_loss"], m["value_loss"], m["entropy"]], g["metrics"][i], rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(al.actor().detach().numpy(), g[f"actor{i + 1}"], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(al.ret_ms.mean.numpy(), g[f"mean{i + 1}"], rtol=1e-6)
+        np.testing.assert_allclose(al.ret_ms.var.numpy(), g[f"var{i + 1}"], rtol=1e-6)
