@@ -53,7 +53,11 @@ class QmixMixer(ctypes.Structure):
 
 class AcConfig(ctypes.Structure):
     _fields_ = [("n_steps", c_int32), ("entropy_coef", c_float), ("value_loss_coef", c_float), ("ppo_clip", c_float),
-                ("gamma", c_double)]
+                ("gamma", c_double), ("ret_mean", c_void_p), ("ret_var", c_void_p), ("ret_count", c_void_p)]
+
+
+class RetStatsStruct(ctypes.Structure):
+    _fields_ = [("mean", c_void_p), ("var", c_void_p), ("count", c_void_p)]
 
 
 class IdqnLearner(ctypes.Structure):
@@ -93,6 +97,12 @@ PROTOTYPES = {
     "marlhip_dqn_loss_grad_replay": (c_int32, [POINTER(NetShape), c_void_p, c_void_p, POINTER(ReplayShape),
                                                POINTER(ReplayBuffers), c_void_p, c_int32, c_int32, c_uint64, c_uint32, c_void_p,
                                                c_float, c_int32, c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "marlhip_dqn_loss_grad_std": (c_int32, [POINTER(NetShape), c_void_p, c_void_p, POINTER(BatchStruct), c_float, c_int32,
+                                            POINTER(RetStatsStruct), c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "marlhip_dqn_loss_grad_std_replay": (c_int32, [POINTER(NetShape), c_void_p, c_void_p, POINTER(ReplayShape),
+                                                   POINTER(ReplayBuffers), c_void_p, c_int32, c_int32, c_uint64, c_uint32, c_void_p,
+                                                   c_float, c_int32, POINTER(RetStatsStruct), c_void_p, c_int64, c_void_p, c_void_p,
+                                                   c_void_p]),
     "marlhip_qmix_nparams": (c_int32, [POINTER(NetShape), c_int32, c_int32, c_int32]),
     "marlhip_qmix_workspace_bytes": (c_int64, [POINTER(NetShape), c_int32, c_int32]),
     "marlhip_qmix_loss_grad": (c_int32, [POINTER(NetShape), c_void_p, c_void_p, POINTER(QmixMixer), POINTER(BatchStruct), c_float,

@@ -48,8 +48,6 @@ class A2CNetwork:
                 raise NotImplementedError(f"{name}.use_rnn: the GRU path is a 'next' row (DESIGN.md)")
         if _get(critic, "centralised", False):
             raise NotImplementedError("critic.centralised (MAA2C / MAPPO) is a 'next' row (DESIGN.md)")
-        if _get(cfg, "standardise_returns", False):
-            raise NotImplementedError("standardise_returns is a 'next' row (DESIGN.md)")
         ha, hc = [int(h) for h in _get(actor, "layers")], [int(h) for h in _get(critic, "layers")]
         if ha != hc or len(ha) != 2 or ha[0] != ha[1]:
             raise NotImplementedError(f"layers actor={ha} critic={hc}: the HIP kernels implement two equal hidden layers (64 or 128), "
@@ -66,7 +64,7 @@ class A2CNetwork:
         self.n_steps, self.grad_clip = int(_get(cfg, "n_steps", 5)), _get(cfg, "grad_clip", False)
         self.value_loss_coef = float(_get(cfg, "value_loss_coef", 0.5))
         self.target_update_interval_or_tau = _get(cfg, "target_update_interval_or_tau", 200)
-        self.standardise_returns = False
+        self.standardise_returns = bool(_get(cfg, "standardise_returns", False))
         self.centralised_critic = False
         self.spec = _hip.NetSpec(P, obs_dims[0], ha[0], act_dims[0], self.sharing)
         if self.sharing is not None:  # one network per distinct index, in order of first appearance (utils/models.py:209-240)
@@ -82,7 +80,8 @@ class A2CNetwork:
         self.updater = _hip.AcUpdater(self.spec, self.block, self.target_critic_params, lr=float(_get(cfg, "lr", 3e-4)),
                                       gamma=self.gamma, n_steps=self.n_steps, entropy_coef=self.entropy_coef,
                                       value_loss_coef=self.value_loss_coef, grad_clip=self.grad_clip,
-                                      ppo_clip=float(_get(cfg, "ppo_clip", 0.2)))
+                                      ppo_clip=float(_get(cfg, "ppo_clip", 0.2)), standardise_returns=self.standardise_returns)
+        self.ret_ms = self.updater.ret_stats
         self.actor_params, self.critic_params = self.updater.actor, self.updater.critic
 
     # ---- reference interface ---------------------------------------------------------------

@@ -148,7 +148,10 @@ int launch_backward_rows(int P, const AgentMap& am, const float* params, const m
 
 // ---- the elementwise stage ---------------------------------------------------------------------------------
 struct AcArgs {
-    int P, T, B, A, n_steps, mode;  // mode 0: A2C; 1: PPO prepare (returns + old log-probs, no gradients); 2: PPO epoch
+    // mode 0: A2C; 1: PPO prepare (returns + old log-probs, no gradients); 2: PPO epoch (stored returns);
+    // 3: A2C on stored returns; 4: returns only (3 and 4 bracket the statistics update of standardise_returns)
+    int P, T, B, A, n_steps, mode;
+    int standardise;                // returns are de-standardised / standardised with st (ac/model.py:195-204)
     float gk[18];                   // (float)(gamma ** k), k = 0..n_steps, formed in fp64 like python's gamma**step
     float ent_coef, vlc, ppo_clip;
 };
@@ -165,6 +168,8 @@ struct AcBufs {
     float* ret;           // [P][T*B]  PPO: returns kept across epochs
     float* oldlogp;       // [P][T*B]  PPO: log-prob under the pre-update policy
     float* partial;       // [blocks][4] per-block sums of (actor row, value row, entropy row, filled)
+    float* rpartial;      // [blocks][P][2] per-block sums of the raw returns and their squares (standardise_returns)
+    RetStats st;
 };
 
 static __global__ __launch_bounds__(256) void ac_elem_kernel(AcArgs a, marlhip_batch bt, AcBufs w) {
@@ -180,18 +185,29 @@ static __global__ __launch_bounds__(256) void ac_elem_kernel(AcArgs a, marlhip_b
     for (int p = 0; p < a.P; ++p) {
         const size_t pi = (size_t)p * TB + i;
         float ret;
-        if (a.mode == 2) {
+        if (a.mode == 2 || a.mode == 3) {
             ret = w.ret[pi];
+            if (a.standardise) ret = (ret - w.st.mean[p]) / sqrtf(w.st.var[p]);  // with the statistics updated from this batch
         } else {  // compute_nstep_returns (utils/utils.py:38-63)
             ret = 0.f;
             for (int k = 0; k <= a.n_steps; ++k) {
                 const int tt = t + k;
                 if (tt >= a.T) break;
                 const float nd = 1.f - bt.dones[(size_t)tt * a.B + b];
-                if (k == a.n_steps) ret += a.gk[k] * w.vnext[(size_t)p * (TB + a.B) + (size_t)tt * a.B + b] * nd;
-                else ret += a.gk[k] * bt.rewards[p * aas + ((size_t)tt * a.B + b) * ars] * nd;
+                if (k == a.n_steps) {
+                    float vn = w.vnext[(size_t)p * (TB + a.B) + (size_t)tt * a.B + b];
+                    if (a.standardise) vn = vn * sqrtf(w.st.var[p]) + w.st.mean[p];  // model.py:195-196, statistics BEFORE the update
+                    ret += a.gk[k] * vn * nd;
+                } else {
+                    ret += a.gk[k] * bt.rewards[p * aas + ((size_t)tt * a.B + b) * ars] * nd;
+                }
             }
-            if (a.mode == 1 && inside) w.ret[pi] = ret;
+            if ((a.mode == 1 || a.mode == 4) && inside) w.ret[pi] = ret;
+            if (a.standardise && (a.mode == 1 || a.mode == 4)) {
+                __shared__ float shr[8];
+                ret_block_partials(inside ? ret : 0.f, shr, w.rpartial + ((size_t)blockIdx.x * a.P + p) * 2);
+            }
+            if (a.mode == 4) continue;
         }
         const float* l = w.logits + pi * a.A;
         float m = l[0];
@@ -209,7 +225,7 @@ static __global__ __launch_bounds__(256) void ac_elem_kernel(AcArgs a, marlhip_b
         }
         const float val = w.v[pi], adv = ret - val;
         float coef;  // d(actor row loss) / d logp
-        if (a.mode == 0) {
+        if (a.mode == 0 || a.mode == 3) {
             la += -logp * adv - a.ent_coef * H;
             coef = -adv;
         } else {  // clipped surrogate (model.py:318-327); min() ties split the gradient, clamp passes it inside the range
@@ -231,7 +247,7 @@ static __global__ __launch_bounds__(256) void ac_elem_kernel(AcArgs a, marlhip_b
         lv += (ret - val) * (ret - val);
         es += H;
     }
-    if (a.mode == 1) return;
+    if (a.mode == 1 || a.mode == 4) return;
     if (inside) {
         w.lrow_a[i] = fl * la;
         w.lrow_v[i] = fl * lv;
@@ -283,7 +299,7 @@ static __global__ __launch_bounds__(1024) void ac_metrics_kernel(int nblocks, fl
 
 // workspace: [vnext | v | logits | dlogits | dv | lrow_a | lrow_v | ent | ret | oldlogp | loss scratch 4][backward workspace]
 struct AcWs {
-    int64_t vnext, v, logits, dlogits, dv, lrow_a, lrow_v, ent, ret, oldlogp, partial, scratch, bwd, total;
+    int64_t vnext, v, logits, dlogits, dv, lrow_a, lrow_v, ent, ret, oldlogp, partial, rpartial, scratch, bwd, total;
 };
 
 template <class SA, class SC>
@@ -303,6 +319,7 @@ AcWs ac_ws_layout(int P, int T, int B) {
     w.ret = take(P * TB);
     w.oldlogp = take(P * TB);
     w.partial = take(4 * ((TB + 255) / 256));
+    w.rpartial = take(2 * P * ((TB + 255) / 256));
     w.scratch = take(8);
     w.bwd = o;
     const int64_t ba = backward_ws_bytes<SA>(P, T, B), bc = backward_ws_bytes<SC>(P, T, B);
@@ -324,15 +341,25 @@ int ac_step(int P, const AgentMap& am, const float* actor, const float* critic, 
     w.logits = f(wl.logits); w.v = f(wl.v); w.vnext = f(wl.vnext); w.dlogits = f(wl.dlogits); w.dv = f(wl.dv);
     w.lrow_a = f(wl.lrow_a); w.lrow_v = f(wl.lrow_v); w.ent = f(wl.ent); w.ret = f(wl.ret); w.oldlogp = f(wl.oldlogp);
     w.partial = f(wl.partial);
+    w.rpartial = f(wl.rpartial);
+    const bool std_on = c->ret_mean != nullptr;
+    w.st.mean = c->ret_mean; w.st.var = c->ret_var; w.st.count = c->ret_count;
     AcArgs a;
     a.P = P; a.T = T; a.B = B; a.A = A; a.n_steps = c->n_steps; a.mode = mode;
     for (int k = 0; k <= c->n_steps; ++k) a.gk[k] = (float)pow(c->gamma, (double)k);
     a.ent_coef = c->entropy_coef; a.vlc = c->value_loss_coef; a.ppo_clip = c->ppo_clip;
+    a.standardise = std_on ? 1 : 0;
     int rc;
     timing_begin(TIMER_LOSSGRAD, st);
     if (mode != 2) {  // target-critic values of all T+1 observations (model.py:190-193); PPO reuses the returns across epochs
         rc = launch_forward_rows<SC>(P, am, target, bt, TB + B, f(wl.vnext), st);
         if (rc != 0) return rc;
+    }
+    if (std_on && mode == 0) {  // A2C with standardise_returns: raw returns -> statistics update -> A2C on the stored returns
+        a.mode = 4;
+        hipLaunchKernelGGL(ac_elem_kernel, dim3((TB + 255) / 256), dim3(256), 0, st, a, *bt, w);
+        hipLaunchKernelGGL(ret_stats_update_kernel, dim3(1), dim3(64), 0, st, w.st, (const float*)w.rpartial, (TB + 255) / 256, P, TB);
+        a.mode = 3;
     }
     rc = launch_forward_rows<SA>(P, am, actor, bt, TB, f(wl.logits), st);
     if (rc != 0) return rc;
@@ -343,6 +370,8 @@ int ac_step(int P, const AgentMap& am, const float* actor, const float* critic, 
     hipLaunchKernelGGL(ac_elem_kernel, dim3((TB + 255) / 256), dim3(256), 0, st, a, *bt, w);
     MARL_CHECK_LAUNCH("ac_elem_kernel");
     if (mode == 1) {
+        if (std_on)
+            hipLaunchKernelGGL(ret_stats_update_kernel, dim3(1), dim3(64), 0, st, w.st, (const float*)w.rpartial, (TB + 255) / 256, P, TB);
         timing_end(TIMER_LOSSGRAD, st);
         return 0;
     }
@@ -404,6 +433,8 @@ static int ac_call(const marlhip_net_shape* s, const float* actor, const float* 
     MARL_REQUIRE(bt->obss && bt->actions && bt->rewards && bt->dones && bt->filled, "ac_loss_grad: NULL batch field");
     MARL_REQUIRE(bt->max_len > 0 && bt->batch > 0, "ac_loss_grad: empty batch");
     MARL_REQUIRE(c->n_steps >= 1 && c->n_steps <= 16, "ac_loss_grad: n_steps %d outside [1, 16]", c->n_steps);
+    MARL_REQUIRE((c->ret_mean == nullptr) == (c->ret_var == nullptr) && (c->ret_mean == nullptr) == (c->ret_count == nullptr),
+                 "ac_loss_grad: return statistics must be given together (mean, var, count) or not at all");
 #define X(d, h)                                                                                                                  \
     if (s->obs_dim == d && s->hidden == h)                                                                                        \
         return ac_step<d, h, 6>(s->n_agents, agent_map(s), actor, critic, target, bt, c, mode, ws, ws_bytes, actor_grad, critic_grad, metrics, \

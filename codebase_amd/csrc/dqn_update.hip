@@ -32,14 +32,16 @@ extern "C" int64_t marlhip_dqn_workspace_bytes(const marlhip_net_shape* s, int32
 
 static int lossgrad_dispatch(const marlhip_net_shape* s, const float* params, const float* target_params, const marlhip_batch* bt,
                              const ReplaySrc* rsrc, float gamma, int32_t double_q, int32_t mode, void* workspace,
-                             int64_t workspace_bytes, float* grad, float* loss, void* stream, const QmixCtx* qx = nullptr) {
-    MARL_REQUIRE(mode == 0 || mode == 1 || (mode == 2 && qx != nullptr), "dqn_loss_grad: mode %d unknown (0 = IDQN, 1 = VDN)", mode);
+                             int64_t workspace_bytes, float* grad, float* loss, void* stream, const QmixCtx* qx = nullptr,
+                             const RetStats* rst = nullptr) {
+    MARL_REQUIRE(mode == 0 || mode == 1 || (mode == 2 && qx != nullptr) || (mode == 3 && rst != nullptr),
+                 "dqn_loss_grad: mode %d unknown (0 = IDQN, 1 = VDN)", mode);
     if (agent_map_validate(s) != 0) return -1;
     MARL_REQUIRE(bt->act_agent_stride == 0 && bt->act_row_stride == 0, "dqn_loss_grad: action / reward strides are an actor-critic option");
 #define X(d, h, a)                                                                                                          \
     if (s->obs_dim == d && s->hidden == h && s->n_actions == a)                                                             \
         return launch_lossgrad<MlpShape<d, h, a>>(s, params, target_params, bt, rsrc, gamma, double_q, mode, workspace,       \
-                                                  workspace_bytes, grad, loss, (hipStream_t)stream, qx);
+                                                  workspace_bytes, grad, loss, (hipStream_t)stream, qx, rst);
     MARL_UPD_SHAPES(X)
 #undef X
     set_error("no update kernel for net shape D=%d H=%d A=%d", s->obs_dim, s->hidden, s->n_actions);
@@ -72,6 +74,46 @@ extern "C" int marlhip_dqn_loss_grad_replay(const marlhip_net_shape* s, const fl
     ReplaySrc src;
     src.rb = *rb; src.idx = idx; src.idx_out = idx_out; src.seed = seed; src.counter = counter; src.length = length;
     return lossgrad_dispatch(s, params, target_params, &bt, &src, gamma, double_q, mode, workspace, workspace_bytes, grad, loss, stream);
+}
+
+// ---- IDQN with standardise_returns (QNetwork._compute_loss, marlbase/dqn/model.py:146-158) -------------------------------
+static int std_stats(const marlhip_ret_stats* st, RetStats* out) {
+    MARL_REQUIRE(st && st->mean && st->var && st->count, "dqn_loss_grad_std: NULL return statistics");
+    out->mean = st->mean; out->var = st->var; out->count = st->count;
+    return 0;
+}
+
+extern "C" int marlhip_dqn_loss_grad_std(const marlhip_net_shape* s, const float* params, const float* target_params,
+                                         const marlhip_batch* batch, float gamma, int32_t double_q, const marlhip_ret_stats* stats,
+                                         void* workspace, int64_t workspace_bytes, float* grad, float* loss, void* stream) {
+    MARL_REQUIRE(s && params && target_params && batch && workspace && grad && loss, "dqn_loss_grad_std: NULL pointer");
+    MARL_REQUIRE(batch->obss && batch->actions && batch->rewards && batch->dones && batch->filled, "dqn_loss_grad_std: NULL batch field");
+    MARL_REQUIRE(batch->max_len > 0 && batch->batch > 0, "dqn_loss_grad_std: empty batch");
+    RetStats rst;
+    if (std_stats(stats, &rst) != 0) return -1;
+    return lossgrad_dispatch(s, params, target_params, batch, nullptr, gamma, double_q, 3, workspace, workspace_bytes, grad, loss, stream,
+                             nullptr, &rst);
+}
+
+extern "C" int marlhip_dqn_loss_grad_std_replay(const marlhip_net_shape* s, const float* params, const float* target_params,
+                                                const marlhip_replay_shape* rs, const marlhip_replay_buffers* rb, const int32_t* idx,
+                                                int32_t batch, int32_t length, uint64_t seed, uint32_t counter, int32_t* idx_out,
+                                                float gamma, int32_t double_q, const marlhip_ret_stats* stats, void* workspace,
+                                                int64_t workspace_bytes, float* grad, float* loss, void* stream) {
+    MARL_REQUIRE(s && params && target_params && rs && rb && workspace && grad && loss, "dqn_loss_grad_std_replay: NULL pointer");
+    MARL_REQUIRE(rb->obs && rb->act && rb->rew && rb->done && rb->filled, "dqn_loss_grad_std_replay: NULL replay buffer");
+    MARL_REQUIRE(rs->n_agents == s->n_agents && rs->obs_dim == s->obs_dim, "dqn_loss_grad_std_replay: replay / net shape mismatch");
+    MARL_REQUIRE(batch > 0 && rs->max_len > 0, "dqn_loss_grad_std_replay: empty batch");
+    MARL_REQUIRE(idx != nullptr || (length > 0 && length <= rs->capacity), "dqn_loss_grad_std_replay: length %d out of range", length);
+    RetStats rst;
+    if (std_stats(stats, &rst) != 0) return -1;
+    marlhip_batch bt = {};
+    bt.max_len = rs->max_len;
+    bt.batch = batch;
+    ReplaySrc src;
+    src.rb = *rb; src.idx = idx; src.idx_out = idx_out; src.seed = seed; src.counter = counter; src.length = length;
+    return lossgrad_dispatch(s, params, target_params, &bt, &src, gamma, double_q, 3, workspace, workspace_bytes, grad, loss, stream,
+                             nullptr, &rst);
 }
 
 // ---- QMIX (QMixNetwork, marlbase/dqn/model.py:334-443) ------------------------------------------------------

@@ -112,6 +112,7 @@ struct MixBufs {
     float* dq;       // [T][B] (agent stride 0) or [P][T][B]
     float* lrow;     // [T][B] filled * delta^2
     int dq_agent_stride;
+    float* rew_all;     // optional [P][T][B]: every agent's reward (MODE 1 publishes it for the standardising mixer)
     const float* dout;  // MODE 4: [P][T][B][A] external gradient w.r.t. EVERY network output (actor-critic learners)
 };
 
@@ -286,6 +287,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dqn_lossgrad_kernel(con
                 const float ch = gather_rows(q, lane, cur.a_sel);
                 if (g == 0 && rowok) {
                     mix.chosen[((size_t)p * T + t) * B + bj] = ch;
+                    if (mix.rew_all != nullptr) mix.rew_all[((size_t)p * T + t) * B + bj] = cur.rw;
                     if (p == 0) {
                         mix.r0[(size_t)t * B + bj] = cur.rw;
                         mix.dn[(size_t)t * B + bj] = cur.dn;
@@ -634,6 +636,7 @@ static __global__ __launch_bounds__(256) void adam_kernel(int64_t n, int nblocks
 
 #include "dqn_update_tp.h"
 #include "qmix.h"
+#include "ret_stats.h"
 
 namespace marl {
 
@@ -730,7 +733,9 @@ inline WsLayout ws_layout(int P, int nwg, int rec, int pack, int T, int B) {
     w.rec_bytes = (int64_t)P * nwg * rec * sizeof(float);
     w.pack_off = (w.rec_bytes + 15) & ~(int64_t)15;
     w.mix_off = w.pack_off + (int64_t)P * pack * sizeof(float);
-    w.total = ((w.mix_off + (int64_t)(4 * P + 5) * T * B * sizeof(float) + 7) & ~(int64_t)7) + 128;  // mixer buffers of either path
+    // mixer buffers of either path ((4P+5) planes of T*B) + the standardising mixer's block partials (2 P per 256 rows)
+    const int64_t tb = (int64_t)T * B, mixf = (4 * P + 5) * tb + 2 * P * (tb / 256 + 1);
+    w.total = ((w.mix_off + mixf * (int64_t)sizeof(float) + 7) & ~(int64_t)7) + 128;
     return w;
 }
 
@@ -775,7 +780,7 @@ int qmix_dispatch_reduce(int P, const QmixCtx& qx, int T, int B, const float* lo
 template <class S, bool REPLAY>
 int launch_lossgrad_tp(const marlhip_net_shape* s, const float* params, const float* tparams, const marlhip_batch* bt,
                        const ReplaySrc& src, float gamma, int double_q, int mode, void* ws, int64_t ws_bytes, float* grad,
-                       float* loss, hipStream_t st, const QmixCtx* qx) {
+                       float* loss, hipStream_t st, const QmixCtx* qx, const RetStats* rst) {
     constexpr int W = 4, TPW = S::H / 64, NB = 2, NBF = MARL_TP_NBF, NT = W * TPW, REC = S::NPARAM + 2;
     const int P = s->n_agents, T = bt->max_len, B = bt->batch;
     const AgentMap am = agent_map(s);
@@ -805,6 +810,10 @@ int launch_lossgrad_tp(const marlhip_net_shape* s, const float* params, const fl
         QmixIo io = {mix.chosen, mix.tqsel, mix.rew, mix.dn, mix.fl, mix.dq, mix.lrow, nullptr};
         const int rc = qmix_dispatch_mix<S::D, REPLAY>(P, *qx, bt, src, io, gamma, st);
         if (rc != 0) return rc;
+    } else if (mode == 3) {  // IDQN, standardised returns; block partials live behind lrow (2 P ceil(tb/256) <= tb floats)
+        const int rc = launch_std_mixer(P, (int)tb, gamma, *rst, mix.chosen, mix.tqsel, mix.rew, mix.dn, mix.fl, mix.dq, mix.lrow,
+                                        mixf + (size_t)(4 * P + 5) * tb, st);
+        if (rc != 0) return rc;
     } else {
         hipLaunchKernelGGL(tp_mix_kernel, dim3((unsigned)((tb + 255) / 256 > 1024 ? 1024 : (tb + 255) / 256)), dim3(256), 0, st, mix, P,
                            T, B, gamma, mode == 1 ? 1 : 0);
@@ -822,9 +831,9 @@ int launch_lossgrad_tp(const marlhip_net_shape* s, const float* params, const fl
 template <class S, bool REPLAY>
 int launch_lossgrad_src(const marlhip_net_shape* s, const float* params, const float* tparams, const marlhip_batch* bt,
                         const ReplaySrc& src, float gamma, int double_q, int mode, void* ws, int64_t ws_bytes, float* grad,
-                        float* loss, hipStream_t st, const QmixCtx* qx) {
+                        float* loss, hipStream_t st, const QmixCtx* qx, const RetStats* rst) {
     if constexpr (S::H > 64) {
-        return launch_lossgrad_tp<S, REPLAY>(s, params, tparams, bt, src, gamma, double_q, mode, ws, ws_bytes, grad, loss, st, qx);
+        return launch_lossgrad_tp<S, REPLAY>(s, params, tparams, bt, src, gamma, double_q, mode, ws, ws_bytes, grad, loss, st, qx, rst);
     } else {
     using L = UpdLds<S>;
     const int P = s->n_agents, T = bt->max_len, B = bt->batch;
@@ -855,10 +864,13 @@ int launch_lossgrad_src(const marlhip_net_shape* s, const float* params, const f
     MixBufs mix;
     mix.chosen = mixf; mix.tqsel = mixf + P * tb; mix.r0 = mixf + 2 * P * tb; mix.dn = mix.r0 + tb; mix.fl = mix.dn + tb;
     mix.dq = mix.fl + tb; mix.lrow = mix.dq + tb; mix.dq_agent_stride = 0;
-    if (mode == 2) {  // QMIX: one dq plane per agent
+    mix.rew_all = nullptr;
+    mix.dout = nullptr;
+    if (mode == 2 || mode == 3) {  // QMIX / standardised IDQN: one dq plane per agent
         mix.lrow = mix.dq + P * tb;
         mix.dq_agent_stride = (int)tb;
     }
+    if (mode == 3) mix.rew_all = mix.lrow + tb;  // [P][tb]; the statistics' block partials follow it
     const dim3 grid(pl.nwg, P), block(256);
     timing_begin(TIMER_LOSSGRAD, st);
     if (mode == 0) {
@@ -870,6 +882,10 @@ int launch_lossgrad_src(const marlhip_net_shape* s, const float* params, const f
         if (mode == 2) {
             QmixIo io = {mix.chosen, mix.tqsel, mix.r0, mix.dn, mix.fl, mix.dq, mix.lrow, nullptr};
             const int rc = qmix_dispatch_mix<S::D, REPLAY>(P, *qx, bt, src, io, gamma, st);
+            if (rc != 0) return rc;
+        } else if (mode == 3) {
+            const int rc = launch_std_mixer(P, (int)tb, gamma, *rst, mix.chosen, mix.tqsel, mix.rew_all, mix.dn, mix.fl, mix.dq,
+                                            mix.lrow, mixf + (size_t)(4 * P + 5) * tb, st);
             if (rc != 0) return rc;
         } else {
             hipLaunchKernelGGL(vdn_mix_kernel, dim3((unsigned)((tb + 255) / 256 > 1024 ? 1024 : (tb + 255) / 256)), dim3(256), 0, st,
@@ -891,11 +907,11 @@ int launch_lossgrad_src(const marlhip_net_shape* s, const float* params, const f
 template <class S>
 int launch_lossgrad(const marlhip_net_shape* s, const float* params, const float* tparams, const marlhip_batch* bt,
                     const ReplaySrc* rsrc, float gamma, int double_q, int mode, void* ws, int64_t ws_bytes, float* grad, float* loss,
-                    hipStream_t st, const QmixCtx* qx) {
+                    hipStream_t st, const QmixCtx* qx, const RetStats* rst) {
     if (rsrc != nullptr)
-        return launch_lossgrad_src<S, true>(s, params, tparams, bt, *rsrc, gamma, double_q, mode, ws, ws_bytes, grad, loss, st, qx);
+        return launch_lossgrad_src<S, true>(s, params, tparams, bt, *rsrc, gamma, double_q, mode, ws, ws_bytes, grad, loss, st, qx, rst);
     ReplaySrc none = {};
-    return launch_lossgrad_src<S, false>(s, params, tparams, bt, none, gamma, double_q, mode, ws, ws_bytes, grad, loss, st, qx);
+    return launch_lossgrad_src<S, false>(s, params, tparams, bt, none, gamma, double_q, mode, ws, ws_bytes, grad, loss, st, qx, rst);
 }
 
 }  // namespace marl

@@ -1,0 +1,106 @@
+// standardise_returns: RunningMeanStd (marlbase/utils/standardise_stream.py:6-41) kept on the device.
+// mean / var are fp32 [P] like the reference's tensors, count is the python float (fp64 here); the parallel-variance
+// update runs in fp64 and is rounded once per update (the reference rounds every intermediate to fp32).
+#pragma once
+
+namespace marl {
+
+struct RetStats {
+    float* mean;    // [P]
+    float* var;     // [P]
+    double* count;  // [1]
+};
+
+// per-block sums of x and x^2 over a block's (row, agent) values: fixed-order wave butterfly + 4 waves
+__device__ __forceinline__ void ret_block_partials(float x, float* sh /*[2][4]*/, float* out2 /*[2]*/) {
+    float s = x, q = x * x;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        s += __shfl_xor(s, off);
+        q += __shfl_xor(q, off);
+    }
+    __syncthreads();  // sh may still be read from the previous agent
+    if ((threadIdx.x & 63) == 0) {
+        sh[threadIdx.x >> 6] = s;
+        sh[4 + (threadIdx.x >> 6)] = q;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out2[0] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+        out2[1] = (sh[4] + sh[5]) + (sh[6] + sh[7]);
+    }
+}
+
+// RunningMeanStd.update: batch mean / unbiased variance of the n values of every agent from the block partials
+// partial[blk][p][2], then update_from_moments.  One workgroup of 64 threads, thread p owns agent p.
+static __global__ __launch_bounds__(64) void ret_stats_update_kernel(RetStats st, const float* __restrict__ partial, int nblk, int P,
+                                                                     int n) {
+    const int p = threadIdx.x;
+    const double count = st.count[0];
+    if (p < P) {
+        double s = 0.0, q = 0.0;
+        for (int b = 0; b < nblk; ++b) {
+            s += (double)partial[((size_t)b * P + p) * 2];
+            q += (double)partial[((size_t)b * P + p) * 2 + 1];
+        }
+        const double bc = (double)n, bm = s / bc;
+        const double bv = n > 1 ? (q - s * s / bc) / (bc - 1.0) : 0.0;
+        const double mean = (double)st.mean[p], var = (double)st.var[p];
+        const double delta = bm - mean, tot = count + bc;
+        const double m2 = var * count + bv * bc + delta * delta * count * bc / tot;
+        st.mean[p] = (float)(mean + delta * bc / tot);
+        st.var[p] = (float)(m2 / tot);
+    }
+    __syncthreads();
+    if (p == 0) st.count[0] = count + (double)n;
+}
+
+// IDQN with standardised returns (QNetwork._compute_loss, dqn/model.py:146-163), between the agent-forward and
+// agent-backward passes: returns from de-standardised bootstrap values (kept in the dq plane), statistics over ALL T*B
+// entries of every agent, then dq_p = 2 filled (chosen_p - standardised return_p).
+static __global__ __launch_bounds__(256) void std_returns_kernel(int P, int n, float gamma, RetStats st, const float* __restrict__ tqsel,
+                                                                 const float* __restrict__ rew, const float* __restrict__ dn,
+                                                                 float* __restrict__ ret, float* __restrict__ partial) {
+    __shared__ float sh[8];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool in = i < n;
+    const float nd = in ? 1.f - dn[i] : 0.f;
+    for (int p = 0; p < P; ++p) {
+        float r = 0.f;
+        if (in) {
+            const float tq = tqsel[(size_t)p * n + i] * sqrtf(st.var[p]) + st.mean[p];
+            r = rew[(size_t)p * n + i] + gamma * tq * nd;
+            ret[(size_t)p * n + i] = r;
+        }
+        ret_block_partials(r, sh, partial + ((size_t)blockIdx.x * P + p) * 2);
+    }
+}
+
+static __global__ __launch_bounds__(256) void std_dq_kernel(int P, int n, RetStats st, const float* __restrict__ chosen,
+                                                            const float* __restrict__ fl, float* __restrict__ ret_dq,
+                                                            float* __restrict__ lrow) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float f = fl[i];
+    float l = 0.f;
+    for (int p = 0; p < P; ++p) {
+        const float r = (ret_dq[(size_t)p * n + i] - st.mean[p]) / sqrtf(st.var[p]);
+        const float delta = chosen[(size_t)p * n + i] - r;
+        ret_dq[(size_t)p * n + i] = 2.f * f * delta;
+        l += delta * delta;
+    }
+    lrow[i] = f * l;
+}
+
+// the three launches; `partial` needs 2 * P * ceil(n / 256) floats
+inline int launch_std_mixer(int P, int n, float gamma, const RetStats& st, const float* chosen, const float* tqsel, const float* rew,
+                            const float* dn, const float* fl, float* dq, float* lrow, float* partial, hipStream_t stream) {
+    const int nblk = (n + 255) / 256;
+    hipLaunchKernelGGL(std_returns_kernel, dim3(nblk), dim3(256), 0, stream, P, n, gamma, st, tqsel, rew, dn, dq, partial);
+    hipLaunchKernelGGL(ret_stats_update_kernel, dim3(1), dim3(64), 0, stream, st, (const float*)partial, nblk, P, n);
+    hipLaunchKernelGGL(std_dq_kernel, dim3(nblk), dim3(256), 0, stream, P, n, st, chosen, fl, dq, lrow);
+    MARL_CHECK_LAUNCH("standardise_returns mixer");
+    return 0;
+}
+
+}  // namespace marl

@@ -96,8 +96,10 @@ class QNetwork:
         opt = get("optimizer", "Adam")
         if (opt if isinstance(opt, str) else getattr(opt, "__name__", "")) != "Adam":
             raise NotImplementedError(f"optimizer {opt}: the fused step implements torch.optim.Adam")
-        if get("standardise_returns", False):
-            raise NotImplementedError("standardise_returns is a 'next' row (DESIGN.md)")
+        self.standardise_returns = bool(get("standardise_returns", False))
+        if self.standardise_returns and type(self).__name__ != "QNetwork":
+            # the reference's VDN / QMIX keep RunningMeanStd(shape=(1,)) but feed it [T, B] returns: per-batch-column statistics
+            raise NotImplementedError("standardise_returns is built for the independent learner (QNetwork) only (DESIGN.md)")
         self.action_space = action_space
         self.n_agents = len(obs_dims)
         self.device = torch.device(device)
@@ -113,10 +115,11 @@ class QNetwork:
         self.double_q = bool(get("double_q", True))
         self.target_update_interval_or_tau = get("target_update_interval_or_tau", 200)
         self.updater = _hip.DqnUpdater(self.spec, self.params, self.target_params, lr=float(get("lr", 3e-4)),
-                                       gamma=self.gamma, grad_clip=self.grad_clip, double_q=self.double_q)
+                                       gamma=self.gamma, grad_clip=self.grad_clip, double_q=self.double_q,
+                                       standardise_returns=self.standardise_returns)
+        self.ret_ms = self.updater.ret_stats  # RunningMeanStd(shape=(n_agents,)) on the device (dqn/model.py:88-89)
         self.updates = 0
         self.last_target_update = 0
-        self.standardise_returns = False
         self.mode = 0  # IDQN
         self._obs1 = torch.zeros(self.n_agents, 1, self.spec.obs_dim, device=self.device)
         self._u1 = torch.ones(1, device=self.device)

@@ -155,7 +155,7 @@ class VectorisedIDQN:
                           use_proper_termination=self.proper)
         self.env_steps += self.fin_length.sum()
         self.rounds += 1
-        if train and self.dist is None and self.U > 0 and m.mode != 2:  # the n-updates library call has no mixer (QMIX loops here)
+        if train and self.dist is None and self.U > 0 and m.mode != 2 and not m.standardise_returns:  # the n-updates library call has no mixer / no return statistics (those loop here)
             if self._fused is None:
                 self._fused = _hip.FusedLearner(m.updater, self.replay, self.B, m.target_update_interval_or_tau, mode=m.mode)
             length = min(self.rounds * self.N, self.capacity)

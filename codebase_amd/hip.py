@@ -8,7 +8,7 @@ from dataclasses import dataclass
 import torch
 
 from . import _lib
-from ._lib import (AcConfig, BatchStruct, IdqnLearner, QmixMixer, LbfBuffers, LbfConfig, MarlHipError, NetShape, ReplayBuffers, ReplayShape, check, lib)
+from ._lib import (AcConfig, BatchStruct, IdqnLearner, RetStatsStruct, QmixMixer, LbfBuffers, LbfConfig, MarlHipError, NetShape, ReplayBuffers, ReplayShape, check, lib)
 
 Batch = namedtuple("Batch", ["obss", "actions", "rewards", "dones", "filled", "action_mask"])  # dqn/train.py:14-16
 
@@ -185,13 +185,30 @@ class DeviceReplay:
         return Batch(obss, actions, rewards, dones, filled, None)
 
 
+class RunningReturnStats:
+    """RunningMeanStd(shape=(n_agents,)) of marlbase/utils/standardise_stream.py, resident on the device."""
+
+    def __init__(self, n_agents, device, epsilon=1e-4):
+        self.mean = torch.zeros(n_agents, dtype=torch.float32, device=device)
+        self.var = torch.ones(n_agents, dtype=torch.float32, device=device)
+        self.count_t = torch.full((1,), epsilon, dtype=torch.float64, device=device)
+
+    @property
+    def count(self):
+        return float(self.count_t.item())
+
+    def c(self):
+        return RetStatsStruct(self.mean.data_ptr(), self.var.data_ptr(), self.count_t.data_ptr())
+
+
 class DqnUpdater:
     """K5-K8: loss + gradient, clip, Adam, target update over flat per-agent parameter blocks."""
 
     def __init__(self, spec: NetSpec, params, target, lr=3e-4, betas=(0.9, 0.999), eps=1e-8, gamma=0.99, grad_clip=1.0,
-                 double_q=True):
+                 double_q=True, standardise_returns=False):
         _require_gpu()
         self.spec, self.params, self.target = spec, params, target
+        self.ret_stats = RunningReturnStats(spec.n_agents, params.device) if standardise_returns else None
         self.lr, self.betas, self.eps, self.gamma = lr, betas, eps, gamma
         self.grad_clip = float(grad_clip) if grad_clip else 0.0
         self.double_q = int(bool(double_q))
@@ -219,6 +236,14 @@ class DqnUpdater:
         bs = BatchStruct(batch.obss.data_ptr(), batch.actions.data_ptr(), batch.rewards.data_ptr(), batch.dones.data_ptr(),
                          batch.filled.data_ptr(), T, B)
         s = self.spec.c()
+        if self.ret_stats is not None:
+            if mode != 0:
+                raise NotImplementedError("standardise_returns is built for independent learners (IDQN) only")
+            st = self.ret_stats.c()
+            check(lib.marlhip_dqn_loss_grad_std(ctypes.byref(s), _ptr(self.params), _ptr(self.target), ctypes.byref(bs),
+                                                float(self.gamma), self.double_q, ctypes.byref(st), _ptr(ws), ws.numel(),
+                                                _ptr(self.grad), _ptr(self.loss), _stream()), "dqn_loss_grad_std")
+            return self.loss, self.grad
         check(lib.marlhip_dqn_loss_grad(ctypes.byref(s), _ptr(self.params), _ptr(self.target), ctypes.byref(bs), float(self.gamma),
                                         self.double_q, int(mode), _ptr(ws), ws.numel(), _ptr(self.grad), _ptr(self.loss), _stream()),
               "dqn_loss_grad")
@@ -228,6 +253,16 @@ class DqnUpdater:
         """Sampling fused into the loss/grad kernel: rows are gathered from the replay in-kernel (no Batch)."""
         ws = self._workspace(replay.T, batch_size)
         s = self.spec.c()
+        if self.ret_stats is not None:
+            if mode != 0:
+                raise NotImplementedError("standardise_returns is built for independent learners (IDQN) only")
+            st = self.ret_stats.c()
+            check(lib.marlhip_dqn_loss_grad_std_replay(ctypes.byref(s), _ptr(self.params), _ptr(self.target), ctypes.byref(replay.shape),
+                                                       ctypes.byref(replay.bufs), _ptr(idx), int(batch_size), int(length or 0),
+                                                       int(seed) & (2**64 - 1), int(counter) & 0xFFFFFFFF, _ptr(idx_out),
+                                                       float(self.gamma), self.double_q, ctypes.byref(st), _ptr(ws), ws.numel(),
+                                                       _ptr(self.grad), _ptr(self.loss), _stream()), "dqn_loss_grad_std_replay")
+            return self.loss, self.grad
         check(lib.marlhip_dqn_loss_grad_replay(ctypes.byref(s), _ptr(self.params), _ptr(self.target), ctypes.byref(replay.shape),
                                                ctypes.byref(replay.bufs), _ptr(idx), int(batch_size), int(length or 0),
                                                int(seed) & (2**64 - 1), int(counter) & 0xFFFFFFFF, _ptr(idx_out),
@@ -320,8 +355,9 @@ class AcUpdater:
     `block` is ONE flat fp32 tensor [P*n_actor + P*n_critic]: actor blocks first (parameters() order), then critic."""
 
     def __init__(self, spec: NetSpec, block, target_critic, lr=3e-4, betas=(0.9, 0.999), eps=1e-8, gamma=0.99, n_steps=5,
-                 entropy_coef=0.001, value_loss_coef=0.5, grad_clip=False, ppo_clip=0.2):
+                 entropy_coef=0.001, value_loss_coef=0.5, grad_clip=False, ppo_clip=0.2, standardise_returns=False):
         _require_gpu()
+        self.ret_stats = RunningReturnStats(spec.n_agents, block.device) if standardise_returns else None
         s = spec.c()
         self.spec = spec
         self.n_actor = spec.nparams()
@@ -339,7 +375,10 @@ class AcUpdater:
         self.scratch = torch.zeros((block.numel() + 255) // 256 + 1, dtype=torch.float32, device=block.device)
         self.gnorm = torch.zeros(1, dtype=torch.float32, device=block.device)
         self.metrics = torch.zeros(5, dtype=torch.float32, device=block.device)
-        self.cfg = AcConfig(int(n_steps), float(entropy_coef), float(value_loss_coef), float(ppo_clip), float(gamma))
+        rs = self.ret_stats
+        self.cfg = AcConfig(int(n_steps), float(entropy_coef), float(value_loss_coef), float(ppo_clip), float(gamma),
+                            rs.mean.data_ptr() if rs else None, rs.var.data_ptr() if rs else None,
+                            rs.count_t.data_ptr() if rs else None)
         self.lr, self.betas, self.eps = lr, betas, eps
         self.grad_clip = float(grad_clip) if grad_clip else 0.0
         self.step = 0

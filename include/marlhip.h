@@ -264,6 +264,11 @@ typedef struct marlhip_ac_config {
     float entropy_coef, value_loss_coef;
     float ppo_clip;       /* PPO only */
     double gamma;         /* python float: gamma ** k is formed in fp64 and rounded once, like the reference */
+    /* cfg.standardise_returns (model.py:195-204): device statistics [P], [P], [1] as in marlhip_ret_stats, or all NULL.
+     * A2C: updated inside marlhip_a2c_loss_grad; PPO: inside marlhip_ppo_prepare (the epochs reuse them). */
+    float* ret_mean;
+    float* ret_var;
+    double* ret_count;
 } marlhip_ac_config;
 
 int marlhip_ac_critic_nparams(const marlhip_net_shape* s);
@@ -315,6 +320,26 @@ typedef struct marlhip_idqn_learner {
 int marlhip_idqn_update_n(const marlhip_idqn_learner* L, int32_t n_updates, int32_t length, uint64_t seed,
                           uint32_t counter0, int64_t* adam_step, int64_t* updates, int64_t* last_target_update,
                           void* stream);
+
+/* cfg.standardise_returns (QNetwork._compute_loss, model.py:146-158; RunningMeanStd, marlbase/utils/standardise_stream.py):
+ * device-resident running statistics, one (mean, var) pair per agent and the shared count (initialise mean 0, var 1,
+ * count 1e-4).  Each call de-standardises the bootstrap values with the CURRENT statistics, updates them with all T*B
+ * returns of every agent (filled or not, as the reference does), and standardises the returns with the UPDATED ones.
+ * Independent learners only (the reference's VDN / QMIX variants keep per-batch-column statistics by accident of shapes). */
+typedef struct marlhip_ret_stats {
+    float* mean;   /* [P] */
+    float* var;    /* [P] */
+    double* count; /* [1] */
+} marlhip_ret_stats;
+
+int marlhip_dqn_loss_grad_std(const marlhip_net_shape* s, const float* params, const float* target_params,
+                              const marlhip_batch* batch, float gamma, int32_t double_q, const marlhip_ret_stats* stats,
+                              void* workspace, int64_t workspace_bytes, float* grad, float* loss, void* stream);
+int marlhip_dqn_loss_grad_std_replay(const marlhip_net_shape* s, const float* params, const float* target_params,
+                                     const marlhip_replay_shape* rs, const marlhip_replay_buffers* rb, const int32_t* idx,
+                                     int32_t batch, int32_t length, uint64_t seed, uint32_t counter, int32_t* idx_out,
+                                     float gamma, int32_t double_q, const marlhip_ret_stats* stats, void* workspace,
+                                     int64_t workspace_bytes, float* grad, float* loss, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * QMIX learner.  Replaces QMixNetwork._compute_loss (marlbase/dqn/model.py:374-427) with QMixer.forward

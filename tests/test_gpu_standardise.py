@@ -1,0 +1,131 @@
+"""GPU parity of cfg.standardise_returns (RunningMeanStd, marlbase/utils/standardise_stream.py) in the IDQN learner
+(dqn/model.py:146-158) and the actor-critic learner (ac/model.py:195-204) against goldens from the reference's own classes:
+losses / metrics, parameters and the running (mean, var, count) after each of 3 updates; H=64 and the split H=128 path
+against the oracle port."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ac_update_port as ap
+from oracle import dqn_port as dp
+from tests.test_gpu_ac_update import dev_ac_batch, golden_ac_batch
+from tests.test_gpu_parity import DEV, dev_batch, golden_batch, hip, load
+
+pytestmark = pytest.mark.gpu
+
+
+def test_idqn_standardised_returns_match_reference_golden():
+    h = hip()
+    g = load("learner_std_idqn_H64.npz")
+    P, D, A, T, B = int(g["P"]), int(g["D"]), int(g["A"]), int(g["T"]), int(g["B"])
+    spec = h.NetSpec(P, D, 64, A)
+    params, target = torch.tensor(g["params0"], device=DEV), torch.tensor(g["target0"], device=DEV)
+    up = h.DqnUpdater(spec, params, target, lr=3e-4, gamma=0.99, grad_clip=1.0, double_q=True, standardise_returns=True)
+    last = 0
+    for i in range(3):
+        if i == 1:  # the in-kernel replay gather entry point on the second update
+            b = golden_batch(g, i)
+            rb = h.DeviceReplay(B, P, D, T)
+            rb.obs.copy_(b["obss"].permute(2, 0, 1, 3))
+            rb.act.copy_(b["actions"].permute(2, 0, 1).to(torch.uint8))
+            rb.rew.copy_(b["rewards"].permute(2, 0, 1))
+            rb.done.copy_(b["dones"].t().to(torch.uint8))
+            rb.filled.copy_(b["filled"].t().to(torch.uint8))
+            loss, _ = up.loss_grad_replay(rb, B, idx=torch.arange(B, dtype=torch.int32, device=DEV))
+        else:
+            loss, _ = up.loss_grad(dev_batch(h, golden_batch(g, i)))
+        hard = (i + 1 - last) >= 2
+        up.apply(hard_update=hard)
+        if hard:
+            last = i + 1
+        assert abs(loss.cpu().numpy()[0] - g["losses"][i]) <= 2e-5 * abs(g["losses"][i])
+        np.testing.assert_allclose(params.cpu().numpy(), g[f"params{i + 1}"], rtol=0, atol=3e-6)
+        np.testing.assert_allclose(up.ret_stats.mean.cpu().numpy(), g[f"mean{i + 1}"], rtol=2e-6)
+        np.testing.assert_allclose(up.ret_stats.var.cpu().numpy(), g[f"var{i + 1}"], rtol=5e-6)
+        assert abs(up.ret_stats.count - float(g[f"count{i + 1}"])) < 1e-6
+
+
+@pytest.mark.parametrize("P,T,B,D,H", [(3, 25, 40, 18, 128), (2, 4, 1, 15, 64), (4, 25, 300, 27, 64)])
+def test_idqn_standardised_returns_vs_oracle_port(P, T, B, D, H):
+    h = hip()
+    A = 6
+    params = dp.init_params(P, D, H, A, seed=1) + 0.05
+    target = dp.init_params(P, D, H, A, seed=3)
+    ms = dp.RunningMeanStd((P,))
+    ms.mean, ms.var, ms.count = torch.linspace(0.2, 0.6, P), torch.linspace(1.5, 0.7, P), 77.5
+    batch = dp.synthetic_batch(P, T, B, D, A, seed=5)
+    pr = params.clone().requires_grad_(True)
+    ref = dp.compute_loss(pr, target, batch, 0.99, True, D, H, A, ret_ms=ms)
+    ref.backward()
+    up = h.DqnUpdater(h.NetSpec(P, D, H, A), params.to(DEV), target.to(DEV), standardise_returns=True)
+    up.ret_stats.mean.copy_(torch.linspace(0.2, 0.6, P))
+    up.ret_stats.var.copy_(torch.linspace(1.5, 0.7, P))
+    up.ret_stats.count_t.fill_(77.5)
+    loss, grad = up.loss_grad(dev_batch(h, batch))
+    assert abs(loss.cpu().numpy()[0] - ref.item()) <= 3e-5 * abs(ref.item())
+    gref = pr.grad.numpy()
+    np.testing.assert_allclose(grad.cpu().numpy(), gref, rtol=3e-4, atol=3e-5 * max(1.0, np.abs(gref).max()))
+    np.testing.assert_allclose(up.ret_stats.mean.cpu().numpy(), ms.mean.numpy(), rtol=5e-6)
+    np.testing.assert_allclose(up.ret_stats.var.cpu().numpy(), ms.var.numpy(), rtol=2e-5)
+
+
+def test_a2c_standardised_returns_match_reference_golden():
+    h = hip()
+    g = load("learner_std_a2c_H64.npz")
+    P, D, A = int(g["P"]), int(g["D"]), int(g["A"])
+    t = lambda k: torch.tensor(g[k])  # noqa: E731
+    block = torch.cat([t("actor0").reshape(-1), t("critic0").reshape(-1)]).to(DEV)
+    up = h.AcUpdater(h.NetSpec(P, D, 64, A), block, t("target0").to(DEV).contiguous(), gamma=0.99, n_steps=5, entropy_coef=0.001,
+                     value_loss_coef=0.5, standardise_returns=True)
+    for i in range(3):
+        m = up.a2c_loss_grad(dev_ac_batch(golden_ac_batch(g, i))).cpu().numpy()
+        up.apply()
+        if int(g["steps"][i]) % 200 == 0:
+            up.target_critic.copy_(up.critic)
+        np.testing.assert_allclose(m[:4], g["metrics"][i], rtol=3e-5, atol=3e-6)
+        np.testing.assert_allclose(up.actor.cpu().numpy(), g[f"actor{i + 1}"], rtol=0, atol=3e-6)
+        np.testing.assert_allclose(up.critic.cpu().numpy(), g[f"critic{i + 1}"], rtol=0, atol=3e-6)
+        np.testing.assert_allclose(up.ret_stats.mean.cpu().numpy(), g[f"mean{i + 1}"], rtol=2e-6)
+        np.testing.assert_allclose(up.ret_stats.var.cpu().numpy(), g[f"var{i + 1}"], rtol=5e-6)
+
+
+def test_ppo_standardised_returns_vs_oracle_port():
+    h = hip()
+    P, T, N, D, H, A = 2, 25, 24, 15, 64, 6
+    actor = dp.init_params(P, D, H, A, seed=1) + 0.03
+    critic = torch.stack([dp.init_params(1, D, H, 1, seed=20 + p)[0] for p in range(P)]) + 0.02
+    target = torch.stack([dp.init_params(1, D, H, 1, seed=40 + p)[0] for p in range(P)])
+    lr = ap.Learner(actor, critic, D, H, A, num_epochs=3, standardise_returns=True)
+    lr.target = target.clone()
+    up = h.AcUpdater(h.NetSpec(P, D, H, A), torch.cat([actor.reshape(-1), critic.reshape(-1)]).to(DEV), target.to(DEV).contiguous(),
+                     standardise_returns=True)
+    for i in range(2):
+        batch = ap.synthetic_batch(P, T, N, D, A, seed=60 + i)
+        want = lr.update(batch, 7)
+        b = dev_ac_batch(batch)
+        up.ppo_prepare(b)
+        acc = np.zeros(4)
+        for _ in range(3):
+            acc += up.ppo_loss_grad(b).cpu().numpy()[:4]
+            up.apply()
+        np.testing.assert_allclose(acc / 3, [want["loss"], want["actor_loss"], want["value_loss"], want["entropy"]], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(up.actor.cpu().numpy(), lr.actor().detach().numpy(), rtol=0, atol=5e-6)
+        np.testing.assert_allclose(up.ret_stats.var.cpu().numpy(), lr.ret_ms.var.numpy(), rtol=1e-5)
+
+
+def test_standardise_returns_through_the_drivers(tmp_path, monkeypatch):
+    """algorithm.standardise_returns=True (the reference's sample sweep toggles it for idqn and ia2c, configs/sweeps/sample.yaml)"""
+    from codebase_amd import run
+
+    name = "lbforaging:Foraging-8x8-2p-3f-v3"
+    for algo, extra in (("idqn", ["algorithm.model.layers=[64,64]", "algorithm.updates_per_round=16", "algorithm.total_steps=300000",
+                                  "algorithm.eval_interval=100000", "algorithm.eval_episodes=128"]),
+                        ("ia2c", ["algorithm.model.actor.layers=[64,64]", "algorithm.model.critic.layers=[64,64]",
+                                  "algorithm.total_steps=60000", "algorithm.eval_interval=20000"])):
+        monkeypatch.setenv("MARLHIP_RUN_DIR", str(tmp_path / algo))
+        df = run.main([f"+algorithm={algo}", f"env.name={name}", "env.time_limit=25", "env.parallel_envs=128", "seed=1",
+                       "algorithm.standardise_returns=True"] + extra)
+        assert df.shape[0] >= 2 and np.isfinite(df["loss"]).all()
+    with pytest.raises(NotImplementedError):
+        run.main(["+algorithm=vdn", f"env.name={name}", "env.time_limit=25", "env.parallel_envs=128", "algorithm.model.layers=[64,64]",
+                  "algorithm.standardise_returns=True", "algorithm.total_steps=1000"])
