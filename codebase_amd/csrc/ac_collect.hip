@@ -133,7 +133,7 @@ __global__ __launch_bounds__(ACOL_BLOCK) void ac_collect_kernel(LbfParams q, con
             const bool trunc = q.time_limit > 0 && s.step >= q.time_limit;
             const bool fin = done || trunc;
             const bool stored_done = proper_term ? done : fin;
-            lbf_wrap_rewards<P>(q, raw, rw);
+            lbf_wrap_rewards<P>(q, env_id, raw, rw, g == 0);
             ++len;
             if (fin) {  // vector-env auto-reset: the observation returned for this step is the next episode's first
                 DrawStream rng;

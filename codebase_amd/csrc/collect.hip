@@ -161,7 +161,7 @@ __global__ __launch_bounds__(COL_BLOCK) void idqn_collect_kernel(LbfParams q, co
             lbf_step(q, s, act, raw, done);
             const bool trunc = q.time_limit > 0 && s.step >= q.time_limit;
             const bool stored_done = proper_term ? done : (done || trunc);  // train.py:219-225
-            lbf_wrap_rewards<P>(q, raw, rw);
+            lbf_wrap_rewards<P>(q, env_id, raw, rw, g == 0);
             ++len;
 #pragma unroll
             for (int p = 0; p < P; ++p) {

@@ -42,6 +42,7 @@ inline LbfParams to_params(const marlhip_lbf_config* c) {
     q.min_food_level = c->min_food_level; q.max_food_level = c->max_food_level;
     q.normalize_reward = c->normalize_reward; q.cooperative = c->cooperative;
     q.penalty = c->penalty; q.seed = c->seed;
+    q.reward_stats = c->reward_stats;
     return q;
 }
 

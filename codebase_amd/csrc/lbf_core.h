@@ -11,6 +11,8 @@
 // function of (state, joint action); only reset draws random numbers.  Header is
 // host+device so the integer logic can be exercised by a g++ build in tests/.
 #pragma once
+#include <math.h>
+
 #include "philox.h"
 
 namespace marl {
@@ -27,6 +29,7 @@ struct LbfParams {
     int cooperative;  // CooperativeReward wrapper (utils/wrappers.py:106-108)
     double penalty;
     uint64_t seed;
+    float* reward_stats;  // StandardiseReward wrapper state (utils/wrappers.py:111-142), [n_envs][3P+1] fp32, or nullptr
 };
 
 template <int P, int F>
@@ -314,16 +317,56 @@ MARL_HD void lbf_observe(const LbfParams& q, const LbfState<P, F>& s, int p, Lbf
 // wrapper arithmetic applied to the env's rewards before they reach the learner:
 // CooperativeReward = P * [python sum(reward)] in fp64, then one cast to fp32.
 template <int P>
-MARL_HD void lbf_wrap_rewards(const LbfParams& q, const double* raw, float* out) {
+MARL_HD void lbf_wrap_rewards(const LbfParams& q, uint32_t env_id, const double* raw, float* out, bool commit = true) {
+    double r[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) r[p] = raw[p];
+    if (q.reward_stats != nullptr) {
+        // StandardiseReward.reward (utils/wrappers.py:118-142) with numpy's precisions: the running arrays are fp32, the
+        // reward list promotes q, r and the result to fp64; per-env record = sumw[P] | wmean[P] | t[P] | n (int32 bits).
+        float* st = q.reward_stats + (size_t)env_id * (3 * P + 1);
+        int n;
+        {
+            const float nf = st[3 * P];
+            n = *reinterpret_cast<const int*>(&nf) + 1;
+        }
+        float sumw[P], wmean[P], tacc[P];
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            const float sw = st[p], wm = st[P + p], ta = st[2 * P + p];
+            const double qd = r[p] - (double)wm;
+            const float tsw = sw + 1.0f;
+            const double rr = qd * 1.0 / (double)tsw;
+            wmean[p] = (float)((double)wm + rr);
+            tacc[p] = (float)((double)ta + qd * rr * (double)sw);
+            sumw[p] = tsw;
+        }
+        if (n > 1) {
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                const float var = (tacc[p] * (float)n) / (sumw[p] * (float)(n - 1));
+                r[p] = (r[p] - (double)wmean[p]) / (double)(sqrtf(var) + 1e-6f);
+            }
+        }
+        if (commit) {
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                st[p] = sumw[p];
+                st[P + p] = wmean[p];
+                st[2 * P + p] = tacc[p];
+            }
+            st[3 * P] = *reinterpret_cast<const float*>(&n);
+        }
+    }
     if (q.cooperative) {
         double t = 0.0;
 #pragma unroll
-        for (int p = 0; p < P; ++p) t += raw[p];
+        for (int p = 0; p < P; ++p) t += r[p];
 #pragma unroll
         for (int p = 0; p < P; ++p) out[p] = (float)t;
     } else {
 #pragma unroll
-        for (int p = 0; p < P; ++p) out[p] = (float)raw[p];
+        for (int p = 0; p < P; ++p) out[p] = (float)r[p];
     }
 }
 

@@ -109,7 +109,7 @@ __global__ __launch_bounds__(ENV_BLOCK) void lbf_step_kernel(LbfParams q, marlhi
                 ret[p] = b.ep_return[(size_t)p * q.n_envs + n] + (float)raw[p];
                 b.ep_return[(size_t)p * q.n_envs + n] = ret[p];
             }
-            lbf_wrap_rewards<P>(q, raw, rw);
+            lbf_wrap_rewards<P>(q, (uint32_t)n, raw, rw);
             if (done || trunc) {
 #pragma unroll
                 for (int p = 0; p < P; ++p) fin_return[(size_t)p * q.n_envs + n] = ret[p];

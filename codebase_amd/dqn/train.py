@@ -177,6 +177,7 @@ class VectorisedIDQN:
         cfg = _hip.LbfConfig.from_buffer_copy(self.cfg)
         cfg.n_envs = int(episodes)
         cfg.seed = (self.cfg.seed ^ 0x5DEECE66D) & (2**64 - 1)  # eval env: its own stream
+        cfg.reward_stats = None  # the eval env has its own wrapper stack; only raw episode returns are reported
         dev = self.model.device
         ret = torch.zeros(self.model.n_agents, episodes, device=dev)
         ln = torch.zeros(episodes, dtype=torch.int32, device=dev)

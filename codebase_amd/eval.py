@@ -28,6 +28,7 @@ def evaluate(model, lbf_cfg, episodes, time_limit, epsilon=0.0, round_idx=0):
     actor-critic models sample from their policy like the reference's act())"""
     cfg = _hip.LbfConfig.from_buffer_copy(lbf_cfg)
     cfg.n_envs = int(episodes)
+    cfg.reward_stats = None  # only RecordEpisodeStatistics' raw returns are reported
     dev = model.device
     ret = torch.zeros(model.n_agents, episodes, device=dev)
     ln = torch.zeros(episodes, dtype=torch.int32, device=dev)

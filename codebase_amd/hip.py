@@ -48,6 +48,15 @@ def lbf_config(name, n_envs, time_limit, seed=0, cooperative=False, **over):
                      cooperative=int(cooperative), **kw)
 
 
+def attach_reward_stats(cfg: LbfConfig, device="cuda"):
+    """env.standardise_rewards: allocate the per-env streaming records [n_envs][3P+1] and point the config at them."""
+    _require_gpu()
+    t = torch.zeros(cfg.n_envs, 3 * cfg.n_agents + 1, dtype=torch.float32, device=device)
+    cfg.reward_stats = t.data_ptr()
+    cfg._reward_stats_tensor = t  # ctypes.Structure instances accept attributes: the tensor lives as long as the config
+    return t
+
+
 class BatchedForaging:
     """N Level-Based Foraging envs resident in HBM (K1)."""
 

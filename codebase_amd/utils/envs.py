@@ -43,8 +43,8 @@ def _build_cfg(name, time_limit, clear_info, observe_id, standardise_rewards, wr
     if "Foraging" not in name:
         raise NotImplementedError(f"{name}: only Level-Based Foraging ids have a HIP env in this round "
                                   "(rware / smaclite are listed under 'next' in DESIGN.md)")
-    if observe_id or standardise_rewards:
-        raise NotImplementedError("observe_id / standardise_rewards are not folded into the HIP env yet")
+    if observe_id:
+        raise NotImplementedError("observe_id is not folded into the HIP env yet (DESIGN.md)")
     cooperative = False
     for w in wrappers or []:
         if w == "CooperativeReward":
@@ -53,7 +53,10 @@ def _build_cfg(name, time_limit, clear_info, observe_id, standardise_rewards, wr
             raise NotImplementedError(f"wrapper {w} is not available on the HIP env")
     if seed is None:
         seed = random.randint(0, 99999)  # utils/envs.py:58-59
-    return _hip.lbf_config(name, n_envs, time_limit, seed=seed, cooperative=cooperative, **kwargs)
+    cfg = _hip.lbf_config(name, n_envs, time_limit, seed=seed, cooperative=cooperative, **kwargs)
+    if standardise_rewards:  # StandardiseReward (utils/wrappers.py:111-142): one streaming record per env, kept with the cfg
+        _hip.attach_reward_stats(cfg)
+    return cfg
 
 
 class HipForagingEnv:

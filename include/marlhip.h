@@ -53,6 +53,10 @@ typedef struct marlhip_lbf_config {
     int32_t cooperative;       /* CooperativeReward wrapper */
     double penalty;
     uint64_t seed;             /* Philox key */
+    float* reward_stats;       /* env.standardise_rewards (StandardiseReward, utils/wrappers.py:111-142): device array
+                                  [n_envs][3*n_agents + 1] fp32, zero-initialised, one streaming mean / variance record per
+                                  env (sumw | wmean | t per agent, step count as int32 bits) that persists across episodes;
+                                  NULL = wrapper off.  Applied before CooperativeReward, after RecordEpisodeStatistics. */
 } marlhip_lbf_config;
 
 /* device buffers of a batched env (allocated by the caller) */

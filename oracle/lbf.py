@@ -393,13 +393,19 @@ class MarlbaseEnv:
     """ForagingEnv under the reference's wrapper stack (utils/envs.py:93-109):
     TimeLimit(time_limit) -> RecordEpisodeStatistics -> [CooperativeReward]."""
 
-    def __init__(self, name, time_limit, cooperative=False, rng=None, **overrides):
+    def __init__(self, name, time_limit, cooperative=False, rng=None, standardise_rewards=False, **overrides):
         kw = parse_env_name(name)
         kw.update(overrides)
         self.env = ForagingEnv(rng=rng, **kw)
         self.n_agents = self.env.n_agents
         self.time_limit = time_limit
         self.cooperative = cooperative
+        self.standardise_rewards = standardise_rewards
+        # StandardiseReward state (utils/wrappers.py:111-117): fp32 arrays + a python int; lives as long as the env object
+        self.sr_sumw = np.zeros(self.n_agents, np.float32)
+        self.sr_wmean = np.zeros(self.n_agents, np.float32)
+        self.sr_t = np.zeros(self.n_agents, np.float32)
+        self.sr_n = 0
         self._elapsed = 0
         self.episode_reward = 0
         self.episode_length = 0
@@ -427,6 +433,17 @@ class MarlbaseEnv:
                 info[f"agent{i}/episode_returns"] = r
             info["episode_length"] = self.episode_length
             info["episode_time"] = perf_counter() - self.t0
+        if self.standardise_rewards:  # wrappers.py:118-142 (streaming mean / variance, numpy dtype promotion as there)
+            q = reward - self.sr_wmean
+            sumw1 = self.sr_sumw + 1.0
+            r = q * 1.0 / sumw1
+            self.sr_wmean += r
+            self.sr_t += q * r * self.sr_sumw
+            self.sr_sumw = sumw1
+            self.sr_n += 1
+            if self.sr_n > 1:
+                var = (self.sr_t * self.sr_n) / (self.sr_sumw * (self.sr_n - 1))
+                reward = (reward - self.sr_wmean) / (np.sqrt(var) + 1e-6)
         if self.cooperative:  # wrappers.py:106-108
             reward = self.n_agents * [sum(reward)]
         return obs, reward, done, truncated, info

@@ -62,11 +62,12 @@ def unpack_state(rec, P, F):
 
 
 class HostCfg(ctypes.Structure):
-    _fields_ = [(k, ctypes.c_int32) for k in CFG_FIELDS] + [("penalty", ctypes.c_double), ("seed", ctypes.c_uint64)]
+    _fields_ = [(k, ctypes.c_int32) for k in CFG_FIELDS] + [("penalty", ctypes.c_double), ("seed", ctypes.c_uint64),
+                                                               ("reward_stats", ctypes.c_void_p)]
 
 
 def host_cfg(cfg):
-    return HostCfg(**{k: cfg[k] for k in CFG_FIELDS}, penalty=cfg["penalty"], seed=cfg["seed"])
+    return HostCfg(**{k: cfg[k] for k in CFG_FIELDS}, penalty=cfg["penalty"], seed=cfg["seed"], reward_stats=cfg.get("reward_stats"))
 
 
 _shim = None

@@ -13,6 +13,7 @@ struct HostCfg {
     int32_t normalize_reward, cooperative;
     double penalty;
     uint64_t seed;
+    float* reward_stats;
 };
 
 static LbfParams conv(const HostCfg* c) {
@@ -22,6 +23,7 @@ static LbfParams conv(const HostCfg* c) {
     q.force_coop = c->force_coop; q.min_player_level = c->min_player_level; q.max_player_level = c->max_player_level;
     q.min_food_level = c->min_food_level; q.max_food_level = c->max_food_level; q.normalize_reward = c->normalize_reward;
     q.cooperative = c->cooperative; q.penalty = c->penalty; q.seed = c->seed;
+    q.reward_stats = c->reward_stats;
     return q;
 }
 
@@ -55,7 +57,7 @@ static void run_step(const LbfParams& q, uint8_t* state, const int32_t* actions,
         bool d = false;
         for (int p = 0; p < P; ++p) a[p] = actions[(size_t)p * q.n_envs + n];
         lbf_step(q, s, a, raw, d);
-        lbf_wrap_rewards<P>(q, raw, rw);
+        lbf_wrap_rewards<P>(q, (uint32_t)n, raw, rw);
         lbf_store(state + (size_t)n * stride, s);
         done[n] = d;
         trunc[n] = q.time_limit > 0 && s.step >= q.time_limit;

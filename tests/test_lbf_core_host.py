@@ -87,3 +87,50 @@ def test_reset_and_step_match_oracle(name, coop):
 def ctypes_byref(x):
     import ctypes
     return ctypes.byref(x)
+
+
+def test_standardise_reward_wrapper_matches_oracle():
+    """env.standardise_rewards: the per-env streaming record of csrc/lbf_core.h against the oracle's restatement of
+    StandardiseReward (utils/wrappers.py:111-142), alone and under CooperativeReward, across episode boundaries"""
+    lib = host_shim()
+    for name, coop in (("lbforaging:Foraging-8x8-2p-3f-v3", False), ("lbforaging:Foraging-10x10-3p-3f-v3", True)):
+        N = 6
+        cfg = lbf_cfg(name, N, time_limit=25, seed=77, cooperative=coop)
+        P, F = cfg["n_agents"], cfg["n_food"]
+        D, S = 3 * (P + F), stride(P, F)
+        stats = np.zeros((N, 3 * P + 1), np.float32)
+        cfg["reward_stats"] = stats.ctypes.data
+        hc = host_cfg(cfg)
+        envs = [oracle_env(name, cfg) for _ in range(N)]
+        for e in envs:
+            e.standardise_rewards = True
+        rng = np.random.default_rng(3)
+        nonzero = 0
+        for episode in range(3):
+            state = np.zeros((N, S), np.uint8)
+            obs = np.zeros((P, N, D), np.float32)
+            epi = np.full(N, episode, np.uint32)
+            assert lib.host_lbf_reset(ctypes_byref(hc), ptr(state), ptr(epi), ptr(obs)) == 0
+            for n, e in enumerate(envs):
+                e.reset(DrawStream(cfg["seed"], n, episode))
+            alive = np.ones(N, bool)
+            for t in range(25):
+                acts = rng.choice(6, size=(P, N), p=[0.05, 0.15, 0.15, 0.15, 0.15, 0.35]).astype(np.int32)
+                rew, raw = np.zeros((P, N), np.float32), np.zeros((P, N), np.float64)
+                done, trunc = np.zeros(N, np.uint8), np.zeros(N, np.uint8)
+                before = stats.copy()
+                assert lib.host_lbf_step(ctypes_byref(hc), ptr(state), ptr(acts), ptr(obs), ptr(rew), ptr(raw), ptr(done), ptr(trunc)) == 0
+                for n in range(N):
+                    if not alive[n]:
+                        stats[n] = before[n]  # the shim steps finished envs too; the reference env is not stepped after its episode
+                        continue
+                    o, r, d, tr, info = envs[n].step([int(a) for a in acts[:, n]])
+                    np.testing.assert_array_equal(np.array(r, dtype=np.float32), rew[:, n])
+                    np.testing.assert_array_equal(stats[n, :P], envs[n].sr_sumw)
+                    np.testing.assert_array_equal(stats[n, P:2 * P], envs[n].sr_wmean)
+                    np.testing.assert_array_equal(stats[n, 2 * P:3 * P], envs[n].sr_t)
+                    assert stats[n, 3 * P:].view(np.int32)[0] == envs[n].sr_n
+                    nonzero += int(np.any(np.abs(rew[:, n]) > 0))
+                    if d or tr:
+                        alive[n] = False
+        assert nonzero > 20  # standardised rewards are non-zero on most steps once food has been eaten
