@@ -18,7 +18,7 @@ class LbfConfig(ctypes.Structure):
         ("sight", c_int32), ("max_episode_steps", c_int32), ("time_limit", c_int32), ("force_coop", c_int32),
         ("min_player_level", c_int32), ("max_player_level", c_int32), ("min_food_level", c_int32),
         ("max_food_level", c_int32), ("normalize_reward", c_int32), ("cooperative", c_int32),
-        ("penalty", c_double), ("seed", c_uint64), ("reward_stats", c_void_p),
+        ("penalty", c_double), ("seed", c_uint64), ("reward_stats", c_void_p), ("observe_id", c_int32),
     ]
 
 

@@ -393,7 +393,8 @@ using namespace marl;
 
 // (obs dim, hidden) pairs with compiled actor (A = 6) and critic (A = 1) kernels: the LBF shapes of common.h
 #define MARL_AC_SHAPES(X) \
-    X(12, 64) X(15, 64) X(18, 64) X(21, 64) X(24, 64) X(27, 64) X(39, 64) X(12, 128) X(15, 128) X(18, 128) X(21, 128) X(24, 128) X(27, 128) X(39, 128)
+    X(12, 64) X(15, 64) X(18, 64) X(21, 64) X(24, 64) X(27, 64) X(39, 64) X(12, 128) X(15, 128) X(18, 128) X(21, 128) X(24, 128) X(27, 128) X(39, 128) \
+    X(14, 64) X(17, 64) X(25, 64) X(31, 64) X(47, 64) X(14, 128) X(17, 128) X(25, 128) X(31, 128) X(47, 128) /* env.observe_id */
 
 static int ac_check(const marlhip_net_shape* s) {
     MARL_REQUIRE(s != nullptr, "net shape is NULL");

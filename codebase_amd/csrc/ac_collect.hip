@@ -1,223 +1,5 @@
-// Fused actor-critic rollout collector for gfx950 - replaces _collect_trajectories
-// (marlbase/ac/train.py:24-119) over N vector envs in ONE launch:
-//   envs.reset() -> while running.any(): model.act (actor MLP -> Categorical sample) -> envs.step
-//   (auto-reset vector env) -> masked writes of the still-running envs into the time-major batch.
-// Same wave organisation as the IDQN collector (16 envs per wave, env state in registers, actor packs in
-// LDS, f32 MFMA).  Reference semantics kept on purpose:
-//   * an env whose episode ended is ignored until every env has finished (train.py:71,110);
-//   * gymnasium(<1.0) AsyncVectorEnv auto-reset: the observation stored at t+1 of the FINAL transition is
-//     the first observation of the env's NEXT episode, not the terminal one (train.py:79,90);
-//   * done = done | truncated unless use_proper_termination (train.py:85-88).
-// Sampling: Categorical(logits=actor_i(o_i)) by inverse CDF on the fp32 softmax with one Philox uniform per
-// (env, step, agent) - torch.multinomial's stream is not reproducible on the device.
-// Reset streams: the collection call with index `round` resets from Philox episode 2*round; the auto-reset
-// observation comes from episode 2*round+1.
-#include "collect_common.h"
-
-namespace marl {
-
-constexpr int ACOL_BLOCK = 256;
-
-// softmax inverse-CDF sample for the env of batch row j; logits in C layout (lane (g,j) holds a = 4g+r)
-template <int A>
-__device__ __forceinline__ int sample_rows(const f4& logits, int lane, float u) {
-    const int j = lane & 15;
-    float l[A];
-#pragma unroll
-    for (int a = 0; a < A; ++a) l[a] = __shfl(logits[a & 3], (a >> 2) * 16 + j);
-    float m = l[0];
-#pragma unroll
-    for (int a = 1; a < A; ++a) m = fmaxf(m, l[a]);
-    float e[A], sum = 0.f;
-#pragma unroll
-    for (int a = 0; a < A; ++a) {
-        e[a] = expf(l[a] - m);
-        sum += e[a];
-    }
-    const float thr = u * sum;
-    float c = 0.f;
-    int act = A - 1;
-#pragma unroll
-    for (int a = A - 1; a >= 0; --a) {  // first a with cumsum(e)[a] > thr
-        float ca = 0.f;
-#pragma unroll
-        for (int b = 0; b <= a; ++b) ca += e[b];
-        if (ca > thr) act = a;
-    }
-    (void)c;
-    return act;
-}
-
-template <int P, int F, int H>
-__global__ __launch_bounds__(ACOL_BLOCK) void ac_collect_kernel(LbfParams q, const float* __restrict__ actor /* pre-packed [P][NFWD] */, uint32_t round, int T,
-                                                                int proper_term, float* __restrict__ b_obs,
-                                                                int64_t* __restrict__ b_act, float* __restrict__ b_rew,
-                                                                uint8_t* __restrict__ b_done, float* __restrict__ b_filled,
-                                                                float* __restrict__ fin_return, int32_t* __restrict__ fin_length,
-                                                                int32_t* __restrict__ t_max) {
-    constexpr int D = 3 * (P + F), A = 6;
-    using S = MlpShape<D, H, A>;
-    using PP = PackPlan<S, P>;
-    constexpr bool RESIDENT = PP::RESIDENT || PP::A3REG;  // no per-step staging
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, j = lane & 15;
-    const int n = (blockIdx.x * 4 + wave) * 16 + j;
-    const int N = q.n_envs;
-    const bool valid = n < N;
-    const uint32_t env_id = (uint32_t)(valid ? n : N - 1);
-    f4 a3[PP::A3REG ? P : 1][S::MT];  // output-layer operands, when the full packs do not fit the LDS
-    if (RESIDENT) {
-        for (int p = 0; p < P; ++p)
-            stage_packed_prefix<S>(actor + (size_t)p * S::NFWD, lds + (size_t)p * PP::STRIDE, PP::STRIDE, tid, ACOL_BLOCK);
-        if (PP::A3REG) {
-#pragma unroll
-            for (int p = 0; p < P; ++p)
-#pragma unroll
-                for (int mt = 0; mt < S::MT; ++mt)
-                    a3[p][mt] = reinterpret_cast<const f4*>(actor + (size_t)p * S::NFWD + S::pA3)[mt * 64 + lane];
-        }
-        __syncthreads();
-    }
-    LbfState<P, F> s;
-    {
-        DrawStream rng;
-        rng.init(q.seed, env_id, 2u * round, STREAM_RESET);
-        lbf_reset(q, s, rng);
-    }
-    // batch_obs[t][n][p*D + d]
-    auto obs_row = [&](int t) { return b_obs + ((size_t)t * N + env_id) * (P * D); };
-    float x[P][S::KS1];
-#pragma unroll
-    for (int p = 0; p < P; ++p) {
-        LbfObs<P, F> o;
-        lbf_observe(q, s, p, o);
-        pick_obs<P, F, S::KS1>(o, g, x[p]);
-        if (valid) {
-#pragma unroll
-            for (int ks = 0; ks < S::KS1; ++ks)
-                if (4 * ks + g < D) obs_row(0)[p * D + 4 * ks + g] = x[p][ks];
-        }
-    }
-    if (valid && g == 0) b_done[env_id] = 0;
-    bool running = valid;
-    float ep_ret[P];
-#pragma unroll
-    for (int p = 0; p < P; ++p) ep_ret[p] = 0.f;
-    int len = 0;
-    for (int t = 0; t < T; ++t) {
-        int act[P];
-        const bool any_running = __any(running);
-        if (RESIDENT ? any_running : true) {
-#pragma unroll
-            for (int p = 0; p < P; ++p) {
-                const float* pack;
-                if (RESIDENT) {
-                    pack = lds + (size_t)p * PP::STRIDE;
-                } else {
-                    __syncthreads();
-                    stage_packed<S>(actor + (size_t)p * S::NFWD, lds, tid, ACOL_BLOCK);
-                    __syncthreads();
-                    pack = lds;
-                }
-                f4 h1[S::MT], h2[S::MT], logits, unused;
-                mlp_forward_p<S, false>(pack, pack, lane, x[p], h1, h2, logits, unused, PP::A3REG ? a3[PP::A3REG ? p : 0] : nullptr);
-                const float u = u01_f32(act_noise_word(q.seed, env_id, 2u * round, (uint32_t)t, 1 + p));
-                act[p] = sample_rows<A>(logits, lane, u);
-            }
-        }
-        if (running) {
-            double raw[P];
-            float rw[P];
-            bool done;
-            lbf_step(q, s, act, raw, done);
-            const bool trunc = q.time_limit > 0 && s.step >= q.time_limit;
-            const bool fin = done || trunc;
-            const bool stored_done = proper_term ? done : fin;
-            lbf_wrap_rewards<P>(q, env_id, raw, rw, g == 0);
-            ++len;
-            if (fin) {  // vector-env auto-reset: the observation returned for this step is the next episode's first
-                DrawStream rng;
-                rng.init(q.seed, env_id, 2u * round + 1u, STREAM_RESET);
-                lbf_reset(q, s, rng);
-            }
-#pragma unroll
-            for (int p = 0; p < P; ++p) {
-                ep_ret[p] += (float)raw[p];
-                LbfObs<P, F> o;
-                lbf_observe(q, s, p, o);
-                pick_obs<P, F, S::KS1>(o, g, x[p]);
-#pragma unroll
-                for (int ks = 0; ks < S::KS1; ++ks)
-                    if (4 * ks + g < D) obs_row(t + 1)[p * D + 4 * ks + g] = x[p][ks];
-                if (g == 0) {
-                    b_act[((size_t)t * N + n) * P + p] = act[p];
-                    b_rew[((size_t)t * N + n) * P + p] = rw[p];
-                }
-            }
-            if (g == 0) {
-                b_done[(size_t)(t + 1) * N + n] = stored_done ? 1 : 0;
-                b_filled[(size_t)t * N + n] = 1.f;
-            }
-            if (fin) {
-                running = false;
-                if (g == 0) {
-#pragma unroll
-                    for (int p = 0; p < P; ++p) fin_return[(size_t)p * N + n] = ep_ret[p];
-                    fin_length[n] = len;
-                    atomicMax(t_max, len);
-                }
-            }
-        } else if (valid) {
-            // rows of an env that is no longer running stay zero, as in the reference's freshly allocated batch
-#pragma unroll
-            for (int p = 0; p < P; ++p) {
-#pragma unroll
-                for (int ks = 0; ks < S::KS1; ++ks)
-                    if (4 * ks + g < D) obs_row(t + 1)[p * D + 4 * ks + g] = 0.f;
-                if (g == 0) {
-                    b_act[((size_t)t * N + n) * P + p] = 0;
-                    b_rew[((size_t)t * N + n) * P + p] = 0.f;
-                }
-            }
-            if (g == 0) {
-                b_done[(size_t)(t + 1) * N + n] = 0;
-                b_filled[(size_t)t * N + n] = 0.f;
-            }
-        }
-    }
-    if (valid && running && g == 0) {  // T shorter than the env's limits
-#pragma unroll
-        for (int p = 0; p < P; ++p) fin_return[(size_t)p * N + n] = ep_ret[p];
-        fin_length[n] = len;
-        atomicMax(t_max, len);
-    }
-}
-
-template <int P, int F, int H>
-int launch_ac_collect(const LbfParams& q, const AgentMap& am, const float* actor, uint32_t round, int T, int proper_term, float* b_obs, int64_t* b_act,
-                      float* b_rew, uint8_t* b_done, float* b_filled, float* fin_return, int32_t* fin_length, int32_t* t_max,
-                      hipStream_t st) {
-    constexpr int D = 3 * (P + F);
-    using S = MlpShape<D, H, 6>;
-    const size_t lds_bytes = PackPlan<S, P>::LDS_BYTES;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ac_collect_kernel<P, F, H>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        attr_set = true;
-    }
-    (void)hipMemsetAsync(t_max, 0, sizeof(int32_t), st);
-    float* packs = nullptr;
-    if (launch_fwd_pack<S>(P, am, actor, &packs, st) != 0) return -1;
-    timing_begin(TIMER_COLLECT, st);
-    hipLaunchKernelGGL((ac_collect_kernel<P, F, H>), dim3((q.n_envs + 63) / 64), dim3(ACOL_BLOCK), lds_bytes, st, q, (const float*)packs, round, T,
-                       proper_term, b_obs, b_act, b_rew, b_done, b_filled, fin_return, fin_length, t_max);
-    timing_end(TIMER_COLLECT, st);
-    MARL_CHECK_LAUNCH("ac_collect_kernel");
-    return 0;
-}
-
-}  // namespace marl
+// extern "C" entry point of the fused actor-critic rollout collector; kernel in ac_collect_kernels.h
+#include "ac_collect_kernels.h"
 
 using namespace marl;
 
@@ -228,22 +10,21 @@ extern "C" int marlhip_ac_collect(const marlhip_lbf_config* cfg, const marlhip_n
     if (lbf_validate(cfg) != 0) return -1;
     MARL_REQUIRE(s && actor_params && batch_obs && batch_act && batch_rew && batch_done && batch_filled && fin_return && fin_length &&
                      t_max, "ac_collect: NULL pointer");
-    MARL_REQUIRE(s->n_agents == cfg->n_agents && s->obs_dim == 3 * (cfg->n_agents + cfg->n_food) && s->n_actions == 6,
+    MARL_REQUIRE(s->n_agents == cfg->n_agents && s->obs_dim == marlhip_lbf_obs_dim(cfg) && s->n_actions == 6,
                  "ac_collect: net shape does not match the env (P=%d D=%d A=6 expected)", cfg->n_agents,
                  3 * (cfg->n_agents + cfg->n_food));
     MARL_REQUIRE(max_len > 0, "ac_collect: max_len must be > 0");
     if (agent_map_validate(s) != 0) return -1;
     const LbfParams q = to_params(cfg);
-#define X(p, f)                                                                                                                  \
-    if (cfg->n_agents == p && cfg->n_food == f) {                                                                                \
-        if (s->hidden == 64)                                                                                                     \
-            return launch_ac_collect<p, f, 64>(q, agent_map(s), actor_params, round, max_len, use_proper_termination, batch_obs, batch_act,     \
-                                               batch_rew, batch_done, batch_filled, fin_return, fin_length, t_max,               \
-                                               (hipStream_t)stream);                                                              \
-        if (s->hidden == 128)                                                                                                    \
-            return launch_ac_collect<p, f, 128>(q, agent_map(s), actor_params, round, max_len, use_proper_termination, batch_obs, batch_act,    \
-                                                batch_rew, batch_done, batch_filled, fin_return, fin_length, t_max,              \
-                                                (hipStream_t)stream);                                                             \
+    if (cfg->observe_id)
+        return ac_collect_dispatch_oid(cfg, s, q, actor_params, round, max_len, use_proper_termination, batch_obs, batch_act, batch_rew,
+                                       batch_done, batch_filled, fin_return, fin_length, t_max, (hipStream_t)stream);
+#define MARL_ACOL_ARGS q, agent_map(s), actor_params, round, max_len, use_proper_termination, batch_obs, batch_act, batch_rew, batch_done, \
+                       batch_filled, fin_return, fin_length, t_max, (hipStream_t)stream
+#define X(p, f)                                                                                         \
+    if (cfg->n_agents == p && cfg->n_food == f) {                                                       \
+        if (s->hidden == 64) return launch_ac_collect<p, f, 64, false>(MARL_ACOL_ARGS);                 \
+        if (s->hidden == 128) return launch_ac_collect<p, f, 128, false>(MARL_ACOL_ARGS);               \
     }
     MARL_LBF_SHAPES(X)
 #undef X

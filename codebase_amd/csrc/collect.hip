@@ -1,234 +1,5 @@
-// K2 (batched QNetwork.act) and the fused IDQN collector for gfx950.
-//
-// marlhip_dqn_act   - marlbase/dqn/model.py:94-116 over N envs (modular entry point).
-// marlhip_idqn_collect - marlbase/dqn/train.py:202-237 (_collect_trajectory) for N envs in ONE
-//   launch per round: reset -> T x (act -> env.step -> ReplayBuffer.add).  A wave owns 16 envs
-//   (the N dimension of the 16x16x4 MFMA); the 4 lanes {j, j+16, j+32, j+48} carry the SAME env
-//   redundantly so that every lane can feed its own B-operand rows (obs element 4ks+g) without
-//   any cross-lane traffic.  Env state lives in registers for the whole episode; the critics sit
-//   in LDS as MFMA A-operand packs; the only HBM traffic is the replay write
-//   (4*P*D + P + 4*P + 2 bytes per env-step).
-#include "common.h"
-#include "mlp.h"
-#include "collect_common.h"
-
-namespace marl {
-
-constexpr int COL_BLOCK = 256;
-
-template <class S>
-__global__ __launch_bounds__(COL_BLOCK) void dqn_act_kernel(int P, int N, AgentMap am, const float* __restrict__ params,
-                                                            const float* __restrict__ obs, float eps,
-                                                            const float* __restrict__ u_in, const int32_t* __restrict__ rand_in,
-                                                            uint64_t seed, const uint32_t* __restrict__ episode,
-                                                            const int32_t* __restrict__ ep_length, int32_t* __restrict__ actions,
-                                                            float* __restrict__ q_out) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, j = lane & 15;
-    const int n = (blockIdx.x * 4 + wave) * 16 + j;
-    const bool valid = n < N;
-    const int nn = valid ? n : N - 1;
-    float u;
-    uint32_t epi = 0, t = 0;
-    if (u_in != nullptr) {
-        u = u_in[nn];
-    } else {
-        epi = episode[nn];
-        t = (uint32_t)ep_length[nn];
-        u = u01_f32(act_noise_word(seed, (uint32_t)nn, epi, t, 0));
-    }
-    const bool explore = eps > u;
-    for (int p = 0; p < P; ++p) {
-        __syncthreads();
-        mlp_stage_fwd<S>(params + (size_t)am.net[p] * S::NPARAM, lds, tid, COL_BLOCK);
-        __syncthreads();
-        float x[S::KS1];
-        const float* xrow = obs + ((size_t)p * N + nn) * S::D;
-#pragma unroll
-        for (int ks = 0; ks < S::KS1; ++ks) {
-            const int d = 4 * ks + g;
-            x[ks] = (d < S::D && valid) ? xrow[d] : 0.f;
-        }
-        f4 h1[S::MT], h2[S::MT], q;
-        mlp_forward<S>(lds, lane, x, h1, h2, q);
-        const int greedy = argmax_rows<S::A>(q, lane);
-        int ra;
-        if (rand_in != nullptr) ra = rand_in[(size_t)p * N + nn];
-        else ra = (int)bounded_nr(act_noise_word(seed, (uint32_t)nn, epi, t, 1 + p), (uint32_t)S::A);
-        if (valid) {
-            if (g == 0) actions[(size_t)p * N + n] = explore ? ra : greedy;
-            if (q_out != nullptr) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (4 * g + r < S::A) q_out[((size_t)p * N + n) * S::A + 4 * g + r] = q[r];
-            }
-        }
-    }
-}
-
-template <int P, int F, int H>
-__global__ __launch_bounds__(COL_BLOCK) void idqn_collect_kernel(LbfParams q, const float* __restrict__ packs, float eps,
-                                                                 uint32_t round, marlhip_replay_shape rs, marlhip_replay_buffers rb,
-                                                                 int slot_base, int write_replay, int clear_stale, int proper_term,
-                                                                 float* __restrict__ fin_return, int32_t* __restrict__ fin_length) {
-    constexpr int D = 3 * (P + F), A = 6;
-    using S = MlpShape<D, H, A>;
-    using PP = PackPlan<S, P>;
-    constexpr bool RESIDENT = PP::RESIDENT || PP::A3REG;  // no per-step staging
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, j = lane & 15;
-    const int n = (blockIdx.x * 4 + wave) * 16 + j;
-    const int N = q.n_envs, T = rs.max_len;
-    const bool valid = n < N;
-    const uint32_t env_id = (uint32_t)(valid ? n : N - 1);
-
-    f4 a3[PP::A3REG ? P : 1][S::MT];  // output-layer operands of every agent, when the full packs do not fit the LDS
-    if (RESIDENT) {
-        for (int p = 0; p < P; ++p)
-            stage_packed_prefix<S>(packs + (size_t)p * S::NFWD, lds + (size_t)p * PP::STRIDE, PP::STRIDE, tid, COL_BLOCK);
-        if (PP::A3REG) {
-#pragma unroll
-            for (int p = 0; p < P; ++p)
-#pragma unroll
-                for (int mt = 0; mt < S::MT; ++mt)
-                    a3[p][mt] = reinterpret_cast<const f4*>(packs + (size_t)p * S::NFWD + S::pA3)[mt * 64 + lane];
-        }
-        __syncthreads();
-    }
-
-    LbfState<P, F> s;
-    {
-        DrawStream rng;
-        rng.init(q.seed, env_id, round, STREAM_RESET);
-        lbf_reset(q, s, rng);
-    }
-    const int slot = (int)(((int64_t)slot_base + (int64_t)env_id) % rs.capacity);
-    float* ro = rb.obs + (size_t)slot * P * (T + 1) * D;
-    uint8_t* ra_ = rb.act + (size_t)slot * P * T;
-    float* rr = rb.rew + (size_t)slot * P * T;
-    uint8_t* rd = rb.done + (size_t)slot * (T + 1);
-    uint8_t* rf = rb.filled + (size_t)slot * T;
-    const bool wr = valid && write_replay;
-
-    float x[P][S::KS1];
-#pragma unroll
-    for (int p = 0; p < P; ++p) {
-        LbfObs<P, F> o;
-        lbf_observe(q, s, p, o);
-        pick_obs<P, F, S::KS1>(o, g, x[p]);
-        if (wr) {  // ReplayBuffer.init_episode (train.py:65-68)
-#pragma unroll
-            for (int ks = 0; ks < S::KS1; ++ks)
-                if (4 * ks + g < D) ro[((size_t)p * (T + 1) + 0) * D + 4 * ks + g] = x[p][ks];
-        }
-    }
-
-    bool alive = valid;
-    float ep_ret[P];
-#pragma unroll
-    for (int p = 0; p < P; ++p) ep_ret[p] = 0.f;
-    int len = 0;
-
-    for (int t = 0; t < T; ++t) {
-        if (RESIDENT) {
-            if (!__any(alive)) break;  // wave-uniform: all 16 envs of this wave are finished
-        }
-        int act[P];
-        float u;
-        int rnd[P];
-        act_noise<P>(q.seed, env_id, round, (uint32_t)t, (uint32_t)A, u, rnd);
-        const bool explore = eps > u;
-#pragma unroll
-        for (int p = 0; p < P; ++p) {
-            const float* pack;
-            if (RESIDENT) {
-                pack = lds + (size_t)p * PP::STRIDE;
-            } else {
-                __syncthreads();
-                stage_packed<S>(packs + (size_t)p * S::NFWD, lds, tid, COL_BLOCK);
-                __syncthreads();
-                pack = lds;
-            }
-            f4 h1[S::MT], h2[S::MT], qv, unused;
-            mlp_forward_p<S, false>(pack, pack, lane, x[p], h1, h2, qv, unused, PP::A3REG ? a3[PP::A3REG ? p : 0] : nullptr);
-            const int greedy = argmax_rows<A>(qv, lane);
-            act[p] = explore ? rnd[p] : greedy;
-        }
-        if (alive) {
-            double raw[P];
-            float rw[P];
-            bool done;
-            lbf_step(q, s, act, raw, done);
-            const bool trunc = q.time_limit > 0 && s.step >= q.time_limit;
-            const bool stored_done = proper_term ? done : (done || trunc);  // train.py:219-225
-            lbf_wrap_rewards<P>(q, env_id, raw, rw, g == 0);
-            ++len;
-#pragma unroll
-            for (int p = 0; p < P; ++p) {
-                ep_ret[p] += (float)raw[p];  // RecordEpisodeStatistics (wrappers.py:33)
-                LbfObs<P, F> o;
-                lbf_observe(q, s, p, o);
-                pick_obs<P, F, S::KS1>(o, g, x[p]);
-                if (wr) {  // ReplayBuffer.add (train.py:73-84)
-#pragma unroll
-                    for (int ks = 0; ks < S::KS1; ++ks)
-                        if (4 * ks + g < D) ro[((size_t)p * (T + 1) + t + 1) * D + 4 * ks + g] = x[p][ks];
-                    if (g == 0) {
-                        ra_[p * T + t] = (uint8_t)act[p];
-                        rr[p * T + t] = rw[p];
-                    }
-                }
-            }
-            if (wr && g == 0) {
-                rd[t + 1] = stored_done ? 1 : 0;
-                rf[t] = 1;
-            }
-            if (done || trunc) {
-                alive = false;
-                if (g == 0) {
-#pragma unroll
-                    for (int p = 0; p < P; ++p) fin_return[(size_t)p * N + n] = ep_ret[p];
-                    fin_length[n] = len;
-                }
-            }
-        }
-    }
-    if (valid && g == 0) {
-        if (alive) {  // rs.max_len shorter than the env's own limits: report what was collected
-#pragma unroll
-            for (int p = 0; p < P; ++p) fin_return[(size_t)p * N + n] = ep_ret[p];
-            fin_length[n] = len;
-        }
-        if (wr && clear_stale)
-            for (int t = len; t < T; ++t) rf[t] = 0;
-    }
-}
-
-template <int P, int F, int H>
-int launch_collect(const LbfParams& q, const AgentMap& am, const float* params, float eps, uint32_t round, const marlhip_replay_shape* rs,
-                   const marlhip_replay_buffers* rb, int slot_base, int write_replay, int clear_stale, int proper_term,
-                   float* fin_return, int32_t* fin_length, hipStream_t st) {
-    constexpr int D = 3 * (P + F);
-    using S = MlpShape<D, H, 6>;
-    const size_t lds_bytes = PackPlan<S, P>::LDS_BYTES;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&idqn_collect_kernel<P, F, H>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        attr_set = true;
-    }
-    const int grid = (q.n_envs + 63) / 64;
-    float* packs = nullptr;
-    if (launch_fwd_pack<S>(P, am, params, &packs, st) != 0) return -1;
-    timing_begin(TIMER_COLLECT, st);
-    hipLaunchKernelGGL((idqn_collect_kernel<P, F, H>), dim3(grid), dim3(COL_BLOCK), lds_bytes, st, q, (const float*)packs, eps, round, *rs, *rb,
-                       slot_base, write_replay, clear_stale, proper_term, fin_return, fin_length);
-    timing_end(TIMER_COLLECT, st);
-    MARL_CHECK_LAUNCH("idqn_collect_kernel");
-    return 0;
-}
-
-}  // namespace marl
+// extern "C" entry points of K2 (batched act) and the fused IDQN collector; kernels in collect_kernels.h
+#include "collect_kernels.h"
 
 using namespace marl;
 
@@ -269,7 +40,7 @@ extern "C" int marlhip_idqn_collect(const marlhip_lbf_config* cfg, const marlhip
     if (lbf_validate(cfg) != 0) return -1;
     MARL_REQUIRE(s && params && rs && rb && fin_return && fin_length, "idqn_collect: NULL pointer");
     if (agent_map_validate(s) != 0) return -1;
-    MARL_REQUIRE(s->n_agents == cfg->n_agents && s->obs_dim == 3 * (cfg->n_agents + cfg->n_food) && s->n_actions == 6,
+    MARL_REQUIRE(s->n_agents == cfg->n_agents && s->obs_dim == marlhip_lbf_obs_dim(cfg) && s->n_actions == 6,
                  "idqn_collect: net shape does not match the env (P=%d D=%d A=6 expected)", cfg->n_agents,
                  3 * (cfg->n_agents + cfg->n_food));
     MARL_REQUIRE(rs->n_agents == cfg->n_agents && rs->obs_dim == s->obs_dim && rs->max_len > 0 && rs->capacity > 0,
@@ -277,14 +48,15 @@ extern "C" int marlhip_idqn_collect(const marlhip_lbf_config* cfg, const marlhip
     MARL_REQUIRE(!write_replay || (rb->obs && rb->act && rb->rew && rb->done && rb->filled), "idqn_collect: NULL replay buffer");
     MARL_REQUIRE(!write_replay || cfg->n_envs <= rs->capacity, "idqn_collect: n_envs %d > replay capacity %d", cfg->n_envs, rs->capacity);
     const LbfParams q = to_params(cfg);
-#define X(p, f)                                                                                                              \
-    if (cfg->n_agents == p && cfg->n_food == f) {                                                                            \
-        if (s->hidden == 64)                                                                                                 \
-            return launch_collect<p, f, 64>(q, agent_map(s), params, epsilon, round, rs, rb, slot_base, write_replay, clear_stale,          \
-                                            use_proper_termination, fin_return, fin_length, (hipStream_t)stream);            \
-        if (s->hidden == 128)                                                                                                \
-            return launch_collect<p, f, 128>(q, agent_map(s), params, epsilon, round, rs, rb, slot_base, write_replay, clear_stale,         \
-                                             use_proper_termination, fin_return, fin_length, (hipStream_t)stream);           \
+    if (cfg->observe_id)
+        return idqn_collect_dispatch_oid(cfg, s, q, params, epsilon, round, rs, rb, slot_base, write_replay, clear_stale, use_proper_termination,
+                                         fin_return, fin_length, (hipStream_t)stream);
+#define MARL_COLLECT_ARGS q, agent_map(s), params, epsilon, round, rs, rb, slot_base, write_replay, clear_stale, use_proper_termination, \
+                          fin_return, fin_length, (hipStream_t)stream
+#define X(p, f)                                                                                            \
+    if (cfg->n_agents == p && cfg->n_food == f) {                                                          \
+        if (s->hidden == 64) return launch_collect<p, f, 64, false>(MARL_COLLECT_ARGS);                    \
+        if (s->hidden == 128) return launch_collect<p, f, 128, false>(MARL_COLLECT_ARGS);                  \
     }
     MARL_LBF_SHAPES(X)
 #undef X

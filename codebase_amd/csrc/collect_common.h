@@ -27,6 +27,26 @@ __device__ __forceinline__ void pick_obs(const LbfObs<P, F>& o, int g, float (&x
     }
 }
 
+// the same with the ObserveID prefix (utils/wrappers.py:97-103): element e < P is the one-hot agent index, then the observation
+template <int P, int F, int KS1, bool OID>
+__device__ __forceinline__ void pick_obs_id(const LbfObs<P, F>& o, int p, int g, float (&x)[KS1]) {
+    if (!OID) {
+        pick_obs<P, F, KS1>(o, g, x);
+        return;
+    }
+    constexpr int D0 = 3 * (P + F), D = D0 + P;
+#pragma unroll
+    for (int ks = 0; ks < KS1; ++ks) {
+        float e[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int i = 4 * ks + c;
+            e[c] = i < P ? (i == p ? 1.f : 0.f) : (i < D ? o.v[(i >= P && i < D) ? i - P : 0] : 0.f);
+        }
+        x[ks] = g == 0 ? e[0] : (g == 1 ? e[1] : (g == 2 ? e[2] : e[3]));
+    }
+}
+
 // Pre-packed actor / critic weights for the collectors: one tiny kernel turns the canonical parameter blocks into the
 // MFMA A-operand packs ([P][NFWD], L2-resident), workgroups then stage them with straight 16-byte copies - once when all
 // agents fit in LDS, once per (step, agent) when they do not (hidden 128, > 1 agent).  The scratch is library-owned,

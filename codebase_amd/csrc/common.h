@@ -43,6 +43,7 @@ inline LbfParams to_params(const marlhip_lbf_config* c) {
     q.normalize_reward = c->normalize_reward; q.cooperative = c->cooperative;
     q.penalty = c->penalty; q.seed = c->seed;
     q.reward_stats = c->reward_stats;
+    q.observe_id = c->observe_id != 0;
     return q;
 }
 
@@ -92,8 +93,11 @@ inline int agent_map_validate(const marlhip_net_shape* s) {
 
 // network shapes (D, H, A) with compiled MFMA kernels.  X(D, H, A)
 //   LBF obs dims: 2p2f 12, 2p3f 15, 3p3f 18, 3p5f 24, 4p3f 21, 4p5f 27, 8p5f 39
+//   with env.observe_id (+P): 14, 17, 21, 27, 25, 31, 47
 #define MARL_NET_SHAPES(X)                                                                         \
     X(12, 64, 6) X(15, 64, 6) X(18, 64, 6) X(21, 64, 6) X(24, 64, 6) X(27, 64, 6) X(39, 64, 6)     \
-    X(12, 128, 6) X(15, 128, 6) X(18, 128, 6) X(21, 128, 6) X(24, 128, 6) X(27, 128, 6) X(39, 128, 6)
+    X(12, 128, 6) X(15, 128, 6) X(18, 128, 6) X(21, 128, 6) X(24, 128, 6) X(27, 128, 6) X(39, 128, 6) \
+    X(14, 64, 6) X(17, 64, 6) X(25, 64, 6) X(31, 64, 6) X(47, 64, 6)                               \
+    X(14, 128, 6) X(17, 128, 6) X(25, 128, 6) X(31, 128, 6) X(47, 128, 6)
 
 }  // namespace marl

@@ -4,10 +4,17 @@
 
 using namespace marl;
 
-// shapes with an update kernel (H=64: packs + tiles = 108 KB LDS, dW accumulators in registers)
-#define MARL_UPD_SHAPES(X)                                                                                 \
-    X(12, 64, 6) X(15, 64, 6) X(18, 64, 6) X(21, 64, 6) X(24, 64, 6) X(27, 64, 6) X(39, 64, 6)             \
-    X(12, 128, 6) X(15, 128, 6) X(18, 128, 6) X(21, 128, 6) X(24, 128, 6) X(27, 128, 6) X(39, 128, 6)
+// the kernel instantiations live in dqn_update_h64.hip / _h64_oid / _h128 / _h128_oid (dqn_update_part.h)
+namespace marl {
+#define MARL_PART_DECL(name)                                                                                                      \
+    int name(const marlhip_net_shape*, const float*, const float*, const marlhip_batch*, const ReplaySrc*, float, int32_t, int32_t, \
+             void*, int64_t, float*, float*, hipStream_t, const QmixCtx*, const RetStats*, bool*);
+MARL_PART_DECL(lossgrad_part_h64)
+MARL_PART_DECL(lossgrad_part_h64_oid)
+MARL_PART_DECL(lossgrad_part_h128)
+MARL_PART_DECL(lossgrad_part_h128_oid)
+#undef MARL_PART_DECL
+}  // namespace marl
 
 extern "C" int marlhip_net_nparams(const marlhip_net_shape* s) {
     MARL_REQUIRE(s != nullptr, "net shape is NULL");
@@ -38,12 +45,12 @@ static int lossgrad_dispatch(const marlhip_net_shape* s, const float* params, co
                  "dqn_loss_grad: mode %d unknown (0 = IDQN, 1 = VDN)", mode);
     if (agent_map_validate(s) != 0) return -1;
     MARL_REQUIRE(bt->act_agent_stride == 0 && bt->act_row_stride == 0, "dqn_loss_grad: action / reward strides are an actor-critic option");
-#define X(d, h, a)                                                                                                          \
-    if (s->obs_dim == d && s->hidden == h && s->n_actions == a)                                                             \
-        return launch_lossgrad<MlpShape<d, h, a>>(s, params, target_params, bt, rsrc, gamma, double_q, mode, workspace,       \
-                                                  workspace_bytes, grad, loss, (hipStream_t)stream, qx, rst);
-    MARL_UPD_SHAPES(X)
-#undef X
+    bool found = false;
+    for (auto part : {&lossgrad_part_h64, &lossgrad_part_h128, &lossgrad_part_h64_oid, &lossgrad_part_h128_oid}) {
+        const int rc = part(s, params, target_params, bt, rsrc, gamma, double_q, mode, workspace, workspace_bytes, grad, loss,
+                            (hipStream_t)stream, qx, rst, &found);
+        if (found) return rc;
+    }
     set_error("no update kernel for net shape D=%d H=%d A=%d", s->obs_dim, s->hidden, s->n_actions);
     return -1;
 }

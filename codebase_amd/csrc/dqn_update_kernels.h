@@ -56,10 +56,11 @@ struct UpdLds {
     static constexpr int TILE = 16 * S::H;                    // one [H][16] transpose tile
     static constexpr int PER_WAVE = 4 * TILE + 256;           // h2, h1, dH2, dH1 transpose tiles + dQ tile
     static constexpr int oC = 0, oT = S::NFWD, oB = 2 * S::NFWD, oTiles = oB + S::NBWD;
-    static constexpr int total(int waves) { return oTiles + waves * PER_WAVE; }  // floats
     static constexpr int REC = S::NPARAM + 2;                 // partial record: grads, loss, n_filled
     static constexpr int FOLD = S::NPARAM + (2 * S::H + 18) * 16;  // per-wave fold region (weights + bias/loss strips)
-    static_assert(4 * FOLD <= oTiles + 4 * PER_WAVE, "fold regions overlay packs + tiles");
+    // floats: packs + tiles during the walk, the per-wave fold regions (overlaying them) in the epilogue
+    static constexpr int total(int waves) { return (oTiles + waves * PER_WAVE) > waves * FOLD ? (oTiles + waves * PER_WAVE) : waves * FOLD; }
+    static_assert(total(4) * 4 <= 160 * 1024, "packs + tiles / fold regions exceed the 160 KiB LDS");
 };
 
 // packs of one agent in the workspace: [critic fwd NFWD][target fwd NFWD][critic bwd NBWD]

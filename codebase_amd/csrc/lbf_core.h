@@ -30,6 +30,7 @@ struct LbfParams {
     double penalty;
     uint64_t seed;
     float* reward_stats;  // StandardiseReward wrapper state (utils/wrappers.py:111-142), [n_envs][3P+1] fp32, or nullptr
+    int observe_id;       // ObserveID wrapper (utils/wrappers.py:73-103): observations carry a one-hot agent-index prefix
 };
 
 template <int P, int F>

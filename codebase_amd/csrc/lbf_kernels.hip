@@ -13,15 +13,17 @@ constexpr int ENV_BLOCK = 256;
 template <int P, int F>
 __device__ __forceinline__ void write_obs_tile(const LbfParams& q, const LbfState<P, F>& s, bool valid, float* tile,
                                                float* __restrict__ obs, int n0, int cnt) {
-    constexpr int D = 3 * (F + P);
+    constexpr int D0 = 3 * (F + P);
+    const int idw = q.observe_id ? P : 0, D = D0 + idw;  // ObserveID: one-hot agent index first (wrappers.py:97-103)
     const int tid = threadIdx.x;
 #pragma unroll
     for (int p = 0; p < P; ++p) {
         if (valid) {
             LbfObs<P, F> o;
             lbf_observe(q, s, p, o);
+            for (int d = 0; d < idw; ++d) tile[tid * D + d] = d == p ? 1.f : 0.f;
 #pragma unroll
-            for (int d = 0; d < D; ++d) tile[tid * D + d] = o.v[d];
+            for (int d = 0; d < D0; ++d) tile[tid * D + idw + d] = o.v[d];
         }
         __syncthreads();
         float* dst = obs + ((size_t)p * q.n_envs + n0) * D;
@@ -120,8 +122,11 @@ __global__ __launch_bounds__(ENV_BLOCK) void lbf_step_kernel(LbfParams q, marlhi
                         for (int p = 0; p < P; ++p) {
                             LbfObs<P, F> o;
                             lbf_observe(q, s, p, o);
+                            const int idw = q.observe_id ? P : 0;
+                            float* fo = final_obs + ((size_t)p * q.n_envs + n) * (D + idw);
+                            for (int d = 0; d < idw; ++d) fo[d] = d == p ? 1.f : 0.f;
 #pragma unroll
-                            for (int d = 0; d < D; ++d) final_obs[((size_t)p * q.n_envs + n) * D + d] = o.v[d];
+                            for (int d = 0; d < D; ++d) fo[idw + d] = o.v[d];
                         }
                     }
                     const uint32_t epi = b.episode[n];
@@ -155,7 +160,7 @@ extern "C" int marlhip_lbf_state_stride(const marlhip_lbf_config* cfg) {
 
 extern "C" int marlhip_lbf_obs_dim(const marlhip_lbf_config* cfg) {
     MARL_REQUIRE(cfg != nullptr, "lbf config is NULL");
-    return 3 * (cfg->n_agents + cfg->n_food);
+    return 3 * (cfg->n_agents + cfg->n_food) + (cfg->observe_id ? cfg->n_agents : 0);
 }
 
 static int check_buffers(const marlhip_lbf_buffers* b) {
@@ -168,7 +173,7 @@ extern "C" int marlhip_lbf_reset(const marlhip_lbf_config* cfg, const marlhip_lb
     if (lbf_validate(cfg) != 0 || check_buffers(buf) != 0) return -1;
     const LbfParams q = to_params(cfg);
     const int grid = (cfg->n_envs + ENV_BLOCK - 1) / ENV_BLOCK;
-    const size_t lds = (size_t)ENV_BLOCK * 3 * (cfg->n_agents + cfg->n_food) * sizeof(float);
+    const size_t lds = (size_t)ENV_BLOCK * marlhip_lbf_obs_dim(cfg) * sizeof(float);
 #define X(p, f)                                                                                                     \
     if (cfg->n_agents == p && cfg->n_food == f)                                                                     \
         hipLaunchKernelGGL((lbf_reset_kernel<p, f>), dim3(grid), dim3(ENV_BLOCK), lds, (hipStream_t)stream, q, *buf, mask, obs);
@@ -183,7 +188,7 @@ extern "C" int marlhip_lbf_observe(const marlhip_lbf_config* cfg, const marlhip_
     MARL_REQUIRE(obs != nullptr, "obs is NULL");
     const LbfParams q = to_params(cfg);
     const int grid = (cfg->n_envs + ENV_BLOCK - 1) / ENV_BLOCK;
-    const size_t lds = (size_t)ENV_BLOCK * 3 * (cfg->n_agents + cfg->n_food) * sizeof(float);
+    const size_t lds = (size_t)ENV_BLOCK * marlhip_lbf_obs_dim(cfg) * sizeof(float);
 #define X(p, f)                                                                                                     \
     if (cfg->n_agents == p && cfg->n_food == f)                                                                     \
         hipLaunchKernelGGL((lbf_observe_kernel<p, f>), dim3(grid), dim3(ENV_BLOCK), lds, (hipStream_t)stream, q, *buf, obs);
@@ -200,7 +205,7 @@ extern "C" int marlhip_lbf_step(const marlhip_lbf_config* cfg, const marlhip_lbf
     MARL_REQUIRE(actions && obs && rewards && done && truncated && fin_return && fin_length, "lbf_step: NULL pointer");
     const LbfParams q = to_params(cfg);
     const int grid = (cfg->n_envs + ENV_BLOCK - 1) / ENV_BLOCK;
-    const size_t lds = (size_t)ENV_BLOCK * 3 * (cfg->n_agents + cfg->n_food) * sizeof(float);
+    const size_t lds = (size_t)ENV_BLOCK * marlhip_lbf_obs_dim(cfg) * sizeof(float);
     timing_begin(TIMER_ENVSTEP, (hipStream_t)stream);
 #define X(p, f)                                                                                                        \
     if (cfg->n_agents == p && cfg->n_food == f)                                                                        \

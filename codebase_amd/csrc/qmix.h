@@ -707,6 +707,7 @@ int qmix_launch_reduce(const QmixCtx& qx, int T, int B, const float* loss, hipSt
 }
 
 // (agents, obs dim) pairs with a compiled mixer = the LBF shapes of common.h
-#define MARL_QMIX_SHAPES(X) X(2, 12) X(2, 15) X(3, 18) X(3, 24) X(4, 21) X(4, 27) X(8, 39)
+#define MARL_QMIX_SHAPES(X) \
+    X(2, 12) X(2, 15) X(3, 18) X(3, 24) X(4, 21) X(4, 27) X(8, 39) /* env.observe_id: */ X(2, 14) X(2, 17) X(3, 21) X(3, 27) X(4, 25) X(4, 31) X(8, 47)
 
 }  // namespace marl

@@ -66,7 +66,7 @@ class BatchedForaging:
         self.device = torch.device(device)
         self.N, self.P, self.F = cfg.n_envs, cfg.n_agents, cfg.n_food
         self.stride = check(lib.marlhip_lbf_state_stride(ctypes.byref(cfg)), "lbf_state_stride")
-        self.D = 3 * (self.P + self.F)
+        self.D = 3 * (self.P + self.F) + (self.P if cfg.observe_id else 0)  # ObserveID: one-hot agent index first
         dev = self.device
         self.state = torch.zeros(self.N, self.stride, dtype=torch.uint8, device=dev)
         self.episode = torch.zeros(self.N, dtype=torch.int32, device=dev)  # u32 bit pattern

@@ -34,6 +34,8 @@ def _space_pair(cfg):
     low = np.array([-1, -1, 0] * (F + P), np.float32)
     high = np.array([cfg.rows - 1, cfg.cols - 1, cfg.max_player_level * min(P, 3)] * F
                     + [cfg.rows - 1, cfg.cols - 1, cfg.max_player_level] * P, np.float32)
+    if cfg.observe_id:  # ObserveID widens every agent's Box by n_agents (utils/wrappers.py:81-95: unbounded there)
+        low, high = np.concatenate((np.zeros(P, np.float32), low)), np.concatenate((np.ones(P, np.float32), high))
     obs = spaces.Tuple([spaces.Box(low, high) for _ in range(P)])
     act = spaces.Tuple([spaces.Discrete(6) for _ in range(P)])
     return obs, act
@@ -43,8 +45,7 @@ def _build_cfg(name, time_limit, clear_info, observe_id, standardise_rewards, wr
     if "Foraging" not in name:
         raise NotImplementedError(f"{name}: only Level-Based Foraging ids have a HIP env in this round "
                                   "(rware / smaclite are listed under 'next' in DESIGN.md)")
-    if observe_id:
-        raise NotImplementedError("observe_id is not folded into the HIP env yet (DESIGN.md)")
+    kwargs = dict(kwargs, observe_id=int(bool(observe_id)))  # ObserveID (utils/wrappers.py:73-103): one-hot prefix, in-kernel
     cooperative = False
     for w in wrappers or []:
         if w == "CooperativeReward":

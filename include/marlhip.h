@@ -57,6 +57,8 @@ typedef struct marlhip_lbf_config {
                                   [n_envs][3*n_agents + 1] fp32, zero-initialised, one streaming mean / variance record per
                                   env (sumw | wmean | t per agent, step count as int32 bits) that persists across episodes;
                                   NULL = wrapper off.  Applied before CooperativeReward, after RecordEpisodeStatistics. */
+    int32_t observe_id;        /* env.observe_id (ObserveID, utils/wrappers.py:73-103): every observation is prefixed with the
+                                  one-hot agent index, obs_dim = n_agents + 3 * (n_food + n_agents) */
 } marlhip_lbf_config;
 
 /* device buffers of a batched env (allocated by the caller) */
@@ -70,7 +72,7 @@ typedef struct marlhip_lbf_buffers {
 } marlhip_lbf_buffers;
 
 int marlhip_lbf_state_stride(const marlhip_lbf_config* cfg); /* bytes per env record, <0 if unsupported */
-int marlhip_lbf_obs_dim(const marlhip_lbf_config* cfg);      /* 3 * (n_food + n_agents) */
+int marlhip_lbf_obs_dim(const marlhip_lbf_config* cfg);      /* 3 * (n_food + n_agents) [+ n_agents with observe_id] */
 
 /* env.reset(): re-spawn the envs with mask[n] != 0 (mask NULL = all), episode[n] += 1 for those,
  * zero their running statistics, write their observations (obs may be NULL).

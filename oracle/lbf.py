@@ -393,7 +393,7 @@ class MarlbaseEnv:
     """ForagingEnv under the reference's wrapper stack (utils/envs.py:93-109):
     TimeLimit(time_limit) -> RecordEpisodeStatistics -> [CooperativeReward]."""
 
-    def __init__(self, name, time_limit, cooperative=False, rng=None, standardise_rewards=False, **overrides):
+    def __init__(self, name, time_limit, cooperative=False, rng=None, standardise_rewards=False, observe_id=False, **overrides):
         kw = parse_env_name(name)
         kw.update(overrides)
         self.env = ForagingEnv(rng=rng, **kw)
@@ -401,6 +401,7 @@ class MarlbaseEnv:
         self.time_limit = time_limit
         self.cooperative = cooperative
         self.standardise_rewards = standardise_rewards
+        self.observe_id = observe_id  # ObserveID (utils/wrappers.py:73-103): np.eye(P) row in front of every observation
         # StandardiseReward state (utils/wrappers.py:111-117): fp32 arrays + a python int; lives as long as the env object
         self.sr_sumw = np.zeros(self.n_agents, np.float32)
         self.sr_wmean = np.zeros(self.n_agents, np.float32)
@@ -411,8 +412,15 @@ class MarlbaseEnv:
         self.episode_length = 0
         self.t0 = perf_counter()
 
+    def _ids(self, obs):
+        if not self.observe_id:
+            return obs
+        eye = np.eye(self.n_agents, dtype=np.float32)
+        return tuple(np.concatenate((eye[p], o)) for p, o in enumerate(obs))
+
     def reset(self, rng=None):
         obs, info = self.env.reset(rng)
+        obs = self._ids(obs)
         self._elapsed = 0
         self.episode_reward = 0  # wrappers.py:26 (int 0, becomes float32 array)
         self.episode_length = 0
@@ -421,6 +429,7 @@ class MarlbaseEnv:
 
     def step(self, actions):
         obs, reward, done, truncated, info = self.env.step(actions)
+        obs = self._ids(obs)
         self._elapsed += 1  # gymnasium TimeLimit
         if self.time_limit and self._elapsed >= self.time_limit:
             truncated = True

@@ -24,6 +24,7 @@ static LbfParams conv(const HostCfg* c) {
     q.min_food_level = c->min_food_level; q.max_food_level = c->max_food_level; q.normalize_reward = c->normalize_reward;
     q.cooperative = c->cooperative; q.penalty = c->penalty; q.seed = c->seed;
     q.reward_stats = c->reward_stats;
+    q.observe_id = 0;
     return q;
 }
 
