@@ -53,7 +53,8 @@ class QmixMixer(ctypes.Structure):
 
 class AcConfig(ctypes.Structure):
     _fields_ = [("n_steps", c_int32), ("entropy_coef", c_float), ("value_loss_coef", c_float), ("ppo_clip", c_float),
-                ("gamma", c_double), ("ret_mean", c_void_p), ("ret_var", c_void_p), ("ret_count", c_void_p)]
+                ("gamma", c_double), ("ret_mean", c_void_p), ("ret_var", c_void_p), ("ret_count", c_void_p),
+                ("centralised_critic", c_int32)]
 
 
 class RetStatsStruct(ctypes.Structure):
@@ -110,8 +111,8 @@ PROTOTYPES = {
     "marlhip_qmix_loss_grad_replay": (c_int32, [POINTER(NetShape), c_void_p, c_void_p, POINTER(QmixMixer), POINTER(ReplayShape),
                                                 POINTER(ReplayBuffers), c_void_p, c_int32, c_int32, c_uint64, c_uint32, c_void_p,
                                                 c_float, c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
-    "marlhip_ac_critic_nparams": (c_int32, [POINTER(NetShape)]),
-    "marlhip_ac_workspace_bytes": (c_int64, [POINTER(NetShape), c_int32, c_int32]),
+    "marlhip_ac_critic_nparams": (c_int32, [POINTER(NetShape), c_int32]),
+    "marlhip_ac_workspace_bytes": (c_int64, [POINTER(NetShape), c_int32, c_int32, c_int32]),
     "marlhip_ac_forward_rows": (c_int32, [POINTER(NetShape), c_int32, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_void_p,
                                           c_void_p]),
     "marlhip_a2c_loss_grad": (c_int32, [POINTER(NetShape), c_void_p, c_void_p, c_void_p, POINTER(BatchStruct), POINTER(AcConfig),

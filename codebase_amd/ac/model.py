@@ -11,8 +11,8 @@ Interface kept: constructor `(obs_space, action_space, cfg, actor, critic, devic
 Storage: ONE flat fp32 block [actor agents | critic agents] (so that clip_grad_norm_(self.parameters()) + Adam is a
 single fused launch) plus the target-critic block; state_dict tensors are slices.
 Built: independent or shared (parameter_sharing True / SePS index list, the same for actor and critic) actors and
-critics (IA2C / IPPO), two equal hidden layers of 64 or 128.  Not built (raise): centralised critic (MAA2C / MAPPO),
-GRU, action masks, return standardisation.
+critics (IA2C / IPPO) and centralised critics (MAA2C / MAPPO: hidden 128 up to 4 agents, hidden 64 for 2), two equal
+hidden layers of 64 or 128.  Not built (raise): GRU, action masks.
 """
 from collections import OrderedDict
 
@@ -46,8 +46,6 @@ class A2CNetwork:
         for name, net in (("actor", actor), ("critic", critic)):
             if _get(net, "use_rnn", False):
                 raise NotImplementedError(f"{name}.use_rnn: the GRU path is a 'next' row (DESIGN.md)")
-        if _get(critic, "centralised", False):
-            raise NotImplementedError("critic.centralised (MAA2C / MAPPO) is a 'next' row (DESIGN.md)")
         ha, hc = [int(h) for h in _get(actor, "layers")], [int(h) for h in _get(critic, "layers")]
         if ha != hc or len(ha) != 2 or ha[0] != ha[1]:
             raise NotImplementedError(f"layers actor={ha} critic={hc}: the HIP kernels implement two equal hidden layers (64 or 128), "
@@ -65,7 +63,7 @@ class A2CNetwork:
         self.value_loss_coef = float(_get(cfg, "value_loss_coef", 0.5))
         self.target_update_interval_or_tau = _get(cfg, "target_update_interval_or_tau", 200)
         self.standardise_returns = bool(_get(cfg, "standardise_returns", False))
-        self.centralised_critic = False
+        self.centralised_critic = bool(_get(critic, "centralised", False))  # MAA2C / MAPPO (model.py:62-66)
         self.spec = _hip.NetSpec(P, obs_dims[0], ha[0], act_dims[0], self.sharing)
         if self.sharing is not None:  # one network per distinct index, in order of first appearance (utils/models.py:209-240)
             first = [self.sharing.index(k) for k in range(max(self.sharing) + 1)]
@@ -73,14 +71,16 @@ class A2CNetwork:
         K = self.spec.n_blocks
         # torch RNG consumption in the reference's order: actor nets, critic nets, target-critic nets (model.py:44-107)
         a0 = _init_blocks(obs_dims, ha, act_dims, _get(actor, "use_orthogonal_init", True))
-        c0 = _init_blocks(obs_dims, hc, [1] * K, _get(critic, "use_orthogonal_init", True))
-        _init_blocks(obs_dims, hc, [1] * K, _get(critic, "use_orthogonal_init", True))  # target: drawn, then overwritten (soft_update(1.0))
+        cdims = [self.n_agents * self.spec.obs_dim] * K if self.centralised_critic else obs_dims  # critic_obs_shape (model.py:63-65)
+        c0 = _init_blocks(cdims, hc, [1] * K, _get(critic, "use_orthogonal_init", True))
+        _init_blocks(cdims, hc, [1] * K, _get(critic, "use_orthogonal_init", True))  # target: drawn, then overwritten (soft_update(1.0))
         self.block = torch.cat([a0.reshape(-1), c0.reshape(-1)]).to(self.device).contiguous()
         self.target_critic_params = c0.clone().to(self.device).contiguous()
         self.updater = _hip.AcUpdater(self.spec, self.block, self.target_critic_params, lr=float(_get(cfg, "lr", 3e-4)),
                                       gamma=self.gamma, n_steps=self.n_steps, entropy_coef=self.entropy_coef,
                                       value_loss_coef=self.value_loss_coef, grad_clip=self.grad_clip,
-                                      ppo_clip=float(_get(cfg, "ppo_clip", 0.2)), standardise_returns=self.standardise_returns)
+                                      ppo_clip=float(_get(cfg, "ppo_clip", 0.2)), standardise_returns=self.standardise_returns,
+                                      centralised_critic=self.centralised_critic)
         self.ret_ms = self.updater.ret_stats
         self.actor_params, self.critic_params = self.updater.actor, self.updater.critic
 
@@ -116,9 +116,15 @@ class A2CNetwork:
 
     def get_value(self, inputs, critic_hiddens, target=False):
         """model.py:155-163: [..., P] values of the (target) critic"""
+        blk = self.target_critic_params if target else self.critic_params
+        if self.centralised_critic:  # every critic reads the concatenation of all agents' observations (model.py:156-157)
+            x = torch.cat([torch.as_tensor(i, dtype=torch.float32).to(self.device) for i in inputs], dim=-1)
+            lead = x.shape[:-1]
+            x = x.reshape(-1, x.shape[-1]).contiguous()
+            out = _hip.ac_forward_rows(self.spec, blk, x, 0, x.shape[1], x.shape[0], value_net=2)
+            return out.reshape(self.n_agents, *lead).movedim(0, -1).contiguous(), critic_hiddens
         x, lead = self._rows(inputs)
         n, D = x.shape[1], x.shape[2]
-        blk = self.target_critic_params if target else self.critic_params
         out = _hip.ac_forward_rows(self.spec, blk, x, n * D, D, n, value_net=True)
         return out.reshape(self.n_agents, *lead).movedim(0, -1).contiguous(), critic_hiddens
 
@@ -159,7 +165,8 @@ class A2CNetwork:
                                  ("target_critic", self.target_critic_params, 1)):
             for i in range(P):
                 o = 0
-                for name, shape in _tensor_layout(S.obs_dim, S.hidden, A):
+                cin = S.n_agents * S.obs_dim if (self.centralised_critic and prefix != "actor") else S.obs_dim
+                for name, shape in _tensor_layout(cin, S.hidden, A):
                     n = int(np.prod(shape))
                     out[f"{prefix}.{group}.{i}.{name}"] = block[i, o:o + n].view(shape)
                     o += n

@@ -83,11 +83,21 @@ _IA2C = {  # configs/algorithm/ia2c.yaml
                   "target_update_interval_or_tau": 200},
 }
 ALGORITHMS["ia2c"] = _IA2C
+def _centralised(base, name):
+    c = copy.deepcopy(base)
+    c["algorithm"]["name"] = name
+    c["algorithm"]["model"]["critic"]["centralised"] = True
+    return c
+
+
 ALGORITHMS["ippo"] = {  # configs/algorithm/ippo.yaml
     "env": {"parallel_envs": 10},
     "algorithm": dict(copy.deepcopy(_IA2C["algorithm"]), name="ippo", num_epochs=4, ppo_clip=0.2,
                       model=dict(copy.deepcopy(_IA2C["algorithm"]["model"]), _target_="ac.model.PPONetwork")),
 }
+
+ALGORITHMS["maa2c"] = _centralised(_IA2C, "maa2c")              # configs/algorithm/maa2c.yaml
+ALGORITHMS["mappo"] = _centralised(ALGORITHMS["ippo"], "mappo")  # configs/algorithm/mappo.yaml
 
 
 def _merge(dst, src):

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void mlp_rows_fwd_kernel(const float* __restri
 template <class S>
 int launch_forward_rows(int P, const AgentMap& am, const float* params, const marlhip_batch* bt, int n_rows, float* out, hipStream_t st) {
     const int T = bt->max_len, B = bt->batch;
-    const size_t as = bt->obs_agent_stride ? (size_t)bt->obs_agent_stride : (size_t)(T + 1) * B * S::D;
+    const size_t as = bt->obs_agent_stride > 0 ? (size_t)bt->obs_agent_stride : (bt->obs_agent_stride < 0 ? 0 : (size_t)(T + 1) * B * S::D);
     const size_t rs = bt->obs_row_stride ? (size_t)bt->obs_row_stride : (size_t)S::D;
     constexpr int LDSB = S::NFWD * (int)sizeof(float);
     static bool attr_set = false;
@@ -327,12 +327,16 @@ AcWs ac_ws_layout(int P, int T, int B) {
     return w;
 }
 
-template <int D, int H, int A>
+// DC = the critics' input width: D (independent critics) or P * D (critic.centralised: every critic reads the whole row)
+template <int D, int H, int A, int DC>
 int ac_step(int P, const AgentMap& am, const float* actor, const float* critic, const float* target, const marlhip_batch* bt, const marlhip_ac_config* c,
             int mode, void* ws, int64_t ws_bytes, float* actor_grad, float* critic_grad, float* metrics, hipStream_t st) {
     using SA = MlpShape<D, H, A>;
-    using SC = MlpShape<D, H, 1>;
+    using SC = MlpShape<DC, H, 1>;
     const int T = bt->max_len, B = bt->batch, TB = T * B;
+    marlhip_batch btc = *bt;  // the critics' view of the batch
+    if (DC != D) btc.obs_agent_stride = -1;
+    const marlhip_batch* bc = &btc;
     const AcWs wl = ac_ws_layout<SA, SC>(P, T, B);
     MARL_REQUIRE(ws_bytes >= wl.total, "ac_loss_grad: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)wl.total);
     char* base = static_cast<char*>(ws);
@@ -352,7 +356,7 @@ int ac_step(int P, const AgentMap& am, const float* actor, const float* critic, 
     int rc;
     timing_begin(TIMER_LOSSGRAD, st);
     if (mode != 2) {  // target-critic values of all T+1 observations (model.py:190-193); PPO reuses the returns across epochs
-        rc = launch_forward_rows<SC>(P, am, target, bt, TB + B, f(wl.vnext), st);
+        rc = launch_forward_rows<SC>(P, am, target, bc, TB + B, f(wl.vnext), st);
         if (rc != 0) return rc;
     }
     if (std_on && mode == 0) {  // A2C with standardise_returns: raw returns -> statistics update -> A2C on the stored returns
@@ -364,7 +368,7 @@ int ac_step(int P, const AgentMap& am, const float* actor, const float* critic, 
     rc = launch_forward_rows<SA>(P, am, actor, bt, TB, f(wl.logits), st);
     if (rc != 0) return rc;
     if (mode != 1) {
-        rc = launch_forward_rows<SC>(P, am, critic, bt, TB, f(wl.v), st);
+        rc = launch_forward_rows<SC>(P, am, critic, bc, TB, f(wl.v), st);
         if (rc != 0) return rc;
     }
     hipLaunchKernelGGL(ac_elem_kernel, dim3((TB + 255) / 256), dim3(256), 0, st, a, *bt, w);
@@ -378,7 +382,7 @@ int ac_step(int P, const AgentMap& am, const float* actor, const float* critic, 
     float* scratch = f(wl.scratch);
     rc = launch_backward_rows<SA>(P, am, actor, bt, w.dlogits, w.lrow_a, base + wl.bwd, ws_bytes - wl.bwd, actor_grad, scratch, st);
     if (rc != 0) return rc;
-    rc = launch_backward_rows<SC>(P, am, critic, bt, w.dv, w.lrow_v, base + wl.bwd, ws_bytes - wl.bwd, critic_grad, scratch + 2, st);
+    rc = launch_backward_rows<SC>(P, am, critic, bc, w.dv, w.lrow_v, base + wl.bwd, ws_bytes - wl.bwd, critic_grad, scratch + 2, st);
     if (rc != 0) return rc;
     hipLaunchKernelGGL(ac_metrics_kernel, dim3(1), dim3(1024), 0, st, (TB + 255) / 256, c->value_loss_coef, (const float*)w.partial,
                        metrics);
@@ -395,11 +399,21 @@ using namespace marl;
 #define MARL_AC_SHAPES(X) \
     X(12, 64) X(15, 64) X(18, 64) X(21, 64) X(24, 64) X(27, 64) X(39, 64) X(12, 128) X(15, 128) X(18, 128) X(21, 128) X(24, 128) X(27, 128) X(39, 128) \
     X(14, 64) X(17, 64) X(25, 64) X(31, 64) X(47, 64) X(14, 128) X(17, 128) X(25, 128) X(31, 128) X(47, 128) /* env.observe_id */
+// (agents, obs dim, hidden) with a compiled CENTRALISED critic (P * D inputs): hidden 128 up to 4 agents (weights and dW1
+// accumulators of a P*D-wide first layer still fit the register file), hidden 64 for 2 agents (LDS-resident packs)
+#define MARL_MAC_SHAPES(X) X(2, 12, 128) X(2, 15, 128) X(3, 18, 128) X(3, 24, 128) X(4, 21, 128) X(4, 27, 128) X(2, 12, 64) X(2, 15, 64)
 
-static int ac_check(const marlhip_net_shape* s) {
+static int ac_check(const marlhip_net_shape* s, int centralised = 0) {
     MARL_REQUIRE(s != nullptr, "net shape is NULL");
     if (agent_map_validate(s) != 0) return -1;
     MARL_REQUIRE(s->n_agents >= 1 && s->n_actions == 6, "ac: the compiled actors have 6 actions (LBF), got %d", s->n_actions);
+    if (centralised) {
+#define X(p, d, h) if (s->n_agents == p && s->obs_dim == d && s->hidden == h) return 0;
+        MARL_MAC_SHAPES(X)
+#undef X
+        set_error("no centralised-critic kernels for %d agents x obs_dim %d, hidden %d (MARL_MAC_SHAPES)", s->n_agents, s->obs_dim, s->hidden);
+        return -1;
+    }
 #define X(d, h) if (s->obs_dim == d && s->hidden == h) return 0;
     MARL_AC_SHAPES(X)
 #undef X
@@ -407,16 +421,28 @@ static int ac_check(const marlhip_net_shape* s) {
     return -1;
 }
 
-extern "C" int marlhip_ac_critic_nparams(const marlhip_net_shape* s) {
-    if (ac_check(s) != 0) return -1;
+extern "C" int marlhip_ac_critic_nparams(const marlhip_net_shape* s, int32_t centralised) {
+    if (ac_check(s, centralised) != 0) return -1;
+    if (centralised) {
+#define X(p, d, h) if (s->n_agents == p && s->obs_dim == d && s->hidden == h) return MlpShape<p * d, h, 1>::NPARAM;
+        MARL_MAC_SHAPES(X)
+#undef X
+    }
 #define X(d, h) if (s->obs_dim == d && s->hidden == h) return MlpShape<d, h, 1>::NPARAM;
     MARL_AC_SHAPES(X)
 #undef X
     return -1;
 }
 
-extern "C" int64_t marlhip_ac_workspace_bytes(const marlhip_net_shape* s, int32_t max_len, int32_t batch) {
-    if (ac_check(s) != 0) return -1;
+extern "C" int64_t marlhip_ac_workspace_bytes(const marlhip_net_shape* s, int32_t centralised, int32_t max_len, int32_t batch) {
+    if (ac_check(s, centralised) != 0) return -1;
+    if (centralised) {
+#define X(p, d, h)                                                   \
+    if (s->n_agents == p && s->obs_dim == d && s->hidden == h)       \
+        return ac_ws_layout<MlpShape<d, h, 6>, MlpShape<p * d, h, 1>>(s->n_agents, max_len, batch).total;
+        MARL_MAC_SHAPES(X)
+#undef X
+    }
 #define X(d, h) \
     if (s->obs_dim == d && s->hidden == h) return ac_ws_layout<MlpShape<d, h, 6>, MlpShape<d, h, 1>>(s->n_agents, max_len, batch).total;
     MARL_AC_SHAPES(X)
@@ -427,8 +453,8 @@ extern "C" int64_t marlhip_ac_workspace_bytes(const marlhip_net_shape* s, int32_
 static int ac_call(const marlhip_net_shape* s, const float* actor, const float* critic, const float* target, const marlhip_batch* bt,
                    const marlhip_ac_config* c, int mode, void* ws, int64_t ws_bytes, float* actor_grad, float* critic_grad,
                    float* metrics, void* stream) {
-    if (ac_check(s) != 0) return -1;
     MARL_REQUIRE(actor && critic && bt && c && ws, "ac_loss_grad: NULL pointer");
+    if (ac_check(s, c->centralised_critic) != 0) return -1;
     MARL_REQUIRE(mode == 1 || (actor_grad && critic_grad && metrics), "ac_loss_grad: NULL output");
     MARL_REQUIRE(mode == 2 || target != nullptr, "ac_loss_grad: NULL target critic");
     MARL_REQUIRE(bt->obss && bt->actions && bt->rewards && bt->dones && bt->filled, "ac_loss_grad: NULL batch field");
@@ -436,22 +462,36 @@ static int ac_call(const marlhip_net_shape* s, const float* actor, const float* 
     MARL_REQUIRE(c->n_steps >= 1 && c->n_steps <= 16, "ac_loss_grad: n_steps %d outside [1, 16]", c->n_steps);
     MARL_REQUIRE((c->ret_mean == nullptr) == (c->ret_var == nullptr) && (c->ret_mean == nullptr) == (c->ret_count == nullptr),
                  "ac_loss_grad: return statistics must be given together (mean, var, count) or not at all");
-#define X(d, h)                                                                                                                  \
-    if (s->obs_dim == d && s->hidden == h)                                                                                        \
-        return ac_step<d, h, 6>(s->n_agents, agent_map(s), actor, critic, target, bt, c, mode, ws, ws_bytes, actor_grad, critic_grad, metrics, \
-                                (hipStream_t)stream);
+#define MARL_AC_ARGS s->n_agents, agent_map(s), actor, critic, target, bt, c, mode, ws, ws_bytes, actor_grad, critic_grad, metrics, (hipStream_t)stream
+    if (c->centralised_critic) {
+        MARL_REQUIRE(bt->obs_row_stride == (int64_t)s->n_agents * s->obs_dim && bt->obs_agent_stride == s->obs_dim,
+                     "ac_loss_grad: a centralised critic needs the ac/train.py Batch layout (agents concatenated in a row)");
+#define X(p, d, h) if (s->n_agents == p && s->obs_dim == d && s->hidden == h) return ac_step<d, h, 6, p * d>(MARL_AC_ARGS);
+        MARL_MAC_SHAPES(X)
+#undef X
+    }
+#define X(d, h) if (s->obs_dim == d && s->hidden == h) return ac_step<d, h, 6, d>(MARL_AC_ARGS);
     MARL_AC_SHAPES(X)
 #undef X
+#undef MARL_AC_ARGS
     return -1;
 }
 
 extern "C" int marlhip_ac_forward_rows(const marlhip_net_shape* s, int32_t value_net, const float* params, const float* obs,
                                        int64_t agent_stride, int64_t row_stride, int32_t n_rows, float* out, void* stream) {
-    if (ac_check(s) != 0) return -1;
-    MARL_REQUIRE(params && obs && out && n_rows > 0 && agent_stride > 0 && row_stride > 0, "ac_forward_rows: bad argument");
+    if (ac_check(s, value_net == 2) != 0) return -1;
+    MARL_REQUIRE(params && obs && out && n_rows > 0 && row_stride > 0 && (agent_stride > 0 || value_net == 2), "ac_forward_rows: bad argument");
     marlhip_batch bt = {};
     bt.obss = obs; bt.max_len = 1; bt.batch = 1;
-    bt.obs_agent_stride = agent_stride; bt.obs_row_stride = row_stride;
+    bt.obs_agent_stride = value_net == 2 ? -1 : agent_stride;
+    bt.obs_row_stride = row_stride;
+    if (value_net == 2) {
+#define X(p, d, h)                                               \
+    if (s->n_agents == p && s->obs_dim == d && s->hidden == h)   \
+        return launch_forward_rows<MlpShape<p * d, h, 1>>(s->n_agents, agent_map(s), params, &bt, n_rows, out, (hipStream_t)stream);
+        MARL_MAC_SHAPES(X)
+#undef X
+    }
 #define X(d, h)                                                                                                            \
     if (s->obs_dim == d && s->hidden == h)                                                                                  \
         return value_net ? launch_forward_rows<MlpShape<d, h, 1>>(s->n_agents, agent_map(s), params, &bt, n_rows, out, (hipStream_t)stream) \

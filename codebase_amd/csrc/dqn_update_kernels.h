@@ -149,7 +149,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dqn_lossgrad_kernel(con
 
     const int P = gridDim.y;
     // row (t, b) of agent p = obss + p * agent stride + (t * B + b) * row stride (defaults: the dqn/train.py Batch)
-    const size_t obs_as = bt.obs_agent_stride ? (size_t)bt.obs_agent_stride : (size_t)(T + 1) * B * D;
+    const size_t obs_as = bt.obs_agent_stride > 0 ? (size_t)bt.obs_agent_stride : (bt.obs_agent_stride < 0 ? 0 : (size_t)(T + 1) * B * D);
     const size_t obs_rs = bt.obs_row_stride ? (size_t)bt.obs_row_stride : (size_t)D;
     const float* obs_p = REPLAY ? nullptr : bt.obss + (size_t)p * obs_as;
     const int64_t* act_p = (REPLAY || MODE == 4) ? nullptr : bt.actions + (size_t)p * T * B;

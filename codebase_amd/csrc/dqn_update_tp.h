@@ -213,7 +213,7 @@ __global__ __launch_bounds__(64 * W, 1) void tp_fwd_kernel(const float* __restri
         }
     }
     TpSrc<S, REPLAY> src;
-    src.obs_p = REPLAY ? nullptr : bt.obss + (size_t)p * (bt.obs_agent_stride ? (size_t)bt.obs_agent_stride : (size_t)(T + 1) * B * S::D);
+    src.obs_p = REPLAY ? nullptr : bt.obss + (size_t)p * (bt.obs_agent_stride > 0 ? (size_t)bt.obs_agent_stride : (bt.obs_agent_stride < 0 ? 0 : (size_t)(T + 1) * B * S::D));
     src.obs_rs = bt.obs_row_stride ? (size_t)bt.obs_row_stride : (size_t)S::D;
     src.act_p = REPLAY ? nullptr : bt.actions + (size_t)p * T * B;
     src.rew_p = REPLAY ? nullptr : bt.rewards + (size_t)p * T * B;
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(64 * W, 1) void tp_bwd_kernel(const float* __restri
     float loss_acc = 0.f, nfill_acc = 0.f;
 
     TpSrc<S, REPLAY> src;
-    src.obs_p = REPLAY ? nullptr : bt.obss + (size_t)p * (bt.obs_agent_stride ? (size_t)bt.obs_agent_stride : (size_t)(T + 1) * B * D);
+    src.obs_p = REPLAY ? nullptr : bt.obss + (size_t)p * (bt.obs_agent_stride > 0 ? (size_t)bt.obs_agent_stride : (bt.obs_agent_stride < 0 ? 0 : (size_t)(T + 1) * B * D));
     src.obs_rs = bt.obs_row_stride ? (size_t)bt.obs_row_stride : (size_t)D;
     src.act_p = (REPLAY || FULL) ? nullptr : bt.actions + (size_t)p * T * B;
     src.rew_p = (REPLAY || FULL) ? nullptr : bt.rewards + (size_t)p * T * B;

@@ -349,11 +349,12 @@ class QmixUpdater(DqnUpdater):
 
 
 def ac_forward_rows(spec: NetSpec, params, obs, agent_stride, row_stride, n_rows, value_net=False):
-    """out[p][row][:] = MLP_p(obs row); value_net: the critic shape (one output)."""
+    """out[p][row][:] = MLP_p(obs row); value_net: 1 = the critic shape (one output), 2 = the centralised critic (P*D inputs,
+    every agent reads the same concatenated row)."""
     _require_gpu()
     s = spec.c()
     out = torch.empty(spec.n_agents, n_rows, 1 if value_net else spec.n_actions, device=params.device)
-    check(lib.marlhip_ac_forward_rows(ctypes.byref(s), int(bool(value_net)), _ptr(params), _ptr(obs), int(agent_stride),
+    check(lib.marlhip_ac_forward_rows(ctypes.byref(s), int(value_net), _ptr(params), _ptr(obs), int(agent_stride),
                                       int(row_stride), int(n_rows), _ptr(out), _stream()), "ac_forward_rows")
     return out
 
@@ -364,13 +365,15 @@ class AcUpdater:
     `block` is ONE flat fp32 tensor [P*n_actor + P*n_critic]: actor blocks first (parameters() order), then critic."""
 
     def __init__(self, spec: NetSpec, block, target_critic, lr=3e-4, betas=(0.9, 0.999), eps=1e-8, gamma=0.99, n_steps=5,
-                 entropy_coef=0.001, value_loss_coef=0.5, grad_clip=False, ppo_clip=0.2, standardise_returns=False):
+                 entropy_coef=0.001, value_loss_coef=0.5, grad_clip=False, ppo_clip=0.2, standardise_returns=False,
+                 centralised_critic=False):
         _require_gpu()
+        self.centralised = int(bool(centralised_critic))
         self.ret_stats = RunningReturnStats(spec.n_agents, block.device) if standardise_returns else None
         s = spec.c()
         self.spec = spec
         self.n_actor = spec.nparams()
-        self.n_critic = check(lib.marlhip_ac_critic_nparams(ctypes.byref(s)), "ac_critic_nparams")
+        self.n_critic = check(lib.marlhip_ac_critic_nparams(ctypes.byref(s), self.centralised), "ac_critic_nparams")
         P = spec.n_blocks
         if block.numel() != P * (self.n_actor + self.n_critic) or target_critic.numel() != P * self.n_critic:
             raise ValueError("actor-critic parameter block has the wrong size for this shape")
@@ -387,7 +390,7 @@ class AcUpdater:
         rs = self.ret_stats
         self.cfg = AcConfig(int(n_steps), float(entropy_coef), float(value_loss_coef), float(ppo_clip), float(gamma),
                             rs.mean.data_ptr() if rs else None, rs.var.data_ptr() if rs else None,
-                            rs.count_t.data_ptr() if rs else None)
+                            rs.count_t.data_ptr() if rs else None, self.centralised)
         self.lr, self.betas, self.eps = lr, betas, eps
         self.grad_clip = float(grad_clip) if grad_clip else 0.0
         self.step = 0
@@ -396,7 +399,7 @@ class AcUpdater:
     def _workspace(self, T, B):
         if (T, B) not in self._ws:
             s = self.spec.c()
-            n = check(lib.marlhip_ac_workspace_bytes(ctypes.byref(s), T, B), "ac_workspace_bytes")
+            n = check(lib.marlhip_ac_workspace_bytes(ctypes.byref(s), self.centralised, T, B), "ac_workspace_bytes")
             self._ws[(T, B)] = torch.empty(int(n), dtype=torch.uint8, device=self.block.device)
         return self._ws[(T, B)]
 

@@ -183,7 +183,8 @@ typedef struct marlhip_batch {
     int32_t max_len, batch; /* T, B */
     /* optional strides in ELEMENTS, 0 = the dqn/train.py layout above.  The ac/train.py Batch (ac/train.py:36-49) keeps the
      * agents innermost: obss [T+1][B][P*D] -> obs_agent_stride = D, obs_row_stride = P*D; actions / rewards [T][B][P] ->
-     * act_agent_stride = 1, act_row_stride = P.  (obs strides: every learner entry point; act strides: marlhip_ac_* only) */
+     * act_agent_stride = 1, act_row_stride = P.  (obs strides: every learner entry point; act strides: marlhip_ac_* only)
+     * obs_agent_stride < 0: every agent reads the SAME rows (centralised critics: the whole P*D row is the input). */
     int64_t obs_agent_stride, obs_row_stride, act_agent_stride, act_row_stride;
 } marlhip_batch;
 
@@ -275,12 +276,16 @@ typedef struct marlhip_ac_config {
     float* ret_mean;
     float* ret_var;
     double* ret_count;
+    int32_t centralised_critic; /* critic.centralised (MAA2C / MAPPO, model.py:62-66,155-157): every agent's critic and target
+                                   critic takes the concatenation of ALL agents' observations (P*D inputs); compiled for
+                                   hidden 128 up to 4 agents and hidden 64 for 2 agents */
 } marlhip_ac_config;
 
-int marlhip_ac_critic_nparams(const marlhip_net_shape* s);
-int64_t marlhip_ac_workspace_bytes(const marlhip_net_shape* s, int32_t max_len, int32_t batch);
+int marlhip_ac_critic_nparams(const marlhip_net_shape* s, int32_t centralised); /* per critic block */
+int64_t marlhip_ac_workspace_bytes(const marlhip_net_shape* s, int32_t centralised, int32_t max_len, int32_t batch);
 /* A2CNetwork.get_value / the actor forward of A2CNetwork.act (model.py:147-163) on arbitrary rows:
- * out[p][row][:] = MLP_p(obs + p * agent_stride + row * row_stride); value_net != 0: the one-output critic shape. */
+ * out[p][row][:] = MLP_p(obs + p * agent_stride + row * row_stride); value_net 1: the one-output critic shape; value_net 2:
+ * the centralised critic (P*D inputs, agent_stride 0: rows are the concatenated observations). */
 int marlhip_ac_forward_rows(const marlhip_net_shape* s, int32_t value_net, const float* params, const float* obs,
                             int64_t agent_stride, int64_t row_stride, int32_t n_rows, float* out, void* stream);
 int marlhip_a2c_loss_grad(const marlhip_net_shape* s, const float* actor, const float* critic, const float* target_critic,

@@ -41,8 +41,11 @@ def _split_obs(obss, P):
 
 
 def values(block, obss, D, H):
-    """[P][n] value-net blocks, obss [..., P*D] -> [..., P]"""
+    """[P][n] value-net blocks, obss [..., P*D] -> [..., P]; a block sized for P*D inputs is a centralised critic
+    (critic.centralised, ac/model.py:62-66,156-157): every agent's critic reads the whole concatenated row."""
     P = block.shape[0]
+    if block.shape[1] == dp.nparams(P * D, H, 1) and P > 1:
+        return torch.cat([dp.mlp(block[p], obss, P * D, H, 1) for p in range(P)], dim=-1)
     xs = _split_obs(obss, P)
     return torch.cat([dp.mlp(block[p], xs[p], D, H, 1) for p in range(P)], dim=-1)
 
@@ -109,7 +112,8 @@ class Learner:
         self.ret_ms = dp.RunningMeanStd((actor.shape[0],)) if standardise_returns else None
         self.D, self.H, self.A, self.P = D, H, A, actor.shape[0]
         self.at = [torch.nn.Parameter(t.clone()) for p in range(self.P) for t in dp.split(actor[p], D, H, A)]
-        self.ct = [torch.nn.Parameter(t.clone()) for p in range(self.P) for t in dp.split(critic[p], D, H, 1)]
+        dc = self.P * D if critic.shape[1] == dp.nparams(self.P * D, H, 1) and self.P > 1 else D  # centralised critic
+        self.ct = [torch.nn.Parameter(t.clone()) for p in range(self.P) for t in dp.split(critic[p], dc, H, 1)]
         self.target = critic.clone()
         self.opt = torch.optim.Adam(self.at + self.ct, lr=lr)
         self.gamma, self.n_steps, self.ec, self.vc = gamma, n_steps, entropy_coef, value_loss_coef

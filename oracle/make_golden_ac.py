@@ -27,9 +27,11 @@ def build(cls, P, D, A, H, seed, **over):
     cfg = Cfg(optimizer="Adam", lr=3e-4, gamma=0.99, grad_clip=False, n_steps=5, entropy_coef=0.001, value_loss_coef=0.5,
               standardise_returns=False, target_update_interval_or_tau=200, num_epochs=4, ppo_clip=0.2)
     cfg.update(over)
+    centralised = bool(over.pop("centralised", False)) if "centralised" in over else False
+    cfg.pop("centralised", None)
     net_cfg = dict(layers=[H, H], parameter_sharing=False, use_orthogonal_init=True, use_rnn=False)
     with contextlib.redirect_stdout(io.StringIO()):
-        net = cls([Box(D)] * P, [Discrete(A)] * P, cfg, Cfg(net_cfg), Cfg(dict(net_cfg, centralised=False)), "cpu")
+        net = cls([Box(D)] * P, [Discrete(A)] * P, cfg, Cfg(net_cfg), Cfg(dict(net_cfg, centralised=centralised)), "cpu")
     g = torch.Generator().manual_seed(seed + 1)
     with torch.no_grad():  # non-zero biases, target != critic
         for p in list(net.actor.parameters()) + list(net.critic.parameters()):
@@ -50,7 +52,7 @@ def fixture(ref_ac_model, ref_ac_train, name, cls, P, D, H, N, seed, **over):
     batches = [synthetic_batch(P, T, N, D, A, seed=seed + 100 + i) for i in range(3)]
     mk = lambda b: ref_ac_train.Batch(b["obss"], b["actions"], b["rewards"], b["dones"], b["filled"], None)  # noqa: E731
     if cls is ref_ac_model.A2CNetwork:  # gradient of the first update, via a throw-away copy stepped with lr = 0
-        probe, _ = build(cls, P, D, A, H, seed, **dict(over, lr=0.0, grad_clip=False))
+        probe, _ = build(cls, P, D, A, H, seed, **dict(over, lr=0.0, grad_clip=False))  # noqa
         probe.update(mk(batches[0]), 1)
         out["actor_grad0"] = torch.stack([torch.cat([p.grad.reshape(-1) for p in m.parameters()]) for m in probe.actor.independent]).numpy()
         out["critic_grad0"] = torch.stack([torch.cat([p.grad.reshape(-1) for p in m.parameters()]) for m in probe.critic.independent]).numpy()
@@ -86,3 +88,6 @@ if __name__ == "__main__":
     fixture(ram, rat, "learner_a2c_H64.npz", ram.A2CNetwork, P=2, D=15, H=64, N=12, seed=500)
     fixture(ram, rat, "learner_a2c_clip_H128.npz", ram.A2CNetwork, P=3, D=18, H=128, N=9, seed=600, grad_clip=0.5, n_steps=3)
     fixture(ram, rat, "learner_ppo_H64.npz", ram.PPONetwork, P=2, D=15, H=64, N=12, seed=700)
+    # critic.centralised = True (maa2c.yaml / mappo.yaml): every critic reads all agents' observations
+    fixture(ram, rat, "learner_maa2c_H64.npz", ram.A2CNetwork, P=2, D=15, H=64, N=12, seed=800, centralised=True)
+    fixture(ram, rat, "learner_mappo_p3_H128.npz", ram.PPONetwork, P=3, D=18, H=128, N=9, seed=900, centralised=True)

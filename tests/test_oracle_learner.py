@@ -127,7 +127,8 @@ def ac_batch_of(g, i):
     return {k: torch.tensor(g[f"batch{i}_{k}"]) for k in ("obss", "actions", "rewards", "dones", "filled")}
 
 
-@pytest.mark.parametrize("name", ["learner_a2c_H64.npz", "learner_a2c_clip_H128.npz", "learner_ppo_H64.npz"])
+@pytest.mark.parametrize("name", ["learner_a2c_H64.npz", "learner_a2c_clip_H128.npz", "learner_ppo_H64.npz",
+                                  "learner_maa2c_H64.npz", "learner_mappo_p3_H128.npz"])  # the last two: critic.centralised
 def test_actor_critic_update_matches_reference(name):
     """oracle/ac_update_port.py against the reference's A2CNetwork / PPONetwork (marlbase/ac/model.py:189-352):
     n-step returns, gradient, metrics and the parameter blocks after 3 updates incl. the step-keyed target copy."""
