@@ -22,6 +22,10 @@
 // non-degenerate parameters.
 #pragma once
 
+#ifndef MARL_QMIX_L1_NB
+#define MARL_QMIX_L1_NB 1  // row blocks per wave and step in qmix_l1_kernel (register blocking vs resident workgroups per CU)
+#endif
+
 namespace marl {
 
 template <int P_, int D_>
@@ -129,7 +133,7 @@ __device__ __forceinline__ size_t qmix_state_off(int k, size_t ps) {  // k < SD
 template <class Q, bool REPLAY>
 __global__ __launch_bounds__(256) void qmix_l1_kernel(const float* __restrict__ pack, QmixRows<Q, REPLAY> src, int toff, int R,
                                                       float* __restrict__ Y1) {
-    constexpr int NB = 2, MT1 = Q::MT1, KS4 = Q::KS4, NCH = Q::NCH, SD = Q::SD;
+    constexpr int NB = MARL_QMIX_L1_NB, MT1 = Q::MT1, KS4 = Q::KS4, NCH = Q::NCH, SD = Q::SD;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     f4* lds4 = reinterpret_cast<f4*>(lds);
     const f4* pack4 = reinterpret_cast<const f4*>(pack);
@@ -677,7 +681,7 @@ int qmix_launch_mix(const QmixCtx& qx, const marlhip_batch* bt, const ReplaySrc&
         attr_set = true;
     }
     hipLaunchKernelGGL((qmix_pack_kernel<Q>), dim3((Q::NPACK + 255) / 256), dim3(256), 0, st, qx.mixer, qx.tmixer, packs);
-    const int ngroups = (R + 127) / 128, nblk = (R + 15) / 16;
+    const int ngroups = (R + 64 * MARL_QMIX_L1_NB - 1) / (64 * MARL_QMIX_L1_NB), nblk = (R + 15) / 16;
     const int g1 = ngroups < 768 ? ngroups : 768;
     const int g2 = (nblk + 3) / 4 < 256 ? (nblk + 3) / 4 : 256;
     timing_begin(TIMER_QMIX, st);
