@@ -294,9 +294,8 @@ class QMixNetwork(QNetwork):
     def update_async(self, batch, grad_sync=None, world=1, replay=None, **sample_kw):
         sync = None
         if grad_sync is not None:
-            def sync(grad):  # the mixer gradient rides the same all-reduce cadence
-                grad_sync(grad)
-                grad_sync(self.updater.mixer_grad)
+            def sync(grad):  # critic + mixer gradients are one contiguous buffer: one all-reduce per update
+                grad_sync(self.updater.joint_grad)
         return super().update_async(batch, grad_sync=sync, world=world, replay=replay, **sample_kw)
 
     def soft_update(self, tau):

@@ -302,7 +302,10 @@ class QmixUpdater(DqnUpdater):
         if mixer.numel() != n or target_mixer.numel() != n:
             raise ValueError(f"mixer block has {mixer.numel()} parameters, the QMixer of this shape has {n}")
         self.mixer, self.target_mixer = mixer, target_mixer
-        self.mixer_grad = torch.zeros_like(mixer)
+        # critic and mixer gradients share one allocation so that data-parallel training all-reduces them in ONE message
+        self.joint_grad = torch.zeros(params.numel() + n, dtype=torch.float32, device=params.device)
+        self.grad = self.joint_grad[:params.numel()].view_as(params)
+        self.mixer_grad = self.joint_grad[params.numel():]
         self.mixer_exp_avg = torch.zeros_like(mixer)
         self.mixer_exp_avg_sq = torch.zeros_like(mixer)
         self.mixer_scratch = torch.zeros((n + 255) // 256 + 1, dtype=torch.float32, device=mixer.device)
