@@ -115,6 +115,9 @@ def _evaluate(env, model, eval_episodes, eval_epsilon):
     return [_episode(env, model, eval_epsilon)[1] for _ in range(eval_episodes)]
 
 
+_NO_FUSED_LOOP = bool(__import__("os").environ.get("MARLHIP_NO_FUSED_LOOP"))  # diagnostics: time the per-update host loop at 1 GPU
+
+
 class VectorisedIDQN:
     """Device-resident training state of the vectorised path: N envs, replay shard, learner."""
 
@@ -155,7 +158,7 @@ class VectorisedIDQN:
                           use_proper_termination=self.proper)
         self.env_steps += self.fin_length.sum()
         self.rounds += 1
-        if train and self.dist is None and self.U > 0 and m.mode != 2 and not m.standardise_returns:  # the n-updates library call has no mixer / no return statistics (those loop here)
+        if train and self.dist is None and self.U > 0 and m.mode != 2 and not m.standardise_returns and not _NO_FUSED_LOOP:  # the n-updates library call has no mixer / no return statistics (those loop here)
             if self._fused is None:
                 self._fused = _hip.FusedLearner(m.updater, self.replay, self.B, m.target_update_interval_or_tau, mode=m.mode)
             length = min(self.rounds * self.N, self.capacity)
