@@ -29,7 +29,15 @@ def test_compose_matches_reference_defaults_and_overrides():
     with pytest.raises(ValueError):
         C.compose(["+algorithm=idqn", "env.time_limit=25"])  # env.name is mandatory (???)
     with pytest.raises(NotImplementedError):
-        C.compose(["+algorithm=mappo", "env.name=a", "env.time_limit=1"])
+        C.compose(["+algorithm=maddpg", "env.name=a", "env.time_limit=1"])  # not one of the reference's seven configs
+    for algo, target, central in (("ia2c", "ac.model.A2CNetwork", False), ("ippo", "ac.model.PPONetwork", False),
+                                  ("maa2c", "ac.model.A2CNetwork", True), ("mappo", "ac.model.PPONetwork", True)):
+        cfg = C.compose([f"+algorithm={algo}", "env.name=lbforaging:Foraging-8x8-2p-3f-v3", "env.time_limit=25"])
+        a = cfg.algorithm  # marlbase/configs/algorithm/{ia2c,ippo,maa2c,mappo}.yaml
+        assert a._target_ == "ac.train.main" and a.model._target_ == target and a.model.critic.centralised is central
+        assert a.n_steps == 5 and a.entropy_coef == 0.001 and a.value_loss_coef == 0.5 and a.grad_clip is False
+        assert cfg.env.parallel_envs == 10 and a.model.actor.layers == [128, 128]
+        assert ("num_epochs" in a) == (algo in ("ippo", "mappo"))
 
 
 def test_reference_target_strings_resolve_to_this_package():
