@@ -85,7 +85,7 @@ int launch_forward_rows(int P, const AgentMap& am, const float* params, const ma
 template <class S>
 int64_t backward_ws_bytes(int P, int T, int B) {
     if constexpr (S::H > 64) {
-        const UpdPlan pl = upd_plan_tp(P, T, B, 2);
+        const UpdPlan pl = upd_plan_tp(P, T, B, S::D > 48 ? 1 : 2);
         return ws_layout(P, pl.nwg, S::NPARAM + 2, 0, T, B).total;
     } else {
         const UpdPlan pl = upd_plan(P, T, B);
@@ -102,7 +102,7 @@ int launch_backward_rows(int P, const AgentMap& am, const float* params, const m
     ReplaySrc none = {};
     int nwg;
     if constexpr (S::H > 64) {
-        constexpr int W = 4, TPW = S::H / 64, NB = 2, NT = W * TPW;
+        constexpr int W = 4, TPW = S::H / 64, NB = S::D > 48 ? 1 : 2, NT = W * TPW;  // wide first layers (centralised critics): one row block per step keeps the kernel out of scratch
         const UpdPlan pl = upd_plan_tp(P, T, B, NB);
         nwg = pl.nwg;
         TpMix mix = {};
