@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--replay-rounds", type=int, default=4, help="replay capacity in rounds of `envs` episodes")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--env-name", default=ENV_NAME, help="other BASELINE.json configs, e.g. lbforaging:Foraging-15x15-4p-5f-v3")
-    ap.add_argument("--algo", default="idqn", choices=["idqn", "vdn", "qmix", "ia2c", "ippo"])
+    ap.add_argument("--algo", default="idqn", choices=["idqn", "vdn", "qmix", "ia2c", "ippo", "maa2c", "mappo"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -122,7 +122,9 @@ def bench_ac(args, rank, world, dist):
     hyper = dict(optimizer="Adam", lr=3e-4, gamma=0.99, grad_clip=False, n_steps=5, entropy_coef=0.001, value_loss_coef=0.5,
                  standardise_returns=False, target_update_interval_or_tau=200, num_epochs=4, ppo_clip=0.2)  # ia2c.yaml / ippo.yaml
     net = dict(layers=[H, H], parameter_sharing=False, use_orthogonal_init=True, use_rnn=False)
-    model = (PPONetwork if args.algo == "ippo" else A2CNetwork)(obs_space, act_space, hyper, net, dict(net, centralised=False), "cuda")
+    central = args.algo in ("maa2c", "mappo")  # critic.centralised (maa2c.yaml / mappo.yaml)
+    model = (PPONetwork if args.algo in ("ippo", "mappo") else A2CNetwork)(obs_space, act_space, hyper, net,
+                                                                           dict(net, centralised=central), "cuda")
     dev = model.device
     b_obs = torch.empty(T + 1, N, P * D, device=dev)
     b_act = torch.empty(T, N, P, dtype=torch.int64, device=dev)
@@ -189,7 +191,7 @@ def bench_ac(args, rank, world, dist):
     upd = timing.get("ac_update (fwd rows x3, elementwise, bwd rows x2)")
     if upd:
         # algorithmic flops per A2C update: target fwd (T+1 rows) + critic fwd+bwd (3x) + actor fwd+bwd (3x) on T rows
-        fa, fc = 2.0 * (D * H + H * H + H * A), 2.0 * (D * H + H * H + H)
+        fa, fc = 2.0 * (D * H + H * H + H * A), 2.0 * ((P * D if central else D) * H + H * H + H)
         flops = P * N * (fc * (T + 1) + 3 * fc * T + 3 * fa * T)
         ach = flops / (upd["avg_us"] * 1e-6) / 1e12
         roofline = {"kernel": "ac_update", "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -231,7 +233,7 @@ def main():
         kw = {"device_id": torch.device("cuda", dev_index)} if backend == "nccl" else {}
         dist.init_process_group(backend, **kw)
 
-    if args.algo in ("ia2c", "ippo"):
+    if args.algo in ("ia2c", "ippo", "maa2c", "mappo"):
         return bench_ac(args, rank, world, dist)
 
     from codebase_amd import hip as h
