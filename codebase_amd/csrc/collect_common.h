@@ -64,17 +64,7 @@ __device__ __forceinline__ void stage_packed(const float* __restrict__ pack, flo
     static_assert(S::NFWD % 4 == 0, "pack is a whole number of float4");
     const f4* src = reinterpret_cast<const f4*>(pack);
     f4* dst = reinterpret_cast<f4*>(lds);
-    // 8 independent 16-byte loads in flight per thread before the first LDS store (the plain copy loop waits for every load)
-    constexpr int N4 = S::NFWD / 4, U = 8;
-    int i = tid;
-    for (; i + (U - 1) * nthreads < N4; i += U * nthreads) {
-        f4 v[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) v[u] = src[i + u * nthreads];
-#pragma unroll
-        for (int u = 0; u < U; ++u) dst[i + u * nthreads] = v[u];
-    }
-    for (; i < N4; i += nthreads) dst[i] = src[i];
+    copy_f4_to_lds(src, dst, S::NFWD / 4, tid, nthreads);
 }
 
 // how a collector keeps P forward packs on chip

@@ -133,7 +133,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dqn_lossgrad_kernel(con
         constexpr int TOT4 = (2 * S::NFWD + S::NBWD) / 4;
         const f4* src = reinterpret_cast<const f4*>(packs + (size_t)p * (2 * S::NFWD + S::NBWD));
         f4* dst = reinterpret_cast<f4*>(lds);
-        for (int i = tid; i < TOT4; i += UPD_BLOCK) dst[i] = src[i];
+        copy_f4_to_lds(src, dst, TOT4, tid, UPD_BLOCK);
     }
     __syncthreads();
 

@@ -113,6 +113,20 @@ __device__ __forceinline__ void mlp_stage_bwd(const float* __restrict__ w, float
     }
 }
 
+// workgroup-cooperative 16-byte copy global -> LDS with 8 independent loads in flight per thread before the first LDS store
+__device__ __forceinline__ void copy_f4_to_lds(const f4* __restrict__ src, f4* dst, int n4, int tid, int nthreads) {
+    constexpr int U = 8;
+    int i = tid;
+    for (; i + (U - 1) * nthreads < n4; i += U * nthreads) {
+        f4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = src[i + u * nthreads];
+#pragma unroll
+        for (int u = 0; u < U; ++u) dst[i + u * nthreads] = v[u];
+    }
+    for (; i < n4; i += nthreads) dst[i] = src[i];
+}
+
 __device__ __forceinline__ f4 relu4(f4 v) {
     f4 o;
     o.x = fmaxf(v.x, 0.f); o.y = fmaxf(v.y, 0.f); o.z = fmaxf(v.z, 0.f); o.w = fmaxf(v.w, 0.f);

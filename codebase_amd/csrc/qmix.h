@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void qmix_l1_kernel(const float* __restrict__ 
     const int ngroups = (R + 64 * NB - 1) / (64 * NB);
     const size_t ps = src.pstride();
     if (NCH == 1) {
-        for (int i = tid; i < KS4 * MT1 * 64; i += 256) lds4[i] = pack4[i];
+        copy_f4_to_lds(pack4, lds4, KS4 * MT1 * 64, tid, 256);
         __syncthreads();
     }
     for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void qmix_l1_kernel(const float* __restrict__ 
             const int n4 = (KS4 - 4 * c) < full ? (KS4 - 4 * c) : full;
             if (NCH > 1) {
                 __syncthreads();
-                for (int i = tid; i < n4 * MT1 * 64; i += 256) lds4[i] = pack4[c * 4 * MT1 * 64 + i];
+                copy_f4_to_lds(pack4 + c * 4 * MT1 * 64, lds4, n4 * MT1 * 64, tid, 256);
                 __syncthreads();
             }
 #pragma unroll
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256, 1) void qmix_mix_kernel(const float* __restric
     {
         f4* l4 = reinterpret_cast<f4*>(lds);
         const f4* p4 = reinterpret_cast<const f4*>(pack);
-        for (int i = tid; i < NPK / 4; i += 256) l4[i] = p4[i];
+        copy_f4_to_lds(p4, l4, NPK / 4, tid, 256);
         __syncthreads();
     }
     const f4* P1 = reinterpret_cast<const f4*>(lds + Q::mP1);
