@@ -22,6 +22,15 @@ class LbfConfig(ctypes.Structure):
     ]
 
 
+class RwareConfig(ctypes.Structure):
+    _fields_ = [
+        ("n_envs", c_int32), ("n_agents", c_int32), ("shelf_rows", c_int32), ("shelf_columns", c_int32),
+        ("column_height", c_int32), ("request_queue_size", c_int32), ("max_steps", c_int32),
+        ("max_inactivity_steps", c_int32), ("time_limit", c_int32), ("reward_type", c_int32), ("cooperative", c_int32),
+        ("observe_id", c_int32), ("seed", c_uint64), ("reward_stats", c_void_p),
+    ]
+
+
 class LbfBuffers(ctypes.Structure):
     _fields_ = [("state", c_void_p), ("episode", c_void_p), ("ep_return", c_void_p), ("ep_length", c_void_p)]
 
@@ -83,6 +92,18 @@ PROTOTYPES = {
     "marlhip_lbf_observe": (c_int32, [POINTER(LbfConfig), POINTER(LbfBuffers), c_void_p, c_void_p]),
     "marlhip_lbf_step": (c_int32, [POINTER(LbfConfig), POINTER(LbfBuffers), c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
+    "marlhip_rware_state_stride": (c_int32, [POINTER(RwareConfig)]),
+    "marlhip_rware_obs_dim": (c_int32, [POINTER(RwareConfig)]),
+    "marlhip_rware_grid": (c_int32, [POINTER(RwareConfig), POINTER(c_int32), POINTER(c_int32), POINTER(c_int32)]),
+    "marlhip_rware_reset": (c_int32, [POINTER(RwareConfig), POINTER(LbfBuffers), c_void_p, c_void_p, c_void_p]),
+    "marlhip_rware_observe": (c_int32, [POINTER(RwareConfig), POINTER(LbfBuffers), c_void_p, c_void_p]),
+    "marlhip_rware_step": (c_int32, [POINTER(RwareConfig), POINTER(LbfBuffers), c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
+    "marlhip_rware_idqn_collect": (c_int32, [POINTER(RwareConfig), POINTER(NetShape), c_void_p, c_float, c_uint32,
+                                             POINTER(ReplayShape), POINTER(ReplayBuffers), c_int32, c_int32, c_int32, c_int32,
+                                             c_void_p, c_void_p, c_void_p]),
+    "marlhip_rware_ac_collect": (c_int32, [POINTER(RwareConfig), POINTER(NetShape), c_void_p, c_uint32, c_int32, c_int32, c_void_p,
+                                           c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "marlhip_net_nparams": (c_int32, [POINTER(NetShape)]),
     "marlhip_dqn_act": (c_int32, [POINTER(NetShape), c_void_p, c_void_p, c_int32, c_float, c_void_p, c_void_p, c_uint64,
                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

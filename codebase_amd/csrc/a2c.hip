@@ -84,7 +84,7 @@ int launch_forward_rows(int P, const AgentMap& am, const float* params, const ma
 // ---- backward rows -----------------------------------------------------------------------------------------
 template <class S>
 int64_t backward_ws_bytes(int P, int T, int B) {
-    if constexpr (S::H > 64) {
+    if constexpr (use_tp<S>()) {
         const UpdPlan pl = upd_plan_tp(P, T, B, S::D > 48 ? 1 : 2);
         return ws_layout(P, pl.nwg, S::NPARAM + 2, 0, T, B).total;
     } else {
@@ -101,7 +101,7 @@ int launch_backward_rows(int P, const AgentMap& am, const float* params, const m
     MARL_REQUIRE(ws_bytes >= backward_ws_bytes<S>(P, T, B), "ac backward: workspace %lld too small", (long long)ws_bytes);
     ReplaySrc none = {};
     int nwg;
-    if constexpr (S::H > 64) {
+    if constexpr (use_tp<S>()) {
         constexpr int W = 4, TPW = S::H / 64, NB = S::D > 48 ? 1 : 2, NT = W * TPW;  // wide first layers (centralised critics): one row block per step keeps the kernel out of scratch
         const UpdPlan pl = upd_plan_tp(P, T, B, NB);
         nwg = pl.nwg;
@@ -395,10 +395,11 @@ int ac_step(int P, const AgentMap& am, const float* actor, const float* critic, 
 
 using namespace marl;
 
-// (obs dim, hidden) pairs with compiled actor (A = 6) and critic (A = 1) kernels: the LBF shapes of common.h
+// (obs dim, hidden, actions) with compiled actor and critic (1 output) kernels: the LBF and warehouse shapes of common.h
 #define MARL_AC_SHAPES(X) \
-    X(12, 64) X(15, 64) X(18, 64) X(21, 64) X(24, 64) X(27, 64) X(39, 64) X(12, 128) X(15, 128) X(18, 128) X(21, 128) X(24, 128) X(27, 128) X(39, 128) \
-    X(14, 64) X(17, 64) X(25, 64) X(31, 64) X(47, 64) X(14, 128) X(17, 128) X(25, 128) X(31, 128) X(47, 128) /* env.observe_id */
+    X(12, 64, 6) X(15, 64, 6) X(18, 64, 6) X(21, 64, 6) X(24, 64, 6) X(27, 64, 6) X(39, 64, 6) X(12, 128, 6) X(15, 128, 6) X(18, 128, 6) X(21, 128, 6) X(24, 128, 6) X(27, 128, 6) X(39, 128, 6) \
+    X(14, 64, 6) X(17, 64, 6) X(25, 64, 6) X(31, 64, 6) X(47, 64, 6) X(14, 128, 6) X(17, 128, 6) X(25, 128, 6) X(31, 128, 6) X(47, 128, 6) /* env.observe_id */ \
+    X(71, 64, 5) X(71, 128, 5) /* rware */
 // (agents, obs dim, hidden) with a compiled CENTRALISED critic (P * D inputs): hidden 128 up to 4 agents (weights and dW1
 // accumulators of a P*D-wide first layer still fit the register file), hidden 64 for 2 agents (LDS-resident packs)
 #define MARL_MAC_SHAPES(X) X(2, 12, 128) X(2, 15, 128) X(3, 18, 128) X(3, 24, 128) X(4, 21, 128) X(4, 27, 128) X(2, 12, 64) X(2, 15, 64)
@@ -406,18 +407,18 @@ using namespace marl;
 static int ac_check(const marlhip_net_shape* s, int centralised = 0) {
     MARL_REQUIRE(s != nullptr, "net shape is NULL");
     if (agent_map_validate(s) != 0) return -1;
-    MARL_REQUIRE(s->n_agents >= 1 && s->n_actions == 6, "ac: the compiled actors have 6 actions (LBF), got %d", s->n_actions);
+    MARL_REQUIRE(s->n_agents >= 1, "ac: no agents");
     if (centralised) {
-#define X(p, d, h) if (s->n_agents == p && s->obs_dim == d && s->hidden == h) return 0;
+#define X(p, d, h) if (s->n_agents == p && s->obs_dim == d && s->hidden == h && s->n_actions == 6) return 0;
         MARL_MAC_SHAPES(X)
 #undef X
         set_error("no centralised-critic kernels for %d agents x obs_dim %d, hidden %d (MARL_MAC_SHAPES)", s->n_agents, s->obs_dim, s->hidden);
         return -1;
     }
-#define X(d, h) if (s->obs_dim == d && s->hidden == h) return 0;
+#define X(d, h, a) if (s->obs_dim == d && s->hidden == h && s->n_actions == a) return 0;
     MARL_AC_SHAPES(X)
 #undef X
-    set_error("no actor-critic kernels for obs_dim %d hidden %d (add the pair to MARL_AC_SHAPES)", s->obs_dim, s->hidden);
+    set_error("no actor-critic kernels for obs_dim %d hidden %d actions %d (add the triple to MARL_AC_SHAPES)", s->obs_dim, s->hidden, s->n_actions);
     return -1;
 }
 
@@ -428,7 +429,7 @@ extern "C" int marlhip_ac_critic_nparams(const marlhip_net_shape* s, int32_t cen
         MARL_MAC_SHAPES(X)
 #undef X
     }
-#define X(d, h) if (s->obs_dim == d && s->hidden == h) return MlpShape<d, h, 1>::NPARAM;
+#define X(d, h, a) if (s->obs_dim == d && s->hidden == h && s->n_actions == a) return MlpShape<d, h, 1>::NPARAM;
     MARL_AC_SHAPES(X)
 #undef X
     return -1;
@@ -443,8 +444,8 @@ extern "C" int64_t marlhip_ac_workspace_bytes(const marlhip_net_shape* s, int32_
         MARL_MAC_SHAPES(X)
 #undef X
     }
-#define X(d, h) \
-    if (s->obs_dim == d && s->hidden == h) return ac_ws_layout<MlpShape<d, h, 6>, MlpShape<d, h, 1>>(s->n_agents, max_len, batch).total;
+#define X(d, h, a) \
+    if (s->obs_dim == d && s->hidden == h && s->n_actions == a) return ac_ws_layout<MlpShape<d, h, a>, MlpShape<d, h, 1>>(s->n_agents, max_len, batch).total;
     MARL_AC_SHAPES(X)
 #undef X
     return -1;
@@ -470,7 +471,7 @@ static int ac_call(const marlhip_net_shape* s, const float* actor, const float* 
         MARL_MAC_SHAPES(X)
 #undef X
     }
-#define X(d, h) if (s->obs_dim == d && s->hidden == h) return ac_step<d, h, 6, d>(MARL_AC_ARGS);
+#define X(d, h, a) if (s->obs_dim == d && s->hidden == h && s->n_actions == a) return ac_step<d, h, a, d>(MARL_AC_ARGS);
     MARL_AC_SHAPES(X)
 #undef X
 #undef MARL_AC_ARGS
@@ -492,10 +493,10 @@ extern "C" int marlhip_ac_forward_rows(const marlhip_net_shape* s, int32_t value
         MARL_MAC_SHAPES(X)
 #undef X
     }
-#define X(d, h)                                                                                                            \
-    if (s->obs_dim == d && s->hidden == h)                                                                                  \
+#define X(d, h, a)                                                                                                         \
+    if (s->obs_dim == d && s->hidden == h && s->n_actions == a)                                                             \
         return value_net ? launch_forward_rows<MlpShape<d, h, 1>>(s->n_agents, agent_map(s), params, &bt, n_rows, out, (hipStream_t)stream) \
-                         : launch_forward_rows<MlpShape<d, h, 6>>(s->n_agents, agent_map(s), params, &bt, n_rows, out, (hipStream_t)stream);
+                         : launch_forward_rows<MlpShape<d, h, a>>(s->n_agents, agent_map(s), params, &bt, n_rows, out, (hipStream_t)stream);
     MARL_AC_SHAPES(X)
 #undef X
     return -1;

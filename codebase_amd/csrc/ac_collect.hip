@@ -23,8 +23,8 @@ extern "C" int marlhip_ac_collect(const marlhip_lbf_config* cfg, const marlhip_n
                        batch_filled, fin_return, fin_length, t_max, (hipStream_t)stream
 #define X(p, f)                                                                                         \
     if (cfg->n_agents == p && cfg->n_food == f) {                                                       \
-        if (s->hidden == 64) return launch_ac_collect<p, f, 64, false>(MARL_ACOL_ARGS);                 \
-        if (s->hidden == 128) return launch_ac_collect<p, f, 128, false>(MARL_ACOL_ARGS);               \
+        if (s->hidden == 64) return launch_ac_collect<LbfEnvT<p, f>, 64, false>(MARL_ACOL_ARGS);                 \
+        if (s->hidden == 128) return launch_ac_collect<LbfEnvT<p, f>, 128, false>(MARL_ACOL_ARGS);               \
     }
     MARL_LBF_SHAPES(X)
 #undef X

@@ -14,6 +14,7 @@
 // observation comes from episode 2*round+1.
 #pragma once
 #include "collect_common.h"
+#include "env_traits.h"
 
 namespace marl {
 
@@ -55,21 +56,23 @@ __device__ __forceinline__ int sample_rows(const f4& logits, int lane, float u) 
     return act;
 }
 
-template <int P, int F, int H, bool OID>
-__global__ __launch_bounds__(ACOL_BLOCK) void ac_collect_kernel(LbfParams q, const float* __restrict__ actor /* pre-packed [P][NFWD] */, uint32_t round, int T,
+template <class ENV, int H, bool OID>
+__global__ __launch_bounds__(ACOL_BLOCK) void ac_collect_kernel(typename ENV::Params q, const float* __restrict__ actor /* pre-packed [P][NFWD] */, uint32_t round, int T,
                                                                 int proper_term, float* __restrict__ b_obs,
                                                                 int64_t* __restrict__ b_act, float* __restrict__ b_rew,
                                                                 uint8_t* __restrict__ b_done, float* __restrict__ b_filled,
                                                                 float* __restrict__ fin_return, int32_t* __restrict__ fin_length,
                                                                 int32_t* __restrict__ t_max) {
-    constexpr int D = 3 * (P + F) + (OID ? P : 0), A = 6;
+    constexpr int P = ENV::P, D = ENV::D0 + (OID ? P : 0), A = ENV::A;
     using S = MlpShape<D, H, A>;
-    using PP = PackPlan<S, P>;
+    using PP = PackPlan<S, P, ENV::LDS_MAX>;
     constexpr bool RESIDENT = PP::RESIDENT || PP::A3REG;  // no per-step staging
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, j = lane & 15;
     const int n = (blockIdx.x * 4 + wave) * 16 + j;
     const int N = q.n_envs;
+    typename ENV::Ctx ctx;
+    ctx.init(q, reinterpret_cast<uint8_t*>(lds) + PP::LDS_BYTES, wave, j);
     const bool valid = n < N;
     const uint32_t env_id = (uint32_t)(valid ? n : N - 1);
     f4 a3[PP::A3REG ? P : 1][S::MT];  // output-layer operands, when the full packs do not fit the LDS
@@ -85,20 +88,14 @@ __global__ __launch_bounds__(ACOL_BLOCK) void ac_collect_kernel(LbfParams q, con
         }
         __syncthreads();
     }
-    LbfState<P, F> s;
-    {
-        DrawStream rng;
-        rng.init(q.seed, env_id, 2u * round, STREAM_RESET);
-        lbf_reset(q, s, rng);
-    }
+    typename ENV::State s;
+    ENV::reset(q, s, ctx, env_id, 2u * round);
     // batch_obs[t][n][p*D + d]
     auto obs_row = [&](int t) { return b_obs + ((size_t)t * N + env_id) * (P * D); };
     float x[P][S::KS1];
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-        LbfObs<P, F> o;
-        lbf_observe(q, s, p, o);
-        pick_obs_id<P, F, S::KS1, OID>(o, p, g, x[p]);
+        ENV::template observe<S::KS1, OID>(q, s, ctx, p, g, x[p]);
         if (valid) {
 #pragma unroll
             for (int ks = 0; ks < S::KS1; ++ks)
@@ -136,23 +133,19 @@ __global__ __launch_bounds__(ACOL_BLOCK) void ac_collect_kernel(LbfParams q, con
             double raw[P];
             float rw[P];
             bool done;
-            lbf_step(q, s, act, raw, done);
-            const bool trunc = q.time_limit > 0 && s.step >= q.time_limit;
+            ENV::step(q, s, ctx, env_id, 2u * round, act, raw, done);
+            const bool trunc = q.time_limit > 0 && ENV::elapsed(s) >= q.time_limit;
             const bool fin = done || trunc;
             const bool stored_done = proper_term ? done : fin;
             lbf_wrap_rewards<P>(q, env_id, raw, rw, g == 0);
             ++len;
             if (fin) {  // vector-env auto-reset: the observation returned for this step is the next episode's first
-                DrawStream rng;
-                rng.init(q.seed, env_id, 2u * round + 1u, STREAM_RESET);
-                lbf_reset(q, s, rng);
+                ENV::reset(q, s, ctx, env_id, 2u * round + 1u);
             }
 #pragma unroll
             for (int p = 0; p < P; ++p) {
                 ep_ret[p] += (float)raw[p];
-                LbfObs<P, F> o;
-                lbf_observe(q, s, p, o);
-                pick_obs_id<P, F, S::KS1, OID>(o, p, g, x[p]);
+                ENV::template observe<S::KS1, OID>(q, s, ctx, p, g, x[p]);
 #pragma unroll
                 for (int ks = 0; ks < S::KS1; ++ks)
                     if (4 * ks + g < D) obs_row(t + 1)[p * D + 4 * ks + g] = x[p][ks];
@@ -200,24 +193,26 @@ __global__ __launch_bounds__(ACOL_BLOCK) void ac_collect_kernel(LbfParams q, con
     }
 }
 
-template <int P, int F, int H, bool OID>
-int launch_ac_collect(const LbfParams& q, const AgentMap& am, const float* actor, uint32_t round, int T, int proper_term, float* b_obs, int64_t* b_act,
+template <class ENV, int H, bool OID>
+int launch_ac_collect(const typename ENV::Params& q, const AgentMap& am, const float* actor, uint32_t round, int T, int proper_term, float* b_obs, int64_t* b_act,
                       float* b_rew, uint8_t* b_done, float* b_filled, float* fin_return, int32_t* fin_length, int32_t* t_max,
                       hipStream_t st) {
-    constexpr int D = 3 * (P + F) + (OID ? P : 0);
-    using S = MlpShape<D, H, 6>;
-    const size_t lds_bytes = PackPlan<S, P>::LDS_BYTES;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ac_collect_kernel<P, F, H, OID>),
+    constexpr int P = ENV::P, D = ENV::D0 + (OID ? P : 0);
+    using S = MlpShape<D, H, ENV::A>;
+    MARL_REQUIRE(ENV::lds_bytes(q) <= ENV::LDS_MAX, "collector: the env needs %zu bytes of LDS per workgroup, compiled for %zu", ENV::lds_bytes(q),
+                 (size_t)ENV::LDS_MAX);
+    const size_t lds_bytes = PackPlan<S, P, ENV::LDS_MAX>::LDS_BYTES + ENV::lds_bytes(q);
+    static size_t attr_set = 0;
+    if (attr_set < lds_bytes) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ac_collect_kernel<ENV, H, OID>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        attr_set = true;
+        attr_set = lds_bytes;
     }
     (void)hipMemsetAsync(t_max, 0, sizeof(int32_t), st);
     float* packs = nullptr;
     if (launch_fwd_pack<S>(P, am, actor, &packs, st) != 0) return -1;
     timing_begin(TIMER_COLLECT, st);
-    hipLaunchKernelGGL((ac_collect_kernel<P, F, H, OID>), dim3((q.n_envs + 63) / 64), dim3(ACOL_BLOCK), lds_bytes, st, q, (const float*)packs, round, T,
+    hipLaunchKernelGGL((ac_collect_kernel<ENV, H, OID>), dim3((q.n_envs + 63) / 64), dim3(ACOL_BLOCK), lds_bytes, st, q, (const float*)packs, round, T,
                        proper_term, b_obs, b_act, b_rew, b_done, b_filled, fin_return, fin_length, t_max);
     timing_end(TIMER_COLLECT, st);
     MARL_CHECK_LAUNCH("ac_collect_kernel");

@@ -11,8 +11,8 @@ int ac_collect_dispatch_oid(const marlhip_lbf_config* cfg, const marlhip_net_sha
                        batch_filled, fin_return, fin_length, t_max, stream
 #define X(p, f)                                                                                         \
     if (cfg->n_agents == p && cfg->n_food == f) {                                                       \
-        if (s->hidden == 64) return launch_ac_collect<p, f, 64, true>(MARL_ACOL_ARGS);                  \
-        if (s->hidden == 128) return launch_ac_collect<p, f, 128, true>(MARL_ACOL_ARGS);                \
+        if (s->hidden == 64) return launch_ac_collect<LbfEnvT<p, f>, 64, true>(MARL_ACOL_ARGS);                  \
+        if (s->hidden == 128) return launch_ac_collect<LbfEnvT<p, f>, 128, true>(MARL_ACOL_ARGS);                \
     }
     MARL_LBF_SHAPES(X)
 #undef X

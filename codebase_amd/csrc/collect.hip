@@ -55,8 +55,8 @@ extern "C" int marlhip_idqn_collect(const marlhip_lbf_config* cfg, const marlhip
                           fin_return, fin_length, (hipStream_t)stream
 #define X(p, f)                                                                                            \
     if (cfg->n_agents == p && cfg->n_food == f) {                                                          \
-        if (s->hidden == 64) return launch_collect<p, f, 64, false>(MARL_COLLECT_ARGS);                    \
-        if (s->hidden == 128) return launch_collect<p, f, 128, false>(MARL_COLLECT_ARGS);                  \
+        if (s->hidden == 64) return launch_collect<LbfEnvT<p, f>, 64, false>(MARL_COLLECT_ARGS);                    \
+        if (s->hidden == 128) return launch_collect<LbfEnvT<p, f>, 128, false>(MARL_COLLECT_ARGS);                  \
     }
     MARL_LBF_SHAPES(X)
 #undef X

@@ -68,9 +68,9 @@ __device__ __forceinline__ void stage_packed(const float* __restrict__ pack, flo
 }
 
 // how a collector keeps P forward packs on chip
-template <class S, int P>
+template <class S, int P, size_t ENV_LDS = 0>
 struct PackPlan {
-    static constexpr size_t LDS_CAP = 150u * 1024u;
+    static constexpr size_t LDS_CAP = 150u * 1024u - ENV_LDS;  // the env's own LDS sits behind the packs
     static constexpr bool RESIDENT = (size_t)P * S::NFWD * sizeof(float) <= LDS_CAP;                 // whole packs in LDS
     static constexpr bool A3REG = !RESIDENT && (size_t)P * S::NFWD_NOA3 * sizeof(float) <= LDS_CAP;   // output layer in registers
     static constexpr int STRIDE = RESIDENT ? S::NFWD : S::NFWD_NOA3;                                   // floats per resident agent

@@ -12,6 +12,7 @@
 #include "common.h"
 #include "mlp.h"
 #include "collect_common.h"
+#include "env_traits.h"
 
 namespace marl {
 
@@ -72,19 +73,21 @@ __global__ __launch_bounds__(COL_BLOCK) void dqn_act_kernel(int P, int N, AgentM
     }
 }
 
-template <int P, int F, int H, bool OID>
-__global__ __launch_bounds__(COL_BLOCK) void idqn_collect_kernel(LbfParams q, const float* __restrict__ packs, float eps,
+template <class ENV, int H, bool OID>
+__global__ __launch_bounds__(COL_BLOCK) void idqn_collect_kernel(typename ENV::Params q, const float* __restrict__ packs, float eps,
                                                                  uint32_t round, marlhip_replay_shape rs, marlhip_replay_buffers rb,
                                                                  int slot_base, int write_replay, int clear_stale, int proper_term,
                                                                  float* __restrict__ fin_return, int32_t* __restrict__ fin_length) {
-    constexpr int D = 3 * (P + F) + (OID ? P : 0), A = 6;
+    constexpr int P = ENV::P, D = ENV::D0 + (OID ? P : 0), A = ENV::A;
     using S = MlpShape<D, H, A>;
-    using PP = PackPlan<S, P>;
+    using PP = PackPlan<S, P, ENV::LDS_MAX>;
     constexpr bool RESIDENT = PP::RESIDENT || PP::A3REG;  // no per-step staging
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, j = lane & 15;
     const int n = (blockIdx.x * 4 + wave) * 16 + j;
     const int N = q.n_envs, T = rs.max_len;
+    typename ENV::Ctx ctx;
+    ctx.init(q, reinterpret_cast<uint8_t*>(lds) + PP::LDS_BYTES, wave, j);
     const bool valid = n < N;
     const uint32_t env_id = (uint32_t)(valid ? n : N - 1);
 
@@ -102,12 +105,8 @@ __global__ __launch_bounds__(COL_BLOCK) void idqn_collect_kernel(LbfParams q, co
         __syncthreads();
     }
 
-    LbfState<P, F> s;
-    {
-        DrawStream rng;
-        rng.init(q.seed, env_id, round, STREAM_RESET);
-        lbf_reset(q, s, rng);
-    }
+    typename ENV::State s;
+    ENV::reset(q, s, ctx, env_id, round);
     const int slot = (int)(((int64_t)slot_base + (int64_t)env_id) % rs.capacity);
     float* ro = rb.obs + (size_t)slot * P * (T + 1) * D;
     uint8_t* ra_ = rb.act + (size_t)slot * P * T;
@@ -119,9 +118,7 @@ __global__ __launch_bounds__(COL_BLOCK) void idqn_collect_kernel(LbfParams q, co
     float x[P][S::KS1];
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-        LbfObs<P, F> o;
-        lbf_observe(q, s, p, o);
-        pick_obs_id<P, F, S::KS1, OID>(o, p, g, x[p]);
+        ENV::template observe<S::KS1, OID>(q, s, ctx, p, g, x[p]);
         if (wr) {  // ReplayBuffer.init_episode (train.py:65-68)
 #pragma unroll
             for (int ks = 0; ks < S::KS1; ++ks)
@@ -164,17 +161,15 @@ __global__ __launch_bounds__(COL_BLOCK) void idqn_collect_kernel(LbfParams q, co
             double raw[P];
             float rw[P];
             bool done;
-            lbf_step(q, s, act, raw, done);
-            const bool trunc = q.time_limit > 0 && s.step >= q.time_limit;
+            ENV::step(q, s, ctx, env_id, round, act, raw, done);
+            const bool trunc = q.time_limit > 0 && ENV::elapsed(s) >= q.time_limit;
             const bool stored_done = proper_term ? done : (done || trunc);  // train.py:219-225
             lbf_wrap_rewards<P>(q, env_id, raw, rw, g == 0);
             ++len;
 #pragma unroll
             for (int p = 0; p < P; ++p) {
                 ep_ret[p] += (float)raw[p];  // RecordEpisodeStatistics (wrappers.py:33)
-                LbfObs<P, F> o;
-                lbf_observe(q, s, p, o);
-                pick_obs_id<P, F, S::KS1, OID>(o, p, g, x[p]);
+                ENV::template observe<S::KS1, OID>(q, s, ctx, p, g, x[p]);
                 if (wr) {  // ReplayBuffer.add (train.py:73-84)
 #pragma unroll
                     for (int ks = 0; ks < S::KS1; ++ks)
@@ -210,24 +205,26 @@ __global__ __launch_bounds__(COL_BLOCK) void idqn_collect_kernel(LbfParams q, co
     }
 }
 
-template <int P, int F, int H, bool OID>
-int launch_collect(const LbfParams& q, const AgentMap& am, const float* params, float eps, uint32_t round, const marlhip_replay_shape* rs,
+template <class ENV, int H, bool OID>
+int launch_collect(const typename ENV::Params& q, const AgentMap& am, const float* params, float eps, uint32_t round, const marlhip_replay_shape* rs,
                    const marlhip_replay_buffers* rb, int slot_base, int write_replay, int clear_stale, int proper_term,
                    float* fin_return, int32_t* fin_length, hipStream_t st) {
-    constexpr int D = 3 * (P + F) + (OID ? P : 0);
-    using S = MlpShape<D, H, 6>;
-    const size_t lds_bytes = PackPlan<S, P>::LDS_BYTES;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&idqn_collect_kernel<P, F, H, OID>),
+    constexpr int P = ENV::P, D = ENV::D0 + (OID ? P : 0);
+    using S = MlpShape<D, H, ENV::A>;
+    MARL_REQUIRE(ENV::lds_bytes(q) <= ENV::LDS_MAX, "collector: the env needs %zu bytes of LDS per workgroup, compiled for %zu", ENV::lds_bytes(q),
+                 (size_t)ENV::LDS_MAX);
+    const size_t lds_bytes = PackPlan<S, P, ENV::LDS_MAX>::LDS_BYTES + ENV::lds_bytes(q);
+    static size_t attr_set = 0;
+    if (attr_set < lds_bytes) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&idqn_collect_kernel<ENV, H, OID>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        attr_set = true;
+        attr_set = lds_bytes;
     }
     const int grid = (q.n_envs + 63) / 64;
     float* packs = nullptr;
     if (launch_fwd_pack<S>(P, am, params, &packs, st) != 0) return -1;
     timing_begin(TIMER_COLLECT, st);
-    hipLaunchKernelGGL((idqn_collect_kernel<P, F, H, OID>), dim3(grid), dim3(COL_BLOCK), lds_bytes, st, q, (const float*)packs, eps, round, *rs, *rb,
+    hipLaunchKernelGGL((idqn_collect_kernel<ENV, H, OID>), dim3(grid), dim3(COL_BLOCK), lds_bytes, st, q, (const float*)packs, eps, round, *rs, *rb,
                        slot_base, write_replay, clear_stale, proper_term, fin_return, fin_length);
     timing_end(TIMER_COLLECT, st);
     MARL_CHECK_LAUNCH("idqn_collect_kernel");

@@ -10,8 +10,8 @@ int idqn_collect_dispatch_oid(const marlhip_lbf_config* cfg, const marlhip_net_s
                           fin_return, fin_length, stream
 #define X(p, f)                                                                                            \
     if (cfg->n_agents == p && cfg->n_food == f) {                                                          \
-        if (s->hidden == 64) return launch_collect<p, f, 64, true>(MARL_COLLECT_ARGS);                     \
-        if (s->hidden == 128) return launch_collect<p, f, 128, true>(MARL_COLLECT_ARGS);                   \
+        if (s->hidden == 64) return launch_collect<LbfEnvT<p, f>, 64, true>(MARL_COLLECT_ARGS);                     \
+        if (s->hidden == 128) return launch_collect<LbfEnvT<p, f>, 128, true>(MARL_COLLECT_ARGS);                   \
     }
     MARL_LBF_SHAPES(X)
 #undef X

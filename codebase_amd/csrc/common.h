@@ -6,6 +6,7 @@
 
 #include "../../include/marlhip.h"
 #include "lbf_core.h"
+#include "rware_core.h"
 
 namespace marl {
 
@@ -50,6 +51,9 @@ inline LbfParams to_params(const marlhip_lbf_config* c) {
 // (players, foods) shapes with compiled kernels.  X(P, F)
 #define MARL_LBF_SHAPES(X) X(2, 2) X(2, 3) X(3, 3) X(3, 5) X(4, 3) X(4, 5) X(8, 5)
 
+// agent counts with compiled warehouse kernels.  X(P)
+#define MARL_RW_SHAPES(X) X(2) X(4) X(8)
+
 inline bool lbf_shape_supported(int P, int F) {
 #define X(p, f) if (P == p && F == f) return true;
     MARL_LBF_SHAPES(X)
@@ -65,6 +69,41 @@ inline int lbf_validate(const marlhip_lbf_config* c) {
     MARL_REQUIRE(c->rows >= 3 && c->cols >= 3 && c->rows <= 255 && c->cols <= 255, "field size %dx%d out of range", c->rows, c->cols);
     MARL_REQUIRE(c->min_player_level >= 1 && c->max_player_level >= c->min_player_level && c->max_player_level <= 20, "player level range");
     MARL_REQUIRE(c->max_episode_steps > 0 && c->max_episode_steps < 65535, "max_episode_steps");
+    return 0;
+}
+
+inline RwParams to_rw_params(const marlhip_rware_config* c) {
+    RwParams q;
+    q.n_envs = c->n_envs; q.n_agents = c->n_agents;
+    q.column_height = c->column_height;
+    q.rows = (c->column_height + 1) * c->shelf_rows + 2;
+    q.cols = 3 * c->shelf_columns + 1;
+    q.n_shelves = rw_count_shelves(q);
+    q.queue_size = c->request_queue_size;
+    q.max_steps = c->max_steps; q.max_inactivity_steps = c->max_inactivity_steps; q.time_limit = c->time_limit;
+    q.reward_type = c->reward_type; q.cooperative = c->cooperative; q.seed = c->seed;
+    q.reward_stats = c->reward_stats; q.observe_id = c->observe_id != 0;
+    return q;
+}
+
+inline int rw_validate(const marlhip_rware_config* c) {
+    MARL_REQUIRE(c != nullptr, "rware config is NULL");
+    bool ok = false;
+#define X(p) ok = ok || c->n_agents == p;
+    MARL_RW_SHAPES(X)
+#undef X
+    MARL_REQUIRE(ok, "no rware kernel for %d agents (add it to MARL_RW_SHAPES in csrc/common.h and rebuild)", c->n_agents);
+    MARL_REQUIRE(c->n_envs > 0, "n_envs must be > 0");
+    MARL_REQUIRE(c->shelf_columns >= 1 && c->shelf_columns % 2 == 1, "rware: only an odd number of shelf columns is supported");
+    MARL_REQUIRE(c->shelf_rows >= 1 && c->column_height >= 1, "rware: shelf_rows / column_height");
+    const RwParams q = to_rw_params(c);
+    MARL_REQUIRE(q.rows <= 255 && q.cols <= 255 && q.n_shelves <= 255, "rware: grid %dx%d with %d shelves does not fit the byte state", q.rows,
+                 q.cols, q.n_shelves);
+    MARL_REQUIRE(c->request_queue_size >= 1 && c->request_queue_size <= 2 * c->n_agents && c->request_queue_size < q.n_shelves,
+                 "rware: request_queue_size %d (1..%d supported)", c->request_queue_size, 2 * c->n_agents);
+    MARL_REQUIRE(q.rows * q.cols >= c->n_agents, "rware: more agents than cells");
+    MARL_REQUIRE(c->max_steps >= 0 && c->max_steps < 65535 && c->max_inactivity_steps >= 0 && c->max_inactivity_steps < 65535, "rware: step limits");
+    MARL_REQUIRE(c->reward_type >= 0 && c->reward_type <= 2, "rware: reward_type %d", c->reward_type);
     return 0;
 }
 
@@ -98,6 +137,7 @@ inline int agent_map_validate(const marlhip_net_shape* s) {
     X(12, 64, 6) X(15, 64, 6) X(18, 64, 6) X(21, 64, 6) X(24, 64, 6) X(27, 64, 6) X(39, 64, 6)     \
     X(12, 128, 6) X(15, 128, 6) X(18, 128, 6) X(21, 128, 6) X(24, 128, 6) X(27, 128, 6) X(39, 128, 6) \
     X(14, 64, 6) X(17, 64, 6) X(25, 64, 6) X(31, 64, 6) X(47, 64, 6)                               \
-    X(14, 128, 6) X(17, 128, 6) X(25, 128, 6) X(31, 128, 6) X(47, 128, 6)
+    X(14, 128, 6) X(17, 128, 6) X(25, 128, 6) X(31, 128, 6) X(47, 128, 6)                          \
+    X(71, 64, 5) X(71, 128, 5) /* rware: 71 floats, 5 actions */
 
 }  // namespace marl

@@ -13,6 +13,7 @@ MARL_PART_DECL(lossgrad_part_h64)
 MARL_PART_DECL(lossgrad_part_h64_oid)
 MARL_PART_DECL(lossgrad_part_h128)
 MARL_PART_DECL(lossgrad_part_h128_oid)
+MARL_PART_DECL(lossgrad_part_rware)
 #undef MARL_PART_DECL
 }  // namespace marl
 
@@ -28,7 +29,11 @@ extern "C" int marlhip_net_nparams(const marlhip_net_shape* s) {
 extern "C" int64_t marlhip_dqn_workspace_bytes(const marlhip_net_shape* s, int32_t max_len, int32_t batch) {
     const int np = marlhip_net_nparams(s);
     if (np < 0) return -1;
-    const UpdPlan pl = s->hidden > 64 ? upd_plan_tp(s->n_agents, max_len, batch, 2) : upd_plan(s->n_agents, max_len, batch);
+    bool tp = s->hidden > 64;
+#define X(d, h, a) if (s->obs_dim == d && s->hidden == h && s->n_actions == a) tp = use_tp<MlpShape<d, h, a>>();
+    MARL_NET_SHAPES(X)
+#undef X
+    const UpdPlan pl = tp ? upd_plan_tp(s->n_agents, max_len, batch, s->obs_dim > 48 ? 1 : 2) : upd_plan(s->n_agents, max_len, batch);
     // partial records + 16 B alignment slack + weight packs (<= 4 x nparams-padded floats per agent; see launch_lossgrad)
     int64_t pack = -1;
 #define X(d, h, a) if (s->obs_dim == d && s->hidden == h && s->n_actions == a) pack = 2 * MlpShape<d, h, a>::NFWD + MlpShape<d, h, a>::NBWD;
@@ -46,7 +51,7 @@ static int lossgrad_dispatch(const marlhip_net_shape* s, const float* params, co
     if (agent_map_validate(s) != 0) return -1;
     MARL_REQUIRE(bt->act_agent_stride == 0 && bt->act_row_stride == 0, "dqn_loss_grad: action / reward strides are an actor-critic option");
     bool found = false;
-    for (auto part : {&lossgrad_part_h64, &lossgrad_part_h128, &lossgrad_part_h64_oid, &lossgrad_part_h128_oid}) {
+    for (auto part : {&lossgrad_part_h64, &lossgrad_part_h128, &lossgrad_part_h64_oid, &lossgrad_part_h128_oid, &lossgrad_part_rware}) {
         const int rc = part(s, params, target_params, bt, rsrc, gamma, double_q, mode, workspace, workspace_bytes, grad, loss,
                             (hipStream_t)stream, qx, rst, &found);
         if (found) return rc;

@@ -60,8 +60,13 @@ struct UpdLds {
     static constexpr int FOLD = S::NPARAM + (2 * S::H + 18) * 16;  // per-wave fold region (weights + bias/loss strips)
     // floats: packs + tiles during the walk, the per-wave fold regions (overlaying them) in the epilogue
     static constexpr int total(int waves) { return (oTiles + waves * PER_WAVE) > waves * FOLD ? (oTiles + waves * PER_WAVE) : waves * FOLD; }
-    static_assert(total(4) * 4 <= 160 * 1024, "packs + tiles / fold regions exceed the 160 KiB LDS");
+    static constexpr bool FITS = total(4) * 4 <= 160 * 1024;  // else the shape runs on the register-resident kernels below
 };
+
+// which learner kernels a shape uses: LDS-resident packs (hidden 64, narrow inputs) or weights in registers split over the
+// waves (hidden 128; hidden 64 when the packs of a wide first layer do not fit the LDS, e.g. the 71-wide warehouse rows)
+template <class S>
+constexpr bool use_tp() { return S::H > 64 || !UpdLds<S>::FITS; }
 
 // packs of one agent in the workspace: [critic fwd NFWD][target fwd NFWD][critic bwd NBWD]
 template <class S>
@@ -782,7 +787,7 @@ template <class S, bool REPLAY>
 int launch_lossgrad_tp(const marlhip_net_shape* s, const float* params, const float* tparams, const marlhip_batch* bt,
                        const ReplaySrc& src, float gamma, int double_q, int mode, void* ws, int64_t ws_bytes, float* grad,
                        float* loss, hipStream_t st, const QmixCtx* qx, const RetStats* rst) {
-    constexpr int W = 4, TPW = S::H / 64, NB = 2, NBF = MARL_TP_NBF, NT = W * TPW, REC = S::NPARAM + 2;
+    constexpr int W = 4, TPW = S::H / 64, NB = S::D > 48 ? 1 : 2, NBF = MARL_TP_NBF, NT = W * TPW, REC = S::NPARAM + 2;  // wide first layers: one row block per step keeps pass B out of scratch
     const int P = s->n_agents, T = bt->max_len, B = bt->batch;
     const AgentMap am = agent_map(s);
     const UpdPlan pl = upd_plan_tp(P, T, B, NB), plF = upd_plan_tp(P, T, B, NBF);
@@ -833,10 +838,11 @@ template <class S, bool REPLAY>
 int launch_lossgrad_src(const marlhip_net_shape* s, const float* params, const float* tparams, const marlhip_batch* bt,
                         const ReplaySrc& src, float gamma, int double_q, int mode, void* ws, int64_t ws_bytes, float* grad,
                         float* loss, hipStream_t st, const QmixCtx* qx, const RetStats* rst) {
-    if constexpr (S::H > 64) {
+    if constexpr (use_tp<S>()) {
         return launch_lossgrad_tp<S, REPLAY>(s, params, tparams, bt, src, gamma, double_q, mode, ws, ws_bytes, grad, loss, st, qx, rst);
     } else {
     using L = UpdLds<S>;
+    static_assert(L::FITS, "packs + tiles / fold regions exceed the 160 KiB LDS");
     const int P = s->n_agents, T = bt->max_len, B = bt->batch;
     const AgentMap am = agent_map(s);
     const UpdPlan pl = upd_plan(P, T, B);

@@ -317,8 +317,8 @@ MARL_HD void lbf_observe(const LbfParams& q, const LbfState<P, F>& s, int p, Lbf
 
 // wrapper arithmetic applied to the env's rewards before they reach the learner:
 // CooperativeReward = P * [python sum(reward)] in fp64, then one cast to fp32.
-template <int P>
-MARL_HD void lbf_wrap_rewards(const LbfParams& q, uint32_t env_id, const double* raw, float* out, bool commit = true) {
+template <int P, class PARAMS>
+MARL_HD void lbf_wrap_rewards(const PARAMS& q, uint32_t env_id, const double* raw, float* out, bool commit = true) {
     double r[P];
 #pragma unroll
     for (int p = 0; p < P; ++p) r[p] = raw[p];

@@ -1,0 +1,68 @@
+// extern "C" entry points of the fused collectors on the warehouse env (their own translation unit: build time).
+// Same kernels as collect.hip / ac_collect.hip, instantiated on RwEnvT: agents in registers, the shelf layer of the
+// workgroup's 64 envs as bytes in LDS behind the weight packs.
+#include "ac_collect_kernels.h"
+#include "collect_kernels.h"
+
+using namespace marl;
+
+// (agents, max grid cells) with compiled fused collectors: the tiny layouts (11 x 10 cells)
+#define MARL_RW_COLLECT_SHAPES(X) X(2, 128) X(4, 128)
+
+static int rw_collect_check(const marlhip_rware_config* cfg, const marlhip_net_shape* s, const char* what) {
+    if (rw_validate(cfg) != 0) return -1;
+    MARL_REQUIRE(s != nullptr, "%s: net shape is NULL", what);
+    MARL_REQUIRE(!cfg->observe_id, "%s: the warehouse collectors are not compiled with env.observe_id", what);
+    MARL_REQUIRE(s->n_agents == cfg->n_agents && s->obs_dim == RW_OBS_DIM && s->n_actions == 5,
+                 "%s: net shape does not match the env (P=%d D=%d A=5 expected)", what, cfg->n_agents, RW_OBS_DIM);
+    return agent_map_validate(s);
+}
+
+extern "C" int marlhip_rware_idqn_collect(const marlhip_rware_config* cfg, const marlhip_net_shape* s, const float* params, float epsilon,
+                                          uint32_t round, const marlhip_replay_shape* rs, const marlhip_replay_buffers* rb, int32_t slot_base,
+                                          int32_t write_replay, int32_t clear_stale, int32_t use_proper_termination, float* fin_return,
+                                          int32_t* fin_length, void* stream) {
+    if (rw_collect_check(cfg, s, "rware_idqn_collect") != 0) return -1;
+    MARL_REQUIRE(params && rs && rb && fin_return && fin_length, "rware_idqn_collect: NULL pointer");
+    MARL_REQUIRE(rs->n_agents == cfg->n_agents && rs->obs_dim == RW_OBS_DIM && rs->max_len > 0 && rs->capacity > 0,
+                 "rware_idqn_collect: replay shape does not match the env");
+    MARL_REQUIRE(!write_replay || rs->capacity >= cfg->n_envs, "rware_idqn_collect: replay capacity %d < n_envs %d", rs->capacity, cfg->n_envs);
+    const RwParams q = to_rw_params(cfg);
+#define MARL_ARGS q, agent_map(s), params, epsilon, round, rs, rb, slot_base, write_replay, clear_stale, use_proper_termination, fin_return, \
+                  fin_length, (hipStream_t)stream
+#define X(p, cells)                                                                                   \
+    if (cfg->n_agents == p && q.rows * q.cols <= cells) {                                             \
+        if (s->hidden == 64) return launch_collect<RwEnvT<p, cells>, 64, false>(MARL_ARGS);           \
+        if (s->hidden == 128) return launch_collect<RwEnvT<p, cells>, 128, false>(MARL_ARGS);         \
+    }
+    MARL_RW_COLLECT_SHAPES(X)
+#undef X
+#undef MARL_ARGS
+    set_error("rware_idqn_collect: no fused collector for %d agents on a %dx%d grid, hidden %d (MARL_RW_COLLECT_SHAPES)", cfg->n_agents, q.rows,
+              q.cols, s->hidden);
+    return -1;
+}
+
+extern "C" int marlhip_rware_ac_collect(const marlhip_rware_config* cfg, const marlhip_net_shape* s, const float* actor_params, uint32_t round,
+                                        int32_t max_len, int32_t use_proper_termination, float* batch_obs, int64_t* batch_act, float* batch_rew,
+                                        uint8_t* batch_done, float* batch_filled, float* fin_return, int32_t* fin_length, int32_t* t_max,
+                                        void* stream) {
+    if (rw_collect_check(cfg, s, "rware_ac_collect") != 0) return -1;
+    MARL_REQUIRE(actor_params && batch_obs && batch_act && batch_rew && batch_done && batch_filled && fin_return && fin_length && t_max,
+                 "rware_ac_collect: NULL pointer");
+    MARL_REQUIRE(max_len > 0, "rware_ac_collect: max_len must be > 0");
+    const RwParams q = to_rw_params(cfg);
+#define MARL_ARGS q, agent_map(s), actor_params, round, max_len, use_proper_termination, batch_obs, batch_act, batch_rew, batch_done, \
+                  batch_filled, fin_return, fin_length, t_max, (hipStream_t)stream
+#define X(p, cells)                                                                                   \
+    if (cfg->n_agents == p && q.rows * q.cols <= cells) {                                             \
+        if (s->hidden == 64) return launch_ac_collect<RwEnvT<p, cells>, 64, false>(MARL_ARGS);        \
+        if (s->hidden == 128) return launch_ac_collect<RwEnvT<p, cells>, 128, false>(MARL_ARGS);      \
+    }
+    MARL_RW_COLLECT_SHAPES(X)
+#undef X
+#undef MARL_ARGS
+    set_error("rware_ac_collect: no fused collector for %d agents on a %dx%d grid, hidden %d (MARL_RW_COLLECT_SHAPES)", cfg->n_agents, q.rows,
+              q.cols, s->hidden);
+    return -1;
+}

@@ -1,0 +1,380 @@
+// Multi-robot warehouse (rware) dynamics: agents in registers, the shelf layer as one byte per cell.
+//
+// Replaces the reference's L0 env arithmetic for config 4: the third-party rware Warehouse.reset / step / _make_obs
+// (flattened observations, msg_bits 0, sensor_range 1) reached through
+//   marlbase/utils/envs.py:27-37,82-97  (gym.make -> TimeLimit -> RecordEpisodeStatistics)
+//   marlbase/ac/train.py:30,79          (envs.reset / envs.step)
+// Restated in oracle/rware.py (parity unpinned: the package is absent; see that file's header for what is pinned).
+//
+// One env = a [rows*cols] byte grid (shelf id standing on / carried over the cell, 0 = none), P agents
+// (x, y, direction, carried shelf id, has_delivered), the request queue (shelf ids) and two step counters.
+// Movement conflicts: upstream's networkx graph (cell -> requested cell) has out-degree <= 1, so a component is a cycle
+// with in-trees or an in-tree draining into a free cell; rw_resolve is the closed form of "commit the cycle (not a
+// 2-cycle), else the longest path", ties between equally long feeder chains going to the lowest agent index.
+// Header is host+device (tests/host_shim builds it with g++).
+#pragma once
+#include "philox.h"
+
+namespace marl {
+
+enum : int { RW_NOOP = 0, RW_FORWARD = 1, RW_LEFT = 2, RW_RIGHT = 3, RW_TOGGLE = 4 };
+enum : int { RW_UP = 0, RW_DOWN = 1, RW_DLEFT = 2, RW_DRIGHT = 3 };
+enum : int { RW_REWARD_GLOBAL = 0, RW_REWARD_INDIVIDUAL = 1, RW_REWARD_TWO_STAGE = 2 };
+enum : uint32_t { STREAM_REQUEST = 3u };
+
+struct RwParams {
+    int n_envs, n_agents, rows, cols, column_height;
+    int n_shelves, queue_size;
+    int max_steps, max_inactivity_steps;  // upstream registration: 500 / none -> `done`
+    int time_limit;                       // gymnasium TimeLimit -> `truncated`; 0 = none
+    int reward_type;
+    int cooperative;      // CooperativeReward wrapper (utils/wrappers.py:106-108)
+    uint64_t seed;
+    float* reward_stats;  // StandardiseReward wrapper state, [n_envs][3P+1] fp32, or nullptr
+    int observe_id;       // ObserveID wrapper: one-hot agent-index prefix
+};
+
+template <int P>
+struct RwState {
+    static constexpr int MAXQ = 2 * P;  // "-easy" tasks queue 2 requests per agent
+    int ax[P], ay[P], ad[P], ac[P], adel[P];
+    int rq[MAXQ];
+    int steps, inactive;
+};
+
+// shelf layer of one env: byte `cell` lives at g[cell * stride]  (stride 1 in an HBM record, 64 in a workgroup's LDS)
+struct RwGrid {
+    uint8_t* g;
+    int stride;
+    MARL_HD int get(int cell) const { return g[(size_t)cell * stride]; }
+    MARL_HD void set(int cell, int v) const { g[(size_t)cell * stride] = (uint8_t)v; }
+};
+
+MARL_HD bool rw_is_highway(const RwParams& q, int x, int y) {
+    return x % 3 == 0 || y % (q.column_height + 1) == 0 || y == q.rows - 1 ||
+           (y > q.rows - (q.column_height + 3) && (x == q.cols / 2 - 1 || x == q.cols / 2));
+}
+
+MARL_HD int rw_count_shelves(const RwParams& q) {
+    int n = 0;
+    for (int y = 0; y < q.rows; ++y)
+        for (int x = 0; x < q.cols; ++x) n += rw_is_highway(q, x, y) ? 0 : 1;
+    return n;
+}
+
+// bytes per env record in HBM: grid | P x (x, y, dir, carry, delivered) | 2P queue ids | steps u16 | inactive u16
+MARL_HD int rw_state_stride(int P, int rows, int cols) { return (rows * cols + 5 * P + 2 * P + 4 + 3) & ~3; }
+
+template <int P>
+MARL_HD void rw_load(const uint8_t* rec, int cells, RwState<P>& s) {
+    const uint8_t* a = rec + cells;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        s.ax[p] = a[5 * p]; s.ay[p] = a[5 * p + 1]; s.ad[p] = a[5 * p + 2]; s.ac[p] = a[5 * p + 3]; s.adel[p] = a[5 * p + 4];
+    }
+#pragma unroll
+    for (int k = 0; k < 2 * P; ++k) s.rq[k] = a[5 * P + k];
+    const uint8_t* t = a + 7 * P;
+    s.steps = t[0] | (t[1] << 8);
+    s.inactive = t[2] | (t[3] << 8);
+}
+
+template <int P>
+MARL_HD void rw_store(uint8_t* rec, int cells, const RwState<P>& s) {
+    uint8_t* a = rec + cells;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        a[5 * p] = (uint8_t)s.ax[p]; a[5 * p + 1] = (uint8_t)s.ay[p]; a[5 * p + 2] = (uint8_t)s.ad[p];
+        a[5 * p + 3] = (uint8_t)s.ac[p]; a[5 * p + 4] = (uint8_t)s.adel[p];
+    }
+#pragma unroll
+    for (int k = 0; k < 2 * P; ++k) a[5 * P + k] = (uint8_t)s.rq[k];
+    uint8_t* t = a + 7 * P;
+    t[0] = (uint8_t)(s.steps & 0xFF); t[1] = (uint8_t)(s.steps >> 8);
+    t[2] = (uint8_t)(s.inactive & 0xFF); t[3] = (uint8_t)(s.inactive >> 8);
+}
+
+// index of the agent standing on (x, y), -1 if none  (== upstream grid[_LAYER_AGENTS] - 1)
+template <int P>
+MARL_HD int rw_agent_at(const RwState<P>& s, int x, int y) {
+    int r = -1;
+#pragma unroll
+    for (int p = 0; p < P; ++p) r = (s.ax[p] == x && s.ay[p] == y) ? p : r;
+    return r;
+}
+
+template <int P>
+MARL_HD bool rw_requested(const RwParams& q, const RwState<P>& s, int shelf) {
+    bool r = false;
+#pragma unroll
+    for (int k = 0; k < 2 * P; ++k) r = r || (k < q.queue_size && s.rq[k] == shelf);
+    return r;
+}
+
+// Warehouse.reset: shelves on every non-highway cell (ids in row-major order), agents on distinct uniform cells with
+// uniform directions, queue_size distinct requested shelves; draws from `rng` in that order.
+template <int P>
+MARL_HD void rw_reset(const RwParams& q, RwState<P>& s, const RwGrid& grid, DrawStream& rng) {
+    int id = 0;
+    for (int y = 0; y < q.rows; ++y)
+        for (int x = 0; x < q.cols; ++x) grid.set(y * q.cols + x, rw_is_highway(q, x, y) ? 0 : ++id);
+    const int cells = q.rows * q.cols;
+    int cell[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        bool fresh;
+        int c;
+        do {
+            c = rng.integers(0, cells);
+            fresh = true;
+#pragma unroll
+            for (int o = 0; o < P; ++o) fresh = fresh && !(o < p && cell[o] == c);
+        } while (!fresh);
+        cell[p] = c;
+    }
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        s.ax[p] = cell[p] % q.cols;
+        s.ay[p] = cell[p] / q.cols;
+        s.ad[p] = rng.integers(0, 4);
+        s.ac[p] = 0;
+        s.adel[p] = 0;
+    }
+#pragma unroll
+    for (int k = 0; k < 2 * P; ++k) s.rq[k] = 0;
+#pragma unroll
+    for (int k = 0; k < 2 * P; ++k) {
+        if (k < q.queue_size) {
+            bool fresh;
+            int c;
+            do {
+                c = rng.integers(1, q.n_shelves + 1);
+                fresh = true;
+#pragma unroll
+                for (int o = 0; o < 2 * P; ++o) fresh = fresh && !(o < k && s.rq[o] == c);
+            } while (!fresh);
+            s.rq[k] = c;
+        }
+    }
+    s.steps = 0;
+    s.inactive = 0;
+}
+
+// nibble-packed per-agent tables (P <= 8 here; 0xF = none)
+MARL_HD int rw_nib(uint64_t w, int i) { return (int)((w >> (4 * i)) & 0xF); }
+MARL_HD uint64_t rw_set_nib(uint64_t w, int i, int v) { return (w & ~(0xFull << (4 * i))) | ((uint64_t)(v & 0xF) << (4 * i)); }
+
+// committed-agent bit mask from the per-agent "agent on my target cell" table (0xF = free cell, self = stationary) and the
+// target cells; see the header comment and oracle/rware.py resolve_rule
+template <int P>
+MARL_HD uint32_t rw_resolve(uint64_t nxt, const int* tcell) {
+    static_assert(P <= 8, "nibble tables sized for <= 8 agents");
+    uint32_t committed = 0, in_tree = 0;
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        // on a cycle iff the walk returns to i; the length decides (a 2-cycle is a swap: nobody moves)
+        int j = rw_nib(nxt, i), n = 1;
+#pragma unroll
+        for (int it = 0; it < P; ++it) {
+            if (j != 0xF && j != i) { j = rw_nib(nxt, j); ++n; }
+        }
+        if (j == i && n != 2) committed |= 1u << i;
+        // drains into a free cell iff the walk from i reaches 0xF
+        int k = i;
+#pragma unroll
+        for (int it = 0; it < P; ++it)
+            if (k != 0xF) k = rw_nib(nxt, k);
+        if (k == 0xF) in_tree |= 1u << i;
+    }
+    uint64_t height = 0;  // longest chain of feeders behind each agent
+#pragma unroll
+    for (int pass = 0; pass < P; ++pass) {
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            const int t = rw_nib(nxt, i);
+            if (t != 0xF && t != i) {
+                const int h = rw_nib(height, i) + 1, ht = rw_nib(height, t);
+                if (h > ht && h <= P) height = rw_set_nib(height, t, h);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        if (rw_nib(nxt, i) != 0xF) continue;
+        bool first = true;  // each free cell once: at its lowest-index direct feeder
+#pragma unroll
+        for (int o = 0; o < P; ++o) first = first && !(o < i && rw_nib(nxt, o) == 0xF && tcell[o] == tcell[i]);
+        if (!first) continue;
+        // walk back from the free cell; at every merge the feeder with the longest chain, lowest index on ties
+        int cur = -1;
+#pragma unroll
+        for (int depth = 0; depth < P; ++depth) {
+            int best = -1, bh = -1;
+#pragma unroll
+            for (int o = 0; o < P; ++o) {
+                const bool feeds = cur < 0 ? (rw_nib(nxt, o) == 0xF && tcell[o] == tcell[i]) : (rw_nib(nxt, o) == cur && o != cur);
+                const int h = rw_nib(height, o);
+                if (feeds && ((in_tree >> o) & 1u) && h > bh) { best = o; bh = h; }
+            }
+            if (best < 0) break;
+            committed |= 1u << best;
+            cur = best;
+        }
+    }
+    return committed;
+}
+
+// Warehouse.step.  rew[] are the env's own per-agent rewards (fp64, as upstream's np.zeros accumulates them); `done` =
+// max_steps / max_inactivity_steps reached.  `req` is the env's replacement-request stream (STREAM_REQUEST); it is
+// positioned at word 8 * step here.
+template <int P>
+MARL_HD void rw_step(const RwParams& q, RwState<P>& s, const RwGrid& grid, const int* act_in, double* rew, bool& done, DrawStream& req) {
+    int act[P], tx[P], ty[P], tcell[P];
+    uint64_t nxt = 0;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        int a = act_in[p];
+        if (a < 0 || a > RW_TOGGLE) a = RW_NOOP;
+        int x = s.ax[p], y = s.ay[p];
+        if (a == RW_FORWARD) {
+            if (s.ad[p] == RW_UP) y = y > 0 ? y - 1 : 0;
+            else if (s.ad[p] == RW_DOWN) y = y < q.rows - 1 ? y + 1 : q.rows - 1;
+            else if (s.ad[p] == RW_DLEFT) x = x > 0 ? x - 1 : 0;
+            else x = x < q.cols - 1 ? x + 1 : q.cols - 1;
+        }
+        // a loaded agent cannot enter a cell with a standing shelf (one another agent carries may move away in time)
+        if (s.ac[p] != 0 && (x != s.ax[p] || y != s.ay[p]) && grid.get(y * q.cols + x) != 0) {
+            const int other = rw_agent_at(s, x, y);
+            bool other_loaded = false;
+#pragma unroll
+            for (int o = 0; o < P; ++o) other_loaded = other_loaded || (o == other && s.ac[o] != 0);
+            if (!other_loaded) { a = RW_NOOP; x = s.ax[p]; y = s.ay[p]; }
+        }
+        act[p] = a; tx[p] = x; ty[p] = y; tcell[p] = y * q.cols + x;
+        rew[p] = 0.0;
+    }
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        const int o = rw_agent_at(s, tx[p], ty[p]);
+        nxt = rw_set_nib(nxt, p, o < 0 ? 0xF : o);
+    }
+    const uint32_t committed = rw_resolve<P>(nxt, tcell);
+    // moves of loaded agents: clear every vacated cell first, then occupy (trains of carriers)
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        if (!((committed >> p) & 1u)) act[p] = RW_NOOP;  // only FORWARD requests can fail
+        if (act[p] == RW_FORWARD && s.ac[p] != 0 && tcell[p] != s.ay[p] * q.cols + s.ax[p]) grid.set(s.ay[p] * q.cols + s.ax[p], 0);
+    }
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        const int a = act[p];
+        if (a == RW_FORWARD) {
+            s.ax[p] = tx[p]; s.ay[p] = ty[p];
+            if (s.ac[p] != 0) grid.set(tcell[p], s.ac[p]);
+        } else if (a == RW_LEFT) {  // clockwise order UP, RIGHT, DOWN, LEFT; LEFT turns against it
+            s.ad[p] = s.ad[p] == RW_UP ? RW_DLEFT : (s.ad[p] == RW_DLEFT ? RW_DOWN : (s.ad[p] == RW_DOWN ? RW_DRIGHT : RW_UP));
+        } else if (a == RW_RIGHT) {
+            s.ad[p] = s.ad[p] == RW_UP ? RW_DRIGHT : (s.ad[p] == RW_DRIGHT ? RW_DOWN : (s.ad[p] == RW_DOWN ? RW_DLEFT : RW_UP));
+        } else if (a == RW_TOGGLE) {
+            if (s.ac[p] == 0) {
+                s.ac[p] = grid.get(s.ay[p] * q.cols + s.ax[p]);
+            } else if (!rw_is_highway(q, s.ax[p], s.ay[p])) {
+                s.ac[p] = 0;
+                if (s.adel[p] && q.reward_type == RW_REWARD_TWO_STAGE) rew[p] += 0.5;
+                s.adel[p] = 0;
+            }
+        }
+    }
+    // deliveries at the two goal cells
+    bool delivered = false;
+    req.idx = 8u * (uint32_t)s.steps;
+#pragma unroll
+    for (int gi = 0; gi < 2; ++gi) {
+        const int gx = q.cols / 2 - 1 + gi, gy = q.rows - 1;
+        const int shelf = grid.get(gy * q.cols + gx);
+        if (shelf == 0 || !rw_requested(q, s, shelf)) continue;
+        delivered = true;
+        // replacement: uniform over the shelves not in the queue, in id order
+        int sorted[2 * P];
+#pragma unroll
+        for (int k = 0; k < 2 * P; ++k) sorted[k] = k < q.queue_size ? s.rq[k] : 0x7FFFFFFF;
+#pragma unroll
+        for (int i = 0; i < 2 * P; ++i)
+#pragma unroll
+            for (int j = 0; j < 2 * P - 1; ++j)
+                if (sorted[j + 1] < sorted[j]) { const int t = sorted[j]; sorted[j] = sorted[j + 1]; sorted[j + 1] = t; }
+        int id = req.integers(0, q.n_shelves - q.queue_size) + 1;
+#pragma unroll
+        for (int k = 0; k < 2 * P; ++k) id += (sorted[k] <= id) ? 1 : 0;
+        bool replaced = false;
+#pragma unroll
+        for (int k = 0; k < 2 * P; ++k) {
+            if (!replaced && k < q.queue_size && s.rq[k] == shelf) { s.rq[k] = id; replaced = true; }
+        }
+        const int carrier = rw_agent_at(s, gx, gy);
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            if (q.reward_type == RW_REWARD_GLOBAL) rew[p] += 1.0;
+            else if (p == carrier) {
+                if (q.reward_type == RW_REWARD_INDIVIDUAL) rew[p] += 1.0;
+                else { s.adel[p] = 1; rew[p] += 0.5; }
+            }
+        }
+    }
+    s.inactive = delivered ? 0 : s.inactive + 1;
+    s.steps += 1;
+    done = (q.max_inactivity_steps > 0 && s.inactive >= q.max_inactivity_steps) || (q.max_steps > 0 && s.steps >= q.max_steps);
+}
+
+// agent p's 3x3 sensor window, one code per cell (row-major): bit0 agent present, bits1-2 its direction, bit3 shelf,
+// bit4 shelf requested; cells off the grid read as empty (np.pad with zeros)
+template <int P>
+MARL_HD void rw_window(const RwParams& q, const RwState<P>& s, const RwGrid& grid, int p, int (&code)[9]) {
+#pragma unroll
+    for (int c = 0; c < 9; ++c) {
+        const int x = s.ax[p] - 1 + c % 3, y = s.ay[p] - 1 + c / 3;
+        int v = 0;
+        if (x >= 0 && y >= 0 && x < q.cols && y < q.rows) {
+            const int o = rw_agent_at(s, x, y);
+            if (o >= 0) {
+                int d = 0;
+#pragma unroll
+                for (int k = 0; k < P; ++k) d = k == o ? s.ad[k] : d;
+                v |= 1 | (d << 1);
+            }
+            const int shelf = grid.get(y * q.cols + x);
+            if (shelf != 0) v |= 8 | (rw_requested(q, s, shelf) ? 16 : 0);
+        }
+        code[c] = v;
+    }
+}
+
+constexpr int RW_OBS_DIM = 8 + 9 * 7;
+
+// element d of agent p's flattened observation (Warehouse._make_obs, fast path):
+//   x, y, carrying, one-hot direction[4], on highway, then per window cell: agent present, one-hot direction[4]
+//   (an empty cell reads as direction 0: Discrete(4) flattens to one-hot(0)), shelf present, shelf requested
+template <int P>
+MARL_HD float rw_obs_elem(const RwParams& q, const RwState<P>& s, int p, const int (&code)[9], int d) {
+    if (d < 8) {
+        switch (d) {
+            case 0: return (float)s.ax[p];
+            case 1: return (float)s.ay[p];
+            case 2: return s.ac[p] != 0 ? 1.f : 0.f;
+            case 7: return rw_is_highway(q, s.ax[p], s.ay[p]) ? 1.f : 0.f;
+            default: return s.ad[p] == d - 3 ? 1.f : 0.f;
+        }
+    }
+    const int c = (d - 8) / 7, f = (d - 8) % 7;
+    int v = 0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) v = k == c ? code[k] : v;
+    const bool has = (v & 1) != 0;
+    const int dir = (v >> 1) & 3;
+    if (f == 0) return has ? 1.f : 0.f;
+    if (f <= 4) return (has ? dir : 0) == f - 1 ? 1.f : 0.f;
+    if (f == 5) return (v & 8) ? 1.f : 0.f;
+    return (v & 16) ? 1.f : 0.f;
+}
+
+}  // namespace marl

@@ -177,7 +177,7 @@ class VectorisedIDQN:
     def evaluate(self, episodes, epsilon, round_idx=0):
         """_evaluate (train.py:177-199) for `episodes` envs in one collector launch (no replay writes);
         returns per-episode info dicts like RecordEpisodeStatistics emits."""
-        cfg = _hip.LbfConfig.from_buffer_copy(self.cfg)
+        cfg = type(self.cfg).from_buffer_copy(self.cfg)
         cfg.n_envs = int(episodes)
         cfg.seed = (self.cfg.seed ^ 0x5DEECE66D) & (2**64 - 1)  # eval env: its own stream
         cfg.reward_stats = None  # the eval env has its own wrapper stack; only raw episode returns are reported

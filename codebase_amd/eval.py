@@ -26,7 +26,7 @@ def latest_step(path):
 def evaluate(model, lbf_cfg, episodes, time_limit, epsilon=0.0, round_idx=0):
     """mean per-episode team return and length of `episodes` fresh episodes (greedy DQN-family models: epsilon as given;
     actor-critic models sample from their policy like the reference's act())"""
-    cfg = _hip.LbfConfig.from_buffer_copy(lbf_cfg)
+    cfg = type(lbf_cfg).from_buffer_copy(lbf_cfg)
     cfg.n_envs = int(episodes)
     cfg.reward_stats = None  # only RecordEpisodeStatistics' raw returns are reported
     dev = model.device

@@ -8,7 +8,7 @@ from dataclasses import dataclass
 import torch
 
 from . import _lib
-from ._lib import (AcConfig, BatchStruct, IdqnLearner, RetStatsStruct, QmixMixer, LbfBuffers, LbfConfig, MarlHipError, NetShape, ReplayBuffers, ReplayShape, check, lib)
+from ._lib import (AcConfig, BatchStruct, IdqnLearner, RetStatsStruct, QmixMixer, LbfBuffers, LbfConfig, MarlHipError, RwareConfig, NetShape, ReplayBuffers, ReplayShape, check, lib)
 
 Batch = namedtuple("Batch", ["obss", "actions", "rewards", "dones", "filled", "action_mask"])  # dqn/train.py:14-16
 
@@ -48,7 +48,50 @@ def lbf_config(name, n_envs, time_limit, seed=0, cooperative=False, **over):
                      cooperative=int(cooperative), **kw)
 
 
-def attach_reward_stats(cfg: LbfConfig, device="cuda"):
+RWARE_SIZES = {"tiny": (1, 3), "small": (2, 3), "medium": (2, 5), "large": (3, 5)}  # (shelf_rows, shelf_columns)
+
+
+def parse_rware_name(name):
+    """'rware:rware-tiny-4ag[-easy|-hard]-v2' (also 'rware:tiny-4ag') -> upstream registration kwargs (rware/__init__.py)."""
+    parts = [p for p in name.split(":")[-1].split("-") if p != "rware" and not (p[:1] == "v" and p[1:].isdigit())]
+    size = next((p for p in parts if p in RWARE_SIZES), None)
+    ag = next((p for p in parts if p.endswith("ag") and p[:-2].isdigit()), None)
+    if size is None or ag is None:
+        raise ValueError(f"not a warehouse id: {name}")
+    agents = int(ag[:-2])
+    scale = 2.0 if "easy" in parts else (0.5 if "hard" in parts else 1.0)
+    return dict(n_agents=agents, shelf_rows=RWARE_SIZES[size][0], shelf_columns=RWARE_SIZES[size][1], column_height=8,
+                request_queue_size=int(agents * scale), max_steps=500, max_inactivity_steps=0, reward_type=1)
+
+
+def rware_config(name, n_envs, time_limit, seed=0, cooperative=False, **over):
+    kw = parse_rware_name(name)
+    kw.update(over)
+    kw["max_steps"] = int(kw["max_steps"] or 0)
+    kw["max_inactivity_steps"] = int(kw["max_inactivity_steps"] or 0)
+    return RwareConfig(n_envs=n_envs, time_limit=int(time_limit or 0), seed=int(seed) & (2**64 - 1),
+                       cooperative=int(cooperative), **kw)
+
+
+def is_rware(cfg):
+    return isinstance(cfg, RwareConfig)
+
+
+def env_config(name, n_envs, time_limit, seed=0, cooperative=False, **over):
+    """LbfConfig or RwareConfig from a gymnasium id"""
+    if "rware" in name:
+        return rware_config(name, n_envs, time_limit, seed=seed, cooperative=cooperative, **over)
+    return lbf_config(name, n_envs, time_limit, seed=seed, cooperative=cooperative, **over)
+
+
+def env_dims(cfg):
+    """(obs_dim, n_actions) of a batched env config"""
+    if is_rware(cfg):
+        return 71 + (cfg.n_agents if cfg.observe_id else 0), 5
+    return 3 * (cfg.n_agents + cfg.n_food) + (cfg.n_agents if cfg.observe_id else 0), 6
+
+
+def attach_reward_stats(cfg, device="cuda"):
     """env.standardise_rewards: allocate the per-env streaming records [n_envs][3P+1] and point the config at them."""
     _require_gpu()
     t = torch.zeros(cfg.n_envs, 3 * cfg.n_agents + 1, dtype=torch.float32, device=device)
@@ -58,15 +101,24 @@ def attach_reward_stats(cfg: LbfConfig, device="cuda"):
 
 
 class BatchedForaging:
-    """N Level-Based Foraging envs resident in HBM (K1)."""
+    """N Level-Based Foraging (or, with an RwareConfig, warehouse) envs resident in HBM (K1)."""
 
-    def __init__(self, cfg: LbfConfig, device="cuda"):
+    def __init__(self, cfg, device="cuda"):
         _require_gpu()
         self.cfg = cfg
         self.device = torch.device(device)
-        self.N, self.P, self.F = cfg.n_envs, cfg.n_agents, cfg.n_food
-        self.stride = check(lib.marlhip_lbf_state_stride(ctypes.byref(cfg)), "lbf_state_stride")
-        self.D = 3 * (self.P + self.F) + (self.P if cfg.observe_id else 0)  # ObserveID: one-hot agent index first
+        self.N, self.P = cfg.n_envs, cfg.n_agents
+        if is_rware(cfg):  # the warehouse env behind the same buffers and call shapes
+            self._fn = (lib.marlhip_rware_reset, lib.marlhip_rware_observe, lib.marlhip_rware_step)
+            self.stride = check(lib.marlhip_rware_state_stride(ctypes.byref(cfg)), "rware_state_stride")
+            r, c, n = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+            check(lib.marlhip_rware_grid(ctypes.byref(cfg), ctypes.byref(r), ctypes.byref(c), ctypes.byref(n)), "rware_grid")
+            self.rows, self.cols, self.n_shelves = r.value, c.value, n.value
+        else:
+            self._fn = (lib.marlhip_lbf_reset, lib.marlhip_lbf_observe, lib.marlhip_lbf_step)
+            self.F = cfg.n_food
+            self.stride = check(lib.marlhip_lbf_state_stride(ctypes.byref(cfg)), "lbf_state_stride")
+        self.D, self.A = env_dims(cfg)  # ObserveID: one-hot agent index first
         dev = self.device
         self.state = torch.zeros(self.N, self.stride, dtype=torch.uint8, device=dev)
         self.episode = torch.zeros(self.N, dtype=torch.int32, device=dev)  # u32 bit pattern
@@ -83,21 +135,20 @@ class BatchedForaging:
                                self.ep_length.data_ptr())
 
     def reset(self, mask=None):
-        check(lib.marlhip_lbf_reset(ctypes.byref(self.cfg), ctypes.byref(self._buf), _ptr(mask), _ptr(self.obs), _stream()),
-              "lbf_reset")
+        check(self._fn[0](ctypes.byref(self.cfg), ctypes.byref(self._buf), _ptr(mask), _ptr(self.obs), _stream()), "env reset")
         return self.obs
 
     def observe(self):
-        check(lib.marlhip_lbf_observe(ctypes.byref(self.cfg), ctypes.byref(self._buf), _ptr(self.obs), _stream()), "lbf_observe")
+        check(self._fn[1](ctypes.byref(self.cfg), ctypes.byref(self._buf), _ptr(self.obs), _stream()), "env observe")
         return self.obs
 
     def step(self, actions, active=None, auto_reset=False):
         """actions int32 [P][N] (device).  Returns (obs, rewards, done, truncated) device tensors."""
         assert actions.dtype == torch.int32 and actions.shape == (self.P, self.N) and actions.is_contiguous()
-        check(lib.marlhip_lbf_step(ctypes.byref(self.cfg), ctypes.byref(self._buf), _ptr(active), _ptr(actions), _ptr(self.obs),
+        check(self._fn[2](ctypes.byref(self.cfg), ctypes.byref(self._buf), _ptr(active), _ptr(actions), _ptr(self.obs),
                                    _ptr(self.rewards), _ptr(self.done), _ptr(self.truncated), _ptr(self.fin_return),
                                    _ptr(self.fin_length), int(auto_reset), _ptr(self.final_obs) if auto_reset else None,
-                                   _stream()), "lbf_step")
+                                   _stream()), "env step")
         return self.obs, self.rewards, self.done, self.truncated
 
 
@@ -448,12 +499,13 @@ class AcUpdater:
                                         _ptr(self.scratch), _ptr(self.gnorm), _stream()), "dqn_clip_adam(actor+critic)")
 
 
-def idqn_collect(cfg: LbfConfig, spec: NetSpec, params, epsilon, round_idx, replay: DeviceReplay, slot_base, fin_return,
+def idqn_collect(cfg, spec: NetSpec, params, epsilon, round_idx, replay: DeviceReplay, slot_base, fin_return,
                  fin_length, write_replay=True, clear_stale=False, use_proper_termination=False):
     """Fused collector: one launch = one round of N episodes (reset -> T x (act, step, add))."""
     _require_gpu()
     s = spec.c()
-    check(lib.marlhip_idqn_collect(ctypes.byref(cfg), ctypes.byref(s), _ptr(params), float(epsilon), int(round_idx) & 0xFFFFFFFF,
+    fn = lib.marlhip_rware_idqn_collect if is_rware(cfg) else lib.marlhip_idqn_collect
+    check(fn(ctypes.byref(cfg), ctypes.byref(s), _ptr(params), float(epsilon), int(round_idx) & 0xFFFFFFFF,
                                    ctypes.byref(replay.shape), ctypes.byref(replay.bufs), int(slot_base), int(bool(write_replay)),
                                    int(bool(clear_stale)), int(bool(use_proper_termination)), _ptr(fin_return), _ptr(fin_length),
                                    _stream()), "idqn_collect")
@@ -493,11 +545,12 @@ class FusedLearner:
         return upd.value, last.value
 
 
-def ac_collect(cfg: LbfConfig, spec: NetSpec, actor_params, round_idx, max_len, use_proper_termination, b_obs, b_act, b_rew,
+def ac_collect(cfg, spec: NetSpec, actor_params, round_idx, max_len, use_proper_termination, b_obs, b_act, b_rew,
                b_done, b_filled, fin_return, fin_length, t_max):
     """Fused actor-critic rollout collector (marlbase/ac/train.py:24-119): one launch = one collection call."""
     _require_gpu()
     s = spec.c()
-    check(lib.marlhip_ac_collect(ctypes.byref(cfg), ctypes.byref(s), _ptr(actor_params), int(round_idx) & 0xFFFFFFFF, int(max_len),
+    fn = lib.marlhip_rware_ac_collect if is_rware(cfg) else lib.marlhip_ac_collect
+    check(fn(ctypes.byref(cfg), ctypes.byref(s), _ptr(actor_params), int(round_idx) & 0xFFFFFFFF, int(max_len),
                                  int(bool(use_proper_termination)), _ptr(b_obs), _ptr(b_act), _ptr(b_rew), _ptr(b_done),
                                  _ptr(b_filled), _ptr(fin_return), _ptr(fin_length), _ptr(t_max), _stream()), "ac_collect")

@@ -1,6 +1,6 @@
 """Env factory with the reference's signature - drop-in for `env._target_: utils.envs.make_env`
 (marlbase/configs/default.yaml:28-35, marlbase/utils/envs.py:68-119) - backed by the batched HIP
-Level-Based Foraging env instead of gym.make + wrapper classes.
+Level-Based Foraging / multi-robot warehouse (rware) envs instead of gym.make + wrapper classes.
 
     make_env(seed, enable_video=False, name=..., time_limit=..., clear_info=False, observe_id=False,
              standardise_rewards=False, wrappers=None[, parallel_envs=N])
@@ -30,7 +30,12 @@ from .. import spaces
 
 
 def _space_pair(cfg):
-    P, F = cfg.n_agents, cfg.n_food
+    P = cfg.n_agents
+    if _hip.is_rware(cfg):  # rware: Box(-inf, inf, (71,)) per agent, Discrete(5)
+        D, A = _hip.env_dims(cfg)
+        obs = spaces.Tuple([spaces.Box(np.full(D, -np.inf, np.float32), np.full(D, np.inf, np.float32)) for _ in range(P)])
+        return obs, spaces.Tuple([spaces.Discrete(A) for _ in range(P)])
+    F = cfg.n_food
     low = np.array([-1, -1, 0] * (F + P), np.float32)
     high = np.array([cfg.rows - 1, cfg.cols - 1, cfg.max_player_level * min(P, 3)] * F
                     + [cfg.rows - 1, cfg.cols - 1, cfg.max_player_level] * P, np.float32)
@@ -42,9 +47,9 @@ def _space_pair(cfg):
 
 
 def _build_cfg(name, time_limit, clear_info, observe_id, standardise_rewards, wrappers, seed, n_envs, kwargs):
-    if "Foraging" not in name:
-        raise NotImplementedError(f"{name}: only Level-Based Foraging ids have a HIP env in this round "
-                                  "(rware / smaclite are listed under 'next' in DESIGN.md)")
+    if "Foraging" not in name and "rware" not in name:
+        raise NotImplementedError(f"{name}: only Level-Based Foraging and rware ids have a HIP env "
+                                  "(smaclite is listed under 'next' in DESIGN.md)")
     kwargs = dict(kwargs, observe_id=int(bool(observe_id)))  # ObserveID (utils/wrappers.py:73-103): one-hot prefix, in-kernel
     cooperative = False
     for w in wrappers or []:
@@ -54,7 +59,7 @@ def _build_cfg(name, time_limit, clear_info, observe_id, standardise_rewards, wr
             raise NotImplementedError(f"wrapper {w} is not available on the HIP env")
     if seed is None:
         seed = random.randint(0, 99999)  # utils/envs.py:58-59
-    cfg = _hip.lbf_config(name, n_envs, time_limit, seed=seed, cooperative=cooperative, **kwargs)
+    cfg = _hip.env_config(name, n_envs, time_limit, seed=seed, cooperative=cooperative, **kwargs)
     if standardise_rewards:  # StandardiseReward (utils/wrappers.py:111-142): one streaming record per env, kept with the cfg
         _hip.attach_reward_stats(cfg)
     return cfg
@@ -123,7 +128,7 @@ class HipForagingVecEnv:
         self.single_observation_space, self.single_action_space = _space_pair(cfg)
         D = self.batched.D
         self.observation_space = spaces.Tuple([spaces.Box(-1.0, 255.0, shape=(cfg.n_envs, D)) for _ in range(cfg.n_agents)])
-        self.action_space = spaces.Tuple([spaces.Discrete(6) for _ in range(cfg.n_agents)])
+        self.action_space = spaces.Tuple([spaces.Discrete(self.batched.A) for _ in range(cfg.n_agents)])
 
     @property
     def unwrapped(self):

@@ -98,6 +98,48 @@ int marlhip_lbf_step(const marlhip_lbf_config* cfg, const marlhip_lbf_buffers* b
                      void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Multi-robot warehouse (rware), batched.   Replaces rware's Warehouse (third-party; reached via gym.make at
+ * marlbase/utils/envs.py:27-37,90-92) with flattened observations, msg_bits 0, sensor_range 1, under the same wrapper
+ * stack as above.  Field values mirror upstream's `rware-{tiny,small,medium,large}-{n}ag[-easy|-hard]-v2`
+ * registration: tiny = 1 shelf row x 3 shelf columns, column_height 8, request_queue_size n (2n easy, n/2 hard),
+ * max_steps 500, individual rewards.  5 actions (noop, forward, left, right, toggle-load); observation = 71 floats
+ * (x, y, carrying, direction one-hot, on-highway, then 3x3 cells x (agent, direction one-hot, shelf, requested)).
+ * Movement conflicts follow upstream's graph rule (cycles move, swaps do not, else the longest chain into a free
+ * cell moves); equally long chains meeting at one cell: the lowest agent index wins (upstream: CPython set order).
+ * Replacement requests draw from Philox stream 3 over the un-queued shelves in id order.
+ * Buffers are a marlhip_lbf_buffers whose state records are marlhip_rware_state_stride bytes:
+ * grid u8[rows*cols] (shelf id on the cell, 0 none) | P x (x, y, dir, carried shelf, has_delivered) u8 |
+ * 2P queue ids u8 | steps u16 LE | inactive steps u16 LE | pad to 4 B.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct marlhip_rware_config {
+    int32_t n_envs;
+    int32_t n_agents;
+    int32_t shelf_rows, shelf_columns, column_height;
+    int32_t request_queue_size;
+    int32_t max_steps;            /* upstream registration: 500 -> `done`; 0 = none */
+    int32_t max_inactivity_steps; /* 0 = none */
+    int32_t time_limit;           /* env.time_limit (TimeLimit wrapper) -> `truncated`; 0 = none */
+    int32_t reward_type;          /* 0 global, 1 individual, 2 two-stage */
+    int32_t cooperative;          /* CooperativeReward wrapper */
+    int32_t observe_id;           /* ObserveID wrapper: one-hot agent index in front of every observation */
+    uint64_t seed;                /* Philox key */
+    float* reward_stats;          /* StandardiseReward records [n_envs][3*n_agents + 1] or NULL (see marlhip_lbf_config) */
+} marlhip_rware_config;
+
+int marlhip_rware_state_stride(const marlhip_rware_config* cfg); /* bytes per env record, <0 if unsupported */
+int marlhip_rware_obs_dim(const marlhip_rware_config* cfg);      /* 71 [+ n_agents with observe_id] */
+int marlhip_rware_grid(const marlhip_rware_config* cfg, int32_t* rows, int32_t* cols, int32_t* n_shelves);
+/* same contracts as marlhip_lbf_reset / _observe / _step; actions in [0, 5) */
+int marlhip_rware_reset(const marlhip_rware_config* cfg, const marlhip_lbf_buffers* buf, const uint8_t* mask,
+                        float* obs /* [P][N][D] */, void* stream);
+int marlhip_rware_observe(const marlhip_rware_config* cfg, const marlhip_lbf_buffers* buf, float* obs, void* stream);
+int marlhip_rware_step(const marlhip_rware_config* cfg, const marlhip_lbf_buffers* buf, const uint8_t* active,
+                       const int32_t* actions /* [P][N] */, float* obs /* [P][N][D] */, float* rewards /* [P][N] */,
+                       uint8_t* done /* [N] */, uint8_t* truncated /* [N] */, float* fin_return /* [P][N] */,
+                       int32_t* fin_length /* [N] */, int32_t auto_reset, float* final_obs /* [P][N][D] or NULL */,
+                       void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Per-agent Q-networks.  All agents share one shape (true for every LBF task); parameters of
  * agent i are one contiguous fp32 block in torch parameters() order of
  * critic.independent.{i}.network.{0,2,4}.{weight,bias} (marlbase/utils/models.py:34-42,146-154):
@@ -253,6 +295,18 @@ int marlhip_ac_collect(const marlhip_lbf_config* cfg, const marlhip_net_shape* s
                        int64_t* batch_act, float* batch_rew, uint8_t* batch_done, float* batch_filled,
                        float* fin_return /* [P][N] */, int32_t* fin_length /* [N] */, int32_t* t_max /* [1] */,
                        void* stream);
+
+/* the two fused collectors on the warehouse env (same contracts; net shape D = 71, A = 5; compiled for the tiny layouts,
+ * 2 and 4 agents: the shelf layer of a workgroup's 64 envs lives in LDS behind the weight packs) */
+int marlhip_rware_idqn_collect(const marlhip_rware_config* cfg, const marlhip_net_shape* s, const float* params, float epsilon,
+                               uint32_t round, const marlhip_replay_shape* rs, const marlhip_replay_buffers* rb,
+                               int32_t slot_base, int32_t write_replay, int32_t clear_stale, int32_t use_proper_termination,
+                               float* fin_return /* [P][N] */, int32_t* fin_length /* [N] */, void* stream);
+int marlhip_rware_ac_collect(const marlhip_rware_config* cfg, const marlhip_net_shape* s, const float* actor_params,
+                             uint32_t round, int32_t max_len, int32_t use_proper_termination, float* batch_obs,
+                             int64_t* batch_act, float* batch_rew, uint8_t* batch_done, float* batch_filled,
+                             float* fin_return /* [P][N] */, int32_t* fin_length /* [N] */, int32_t* t_max /* [1] */,
+                             void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Actor-critic learner step (IA2C / IPPO).  Replaces A2CNetwork.update / PPONetwork.update

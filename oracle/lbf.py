@@ -394,9 +394,16 @@ class MarlbaseEnv:
     TimeLimit(time_limit) -> RecordEpisodeStatistics -> [CooperativeReward]."""
 
     def __init__(self, name, time_limit, cooperative=False, rng=None, standardise_rewards=False, observe_id=False, **overrides):
-        kw = parse_env_name(name)
-        kw.update(overrides)
-        self.env = ForagingEnv(rng=rng, **kw)
+        if "rware" in name:  # the warehouse env sits under the same wrapper stack (utils/envs.py:82-97)
+            from oracle import rware
+
+            kw = rware.parse_env_name(name)
+            kw.update(overrides)
+            self.env = rware.Warehouse(rng=rng, **kw)
+        else:
+            kw = parse_env_name(name)
+            kw.update(overrides)
+            self.env = ForagingEnv(rng=rng, **kw)
         self.n_agents = self.env.n_agents
         self.time_limit = time_limit
         self.cooperative = cooperative

@@ -79,7 +79,7 @@ def host_shim():
     if _shim is None:
         out = os.path.join(ROOT, "tests", "host_shim", "_lbf_host.so")
         src = os.path.join(ROOT, "tests", "host_shim", "lbf_host.cpp")
-        deps = [src] + [os.path.join(ROOT, "codebase_amd", "csrc", f) for f in ("lbf_core.h", "philox.h")]
+        deps = [src] + [os.path.join(ROOT, "codebase_amd", "csrc", f) for f in ("lbf_core.h", "philox.h", "rware_core.h")]
         if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
             subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", src, "-o", out])
         _shim = ctypes.CDLL(out)

@@ -98,3 +98,92 @@ extern "C" void host_philox(const uint32_t* ctr, const uint32_t* key, uint32_t* 
     U4 r = philox4x32_10(c, key[0], key[1]);
     out[0] = r.x; out[1] = r.y; out[2] = r.z; out[3] = r.w;
 }
+
+// ---- multi-robot warehouse core (csrc/rware_core.h) against oracle/rware.py ----
+#include "../../codebase_amd/csrc/rware_core.h"
+
+struct HostRwCfg {
+    int32_t n_envs, n_agents, rows, cols, column_height, n_shelves, queue_size, max_steps, max_inactivity_steps, time_limit;
+    int32_t reward_type, cooperative;
+    uint64_t seed;
+};
+
+static RwParams rw_conv(const HostRwCfg* c) {
+    RwParams q;
+    q.n_envs = c->n_envs; q.n_agents = c->n_agents; q.rows = c->rows; q.cols = c->cols; q.column_height = c->column_height;
+    q.n_shelves = c->n_shelves; q.queue_size = c->queue_size; q.max_steps = c->max_steps;
+    q.max_inactivity_steps = c->max_inactivity_steps; q.time_limit = c->time_limit; q.reward_type = c->reward_type;
+    q.cooperative = c->cooperative; q.seed = c->seed; q.reward_stats = nullptr; q.observe_id = 0;
+    return q;
+}
+
+template <int P>
+static void rw_obs_all(const RwParams& q, const RwState<P>& s, const RwGrid& grid, int n, float* obs) {
+    for (int p = 0; p < P; ++p) {
+        int code[9];
+        rw_window(q, s, grid, p, code);
+        for (int d = 0; d < RW_OBS_DIM; ++d) obs[((size_t)p * q.n_envs + n) * RW_OBS_DIM + d] = rw_obs_elem(q, s, p, code, d);
+    }
+}
+
+template <int P>
+static void rw_run_reset(const RwParams& q, uint8_t* state, const uint32_t* episode, float* obs) {
+    const int stride = rw_state_stride(P, q.rows, q.cols), cells = q.rows * q.cols;
+    for (int n = 0; n < q.n_envs; ++n) {
+        RwState<P> s;
+        uint8_t* rec = state + (size_t)n * stride;
+        const RwGrid grid{rec, 1};
+        DrawStream rng;
+        rng.init(q.seed, (uint32_t)n, episode[n], STREAM_RESET);
+        rw_reset(q, s, grid, rng);
+        rw_store(rec, cells, s);
+        rw_obs_all<P>(q, s, grid, n, obs);
+    }
+}
+
+template <int P>
+static void rw_run_step(const RwParams& q, uint8_t* state, const uint32_t* episode, const int32_t* actions, float* obs, float* rew,
+                        uint8_t* done, uint8_t* trunc) {
+    const int stride = rw_state_stride(P, q.rows, q.cols), cells = q.rows * q.cols;
+    for (int n = 0; n < q.n_envs; ++n) {
+        RwState<P> s;
+        uint8_t* rec = state + (size_t)n * stride;
+        const RwGrid grid{rec, 1};
+        rw_load(rec, cells, s);
+        int a[P];
+        double raw[P];
+        float rw[P];
+        bool d = false;
+        for (int p = 0; p < P; ++p) a[p] = actions[(size_t)p * q.n_envs + n];
+        DrawStream req;
+        req.init(q.seed, (uint32_t)n, episode[n], STREAM_REQUEST);
+        rw_step(q, s, grid, a, raw, d, req);
+        lbf_wrap_rewards<P>(q, (uint32_t)n, raw, rw);
+        rw_store(rec, cells, s);
+        done[n] = d;
+        trunc[n] = q.time_limit > 0 && s.steps >= q.time_limit;
+        for (int p = 0; p < P; ++p) rew[(size_t)p * q.n_envs + n] = rw[p];
+        rw_obs_all<P>(q, s, grid, n, obs);
+    }
+}
+
+extern "C" int host_rw_stride(int P, int rows, int cols) { return rw_state_stride(P, rows, cols); }
+
+extern "C" int host_rw_count_shelves(const HostRwCfg* c) { return rw_count_shelves(rw_conv(c)); }
+
+extern "C" int host_rw_reset(const HostRwCfg* c, uint8_t* state, const uint32_t* episode, float* obs) {
+    const RwParams q = rw_conv(c);
+#define X(p) if (c->n_agents == p) { rw_run_reset<p>(q, state, episode, obs); return 0; }
+    X(2) X(4) X(8)
+#undef X
+    return -1;
+}
+
+extern "C" int host_rw_step(const HostRwCfg* c, uint8_t* state, const uint32_t* episode, const int32_t* actions, float* obs, float* rew,
+                            uint8_t* done, uint8_t* trunc) {
+    const RwParams q = rw_conv(c);
+#define X(p) if (c->n_agents == p) { rw_run_step<p>(q, state, episode, actions, obs, rew, done, trunc); return 0; }
+    X(2) X(4) X(8)
+#undef X
+    return -1;
+}
