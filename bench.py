@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--updates-per-round", type=int, default=0)
     ap.add_argument("--replay-rounds", type=int, default=4, help="replay capacity in rounds of `envs` episodes")
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--env-name", default=ENV_NAME, help="other BASELINE.json configs, e.g. lbforaging:Foraging-15x15-4p-5f-v3")
+    ap.add_argument("--env-name", default=ENV_NAME, help="other BASELINE.json configs, e.g. lbforaging:Foraging-15x15-4p-5f-v3 or rware:rware-tiny-4ag-v2 (with --time-limit 500)")
     ap.add_argument("--algo", default="idqn", choices=["idqn", "vdn", "qmix", "ia2c", "ippo", "maa2c", "mappo"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -115,8 +115,8 @@ def bench_ac(args, rank, world, dist):
     from codebase_amd.utils.envs import _space_pair
 
     N, T, H = args.envs, args.time_limit, args.hidden
-    cfg = h.lbf_config(args.env_name, N, T, seed=rank_env_seed(args.seed, rank))
-    P, D, A = cfg.n_agents, 3 * (cfg.n_agents + cfg.n_food), 6
+    cfg = h.env_config(args.env_name, N, T, seed=rank_env_seed(args.seed, rank))
+    P, (D, A) = cfg.n_agents, h.env_dims(cfg)
     torch.manual_seed(args.seed)
     obs_space, act_space = _space_pair(cfg)
     hyper = dict(optimizer="Adam", lr=3e-4, gamma=0.99, grad_clip=False, n_steps=5, entropy_coef=0.001, value_loss_coef=0.5,
@@ -186,7 +186,7 @@ def bench_ac(args, rank, world, dist):
         if dist is not None:
             dist.destroy_process_group()
         return
-    name = args.env_name.split(":")[-1].replace("-v3", "")
+    name = args.env_name.split(":")[-1].replace("-v3", "").replace("-v2", "")
     roofline = None
     upd = timing.get("ac_update (fwd rows x3, elementwise, bwd rows x2)")
     if upd:
@@ -200,7 +200,7 @@ def bench_ac(args, rank, world, dist):
         "metric": f"env-steps/sec (whole node) {args.algo.upper()} {name}", "value": env_steps / dt, "unit": "env-steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-        "data": "synthetic (Philox-seeded LBF layouts, orthogonal-init weights)",
+        "data": "synthetic (Philox-seeded env layouts, orthogonal-init weights)",
         "config": {"workload": f"{args.algo.upper()} on {name}, {N} batched HIP envs per GPU, actor/critic 2-layer-{H} MLPs, "
                                f"time_limit {T}, one update per rollout", "envs_per_gpu": N, "env_steps_timed": env_steps,
                    "reference_step_counter": int(ref_steps.item()),
@@ -245,8 +245,8 @@ def main():
     N, T, H = args.envs, args.time_limit, args.hidden
     from codebase_amd.parallel import rank_env_seed
 
-    cfg = h.lbf_config(args.env_name, N, T, seed=rank_env_seed(args.seed, rank), cooperative=args.algo != "idqn")
-    P, D, A = cfg.n_agents, 3 * (cfg.n_agents + cfg.n_food), 6
+    cfg = h.env_config(args.env_name, N, T, seed=rank_env_seed(args.seed, rank), cooperative=args.algo != "idqn")
+    P, (D, A) = cfg.n_agents, h.env_dims(cfg)
     if args.cadence == "ratio":
         B = args.update_batch or N
         U = args.updates_per_round or max(1, (32 * N) // B)
@@ -353,7 +353,7 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f32",
-        "data": "synthetic (Philox-seeded LBF layouts, orthogonal-init weights)",
+        "data": "synthetic (Philox-seeded env layouts, orthogonal-init weights)",
         "config": {
             "workload": f"{args.algo.upper()} on {args.env_name.split(':')[-1].replace('-v3', '')}, {N} batched HIP envs per GPU, "
                         f"2-layer-{H} MLP, time_limit {T}",
