@@ -710,8 +710,8 @@ int qmix_launch_reduce(const QmixCtx& qx, int T, int B, const float* loss, hipSt
     return 0;
 }
 
-// (agents, obs dim) pairs with a compiled mixer = the LBF shapes of common.h
+// (agents, obs dim) pairs with a compiled mixer = the LBF and warehouse shapes of common.h
 #define MARL_QMIX_SHAPES(X) \
-    X(2, 12) X(2, 15) X(3, 18) X(3, 24) X(4, 21) X(4, 27) X(8, 39) /* env.observe_id: */ X(2, 14) X(2, 17) X(3, 21) X(3, 27) X(4, 25) X(4, 31) X(8, 47)
+    X(2, 12) X(2, 15) X(3, 18) X(3, 24) X(4, 21) X(4, 27) X(8, 39) /* env.observe_id: */ X(2, 14) X(2, 17) X(3, 21) X(3, 27) X(4, 25) X(4, 31) X(8, 47) /* rware: */ X(2, 71) X(4, 71)
 
 }  // namespace marl

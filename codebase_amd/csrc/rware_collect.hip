@@ -6,8 +6,18 @@
 
 using namespace marl;
 
-// (agents, max grid cells) with compiled fused collectors: the tiny layouts (11 x 10 cells)
+// (agents, max grid cells) with compiled fused collectors in this file: the tiny layouts (11 x 10 cells) with 2 / 4 agents;
+// 8 agents and the small / medium / large layouts (up to 29 x 16 cells = 29 KB of LDS per workgroup) build in rware_collect_big.hip
 #define MARL_RW_COLLECT_SHAPES(X) X(2, 128) X(4, 128)
+
+namespace marl {
+int rware_idqn_collect_big(const RwParams& q, const marlhip_net_shape* s, const float* params, float epsilon, uint32_t round,
+                           const marlhip_replay_shape* rs, const marlhip_replay_buffers* rb, int slot_base, int write_replay, int clear_stale,
+                           int use_proper_termination, float* fin_return, int32_t* fin_length, hipStream_t stream);
+int rware_ac_collect_big(const RwParams& q, const marlhip_net_shape* s, const float* actor_params, uint32_t round, int max_len,
+                         int use_proper_termination, float* batch_obs, int64_t* batch_act, float* batch_rew, uint8_t* batch_done,
+                         float* batch_filled, float* fin_return, int32_t* fin_length, int32_t* t_max, hipStream_t stream);
+}
 
 static int rw_collect_check(const marlhip_rware_config* cfg, const marlhip_net_shape* s, const char* what) {
     if (rw_validate(cfg) != 0) return -1;
@@ -38,9 +48,8 @@ extern "C" int marlhip_rware_idqn_collect(const marlhip_rware_config* cfg, const
     MARL_RW_COLLECT_SHAPES(X)
 #undef X
 #undef MARL_ARGS
-    set_error("rware_idqn_collect: no fused collector for %d agents on a %dx%d grid, hidden %d (MARL_RW_COLLECT_SHAPES)", cfg->n_agents, q.rows,
-              q.cols, s->hidden);
-    return -1;
+    return rware_idqn_collect_big(q, s, params, epsilon, round, rs, rb, slot_base, write_replay, clear_stale, use_proper_termination, fin_return,
+                                  fin_length, (hipStream_t)stream);
 }
 
 extern "C" int marlhip_rware_ac_collect(const marlhip_rware_config* cfg, const marlhip_net_shape* s, const float* actor_params, uint32_t round,
@@ -62,7 +71,6 @@ extern "C" int marlhip_rware_ac_collect(const marlhip_rware_config* cfg, const m
     MARL_RW_COLLECT_SHAPES(X)
 #undef X
 #undef MARL_ARGS
-    set_error("rware_ac_collect: no fused collector for %d agents on a %dx%d grid, hidden %d (MARL_RW_COLLECT_SHAPES)", cfg->n_agents, q.rows,
-              q.cols, s->hidden);
-    return -1;
+    return rware_ac_collect_big(q, s, actor_params, round, max_len, use_proper_termination, batch_obs, batch_act, batch_rew, batch_done,
+                                batch_filled, fin_return, fin_length, t_max, (hipStream_t)stream);
 }

@@ -83,7 +83,8 @@ def test_env_reset_step_bit_exact_vs_oracle(name, over, coop):
     assert delivered > 0
 
 
-@pytest.mark.parametrize("name,H", [(TINY4, 64), (TINY4, 128), ("rware:rware-tiny-2ag-v2", 64)])
+@pytest.mark.parametrize("name,H", [(TINY4, 64), (TINY4, 128), ("rware:rware-tiny-2ag-v2", 64), ("rware:rware-small-4ag-v2", 64),
+                                    ("rware:rware-tiny-8ag-hard-v2", 64), ("rware:rware-large-2ag-easy-v2", 128)])
 def test_fused_ac_collector_matches_oracle(name, H):
     """the fused rollout collector on the warehouse env == the oracle vector env driven by the kernel's own logits
     through the restated inverse-CDF sampler (same check as tests/test_ac_collector.py does for Level-Based Foraging)"""
@@ -190,6 +191,30 @@ def test_dqn_learner_on_warehouse_shapes_vs_torch_port(H, mode):
     np.testing.assert_allclose(grad.cpu().numpy(), gref, rtol=3e-4, atol=3e-5 * max(1.0, np.abs(gref).max()))
 
 
+@pytest.mark.parametrize("P,H", [(4, 64), (2, 128)])
+def test_qmix_on_warehouse_shapes_vs_oracle_port(P, H):
+    from oracle import qmix_port as qp
+    from tests.test_gpu_qmix import assert_grad_close as qclose
+
+    h = hip()
+    T, B, D, A = 7, 35, 71, 5
+    spec = h.NetSpec(P, D, H, A)
+    params = dp.init_params(P, D, H, A, seed=1) + 0.05
+    target = dp.init_params(P, D, H, A, seed=3)
+    mixer, tmixer = qp.mixer_init(P, P * D, seed=11), qp.mixer_init(P, P * D, seed=12)
+    batch = dp.synthetic_batch(P, T, B, D, A, seed=5)
+    batch["rewards"][1:] = batch["rewards"][0]
+    batch["obss"] = batch["obss"] * 0.25
+    pr, mr = params.clone().requires_grad_(True), mixer.clone().requires_grad_(True)
+    ref = qp.compute_loss(pr, target, mr, tmixer, batch, 0.99, True, D, H, A)
+    ref.backward()
+    up = h.QmixUpdater(spec, params.to(DEV), target.to(DEV), mixer.to(DEV), tmixer.to(DEV))
+    loss, grad = up.loss_grad(dev_batch(h, batch))
+    assert abs(loss.cpu().numpy()[0] - ref.item()) <= 3e-5 * abs(ref.item())
+    qclose(grad.cpu().numpy(), pr.grad.numpy(), 3e-4)
+    qclose(up.mixer_grad.cpu().numpy(), mr.grad.numpy(), 3e-4)
+
+
 @pytest.mark.parametrize("H", [64, 128])
 def test_a2c_and_ppo_on_warehouse_shapes_vs_oracle_port(H):
     h = hip()
@@ -224,11 +249,11 @@ def test_a2c_and_ppo_on_warehouse_shapes_vs_oracle_port(H):
     np.testing.assert_allclose(up.block[:actor.numel()].cpu().numpy(), lr.actor().detach().reshape(-1).numpy(), rtol=0, atol=5e-6)
 
 
-def test_ia2c_and_idqn_on_the_warehouse_end_to_end(tmp_path, monkeypatch):
+def test_ia2c_idqn_and_qmix_on_the_warehouse_end_to_end(tmp_path, monkeypatch):
     """config 4's algorithm / env pair through the drop-in surface: run.py +algorithm=ia2c env.name=rware:... (and IDQN)"""
     from codebase_amd import run
 
-    for algo, extra in (("ia2c", []), ("idqn", ["algorithm.model.layers=[64,64]"])):
+    for algo, extra in (("ia2c", []), ("idqn", ["algorithm.model.layers=[64,64]"]), ("qmix", ["algorithm.model.layers=[64,64]"])):
         monkeypatch.setenv("MARLHIP_RUN_DIR", str(tmp_path / algo))
         df = run.main([f"+algorithm={algo}", f"env.name={TINY4}", "env.time_limit=50", "env.parallel_envs=128", "seed=1",
                        "algorithm.total_steps=60000", "algorithm.eval_interval=20000"] + extra)
