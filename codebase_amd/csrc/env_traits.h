@@ -42,6 +42,7 @@ struct RwEnvT {
     using State = RwState<P_>;
     struct Ctx {
         RwGrid grid;
+        RwRequested<P_> rq;  // the queue as a bit set, rebuilt whenever the state changes (reset / step)
         // env (wave, j) of the workgroup owns byte column wave*16+j of every cell row; the 4 lanes that carry one env
         // redundantly read and write the same bytes with the same values
         __device__ __forceinline__ void init(const Params&, uint8_t* lds, int wave, int j) { grid.g = lds + wave * 16 + j; grid.stride = 64; }
@@ -51,28 +52,27 @@ struct RwEnvT {
         DrawStream rng;
         rng.init(q.seed, env, episode, STREAM_RESET);
         rw_reset(q, s, c.grid, rng);
+        c.rq.build(q, s);
     }
     static __device__ __forceinline__ void step(const Params& q, State& s, Ctx& c, uint32_t env, uint32_t episode, const int* act, double* raw,
                                                 bool& done) {
         DrawStream req;
         req.init(q.seed, env, episode, STREAM_REQUEST);
         rw_step(q, s, c.grid, act, raw, done, req);
+        c.rq.build(q, s);
     }
     static __device__ __forceinline__ int elapsed(const State& s) { return s.steps; }
     template <int KS1, bool OID>
     static __device__ __forceinline__ void observe(const Params& q, const State& s, Ctx& c, int p, int g, float (&x)[KS1]) {
-        int code[9];
-        rw_window(q, s, c.grid, p, code);
+        const uint64_t word = rw_window_word(q, s, c.grid, c.rq, p);
         constexpr int IDW = OID ? P_ : 0, D = D0 + IDW;
 #pragma unroll
         for (int ks = 0; ks < KS1; ++ks) {
-            float e[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int i = 4 * ks + k;  // compile-time element index
-                e[k] = i < IDW ? (i == p ? 1.f : 0.f) : (i < D ? rw_obs_elem(q, s, p, code, i - IDW < 0 ? 0 : i - IDW) : 0.f);
-            }
-            x[ks] = g == 0 ? e[0] : (g == 1 ? e[1] : (g == 2 ? e[2] : e[3]));
+            const int i = 4 * ks + g;  // the lane's own element of this k-step
+            float v = 0.f;
+            if (i < IDW) v = i == p ? 1.f : 0.f;
+            else if (i < D) v = rw_obs_elem_word(q, s, p, word, i - IDW);
+            x[ks] = v;
         }
     }
 };

@@ -187,3 +187,31 @@ extern "C" int host_rw_step(const HostRwCfg* c, uint8_t* state, const uint32_t* 
 #undef X
     return -1;
 }
+
+// the collectors' packed-window observation route against the per-cell one
+extern "C" int host_rw_obs_word_check(const HostRwCfg* c, const uint8_t* state) {
+    const RwParams q = rw_conv(c);
+    int bad = 0;
+#define X(p)                                                                                                     \
+    if (c->n_agents == p) {                                                                                      \
+        const int stride = rw_state_stride(p, q.rows, q.cols), cells = q.rows * q.cols;                          \
+        for (int n = 0; n < q.n_envs; ++n) {                                                                     \
+            RwState<p> s;                                                                                        \
+            uint8_t* rec = const_cast<uint8_t*>(state) + (size_t)n * stride;                                     \
+            const RwGrid grid{rec, 1};                                                                           \
+            rw_load(rec, cells, s);                                                                              \
+            RwRequested<p> rq;                                                                                   \
+            rq.build(q, s);                                                                                      \
+            for (int a = 0; a < p; ++a) {                                                                        \
+                int code[9];                                                                                     \
+                rw_window(q, s, grid, a, code);                                                                  \
+                const uint64_t w = rw_window_word(q, s, grid, rq, a);                                            \
+                for (int d = 0; d < RW_OBS_DIM; ++d) bad += rw_obs_elem(q, s, a, code, d) != rw_obs_elem_word(q, s, a, w, d); \
+            }                                                                                                    \
+        }                                                                                                        \
+        return bad;                                                                                              \
+    }
+    X(2) X(4) X(8)
+#undef X
+    return -1;
+}

@@ -223,6 +223,7 @@ def test_core_matches_oracle(name, over, coop):
                 np.testing.assert_array_equal(np.array(r, np.float32), rew[:, n])
                 assert bool(done[n]) == d and bool(trunc[n]) == tr
                 delivered += sum(r) > 0
+            assert lib.host_rw_obs_word_check(ctypes.byref(hc), ptr(state)) == 0  # the collectors' packed-window route
             if done.any() or trunc.any():
                 break
     assert delivered > 0
