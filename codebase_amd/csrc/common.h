@@ -95,7 +95,7 @@ inline int rw_validate(const marlhip_rware_config* c) {
     MARL_REQUIRE(ok, "no rware kernel for %d agents (add it to MARL_RW_SHAPES in csrc/common.h and rebuild)", c->n_agents);
     MARL_REQUIRE(c->n_envs > 0, "n_envs must be > 0");
     MARL_REQUIRE(c->shelf_columns >= 1 && c->shelf_columns % 2 == 1, "rware: only an odd number of shelf columns is supported");
-    MARL_REQUIRE(c->shelf_rows >= 1 && c->column_height >= 1, "rware: shelf_rows / column_height");
+    MARL_REQUIRE(c->shelf_rows >= 1 && c->shelf_rows <= 5 && c->column_height >= 1, "rware: shelf_rows (1..5) / column_height");
     const RwParams q = to_rw_params(c);
     MARL_REQUIRE(q.rows <= 255 && q.cols <= 255 && q.n_shelves <= 255, "rware: grid %dx%d with %d shelves does not fit the byte state", q.rows,
                  q.cols, q.n_shelves);

@@ -51,7 +51,9 @@ struct RwGrid {
 };
 
 MARL_HD bool rw_is_highway(const RwParams& q, int x, int y) {
-    return x % 3 == 0 || y % (q.column_height + 1) == 0 || y == q.rows - 1 ||
+    const int m = q.column_height + 1;  // y % m == 0 for the at most 6 multiples a validated layout has (rows = m * shelf_rows + 2, shelf_rows <= 5)
+    const bool cross = y == 0 || y == m || y == 2 * m || y == 3 * m || y == 4 * m || y == 5 * m;
+    return x % 3 == 0 || cross || y == q.rows - 1 ||
            (y > q.rows - (q.column_height + 3) && (x == q.cols / 2 - 1 || x == q.cols / 2));
 }
 
@@ -172,23 +174,19 @@ MARL_HD uint32_t rw_resolve(uint64_t nxt, const int* tcell) {
     uint32_t committed = 0, in_tree = 0;
 #pragma unroll
     for (int i = 0; i < P; ++i) {
-        // on a cycle iff the walk returns to i; the length decides (a 2-cycle is a swap: nobody moves)
+        // follow the chain from i: back at i = on a cycle, whose length decides (a 2-cycle is a swap: nobody moves);
+        // at a free cell = i sits in an in-tree; neither = i feeds a cycle it is not on (and cannot move)
         int j = rw_nib(nxt, i), n = 1;
 #pragma unroll
         for (int it = 0; it < P; ++it) {
             if (j != 0xF && j != i) { j = rw_nib(nxt, j); ++n; }
         }
         if (j == i && n != 2) committed |= 1u << i;
-        // drains into a free cell iff the walk from i reaches 0xF
-        int k = i;
-#pragma unroll
-        for (int it = 0; it < P; ++it)
-            if (k != 0xF) k = rw_nib(nxt, k);
-        if (k == 0xF) in_tree |= 1u << i;
+        if (j == 0xF) in_tree |= 1u << i;
     }
     uint64_t height = 0;  // longest chain of feeders behind each agent
 #pragma unroll
-    for (int pass = 0; pass < P; ++pass) {
+    for (int pass = 0; pass < P - 1; ++pass) {
 #pragma unroll
         for (int i = 0; i < P; ++i) {
             const int t = rw_nib(nxt, i);
@@ -198,30 +196,31 @@ MARL_HD uint32_t rw_resolve(uint64_t nxt, const int* tcell) {
             }
         }
     }
+    // dag_longest_path walked back from the free cell = at every cell the feeder with the longest chain behind it wins
+    // (lowest index on ties), and a winner moves iff its target is free or the agent on it moves
+    uint32_t win = 0;
 #pragma unroll
     for (int i = 0; i < P; ++i) {
-        if (rw_nib(nxt, i) != 0xF) continue;
-        bool first = true;  // each free cell once: at its lowest-index direct feeder
+        bool w = ((in_tree >> i) & 1u) != 0;
+        const int hi = rw_nib(height, i);
 #pragma unroll
-        for (int o = 0; o < P; ++o) first = first && !(o < i && rw_nib(nxt, o) == 0xF && tcell[o] == tcell[i]);
-        if (!first) continue;
-        // walk back from the free cell; at every merge the feeder with the longest chain, lowest index on ties
-        int cur = -1;
-#pragma unroll
-        for (int depth = 0; depth < P; ++depth) {
-            int best = -1, bh = -1;
-#pragma unroll
-            for (int o = 0; o < P; ++o) {
-                const bool feeds = cur < 0 ? (rw_nib(nxt, o) == 0xF && tcell[o] == tcell[i]) : (rw_nib(nxt, o) == cur && o != cur);
-                const int h = rw_nib(height, o);
-                if (feeds && ((in_tree >> o) & 1u) && h > bh) { best = o; bh = h; }
+        for (int o = 0; o < P; ++o) {
+            if (o != i) {
+                const int ho = rw_nib(height, o);
+                w = w && !(tcell[o] == tcell[i] && ((in_tree >> o) & 1u) && (ho > hi || (ho == hi && o < i)));
             }
-            if (best < 0) break;
-            committed |= 1u << best;
-            cur = best;
         }
+        win |= (w ? 1u : 0u) << i;
     }
-    return committed;
+    uint32_t mv = 0;
+#pragma unroll
+    for (int i = 0; i < P; ++i) mv |= (((win >> i) & 1u) && rw_nib(nxt, i) == 0xF) ? 1u << i : 0u;
+#pragma unroll
+    for (int pass = 0; pass < P - 1; ++pass) {
+#pragma unroll
+        for (int i = 0; i < P; ++i) mv |= (((win >> i) & 1u) && ((mv >> rw_nib(nxt, i)) & 1u)) ? 1u << i : 0u;
+    }
+    return committed | mv;
 }
 
 // Warehouse.step.  rew[] are the env's own per-agent rewards (fp64, as upstream's np.zeros accumulates them); `done` =

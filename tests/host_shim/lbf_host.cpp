@@ -215,3 +215,20 @@ extern "C" int host_rw_obs_word_check(const HostRwCfg* c, const uint8_t* state) 
 #undef X
     return -1;
 }
+
+// the movement-conflict rule alone: edges as (start cell, target cell) per agent -> committed-agent bit mask
+extern "C" int host_rw_resolve(int P, const int32_t* start, const int32_t* target) {
+    uint64_t nxt = 0;
+    int tc[8];
+    for (int p = 0; p < P; ++p) {
+        int o = 0xF;
+        for (int k = 0; k < P; ++k)
+            if (start[k] == target[p]) o = k;
+        nxt = rw_set_nib(nxt, p, o);
+        tc[p] = target[p];
+    }
+    if (P == 2) return (int)rw_resolve<2>(nxt, tc);
+    if (P == 4) return (int)rw_resolve<4>(nxt, tc);
+    if (P == 8) return (int)rw_resolve<8>(nxt, tc);
+    return -1;
+}

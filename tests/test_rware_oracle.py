@@ -65,6 +65,9 @@ def test_conflict_rule_matches_networkx():
             a.req_action = rw.FORWARD if rng.random() < 0.8 else rng.randrange(5)
         edges = e._edges()
         nxc, rule = frozenset(e.resolve_networkx(edges)), frozenset(e.resolve_rule(edges))
+        st_, tg_ = (np.array([c[0] + 10 * c[1] for c in col], np.int32) for col in zip(*edges))
+        mask = host_shim().host_rw_resolve(4, ptr(st_), ptr(tg_))  # the C++ rule the kernels inline
+        assert {i + 1 for i in range(4) if mask >> i & 1} == set(rule), (edges, mask, rule)
         outs = _relabellings(edges)
         assert nxc in outs, (edges, nxc, outs)
         if len(outs) == 1:
@@ -73,6 +76,20 @@ def test_conflict_rule_matches_networkx():
         else:
             ties += 1
     assert agree > 400 and ties > 10
+
+
+def test_conflict_rule_cpp_equals_python_rule_dense_8_agents():
+    lib = host_shim()
+    rng = random.Random(5)
+    for trial in range(3000):
+        cells = rng.sample([(i, j) for i in range(4) for j in range(3)], 8)  # 8 agents on 12 cells
+        edges = []
+        for (x, y) in cells:
+            dx, dy = rng.choice([(0, 0), (1, 0), (-1, 0), (0, 1), (0, -1), (1, 0), (0, 1)])
+            edges.append(((x, y), (min(max(x + dx, 0), 3), min(max(y + dy, 0), 2))))
+        st_, tg_ = (np.array([c[0] + 10 * c[1] for c in col], np.int32) for col in zip(*edges))
+        mask = lib.host_rw_resolve(8, ptr(st_), ptr(tg_))
+        assert {i + 1 for i in range(8) if mask >> i & 1} == rw.Warehouse.resolve_rule(edges), edges
 
 
 def _state(e, agents, queue=(1, 2, 3, 4), grid=None, steps=0):
