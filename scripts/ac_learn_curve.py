@@ -1,5 +1,5 @@
 """Learning curve of IA2C / IPPO on the HIP path: mean episode return vs env steps (LBF 8x8-2p-3f).
-    python scripts/ac_learn_curve.py [ia2c|ippo] [total_steps] [envs] [hidden]"""
+    python scripts/ac_learn_curve.py [ia2c|ippo] [total_steps] [envs] [hidden] [env name] [time limit]"""
 import os
 import sys
 import tempfile
@@ -9,10 +9,12 @@ algo = sys.argv[1] if len(sys.argv) > 1 else "ia2c"
 steps = int(float(sys.argv[2])) if len(sys.argv) > 2 else 20_000_000
 envs = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
 hidden = int(sys.argv[4]) if len(sys.argv) > 4 else 64
+name = sys.argv[5] if len(sys.argv) > 5 else "lbforaging:Foraging-8x8-2p-3f-v3"
+limit = int(sys.argv[6]) if len(sys.argv) > 6 else 25
 os.environ.setdefault("MARLHIP_RUN_DIR", tempfile.mkdtemp())
 from codebase_amd import run  # noqa: E402
 
-df = run.main([f"+algorithm={algo}", "env.name=lbforaging:Foraging-8x8-2p-3f-v3", "env.time_limit=25", f"env.parallel_envs={envs}",
+df = run.main([f"+algorithm={algo}", f"env.name={name}", f"env.time_limit={limit}", f"env.parallel_envs={envs}",
                f"algorithm.model.actor.layers=[{hidden},{hidden}]", f"algorithm.model.critic.layers=[{hidden},{hidden}]", "seed=0",
                f"algorithm.total_steps={steps}", f"algorithm.eval_interval={steps // 20}", "algorithm.entropy_coef=0.01"])
 print(df[[c for c in ("environment_steps", "environment_timesteps", "mean_episode_returns", "loss", "entropy") if c in df.columns]].to_string())
