@@ -52,7 +52,9 @@ def test_cooperative_wrapper_and_unsupported_options():
     with pytest.raises(NotImplementedError):
         make_env(seed=1, name=NAME, time_limit=25, wrappers=["FlattenObservation"])
     with pytest.raises(NotImplementedError):
-        make_env(seed=1, name="rware:rware-tiny-4ag-v2", time_limit=500)
+        make_env(seed=1, name="smaclite/2s3z-v0", time_limit=150)
+    rw = make_env(seed=1, name="rware:rware-tiny-4ag-v2", time_limit=500)  # the warehouse has a HIP env
+    assert rw.n_agents == 4 and rw.observation_space[0].shape == (71,) and rw.action_space[0].n == 5
 
 
 def reference_style_net(sd, i, D, H, A):
