@@ -15,9 +15,10 @@ unchanged, not for speed.
 (marlbase/ac/train.py:24-119).
 
 The wrapper stack of utils/envs.py:93-109 is folded into the kernels: TimeLimit -> `truncated`,
-RecordEpisodeStatistics -> info on episode end, CooperativeReward -> cfg.cooperative.
-ObserveID / StandardiseReward / FlattenObservation / video are outside this round's hot path and
-raise NotImplementedError rather than silently doing something else.
+RecordEpisodeStatistics -> info on episode end, CooperativeReward -> cfg.cooperative, StandardiseReward ->
+cfg.reward_stats (one streaming record per env), ObserveID -> cfg.observe_id.  FlattenObservation (the envs here
+already return flat vectors), other wrapper names and video raise NotImplementedError rather than silently doing
+something else.  `rware:` ids build the same two classes over the warehouse kernels (5 actions, 71-float observations).
 """
 import random
 from time import perf_counter
