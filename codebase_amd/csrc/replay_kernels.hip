@@ -288,10 +288,13 @@ extern "C" int marlhip_replay_sample(const marlhip_replay_shape* rs, const marlh
         idx = idx_out;
     }
     const int P = rs->n_agents, D = rs->obs_dim, T = rs->max_len;
-    // episodes per workgroup: as many as fit 52 KB of LDS (3 workgroups per CU), at most 16
+    // episodes per workgroup: as many as fit 52 KB of LDS, at most 8 (more, smaller workgroups per CU hide the gather latency better
+    // than longer output runs help)
     const int ep_bytes = P * (T + 1) * D * (int)sizeof(float);
-    int EB = (52 * 1024) / ep_bytes;  // 3 x 52 KB <= 160 KB
-    if (EB > 16) EB = 16;
+    static const int lds_kb = getenv("MARLHIP_SAMPLE_LDS_KB") ? atoi(getenv("MARLHIP_SAMPLE_LDS_KB")) : 52;  // 3 x 52 KB <= 160 KB
+    static const int eb_max = getenv("MARLHIP_SAMPLE_EB_MAX") ? atoi(getenv("MARLHIP_SAMPLE_EB_MAX")) : 8;  // measured at B = 65536 from a 4.5 GB replay: 8 -> 3.0 TB/s, 16 -> 2.8, 4 -> 2.5
+    int EB = (lds_kb * 1024) / ep_bytes;
+    if (EB > eb_max) EB = eb_max;
     if (EB >= 4) EB &= ~3;  // whole float4 runs in the output (16-byte stores)
     if (getenv("MARLHIP_SAMPLE_SIMPLE") != nullptr || EB < 1) {  // one-thread-per-element gather (reference variant)
         const int64_t total = (int64_t)P * (T + 1) * batch * D + (int64_t)P * T * batch + (int64_t)(2 * T + 1) * batch;
@@ -306,6 +309,11 @@ extern "C" int marlhip_replay_sample(const marlhip_replay_shape* rs, const marlh
                       getenv("MARLHIP_SAMPLE_SCALAR") == nullptr;
     timing_begin(TIMER_SAMPLE, (hipStream_t)stream);
     if (vec4) {  // one kernel: observations + the small records
+        static size_t attr = 0;
+        if ((size_t)EB * ep_bytes > attr) {
+            attr = (size_t)EB * ep_bytes;
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&replay_sample_obs4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)attr);
+        }
         hipLaunchKernelGGL(replay_sample_obs4_kernel, dim3((batch + EB - 1) / EB), dim3(256), (size_t)EB * ep_bytes,
                            (hipStream_t)stream, *rs, *rb, idx, batch, EB, obss, actions, rewards, dones, filled);
         timing_end(TIMER_SAMPLE, (hipStream_t)stream);
