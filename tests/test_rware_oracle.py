@@ -1,7 +1,7 @@
 """Multi-robot warehouse (config 4's env; parity unpinned: the rware package is absent, see oracle/rware.py).
 CPU: (1) the movement-conflict rule the kernel implements against upstream's networkx resolution run on the real
 networkx - equal on every tie-free case, and on ties the networkx outcome is the rule's under some relabelling;
-(2) hand-derived known-answer transitions; (3) the env core the HIP kernels inline (csrc/rware_core.h, built with
+(2) 22 hand-derived known-answer transitions, each run through the oracle AND the C++ core; (3) the env core the HIP kernels inline (csrc/rware_core.h, built with
 g++) against the oracle: reset (same Philox stream) and step (same state, same joint action) agree bit for bit -
 state records, observations, rewards, done / truncated."""
 import ctypes
@@ -104,72 +104,6 @@ def _pos(e):
     return [(a.x, a.y, a.dir, a.carrying_shelf.id if a.carrying_shelf else 0) for a in e.agents]
 
 
-def test_known_answer_transitions():
-    # hand-derived from the rules in oracle/rware.py's header; agents (x, y, dir, carried shelf, has_delivered)
-    far = [(9, 0, rw.UP, 0, 0), (9, 2, rw.UP, 0, 0)]  # two bystanders facing the wall / a free cell
-    # 1. two agents into the same free cell: the lower index gets it
-    e = _state(make(), [(3, 0, rw.DRIGHT, 0, 0), (5, 0, rw.DLEFT, 0, 0)] + far)
-    e.step([1, 1, 0, 0])
-    assert _pos(e)[:2] == [(4, 0, rw.DRIGHT, 0), (5, 0, rw.DLEFT, 0)]
-    # 2. a swap (2-cycle) moves nobody
-    e = _state(make(), [(3, 0, rw.DRIGHT, 0, 0), (4, 0, rw.DLEFT, 0, 0)] + far)
-    e.step([1, 1, 0, 0])
-    assert _pos(e)[:2] == [(3, 0, rw.DRIGHT, 0), (4, 0, rw.DLEFT, 0)]
-    # 3. a train: the follower moves into the cell its leader vacates
-    e = _state(make(), [(3, 0, rw.DRIGHT, 0, 0), (4, 0, rw.DRIGHT, 0, 0)] + far)
-    e.step([1, 1, 0, 0])
-    assert _pos(e)[:2] == [(4, 0, rw.DRIGHT, 0), (5, 0, rw.DRIGHT, 0)]
-    # 4. the longer chain wins a merge: agents 1->2->free cell (4,0) against agent 0 alone
-    e = _state(make(), [(4, 1, rw.UP, 0, 0), (2, 0, rw.DRIGHT, 0, 0), (3, 0, rw.DRIGHT, 0, 0), (9, 5, rw.UP, 0, 0)])
-    e.step([1, 1, 1, 0])
-    assert _pos(e)[:3] == [(4, 1, rw.UP, 0), (3, 0, rw.DRIGHT, 0), (4, 0, rw.DRIGHT, 0)]
-    # 5. a 4-cycle rotates
-    e = _state(make(), [(3, 0, rw.DRIGHT, 0, 0), (4, 0, rw.DOWN, 0, 0), (4, 1, rw.DLEFT, 0, 0), (3, 1, rw.UP, 0, 0)])
-    e.step([1, 1, 1, 1])
-    assert [p[:2] for p in _pos(e)] == [(4, 0), (4, 1), (3, 1), (3, 0)]
-    # 6. FORWARD into the wall stays (and still blocks the agent behind it)
-    e = _state(make(), [(0, 0, rw.DLEFT, 0, 0), (1, 0, rw.DLEFT, 0, 0)] + far)
-    e.step([1, 1, 0, 0])
-    assert _pos(e)[:2] == [(0, 0, rw.DLEFT, 0), (1, 0, rw.DLEFT, 0)]
-    # 7. turns: LEFT from UP faces LEFT, RIGHT from UP faces RIGHT, RIGHT from LEFT faces UP
-    e = _state(make(), [(3, 0, rw.UP, 0, 0), (5, 0, rw.UP, 0, 0), (9, 0, rw.DLEFT, 0, 0), (9, 2, rw.DOWN, 0, 0)])
-    e.step([2, 3, 3, 2])
-    assert [p[2] for p in _pos(e)] == [rw.DLEFT, rw.DRIGHT, rw.UP, rw.DRIGHT]
-    # 8. load under a shelf, carry it out, cannot unload on a highway, unload in the rack
-    e = _state(make(), [(1, 1, rw.UP, 0, 0), (5, 0, rw.UP, 0, 0)] + far)  # shelf 1 stands on (1,1)
-    e.step([4, 0, 0, 0])
-    assert _pos(e)[0] == (1, 1, rw.UP, 1)
-    e.step([1, 0, 0, 0])  # up to (1,0): highway row
-    assert _pos(e)[0] == (1, 0, rw.UP, 1) and e.grid[1, 0, 1] == 1 and e.grid[1, 1, 1] == 0
-    e.step([4, 0, 0, 0])
-    assert _pos(e)[0][3] == 1  # still carrying
-    # 9. a loaded agent cannot drive into a standing shelf; an unloaded one can
-    e = _state(make(), [(1, 1, rw.DRIGHT, 1, 0), (7, 1, rw.DRIGHT, 0, 0)] + far)  # shelf 2 stands on (2,1), shelf 4 on (8,1)
-    e.step([1, 1, 0, 0])
-    assert _pos(e)[:2] == [(1, 1, rw.DRIGHT, 1), (8, 1, rw.DRIGHT, 0)]
-    # 10. delivery: a requested shelf carried onto a goal cell pays its carrier and is replaced in the queue
-    g = make()
-    g.reset(DrawStream(0, 0, 0))
-    grid = g.get_state()["grid"].copy()
-    grid[1, 1] = 0
-    grid[9, 4] = 1  # shelf 1 is carried by agent 0 standing on (4, 9), one step above the goal (4, 10)
-    e = _state(make(), [(4, 9, rw.DOWN, 1, 0), (5, 0, rw.UP, 0, 0)] + far, queue=(1, 2, 3, 4), grid=grid, steps=7)
-    obs, rew, done, trunc, _ = e.step([1, 0, 0, 0])
-    assert rew == [1.0, 0.0, 0.0, 0.0] and not done
-    k = DrawStream(0, 0, 0, rw.STREAM_REQUEST)
-    k.idx = 8 * 7
-    expect = [s for s in range(1, 33) if s not in (1, 2, 3, 4)][k.integers(0, 28)]
-    assert [s.id for s in e.request_queue] == [expect, 2, 3, 4] and e._cur_inactive_steps == 0 and e._cur_steps == 8
-    assert obs[0][:8].tolist() == [4.0, 10.0, 1.0, 0.0, 1.0, 0.0, 0.0, 1.0]
-    # the centre cell of agent 0's window: itself (facing DOWN) on its shelf, which is no longer requested
-    assert obs[0][8 + 4 * 7:8 + 5 * 7].tolist() == [1.0, 0.0, 1.0, 0.0, 0.0, 1.0, 0.0]
-    # cells below the grid read as empty: no agent -> direction one-hot(0)
-    assert obs[0][8 + 7 * 7:8 + 8 * 7].tolist() == [0.0, 1.0, 0.0, 0.0, 0.0, 0.0, 0.0]
-    # 11. episode end at max_steps
-    e = _state(make(max_steps=9), [(3, 0, rw.UP, 0, 0), (5, 0, rw.UP, 0, 0)] + far, steps=8)
-    assert e.step([0, 0, 0, 0])[2] is True
-
-
 class RwCfg(ctypes.Structure):
     _fields_ = [(k, ctypes.c_int32) for k in ("n_envs", "n_agents", "rows", "cols", "column_height", "n_shelves", "queue_size",
                                                "max_steps", "max_inactivity_steps", "time_limit", "reward_type", "cooperative")] + [
@@ -183,6 +117,167 @@ def pack_state(e, P):
     tail = np.array([st["steps"] & 255, st["steps"] >> 8, st["inactive"] & 255, st["inactive"] >> 8], np.uint8)
     rec = np.concatenate([st["grid"].reshape(-1), st["agents"].reshape(-1), q, tail])
     return np.concatenate([rec, np.zeros((-len(rec)) % 4, np.uint8)])
+
+
+def both(e, acts):
+    """e.step(acts) on the oracle AND the same transition through the C++ core the kernels inline (same state, same request
+    stream): records, observations, rewards and done must agree bit for bit"""
+    lib = host_shim()
+    P = e.n_agents
+    R, C = e.grid_size
+    hc = RwCfg(n_envs=1, n_agents=P, rows=R, cols=C, column_height=e.column_height, n_shelves=len(e.shelfs), queue_size=e.request_queue_size,
+               max_steps=e.max_steps or 0, max_inactivity_steps=e.max_inactivity_steps or 0, time_limit=0, reward_type=e.reward_type,
+               cooperative=0, seed=0)
+    state = pack_state(e, P)[None].copy()
+    out = e.step(acts)
+    obs, rew = np.zeros((P, 1, 71), np.float32), np.zeros((P, 1), np.float32)
+    done, trunc, epi = np.zeros(1, np.uint8), np.zeros(1, np.uint8), np.zeros(1, np.uint32)
+    a = np.array(acts, np.int32).reshape(P, 1)
+    assert lib.host_rw_step(ctypes.byref(hc), ptr(state), ptr(epi), ptr(a), ptr(obs), ptr(rew), ptr(done), ptr(trunc)) == 0
+    np.testing.assert_array_equal(state[0], pack_state(e, P))
+    for p in range(P):
+        np.testing.assert_array_equal(obs[p, 0], out[0][p])
+    np.testing.assert_array_equal(rew[:, 0], np.array(out[1], np.float32))
+    assert bool(done[0]) == out[2]
+    return out
+
+
+def test_known_answer_transitions():
+    # hand-derived from the rules in oracle/rware.py's header; agents (x, y, dir, carried shelf, has_delivered)
+    far = [(9, 0, rw.UP, 0, 0), (9, 2, rw.UP, 0, 0)]  # two bystanders facing the wall / a free cell
+    # 1. two agents into the same free cell: the lower index gets it
+    e = _state(make(), [(3, 0, rw.DRIGHT, 0, 0), (5, 0, rw.DLEFT, 0, 0)] + far)
+    both(e, [1, 1, 0, 0])
+    assert _pos(e)[:2] == [(4, 0, rw.DRIGHT, 0), (5, 0, rw.DLEFT, 0)]
+    # 2. a swap (2-cycle) moves nobody
+    e = _state(make(), [(3, 0, rw.DRIGHT, 0, 0), (4, 0, rw.DLEFT, 0, 0)] + far)
+    both(e, [1, 1, 0, 0])
+    assert _pos(e)[:2] == [(3, 0, rw.DRIGHT, 0), (4, 0, rw.DLEFT, 0)]
+    # 3. a train: the follower moves into the cell its leader vacates
+    e = _state(make(), [(3, 0, rw.DRIGHT, 0, 0), (4, 0, rw.DRIGHT, 0, 0)] + far)
+    both(e, [1, 1, 0, 0])
+    assert _pos(e)[:2] == [(4, 0, rw.DRIGHT, 0), (5, 0, rw.DRIGHT, 0)]
+    # 4. the longer chain wins a merge: agents 1->2->free cell (4,0) against agent 0 alone
+    e = _state(make(), [(4, 1, rw.UP, 0, 0), (2, 0, rw.DRIGHT, 0, 0), (3, 0, rw.DRIGHT, 0, 0), (9, 5, rw.UP, 0, 0)])
+    both(e, [1, 1, 1, 0])
+    assert _pos(e)[:3] == [(4, 1, rw.UP, 0), (3, 0, rw.DRIGHT, 0), (4, 0, rw.DRIGHT, 0)]
+    # 5. a 4-cycle rotates
+    e = _state(make(), [(3, 0, rw.DRIGHT, 0, 0), (4, 0, rw.DOWN, 0, 0), (4, 1, rw.DLEFT, 0, 0), (3, 1, rw.UP, 0, 0)])
+    both(e, [1, 1, 1, 1])
+    assert [p[:2] for p in _pos(e)] == [(4, 0), (4, 1), (3, 1), (3, 0)]
+    # 6. FORWARD into the wall stays (and still blocks the agent behind it)
+    e = _state(make(), [(0, 0, rw.DLEFT, 0, 0), (1, 0, rw.DLEFT, 0, 0)] + far)
+    both(e, [1, 1, 0, 0])
+    assert _pos(e)[:2] == [(0, 0, rw.DLEFT, 0), (1, 0, rw.DLEFT, 0)]
+    # 7. turns: LEFT from UP faces LEFT, RIGHT from UP faces RIGHT, RIGHT from LEFT faces UP
+    e = _state(make(), [(3, 0, rw.UP, 0, 0), (5, 0, rw.UP, 0, 0), (9, 0, rw.DLEFT, 0, 0), (9, 2, rw.DOWN, 0, 0)])
+    both(e, [2, 3, 3, 2])
+    assert [p[2] for p in _pos(e)] == [rw.DLEFT, rw.DRIGHT, rw.UP, rw.DRIGHT]
+    # 8. load under a shelf, carry it out, cannot unload on a highway, unload in the rack
+    e = _state(make(), [(1, 1, rw.UP, 0, 0), (5, 0, rw.UP, 0, 0)] + far)  # shelf 1 stands on (1,1)
+    both(e, [4, 0, 0, 0])
+    assert _pos(e)[0] == (1, 1, rw.UP, 1)
+    both(e, [1, 0, 0, 0])  # up to (1,0): highway row
+    assert _pos(e)[0] == (1, 0, rw.UP, 1) and e.grid[1, 0, 1] == 1 and e.grid[1, 1, 1] == 0
+    both(e, [4, 0, 0, 0])
+    assert _pos(e)[0][3] == 1  # still carrying
+    # 9. a loaded agent cannot drive into a standing shelf; an unloaded one can
+    e = _state(make(), [(1, 1, rw.DRIGHT, 1, 0), (7, 1, rw.DRIGHT, 0, 0)] + far)  # shelf 2 stands on (2,1), shelf 4 on (8,1)
+    both(e, [1, 1, 0, 0])
+    assert _pos(e)[:2] == [(1, 1, rw.DRIGHT, 1), (8, 1, rw.DRIGHT, 0)]
+    # 10. delivery: a requested shelf carried onto a goal cell pays its carrier and is replaced in the queue
+    g = make()
+    g.reset(DrawStream(0, 0, 0))
+    grid = g.get_state()["grid"].copy()
+    grid[1, 1] = 0
+    grid[9, 4] = 1  # shelf 1 is carried by agent 0 standing on (4, 9), one step above the goal (4, 10)
+    e = _state(make(), [(4, 9, rw.DOWN, 1, 0), (5, 0, rw.UP, 0, 0)] + far, queue=(1, 2, 3, 4), grid=grid, steps=7)
+    obs, rew, done, trunc, _ = both(e, [1, 0, 0, 0])
+    assert rew == [1.0, 0.0, 0.0, 0.0] and not done
+    k = DrawStream(0, 0, 0, rw.STREAM_REQUEST)
+    k.idx = 8 * 7
+    expect = [s for s in range(1, 33) if s not in (1, 2, 3, 4)][k.integers(0, 28)]
+    assert [s.id for s in e.request_queue] == [expect, 2, 3, 4] and e._cur_inactive_steps == 0 and e._cur_steps == 8
+    assert obs[0][:8].tolist() == [4.0, 10.0, 1.0, 0.0, 1.0, 0.0, 0.0, 1.0]
+    # the centre cell of agent 0's window: itself (facing DOWN) on its shelf, which is no longer requested
+    assert obs[0][8 + 4 * 7:8 + 5 * 7].tolist() == [1.0, 0.0, 1.0, 0.0, 0.0, 1.0, 0.0]
+    # cells below the grid read as empty: no agent -> direction one-hot(0)
+    assert obs[0][8 + 7 * 7:8 + 8 * 7].tolist() == [0.0, 1.0, 0.0, 0.0, 0.0, 0.0, 0.0]
+    # 11. episode end at max_steps
+    e = _state(make(max_steps=9), [(3, 0, rw.UP, 0, 0), (5, 0, rw.UP, 0, 0)] + far, steps=8)
+    assert both(e, [0, 0, 0, 0])[2] is True
+
+
+def test_known_answer_transitions_rewards_queue_and_carriers():
+    far = [(9, 0, rw.UP, 0, 0), (9, 2, rw.UP, 0, 0)]
+    g = make()
+    g.reset(DrawStream(0, 0, 0))
+    base = g.get_state()["grid"]
+
+    def grid_with(moves):  # {(x, y): shelf id or 0}
+        gr = base.copy()
+        for (x, y), v in moves.items():
+            gr[y, x] = v
+        return gr
+
+    # 12. unloading inside the rack puts the shelf down where the agent stands; the agent keeps standing under it
+    e = _state(make(), [(1, 1, rw.UP, 1, 0), (5, 0, rw.UP, 0, 0)] + far)
+    both(e, [4, 0, 0, 0])
+    assert _pos(e)[0] == (1, 1, rw.UP, 0) and e.grid[1, 1, 1] == 1
+    # 13. two carriers in a train: the follower's shelf enters the cell the leader's shelf leaves
+    gr = grid_with({(1, 1): 0, (2, 1): 0, (3, 0): 1, (4, 0): 2})
+    e = _state(make(), [(3, 0, rw.DRIGHT, 1, 0), (4, 0, rw.DRIGHT, 2, 0)] + far, grid=gr, queue=(5, 6, 7, 8))
+    both(e, [1, 1, 0, 0])
+    assert _pos(e)[:2] == [(4, 0, rw.DRIGHT, 1), (5, 0, rw.DRIGHT, 2)]
+    assert e.grid[1, 0, 3] == 0 and e.grid[1, 0, 4] == 1 and e.grid[1, 0, 5] == 2
+    # 14. ... but a carrier is stopped by a carrier that stays (its shelf is a standing obstacle for this step)
+    e = _state(make(), [(3, 0, rw.DRIGHT, 1, 0), (4, 0, rw.DRIGHT, 2, 0)] + far, grid=gr, queue=(5, 6, 7, 8))
+    both(e, [1, 0, 0, 0])
+    assert _pos(e)[:2] == [(3, 0, rw.DRIGHT, 1), (4, 0, rw.DRIGHT, 2)]
+    # 15. an unloaded agent drives under a standing shelf and can pick it up there next step
+    e = _state(make(), [(0, 1, rw.DRIGHT, 0, 0), (5, 0, rw.UP, 0, 0)] + far)
+    both(e, [1, 0, 0, 0])
+    both(e, [4, 0, 0, 0])
+    assert _pos(e)[0] == (1, 1, rw.DRIGHT, 1)
+    # 16. a shelf that is NOT requested earns nothing on the goal and the queue is untouched
+    gr = grid_with({(1, 1): 0, (4, 9): 1})
+    e = _state(make(), [(4, 9, rw.DOWN, 1, 0), (5, 0, rw.UP, 0, 0)] + far, grid=gr, queue=(5, 6, 7, 8))
+    _, rew, _, _, _ = both(e, [1, 0, 0, 0])
+    assert rew == [0.0] * 4 and [s.id for s in e.request_queue] == [5, 6, 7, 8] and e._cur_inactive_steps == 1
+    # 17. global rewards: every agent is paid for a delivery
+    e = _state(make(reward_type=rw.REWARD_GLOBAL), [(4, 9, rw.DOWN, 1, 0), (5, 0, rw.UP, 0, 0)] + far, grid=gr, queue=(1, 6, 7, 8))
+    assert both(e, [1, 0, 0, 0])[1] == [1.0] * 4
+    # 18. two-stage rewards: half on delivery, the other half when the delivered shelf is put back into the rack
+    e = _state(make(reward_type=rw.REWARD_TWO_STAGE), [(4, 9, rw.DOWN, 1, 0), (5, 0, rw.UP, 0, 0)] + far, grid=gr, queue=(1, 6, 7, 8))
+    assert both(e, [1, 0, 0, 0])[1] == [0.5, 0.0, 0.0, 0.0] and e.agents[0].has_delivered
+    assert both(e, [4, 0, 0, 0])[1] == [0.0] * 4 and e.agents[0].carrying_shelf is not None  # the goal row is a highway: no unloading
+    gr2 = grid_with({(1, 1): 1})
+    e = _state(make(reward_type=rw.REWARD_TWO_STAGE), [(1, 1, rw.UP, 1, 1), (5, 0, rw.UP, 0, 0)] + far, grid=gr2, queue=(5, 6, 7, 8))
+    assert both(e, [4, 0, 0, 0])[1] == [0.5, 0.0, 0.0, 0.0] and not e.agents[0].has_delivered and e.agents[0].carrying_shelf is None
+    # 19. both goal cells can deliver in the same step; each replacement excludes the shelves queued at that moment
+    gr = grid_with({(1, 1): 0, (2, 1): 0, (4, 9): 1, (5, 9): 2})
+    e = _state(make(), [(4, 9, rw.DOWN, 1, 0), (5, 9, rw.DOWN, 2, 0)] + far, grid=gr, queue=(1, 2, 3, 4), steps=3)
+    _, rew, _, _, _ = both(e, [1, 1, 0, 0])
+    k = DrawStream(0, 0, 0, rw.STREAM_REQUEST)
+    k.idx = 8 * 3
+    first = [s for s in range(1, 33) if s not in (1, 2, 3, 4)][k.integers(0, 28)]
+    second = [s for s in range(1, 33) if s not in (first, 2, 3, 4)][k.integers(0, 28)]
+    assert rew == [1.0, 1.0, 0.0, 0.0] and [s.id for s in e.request_queue] == [first, second, 3, 4]
+    # 20. max_inactivity_steps ends the episode after that many delivery-free steps; a delivery resets the count
+    e = _state(make(max_inactivity_steps=3), [(3, 0, rw.UP, 0, 0), (5, 0, rw.UP, 0, 0)] + far)
+    assert [both(e, [0, 0, 0, 0])[2] for _ in range(3)] == [False, False, True]
+    # 21. the time limit wrapper truncates, the env's own max_steps terminates (marlbase stores done | truncated)
+    m = MarlbaseEnv(TINY4, 5, max_steps=7)
+    m.reset(DrawStream(1, 0, 0))
+    flags = [m.step([0, 0, 0, 0])[2:4] for _ in range(5)]
+    assert flags[3] == (False, False) and flags[4] == (False, True)
+    # 22. observation of a neighbour: agent 1 (facing LEFT, carrying requested shelf 2) sits right of agent 0
+    gr = grid_with({(2, 1): 0, (4, 0): 2})
+    e = _state(make(), [(3, 0, rw.UP, 0, 0), (4, 0, rw.DLEFT, 2, 0)] + far, grid=gr, queue=(2, 6, 7, 8))
+    obs = both(e, [0, 0, 0, 0])[0]
+    assert obs[0][8 + 5 * 7:8 + 6 * 7].tolist() == [1.0, 0.0, 0.0, 1.0, 0.0, 1.0, 1.0]  # window cell 5 = (x+1, y)
+    assert obs[0][8:8 + 3 * 7].tolist() == [0.0, 1.0, 0.0, 0.0, 0.0, 0.0, 0.0] * 3       # the row above the grid is padding
+    assert obs[1][:8].tolist() == [4.0, 0.0, 1.0, 0.0, 0.0, 1.0, 0.0, 1.0]
 
 
 @pytest.mark.parametrize("name,over,coop", [(TINY4, {}, False), ("rware:rware-tiny-2ag-easy-v2", {}, True),
