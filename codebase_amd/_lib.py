@@ -52,7 +52,7 @@ class BatchStruct(ctypes.Structure):
     _fields_ = [("obss", c_void_p), ("actions", c_void_p), ("rewards", c_void_p), ("dones", c_void_p),
                 ("filled", c_void_p), ("max_len", c_int32), ("batch", c_int32),
                 ("obs_agent_stride", c_int64), ("obs_row_stride", c_int64), ("act_agent_stride", c_int64),
-                ("act_row_stride", c_int64)]
+                ("act_row_stride", c_int64), ("action_mask", c_void_p)]
 
 
 class QmixMixer(ctypes.Structure):

@@ -108,9 +108,10 @@ class A2CNetwork:
 
     def act(self, inputs, actor_hiddens, action_mask=None):
         """model.py:147-153: Categorical(logits).sample() per agent; returns ([P, N, 1] int64, hiddens)"""
-        if action_mask is not None:
-            raise NotImplementedError("action masks (SMAClite) are outside this round's hot path")
         lg = self.logits(inputs)
+        if action_mask is not None:  # get_dist (model.py:135-145): one mask per agent, shaped like that agent's logits
+            m = torch.stack([torch.as_tensor(x, dtype=torch.float32) for x in action_mask]).to(lg.device).reshape(lg.shape)
+            lg = lg * m + (1 - m) * -1e8
         acts = torch.distributions.Categorical(logits=lg).sample()
         return acts.unsqueeze(-1), actor_hiddens
 

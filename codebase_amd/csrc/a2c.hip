@@ -209,16 +209,19 @@ static __global__ __launch_bounds__(256) void ac_elem_kernel(AcArgs a, marlhip_b
             }
             if (a.mode == 4) continue;
         }
-        const float* l = w.logits + pi * a.A;
-        float m = l[0];
-        for (int k = 1; k < a.A; ++k) m = fmaxf(m, l[k]);
+        const float* lraw = w.logits + pi * a.A;
+        // get_dist (ac/model.py:135-145): logits * mask + (1 - mask) * -1e8 with batch.action_masks[t] ([T+1][B][P][A])
+        const float* mrow = bt.action_mask != nullptr ? bt.action_mask + (((size_t)t * a.B + b) * a.P + p) * a.A : nullptr;
+        auto l = [&](int k) { return mrow != nullptr ? lraw[k] * mrow[k] + (1.f - mrow[k]) * -1e8f : lraw[k]; };  // re-read, no local array
+        float m = l(0);
+        for (int k = 1; k < a.A; ++k) m = fmaxf(m, l(k));
         float s = 0.f;
-        for (int k = 0; k < a.A; ++k) s += expf(l[k] - m);
+        for (int k = 0; k < a.A; ++k) s += expf(l(k) - m);
         const float lse = m + logf(s);
         const int act = (int)bt.actions[p * aas + (size_t)i * ars];
-        const float logp = l[act] - lse;
+        const float logp = l(act) - lse;
         float H = 0.f;
-        for (int k = 0; k < a.A; ++k) H -= expf(l[k] - lse) * (l[k] - lse);
+        for (int k = 0; k < a.A; ++k) H -= expf(l(k) - lse) * (l(k) - lse);
         if (a.mode == 1) {
             if (inside) w.oldlogp[pi] = logp;
             continue;
@@ -239,8 +242,9 @@ static __global__ __launch_bounds__(256) void ac_elem_kernel(AcArgs a, marlhip_b
         }
         if (inside) {
             for (int k = 0; k < a.A; ++k) {
-                const float lp = l[k] - lse, pk = expf(lp);
-                w.dlogits[pi * a.A + k] = fl * (coef * ((k == act ? 1.f : 0.f) - pk) + a.ent_coef * pk * (lp + H));
+                const float lp = l(k) - lse, pk = expf(lp);
+                const float dl = fl * (coef * ((k == act ? 1.f : 0.f) - pk) + a.ent_coef * pk * (lp + H));
+                w.dlogits[pi * a.A + k] = mrow != nullptr ? dl * mrow[k] : dl;  // d(masked logit)/d(logit) = mask
             }
             w.dv[pi] = fl * (-2.f * a.vlc * (ret - val));
         }

@@ -212,6 +212,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dqn_lossgrad_kernel(con
             float rw, dn, fl;
             float dq, lr;      // MODE 2: external dL/dchosen and per-row loss
             float dqv[4];      // MODE 4: external dL/d(output 4g+r)
+            float mk[4];       // batch.action_mask of outputs 4g+r at this observation (1 = allowed); all ones without masks
         };
         // branch-free: every address is clamped in-bounds and loaded unconditionally (a guarded load is
         // an exec-masked branch + a conservative vmcnt(0) at the join); masks are applied at the point of use
@@ -255,6 +256,11 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dqn_lossgrad_kernel(con
                     R.dn = bt.dones[(size_t)(tt + 1) * B + bj];
                 }
                 R.fl = bt.filled[(size_t)tt * B + bj];
+            }
+            if (!REPLAY && (MODE == 0 || MODE == 1) && bt.action_mask != nullptr) {
+                const float* mrow = bt.action_mask + (((size_t)p * (T + 1) + t) * B + bj) * A;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) R.mk[r] = mrow[4 * g + r < A ? 4 * g + r : A - 1];
             }
             if (MODE == 2) {
                 R.dq = mix.dq[(size_t)p * mix.dq_agent_stride + (size_t)tt * B + bj];
@@ -435,6 +441,12 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dqn_lossgrad_kernel(con
             MARL_PHASE(6)
             if (MODE != 2 && MODE != 4 && t > t0) {
                 // ---- bootstrap value for transition t-1 (model.py:132-145)
+                if (!REPLAY && bt.action_mask != nullptr) {  // model.py:136-142: disallowed actions of o_t read as -1e8
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (cur.mk[r] == 0.f) { q[r] = -1e8f; tq[r] = -1e8f; }
+                    }
+                }
                 const int a_p = double_q ? argmax_rows<A>(q, lane) : argmax_rows<A>(tq, lane);
                 tq_next = gather_rows(tq, lane, a_p);
                 if (MODE == 1 && g == 0 && rowok) mix.tqsel[((size_t)p * T + (t - 1)) * B + bj] = tq_next;

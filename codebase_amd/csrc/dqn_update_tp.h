@@ -61,10 +61,12 @@ struct TpRows {
     int a_sel;
     float rw, dn, fl, dq, lr;
     float dqv[4];  // FULL: dL/d(output 4g+r)
+    float mk[4];   // pass F: batch.action_mask of outputs 4g+r (see marlhip_batch)
 };
 
 template <class S, bool REPLAY>
 struct TpSrc {  // everything load_rows needs, per block
+    const float* mask_p;  // batch.action_mask of this agent ([T+1][B][A]) or nullptr
     const float* obs_p;
     const int64_t* act_p;
     const float* rew_p;
@@ -124,6 +126,11 @@ __device__ __forceinline__ void tp_load_rows(const TpSrc<S, REPLAY>& s, const Tp
             R.dn = s.dones[(size_t)(tt + 1) * B + bj];
         }
         R.fl = s.filled[(size_t)tt * B + bj];
+    }
+    if (!BWD && !REPLAY && s.mask_p != nullptr) {
+        const float* mrow = s.mask_p + ((size_t)t * B + bj) * S::A;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) R.mk[r] = mrow[4 * g + r < S::A ? 4 * g + r : S::A - 1];
     }
     if (BWD) {
         if (FULL) {
@@ -214,6 +221,7 @@ __global__ __launch_bounds__(64 * W, 1) void tp_fwd_kernel(const float* __restri
     }
     TpSrc<S, REPLAY> src;
     src.obs_p = REPLAY ? nullptr : bt.obss + (size_t)p * (bt.obs_agent_stride > 0 ? (size_t)bt.obs_agent_stride : (bt.obs_agent_stride < 0 ? 0 : (size_t)(T + 1) * B * S::D));
+    src.mask_p = (REPLAY || bt.action_mask == nullptr) ? nullptr : bt.action_mask + (size_t)p * (T + 1) * B * S::A;
     src.obs_rs = bt.obs_row_stride ? (size_t)bt.obs_row_stride : (size_t)S::D;
     src.act_p = REPLAY ? nullptr : bt.actions + (size_t)p * T * B;
     src.rew_p = REPLAY ? nullptr : bt.rewards + (size_t)p * T * B;
@@ -313,6 +321,12 @@ __global__ __launch_bounds__(64 * W, 1) void tp_fwd_kernel(const float* __restri
                         }
                     }
                     if (need_t) {
+                        if (!REPLAY && src.mask_p != nullptr) {  // dqn/model.py:136-142
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                if (cur[nb].mk[r] == 0.f) { q[r] = -1e8f; tq[r] = -1e8f; }
+                            }
+                        }
                         const int a_p = double_q ? argmax_rows<A>(q, lane) : argmax_rows<A>(tq, lane);
                         const float tv = gather_rows(tq, lane, a_p);
                         if (g == 0 && rowok) mix.tqsel[((size_t)p * T + (t - 1)) * B + bj] = tv;
@@ -405,6 +419,7 @@ __global__ __launch_bounds__(64 * W, 1) void tp_bwd_kernel(const float* __restri
 
     TpSrc<S, REPLAY> src;
     src.obs_p = REPLAY ? nullptr : bt.obss + (size_t)p * (bt.obs_agent_stride > 0 ? (size_t)bt.obs_agent_stride : (bt.obs_agent_stride < 0 ? 0 : (size_t)(T + 1) * B * D));
+    src.mask_p = nullptr;
     src.obs_rs = bt.obs_row_stride ? (size_t)bt.obs_row_stride : (size_t)D;
     src.act_p = (REPLAY || FULL) ? nullptr : bt.actions + (size_t)p * T * B;
     src.rew_p = (REPLAY || FULL) ? nullptr : bt.rewards + (size_t)p * T * B;

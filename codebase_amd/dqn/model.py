@@ -142,12 +142,16 @@ class QNetwork:
 
     def act(self, inputs, hiddens, epsilon, action_masks=None):
         """One env (dqn/model.py:94-116): ONE python `random.random()` draw decides the joint action."""
-        if action_masks is not None:
-            raise NotImplementedError("action masks (SMAClite) are outside this round's hot path")
         if epsilon > random.random():
+            if action_masks is not None:  # model.py:106-111: a random ALLOWED action per agent
+                return [random.choice([i for i, m in enumerate(mask) if m == 1]) for mask in action_masks], hiddens
             return list(self.action_space.sample()), hiddens
         for p, o in enumerate(inputs):
             self._obs1[p, 0].copy_(torch.as_tensor(o, dtype=torch.float32))
+        if action_masks is not None:  # model.py:100-104: value * mask + (1 - mask) * -1e8, then argmax
+            q = self.q_values(self._obs1)[:, 0]
+            m = torch.as_tensor(np.asarray(action_masks, np.float32)).to(q.device)
+            return [int(a) for a in (q * m + (1 - m) * -1e8).argmax(-1).tolist()], hiddens
         acts = _hip.dqn_act(self.spec, self.params, self._obs1, 0.0, u=self._u1, rand_actions=self._ra1)
         return [int(a) for a in acts[:, 0].tolist()], hiddens
 
@@ -158,7 +162,8 @@ class QNetwork:
     def _to_device_batch(self, batch):
         f = lambda t, dt: t.to(self.device, dt).contiguous()
         return _hip.Batch(f(batch.obss, torch.float32), f(batch.actions, torch.int64), f(batch.rewards, torch.float32),
-                          f(batch.dones, torch.float32), f(batch.filled, torch.float32), None)
+                          f(batch.dones, torch.float32), f(batch.filled, torch.float32),
+                          None if batch.action_mask is None else f(batch.action_mask, torch.float32))
 
     def update_async(self, batch, grad_sync=None, world=1, replay=None, **sample_kw):
         """loss/grad -> [grad_sync(grad)] -> clip+Adam -> target update; returns the device loss tensor.

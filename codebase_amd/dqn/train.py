@@ -28,12 +28,13 @@ class ReplayBuffer:
 
     def __init__(self, buffer_size, n_agents, observation_space, action_space, max_episode_length, device,
                  store_action_masks=False):
-        if store_action_masks:
-            raise NotImplementedError("action masks are outside this round's hot path")
+        self.store_action_masks = store_action_masks
         self.buffer_size, self.n_agents, self.max_episode_length = buffer_size, n_agents, max_episode_length
         self.device = torch.device(device)
         D = int(np.prod(observation_space[0].shape))
         self.store = _hip.DeviceReplay(buffer_size, n_agents, D, max_episode_length, device=device)
+        if store_action_masks:  # train.py:55-63: [P][T+1][cap][A] f32, kept next to the episode-major store, gathered by sample()
+            self.action_masks = torch.zeros(n_agents, max_episode_length + 1, buffer_size, int(action_space[0].n), device=self.device)
         self.pos = self.cur_pos = self.t = 0
         self._slot = torch.zeros(1, dtype=torch.int32, device=self.device)
         self._t = torch.zeros(1, dtype=torch.int32, device=self.device)
@@ -48,6 +49,9 @@ class ReplayBuffer:
         self.t = 0
         self._slot.fill_(self.cur_pos)
         self.store.init_episode(self._slot, self._obs(obss))
+        if action_masks is not None:
+            assert self.store_action_masks, "Action masks not stored in buffer!"
+            self.action_masks[:, 0, self.cur_pos] = torch.as_tensor(np.asarray(action_masks, np.float32)).to(self.device)
 
     def add(self, obss, acts, rews, done, action_masks=None):
         assert self.t < self.max_episode_length, "Episode longer than given max length!"
@@ -58,6 +62,9 @@ class ReplayBuffer:
                        torch.as_tensor(np.asarray(acts, np.int32).reshape(-1, 1)).to(dev),
                        torch.as_tensor(np.asarray(rews, np.float32).reshape(-1, 1)).to(dev),
                        torch.tensor([1 if done else 0], dtype=torch.uint8, device=dev))
+        if action_masks is not None:
+            assert self.store_action_masks, "Action masks not stored in buffer!"
+            self.action_masks[:, self.t + 1, self.cur_pos] = torch.as_tensor(np.asarray(action_masks, np.float32)).to(dev)
         self.t += 1
         if done:
             self.pos += 1
@@ -69,7 +76,11 @@ class ReplayBuffer:
 
     def sample(self, batch_size):
         idx = np.random.randint(0, len(self), size=batch_size)  # legacy global RNG, as train.py:95
-        return self.store.sample(batch_size, idx=torch.as_tensor(idx, dtype=torch.int32).to(self.device), fresh=True)
+        idx_d = torch.as_tensor(idx, dtype=torch.int32).to(self.device)
+        batch = self.store.sample(batch_size, idx=idx_d, fresh=True)
+        if self.store_action_masks:  # train.py:118-124
+            batch = batch._replace(action_mask=self.action_masks[:, :, idx_d.long()].contiguous())
+        return batch
 
 
 def _epsilon_schedule(decay_style, decay_over, eps_start, eps_end, exp_decay_rate, total_steps):
@@ -93,16 +104,18 @@ def _episode(env, model, epsilon, rb=None, use_proper_termination=False):
     """one episode through the scalar API: _collect_trajectory (train.py:202-237) when `rb` is given,
     else one iteration of _evaluate (train.py:177-199)."""
     obss, info = env.reset()
+    mask = np.stack(info["action_mask"]).astype(np.float32) if "action_mask" in info else None  # train.py:204-208
     if rb is not None:
-        rb.init_episode(obss)
+        rb.init_episode(obss, mask)
     hiddens = model.init_hiddens(1)
     done, t = False, 0
     while not done:
-        actions, hiddens = model.act(obss, hiddens, epsilon)
+        actions, hiddens = model.act(obss, hiddens, epsilon, mask)
         obss, rews, term, truncated, info = env.step(actions)
         done = term or truncated
+        mask = np.stack(info["action_mask"]).astype(np.float32) if "action_mask" in info else None
         if rb is not None:
-            rb.add(obss, actions, rews, term if use_proper_termination else done)
+            rb.add(obss, actions, rews, term if use_proper_termination else done, mask)
         t += 1
     return t, info
 
@@ -235,8 +248,9 @@ def main(env, eval_env, logger, time_limit, **cfg):
         trainer = VectorisedIDQN(env.cfg, model, max(g("buffer_size"), N), time_limit, B, U, seed=env.cfg.seed,
                                  use_proper_termination=g("use_proper_termination", False))
     else:
+        _, info0 = env.reset()  # train.py:265,281: the buffer stores masks iff the env's info carries them
         rb = ReplayBuffer(g("buffer_size"), env.unwrapped.n_agents, env.observation_space, env.action_space, time_limit,
-                          _cfg_get(cfg, "model.device", "cuda"))
+                          _cfg_get(cfg, "model.device", "cuda"), store_action_masks="action_mask" in info0)
     while step < total_steps + 1:
         if vectorised:
             train = step > g("training_start") and trainer.rounds * N >= g("batch_size")

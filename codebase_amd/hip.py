@@ -22,6 +22,15 @@ def _ptr(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+def _mask_ptr(mask, shape):
+    """device pointer of an optional f32 action-mask tensor of the given shape (marlhip_batch.action_mask), None when absent"""
+    if mask is None:
+        return None
+    assert mask.dtype == torch.float32 and tuple(mask.shape) == tuple(shape) and mask.is_contiguous() and mask.is_cuda, \
+        f"action mask must be a contiguous f32 device tensor of shape {tuple(shape)}"
+    return mask.data_ptr()
+
+
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -294,7 +303,7 @@ class DqnUpdater:
         T, B = batch.filled.shape
         ws = self._workspace(T, B)
         bs = BatchStruct(batch.obss.data_ptr(), batch.actions.data_ptr(), batch.rewards.data_ptr(), batch.dones.data_ptr(),
-                         batch.filled.data_ptr(), T, B)
+                         batch.filled.data_ptr(), T, B, 0, 0, 0, 0, _mask_ptr(batch.action_mask, (self.spec.n_agents, T + 1, B, self.spec.n_actions)))
         s = self.spec.c()
         if self.ret_stats is not None:
             if mode != 0:
@@ -376,7 +385,7 @@ class QmixUpdater(DqnUpdater):
         T, B = batch.filled.shape
         ws = self._workspace(T, B)
         bs = BatchStruct(batch.obss.data_ptr(), batch.actions.data_ptr(), batch.rewards.data_ptr(), batch.dones.data_ptr(),
-                         batch.filled.data_ptr(), T, B)
+                         batch.filled.data_ptr(), T, B, 0, 0, 0, 0, _mask_ptr(batch.action_mask, (self.spec.n_agents, T + 1, B, self.spec.n_actions)))
         s, mx = self.spec.c(), self._mx()
         check(lib.marlhip_qmix_loss_grad(ctypes.byref(s), _ptr(self.params), _ptr(self.target), ctypes.byref(mx), ctypes.byref(bs),
                                          float(self.gamma), self.double_q, _ptr(ws), ws.numel(), _ptr(self.grad), _ptr(self.loss),
@@ -464,8 +473,12 @@ class AcUpdater:
         dones = batch.dones if batch.dones.dtype == torch.float32 else batch.dones.float()  # model.py:198
         keep = (batch.obss.contiguous(), batch.actions.contiguous(), batch.rewards.contiguous(), dones.contiguous(),
                 batch.filled.contiguous())
+        masks = getattr(batch, "action_masks", None)  # ac/train.py:53-63: [T+1][N][P][A] f32 or None
+        if masks is not None:
+            masks = masks.to(torch.float32).contiguous()
+            keep = keep + (masks,)
         bs = BatchStruct(keep[0].data_ptr(), keep[1].data_ptr(), keep[2].data_ptr(), keep[3].data_ptr(), keep[4].data_ptr(), T, N,
-                         D, P * D, 1, P)
+                         D, P * D, 1, P, _mask_ptr(masks, (T + 1, N, P, self.spec.n_actions)))
         return bs, keep, T, N
 
     def a2c_loss_grad(self, batch):

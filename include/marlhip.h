@@ -228,6 +228,13 @@ typedef struct marlhip_batch {
      * act_agent_stride = 1, act_row_stride = P.  (obs strides: every learner entry point; act strides: marlhip_ac_* only)
      * obs_agent_stride < 0: every agent reads the SAME rows (centralised critics: the whole P*D row is the input). */
     int64_t obs_agent_stride, obs_row_stride, act_agent_stride, act_row_stride;
+    /* batch.action_mask (dqn/train.py:118-124; dqn/model.py:133-143): f32 [P][T+1][B][A], 1 = allowed, or NULL.  In the DQN
+     * family the bootstrap of transition t reads the target (and, for Double-Q, the online) values of observation t+1 with
+     * the disallowed actions at -1e8, exactly as the reference overwrites them.  For the actor-critic learners
+     * (batch.action_masks, ac/train.py:53-63; ac/model.py:135-145) the layout is the Batch's [T+1][B][P][A] and the
+     * logits become logits * mask + (1 - mask) * -1e8 before the Categorical.  No env on this path emits masks (LBF and
+     * rware do not); they enter through the scalar-env python loops and the Batch arguments. */
+    const float* action_mask;
 } marlhip_batch;
 
 /* bytes of scratch marlhip_dqn_loss_grad needs for this (shape, T, B) */

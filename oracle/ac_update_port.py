@@ -56,6 +56,14 @@ def logits(block, obss, D, H, A):
     return [dp.mlp(block[p], xs[p], D, H, A) for p in range(P)]
 
 
+def _masked(lg, batch):
+    """get_dist (ac/model.py:135-145) with batch["action_masks"][:-1] ([T+1][N][P][A]) when present"""
+    m = batch.get("action_masks")
+    if m is None:
+        return lg
+    return [l * m[:-1, :, p] + (1 - m[:-1, :, p]) * -1e8 for p, l in enumerate(lg)]
+
+
 def evaluate(actor, critic, target, batch, D, H, A, n_steps, gamma, ret_ms=None):
     obss, actions = batch["obss"], batch["actions"]
     P = actor.shape[0]
@@ -69,7 +77,7 @@ def evaluate(actor, critic, target, batch, D, H, A, n_steps, gamma, ret_ms=None)
         ret_ms.update(returns)
         returns = (returns - ret_ms.mean) / torch.sqrt(ret_ms.var)
     v = values(critic, obss[:-1], D, H)
-    lg = logits(actor, obss[:-1], D, H, A)
+    lg = _masked(logits(actor, obss[:-1], D, H, A), batch)
     dists = [torch.distributions.Categorical(logits=l) for l in lg]
     logp = torch.stack([d.log_prob(actions[..., p]) for p, d in enumerate(dists)], dim=-1)
     ent = torch.stack([d.entropy() for d in dists], dim=-1).sum(-1)
@@ -90,7 +98,7 @@ def a2c_loss(actor, critic, target, batch, D, H, A, n_steps=5, gamma=0.99, entro
 def ppo_loss(actor, critic, returns, old_logp, batch, D, H, A, entropy_coef, value_loss_coef, ppo_clip):
     obss, actions, filled = batch["obss"], batch["actions"], batch["filled"]
     v = values(critic, obss[:-1], D, H)
-    lg = logits(actor, obss[:-1], D, H, A)
+    lg = _masked(logits(actor, obss[:-1], D, H, A), batch)
     dists = [torch.distributions.Categorical(logits=l) for l in lg]
     logp = torch.stack([d.log_prob(actions[..., p]) for p, d in enumerate(dists)], dim=-1)
     ent = torch.stack([d.entropy() for d in dists], dim=-1).sum(-1)

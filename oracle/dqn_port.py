@@ -105,10 +105,16 @@ def compute_loss(params, tparams, batch, gamma, double_q, D, H, A, mode="idqn", 
     P = obss.shape[0]
     q = q_values(params, obss, D, H, A)
     chosen = q[:, :-1].gather(-1, actions).squeeze(-1)
+    mask = batch.get("action_mask")  # [P][T+1][B][A] f32 or absent (model.py:124,133-143)
     with torch.no_grad():
         tq = q_values(tparams, obss, D, H, A)[:, 1:]
+        if mask is not None:
+            tq = torch.where(mask[:, 1:] == 0, torch.full_like(tq, -1e8), tq)
     if double_q:
-        a_prime = q.detach()[:, 1:].argmax(-1)
+        qd = q.detach()[:, 1:]
+        if mask is not None:
+            qd = torch.where(mask[:, 1:] == 0, torch.full_like(qd, -1e8), qd)
+        a_prime = qd.argmax(-1)
         target_qs = tq.gather(-1, a_prime.unsqueeze(-1)).squeeze(-1)
     else:
         target_qs, _ = tq.max(dim=-1)

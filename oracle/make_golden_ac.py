@@ -41,7 +41,7 @@ def build(cls, P, D, A, H, seed, **over):
     return net, cfg
 
 
-def fixture(ref_ac_model, ref_ac_train, name, cls, P, D, H, N, seed, **over):
+def fixture(ref_ac_model, ref_ac_train, name, cls, P, D, H, N, seed, masked=False, **over):
     T, A = 25, 6
     net, cfg = build(cls, P, D, A, H, seed, **over)
     out = dict(P=P, T=T, N=N, D=D, A=A, H=H, n_steps=cfg.n_steps, gamma=cfg.gamma, entropy_coef=cfg.entropy_coef,
@@ -50,7 +50,14 @@ def fixture(ref_ac_model, ref_ac_train, name, cls, P, D, H, N, seed, **over):
                target0=flat_params(net.target_critic).numpy())
     steps = [0, 250, 400]
     batches = [synthetic_batch(P, T, N, D, A, seed=seed + 100 + i) for i in range(3)]
-    mk = lambda b: ref_ac_train.Batch(b["obss"], b["actions"], b["rewards"], b["dones"], b["filled"], None)  # noqa: E731
+    if masked:  # batch.action_masks [T+1][N][P][A] (ac/train.py:53-63): random, never empty, the taken action allowed
+        for i, b in enumerate(batches):
+            g = torch.Generator().manual_seed(seed + 300 + i)
+            m = (torch.rand(T + 1, N, P, A, generator=g) < 0.6).float()
+            m[..., 0] = torch.maximum(m[..., 0], (m.sum(-1) == 0).float())
+            m[:-1].scatter_(-1, b["actions"].unsqueeze(-1), 1.0)
+            b["action_masks"] = m
+    mk = lambda b: ref_ac_train.Batch(b["obss"], b["actions"], b["rewards"], b["dones"], b["filled"], b.get("action_masks"))  # noqa: E731
     if cls is ref_ac_model.A2CNetwork:  # gradient of the first update, via a throw-away copy stepped with lr = 0
         probe, _ = build(cls, P, D, A, H, seed, **dict(over, lr=0.0, grad_clip=False))  # noqa
         probe.update(mk(batches[0]), 1)
@@ -91,3 +98,6 @@ if __name__ == "__main__":
     # critic.centralised = True (maa2c.yaml / mappo.yaml): every critic reads all agents' observations
     fixture(ram, rat, "learner_maa2c_H64.npz", ram.A2CNetwork, P=2, D=15, H=64, N=12, seed=800, centralised=True)
     fixture(ram, rat, "learner_mappo_p3_H128.npz", ram.PPONetwork, P=3, D=18, H=128, N=9, seed=900, centralised=True)
+    # batch.action_masks set (get_dist masks the logits, ac/model.py:135-145)
+    fixture(ram, rat, "learner_a2c_masks_H64.npz", ram.A2CNetwork, P=2, D=15, H=64, N=12, seed=1300, masked=True)
+    fixture(ram, rat, "learner_ppo_masks_H128.npz", ram.PPONetwork, P=2, D=15, H=128, N=10, seed=1400, masked=True)
