@@ -1,0 +1,75 @@
+"""TEST INFRASTRUCTURE ONLY - CPU restatement of the reference's recurrent Q-network (`use_rnn: True`).
+
+Follows marlbase/utils/models.py:51-116 (RNNNetwork: Linear(D, H) -> ReLU -> one-layer nn.GRU(H, H) -> Linear(H, A); with
+`layers: [H, H]` the GRU has len(layers) - 1 = 1 layer) and the way the DQN family drives it:
+  QNetwork.act            dqn/model.py:94-116   one step, hidden state [1, 1, H] per agent carried by the caller
+  QNetwork._compute_loss  dqn/model.py:118-163  whole [T+1, B] sequences from a zero hidden state (`hiddens=None`)
+torch.nn.GRU's cell (gate order r, z, n in weight_ih_l0 / weight_hh_l0):
+  r = sigmoid(W_ir x + b_ir + W_hr h + b_hr)      z = sigmoid(W_iz x + b_iz + W_hz h + b_hz)
+  n = tanh(W_in x + b_in + r * (W_hn h + b_hn))   h' = (1 - z) * n + z * h
+Parameters of one agent = one flat fp32 block in parameters() order:
+  first_layer.weight [H, D] | first_layer.bias [H] | rnn.weight_ih_l0 [3H, H] | rnn.weight_hh_l0 [3H, H] |
+  rnn.bias_ih_l0 [3H] | rnn.bias_hh_l0 [3H] | final_layer.weight [A, H] | final_layer.bias [A]
+PINNED by tests/golden/learner_gru_*.npz (oracle/make_golden_gru.py runs the reference's own QNetwork(use_rnn=True)).
+"""
+import numpy as np
+import torch
+
+from . import dqn_port as dp
+
+SHAPES = lambda D, H, A: ((H, D), (H,), (3 * H, H), (3 * H, H), (3 * H,), (3 * H,), (A, H), (A,))  # noqa: E731
+NAMES = ("first_layer.weight", "first_layer.bias", "rnn.weight_ih_l0", "rnn.weight_hh_l0", "rnn.bias_ih_l0", "rnn.bias_hh_l0",
+         "final_layer.weight", "final_layer.bias")
+
+
+def nparams(D, H, A):
+    return sum(int(np.prod(s)) for s in SHAPES(D, H, A))
+
+
+def split(block, D, H, A):
+    out, o = [], 0
+    for s in SHAPES(D, H, A):
+        n = int(np.prod(s))
+        out.append(block[o:o + n].reshape(s))
+        o += n
+    return out
+
+
+def cell(parts, x, h):
+    """one step: x [..., D], h [..., H] -> (q [..., A], h' [..., H])"""
+    W1, b1, Wih, Whh, bih, bhh, W3, b3 = parts
+    H = h.shape[-1]
+    x1 = torch.relu(torch.nn.functional.linear(x, W1, b1))
+    gi = torch.nn.functional.linear(x1, Wih, bih)
+    gh = torch.nn.functional.linear(h, Whh, bhh)
+    r = torch.sigmoid(gi[..., :H] + gh[..., :H])
+    z = torch.sigmoid(gi[..., H:2 * H] + gh[..., H:2 * H])
+    n = torch.tanh(gi[..., 2 * H:] + r * gh[..., 2 * H:])
+    hn = (1 - z) * n + z * h
+    return torch.nn.functional.linear(hn, W3, b3), hn
+
+
+def sequence(block, obss, D, H, A, h0=None):
+    """obss [S, B, D] -> (q [S, B, A], h_S [B, H]) from h0 (zeros when None), one step after the other"""
+    parts = split(block, D, H, A)
+    h = torch.zeros(obss.shape[1], H) if h0 is None else h0
+    qs = []
+    for t in range(obss.shape[0]):
+        q, h = cell(parts, obss[t], h)
+        qs.append(q)
+    return torch.stack(qs), h
+
+
+def q_values(params, obss, D, H, A):
+    """obss [P, S, B, D] -> [P, S, B, A]"""
+    return torch.stack([sequence(params[p], obss[p], D, H, A)[0] for p in range(params.shape[0])])
+
+
+def compute_loss(params, tparams, batch, gamma, double_q, D, H, A, mode="idqn"):
+    """dqn_port.compute_loss with the recurrent networks (same TD arithmetic, dqn/model.py:118-163 / 224-269)"""
+    saved = dp.q_values
+    dp.q_values = q_values
+    try:
+        return dp.compute_loss(params, tparams, batch, gamma, double_q, D, H, A, mode=mode)
+    finally:
+        dp.q_values = saved

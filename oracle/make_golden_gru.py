@@ -1,0 +1,75 @@
+"""Generate tests/golden/learner_gru_*.npz from the REFERENCE's own QNetwork / VDNetwork with use_rnn=True
+(marlbase/utils/models.py:51-116, marlbase/dqn/model.py:94-163).  Runs only in the build container.
+
+    PYTHONDONTWRITEBYTECODE=1 python -m oracle.make_golden_gru
+
+Each file: critic / target blocks in parameters() order (oracle/gru_port.py), the state_dict key list, one Batch, the
+Q-values of the whole batch (critic) for a forward-only check, loss and gradient of _compute_loss, parameters after 2 x
+update(), and an `act` trace: 6 greedy steps of one env with the hidden states the reference carries between them.
+  learner_gru_idqn_H64.npz   2 agents x 15 obs, QNetwork, 64-64
+  learner_gru_vdn_H64.npz    3 agents x 18 obs, VDNetwork, 64-64
+"""
+import contextlib
+import io
+import os
+
+import numpy as np
+import torch
+
+from .dqn_port import synthetic_batch
+from .make_golden import OUT, Box, Cfg, Discrete, flat_params, import_reference
+
+
+def fixture(ref_model, ref_train, name, cls, P, D, H, B, seed):
+    T, A = 10, 6
+    torch.manual_seed(seed)
+    cfg = Cfg(optimizer="Adam", lr=3e-4, gamma=0.99, grad_clip=1.0, target_update_interval_or_tau=200, double_q=True,
+              standardise_returns=False)
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = cls([Box(D)] * P, [Discrete(A)] * P, cfg, [H, H], False, True, True, "cpu")
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for p in net.target.parameters():
+            p.add_(0.05 * torch.randn(p.shape, generator=g))
+    out = dict(P=P, T=T, B=B, D=D, A=A, H=H, keys=np.array(list(net.state_dict().keys())),
+               params0=flat_params(net.critic).numpy(), target0=flat_params(net.target).numpy())
+    batch = synthetic_batch(P, T, B, D, A, seed=seed + 7)
+    batch["obss"] = batch["obss"] * 0.25
+    if cls is ref_model.VDNetwork:
+        batch["rewards"][1:] = batch["rewards"][0]
+    for k, v in batch.items():
+        out[f"batch_{k}"] = v.numpy()
+    bb = ref_train.Batch(batch["obss"], batch["actions"], batch["rewards"], batch["dones"], batch["filled"], None)
+    with torch.no_grad():
+        q, _ = net.critic(bb.obss, None)
+        out["q0"] = torch.stack(q).numpy()
+    loss = net._compute_loss(bb)
+    net.optimizer.zero_grad()
+    loss.backward()
+    out["loss0"] = np.float32(loss.item())
+    out["grad0"] = torch.stack([torch.cat([p.grad.reshape(-1) for p in m.parameters()]) for m in net.critic.independent]).numpy()
+    net.optimizer.zero_grad()
+    # act trace (epsilon 0): the reference carries `hiddens` between calls (dqn/train.py:210-216)
+    ga = torch.Generator().manual_seed(seed + 3)
+    obs = torch.randint(-1, 8, (6, P, D), generator=ga).float() * 0.25
+    hid = net.init_hiddens(1)
+    acts, hids = [], []
+    for t in range(6):
+        a, hid = net.act([o.numpy() for o in obs[t]], hid, 0.0)
+        acts.append(a)
+        hids.append(torch.stack([h.reshape(-1) for h in hid]).numpy())
+    out["act_obs"], out["act_actions"], out["act_hiddens"] = obs.numpy(), np.array(acts, np.int64), np.array(hids)
+    out["losses"] = np.array([net.update(bb)["loss"] for _ in range(2)], np.float32)
+    out["params2"] = flat_params(net.critic).numpy()
+    np.savez_compressed(os.path.join(OUT, name), **out)
+    print(name, float(out["loss0"]), out["losses"].tolist(), out["params0"].shape)
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(1)
+    import_reference()
+    from marlbase.dqn import model as rm
+    from marlbase.dqn import train as rt
+
+    fixture(rm, rt, "learner_gru_idqn_H64.npz", rm.QNetwork, P=2, D=15, H=64, B=37, seed=2100)
+    fixture(rm, rt, "learner_gru_vdn_H64.npz", rm.VDNetwork, P=3, D=18, H=64, B=21, seed=2200)
