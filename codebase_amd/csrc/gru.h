@@ -1,0 +1,207 @@
+// Recurrent Q-networks (`use_rnn: True`): Linear(D, H) -> ReLU -> one-layer GRU(H, H) -> Linear(H, A)
+// (marlbase/utils/models.py:51-116), hidden 64, on the same transposed-activation f32 MFMA scheme as mlp.h.
+//
+// One agent's block, parameters() order:
+//   first_layer.weight [H][D] | .bias [H] | rnn.weight_ih_l0 [3H][H] | rnn.weight_hh_l0 [3H][H] | rnn.bias_ih_l0 [3H] |
+//   rnn.bias_hh_l0 [3H] | final_layer.weight [A][H] | .bias [A]            (gate order r, z, n: torch.nn.GRU)
+// A wave owns 16 sequences (batch rows) and walks them one step after the other with the hidden state in registers
+// (C layout = the next step's B operand, as everywhere in mlp.h); the whole network (108 KB of A-operand packs at
+// D = 15) sits in LDS, so the four waves of a workgroup share nothing but the weights.
+//   gru_seq_fwd_kernel : q[t] for t = 0..S-1 from h_in (zeros when NULL), optional h_out, optional per-step activation
+//                        record (x1, r, z, n, h, W_hn h + b_hn) for the backward pass
+#pragma once
+#include "common.h"
+#include "mlp.h"
+
+namespace marl {
+
+template <int D_, int H_, int A_>
+struct GruShape {
+    static constexpr int D = D_, H = H_, A = A_;
+    static constexpr int DP = (D_ + 15) / 16 * 16, KS1 = DP / 4, MT = H_ / 16;
+    static_assert(H_ % 16 == 0 && A_ <= 16, "shape");
+    // canonical offsets
+    static constexpr int oW1 = 0, ob1 = oW1 + H_ * D_, oWih = ob1 + H_, oWhh = oWih + 3 * H_ * H_, obih = oWhh + 3 * H_ * H_,
+                         obhh = obih + 3 * H_, oW3 = obhh + 3 * H_, ob3 = oW3 + A_ * H_;
+    static constexpr int NPARAM = ob3 + A_;
+    // forward pack: A1[MT][KS1/4][64][4] | Gi[3][MT][MT][64][4] | Gh[3][MT][MT][64][4] | A3[MT][64][4] | b1[H] | bih[3H] | bhh[3H] | b3[16]
+    static constexpr int pA1 = 0, pGi = pA1 + MT * KS1 * 64, pGh = pGi + 3 * MT * MT * 256, pA3 = pGh + 3 * MT * MT * 256,
+                         pb1 = pA3 + MT * 256, pbih = pb1 + H_, pbhh = pbih + 3 * H_, pb3 = pbhh + 3 * H_;
+    static constexpr int NFWD = pb3 + 16;
+    static_assert(NFWD % 4 == 0, "pack is whole float4s");
+    static_assert(NFWD * 4 <= 156 * 1024, "the recurrent network's packs must fit the LDS (hidden 64)");
+    // per (step, 16-row block) activation record for the backward pass: 6 arrays x MT tiles x 64 lanes x f4
+    static constexpr int REC_ARRAYS = 6, REC = REC_ARRAYS * MT * 256;
+};
+
+template <class S>
+__device__ __forceinline__ float gru_fwd_pack_elem(const float* __restrict__ w, int idx) {
+    if (idx < S::pGi) {  // A1[mt][ks4][lane][e]: W1[16mt+i][4(4ks4+e)+g]
+        const int e = idx & 3, lane = (idx >> 2) & 63, rest = idx >> 8;
+        const int ks4 = rest % (S::KS1 / 4), mt = rest / (S::KS1 / 4);
+        const int o = 16 * mt + (lane & 15), k = 4 * (4 * ks4 + e) + (lane >> 4);
+        return k < S::D ? w[S::oW1 + o * S::D + k] : 0.f;
+    } else if (idx < S::pA3) {  // G?[gate][mt2][mt1][lane][r]: W[gate*H + 16mt2+i][16mt1+4g+r]
+        const bool hh = idx >= S::pGh;
+        const int j = idx - (hh ? S::pGh : S::pGi);
+        const int r = j & 3, lane = (j >> 2) & 63, rest = j >> 8;
+        const int mt1 = rest % S::MT, mt2 = (rest / S::MT) % S::MT, gate = rest / (S::MT * S::MT);
+        return w[(hh ? S::oWhh : S::oWih) + (gate * S::H + 16 * mt2 + (lane & 15)) * S::H + 16 * mt1 + 4 * (lane >> 4) + r];
+    } else if (idx < S::pb1) {  // A3[mt1][lane][r]: W3[i][16mt1+4g+r]
+        const int j = idx - S::pA3;
+        const int r = j & 3, lane = (j >> 2) & 63, mt1 = j >> 8, o = lane & 15;
+        return o < S::A ? w[S::oW3 + o * S::H + 16 * mt1 + 4 * (lane >> 4) + r] : 0.f;
+    } else if (idx < S::pbih) {
+        return w[S::ob1 + idx - S::pb1];
+    } else if (idx < S::pbhh) {
+        return w[S::obih + idx - S::pbih];
+    } else if (idx < S::pb3) {
+        return w[S::obhh + idx - S::pbhh];
+    }
+    const int o = idx - S::pb3;
+    return o < S::A ? w[S::ob3 + o] : 0.f;
+}
+
+template <class S>
+__global__ __launch_bounds__(256) void gru_pack_kernel(const float* __restrict__ params, AgentMap am, float* __restrict__ packs) {
+    const int p = blockIdx.y, idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx < S::NFWD) packs[(size_t)p * S::NFWD + idx] = gru_fwd_pack_elem<S>(params + (size_t)am.net[p] * S::NPARAM, idx);
+}
+
+__device__ __forceinline__ f4 sigmoid4(f4 v) {
+    f4 o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = 1.f / (1.f + expf(-v[r]));
+    return o;
+}
+
+__device__ __forceinline__ f4 tanh4(f4 v) {
+    f4 o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = tanhf(v[r]);
+    return o;
+}
+
+// gate pre-activations of one gate: out[mt] = bias[16mt+4g..] + sum_{mt1, r} G[gate][mt][mt1][lane][r] * b[mt1][r]
+template <class S>
+__device__ __forceinline__ void gru_gate(const float* lds, int pG, int pb, int gate, int lane, const f4 (&b)[S::MT], f4 (&out)[S::MT]) {
+    constexpr int MT = S::MT;
+    const int g = lane >> 4;
+    const f4* G = reinterpret_cast<const f4*>(lds + pG) + (size_t)gate * MT * MT * 64;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) out[mt] = *reinterpret_cast<const f4*>(lds + pb + gate * S::H + 16 * mt + 4 * g);
+#pragma unroll
+    for (int k1 = 0; k1 < MT; ++k1) {
+        f4 a[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) a[mt] = G[(mt * MT + k1) * 64 + lane];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) out[mt] = MARL_MFMA(a[mt][r], b[k1][r], out[mt]);
+    }
+}
+
+// obs: [P][S][B][D] (the dqn/train.py Batch layout; S = 1 for acting), q: [P][S][B][A], h_in / h_out: [P][B][H] or NULL,
+// rec: [P][S][nblk][REC] or NULL (nblk = ceil(B / 16))
+template <class S>
+__global__ __launch_bounds__(256) void gru_seq_fwd_kernel(const float* __restrict__ packs, const float* __restrict__ obs, int steps, int B,
+                                                          const float* __restrict__ h_in, float* __restrict__ h_out,
+                                                          float* __restrict__ q_out, float* __restrict__ rec) {
+    constexpr int MT = S::MT, D = S::D, H = S::H, A = S::A;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, j = lane & 15;
+    const int p = blockIdx.y;
+    copy_f4_to_lds(reinterpret_cast<const f4*>(packs + (size_t)p * S::NFWD), reinterpret_cast<f4*>(lds), S::NFWD / 4, tid, 256);
+    __syncthreads();
+    const int nblk = (B + 15) >> 4;
+    const int blk = blockIdx.x * 4 + wave;
+    if (blk >= nblk) return;
+    const int b0 = blk * 16;
+    const bool rowok = b0 + j < B;
+    const int bj = rowok ? b0 + j : B - 1;
+    f4 h[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        if (h_in != nullptr) h[mt] = *reinterpret_cast<const f4*>(h_in + ((size_t)p * B + bj) * H + 16 * mt + 4 * g);
+        else h[mt] = f4{0.f, 0.f, 0.f, 0.f};
+    }
+    const f4* A1 = reinterpret_cast<const f4*>(lds + S::pA1);
+    const f4* A3 = reinterpret_cast<const f4*>(lds + S::pA3);
+    for (int t = 0; t < steps; ++t) {
+        asm volatile("" ::: "memory");  // the packs never change, so the compiler would hoist every weight read out of the time
+                                        // loop (and spill ~1 KB per lane): re-read them from LDS each step
+        const float* xrow = obs + (((size_t)p * steps + t) * B + bj) * D;
+        float x[S::KS1];
+#pragma unroll
+        for (int ks = 0; ks < S::KS1; ++ks) {
+            const int d = 4 * ks + g;
+            x[ks] = (d < D && rowok) ? xrow[d < D ? d : D - 1] : 0.f;
+        }
+        // x1 = relu(W1 x + b1)
+        f4 x1[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) x1[mt] = *reinterpret_cast<const f4*>(lds + S::pb1 + 16 * mt + 4 * g);
+#pragma unroll
+        for (int ks4 = 0; ks4 < S::KS1 / 4; ++ks4) {
+            f4 a[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) a[mt] = A1[(mt * (S::KS1 / 4) + ks4) * 64 + lane];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) x1[mt] = MARL_MFMA(a[mt][e], x[4 * ks4 + e], x1[mt]);
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) x1[mt] = relu4(x1[mt]);
+        // gates (torch.nn.GRU): r, z, n
+        f4 gi[MT], gh[MT], rg[MT], zg[MT], ng[MT], ghn[MT];
+        gru_gate<S>(lds, S::pGi, S::pbih, 0, lane, x1, gi);
+        gru_gate<S>(lds, S::pGh, S::pbhh, 0, lane, h, gh);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) rg[mt] = sigmoid4(gi[mt] + gh[mt]);
+        gru_gate<S>(lds, S::pGi, S::pbih, 1, lane, x1, gi);
+        gru_gate<S>(lds, S::pGh, S::pbhh, 1, lane, h, gh);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) zg[mt] = sigmoid4(gi[mt] + gh[mt]);
+        gru_gate<S>(lds, S::pGi, S::pbih, 2, lane, x1, gi);
+        gru_gate<S>(lds, S::pGh, S::pbhh, 2, lane, h, ghn);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            ng[mt] = tanh4(gi[mt] + rg[mt] * ghn[mt]);
+            h[mt] = (1.f - zg[mt]) * ng[mt] + zg[mt] * h[mt];
+        }
+        if (rec != nullptr) {
+            f4* R = reinterpret_cast<f4*>(rec + (((size_t)p * steps + t) * nblk + blk) * S::REC);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                R[(0 * MT + mt) * 64 + lane] = x1[mt];
+                R[(1 * MT + mt) * 64 + lane] = rg[mt];
+                R[(2 * MT + mt) * 64 + lane] = zg[mt];
+                R[(3 * MT + mt) * 64 + lane] = ng[mt];
+                R[(4 * MT + mt) * 64 + lane] = h[mt];
+                R[(5 * MT + mt) * 64 + lane] = ghn[mt];
+            }
+        }
+        // q = W3 h + b3
+        f4 q = *reinterpret_cast<const f4*>(lds + S::pb3 + 4 * g);
+#pragma unroll
+        for (int k1 = 0; k1 < MT; ++k1) {
+            const f4 a = A3[k1 * 64 + lane];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) q = MARL_MFMA(a[r], h[k1][r], q);
+        }
+        if (rowok) {
+            float* qo = q_out + (((size_t)p * steps + t) * B + b0 + j) * A;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (4 * g + r < A) qo[4 * g + r] = q[r];
+        }
+    }
+    if (h_out != nullptr && rowok) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) *reinterpret_cast<f4*>(h_out + ((size_t)p * B + b0 + j) * H + 16 * mt + 4 * g) = h[mt];
+    }
+}
+
+}  // namespace marl

@@ -567,3 +567,17 @@ def ac_collect(cfg, spec: NetSpec, actor_params, round_idx, max_len, use_proper_
     check(fn(ctypes.byref(cfg), ctypes.byref(s), _ptr(actor_params), int(round_idx) & 0xFFFFFFFF, int(max_len),
                                  int(bool(use_proper_termination)), _ptr(b_obs), _ptr(b_act), _ptr(b_rew), _ptr(b_done),
                                  _ptr(b_filled), _ptr(fin_return), _ptr(fin_length), _ptr(t_max), _stream()), "ac_collect")
+
+
+def gru_forward(spec: NetSpec, params, obs, h_in=None, want_h=False, record=None):
+    """recurrent Q-networks (use_rnn): obs f32 [P][S][B][D] on the device -> q [P][S][B][A] (and the final hidden state
+    [P][B][H] when want_h); h_in [P][B][H] or None (zeros).  `record`: float tensor of marlhip_gru_record_floats for BPTT."""
+    _require_gpu()
+    P, S, B, D = obs.shape
+    assert obs.is_contiguous() and obs.dtype == torch.float32 and D == spec.obs_dim and P == spec.n_agents
+    q = torch.empty(P, S, B, spec.n_actions, device=obs.device)
+    h_out = torch.empty(P, B, spec.hidden, device=obs.device) if want_h else None
+    s = spec.c()
+    check(lib.marlhip_gru_forward(ctypes.byref(s), _ptr(params), _ptr(obs), S, B, _ptr(h_in), _ptr(h_out), _ptr(q), _ptr(record),
+                                  _stream()), "gru_forward")
+    return (q, h_out) if want_h else q

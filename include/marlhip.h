@@ -303,6 +303,22 @@ int marlhip_ac_collect(const marlhip_lbf_config* cfg, const marlhip_net_shape* s
                        float* fin_return /* [P][N] */, int32_t* fin_length /* [N] */, int32_t* t_max /* [1] */,
                        void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Recurrent Q-networks (`use_rnn: True`; RNNNetwork, marlbase/utils/models.py:51-116): Linear(D, H) -> ReLU -> one-layer
+ * nn.GRU(H, H) -> Linear(H, A), compiled for hidden 64.  One agent's block in parameters() order:
+ *   first_layer.weight [H][D] | .bias [H] | rnn.weight_ih_l0 [3H][H] | rnn.weight_hh_l0 [3H][H] | rnn.bias_ih_l0 [3H] |
+ *   rnn.bias_hh_l0 [3H] | final_layer.weight [A][H] | .bias [A]                       (gate order r, z, n)
+ * marlhip_gru_forward: q[p][t][b][:] for t = 0..steps-1 of the sequences obs [P][steps][B][D], from the hidden state h_in
+ * [P][B][H] (NULL = zeros: `hiddens=None`, dqn/model.py:127,133), final hidden state to h_out (NULL = not wanted).
+ * steps = 1 is QNetwork.act's forward (dqn/model.py:99) with the caller carrying the hidden state; steps = T+1 is the
+ * learner's.  record (NULL or marlhip_gru_record_floats floats) receives the per-step activations the backward pass reads.
+ * ---------------------------------------------------------------------------------------- */
+int marlhip_gru_nparams(const marlhip_net_shape* s); /* per agent block; <0 if the shape has no recurrent kernel */
+int64_t marlhip_gru_record_floats(const marlhip_net_shape* s, int32_t steps, int32_t batch);
+int marlhip_gru_forward(const marlhip_net_shape* s, const float* params /* [P][nparams] */, const float* obs, int32_t steps,
+                        int32_t batch, const float* h_in, float* h_out, float* q_out /* [P][steps][B][A] */, float* record,
+                        void* stream);
+
 /* the two fused collectors on the warehouse env (same contracts; net shape D = 71, A = 5; compiled for the tiny layouts,
  * 2 and 4 agents: the shelf layer of a workgroup's 64 envs lives in LDS behind the weight packs) */
 int marlhip_rware_idqn_collect(const marlhip_rware_config* cfg, const marlhip_net_shape* s, const float* params, float epsilon,

@@ -38,3 +38,32 @@ def test_oracle_port_matches_reference(name, mode):
             if top[-1] - top[-2] > 1e-5:
                 assert int(q.argmax()) == g["act_actions"][t, p]
             np.testing.assert_allclose(h[p][0].numpy(), g["act_hiddens"][t, p], rtol=0, atol=2e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,mode", FILES)
+def test_hip_forward_matches_reference(name, mode):
+    from codebase_amd import hip as h
+
+    g, batch = load(name)
+    P, D, H, A = int(g["P"]), int(g["D"]), int(g["H"]), int(g["A"])
+    spec = h.NetSpec(P, D, H, A)
+    params = torch.tensor(g["params0"]).cuda()
+    q = h.gru_forward(spec, params, batch["obss"].cuda().contiguous())
+    np.testing.assert_allclose(q.cpu().numpy(), g["q0"], rtol=0, atol=5e-6)
+    # one step at a time with the hidden state carried by the caller == the whole sequence at once
+    hid, outs = None, []
+    for t in range(batch["obss"].shape[1]):
+        qt, hid = h.gru_forward(spec, params, batch["obss"][:, t:t + 1].cuda().contiguous(), h_in=hid, want_h=True)
+        outs.append(qt)
+    np.testing.assert_allclose(torch.cat(outs, 1).cpu().numpy(), q.cpu().numpy(), rtol=0, atol=1e-6)
+    # the reference's act trace: greedy actions + hidden states
+    hid = None
+    for t in range(6):
+        qt, hid = h.gru_forward(spec, params, torch.tensor(g["act_obs"][t]).reshape(P, 1, 1, D).cuda(), h_in=hid, want_h=True)
+        np.testing.assert_allclose(hid[:, 0].cpu().numpy(), g["act_hiddens"][t], rtol=0, atol=5e-6)
+        qn = qt[:, 0, 0].cpu().numpy()
+        for p in range(P):
+            top = np.sort(qn[p])
+            if top[-1] - top[-2] > 1e-5:
+                assert int(qn[p].argmax()) == g["act_actions"][t, p]
