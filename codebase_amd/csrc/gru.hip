@@ -1,5 +1,5 @@
 // extern "C" entry points of the recurrent (use_rnn) Q-network path; kernels in gru.h / gru_bwd.h
-#include "gru.h"
+#include "gru_bwd.h"
 #include "collect_common.h"
 
 using namespace marl;
@@ -57,6 +57,109 @@ extern "C" int marlhip_gru_forward(const marlhip_net_shape* s, const float* para
     MARL_REQUIRE(params && obs && q_out && steps > 0 && batch > 0, "gru_forward: bad argument");
 #define X(d, a) \
     if (s->obs_dim == d && s->n_actions == a) return gru_forward<GruShape<d, 64, a>>(s, params, obs, steps, batch, h_in, h_out, q_out, record, (hipStream_t)stream);
+    MARL_GRU_SHAPES(X)
+#undef X
+    return -1;
+}
+
+// ---- learner step: QNetwork._compute_loss / VDNetwork._compute_loss + backward with recurrent networks ----------------------
+namespace {
+struct GruWs {
+    int64_t q, tq, dq, lrow, rec, rec2, partials, packC, packT, packB, total;
+    int nwg;
+};
+
+template <class S>
+GruWs gru_ws_layout(int P, int T, int B) {
+    const int64_t steps = T + 1, nblk = (B + 15) / 16;
+    GruWs w;
+    int64_t off = 0;
+    auto take = [&](int64_t floats) { const int64_t o = off; off += (floats * 4 + 255) / 256 * 256; return o; };
+    w.q = take(P * steps * B * S::A);
+    w.tq = take(P * steps * B * S::A);
+    w.dq = take(P * steps * B * S::A);
+    w.lrow = take((int64_t)T * B);
+    w.rec = take(P * steps * nblk * S::REC);
+    w.rec2 = take(P * steps * nblk * GruBwd<S>::REC2);
+    const int64_t items = steps * nblk;
+    const int cap = 256 / P > 1 ? 256 / P : 1;
+    w.nwg = (int)(items < cap ? items : cap);
+    w.partials = take((int64_t)P * w.nwg * (S::NPARAM + 2));
+    w.packC = take((int64_t)P * S::NFWD);
+    w.packT = take((int64_t)P * S::NFWD);
+    w.packB = take((int64_t)P * GruBwd<S>::NBWD);
+    w.total = off;
+    return w;
+}
+
+template <class S>
+int gru_loss_grad(const marlhip_net_shape* s, const float* params, const float* target, const marlhip_batch* bt, float gamma, int double_q,
+                  int mode, void* ws, int64_t ws_bytes, float* grad, float* loss, hipStream_t st) {
+    using Bk = GruBwd<S>;
+    const int P = s->n_agents, T = bt->max_len, B = bt->batch, steps = T + 1;
+    const GruWs wl = gru_ws_layout<S>(P, T, B);
+    MARL_REQUIRE(ws_bytes >= wl.total, "gru_loss_grad: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)wl.total);
+    char* base = static_cast<char*>(ws);
+    auto f = [&](int64_t o) { return reinterpret_cast<float*>(base + o); };
+    const AgentMap am = agent_map(s);
+    hipLaunchKernelGGL((gru_pack_kernel<S>), dim3((S::NFWD + 255) / 256, P), dim3(256), 0, st, params, am, f(wl.packC));
+    hipLaunchKernelGGL((gru_pack_kernel<S>), dim3((S::NFWD + 255) / 256, P), dim3(256), 0, st, target, am, f(wl.packT));
+    hipLaunchKernelGGL((gru_bwd_pack_kernel<S>), dim3((Bk::NBWD + 255) / 256, P), dim3(256), 0, st, params, am, f(wl.packB));
+    MARL_CHECK_LAUNCH("gru pack kernels");
+    const size_t ldsF = (size_t)S::NFWD * sizeof(float), ldsB = (size_t)Bk::NBWD * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_seq_fwd_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsF);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_seq_bwd_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsB);
+        attr = true;
+    }
+    const dim3 gridS((B + 63) / 64, P);
+    timing_begin(TIMER_LOSSGRAD, st);
+    hipLaunchKernelGGL((gru_seq_fwd_kernel<S>), gridS, dim3(256), ldsF, st, (const float*)f(wl.packC), bt->obss, steps, B, (const float*)nullptr,
+                       (float*)nullptr, f(wl.q), f(wl.rec));
+    hipLaunchKernelGGL((gru_seq_fwd_kernel<S>), gridS, dim3(256), ldsF, st, (const float*)f(wl.packT), bt->obss, steps, B, (const float*)nullptr,
+                       (float*)nullptr, f(wl.tq), (float*)nullptr);
+    MARL_CHECK_LAUNCH("gru_seq_fwd_kernel");
+    (void)hipMemsetAsync(f(wl.dq), 0, (size_t)P * steps * B * S::A * sizeof(float), st);
+    hipLaunchKernelGGL(gru_td_kernel, dim3((T * B + 255) / 256), dim3(256), 0, st, P, T, B, S::A, (const float*)f(wl.q), (const float*)f(wl.tq), *bt,
+                       gamma, double_q, mode == 1 ? 1 : 0, f(wl.dq), f(wl.lrow));
+    MARL_CHECK_LAUNCH("gru_td_kernel");
+    hipLaunchKernelGGL((gru_seq_bwd_kernel<S>), gridS, dim3(256), ldsB, st, (const float*)f(wl.packB), steps, B, (const float*)f(wl.rec),
+                       (const float*)f(wl.dq), f(wl.rec2));
+    MARL_CHECK_LAUNCH("gru_seq_bwd_kernel");
+    hipLaunchKernelGGL((gru_wgrad_kernel<S>), dim3(wl.nwg, P), dim3(256), 0, st, steps, B, bt->obss, (const float*)f(wl.rec), (const float*)f(wl.rec2),
+                       (const float*)f(wl.dq), (const float*)f(wl.lrow), bt->filled, f(wl.partials));
+    MARL_CHECK_LAUNCH("gru_wgrad_kernel");
+    const int n = P * S::NPARAM;
+    hipLaunchKernelGGL(dqn_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, st, (const float*)f(wl.partials), P, wl.nwg, S::NPARAM, am, grad, loss);
+    timing_end(TIMER_LOSSGRAD, st);
+    MARL_CHECK_LAUNCH("dqn_reduce_kernel");
+    return 0;
+}
+}  // namespace
+
+extern "C" int64_t marlhip_gru_workspace_bytes(const marlhip_net_shape* s, int32_t max_len, int32_t batch) {
+    if (gru_check(s) != 0) return -1;
+#define X(d, a) if (s->obs_dim == d && s->n_actions == a) return gru_ws_layout<GruShape<d, 64, a>>(s->n_agents, max_len, batch).total;
+    MARL_GRU_SHAPES(X)
+#undef X
+    return -1;
+}
+
+extern "C" int marlhip_gru_loss_grad(const marlhip_net_shape* s, const float* params, const float* target_params, const marlhip_batch* batch,
+                                     float gamma, int32_t double_q, int32_t mode, void* workspace, int64_t workspace_bytes, float* grad,
+                                     float* loss, void* stream) {
+    if (gru_check(s) != 0) return -1;
+    MARL_REQUIRE(params && target_params && batch && workspace && grad && loss, "gru_loss_grad: NULL pointer");
+    MARL_REQUIRE(mode == 0 || mode == 1, "gru_loss_grad: mode %d (0 = IDQN, 1 = VDN; the recurrent QMIX path is not built)", mode);
+    MARL_REQUIRE(s->n_networks == 0, "gru_loss_grad: parameter sharing is not built for recurrent networks");
+    MARL_REQUIRE(batch->obss && batch->actions && batch->rewards && batch->dones && batch->filled && batch->max_len > 0 && batch->batch > 0,
+                 "gru_loss_grad: bad batch");
+    MARL_REQUIRE(batch->obs_agent_stride == 0 && batch->obs_row_stride == 0, "gru_loss_grad: the dqn/train.py Batch layout only");
+#define X(d, a)                                                  \
+    if (s->obs_dim == d && s->n_actions == a)                    \
+        return gru_loss_grad<GruShape<d, 64, a>>(s, params, target_params, batch, gamma, double_q, mode, workspace, workspace_bytes, grad, loss, \
+                                                 (hipStream_t)stream);
     MARL_GRU_SHAPES(X)
 #undef X
     return -1;

@@ -1,0 +1,381 @@
+// Backward of the recurrent Q-networks (BPTT through gru_seq_fwd_kernel's activation record) and the TD error.
+//   gru_td_kernel      : online q / target q of every observation -> dL/dq rows (dense [P][T+1][B][A], unnormalised) and
+//                        the per-row loss (QNetwork._compute_loss dqn/model.py:118-163, VDNetwork :224-269)
+//   gru_seq_bwd_kernel : a wave walks its 16 sequences BACKWARDS with dL/dh in registers: dh += W3^T dq, the gate
+//                        derivatives of the GRU cell, dh_prev = dh z + W_hh^T dgh, dx1 = relu'(W_ih^T dgi); the per-step
+//                        gate gradients (dr, dz, dn, r*dn, dx1) go to a second record
+//   gru_wgrad_kernel   : the weight gradients are plain sums over all (t, b) rows of outer products of the two records
+//                        (dW_ih = dgi^T x1, dW_hh = dgh^T h_prev, dW1 = dx1^T x, dW3 = dq^T h): one workgroup pass, the
+//                        four waves own disjoint parameter slices (gate r / z / n, and first + output layer), operands
+//                        transposed through LDS tiles as in the feed-forward kernels; one partial record per workgroup,
+//                        summed in fixed order by dqn_reduce_kernel.
+#pragma once
+#include "dqn_update_kernels.h"
+#include "gru.h"
+
+namespace marl {
+
+template <class S>
+struct GruBwd {
+    static constexpr int MT = S::MT;
+    // backward-data pack: T3[MT][64][4] | Thh[3][MT][MT][64][4] | Tih[3][MT][MT][64][4]
+    static constexpr int pT3 = 0, pThh = pT3 + MT * 256, pTih = pThh + 3 * MT * MT * 256, NBWD = pTih + 3 * MT * MT * 256;
+    static constexpr int REC2_ARRAYS = 5, REC2 = REC2_ARRAYS * MT * 256;  // dr, dz, dn, r * dn, dx1
+};
+
+template <class S>
+__device__ __forceinline__ float gru_bwd_pack_elem(const float* __restrict__ w, int idx) {
+    using Bk = GruBwd<S>;
+    if (idx < Bk::pThh) {  // T3[mt][lane][r]: A[i = unit 16mt+i][k = a 4g+r] = W3[4g+r][16mt+i]
+        const int r = idx & 3, lane = (idx >> 2) & 63, mt = idx >> 8;
+        const int a = 4 * (lane >> 4) + r;
+        return a < S::A ? w[S::oW3 + a * S::H + 16 * mt + (lane & 15)] : 0.f;
+    }
+    // T??[gate][mt1][mt2][lane][r]: A[i = input unit 16mt1+i][k = gate unit 16mt2+4g+r] = W[gate*H + 16mt2+4g+r][16mt1+i]
+    const bool ih = idx >= Bk::pTih;
+    const int j = idx - (ih ? Bk::pTih : Bk::pThh);
+    const int r = j & 3, lane = (j >> 2) & 63, rest = j >> 8;
+    const int mt2 = rest % S::MT, mt1 = (rest / S::MT) % S::MT, gate = rest / (S::MT * S::MT);
+    return w[(ih ? S::oWih : S::oWhh) + (gate * S::H + 16 * mt2 + 4 * (lane >> 4) + r) * S::H + 16 * mt1 + (lane & 15)];
+}
+
+template <class S>
+__global__ __launch_bounds__(256) void gru_bwd_pack_kernel(const float* __restrict__ params, AgentMap am, float* __restrict__ packs) {
+    const int p = blockIdx.y, idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx < GruBwd<S>::NBWD) packs[(size_t)p * GruBwd<S>::NBWD + idx] = gru_bwd_pack_elem<S>(params + (size_t)am.net[p] * S::NPARAM, idx);
+}
+
+// q, tq: [P][T+1][B][A]; dq: [P][T+1][B][A] (row T stays zero); lrow: [T][B]
+static __global__ __launch_bounds__(256) void gru_td_kernel(int P, int T, int B, int A, const float* __restrict__ q, const float* __restrict__ tq,
+                                                     marlhip_batch bt, float gamma, int double_q, int vdn, float* __restrict__ dq,
+                                                     float* __restrict__ lrow) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= T * B) return;
+    const int t = i / B, b = i - t * B;
+    const float fl = bt.filled[i], dn = bt.dones[(size_t)(t + 1) * B + b];
+    float tot_ch = 0.f, tot_tq = 0.f, loss = 0.f;
+    for (int p = 0; p < P; ++p) {
+        const float* qn = q + (((size_t)p * (T + 1) + t + 1) * B + b) * A;
+        const float* tn = tq + (((size_t)p * (T + 1) + t + 1) * B + b) * A;
+        const float* mk = bt.action_mask ? bt.action_mask + (((size_t)p * (T + 1) + t + 1) * B + b) * A : nullptr;
+        int best = 0;
+        float bv = -__builtin_huge_valf();
+        for (int a = 0; a < A; ++a) {  // first index of the maximum (torch.argmax), over the online (Double-Q) or target values
+            float v = double_q ? qn[a] : tn[a];
+            if (mk != nullptr && mk[a] == 0.f) v = -1e8f;
+            if (v > bv) { bv = v; best = a; }
+        }
+        float boot = tn[best];
+        if (mk != nullptr && mk[best] == 0.f) boot = -1e8f;
+        const int act = (int)bt.actions[((size_t)p * T + t) * B + b];
+        const float ch = q[(((size_t)p * (T + 1) + t) * B + b) * A + act];
+        if (vdn) {
+            tot_ch += ch;
+            tot_tq += boot;
+        } else {
+            const float y = bt.rewards[((size_t)p * T + t) * B + b] + gamma * boot * (1.f - dn);
+            const float delta = ch - y;
+            loss += delta * delta;
+            for (int a = 0; a < A; ++a) dq[(((size_t)p * (T + 1) + t) * B + b) * A + a] = a == act ? 2.f * fl * delta : 0.f;
+        }
+    }
+    if (vdn) {
+        const float y = bt.rewards[(size_t)t * B + b] + gamma * tot_tq * (1.f - dn);  // batch.rewards[0] (model.py:228)
+        const float delta = tot_ch - y;
+        loss = delta * delta;
+        for (int p = 0; p < P; ++p) {
+            const int act = (int)bt.actions[((size_t)p * T + t) * B + b];
+            for (int a = 0; a < A; ++a) dq[(((size_t)p * (T + 1) + t) * B + b) * A + a] = a == act ? 2.f * fl * delta : 0.f;
+        }
+    }
+    lrow[i] = fl * loss;
+}
+
+// transposed product: out[mt1] += sum_{gate-unit tiles mt2, r} T[gate][mt1][mt2][lane][r] * dg[mt2][r]
+template <class S>
+__device__ __forceinline__ void gru_tgate(const float* lds, int pT, int gate, int lane, const f4 (&dg)[S::MT], f4 (&out)[S::MT]) {
+    constexpr int MT = S::MT;
+    const f4* Tm = reinterpret_cast<const f4*>(lds + pT) + (size_t)gate * MT * MT * 64;
+#pragma unroll
+    for (int m2 = 0; m2 < MT; ++m2) {
+        f4 a[MT];
+#pragma unroll
+        for (int m1 = 0; m1 < MT; ++m1) a[m1] = Tm[(m1 * MT + m2) * 64 + lane];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int m1 = 0; m1 < MT; ++m1) out[m1] = MARL_MFMA(a[m1][r], dg[m2][r], out[m1]);
+    }
+}
+
+// rec: forward record [P][S][nblk][REC]; dq: [P][S][B][A]; rec2: [P][S][nblk][REC2]
+template <class S>
+__global__ __launch_bounds__(256) void gru_seq_bwd_kernel(const float* __restrict__ packs, int steps, int B, const float* __restrict__ rec,
+                                                          const float* __restrict__ dq, float* __restrict__ rec2) {
+    using Bk = GruBwd<S>;
+    constexpr int MT = S::MT, A = S::A;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, j = lane & 15;
+    const int p = blockIdx.y;
+    copy_f4_to_lds(reinterpret_cast<const f4*>(packs + (size_t)p * Bk::NBWD), reinterpret_cast<f4*>(lds), Bk::NBWD / 4, tid, 256);
+    __syncthreads();
+    const int nblk = (B + 15) >> 4;
+    const int blk = blockIdx.x * 4 + wave;
+    if (blk >= nblk) return;
+    const int b0 = blk * 16;
+    const bool rowok = b0 + j < B;
+    const int bj = rowok ? b0 + j : B - 1;
+    const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const f4* T3 = reinterpret_cast<const f4*>(lds + Bk::pT3);
+    f4 carry[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) carry[mt] = zero4;
+    for (int t = steps - 1; t >= 0; --t) {
+        asm volatile("" ::: "memory");  // keep the weight reads inside the loop (see gru_seq_fwd_kernel)
+        const f4* R = reinterpret_cast<const f4*>(rec + (((size_t)p * steps + t) * nblk + blk) * S::REC);
+        const f4* Rp = reinterpret_cast<const f4*>(rec + (((size_t)p * steps + (t > 0 ? t - 1 : 0)) * nblk + blk) * S::REC);
+        f4 x1[MT], rg[MT], zg[MT], ng[MT], ghn[MT], hp[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            x1[mt] = R[(0 * MT + mt) * 64 + lane];
+            rg[mt] = R[(1 * MT + mt) * 64 + lane];
+            zg[mt] = R[(2 * MT + mt) * 64 + lane];
+            ng[mt] = R[(3 * MT + mt) * 64 + lane];
+            ghn[mt] = R[(5 * MT + mt) * 64 + lane];
+            hp[mt] = t > 0 ? Rp[(4 * MT + mt) * 64 + lane] : zero4;
+        }
+        f4 dQ;
+        {
+            const float* drow = dq + (((size_t)p * steps + t) * B + bj) * A;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dQ[r] = (rowok && 4 * g + r < A) ? drow[4 * g + r < A ? 4 * g + r : A - 1] : 0.f;
+        }
+        // dh = carried + W3^T dq
+        f4 dh[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            dh[mt] = carry[mt];
+            const f4 a = T3[mt * 64 + lane];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dh[mt] = MARL_MFMA(a[r], dQ[r], dh[mt]);
+        }
+        // gate derivatives (h' = (1 - z) n + z h;  n = tanh(gi_n + r ghn);  r, z = sigmoid(...))
+        f4 dr[MT], dz[MT], dng[MT], drn[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            dng[mt] = dh[mt] * (1.f - zg[mt]) * (1.f - ng[mt] * ng[mt]);
+            dz[mt] = dh[mt] * (hp[mt] - ng[mt]) * zg[mt] * (1.f - zg[mt]);
+            drn[mt] = dng[mt] * rg[mt];
+            dr[mt] = dng[mt] * ghn[mt] * rg[mt] * (1.f - rg[mt]);
+            carry[mt] = dh[mt] * zg[mt];
+        }
+        gru_tgate<S>(lds, Bk::pThh, 0, lane, dr, carry);
+        gru_tgate<S>(lds, Bk::pThh, 1, lane, dz, carry);
+        gru_tgate<S>(lds, Bk::pThh, 2, lane, drn, carry);
+        f4 dx1[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) dx1[mt] = zero4;
+        gru_tgate<S>(lds, Bk::pTih, 0, lane, dr, dx1);
+        gru_tgate<S>(lds, Bk::pTih, 1, lane, dz, dx1);
+        gru_tgate<S>(lds, Bk::pTih, 2, lane, dng, dx1);
+        f4* R2 = reinterpret_cast<f4*>(rec2 + (((size_t)p * steps + t) * nblk + blk) * Bk::REC2);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dx1[mt][r] = x1[mt][r] > 0.f ? dx1[mt][r] : 0.f;
+            R2[(0 * MT + mt) * 64 + lane] = dr[mt];
+            R2[(1 * MT + mt) * 64 + lane] = dz[mt];
+            R2[(2 * MT + mt) * 64 + lane] = dng[mt];
+            R2[(3 * MT + mt) * 64 + lane] = drn[mt];
+            R2[(4 * MT + mt) * 64 + lane] = dx1[mt];
+        }
+    }
+}
+
+// One partial record [NPARAM + 2] per workgroup (canonical parameter order, then loss and n_filled from agent 0's rows).
+template <class S>
+__global__ __launch_bounds__(256) void gru_wgrad_kernel(int steps, int B, const float* __restrict__ obs, const float* __restrict__ rec,
+                                                        const float* __restrict__ rec2, const float* __restrict__ dq,
+                                                        const float* __restrict__ lrow, const float* __restrict__ filled,
+                                                        float* __restrict__ partials) {
+    using Bk = GruBwd<S>;
+    constexpr int MT = S::MT, H = S::H, D = S::D, A = S::A, NT1 = S::DP / 16, TILE = 16 * H;
+    __shared__ __attribute__((aligned(16))) float tiles[8 * TILE + 256];
+    float* Tdr = tiles;             // gate gradients, [unit][16 rows]
+    float* Tdz = Tdr + TILE;
+    float* Tdn = Tdz + TILE;
+    float* Tdrn = Tdn + TILE;
+    float* Tx1 = Tdrn + TILE;
+    float* Thp = Tx1 + TILE;
+    float* Tdx = Thp + TILE;
+    float* Th = Tdx + TILE;
+    float* TQ = Th + TILE;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, j = lane & 15;
+    const int p = blockIdx.y, P = gridDim.y;
+    const int nblk = (B + 15) >> 4, T = steps - 1;
+    const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f4 dWa[MT][MT], dWb[MT][MT], dba[MT], dbb[MT];  // waves 0..2: dW_ih / dW_hh rows of their gate and the two bias sums
+    f4 dW1[MT][NT1], dW3[MT], db3 = zero4;           // wave 3 (its db1 lives in dba)
+#pragma unroll
+    for (int a = 0; a < MT; ++a) {
+        dba[a] = zero4; dbb[a] = zero4; dW3[a] = zero4;
+#pragma unroll
+        for (int b = 0; b < MT; ++b) { dWa[a][b] = zero4; dWb[a][b] = zero4; }
+#pragma unroll
+        for (int b = 0; b < NT1; ++b) dW1[a][b] = zero4;
+    }
+    float loss_acc = 0.f, nf_acc = 0.f;
+    const int total = steps * nblk;
+    for (int item = blockIdx.x; item < total; item += gridDim.x) {
+        const int t = item / nblk, blk = item - t * nblk;
+        const int b0 = blk * 16;
+        const f4* R = reinterpret_cast<const f4*>(rec + (((size_t)p * steps + t) * nblk + blk) * S::REC);
+        const f4* Rp = reinterpret_cast<const f4*>(rec + (((size_t)p * steps + (t > 0 ? t - 1 : 0)) * nblk + blk) * S::REC);
+        const f4* R2 = reinterpret_cast<const f4*>(rec2 + (((size_t)p * steps + t) * nblk + blk) * Bk::REC2);
+        // ---- each wave transposes the arrays it is responsible for into the shared tiles (rows beyond B carry zeros already:
+        //      their dq is zero, so every gradient array is zero there; x1 / h of padding rows multiply those zeros)
+        f4 mine[MT], other[MT];
+        if (wave == 0) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) { mine[mt] = R2[(0 * MT + mt) * 64 + lane]; other[mt] = R[(0 * MT + mt) * 64 + lane]; }
+            tile_write<MT>(Tdr, mine, g, j);
+            tile_write<MT>(Tx1, other, g, j);
+        } else if (wave == 1) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) { mine[mt] = R2[(1 * MT + mt) * 64 + lane]; other[mt] = t > 0 ? Rp[(4 * MT + mt) * 64 + lane] : zero4; }
+            tile_write<MT>(Tdz, mine, g, j);
+            tile_write<MT>(Thp, other, g, j);
+        } else if (wave == 2) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) { mine[mt] = R2[(2 * MT + mt) * 64 + lane]; other[mt] = R2[(3 * MT + mt) * 64 + lane]; }
+            tile_write<MT>(Tdn, mine, g, j);
+            tile_write<MT>(Tdrn, other, g, j);
+        } else {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) { mine[mt] = R2[(4 * MT + mt) * 64 + lane]; other[mt] = R[(4 * MT + mt) * 64 + lane]; }
+            tile_write<MT>(Tdx, mine, g, j);
+            tile_write<MT>(Th, other, g, j);
+            f4 dQ[1];
+            const bool rowok = b0 + j < B;
+            const float* drow = dq + (((size_t)p * steps + t) * B + (rowok ? b0 + j : B - 1)) * A;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dQ[0][r] = (rowok && 4 * g + r < A) ? drow[4 * g + r < A ? 4 * g + r : A - 1] : 0.f;
+            tile_write<1>(TQ, dQ, g, j);
+            db3 += dQ[0];
+            if (g == 0 && p == 0 && rowok && t < T) {
+                loss_acc += lrow[(size_t)t * B + b0 + j];
+                nf_acc += filled[(size_t)t * B + b0 + j];
+            }
+        }
+        __syncthreads();
+        if (wave < 3) {
+            // gate `wave`: dW_ih[gate rows][:] += dgi^T x1, dW_hh[gate rows][:] += dgh^T h_prev, bias sums of both
+            const float* Tgi = wave == 0 ? Tdr : (wave == 1 ? Tdz : Tdn);
+            const float* Tgh = wave == 0 ? Tdr : (wave == 1 ? Tdz : Tdrn);
+            f4 aI[MT], aH[MT], bX[MT], bH[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                aI[mt] = tile_read(Tgi, mt, g, j);
+                aH[mt] = tile_read(Tgh, mt, g, j);
+                bX[mt] = tile_read(Tx1, mt, g, j);
+                bH[mt] = tile_read(Thp, mt, g, j);
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                    for (int nt = 0; nt < MT; ++nt) {
+                        dWa[mt][nt] = MARL_MFMA(aI[mt][ks], bX[nt][ks], dWa[mt][nt]);
+                        dWb[mt][nt] = MARL_MFMA(aH[mt][ks], bH[nt][ks], dWb[mt][nt]);
+                    }
+            // bias sums from the C-layout registers this wave loaded (gate r / z: dgi == dgh; gate n: dn and r * dn)
+            if (wave == 2) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) { dba[mt] += mine[mt]; dbb[mt] += other[mt]; }
+            } else {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) { dba[mt] += mine[mt]; dbb[mt] += mine[mt]; }
+            }
+        } else {
+            // first layer: dW1 += dx1^T x (B operand straight from the observations), db1; output layer: dW3 += dq^T h, db3
+            f4 aX[MT], bHt[MT];
+            const f4 aQ = tile_read(TQ, 0, g, j);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                aX[mt] = tile_read(Tdx, mt, g, j);
+                bHt[mt] = tile_read(Th, mt, g, j);
+                dba[mt] += mine[mt];
+            }
+            float bx[NT1][4];
+#pragma unroll
+            for (int nt = 0; nt < NT1; ++nt)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int row = b0 + 4 * g + ks, d = 16 * nt + j;
+                    const float v = obs[(((size_t)p * steps + t) * B + (row < B ? row : B - 1)) * D + (d < D ? d : D - 1)];
+                    bx[nt][ks] = (row < B && d < D) ? v : 0.f;
+                }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+                for (int nt = 0; nt < MT; ++nt) dW3[nt] = MARL_MFMA(aQ[ks], bHt[nt][ks], dW3[nt]);
+#pragma unroll
+                for (int nt = 0; nt < NT1; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) dW1[mt][nt] = MARL_MFMA(aX[mt][ks], bx[nt][ks], dW1[mt][nt]);
+            }
+        }
+        __syncthreads();  // tiles are rewritten by the next item
+    }
+    // ---- record: every wave stores its own slices (no fold: the slices are disjoint)
+    float* recd = partials + ((size_t)p * gridDim.x + blockIdx.x) * (S::NPARAM + 2);
+    (void)P;
+    if (wave < 3) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int v = wave * H + 16 * mt + 4 * g + r;
+#pragma unroll
+                for (int nt = 0; nt < MT; ++nt) {
+                    recd[S::oWih + v * H + 16 * nt + j] = dWa[mt][nt][r];
+                    recd[S::oWhh + v * H + 16 * nt + j] = dWb[mt][nt][r];
+                }
+                const float sa = sum16(dba[mt][r]), sb = sum16(dbb[mt][r]);
+                if (j == 0) {
+                    recd[S::obih + v] = sa;
+                    recd[S::obhh + v] = sb;
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int v = 16 * mt + 4 * g + r;
+#pragma unroll
+                for (int nt = 0; nt < NT1; ++nt)
+                    if (16 * nt + j < D) recd[S::oW1 + v * D + 16 * nt + j] = dW1[mt][nt][r];
+                const float s1 = sum16(dba[mt][r]);
+                if (j == 0) recd[S::ob1 + v] = s1;
+                const int a = 4 * g + r;  // dW3[nt][r]: element (a, unit 16nt + j) - here `mt` plays nt
+                if (a < A) recd[S::oW3 + a * H + 16 * mt + j] = dW3[mt][r];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float s3 = sum16(db3[r]);
+            if (j == 0 && 4 * g + r < A) recd[S::ob3 + 4 * g + r] = s3;
+        }
+        // loss / n_filled: lanes g == 0 hold the per-row values; sum over the 16 rows
+        const float ls = sum16(loss_acc), nf = sum16(nf_acc);
+        if (lane == 0) {
+            recd[S::NPARAM] = ls;
+            recd[S::NPARAM + 1] = nf;
+        }
+    }
+}
+
+}  // namespace marl

@@ -581,3 +581,28 @@ def gru_forward(spec: NetSpec, params, obs, h_in=None, want_h=False, record=None
     check(lib.marlhip_gru_forward(ctypes.byref(s), _ptr(params), _ptr(obs), S, B, _ptr(h_in), _ptr(h_out), _ptr(q), _ptr(record),
                                   _stream()), "gru_forward")
     return (q, h_out) if want_h else q
+
+
+def gru_nparams(spec: NetSpec):
+    s = spec.c()
+    return check(lib.marlhip_gru_nparams(ctypes.byref(s)), "gru_nparams")
+
+
+def gru_loss_grad(spec: NetSpec, params, target, batch, gamma=0.99, double_q=True, mode=0, grad=None, loss=None, _cache={}):
+    """loss / gradient of the recurrent DQN-family learners (marlhip_gru_loss_grad); batch = hip.Batch on the device"""
+    _require_gpu()
+    T, B = batch.filled.shape
+    s = spec.c()
+    n = check(lib.marlhip_gru_workspace_bytes(ctypes.byref(s), T, B), "gru_workspace_bytes")
+    key = (params.device, n)
+    if key not in _cache:
+        _cache.clear()
+        _cache[key] = torch.empty(n, dtype=torch.uint8, device=params.device)
+    ws = _cache[key]
+    grad = torch.empty_like(params) if grad is None else grad
+    loss = torch.empty(2, device=params.device) if loss is None else loss
+    bs = BatchStruct(batch.obss.data_ptr(), batch.actions.data_ptr(), batch.rewards.data_ptr(), batch.dones.data_ptr(),
+                     batch.filled.data_ptr(), T, B, 0, 0, 0, 0, _mask_ptr(batch.action_mask, (spec.n_agents, T + 1, B, spec.n_actions)))
+    check(lib.marlhip_gru_loss_grad(ctypes.byref(s), _ptr(params), _ptr(target), ctypes.byref(bs), float(gamma), int(bool(double_q)), int(mode),
+                                    _ptr(ws), ws.numel(), _ptr(grad), _ptr(loss), _stream()), "gru_loss_grad")
+    return loss, grad

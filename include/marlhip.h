@@ -319,6 +319,15 @@ int marlhip_gru_forward(const marlhip_net_shape* s, const float* params /* [P][n
                         int32_t batch, const float* h_in, float* h_out, float* q_out /* [P][steps][B][A] */, float* record,
                         void* stream);
 
+/* QNetwork._compute_loss / VDNetwork._compute_loss + loss.backward() with recurrent networks (mode 0 / 1): sequence forward of
+ * the critic (activations recorded) and the target from zero hidden states, TD rows (Double-Q or max, action masks honoured),
+ * back-propagation through time, weight-gradient sums, deterministic record reduce.  grad [P][marlhip_gru_nparams], loss[2] =
+ * (loss, sum(filled)) as marlhip_dqn_loss_grad; afterwards marlhip_dqn_clip_adam as for the feed-forward networks. */
+int64_t marlhip_gru_workspace_bytes(const marlhip_net_shape* s, int32_t max_len, int32_t batch);
+int marlhip_gru_loss_grad(const marlhip_net_shape* s, const float* params, const float* target_params, const marlhip_batch* batch,
+                          float gamma, int32_t double_q, int32_t mode, void* workspace, int64_t workspace_bytes, float* grad,
+                          float* loss /* [2] */, void* stream);
+
 /* the two fused collectors on the warehouse env (same contracts; net shape D = 71, A = 5; compiled for the tiny layouts,
  * 2 and 4 agents: the shelf layer of a workgroup's 64 envs lives in LDS behind the weight packs) */
 int marlhip_rware_idqn_collect(const marlhip_rware_config* cfg, const marlhip_net_shape* s, const float* params, float epsilon,

@@ -67,3 +67,50 @@ def test_hip_forward_matches_reference(name, mode):
             top = np.sort(qn[p])
             if top[-1] - top[-2] > 1e-5:
                 assert int(qn[p].argmax()) == g["act_actions"][t, p]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,mode", FILES)
+def test_hip_loss_and_gradient_match_reference(name, mode):
+    from codebase_amd import hip as h
+
+    g, batch = load(name)
+    P, D, H, A = int(g["P"]), int(g["D"]), int(g["H"]), int(g["A"])
+    spec = h.NetSpec(P, D, H, A)
+    assert h.gru_nparams(spec) == g["params0"].shape[1]
+    hb = h.Batch(*(batch[k].cuda().contiguous() for k in ("obss", "actions", "rewards", "dones", "filled")), None)
+    loss, grad = h.gru_loss_grad(spec, torch.tensor(g["params0"]).cuda(), torch.tensor(g["target0"]).cuda(), hb, mode=1 if mode == "vdn" else 0)
+    assert abs(loss.cpu().numpy()[0] - g["loss0"]) <= 3e-5 * abs(g["loss0"])
+    assert loss.cpu().numpy()[1] == batch["filled"].sum().item()
+    gref = g["grad0"]
+    np.testing.assert_allclose(grad.cpu().numpy(), gref, rtol=3e-4, atol=3e-5 * max(1e-2, np.abs(gref).max()))
+    # bitwise reproducible
+    g1 = grad.clone()
+    _, g2 = h.gru_loss_grad(spec, torch.tensor(g["params0"]).cuda(), torch.tensor(g["target0"]).cuda(), hb, mode=1 if mode == "vdn" else 0)
+    assert torch.equal(g1, g2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("P,T,B,D,A,mode,dq", [(2, 25, 70, 15, 6, "idqn", True), (4, 6, 16, 27, 6, "vdn", False), (8, 5, 33, 39, 6, "idqn", True),
+                                               (4, 12, 20, 71, 5, "idqn", False), (2, 1, 1, 12, 6, "vdn", True)])
+def test_hip_loss_and_gradient_other_shapes_vs_port(P, T, B, D, A, mode, dq):
+    from codebase_amd import hip as h
+    from oracle import dqn_port as dp
+
+    H = 64
+    gen = torch.Generator().manual_seed(P * 100 + D)
+    params = 0.15 * torch.randn(P, gp.nparams(D, H, A), generator=gen)
+    target = params + 0.05 * torch.randn(P, gp.nparams(D, H, A), generator=gen)
+    batch = dp.synthetic_batch(P, T, B, D, A, seed=5)
+    batch["obss"] = batch["obss"] * 0.25
+    if mode == "vdn":
+        batch["rewards"][1:] = batch["rewards"][0]
+    pr = params.clone().requires_grad_(True)
+    ref = gp.compute_loss(pr, target, batch, 0.99, dq, D, H, A, mode=mode)
+    ref.backward()
+    spec = h.NetSpec(P, D, H, A)
+    hb = h.Batch(*(batch[k].cuda().contiguous() for k in ("obss", "actions", "rewards", "dones", "filled")), None)
+    loss, grad = h.gru_loss_grad(spec, params.cuda(), target.cuda(), hb, double_q=dq, mode=1 if mode == "vdn" else 0)
+    assert abs(loss.cpu().numpy()[0] - ref.item()) <= 5e-5 * max(abs(ref.item()), 1e-3)
+    gref = pr.grad.numpy()
+    np.testing.assert_allclose(grad.cpu().numpy(), gref, rtol=5e-4, atol=5e-5 * max(1e-2, np.abs(gref).max()))
