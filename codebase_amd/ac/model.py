@@ -45,7 +45,7 @@ class A2CNetwork:
             raise NotImplementedError("actor.parameter_sharing != critic.parameter_sharing: one agent -> network map serves both")
         for name, net in (("actor", actor), ("critic", critic)):
             if _get(net, "use_rnn", False):
-                raise NotImplementedError(f"{name}.use_rnn: the GRU path is a 'next' row (DESIGN.md)")
+                raise NotImplementedError(f"{name}.use_rnn: recurrent networks are built for the DQN family (QNetwork / VDNetwork) only (DESIGN.md)")
         ha, hc = [int(h) for h in _get(actor, "layers")], [int(h) for h in _get(critic, "layers")]
         if ha != hc or len(ha) != 2 or ha[0] != ha[1]:
             raise NotImplementedError(f"layers actor={ha} critic={hc}: the HIP kernels implement two equal hidden layers (64 or 128), "

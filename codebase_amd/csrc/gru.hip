@@ -164,3 +164,30 @@ extern "C" int marlhip_gru_loss_grad(const marlhip_net_shape* s, const float* pa
 #undef X
     return -1;
 }
+
+static __global__ __launch_bounds__(256) void act_from_q_kernel(int P, int N, int A, const float* __restrict__ q, float eps, uint64_t seed,
+                                                         const uint32_t* __restrict__ episode, const int32_t* __restrict__ ep_length,
+                                                         int32_t* __restrict__ actions) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const uint32_t epi = episode[n], t = (uint32_t)ep_length[n];
+    const bool explore = eps > u01_f32(act_noise_word(seed, (uint32_t)n, epi, t, 0));
+    for (int p = 0; p < P; ++p) {
+        const float* row = q + ((size_t)p * N + n) * A;
+        int best = 0;
+        float bv = row[0];
+        for (int a = 1; a < A; ++a)
+            if (row[a] > bv) { bv = row[a]; best = a; }
+        const int ra = (int)bounded_nr(act_noise_word(seed, (uint32_t)n, epi, t, 1 + p), (uint32_t)A);
+        actions[(size_t)p * N + n] = explore ? ra : best;
+    }
+}
+
+extern "C" int marlhip_act_from_q(int32_t n_agents, int32_t n_envs, int32_t n_actions, const float* q, float epsilon, uint64_t seed,
+                                  const uint32_t* episode, const int32_t* ep_length, int32_t* actions, void* stream) {
+    MARL_REQUIRE(q && episode && ep_length && actions && n_agents > 0 && n_envs > 0 && n_actions > 0, "act_from_q: bad argument");
+    hipLaunchKernelGGL(act_from_q_kernel, dim3((n_envs + 255) / 256), dim3(256), 0, (hipStream_t)stream, n_agents, n_envs, n_actions, q, epsilon, seed,
+                       episode, ep_length, actions);
+    MARL_CHECK_LAUNCH("act_from_q_kernel");
+    return 0;
+}

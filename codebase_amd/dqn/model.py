@@ -73,6 +73,32 @@ def init_flat_params(obs_dims, hidden_dims, act_dims, use_orthogonal_init=True, 
     return critic, critic.clone()  # hard_update (dqn/model.py:60)
 
 
+def _gru_layout(D, H, A):
+    """RNNNetwork's parameters() order (utils/models.py:83-92)"""
+    return [("first_layer.weight", (H, D)), ("first_layer.bias", (H,)), ("rnn.weight_ih_l0", (3 * H, H)), ("rnn.weight_hh_l0", (3 * H, H)),
+            ("rnn.bias_ih_l0", (3 * H,)), ("rnn.bias_hh_l0", (3 * H,)), ("final_layer.weight", (A, H)), ("final_layer.bias", (A,))]
+
+
+def init_flat_gru_params(obs_dims, hidden, act_dims, use_orthogonal_init=True):
+    """Initial critic / target blocks of recurrent networks, consuming torch's global RNG like RNNNetwork.__init__ does
+    (utils/models.py:83-94: nn.Linear and nn.GRU default inits, orthogonal gain sqrt(2) + zero bias on the output layer only),
+    critic nets first, then target nets, then hard_update (dqn/model.py:36-41,60)."""
+    blocks = []
+    for _ in range(2):
+        per_agent = []
+        for d, a in zip(obs_dims, act_dims):
+            first = nn.Linear(d, hidden)
+            rnn = nn.GRU(input_size=hidden, hidden_size=hidden, num_layers=1, batch_first=False)
+            final = nn.Linear(hidden, a)
+            if use_orthogonal_init:
+                nn.init.orthogonal_(final.weight.data, gain=np.sqrt(2))
+                nn.init.constant_(final.bias.data, 0)
+            per_agent.append(torch.cat([t.detach().reshape(-1) for t in (first.weight, first.bias, rnn.weight_ih_l0, rnn.weight_hh_l0,
+                                                                         rnn.bias_ih_l0, rnn.bias_hh_l0, final.weight, final.bias)]))
+        blocks.append(torch.stack(per_agent))
+    return blocks[0], blocks[0].clone()
+
+
 def _tensor_layout(D, H, A):
     return [("network.0.weight", (H, D)), ("network.0.bias", (H,)), ("network.2.weight", (H, H)),
             ("network.2.bias", (H,)), ("network.4.weight", (A, H)), ("network.4.bias", (A,))]
@@ -84,8 +110,10 @@ class QNetwork:
         hidden = [int(h) for h in layers]
         obs_dims = [flatdim(o) for o in obs_space]
         act_dims = [flatdim(a) for a in action_space]
-        if use_rnn:
-            raise NotImplementedError("use_rnn: the GRU path is a 'next' row (DESIGN.md)")
+        self.recurrent = bool(use_rnn)
+        if use_rnn and (hidden != [64, 64] or parameter_sharing):
+            raise NotImplementedError(f"use_rnn with layers={hidden}, parameter_sharing={parameter_sharing}: the recurrent kernels are "
+                                      "built for layers [64, 64] and independent networks (DESIGN.md)")
         if len(hidden) != 2 or hidden[0] != hidden[1]:
             raise NotImplementedError(f"layers={hidden}: the HIP kernels implement two equal hidden layers (64 or 128)")
         if len(set(obs_dims)) != 1 or len(set(act_dims)) != 1:
@@ -105,8 +133,14 @@ class QNetwork:
         self.device = torch.device(device)
         self.sharing = sharing_indices(parameter_sharing, self.n_agents)
         self.spec = _hip.NetSpec(self.n_agents, obs_dims[0], hidden[0], act_dims[0], self.sharing)
-        self.nparams = self.spec.nparams()
-        critic, target = init_flat_params(obs_dims, hidden, act_dims, use_orthogonal_init, self.sharing)
+        if self.recurrent:  # RNNNetwork (utils/models.py:51-116): Linear -> ReLU -> GRU -> Linear
+            if self.standardise_returns or type(self).__name__ == "QMixNetwork":
+                raise NotImplementedError("use_rnn is built for QNetwork / VDNetwork without standardise_returns")
+            self.nparams = _hip.gru_nparams(self.spec)
+            critic, target = init_flat_gru_params(obs_dims, hidden[0], act_dims, use_orthogonal_init)
+        else:
+            self.nparams = self.spec.nparams()
+            critic, target = init_flat_params(obs_dims, hidden, act_dims, use_orthogonal_init, self.sharing)
         assert critic.shape == (self.spec.n_blocks, self.nparams)
         self.params = critic.to(self.device).contiguous()
         self.target_params = target.to(self.device).contiguous()
@@ -114,7 +148,7 @@ class QNetwork:
         self.grad_clip = get("grad_clip", 1.0)
         self.double_q = bool(get("double_q", True))
         self.target_update_interval_or_tau = get("target_update_interval_or_tau", 200)
-        self.updater = _hip.DqnUpdater(self.spec, self.params, self.target_params, lr=float(get("lr", 3e-4)),
+        self.updater = (_hip.GruUpdater if self.recurrent else _hip.DqnUpdater)(self.spec, self.params, self.target_params, lr=float(get("lr", 3e-4)),
                                        gamma=self.gamma, grad_clip=self.grad_clip, double_q=self.double_q,
                                        standardise_returns=self.standardise_returns)
         self.ret_ms = self.updater.ret_stats  # RunningMeanStd(shape=(n_agents,)) on the device (dqn/model.py:88-89)
@@ -130,10 +164,16 @@ class QNetwork:
         raise NotImplementedError("Forward not implemented. Use act or update instead!")
 
     def init_hiddens(self, batch_size):
+        if self.recurrent:  # RNNNetwork.init_hiddens (utils/models.py:96-102): [num_layers, batch, H] zeros per agent
+            return [torch.zeros(1, batch_size, self.spec.hidden, device=self.device) for _ in range(self.n_agents)]
         return [None] * self.n_agents
 
-    def q_values(self, obs):
-        """obs f32 [P][N][D] on the device -> Q [P][N][A] (critic forward, K2)."""
+    def q_values(self, obs, hiddens=None):
+        """obs f32 [P][N][D] on the device -> Q [P][N][A] (critic forward, K2); recurrent networks also take / return the hidden
+        state [P][N][H]: (Q, hiddens)"""
+        if self.recurrent:
+            q, h = _hip.gru_forward(self.spec, self.params, obs.unsqueeze(1).contiguous(), h_in=hiddens, want_h=True)
+            return q[:, 0], h
         q = torch.empty(obs.shape[0], obs.shape[1], self.spec.n_actions, device=obs.device)
         n = obs.shape[1]
         _hip.dqn_act(self.spec, self.params, obs, 0.0, u=torch.ones(n, device=obs.device),
@@ -142,6 +182,21 @@ class QNetwork:
 
     def act(self, inputs, hiddens, epsilon, action_masks=None):
         """One env (dqn/model.py:94-116): ONE python `random.random()` draw decides the joint action."""
+        if self.recurrent:  # the networks run even on a random step: the hidden state advances (model.py:99)
+            for p, o in enumerate(inputs):
+                self._obs1[p, 0].copy_(torch.as_tensor(o, dtype=torch.float32))
+            h_in = None if hiddens is None or hiddens[0] is None else torch.stack([h.reshape(1, -1) for h in hiddens]).to(self.device).contiguous()
+            q, h = self.q_values(self._obs1, h_in)
+            hiddens = [h[p].reshape(1, 1, -1) for p in range(self.n_agents)]
+            if epsilon > random.random():
+                if action_masks is not None:
+                    return [random.choice([i for i, m in enumerate(mask) if m == 1]) for mask in action_masks], hiddens
+                return list(self.action_space.sample()), hiddens
+            qv = q[:, 0]
+            if action_masks is not None:
+                m = torch.as_tensor(np.asarray(action_masks, np.float32)).to(qv.device)
+                qv = qv * m + (1 - m) * -1e8
+            return [int(a) for a in qv.argmax(-1).tolist()], hiddens
         if epsilon > random.random():
             if action_masks is not None:  # model.py:106-111: a random ALLOWED action per agent
                 return [random.choice([i for i, m in enumerate(mask) if m == 1]) for mask in action_masks], hiddens
@@ -206,9 +261,10 @@ class QNetwork:
         out = OrderedDict()
         S = self.spec
         group = "independent" if self.sharing is None else "networks"  # utils/models.py:146 / :204
+        layout = (_gru_layout if self.recurrent else _tensor_layout)(S.obs_dim, S.hidden, S.n_actions)
         for i in range(S.n_blocks):
             o = 0
-            for name, shape in _tensor_layout(S.obs_dim, S.hidden, S.n_actions):
+            for name, shape in layout:
                 n = int(torch.tensor(shape).prod())
                 out[f"{prefix}.{group}.{i}.{name}"] = block[i, o:o + n].view(shape)
                 o += n

@@ -162,16 +162,51 @@ class VectorisedIDQN:
             self._sync = GradSync(self.dist)  # all-reduce(SUM) over RCCL/xGMI; clip+Adam applies 1/world
         self._sync(grad)
 
+    def _collect_recurrent(self, cfg, epsilon, round_idx, replay, slot_base, fin_return, fin_length):
+        """_collect_trajectory for N envs with recurrent networks (use_rnn): the hidden state has to live between steps, so the
+        round runs through the modular entry points - reset, then T x (sequence kernel with one step -> joint epsilon-greedy from
+        the values -> env step -> replay add); same Philox streams and replay contents as the fused collector produces for
+        feed-forward nets (tests/test_gpu_parity.py checks that equivalence for them)."""
+        m, N, T = self.model, cfg.n_envs, self.T
+        key = (cfg.n_envs, int(cfg.seed))
+        if getattr(self, "_renv_key", None) != key:
+            self._renv, self._renv_key = _hip.BatchedForaging(cfg), key
+        env = self._renv
+        env.cfg = cfg
+        env.episode.fill_(round_idx)
+        obs = env.reset()
+        env.episode.fill_(round_idx)  # the action noise is keyed by the running episode's index
+        dev = m.device
+        slot = ((torch.arange(N, device=dev) + slot_base) % max(self.capacity, 1)).to(torch.int32)
+        if replay is not None:
+            replay.init_episode(slot, obs)
+        alive = torch.ones(N, dtype=torch.uint8, device=dev)
+        hid = None
+        for _ in range(T):
+            q, hid = m.q_values(obs, hid)
+            acts = _hip.act_from_q(q, epsilon, cfg.seed, env.episode, env.ep_length)
+            tt = env.ep_length.clone()
+            obs, rew, done, trunc = env.step(acts, active=alive)
+            fin = ((done | trunc) > 0).to(torch.uint8)
+            if replay is not None:
+                replay.add(slot, tt, obs, acts, rew, done if self.proper else fin, active=alive)
+            alive = alive & (1 - fin)
+        fin_return.copy_(env.fin_return)
+        fin_length.copy_(env.fin_length)
+
     def round(self, epsilon, train=True):
         """collect N episodes (one launch), then U updates; nothing here synchronises with the host."""
         m = self.model
         slot_base = (self.rounds * self.N) % self.capacity
-        _hip.idqn_collect(self.cfg, m.spec, m.params, epsilon, self.rounds, self.replay, slot_base, self.fin_return,
-                          self.fin_length, write_replay=True, clear_stale=self.clear_stale,
-                          use_proper_termination=self.proper)
+        if getattr(m, "recurrent", False):
+            self._collect_recurrent(self.cfg, epsilon, self.rounds, self.replay, slot_base, self.fin_return, self.fin_length)
+        else:
+            _hip.idqn_collect(self.cfg, m.spec, m.params, epsilon, self.rounds, self.replay, slot_base, self.fin_return,
+                              self.fin_length, write_replay=True, clear_stale=self.clear_stale,
+                              use_proper_termination=self.proper)
         self.env_steps += self.fin_length.sum()
         self.rounds += 1
-        if train and self.dist is None and self.U > 0 and m.mode != 2 and not m.standardise_returns and not _NO_FUSED_LOOP:  # the n-updates library call has no mixer / no return statistics (those loop here)
+        if train and self.dist is None and self.U > 0 and m.mode != 2 and not m.standardise_returns and not _NO_FUSED_LOOP and not getattr(m, "recurrent", False):  # the n-updates library call has no mixer / no return statistics (those loop here)
             if self._fused is None:
                 self._fused = _hip.FusedLearner(m.updater, self.replay, self.B, m.target_update_interval_or_tau, mode=m.mode)
             length = min(self.rounds * self.N, self.capacity)
@@ -197,8 +232,11 @@ class VectorisedIDQN:
         dev = self.model.device
         ret = torch.zeros(self.model.n_agents, episodes, device=dev)
         ln = torch.zeros(episodes, dtype=torch.int32, device=dev)
-        _hip.idqn_collect(cfg, self.model.spec, self.model.params, epsilon, round_idx, self.replay, 0, ret, ln,
-                          write_replay=False)
+        if getattr(self.model, "recurrent", False):
+            self._collect_recurrent(cfg, epsilon, round_idx, None, 0, ret, ln)
+        else:
+            _hip.idqn_collect(cfg, self.model.spec, self.model.params, epsilon, round_idx, self.replay, 0, ret, ln,
+                              write_replay=False)
         ret, ln = ret.cpu().numpy(), ln.cpu().numpy()
         infos = []
         for i in range(episodes):

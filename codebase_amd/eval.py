@@ -38,6 +38,11 @@ def evaluate(model, lbf_cfg, episodes, time_limit, epsilon=0.0, round_idx=0):
         _hip.ac_collect(cfg, model.spec, model.actor_params, round_idx, T, False, torch.empty(T + 1, episodes, P * D, device=dev),
                         torch.empty(T, episodes, P, dtype=torch.int64, device=dev), torch.empty(T, episodes, P, device=dev),
                         torch.empty(T + 1, episodes, dtype=torch.uint8, device=dev), torch.empty(T, episodes, device=dev), ret, ln, t_max)
+    elif getattr(model, "recurrent", False):  # use_rnn: the hidden state lives between steps -> the modular collection loop
+        from .dqn.train import VectorisedIDQN
+
+        tr = VectorisedIDQN(cfg, model, episodes, int(time_limit), 1, 0)
+        tr._collect_recurrent(cfg, epsilon, round_idx, None, 0, ret, ln)
     else:
         replay = _hip.DeviceReplay(episodes, model.n_agents, model.spec.obs_dim, int(time_limit), device=dev)
         _hip.idqn_collect(cfg, model.spec, model.params, epsilon, round_idx, replay, 0, ret, ln, write_replay=False)

@@ -606,3 +606,28 @@ def gru_loss_grad(spec: NetSpec, params, target, batch, gamma=0.99, double_q=Tru
     check(lib.marlhip_gru_loss_grad(ctypes.byref(s), _ptr(params), _ptr(target), ctypes.byref(bs), float(gamma), int(bool(double_q)), int(mode),
                                     _ptr(ws), ws.numel(), _ptr(grad), _ptr(loss), _stream()), "gru_loss_grad")
     return loss, grad
+
+
+class GruUpdater(DqnUpdater):
+    """DqnUpdater for the recurrent networks: same buffers / clip+Adam / target update, marlhip_gru_loss_grad for the step."""
+
+    def loss_grad(self, batch, mode=0):
+        if self.ret_stats is not None:
+            raise NotImplementedError("standardise_returns is not built for recurrent networks")
+        return gru_loss_grad(self.spec, self.params, self.target, batch, gamma=self.gamma, double_q=self.double_q, mode=mode,
+                             grad=self.grad, loss=self.loss)
+
+    def loss_grad_replay(self, replay, batch_size, length=None, idx=None, seed=0, counter=0, idx_out=None, mode=0):
+        """the recurrent learner reads a materialised Batch: sample kernel first (no in-kernel gather)"""
+        return self.loss_grad(replay.sample(batch_size, length=length, idx=idx, seed=seed, counter=counter), mode=mode)
+
+
+def act_from_q(q, epsilon, seed, episode, ep_length, actions=None):
+    """joint epsilon-greedy of QNetwork.act (dqn/model.py:105-115) from given values q [P][N][A]: ONE Philox uniform per env decides
+    random-vs-greedy for the whole joint action, greedy = first maximum; same noise words as marlhip_dqn_act / the fused collector"""
+    _require_gpu()
+    P, N, A = q.shape
+    actions = torch.empty(P, N, dtype=torch.int32, device=q.device) if actions is None else actions
+    check(lib.marlhip_act_from_q(P, N, A, _ptr(q.contiguous()), float(epsilon), int(seed) & (2**64 - 1), _ptr(episode), _ptr(ep_length),
+                                 _ptr(actions), _stream()), "act_from_q")
+    return actions

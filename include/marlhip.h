@@ -328,6 +328,13 @@ int marlhip_gru_loss_grad(const marlhip_net_shape* s, const float* params, const
                           float gamma, int32_t double_q, int32_t mode, void* workspace, int64_t workspace_bytes, float* grad,
                           float* loss /* [2] */, void* stream);
 
+/* the action choice of QNetwork.act (dqn/model.py:105-115) from given values q [P][N][A] (the recurrent path computes them with
+ * marlhip_gru_forward): explore iff epsilon > u with ONE Philox uniform per env (env n, episode[n], t = ep_length[n], word 0),
+ * random action of agent p = word 1+p, greedy = first maximum - the same words marlhip_dqn_act and the fused collector use. */
+int marlhip_act_from_q(int32_t n_agents, int32_t n_envs, int32_t n_actions, const float* q, float epsilon, uint64_t seed,
+                       const uint32_t* episode /* [N] */, const int32_t* ep_length /* [N] */, int32_t* actions /* [P][N] */,
+                       void* stream);
+
 /* the two fused collectors on the warehouse env (same contracts; net shape D = 71, A = 5; compiled for the tiny layouts,
  * 2 and 4 agents: the shelf layer of a workgroup's 64 envs lives in LDS behind the weight packs) */
 int marlhip_rware_idqn_collect(const marlhip_rware_config* cfg, const marlhip_net_shape* s, const float* params, float epsilon,
