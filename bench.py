@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--env-name", default=ENV_NAME, help="other BASELINE.json configs, e.g. lbforaging:Foraging-15x15-4p-5f-v3 or rware:rware-tiny-4ag-v2 (with --time-limit 500)")
     ap.add_argument("--algo", default="idqn", choices=["idqn", "vdn", "qmix", "ia2c", "ippo", "maa2c", "mappo"])
+    ap.add_argument("--rnn", action="store_true", help="recurrent Q-networks (algorithm.model.use_rnn=True; idqn / vdn, hidden 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -265,7 +266,7 @@ def main():
         model = QMixNetwork(obs_space, act_space, hyper, [H, H], False, False, True,
                             dict(embed_dim=64, hypernet_layers=2, hypernet_embed=32), "cuda")
     else:
-        model = (VDNetwork if args.algo == "vdn" else QNetwork)(obs_space, act_space, hyper, [H, H], False, False, True, "cuda")
+        model = (VDNetwork if args.algo == "vdn" else QNetwork)(obs_space, act_space, hyper, [H, H], False, bool(args.rnn), True, "cuda")
     cap = args.replay_rounds * N
     trainer = VectorisedIDQN(cfg, model, cap, T, B, U, seed=args.seed, dist=dist)
     eps_sched = _epsilon_schedule("linear", 0.5, 1.0, 0.05, 6.5, 100_000_000)
@@ -356,7 +357,7 @@ def main():
         "data": "synthetic (Philox-seeded env layouts, orthogonal-init weights)",
         "config": {
             "workload": f"{args.algo.upper()} on {args.env_name.split(':')[-1].replace('-v3', '')}, {N} batched HIP envs per GPU, "
-                        f"2-layer-{H} MLP, time_limit {T}",
+                        + (f"GRU-{H} networks (use_rnn), " if args.rnn else f"2-layer-{H} MLP, ") + f"time_limit {T}",
             "cadence": args.cadence,
             "envs_per_gpu": N,
             "updates_per_round": U,
