@@ -1,5 +1,5 @@
 // Recurrent Q-networks (`use_rnn: True`): Linear(D, H) -> ReLU -> one-layer GRU(H, H) -> Linear(H, A)
-// (marlbase/utils/models.py:51-116), hidden 64, on the same transposed-activation f32 MFMA scheme as mlp.h.
+// (marlbase/utils/models.py:51-116), hidden 64 and 128, on the same transposed-activation f32 MFMA scheme as mlp.h.
 //
 // One agent's block, parameters() order:
 //   first_layer.weight [H][D] | .bias [H] | rnn.weight_ih_l0 [3H][H] | rnn.weight_hh_l0 [3H][H] | rnn.bias_ih_l0 [3H] |
@@ -29,7 +29,15 @@ struct GruShape {
                          pb1 = pA3 + MT * 256, pbih = pb1 + H_, pbhh = pbih + 3 * H_, pb3 = pbhh + 3 * H_;
     static constexpr int NFWD = pb3 + 16;
     static_assert(NFWD % 4 == 0, "pack is whole float4s");
-    static_assert(NFWD * 4 <= 156 * 1024, "the recurrent network's packs must fit the LDS (hidden 64)");
+    // hidden 64: the whole pack is LDS-resident.  hidden 128: the six H x H gate matrices (393 KB) stream through ONE LDS chunk
+    // buffer, a gate at a time, every step (they stay L2-resident); W1, W3 and the biases are resident.
+    static constexpr int CHUNK = MT * MT * 256;                  // one gate matrix as an A-operand pack
+    static constexpr bool STREAM = NFWD * 4 > 156 * 1024;
+    static constexpr int TAIL = NFWD - pA3;                      // A3 + biases
+    // streamed LDS layout: A1 | A3 + biases | chunk buffer
+    static constexpr int sA1 = 0, sTail = pGi, sChunk = sTail + TAIL, LDS_STREAM = sChunk + CHUNK;
+    static constexpr int LDS_FLOATS = STREAM ? LDS_STREAM : NFWD;
+    static_assert(LDS_FLOATS * 4 <= 158 * 1024, "recurrent network: LDS budget");
     // per (step, 16-row block) activation record for the backward pass: 6 arrays x MT tiles x 64 lanes x f4
     static constexpr int REC_ARRAYS = 6, REC = REC_ARRAYS * MT * 256;
 };
@@ -84,12 +92,12 @@ __device__ __forceinline__ f4 tanh4(f4 v) {
 
 // gate pre-activations of one gate: out[mt] = bias[16mt+4g..] + sum_{mt1, r} G[gate][mt][mt1][lane][r] * b[mt1][r]
 template <class S>
-__device__ __forceinline__ void gru_gate(const float* lds, int pG, int pb, int gate, int lane, const f4 (&b)[S::MT], f4 (&out)[S::MT]) {
+__device__ __forceinline__ void gru_gate(const f4* G /* [MT][MT][64] chunk */, const float* bias /* [H] of this gate */, int lane,
+                                         const f4 (&b)[S::MT], f4 (&out)[S::MT]) {
     constexpr int MT = S::MT;
     const int g = lane >> 4;
-    const f4* G = reinterpret_cast<const f4*>(lds + pG) + (size_t)gate * MT * MT * 64;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) out[mt] = *reinterpret_cast<const f4*>(lds + pb + gate * S::H + 16 * mt + 4 * g);
+    for (int mt = 0; mt < MT; ++mt) out[mt] = *reinterpret_cast<const f4*>(bias + 16 * mt + 4 * g);
 #pragma unroll
     for (int k1 = 0; k1 < MT; ++k1) {
         f4 a[MT];
@@ -109,25 +117,50 @@ __global__ __launch_bounds__(256) void gru_seq_fwd_kernel(const float* __restric
                                                           const float* __restrict__ h_in, float* __restrict__ h_out,
                                                           float* __restrict__ q_out, float* __restrict__ rec) {
     constexpr int MT = S::MT, D = S::D, H = S::H, A = S::A;
+    constexpr bool STREAM = S::STREAM;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, j = lane & 15;
     const int p = blockIdx.y;
-    copy_f4_to_lds(reinterpret_cast<const f4*>(packs + (size_t)p * S::NFWD), reinterpret_cast<f4*>(lds), S::NFWD / 4, tid, 256);
+    const float* pack = packs + (size_t)p * S::NFWD;
+    if (!STREAM) {
+        copy_f4_to_lds(reinterpret_cast<const f4*>(pack), reinterpret_cast<f4*>(lds), S::NFWD / 4, tid, 256);
+    } else {
+        copy_f4_to_lds(reinterpret_cast<const f4*>(pack + S::pA1), reinterpret_cast<f4*>(lds + S::sA1), S::pGi / 4, tid, 256);
+        copy_f4_to_lds(reinterpret_cast<const f4*>(pack + S::pA3), reinterpret_cast<f4*>(lds + S::sTail), S::TAIL / 4, tid, 256);
+    }
     __syncthreads();
+    // LDS addresses of the resident parts
+    const float* lA1 = lds + (STREAM ? S::sA1 : S::pA1);
+    const float* tail = lds + (STREAM ? S::sTail : S::pA3);  // A3 | b1 | bih | bhh | b3
+    const float* lA3 = tail;
+    const float* lb1 = tail + (S::pb1 - S::pA3);
+    const float* lbih = tail + (S::pbih - S::pA3);
+    const float* lbhh = tail + (S::pbhh - S::pA3);
+    const float* lb3 = tail + (S::pb3 - S::pA3);
     const int nblk = (B + 15) >> 4;
     const int blk = blockIdx.x * 4 + wave;
-    if (blk >= nblk) return;
-    const int b0 = blk * 16;
-    const bool rowok = b0 + j < B;
-    const int bj = rowok ? b0 + j : B - 1;
+    const bool active = blk < nblk;
+    if (!STREAM && !active) return;  // streamed: every wave keeps staging and meeting the barriers
+    const int b0 = (active ? blk : nblk - 1) * 16;
+    const bool rowok = active && b0 + j < B;
+    const int bj = b0 + j < B ? b0 + j : B - 1;
     f4 h[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         if (h_in != nullptr) h[mt] = *reinterpret_cast<const f4*>(h_in + ((size_t)p * B + bj) * H + 16 * mt + 4 * g);
         else h[mt] = f4{0.f, 0.f, 0.f, 0.f};
     }
-    const f4* A1 = reinterpret_cast<const f4*>(lds + S::pA1);
-    const f4* A3 = reinterpret_cast<const f4*>(lds + S::pA3);
+    const f4* A1 = reinterpret_cast<const f4*>(lA1);
+    const f4* A3 = reinterpret_cast<const f4*>(lA3);
+    // gate matrix `c` (0..2: W_ih r, z, n; 3..5: W_hh r, z, n) as an A-operand chunk in LDS
+    auto gate_chunk = [&](int c) -> const f4* {
+        if (!STREAM) return reinterpret_cast<const f4*>(lds + S::pGi) + (size_t)c * MT * MT * 64;
+        __syncthreads();  // everybody is done with the previous chunk
+        copy_f4_to_lds(reinterpret_cast<const f4*>(pack + S::pGi) + (size_t)c * MT * MT * 64, reinterpret_cast<f4*>(lds + S::sChunk), S::CHUNK / 4,
+                       tid, 256);
+        __syncthreads();
+        return reinterpret_cast<const f4*>(lds + S::sChunk);
+    };
     for (int t = 0; t < steps; ++t) {
         asm volatile("" ::: "memory");  // the packs never change, so the compiler would hoist every weight read out of the time
                                         // loop (and spill ~1 KB per lane): re-read them from LDS each step
@@ -141,7 +174,7 @@ __global__ __launch_bounds__(256) void gru_seq_fwd_kernel(const float* __restric
         // x1 = relu(W1 x + b1)
         f4 x1[MT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) x1[mt] = *reinterpret_cast<const f4*>(lds + S::pb1 + 16 * mt + 4 * g);
+        for (int mt = 0; mt < MT; ++mt) x1[mt] = *reinterpret_cast<const f4*>(lb1 + 16 * mt + 4 * g);
 #pragma unroll
         for (int ks4 = 0; ks4 < S::KS1 / 4; ++ks4) {
             f4 a[MT];
@@ -156,22 +189,22 @@ __global__ __launch_bounds__(256) void gru_seq_fwd_kernel(const float* __restric
         for (int mt = 0; mt < MT; ++mt) x1[mt] = relu4(x1[mt]);
         // gates (torch.nn.GRU): r, z, n
         f4 gi[MT], gh[MT], rg[MT], zg[MT], ng[MT], ghn[MT];
-        gru_gate<S>(lds, S::pGi, S::pbih, 0, lane, x1, gi);
-        gru_gate<S>(lds, S::pGh, S::pbhh, 0, lane, h, gh);
+        gru_gate<S>(gate_chunk(0), lbih + 0 * H, lane, x1, gi);
+        gru_gate<S>(gate_chunk(3), lbhh + 0 * H, lane, h, gh);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) rg[mt] = sigmoid4(gi[mt] + gh[mt]);
-        gru_gate<S>(lds, S::pGi, S::pbih, 1, lane, x1, gi);
-        gru_gate<S>(lds, S::pGh, S::pbhh, 1, lane, h, gh);
+        gru_gate<S>(gate_chunk(1), lbih + 1 * H, lane, x1, gi);
+        gru_gate<S>(gate_chunk(4), lbhh + 1 * H, lane, h, gh);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) zg[mt] = sigmoid4(gi[mt] + gh[mt]);
-        gru_gate<S>(lds, S::pGi, S::pbih, 2, lane, x1, gi);
-        gru_gate<S>(lds, S::pGh, S::pbhh, 2, lane, h, ghn);
+        gru_gate<S>(gate_chunk(2), lbih + 2 * H, lane, x1, gi);
+        gru_gate<S>(gate_chunk(5), lbhh + 2 * H, lane, h, ghn);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             ng[mt] = tanh4(gi[mt] + rg[mt] * ghn[mt]);
             h[mt] = (1.f - zg[mt]) * ng[mt] + zg[mt] * h[mt];
         }
-        if (rec != nullptr) {
+        if (rec != nullptr && active) {
             f4* R = reinterpret_cast<f4*>(rec + (((size_t)p * steps + t) * nblk + blk) * S::REC);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
@@ -184,7 +217,7 @@ __global__ __launch_bounds__(256) void gru_seq_fwd_kernel(const float* __restric
             }
         }
         // q = W3 h + b3
-        f4 q = *reinterpret_cast<const f4*>(lds + S::pb3 + 4 * g);
+        f4 q = *reinterpret_cast<const f4*>(lb3 + 4 * g);
 #pragma unroll
         for (int k1 = 0; k1 < MT; ++k1) {
             const f4 a = A3[k1 * 64 + lane];

@@ -4,23 +4,25 @@
 
 using namespace marl;
 
-// (obs dim, actions) with compiled recurrent kernels, hidden 64: the LBF widths and the warehouse
-#define MARL_GRU_SHAPES(X) X(12, 6) X(15, 6) X(18, 6) X(21, 6) X(24, 6) X(27, 6) X(39, 6) X(71, 5)
+// (obs dim, hidden, actions) with compiled recurrent kernels: the LBF widths and the warehouse, hidden 64 (whole network LDS-resident)
+// and 128 (gate matrices streamed)
+#define MARL_GRU_SHAPES(X)                                                                                   \
+    X(12, 64, 6) X(15, 64, 6) X(18, 64, 6) X(21, 64, 6) X(24, 64, 6) X(27, 64, 6) X(39, 64, 6) X(71, 64, 5) \
+    X(12, 128, 6) X(15, 128, 6) X(18, 128, 6) X(21, 128, 6) X(24, 128, 6) X(27, 128, 6) X(39, 128, 6) X(71, 128, 5)
 
 static int gru_check(const marlhip_net_shape* s) {
     MARL_REQUIRE(s != nullptr, "net shape is NULL");
     if (agent_map_validate(s) != 0) return -1;
-    MARL_REQUIRE(s->hidden == 64, "recurrent networks are compiled for hidden 64 (layers: [64, 64]), got %d", s->hidden);
-#define X(d, a) if (s->obs_dim == d && s->n_actions == a) return 0;
+#define X(d, h, a) if (s->obs_dim == d && s->hidden == h && s->n_actions == a) return 0;
     MARL_GRU_SHAPES(X)
 #undef X
-    set_error("no recurrent kernels for obs_dim %d, %d actions (MARL_GRU_SHAPES)", s->obs_dim, s->n_actions);
+    set_error("no recurrent kernels for obs_dim %d, hidden %d, %d actions (MARL_GRU_SHAPES)", s->obs_dim, s->hidden, s->n_actions);
     return -1;
 }
 
 extern "C" int marlhip_gru_nparams(const marlhip_net_shape* s) {
     if (gru_check(s) != 0) return -1;
-#define X(d, a) if (s->obs_dim == d && s->n_actions == a) return GruShape<d, 64, a>::NPARAM;
+#define X(d, h, a) if (s->obs_dim == d && s->hidden == h && s->n_actions == a) return GruShape<d, h, a>::NPARAM;
     MARL_GRU_SHAPES(X)
 #undef X
     return -1;
@@ -28,7 +30,7 @@ extern "C" int marlhip_gru_nparams(const marlhip_net_shape* s) {
 
 extern "C" int64_t marlhip_gru_record_floats(const marlhip_net_shape* s, int32_t steps, int32_t batch) {
     if (gru_check(s) != 0) return -1;
-    return (int64_t)s->n_agents * steps * ((batch + 15) / 16) * GruShape<15, 64, 6>::REC;  // REC depends on H only
+    return (int64_t)s->n_agents * steps * ((batch + 15) / 16) * (s->hidden == 64 ? GruShape<15, 64, 6>::REC : GruShape<15, 128, 6>::REC);  // REC depends on H only
 }
 
 template <class S>
@@ -39,7 +41,7 @@ static int gru_forward(const marlhip_net_shape* s, const float* params, const fl
     MARL_REQUIRE(packs != nullptr, "gru_forward: cannot allocate the pack scratch");
     hipLaunchKernelGGL((gru_pack_kernel<S>), dim3((S::NFWD + 255) / 256, P), dim3(256), 0, st, params, agent_map(s), packs);
     MARL_CHECK_LAUNCH("gru_pack_kernel");
-    const size_t lds = (size_t)S::NFWD * sizeof(float);
+    const size_t lds = (size_t)S::LDS_FLOATS * sizeof(float);
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_seq_fwd_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -55,8 +57,8 @@ extern "C" int marlhip_gru_forward(const marlhip_net_shape* s, const float* para
                                    const float* h_in, float* h_out, float* q_out, float* record, void* stream) {
     if (gru_check(s) != 0) return -1;
     MARL_REQUIRE(params && obs && q_out && steps > 0 && batch > 0, "gru_forward: bad argument");
-#define X(d, a) \
-    if (s->obs_dim == d && s->n_actions == a) return gru_forward<GruShape<d, 64, a>>(s, params, obs, steps, batch, h_in, h_out, q_out, record, (hipStream_t)stream);
+#define X(d, h, a) \
+    if (s->obs_dim == d && s->hidden == h && s->n_actions == a) return gru_forward<GruShape<d, h, a>>(s, params, obs, steps, batch, h_in, h_out, q_out, record, (hipStream_t)stream);
     MARL_GRU_SHAPES(X)
 #undef X
     return -1;
@@ -84,7 +86,7 @@ GruWs gru_ws_layout(int P, int T, int B) {
     const int64_t items = steps * nblk;
     const int cap = 256 / P > 1 ? 256 / P : 1;
     w.nwg = (int)(items < cap ? items : cap);
-    w.partials = take((int64_t)P * w.nwg * (S::NPARAM + 2));
+    w.partials = take((int64_t)P * w.nwg * GruBwd<S>::NH * (S::NPARAM + 2));
     w.packC = take((int64_t)P * S::NFWD);
     w.packT = take((int64_t)P * S::NFWD);
     w.packB = take((int64_t)P * GruBwd<S>::NBWD);
@@ -106,11 +108,13 @@ int gru_loss_grad(const marlhip_net_shape* s, const float* params, const float* 
     hipLaunchKernelGGL((gru_pack_kernel<S>), dim3((S::NFWD + 255) / 256, P), dim3(256), 0, st, target, am, f(wl.packT));
     hipLaunchKernelGGL((gru_bwd_pack_kernel<S>), dim3((Bk::NBWD + 255) / 256, P), dim3(256), 0, st, params, am, f(wl.packB));
     MARL_CHECK_LAUNCH("gru pack kernels");
-    const size_t ldsF = (size_t)S::NFWD * sizeof(float), ldsB = (size_t)Bk::NBWD * sizeof(float);
+    const size_t ldsF = (size_t)S::LDS_FLOATS * sizeof(float), ldsB = (size_t)Bk::LDS_FLOATS * sizeof(float);
+    const size_t ldsW = (size_t)(8 * 16 * S::H + 256) * sizeof(float);
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_seq_fwd_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsF);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_seq_bwd_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsB);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_wgrad_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsW);
         attr = true;
     }
     const dim3 gridS((B + 63) / 64, P);
@@ -127,11 +131,12 @@ int gru_loss_grad(const marlhip_net_shape* s, const float* params, const float* 
     hipLaunchKernelGGL((gru_seq_bwd_kernel<S>), gridS, dim3(256), ldsB, st, (const float*)f(wl.packB), steps, B, (const float*)f(wl.rec),
                        (const float*)f(wl.dq), f(wl.rec2));
     MARL_CHECK_LAUNCH("gru_seq_bwd_kernel");
-    hipLaunchKernelGGL((gru_wgrad_kernel<S>), dim3(wl.nwg, P), dim3(256), 0, st, steps, B, bt->obss, (const float*)f(wl.rec), (const float*)f(wl.rec2),
+    (void)hipMemsetAsync(f(wl.partials), 0, (size_t)P * wl.nwg * Bk::NH * (S::NPARAM + 2) * sizeof(float), st);
+    hipLaunchKernelGGL((gru_wgrad_kernel<S>), dim3(wl.nwg, P, Bk::NH), dim3(256), ldsW, st, steps, B, bt->obss, (const float*)f(wl.rec), (const float*)f(wl.rec2),
                        (const float*)f(wl.dq), (const float*)f(wl.lrow), bt->filled, f(wl.partials));
     MARL_CHECK_LAUNCH("gru_wgrad_kernel");
     const int n = P * S::NPARAM;
-    hipLaunchKernelGGL(dqn_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, st, (const float*)f(wl.partials), P, wl.nwg, S::NPARAM, am, grad, loss);
+    hipLaunchKernelGGL(dqn_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, st, (const float*)f(wl.partials), P, wl.nwg * Bk::NH, S::NPARAM, am, grad, loss);
     timing_end(TIMER_LOSSGRAD, st);
     MARL_CHECK_LAUNCH("dqn_reduce_kernel");
     return 0;
@@ -140,7 +145,7 @@ int gru_loss_grad(const marlhip_net_shape* s, const float* params, const float* 
 
 extern "C" int64_t marlhip_gru_workspace_bytes(const marlhip_net_shape* s, int32_t max_len, int32_t batch) {
     if (gru_check(s) != 0) return -1;
-#define X(d, a) if (s->obs_dim == d && s->n_actions == a) return gru_ws_layout<GruShape<d, 64, a>>(s->n_agents, max_len, batch).total;
+#define X(d, h, a) if (s->obs_dim == d && s->hidden == h && s->n_actions == a) return gru_ws_layout<GruShape<d, h, a>>(s->n_agents, max_len, batch).total;
     MARL_GRU_SHAPES(X)
 #undef X
     return -1;
@@ -156,9 +161,9 @@ extern "C" int marlhip_gru_loss_grad(const marlhip_net_shape* s, const float* pa
     MARL_REQUIRE(batch->obss && batch->actions && batch->rewards && batch->dones && batch->filled && batch->max_len > 0 && batch->batch > 0,
                  "gru_loss_grad: bad batch");
     MARL_REQUIRE(batch->obs_agent_stride == 0 && batch->obs_row_stride == 0, "gru_loss_grad: the dqn/train.py Batch layout only");
-#define X(d, a)                                                  \
-    if (s->obs_dim == d && s->n_actions == a)                    \
-        return gru_loss_grad<GruShape<d, 64, a>>(s, params, target_params, batch, gamma, double_q, mode, workspace, workspace_bytes, grad, loss, \
+#define X(d, h, a)                                               \
+    if (s->obs_dim == d && s->hidden == h && s->n_actions == a)  \
+        return gru_loss_grad<GruShape<d, h, a>>(s, params, target_params, batch, gamma, double_q, mode, workspace, workspace_bytes, grad, loss, \
                                                  (hipStream_t)stream);
     MARL_GRU_SHAPES(X)
 #undef X

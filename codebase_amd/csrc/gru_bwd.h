@@ -21,6 +21,12 @@ struct GruBwd {
     // backward-data pack: T3[MT][64][4] | Thh[3][MT][MT][64][4] | Tih[3][MT][MT][64][4]
     static constexpr int pT3 = 0, pThh = pT3 + MT * 256, pTih = pThh + 3 * MT * MT * 256, NBWD = pTih + 3 * MT * MT * 256;
     static constexpr int REC2_ARRAYS = 5, REC2 = REC2_ARRAYS * MT * 256;  // dr, dz, dn, r * dn, dx1
+    // hidden 128: T3 resident, the six transposed gate matrices stream through one chunk buffer (as in the forward kernel)
+    static constexpr int CHUNK = MT * MT * 256;
+    static constexpr bool STREAM = S::STREAM;
+    static constexpr int LDS_FLOATS = STREAM ? pThh + CHUNK : NBWD;
+    // weight-gradient pass: column halves per workgroup so that the gate slices' accumulators fit the register file
+    static constexpr int NH = MT > 4 ? 4 : 1, MTN = MT / NH;
 };
 
 template <class S>
@@ -93,9 +99,8 @@ static __global__ __launch_bounds__(256) void gru_td_kernel(int P, int T, int B,
 
 // transposed product: out[mt1] += sum_{gate-unit tiles mt2, r} T[gate][mt1][mt2][lane][r] * dg[mt2][r]
 template <class S>
-__device__ __forceinline__ void gru_tgate(const float* lds, int pT, int gate, int lane, const f4 (&dg)[S::MT], f4 (&out)[S::MT]) {
+__device__ __forceinline__ void gru_tgate(const f4* Tm /* [MT][MT][64] chunk */, int lane, const f4 (&dg)[S::MT], f4 (&out)[S::MT]) {
     constexpr int MT = S::MT;
-    const f4* Tm = reinterpret_cast<const f4*>(lds + pT) + (size_t)gate * MT * MT * 64;
 #pragma unroll
     for (int m2 = 0; m2 < MT; ++m2) {
         f4 a[MT];
@@ -117,15 +122,28 @@ __global__ __launch_bounds__(256) void gru_seq_bwd_kernel(const float* __restric
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, j = lane & 15;
     const int p = blockIdx.y;
-    copy_f4_to_lds(reinterpret_cast<const f4*>(packs + (size_t)p * Bk::NBWD), reinterpret_cast<f4*>(lds), Bk::NBWD / 4, tid, 256);
+    constexpr bool STREAM = Bk::STREAM;
+    const float* pack = packs + (size_t)p * Bk::NBWD;
+    copy_f4_to_lds(reinterpret_cast<const f4*>(pack), reinterpret_cast<f4*>(lds), (STREAM ? Bk::pThh : Bk::NBWD) / 4, tid, 256);
     __syncthreads();
     const int nblk = (B + 15) >> 4;
-    const int blk = blockIdx.x * 4 + wave;
-    if (blk >= nblk) return;
+    const int blk0 = blockIdx.x * 4 + wave;
+    const bool active = blk0 < nblk;
+    if (!STREAM && !active) return;  // streamed: every wave keeps staging and meeting the barriers
+    const int blk = active ? blk0 : nblk - 1;
     const int b0 = blk * 16;
-    const bool rowok = b0 + j < B;
-    const int bj = rowok ? b0 + j : B - 1;
+    const bool rowok = active && b0 + j < B;
+    const int bj = b0 + j < B ? b0 + j : B - 1;
     const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    // transposed gate matrix `c` (0..2: W_hh^T r, z, n; 3..5: W_ih^T r, z, n)
+    auto tchunk = [&](int c) -> const f4* {
+        if (!STREAM) return reinterpret_cast<const f4*>(lds + Bk::pThh) + (size_t)c * MT * MT * 64;
+        __syncthreads();
+        copy_f4_to_lds(reinterpret_cast<const f4*>(pack + Bk::pThh) + (size_t)c * MT * MT * 64, reinterpret_cast<f4*>(lds + Bk::pThh), Bk::CHUNK / 4,
+                       tid, 256);
+        __syncthreads();
+        return reinterpret_cast<const f4*>(lds + Bk::pThh);
+    };
     const f4* T3 = reinterpret_cast<const f4*>(lds + Bk::pT3);
     f4 carry[MT];
 #pragma unroll
@@ -169,15 +187,16 @@ __global__ __launch_bounds__(256) void gru_seq_bwd_kernel(const float* __restric
             dr[mt] = dng[mt] * ghn[mt] * rg[mt] * (1.f - rg[mt]);
             carry[mt] = dh[mt] * zg[mt];
         }
-        gru_tgate<S>(lds, Bk::pThh, 0, lane, dr, carry);
-        gru_tgate<S>(lds, Bk::pThh, 1, lane, dz, carry);
-        gru_tgate<S>(lds, Bk::pThh, 2, lane, drn, carry);
+        gru_tgate<S>(tchunk(0), lane, dr, carry);
+        gru_tgate<S>(tchunk(1), lane, dz, carry);
+        gru_tgate<S>(tchunk(2), lane, drn, carry);
         f4 dx1[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) dx1[mt] = zero4;
-        gru_tgate<S>(lds, Bk::pTih, 0, lane, dr, dx1);
-        gru_tgate<S>(lds, Bk::pTih, 1, lane, dz, dx1);
-        gru_tgate<S>(lds, Bk::pTih, 2, lane, dng, dx1);
+        gru_tgate<S>(tchunk(3), lane, dr, dx1);
+        gru_tgate<S>(tchunk(4), lane, dz, dx1);
+        gru_tgate<S>(tchunk(5), lane, dng, dx1);
+        if (!active) continue;
         f4* R2 = reinterpret_cast<f4*>(rec2 + (((size_t)p * steps + t) * nblk + blk) * Bk::REC2);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
@@ -199,8 +218,9 @@ __global__ __launch_bounds__(256) void gru_wgrad_kernel(int steps, int B, const 
                                                         const float* __restrict__ lrow, const float* __restrict__ filled,
                                                         float* __restrict__ partials) {
     using Bk = GruBwd<S>;
-    constexpr int MT = S::MT, H = S::H, D = S::D, A = S::A, NT1 = S::DP / 16, TILE = 16 * H;
-    __shared__ __attribute__((aligned(16))) float tiles[8 * TILE + 256];
+    constexpr int MT = S::MT, H = S::H, D = S::D, A = S::A, NT1 = S::DP / 16, TILE = 16 * H, MTN = Bk::MTN;
+    extern __shared__ __attribute__((aligned(16))) float tiles[];  // 8 * TILE + 256 floats
+    const int half = blockIdx.z, nt0 = half * MTN;  // this workgroup's column tiles of the gate matrices (hidden 128: four column groups)
     float* Tdr = tiles;             // gate gradients, [unit][16 rows]
     float* Tdz = Tdr + TILE;
     float* Tdn = Tdz + TILE;
@@ -214,13 +234,13 @@ __global__ __launch_bounds__(256) void gru_wgrad_kernel(int steps, int B, const 
     const int p = blockIdx.y, P = gridDim.y;
     const int nblk = (B + 15) >> 4, T = steps - 1;
     const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    f4 dWa[MT][MT], dWb[MT][MT], dba[MT], dbb[MT];  // waves 0..2: dW_ih / dW_hh rows of their gate and the two bias sums
+    f4 dWa[MT][MTN], dWb[MT][MTN], dba[MT], dbb[MT];  // waves 0..2: dW_ih / dW_hh rows of their gate and the two bias sums
     f4 dW1[MT][NT1], dW3[MT], db3 = zero4;           // wave 3 (its db1 lives in dba)
 #pragma unroll
     for (int a = 0; a < MT; ++a) {
         dba[a] = zero4; dbb[a] = zero4; dW3[a] = zero4;
 #pragma unroll
-        for (int b = 0; b < MT; ++b) { dWa[a][b] = zero4; dWb[a][b] = zero4; }
+        for (int b = 0; b < MTN; ++b) { dWa[a][b] = zero4; dWb[a][b] = zero4; }
 #pragma unroll
         for (int b = 0; b < NT1; ++b) dW1[a][b] = zero4;
     }
@@ -272,23 +292,23 @@ __global__ __launch_bounds__(256) void gru_wgrad_kernel(int steps, int B, const 
             // gate `wave`: dW_ih[gate rows][:] += dgi^T x1, dW_hh[gate rows][:] += dgh^T h_prev, bias sums of both
             const float* Tgi = wave == 0 ? Tdr : (wave == 1 ? Tdz : Tdn);
             const float* Tgh = wave == 0 ? Tdr : (wave == 1 ? Tdz : Tdrn);
-            f4 aI[MT], aH[MT], bX[MT], bH[MT];
+            f4 bX[MTN], bH[MTN];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                aI[mt] = tile_read(Tgi, mt, g, j);
-                aH[mt] = tile_read(Tgh, mt, g, j);
-                bX[mt] = tile_read(Tx1, mt, g, j);
-                bH[mt] = tile_read(Thp, mt, g, j);
+            for (int nt = 0; nt < MTN; ++nt) {
+                bX[nt] = tile_read(Tx1, nt0 + nt, g, j);
+                bH[nt] = tile_read(Thp, nt0 + nt, g, j);
             }
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+            for (int mt = 0; mt < MT; ++mt) {
+                const f4 aI = tile_read(Tgi, mt, g, j), aH = tile_read(Tgh, mt, g, j);
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-                    for (int nt = 0; nt < MT; ++nt) {
-                        dWa[mt][nt] = MARL_MFMA(aI[mt][ks], bX[nt][ks], dWa[mt][nt]);
-                        dWb[mt][nt] = MARL_MFMA(aH[mt][ks], bH[nt][ks], dWb[mt][nt]);
+                    for (int nt = 0; nt < MTN; ++nt) {
+                        dWa[mt][nt] = MARL_MFMA(aI[ks], bX[nt][ks], dWa[mt][nt]);
+                        dWb[mt][nt] = MARL_MFMA(aH[ks], bH[nt][ks], dWb[mt][nt]);
                     }
+            }
             // bias sums from the C-layout registers this wave loaded (gate r / z: dgi == dgh; gate n: dn and r * dn)
             if (wave == 2) {
 #pragma unroll
@@ -297,7 +317,7 @@ __global__ __launch_bounds__(256) void gru_wgrad_kernel(int steps, int B, const 
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) { dba[mt] += mine[mt]; dbb[mt] += mine[mt]; }
             }
-        } else {
+        } else if (half == 0) {
             // first layer: dW1 += dx1^T x (B operand straight from the observations), db1; output layer: dW3 += dq^T h, db3
             f4 aX[MT], bHt[MT];
             const f4 aQ = tile_read(TQ, 0, g, j);
@@ -329,7 +349,8 @@ __global__ __launch_bounds__(256) void gru_wgrad_kernel(int steps, int B, const 
         __syncthreads();  // tiles are rewritten by the next item
     }
     // ---- record: every wave stores its own slices (no fold: the slices are disjoint)
-    float* recd = partials + ((size_t)p * gridDim.x + blockIdx.x) * (S::NPARAM + 2);
+    // (the records are zeroed before the launch: with two column halves a workgroup fills only its part)
+    float* recd = partials + ((size_t)p * gridDim.x * Bk::NH + (size_t)half * gridDim.x + blockIdx.x) * (S::NPARAM + 2);
     (void)P;
     if (wave < 3) {
 #pragma unroll
@@ -338,18 +359,18 @@ __global__ __launch_bounds__(256) void gru_wgrad_kernel(int steps, int B, const 
             for (int r = 0; r < 4; ++r) {
                 const int v = wave * H + 16 * mt + 4 * g + r;
 #pragma unroll
-                for (int nt = 0; nt < MT; ++nt) {
-                    recd[S::oWih + v * H + 16 * nt + j] = dWa[mt][nt][r];
-                    recd[S::oWhh + v * H + 16 * nt + j] = dWb[mt][nt][r];
+                for (int nt = 0; nt < MTN; ++nt) {
+                    recd[S::oWih + v * H + 16 * (nt0 + nt) + j] = dWa[mt][nt][r];
+                    recd[S::oWhh + v * H + 16 * (nt0 + nt) + j] = dWb[mt][nt][r];
                 }
                 const float sa = sum16(dba[mt][r]), sb = sum16(dbb[mt][r]);
-                if (j == 0) {
+                if (j == 0 && half == 0) {
                     recd[S::obih + v] = sa;
                     recd[S::obhh + v] = sb;
                 }
             }
         }
-    } else {
+    } else if (half == 0) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll

@@ -111,9 +111,9 @@ class QNetwork:
         obs_dims = [flatdim(o) for o in obs_space]
         act_dims = [flatdim(a) for a in action_space]
         self.recurrent = bool(use_rnn)
-        if use_rnn and (hidden != [64, 64] or parameter_sharing):
+        if use_rnn and (hidden not in ([64, 64], [128, 128]) or parameter_sharing):
             raise NotImplementedError(f"use_rnn with layers={hidden}, parameter_sharing={parameter_sharing}: the recurrent kernels are "
-                                      "built for layers [64, 64] and independent networks (DESIGN.md)")
+                                      "built for layers [64, 64] / [128, 128] and independent networks (DESIGN.md)")
         if len(hidden) != 2 or hidden[0] != hidden[1]:
             raise NotImplementedError(f"layers={hidden}: the HIP kernels implement two equal hidden layers (64 or 128)")
         if len(set(obs_dims)) != 1 or len(set(act_dims)) != 1:

@@ -91,13 +91,16 @@ def test_hip_loss_and_gradient_match_reference(name, mode):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("P,T,B,D,A,mode,dq", [(2, 25, 70, 15, 6, "idqn", True), (4, 6, 16, 27, 6, "vdn", False), (8, 5, 33, 39, 6, "idqn", True),
-                                               (4, 12, 20, 71, 5, "idqn", False), (2, 1, 1, 12, 6, "vdn", True)])
-def test_hip_loss_and_gradient_other_shapes_vs_port(P, T, B, D, A, mode, dq):
+@pytest.mark.parametrize("P,T,B,D,A,mode,dq,H", [(2, 25, 70, 15, 6, "idqn", True, 64), (4, 6, 16, 27, 6, "vdn", False, 64),
+                                                 (8, 5, 33, 39, 6, "idqn", True, 64), (4, 12, 20, 71, 5, "idqn", False, 64),
+                                                 (2, 1, 1, 12, 6, "vdn", True, 64), (2, 25, 70, 15, 6, "idqn", True, 128),
+                                                 (3, 7, 130, 18, 6, "vdn", False, 128), (4, 5, 20, 71, 5, "idqn", True, 128),
+                                                 (8, 3, 17, 39, 6, "idqn", False, 128)])
+def test_hip_loss_and_gradient_other_shapes_vs_port(P, T, B, D, A, mode, dq, H):
+    """hidden 64 (the whole network LDS-resident) and hidden 128 (the reference default: gate matrices streamed through LDS)"""
     from codebase_amd import hip as h
     from oracle import dqn_port as dp
 
-    H = 64
     gen = torch.Generator().manual_seed(P * 100 + D)
     params = 0.15 * torch.randn(P, gp.nparams(D, H, A), generator=gen)
     target = params + 0.05 * torch.randn(P, gp.nparams(D, H, A), generator=gen)
@@ -152,7 +155,11 @@ def test_recurrent_qnetwork_interface_matches_reference(name, mode):
     np.testing.assert_allclose(losses, g["losses"], rtol=5e-5)
     np.testing.assert_allclose(net.params.cpu().numpy(), g["params2"], rtol=0, atol=5e-6)
     with pytest.raises(NotImplementedError):
-        QNetwork(Tuple([Box(-1, 8, (D,))] * P), Tuple([Discrete(A)] * P), hyper, [128, 128], False, True, True, "cuda")
+        QNetwork(Tuple([Box(-1, 8, (D,))] * P), Tuple([Discrete(A)] * P), hyper, [32, 32], False, True, True, "cuda")
+    wide = QNetwork(Tuple([Box(-1, 8, (D,))] * P), Tuple([Discrete(A)] * P), hyper, [128, 128], False, True, True, "cuda")  # reference default
+    assert wide.state_dict()["critic.independent.0.rnn.weight_ih_l0"].shape == (384, 128)
+    acts, hid = wide.act([o for o in g["act_obs"][0]], wide.init_hiddens(1), 0.0)
+    assert hid[0].shape == (1, 1, 128) and len(acts) == P
 
 
 @pytest.mark.gpu
@@ -174,3 +181,23 @@ def test_recurrent_idqn_end_to_end(tmp_path, monkeypatch):
                    "seed=1", "algorithm.total_steps=400", "algorithm.training_start=100", "algorithm.batch_size=4",
                    "algorithm.eval_interval=200", "algorithm.eval_episodes=3"])
     assert df.shape[0] >= 1 and np.isfinite(df["loss"]).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("P,S,B,D,A", [(2, 26, 70, 15, 6), (4, 3, 16, 71, 5)])
+def test_hip_forward_hidden128_vs_port(P, S, B, D, A):
+    from codebase_amd import hip as h
+
+    H = 128
+    gen = torch.Generator().manual_seed(7)
+    params = 0.1 * torch.randn(P, gp.nparams(D, H, A), generator=gen)
+    obs = torch.randint(-1, 8, (P, S, B, D), generator=gen).float() * 0.25
+    spec = h.NetSpec(P, D, H, A)
+    q = h.gru_forward(spec, params.cuda(), obs.cuda())
+    np.testing.assert_allclose(q.cpu().numpy(), gp.q_values(params, obs, D, H, A).numpy(), rtol=0, atol=2e-5)
+    h0 = 0.3 * torch.randn(P, B, H, generator=gen)
+    q1, h1 = h.gru_forward(spec, params.cuda(), obs[:, :1].contiguous().cuda(), h_in=h0.cuda(), want_h=True)
+    for p in range(P):
+        qr, hr = gp.cell(gp.split(params[p], D, H, A), obs[p, 0], h0[p])
+        np.testing.assert_allclose(q1[p, 0].cpu().numpy(), qr.numpy(), rtol=0, atol=2e-5)
+        np.testing.assert_allclose(h1[p].cpu().numpy(), hr.numpy(), rtol=0, atol=2e-5)
