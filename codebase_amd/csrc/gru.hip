@@ -86,7 +86,7 @@ GruWs gru_ws_layout(int P, int T, int B) {
     const int64_t items = steps * nblk;
     const int cap = 256 / P > 1 ? 256 / P : 1;
     w.nwg = (int)(items < cap ? items : cap);
-    w.partials = take((int64_t)P * w.nwg * GruBwd<S>::NH * (S::NPARAM + 2));
+    w.partials = take((int64_t)P * w.nwg * (S::NPARAM + 2));
     w.packC = take((int64_t)P * S::NFWD);
     w.packT = take((int64_t)P * S::NFWD);
     w.packB = take((int64_t)P * GruBwd<S>::NBWD);
@@ -109,7 +109,7 @@ int gru_loss_grad(const marlhip_net_shape* s, const float* params, const float* 
     hipLaunchKernelGGL((gru_bwd_pack_kernel<S>), dim3((Bk::NBWD + 255) / 256, P), dim3(256), 0, st, params, am, f(wl.packB));
     MARL_CHECK_LAUNCH("gru pack kernels");
     const size_t ldsF = (size_t)S::LDS_FLOATS * sizeof(float), ldsB = (size_t)Bk::LDS_FLOATS * sizeof(float);
-    const size_t ldsW = (size_t)(8 * 16 * S::H + 256) * sizeof(float);
+    const size_t ldsW = (size_t)(4 * 16 * S::H + 256) * sizeof(float);
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_seq_fwd_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsF);
@@ -131,12 +131,11 @@ int gru_loss_grad(const marlhip_net_shape* s, const float* params, const float* 
     hipLaunchKernelGGL((gru_seq_bwd_kernel<S>), gridS, dim3(256), ldsB, st, (const float*)f(wl.packB), steps, B, (const float*)f(wl.rec),
                        (const float*)f(wl.dq), f(wl.rec2));
     MARL_CHECK_LAUNCH("gru_seq_bwd_kernel");
-    (void)hipMemsetAsync(f(wl.partials), 0, (size_t)P * wl.nwg * Bk::NH * (S::NPARAM + 2) * sizeof(float), st);
-    hipLaunchKernelGGL((gru_wgrad_kernel<S>), dim3(wl.nwg, P, Bk::NH), dim3(256), ldsW, st, steps, B, bt->obss, (const float*)f(wl.rec), (const float*)f(wl.rec2),
+    hipLaunchKernelGGL((gru_wgrad_kernel<S>), dim3(wl.nwg, P, 4), dim3(256), ldsW, st, steps, B, bt->obss, (const float*)f(wl.rec), (const float*)f(wl.rec2),
                        (const float*)f(wl.dq), (const float*)f(wl.lrow), bt->filled, f(wl.partials));
     MARL_CHECK_LAUNCH("gru_wgrad_kernel");
     const int n = P * S::NPARAM;
-    hipLaunchKernelGGL(dqn_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, st, (const float*)f(wl.partials), P, wl.nwg * Bk::NH, S::NPARAM, am, grad, loss);
+    hipLaunchKernelGGL(dqn_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, st, (const float*)f(wl.partials), P, wl.nwg, S::NPARAM, am, grad, loss);
     timing_end(TIMER_LOSSGRAD, st);
     MARL_CHECK_LAUNCH("dqn_reduce_kernel");
     return 0;

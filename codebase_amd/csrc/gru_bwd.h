@@ -25,8 +25,6 @@ struct GruBwd {
     static constexpr int CHUNK = MT * MT * 256;
     static constexpr bool STREAM = S::STREAM;
     static constexpr int LDS_FLOATS = STREAM ? pThh + CHUNK : NBWD;
-    // weight-gradient pass: column halves per workgroup so that the gate slices' accumulators fit the register file
-    static constexpr int NH = MT > 4 ? 4 : 1, MTN = MT / NH;
 };
 
 template <class S>
@@ -211,96 +209,63 @@ __global__ __launch_bounds__(256) void gru_seq_bwd_kernel(const float* __restric
     }
 }
 
-// One partial record [NPARAM + 2] per workgroup (canonical parameter order, then loss and n_filled from agent 0's rows).
+// One partial record [NPARAM + 2] per blockIdx.x (canonical parameter order, then loss and n_filled from agent 0's rows), filled
+// by four workgroups with disjoint roles (blockIdx.z): 0..2 = the rows of gate r / z / n of dW_ih and dW_hh, their four waves
+// owning a quarter of the columns each; 3 = the small parts (wave 0: dW1, db1; wave 1: dW3, db3, loss; wave 2: bias sums of
+// gates r, z; wave 3: bias sums of gate n).  Every role reads only the record arrays it needs.
 template <class S>
 __global__ __launch_bounds__(256) void gru_wgrad_kernel(int steps, int B, const float* __restrict__ obs, const float* __restrict__ rec,
                                                         const float* __restrict__ rec2, const float* __restrict__ dq,
                                                         const float* __restrict__ lrow, const float* __restrict__ filled,
                                                         float* __restrict__ partials) {
     using Bk = GruBwd<S>;
-    constexpr int MT = S::MT, H = S::H, D = S::D, A = S::A, NT1 = S::DP / 16, TILE = 16 * H, MTN = Bk::MTN;
-    extern __shared__ __attribute__((aligned(16))) float tiles[];  // 8 * TILE + 256 floats
-    const int half = blockIdx.z, nt0 = half * MTN;  // this workgroup's column tiles of the gate matrices (hidden 128: four column groups)
-    float* Tdr = tiles;             // gate gradients, [unit][16 rows]
-    float* Tdz = Tdr + TILE;
-    float* Tdn = Tdz + TILE;
-    float* Tdrn = Tdn + TILE;
-    float* Tx1 = Tdrn + TILE;
-    float* Thp = Tx1 + TILE;
-    float* Tdx = Thp + TILE;
-    float* Th = Tdx + TILE;
-    float* TQ = Th + TILE;
+    constexpr int MT = S::MT, H = S::H, D = S::D, A = S::A, NT1 = S::DP / 16, TILE = 16 * H, MTN = MT / 4;
+    extern __shared__ __attribute__((aligned(16))) float tiles[];  // 4 * TILE + 256 floats
+    float* T0 = tiles;
+    float* T1 = T0 + TILE;
+    float* T2 = T1 + TILE;
+    float* T3 = T2 + TILE;
+    float* TQ = T3 + TILE;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, j = lane & 15;
-    const int p = blockIdx.y, P = gridDim.y;
+    const int p = blockIdx.y, role = blockIdx.z;
     const int nblk = (B + 15) >> 4, T = steps - 1;
     const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    f4 dWa[MT][MTN], dWb[MT][MTN], dba[MT], dbb[MT];  // waves 0..2: dW_ih / dW_hh rows of their gate and the two bias sums
-    f4 dW1[MT][NT1], dW3[MT], db3 = zero4;           // wave 3 (its db1 lives in dba)
-#pragma unroll
-    for (int a = 0; a < MT; ++a) {
-        dba[a] = zero4; dbb[a] = zero4; dW3[a] = zero4;
-#pragma unroll
-        for (int b = 0; b < MTN; ++b) { dWa[a][b] = zero4; dWb[a][b] = zero4; }
-#pragma unroll
-        for (int b = 0; b < NT1; ++b) dW1[a][b] = zero4;
-    }
-    float loss_acc = 0.f, nf_acc = 0.f;
+    float* recd = partials + ((size_t)p * gridDim.x + blockIdx.x) * (S::NPARAM + 2);
     const int total = steps * nblk;
-    for (int item = blockIdx.x; item < total; item += gridDim.x) {
-        const int t = item / nblk, blk = item - t * nblk;
-        const int b0 = blk * 16;
-        const f4* R = reinterpret_cast<const f4*>(rec + (((size_t)p * steps + t) * nblk + blk) * S::REC);
-        const f4* Rp = reinterpret_cast<const f4*>(rec + (((size_t)p * steps + (t > 0 ? t - 1 : 0)) * nblk + blk) * S::REC);
-        const f4* R2 = reinterpret_cast<const f4*>(rec2 + (((size_t)p * steps + t) * nblk + blk) * Bk::REC2);
-        // ---- each wave transposes the arrays it is responsible for into the shared tiles (rows beyond B carry zeros already:
-        //      their dq is zero, so every gradient array is zero there; x1 / h of padding rows multiply those zeros)
-        f4 mine[MT], other[MT];
-        if (wave == 0) {
+    if (role < 3) {
+        // ---- gate `role`: dW_ih[gate rows][my columns] += dgi^T x1, dW_hh[...] += dgh^T h_prev
+        const int nt0 = wave * MTN;
+        f4 dWa[MT][MTN], dWb[MT][MTN];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) { mine[mt] = R2[(0 * MT + mt) * 64 + lane]; other[mt] = R[(0 * MT + mt) * 64 + lane]; }
-            tile_write<MT>(Tdr, mine, g, j);
-            tile_write<MT>(Tx1, other, g, j);
-        } else if (wave == 1) {
+        for (int a = 0; a < MT; ++a)
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) { mine[mt] = R2[(1 * MT + mt) * 64 + lane]; other[mt] = t > 0 ? Rp[(4 * MT + mt) * 64 + lane] : zero4; }
-            tile_write<MT>(Tdz, mine, g, j);
-            tile_write<MT>(Thp, other, g, j);
-        } else if (wave == 2) {
+            for (int b = 0; b < MTN; ++b) { dWa[a][b] = zero4; dWb[a][b] = zero4; }
+        const int gi_arr = role, gh_arr = role == 2 ? 3 : role;  // rec2 arrays: dr, dz, dn, r * dn
+        for (int item = blockIdx.x; item < total; item += gridDim.x) {
+            const int t = item / nblk, blk = item - t * nblk;
+            const f4* R = reinterpret_cast<const f4*>(rec + (((size_t)p * steps + t) * nblk + blk) * S::REC);
+            const f4* Rp = reinterpret_cast<const f4*>(rec + (((size_t)p * steps + (t > 0 ? t - 1 : 0)) * nblk + blk) * S::REC);
+            const f4* R2 = reinterpret_cast<const f4*>(rec2 + (((size_t)p * steps + t) * nblk + blk) * Bk::REC2);
+            // the four waves transpose one array each into the shared tiles ([unit][16 rows])
+            f4 v[MT];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) { mine[mt] = R2[(2 * MT + mt) * 64 + lane]; other[mt] = R2[(3 * MT + mt) * 64 + lane]; }
-            tile_write<MT>(Tdn, mine, g, j);
-            tile_write<MT>(Tdrn, other, g, j);
-        } else {
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) { mine[mt] = R2[(4 * MT + mt) * 64 + lane]; other[mt] = R[(4 * MT + mt) * 64 + lane]; }
-            tile_write<MT>(Tdx, mine, g, j);
-            tile_write<MT>(Th, other, g, j);
-            f4 dQ[1];
-            const bool rowok = b0 + j < B;
-            const float* drow = dq + (((size_t)p * steps + t) * B + (rowok ? b0 + j : B - 1)) * A;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) dQ[0][r] = (rowok && 4 * g + r < A) ? drow[4 * g + r < A ? 4 * g + r : A - 1] : 0.f;
-            tile_write<1>(TQ, dQ, g, j);
-            db3 += dQ[0];
-            if (g == 0 && p == 0 && rowok && t < T) {
-                loss_acc += lrow[(size_t)t * B + b0 + j];
-                nf_acc += filled[(size_t)t * B + b0 + j];
+            for (int mt = 0; mt < MT; ++mt) {
+                if (wave == 0) v[mt] = R2[(gi_arr * MT + mt) * 64 + lane];
+                else if (wave == 1) v[mt] = R2[(gh_arr * MT + mt) * 64 + lane];
+                else if (wave == 2) v[mt] = R[(0 * MT + mt) * 64 + lane];                      // x1
+                else v[mt] = t > 0 ? Rp[(4 * MT + mt) * 64 + lane] : zero4;                    // h_{t-1}
             }
-        }
-        __syncthreads();
-        if (wave < 3) {
-            // gate `wave`: dW_ih[gate rows][:] += dgi^T x1, dW_hh[gate rows][:] += dgh^T h_prev, bias sums of both
-            const float* Tgi = wave == 0 ? Tdr : (wave == 1 ? Tdz : Tdn);
-            const float* Tgh = wave == 0 ? Tdr : (wave == 1 ? Tdz : Tdrn);
+            tile_write<MT>(wave == 0 ? T0 : (wave == 1 ? T1 : (wave == 2 ? T2 : T3)), v, g, j);
+            __syncthreads();
             f4 bX[MTN], bH[MTN];
 #pragma unroll
             for (int nt = 0; nt < MTN; ++nt) {
-                bX[nt] = tile_read(Tx1, nt0 + nt, g, j);
-                bH[nt] = tile_read(Thp, nt0 + nt, g, j);
+                bX[nt] = tile_read(T2, nt0 + nt, g, j);
+                bH[nt] = tile_read(T3, nt0 + nt, g, j);
             }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                const f4 aI = tile_read(Tgi, mt, g, j), aH = tile_read(Tgh, mt, g, j);
+                const f4 aI = tile_read(T0, mt, g, j), aH = tile_read(T1, mt, g, j);
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
@@ -309,88 +274,122 @@ __global__ __launch_bounds__(256) void gru_wgrad_kernel(int steps, int B, const 
                         dWb[mt][nt] = MARL_MFMA(aH[ks], bH[nt][ks], dWb[mt][nt]);
                     }
             }
-            // bias sums from the C-layout registers this wave loaded (gate r / z: dgi == dgh; gate n: dn and r * dn)
-            if (wave == 2) {
+            __syncthreads();  // tiles are rewritten by the next item
+        }
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) { dba[mt] += mine[mt]; dbb[mt] += other[mt]; }
-            } else {
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) { dba[mt] += mine[mt]; dbb[mt] += mine[mt]; }
+            for (int r = 0; r < 4; ++r) {
+                const int v = role * H + 16 * mt + 4 * g + r;
+#pragma unroll
+                for (int nt = 0; nt < MTN; ++nt) {
+                    recd[S::oWih + v * H + 16 * (nt0 + nt) + j] = dWa[mt][nt][r];
+                    recd[S::oWhh + v * H + 16 * (nt0 + nt) + j] = dWb[mt][nt][r];
+                }
             }
-        } else if (half == 0) {
-            // first layer: dW1 += dx1^T x (B operand straight from the observations), db1; output layer: dW3 += dq^T h, db3
-            f4 aX[MT], bHt[MT];
-            const f4 aQ = tile_read(TQ, 0, g, j);
+        return;
+    }
+    // ---- role 3: the small parts, one per wave (no cross-wave traffic: per-wave tiles)
+    float* TA = wave == 0 ? T0 : T1;  // wave 0: dx1 tile; wave 1: h tile (+ TQ)
+    f4 acc1[MT][NT1], acc3[MT], sa[MT], sb[MT], sc[MT], db3 = zero4;
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                aX[mt] = tile_read(Tdx, mt, g, j);
-                bHt[mt] = tile_read(Th, mt, g, j);
-                dba[mt] += mine[mt];
-            }
+    for (int a = 0; a < MT; ++a) {
+        acc3[a] = zero4; sa[a] = zero4; sb[a] = zero4; sc[a] = zero4;
+#pragma unroll
+        for (int b = 0; b < NT1; ++b) acc1[a][b] = zero4;
+    }
+    float loss_acc = 0.f, nf_acc = 0.f;
+    for (int item = blockIdx.x; item < total; item += gridDim.x) {
+        const int t = item / nblk, blk = item - t * nblk;
+        const int b0 = blk * 16;
+        const f4* R = reinterpret_cast<const f4*>(rec + (((size_t)p * steps + t) * nblk + blk) * S::REC);
+        const f4* R2 = reinterpret_cast<const f4*>(rec2 + (((size_t)p * steps + t) * nblk + blk) * Bk::REC2);
+        if (wave == 0) {  // dW1 += dx1^T x (B operand straight from the observations), db1
+            f4 v[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) { v[mt] = R2[(4 * MT + mt) * 64 + lane]; sa[mt] += v[mt]; }
+            wave_lds_fence();
+            tile_write<MT>(TA, v, g, j);
+            wave_lds_fence();
             float bx[NT1][4];
 #pragma unroll
             for (int nt = 0; nt < NT1; ++nt)
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
                     const int row = b0 + 4 * g + ks, d = 16 * nt + j;
-                    const float v = obs[(((size_t)p * steps + t) * B + (row < B ? row : B - 1)) * D + (d < D ? d : D - 1)];
-                    bx[nt][ks] = (row < B && d < D) ? v : 0.f;
+                    const float xv = obs[(((size_t)p * steps + t) * B + (row < B ? row : B - 1)) * D + (d < D ? d : D - 1)];
+                    bx[nt][ks] = (row < B && d < D) ? xv : 0.f;
                 }
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
+            for (int mt = 0; mt < MT; ++mt) {
+                const f4 aX = tile_read(TA, mt, g, j);
 #pragma unroll
-                for (int nt = 0; nt < MT; ++nt) dW3[nt] = MARL_MFMA(aQ[ks], bHt[nt][ks], dW3[nt]);
+                for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-                for (int nt = 0; nt < NT1; ++nt)
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) dW1[mt][nt] = MARL_MFMA(aX[mt][ks], bx[nt][ks], dW1[mt][nt]);
+                    for (int nt = 0; nt < NT1; ++nt) acc1[mt][nt] = MARL_MFMA(aX[ks], bx[nt][ks], acc1[mt][nt]);
             }
+        } else if (wave == 1) {  // dW3 += dq^T h, db3, loss bookkeeping
+            f4 v[MT], dQ[1];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) v[mt] = R[(4 * MT + mt) * 64 + lane];
+            const bool rowok = b0 + j < B;
+            const float* drow = dq + (((size_t)p * steps + t) * B + (rowok ? b0 + j : B - 1)) * A;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dQ[0][r] = (rowok && 4 * g + r < A) ? drow[4 * g + r < A ? 4 * g + r : A - 1] : 0.f;
+            db3 += dQ[0];
+            if (g == 0 && p == 0 && rowok && t < T) {
+                loss_acc += lrow[(size_t)t * B + b0 + j];
+                nf_acc += filled[(size_t)t * B + b0 + j];
+            }
+            wave_lds_fence();
+            tile_write<MT>(TA, v, g, j);
+            tile_write<1>(TQ, dQ, g, j);
+            wave_lds_fence();
+            const f4 aQ = tile_read(TQ, 0, g, j);
+#pragma unroll
+            for (int nt = 0; nt < MT; ++nt) {
+                const f4 bH = tile_read(TA, nt, g, j);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) acc3[nt] = MARL_MFMA(aQ[ks], bH[ks], acc3[nt]);
+            }
+        } else if (wave == 2) {  // bias sums of gates r and z (dgi == dgh there)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) { sa[mt] += R2[(0 * MT + mt) * 64 + lane]; sb[mt] += R2[(1 * MT + mt) * 64 + lane]; }
+        } else {  // bias sums of gate n: dn (ih) and r * dn (hh)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) { sa[mt] += R2[(2 * MT + mt) * 64 + lane]; sc[mt] += R2[(3 * MT + mt) * 64 + lane]; }
         }
-        __syncthreads();  // tiles are rewritten by the next item
     }
-    // ---- record: every wave stores its own slices (no fold: the slices are disjoint)
-    // (the records are zeroed before the launch: with two column halves a workgroup fills only its part)
-    float* recd = partials + ((size_t)p * gridDim.x * Bk::NH + (size_t)half * gridDim.x + blockIdx.x) * (S::NPARAM + 2);
-    (void)P;
-    if (wave < 3) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int v = wave * H + 16 * mt + 4 * g + r;
-#pragma unroll
-                for (int nt = 0; nt < MTN; ++nt) {
-                    recd[S::oWih + v * H + 16 * (nt0 + nt) + j] = dWa[mt][nt][r];
-                    recd[S::oWhh + v * H + 16 * (nt0 + nt) + j] = dWb[mt][nt][r];
-                }
-                const float sa = sum16(dba[mt][r]), sb = sum16(dbb[mt][r]);
-                if (j == 0 && half == 0) {
-                    recd[S::obih + v] = sa;
-                    recd[S::obhh + v] = sb;
-                }
-            }
-        }
-    } else if (half == 0) {
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int v = 16 * mt + 4 * g + r;
+        for (int r = 0; r < 4; ++r) {
+            const int v = 16 * mt + 4 * g + r;
+            const float s_a = sum16(sa[mt][r]), s_b = sum16(sb[mt][r]), s_c = sum16(sc[mt][r]);
+            if (wave == 0) {
 #pragma unroll
                 for (int nt = 0; nt < NT1; ++nt)
-                    if (16 * nt + j < D) recd[S::oW1 + v * D + 16 * nt + j] = dW1[mt][nt][r];
-                const float s1 = sum16(dba[mt][r]);
-                if (j == 0) recd[S::ob1 + v] = s1;
-                const int a = 4 * g + r;  // dW3[nt][r]: element (a, unit 16nt + j) - here `mt` plays nt
-                if (a < A) recd[S::oW3 + a * H + 16 * mt + j] = dW3[mt][r];
+                    if (16 * nt + j < D) recd[S::oW1 + v * D + 16 * nt + j] = acc1[mt][nt][r];
+                if (j == 0) recd[S::ob1 + v] = s_a;
+            } else if (wave == 1) {
+                const int a = 4 * g + r;  // acc3[nt][r]: element (a, unit 16nt + j) - here `mt` plays nt
+                if (a < A) recd[S::oW3 + a * H + 16 * mt + j] = acc3[mt][r];
+            } else if (wave == 2) {
+                if (j == 0) {
+                    recd[S::obih + v] = s_a; recd[S::obhh + v] = s_a;
+                    recd[S::obih + H + v] = s_b; recd[S::obhh + H + v] = s_b;
+                }
+            } else if (j == 0) {
+                recd[S::obih + 2 * H + v] = s_a;
+                recd[S::obhh + 2 * H + v] = s_c;
             }
         }
+    if (wave == 1) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float s3 = sum16(db3[r]);
             if (j == 0 && 4 * g + r < A) recd[S::ob3 + 4 * g + r] = s3;
         }
-        // loss / n_filled: lanes g == 0 hold the per-row values; sum over the 16 rows
         const float ls = sum16(loss_acc), nf = sum16(nf_acc);
         if (lane == 0) {
             recd[S::NPARAM] = ls;
