@@ -15,6 +15,32 @@ MARL_PART_DECL(lossgrad_part_h128)
 MARL_PART_DECL(lossgrad_part_h128_oid)
 MARL_PART_DECL(lossgrad_part_rware)
 #undef MARL_PART_DECL
+#define MARL_PART_MIX_DECL(name) \
+    int name(const marlhip_net_shape*, const QmixCtx*, const marlhip_batch*, const QmixIo*, float, int, const float*, hipStream_t, bool*);
+MARL_PART_MIX_DECL(lossgrad_part_h64_mix)
+MARL_PART_MIX_DECL(lossgrad_part_h64_oid_mix)
+MARL_PART_MIX_DECL(lossgrad_part_rware_mix)
+#undef MARL_PART_MIX_DECL
+
+// QMIX mixer stage for callers that ran the agent networks themselves (gru.hip): phase 0 = mix, phase 1 = mixer-gradient reduce
+int qmix_mix_stage(const marlhip_net_shape* s, const QmixCtx* qx, const marlhip_batch* bt, const QmixIo* io, float gamma, int phase,
+                   const float* loss, hipStream_t stream) {
+    bool found = false;
+    for (auto part : {&lossgrad_part_h64_mix, &lossgrad_part_h64_oid_mix, &lossgrad_part_rware_mix}) {
+        const int rc = part(s, qx, bt, io, gamma, phase, loss, stream, &found);
+        if (found) return rc;
+    }
+    set_error("no QMIX mixer kernel for %d agents x %d observations", s->n_agents, s->obs_dim);
+    return -1;
+}
+
+int64_t qmix_mixer_ws_bytes(const marlhip_net_shape* s, int32_t max_len, int32_t batch) {
+#define X(p, d) if (s->n_agents == p && s->obs_dim == d) return qmix_ws_layout<QmixShape<p, d>>(max_len, batch).total;
+    MARL_QMIX_SHAPES(X)
+#undef X
+    set_error("no QMIX mixer kernel for %d agents x %d observations", s->n_agents, s->obs_dim);
+    return -1;
+}
 }  // namespace marl
 
 extern "C" int marlhip_net_nparams(const marlhip_net_shape* s) {

@@ -18,4 +18,22 @@ int MARL_PART_NAME(const marlhip_net_shape* s, const float* params, const float*
     return 0;
 }
 
+// the QMIX mixer stage alone (phase 0: mixers forward + backward from given chosen / bootstrap values; phase 1: the mixer-gradient
+// reduce), for callers that compute the agent networks themselves (the recurrent path, gru.hip); keyed on the observation width
+#define MARL_PART_CAT2(a, b) a##b
+#define MARL_PART_CAT(a, b) MARL_PART_CAT2(a, b)
+int MARL_PART_CAT(MARL_PART_NAME, _mix)(const marlhip_net_shape* s, const QmixCtx* qx, const marlhip_batch* bt, const QmixIo* io, float gamma,
+                                       int phase, const float* loss, hipStream_t stream, bool* found) {
+    *found = true;
+    const ReplaySrc none = {};
+#define X(d, h, a)                                                                                                       \
+    if (s->obs_dim == d)                                                                                                 \
+        return phase == 0 ? qmix_dispatch_mix<d, false>(s->n_agents, *qx, bt, none, *io, gamma, stream)                   \
+                          : qmix_dispatch_reduce<d>(s->n_agents, *qx, bt->max_len, bt->batch, loss, stream);
+    MARL_PART_SHAPES(X)
+#undef X
+    *found = false;
+    return 0;
+}
+
 }  // namespace marl

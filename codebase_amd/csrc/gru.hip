@@ -195,3 +195,141 @@ extern "C" int marlhip_act_from_q(int32_t n_agents, int32_t n_envs, int32_t n_ac
     MARL_CHECK_LAUNCH("act_from_q_kernel");
     return 0;
 }
+
+// ---- recurrent QMIX: the agent networks here, the mixer stage of qmix.h through dqn_update.hip ------------------------------
+namespace marl {
+int qmix_mix_stage(const marlhip_net_shape* s, const QmixCtx* qx, const marlhip_batch* bt, const QmixIo* io, float gamma, int phase,
+                   const float* loss, hipStream_t stream);
+int64_t qmix_mixer_ws_bytes(const marlhip_net_shape* s, int32_t max_len, int32_t batch);
+}
+
+// chosen_p = Q_p(o_t)[a_t], bootstrap_p = target Q_p(o_{t+1})[argmax] (QMixNetwork._compute_loss, dqn/model.py:384-410), and the
+// transition's scalars in the [R] = [T * B] layout the mixer kernels read
+static __global__ __launch_bounds__(256) void gru_qsel_kernel(int P, int T, int B, int A, const float* __restrict__ q, const float* __restrict__ tq,
+                                                       marlhip_batch bt, int double_q, float* __restrict__ chosen, float* __restrict__ tqsel,
+                                                       float* __restrict__ r0, float* __restrict__ dn, float* __restrict__ fl) {
+    const int i = blockIdx.x * 256 + threadIdx.x, R = T * B;
+    if (i >= R) return;
+    const int t = i / B, b = i - t * B;
+    for (int p = 0; p < P; ++p) {
+        const float* qn = q + (((size_t)p * (T + 1) + t + 1) * B + b) * A;
+        const float* tn = tq + (((size_t)p * (T + 1) + t + 1) * B + b) * A;
+        const float* mk = bt.action_mask ? bt.action_mask + (((size_t)p * (T + 1) + t + 1) * B + b) * A : nullptr;
+        int best = 0;
+        float bv = -__builtin_huge_valf();
+        for (int a = 0; a < A; ++a) {
+            float v = double_q ? qn[a] : tn[a];
+            if (mk != nullptr && mk[a] == 0.f) v = -1e8f;
+            if (v > bv) { bv = v; best = a; }
+        }
+        float boot = tn[best];
+        if (mk != nullptr && mk[best] == 0.f) boot = -1e8f;
+        tqsel[(size_t)p * R + i] = boot;
+        chosen[(size_t)p * R + i] = q[(((size_t)p * (T + 1) + t) * B + b) * A + (int)bt.actions[((size_t)p * T + t) * B + b]];
+    }
+    r0[i] = bt.rewards[i];  // batch.rewards[0] (model.py:379)
+    dn[i] = bt.dones[(size_t)(t + 1) * B + b];
+    fl[i] = bt.filled[i];
+}
+
+// dL/dchosen_p [P][R] from the mixer -> dense dL/dq rows [P][T+1][B][A] (row T was zeroed)
+static __global__ __launch_bounds__(256) void gru_expand_dq_kernel(int P, int T, int B, int A, const float* __restrict__ dqm, marlhip_batch bt,
+                                                            float* __restrict__ dq) {
+    const int i = blockIdx.x * 256 + threadIdx.x, R = T * B;
+    if (i >= R) return;
+    const int t = i / B, b = i - t * B;
+    for (int p = 0; p < P; ++p) {
+        const int act = (int)bt.actions[((size_t)p * T + t) * B + b];
+        const float v = dqm[(size_t)p * R + i];
+        for (int a = 0; a < A; ++a) dq[(((size_t)p * (T + 1) + t) * B + b) * A + a] = a == act ? v : 0.f;
+    }
+}
+
+namespace {
+template <class S>
+int gru_qmix_loss_grad(const marlhip_net_shape* s, const float* params, const float* target, const marlhip_qmix_mixer* mx, const marlhip_batch* bt,
+                       float gamma, int double_q, void* ws, int64_t ws_bytes, float* grad, float* loss, hipStream_t st) {
+    using Bk = GruBwd<S>;
+    const int P = s->n_agents, T = bt->max_len, B = bt->batch, steps = T + 1;
+    const int64_t R = (int64_t)T * B;
+    const GruWs wl = gru_ws_layout<S>(P, T, B);
+    const int64_t extra = ((3 * P + 3) * R * 4 + 255) / 256 * 256;  // chosen, tqsel, dqm [P][R]; r0, dn, fl [R]
+    const int64_t mixws = qmix_mixer_ws_bytes(s, T, B);
+    if (mixws < 0) return -1;
+    MARL_REQUIRE(ws_bytes >= wl.total + extra + mixws, "gru_qmix_loss_grad: workspace %lld < %lld bytes", (long long)ws_bytes,
+                 (long long)(wl.total + extra + mixws));
+    char* base = static_cast<char*>(ws);
+    auto f = [&](int64_t o) { return reinterpret_cast<float*>(base + o); };
+    float* chosen = f(wl.total);
+    float* tqsel = chosen + P * R;
+    float* dqm = tqsel + P * R;
+    float* r0 = dqm + P * R;
+    float* dn = r0 + R;
+    float* fl = dn + R;
+    QmixCtx qx;
+    qx.mixer = mx->mixer; qx.tmixer = mx->target_mixer; qx.mgrad = mx->mixer_grad;
+    qx.ws = base + wl.total + extra; qx.ws_bytes = mixws;
+    const AgentMap am = agent_map(s);
+    hipLaunchKernelGGL((gru_pack_kernel<S>), dim3((S::NFWD + 255) / 256, P), dim3(256), 0, st, params, am, f(wl.packC));
+    hipLaunchKernelGGL((gru_pack_kernel<S>), dim3((S::NFWD + 255) / 256, P), dim3(256), 0, st, target, am, f(wl.packT));
+    hipLaunchKernelGGL((gru_bwd_pack_kernel<S>), dim3((Bk::NBWD + 255) / 256, P), dim3(256), 0, st, params, am, f(wl.packB));
+    MARL_CHECK_LAUNCH("gru pack kernels");
+    const size_t ldsF = (size_t)S::LDS_FLOATS * sizeof(float), ldsB = (size_t)Bk::LDS_FLOATS * sizeof(float);
+    const size_t ldsW = (size_t)(4 * 16 * S::H + 256) * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_seq_fwd_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsF);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_seq_bwd_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsB);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_wgrad_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsW);
+        attr = true;
+    }
+    const dim3 gridS((B + 63) / 64, P), gridR((unsigned)((R + 255) / 256));
+    timing_begin(TIMER_LOSSGRAD, st);
+    hipLaunchKernelGGL((gru_seq_fwd_kernel<S>), gridS, dim3(256), ldsF, st, (const float*)f(wl.packC), bt->obss, steps, B, (const float*)nullptr,
+                       (float*)nullptr, f(wl.q), f(wl.rec));
+    hipLaunchKernelGGL((gru_seq_fwd_kernel<S>), gridS, dim3(256), ldsF, st, (const float*)f(wl.packT), bt->obss, steps, B, (const float*)nullptr,
+                       (float*)nullptr, f(wl.tq), (float*)nullptr);
+    hipLaunchKernelGGL(gru_qsel_kernel, gridR, dim3(256), 0, st, P, T, B, S::A, (const float*)f(wl.q), (const float*)f(wl.tq), *bt, double_q, chosen,
+                       tqsel, r0, dn, fl);
+    MARL_CHECK_LAUNCH("gru forward / qsel");
+    QmixIo io = {chosen, tqsel, r0, dn, fl, dqm, f(wl.lrow), nullptr};
+    int rc = qmix_mix_stage(s, &qx, bt, &io, gamma, 0, nullptr, st);
+    if (rc != 0) return rc;
+    (void)hipMemsetAsync(f(wl.dq), 0, (size_t)P * steps * B * S::A * sizeof(float), st);
+    hipLaunchKernelGGL(gru_expand_dq_kernel, gridR, dim3(256), 0, st, P, T, B, S::A, (const float*)dqm, *bt, f(wl.dq));
+    hipLaunchKernelGGL((gru_seq_bwd_kernel<S>), gridS, dim3(256), ldsB, st, (const float*)f(wl.packB), steps, B, (const float*)f(wl.rec),
+                       (const float*)f(wl.dq), f(wl.rec2));
+    hipLaunchKernelGGL((gru_wgrad_kernel<S>), dim3(wl.nwg, P, 4), dim3(256), ldsW, st, steps, B, bt->obss, (const float*)f(wl.rec), (const float*)f(wl.rec2),
+                       (const float*)f(wl.dq), (const float*)f(wl.lrow), bt->filled, f(wl.partials));
+    MARL_CHECK_LAUNCH("gru backward");
+    const int n = P * S::NPARAM;
+    hipLaunchKernelGGL(dqn_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, st, (const float*)f(wl.partials), P, wl.nwg, S::NPARAM, am, grad, loss);
+    timing_end(TIMER_LOSSGRAD, st);
+    MARL_CHECK_LAUNCH("dqn_reduce_kernel");
+    return qmix_mix_stage(s, &qx, bt, &io, gamma, 1, loss, st);
+}
+}  // namespace
+
+extern "C" int64_t marlhip_gru_qmix_workspace_bytes(const marlhip_net_shape* s, int32_t max_len, int32_t batch) {
+    const int64_t a = marlhip_gru_workspace_bytes(s, max_len, batch), m = a < 0 ? -1 : qmix_mixer_ws_bytes(s, max_len, batch);
+    if (a < 0 || m < 0) return -1;
+    return a + (((int64_t)(3 * s->n_agents + 3) * max_len * batch * 4 + 255) / 256 * 256) + m;
+}
+
+extern "C" int marlhip_gru_qmix_loss_grad(const marlhip_net_shape* s, const float* params, const float* target_params, const marlhip_qmix_mixer* mixer,
+                                          const marlhip_batch* batch, float gamma, int32_t double_q, void* workspace, int64_t workspace_bytes,
+                                          float* grad, float* loss, void* stream) {
+    if (gru_check(s) != 0) return -1;
+    MARL_REQUIRE(params && target_params && mixer && mixer->mixer && mixer->target_mixer && mixer->mixer_grad && batch && workspace && grad && loss,
+                 "gru_qmix_loss_grad: NULL pointer");
+    MARL_REQUIRE(mixer->embed_dim == 64 && mixer->hypernet_layers == 2 && mixer->hypernet_embed == 32, "gru_qmix_loss_grad: mixing = {64, 2, 32} only");
+    MARL_REQUIRE(s->n_networks == 0, "gru_qmix_loss_grad: parameter sharing is not built for recurrent networks");
+    MARL_REQUIRE(batch->obs_agent_stride == 0 && batch->obs_row_stride == 0, "gru_qmix_loss_grad: the dqn/train.py Batch layout only");
+#define X(d, h, a)                                               \
+    if (s->obs_dim == d && s->hidden == h && s->n_actions == a)  \
+        return gru_qmix_loss_grad<GruShape<d, h, a>>(s, params, target_params, mixer, batch, gamma, double_q, workspace, workspace_bytes, grad, loss, \
+                                                     (hipStream_t)stream);
+    MARL_GRU_SHAPES(X)
+#undef X
+    return -1;
+}

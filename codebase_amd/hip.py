@@ -631,3 +631,31 @@ def act_from_q(q, epsilon, seed, episode, ep_length, actions=None):
     check(lib.marlhip_act_from_q(P, N, A, _ptr(q.contiguous()), float(epsilon), int(seed) & (2**64 - 1), _ptr(episode), _ptr(ep_length),
                                  _ptr(actions), _stream()), "act_from_q")
     return actions
+
+
+class GruQmixUpdater(QmixUpdater):
+    """QmixUpdater with recurrent agent networks: marlhip_gru_qmix_loss_grad for the step, everything else inherited
+    (joint critic | mixer gradient buffer, critic-only clipping, one Adam step count)."""
+
+    def _gru_ws(self, T, B):
+        key = ("gru", T, B)
+        if key not in self._ws:
+            s = self.spec.c()
+            n = check(lib.marlhip_gru_qmix_workspace_bytes(ctypes.byref(s), T, B), "gru_qmix_workspace_bytes")
+            self._ws.clear()
+            self._ws[key] = torch.empty(int(n), dtype=torch.uint8, device=self.params.device)
+        return self._ws[key]
+
+    def loss_grad(self, batch, mode=2):
+        T, B = batch.filled.shape
+        ws = self._gru_ws(T, B)
+        bs = BatchStruct(batch.obss.data_ptr(), batch.actions.data_ptr(), batch.rewards.data_ptr(), batch.dones.data_ptr(),
+                         batch.filled.data_ptr(), T, B, 0, 0, 0, 0, _mask_ptr(batch.action_mask, (self.spec.n_agents, T + 1, B, self.spec.n_actions)))
+        s, mx = self.spec.c(), self._mx()
+        check(lib.marlhip_gru_qmix_loss_grad(ctypes.byref(s), _ptr(self.params), _ptr(self.target), ctypes.byref(mx), ctypes.byref(bs),
+                                             float(self.gamma), self.double_q, _ptr(ws), ws.numel(), _ptr(self.grad), _ptr(self.loss),
+                                             _stream()), "gru_qmix_loss_grad")
+        return self.loss, self.grad
+
+    def loss_grad_replay(self, replay, batch_size, length=None, idx=None, seed=0, counter=0, idx_out=None, mode=2):
+        return self.loss_grad(replay.sample(batch_size, length=length, idx=idx, seed=seed, counter=counter), mode=mode)

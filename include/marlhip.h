@@ -328,6 +328,14 @@ int marlhip_gru_loss_grad(const marlhip_net_shape* s, const float* params, const
                           float gamma, int32_t double_q, int32_t mode, void* workspace, int64_t workspace_bytes, float* grad,
                           float* loss /* [2] */, void* stream);
 
+/* QMixNetwork._compute_loss + backward with recurrent agent networks: the sequence kernels above for the agents, the mixer stage
+ * of marlhip_qmix_loss_grad (same kernels, same mixer block layout) between them.  grad: agents' blocks; mixer->mixer_grad: the
+ * mixer's; loss[2] as everywhere. */
+int64_t marlhip_gru_qmix_workspace_bytes(const marlhip_net_shape* s, int32_t max_len, int32_t batch);
+int marlhip_gru_qmix_loss_grad(const marlhip_net_shape* s, const float* params, const float* target_params,
+                               const struct marlhip_qmix_mixer* mixer, const marlhip_batch* batch, float gamma, int32_t double_q,
+                               void* workspace, int64_t workspace_bytes, float* grad, float* loss /* [2] */, void* stream);
+
 /* the action choice of QNetwork.act (dqn/model.py:105-115) from given values q [P][N][A] (the recurrent path computes them with
  * marlhip_gru_forward): explore iff epsilon > u with ONE Philox uniform per env (env n, episode[n], t = ep_length[n], word 0),
  * random action of agent p = word 1+p, greedy = first maximum - the same words marlhip_dqn_act and the fused collector use. */

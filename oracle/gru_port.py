@@ -73,3 +73,15 @@ def compute_loss(params, tparams, batch, gamma, double_q, D, H, A, mode="idqn"):
         return dp.compute_loss(params, tparams, batch, gamma, double_q, D, H, A, mode=mode)
     finally:
         dp.q_values = saved
+
+
+def compute_qmix_loss(params, tparams, mixer, tmixer, batch, gamma, double_q, D, H, A):
+    """qmix_port.compute_loss with the recurrent agent networks (QMixNetwork._compute_loss, dqn/model.py:374-427)"""
+    from . import qmix_port as qp
+
+    saved = dp.q_values
+    dp.q_values = q_values
+    try:
+        return qp.compute_loss(params, tparams, mixer, tmixer, batch, gamma, double_q, D, H, A)
+    finally:
+        dp.q_values = saved

@@ -8,6 +8,7 @@ Q-values of the whole batch (critic) for a forward-only check, loss and gradient
 update(), and an `act` trace: 6 greedy steps of one env with the hidden states the reference carries between them.
   learner_gru_idqn_H64.npz   2 agents x 15 obs, QNetwork, 64-64
   learner_gru_vdn_H64.npz    3 agents x 18 obs, VDNetwork, 64-64
+  learner_gru_qmix_H64.npz   2 agents x 15 obs, QMixNetwork (loss, agent + mixer gradients, 2 updates)
 """
 import contextlib
 import io
@@ -65,6 +66,42 @@ def fixture(ref_model, ref_train, name, cls, P, D, H, B, seed):
     print(name, float(out["loss0"]), out["losses"].tolist(), out["params0"].shape)
 
 
+def qmix_fixture(ref_model, ref_train, name, P, D, H, B, seed):
+    """QMixNetwork(use_rnn=True): loss, agent and mixer gradients, 2 updates"""
+    from .make_golden_qmix import mixer_flat, mixer_grad
+
+    T, A = 8, 6
+    torch.manual_seed(seed)
+    cfg = Cfg(optimizer="Adam", lr=3e-4, gamma=0.99, grad_clip=1.0, target_update_interval_or_tau=200, double_q=True,
+              standardise_returns=False)
+    mixing = dict(embed_dim=64, hypernet_layers=2, hypernet_embed=32)
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = ref_model.QMixNetwork([Box(D)] * P, [Discrete(A)] * P, cfg, [H, H], False, True, True, mixing, "cpu")
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for p in list(net.target.parameters()) + list(net.target_mixer.parameters()):
+            p.add_(0.04 * torch.randn(p.shape, generator=g))
+    out = dict(P=P, T=T, B=B, D=D, A=A, H=H, params0=flat_params(net.critic).numpy(), target0=flat_params(net.target).numpy(),
+               mixer0=mixer_flat(net.mixer).numpy(), tmixer0=mixer_flat(net.target_mixer).numpy(), keys=np.array(list(net.state_dict().keys())))
+    batch = synthetic_batch(P, T, B, D, A, seed=seed + 7)
+    batch["obss"] = batch["obss"] * 0.25
+    batch["rewards"][1:] = batch["rewards"][0]
+    for k, v in batch.items():
+        out[f"batch_{k}"] = v.numpy()
+    bb = ref_train.Batch(batch["obss"], batch["actions"], batch["rewards"], batch["dones"], batch["filled"], None)
+    loss = net._compute_loss(bb)
+    net.optimizer.zero_grad()
+    loss.backward()
+    out["loss0"] = np.float32(loss.item())
+    out["grad0"] = torch.stack([torch.cat([p.grad.reshape(-1) for p in m.parameters()]) for m in net.critic.independent]).numpy()
+    out["mgrad0"] = mixer_grad(net.mixer).numpy()
+    net.optimizer.zero_grad()
+    out["losses"] = np.array([net.update(bb)["loss"] for _ in range(2)], np.float32)
+    out["params2"], out["mixer2"] = flat_params(net.critic).numpy(), mixer_flat(net.mixer).numpy()
+    np.savez_compressed(os.path.join(OUT, name), **out)
+    print(name, float(out["loss0"]), out["losses"].tolist())
+
+
 if __name__ == "__main__":
     torch.set_num_threads(1)
     import_reference()
@@ -73,3 +110,4 @@ if __name__ == "__main__":
 
     fixture(rm, rt, "learner_gru_idqn_H64.npz", rm.QNetwork, P=2, D=15, H=64, B=37, seed=2100)
     fixture(rm, rt, "learner_gru_vdn_H64.npz", rm.VDNetwork, P=3, D=18, H=64, B=21, seed=2200)
+    qmix_fixture(rm, rt, "learner_gru_qmix_H64.npz", P=2, D=15, H=64, B=19, seed=2300)
