@@ -20,7 +20,7 @@ import numpy as np
 import torch
 
 from .. import hip as _hip
-from ..dqn.model import _fc, _tensor_layout, sharing_indices
+from ..dqn.model import _fc, _gru_layout, _tensor_layout, init_flat_gru_params, sharing_indices
 from ..spaces import flatdim
 
 
@@ -43,9 +43,11 @@ class A2CNetwork:
         self.sharing = sharing_indices(_get(actor, "parameter_sharing", False), P)
         if sharing_indices(_get(critic, "parameter_sharing", False), P) != self.sharing:
             raise NotImplementedError("actor.parameter_sharing != critic.parameter_sharing: one agent -> network map serves both")
-        for name, net in (("actor", actor), ("critic", critic)):
-            if _get(net, "use_rnn", False):
-                raise NotImplementedError(f"{name}.use_rnn: recurrent networks are built for the DQN family (QNetwork / VDNetwork) only (DESIGN.md)")
+        self.recurrent = bool(_get(actor, "use_rnn", False))
+        if bool(_get(critic, "use_rnn", False)) != self.recurrent:
+            raise NotImplementedError("actor.use_rnn != critic.use_rnn: the recurrent step is built for recurrent actors AND critics")
+        if self.recurrent and (self.sharing is not None or bool(_get(critic, "centralised", False))):
+            raise NotImplementedError("use_rnn with parameter sharing / centralised critics is not built (DESIGN.md)")
         ha, hc = [int(h) for h in _get(actor, "layers")], [int(h) for h in _get(critic, "layers")]
         if ha != hc or len(ha) != 2 or ha[0] != ha[1]:
             raise NotImplementedError(f"layers actor={ha} critic={hc}: the HIP kernels implement two equal hidden layers (64 or 128), "
@@ -70,26 +72,45 @@ class A2CNetwork:
             obs_dims, act_dims = [obs_dims[i] for i in first], [act_dims[i] for i in first]
         K = self.spec.n_blocks
         # torch RNG consumption in the reference's order: actor nets, critic nets, target-critic nets (model.py:44-107)
-        a0 = _init_blocks(obs_dims, ha, act_dims, _get(actor, "use_orthogonal_init", True))
         cdims = [self.n_agents * self.spec.obs_dim] * K if self.centralised_critic else obs_dims  # critic_obs_shape (model.py:63-65)
-        c0 = _init_blocks(cdims, hc, [1] * K, _get(critic, "use_orthogonal_init", True))
-        _init_blocks(cdims, hc, [1] * K, _get(critic, "use_orthogonal_init", True))  # target: drawn, then overwritten (soft_update(1.0))
+        if self.recurrent:  # RNNNetwork inits (utils/models.py:83-94); init_flat_gru_params draws one set per call
+            a0 = init_flat_gru_params(obs_dims, ha[0], act_dims, _get(actor, "use_orthogonal_init", True))[0]
+            c0 = init_flat_gru_params(cdims, hc[0], [1] * K, _get(critic, "use_orthogonal_init", True))[0]
+        else:
+            a0 = _init_blocks(obs_dims, ha, act_dims, _get(actor, "use_orthogonal_init", True))
+            c0 = _init_blocks(cdims, hc, [1] * K, _get(critic, "use_orthogonal_init", True))
+            _init_blocks(cdims, hc, [1] * K, _get(critic, "use_orthogonal_init", True))  # target: drawn, then overwritten (soft_update(1.0))
         self.block = torch.cat([a0.reshape(-1), c0.reshape(-1)]).to(self.device).contiguous()
         self.target_critic_params = c0.clone().to(self.device).contiguous()
         self.updater = _hip.AcUpdater(self.spec, self.block, self.target_critic_params, lr=float(_get(cfg, "lr", 3e-4)),
                                       gamma=self.gamma, n_steps=self.n_steps, entropy_coef=self.entropy_coef,
                                       value_loss_coef=self.value_loss_coef, grad_clip=self.grad_clip,
                                       ppo_clip=float(_get(cfg, "ppo_clip", 0.2)), standardise_returns=self.standardise_returns,
-                                      centralised_critic=self.centralised_critic)
+                                      centralised_critic=self.centralised_critic, recurrent=self.recurrent)
         self.ret_ms = self.updater.ret_stats
         self.actor_params, self.critic_params = self.updater.actor, self.updater.critic
 
     # ---- reference interface ---------------------------------------------------------------
     def init_critic_hiddens(self, batch_size, target=False):
+        if self.recurrent:
+            return [torch.zeros(1, batch_size, self.spec.hidden, device=self.device) for _ in range(self.n_agents)]
         return [None] * self.n_agents
 
     def init_actor_hiddens(self, batch_size):
+        if self.recurrent:
+            return [torch.zeros(1, batch_size, self.spec.hidden, device=self.device) for _ in range(self.n_agents)]
         return [None] * self.n_agents
+
+    def _seq(self, block, inputs, hiddens, value_net):
+        """recurrent networks on inputs (list of P tensors [N, D] = one step, or [S, N, D]); hiddens list of [1, N, H] or None"""
+        x = torch.stack([torch.as_tensor(i, dtype=torch.float32) for i in inputs]).to(self.device)
+        if x.dim() == 3:
+            x = x.unsqueeze(1)
+        P, S, N, D = x.shape
+        x = x.contiguous()
+        h_in = None if hiddens is None or hiddens[0] is None else torch.stack([h.reshape(N, -1) for h in hiddens]).to(self.device).contiguous()
+        out, h = _hip.gru_ac_forward(self.spec, block, x, S * N * D, D, S, N, value_net=value_net, h_in=h_in, want_h=True)
+        return out, [h[p].reshape(1, N, -1) for p in range(P)]
 
     def forward(self, inputs, rnn_hxs, masks):
         raise NotImplementedError("Forward not implemented. Use act, get_value, get_target_value or evaluate_actions instead.")
@@ -108,7 +129,11 @@ class A2CNetwork:
 
     def act(self, inputs, actor_hiddens, action_mask=None):
         """model.py:147-153: Categorical(logits).sample() per agent; returns ([P, N, 1] int64, hiddens)"""
-        lg = self.logits(inputs)
+        if self.recurrent:
+            out, actor_hiddens = self._seq(self.actor_params, inputs, actor_hiddens, False)
+            lg = out[:, 0]
+        else:
+            lg = self.logits(inputs)
         if action_mask is not None:  # get_dist (model.py:135-145): one mask per agent, shaped like that agent's logits
             m = torch.stack([torch.as_tensor(x, dtype=torch.float32) for x in action_mask]).to(lg.device).reshape(lg.shape)
             lg = lg * m + (1 - m) * -1e8
@@ -118,6 +143,11 @@ class A2CNetwork:
     def get_value(self, inputs, critic_hiddens, target=False):
         """model.py:155-163: [..., P] values of the (target) critic"""
         blk = self.target_critic_params if target else self.critic_params
+        if self.recurrent:
+            out, critic_hiddens = self._seq(blk, inputs, critic_hiddens, True)
+            out = out[..., 0]  # [P][S][N]
+            lead_one = torch.as_tensor(inputs[0]).dim() == 2
+            return (out[:, 0] if lead_one else out).movedim(0, -1).contiguous(), critic_hiddens
         if self.centralised_critic:  # every critic reads the concatenation of all agents' observations (model.py:156-157)
             x = torch.cat([torch.as_tensor(i, dtype=torch.float32).to(self.device) for i in inputs], dim=-1)
             lead = x.shape[:-1]
@@ -167,7 +197,7 @@ class A2CNetwork:
             for i in range(P):
                 o = 0
                 cin = S.n_agents * S.obs_dim if (self.centralised_critic and prefix != "actor") else S.obs_dim
-                for name, shape in _tensor_layout(cin, S.hidden, A):
+                for name, shape in (_gru_layout if self.recurrent else _tensor_layout)(cin, S.hidden, A):
                     n = int(np.prod(shape))
                     out[f"{prefix}.{group}.{i}.{name}"] = block[i, o:o + n].view(shape)
                     o += n

@@ -38,6 +38,49 @@ class ActorNetworks:
         return out
 
 
+def _collect_trajectories_recurrent(envs, model, T, use_proper_termination, round_idx):
+    """_collect_trajectories (ac/train.py:24-119) with recurrent actors: the hidden state lives between steps, so the rollout runs
+    through the modular entry points - sequence kernel with one step -> Philox inverse-CDF sample -> auto-resetting vector-env
+    step -> masked writes of the still-running envs.  Same streams as the fused collector: reset from episode 2 * round, action
+    noise keyed on it, the auto-reset observation from 2 * round + 1."""
+    cfg, env = envs.cfg, envs.batched
+    N, P, D = cfg.n_envs, cfg.n_agents, model.spec.obs_dim
+    dev = model.actor_params.device
+    b_obs = torch.zeros(T + 1, N, P * D, device=dev)
+    b_act = torch.zeros(T, N, P, dtype=torch.int64, device=dev)
+    b_rew = torch.zeros(T, N, P, device=dev)
+    b_done = torch.zeros(T + 1, N, dtype=torch.bool, device=dev)
+    b_fill = torch.zeros(T, N, device=dev)
+    fin_ret = torch.zeros(P, N, device=dev)
+    fin_len = torch.zeros(N, dtype=torch.int32, device=dev)
+    env.episode.fill_(2 * round_idx)
+    obs = env.reset()  # episode[n] = 2 * round + 1 afterwards: the stream of the auto-reset inside step()
+    noise_episode = torch.full((N,), 2 * round_idx, dtype=torch.int32, device=dev)
+    b_obs[0] = obs.permute(1, 0, 2).reshape(N, P * D)
+    running = torch.ones(N, dtype=torch.bool, device=dev)
+    hid, t = None, 0
+    while t < T:
+        logits, hid = _hip.gru_ac_forward(model.spec, model.actor_params, obs, N * D, D, 1, N, h_in=hid, want_h=True)
+        acts = _hip.sample_from_logits(logits[:, 0], cfg.seed, noise_episode, t)
+        obs, rew, done, trunc = env.step(acts.to(torch.int32), auto_reset=True)
+        fin = (done | trunc) > 0
+        stored = (done > 0) if use_proper_termination else fin
+        b_obs[t + 1] = torch.where(running[:, None], obs.permute(1, 0, 2).reshape(N, P * D), b_obs[t + 1])
+        b_act[t] = torch.where(running[:, None], acts.t(), b_act[t])
+        b_rew[t] = torch.where(running[:, None], rew.t(), b_rew[t])
+        b_done[t + 1] = torch.where(running, stored, b_done[t + 1])
+        b_fill[t] = running.float()
+        first = running & fin  # the statistics of an env's FIRST episode of the rollout (it keeps auto-resetting afterwards)
+        fin_ret = torch.where(first[None, :], env.fin_return, fin_ret)
+        fin_len = torch.where(first, env.fin_length, fin_len)
+        running = running & ~fin
+        t += 1
+        if t % 8 == 0 and not bool(running.any()):
+            break
+    filled_steps = int(b_fill.sum(1).gt(0).sum().item())
+    return filled_steps, Batch(b_obs, b_act, b_rew, b_done, b_fill, None), fin_ret, fin_len
+
+
 def _collect_trajectories(envs, model, max_ep_length, parallel_envs, n_agents, device, use_proper_termination, round_idx=0):
     """(t, Batch, infos) exactly as the reference returns them; `envs` is a HipForagingVecEnv, `model` carries
     `actor_params` / `spec` (ActorNetworks).  One kernel launch; the only host sync is reading `t` and the
@@ -53,9 +96,13 @@ def _collect_trajectories(envs, model, max_ep_length, parallel_envs, n_agents, d
     fin_ret = torch.zeros(P, N, device=dev)
     fin_len = torch.zeros(N, dtype=torch.int32, device=dev)
     t_max = torch.zeros(1, dtype=torch.int32, device=dev)
-    _hip.ac_collect(cfg, model.spec, model.actor_params, round_idx, T, use_proper_termination, b_obs, b_act, b_rew, b_done,
-                    b_fill, fin_ret, fin_len, t_max)
-    t = int(t_max.item())
+    if getattr(model, "recurrent", False):
+        t, batch, fin_ret, fin_len = _collect_trajectories_recurrent(envs, model, T, use_proper_termination, round_idx)
+    else:
+        _hip.ac_collect(cfg, model.spec, model.actor_params, round_idx, T, use_proper_termination, b_obs, b_act, b_rew, b_done,
+                        b_fill, fin_ret, fin_len, t_max)
+        t = int(t_max.item())
+        batch = Batch(b_obs, b_act, b_rew, b_done.bool(), b_fill, None)
     ret, ln = fin_ret.cpu().numpy(), fin_len.cpu().numpy()
     infos = []
     for i in range(N):
@@ -63,7 +110,7 @@ def _collect_trajectories(envs, model, max_ep_length, parallel_envs, n_agents, d
         for p in range(P):
             d[f"agent{p}/episode_returns"] = ret[p, i]
         infos.append(d)
-    return t, Batch(b_obs, b_act, b_rew, b_done.bool(), b_fill, None), infos
+    return t, batch, infos
 
 
 def _log_progress(infos, step, updates, logger):

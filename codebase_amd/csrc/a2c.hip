@@ -12,390 +12,7 @@
 //   backward rows  dqn_lossgrad_kernel MODE 4 (hidden 64) / tp_bwd_kernel FULL (hidden 128): forward again +
 //                  backward with the external output gradient, deterministic partial-record reduction, 1/sum(filled).
 // Rows come straight from the ac/train.py Batch (agents innermost) through marlhip_batch's strides.
-#include "dqn_update_kernels.h"
-#include "collect_common.h"
-
-namespace marl {
-
-// ---- forward rows ------------------------------------------------------------------------------------------
-template <class S>
-__global__ __launch_bounds__(256) void mlp_rows_fwd_kernel(const float* __restrict__ packs /* pre-packed [P][NFWD] */, const float* __restrict__ obs,
-                                                           size_t agent_stride, size_t row_stride, int n_rows,
-                                                           float* __restrict__ out) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, j = lane & 15;
-    const int p = blockIdx.y;
-    stage_packed<S>(packs + (size_t)p * S::NFWD, lds, tid, 256);
-    __syncthreads();
-    const float* obs_p = obs + (size_t)p * agent_stride;
-    const int nblk = (n_rows + 15) >> 4, npair = (nblk + 1) >> 1;
-    for (int pr = blockIdx.x * 4 + wave; pr < npair; pr += gridDim.x * 4) {  // two row blocks per wave and step
-        float x[2][S::KS1];
-        int row[2];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            row[h] = (2 * pr + h) * 16 + j;
-            const bool ok = row[h] < n_rows;
-            const float* xrow = obs_p + (size_t)(ok ? row[h] : n_rows - 1) * row_stride;
-#pragma unroll
-            for (int ks = 0; ks < S::KS1; ++ks) {
-                const int d = 4 * ks + g;
-                const float v = xrow[d < S::D ? d : S::D - 1];
-                x[h][ks] = (d < S::D && ok) ? v : 0.f;
-            }
-        }
-        f4 q[2];
-        mlp_forward_p2<S>(lds, lane, x, q);
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            if (row[h] < n_rows) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (4 * g + r < S::A) out[((size_t)p * n_rows + row[h]) * S::A + 4 * g + r] = q[h][r];
-            }
-        }
-    }
-}
-
-template <class S>
-int launch_forward_rows(int P, const AgentMap& am, const float* params, const marlhip_batch* bt, int n_rows, float* out, hipStream_t st) {
-    const int T = bt->max_len, B = bt->batch;
-    const size_t as = bt->obs_agent_stride > 0 ? (size_t)bt->obs_agent_stride : (bt->obs_agent_stride < 0 ? 0 : (size_t)(T + 1) * B * S::D);
-    const size_t rs = bt->obs_row_stride ? (size_t)bt->obs_row_stride : (size_t)S::D;
-    constexpr int LDSB = S::NFWD * (int)sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_rows_fwd_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
-        attr_set = true;
-    }
-    const int npair = ((n_rows + 15) / 16 + 1) / 2;
-    int gx = (npair + 3) / 4;
-    // one resident workgroup per CU when the pack fills most of the LDS (hidden 128), two otherwise: every workgroup stages once
-    const int per_cu = LDSB > 80 * 1024 ? 1 : 2;
-    const int cap = (256 * per_cu) / P > 1 ? (256 * per_cu) / P : 1;
-    if (gx > cap) gx = cap;
-    float* packs = nullptr;
-    if (launch_fwd_pack<S>(P, am, params, &packs, st) != 0) return -1;
-    hipLaunchKernelGGL((mlp_rows_fwd_kernel<S>), dim3(gx, P), dim3(256), LDSB, st, (const float*)packs, bt->obss, as, rs, n_rows, out);
-    MARL_CHECK_LAUNCH("mlp_rows_fwd_kernel");
-    return 0;
-}
-
-// ---- backward rows -----------------------------------------------------------------------------------------
-template <class S>
-int64_t backward_ws_bytes(int P, int T, int B) {
-    if constexpr (use_tp<S>()) {
-        const UpdPlan pl = upd_plan_tp(P, T, B, S::D > 48 ? 1 : 2);
-        return ws_layout(P, pl.nwg, S::NPARAM + 2, 0, T, B).total;
-    } else {
-        const UpdPlan pl = upd_plan(P, T, B);
-        return ws_layout(P, pl.nwg, UpdLds<S>::REC, 2 * S::NFWD + S::NBWD, T, B).total;
-    }
-}
-
-// grad[P][NPARAM] = d(sum_rows lrow-loss)/dparams / sum(filled) from dout[P][T][B][A]; loss[0] = sum(lrow)/sum(filled)
-template <class S>
-int launch_backward_rows(int P, const AgentMap& am, const float* params, const marlhip_batch* bt, const float* dout, float* lrow, void* ws,
-                         int64_t ws_bytes, float* grad, float* loss, hipStream_t st) {
-    const int T = bt->max_len, B = bt->batch;
-    MARL_REQUIRE(ws_bytes >= backward_ws_bytes<S>(P, T, B), "ac backward: workspace %lld too small", (long long)ws_bytes);
-    ReplaySrc none = {};
-    int nwg;
-    if constexpr (use_tp<S>()) {
-        constexpr int W = 4, TPW = S::H / 64, NB = S::D > 48 ? 1 : 2, NT = W * TPW;  // wide first layers (centralised critics): one row block per step keeps the kernel out of scratch
-        const UpdPlan pl = upd_plan_tp(P, T, B, NB);
-        nwg = pl.nwg;
-        TpMix mix = {};
-        mix.lrow = lrow;
-        mix.dout = dout;
-        const size_t ldsB = (size_t)(NB * NT * 256 + NB * S::H * 16 + NB * NT * 256 + W * 256 * (1 + 3 * TPW)) * sizeof(float);
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tp_bwd_kernel<S, W, TPW, false, NB, true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsB);
-            attr_set = true;
-        }
-        hipLaunchKernelGGL((tp_bwd_kernel<S, W, TPW, false, NB, true>), dim3(pl.nwg, P), dim3(64 * W), ldsB, st, params, am, *bt, none, mix,
-                           pl.n_chunks, (float*)ws);
-        MARL_CHECK_LAUNCH("tp_bwd_kernel<FULL>");
-    } else {
-        using L = UpdLds<S>;
-        constexpr int PACK = 2 * S::NFWD + S::NBWD;
-        const UpdPlan pl = upd_plan(P, T, B);
-        nwg = pl.nwg;
-        const WsLayout wl = ws_layout(P, pl.nwg, L::REC, PACK, T, B);
-        float* packs = reinterpret_cast<float*>(static_cast<char*>(ws) + wl.pack_off);
-        const size_t lds_bytes = (size_t)L::total(4) * sizeof(float);
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dqn_lossgrad_kernel<S, 4, false, 4>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-            attr_set = true;
-        }
-        hipLaunchKernelGGL((dqn_pack_kernel<S>), dim3((PACK + 255) / 256, P), dim3(256), 0, st, params, params, am, packs);
-        MixBufs mix = {};
-        mix.lrow = lrow;
-        mix.dout = dout;
-        hipLaunchKernelGGL((dqn_lossgrad_kernel<S, 4, false, 4>), dim3(pl.nwg, P), dim3(256), lds_bytes, st, (const float*)packs, *bt, none,
-                           mix, 0.f, 0, pl.n_chunks, (float*)ws, (unsigned long long*)nullptr);
-        MARL_CHECK_LAUNCH("dqn_lossgrad_kernel<MODE 4>");
-    }
-    const int n = am.nblk * S::NPARAM;
-    hipLaunchKernelGGL(dqn_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, st, (const float*)ws, P, nwg, S::NPARAM, am, grad, loss);
-    MARL_CHECK_LAUNCH("dqn_reduce_kernel");
-    return 0;
-}
-
-// ---- the elementwise stage ---------------------------------------------------------------------------------
-struct AcArgs {
-    // mode 0: A2C; 1: PPO prepare (returns + old log-probs, no gradients); 2: PPO epoch (stored returns);
-    // 3: A2C on stored returns; 4: returns only (3 and 4 bracket the statistics update of standardise_returns)
-    int P, T, B, A, n_steps, mode;
-    int standardise;                // returns are de-standardised / standardised with st (ac/model.py:195-204)
-    float gk[18];                   // (float)(gamma ** k), k = 0..n_steps, formed in fp64 like python's gamma**step
-    float ent_coef, vlc, ppo_clip;
-};
-
-struct AcBufs {
-    const float* logits;  // [P][T*B][A]
-    const float* v;       // [P][T*B]
-    const float* vnext;   // [P][(T+1)*B] target-critic values of every observation
-    float* dlogits;       // [P][T*B][A]
-    float* dv;            // [P][T*B]
-    float* lrow_a;        // [T*B] filled * actor-loss row
-    float* lrow_v;        // [T*B] filled * value-loss row
-    float* ent;           // [T*B] filled * sum_p entropy
-    float* ret;           // [P][T*B]  PPO: returns kept across epochs
-    float* oldlogp;       // [P][T*B]  PPO: log-prob under the pre-update policy
-    float* partial;       // [blocks][4] per-block sums of (actor row, value row, entropy row, filled)
-    float* rpartial;      // [blocks][P][2] per-block sums of the raw returns and their squares (standardise_returns)
-    RetStats st;
-};
-
-static __global__ __launch_bounds__(256) void ac_elem_kernel(AcArgs a, marlhip_batch bt, AcBufs w) {
-    const int TB = a.T * a.B;
-    const int i0 = blockIdx.x * 256 + threadIdx.x;
-    const bool inside = i0 < TB;
-    const int i = inside ? i0 : TB - 1;  // out-of-range threads shadow the last row and contribute nothing
-    const int t = i / a.B, b = i - t * a.B;
-    const size_t aas = bt.act_agent_stride ? (size_t)bt.act_agent_stride : (size_t)TB;
-    const size_t ars = bt.act_row_stride ? (size_t)bt.act_row_stride : 1;
-    const float fl = inside ? bt.filled[i] : 0.f;
-    float la = 0.f, lv = 0.f, es = 0.f;
-    for (int p = 0; p < a.P; ++p) {
-        const size_t pi = (size_t)p * TB + i;
-        float ret;
-        if (a.mode == 2 || a.mode == 3) {
-            ret = w.ret[pi];
-            if (a.standardise) ret = (ret - w.st.mean[p]) / sqrtf(w.st.var[p]);  // with the statistics updated from this batch
-        } else {  // compute_nstep_returns (utils/utils.py:38-63)
-            ret = 0.f;
-            for (int k = 0; k <= a.n_steps; ++k) {
-                const int tt = t + k;
-                if (tt >= a.T) break;
-                const float nd = 1.f - bt.dones[(size_t)tt * a.B + b];
-                if (k == a.n_steps) {
-                    float vn = w.vnext[(size_t)p * (TB + a.B) + (size_t)tt * a.B + b];
-                    if (a.standardise) vn = vn * sqrtf(w.st.var[p]) + w.st.mean[p];  // model.py:195-196, statistics BEFORE the update
-                    ret += a.gk[k] * vn * nd;
-                } else {
-                    ret += a.gk[k] * bt.rewards[p * aas + ((size_t)tt * a.B + b) * ars] * nd;
-                }
-            }
-            if ((a.mode == 1 || a.mode == 4) && inside) w.ret[pi] = ret;
-            if (a.standardise && (a.mode == 1 || a.mode == 4)) {
-                __shared__ float shr[8];
-                ret_block_partials(inside ? ret : 0.f, shr, w.rpartial + ((size_t)blockIdx.x * a.P + p) * 2);
-            }
-            if (a.mode == 4) continue;
-        }
-        const float* lraw = w.logits + pi * a.A;
-        // get_dist (ac/model.py:135-145): logits * mask + (1 - mask) * -1e8 with batch.action_masks[t] ([T+1][B][P][A])
-        const float* mrow = bt.action_mask != nullptr ? bt.action_mask + (((size_t)t * a.B + b) * a.P + p) * a.A : nullptr;
-        auto l = [&](int k) { return mrow != nullptr ? lraw[k] * mrow[k] + (1.f - mrow[k]) * -1e8f : lraw[k]; };  // re-read, no local array
-        float m = l(0);
-        for (int k = 1; k < a.A; ++k) m = fmaxf(m, l(k));
-        float s = 0.f;
-        for (int k = 0; k < a.A; ++k) s += expf(l(k) - m);
-        const float lse = m + logf(s);
-        const int act = (int)bt.actions[p * aas + (size_t)i * ars];
-        const float logp = l(act) - lse;
-        float H = 0.f;
-        for (int k = 0; k < a.A; ++k) H -= expf(l(k) - lse) * (l(k) - lse);
-        if (a.mode == 1) {
-            if (inside) w.oldlogp[pi] = logp;
-            continue;
-        }
-        const float val = w.v[pi], adv = ret - val;
-        float coef;  // d(actor row loss) / d logp
-        if (a.mode == 0 || a.mode == 3) {
-            la += -logp * adv - a.ent_coef * H;
-            coef = -adv;
-        } else {  // clipped surrogate (model.py:318-327); min() ties split the gradient, clamp passes it inside the range
-            const float ratio = expf(logp - w.oldlogp[pi]);
-            const float rc = fminf(fmaxf(ratio, 1.f - a.ppo_clip), 1.f + a.ppo_clip);
-            const float s1 = ratio * adv, s2 = rc * adv;
-            la += -fminf(s1, s2) - a.ent_coef * H;
-            const bool in_clip = ratio >= 1.f - a.ppo_clip && ratio <= 1.f + a.ppo_clip;
-            const float share = s1 < s2 ? 1.f : (s1 == s2 ? (in_clip ? 1.f : 0.5f) : (0.f));
-            coef = -adv * ratio * share;
-        }
-        if (inside) {
-            for (int k = 0; k < a.A; ++k) {
-                const float lp = l(k) - lse, pk = expf(lp);
-                const float dl = fl * (coef * ((k == act ? 1.f : 0.f) - pk) + a.ent_coef * pk * (lp + H));
-                w.dlogits[pi * a.A + k] = mrow != nullptr ? dl * mrow[k] : dl;  // d(masked logit)/d(logit) = mask
-            }
-            w.dv[pi] = fl * (-2.f * a.vlc * (ret - val));
-        }
-        lv += (ret - val) * (ret - val);
-        es += H;
-    }
-    if (a.mode == 1 || a.mode == 4) return;
-    if (inside) {
-        w.lrow_a[i] = fl * la;
-        w.lrow_v[i] = fl * lv;
-        w.ent[i] = fl * es;
-    }
-    // per-block sums for the metrics (fixed order: wave butterfly, then waves 0..3)
-    __shared__ float sh[4][4];
-    float s4[4] = {fl * la, fl * lv, fl * es, fl};
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) s4[k] += __shfl_xor(s4[k], off);
-        if ((threadIdx.x & 63) == 0) sh[k][threadIdx.x >> 6] = s4[k];
-    }
-    __syncthreads();
-    if (threadIdx.x < 4) w.partial[blockIdx.x * 4 + threadIdx.x] = (sh[threadIdx.x][0] + sh[threadIdx.x][1]) + (sh[threadIdx.x][2] + sh[threadIdx.x][3]);
-}
-
-// metrics[0..4] = loss, actor_loss, value_loss, entropy, sum(filled)  (fixed-order tree: reproducible)
-static __global__ __launch_bounds__(1024) void ac_metrics_kernel(int nblocks, float vlc, const float* __restrict__ partial,
-                                                                 float* __restrict__ metrics) {
-    __shared__ float sh[4][16];
-    float s[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int i = threadIdx.x; i < nblocks; i += 1024) {
-        s[0] += partial[4 * i]; s[1] += partial[4 * i + 1]; s[2] += partial[4 * i + 2]; s[3] += partial[4 * i + 3];
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) s[k] += __shfl_xor(s[k], off);
-        if ((threadIdx.x & 63) == 0) sh[k][threadIdx.x >> 6] = s[k];
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        float tot[4];
-        for (int k = 0; k < 4; ++k) {
-            float acc = 0.f;
-            for (int wv = 0; wv < 16; ++wv) acc += sh[k][wv];
-            tot[k] = acc;
-        }
-        const float al = tot[0] / tot[3], vl = tot[1] / tot[3];
-        metrics[0] = al + vlc * vl;
-        metrics[1] = al;
-        metrics[2] = vl;
-        metrics[3] = tot[2] / tot[3];
-        metrics[4] = tot[3];
-    }
-}
-
-// workspace: [vnext | v | logits | dlogits | dv | lrow_a | lrow_v | ent | ret | oldlogp | loss scratch 4][backward workspace]
-struct AcWs {
-    int64_t vnext, v, logits, dlogits, dv, lrow_a, lrow_v, ent, ret, oldlogp, partial, rpartial, scratch, bwd, total;
-};
-
-template <class SA, class SC>
-AcWs ac_ws_layout(int P, int T, int B) {
-    const int64_t TB = (int64_t)T * B;
-    AcWs w;
-    int64_t o = 0;
-    auto take = [&](int64_t nfloat) { const int64_t at = o; o = (o + nfloat * 4 + 255) & ~(int64_t)255; return at; };
-    w.vnext = take((int64_t)P * (TB + B));
-    w.v = take(P * TB);
-    w.logits = take(P * TB * SA::A);
-    w.dlogits = take(P * TB * SA::A);
-    w.dv = take(P * TB);
-    w.lrow_a = take(TB);
-    w.lrow_v = take(TB);
-    w.ent = take(TB);
-    w.ret = take(P * TB);
-    w.oldlogp = take(P * TB);
-    w.partial = take(4 * ((TB + 255) / 256));
-    w.rpartial = take(2 * P * ((TB + 255) / 256));
-    w.scratch = take(8);
-    w.bwd = o;
-    const int64_t ba = backward_ws_bytes<SA>(P, T, B), bc = backward_ws_bytes<SC>(P, T, B);
-    w.total = o + (ba > bc ? ba : bc);
-    return w;
-}
-
-// DC = the critics' input width: D (independent critics) or P * D (critic.centralised: every critic reads the whole row)
-template <int D, int H, int A, int DC>
-int ac_step(int P, const AgentMap& am, const float* actor, const float* critic, const float* target, const marlhip_batch* bt, const marlhip_ac_config* c,
-            int mode, void* ws, int64_t ws_bytes, float* actor_grad, float* critic_grad, float* metrics, hipStream_t st) {
-    using SA = MlpShape<D, H, A>;
-    using SC = MlpShape<DC, H, 1>;
-    const int T = bt->max_len, B = bt->batch, TB = T * B;
-    marlhip_batch btc = *bt;  // the critics' view of the batch
-    if (DC != D) btc.obs_agent_stride = -1;
-    const marlhip_batch* bc = &btc;
-    const AcWs wl = ac_ws_layout<SA, SC>(P, T, B);
-    MARL_REQUIRE(ws_bytes >= wl.total, "ac_loss_grad: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)wl.total);
-    char* base = static_cast<char*>(ws);
-    auto f = [&](int64_t off) { return reinterpret_cast<float*>(base + off); };
-    AcBufs w;
-    w.logits = f(wl.logits); w.v = f(wl.v); w.vnext = f(wl.vnext); w.dlogits = f(wl.dlogits); w.dv = f(wl.dv);
-    w.lrow_a = f(wl.lrow_a); w.lrow_v = f(wl.lrow_v); w.ent = f(wl.ent); w.ret = f(wl.ret); w.oldlogp = f(wl.oldlogp);
-    w.partial = f(wl.partial);
-    w.rpartial = f(wl.rpartial);
-    const bool std_on = c->ret_mean != nullptr;
-    w.st.mean = c->ret_mean; w.st.var = c->ret_var; w.st.count = c->ret_count;
-    AcArgs a;
-    a.P = P; a.T = T; a.B = B; a.A = A; a.n_steps = c->n_steps; a.mode = mode;
-    for (int k = 0; k <= c->n_steps; ++k) a.gk[k] = (float)pow(c->gamma, (double)k);
-    a.ent_coef = c->entropy_coef; a.vlc = c->value_loss_coef; a.ppo_clip = c->ppo_clip;
-    a.standardise = std_on ? 1 : 0;
-    int rc;
-    timing_begin(TIMER_LOSSGRAD, st);
-    if (mode != 2) {  // target-critic values of all T+1 observations (model.py:190-193); PPO reuses the returns across epochs
-        rc = launch_forward_rows<SC>(P, am, target, bc, TB + B, f(wl.vnext), st);
-        if (rc != 0) return rc;
-    }
-    if (std_on && mode == 0) {  // A2C with standardise_returns: raw returns -> statistics update -> A2C on the stored returns
-        a.mode = 4;
-        hipLaunchKernelGGL(ac_elem_kernel, dim3((TB + 255) / 256), dim3(256), 0, st, a, *bt, w);
-        hipLaunchKernelGGL(ret_stats_update_kernel, dim3(1), dim3(64), 0, st, w.st, (const float*)w.rpartial, (TB + 255) / 256, P, TB);
-        a.mode = 3;
-    }
-    rc = launch_forward_rows<SA>(P, am, actor, bt, TB, f(wl.logits), st);
-    if (rc != 0) return rc;
-    if (mode != 1) {
-        rc = launch_forward_rows<SC>(P, am, critic, bc, TB, f(wl.v), st);
-        if (rc != 0) return rc;
-    }
-    hipLaunchKernelGGL(ac_elem_kernel, dim3((TB + 255) / 256), dim3(256), 0, st, a, *bt, w);
-    MARL_CHECK_LAUNCH("ac_elem_kernel");
-    if (mode == 1) {
-        if (std_on)
-            hipLaunchKernelGGL(ret_stats_update_kernel, dim3(1), dim3(64), 0, st, w.st, (const float*)w.rpartial, (TB + 255) / 256, P, TB);
-        timing_end(TIMER_LOSSGRAD, st);
-        return 0;
-    }
-    float* scratch = f(wl.scratch);
-    rc = launch_backward_rows<SA>(P, am, actor, bt, w.dlogits, w.lrow_a, base + wl.bwd, ws_bytes - wl.bwd, actor_grad, scratch, st);
-    if (rc != 0) return rc;
-    rc = launch_backward_rows<SC>(P, am, critic, bc, w.dv, w.lrow_v, base + wl.bwd, ws_bytes - wl.bwd, critic_grad, scratch + 2, st);
-    if (rc != 0) return rc;
-    hipLaunchKernelGGL(ac_metrics_kernel, dim3(1), dim3(1024), 0, st, (TB + 255) / 256, c->value_loss_coef, (const float*)w.partial,
-                       metrics);
-    timing_end(TIMER_LOSSGRAD, st);
-    MARL_CHECK_LAUNCH("ac_metrics_kernel");
-    return 0;
-}
-
-}  // namespace marl
+#include "a2c_core.h"
 
 using namespace marl;
 

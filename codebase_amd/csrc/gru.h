@@ -110,12 +110,13 @@ __device__ __forceinline__ void gru_gate(const f4* G /* [MT][MT][64] chunk */, c
     }
 }
 
-// obs: [P][S][B][D] (the dqn/train.py Batch layout; S = 1 for acting), q: [P][S][B][A], h_in / h_out: [P][B][H] or NULL,
+// obs: row (t, b) of agent p at obs + p * obs_as + (t * B + b) * obs_rs (dqn/train.py Batch [P][S][B][D]: as = S*B*D, rs = D; the
+// ac/train.py Batch [S][B][P*D]: as = D, rs = P*D); q: [P][S][B][A], h_in / h_out: [P][B][H] or NULL,
 // rec: [P][S][nblk][REC] or NULL (nblk = ceil(B / 16))
 template <class S>
-__global__ __launch_bounds__(256) void gru_seq_fwd_kernel(const float* __restrict__ packs, const float* __restrict__ obs, int steps, int B,
-                                                          const float* __restrict__ h_in, float* __restrict__ h_out,
-                                                          float* __restrict__ q_out, float* __restrict__ rec) {
+__global__ __launch_bounds__(256) void gru_seq_fwd_kernel(const float* __restrict__ packs, const float* __restrict__ obs, size_t obs_as,
+                                                          size_t obs_rs, int steps, int B, const float* __restrict__ h_in,
+                                                          float* __restrict__ h_out, float* __restrict__ q_out, float* __restrict__ rec) {
     constexpr int MT = S::MT, D = S::D, H = S::H, A = S::A;
     constexpr bool STREAM = S::STREAM;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(256) void gru_seq_fwd_kernel(const float* __restric
     for (int t = 0; t < steps; ++t) {
         asm volatile("" ::: "memory");  // the packs never change, so the compiler would hoist every weight read out of the time
                                         // loop (and spill ~1 KB per lane): re-read them from LDS each step
-        const float* xrow = obs + (((size_t)p * steps + t) * B + bj) * D;
+        const float* xrow = obs + (size_t)p * obs_as + ((size_t)t * B + bj) * obs_rs;  // row (t, b) of agent p
         float x[S::KS1];
 #pragma unroll
         for (int ks = 0; ks < S::KS1; ++ks) {

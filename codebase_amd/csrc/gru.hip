@@ -47,8 +47,8 @@ static int gru_forward(const marlhip_net_shape* s, const float* params, const fl
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_seq_fwd_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
-    hipLaunchKernelGGL((gru_seq_fwd_kernel<S>), dim3((B + 63) / 64, P), dim3(256), lds, st, (const float*)packs, obs, steps, B, h_in, h_out, q_out,
-                       rec);
+    hipLaunchKernelGGL((gru_seq_fwd_kernel<S>), dim3((B + 63) / 64, P), dim3(256), lds, st, (const float*)packs, obs, (size_t)steps * B * S::D,
+                       (size_t)S::D, steps, B, h_in, h_out, q_out, rec);
     MARL_CHECK_LAUNCH("gru_seq_fwd_kernel");
     return 0;
 }
@@ -119,10 +119,10 @@ int gru_loss_grad(const marlhip_net_shape* s, const float* params, const float* 
     }
     const dim3 gridS((B + 63) / 64, P);
     timing_begin(TIMER_LOSSGRAD, st);
-    hipLaunchKernelGGL((gru_seq_fwd_kernel<S>), gridS, dim3(256), ldsF, st, (const float*)f(wl.packC), bt->obss, steps, B, (const float*)nullptr,
-                       (float*)nullptr, f(wl.q), f(wl.rec));
-    hipLaunchKernelGGL((gru_seq_fwd_kernel<S>), gridS, dim3(256), ldsF, st, (const float*)f(wl.packT), bt->obss, steps, B, (const float*)nullptr,
-                       (float*)nullptr, f(wl.tq), (float*)nullptr);
+    hipLaunchKernelGGL((gru_seq_fwd_kernel<S>), gridS, dim3(256), ldsF, st, (const float*)f(wl.packC), bt->obss, (size_t)steps * B * S::D, (size_t)S::D, steps, B,
+                       (const float*)nullptr, (float*)nullptr, f(wl.q), f(wl.rec));
+    hipLaunchKernelGGL((gru_seq_fwd_kernel<S>), gridS, dim3(256), ldsF, st, (const float*)f(wl.packT), bt->obss, (size_t)steps * B * S::D, (size_t)S::D, steps, B,
+                       (const float*)nullptr, (float*)nullptr, f(wl.tq), (float*)nullptr);
     MARL_CHECK_LAUNCH("gru_seq_fwd_kernel");
     (void)hipMemsetAsync(f(wl.dq), 0, (size_t)P * steps * B * S::A * sizeof(float), st);
     hipLaunchKernelGGL(gru_td_kernel, dim3((T * B + 255) / 256), dim3(256), 0, st, P, T, B, S::A, (const float*)f(wl.q), (const float*)f(wl.tq), *bt,
@@ -131,8 +131,8 @@ int gru_loss_grad(const marlhip_net_shape* s, const float* params, const float* 
     hipLaunchKernelGGL((gru_seq_bwd_kernel<S>), gridS, dim3(256), ldsB, st, (const float*)f(wl.packB), steps, B, (const float*)f(wl.rec),
                        (const float*)f(wl.dq), f(wl.rec2));
     MARL_CHECK_LAUNCH("gru_seq_bwd_kernel");
-    hipLaunchKernelGGL((gru_wgrad_kernel<S>), dim3(wl.nwg, P, 4), dim3(256), ldsW, st, steps, B, bt->obss, (const float*)f(wl.rec), (const float*)f(wl.rec2),
-                       (const float*)f(wl.dq), (const float*)f(wl.lrow), bt->filled, f(wl.partials));
+    hipLaunchKernelGGL((gru_wgrad_kernel<S>), dim3(wl.nwg, P, 4), dim3(256), ldsW, st, steps, B, bt->obss, (size_t)steps * B * S::D, (size_t)S::D, (const float*)f(wl.rec), (const float*)f(wl.rec2),
+                       (const float*)f(wl.dq), (const float*)f(wl.lrow), bt->filled, T, f(wl.partials));
     MARL_CHECK_LAUNCH("gru_wgrad_kernel");
     const int n = P * S::NPARAM;
     hipLaunchKernelGGL(dqn_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, st, (const float*)f(wl.partials), P, wl.nwg, S::NPARAM, am, grad, loss);
@@ -285,10 +285,10 @@ int gru_qmix_loss_grad(const marlhip_net_shape* s, const float* params, const fl
     }
     const dim3 gridS((B + 63) / 64, P), gridR((unsigned)((R + 255) / 256));
     timing_begin(TIMER_LOSSGRAD, st);
-    hipLaunchKernelGGL((gru_seq_fwd_kernel<S>), gridS, dim3(256), ldsF, st, (const float*)f(wl.packC), bt->obss, steps, B, (const float*)nullptr,
-                       (float*)nullptr, f(wl.q), f(wl.rec));
-    hipLaunchKernelGGL((gru_seq_fwd_kernel<S>), gridS, dim3(256), ldsF, st, (const float*)f(wl.packT), bt->obss, steps, B, (const float*)nullptr,
-                       (float*)nullptr, f(wl.tq), (float*)nullptr);
+    hipLaunchKernelGGL((gru_seq_fwd_kernel<S>), gridS, dim3(256), ldsF, st, (const float*)f(wl.packC), bt->obss, (size_t)steps * B * S::D, (size_t)S::D, steps, B,
+                       (const float*)nullptr, (float*)nullptr, f(wl.q), f(wl.rec));
+    hipLaunchKernelGGL((gru_seq_fwd_kernel<S>), gridS, dim3(256), ldsF, st, (const float*)f(wl.packT), bt->obss, (size_t)steps * B * S::D, (size_t)S::D, steps, B,
+                       (const float*)nullptr, (float*)nullptr, f(wl.tq), (float*)nullptr);
     hipLaunchKernelGGL(gru_qsel_kernel, gridR, dim3(256), 0, st, P, T, B, S::A, (const float*)f(wl.q), (const float*)f(wl.tq), *bt, double_q, chosen,
                        tqsel, r0, dn, fl);
     MARL_CHECK_LAUNCH("gru forward / qsel");
@@ -299,8 +299,8 @@ int gru_qmix_loss_grad(const marlhip_net_shape* s, const float* params, const fl
     hipLaunchKernelGGL(gru_expand_dq_kernel, gridR, dim3(256), 0, st, P, T, B, S::A, (const float*)dqm, *bt, f(wl.dq));
     hipLaunchKernelGGL((gru_seq_bwd_kernel<S>), gridS, dim3(256), ldsB, st, (const float*)f(wl.packB), steps, B, (const float*)f(wl.rec),
                        (const float*)f(wl.dq), f(wl.rec2));
-    hipLaunchKernelGGL((gru_wgrad_kernel<S>), dim3(wl.nwg, P, 4), dim3(256), ldsW, st, steps, B, bt->obss, (const float*)f(wl.rec), (const float*)f(wl.rec2),
-                       (const float*)f(wl.dq), (const float*)f(wl.lrow), bt->filled, f(wl.partials));
+    hipLaunchKernelGGL((gru_wgrad_kernel<S>), dim3(wl.nwg, P, 4), dim3(256), ldsW, st, steps, B, bt->obss, (size_t)steps * B * S::D, (size_t)S::D, (const float*)f(wl.rec), (const float*)f(wl.rec2),
+                       (const float*)f(wl.dq), (const float*)f(wl.lrow), bt->filled, T, f(wl.partials));
     MARL_CHECK_LAUNCH("gru backward");
     const int n = P * S::NPARAM;
     hipLaunchKernelGGL(dqn_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, st, (const float*)f(wl.partials), P, wl.nwg, S::NPARAM, am, grad, loss);

@@ -214,9 +214,10 @@ __global__ __launch_bounds__(256) void gru_seq_bwd_kernel(const float* __restric
 // owning a quarter of the columns each; 3 = the small parts (wave 0: dW1, db1; wave 1: dW3, db3, loss; wave 2: bias sums of
 // gates r, z; wave 3: bias sums of gate n).  Every role reads only the record arrays it needs.
 template <class S>
-__global__ __launch_bounds__(256) void gru_wgrad_kernel(int steps, int B, const float* __restrict__ obs, const float* __restrict__ rec,
+__global__ __launch_bounds__(256) void gru_wgrad_kernel(int steps, int B, const float* __restrict__ obs, size_t obs_as, size_t obs_rs,
+                                                        const float* __restrict__ rec,
                                                         const float* __restrict__ rec2, const float* __restrict__ dq,
-                                                        const float* __restrict__ lrow, const float* __restrict__ filled,
+                                                        const float* __restrict__ lrow, const float* __restrict__ filled, int loss_steps,
                                                         float* __restrict__ partials) {
     using Bk = GruBwd<S>;
     constexpr int MT = S::MT, H = S::H, D = S::D, A = S::A, NT1 = S::DP / 16, TILE = 16 * H, MTN = MT / 4;
@@ -228,7 +229,7 @@ __global__ __launch_bounds__(256) void gru_wgrad_kernel(int steps, int B, const 
     float* TQ = T3 + TILE;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, j = lane & 15;
     const int p = blockIdx.y, role = blockIdx.z;
-    const int nblk = (B + 15) >> 4, T = steps - 1;
+    const int nblk = (B + 15) >> 4, T = loss_steps;  // lrow / filled have loss_steps rows (DQN: steps - 1; actor-critic: steps)
     const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
     float* recd = partials + ((size_t)p * gridDim.x + blockIdx.x) * (S::NPARAM + 2);
     const int total = steps * nblk;
@@ -317,7 +318,7 @@ __global__ __launch_bounds__(256) void gru_wgrad_kernel(int steps, int B, const 
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
                     const int row = b0 + 4 * g + ks, d = 16 * nt + j;
-                    const float xv = obs[(((size_t)p * steps + t) * B + (row < B ? row : B - 1)) * D + (d < D ? d : D - 1)];
+                    const float xv = obs[(size_t)p * obs_as + ((size_t)t * B + (row < B ? row : B - 1)) * obs_rs + (d < D ? d : D - 1)];
                     bx[nt][ks] = (row < B && d < D) ? xv : 0.f;
                 }
 #pragma unroll

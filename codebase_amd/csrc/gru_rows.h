@@ -1,0 +1,103 @@
+// Row-level launchers of the recurrent kernels for the actor-critic learner step (a2c_core.h): the same two calls the
+// feed-forward networks offer - forward of every row (here: of every sequence, step by step) and backward with an external
+// output gradient - so that A2CNetwork.update / PPONetwork.update run unchanged around them.
+#pragma once
+#include <type_traits>
+
+#include "collect_common.h"
+#include "gru_bwd.h"
+
+namespace marl {
+
+template <class S>
+struct IsGru : std::false_type {};
+template <int D, int H, int A>
+struct IsGru<GruShape<D, H, A>> : std::true_type {};
+
+struct GruRowsWs {
+    int64_t q, rec, rec2, partials, packF, packB, total;
+    int nwg;
+};
+
+template <class S>
+GruRowsWs gru_rows_ws(int P, int steps, int B) {
+    const int64_t nblk = (B + 15) / 16;
+    GruRowsWs w;
+    int64_t off = 0;
+    auto take = [&](int64_t floats) { const int64_t o = off; off += (floats * 4 + 255) / 256 * 256; return o; };
+    w.q = take((int64_t)P * steps * B * S::A);
+    w.rec = take((int64_t)P * steps * nblk * S::REC);
+    w.rec2 = take((int64_t)P * steps * nblk * GruBwd<S>::REC2);
+    const int64_t items = (int64_t)steps * nblk;
+    const int cap = 256 / P > 1 ? 256 / P : 1;
+    w.nwg = (int)(items < cap ? items : cap);
+    w.partials = take((int64_t)P * w.nwg * (S::NPARAM + 2));
+    w.packF = take((int64_t)P * S::NFWD);
+    w.packB = take((int64_t)P * GruBwd<S>::NBWD);
+    w.total = off;
+    return w;
+}
+
+inline void gru_obs_strides(const marlhip_batch* bt, int D, size_t* as, size_t* rs) {
+    *as = bt->obs_agent_stride > 0 ? (size_t)bt->obs_agent_stride : (bt->obs_agent_stride < 0 ? 0 : (size_t)(bt->max_len + 1) * bt->batch * D);
+    *rs = bt->obs_row_stride ? (size_t)bt->obs_row_stride : (size_t)D;
+}
+
+template <class S>
+void gru_set_attrs() {
+    static bool done = false;
+    if (done) return;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_seq_fwd_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)(S::LDS_FLOATS * sizeof(float)));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_seq_bwd_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)(GruBwd<S>::LDS_FLOATS * sizeof(float)));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_wgrad_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)((4 * 16 * S::H + 256) * sizeof(float)));
+    done = true;
+}
+
+// out[p][t][b][:] for t < steps, sequences from zero hidden states (`hiddens=None`, ac/model.py:191,206-207)
+template <class S>
+int gru_forward_rows(int P, const AgentMap& am, const float* params, const marlhip_batch* bt, int steps, float* out, hipStream_t st) {
+    float* packs = collect_pack_scratch((size_t)P * S::NFWD * sizeof(float), st);
+    MARL_REQUIRE(packs != nullptr, "gru_forward_rows: cannot allocate the pack scratch");
+    gru_set_attrs<S>();
+    size_t as, rs;
+    gru_obs_strides(bt, S::D, &as, &rs);
+    hipLaunchKernelGGL((gru_pack_kernel<S>), dim3((S::NFWD + 255) / 256, P), dim3(256), 0, st, params, am, packs);
+    hipLaunchKernelGGL((gru_seq_fwd_kernel<S>), dim3((bt->batch + 63) / 64, P), dim3(256), S::LDS_FLOATS * sizeof(float), st, (const float*)packs, bt->obss,
+                       as, rs, steps, bt->batch, (const float*)nullptr, (float*)nullptr, out, (float*)nullptr);
+    MARL_CHECK_LAUNCH("gru_seq_fwd_kernel (rows)");
+    return 0;
+}
+
+// grad[P][NPARAM] = d(sum of row losses)/dparams / sum(filled) from dout[P][steps][B][A]; loss[0] = sum(lrow)/sum(filled), loss[1] = sum(filled)
+template <class S>
+int gru_backward_rows(int P, const AgentMap& am, const float* params, const marlhip_batch* bt, int steps, const float* dout, const float* lrow,
+                      void* ws, int64_t ws_bytes, float* grad, float* loss, hipStream_t st) {
+    using Bk = GruBwd<S>;
+    const int B = bt->batch;
+    const GruRowsWs wl = gru_rows_ws<S>(P, steps, B);
+    MARL_REQUIRE(ws_bytes >= wl.total, "gru_backward_rows: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)wl.total);
+    char* base = static_cast<char*>(ws);
+    auto f = [&](int64_t o) { return reinterpret_cast<float*>(base + o); };
+    gru_set_attrs<S>();
+    size_t as, rs;
+    gru_obs_strides(bt, S::D, &as, &rs);
+    hipLaunchKernelGGL((gru_pack_kernel<S>), dim3((S::NFWD + 255) / 256, P), dim3(256), 0, st, params, am, f(wl.packF));
+    hipLaunchKernelGGL((gru_bwd_pack_kernel<S>), dim3((Bk::NBWD + 255) / 256, P), dim3(256), 0, st, params, am, f(wl.packB));
+    const dim3 gridS((B + 63) / 64, P);
+    hipLaunchKernelGGL((gru_seq_fwd_kernel<S>), gridS, dim3(256), S::LDS_FLOATS * sizeof(float), st, (const float*)f(wl.packF), bt->obss, as, rs, steps, B,
+                       (const float*)nullptr, (float*)nullptr, f(wl.q), f(wl.rec));
+    hipLaunchKernelGGL((gru_seq_bwd_kernel<S>), gridS, dim3(256), Bk::LDS_FLOATS * sizeof(float), st, (const float*)f(wl.packB), steps, B,
+                       (const float*)f(wl.rec), dout, f(wl.rec2));
+    hipLaunchKernelGGL((gru_wgrad_kernel<S>), dim3(wl.nwg, P, 4), dim3(256), (4 * 16 * S::H + 256) * sizeof(float), st, steps, B, bt->obss, as, rs,
+                       (const float*)f(wl.rec), (const float*)f(wl.rec2), dout, lrow, bt->filled, steps, f(wl.partials));
+    MARL_CHECK_LAUNCH("gru backward rows");
+    const int n = P * S::NPARAM;
+    hipLaunchKernelGGL(dqn_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, st, (const float*)f(wl.partials), P, wl.nwg, S::NPARAM, am, grad, loss);
+    MARL_CHECK_LAUNCH("dqn_reduce_kernel");
+    return 0;
+}
+
+}  // namespace marl

@@ -32,7 +32,14 @@ def evaluate(model, lbf_cfg, episodes, time_limit, epsilon=0.0, round_idx=0):
     dev = model.device
     ret = torch.zeros(model.n_agents, episodes, device=dev)
     ln = torch.zeros(episodes, dtype=torch.int32, device=dev)
-    if hasattr(model, "actor_params"):
+    if hasattr(model, "actor_params") and getattr(model, "recurrent", False):  # use_rnn actors: the modular rollout loop
+        from .ac.train import _collect_trajectories_recurrent
+        from .utils.envs import HipForagingVecEnv
+
+        _, _, r, l = _collect_trajectories_recurrent(HipForagingVecEnv(cfg), model, int(time_limit), False, round_idx)
+        ret.copy_(r)
+        ln.copy_(l)
+    elif hasattr(model, "actor_params"):
         P, D, T = model.n_agents, model.spec.obs_dim, int(time_limit)
         t_max = torch.zeros(1, dtype=torch.int32, device=dev)
         _hip.ac_collect(cfg, model.spec, model.actor_params, round_idx, T, False, torch.empty(T + 1, episodes, P * D, device=dev),

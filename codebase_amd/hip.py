@@ -429,14 +429,23 @@ class AcUpdater:
 
     def __init__(self, spec: NetSpec, block, target_critic, lr=3e-4, betas=(0.9, 0.999), eps=1e-8, gamma=0.99, n_steps=5,
                  entropy_coef=0.001, value_loss_coef=0.5, grad_clip=False, ppo_clip=0.2, standardise_returns=False,
-                 centralised_critic=False):
+                 centralised_critic=False, recurrent=False):
         _require_gpu()
+        self.recurrent = bool(recurrent)  # use_rnn actors and critics: the marlhip_gru_* entry points, recurrent block layout
+        if self.recurrent and centralised_critic:
+            raise NotImplementedError("recurrent actor-critic networks: centralised critics are not built")
+        self._fn = ((lib.marlhip_gru_a2c_loss_grad, lib.marlhip_gru_ppo_prepare, lib.marlhip_gru_ppo_loss_grad) if self.recurrent else
+                    (lib.marlhip_a2c_loss_grad, lib.marlhip_ppo_prepare, lib.marlhip_ppo_loss_grad))
         self.centralised = int(bool(centralised_critic))
         self.ret_stats = RunningReturnStats(spec.n_agents, block.device) if standardise_returns else None
         s = spec.c()
         self.spec = spec
-        self.n_actor = spec.nparams()
-        self.n_critic = check(lib.marlhip_ac_critic_nparams(ctypes.byref(s), self.centralised), "ac_critic_nparams")
+        if self.recurrent:
+            self.n_actor = check(lib.marlhip_gru_nparams(ctypes.byref(s)), "gru_nparams")
+            self.n_critic = check(lib.marlhip_gru_ac_critic_nparams(ctypes.byref(s)), "gru_ac_critic_nparams")
+        else:
+            self.n_actor = spec.nparams()
+            self.n_critic = check(lib.marlhip_ac_critic_nparams(ctypes.byref(s), self.centralised), "ac_critic_nparams")
         P = spec.n_blocks
         if block.numel() != P * (self.n_actor + self.n_critic) or target_critic.numel() != P * self.n_critic:
             raise ValueError("actor-critic parameter block has the wrong size for this shape")
@@ -462,7 +471,10 @@ class AcUpdater:
     def _workspace(self, T, B):
         if (T, B) not in self._ws:
             s = self.spec.c()
-            n = check(lib.marlhip_ac_workspace_bytes(ctypes.byref(s), self.centralised, T, B), "ac_workspace_bytes")
+            if self.recurrent:
+                n = check(lib.marlhip_gru_ac_workspace_bytes(ctypes.byref(s), T, B), "gru_ac_workspace_bytes")
+            else:
+                n = check(lib.marlhip_ac_workspace_bytes(ctypes.byref(s), self.centralised, T, B), "ac_workspace_bytes")
             self._ws[(T, B)] = torch.empty(int(n), dtype=torch.uint8, device=self.block.device)
         return self._ws[(T, B)]
 
@@ -484,7 +496,7 @@ class AcUpdater:
     def a2c_loss_grad(self, batch):
         bs, keep, T, N = self._batch(batch)
         ws, s = self._workspace(T, N), self.spec.c()
-        check(lib.marlhip_a2c_loss_grad(ctypes.byref(s), _ptr(self.actor), _ptr(self.critic), _ptr(self.target_critic),
+        check(self._fn[0](ctypes.byref(s), _ptr(self.actor), _ptr(self.critic), _ptr(self.target_critic),
                                         ctypes.byref(bs), ctypes.byref(self.cfg), _ptr(ws), ws.numel(), _ptr(self.actor_grad),
                                         _ptr(self.critic_grad), _ptr(self.metrics), _stream()), "a2c_loss_grad")
         return self.metrics
@@ -492,13 +504,13 @@ class AcUpdater:
     def ppo_prepare(self, batch):
         bs, keep, T, N = self._batch(batch)
         ws, s = self._workspace(T, N), self.spec.c()
-        check(lib.marlhip_ppo_prepare(ctypes.byref(s), _ptr(self.actor), _ptr(self.critic), _ptr(self.target_critic),
+        check(self._fn[1](ctypes.byref(s), _ptr(self.actor), _ptr(self.critic), _ptr(self.target_critic),
                                       ctypes.byref(bs), ctypes.byref(self.cfg), _ptr(ws), ws.numel(), _stream()), "ppo_prepare")
 
     def ppo_loss_grad(self, batch):
         bs, keep, T, N = self._batch(batch)
         ws, s = self._workspace(T, N), self.spec.c()
-        check(lib.marlhip_ppo_loss_grad(ctypes.byref(s), _ptr(self.actor), _ptr(self.critic), ctypes.byref(bs), ctypes.byref(self.cfg),
+        check(self._fn[2](ctypes.byref(s), _ptr(self.actor), _ptr(self.critic), ctypes.byref(bs), ctypes.byref(self.cfg),
                                         _ptr(ws), ws.numel(), _ptr(self.actor_grad), _ptr(self.critic_grad), _ptr(self.metrics),
                                         _stream()), "ppo_loss_grad")
         return self.metrics
@@ -659,3 +671,26 @@ class GruQmixUpdater(QmixUpdater):
 
     def loss_grad_replay(self, replay, batch_size, length=None, idx=None, seed=0, counter=0, idx_out=None, mode=2):
         return self.loss_grad(replay.sample(batch_size, length=length, idx=idx, seed=seed, counter=counter), mode=mode)
+
+
+def gru_ac_forward(spec: NetSpec, params, obs, agent_stride, row_stride, steps, batch, value_net=False, h_in=None, want_h=False):
+    """sequence forward of recurrent actors (logits [P][steps][B][A]) or critics (values [P][steps][B][1]); rows of agent p at
+    obs + p * agent_stride + (t * B + b) * row_stride; hidden state [P][B][H] in / out"""
+    _require_gpu()
+    P = spec.n_agents
+    out = torch.empty(P, steps, batch, 1 if value_net else spec.n_actions, device=params.device)
+    h_out = torch.empty(P, batch, spec.hidden, device=params.device) if want_h else None
+    s = spec.c()
+    check(lib.marlhip_gru_ac_forward(ctypes.byref(s), int(bool(value_net)), _ptr(params), _ptr(obs), int(agent_stride), int(row_stride), int(steps),
+                                     int(batch), _ptr(h_in), _ptr(h_out), _ptr(out), _stream()), "gru_ac_forward")
+    return (out, h_out) if want_h else out
+
+
+def sample_from_logits(logits, seed, episode, t):
+    """logits f32 [P][N][A] -> sampled actions i64 [P][N] (Philox inverse-CDF draw of the fused rollout collector)"""
+    _require_gpu()
+    P, N, A = logits.shape
+    actions = torch.empty(P, N, dtype=torch.int64, device=logits.device)
+    check(lib.marlhip_sample_from_logits(P, N, A, _ptr(logits.contiguous()), int(seed) & (2**64 - 1), _ptr(episode), int(t), _ptr(actions),
+                                         _stream()), "sample_from_logits")
+    return actions

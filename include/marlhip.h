@@ -336,6 +336,29 @@ int marlhip_gru_qmix_loss_grad(const marlhip_net_shape* s, const float* params, 
                                const struct marlhip_qmix_mixer* mixer, const marlhip_batch* batch, float gamma, int32_t double_q,
                                void* workspace, int64_t workspace_bytes, float* grad, float* loss /* [2] */, void* stream);
 
+/* Actor-critic learner step with recurrent networks (`use_rnn: True` for actor and critic; ia2c.yaml / ippo.yaml): same contracts as
+ * marlhip_a2c_loss_grad / marlhip_ppo_prepare / marlhip_ppo_loss_grad, the blocks in the recurrent layout (marlhip_gru_nparams for the
+ * actors, marlhip_gru_ac_critic_nparams for the critics); independent networks and critics only.  marlhip_gru_ac_forward: sequence
+ * forward of the actors (value_net = 0) or critics (1) with the hidden state carried by the caller (A2CNetwork.act / get_value). */
+int marlhip_gru_ac_critic_nparams(const marlhip_net_shape* s);
+int64_t marlhip_gru_ac_workspace_bytes(const marlhip_net_shape* s, int32_t max_len, int32_t batch);
+int marlhip_gru_a2c_loss_grad(const marlhip_net_shape* s, const float* actor, const float* critic, const float* target_critic,
+                              const marlhip_batch* batch, const struct marlhip_ac_config* cfg, void* workspace, int64_t workspace_bytes,
+                              float* actor_grad, float* critic_grad, float* metrics /* [5] */, void* stream);
+int marlhip_gru_ppo_prepare(const marlhip_net_shape* s, const float* actor, const float* critic, const float* target_critic,
+                            const marlhip_batch* batch, const struct marlhip_ac_config* cfg, void* workspace, int64_t workspace_bytes,
+                            void* stream);
+int marlhip_gru_ppo_loss_grad(const marlhip_net_shape* s, const float* actor, const float* critic, const marlhip_batch* batch,
+                              const struct marlhip_ac_config* cfg, void* workspace, int64_t workspace_bytes, float* actor_grad,
+                              float* critic_grad, float* metrics /* [5] */, void* stream);
+int marlhip_gru_ac_forward(const marlhip_net_shape* s, int32_t value_net, const float* params, const float* obs, int64_t agent_stride,
+                           int64_t row_stride, int32_t steps, int32_t batch, const float* h_in, float* h_out, float* out, void* stream);
+
+/* Categorical(logits=logits[p][n]).sample() for every (agent, env) (ac/model.py:147-153), drawn as the fused rollout collector draws
+ * it: inverse CDF of the fp32 softmax with the Philox uniform of (env n, episode[n], step t, word 1 + p).  actions: i64 [P][N]. */
+int marlhip_sample_from_logits(int32_t n_agents, int32_t n_envs, int32_t n_actions, const float* logits /* [P][N][A] */, uint64_t seed,
+                               const uint32_t* episode /* [N] */, int32_t t, int64_t* actions, void* stream);
+
 /* the action choice of QNetwork.act (dqn/model.py:105-115) from given values q [P][N][A] (the recurrent path computes them with
  * marlhip_gru_forward): explore iff epsilon > u with ONE Philox uniform per env (env n, episode[n], t = ep_length[n], word 0),
  * random action of agent p = word 1+p, greedy = first maximum - the same words marlhip_dqn_act and the fused collector use. */

@@ -85,3 +85,19 @@ def compute_qmix_loss(params, tparams, mixer, tmixer, batch, gamma, double_q, D,
         return qp.compute_loss(params, tparams, mixer, tmixer, batch, gamma, double_q, D, H, A)
     finally:
         dp.q_values = saved
+
+
+import contextlib
+
+
+@contextlib.contextmanager
+def recurrent_ac():
+    """oracle.ac_update_port with recurrent actors and critics (ac/model.py:189-352 with use_rnn): its mlp / split / nparams hooks
+    become the sequence forward and the recurrent block layout for the duration of the `with` block"""
+    saved = dp.mlp, dp.split, dp.nparams
+    dp.mlp = lambda block, x, D, H, A: sequence(block, x, D, H, A)[0]  # x [S, N, D] from zero hidden states
+    dp.split, dp.nparams = split, nparams
+    try:
+        yield
+    finally:
+        dp.mlp, dp.split, dp.nparams = saved

@@ -29,7 +29,7 @@ def build(cls, P, D, A, H, seed, **over):
     cfg.update(over)
     centralised = bool(over.pop("centralised", False)) if "centralised" in over else False
     cfg.pop("centralised", None)
-    net_cfg = dict(layers=[H, H], parameter_sharing=False, use_orthogonal_init=True, use_rnn=False)
+    net_cfg = dict(layers=[H, H], parameter_sharing=False, use_orthogonal_init=True, use_rnn=bool(cfg.pop("use_rnn", False)))
     with contextlib.redirect_stdout(io.StringIO()):
         net = cls([Box(D)] * P, [Discrete(A)] * P, cfg, Cfg(net_cfg), Cfg(dict(net_cfg, centralised=centralised)), "cpu")
     g = torch.Generator().manual_seed(seed + 1)
@@ -58,7 +58,7 @@ def fixture(ref_ac_model, ref_ac_train, name, cls, P, D, H, N, seed, masked=Fals
             m[:-1].scatter_(-1, b["actions"].unsqueeze(-1), 1.0)
             b["action_masks"] = m
     mk = lambda b: ref_ac_train.Batch(b["obss"], b["actions"], b["rewards"], b["dones"], b["filled"], b.get("action_masks"))  # noqa: E731
-    if cls is ref_ac_model.A2CNetwork:  # gradient of the first update, via a throw-away copy stepped with lr = 0
+    if cls is ref_ac_model.A2CNetwork and not over.get("use_rnn"):  # gradient of the first update, via a throw-away copy stepped with lr = 0
         probe, _ = build(cls, P, D, A, H, seed, **dict(over, lr=0.0, grad_clip=False))  # noqa
         probe.update(mk(batches[0]), 1)
         out["actor_grad0"] = torch.stack([torch.cat([p.grad.reshape(-1) for p in m.parameters()]) for m in probe.actor.independent]).numpy()
@@ -101,3 +101,6 @@ if __name__ == "__main__":
     # batch.action_masks set (get_dist masks the logits, ac/model.py:135-145)
     fixture(ram, rat, "learner_a2c_masks_H64.npz", ram.A2CNetwork, P=2, D=15, H=64, N=12, seed=1300, masked=True)
     fixture(ram, rat, "learner_ppo_masks_H128.npz", ram.PPONetwork, P=2, D=15, H=128, N=10, seed=1400, masked=True)
+    # recurrent actors and critics (use_rnn: RNNNetwork, utils/models.py:51-116)
+    fixture(ram, rat, "learner_a2c_gru_H64.npz", ram.A2CNetwork, P=2, D=15, H=64, N=12, seed=1500, use_rnn=True)
+    fixture(ram, rat, "learner_ppo_gru_H128.npz", ram.PPONetwork, P=2, D=15, H=128, N=10, seed=1600, use_rnn=True)

@@ -242,3 +242,95 @@ def test_recurrent_qmix_matches_reference():
     np.testing.assert_allclose(losses, g["losses"], rtol=5e-5)
     np.testing.assert_allclose(net.params.cpu().numpy(), g["params2"], rtol=0, atol=5e-6)
     np.testing.assert_allclose(net.mixer_params.cpu().numpy(), g["mixer2"], rtol=0, atol=5e-6)
+
+
+# ---- actor-critic learners with recurrent actors and critics (ac/model.py:189-352 with use_rnn)
+AC_GRU = ["learner_a2c_gru_H64.npz", "learner_ppo_gru_H128.npz"]
+
+
+def _ac_batch(g, i):
+    return {k: torch.tensor(g[f"batch{i}_{k}"]) for k in ("obss", "actions", "rewards", "dones", "filled")}
+
+
+@pytest.mark.parametrize("name", AC_GRU)
+def test_ac_oracle_port_with_recurrent_networks_matches_reference(name):
+    from oracle import ac_update_port as ap
+
+    g = dict(np.load(os.path.join(G, name)))
+    D, H, A = int(g["D"]), int(g["H"]), int(g["A"])
+    with gp.recurrent_ac():
+        lr = ap.Learner(torch.tensor(g["actor0"]), torch.tensor(g["critic0"]), D, H, A, gamma=float(g["gamma"]), n_steps=int(g["n_steps"]),
+                        entropy_coef=float(g["entropy_coef"]), value_loss_coef=float(g["value_loss_coef"]),
+                        num_epochs=int(g["num_epochs"]) if "ppo" in name else 0, ppo_clip=float(g["ppo_clip"]))
+        lr.target = torch.tensor(g["target0"])
+        for i in range(3):
+            m = lr.update(_ac_batch(g, i), int(g["steps"][i]))
+            np.testing.assert_allclose([m["loss"], m["actor_loss"], m["value_loss"], m["entropy"]], g["metrics"][i], rtol=2e-5, atol=2e-6)
+            np.testing.assert_allclose(lr.actor().detach().numpy(), g[f"actor{i + 1}"], rtol=0, atol=3e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", AC_GRU)
+def test_hip_recurrent_actor_critic_matches_reference(name):
+    from collections import namedtuple
+
+    from codebase_amd import hip as h
+
+    Batch = namedtuple("Batch", ["obss", "actions", "rewards", "dones", "filled", "action_masks"])
+    g = dict(np.load(os.path.join(G, name)))
+    P, D, H, A = int(g["P"]), int(g["D"]), int(g["H"]), int(g["A"])
+    spec = h.NetSpec(P, D, H, A)
+    block = torch.cat([torch.tensor(g["actor0"]).reshape(-1), torch.tensor(g["critic0"]).reshape(-1)]).cuda()
+    up = h.AcUpdater(spec, block, torch.tensor(g["target0"]).cuda().contiguous(), lr=3e-4, gamma=float(g["gamma"]), n_steps=int(g["n_steps"]),
+                     entropy_coef=float(g["entropy_coef"]), value_loss_coef=float(g["value_loss_coef"]), grad_clip=False,
+                     ppo_clip=float(g["ppo_clip"]), recurrent=True)
+    assert up.n_actor == g["actor0"].shape[1] and up.n_critic == g["critic0"].shape[1]
+    ppo = "ppo" in name
+    for i in range(3):
+        b = Batch(*(v.cuda() for v in _ac_batch(g, i).values()), None)
+        if ppo:
+            up.ppo_prepare(b)
+            acc = np.zeros(4)
+            for _ in range(int(g["num_epochs"])):
+                acc += up.ppo_loss_grad(b).cpu().numpy()[:4]
+                up.apply()
+            m = acc / int(g["num_epochs"])
+        else:
+            m = up.a2c_loss_grad(b).cpu().numpy()[:4]
+            up.apply()
+        np.testing.assert_allclose(m, g["metrics"][i], rtol=1e-4, atol=1e-5)
+        if int(g["steps"][i]) % 200 == 0:
+            up.target_critic.copy_(up.critic)
+        np.testing.assert_allclose(up.block[:P * up.n_actor].cpu().numpy().reshape(P, -1), g[f"actor{i + 1}"], rtol=0, atol=5e-6)
+        np.testing.assert_allclose(up.block[P * up.n_actor:].cpu().numpy().reshape(P, -1), g[f"critic{i + 1}"], rtol=0, atol=5e-6)
+
+
+@pytest.mark.gpu
+def test_recurrent_ia2c_and_ippo_end_to_end(tmp_path, monkeypatch):
+    """+algorithm=ia2c / ippo with use_rnn for actor and critic: recurrent rollout collection (hidden state carried on the device,
+    Philox sampling), recurrent update, reference-shaped act / get_value with hidden states"""
+    from codebase_amd import run
+    from codebase_amd.ac.model import A2CNetwork
+    from codebase_amd.spaces import Box, Discrete, Tuple
+
+    net_cfg = dict(layers=[64, 64], parameter_sharing=False, use_orthogonal_init=True, use_rnn=True)
+    cfg = dict(optimizer="Adam", lr=3e-4, gamma=0.99, grad_clip=False, n_steps=5, entropy_coef=0.001, value_loss_coef=0.5,
+               standardise_returns=False, target_update_interval_or_tau=200)
+    net = A2CNetwork(Tuple([Box(-1, 8, (15,))] * 2), Tuple([Discrete(6)] * 2), cfg, net_cfg, dict(net_cfg, centralised=False), "cuda")
+    sd = net.state_dict()
+    assert "actor.independent.0.rnn.weight_hh_l0" in sd and sd["critic.independent.1.final_layer.weight"].shape == (1, 64)
+    obs = [torch.rand(5, 15) for _ in range(2)]
+    hid = net.init_actor_hiddens(5)
+    acts, hid = net.act(obs, hid)
+    assert acts.shape == (2, 5, 1) and hid[0].shape == (1, 5, 64)
+    v, ch = net.get_value(obs, net.init_critic_hiddens(5))
+    assert v.shape == (5, 2) and ch[1].shape == (1, 5, 64)
+    ref = torch.cat([gp.cell(gp.split(net.critic_params[p].cpu(), 15, 64, 1), obs[p], torch.zeros(5, 64))[0] for p in range(2)], dim=-1)
+    np.testing.assert_allclose(v.cpu().numpy(), ref.numpy(), rtol=1e-5, atol=1e-5)
+    NAME = "lbforaging:Foraging-8x8-2p-3f-v3"
+    for algo in ("ia2c", "ippo"):
+        monkeypatch.setenv("MARLHIP_RUN_DIR", str(tmp_path / algo))
+        df = run.main([f"+algorithm={algo}", f"env.name={NAME}", "env.time_limit=25", "env.parallel_envs=128",
+                       "algorithm.model.actor.layers=[64,64]", "algorithm.model.critic.layers=[64,64]", "algorithm.model.actor.use_rnn=True",
+                       "algorithm.model.critic.use_rnn=True", "seed=1", "algorithm.total_steps=40000", "algorithm.eval_interval=15000"])
+        assert df.shape[0] >= 2 and np.isfinite(df["loss"]).all() and np.isfinite(df["mean_episode_returns"]).all()
