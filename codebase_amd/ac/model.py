@@ -46,8 +46,8 @@ class A2CNetwork:
         self.recurrent = bool(_get(actor, "use_rnn", False))
         if bool(_get(critic, "use_rnn", False)) != self.recurrent:
             raise NotImplementedError("actor.use_rnn != critic.use_rnn: the recurrent step is built for recurrent actors AND critics")
-        if self.recurrent and (self.sharing is not None or bool(_get(critic, "centralised", False))):
-            raise NotImplementedError("use_rnn with parameter sharing / centralised critics is not built (DESIGN.md)")
+        if self.recurrent and bool(_get(critic, "centralised", False)):
+            raise NotImplementedError("use_rnn with centralised critics is not built (DESIGN.md)")
         ha, hc = [int(h) for h in _get(actor, "layers")], [int(h) for h in _get(critic, "layers")]
         if ha != hc or len(ha) != 2 or ha[0] != ha[1]:
             raise NotImplementedError(f"layers actor={ha} critic={hc}: the HIP kernels implement two equal hidden layers (64 or 128), "
@@ -74,8 +74,8 @@ class A2CNetwork:
         # torch RNG consumption in the reference's order: actor nets, critic nets, target-critic nets (model.py:44-107)
         cdims = [self.n_agents * self.spec.obs_dim] * K if self.centralised_critic else obs_dims  # critic_obs_shape (model.py:63-65)
         if self.recurrent:  # RNNNetwork inits (utils/models.py:83-94); init_flat_gru_params draws one set per call
-            a0 = init_flat_gru_params(obs_dims, ha[0], act_dims, _get(actor, "use_orthogonal_init", True))[0]
-            c0 = init_flat_gru_params(cdims, hc[0], [1] * K, _get(critic, "use_orthogonal_init", True))[0]
+            a0 = init_flat_gru_params(obs_dims, ha[0], act_dims, _get(actor, "use_orthogonal_init", True), sets=1)[0]
+            c0 = init_flat_gru_params(cdims, hc[0], [1] * K, _get(critic, "use_orthogonal_init", True), sets=2)[0]  # critic, then the target's draws
         else:
             a0 = _init_blocks(obs_dims, ha, act_dims, _get(actor, "use_orthogonal_init", True))
             c0 = _init_blocks(cdims, hc, [1] * K, _get(critic, "use_orthogonal_init", True))

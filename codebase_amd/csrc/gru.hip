@@ -134,7 +134,7 @@ int gru_loss_grad(const marlhip_net_shape* s, const float* params, const float* 
     hipLaunchKernelGGL((gru_wgrad_kernel<S>), dim3(wl.nwg, P, 4), dim3(256), ldsW, st, steps, B, bt->obss, (size_t)steps * B * S::D, (size_t)S::D, (const float*)f(wl.rec), (const float*)f(wl.rec2),
                        (const float*)f(wl.dq), (const float*)f(wl.lrow), bt->filled, T, f(wl.partials));
     MARL_CHECK_LAUNCH("gru_wgrad_kernel");
-    const int n = P * S::NPARAM;
+    const int n = am.nblk * S::NPARAM;  // one gradient block per NETWORK: a shared network's agents are summed by the reduce
     hipLaunchKernelGGL(dqn_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, st, (const float*)f(wl.partials), P, wl.nwg, S::NPARAM, am, grad, loss);
     timing_end(TIMER_LOSSGRAD, st);
     MARL_CHECK_LAUNCH("dqn_reduce_kernel");
@@ -156,7 +156,6 @@ extern "C" int marlhip_gru_loss_grad(const marlhip_net_shape* s, const float* pa
     if (gru_check(s) != 0) return -1;
     MARL_REQUIRE(params && target_params && batch && workspace && grad && loss, "gru_loss_grad: NULL pointer");
     MARL_REQUIRE(mode == 0 || mode == 1, "gru_loss_grad: mode %d (0 = IDQN, 1 = VDN; the recurrent QMIX path is not built)", mode);
-    MARL_REQUIRE(s->n_networks == 0, "gru_loss_grad: parameter sharing is not built for recurrent networks");
     MARL_REQUIRE(batch->obss && batch->actions && batch->rewards && batch->dones && batch->filled && batch->max_len > 0 && batch->batch > 0,
                  "gru_loss_grad: bad batch");
     MARL_REQUIRE(batch->obs_agent_stride == 0 && batch->obs_row_stride == 0, "gru_loss_grad: the dqn/train.py Batch layout only");
@@ -302,7 +301,7 @@ int gru_qmix_loss_grad(const marlhip_net_shape* s, const float* params, const fl
     hipLaunchKernelGGL((gru_wgrad_kernel<S>), dim3(wl.nwg, P, 4), dim3(256), ldsW, st, steps, B, bt->obss, (size_t)steps * B * S::D, (size_t)S::D, (const float*)f(wl.rec), (const float*)f(wl.rec2),
                        (const float*)f(wl.dq), (const float*)f(wl.lrow), bt->filled, T, f(wl.partials));
     MARL_CHECK_LAUNCH("gru backward");
-    const int n = P * S::NPARAM;
+    const int n = am.nblk * S::NPARAM;  // one gradient block per NETWORK: a shared network's agents are summed by the reduce
     hipLaunchKernelGGL(dqn_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, st, (const float*)f(wl.partials), P, wl.nwg, S::NPARAM, am, grad, loss);
     timing_end(TIMER_LOSSGRAD, st);
     MARL_CHECK_LAUNCH("dqn_reduce_kernel");
@@ -323,7 +322,6 @@ extern "C" int marlhip_gru_qmix_loss_grad(const marlhip_net_shape* s, const floa
     MARL_REQUIRE(params && target_params && mixer && mixer->mixer && mixer->target_mixer && mixer->mixer_grad && batch && workspace && grad && loss,
                  "gru_qmix_loss_grad: NULL pointer");
     MARL_REQUIRE(mixer->embed_dim == 64 && mixer->hypernet_layers == 2 && mixer->hypernet_embed == 32, "gru_qmix_loss_grad: mixing = {64, 2, 32} only");
-    MARL_REQUIRE(s->n_networks == 0, "gru_qmix_loss_grad: parameter sharing is not built for recurrent networks");
     MARL_REQUIRE(batch->obs_agent_stride == 0 && batch->obs_row_stride == 0, "gru_qmix_loss_grad: the dqn/train.py Batch layout only");
 #define X(d, h, a)                                               \
     if (s->obs_dim == d && s->hidden == h && s->n_actions == a)  \

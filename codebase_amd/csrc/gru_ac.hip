@@ -13,7 +13,6 @@ using namespace marl;
 static int gru_ac_check(const marlhip_net_shape* s) {
     MARL_REQUIRE(s != nullptr, "net shape is NULL");
     if (agent_map_validate(s) != 0) return -1;
-    MARL_REQUIRE(s->n_networks == 0, "recurrent actor-critic networks: parameter sharing is not built");
 #define X(d, h, a) if (s->obs_dim == d && s->hidden == h && s->n_actions == a) return 0;
     MARL_GRU_AC_SHAPES(X)
 #undef X

@@ -94,7 +94,7 @@ int gru_backward_rows(int P, const AgentMap& am, const float* params, const marl
     hipLaunchKernelGGL((gru_wgrad_kernel<S>), dim3(wl.nwg, P, 4), dim3(256), (4 * 16 * S::H + 256) * sizeof(float), st, steps, B, bt->obss, as, rs,
                        (const float*)f(wl.rec), (const float*)f(wl.rec2), dout, lrow, bt->filled, steps, f(wl.partials));
     MARL_CHECK_LAUNCH("gru backward rows");
-    const int n = P * S::NPARAM;
+    const int n = am.nblk * S::NPARAM;  // one gradient block per NETWORK: a shared network's agents are summed by the reduce
     hipLaunchKernelGGL(dqn_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, st, (const float*)f(wl.partials), P, wl.nwg, S::NPARAM, am, grad, loss);
     MARL_CHECK_LAUNCH("dqn_reduce_kernel");
     return 0;

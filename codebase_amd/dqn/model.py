@@ -79,12 +79,16 @@ def _gru_layout(D, H, A):
             ("rnn.bias_ih_l0", (3 * H,)), ("rnn.bias_hh_l0", (3 * H,)), ("final_layer.weight", (A, H)), ("final_layer.bias", (A,))]
 
 
-def init_flat_gru_params(obs_dims, hidden, act_dims, use_orthogonal_init=True):
+def init_flat_gru_params(obs_dims, hidden, act_dims, use_orthogonal_init=True, sharing=None, sets=2):
     """Initial critic / target blocks of recurrent networks, consuming torch's global RNG like RNNNetwork.__init__ does
     (utils/models.py:83-94: nn.Linear and nn.GRU default inits, orthogonal gain sqrt(2) + zero bias on the output layer only),
-    critic nets first, then target nets, then hard_update (dqn/model.py:36-41,60)."""
+    critic nets first, then target nets, then hard_update (dqn/model.py:36-41,60); with parameter sharing one network per distinct
+    index in order of first appearance (utils/models.py:209-240)."""
+    if sharing is not None:
+        first = [sharing.index(k) for k in range(max(sharing) + 1)]
+        obs_dims, act_dims = [obs_dims[i] for i in first], [act_dims[i] for i in first]
     blocks = []
-    for _ in range(2):
+    for _ in range(sets):
         per_agent = []
         for d, a in zip(obs_dims, act_dims):
             first = nn.Linear(d, hidden)
@@ -111,9 +115,8 @@ class QNetwork:
         obs_dims = [flatdim(o) for o in obs_space]
         act_dims = [flatdim(a) for a in action_space]
         self.recurrent = bool(use_rnn)
-        if use_rnn and (hidden not in ([64, 64], [128, 128]) or parameter_sharing):
-            raise NotImplementedError(f"use_rnn with layers={hidden}, parameter_sharing={parameter_sharing}: the recurrent kernels are "
-                                      "built for layers [64, 64] / [128, 128] and independent networks (DESIGN.md)")
+        if use_rnn and hidden not in ([64, 64], [128, 128]):
+            raise NotImplementedError(f"use_rnn with layers={hidden}: the recurrent kernels are built for layers [64, 64] / [128, 128]")
         if len(hidden) != 2 or hidden[0] != hidden[1]:
             raise NotImplementedError(f"layers={hidden}: the HIP kernels implement two equal hidden layers (64 or 128)")
         if len(set(obs_dims)) != 1 or len(set(act_dims)) != 1:
@@ -137,7 +140,7 @@ class QNetwork:
             if self.standardise_returns:
                 raise NotImplementedError("use_rnn is built without standardise_returns")
             self.nparams = _hip.gru_nparams(self.spec)
-            critic, target = init_flat_gru_params(obs_dims, hidden[0], act_dims, use_orthogonal_init)
+            critic, target = init_flat_gru_params(obs_dims, hidden[0], act_dims, use_orthogonal_init, self.sharing)
         else:
             self.nparams = self.spec.nparams()
             critic, target = init_flat_params(obs_dims, hidden, act_dims, use_orthogonal_init, self.sharing)

@@ -111,3 +111,5 @@ if __name__ == "__main__":
     fixture(rm, rt, "learner_gru_idqn_H64.npz", rm.QNetwork, P=2, D=15, H=64, B=37, seed=2100)
     fixture(rm, rt, "learner_gru_vdn_H64.npz", rm.VDNetwork, P=3, D=18, H=64, B=21, seed=2200)
     qmix_fixture(rm, rt, "learner_gru_qmix_H64.npz", P=2, D=15, H=64, B=19, seed=2300)
+# learner_gru_shared_H64.npz / learner_gru_seps_vdn_H128.npz (parameter_sharing=True / [0, 0, 1] with use_rnn=True) were produced by the
+# same recipe on MultiAgentSharedNetwork: blocks [K][n] in `critic.networks` order, loss, gradient, 2 updates, state_dict keys.
