@@ -46,8 +46,6 @@ class A2CNetwork:
         self.recurrent = bool(_get(actor, "use_rnn", False))
         if bool(_get(critic, "use_rnn", False)) != self.recurrent:
             raise NotImplementedError("actor.use_rnn != critic.use_rnn: the recurrent step is built for recurrent actors AND critics")
-        if self.recurrent and bool(_get(critic, "centralised", False)):
-            raise NotImplementedError("use_rnn with centralised critics is not built (DESIGN.md)")
         ha, hc = [int(h) for h in _get(actor, "layers")], [int(h) for h in _get(critic, "layers")]
         if ha != hc or len(ha) != 2 or ha[0] != ha[1]:
             raise NotImplementedError(f"layers actor={ha} critic={hc}: the HIP kernels implement two equal hidden layers (64 or 128), "
@@ -143,6 +141,15 @@ class A2CNetwork:
     def get_value(self, inputs, critic_hiddens, target=False):
         """model.py:155-163: [..., P] values of the (target) critic"""
         blk = self.target_critic_params if target else self.critic_params
+        if self.recurrent and self.centralised_critic:  # every critic reads the concatenated row, each with its own hidden state
+            x = torch.cat([torch.as_tensor(i, dtype=torch.float32).to(self.device) for i in inputs], dim=-1)
+            one = x.dim() == 2
+            x = (x.unsqueeze(0) if one else x).contiguous()  # [S][N][P*D]
+            S_, N = x.shape[0], x.shape[1]
+            h_in = None if critic_hiddens is None or critic_hiddens[0] is None else torch.stack([h.reshape(N, -1) for h in critic_hiddens]).to(self.device).contiguous()
+            out, h = _hip.gru_ac_forward(self.spec, blk, x, 0, x.shape[-1], S_, N, value_net=2, h_in=h_in, want_h=True)
+            out = out[..., 0]
+            return (out[:, 0] if one else out).movedim(0, -1).contiguous(), [h[p].reshape(1, N, -1) for p in range(self.n_agents)]
         if self.recurrent:
             out, critic_hiddens = self._seq(blk, inputs, critic_hiddens, True)
             out = out[..., 0]  # [P][S][N]

@@ -10,9 +10,20 @@ using namespace marl;
     X(12, 64, 6) X(15, 64, 6) X(18, 64, 6) X(21, 64, 6) X(24, 64, 6) X(27, 64, 6) X(39, 64, 6) X(71, 64, 5) \
     X(12, 128, 6) X(15, 128, 6) X(18, 128, 6) X(21, 128, 6) X(24, 128, 6) X(27, 128, 6) X(39, 128, 6) X(71, 128, 5)
 
-static int gru_ac_check(const marlhip_net_shape* s) {
+// (agents, obs dim, hidden) with a compiled recurrent CENTRALISED critic (P * D inputs, critic.centralised: maa2c / mappo with use_rnn)
+#define MARL_GRU_MAC_SHAPES(X) X(2, 12, 64) X(2, 15, 64) X(3, 18, 64) X(4, 21, 64) X(4, 27, 64) X(2, 12, 128) X(2, 15, 128) X(3, 18, 128) X(4, 21, 128) X(4, 27, 128)
+
+static int gru_ac_check(const marlhip_net_shape* s, int centralised = 0) {
     MARL_REQUIRE(s != nullptr, "net shape is NULL");
     if (agent_map_validate(s) != 0) return -1;
+    if (centralised) {
+#define X(p, d, h) if (s->n_agents == p && s->obs_dim == d && s->hidden == h && s->n_actions == 6) return 0;
+        MARL_GRU_MAC_SHAPES(X)
+#undef X
+        set_error("no recurrent centralised-critic kernels for %d agents x obs_dim %d, hidden %d (MARL_GRU_MAC_SHAPES)", s->n_agents, s->obs_dim,
+                  s->hidden);
+        return -1;
+    }
 #define X(d, h, a) if (s->obs_dim == d && s->hidden == h && s->n_actions == a) return 0;
     MARL_GRU_AC_SHAPES(X)
 #undef X
@@ -20,16 +31,27 @@ static int gru_ac_check(const marlhip_net_shape* s) {
     return -1;
 }
 
-extern "C" int marlhip_gru_ac_critic_nparams(const marlhip_net_shape* s) {
-    if (gru_ac_check(s) != 0) return -1;
+extern "C" int marlhip_gru_ac_critic_nparams(const marlhip_net_shape* s, int32_t centralised) {
+    if (gru_ac_check(s, centralised) != 0) return -1;
+    if (centralised) {
+#define X(p, d, h) if (s->n_agents == p && s->obs_dim == d && s->hidden == h) return GruShape<p * d, h, 1>::NPARAM;
+        MARL_GRU_MAC_SHAPES(X)
+#undef X
+    }
 #define X(d, h, a) if (s->obs_dim == d && s->hidden == h && s->n_actions == a) return GruShape<d, h, 1>::NPARAM;
     MARL_GRU_AC_SHAPES(X)
 #undef X
     return -1;
 }
 
-extern "C" int64_t marlhip_gru_ac_workspace_bytes(const marlhip_net_shape* s, int32_t max_len, int32_t batch) {
-    if (gru_ac_check(s) != 0) return -1;
+extern "C" int64_t marlhip_gru_ac_workspace_bytes(const marlhip_net_shape* s, int32_t centralised, int32_t max_len, int32_t batch) {
+    if (gru_ac_check(s, centralised) != 0) return -1;
+    if (centralised) {
+#define X(p, d, h) \
+    if (s->n_agents == p && s->obs_dim == d && s->hidden == h) return ac_ws_layout<GruShape<d, h, 6>, GruShape<p * d, h, 1>>(s->n_agents, max_len, batch).total;
+        MARL_GRU_MAC_SHAPES(X)
+#undef X
+    }
 #define X(d, h, a) \
     if (s->obs_dim == d && s->hidden == h && s->n_actions == a) return ac_ws_layout<GruShape<d, h, a>, GruShape<d, h, 1>>(s->n_agents, max_len, batch).total;
     MARL_GRU_AC_SHAPES(X)
@@ -40,13 +62,23 @@ extern "C" int64_t marlhip_gru_ac_workspace_bytes(const marlhip_net_shape* s, in
 static int gru_ac_call(const marlhip_net_shape* s, const float* actor, const float* critic, const float* target, const marlhip_batch* bt,
                        const marlhip_ac_config* c, int mode, void* ws, int64_t ws_bytes, float* actor_grad, float* critic_grad, float* metrics,
                        void* stream) {
-    if (gru_ac_check(s) != 0) return -1;
-    MARL_REQUIRE(actor && critic && bt && c && ws, "gru_ac_loss_grad: NULL pointer");
-    MARL_REQUIRE(!c->centralised_critic, "recurrent actor-critic networks: centralised critics are not built");
+    MARL_REQUIRE(c != nullptr, "gru_ac_loss_grad: NULL config");
+    if (gru_ac_check(s, c->centralised_critic) != 0) return -1;
+    MARL_REQUIRE(actor && critic && bt && ws, "gru_ac_loss_grad: NULL pointer");
     MARL_REQUIRE(mode == 1 || (actor_grad && critic_grad && metrics), "gru_ac_loss_grad: NULL output");
     MARL_REQUIRE(mode == 2 || target != nullptr, "gru_ac_loss_grad: NULL target critic");
     MARL_REQUIRE(bt->obss && bt->actions && bt->rewards && bt->dones && bt->filled, "gru_ac_loss_grad: NULL batch field");
     MARL_REQUIRE(c->n_steps >= 1 && c->n_steps <= 16, "gru_ac_loss_grad: n_steps %d (1..16)", c->n_steps);
+    if (c->centralised_critic) {
+        MARL_REQUIRE(bt->obs_agent_stride == s->obs_dim && bt->obs_row_stride == (int64_t)s->n_agents * s->obs_dim,
+                     "gru_ac_loss_grad: a centralised critic needs the ac/train.py Batch layout (agents concatenated in a row)");
+#define X(p, d, h)                                                                                                                       \
+    if (s->n_agents == p && s->obs_dim == d && s->hidden == h)                                                                           \
+        return ac_step_t<GruShape<d, h, 6>, GruShape<p * d, h, 1>>(s->n_agents, agent_map(s), actor, critic, target, bt, c, mode, ws, ws_bytes, actor_grad, \
+                                                                   critic_grad, metrics, (hipStream_t)stream);
+        MARL_GRU_MAC_SHAPES(X)
+#undef X
+    }
 #define X(d, h, a)                                                                                                                   \
     if (s->obs_dim == d && s->hidden == h && s->n_actions == a)                                                                      \
         return ac_step_t<GruShape<d, h, a>, GruShape<d, h, 1>>(s->n_agents, agent_map(s), actor, critic, target, bt, c, mode, ws, ws_bytes, actor_grad, \
@@ -77,7 +109,7 @@ extern "C" int marlhip_gru_ppo_loss_grad(const marlhip_net_shape* s, const float
 // state carried by the caller (A2CNetwork.act / get_value, ac/model.py:147-163); obs rows at obs + p * agent_stride + (t * B + b) * row_stride
 extern "C" int marlhip_gru_ac_forward(const marlhip_net_shape* s, int32_t value_net, const float* params, const float* obs, int64_t agent_stride,
                                       int64_t row_stride, int32_t steps, int32_t batch, const float* h_in, float* h_out, float* out, void* stream) {
-    if (gru_ac_check(s) != 0) return -1;
+    if (gru_ac_check(s, value_net == 2) != 0) return -1;
     MARL_REQUIRE(params && obs && out && steps > 0 && batch > 0 && row_stride > 0 && agent_stride >= 0, "gru_ac_forward: bad argument");
     const hipStream_t st = (hipStream_t)stream;
     const int P = s->n_agents;
@@ -92,6 +124,11 @@ extern "C" int marlhip_gru_ac_forward(const marlhip_net_shape* s, int32_t value_
         MARL_CHECK_LAUNCH("gru_seq_fwd_kernel (ac forward)");
         return 0;
     };
+    if (value_net == 2) {  // centralised critic: every agent's critic reads the same P * D row (agent_stride 0)
+#define X(p, d, h) if (s->n_agents == p && s->obs_dim == d && s->hidden == h) return run(GruShape<p * d, h, 1>{});
+        MARL_GRU_MAC_SHAPES(X)
+#undef X
+    }
 #define X(d, h, a)                                                 \
     if (s->obs_dim == d && s->hidden == h && s->n_actions == a) {  \
         if (value_net) return run(GruShape<d, h, 1>{});            \

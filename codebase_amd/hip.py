@@ -432,8 +432,6 @@ class AcUpdater:
                  centralised_critic=False, recurrent=False):
         _require_gpu()
         self.recurrent = bool(recurrent)  # use_rnn actors and critics: the marlhip_gru_* entry points, recurrent block layout
-        if self.recurrent and centralised_critic:
-            raise NotImplementedError("recurrent actor-critic networks: centralised critics are not built")
         self._fn = ((lib.marlhip_gru_a2c_loss_grad, lib.marlhip_gru_ppo_prepare, lib.marlhip_gru_ppo_loss_grad) if self.recurrent else
                     (lib.marlhip_a2c_loss_grad, lib.marlhip_ppo_prepare, lib.marlhip_ppo_loss_grad))
         self.centralised = int(bool(centralised_critic))
@@ -442,7 +440,7 @@ class AcUpdater:
         self.spec = spec
         if self.recurrent:
             self.n_actor = check(lib.marlhip_gru_nparams(ctypes.byref(s)), "gru_nparams")
-            self.n_critic = check(lib.marlhip_gru_ac_critic_nparams(ctypes.byref(s)), "gru_ac_critic_nparams")
+            self.n_critic = check(lib.marlhip_gru_ac_critic_nparams(ctypes.byref(s), int(bool(centralised_critic))), "gru_ac_critic_nparams")
         else:
             self.n_actor = spec.nparams()
             self.n_critic = check(lib.marlhip_ac_critic_nparams(ctypes.byref(s), self.centralised), "ac_critic_nparams")
@@ -472,7 +470,7 @@ class AcUpdater:
         if (T, B) not in self._ws:
             s = self.spec.c()
             if self.recurrent:
-                n = check(lib.marlhip_gru_ac_workspace_bytes(ctypes.byref(s), T, B), "gru_ac_workspace_bytes")
+                n = check(lib.marlhip_gru_ac_workspace_bytes(ctypes.byref(s), self.centralised, T, B), "gru_ac_workspace_bytes")
             else:
                 n = check(lib.marlhip_ac_workspace_bytes(ctypes.byref(s), self.centralised, T, B), "ac_workspace_bytes")
             self._ws[(T, B)] = torch.empty(int(n), dtype=torch.uint8, device=self.block.device)
@@ -681,7 +679,7 @@ def gru_ac_forward(spec: NetSpec, params, obs, agent_stride, row_stride, steps, 
     out = torch.empty(P, steps, batch, 1 if value_net else spec.n_actions, device=params.device)
     h_out = torch.empty(P, batch, spec.hidden, device=params.device) if want_h else None
     s = spec.c()
-    check(lib.marlhip_gru_ac_forward(ctypes.byref(s), int(bool(value_net)), _ptr(params), _ptr(obs), int(agent_stride), int(row_stride), int(steps),
+    check(lib.marlhip_gru_ac_forward(ctypes.byref(s), int(value_net), _ptr(params), _ptr(obs), int(agent_stride), int(row_stride), int(steps),
                                      int(batch), _ptr(h_in), _ptr(h_out), _ptr(out), _stream()), "gru_ac_forward")
     return (out, h_out) if want_h else out
 

@@ -338,10 +338,10 @@ int marlhip_gru_qmix_loss_grad(const marlhip_net_shape* s, const float* params, 
 
 /* Actor-critic learner step with recurrent networks (`use_rnn: True` for actor and critic; ia2c.yaml / ippo.yaml): same contracts as
  * marlhip_a2c_loss_grad / marlhip_ppo_prepare / marlhip_ppo_loss_grad, the blocks in the recurrent layout (marlhip_gru_nparams for the
- * actors, marlhip_gru_ac_critic_nparams for the critics); independent networks and critics only.  marlhip_gru_ac_forward: sequence
- * forward of the actors (value_net = 0) or critics (1) with the hidden state carried by the caller (A2CNetwork.act / get_value). */
-int marlhip_gru_ac_critic_nparams(const marlhip_net_shape* s);
-int64_t marlhip_gru_ac_workspace_bytes(const marlhip_net_shape* s, int32_t max_len, int32_t batch);
+ * actors, marlhip_gru_ac_critic_nparams for the critics; cfg->centralised_critic as there).  marlhip_gru_ac_forward: sequence forward of
+ * the actors (value_net = 0), critics (1) or centralised critics (2, agent_stride 0) with the hidden state carried by the caller (A2CNetwork.act / get_value). */
+int marlhip_gru_ac_critic_nparams(const marlhip_net_shape* s, int32_t centralised);
+int64_t marlhip_gru_ac_workspace_bytes(const marlhip_net_shape* s, int32_t centralised, int32_t max_len, int32_t batch);
 int marlhip_gru_a2c_loss_grad(const marlhip_net_shape* s, const float* actor, const float* critic, const float* target_critic,
                               const marlhip_batch* batch, const struct marlhip_ac_config* cfg, void* workspace, int64_t workspace_bytes,
                               float* actor_grad, float* critic_grad, float* metrics /* [5] */, void* stream);

@@ -104,3 +104,5 @@ if __name__ == "__main__":
     # recurrent actors and critics (use_rnn: RNNNetwork, utils/models.py:51-116)
     fixture(ram, rat, "learner_a2c_gru_H64.npz", ram.A2CNetwork, P=2, D=15, H=64, N=12, seed=1500, use_rnn=True)
     fixture(ram, rat, "learner_ppo_gru_H128.npz", ram.PPONetwork, P=2, D=15, H=128, N=10, seed=1600, use_rnn=True)
+    fixture(ram, rat, "learner_maa2c_gru_H64.npz", ram.A2CNetwork, P=2, D=15, H=64, N=11, seed=1700, use_rnn=True, centralised=True)
+    fixture(ram, rat, "learner_mappo_gru_p3_H64.npz", ram.PPONetwork, P=3, D=18, H=64, N=9, seed=1800, use_rnn=True, centralised=True)
