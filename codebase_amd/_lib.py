@@ -111,6 +111,8 @@ PROTOTYPES = {
     "marlhip_gru_workspace_bytes": (c_int64, [POINTER(NetShape), c_int32, c_int32]),
     "marlhip_gru_loss_grad": (c_int32, [POINTER(NetShape), c_void_p, c_void_p, POINTER(BatchStruct), c_float, c_int32, c_int32, c_void_p,
                                         c_int64, c_void_p, c_void_p, c_void_p]),
+    "marlhip_gru_loss_grad_std": (c_int32, [POINTER(NetShape), c_void_p, c_void_p, POINTER(BatchStruct), c_float, c_int32, POINTER(RetStatsStruct),
+                                            c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "marlhip_gru_qmix_workspace_bytes": (c_int64, [POINTER(NetShape), c_int32, c_int32]),
     "marlhip_gru_qmix_loss_grad": (c_int32, [POINTER(NetShape), c_void_p, c_void_p, POINTER(QmixMixer), POINTER(BatchStruct), c_float, c_int32,
                                              c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),

@@ -64,6 +64,48 @@ extern "C" int marlhip_gru_forward(const marlhip_net_shape* s, const float* para
     return -1;
 }
 
+// chosen_p = Q_p(o_t)[a_t], bootstrap_p = target Q_p(o_{t+1})[argmax] (QMixNetwork._compute_loss, dqn/model.py:384-410), and the
+// transition's scalars in the [R] = [T * B] layout the mixer kernels read
+static __global__ __launch_bounds__(256) void gru_qsel_kernel(int P, int T, int B, int A, const float* __restrict__ q, const float* __restrict__ tq,
+                                                       marlhip_batch bt, int double_q, float* __restrict__ chosen, float* __restrict__ tqsel,
+                                                       float* __restrict__ r0, float* __restrict__ dn, float* __restrict__ fl) {
+    const int i = blockIdx.x * 256 + threadIdx.x, R = T * B;
+    if (i >= R) return;
+    const int t = i / B, b = i - t * B;
+    for (int p = 0; p < P; ++p) {
+        const float* qn = q + (((size_t)p * (T + 1) + t + 1) * B + b) * A;
+        const float* tn = tq + (((size_t)p * (T + 1) + t + 1) * B + b) * A;
+        const float* mk = bt.action_mask ? bt.action_mask + (((size_t)p * (T + 1) + t + 1) * B + b) * A : nullptr;
+        int best = 0;
+        float bv = -__builtin_huge_valf();
+        for (int a = 0; a < A; ++a) {
+            float v = double_q ? qn[a] : tn[a];
+            if (mk != nullptr && mk[a] == 0.f) v = -1e8f;
+            if (v > bv) { bv = v; best = a; }
+        }
+        float boot = tn[best];
+        if (mk != nullptr && mk[best] == 0.f) boot = -1e8f;
+        tqsel[(size_t)p * R + i] = boot;
+        chosen[(size_t)p * R + i] = q[(((size_t)p * (T + 1) + t) * B + b) * A + (int)bt.actions[((size_t)p * T + t) * B + b]];
+    }
+    r0[i] = bt.rewards[i];  // batch.rewards[0] (model.py:379)
+    dn[i] = bt.dones[(size_t)(t + 1) * B + b];
+    fl[i] = bt.filled[i];
+}
+
+// dL/dchosen_p [P][R] from the mixer -> dense dL/dq rows [P][T+1][B][A] (row T was zeroed)
+static __global__ __launch_bounds__(256) void gru_expand_dq_kernel(int P, int T, int B, int A, const float* __restrict__ dqm, marlhip_batch bt,
+                                                            float* __restrict__ dq) {
+    const int i = blockIdx.x * 256 + threadIdx.x, R = T * B;
+    if (i >= R) return;
+    const int t = i / B, b = i - t * B;
+    for (int p = 0; p < P; ++p) {
+        const int act = (int)bt.actions[((size_t)p * T + t) * B + b];
+        const float v = dqm[(size_t)p * R + i];
+        for (int a = 0; a < A; ++a) dq[(((size_t)p * (T + 1) + t) * B + b) * A + a] = a == act ? v : 0.f;
+    }
+}
+
 // ---- learner step: QNetwork._compute_loss / VDNetwork._compute_loss + backward with recurrent networks ----------------------
 namespace {
 struct GruWs {
@@ -96,7 +138,7 @@ GruWs gru_ws_layout(int P, int T, int B) {
 
 template <class S>
 int gru_loss_grad(const marlhip_net_shape* s, const float* params, const float* target, const marlhip_batch* bt, float gamma, int double_q,
-                  int mode, void* ws, int64_t ws_bytes, float* grad, float* loss, hipStream_t st) {
+                  int mode, void* ws, int64_t ws_bytes, float* grad, float* loss, hipStream_t st, const RetStats* rst = nullptr) {
     using Bk = GruBwd<S>;
     const int P = s->n_agents, T = bt->max_len, B = bt->batch, steps = T + 1;
     const GruWs wl = gru_ws_layout<S>(P, T, B);
@@ -125,8 +167,29 @@ int gru_loss_grad(const marlhip_net_shape* s, const float* params, const float* 
                        (const float*)nullptr, (float*)nullptr, f(wl.tq), (float*)nullptr);
     MARL_CHECK_LAUNCH("gru_seq_fwd_kernel");
     (void)hipMemsetAsync(f(wl.dq), 0, (size_t)P * steps * B * S::A * sizeof(float), st);
-    hipLaunchKernelGGL(gru_td_kernel, dim3((T * B + 255) / 256), dim3(256), 0, st, P, T, B, S::A, (const float*)f(wl.q), (const float*)f(wl.tq), *bt,
-                       gamma, double_q, mode == 1 ? 1 : 0, f(wl.dq), f(wl.lrow));
+    if (rst != nullptr) {
+        // standardise_returns (dqn/model.py:146-158): chosen / bootstrap values -> the standardising mixer of the feed-forward path
+        // (returns from the de-standardised bootstrap, running statistics update, dL/dchosen) -> dense rows.  The scratch arrays
+        // borrow the backward record's space, which is written only afterwards.
+        const int64_t R = (int64_t)T * B;
+        float* chosen = f(wl.rec2);
+        float* tqsel = chosen + P * R;
+        float* dqm = tqsel + P * R;
+        float* r0 = dqm + P * R;
+        float* dn = r0 + R;
+        float* fl = dn + R;
+        float* partial = fl + R;
+        MARL_REQUIRE((3 * P + 3) * R + 2 * P * ((R + 255) / 256) <= (int64_t)P * steps * ((B + 15) / 16) * Bk::REC2, "gru_loss_grad: scratch");
+        const dim3 gridR((unsigned)((R + 255) / 256));
+        hipLaunchKernelGGL(gru_qsel_kernel, gridR, dim3(256), 0, st, P, T, B, S::A, (const float*)f(wl.q), (const float*)f(wl.tq), *bt, double_q, chosen,
+                           tqsel, r0, dn, fl);
+        const int rc = launch_std_mixer(P, (int)R, gamma, *rst, chosen, tqsel, bt->rewards, dn, fl, dqm, f(wl.lrow), partial, st);
+        if (rc != 0) return rc;
+        hipLaunchKernelGGL(gru_expand_dq_kernel, gridR, dim3(256), 0, st, P, T, B, S::A, (const float*)dqm, *bt, f(wl.dq));
+    } else {
+        hipLaunchKernelGGL(gru_td_kernel, dim3((T * B + 255) / 256), dim3(256), 0, st, P, T, B, S::A, (const float*)f(wl.q), (const float*)f(wl.tq), *bt,
+                           gamma, double_q, mode == 1 ? 1 : 0, f(wl.dq), f(wl.lrow));
+    }
     MARL_CHECK_LAUNCH("gru_td_kernel");
     hipLaunchKernelGGL((gru_seq_bwd_kernel<S>), gridS, dim3(256), ldsB, st, (const float*)f(wl.packB), steps, B, (const float*)f(wl.rec),
                        (const float*)f(wl.dq), f(wl.rec2));
@@ -200,48 +263,6 @@ namespace marl {
 int qmix_mix_stage(const marlhip_net_shape* s, const QmixCtx* qx, const marlhip_batch* bt, const QmixIo* io, float gamma, int phase,
                    const float* loss, hipStream_t stream);
 int64_t qmix_mixer_ws_bytes(const marlhip_net_shape* s, int32_t max_len, int32_t batch);
-}
-
-// chosen_p = Q_p(o_t)[a_t], bootstrap_p = target Q_p(o_{t+1})[argmax] (QMixNetwork._compute_loss, dqn/model.py:384-410), and the
-// transition's scalars in the [R] = [T * B] layout the mixer kernels read
-static __global__ __launch_bounds__(256) void gru_qsel_kernel(int P, int T, int B, int A, const float* __restrict__ q, const float* __restrict__ tq,
-                                                       marlhip_batch bt, int double_q, float* __restrict__ chosen, float* __restrict__ tqsel,
-                                                       float* __restrict__ r0, float* __restrict__ dn, float* __restrict__ fl) {
-    const int i = blockIdx.x * 256 + threadIdx.x, R = T * B;
-    if (i >= R) return;
-    const int t = i / B, b = i - t * B;
-    for (int p = 0; p < P; ++p) {
-        const float* qn = q + (((size_t)p * (T + 1) + t + 1) * B + b) * A;
-        const float* tn = tq + (((size_t)p * (T + 1) + t + 1) * B + b) * A;
-        const float* mk = bt.action_mask ? bt.action_mask + (((size_t)p * (T + 1) + t + 1) * B + b) * A : nullptr;
-        int best = 0;
-        float bv = -__builtin_huge_valf();
-        for (int a = 0; a < A; ++a) {
-            float v = double_q ? qn[a] : tn[a];
-            if (mk != nullptr && mk[a] == 0.f) v = -1e8f;
-            if (v > bv) { bv = v; best = a; }
-        }
-        float boot = tn[best];
-        if (mk != nullptr && mk[best] == 0.f) boot = -1e8f;
-        tqsel[(size_t)p * R + i] = boot;
-        chosen[(size_t)p * R + i] = q[(((size_t)p * (T + 1) + t) * B + b) * A + (int)bt.actions[((size_t)p * T + t) * B + b]];
-    }
-    r0[i] = bt.rewards[i];  // batch.rewards[0] (model.py:379)
-    dn[i] = bt.dones[(size_t)(t + 1) * B + b];
-    fl[i] = bt.filled[i];
-}
-
-// dL/dchosen_p [P][R] from the mixer -> dense dL/dq rows [P][T+1][B][A] (row T was zeroed)
-static __global__ __launch_bounds__(256) void gru_expand_dq_kernel(int P, int T, int B, int A, const float* __restrict__ dqm, marlhip_batch bt,
-                                                            float* __restrict__ dq) {
-    const int i = blockIdx.x * 256 + threadIdx.x, R = T * B;
-    if (i >= R) return;
-    const int t = i / B, b = i - t * B;
-    for (int p = 0; p < P; ++p) {
-        const int act = (int)bt.actions[((size_t)p * T + t) * B + b];
-        const float v = dqm[(size_t)p * R + i];
-        for (int a = 0; a < A; ++a) dq[(((size_t)p * (T + 1) + t) * B + b) * A + a] = a == act ? v : 0.f;
-    }
 }
 
 namespace {
@@ -327,6 +348,24 @@ extern "C" int marlhip_gru_qmix_loss_grad(const marlhip_net_shape* s, const floa
     if (s->obs_dim == d && s->hidden == h && s->n_actions == a)  \
         return gru_qmix_loss_grad<GruShape<d, h, a>>(s, params, target_params, mixer, batch, gamma, double_q, workspace, workspace_bytes, grad, loss, \
                                                      (hipStream_t)stream);
+    MARL_GRU_SHAPES(X)
+#undef X
+    return -1;
+}
+
+extern "C" int marlhip_gru_loss_grad_std(const marlhip_net_shape* s, const float* params, const float* target_params, const marlhip_batch* batch,
+                                         float gamma, int32_t double_q, const marlhip_ret_stats* stats, void* workspace, int64_t workspace_bytes,
+                                         float* grad, float* loss, void* stream) {
+    if (gru_check(s) != 0) return -1;
+    MARL_REQUIRE(params && target_params && batch && workspace && grad && loss && stats && stats->mean && stats->var && stats->count,
+                 "gru_loss_grad_std: NULL pointer");
+    MARL_REQUIRE(batch->obs_agent_stride == 0 && batch->obs_row_stride == 0, "gru_loss_grad_std: the dqn/train.py Batch layout only");
+    RetStats rst;
+    rst.mean = stats->mean; rst.var = stats->var; rst.count = stats->count;
+#define X(d, h, a)                                               \
+    if (s->obs_dim == d && s->hidden == h && s->n_actions == a)  \
+        return gru_loss_grad<GruShape<d, h, a>>(s, params, target_params, batch, gamma, double_q, 0, workspace, workspace_bytes, grad, loss, \
+                                                (hipStream_t)stream, &rst);
     MARL_GRU_SHAPES(X)
 #undef X
     return -1;

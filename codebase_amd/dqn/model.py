@@ -137,8 +137,6 @@ class QNetwork:
         self.sharing = sharing_indices(parameter_sharing, self.n_agents)
         self.spec = _hip.NetSpec(self.n_agents, obs_dims[0], hidden[0], act_dims[0], self.sharing)
         if self.recurrent:  # RNNNetwork (utils/models.py:51-116): Linear -> ReLU -> GRU -> Linear
-            if self.standardise_returns:
-                raise NotImplementedError("use_rnn is built without standardise_returns")
             self.nparams = _hip.gru_nparams(self.spec)
             critic, target = init_flat_gru_params(obs_dims, hidden[0], act_dims, use_orthogonal_init, self.sharing)
         else:

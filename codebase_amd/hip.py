@@ -622,8 +622,21 @@ class GruUpdater(DqnUpdater):
     """DqnUpdater for the recurrent networks: same buffers / clip+Adam / target update, marlhip_gru_loss_grad for the step."""
 
     def loss_grad(self, batch, mode=0):
-        if self.ret_stats is not None:
-            raise NotImplementedError("standardise_returns is not built for recurrent networks")
+        if self.ret_stats is not None:  # standardise_returns: the independent learner only (as for feed-forward networks)
+            if mode != 0:
+                raise NotImplementedError("standardise_returns is built for independent learners (IDQN) only")
+            T, B = batch.filled.shape
+            s, st = self.spec.c(), self.ret_stats.c()
+            n = check(lib.marlhip_gru_workspace_bytes(ctypes.byref(s), T, B), "gru_workspace_bytes")
+            if self._ws.get("gru_std_n") != n:
+                self._ws = {"gru_std_n": n, "buf": torch.empty(n, dtype=torch.uint8, device=self.params.device)}
+            ws = self._ws["buf"]
+            bs = BatchStruct(batch.obss.data_ptr(), batch.actions.data_ptr(), batch.rewards.data_ptr(), batch.dones.data_ptr(),
+                             batch.filled.data_ptr(), T, B, 0, 0, 0, 0, _mask_ptr(batch.action_mask, (self.spec.n_agents, T + 1, B, self.spec.n_actions)))
+            check(lib.marlhip_gru_loss_grad_std(ctypes.byref(s), _ptr(self.params), _ptr(self.target), ctypes.byref(bs), float(self.gamma),
+                                                self.double_q, ctypes.byref(st), _ptr(ws), ws.numel(), _ptr(self.grad), _ptr(self.loss), _stream()),
+                  "gru_loss_grad_std")
+            return self.loss, self.grad
         return gru_loss_grad(self.spec, self.params, self.target, batch, gamma=self.gamma, double_q=self.double_q, mode=mode,
                              grad=self.grad, loss=self.loss)
 

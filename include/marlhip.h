@@ -328,6 +328,11 @@ int marlhip_gru_loss_grad(const marlhip_net_shape* s, const float* params, const
                           float gamma, int32_t double_q, int32_t mode, void* workspace, int64_t workspace_bytes, float* grad,
                           float* loss /* [2] */, void* stream);
 
+/* the recurrent independent learner with standardise_returns (dqn/model.py:146-158; statistics as marlhip_dqn_loss_grad_std) */
+int marlhip_gru_loss_grad_std(const marlhip_net_shape* s, const float* params, const float* target_params, const marlhip_batch* batch,
+                              float gamma, int32_t double_q, const struct marlhip_ret_stats* stats, void* workspace,
+                              int64_t workspace_bytes, float* grad, float* loss /* [2] */, void* stream);
+
 /* QMixNetwork._compute_loss + backward with recurrent agent networks: the sequence kernels above for the agents, the mixer stage
  * of marlhip_qmix_loss_grad (same kernels, same mixer block layout) between them.  grad: agents' blocks; mixer->mixer_grad: the
  * mixer's; loss[2] as everywhere. */

@@ -113,3 +113,5 @@ if __name__ == "__main__":
     qmix_fixture(rm, rt, "learner_gru_qmix_H64.npz", P=2, D=15, H=64, B=19, seed=2300)
 # learner_gru_shared_H64.npz / learner_gru_seps_vdn_H128.npz (parameter_sharing=True / [0, 0, 1] with use_rnn=True) were produced by the
 # same recipe on MultiAgentSharedNetwork: blocks [K][n] in `critic.networks` order, loss, gradient, 2 updates, state_dict keys.
+# learner_gru_std_H64.npz: QNetwork(use_rnn=True, standardise_returns=True), 3 x update() on 3 batches: losses, parameters and the
+# RunningMeanStd (mean, var, count) after each (same recipe as oracle/make_golden_std.py).

@@ -365,3 +365,26 @@ def test_recurrent_networks_with_parameter_sharing_match_reference(name, mode):
     b = Batch(*(batch[k] for k in ("obss", "actions", "rewards", "dones", "filled")), None)
     np.testing.assert_allclose([net.update(b)["loss"] for _ in range(2)], g["losses"], rtol=5e-5)
     np.testing.assert_allclose(net.params.cpu().numpy(), g["params2"], rtol=0, atol=5e-6)
+
+
+@pytest.mark.gpu
+def test_recurrent_idqn_with_standardise_returns_matches_reference():
+    from codebase_amd.dqn.model import QNetwork
+    from codebase_amd.hip import Batch
+    from codebase_amd.spaces import Box, Discrete, Tuple
+
+    g = dict(np.load(os.path.join(G, "learner_gru_std_H64.npz")))
+    P, D, H, A = int(g["P"]), int(g["D"]), int(g["H"]), int(g["A"])
+    hyper = dict(optimizer="Adam", lr=3e-4, gamma=0.99, grad_clip=1.0, double_q=True, standardise_returns=True,
+                 target_update_interval_or_tau=200)
+    net = QNetwork(Tuple([Box(-1, 8, (D,))] * P), Tuple([Discrete(A)] * P), hyper, [H, H], False, True, True, "cuda")
+    net.params.copy_(torch.tensor(g["params0"]))
+    net.target_params.copy_(torch.tensor(g["target0"]))
+    for i in range(3):
+        b = Batch(*(torch.tensor(g[f"batch{i}_{k}"]) for k in ("obss", "actions", "rewards", "dones", "filled")), None)
+        loss = net.update(b)["loss"]
+        assert abs(loss - g["losses"][i]) <= 5e-5 * abs(g["losses"][i])
+        np.testing.assert_allclose(net.ret_ms.mean.cpu().numpy(), g[f"ret_mean{i + 1}"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(net.ret_ms.var.cpu().numpy(), g[f"ret_var{i + 1}"], rtol=1e-5, atol=1e-6)
+        assert abs(net.ret_ms.count - float(g[f"ret_count{i + 1}"])) < 1e-6
+        np.testing.assert_allclose(net.params.cpu().numpy(), g[f"params{i + 1}"], rtol=0, atol=5e-6)
