@@ -122,7 +122,7 @@ def bench_ac(args, rank, world, dist):
     obs_space, act_space = _space_pair(cfg)
     hyper = dict(optimizer="Adam", lr=3e-4, gamma=0.99, grad_clip=False, n_steps=5, entropy_coef=0.001, value_loss_coef=0.5,
                  standardise_returns=False, target_update_interval_or_tau=200, num_epochs=4, ppo_clip=0.2)  # ia2c.yaml / ippo.yaml
-    net = dict(layers=[H, H], parameter_sharing=False, use_orthogonal_init=True, use_rnn=False)
+    net = dict(layers=[H, H], parameter_sharing=False, use_orthogonal_init=True, use_rnn=bool(args.rnn))
     central = args.algo in ("maa2c", "mappo")  # critic.centralised (maa2c.yaml / mappo.yaml)
     model = (PPONetwork if args.algo in ("ippo", "mappo") else A2CNetwork)(obs_space, act_space, hyper, net,
                                                                            dict(net, centralised=central), "cuda")
@@ -141,7 +141,21 @@ def bench_ac(args, rank, world, dist):
     sync_grad = GradSync(dist) if dist is not None else None
     state = {"round": 0, "step": 0}
 
+    if args.rnn:  # recurrent actors: the rollout runs through the modular entry points (hidden state carried between steps)
+        from codebase_amd.ac.train import _collect_trajectories_recurrent
+        from codebase_amd.utils.envs import HipForagingVecEnv
+
+        vec = HipForagingVecEnv(cfg)
+
     def one_round():
+        if args.rnn:
+            tmax, batch, _, _ = _collect_trajectories_recurrent(vec, model, T, False, state["round"])
+            model.update_async(batch._replace(dones=batch.dones.float()), state["step"], grad_sync=sync_grad, world=world)
+            steps_dev.add_(batch.filled.sum().to(torch.int64))
+            ref_steps.add_(tmax * N)
+            state["round"] += 1
+            state["step"] += T * N
+            return
         h.ac_collect(cfg, model.spec, model.actor_params, state["round"], T, False, b_obs, b_act, b_rew, b_done, b_fill, fin_ret,
                      fin_len, t_max)
         b_donef.copy_(b_done)  # batch.dones.float() (ac/model.py:198)
@@ -202,8 +216,8 @@ def bench_ac(args, rank, world, dist):
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic (Philox-seeded env layouts, orthogonal-init weights)",
-        "config": {"workload": f"{args.algo.upper()} on {name}, {N} batched HIP envs per GPU, actor/critic 2-layer-{H} MLPs, "
-                               f"time_limit {T}, one update per rollout", "envs_per_gpu": N, "env_steps_timed": env_steps,
+        "config": {"workload": f"{args.algo.upper()} on {name}, {N} batched HIP envs per GPU, actor/critic " + (f"GRU-{H} networks (use_rnn), " if args.rnn else f"2-layer-{H} MLPs, ")
+                               + f"time_limit {T}, one update per rollout", "envs_per_gpu": N, "env_steps_timed": env_steps,
                    "reference_step_counter": int(ref_steps.item()),
                    "parallelism": f"dp{world} (envs sharded per GPU, RCCL grad all-reduce per update)" if world > 1 else "1 GPU"},
         "kernels": timing, "roofline": roofline,
@@ -263,7 +277,7 @@ def main():
     from codebase_amd.dqn.model import QMixNetwork, VDNetwork
 
     if args.algo == "qmix":  # marlbase/configs/algorithm/qmix.yaml:14-17
-        model = QMixNetwork(obs_space, act_space, hyper, [H, H], False, False, True,
+        model = QMixNetwork(obs_space, act_space, hyper, [H, H], False, bool(args.rnn), True,
                             dict(embed_dim=64, hypernet_layers=2, hypernet_embed=32), "cuda")
     else:
         model = (VDNetwork if args.algo == "vdn" else QNetwork)(obs_space, act_space, hyper, [H, H], False, bool(args.rnn), True, "cuda")
