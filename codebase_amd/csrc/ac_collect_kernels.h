@@ -43,7 +43,6 @@ __device__ __forceinline__ int sample_rows(const f4& logits, int lane, float u) 
         sum += e[a];
     }
     const float thr = u * sum;
-    float c = 0.f;
     int act = A - 1;
 #pragma unroll
     for (int a = A - 1; a >= 0; --a) {  // first a with cumsum(e)[a] > thr
@@ -52,7 +51,6 @@ __device__ __forceinline__ int sample_rows(const f4& logits, int lane, float u) 
         for (int b = 0; b <= a; ++b) ca += e[b];
         if (ca > thr) act = a;
     }
-    (void)c;
     return act;
 }
 

@@ -152,14 +152,12 @@ static __global__ __launch_bounds__(256) void sample_logits_kernel(int P, int N,
         float sum = 0.f;
         for (int a = 0; a < A; ++a) sum += expf(l[a] - m);
         const float thr = u01_f32(act_noise_word(seed, (uint32_t)n, episode[n], (uint32_t)t, 1 + p)) * sum;
-        float c = 0.f;
         int act = A - 1;
         for (int a = A - 1; a >= 0; --a) {  // first a with cumsum(e)[a] > thr (cumsums formed front to back)
             float ca = 0.f;
             for (int b = 0; b <= a; ++b) ca += expf(l[b] - m);
             if (ca > thr) act = a;
         }
-        (void)c;
         actions[(size_t)p * N + n] = act;
     }
 }
