@@ -8,7 +8,8 @@ using namespace marl;
 // (obs dim, hidden, actions): the LBF widths and the warehouse, hidden 64 and 128; critics are the same template with one output
 #define MARL_GRU_AC_SHAPES(X)                                                                                \
     X(12, 64, 6) X(15, 64, 6) X(18, 64, 6) X(21, 64, 6) X(24, 64, 6) X(27, 64, 6) X(39, 64, 6) X(71, 64, 5) \
-    X(12, 128, 6) X(15, 128, 6) X(18, 128, 6) X(21, 128, 6) X(24, 128, 6) X(27, 128, 6) X(39, 128, 6) X(71, 128, 5)
+    X(12, 128, 6) X(15, 128, 6) X(18, 128, 6) X(21, 128, 6) X(24, 128, 6) X(27, 128, 6) X(39, 128, 6) X(71, 128, 5) \
+    X(14, 64, 6) X(17, 64, 6) X(25, 64, 6) X(31, 64, 6) X(47, 64, 6) X(14, 128, 6) X(17, 128, 6) X(25, 128, 6) X(31, 128, 6) X(47, 128, 6) /* env.observe_id */
 
 // (agents, obs dim, hidden) with a compiled recurrent CENTRALISED critic (P * D inputs, critic.centralised: maa2c / mappo with use_rnn)
 #define MARL_GRU_MAC_SHAPES(X) X(2, 12, 64) X(2, 15, 64) X(3, 18, 64) X(4, 21, 64) X(4, 27, 64) X(2, 12, 128) X(2, 15, 128) X(3, 18, 128) X(4, 21, 128) X(4, 27, 128)
