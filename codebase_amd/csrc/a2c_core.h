@@ -47,10 +47,12 @@ __global__ __launch_bounds__(256) void mlp_rows_fwd_kernel(const float* __restri
 }
 
 template <class S>
-int launch_forward_rows(int P, const AgentMap& am, const float* params, const marlhip_batch* bt, int n_rows, float* out, hipStream_t st) {
+int launch_forward_rows(int P, const AgentMap& am, const float* params, const marlhip_batch* bt, int n_rows, float* out, hipStream_t st,
+                        float* rec = nullptr) {
     if constexpr (IsGru<S>::value) {
-        return gru_forward_rows<S>(P, am, params, bt, n_rows / bt->batch, out, st);
+        return gru_forward_rows<S>(P, am, params, bt, n_rows / bt->batch, out, st, rec);
     } else {
+    (void)rec;
     const int T = bt->max_len, B = bt->batch;
     const size_t as = bt->obs_agent_stride > 0 ? (size_t)bt->obs_agent_stride : (bt->obs_agent_stride < 0 ? 0 : (size_t)(T + 1) * B * S::D);
     const size_t rs = bt->obs_row_stride ? (size_t)bt->obs_row_stride : (size_t)S::D;
@@ -78,7 +80,7 @@ int launch_forward_rows(int P, const AgentMap& am, const float* params, const ma
 template <class S>
 int64_t backward_ws_bytes(int P, int T, int B) {
     if constexpr (IsGru<S>::value) {
-        return gru_rows_ws<S>(P, T, B).total;
+        return gru_rows_ws<S>(P, T, B, false).total;  // the step's forward passes write the records (AcWs::rec_a / rec_c)
     } else if constexpr (use_tp<S>()) {
         const UpdPlan pl = upd_plan_tp(P, T, B, S::D > 48 ? 1 : 2);
         return ws_layout(P, pl.nwg, S::NPARAM + 2, 0, T, B).total;
@@ -91,10 +93,12 @@ int64_t backward_ws_bytes(int P, int T, int B) {
 // grad[P][NPARAM] = d(sum_rows lrow-loss)/dparams / sum(filled) from dout[P][T][B][A]; loss[0] = sum(lrow)/sum(filled)
 template <class S>
 int launch_backward_rows(int P, const AgentMap& am, const float* params, const marlhip_batch* bt, const float* dout, float* lrow, void* ws,
-                         int64_t ws_bytes, float* grad, float* loss, hipStream_t st) {
+                         int64_t ws_bytes, float* grad, float* loss, hipStream_t st, const float* rec = nullptr) {
     if constexpr (IsGru<S>::value) {
-        return gru_backward_rows<S>(P, am, params, bt, bt->max_len, dout, lrow, ws, ws_bytes, grad, loss, st);
+        MARL_REQUIRE(rec != nullptr, "ac backward: the recurrent networks need the forward record");
+        return gru_backward_rows<S>(P, am, params, bt, bt->max_len, dout, lrow, ws, ws_bytes, grad, loss, st, rec);
     } else {
+    (void)rec;
     const int T = bt->max_len, B = bt->batch;
     MARL_REQUIRE(ws_bytes >= backward_ws_bytes<S>(P, T, B), "ac backward: workspace %lld too small", (long long)ws_bytes);
     ReplaySrc none = {};
@@ -302,7 +306,7 @@ static __global__ __launch_bounds__(1024) void ac_metrics_kernel(int nblocks, fl
 
 // workspace: [vnext | v | logits | dlogits | dv | lrow_a | lrow_v | ent | ret | oldlogp | loss scratch 4][backward workspace]
 struct AcWs {
-    int64_t vnext, v, logits, dlogits, dv, lrow_a, lrow_v, ent, ret, oldlogp, partial, rpartial, scratch, bwd, total;
+    int64_t vnext, v, logits, dlogits, dv, lrow_a, lrow_v, ent, ret, oldlogp, partial, rpartial, scratch, rec_a, rec_c, bwd, total;
 };
 
 template <class SA, class SC>
@@ -324,6 +328,9 @@ AcWs ac_ws_layout(int P, int T, int B) {
     w.partial = take(4 * ((TB + 255) / 256));
     w.rpartial = take(2 * P * ((TB + 255) / 256));
     w.scratch = take(8);
+    w.rec_a = w.rec_c = o;  // recurrent networks: the activation records of this step's actor / critic forward passes
+    if constexpr (IsGru<SA>::value) w.rec_a = take(gru_rec_floats<SA>(P, T, B));
+    if constexpr (IsGru<SC>::value) w.rec_c = take(gru_rec_floats<SC>(P, T, B));
     w.bwd = o;
     const int64_t ba = backward_ws_bytes<SA>(P, T, B), bc = backward_ws_bytes<SC>(P, T, B);
     w.total = o + (ba > bc ? ba : bc);
@@ -367,10 +374,12 @@ int ac_step_t(int P, const AgentMap& am, const float* actor, const float* critic
         hipLaunchKernelGGL(ret_stats_update_kernel, dim3(1), dim3(64), 0, st, w.st, (const float*)w.rpartial, (TB + 255) / 256, P, TB);
         a.mode = 3;
     }
-    rc = launch_forward_rows<SA>(P, am, actor, bt, TB, f(wl.logits), st);
+    float* rec_a = IsGru<SA>::value && mode != 1 ? f(wl.rec_a) : nullptr;
+    float* rec_c = IsGru<SC>::value ? f(wl.rec_c) : nullptr;
+    rc = launch_forward_rows<SA>(P, am, actor, bt, TB, f(wl.logits), st, rec_a);
     if (rc != 0) return rc;
     if (mode != 1) {
-        rc = launch_forward_rows<SC>(P, am, critic, bc, TB, f(wl.v), st);
+        rc = launch_forward_rows<SC>(P, am, critic, bc, TB, f(wl.v), st, rec_c);
         if (rc != 0) return rc;
     }
     hipLaunchKernelGGL(ac_elem_kernel, dim3((TB + 255) / 256), dim3(256), 0, st, a, *bt, w);
@@ -382,9 +391,9 @@ int ac_step_t(int P, const AgentMap& am, const float* actor, const float* critic
         return 0;
     }
     float* scratch = f(wl.scratch);
-    rc = launch_backward_rows<SA>(P, am, actor, bt, w.dlogits, w.lrow_a, base + wl.bwd, ws_bytes - wl.bwd, actor_grad, scratch, st);
+    rc = launch_backward_rows<SA>(P, am, actor, bt, w.dlogits, w.lrow_a, base + wl.bwd, ws_bytes - wl.bwd, actor_grad, scratch, st, rec_a);
     if (rc != 0) return rc;
-    rc = launch_backward_rows<SC>(P, am, critic, bc, w.dv, w.lrow_v, base + wl.bwd, ws_bytes - wl.bwd, critic_grad, scratch + 2, st);
+    rc = launch_backward_rows<SC>(P, am, critic, bc, w.dv, w.lrow_v, base + wl.bwd, ws_bytes - wl.bwd, critic_grad, scratch + 2, st, rec_c);
     if (rc != 0) return rc;
     hipLaunchKernelGGL(ac_metrics_kernel, dim3(1), dim3(1024), 0, st, (TB + 255) / 256, c->value_loss_coef, (const float*)w.partial,
                        metrics);

@@ -19,14 +19,15 @@ struct GruRowsWs {
     int nwg;
 };
 
+// own_rec: the backward also runs the recording forward; false when the caller's forward already wrote the record elsewhere
 template <class S>
-GruRowsWs gru_rows_ws(int P, int steps, int B) {
+GruRowsWs gru_rows_ws(int P, int steps, int B, bool own_rec = true) {
     const int64_t nblk = (B + 15) / 16;
     GruRowsWs w;
     int64_t off = 0;
     auto take = [&](int64_t floats) { const int64_t o = off; off += (floats * 4 + 255) / 256 * 256; return o; };
     w.q = take((int64_t)P * steps * B * S::A);
-    w.rec = take((int64_t)P * steps * nblk * S::REC);
+    w.rec = take(own_rec ? (int64_t)P * steps * nblk * S::REC : 0);
     w.rec2 = take((int64_t)P * steps * nblk * GruBwd<S>::REC2);
     const int64_t items = (int64_t)steps * nblk;
     const int cap = 256 / P > 1 ? 256 / P : 1;
@@ -56,9 +57,16 @@ void gru_set_attrs() {
     done = true;
 }
 
-// out[p][t][b][:] for t < steps, sequences from zero hidden states (`hiddens=None`, ac/model.py:191,206-207)
 template <class S>
-int gru_forward_rows(int P, const AgentMap& am, const float* params, const marlhip_batch* bt, int steps, float* out, hipStream_t st) {
+int64_t gru_rec_floats(int P, int steps, int B) {
+    return (int64_t)P * steps * ((B + 15) / 16) * S::REC;
+}
+
+// out[p][t][b][:] for t < steps, sequences from zero hidden states (`hiddens=None`, ac/model.py:191,206-207); rec (optional)
+// receives the activation record gru_backward_rows would otherwise recompute
+template <class S>
+int gru_forward_rows(int P, const AgentMap& am, const float* params, const marlhip_batch* bt, int steps, float* out, hipStream_t st,
+                     float* rec = nullptr) {
     float* packs = collect_pack_scratch((size_t)P * S::NFWD * sizeof(float), st);
     MARL_REQUIRE(packs != nullptr, "gru_forward_rows: cannot allocate the pack scratch");
     gru_set_attrs<S>();
@@ -66,7 +74,7 @@ int gru_forward_rows(int P, const AgentMap& am, const float* params, const marlh
     gru_obs_strides(bt, S::D, &as, &rs);
     hipLaunchKernelGGL((gru_pack_kernel<S>), dim3((S::NFWD + 255) / 256, P), dim3(256), 0, st, params, am, packs);
     hipLaunchKernelGGL((gru_seq_fwd_kernel<S>), dim3((bt->batch + 63) / 64, P), dim3(256), S::LDS_FLOATS * sizeof(float), st, (const float*)packs, bt->obss,
-                       as, rs, steps, bt->batch, (const float*)nullptr, (float*)nullptr, out, (float*)nullptr);
+                       as, rs, steps, bt->batch, (const float*)nullptr, (float*)nullptr, out, rec);
     MARL_CHECK_LAUNCH("gru_seq_fwd_kernel (rows)");
     return 0;
 }
@@ -74,25 +82,29 @@ int gru_forward_rows(int P, const AgentMap& am, const float* params, const marlh
 // grad[P][NPARAM] = d(sum of row losses)/dparams / sum(filled) from dout[P][steps][B][A]; loss[0] = sum(lrow)/sum(filled), loss[1] = sum(filled)
 template <class S>
 int gru_backward_rows(int P, const AgentMap& am, const float* params, const marlhip_batch* bt, int steps, const float* dout, const float* lrow,
-                      void* ws, int64_t ws_bytes, float* grad, float* loss, hipStream_t st) {
+                      void* ws, int64_t ws_bytes, float* grad, float* loss, hipStream_t st, const float* rec_in = nullptr) {
     using Bk = GruBwd<S>;
     const int B = bt->batch;
-    const GruRowsWs wl = gru_rows_ws<S>(P, steps, B);
+    const GruRowsWs wl = gru_rows_ws<S>(P, steps, B, rec_in == nullptr);
     MARL_REQUIRE(ws_bytes >= wl.total, "gru_backward_rows: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)wl.total);
     char* base = static_cast<char*>(ws);
     auto f = [&](int64_t o) { return reinterpret_cast<float*>(base + o); };
     gru_set_attrs<S>();
     size_t as, rs;
     gru_obs_strides(bt, S::D, &as, &rs);
-    hipLaunchKernelGGL((gru_pack_kernel<S>), dim3((S::NFWD + 255) / 256, P), dim3(256), 0, st, params, am, f(wl.packF));
     hipLaunchKernelGGL((gru_bwd_pack_kernel<S>), dim3((Bk::NBWD + 255) / 256, P), dim3(256), 0, st, params, am, f(wl.packB));
     const dim3 gridS((B + 63) / 64, P);
-    hipLaunchKernelGGL((gru_seq_fwd_kernel<S>), gridS, dim3(256), S::LDS_FLOATS * sizeof(float), st, (const float*)f(wl.packF), bt->obss, as, rs, steps, B,
-                       (const float*)nullptr, (float*)nullptr, f(wl.q), f(wl.rec));
-    hipLaunchKernelGGL((gru_seq_bwd_kernel<S>), gridS, dim3(256), Bk::LDS_FLOATS * sizeof(float), st, (const float*)f(wl.packB), steps, B,
-                       (const float*)f(wl.rec), dout, f(wl.rec2));
-    hipLaunchKernelGGL((gru_wgrad_kernel<S>), dim3(wl.nwg, P, 4), dim3(256), (4 * 16 * S::H + 256) * sizeof(float), st, steps, B, bt->obss, as, rs,
-                       (const float*)f(wl.rec), (const float*)f(wl.rec2), dout, lrow, bt->filled, steps, f(wl.partials));
+    const float* rec = rec_in;
+    if (rec == nullptr) {  // no record from the caller's forward: recompute it
+        hipLaunchKernelGGL((gru_pack_kernel<S>), dim3((S::NFWD + 255) / 256, P), dim3(256), 0, st, params, am, f(wl.packF));
+        hipLaunchKernelGGL((gru_seq_fwd_kernel<S>), gridS, dim3(256), S::LDS_FLOATS * sizeof(float), st, (const float*)f(wl.packF), bt->obss, as, rs, steps,
+                           B, (const float*)nullptr, (float*)nullptr, f(wl.q), f(wl.rec));
+        rec = f(wl.rec);
+    }
+    hipLaunchKernelGGL((gru_seq_bwd_kernel<S>), gridS, dim3(256), Bk::LDS_FLOATS * sizeof(float), st, (const float*)f(wl.packB), steps, B, rec, dout,
+                       f(wl.rec2));
+    hipLaunchKernelGGL((gru_wgrad_kernel<S>), dim3(wl.nwg, P, 4), dim3(256), (4 * 16 * S::H + 256) * sizeof(float), st, steps, B, bt->obss, as, rs, rec,
+                       (const float*)f(wl.rec2), dout, lrow, bt->filled, steps, f(wl.partials));
     MARL_CHECK_LAUNCH("gru backward rows");
     const int n = am.nblk * S::NPARAM;  // one gradient block per NETWORK: a shared network's agents are summed by the reduce
     hipLaunchKernelGGL(dqn_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, st, (const float*)f(wl.partials), P, wl.nwg, S::NPARAM, am, grad, loss);
