@@ -364,9 +364,21 @@ int ac_step_t(int P, const AgentMap& am, const float* actor, const float* critic
     a.standardise = std_on ? 1 : 0;
     int rc;
     timing_begin(TIMER_LOSSGRAD, st);
+    float* rec_a = IsGru<SA>::value && mode != 1 ? f(wl.rec_a) : nullptr;
+    float* rec_c = IsGru<SC>::value ? f(wl.rec_c) : nullptr;
+    bool v_done = false;
     if (mode != 2) {  // target-critic values of all T+1 observations (model.py:190-193); PPO reuses the returns across epochs
-        rc = launch_forward_rows<SC>(P, am, target, bc, TB + B, f(wl.vnext), st);
-        if (rc != 0) return rc;
+        if constexpr (IsGru<SC>::value) {
+            if (mode != 1) {  // recurrent critics: the critics' own pass rides in the same launch (each fills half the chip)
+                rc = gru_forward_rows_pair<SC>(P, am, critic, target, bc, T, T + 1, f(wl.v), f(wl.vnext), st, rec_c);
+                if (rc != 0) return rc;
+                v_done = true;
+            }
+        }
+        if (!v_done) {
+            rc = launch_forward_rows<SC>(P, am, target, bc, TB + B, f(wl.vnext), st);
+            if (rc != 0) return rc;
+        }
     }
     if (std_on && mode == 0) {  // A2C with standardise_returns: raw returns -> statistics update -> A2C on the stored returns
         a.mode = 4;
@@ -374,11 +386,9 @@ int ac_step_t(int P, const AgentMap& am, const float* actor, const float* critic
         hipLaunchKernelGGL(ret_stats_update_kernel, dim3(1), dim3(64), 0, st, w.st, (const float*)w.rpartial, (TB + 255) / 256, P, TB);
         a.mode = 3;
     }
-    float* rec_a = IsGru<SA>::value && mode != 1 ? f(wl.rec_a) : nullptr;
-    float* rec_c = IsGru<SC>::value ? f(wl.rec_c) : nullptr;
     rc = launch_forward_rows<SA>(P, am, actor, bt, TB, f(wl.logits), st, rec_a);
     if (rc != 0) return rc;
-    if (mode != 1) {
+    if (mode != 1 && !v_done) {
         rc = launch_forward_rows<SC>(P, am, critic, bc, TB, f(wl.v), st, rec_c);
         if (rc != 0) return rc;
     }

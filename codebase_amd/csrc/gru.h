@@ -7,6 +7,7 @@
 // A wave owns 16 sequences (batch rows) and walks them one step after the other with the hidden state in registers
 // (C layout = the next step's B operand, as everywhere in mlp.h); the whole network (108 KB of A-operand packs at
 // D = 15) sits in LDS, so the four waves of a workgroup share nothing but the weights.
+//   gru_seq_fwd2_kernel: two such passes (online + target networks) in one launch
 //   gru_seq_fwd_kernel : q[t] for t = 0..S-1 from h_in (zeros when NULL), optional h_out, optional per-step activation
 //                        record (x1, r, z, n, h, W_hn h + b_hn) for the backward pass
 #pragma once
@@ -114,9 +115,9 @@ __device__ __forceinline__ void gru_gate(const f4* G /* [MT][MT][64] chunk */, c
 // ac/train.py Batch [S][B][P*D]: as = D, rs = P*D); q: [P][S][B][A], h_in / h_out: [P][B][H] or NULL,
 // rec: [P][S][nblk][REC] or NULL (nblk = ceil(B / 16))
 template <class S>
-__global__ __launch_bounds__(256) void gru_seq_fwd_kernel(const float* __restrict__ packs, const float* __restrict__ obs, size_t obs_as,
-                                                          size_t obs_rs, int steps, int B, const float* __restrict__ h_in,
-                                                          float* __restrict__ h_out, float* __restrict__ q_out, float* __restrict__ rec) {
+__device__ __forceinline__ void gru_seq_fwd_body(const float* __restrict__ packs, const float* __restrict__ obs, size_t obs_as, size_t obs_rs,
+                                                 int steps, int B, const float* __restrict__ h_in, float* __restrict__ h_out,
+                                                 float* __restrict__ q_out, float* __restrict__ rec) {
     constexpr int MT = S::MT, D = S::D, H = S::H, A = S::A;
     constexpr bool STREAM = S::STREAM;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -236,6 +237,25 @@ __global__ __launch_bounds__(256) void gru_seq_fwd_kernel(const float* __restric
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) *reinterpret_cast<f4*>(h_out + ((size_t)p * B + b0 + j) * H + 16 * mt + 4 * g) = h[mt];
     }
+}
+
+template <class S>
+__global__ __launch_bounds__(256) void gru_seq_fwd_kernel(const float* __restrict__ packs, const float* __restrict__ obs, size_t obs_as,
+                                                          size_t obs_rs, int steps, int B, const float* __restrict__ h_in,
+                                                          float* __restrict__ h_out, float* __restrict__ q_out, float* __restrict__ rec) {
+    gru_seq_fwd_body<S>(packs, obs, obs_as, obs_rs, steps, B, h_in, h_out, q_out, rec);
+}
+
+// Two independent passes over the same observations in one launch (blockIdx.z): the online networks (with the activation record) and
+// the target networks.  One pass of B = 4096 sequences occupies 512 of the 1024 SIMDs and a sequence cannot be split, so the pair
+// costs what one of them does.  Zero initial hidden states.
+template <class S>
+__global__ __launch_bounds__(256) void gru_seq_fwd2_kernel(const float* __restrict__ packs, const float* __restrict__ packs2,
+                                                           const float* __restrict__ obs, size_t obs_as, size_t obs_rs, int steps, int steps2, int B,
+                                                           float* __restrict__ q_out, float* __restrict__ q_out2, float* __restrict__ rec) {
+    const bool second = blockIdx.z == 1;
+    gru_seq_fwd_body<S>(second ? packs2 : packs, obs, obs_as, obs_rs, second ? steps2 : steps, B, nullptr, nullptr, second ? q_out2 : q_out,
+                        second ? nullptr : rec);
 }
 
 }  // namespace marl

@@ -155,17 +155,15 @@ int gru_loss_grad(const marlhip_net_shape* s, const float* params, const float* 
     const size_t ldsW = (size_t)(4 * 16 * S::H + 256) * sizeof(float);
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_seq_fwd_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsF);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_seq_fwd2_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsF);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_seq_bwd_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsB);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_wgrad_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsW);
         attr = true;
     }
     const dim3 gridS((B + 63) / 64, P);
     timing_begin(TIMER_LOSSGRAD, st);
-    hipLaunchKernelGGL((gru_seq_fwd_kernel<S>), gridS, dim3(256), ldsF, st, (const float*)f(wl.packC), bt->obss, (size_t)steps * B * S::D, (size_t)S::D, steps, B,
-                       (const float*)nullptr, (float*)nullptr, f(wl.q), f(wl.rec));
-    hipLaunchKernelGGL((gru_seq_fwd_kernel<S>), gridS, dim3(256), ldsF, st, (const float*)f(wl.packT), bt->obss, (size_t)steps * B * S::D, (size_t)S::D, steps, B,
-                       (const float*)nullptr, (float*)nullptr, f(wl.tq), (float*)nullptr);
+    hipLaunchKernelGGL((gru_seq_fwd2_kernel<S>), dim3(gridS.x, gridS.y, 2), dim3(256), ldsF, st, (const float*)f(wl.packC), (const float*)f(wl.packT), bt->obss,
+                       (size_t)steps * B * S::D, (size_t)S::D, steps, steps, B, f(wl.q), f(wl.tq), f(wl.rec));
     MARL_CHECK_LAUNCH("gru_seq_fwd_kernel");
     (void)hipMemsetAsync(f(wl.dq), 0, (size_t)P * steps * B * S::A * sizeof(float), st);
     if (rst != nullptr) {
@@ -299,17 +297,15 @@ int gru_qmix_loss_grad(const marlhip_net_shape* s, const float* params, const fl
     const size_t ldsW = (size_t)(4 * 16 * S::H + 256) * sizeof(float);
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_seq_fwd_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsF);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_seq_fwd2_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsF);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_seq_bwd_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsB);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_wgrad_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsW);
         attr = true;
     }
     const dim3 gridS((B + 63) / 64, P), gridR((unsigned)((R + 255) / 256));
     timing_begin(TIMER_LOSSGRAD, st);
-    hipLaunchKernelGGL((gru_seq_fwd_kernel<S>), gridS, dim3(256), ldsF, st, (const float*)f(wl.packC), bt->obss, (size_t)steps * B * S::D, (size_t)S::D, steps, B,
-                       (const float*)nullptr, (float*)nullptr, f(wl.q), f(wl.rec));
-    hipLaunchKernelGGL((gru_seq_fwd_kernel<S>), gridS, dim3(256), ldsF, st, (const float*)f(wl.packT), bt->obss, (size_t)steps * B * S::D, (size_t)S::D, steps, B,
-                       (const float*)nullptr, (float*)nullptr, f(wl.tq), (float*)nullptr);
+    hipLaunchKernelGGL((gru_seq_fwd2_kernel<S>), dim3(gridS.x, gridS.y, 2), dim3(256), ldsF, st, (const float*)f(wl.packC), (const float*)f(wl.packT), bt->obss,
+                       (size_t)steps * B * S::D, (size_t)S::D, steps, steps, B, f(wl.q), f(wl.tq), f(wl.rec));
     hipLaunchKernelGGL(gru_qsel_kernel, gridR, dim3(256), 0, st, P, T, B, S::A, (const float*)f(wl.q), (const float*)f(wl.tq), *bt, double_q, chosen,
                        tqsel, r0, dn, fl);
     MARL_CHECK_LAUNCH("gru forward / qsel");

@@ -50,6 +50,8 @@ void gru_set_attrs() {
     if (done) return;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_seq_fwd_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)(S::LDS_FLOATS * sizeof(float)));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_seq_fwd2_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)(S::LDS_FLOATS * sizeof(float)));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_seq_bwd_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)(GruBwd<S>::LDS_FLOATS * sizeof(float)));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_wgrad_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -76,6 +78,25 @@ int gru_forward_rows(int P, const AgentMap& am, const float* params, const marlh
     hipLaunchKernelGGL((gru_seq_fwd_kernel<S>), dim3((bt->batch + 63) / 64, P), dim3(256), S::LDS_FLOATS * sizeof(float), st, (const float*)packs, bt->obss,
                        as, rs, steps, bt->batch, (const float*)nullptr, (float*)nullptr, out, rec);
     MARL_CHECK_LAUNCH("gru_seq_fwd_kernel (rows)");
+    return 0;
+}
+
+// Two networks of one shape over the same batch in one launch: out[p][t][b][:] for t < steps from `params` (with the record) and
+// out2 for t < steps2 from `params2` (the critics and their targets, ac/model.py:190-193,206-207)
+template <class S>
+int gru_forward_rows_pair(int P, const AgentMap& am, const float* params, const float* params2, const marlhip_batch* bt, int steps, int steps2,
+                          float* out, float* out2, hipStream_t st, float* rec) {
+    float* packs = collect_pack_scratch((size_t)2 * P * S::NFWD * sizeof(float), st);
+    MARL_REQUIRE(packs != nullptr, "gru_forward_rows_pair: cannot allocate the pack scratch");
+    float* packs2 = packs + (size_t)P * S::NFWD;
+    gru_set_attrs<S>();
+    size_t as, rs;
+    gru_obs_strides(bt, S::D, &as, &rs);
+    hipLaunchKernelGGL((gru_pack_kernel<S>), dim3((S::NFWD + 255) / 256, P), dim3(256), 0, st, params, am, packs);
+    hipLaunchKernelGGL((gru_pack_kernel<S>), dim3((S::NFWD + 255) / 256, P), dim3(256), 0, st, params2, am, packs2);
+    hipLaunchKernelGGL((gru_seq_fwd2_kernel<S>), dim3((bt->batch + 63) / 64, P, 2), dim3(256), S::LDS_FLOATS * sizeof(float), st, (const float*)packs,
+                       (const float*)packs2, bt->obss, as, rs, steps, steps2, bt->batch, out, out2, rec);
+    MARL_CHECK_LAUNCH("gru_seq_fwd2_kernel (rows)");
     return 0;
 }
 
