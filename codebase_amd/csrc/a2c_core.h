@@ -304,9 +304,32 @@ static __global__ __launch_bounds__(1024) void ac_metrics_kernel(int nblocks, fl
     }
 }
 
+// A second stream per device for the recurrent step's critic BPTT: one sequence pass of the bench batch fills half of the SIMDs and
+// the actor's and the critics' passes are different kernels, so they overlap through a fork / join on events instead of a shared grid.
+struct SideStream {
+    hipStream_t s = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+};
+inline SideStream* side_stream() {
+    static SideStream per_dev[16];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    SideStream& x = per_dev[dev & 15];
+    if (x.s == nullptr) {
+        if (hipStreamCreateWithFlags(&x.s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+        if (hipEventCreateWithFlags(&x.fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&x.join, hipEventDisableTiming) != hipSuccess) {
+            (void)hipStreamDestroy(x.s);
+            x.s = nullptr;
+            return nullptr;
+        }
+    }
+    return &x;
+}
+
 // workspace: [vnext | v | logits | dlogits | dv | lrow_a | lrow_v | ent | ret | oldlogp | loss scratch 4][backward workspace]
 struct AcWs {
-    int64_t vnext, v, logits, dlogits, dv, lrow_a, lrow_v, ent, ret, oldlogp, partial, rpartial, scratch, rec_a, rec_c, bwd, total;
+    int64_t vnext, v, logits, dlogits, dv, lrow_a, lrow_v, ent, ret, oldlogp, partial, rpartial, scratch, rec_a, rec_c, bwd, bwd_c, total;
 };
 
 template <class SA, class SC>
@@ -333,7 +356,9 @@ AcWs ac_ws_layout(int P, int T, int B) {
     if constexpr (IsGru<SC>::value) w.rec_c = take(gru_rec_floats<SC>(P, T, B));
     w.bwd = o;
     const int64_t ba = backward_ws_bytes<SA>(P, T, B), bc = backward_ws_bytes<SC>(P, T, B);
-    w.total = o + (ba > bc ? ba : bc);
+    // recurrent networks: the two backward passes run side by side (side_stream) and need a workspace each
+    w.bwd_c = IsGru<SA>::value && IsGru<SC>::value ? o + ((ba + 255) & ~(int64_t)255) : o;
+    w.total = w.bwd_c != o ? w.bwd_c + bc : o + (ba > bc ? ba : bc);
     return w;
 }
 
@@ -367,13 +392,34 @@ int ac_step_t(int P, const AgentMap& am, const float* actor, const float* critic
     float* rec_a = IsGru<SA>::value && mode != 1 ? f(wl.rec_a) : nullptr;
     float* rec_c = IsGru<SC>::value ? f(wl.rec_c) : nullptr;
     bool v_done = false;
-    if (mode != 2) {  // target-critic values of all T+1 observations (model.py:190-193); PPO reuses the returns across epochs
-        if constexpr (IsGru<SC>::value) {
-            if (mode != 1) {  // recurrent critics: the critics' own pass rides in the same launch (each fills half the chip)
-                rc = gru_forward_rows_pair<SC>(P, am, critic, target, bc, T, T + 1, f(wl.v), f(wl.vnext), st, rec_c);
-                if (rc != 0) return rc;
-                v_done = true;
-            }
+    // PPO's passes with recurrent networks (prepare: target critics + actors; epochs: actors + critics): the critics' sequence pass
+    // goes to the side stream next to the actors' (each fills half of the SIMDs), with its packs in the critics' backward workspace
+    SideStream* fwd_side = nullptr;
+    auto side_forward = [&](const float* prm, int steps, float* out, float* rec) -> int {  // -2: not available
+        if constexpr (IsGru<SA>::value && IsGru<SC>::value) {
+            SideStream* sd = side_stream();
+            if (sd == nullptr) return -2;
+            float* pk = reinterpret_cast<float*>(base + wl.bwd_c + gru_rows_ws<SC>(P, T, B, false).packF);
+            (void)hipEventRecord(sd->fork, st);
+            (void)hipStreamWaitEvent(sd->s, sd->fork, 0);
+            const int r = gru_forward_rows<SC>(P, am, prm, bc, steps, out, sd->s, rec, pk);
+            (void)hipEventRecord(sd->join, sd->s);
+            fwd_side = sd;
+            return r;
+        } else {
+            (void)prm; (void)steps; (void)out; (void)rec;
+            return -2;
+        }
+    };
+    if (mode == 1) {
+        rc = side_forward(target, T + 1, f(wl.vnext), nullptr);
+        if (rc == -2) rc = launch_forward_rows<SC>(P, am, target, bc, TB + B, f(wl.vnext), st);
+        if (rc != 0) return rc;
+    } else if (mode != 2) {  // target-critic values of all T+1 observations (model.py:190-193); PPO reuses the returns across epochs
+        if constexpr (IsGru<SC>::value) {  // recurrent critics: the critics' own pass rides in the same launch (each fills half the chip)
+            rc = gru_forward_rows_pair<SC>(P, am, critic, target, bc, T, T + 1, f(wl.v), f(wl.vnext), st, rec_c);
+            if (rc != 0) return rc;
+            v_done = true;
         }
         if (!v_done) {
             rc = launch_forward_rows<SC>(P, am, target, bc, TB + B, f(wl.vnext), st);
@@ -386,12 +432,14 @@ int ac_step_t(int P, const AgentMap& am, const float* actor, const float* critic
         hipLaunchKernelGGL(ret_stats_update_kernel, dim3(1), dim3(64), 0, st, w.st, (const float*)w.rpartial, (TB + 255) / 256, P, TB);
         a.mode = 3;
     }
-    rc = launch_forward_rows<SA>(P, am, actor, bt, TB, f(wl.logits), st, rec_a);
-    if (rc != 0) return rc;
-    if (mode != 1 && !v_done) {
-        rc = launch_forward_rows<SC>(P, am, critic, bc, TB, f(wl.v), st, rec_c);
+    if (mode != 1 && !v_done) {  // (forked before the actors' pass is queued, or there is nothing to overlap with)
+        rc = side_forward(critic, T, f(wl.v), rec_c);
+        if (rc == -2) rc = launch_forward_rows<SC>(P, am, critic, bc, TB, f(wl.v), st, rec_c);
         if (rc != 0) return rc;
     }
+    rc = launch_forward_rows<SA>(P, am, actor, bt, TB, f(wl.logits), st, rec_a);
+    if (rc != 0) return rc;
+    if (fwd_side != nullptr) (void)hipStreamWaitEvent(st, fwd_side->join, 0);  // join before the elementwise stage
     hipLaunchKernelGGL(ac_elem_kernel, dim3((TB + 255) / 256), dim3(256), 0, st, a, *bt, w);
     MARL_CHECK_LAUNCH("ac_elem_kernel");
     if (mode == 1) {
@@ -401,10 +449,21 @@ int ac_step_t(int P, const AgentMap& am, const float* actor, const float* critic
         return 0;
     }
     float* scratch = f(wl.scratch);
-    rc = launch_backward_rows<SA>(P, am, actor, bt, w.dlogits, w.lrow_a, base + wl.bwd, ws_bytes - wl.bwd, actor_grad, scratch, st, rec_a);
-    if (rc != 0) return rc;
-    rc = launch_backward_rows<SC>(P, am, critic, bc, w.dv, w.lrow_v, base + wl.bwd, ws_bytes - wl.bwd, critic_grad, scratch + 2, st, rec_c);
-    if (rc != 0) return rc;
+    SideStream* side = wl.bwd_c != wl.bwd ? side_stream() : nullptr;
+    hipStream_t st_c = st;
+    if (side != nullptr) {  // fork: the critics' backward on the side stream, behind everything queued so far
+        (void)hipEventRecord(side->fork, st);
+        (void)hipStreamWaitEvent(side->s, side->fork, 0);
+        st_c = side->s;
+    }
+    rc = launch_backward_rows<SC>(P, am, critic, bc, w.dv, w.lrow_v, base + wl.bwd_c, ws_bytes - wl.bwd_c, critic_grad, scratch + 2, st_c, rec_c);
+    const int rc_a = launch_backward_rows<SA>(P, am, actor, bt, w.dlogits, w.lrow_a, base + wl.bwd, wl.bwd_c != wl.bwd ? wl.bwd_c - wl.bwd : ws_bytes - wl.bwd,
+                                              actor_grad, scratch, st, rec_a);
+    if (side != nullptr) {  // join
+        (void)hipEventRecord(side->join, side->s);
+        (void)hipStreamWaitEvent(st, side->join, 0);
+    }
+    if (rc != 0 || rc_a != 0) return rc != 0 ? rc : rc_a;
     hipLaunchKernelGGL(ac_metrics_kernel, dim3(1), dim3(1024), 0, st, (TB + 255) / 256, c->value_loss_coef, (const float*)w.partial,
                        metrics);
     timing_end(TIMER_LOSSGRAD, st);

@@ -68,8 +68,9 @@ int64_t gru_rec_floats(int P, int steps, int B) {
 // receives the activation record gru_backward_rows would otherwise recompute
 template <class S>
 int gru_forward_rows(int P, const AgentMap& am, const float* params, const marlhip_batch* bt, int steps, float* out, hipStream_t st,
-                     float* rec = nullptr) {
-    float* packs = collect_pack_scratch((size_t)P * S::NFWD * sizeof(float), st);
+                     float* rec = nullptr, float* packs_buf = nullptr) {
+    // packs_buf: the caller's own [P][NFWD] pack space (a pass on a side stream must not share the per-process scratch)
+    float* packs = packs_buf != nullptr ? packs_buf : collect_pack_scratch((size_t)P * S::NFWD * sizeof(float), st);
     MARL_REQUIRE(packs != nullptr, "gru_forward_rows: cannot allocate the pack scratch");
     gru_set_attrs<S>();
     size_t as, rs;
