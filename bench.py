@@ -1,7 +1,11 @@
 #!/usr/bin/env python
 """bench.py - env-steps/s of the IDQN hot path on Foraging-8x8-2p-3f (BASELINE.json metric).
 
-    python bench.py [--gpus N --steps K --warmup W]          (N>1: launched by torch.distributed.run)
+    python bench.py [--gpus N --steps K --warmup W]
+
+`--gpus N` with N > 1 and no torchrun environment re-executes itself under
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1` (one rank per GPU,
+backend nccl == RCCL); launched under torch.distributed.run directly it checks WORLD_SIZE == N.
 
 One "step" = one ROUND of the hot path on this rank's N_env batched envs:
     fused collector (reset -> T x (act, env.step, replay add))             1 launch
@@ -100,6 +104,11 @@ def cpu_baseline(seconds, hidden):
             "sample": f"{steps - s0} env-steps / {updates} updates of oracle/lbf.py + oracle/dqn_port.py "
                       f"(python LBF env + torch-CPU IDQN {hidden}-{hidden}, reference cadence: 1 update of 32 episodes "
                       f"per episode, 1 thread) in {dt:.1f} s; host has {os.cpu_count()} cores"}
+
+
+def _ranks_field(world, dist, args):
+    """Ranks that took part in the gradient all-reduce, as torch.distributed reports them (and the backend: nccl == RCCL)."""
+    return {"world_size": dist.get_world_size() if dist is not None else 1, "backend": args.backend if dist is not None else None}
 
 
 def bench_ac(args, rank, world, dist):
@@ -213,7 +222,7 @@ def bench_ac(args, rank, world, dist):
                     "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None, "flops_per_launch": flops, "avg_launch_us": upd["avg_us"]}
     out = {
         "metric": f"env-steps/sec (whole node) {args.algo.upper()} {name}", "value": env_steps / dt, "unit": "env-steps/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+        "n_gpus": world, "rccl_ranks": _ranks_field(world, dist, args), "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic (Philox-seeded env layouts, orthogonal-init weights)",
         "config": {"workload": f"{args.algo.upper()} on {name}, {N} batched HIP envs per GPU, actor/critic " + (f"GRU-{H} networks (use_rnn), " if args.rnn else f"2-layer-{H} MLPs, ")
@@ -227,15 +236,57 @@ def bench_ac(args, rank, world, dist):
         dist.destroy_process_group()
 
 
+def _self_launch(n):
+    """`python bench.py --gpus N` outside torchrun: become `python -m torch.distributed.run ... bench.py <same args>`
+    (exec, so the driver's clock and exit code see the N-rank job; rank 0 prints the one JSON line)."""
+    import socket
+
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = str(s.getsockname()[1])
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        _self_launch(args.gpus)
     import torch
 
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} "
+                         f"(or plain `python bench.py --gpus {args.gpus}`, which launches the ranks itself)")
+    if os.environ.get("MARLHIP_BENCH_DRYRUN"):
+        # launch-plumbing check without a GPU (tests/test_bench_launch.py): rendezvous over gloo, one all-reduce, no hot path
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world > 1:
+            dist.init_process_group("gloo")
+            t = torch.ones(1)
+            dist.all_reduce(t)
+            assert dist.get_world_size() == args.gpus
+            ranks = int(t[0])
+            dist.destroy_process_group()
+        else:
+            ranks = 1
+        if rank == 0:
+            print(json.dumps({"dryrun": True, "n_gpus": world, "ranks_in_allreduce": ranks}), flush=True)
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an AMD GPU: the marlhip hot path has no CPU fallback")
+    if world > 1 and not os.environ.get("MARLHIP_BENCH_ONE_DEVICE") and torch.cuda.device_count() < world:
+        raise SystemExit(f"bench.py: --gpus {world} needs {world} visible devices, found {torch.cuda.device_count()}")
     # MARLHIP_BENCH_BACKEND=gloo + MARLHIP_BENCH_ONE_DEVICE=1 let the N>1 code path be exercised on a 1-GPU box
     backend = os.environ.get("MARLHIP_BENCH_BACKEND", "nccl")  # nccl == RCCL on ROCm
     dev_index = 0 if os.environ.get("MARLHIP_BENCH_ONE_DEVICE") else local_rank
@@ -247,6 +298,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         kw = {"device_id": torch.device("cuda", dev_index)} if backend == "nccl" else {}
         dist.init_process_group(backend, **kw)
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
+    args.backend = backend
 
     if args.algo in ("ia2c", "ippo", "maa2c", "mappo"):
         return bench_ac(args, rank, world, dist)
@@ -361,6 +414,7 @@ def main():
         "value": env_steps / dt,
         "unit": "env-steps/s",
         "n_gpus": world,
+        "rccl_ranks": _ranks_field(world, dist, args),
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps,

@@ -1,0 +1,54 @@
+"""`python bench.py --gpus N` must run N ranks by itself (the driver's literal command form) and also accept being
+launched under torch.distributed.run; a --gpus / WORLD_SIZE mismatch is an error, not a silent 1-rank run."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _env(**kw):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(kw)
+    return env
+
+
+def _json_line(stdout):
+    lines = [ln for ln in stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, stdout
+    return json.loads(lines[0])
+
+
+def test_gpus_flag_self_launches_n_ranks_dryrun():
+    out = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "1", "--warmup", "0"], cwd=ROOT,
+                         env=_env(MARLHIP_BENCH_DRYRUN="1"), capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = _json_line(out.stdout)
+    assert line["n_gpus"] == 2 and line["ranks_in_allreduce"] == 2
+
+
+def test_gpus_flag_under_torchrun_and_mismatch_dryrun():
+    base = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+            "--master-port", "29547", BENCH, "--steps", "1", "--warmup", "0"]
+    ok = subprocess.run(base + ["--gpus", "2"], cwd=ROOT, env=_env(MARLHIP_BENCH_DRYRUN="1"), capture_output=True, text=True, timeout=300)
+    assert ok.returncode == 0, ok.stderr[-3000:]
+    assert _json_line(ok.stdout)["n_gpus"] == 2
+    bad = subprocess.run(base + ["--gpus", "4"], cwd=ROOT, env=_env(MARLHIP_BENCH_DRYRUN="1"), capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0 and "WORLD_SIZE=2" in bad.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("algo", ["idqn", "ia2c"])
+def test_bench_gpus_2_runs_two_ranks_on_the_real_kernels(algo):
+    """Two ranks share cuda:0 over gloo (the RCCL path differs only in the backend string): the JSON line must say 2."""
+    out = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "2", "--warmup", "1", "--envs", "256", "--algo", algo,
+                          "--no-cpu-baseline"], cwd=ROOT, env=_env(MARLHIP_BENCH_BACKEND="gloo", MARLHIP_BENCH_ONE_DEVICE="1"),
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    line = _json_line(out.stdout)
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == {"world_size": 2, "backend": "gloo"}
+    assert line["value"] > 0 and line["scaling"] == "weak"
