@@ -12,7 +12,7 @@ Storage: ONE flat fp32 block [actor agents | critic agents] (so that clip_grad_n
 single fused launch) plus the target-critic block; state_dict tensors are slices.
 Built: independent or shared (parameter_sharing True / SePS index list, the same for actor and critic) actors and
 critics (IA2C / IPPO) and centralised critics (MAA2C / MAPPO: hidden 128 up to 4 agents, hidden 64 for 2), two equal
-hidden layers of 64 or 128.  Not built (raise): GRU, action masks.
+hidden layers of 64 or 128, recurrent actors / critics (`use_rnn`), `action_mask`.
 """
 from collections import OrderedDict
 

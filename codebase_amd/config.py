@@ -14,6 +14,7 @@ this module provides the small part of their behaviour the hot path needs:
 import copy
 import importlib
 import os
+import re
 
 import yaml
 
@@ -117,15 +118,31 @@ def _set(cfg, dotted, value):
     cur[parts[-1]] = value
 
 
+_NUMERIC = re.compile(r"^[-+]?(\d+\.?\d*|\.\d+)([eE][-+]?\d+)?$")
+
+
+def _numbers(x):
+    """PyYAML follows YAML 1.1, where `1e6` / `3e-4` (no dot) are strings; Hydra / OmegaConf read them as floats.
+    Re-type such scalars (recursively) so `algorithm.total_steps=1e6` means what it means to the reference."""
+    if isinstance(x, dict):
+        return {k: _numbers(v) for k, v in x.items()}
+    if isinstance(x, list):
+        return [_numbers(v) for v in x]
+    if isinstance(x, str) and _NUMERIC.match(x.strip()):
+        f = float(x)
+        return int(f) if re.fullmatch(r"[-+]?\d+", x.strip()) else f
+    return x
+
+
 def _load_yaml_tree(config_dir, algorithm):
-    base = yaml.safe_load(open(os.path.join(config_dir, "default.yaml"))) or {}
+    base = _numbers(yaml.safe_load(open(os.path.join(config_dir, "default.yaml"))) or {})
     base.pop("defaults", None)
     base.pop("hydra", None)
     stack = [algorithm]
     docs = []
     while stack:
         a = stack.pop()
-        d = yaml.safe_load(open(os.path.join(config_dir, "algorithm", f"{a}.yaml"))) or {}
+        d = _numbers(yaml.safe_load(open(os.path.join(config_dir, "algorithm", f"{a}.yaml"))) or {})
         for inc in d.pop("defaults", []) or []:
             if isinstance(inc, str):
                 stack.append(inc)
@@ -155,7 +172,7 @@ def compose(argv, config_dir=None):
             raise NotImplementedError(f"+algorithm={algo}: built-in configs cover {sorted(ALGORITHMS)}")
         _merge(cfg, ALGORITHMS[algo])
     for k, v in overrides:
-        _set(cfg, k, yaml.safe_load(v))
+        _set(cfg, k, _numbers(yaml.safe_load(v)))
     for key in ("name", "time_limit"):
         if cfg["env"].get(key) == "???":
             raise ValueError(f"env.{key} must be set (mandatory value, configs/default.yaml:30-31)")

@@ -73,6 +73,10 @@ def main(argv=None):
     ckpt = path / "checkpoints" / f"model_s{step}.pt"
     assert ckpt.exists(), f"Checkpoint {ckpt} does not exist."
     algo = run_config.algorithm
+    # run directories written by the reference carry `model.device: cpu` (configs/algorithm/*.yaml); the networks here live on
+    # the HIP device whatever the run was trained on, so the stored device is replaced (device=<...> on the command line wins)
+    if "device" in algo.model:
+        algo.model["device"] = args.get("device", "cuda")
     obs_space = getattr(env, "single_observation_space", None) or env.observation_space
     act_space = getattr(env, "single_action_space", None) or env.action_space
     model = C.instantiate(algo.model, obs_space, act_space, algo)

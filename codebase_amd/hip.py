@@ -290,6 +290,7 @@ class DqnUpdater:
         self.scratch = torch.zeros((params.numel() + 255) // 256 + 1, dtype=torch.float32, device=dev)
         self.step = 0
         self._ws = {}
+        self._gru_ws = {}
 
     def _workspace(self, T, B):
         key = (T, B)
@@ -598,17 +599,20 @@ def gru_nparams(spec: NetSpec):
     return check(lib.marlhip_gru_nparams(ctypes.byref(s)), "gru_nparams")
 
 
-def gru_loss_grad(spec: NetSpec, params, target, batch, gamma=0.99, double_q=True, mode=0, grad=None, loss=None, _cache={}):
-    """loss / gradient of the recurrent DQN-family learners (marlhip_gru_loss_grad); batch = hip.Batch on the device"""
+def gru_loss_grad(spec: NetSpec, params, target, batch, gamma=0.99, double_q=True, mode=0, grad=None, loss=None, ws_cache=None):
+    """loss / gradient of the recurrent DQN-family learners (marlhip_gru_loss_grad); batch = hip.Batch on the device.
+    `ws_cache`: a dict owned by the caller (GruUpdater keeps one per instance) holding the workspace per (T, B); without
+    it the workspace lives for this call only."""
     _require_gpu()
     T, B = batch.filled.shape
     s = spec.c()
     n = check(lib.marlhip_gru_workspace_bytes(ctypes.byref(s), T, B), "gru_workspace_bytes")
-    key = (params.device, n)
-    if key not in _cache:
-        _cache.clear()
-        _cache[key] = torch.empty(n, dtype=torch.uint8, device=params.device)
-    ws = _cache[key]
+    key = ("gru", T, B)
+    ws = ws_cache.get(key) if ws_cache is not None else None
+    if ws is None or ws.numel() != n or ws.device != params.device:
+        ws = torch.empty(n, dtype=torch.uint8, device=params.device)
+        if ws_cache is not None:
+            ws_cache[key] = ws
     grad = torch.empty_like(params) if grad is None else grad
     loss = torch.empty(2, device=params.device) if loss is None else loss
     bs = BatchStruct(batch.obss.data_ptr(), batch.actions.data_ptr(), batch.rewards.data_ptr(), batch.dones.data_ptr(),
@@ -638,7 +642,7 @@ class GruUpdater(DqnUpdater):
                   "gru_loss_grad_std")
             return self.loss, self.grad
         return gru_loss_grad(self.spec, self.params, self.target, batch, gamma=self.gamma, double_q=self.double_q, mode=mode,
-                             grad=self.grad, loss=self.loss)
+                             grad=self.grad, loss=self.loss, ws_cache=self._gru_ws)
 
     def loss_grad_replay(self, replay, batch_size, length=None, idx=None, seed=0, counter=0, idx_out=None, mode=0):
         """the recurrent learner reads a materialised Batch: sample kernel first (no in-kernel gather)"""

@@ -81,19 +81,36 @@ class FileSystemLogger(Logger):
     def __init__(self, project_name="marlhip", cfg=None):
         super().__init__(project_name, cfg)
         self.results_path, self.config_path = "results.csv", "config.yaml"
+        self._cols = self._rows = None
         if cfg is not None:
             with open(self.config_path, "w") as f:
                 yaml.safe_dump(_plain(cfg), f)
 
     def log_metrics(self, metrics):
+        """One row per call under ONE header.  The reference writes the header from its first row and assumes every later row
+        has the same keys (loggers.py:144-158) - true there because its first evaluation always follows an update; the vectorised
+        loop can evaluate before the first update (no `loss` yet), so a key that appears later widens the header and the file is
+        rewritten with the earlier rows' new cells empty (pandas reads them as NaN)."""
         d = squash_info(metrics)
-        cols = ["environment_steps"] + sorted(k for k in d if k != "environment_steps")
-        new = not os.path.exists(self.results_path) or os.path.getsize(self.results_path) == 0
-        with open(self.results_path, "a", newline="") as f:
-            w = csv.writer(f)
-            if new:
-                w.writerow(cols)
-            w.writerow([d[c] for c in cols])
+        if self._cols is None and os.path.exists(self.results_path) and os.path.getsize(self.results_path):
+            with open(self.results_path, newline="") as f:  # resumed run directory
+                rows = list(csv.reader(f))
+            self._cols, self._rows = rows[0], [dict(zip(rows[0], r)) for r in rows[1:]]
+        if self._cols is None:
+            self._cols, self._rows = [], []
+        fresh = [k for k in d if k not in self._cols]
+        row = {k: d[k] for k in d}
+        self._rows.append(row)
+        if fresh:
+            self._cols = ["environment_steps"] + sorted(k for k in set(self._cols) | set(fresh) if k != "environment_steps")
+            with open(self.results_path, "w", newline="") as f:
+                w = csv.writer(f)
+                w.writerow(self._cols)
+                for r in self._rows:
+                    w.writerow([r.get(c, "") for c in self._cols])
+        else:
+            with open(self.results_path, "a", newline="") as f:
+                csv.writer(f).writerow([row.get(c, "") for c in self._cols])
         self.print_progress(d["updates"], d["environment_steps"], d["mean_episode_returns"], len(metrics) - 1)
 
     def get_state(self):
