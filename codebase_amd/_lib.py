@@ -5,7 +5,8 @@ import os
 from ctypes import POINTER, c_char_p, c_double, c_float, c_int32, c_int64, c_uint8, c_uint32, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmarlhip.so")
+# MARLHIP_LIB: an experiment build of the same library (scripts/build_variants.py); the product path is the in-tree default
+LIB_PATH = os.environ.get("MARLHIP_LIB") or os.path.join(_HERE, "csrc", "libmarlhip.so")
 
 
 class MarlHipError(RuntimeError):

@@ -21,6 +21,12 @@ MARL_PART_MIX_DECL(lossgrad_part_h64_mix)
 MARL_PART_MIX_DECL(lossgrad_part_h64_oid_mix)
 MARL_PART_MIX_DECL(lossgrad_part_rware_mix)
 #undef MARL_PART_MIX_DECL
+#define MARL_PART_FUSED_DECL(name)                                                                                                 \
+    int name(const marlhip_net_shape*, const float*, const float*, const marlhip_batch*, const ReplaySrc*, float, int32_t, int32_t, \
+             void*, int64_t, float*, float*, hipStream_t, UpdFuse*, bool*);
+MARL_PART_FUSED_DECL(lossgrad_part_h64_fused)
+MARL_PART_FUSED_DECL(lossgrad_part_h64_oid_fused)
+#undef MARL_PART_FUSED_DECL
 
 // QMIX mixer stage for callers that ran the agent networks themselves (gru.hip): phase 0 = mix, phase 1 = mixer-gradient reduce
 int qmix_mix_stage(const marlhip_net_shape* s, const QmixCtx* qx, const marlhip_batch* bt, const QmixIo* io, float gamma, int phase,
@@ -231,14 +237,8 @@ extern "C" int marlhip_qmix_loss_grad_replay(const marlhip_net_shape* s, const f
     return qmix_call(s, params, target_params, mixer, &bt, &src, gamma, double_q, workspace, workspace_bytes, grad, loss, stream);
 }
 
-extern "C" int marlhip_dqn_clip_adam(int64_t n, float* params, const float* grad, float* exp_avg, float* exp_avg_sq,
-                                     float* target_params, int64_t step, double lr, double beta1, double beta2, double eps,
-                                     float max_norm, float grad_scale, int32_t hard_update, float tau, float* scratch,
-                                     float* gnorm_out, void* stream) {
-    MARL_REQUIRE(n > 0 && params && grad && exp_avg && exp_avg_sq && scratch, "dqn_clip_adam: NULL pointer");
-    MARL_REQUIRE(step >= 1, "dqn_clip_adam: step must be >= 1");
-    const int nblocks = (int)((n + 255) / 256);
-    hipStream_t st = (hipStream_t)stream;
+static AdamArgs adam_args(int64_t step, double lr, double beta1, double beta2, double eps, float max_norm, float grad_scale,
+                          int32_t hard_update, float tau) {
     AdamArgs a;
     // python-float (fp64) scalars exactly as torch.optim.adam._single_tensor_adam forms them
     const double bc1 = 1.0 - pow(beta1, (double)step);
@@ -249,6 +249,71 @@ extern "C" int marlhip_dqn_clip_adam(int64_t n, float* params, const float* grad
     a.beta2 = (float)beta2;
     a.w2 = (float)(1.0 - beta2);
     a.eps = (float)eps; a.max_norm = max_norm; a.grad_scale = grad_scale; a.tau = tau; a.hard_update = hard_update;
+    return a;
+}
+
+// marlhip_idqn_update_n for the LDS-resident-pack learner shapes (hidden 64, IDQN / VDN): per update 3 launches instead of 4 -
+// loss/grad (packs kept current by the previous update's Adam launch), reduce + clip-norm partials, clip + Adam + target + packs.
+// *handled = false: not such a learner, the caller runs the generic loop.
+namespace marl {
+int idqn_update_n_fused(const marlhip_idqn_learner* L, int32_t n_updates, int32_t length, uint64_t seed, uint32_t counter0,
+                        int64_t* adam_step, int64_t* updates, int64_t* last_target_update, void* stream, bool* handled) {
+    *handled = false;
+    if (getenv("MARLHIP_NO_FUSED_EPILOGUE") != nullptr || (L->mode != 0 && L->mode != 1) || L->net.hidden > 64) return 0;
+    if (agent_map_validate(&L->net) != 0) return -1;
+    marlhip_batch bt = {};
+    bt.obss = L->obss; bt.actions = L->actions; bt.rewards = L->rewards; bt.dones = L->dones; bt.filled = L->filled;
+    bt.max_len = L->rs.max_len; bt.batch = L->batch;
+    const double tui = L->target_update_interval_or_tau;
+    const int np = marlhip_net_nparams(&L->net);
+    if (np < 0) return -1;
+    UpdFuse fuse = {};
+    fuse.packs_valid = 0;
+    fuse.params_rw = L->params; fuse.target_rw = L->target; fuse.exp_avg = L->exp_avg; fuse.exp_avg_sq = L->exp_avg_sq;
+    fuse.gnorm = L->gnorm;
+    for (int u = 0; u < n_updates; ++u) {
+        const bool hard = tui > 1.0 && (double)(*updates + 1 - *last_target_update) >= tui;
+        const float tau = tui < 1.0 ? (float)tui : 0.f;
+        fuse.adam = adam_args(*adam_step + 1, L->lr, L->beta1, L->beta2, L->eps, L->max_norm, 1.0f, hard ? 1 : 0, tau);
+        ReplaySrc src;
+        src.rb = L->rb; src.idx = nullptr; src.idx_out = L->idx; src.seed = seed; src.counter = counter0 + (uint32_t)u; src.length = length;
+        if (L->materialise_batch) {
+            const int rc = marlhip_replay_sample(&L->rs, &L->rb, nullptr, L->batch, length, seed, counter0 + (uint32_t)u, L->idx, L->obss,
+                                                 L->actions, L->rewards, L->dones, L->filled, stream);
+            if (rc < 0) return rc;
+        }
+        bool found = false;
+        int rc = 0;
+        fuse.sumsq = L->scratch;  // clip-norm partials: ceil(n / 64) floats (marlhip_idqn_learner.scratch)
+        for (auto part : {&lossgrad_part_h64_fused, &lossgrad_part_h64_oid_fused}) {
+            rc = part(&L->net, L->params, L->target, &bt, L->materialise_batch ? nullptr : &src, L->gamma, L->double_q, L->mode,
+                      L->workspace, L->workspace_bytes, L->grad, L->loss, (hipStream_t)stream, &fuse, &found);
+            if (found) break;
+        }
+        if (!found) {
+            if (u == 0) return 0;  // not a fused-kernel shape: nothing was enqueued
+            set_error("idqn_update_n: fused epilogue lost its shape");
+            return -1;
+        }
+        if (rc < 0) return rc;
+        *updates += 1;
+        *adam_step += 1;
+        if (hard) *last_target_update = *updates;
+    }
+    *handled = true;
+    return 0;
+}
+}  // namespace marl
+
+extern "C" int marlhip_dqn_clip_adam(int64_t n, float* params, const float* grad, float* exp_avg, float* exp_avg_sq,
+                                     float* target_params, int64_t step, double lr, double beta1, double beta2, double eps,
+                                     float max_norm, float grad_scale, int32_t hard_update, float tau, float* scratch,
+                                     float* gnorm_out, void* stream) {
+    MARL_REQUIRE(n > 0 && params && grad && exp_avg && exp_avg_sq && scratch, "dqn_clip_adam: NULL pointer");
+    MARL_REQUIRE(step >= 1, "dqn_clip_adam: step must be >= 1");
+    const int nblocks = (int)((n + 255) / 256);
+    hipStream_t st = (hipStream_t)stream;
+    const AdamArgs a = adam_args(step, lr, beta1, beta2, eps, max_norm, grad_scale, hard_update, tau);
     if (n <= 32768) {  // one workgroup does norm + clip + Adam + target: one launch, best while the block is small
         hipLaunchKernelGGL(adam_fused_kernel, dim3(1), dim3(1024), 0, st, n, params, grad, exp_avg, exp_avg_sq, target_params, a,
                            gnorm_out);

@@ -29,19 +29,27 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_wave_barrier();
 }
 
-// C-layout registers regs[MT] -> LDS tile[h][16 rows]
-template <int MT>
-__device__ __forceinline__ void tile_write(float* tile, const f4 (&regs)[MT], int g, int j) {
+// C-layout registers regs[MT] -> LDS tile[h][TS] (row j of hidden unit h at h * TS + j).  TS = 24 keeps the ds_read_b128 of
+// tile_read conflict-free (lane (g, i) reads 4 rows of unit 16mt+i: with TS = 16 the 16 lanes of a read group land 2-way on the
+// same banks, with 24 they spread over all 64) and the ds_write_b32 of tile_write at 2-way, which costs nothing extra.
+template <int TS, int MT>
+__device__ __forceinline__ void tile_write_s(float* tile, const f4 (&regs)[MT], int g, int j) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) tile[(16 * mt + 4 * g + r) * 16 + j] = regs[mt][r];
+        for (int r = 0; r < 4; ++r) tile[(16 * mt + 4 * g + r) * TS + j] = regs[mt][r];
 }
 
 // lane (g,i) reads tile[16mt+i][4g..4g+3]: operand registers of k-steps ks=0..3 (row 4g+ks)
-__device__ __forceinline__ f4 tile_read(const float* tile, int mt, int g, int i) {
-    return *reinterpret_cast<const f4*>(tile + (16 * mt + i) * 16 + 4 * g);
+template <int TS>
+__device__ __forceinline__ f4 tile_read_s(const float* tile, int mt, int g, int i) {
+    return *reinterpret_cast<const f4*>(tile + (16 * mt + i) * TS + 4 * g);
 }
+
+// stride-16 forms (the register-resident kernels of dqn_update_tp.h, gru_bwd.h, qmix.h keep unpadded tiles)
+template <int MT>
+__device__ __forceinline__ void tile_write(float* tile, const f4 (&regs)[MT], int g, int j) { tile_write_s<16, MT>(tile, regs, g, j); }
+__device__ __forceinline__ f4 tile_read(const float* tile, int mt, int g, int i) { return tile_read_s<16>(tile, mt, g, i); }
 
 __device__ __forceinline__ float sum16(float v) {  // over the 16 lanes j of one g
     v += __shfl_xor(v, 1);
@@ -53,13 +61,20 @@ __device__ __forceinline__ float sum16(float v) {  // over the 16 lanes j of one
 
 template <class S>
 struct UpdLds {
-    static constexpr int TILE = 16 * S::H;                    // one [H][16] transpose tile
-    static constexpr int PER_WAVE = 4 * TILE + 256;           // h2, h1, dH2, dH1 transpose tiles + dQ tile
     static constexpr int oC = 0, oT = S::NFWD, oB = 2 * S::NFWD, oTiles = oB + S::NBWD;
     static constexpr int REC = S::NPARAM + 2;                 // partial record: grads, loss, n_filled
     static constexpr int FOLD = S::NPARAM + (2 * S::H + 18) * 16;  // per-wave fold region (weights + bias/loss strips)
+    // per wave: [h2 tile, later the dH1 tile][h1 tile][dH2 tile][dQ tile]; the dH1 tile re-uses the h2 tile, whose only reader
+    // (the dW3 operands) has retired long before dH1 exists
+    static constexpr int per_wave(int ts) { return 3 * ts * S::H + 16 * ts; }
+    static constexpr int total_ts(int waves, int ts) {
+        return (oTiles + waves * per_wave(ts)) > waves * FOLD ? (oTiles + waves * per_wave(ts)) : waves * FOLD;
+    }
+    static constexpr int TS = total_ts(4, 24) * 4 <= 160 * 1024 ? 24 : 16;  // padded tiles when they fit next to the packs
+    static constexpr int TILE = TS * S::H;
+    static constexpr int PER_WAVE = per_wave(TS);
     // floats: packs + tiles during the walk, the per-wave fold regions (overlaying them) in the epilogue
-    static constexpr int total(int waves) { return (oTiles + waves * PER_WAVE) > waves * FOLD ? (oTiles + waves * PER_WAVE) : waves * FOLD; }
+    static constexpr int total(int waves) { return total_ts(waves, TS); }
     static constexpr bool FITS = total(4) * 4 <= 160 * 1024;  // else the shape runs on the register-resident kernels below
 };
 
@@ -122,17 +137,50 @@ struct MixBufs {
     const float* dout;  // MODE 4: [P][T][B][A] external gradient w.r.t. EVERY network output (actor-critic learners)
 };
 
+template <int I>
+struct IntC { static constexpr int value = I; };
+
+// MARL_STEP_PROF=1 (profiling builds only, scripts/build_variants.py): s_memtime at the region boundaries of a step, summed per
+// region and added to prof[0..5] by every wave: 0 row loads + masks, 1 critic forward, 2 target forward (+ TD, tile writes),
+// 3 dH2 + dW3, 4 dH1 (+ bootstrap), 5 dW2 + dW1.  Reading the counter drains the LDS queue, so the instrumented kernel runs a
+// few percent slower than the product build.
+#ifndef MARL_STEP_PROF
+#define MARL_STEP_PROF 0
+#endif
+#if MARL_STEP_PROF
+#define MARL_TS_BEGIN unsigned long long ts_ = __builtin_readcyclecounter();
+#define MARL_TS(k)                                                      \
+    {                                                                   \
+        const unsigned long long now_ = __builtin_readcyclecounter();   \
+        sp[k] += now_ - ts_;                                            \
+        ts_ = now_;                                                     \
+    }
+#else
+#define MARL_TS_BEGIN
+#define MARL_TS(k)
+#endif
+
+// Schedule of one time step (what runs in the shadow of which MFMAs; one wave per SIMD, so everything that is not an MFMA has
+// to hide behind one):
+//   A  critic forward(t)         96 MFMA   | row loads of step t-1 in flight
+//   B  target forward(t)         96 MFMA   | TD error of transition t -> dQ, tile writes (dQ, h2, h1), first backward operands
+//   C  backward(t)              176 MFMA   | bootstrap value for transition t-1 (argmax / gather on permlane swaps), relu masks
+//                                          | and tile writes of dH2 / dH1 next to dW3 / the first half of dW2
+// The first step of a chunk (t = t1) has no transition (A, B, bootstrap), the last (t = t0) needs no target (A, TD, C).
 template <class S, int WAVES, bool REPLAY, int MODE>
 __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dqn_lossgrad_kernel(const float* __restrict__ packs, marlhip_batch bt, ReplaySrc rs,
                                                                  MixBufs mix, float gamma, int double_q, int n_chunks,
                                                                  float* __restrict__ partials, unsigned long long* prof) {
     using L = UpdLds<S>;
-    constexpr int MT = S::MT, NT1 = S::DP / 16, D = S::D, H = S::H, A = S::A;
+    constexpr int MT = S::MT, NT1 = S::DP / 16, D = S::D, H = S::H, A = S::A, TS = L::TS, N1 = S::KS1 / 4;
     constexpr int UPD_BLOCK = 64 * WAVES;
+    constexpr bool HAS_TGT = (MODE == 0 || MODE == 1);  // target forward + bootstrap value in this pass
+    constexpr bool HAS_BWD = (MODE != 1);               // backward of the row block in this pass
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, j = lane & 15;
     const int p = blockIdx.y;
     const int T = bt.max_len, B = bt.batch;
+    const unsigned long long t_begin = prof ? __builtin_readcyclecounter() : 0;
 
     {   // the three packs were laid out by dqn_pack_kernel exactly as LDS wants them: 16-byte linear copy
         constexpr int TOT4 = (2 * S::NFWD + S::NBWD) / 4;
@@ -144,13 +192,18 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dqn_lossgrad_kernel(con
 
     const float* cpk = lds + L::oC;
     const float* tpk = lds + L::oT;
+    FwdHead<S> chead, thead;
+    if (FwdHead<S>::RESIDENT) {
+        chead.load(cpk, lane);
+        if (HAS_TGT) thead.load(tpk, lane);
+    }
     const f4* T3 = reinterpret_cast<const f4*>(lds + L::oB + S::pT3);
     const f4* T2 = reinterpret_cast<const f4*>(lds + L::oB + S::pT2);
     float* TH2 = lds + L::oTiles + wave * L::PER_WAVE;
     float* TH1 = TH2 + L::TILE;
     float* TG2 = TH1 + L::TILE;
-    float* TG1 = TG2 + L::TILE;
-    float* TQ = TG1 + L::TILE;
+    float* TQ = TG2 + L::TILE;
+    float* TG1 = TH2;  // alias (see UpdLds)
 
     const int P = gridDim.y;
     // row (t, b) of agent p = obss + p * agent stride + (t * B + b) * row stride (defaults: the dqn/train.py Batch)
@@ -171,15 +224,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dqn_lossgrad_kernel(con
         for (int b = 0; b < NT1; ++b) dW1[a][b] = zero4;
     }
     float loss_acc = 0.f, nfill_acc = 0.f;
-    // optional per-phase cycle accounting (MARLHIP_PROF=1): s_memtime deltas summed per phase
-    unsigned long long pc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pt = 0;
-    const unsigned long long t_begin = prof ? __builtin_readcyclecounter() : 0;
-#define MARL_PHASE(k)                                         \
-    if (prof != nullptr) {                                    \
-        const unsigned long long now_ = __builtin_readcyclecounter(); \
-        pc[k] += now_ - pt;                                   \
-        pt = now_;                                            \
-    }
+#if MARL_STEP_PROF
+    unsigned long long sp[6] = {0, 0, 0, 0, 0, 0};
+#endif
 
     const unsigned long long t_loop_begin = prof ? __builtin_readcyclecounter() : 0;
     const int ngroups = (B + 15) >> 4;
@@ -210,6 +257,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dqn_lossgrad_kernel(con
             float bx[NT1][4];  // dW1 B operand:     X[row 4g+ks][16nt+j]
             int a_sel;
             float rw, dn, fl;
+            int dn_raw, fl_raw;  // replay form: the done / filled BYTES as loaded; turned into 0.f / 1.f by mask_rows one step later -
+                                 // converting them in load_rows would make every step wait for loads it has only just issued
             float dq, lr;      // MODE 2: external dL/dchosen and per-row loss
             float dqv[4];      // MODE 4: external dL/d(output 4g+r)
             float mk[4];       // batch.action_mask of outputs 4g+r at this observation (1 = allowed); all ones without masks
@@ -234,8 +283,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dqn_lossgrad_kernel(con
                     }
                 R.a_sel = (int)rs.rb.act[((size_t)ej * P + p) * T + tt];
                 R.rw = rs.rb.rew[((size_t)ej * P + p) * T + tt];
-                R.dn = rs.rb.done[(size_t)ej * (T + 1) + tt + 1] ? 1.f : 0.f;
-                R.fl = rs.rb.filled[(size_t)ej * T + tt] ? 1.f : 0.f;
+                R.dn_raw = rs.rb.done[(size_t)ej * (T + 1) + tt + 1];
+                R.fl_raw = rs.rb.filled[(size_t)ej * T + tt];
             } else {
                 const float* xrow = obs_p + ((size_t)t * B + bj) * obs_rs;
 #pragma unroll
@@ -280,70 +329,121 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dqn_lossgrad_kernel(con
             for (int nt = 0; nt < NT1; ++nt)
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) R.bx[nt][ks] = (b0 + 4 * g + ks < B && 16 * nt + j < D) ? R.bx[nt][ks] : 0.f;
+            if (REPLAY) {
+                R.dn = R.dn_raw ? 1.f : 0.f;
+                R.fl = R.fl_raw ? 1.f : 0.f;
+            }
             R.fl = rowok ? R.fl : 0.f;
         };
-        Rows cur;
-        load_rows(t1, cur);
-        for (int t = t1; t >= t0; --t) {
-            Rows nxt;
-            if (prof != nullptr) pt = __builtin_readcyclecounter();
-            load_rows(t > t0 ? t - 1 : t0, nxt);  // unconditional (the last step re-reads its own rows)
+
+        // FIRST: t == t1, no transition to learn from (forwards + bootstrap only); LAST: t == t0, nobody needs its bootstrap value.
+        // cur: rows of step t (loaded one step ago); nxt: receives the rows of step t-1.  The two buffers alternate between
+        // steps (the walk is unrolled by two), so no register copies - and no waits for loads that were only just issued -
+        // sit between steps.
+        auto step = [&](auto first_c, auto last_c, const int t, Rows& cur, Rows& nxt) {
+            constexpr bool FIRST = decltype(first_c)::value != 0, LAST = decltype(last_c)::value != 0;
+            constexpr bool DO_TGT = HAS_TGT && !LAST, DO_BWD = HAS_BWD && !FIRST, DO_PUB = MODE == 1 && !FIRST;
+            MARL_TS_BEGIN
+            if (!LAST) load_rows(t - 1, nxt);
             mask_rows(cur);
-            MARL_PHASE(0)
-            f4 h1[MT], h2[MT], q, tq;
-            if (MODE != 2 && MODE != 4 && t > t0) mlp_forward_p<S, true>(cpk, tpk, lane, cur.x, h1, h2, q, tq);  // target value feeds transition t-1
-            else mlp_forward_p<S, false>(cpk, tpk, lane, cur.x, h1, h2, q, tq);
-            MARL_PHASE(1)
-            if (MODE == 1 && t < t1) {
-                // qsel pass: publish Q_p(o_t)[a_t] and (agent 0) the transition's scalars for the mixer
-                const float ch = gather_rows(q, lane, cur.a_sel);
-                if (g == 0 && rowok) {
-                    mix.chosen[((size_t)p * T + t) * B + bj] = ch;
-                    if (mix.rew_all != nullptr) mix.rew_all[((size_t)p * T + t) * B + bj] = cur.rw;
-                    if (p == 0) {
-                        mix.r0[(size_t)t * B + bj] = cur.rw;
-                        mix.dn[(size_t)t * B + bj] = cur.dn;
-                        mix.fl[(size_t)t * B + bj] = cur.fl;
+            MARL_TS(0)
+            f4 h1[MT], h2[MT], q, tq = zero4;
+            // ---- A: critic forward
+            mlp_forward_f<S>(cpk, chead, lane, cur.x, h1, h2, q, [](int) {});
+            MARL_TS(1)
+            // ---- the critic's epilogue, emitted as fillers of the target forward's MFMA groups (or on its own without one)
+            f4 dQ[1] = {zero4};
+            f4 t3[MT], t2[2][MT], aQ = zero4, bH2[MT];
+            auto epilogue = [&](int k) {
+                if (k == 0) {
+                    if (DO_PUB) {
+                        // qsel pass: publish Q_p(o_t)[a_t] and (agent 0) the transition's scalars for the mixer
+                        const float ch = gather_rows_pl(q, lane, cur.a_sel);
+                        if (g == 0 && rowok) {
+                            mix.chosen[((size_t)p * T + t) * B + bj] = ch;
+                            if (mix.rew_all != nullptr) mix.rew_all[((size_t)p * T + t) * B + bj] = cur.rw;
+                            if (p == 0) {
+                                mix.r0[(size_t)t * B + bj] = cur.rw;
+                                mix.dn[(size_t)t * B + bj] = cur.dn;
+                                mix.fl[(size_t)t * B + bj] = cur.fl;
+                            }
+                        }
+                    }
+                    if (DO_BWD) {
+                        // ---- TD error of transition t (model.py:129,152,160-163)
+                        const int a_sel = cur.a_sel;
+                        const float fl = cur.fl;
+                        float dqs;
+                        if (MODE == 0) {
+                            const float y = cur.rw + gamma * tq_next * (1.f - cur.dn);
+                            const float delta = gather_rows_pl(q, lane, a_sel) - y;
+                            loss_acc += fl * delta * delta;  // every g lane of row j carries the same sums; the fold reads g == 0
+                            nfill_acc += fl;
+                            dqs = 2.f * fl * delta;
+                        } else {  // the mixer already formed dL/dchosen; agent 0's rows carry the loss bookkeeping
+                            dqs = rowok ? cur.dq : 0.f;
+                            const bool book = p == 0 && rowok;
+                            loss_acc += book ? cur.lr : 0.f;
+                            nfill_acc += book ? fl : 0.f;
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            if (MODE == 4) dQ[0][r] = (rowok && 4 * g + r < A) ? cur.dqv[r] : 0.f;
+                            else dQ[0][r] = (4 * g + r == a_sel) ? dqs : 0.f;
+                        }
+                        db3 += dQ[0];
                     }
                 }
-            }
-            if (MODE != 1 && t < t1) {
-                // ---- TD error of transition t (model.py:129,152,160-163)
-                const int a_sel = cur.a_sel;
-                const float fl = cur.fl;
-                float dqs;
-                if (MODE == 0) {
-                    const float y = cur.rw + gamma * tq_next * (1.f - cur.dn);
-                    const float delta = gather_rows(q, lane, a_sel) - y;
-                    if (g == 0) { loss_acc += fl * delta * delta; nfill_acc += fl; }
-                    dqs = 2.f * fl * delta;
-                } else {  // the mixer already formed dL/dchosen; agent 0's rows carry the loss bookkeeping
-                    dqs = rowok ? cur.dq : 0.f;
-                    if (g == 0 && p == 0 && rowok) { loss_acc += cur.lr; nfill_acc += fl; }
-                }
-                f4 dQ[1];
+                if (DO_BWD) {
+                    if (k == 1) {
+                        wave_lds_fence();  // the previous step's tile reads precede these writes in program order
+                        tile_write_s<TS, 1>(TQ, dQ, g, j);
+                        tile_write_s<TS, MT>(TH2, h2, g, j);
+                    }
+                    if (k == 2) tile_write_s<TS, MT>(TH1, h1, g, j);
+                    if (k == 3) {
+                        wave_lds_fence();
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (MODE == 4) dQ[0][r] = (rowok && 4 * g + r < A) ? cur.dqv[r] : 0.f;
-                    else dQ[0][r] = (4 * g + r == a_sel) ? dqs : 0.f;
-                }
-                MARL_PHASE(2)
-                // ---- backward of row block t.  Phases are fenced with sched_barrier so that every LDS
-                // operand (weight packs, transposed tiles) is requested >= 16 MFMAs before its first use and
-                // every transposed tile is read >= 16 MFMAs after it was written.
-                f4 t3[MT], t2[2][MT];
+                        for (int mt = 0; mt < MT; ++mt) {
+                            t3[mt] = T3[mt * 64 + lane];
+                            t2[0][mt] = T2[(mt * MT + 0) * 64 + lane];
+                        }
+                        aQ = tile_read_s<TS>(TQ, 0, g, j);
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    t3[mt] = T3[mt * 64 + lane];
-                    t2[0][mt] = T2[(mt * MT + 0) * 64 + lane];
+                        for (int nt = 0; nt < MT; ++nt) bH2[nt] = tile_read_s<TS>(TH2, nt, g, j);
+                    }
                 }
-                wave_lds_fence();
-                tile_write<1>(TQ, dQ, g, j);
-                tile_write<MT>(TH2, h2, g, j);
-                tile_write<MT>(TH1, h1, g, j);
-                db3 += dQ[0];
+            };
+            // ---- B: target forward (its hidden activations are scratch)
+            if (DO_TGT) {
+                f4 g1[MT], g2[MT];
+                static_assert(N1 + MT + 1 >= 4, "epilogue stages need four MFMA groups");
+                mlp_forward_f<S>(tpk, thead, lane, cur.x, g1, g2, tq, epilogue);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) epilogue(k);
                 __builtin_amdgcn_sched_barrier(0);
-                // P1: dH2^T = W3^T dQ^T
+            }
+            MARL_TS(2)
+            // ---- bootstrap value for transition t-1 (model.py:132-145): a filler of the backward's MFMA groups
+            auto bootstrap = [&]() {
+                if (!REPLAY && bt.action_mask != nullptr) {  // model.py:136-142: disallowed actions of o_t read as -1e8
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (cur.mk[r] == 0.f) { q[r] = -1e8f; tq[r] = -1e8f; }
+                    }
+                }
+                f4 qsel;  // Double-Q: the online network picks the action (model.py:138-145); a select, not a branch
+#pragma unroll
+                for (int r = 0; r < 4; ++r) qsel[r] = double_q ? q[r] : tq[r];
+                const int a_p = argmax_rows_pl<A>(qsel, lane);
+                tq_next = gather_rows_pl(tq, lane, a_p);
+                if (MODE == 1 && g == 0 && rowok) mix.tqsel[((size_t)p * T + (t - 1)) * B + bj] = tq_next;
+            };
+            if (DO_BWD) {
+                // ---- C: backward of row block t.  Regions are fenced with sched_barrier; inside a region the listed VALU / LDS
+                // work has no dependence on the region's MFMAs, so it issues in their shadow.
+                // C0: dH2^T = W3^T dQ^T
                 f4 dH2[MT];
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) dH2[mt] = zero4;
@@ -352,84 +452,77 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dqn_lossgrad_kernel(con
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) dH2[mt] = MARL_MFMA(t3[mt][r], dQ[0][r], dH2[mt]);
                 __builtin_amdgcn_sched_barrier(0);
-                MARL_PHASE(3)
-                // P2: relu mask, db2, publish dH2 tile; request dW3 operands and the next W2^T step
+                // C1: relu mask, db2, publish the dH2 tile | dW3[a][h2] += dQ^T H2; request the second W2^T step and the h1 tile
+                f4 bH1[MT], aG2[MT];
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) dH2[mt][r] = h2[mt][r] > 0.f ? dH2[mt][r] : 0.f;
                     db2[mt] += dH2[mt];
                 }
-                tile_write<MT>(TG2, dH2, g, j);
-                wave_lds_fence();
-                const f4 aQ = tile_read(TQ, 0, g, j);
-                f4 bH2[MT];
-#pragma unroll
-                for (int nt = 0; nt < MT; ++nt) bH2[nt] = tile_read(TH2, nt, g, j);
+                tile_write_s<TS, MT>(TG2, dH2, g, j);
 #pragma unroll
                 for (int m1 = 0; m1 < MT; ++m1) t2[1][m1] = T2[(m1 * MT + 1) * 64 + lane];
+#pragma unroll
+                for (int nt = 0; nt < MT; ++nt) bH1[nt] = tile_read_s<TS>(TH1, nt, g, j);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                    for (int nt = 0; nt < MT; ++nt) dW3[nt] = MARL_MFMA(aQ[ks], bH2[nt][ks], dW3[nt]);
                 __builtin_amdgcn_sched_barrier(0);
-                MARL_PHASE(4)
-                // P3..: dH1^T = W2^T dH2^T in MT steps (m2), dW3 slotted after the first step
-                f4 dH1[MT], bH1[MT], aG2[MT];
+                wave_lds_fence();
+                MARL_TS(3)
+                // C2..: dH1^T = W2^T dH2^T in MT steps (m2); the bootstrap value rides in the first
+                f4 dH1[MT];
 #pragma unroll
                 for (int m1 = 0; m1 < MT; ++m1) dH1[m1] = zero4;
 #pragma unroll
                 for (int m2 = 0; m2 < MT; ++m2) {
                     const int cb = m2 & 1;
+                    if (m2 == 0) {
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) aG2[mt] = tile_read_s<TS>(TG2, mt, g, j);
+                        if (DO_TGT) bootstrap();
+                    }
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
 #pragma unroll
                         for (int m1 = 0; m1 < MT; ++m1) dH1[m1] = MARL_MFMA(t2[cb][m1][r], dH2[m2][r], dH1[m1]);
                     __builtin_amdgcn_sched_barrier(0);
-                    if (m2 == 0) {
-                        // dW3[a][h2] += dQ^T H2   (operands requested in P2)
-#pragma unroll
-                        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                            for (int nt = 0; nt < MT; ++nt) dW3[nt] = MARL_MFMA(aQ[ks], bH2[nt][ks], dW3[nt]);
-#pragma unroll
-                        for (int nt = 0; nt < MT; ++nt) bH1[nt] = tile_read(TH1, nt, g, j);
-                    }
                     if (m2 + 2 < MT) {
 #pragma unroll
                         for (int m1 = 0; m1 < MT; ++m1) t2[cb][m1] = T2[(m1 * MT + m2 + 2) * 64 + lane];
                     }
-                    if (m2 == MT - 2) {
-#pragma unroll
-                        for (int mt = 0; mt < MT; ++mt) aG2[mt] = tile_read(TG2, mt, g, j);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
                 }
-                MARL_PHASE(5)
-                // relu mask, db1, publish dH1 tile
+                MARL_TS(4)
+                // C6: relu mask, db1, publish the dH1 tile (over the retired h2 tile) | first half of dW2[h2][h1] += dH2^T H1
 #pragma unroll
                 for (int m1 = 0; m1 < MT; ++m1) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) dH1[m1][r] = h1[m1][r] > 0.f ? dH1[m1][r] : 0.f;
                     db1[m1] += dH1[m1];
                 }
-                tile_write<MT>(TG1, dH1, g, j);
-                wave_lds_fence();
-                __builtin_amdgcn_sched_barrier(0);
-                // dW2[h2][h1] += dH2^T H1 (first half), request the dH1 tile under it, then the rest + dW1
-                f4 aG1[MT];
+                tile_write_s<TS, MT>(TG1, dH1, g, j);
 #pragma unroll
                 for (int mt = 0; mt < MT / 2; ++mt)
 #pragma unroll
                     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
                         for (int nt = 0; nt < MT; ++nt) dW2[mt][nt] = MARL_MFMA(aG2[mt][ks], bH1[nt][ks], dW2[mt][nt]);
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) aG1[mt] = tile_read(TG1, mt, g, j);
                 __builtin_amdgcn_sched_barrier(0);
+                wave_lds_fence();
+                // C7: request the dH1 tile | second half of dW2
+                f4 aG1[MT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) aG1[mt] = tile_read_s<TS>(TG1, mt, g, j);
 #pragma unroll
                 for (int mt = MT / 2; mt < MT; ++mt)
 #pragma unroll
                     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
                         for (int nt = 0; nt < MT; ++nt) dW2[mt][nt] = MARL_MFMA(aG2[mt][ks], bH1[nt][ks], dW2[mt][nt]);
-                // dW1[h1][d] += dH1^T X   (B operand prefetched from global one step ahead)
+                __builtin_amdgcn_sched_barrier(0);
+                // C8: dW1[h1][d] += dH1^T X   (B operand prefetched from global one step ahead)
 #pragma unroll
                 for (int nt = 0; nt < NT1; ++nt)
 #pragma unroll
@@ -437,27 +530,38 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dqn_lossgrad_kernel(con
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt) dW1[mt][nt] = MARL_MFMA(aG1[mt][ks], cur.bx[nt][ks], dW1[mt][nt]);
                 __builtin_amdgcn_sched_barrier(0);
+                MARL_TS(5)
+            } else if (DO_TGT) {
+                bootstrap();
             }
-            MARL_PHASE(6)
-            if (MODE != 2 && MODE != 4 && t > t0) {
-                // ---- bootstrap value for transition t-1 (model.py:132-145)
-                if (!REPLAY && bt.action_mask != nullptr) {  // model.py:136-142: disallowed actions of o_t read as -1e8
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        if (cur.mk[r] == 0.f) { q[r] = -1e8f; tq[r] = -1e8f; }
-                    }
-                }
-                const int a_p = double_q ? argmax_rows<A>(q, lane) : argmax_rows<A>(tq, lane);
-                tq_next = gather_rows(tq, lane, a_p);
-                if (MODE == 1 && g == 0 && rowok) mix.tqsel[((size_t)p * T + (t - 1)) * B + bj] = tq_next;
+        };
+
+        Rows ra, rb;
+        if (HAS_TGT) {
+            load_rows(t1, ra);
+            step(IntC<1>{}, IntC<0>{}, t1, ra, rb);
+            int t = t1 - 1;
+            for (; t - 1 > t0; t -= 2) {
+                step(IntC<0>{}, IntC<0>{}, t, rb, ra);
+                step(IntC<0>{}, IntC<0>{}, t - 1, ra, rb);
             }
-            cur = nxt;
-            MARL_PHASE(7)
+            if (t > t0) {
+                step(IntC<0>{}, IntC<0>{}, t, rb, ra);
+                step(IntC<0>{}, IntC<1>{}, t0, ra, rb);
+            } else {
+                step(IntC<0>{}, IntC<1>{}, t0, rb, ra);
+            }
+        } else {  // no target in this pass: every step is critic forward + backward; rows t1-1 .. t0
+            load_rows(t1 - 1, ra);
+            for (int t = t1 - 1; t >= t0; --t) {
+                load_rows(t > t0 ? t - 1 : t0, rb);
+                step(IntC<0>{}, IntC<1>{}, t, ra, rb);
+                ra = rb;
+            }
         }
     }
 
     const unsigned long long t_loop_end = prof ? __builtin_readcyclecounter() : 0;
-#undef MARL_PHASE
     if (MODE == 1) return;  // forward-only pass: nothing to fold
     // ---- fold the waves through LDS and write ONE partial record per workgroup.  Every wave stores its
     // accumulators into its own LDS region in parallel (weights at their canonical index, bias / loss
@@ -523,19 +627,22 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dqn_lossgrad_kernel(con
     }
     if (prof != nullptr && lane == 0) {
         const unsigned long long t_end = __builtin_readcyclecounter();
-        pc[8] = t_loop_begin - t_begin;   // pack staging
-        pc[9] = t_loop_end - t_loop_begin;  // whole task loop
-        pc[10] = t_end - t_loop_end;      // fold + record write
-        pc[11] = t_end - t_begin;
+#if MARL_STEP_PROF
 #pragma unroll
-        for (int k = 0; k < 12; ++k) atomicAdd(&prof[k], pc[k]);
+        for (int k = 0; k < 6; ++k) atomicAdd(&prof[k], sp[k]);
+#endif
+        atomicAdd(&prof[8], t_loop_begin - t_begin);    // pack staging
+        atomicAdd(&prof[9], t_loop_end - t_loop_begin);  // whole task loop
+        atomicAdd(&prof[10], t_end - t_loop_end);        // fold + record write
+        atomicAdd(&prof[11], t_end - t_begin);
     }
 }
 
 // grad[p][i] = (sum over the agent's records) / n_filled ; loss = sum of all loss fields / n_filled.
 // n_filled comes from agent 0's records only (every agent sees the same filled mask).
-static __global__ __launch_bounds__(256) void dqn_reduce_kernel(const float* __restrict__ partials, int P, int nwg, int nparam,
-                                                         AgentMap am, float* __restrict__ grad, float* __restrict__ loss) {
+// sumsq_out (may be null): per-block sum of squares of the block's 64 gradient values, for the clip norm of adam_pack_kernel
+__device__ __forceinline__ void dqn_reduce_body(const float* __restrict__ partials, int P, int nwg, int nparam, const AgentMap& am,
+                                                float* __restrict__ grad, float* __restrict__ loss, float* __restrict__ sumsq_out) {
     __shared__ float s_red[8];
     const int rec = nparam + 2;
     // n_filled (agent 0's records) and the loss sum (all records): strided loads + fixed-order tree
@@ -575,11 +682,32 @@ static __global__ __launch_bounds__(256) void dqn_reduce_kernel(const float* __r
     }
     s_part[slice][l64] = acc;
     __syncthreads();
-    if (slice == 0 && i < am.nblk * nparam) grad[i] = ((s_part[0][l64] + s_part[1][l64]) + (s_part[2][l64] + s_part[3][l64])) / nf;
+    float gv = 0.f;
+    if (slice == 0 && i < am.nblk * nparam) {
+        gv = ((s_part[0][l64] + s_part[1][l64]) + (s_part[2][l64] + s_part[3][l64])) / nf;
+        grad[i] = gv;
+    }
+    if (sumsq_out != nullptr && slice == 0) {  // wave 0 holds the block's 64 values: fixed-order butterfly
+        float sq = gv * gv;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) sq += __shfl_xor(sq, off);
+        if (l64 == 0) sumsq_out[blockIdx.x] = sq;
+    }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         loss[0] = ls / nf;
         loss[1] = nf;
     }
+}
+
+static __global__ __launch_bounds__(256) void dqn_reduce_kernel(const float* __restrict__ partials, int P, int nwg, int nparam,
+                                                         AgentMap am, float* __restrict__ grad, float* __restrict__ loss) {
+    dqn_reduce_body(partials, P, nwg, nparam, am, grad, loss, nullptr);
+}
+
+static __global__ __launch_bounds__(256) void dqn_reduce_sq_kernel(const float* __restrict__ partials, int P, int nwg, int nparam,
+                                                            AgentMap am, float* __restrict__ grad, float* __restrict__ loss,
+                                                            float* __restrict__ sumsq_out) {
+    dqn_reduce_body(partials, P, nwg, nparam, am, grad, loss, sumsq_out);
 }
 
 // ---- clip_grad_norm_ + Adam + target update (model.py:169-196) -----------------------------
@@ -698,6 +826,61 @@ static __global__ __launch_bounds__(1024) void adam_fused_kernel(int64_t n, floa
             if (a.hard_update) target[i] = pi;
             else if (a.tau > 0.f) target[i] = (1.f - a.tau) * target[i] + a.tau * pi;
         }
+    }
+}
+
+// clip + Adam + target update as adam_kernel, and the step's parameter values written straight into the MFMA packs the next
+// loss/grad launch stages (marlhip_idqn_update_n keeps the packs alive between updates, so dqn_pack_kernel runs once per call
+// instead of once per update).  sumsq: per-block partials of dqn_reduce_sq_kernel (nsq of them).
+template <class S>
+static __global__ __launch_bounds__(256) void adam_pack_kernel(int n, int nsq, float* __restrict__ params, const float* __restrict__ grad,
+                                                        float* __restrict__ m, float* __restrict__ v, float* __restrict__ target,
+                                                        AdamArgs a, const float* __restrict__ sumsq, float* __restrict__ gnorm_out,
+                                                        AgentMap am, int P, float* __restrict__ packs) {
+    constexpr int TOT = 2 * S::NFWD + S::NBWD;
+    __shared__ float s_coef;
+    __shared__ float s_red[4];
+    {
+        float ss = 0.f;
+        for (int b = threadIdx.x; b < nsq; b += 256) ss += sumsq[b];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) ss += __shfl_xor(ss, off);
+        if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = ss;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float total = sqrtf((s_red[0] + s_red[1]) + (s_red[2] + s_red[3]));
+        s_coef = a.max_norm > 0.f ? fminf(a.max_norm / (total + 1e-6f), 1.f) : 1.f;
+        if (gnorm_out != nullptr && blockIdx.x == 0) gnorm_out[0] = total;
+    }
+    __syncthreads();
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float gv = (grad[i] * a.grad_scale) * s_coef;
+    float mi = m[i], vi = v[i];
+    mi = mi + a.w1 * (gv - mi);
+    vi = vi * a.beta2 + a.w2 * gv * gv;
+    const float denom = sqrtf(vi) / a.bc2_sqrt + a.eps;
+    float pi = params[i];
+    pi = pi + (-a.lr_step) * (mi / denom);
+    m[i] = mi;
+    v[i] = vi;
+    params[i] = pi;
+    float ti = 0.f;
+    const bool tgt = a.hard_update || a.tau > 0.f;
+    if (tgt) {
+        ti = a.hard_update ? pi : (1.f - a.tau) * target[i] + a.tau * pi;
+        target[i] = ti;
+    }
+    const int blk = i / S::NPARAM, k = i - blk * S::NPARAM;
+    int fwd, bwd;
+    mlp_param_to_pack<S>(k, fwd, bwd);
+    for (int p = 0; p < P; ++p) {
+        if (am.net[p] != blk) continue;
+        float* pk = packs + (size_t)p * TOT;
+        pk[fwd] = pi;
+        if (bwd >= 0) pk[2 * S::NFWD + bwd] = pi;
+        if (tgt) pk[S::NFWD + fwd] = ti;
     }
 }
 
@@ -846,11 +1029,21 @@ int launch_lossgrad_tp(const marlhip_net_shape* s, const float* params, const fl
     return 0;
 }
 
+// marlhip_idqn_update_n's in-call state: the packs in the workspace stay valid from one update to the next because the Adam launch
+// of update u writes them for update u+1 (adam_pack_kernel); the reduce launch leaves the clip norm's partial sums
+struct UpdFuse {
+    int packs_valid;  // in: skip dqn_pack_kernel; out: 1 after a step that kept them current
+    AdamArgs adam;
+    float *params_rw, *target_rw, *exp_avg, *exp_avg_sq, *gnorm;
+    float* sumsq;     // >= ceil(n / 64) floats
+};
+
 template <class S, bool REPLAY>
 int launch_lossgrad_src(const marlhip_net_shape* s, const float* params, const float* tparams, const marlhip_batch* bt,
                         const ReplaySrc& src, float gamma, int double_q, int mode, void* ws, int64_t ws_bytes, float* grad,
-                        float* loss, hipStream_t st, const QmixCtx* qx, const RetStats* rst) {
+                        float* loss, hipStream_t st, const QmixCtx* qx, const RetStats* rst, UpdFuse* fuse = nullptr) {
     if constexpr (use_tp<S>()) {
+        if (fuse != nullptr) { set_error("fused update epilogue: not a fused-kernel shape"); return -1; }
         return launch_lossgrad_tp<S, REPLAY>(s, params, tparams, bt, src, gamma, double_q, mode, ws, ws_bytes, grad, loss, st, qx, rst);
     } else {
     using L = UpdLds<S>;
@@ -875,8 +1068,10 @@ int launch_lossgrad_src(const marlhip_net_shape* s, const float* params, const f
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         attr_set = true;
     }
-    hipLaunchKernelGGL((dqn_pack_kernel<S>), dim3((PACK + 255) / 256, P), dim3(256), 0, st, params, tparams, am, packs);
-    MARL_CHECK_LAUNCH("dqn_pack_kernel");
+    if (fuse == nullptr || !fuse->packs_valid) {
+        hipLaunchKernelGGL((dqn_pack_kernel<S>), dim3((PACK + 255) / 256, P), dim3(256), 0, st, params, tparams, am, packs);
+        MARL_CHECK_LAUNCH("dqn_pack_kernel");
+    }
     unsigned long long* prof =
         getenv("MARLHIP_PROF") ? reinterpret_cast<unsigned long long*>(static_cast<char*>(ws) + ws_bytes - 128) : nullptr;
     const size_t tb = (size_t)T * B;
@@ -916,6 +1111,19 @@ int launch_lossgrad_src(const marlhip_net_shape* s, const float* params, const f
     timing_end(TIMER_LOSSGRAD, st);
     MARL_CHECK_LAUNCH("dqn_lossgrad_kernel");
     const int n = am.nblk * S::NPARAM;
+    if (fuse != nullptr) {  // reduce (+ clip-norm partials) -> clip + Adam + target + next update's packs: two launches
+        MARL_REQUIRE(mode == 0 || mode == 1, "fused update epilogue: IDQN / VDN only");
+        const int nsq = (n + 63) / 64;
+        hipLaunchKernelGGL(dqn_reduce_sq_kernel, dim3(nsq), dim3(256), 0, st, (const float*)ws, P, pl.nwg, S::NPARAM, am, grad, loss,
+                           fuse->sumsq);
+        MARL_CHECK_LAUNCH("dqn_reduce_sq_kernel");
+        hipLaunchKernelGGL((adam_pack_kernel<S>), dim3((n + 255) / 256), dim3(256), 0, st, n, nsq, fuse->params_rw, (const float*)grad,
+                           fuse->exp_avg, fuse->exp_avg_sq, fuse->target_rw, fuse->adam, (const float*)fuse->sumsq, fuse->gnorm, am, P,
+                           packs);
+        MARL_CHECK_LAUNCH("adam_pack_kernel");
+        fuse->packs_valid = 1;
+        return 0;
+    }
     hipLaunchKernelGGL(dqn_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, st, (const float*)ws, P, pl.nwg, S::NPARAM, am, grad, loss);
     MARL_CHECK_LAUNCH("dqn_reduce_kernel");
     if (mode == 2) return qmix_dispatch_reduce<S::D>(P, *qx, T, B, loss, st);
@@ -926,12 +1134,16 @@ int launch_lossgrad_src(const marlhip_net_shape* s, const float* params, const f
 template <class S>
 int launch_lossgrad(const marlhip_net_shape* s, const float* params, const float* tparams, const marlhip_batch* bt,
                     const ReplaySrc* rsrc, float gamma, int double_q, int mode, void* ws, int64_t ws_bytes, float* grad, float* loss,
-                    hipStream_t st, const QmixCtx* qx, const RetStats* rst) {
+                    hipStream_t st, const QmixCtx* qx, const RetStats* rst, UpdFuse* fuse = nullptr) {
     if (rsrc != nullptr)
-        return launch_lossgrad_src<S, true>(s, params, tparams, bt, *rsrc, gamma, double_q, mode, ws, ws_bytes, grad, loss, st, qx, rst);
+        return launch_lossgrad_src<S, true>(s, params, tparams, bt, *rsrc, gamma, double_q, mode, ws, ws_bytes, grad, loss, st, qx, rst, fuse);
     ReplaySrc none = {};
-    return launch_lossgrad_src<S, false>(s, params, tparams, bt, none, gamma, double_q, mode, ws, ws_bytes, grad, loss, st, qx, rst);
+    return launch_lossgrad_src<S, false>(s, params, tparams, bt, none, gamma, double_q, mode, ws, ws_bytes, grad, loss, st, qx, rst, fuse);
 }
+
+// can this shape take marlhip_idqn_update_n's fused epilogue (LDS-resident-pack learner kernel)?
+template <class S>
+constexpr bool fused_epilogue_ok() { return !use_tp<S>(); }
 
 }  // namespace marl
 

@@ -113,6 +113,33 @@ __device__ __forceinline__ void mlp_stage_bwd(const float* __restrict__ w, float
     }
 }
 
+// inverse of mlp_fwd_pack_elem / mlp_bwd_pack_elem: where canonical parameter k of a network sits in the forward pack (always) and
+// in the backward pack (W2, W3; -1 otherwise).  Zero padding of the packs (k-steps beyond D, outputs beyond A) has no parameter.
+template <class S>
+__device__ __forceinline__ void mlp_param_to_pack(int k, int& fwd, int& bwd) {
+    constexpr int MT = S::MT;
+    bwd = -1;
+    if (k < S::ob1) {  // W1[o][d]
+        const int o = k / S::D, d = k - o * S::D;
+        const int ks = d >> 2, gq = d & 3;
+        fwd = S::pA1 + (((o >> 4) * (S::KS1 / 4) + (ks >> 2)) * 64 + gq * 16 + (o & 15)) * 4 + (ks & 3);
+    } else if (k < S::oW2) {
+        fwd = S::pb1 + (k - S::ob1);
+    } else if (k < S::ob2) {  // W2[o2][i1]
+        const int j = k - S::oW2, o2 = j / S::H, i1 = j - o2 * S::H;
+        fwd = S::pA2 + (((o2 >> 4) * MT + (i1 >> 4)) * 64 + ((i1 & 15) >> 2) * 16 + (o2 & 15)) * 4 + (i1 & 3);
+        bwd = S::pT2 + (((i1 >> 4) * MT + (o2 >> 4)) * 64 + ((o2 & 15) >> 2) * 16 + (i1 & 15)) * 4 + (o2 & 3);
+    } else if (k < S::oW3) {
+        fwd = S::pb2 + (k - S::ob2);
+    } else if (k < S::ob3) {  // W3[a][h]
+        const int j = k - S::oW3, a = j / S::H, h = j - a * S::H;
+        fwd = S::pA3 + ((h >> 4) * 64 + ((h & 15) >> 2) * 16 + a) * 4 + (h & 3);
+        bwd = S::pT3 + ((h >> 4) * 64 + (a >> 2) * 16 + (h & 15)) * 4 + (a & 3);
+    } else {
+        fwd = S::pb3 + (k - S::ob3);
+    }
+}
+
 // workgroup-cooperative 16-byte copy global -> LDS with 8 independent loads in flight per thread before the first LDS store
 __device__ __forceinline__ void copy_f4_to_lds(const f4* __restrict__ src, f4* dst, int n4, int tid, int nthreads) {
     constexpr int U = 8;
@@ -370,6 +397,194 @@ __device__ __forceinline__ void mlp_forward_p2(const float* lds, int lane, const
             q[0] = MARL_MFMA(op[c3][k1][r], h20[r], q[0]);
             q[1] = MARL_MFMA(op[c3][k1][r], h21[r], q[1]);
         }
+}
+
+// ---- cross-lane helpers on gfx950's v_permlane16_swap / v_permlane32_swap (VALU only: no LDS queue entry, no lgkmcnt wait).
+// permlane16_swap(a, b): rows (16 lanes) 1, 3 of a <-> rows 0, 2 of b; permlane32_swap(a, b): lanes 32..63 of a <-> lanes 0..31 of b.
+// With a == b == v the two results are [r0 r0 r2 r2] / [r1 r1 r3 r3] (resp. [lo lo] / [hi hi]): their sum is the xor-16 (xor-32)
+// pair sum in every lane, and "the other lane's value" is result[1] in even rows (lower half), result[0] in odd rows (upper half).
+__device__ __forceinline__ float xor16_other(float v, int lane) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float((lane & 16) ? r[0] : r[1]);
+}
+__device__ __forceinline__ float xor32_other(float v, int lane) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float((lane & 32) ? r[0] : r[1]);
+}
+__device__ __forceinline__ int xor16_other(int v, int lane) {
+    const auto r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+    return (int)((lane & 16) ? r[0] : r[1]);
+}
+__device__ __forceinline__ int xor32_other(int v, int lane) {
+    const auto r = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+    return (int)((lane & 32) ? r[0] : r[1]);
+}
+// sum over the four lanes {j, j+16, j+32, j+48} that carry batch row j (every lane gets it)
+__device__ __forceinline__ float sum_g(float v) {
+    const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    const float s = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
+// argmax_rows / gather_rows without LDS traffic (same results: first index of the maximum; exactly one non-zero addend)
+template <int A>
+__device__ __forceinline__ int argmax_rows_pl(const f4& q, int lane) {
+    // selects only (& / | on the predicates, no short-circuit): a branch here would split the MFMA region it hides in
+    const int g = lane >> 4;
+    float bv = -__builtin_huge_valf();
+    int ba = 0x7FFFFFFF;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int a = 4 * g + r;
+        const bool take = (a < A) & ((q[r] > bv) | (ba == 0x7FFFFFFF));
+        bv = take ? q[r] : bv;
+        ba = take ? a : ba;
+    }
+    {
+        const float ov = xor16_other(bv, lane);
+        const int oa = xor16_other(ba, lane);
+        const bool take = (oa != 0x7FFFFFFF) & ((ba == 0x7FFFFFFF) | (ov > bv) | ((ov == bv) & (oa < ba)));
+        bv = take ? ov : bv;
+        ba = take ? oa : ba;
+    }
+    {
+        const float ov = xor32_other(bv, lane);
+        const int oa = xor32_other(ba, lane);
+        const bool take = (oa != 0x7FFFFFFF) & ((ba == 0x7FFFFFFF) | (ov > bv) | ((ov == bv) & (oa < ba)));
+        bv = take ? ov : bv;
+        ba = take ? oa : ba;
+    }
+    return ba;
+}
+__device__ __forceinline__ float gather_rows_pl(const f4& q, int lane, int a_sel) {
+    const int g = lane >> 4;
+    float v = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v += (4 * g + r == a_sel) ? q[r] : 0.f;
+    return sum_g(v);
+}
+
+// Single-network forward for the learner kernels: MFMA groups of 16 (layer-1 steps, layer-2 steps, layer 3), the A operands of
+// group s+1 requested inside group s and spread behind its first MFMAs (sched_group_barrier), and a caller-supplied filler
+// `fill(k)` emitted INSIDE the scheduling region of group k (k = 0 .. N1 + MT) so that independent VALU / LDS / VMEM work of the
+// caller issues in the shadow of that group's MFMAs instead of between groups.  Layer 3 runs as two interleaved chains (even / odd
+// k-tiles) that are added at the end: a dependent 16x16x4 chain costs 40 cycles per MFMA instead of 32.
+// scheduling pipeline of one MFMA group of `nmfma` MFMAs that also holds `nreads` LDS reads (the next group's operands): the reads
+// issue one per MFMA shadow behind the FIRST MFMAs of the group (a full group of latency before their consumer), the rest of the
+// MFMAs follow; everything else in the region floats.  The whole group is described (the solver assigns bottom-up: a partial
+// pipeline would bind the LAST MFMAs and leave the reads at the end of the group, ~3 MFMAs in front of their first use).
+// MARL_READS_MODE: 0 = no pipeline (reads where the compiler puts them: a clump in front of the group), 1 = this pipeline.
+#ifndef MARL_READS_MODE
+#define MARL_READS_MODE 1
+#endif
+#if MARL_READS_MODE == 1
+#define MARL_SPREAD_READS(nreads, nmfma)                        \
+    _Pragma("unroll") for (int i_ = 0; i_ < (nreads); ++i_) {   \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      \
+    }                                                           \
+    _Pragma("unroll") for (int i_ = (nreads); i_ < (nmfma); ++i_) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+#else
+#define MARL_SPREAD_READS(nreads, nmfma)
+#endif
+
+// the operands of the first MFMA group (first layer-1 k-step of every hidden tile + the layer-1 bias in accumulator layout): the
+// same registers every time step, so a learner wave keeps them for the whole kernel instead of re-reading them from LDS in front of
+// every forward, where nothing hides the read latency
+template <class S>
+struct FwdHead {
+    static constexpr bool RESIDENT = S::DP <= 16;  // wide first layers need the registers for their x / dW1 tiles: re-read per forward
+    f4 op0[S::MT], b1[S::MT];
+    __device__ __forceinline__ void load(const float* lds, int lane) {
+        const f4* A1 = reinterpret_cast<const f4*>(lds + S::pA1);
+#pragma unroll
+        for (int mt = 0; mt < S::MT; ++mt) {
+            op0[mt] = A1[(mt * (S::KS1 / 4) + 0) * 64 + lane];
+            b1[mt] = *reinterpret_cast<const f4*>(lds + S::pb1 + 16 * mt + 4 * (lane >> 4));
+        }
+    }
+};
+
+template <class S, class F>
+__device__ __forceinline__ void mlp_forward_f(const float* lds, const FwdHead<S>& head, int lane, const float (&x)[S::KS1], f4 (&h1)[S::MT],
+                                              f4 (&h2)[S::MT], f4& q, F&& fill) {
+    constexpr int MT = S::MT, N1 = S::KS1 / 4;
+    const int g = lane >> 4;
+    const f4* A1 = reinterpret_cast<const f4*>(lds + S::pA1);
+    const f4* A2 = reinterpret_cast<const f4*>(lds + S::pA2);
+    const f4* A3 = reinterpret_cast<const f4*>(lds + S::pA3);
+    f4 op[2][MT], acc[MT], nb[MT];
+    if (FwdHead<S>::RESIDENT) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            op[0][mt] = head.op0[mt];
+            acc[mt] = head.b1[mt];
+        }
+    } else {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            op[0][mt] = A1[(mt * N1 + 0) * 64 + lane];
+            acc[mt] = *reinterpret_cast<const f4*>(lds + S::pb1 + 16 * mt + 4 * g);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- layer 1
+#pragma unroll
+    for (int s = 0; s < N1; ++s) {
+        const int cur = s & 1, nxt = cur ^ 1;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            if (s + 1 < N1) {
+                op[nxt][mt] = A1[(mt * N1 + s + 1) * 64 + lane];
+            } else {
+                op[nxt][mt] = A2[(mt * MT + 0) * 64 + lane];
+                nb[mt] = *reinterpret_cast<const f4*>(lds + S::pb2 + 16 * mt + 4 * g);
+            }
+        }
+        fill(s);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = MARL_MFMA(op[cur][mt][e], x[4 * s + e], acc[mt]);
+        MARL_SPREAD_READS(s + 1 < N1 ? MT : 2 * MT, 4 * MT)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        h1[mt] = relu4(acc[mt]);
+        acc[mt] = nb[mt];
+    }
+    // ---- layer 2
+    f4 o3a, o3b = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k1 = 0; k1 < MT; ++k1) {
+        const int cur = (N1 + k1) & 1, nxt = cur ^ 1;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) op[nxt][mt] = (k1 + 1 < MT) ? A2[(mt * MT + k1 + 1) * 64 + lane] : A3[mt * 64 + lane];
+        if (k1 + 1 == MT) o3a = *reinterpret_cast<const f4*>(lds + S::pb3 + 4 * g);
+        fill(N1 + k1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = MARL_MFMA(op[cur][mt][r], h1[k1][r], acc[mt]);
+        MARL_SPREAD_READS(k1 + 1 < MT ? MT : MT + 1, 4 * MT)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) h2[mt] = relu4(acc[mt]);
+    // ---- layer 3: chains over the even and the odd k-tiles
+    constexpr int c3 = (N1 + MT) & 1;
+    fill(N1 + MT);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int k1 = 0; k1 < MT; k1 += 2) {
+            o3a = MARL_MFMA(op[c3][k1][r], h2[k1][r], o3a);
+            if (k1 + 1 < MT) o3b = MARL_MFMA(op[c3][k1 + 1][r], h2[k1 + 1][r], o3b);
+        }
+    __builtin_amdgcn_sched_barrier(0);
+    q = o3a + o3b;
 }
 
 // greedy action of batch row j from q in C layout (lane (g,j) holds Q[4g+r]):

@@ -5,6 +5,11 @@
 // The update / target-update bookkeeping is QNetwork.update + update_target (marlbase/dqn/model.py:165-185).
 #include "common.h"
 
+namespace marl {
+int idqn_update_n_fused(const marlhip_idqn_learner* L, int32_t n_updates, int32_t length, uint64_t seed, uint32_t counter0,
+                        int64_t* adam_step, int64_t* updates, int64_t* last_target_update, void* stream, bool* handled);
+}
+
 extern "C" int marlhip_idqn_update_n(const marlhip_idqn_learner* L, int32_t n_updates, int32_t length, uint64_t seed,
                                      uint32_t counter0, int64_t* adam_step, int64_t* updates, int64_t* last_target_update,
                                      void* stream) {
@@ -16,6 +21,11 @@ extern "C" int marlhip_idqn_update_n(const marlhip_idqn_learner* L, int32_t n_up
     bt.obss = L->obss; bt.actions = L->actions; bt.rewards = L->rewards; bt.dones = L->dones; bt.filled = L->filled;
     bt.max_len = L->rs.max_len; bt.batch = L->batch;
     const double tui = L->target_update_interval_or_tau;
+    {   // hidden-64 IDQN / VDN learners: 3 launches per update (the Adam launch writes the next update's weight packs)
+        bool handled = false;
+        const int rc = marl::idqn_update_n_fused(L, n_updates, length, seed, counter0, adam_step, updates, last_target_update, stream, &handled);
+        if (rc < 0 || handled) return rc;
+    }
     for (int u = 0; u < n_updates; ++u) {
         int rc;
         if (L->materialise_batch) {

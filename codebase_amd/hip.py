@@ -287,10 +287,10 @@ class DqnUpdater:
         self.grad = torch.zeros_like(params)
         self.loss = torch.zeros(2, dtype=torch.float32, device=dev)
         self.gnorm = torch.zeros(1, dtype=torch.float32, device=dev)
-        self.scratch = torch.zeros((params.numel() + 255) // 256 + 1, dtype=torch.float32, device=dev)
+        self.scratch = torch.zeros((params.numel() + 63) // 64 + 1, dtype=torch.float32, device=dev)  # clip-norm partials (update_n: one per 64)
         self.step = 0
         self._ws = {}
-        self._gru_ws = {}
+        self._gru_ws_cache = {}
 
     def _workspace(self, T, B):
         key = (T, B)
@@ -642,7 +642,7 @@ class GruUpdater(DqnUpdater):
                   "gru_loss_grad_std")
             return self.loss, self.grad
         return gru_loss_grad(self.spec, self.params, self.target, batch, gamma=self.gamma, double_q=self.double_q, mode=mode,
-                             grad=self.grad, loss=self.loss, ws_cache=self._gru_ws)
+                             grad=self.grad, loss=self.loss, ws_cache=self._gru_ws_cache)
 
     def loss_grad_replay(self, replay, batch_size, length=None, idx=None, seed=0, counter=0, idx_out=None, mode=0):
         """the recurrent learner reads a materialised Batch: sample kernel first (no in-kernel gather)"""

@@ -434,13 +434,17 @@ int marlhip_ppo_loss_grad(const marlhip_net_shape* s, const float* actor, const 
  * marlhip_dqn_loss_grad -> marlhip_dqn_clip_adam), with QNetwork.update's bookkeeping
  * (marlbase/dqn/model.py:165-185): *updates += 1 per update, hard target copy when
  * updates - last_target_update >= target_update_interval_or_tau (> 1), Polyak when < 1.
- * Single-GPU convenience (no hook for a gradient all-reduce): identical kernels, fewer host calls.
+ * Single-GPU convenience (no hook for a gradient all-reduce): identical arithmetic, fewer host calls.  For the hidden-64
+ * IDQN / VDN learners an update is 3 launches here instead of 4: the MFMA weight packs are built once per call and kept current
+ * by the Adam launch of every update (which also takes the clip norm from partial sums the gradient reduce leaves behind).
  * ---------------------------------------------------------------------------------------- */
 typedef struct marlhip_idqn_learner {
     marlhip_net_shape net;
     marlhip_replay_shape rs;
     marlhip_replay_buffers rb;
-    float *params, *target, *exp_avg, *exp_avg_sq, *grad, *loss, *scratch, *gnorm;
+    float *params, *target, *exp_avg, *exp_avg_sq, *grad, *loss;
+    float* scratch; /* >= ceil(n / 64) floats, n = all parameters of all networks (clip-norm partial sums) */
+    float* gnorm;
     void* workspace;
     int64_t workspace_bytes;
     float* obss;      /* sample outputs, shaped for `batch` episodes (marlhip_replay_sample) */

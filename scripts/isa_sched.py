@@ -86,6 +86,8 @@ def estimate(seq):
 
 def main():
     path, key = sys.argv[1], sys.argv[2]
+    if len(sys.argv) > 4 and sys.argv[3] == "--gaps":
+        return gaps_report(path, key, sys.argv[4])
     verbose = len(sys.argv) > 3
     for name, ins in blocks(path, key):
         seq = "".join(c for c, _ in ins)
@@ -99,6 +101,23 @@ def main():
         if verbose:
             # run-length compress
             print("   " + re.sub(r"(.)\1{3,}", lambda m: f"{m.group(1)}{len(m.group(0))}", seq))
+
+
+
+
+def gaps_report(path, key, block):
+    """per-gap filler cost for one block: python isa_sched.py x.s key --gaps .LBBn_m"""
+    for name, ins in blocks(path, key):
+        if name != block:
+            continue
+        seq = "".join(c for c, _ in ins)
+        parts = re.split("M", seq)
+        out = []
+        for i, g in enumerate(parts):
+            cost = sum(COST[c] for c in g)
+            mark = "!" if cost > 28 else ""
+            out.append(f"{g or '.'}{mark}")
+        print(" ".join(out))
 
 
 if __name__ == "__main__":

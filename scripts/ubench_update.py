@@ -33,10 +33,8 @@ if os.environ.get("MARLHIP_PROF"):
     up.loss_grad(batch)
     torch.cuda.synchronize()
     pc = ws[-128:].view(torch.int64).cpu().numpy()[:12]
-    names = ["load+mask", "forward", "TD", "P0+P1 dH2", "P2 mask/tile", "dH1+dW3", "mask/tile+dW2+dW1", "bootstrap+copy",
-             "[staging]", "[task loop]", "[fold+write]", "[kernel total]"]
-    tot = pc[:8].sum()
-    print("phase cycles per wave (1024 waves):")
-    for n, c in zip(names, pc):
-        print(f"  {n:22s} {c / 1024:10.0f}  {100.0 * c / tot:5.1f}%")
-    print(f"  total {tot / 1024:.0f} cycles/wave")
+    names = {0: "row loads + masks", 1: "critic forward", 2: "target forward + TD + tile writes", 3: "dH2 + dW3", 4: "dH1 + bootstrap",
+             5: "dW2 + dW1", 8: "[staging]", 9: "[task loop]", 10: "[fold+write]", 11: "[kernel total]"}  # 0-5: MARL_STEP_PROF builds only
+    print("cycles per wave (1024 waves; one lane per wave reports):")
+    for k, n in names.items():
+        print(f"  {n:34s} {pc[k] / 1024:10.0f}")
