@@ -176,6 +176,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dqn_lossgrad_kernel(con
     constexpr int UPD_BLOCK = 64 * WAVES;
     constexpr bool HAS_TGT = (MODE == 0 || MODE == 1);  // target forward + bootstrap value in this pass
     constexpr bool HAS_BWD = (MODE != 1);               // backward of the row block in this pass
+    constexpr bool DB1_FREE = (D % 16) != 0;            // a padding column exists in the dW1 operand
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, j = lane & 15;
     const int p = blockIdx.y;
@@ -322,13 +323,15 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dqn_lossgrad_kernel(con
                 R.lr = mix.lrow[(size_t)tt * B + bj];
             }
         };
-        auto mask_rows = [&](Rows& R) {  // zero the padding (obs dims >= D, rows >= B)
+        // Padding needs no zeroing: observation columns >= D meet zero weights in the forward pack and land in dW1 columns the fold
+        // drops; batch rows >= B carry filled = 0, hence dQ = 0 and zero gradient rows whatever their (finite, clamped-address)
+        // observations are.  The first padding column of the dW1 operand is set to ONE instead: dW1[h][D] then accumulates
+        // sum_rows dH1[row][h] = db1 inside the MFMAs (DB1_FREE; shapes without padding keep the VALU adds).
+        auto mask_rows = [&](Rows& R) {
+            if (DB1_FREE) {
 #pragma unroll
-            for (int ks = 0; ks < S::KS1; ++ks) R.x[ks] = (4 * ks + g < D && rowok) ? R.x[ks] : 0.f;
-#pragma unroll
-            for (int nt = 0; nt < NT1; ++nt)
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) R.bx[nt][ks] = (b0 + 4 * g + ks < B && 16 * nt + j < D) ? R.bx[nt][ks] : 0.f;
+                for (int ks = 0; ks < 4; ++ks) R.bx[D / 16][ks] = (j == D % 16) ? 1.f : R.bx[D / 16][ks];
+            }
             if (REPLAY) {
                 R.dn = R.dn_raw ? 1.f : 0.f;
                 R.fl = R.fl_raw ? 1.f : 0.f;
@@ -347,18 +350,24 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dqn_lossgrad_kernel(con
             if (!LAST) load_rows(t - 1, nxt);
             mask_rows(cur);
             MARL_TS(0)
-            f4 h1[MT], h2[MT], q, tq = zero4;
-            // ---- A: critic forward
-            mlp_forward_f<S>(cpk, chead, lane, cur.x, h1, h2, q, [](int) {});
+            f4 h1[MT], h2[MT], q, qb, tq = zero4, tqb = zero4;
+            // ---- A: critic forward (q arrives as two partial chains, added where it is first used)
+            mlp_forward_f<S>(cpk, chead, lane, cur.x, h1, h2, q, qb, [](int) {});
             MARL_TS(1)
             // ---- the critic's epilogue, emitted as fillers of the target forward's MFMA groups (or on its own without one)
             f4 dQ[1] = {zero4};
             f4 t3[MT], t2[2][MT], aQ = zero4, bH2[MT];
+            // MODE 0 / 2: dQ has ONE non-zero per row (the chosen action), so dH2 = W3^T dQ^T is row a_sel of W3 times that
+            // value: 4 LDS reads + 16 multiplies instead of 16 MFMAs whose operand is 15/16 zeros (and no accumulator read-out)
+            constexpr bool ONE_HOT = (MODE == 0 || MODE == 2);
+            f4 w3sel[MT];
+            float dqs_row = 0.f;
             auto epilogue = [&](int k) {
                 if (k == 0) {
+                    q += qb;
                     if (DO_PUB) {
                         // qsel pass: publish Q_p(o_t)[a_t] and (agent 0) the transition's scalars for the mixer
-                        const float ch = gather_rows_pl(q, lane, cur.a_sel);
+                        const float ch = gather_rows_pl<A>(q, lane, cur.a_sel);
                         if (g == 0 && rowok) {
                             mix.chosen[((size_t)p * T + t) * B + bj] = ch;
                             if (mix.rew_all != nullptr) mix.rew_all[((size_t)p * T + t) * B + bj] = cur.rw;
@@ -373,10 +382,11 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dqn_lossgrad_kernel(con
                         // ---- TD error of transition t (model.py:129,152,160-163)
                         const int a_sel = cur.a_sel;
                         const float fl = cur.fl;
-                        float dqs;
+                        float dqs = 0.f;
+                        if (ONE_HOT) mlp_w3_row<S>(cpk, lane, a_sel < A ? (a_sel < 0 ? 0 : a_sel) : A - 1, w3sel);
                         if (MODE == 0) {
                             const float y = cur.rw + gamma * tq_next * (1.f - cur.dn);
-                            const float delta = gather_rows_pl(q, lane, a_sel) - y;
+                            const float delta = gather_rows_pl<A>(q, lane, a_sel) - y;
                             loss_acc += fl * delta * delta;  // every g lane of row j carries the same sums; the fold reads g == 0
                             nfill_acc += fl;
                             dqs = 2.f * fl * delta;
@@ -392,6 +402,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dqn_lossgrad_kernel(con
                             else dQ[0][r] = (4 * g + r == a_sel) ? dqs : 0.f;
                         }
                         db3 += dQ[0];
+                        dqs_row = dqs;
                     }
                 }
                 if (DO_BWD) {
@@ -405,7 +416,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dqn_lossgrad_kernel(con
                         wave_lds_fence();
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt) {
-                            t3[mt] = T3[mt * 64 + lane];
+                            if (!ONE_HOT) t3[mt] = T3[mt * 64 + lane];
                             t2[0][mt] = T2[(mt * MT + 0) * 64 + lane];
                         }
                         aQ = tile_read_s<TS>(TQ, 0, g, j);
@@ -414,11 +425,14 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dqn_lossgrad_kernel(con
                     }
                 }
             };
-            // ---- B: target forward (its hidden activations are scratch)
+            // ---- B: target forward (its hidden activations are scratch).  Under Double-Q only ONE target output per row is
+            // needed (the action the online network picks): the output layer is then a dot product in the bootstrap stage
+            f4 g2[MT];
             if (DO_TGT) {
-                f4 g1[MT], g2[MT];
+                f4 g1[MT];
                 static_assert(N1 + MT + 1 >= 4, "epilogue stages need four MFMA groups");
-                mlp_forward_f<S>(tpk, thead, lane, cur.x, g1, g2, tq, epilogue);
+                if (double_q) mlp_forward_f<S, false>(tpk, thead, lane, cur.x, g1, g2, tq, tqb, epilogue);
+                else mlp_forward_f<S, true>(tpk, thead, lane, cur.x, g1, g2, tq, tqb, epilogue);
             } else {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) epilogue(k);
@@ -427,17 +441,27 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dqn_lossgrad_kernel(con
             MARL_TS(2)
             // ---- bootstrap value for transition t-1 (model.py:132-145): a filler of the backward's MFMA groups
             auto bootstrap = [&]() {
-                if (!REPLAY && bt.action_mask != nullptr) {  // model.py:136-142: disallowed actions of o_t read as -1e8
+                const bool masked = !REPLAY && bt.action_mask != nullptr;
+                if (double_q) {  // the online network picks the action (model.py:138-145), the target network values it
+                    if (masked) {  // model.py:136-142: disallowed actions of o_t read as -1e8
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        if (cur.mk[r] == 0.f) { q[r] = -1e8f; tq[r] = -1e8f; }
+                        for (int r = 0; r < 4; ++r) q[r] = cur.mk[r] == 0.f ? -1e8f : q[r];
                     }
-                }
-                f4 qsel;  // Double-Q: the online network picks the action (model.py:138-145); a select, not a branch
+                    const int a_p = argmax_rows_pl<A>(q, lane);
+                    tq_next = mlp_output_at<S>(tpk, lane, a_p, g2);  // the same a_p in all four lanes of a row
+                    if (masked) {  // every action disallowed: the reference's target reads -1e8 there too
+                        f4 mk4 = {cur.mk[0], cur.mk[1], cur.mk[2], cur.mk[3]};
+                        tq_next = gather_rows_pl<A>(mk4, lane, a_p) == 0.f ? -1e8f : tq_next;
+                    }
+                } else {
+                    tq += tqb;
+                    if (masked) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) qsel[r] = double_q ? q[r] : tq[r];
-                const int a_p = argmax_rows_pl<A>(qsel, lane);
-                tq_next = gather_rows_pl(tq, lane, a_p);
+                        for (int r = 0; r < 4; ++r) tq[r] = cur.mk[r] == 0.f ? -1e8f : tq[r];
+                    }
+                    const int a_p = argmax_rows_pl<A>(tq, lane);
+                    tq_next = gather_rows_pl<A>(tq, lane, a_p);
+                }
                 if (MODE == 1 && g == 0 && rowok) mix.tqsel[((size_t)p * T + (t - 1)) * B + bj] = tq_next;
             };
             if (DO_BWD) {
@@ -445,13 +469,18 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dqn_lossgrad_kernel(con
                 // work has no dependence on the region's MFMAs, so it issues in their shadow.
                 // C0: dH2^T = W3^T dQ^T
                 f4 dH2[MT];
+                if (ONE_HOT) {
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) dH2[mt] = zero4;
+                    for (int mt = 0; mt < MT; ++mt) dH2[mt] = w3sel[mt] * dqs_row;
+                } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
+                    for (int mt = 0; mt < MT; ++mt) dH2[mt] = zero4;
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) dH2[mt] = MARL_MFMA(t3[mt][r], dQ[0][r], dH2[mt]);
-                __builtin_amdgcn_sched_barrier(0);
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) dH2[mt] = MARL_MFMA(t3[mt][r], dQ[0][r], dH2[mt]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 // C1: relu mask, db2, publish the dH2 tile | dW3[a][h2] += dQ^T H2; request the second W2^T step and the h1 tile
                 f4 bH1[MT], aG2[MT];
 #pragma unroll
@@ -465,6 +494,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dqn_lossgrad_kernel(con
                 for (int m1 = 0; m1 < MT; ++m1) t2[1][m1] = T2[(m1 * MT + 1) * 64 + lane];
 #pragma unroll
                 for (int nt = 0; nt < MT; ++nt) bH1[nt] = tile_read_s<TS>(TH1, nt, g, j);
+                MARL_VB()
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
@@ -483,6 +513,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dqn_lossgrad_kernel(con
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt) aG2[mt] = tile_read_s<TS>(TG2, mt, g, j);
                         if (DO_TGT) bootstrap();
+                        MARL_VB()
                     }
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
@@ -500,9 +531,10 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dqn_lossgrad_kernel(con
                 for (int m1 = 0; m1 < MT; ++m1) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) dH1[m1][r] = h1[m1][r] > 0.f ? dH1[m1][r] : 0.f;
-                    db1[m1] += dH1[m1];
+                    if (!DB1_FREE) db1[m1] += dH1[m1];
                 }
                 tile_write_s<TS, MT>(TG1, dH1, g, j);
+                MARL_VB()
 #pragma unroll
                 for (int mt = 0; mt < MT / 2; ++mt)
 #pragma unroll
@@ -583,7 +615,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dqn_lossgrad_kernel(con
                 }
 #pragma unroll
                 for (int nt = 0; nt < MT; ++nt) mine[S::oW2 + o * H + 16 * nt + j] = dW2[mt][nt][r];
-                strips[o * 16 + j] = db1[mt][r];
+                strips[o * 16 + j] = DB1_FREE ? (j == D % 16 ? dW1[mt][D / 16][r] : 0.f) : db1[mt][r];
                 strips[(H + o) * 16 + j] = db2[mt][r];
             }
         }

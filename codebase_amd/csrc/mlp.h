@@ -448,15 +448,19 @@ __device__ __forceinline__ int argmax_rows_pl(const f4& q, int lane) {
         bv = take ? ov : bv;
         ba = take ? oa : ba;
     }
-    {
+    if (A > 8) {
         const float ov = xor32_other(bv, lane);
         const int oa = xor32_other(ba, lane);
         const bool take = (oa != 0x7FFFFFFF) & ((ba == 0x7FFFFFFF) | (ov > bv) | ((ov == bv) & (oa < ba)));
         bv = take ? ov : bv;
         ba = take ? oa : ba;
+    } else {  // up to 8 actions sit in lane groups g = 0, 1: the 16-lane exchange decided; groups 2, 3 just take the result over
+        const int oa = xor32_other(ba, lane);
+        ba = (lane & 32) ? oa : ba;
     }
     return ba;
 }
+template <int A>
 __device__ __forceinline__ float gather_rows_pl(const f4& q, int lane, int a_sel) {
     const int g = lane >> 4;
     float v = 0.f;
@@ -489,6 +493,25 @@ __device__ __forceinline__ float gather_rows_pl(const f4& q, int lane, int a_sel
 #define MARL_SPREAD_READS(nreads, nmfma)
 #endif
 
+// relu for the learner kernels: ONE VALU instruction per element (equal to fmaxf(v, 0) for every non-NaN input)
+#ifndef MARL_RELU_MED3
+#define MARL_RELU_MED3 1
+#endif
+__device__ __forceinline__ f4 relu4l(f4 v) {
+#if MARL_RELU_MED3
+    // one v_max_f32 per element, spelled in asm: fmaxf / fmed3 lower to a canonicalising v_max(v, v) in front of the max (two VALU
+    // instructions, and every VALU instruction next to f32 MFMAs costs matrix time - see MARL_BURST below)
+    f4 o;
+    asm("v_max_f32 %0, 0, %1" : "=v"(o.x) : "v"(v.x));
+    asm("v_max_f32 %0, 0, %1" : "=v"(o.y) : "v"(v.y));
+    asm("v_max_f32 %0, 0, %1" : "=v"(o.z) : "v"(v.z));
+    asm("v_max_f32 %0, 0, %1" : "=v"(o.w) : "v"(v.w));
+    return o;
+#else
+    return relu4(v);
+#endif
+}
+
 // the operands of the first MFMA group (first layer-1 k-step of every hidden tile + the layer-1 bias in accumulator layout): the
 // same registers every time step, so a learner wave keeps them for the whole kernel instead of re-reading them from LDS in front of
 // every forward, where nothing hides the read latency
@@ -506,9 +529,28 @@ struct FwdHead {
     }
 };
 
-template <class S, class F>
+// MARL_BURST (default 1): VALU work is issued in BURSTS between MFMA groups, never interleaved with them.  On gfx950 the f32-input
+// MFMA runs on the vector ALU's own datapath (guide: "at the f32 VECTOR rate"): scripts/mfma_ubench2/3.hip measure that a VALU
+// instruction placed between two v_mfma_f32_16x16x4_f32 costs 9-13 cycles of matrix time (nothing is hidden), the same instruction in
+// a run of 16-64 costs 4-7, and LDS reads / b32 writes cost ~0.  So: MFMAs back to back, LDS traffic among them, VALU clumped.
+#ifndef MARL_BURST
+#define MARL_BURST 1
+#endif
+#if MARL_BURST
+#define MARL_VB() __builtin_amdgcn_sched_barrier(0);
+#else
+#define MARL_VB()
+#endif
+
+// WITH_L3 = false stops after the second hidden layer (h2 only): the caller wants ONE output per row (the target value of the
+// bootstrap action) and forms it as a dot product (mlp_output_at) instead of 16 output-layer MFMAs that are 10/16 padding
+template <class S, bool WITH_L3 = true, class F>
 __device__ __forceinline__ void mlp_forward_f(const float* lds, const FwdHead<S>& head, int lane, const float (&x)[S::KS1], f4 (&h1)[S::MT],
-                                              f4 (&h2)[S::MT], f4& q, F&& fill) {
+                                              f4 (&h2)[S::MT], f4& qa, f4& qb, F&& fill) {
+    // groups of 4 MT MFMAs (layer-1 k-steps, layer-2 k-tiles, layer 3); the A operands of group s+1 are requested at the top of
+    // group s; `fill(k)` - the caller's VALU / LDS work for group k - is emitted in front of the group's MFMAs as one burst; the
+    // relu of a layer is one burst behind its last group.  Layer 3 runs as two chains (even / odd k-tiles -> qa / qb, added by
+    // the caller where it first needs q): a single dependent 16x16x4 chain would cost 40 cycles per MFMA instead of 32.
     constexpr int MT = S::MT, N1 = S::KS1 / 4;
     const int g = lane >> 4;
     const f4* A1 = reinterpret_cast<const f4*>(lds + S::pA1);
@@ -543,16 +585,16 @@ __device__ __forceinline__ void mlp_forward_f(const float* lds, const FwdHead<S>
             }
         }
         fill(s);
+        MARL_VB()
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) acc[mt] = MARL_MFMA(op[cur][mt][e], x[4 * s + e], acc[mt]);
-        MARL_SPREAD_READS(s + 1 < N1 ? MT : 2 * MT, 4 * MT)
         __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        h1[mt] = relu4(acc[mt]);
+        h1[mt] = relu4l(acc[mt]);
         acc[mt] = nb[mt];
     }
     // ---- layer 2
@@ -561,30 +603,62 @@ __device__ __forceinline__ void mlp_forward_f(const float* lds, const FwdHead<S>
     for (int k1 = 0; k1 < MT; ++k1) {
         const int cur = (N1 + k1) & 1, nxt = cur ^ 1;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) op[nxt][mt] = (k1 + 1 < MT) ? A2[(mt * MT + k1 + 1) * 64 + lane] : A3[mt * 64 + lane];
-        if (k1 + 1 == MT) o3a = *reinterpret_cast<const f4*>(lds + S::pb3 + 4 * g);
+        for (int mt = 0; mt < MT; ++mt) {
+            if (k1 + 1 < MT) op[nxt][mt] = A2[(mt * MT + k1 + 1) * 64 + lane];
+            else if (WITH_L3) op[nxt][mt] = A3[mt * 64 + lane];
+        }
+        if (WITH_L3 && k1 + 1 == MT) o3a = *reinterpret_cast<const f4*>(lds + S::pb3 + 4 * g);
         fill(N1 + k1);
+        MARL_VB()
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) acc[mt] = MARL_MFMA(op[cur][mt][r], h1[k1][r], acc[mt]);
-        MARL_SPREAD_READS(k1 + 1 < MT ? MT : MT + 1, 4 * MT)
         __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) h2[mt] = relu4(acc[mt]);
-    // ---- layer 3: chains over the even and the odd k-tiles
+    for (int mt = 0; mt < MT; ++mt) h2[mt] = relu4l(acc[mt]);
+    // ---- layer 3
     constexpr int c3 = (N1 + MT) & 1;
     fill(N1 + MT);
+    if (WITH_L3) {
+        MARL_VB()
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int k1 = 0; k1 < MT; k1 += 2) {
-            o3a = MARL_MFMA(op[c3][k1][r], h2[k1][r], o3a);
-            if (k1 + 1 < MT) o3b = MARL_MFMA(op[c3][k1 + 1][r], h2[k1 + 1][r], o3b);
-        }
-    __builtin_amdgcn_sched_barrier(0);
-    q = o3a + o3b;
+            for (int k1 = 0; k1 < MT; k1 += 2) {
+                o3a = MARL_MFMA(op[c3][k1][r], h2[k1][r], o3a);
+                if (k1 + 1 < MT) o3b = MARL_MFMA(op[c3][k1 + 1][r], h2[k1 + 1][r], o3b);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        qa = o3a;
+        qb = o3b;
+    }
+}
+
+// row `a` of the output layer as the registers of lane (g, .): W3[a][16mt + 4g + r] for mt = 0..MT-1, r = 0..3 - straight out of the
+// A3 block of the forward pack (A3[mt][lane = (g, i = a)][r]), one ds_read_b128 per hidden tile with a per-lane address
+template <class S>
+__device__ __forceinline__ void mlp_w3_row(const float* lds, int lane, int a, f4 (&w)[S::MT]) {
+    const f4* A3 = reinterpret_cast<const f4*>(lds + S::pA3);
+    const int g = lane >> 4;
+#pragma unroll
+    for (int mt = 0; mt < S::MT; ++mt) w[mt] = A3[mt * 64 + g * 16 + a];
+}
+
+// output `a` (per row j, a may differ between rows) of the network whose second hidden layer is h2 (C layout): b3[a] + sum_h
+// W3[a][h] h2[h], the 16 products of a lane first, then the four lane groups of the row; every lane of row j gets it
+template <class S>
+__device__ __forceinline__ float mlp_output_at(const float* lds, int lane, int a, const f4 (&h2)[S::MT]) {
+    f4 w[S::MT];
+    mlp_w3_row<S>(lds, lane, a, w);
+    const float b3 = lds[S::pb3 + a];
+    float acc = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < S::MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc = fmaf(w[mt][r], h2[mt][r], acc);
+    return sum_g(acc) + b3;
 }
 
 // greedy action of batch row j from q in C layout (lane (g,j) holds Q[4g+r]):
