@@ -63,7 +63,8 @@ template <class S>
 struct UpdLds {
     static constexpr int oC = 0, oT = S::NFWD, oB = 2 * S::NFWD, oTiles = oB + S::NBWD;
     static constexpr int REC = S::NPARAM + 2;                 // partial record: grads, loss, n_filled
-    static constexpr int FOLD = S::NPARAM + (2 * S::H + 18) * 16;  // per-wave fold region (weights + bias/loss strips)
+    static constexpr int STRIP_OFF = (S::NPARAM + 3) / 4 * 4;     // strips start 16-byte aligned behind the weights
+    static constexpr int FOLD = STRIP_OFF + (2 * S::H + 18) * 16;  // per-wave fold region (weights + bias/loss strips)
     // per wave: [h2 tile, later the dH1 tile][h1 tile][dH2 tile][dQ tile]; the dH1 tile re-uses the h2 tile, whose only reader
     // (the dW3 operands) has retired long before dH1 exists
     static constexpr int per_wave(int ts) { return 3 * ts * S::H + 16 * ts; }
@@ -515,10 +516,15 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dqn_lossgrad_kernel(con
                         if (DO_TGT) bootstrap();
                         MARL_VB()
                     }
+                    if constexpr (MARL_MFMA_VGPR && MT == 4) {
+                        mfma16_v(dH1, t2[cb], dH2[m2].x, dH2[m2].y, dH2[m2].z, dH2[m2].w);
+                        if (m2 == MT - 1) mfma_settle(dH1);
+                    } else {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
+                        for (int r = 0; r < 4; ++r)
 #pragma unroll
-                        for (int m1 = 0; m1 < MT; ++m1) dH1[m1] = MARL_MFMA(t2[cb][m1][r], dH2[m2][r], dH1[m1]);
+                            for (int m1 = 0; m1 < MT; ++m1) dH1[m1] = MARL_MFMA(t2[cb][m1][r], dH2[m2][r], dH1[m1]);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                     if (m2 + 2 < MT) {
 #pragma unroll
@@ -602,7 +608,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dqn_lossgrad_kernel(con
     __syncthreads();
     {
         float* mine = lds + (size_t)wave * L::FOLD;
-        float* strips = mine + S::NPARAM;  // [(2H + 16) bias rows + 2 loss rows][16]
+        float* strips = mine + L::STRIP_OFF;  // [(2H + 16) bias rows + 2 loss rows][16]
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -634,26 +640,43 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dqn_lossgrad_kernel(con
     }
     __syncthreads();
     float* rec = partials + ((size_t)p * gridDim.x + blockIdx.x) * L::REC;
-    for (int i = tid; i < L::REC; i += UPD_BLOCK) {
-        // which strip (if any) holds element i
-        int strip = -1;
-        if (i >= S::ob1 && i < S::ob1 + H) strip = i - S::ob1;
-        else if (i >= S::ob2 && i < S::ob2 + H) strip = H + i - S::ob2;
-        else if (i >= S::ob3 && i < S::ob3 + A) strip = 2 * H + i - S::ob3;
-        else if (i >= S::NPARAM) strip = 2 * H + 16 + (i - S::NPARAM);
+    // plain elements: sum of the four regions in wave order, 16 bytes per thread and step (the bias / loss slots are written by
+    // the strip pass below; what this pass leaves there is overwritten)
+    if constexpr (L::REC % 4 == 0 && L::FOLD % 4 == 0) {
+        for (int i4 = tid; i4 < L::REC / 4; i4 += UPD_BLOCK) {
+            f4 acc = reinterpret_cast<const f4*>(lds)[i4];
+#pragma unroll
+            for (int w = 1; w < WAVES; ++w) acc += reinterpret_cast<const f4*>(lds + (size_t)w * L::FOLD)[i4];
+            reinterpret_cast<f4*>(rec)[i4] = acc;
+        }
+    } else {
+        for (int i = tid; i < L::REC; i += UPD_BLOCK) {
+            float acc = lds[i];
+#pragma unroll
+            for (int w = 1; w < WAVES; ++w) acc += lds[(size_t)w * L::FOLD + i];
+            rec[i] = acc;
+        }
+    }
+    __syncthreads();  // the strip pass overwrites slots the plain pass has just stored (same workgroup, global memory)
+    // strips: b1 (H), b2 (H), b3 (16 slots, A used), loss, n_filled - one thread per strip, 16 lane partials per wave region
+    for (int sidx = tid; sidx < 2 * H + 18; sidx += UPD_BLOCK) {
+        int i = -1;
+        if (sidx < H) i = S::ob1 + sidx;
+        else if (sidx < 2 * H) i = S::ob2 + (sidx - H);
+        else if (sidx < 2 * H + 16) i = (sidx - 2 * H) < A ? S::ob3 + (sidx - 2 * H) : -1;
+        else i = S::NPARAM + (sidx - 2 * H - 16);
+        if (i < 0) continue;
         float acc = 0.f;
 #pragma unroll
         for (int w = 0; w < WAVES; ++w) {
-            const float* reg = lds + (size_t)w * L::FOLD;
-            if (strip < 0) {
-                acc += reg[i];
-            } else {
-                const float* sp = reg + S::NPARAM + strip * 16;
-                float t = 0.f;
+            const f4* sp = reinterpret_cast<const f4*>(lds + (size_t)w * L::FOLD + L::STRIP_OFF + sidx * 16);
+            float t = 0.f;
 #pragma unroll
-                for (int k = 0; k < 16; ++k) t += sp[k];
-                acc += t;
+            for (int k4 = 0; k4 < 4; ++k4) {
+                const f4 v = sp[k4];
+                t += v.x; t += v.y; t += v.z; t += v.w;
             }
+            acc += t;
         }
         rec[i] = acc;
     }

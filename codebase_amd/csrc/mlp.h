@@ -26,6 +26,10 @@ namespace marl {
 typedef float f4 __attribute__((ext_vector_type(4)));
 
 #define MARL_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+#ifndef MARL_MFMA_VGPR
+#define MARL_MFMA_VGPR 1
+#endif
+#define MARL_MFMA_VGPR_DEFAULT MARL_MFMA_VGPR
 
 template <int D_, int H_, int A_>
 struct MlpShape {
@@ -517,7 +521,8 @@ __device__ __forceinline__ f4 relu4l(f4 v) {
 // every forward, where nothing hides the read latency
 template <class S>
 struct FwdHead {
-    static constexpr bool RESIDENT = S::DP <= 16;  // wide first layers need the registers for their x / dW1 tiles: re-read per forward
+    // (not with VGPR accumulators, which need the registers; nor for wide first layers, whose x / dW1 tiles do)
+    static constexpr bool RESIDENT = S::DP <= 16 && !(MARL_MFMA_VGPR_DEFAULT && S::MT == 4);
     f4 op0[S::MT], b1[S::MT];
     __device__ __forceinline__ void load(const float* lds, int lane) {
         const f4* A1 = reinterpret_cast<const f4*>(lds + S::pA1);
@@ -544,6 +549,61 @@ struct FwdHead {
 
 // WITH_L3 = false stops after the second hidden layer (h2 only): the caller wants ONE output per row (the target value of the
 // bootstrap action) and forms it as a dot product (mlp_output_at) instead of 16 output-layer MFMAs that are 10/16 padding
+// MARL_MFMA_VGPR (default 1): the MFMA groups whose results the VALU reads next (hidden-layer pre-activations, dH1) are written
+// as inline asm with VGPR accumulators.  hipcc gives every MFMA of a kernel that may use more than 256 registers an AGPR
+// destination, so each element a relu / mask touches first costs a v_accvgpr_read - and next to f32 MFMAs a VALU instruction is
+// never free (MARL_BURST above).  The weight-gradient accumulators, which no VALU instruction reads before the fold, stay on the
+// builtin (AGPR) form.  Wait states the compiler does not insert for asm (guide 5.7 item 2): `s_nop 1` in front (a just-written
+// VGPR operand), and mfma_settle() - 12 states - between the last MFMA of a chain and the first non-MFMA reader of its result.
+#ifndef MARL_MFMA_VGPR
+#define MARL_MFMA_VGPR 1
+#endif
+
+// acc[mt] += a[mt][e] * b_e for e = 0..3 (outer), mt = 0..3 (inner): 16 MFMAs on four chains, VGPR accumulators
+__device__ __forceinline__ void mfma16_v(f4 (&acc)[4], const f4 (&a)[4], float b0, float b1, float b2, float b3) {
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_mfma_f32_16x16x4_f32 %0, %4, %20, %0\n\t"
+        "v_mfma_f32_16x16x4_f32 %1, %8, %20, %1\n\t"
+        "v_mfma_f32_16x16x4_f32 %2, %12, %20, %2\n\t"
+        "v_mfma_f32_16x16x4_f32 %3, %16, %20, %3\n\t"
+        "v_mfma_f32_16x16x4_f32 %0, %5, %21, %0\n\t"
+        "v_mfma_f32_16x16x4_f32 %1, %9, %21, %1\n\t"
+        "v_mfma_f32_16x16x4_f32 %2, %13, %21, %2\n\t"
+        "v_mfma_f32_16x16x4_f32 %3, %17, %21, %3\n\t"
+        "v_mfma_f32_16x16x4_f32 %0, %6, %22, %0\n\t"
+        "v_mfma_f32_16x16x4_f32 %1, %10, %22, %1\n\t"
+        "v_mfma_f32_16x16x4_f32 %2, %14, %22, %2\n\t"
+        "v_mfma_f32_16x16x4_f32 %3, %18, %22, %3\n\t"
+        "v_mfma_f32_16x16x4_f32 %0, %7, %23, %0\n\t"
+        "v_mfma_f32_16x16x4_f32 %1, %11, %23, %1\n\t"
+        "v_mfma_f32_16x16x4_f32 %2, %15, %23, %2\n\t"
+        "v_mfma_f32_16x16x4_f32 %3, %19, %23, %3\n\t"
+        : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3])
+        : "v"(a[0].x), "v"(a[0].y), "v"(a[0].z), "v"(a[0].w), "v"(a[1].x), "v"(a[1].y), "v"(a[1].z), "v"(a[1].w), "v"(a[2].x), "v"(a[2].y),
+          "v"(a[2].z), "v"(a[2].w), "v"(a[3].x), "v"(a[3].y), "v"(a[3].z), "v"(a[3].w), "v"(b0), "v"(b1), "v"(b2), "v"(b3));
+}
+// acc0 += a0[r] * b0[r], acc1 += a1[r] * b1[r] for r = 0..3: 8 MFMAs on two chains (the output layer's even / odd k-tiles)
+__device__ __forceinline__ void mfma8_v2(f4& acc0, f4& acc1, const f4& a0, const f4& a1, const f4& b0, const f4& b1) {
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_mfma_f32_16x16x4_f32 %0, %2, %10, %0\n\t"
+        "v_mfma_f32_16x16x4_f32 %1, %6, %14, %1\n\t"
+        "v_mfma_f32_16x16x4_f32 %0, %3, %11, %0\n\t"
+        "v_mfma_f32_16x16x4_f32 %1, %7, %15, %1\n\t"
+        "v_mfma_f32_16x16x4_f32 %0, %4, %12, %0\n\t"
+        "v_mfma_f32_16x16x4_f32 %1, %8, %16, %1\n\t"
+        "v_mfma_f32_16x16x4_f32 %0, %5, %13, %0\n\t"
+        "v_mfma_f32_16x16x4_f32 %1, %9, %17, %1\n\t"
+        : "+v"(acc0), "+v"(acc1)
+        : "v"(a0.x), "v"(a0.y), "v"(a0.z), "v"(a0.w), "v"(a1.x), "v"(a1.y), "v"(a1.z), "v"(a1.w), "v"(b0.x), "v"(b0.y), "v"(b0.z), "v"(b0.w),
+          "v"(b1.x), "v"(b1.y), "v"(b1.z), "v"(b1.w));
+}
+__device__ __forceinline__ void mfma_settle(f4 (&acc)[4]) {
+    asm volatile("s_nop 11" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+}
+__device__ __forceinline__ void mfma_settle2(f4& a, f4& b) { asm volatile("s_nop 11" : "+v"(a), "+v"(b)); }
+
 template <class S, bool WITH_L3 = true, class F>
 __device__ __forceinline__ void mlp_forward_f(const float* lds, const FwdHead<S>& head, int lane, const float (&x)[S::KS1], f4 (&h1)[S::MT],
                                               f4 (&h2)[S::MT], f4& qa, f4& qb, F&& fill) {
@@ -552,6 +612,7 @@ __device__ __forceinline__ void mlp_forward_f(const float* lds, const FwdHead<S>
     // relu of a layer is one burst behind its last group.  Layer 3 runs as two chains (even / odd k-tiles -> qa / qb, added by
     // the caller where it first needs q): a single dependent 16x16x4 chain would cost 40 cycles per MFMA instead of 32.
     constexpr int MT = S::MT, N1 = S::KS1 / 4;
+    constexpr bool VG = MARL_MFMA_VGPR && MT == 4;  // asm groups are written for four hidden tiles
     const int g = lane >> 4;
     const f4* A1 = reinterpret_cast<const f4*>(lds + S::pA1);
     const f4* A2 = reinterpret_cast<const f4*>(lds + S::pA2);
@@ -586,12 +647,17 @@ __device__ __forceinline__ void mlp_forward_f(const float* lds, const FwdHead<S>
         }
         fill(s);
         MARL_VB()
+        if constexpr (VG) {
+            mfma16_v(acc, op[cur], x[4 * s], x[4 * s + 1], x[4 * s + 2], x[4 * s + 3]);
+        } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
+            for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[mt] = MARL_MFMA(op[cur][mt][e], x[4 * s + e], acc[mt]);
+                for (int mt = 0; mt < MT; ++mt) acc[mt] = MARL_MFMA(op[cur][mt][e], x[4 * s + e], acc[mt]);
+        }
         __builtin_amdgcn_sched_barrier(0);
     }
+    if constexpr (VG) mfma_settle(acc);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         h1[mt] = relu4l(acc[mt]);
@@ -610,12 +676,17 @@ __device__ __forceinline__ void mlp_forward_f(const float* lds, const FwdHead<S>
         if (WITH_L3 && k1 + 1 == MT) o3a = *reinterpret_cast<const f4*>(lds + S::pb3 + 4 * g);
         fill(N1 + k1);
         MARL_VB()
+        if constexpr (VG) {
+            mfma16_v(acc, op[cur], h1[k1].x, h1[k1].y, h1[k1].z, h1[k1].w);
+        } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+            for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[mt] = MARL_MFMA(op[cur][mt][r], h1[k1][r], acc[mt]);
+                for (int mt = 0; mt < MT; ++mt) acc[mt] = MARL_MFMA(op[cur][mt][r], h1[k1][r], acc[mt]);
+        }
         __builtin_amdgcn_sched_barrier(0);
     }
+    if constexpr (VG) mfma_settle(acc);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) h2[mt] = relu4l(acc[mt]);
     // ---- layer 3
@@ -623,13 +694,19 @@ __device__ __forceinline__ void mlp_forward_f(const float* lds, const FwdHead<S>
     fill(N1 + MT);
     if (WITH_L3) {
         MARL_VB()
+        if constexpr (VG) {
+            mfma8_v2(o3a, o3b, op[c3][0], op[c3][1], h2[0], h2[1]);
+            mfma8_v2(o3a, o3b, op[c3][2], op[c3][3], h2[2], h2[3]);
+            mfma_settle2(o3a, o3b);
+        } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+            for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int k1 = 0; k1 < MT; k1 += 2) {
-                o3a = MARL_MFMA(op[c3][k1][r], h2[k1][r], o3a);
-                if (k1 + 1 < MT) o3b = MARL_MFMA(op[c3][k1 + 1][r], h2[k1 + 1][r], o3b);
-            }
+                for (int k1 = 0; k1 < MT; k1 += 2) {
+                    o3a = MARL_MFMA(op[c3][k1][r], h2[k1][r], o3a);
+                    if (k1 + 1 < MT) o3b = MARL_MFMA(op[c3][k1 + 1][r], h2[k1 + 1][r], o3b);
+                }
+        }
         __builtin_amdgcn_sched_barrier(0);
         qa = o3a;
         qb = o3b;

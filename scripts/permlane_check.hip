@@ -22,7 +22,7 @@ __global__ void k(const float* in, float* out, int* iout) {
     iout[lane] = argmax_rows_pl<6>(q, lane);
     iout[64 + lane] = argmax_rows<6>(q, lane);
     const int a = (lane * 7) % 6;
-    out[320 + lane] = gather_rows_pl(q, lane, a);
+    out[320 + lane] = gather_rows_pl<6>(q, lane, a);
     out[384 + lane] = gather_rows(q, lane, a);
 }
 
