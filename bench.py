@@ -39,8 +39,8 @@ PEAK_HBM_GBS = 8000.0
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--envs", type=int, default=4096, help="batched envs per GPU")
     ap.add_argument("--hidden", type=int, default=64)
     ap.add_argument("--time-limit", type=int, default=25)
@@ -100,10 +100,67 @@ def cpu_baseline(seconds, hidden):
             learner.update(rb.sample(32))
             updates += 1
     dt = time.perf_counter() - t0
-    return {"value": (steps - s0) / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
+    v = (steps - s0) / dt
+    return {"value": v, "unit": "env-steps/s", "cores": 1, "kind": "port", "host_cores": os.cpu_count(),
+            "whole_node_estimate": v * (os.cpu_count() or 1),  # independent 1-thread runs on every host core (marlbase/run.py:29)
             "sample": f"{steps - s0} env-steps / {updates} updates of oracle/lbf.py + oracle/dqn_port.py "
                       f"(python LBF env + torch-CPU IDQN {hidden}-{hidden}, reference cadence: 1 update of 32 episodes "
                       f"per episode, 1 thread) in {dt:.1f} s; host has {os.cpu_count()} cores"}
+
+
+# ---- algorithmic FLOPs of one learner update (what `roofline.achieved` divides by the measured stage time) -------------------------
+def mlp_fwd_flops(D, H, A):
+    """one row through Linear(D,H)-ReLU-Linear(H,H)-ReLU-Linear(H,A) (utils/models.py:34-48)"""
+    return 2.0 * (D * H + H * H + H * A)
+
+
+def gru_fwd_flops(D, H, A):
+    """one row-step through Linear(D,H)-ReLU-GRU(H,H)-Linear(H,A) (utils/models.py:51-116): W_ih and W_hh are [3H][H] each"""
+    return 2.0 * (D * H + 6 * H * H + H * A)
+
+
+def qmix_mixer_fwd_flops(P, SD):
+    """QMixer.forward per (t, b) row with mixing = {embed 64, hypernet 2 x 32} (dqn/model.py:313-331): the four state-fed first
+    layers as one [192 x SD] product, hyper_w_1.2 [32 -> 64 P], hyper_w_final.2 [32 -> 64], V.2 [64 -> 1]"""
+    return 2.0 * (192 * SD + 32 * 64 * P + 32 * 64 + 64)
+
+
+def dqn_update_flops(algo, rnn, P, D, A, H, T, B):
+    """critic forward on T+1 observations, target forward on T (T+1 for recurrent nets: the sequence starts at t = 0), backward =
+    2 x forward on the T transitions (T+1 steps of BPTT for recurrent nets); QMIX adds online + target mixer forward and the
+    online mixer's backward (2 x) on the T * B rows."""
+    if rnn:
+        agents = gru_fwd_flops(D, H, A) * P * B * 4 * (T + 1)
+    else:
+        agents = mlp_fwd_flops(D, H, A) * P * B * ((T + 1) + T + 2 * T)
+    mixer = 4.0 * qmix_mixer_fwd_flops(P, P * D) * T * B if algo == "qmix" else 0.0
+    return agents + mixer, {"agent_networks": agents, "mixer": mixer}
+
+
+def ac_update_flops(rnn, P, D, A, H, T, N, central, epochs=1):
+    """target-critic forward on T+1 rows, critic and actor forward + backward (3 x forward) on T rows; recurrent nets walk
+    T+1 / T steps the same way.  PPO (`epochs` > 1): the prepare pass (target critic + old log-probs = one actor forward) once,
+    then critic + actor forward / backward per epoch - the timer brackets one launch group, so this returns the per-call mean."""
+    f = gru_fwd_flops if rnn else mlp_fwd_flops
+    fa, fc = f(D, H, A), f(P * D if central else D, H, 1)
+    if epochs > 1:  # launch groups under the timer per rollout: 1 prepare + `epochs` epoch steps
+        return P * N * ((fc * (T + 1) + fa * T) + epochs * (3 * fc + 3 * fa) * T) / (1 + epochs)
+    return P * N * (fc * (T + 1) + 3 * fc * T + 3 * fa * T)
+
+
+def traffic_from_profile(key):
+    """HBM bytes per launch of the named workload's dominant kernel from the committed rocprofv3 PMC passes (bench.py cannot run
+    rocprofv3 on itself): profiles/r02_pmc_traffic.json records the git head and the exact workload it was taken on; anything
+    else gets null."""
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
+        ent = pmc["workloads"].get(key)
+        if ent is None:
+            return None, None
+        return ent["traffic_bytes"], {"file": "profiles/r02_pmc_traffic.json", "head": pmc.get("head"), "kernel": ent.get("kernel"),
+                                      "algorithmic_bytes": ent.get("algorithmic_bytes")}
+    except (OSError, KeyError, ValueError):
+        return None, None
 
 
 def _ranks_field(world, dist, args):
@@ -213,13 +270,19 @@ def bench_ac(args, rank, world, dist):
     name = args.env_name.split(":")[-1].replace("-v3", "").replace("-v2", "")
     roofline = None
     upd = timing.get("ac_update (fwd rows x3, elementwise, bwd rows x2)")
+    col = timing.get("ac_collect_kernel")
     if upd:
-        # algorithmic flops per A2C update: target fwd (T+1 rows) + critic fwd+bwd (3x) + actor fwd+bwd (3x) on T rows
-        fa, fc = 2.0 * (D * H + H * H + H * A), 2.0 * ((P * D if central else D) * H + H * H + H)
-        flops = P * N * (fc * (T + 1) + 3 * fc * T + 3 * fa * T)
+        flops = ac_update_flops(bool(args.rnn), P, D, A, H, T, N, central, epochs=hyper["num_epochs"] if args.algo in ("ippo", "mappo") else 1)
         ach = flops / (upd["avg_us"] * 1e-6) / 1e12
-        roofline = {"kernel": "ac_update", "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None, "flops_per_launch": flops, "avg_launch_us": upd["avg_us"]}
+        roofline = {"kernel": "ac_update stage (forward rows, elementwise, backward rows)", "bound": "mfma", "achieved": ach,
+                    "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                    "flops_per_launch": flops, "avg_launch_us": upd["avg_us"],
+                    "dominant_stage_by_time": "ac_update" if not col or upd["total_ms"] >= col["total_ms"] else "ac_collect_kernel"}
+        if col and col["total_ms"] > upd["total_ms"]:  # the rollout dominates (long episodes, few envs): its acting forward next to it
+            cf = (gru_fwd_flops if args.rnn else mlp_fwd_flops)(D, H, A) * P * (env_steps / args.steps)
+            roofline["collector"] = {"kernel": "ac_collect_kernel", "bound": "mfma (latency-bound in practice: one wave per 16 envs walks the episode)",
+                                     "flops_per_launch": cf, "avg_launch_us": col["avg_us"],
+                                     "frac": cf / (col["avg_us"] * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS}
     out = {
         "metric": f"env-steps/sec (whole node) {args.algo.upper()} {name}", "value": env_steps / dt, "unit": "env-steps/s",
         "n_gpus": world, "rccl_ranks": _ranks_field(world, dist, args), "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
@@ -380,34 +443,33 @@ def main():
             dist.destroy_process_group()
         return
 
-    fwd_flops_row = 2.0 * (D * H + H * H + H * A)
     roofline = None
-    if U and "dqn_lossgrad_kernel" in timing:
-        # algorithmic flops per launch: critic fwd on P*B*(T+1) rows, target fwd on P*B*T, backward (2x fwd) on P*B*T
-        flops = fwd_flops_row * P * B * ((T + 1) + T + 2 * T)
-        avg_s = timing["dqn_lossgrad_kernel"]["avg_us"] * 1e-6
+    lg, col = timing.get("dqn_lossgrad_kernel"), timing.get("idqn_collect_kernel")
+    if U and lg:
+        # the timer brackets the loss/grad launch group of one update: agent forward(s) [+ mixer stage] + agent backward
+        flops, parts = dqn_update_flops(args.algo, bool(args.rnn), P, D, A, H, T, B)
+        avg_s = lg["avg_us"] * 1e-6
         ach = flops / avg_s / 1e12
-        # HBM traffic per launch from the committed rocprofv3 PMC passes (FETCH_SIZE doubled per the gfx950 note,
-        # + WRITE_SIZE), valid for the profiled workload only; bench.py cannot run rocprofv3 on itself
-        traffic = None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            if (N, H, B, T) == (4096, 64, 4096, 25):
-                traffic = pmc["kernels"]["dqn_lossgrad_kernel<15,64,6> (replay gather, B=4096)"]["traffic_bytes"]
-        except (OSError, KeyError, ValueError):
-            pass
-        roofline = {"kernel": "dqn_lossgrad_kernel", "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
-                    "flops_per_launch": flops, "avg_launch_us": timing["dqn_lossgrad_kernel"]["avg_us"]}
-    elif "idqn_collect_kernel" in timing:
+        key = f"{args.algo}:{args.env_name}:N{N}:H{H}:B{B}:T{T}:rnn{int(bool(args.rnn))}"
+        traffic, tsrc = traffic_from_profile(key)
+        kname = ("gru_seq_fwd2 + gru_td + gru_seq_bwd + gru_wgrad" if args.rnn else
+                 ("dqn_lossgrad_kernel" if H <= 64 and D <= 48 else "tp_fwd_kernel + tp_mix_kernel + tp_bwd_kernel")) + (" + qmix mixer stage" if args.algo == "qmix" else "")
+        roofline = {"kernel": kname, "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": tsrc, "flops_per_launch": flops,
+                    "flops_parts": parts, "avg_launch_us": lg["avg_us"],
+                    "dominant_stage_by_time": "loss/grad" if not col or lg["total_ms"] >= col["total_ms"] else "idqn_collect_kernel"}
+        if col and col["total_ms"] > lg["total_ms"]:
+            cf = (gru_fwd_flops if args.rnn else mlp_fwd_flops)(D, H, A) * P * (env_steps / args.steps)
+            roofline["collector"] = {"kernel": "idqn_collect_kernel", "bound": "mfma (latency-bound in practice)", "flops_per_launch": cf,
+                                     "avg_launch_us": col["avg_us"], "frac": cf / (col["avg_us"] * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS}
+    elif col:
         # env-only: the collector's HBM traffic is the replay write, 4*P*D + P + 4*P + 2 bytes per env-step (+ row 0)
         per_step = 4 * P * D + P + 4 * P + 2
         byts = per_step * env_steps / args.steps + 4 * P * D * N
-        avg_s = timing["idqn_collect_kernel"]["avg_us"] * 1e-6
+        avg_s = col["avg_us"] * 1e-6
         ach = byts / avg_s / 1e9
         roofline = {"kernel": "idqn_collect_kernel", "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                    "frac": ach / PEAK_HBM_GBS, "traffic": None, "bytes_per_launch": byts,
-                    "avg_launch_us": timing["idqn_collect_kernel"]["avg_us"]}
+                    "frac": ach / PEAK_HBM_GBS, "traffic": None, "bytes_per_launch": byts, "avg_launch_us": col["avg_us"]}
 
     out = {
         "metric": f"env-steps/sec (whole node) {args.algo.upper()} {args.env_name.split(':')[-1].replace('-v3', '')}",
@@ -427,6 +489,10 @@ def main():
             "workload": f"{args.algo.upper()} on {args.env_name.split(':')[-1].replace('-v3', '')}, {N} batched HIP envs per GPU, "
                         + (f"GRU-{H} networks (use_rnn), " if args.rnn else f"2-layer-{H} MLP, ") + f"time_limit {T}",
             "cadence": args.cadence,
+            "cadence_note": ("the reference's replay ratio (32 sampled episodes per collected episode), gradient steps batched: U updates of B "
+                             "episodes per round; return-vs-env-steps against the reference cadence: profiles/r02_learning_parity.md")
+            if args.cadence == "ratio" else ("the reference's own cadence: one update of 32 episodes per collected episode, sequentially"
+                                             if args.cadence == "reference" else "collection only"),
             "envs_per_gpu": N,
             "updates_per_round": U,
             "update_batch_episodes": B,

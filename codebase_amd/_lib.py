@@ -64,7 +64,7 @@ class QmixMixer(ctypes.Structure):
 class AcConfig(ctypes.Structure):
     _fields_ = [("n_steps", c_int32), ("entropy_coef", c_float), ("value_loss_coef", c_float), ("ppo_clip", c_float),
                 ("gamma", c_double), ("ret_mean", c_void_p), ("ret_var", c_void_p), ("ret_count", c_void_p),
-                ("centralised_critic", c_int32)]
+                ("centralised_critic", c_int32), ("side_stream", c_void_p)]
 
 
 class RetStatsStruct(ctypes.Structure):
@@ -102,13 +102,14 @@ PROTOTYPES = {
                                      c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
     "marlhip_rware_idqn_collect": (c_int32, [POINTER(RwareConfig), POINTER(NetShape), c_void_p, c_float, c_uint32,
                                              POINTER(ReplayShape), POINTER(ReplayBuffers), c_int32, c_int32, c_int32, c_int32,
-                                             c_void_p, c_void_p, c_void_p]),
+                                             c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "marlhip_rware_ac_collect": (c_int32, [POINTER(RwareConfig), POINTER(NetShape), c_void_p, c_uint32, c_int32, c_int32, c_void_p,
-                                           c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                           c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                           c_void_p]),
     "marlhip_gru_nparams": (c_int32, [POINTER(NetShape)]),
     "marlhip_gru_record_floats": (c_int64, [POINTER(NetShape), c_int32, c_int32]),
     "marlhip_gru_forward": (c_int32, [POINTER(NetShape), c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
-                                      c_void_p]),
+                                      c_void_p, c_int64, c_void_p]),
     "marlhip_gru_workspace_bytes": (c_int64, [POINTER(NetShape), c_int32, c_int32]),
     "marlhip_gru_loss_grad": (c_int32, [POINTER(NetShape), c_void_p, c_void_p, POINTER(BatchStruct), c_float, c_int32, c_int32, c_void_p,
                                         c_int64, c_void_p, c_void_p, c_void_p]),
@@ -126,7 +127,7 @@ PROTOTYPES = {
     "marlhip_gru_ppo_loss_grad": (c_int32, [POINTER(NetShape), c_void_p, c_void_p, POINTER(BatchStruct), POINTER(AcConfig),
                                             c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "marlhip_gru_ac_forward": (c_int32, [POINTER(NetShape), c_int32, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int32, c_void_p,
-                                         c_void_p, c_void_p, c_void_p]),
+                                         c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "marlhip_sample_from_logits": (c_int32, [c_int32, c_int32, c_int32, c_void_p, c_uint64, c_void_p, c_int32, c_void_p, c_void_p]),
     "marlhip_act_from_q": (c_int32, [c_int32, c_int32, c_int32, c_void_p, c_float, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "marlhip_net_nparams": (c_int32, [POINTER(NetShape)]),
@@ -160,7 +161,7 @@ PROTOTYPES = {
     "marlhip_ac_critic_nparams": (c_int32, [POINTER(NetShape), c_int32]),
     "marlhip_ac_workspace_bytes": (c_int64, [POINTER(NetShape), c_int32, c_int32, c_int32]),
     "marlhip_ac_forward_rows": (c_int32, [POINTER(NetShape), c_int32, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_void_p,
-                                          c_void_p]),
+                                          c_void_p, c_int64, c_void_p]),
     "marlhip_a2c_loss_grad": (c_int32, [POINTER(NetShape), c_void_p, c_void_p, c_void_p, POINTER(BatchStruct), POINTER(AcConfig),
                                         c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "marlhip_ppo_prepare": (c_int32, [POINTER(NetShape), c_void_p, c_void_p, c_void_p, POINTER(BatchStruct), POINTER(AcConfig),
@@ -171,14 +172,15 @@ PROTOTYPES = {
                                         c_double, c_double, c_double, c_float, c_float, c_int32, c_float, c_void_p,
                                         c_void_p, c_void_p]),
     "marlhip_ac_collect": (c_int32, [POINTER(LbfConfig), POINTER(NetShape), c_void_p, c_uint32, c_int32, c_int32, c_void_p,
-                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "marlhip_idqn_update_n": (c_int32, [POINTER(IdqnLearner), c_int32, c_int32, c_uint64, c_uint32, POINTER(c_int64),
                                         POINTER(c_int64), POINTER(c_int64), c_void_p]),
     "marlhip_timing_enable": (c_int32, [c_int32]),
     "marlhip_timing_read": (c_int32, [c_int32, POINTER(c_int64), POINTER(c_double)]),
     "marlhip_idqn_collect": (c_int32, [POINTER(LbfConfig), POINTER(NetShape), c_void_p, c_float, c_uint32,
                                        POINTER(ReplayShape), POINTER(ReplayBuffers), c_int32, c_int32, c_int32, c_int32,
-                                       c_void_p, c_void_p, c_void_p]),
+                                       c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "marlhip_forward_workspace_bytes": (c_int64, [POINTER(NetShape)]),
 }
 
 if not os.path.exists(LIB_PATH):

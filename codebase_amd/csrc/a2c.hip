@@ -100,8 +100,10 @@ static int ac_call(const marlhip_net_shape* s, const float* actor, const float* 
 }
 
 extern "C" int marlhip_ac_forward_rows(const marlhip_net_shape* s, int32_t value_net, const float* params, const float* obs,
-                                       int64_t agent_stride, int64_t row_stride, int32_t n_rows, float* out, void* stream) {
+                                       int64_t agent_stride, int64_t row_stride, int32_t n_rows, float* out, void* workspace,
+                                       int64_t workspace_bytes, void* stream) {
     if (ac_check(s, value_net == 2) != 0) return -1;
+    ScratchScope scratch(workspace, workspace_bytes);
     MARL_REQUIRE(params && obs && out && n_rows > 0 && row_stride > 0 && (agent_stride > 0 || value_net == 2), "ac_forward_rows: bad argument");
     marlhip_batch bt = {};
     bt.obss = obs; bt.max_len = 1; bt.batch = 1;

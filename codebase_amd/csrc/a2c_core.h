@@ -57,10 +57,10 @@ int launch_forward_rows(int P, const AgentMap& am, const float* params, const ma
     const size_t as = bt->obs_agent_stride > 0 ? (size_t)bt->obs_agent_stride : (bt->obs_agent_stride < 0 ? 0 : (size_t)(T + 1) * B * S::D);
     const size_t rs = bt->obs_row_stride ? (size_t)bt->obs_row_stride : (size_t)S::D;
     constexpr int LDSB = S::NFWD * (int)sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static LdsAttr attr_set;
+    if (attr_set.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_rows_fwd_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
-        attr_set = true;
+        attr_set.done();
     }
     const int npair = ((n_rows + 15) / 16 + 1) / 2;
     int gx = (npair + 3) / 4;
@@ -111,11 +111,11 @@ int launch_backward_rows(int P, const AgentMap& am, const float* params, const m
         mix.lrow = lrow;
         mix.dout = dout;
         const size_t ldsB = (size_t)(NB * NT * 256 + NB * S::H * 16 + NB * NT * 256 + W * 256 * (1 + 3 * TPW)) * sizeof(float);
-        static bool attr_set = false;
-        if (!attr_set) {
+        static LdsAttr attr_set;
+        if (attr_set.need()) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tp_bwd_kernel<S, W, TPW, false, NB, true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsB);
-            attr_set = true;
+            attr_set.done();
         }
         hipLaunchKernelGGL((tp_bwd_kernel<S, W, TPW, false, NB, true>), dim3(pl.nwg, P), dim3(64 * W), ldsB, st, params, am, *bt, none, mix,
                            pl.n_chunks, (float*)ws);
@@ -128,11 +128,11 @@ int launch_backward_rows(int P, const AgentMap& am, const float* params, const m
         const WsLayout wl = ws_layout(P, pl.nwg, L::REC, PACK, T, B);
         float* packs = reinterpret_cast<float*>(static_cast<char*>(ws) + wl.pack_off);
         const size_t lds_bytes = (size_t)L::total(4) * sizeof(float);
-        static bool attr_set = false;
-        if (!attr_set) {
+        static LdsAttr attr_set;
+        if (attr_set.need()) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dqn_lossgrad_kernel<S, 4, false, 4>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-            attr_set = true;
+            attr_set.done();
         }
         hipLaunchKernelGGL((dqn_pack_kernel<S>), dim3((PACK + 255) / 256, P), dim3(256), 0, st, params, params, am, packs);
         MixBufs mix = {};
@@ -304,32 +304,46 @@ static __global__ __launch_bounds__(1024) void ac_metrics_kernel(int nblocks, fl
     }
 }
 
-// A second stream per device for the recurrent step's critic BPTT: one sequence pass of the bench batch fills half of the SIMDs and
-// the actor's and the critics' passes are different kernels, so they overlap through a fork / join on events instead of a shared grid.
+// The recurrent step overlaps the critics' sequence passes with the actors' on a second stream: one pass of the bench batch fills half
+// of the SIMDs and the two are different kernels, so they overlap through a fork / join on events instead of a shared grid.  The
+// stream is the CALLER's (marlhip_ac_config.side_stream; NULL = everything on the call's stream); the two events live for the
+// duration of the call (created here, destroyed on return - a destroyed event's pending record still completes), and the join is
+// waited for on every exit path so that no side-stream kernel outlives the caller's ordering of the buffers it reads.
 struct SideStream {
-    hipStream_t s = nullptr;
+    hipStream_t s = nullptr, main = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
-};
-inline SideStream* side_stream() {
-    static SideStream per_dev[16];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    SideStream& x = per_dev[dev & 15];
-    if (x.s == nullptr) {
-        if (hipStreamCreateWithFlags(&x.s, hipStreamNonBlocking) != hipSuccess) return nullptr;
-        if (hipEventCreateWithFlags(&x.fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&x.join, hipEventDisableTiming) != hipSuccess) {
-            (void)hipStreamDestroy(x.s);
-            x.s = nullptr;
-            return nullptr;
-        }
+    bool forked = false;
+    SideStream(void* side, hipStream_t main_st) : main(main_st) {
+        if (side == nullptr || side == (void*)main_st) return;
+        if (hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess) { fork = nullptr; return; }
+        if (hipEventCreateWithFlags(&join, hipEventDisableTiming) != hipSuccess) { (void)hipEventDestroy(fork); fork = join = nullptr; return; }
+        s = (hipStream_t)side;
     }
-    return &x;
-}
+    bool ok() const { return s != nullptr; }
+    void do_fork() {  // the side stream continues behind everything queued on the main stream so far
+        (void)hipEventRecord(fork, main);
+        (void)hipStreamWaitEvent(s, fork, 0);
+        forked = true;
+    }
+    void do_join() {  // the main stream continues behind everything queued on the side stream so far
+        if (!forked) return;
+        (void)hipEventRecord(join, s);
+        (void)hipStreamWaitEvent(main, join, 0);
+        forked = false;
+    }
+    ~SideStream() {
+        if (s == nullptr) return;
+        do_join();
+        (void)hipEventDestroy(fork);
+        (void)hipEventDestroy(join);
+    }
+    SideStream(const SideStream&) = delete;
+    SideStream& operator=(const SideStream&) = delete;
+};
 
 // workspace: [vnext | v | logits | dlogits | dv | lrow_a | lrow_v | ent | ret | oldlogp | loss scratch 4][backward workspace]
 struct AcWs {
-    int64_t vnext, v, logits, dlogits, dv, lrow_a, lrow_v, ent, ret, oldlogp, partial, rpartial, scratch, rec_a, rec_c, bwd, bwd_c, total;
+    int64_t vnext, v, logits, dlogits, dv, lrow_a, lrow_v, ent, ret, oldlogp, partial, rpartial, scratch, packs, packs_bytes, rec_a, rec_c, bwd, bwd_c, total;
 };
 
 template <class SA, class SC>
@@ -351,6 +365,9 @@ AcWs ac_ws_layout(int P, int T, int B) {
     w.partial = take(4 * ((TB + 255) / 256));
     w.rpartial = take(2 * P * ((TB + 255) / 256));
     w.scratch = take(8);
+    // weight packs of the forward-rows launches (two networks at once for the paired recurrent pass): collect_pack_scratch's region
+    w.packs_bytes = (int64_t)2 * P * (SA::NFWD > SC::NFWD ? SA::NFWD : SC::NFWD) * 4 + 16;
+    w.packs = take(w.packs_bytes / 4 + 1);
     w.rec_a = w.rec_c = o;  // recurrent networks: the activation records of this step's actor / critic forward passes
     if constexpr (IsGru<SA>::value) w.rec_a = take(gru_rec_floats<SA>(P, T, B));
     if constexpr (IsGru<SC>::value) w.rec_c = take(gru_rec_floats<SC>(P, T, B));
@@ -374,6 +391,7 @@ int ac_step_t(int P, const AgentMap& am, const float* actor, const float* critic
     const AcWs wl = ac_ws_layout<SA, SC>(P, T, B);
     MARL_REQUIRE(ws_bytes >= wl.total, "ac_loss_grad: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)wl.total);
     char* base = static_cast<char*>(ws);
+    ScratchScope pack_scope(base + wl.packs, wl.packs_bytes);
     auto f = [&](int64_t off) { return reinterpret_cast<float*>(base + off); };
     AcBufs w;
     w.logits = f(wl.logits); w.v = f(wl.v); w.vnext = f(wl.vnext); w.dlogits = f(wl.dlogits); w.dv = f(wl.dv);
@@ -394,18 +412,13 @@ int ac_step_t(int P, const AgentMap& am, const float* actor, const float* critic
     bool v_done = false;
     // PPO's passes with recurrent networks (prepare: target critics + actors; epochs: actors + critics): the critics' sequence pass
     // goes to the side stream next to the actors' (each fills half of the SIMDs), with its packs in the critics' backward workspace
-    SideStream* fwd_side = nullptr;
+    SideStream side(IsGru<SA>::value && IsGru<SC>::value ? c->side_stream : nullptr, st);  // joins on every return path
     auto side_forward = [&](const float* prm, int steps, float* out, float* rec) -> int {  // -2: not available
         if constexpr (IsGru<SA>::value && IsGru<SC>::value) {
-            SideStream* sd = side_stream();
-            if (sd == nullptr) return -2;
+            if (!side.ok()) return -2;
             float* pk = reinterpret_cast<float*>(base + wl.bwd_c + gru_rows_ws<SC>(P, T, B, false).packF);
-            (void)hipEventRecord(sd->fork, st);
-            (void)hipStreamWaitEvent(sd->s, sd->fork, 0);
-            const int r = gru_forward_rows<SC>(P, am, prm, bc, steps, out, sd->s, rec, pk);
-            (void)hipEventRecord(sd->join, sd->s);
-            fwd_side = sd;
-            return r;
+            side.do_fork();
+            return gru_forward_rows<SC>(P, am, prm, bc, steps, out, side.s, rec, pk);
         } else {
             (void)prm; (void)steps; (void)out; (void)rec;
             return -2;
@@ -439,7 +452,7 @@ int ac_step_t(int P, const AgentMap& am, const float* actor, const float* critic
     }
     rc = launch_forward_rows<SA>(P, am, actor, bt, TB, f(wl.logits), st, rec_a);
     if (rc != 0) return rc;
-    if (fwd_side != nullptr) (void)hipStreamWaitEvent(st, fwd_side->join, 0);  // join before the elementwise stage
+    side.do_join();  // before the elementwise stage
     hipLaunchKernelGGL(ac_elem_kernel, dim3((TB + 255) / 256), dim3(256), 0, st, a, *bt, w);
     MARL_CHECK_LAUNCH("ac_elem_kernel");
     if (mode == 1) {
@@ -449,20 +462,15 @@ int ac_step_t(int P, const AgentMap& am, const float* actor, const float* critic
         return 0;
     }
     float* scratch = f(wl.scratch);
-    SideStream* side = wl.bwd_c != wl.bwd ? side_stream() : nullptr;
     hipStream_t st_c = st;
-    if (side != nullptr) {  // fork: the critics' backward on the side stream, behind everything queued so far
-        (void)hipEventRecord(side->fork, st);
-        (void)hipStreamWaitEvent(side->s, side->fork, 0);
-        st_c = side->s;
+    if (wl.bwd_c != wl.bwd && side.ok()) {  // fork: the critics' backward on the side stream, behind everything queued so far
+        side.do_fork();
+        st_c = side.s;
     }
     rc = launch_backward_rows<SC>(P, am, critic, bc, w.dv, w.lrow_v, base + wl.bwd_c, ws_bytes - wl.bwd_c, critic_grad, scratch + 2, st_c, rec_c);
     const int rc_a = launch_backward_rows<SA>(P, am, actor, bt, w.dlogits, w.lrow_a, base + wl.bwd, wl.bwd_c != wl.bwd ? wl.bwd_c - wl.bwd : ws_bytes - wl.bwd,
                                               actor_grad, scratch, st, rec_a);
-    if (side != nullptr) {  // join
-        (void)hipEventRecord(side->join, side->s);
-        (void)hipStreamWaitEvent(st, side->join, 0);
-    }
+    side.do_join();
     if (rc != 0 || rc_a != 0) return rc != 0 ? rc : rc_a;
     hipLaunchKernelGGL(ac_metrics_kernel, dim3(1), dim3(1024), 0, st, (TB + 255) / 256, c->value_loss_coef, (const float*)w.partial,
                        metrics);

@@ -6,8 +6,9 @@ using namespace marl;
 extern "C" int marlhip_ac_collect(const marlhip_lbf_config* cfg, const marlhip_net_shape* s, const float* actor_params, uint32_t round,
                                   int32_t max_len, int32_t use_proper_termination, float* batch_obs, int64_t* batch_act,
                                   float* batch_rew, uint8_t* batch_done, float* batch_filled, float* fin_return,
-                                  int32_t* fin_length, int32_t* t_max, void* stream) {
+                                  int32_t* fin_length, int32_t* t_max, void* workspace, int64_t workspace_bytes, void* stream) {
     if (lbf_validate(cfg) != 0) return -1;
+    ScratchScope scratch(workspace, workspace_bytes);
     MARL_REQUIRE(s && actor_params && batch_obs && batch_act && batch_rew && batch_done && batch_filled && fin_return && fin_length &&
                      t_max, "ac_collect: NULL pointer");
     MARL_REQUIRE(s->n_agents == cfg->n_agents && s->obs_dim == marlhip_lbf_obs_dim(cfg) && s->n_actions == 6,

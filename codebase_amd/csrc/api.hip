@@ -42,39 +42,23 @@ void timing_end(int id, hipStream_t st) {
     t.open = false;
 }
 
-struct PackScratch {
-    int dev;
-    hipStream_t st;
-    float* buf;
-    size_t cap;
-};
-static PackScratch g_scratch[16];
-static int g_nscratch = 0;
+static thread_local char* g_scratch_base = nullptr;
+static thread_local int64_t g_scratch_bytes = 0;
 
-float* collect_pack_scratch(size_t bytes, hipStream_t st) {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    PackScratch* e = nullptr;
-    for (int i = 0; i < g_nscratch; ++i)
-        if (g_scratch[i].dev == dev && g_scratch[i].st == st) e = &g_scratch[i];
-    if (e == nullptr) {
-        if (g_nscratch == 16) return nullptr;
-        e = &g_scratch[g_nscratch++];
-        e->dev = dev; e->st = st; e->buf = nullptr; e->cap = 0;
+void scratch_bind(void* base, int64_t bytes) {
+    g_scratch_base = static_cast<char*>(base);
+    g_scratch_bytes = base != nullptr ? bytes : 0;
+}
+
+float* collect_pack_scratch(size_t bytes, hipStream_t) {
+    char* b = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(g_scratch_base) + 15) & ~(uintptr_t)15);
+    const int64_t avail = g_scratch_base != nullptr ? g_scratch_bytes - (b - g_scratch_base) : 0;
+    if (g_scratch_base == nullptr || (int64_t)bytes > avail) {
+        set_error("workspace: %zu bytes of weight-pack scratch needed, the caller's workspace holds %lld (marlhip_forward_workspace_bytes)",
+                  bytes + 16, (long long)(avail > 0 ? avail : 0));
+        return nullptr;
     }
-    if (bytes > e->cap) {
-        if (e->buf != nullptr) {
-            (void)hipStreamSynchronize(st);  // a kernel of this stream may still read the old buffer
-            (void)hipFree(e->buf);
-        }
-        const size_t want = bytes < (1u << 20) ? (1u << 20) : bytes;
-        if (hipMalloc(reinterpret_cast<void**>(&e->buf), want) != hipSuccess) {
-            e->buf = nullptr; e->cap = 0;
-            return nullptr;
-        }
-        e->cap = want;
-    }
-    return e->buf;
+    return reinterpret_cast<float*>(b);
 }
 }  // namespace marl
 
@@ -84,6 +68,20 @@ extern "C" int marlhip_device_available(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n > 0 ? 1 : 0;
+}
+
+extern "C" int64_t marlhip_forward_workspace_bytes(const marlhip_net_shape* s) {
+    if (s == nullptr || s->n_agents < 1 || s->n_agents > 16 || s->hidden < 16 || s->hidden % 16 != 0 || s->obs_dim < 1) {
+        marl::set_error("forward_workspace_bytes: bad net shape");
+        return -1;
+    }
+    // the largest forward pack any entry point builds for this shape: MLP or recurrent layout (mlp.h / gru.h), own or concatenated
+    // (centralised critic) observations; two pack sets (paired recurrent passes) of every agent
+    const int64_t P = s->n_agents, H = s->hidden, MT = H / 16;
+    const int64_t Dmax = (int64_t)s->obs_dim * P, KS1 = (Dmax + 15) / 16 * 4;
+    const int64_t mlp = MT * KS1 * 64 + MT * MT * 256 + 2 * H + 16 + MT * 256;
+    const int64_t gru = MT * KS1 * 64 + 6 * MT * MT * 256 + MT * 256 + 7 * H + 16;
+    return 2 * P * (mlp > gru ? mlp : gru) * 4 + 256;
 }
 
 extern "C" int marlhip_timing_enable(int on) {

@@ -16,11 +16,11 @@ extern "C" int marlhip_dqn_act(const marlhip_net_shape* s, const float* params, 
     if (s->obs_dim == d && s->hidden == h && s->n_actions == a) {                                                           \
         using S_ = MlpShape<d, h, a>;                                                                                       \
         const size_t lds_bytes = (size_t)S_::NFWD * sizeof(float);                                                          \
-        static bool attr_set = false;                                                                                       \
-        if (!attr_set) {                                                                                                    \
+        static LdsAttr attr_set;                                                                                       \
+        if (attr_set.need()) {                                                                                                    \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dqn_act_kernel<S_>),                                   \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);                          \
-            attr_set = true;                                                                                                \
+            attr_set.done();                                                                                                \
         }                                                                                                                   \
         hipLaunchKernelGGL((dqn_act_kernel<S_>), dim3(grid), dim3(COL_BLOCK), lds_bytes, (hipStream_t)stream, s->n_agents,  \
                            n_envs, agent_map(s), params, obs, epsilon, u, rand_actions, seed, episode, ep_length, actions, q_out);        \
@@ -36,9 +36,10 @@ extern "C" int marlhip_dqn_act(const marlhip_net_shape* s, const float* params, 
 extern "C" int marlhip_idqn_collect(const marlhip_lbf_config* cfg, const marlhip_net_shape* s, const float* params, float epsilon,
                                     uint32_t round, const marlhip_replay_shape* rs, const marlhip_replay_buffers* rb,
                                     int32_t slot_base, int32_t write_replay, int32_t clear_stale, int32_t use_proper_termination,
-                                    float* fin_return, int32_t* fin_length, void* stream) {
+                                    float* fin_return, int32_t* fin_length, void* workspace, int64_t workspace_bytes, void* stream) {
     if (lbf_validate(cfg) != 0) return -1;
     MARL_REQUIRE(s && params && rs && rb && fin_return && fin_length, "idqn_collect: NULL pointer");
+    ScratchScope scratch(workspace, workspace_bytes);
     if (agent_map_validate(s) != 0) return -1;
     MARL_REQUIRE(s->n_agents == cfg->n_agents && s->obs_dim == marlhip_lbf_obs_dim(cfg) && s->n_actions == 6,
                  "idqn_collect: net shape does not match the env (P=%d D=%d A=6 expected)", cfg->n_agents,

@@ -49,9 +49,8 @@ __device__ __forceinline__ void pick_obs_id(const LbfObs<P, F>& o, int p, int g,
 
 // Pre-packed actor / critic weights for the collectors: one tiny kernel turns the canonical parameter blocks into the
 // MFMA A-operand packs ([P][NFWD], L2-resident), workgroups then stage them with straight 16-byte copies - once when all
-// agents fit in LDS, once per (step, agent) when they do not (hidden 128, > 1 agent).  The scratch is library-owned,
-// grow-only, one per (device, stream) so that collectors on different streams never share it.
-float* collect_pack_scratch(size_t bytes, hipStream_t st);  // api.hip; nullptr on allocation failure
+// agents fit in LDS, once per (step, agent) when they do not (hidden 128, > 1 agent).  The scratch is the caller's workspace
+// (common.h: ScratchScope / collect_pack_scratch).
 
 template <class S>
 __global__ __launch_bounds__(256) void fwd_pack_kernel(const float* __restrict__ params, AgentMap am, float* __restrict__ packs) {
@@ -87,7 +86,7 @@ __device__ __forceinline__ void stage_packed_prefix(const float* __restrict__ pa
 template <class S>
 int launch_fwd_pack(int P, const AgentMap& am, const float* params, float** packs_out, hipStream_t st) {
     float* packs = collect_pack_scratch((size_t)P * S::NFWD * sizeof(float), st);
-    MARL_REQUIRE(packs != nullptr, "collector: cannot allocate %zu bytes of pack scratch", (size_t)P * S::NFWD * sizeof(float));
+    if (packs == nullptr) return -1;  // error text set by collect_pack_scratch
     hipLaunchKernelGGL((fwd_pack_kernel<S>), dim3((S::NFWD + 255) / 256, P), dim3(256), 0, st, params, am, packs);
     MARL_CHECK_LAUNCH("fwd_pack_kernel");
     *packs_out = packs;

@@ -214,11 +214,11 @@ int launch_collect(const typename ENV::Params& q, const AgentMap& am, const floa
     MARL_REQUIRE(ENV::lds_bytes(q) <= ENV::LDS_MAX, "collector: the env needs %zu bytes of LDS per workgroup, compiled for %zu", ENV::lds_bytes(q),
                  (size_t)ENV::LDS_MAX);
     const size_t lds_bytes = PackPlan<S, P, ENV::LDS_MAX>::LDS_BYTES + ENV::lds_bytes(q);
-    static size_t attr_set = 0;
-    if (attr_set < lds_bytes) {
+    static LdsAttr attr_set;
+    if (attr_set.need(lds_bytes)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&idqn_collect_kernel<ENV, H, OID>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        attr_set = lds_bytes;
+        attr_set.done(lds_bytes);
     }
     const int grid = (q.n_envs + 63) / 64;
     float* packs = nullptr;

@@ -17,6 +17,32 @@ enum { TIMER_LOSSGRAD = 0, TIMER_COLLECT = 1, TIMER_SAMPLE = 2, TIMER_ENVSTEP = 
 void timing_begin(int id, hipStream_t st);
 void timing_end(int id, hipStream_t st);
 
+// Pack scratch of the forward-only entry points (collectors, act, sequence forwards): CALLER memory.  An extern "C" entry point binds
+// the workspace it was given for the duration of the call (thread-local, so calls on different host threads never meet);
+// collect_pack_scratch hands out its start (one pack set alive at a time per call, as the launches of a call are stream-ordered)
+// and fails with the size it wanted when the region is missing or too small.  Nothing is allocated, nothing outlives the call.
+void scratch_bind(void* base, int64_t bytes);
+struct ScratchScope {
+    ScratchScope(void* base, int64_t bytes) { scratch_bind(base, bytes); }
+    ~ScratchScope() { scratch_bind(nullptr, 0); }
+    ScratchScope(const ScratchScope&) = delete;
+    ScratchScope& operator=(const ScratchScope&) = delete;
+};
+float* collect_pack_scratch(size_t bytes, hipStream_t st);  // nullptr + marlhip_last_error() text when the bound region cannot hold it
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: one slot per device ordinal, raised monotonically (a racing second
+// call sets the same value)
+struct LdsAttr {
+    size_t set[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    static int dev() {
+        int d = 0;
+        (void)hipGetDevice(&d);
+        return d & 15;
+    }
+    bool need(size_t bytes = 1) const { return set[dev()] < bytes; }  // call sites: if (a.need(n)) { hipFuncSetAttribute...; a.done(n); }
+    void done(size_t bytes = 1) { set[dev()] = bytes; }
+};
+
 #define MARL_CHECK_LAUNCH(what)                                                   \
     do {                                                                          \
         hipError_t e_ = hipGetLastError();                                        \

@@ -116,7 +116,7 @@ extern "C" int marlhip_dqn_loss_grad_replay(const marlhip_net_shape* s, const fl
     bt.max_len = rs->max_len;
     bt.batch = batch;
     ReplaySrc src;
-    src.rb = *rb; src.idx = idx; src.idx_out = idx_out; src.seed = seed; src.counter = counter; src.length = length;
+    src.rb = *rb; src.idx = idx; src.idx_out = idx_out; src.seed = seed; src.counter = counter; src.length = length; src.capacity = rs->capacity;
     return lossgrad_dispatch(s, params, target_params, &bt, &src, gamma, double_q, mode, workspace, workspace_bytes, grad, loss, stream);
 }
 
@@ -155,7 +155,7 @@ extern "C" int marlhip_dqn_loss_grad_std_replay(const marlhip_net_shape* s, cons
     bt.max_len = rs->max_len;
     bt.batch = batch;
     ReplaySrc src;
-    src.rb = *rb; src.idx = idx; src.idx_out = idx_out; src.seed = seed; src.counter = counter; src.length = length;
+    src.rb = *rb; src.idx = idx; src.idx_out = idx_out; src.seed = seed; src.counter = counter; src.length = length; src.capacity = rs->capacity;
     return lossgrad_dispatch(s, params, target_params, &bt, &src, gamma, double_q, 3, workspace, workspace_bytes, grad, loss, stream,
                              nullptr, &rst);
 }
@@ -233,7 +233,7 @@ extern "C" int marlhip_qmix_loss_grad_replay(const marlhip_net_shape* s, const f
     bt.max_len = rs->max_len;
     bt.batch = batch;
     ReplaySrc src;
-    src.rb = *rb; src.idx = idx; src.idx_out = idx_out; src.seed = seed; src.counter = counter; src.length = length;
+    src.rb = *rb; src.idx = idx; src.idx_out = idx_out; src.seed = seed; src.counter = counter; src.length = length; src.capacity = rs->capacity;
     return qmix_call(s, params, target_params, mixer, &bt, &src, gamma, double_q, workspace, workspace_bytes, grad, loss, stream);
 }
 
@@ -276,7 +276,7 @@ int idqn_update_n_fused(const marlhip_idqn_learner* L, int32_t n_updates, int32_
         const float tau = tui < 1.0 ? (float)tui : 0.f;
         fuse.adam = adam_args(*adam_step + 1, L->lr, L->beta1, L->beta2, L->eps, L->max_norm, 1.0f, hard ? 1 : 0, tau);
         ReplaySrc src;
-        src.rb = L->rb; src.idx = nullptr; src.idx_out = L->idx; src.seed = seed; src.counter = counter0 + (uint32_t)u; src.length = length;
+        src.rb = L->rb; src.idx = nullptr; src.idx_out = L->idx; src.seed = seed; src.counter = counter0 + (uint32_t)u; src.length = length; src.capacity = L->rs.capacity;
         if (L->materialise_batch) {
             const int rc = marlhip_replay_sample(&L->rs, &L->rb, nullptr, L->batch, length, seed, counter0 + (uint32_t)u, L->idx, L->obss,
                                                  L->actions, L->rewards, L->dones, L->filled, stream);

@@ -110,6 +110,7 @@ struct ReplaySrc {
     uint64_t seed;
     uint32_t counter;
     int length;
+    int capacity;  // episodes in the replay: when every array is < 2 GB the kernel addresses it through buffer descriptors (32-bit offsets)
 };
 
 __device__ __forceinline__ int replay_draw(const ReplaySrc& r, int b) {
@@ -215,6 +216,17 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dqn_lossgrad_kernel(con
     const int64_t* act_p = (REPLAY || MODE == 4) ? nullptr : bt.actions + (size_t)p * T * B;
     const float* rew_p = (REPLAY || MODE == 4) ? nullptr : bt.rewards + (size_t)p * T * B;
 
+    // buffer descriptors of the replay arrays (raw buffers, 32-bit offsets): usable while the largest array stays below 2 GB
+    const long long rp_eps = REPLAY ? rs.capacity : 0, rp_obs_bytes = rp_eps * P * (T + 1) * D * 4;
+    const bool buf32 = REPLAY && rp_eps > 0 && rp_obs_bytes < (1ll << 31);
+    constexpr int kRaw = 0x00020000;  // raw buffer, dword data format (gfx90a / gfx94x / gfx950)
+    const int rp_n = buf32 ? (int)rp_eps : 0;  // (descriptors of an unused path cover nothing)
+    const __amdgpu_buffer_rsrc_t r_obs = __builtin_amdgcn_make_buffer_rsrc((void*)rs.rb.obs, 0, rp_n * P * (T + 1) * D * 4, kRaw);
+    const __amdgpu_buffer_rsrc_t r_act = __builtin_amdgcn_make_buffer_rsrc((void*)rs.rb.act, 0, rp_n * P * T, kRaw);
+    const __amdgpu_buffer_rsrc_t r_rew = __builtin_amdgcn_make_buffer_rsrc((void*)rs.rb.rew, 0, rp_n * P * T * 4, kRaw);
+    const __amdgpu_buffer_rsrc_t r_done = __builtin_amdgcn_make_buffer_rsrc((void*)rs.rb.done, 0, rp_n * (T + 1), kRaw);
+    const __amdgpu_buffer_rsrc_t r_fill = __builtin_amdgcn_make_buffer_rsrc((void*)rs.rb.filled, 0, rp_n * T, kRaw);
+
     const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
     f4 dW1[MT][NT1], dW2[MT][MT], dW3[MT], db1[MT], db2[MT], db3 = zero4;
 #pragma unroll
@@ -267,9 +279,44 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dqn_lossgrad_kernel(con
         };
         // branch-free: every address is clamped in-bounds and loaded unconditionally (a guarded load is
         // an exec-masked branch + a conservative vmcnt(0) at the join); masks are applied at the point of use
+        // Replay rows through buffer descriptors when the arrays allow 32-bit offsets: address = descriptor base + per-lane
+        // offset (fixed for the whole task, one VGPR) + scalar offset (the time step, SALU) + immediate - no vector address
+        // arithmetic per step.  Arrays of 2 GB and more take the 64-bit global path below.
+        int vx = 0, vxl = 0, vbx0[4] = {0, 0, 0, 0}, vbxl[4] = {0, 0, 0, 0}, vsc = 0, vdn = 0, vfl = 0;
+        if (REPLAY && buf32) {
+            const int ebase = (ej * P + p) * (T + 1) * D * 4;
+            vx = ebase + 4 * g;
+            vxl = ebase + 4 * ((4 * (S::KS1 - 1) + g) < D ? (4 * (S::KS1 - 1) + g) : D - 1);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int gb = (eg[ks] * P + p) * (T + 1) * D * 4;
+                vbx0[ks] = gb + 4 * j;
+                vbxl[ks] = gb + 4 * ((16 * (NT1 - 1) + j) < D ? (16 * (NT1 - 1) + j) : D - 1);
+            }
+            vsc = (ej * P + p) * T;
+            vdn = ej * (T + 1) + 1;
+            vfl = ej * T;
+        }
         auto load_rows = [&](int t, Rows& R) {
             const int tt = t < T ? t : T - 1;
-            if (REPLAY) {
+            if (REPLAY && buf32) {
+                const int so = t * D * 4;
+#pragma unroll
+                for (int ks = 0; ks + 1 < S::KS1; ++ks)
+                    R.x[ks] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_obs, vx + 16 * ks, so, 0));
+                R.x[S::KS1 - 1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_obs, vxl, so, 0));
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+                    for (int nt = 0; nt + 1 < NT1; ++nt)
+                        R.bx[nt][ks] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_obs, vbx0[ks] + 64 * nt, so, 0));
+                    R.bx[NT1 - 1][ks] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_obs, vbxl[ks], so, 0));
+                }
+                R.a_sel = (int)__builtin_amdgcn_raw_buffer_load_b8(r_act, vsc, tt, 0);
+                R.rw = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_rew, 4 * vsc, 4 * tt, 0));
+                R.dn_raw = (int)__builtin_amdgcn_raw_buffer_load_b8(r_done, vdn, tt, 0);
+                R.fl_raw = (int)__builtin_amdgcn_raw_buffer_load_b8(r_fill, vfl, tt, 0);
+            } else if (REPLAY) {
                 const float* xrow = rs.rb.obs + (((size_t)ej * P + p) * (T + 1) + t) * D;
 #pragma unroll
                 for (int ks = 0; ks < S::KS1; ++ks) {
@@ -353,7 +400,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dqn_lossgrad_kernel(con
             MARL_TS(0)
             f4 h1[MT], h2[MT], q, qb, tq = zero4, tqb = zero4;
             // ---- A: critic forward (q arrives as two partial chains, added where it is first used)
-            mlp_forward_f<S>(cpk, chead, lane, cur.x, h1, h2, q, qb, [](int) {});
+            mlp_forward_f<S>(cpk, chead, lane, cur.x, h1, h2, q, qb, [](int, int) {});
             MARL_TS(1)
             // ---- the critic's epilogue, emitted as fillers of the target forward's MFMA groups (or on its own without one)
             f4 dQ[1] = {zero4};
@@ -363,8 +410,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dqn_lossgrad_kernel(con
             constexpr bool ONE_HOT = (MODE == 0 || MODE == 2);
             f4 w3sel[MT];
             float dqs_row = 0.f;
-            auto epilogue = [&](int k) {
-                if (k == 0) {
+            // (k, e): MFMA group k of the target forward, e = -1 the VALU burst in front of it, e = 0..3 LDS traffic in front of its quarters
+            auto epilogue = [&](int k, int e) {
+                if (k == 0 && e == -1) {
                     q += qb;
                     if (DO_PUB) {
                         // qsel pass: publish Q_p(o_t)[a_t] and (agent 0) the transition's scalars for the mixer
@@ -406,23 +454,32 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dqn_lossgrad_kernel(con
                         dqs_row = dqs;
                     }
                 }
-                if (DO_BWD) {
+                if (DO_BWD && e >= 0) {  // one hidden tile per quarter
+                    const int mt = e;
                     if (k == 1) {
-                        wave_lds_fence();  // the previous step's tile reads precede these writes in program order
-                        tile_write_s<TS, 1>(TQ, dQ, g, j);
-                        tile_write_s<TS, MT>(TH2, h2, g, j);
-                    }
-                    if (k == 2) tile_write_s<TS, MT>(TH1, h1, g, j);
-                    if (k == 3) {
-                        wave_lds_fence();
+                        if (e == 0) {
+                            wave_lds_fence();  // the previous step's tile reads precede these writes in program order
+                            tile_write_s<TS, 1>(TQ, dQ, g, j);
+                        }
+                        if (mt < MT) {
 #pragma unroll
-                        for (int mt = 0; mt < MT; ++mt) {
+                            for (int r = 0; r < 4; ++r) TH2[(16 * mt + 4 * g + r) * TS + j] = h2[mt][r];
+                        }
+                    }
+                    if (k == 2 && mt < MT) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) TH1[(16 * mt + 4 * g + r) * TS + j] = h1[mt][r];
+                    }
+                    if (k == 3) {
+                        if (e == 0) {
+                            wave_lds_fence();
+                            aQ = tile_read_s<TS>(TQ, 0, g, j);
+                        }
+                        if (mt < MT) {
                             if (!ONE_HOT) t3[mt] = T3[mt * 64 + lane];
                             t2[0][mt] = T2[(mt * MT + 0) * 64 + lane];
+                            bH2[mt] = tile_read_s<TS>(TH2, mt, g, j);
                         }
-                        aQ = tile_read_s<TS>(TQ, 0, g, j);
-#pragma unroll
-                        for (int nt = 0; nt < MT; ++nt) bH2[nt] = tile_read_s<TS>(TH2, nt, g, j);
                     }
                 }
             };
@@ -436,7 +493,11 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dqn_lossgrad_kernel(con
                 else mlp_forward_f<S, true>(tpk, thead, lane, cur.x, g1, g2, tq, tqb, epilogue);
             } else {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) epilogue(k);
+                for (int k = 0; k < 4; ++k) {
+                    epilogue(k, -1);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) epilogue(k, e);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
             MARL_TS(2)
@@ -517,7 +578,11 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dqn_lossgrad_kernel(con
                         MARL_VB()
                     }
                     if constexpr (MARL_MFMA_VGPR && MT == 4) {
-                        mfma16_v(dH1, t2[cb], dH2[m2].x, dH2[m2].y, dH2[m2].z, dH2[m2].w);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            mfma4_v(dH1, t2[cb][0][r], t2[cb][1][r], t2[cb][2][r], t2[cb][3][r], dH2[m2][r]);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
                         if (m2 == MT - 1) mfma_settle(dH1);
                     } else {
 #pragma unroll
@@ -1050,13 +1115,13 @@ int launch_lossgrad_tp(const marlhip_net_shape* s, const float* params, const fl
     mix.dn = mixf + 4 * P * tb; mix.fl = mix.dn + tb; mix.lrow = mix.fl + tb;
     const size_t ldsF = (size_t)(2 * NBF * NT + 2 * NBF * W) * 256 * sizeof(float);
     const size_t ldsB = (size_t)(NB * NT * 256 + NB * S::H * 16 + NB * NT * 256 + W * 256 * (1 + 3 * TPW)) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static LdsAttr attr_set;
+    if (attr_set.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tp_fwd_kernel<S, W, TPW, REPLAY, NBF>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsF);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tp_bwd_kernel<S, W, TPW, REPLAY, NB>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsB);
-        attr_set = true;
+        attr_set.done();
     }
     const dim3 grid(pl.nwg, P), block(64 * W);
     timing_begin(TIMER_LOSSGRAD, st);
@@ -1113,15 +1178,15 @@ int launch_lossgrad_src(const marlhip_net_shape* s, const float* params, const f
     float* packs = reinterpret_cast<float*>(static_cast<char*>(ws) + wl.pack_off);
     float* mixf = reinterpret_cast<float*>(static_cast<char*>(ws) + wl.mix_off);
     const size_t lds_bytes = (size_t)L::total(4) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static LdsAttr attr_set;
+    if (attr_set.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dqn_lossgrad_kernel<S, 4, REPLAY, 0>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dqn_lossgrad_kernel<S, 4, REPLAY, 1>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dqn_lossgrad_kernel<S, 4, REPLAY, 2>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        attr_set = true;
+        attr_set.done();
     }
     if (fuse == nullptr || !fuse->packs_valid) {
         hipLaunchKernelGGL((dqn_pack_kernel<S>), dim3((PACK + 255) / 256, P), dim3(256), 0, st, params, tparams, am, packs);

@@ -39,14 +39,14 @@ static int gru_forward(const marlhip_net_shape* s, const float* params, const fl
                        float* q_out, float* rec, hipStream_t st) {
     const int P = s->n_agents;
     float* packs = collect_pack_scratch((size_t)P * S::NFWD * sizeof(float), st);
-    MARL_REQUIRE(packs != nullptr, "gru_forward: cannot allocate the pack scratch");
+    if (packs == nullptr) return -1;  // error text set by collect_pack_scratch
     hipLaunchKernelGGL((gru_pack_kernel<S>), dim3((S::NFWD + 255) / 256, P), dim3(256), 0, st, params, agent_map(s), packs);
     MARL_CHECK_LAUNCH("gru_pack_kernel");
     const size_t lds = (size_t)S::LDS_FLOATS * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
+    static LdsAttr attr;
+    if (attr.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_seq_fwd_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = true;
+        attr.done();
     }
     hipLaunchKernelGGL((gru_seq_fwd_kernel<S>), dim3((B + 63) / 64, P), dim3(256), lds, st, (const float*)packs, obs, (size_t)steps * B * S::D,
                        (size_t)S::D, steps, B, h_in, h_out, q_out, rec);
@@ -55,8 +55,10 @@ static int gru_forward(const marlhip_net_shape* s, const float* params, const fl
 }
 
 extern "C" int marlhip_gru_forward(const marlhip_net_shape* s, const float* params, const float* obs, int32_t steps, int32_t batch,
-                                   const float* h_in, float* h_out, float* q_out, float* record, void* stream) {
+                                   const float* h_in, float* h_out, float* q_out, float* record, void* workspace, int64_t workspace_bytes,
+                                   void* stream) {
     if (gru_check(s) != 0) return -1;
+    ScratchScope scratch(workspace, workspace_bytes);
     MARL_REQUIRE(params && obs && q_out && steps > 0 && batch > 0, "gru_forward: bad argument");
 #define X(d, h, a) \
     if (s->obs_dim == d && s->hidden == h && s->n_actions == a) return gru_forward<GruShape<d, h, a>>(s, params, obs, steps, batch, h_in, h_out, q_out, record, (hipStream_t)stream);
@@ -153,12 +155,12 @@ int gru_loss_grad(const marlhip_net_shape* s, const float* params, const float* 
     MARL_CHECK_LAUNCH("gru pack kernels");
     const size_t ldsF = (size_t)S::LDS_FLOATS * sizeof(float), ldsB = (size_t)Bk::LDS_FLOATS * sizeof(float);
     const size_t ldsW = (size_t)(4 * 16 * S::H + 256) * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
+    static LdsAttr attr;
+    if (attr.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_seq_fwd2_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsF);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_seq_bwd_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsB);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_wgrad_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsW);
-        attr = true;
+        attr.done();
     }
     const dim3 gridS((B + 63) / 64, P);
     timing_begin(TIMER_LOSSGRAD, st);
@@ -295,12 +297,12 @@ int gru_qmix_loss_grad(const marlhip_net_shape* s, const float* params, const fl
     MARL_CHECK_LAUNCH("gru pack kernels");
     const size_t ldsF = (size_t)S::LDS_FLOATS * sizeof(float), ldsB = (size_t)Bk::LDS_FLOATS * sizeof(float);
     const size_t ldsW = (size_t)(4 * 16 * S::H + 256) * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
+    static LdsAttr attr;
+    if (attr.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_seq_fwd2_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsF);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_seq_bwd_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsB);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_wgrad_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsW);
-        attr = true;
+        attr.done();
     }
     const dim3 gridS((B + 63) / 64, P), gridR((unsigned)((R + 255) / 256));
     timing_begin(TIMER_LOSSGRAD, st);

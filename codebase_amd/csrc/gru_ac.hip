@@ -109,15 +109,17 @@ extern "C" int marlhip_gru_ppo_loss_grad(const marlhip_net_shape* s, const float
 // sequence forward of the actors (value_net = 0: logits [P][steps][B][A]) or critics (value_net = 1: values [P][steps][B][1]) with the hidden
 // state carried by the caller (A2CNetwork.act / get_value, ac/model.py:147-163); obs rows at obs + p * agent_stride + (t * B + b) * row_stride
 extern "C" int marlhip_gru_ac_forward(const marlhip_net_shape* s, int32_t value_net, const float* params, const float* obs, int64_t agent_stride,
-                                      int64_t row_stride, int32_t steps, int32_t batch, const float* h_in, float* h_out, float* out, void* stream) {
+                                      int64_t row_stride, int32_t steps, int32_t batch, const float* h_in, float* h_out, float* out, void* workspace,
+                                      int64_t workspace_bytes, void* stream) {
     if (gru_ac_check(s, value_net == 2) != 0) return -1;
+    ScratchScope scratch(workspace, workspace_bytes);
     MARL_REQUIRE(params && obs && out && steps > 0 && batch > 0 && row_stride > 0 && agent_stride >= 0, "gru_ac_forward: bad argument");
     const hipStream_t st = (hipStream_t)stream;
     const int P = s->n_agents;
     auto run = [&](auto shape) -> int {
         using S = decltype(shape);
         float* packs = collect_pack_scratch((size_t)P * S::NFWD * sizeof(float), st);
-        MARL_REQUIRE(packs != nullptr, "gru_ac_forward: cannot allocate the pack scratch");
+        if (packs == nullptr) return -1;  // error text set by collect_pack_scratch
         gru_set_attrs<S>();
         hipLaunchKernelGGL((gru_pack_kernel<S>), dim3((S::NFWD + 255) / 256, P), dim3(256), 0, st, params, agent_map(s), packs);
         hipLaunchKernelGGL((gru_seq_fwd_kernel<S>), dim3((batch + 63) / 64, P), dim3(256), S::LDS_FLOATS * sizeof(float), st, (const float*)packs, obs,

@@ -46,8 +46,8 @@ inline void gru_obs_strides(const marlhip_batch* bt, int D, size_t* as, size_t* 
 
 template <class S>
 void gru_set_attrs() {
-    static bool done = false;
-    if (done) return;
+    static LdsAttr done;
+    if (!done.need()) return;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_seq_fwd_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)(S::LDS_FLOATS * sizeof(float)));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_seq_fwd2_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -56,7 +56,7 @@ void gru_set_attrs() {
                               (int)(GruBwd<S>::LDS_FLOATS * sizeof(float)));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_wgrad_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)((4 * 16 * S::H + 256) * sizeof(float)));
-    done = true;
+    done.done();
 }
 
 template <class S>
@@ -71,7 +71,7 @@ int gru_forward_rows(int P, const AgentMap& am, const float* params, const marlh
                      float* rec = nullptr, float* packs_buf = nullptr) {
     // packs_buf: the caller's own [P][NFWD] pack space (a pass on a side stream must not share the per-process scratch)
     float* packs = packs_buf != nullptr ? packs_buf : collect_pack_scratch((size_t)P * S::NFWD * sizeof(float), st);
-    MARL_REQUIRE(packs != nullptr, "gru_forward_rows: cannot allocate the pack scratch");
+    if (packs == nullptr) return -1;  // error text set by collect_pack_scratch
     gru_set_attrs<S>();
     size_t as, rs;
     gru_obs_strides(bt, S::D, &as, &rs);
@@ -88,7 +88,7 @@ template <class S>
 int gru_forward_rows_pair(int P, const AgentMap& am, const float* params, const float* params2, const marlhip_batch* bt, int steps, int steps2,
                           float* out, float* out2, hipStream_t st, float* rec) {
     float* packs = collect_pack_scratch((size_t)2 * P * S::NFWD * sizeof(float), st);
-    MARL_REQUIRE(packs != nullptr, "gru_forward_rows_pair: cannot allocate the pack scratch");
+    if (packs == nullptr) return -1;  // error text set by collect_pack_scratch
     float* packs2 = packs + (size_t)P * S::NFWD;
     gru_set_attrs<S>();
     size_t as, rs;

@@ -583,6 +583,19 @@ __device__ __forceinline__ void mfma16_v(f4 (&acc)[4], const f4 (&a)[4], float b
         : "v"(a[0].x), "v"(a[0].y), "v"(a[0].z), "v"(a[0].w), "v"(a[1].x), "v"(a[1].y), "v"(a[1].z), "v"(a[1].w), "v"(a[2].x), "v"(a[2].y),
           "v"(a[2].z), "v"(a[2].w), "v"(a[3].x), "v"(a[3].y), "v"(a[3].z), "v"(a[3].w), "v"(b0), "v"(b1), "v"(b2), "v"(b3));
 }
+// one quarter of that group: acc[mt] += a_mt * b for mt = 0..3 (4 MFMAs), so that LDS instructions can sit between the quarters -
+// next to f32 MFMAs an LDS read or b32 write costs nothing when it issues between two MFMAs, and its full issue time when it is
+// clumped in front of the group (scripts/mfma_ubench2.hip)
+__device__ __forceinline__ void mfma4_v(f4 (&acc)[4], float a0, float a1, float a2, float a3, float b) {
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_mfma_f32_16x16x4_f32 %0, %4, %8, %0\n\t"
+        "v_mfma_f32_16x16x4_f32 %1, %5, %8, %1\n\t"
+        "v_mfma_f32_16x16x4_f32 %2, %6, %8, %2\n\t"
+        "v_mfma_f32_16x16x4_f32 %3, %7, %8, %3\n\t"
+        : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3])
+        : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(b));
+}
 // acc0 += a0[r] * b0[r], acc1 += a1[r] * b1[r] for r = 0..3: 8 MFMAs on two chains (the output layer's even / odd k-tiles)
 __device__ __forceinline__ void mfma8_v2(f4& acc0, f4& acc1, const f4& a0, const f4& a1, const f4& b0, const f4& b1) {
     asm volatile(
@@ -607,9 +620,10 @@ __device__ __forceinline__ void mfma_settle2(f4& a, f4& b) { asm volatile("s_nop
 template <class S, bool WITH_L3 = true, class F>
 __device__ __forceinline__ void mlp_forward_f(const float* lds, const FwdHead<S>& head, int lane, const float (&x)[S::KS1], f4 (&h1)[S::MT],
                                               f4 (&h2)[S::MT], f4& qa, f4& qb, F&& fill) {
-    // groups of 4 MT MFMAs (layer-1 k-steps, layer-2 k-tiles, layer 3); the A operands of group s+1 are requested at the top of
-    // group s; `fill(k)` - the caller's VALU / LDS work for group k - is emitted in front of the group's MFMAs as one burst; the
-    // relu of a layer is one burst behind its last group.  Layer 3 runs as two chains (even / odd k-tiles -> qa / qb, added by
+    // groups of 4 MT MFMAs (layer-1 k-steps, layer-2 k-tiles, layer 3), each issued as four quarters; the A operands of group
+    // s+1 are requested one hidden tile per quarter of group s.  `fill(k, -1)` - the caller's VALU work for group k - is emitted in
+    // front of the group as one burst, `fill(k, e)` (e = 0..3: LDS traffic only) in front of quarter e; the relu of a layer is one
+    // burst behind its last group.  Layer 3 runs as two chains (even / odd k-tiles -> qa / qb, added by
     // the caller where it first needs q): a single dependent 16x16x4 chain would cost 40 cycles per MFMA instead of 32.
     constexpr int MT = S::MT, N1 = S::KS1 / 4;
     constexpr bool VG = MARL_MFMA_VGPR && MT == 4;  // asm groups are written for four hidden tiles
@@ -636,20 +650,32 @@ __device__ __forceinline__ void mlp_forward_f(const float* lds, const FwdHead<S>
 #pragma unroll
     for (int s = 0; s < N1; ++s) {
         const int cur = s & 1, nxt = cur ^ 1;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
+        auto next_ops1 = [&](int mt) {
             if (s + 1 < N1) {
                 op[nxt][mt] = A1[(mt * N1 + s + 1) * 64 + lane];
             } else {
                 op[nxt][mt] = A2[(mt * MT + 0) * 64 + lane];
                 nb[mt] = *reinterpret_cast<const f4*>(lds + S::pb2 + 16 * mt + 4 * g);
             }
+        };
+        if constexpr (!VG) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) next_ops1(mt);
         }
-        fill(s);
+        fill(s, -1);
         MARL_VB()
         if constexpr (VG) {
-            mfma16_v(acc, op[cur], x[4 * s], x[4 * s + 1], x[4 * s + 2], x[4 * s + 3]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                next_ops1(e);  // one hidden tile of the next group's operands per quarter (MT == 4)
+                fill(s, e);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma4_v(acc, op[cur][0][e], op[cur][1][e], op[cur][2][e], op[cur][3][e], x[4 * s + e]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) fill(s, e);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -668,17 +694,29 @@ __device__ __forceinline__ void mlp_forward_f(const float* lds, const FwdHead<S>
 #pragma unroll
     for (int k1 = 0; k1 < MT; ++k1) {
         const int cur = (N1 + k1) & 1, nxt = cur ^ 1;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
+        auto next_ops2 = [&](int mt) {
             if (k1 + 1 < MT) op[nxt][mt] = A2[(mt * MT + k1 + 1) * 64 + lane];
             else if (WITH_L3) op[nxt][mt] = A3[mt * 64 + lane];
+            if (WITH_L3 && k1 + 1 == MT && mt == 0) o3a = *reinterpret_cast<const f4*>(lds + S::pb3 + 4 * g);
+        };
+        if constexpr (!VG) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) next_ops2(mt);
         }
-        if (WITH_L3 && k1 + 1 == MT) o3a = *reinterpret_cast<const f4*>(lds + S::pb3 + 4 * g);
-        fill(N1 + k1);
+        fill(N1 + k1, -1);
         MARL_VB()
         if constexpr (VG) {
-            mfma16_v(acc, op[cur], h1[k1].x, h1[k1].y, h1[k1].z, h1[k1].w);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                next_ops2(r);
+                fill(N1 + k1, r);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma4_v(acc, op[cur][0][r], op[cur][1][r], op[cur][2][r], op[cur][3][r], h1[k1][r]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) fill(N1 + k1, r);
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -691,7 +729,9 @@ __device__ __forceinline__ void mlp_forward_f(const float* lds, const FwdHead<S>
     for (int mt = 0; mt < MT; ++mt) h2[mt] = relu4l(acc[mt]);
     // ---- layer 3
     constexpr int c3 = (N1 + MT) & 1;
-    fill(N1 + MT);
+    fill(N1 + MT, -1);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) fill(N1 + MT, r);
     if (WITH_L3) {
         MARL_VB()
         if constexpr (VG) {

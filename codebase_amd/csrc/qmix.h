@@ -673,12 +673,12 @@ int qmix_launch_mix(const QmixCtx& qx, const marlhip_batch* bt, const ReplaySrc&
     }
     constexpr int CH = (Q::NCH == 1 ? Q::KS4 : 4) * Q::MT1 * 256 * (int)sizeof(float);
     constexpr int LM_ON = Q::NMIX * (int)sizeof(float), LM_TG = Q::NMIX_FWD * (int)sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static LdsAttr attr_set;
+    if (attr_set.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qmix_l1_kernel<Q, REPLAY>), hipFuncAttributeMaxDynamicSharedMemorySize, CH);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qmix_mix_kernel<Q, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LM_ON);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qmix_mix_kernel<Q, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LM_TG);
-        attr_set = true;
+        attr_set.done();
     }
     hipLaunchKernelGGL((qmix_pack_kernel<Q>), dim3((Q::NPACK + 255) / 256), dim3(256), 0, st, qx.mixer, qx.tmixer, packs);
     const int ngroups = (R + 64 * MARL_QMIX_L1_NB - 1) / (64 * MARL_QMIX_L1_NB), nblk = (R + 15) / 16;

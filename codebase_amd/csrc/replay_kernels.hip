@@ -309,10 +309,11 @@ extern "C" int marlhip_replay_sample(const marlhip_replay_shape* rs, const marlh
                       getenv("MARLHIP_SAMPLE_SCALAR") == nullptr;
     timing_begin(TIMER_SAMPLE, (hipStream_t)stream);
     if (vec4) {  // one kernel: observations + the small records
-        static size_t attr = 0;
-        if ((size_t)EB * ep_bytes > attr) {
-            attr = (size_t)EB * ep_bytes;
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&replay_sample_obs4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)attr);
+        static LdsAttr attr;
+        if (attr.need((size_t)EB * ep_bytes)) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&replay_sample_obs4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)((size_t)EB * ep_bytes));
+            attr.done((size_t)EB * ep_bytes);
         }
         hipLaunchKernelGGL(replay_sample_obs4_kernel, dim3((batch + EB - 1) / EB), dim3(256), (size_t)EB * ep_bytes,
                            (hipStream_t)stream, *rs, *rb, idx, batch, EB, obss, actions, rewards, dones, filled);

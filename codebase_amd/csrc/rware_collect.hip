@@ -31,8 +31,9 @@ static int rw_collect_check(const marlhip_rware_config* cfg, const marlhip_net_s
 extern "C" int marlhip_rware_idqn_collect(const marlhip_rware_config* cfg, const marlhip_net_shape* s, const float* params, float epsilon,
                                           uint32_t round, const marlhip_replay_shape* rs, const marlhip_replay_buffers* rb, int32_t slot_base,
                                           int32_t write_replay, int32_t clear_stale, int32_t use_proper_termination, float* fin_return,
-                                          int32_t* fin_length, void* stream) {
+                                          int32_t* fin_length, void* workspace, int64_t workspace_bytes, void* stream) {
     if (rw_collect_check(cfg, s, "rware_idqn_collect") != 0) return -1;
+    ScratchScope scratch(workspace, workspace_bytes);
     MARL_REQUIRE(params && rs && rb && fin_return && fin_length, "rware_idqn_collect: NULL pointer");
     MARL_REQUIRE(rs->n_agents == cfg->n_agents && rs->obs_dim == RW_OBS_DIM && rs->max_len > 0 && rs->capacity > 0,
                  "rware_idqn_collect: replay shape does not match the env");
@@ -55,8 +56,9 @@ extern "C" int marlhip_rware_idqn_collect(const marlhip_rware_config* cfg, const
 extern "C" int marlhip_rware_ac_collect(const marlhip_rware_config* cfg, const marlhip_net_shape* s, const float* actor_params, uint32_t round,
                                         int32_t max_len, int32_t use_proper_termination, float* batch_obs, int64_t* batch_act, float* batch_rew,
                                         uint8_t* batch_done, float* batch_filled, float* fin_return, int32_t* fin_length, int32_t* t_max,
-                                        void* stream) {
+                                        void* workspace, int64_t workspace_bytes, void* stream) {
     if (rw_collect_check(cfg, s, "rware_ac_collect") != 0) return -1;
+    ScratchScope scratch(workspace, workspace_bytes);
     MARL_REQUIRE(actor_params && batch_obs && batch_act && batch_rew && batch_done && batch_filled && fin_return && fin_length && t_max,
                  "rware_ac_collect: NULL pointer");
     MARL_REQUIRE(max_len > 0, "rware_ac_collect: max_len must be > 0");

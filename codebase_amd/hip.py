@@ -35,6 +35,21 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+_FWD_WS = {}
+
+
+def _fwd_ws(spec, device):
+    """(pointer, bytes) of the weight-pack workspace the forward-only entry points take (marlhip_forward_workspace_bytes): one
+    buffer per (net shape, device, stream) - a call's packs are read by that call's kernels only, and calls on one stream are ordered"""
+    key = (spec.n_agents, spec.obs_dim, spec.hidden, torch.device(device).index, torch.cuda.current_stream().cuda_stream)
+    ws = _FWD_WS.get(key)
+    if ws is None:
+        s = spec.c()
+        n = check(lib.marlhip_forward_workspace_bytes(ctypes.byref(s)), "forward_workspace_bytes")
+        ws = _FWD_WS[key] = torch.empty(n, dtype=torch.uint8, device=device)
+    return ctypes.c_void_p(ws.data_ptr()), ws.numel()
+
+
 def parse_lbf_name(name):
     """'lbforaging:Foraging-8x8-2p-3f[-coop][-2s][-pen]-v3' -> upstream registration kwargs."""
     base = name.split(":")[-1]
@@ -419,7 +434,7 @@ def ac_forward_rows(spec: NetSpec, params, obs, agent_stride, row_stride, n_rows
     s = spec.c()
     out = torch.empty(spec.n_agents, n_rows, 1 if value_net else spec.n_actions, device=params.device)
     check(lib.marlhip_ac_forward_rows(ctypes.byref(s), int(value_net), _ptr(params), _ptr(obs), int(agent_stride),
-                                      int(row_stride), int(n_rows), _ptr(out), _stream()), "ac_forward_rows")
+                                      int(row_stride), int(n_rows), _ptr(out), *_fwd_ws(spec, params.device), _stream()), "ac_forward_rows")
     return out
 
 
@@ -461,7 +476,11 @@ class AcUpdater:
         rs = self.ret_stats
         self.cfg = AcConfig(int(n_steps), float(entropy_coef), float(value_loss_coef), float(ppo_clip), float(gamma),
                             rs.mean.data_ptr() if rs else None, rs.var.data_ptr() if rs else None,
-                            rs.count_t.data_ptr() if rs else None, self.centralised)
+                            rs.count_t.data_ptr() if rs else None, self.centralised, None)
+        if self.recurrent:
+            # recurrent actors + critics: the critics' sequence passes overlap the actors' on this second stream (joined inside the call)
+            self._side = torch.cuda.Stream(device=block.device)
+            self.cfg.side_stream = self._side.cuda_stream
         self.lr, self.betas, self.eps = lr, betas, eps
         self.grad_clip = float(grad_clip) if grad_clip else 0.0
         self.step = 0
@@ -532,7 +551,7 @@ def idqn_collect(cfg, spec: NetSpec, params, epsilon, round_idx, replay: DeviceR
     check(fn(ctypes.byref(cfg), ctypes.byref(s), _ptr(params), float(epsilon), int(round_idx) & 0xFFFFFFFF,
                                    ctypes.byref(replay.shape), ctypes.byref(replay.bufs), int(slot_base), int(bool(write_replay)),
                                    int(bool(clear_stale)), int(bool(use_proper_termination)), _ptr(fin_return), _ptr(fin_length),
-                                   _stream()), "idqn_collect")
+                                   *_fwd_ws(spec, params.device), _stream()), "idqn_collect")
 
 
 class FusedLearner:
@@ -577,7 +596,8 @@ def ac_collect(cfg, spec: NetSpec, actor_params, round_idx, max_len, use_proper_
     fn = lib.marlhip_rware_ac_collect if is_rware(cfg) else lib.marlhip_ac_collect
     check(fn(ctypes.byref(cfg), ctypes.byref(s), _ptr(actor_params), int(round_idx) & 0xFFFFFFFF, int(max_len),
                                  int(bool(use_proper_termination)), _ptr(b_obs), _ptr(b_act), _ptr(b_rew), _ptr(b_done),
-                                 _ptr(b_filled), _ptr(fin_return), _ptr(fin_length), _ptr(t_max), _stream()), "ac_collect")
+                                 _ptr(b_filled), _ptr(fin_return), _ptr(fin_length), _ptr(t_max), *_fwd_ws(spec, actor_params.device),
+                                 _stream()), "ac_collect")
 
 
 def gru_forward(spec: NetSpec, params, obs, h_in=None, want_h=False, record=None):
@@ -590,7 +610,7 @@ def gru_forward(spec: NetSpec, params, obs, h_in=None, want_h=False, record=None
     h_out = torch.empty(P, B, spec.hidden, device=obs.device) if want_h else None
     s = spec.c()
     check(lib.marlhip_gru_forward(ctypes.byref(s), _ptr(params), _ptr(obs), S, B, _ptr(h_in), _ptr(h_out), _ptr(q), _ptr(record),
-                                  _stream()), "gru_forward")
+                                  *_fwd_ws(spec, params.device), _stream()), "gru_forward")
     return (q, h_out) if want_h else q
 
 
@@ -697,7 +717,7 @@ def gru_ac_forward(spec: NetSpec, params, obs, agent_stride, row_stride, steps, 
     h_out = torch.empty(P, batch, spec.hidden, device=params.device) if want_h else None
     s = spec.c()
     check(lib.marlhip_gru_ac_forward(ctypes.byref(s), int(value_net), _ptr(params), _ptr(obs), int(agent_stride), int(row_stride), int(steps),
-                                     int(batch), _ptr(h_in), _ptr(h_out), _ptr(out), _stream()), "gru_ac_forward")
+                                     int(batch), _ptr(h_in), _ptr(h_out), _ptr(out), *_fwd_ws(spec, params.device), _stream()), "gru_ac_forward")
     return (out, h_out) if want_h else out
 
 

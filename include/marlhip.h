@@ -10,8 +10,15 @@
  * Conventions
  *  - every call returns 0 on success, <0 on error (text: marlhip_last_error()).
  *  - the CALLER owns all memory: arguments are raw DEVICE pointers (PyTorch-ROCm tensors) plus
- *    element counts; the library never allocates, never frees, keeps no state between calls.
- *  - every call takes a hipStream_t (as void*), only enqueues, never synchronises.
+ *    element counts; the library never allocates or frees device memory.  Entry points that need
+ *    scratch take a `workspace` (sizes: the marlhip_*_workspace_bytes functions).
+ *  - every call takes a hipStream_t (as void*), only enqueues, never synchronises.  The one call that
+ *    overlaps work on a second stream (the recurrent actor-critic step) takes that stream from the
+ *    caller (marlhip_ac_config.side_stream) and joins it back before it returns.
+ *  - state kept between calls: the text behind marlhip_last_error() (per host thread), whether a
+ *    kernel's dynamic-LDS attribute has been raised on a device (idempotent), and - only while
+ *    marlhip_timing_enable(1) - the HIP events of the measurement aid at the end of this file.
+ *    Nothing else: calls on different host threads / streams share no buffers.
  *  - layouts are agent-major, env-minor: obs[P][N][D] f32, actions[P][N] i32, rewards[P][N] f32,
  *    done[N] u8.  N = envs, P = agents, D = obs dim, A = actions, T = time_limit, B = batch.
  *  - integer results (env state, done flags, observations, greedy actions, sampled indices) are
@@ -25,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MARLHIP_VERSION 100
+#define MARLHIP_VERSION 200
 
 int marlhip_version(void);
 const char* marlhip_last_error(void);
@@ -160,6 +167,12 @@ typedef struct marlhip_net_shape {
 
 int marlhip_net_nparams(const marlhip_net_shape* s); /* per network block; <0 if the shape has no kernel */
 
+/* bytes of `workspace` the forward-only entry points below need for this network shape (the collectors, marlhip_ac_forward_rows,
+ * marlhip_gru_forward, marlhip_gru_ac_forward: MFMA weight packs of every agent, built per call from the canonical parameters;
+ * covers the one-output critic and the centralised-critic variants of the shape).  The learner entry points size their own
+ * workspaces (marlhip_dqn_workspace_bytes, marlhip_ac_workspace_bytes, ...). */
+int64_t marlhip_forward_workspace_bytes(const marlhip_net_shape* s);
+
 /* QNetwork.act (marlbase/dqn/model.py:94-116), batched over N envs: Q = critic_i(obs_i);
  * ONE uniform per env decides random-vs-greedy for the whole joint action (model.py:105);
  * greedy = first index of the max (torch.argmax).  Noise: if u != NULL use u[n] and
@@ -283,7 +296,8 @@ int marlhip_dqn_clip_adam(int64_t n, float* params, const float* grad, float* ex
 int marlhip_idqn_collect(const marlhip_lbf_config* cfg, const marlhip_net_shape* s, const float* params, float epsilon,
                          uint32_t round, const marlhip_replay_shape* rs, const marlhip_replay_buffers* rb,
                          int32_t slot_base, int32_t write_replay, int32_t clear_stale, int32_t use_proper_termination,
-                         float* fin_return /* [P][N] */, int32_t* fin_length /* [N] */, void* stream);
+                         float* fin_return /* [P][N] */, int32_t* fin_length /* [N] */, void* workspace,
+                         int64_t workspace_bytes /* >= marlhip_forward_workspace_bytes(s) */, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Fused actor-critic rollout collector.  Replaces _collect_trajectories (marlbase/ac/train.py:24-119)
@@ -301,7 +315,7 @@ int marlhip_ac_collect(const marlhip_lbf_config* cfg, const marlhip_net_shape* s
                        uint32_t round, int32_t max_len, int32_t use_proper_termination, float* batch_obs,
                        int64_t* batch_act, float* batch_rew, uint8_t* batch_done, float* batch_filled,
                        float* fin_return /* [P][N] */, int32_t* fin_length /* [N] */, int32_t* t_max /* [1] */,
-                       void* stream);
+                       void* workspace, int64_t workspace_bytes /* >= marlhip_forward_workspace_bytes(s) */, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Recurrent Q-networks (`use_rnn: True`; RNNNetwork, marlbase/utils/models.py:51-116): Linear(D, H) -> ReLU -> one-layer
@@ -317,7 +331,7 @@ int marlhip_gru_nparams(const marlhip_net_shape* s); /* per agent block; <0 if t
 int64_t marlhip_gru_record_floats(const marlhip_net_shape* s, int32_t steps, int32_t batch);
 int marlhip_gru_forward(const marlhip_net_shape* s, const float* params /* [P][nparams] */, const float* obs, int32_t steps,
                         int32_t batch, const float* h_in, float* h_out, float* q_out /* [P][steps][B][A] */, float* record,
-                        void* stream);
+                        void* workspace, int64_t workspace_bytes /* >= marlhip_forward_workspace_bytes(s) */, void* stream);
 
 /* QNetwork._compute_loss / VDNetwork._compute_loss + loss.backward() with recurrent networks (mode 0 / 1): sequence forward of
  * the critic (activations recorded) and the target from zero hidden states, TD rows (Double-Q or max, action masks honoured),
@@ -357,7 +371,8 @@ int marlhip_gru_ppo_loss_grad(const marlhip_net_shape* s, const float* actor, co
                               const struct marlhip_ac_config* cfg, void* workspace, int64_t workspace_bytes, float* actor_grad,
                               float* critic_grad, float* metrics /* [5] */, void* stream);
 int marlhip_gru_ac_forward(const marlhip_net_shape* s, int32_t value_net, const float* params, const float* obs, int64_t agent_stride,
-                           int64_t row_stride, int32_t steps, int32_t batch, const float* h_in, float* h_out, float* out, void* stream);
+                           int64_t row_stride, int32_t steps, int32_t batch, const float* h_in, float* h_out, float* out, void* workspace,
+                           int64_t workspace_bytes /* >= marlhip_forward_workspace_bytes(s) */, void* stream);
 
 /* Categorical(logits=logits[p][n]).sample() for every (agent, env) (ac/model.py:147-153), drawn as the fused rollout collector draws
  * it: inverse CDF of the fp32 softmax with the Philox uniform of (env n, episode[n], step t, word 1 + p).  actions: i64 [P][N]. */
@@ -376,12 +391,13 @@ int marlhip_act_from_q(int32_t n_agents, int32_t n_envs, int32_t n_actions, cons
 int marlhip_rware_idqn_collect(const marlhip_rware_config* cfg, const marlhip_net_shape* s, const float* params, float epsilon,
                                uint32_t round, const marlhip_replay_shape* rs, const marlhip_replay_buffers* rb,
                                int32_t slot_base, int32_t write_replay, int32_t clear_stale, int32_t use_proper_termination,
-                               float* fin_return /* [P][N] */, int32_t* fin_length /* [N] */, void* stream);
+                               float* fin_return /* [P][N] */, int32_t* fin_length /* [N] */, void* workspace, int64_t workspace_bytes,
+                               void* stream);
 int marlhip_rware_ac_collect(const marlhip_rware_config* cfg, const marlhip_net_shape* s, const float* actor_params,
                              uint32_t round, int32_t max_len, int32_t use_proper_termination, float* batch_obs,
                              int64_t* batch_act, float* batch_rew, uint8_t* batch_done, float* batch_filled,
                              float* fin_return /* [P][N] */, int32_t* fin_length /* [N] */, int32_t* t_max /* [1] */,
-                             void* stream);
+                             void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Actor-critic learner step (IA2C / IPPO).  Replaces A2CNetwork.update / PPONetwork.update
@@ -408,6 +424,10 @@ typedef struct marlhip_ac_config {
     int32_t centralised_critic; /* critic.centralised (MAA2C / MAPPO, model.py:62-66,155-157): every agent's critic and target
                                    critic takes the concatenation of ALL agents' observations (P*D inputs); compiled for
                                    hidden 128 up to 4 agents and hidden 64 for 2 agents */
+    void* side_stream;          /* hipStream_t of the caller on the same device, or NULL.  Recurrent actors + critics only: the
+                                   critics' sequence passes are enqueued on it next to the actors' on the call's stream (fork /
+                                   join through events inside the call; everything is joined back before the call returns).
+                                   NULL: one stream, no overlap, same results. */
 } marlhip_ac_config;
 
 int marlhip_ac_critic_nparams(const marlhip_net_shape* s, int32_t centralised); /* per critic block */
@@ -416,7 +436,8 @@ int64_t marlhip_ac_workspace_bytes(const marlhip_net_shape* s, int32_t centralis
  * out[p][row][:] = MLP_p(obs + p * agent_stride + row * row_stride); value_net 1: the one-output critic shape; value_net 2:
  * the centralised critic (P*D inputs, agent_stride 0: rows are the concatenated observations). */
 int marlhip_ac_forward_rows(const marlhip_net_shape* s, int32_t value_net, const float* params, const float* obs,
-                            int64_t agent_stride, int64_t row_stride, int32_t n_rows, float* out, void* stream);
+                            int64_t agent_stride, int64_t row_stride, int32_t n_rows, float* out, void* workspace,
+                            int64_t workspace_bytes /* >= marlhip_forward_workspace_bytes(s) */, void* stream);
 int marlhip_a2c_loss_grad(const marlhip_net_shape* s, const float* actor, const float* critic, const float* target_critic,
                           const marlhip_batch* batch, const marlhip_ac_config* cfg, void* workspace, int64_t workspace_bytes,
                           float* actor_grad, float* critic_grad, float* metrics, void* stream);

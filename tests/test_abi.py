@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(_lib.lib, s), f"{s} declared in marlhip.h but not exported"
     assert sorted(_lib.PROTOTYPES) == syms, "ctypes prototypes and header disagree"
-    assert _lib.lib.marlhip_version() == 100
+    assert _lib.lib.marlhip_version() == 200
 
 
 def test_validation_errors_are_loud_and_need_no_gpu():
@@ -43,6 +43,10 @@ def test_validation_errors_are_loud_and_need_no_gpu():
     s = _lib.NetShape(2, 15, 96, 6)
     assert _lib.lib.marlhip_net_nparams(ctypes.byref(s)) < 0
     assert _lib.lib.marlhip_dqn_workspace_bytes(ctypes.byref(_lib.NetShape(2, 15, 64, 6)), 25, 32) > 0
+    # forward-only entry points take their weight-pack scratch from the caller: the size query needs no GPU
+    n64, n128 = (_lib.lib.marlhip_forward_workspace_bytes(ctypes.byref(_lib.NetShape(2, 15, h, 6))) for h in (64, 128))
+    assert 2 * 2 * 6288 * 4 <= n64 < n128
+    assert _lib.lib.marlhip_forward_workspace_bytes(ctypes.byref(_lib.NetShape(0, 15, 64, 6))) < 0
 
 
 def test_product_path_refuses_to_run_without_a_gpu():
