@@ -58,7 +58,7 @@ class BatchStruct(ctypes.Structure):
 
 class QmixMixer(ctypes.Structure):
     _fields_ = [("mixer", c_void_p), ("target_mixer", c_void_p), ("mixer_grad", c_void_p), ("embed_dim", c_int32),
-                ("hypernet_layers", c_int32), ("hypernet_embed", c_int32)]
+                ("hypernet_layers", c_int32), ("hypernet_embed", c_int32), ("ret_stats", c_void_p)]
 
 
 class AcConfig(ctypes.Structure):
@@ -68,7 +68,7 @@ class AcConfig(ctypes.Structure):
 
 
 class RetStatsStruct(ctypes.Structure):
-    _fields_ = [("mean", c_void_p), ("var", c_void_p), ("count", c_void_p)]
+    _fields_ = [("mean", c_void_p), ("var", c_void_p), ("count", c_void_p), ("columns", c_int32)]
 
 
 class IdqnLearner(ctypes.Structure):
@@ -145,11 +145,11 @@ PROTOTYPES = {
     "marlhip_dqn_loss_grad_replay": (c_int32, [POINTER(NetShape), c_void_p, c_void_p, POINTER(ReplayShape),
                                                POINTER(ReplayBuffers), c_void_p, c_int32, c_int32, c_uint64, c_uint32, c_void_p,
                                                c_float, c_int32, c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
-    "marlhip_dqn_loss_grad_std": (c_int32, [POINTER(NetShape), c_void_p, c_void_p, POINTER(BatchStruct), c_float, c_int32,
+    "marlhip_dqn_loss_grad_std": (c_int32, [POINTER(NetShape), c_void_p, c_void_p, POINTER(BatchStruct), c_float, c_int32, c_int32,
                                             POINTER(RetStatsStruct), c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "marlhip_dqn_loss_grad_std_replay": (c_int32, [POINTER(NetShape), c_void_p, c_void_p, POINTER(ReplayShape),
                                                    POINTER(ReplayBuffers), c_void_p, c_int32, c_int32, c_uint64, c_uint32, c_void_p,
-                                                   c_float, c_int32, POINTER(RetStatsStruct), c_void_p, c_int64, c_void_p, c_void_p,
+                                                   c_float, c_int32, c_int32, POINTER(RetStatsStruct), c_void_p, c_int64, c_void_p, c_void_p,
                                                    c_void_p]),
     "marlhip_qmix_nparams": (c_int32, [POINTER(NetShape), c_int32, c_int32, c_int32]),
     "marlhip_qmix_workspace_bytes": (c_int64, [POINTER(NetShape), c_int32, c_int32]),

@@ -78,6 +78,7 @@ static int lossgrad_dispatch(const marlhip_net_shape* s, const float* params, co
                              const ReplaySrc* rsrc, float gamma, int32_t double_q, int32_t mode, void* workspace,
                              int64_t workspace_bytes, float* grad, float* loss, void* stream, const QmixCtx* qx = nullptr,
                              const RetStats* rst = nullptr) {
+    MARL_REQUIRE(rst == nullptr || mode == 3 || mode == 1, "dqn_loss_grad: return statistics go with the IDQN (3) / VDN (1) steps");
     MARL_REQUIRE(mode == 0 || mode == 1 || (mode == 2 && qx != nullptr) || (mode == 3 && rst != nullptr),
                  "dqn_loss_grad: mode %d unknown (0 = IDQN, 1 = VDN)", mode);
     if (agent_map_validate(s) != 0) return -1;
@@ -121,28 +122,33 @@ extern "C" int marlhip_dqn_loss_grad_replay(const marlhip_net_shape* s, const fl
 }
 
 // ---- IDQN with standardise_returns (QNetwork._compute_loss, marlbase/dqn/model.py:146-158) -------------------------------
-static int std_stats(const marlhip_ret_stats* st, RetStats* out) {
+static int std_stats(const marlhip_ret_stats* st, RetStats* out, int mode, int batch) {
     MARL_REQUIRE(st && st->mean && st->var && st->count, "dqn_loss_grad_std: NULL return statistics");
-    out->mean = st->mean; out->var = st->var; out->count = st->count;
+    MARL_REQUIRE(mode == 0 || mode == 1, "dqn_loss_grad_std: mode %d (0 = IDQN, per-agent statistics; 1 = VDN, per-batch-column statistics)", mode);
+    MARL_REQUIRE(mode == 0 ? st->columns == 0 : st->columns == batch,
+                 "dqn_loss_grad_std: statistics with %d columns for mode %d and a batch of %d (IDQN: columns = 0, mean / var [n_agents]; VDN: "
+                 "columns = batch, mean / var [batch])", st->columns, mode, batch);
+    out->mean = st->mean; out->var = st->var; out->count = st->count; out->columns = st->columns;
     return 0;
 }
 
 extern "C" int marlhip_dqn_loss_grad_std(const marlhip_net_shape* s, const float* params, const float* target_params,
-                                         const marlhip_batch* batch, float gamma, int32_t double_q, const marlhip_ret_stats* stats,
-                                         void* workspace, int64_t workspace_bytes, float* grad, float* loss, void* stream) {
+                                         const marlhip_batch* batch, float gamma, int32_t double_q, int32_t mode,
+                                         const marlhip_ret_stats* stats, void* workspace, int64_t workspace_bytes, float* grad, float* loss,
+                                         void* stream) {
     MARL_REQUIRE(s && params && target_params && batch && workspace && grad && loss, "dqn_loss_grad_std: NULL pointer");
     MARL_REQUIRE(batch->obss && batch->actions && batch->rewards && batch->dones && batch->filled, "dqn_loss_grad_std: NULL batch field");
     MARL_REQUIRE(batch->max_len > 0 && batch->batch > 0, "dqn_loss_grad_std: empty batch");
     RetStats rst;
-    if (std_stats(stats, &rst) != 0) return -1;
-    return lossgrad_dispatch(s, params, target_params, batch, nullptr, gamma, double_q, 3, workspace, workspace_bytes, grad, loss, stream,
-                             nullptr, &rst);
+    if (std_stats(stats, &rst, mode, batch->batch) != 0) return -1;
+    return lossgrad_dispatch(s, params, target_params, batch, nullptr, gamma, double_q, mode == 0 ? 3 : 1, workspace, workspace_bytes, grad, loss,
+                             stream, nullptr, &rst);
 }
 
 extern "C" int marlhip_dqn_loss_grad_std_replay(const marlhip_net_shape* s, const float* params, const float* target_params,
                                                 const marlhip_replay_shape* rs, const marlhip_replay_buffers* rb, const int32_t* idx,
                                                 int32_t batch, int32_t length, uint64_t seed, uint32_t counter, int32_t* idx_out,
-                                                float gamma, int32_t double_q, const marlhip_ret_stats* stats, void* workspace,
+                                                float gamma, int32_t double_q, int32_t mode, const marlhip_ret_stats* stats, void* workspace,
                                                 int64_t workspace_bytes, float* grad, float* loss, void* stream) {
     MARL_REQUIRE(s && params && target_params && rs && rb && workspace && grad && loss, "dqn_loss_grad_std_replay: NULL pointer");
     MARL_REQUIRE(rb->obs && rb->act && rb->rew && rb->done && rb->filled, "dqn_loss_grad_std_replay: NULL replay buffer");
@@ -150,14 +156,14 @@ extern "C" int marlhip_dqn_loss_grad_std_replay(const marlhip_net_shape* s, cons
     MARL_REQUIRE(batch > 0 && rs->max_len > 0, "dqn_loss_grad_std_replay: empty batch");
     MARL_REQUIRE(idx != nullptr || (length > 0 && length <= rs->capacity), "dqn_loss_grad_std_replay: length %d out of range", length);
     RetStats rst;
-    if (std_stats(stats, &rst) != 0) return -1;
+    if (std_stats(stats, &rst, mode, batch) != 0) return -1;
     marlhip_batch bt = {};
     bt.max_len = rs->max_len;
     bt.batch = batch;
     ReplaySrc src;
     src.rb = *rb; src.idx = idx; src.idx_out = idx_out; src.seed = seed; src.counter = counter; src.length = length; src.capacity = rs->capacity;
-    return lossgrad_dispatch(s, params, target_params, &bt, &src, gamma, double_q, 3, workspace, workspace_bytes, grad, loss, stream,
-                             nullptr, &rst);
+    return lossgrad_dispatch(s, params, target_params, &bt, &src, gamma, double_q, mode == 0 ? 3 : 1, workspace, workspace_bytes, grad, loss,
+                             stream, nullptr, &rst);
 }
 
 // ---- QMIX (QMixNetwork, marlbase/dqn/model.py:334-443) ------------------------------------------------------
@@ -207,6 +213,14 @@ static int qmix_call(const marlhip_net_shape* s, const float* params, const floa
     qx.mixer = mx->mixer; qx.tmixer = mx->target_mixer; qx.mgrad = mx->mixer_grad;
     qx.ws = static_cast<char*>(workspace) + a;
     qx.ws_bytes = workspace_bytes - a;
+    RetStats rst;
+    if (mx->ret_stats != nullptr) {  // QMixNetwork with standardise_returns: per-batch-column statistics (model.py:415-422)
+        const marlhip_ret_stats* st = mx->ret_stats;
+        MARL_REQUIRE(st->mean && st->var && st->count && st->columns == bt->batch,
+                     "qmix_loss_grad: return statistics need mean / var [batch] and columns = batch (%d), got columns = %d", bt->batch, st->columns);
+        rst.mean = st->mean; rst.var = st->var; rst.count = st->count; rst.columns = st->columns;
+        qx.rst = &rst;
+    }
     return lossgrad_dispatch(s, params, target_params, bt, rsrc, gamma, double_q, 2, workspace, a, grad, loss, stream, &qx);
 }
 

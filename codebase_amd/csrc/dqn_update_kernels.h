@@ -900,9 +900,9 @@ static __global__ __launch_bounds__(256) void adam_kernel(int64_t n, int nblocks
 
 }  // namespace marl
 
+#include "ret_stats.h"
 #include "dqn_update_tp.h"
 #include "qmix.h"
-#include "ret_stats.h"
 
 namespace marl {
 
@@ -1028,7 +1028,8 @@ inline UpdPlan upd_plan(int P, int T, int B) {
 
 // VDN mixer (VDNetwork._compute_loss, dqn/model.py:237,254-269): chosen_tot = sum_p chosen_p, target_tot = sum_p tq_p,
 // y = r_0 + gamma * target_tot * (1 - done), delta = chosen_tot - y; dL/dchosen_p = 2 * filled * delta for every p.
-static __global__ __launch_bounds__(256) void vdn_mix_kernel(MixBufs mix, int P, int T, int B, float gamma) {
+// ret (optional): the standardised returns of colstd_returns_kernel instead of r + gamma * target * (1 - done)
+static __global__ __launch_bounds__(256) void vdn_mix_kernel(MixBufs mix, int P, int T, int B, float gamma, const float* __restrict__ ret) {
     const int n = T * B;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         float ch = 0.f, tq = 0.f;
@@ -1036,7 +1037,7 @@ static __global__ __launch_bounds__(256) void vdn_mix_kernel(MixBufs mix, int P,
             ch += mix.chosen[(size_t)p * n + i];
             tq += mix.tqsel[(size_t)p * n + i];
         }
-        const float y = mix.r0[i] + gamma * tq * (1.f - mix.dn[i]);
+        const float y = ret != nullptr ? ret[i] : mix.r0[i] + gamma * tq * (1.f - mix.dn[i]);
         const float delta = ch - y;
         const float fl = mix.fl[i];
         mix.dq[i] = 2.f * fl * delta;
@@ -1136,8 +1137,15 @@ int launch_lossgrad_tp(const marlhip_net_shape* s, const float* params, const fl
                                         mixf + (size_t)(4 * P + 5) * tb, st);
         if (rc != 0) return rc;
     } else {
+        const float* ret = nullptr;
+        if (mode == 1 && rst != nullptr) {  // VDN with standardise_returns (the returns take a spare plane behind lrow)
+            float* rbuf = mixf + (size_t)(4 * P + 3) * tb;
+            const int rc = launch_colstd(T, B, gamma, *rst, mix.tqsel, P, tb, mix.rew, mix.dn, rbuf, st);
+            if (rc != 0) return rc;
+            ret = rbuf;
+        }
         hipLaunchKernelGGL(tp_mix_kernel, dim3((unsigned)((tb + 255) / 256 > 1024 ? 1024 : (tb + 255) / 256)), dim3(256), 0, st, mix, P,
-                           T, B, gamma, mode == 1 ? 1 : 0);
+                           T, B, gamma, mode == 1 ? 1 : 0, ret);
     }
     hipLaunchKernelGGL((tp_bwd_kernel<S, W, TPW, REPLAY, NB>), grid, block, ldsB, st, params, am, *bt, src, mix, pl.n_chunks, (float*)ws);
     timing_end(TIMER_LOSSGRAD, st);
@@ -1222,8 +1230,15 @@ int launch_lossgrad_src(const marlhip_net_shape* s, const float* params, const f
                                             mix.lrow, mixf + (size_t)(4 * P + 5) * tb, st);
             if (rc != 0) return rc;
         } else {
+            const float* ret = nullptr;
+            if (rst != nullptr) {  // VDN with standardise_returns: per-batch-column statistics; the returns take a spare mixer plane
+                float* rbuf = mixf + (size_t)(2 * P + 5) * tb;
+                const int rc = launch_colstd(T, B, gamma, *rst, mix.tqsel, P, tb, mix.r0, mix.dn, rbuf, st);
+                if (rc != 0) return rc;
+                ret = rbuf;
+            }
             hipLaunchKernelGGL(vdn_mix_kernel, dim3((unsigned)((tb + 255) / 256 > 1024 ? 1024 : (tb + 255) / 256)), dim3(256), 0, st,
-                               mix, P, T, B, gamma);
+                               mix, P, T, B, gamma, ret);
         }
         hipLaunchKernelGGL((dqn_lossgrad_kernel<S, 4, REPLAY, 2>), grid, block, lds_bytes, st, (const float*)packs, *bt, src, mix,
                            gamma, double_q, pl.n_chunks, (float*)ws, prof);

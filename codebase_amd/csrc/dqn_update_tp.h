@@ -341,7 +341,7 @@ __global__ __launch_bounds__(64 * W, 1) void tp_fwd_kernel(const float* __restri
 }
 
 // mixers: dq_p[t][b] = dL/dchosen_p (unnormalised), lrow[t][b] = per-row loss (dqn/model.py:152,160-163 / 254-269)
-static __global__ __launch_bounds__(256) void tp_mix_kernel(TpMix mix, int P, int T, int B, float gamma, int vdn) {
+static __global__ __launch_bounds__(256) void tp_mix_kernel(TpMix mix, int P, int T, int B, float gamma, int vdn, const float* __restrict__ ret) {
     const int n = T * B;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         const float fl = mix.fl[i], nd = 1.f - mix.dn[i];
@@ -351,7 +351,7 @@ static __global__ __launch_bounds__(256) void tp_mix_kernel(TpMix mix, int P, in
                 ch += mix.chosen[(size_t)p * n + i];
                 tq += mix.tqsel[(size_t)p * n + i];
             }
-            const float delta = ch - (mix.rew[i] + gamma * tq * nd);
+            const float delta = ch - (ret != nullptr ? ret[i] : mix.rew[i] + gamma * tq * nd);
             for (int p = 0; p < P; ++p) mix.dq[(size_t)p * n + i] = 2.f * fl * delta;
             mix.lrow[i] = fl * delta * delta;
         } else {

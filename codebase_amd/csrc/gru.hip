@@ -360,7 +360,8 @@ extern "C" int marlhip_gru_loss_grad_std(const marlhip_net_shape* s, const float
                  "gru_loss_grad_std: NULL pointer");
     MARL_REQUIRE(batch->obs_agent_stride == 0 && batch->obs_row_stride == 0, "gru_loss_grad_std: the dqn/train.py Batch layout only");
     RetStats rst;
-    rst.mean = stats->mean; rst.var = stats->var; rst.count = stats->count;
+    rst.mean = stats->mean; rst.var = stats->var; rst.count = stats->count; rst.columns = 0;
+    MARL_REQUIRE(stats->columns == 0, "gru_loss_grad_std: per-agent statistics (the independent learner) only");
 #define X(d, h, a)                                               \
     if (s->obs_dim == d && s->hidden == h && s->n_actions == a)  \
         return gru_loss_grad<GruShape<d, h, a>>(s, params, target_params, batch, gamma, double_q, 0, workspace, workspace_bytes, grad, loss, \

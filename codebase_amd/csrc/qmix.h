@@ -217,6 +217,7 @@ struct QmixIo {
     float* dq;            // [P][R]
     float* lrow;          // [R]
     float* ytgt;          // [R] target-mixer output
+    int ytgt_is_return;   // standardise_returns: ytgt already holds the standardised return (colstd_returns_kernel ran on it in place)
 };
 
 // backward operands, written by the online instance (Rp = rows padded to whole blocks, nblk = Rp/16):
@@ -333,7 +334,7 @@ __global__ __launch_bounds__(256, 1) void qmix_mix_kernel(const float* __restric
         } else {
         // ---- TD error and backward (model.py:419-427)
         const float fl = ok ? io.fl[rc] : 0.f;
-        const float delta = y - (io.r0[rc] + gamma * io.ytgt[rc] * (1.f - io.dn[rc]));
+        const float delta = y - (io.ytgt_is_return ? io.ytgt[rc] : io.r0[rc] + gamma * io.ytgt[rc] * (1.f - io.dn[rc]));
         const float dy = 2.f * fl * delta;
         if (g == 0) {
             bw.DY[blk * 16 + j] = dy;
@@ -618,6 +619,7 @@ struct QmixCtx {  // what marlhip_qmix_loss_grad adds to the agent-network call
     float* mgrad;
     void* ws;  // qmix part of the workspace
     int64_t ws_bytes;
+    const RetStats* rst = nullptr;  // standardise_returns: per-batch-column statistics (ret_stats.h), or null
 };
 
 struct QmixWs {
@@ -688,6 +690,11 @@ int qmix_launch_mix(const QmixCtx& qx, const marlhip_batch* bt, const ReplaySrc&
     hipLaunchKernelGGL((qmix_l1_kernel<Q, REPLAY>), dim3(g1), dim3(256), CH, st, (const float*)(packs + Q::NL1), src, 1, R, y1t);
     hipLaunchKernelGGL((qmix_mix_kernel<Q, false>), dim3(g2), dim3(256), LM_TG, st, (const float*)(packs + 2 * Q::NL1 + Q::NMIX),
                        (const float*)y1t, io2, R, gamma, bw);
+    if (qx.rst != nullptr) {  // QMixNetwork with standardise_returns: the target mixer's output becomes the standardised return
+        const int rc = launch_colstd(T, B, gamma, *qx.rst, io2.ytgt, 1, 0, io2.r0, io2.dn, io2.ytgt, st);
+        if (rc != 0) return rc;
+        io2.ytgt_is_return = 1;
+    }
     hipLaunchKernelGGL((qmix_l1_kernel<Q, REPLAY>), dim3(g1), dim3(256), CH, st, (const float*)packs, src, 0, R, y1o);
     hipLaunchKernelGGL((qmix_mix_kernel<Q, true>), dim3(g2), dim3(256), LM_ON, st, (const float*)(packs + 2 * Q::NL1), (const float*)y1o,
                        io2, R, gamma, bw);

@@ -2,13 +2,15 @@
 // mean / var are fp32 [P] like the reference's tensors, count is the python float (fp64 here); the parallel-variance
 // update runs in fp64 and is rounded once per update (the reference rounds every intermediate to fp32).
 #pragma once
+#include "common.h"
 
 namespace marl {
 
 struct RetStats {
-    float* mean;    // [P]
-    float* var;     // [P]
+    float* mean;    // [P]   (per-column statistics: [B])
+    float* var;     // [P]   (per-column statistics: [B])
     double* count;  // [1]
+    int columns;    // 0: one (mean, var) per agent (IDQN); B > 0: one per batch column (VDN / QMIX, see colstd_returns_kernel)
 };
 
 // per-block sums of x and x^2 over a block's (row, agent) values: fixed-order wave butterfly + 4 waves
@@ -90,6 +92,65 @@ static __global__ __launch_bounds__(256) void std_dq_kernel(int P, int n, RetSta
         l += delta * delta;
     }
     lrow[i] = f * l;
+}
+
+// VDN / QMIX with standardise_returns (dqn/model.py:256-264, 415-422).  Their `RunningMeanStd(shape=(1,))` is fed the [T, B] returns:
+// `update` flattens to [T, B], takes mean / unbiased variance over dim 0 (the T time steps) and broadcasts the (1,)-shaped state
+// against the [B] moments - from the first update on the state IS [B]: one running (mean, var) per BATCH COLUMN, count += T per
+// update.  Reproduced as the reference computes it: one thread per column b,
+//   tq_tot[t] = sum of the `n_planes` planes (VDN: the agents' bootstrap values; QMIX: the target mixer's output)
+//   ret[t] = r0[t] + gamma * (tq_tot[t] * sqrt(var[b]) + mean[b]) * (1 - done[t])          with the OLD statistics
+//   update_from_moments(mean_t ret, var_t ret (unbiased), T) in the reference's fp32 operation order (the moments themselves are
+//   accumulated in fp64 and rounded once), then out[t] = (ret[t] - mean[b]) / sqrt(var[b])  with the NEW statistics.
+// `out` may alias the single plane (QMIX transforms the target mixer's output in place).
+static __global__ __launch_bounds__(256) void colstd_returns_kernel(int T, int B, float gamma, RetStats st, const float* __restrict__ tq,
+                                                                    int n_planes, size_t plane_stride, const float* __restrict__ r0,
+                                                                    const float* __restrict__ dn, float* out) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    const float mean = st.mean[b], sd = sqrtf(st.var[b]), var = st.var[b];
+    const float cnt = (float)st.count[0];  // the python float meets fp32 tensors: every product / quotient below is fp32
+    auto ret_at = [&](int t) {
+        const size_t i = (size_t)t * B + b;
+        float tot = 0.f;
+        for (int p = 0; p < n_planes; ++p) tot += tq[(size_t)p * plane_stride + i];
+        return r0[i] + gamma * (tot * sd + mean) * (1.f - dn[i]);
+    };
+    double s = 0.0;
+    for (int t = 0; t < T; ++t) s += (double)ret_at(t);
+    const double bm64 = s / (double)T;
+    double q = 0.0;
+    for (int t = 0; t < T; ++t) {
+        const double d = (double)ret_at(t) - bm64;
+        q += d * d;
+    }
+    const float bm = (float)bm64, bv = (float)(q / (double)(T - 1)), bc = (float)T;
+    const float delta = bm - mean;
+    const float tot_f = (float)(st.count[0] + (double)T);
+    const float new_mean = mean + delta * bc / tot_f;
+    const float m_a = var * cnt, m_b = bv * bc;
+    const float m_2 = m_a + m_b + delta * delta * cnt * bc / tot_f;
+    const float new_var = m_2 / tot_f;
+    const float nsd = sqrtf(new_var);
+    for (int t = 0; t < T; ++t) {
+        const float r = ret_at(t);
+        out[(size_t)t * B + b] = (r - new_mean) / nsd;
+    }
+    st.mean[b] = new_mean;
+    st.var[b] = new_var;
+}
+
+static __global__ void ret_count_add_kernel(double* count, double n) { count[0] += n; }
+
+inline int launch_colstd(int T, int B, float gamma, const RetStats& st, const float* tq, int n_planes, size_t plane_stride, const float* r0,
+                         const float* dn, float* out, hipStream_t stream) {
+    MARL_REQUIRE(st.columns == B, "standardise_returns: the statistics hold %d batch columns, the batch has %d (the reference's shapes "
+                 "pin the batch size after the first update)", st.columns, B);
+    hipLaunchKernelGGL(colstd_returns_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, T, B, gamma, st, tq, n_planes, plane_stride, r0, dn,
+                       out);
+    hipLaunchKernelGGL(ret_count_add_kernel, dim3(1), dim3(1), 0, stream, st.count, (double)T);
+    MARL_CHECK_LAUNCH("standardise_returns (per batch column)");
+    return 0;
 }
 
 // the three launches; `partial` needs 2 * P * ceil(n / 256) floats

@@ -128,9 +128,10 @@ class QNetwork:
         if (opt if isinstance(opt, str) else getattr(opt, "__name__", "")) != "Adam":
             raise NotImplementedError(f"optimizer {opt}: the fused step implements torch.optim.Adam")
         self.standardise_returns = bool(get("standardise_returns", False))
-        if self.standardise_returns and type(self).__name__ != "QNetwork":
-            # the reference's VDN / QMIX keep RunningMeanStd(shape=(1,)) but feed it [T, B] returns: per-batch-column statistics
-            raise NotImplementedError("standardise_returns is built for the independent learner (QNetwork) only (DESIGN.md)")
+        if self.standardise_returns and type(self).__name__ != "QNetwork" and self.recurrent:
+            # VDN / QMIX keep RunningMeanStd(shape=(1,)) but feed it [T, B] returns: per-batch-column statistics, reproduced for the
+            # feed-forward networks (hip.RunningReturnStats(columns=B)); the recurrent TD kernel does not take them yet
+            raise NotImplementedError("standardise_returns with use_rnn is built for the independent learner (QNetwork) only")
         self.action_space = action_space
         self.n_agents = len(obs_dims)
         self.device = torch.device(device)
@@ -152,7 +153,6 @@ class QNetwork:
         self.updater = (_hip.GruUpdater if self.recurrent else _hip.DqnUpdater)(self.spec, self.params, self.target_params, lr=float(get("lr", 3e-4)),
                                        gamma=self.gamma, grad_clip=self.grad_clip, double_q=self.double_q,
                                        standardise_returns=self.standardise_returns)
-        self.ret_ms = self.updater.ret_stats  # RunningMeanStd(shape=(n_agents,)) on the device (dqn/model.py:88-89)
         self.updates = 0
         self.last_target_update = 0
         self.mode = 0  # IDQN
@@ -163,6 +163,12 @@ class QNetwork:
     # ---- reference interface ---------------------------------------------------------------
     def forward(self, inputs):
         raise NotImplementedError("Forward not implemented. Use act or update instead!")
+
+    @property
+    def ret_ms(self):
+        """RunningMeanStd on the device (dqn/model.py:88-89): shape (n_agents,) for QNetwork; VDNetwork / QMixNetwork: one (mean, var) per
+        batch column once the first update has run (the reference's (1,)-shaped statistics broadcast to that shape there too)"""
+        return self.updater.ret_stats
 
     def init_hiddens(self, batch_size):
         if self.recurrent:  # RNNNetwork.init_hiddens (utils/models.py:96-102): [num_layers, batch, H] zeros per agent

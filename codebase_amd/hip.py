@@ -270,11 +270,14 @@ class DeviceReplay:
 
 
 class RunningReturnStats:
-    """RunningMeanStd(shape=(n_agents,)) of marlbase/utils/standardise_stream.py, resident on the device."""
+    """RunningMeanStd of marlbase/utils/standardise_stream.py, resident on the device: shape (n_agents,) for the independent
+    learner; for VDNetwork / QMixNetwork `columns` = batch size - their RunningMeanStd(shape=(1,)) turns into one (mean, var) per
+    batch column at its first update (dqn/model.py:256-264,415-422; include/marlhip.h, marlhip_ret_stats)."""
 
-    def __init__(self, n_agents, device, epsilon=1e-4):
-        self.mean = torch.zeros(n_agents, dtype=torch.float32, device=device)
-        self.var = torch.ones(n_agents, dtype=torch.float32, device=device)
+    def __init__(self, n, device, epsilon=1e-4, columns=0):
+        self.columns = int(columns)
+        self.mean = torch.zeros(n, dtype=torch.float32, device=device)
+        self.var = torch.ones(n, dtype=torch.float32, device=device)
         self.count_t = torch.full((1,), epsilon, dtype=torch.float64, device=device)
 
     @property
@@ -282,7 +285,7 @@ class RunningReturnStats:
         return float(self.count_t.item())
 
     def c(self):
-        return RetStatsStruct(self.mean.data_ptr(), self.var.data_ptr(), self.count_t.data_ptr())
+        return RetStatsStruct(self.mean.data_ptr(), self.var.data_ptr(), self.count_t.data_ptr(), self.columns)
 
 
 class DqnUpdater:
@@ -315,6 +318,21 @@ class DqnUpdater:
             self._ws[key] = torch.empty(max(int(n), 4), dtype=torch.uint8, device=self.params.device)
         return self._ws[key]
 
+    def _stats_for(self, mode, B):
+        """the running return statistics in the shape the learner keeps them: per agent (IDQN, mode 0) or per batch column (VDN /
+        QMIX: the reference's (1,)-shaped RunningMeanStd becomes [B] at its first update and pins the batch size)"""
+        st = self.ret_stats
+        if mode == 0:
+            if st.columns != 0:
+                raise MarlHipError("standardise_returns: these statistics belong to a VDN / QMIX learner")
+            return st
+        if st.columns == 0 and st.count <= 1e-4:  # untouched per-agent placeholder of the constructor: take the column form
+            st = self.ret_stats = RunningReturnStats(B, self.params.device, columns=B)
+        if st.columns != B:
+            raise MarlHipError(f"standardise_returns: the statistics hold {st.columns} batch columns, the batch has {B} "
+                               "(VDNetwork / QMixNetwork: RunningMeanStd(shape=(1,)) pins the batch size at its first update)")
+        return st
+
     def loss_grad(self, batch, mode=0):
         T, B = batch.filled.shape
         ws = self._workspace(T, B)
@@ -322,11 +340,9 @@ class DqnUpdater:
                          batch.filled.data_ptr(), T, B, 0, 0, 0, 0, _mask_ptr(batch.action_mask, (self.spec.n_agents, T + 1, B, self.spec.n_actions)))
         s = self.spec.c()
         if self.ret_stats is not None:
-            if mode != 0:
-                raise NotImplementedError("standardise_returns is built for independent learners (IDQN) only")
-            st = self.ret_stats.c()
+            st = self._stats_for(mode, B).c()
             check(lib.marlhip_dqn_loss_grad_std(ctypes.byref(s), _ptr(self.params), _ptr(self.target), ctypes.byref(bs),
-                                                float(self.gamma), self.double_q, ctypes.byref(st), _ptr(ws), ws.numel(),
+                                                float(self.gamma), self.double_q, int(mode), ctypes.byref(st), _ptr(ws), ws.numel(),
                                                 _ptr(self.grad), _ptr(self.loss), _stream()), "dqn_loss_grad_std")
             return self.loss, self.grad
         check(lib.marlhip_dqn_loss_grad(ctypes.byref(s), _ptr(self.params), _ptr(self.target), ctypes.byref(bs), float(self.gamma),
@@ -339,13 +355,11 @@ class DqnUpdater:
         ws = self._workspace(replay.T, batch_size)
         s = self.spec.c()
         if self.ret_stats is not None:
-            if mode != 0:
-                raise NotImplementedError("standardise_returns is built for independent learners (IDQN) only")
-            st = self.ret_stats.c()
+            st = self._stats_for(mode, batch_size).c()
             check(lib.marlhip_dqn_loss_grad_std_replay(ctypes.byref(s), _ptr(self.params), _ptr(self.target), ctypes.byref(replay.shape),
                                                        ctypes.byref(replay.bufs), _ptr(idx), int(batch_size), int(length or 0),
                                                        int(seed) & (2**64 - 1), int(counter) & 0xFFFFFFFF, _ptr(idx_out),
-                                                       float(self.gamma), self.double_q, ctypes.byref(st), _ptr(ws), ws.numel(),
+                                                       float(self.gamma), self.double_q, int(mode), ctypes.byref(st), _ptr(ws), ws.numel(),
                                                        _ptr(self.grad), _ptr(self.loss), _stream()), "dqn_loss_grad_std_replay")
             return self.loss, self.grad
         check(lib.marlhip_dqn_loss_grad_replay(ctypes.byref(s), _ptr(self.params), _ptr(self.target), ctypes.byref(replay.shape),
@@ -394,15 +408,19 @@ class QmixUpdater(DqnUpdater):
             self._ws[key] = torch.empty(max(int(n), 4), dtype=torch.uint8, device=self.params.device)
         return self._ws[key]
 
-    def _mx(self):
-        return QmixMixer(self.mixer.data_ptr(), self.target_mixer.data_ptr(), self.mixer_grad.data_ptr(), *self.mixing)
+    def _mx(self, B=None):
+        mx = QmixMixer(self.mixer.data_ptr(), self.target_mixer.data_ptr(), self.mixer_grad.data_ptr(), *self.mixing)
+        if self.ret_stats is not None:  # standardise_returns: per-batch-column statistics (dqn/model.py:415-422)
+            self._st_c = self._stats_for(2, B).c()
+            mx.ret_stats = ctypes.cast(ctypes.pointer(self._st_c), ctypes.c_void_p)
+        return mx
 
     def loss_grad(self, batch, mode=2):
         T, B = batch.filled.shape
         ws = self._workspace(T, B)
         bs = BatchStruct(batch.obss.data_ptr(), batch.actions.data_ptr(), batch.rewards.data_ptr(), batch.dones.data_ptr(),
                          batch.filled.data_ptr(), T, B, 0, 0, 0, 0, _mask_ptr(batch.action_mask, (self.spec.n_agents, T + 1, B, self.spec.n_actions)))
-        s, mx = self.spec.c(), self._mx()
+        s, mx = self.spec.c(), self._mx(B)
         check(lib.marlhip_qmix_loss_grad(ctypes.byref(s), _ptr(self.params), _ptr(self.target), ctypes.byref(mx), ctypes.byref(bs),
                                          float(self.gamma), self.double_q, _ptr(ws), ws.numel(), _ptr(self.grad), _ptr(self.loss),
                                          _stream()), "qmix_loss_grad")
@@ -410,7 +428,7 @@ class QmixUpdater(DqnUpdater):
 
     def loss_grad_replay(self, replay, batch_size, length=None, idx=None, seed=0, counter=0, idx_out=None, mode=2):
         ws = self._workspace(replay.T, batch_size)
-        s, mx = self.spec.c(), self._mx()
+        s, mx = self.spec.c(), self._mx(batch_size)
         check(lib.marlhip_qmix_loss_grad_replay(ctypes.byref(s), _ptr(self.params), _ptr(self.target), ctypes.byref(mx),
                                                 ctypes.byref(replay.shape), ctypes.byref(replay.bufs), _ptr(idx), int(batch_size),
                                                 int(length or 0), int(seed) & (2**64 - 1), int(counter) & 0xFFFFFFFF,
@@ -698,6 +716,8 @@ class GruQmixUpdater(QmixUpdater):
         ws = self._gru_ws(T, B)
         bs = BatchStruct(batch.obss.data_ptr(), batch.actions.data_ptr(), batch.rewards.data_ptr(), batch.dones.data_ptr(),
                          batch.filled.data_ptr(), T, B, 0, 0, 0, 0, _mask_ptr(batch.action_mask, (self.spec.n_agents, T + 1, B, self.spec.n_actions)))
+        if self.ret_stats is not None:
+            raise NotImplementedError("standardise_returns with recurrent QMIX agents is not built")
         s, mx = self.spec.c(), self._mx()
         check(lib.marlhip_gru_qmix_loss_grad(ctypes.byref(s), _ptr(self.params), _ptr(self.target), ctypes.byref(mx), ctypes.byref(bs),
                                              float(self.gamma), self.double_q, _ptr(ws), ws.numel(), _ptr(self.grad), _ptr(self.loss),

@@ -490,20 +490,28 @@ int marlhip_idqn_update_n(const marlhip_idqn_learner* L, int32_t n_updates, int3
  * device-resident running statistics, one (mean, var) pair per agent and the shared count (initialise mean 0, var 1,
  * count 1e-4).  Each call de-standardises the bootstrap values with the CURRENT statistics, updates them with all T*B
  * returns of every agent (filled or not, as the reference does), and standardises the returns with the UPDATED ones.
- * Independent learners only (the reference's VDN / QMIX variants keep per-batch-column statistics by accident of shapes). */
+ *
+ * VDNetwork / QMixNetwork (model.py:221-222,256-264 / 357-358,415-422) build `RunningMeanStd(shape=(1,))` and feed it the [T, B]
+ * returns: `update` takes the moments over dim 0 and broadcasts the (1,)-shaped state against the [B] results, so from the first
+ * update on the state is ONE (mean, var) PER BATCH COLUMN, updated with T samples per call (count += T).  Reproduced as is:
+ * columns = B, mean / var [B] (initialise mean 0, var 1, count 1e-4); the batch size is then fixed for the run, as it is there. */
 typedef struct marlhip_ret_stats {
-    float* mean;   /* [P] */
-    float* var;    /* [P] */
-    double* count; /* [1] */
+    float* mean;     /* [P]; per-column statistics: [columns] */
+    float* var;      /* [P]; per-column statistics: [columns] */
+    double* count;   /* [1] */
+    int32_t columns; /* 0: one pair per agent (QNetwork); B: one pair per batch column (VDNetwork, QMixNetwork) */
 } marlhip_ret_stats;
 
+/* mode: 0 = IDQN (QNetwork, stats->columns = 0), 1 = VDN (VDNetwork, stats->columns = batch).  QMIX takes its statistics through
+ * marlhip_qmix_mixer.ret_stats. */
 int marlhip_dqn_loss_grad_std(const marlhip_net_shape* s, const float* params, const float* target_params,
-                              const marlhip_batch* batch, float gamma, int32_t double_q, const marlhip_ret_stats* stats,
-                              void* workspace, int64_t workspace_bytes, float* grad, float* loss, void* stream);
+                              const marlhip_batch* batch, float gamma, int32_t double_q, int32_t mode,
+                              const marlhip_ret_stats* stats, void* workspace, int64_t workspace_bytes, float* grad, float* loss,
+                              void* stream);
 int marlhip_dqn_loss_grad_std_replay(const marlhip_net_shape* s, const float* params, const float* target_params,
                                      const marlhip_replay_shape* rs, const marlhip_replay_buffers* rb, const int32_t* idx,
                                      int32_t batch, int32_t length, uint64_t seed, uint32_t counter, int32_t* idx_out,
-                                     float gamma, int32_t double_q, const marlhip_ret_stats* stats, void* workspace,
+                                     float gamma, int32_t double_q, int32_t mode, const marlhip_ret_stats* stats, void* workspace,
                                      int64_t workspace_bytes, float* grad, float* loss, void* stream);
 
 /* ------------------------------------------------------------------------------------------
@@ -522,6 +530,7 @@ typedef struct marlhip_qmix_mixer {
     const float* target_mixer; /* same layout */
     float* mixer_grad;         /* out: d loss / d mixer */
     int32_t embed_dim, hypernet_layers, hypernet_embed;
+    const struct marlhip_ret_stats* ret_stats; /* cfg.standardise_returns: per-batch-column statistics (columns = batch), or NULL */
 } marlhip_qmix_mixer;
 
 int marlhip_qmix_nparams(const marlhip_net_shape* s, int32_t embed_dim, int32_t hypernet_layers, int32_t hypernet_embed);

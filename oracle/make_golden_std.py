@@ -71,6 +71,58 @@ def a2c(ram, rat):
     print("learner_std_a2c_H64", np.array(metrics).round(5).tolist(), out["mean3"], out["var3"])
 
 
+
+
+def vdn_qmix(rm, rt):
+    """learner_std_vdn_H64.npz / learner_std_qmix_H64.npz: VDNetwork / QMixNetwork with standardise_returns (dqn/model.py:221-222,
+    256-264 / 357-358,415-422).  Their RunningMeanStd(shape=(1,)) is fed [T, B] returns: after the first update the statistics are
+    per BATCH COLUMN (mean, var: [B]; count += T) - stored here exactly as the reference ends up holding them."""
+    from .make_golden_qmix import build as build_qmix
+    from .make_golden_qmix import mixer_flat
+
+    P, T, B, D, A, H = 2, 25, 48, 15, 6, 64
+    for kind in ("vdn", "qmix"):
+        torch.manual_seed(2000 if kind == "vdn" else 2100)
+        if kind == "vdn":
+            cfg = Cfg(optimizer="Adam", lr=3e-4, gamma=0.99, grad_clip=1.0, target_update_interval_or_tau=2, double_q=True,
+                      standardise_returns=True)
+            with contextlib.redirect_stdout(io.StringIO()):
+                net = rm.VDNetwork([Box(D)] * P, [Discrete(A)] * P, cfg, [H, H], False, False, True, "cpu")
+            g = torch.Generator().manual_seed(2001)
+            with torch.no_grad():
+                for p in net.critic.parameters():
+                    p.add_(0.05 * torch.randn(p.shape, generator=g))
+                for p in net.target.parameters():
+                    p.add_(0.08 * torch.randn(p.shape, generator=g))
+        else:
+            net = build_qmix(rm, P, D, A, H, 2100)
+            net.standardise_returns = True
+            from marlbase.utils.standardise_stream import RunningMeanStd
+
+            net.ret_ms = RunningMeanStd(shape=(1,))
+        out = dict(P=P, T=T, B=B, D=D, A=A, H=H, params0=flat_params(net.critic).numpy(), target0=flat_params(net.target).numpy())
+        if kind == "qmix":
+            out["mixer0"], out["tmixer0"] = mixer_flat(net.mixer).numpy(), mixer_flat(net.target_mixer).numpy()
+        losses = []
+        for i in range(3):
+            b = synthetic_batch(P, T, B, D, A, seed=2200 + i)
+            b["rewards"][1:] = b["rewards"][0]  # CooperativeReward
+            if kind == "qmix":
+                b["obss"] = b["obss"] * 0.25
+            losses.append(net.update(rt.Batch(b["obss"], b["actions"], b["rewards"], b["dones"], b["filled"], None))["loss"])
+            out[f"params{i + 1}"] = flat_params(net.critic).numpy()
+            if kind == "qmix":
+                out[f"mixer{i + 1}"] = mixer_flat(net.mixer).numpy()
+            out[f"mean{i + 1}"], out[f"var{i + 1}"] = net.ret_ms.mean.numpy(), net.ret_ms.var.numpy()
+            out[f"count{i + 1}"] = np.float64(net.ret_ms.count)
+            assert out[f"mean{i + 1}"].shape == (B,), out[f"mean{i + 1}"].shape  # per-batch-column statistics
+            for k, v in b.items():
+                out[f"batch{i}_{k}"] = v.numpy()
+        out["losses"] = np.array(losses, np.float32)
+        np.savez_compressed(os.path.join(OUT, f"learner_std_{kind}_H64.npz"), **out)
+        print(f"learner_std_{kind}_H64", losses, out["mean3"][:3], out["var3"][:3], out["count3"])
+
+
 if __name__ == "__main__":
     torch.set_num_threads(1)
     rm, rt = import_reference()
@@ -78,3 +130,4 @@ if __name__ == "__main__":
     from marlbase.ac import train as rat
     idqn(rm, rt)
     a2c(ram, rat)
+    vdn_qmix(rm, rt)

@@ -1,0 +1,119 @@
+#!/usr/bin/env python
+"""Turn gpurun_out/prof2/ (scripts/collect_profiles.sh, run on the MI355X box) into the committed round-2 evidence under profiles/."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "gpurun_out", "prof2")
+DST = os.path.join(ROOT, "profiles")
+
+
+def first(pattern):
+    g = glob.glob(os.path.join(SRC, pattern), recursive=True)
+    return g[0] if g else None
+
+
+def counters(tag):
+    f = first(f"pmc_{tag}/**/*_counter_collection.csv")
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    if f is None:
+        return acc
+    for r in csv.DictReader(open(f)):
+        acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return acc
+
+
+def short(name):
+    n = name.replace("void marl::", "").replace("marl::", "")
+    return n.split("(")[0]
+
+
+def main():
+    head = open(os.path.join(ROOT, "scripts", "_bin", "head.txt")).read().strip() if os.path.exists(os.path.join(ROOT, "scripts", "_bin", "head.txt")) else None
+    for tag, out in (("stats", "r02_bench_ratio_kernel_stats.csv"), ("stats_h128", "r02_bench_ratio_H128_kernel_stats.csv"),
+                     ("stats_hbm", "r02_hbm_ubench_kernel_stats.csv")):
+        f = first(f"{tag}/**/*_kernel_stats.csv")
+        if f:
+            shutil.copy(f, os.path.join(DST, out))
+    if os.path.exists(os.path.join(SRC, "matrix.jsonl")):
+        shutil.copy(os.path.join(SRC, "matrix.jsonl"), os.path.join(DST, "r02_bench_matrix.jsonl"))
+    with open(os.path.join(DST, "r02_mfma_valu_ubench.txt"), "w") as o:
+        for f in ("mfma_ubench.txt", "mfma_ubench2.txt", "mfma_ubench3.txt"):
+            p = os.path.join(SRC, f)
+            if os.path.exists(p):
+                o.write(f"==== scripts/{f.replace('.txt', '.hip')} (MI355X, one wave per SIMD, 256 workgroups x 256 threads) ====\n{open(p).read()}\n")
+    if os.path.exists(os.path.join(SRC, "hbm_ubench.txt")):
+        shutil.copy(os.path.join(SRC, "hbm_ubench.txt"), os.path.join(DST, "r02_hbm_ubench.txt"))
+    # ---- HBM traffic of the learner kernel (two TCC passes; FETCH_SIZE doubled per MI355X_MICROARCH.md "HBM")
+    fe, wr, tcc = counters("FETCH_SIZE"), counters("WRITE_SIZE"), counters("TCC")
+    kernels = {}
+    for k in sorted(set(fe) | set(wr)):
+        if "marl::" not in k:
+            continue
+        f = fe[k].get("FETCH_SIZE", [])
+        w = wr[k].get("WRITE_SIZE", [])
+        ent = {"launches_profiled": max(len(f), len(w))}
+        if f:
+            ent["FETCH_SIZE_KiB_per_launch"] = sum(f) / len(f)
+            ent["hbm_read_bytes_corrected"] = 2.0 * 1024.0 * sum(f) / len(f)
+        if w:
+            ent["WRITE_SIZE_KiB_per_launch"] = sum(w) / len(w)
+            ent["hbm_write_bytes"] = 1024.0 * sum(w) / len(w)
+        if f and w:
+            ent["traffic_bytes"] = ent["hbm_read_bytes_corrected"] + ent["hbm_write_bytes"]
+        if k in tcc:
+            h, m = tcc[k].get("TCC_HIT_sum", []), tcc[k].get("TCC_MISS_sum", [])
+            if h and m:
+                ent["l2_hit_rate"] = sum(h) / max(1.0, sum(h) + sum(m))
+        kernels[short(k)] = ent
+    P, D, T, B = 2, 15, 25, 4096
+    alg_read = B * (4 * P * D * (T + 1) + P * T * 5 + (T + 1) + T)
+    lg = next((v for k, v in kernels.items() if k.startswith("dqn_lossgrad_kernel")), None)
+    out = {"source": "rocprofv3 --kernel-trace --pmc <FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum> -- python bench.py --steps 4 --warmup 1 "
+                     "--no-cpu-baseline --no-kernel-timing (one counter set per run, scripts/collect_profiles.sh), MI355X, round 2",
+           "head": head,
+           "units": "FETCH_SIZE / WRITE_SIZE are reported in KiB; read bytes = 2 x FETCH_SIZE (MI355X_MICROARCH.md, HBM: gfx950 tallies 128-B "
+                    "read requests at 64 B), write bytes = WRITE_SIZE (the reduce kernel's known 5.7 MB record read calibrates the read side)",
+           "kernels": kernels, "workloads": {}}
+    if lg and "traffic_bytes" in lg:
+        out["workloads"]["idqn:lbforaging:Foraging-8x8-2p-3f-v3:N4096:H64:B4096:T25:rnn0"] = {
+            "kernel": "dqn_lossgrad_kernel<MlpShape<15, 64, 6>, 4, true, 0>", "traffic_bytes": lg["traffic_bytes"],
+            "algorithmic_bytes": {"replay_read": alg_read, "partial_records_write": 256 * (5574 + 2) * 4}}
+    json.dump(out, open(os.path.join(DST, "r02_pmc_traffic.json"), "w"), indent=1)
+    # ---- SQ counters
+    sq, inst = counters("SQ"), counters("INST")
+    rows = []
+    for k, v in sq.items():
+        if "marl::" not in k or "SQ_WAVE_CYCLES" not in v:
+            continue
+        w = sum(v["SQ_WAVE_CYCLES"])
+        g = lambda n: sum(v.get(n, [0.0])) / w  # noqa: E731
+        lds = sum(v.get("SQ_LDS_IDX_ACTIVE", [0.0]))
+        row = [short(k)[:70], len(v["SQ_WAVE_CYCLES"]), f"{w / len(v['SQ_WAVE_CYCLES']):.3g}", f"{g('SQ_WAIT_ANY'):.2f}", f"{g('SQ_WAIT_INST_ANY'):.2f}",
+               f"{g('SQ_ACTIVE_INST_ANY'):.2f}", f"{g('SQ_WAIT_INST_LDS'):.3f}", f"{sum(v.get('SQ_VALU_MFMA_BUSY_CYCLES', [0.0])) / (4 * w):.3f}",
+               f"{sum(v.get('SQ_LDS_BANK_CONFLICT', [0.0])) / lds:.2f}" if lds else "-"]
+        if k in inst:
+            iv = inst[k]
+            n = max(1, len(iv.get("SQ_INSTS_MFMA", [1])))
+            row.append(" / ".join(f"{sum(iv.get(c, [0.0])) / n:.3g}" for c in ("SQ_INSTS_VALU", "SQ_INSTS_MFMA", "SQ_INSTS_LDS", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD")))
+        else:
+            row.append("-")
+        rows.append(row)
+    with open(os.path.join(DST, "r02_sq_pmc_summary.md"), "w") as o:
+        o.write("# SQ counters of the round-2 kernels (rocprofv3 --pmc, MI355X; scripts/collect_profiles.sh)\n\n"
+                f"git head of the profiled tree: `{head}`.  Fractions are of SQ_WAVE_CYCLES (quad-cycles); `mfma_busy` = SQ_VALU_MFMA_BUSY_CYCLES / (4 x "
+                "SQ_WAVE_CYCLES).  Instruction counts are per launch (all waves): VALU / MFMA / LDS / SALU / VMEM_RD.\n\n"
+                "| kernel | launches | wave quad-cycles / launch | WAIT_ANY | WAIT_INST_ANY | ACTIVE_INST_ANY | WAIT_INST_LDS | mfma_busy | LDS bank-conflict / LDS active | instructions per launch |\n"
+                "|---|---|---|---|---|---|---|---|---|---|\n")
+        for r in sorted(rows, key=lambda r: -float(r[2])):
+            o.write("| " + " | ".join(str(x) for x in r) + " |\n")
+    print("profiles written:", sorted(f for f in os.listdir(DST) if f.startswith("r02_")))
+
+
+if __name__ == "__main__":
+    main()

@@ -126,6 +126,83 @@ def test_standardise_returns_through_the_drivers(tmp_path, monkeypatch):
         df = run.main([f"+algorithm={algo}", f"env.name={name}", "env.time_limit=25", "env.parallel_envs=128", "seed=1",
                        "algorithm.standardise_returns=True"] + extra)
         assert df.shape[0] >= 2 and np.isfinite(df["loss"]).all()
+    # VDN / QMIX: per-batch-column statistics as the reference's shapes produce them (feed-forward networks; the recurrent TD kernel raises)
+    for algo in ("vdn", "qmix"):
+        monkeypatch.setenv("MARLHIP_RUN_DIR", str(tmp_path / algo))
+        df = run.main([f"+algorithm={algo}", f"env.name={name}", "env.time_limit=25", "env.parallel_envs=128", "seed=1", "algorithm.model.layers=[64,64]",
+                       "algorithm.standardise_returns=True", "algorithm.updates_per_round=8", "algorithm.total_steps=150000",
+                       "algorithm.eval_interval=50000", "algorithm.eval_episodes=128"])
+        assert df.shape[0] >= 2 and np.isfinite(df["loss"]).all()
     with pytest.raises(NotImplementedError):
         run.main(["+algorithm=vdn", f"env.name={name}", "env.time_limit=25", "env.parallel_envs=128", "algorithm.model.layers=[64,64]",
-                  "algorithm.standardise_returns=True", "algorithm.total_steps=1000"])
+                  "algorithm.model.use_rnn=True", "algorithm.standardise_returns=True", "algorithm.total_steps=1000"])
+
+
+@pytest.mark.parametrize("kind", ["vdn", "qmix"])
+def test_vdn_qmix_standardised_returns_match_reference_golden(kind):
+    """VDNetwork / QMixNetwork with standardise_returns (dqn/model.py:256-264, 415-422): 3 updates of the reference's own classes -
+    losses, parameters (and mixer) and the per-BATCH-COLUMN running statistics the reference's RunningMeanStd(shape=(1,)) turns into."""
+    h = hip()
+    g = load(f"learner_std_{kind}_H64.npz")
+    P, D, A, T, B = int(g["P"]), int(g["D"]), int(g["A"]), int(g["T"]), int(g["B"])
+    spec = h.NetSpec(P, D, 64, A)
+    t = lambda k: torch.tensor(g[k], device=DEV)  # noqa: E731
+    if kind == "vdn":
+        up = h.DqnUpdater(spec, t("params0"), t("target0"), lr=3e-4, gamma=0.99, grad_clip=1.0, double_q=True, standardise_returns=True)
+        mode = 1
+    else:
+        up = h.QmixUpdater(spec, t("params0"), t("target0"), t("mixer0"), t("tmixer0"), lr=3e-4, gamma=0.99, grad_clip=1.0, double_q=True,
+                           standardise_returns=True)
+        mode = 2
+    last = 0
+    for i in range(3):
+        b = golden_batch(g, i)
+        if i == 1:  # the in-kernel replay gather entry point on the second update
+            rb = h.DeviceReplay(B, P, D, T)
+            rb.obs.copy_(b["obss"].permute(2, 0, 1, 3))
+            rb.act.copy_(b["actions"].permute(2, 0, 1).to(torch.uint8))
+            rb.rew.copy_(b["rewards"].permute(2, 0, 1))
+            rb.done.copy_(b["dones"].t().to(torch.uint8))
+            rb.filled.copy_(b["filled"].t().to(torch.uint8))
+            loss, _ = up.loss_grad_replay(rb, B, idx=torch.arange(B, dtype=torch.int32, device=DEV), mode=mode)
+        else:
+            loss, _ = up.loss_grad(dev_batch(h, b), mode=mode)
+        hard = (i + 1 - last) >= 2
+        up.apply(hard_update=hard)
+        if hard:
+            last = i + 1
+        assert abs(loss.cpu().numpy()[0] - g["losses"][i]) <= 3e-5 * abs(g["losses"][i]), (i, loss.cpu().numpy(), g["losses"][i])
+        np.testing.assert_allclose(up.params.cpu().numpy(), g[f"params{i + 1}"], rtol=0, atol=3e-6)
+        if kind == "qmix":
+            np.testing.assert_allclose(up.mixer.cpu().numpy(), g[f"mixer{i + 1}"], rtol=0, atol=3e-6)
+        st = up.ret_stats
+        assert st.columns == B and st.mean.shape == (B,)
+        np.testing.assert_allclose(st.mean.cpu().numpy(), g[f"mean{i + 1}"], rtol=5e-6, atol=1e-6)
+        np.testing.assert_allclose(st.var.cpu().numpy(), g[f"var{i + 1}"], rtol=2e-5)
+        assert abs(st.count - float(g[f"count{i + 1}"])) < 1e-6
+    # the statistics pin the batch size, as the reference's broadcasting does
+    b = golden_batch(g, 0)
+    small = {k: (v[..., : B // 2, :] if k == "obss" else v[..., : B // 2]).contiguous() for k, v in b.items()}
+    with pytest.raises(h.MarlHipError):
+        up.loss_grad(dev_batch(h, small), mode=mode)
+
+
+def test_vdn_standardised_returns_hidden128_vs_hidden64_statistics():
+    """the register-resident (hidden 128) learner path feeds the same column statistics kernel: with equal bootstrap values the
+    statistics cannot depend on the path, so run both widths on one batch with ZERO networks (Q = 0 everywhere): returns = rewards."""
+    h = hip()
+    P, D, A, T, B = 2, 15, 6, 25, 32
+    b = dp.synthetic_batch(P, T, B, D, A, seed=9)
+    b["rewards"][1:] = b["rewards"][0]
+    stats = []
+    for H in (64, 128):
+        n = h.NetSpec(P, D, H, A).nparams()
+        up = h.DqnUpdater(h.NetSpec(P, D, H, A), torch.zeros(P, n, device=DEV), torch.zeros(P, n, device=DEV), standardise_returns=True)
+        up.loss_grad(dev_batch(h, b), mode=1)
+        stats.append((up.ret_stats.mean.cpu().numpy(), up.ret_stats.var.cpu().numpy(), up.ret_stats.count))
+    r = b["rewards"][0].double().numpy()  # [T, B]
+    cnt = 1e-4
+    mean = r.mean(0) * T / (cnt + T)
+    np.testing.assert_allclose(stats[0][0], mean, rtol=1e-5, atol=1e-6)
+    for a, c in zip(stats[0], stats[1]):
+        np.testing.assert_array_equal(a, c)
