@@ -390,6 +390,10 @@ def main():
     obs_space, act_space = _space_pair(cfg)
     hyper = dict(optimizer="Adam", lr=3e-4, gamma=0.99, grad_clip=1.0, double_q=True, standardise_returns=False,
                  target_update_interval_or_tau=200)  # marlbase/configs/algorithm/idqn.yaml:16-37
+    if args.cadence == "ratio" and args.algo == "idqn":
+        # batched gradient steps want a larger step and a faster target (profiles/r02_learning_parity.md: with the reference's lr /
+        # target interval the batched cadence barely learns); U = 32: lr 3e-3 + Polyak 0.1; U >= 128: lr 1e-3 + hard copy every 50 updates
+        hyper.update(dict(lr=3e-3, target_update_interval_or_tau=0.1) if U < 128 else dict(lr=1e-3, target_update_interval_or_tau=50))
     from codebase_amd.dqn.model import QMixNetwork, VDNetwork
 
     if args.algo == "qmix":  # marlbase/configs/algorithm/qmix.yaml:14-17
@@ -498,6 +502,7 @@ def main():
             "update_batch_episodes": B,
             "sampled_episodes_per_collected_episode": (U * B) / N if N else 0,
             "replay_capacity_episodes": cap,
+            "lr": hyper["lr"], "target_update_interval_or_tau": hyper["target_update_interval_or_tau"],
             "parallelism": f"dp{world} (envs + replay sharded per GPU, RCCL grad all-reduce per update)" if world > 1 else "1 GPU",
             "env_steps_timed": env_steps,
         },

@@ -310,7 +310,7 @@ __global__ __launch_bounds__(64 * W, 1) void tp_fwd_kernel(const float* __restri
                         tq += Tp[(nb * W + w2) * 64 + lane];
                     }
                     if (t < t1) {
-                        const float ch = gather_rows(q, lane, cur[nb].a_sel);
+                        const float ch = gather_rows_pl<A>(q, lane, cur[nb].a_sel);
                         if (g == 0 && rowok) {
                             mix.chosen[((size_t)p * T + t) * B + bj] = ch;
                             mix.rew[((size_t)p * T + t) * B + bj] = cur[nb].rw;
@@ -327,8 +327,8 @@ __global__ __launch_bounds__(64 * W, 1) void tp_fwd_kernel(const float* __restri
                                 if (cur[nb].mk[r] == 0.f) { q[r] = -1e8f; tq[r] = -1e8f; }
                             }
                         }
-                        const int a_p = double_q ? argmax_rows<A>(q, lane) : argmax_rows<A>(tq, lane);
-                        const float tv = gather_rows(tq, lane, a_p);
+                        const int a_p = double_q ? argmax_rows_pl<A>(q, lane) : argmax_rows_pl<A>(tq, lane);
+                        const float tv = gather_rows_pl<A>(tq, lane, a_p);
                         if (g == 0 && rowok) mix.tqsel[((size_t)p * T + (t - 1)) * B + bj] = tv;
                     }
                 }
