@@ -11,8 +11,8 @@ Interface kept: constructor `(obs_space, action_space, cfg, actor, critic, devic
 Storage: ONE flat fp32 block [actor agents | critic agents] (so that clip_grad_norm_(self.parameters()) + Adam is a
 single fused launch) plus the target-critic block; state_dict tensors are slices.
 Built: independent or shared (parameter_sharing True / SePS index list, the same for actor and critic) actors and
-critics (IA2C / IPPO) and centralised critics (MAA2C / MAPPO: hidden 128 up to 4 agents, hidden 64 for 2), two equal
-hidden layers of 64 or 128, recurrent actors / critics (`use_rnn`), `action_mask`.
+critics (IA2C / IPPO) and centralised critics (MAA2C / MAPPO: width 128 up to 4 agents, 64 for 2), two hidden layers of any widths <= 128
+(zero-padded to the compiled 64 / 128, exact), recurrent actors / critics (`use_rnn`, widths 64 / 128), `action_mask`.
 """
 from collections import OrderedDict
 
@@ -20,7 +20,7 @@ import numpy as np
 import torch
 
 from .. import hip as _hip
-from ..dqn.model import _fc, _gru_layout, _tensor_layout, init_flat_gru_params, sharing_indices
+from ..dqn.model import _fc, _gru_layout, block_views, compiled_width, init_flat_gru_params, pad_blocks, sharing_indices
 from ..spaces import flatdim
 
 
@@ -47,9 +47,13 @@ class A2CNetwork:
         if bool(_get(critic, "use_rnn", False)) != self.recurrent:
             raise NotImplementedError("actor.use_rnn != critic.use_rnn: the recurrent step is built for recurrent actors AND critics")
         ha, hc = [int(h) for h in _get(actor, "layers")], [int(h) for h in _get(critic, "layers")]
-        if ha != hc or len(ha) != 2 or ha[0] != ha[1]:
-            raise NotImplementedError(f"layers actor={ha} critic={hc}: the HIP kernels implement two equal hidden layers (64 or 128), "
-                                      "the same for actor and critic")
+        if self.recurrent and (ha != hc or ha not in ([64, 64], [128, 128])):
+            raise NotImplementedError(f"use_rnn with layers actor={ha} critic={hc}: the recurrent kernels are built for [64, 64] / [128, 128]")
+        # any two-layer widths up to 128, actor and critic independently: zero-padded to one compiled width (dqn/model.py pad_blocks)
+        Hk = max(compiled_width(ha), compiled_width(hc))
+        if bool(_get(critic, "centralised", False)) and not self.recurrent and P > 2:
+            Hk = 128  # the feed-forward centralised critics for 3 / 4 agents are compiled at width 128 only (a2c.hip MARL_MAC_SHAPES)
+        self.live_hidden = {"actor": tuple(ha), "critic": tuple(hc), "target_critic": tuple(hc)}
         if len(set(obs_dims)) != 1 or len(set(act_dims)) != 1:
             raise NotImplementedError("agents with different observation / action sizes")
         if str(device) == "cpu":
@@ -64,7 +68,7 @@ class A2CNetwork:
         self.target_update_interval_or_tau = _get(cfg, "target_update_interval_or_tau", 200)
         self.standardise_returns = bool(_get(cfg, "standardise_returns", False))
         self.centralised_critic = bool(_get(critic, "centralised", False))  # MAA2C / MAPPO (model.py:62-66)
-        self.spec = _hip.NetSpec(P, obs_dims[0], ha[0], act_dims[0], self.sharing)
+        self.spec = _hip.NetSpec(P, obs_dims[0], Hk, act_dims[0], self.sharing)
         if self.sharing is not None:  # one network per distinct index, in order of first appearance (utils/models.py:209-240)
             first = [self.sharing.index(k) for k in range(max(self.sharing) + 1)]
             obs_dims, act_dims = [obs_dims[i] for i in first], [act_dims[i] for i in first]
@@ -78,6 +82,8 @@ class A2CNetwork:
             a0 = _init_blocks(obs_dims, ha, act_dims, _get(actor, "use_orthogonal_init", True))
             c0 = _init_blocks(cdims, hc, [1] * K, _get(critic, "use_orthogonal_init", True))
             _init_blocks(cdims, hc, [1] * K, _get(critic, "use_orthogonal_init", True))  # target: drawn, then overwritten (soft_update(1.0))
+            a0 = pad_blocks(a0, obs_dims[0], ha[0], ha[1], act_dims[0], Hk)
+            c0 = pad_blocks(c0, cdims[0], hc[0], hc[1], 1, Hk)
         self.block = torch.cat([a0.reshape(-1), c0.reshape(-1)]).to(self.device).contiguous()
         self.target_critic_params = c0.clone().to(self.device).contiguous()
         self.updater = _hip.AcUpdater(self.spec, self.block, self.target_critic_params, lr=float(_get(cfg, "lr", 3e-4)),
@@ -204,7 +210,12 @@ class A2CNetwork:
             for i in range(P):
                 o = 0
                 cin = S.n_agents * S.obs_dim if (self.centralised_critic and prefix != "actor") else S.obs_dim
-                for name, shape in (_gru_layout if self.recurrent else _tensor_layout)(cin, S.hidden, A):
+                if not self.recurrent:  # the live tensors inside the (possibly zero-padded) blocks
+                    h1, h2 = self.live_hidden[prefix]
+                    for name, view in block_views(block[i], cin, h1, h2, A, S.hidden):
+                        out[f"{prefix}.{group}.{i}.{name}"] = view
+                    continue
+                for name, shape in _gru_layout(cin, S.hidden, A):
                     n = int(np.prod(shape))
                     out[f"{prefix}.{group}.{i}.{name}"] = block[i, o:o + n].view(shape)
                     o += n
@@ -225,8 +236,9 @@ class A2CNetwork:
 
     def __repr__(self):
         S = self.spec
-        return (f"{type(self).__name__}[HIP](agents={S.n_agents}, actor={S.obs_dim}-{S.hidden}-{S.hidden}-{S.n_actions}, "
-                f"critic={S.obs_dim}-{S.hidden}-{S.hidden}-1)")
+        (a1, a2), (c1, c2) = self.live_hidden["actor"], self.live_hidden["critic"]
+        return (f"{type(self).__name__}[HIP](agents={S.n_agents}, actor={S.obs_dim}-{a1}-{a2}-{S.n_actions}, "
+                f"critic={S.obs_dim}-{c1}-{c2}-1, kernels at width {S.hidden})")
 
 
 class PPONetwork(A2CNetwork):

@@ -14,7 +14,8 @@
 // (mt, r) with k-index 16*mt+4g+r: layers chain with NO cross-lane movement; only
 // the weight packing knows about the permuted k order.  Per output the f32 sum is
 //   acc = bias; for mt: for r: for g=0..3: acc = fmaf(W[o][16mt+4g+r], x[16mt+4g+r], acc)
-// (layer 1: for ks: for g: k = 4ks+g) - oracle/mlp_exact.c restates this order.
+// (layer 1: for ks: for g: k = 4ks+g) - oracle/mfma_emul.py is the lane-level statement of this order (the learner kernels of
+// dqn_update_kernels.h split the output layer into two chains and shortcut one-hot products: same math, different rounding order).
 //
 // Canonical parameters of one agent = torch parameters() order of FCNetwork:
 //   W1[H][D] b1[H] W2[H][H] b2[H] W3[A][H] b3[A]      (row-major, nn.Linear layout)
@@ -158,17 +159,10 @@ __device__ __forceinline__ void copy_f4_to_lds(const f4* __restrict__ src, f4* d
     for (; i < n4; i += nthreads) dst[i] = src[i];
 }
 
-// relu on four accumulator values: ONE v_max_f32 each, spelled in asm - fmaxf lowers to a canonicalising v_max(v, v) in front of the
-// max (two VALU instructions), and next to f32 MFMAs every VALU instruction costs matrix time.  Same value as
-// fmaxf(v, 0) for every non-NaN input.
-__device__ __forceinline__ f4 relu4(f4 v) {
-    f4 o;
-    asm("v_max_f32 %0, 0, %1" : "=v"(o.x) : "v"(v.x));
-    asm("v_max_f32 %0, 0, %1" : "=v"(o.y) : "v"(v.y));
-    asm("v_max_f32 %0, 0, %1" : "=v"(o.z) : "v"(v.z));
-    asm("v_max_f32 %0, 0, %1" : "=v"(o.w) : "v"(v.w));
-    return o;
-}
+// relu on four accumulator values.  (fmaxf lowers to a canonicalising v_max(v, v) in front of the max; the one-instruction asm
+// spelling is relu4_settled below - inline asm is invisible to the compiler's MFMA -> VALU hazard pass, so it may only read accumulators
+// that an explicit mfma_settle() has already waited for.  Used anywhere else it reads stale registers: r02 ac_collector regression.)
+__device__ __forceinline__ f4 relu4(f4 v) { return f4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)}; }
 
 // forward of one 16-row block.  x[ks] = X[row j][4ks+g] (zero beyond D).
 // h1/h2 (post-ReLU) and q come back in C layout: [16mt+4g+r][row j].
@@ -504,22 +498,15 @@ __device__ __forceinline__ float gather_rows_pl(const f4& q, int lane, int a_sel
 #endif
 
 // relu for the learner kernels: ONE VALU instruction per element (equal to fmaxf(v, 0) for every non-NaN input)
-#ifndef MARL_RELU_MED3
-#define MARL_RELU_MED3 1
-#endif
-__device__ __forceinline__ f4 relu4l(f4 v) {
-#if MARL_RELU_MED3
-    // one v_max_f32 per element, spelled in asm: fmaxf / fmed3 lower to a canonicalising v_max(v, v) in front of the max (two VALU
-    // instructions, and every VALU instruction next to f32 MFMAs costs matrix time - see MARL_BURST below)
+// one v_max_f32 per element, spelled in asm (every VALU instruction next to f32 MFMAs costs matrix time - see MARL_BURST below).
+// ONLY for accumulators already waited for by mfma_settle(): the compiler inserts no MFMA -> VALU wait states in front of inline asm.
+__device__ __forceinline__ f4 relu4_settled(f4 v) {
     f4 o;
     asm("v_max_f32 %0, 0, %1" : "=v"(o.x) : "v"(v.x));
     asm("v_max_f32 %0, 0, %1" : "=v"(o.y) : "v"(v.y));
     asm("v_max_f32 %0, 0, %1" : "=v"(o.z) : "v"(v.z));
     asm("v_max_f32 %0, 0, %1" : "=v"(o.w) : "v"(v.w));
     return o;
-#else
-    return relu4(v);
-#endif
 }
 
 // the operands of the first MFMA group (first layer-1 k-step of every hidden tile + the layer-1 bias in accumulator layout): the
@@ -692,7 +679,7 @@ __device__ __forceinline__ void mlp_forward_f(const float* lds, const FwdHead<S>
     if constexpr (VG) mfma_settle(acc);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        h1[mt] = relu4l(acc[mt]);
+        h1[mt] = VG ? relu4_settled(acc[mt]) : relu4(acc[mt]);
         acc[mt] = nb[mt];
     }
     // ---- layer 2
@@ -732,7 +719,7 @@ __device__ __forceinline__ void mlp_forward_f(const float* lds, const FwdHead<S>
     }
     if constexpr (VG) mfma_settle(acc);
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) h2[mt] = relu4l(acc[mt]);
+    for (int mt = 0; mt < MT; ++mt) h2[mt] = VG ? relu4_settled(acc[mt]) : relu4(acc[mt]);
     // ---- layer 3
     constexpr int c3 = (N1 + MT) & 1;
     fill(N1 + MT, -1);

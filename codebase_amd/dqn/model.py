@@ -108,6 +108,50 @@ def _tensor_layout(D, H, A):
             ("network.2.bias", (H,)), ("network.4.weight", (A, H)), ("network.4.bias", (A,))]
 
 
+# ---- hidden widths other than the compiled ones -------------------------------------------------------------------------------
+# The kernels are instantiated for two equal hidden layers of 64 or 128 units.  A two-layer list [h1, h2] with h1, h2 <= 128 runs
+# EXACTLY on the next compiled width H by zero padding: a padded unit has zero weights and bias, so its activation is relu(0) = 0,
+# its relu mask is 0, every gradient that touches a padded entry is a product with one of those zeros, and Adam maps a zero gradient
+# with zero moments to a zero step - the padding stays zero for the whole run, the live sub-network computes what FCNetwork([h1, h2])
+# computes (utils/models.py:34-48), and state_dict exposes the live tensors in the reference's shapes.
+def compiled_width(hidden):
+    """(h1, h2) -> the compiled kernel width they run on, or raise"""
+    if len(hidden) != 2:
+        raise NotImplementedError(f"layers={list(hidden)}: the HIP kernels implement two hidden layers (widths up to 128)")
+    h = max(hidden)
+    if min(hidden) < 1 or h > 128:
+        raise NotImplementedError(f"layers={list(hidden)}: hidden widths 1..128 (padded to the compiled 64 / 128)")
+    return 64 if h <= 64 else 128
+
+
+def pad_blocks(flat, D, h1, h2, A, H):
+    """[K][n(h1, h2)] parameter blocks in FCNetwork's parameters() order -> [K][n(H, H)] zero-padded blocks"""
+    if h1 == H and h2 == H:
+        return flat
+    K = flat.shape[0]
+    out = torch.zeros(K, H * D + H + H * H + H + A * H + A, dtype=flat.dtype)
+    for k in range(K):
+        for (_, dst), (_, src) in zip(block_views(out[k], D, h1, h2, A, H), block_views(flat[k], D, h1, h2, A, None)):
+            dst.copy_(src)
+    return out
+
+
+def block_views(row, D, h1, h2, A, H):
+    """(name, view) of the LIVE tensors inside one flat block laid out for width H (H None: the unpadded layout)"""
+    Hk = H if H is not None else None
+    a, b = (Hk, Hk) if Hk is not None else (h1, h2)
+    o, out = 0, []
+    for name, full, live in (("network.0.weight", (a, D), (slice(0, h1), slice(None))), ("network.0.bias", (a,), (slice(0, h1),)),
+                             ("network.2.weight", (b, a), (slice(0, h2), slice(0, h1))), ("network.2.bias", (b,), (slice(0, h2),)),
+                             ("network.4.weight", (A, b), (slice(None), slice(0, h2))), ("network.4.bias", (A,), (slice(None),))):
+        n = 1
+        for d in full:
+            n *= d
+        out.append((name, row[o:o + n].view(full)[live]))
+        o += n
+    return out
+
+
 class QNetwork:
     def __init__(self, obs_space, action_space, cfg, layers, parameter_sharing=False, use_rnn=False,
                  use_orthogonal_init=True, device="cuda"):
@@ -117,8 +161,9 @@ class QNetwork:
         self.recurrent = bool(use_rnn)
         if use_rnn and hidden not in ([64, 64], [128, 128]):
             raise NotImplementedError(f"use_rnn with layers={hidden}: the recurrent kernels are built for layers [64, 64] / [128, 128]")
-        if len(hidden) != 2 or hidden[0] != hidden[1]:
-            raise NotImplementedError(f"layers={hidden}: the HIP kernels implement two equal hidden layers (64 or 128)")
+        self.live_hidden = tuple(hidden)
+        Hk = compiled_width(hidden)  # the width the kernels run at ([h1, h2] zero-padded to it, see pad_blocks)
+        hidden_k = [Hk, Hk]
         if len(set(obs_dims)) != 1 or len(set(act_dims)) != 1:
             raise NotImplementedError("agents with different observation / action sizes")
         if str(device) == "cpu":
@@ -136,13 +181,15 @@ class QNetwork:
         self.n_agents = len(obs_dims)
         self.device = torch.device(device)
         self.sharing = sharing_indices(parameter_sharing, self.n_agents)
-        self.spec = _hip.NetSpec(self.n_agents, obs_dims[0], hidden[0], act_dims[0], self.sharing)
+        self.spec = _hip.NetSpec(self.n_agents, obs_dims[0], hidden_k[0], act_dims[0], self.sharing)
         if self.recurrent:  # RNNNetwork (utils/models.py:51-116): Linear -> ReLU -> GRU -> Linear
             self.nparams = _hip.gru_nparams(self.spec)
             critic, target = init_flat_gru_params(obs_dims, hidden[0], act_dims, use_orthogonal_init, self.sharing)
         else:
             self.nparams = self.spec.nparams()
-            critic, target = init_flat_params(obs_dims, hidden, act_dims, use_orthogonal_init, self.sharing)
+            critic, target = init_flat_params(obs_dims, hidden, act_dims, use_orthogonal_init, self.sharing)  # the reference's RNG draws
+            critic = pad_blocks(critic, obs_dims[0], hidden[0], hidden[1], act_dims[0], Hk)
+            target = critic.clone()
         assert critic.shape == (self.spec.n_blocks, self.nparams)
         self.params = critic.to(self.device).contiguous()
         self.target_params = target.to(self.device).contiguous()
@@ -268,7 +315,12 @@ class QNetwork:
         out = OrderedDict()
         S = self.spec
         group = "independent" if self.sharing is None else "networks"  # utils/models.py:146 / :204
-        layout = (_gru_layout if self.recurrent else _tensor_layout)(S.obs_dim, S.hidden, S.n_actions)
+        if not self.recurrent:  # the live [h1, h2] tensors inside the (possibly zero-padded) blocks
+            for i in range(S.n_blocks):
+                for name, view in block_views(block[i], S.obs_dim, self.live_hidden[0], self.live_hidden[1], S.n_actions, S.hidden):
+                    out[f"{prefix}.{group}.{i}.{name}"] = view
+            return out
+        layout = _gru_layout(S.obs_dim, S.hidden, S.n_actions)
         for i in range(S.n_blocks):
             o = 0
             for name, shape in layout:
@@ -297,7 +349,8 @@ class QNetwork:
     def __repr__(self):
         S = self.spec
         share = "" if self.sharing is None else f", sharing={list(self.sharing)}"
-        return (f"QNetwork[HIP](agents={S.n_agents}, mlp={S.obs_dim}-{S.hidden}-{S.hidden}-{S.n_actions}, "
+        pad = "" if self.live_hidden == (S.hidden, S.hidden) else f" zero-padded to {S.hidden}-{S.hidden}"
+        return (f"QNetwork[HIP](agents={S.n_agents}, mlp={S.obs_dim}-{self.live_hidden[0]}-{self.live_hidden[1]}-{S.n_actions}{pad}, "
                 f"params={self.nparams}/network{share})")
 
 

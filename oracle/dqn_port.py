@@ -22,15 +22,22 @@ import numpy as np
 import torch
 
 
+def _widths(H):
+    """H: one width (two equal hidden layers) or (h1, h2) - FCNetwork takes any list (utils/models.py:34-42)"""
+    return (H, H) if isinstance(H, int) else (int(H[0]), int(H[1]))
+
+
 def nparams(D, H, A):
-    return H * D + H + H * H + H + A * H + A
+    h1, h2 = _widths(H)
+    return h1 * D + h1 + h2 * h1 + h2 + A * h2 + A
 
 
 def split(block, D, H, A):
     """flat [nparams] -> (W1[H,D], b1[H], W2[H,H], b2[H], W3[A,H], b3[A]) views"""
     o = 0
     out = []
-    for shape in ((H, D), (H,), (H, H), (H,), (A, H), (A,)):
+    h1, h2 = _widths(H)
+    for shape in ((h1, D), (h1,), (h2, h1), (h2,), (A, h2), (A,)):
         n = int(np.prod(shape))
         out.append(block[o:o + n].reshape(shape))
         o += n
@@ -43,7 +50,8 @@ def init_params(P, D, H, A, seed=0, orthogonal=True):
     blocks = []
     for _ in range(P):
         parts = []
-        for (o, i) in ((H, D), (H, H), (A, H)):
+        h1, h2 = _widths(H)
+        for (o, i) in ((h1, D), (h2, h1), (A, h2)):
             w = torch.empty(o, i)
             if orthogonal:
                 torch.nn.init.orthogonal_(w, gain=math.sqrt(2), generator=g)

@@ -65,3 +65,42 @@ def test_fused_epilogue_matches_generic_loop(mode, D, sharing, tui):
     if tui == 3:
         assert a["last"] == 6  # hard copies after updates 3 and 6: the target packs were rewritten by adam_pack_kernel
         assert not torch.equal(a["target"], a["params"])
+
+
+def test_replay_gather_above_2gb_takes_the_64bit_path_and_matches_the_buffer_path():
+    """The learner gathers its rows through buffer descriptors (32-bit offsets) while every replay array is below 2 GB and through
+    64-bit global loads above: the same 512 episodes placed in a 2.2 GB replay (704,512 episodes x 3,120 B of observations) and in
+    a small one must give bitwise the same loss and gradient."""
+    from codebase_amd import hip as h
+    from oracle import dqn_port as dp
+
+    P, D, H, A, T, B = 2, 15, 64, 6, 25, 512
+    big_cap, small_cap = 704512, 1024
+    assert big_cap * P * (T + 1) * D * 4 >= 2**31
+    g = torch.Generator().manual_seed(5)
+    ep_obs = torch.randint(-1, 8, (B, P, T + 1, D), generator=g).float()
+    ep_act = torch.randint(0, A, (B, P, T), generator=g).to(torch.uint8)
+    ep_rew = torch.rand((B, P, T), generator=g)
+    ln = torch.randint(3, T + 1, (B,), generator=g)
+    t = torch.arange(T + 1)[None, :]
+    ep_done = (t == ln[:, None]).to(torch.uint8)
+    ep_fill = (t[:, :T] < ln[:, None]).to(torch.uint8)
+    spec = h.NetSpec(P, D, H, A)
+    params, target = dp.init_params(P, D, H, A, seed=1).to(DEV), dp.init_params(P, D, H, A, seed=2).to(DEV)
+    out = []
+    for cap in (small_cap, big_cap):
+        rb = h.DeviceReplay(cap, P, D, T)
+        slots = (torch.arange(B) * (cap // B) + 3) % cap  # spread over the whole buffer (the last ones sit above the 2 GB mark)
+        sl = slots.to(DEV)
+        rb.obs[sl] = ep_obs.to(DEV)
+        rb.act[sl] = ep_act.to(DEV)
+        rb.rew[sl] = ep_rew.to(DEV)
+        rb.done[sl] = ep_done.to(DEV)
+        rb.filled[sl] = ep_fill.to(DEV)
+        up = h.DqnUpdater(spec, params, target)
+        loss, grad = up.loss_grad_replay(rb, B, idx=slots.to(torch.int32).to(DEV))
+        out.append((loss.clone().cpu(), grad.clone().cpu()))
+        del rb
+        torch.cuda.empty_cache()
+    assert torch.isfinite(out[0][0]).all() and out[0][0][1] == float(ep_fill.sum())
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
