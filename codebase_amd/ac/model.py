@@ -11,7 +11,7 @@ Interface kept: constructor `(obs_space, action_space, cfg, actor, critic, devic
 Storage: ONE flat fp32 block [actor agents | critic agents] (so that clip_grad_norm_(self.parameters()) + Adam is a
 single fused launch) plus the target-critic block; state_dict tensors are slices.
 Built: independent or shared (parameter_sharing True / SePS index list, the same for actor and critic) actors and
-critics (IA2C / IPPO) and centralised critics (MAA2C / MAPPO: width 128 up to 4 agents, 64 for 2), two hidden layers of any widths <= 128
+critics (IA2C / IPPO) and centralised critics (MAA2C / MAPPO: fused kernels up to 4 LBF agents, GEMM path beyond), two hidden layers of any widths <= 128
 (zero-padded to the compiled 64 / 128, exact), recurrent actors / critics (`use_rnn`, widths 64 / 128), `action_mask`.
 """
 from collections import OrderedDict
@@ -35,6 +35,9 @@ def _init_blocks(obs_dims, hidden, out_dims, orth):
                         for d, a in zip(obs_dims, out_dims)])
 
 
+_FUSED_CENTRALISED_128 = {(3, 18), (3, 24), (4, 21), (4, 27)}
+
+
 class A2CNetwork:
     def __init__(self, obs_space, action_space, cfg, actor, critic, device="cuda"):
         obs_dims = [flatdim(o) for o in obs_space]
@@ -51,8 +54,9 @@ class A2CNetwork:
             raise NotImplementedError(f"use_rnn with layers actor={ha} critic={hc}: the recurrent kernels are built for [64, 64] / [128, 128]")
         # any two-layer widths up to 128, actor and critic independently: zero-padded to one compiled width (dqn/model.py pad_blocks)
         Hk = max(compiled_width(ha), compiled_width(hc))
-        if bool(_get(critic, "centralised", False)) and not self.recurrent and P > 2:
-            Hk = 128  # the feed-forward centralised critics for 3 / 4 agents are compiled at width 128 only (a2c.hip MARL_MAC_SHAPES)
+        if bool(_get(critic, "centralised", False)) and not self.recurrent and (P, obs_dims[0]) in _FUSED_CENTRALISED_128:
+            Hk = 128  # fused centralised-critic kernels for 3 / 4 agents exist at width 128 only (a2c.hip MARL_MAC_SHAPES); every other
+            #           (agents, observation width) runs the critics on the wide path (csrc/wide_mlp.h) at the compiled width of the layers
         self.live_hidden = {"actor": tuple(ha), "critic": tuple(hc), "target_critic": tuple(hc)}
         if len(set(obs_dims)) != 1 or len(set(act_dims)) != 1:
             raise NotImplementedError("agents with different observation / action sizes")

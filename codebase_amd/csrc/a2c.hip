@@ -25,17 +25,19 @@ using namespace marl;
 // accumulators of a P*D-wide first layer still fit the register file), hidden 64 for 2 agents (LDS-resident packs)
 #define MARL_MAC_SHAPES(X) X(2, 12, 128) X(2, 15, 128) X(3, 18, 128) X(3, 24, 128) X(4, 21, 128) X(4, 27, 128) X(2, 12, 64) X(2, 15, 64)
 
+// a centralised critic with a fused kernel (MARL_MAC_SHAPES); every other (agents, obs dim) takes the wide path (wide_mlp.h: run-time
+// input width, activations in HBM) next to the fused actor kernels of MARL_AC_SHAPES
+static bool mac_compiled(const marlhip_net_shape* s) {
+#define X(p, d, h) if (s->n_agents == p && s->obs_dim == d && s->hidden == h && s->n_actions == 6) return true;
+    MARL_MAC_SHAPES(X)
+#undef X
+    return false;
+}
+
 static int ac_check(const marlhip_net_shape* s, int centralised = 0) {
     MARL_REQUIRE(s != nullptr, "net shape is NULL");
     if (agent_map_validate(s) != 0) return -1;
     MARL_REQUIRE(s->n_agents >= 1, "ac: no agents");
-    if (centralised) {
-#define X(p, d, h) if (s->n_agents == p && s->obs_dim == d && s->hidden == h && s->n_actions == 6) return 0;
-        MARL_MAC_SHAPES(X)
-#undef X
-        set_error("no centralised-critic kernels for %d agents x obs_dim %d, hidden %d (MARL_MAC_SHAPES)", s->n_agents, s->obs_dim, s->hidden);
-        return -1;
-    }
 #define X(d, h, a) if (s->obs_dim == d && s->hidden == h && s->n_actions == a) return 0;
     MARL_AC_SHAPES(X)
 #undef X
@@ -45,11 +47,12 @@ static int ac_check(const marlhip_net_shape* s, int centralised = 0) {
 
 extern "C" int marlhip_ac_critic_nparams(const marlhip_net_shape* s, int32_t centralised) {
     if (ac_check(s, centralised) != 0) return -1;
-    if (centralised) {
+    if (centralised && mac_compiled(s)) {
 #define X(p, d, h) if (s->n_agents == p && s->obs_dim == d && s->hidden == h) return MlpShape<p * d, h, 1>::NPARAM;
         MARL_MAC_SHAPES(X)
 #undef X
     }
+    if (centralised) return (int)WideNet{s->n_agents * s->obs_dim, s->hidden, 1}.nparam();
 #define X(d, h, a) if (s->obs_dim == d && s->hidden == h && s->n_actions == a) return MlpShape<d, h, 1>::NPARAM;
     MARL_AC_SHAPES(X)
 #undef X
@@ -58,11 +61,20 @@ extern "C" int marlhip_ac_critic_nparams(const marlhip_net_shape* s, int32_t cen
 
 extern "C" int64_t marlhip_ac_workspace_bytes(const marlhip_net_shape* s, int32_t centralised, int32_t max_len, int32_t batch) {
     if (ac_check(s, centralised) != 0) return -1;
-    if (centralised) {
+    if (centralised && mac_compiled(s)) {
 #define X(p, d, h)                                                   \
     if (s->n_agents == p && s->obs_dim == d && s->hidden == h)       \
         return ac_ws_layout<MlpShape<d, h, 6>, MlpShape<p * d, h, 1>>(s->n_agents, max_len, batch).total;
         MARL_MAC_SHAPES(X)
+#undef X
+    }
+    if (centralised) {
+#define X(d, h, a)                                                       \
+    if (s->obs_dim == d && s->hidden == h && s->n_actions == a) {        \
+        WideCritic<h>::D = s->n_agents * d;                              \
+        return ac_ws_layout<MlpShape<d, h, a>, WideCritic<h>>(s->n_agents, max_len, batch).total; \
+    }
+        MARL_AC_SHAPES(X)
 #undef X
     }
 #define X(d, h, a) \
@@ -88,8 +100,17 @@ static int ac_call(const marlhip_net_shape* s, const float* actor, const float* 
     if (c->centralised_critic) {
         MARL_REQUIRE(bt->obs_row_stride == (int64_t)s->n_agents * s->obs_dim && bt->obs_agent_stride == s->obs_dim,
                      "ac_loss_grad: a centralised critic needs the ac/train.py Batch layout (agents concatenated in a row)");
+        if (mac_compiled(s)) {
 #define X(p, d, h) if (s->n_agents == p && s->obs_dim == d && s->hidden == h) return ac_step<d, h, 6, p * d>(MARL_AC_ARGS);
-        MARL_MAC_SHAPES(X)
+            MARL_MAC_SHAPES(X)
+#undef X
+        }
+#define X(d, h, a)                                                       \
+    if (s->obs_dim == d && s->hidden == h && s->n_actions == a) {        \
+        WideCritic<h>::D = s->n_agents * d;                              \
+        return ac_step_t<MlpShape<d, h, a>, WideCritic<h>>(MARL_AC_ARGS); \
+    }
+        MARL_AC_SHAPES(X)
 #undef X
     }
 #define X(d, h, a) if (s->obs_dim == d && s->hidden == h && s->n_actions == a) return ac_step<d, h, a, d>(MARL_AC_ARGS);
@@ -109,12 +130,21 @@ extern "C" int marlhip_ac_forward_rows(const marlhip_net_shape* s, int32_t value
     bt.obss = obs; bt.max_len = 1; bt.batch = 1;
     bt.obs_agent_stride = value_net == 2 ? -1 : agent_stride;
     bt.obs_row_stride = row_stride;
-    if (value_net == 2) {
+    if (value_net == 2 && mac_compiled(s)) {
 #define X(p, d, h)                                               \
     if (s->n_agents == p && s->obs_dim == d && s->hidden == h)   \
         return launch_forward_rows<MlpShape<p * d, h, 1>>(s->n_agents, agent_map(s), params, &bt, n_rows, out, (hipStream_t)stream);
         MARL_MAC_SHAPES(X)
 #undef X
+    }
+    if (value_net == 2) {  // the wide path; hidden 64 / 128 as the actors' kernels
+        MARL_REQUIRE(s->hidden == 64 || s->hidden == 128, "ac_forward_rows: centralised critics are built for hidden 64 / 128");
+        if (s->hidden == 64) {
+            WideCritic<64>::D = s->n_agents * s->obs_dim;
+            return launch_forward_rows<WideCritic<64>>(s->n_agents, agent_map(s), params, &bt, n_rows, out, (hipStream_t)stream);
+        }
+        WideCritic<128>::D = s->n_agents * s->obs_dim;
+        return launch_forward_rows<WideCritic<128>>(s->n_agents, agent_map(s), params, &bt, n_rows, out, (hipStream_t)stream);
     }
 #define X(d, h, a)                                                                                                         \
     if (s->obs_dim == d && s->hidden == h && s->n_actions == a)                                                             \

@@ -3,8 +3,29 @@
 #include "dqn_update_kernels.h"
 #include "collect_common.h"
 #include "gru_rows.h"
+#include "wide_mlp.h"
 
 namespace marl {
+
+// A critic whose input is too wide for the fused kernels (wide_mlp.h): hidden width H fixed by the type, the input width set by the
+// entry point for the duration of its call (thread-local: calls on different host threads never meet).
+template <int H_>
+struct WideCritic {
+    static constexpr int H = H_, A = 1;
+    static inline thread_local int D = 0;
+    static WideNet net() { return WideNet{D, H, A}; }
+};
+template <class S>
+struct IsWide : std::false_type {};
+template <int H>
+struct IsWide<WideCritic<H>> : std::true_type {};
+
+// bytes of forward-pack scratch (collect_pack_scratch) a forward-rows launch of shape S over n_rows rows wants
+template <class S>
+int64_t forward_scratch_bytes(int P, int n_rows) {
+    if constexpr (IsWide<S>::value) return wide_ws(S::net(), P, n_rows, false).total + 16;
+    else return (int64_t)P * S::NFWD * 4 + 16;
+}
 
 // ---- forward rows ------------------------------------------------------------------------------------------
 template <class S>
@@ -51,6 +72,32 @@ int launch_forward_rows(int P, const AgentMap& am, const float* params, const ma
                         float* rec = nullptr) {
     if constexpr (IsGru<S>::value) {
         return gru_forward_rows<S>(P, am, params, bt, n_rows / bt->batch, out, st, rec);
+    } else if constexpr (IsWide<S>::value) {
+        (void)rec;
+        const WideNet s = S::net();
+        MARL_REQUIRE(s.D > 0, "wide critic: input width not set");
+        const int64_t as = bt->obs_agent_stride > 0 ? bt->obs_agent_stride : (bt->obs_agent_stride < 0 ? 0 : (int64_t)(bt->max_len + 1) * bt->batch * s.D);
+        const int64_t rs = bt->obs_row_stride ? bt->obs_row_stride : s.D;
+        // as many rows per pass as the caller's scratch holds activations for (the learner step sizes it for all rows at once)
+        const int64_t avail = scratch_avail(), per_row = (int64_t)2 * s.H * 4;
+        int chunk = (int)((avail - 1024) / per_row < n_rows ? (avail - 1024) / per_row : n_rows);
+        chunk &= ~63;
+        if (chunk >= n_rows || n_rows < 64) chunk = n_rows;
+        MARL_REQUIRE(chunk >= 64 || chunk == n_rows, "wide critic forward: the workspace holds no 64-row slice of activations (%lld bytes)", (long long)avail);
+        float* scratch = collect_pack_scratch((size_t)wide_ws(s, P, chunk, false).total, st);
+        if (scratch == nullptr) return -1;
+        for (int r0 = 0; r0 < n_rows; r0 += chunk) {
+            const int nr = n_rows - r0 < chunk ? n_rows - r0 : chunk;
+            // out is [P][n_rows][A]: a slice keeps the full agent stride, so slices go agent by agent through one-agent views
+            for (int p = 0; p < P; ++p) {
+                AgentMap one = am;
+                one.net[0] = am.net[p];
+                const int rc = wide_forward_rows(s, 1, one, params, bt->obss + (int64_t)p * as + (int64_t)r0 * rs, 0, rs, nr,
+                                                 out + ((int64_t)p * n_rows + r0) * s.A, scratch, st);
+                if (rc != 0) return rc;
+            }
+        }
+        return 0;
     } else {
     (void)rec;
     const int T = bt->max_len, B = bt->batch;
@@ -81,6 +128,8 @@ template <class S>
 int64_t backward_ws_bytes(int P, int T, int B) {
     if constexpr (IsGru<S>::value) {
         return gru_rows_ws<S>(P, T, B, false).total;  // the step's forward passes write the records (AcWs::rec_a / rec_c)
+    } else if constexpr (IsWide<S>::value) {
+        return wide_ws(S::net(), P, T * B, true).total;
     } else if constexpr (use_tp<S>()) {
         const UpdPlan pl = upd_plan_tp(P, T, B, S::D > 48 ? 1 : 2);
         return ws_layout(P, pl.nwg, S::NPARAM + 2, 0, T, B).total;
@@ -97,6 +146,14 @@ int launch_backward_rows(int P, const AgentMap& am, const float* params, const m
     if constexpr (IsGru<S>::value) {
         MARL_REQUIRE(rec != nullptr, "ac backward: the recurrent networks need the forward record");
         return gru_backward_rows<S>(P, am, params, bt, bt->max_len, dout, lrow, ws, ws_bytes, grad, loss, st, rec);
+    } else if constexpr (IsWide<S>::value) {
+        (void)rec;
+        const WideNet s = S::net();
+        const int T = bt->max_len, B = bt->batch;
+        MARL_REQUIRE(ws_bytes >= backward_ws_bytes<S>(P, T, B), "ac backward: workspace %lld too small", (long long)ws_bytes);
+        const int64_t as = bt->obs_agent_stride > 0 ? bt->obs_agent_stride : (bt->obs_agent_stride < 0 ? 0 : (int64_t)(T + 1) * B * s.D);
+        const int64_t rs = bt->obs_row_stride ? bt->obs_row_stride : s.D;
+        return wide_backward_rows(s, P, am, params, bt->obss, as, rs, T * B, bt->filled, dout, lrow, ws, grad, loss, st);
     } else {
     (void)rec;
     const int T = bt->max_len, B = bt->batch;
@@ -366,7 +423,10 @@ AcWs ac_ws_layout(int P, int T, int B) {
     w.rpartial = take(2 * P * ((TB + 255) / 256));
     w.scratch = take(8);
     // weight packs of the forward-rows launches (two networks at once for the paired recurrent pass): collect_pack_scratch's region
-    w.packs_bytes = (int64_t)2 * P * (SA::NFWD > SC::NFWD ? SA::NFWD : SC::NFWD) * 4 + 16;
+    {
+        const int64_t fa = forward_scratch_bytes<SA>(P, (int)(TB + B)), fc = forward_scratch_bytes<SC>(P, (int)(TB + B));
+        w.packs_bytes = 2 * (fa > fc ? fa : fc);
+    }
     w.packs = take(w.packs_bytes / 4 + 1);
     w.rec_a = w.rec_c = o;  // recurrent networks: the activation records of this step's actor / critic forward passes
     if constexpr (IsGru<SA>::value) w.rec_a = take(gru_rec_floats<SA>(P, T, B));
@@ -383,7 +443,8 @@ AcWs ac_ws_layout(int P, int T, int B) {
 template <class SA, class SC>
 int ac_step_t(int P, const AgentMap& am, const float* actor, const float* critic, const float* target, const marlhip_batch* bt, const marlhip_ac_config* c,
               int mode, void* ws, int64_t ws_bytes, float* actor_grad, float* critic_grad, float* metrics, hipStream_t st) {
-    constexpr int D = SA::D, A = SA::A, DC = SC::D;
+    constexpr int D = SA::D, A = SA::A;
+    const int DC = SC::D;  // (a run-time value for the wide critics)
     const int T = bt->max_len, B = bt->batch, TB = T * B;
     marlhip_batch btc = *bt;  // the critics' view of the batch
     if (DC != D) btc.obs_agent_stride = -1;

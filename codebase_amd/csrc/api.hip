@@ -50,6 +50,13 @@ void scratch_bind(void* base, int64_t bytes) {
     g_scratch_bytes = base != nullptr ? bytes : 0;
 }
 
+int64_t scratch_avail() {  // bytes collect_pack_scratch can hand out in this call
+    if (g_scratch_base == nullptr) return 0;
+    char* b = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(g_scratch_base) + 15) & ~(uintptr_t)15);
+    const int64_t avail = g_scratch_bytes - (b - g_scratch_base);
+    return avail > 0 ? avail : 0;
+}
+
 float* collect_pack_scratch(size_t bytes, hipStream_t) {
     char* b = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(g_scratch_base) + 15) & ~(uintptr_t)15);
     const int64_t avail = g_scratch_base != nullptr ? g_scratch_bytes - (b - g_scratch_base) : 0;

@@ -28,6 +28,7 @@ struct ScratchScope {
     ScratchScope(const ScratchScope&) = delete;
     ScratchScope& operator=(const ScratchScope&) = delete;
 };
+int64_t scratch_avail();
 float* collect_pack_scratch(size_t bytes, hipStream_t st);  // nullptr + marlhip_last_error() text when the bound region cannot hold it
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: one slot per device ordinal, raised monotonically (a racing second

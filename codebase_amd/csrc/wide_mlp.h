@@ -1,0 +1,281 @@
+// Two-hidden-layer MLPs whose first layer is too wide for the fused kernels: centralised critics (critic.centralised, marlbase/ac/model.py:62-66,
+// 155-157: every critic reads the concatenation of all agents' observations) of more than 4 agents or of the warehouse's 71-wide
+// observations.  The fused kernels keep one agent's weights in LDS / registers and the dW1 accumulators in registers, which caps the
+// input width; here the three layers are plain f32 MFMA GEMMs over all rows with the activations in HBM, sized at RUN time
+// (input width, hidden width, outputs): any width works, at the price of writing and re-reading [rows][H] activations.
+//
+//   forward   Y1 = relu(X W1^T + b1), Y2 = relu(Y1 W2^T + b2), out = Y2 W3^T + b3                              (FCNetwork, utils/models.py:34-48)
+//   backward  dY2 = (dout W3) * (Y2 > 0), dY1 = (dY2 W2) * (Y1 > 0), dWk = dYk^T [Y(k-1) | 1]  (the ones column yields dbk)
+//
+// One kernel, wide_gemm_kernel: C[m][n] = sum_k A(m, k) B(k, n) on v_mfma_f32_16x16x4_f32, a 64 x 64 tile per workgroup (wave w: rows
+// 16w..16w+15, four 16 x 16 column tiles), k in slices of 16 staged through LDS ([k][64 + 16] floats: the four k-quarters of an MFMA
+// operand read land in different banks), the next slice prefetched into registers while the current one multiplies.  Operands are
+// addressed by (row, column) strides, so X^T / W^T never exist in memory; weight gradients split the row dimension over grid.z and a
+// second kernel adds the partial tiles in a fixed order (bitwise reproducible, no atomics) and applies 1 / sum(filled).
+#pragma once
+#include "common.h"
+#include "mlp.h"
+
+namespace marl {
+
+struct GemmOp {
+    const float* A; int64_t a_m, a_k;      // A(m, k) = A[m * a_m + k * a_k]
+    const float* B; int64_t b_k, b_n;      // B(k, n) = B[k * b_k + n * b_n]; column n == b_ones reads as 1 (bias-gradient column)
+    float* C; int64_t c_m;                 // C[z * c_split + m * c_m + n]
+    int M, N, K;
+    int k_chunk;                           // grid.z = z covers k in [z * k_chunk, min(K, (z + 1) * k_chunk))
+    int64_t c_split;
+    const float* bias;                     // epi 1, 2: + bias[n]
+    const float* gate; int64_t gate_m;     // epi 3: * (gate[m * gate_m + n] > 0)   (relu mask of the activation the gradient flows into)
+    int b_ones;                            // -1: none
+    int epi;                               // 0 store, 1 + bias, 2 relu(+ bias), 3 gate
+};
+
+// A_KC / B_KC: the operand is contiguous along k (true) or along m / n (false) - picks the global-load pattern that coalesces
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void wide_gemm_kernel(const GemmOp g) {
+    constexpr int LD = 80;
+    __shared__ float As[16 * LD], Bs[16 * LD];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 15, q = lane >> 4;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int kbeg = blockIdx.z * g.k_chunk, kend = min(g.K, kbeg + g.k_chunk);
+    f4 acc[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) acc[nt] = f4{0.f, 0.f, 0.f, 0.f};
+    float ra[4], rb[4];
+    auto load = [&](int k0) {
+        if (A_KC) {  // thread: one m, four consecutive k
+            const int m = m0 + (tid & 63), kq = k0 + 4 * (tid >> 6);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ra[e] = (m < g.M && kq + e < kend) ? g.A[(int64_t)m * g.a_m + (int64_t)(kq + e) * g.a_k] : 0.f;
+        } else {  // thread: one k, four consecutive m
+            const int k = k0 + (tid >> 4), mm = m0 + 4 * (tid & 15);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ra[e] = (mm + e < g.M && k < kend) ? g.A[(int64_t)(mm + e) * g.a_m + (int64_t)k * g.a_k] : 0.f;
+        }
+        if (B_KC) {
+            const int n = n0 + (tid & 63), kq = k0 + 4 * (tid >> 6);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                rb[e] = (n < g.N && kq + e < kend) ? (n == g.b_ones ? 1.f : g.B[(int64_t)(kq + e) * g.b_k + (int64_t)n * g.b_n]) : 0.f;
+        } else {
+            const int k = k0 + (tid >> 4), nn = n0 + 4 * (tid & 15);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                rb[e] = (nn + e < g.N && k < kend) ? (nn + e == g.b_ones ? 1.f : g.B[(int64_t)k * g.b_k + (int64_t)(nn + e) * g.b_n]) : 0.f;
+        }
+    };
+    auto store = [&]() {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (A_KC) As[(4 * (tid >> 6) + e) * LD + (tid & 63)] = ra[e];
+            else As[(tid >> 4) * LD + 4 * (tid & 15) + e] = ra[e];
+            if (B_KC) Bs[(4 * (tid >> 6) + e) * LD + (tid & 63)] = rb[e];
+            else Bs[(tid >> 4) * LD + 4 * (tid & 15) + e] = rb[e];
+        }
+    };
+    if (kbeg < kend) load(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += 16) {
+        __syncthreads();  // the previous slice has been multiplied
+        store();
+        __syncthreads();
+        if (k0 + 16 < kend) load(k0 + 16);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const float a = As[(4 * s + q) * LD + 16 * wave + i];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[nt] = MARL_MFMA(a, Bs[(4 * s + q) * LD + 16 * nt + i], acc[nt]);
+        }
+    }
+    float* C = g.C + (int64_t)blockIdx.z * g.c_split;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int n = n0 + 16 * nt + i;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + 16 * wave + 4 * q + r;
+            if (m < g.M && n < g.N) {
+                float v = acc[nt][r];
+                if (g.epi == 1 || g.epi == 2) v += g.bias[n];
+                if (g.epi == 2) v = fmaxf(v, 0.f);
+                if (g.epi == 3) v = g.gate[(int64_t)m * g.gate_m + n] > 0.f ? v : 0.f;
+                C[(int64_t)m * g.c_m + n] = v;
+            }
+        }
+    }
+}
+
+// dW[m][n < N - 1] and db[m] (column N - 1) = (sum over the splits, in split order) * inv, inv = 1 / nf[0]
+static __global__ __launch_bounds__(256) void wide_fold_kernel(const float* __restrict__ partial, int splits, int64_t split_stride, int M, int N,
+                                                               const float* __restrict__ nf, float* __restrict__ dW, float* __restrict__ db) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= M * N) return;
+    float acc = 0.f;
+    for (int z = 0; z < splits; ++z) acc += partial[(int64_t)z * split_stride + idx];
+    acc /= nf[0];
+    const int m = idx / N, n = idx - m * N;
+    if (n < N - 1) dW[(int64_t)m * (N - 1) + n] = acc;
+    else db[m] = acc;
+}
+
+// out[0] = sum(lrow) / nf, out[1] = nf = sum(filled): one workgroup, fixed order (the launch_backward_rows contract)
+static __global__ __launch_bounds__(256) void wide_count_kernel(const float* __restrict__ filled, const float* __restrict__ lrow, int n,
+                                                                float* __restrict__ out) {
+    __shared__ float sh[2][4];
+    float nf = 0.f, ls = 0.f;
+    for (int k = threadIdx.x; k < n; k += 256) {
+        nf += filled[k];
+        if (lrow != nullptr) ls += lrow[k];
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        nf += __shfl_xor(nf, off);
+        ls += __shfl_xor(ls, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        sh[0][threadIdx.x >> 6] = nf;
+        sh[1][threadIdx.x >> 6] = ls;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        nf = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]);
+        ls = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
+        out[0] = ls / nf;
+        out[1] = nf;
+    }
+}
+
+// grad[blk][i] = sum over the agents of block blk, in agent order, of gp[p][i]
+static __global__ __launch_bounds__(256) void wide_gather_kernel(const float* __restrict__ gp, int P, int nparam, AgentMap am,
+                                                                 float* __restrict__ grad) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= am.nblk * nparam) return;
+    const int blk = idx / nparam, k = idx - blk * nparam;
+    float acc = 0.f;
+    for (int p = 0; p < P; ++p)
+        if (am.net[p] == blk) acc += gp[(int64_t)p * nparam + k];
+    grad[idx] = acc;
+}
+
+// run-time shape of one network: D inputs, two hidden layers of H, A outputs; parameters in FCNetwork's parameters() order
+struct WideNet {
+    int D, H, A;
+    int64_t oW1() const { return 0; }
+    int64_t ob1() const { return (int64_t)H * D; }
+    int64_t oW2() const { return ob1() + H; }
+    int64_t ob2() const { return oW2() + (int64_t)H * H; }
+    int64_t oW3() const { return ob2() + H; }
+    int64_t ob3() const { return oW3() + (int64_t)A * H; }
+    int64_t nparam() const { return ob3() + A; }
+    int widest() const { return D > H ? D : H; }
+};
+
+inline int wide_splits(int rows) {  // row slices of the weight-gradient GEMMs: >= 2048 rows each, at most 256 slices
+    int s = rows / 2048;
+    return s < 1 ? 1 : (s > 256 ? 256 : s);
+}
+
+struct WideWs {
+    int64_t y1, y2, d2, d1, partial, gp, nf, total;  // byte offsets
+};
+
+// backward = true: the whole workspace of wide_backward_rows; false: the two activation buffers of wide_forward_rows
+inline WideWs wide_ws(const WideNet& s, int P, int rows, bool backward) {
+    WideWs w = {};
+    int64_t o = 0;
+    auto take = [&](int64_t nfloat) { const int64_t at = o; o = (o + nfloat * 4 + 255) & ~(int64_t)255; return at; };
+    w.y1 = take((int64_t)rows * s.H);
+    w.y2 = take((int64_t)rows * s.H);
+    if (backward) {
+        w.d2 = take((int64_t)rows * s.H);
+        w.d1 = take((int64_t)rows * s.H);
+        w.partial = take((int64_t)wide_splits(rows) * s.H * (s.widest() + 1));
+        w.gp = take((int64_t)P * s.nparam());
+        w.nf = take(4);
+    }
+    w.total = o;
+    return w;
+}
+
+template <bool A_KC, bool B_KC>
+inline void wide_gemm(const GemmOp& g, int splits, hipStream_t st) {
+    hipLaunchKernelGGL((wide_gemm_kernel<A_KC, B_KC>), dim3((g.N + 63) / 64, (g.M + 63) / 64, splits), dim3(256), 0, st, g);
+}
+
+// Y1, Y2 of `rows` rows x (row r at x + r * row_stride) for one network
+inline void wide_hidden(const WideNet& s, const float* prm, const float* x, int64_t row_stride, int rows, float* y1, float* y2, hipStream_t st) {
+    GemmOp g = {};
+    g.M = rows; g.k_chunk = 1 << 30; g.b_ones = -1; g.epi = 2;
+    g.A = x; g.a_m = row_stride; g.a_k = 1; g.B = prm + s.oW1(); g.b_k = 1; g.b_n = s.D; g.C = y1; g.c_m = s.H; g.N = s.H; g.K = s.D;
+    g.bias = prm + s.ob1();
+    wide_gemm<true, true>(g, 1, st);
+    g.A = y1; g.a_m = s.H; g.B = prm + s.oW2(); g.b_n = s.H; g.C = y2; g.K = s.H; g.bias = prm + s.ob2();
+    wide_gemm<true, true>(g, 1, st);
+}
+
+// out[p][row][A] = MLP_p(x row); x row r of agent p at obs + p * agent_stride + r * row_stride; scratch: wide_ws(.., false).total bytes
+inline int wide_forward_rows(const WideNet& s, int P, const AgentMap& am, const float* params, const float* obs, int64_t agent_stride,
+                             int64_t row_stride, int rows, float* out, void* scratch, hipStream_t st) {
+    const WideWs w = wide_ws(s, P, rows, false);
+    float* y1 = reinterpret_cast<float*>(static_cast<char*>(scratch) + w.y1);
+    float* y2 = reinterpret_cast<float*>(static_cast<char*>(scratch) + w.y2);
+    for (int p = 0; p < P; ++p) {
+        const float* prm = params + (int64_t)am.net[p] * s.nparam();
+        wide_hidden(s, prm, obs + (int64_t)p * agent_stride, row_stride, rows, y1, y2, st);
+        GemmOp g = {};
+        g.M = rows; g.N = s.A; g.K = s.H; g.k_chunk = 1 << 30; g.b_ones = -1; g.epi = 1;
+        g.A = y2; g.a_m = s.H; g.a_k = 1; g.B = prm + s.oW3(); g.b_k = 1; g.b_n = s.H; g.C = out + (int64_t)p * rows * s.A; g.c_m = s.A;
+        g.bias = prm + s.ob3();
+        wide_gemm<true, true>(g, 1, st);
+    }
+    MARL_CHECK_LAUNCH("wide_gemm_kernel (forward)");
+    return 0;
+}
+
+// grad[blk][nparam] = d(sum_rows <dout row, MLP(x row)>)/dparams / sum(filled); dout [P][rows][A] (already masked by filled);
+// loss[0] = sum(lrow) / sum(filled), loss[1] = sum(filled).  ws: wide_ws(.., true).total bytes.
+inline int wide_backward_rows(const WideNet& s, int P, const AgentMap& am, const float* params, const float* obs, int64_t agent_stride,
+                              int64_t row_stride, int rows, const float* filled, const float* dout, const float* lrow, void* ws, float* grad,
+                              float* loss, hipStream_t st) {
+    const WideWs w = wide_ws(s, P, rows, true);
+    char* base = static_cast<char*>(ws);
+    auto f = [&](int64_t off) { return reinterpret_cast<float*>(base + off); };
+    float *y1 = f(w.y1), *y2 = f(w.y2), *d2 = f(w.d2), *d1 = f(w.d1), *part = f(w.partial), *gp = f(w.gp), *nf = f(w.nf);
+    hipLaunchKernelGGL(wide_count_kernel, dim3(1), dim3(256), 0, st, filled, lrow, rows, nf);
+    const int splits = wide_splits(rows), chunk = (((rows + splits - 1) / splits) + 15) & ~15;
+    const int H = s.H, A = s.A, D = s.D;
+    for (int p = 0; p < P; ++p) {
+        const float* prm = params + (int64_t)am.net[p] * s.nparam();
+        const float* x = obs + (int64_t)p * agent_stride;
+        const float* dq = dout + (int64_t)p * rows * A;
+        float* gpp = gp + (int64_t)p * s.nparam();
+        wide_hidden(s, prm, x, row_stride, rows, y1, y2, st);
+        // weight gradient of a layer: dW[out][in] (+ bias column) = dY^T [Yprev | 1], rows sliced over grid.z, then the fold
+        auto wgrad = [&](const float* dy, int n_out, const float* yprev, int64_t yprev_stride, int n_in, float* dW, float* db) {
+            GemmOp g = {};
+            g.M = n_out; g.N = n_in + 1; g.K = rows; g.k_chunk = chunk; g.b_ones = n_in; g.epi = 0;
+            g.A = dy; g.a_m = 1; g.a_k = n_out; g.B = yprev; g.b_k = yprev_stride; g.b_n = 1;
+            g.C = part; g.c_m = n_in + 1; g.c_split = (int64_t)n_out * (n_in + 1);
+            wide_gemm<false, false>(g, splits, st);
+            const int n = n_out * (n_in + 1);
+            hipLaunchKernelGGL(wide_fold_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)part, splits, g.c_split, n_out, n_in + 1,
+                               (const float*)nf + 1, dW, db);
+        };
+        wgrad(dq, A, y2, H, H, gpp + s.oW3(), gpp + s.ob3());
+        GemmOp g = {};
+        g.M = rows; g.N = H; g.k_chunk = 1 << 30; g.b_ones = -1; g.epi = 3;
+        g.A = dq; g.a_m = A; g.a_k = 1; g.K = A; g.B = prm + s.oW3(); g.b_k = H; g.b_n = 1; g.C = d2; g.c_m = H; g.gate = y2; g.gate_m = H;
+        wide_gemm<true, false>(g, 1, st);  // dY2 = (dout W3) * (Y2 > 0)
+        wgrad(d2, H, y1, H, H, gpp + s.oW2(), gpp + s.ob2());
+        g.A = d2; g.a_m = H; g.K = H; g.B = prm + s.oW2(); g.C = d1; g.gate = y1;
+        wide_gemm<true, false>(g, 1, st);  // dY1 = (dY2 W2) * (Y1 > 0)
+        wgrad(d1, H, x, row_stride, D, gpp + s.oW1(), gpp + s.ob1());
+    }
+    const int n = am.nblk * (int)s.nparam();
+    hipLaunchKernelGGL(wide_gather_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)gp, P, (int)s.nparam(), am, grad);
+    hipLaunchKernelGGL(wide_count_kernel, dim3(1), dim3(256), 0, st, filled, lrow, rows, loss);
+    MARL_CHECK_LAUNCH("wide_gemm_kernel (backward)");
+    return 0;
+}
+
+}  // namespace marl

@@ -186,6 +186,38 @@ def test_centralised_critic_algorithms_end_to_end(tmp_path, monkeypatch):
         df = run.main([f"+algorithm={algo}", "env.name=lbforaging:Foraging-8x8-2p-3f-v3", "env.time_limit=25", "env.parallel_envs=256",
                        "seed=1", "algorithm.total_steps=60000", "algorithm.eval_interval=20000"])
         assert df.shape[0] >= 2 and np.isfinite(df["loss"]).all()
-    with pytest.raises(Exception):  # 8 agents: no centralised-critic kernel (312 inputs) - a loud error, not a fallback
-        run.main(["+algorithm=maa2c", "env.name=lbforaging:Foraging-15x15-8p-5f-v3", "env.time_limit=25", "env.parallel_envs=64",
-                  "algorithm.total_steps=1000"])
+    # 8 agents (312-wide critics) and the warehouse (4 x 71): the critics take the GEMM path of csrc/wide_mlp.h
+    for algo, env, tl in (("maa2c", "lbforaging:Foraging-15x15-8p-5f-v3", 25), ("mappo", "rware:rware-tiny-4ag-v2", 50)):
+        monkeypatch.setenv("MARLHIP_RUN_DIR", str(tmp_path / (algo + "_wide")))
+        df = run.main([f"+algorithm={algo}", f"env.name={env}", f"env.time_limit={tl}", "env.parallel_envs=128", "seed=1",
+                       "algorithm.total_steps=60000", "algorithm.eval_interval=20000"])
+        assert df.shape[0] >= 2 and np.isfinite(df["loss"]).all()
+
+
+@pytest.mark.parametrize("P,T,N,D,H,A,n", [(8, 25, 20, 39, 128, 6, 5), (8, 9, 70, 39, 64, 6, 3), (4, 12, 33, 71, 128, 5, 5), (2, 6, 300, 71, 64, 5, 2),
+                                           (5, 7, 130, 27, 64, 6, 5)])
+def test_wide_centralised_critics_vs_oracle_port(P, T, N, D, H, A, n):
+    """centralised critics the fused kernels do not cover (8 LBF agents: 312 inputs; the warehouse: 71 per agent; 5 agents): the GEMM
+    path of csrc/wide_mlp.h - loss pieces, actor and critic gradients vs the port, and the value rows through marlhip_ac_forward_rows"""
+    h = hip()
+    actor = dp.init_params(P, D, H, A, seed=1) + 0.03
+    critic = torch.stack([dp.init_params(1, P * D, H, 1, seed=20 + p)[0] for p in range(P)]) + 0.02
+    target = torch.stack([dp.init_params(1, P * D, H, 1, seed=40 + p)[0] for p in range(P)])
+    batch = ap.synthetic_batch(P, T, N, D, A, seed=7)
+    a, c = actor.clone().requires_grad_(True), critic.clone().requires_grad_(True)
+    loss, m = ap.a2c_loss(a, c, target, batch, D, H, A, n_steps=n, gamma=0.97, entropy_coef=0.01, value_loss_coef=0.5)
+    loss.backward()
+    spec = h.NetSpec(P, D, H, A)
+    up = h.AcUpdater(spec, torch.cat([actor.reshape(-1), critic.reshape(-1)]).to(DEV), target.to(DEV).contiguous(), gamma=0.97,
+                     n_steps=n, entropy_coef=0.01, value_loss_coef=0.5, centralised_critic=True)
+    assert up.n_critic == dp.nparams(P * D, H, 1)
+    got = up.a2c_loss_grad(dev_ac_batch(batch)).cpu().numpy()
+    ref = [m["loss"].item(), m["actor_loss"].item(), m["value_loss"].item(), m["entropy"].item()]
+    np.testing.assert_allclose(got[:4], ref, rtol=5e-5, atol=5e-6)
+    assert_grad_close(up.actor_grad.cpu().numpy(), a.grad.numpy(), 3e-4)
+    assert_grad_close(up.critic_grad.cpu().numpy(), c.grad.numpy(), 3e-4)
+    # get_value's rows: every critic on the concatenated observations
+    rows = (T + 1) * N
+    v = h.ac_forward_rows(spec, up.target_critic, batch["obss"].to(DEV), D, P * D, rows, value_net=2).cpu()
+    want = ap.values(target, batch["obss"], D, H).reshape(rows, P).T
+    np.testing.assert_allclose(v.reshape(P, rows).numpy(), want.detach().numpy(), rtol=2e-5, atol=2e-5)
