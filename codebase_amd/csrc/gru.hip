@@ -154,7 +154,7 @@ int gru_loss_grad(const marlhip_net_shape* s, const float* params, const float* 
     hipLaunchKernelGGL((gru_bwd_pack_kernel<S>), dim3((Bk::NBWD + 255) / 256, P), dim3(256), 0, st, params, am, f(wl.packB));
     MARL_CHECK_LAUNCH("gru pack kernels");
     const size_t ldsF = (size_t)S::LDS_FLOATS * sizeof(float), ldsB = (size_t)Bk::LDS_FLOATS * sizeof(float);
-    const size_t ldsW = (size_t)(4 * 16 * S::H + 256) * sizeof(float);
+    const size_t ldsW = gru_wgrad_lds_bytes<S>();
     static LdsAttr attr;
     if (attr.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_seq_fwd2_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsF);
@@ -195,7 +195,7 @@ int gru_loss_grad(const marlhip_net_shape* s, const float* params, const float* 
     hipLaunchKernelGGL((gru_seq_bwd_kernel<S>), gridS, dim3(256), ldsB, st, (const float*)f(wl.packB), steps, B, (const float*)f(wl.rec),
                        (const float*)f(wl.dq), f(wl.rec2));
     MARL_CHECK_LAUNCH("gru_seq_bwd_kernel");
-    hipLaunchKernelGGL((gru_wgrad_kernel<S>), dim3(wl.nwg, P, 4), dim3(256), ldsW, st, steps, B, bt->obss, (size_t)steps * B * S::D, (size_t)S::D, (const float*)f(wl.rec), (const float*)f(wl.rec2),
+    hipLaunchKernelGGL((gru_wgrad_kernel<S>), dim3(wl.nwg, P, gru_wgrad_roles<S>()), dim3(256), ldsW, st, steps, B, bt->obss, (size_t)steps * B * S::D, (size_t)S::D, (const float*)f(wl.rec), (const float*)f(wl.rec2),
                        (const float*)f(wl.dq), (const float*)f(wl.lrow), bt->filled, T, f(wl.partials));
     MARL_CHECK_LAUNCH("gru_wgrad_kernel");
     const int n = am.nblk * S::NPARAM;  // one gradient block per NETWORK: a shared network's agents are summed by the reduce
@@ -296,7 +296,7 @@ int gru_qmix_loss_grad(const marlhip_net_shape* s, const float* params, const fl
     hipLaunchKernelGGL((gru_bwd_pack_kernel<S>), dim3((Bk::NBWD + 255) / 256, P), dim3(256), 0, st, params, am, f(wl.packB));
     MARL_CHECK_LAUNCH("gru pack kernels");
     const size_t ldsF = (size_t)S::LDS_FLOATS * sizeof(float), ldsB = (size_t)Bk::LDS_FLOATS * sizeof(float);
-    const size_t ldsW = (size_t)(4 * 16 * S::H + 256) * sizeof(float);
+    const size_t ldsW = gru_wgrad_lds_bytes<S>();
     static LdsAttr attr;
     if (attr.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_seq_fwd2_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsF);
@@ -318,7 +318,7 @@ int gru_qmix_loss_grad(const marlhip_net_shape* s, const float* params, const fl
     hipLaunchKernelGGL(gru_expand_dq_kernel, gridR, dim3(256), 0, st, P, T, B, S::A, (const float*)dqm, *bt, f(wl.dq));
     hipLaunchKernelGGL((gru_seq_bwd_kernel<S>), gridS, dim3(256), ldsB, st, (const float*)f(wl.packB), steps, B, (const float*)f(wl.rec),
                        (const float*)f(wl.dq), f(wl.rec2));
-    hipLaunchKernelGGL((gru_wgrad_kernel<S>), dim3(wl.nwg, P, 4), dim3(256), ldsW, st, steps, B, bt->obss, (size_t)steps * B * S::D, (size_t)S::D, (const float*)f(wl.rec), (const float*)f(wl.rec2),
+    hipLaunchKernelGGL((gru_wgrad_kernel<S>), dim3(wl.nwg, P, gru_wgrad_roles<S>()), dim3(256), ldsW, st, steps, B, bt->obss, (size_t)steps * B * S::D, (size_t)S::D, (const float*)f(wl.rec), (const float*)f(wl.rec2),
                        (const float*)f(wl.dq), (const float*)f(wl.lrow), bt->filled, T, f(wl.partials));
     MARL_CHECK_LAUNCH("gru backward");
     const int n = am.nblk * S::NPARAM;  // one gradient block per NETWORK: a shared network's agents are summed by the reduce

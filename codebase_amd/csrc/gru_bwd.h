@@ -209,6 +209,17 @@ __global__ __launch_bounds__(256) void gru_seq_bwd_kernel(const float* __restric
     }
 }
 
+// hidden 64 (four unit tiles): the three gate roles below are one workgroup role (the FUSED branch of the kernel); launches use
+// gru_wgrad_roles / gru_wgrad_lds_bytes
+template <class S>
+struct GruWgradFused : std::integral_constant<bool, S::MT == 4> {};
+template <class S>
+constexpr int gru_wgrad_roles() { return GruWgradFused<S>::value ? 2 : 4; }
+template <class S>
+constexpr size_t gru_wgrad_lds_bytes() {
+    return (GruWgradFused<S>::value ? (size_t)6 * S::H * 24 : (size_t)4 * 16 * S::H + 256) * sizeof(float);
+}
+
 // One partial record [NPARAM + 2] per blockIdx.x (canonical parameter order, then loss and n_filled from agent 0's rows), filled
 // by four workgroups with disjoint roles (blockIdx.z): 0..2 = the rows of gate r / z / n of dW_ih and dW_hh, their four waves
 // owning a quarter of the columns each; 3 = the small parts (wave 0: dW1, db1; wave 1: dW3, db3, loss; wave 2: bias sums of
@@ -228,11 +239,93 @@ __global__ __launch_bounds__(256) void gru_wgrad_kernel(int steps, int B, const 
     float* T3 = T2 + TILE;
     float* TQ = T3 + TILE;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, j = lane & 15;
-    const int p = blockIdx.y, role = blockIdx.z;
+    constexpr bool FUSED = GruWgradFused<S>::value;  // hidden 64: ONE workgroup role for the three gates (grid.z = 2)
+    const int p = blockIdx.y, role = FUSED ? (blockIdx.z == 0 ? 0 : 3) : (int)blockIdx.z;
     const int nblk = (B + 15) >> 4, T = loss_steps;  // lrow / filled have loss_steps rows (DQN: steps - 1; actor-critic: steps)
     const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
     float* recd = partials + ((size_t)p * gridDim.x + blockIdx.x) * (S::NPARAM + 2);
     const int total = steps * nblk;
+    if constexpr (FUSED) {
+        if (role == 0) {
+            // ---- all three gates in one workgroup: x1 and h_{t-1} are read once instead of once per gate, the gate gradients once
+            // instead of twice (their row sums = the gate biases are taken here, from the registers on their way to the tiles), and a
+            // wave issues 96 MFMAs between two barriers instead of 32.  Six padded [unit][24] tiles: dr, dz, dn, r*dn, x1, h_{t-1};
+            // the 24 (array, unit tile) pairs are transposed 6 per wave; the next item's loads fly during the MFMAs.
+            constexpr int TS = 24, TL = H * TS;
+            f4 dWa[3][MT], dWb[3][MT], bs[6], v[6];
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < MT; ++b) { dWa[a][b] = zero4; dWb[a][b] = zero4; }
+#pragma unroll
+            for (int k = 0; k < 6; ++k) bs[k] = zero4;
+            auto load = [&](int item) {
+                const int t = item / nblk, blk = item - t * nblk;
+                const f4* R = reinterpret_cast<const f4*>(rec + (((size_t)p * steps + t) * nblk + blk) * S::REC);
+                const f4* Rp = reinterpret_cast<const f4*>(rec + (((size_t)p * steps + (t > 0 ? t - 1 : 0)) * nblk + blk) * S::REC);
+                const f4* R2 = reinterpret_cast<const f4*>(rec2 + (((size_t)p * steps + t) * nblk + blk) * Bk::REC2);
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    const int u = wave * 6 + k, arr = u >> 2, mt = u & 3;
+                    if (arr < 4) v[k] = R2[(arr * MT + mt) * 64 + lane];
+                    else if (arr == 4) v[k] = R[(0 * MT + mt) * 64 + lane];
+                    else v[k] = t > 0 ? Rp[(4 * MT + mt) * 64 + lane] : zero4;
+                }
+            };
+            if ((int)blockIdx.x < total) load(blockIdx.x);
+            for (int item = blockIdx.x; item < total; item += gridDim.x) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    const int u = wave * 6 + k, arr = u >> 2, mt = u & 3;
+                    bs[k] += v[k];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) tiles[arr * TL + (16 * mt + 4 * g + r) * TS + j] = v[k][r];
+                }
+                __syncthreads();
+                if (item + (int)gridDim.x < total) load(item + gridDim.x);
+                const f4 bX = tile_read_s<TS>(tiles + 4 * TL, wave, g, j), bH = tile_read_s<TS>(tiles + 5 * TL, wave, g, j);
+#pragma unroll
+                for (int gate = 0; gate < 3; ++gate)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        const f4 aI = tile_read_s<TS>(tiles + gate * TL, mt, g, j);
+                        const f4 aH = gate == 2 ? tile_read_s<TS>(tiles + 3 * TL, mt, g, j) : aI;
+#pragma unroll
+                        for (int ks = 0; ks < 4; ++ks) {
+                            dWa[gate][mt] = MARL_MFMA(aI[ks], bX[ks], dWa[gate][mt]);
+                            dWb[gate][mt] = MARL_MFMA(aH[ks], bH[ks], dWb[gate][mt]);
+                        }
+                    }
+                __syncthreads();  // tiles are rewritten by the next item
+            }
+#pragma unroll
+            for (int gate = 0; gate < 3; ++gate)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int vv = gate * H + 16 * mt + 4 * g + r;
+                        recd[S::oWih + vv * H + 16 * wave + j] = dWa[gate][mt][r];
+                        recd[S::oWhh + vv * H + 16 * wave + j] = dWb[gate][mt][r];
+                    }
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const int u = wave * 6 + k, arr = u >> 2, mt = u & 3;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float sv = sum16(bs[k][r]);
+                    const int vv = 16 * mt + 4 * g + r;
+                    if (j == 0 && arr < 4) {
+                        if (arr < 2) { recd[S::obih + arr * H + vv] = sv; recd[S::obhh + arr * H + vv] = sv; }  // gates r, z: dgi == dgh
+                        else if (arr == 2) recd[S::obih + 2 * H + vv] = sv;                                         // dn
+                        else recd[S::obhh + 2 * H + vv] = sv;                                                       // r * dn
+                    }
+                }
+            }
+            return;
+        }
+        if (wave >= 2) return;  // the gate biases were summed by the gate workgroup
+    }
     if (role < 3) {
         // ---- gate `role`: dW_ih[gate rows][my columns] += dgi^T x1, dW_hh[...] += dgh^T h_prev
         const int nt0 = wave * MTN;

@@ -55,7 +55,7 @@ void gru_set_attrs() {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_seq_bwd_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)(GruBwd<S>::LDS_FLOATS * sizeof(float)));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_wgrad_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)((4 * 16 * S::H + 256) * sizeof(float)));
+                              (int)gru_wgrad_lds_bytes<S>());
     done.done();
 }
 
@@ -125,7 +125,7 @@ int gru_backward_rows(int P, const AgentMap& am, const float* params, const marl
     }
     hipLaunchKernelGGL((gru_seq_bwd_kernel<S>), gridS, dim3(256), Bk::LDS_FLOATS * sizeof(float), st, (const float*)f(wl.packB), steps, B, rec, dout,
                        f(wl.rec2));
-    hipLaunchKernelGGL((gru_wgrad_kernel<S>), dim3(wl.nwg, P, 4), dim3(256), (4 * 16 * S::H + 256) * sizeof(float), st, steps, B, bt->obss, as, rs, rec,
+    hipLaunchKernelGGL((gru_wgrad_kernel<S>), dim3(wl.nwg, P, gru_wgrad_roles<S>()), dim3(256), gru_wgrad_lds_bytes<S>(), st, steps, B, bt->obss, as, rs, rec,
                        (const float*)f(wl.rec2), dout, lrow, bt->filled, steps, f(wl.partials));
     MARL_CHECK_LAUNCH("gru backward rows");
     const int n = am.nblk * S::NPARAM;  // one gradient block per NETWORK: a shared network's agents are summed by the reduce
