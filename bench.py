@@ -355,8 +355,12 @@ def main():
     dev_index = 0 if os.environ.get("MARLHIP_BENCH_ONE_DEVICE") else local_rank
     torch.cuda.set_device(dev_index)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("MARLHIP_BENCH_FORCE_DIST"):  # FORCE_DIST: the N > 1 code path (RCCL all-reduce per update) with one rank, to time its host side
         import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         kw = {"device_id": torch.device("cuda", dev_index)} if backend == "nccl" else {}

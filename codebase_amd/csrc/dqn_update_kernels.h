@@ -953,10 +953,10 @@ static __global__ __launch_bounds__(1024) void adam_fused_kernel(int64_t n, floa
 // loss/grad launch stages (marlhip_idqn_update_n keeps the packs alive between updates, so dqn_pack_kernel runs once per call
 // instead of once per update).  sumsq: per-block partials of dqn_reduce_sq_kernel (nsq of them).
 template <class S>
-static __global__ __launch_bounds__(256) void adam_pack_kernel(int n, int nsq, float* __restrict__ params, const float* __restrict__ grad,
-                                                        float* __restrict__ m, float* __restrict__ v, float* __restrict__ target,
-                                                        AdamArgs a, const float* __restrict__ sumsq, float* __restrict__ gnorm_out,
-                                                        AgentMap am, int P, float* __restrict__ packs) {
+__device__ __forceinline__ void adam_pack_body(int i, int n, int nsq, float* __restrict__ params, const float* grad,
+                                               float* __restrict__ m, float* __restrict__ v, float* __restrict__ target,
+                                               const AdamArgs& a, const float* sumsq, float* __restrict__ gnorm_out,
+                                               const AgentMap& am, int P, float* __restrict__ packs) {
     constexpr int TOT = 2 * S::NFWD + S::NBWD;
     __shared__ float s_coef;
     __shared__ float s_red[4];
@@ -974,8 +974,7 @@ static __global__ __launch_bounds__(256) void adam_pack_kernel(int n, int nsq, f
         if (gnorm_out != nullptr && blockIdx.x == 0) gnorm_out[0] = total;
     }
     __syncthreads();
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+    if (i < 0 || i >= n) return;
     const float gv = (grad[i] * a.grad_scale) * s_coef;
     float mi = m[i], vi = v[i];
     mi = mi + a.w1 * (gv - mi);
@@ -1003,6 +1002,19 @@ static __global__ __launch_bounds__(256) void adam_pack_kernel(int n, int nsq, f
         if (tgt) pk[S::NFWD + fwd] = ti;
     }
 }
+
+template <class S>
+static __global__ __launch_bounds__(256) void adam_pack_kernel(int n, int nsq, float* __restrict__ params, const float* __restrict__ grad,
+                                                        float* __restrict__ m, float* __restrict__ v, float* __restrict__ target,
+                                                        AdamArgs a, const float* __restrict__ sumsq, float* __restrict__ gnorm_out,
+                                                        AgentMap am, int P, float* __restrict__ packs) {
+    adam_pack_body<S>(blockIdx.x * 256 + threadIdx.x, n, nsq, params, grad, m, v, target, a, sumsq, gnorm_out, am, P, packs);
+}
+
+// (Measured and dropped, r02: the same epilogue as ONE launch - reduce, a grid barrier, then Adam + packs in the same workgroups.
+// Through hipLaunchCooperativeKernel the launch itself costs ~30 us (bench 27.1 -> 21.8 M env-steps/s); with a hand-rolled barrier
+// on a plain launch (agent-scope release / acquire around an atomic arrival counter) the L2 write-back + invalidate of the fences
+// costs more than the kernel boundary it replaces (27.1 -> 26.3 M; 0.92 -> 0.75 M at the reference cadence).  Two launches it is.)
 
 struct UpdPlan {
     int nwg, n_chunks;
