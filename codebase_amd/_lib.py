@@ -131,6 +131,13 @@ PROTOTYPES = {
     "marlhip_sample_from_logits": (c_int32, [c_int32, c_int32, c_int32, c_void_p, c_uint64, c_void_p, c_int32, c_void_p, c_void_p]),
     "marlhip_act_from_q": (c_int32, [c_int32, c_int32, c_int32, c_void_p, c_float, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "marlhip_net_nparams": (c_int32, [POINTER(NetShape)]),
+    "marlhip_wide_nparams": (c_int32, [POINTER(NetShape), c_int32]),
+    "marlhip_wide_forward_workspace_bytes": (c_int64, [POINTER(NetShape), c_int32]),
+    "marlhip_wide_forward": (c_int32, [POINTER(NetShape), c_int32, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_void_p, c_void_p, c_int64,
+                                       c_void_p]),
+    "marlhip_wide_dqn_workspace_bytes": (c_int64, [POINTER(NetShape), c_int32, c_int32]),
+    "marlhip_wide_dqn_loss_grad": (c_int32, [POINTER(NetShape), c_void_p, c_void_p, POINTER(BatchStruct), c_float, c_int32, c_int32, c_void_p,
+                                             c_int64, c_void_p, c_void_p, c_void_p]),
     "marlhip_dqn_act": (c_int32, [POINTER(NetShape), c_void_p, c_void_p, c_int32, c_float, c_void_p, c_void_p, c_uint64,
                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "marlhip_replay_init_episode": (c_int32, [POINTER(ReplayShape), POINTER(ReplayBuffers), c_void_p, c_void_p, c_void_p,

@@ -52,9 +52,9 @@ class A2CNetwork:
         ha, hc = [int(h) for h in _get(actor, "layers")], [int(h) for h in _get(critic, "layers")]
         if self.recurrent and (ha != hc or ha not in ([64, 64], [128, 128])):
             raise NotImplementedError(f"use_rnn with layers actor={ha} critic={hc}: the recurrent kernels are built for [64, 64] / [128, 128]")
-        # any two-layer widths up to 128, actor and critic independently: zero-padded to one compiled width (dqn/model.py pad_blocks)
+        # any two-layer widths, actor and critic independently: zero-padded to one kernel width (dqn/model.py pad_blocks; > 128: the GEMM path)
         Hk = max(compiled_width(ha), compiled_width(hc))
-        if bool(_get(critic, "centralised", False)) and not self.recurrent and (P, obs_dims[0]) in _FUSED_CENTRALISED_128:
+        if bool(_get(critic, "centralised", False)) and not self.recurrent and Hk <= 128 and (P, obs_dims[0]) in _FUSED_CENTRALISED_128:
             Hk = 128  # fused centralised-critic kernels for 3 / 4 agents exist at width 128 only (a2c.hip MARL_MAC_SHAPES); every other
             #           (agents, observation width) runs the critics on the wide path (csrc/wide_mlp.h) at the compiled width of the layers
         self.live_hidden = {"actor": tuple(ha), "critic": tuple(hc), "target_critic": tuple(hc)}
@@ -72,7 +72,7 @@ class A2CNetwork:
         self.target_update_interval_or_tau = _get(cfg, "target_update_interval_or_tau", 200)
         self.standardise_returns = bool(_get(cfg, "standardise_returns", False))
         self.centralised_critic = bool(_get(critic, "centralised", False))  # MAA2C / MAPPO (model.py:62-66)
-        self.spec = _hip.NetSpec(P, obs_dims[0], Hk, act_dims[0], self.sharing)
+        self.spec = _hip.NetSpec(P, obs_dims[0], Hk, act_dims[0], self.sharing, wide=Hk > 128)  # > 128: actors and critics on the GEMM path
         if self.sharing is not None:  # one network per distinct index, in order of first appearance (utils/models.py:209-240)
             first = [self.sharing.index(k) for k in range(max(self.sharing) + 1)]
             obs_dims, act_dims = [obs_dims[i] for i in first], [act_dims[i] for i in first]

@@ -39,7 +39,7 @@ class ActorNetworks:
 
 
 def _collect_trajectories_recurrent(envs, model, T, use_proper_termination, round_idx):
-    """_collect_trajectories (ac/train.py:24-119) with recurrent actors: the hidden state lives between steps, so the rollout runs
+    """_collect_trajectories (ac/train.py:24-119) with recurrent actors (or actors wider than the fused collector's): the hidden state lives between steps, so the rollout runs
     through the modular entry points - sequence kernel with one step -> Philox inverse-CDF sample -> auto-resetting vector-env
     step -> masked writes of the still-running envs.  Same streams as the fused collector: reset from episode 2 * round, action
     noise keyed on it, the auto-reset observation from 2 * round + 1."""
@@ -60,8 +60,12 @@ def _collect_trajectories_recurrent(envs, model, T, use_proper_termination, roun
     running = torch.ones(N, dtype=torch.bool, device=dev)
     hid, t = None, 0
     while t < T:
-        logits, hid = _hip.gru_ac_forward(model.spec, model.actor_params, obs, N * D, D, 1, N, h_in=hid, want_h=True)
-        acts = _hip.sample_from_logits(logits[:, 0], cfg.seed, noise_episode, t)
+        if getattr(model, "recurrent", False):
+            logits, hid = _hip.gru_ac_forward(model.spec, model.actor_params, obs, N * D, D, 1, N, h_in=hid, want_h=True)
+            logits = logits[:, 0]
+        else:  # feed-forward actors without a fused collector (layers wider than 128): the GEMM path's logits, no state
+            logits = _hip.ac_forward_rows(model.spec, model.actor_params, obs.contiguous(), N * D, D, N)
+        acts = _hip.sample_from_logits(logits, cfg.seed, noise_episode, t)
         obs, rew, done, trunc = env.step(acts.to(torch.int32), auto_reset=True)
         fin = (done | trunc) > 0
         stored = (done > 0) if use_proper_termination else fin
@@ -96,7 +100,7 @@ def _collect_trajectories(envs, model, max_ep_length, parallel_envs, n_agents, d
     fin_ret = torch.zeros(P, N, device=dev)
     fin_len = torch.zeros(N, dtype=torch.int32, device=dev)
     t_max = torch.zeros(1, dtype=torch.int32, device=dev)
-    if getattr(model, "recurrent", False):
+    if getattr(model, "recurrent", False) or model.spec.wide:  # no fused collector for these: the modular loop
         t, batch, fin_ret, fin_len = _collect_trajectories_recurrent(envs, model, T, use_proper_termination, round_idx)
     else:
         _hip.ac_collect(cfg, model.spec, model.actor_params, round_idx, T, use_proper_termination, b_obs, b_act, b_rew, b_done,

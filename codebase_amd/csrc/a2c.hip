@@ -34,15 +34,29 @@ static bool mac_compiled(const marlhip_net_shape* s) {
     return false;
 }
 
+// actors (and independent critics) with fused kernels; every other two-layer shape runs BOTH networks on the GEMM path of
+// wide_mlp.h (hidden > 128, observation widths / action counts outside MARL_AC_SHAPES): slower, any size
+static bool ac_compiled(const marlhip_net_shape* s) {
+#define X(d, h, a) if (s->obs_dim == d && s->hidden == h && s->n_actions == a) return true;
+    MARL_AC_SHAPES(X)
+#undef X
+    return false;
+}
+
 static int ac_check(const marlhip_net_shape* s, int centralised = 0) {
+    (void)centralised;
     MARL_REQUIRE(s != nullptr, "net shape is NULL");
     if (agent_map_validate(s) != 0) return -1;
     MARL_REQUIRE(s->n_agents >= 1, "ac: no agents");
-#define X(d, h, a) if (s->obs_dim == d && s->hidden == h && s->n_actions == a) return 0;
-    MARL_AC_SHAPES(X)
-#undef X
-    set_error("no actor-critic kernels for obs_dim %d hidden %d actions %d (add the triple to MARL_AC_SHAPES)", s->obs_dim, s->hidden, s->n_actions);
-    return -1;
+    MARL_REQUIRE(s->obs_dim >= 1 && s->hidden >= 1 && s->hidden <= 1024 && s->n_actions >= 1 && s->n_actions <= 64,
+                 "ac: net shape D=%d H=%d A=%d out of range", s->obs_dim, s->hidden, s->n_actions);
+    return 0;
+}
+
+// the run-time shapes of the all-GEMM step: actor D -> H -> H -> A, critic (P * D or D) -> H -> H -> 1
+static void wide_set(const marlhip_net_shape* s, int centralised) {
+    WideRt<0>::set(s->obs_dim, s->hidden, s->n_actions);
+    WideRt<1>::set(centralised ? s->n_agents * s->obs_dim : s->obs_dim, s->hidden, 1);
 }
 
 extern "C" int marlhip_ac_critic_nparams(const marlhip_net_shape* s, int32_t centralised) {
@@ -53,6 +67,7 @@ extern "C" int marlhip_ac_critic_nparams(const marlhip_net_shape* s, int32_t cen
 #undef X
     }
     if (centralised) return (int)WideNet{s->n_agents * s->obs_dim, s->hidden, 1}.nparam();
+    if (!ac_compiled(s)) return (int)WideNet{s->obs_dim, s->hidden, 1}.nparam();
 #define X(d, h, a) if (s->obs_dim == d && s->hidden == h && s->n_actions == a) return MlpShape<d, h, 1>::NPARAM;
     MARL_AC_SHAPES(X)
 #undef X
@@ -67,6 +82,10 @@ extern "C" int64_t marlhip_ac_workspace_bytes(const marlhip_net_shape* s, int32_
         return ac_ws_layout<MlpShape<d, h, 6>, MlpShape<p * d, h, 1>>(s->n_agents, max_len, batch).total;
         MARL_MAC_SHAPES(X)
 #undef X
+    }
+    if (!ac_compiled(s)) {
+        wide_set(s, centralised);
+        return ac_ws_layout<WideRt<0>, WideRt<1>>(s->n_agents, max_len, batch).total;
     }
     if (centralised) {
 #define X(d, h, a)                                                       \
@@ -97,6 +116,12 @@ static int ac_call(const marlhip_net_shape* s, const float* actor, const float* 
     MARL_REQUIRE((c->ret_mean == nullptr) == (c->ret_var == nullptr) && (c->ret_mean == nullptr) == (c->ret_count == nullptr),
                  "ac_loss_grad: return statistics must be given together (mean, var, count) or not at all");
 #define MARL_AC_ARGS s->n_agents, agent_map(s), actor, critic, target, bt, c, mode, ws, ws_bytes, actor_grad, critic_grad, metrics, (hipStream_t)stream
+    if (!ac_compiled(s)) {  // both networks on the GEMM path
+        MARL_REQUIRE(!c->centralised_critic || (bt->obs_row_stride == (int64_t)s->n_agents * s->obs_dim && bt->obs_agent_stride == s->obs_dim),
+                     "ac_loss_grad: a centralised critic needs the ac/train.py Batch layout (agents concatenated in a row)");
+        wide_set(s, c->centralised_critic);
+        return ac_step_t<WideRt<0>, WideRt<1>>(MARL_AC_ARGS);
+    }
     if (c->centralised_critic) {
         MARL_REQUIRE(bt->obs_row_stride == (int64_t)s->n_agents * s->obs_dim && bt->obs_agent_stride == s->obs_dim,
                      "ac_loss_grad: a centralised critic needs the ac/train.py Batch layout (agents concatenated in a row)");
@@ -137,14 +162,9 @@ extern "C" int marlhip_ac_forward_rows(const marlhip_net_shape* s, int32_t value
         MARL_MAC_SHAPES(X)
 #undef X
     }
-    if (value_net == 2) {  // the wide path; hidden 64 / 128 as the actors' kernels
-        MARL_REQUIRE(s->hidden == 64 || s->hidden == 128, "ac_forward_rows: centralised critics are built for hidden 64 / 128");
-        if (s->hidden == 64) {
-            WideCritic<64>::D = s->n_agents * s->obs_dim;
-            return launch_forward_rows<WideCritic<64>>(s->n_agents, agent_map(s), params, &bt, n_rows, out, (hipStream_t)stream);
-        }
-        WideCritic<128>::D = s->n_agents * s->obs_dim;
-        return launch_forward_rows<WideCritic<128>>(s->n_agents, agent_map(s), params, &bt, n_rows, out, (hipStream_t)stream);
+    if (value_net == 2 || !ac_compiled(s)) {  // the GEMM path: any input / hidden width
+        WideRt<1>::set(value_net == 2 ? s->n_agents * s->obs_dim : s->obs_dim, s->hidden, value_net ? 1 : s->n_actions);
+        return launch_forward_rows<WideRt<1>>(s->n_agents, agent_map(s), params, &bt, n_rows, out, (hipStream_t)stream);
     }
 #define X(d, h, a)                                                                                                         \
     if (s->obs_dim == d && s->hidden == h && s->n_actions == a)                                                             \

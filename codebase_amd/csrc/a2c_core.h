@@ -15,10 +15,20 @@ struct WideCritic {
     static inline thread_local int D = 0;
     static WideNet net() { return WideNet{D, H, A}; }
 };
+// both widths, inputs and outputs at run time (actors AND critics without a fused kernel: hidden > 128, other observation widths);
+// TAG keeps the actor's and the critic's thread-local shapes apart
+template <int TAG>
+struct WideRt {
+    static inline thread_local int D = 0, H = 0, A = 0;
+    static WideNet net() { return WideNet{D, H, A}; }
+    static void set(int d, int h, int a) { D = d; H = h; A = a; }
+};
 template <class S>
 struct IsWide : std::false_type {};
 template <int H>
 struct IsWide<WideCritic<H>> : std::true_type {};
+template <int TAG>
+struct IsWide<WideRt<TAG>> : std::true_type {};
 
 // bytes of forward-pack scratch (collect_pack_scratch) a forward-rows launch of shape S over n_rows rows wants
 template <class S>
@@ -153,7 +163,7 @@ int launch_backward_rows(int P, const AgentMap& am, const float* params, const m
         MARL_REQUIRE(ws_bytes >= backward_ws_bytes<S>(P, T, B), "ac backward: workspace %lld too small", (long long)ws_bytes);
         const int64_t as = bt->obs_agent_stride > 0 ? bt->obs_agent_stride : (bt->obs_agent_stride < 0 ? 0 : (int64_t)(T + 1) * B * s.D);
         const int64_t rs = bt->obs_row_stride ? bt->obs_row_stride : s.D;
-        return wide_backward_rows(s, P, am, params, bt->obss, as, rs, T * B, bt->filled, dout, lrow, ws, grad, loss, st);
+        return wide_backward_rows(s, P, am, params, bt->obss, as, rs, T * B, bt->filled, dout, (int64_t)T * B * s.A, lrow, ws, grad, loss, st);
     } else {
     (void)rec;
     const int T = bt->max_len, B = bt->batch;
@@ -443,8 +453,7 @@ AcWs ac_ws_layout(int P, int T, int B) {
 template <class SA, class SC>
 int ac_step_t(int P, const AgentMap& am, const float* actor, const float* critic, const float* target, const marlhip_batch* bt, const marlhip_ac_config* c,
               int mode, void* ws, int64_t ws_bytes, float* actor_grad, float* critic_grad, float* metrics, hipStream_t st) {
-    constexpr int D = SA::D, A = SA::A;
-    const int DC = SC::D;  // (a run-time value for the wide critics)
+    const int D = SA::D, A = SA::A, DC = SC::D;  // (run-time values for the wide networks)
     const int T = bt->max_len, B = bt->batch, TB = T * B;
     marlhip_batch btc = *bt;  // the critics' view of the batch
     if (DC != D) btc.obs_agent_stride = -1;

@@ -10,6 +10,7 @@
 //                        transposed through LDS tiles as in the feed-forward kernels; one partial record per workgroup,
 //                        summed in fixed order by dqn_reduce_kernel.
 #pragma once
+#include "td_rows.h"
 #include "dqn_update_kernels.h"
 #include "gru.h"
 
@@ -47,52 +48,6 @@ template <class S>
 __global__ __launch_bounds__(256) void gru_bwd_pack_kernel(const float* __restrict__ params, AgentMap am, float* __restrict__ packs) {
     const int p = blockIdx.y, idx = blockIdx.x * 256 + threadIdx.x;
     if (idx < GruBwd<S>::NBWD) packs[(size_t)p * GruBwd<S>::NBWD + idx] = gru_bwd_pack_elem<S>(params + (size_t)am.net[p] * S::NPARAM, idx);
-}
-
-// q, tq: [P][T+1][B][A]; dq: [P][T+1][B][A] (row T stays zero); lrow: [T][B]
-static __global__ __launch_bounds__(256) void gru_td_kernel(int P, int T, int B, int A, const float* __restrict__ q, const float* __restrict__ tq,
-                                                     marlhip_batch bt, float gamma, int double_q, int vdn, float* __restrict__ dq,
-                                                     float* __restrict__ lrow) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= T * B) return;
-    const int t = i / B, b = i - t * B;
-    const float fl = bt.filled[i], dn = bt.dones[(size_t)(t + 1) * B + b];
-    float tot_ch = 0.f, tot_tq = 0.f, loss = 0.f;
-    for (int p = 0; p < P; ++p) {
-        const float* qn = q + (((size_t)p * (T + 1) + t + 1) * B + b) * A;
-        const float* tn = tq + (((size_t)p * (T + 1) + t + 1) * B + b) * A;
-        const float* mk = bt.action_mask ? bt.action_mask + (((size_t)p * (T + 1) + t + 1) * B + b) * A : nullptr;
-        int best = 0;
-        float bv = -__builtin_huge_valf();
-        for (int a = 0; a < A; ++a) {  // first index of the maximum (torch.argmax), over the online (Double-Q) or target values
-            float v = double_q ? qn[a] : tn[a];
-            if (mk != nullptr && mk[a] == 0.f) v = -1e8f;
-            if (v > bv) { bv = v; best = a; }
-        }
-        float boot = tn[best];
-        if (mk != nullptr && mk[best] == 0.f) boot = -1e8f;
-        const int act = (int)bt.actions[((size_t)p * T + t) * B + b];
-        const float ch = q[(((size_t)p * (T + 1) + t) * B + b) * A + act];
-        if (vdn) {
-            tot_ch += ch;
-            tot_tq += boot;
-        } else {
-            const float y = bt.rewards[((size_t)p * T + t) * B + b] + gamma * boot * (1.f - dn);
-            const float delta = ch - y;
-            loss += delta * delta;
-            for (int a = 0; a < A; ++a) dq[(((size_t)p * (T + 1) + t) * B + b) * A + a] = a == act ? 2.f * fl * delta : 0.f;
-        }
-    }
-    if (vdn) {
-        const float y = bt.rewards[(size_t)t * B + b] + gamma * tot_tq * (1.f - dn);  // batch.rewards[0] (model.py:228)
-        const float delta = tot_ch - y;
-        loss = delta * delta;
-        for (int p = 0; p < P; ++p) {
-            const int act = (int)bt.actions[((size_t)p * T + t) * B + b];
-            for (int a = 0; a < A; ++a) dq[(((size_t)p * (T + 1) + t) * B + b) * A + a] = a == act ? 2.f * fl * delta : 0.f;
-        }
-    }
-    lrow[i] = fl * loss;
 }
 
 // transposed product: out[mt1] += sum_{gate-unit tiles mt2, r} T[gate][mt1][mt2][lane][r] * dg[mt2][r]

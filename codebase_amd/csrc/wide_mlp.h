@@ -232,11 +232,12 @@ inline int wide_forward_rows(const WideNet& s, int P, const AgentMap& am, const 
     return 0;
 }
 
-// grad[blk][nparam] = d(sum_rows <dout row, MLP(x row)>)/dparams / sum(filled); dout [P][rows][A] (already masked by filled);
+// grad[blk][nparam] = d(sum_rows <dout row, MLP(x row)>)/dparams / sum(filled); dout: agent p's [rows][A] at dout + p * dout_agent_stride
+// (already masked by filled);
 // loss[0] = sum(lrow) / sum(filled), loss[1] = sum(filled).  ws: wide_ws(.., true).total bytes.
 inline int wide_backward_rows(const WideNet& s, int P, const AgentMap& am, const float* params, const float* obs, int64_t agent_stride,
-                              int64_t row_stride, int rows, const float* filled, const float* dout, const float* lrow, void* ws, float* grad,
-                              float* loss, hipStream_t st) {
+                              int64_t row_stride, int rows, const float* filled, const float* dout, int64_t dout_agent_stride,
+                              const float* lrow, void* ws, float* grad, float* loss, hipStream_t st) {
     const WideWs w = wide_ws(s, P, rows, true);
     char* base = static_cast<char*>(ws);
     auto f = [&](int64_t off) { return reinterpret_cast<float*>(base + off); };
@@ -247,7 +248,7 @@ inline int wide_backward_rows(const WideNet& s, int P, const AgentMap& am, const
     for (int p = 0; p < P; ++p) {
         const float* prm = params + (int64_t)am.net[p] * s.nparam();
         const float* x = obs + (int64_t)p * agent_stride;
-        const float* dq = dout + (int64_t)p * rows * A;
+        const float* dq = dout + (int64_t)p * dout_agent_stride;
         float* gpp = gp + (int64_t)p * s.nparam();
         wide_hidden(s, prm, x, row_stride, rows, y1, y2, st);
         // weight gradient of a layer: dW[out][in] (+ bias column) = dY^T [Yprev | 1], rows sliced over grid.z, then the fold

@@ -109,19 +109,20 @@ def _tensor_layout(D, H, A):
 
 
 # ---- hidden widths other than the compiled ones -------------------------------------------------------------------------------
-# The kernels are instantiated for two equal hidden layers of 64 or 128 units.  A two-layer list [h1, h2] with h1, h2 <= 128 runs
-# EXACTLY on the next compiled width H by zero padding: a padded unit has zero weights and bias, so its activation is relu(0) = 0,
+# The fused kernels are instantiated for two equal hidden layers of 64 or 128 units; wider layers (up to 1024, e.g. [256, 256]) run on
+# the GEMM path (csrc/wide_mlp.h, marlhip_wide_*: slower, any width) at max(h1, h2) rounded up to 16.  A two-layer list [h1, h2] runs
+# EXACTLY on the kernel width H >= h1, h2 by zero padding: a padded unit has zero weights and bias, so its activation is relu(0) = 0,
 # its relu mask is 0, every gradient that touches a padded entry is a product with one of those zeros, and Adam maps a zero gradient
 # with zero moments to a zero step - the padding stays zero for the whole run, the live sub-network computes what FCNetwork([h1, h2])
 # computes (utils/models.py:34-48), and state_dict exposes the live tensors in the reference's shapes.
 def compiled_width(hidden):
     """(h1, h2) -> the compiled kernel width they run on, or raise"""
     if len(hidden) != 2:
-        raise NotImplementedError(f"layers={list(hidden)}: the HIP kernels implement two hidden layers (widths up to 128)")
+        raise NotImplementedError(f"layers={list(hidden)}: the HIP kernels implement two hidden layers")
     h = max(hidden)
-    if min(hidden) < 1 or h > 128:
-        raise NotImplementedError(f"layers={list(hidden)}: hidden widths 1..128 (padded to the compiled 64 / 128)")
-    return 64 if h <= 64 else 128
+    if min(hidden) < 1 or h > 1024:
+        raise NotImplementedError(f"layers={list(hidden)}: hidden widths 1..1024")
+    return 64 if h <= 64 else 128 if h <= 128 else (h + 15) // 16 * 16  # > 128: the GEMM path (NetSpec.wide)
 
 
 def pad_blocks(flat, D, h1, h2, A, H):
@@ -181,7 +182,9 @@ class QNetwork:
         self.n_agents = len(obs_dims)
         self.device = torch.device(device)
         self.sharing = sharing_indices(parameter_sharing, self.n_agents)
-        self.spec = _hip.NetSpec(self.n_agents, obs_dims[0], hidden_k[0], act_dims[0], self.sharing)
+        self.spec = _hip.NetSpec(self.n_agents, obs_dims[0], hidden_k[0], act_dims[0], self.sharing, wide=Hk > 128)
+        if self.spec.wide and (self.standardise_returns or type(self).__name__ == "QMixNetwork"):
+            raise NotImplementedError(f"layers={hidden}: layers wider than 128 run IDQN / VDN without return standardisation (the GEMM path)")
         if self.recurrent:  # RNNNetwork (utils/models.py:51-116): Linear -> ReLU -> GRU -> Linear
             self.nparams = _hip.gru_nparams(self.spec)
             critic, target = init_flat_gru_params(obs_dims, hidden[0], act_dims, use_orthogonal_init, self.sharing)
@@ -197,7 +200,7 @@ class QNetwork:
         self.grad_clip = get("grad_clip", 1.0)
         self.double_q = bool(get("double_q", True))
         self.target_update_interval_or_tau = get("target_update_interval_or_tau", 200)
-        self.updater = (_hip.GruUpdater if self.recurrent else _hip.DqnUpdater)(self.spec, self.params, self.target_params, lr=float(get("lr", 3e-4)),
+        self.updater = (_hip.GruUpdater if self.recurrent else _hip.WideDqnUpdater if self.spec.wide else _hip.DqnUpdater)(self.spec, self.params, self.target_params, lr=float(get("lr", 3e-4)),
                                        gamma=self.gamma, grad_clip=self.grad_clip, double_q=self.double_q,
                                        standardise_returns=self.standardise_returns)
         self.updates = 0
@@ -228,6 +231,8 @@ class QNetwork:
         if self.recurrent:
             q, h = _hip.gru_forward(self.spec, self.params, obs.unsqueeze(1).contiguous(), h_in=hiddens, want_h=True)
             return q[:, 0], h
+        if self.spec.wide:
+            return _hip.wide_forward(self.spec, self.params, obs.contiguous())
         q = torch.empty(obs.shape[0], obs.shape[1], self.spec.n_actions, device=obs.device)
         n = obs.shape[1]
         _hip.dqn_act(self.spec, self.params, obs, 0.0, u=torch.ones(n, device=obs.device),
@@ -261,11 +266,15 @@ class QNetwork:
             q = self.q_values(self._obs1)[:, 0]
             m = torch.as_tensor(np.asarray(action_masks, np.float32)).to(q.device)
             return [int(a) for a in (q * m + (1 - m) * -1e8).argmax(-1).tolist()], hiddens
+        if self.spec.wide:  # no fused act kernel for this shape: values from the GEMM path, first maximum (torch.argmax)
+            return [int(a) for a in self.q_values(self._obs1)[:, 0].argmax(-1).tolist()], hiddens
         acts = _hip.dqn_act(self.spec, self.params, self._obs1, 0.0, u=self._u1, rand_actions=self._ra1)
         return [int(a) for a in acts[:, 0].tolist()], hiddens
 
     def act_batched(self, obs, epsilon, seed, episode, ep_length):
         """N envs on the device, Philox noise keyed like the fused collector."""
+        if self.spec.wide:
+            return _hip.act_from_q(self.q_values(obs), epsilon, seed, episode, ep_length)
         return _hip.dqn_act(self.spec, self.params, obs, epsilon, seed=seed, episode=episode, ep_length=ep_length)
 
     def _to_device_batch(self, batch):

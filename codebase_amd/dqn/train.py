@@ -183,7 +183,8 @@ class VectorisedIDQN:
         alive = torch.ones(N, dtype=torch.uint8, device=dev)
         hid = None
         for _ in range(T):
-            q, hid = m.q_values(obs, hid)
+            out = m.q_values(obs, hid)
+            q, hid = out if isinstance(out, tuple) else (out, None)  # feed-forward networks on the GEMM path carry no state
             acts = _hip.act_from_q(q, epsilon, cfg.seed, env.episode, env.ep_length)
             tt = env.ep_length.clone()
             obs, rew, done, trunc = env.step(acts, active=alive)
@@ -198,7 +199,7 @@ class VectorisedIDQN:
         """collect N episodes (one launch), then U updates; nothing here synchronises with the host."""
         m = self.model
         slot_base = (self.rounds * self.N) % self.capacity
-        if getattr(m, "recurrent", False):
+        if getattr(m, "recurrent", False) or m.spec.wide:  # no fused collector: the modular loop
             self._collect_recurrent(self.cfg, epsilon, self.rounds, self.replay, slot_base, self.fin_return, self.fin_length)
         else:
             _hip.idqn_collect(self.cfg, m.spec, m.params, epsilon, self.rounds, self.replay, slot_base, self.fin_return,
@@ -206,7 +207,7 @@ class VectorisedIDQN:
                               use_proper_termination=self.proper)
         self.env_steps += self.fin_length.sum()
         self.rounds += 1
-        if train and self.dist is None and self.U > 0 and m.mode != 2 and not m.standardise_returns and not _NO_FUSED_LOOP and not getattr(m, "recurrent", False):  # the n-updates library call has no mixer / no return statistics (those loop here)
+        if train and self.dist is None and self.U > 0 and m.mode != 2 and not m.standardise_returns and not _NO_FUSED_LOOP and not getattr(m, "recurrent", False) and not m.spec.wide:  # the n-updates library call has no mixer / no return statistics (those loop here)
             if self._fused is None:
                 self._fused = _hip.FusedLearner(m.updater, self.replay, self.B, m.target_update_interval_or_tau, mode=m.mode)
             length = min(self.rounds * self.N, self.capacity)
@@ -232,7 +233,7 @@ class VectorisedIDQN:
         dev = self.model.device
         ret = torch.zeros(self.model.n_agents, episodes, device=dev)
         ln = torch.zeros(episodes, dtype=torch.int32, device=dev)
-        if getattr(self.model, "recurrent", False):
+        if getattr(self.model, "recurrent", False) or self.model.spec.wide:
             self._collect_recurrent(cfg, epsilon, round_idx, None, 0, ret, ln)
         else:
             _hip.idqn_collect(cfg, self.model.spec, self.model.params, epsilon, round_idx, self.replay, 0, ret, ln,

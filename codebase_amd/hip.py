@@ -183,6 +183,7 @@ class NetSpec:
     hidden: int
     n_actions: int
     sharing: tuple = None  # agent -> network index (parameter sharing / SePS); None = independent networks
+    wide: bool = False     # no fused kernels for this shape (hidden > 128, ...): the GEMM path (marlhip_wide_*, csrc/wide_mlp.h)
 
     def c(self):
         s = NetShape(self.n_agents, self.obs_dim, self.hidden, self.n_actions)
@@ -200,7 +201,34 @@ class NetSpec:
 
     def nparams(self):
         s = self.c()
+        if self.wide:
+            return check(lib.marlhip_wide_nparams(ctypes.byref(s), self.n_actions), "wide_nparams")
         return check(lib.marlhip_net_nparams(ctypes.byref(s)), "net_nparams")
+
+
+_WIDE_WS = {}
+
+
+def wide_forward(spec: NetSpec, params, obs, n_out=None, agent_stride=None, row_stride=None, n_rows=None):
+    """networks without a fused kernel (spec.wide): out[p][row][:] = MLP_p(obs row) through the GEMM path.  obs f32 [P][N][D]
+    (or any layout given agent_stride / row_stride / n_rows) -> [P][N][n_out]"""
+    _require_gpu()
+    if n_rows is None:
+        P, n_rows, D = obs.shape
+        agent_stride, row_stride = n_rows * D, D
+    n_out = spec.n_actions if n_out is None else int(n_out)
+    s = spec.c()
+    key = (spec.n_agents, spec.obs_dim, spec.hidden, int(n_rows), params.device.index, torch.cuda.current_stream().cuda_stream)
+    ws = _WIDE_WS.get(key)
+    if ws is None:
+        if len(_WIDE_WS) > 32:
+            _WIDE_WS.clear()
+        n = check(lib.marlhip_wide_forward_workspace_bytes(ctypes.byref(s), int(n_rows)), "wide_forward_workspace_bytes")
+        ws = _WIDE_WS[key] = torch.empty(int(n), dtype=torch.uint8, device=params.device)
+    out = torch.empty(spec.n_agents, int(n_rows), n_out, device=params.device)
+    check(lib.marlhip_wide_forward(ctypes.byref(s), n_out, _ptr(params), _ptr(obs), int(agent_stride), int(row_stride), int(n_rows), _ptr(out),
+                                   _ptr(ws), ws.numel(), _stream()), "wide_forward")
+    return out
 
 
 def dqn_act(spec: NetSpec, params, obs, epsilon, u=None, rand_actions=None, seed=0, episode=None, ep_length=None,
@@ -377,6 +405,40 @@ class DqnUpdater:
                                         int(bool(hard_update)), float(tau), _ptr(self.scratch), _ptr(self.gnorm), _stream()),
               "dqn_clip_adam")
 
+
+
+class WideDqnUpdater(DqnUpdater):
+    """DqnUpdater for networks without a fused kernel (spec.wide): marlhip_wide_dqn_loss_grad (GEMM path + the TD stage of the
+    recurrent learner); sampling materialises the Batch first.  IDQN and VDN, no return standardisation."""
+
+    def __init__(self, spec, params, target, **kw):
+        if kw.get("standardise_returns"):
+            raise NotImplementedError("standardise_returns with layers wider than 128 (the GEMM path)")
+        super().__init__(spec, params, target, **kw)
+
+    def _workspace(self, T, B):
+        key = (T, B)
+        if key not in self._ws:
+            s = self.spec.c()
+            n = check(lib.marlhip_wide_dqn_workspace_bytes(ctypes.byref(s), T, B), "wide_dqn_workspace_bytes")
+            self._ws = {key: torch.empty(int(n), dtype=torch.uint8, device=self.params.device)}  # one shape alive: these are large
+        return self._ws[key]
+
+    def loss_grad(self, batch, mode=0):
+        if mode not in (0, 1):
+            raise NotImplementedError("QMIX with layers wider than 128: the mixer stage goes with the fused agent kernels")
+        T, B = batch.filled.shape
+        ws = self._workspace(T, B)
+        bs = BatchStruct(batch.obss.data_ptr(), batch.actions.data_ptr(), batch.rewards.data_ptr(), batch.dones.data_ptr(),
+                         batch.filled.data_ptr(), T, B, 0, 0, 0, 0, _mask_ptr(batch.action_mask, (self.spec.n_agents, T + 1, B, self.spec.n_actions)))
+        s = self.spec.c()
+        check(lib.marlhip_wide_dqn_loss_grad(ctypes.byref(s), _ptr(self.params), _ptr(self.target), ctypes.byref(bs), float(self.gamma),
+                                             self.double_q, int(mode), _ptr(ws), ws.numel(), _ptr(self.grad), _ptr(self.loss), _stream()),
+              "wide_dqn_loss_grad")
+        return self.loss, self.grad
+
+    def loss_grad_replay(self, replay, batch_size, length=None, idx=None, seed=0, counter=0, idx_out=None, mode=0):
+        return self.loss_grad(replay.sample(batch_size, length=length, idx=idx, seed=seed, counter=counter), mode=mode)
 
 class QmixUpdater(DqnUpdater):
     """QMixNetwork's learner step (marlbase/dqn/model.py:334-443): agent networks + monotonic mixer.  The mixer block is a

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MARLHIP_VERSION 200
+#define MARLHIP_VERSION 201
 
 int marlhip_version(void);
 const char* marlhip_last_error(void);
@@ -378,6 +378,27 @@ int marlhip_gru_ac_forward(const marlhip_net_shape* s, int32_t value_net, const 
  * it: inverse CDF of the fp32 softmax with the Philox uniform of (env n, episode[n], step t, word 1 + p).  actions: i64 [P][N]. */
 int marlhip_sample_from_logits(int32_t n_agents, int32_t n_envs, int32_t n_actions, const float* logits /* [P][N][A] */, uint64_t seed,
                                const uint32_t* episode /* [N] */, int32_t t, int64_t* actions, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Networks without a fused kernel: two hidden layers of ANY width (FCNetwork takes any list, marlbase/utils/models.py:14-48;
+ * hidden > 128 - e.g. layers [256, 256] - or an observation / action width outside the compiled lists).  The three layers run as
+ * f32 MFMA GEMMs over all rows with the activations in HBM (csrc/wide_mlp.h): slower than the fused kernels, any size.  Parameters
+ * in FCNetwork's parameters() order per block; net shape as everywhere (hidden = the width of both layers; unequal widths are
+ * zero-padded by the caller, which is exact).  marlhip_wide_forward serves QNetwork.act / get_value and the modular collectors
+ * (-> marlhip_act_from_q / marlhip_sample_from_logits); marlhip_wide_dqn_loss_grad is marlhip_dqn_loss_grad for such networks
+ * (mode 0 IDQN, 1 VDN; same batch, outputs and 1 / sum(filled) normalisation; marlhip_dqn_clip_adam applies it).  The actor-critic
+ * entry points (marlhip_a2c_loss_grad, marlhip_ppo_*, marlhip_ac_forward_rows, marlhip_ac_critic_nparams, marlhip_ac_workspace_bytes)
+ * take such shapes directly: a shape without fused kernels runs actors and critics on this path. */
+int marlhip_wide_nparams(const marlhip_net_shape* s, int32_t n_out /* outputs: n_actions, or 1 for a critic */);
+int64_t marlhip_wide_forward_workspace_bytes(const marlhip_net_shape* s, int32_t n_rows);
+int marlhip_wide_forward(const marlhip_net_shape* s, int32_t n_out, const float* params /* [blocks][marlhip_wide_nparams] */,
+                         const float* obs /* agent p, row r at obs + p * agent_stride + r * row_stride */, int64_t agent_stride,
+                         int64_t row_stride, int32_t n_rows, float* out /* [P][n_rows][n_out] */, void* workspace,
+                         int64_t workspace_bytes /* >= marlhip_wide_forward_workspace_bytes(s, n_rows) */, void* stream);
+int64_t marlhip_wide_dqn_workspace_bytes(const marlhip_net_shape* s, int32_t max_len, int32_t batch);
+int marlhip_wide_dqn_loss_grad(const marlhip_net_shape* s, const float* params, const float* target_params, const marlhip_batch* batch,
+                               float gamma, int32_t double_q, int32_t mode, void* workspace, int64_t workspace_bytes, float* grad,
+                               float* loss /* [2]: loss, sum(filled) */, void* stream);
 
 /* the action choice of QNetwork.act (dqn/model.py:105-115) from given values q [P][N][A] (the recurrent path computes them with
  * marlhip_gru_forward): explore iff epsilon > u with ONE Philox uniform per env (env n, episode[n], t = ep_length[n], word 0),

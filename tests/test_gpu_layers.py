@@ -25,7 +25,7 @@ def live_blocks(sd, prefix, P):
 
 
 @pytest.mark.parametrize("cls_name,mode", [("QNetwork", "idqn"), ("VDNetwork", "vdn")])
-@pytest.mark.parametrize("layers", [[32, 32], [48, 24], [96, 128], [128, 40]])
+@pytest.mark.parametrize("layers", [[32, 32], [48, 24], [96, 128], [128, 40], [256, 256], [200, 96]])  # > 128: the GEMM path
 def test_dqn_family_with_other_widths_matches_the_port_at_the_true_widths(cls_name, mode, layers):
     from codebase_amd import hip as h
     from codebase_amd.dqn import model as M
@@ -73,14 +73,15 @@ def test_layer_lists_the_kernels_do_not_cover_raise():
     from codebase_amd.dqn.model import QNetwork
     obs_space, act_space = spaces(2, 15, 6)
     hyper = dict(optimizer="Adam", lr=3e-4)
-    for layers in ([64], [64, 64, 64], [256, 256], [0, 64]):
+    for layers in ([64], [64, 64, 64], [2048, 2048], [0, 64]):
         with pytest.raises(NotImplementedError):
             QNetwork(obs_space, act_space, hyper, layers, False, False, True, DEV)
     with pytest.raises(NotImplementedError):  # recurrent: the GRU width is not padded
         QNetwork(obs_space, act_space, hyper, [32, 32], False, True, True, DEV)
 
 
-@pytest.mark.parametrize("layers,centralised,P", [([32, 48], False, 2), ([100, 20], False, 3), ([64, 64], True, 4), ([48, 48], True, 3)])
+@pytest.mark.parametrize("layers,centralised,P", [([32, 48], False, 2), ([100, 20], False, 3), ([64, 64], True, 4), ([48, 48], True, 3),
+                                                  ([256, 256], False, 2), ([160, 200], True, 3)])  # > 128: actors and critics on the GEMM path
 def test_actor_critic_with_other_widths_matches_the_port_at_the_true_widths(layers, centralised, P):
     """A2CNetwork with layers the kernels are not compiled for; [64, 64] centralised critics for 3 / 4 agents run padded to 128"""
     from codebase_amd.ac.model import A2CNetwork
@@ -133,3 +134,17 @@ def test_actor_and_critic_may_differ_in_width():
     v, _ = net.get_value(obs, None)
     ref = torch.cat([dp.mlp(live_blocks(sd, "critic", 2)[p], obs[p], 15, (128, 96), 1) for p in range(2)], dim=-1)
     np.testing.assert_allclose(v.cpu().numpy(), ref.numpy(), rtol=1e-5, atol=1e-5)
+
+
+def test_wide_layers_run_end_to_end(tmp_path, monkeypatch):
+    """layers [256, 256] through the reference-shaped drivers: modular collection (GEMM forward -> Philox action choice -> env step ->
+    replay add), the GEMM learner, evaluation, checkpoints in the reference's shapes"""
+    from codebase_amd import run
+    NAME = "lbforaging:Foraging-8x8-2p-3f-v3"
+    for algo, extra in (("idqn", ["algorithm.model.layers=[256,256]", "algorithm.batch_size=64"]),
+                        ("vdn", ["algorithm.model.layers=[192,256]", "algorithm.batch_size=64"]),
+                        ("ia2c", ["algorithm.model.actor.layers=[256,256]", "algorithm.model.critic.layers=[256,256]"])):
+        monkeypatch.setenv("MARLHIP_RUN_DIR", str(tmp_path / algo))
+        df = run.main([f"+algorithm={algo}", f"env.name={NAME}", "env.time_limit=25", "env.parallel_envs=256", "seed=1",
+                       "algorithm.total_steps=60000", "algorithm.eval_interval=20000"] + extra)
+        assert df.shape[0] >= 2 and np.isfinite(df["loss"].dropna()).all() and np.isfinite(df["mean_episode_returns"]).all()
