@@ -38,7 +38,7 @@ class LbfBuffers(ctypes.Structure):
 
 class NetShape(ctypes.Structure):
     _fields_ = [("n_agents", c_int32), ("obs_dim", c_int32), ("hidden", c_int32), ("n_actions", c_int32),
-                ("n_networks", c_int32), ("net_of", c_int32 * 16)]
+                ("n_networks", c_int32), ("net_of", c_int32 * 16), ("n_hidden", c_int32)]
 
 
 class ReplayShape(ctypes.Structure):

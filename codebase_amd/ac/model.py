@@ -20,7 +20,7 @@ import numpy as np
 import torch
 
 from .. import hip as _hip
-from ..dqn.model import _fc, _gru_layout, block_views, compiled_width, init_flat_gru_params, pad_blocks, sharing_indices
+from ..dqn.model import _fc, _gru_layout, block_views, compiled_width, init_flat_gru_params, is_wide, pad_blocks, sharing_indices
 from ..spaces import flatdim
 
 
@@ -54,7 +54,12 @@ class A2CNetwork:
             raise NotImplementedError(f"use_rnn with layers actor={ha} critic={hc}: the recurrent kernels are built for [64, 64] / [128, 128]")
         # any two-layer widths, actor and critic independently: zero-padded to one kernel width (dqn/model.py pad_blocks; > 128: the GEMM path)
         Hk = max(compiled_width(ha), compiled_width(hc))
-        if bool(_get(critic, "centralised", False)) and not self.recurrent and Hk <= 128 and (P, obs_dims[0]) in _FUSED_CENTRALISED_128:
+        wide = is_wide(ha) or is_wide(hc)
+        if len(ha) != len(hc):
+            raise NotImplementedError(f"layers actor={ha} critic={hc}: the same number of hidden layers for actor and critic")
+        if wide:
+            Hk = max(Hk, 144 if len(ha) == 2 else 16)
+        if bool(_get(critic, "centralised", False)) and not self.recurrent and not wide and (P, obs_dims[0]) in _FUSED_CENTRALISED_128:
             Hk = 128  # fused centralised-critic kernels for 3 / 4 agents exist at width 128 only (a2c.hip MARL_MAC_SHAPES); every other
             #           (agents, observation width) runs the critics on the wide path (csrc/wide_mlp.h) at the compiled width of the layers
         self.live_hidden = {"actor": tuple(ha), "critic": tuple(hc), "target_critic": tuple(hc)}
@@ -72,7 +77,7 @@ class A2CNetwork:
         self.target_update_interval_or_tau = _get(cfg, "target_update_interval_or_tau", 200)
         self.standardise_returns = bool(_get(cfg, "standardise_returns", False))
         self.centralised_critic = bool(_get(critic, "centralised", False))  # MAA2C / MAPPO (model.py:62-66)
-        self.spec = _hip.NetSpec(P, obs_dims[0], Hk, act_dims[0], self.sharing, wide=Hk > 128)  # > 128: actors and critics on the GEMM path
+        self.spec = _hip.NetSpec(P, obs_dims[0], Hk, act_dims[0], self.sharing, wide=wide, n_hidden=len(ha))  # wide: actors and critics on the GEMM path
         if self.sharing is not None:  # one network per distinct index, in order of first appearance (utils/models.py:209-240)
             first = [self.sharing.index(k) for k in range(max(self.sharing) + 1)]
             obs_dims, act_dims = [obs_dims[i] for i in first], [act_dims[i] for i in first]
@@ -86,8 +91,8 @@ class A2CNetwork:
             a0 = _init_blocks(obs_dims, ha, act_dims, _get(actor, "use_orthogonal_init", True))
             c0 = _init_blocks(cdims, hc, [1] * K, _get(critic, "use_orthogonal_init", True))
             _init_blocks(cdims, hc, [1] * K, _get(critic, "use_orthogonal_init", True))  # target: drawn, then overwritten (soft_update(1.0))
-            a0 = pad_blocks(a0, obs_dims[0], ha[0], ha[1], act_dims[0], Hk)
-            c0 = pad_blocks(c0, cdims[0], hc[0], hc[1], 1, Hk)
+            a0 = pad_blocks(a0, obs_dims[0], ha, act_dims[0], Hk)
+            c0 = pad_blocks(c0, cdims[0], hc, 1, Hk)
         self.block = torch.cat([a0.reshape(-1), c0.reshape(-1)]).to(self.device).contiguous()
         self.target_critic_params = c0.clone().to(self.device).contiguous()
         self.updater = _hip.AcUpdater(self.spec, self.block, self.target_critic_params, lr=float(_get(cfg, "lr", 3e-4)),
@@ -215,8 +220,7 @@ class A2CNetwork:
                 o = 0
                 cin = S.n_agents * S.obs_dim if (self.centralised_critic and prefix != "actor") else S.obs_dim
                 if not self.recurrent:  # the live tensors inside the (possibly zero-padded) blocks
-                    h1, h2 = self.live_hidden[prefix]
-                    for name, view in block_views(block[i], cin, h1, h2, A, S.hidden):
+                    for name, view in block_views(block[i], cin, self.live_hidden[prefix], A, S.hidden):
                         out[f"{prefix}.{group}.{i}.{name}"] = view
                     continue
                 for name, shape in _gru_layout(cin, S.hidden, A):
@@ -240,9 +244,9 @@ class A2CNetwork:
 
     def __repr__(self):
         S = self.spec
-        (a1, a2), (c1, c2) = self.live_hidden["actor"], self.live_hidden["critic"]
-        return (f"{type(self).__name__}[HIP](agents={S.n_agents}, actor={S.obs_dim}-{a1}-{a2}-{S.n_actions}, "
-                f"critic={S.obs_dim}-{c1}-{c2}-1, kernels at width {S.hidden})")
+        a, c = ("-".join(str(h) for h in self.live_hidden[k]) for k in ("actor", "critic"))
+        return (f"{type(self).__name__}[HIP](agents={S.n_agents}, actor={S.obs_dim}-{a}-{S.n_actions}, "
+                f"critic={S.obs_dim}-{c}-1, kernels at width {S.hidden})")
 
 
 class PPONetwork(A2CNetwork):

@@ -28,6 +28,7 @@ using namespace marl;
 // a centralised critic with a fused kernel (MARL_MAC_SHAPES); every other (agents, obs dim) takes the wide path (wide_mlp.h: run-time
 // input width, activations in HBM) next to the fused actor kernels of MARL_AC_SHAPES
 static bool mac_compiled(const marlhip_net_shape* s) {
+    if (s->n_hidden != 0 && s->n_hidden != 2) return false;
 #define X(p, d, h) if (s->n_agents == p && s->obs_dim == d && s->hidden == h && s->n_actions == 6) return true;
     MARL_MAC_SHAPES(X)
 #undef X
@@ -37,6 +38,7 @@ static bool mac_compiled(const marlhip_net_shape* s) {
 // actors (and independent critics) with fused kernels; every other two-layer shape runs BOTH networks on the GEMM path of
 // wide_mlp.h (hidden > 128, observation widths / action counts outside MARL_AC_SHAPES): slower, any size
 static bool ac_compiled(const marlhip_net_shape* s) {
+    if (s->n_hidden != 0 && s->n_hidden != 2) return false;
 #define X(d, h, a) if (s->obs_dim == d && s->hidden == h && s->n_actions == a) return true;
     MARL_AC_SHAPES(X)
 #undef X
@@ -46,7 +48,7 @@ static bool ac_compiled(const marlhip_net_shape* s) {
 static int ac_check(const marlhip_net_shape* s, int centralised = 0) {
     (void)centralised;
     MARL_REQUIRE(s != nullptr, "net shape is NULL");
-    if (agent_map_validate(s) != 0) return -1;
+    if (agent_map_validate(s, true) != 0) return -1;
     MARL_REQUIRE(s->n_agents >= 1, "ac: no agents");
     MARL_REQUIRE(s->obs_dim >= 1 && s->hidden >= 1 && s->hidden <= 1024 && s->n_actions >= 1 && s->n_actions <= 64,
                  "ac: net shape D=%d H=%d A=%d out of range", s->obs_dim, s->hidden, s->n_actions);
@@ -55,8 +57,9 @@ static int ac_check(const marlhip_net_shape* s, int centralised = 0) {
 
 // the run-time shapes of the all-GEMM step: actor D -> H -> H -> A, critic (P * D or D) -> H -> H -> 1
 static void wide_set(const marlhip_net_shape* s, int centralised) {
-    WideRt<0>::set(s->obs_dim, s->hidden, s->n_actions);
-    WideRt<1>::set(centralised ? s->n_agents * s->obs_dim : s->obs_dim, s->hidden, 1);
+    const int L = s->n_hidden > 0 ? s->n_hidden : 2;
+    WideRt<0>::set(s->obs_dim, s->hidden, s->n_actions, L);
+    WideRt<1>::set(centralised ? s->n_agents * s->obs_dim : s->obs_dim, s->hidden, 1, L);
 }
 
 extern "C" int marlhip_ac_critic_nparams(const marlhip_net_shape* s, int32_t centralised) {
@@ -66,8 +69,8 @@ extern "C" int marlhip_ac_critic_nparams(const marlhip_net_shape* s, int32_t cen
         MARL_MAC_SHAPES(X)
 #undef X
     }
+    if (!ac_compiled(s)) return (int)WideNet{centralised ? s->n_agents * s->obs_dim : s->obs_dim, s->hidden, 1, s->n_hidden > 0 ? s->n_hidden : 2}.nparam();
     if (centralised) return (int)WideNet{s->n_agents * s->obs_dim, s->hidden, 1}.nparam();
-    if (!ac_compiled(s)) return (int)WideNet{s->obs_dim, s->hidden, 1}.nparam();
 #define X(d, h, a) if (s->obs_dim == d && s->hidden == h && s->n_actions == a) return MlpShape<d, h, 1>::NPARAM;
     MARL_AC_SHAPES(X)
 #undef X
@@ -163,7 +166,7 @@ extern "C" int marlhip_ac_forward_rows(const marlhip_net_shape* s, int32_t value
 #undef X
     }
     if (value_net == 2 || !ac_compiled(s)) {  // the GEMM path: any input / hidden width
-        WideRt<1>::set(value_net == 2 ? s->n_agents * s->obs_dim : s->obs_dim, s->hidden, value_net ? 1 : s->n_actions);
+        WideRt<1>::set(value_net == 2 ? s->n_agents * s->obs_dim : s->obs_dim, s->hidden, value_net ? 1 : s->n_actions, s->n_hidden > 0 ? s->n_hidden : 2);
         return launch_forward_rows<WideRt<1>>(s->n_agents, agent_map(s), params, &bt, n_rows, out, (hipStream_t)stream);
     }
 #define X(d, h, a)                                                                                                         \

@@ -13,15 +13,15 @@ template <int H_>
 struct WideCritic {
     static constexpr int H = H_, A = 1;
     static inline thread_local int D = 0;
-    static WideNet net() { return WideNet{D, H, A}; }
+    static WideNet net() { return WideNet{D, H, A, 2}; }
 };
 // both widths, inputs and outputs at run time (actors AND critics without a fused kernel: hidden > 128, other observation widths);
 // TAG keeps the actor's and the critic's thread-local shapes apart
 template <int TAG>
 struct WideRt {
-    static inline thread_local int D = 0, H = 0, A = 0;
-    static WideNet net() { return WideNet{D, H, A}; }
-    static void set(int d, int h, int a) { D = d; H = h; A = a; }
+    static inline thread_local int D = 0, H = 0, A = 0, L = 2;
+    static WideNet net() { return WideNet{D, H, A, L}; }
+    static void set(int d, int h, int a, int l) { D = d; H = h; A = a; L = l; }
 };
 template <class S>
 struct IsWide : std::false_type {};
@@ -89,7 +89,7 @@ int launch_forward_rows(int P, const AgentMap& am, const float* params, const ma
         const int64_t as = bt->obs_agent_stride > 0 ? bt->obs_agent_stride : (bt->obs_agent_stride < 0 ? 0 : (int64_t)(bt->max_len + 1) * bt->batch * s.D);
         const int64_t rs = bt->obs_row_stride ? bt->obs_row_stride : s.D;
         // as many rows per pass as the caller's scratch holds activations for (the learner step sizes it for all rows at once)
-        const int64_t avail = scratch_avail(), per_row = (int64_t)2 * s.H * 4;
+        const int64_t avail = scratch_avail(), per_row = (int64_t)s.L * s.H * 4;
         int chunk = (int)((avail - 1024) / per_row < n_rows ? (avail - 1024) / per_row : n_rows);
         chunk &= ~63;
         if (chunk >= n_rows || n_rows < 64) chunk = n_rows;

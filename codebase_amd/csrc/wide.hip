@@ -9,9 +9,11 @@
 
 using namespace marl;
 
+static WideNet wide_net(const marlhip_net_shape* s, int n_out) { return WideNet{s->obs_dim, s->hidden, n_out, s->n_hidden > 0 ? s->n_hidden : 2}; }
+
 static int wide_check(const marlhip_net_shape* s, int n_out) {
     MARL_REQUIRE(s != nullptr, "net shape is NULL");
-    if (agent_map_validate(s) != 0) return -1;
+    if (agent_map_validate(s, true) != 0) return -1;
     MARL_REQUIRE(s->n_agents >= 1 && s->n_agents <= 16 && s->obs_dim >= 1 && s->hidden >= 1 && s->hidden <= 1024 && n_out >= 1 && n_out <= 64,
                  "wide network: shape P=%d D=%d H=%d outputs=%d out of range", s->n_agents, s->obs_dim, s->hidden, n_out);
     return 0;
@@ -19,20 +21,20 @@ static int wide_check(const marlhip_net_shape* s, int n_out) {
 
 extern "C" int marlhip_wide_nparams(const marlhip_net_shape* s, int32_t n_out) {
     if (wide_check(s, n_out) != 0) return -1;
-    return (int)WideNet{s->obs_dim, s->hidden, n_out}.nparam();
+    return (int)wide_net(s, n_out).nparam();
 }
 
 extern "C" int64_t marlhip_wide_forward_workspace_bytes(const marlhip_net_shape* s, int32_t n_rows) {
     if (wide_check(s, 1) != 0) return -1;
     MARL_REQUIRE(n_rows > 0, "wide_forward_workspace_bytes: n_rows must be > 0");
-    return wide_ws(WideNet{s->obs_dim, s->hidden, 1}, s->n_agents, n_rows, false).total;
+    return wide_ws(wide_net(s, 1), s->n_agents, n_rows, false).total;
 }
 
 extern "C" int marlhip_wide_forward(const marlhip_net_shape* s, int32_t n_out, const float* params, const float* obs, int64_t agent_stride,
                                     int64_t row_stride, int32_t n_rows, float* out, void* workspace, int64_t workspace_bytes, void* stream) {
     if (wide_check(s, n_out) != 0) return -1;
     MARL_REQUIRE(params && obs && out && workspace && n_rows > 0 && row_stride > 0 && agent_stride >= 0, "wide_forward: bad argument");
-    const WideNet net{s->obs_dim, s->hidden, n_out};
+    const WideNet net = wide_net(s, n_out);
     MARL_REQUIRE(workspace_bytes >= wide_ws(net, s->n_agents, n_rows, false).total, "wide_forward: workspace %lld < %lld bytes",
                  (long long)workspace_bytes, (long long)wide_ws(net, s->n_agents, n_rows, false).total);
     return wide_forward_rows(net, s->n_agents, agent_map(s), params, obs, agent_stride, row_stride, n_rows, out, workspace, (hipStream_t)stream);
@@ -60,7 +62,7 @@ WideDqnWs wide_dqn_ws(const WideNet& net, int P, int T, int B) {
 extern "C" int64_t marlhip_wide_dqn_workspace_bytes(const marlhip_net_shape* s, int32_t max_len, int32_t batch) {
     if (wide_check(s, s ? s->n_actions : 0) != 0) return -1;
     MARL_REQUIRE(max_len > 0 && batch > 0, "wide_dqn_workspace_bytes: empty batch");
-    return wide_dqn_ws(WideNet{s->obs_dim, s->hidden, s->n_actions}, s->n_agents, max_len, batch).total;
+    return wide_dqn_ws(wide_net(s, s->n_actions), s->n_agents, max_len, batch).total;
 }
 
 extern "C" int marlhip_wide_dqn_loss_grad(const marlhip_net_shape* s, const float* params, const float* target_params, const marlhip_batch* bt,
@@ -73,7 +75,7 @@ extern "C" int marlhip_wide_dqn_loss_grad(const marlhip_net_shape* s, const floa
     MARL_REQUIRE(bt->obs_agent_stride == 0 && bt->obs_row_stride == 0 && bt->act_agent_stride == 0 && bt->act_row_stride == 0,
                  "wide_dqn_loss_grad: the dqn/train.py Batch layout only");
     const int P = s->n_agents, T = bt->max_len, B = bt->batch, A = s->n_actions, D = s->obs_dim;
-    const WideNet net{D, s->hidden, A};
+    const WideNet net = wide_net(s, A);
     const WideDqnWs wl = wide_dqn_ws(net, P, T, B);
     MARL_REQUIRE(workspace_bytes >= wl.total, "wide_dqn_loss_grad: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)wl.total);
     hipStream_t st = (hipStream_t)stream;

@@ -4,7 +4,7 @@
 // input width; here the three layers are plain f32 MFMA GEMMs over all rows with the activations in HBM, sized at RUN time
 // (input width, hidden width, outputs): any width works, at the price of writing and re-reading [rows][H] activations.
 //
-//   forward   Y1 = relu(X W1^T + b1), Y2 = relu(Y1 W2^T + b2), out = Y2 W3^T + b3                              (FCNetwork, utils/models.py:34-48)
+//   forward   Y1 = relu(X W1^T + b1), Y2 = relu(Y1 W2^T + b2), out = Y2 W3^T + b3      (FCNetwork, utils/models.py:34-48; 1 .. 4 hidden layers)
 //   backward  dY2 = (dout W3) * (Y2 > 0), dY1 = (dY2 W2) * (Y1 > 0), dWk = dYk^T [Y(k-1) | 1]  (the ones column yields dbk)
 //
 // One kernel, wide_gemm_kernel: C[m][n] = sum_k A(m, k) B(k, n) on v_mfma_f32_16x16x4_f32, a 64 x 64 tile per workgroup (wave w: rows
@@ -157,16 +157,22 @@ static __global__ __launch_bounds__(256) void wide_gather_kernel(const float* __
     grad[idx] = acc;
 }
 
-// run-time shape of one network: D inputs, two hidden layers of H, A outputs; parameters in FCNetwork's parameters() order
+// run-time shape of one network: D inputs, L hidden layers of H units (FCNetwork builds any list, marlbase/utils/models.py:34-48;
+// unequal widths are zero-padded to H by the caller), A outputs; parameters in FCNetwork's parameters() order.
+// Layers are numbered 1 .. L (hidden) and L + 1 (output).
 struct WideNet {
+    static constexpr int MAXL = 4;
     int D, H, A;
-    int64_t oW1() const { return 0; }
-    int64_t ob1() const { return (int64_t)H * D; }
-    int64_t oW2() const { return ob1() + H; }
-    int64_t ob2() const { return oW2() + (int64_t)H * H; }
-    int64_t oW3() const { return ob2() + H; }
-    int64_t ob3() const { return oW3() + (int64_t)A * H; }
-    int64_t nparam() const { return ob3() + A; }
+    int L = 2;
+    int n_in(int k) const { return k == 1 ? D : H; }
+    int n_out(int k) const { return k <= L ? H : A; }
+    int64_t oW(int k) const {
+        int64_t off = 0;
+        for (int j = 1; j < k; ++j) off += (int64_t)n_out(j) * n_in(j) + n_out(j);
+        return off;
+    }
+    int64_t ob(int k) const { return oW(k) + (int64_t)n_out(k) * n_in(k); }
+    int64_t nparam() const { return oW(L + 2); }
     int widest() const { return D > H ? D : H; }
 };
 
@@ -176,19 +182,18 @@ inline int wide_splits(int rows) {  // row slices of the weight-gradient GEMMs: 
 }
 
 struct WideWs {
-    int64_t y1, y2, d2, d1, partial, gp, nf, total;  // byte offsets
+    int64_t y[WideNet::MAXL], d[2], partial, gp, nf, total;  // byte offsets
 };
 
-// backward = true: the whole workspace of wide_backward_rows; false: the two activation buffers of wide_forward_rows
+// backward = true: the whole workspace of wide_backward_rows; false: the activation buffers of wide_forward_rows
 inline WideWs wide_ws(const WideNet& s, int P, int rows, bool backward) {
     WideWs w = {};
     int64_t o = 0;
     auto take = [&](int64_t nfloat) { const int64_t at = o; o = (o + nfloat * 4 + 255) & ~(int64_t)255; return at; };
-    w.y1 = take((int64_t)rows * s.H);
-    w.y2 = take((int64_t)rows * s.H);
+    for (int k = 0; k < s.L; ++k) w.y[k] = take((int64_t)rows * s.H);
     if (backward) {
-        w.d2 = take((int64_t)rows * s.H);
-        w.d1 = take((int64_t)rows * s.H);
+        w.d[0] = take((int64_t)rows * s.H);
+        w.d[1] = take((int64_t)rows * s.H);
         w.partial = take((int64_t)wide_splits(rows) * s.H * (s.widest() + 1));
         w.gp = take((int64_t)P * s.nparam());
         w.nf = take(4);
@@ -202,30 +207,31 @@ inline void wide_gemm(const GemmOp& g, int splits, hipStream_t st) {
     hipLaunchKernelGGL((wide_gemm_kernel<A_KC, B_KC>), dim3((g.N + 63) / 64, (g.M + 63) / 64, splits), dim3(256), 0, st, g);
 }
 
-// Y1, Y2 of `rows` rows x (row r at x + r * row_stride) for one network
-inline void wide_hidden(const WideNet& s, const float* prm, const float* x, int64_t row_stride, int rows, float* y1, float* y2, hipStream_t st) {
-    GemmOp g = {};
-    g.M = rows; g.k_chunk = 1 << 30; g.b_ones = -1; g.epi = 2;
-    g.A = x; g.a_m = row_stride; g.a_k = 1; g.B = prm + s.oW1(); g.b_k = 1; g.b_n = s.D; g.C = y1; g.c_m = s.H; g.N = s.H; g.K = s.D;
-    g.bias = prm + s.ob1();
-    wide_gemm<true, true>(g, 1, st);
-    g.A = y1; g.a_m = s.H; g.B = prm + s.oW2(); g.b_n = s.H; g.C = y2; g.K = s.H; g.bias = prm + s.ob2();
-    wide_gemm<true, true>(g, 1, st);
+// hidden activations Y_1 .. Y_L of `rows` rows x (row r at x + r * row_stride) for one network: y[k - 1] = Y_k [rows][H]
+inline void wide_hidden(const WideNet& s, const float* prm, const float* x, int64_t row_stride, int rows, float* const* y, hipStream_t st) {
+    for (int k = 1; k <= s.L; ++k) {
+        GemmOp g = {};
+        g.M = rows; g.N = s.H; g.K = s.n_in(k); g.k_chunk = 1 << 30; g.b_ones = -1; g.epi = 2;
+        g.A = k == 1 ? x : y[k - 2]; g.a_m = k == 1 ? row_stride : s.H; g.a_k = 1;
+        g.B = prm + s.oW(k); g.b_k = 1; g.b_n = s.n_in(k);
+        g.C = y[k - 1]; g.c_m = s.H; g.bias = prm + s.ob(k);
+        wide_gemm<true, true>(g, 1, st);
+    }
 }
 
 // out[p][row][A] = MLP_p(x row); x row r of agent p at obs + p * agent_stride + r * row_stride; scratch: wide_ws(.., false).total bytes
 inline int wide_forward_rows(const WideNet& s, int P, const AgentMap& am, const float* params, const float* obs, int64_t agent_stride,
                              int64_t row_stride, int rows, float* out, void* scratch, hipStream_t st) {
     const WideWs w = wide_ws(s, P, rows, false);
-    float* y1 = reinterpret_cast<float*>(static_cast<char*>(scratch) + w.y1);
-    float* y2 = reinterpret_cast<float*>(static_cast<char*>(scratch) + w.y2);
+    float* y[WideNet::MAXL];
+    for (int k = 0; k < s.L; ++k) y[k] = reinterpret_cast<float*>(static_cast<char*>(scratch) + w.y[k]);
     for (int p = 0; p < P; ++p) {
         const float* prm = params + (int64_t)am.net[p] * s.nparam();
-        wide_hidden(s, prm, obs + (int64_t)p * agent_stride, row_stride, rows, y1, y2, st);
+        wide_hidden(s, prm, obs + (int64_t)p * agent_stride, row_stride, rows, y, st);
         GemmOp g = {};
         g.M = rows; g.N = s.A; g.K = s.H; g.k_chunk = 1 << 30; g.b_ones = -1; g.epi = 1;
-        g.A = y2; g.a_m = s.H; g.a_k = 1; g.B = prm + s.oW3(); g.b_k = 1; g.b_n = s.H; g.C = out + (int64_t)p * rows * s.A; g.c_m = s.A;
-        g.bias = prm + s.ob3();
+        g.A = y[s.L - 1]; g.a_m = s.H; g.a_k = 1; g.B = prm + s.oW(s.L + 1); g.b_k = 1; g.b_n = s.H; g.C = out + (int64_t)p * rows * s.A; g.c_m = s.A;
+        g.bias = prm + s.ob(s.L + 1);
         wide_gemm<true, true>(g, 1, st);
     }
     MARL_CHECK_LAUNCH("wide_gemm_kernel (forward)");
@@ -241,16 +247,18 @@ inline int wide_backward_rows(const WideNet& s, int P, const AgentMap& am, const
     const WideWs w = wide_ws(s, P, rows, true);
     char* base = static_cast<char*>(ws);
     auto f = [&](int64_t off) { return reinterpret_cast<float*>(base + off); };
-    float *y1 = f(w.y1), *y2 = f(w.y2), *d2 = f(w.d2), *d1 = f(w.d1), *part = f(w.partial), *gp = f(w.gp), *nf = f(w.nf);
+    float* y[WideNet::MAXL];
+    for (int k = 0; k < s.L; ++k) y[k] = f(w.y[k]);
+    float *dbuf[2] = {f(w.d[0]), f(w.d[1])}, *part = f(w.partial), *gp = f(w.gp), *nf = f(w.nf);
     hipLaunchKernelGGL(wide_count_kernel, dim3(1), dim3(256), 0, st, filled, lrow, rows, nf);
     const int splits = wide_splits(rows), chunk = (((rows + splits - 1) / splits) + 15) & ~15;
-    const int H = s.H, A = s.A, D = s.D;
+    const int H = s.H, A = s.A, L = s.L;
     for (int p = 0; p < P; ++p) {
         const float* prm = params + (int64_t)am.net[p] * s.nparam();
         const float* x = obs + (int64_t)p * agent_stride;
         const float* dq = dout + (int64_t)p * dout_agent_stride;
         float* gpp = gp + (int64_t)p * s.nparam();
-        wide_hidden(s, prm, x, row_stride, rows, y1, y2, st);
+        wide_hidden(s, prm, x, row_stride, rows, y, st);
         // weight gradient of a layer: dW[out][in] (+ bias column) = dY^T [Yprev | 1], rows sliced over grid.z, then the fold
         auto wgrad = [&](const float* dy, int n_out, const float* yprev, int64_t yprev_stride, int n_in, float* dW, float* db) {
             GemmOp g = {};
@@ -262,15 +270,20 @@ inline int wide_backward_rows(const WideNet& s, int P, const AgentMap& am, const
             hipLaunchKernelGGL(wide_fold_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)part, splits, g.c_split, n_out, n_in + 1,
                                (const float*)nf + 1, dW, db);
         };
-        wgrad(dq, A, y2, H, H, gpp + s.oW3(), gpp + s.ob3());
-        GemmOp g = {};
-        g.M = rows; g.N = H; g.k_chunk = 1 << 30; g.b_ones = -1; g.epi = 3;
-        g.A = dq; g.a_m = A; g.a_k = 1; g.K = A; g.B = prm + s.oW3(); g.b_k = H; g.b_n = 1; g.C = d2; g.c_m = H; g.gate = y2; g.gate_m = H;
-        wide_gemm<true, false>(g, 1, st);  // dY2 = (dout W3) * (Y2 > 0)
-        wgrad(d2, H, y1, H, H, gpp + s.oW2(), gpp + s.ob2());
-        g.A = d2; g.a_m = H; g.K = H; g.B = prm + s.oW2(); g.C = d1; g.gate = y1;
-        wide_gemm<true, false>(g, 1, st);  // dY1 = (dY2 W2) * (Y1 > 0)
-        wgrad(d1, H, x, row_stride, D, gpp + s.oW1(), gpp + s.ob1());
+        // output layer, then the hidden layers from the last to the first: dY_k = (dY_{k+1} W_{k+1}) * (Y_k > 0), dW_k = dY_k^T [Y_{k-1} | 1]
+        wgrad(dq, A, y[L - 1], H, H, gpp + s.oW(L + 1), gpp + s.ob(L + 1));
+        const float* dnext = dq;
+        int n_next = A;
+        for (int k = L; k >= 1; --k) {
+            float* dk = dbuf[k & 1];
+            GemmOp g = {};
+            g.M = rows; g.N = H; g.K = n_next; g.k_chunk = 1 << 30; g.b_ones = -1; g.epi = 3;
+            g.A = dnext; g.a_m = n_next; g.a_k = 1; g.B = prm + s.oW(k + 1); g.b_k = H; g.b_n = 1; g.C = dk; g.c_m = H; g.gate = y[k - 1]; g.gate_m = H;
+            wide_gemm<true, false>(g, 1, st);
+            wgrad(dk, H, k == 1 ? x : y[k - 2], k == 1 ? row_stride : H, s.n_in(k), gpp + s.oW(k), gpp + s.ob(k));
+            dnext = dk;
+            n_next = H;
+        }
     }
     const int n = am.nblk * (int)s.nparam();
     hipLaunchKernelGGL(wide_gather_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)gp, P, (int)s.nparam(), am, grad);

@@ -116,40 +116,46 @@ def _tensor_layout(D, H, A):
 # with zero moments to a zero step - the padding stays zero for the whole run, the live sub-network computes what FCNetwork([h1, h2])
 # computes (utils/models.py:34-48), and state_dict exposes the live tensors in the reference's shapes.
 def compiled_width(hidden):
-    """(h1, h2) -> the compiled kernel width they run on, or raise"""
-    if len(hidden) != 2:
-        raise NotImplementedError(f"layers={list(hidden)}: the HIP kernels implement two hidden layers")
+    """hidden layer list -> the width the kernels run it at (<= 128 with two layers: a fused kernel; otherwise the GEMM path), or raise"""
+    if not 1 <= len(hidden) <= 4:
+        raise NotImplementedError(f"layers={list(hidden)}: one to four hidden layers")
     h = max(hidden)
     if min(hidden) < 1 or h > 1024:
         raise NotImplementedError(f"layers={list(hidden)}: hidden widths 1..1024")
-    return 64 if h <= 64 else 128 if h <= 128 else (h + 15) // 16 * 16  # > 128: the GEMM path (NetSpec.wide)
+    if len(hidden) == 2 and h <= 128:
+        return 64 if h <= 64 else 128
+    return max((h + 15) // 16 * 16, 144 if len(hidden) == 2 else 16)  # the GEMM path (NetSpec.wide): any width, any of 1..4 layers
 
 
-def pad_blocks(flat, D, h1, h2, A, H):
-    """[K][n(h1, h2)] parameter blocks in FCNetwork's parameters() order -> [K][n(H, H)] zero-padded blocks"""
-    if h1 == H and h2 == H:
+def is_wide(hidden):
+    return len(hidden) != 2 or max(hidden) > 128
+
+
+def pad_blocks(flat, D, hidden, A, H):
+    """[K][n(hidden)] parameter blocks in FCNetwork's parameters() order -> [K][n(H, ..., H)] zero-padded blocks"""
+    if all(h == H for h in hidden):
         return flat
     K = flat.shape[0]
-    out = torch.zeros(K, H * D + H + H * H + H + A * H + A, dtype=flat.dtype)
+    n = sum(o * i + o for o, i in zip([H] * len(hidden) + [A], [D] + [H] * len(hidden)))
+    out = torch.zeros(K, n, dtype=flat.dtype)
     for k in range(K):
-        for (_, dst), (_, src) in zip(block_views(out[k], D, h1, h2, A, H), block_views(flat[k], D, h1, h2, A, None)):
+        for (_, dst), (_, src) in zip(block_views(out[k], D, hidden, A, H), block_views(flat[k], D, hidden, A, None)):
             dst.copy_(src)
     return out
 
 
-def block_views(row, D, h1, h2, A, H):
+def block_views(row, D, hidden, A, H):
     """(name, view) of the LIVE tensors inside one flat block laid out for width H (H None: the unpadded layout)"""
-    Hk = H if H is not None else None
-    a, b = (Hk, Hk) if Hk is not None else (h1, h2)
+    live_out = list(hidden) + [A]
+    live_in = [D] + list(hidden)
+    full_out = live_out if H is None else [H] * len(hidden) + [A]
+    full_in = live_in if H is None else [D] + [H] * len(hidden)
     o, out = 0, []
-    for name, full, live in (("network.0.weight", (a, D), (slice(0, h1), slice(None))), ("network.0.bias", (a,), (slice(0, h1),)),
-                             ("network.2.weight", (b, a), (slice(0, h2), slice(0, h1))), ("network.2.bias", (b,), (slice(0, h2),)),
-                             ("network.4.weight", (A, b), (slice(None), slice(0, h2))), ("network.4.bias", (A,), (slice(None),))):
-        n = 1
-        for d in full:
-            n *= d
-        out.append((name, row[o:o + n].view(full)[live]))
-        o += n
+    for k, (fo, fi, lo, li) in enumerate(zip(full_out, full_in, live_out, live_in)):
+        out.append((f"network.{2 * k}.weight", row[o:o + fo * fi].view(fo, fi)[:lo, :li]))
+        o += fo * fi
+        out.append((f"network.{2 * k}.bias", row[o:o + fo][:lo]))
+        o += fo
     return out
 
 
@@ -163,8 +169,8 @@ class QNetwork:
         if use_rnn and hidden not in ([64, 64], [128, 128]):
             raise NotImplementedError(f"use_rnn with layers={hidden}: the recurrent kernels are built for layers [64, 64] / [128, 128]")
         self.live_hidden = tuple(hidden)
-        Hk = compiled_width(hidden)  # the width the kernels run at ([h1, h2] zero-padded to it, see pad_blocks)
-        hidden_k = [Hk, Hk]
+        Hk = compiled_width(hidden)  # the width the kernels run at (the layers zero-padded to it, see pad_blocks)
+        hidden_k = [Hk] * len(hidden)
         if len(set(obs_dims)) != 1 or len(set(act_dims)) != 1:
             raise NotImplementedError("agents with different observation / action sizes")
         if str(device) == "cpu":
@@ -182,16 +188,16 @@ class QNetwork:
         self.n_agents = len(obs_dims)
         self.device = torch.device(device)
         self.sharing = sharing_indices(parameter_sharing, self.n_agents)
-        self.spec = _hip.NetSpec(self.n_agents, obs_dims[0], hidden_k[0], act_dims[0], self.sharing, wide=Hk > 128)
+        self.spec = _hip.NetSpec(self.n_agents, obs_dims[0], hidden_k[0], act_dims[0], self.sharing, wide=is_wide(hidden), n_hidden=len(hidden))
         if self.spec.wide and (self.standardise_returns or type(self).__name__ == "QMixNetwork"):
-            raise NotImplementedError(f"layers={hidden}: layers wider than 128 run IDQN / VDN without return standardisation (the GEMM path)")
+            raise NotImplementedError(f"layers={hidden}: lists other than two layers of at most 128 units run IDQN / VDN without return standardisation (the GEMM path)")
         if self.recurrent:  # RNNNetwork (utils/models.py:51-116): Linear -> ReLU -> GRU -> Linear
             self.nparams = _hip.gru_nparams(self.spec)
             critic, target = init_flat_gru_params(obs_dims, hidden[0], act_dims, use_orthogonal_init, self.sharing)
         else:
             self.nparams = self.spec.nparams()
             critic, target = init_flat_params(obs_dims, hidden, act_dims, use_orthogonal_init, self.sharing)  # the reference's RNG draws
-            critic = pad_blocks(critic, obs_dims[0], hidden[0], hidden[1], act_dims[0], Hk)
+            critic = pad_blocks(critic, obs_dims[0], hidden, act_dims[0], Hk)
             target = critic.clone()
         assert critic.shape == (self.spec.n_blocks, self.nparams)
         self.params = critic.to(self.device).contiguous()
@@ -326,7 +332,7 @@ class QNetwork:
         group = "independent" if self.sharing is None else "networks"  # utils/models.py:146 / :204
         if not self.recurrent:  # the live [h1, h2] tensors inside the (possibly zero-padded) blocks
             for i in range(S.n_blocks):
-                for name, view in block_views(block[i], S.obs_dim, self.live_hidden[0], self.live_hidden[1], S.n_actions, S.hidden):
+                for name, view in block_views(block[i], S.obs_dim, self.live_hidden, S.n_actions, S.hidden):
                     out[f"{prefix}.{group}.{i}.{name}"] = view
             return out
         layout = _gru_layout(S.obs_dim, S.hidden, S.n_actions)
@@ -358,8 +364,8 @@ class QNetwork:
     def __repr__(self):
         S = self.spec
         share = "" if self.sharing is None else f", sharing={list(self.sharing)}"
-        pad = "" if self.live_hidden == (S.hidden, S.hidden) else f" zero-padded to {S.hidden}-{S.hidden}"
-        return (f"QNetwork[HIP](agents={S.n_agents}, mlp={S.obs_dim}-{self.live_hidden[0]}-{self.live_hidden[1]}-{S.n_actions}{pad}, "
+        pad = "" if all(h == S.hidden for h in self.live_hidden) else f" zero-padded to width {S.hidden}"
+        return (f"QNetwork[HIP](agents={S.n_agents}, mlp={S.obs_dim}-{'-'.join(str(h) for h in self.live_hidden)}-{S.n_actions}{pad}, "
                 f"params={self.nparams}/network{share})")
 
 

@@ -184,9 +184,11 @@ class NetSpec:
     n_actions: int
     sharing: tuple = None  # agent -> network index (parameter sharing / SePS); None = independent networks
     wide: bool = False     # no fused kernels for this shape (hidden > 128, ...): the GEMM path (marlhip_wide_*, csrc/wide_mlp.h)
+    n_hidden: int = 2      # hidden layers (the fused kernels: 2; 1..4 on the GEMM path)
 
     def c(self):
         s = NetShape(self.n_agents, self.obs_dim, self.hidden, self.n_actions)
+        s.n_hidden = int(self.n_hidden)
         if self.sharing is not None:
             if len(self.sharing) != self.n_agents or self.n_agents > 16:
                 raise ValueError("sharing indices: one per agent, at most 16 agents")
@@ -218,7 +220,7 @@ def wide_forward(spec: NetSpec, params, obs, n_out=None, agent_stride=None, row_
         agent_stride, row_stride = n_rows * D, D
     n_out = spec.n_actions if n_out is None else int(n_out)
     s = spec.c()
-    key = (spec.n_agents, spec.obs_dim, spec.hidden, int(n_rows), params.device.index, torch.cuda.current_stream().cuda_stream)
+    key = (spec.n_agents, spec.obs_dim, spec.hidden, spec.n_hidden, int(n_rows), params.device.index, torch.cuda.current_stream().cuda_stream)
     ws = _WIDE_WS.get(key)
     if ws is None:
         if len(_WIDE_WS) > 32:

@@ -23,21 +23,24 @@ import torch
 
 
 def _widths(H):
-    """H: one width (two equal hidden layers) or (h1, h2) - FCNetwork takes any list (utils/models.py:34-42)"""
-    return (H, H) if isinstance(H, int) else (int(H[0]), int(H[1]))
+    """H: one width (two equal hidden layers) or a list of hidden widths - FCNetwork takes any list (utils/models.py:34-42)"""
+    return (H, H) if isinstance(H, int) else tuple(int(h) for h in H)
+
+
+def _layer_shapes(D, H, A):
+    dims = (D,) + _widths(H) + (A,)
+    return [(dims[i + 1], dims[i]) for i in range(len(dims) - 1)]
 
 
 def nparams(D, H, A):
-    h1, h2 = _widths(H)
-    return h1 * D + h1 + h2 * h1 + h2 + A * h2 + A
+    return sum(o * i + o for o, i in _layer_shapes(D, H, A))
 
 
 def split(block, D, H, A):
     """flat [nparams] -> (W1[H,D], b1[H], W2[H,H], b2[H], W3[A,H], b3[A]) views"""
     o = 0
     out = []
-    h1, h2 = _widths(H)
-    for shape in ((h1, D), (h1,), (h2, h1), (h2,), (A, h2), (A,)):
+    for shape in [s_ for (a, b) in _layer_shapes(D, H, A) for s_ in ((a, b), (a,))]:
         n = int(np.prod(shape))
         out.append(block[o:o + n].reshape(shape))
         o += n
@@ -50,8 +53,7 @@ def init_params(P, D, H, A, seed=0, orthogonal=True):
     blocks = []
     for _ in range(P):
         parts = []
-        h1, h2 = _widths(H)
-        for (o, i) in ((h1, D), (h2, h1), (A, h2)):
+        for (o, i) in _layer_shapes(D, H, A):
             w = torch.empty(o, i)
             if orthogonal:
                 torch.nn.init.orthogonal_(w, gain=math.sqrt(2), generator=g)
@@ -63,10 +65,11 @@ def init_params(P, D, H, A, seed=0, orthogonal=True):
 
 
 def mlp(block, x, D, H, A):
-    W1, b1, W2, b2, W3, b3 = split(block, D, H, A)
-    h = torch.relu(torch.nn.functional.linear(x, W1, b1))
-    h = torch.relu(torch.nn.functional.linear(h, W2, b2))
-    return torch.nn.functional.linear(h, W3, b3)
+    t = split(block, D, H, A)
+    h = x
+    for k in range(0, len(t) - 2, 2):
+        h = torch.relu(torch.nn.functional.linear(h, t[k], t[k + 1]))
+    return torch.nn.functional.linear(h, t[-2], t[-1])
 
 
 def q_values(params, obss, D, H, A):
