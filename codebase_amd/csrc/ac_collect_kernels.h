@@ -54,7 +54,16 @@ __device__ __forceinline__ int sample_rows(const f4& logits, int lane, float u) 
     return act;
 }
 
-template <class ENV, int H, bool OID>
+// NW = waves that share one block of 16 envs, each running the actors p = w mod NW: every one of them keeps its own copy of the
+// env state (registers + its own LDS byte columns), computes only its agents' forward passes and samples, and the NW waves swap the
+// sampled actions through LDS once per step; then each steps its copy with the full joint action - the same deterministic integer
+// work, so the copies never diverge.  It buys latency when the launch cannot fill the chip anyway (N / 16 < number of SIMDs): the
+// per-step chain of P forward passes becomes P / NW.  Actor packs that do not fit the LDS are then read straight from global memory
+// (L2) by the wave that needs them - no per-step staging of every agent's pack by the whole workgroup.
+template <int P>
+constexpr int acol_max_nw() { return P % 4 == 0 ? 4 : (P % 2 == 0 ? 2 : 1); }
+
+template <class ENV, int H, bool OID, int NW>
 __global__ __launch_bounds__(ACOL_BLOCK) void ac_collect_kernel(typename ENV::Params q, const float* __restrict__ actor /* pre-packed [P][NFWD] */, uint32_t round, int T,
                                                                 int proper_term, float* __restrict__ b_obs,
                                                                 int64_t* __restrict__ b_act, float* __restrict__ b_rew,
@@ -65,12 +74,15 @@ __global__ __launch_bounds__(ACOL_BLOCK) void ac_collect_kernel(typename ENV::Pa
     using S = MlpShape<D, H, A>;
     using PP = PackPlan<S, P, ENV::LDS_MAX>;
     constexpr bool RESIDENT = PP::RESIDENT || PP::A3REG;  // no per-step staging
+    constexpr bool FROM_GLOBAL = NW > 1 && !RESIDENT;      // packs too large for the LDS: each wave reads its agents' from L2
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ int s_act[NW > 1 ? 2 * 4 * P * 16 : 1];     // [step parity][env block of the workgroup][agent][env]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, j = lane & 15;
-    const int n = (blockIdx.x * 4 + wave) * 16 + j;
+    const int blk = wave / NW, aw = wave % NW;             // env block inside the workgroup, this wave's agent residue
+    const int n = (blockIdx.x * (4 / NW) + blk) * 16 + j;
     const int N = q.n_envs;
     typename ENV::Ctx ctx;
-    ctx.init(q, reinterpret_cast<uint8_t*>(lds) + PP::LDS_BYTES, wave, j);
+    ctx.init(q, reinterpret_cast<uint8_t*>(lds) + (FROM_GLOBAL ? 0 : PP::LDS_BYTES), wave, j);
     const bool valid = n < N;
     const uint32_t env_id = (uint32_t)(valid ? n : N - 1);
     f4 a3[PP::A3REG ? P : 1][S::MT];  // output-layer operands, when the full packs do not fit the LDS
@@ -93,6 +105,7 @@ __global__ __launch_bounds__(ACOL_BLOCK) void ac_collect_kernel(typename ENV::Pa
     float x[P][S::KS1];
 #pragma unroll
     for (int p = 0; p < P; ++p) {
+        if (p % NW != aw) continue;  // (a wave's own agents: it observes, forwards, samples and stores for them)
         ENV::template observe<S::KS1, OID>(q, s, ctx, p, g, x[p]);
         if (valid) {
 #pragma unroll
@@ -100,7 +113,8 @@ __global__ __launch_bounds__(ACOL_BLOCK) void ac_collect_kernel(typename ENV::Pa
                 if (4 * ks + g < D) obs_row(0)[p * D + 4 * ks + g] = x[p][ks];
         }
     }
-    if (valid && g == 0) b_done[env_id] = 0;
+    const bool lead = g == 0 && aw == 0;  // the lane that writes an env's per-env records
+    if (valid && lead) b_done[env_id] = 0;
     bool running = valid;
     float ep_ret[P];
 #pragma unroll
@@ -108,13 +122,18 @@ __global__ __launch_bounds__(ACOL_BLOCK) void ac_collect_kernel(typename ENV::Pa
     int len = 0;
     for (int t = 0; t < T; ++t) {
         int act[P];
+#pragma unroll
+        for (int p = 0; p < P; ++p) act[p] = 0;
         const bool any_running = __any(running);
-        if (RESIDENT ? any_running : true) {
+        if ((RESIDENT || FROM_GLOBAL) ? any_running : true) {
 #pragma unroll
             for (int p = 0; p < P; ++p) {
+                if (p % NW != aw) continue;
                 const float* pack;
                 if (RESIDENT) {
                     pack = lds + (size_t)p * PP::STRIDE;
+                } else if (FROM_GLOBAL) {
+                    pack = actor + (size_t)p * S::NFWD;
                 } else {
                     __syncthreads();
                     stage_packed<S>(actor + (size_t)p * S::NFWD, lds, tid, ACOL_BLOCK);
@@ -127,6 +146,15 @@ __global__ __launch_bounds__(ACOL_BLOCK) void ac_collect_kernel(typename ENV::Pa
                 act[p] = sample_rows<A>(logits, lane, u);
             }
         }
+        if (NW > 1) {  // swap the sampled actions among the waves of the env block (double-buffered: one barrier per step)
+            int* sa = s_act + (((t & 1) * 4 + blk) * P) * 16;
+#pragma unroll
+            for (int p = 0; p < P; ++p)
+                if (p % NW == aw && g == 0) sa[p * 16 + j] = act[p];
+            __syncthreads();
+#pragma unroll
+            for (int p = 0; p < P; ++p) act[p] = sa[p * 16 + j];
+        }
         if (running) {
             double raw[P];
             float rw[P];
@@ -135,7 +163,7 @@ __global__ __launch_bounds__(ACOL_BLOCK) void ac_collect_kernel(typename ENV::Pa
             const bool trunc = q.time_limit > 0 && ENV::elapsed(s) >= q.time_limit;
             const bool fin = done || trunc;
             const bool stored_done = proper_term ? done : fin;
-            lbf_wrap_rewards<P>(q, env_id, raw, rw, g == 0);
+            lbf_wrap_rewards<P>(q, env_id, raw, rw, lead);
             ++len;
             if (fin) {  // vector-env auto-reset: the observation returned for this step is the next episode's first
                 ENV::reset(q, s, ctx, env_id, 2u * round + 1u);
@@ -143,6 +171,7 @@ __global__ __launch_bounds__(ACOL_BLOCK) void ac_collect_kernel(typename ENV::Pa
 #pragma unroll
             for (int p = 0; p < P; ++p) {
                 ep_ret[p] += (float)raw[p];
+                if (p % NW != aw) continue;
                 ENV::template observe<S::KS1, OID>(q, s, ctx, p, g, x[p]);
 #pragma unroll
                 for (int ks = 0; ks < S::KS1; ++ks)
@@ -152,13 +181,13 @@ __global__ __launch_bounds__(ACOL_BLOCK) void ac_collect_kernel(typename ENV::Pa
                     b_rew[((size_t)t * N + n) * P + p] = rw[p];
                 }
             }
-            if (g == 0) {
+            if (lead) {
                 b_done[(size_t)(t + 1) * N + n] = stored_done ? 1 : 0;
                 b_filled[(size_t)t * N + n] = 1.f;
             }
             if (fin) {
                 running = false;
-                if (g == 0) {
+                if (lead) {
 #pragma unroll
                     for (int p = 0; p < P; ++p) fin_return[(size_t)p * N + n] = ep_ret[p];
                     fin_length[n] = len;
@@ -169,6 +198,7 @@ __global__ __launch_bounds__(ACOL_BLOCK) void ac_collect_kernel(typename ENV::Pa
             // rows of an env that is no longer running stay zero, as in the reference's freshly allocated batch
 #pragma unroll
             for (int p = 0; p < P; ++p) {
+                if (p % NW != aw) continue;
 #pragma unroll
                 for (int ks = 0; ks < S::KS1; ++ks)
                     if (4 * ks + g < D) obs_row(t + 1)[p * D + 4 * ks + g] = 0.f;
@@ -177,13 +207,13 @@ __global__ __launch_bounds__(ACOL_BLOCK) void ac_collect_kernel(typename ENV::Pa
                     b_rew[((size_t)t * N + n) * P + p] = 0.f;
                 }
             }
-            if (g == 0) {
+            if (lead) {
                 b_done[(size_t)(t + 1) * N + n] = 0;
                 b_filled[(size_t)t * N + n] = 0.f;
             }
         }
     }
-    if (valid && running && g == 0) {  // T shorter than the env's limits
+    if (valid && running && lead) {  // T shorter than the env's limits
 #pragma unroll
         for (int p = 0; p < P; ++p) fin_return[(size_t)p * N + n] = ep_ret[p];
         fin_length[n] = len;
@@ -191,30 +221,50 @@ __global__ __launch_bounds__(ACOL_BLOCK) void ac_collect_kernel(typename ENV::Pa
     }
 }
 
-template <class ENV, int H, bool OID>
-int launch_ac_collect(const typename ENV::Params& q, const AgentMap& am, const float* actor, uint32_t round, int T, int proper_term, float* b_obs, int64_t* b_act,
-                      float* b_rew, uint8_t* b_done, float* b_filled, float* fin_return, int32_t* fin_length, int32_t* t_max,
-                      hipStream_t st) {
+template <class ENV, int H, bool OID, int NW>
+int launch_ac_collect_nw(const typename ENV::Params& q, const float* packs, uint32_t round, int T, int proper_term, float* b_obs, int64_t* b_act,
+                         float* b_rew, uint8_t* b_done, float* b_filled, float* fin_return, int32_t* fin_length, int32_t* t_max, hipStream_t st) {
     constexpr int P = ENV::P, D = ENV::D0 + (OID ? P : 0);
     using S = MlpShape<D, H, ENV::A>;
-    MARL_REQUIRE(ENV::lds_bytes(q) <= ENV::LDS_MAX, "collector: the env needs %zu bytes of LDS per workgroup, compiled for %zu", ENV::lds_bytes(q),
-                 (size_t)ENV::LDS_MAX);
-    const size_t lds_bytes = PackPlan<S, P, ENV::LDS_MAX>::LDS_BYTES + ENV::lds_bytes(q);
+    using PP = PackPlan<S, P, ENV::LDS_MAX>;
+    // packs read from global memory (NW > 1, not resident): the LDS holds the env's own bytes only
+    const size_t lds_bytes = ((NW > 1 && !(PP::RESIDENT || PP::A3REG)) ? 0 : PP::LDS_BYTES) + ENV::lds_bytes(q);
     static LdsAttr attr_set;
     if (attr_set.need(lds_bytes)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ac_collect_kernel<ENV, H, OID>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ac_collect_kernel<ENV, H, OID, NW>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         attr_set.done(lds_bytes);
     }
-    (void)hipMemsetAsync(t_max, 0, sizeof(int32_t), st);
-    float* packs = nullptr;
-    if (launch_fwd_pack<S>(P, am, actor, &packs, st) != 0) return -1;
+    const int per_wg = 64 / NW;  // envs per workgroup
     timing_begin(TIMER_COLLECT, st);
-    hipLaunchKernelGGL((ac_collect_kernel<ENV, H, OID>), dim3((q.n_envs + 63) / 64), dim3(ACOL_BLOCK), lds_bytes, st, q, (const float*)packs, round, T,
+    hipLaunchKernelGGL((ac_collect_kernel<ENV, H, OID, NW>), dim3((q.n_envs + per_wg - 1) / per_wg), dim3(ACOL_BLOCK), lds_bytes, st, q, packs, round, T,
                        proper_term, b_obs, b_act, b_rew, b_done, b_filled, fin_return, fin_length, t_max);
     timing_end(TIMER_COLLECT, st);
     MARL_CHECK_LAUNCH("ac_collect_kernel");
     return 0;
+}
+
+template <class ENV, int H, bool OID>
+int launch_ac_collect(const typename ENV::Params& q, const AgentMap& am, const float* actor, uint32_t round, int T, int proper_term, float* b_obs, int64_t* b_act,
+                      float* b_rew, uint8_t* b_done, float* b_filled, float* fin_return, int32_t* fin_length, int32_t* t_max,
+                      hipStream_t st) {
+    constexpr int P = ENV::P, D = ENV::D0 + (OID ? P : 0), NWMAX = acol_max_nw<P>();
+    using S = MlpShape<D, H, ENV::A>;
+    MARL_REQUIRE(ENV::lds_bytes(q) <= ENV::LDS_MAX, "collector: the env needs %zu bytes of LDS per workgroup, compiled for %zu", ENV::lds_bytes(q),
+                 (size_t)ENV::LDS_MAX);
+    (void)hipMemsetAsync(t_max, 0, sizeof(int32_t), st);
+    float* packs = nullptr;
+    if (launch_fwd_pack<S>(P, am, actor, &packs, st) != 0) return -1;
+    // agent-per-wave copies when the launch would leave most SIMDs empty anyway (N / 16 waves on 1024 SIMDs); MARLHIP_ACOL_NW=1 keeps one wave per env block
+    static const int forced = getenv("MARLHIP_ACOL_NW") ? atoi(getenv("MARLHIP_ACOL_NW")) : 0;
+    // (env.standardise_rewards keeps per-env running records in memory that one wave per env must read and commit in lockstep)
+    const bool split = NWMAX > 1 && q.reward_stats == nullptr && (forced ? forced > 1 : (int64_t)q.n_envs * NWMAX <= 16384);
+#define MARL_ACOL_LAUNCH_ARGS q, (const float*)packs, round, T, proper_term, b_obs, b_act, b_rew, b_done, b_filled, fin_return, fin_length, t_max, st
+    if constexpr (NWMAX > 1) {
+        if (split) return launch_ac_collect_nw<ENV, H, OID, NWMAX>(MARL_ACOL_LAUNCH_ARGS);
+    }
+    return launch_ac_collect_nw<ENV, H, OID, 1>(MARL_ACOL_LAUNCH_ARGS);
+#undef MARL_ACOL_LAUNCH_ARGS
 }
 
 }  // namespace marl

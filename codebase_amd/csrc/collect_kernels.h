@@ -73,7 +73,9 @@ __global__ __launch_bounds__(COL_BLOCK) void dqn_act_kernel(int P, int N, AgentM
     }
 }
 
-template <class ENV, int H, bool OID>
+// NW: waves per block of 16 envs, each running the Q-networks of the agents p = w mod NW on its own copy of the env state (see
+// ac_collect_kernel: the joint action is swapped through LDS once per step, every copy steps with it)
+template <class ENV, int H, bool OID, int NW>
 __global__ __launch_bounds__(COL_BLOCK) void idqn_collect_kernel(typename ENV::Params q, const float* __restrict__ packs, float eps,
                                                                  uint32_t round, marlhip_replay_shape rs, marlhip_replay_buffers rb,
                                                                  int slot_base, int write_replay, int clear_stale, int proper_term,
@@ -82,12 +84,16 @@ __global__ __launch_bounds__(COL_BLOCK) void idqn_collect_kernel(typename ENV::P
     using S = MlpShape<D, H, A>;
     using PP = PackPlan<S, P, ENV::LDS_MAX>;
     constexpr bool RESIDENT = PP::RESIDENT || PP::A3REG;  // no per-step staging
+    constexpr bool FROM_GLOBAL = NW > 1 && !RESIDENT;      // packs too large for the LDS: each wave reads its agents' from L2
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ int s_act[NW > 1 ? 2 * 4 * P * 16 : 1];     // [step parity][env block of the workgroup][agent][env]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, j = lane & 15;
-    const int n = (blockIdx.x * 4 + wave) * 16 + j;
+    const int blk = wave / NW, aw = wave % NW;
+    const int n = (blockIdx.x * (4 / NW) + blk) * 16 + j;
     const int N = q.n_envs, T = rs.max_len;
     typename ENV::Ctx ctx;
-    ctx.init(q, reinterpret_cast<uint8_t*>(lds) + PP::LDS_BYTES, wave, j);
+    ctx.init(q, reinterpret_cast<uint8_t*>(lds) + (FROM_GLOBAL ? 0 : PP::LDS_BYTES), wave, j);
+    const bool lead = g == 0 && aw == 0;  // the lane that writes an env's per-env records
     const bool valid = n < N;
     const uint32_t env_id = (uint32_t)(valid ? n : N - 1);
 
@@ -118,6 +124,7 @@ __global__ __launch_bounds__(COL_BLOCK) void idqn_collect_kernel(typename ENV::P
     float x[P][S::KS1];
 #pragma unroll
     for (int p = 0; p < P; ++p) {
+        if (p % NW != aw) continue;  // a wave observes, forwards and stores for its own agents
         ENV::template observe<S::KS1, OID>(q, s, ctx, p, g, x[p]);
         if (wr) {  // ReplayBuffer.init_episode (train.py:65-68)
 #pragma unroll
@@ -133,8 +140,9 @@ __global__ __launch_bounds__(COL_BLOCK) void idqn_collect_kernel(typename ENV::P
     int len = 0;
 
     for (int t = 0; t < T; ++t) {
-        if (RESIDENT) {
-            if (!__any(alive)) break;  // wave-uniform: all 16 envs of this wave are finished
+        const bool any_alive = __any(alive);
+        if (RESIDENT && NW == 1) {
+            if (!any_alive) break;  // wave-uniform: all 16 envs of this wave are finished (NW > 1: the barrier below keeps every wave looping)
         }
         int act[P];
         float u;
@@ -143,9 +151,13 @@ __global__ __launch_bounds__(COL_BLOCK) void idqn_collect_kernel(typename ENV::P
         const bool explore = eps > u;
 #pragma unroll
         for (int p = 0; p < P; ++p) {
+            act[p] = 0;
+            if (p % NW != aw || (NW > 1 && !any_alive)) continue;
             const float* pack;
             if (RESIDENT) {
                 pack = lds + (size_t)p * PP::STRIDE;
+            } else if (FROM_GLOBAL) {
+                pack = packs + (size_t)p * S::NFWD;
             } else {
                 __syncthreads();
                 stage_packed<S>(packs + (size_t)p * S::NFWD, lds, tid, COL_BLOCK);
@@ -157,6 +169,15 @@ __global__ __launch_bounds__(COL_BLOCK) void idqn_collect_kernel(typename ENV::P
             const int greedy = argmax_rows<A>(qv, lane);
             act[p] = explore ? rnd[p] : greedy;
         }
+        if (NW > 1) {  // swap the chosen actions among the waves of the env block (double-buffered: one barrier per step)
+            int* sa = s_act + (((t & 1) * 4 + blk) * P) * 16;
+#pragma unroll
+            for (int p = 0; p < P; ++p)
+                if (p % NW == aw && g == 0) sa[p * 16 + j] = act[p];
+            __syncthreads();
+#pragma unroll
+            for (int p = 0; p < P; ++p) act[p] = sa[p * 16 + j];
+        }
         if (alive) {
             double raw[P];
             float rw[P];
@@ -164,11 +185,12 @@ __global__ __launch_bounds__(COL_BLOCK) void idqn_collect_kernel(typename ENV::P
             ENV::step(q, s, ctx, env_id, round, act, raw, done);
             const bool trunc = q.time_limit > 0 && ENV::elapsed(s) >= q.time_limit;
             const bool stored_done = proper_term ? done : (done || trunc);  // train.py:219-225
-            lbf_wrap_rewards<P>(q, env_id, raw, rw, g == 0);
+            lbf_wrap_rewards<P>(q, env_id, raw, rw, lead);
             ++len;
 #pragma unroll
             for (int p = 0; p < P; ++p) {
                 ep_ret[p] += (float)raw[p];  // RecordEpisodeStatistics (wrappers.py:33)
+                if (p % NW != aw) continue;
                 ENV::template observe<S::KS1, OID>(q, s, ctx, p, g, x[p]);
                 if (wr) {  // ReplayBuffer.add (train.py:73-84)
 #pragma unroll
@@ -180,13 +202,13 @@ __global__ __launch_bounds__(COL_BLOCK) void idqn_collect_kernel(typename ENV::P
                     }
                 }
             }
-            if (wr && g == 0) {
+            if (wr && lead) {
                 rd[t + 1] = stored_done ? 1 : 0;
                 rf[t] = 1;
             }
             if (done || trunc) {
                 alive = false;
-                if (g == 0) {
+                if (lead) {
 #pragma unroll
                     for (int p = 0; p < P; ++p) fin_return[(size_t)p * N + n] = ep_ret[p];
                     fin_length[n] = len;
@@ -194,7 +216,7 @@ __global__ __launch_bounds__(COL_BLOCK) void idqn_collect_kernel(typename ENV::P
             }
         }
     }
-    if (valid && g == 0) {
+    if (valid && lead) {
         if (alive) {  // rs.max_len shorter than the env's own limits: report what was collected
 #pragma unroll
             for (int p = 0; p < P; ++p) fin_return[(size_t)p * N + n] = ep_ret[p];
@@ -205,30 +227,52 @@ __global__ __launch_bounds__(COL_BLOCK) void idqn_collect_kernel(typename ENV::P
     }
 }
 
+template <class ENV, int H, bool OID, int NW>
+int launch_collect_nw(const typename ENV::Params& q, const float* packs, float eps, uint32_t round, const marlhip_replay_shape* rs,
+                      const marlhip_replay_buffers* rb, int slot_base, int write_replay, int clear_stale, int proper_term, float* fin_return,
+                      int32_t* fin_length, hipStream_t st) {
+    constexpr int P = ENV::P, D = ENV::D0 + (OID ? P : 0);
+    using S = MlpShape<D, H, ENV::A>;
+    using PP = PackPlan<S, P, ENV::LDS_MAX>;
+    const size_t lds_bytes = ((NW > 1 && !(PP::RESIDENT || PP::A3REG)) ? 0 : PP::LDS_BYTES) + ENV::lds_bytes(q);
+    static LdsAttr attr_set;
+    if (attr_set.need(lds_bytes)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&idqn_collect_kernel<ENV, H, OID, NW>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        attr_set.done(lds_bytes);
+    }
+    const int per_wg = 64 / NW;
+    timing_begin(TIMER_COLLECT, st);
+    hipLaunchKernelGGL((idqn_collect_kernel<ENV, H, OID, NW>), dim3((q.n_envs + per_wg - 1) / per_wg), dim3(COL_BLOCK), lds_bytes, st, q, packs, eps, round,
+                       *rs, *rb, slot_base, write_replay, clear_stale, proper_term, fin_return, fin_length);
+    timing_end(TIMER_COLLECT, st);
+    MARL_CHECK_LAUNCH("idqn_collect_kernel");
+    return 0;
+}
+
+template <int P>
+constexpr int col_max_nw() { return P % 4 == 0 ? 4 : (P % 2 == 0 ? 2 : 1); }
+
 template <class ENV, int H, bool OID>
 int launch_collect(const typename ENV::Params& q, const AgentMap& am, const float* params, float eps, uint32_t round, const marlhip_replay_shape* rs,
                    const marlhip_replay_buffers* rb, int slot_base, int write_replay, int clear_stale, int proper_term,
                    float* fin_return, int32_t* fin_length, hipStream_t st) {
-    constexpr int P = ENV::P, D = ENV::D0 + (OID ? P : 0);
+    constexpr int P = ENV::P, D = ENV::D0 + (OID ? P : 0), NWMAX = col_max_nw<P>();
     using S = MlpShape<D, H, ENV::A>;
     MARL_REQUIRE(ENV::lds_bytes(q) <= ENV::LDS_MAX, "collector: the env needs %zu bytes of LDS per workgroup, compiled for %zu", ENV::lds_bytes(q),
                  (size_t)ENV::LDS_MAX);
-    const size_t lds_bytes = PackPlan<S, P, ENV::LDS_MAX>::LDS_BYTES + ENV::lds_bytes(q);
-    static LdsAttr attr_set;
-    if (attr_set.need(lds_bytes)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&idqn_collect_kernel<ENV, H, OID>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        attr_set.done(lds_bytes);
-    }
-    const int grid = (q.n_envs + 63) / 64;
     float* packs = nullptr;
     if (launch_fwd_pack<S>(P, am, params, &packs, st) != 0) return -1;
-    timing_begin(TIMER_COLLECT, st);
-    hipLaunchKernelGGL((idqn_collect_kernel<ENV, H, OID>), dim3(grid), dim3(COL_BLOCK), lds_bytes, st, q, (const float*)packs, eps, round, *rs, *rb,
-                       slot_base, write_replay, clear_stale, proper_term, fin_return, fin_length);
-    timing_end(TIMER_COLLECT, st);
-    MARL_CHECK_LAUNCH("idqn_collect_kernel");
-    return 0;
+    // agent-per-wave copies while the launch leaves SIMDs empty (N / 16 waves on 1024 SIMDs); never with env.standardise_rewards (its
+    // per-env running records are read and committed by one wave in lockstep); MARLHIP_COL_NW=1 keeps one wave per env block
+    static const int forced = getenv("MARLHIP_COL_NW") ? atoi(getenv("MARLHIP_COL_NW")) : 0;
+    const bool split = NWMAX > 1 && q.reward_stats == nullptr && (forced ? forced > 1 : (int64_t)q.n_envs * NWMAX <= 16384);
+#define MARL_COL_LAUNCH_ARGS q, (const float*)packs, eps, round, rs, rb, slot_base, write_replay, clear_stale, proper_term, fin_return, fin_length, st
+    if constexpr (NWMAX > 1) {
+        if (split) return launch_collect_nw<ENV, H, OID, NWMAX>(MARL_COL_LAUNCH_ARGS);
+    }
+    return launch_collect_nw<ENV, H, OID, 1>(MARL_COL_LAUNCH_ARGS);
+#undef MARL_COL_LAUNCH_ARGS
 }
 
 }  // namespace marl
