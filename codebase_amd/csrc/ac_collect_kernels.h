@@ -85,16 +85,17 @@ __global__ __launch_bounds__(ACOL_BLOCK) void ac_collect_kernel(typename ENV::Pa
     ctx.init(q, reinterpret_cast<uint8_t*>(lds) + (FROM_GLOBAL ? 0 : PP::LDS_BYTES), wave, j);
     const bool valid = n < N;
     const uint32_t env_id = (uint32_t)(valid ? n : N - 1);
-    f4 a3[PP::A3REG ? P : 1][S::MT];  // output-layer operands, when the full packs do not fit the LDS
+    constexpr int K = P / NW;  // a wave's own agents: p = aw + k * NW, k < K (NW = 1: every agent, p = k)
+    f4 a3[PP::A3REG ? K : 1][S::MT];  // output-layer operands of the wave's agents, when the full packs do not fit the LDS
     if (RESIDENT) {
         for (int p = 0; p < P; ++p)
             stage_packed_prefix<S>(actor + (size_t)p * S::NFWD, lds + (size_t)p * PP::STRIDE, PP::STRIDE, tid, ACOL_BLOCK);
         if (PP::A3REG) {
 #pragma unroll
-            for (int p = 0; p < P; ++p)
+            for (int k = 0; k < K; ++k)
 #pragma unroll
                 for (int mt = 0; mt < S::MT; ++mt)
-                    a3[p][mt] = reinterpret_cast<const f4*>(actor + (size_t)p * S::NFWD + S::pA3)[mt * 64 + lane];
+                    a3[k][mt] = reinterpret_cast<const f4*>(actor + (size_t)(aw + k * NW) * S::NFWD + S::pA3)[mt * 64 + lane];
         }
         __syncthreads();
     }
@@ -102,15 +103,15 @@ __global__ __launch_bounds__(ACOL_BLOCK) void ac_collect_kernel(typename ENV::Pa
     ENV::reset(q, s, ctx, env_id, 2u * round);
     // batch_obs[t][n][p*D + d]
     auto obs_row = [&](int t) { return b_obs + ((size_t)t * N + env_id) * (P * D); };
-    float x[P][S::KS1];
+    float x[K][S::KS1];  // the wave observes, forwards, samples and stores for its own agents
 #pragma unroll
-    for (int p = 0; p < P; ++p) {
-        if (p % NW != aw) continue;  // (a wave's own agents: it observes, forwards, samples and stores for them)
-        ENV::template observe<S::KS1, OID>(q, s, ctx, p, g, x[p]);
+    for (int k = 0; k < K; ++k) {
+        const int p = aw + k * NW;
+        ENV::template observe<S::KS1, OID>(q, s, ctx, p, g, x[k]);
         if (valid) {
 #pragma unroll
             for (int ks = 0; ks < S::KS1; ++ks)
-                if (4 * ks + g < D) obs_row(0)[p * D + 4 * ks + g] = x[p][ks];
+                if (4 * ks + g < D) obs_row(0)[p * D + 4 * ks + g] = x[k][ks];
         }
     }
     const bool lead = g == 0 && aw == 0;  // the lane that writes an env's per-env records
@@ -121,14 +122,16 @@ __global__ __launch_bounds__(ACOL_BLOCK) void ac_collect_kernel(typename ENV::Pa
     for (int p = 0; p < P; ++p) ep_ret[p] = 0.f;
     int len = 0;
     for (int t = 0; t < T; ++t) {
-        int act[P];
+        int act[P], own[K];
 #pragma unroll
         for (int p = 0; p < P; ++p) act[p] = 0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) own[k] = 0;
         const bool any_running = __any(running);
         if ((RESIDENT || FROM_GLOBAL) ? any_running : true) {
 #pragma unroll
-            for (int p = 0; p < P; ++p) {
-                if (p % NW != aw) continue;
+            for (int k = 0; k < K; ++k) {
+                const int p = aw + k * NW;
                 const float* pack;
                 if (RESIDENT) {
                     pack = lds + (size_t)p * PP::STRIDE;
@@ -141,16 +144,18 @@ __global__ __launch_bounds__(ACOL_BLOCK) void ac_collect_kernel(typename ENV::Pa
                     pack = lds;
                 }
                 f4 h1[S::MT], h2[S::MT], logits, unused;
-                mlp_forward_p<S, false>(pack, pack, lane, x[p], h1, h2, logits, unused, PP::A3REG ? a3[PP::A3REG ? p : 0] : nullptr);
+                if constexpr (FROM_GLOBAL) mlp_forward_g<S>(pack, lane, x[k], logits);
+                else mlp_forward_p<S, false>(pack, pack, lane, x[k], h1, h2, logits, unused, PP::A3REG ? a3[PP::A3REG ? k : 0] : nullptr);
                 const float u = u01_f32(act_noise_word(q.seed, env_id, 2u * round, (uint32_t)t, 1 + p));
-                act[p] = sample_rows<A>(logits, lane, u);
+                own[k] = sample_rows<A>(logits, lane, u);
+                if (NW == 1) act[k] = own[k];
             }
         }
         if (NW > 1) {  // swap the sampled actions among the waves of the env block (double-buffered: one barrier per step)
             int* sa = s_act + (((t & 1) * 4 + blk) * P) * 16;
 #pragma unroll
-            for (int p = 0; p < P; ++p)
-                if (p % NW == aw && g == 0) sa[p * 16 + j] = act[p];
+            for (int k = 0; k < K; ++k)
+                if (g == 0) sa[(aw + k * NW) * 16 + j] = own[k];
             __syncthreads();
 #pragma unroll
             for (int p = 0; p < P; ++p) act[p] = sa[p * 16 + j];
@@ -169,16 +174,17 @@ __global__ __launch_bounds__(ACOL_BLOCK) void ac_collect_kernel(typename ENV::Pa
                 ENV::reset(q, s, ctx, env_id, 2u * round + 1u);
             }
 #pragma unroll
-            for (int p = 0; p < P; ++p) {
-                ep_ret[p] += (float)raw[p];
-                if (p % NW != aw) continue;
-                ENV::template observe<S::KS1, OID>(q, s, ctx, p, g, x[p]);
+            for (int p = 0; p < P; ++p) ep_ret[p] += (float)raw[p];
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const int p = aw + k * NW;
+                ENV::template observe<S::KS1, OID>(q, s, ctx, p, g, x[k]);
 #pragma unroll
                 for (int ks = 0; ks < S::KS1; ++ks)
-                    if (4 * ks + g < D) obs_row(t + 1)[p * D + 4 * ks + g] = x[p][ks];
+                    if (4 * ks + g < D) obs_row(t + 1)[p * D + 4 * ks + g] = x[k][ks];
                 if (g == 0) {
-                    b_act[((size_t)t * N + n) * P + p] = act[p];
-                    b_rew[((size_t)t * N + n) * P + p] = rw[p];
+                    b_act[((size_t)t * N + n) * P + p] = own[k];
+                    b_rew[((size_t)t * N + n) * P + p] = pick_agent<P>(rw, p);
                 }
             }
             if (lead) {
@@ -197,8 +203,8 @@ __global__ __launch_bounds__(ACOL_BLOCK) void ac_collect_kernel(typename ENV::Pa
         } else if (valid) {
             // rows of an env that is no longer running stay zero, as in the reference's freshly allocated batch
 #pragma unroll
-            for (int p = 0; p < P; ++p) {
-                if (p % NW != aw) continue;
+            for (int k = 0; k < K; ++k) {
+                const int p = aw + k * NW;
 #pragma unroll
                 for (int ks = 0; ks < S::KS1; ++ks)
                     if (4 * ks + g < D) obs_row(t + 1)[p * D + 4 * ks + g] = 0.f;
@@ -258,7 +264,7 @@ int launch_ac_collect(const typename ENV::Params& q, const AgentMap& am, const f
     // agent-per-wave copies when the launch would leave most SIMDs empty anyway (N / 16 waves on 1024 SIMDs); MARLHIP_ACOL_NW=1 keeps one wave per env block
     static const int forced = getenv("MARLHIP_ACOL_NW") ? atoi(getenv("MARLHIP_ACOL_NW")) : 0;
     // (env.standardise_rewards keeps per-env running records in memory that one wave per env must read and commit in lockstep)
-    const bool split = NWMAX > 1 && q.reward_stats == nullptr && (forced ? forced > 1 : (int64_t)q.n_envs * NWMAX <= 16384);
+    const bool split = NWMAX > 1 && q.reward_stats == nullptr && (forced ? forced > 1 : q.n_envs <= 8192);  // measured: ahead up to 8192 envs (2 and 4 agents), behind from 16384
 #define MARL_ACOL_LAUNCH_ARGS q, (const float*)packs, round, T, proper_term, b_obs, b_act, b_rew, b_done, b_filled, fin_return, fin_length, t_max, st
     if constexpr (NWMAX > 1) {
         if (split) return launch_ac_collect_nw<ENV, H, OID, NWMAX>(MARL_ACOL_LAUNCH_ARGS);

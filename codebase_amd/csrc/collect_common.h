@@ -66,6 +66,15 @@ __device__ __forceinline__ void stage_packed(const float* __restrict__ pack, flo
     copy_f4_to_lds(src, dst, S::NFWD / 4, tid, nthreads);
 }
 
+// arr[p] for a run-time p without a dynamically indexed register array
+template <int P, class T>
+__device__ __forceinline__ T pick_agent(const T (&arr)[P], int p) {
+    T v = arr[0];
+#pragma unroll
+    for (int o = 1; o < P; ++o) v = o == p ? arr[o] : v;
+    return v;
+}
+
 // how a collector keeps P forward packs on chip
 template <class S, int P, size_t ENV_LDS = 0>
 struct PackPlan {

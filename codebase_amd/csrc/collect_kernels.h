@@ -97,16 +97,17 @@ __global__ __launch_bounds__(COL_BLOCK) void idqn_collect_kernel(typename ENV::P
     const bool valid = n < N;
     const uint32_t env_id = (uint32_t)(valid ? n : N - 1);
 
-    f4 a3[PP::A3REG ? P : 1][S::MT];  // output-layer operands of every agent, when the full packs do not fit the LDS
+    constexpr int K = P / NW;  // a wave's own agents: p = aw + k * NW, k < K (NW = 1: every agent, p = k)
+    f4 a3[PP::A3REG ? K : 1][S::MT];  // output-layer operands of the wave's agents, when the full packs do not fit the LDS
     if (RESIDENT) {
         for (int p = 0; p < P; ++p)
             stage_packed_prefix<S>(packs + (size_t)p * S::NFWD, lds + (size_t)p * PP::STRIDE, PP::STRIDE, tid, COL_BLOCK);
         if (PP::A3REG) {
 #pragma unroll
-            for (int p = 0; p < P; ++p)
+            for (int k = 0; k < K; ++k)
 #pragma unroll
                 for (int mt = 0; mt < S::MT; ++mt)
-                    a3[p][mt] = reinterpret_cast<const f4*>(packs + (size_t)p * S::NFWD + S::pA3)[mt * 64 + lane];
+                    a3[k][mt] = reinterpret_cast<const f4*>(packs + (size_t)(aw + k * NW) * S::NFWD + S::pA3)[mt * 64 + lane];
         }
         __syncthreads();
     }
@@ -121,15 +122,15 @@ __global__ __launch_bounds__(COL_BLOCK) void idqn_collect_kernel(typename ENV::P
     uint8_t* rf = rb.filled + (size_t)slot * T;
     const bool wr = valid && write_replay;
 
-    float x[P][S::KS1];
+    float x[K][S::KS1];  // the wave observes, forwards and stores for its own agents
 #pragma unroll
-    for (int p = 0; p < P; ++p) {
-        if (p % NW != aw) continue;  // a wave observes, forwards and stores for its own agents
-        ENV::template observe<S::KS1, OID>(q, s, ctx, p, g, x[p]);
+    for (int k = 0; k < K; ++k) {
+        const int p = aw + k * NW;
+        ENV::template observe<S::KS1, OID>(q, s, ctx, p, g, x[k]);
         if (wr) {  // ReplayBuffer.init_episode (train.py:65-68)
 #pragma unroll
             for (int ks = 0; ks < S::KS1; ++ks)
-                if (4 * ks + g < D) ro[((size_t)p * (T + 1) + 0) * D + 4 * ks + g] = x[p][ks];
+                if (4 * ks + g < D) ro[((size_t)p * (T + 1) + 0) * D + 4 * ks + g] = x[k][ks];
         }
     }
 
@@ -144,15 +145,18 @@ __global__ __launch_bounds__(COL_BLOCK) void idqn_collect_kernel(typename ENV::P
         if (RESIDENT && NW == 1) {
             if (!any_alive) break;  // wave-uniform: all 16 envs of this wave are finished (NW > 1: the barrier below keeps every wave looping)
         }
-        int act[P];
+        int act[P], own[K];
         float u;
         int rnd[P];
         act_noise<P>(q.seed, env_id, round, (uint32_t)t, (uint32_t)A, u, rnd);
         const bool explore = eps > u;
 #pragma unroll
-        for (int p = 0; p < P; ++p) {
-            act[p] = 0;
-            if (p % NW != aw || (NW > 1 && !any_alive)) continue;
+        for (int p = 0; p < P; ++p) act[p] = 0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int p = aw + k * NW;
+            own[k] = 0;
+            if (NW > 1 && !any_alive) continue;
             const float* pack;
             if (RESIDENT) {
                 pack = lds + (size_t)p * PP::STRIDE;
@@ -165,15 +169,17 @@ __global__ __launch_bounds__(COL_BLOCK) void idqn_collect_kernel(typename ENV::P
                 pack = lds;
             }
             f4 h1[S::MT], h2[S::MT], qv, unused;
-            mlp_forward_p<S, false>(pack, pack, lane, x[p], h1, h2, qv, unused, PP::A3REG ? a3[PP::A3REG ? p : 0] : nullptr);
+            if constexpr (FROM_GLOBAL) mlp_forward_g<S>(pack, lane, x[k], qv);
+            else mlp_forward_p<S, false>(pack, pack, lane, x[k], h1, h2, qv, unused, PP::A3REG ? a3[PP::A3REG ? k : 0] : nullptr);
             const int greedy = argmax_rows<A>(qv, lane);
-            act[p] = explore ? rnd[p] : greedy;
+            own[k] = explore ? pick_agent<P>(rnd, p) : greedy;
+            if (NW == 1) act[k] = own[k];
         }
         if (NW > 1) {  // swap the chosen actions among the waves of the env block (double-buffered: one barrier per step)
             int* sa = s_act + (((t & 1) * 4 + blk) * P) * 16;
 #pragma unroll
-            for (int p = 0; p < P; ++p)
-                if (p % NW == aw && g == 0) sa[p * 16 + j] = act[p];
+            for (int k = 0; k < K; ++k)
+                if (g == 0) sa[(aw + k * NW) * 16 + j] = own[k];
             __syncthreads();
 #pragma unroll
             for (int p = 0; p < P; ++p) act[p] = sa[p * 16 + j];
@@ -188,17 +194,18 @@ __global__ __launch_bounds__(COL_BLOCK) void idqn_collect_kernel(typename ENV::P
             lbf_wrap_rewards<P>(q, env_id, raw, rw, lead);
             ++len;
 #pragma unroll
-            for (int p = 0; p < P; ++p) {
-                ep_ret[p] += (float)raw[p];  // RecordEpisodeStatistics (wrappers.py:33)
-                if (p % NW != aw) continue;
-                ENV::template observe<S::KS1, OID>(q, s, ctx, p, g, x[p]);
+            for (int p = 0; p < P; ++p) ep_ret[p] += (float)raw[p];  // RecordEpisodeStatistics (wrappers.py:33)
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const int p = aw + k * NW;
+                ENV::template observe<S::KS1, OID>(q, s, ctx, p, g, x[k]);
                 if (wr) {  // ReplayBuffer.add (train.py:73-84)
 #pragma unroll
                     for (int ks = 0; ks < S::KS1; ++ks)
-                        if (4 * ks + g < D) ro[((size_t)p * (T + 1) + t + 1) * D + 4 * ks + g] = x[p][ks];
+                        if (4 * ks + g < D) ro[((size_t)p * (T + 1) + t + 1) * D + 4 * ks + g] = x[k][ks];
                     if (g == 0) {
-                        ra_[p * T + t] = (uint8_t)act[p];
-                        rr[p * T + t] = rw[p];
+                        ra_[p * T + t] = (uint8_t)own[k];
+                        rr[p * T + t] = pick_agent<P>(rw, p);
                     }
                 }
             }
@@ -266,7 +273,7 @@ int launch_collect(const typename ENV::Params& q, const AgentMap& am, const floa
     // agent-per-wave copies while the launch leaves SIMDs empty (N / 16 waves on 1024 SIMDs); never with env.standardise_rewards (its
     // per-env running records are read and committed by one wave in lockstep); MARLHIP_COL_NW=1 keeps one wave per env block
     static const int forced = getenv("MARLHIP_COL_NW") ? atoi(getenv("MARLHIP_COL_NW")) : 0;
-    const bool split = NWMAX > 1 && q.reward_stats == nullptr && (forced ? forced > 1 : (int64_t)q.n_envs * NWMAX <= 16384);
+    const bool split = NWMAX > 1 && q.reward_stats == nullptr && (forced ? forced > 1 : q.n_envs <= 8192);  // measured: ahead up to 8192 envs (2 and 4 agents), behind from 16384
 #define MARL_COL_LAUNCH_ARGS q, (const float*)packs, eps, round, rs, rb, slot_base, write_replay, clear_stale, proper_term, fin_return, fin_length, st
     if constexpr (NWMAX > 1) {
         if (split) return launch_collect_nw<ENV, H, OID, NWMAX>(MARL_COL_LAUNCH_ARGS);

@@ -20,6 +20,8 @@
 // Canonical parameters of one agent = torch parameters() order of FCNetwork:
 //   W1[H][D] b1[H] W2[H][H] b2[H] W3[A][H] b3[A]      (row-major, nn.Linear layout)
 #pragma once
+#include <type_traits>
+#include <utility>
 #include <hip/hip_runtime.h>
 
 namespace marl {
@@ -325,6 +327,80 @@ __device__ __forceinline__ void mlp_forward_p(const float* ldsA, const float* ld
         }
     qA = o3A;
     if (DUAL) qB = o3B;
+}
+
+template <int I, int N, class F>
+__device__ __forceinline__ void marl_static_for(F& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        marl_static_for<I + 1, N>(f);
+    }
+}
+
+// mlp_forward_p for a pack that stays in GLOBAL memory (the collectors' agent-per-wave form when the packs of all agents do not fit
+// the LDS): the same operand groups in the same order - N1 first-layer k-groups, MT second-layer groups, the output group - but
+// fetched THREE groups deep (a group = MT 16-byte loads feeding 4 * MT MFMAs, ~1000 cycles at hidden 128: one group of lookahead
+// does not cover an L2 round trip, two do).  Same per-output summation order as mlp_forward_p / mlp_forward.
+template <class S>
+__device__ __forceinline__ void mlp_forward_g(const float* __restrict__ gpack, int lane, const float (&x)[S::KS1], f4& q) {
+    constexpr int MT = S::MT, N1 = S::KS1 / 4, G = N1 + MT + 1;
+    const int g = lane >> 4;
+    const f4* A1 = reinterpret_cast<const f4*>(gpack + S::pA1);
+    const f4* A2 = reinterpret_cast<const f4*>(gpack + S::pA2);
+    const f4* A3 = reinterpret_cast<const f4*>(gpack + S::pA3);
+    f4 op[3][MT], acc[MT], nb[MT], h1[MT], h2[MT], o3;
+    auto fetch = [&](auto gi_c) {
+        constexpr int gi = decltype(gi_c)::value;
+        if constexpr (gi < G) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                op[gi % 3][mt] = gi < N1 ? A1[(mt * N1 + gi) * 64 + lane] : (gi < N1 + MT ? A2[(mt * MT + (gi - N1)) * 64 + lane] : A3[mt * 64 + lane]);
+        }
+    };
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        acc[mt] = *reinterpret_cast<const f4*>(gpack + S::pb1 + 16 * mt + 4 * g);
+        nb[mt] = *reinterpret_cast<const f4*>(gpack + S::pb2 + 16 * mt + 4 * g);
+    }
+    o3 = *reinterpret_cast<const f4*>(gpack + S::pb3 + 4 * g);
+    fetch(std::integral_constant<int, 0>{});
+    fetch(std::integral_constant<int, 1>{});
+    auto step = [&](auto gi_c) {
+        constexpr int gi = decltype(gi_c)::value;
+        fetch(std::integral_constant<int, gi + 2>{});
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (gi < N1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[mt] = MARL_MFMA(op[gi % 3][mt][e], x[4 * gi + e], acc[mt]);
+            if constexpr (gi == N1 - 1) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    h1[mt] = relu4(acc[mt]);
+                    acc[mt] = nb[mt];
+                }
+            }
+        } else if constexpr (gi < N1 + MT) {
+            constexpr int k1 = gi - N1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[mt] = MARL_MFMA(op[gi % 3][mt][r], h1[k1][r], acc[mt]);
+            if constexpr (k1 == MT - 1) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) h2[mt] = relu4(acc[mt]);
+            }
+        } else {
+#pragma unroll
+            for (int k1 = 0; k1 < MT; ++k1)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o3 = MARL_MFMA(op[gi % 3][k1][r], h2[k1][r], o3);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    marl_static_for<0, G>(step);  // every group index is a compile-time constant
+    q = o3;
 }
 
 // One network on TWO 16-row blocks at once: every A operand fetched from LDS feeds two MFMAs, which halves the LDS
