@@ -67,48 +67,6 @@ extern "C" int marlhip_gru_forward(const marlhip_net_shape* s, const float* para
     return -1;
 }
 
-// chosen_p = Q_p(o_t)[a_t], bootstrap_p = target Q_p(o_{t+1})[argmax] (QMixNetwork._compute_loss, dqn/model.py:384-410), and the
-// transition's scalars in the [R] = [T * B] layout the mixer kernels read
-static __global__ __launch_bounds__(256) void gru_qsel_kernel(int P, int T, int B, int A, const float* __restrict__ q, const float* __restrict__ tq,
-                                                       marlhip_batch bt, int double_q, float* __restrict__ chosen, float* __restrict__ tqsel,
-                                                       float* __restrict__ r0, float* __restrict__ dn, float* __restrict__ fl) {
-    const int i = blockIdx.x * 256 + threadIdx.x, R = T * B;
-    if (i >= R) return;
-    const int t = i / B, b = i - t * B;
-    for (int p = 0; p < P; ++p) {
-        const float* qn = q + (((size_t)p * (T + 1) + t + 1) * B + b) * A;
-        const float* tn = tq + (((size_t)p * (T + 1) + t + 1) * B + b) * A;
-        const float* mk = bt.action_mask ? bt.action_mask + (((size_t)p * (T + 1) + t + 1) * B + b) * A : nullptr;
-        int best = 0;
-        float bv = -__builtin_huge_valf();
-        for (int a = 0; a < A; ++a) {
-            float v = double_q ? qn[a] : tn[a];
-            if (mk != nullptr && mk[a] == 0.f) v = -1e8f;
-            if (v > bv) { bv = v; best = a; }
-        }
-        float boot = tn[best];
-        if (mk != nullptr && mk[best] == 0.f) boot = -1e8f;
-        tqsel[(size_t)p * R + i] = boot;
-        chosen[(size_t)p * R + i] = q[(((size_t)p * (T + 1) + t) * B + b) * A + (int)bt.actions[((size_t)p * T + t) * B + b]];
-    }
-    r0[i] = bt.rewards[i];  // batch.rewards[0] (model.py:379)
-    dn[i] = bt.dones[(size_t)(t + 1) * B + b];
-    fl[i] = bt.filled[i];
-}
-
-// dL/dchosen_p [P][R] from the mixer -> dense dL/dq rows [P][T+1][B][A] (row T was zeroed)
-static __global__ __launch_bounds__(256) void gru_expand_dq_kernel(int P, int T, int B, int A, const float* __restrict__ dqm, marlhip_batch bt,
-                                                            float* __restrict__ dq) {
-    const int i = blockIdx.x * 256 + threadIdx.x, R = T * B;
-    if (i >= R) return;
-    const int t = i / B, b = i - t * B;
-    for (int p = 0; p < P; ++p) {
-        const int act = (int)bt.actions[((size_t)p * T + t) * B + b];
-        const float v = dqm[(size_t)p * R + i];
-        for (int a = 0; a < A; ++a) dq[(((size_t)p * (T + 1) + t) * B + b) * A + a] = a == act ? v : 0.f;
-    }
-}
-
 // ---- learner step: QNetwork._compute_loss / VDNetwork._compute_loss + backward with recurrent networks ----------------------
 namespace {
 struct GruWs {

@@ -6,6 +6,7 @@
 // marlhip_act_from_q / marlhip_sample_from_logits -> env step -> replay add).
 #include "td_rows.h"
 #include "wide_mlp.h"
+#include "dqn_update_kernels.h"  // QmixCtx / QmixIo of the mixer stage (templates only: nothing is instantiated here)
 
 using namespace marl;
 
@@ -97,4 +98,74 @@ extern "C" int marlhip_wide_dqn_loss_grad(const marlhip_net_shape* s, const floa
     rc = wide_backward_rows(net, P, am, params, bt->obss, as, D, T * B, bt->filled, f(wl.dq), (int64_t)rows_all * A, f(wl.lrow), base + wl.bwd, grad, loss, st);
     timing_end(TIMER_LOSSGRAD, st);
     return rc;
+}
+
+// ---- QMIX with such agent networks: GEMM forward of the online and target networks -> chosen / bootstrap values -> the mixer stage of
+// qmix.h (through dqn_update.hip, as the recurrent learner uses it) -> dL/dchosen expanded to dense rows -> GEMM backward
+namespace marl {
+int qmix_mix_stage(const marlhip_net_shape* s, const QmixCtx* qx, const marlhip_batch* bt, const QmixIo* io, float gamma, int phase,
+                   const float* loss, hipStream_t stream);
+int64_t qmix_mixer_ws_bytes(const marlhip_net_shape* s, int32_t max_len, int32_t batch);
+}
+
+static int64_t wide_qmix_extra(const marlhip_net_shape* s, int T, int B) { return ((int64_t)(3 * s->n_agents + 3) * T * B * 4 + 255) / 256 * 256; }
+
+extern "C" int64_t marlhip_wide_qmix_workspace_bytes(const marlhip_net_shape* s, int32_t max_len, int32_t batch) {
+    const int64_t a = marlhip_wide_dqn_workspace_bytes(s, max_len, batch), m = a < 0 ? -1 : qmix_mixer_ws_bytes(s, max_len, batch);
+    if (a < 0 || m < 0) return -1;
+    return a + wide_qmix_extra(s, max_len, batch) + m;
+}
+
+extern "C" int marlhip_wide_qmix_loss_grad(const marlhip_net_shape* s, const float* params, const float* target_params, const marlhip_qmix_mixer* mx,
+                                           const marlhip_batch* bt, float gamma, int32_t double_q, void* workspace, int64_t workspace_bytes,
+                                           float* grad, float* loss, void* stream) {
+    MARL_REQUIRE(s && params && target_params && mx && mx->mixer && mx->target_mixer && mx->mixer_grad && bt && workspace && grad && loss,
+                 "wide_qmix_loss_grad: NULL pointer");
+    if (wide_check(s, s->n_actions) != 0) return -1;
+    MARL_REQUIRE(mx->embed_dim == 64 && mx->hypernet_layers == 2 && mx->hypernet_embed == 32, "wide_qmix_loss_grad: mixing = {64, 2, 32} only");
+    MARL_REQUIRE(mx->ret_stats == nullptr, "wide_qmix_loss_grad: no return standardisation on this path");
+    MARL_REQUIRE(bt->obss && bt->actions && bt->rewards && bt->dones && bt->filled && bt->max_len > 0 && bt->batch > 0, "wide_qmix_loss_grad: bad batch");
+    MARL_REQUIRE(bt->obs_agent_stride == 0 && bt->obs_row_stride == 0, "wide_qmix_loss_grad: the dqn/train.py Batch layout only");
+    const int P = s->n_agents, T = bt->max_len, B = bt->batch, A = s->n_actions, D = s->obs_dim;
+    const int64_t R = (int64_t)T * B;
+    const WideNet net = wide_net(s, A);
+    const WideDqnWs wl = wide_dqn_ws(net, P, T, B);
+    const int64_t extra = wide_qmix_extra(s, T, B), mixws = qmix_mixer_ws_bytes(s, T, B);
+    if (mixws < 0) return -1;
+    MARL_REQUIRE(workspace_bytes >= wl.total + extra + mixws, "wide_qmix_loss_grad: workspace %lld < %lld bytes", (long long)workspace_bytes,
+                 (long long)(wl.total + extra + mixws));
+    hipStream_t st = (hipStream_t)stream;
+    char* base = static_cast<char*>(workspace);
+    auto f = [&](int64_t off) { return reinterpret_cast<float*>(base + off); };
+    float* chosen = f(wl.total);
+    float* tqsel = chosen + P * R;
+    float* dqm = tqsel + P * R;
+    float* r0 = dqm + P * R;
+    float* dn = r0 + R;
+    float* fl = dn + R;
+    QmixCtx qx;
+    qx.mixer = mx->mixer; qx.tmixer = mx->target_mixer; qx.mgrad = mx->mixer_grad;
+    qx.ws = base + wl.total + extra; qx.ws_bytes = mixws;
+    const AgentMap am = agent_map(s);
+    const int rows_all = (T + 1) * B;
+    const int64_t as = (int64_t)rows_all * D;
+    const dim3 gridR((unsigned)((R + 255) / 256));
+    timing_begin(TIMER_LOSSGRAD, st);
+    int rc = wide_forward_rows(net, P, am, params, bt->obss, as, D, rows_all, f(wl.q), base + wl.bwd, st);
+    if (rc != 0) return rc;
+    rc = wide_forward_rows(net, P, am, target_params, bt->obss, as, D, rows_all, f(wl.tq), base + wl.bwd, st);
+    if (rc != 0) return rc;
+    hipLaunchKernelGGL(gru_qsel_kernel, gridR, dim3(256), 0, st, P, T, B, A, (const float*)f(wl.q), (const float*)f(wl.tq), *bt, double_q, chosen, tqsel,
+                       r0, dn, fl);
+    MARL_CHECK_LAUNCH("gru_qsel_kernel (wide)");
+    QmixIo io = {chosen, tqsel, r0, dn, fl, dqm, f(wl.lrow), nullptr};
+    rc = qmix_mix_stage(s, &qx, bt, &io, gamma, 0, nullptr, st);
+    if (rc != 0) return rc;
+    (void)hipMemsetAsync(f(wl.dq), 0, (size_t)P * rows_all * A * sizeof(float), st);
+    hipLaunchKernelGGL(gru_expand_dq_kernel, gridR, dim3(256), 0, st, P, T, B, A, (const float*)dqm, *bt, f(wl.dq));
+    MARL_CHECK_LAUNCH("gru_expand_dq_kernel (wide)");
+    rc = wide_backward_rows(net, P, am, params, bt->obss, as, D, T * B, bt->filled, f(wl.dq), (int64_t)rows_all * A, f(wl.lrow), base + wl.bwd, grad, loss, st);
+    timing_end(TIMER_LOSSGRAD, st);
+    if (rc != 0) return rc;
+    return qmix_mix_stage(s, &qx, bt, &io, gamma, 1, loss, st);
 }

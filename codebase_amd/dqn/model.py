@@ -189,8 +189,8 @@ class QNetwork:
         self.device = torch.device(device)
         self.sharing = sharing_indices(parameter_sharing, self.n_agents)
         self.spec = _hip.NetSpec(self.n_agents, obs_dims[0], hidden_k[0], act_dims[0], self.sharing, wide=is_wide(hidden), n_hidden=len(hidden))
-        if self.spec.wide and (self.standardise_returns or type(self).__name__ == "QMixNetwork"):
-            raise NotImplementedError(f"layers={hidden}: lists other than two layers of at most 128 units run IDQN / VDN without return standardisation (the GEMM path)")
+        if self.spec.wide and self.standardise_returns:
+            raise NotImplementedError(f"layers={hidden}: lists other than two layers of at most 128 units run without return standardisation (the GEMM path)")
         if self.recurrent:  # RNNNetwork (utils/models.py:51-116): Linear -> ReLU -> GRU -> Linear
             self.nparams = _hip.gru_nparams(self.spec)
             critic, target = init_flat_gru_params(obs_dims, hidden[0], act_dims, use_orthogonal_init, self.sharing)
@@ -422,7 +422,7 @@ class QMixNetwork(QNetwork):
         self.mixer_params = mixer.to(self.device).contiguous()
         self.target_mixer_params = tmixer.to(self.device).contiguous()
         up = self.updater
-        self.updater = (_hip.GruQmixUpdater if self.recurrent else _hip.QmixUpdater)(self.spec, self.params, self.target_params, self.mixer_params, self.target_mixer_params,
+        self.updater = (_hip.GruQmixUpdater if self.recurrent else _hip.WideQmixUpdater if self.spec.wide else _hip.QmixUpdater)(self.spec, self.params, self.target_params, self.mixer_params, self.target_mixer_params,
                                         mixing=self.mixing, lr=up.lr, gamma=self.gamma, grad_clip=self.grad_clip,
                                         double_q=self.double_q)
         self.mode = 2

@@ -792,6 +792,35 @@ class GruQmixUpdater(QmixUpdater):
         return self.loss_grad(replay.sample(batch_size, length=length, idx=idx, seed=seed, counter=counter), mode=mode)
 
 
+class WideQmixUpdater(QmixUpdater):
+    """QmixUpdater with agent networks on the GEMM path (spec.wide): marlhip_wide_qmix_loss_grad for the step, everything else inherited"""
+
+    def _wide_ws(self, T, B):
+        key = ("wide", T, B)
+        if key not in self._ws:
+            s = self.spec.c()
+            n = check(lib.marlhip_wide_qmix_workspace_bytes(ctypes.byref(s), T, B), "wide_qmix_workspace_bytes")
+            self._ws.clear()
+            self._ws[key] = torch.empty(int(n), dtype=torch.uint8, device=self.params.device)
+        return self._ws[key]
+
+    def loss_grad(self, batch, mode=2):
+        T, B = batch.filled.shape
+        ws = self._wide_ws(T, B)
+        bs = BatchStruct(batch.obss.data_ptr(), batch.actions.data_ptr(), batch.rewards.data_ptr(), batch.dones.data_ptr(),
+                         batch.filled.data_ptr(), T, B, 0, 0, 0, 0, _mask_ptr(batch.action_mask, (self.spec.n_agents, T + 1, B, self.spec.n_actions)))
+        if self.ret_stats is not None:
+            raise NotImplementedError("standardise_returns with QMIX agents on the GEMM path is not built")
+        s, mx = self.spec.c(), self._mx()
+        check(lib.marlhip_wide_qmix_loss_grad(ctypes.byref(s), _ptr(self.params), _ptr(self.target), ctypes.byref(mx), ctypes.byref(bs),
+                                              float(self.gamma), self.double_q, _ptr(ws), ws.numel(), _ptr(self.grad), _ptr(self.loss),
+                                              _stream()), "wide_qmix_loss_grad")
+        return self.loss, self.grad
+
+    def loss_grad_replay(self, replay, batch_size, length=None, idx=None, seed=0, counter=0, idx_out=None, mode=2):
+        return self.loss_grad(replay.sample(batch_size, length=length, idx=idx, seed=seed, counter=counter), mode=mode)
+
+
 def gru_ac_forward(spec: NetSpec, params, obs, agent_stride, row_stride, steps, batch, value_net=False, h_in=None, want_h=False):
     """sequence forward of recurrent actors (logits [P][steps][B][A]) or critics (values [P][steps][B][1]); rows of agent p at
     obs + p * agent_stride + (t * B + b) * row_stride; hidden state [P][B][H] in / out"""

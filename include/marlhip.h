@@ -356,6 +356,13 @@ int64_t marlhip_gru_qmix_workspace_bytes(const marlhip_net_shape* s, int32_t max
 int marlhip_gru_qmix_loss_grad(const marlhip_net_shape* s, const float* params, const float* target_params,
                                const struct marlhip_qmix_mixer* mixer, const marlhip_batch* batch, float gamma, int32_t double_q,
                                void* workspace, int64_t workspace_bytes, float* grad, float* loss /* [2] */, void* stream);
+/* marlhip_qmix_loss_grad with agent networks on the GEMM path (marlhip_wide_*: layers wider than 128 or not two deep); the mixer stage is
+ * the same one, no return standardisation */
+int64_t marlhip_wide_qmix_workspace_bytes(const marlhip_net_shape* s, int32_t max_len, int32_t batch);
+int marlhip_wide_qmix_loss_grad(const marlhip_net_shape* s, const float* params, const float* target_params, const marlhip_qmix_mixer* mixer,
+                                const marlhip_batch* batch, float gamma, int32_t double_q, void* workspace, int64_t workspace_bytes,
+                                float* grad, float* loss, void* stream);
+
 
 /* Actor-critic learner step with recurrent networks (`use_rnn: True` for actor and critic; ia2c.yaml / ippo.yaml): same contracts as
  * marlhip_a2c_loss_grad / marlhip_ppo_prepare / marlhip_ppo_loss_grad, the blocks in the recurrent layout (marlhip_gru_nparams for the

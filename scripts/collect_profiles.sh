@@ -11,8 +11,11 @@ timeout 300 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum -d $O/pmc_TC
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS -d $O/pmc_SQ --output-format csv -- $B --steps 3 --warmup 1 --no-kernel-timing > $O/pmc_SQ.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VALU_MFMA_MOPS_F32 -d $O/pmc_INST --output-format csv -- $B --steps 3 --warmup 1 --no-kernel-timing > $O/pmc_INST.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/stats_h128 --output-format csv -- $B --steps 10 --warmup 2 --hidden 128 > $O/stats_h128.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/stats_gru64 --output-format csv -- $B --steps 4 --warmup 1 --rnn > $O/stats_gru64.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/stats_rware_ia2c --output-format csv -- $B --steps 4 --warmup 1 --algo ia2c --env-name rware:rware-tiny-4ag-v2 --time-limit 500 --envs 2048 --hidden 128 > $O/stats_rware_ia2c.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/stats_qmix8p --output-format csv -- $B --steps 2 --warmup 1 --algo qmix --env-name lbforaging:Foraging-15x15-8p-5f-v3 --envs 8192 --hidden 128 > $O/stats_qmix8p.log 2>&1
 cd $R
-./scripts/_bin/mfma_ubench > $O/mfma_ubench.txt 2>&1; ./scripts/_bin/mfma_ubench2 > $O/mfma_ubench2.txt 2>&1; ./scripts/_bin/mfma_ubench3 > $O/mfma_ubench3.txt 2>&1
+./scripts/_bin/mfma_ubench > $O/mfma_ubench.txt 2>&1; ./scripts/_bin/mfma_ubench2 > $O/mfma_ubench2.txt 2>&1; ./scripts/_bin/mfma_ubench3 > $O/mfma_ubench3.txt 2>&1; ./scripts/_bin/mfma_ubench4 > $O/mfma_ubench4.txt 2>&1
 : > $O/matrix.jsonl
 run() { timeout 400 $B "$@" 2>/dev/null | grep '^{' >> $O/matrix.jsonl; }
 run --steps 60 --warmup 5
@@ -31,6 +34,9 @@ run --steps 20 --warmup 3 --algo ia2c --env-name lbforaging:Foraging-15x15-4p-5f
 run --steps 100 --warmup 5 --algo maa2c --hidden 128
 run --steps 50 --warmup 5 --algo mappo --hidden 128
 run --steps 5 --warmup 1 --algo ia2c --env-name rware:rware-tiny-4ag-v2 --time-limit 500 --envs 2048 --hidden 128
+run --steps 3 --warmup 1 --algo ia2c --env-name rware:rware-tiny-4ag-v2 --time-limit 500 --envs 16384 --hidden 128
+run --steps 3 --warmup 1 --algo mappo --env-name rware:rware-tiny-4ag-v2 --time-limit 500 --envs 2048 --hidden 128
+run --steps 3 --warmup 1 --algo maa2c --env-name lbforaging:Foraging-15x15-8p-5f-v3 --envs 4096 --hidden 128
 run --steps 5 --warmup 1 --algo ia2c --env-name rware:rware-tiny-4ag-v2 --time-limit 500 --envs 2048 --hidden 64
 run --steps 3 --warmup 1 --algo idqn --env-name rware:rware-tiny-4ag-v2 --time-limit 500 --envs 2048 --hidden 64
 run --steps 3 --warmup 1 --algo qmix --env-name rware:rware-tiny-4ag-v2 --time-limit 500 --envs 2048 --hidden 64

@@ -36,17 +36,23 @@ def short(name):
 def main():
     head = open(os.path.join(ROOT, "scripts", "_bin", "head.txt")).read().strip() if os.path.exists(os.path.join(ROOT, "scripts", "_bin", "head.txt")) else None
     for tag, out in (("stats", "r02_bench_ratio_kernel_stats.csv"), ("stats_h128", "r02_bench_ratio_H128_kernel_stats.csv"),
-                     ("stats_hbm", "r02_hbm_ubench_kernel_stats.csv")):
+                     ("stats_hbm", "r02_hbm_ubench_kernel_stats.csv"), ("stats_gru64", "r02_gru_H64_kernel_stats.csv"),
+                     ("stats_rware_ia2c", "r02_rware_ia2c_tiny4ag_H128_kernel_stats.csv"),
+                     ("stats_qmix8p", "r02_qmix_15x15_8p5f_H128_kernel_stats.csv")):
         f = first(f"{tag}/**/*_kernel_stats.csv")
         if f:
             shutil.copy(f, os.path.join(DST, out))
     if os.path.exists(os.path.join(SRC, "matrix.jsonl")):
         shutil.copy(os.path.join(SRC, "matrix.jsonl"), os.path.join(DST, "r02_bench_matrix.jsonl"))
     with open(os.path.join(DST, "r02_mfma_valu_ubench.txt"), "w") as o:
-        for f in ("mfma_ubench.txt", "mfma_ubench2.txt", "mfma_ubench3.txt"):
+        for f in ("mfma_ubench.txt", "mfma_ubench2.txt", "mfma_ubench3.txt", "mfma_ubench4.txt"):
             p = os.path.join(SRC, f)
             if os.path.exists(p):
-                o.write(f"==== scripts/{f.replace('.txt', '.hip')} (MI355X, one wave per SIMD, 256 workgroups x 256 threads) ====\n{open(p).read()}\n")
+                o.write(f"==== scripts/{f.replace('.txt', '.hip')} (MI355X, one wave per SIMD unless stated, 256 workgroups x 256 threads) ====\n{open(p).read()}\n")
+        o.write("-> mfma_ubench4 (read its TFLOP/s column): a second / fourth wave on the SIMD recovers only ~10-13 % (69 -> 76 -> 78 TFLOP/s at 4 VALU\n"
+                "   per MFMA): the VALU work occupies the pipe the f32 MFMA runs on (about 7 cycles per v_fma even when another wave's MFMAs are\n"
+                "   ready), it is not an in-order-issue stall of one wave.  Restructuring the learner for 2 waves per SIMD (it needs 444 of 512\n"
+                "   registers today) would not pay.\n")
     if os.path.exists(os.path.join(SRC, "hbm_ubench.txt")):
         shutil.copy(os.path.join(SRC, "hbm_ubench.txt"), os.path.join(DST, "r02_hbm_ubench.txt"))
     # ---- HBM traffic of the learner kernel (two TCC passes; FETCH_SIZE doubled per MI355X_MICROARCH.md "HBM")

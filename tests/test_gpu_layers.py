@@ -147,6 +147,7 @@ def test_wide_layers_run_end_to_end(tmp_path, monkeypatch):
     NAME = "lbforaging:Foraging-8x8-2p-3f-v3"
     for algo, extra in (("idqn", ["algorithm.model.layers=[256,256]", "algorithm.batch_size=64"]),
                         ("vdn", ["algorithm.model.layers=[192,256]", "algorithm.batch_size=64"]),
+                        ("qmix", ["algorithm.model.layers=[64,64,64]", "algorithm.batch_size=64"]),
                         ("ia2c", ["algorithm.model.actor.layers=[256,256]", "algorithm.model.critic.layers=[256,256]"])):
         monkeypatch.setenv("MARLHIP_RUN_DIR", str(tmp_path / algo))
         df = run.main([f"+algorithm={algo}", f"env.name={NAME}", "env.time_limit=25", "env.parallel_envs=256", "seed=1",

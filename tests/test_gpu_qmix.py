@@ -105,3 +105,27 @@ def test_qmix_rejects_other_mixing_configs():
     with pytest.raises(MarlHipError):
         h.QmixUpdater(spec, dp.init_params(2, 15, 64, 6).to(DEV), dp.init_params(2, 15, 64, 6).to(DEV), z, z,
                       mixing=dict(embed_dim=32, hypernet_layers=1, hypernet_embed=64))
+
+
+@pytest.mark.parametrize("P,T,B,D,H,L", [(2, 25, 33, 15, 256, 2), (4, 9, 50, 27, 160, 2), (2, 12, 40, 15, 64, 3), (3, 7, 21, 18, 96, 1)])
+def test_qmix_with_agent_networks_on_the_gemm_path_vs_oracle_port(P, T, B, D, H, L):
+    """layers wider than 128 or not two deep: marlhip_wide_qmix_loss_grad (GEMM agent networks around the same mixer stage)"""
+    h = hip()
+    A = 6
+    hid = (H,) * L
+    spec = h.NetSpec(P, D, H, A, wide=True, n_hidden=L)
+    params = dp.init_params(P, D, hid, A, seed=1) + 0.05
+    target = dp.init_params(P, D, hid, A, seed=3)
+    mixer = qp.mixer_init(P, P * D, seed=11)
+    tmixer = qp.mixer_init(P, P * D, seed=12)
+    batch = dp.synthetic_batch(P, T, B, D, A, seed=5)
+    batch["rewards"][1:] = batch["rewards"][0]
+    batch["obss"] = batch["obss"] * 0.25
+    pr, mr = params.clone().requires_grad_(True), mixer.clone().requires_grad_(True)
+    ref = qp.compute_loss(pr, target, mr, tmixer, batch, 0.99, True, D, hid, A)
+    ref.backward()
+    up = h.WideQmixUpdater(spec, params.to(DEV), target.to(DEV), mixer.to(DEV), tmixer.to(DEV))
+    loss, grad = up.loss_grad(dev_batch(h, batch))
+    assert abs(loss.cpu().numpy()[0] - ref.item()) <= 3e-5 * abs(ref.item())
+    assert_grad_close(grad.cpu().numpy(), pr.grad.numpy(), 3e-4)
+    assert_grad_close(up.mixer_grad.cpu().numpy(), mr.grad.numpy(), 3e-4)
