@@ -138,12 +138,23 @@ int gru_loss_grad(const marlhip_net_shape* s, const float* params, const float* 
         float* dn = r0 + R;
         float* fl = dn + R;
         float* partial = fl + R;
-        MARL_REQUIRE((3 * P + 3) * R + 2 * P * ((R + 255) / 256) <= (int64_t)P * steps * ((B + 15) / 16) * Bk::REC2, "gru_loss_grad: scratch");
+        float* rbuf = partial + 2 * P * ((R + 255) / 256);  // VDN: the standardised returns [R]
+        MARL_REQUIRE((3 * P + 4) * R + 2 * P * ((R + 255) / 256) <= (int64_t)P * steps * ((B + 15) / 16) * Bk::REC2, "gru_loss_grad: scratch");
         const dim3 gridR((unsigned)((R + 255) / 256));
         hipLaunchKernelGGL(gru_qsel_kernel, gridR, dim3(256), 0, st, P, T, B, S::A, (const float*)f(wl.q), (const float*)f(wl.tq), *bt, double_q, chosen,
                            tqsel, r0, dn, fl);
-        const int rc = launch_std_mixer(P, (int)R, gamma, *rst, chosen, tqsel, bt->rewards, dn, fl, dqm, f(wl.lrow), partial, st);
-        if (rc != 0) return rc;
+        if (mode == 1) {  // VDNetwork (dqn/model.py:256-264): per-batch-column statistics on the summed bootstrap, then the VDN rows
+            int rc = launch_colstd(T, B, gamma, *rst, tqsel, P, (size_t)R, r0, dn, rbuf, st);
+            if (rc != 0) return rc;
+            MixBufs mix = {};
+            mix.chosen = chosen; mix.tqsel = tqsel; mix.r0 = r0; mix.dn = dn; mix.fl = fl; mix.dq = dqm; mix.lrow = f(wl.lrow);
+            hipLaunchKernelGGL(vdn_mix_kernel, dim3((unsigned)(gridR.x > 1024 ? 1024 : gridR.x)), dim3(256), 0, st, mix, P, T, B, gamma, (const float*)rbuf);
+            for (int p = 1; p < P; ++p)  // one dL/dchosen for every agent
+                (void)hipMemcpyAsync(dqm + (size_t)p * R, dqm, (size_t)R * sizeof(float), hipMemcpyDeviceToDevice, st);
+        } else {
+            const int rc = launch_std_mixer(P, (int)R, gamma, *rst, chosen, tqsel, bt->rewards, dn, fl, dqm, f(wl.lrow), partial, st);
+            if (rc != 0) return rc;
+        }
         hipLaunchKernelGGL(gru_expand_dq_kernel, gridR, dim3(256), 0, st, P, T, B, S::A, (const float*)dqm, *bt, f(wl.dq));
     } else {
         hipLaunchKernelGGL(gru_td_kernel, dim3((T * B + 255) / 256), dim3(256), 0, st, P, T, B, S::A, (const float*)f(wl.q), (const float*)f(wl.tq), *bt,
@@ -248,6 +259,14 @@ int gru_qmix_loss_grad(const marlhip_net_shape* s, const float* params, const fl
     QmixCtx qx;
     qx.mixer = mx->mixer; qx.tmixer = mx->target_mixer; qx.mgrad = mx->mixer_grad;
     qx.ws = base + wl.total + extra; qx.ws_bytes = mixws;
+    RetStats rst;
+    if (mx->ret_stats != nullptr) {  // standardise_returns: the mixer stage standardises the target mixer's output per batch column
+        const marlhip_ret_stats* stt = mx->ret_stats;
+        MARL_REQUIRE(stt->mean && stt->var && stt->count && stt->columns == B, "gru_qmix_loss_grad: return statistics need columns = batch (%d), got %d", B,
+                     stt->columns);
+        rst.mean = stt->mean; rst.var = stt->var; rst.count = stt->count; rst.columns = stt->columns;
+        qx.rst = &rst;
+    }
     const AgentMap am = agent_map(s);
     hipLaunchKernelGGL((gru_pack_kernel<S>), dim3((S::NFWD + 255) / 256, P), dim3(256), 0, st, params, am, f(wl.packC));
     hipLaunchKernelGGL((gru_pack_kernel<S>), dim3((S::NFWD + 255) / 256, P), dim3(256), 0, st, target, am, f(wl.packT));
@@ -318,11 +337,14 @@ extern "C" int marlhip_gru_loss_grad_std(const marlhip_net_shape* s, const float
                  "gru_loss_grad_std: NULL pointer");
     MARL_REQUIRE(batch->obs_agent_stride == 0 && batch->obs_row_stride == 0, "gru_loss_grad_std: the dqn/train.py Batch layout only");
     RetStats rst;
-    rst.mean = stats->mean; rst.var = stats->var; rst.count = stats->count; rst.columns = 0;
-    MARL_REQUIRE(stats->columns == 0, "gru_loss_grad_std: per-agent statistics (the independent learner) only");
+    rst.mean = stats->mean; rst.var = stats->var; rst.count = stats->count; rst.columns = stats->columns;
+    // columns = 0: per-agent statistics, the independent learner; columns = batch: VDNetwork's per-batch-column statistics (marlhip_ret_stats)
+    MARL_REQUIRE(stats->columns == 0 || stats->columns == batch->batch, "gru_loss_grad_std: statistics with %d columns for a batch of %d",
+                 stats->columns, batch->batch);
+    const int mode = stats->columns == 0 ? 0 : 1;
 #define X(d, h, a)                                               \
     if (s->obs_dim == d && s->hidden == h && s->n_actions == a)  \
-        return gru_loss_grad<GruShape<d, h, a>>(s, params, target_params, batch, gamma, double_q, 0, workspace, workspace_bytes, grad, loss, \
+        return gru_loss_grad<GruShape<d, h, a>>(s, params, target_params, batch, gamma, double_q, mode, workspace, workspace_bytes, grad, loss, \
                                                 (hipStream_t)stream, &rst);
     MARL_GRU_SHAPES(X)
 #undef X

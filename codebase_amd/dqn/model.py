@@ -180,10 +180,6 @@ class QNetwork:
         if (opt if isinstance(opt, str) else getattr(opt, "__name__", "")) != "Adam":
             raise NotImplementedError(f"optimizer {opt}: the fused step implements torch.optim.Adam")
         self.standardise_returns = bool(get("standardise_returns", False))
-        if self.standardise_returns and type(self).__name__ != "QNetwork" and self.recurrent:
-            # VDN / QMIX keep RunningMeanStd(shape=(1,)) but feed it [T, B] returns: per-batch-column statistics, reproduced for the
-            # feed-forward networks (hip.RunningReturnStats(columns=B)); the recurrent TD kernel does not take them yet
-            raise NotImplementedError("standardise_returns with use_rnn is built for the independent learner (QNetwork) only")
         self.action_space = action_space
         self.n_agents = len(obs_dims)
         self.device = torch.device(device)
@@ -424,7 +420,7 @@ class QMixNetwork(QNetwork):
         up = self.updater
         self.updater = (_hip.GruQmixUpdater if self.recurrent else _hip.WideQmixUpdater if self.spec.wide else _hip.QmixUpdater)(self.spec, self.params, self.target_params, self.mixer_params, self.target_mixer_params,
                                         mixing=self.mixing, lr=up.lr, gamma=self.gamma, grad_clip=self.grad_clip,
-                                        double_q=self.double_q)
+                                        double_q=self.double_q, standardise_returns=self.standardise_returns)
         self.mode = 2
 
     def update_async(self, batch, grad_sync=None, world=1, replay=None, **sample_kw):

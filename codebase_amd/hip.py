@@ -728,11 +728,9 @@ class GruUpdater(DqnUpdater):
     """DqnUpdater for the recurrent networks: same buffers / clip+Adam / target update, marlhip_gru_loss_grad for the step."""
 
     def loss_grad(self, batch, mode=0):
-        if self.ret_stats is not None:  # standardise_returns: the independent learner only (as for feed-forward networks)
-            if mode != 0:
-                raise NotImplementedError("standardise_returns is built for independent learners (IDQN) only")
+        if self.ret_stats is not None:  # standardise_returns: per-agent statistics (IDQN) or VDNetwork's per-batch-column ones
             T, B = batch.filled.shape
-            s, st = self.spec.c(), self.ret_stats.c()
+            s, st = self.spec.c(), self._stats_for(mode, B).c()
             n = check(lib.marlhip_gru_workspace_bytes(ctypes.byref(s), T, B), "gru_workspace_bytes")
             if self._ws.get("gru_std_n") != n:
                 self._ws = {"gru_std_n": n, "buf": torch.empty(n, dtype=torch.uint8, device=self.params.device)}
@@ -780,9 +778,7 @@ class GruQmixUpdater(QmixUpdater):
         ws = self._gru_ws(T, B)
         bs = BatchStruct(batch.obss.data_ptr(), batch.actions.data_ptr(), batch.rewards.data_ptr(), batch.dones.data_ptr(),
                          batch.filled.data_ptr(), T, B, 0, 0, 0, 0, _mask_ptr(batch.action_mask, (self.spec.n_agents, T + 1, B, self.spec.n_actions)))
-        if self.ret_stats is not None:
-            raise NotImplementedError("standardise_returns with recurrent QMIX agents is not built")
-        s, mx = self.spec.c(), self._mx()
+        s, mx = self.spec.c(), self._mx(B)
         check(lib.marlhip_gru_qmix_loss_grad(ctypes.byref(s), _ptr(self.params), _ptr(self.target), ctypes.byref(mx), ctypes.byref(bs),
                                              float(self.gamma), self.double_q, _ptr(ws), ws.numel(), _ptr(self.grad), _ptr(self.loss),
                                              _stream()), "gru_qmix_loss_grad")

@@ -123,6 +123,49 @@ def vdn_qmix(rm, rt):
         print(f"learner_std_{kind}_H64", losses, out["mean3"][:3], out["var3"][:3], out["count3"])
 
 
+def vdn_qmix_rnn(rm, rt):
+    """learner_std_vdn_gru_H64.npz / learner_std_qmix_gru_H64.npz: the same with recurrent agents (use_rnn=True: RNNNetwork,
+    utils/models.py:51-116; whole [T + 1, B] sequences from zero hidden states, dqn/model.py:118-163)"""
+    from .make_golden_qmix import mixer_flat
+
+    P, T, B, D, A, H = 2, 10, 32, 15, 6, 64
+    mixing = dict(embed_dim=64, hypernet_layers=2, hypernet_embed=32)
+    for kind in ("vdn", "qmix"):
+        torch.manual_seed(2300 if kind == "vdn" else 2400)
+        cfg = Cfg(optimizer="Adam", lr=3e-4, gamma=0.99, grad_clip=1.0, target_update_interval_or_tau=2, double_q=True,
+                  standardise_returns=True)
+        with contextlib.redirect_stdout(io.StringIO()):
+            if kind == "vdn":
+                net = rm.VDNetwork([Box(D)] * P, [Discrete(A)] * P, cfg, [H, H], False, True, True, "cpu")
+            else:
+                net = rm.QMixNetwork([Box(D)] * P, [Discrete(A)] * P, cfg, [H, H], False, True, True, mixing, "cpu")
+        g = torch.Generator().manual_seed(2301)
+        with torch.no_grad():
+            extra = list(net.target_mixer.parameters()) if kind == "qmix" else []
+            for p in list(net.target.parameters()) + extra:
+                p.add_(0.05 * torch.randn(p.shape, generator=g))
+        out = dict(P=P, T=T, B=B, D=D, A=A, H=H, params0=flat_params(net.critic).numpy(), target0=flat_params(net.target).numpy())
+        if kind == "qmix":
+            out["mixer0"], out["tmixer0"] = mixer_flat(net.mixer).numpy(), mixer_flat(net.target_mixer).numpy()
+        losses = []
+        for i in range(3):
+            b = synthetic_batch(P, T, B, D, A, seed=2500 + i)
+            b["rewards"][1:] = b["rewards"][0]  # CooperativeReward
+            b["obss"] = b["obss"] * 0.25
+            losses.append(net.update(rt.Batch(b["obss"], b["actions"], b["rewards"], b["dones"], b["filled"], None))["loss"])
+            out[f"params{i + 1}"] = flat_params(net.critic).numpy()
+            if kind == "qmix":
+                out[f"mixer{i + 1}"] = mixer_flat(net.mixer).numpy()
+            out[f"mean{i + 1}"], out[f"var{i + 1}"] = net.ret_ms.mean.numpy(), net.ret_ms.var.numpy()
+            out[f"count{i + 1}"] = np.float64(net.ret_ms.count)
+            assert out[f"mean{i + 1}"].shape == (B,), out[f"mean{i + 1}"].shape
+            for k, v in b.items():
+                out[f"batch{i}_{k}"] = v.numpy()
+        out["losses"] = np.array(losses, np.float32)
+        np.savez_compressed(os.path.join(OUT, f"learner_std_{kind}_gru_H64.npz"), **out)
+        print(f"learner_std_{kind}_gru_H64", losses, out["mean3"][:3], out["var3"][:3], out["count3"])
+
+
 if __name__ == "__main__":
     torch.set_num_threads(1)
     rm, rt = import_reference()
@@ -131,3 +174,4 @@ if __name__ == "__main__":
     idqn(rm, rt)
     a2c(ram, rat)
     vdn_qmix(rm, rt)
+    vdn_qmix_rnn(rm, rt)
