@@ -69,3 +69,19 @@ def test_product_code_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f"{f} imports the oracle"
+
+
+def test_integration_md_stub_structs_match_the_binding():
+    """the ctypes stub printed in INTEGRATION.md declares the same struct layouts as codebase_amd/_lib.py (and so include/marlhip.h)"""
+    from codebase_amd import _lib
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    md = open(os.path.join(root, "INTEGRATION.md")).read()
+    code = re.search(r"```python\n# marlbase/utils/marlhip_stub.py\n(.*?)```", md, re.S).group(1)
+    # the two struct classes only: no library load, no torch
+    classes = "import ctypes\n" + "\n".join(m.group(0) for m in re.finditer(r"class \w+\(ctypes\.Structure\):.*?(?=\nclass |\nlib\.)", code, re.S))
+    ns = {}
+    exec(classes, ns)
+    for stub, real in ((ns["NetShape"], _lib.NetShape), (ns["Batch"], _lib.BatchStruct)):
+        assert ctypes.sizeof(stub) == ctypes.sizeof(real)
+        assert [(n, ctypes.sizeof(t)) for n, t in stub._fields_] == [(n, ctypes.sizeof(t)) for n, t in real._fields_]
