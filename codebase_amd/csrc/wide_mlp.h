@@ -13,6 +13,8 @@
 // addressed by (row, column) strides, so X^T / W^T never exist in memory; weight gradients split the row dimension over grid.z and a
 // second kernel adds the partial tiles in a fixed order (bitwise reproducible, no atomics) and applies 1 / sum(filled).
 #pragma once
+#include <stdlib.h>
+
 #include "common.h"
 #include "mlp.h"
 
@@ -105,6 +107,95 @@ __global__ __launch_bounds__(256) void wide_gemm_kernel(const GemmOp g) {
     }
 }
 
+// The same product on a 128 x 128 tile per workgroup for the large GEMMs (both output dimensions >= 128: hidden layers over all rows,
+// weight gradients of wide layers): wave w owns a 64 x 64 quadrant = 4 x 4 MFMA tiles, so a 16-deep k-slice costs 8 ds_read_b128
+// for 64 MFMAs (the 64 x 64 kernel above: 20 ds_read_b32 for 16).  LDS layout [row][16 + 4] with k PERMUTED inside a row - slot
+// 4 q + s holds k = 4 s + q - so that the four k-steps' operands of a lane (its k-quarter q) are one 16-byte read.
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void wide_gemm128_kernel(const GemmOp g) {
+    constexpr int LD = 20;
+    __shared__ __attribute__((aligned(16))) float As[128 * LD], Bs[128 * LD];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 15, q = lane >> 4;
+    const int wm = wave >> 1, wn = wave & 1;  // the wave's quadrant
+    const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
+    const int kbeg = blockIdx.z * g.k_chunk, kend = min(g.K, kbeg + g.k_chunk);
+    f4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f4{0.f, 0.f, 0.f, 0.f};
+    float ra[8], rb[8];
+    auto load = [&](int k0) {
+        if (A_KC) {  // thread: one row, eight consecutive k
+            const int m = m0 + (tid & 127), kq = k0 + 8 * (tid >> 7);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ra[e] = (m < g.M && kq + e < kend) ? g.A[(int64_t)m * g.a_m + (int64_t)(kq + e) * g.a_k] : 0.f;
+        } else {  // thread: one k, eight consecutive rows
+            const int k = k0 + (tid >> 4), mm = m0 + 8 * (tid & 15);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ra[e] = (mm + e < g.M && k < kend) ? g.A[(int64_t)(mm + e) * g.a_m + (int64_t)k * g.a_k] : 0.f;
+        }
+        if (B_KC) {
+            const int n = n0 + (tid & 127), kq = k0 + 8 * (tid >> 7);
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                rb[e] = (n < g.N && kq + e < kend) ? (n == g.b_ones ? 1.f : g.B[(int64_t)(kq + e) * g.b_k + (int64_t)n * g.b_n]) : 0.f;
+        } else {
+            const int k = k0 + (tid >> 4), nn = n0 + 8 * (tid & 15);
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                rb[e] = (nn + e < g.N && k < kend) ? (nn + e == g.b_ones ? 1.f : g.B[(int64_t)k * g.b_k + (int64_t)(nn + e) * g.b_n]) : 0.f;
+        }
+    };
+    auto slot = [](int k) { return 4 * (k & 3) + (k >> 2); };  // k = 4 s + q  ->  4 q + s
+    auto store = [&]() {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            if (A_KC) As[(tid & 127) * LD + slot(8 * (tid >> 7) + e)] = ra[e];
+            else As[(8 * (tid & 15) + e) * LD + slot(tid >> 4)] = ra[e];
+            if (B_KC) Bs[(tid & 127) * LD + slot(8 * (tid >> 7) + e)] = rb[e];
+            else Bs[(8 * (tid & 15) + e) * LD + slot(tid >> 4)] = rb[e];
+        }
+    };
+    if (kbeg < kend) load(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += 16) {
+        __syncthreads();
+        store();
+        __syncthreads();
+        if (k0 + 16 < kend) load(k0 + 16);
+        f4 a[4], b[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            a[t] = *reinterpret_cast<const f4*>(As + (64 * wm + 16 * t + i) * LD + 4 * q);
+            b[t] = *reinterpret_cast<const f4*>(Bs + (64 * wn + 16 * t + i) * LD + 4 * q);
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = MARL_MFMA(a[mt][s2], b[nt][s2], acc[mt][nt]);
+    }
+    float* C = g.C + (int64_t)blockIdx.z * g.c_split;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int n = n0 + 64 * wn + 16 * nt + i;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + 64 * wm + 16 * mt + 4 * q + r;
+                if (m < g.M && n < g.N) {
+                    float v = acc[mt][nt][r];
+                    if (g.epi == 1 || g.epi == 2) v += g.bias[n];
+                    if (g.epi == 2) v = fmaxf(v, 0.f);
+                    if (g.epi == 3) v = g.gate[(int64_t)m * g.gate_m + n] > 0.f ? v : 0.f;
+                    C[(int64_t)m * g.c_m + n] = v;
+                }
+            }
+        }
+}
+
 // dW[m][n < N - 1] and db[m] (column N - 1) = (sum over the splits, in split order) * inv, inv = 1 / nf[0]
 static __global__ __launch_bounds__(256) void wide_fold_kernel(const float* __restrict__ partial, int splits, int64_t split_stride, int M, int N,
                                                                const float* __restrict__ nf, float* __restrict__ dW, float* __restrict__ db) {
@@ -118,12 +209,15 @@ static __global__ __launch_bounds__(256) void wide_fold_kernel(const float* __re
     else db[m] = acc;
 }
 
-// out[0] = sum(lrow) / nf, out[1] = nf = sum(filled): one workgroup, fixed order (the launch_backward_rows contract)
+// out[0] = sum(lrow) / nf, out[1] = nf = sum(filled) in two fixed-order stages (the launch_backward_rows contract): per-workgroup sums of a
+// contiguous slice each, then one workgroup adds them in slice order
+constexpr int WIDE_COUNT_MAX_WG = 256;
 static __global__ __launch_bounds__(256) void wide_count_kernel(const float* __restrict__ filled, const float* __restrict__ lrow, int n,
-                                                                float* __restrict__ out) {
+                                                                float* __restrict__ part /* [gridDim.x][2] */) {
     __shared__ float sh[2][4];
+    const int per = (n + gridDim.x - 1) / gridDim.x, beg = blockIdx.x * per, end = min(n, beg + per);
     float nf = 0.f, ls = 0.f;
-    for (int k = threadIdx.x; k < n; k += 256) {
+    for (int k = beg + threadIdx.x; k < end; k += 256) {
         nf += filled[k];
         if (lrow != nullptr) ls += lrow[k];
     }
@@ -138,11 +232,25 @@ static __global__ __launch_bounds__(256) void wide_count_kernel(const float* __r
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        nf = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]);
-        ls = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
-        out[0] = ls / nf;
-        out[1] = nf;
+        part[2 * blockIdx.x] = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]);
+        part[2 * blockIdx.x + 1] = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
     }
+}
+static __global__ __launch_bounds__(64) void wide_count_final_kernel(const float* __restrict__ part, int nwg, float* __restrict__ out) {
+    if (threadIdx.x != 0) return;
+    float nf = 0.f, ls = 0.f;
+    for (int w = 0; w < nwg; ++w) {
+        nf += part[2 * w];
+        ls += part[2 * w + 1];
+    }
+    out[0] = ls / nf;
+    out[1] = nf;
+}
+inline void wide_count(const float* filled, const float* lrow, int n, float* part, float* out, hipStream_t st) {
+    int nwg = (n + 4095) / 4096;
+    nwg = nwg < 1 ? 1 : (nwg > WIDE_COUNT_MAX_WG ? WIDE_COUNT_MAX_WG : nwg);
+    hipLaunchKernelGGL(wide_count_kernel, dim3(nwg), dim3(256), 0, st, filled, lrow, n, part);
+    hipLaunchKernelGGL(wide_count_final_kernel, dim3(1), dim3(64), 0, st, (const float*)part, nwg, out);
 }
 
 // grad[blk][i] = sum over the agents of block blk, in agent order, of gp[p][i]
@@ -196,7 +304,7 @@ inline WideWs wide_ws(const WideNet& s, int P, int rows, bool backward) {
         w.d[1] = take((int64_t)rows * s.H);
         w.partial = take((int64_t)wide_splits(rows) * s.H * (s.widest() + 1));
         w.gp = take((int64_t)P * s.nparam());
-        w.nf = take(4);
+        w.nf = take(4 + 2 * WIDE_COUNT_MAX_WG);  // [loss, nf | slack | per-workgroup partials]
     }
     w.total = o;
     return w;
@@ -204,7 +312,12 @@ inline WideWs wide_ws(const WideNet& s, int P, int rows, bool backward) {
 
 template <bool A_KC, bool B_KC>
 inline void wide_gemm(const GemmOp& g, int splits, hipStream_t st) {
-    hipLaunchKernelGGL((wide_gemm_kernel<A_KC, B_KC>), dim3((g.N + 63) / 64, (g.M + 63) / 64, splits), dim3(256), 0, st, g);
+    static const bool small_only = getenv("MARLHIP_WIDE_GEMM64") != nullptr;  // diagnostics: the 64 x 64 kernel for everything
+    const int64_t wgs128 = (int64_t)((g.N + 127) / 128) * ((g.M + 127) / 128) * splits;
+    if (g.M >= 128 && g.N >= 128 && wgs128 >= 512 && !small_only)  // (a smaller launch fills the chip better with 64 x 64 tiles)
+        hipLaunchKernelGGL((wide_gemm128_kernel<A_KC, B_KC>), dim3((g.N + 127) / 128, (g.M + 127) / 128, splits), dim3(256), 0, st, g);
+    else
+        hipLaunchKernelGGL((wide_gemm_kernel<A_KC, B_KC>), dim3((g.N + 63) / 64, (g.M + 63) / 64, splits), dim3(256), 0, st, g);
 }
 
 // hidden activations Y_1 .. Y_L of `rows` rows x (row r at x + r * row_stride) for one network: y[k - 1] = Y_k [rows][H]
@@ -250,7 +363,7 @@ inline int wide_backward_rows(const WideNet& s, int P, const AgentMap& am, const
     float* y[WideNet::MAXL];
     for (int k = 0; k < s.L; ++k) y[k] = f(w.y[k]);
     float *dbuf[2] = {f(w.d[0]), f(w.d[1])}, *part = f(w.partial), *gp = f(w.gp), *nf = f(w.nf);
-    hipLaunchKernelGGL(wide_count_kernel, dim3(1), dim3(256), 0, st, filled, lrow, rows, nf);
+    wide_count(filled, lrow, rows, nf + 4, nf, st);
     const int splits = wide_splits(rows), chunk = (((rows + splits - 1) / splits) + 15) & ~15;
     const int H = s.H, A = s.A, L = s.L;
     for (int p = 0; p < P; ++p) {
@@ -287,7 +400,7 @@ inline int wide_backward_rows(const WideNet& s, int P, const AgentMap& am, const
     }
     const int n = am.nblk * (int)s.nparam();
     hipLaunchKernelGGL(wide_gather_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)gp, P, (int)s.nparam(), am, grad);
-    hipLaunchKernelGGL(wide_count_kernel, dim3(1), dim3(256), 0, st, filled, lrow, rows, loss);
+    wide_count(filled, lrow, rows, nf + 4, loss, st);
     MARL_CHECK_LAUNCH("wide_gemm_kernel (backward)");
     return 0;
 }
