@@ -1,5 +1,5 @@
 mkdir -p gpurun_out/learn; O=gpurun_out/learn
-L="python scripts/learning_parity.py"
+L="python tests/tools/learning_parity.py"
 for s in 0 1 2; do timeout 300 $L scalar $s 400000 2>/dev/null | grep '^{' > $O/scalar_s$s.jsonl; tail -1 $O/scalar_s$s.jsonl; done
 V="$L vec"
 for s in 0 1 2; do timeout 120 $V $s 3e7 4096 32 4096 2>/dev/null | grep '^{' > $O/vec_default_s$s.jsonl; tail -1 $O/vec_default_s$s.jsonl; done

@@ -1,5 +1,5 @@
 mkdir -p gpurun_out/learn2; O=gpurun_out/learn2
-V="python scripts/learning_parity.py vec"
+V="python tests/tools/learning_parity.py vec"
 i=0
 for cfg in "64 64 32" "256 256 32" "32 32 32" \
            "4096 32 4096 algorithm.lr=1e-3 algorithm.target_update_interval_or_tau=20" "4096 32 4096 algorithm.lr=3e-3 algorithm.target_update_interval_or_tau=20" \

@@ -1,5 +1,5 @@
 mkdir -p gpurun_out/learn3; O=gpurun_out/learn3
-V="python scripts/learning_parity.py vec"
+V="python tests/tools/learning_parity.py vec"
 i=0
 for cfg in "4096 128 4096 algorithm.lr=1e-3 algorithm.target_update_interval_or_tau=50" "4096 128 4096 algorithm.lr=3e-3 algorithm.target_update_interval_or_tau=0.05" \
            "4096 256 4096 algorithm.lr=1e-3 algorithm.target_update_interval_or_tau=100" "4096 256 4096 algorithm.lr=3e-3 algorithm.target_update_interval_or_tau=0.05" \

@@ -1,5 +1,5 @@
 mkdir -p gpurun_out/learn5
-V="python scripts/learning_parity.py vec"
+V="python tests/tools/learning_parity.py vec"
 i=0
 for cfg in "0 1.5e6 64 64 32" "1 1.5e6 64 64 32" "2 1.5e6 64 64 32" "0 1.5e6 1 1 32" \
            "1 3e8 4096 32 4096 algorithm.lr=3e-3 algorithm.target_update_interval_or_tau=0.1" "2 3e8 4096 32 4096 algorithm.lr=3e-3 algorithm.target_update_interval_or_tau=0.1" \

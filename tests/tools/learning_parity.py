@@ -2,10 +2,10 @@
 """Learning parity of the headline cadence: IDQN 64-64 on Foraging-8x8-2p-3f, time_limit 25, the reference's
 hyper-parameters (configs/algorithm/idqn.yaml), evaluation at epsilon 0.05.  One JSON line per evaluation point.
 
-    python scripts/learning_parity.py oracle SEED STEPS          # CPU: oracle restatement of dqn/train.py:298-327 (1 update of 32
+    python tests/tools/learning_parity.py oracle SEED STEPS          # CPU: oracle restatement of dqn/train.py:298-327 (1 update of 32
                                                                  #      episodes per collected episode), no GPU
-    python scripts/learning_parity.py scalar SEED STEPS          # GPU: the drop-in scalar path (reference cadence, HIP env + learner)
-    python scripts/learning_parity.py vec SEED STEPS N U B [k=v ...]   # GPU: vectorised path, U updates of B episodes per round of N
+    python tests/tools/learning_parity.py scalar SEED STEPS          # GPU: the drop-in scalar path (reference cadence, HIP env + learner)
+    python tests/tools/learning_parity.py vec SEED STEPS N U B [k=v ...]   # GPU: vectorised path, U updates of B episodes per round of N
 
 `oracle` imports oracle/ (it IS the CPU baseline being compared against); the other modes are the product path.
 """
@@ -15,7 +15,7 @@ import sys
 import tempfile
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 NAME, T, H = "lbforaging:Foraging-8x8-2p-3f-v3", 25, 64
 EVALS, EVAL_EPISODES = 10, 200

@@ -1,5 +1,5 @@
 """CPU learning-curve probe of the ORACLE restatement of the reference loop (dqn/train.py:298-327):
-python scripts/oracle_learn_curve.py TOTAL_STEPS [HIDDEN]"""
+python tests/tools/oracle_learn_curve.py TOTAL_STEPS [HIDDEN]"""
 import os
 import sys
 import time
@@ -7,7 +7,7 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import dqn_port as dp
 from oracle.lbf import MarlbaseEnv
 

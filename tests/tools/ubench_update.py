@@ -1,12 +1,12 @@
 """Micro-benchmark of the fused loss/grad kernel alone (for rocprofv3 --pmc passes):
-python scripts/ubench_update.py [B] [iters]"""
+python tests/tools/ubench_update.py [B] [iters]"""
 import os
 import sys
 import time
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from codebase_amd import hip as h
 from oracle import dqn_port as dp
 
