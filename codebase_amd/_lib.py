@@ -181,6 +181,8 @@ PROTOTYPES = {
     "marlhip_dqn_clip_adam": (c_int32, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_double,
                                         c_double, c_double, c_double, c_float, c_float, c_int32, c_float, c_void_p,
                                         c_void_p, c_void_p]),
+    "marlhip_dqn_clip_step": (c_int32, [c_int32, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_double, c_float, c_float,
+                                        c_int32, c_float, c_void_p, c_void_p, c_void_p]),
     "marlhip_ac_collect": (c_int32, [POINTER(LbfConfig), POINTER(NetShape), c_void_p, c_uint32, c_int32, c_int32, c_void_p,
                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "marlhip_idqn_update_n": (c_int32, [POINTER(IdqnLearner), c_int32, c_int32, c_uint64, c_uint32, POINTER(c_int64),

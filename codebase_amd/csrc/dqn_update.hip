@@ -319,25 +319,46 @@ int idqn_update_n_fused(const marlhip_idqn_learner* L, int32_t n_updates, int32_
 }
 }  // namespace marl
 
+static int clip_step(const AdamArgs& a, int64_t n, float* params, const float* grad, float* state1, float* state2, float* target_params,
+                     float grad_scale, float* scratch, float* gnorm_out, hipStream_t st) {
+    const int nblocks = (int)((n + 255) / 256);
+    if (n <= 32768) {  // one workgroup does norm + clip + step + target: one launch, best while the block is small
+        hipLaunchKernelGGL(adam_fused_kernel, dim3(1), dim3(1024), 0, st, n, params, grad, state1, state2, target_params, a, gnorm_out);
+        MARL_CHECK_LAUNCH("adam_fused_kernel");
+    } else {
+        hipLaunchKernelGGL(sumsq_kernel, dim3(nblocks), dim3(256), 0, st, grad, n, grad_scale, scratch);
+        MARL_CHECK_LAUNCH("sumsq_kernel");
+        hipLaunchKernelGGL(adam_kernel, dim3(nblocks), dim3(256), 0, st, n, nblocks, params, grad, state1, state2, target_params, a,
+                           (const float*)scratch, gnorm_out);
+        MARL_CHECK_LAUNCH("adam_kernel");
+    }
+    return 0;
+}
+
 extern "C" int marlhip_dqn_clip_adam(int64_t n, float* params, const float* grad, float* exp_avg, float* exp_avg_sq,
                                      float* target_params, int64_t step, double lr, double beta1, double beta2, double eps,
                                      float max_norm, float grad_scale, int32_t hard_update, float tau, float* scratch,
                                      float* gnorm_out, void* stream) {
     MARL_REQUIRE(n > 0 && params && grad && exp_avg && exp_avg_sq && scratch, "dqn_clip_adam: NULL pointer");
     MARL_REQUIRE(step >= 1, "dqn_clip_adam: step must be >= 1");
-    const int nblocks = (int)((n + 255) / 256);
-    hipStream_t st = (hipStream_t)stream;
     const AdamArgs a = adam_args(step, lr, beta1, beta2, eps, max_norm, grad_scale, hard_update, tau);
-    if (n <= 32768) {  // one workgroup does norm + clip + Adam + target: one launch, best while the block is small
-        hipLaunchKernelGGL(adam_fused_kernel, dim3(1), dim3(1024), 0, st, n, params, grad, exp_avg, exp_avg_sq, target_params, a,
-                           gnorm_out);
-        MARL_CHECK_LAUNCH("adam_fused_kernel");
-    } else {
-        hipLaunchKernelGGL(sumsq_kernel, dim3(nblocks), dim3(256), 0, st, grad, n, grad_scale, scratch);
-        MARL_CHECK_LAUNCH("sumsq_kernel");
-        hipLaunchKernelGGL(adam_kernel, dim3(nblocks), dim3(256), 0, st, n, nblocks, params, grad, exp_avg, exp_avg_sq,
-                           target_params, a, (const float*)scratch, gnorm_out);
-        MARL_CHECK_LAUNCH("adam_kernel");
+    return clip_step(a, n, params, grad, exp_avg, exp_avg_sq, target_params, grad_scale, scratch, gnorm_out, (hipStream_t)stream);
+}
+
+extern "C" int marlhip_dqn_clip_step(int32_t optimizer, int64_t n, float* params, const float* grad, float* state1, float* state2,
+                                     float* target_params, int64_t step, double lr, float max_norm, float grad_scale, int32_t hard_update,
+                                     float tau, float* scratch, float* gnorm_out, void* stream) {
+    MARL_REQUIRE(n > 0 && params && grad && state1 && state2 && scratch, "dqn_clip_step: NULL pointer");
+    MARL_REQUIRE(step >= 1, "dqn_clip_step: step must be >= 1");
+    MARL_REQUIRE(optimizer >= 0 && optimizer <= 3, "dqn_clip_step: optimizer %d (0 Adam, 1 SGD, 2 RMSprop, 3 AdamW)", optimizer);
+    // torch's defaults: Adam / AdamW betas (0.9, 0.999), eps 1e-8, AdamW weight_decay 1e-2; RMSprop alpha 0.99, eps 1e-8
+    AdamArgs a = adam_args(step, lr, 0.9, 0.999, 1e-8, max_norm, grad_scale, hard_update, tau);
+    a.opt = optimizer;
+    a.neg_lr = (float)(-lr);
+    if (optimizer == 2) {
+        a.alpha = (float)0.99;
+        a.w2 = (float)(1.0 - 0.99);
     }
-    return 0;
+    if (optimizer == 3) a.decay = (float)(1.0 - lr * 1e-2);
+    return clip_step(a, n, params, grad, state1, state2, target_params, grad_scale, scratch, gnorm_out, (hipStream_t)stream);
 }

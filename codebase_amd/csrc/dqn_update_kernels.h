@@ -854,7 +854,33 @@ struct AdamArgs {
     float beta2, w2;  // beta2, fp32(1 - beta2)
     float eps, max_norm, grad_scale, tau;
     int hard_update;
+    // getattr(optim, cfg.optimizer)(params, lr=cfg.lr) (dqn/model.py:66-71, ac/model.py:103-105) with torch's default hyper-parameters:
+    // 0 Adam, 1 SGD (p += -lr g), 2 RMSprop (alpha 0.99, not centred, no momentum), 3 AdamW (decoupled weight decay 1e-2, then Adam)
+    int opt = 0;
+    float neg_lr = 0.f;   // fp32(-lr)                     (SGD, RMSprop)
+    float alpha = 0.f;    // RMSprop smoothing, w2 = fp32(1 - alpha)
+    float decay = 1.f;    // AdamW: fp32(1 - lr * weight_decay)
 };
+
+// one parameter's step; m / v are the optimiser's two state slots (Adam: exp_avg / exp_avg_sq; RMSprop: v = square_avg)
+__device__ __forceinline__ void opt_step(const AdamArgs& a, float gv, float& mi, float& vi, float& pi) {
+    if (a.opt == 1) {  // torch.optim.SGD: param.add_(grad, alpha=-lr)
+        pi = pi + a.neg_lr * gv;
+        return;
+    }
+    if (a.opt == 2) {  // torch.optim.RMSprop: square_avg.mul_(alpha).addcmul_(g, g, value=1 - alpha); avg = sqrt + eps; addcdiv_(g, avg, -lr)
+        vi = vi * a.alpha + (a.w2 * gv) * gv;
+        const float avg = sqrtf(vi) + a.eps;
+        pi = pi + a.neg_lr * (gv / avg);
+        return;
+    }
+    if (a.opt == 3) pi = pi * a.decay;  // torch.optim.AdamW: param.mul_(1 - lr * weight_decay) first
+    // torch.optim.Adam (single-tensor): lerp_, mul_/addcmul_, sqrt/div/add_, addcdiv_
+    mi = mi + a.w1 * (gv - mi);
+    vi = vi * a.beta2 + a.w2 * gv * gv;
+    const float denom = sqrtf(vi) / a.bc2_sqrt + a.eps;
+    pi = pi + (-a.lr_step) * (mi / denom);
+}
 
 static __global__ __launch_bounds__(256) void adam_kernel(int64_t n, int nblocks, float* __restrict__ params,
                                                    const float* __restrict__ grad, float* __restrict__ m,
@@ -882,13 +908,8 @@ static __global__ __launch_bounds__(256) void adam_kernel(int64_t n, int nblocks
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const float gv = (grad[i] * a.grad_scale) * s_coef;
-    // torch.optim.Adam (single-tensor): lerp_, mul_/addcmul_, sqrt/div/add_, addcdiv_
-    float mi = m[i], vi = v[i];
-    mi = mi + a.w1 * (gv - mi);
-    vi = vi * a.beta2 + a.w2 * gv * gv;
-    const float denom = sqrtf(vi) / a.bc2_sqrt + a.eps;
-    float pi = params[i];
-    pi = pi + (-a.lr_step) * (mi / denom);
+    float mi = m[i], vi = v[i], pi = params[i];
+    opt_step(a, gv, mi, vi, pi);
     m[i] = mi;
     v[i] = vi;
     params[i] = pi;
@@ -933,12 +954,8 @@ static __global__ __launch_bounds__(1024) void adam_fused_kernel(int64_t n, floa
     const float coef = s_coef;
     for (int64_t i = threadIdx.x; i < n; i += 1024) {
         const float gv = (grad[i] * a.grad_scale) * coef;
-        float mi = m[i], vi = v[i];
-        mi = mi + a.w1 * (gv - mi);
-        vi = vi * a.beta2 + a.w2 * gv * gv;
-        const float denom = sqrtf(vi) / a.bc2_sqrt + a.eps;
-        float pi = params[i];
-        pi = pi + (-a.lr_step) * (mi / denom);
+        float mi = m[i], vi = v[i], pi = params[i];
+        opt_step(a, gv, mi, vi, pi);
         m[i] = mi;
         v[i] = vi;
         params[i] = pi;

@@ -207,7 +207,7 @@ class VectorisedIDQN:
                               use_proper_termination=self.proper)
         self.env_steps += self.fin_length.sum()
         self.rounds += 1
-        if train and self.dist is None and self.U > 0 and m.mode != 2 and not m.standardise_returns and not _NO_FUSED_LOOP and not getattr(m, "recurrent", False) and not m.spec.wide:  # the n-updates library call has no mixer / no return statistics (those loop here)
+        if train and self.dist is None and self.U > 0 and m.mode != 2 and not m.standardise_returns and not _NO_FUSED_LOOP and not getattr(m, "recurrent", False) and not m.spec.wide and m.updater.optimizer == 0:  # the n-updates library call has no mixer / no return statistics (those loop here)
             if self._fused is None:
                 self._fused = _hip.FusedLearner(m.updater, self.replay, self.B, m.target_update_interval_or_tau, mode=m.mode)
             length = min(self.rounds * self.N, self.capacity)

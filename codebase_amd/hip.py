@@ -299,6 +299,27 @@ class DeviceReplay:
         return Batch(obss, actions, rewards, dones, filled, None)
 
 
+OPTIMIZERS = {"Adam": 0, "SGD": 1, "RMSprop": 2, "AdamW": 3}  # marlhip_dqn_clip_step's ids (torch's default hyper-parameters)
+
+
+def optimizer_id(opt):
+    """cfg.optimizer (a name, or the torch.optim class itself) -> marlhip_dqn_clip_step's id"""
+    name = opt if isinstance(opt, str) else getattr(opt, "__name__", str(opt))
+    if name not in OPTIMIZERS:
+        raise NotImplementedError(f"optimizer {name}: built are {sorted(OPTIMIZERS)} (torch.optim defaults, lr from the config)")
+    return OPTIMIZERS[name]
+
+
+def _clip_step(opt, n_tensor, params, grad, s1, s2, target, step, lr, betas, eps, clip, grad_scale, hard, tau, scratch, gnorm, what):
+    if opt == 0:
+        check(lib.marlhip_dqn_clip_adam(n_tensor, _ptr(params), _ptr(grad), _ptr(s1), _ptr(s2), _ptr(target), step, float(lr), float(betas[0]),
+                                        float(betas[1]), float(eps), float(clip), float(grad_scale), int(bool(hard)), float(tau), _ptr(scratch),
+                                        _ptr(gnorm), _stream()), what)
+    else:
+        check(lib.marlhip_dqn_clip_step(int(opt), n_tensor, _ptr(params), _ptr(grad), _ptr(s1), _ptr(s2), _ptr(target), step, float(lr), float(clip),
+                                        float(grad_scale), int(bool(hard)), float(tau), _ptr(scratch), _ptr(gnorm), _stream()), what)
+
+
 class RunningReturnStats:
     """RunningMeanStd of marlbase/utils/standardise_stream.py, resident on the device: shape (n_agents,) for the independent
     learner; for VDNetwork / QMixNetwork `columns` = batch size - their RunningMeanStd(shape=(1,)) turns into one (mean, var) per
@@ -322,8 +343,9 @@ class DqnUpdater:
     """K5-K8: loss + gradient, clip, Adam, target update over flat per-agent parameter blocks."""
 
     def __init__(self, spec: NetSpec, params, target, lr=3e-4, betas=(0.9, 0.999), eps=1e-8, gamma=0.99, grad_clip=1.0,
-                 double_q=True, standardise_returns=False):
+                 double_q=True, standardise_returns=False, optimizer="Adam"):
         _require_gpu()
+        self.optimizer = optimizer_id(optimizer)
         self.spec, self.params, self.target = spec, params, target
         self.ret_stats = RunningReturnStats(spec.n_agents, params.device) if standardise_returns else None
         self.lr, self.betas, self.eps, self.gamma = lr, betas, eps, gamma
@@ -401,11 +423,8 @@ class DqnUpdater:
 
     def apply(self, hard_update=False, tau=0.0, grad_scale=1.0):
         self.step += 1
-        check(lib.marlhip_dqn_clip_adam(self.params.numel(), _ptr(self.params), _ptr(self.grad), _ptr(self.exp_avg),
-                                        _ptr(self.exp_avg_sq), _ptr(self.target), self.step, float(self.lr), float(self.betas[0]),
-                                        float(self.betas[1]), float(self.eps), float(self.grad_clip), float(grad_scale),
-                                        int(bool(hard_update)), float(tau), _ptr(self.scratch), _ptr(self.gnorm), _stream()),
-              "dqn_clip_adam")
+        _clip_step(self.optimizer, self.params.numel(), self.params, self.grad, self.exp_avg, self.exp_avg_sq, self.target, self.step, self.lr,
+                   self.betas, self.eps, self.grad_clip, grad_scale, hard_update, tau, self.scratch, self.gnorm, "dqn_clip_step")
 
 
 
@@ -502,11 +521,8 @@ class QmixUpdater(DqnUpdater):
 
     def apply(self, hard_update=False, tau=0.0, grad_scale=1.0):
         super().apply(hard_update, tau, grad_scale)  # critic: clip + Adam + target; advances self.step
-        check(lib.marlhip_dqn_clip_adam(self.mixer.numel(), _ptr(self.mixer), _ptr(self.mixer_grad), _ptr(self.mixer_exp_avg),
-                                        _ptr(self.mixer_exp_avg_sq), _ptr(self.target_mixer), self.step, float(self.lr),
-                                        float(self.betas[0]), float(self.betas[1]), float(self.eps), 0.0, float(grad_scale),
-                                        int(bool(hard_update)), float(tau), _ptr(self.mixer_scratch), None, _stream()),
-              "dqn_clip_adam(mixer)")
+        _clip_step(self.optimizer, self.mixer.numel(), self.mixer, self.mixer_grad, self.mixer_exp_avg, self.mixer_exp_avg_sq, self.target_mixer,
+                   self.step, self.lr, self.betas, self.eps, 0.0, grad_scale, hard_update, tau, self.mixer_scratch, None, "dqn_clip_step(mixer)")
 
 
 def ac_forward_rows(spec: NetSpec, params, obs, agent_stride, row_stride, n_rows, value_net=False):
@@ -527,8 +543,9 @@ class AcUpdater:
 
     def __init__(self, spec: NetSpec, block, target_critic, lr=3e-4, betas=(0.9, 0.999), eps=1e-8, gamma=0.99, n_steps=5,
                  entropy_coef=0.001, value_loss_coef=0.5, grad_clip=False, ppo_clip=0.2, standardise_returns=False,
-                 centralised_critic=False, recurrent=False):
+                 centralised_critic=False, recurrent=False, optimizer="Adam"):
         _require_gpu()
+        self.optimizer = optimizer_id(optimizer)
         self.recurrent = bool(recurrent)  # use_rnn actors and critics: the marlhip_gru_* entry points, recurrent block layout
         self._fn = ((lib.marlhip_gru_a2c_loss_grad, lib.marlhip_gru_ppo_prepare, lib.marlhip_gru_ppo_loss_grad) if self.recurrent else
                     (lib.marlhip_a2c_loss_grad, lib.marlhip_ppo_prepare, lib.marlhip_ppo_loss_grad))
@@ -618,10 +635,8 @@ class AcUpdater:
     def apply(self, grad_scale=1.0):
         """clip_grad_norm_(self.parameters(), grad_clip) + optimizer.step() (model.py:227-231): one norm over actor + critic"""
         self.step += 1
-        check(lib.marlhip_dqn_clip_adam(self.block.numel(), _ptr(self.block), _ptr(self.grad), _ptr(self.exp_avg),
-                                        _ptr(self.exp_avg_sq), None, self.step, float(self.lr), float(self.betas[0]),
-                                        float(self.betas[1]), float(self.eps), float(self.grad_clip), float(grad_scale), 0, 0.0,
-                                        _ptr(self.scratch), _ptr(self.gnorm), _stream()), "dqn_clip_adam(actor+critic)")
+        _clip_step(self.optimizer, self.block.numel(), self.block, self.grad, self.exp_avg, self.exp_avg_sq, None, self.step, self.lr, self.betas,
+                   self.eps, self.grad_clip, grad_scale, False, 0.0, self.scratch, self.gnorm, "dqn_clip_step(actor+critic)")
 
 
 def idqn_collect(cfg, spec: NetSpec, params, epsilon, round_idx, replay: DeviceReplay, slot_base, fin_return,

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MARLHIP_VERSION 201
+#define MARLHIP_VERSION 202
 
 int marlhip_version(void);
 const char* marlhip_last_error(void);
@@ -284,6 +284,14 @@ int marlhip_dqn_loss_grad_replay(const marlhip_net_shape* s, const float* params
 int marlhip_dqn_clip_adam(int64_t n, float* params, const float* grad, float* exp_avg, float* exp_avg_sq,
                           float* target_params, int64_t step, double lr, double beta1, double beta2, double eps,
                           float max_norm, float grad_scale, int32_t hard_update, float tau,
+                          float* scratch /* >= ceil(n/256) floats */, float* gnorm_out, void* stream);
+
+/* the same step for the other optimisers `getattr(optim, cfg.optimizer)(params, lr=cfg.lr)` can name (dqn/model.py:66-71, ac/model.py:
+ * 103-105), with torch's default hyper-parameters: optimizer 0 = Adam (as marlhip_dqn_clip_adam with betas (0.9, 0.999), eps 1e-8),
+ * 1 = SGD, 2 = RMSprop (alpha 0.99, eps 1e-8; state2 = square_avg), 3 = AdamW (weight_decay 1e-2).  state1 / state2: the optimiser's
+ * two [n] state slots (unused ones still have to be valid memory). */
+int marlhip_dqn_clip_step(int32_t optimizer, int64_t n, float* params, const float* grad, float* state1, float* state2,
+                          float* target_params, int64_t step, double lr, float max_norm, float grad_scale, int32_t hard_update, float tau,
                           float* scratch /* >= ceil(n/256) floats */, float* gnorm_out, void* stream);
 
 /* ------------------------------------------------------------------------------------------

@@ -151,7 +151,7 @@ class Learner:
     parameters, torch.optim.Adam, hard / soft target update."""
 
     def __init__(self, params, D, H, A, lr=3e-4, gamma=0.99, grad_clip=1.0, double_q=True,
-                 target_update_interval_or_tau=200, mode="idqn", sharing=None, standardise_returns=False):
+                 target_update_interval_or_tau=200, mode="idqn", sharing=None, standardise_returns=False, optimizer="Adam"):
         self.D, self.H, self.A = D, H, A
         self.sharing = sharing
         self.ret_ms = RunningMeanStd((params.shape[0],)) if standardise_returns else None
@@ -160,7 +160,7 @@ class Learner:
         self.tensors = [torch.nn.Parameter(t.clone()) for p in range(P) for t in split(params[p], D, H, A)]
         self.P = P
         self.target = params.clone()
-        self.opt = torch.optim.Adam(self.tensors, lr=lr)
+        self.opt = getattr(torch.optim, optimizer)(self.tensors, lr=lr)  # dqn/model.py:66-71
         self.gamma, self.grad_clip, self.double_q = gamma, grad_clip, double_q
         self.tui = target_update_interval_or_tau
         self.updates = 0
