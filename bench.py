@@ -215,7 +215,7 @@ def bench_ac(args, rank, world, dist):
 
     def one_round():
         if args.rnn:
-            tmax, batch, _, _ = _collect_trajectories_recurrent(vec, model, T, False, state["round"])
+            tmax, batch, _, _, _ = _collect_trajectories_recurrent(vec, model, T, False, state["round"])
             model.update_async(batch._replace(dones=batch.dones.float()), state["step"], grad_sync=sync_grad, world=world)
             steps_dev.add_(batch.filled.sum().to(torch.int64))
             ref_steps.add_(tmax * N)

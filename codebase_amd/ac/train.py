@@ -38,6 +38,16 @@ class ActorNetworks:
         return out
 
 
+class EpisodeInfo(dict):
+    """one `final_info` of a rollout; `.env` = the env it came from (not a key: squash_info averages the keys)"""
+    env = -1
+
+
+# MARLHIP_FIRST_EPISODES_ONLY: skip the second pass (later episodes of early finishers: logging, and the reward statistics of
+# env.standardise_rewards) - diagnostics / the round-1 behaviour
+_FIRST_EPISODES_ONLY = bool(__import__("os").environ.get("MARLHIP_FIRST_EPISODES_ONLY"))
+
+
 def _collect_trajectories_recurrent(envs, model, T, use_proper_termination, round_idx):
     """_collect_trajectories (ac/train.py:24-119) with recurrent actors (or actors wider than the fused collector's): the hidden state lives between steps, so the rollout runs
     through the modular entry points - sequence kernel with one step -> Philox inverse-CDF sample -> auto-resetting vector-env
@@ -58,6 +68,7 @@ def _collect_trajectories_recurrent(envs, model, T, use_proper_termination, roun
     noise_episode = torch.full((N,), 2 * round_idx, dtype=torch.int32, device=dev)
     b_obs[0] = obs.permute(1, 0, 2).reshape(N, P * D)
     running = torch.ones(N, dtype=torch.bool, device=dev)
+    later = []
     hid, t = None, 0
     while t < T:
         if getattr(model, "recurrent", False):
@@ -77,18 +88,24 @@ def _collect_trajectories_recurrent(envs, model, T, use_proper_termination, roun
         first = running & fin  # the statistics of an env's FIRST episode of the rollout (it keeps auto-resetting afterwards)
         fin_ret = torch.where(first[None, :], env.fin_return, fin_ret)
         fin_len = torch.where(first, env.fin_length, fin_len)
+        again = fin & ~running  # a later episode of an env that is no longer part of the batch
+        if bool(again.any()):
+            idx = torch.nonzero(again).flatten()
+            fr, fl = env.fin_return[:, idx].t().cpu().numpy(), env.fin_length[idx].cpu().numpy()
+            later += [(t + 1, int(i), fr[k].copy(), int(fl[k])) for k, i in enumerate(idx.tolist())]
         running = running & ~fin
         t += 1
         if t % 8 == 0 and not bool(running.any()):
             break
     filled_steps = int(b_fill.sum(1).gt(0).sum().item())
-    return filled_steps, Batch(b_obs, b_act, b_rew, b_done, b_fill, None), fin_ret, fin_len
+    return filled_steps, Batch(b_obs, b_act, b_rew, b_done, b_fill, None), fin_ret, fin_len, later
 
 
-def _collect_trajectories(envs, model, max_ep_length, parallel_envs, n_agents, device, use_proper_termination, round_idx=0):
+def _collect_trajectories(envs, model, max_ep_length, parallel_envs, n_agents, device, use_proper_termination, round_idx=0, want_infos=True):
     """(t, Batch, infos) exactly as the reference returns them; `envs` is a HipForagingVecEnv, `model` carries
     `actor_params` / `spec` (ActorNetworks).  One kernel launch; the only host sync is reading `t` and the
-    episode statistics at the end."""
+    episode statistics at the end.  want_infos=False (the driver's rollouts between two log points, whose infos the reference
+    builds and drops): no per-episode dicts, and no second pass unless env.standardise_rewards needs its steps."""
     cfg = envs.cfg
     N, P, D, T = cfg.n_envs, cfg.n_agents, model.spec.obs_dim, int(max_ep_length)
     dev = model.actor_params.device
@@ -100,19 +117,34 @@ def _collect_trajectories(envs, model, max_ep_length, parallel_envs, n_agents, d
     fin_ret = torch.zeros(P, N, device=dev)
     fin_len = torch.zeros(N, dtype=torch.int32, device=dev)
     t_max = torch.zeros(1, dtype=torch.int32, device=dev)
+    later = []  # (finishing step, env, returns [P], length) of episodes that ended after an env's first one (ac/train.py:101-110)
     if getattr(model, "recurrent", False) or model.spec.wide:  # no fused collector for these: the modular loop
-        t, batch, fin_ret, fin_len = _collect_trajectories_recurrent(envs, model, T, use_proper_termination, round_idx)
+        t, batch, fin_ret, fin_len, later = _collect_trajectories_recurrent(envs, model, T, use_proper_termination, round_idx)
     else:
         _hip.ac_collect(cfg, model.spec, model.actor_params, round_idx, T, use_proper_termination, b_obs, b_act, b_rew, b_done,
                         b_fill, fin_ret, fin_len, t_max)
         t = int(t_max.item())
         batch = Batch(b_obs, b_act, b_rew, b_done.bool(), b_fill, None)
+        second = (want_infos or bool(getattr(cfg, "reward_stats", None))) and not _FIRST_EPISODES_ONLY
+        early = torch.nonzero(fin_len < t).flatten().to(torch.int32) if second else None
+        if second and early.numel() > 0:
+            # the reference's vector env keeps stepping the envs that finished early until the last one is done: second pass
+            g_ret, g_meta, g_cnt = _hip.ac_collect_later_episodes(cfg, model.spec, model.actor_params, round_idx, T, early,
+                                                                  fin_len[early.long()].contiguous(), t)
+            ids, g_ret, g_meta, g_cnt = early.cpu().numpy(), g_ret.cpu().numpy(), g_meta.cpu().numpy(), g_cnt.cpu().numpy()
+            for i in range(len(ids)):
+                for k in range(int(g_cnt[i])):
+                    later.append((int(g_meta[i, k, 1]), int(ids[i]), g_ret[i, k].copy(), int(g_meta[i, k, 0])))
+    if not want_infos:
+        return t, batch, []
     ret, ln = fin_ret.cpu().numpy(), fin_len.cpu().numpy()
+    entries = [(int(ln[i]), i, ret[:, i].copy(), int(ln[i])) for i in range(N)] + [e for e in later if e[0] <= t]
     infos = []
-    for i in range(N):
-        d = {"episode_returns": ret[:, i].copy(), "episode_length": int(ln[i])}
+    for _, i, r, length in sorted(entries, key=lambda e: (e[0], e[1])):  # the reference appends step by step, env by env
+        d = EpisodeInfo({"episode_returns": r, "episode_length": length})
+        d.env = i
         for p in range(P):
-            d[f"agent{p}/episode_returns"] = ret[p, i]
+            d[f"agent{p}/episode_returns"] = r[p]
         infos.append(d)
     return t, batch, infos
 
@@ -137,10 +169,11 @@ def main(envs, eval_env, logger, time_limit, **cfg):
     device = g("model.device", "cuda")
     step = updates = last_eval = last_save = 0
     while step < g("total_steps") + 1:
+        log_now = (step - last_eval) >= g("eval_interval")  # the only consumer of a rollout's infos
         t, batch, infos = _collect_trajectories(envs, model, time_limit, parallel_envs, model.n_agents, device,
-                                                g("use_proper_termination", False), round_idx=updates)
-        infos.append(model.update(batch, step))
-        if (step - last_eval) >= g("eval_interval"):
+                                                g("use_proper_termination", False), round_idx=updates, want_infos=log_now)
+        infos.append(model.update(batch, step) if log_now else model.update_async(batch, step))
+        if log_now:
             _log_progress(infos, step, updates, logger)
             last_eval = step
         if g("save_interval") and (step - last_save) >= g("save_interval"):

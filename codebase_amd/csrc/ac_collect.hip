@@ -32,3 +32,29 @@ extern "C" int marlhip_ac_collect(const marlhip_lbf_config* cfg, const marlhip_n
     set_error("ac_collect: no kernel for %dp-%df hidden=%d", cfg->n_agents, cfg->n_food, s->hidden);
     return -1;
 }
+
+namespace {
+int ghost_check(const int32_t* env_ids, const int32_t* t_start, int32_t n, int32_t t_stop, int32_t cap, const float* ret, const int32_t* meta,
+                const int32_t* cnt, const char* what) {
+    MARL_REQUIRE(env_ids && t_start && ret && meta && cnt, "%s: NULL pointer", what);
+    MARL_REQUIRE(n > 0 && t_stop > 0 && cap > 0, "%s: n_envs %d, t_stop %d, cap %d must be > 0", what, n, t_stop, cap);
+    return 0;
+}
+}  // namespace
+
+// the second pass of a rollout (AcGhost, common.h): the same collector kernels over the listed envs, writing episode records only.
+// The batch / statistics pointers of the first-pass signature are not touched in this mode; they get the record buffers as stand-ins.
+extern "C" int marlhip_ac_collect_later_episodes(const marlhip_lbf_config* cfg, const marlhip_net_shape* s, const float* actor_params, uint32_t round,
+                                                 int32_t max_len, const int32_t* env_ids, const int32_t* t_start, int32_t n_envs, int32_t t_stop,
+                                                 int32_t cap, float* ret, int32_t* meta, int32_t* cnt, void* workspace, int64_t workspace_bytes,
+                                                 void* stream) {
+    MARL_REQUIRE(cfg != nullptr, "ac_collect_later_episodes: NULL config");
+    if (ghost_check(env_ids, t_start, n_envs, t_stop, cap, ret, meta, cnt, "ac_collect_later_episodes") != 0) return -1;
+    marlhip_lbf_config c2 = *cfg;
+    c2.n_envs = n_envs;
+    (void)hipMemsetAsync(cnt, 0, (size_t)n_envs * sizeof(int32_t), (hipStream_t)stream);
+    const AcGhost g = {env_ids, t_start, t_stop < max_len ? t_stop : max_len, cap, ret, meta, cnt};
+    AcGhostScope scope(g);
+    return marlhip_ac_collect(&c2, s, actor_params, round, max_len, 0, ret, reinterpret_cast<int64_t*>(meta), ret, reinterpret_cast<uint8_t*>(meta), ret, ret,
+                              meta, meta + 2 * (size_t)n_envs * cap - 1, workspace, workspace_bytes, stream);
+}

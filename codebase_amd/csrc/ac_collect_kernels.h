@@ -26,6 +26,7 @@ int ac_collect_dispatch_oid(const marlhip_lbf_config* cfg, const marlhip_net_sha
 
 constexpr int ACOL_BLOCK = 256;
 
+
 // softmax inverse-CDF sample for the env of batch row j; logits in C layout (lane (g,j) holds a = 4g+r)
 template <int A>
 __device__ __forceinline__ int sample_rows(const f4& logits, int lane, float u) {
@@ -69,12 +70,13 @@ __global__ __launch_bounds__(ACOL_BLOCK) void ac_collect_kernel(typename ENV::Pa
                                                                 int64_t* __restrict__ b_act, float* __restrict__ b_rew,
                                                                 uint8_t* __restrict__ b_done, float* __restrict__ b_filled,
                                                                 float* __restrict__ fin_return, int32_t* __restrict__ fin_length,
-                                                                int32_t* __restrict__ t_max) {
+                                                                int32_t* __restrict__ t_max, AcGhost gh) {
     constexpr int P = ENV::P, D = ENV::D0 + (OID ? P : 0), A = ENV::A;
     using S = MlpShape<D, H, A>;
     using PP = PackPlan<S, P, ENV::LDS_MAX>;
     constexpr bool RESIDENT = PP::RESIDENT || PP::A3REG;  // no per-step staging
     constexpr bool FROM_GLOBAL = NW > 1 && !RESIDENT;      // packs too large for the LDS: each wave reads its agents' from L2
+    const bool ghost = gh.env_ids != nullptr;              // second pass (AcGhost): no batch writes, episode records instead
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ int s_act[NW > 1 ? 2 * 4 * P * 16 : 1];     // [step parity][env block of the workgroup][agent][env]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, j = lane & 15;
@@ -84,7 +86,10 @@ __global__ __launch_bounds__(ACOL_BLOCK) void ac_collect_kernel(typename ENV::Pa
     typename ENV::Ctx ctx;
     ctx.init(q, reinterpret_cast<uint8_t*>(lds) + (FROM_GLOBAL ? 0 : PP::LDS_BYTES), wave, j);
     const bool valid = n < N;
-    const uint32_t env_id = (uint32_t)(valid ? n : N - 1);
+    const int nn = valid ? n : N - 1;
+    const uint32_t env_id = (uint32_t)(ghost ? gh.env_ids[nn] : nn);
+    const int t_first = ghost ? gh.t_start[nn] : 0;
+    uint32_t gen = ghost ? 1u : 0u;  // episode generation of the env inside this rollout: reset stream 2 * round + gen
     constexpr int K = P / NW;  // a wave's own agents: p = aw + k * NW, k < K (NW = 1: every agent, p = k)
     f4 a3[PP::A3REG ? K : 1][S::MT];  // output-layer operands of the wave's agents, when the full packs do not fit the LDS
     if (RESIDENT) {
@@ -100,7 +105,7 @@ __global__ __launch_bounds__(ACOL_BLOCK) void ac_collect_kernel(typename ENV::Pa
         __syncthreads();
     }
     typename ENV::State s;
-    ENV::reset(q, s, ctx, env_id, 2u * round);
+    ENV::reset(q, s, ctx, env_id, 2u * round + gen);
     // batch_obs[t][n][p*D + d]
     auto obs_row = [&](int t) { return b_obs + ((size_t)t * N + env_id) * (P * D); };
     float x[K][S::KS1];  // the wave observes, forwards, samples and stores for its own agents
@@ -108,15 +113,16 @@ __global__ __launch_bounds__(ACOL_BLOCK) void ac_collect_kernel(typename ENV::Pa
     for (int k = 0; k < K; ++k) {
         const int p = aw + k * NW;
         ENV::template observe<S::KS1, OID>(q, s, ctx, p, g, x[k]);
-        if (valid) {
+        if (valid && !ghost) {
 #pragma unroll
             for (int ks = 0; ks < S::KS1; ++ks)
                 if (4 * ks + g < D) obs_row(0)[p * D + 4 * ks + g] = x[k][ks];
         }
     }
     const bool lead = g == 0 && aw == 0;  // the lane that writes an env's per-env records
-    if (valid && lead) b_done[env_id] = 0;
-    bool running = valid;
+    if (valid && lead && !ghost) b_done[env_id] = 0;
+    bool running = valid && !ghost;
+    int n_rec = 0;  // second pass: episodes recorded for this env
     float ep_ret[P];
 #pragma unroll
     for (int p = 0; p < P; ++p) ep_ret[p] = 0.f;
@@ -127,6 +133,7 @@ __global__ __launch_bounds__(ACOL_BLOCK) void ac_collect_kernel(typename ENV::Pa
         for (int p = 0; p < P; ++p) act[p] = 0;
 #pragma unroll
         for (int k = 0; k < K; ++k) own[k] = 0;
+        if (ghost) running = valid && t >= t_first && t < gh.t_stop;
         const bool any_running = __any(running);
         if ((RESIDENT || FROM_GLOBAL) ? any_running : true) {
 #pragma unroll
@@ -164,21 +171,37 @@ __global__ __launch_bounds__(ACOL_BLOCK) void ac_collect_kernel(typename ENV::Pa
             double raw[P];
             float rw[P];
             bool done;
-            ENV::step(q, s, ctx, env_id, 2u * round, act, raw, done);
+            ENV::step(q, s, ctx, env_id, 2u * round + gen, act, raw, done);
             const bool trunc = q.time_limit > 0 && ENV::elapsed(s) >= q.time_limit;
             const bool fin = done || trunc;
             const bool stored_done = proper_term ? done : fin;
             lbf_wrap_rewards<P>(q, env_id, raw, rw, lead);
             ++len;
-            if (fin) {  // vector-env auto-reset: the observation returned for this step is the next episode's first
-                ENV::reset(q, s, ctx, env_id, 2u * round + 1u);
-            }
 #pragma unroll
             for (int p = 0; p < P; ++p) ep_ret[p] += (float)raw[p];
+            if (fin && ghost) {  // a further episode of an env that is no longer part of the batch: its statistics, then the next one
+                if (lead && n_rec < gh.cap) {
+                    const size_t at = (size_t)n * gh.cap + n_rec;
+#pragma unroll
+                    for (int p = 0; p < P; ++p) gh.ret[at * P + p] = ep_ret[p];
+                    gh.meta[2 * at] = len;
+                    gh.meta[2 * at + 1] = t + 1;
+                    gh.cnt[n] = n_rec + 1;
+                }
+                ++n_rec;
+                len = 0;
+#pragma unroll
+                for (int p = 0; p < P; ++p) ep_ret[p] = 0.f;
+            }
+            if (fin) {  // vector-env auto-reset: the observation returned for this step is the next episode's first
+                ++gen;
+                ENV::reset(q, s, ctx, env_id, 2u * round + gen);
+            }
 #pragma unroll
             for (int k = 0; k < K; ++k) {
                 const int p = aw + k * NW;
                 ENV::template observe<S::KS1, OID>(q, s, ctx, p, g, x[k]);
+                if (ghost) continue;
 #pragma unroll
                 for (int ks = 0; ks < S::KS1; ++ks)
                     if (4 * ks + g < D) obs_row(t + 1)[p * D + 4 * ks + g] = x[k][ks];
@@ -187,11 +210,11 @@ __global__ __launch_bounds__(ACOL_BLOCK) void ac_collect_kernel(typename ENV::Pa
                     b_rew[((size_t)t * N + n) * P + p] = pick_agent<P>(rw, p);
                 }
             }
-            if (lead) {
+            if (lead && !ghost) {
                 b_done[(size_t)(t + 1) * N + n] = stored_done ? 1 : 0;
                 b_filled[(size_t)t * N + n] = 1.f;
             }
-            if (fin) {
+            if (fin && !ghost) {
                 running = false;
                 if (lead) {
 #pragma unroll
@@ -200,7 +223,7 @@ __global__ __launch_bounds__(ACOL_BLOCK) void ac_collect_kernel(typename ENV::Pa
                     atomicMax(t_max, len);
                 }
             }
-        } else if (valid) {
+        } else if (valid && !ghost) {
             // rows of an env that is no longer running stay zero, as in the reference's freshly allocated batch
 #pragma unroll
             for (int k = 0; k < K; ++k) {
@@ -219,7 +242,7 @@ __global__ __launch_bounds__(ACOL_BLOCK) void ac_collect_kernel(typename ENV::Pa
             }
         }
     }
-    if (valid && running && lead) {  // T shorter than the env's limits
+    if (valid && running && lead && !ghost) {  // T shorter than the env's limits
 #pragma unroll
         for (int p = 0; p < P; ++p) fin_return[(size_t)p * N + n] = ep_ret[p];
         fin_length[n] = len;
@@ -244,7 +267,7 @@ int launch_ac_collect_nw(const typename ENV::Params& q, const float* packs, uint
     const int per_wg = 64 / NW;  // envs per workgroup
     timing_begin(TIMER_COLLECT, st);
     hipLaunchKernelGGL((ac_collect_kernel<ENV, H, OID, NW>), dim3((q.n_envs + per_wg - 1) / per_wg), dim3(ACOL_BLOCK), lds_bytes, st, q, packs, round, T,
-                       proper_term, b_obs, b_act, b_rew, b_done, b_filled, fin_return, fin_length, t_max);
+                       proper_term, b_obs, b_act, b_rew, b_done, b_filled, fin_return, fin_length, t_max, ac_ghost_current());
     timing_end(TIMER_COLLECT, st);
     MARL_CHECK_LAUNCH("ac_collect_kernel");
     return 0;

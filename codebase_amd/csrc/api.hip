@@ -50,6 +50,10 @@ void scratch_bind(void* base, int64_t bytes) {
     g_scratch_bytes = base != nullptr ? bytes : 0;
 }
 
+static thread_local AcGhost g_ac_ghost = {};
+const AcGhost& ac_ghost_current() { return g_ac_ghost; }
+void ac_ghost_bind(const AcGhost* g) { g_ac_ghost = g != nullptr ? *g : AcGhost{}; }
+
 int64_t scratch_avail() {  // bytes collect_pack_scratch can hand out in this call
     if (g_scratch_base == nullptr) return 0;
     char* b = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(g_scratch_base) + 15) & ~(uintptr_t)15);

@@ -31,6 +31,29 @@ struct ScratchScope {
 int64_t scratch_avail();
 float* collect_pack_scratch(size_t bytes, hipStream_t st);  // nullptr + marlhip_last_error() text when the bound region cannot hold it
 
+// Second pass of a rollout: the reference keeps stepping the envs whose episode ended (auto-reset vector env, the policy acts on
+// them too) until the LAST env's first episode ends, and appends the info of every further episode that finishes meanwhile
+// (ac/train.py:71,101-110); with env.standardise_rewards those steps also move the envs' running reward statistics.  The first
+// pass ignores finished envs, so the envs that finished before t_stop run again here - from the auto-reset state (reset stream
+// 2 * round + 1, then + 2, ...), from their own finishing step t_start to t_stop, same action noise (keyed on the global step),
+// no batch writes - and leave (returns, length, finishing step) of up to `cap` further episodes each.  env_ids == NULL: first pass.
+struct AcGhost {
+    const int32_t* env_ids;  // [n] env index of lane n (Philox streams, reward statistics)
+    const int32_t* t_start;  // [n] first step of the second pass = length of the env's first episode
+    int t_stop, cap;
+    float* ret;              // [n][cap][P]
+    int32_t* meta;           // [n][cap][2] = (episode length, finishing step)
+    int32_t* cnt;            // [n] episodes recorded (<= cap)
+};
+const AcGhost& ac_ghost_current();        // the calling host thread's pass description (api.hip); env_ids == NULL outside a second pass
+void ac_ghost_bind(const AcGhost* g);
+struct AcGhostScope {
+    explicit AcGhostScope(const AcGhost& g) { ac_ghost_bind(&g); }
+    ~AcGhostScope() { ac_ghost_bind(nullptr); }
+    AcGhostScope(const AcGhostScope&) = delete;
+    AcGhostScope& operator=(const AcGhostScope&) = delete;
+};
+
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: one slot per device ordinal, raised monotonically (a racing second
 // call sets the same value)
 struct LdsAttr {

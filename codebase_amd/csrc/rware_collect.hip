@@ -76,3 +76,19 @@ extern "C" int marlhip_rware_ac_collect(const marlhip_rware_config* cfg, const m
     return rware_ac_collect_big(q, s, actor_params, round, max_len, use_proper_termination, batch_obs, batch_act, batch_rew, batch_done,
                                 batch_filled, fin_return, fin_length, t_max, (hipStream_t)stream);
 }
+
+// the second pass of a rollout on the warehouse (AcGhost, common.h; marlhip_ac_collect_later_episodes)
+extern "C" int marlhip_rware_ac_collect_later_episodes(const marlhip_rware_config* cfg, const marlhip_net_shape* s, const float* actor_params,
+                                                       uint32_t round, int32_t max_len, const int32_t* env_ids, const int32_t* t_start,
+                                                       int32_t n_envs, int32_t t_stop, int32_t cap, float* ret, int32_t* meta, int32_t* cnt,
+                                                       void* workspace, int64_t workspace_bytes, void* stream) {
+    MARL_REQUIRE(cfg && env_ids && t_start && ret && meta && cnt, "rware_ac_collect_later_episodes: NULL pointer");
+    MARL_REQUIRE(n_envs > 0 && t_stop > 0 && cap > 0, "rware_ac_collect_later_episodes: n_envs %d, t_stop %d, cap %d must be > 0", n_envs, t_stop, cap);
+    marlhip_rware_config c2 = *cfg;
+    c2.n_envs = n_envs;
+    (void)hipMemsetAsync(cnt, 0, (size_t)n_envs * sizeof(int32_t), (hipStream_t)stream);
+    const AcGhost g = {env_ids, t_start, t_stop < max_len ? t_stop : max_len, cap, ret, meta, cnt};
+    AcGhostScope scope(g);
+    return marlhip_rware_ac_collect(&c2, s, actor_params, round, max_len, 0, ret, reinterpret_cast<int64_t*>(meta), ret, reinterpret_cast<uint8_t*>(meta), ret,
+                                    ret, meta, meta + 2 * (size_t)n_envs * cap - 1, workspace, workspace_bytes, stream);
+}

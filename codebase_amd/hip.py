@@ -697,6 +697,22 @@ def ac_collect(cfg, spec: NetSpec, actor_params, round_idx, max_len, use_proper_
                                  _stream()), "ac_collect")
 
 
+def ac_collect_later_episodes(cfg, spec: NetSpec, actor_params, round_idx, max_len, env_ids, t_start, t_stop, cap=8):
+    """The second pass of a rollout (marlhip_ac_collect_later_episodes): the envs `env_ids` (int32 device tensor) whose first episode
+    ended at `t_start` < t_stop keep stepping, as the reference's auto-resetting vector env does until the last env has finished
+    (ac/train.py:71,101-110).  Returns (returns [n][cap][P], meta [n][cap][2] = (length, finishing step), count [n])."""
+    _require_gpu()
+    n, dev = int(env_ids.numel()), actor_params.device
+    ret = torch.zeros(n, cap, spec.n_agents, device=dev)
+    meta = torch.zeros(n, cap, 2, dtype=torch.int32, device=dev)
+    cnt = torch.zeros(n, dtype=torch.int32, device=dev)
+    s = spec.c()
+    fn = lib.marlhip_rware_ac_collect_later_episodes if is_rware(cfg) else lib.marlhip_ac_collect_later_episodes
+    check(fn(ctypes.byref(cfg), ctypes.byref(s), _ptr(actor_params), int(round_idx) & 0xFFFFFFFF, int(max_len), _ptr(env_ids), _ptr(t_start), n,
+             int(t_stop), int(cap), _ptr(ret), _ptr(meta), _ptr(cnt), *_fwd_ws(spec, dev), _stream()), "ac_collect_later_episodes")
+    return ret, meta, cnt
+
+
 def gru_forward(spec: NetSpec, params, obs, h_in=None, want_h=False, record=None):
     """recurrent Q-networks (use_rnn): obs f32 [P][S][B][D] on the device -> q [P][S][B][A] (and the final hidden state
     [P][B][H] when want_h); h_in [P][B][H] or None (zeros).  `record`: float tensor of marlhip_gru_record_floats for BPTT."""

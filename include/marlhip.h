@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MARLHIP_VERSION 202
+#define MARLHIP_VERSION 203
 
 int marlhip_version(void);
 const char* marlhip_last_error(void);
@@ -327,6 +327,19 @@ int marlhip_ac_collect(const marlhip_lbf_config* cfg, const marlhip_net_shape* s
                        float* fin_return /* [P][N] */, int32_t* fin_length /* [N] */, int32_t* t_max /* [1] */,
                        void* workspace, int64_t workspace_bytes /* >= marlhip_forward_workspace_bytes(s) */, void* stream);
 
+/* The second pass of a rollout.  The reference keeps stepping the envs whose episode has ended (auto-reset vector env; the policy acts
+ * on them too) until the LAST env's first episode ends and appends the `final_info` of every further episode finishing meanwhile to the
+ * rollout's infos (ac/train.py:71,101-110); with env.standardise_rewards those steps also move the envs' running reward statistics.
+ * marlhip_ac_collect ignores an env once its first episode is over; this call runs the listed envs again - from the auto-reset state
+ * (reset stream 2 * round + 1, then + 2, ...), from step t_start[i] (= the length of env_ids[i]'s first episode) to t_stop (= the
+ * first pass's t_max), with the first pass's action noise - writes no batch and leaves, per listed env i, cnt[i] <= cap records:
+ * ret[i][k][P] episode returns, meta[i][k] = (episode length, finishing step).  Same collector kernels, same workspace. */
+int marlhip_ac_collect_later_episodes(const marlhip_lbf_config* cfg, const marlhip_net_shape* s, const float* actor_params, uint32_t round,
+                                      int32_t max_len, const int32_t* env_ids /* [n_envs] */, const int32_t* t_start /* [n_envs] */,
+                                      int32_t n_envs, int32_t t_stop, int32_t cap, float* ret /* [n_envs][cap][P] */,
+                                      int32_t* meta /* [n_envs][cap][2] */, int32_t* cnt /* [n_envs] */, void* workspace,
+                                      int64_t workspace_bytes /* >= marlhip_forward_workspace_bytes(s) */, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Recurrent Q-networks (`use_rnn: True`; RNNNetwork, marlbase/utils/models.py:51-116): Linear(D, H) -> ReLU -> one-layer
  * nn.GRU(H, H) -> Linear(H, A), compiled for hidden 64.  One agent's block in parameters() order:
@@ -436,6 +449,10 @@ int marlhip_rware_ac_collect(const marlhip_rware_config* cfg, const marlhip_net_
                              int64_t* batch_act, float* batch_rew, uint8_t* batch_done, float* batch_filled,
                              float* fin_return /* [P][N] */, int32_t* fin_length /* [N] */, int32_t* t_max /* [1] */,
                              void* workspace, int64_t workspace_bytes, void* stream);
+int marlhip_rware_ac_collect_later_episodes(const marlhip_rware_config* cfg, const marlhip_net_shape* s, const float* actor_params, uint32_t round,
+                                            int32_t max_len, const int32_t* env_ids, const int32_t* t_start, int32_t n_envs, int32_t t_stop,
+                                            int32_t cap, float* ret, int32_t* meta, int32_t* cnt, void* workspace, int64_t workspace_bytes,
+                                            void* stream); /* marlhip_ac_collect_later_episodes on the warehouse */
 
 /* ------------------------------------------------------------------------------------------
  * Actor-critic learner step (IA2C / IPPO).  Replaces A2CNetwork.update / PPONetwork.update

@@ -48,17 +48,21 @@ def test_inverse_cdf_sampler_properties():
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,H,coop,over", [("lbforaging:Foraging-8x8-2p-3f-v3", 128, False, {}),
                                                ("lbforaging:Foraging-8x8-2p-3f-v3", 64, False, {"max_episode_steps": 9}),
-                                               ("lbforaging:Foraging-10x10-3p-3f-v3", 64, True, {})])
+                                               ("lbforaging:Foraging-10x10-3p-3f-v3", 64, True, {}),
+                                               ("lbforaging:Foraging-5x5-2p-2f-v3", 64, False, {"T": 50, "N": 96, "max_food_level": 1})])  # level-1 food on a 5x5 field: early finishers and later episodes
 def test_fused_ac_collector_matches_oracle(name, H, coop, over):
     from codebase_amd import hip as h
     from codebase_amd.ac.train import ActorNetworks, _collect_trajectories
     from codebase_amd.utils.envs import make_env
 
     N, T, seed, rnd = 48, 25, 77, 2
+    over = dict(over)
+    N, T = over.pop("N", N), over.pop("T", T)
     torch.manual_seed(5)
     envs = make_env(seed=seed, name=name, time_limit=T, parallel_envs=N, wrappers=["CooperativeReward"] if coop else None, **over)
     model = ActorNetworks(envs.single_observation_space, envs.single_action_space, [H, H])
-    model.actor_params.mul_(4.0)  # sharper policies: some envs finish early
+    if T == 25:
+        model.actor_params.mul_(4.0)  # sharper policies: some envs finish early
     P = envs.n_agents
     t, batch, infos = _collect_trajectories(envs, model, T, N, P, "cuda", False, round_idx=rnd)
 
@@ -100,13 +104,30 @@ def test_fused_ac_collector_matches_oracle(name, H, coop, over):
     live = ob["filled"] > 0
     np.testing.assert_array_equal(kact[live], ob["actions"][live])
     assert not kact[~live].any()
-    first = {}
+    # infos: every finished episode of the rollout in the reference's order (step by step, env by env) - each env's first episode,
+    # and the later episodes of the envs that finished early and kept auto-resetting until the last env was done (second pass)
+    first_o, first_k = {}, {}
     for i, info in infos_o:
-        first.setdefault(i, info)  # the kernel reports each env's FIRST episode (later ones are logging-only)
+        first_o.setdefault(i, info)
+    for d in infos:
+        first_k.setdefault(d.env, d)
     for i in range(N):
-        np.testing.assert_array_equal(infos[i]["episode_returns"], first[i]["episode_returns"].astype(np.float32))
-        assert infos[i]["episode_length"] == first[i]["episode_length"]
+        np.testing.assert_array_equal(first_k[i]["episode_returns"], first_o[i]["episode_returns"].astype(np.float32))
+        assert first_k[i]["episode_length"] == first_o[i]["episode_length"]
+    assert [d.env for d in infos if d is first_k[d.env]] == [i for i, info in infos_o if info is first_o[i]]
+    later_o = [(i, info) for i, info in infos_o if info is not first_o[i]]
+    later_k = [d for d in infos if d is not first_k[d.env]]
+    # the later episodes replay the policy on envs whose actions were not stored: a sampler disagreement (libm vs device expf at a CDF
+    # boundary, counted above for the live envs) would fork such an episode, so a stray difference is tolerated, a systematic one is not
+    bad = abs(len(later_o) - len(later_k))
+    for (i, info), d in zip(later_o, later_k):
+        same = d.env == i and d["episode_length"] == info["episode_length"] and np.array_equal(d["episode_returns"], info["episode_returns"].astype(np.float32))
+        bad += 0 if same else 1
+    assert bad <= max(1, len(later_o) // 20), (bad, len(later_o), len(later_k))
+    print("later episodes:", len(later_o), "differences:", bad)
+    if T == 50:
+        assert len(later_o) >= 3  # the case exists to exercise the second pass
     lens = ob["filled"].sum(0)
-    if over:  # env-side step limit 9 < time_limit: every episode ends by `done` at step 9, rows beyond stay zero
+    if over.get("max_episode_steps") == 9:  # env-side step limit 9 < time_limit: every episode ends by `done` at step 9, rows beyond stay zero
         assert (lens == 9).all() and t == 9 and not batch.obss.cpu().numpy()[11:].any()
     print("episode lengths min/max:", lens.min(), lens.max(), "sampler disagreements:", mism)
