@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--env-name", default=ENV_NAME, help="other BASELINE.json configs, e.g. lbforaging:Foraging-15x15-4p-5f-v3 or rware:rware-tiny-4ag-v2 (with --time-limit 500)")
     ap.add_argument("--algo", default="idqn", choices=["idqn", "vdn", "qmix", "ia2c", "ippo", "maa2c", "mappo"])
     ap.add_argument("--rnn", action="store_true", help="recurrent Q-networks (algorithm.model.use_rnn=True; idqn / vdn, hidden 64)")
+    ap.add_argument("--mixer-fp16", action="store_true", help="qmix: the opt-in fp16 first mixer layers (BASELINE config 5; a deviation from the fp32 reference)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -402,7 +403,7 @@ def main():
 
     if args.algo == "qmix":  # marlbase/configs/algorithm/qmix.yaml:14-17
         model = QMixNetwork(obs_space, act_space, hyper, [H, H], False, bool(args.rnn), True,
-                            dict(embed_dim=64, hypernet_layers=2, hypernet_embed=32), "cuda")
+                            dict(embed_dim=64, hypernet_layers=2, hypernet_embed=32, fp16=bool(args.mixer_fp16)), "cuda")
     else:
         model = (VDNetwork if args.algo == "vdn" else QNetwork)(obs_space, act_space, hyper, [H, H], False, bool(args.rnn), True, "cuda")
     cap = args.replay_rounds * N
@@ -491,7 +492,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": "f32" if not (args.algo == "qmix" and args.mixer_fp16) else "f32 (mixer first layers: fp16 inputs on MFMA, fp32 accumulate - opt-in)",
         "data": "synthetic (Philox-seeded env layouts, orthogonal-init weights)",
         "config": {
             "workload": f"{args.algo.upper()} on {args.env_name.split(':')[-1].replace('-v3', '')}, {N} batched HIP envs per GPU, "

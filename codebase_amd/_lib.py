@@ -58,7 +58,7 @@ class BatchStruct(ctypes.Structure):
 
 class QmixMixer(ctypes.Structure):
     _fields_ = [("mixer", c_void_p), ("target_mixer", c_void_p), ("mixer_grad", c_void_p), ("embed_dim", c_int32),
-                ("hypernet_layers", c_int32), ("hypernet_embed", c_int32), ("ret_stats", c_void_p)]
+                ("hypernet_layers", c_int32), ("hypernet_embed", c_int32), ("ret_stats", c_void_p), ("l1_fp16", c_int32)]
 
 
 class AcConfig(ctypes.Structure):

@@ -213,6 +213,7 @@ static int qmix_call(const marlhip_net_shape* s, const float* params, const floa
     qx.mixer = mx->mixer; qx.tmixer = mx->target_mixer; qx.mgrad = mx->mixer_grad;
     qx.ws = static_cast<char*>(workspace) + a;
     qx.ws_bytes = workspace_bytes - a;
+    qx.l1_fp16 = mx->l1_fp16 != 0;
     RetStats rst;
     if (mx->ret_stats != nullptr) {  // QMixNetwork with standardise_returns: per-batch-column statistics (model.py:415-422)
         const marlhip_ret_stats* st = mx->ret_stats;

@@ -259,6 +259,7 @@ int gru_qmix_loss_grad(const marlhip_net_shape* s, const float* params, const fl
     QmixCtx qx;
     qx.mixer = mx->mixer; qx.tmixer = mx->target_mixer; qx.mgrad = mx->mixer_grad;
     qx.ws = base + wl.total + extra; qx.ws_bytes = mixws;
+    qx.l1_fp16 = mx->l1_fp16 != 0;
     RetStats rst;
     if (mx->ret_stats != nullptr) {  // standardise_returns: the mixer stage standardises the target mixer's output per batch column
         const marlhip_ret_stats* stt = mx->ret_stats;

@@ -47,6 +47,9 @@ struct QmixShape {
     static constexpr int mP1 = 0, mc1 = mP1 + W1T * 512, mPF = mc1 + E * P, mcf = mPF + 2048, mbv = mcf + 64, mcv = mbv + 64,
                          mT1 = mcv + 4, mTF = mT1 + W1T * 512, NMIX = mTF + 2048, NMIX_FWD = mT1;
     static constexpr int NPACK = 2 * NL1 + NMIX + NMIX_FWD;  // online L1 | target L1 | online mix | target mix (forward part)
+    // opt-in fp16 first layers (marlhip_qmix_mixer.l1_fp16): the same A operands as four halfs (8 bytes) per (k-group, tile, lane),
+    // behind the fp32 packs: [online | target], NL1H float slots each
+    static constexpr int NL1H = KS4 * MT1 * 64 * 2, NPACK_ALL = NPACK + 2 * NL1H;
 };
 
 template <class Q>
@@ -103,6 +106,22 @@ __global__ __launch_bounds__(256) void qmix_pack_kernel(const float* __restrict_
     packs[idx] = v;
 }
 
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+
+// the first-layer A operands rounded to fp16 (round-to-nearest-even), [online | target] behind the fp32 packs
+template <class Q>
+__global__ __launch_bounds__(256) void qmix_pack_half_kernel(const float* __restrict__ mixer, const float* __restrict__ tmixer, float* __restrict__ packs) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;  // one (net, k-group, tile, lane) entry = 4 halfs
+    constexpr int N = Q::KS4 * Q::MT1 * 64;
+    if (idx >= 2 * N) return;
+    const int net = idx / N, ent = idx - net * N;
+    const float* w = net == 0 ? mixer : tmixer;
+    h4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (_Float16)qmix_l1_pack_elem<Q>(w, 4 * ent + e);
+    reinterpret_cast<h4*>(packs + Q::NPACK)[idx] = v;
+}
+
 // where the state rows come from: the reference-layout Batch obss[P][T+1][B][D] or the episode-major replay
 template <class Q, bool REPLAY>
 struct QmixRows {
@@ -130,18 +149,22 @@ __device__ __forceinline__ size_t qmix_state_off(int k, size_t ps) {  // k < SD
 // ---------------------------------------------------------------------------------------------------------
 // first layers: Y1[row][192]
 // ---------------------------------------------------------------------------------------------------------
-template <class Q, bool REPLAY>
+// HALF: the A operands come as fp16 (packh: h4 per entry) and the states are rounded to fp16 on the way in (LBF / warehouse observations
+// are small integers: exact); one v_mfma_f32_16x16x16_f16 per (k-group, tile) instead of four f32 MFMAs, fp32 accumulation, fp32 bias.
+template <class Q, bool REPLAY, bool HALF = false>
 __global__ __launch_bounds__(256) void qmix_l1_kernel(const float* __restrict__ pack, QmixRows<Q, REPLAY> src, int toff, int R,
-                                                      float* __restrict__ Y1) {
+                                                      float* __restrict__ Y1, const h4* __restrict__ packh = nullptr) {
     constexpr int NB = MARL_QMIX_L1_NB, MT1 = Q::MT1, KS4 = Q::KS4, NCH = Q::NCH, SD = Q::SD;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     f4* lds4 = reinterpret_cast<f4*>(lds);
+    h4* ldsh = reinterpret_cast<h4*>(lds);
     const f4* pack4 = reinterpret_cast<const f4*>(pack);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, j = lane & 15;
     const int ngroups = (R + 64 * NB - 1) / (64 * NB);
     const size_t ps = src.pstride();
     if (NCH == 1) {
-        copy_f4_to_lds(pack4, lds4, KS4 * MT1 * 64, tid, 256);
+        if (HALF) copy_f4_to_lds(reinterpret_cast<const f4*>(packh), lds4, KS4 * MT1 * 64 / 2, tid, 256);  // 8-byte entries, copied 16 bytes at a time
+        else copy_f4_to_lds(pack4, lds4, KS4 * MT1 * 64, tid, 256);
         __syncthreads();
     }
     for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
@@ -165,7 +188,8 @@ __global__ __launch_bounds__(256) void qmix_l1_kernel(const float* __restrict__ 
             const int n4 = (KS4 - 4 * c) < full ? (KS4 - 4 * c) : full;
             if (NCH > 1) {
                 __syncthreads();
-                copy_f4_to_lds(pack4 + c * 4 * MT1 * 64, lds4, n4 * MT1 * 64, tid, 256);
+                if (HALF) copy_f4_to_lds(reinterpret_cast<const f4*>(packh + c * 4 * MT1 * 64), lds4, n4 * MT1 * 64 / 2, tid, 256);
+                else copy_f4_to_lds(pack4 + c * 4 * MT1 * 64, lds4, n4 * MT1 * 64, tid, 256);
                 __syncthreads();
             }
 #pragma unroll
@@ -182,13 +206,27 @@ __global__ __launch_bounds__(256) void qmix_l1_kernel(const float* __restrict__ 
                             x[nb][e] = k < SD ? v : 0.f;
                         }
                     }
+                    if constexpr (HALF) {
+                        h4 xh[NB];
 #pragma unroll
-                    for (int mt = 0; mt < MT1; ++mt) {
-                        const f4 a = lds4[(q4 * MT1 + mt) * 64 + lane];
+                        for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e)
+                            for (int e = 0; e < 4; ++e) xh[nb][e] = (_Float16)x[nb][e];
 #pragma unroll
-                            for (int nb = 0; nb < NB; ++nb) acc[nb][mt] = MARL_MFMA(a[e], x[nb][e], acc[nb][mt]);
+                        for (int mt = 0; mt < MT1; ++mt) {
+                            const h4 a = ldsh[(q4 * MT1 + mt) * 64 + lane];
+#pragma unroll
+                            for (int nb = 0; nb < NB; ++nb) acc[nb][mt] = __builtin_amdgcn_mfma_f32_16x16x16f16(a, xh[nb], acc[nb][mt], 0, 0, 0);
+                        }
+                    } else {
+#pragma unroll
+                        for (int mt = 0; mt < MT1; ++mt) {
+                            const f4 a = lds4[(q4 * MT1 + mt) * 64 + lane];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                                for (int nb = 0; nb < NB; ++nb) acc[nb][mt] = MARL_MFMA(a[e], x[nb][e], acc[nb][mt]);
+                        }
                     }
                 }
             }
@@ -620,6 +658,7 @@ struct QmixCtx {  // what marlhip_qmix_loss_grad adds to the agent-network call
     void* ws;  // qmix part of the workspace
     int64_t ws_bytes;
     const RetStats* rst = nullptr;  // standardise_returns: per-batch-column statistics (ret_stats.h), or null
+    bool l1_fp16 = false;           // marlhip_qmix_mixer.l1_fp16: first layers of both mixers on the fp16 MFMA
 };
 
 struct QmixWs {
@@ -633,7 +672,7 @@ inline QmixWs qmix_ws_layout(int T, int B) {
     QmixWs w;
     auto al = [](int64_t x) { return (x + 255) & ~(int64_t)255; };
     w.packs = 0;
-    w.y1o = al(w.packs + (int64_t)Q::NPACK * 4);
+    w.y1o = al(w.packs + (int64_t)Q::NPACK_ALL * 4);
     w.y1t = al(w.y1o + Rp * Q::NF1 * 4);  // target first layers, then (dead) reused as G1T
     w.dw1 = al(w.y1t + Rp * Q::NF1 * 4);
     w.dwf = al(w.dw1 + Rp * Q::E * Q::P * 4);
@@ -678,16 +717,24 @@ int qmix_launch_mix(const QmixCtx& qx, const marlhip_batch* bt, const ReplaySrc&
     static LdsAttr attr_set;
     if (attr_set.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qmix_l1_kernel<Q, REPLAY>), hipFuncAttributeMaxDynamicSharedMemorySize, CH);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qmix_l1_kernel<Q, REPLAY, true>), hipFuncAttributeMaxDynamicSharedMemorySize, CH);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qmix_mix_kernel<Q, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LM_ON);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qmix_mix_kernel<Q, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LM_TG);
         attr_set.done();
     }
     hipLaunchKernelGGL((qmix_pack_kernel<Q>), dim3((Q::NPACK + 255) / 256), dim3(256), 0, st, qx.mixer, qx.tmixer, packs);
+    const h4* packh = reinterpret_cast<const h4*>(packs + Q::NPACK);  // [online | target], Q::KS4 * Q::MT1 * 64 entries each
+    if (qx.l1_fp16)
+        hipLaunchKernelGGL((qmix_pack_half_kernel<Q>), dim3((2 * Q::KS4 * Q::MT1 * 64 + 255) / 256), dim3(256), 0, st, qx.mixer, qx.tmixer, packs);
     const int ngroups = (R + 64 * MARL_QMIX_L1_NB - 1) / (64 * MARL_QMIX_L1_NB), nblk = (R + 15) / 16;
     const int g1 = ngroups < 768 ? ngroups : 768;
     const int g2 = (nblk + 3) / 4 < 256 ? (nblk + 3) / 4 : 256;
     timing_begin(TIMER_QMIX, st);
-    hipLaunchKernelGGL((qmix_l1_kernel<Q, REPLAY>), dim3(g1), dim3(256), CH, st, (const float*)(packs + Q::NL1), src, 1, R, y1t);
+    if (qx.l1_fp16)
+        hipLaunchKernelGGL((qmix_l1_kernel<Q, REPLAY, true>), dim3(g1), dim3(256), CH / 2, st, (const float*)(packs + Q::NL1), src, 1, R, y1t,
+                           packh + Q::KS4 * Q::MT1 * 64);
+    else
+        hipLaunchKernelGGL((qmix_l1_kernel<Q, REPLAY>), dim3(g1), dim3(256), CH, st, (const float*)(packs + Q::NL1), src, 1, R, y1t, (const h4*)nullptr);
     hipLaunchKernelGGL((qmix_mix_kernel<Q, false>), dim3(g2), dim3(256), LM_TG, st, (const float*)(packs + 2 * Q::NL1 + Q::NMIX),
                        (const float*)y1t, io2, R, gamma, bw);
     if (qx.rst != nullptr) {  // QMixNetwork with standardise_returns: the target mixer's output becomes the standardised return
@@ -695,7 +742,10 @@ int qmix_launch_mix(const QmixCtx& qx, const marlhip_batch* bt, const ReplaySrc&
         if (rc != 0) return rc;
         io2.ytgt_is_return = 1;
     }
-    hipLaunchKernelGGL((qmix_l1_kernel<Q, REPLAY>), dim3(g1), dim3(256), CH, st, (const float*)packs, src, 0, R, y1o);
+    if (qx.l1_fp16)
+        hipLaunchKernelGGL((qmix_l1_kernel<Q, REPLAY, true>), dim3(g1), dim3(256), CH / 2, st, (const float*)packs, src, 0, R, y1o, packh);
+    else
+        hipLaunchKernelGGL((qmix_l1_kernel<Q, REPLAY>), dim3(g1), dim3(256), CH, st, (const float*)packs, src, 0, R, y1o, (const h4*)nullptr);
     hipLaunchKernelGGL((qmix_mix_kernel<Q, true>), dim3(g2), dim3(256), LM_ON, st, (const float*)(packs + 2 * Q::NL1), (const float*)y1o,
                        io2, R, gamma, bw);
     hipLaunchKernelGGL((qmix_wgrad1_kernel<Q, REPLAY>), dim3(wl.nwg3), dim3(512), 0, st, src, bw, R,

@@ -146,6 +146,7 @@ extern "C" int marlhip_wide_qmix_loss_grad(const marlhip_net_shape* s, const flo
     QmixCtx qx;
     qx.mixer = mx->mixer; qx.tmixer = mx->target_mixer; qx.mgrad = mx->mixer_grad;
     qx.ws = base + wl.total + extra; qx.ws_bytes = mixws;
+    qx.l1_fp16 = mx->l1_fp16 != 0;
     const AgentMap am = agent_map(s);
     const int rows_all = (T + 1) * B;
     const int64_t as = (int64_t)rows_all * D;

@@ -412,13 +412,14 @@ class QMixNetwork(QNetwork):
         mixing = dict(mixing or dict(embed_dim=64, hypernet_layers=2, hypernet_embed=32))
         self.mixing = dict(embed_dim=int(mixing["embed_dim"]), hypernet_layers=int(mixing["hypernet_layers"]),
                            hypernet_embed=int(mixing["hypernet_embed"]))
+        self.mixer_fp16 = bool(mixing.get("fp16", False))  # opt-in deviation (not a reference key): first mixer layers on the fp16 MFMA
         state_dim = sum(flatdim(o) for o in obs_space)
         mixer, tmixer, self._mixer_shapes = init_flat_mixer(self.n_agents, state_dim, **self.mixing)
         self.mixer_params = mixer.to(self.device).contiguous()
         self.target_mixer_params = tmixer.to(self.device).contiguous()
         up = self.updater
         self.updater = (_hip.GruQmixUpdater if self.recurrent else _hip.WideQmixUpdater if self.spec.wide else _hip.QmixUpdater)(self.spec, self.params, self.target_params, self.mixer_params, self.target_mixer_params,
-                                        mixing=self.mixing, lr=up.lr, gamma=self.gamma, grad_clip=self.grad_clip,
+                                        mixing=dict(self.mixing, fp16=self.mixer_fp16), lr=up.lr, gamma=self.gamma, grad_clip=self.grad_clip,
                                         double_q=self.double_q, standardise_returns=self.standardise_returns, optimizer=self.optimizer)
         self.mode = 2
 

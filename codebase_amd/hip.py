@@ -470,6 +470,7 @@ class QmixUpdater(DqnUpdater):
         super().__init__(spec, params, target, **kw)
         mixing = dict(mixing or dict(embed_dim=64, hypernet_layers=2, hypernet_embed=32))
         self.mixing = (int(mixing["embed_dim"]), int(mixing["hypernet_layers"]), int(mixing["hypernet_embed"]))
+        self.l1_fp16 = int(bool(mixing.get("fp16", False)))  # opt-in: the mixers' first layers on the fp16 MFMA (marlhip_qmix_mixer.l1_fp16)
         s = spec.c()
         n = check(lib.marlhip_qmix_nparams(ctypes.byref(s), *self.mixing), "qmix_nparams")
         if mixer.numel() != n or target_mixer.numel() != n:
@@ -493,6 +494,7 @@ class QmixUpdater(DqnUpdater):
 
     def _mx(self, B=None):
         mx = QmixMixer(self.mixer.data_ptr(), self.target_mixer.data_ptr(), self.mixer_grad.data_ptr(), *self.mixing)
+        mx.l1_fp16 = self.l1_fp16
         if self.ret_stats is not None:  # standardise_returns: per-batch-column statistics (dqn/model.py:415-422)
             self._st_c = self._stats_for(2, B).c()
             mx.ret_stats = ctypes.cast(ctypes.pointer(self._st_c), ctypes.c_void_p)

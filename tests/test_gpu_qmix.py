@@ -129,3 +129,28 @@ def test_qmix_with_agent_networks_on_the_gemm_path_vs_oracle_port(P, T, B, D, H,
     assert abs(loss.cpu().numpy()[0] - ref.item()) <= 3e-5 * abs(ref.item())
     assert_grad_close(grad.cpu().numpy(), pr.grad.numpy(), 3e-4)
     assert_grad_close(up.mixer_grad.cpu().numpy(), mr.grad.numpy(), 3e-4)
+
+
+@pytest.mark.parametrize("P,T,B,D,H", [(2, 25, 33, 15, 64), (8, 9, 40, 39, 128), (4, 25, 50, 27, 64)])
+def test_qmix_opt_in_fp16_first_mixer_layers_stay_close_to_fp32(P, T, B, D, H):
+    """marlhip_qmix_mixer.l1_fp16 (BASELINE config 5's "fp16 mixer on MFMA", a deviation from the fp32 reference): weights of the mixers'
+    state-fed first layers rounded to fp16, states exact, fp32 accumulation - loss and gradients move by fp16 rounding, no more"""
+    h = hip()
+    A = 6
+    spec = h.NetSpec(P, D, H, A)
+    params = dp.init_params(P, D, H, A, seed=1) + 0.05
+    target = dp.init_params(P, D, H, A, seed=3)
+    mixer = qp.mixer_init(P, P * D, seed=11)
+    tmixer = qp.mixer_init(P, P * D, seed=12)
+    batch = dp.synthetic_batch(P, T, B, D, A, seed=5)
+    batch["rewards"][1:] = batch["rewards"][0]
+    out = []
+    for fp16 in (False, True):
+        up = h.QmixUpdater(spec, params.clone().to(DEV), target.clone().to(DEV), mixer.clone().to(DEV), tmixer.clone().to(DEV),
+                           mixing=dict(embed_dim=64, hypernet_layers=2, hypernet_embed=32, fp16=fp16))
+        loss, grad = up.loss_grad(dev_batch(h, batch))
+        out.append((float(loss[0]), grad.cpu().numpy().copy(), up.mixer_grad.cpu().numpy().copy()))
+    (l32, g32, m32), (l16, g16, m16) = out
+    assert l16 != l32 and abs(l16 - l32) <= 5e-3 * abs(l32), (l32, l16)
+    assert np.abs(g16 - g32).max() <= 2e-2 * np.abs(g32).max()
+    assert np.abs(m16 - m32).max() <= 2e-2 * np.abs(m32).max()
