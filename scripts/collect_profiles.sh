@@ -27,6 +27,7 @@ run --steps 10 --warmup 2 --algo vdn --env-name lbforaging:Foraging-15x15-4p-5f-
 run --steps 6 --warmup 2 --algo vdn --env-name lbforaging:Foraging-15x15-4p-5f-v3 --envs 8192 --hidden 128
 run --steps 20 --warmup 3 --algo qmix
 run --steps 4 --warmup 1 --algo qmix --env-name lbforaging:Foraging-15x15-8p-5f-v3 --envs 8192 --hidden 128
+run --steps 4 --warmup 1 --algo qmix --env-name lbforaging:Foraging-15x15-8p-5f-v3 --envs 8192 --hidden 128 --mixer-fp16
 run --steps 100 --warmup 5 --algo ia2c
 run --steps 100 --warmup 5 --algo ia2c --hidden 128
 run --steps 50 --warmup 5 --algo ippo --hidden 128
