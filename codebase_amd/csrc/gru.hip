@@ -161,8 +161,7 @@ int gru_loss_grad(const marlhip_net_shape* s, const float* params, const float* 
                            gamma, double_q, mode == 1 ? 1 : 0, f(wl.dq), f(wl.lrow));
     }
     MARL_CHECK_LAUNCH("gru_td_kernel");
-    hipLaunchKernelGGL((gru_seq_bwd_kernel<S>), gridS, dim3(256), ldsB, st, (const float*)f(wl.packB), steps, B, (const float*)f(wl.rec),
-                       (const float*)f(wl.dq), f(wl.rec2));
+    gru_launch_seq_bwd<S>(P, B, (const float*)f(wl.packB), steps, (const float*)f(wl.rec), (const float*)f(wl.dq), f(wl.rec2), st);
     MARL_CHECK_LAUNCH("gru_seq_bwd_kernel");
     hipLaunchKernelGGL((gru_wgrad_kernel<S>), dim3(wl.nwg, P, gru_wgrad_roles<S>()), dim3(256), ldsW, st, steps, B, bt->obss, (size_t)steps * B * S::D, (size_t)S::D, (const float*)f(wl.rec), (const float*)f(wl.rec2),
                        (const float*)f(wl.dq), (const float*)f(wl.lrow), bt->filled, T, f(wl.partials));
@@ -294,8 +293,7 @@ int gru_qmix_loss_grad(const marlhip_net_shape* s, const float* params, const fl
     if (rc != 0) return rc;
     (void)hipMemsetAsync(f(wl.dq), 0, (size_t)P * steps * B * S::A * sizeof(float), st);
     hipLaunchKernelGGL(gru_expand_dq_kernel, gridR, dim3(256), 0, st, P, T, B, S::A, (const float*)dqm, *bt, f(wl.dq));
-    hipLaunchKernelGGL((gru_seq_bwd_kernel<S>), gridS, dim3(256), ldsB, st, (const float*)f(wl.packB), steps, B, (const float*)f(wl.rec),
-                       (const float*)f(wl.dq), f(wl.rec2));
+    gru_launch_seq_bwd<S>(P, B, (const float*)f(wl.packB), steps, (const float*)f(wl.rec), (const float*)f(wl.dq), f(wl.rec2), st);
     hipLaunchKernelGGL((gru_wgrad_kernel<S>), dim3(wl.nwg, P, gru_wgrad_roles<S>()), dim3(256), ldsW, st, steps, B, bt->obss, (size_t)steps * B * S::D, (size_t)S::D, (const float*)f(wl.rec), (const float*)f(wl.rec2),
                        (const float*)f(wl.dq), (const float*)f(wl.lrow), bt->filled, T, f(wl.partials));
     MARL_CHECK_LAUNCH("gru backward");

@@ -164,6 +164,150 @@ __global__ __launch_bounds__(256) void gru_seq_bwd_kernel(const float* __restric
     }
 }
 
+// The same walk with TWO waves per block of 16 sequences (hidden 64): B / 16 blocks of a bench batch are 512 waves for 1024 SIMDs, and the
+// walk is a chain of dependent steps, so the one-wave form leaves half of the chip idle.  Here each wave of a pair owns half of the hidden
+// tiles: it loads the record, forms dh and the gate derivatives and keeps the carried dh for ITS tiles only, the pair swaps the four
+// gate-gradient arrays through LDS (the transposed products need every gate unit as input), and each wave multiplies out only its own
+// output tiles - half of the MFMAs, of the record traffic and of the gate arithmetic per wave and step, for two barriers.
+template <class S>
+struct GruBwdSplit : std::integral_constant<bool, S::MT == 4 && !GruBwd<S>::STREAM> {};
+template <class S>
+constexpr size_t gru_bwd_lds_bytes() {
+    return (size_t)(GruBwd<S>::LDS_FLOATS + (GruBwdSplit<S>::value ? 2 * 4 * S::MT * 256 : 0)) * sizeof(float);
+}
+
+template <class S>
+__global__ __launch_bounds__(256) void gru_seq_bwd2_kernel(const float* __restrict__ packs, int steps, int B, const float* __restrict__ rec,
+                                                           const float* __restrict__ dq, float* __restrict__ rec2) {
+    using Bk = GruBwd<S>;
+    constexpr int MT = S::MT, MH = MT / 2, A = S::A;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, j = lane & 15;
+    const int pairw = wave >> 1, half = wave & 1, m0 = half * MH;  // the pair's block inside the workgroup, this wave's tiles m0 .. m0 + MH - 1
+    const int p = blockIdx.y;
+    const float* pack = packs + (size_t)p * Bk::NBWD;
+    copy_f4_to_lds(reinterpret_cast<const f4*>(pack), reinterpret_cast<f4*>(lds), Bk::NBWD / 4, tid, 256);
+    __syncthreads();
+    f4* X = reinterpret_cast<f4*>(lds + Bk::NBWD) + (size_t)pairw * 4 * MT * 64;  // the pair's exchange: [dr, dz, dn, r * dn][unit tile][lane]
+    const int nblk = (B + 15) >> 4;
+    const int blk0 = blockIdx.x * 2 + pairw;
+    const bool active = blk0 < nblk;  // (an idle pair keeps walking: the barriers are workgroup-wide)
+    const int blk = active ? blk0 : nblk - 1;
+    const int b0 = blk * 16;
+    const bool rowok = active && b0 + j < B;
+    const int bj = b0 + j < B ? b0 + j : B - 1;
+    const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const f4* T3 = reinterpret_cast<const f4*>(lds + Bk::pT3);
+    auto tmat = [&](int c) { return reinterpret_cast<const f4*>(lds + Bk::pThh) + (size_t)c * MT * MT * 64; };
+    // out[own tile] += (transposed gate matrix c) x dg, every gate-unit tile of dg as input
+    auto tgate = [&](int c, const f4 (&dgx)[MT], f4 (&out)[MH]) {
+        const f4* Tm = tmat(c);
+#pragma unroll
+        for (int m2 = 0; m2 < MT; ++m2) {
+            f4 a[MH];
+#pragma unroll
+            for (int u = 0; u < MH; ++u) a[u] = Tm[((m0 + u) * MT + m2) * 64 + lane];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int u = 0; u < MH; ++u) out[u] = MARL_MFMA(a[u][r], dgx[m2][r], out[u]);
+        }
+    };
+    f4 carry[MH];
+#pragma unroll
+    for (int u = 0; u < MH; ++u) carry[u] = zero4;
+    for (int t = steps - 1; t >= 0; --t) {
+        asm volatile("" ::: "memory");  // keep the weight reads inside the loop (see gru_seq_fwd_kernel)
+        const f4* R = reinterpret_cast<const f4*>(rec + (((size_t)p * steps + t) * nblk + blk) * S::REC);
+        const f4* Rp = reinterpret_cast<const f4*>(rec + (((size_t)p * steps + (t > 0 ? t - 1 : 0)) * nblk + blk) * S::REC);
+        f4 x1[MH], rg[MH], zg[MH], ng[MH], ghn[MH], hp[MH];
+#pragma unroll
+        for (int u = 0; u < MH; ++u) {
+            const int mt = m0 + u;
+            x1[u] = R[(0 * MT + mt) * 64 + lane];
+            rg[u] = R[(1 * MT + mt) * 64 + lane];
+            zg[u] = R[(2 * MT + mt) * 64 + lane];
+            ng[u] = R[(3 * MT + mt) * 64 + lane];
+            ghn[u] = R[(5 * MT + mt) * 64 + lane];
+            hp[u] = t > 0 ? Rp[(4 * MT + mt) * 64 + lane] : zero4;
+        }
+        f4 dQ;
+        {
+            const float* drow = dq + (((size_t)p * steps + t) * B + bj) * A;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dQ[r] = (rowok && 4 * g + r < A) ? drow[4 * g + r < A ? 4 * g + r : A - 1] : 0.f;
+        }
+        f4 dr[MH], dz[MH], dng[MH], drn[MH];
+#pragma unroll
+        for (int u = 0; u < MH; ++u) {
+            f4 dh = carry[u];  // dh = carried + W3^T dq
+            const f4 a = T3[(m0 + u) * 64 + lane];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dh = MARL_MFMA(a[r], dQ[r], dh);
+            dng[u] = dh * (1.f - zg[u]) * (1.f - ng[u] * ng[u]);
+            dz[u] = dh * (hp[u] - ng[u]) * zg[u] * (1.f - zg[u]);
+            drn[u] = dng[u] * rg[u];
+            dr[u] = dng[u] * ghn[u] * rg[u] * (1.f - rg[u]);
+            carry[u] = dh * zg[u];
+            X[(0 * MT + m0 + u) * 64 + lane] = dr[u];
+            X[(1 * MT + m0 + u) * 64 + lane] = dz[u];
+            X[(2 * MT + m0 + u) * 64 + lane] = dng[u];
+            X[(3 * MT + m0 + u) * 64 + lane] = drn[u];
+        }
+        __syncthreads();
+        f4 ar[MT], az[MT], an[MT], arn[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            ar[mt] = X[(0 * MT + mt) * 64 + lane];
+            az[mt] = X[(1 * MT + mt) * 64 + lane];
+            an[mt] = X[(2 * MT + mt) * 64 + lane];
+            arn[mt] = X[(3 * MT + mt) * 64 + lane];
+        }
+        __syncthreads();  // everybody has read: the next step may overwrite the exchange
+        tgate(0, ar, carry);
+        tgate(1, az, carry);
+        tgate(2, arn, carry);
+        f4 dx1[MH];
+#pragma unroll
+        for (int u = 0; u < MH; ++u) dx1[u] = zero4;
+        tgate(3, ar, dx1);
+        tgate(4, az, dx1);
+        tgate(5, an, dx1);
+        if (!active) continue;
+        f4* R2 = reinterpret_cast<f4*>(rec2 + (((size_t)p * steps + t) * nblk + blk) * Bk::REC2);
+#pragma unroll
+        for (int u = 0; u < MH; ++u) {
+            const int mt = m0 + u;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dx1[u][r] = x1[u][r] > 0.f ? dx1[u][r] : 0.f;
+            R2[(0 * MT + mt) * 64 + lane] = dr[u];
+            R2[(1 * MT + mt) * 64 + lane] = dz[u];
+            R2[(2 * MT + mt) * 64 + lane] = dng[u];
+            R2[(3 * MT + mt) * 64 + lane] = drn[u];
+            R2[(4 * MT + mt) * 64 + lane] = dx1[u];
+        }
+    }
+}
+
+// the backward walk of P agents over B sequences: the two-wave form where it exists (MARLHIP_GRU_BWD_ONE_WAVE=1 keeps the one-wave form)
+template <class S>
+void gru_launch_seq_bwd(int P, int B, const float* packB, int steps, const float* rec, const float* dq, float* rec2, hipStream_t st) {
+    static const bool one_wave = getenv("MARLHIP_GRU_BWD_ONE_WAVE") != nullptr;
+    if constexpr (GruBwdSplit<S>::value) {
+        if (!one_wave) {
+            static LdsAttr attr;
+            if (attr.need()) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_seq_bwd2_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)gru_bwd_lds_bytes<S>());
+                attr.done();
+            }
+            hipLaunchKernelGGL((gru_seq_bwd2_kernel<S>), dim3((B + 31) / 32, P), dim3(256), gru_bwd_lds_bytes<S>(), st, packB, steps, B, rec, dq, rec2);
+            return;
+        }
+    }
+    hipLaunchKernelGGL((gru_seq_bwd_kernel<S>), dim3((B + 63) / 64, P), dim3(256), GruBwd<S>::LDS_FLOATS * sizeof(float), st, packB, steps, B, rec, dq, rec2);
+}
+
 // hidden 64 (four unit tiles): the three gate roles below are one workgroup role (the FUSED branch of the kernel); launches use
 // gru_wgrad_roles / gru_wgrad_lds_bytes
 template <class S>
