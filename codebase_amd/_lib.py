@@ -185,6 +185,7 @@ PROTOTYPES = {
                                         c_int32, c_float, c_void_p, c_void_p, c_void_p]),
     "marlhip_ac_collect": (c_int32, [POINTER(LbfConfig), POINTER(NetShape), c_void_p, c_uint32, c_int32, c_int32, c_void_p,
                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "marlhip_ac_store_step": (c_int32, [c_int32, c_int32, c_int32, c_int32, c_int32] + [c_void_p] * 16 + [c_int32, c_void_p, c_void_p, c_void_p]),
     "marlhip_ac_collect_later_episodes": (c_int32, [c_void_p, POINTER(NetShape), c_void_p, c_uint32, c_int32, c_void_p, c_void_p, c_int32, c_int32,
                                                     c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "marlhip_rware_ac_collect_later_episodes": (c_int32, [c_void_p, POINTER(NetShape), c_void_p, c_uint32, c_int32, c_void_p, c_void_p, c_int32,

@@ -67,8 +67,9 @@ def _collect_trajectories_recurrent(envs, model, T, use_proper_termination, roun
     obs = env.reset()  # episode[n] = 2 * round + 1 afterwards: the stream of the auto-reset inside step()
     noise_episode = torch.full((N,), 2 * round_idx, dtype=torch.int32, device=dev)
     b_obs[0] = obs.permute(1, 0, 2).reshape(N, P * D)
-    running = torch.ones(N, dtype=torch.bool, device=dev)
-    later = []
+    running = torch.ones(N, dtype=torch.uint8, device=dev)
+    cap = 4 * N  # records of later episodes (envs that finished early keep auto-resetting); the count says if any were dropped
+    later_dev = (torch.zeros(1, dtype=torch.int32, device=dev), torch.zeros(cap, P, device=dev), torch.zeros(cap, 3, dtype=torch.int32, device=dev))
     hid, t = None, 0
     while t < T:
         if getattr(model, "recurrent", False):
@@ -77,27 +78,18 @@ def _collect_trajectories_recurrent(envs, model, T, use_proper_termination, roun
         else:  # feed-forward actors without a fused collector (layers wider than 128): the GEMM path's logits, no state
             logits = _hip.ac_forward_rows(model.spec, model.actor_params, obs.contiguous(), N * D, D, N)
         acts = _hip.sample_from_logits(logits, cfg.seed, noise_episode, t)
-        obs, rew, done, trunc = env.step(acts.to(torch.int32), auto_reset=True)
-        fin = (done | trunc) > 0
-        stored = (done > 0) if use_proper_termination else fin
-        b_obs[t + 1] = torch.where(running[:, None], obs.permute(1, 0, 2).reshape(N, P * D), b_obs[t + 1])
-        b_act[t] = torch.where(running[:, None], acts.t(), b_act[t])
-        b_rew[t] = torch.where(running[:, None], rew.t(), b_rew[t])
-        b_done[t + 1] = torch.where(running, stored, b_done[t + 1])
-        b_fill[t] = running.float()
-        first = running & fin  # the statistics of an env's FIRST episode of the rollout (it keeps auto-resetting afterwards)
-        fin_ret = torch.where(first[None, :], env.fin_return, fin_ret)
-        fin_len = torch.where(first, env.fin_length, fin_len)
-        again = fin & ~running  # a later episode of an env that is no longer part of the batch
-        if bool(again.any()):
-            idx = torch.nonzero(again).flatten()
-            fr, fl = env.fin_return[:, idx].t().cpu().numpy(), env.fin_length[idx].cpu().numpy()
-            later += [(t + 1, int(i), fr[k].copy(), int(fl[k])) for k, i in enumerate(idx.tolist())]
-        running = running & ~fin
+        obs, _, _, _ = env.step(acts.to(torch.int32), auto_reset=True)
+        # masked batch writes, first-episode statistics, later-episode records, running &= ~finished: one call (ac/train.py:90-110)
+        _hip.ac_store_step(env, t, use_proper_termination, running, acts, b_obs, b_act, b_rew, b_done, b_fill, fin_ret, fin_len, later_dev)
         t += 1
         if t % 8 == 0 and not bool(running.any()):
             break
     filled_steps = int(b_fill.sum(1).gt(0).sum().item())
+    n_later = min(int(later_dev[0].item()), cap)
+    later = []
+    if n_later:
+        lret, lmeta = later_dev[1][:n_later].cpu().numpy(), later_dev[2][:n_later].cpu().numpy()
+        later = [(int(lmeta[k, 0]), int(lmeta[k, 1]), lret[k].copy(), int(lmeta[k, 2])) for k in range(n_later)]
     return filled_steps, Batch(b_obs, b_act, b_rew, b_done, b_fill, None), fin_ret, fin_len, later
 
 

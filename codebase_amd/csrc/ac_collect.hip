@@ -58,3 +58,75 @@ extern "C" int marlhip_ac_collect_later_episodes(const marlhip_lbf_config* cfg, 
     return marlhip_ac_collect(&c2, s, actor_params, round, max_len, 0, ret, reinterpret_cast<int64_t*>(meta), ret, reinterpret_cast<uint8_t*>(meta), ret, ret,
                               meta, meta + 2 * (size_t)n_envs * cap - 1, workspace, workspace_bytes, stream);
 }
+
+// ---- the bookkeeping of ONE step of a modular rollout (recurrent actors, actors on the GEMM path: the forward and the env step are
+// their own launches) - ac/train.py:90-110 for all N envs in one launch instead of a dozen tensor operations: masked writes of the
+// still-running envs into the time-major batch, the first episode's statistics, the records of later episodes (envs that keep
+// auto-resetting while the others finish), running &= ~finished.
+namespace {
+__global__ __launch_bounds__(256) void ac_store_step_kernel(int N, int P, int D, int t, int proper_term, uint8_t* __restrict__ running,
+                                                            const float* __restrict__ obs /* [P][N][D] */, const int64_t* __restrict__ acts /* [P][N] */,
+                                                            const float* __restrict__ rew /* [P][N] */, const uint8_t* __restrict__ done,
+                                                            const uint8_t* __restrict__ trunc, const float* __restrict__ env_fin_return /* [P][N] */,
+                                                            const int32_t* __restrict__ env_fin_length, float* __restrict__ b_obs_t1 /* [N][P*D] */,
+                                                            int64_t* __restrict__ b_act_t /* [N][P] */, float* __restrict__ b_rew_t, uint8_t* __restrict__ b_done_t1,
+                                                            float* __restrict__ b_fill_t, float* __restrict__ fin_ret /* [P][N] */,
+                                                            int32_t* __restrict__ fin_len, int32_t* __restrict__ later_cnt, int later_cap,
+                                                            float* __restrict__ later_ret /* [cap][P] */, int32_t* __restrict__ later_meta /* [cap][3] */) {
+    const int PD = P * D;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)N * PD) return;
+    const int n = (int)(i / PD), e = (int)(i - (int64_t)n * PD);
+    const bool run = running[n] != 0;  // (read by every thread of the env before thread e == 0 of it may clear it: see the launch note)
+    const bool fin = (done[n] | trunc[n]) != 0;
+    if (run) {
+        const int p = e / D, d = e - p * D;
+        b_obs_t1[(size_t)n * PD + e] = obs[((size_t)p * N + n) * D + d];
+    }
+    if (e != 0) return;
+    b_fill_t[n] = run ? 1.f : 0.f;
+    if (run) {
+        for (int p = 0; p < P; ++p) {
+            b_act_t[(size_t)n * P + p] = acts[(size_t)p * N + n];
+            b_rew_t[(size_t)n * P + p] = rew[(size_t)p * N + n];
+        }
+        b_done_t1[n] = (proper_term ? done[n] != 0 : fin) ? 1 : 0;
+        if (fin) {
+            for (int p = 0; p < P; ++p) fin_ret[(size_t)p * N + n] = env_fin_return[(size_t)p * N + n];
+            fin_len[n] = env_fin_length[n];
+        }
+    } else if (fin && later_cnt != nullptr) {
+        const int k = atomicAdd(later_cnt, 1);
+        if (k < later_cap) {
+            for (int p = 0; p < P; ++p) later_ret[(size_t)k * P + p] = env_fin_return[(size_t)p * N + n];
+            later_meta[3 * k] = t + 1;
+            later_meta[3 * k + 1] = n;
+            later_meta[3 * k + 2] = env_fin_length[n];
+        }
+    }
+}
+// second launch: running &= ~finished (its own launch, so that every thread of the step above has read `running` first)
+__global__ __launch_bounds__(256) void ac_clear_running_kernel(int N, uint8_t* __restrict__ running, const uint8_t* __restrict__ done,
+                                                               const uint8_t* __restrict__ trunc) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n < N && (done[n] | trunc[n]) != 0) running[n] = 0;
+}
+}  // namespace
+
+extern "C" int marlhip_ac_store_step(int32_t n_envs, int32_t n_agents, int32_t obs_dim, int32_t t, int32_t use_proper_termination, uint8_t* running,
+                                     const float* obs, const int64_t* actions, const float* rewards, const uint8_t* done, const uint8_t* truncated,
+                                     const float* env_fin_return, const int32_t* env_fin_length, float* batch_obs_t1, int64_t* batch_act_t,
+                                     float* batch_rew_t, uint8_t* batch_done_t1, float* batch_filled_t, float* fin_return, int32_t* fin_length,
+                                     int32_t* later_count, int32_t later_cap, float* later_returns, int32_t* later_meta, void* stream) {
+    MARL_REQUIRE(n_envs > 0 && n_agents > 0 && obs_dim > 0 && t >= 0, "ac_store_step: bad sizes");
+    MARL_REQUIRE(running && obs && actions && rewards && done && truncated && env_fin_return && env_fin_length && batch_obs_t1 && batch_act_t &&
+                     batch_rew_t && batch_done_t1 && batch_filled_t && fin_return && fin_length, "ac_store_step: NULL pointer");
+    MARL_REQUIRE(later_count == nullptr || (later_cap > 0 && later_returns && later_meta), "ac_store_step: later-episode buffers");
+    const int64_t total = (int64_t)n_envs * n_agents * obs_dim;
+    hipLaunchKernelGGL(ac_store_step_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n_envs, n_agents, obs_dim, t,
+                       use_proper_termination, running, obs, actions, rewards, done, truncated, env_fin_return, env_fin_length, batch_obs_t1, batch_act_t,
+                       batch_rew_t, batch_done_t1, batch_filled_t, fin_return, fin_length, later_count, later_cap, later_returns, later_meta);
+    hipLaunchKernelGGL(ac_clear_running_kernel, dim3((n_envs + 255) / 256), dim3(256), 0, (hipStream_t)stream, n_envs, running, done, truncated);
+    MARL_CHECK_LAUNCH("ac_store_step");
+    return 0;
+}

@@ -699,6 +699,16 @@ def ac_collect(cfg, spec: NetSpec, actor_params, round_idx, max_len, use_proper_
                                  _stream()), "ac_collect")
 
 
+def ac_store_step(env, t, proper, running, acts, b_obs, b_act, b_rew, b_done, b_fill, fin_ret, fin_len, later=None):
+    """marlhip_ac_store_step: one step's bookkeeping of a modular rollout after env.step() (ac/train.py:90-110) in one library call;
+    `later` = (count int32[1], returns [cap][P], meta int32 [cap][3]) or None"""
+    cnt, lret, lmeta = later if later is not None else (None, None, None)
+    check(lib.marlhip_ac_store_step(env.N, env.P, env.D, int(t), int(bool(proper)), _ptr(running), _ptr(env.obs), _ptr(acts), _ptr(env.rewards),
+                                    _ptr(env.done), _ptr(env.truncated), _ptr(env.fin_return), _ptr(env.fin_length), _ptr(b_obs[t + 1]), _ptr(b_act[t]),
+                                    _ptr(b_rew[t]), _ptr(b_done[t + 1]), _ptr(b_fill[t]), _ptr(fin_ret), _ptr(fin_len), _ptr(cnt),
+                                    int(lret.shape[0]) if lret is not None else 0, _ptr(lret), _ptr(lmeta), _stream()), "ac_store_step")
+
+
 def ac_collect_later_episodes(cfg, spec: NetSpec, actor_params, round_idx, max_len, env_ids, t_start, t_stop, cap=8):
     """The second pass of a rollout (marlhip_ac_collect_later_episodes): the envs `env_ids` (int32 device tensor) whose first episode
     ended at `t_start` < t_stop keep stepping, as the reference's auto-resetting vector env does until the last env has finished

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MARLHIP_VERSION 204
+#define MARLHIP_VERSION 205
 
 int marlhip_version(void);
 const char* marlhip_last_error(void);
@@ -339,6 +339,19 @@ int marlhip_ac_collect_later_episodes(const marlhip_lbf_config* cfg, const marlh
                                       int32_t n_envs, int32_t t_stop, int32_t cap, float* ret /* [n_envs][cap][P] */,
                                       int32_t* meta /* [n_envs][cap][2] */, int32_t* cnt /* [n_envs] */, void* workspace,
                                       int64_t workspace_bytes /* >= marlhip_forward_workspace_bytes(s) */, void* stream);
+
+/* One step's bookkeeping of a MODULAR rollout (recurrent actors, actors on the GEMM path: forward, sampling and env step are their own
+ * calls): ac/train.py:90-110 for all envs - masked writes of the still-running envs into row t / t + 1 of the time-major batch, the first
+ * episode's statistics from the env's fin_return / fin_length, a record (finishing step, env, length | returns) for every LATER episode
+ * that finishes (later_count may be NULL: no records; the count may exceed later_cap, the records do not), then running &= ~finished.
+ * `obs` / `rewards` / `done` / `truncated` / `env_fin_*` are the env-step call's outputs, `actions` the sampled actions. */
+int marlhip_ac_store_step(int32_t n_envs, int32_t n_agents, int32_t obs_dim, int32_t t, int32_t use_proper_termination, uint8_t* running /* [N] in/out */,
+                          const float* obs /* [P][N][D] */, const int64_t* actions /* [P][N] */, const float* rewards /* [P][N] */,
+                          const uint8_t* done, const uint8_t* truncated, const float* env_fin_return /* [P][N] */, const int32_t* env_fin_length,
+                          float* batch_obs_t1 /* [N][P*D] */, int64_t* batch_act_t /* [N][P] */, float* batch_rew_t /* [N][P] */,
+                          uint8_t* batch_done_t1 /* [N] */, float* batch_filled_t /* [N] */, float* fin_return /* [P][N] */, int32_t* fin_length,
+                          int32_t* later_count, int32_t later_cap, float* later_returns /* [cap][P] */, int32_t* later_meta /* [cap][3] */,
+                          void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Recurrent Q-networks (`use_rnn: True`; RNNNetwork, marlbase/utils/models.py:51-116): Linear(D, H) -> ReLU -> one-layer
