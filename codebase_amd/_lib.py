@@ -145,6 +145,8 @@ PROTOTYPES = {
                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "marlhip_replay_init_episode": (c_int32, [POINTER(ReplayShape), POINTER(ReplayBuffers), c_void_p, c_void_p, c_void_p,
                                               c_int32, c_void_p]),
+    "marlhip_replay_add_step": (c_int32, [POINTER(ReplayShape), POINTER(ReplayBuffers), c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
+                                          c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
     "marlhip_replay_add": (c_int32, [POINTER(ReplayShape), POINTER(ReplayBuffers), c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
     "marlhip_replay_sample": (c_int32, [POINTER(ReplayShape), POINTER(ReplayBuffers), c_void_p, c_int32, c_int32, c_uint64,

@@ -275,6 +275,49 @@ extern "C" int marlhip_replay_add(const marlhip_replay_shape* rs, const marlhip_
     return 0;
 }
 
+// ---- one step of a modular collection round (recurrent Q-networks, Q-networks on the GEMM path): ReplayBuffer.add for the envs that are
+// still alive at step t (dqn/train.py:73-89, 219-225) with the env-step call's outputs as they are, then alive &= ~(done | truncated) -
+// what the vectorised driver otherwise does with half a dozen tensor operations around marlhip_replay_add
+namespace marl {
+__global__ __launch_bounds__(256) void replay_add_step_kernel(marlhip_replay_shape rs, marlhip_replay_buffers rb, const int32_t* __restrict__ slot, int t,
+                                                              int proper_term, const uint8_t* __restrict__ alive, const float* __restrict__ obs,
+                                                              const int32_t* __restrict__ actions, const float* __restrict__ rewards,
+                                                              const uint8_t* __restrict__ done, const uint8_t* __restrict__ trunc, int N) {
+    const int P = rs.n_agents, D = rs.obs_dim, T = rs.max_len;
+    const uint32_t nd = blockIdx.x * 256u + threadIdx.x;
+    if (nd >= (uint32_t)N * (uint32_t)D) return;
+    const int n = (int)(nd / (uint32_t)D), d = (int)(nd - (uint32_t)n * (uint32_t)D), p = blockIdx.y;
+    if (!alive[n] || t + 1 > T) return;
+    const size_t sp = (size_t)slot[n] * P + p;
+    rb.obs[(sp * (T + 1) + t + 1) * D + d] = obs[(size_t)p * N * D + nd];
+    if (d == 0) {
+        rb.act[sp * T + t] = (uint8_t)actions[(size_t)p * N + n];
+        rb.rew[sp * T + t] = rewards[(size_t)p * N + n];
+        if (p == 0) {
+            rb.done[(size_t)slot[n] * (T + 1) + t + 1] = (proper_term ? done[n] != 0 : (done[n] | trunc[n]) != 0) ? 1 : 0;
+            rb.filled[(size_t)slot[n] * T + t] = 1;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void clear_alive_kernel(int N, uint8_t* __restrict__ alive, const uint8_t* __restrict__ done, const uint8_t* __restrict__ trunc) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n < N && (done[n] | trunc[n]) != 0) alive[n] = 0;
+}
+}  // namespace marl
+
+extern "C" int marlhip_replay_add_step(const marlhip_replay_shape* rs, const marlhip_replay_buffers* rb, const int32_t* slot, int32_t t,
+                                       int32_t use_proper_termination, uint8_t* alive, const float* obs, const int32_t* actions, const float* rewards,
+                                       const uint8_t* done, const uint8_t* truncated, int32_t n_envs, void* stream) {
+    if (check_replay(rs, rb) != 0) return -1;
+    MARL_REQUIRE(slot && alive && obs && actions && rewards && done && truncated && n_envs > 0 && t >= 0, "replay_add_step: bad argument");
+    MARL_REQUIRE((int64_t)n_envs * rs->obs_dim < ((int64_t)1 << 31), "replay_add_step: n_envs * obs_dim must stay below 2^31");
+    hipLaunchKernelGGL(replay_add_step_kernel, dim3((unsigned)(((int64_t)n_envs * rs->obs_dim + 255) / 256), rs->n_agents), dim3(256), 0,
+                       (hipStream_t)stream, *rs, *rb, slot, t, use_proper_termination, (const uint8_t*)alive, obs, actions, rewards, done, truncated, n_envs);
+    hipLaunchKernelGGL(clear_alive_kernel, dim3((n_envs + 255) / 256), dim3(256), 0, (hipStream_t)stream, n_envs, alive, done, truncated);
+    MARL_CHECK_LAUNCH("replay_add_step");
+    return 0;
+}
+
 extern "C" int marlhip_replay_sample(const marlhip_replay_shape* rs, const marlhip_replay_buffers* rb, const int32_t* idx,
                                      int32_t batch, int32_t length, uint64_t seed, uint32_t counter, int32_t* idx_out, float* obss,
                                      int64_t* actions, float* rewards, float* dones, float* filled, void* stream) {

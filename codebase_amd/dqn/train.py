@@ -182,16 +182,15 @@ class VectorisedIDQN:
             replay.init_episode(slot, obs)
         alive = torch.ones(N, dtype=torch.uint8, device=dev)
         hid = None
-        for _ in range(T):
+        for t in range(T):  # every env of the round starts together: t is the episode step of the envs that are still alive
             out = m.q_values(obs, hid)
             q, hid = out if isinstance(out, tuple) else (out, None)  # feed-forward networks on the GEMM path carry no state
             acts = _hip.act_from_q(q, epsilon, cfg.seed, env.episode, env.ep_length)
-            tt = env.ep_length.clone()
-            obs, rew, done, trunc = env.step(acts, active=alive)
-            fin = ((done | trunc) > 0).to(torch.uint8)
-            if replay is not None:
-                replay.add(slot, tt, obs, acts, rew, done if self.proper else fin, active=alive)
-            alive = alive & (1 - fin)
+            obs, _, done, trunc = env.step(acts, active=alive)
+            if replay is not None:  # ReplayBuffer.add of the alive envs + alive &= ~finished: one call
+                replay.add_step(slot, t, env, acts, alive, proper=self.proper)
+            else:
+                alive &= ((done | trunc) == 0).to(torch.uint8)
         fin_return.copy_(env.fin_return)
         fin_length.copy_(env.fin_length)
 

@@ -273,6 +273,13 @@ class DeviceReplay:
         check(lib.marlhip_replay_add(ctypes.byref(self.shape), ctypes.byref(self.bufs), _ptr(slot), _ptr(t), _ptr(active),
                                      _ptr(obs), _ptr(actions), _ptr(rewards), _ptr(done), obs.shape[1], _stream()), "replay_add")
 
+    def add_step(self, slot, t, env, actions, alive, proper=False):
+        """marlhip_replay_add_step: ReplayBuffer.add of step t for the alive envs straight from the env-step outputs, then
+        alive &= ~(done | truncated)"""
+        check(lib.marlhip_replay_add_step(ctypes.byref(self.shape), ctypes.byref(self.bufs), _ptr(slot), int(t), int(bool(proper)), _ptr(alive),
+                                          _ptr(env.obs), _ptr(actions), _ptr(env.rewards), _ptr(env.done), _ptr(env.truncated), env.N, _stream()),
+              "replay_add_step")
+
     def _outputs(self, B):
         if B not in self._out:
             dev, P, T, D = self.device, self.P, self.T, self.D

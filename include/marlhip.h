@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MARLHIP_VERSION 205
+#define MARLHIP_VERSION 206
 
 int marlhip_version(void);
 const char* marlhip_last_error(void);
@@ -216,6 +216,13 @@ int marlhip_replay_init_episode(const marlhip_replay_shape* rs, const marlhip_re
 int marlhip_replay_add(const marlhip_replay_shape* rs, const marlhip_replay_buffers* rb, const int32_t* slot,
                        const int32_t* t /* [N] */, const uint8_t* active, const float* obs, const int32_t* actions,
                        const float* rewards, const uint8_t* done, int32_t n_envs, void* stream);
+/* marlhip_replay_add for one step of a modular collection round, with the bookkeeping around it: rows of the envs with alive[n] != 0 are
+ * stored at step t (= their episode step: all envs of a round start together), the stored done flag is done | truncated unless
+ * use_proper_termination (dqn/train.py:219-225), then alive[n] &= ~(done | truncated). */
+int marlhip_replay_add_step(const marlhip_replay_shape* rs, const marlhip_replay_buffers* rb, const int32_t* slot /* [N] */, int32_t t,
+                            int32_t use_proper_termination, uint8_t* alive /* [N] in/out */, const float* obs /* [P][N][D] */,
+                            const int32_t* actions /* [P][N] */, const float* rewards /* [P][N] */, const uint8_t* done, const uint8_t* truncated,
+                            int32_t n_envs, void* stream);
 
 /* ReplayBuffer.sample (train.py:94-124): gather B whole episodes into the reference's Batch
  * layout: obss f32 [P][T+1][B][D], actions i64 [P][T][B], rewards f32 [P][T][B],
