@@ -141,6 +141,8 @@ PROTOTYPES = {
     "marlhip_wide_dqn_workspace_bytes": (c_int64, [POINTER(NetShape), c_int32, c_int32]),
     "marlhip_wide_dqn_loss_grad": (c_int32, [POINTER(NetShape), c_void_p, c_void_p, POINTER(BatchStruct), c_float, c_int32, c_int32, c_void_p,
                                              c_int64, c_void_p, c_void_p, c_void_p]),
+    "marlhip_wide_dqn_loss_grad_std": (c_int32, [POINTER(NetShape), c_void_p, c_void_p, POINTER(BatchStruct), c_float, c_int32,
+                                                 POINTER(RetStatsStruct), c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "marlhip_dqn_act": (c_int32, [POINTER(NetShape), c_void_p, c_void_p, c_int32, c_float, c_void_p, c_void_p, c_uint64,
                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "marlhip_replay_init_episode": (c_int32, [POINTER(ReplayShape), POINTER(ReplayBuffers), c_void_p, c_void_p, c_void_p,

@@ -549,30 +549,6 @@ __device__ __forceinline__ float gather_rows_pl(const f4& q, int lane, int a_sel
     return sum_g(v);
 }
 
-// Single-network forward for the learner kernels: MFMA groups of 16 (layer-1 steps, layer-2 steps, layer 3), the A operands of
-// group s+1 requested inside group s and spread behind its first MFMAs (sched_group_barrier), and a caller-supplied filler
-// `fill(k)` emitted INSIDE the scheduling region of group k (k = 0 .. N1 + MT) so that independent VALU / LDS / VMEM work of the
-// caller issues in the shadow of that group's MFMAs instead of between groups.  Layer 3 runs as two interleaved chains (even / odd
-// k-tiles) that are added at the end: a dependent 16x16x4 chain costs 40 cycles per MFMA instead of 32.
-// scheduling pipeline of one MFMA group of `nmfma` MFMAs that also holds `nreads` LDS reads (the next group's operands): the reads
-// issue one per MFMA shadow behind the FIRST MFMAs of the group (a full group of latency before their consumer), the rest of the
-// MFMAs follow; everything else in the region floats.  The whole group is described (the solver assigns bottom-up: a partial
-// pipeline would bind the LAST MFMAs and leave the reads at the end of the group, ~3 MFMAs in front of their first use).
-// MARL_READS_MODE: 0 = no pipeline (reads where the compiler puts them: a clump in front of the group), 1 = this pipeline.
-#ifndef MARL_READS_MODE
-#define MARL_READS_MODE 1
-#endif
-#if MARL_READS_MODE == 1
-#define MARL_SPREAD_READS(nreads, nmfma)                        \
-    _Pragma("unroll") for (int i_ = 0; i_ < (nreads); ++i_) {   \
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      \
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      \
-    }                                                           \
-    _Pragma("unroll") for (int i_ = (nreads); i_ < (nmfma); ++i_) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-#else
-#define MARL_SPREAD_READS(nreads, nmfma)
-#endif
-
 // relu for the learner kernels: ONE VALU instruction per element (equal to fmaxf(v, 0) for every non-NaN input)
 // one v_max_f32 per element, spelled in asm (every VALU instruction next to f32 MFMAs costs matrix time - see MARL_BURST below).
 // ONLY for accumulators already waited for by mfma_settle(): the compiler inserts no MFMA -> VALU wait states in front of inline asm.

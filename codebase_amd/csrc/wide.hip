@@ -43,8 +43,9 @@ extern "C" int marlhip_wide_forward(const marlhip_net_shape* s, int32_t n_out, c
 
 namespace {
 struct WideDqnWs {
-    int64_t q, tq, dq, lrow, bwd, total;
+    int64_t q, tq, dq, lrow, std, bwd, total;
 };
+int64_t wide_std_floats(int P, int64_t R) { return (3 * P + 4) * R + 2 * P * ((R + 255) / 256); }
 WideDqnWs wide_dqn_ws(const WideNet& net, int P, int T, int B) {
     WideDqnWs w;
     int64_t o = 0;
@@ -54,6 +55,7 @@ WideDqnWs wide_dqn_ws(const WideNet& net, int P, int T, int B) {
     w.tq = take(P * rows_all * net.A * 4);
     w.dq = take(P * rows_all * net.A * 4);
     w.lrow = take((int64_t)T * B * 4);
+    w.std = take(wide_std_floats(P, (int64_t)T * B) * 4);  // chosen / bootstrap values, dL/dchosen, r, (1 - done), filled, partial sums, returns
     w.bwd = o;  // the forward passes' activation buffers share the backward workspace (sized for all T + 1 steps)
     w.total = o + wide_ws(net, P, (int)rows_all, true).total;
     return w;
@@ -66,12 +68,9 @@ extern "C" int64_t marlhip_wide_dqn_workspace_bytes(const marlhip_net_shape* s, 
     return wide_dqn_ws(wide_net(s, s->n_actions), s->n_agents, max_len, batch).total;
 }
 
-extern "C" int marlhip_wide_dqn_loss_grad(const marlhip_net_shape* s, const float* params, const float* target_params, const marlhip_batch* bt,
-                                          float gamma, int32_t double_q, int32_t mode, void* workspace, int64_t workspace_bytes, float* grad,
-                                          float* loss, void* stream) {
-    MARL_REQUIRE(s && params && target_params && bt && workspace && grad && loss, "wide_dqn_loss_grad: NULL pointer");
+static int wide_dqn_body(const marlhip_net_shape* s, const float* params, const float* target_params, const marlhip_batch* bt, float gamma,
+                         int double_q, int mode, const RetStats* rst, void* workspace, int64_t workspace_bytes, float* grad, float* loss, void* stream) {
     if (wide_check(s, s->n_actions) != 0) return -1;
-    MARL_REQUIRE(mode == 0 || mode == 1, "wide_dqn_loss_grad: mode %d (0 = IDQN, 1 = VDN; the mixer of QMIX goes with the fused agent kernels)", mode);
     MARL_REQUIRE(bt->obss && bt->actions && bt->rewards && bt->dones && bt->filled && bt->max_len > 0 && bt->batch > 0, "wide_dqn_loss_grad: bad batch");
     MARL_REQUIRE(bt->obs_agent_stride == 0 && bt->obs_row_stride == 0 && bt->act_agent_stride == 0 && bt->act_row_stride == 0,
                  "wide_dqn_loss_grad: the dqn/train.py Batch layout only");
@@ -91,13 +90,67 @@ extern "C" int marlhip_wide_dqn_loss_grad(const marlhip_net_shape* s, const floa
     rc = wide_forward_rows(net, P, am, target_params, bt->obss, as, D, rows_all, f(wl.tq), base + wl.bwd, st);
     if (rc != 0) return rc;
     (void)hipMemsetAsync(f(wl.dq), 0, (size_t)P * rows_all * A * sizeof(float), st);
-    hipLaunchKernelGGL(gru_td_kernel, dim3((T * B + 255) / 256), dim3(256), 0, st, P, T, B, A, (const float*)f(wl.q), (const float*)f(wl.tq), *bt, gamma,
-                       double_q, mode == 1 ? 1 : 0, f(wl.dq), f(wl.lrow));
-    MARL_CHECK_LAUNCH("gru_td_kernel (wide)");
+    if (rst != nullptr) {
+        // standardise_returns (dqn/model.py:146-158, 256-264): the stage the recurrent learner runs between its sequence passes (gru.hip) -
+        // chosen / bootstrap values -> returns from the de-standardised bootstrap, statistics update, dL/dchosen -> dense rows
+        const int64_t R = (int64_t)T * B;
+        float* chosen = f(wl.std);
+        float* tqsel = chosen + P * R;
+        float* dqm = tqsel + P * R;
+        float* r0 = dqm + P * R;
+        float* dn = r0 + R;
+        float* fl = dn + R;
+        float* rbuf = fl + R;  // VDN: the standardised returns [R]
+        float* partial = rbuf + R;
+        const dim3 gridR((unsigned)((R + 255) / 256));
+        hipLaunchKernelGGL(gru_qsel_kernel, gridR, dim3(256), 0, st, P, T, B, A, (const float*)f(wl.q), (const float*)f(wl.tq), *bt, double_q, chosen, tqsel,
+                           r0, dn, fl);
+        MARL_CHECK_LAUNCH("gru_qsel_kernel (wide)");
+        if (mode == 1) {
+            rc = launch_colstd(T, B, gamma, *rst, tqsel, P, (size_t)R, r0, dn, rbuf, st);
+            if (rc != 0) return rc;
+            MixBufs mix = {};
+            mix.chosen = chosen; mix.tqsel = tqsel; mix.r0 = r0; mix.dn = dn; mix.fl = fl; mix.dq = dqm; mix.lrow = f(wl.lrow);
+            hipLaunchKernelGGL(vdn_mix_kernel, dim3((unsigned)(gridR.x > 1024 ? 1024 : gridR.x)), dim3(256), 0, st, mix, P, T, B, gamma, (const float*)rbuf);
+            for (int p = 1; p < P; ++p)  // one dL/dchosen for every agent
+                (void)hipMemcpyAsync(dqm + (size_t)p * R, dqm, (size_t)R * sizeof(float), hipMemcpyDeviceToDevice, st);
+        } else {
+            rc = launch_std_mixer(P, (int)R, gamma, *rst, chosen, tqsel, bt->rewards, dn, fl, dqm, f(wl.lrow), partial, st);
+            if (rc != 0) return rc;
+        }
+        hipLaunchKernelGGL(gru_expand_dq_kernel, gridR, dim3(256), 0, st, P, T, B, A, (const float*)dqm, *bt, f(wl.dq));
+        MARL_CHECK_LAUNCH("gru_expand_dq_kernel (wide)");
+    } else {
+        hipLaunchKernelGGL(gru_td_kernel, dim3((T * B + 255) / 256), dim3(256), 0, st, P, T, B, A, (const float*)f(wl.q), (const float*)f(wl.tq), *bt, gamma,
+                           double_q, mode == 1 ? 1 : 0, f(wl.dq), f(wl.lrow));
+        MARL_CHECK_LAUNCH("gru_td_kernel (wide)");
+    }
     // rows t < T of every agent's [T + 1][B] block: the first T * B rows
     rc = wide_backward_rows(net, P, am, params, bt->obss, as, D, T * B, bt->filled, f(wl.dq), (int64_t)rows_all * A, f(wl.lrow), base + wl.bwd, grad, loss, st);
     timing_end(TIMER_LOSSGRAD, st);
     return rc;
+}
+
+extern "C" int marlhip_wide_dqn_loss_grad(const marlhip_net_shape* s, const float* params, const float* target_params, const marlhip_batch* bt,
+                                          float gamma, int32_t double_q, int32_t mode, void* workspace, int64_t workspace_bytes, float* grad,
+                                          float* loss, void* stream) {
+    MARL_REQUIRE(s && params && target_params && bt && workspace && grad && loss, "wide_dqn_loss_grad: NULL pointer");
+    MARL_REQUIRE(mode == 0 || mode == 1, "wide_dqn_loss_grad: mode %d (0 = IDQN, 1 = VDN; QMIX: marlhip_wide_qmix_loss_grad)", mode);
+    return wide_dqn_body(s, params, target_params, bt, gamma, double_q, mode, nullptr, workspace, workspace_bytes, grad, loss, stream);
+}
+
+extern "C" int marlhip_wide_dqn_loss_grad_std(const marlhip_net_shape* s, const float* params, const float* target_params, const marlhip_batch* bt,
+                                              float gamma, int32_t double_q, const marlhip_ret_stats* stats, void* workspace,
+                                              int64_t workspace_bytes, float* grad, float* loss, void* stream) {
+    MARL_REQUIRE(s && params && target_params && bt && workspace && grad && loss && stats && stats->mean && stats->var && stats->count,
+                 "wide_dqn_loss_grad_std: NULL pointer");
+    // columns = 0: per-agent statistics, the independent learner; columns = batch: VDNetwork's per-batch-column statistics (marlhip_ret_stats)
+    MARL_REQUIRE(stats->columns == 0 || stats->columns == bt->batch, "wide_dqn_loss_grad_std: statistics with %d columns for a batch of %d",
+                 stats->columns, bt->batch);
+    RetStats rst;
+    rst.mean = stats->mean; rst.var = stats->var; rst.count = stats->count; rst.columns = stats->columns;
+    return wide_dqn_body(s, params, target_params, bt, gamma, double_q, stats->columns == 0 ? 0 : 1, &rst, workspace, workspace_bytes, grad, loss,
+                         stream);
 }
 
 // ---- QMIX with such agent networks: GEMM forward of the online and target networks -> chosen / bootstrap values -> the mixer stage of
@@ -123,7 +176,6 @@ extern "C" int marlhip_wide_qmix_loss_grad(const marlhip_net_shape* s, const flo
                  "wide_qmix_loss_grad: NULL pointer");
     if (wide_check(s, s->n_actions) != 0) return -1;
     MARL_REQUIRE(mx->embed_dim == 64 && mx->hypernet_layers == 2 && mx->hypernet_embed == 32, "wide_qmix_loss_grad: mixing = {64, 2, 32} only");
-    MARL_REQUIRE(mx->ret_stats == nullptr, "wide_qmix_loss_grad: no return standardisation on this path");
     MARL_REQUIRE(bt->obss && bt->actions && bt->rewards && bt->dones && bt->filled && bt->max_len > 0 && bt->batch > 0, "wide_qmix_loss_grad: bad batch");
     MARL_REQUIRE(bt->obs_agent_stride == 0 && bt->obs_row_stride == 0, "wide_qmix_loss_grad: the dqn/train.py Batch layout only");
     const int P = s->n_agents, T = bt->max_len, B = bt->batch, A = s->n_actions, D = s->obs_dim;
@@ -147,6 +199,14 @@ extern "C" int marlhip_wide_qmix_loss_grad(const marlhip_net_shape* s, const flo
     qx.mixer = mx->mixer; qx.tmixer = mx->target_mixer; qx.mgrad = mx->mixer_grad;
     qx.ws = base + wl.total + extra; qx.ws_bytes = mixws;
     qx.l1_fp16 = mx->l1_fp16 != 0;
+    RetStats rst;
+    if (mx->ret_stats != nullptr) {  // standardise_returns: the mixer stage standardises the target mixer's output per batch column
+        const marlhip_ret_stats* stt = mx->ret_stats;
+        MARL_REQUIRE(stt->mean && stt->var && stt->count && stt->columns == B, "wide_qmix_loss_grad: return statistics need columns = batch (%d), got %d",
+                     B, stt->columns);
+        rst.mean = stt->mean; rst.var = stt->var; rst.count = stt->count; rst.columns = stt->columns;
+        qx.rst = &rst;
+    }
     const AgentMap am = agent_map(s);
     const int rows_all = (T + 1) * B;
     const int64_t as = (int64_t)rows_all * D;

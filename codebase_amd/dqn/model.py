@@ -184,8 +184,6 @@ class QNetwork:
         self.device = torch.device(device)
         self.sharing = sharing_indices(parameter_sharing, self.n_agents)
         self.spec = _hip.NetSpec(self.n_agents, obs_dims[0], hidden_k[0], act_dims[0], self.sharing, wide=is_wide(hidden), n_hidden=len(hidden))
-        if self.spec.wide and self.standardise_returns:
-            raise NotImplementedError(f"layers={hidden}: lists other than two layers of at most 128 units run without return standardisation (the GEMM path)")
         if self.recurrent:  # RNNNetwork (utils/models.py:51-116): Linear -> ReLU -> GRU -> Linear
             self.nparams = _hip.gru_nparams(self.spec)
             critic, target = init_flat_gru_params(obs_dims, hidden[0], act_dims, use_orthogonal_init, self.sharing)

@@ -437,12 +437,7 @@ class DqnUpdater:
 
 class WideDqnUpdater(DqnUpdater):
     """DqnUpdater for networks without a fused kernel (spec.wide): marlhip_wide_dqn_loss_grad (GEMM path + the TD stage of the
-    recurrent learner); sampling materialises the Batch first.  IDQN and VDN, no return standardisation."""
-
-    def __init__(self, spec, params, target, **kw):
-        if kw.get("standardise_returns"):
-            raise NotImplementedError("standardise_returns with layers wider than 128 (the GEMM path)")
-        super().__init__(spec, params, target, **kw)
+    recurrent learner, its standardise_returns stage included); sampling materialises the Batch first.  IDQN and VDN."""
 
     def _workspace(self, T, B):
         key = (T, B)
@@ -460,6 +455,12 @@ class WideDqnUpdater(DqnUpdater):
         bs = BatchStruct(batch.obss.data_ptr(), batch.actions.data_ptr(), batch.rewards.data_ptr(), batch.dones.data_ptr(),
                          batch.filled.data_ptr(), T, B, 0, 0, 0, 0, _mask_ptr(batch.action_mask, (self.spec.n_agents, T + 1, B, self.spec.n_actions)))
         s = self.spec.c()
+        if self.ret_stats is not None:  # standardise_returns: per-agent statistics (IDQN) or VDNetwork's per-batch-column ones
+            st = self._stats_for(mode, B).c()
+            check(lib.marlhip_wide_dqn_loss_grad_std(ctypes.byref(s), _ptr(self.params), _ptr(self.target), ctypes.byref(bs), float(self.gamma),
+                                                     self.double_q, ctypes.byref(st), _ptr(ws), ws.numel(), _ptr(self.grad), _ptr(self.loss),
+                                                     _stream()), "wide_dqn_loss_grad_std")
+            return self.loss, self.grad
         check(lib.marlhip_wide_dqn_loss_grad(ctypes.byref(s), _ptr(self.params), _ptr(self.target), ctypes.byref(bs), float(self.gamma),
                                              self.double_q, int(mode), _ptr(ws), ws.numel(), _ptr(self.grad), _ptr(self.loss), _stream()),
               "wide_dqn_loss_grad")
@@ -855,9 +856,7 @@ class WideQmixUpdater(QmixUpdater):
         ws = self._wide_ws(T, B)
         bs = BatchStruct(batch.obss.data_ptr(), batch.actions.data_ptr(), batch.rewards.data_ptr(), batch.dones.data_ptr(),
                          batch.filled.data_ptr(), T, B, 0, 0, 0, 0, _mask_ptr(batch.action_mask, (self.spec.n_agents, T + 1, B, self.spec.n_actions)))
-        if self.ret_stats is not None:
-            raise NotImplementedError("standardise_returns with QMIX agents on the GEMM path is not built")
-        s, mx = self.spec.c(), self._mx()
+        s, mx = self.spec.c(), self._mx(B)
         check(lib.marlhip_wide_qmix_loss_grad(ctypes.byref(s), _ptr(self.params), _ptr(self.target), ctypes.byref(mx), ctypes.byref(bs),
                                               float(self.gamma), self.double_q, _ptr(ws), ws.numel(), _ptr(self.grad), _ptr(self.loss),
                                               _stream()), "wide_qmix_loss_grad")

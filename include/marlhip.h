@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MARLHIP_VERSION 206
+#define MARLHIP_VERSION 207
 
 int marlhip_version(void);
 const char* marlhip_last_error(void);
@@ -398,7 +398,7 @@ int marlhip_gru_qmix_loss_grad(const marlhip_net_shape* s, const float* params, 
                                const struct marlhip_qmix_mixer* mixer, const marlhip_batch* batch, float gamma, int32_t double_q,
                                void* workspace, int64_t workspace_bytes, float* grad, float* loss /* [2] */, void* stream);
 /* marlhip_qmix_loss_grad with agent networks on the GEMM path (marlhip_wide_*: layers wider than 128 or not two deep); the mixer stage is
- * the same one, no return standardisation */
+ * the same one, mixer->ret_stats (columns = batch) included */
 int64_t marlhip_wide_qmix_workspace_bytes(const marlhip_net_shape* s, int32_t max_len, int32_t batch);
 int marlhip_wide_qmix_loss_grad(const marlhip_net_shape* s, const float* params, const float* target_params, const marlhip_qmix_mixer* mixer,
                                 const marlhip_batch* batch, float gamma, int32_t double_q, void* workspace, int64_t workspace_bytes,
@@ -449,6 +449,11 @@ int64_t marlhip_wide_dqn_workspace_bytes(const marlhip_net_shape* s, int32_t max
 int marlhip_wide_dqn_loss_grad(const marlhip_net_shape* s, const float* params, const float* target_params, const marlhip_batch* batch,
                                float gamma, int32_t double_q, int32_t mode, void* workspace, int64_t workspace_bytes, float* grad,
                                float* loss /* [2]: loss, sum(filled) */, void* stream);
+/* the same with standardise_returns (marlhip_dqn_loss_grad_std's contract: stats->columns = 0 -> per-agent statistics, the independent
+ * learner; columns = batch -> VDNetwork's per-batch-column statistics); the statistics are updated in place */
+int marlhip_wide_dqn_loss_grad_std(const marlhip_net_shape* s, const float* params, const float* target_params, const marlhip_batch* batch,
+                                   float gamma, int32_t double_q, const struct marlhip_ret_stats* stats, void* workspace,
+                                   int64_t workspace_bytes, float* grad, float* loss /* [2] */, void* stream);
 
 /* the action choice of QNetwork.act (dqn/model.py:105-115) from given values q [P][N][A] (the recurrent path computes them with
  * marlhip_gru_forward): explore iff epsilon > u with ONE Philox uniform per env (env n, episode[n], t = ep_length[n], word 0),

@@ -3,7 +3,7 @@
 with extra -D flags, linked with the product objects.  Variants land in codebase_amd/csrc/variants/libmarlhip_<name>.so
 (git-ignored; they travel to the GPU box) and are selected with MARLHIP_LIB=<path> (codebase_amd/_lib.py).
 
-    python scripts/build_variants.py name1:-DMARL_READS_MODE=0 name2:-DMARL_STEP_PROF=1,-DFOO=2
+    python scripts/build_variants.py name1:-DMARL_BURST=0 name2:-DMARL_STEP_PROF=1,-DFOO=2
 """
 import os
 import subprocess
