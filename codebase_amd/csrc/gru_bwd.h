@@ -164,13 +164,15 @@ __global__ __launch_bounds__(256) void gru_seq_bwd_kernel(const float* __restric
     }
 }
 
-// The same walk with TWO waves per block of 16 sequences (hidden 64): B / 16 blocks of a bench batch are 512 waves for 1024 SIMDs, and the
+// The same walk with TWO waves per block of 16 sequences: B / 16 blocks of a bench batch are 512 waves for 1024 SIMDs, and the
 // walk is a chain of dependent steps, so the one-wave form leaves half of the chip idle.  Here each wave of a pair owns half of the hidden
 // tiles: it loads the record, forms dh and the gate derivatives and keeps the carried dh for ITS tiles only, the pair swaps the four
 // gate-gradient arrays through LDS (the transposed products need every gate unit as input), and each wave multiplies out only its own
 // output tiles - half of the MFMAs, of the record traffic and of the gate arithmetic per wave and step, for two barriers.
+// Hidden 128 streams the six transposed gate matrices through the chunk buffer exactly as the one-wave form does (the workgroup's two
+// pairs share each staged matrix); the staging per workgroup and step is unchanged, the ~49 k cycles of MFMAs per wave and step halve.
 template <class S>
-struct GruBwdSplit : std::integral_constant<bool, S::MT == 4 && !GruBwd<S>::STREAM> {};
+struct GruBwdSplit : std::integral_constant<bool, S::MT == 4 || S::MT == 8> {};
 template <class S>
 constexpr size_t gru_bwd_lds_bytes() {
     return (size_t)(GruBwd<S>::LDS_FLOATS + (GruBwdSplit<S>::value ? 2 * 4 * S::MT * 256 : 0)) * sizeof(float);
@@ -181,14 +183,15 @@ __global__ __launch_bounds__(256) void gru_seq_bwd2_kernel(const float* __restri
                                                            const float* __restrict__ dq, float* __restrict__ rec2) {
     using Bk = GruBwd<S>;
     constexpr int MT = S::MT, MH = MT / 2, A = S::A;
+    constexpr bool STREAM = Bk::STREAM;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, j = lane & 15;
     const int pairw = wave >> 1, half = wave & 1, m0 = half * MH;  // the pair's block inside the workgroup, this wave's tiles m0 .. m0 + MH - 1
     const int p = blockIdx.y;
     const float* pack = packs + (size_t)p * Bk::NBWD;
-    copy_f4_to_lds(reinterpret_cast<const f4*>(pack), reinterpret_cast<f4*>(lds), Bk::NBWD / 4, tid, 256);
+    copy_f4_to_lds(reinterpret_cast<const f4*>(pack), reinterpret_cast<f4*>(lds), (STREAM ? Bk::pThh : Bk::NBWD) / 4, tid, 256);
     __syncthreads();
-    f4* X = reinterpret_cast<f4*>(lds + Bk::NBWD) + (size_t)pairw * 4 * MT * 64;  // the pair's exchange: [dr, dz, dn, r * dn][unit tile][lane]
+    f4* X = reinterpret_cast<f4*>(lds + Bk::LDS_FLOATS) + (size_t)pairw * 4 * MT * 64;  // the pair's exchange: [dr, dz, dn, r * dn][unit tile][lane]
     const int nblk = (B + 15) >> 4;
     const int blk0 = blockIdx.x * 2 + pairw;
     const bool active = blk0 < nblk;  // (an idle pair keeps walking: the barriers are workgroup-wide)
@@ -198,7 +201,14 @@ __global__ __launch_bounds__(256) void gru_seq_bwd2_kernel(const float* __restri
     const int bj = b0 + j < B ? b0 + j : B - 1;
     const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
     const f4* T3 = reinterpret_cast<const f4*>(lds + Bk::pT3);
-    auto tmat = [&](int c) { return reinterpret_cast<const f4*>(lds + Bk::pThh) + (size_t)c * MT * MT * 64; };
+    auto tmat = [&](int c) -> const f4* {
+        if (!STREAM) return reinterpret_cast<const f4*>(lds + Bk::pThh) + (size_t)c * MT * MT * 64;
+        __syncthreads();  // (every wave of the workgroup walks every step: see `active`)
+        copy_f4_to_lds(reinterpret_cast<const f4*>(pack + Bk::pThh) + (size_t)c * MT * MT * 64, reinterpret_cast<f4*>(lds + Bk::pThh), Bk::CHUNK / 4,
+                       tid, 256);
+        __syncthreads();
+        return reinterpret_cast<const f4*>(lds + Bk::pThh);
+    };
     // out[own tile] += (transposed gate matrix c) x dg, every gate-unit tile of dg as input
     auto tgate = [&](int c, const f4 (&dgx)[MT], f4 (&out)[MH]) {
         const f4* Tm = tmat(c);
@@ -289,12 +299,15 @@ __global__ __launch_bounds__(256) void gru_seq_bwd2_kernel(const float* __restri
     }
 }
 
-// the backward walk of P agents over B sequences: the two-wave form where it exists (MARLHIP_GRU_BWD_ONE_WAVE=1 keeps the one-wave form)
+// the backward walk of P agents over B sequences: the two-wave form where it exists (MARLHIP_GRU_BWD_ONE_WAVE=1 keeps the one-wave form).
+// `alone` = no sibling launch shares the chip (the actor-critic learner walks actors and critics on two streams: with streamed
+// matrices the pair of one-wave launches already fills the CUs and the two-wave form only adds staging - measured 7.54 vs 7.69 ms
+// per recurrent IA2C GRU-128 round; alone, the hidden-128 walk goes 1045 -> 650 us).
 template <class S>
-void gru_launch_seq_bwd(int P, int B, const float* packB, int steps, const float* rec, const float* dq, float* rec2, hipStream_t st) {
+void gru_launch_seq_bwd(int P, int B, const float* packB, int steps, const float* rec, const float* dq, float* rec2, hipStream_t st, bool alone = true) {
     static const bool one_wave = getenv("MARLHIP_GRU_BWD_ONE_WAVE") != nullptr;
     if constexpr (GruBwdSplit<S>::value) {
-        if (!one_wave) {
+        if (!one_wave && (alone || !GruBwd<S>::STREAM)) {
             static LdsAttr attr;
             if (attr.need()) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_seq_bwd2_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -427,6 +440,9 @@ __global__ __launch_bounds__(256) void gru_wgrad_kernel(int steps, int B, const 
     }
     if (role < 3) {
         // ---- gate `role`: dW_ih[gate rows][my columns] += dgi^T x1, dW_hh[...] += dgh^T h_prev
+        // (hidden 128: 1054 us for 267 us of MFMAs.  Requesting the next item's record arrays behind the first barrier - the hidden-64
+        // form's recipe - made it 1133 us: the item loop is not waiting on load latency; the transposes through LDS and the three-fold
+        // re-read of x1 / h_{t-1} across the gate roles are what is left to look at.)
         const int nt0 = wave * MTN;
         f4 dWa[MT][MTN], dWb[MT][MTN];
 #pragma unroll

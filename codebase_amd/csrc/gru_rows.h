@@ -123,7 +123,7 @@ int gru_backward_rows(int P, const AgentMap& am, const float* params, const marl
                            B, (const float*)nullptr, (float*)nullptr, f(wl.q), f(wl.rec));
         rec = f(wl.rec);
     }
-    gru_launch_seq_bwd<S>(P, B, (const float*)f(wl.packB), steps, rec, dout, f(wl.rec2), st);
+    gru_launch_seq_bwd<S>(P, B, (const float*)f(wl.packB), steps, rec, dout, f(wl.rec2), st, /*alone=*/false);
     hipLaunchKernelGGL((gru_wgrad_kernel<S>), dim3(wl.nwg, P, gru_wgrad_roles<S>()), dim3(256), gru_wgrad_lds_bytes<S>(), st, steps, B, bt->obss, as, rs, rec,
                        (const float*)f(wl.rec2), dout, lrow, bt->filled, steps, f(wl.partials));
     MARL_CHECK_LAUNCH("gru backward rows");
