@@ -11,6 +11,9 @@
 //   gru_seq_fwd_kernel : q[t] for t = 0..S-1 from h_in (zeros when NULL), optional h_out, optional per-step activation
 //                        record (x1, r, z, n, h, W_hn h + b_hn) for the backward pass
 #pragma once
+#ifndef MARLHIP_GRU_FWD_DBUF
+#define MARLHIP_GRU_FWD_DBUF 1
+#endif
 #include "common.h"
 #include "mlp.h"
 
@@ -36,7 +39,11 @@ struct GruShape {
     static constexpr bool STREAM = NFWD * 4 > 156 * 1024;
     static constexpr int TAIL = NFWD - pA3;                      // A3 + biases
     // streamed LDS layout: A1 | A3 + biases | chunk buffer
-    static constexpr int sA1 = 0, sTail = pGi, sChunk = sTail + TAIL, LDS_STREAM = sChunk + CHUNK;
+    // DBUF: a second chunk buffer where it fits (observation widths up to 32) - the next gate matrix lands in it by LDS-DMA while the
+    // MFMAs of the current one run (gru_seq_fwd_body); MARLHIP_GRU_FWD_DBUF=0 at build time keeps the single buffer everywhere
+    static constexpr int sA1 = 0, sTail = pGi, sChunk = sTail + TAIL;
+    static constexpr bool DBUF = STREAM && MARLHIP_GRU_FWD_DBUF && (sChunk + 2 * CHUNK) * 4 <= 158 * 1024;
+    static constexpr int LDS_STREAM = sChunk + (DBUF ? 2 : 1) * CHUNK;
     static constexpr int LDS_FLOATS = STREAM ? LDS_STREAM : NFWD;
     static_assert(LDS_FLOATS * 4 <= 158 * 1024, "recurrent network: LDS budget");
     // per (step, 16-row block) activation record for the backward pass: 6 arrays x MT tiles x 64 lanes x f4
@@ -154,9 +161,33 @@ __device__ __forceinline__ void gru_seq_fwd_body(const float* __restrict__ packs
     }
     const f4* A1 = reinterpret_cast<const f4*>(lA1);
     const f4* A3 = reinterpret_cast<const f4*>(lA3);
-    // gate matrix `c` (0..2: W_ih r, z, n; 3..5: W_hh r, z, n) as an A-operand chunk in LDS
-    auto gate_chunk = [&](int c) -> const f4* {
+    // DBUF: the i-th gate product of a step (matrices in the order 0, 3, 1, 4, 2, 5) reads chunk buffer i & 1.  A wave requests its 16
+    // one-KB pieces of a matrix with global_load_lds (LDS address = wave-uniform base + 16 * lane); they are ordered for the readers
+    // by the issuing wave's vmcnt(0) followed by the workgroup barrier in front of the product that uses them, and a buffer is
+    // requested again only behind the barrier that follows its last reader.
+    constexpr bool DBUF = S::DBUF;
+    int t_now = 0;
+    auto request = [&](int c, int buf) {
+        const char* src = reinterpret_cast<const char*>(pack + S::pGi + (size_t)c * S::CHUNK) + 16 * lane;
+        char* dst = reinterpret_cast<char*>(lds + S::sChunk + (size_t)buf * S::CHUNK);
+#pragma unroll 1
+        for (int k = 0; k < S::CHUNK * 4 / 1024 / 4; ++k) {
+            const int piece = 4 * k + wave;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 1024 * piece),
+                                             (__attribute__((address_space(3))) void*)(dst + 1024 * piece), 16, 0, 0);
+        }
+    };
+    if (DBUF && steps > 0) request(0, 0);
+    // gate matrix `c` (0..2: W_ih r, z, n; 3..5: W_hh r, z, n) as an A-operand chunk in LDS; `i` = its position in the step
+    auto gate_chunk = [&](int c, int i) -> const f4* {
         if (!STREAM) return reinterpret_cast<const f4*>(lds + S::pGi) + (size_t)c * MT * MT * 64;
+        if (DBUF) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my pieces of matrix c have landed
+            __syncthreads();                                     // everybody's have; everybody is done with the other buffer
+            const int nxt = i == 0 ? 3 : (i == 1 ? 1 : (i == 2 ? 4 : (i == 3 ? 2 : (i == 4 ? 5 : 0))));
+            if (i < 5 || t_now + 1 < steps) request(nxt, (i + 1) & 1);  // (nothing may be in flight when the workgroup ends)
+            return reinterpret_cast<const f4*>(lds + S::sChunk + (size_t)(i & 1) * S::CHUNK);
+        }
         __syncthreads();  // everybody is done with the previous chunk
         copy_f4_to_lds(reinterpret_cast<const f4*>(pack + S::pGi) + (size_t)c * MT * MT * 64, reinterpret_cast<f4*>(lds + S::sChunk), S::CHUNK / 4,
                        tid, 256);
@@ -164,6 +195,7 @@ __device__ __forceinline__ void gru_seq_fwd_body(const float* __restrict__ packs
         return reinterpret_cast<const f4*>(lds + S::sChunk);
     };
     for (int t = 0; t < steps; ++t) {
+        t_now = t;
         asm volatile("" ::: "memory");  // the packs never change, so the compiler would hoist every weight read out of the time
                                         // loop (and spill ~1 KB per lane): re-read them from LDS each step
         const float* xrow = obs + (size_t)p * obs_as + ((size_t)t * B + bj) * obs_rs;  // row (t, b) of agent p
@@ -191,16 +223,16 @@ __device__ __forceinline__ void gru_seq_fwd_body(const float* __restrict__ packs
         for (int mt = 0; mt < MT; ++mt) x1[mt] = relu4(x1[mt]);
         // gates (torch.nn.GRU): r, z, n
         f4 gi[MT], gh[MT], rg[MT], zg[MT], ng[MT], ghn[MT];
-        gru_gate<S>(gate_chunk(0), lbih + 0 * H, lane, x1, gi);
-        gru_gate<S>(gate_chunk(3), lbhh + 0 * H, lane, h, gh);
+        gru_gate<S>(gate_chunk(0, 0), lbih + 0 * H, lane, x1, gi);
+        gru_gate<S>(gate_chunk(3, 1), lbhh + 0 * H, lane, h, gh);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) rg[mt] = sigmoid4(gi[mt] + gh[mt]);
-        gru_gate<S>(gate_chunk(1), lbih + 1 * H, lane, x1, gi);
-        gru_gate<S>(gate_chunk(4), lbhh + 1 * H, lane, h, gh);
+        gru_gate<S>(gate_chunk(1, 2), lbih + 1 * H, lane, x1, gi);
+        gru_gate<S>(gate_chunk(4, 3), lbhh + 1 * H, lane, h, gh);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) zg[mt] = sigmoid4(gi[mt] + gh[mt]);
-        gru_gate<S>(gate_chunk(2), lbih + 2 * H, lane, x1, gi);
-        gru_gate<S>(gate_chunk(5), lbhh + 2 * H, lane, h, ghn);
+        gru_gate<S>(gate_chunk(2, 4), lbih + 2 * H, lane, x1, gi);
+        gru_gate<S>(gate_chunk(5, 5), lbhh + 2 * H, lane, h, ghn);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             ng[mt] = tanh4(gi[mt] + rg[mt] * ghn[mt]);
