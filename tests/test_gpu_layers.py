@@ -72,6 +72,38 @@ def test_dqn_family_with_other_widths_matches_the_port_at_the_true_widths(cls_na
             assert acts[p] == int(q[p].argmax())
 
 
+@pytest.mark.parametrize("layers", [[200, 96], [256, 256], [64, 64, 64]])
+def test_idqn_standardise_returns_on_the_gemm_path_matches_the_port(layers):
+    """standardise_returns with a layer list that has no fused kernel (csrc/wide.hip: marlhip_wide_dqn_loss_grad_std) against the port at
+    the true widths: losses, parameters and the per-agent running (mean, var, count) of three updates"""
+    from codebase_amd import hip as h
+    from codebase_amd.dqn import model as M
+
+    P, D, A, T, B = 2, 15, 6, 25, 37
+    obs_space, act_space = spaces(P, D, A)
+    hyper = dict(optimizer="Adam", lr=1e-3, gamma=0.99, grad_clip=1.0, double_q=True, standardise_returns=True,
+                 target_update_interval_or_tau=2)
+    torch.manual_seed(6)
+    net = M.QNetwork(obs_space, act_space, hyper, layers, False, False, True, DEV)
+    assert net.spec.wide
+    sd = net.state_dict()
+    net.load_state_dict({k: v + 0.01 for k, v in sd.items()})
+    start = live_blocks(net.state_dict(), "critic", P)
+    ref = dp.Learner(start, D, tuple(layers), A, lr=1e-3, gamma=0.99, grad_clip=1.0, double_q=True, target_update_interval_or_tau=2,
+                     standardise_returns=True)
+    ref.target = live_blocks(net.state_dict(), "target", P).clone()
+    for i in range(3):
+        b = dp.synthetic_batch(P, T, B, D, A, seed=40 + i)
+        got = net.update(h.Batch(b["obss"], b["actions"], b["rewards"], b["dones"], b["filled"], None))
+        exp = ref.update(b)
+        assert abs(got["loss"] - exp["loss"]) <= 5e-5 * abs(exp["loss"]), (i, got["loss"], exp["loss"])
+        st = net.ret_ms
+        np.testing.assert_allclose(st.mean.cpu().numpy(), ref.ret_ms.mean.numpy(), rtol=2e-5, atol=1e-6)
+        np.testing.assert_allclose(st.var.cpu().numpy(), ref.ret_ms.var.numpy(), rtol=5e-5)
+        assert abs(st.count - ref.ret_ms.count) < 1e-6
+    np.testing.assert_allclose(live_blocks(net.state_dict(), "critic", P).numpy(), ref.flat().detach().numpy(), rtol=0, atol=1e-5)
+
+
 def test_layer_lists_the_kernels_do_not_cover_raise():
     from codebase_amd.dqn.model import QNetwork
     obs_space, act_space = spaces(2, 15, 6)
