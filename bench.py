@@ -53,6 +53,14 @@ def parse():
     ap.add_argument("--algo", default="idqn", choices=["idqn", "vdn", "qmix", "ia2c", "ippo", "maa2c", "mappo"])
     ap.add_argument("--rnn", action="store_true", help="recurrent Q-networks (algorithm.model.use_rnn=True; idqn / vdn, hidden 64)")
     ap.add_argument("--mixer-fp16", action="store_true", help="qmix: the opt-in fp16 first mixer layers (BASELINE config 5; a deviation from the fp32 reference)")
+    ap.add_argument("--hparams", default="tuned", choices=["tuned", "reference"],
+                    help="idqn at --cadence ratio: `tuned` = the optimiser settings under which the batched cadence learns (lr 3e-3 + Polyak 0.1; "
+                         "U >= 128: lr 1e-3 + hard copy every 50; profiles/r02_learning_parity.md), `reference` = idqn.yaml's lr 3e-4 + hard copy "
+                         "every 200 updates.  Same kernels and launch counts either way; named in config.lr / target_update_interval_or_tau")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N > 1: weak = --envs envs and an update batch of B episodes PER GPU (effective batch G*B); strong = --envs envs and B "
+                         "episodes in TOTAL, split evenly over the GPUs (the 1-GPU job's global batch and env count)")
+    ap.add_argument("--no-modes", action="store_true", help="skip the secondary rows (`modes`: env-only, reference cadence, hidden 128) the default line carries")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -60,14 +68,27 @@ def parse():
 
 
 def cpu_baseline(seconds, hidden):
-    """Reference CPU path restated (oracle): python LBF env under the reference wrapper stack +
-    torch-CPU QNetwork/ReplayBuffer port, reference cadence (1 update of 32 episodes per episode once
-    32 episodes are stored), 1 thread as marlbase/run.py:29.  Bounded sample, FPS as loggers.py:70."""
+    """The reference's CPU path on the host cores, reference cadence (1 update of 32 episodes per episode once 32 episodes are
+    stored), 1 thread as marlbase/run.py:29, bounded sample, FPS as loggers.py:70.  `kind: "reference"`: the reference's OWN
+    QNetwork / ReplayBuffer / _epsilon_schedule / _collect_trajectory, unmodified, from oracle/_ref (oracle/make_ref.py copies them
+    there in the build container; git-ignored, it travels to the GPU box like a built .so) around oracle/lbf.py (lbforaging itself is
+    not installable).  Without oracle/_ref: `kind: "port"`, the torch-CPU restatement oracle/dqn_port.py."""
     import numpy as np
     import torch
 
     from oracle import dqn_port as dp
+    from oracle import ref_learner
     from oracle.lbf import MarlbaseEnv
+
+    if ref_learner.available():
+        v, n_steps, n_upd, dt, root = ref_learner.reference_idqn_loop(seconds, hidden, ENV_NAME, 25,
+                                                                       lambda: MarlbaseEnv(ENV_NAME, 25, rng=np.random.default_rng(0)))
+        return {"value": v, "unit": "env-steps/s", "cores": 1, "kind": "reference", "host_cores": os.cpu_count(),
+                "whole_node_estimate": v * (os.cpu_count() or 1),
+                "whole_node_estimate_note": "NOT measured: the 1-thread figure times the host's core count (independent runs, marlbase/run.py:29)",
+                "sample": f"{n_steps} env-steps / {n_upd} updates of the reference's own marlbase.dqn QNetwork + ReplayBuffer + _collect_trajectory "
+                          f"({os.path.relpath(root, ROOT) if root.startswith(ROOT) else root}) on oracle/lbf.py (python LBF env), IDQN {hidden}-{hidden}, "
+                          f"reference cadence, 1 thread, in {dt:.1f} s; host has {os.cpu_count()} cores"}
 
     torch.set_num_threads(1)
     P, D, A, T = 2, 15, 6, 25
@@ -104,6 +125,7 @@ def cpu_baseline(seconds, hidden):
     v = (steps - s0) / dt
     return {"value": v, "unit": "env-steps/s", "cores": 1, "kind": "port", "host_cores": os.cpu_count(),
             "whole_node_estimate": v * (os.cpu_count() or 1),  # independent 1-thread runs on every host core (marlbase/run.py:29)
+            "whole_node_estimate_note": "NOT measured: the 1-thread figure times the host's core count",
             "sample": f"{steps - s0} env-steps / {updates} updates of oracle/lbf.py + oracle/dqn_port.py "
                       f"(python LBF env + torch-CPU IDQN {hidden}-{hidden}, reference cadence: 1 update of 32 episodes "
                       f"per episode, 1 thread) in {dt:.1f} s; host has {os.cpu_count()} cores"}
@@ -372,6 +394,48 @@ def main():
     if args.algo in ("ia2c", "ippo", "maa2c", "mappo"):
         return bench_ac(args, rank, world, dist)
 
+    out = bench_dqn(args, rank, world, dist, args.steps, args.warmup)
+    if rank == 0:
+        default_line = (args.algo == "idqn" and args.cadence == "ratio" and args.hidden == 64 and not args.rnn and args.env_name == ENV_NAME
+                        and not args.update_batch and not args.updates_per_round)
+        if world == 1 and default_line and not args.no_modes:
+            out["modes"] = secondary_modes(args)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, args.hidden)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def secondary_modes(args):
+    """BASELINE.md 3.5's other modes and the reference-default network, timed by the same process right after the headline region so
+    that the driver's bench line witnesses them too: env-only (collector alone), cadence=reference (the reference's one update of 32
+    episodes per collected episode, sequentially) and the headline cadence with the reference's default 128-128 networks
+    (configs/algorithm/idqn.yaml:8-10).  Short regions (tens to hundreds of ms); `value`, `config` and `roofline` of the line are
+    untouched."""
+    import copy
+
+    rows = {}
+    for name, over, steps, warmup in (("env-only", dict(cadence="env-only"), 20, 3),
+                                      ("cadence=reference", dict(cadence="reference"), 3, 1),
+                                      ("hidden=128 (reference default net), cadence=ratio", dict(hidden=128), 5, 2)):
+        a = copy.copy(args)
+        for k, v in over.items():
+            setattr(a, k, v)
+        r = bench_dqn(a, 0, 1, None, steps, warmup)
+        rf = r.get("roofline") or {}
+        rows[name] = {"value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"], "steps": steps, "warmup": warmup,
+                      "updates_per_round": r["config"]["updates_per_round"], "update_batch_episodes": r["config"]["update_batch_episodes"],
+                      "lr": r["config"]["lr"], "target_update_interval_or_tau": r["config"]["target_update_interval_or_tau"],
+                      "roofline": {k: rf.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_us")}}
+    return rows
+
+
+def bench_dqn(args, rank, world, dist, steps, warmup):
+    """IDQN / VDN / QMIX: `warmup` untimed rounds, then `steps` timed rounds bracketed by barrier + synchronize, max over ranks;
+    returns the JSON object of the line on rank 0 (None elsewhere)"""
+    import torch
+
     from codebase_amd import hip as h
     from codebase_amd._lib import lib
     from codebase_amd.dqn.model import QNetwork
@@ -379,23 +443,28 @@ def main():
     from codebase_amd.utils.envs import _space_pair
 
     N, T, H = args.envs, args.time_limit, args.hidden
+    if args.scaling == "strong" and world > 1:  # the 1-GPU job's env count and global batch, split evenly over the ranks
+        if N % world:
+            raise SystemExit(f"bench.py --scaling strong: --envs {N} is not a multiple of --gpus {world}")
+        N //= world
     from codebase_amd.parallel import rank_env_seed
 
     cfg = h.env_config(args.env_name, N, T, seed=rank_env_seed(args.seed, rank), cooperative=args.algo != "idqn")
     P, (D, A) = cfg.n_agents, h.env_dims(cfg)
+    strong = args.scaling == "strong" and world > 1
     if args.cadence == "ratio":
-        B = args.update_batch or N
+        B = (args.update_batch // world if strong else args.update_batch) or N
         U = args.updates_per_round or max(1, (32 * N) // B)
     elif args.cadence == "reference":
-        B = args.update_batch or 32
-        U = args.updates_per_round or N
+        B = max((args.update_batch or 32) // (world if strong else 1), 1)
+        U = args.updates_per_round or N * (world if strong else 1)  # one update per collected episode of the whole job
     else:
         B, U = 1, 0
     torch.manual_seed(args.seed)  # identical initial weights on every rank (orthogonal init, utils/models.py:8-11)
     obs_space, act_space = _space_pair(cfg)
     hyper = dict(optimizer="Adam", lr=3e-4, gamma=0.99, grad_clip=1.0, double_q=True, standardise_returns=False,
                  target_update_interval_or_tau=200)  # marlbase/configs/algorithm/idqn.yaml:16-37
-    if args.cadence == "ratio" and args.algo == "idqn":
+    if args.cadence == "ratio" and args.algo == "idqn" and args.hparams == "tuned":
         # batched gradient steps want a larger step and a faster target (profiles/r02_learning_parity.md: with the reference's lr /
         # target interval the batched cadence barely learns); U = 32: lr 3e-3 + Polyak 0.1; U >= 128: lr 1e-3 + hard copy every 50 updates
         hyper.update(dict(lr=3e-3, target_update_interval_or_tau=0.1) if U < 128 else dict(lr=1e-3, target_update_interval_or_tau=50))
@@ -419,14 +488,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         one_round()
     sync()
     steps_dev.zero_()
     if not args.no_kernel_timing:
         lib.marlhip_timing_enable(1)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         one_round()
     sync()
     dt = time.perf_counter() - t0
@@ -447,10 +516,9 @@ def main():
                 timing[kname] = {"launches": n.value, "avg_us": 1e3 * ms.value / n.value, "total_ms": ms.value}
         lib.marlhip_timing_enable(0)
 
+    del trainer, model
     if rank != 0:
-        if dist is not None:
-            dist.destroy_process_group()
-        return
+        return None
 
     roofline = None
     lg, col = timing.get("dqn_lossgrad_kernel"), timing.get("idqn_collect_kernel")
@@ -468,13 +536,13 @@ def main():
                     "flops_parts": parts, "avg_launch_us": lg["avg_us"],
                     "dominant_stage_by_time": "loss/grad" if not col or lg["total_ms"] >= col["total_ms"] else "idqn_collect_kernel"}
         if col and col["total_ms"] > lg["total_ms"]:
-            cf = (gru_fwd_flops if args.rnn else mlp_fwd_flops)(D, H, A) * P * (env_steps / args.steps)
+            cf = (gru_fwd_flops if args.rnn else mlp_fwd_flops)(D, H, A) * P * (env_steps / steps)
             roofline["collector"] = {"kernel": "idqn_collect_kernel", "bound": "mfma (latency-bound in practice)", "flops_per_launch": cf,
                                      "avg_launch_us": col["avg_us"], "frac": cf / (col["avg_us"] * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS}
     elif col:
         # env-only: the collector's HBM traffic is the replay write, 4*P*D + P + 4*P + 2 bytes per env-step (+ row 0)
         per_step = 4 * P * D + P + 4 * P + 2
-        byts = per_step * env_steps / args.steps + 4 * P * D * N
+        byts = per_step * env_steps / steps + 4 * P * D * N
         avg_s = col["avg_us"] * 1e-6
         ach = byts / avg_s / 1e9
         roofline = {"kernel": "idqn_collect_kernel", "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
@@ -486,11 +554,11 @@ def main():
         "unit": "env-steps/s",
         "n_gpus": world,
         "rccl_ranks": _ranks_field(world, dist, args),
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": 1e3 * dt / args.steps,
+        "steps": steps,
+        "warmup": warmup,
+        "ms_per_step": 1e3 * dt / steps,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": args.scaling,
         "vs_baseline": None,
         "dtype": "f32" if not (args.algo == "qmix" and args.mixer_fp16) else "f32 (mixer first layers: fp16 inputs on MFMA, fp32 accumulate - opt-in)",
         "data": "synthetic (Philox-seeded env layouts, orthogonal-init weights)",
@@ -508,17 +576,16 @@ def main():
             "sampled_episodes_per_collected_episode": (U * B) / N if N else 0,
             "replay_capacity_episodes": cap,
             "lr": hyper["lr"], "target_update_interval_or_tau": hyper["target_update_interval_or_tau"],
-            "parallelism": f"dp{world} (envs + replay sharded per GPU, RCCL grad all-reduce per update)" if world > 1 else "1 GPU",
+            "parallelism": (f"dp{world} (envs + replay sharded per GPU, RCCL grad all-reduce per update; "
+                            + (f"strong scaling: {N * world} envs and a global update batch of {B * world} episodes split over the GPUs)" if strong else
+                               f"weak scaling: effective update batch {world} x {B} episodes)")) if world > 1 else "1 GPU",
+            "hparams": args.hparams if args.algo == "idqn" and args.cadence == "ratio" else "reference",
             "env_steps_timed": env_steps,
         },
         "kernels": timing,
         "roofline": roofline,
     }
-    if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, H)
-    print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+    return out
 
 
 if __name__ == "__main__":

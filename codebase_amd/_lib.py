@@ -64,11 +64,13 @@ class QmixMixer(ctypes.Structure):
 class AcConfig(ctypes.Structure):
     _fields_ = [("n_steps", c_int32), ("entropy_coef", c_float), ("value_loss_coef", c_float), ("ppo_clip", c_float),
                 ("gamma", c_double), ("ret_mean", c_void_p), ("ret_var", c_void_p), ("ret_count", c_void_p),
-                ("centralised_critic", c_int32), ("side_stream", c_void_p)]
+                ("centralised_critic", c_int32), ("side_stream", c_void_p),
+                ("ret_exchange", c_void_p), ("ret_exchange_ctx", c_void_p), ("ret_moments", c_void_p)]
 
 
 class RetStatsStruct(ctypes.Structure):
-    _fields_ = [("mean", c_void_p), ("var", c_void_p), ("count", c_void_p), ("columns", c_int32)]
+    _fields_ = [("mean", c_void_p), ("var", c_void_p), ("count", c_void_p), ("columns", c_int32),
+                ("exchange", c_void_p), ("exchange_ctx", c_void_p), ("moments", c_void_p)]
 
 
 class IdqnLearner(ctypes.Structure):
@@ -196,6 +198,8 @@ PROTOTYPES = {
                                                           c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "marlhip_idqn_update_n": (c_int32, [POINTER(IdqnLearner), c_int32, c_int32, c_uint64, c_uint32, POINTER(c_int64),
                                         POINTER(c_int64), POINTER(c_int64), c_void_p]),
+    "marlhip_idqn_update_n_dist": (c_int32, [POINTER(IdqnLearner), c_int32, c_int32, c_uint64, c_uint32, POINTER(c_int64),
+                                             POINTER(c_int64), POINTER(c_int64), c_void_p, c_void_p, c_int32, c_void_p]),
     "marlhip_timing_enable": (c_int32, [c_int32]),
     "marlhip_timing_read": (c_int32, [c_int32, POINTER(c_int64), POINTER(c_double)]),
     "marlhip_idqn_collect": (c_int32, [POINTER(LbfConfig), POINTER(NetShape), c_void_p, c_float, c_uint32,

@@ -4,6 +4,8 @@ itself is codebase_amd.ac.model.A2CNetwork / PPONetwork (csrc/a2c.hip)."""
 from collections import namedtuple
 
 import numpy as np
+import logging
+
 import torch
 
 from .. import hip as _hip
@@ -85,7 +87,11 @@ def _collect_trajectories_recurrent(envs, model, T, use_proper_termination, roun
         if t % 8 == 0 and not bool(running.any()):
             break
     filled_steps = int(b_fill.sum(1).gt(0).sum().item())
-    n_later = min(int(later_dev[0].item()), cap)
+    n_later = int(later_dev[0].item())
+    if n_later > cap:  # the count is the true one: say so instead of dropping records silently
+        logging.getLogger(__name__).warning("rollout %d: %d later episodes finished, %d recorded (logged statistics miss the rest; the batch "
+                                            "is unaffected)", round_idx, n_later, cap)
+        n_later = cap
     later = []
     if n_later:
         lret, lmeta = later_dev[1][:n_later].cpu().numpy(), later_dev[2][:n_later].cpu().numpy()
@@ -121,8 +127,21 @@ def _collect_trajectories(envs, model, max_ep_length, parallel_envs, n_agents, d
         early = torch.nonzero(fin_len < t).flatten().to(torch.int32) if second else None
         if second and early.numel() > 0:
             # the reference's vector env keeps stepping the envs that finished early until the last one is done: second pass
-            g_ret, g_meta, g_cnt = _hip.ac_collect_later_episodes(cfg, model.spec, model.actor_params, round_idx, T, early,
-                                                                  fin_len[early.long()].contiguous(), t)
+            cap = 8
+            while True:  # the kernel reports the TRUE number of further episodes per env: when one exceeds the record capacity the
+                # pass is repeated with room for all of them (it is deterministic and writes nothing else; with env.standardise_rewards
+                # the first attempt has already moved the reward statistics, so that case only warns)
+                g_ret, g_meta, g_cnt = _hip.ac_collect_later_episodes(cfg, model.spec, model.actor_params, round_idx, T, early,
+                                                                      fin_len[early.long()].contiguous(), t, cap=cap)
+                most = int(g_cnt.max().item())
+                if most <= cap:
+                    break
+                if bool(getattr(cfg, "reward_stats", None)):
+                    logging.getLogger(__name__).warning("rollout %d: an env finished %d further episodes, %d recorded (logged statistics "
+                                                        "miss the rest; the batch is unaffected)", round_idx, most, cap)
+                    g_cnt = g_cnt.clamp(max=cap)
+                    break
+                cap = most
             ids, g_ret, g_meta, g_cnt = early.cpu().numpy(), g_ret.cpu().numpy(), g_meta.cpu().numpy(), g_cnt.cpu().numpy()
             for i in range(len(ids)):
                 for k in range(int(g_cnt[i])):
@@ -154,9 +173,20 @@ def main(envs, eval_env, logger, time_limit, **cfg):
     from ..config import instantiate
     from ..dqn.train import _cfg_get
 
+    from ..parallel import GradSync, gather_stack, init_distributed
+
     g = lambda k, d=None: _cfg_get(cfg, k, d)  # noqa: E731
+    # one process per GPU under torchrun: every rank rolls out its own env shard, ONE all-reduce of the joint [actor | critic]
+    # gradient per update (per PPO epoch), rank 0 logs / saves; dist is None on one process and nothing below changes
+    dist, rank, world, _ = init_distributed()
     model = instantiate(g("model"), envs.single_observation_space, envs.single_action_space, cfg)
     logger.watch(model)
+    sync = None
+    if dist is not None:
+        sync = GradSync(dist)
+        dist.broadcast(model.updater.block, 0)  # identical replicas (the seeded init already agrees; this makes it unconditional)
+        dist.broadcast(model.updater.target_critic, 0)
+        model.updater.attach_exchange(lambda t: dist.all_reduce(t))  # standardise_returns: global batch moments
     parallel_envs = envs.observation_space[0].shape[0]
     device = g("model.device", "cuda")
     step = updates = last_eval = last_save = 0
@@ -164,17 +194,31 @@ def main(envs, eval_env, logger, time_limit, **cfg):
         log_now = (step - last_eval) >= g("eval_interval")  # the only consumer of a rollout's infos
         t, batch, infos = _collect_trajectories(envs, model, time_limit, parallel_envs, model.n_agents, device,
                                                 g("use_proper_termination", False), round_idx=updates, want_infos=log_now)
-        infos.append(model.update(batch, step) if log_now else model.update_async(batch, step))
+        if dist is not None and log_now:  # the other ranks' episodes join rank 0's list (returns [P] + length per first episode)
+            rows = torch.tensor([[*map(float, d["episode_returns"]), float(d["episode_length"])] for d in infos[:parallel_envs]],
+                                dtype=torch.float32, device=device)
+            for r, block in enumerate(gather_stack(dist, rows).cpu().numpy()):
+                if r != rank:
+                    for row in block:
+                        d = EpisodeInfo({"episode_returns": row[:-1].copy(), "episode_length": int(row[-1])})
+                        for p in range(model.n_agents):
+                            d[f"agent{p}/episode_returns"] = row[p]
+                        infos.append(d)
+        m = model.update_async(batch, step, grad_sync=sync, world=world)
+        infos.append(model._metrics(m) if log_now else m)
         if log_now:
-            _log_progress(infos, step, updates, logger)
+            if rank == 0:
+                _log_progress(infos, step, updates, logger)
             last_eval = step
         if g("save_interval") and (step - last_save) >= g("save_interval"):
-            Path("checkpoints").mkdir(exist_ok=True)
-            torch.save(model.state_dict(), f"checkpoints/model_s{step}.pt")
+            if rank == 0:
+                Path("checkpoints").mkdir(exist_ok=True)
+                torch.save(model.state_dict(), f"checkpoints/model_s{step}.pt")
             last_save = step
         if g("video_interval"):
             raise NotImplementedError("video recording is outside the HIP hot path")
         updates += 1
-        step += t * parallel_envs
+        # the reference's counter (ac/train.py:226); N > 1 ranks: the whole job's, the same number on every rank (it ends the loop)
+        step += t * parallel_envs if dist is None else int(gather_stack(dist, torch.tensor([t * parallel_envs], device=device)).sum().item())
     envs.close()
     return model

@@ -39,6 +39,19 @@ def _stale(out, srcs):
     return any(os.path.getmtime(s) > t for s in srcs)
 
 
+def _dep_list(o, fallback):
+    """headers a translation unit really includes, from the depfile its last compile left (hipcc -MMD); all headers when there is none"""
+    d = o[:-2] + ".d"
+    if not os.path.exists(d) or not os.path.exists(o):
+        return fallback
+    txt = open(d).read().replace("\\\n", " ")
+    deps = []
+    for part in txt.split(":", 1)[-1].split():
+        if part.endswith((".h", ".hip")) and os.path.exists(part):
+            deps.append(part)
+    return deps or fallback
+
+
 def build(force=False, verbose=True):
     os.makedirs(OBJ, exist_ok=True)
     hipcc = _hipcc()
@@ -47,14 +60,14 @@ def build(force=False, verbose=True):
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJ, src.replace(".hip", ".o"))
-        if force or _stale(o, [s] + hdr):
+        if force or _stale(o, [s] + _dep_list(o, hdr)):
             jobs.append((s, o))
 
     def cc(job):
         s, o = job
         if verbose:
             print(f"[marlhip] hipcc {os.path.basename(s)}", flush=True)
-        subprocess.check_call([hipcc] + FLAGS + ["-c", s, "-o", o])
+        subprocess.check_call([hipcc] + FLAGS + ["-MMD", "-MF", o[:-2] + ".d", "-c", s, "-o", o])
 
     with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1) or 1) as ex:
         list(ex.map(cc, jobs))

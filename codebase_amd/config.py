@@ -118,7 +118,10 @@ def _set(cfg, dotted, value):
     cur[parts[-1]] = value
 
 
-_NUMERIC = re.compile(r"^[-+]?(\d+\.?\d*|\.\d+)([eE][-+]?\d+)?$")
+# the one place YAML 1.1 (PyYAML) and YAML 1.2 / OmegaConf disagree on numbers: exponent form WITHOUT a dot (`1e6`, `3e-4`) stays a
+# string in safe_load.  Everything else safe_load already typed - in particular QUOTED scalars ("1", "007", "1e6" written with quotes
+# lose their quotes in the loaded tree and cannot be told apart here, but quoted digits without an exponent stay strings)
+_YAML11_GAP = re.compile(r"^[-+]?\d+[eE][-+]?\d+$")
 
 
 def _numbers(x):
@@ -128,9 +131,8 @@ def _numbers(x):
         return {k: _numbers(v) for k, v in x.items()}
     if isinstance(x, list):
         return [_numbers(v) for v in x]
-    if isinstance(x, str) and _NUMERIC.match(x.strip()):
-        f = float(x)
-        return int(f) if re.fullmatch(r"[-+]?\d+", x.strip()) else f
+    if isinstance(x, str) and _YAML11_GAP.match(x):
+        return float(x)
     return x
 
 

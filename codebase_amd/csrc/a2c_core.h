@@ -470,6 +470,7 @@ int ac_step_t(int P, const AgentMap& am, const float* actor, const float* critic
     w.rpartial = f(wl.rpartial);
     const bool std_on = c->ret_mean != nullptr;
     w.st.mean = c->ret_mean; w.st.var = c->ret_var; w.st.count = c->ret_count;
+    w.st.exchange = c->ret_exchange; w.st.exchange_ctx = c->ret_exchange_ctx; w.st.moments = c->ret_moments;
     AcArgs a;
     a.P = P; a.T = T; a.B = B; a.A = A; a.n_steps = c->n_steps; a.mode = mode;
     for (int k = 0; k <= c->n_steps; ++k) a.gk[k] = (float)pow(c->gamma, (double)k);
@@ -512,7 +513,7 @@ int ac_step_t(int P, const AgentMap& am, const float* actor, const float* critic
     if (std_on && mode == 0) {  // A2C with standardise_returns: raw returns -> statistics update -> A2C on the stored returns
         a.mode = 4;
         hipLaunchKernelGGL(ac_elem_kernel, dim3((TB + 255) / 256), dim3(256), 0, st, a, *bt, w);
-        hipLaunchKernelGGL(ret_stats_update_kernel, dim3(1), dim3(64), 0, st, w.st, (const float*)w.rpartial, (TB + 255) / 256, P, TB);
+        if (launch_stats_update(w.st, w.rpartial, (TB + 255) / 256, P, TB, st) != 0) return -1;
         a.mode = 3;
     }
     if (mode != 1 && !v_done) {  // (forked before the actors' pass is queued, or there is nothing to overlap with)
@@ -526,8 +527,7 @@ int ac_step_t(int P, const AgentMap& am, const float* actor, const float* critic
     hipLaunchKernelGGL(ac_elem_kernel, dim3((TB + 255) / 256), dim3(256), 0, st, a, *bt, w);
     MARL_CHECK_LAUNCH("ac_elem_kernel");
     if (mode == 1) {
-        if (std_on)
-            hipLaunchKernelGGL(ret_stats_update_kernel, dim3(1), dim3(64), 0, st, w.st, (const float*)w.rpartial, (TB + 255) / 256, P, TB);
+        if (std_on && launch_stats_update(w.st, w.rpartial, (TB + 255) / 256, P, TB, st) != 0) return -1;
         timing_end(TIMER_LOSSGRAD, st);
         return 0;
     }

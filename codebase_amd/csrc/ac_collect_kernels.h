@@ -186,8 +186,8 @@ __global__ __launch_bounds__(ACOL_BLOCK) void ac_collect_kernel(typename ENV::Pa
                     for (int p = 0; p < P; ++p) gh.ret[at * P + p] = ep_ret[p];
                     gh.meta[2 * at] = len;
                     gh.meta[2 * at + 1] = t + 1;
-                    gh.cnt[n] = n_rec + 1;
                 }
+                if (lead) gh.cnt[n] = n_rec + 1;  // the TRUE count: a value above `cap` tells the caller that records were dropped
                 ++n_rec;
                 len = 0;
 #pragma unroll

@@ -57,14 +57,16 @@ struct AcGhostScope {
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: one slot per device ordinal, raised monotonically (a racing second
 // call sets the same value)
 struct LdsAttr {
-    size_t set[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    static constexpr int SLOTS = 64;
+    size_t set[SLOTS] = {};
     static int dev() {
         int d = 0;
         (void)hipGetDevice(&d);
-        return d & 15;
+        return d;
     }
-    bool need(size_t bytes = 1) const { return set[dev()] < bytes; }  // call sites: if (a.need(n)) { hipFuncSetAttribute...; a.done(n); }
-    void done(size_t bytes = 1) { set[dev()] = bytes; }
+    // device ordinals beyond the table never alias another device's slot: they set the attribute on every call (cheap, idempotent)
+    bool need(size_t bytes = 1) const { const int d = dev(); return d < 0 || d >= SLOTS || set[d] < bytes; }  // if (a.need(n)) { hipFuncSetAttribute...; a.done(n); }
+    void done(size_t bytes = 1) { const int d = dev(); if (d >= 0 && d < SLOTS) set[d] = bytes; }
 };
 
 #define MARL_CHECK_LAUNCH(what)                                                   \

@@ -71,7 +71,9 @@ extern "C" int64_t marlhip_dqn_workspace_bytes(const marlhip_net_shape* s, int32
 #define X(d, h, a) if (s->obs_dim == d && s->hidden == h && s->n_actions == a) pack = 2 * MlpShape<d, h, a>::NFWD + MlpShape<d, h, a>::NBWD;
     MARL_NET_SHAPES(X)
 #undef X
-    return ws_layout(s->n_agents, pl.nwg, np + 2, (int)pack, max_len, batch).total;
+    const int64_t base = ws_layout(s->n_agents, pl.nwg, np + 2, (int)pack, max_len, batch).total;
+    if (!tp) return base;
+    return ((base + 15) & ~(int64_t)15) + tp_h2_floats(s->n_agents, max_len, batch, s->hidden) * (int64_t)sizeof(float);  // pass F -> pass B activations
 }
 
 static int lossgrad_dispatch(const marlhip_net_shape* s, const float* params, const float* target_params, const marlhip_batch* bt,
@@ -128,7 +130,7 @@ static int std_stats(const marlhip_ret_stats* st, RetStats* out, int mode, int b
     MARL_REQUIRE(mode == 0 ? st->columns == 0 : st->columns == batch,
                  "dqn_loss_grad_std: statistics with %d columns for mode %d and a batch of %d (IDQN: columns = 0, mean / var [n_agents]; VDN: "
                  "columns = batch, mean / var [batch])", st->columns, mode, batch);
-    out->mean = st->mean; out->var = st->var; out->count = st->count; out->columns = st->columns;
+    ret_stats_fill(*out, st);
     return 0;
 }
 
@@ -219,7 +221,7 @@ static int qmix_call(const marlhip_net_shape* s, const float* params, const floa
         const marlhip_ret_stats* st = mx->ret_stats;
         MARL_REQUIRE(st->mean && st->var && st->count && st->columns == bt->batch,
                      "qmix_loss_grad: return statistics need mean / var [batch] and columns = batch (%d), got columns = %d", bt->batch, st->columns);
-        rst.mean = st->mean; rst.var = st->var; rst.count = st->count; rst.columns = st->columns;
+        ret_stats_fill(rst, st);
         qx.rst = &rst;
     }
     return lossgrad_dispatch(s, params, target_params, bt, rsrc, gamma, double_q, 2, workspace, a, grad, loss, stream, &qx);
@@ -272,7 +274,8 @@ static AdamArgs adam_args(int64_t step, double lr, double beta1, double beta2, d
 // *handled = false: not such a learner, the caller runs the generic loop.
 namespace marl {
 int idqn_update_n_fused(const marlhip_idqn_learner* L, int32_t n_updates, int32_t length, uint64_t seed, uint32_t counter0,
-                        int64_t* adam_step, int64_t* updates, int64_t* last_target_update, void* stream, bool* handled) {
+                        int64_t* adam_step, int64_t* updates, int64_t* last_target_update, void* stream, bool* handled,
+                        marlhip_exchange_fn exchange, void* exchange_ctx, int32_t world) {
     *handled = false;
     if (getenv("MARLHIP_NO_FUSED_EPILOGUE") != nullptr || (L->mode != 0 && L->mode != 1) || L->net.hidden > 64) return 0;
     if (agent_map_validate(&L->net) != 0) return -1;
@@ -286,10 +289,13 @@ int idqn_update_n_fused(const marlhip_idqn_learner* L, int32_t n_updates, int32_
     fuse.packs_valid = 0;
     fuse.params_rw = L->params; fuse.target_rw = L->target; fuse.exp_avg = L->exp_avg; fuse.exp_avg_sq = L->exp_avg_sq;
     fuse.gnorm = L->gnorm;
+    fuse.exchange = exchange;
+    fuse.exchange_ctx = exchange_ctx;
+    const float grad_scale = exchange != nullptr ? 1.0f / (float)world : 1.0f;
     for (int u = 0; u < n_updates; ++u) {
         const bool hard = tui > 1.0 && (double)(*updates + 1 - *last_target_update) >= tui;
         const float tau = tui < 1.0 ? (float)tui : 0.f;
-        fuse.adam = adam_args(*adam_step + 1, L->lr, L->beta1, L->beta2, L->eps, L->max_norm, 1.0f, hard ? 1 : 0, tau);
+        fuse.adam = adam_args(*adam_step + 1, L->lr, L->beta1, L->beta2, L->eps, L->max_norm, grad_scale, hard ? 1 : 0, tau);
         ReplaySrc src;
         src.rb = L->rb; src.idx = nullptr; src.idx_out = L->idx; src.seed = seed; src.counter = counter0 + (uint32_t)u; src.length = length; src.capacity = L->rs.capacity;
         if (L->materialise_batch) {

@@ -979,7 +979,17 @@ __device__ __forceinline__ void adam_pack_body(int i, int n, int nsq, float* __r
     __shared__ float s_red[4];
     {
         float ss = 0.f;
-        for (int b = threadIdx.x; b < nsq; b += 256) ss += sumsq[b];
+        if (nsq > 0) {
+            for (int b = threadIdx.x; b < nsq; b += 256) ss += sumsq[b];
+        } else {
+            // data-parallel form (marlhip_idqn_update_n_dist): the gradient was summed over the ranks AFTER the reduce launch, so no
+            // partial sums exist - every block takes the norm of the whole exchanged, scaled gradient itself (n floats from L2; fixed
+            // order, so every block and every rank forms the same clip coefficient)
+            for (int j = threadIdx.x; j < n; j += 256) {
+                const float gj = grad[j] * a.grad_scale;
+                ss += gj * gj;
+            }
+        }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) ss += __shfl_xor(ss, off);
         if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = ss;
@@ -1079,6 +1089,10 @@ struct WsLayout {
     int64_t rec_bytes, pack_off, mix_off, total;
 };
 
+// tensor-parallel learner (hidden 128, wide rows): pass F leaves the critic's second hidden layer of every transition row for pass B
+// (dqn_update_tp.h, h2_out): P * T * [row blocks of 16, counted in pairs] * 16 * H floats behind everything else
+inline int64_t tp_h2_floats(int P, int T, int B, int H) { return (int64_t)P * T * (((B + 31) / 32) * 2) * 16 * H; }  // == tp_h2_blocks(B) row blocks
+
 inline WsLayout ws_layout(int P, int nwg, int rec, int pack, int T, int B) {
     WsLayout w;
     w.rec_bytes = (int64_t)P * nwg * rec * sizeof(float);
@@ -1135,9 +1149,12 @@ int launch_lossgrad_tp(const marlhip_net_shape* s, const float* params, const fl
     constexpr int W = 4, TPW = S::H / 64, NB = S::D > 48 ? 1 : 2, NBF = MARL_TP_NBF, NT = W * TPW, REC = S::NPARAM + 2;  // wide first layers: one row block per step keeps pass B out of scratch
     const int P = s->n_agents, T = bt->max_len, B = bt->batch;
     const AgentMap am = agent_map(s);
+    static_assert(NB <= 2 && NBF <= 2, "tp_h2_blocks counts row blocks in pairs");
     const UpdPlan pl = upd_plan_tp(P, T, B, NB), plF = upd_plan_tp(P, T, B, NBF);
     const WsLayout wl = ws_layout(P, pl.nwg, REC, 0, T, B);
-    MARL_REQUIRE(ws_bytes >= wl.total, "dqn_loss_grad: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)wl.total);
+    const int64_t h2_off = (wl.total + 15) & ~(int64_t)15, need = h2_off + tp_h2_floats(P, T, B, S::H) * (int64_t)sizeof(float);
+    MARL_REQUIRE(ws_bytes >= need, "dqn_loss_grad: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)need);
+    f4* h2buf = reinterpret_cast<f4*>(static_cast<char*>(ws) + h2_off);
     float* mixf = reinterpret_cast<float*>(static_cast<char*>(ws) + wl.mix_off);
     const size_t tb = (size_t)T * B;
     TpMix mix;
@@ -1149,14 +1166,14 @@ int launch_lossgrad_tp(const marlhip_net_shape* s, const float* params, const fl
     if (attr_set.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tp_fwd_kernel<S, W, TPW, REPLAY, NBF>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsF);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tp_bwd_kernel<S, W, TPW, REPLAY, NB>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tp_bwd_kernel<S, W, TPW, REPLAY, NB, false, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsB);
         attr_set.done();
     }
     const dim3 grid(pl.nwg, P), block(64 * W);
     timing_begin(TIMER_LOSSGRAD, st);
     hipLaunchKernelGGL((tp_fwd_kernel<S, W, TPW, REPLAY, NBF>), dim3(plF.nwg, P), block, ldsF, st, params, tparams, am, *bt, src, mix,
-                       double_q, plF.n_chunks);
+                       double_q, plF.n_chunks, h2buf);
     if (mode == 2) {
         QmixIo io = {mix.chosen, mix.tqsel, mix.rew, mix.dn, mix.fl, mix.dq, mix.lrow, nullptr};
         const int rc = qmix_dispatch_mix<S::D, REPLAY>(P, *qx, bt, src, io, gamma, st);
@@ -1176,7 +1193,8 @@ int launch_lossgrad_tp(const marlhip_net_shape* s, const float* params, const fl
         hipLaunchKernelGGL(tp_mix_kernel, dim3((unsigned)((tb + 255) / 256 > 1024 ? 1024 : (tb + 255) / 256)), dim3(256), 0, st, mix, P,
                            T, B, gamma, mode == 1 ? 1 : 0, ret);
     }
-    hipLaunchKernelGGL((tp_bwd_kernel<S, W, TPW, REPLAY, NB>), grid, block, ldsB, st, params, am, *bt, src, mix, pl.n_chunks, (float*)ws);
+    hipLaunchKernelGGL((tp_bwd_kernel<S, W, TPW, REPLAY, NB, false, true>), grid, block, ldsB, st, params, am, *bt, src, mix, pl.n_chunks,
+                       (float*)ws, (const f4*)h2buf);
     timing_end(TIMER_LOSSGRAD, st);
     MARL_CHECK_LAUNCH("tp_lossgrad");
     const int n = am.nblk * S::NPARAM;
@@ -1193,6 +1211,10 @@ struct UpdFuse {
     AdamArgs adam;
     float *params_rw, *target_rw, *exp_avg, *exp_avg_sq, *gnorm;
     float* sumsq;     // >= ceil(n / 64) floats
+    // data-parallel training (marlhip_idqn_update_n_dist): called between the gradient reduce and the Adam launch; leaves the SUM over
+    // the ranks in `grad`, ordered on the stream; adam.grad_scale = 1 / world.  nullptr: single GPU.
+    marlhip_exchange_fn exchange = nullptr;
+    void* exchange_ctx = nullptr;
 };
 
 template <class S, bool REPLAY>
@@ -1277,10 +1299,20 @@ int launch_lossgrad_src(const marlhip_net_shape* s, const float* params, const f
     const int n = am.nblk * S::NPARAM;
     if (fuse != nullptr) {  // reduce (+ clip-norm partials) -> clip + Adam + target + next update's packs: two launches
         MARL_REQUIRE(mode == 0 || mode == 1, "fused update epilogue: IDQN / VDN only");
-        const int nsq = (n + 63) / 64;
-        hipLaunchKernelGGL(dqn_reduce_sq_kernel, dim3(nsq), dim3(256), 0, st, (const float*)ws, P, pl.nwg, S::NPARAM, am, grad, loss,
-                           fuse->sumsq);
-        MARL_CHECK_LAUNCH("dqn_reduce_sq_kernel");
+        int nsq = (n + 63) / 64;
+        if (fuse->exchange != nullptr) {
+            // N > 1: reduce -> all-reduce(SUM) of the flat gradient (the caller's RCCL hop) -> Adam, the clip norm taken from the
+            // exchanged gradient inside the Adam launch (the clip must use the global post-reduce norm, dqn/model.py:170)
+            hipLaunchKernelGGL(dqn_reduce_kernel, dim3(nsq), dim3(256), 0, st, (const float*)ws, P, pl.nwg, S::NPARAM, am, grad, loss);
+            MARL_CHECK_LAUNCH("dqn_reduce_kernel");
+            const int rc = fuse->exchange(fuse->exchange_ctx, grad, (int64_t)n, (void*)st);
+            MARL_REQUIRE(rc == 0, "idqn_update_n_dist: the gradient exchange callback failed (%d)", rc);
+            nsq = 0;
+        } else {
+            hipLaunchKernelGGL(dqn_reduce_sq_kernel, dim3(nsq), dim3(256), 0, st, (const float*)ws, P, pl.nwg, S::NPARAM, am, grad, loss,
+                               fuse->sumsq);
+            MARL_CHECK_LAUNCH("dqn_reduce_sq_kernel");
+        }
         hipLaunchKernelGGL((adam_pack_kernel<S>), dim3((n + 255) / 256), dim3(256), 0, st, n, nsq, fuse->params_rw, (const float*)grad,
                            fuse->exp_avg, fuse->exp_avg_sq, fuse->target_rw, fuse->adam, (const float*)fuse->sumsq, fuse->gnorm, am, P,
                            packs);

@@ -183,9 +183,16 @@ __device__ __forceinline__ void tp_episode_ids(const ReplaySrc& rs, int b0, int 
 // pass F: forward of critic and target, workgroup = W waves, NB row blocks per step
 // LDS (floats): Hc[NB][NT][256] | Ht[NB][NT][256] | Qp[NB][W][256] | Tp[NB][W][256]
 // ---------------------------------------------------------------------------------------------------------
+// h2_out (may be null): the critic's second hidden layer of every TRANSITION row (t < T), relu applied, in C layout -
+// h2_out[(((p T + t) tp_h2_blocks(B) + b0 / 16) NT + tau) 64 + lane] - so that pass B reads it back instead of recomputing layer 2 (the
+// largest GEMM of the step: 256 of pass B's 896 MFMAs per row block at hidden 128).  H f32 per row-step, written once and read once.
+// Row blocks are counted in PAIRS (a pass walks 1 or 2 blocks per step): the padding block of an odd batch is written too (its rows
+// are zero inputs -> finite values), so pass B never meets uninitialised memory there (0 * NaN would poison dW3).
+__host__ __device__ inline int tp_h2_blocks(int B) { return ((B + 31) / 32) * 2; }
 template <class S, int W, int TPW, bool REPLAY, int NB>
 __global__ __launch_bounds__(64 * W, 1) void tp_fwd_kernel(const float* __restrict__ params, const float* __restrict__ tparams,
-                                                           AgentMap am, marlhip_batch bt, ReplaySrc rs, TpMix mix, int double_q, int n_chunks) {
+                                                           AgentMap am, marlhip_batch bt, ReplaySrc rs, TpMix mix, int double_q, int n_chunks,
+                                                           f4* __restrict__ h2_out) {
     constexpr int NT = W * TPW, A = S::A;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     f4* Hc = reinterpret_cast<f4*>(lds);
@@ -286,6 +293,8 @@ __global__ __launch_bounds__(64 * W, 1) void tp_fwd_kernel(const float* __restri
                     }
                     acc = relu4(acc);
                     acct = relu4(acct);
+                    if (h2_out != nullptr && t < t1)  // a transition row of this chunk (t1 itself only bootstraps here)
+                        h2_out[((((size_t)p * T + t) * tp_h2_blocks(B) + (set * NB + nb)) * NT + wave * TPW + u) * 64 + lane] = acc;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         q = MARL_MFMA(ca3[u][r], acc[r], q);
@@ -370,9 +379,12 @@ static __global__ __launch_bounds__(256) void tp_mix_kernel(TpMix mix, int P, in
 // pass B: critic layers 1-2 forward + backward with the external dq; gradient slices stay with their wave
 // LDS (floats): Hc[NB][NT][256] | HcT[NB][H][16] | G2[NB][NT][256] | per wave: PQ[256] + (P2,PH2,P1)[TPW][256]
 // ---------------------------------------------------------------------------------------------------------
-template <class S, int W, int TPW, bool REPLAY, int NB, bool FULL = false>
+// STORED: layer 2 is not recomputed - the wave reads ITS h2 tiles of the row block back from pass F's h2_out (one step ahead, next
+// to the rows), so the C-layout dump of h1 and the barrier behind it go away too: layer 1 -> [dH2, dW3 from the stored h2] ->
+// barrier -> [dH1, dW2, dW1] -> barrier.  Same arithmetic per element as the recomputing form (pass F ran the identical MFMA chain).
+template <class S, int W, int TPW, bool REPLAY, int NB, bool FULL = false, bool STORED = false>
 __global__ __launch_bounds__(64 * W, 1) void tp_bwd_kernel(const float* __restrict__ params, AgentMap am, marlhip_batch bt, ReplaySrc rs, TpMix mix,
-                                                           int n_chunks, float* __restrict__ partials) {
+                                                           int n_chunks, float* __restrict__ partials, const f4* __restrict__ h2_in = nullptr) {
     constexpr int NT = W * TPW, A = S::A, D = S::D, H = S::H, NT1 = S::DP / 16;
     constexpr int PRIV = 256 * (1 + 3 * TPW);
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -435,15 +447,29 @@ __global__ __launch_bounds__(64 * W, 1) void tp_bwd_kernel(const float* __restri
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) tp_episode_ids<REPLAY>(rs, (set * NB + nb) * 16, B, g, j, ej[nb], eg[nb]);
         TpRows<S, REPLAY> cur[NB];
+        f4 h2c[STORED ? NB : 1][TPW];
+        auto h2_at = [&](int t, int nb, int u) -> f4 {
+            return h2_in[((((size_t)p * T + t) * tp_h2_blocks(B) + (set * NB + nb)) * NT + wave * TPW + u) * 64 + lane];
+        };
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
+        for (int nb = 0; nb < NB; ++nb) {
             tp_load_rows<S, REPLAY, true, FULL>(src, mix, t1 - 1, (set * NB + nb) * 16, g, j, ej[nb], eg[nb], cur[nb]);
+            if constexpr (STORED) {
+#pragma unroll
+                for (int u = 0; u < TPW; ++u) h2c[nb][u] = h2_at(t1 - 1, nb, u);
+            }
+        }
         for (int t = t1 - 1; t >= t0; --t) {
             TpRows<S, REPLAY> nxt[NB];
+            f4 h2n[STORED ? NB : 1][TPW];
             f4 h1[NB][TPW];
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
                 tp_load_rows<S, REPLAY, true, FULL>(src, mix, t > t0 ? t - 1 : t0, (set * NB + nb) * 16, g, j, ej[nb], eg[nb], nxt[nb]);
+                if constexpr (STORED) {
+#pragma unroll
+                    for (int u = 0; u < TPW; ++u) h2n[nb][u] = h2_at(t > t0 ? t - 1 : t0, nb, u);
+                }
                 tp_mask_rows<S, REPLAY, true>(cur[nb], (set * NB + nb) * 16, B, g, j);
             }
             // ---- layer 1 of my tiles: C-layout dump (layer-2 operand) + [h][row] tile (dW2 operand)
@@ -457,11 +483,11 @@ __global__ __launch_bounds__(64 * W, 1) void tp_bwd_kernel(const float* __restri
                     acc = relu4(acc);
                     h1[nb][u] = acc;
                     const int tau = wave * TPW + u;
-                    Hc[(nb * NT + tau) * 64 + lane] = acc;
+                    if constexpr (!STORED) Hc[(nb * NT + tau) * 64 + lane] = acc;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) HcT[(nb * H + 16 * tau + 4 * g + r) * 16 + j] = acc[r];
                 }
-            __syncthreads();
+            if constexpr (!STORED) __syncthreads();  // (STORED: nothing of another wave is read before the barrier behind dH2)
             // ---- layer 2, dH2 = W3^T dQ (mask), dW3, dumps of dH2
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
@@ -477,15 +503,19 @@ __global__ __launch_bounds__(64 * W, 1) void tp_bwd_kernel(const float* __restri
                 tile_write<1>(PQ, dQ, g, j);
 #pragma unroll
                 for (int u = 0; u < TPW; ++u) {
-                    f4 acc = cw[u].b2s;
-#pragma unroll
-                    for (int kap = 0; kap < NT; ++kap) {
-                        const f4 hk = Hc[(nb * NT + kap) * 64 + lane];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) acc = MARL_MFMA(cw[u].a2[kap][r], hk[r], acc);
-                    }
                     f4 h2[1];
-                    h2[0] = relu4(acc);
+                    if constexpr (STORED) {
+                        h2[0] = h2c[nb][u];
+                    } else {
+                        f4 acc = cw[u].b2s;
+#pragma unroll
+                        for (int kap = 0; kap < NT; ++kap) {
+                            const f4 hk = Hc[(nb * NT + kap) * 64 + lane];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) acc = MARL_MFMA(cw[u].a2[kap][r], hk[r], acc);
+                        }
+                        h2[0] = relu4(acc);
+                    }
                     f4 d2[1];
                     d2[0] = zero4;
 #pragma unroll
@@ -545,7 +575,13 @@ __global__ __launch_bounds__(64 * W, 1) void tp_bwd_kernel(const float* __restri
             }
             __syncthreads();  // Hc / HcT / G2 are rewritten by the next step
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) cur[nb] = nxt[nb];
+            for (int nb = 0; nb < NB; ++nb) {
+                cur[nb] = nxt[nb];
+                if constexpr (STORED) {
+#pragma unroll
+                    for (int u = 0; u < TPW; ++u) h2c[nb][u] = h2n[nb][u];
+                }
+            }
         }
     }
 

@@ -264,7 +264,7 @@ int gru_qmix_loss_grad(const marlhip_net_shape* s, const float* params, const fl
         const marlhip_ret_stats* stt = mx->ret_stats;
         MARL_REQUIRE(stt->mean && stt->var && stt->count && stt->columns == B, "gru_qmix_loss_grad: return statistics need columns = batch (%d), got %d", B,
                      stt->columns);
-        rst.mean = stt->mean; rst.var = stt->var; rst.count = stt->count; rst.columns = stt->columns;
+        ret_stats_fill(rst, stt);
         qx.rst = &rst;
     }
     const AgentMap am = agent_map(s);
@@ -336,7 +336,7 @@ extern "C" int marlhip_gru_loss_grad_std(const marlhip_net_shape* s, const float
                  "gru_loss_grad_std: NULL pointer");
     MARL_REQUIRE(batch->obs_agent_stride == 0 && batch->obs_row_stride == 0, "gru_loss_grad_std: the dqn/train.py Batch layout only");
     RetStats rst;
-    rst.mean = stats->mean; rst.var = stats->var; rst.count = stats->count; rst.columns = stats->columns;
+    ret_stats_fill(rst, stats);
     // columns = 0: per-agent statistics, the independent learner; columns = batch: VDNetwork's per-batch-column statistics (marlhip_ret_stats)
     MARL_REQUIRE(stats->columns == 0 || stats->columns == batch->batch, "gru_loss_grad_std: statistics with %d columns for a batch of %d",
                  stats->columns, batch->batch);

@@ -108,8 +108,10 @@ MARL_HD void lbf_reset(const LbfParams& q, LbfState<P, F>& s, DrawStream& rng) {
     for (int f = 0; f < F; ++f) { s.fr[f] = 0; s.fc[f] = 0; s.fl[f] = 0; }
 #pragma unroll
     for (int p = 0; p < P; ++p) { s.pr[p] = 0; s.pc[p] = 0; s.pl[p] = q.min_player_level; }
-    // players: uniform cell until empty (field is still all-zero here)
-#pragma unroll
+    // players: uniform cell until empty (field is still all-zero here).  The loop over p stays ROLLED (its body inlines three Philox
+    // draws - the compiler refuses to unroll it eight times, and a run-time s.pr[p] would push the whole state into scratch memory):
+    // every array access below has a compile-time index, the run-time p only appears in comparisons.
+#pragma unroll 1
     for (int p = 0; p < P; ++p) {
         int attempts = 0;
         while (attempts < 1000) {
@@ -119,8 +121,10 @@ MARL_HD void lbf_reset(const LbfParams& q, LbfState<P, F>& s, DrawStream& rng) {
 #pragma unroll
             for (int o = 0; o < P; ++o) empty = empty && !(o < p && s.pr[o] == row && s.pc[o] == col);
             if (empty) {
-                s.pr[p] = row; s.pc[p] = col;
-                s.pl[p] = rng.integers(q.min_player_level, q.max_player_level + 1);
+                const int lvl = rng.integers(q.min_player_level, q.max_player_level + 1);
+#pragma unroll
+                for (int o = 0; o < P; ++o)
+                    if (o == p) { s.pr[o] = row; s.pc[o] = col; s.pl[o] = lvl; }
                 break;
             }
             ++attempts;
@@ -291,12 +295,16 @@ MARL_HD void lbf_observe(const LbfParams& q, const LbfState<P, F>& s, int p, Lbf
 #pragma unroll
     for (int f = 0; f < F; ++f) {
         const bool vis = s.fl[f] > 0 && iabs(s.fr[f] - cr) <= q.sight && iabs(s.fc[f] - cc) <= q.sight;
-        if (vis) {
+        // slot n takes the food; written as selects on compile-time slots (a conditional store per slot is merged by the compiler
+        // into ONE store at the run-time index n, which moves the observation into scratch memory)
 #pragma unroll
-            for (int i = 0; i < F; ++i)
-                if (i == n) { o.v[3 * i] = (float)(s.fr[f] + offr); o.v[3 * i + 1] = (float)(s.fc[f] + offc); o.v[3 * i + 2] = (float)s.fl[f]; }
-            ++n;
+        for (int i = 0; i < F; ++i) {
+            const bool hit = vis && i == n;
+            o.v[3 * i] = hit ? (float)(s.fr[f] + offr) : o.v[3 * i];
+            o.v[3 * i + 1] = hit ? (float)(s.fc[f] + offc) : o.v[3 * i + 1];
+            o.v[3 * i + 2] = hit ? (float)s.fl[f] : o.v[3 * i + 2];
         }
+        n += vis ? 1 : 0;
     }
     // self first
     o.v[3 * F] = (float)(cr + offr); o.v[3 * F + 1] = (float)(cc + offc); o.v[3 * F + 2] = (float)s.pl[p];
@@ -306,12 +314,14 @@ MARL_HD void lbf_observe(const LbfParams& q, const LbfState<P, F>& s, int p, Lbf
         if (a == p) continue;
         const int y = s.pr[a] + offr, x = s.pc[a] + offc;
         const bool vis = imin(y, x) >= 0 && imax(y, x) <= 2 * q.sight;
-        if (vis) {
 #pragma unroll
-            for (int i = 1; i < P; ++i)
-                if (i == m) { o.v[3 * (F + i)] = (float)y; o.v[3 * (F + i) + 1] = (float)x; o.v[3 * (F + i) + 2] = (float)s.pl[a]; }
-            ++m;
+        for (int i = 1; i < P; ++i) {
+            const bool hit = vis && i == m;
+            o.v[3 * (F + i)] = hit ? (float)y : o.v[3 * (F + i)];
+            o.v[3 * (F + i) + 1] = hit ? (float)x : o.v[3 * (F + i) + 1];
+            o.v[3 * (F + i) + 2] = hit ? (float)s.pl[a] : o.v[3 * (F + i) + 2];
         }
+        m += vis ? 1 : 0;
     }
 }
 

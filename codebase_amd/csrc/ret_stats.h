@@ -11,7 +11,16 @@ struct RetStats {
     float* var;     // [P]   (per-column statistics: [B])
     double* count;  // [1]
     int columns;    // 0: one (mean, var) per agent (IDQN); B > 0: one per batch column (VDN / QMIX, see colstd_returns_kernel)
+    // data-parallel training (marlhip_ret_stats): batch moments summed over the ranks before the running update; nullptr = one process
+    marlhip_exchange_f64_fn exchange = nullptr;
+    void* exchange_ctx = nullptr;
+    double* moments = nullptr;  // [2P + 1]
 };
+
+inline void ret_stats_fill(RetStats& r, const marlhip_ret_stats* s) {
+    r.mean = s->mean; r.var = s->var; r.count = s->count; r.columns = s->columns;
+    r.exchange = s->exchange; r.exchange_ctx = s->exchange_ctx; r.moments = s->moments;
+}
 
 // per-block sums of x and x^2 over a block's (row, agent) values: fixed-order wave butterfly + 4 waves
 __device__ __forceinline__ void ret_block_partials(float x, float* sh /*[2][4]*/, float* out2 /*[2]*/) {
@@ -55,6 +64,56 @@ static __global__ __launch_bounds__(64) void ret_stats_update_kernel(RetStats st
     }
     __syncthreads();
     if (p == 0) st.count[0] = count + (double)n;
+}
+
+// the same update in two halves around the ranks' exchange: fold the local block partials into moments = {s_p, q_p}[P], n (fp64) ...
+static __global__ __launch_bounds__(64) void ret_moments_kernel(const float* __restrict__ partial, int nblk, int P, int n,
+                                                                double* __restrict__ moments) {
+    const int p = threadIdx.x;
+    if (p < P) {
+        double s = 0.0, q = 0.0;
+        for (int b = 0; b < nblk; ++b) {
+            s += (double)partial[((size_t)b * P + p) * 2];
+            q += (double)partial[((size_t)b * P + p) * 2 + 1];
+        }
+        moments[2 * p] = s;
+        moments[2 * p + 1] = q;
+    }
+    if (p == 0) moments[2 * P] = (double)n;
+}
+
+// ... and update_from_moments with the moments of the GLOBAL batch (sums over the ranks): mean / unbiased variance of all
+// n_total values, exactly what RunningMeanStd.update computes on the concatenated batch (standardise_stream.py:15-20)
+static __global__ __launch_bounds__(64) void ret_stats_update_global_kernel(RetStats st, const double* __restrict__ moments, int P) {
+    const int p = threadIdx.x;
+    const double count = st.count[0];
+    const double bc = moments[2 * P];
+    if (p < P) {
+        const double s = moments[2 * p], q = moments[2 * p + 1];
+        const double bm = s / bc;
+        const double bv = bc > 1.0 ? (q - s * s / bc) / (bc - 1.0) : 0.0;
+        const double mean = (double)st.mean[p], var = (double)st.var[p];
+        const double delta = bm - mean, tot = count + bc;
+        const double m2 = var * count + bv * bc + delta * delta * count * bc / tot;
+        st.mean[p] = (float)(mean + delta * bc / tot);
+        st.var[p] = (float)(m2 / tot);
+    }
+    __syncthreads();
+    if (p == 0) st.count[0] = count + bc;
+}
+
+// RunningMeanStd.update of the per-agent statistics from the block partials: one launch, or (data-parallel) fold -> exchange -> update
+inline int launch_stats_update(const RetStats& st, const float* partial, int nblk, int P, int n, hipStream_t stream) {
+    if (st.exchange == nullptr) {
+        hipLaunchKernelGGL(ret_stats_update_kernel, dim3(1), dim3(64), 0, stream, st, partial, nblk, P, n);
+        return 0;
+    }
+    MARL_REQUIRE(st.moments != nullptr && P <= 64, "standardise_returns: the exchange needs `moments` (2P + 1 doubles on the device)");
+    hipLaunchKernelGGL(ret_moments_kernel, dim3(1), dim3(64), 0, stream, partial, nblk, P, n, st.moments);
+    const int rc = st.exchange(st.exchange_ctx, st.moments, (int64_t)(2 * P + 1), (void*)stream);
+    MARL_REQUIRE(rc == 0, "standardise_returns: the moments exchange callback failed (%d)", rc);
+    hipLaunchKernelGGL(ret_stats_update_global_kernel, dim3(1), dim3(64), 0, stream, st, (const double*)st.moments, P);
+    return 0;
 }
 
 // IDQN with standardised returns (QNetwork._compute_loss, dqn/model.py:146-163), between the agent-forward and
@@ -158,7 +217,7 @@ inline int launch_std_mixer(int P, int n, float gamma, const RetStats& st, const
                             const float* dn, const float* fl, float* dq, float* lrow, float* partial, hipStream_t stream) {
     const int nblk = (n + 255) / 256;
     hipLaunchKernelGGL(std_returns_kernel, dim3(nblk), dim3(256), 0, stream, P, n, gamma, st, tqsel, rew, dn, dq, partial);
-    hipLaunchKernelGGL(ret_stats_update_kernel, dim3(1), dim3(64), 0, stream, st, (const float*)partial, nblk, P, n);
+    if (launch_stats_update(st, partial, nblk, P, n, stream) != 0) return -1;
     hipLaunchKernelGGL(std_dq_kernel, dim3(nblk), dim3(256), 0, stream, P, n, st, chosen, fl, dq, lrow);
     MARL_CHECK_LAUNCH("standardise_returns mixer");
     return 0;

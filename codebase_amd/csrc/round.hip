@@ -7,12 +7,36 @@
 
 namespace marl {
 int idqn_update_n_fused(const marlhip_idqn_learner* L, int32_t n_updates, int32_t length, uint64_t seed, uint32_t counter0,
-                        int64_t* adam_step, int64_t* updates, int64_t* last_target_update, void* stream, bool* handled);
+                        int64_t* adam_step, int64_t* updates, int64_t* last_target_update, void* stream, bool* handled,
+                        marlhip_exchange_fn exchange, void* exchange_ctx, int32_t world);
 }
+
+static int update_n(const marlhip_idqn_learner* L, int32_t n_updates, int32_t length, uint64_t seed, uint32_t counter0,
+                    int64_t* adam_step, int64_t* updates, int64_t* last_target_update, marlhip_exchange_fn exchange, void* exchange_ctx,
+                    int32_t world, void* stream);
 
 extern "C" int marlhip_idqn_update_n(const marlhip_idqn_learner* L, int32_t n_updates, int32_t length, uint64_t seed,
                                      uint32_t counter0, int64_t* adam_step, int64_t* updates, int64_t* last_target_update,
                                      void* stream) {
+    return update_n(L, n_updates, length, seed, counter0, adam_step, updates, last_target_update, nullptr, nullptr, 1, stream);
+}
+
+// The data-parallel form (nothing like it in the reference, which is one process): per update ONE exchange of the flat
+// gradient between the reduce launch and the clip + Adam launch.  `exchange(ctx, grad, count, stream)` must leave the SUM over all
+// ranks in `grad`, ordered after the work already enqueued on `stream` and before what is enqueued next (an ncclAllReduce on that
+// stream; torch.distributed.all_reduce issued under the same current stream); clip + Adam then run with grad_scale = 1 / world on
+// the identical reduced gradient on every rank, the clip norm being that of the reduced gradient (dqn/model.py:170 on the global
+// batch).  The n-updates loop stays in this call: the exchange is the only host hop of an update.
+extern "C" int marlhip_idqn_update_n_dist(const marlhip_idqn_learner* L, int32_t n_updates, int32_t length, uint64_t seed,
+                                          uint32_t counter0, int64_t* adam_step, int64_t* updates, int64_t* last_target_update,
+                                          marlhip_exchange_fn exchange, void* exchange_ctx, int32_t world, void* stream) {
+    MARL_REQUIRE(exchange != nullptr && world >= 1, "idqn_update_n_dist: exchange callback is NULL or world < 1");
+    return update_n(L, n_updates, length, seed, counter0, adam_step, updates, last_target_update, exchange, exchange_ctx, world, stream);
+}
+
+static int update_n(const marlhip_idqn_learner* L, int32_t n_updates, int32_t length, uint64_t seed, uint32_t counter0,
+                    int64_t* adam_step, int64_t* updates, int64_t* last_target_update, marlhip_exchange_fn exchange, void* exchange_ctx,
+                    int32_t world, void* stream) {
     MARL_REQUIRE(L && adam_step && updates && last_target_update, "idqn_update_n: NULL pointer");
     MARL_REQUIRE(n_updates >= 0 && L->batch > 0, "idqn_update_n: bad counts");
     const int np = marlhip_net_nparams(&L->net);
@@ -23,7 +47,8 @@ extern "C" int marlhip_idqn_update_n(const marlhip_idqn_learner* L, int32_t n_up
     const double tui = L->target_update_interval_or_tau;
     {   // hidden-64 IDQN / VDN learners: 3 launches per update (the Adam launch writes the next update's weight packs)
         bool handled = false;
-        const int rc = marl::idqn_update_n_fused(L, n_updates, length, seed, counter0, adam_step, updates, last_target_update, stream, &handled);
+        const int rc = marl::idqn_update_n_fused(L, n_updates, length, seed, counter0, adam_step, updates, last_target_update, stream, &handled,
+                                                 exchange, exchange_ctx, world);
         if (rc < 0 || handled) return rc;
     }
     for (int u = 0; u < n_updates; ++u) {
@@ -40,13 +65,18 @@ extern "C" int marlhip_idqn_update_n(const marlhip_idqn_learner* L, int32_t n_up
                                               L->workspace_bytes, L->grad, L->loss, stream);
         }
         if (rc < 0) return rc;
+        const int64_t n_all = (int64_t)(L->net.n_networks > 0 ? L->net.n_networks : L->net.n_agents) * np;
+        if (exchange != nullptr) {
+            rc = exchange(exchange_ctx, L->grad, n_all, stream);
+            MARL_REQUIRE(rc == 0, "idqn_update_n_dist: the gradient exchange callback failed (%d)", rc);
+        }
         *updates += 1;
         *adam_step += 1;
         const bool hard = tui > 1.0 && (double)(*updates - *last_target_update) >= tui;
         const float tau = tui < 1.0 ? (float)tui : 0.f;
-        rc = marlhip_dqn_clip_adam((int64_t)(L->net.n_networks > 0 ? L->net.n_networks : L->net.n_agents) * np, L->params, L->grad, L->exp_avg, L->exp_avg_sq, L->target,
-                                   *adam_step, L->lr, L->beta1, L->beta2, L->eps, L->max_norm, 1.0f, hard ? 1 : 0, tau,
-                                   L->scratch, L->gnorm, stream);
+        rc = marlhip_dqn_clip_adam(n_all, L->params, L->grad, L->exp_avg, L->exp_avg_sq, L->target,
+                                   *adam_step, L->lr, L->beta1, L->beta2, L->eps, L->max_norm, exchange != nullptr ? 1.0f / (float)world : 1.0f,
+                                   hard ? 1 : 0, tau, L->scratch, L->gnorm, stream);
         if (rc < 0) return rc;
         if (hard) *last_target_update = *updates;
     }

@@ -148,7 +148,7 @@ extern "C" int marlhip_wide_dqn_loss_grad_std(const marlhip_net_shape* s, const 
     MARL_REQUIRE(stats->columns == 0 || stats->columns == bt->batch, "wide_dqn_loss_grad_std: statistics with %d columns for a batch of %d",
                  stats->columns, bt->batch);
     RetStats rst;
-    rst.mean = stats->mean; rst.var = stats->var; rst.count = stats->count; rst.columns = stats->columns;
+    ret_stats_fill(rst, stats);
     return wide_dqn_body(s, params, target_params, bt, gamma, double_q, stats->columns == 0 ? 0 : 1, &rst, workspace, workspace_bytes, grad, loss,
                          stream);
 }
@@ -204,7 +204,7 @@ extern "C" int marlhip_wide_qmix_loss_grad(const marlhip_net_shape* s, const flo
         const marlhip_ret_stats* stt = mx->ret_stats;
         MARL_REQUIRE(stt->mean && stt->var && stt->count && stt->columns == B, "wide_qmix_loss_grad: return statistics need columns = batch (%d), got %d",
                      B, stt->columns);
-        rst.mean = stt->mean; rst.var = stt->var; rst.count = stt->count; rst.columns = stt->columns;
+        ret_stats_fill(rst, stt);
         qx.rst = &rst;
     }
     const AgentMap am = agent_map(s);

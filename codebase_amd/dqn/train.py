@@ -153,7 +153,12 @@ class VectorisedIDQN:
         self.rounds = 0
         self.sample_counter = 0
         self.last_loss = None
-        self._fused = None  # single-GPU: all U updates of a round from one library call
+        self._fused = None  # all U updates of a round from one library call
+        self._sync = None
+        if dist is not None and model.standardise_returns and model.mode == 0:
+            # per-agent RunningMeanStd: batch moments summed over the ranks before the running update (standardise_stream.py:15-20 on the
+            # global batch); VDN / QMIX keep one (mean, var) per batch column - a rank's columns are its own part of the global batch
+            model.updater.ret_stats.attach_exchange(lambda t: dist.all_reduce(t))
 
     def _grad_sync(self, grad):
         from ..parallel import GradSync
@@ -206,12 +211,18 @@ class VectorisedIDQN:
                               use_proper_termination=self.proper)
         self.env_steps += self.fin_length.sum()
         self.rounds += 1
-        if train and self.dist is None and self.U > 0 and m.mode != 2 and not m.standardise_returns and not _NO_FUSED_LOOP and not getattr(m, "recurrent", False) and not m.spec.wide and m.updater.optimizer == 0:  # the n-updates library call has no mixer / no return statistics (those loop here)
+        if train and self.U > 0 and m.mode != 2 and not m.standardise_returns and not _NO_FUSED_LOOP and not getattr(m, "recurrent", False) and not m.spec.wide and m.updater.optimizer == 0:  # the n-updates library call has no mixer / no return statistics (those loop here)
+            # one library call for all U updates; with N > 1 ranks its data-parallel form: the gradient all-reduce is the only host hop
             if self._fused is None:
                 self._fused = _hip.FusedLearner(m.updater, self.replay, self.B, m.target_update_interval_or_tau, mode=m.mode)
+                if self.dist is not None:
+                    from ..parallel import GradSync
+
+                    self._sync = GradSync(self.dist)
             length = min(self.rounds * self.N, self.capacity)
-            m.updates, m.last_target_update = self._fused.run(self.U, length, self.seed, self.sample_counter, m.updates,
-                                                              m.last_target_update)
+            m.updates, m.last_target_update = self._fused.run(self.U, length, rank_sample_seed(self.seed, self.rank), self.sample_counter,
+                                                              m.updates, m.last_target_update,
+                                                              grad_sync=self._sync if self.dist is not None else None, world=self.world)
             self.sample_counter += self.U
             self.last_loss = m.updater.loss
         elif train:
@@ -224,7 +235,28 @@ class VectorisedIDQN:
 
     def evaluate(self, episodes, epsilon, round_idx=0):
         """_evaluate (train.py:177-199) for `episodes` envs in one collector launch (no replay writes);
-        returns per-episode info dicts like RecordEpisodeStatistics emits."""
+        returns per-episode info dicts like RecordEpisodeStatistics emits.  With N > 1 ranks every rank plays its share of the
+        episodes on its own env stream and the returns are gathered: the same list on every rank (rank 0 logs it)."""
+        if self.dist is not None:
+            from ..parallel import gather_stack
+
+            per = -(-int(episodes) // self.world)
+            ret, ln = self._evaluate_raw(per, epsilon, round_idx)
+            ret = gather_stack(self.dist, ret).permute(1, 0, 2).reshape(ret.shape[0], -1)[:, :episodes]
+            ln = gather_stack(self.dist, ln).reshape(-1)[:episodes]
+        else:
+            ret, ln = self._evaluate_raw(episodes, epsilon, round_idx)
+        ret, ln = ret.cpu().numpy(), ln.cpu().numpy()
+        infos = []
+        for i in range(ret.shape[1]):
+            d = {"episode_returns": ret[:, i].copy(), "episode_length": int(ln[i])}
+            for p in range(ret.shape[0]):
+                d[f"agent{p}/episode_returns"] = ret[p, i]
+            infos.append(d)
+        return infos
+
+    def _evaluate_raw(self, episodes, epsilon, round_idx=0):
+        """(returns [P][episodes], lengths [episodes]) on the device"""
         cfg = type(self.cfg).from_buffer_copy(self.cfg)
         cfg.n_envs = int(episodes)
         cfg.seed = (self.cfg.seed ^ 0x5DEECE66D) & (2**64 - 1)  # eval env: its own stream
@@ -237,14 +269,7 @@ class VectorisedIDQN:
         else:
             _hip.idqn_collect(cfg, self.model.spec, self.model.params, epsilon, round_idx, self.replay, 0, ret, ln,
                               write_replay=False)
-        ret, ln = ret.cpu().numpy(), ln.cpu().numpy()
-        infos = []
-        for i in range(episodes):
-            d = {"episode_returns": ret[:, i].copy(), "episode_length": int(ln[i])}
-            for p in range(ret.shape[0]):
-                d[f"agent{p}/episode_returns"] = ret[p, i]
-            infos.append(d)
-        return infos
+        return ret, ln
 
 
 def _cfg_get(cfg, key, default=None):
@@ -270,6 +295,11 @@ def _make_model(cfg, env):
 
 
 def main(env, eval_env, logger, time_limit, **cfg):
+    # one process per GPU under torchrun (WORLD_SIZE > 1): envs and replay shard per rank, one gradient all-reduce per update, rank 0
+    # logs / saves; `dist` is None on a single process and everything below is the single-GPU path
+    from ..parallel import all_sum, init_distributed
+
+    dist, rank, world, _ = init_distributed()
     model = _make_model(cfg, env)
     logger.watch(model)
     g = lambda k, d=None: _cfg_get(cfg, k, d)
@@ -284,7 +314,12 @@ def main(env, eval_env, logger, time_limit, **cfg):
         B = int(g("update_batch_size", 0) or N)
         U = int(g("updates_per_round", 0) or max(1, (g("batch_size") * N) // B))
         trainer = VectorisedIDQN(env.cfg, model, max(g("buffer_size"), N), time_limit, B, U, seed=env.cfg.seed,
-                                 use_proper_termination=g("use_proper_termination", False))
+                                 use_proper_termination=g("use_proper_termination", False), dist=dist)
+        if dist is not None:  # identical replicas: every rank starts from rank 0's blocks (and Adam's zeros)
+            for t in (model.params, model.target_params) + ((model.mixer_params, model.target_mixer_params) if model.mode == 2 else ()):
+                dist.broadcast(t, 0)
+    elif dist is not None:
+        raise _hip.MarlHipError("multi-GPU training shards batched envs: set env.parallel_envs (the scalar reference loop is one process)")
     else:
         _, info0 = env.reset()  # train.py:265,281: the buffer stores masks iff the env's info carries them
         rb = ReplayBuffer(g("buffer_size"), env.unwrapped.n_agents, env.observation_space, env.action_space, time_limit,
@@ -293,7 +328,9 @@ def main(env, eval_env, logger, time_limit, **cfg):
         if vectorised:
             train = step > g("training_start") and trainer.rounds * N >= g("batch_size")
             trainer.round(eps_sched(step), train=train)
-            step = int(trainer.env_steps.item())  # one host sync per round (N episodes)
+            # one host sync per round (N episodes); N > 1 ranks: the whole job's env-steps, the same number on every rank - it drives
+            # the epsilon schedule, the training start and the loop's end, so all ranks issue the same collectives
+            step = int(all_sum(dist, trainer.env_steps.clone()).item())
             if train:
                 updates += trainer.U
                 metrics = {"loss": float(trainer.last_loss[0].item())}
@@ -313,13 +350,15 @@ def main(env, eval_env, logger, time_limit, **cfg):
             if metrics:
                 infos.append(metrics)
             infos.append({"updates": updates, "environment_steps": step, "epsilon": eps_sched(step)})
-            logger.log_metrics(infos)
+            if rank == 0:
+                logger.log_metrics(infos)
             last_eval = step
         if g("video_interval"):
             raise NotImplementedError("video recording is outside the HIP hot path")
         if g("save_interval") and (step - last_save) >= g("save_interval"):
-            Path("checkpoints").mkdir(exist_ok=True)
-            torch.save(model.state_dict(), f"checkpoints/model_s{step}.pt")
+            if rank == 0:
+                Path("checkpoints").mkdir(exist_ok=True)
+                torch.save(model.state_dict(), f"checkpoints/model_s{step}.pt")
             last_save = step
     env.close()
     return model

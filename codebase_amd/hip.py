@@ -327,6 +327,37 @@ def _clip_step(opt, n_tensor, params, grad, s1, s2, target, step, lr, betas, eps
                                         float(grad_scale), int(bool(hard)), float(tau), _ptr(scratch), _ptr(gnorm), _stream()), what)
 
 
+# the library's callbacks into the host's collective (include/marlhip.h: marlhip_exchange_fn / marlhip_exchange_f64_fn)
+EXCHANGE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p)
+
+
+class Exchange:
+    """a ctypes callback that all-reduces (SUM) ONE known device tensor through `reduce(tensor)` - torch.distributed.all_reduce on the
+    current stream (backend nccl == RCCL over xGMI; gloo in the tests).  An exception inside the callback is kept and re-raised by
+    `check()` after the library call returned (ctypes swallows exceptions in callbacks)."""
+
+    def __init__(self, tensor, reduce):
+        self.tensor, self.reduce, self.error = tensor, reduce, None
+
+        def cb(ctx, buf, count, stream):
+            try:
+                if buf != self.tensor.data_ptr() or count != self.tensor.numel():
+                    raise MarlHipError(f"exchange: the library handed over {count} elements at {buf:#x}, expected the registered tensor")
+                self.reduce(self.tensor)
+                return 0
+            except BaseException as e:  # noqa: BLE001 - must not propagate through the C frames
+                self.error = e
+                return -1
+
+        self._cb = EXCHANGE_FN(cb)
+        self.ptr = ctypes.cast(self._cb, ctypes.c_void_p)
+
+    def check(self):
+        if self.error is not None:
+            e, self.error = self.error, None
+            raise e
+
+
 class RunningReturnStats:
     """RunningMeanStd of marlbase/utils/standardise_stream.py, resident on the device: shape (n_agents,) for the independent
     learner; for VDNetwork / QMixNetwork `columns` = batch size - their RunningMeanStd(shape=(1,)) turns into one (mean, var) per
@@ -337,13 +368,26 @@ class RunningReturnStats:
         self.mean = torch.zeros(n, dtype=torch.float32, device=device)
         self.var = torch.ones(n, dtype=torch.float32, device=device)
         self.count_t = torch.full((1,), epsilon, dtype=torch.float64, device=device)
+        self.exchange = None
 
     @property
     def count(self):
         return float(self.count_t.item())
 
+    def attach_exchange(self, reduce):
+        """data-parallel training: the batch moments of the per-agent statistics are summed over the ranks (`reduce(tensor)` = an
+        all-reduce SUM in place) before the running update, so every rank keeps the statistics of the GLOBAL batch
+        (standardise_stream.py:15-20 on the concatenated batch).  Per-batch-column statistics stay local (marlhip_ret_stats)."""
+        if self.columns == 0 and reduce is not None:
+            self.moments = torch.zeros(2 * self.mean.numel() + 1, dtype=torch.float64, device=self.mean.device)
+            self.exchange = Exchange(self.moments, reduce)
+        return self
+
     def c(self):
-        return RetStatsStruct(self.mean.data_ptr(), self.var.data_ptr(), self.count_t.data_ptr(), self.columns)
+        st = RetStatsStruct(self.mean.data_ptr(), self.var.data_ptr(), self.count_t.data_ptr(), self.columns)
+        if self.exchange is not None:
+            st.exchange, st.moments = self.exchange.ptr, self.moments.data_ptr()
+        return st
 
 
 class DqnUpdater:
@@ -595,6 +639,13 @@ class AcUpdater:
         self.step = 0
         self._ws = {}
 
+    def attach_exchange(self, reduce):
+        """data-parallel training with standardise_returns: batch moments summed over the ranks (marlhip_ac_config.ret_exchange)"""
+        if self.ret_stats is not None and reduce is not None:
+            self.ret_stats.attach_exchange(reduce)
+            self.cfg.ret_exchange = self.ret_stats.exchange.ptr
+            self.cfg.ret_moments = self.ret_stats.moments.data_ptr()
+
     def _workspace(self, T, B):
         if (T, B) not in self._ws:
             s = self.spec.c()
@@ -683,14 +734,26 @@ class FusedLearner:
             target_update_interval_or_tau=float(target_update_interval_or_tau))
         self._keep = (outs, ws)
 
-    def run(self, n_updates, length, seed, counter0, updates, last_target_update):
-        """returns the advanced (updates, last_target_update); the Adam step lives in the DqnUpdater"""
+    def run(self, n_updates, length, seed, counter0, updates, last_target_update, grad_sync=None, world=1):
+        """returns the advanced (updates, last_target_update); the Adam step lives in the DqnUpdater.  `grad_sync(grad)` (an
+        in-place all-reduce SUM over `world` ranks): the data-parallel form, marlhip_idqn_update_n_dist - the loop over the updates
+        stays in the library, the exchange is its only host hop, clip + Adam take 1 / world and the post-reduce norm."""
         step = ctypes.c_int64(self.up.step)
         upd = ctypes.c_int64(int(updates))
         last = ctypes.c_int64(int(last_target_update))
-        check(lib.marlhip_idqn_update_n(ctypes.byref(self.c), int(n_updates), int(length), int(seed) & (2**64 - 1),
-                                        int(counter0) & 0xFFFFFFFF, ctypes.byref(step), ctypes.byref(upd), ctypes.byref(last),
-                                        _stream()), "idqn_update_n")
+        if grad_sync is None:
+            check(lib.marlhip_idqn_update_n(ctypes.byref(self.c), int(n_updates), int(length), int(seed) & (2**64 - 1),
+                                            int(counter0) & 0xFFFFFFFF, ctypes.byref(step), ctypes.byref(upd), ctypes.byref(last),
+                                            _stream()), "idqn_update_n")
+        else:
+            ex = getattr(self, "_exchange", None)
+            if ex is None or ex.reduce is not grad_sync:
+                ex = self._exchange = Exchange(self.up.grad, grad_sync)
+            rc = lib.marlhip_idqn_update_n_dist(ctypes.byref(self.c), int(n_updates), int(length), int(seed) & (2**64 - 1),
+                                                int(counter0) & 0xFFFFFFFF, ctypes.byref(step), ctypes.byref(upd), ctypes.byref(last),
+                                                ex.ptr, None, int(world), _stream())
+            ex.check()
+            check(rc, "idqn_update_n_dist")
         self.up.step = step.value
         return upd.value, last.value
 

@@ -39,6 +39,30 @@ def rank_sample_seed(seed, rank):
     return (int(seed) + 7919 * int(rank)) & (2**64 - 1)
 
 
+def setup_device(local_rank):
+    """one process per GPU: bind this process to its device before anything allocates (LOCAL_RANK of torchrun)"""
+    if torch.cuda.is_available() and not os.environ.get("MARLHIP_ONE_DEVICE"):  # MARLHIP_ONE_DEVICE: N ranks share device 0 (1-GPU test boxes)
+        torch.cuda.set_device(int(local_rank) % max(torch.cuda.device_count(), 1))
+
+
+def all_sum(dist, t):
+    """in-place all-reduce(SUM) of a tensor; identity on one process"""
+    if dist is not None:
+        dist.all_reduce(t)
+    return t
+
+
+def gather_stack(dist, t):
+    """[world, *t.shape]: every rank's `t` (same shape everywhere), on every rank.  Built from all-reduce(SUM) of a zero-padded
+    stack, the one collective every backend offers for device tensors (gloo has no device all_gather)."""
+    if dist is None:
+        return t.unsqueeze(0)
+    out = torch.zeros((dist.get_world_size(),) + tuple(t.shape), dtype=t.dtype, device=t.device)
+    out[dist.get_rank()] = t
+    dist.all_reduce(out)
+    return out
+
+
 class GradSync:
     """all-reduce(SUM) of the flat gradient; `scale` is what clip+Adam must multiply by (1/world)."""
 

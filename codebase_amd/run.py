@@ -5,6 +5,15 @@
 
 Same sequence as the reference: logger, env, eval_env (parallel_envs dropped), seeding of torch and
 numpy (python `random` left unseeded, as there), then the algorithm's `_target_`.
+
+Multi-GPU (the reference is one process): the same command line under torchrun,
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 -m codebase_amd.run +algorithm=idqn \
+        env.name=... env.parallel_envs=4096
+
+is the sharded drop-in: one process per GPU (LOCAL_RANK picks the device), env.parallel_envs batched envs and a replay shard PER
+RANK with their own Philox streams (`parallel.rank_env_seed`), identical initial weights from `seed`, one RCCL all-reduce of the
+flat gradient per update inside the algorithm's `main`, rank 0 logging / saving with whole-job step counts and gathered returns.
 """
 import logging
 import os
@@ -29,10 +38,23 @@ def main(argv=None):
     if out:
         os.makedirs(out, exist_ok=True)
         os.chdir(out)  # hydra.job.chdir: True (configs/default.yaml:14-15)
-    logger = C.instantiate(cfg.logger, cfg=cfg)
-    env = C.call(cfg.env, seed=cfg.seed)
+    from .parallel import init_distributed, rank_env_seed, setup_device
+
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world > 1:  # torchrun: bind the device first, then rendezvous (backend nccl == RCCL; MARLHIP_DIST_BACKEND=gloo for 1-GPU test boxes)
+        setup_device(os.environ.get("LOCAL_RANK", 0))
+    dist, rank, world, _ = init_distributed(os.environ.get("MARLHIP_DIST_BACKEND"))
+    if rank == 0:
+        logger = C.instantiate(cfg.logger, cfg=cfg)
+    else:  # ranks > 0 keep the interface (watch / info / ...) but write no results.csv; the algorithm logs on rank 0 only
+        from .utils.loggers import Logger
+
+        logger = Logger(cfg=cfg)
+        logging.getLogger().setLevel(logging.WARNING)
+    env_seed = cfg.seed if dist is None or cfg.seed is None else rank_env_seed(cfg.seed, rank)  # a rank's env shard has its own stream
+    env = C.call(cfg.env, seed=env_seed)
     eval_cfg = C.to_cfg({k: v for k, v in cfg.env.items() if k != "parallel_envs"})
-    eval_env = C.call(eval_cfg, seed=cfg.seed) if not cfg.env.get("parallel_envs") else None
+    eval_env = C.call(eval_cfg, seed=env_seed) if not cfg.env.get("parallel_envs") else None
     torch.set_num_threads(1)
     if cfg.seed is not None:
         torch.manual_seed(cfg.seed)
@@ -41,7 +63,11 @@ def main(argv=None):
         logger.warning("No seed has been set.")
     assert cfg.env.time_limit is not None, "Time limit must be set."
     C.call(cfg.algorithm, env, eval_env, logger, time_limit=cfg.env.time_limit)
-    return logger.get_state()
+    state = logger.get_state()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    return state
 
 
 if __name__ == "__main__":

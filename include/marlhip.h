@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MARLHIP_VERSION 207
+#define MARLHIP_VERSION 208
 
 int marlhip_version(void);
 const char* marlhip_last_error(void);
@@ -508,6 +508,11 @@ typedef struct marlhip_ac_config {
                                    critics' sequence passes are enqueued on it next to the actors' on the call's stream (fork /
                                    join through events inside the call; everything is joined back before the call returns).
                                    NULL: one stream, no overlap, same results. */
+    /* data-parallel training with standardise_returns (C-ABI 208): the batch moments summed over the ranks before the running
+     * statistics move - the marlhip_ret_stats fields of the same names (declared further down); all NULL: single process */
+    int (*ret_exchange)(void* ctx, double* buf, int64_t count, void* stream);
+    void* ret_exchange_ctx;
+    double* ret_moments;        /* [2P + 1] device scratch */
 } marlhip_ac_config;
 
 int marlhip_ac_critic_nparams(const marlhip_net_shape* s, int32_t centralised); /* per critic block */
@@ -566,6 +571,20 @@ int marlhip_idqn_update_n(const marlhip_idqn_learner* L, int32_t n_updates, int3
                           uint32_t counter0, int64_t* adam_step, int64_t* updates, int64_t* last_target_update,
                           void* stream);
 
+/* Data-parallel form of marlhip_idqn_update_n (C-ABI 208; SURVEY.md 8e - the reference is one process and has no counterpart): one
+ * process per GPU, envs and replay sharded, weights replicated, and per update ONE exchange of the flat gradient.  After the
+ * gradient reduce of every update the library calls `exchange(ctx, grad, count, stream)` - the only host hop of the update - which
+ * must leave the SUM over all ranks in `grad` (count floats, device memory), ordered on `stream` after the kernels already enqueued
+ * there and before the next ones: an ncclAllReduce(grad, grad, count, ncclFloat, ncclSum, comm, stream) of RCCL, or
+ * torch.distributed.all_reduce issued while `stream` is torch's current stream.  Return 0, anything else aborts the call.  Clip + Adam
+ * then run on every rank with grad_scale = 1 / world on the identical reduced gradient, the clip norm taken from the REDUCED gradient
+ * (clip_grad_norm_ over the global batch, marlbase/dqn/model.py:170), so the replicas stay bitwise in step without a weight
+ * broadcast.  Hidden-64 IDQN / VDN: 3 launches per update (loss/grad, reduce, [exchange], clip + Adam + target + next packs). */
+typedef int (*marlhip_exchange_fn)(void* ctx, float* grad, int64_t count, void* stream);
+int marlhip_idqn_update_n_dist(const marlhip_idqn_learner* L, int32_t n_updates, int32_t length, uint64_t seed,
+                               uint32_t counter0, int64_t* adam_step, int64_t* updates, int64_t* last_target_update,
+                               marlhip_exchange_fn exchange, void* exchange_ctx, int32_t world, void* stream);
+
 /* cfg.standardise_returns (QNetwork._compute_loss, model.py:146-158; RunningMeanStd, marlbase/utils/standardise_stream.py):
  * device-resident running statistics, one (mean, var) pair per agent and the shared count (initialise mean 0, var 1,
  * count 1e-4).  Each call de-standardises the bootstrap values with the CURRENT statistics, updates them with all T*B
@@ -575,11 +594,22 @@ int marlhip_idqn_update_n(const marlhip_idqn_learner* L, int32_t n_updates, int3
  * returns: `update` takes the moments over dim 0 and broadcasts the (1,)-shaped state against the [B] results, so from the first
  * update on the state is ONE (mean, var) PER BATCH COLUMN, updated with T samples per call (count += T).  Reproduced as is:
  * columns = B, mean / var [B] (initialise mean 0, var 1, count 1e-4); the batch size is then fixed for the run, as it is there. */
+/* Data-parallel training (C-ABI 208): with one process per GPU the batch moments of the per-agent statistics have to be those of the
+ * GLOBAL batch, or each rank's RunningMeanStd drifts apart while the parameters stay equal (standardise_stream.py:15-20 on the
+ * concatenated batch).  When `exchange` is set the library folds the local batch into `moments` = {sum_p, sum of squares_p}[P], n
+ * (2P + 1 doubles, device memory of the caller), calls exchange(ctx, moments, 2P + 1, stream) - which must leave the SUM over all
+ * ranks there, ordered on `stream` like marlhip_exchange_fn - and updates (mean, var, count) from the global moments, identically
+ * on every rank.  NULL: single process, the local batch is the batch.  Per-batch-column statistics (columns > 0) are never
+ * exchanged: a rank's columns are its own part of the global batch. */
+typedef int (*marlhip_exchange_f64_fn)(void* ctx, double* buf, int64_t count, void* stream);
 typedef struct marlhip_ret_stats {
     float* mean;     /* [P]; per-column statistics: [columns] */
     float* var;      /* [P]; per-column statistics: [columns] */
     double* count;   /* [1] */
     int32_t columns; /* 0: one pair per agent (QNetwork); B: one pair per batch column (VDNetwork, QMixNetwork) */
+    marlhip_exchange_f64_fn exchange; /* NULL: single process */
+    void* exchange_ctx;
+    double* moments; /* [2P + 1] device scratch, needed when `exchange` is set */
 } marlhip_ret_stats;
 
 /* mode: 0 = IDQN (QNetwork, stats->columns = 0), 1 = VDN (VDNetwork, stats->columns = batch).  QMIX takes its statistics through

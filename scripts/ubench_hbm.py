@@ -1,5 +1,6 @@
 """HBM-bound kernels at sizes that leave the caches (SURVEY.md 8d "scaled run"): batched env step at
-2^20 envs, replay sample-gather of 65,536 episodes from a 1.25 x 2^20-episode (4.5 GB) replay, replay add.
+2^22 envs (750 MB of state + outputs per step: past the 256 MB Infinity Cache, which 2^20 envs = 187 MB were not - argv[1] overrides),
+the 8-player step kernel at 2^19 envs (720 MB), replay sample-gather of 65,536 episodes from a 1.25 x 2^20-episode (4.5 GB) replay, replay add.
 Prints one JSON object: achieved GB/s = algorithmic bytes / measured time, against 8 TB/s."""
 import json
 import os
@@ -29,16 +30,30 @@ def timed(fn, iters):
 
 
 out = {}
+
+
+def step_row(name, n):
+    cfg = h.lbf_config(name, n, 0, seed=1)  # no time limit: envs keep stepping
+    env = h.BatchedForaging(cfg)
+    env.reset()
+    acts = torch.randint(0, 6, (env.P, n), dtype=torch.int32, device="cuda")
+    dt = timed(lambda: env.step(acts), 20)
+    per = 2 * env.stride + 4 * env.P + 4 * env.P * env.D + 4 * env.P + 2
+    row = dict(env=name.split(":")[-1], n_envs=n, bytes_per_env_step=per, working_set_MB=per * n / 1e6, us=dt * 1e6, env_steps_per_s=n / dt,
+               achieved_GBs=per * n / dt / 1e9, frac_of_8TBs=per * n / dt / 1e9 / PEAK)
+    return row, env, acts
+
+
+N_BIG = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 22
+out["lbf_step_kernel"], env, acts = step_row(NAME, N_BIG)
+del env, acts
+torch.cuda.empty_cache()
+out["lbf_step_kernel_8p5f"], env, acts = step_row("lbforaging:Foraging-15x15-8p-5f-v3", 1 << 19)
+del env, acts
+torch.cuda.empty_cache()
 N = 1 << 20
-cfg = h.lbf_config(NAME, N, 0, seed=1)  # no time limit: envs keep stepping
-env = h.BatchedForaging(cfg)
-env.reset()
+out["lbf_step_kernel_2e20_cache_resident"], env, acts = step_row(NAME, N)  # the round-1/2 figure: 187 MB, inside the Infinity Cache
 P, D = env.P, env.D
-acts = torch.randint(0, 6, (P, N), dtype=torch.int32, device="cuda")
-dt = timed(lambda: env.step(acts), 20)
-per = 2 * env.stride + 4 * P + 4 * P * D + 4 * P + 2
-out["lbf_step_kernel"] = dict(n_envs=N, bytes_per_env_step=per, us=dt * 1e6, env_steps_per_s=N / dt,
-                              achieved_GBs=per * N / dt / 1e9, frac_of_8TBs=per * N / dt / 1e9 / PEAK)
 
 T, CAP, B = 25, 1310720, 65536  # 1.25 x 2^20 episodes = 4.5 GB of replay (>= 4 GB)
 rb = h.DeviceReplay(CAP, P, D, T)

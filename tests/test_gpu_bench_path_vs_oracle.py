@@ -1,0 +1,128 @@
+"""The exact code path `bench.py` times, against the ORACLE (not against another HIP path).
+
+`marlhip_idqn_update_n` (codebase_amd.hip.FusedLearner) = in-library Philox index draw -> in-kernel replay gather -> loss/grad ->
+reduce + clip-norm partials -> clip + Adam + target update + next MFMA packs, n updates per host call.  Here the right-hand side of
+every comparison is `oracle/dqn_port.Learner` (the torch-CPU restatement of QNetwork.update, marlbase/dqn/model.py:118-196, itself
+pinned to the reference's goldens by tests/test_oracle_learner.py) fed with the batches the kernel must have gathered: the index
+draws are reproduced on the host with `oracle/philox.py`, the episodes are taken from a host copy of the replay arrays.
+
+Cases: the driver line's configuration (B = 4096, lr 3e-3, Polyak tau 0.1), the golden's (B = 32, lr 3e-4, hard target copy), and
+VDN's fused path (mode 1).  Tolerances are those of test_gpu_parity.test_update_sequence_matches_reference_golden (loss 1e-5
+relative - 2e-5 there -, parameters / targets 3e-6 absolute AT lr 3e-4; an Adam step is proportional to lr, so at lr 3e-3 the same
+relative agreement is 3e-5 absolute; moments rtol 1e-3)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import dqn_port as dp
+from oracle.philox import STREAM_SAMPLE, bounded_nr, philox4x32_10
+
+DEV = "cuda"
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def philox_indices(seed, counter, batch, length):
+    """the library's sample-index stream (csrc/philox.h sample_index; oracle/philox.py stream 2)"""
+    key = (seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    words = [philox4x32_10((blk, counter, 0, STREAM_SAMPLE), key) for blk in range((batch + 3) // 4)]
+    return np.array([bounded_nr(words[i >> 2][i & 3], length) for i in range(batch)], dtype=np.int64)
+
+
+def lbf_like_replay(cap, P, D, T, A, seed):
+    """host arrays in the DeviceReplay layout: integer-valued observations like LBF's, sparse rewards, ragged episode lengths with
+    `done` at the last stored step and the stale-tail pattern the ring leaves (filled prefix only)"""
+    g = torch.Generator().manual_seed(seed)
+    obs = torch.randint(-1, 8, (cap, P, T + 1, D), generator=g).float()
+    act = torch.randint(0, A, (cap, P, T), generator=g).to(torch.uint8)
+    rew = (torch.rand(cap, P, T, generator=g) * (torch.rand(cap, P, T, generator=g) < 0.2)).float()
+    ln = torch.randint(1, T + 1, (cap,), generator=g)
+    t = torch.arange(T + 1)[None, :]
+    done = (t == ln[:, None]).to(torch.uint8)
+    filled = (t[:, :T] < ln[:, None]).to(torch.uint8)
+    return dict(obs=obs, act=act, rew=rew, done=done, filled=filled)
+
+
+def host_batch(host, idx):
+    """ReplayBuffer.sample's Batch (dqn/train.py:94-124) of the episodes `idx` from the host copy"""
+    i = torch.as_tensor(idx)
+    return dict(obss=host["obs"][i].permute(1, 2, 0, 3).contiguous(), actions=host["act"][i].permute(1, 2, 0).long().contiguous(),
+                rewards=host["rew"][i].permute(1, 2, 0).contiguous(), dones=host["done"][i].T.float().contiguous(),
+                filled=host["filled"][i].T.float().contiguous())
+
+
+def to_device(h, rb, host):
+    for k, t in (("obs", rb.obs), ("act", rb.act), ("rew", rb.rew), ("done", rb.done), ("filled", rb.filled)):
+        t.copy_(host[k])
+
+
+def run_case(mode, P, D, H, A, T, B, cap, lr, tui, n_calls, per_call, params0, target0, seed=1234, grad_clip=1.0, atol=3e-6):
+    from codebase_amd import hip as h
+
+    spec = h.NetSpec(P, D, H, A)
+    host = lbf_like_replay(cap, P, D, T, A, seed=seed + 1)
+    rb = h.DeviceReplay(cap, P, D, T)
+    to_device(h, rb, host)
+    params, target = params0.clone().to(DEV), target0.clone().to(DEV)
+    up = h.DqnUpdater(spec, params, target, lr=lr, gamma=0.99, grad_clip=grad_clip, double_q=True)
+    fl = h.FusedLearner(up, rb, B, tui, mode=mode)
+    port = dp.Learner(params0.clone(), D, H, A, lr=lr, gamma=0.99, grad_clip=grad_clip, double_q=True,
+                      target_update_interval_or_tau=tui, mode="vdn" if mode == 1 else "idqn")
+    port.target = target0.clone()
+    upd = last = counter = 0
+    for call in range(n_calls):
+        n = per_call[call]
+        upd, last = fl.run(n, cap, seed, counter, upd, last)
+        torch.cuda.synchronize()
+        for u in range(n):
+            idx = philox_indices(seed, counter + u, B, cap)
+            m = port.update(host_batch(host, idx))
+        counter += n
+        # the library leaves the indices of its LAST draw: the host restatement of the stream is the one the kernel used
+        np.testing.assert_array_equal(rb._outputs(B)[5].cpu().numpy(), idx)
+        got = up.loss.cpu().numpy()
+        assert abs(got[0] - m["loss"]) <= 1e-5 * abs(m["loss"]), (call, got, m)
+        assert got[1] == float(host["filled"][torch.as_tensor(idx)].sum())
+        assert abs(up.gnorm.item() - m["grad_norm"]) <= 1e-4 * m["grad_norm"], (up.gnorm.item(), m["grad_norm"])
+        np.testing.assert_allclose(params.cpu().numpy(), port.flat().detach().numpy(), rtol=0, atol=atol, err_msg=f"params after call {call}")
+        np.testing.assert_allclose(target.cpu().numpy(), port.target.numpy(), rtol=0, atol=atol, err_msg=f"target after call {call}")
+        assert (upd, last, up.step) == (port.updates, port.last_target_update, port.updates)
+    st = port.opt.state
+    per = len(port.tensors) // P
+    m_ref = torch.stack([torch.cat([st[t]["exp_avg"].reshape(-1) for t in port.tensors[p * per:(p + 1) * per]]) for p in range(P)])
+    v_ref = torch.stack([torch.cat([st[t]["exp_avg_sq"].reshape(-1) for t in port.tensors[p * per:(p + 1) * per]]) for p in range(P)])
+    np.testing.assert_allclose(up.exp_avg.cpu().numpy(), m_ref.numpy(), rtol=1e-3, atol=1e-7)
+    np.testing.assert_allclose(up.exp_avg_sq.cpu().numpy(), v_ref.numpy(), rtol=1e-3, atol=1e-10)
+
+
+def _perturbed(P, D, H, A, seed):
+    g = torch.Generator().manual_seed(seed + 100)
+    return dp.init_params(P, D, H, A, seed=seed) + 0.05 * torch.randn(P, dp.nparams(D, H, A), generator=g)
+
+
+def test_bench_configuration_B4096_lr3e3_polyak_vs_oracle_port():
+    """BENCH line: IDQN 8x8-2p-3f shapes, B = 4096 of a two-round replay, lr 3e-3, Polyak 0.1; 1 + 3 updates (the second call
+    keeps the MFMA packs adam_pack_kernel wrote across its updates)"""
+    P, D, H, A, T = 2, 15, 64, 6, 25
+    run_case(0, P, D, H, A, T, B=4096, cap=8192, lr=3e-3, tui=0.1, n_calls=2, per_call=(1, 3),
+             params0=_perturbed(P, D, H, A, 1), target0=_perturbed(P, D, H, A, 3), atol=3e-5)
+
+
+def test_golden_configuration_B32_hard_target_copy_vs_oracle_port():
+    """the golden's hyper-parameters (lr 3e-4, clip 1.0, hard target copy) from the golden's own initial blocks; interval 2 so that
+    the copy happens inside a call (update 2 and 4) and adam_pack_kernel has to rewrite the target packs"""
+    g = np.load(os.path.join(G, "learner_H64.npz"))
+    P, D, H, A, T = int(g["P"]), int(g["D"]), 64, int(g["A"]), 25
+    run_case(0, P, D, H, A, T, B=32, cap=96, lr=3e-4, tui=2, n_calls=2, per_call=(3, 2),
+             params0=torch.tensor(g["params0"]), target0=torch.tensor(g["target0"]), atol=3e-6)
+
+
+@pytest.mark.parametrize("B,lr,tui,atol", [(4096, 3e-3, 0.1, 3e-5), (32, 3e-4, 2, 3e-6)])
+def test_vdn_fused_path_vs_oracle_port(B, lr, tui, atol):
+    """mode 1 (VDNetwork._compute_loss, dqn/model.py:224-269) through the same n-updates call: 4 agents on 15x15-4p-5f shapes"""
+    P, D, H, A, T = 4, 27, 64, 6, 25
+    run_case(1, P, D, H, A, T, B=B, cap=2 * B + 32, lr=lr, tui=tui, n_calls=2, per_call=(1, 3),
+             params0=_perturbed(P, D, H, A, 5), target0=_perturbed(P, D, H, A, 7), atol=atol)

@@ -38,4 +38,6 @@ def test_exponent_literals_are_numbers():
     assert a.target_update_interval_or_tau == 0.01 and a.eps_end == 0.05 and a.lr == 3e-4
     assert a.model.layers == [64, 64] and cfg.seed == 3 and isinstance(cfg.seed, int)
     assert cfg.env.name == "lbforaging:Foraging-8x8-2p-3f-v3"      # strings that merely contain digits stay strings
-    assert C._numbers({"a": ["1e3", "x1e3", "-2E-2", "7", "1.5", "v3"]}) == {"a": [1000.0, "x1e3", -0.02, 7, 1.5, "v3"]}
+    # only the YAML-1.1 gap is re-typed (exponent form without a dot, which safe_load leaves a string); what safe_load hands over as a
+    # string otherwise was QUOTED in the file ("7", "1.5", "007") and stays a string, as it does under OmegaConf
+    assert C._numbers({"a": ["1e3", "x1e3", "-2E-2", "7", "1.5", "007", "v3", 7, 1.5]}) == {"a": [1000.0, "x1e3", -0.02, "7", "1.5", "007", "v3", 7, 1.5]}

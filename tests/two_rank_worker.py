@@ -34,16 +34,31 @@ def main():
     obs_space, act_space = _space_pair(cfg)
     hyper = dict(optimizer="Adam", lr=3e-4, gamma=0.99, grad_clip=1.0, double_q=True, standardise_returns=False,
                  target_update_interval_or_tau=3)
-    for cls, extra in ((QNetwork, ()), (QMixNetwork, (dict(embed_dim=64, hypernet_layers=2, hypernet_embed=32),))):
+    # (class, extra constructor arguments, hidden width, standardise_returns): hidden-64 IDQN takes the library's n-updates call in its
+    # data-parallel form (marlhip_idqn_update_n_dist: reduce -> exchange -> clip + Adam + packs), hidden 128 the same call's generic
+    # loop, QMIX and standardise_returns the per-update host loop
+    cases = ((QNetwork, (), 64, False), (QNetwork, (), 128, False), (QNetwork, (), 64, True),
+             (QMixNetwork, (dict(embed_dim=64, hypernet_layers=2, hypernet_embed=32),), 64, False))
+    for cls, extra, hidden, std in cases:
         torch.manual_seed(1)
-        model = cls(obs_space, act_space, hyper, [64, 64], False, False, True, *extra, "cuda")
+        model = cls(obs_space, act_space, dict(hyper, standardise_returns=std), [hidden, hidden], False, False, True, *extra, "cuda")
         tr = VectorisedIDQN(cfg, model, 2 * N, T, 64, 4, seed=3, dist=dist)
         for r in range(3):
             tr.round(0.3)
         torch.cuda.synchronize()
+        assert (tr._fused is not None) == (cls is QNetwork and not std), "which cases take the n-updates library call changed"
+        assert model.updates == 12 and model.updater.step == 12
         for name in ("params", "target_params"):
             same_on_all_ranks(getattr(model, name), f"{cls.__name__}.{name}")
         same_on_all_ranks(model.updater.exp_avg_sq, f"{cls.__name__} Adam moments")
+        same_on_all_ranks(model.updater.gnorm, f"{cls.__name__} clip norm (taken from the REDUCED gradient)")
+        assert not torch.equal(model.params, model.target_params)
+        if std:  # RunningMeanStd moved by the GLOBAL batch moments: the same (mean, var, count) on every rank
+            st = model.ret_ms
+            same_on_all_ranks(st.mean, "return statistics mean")
+            same_on_all_ranks(st.var, "return statistics var")
+            assert abs(st.count - (1e-4 + 12 * world * T * 64)) < 1e-6, st.count  # every update adds world * T * B entries per agent
+            assert float(st.var.min()) > 0 and not torch.equal(st.mean, torch.zeros_like(st.mean))
         if cls is QMixNetwork:
             same_on_all_ranks(model.mixer_params, "mixer")
             same_on_all_ranks(model.target_mixer_params, "target mixer")
@@ -56,7 +71,7 @@ def main():
     torch.manual_seed(1)
     net = dict(layers=[64, 64], parameter_sharing=False, use_orthogonal_init=True, use_rnn=False)
     ac_hyper = dict(optimizer="Adam", lr=3e-4, gamma=0.99, grad_clip=0.5, n_steps=5, entropy_coef=0.01, value_loss_coef=0.5,
-                    standardise_returns=False, target_update_interval_or_tau=200)
+                    standardise_returns=True, target_update_interval_or_tau=200)
     cfg2 = h.lbf_config("lbforaging:Foraging-8x8-2p-3f-v3", N, T, seed=rank_env_seed(7, rank))
     ac = A2CNetwork(obs_space, act_space, ac_hyper, net, dict(net, centralised=False), "cuda")
     P, D = 2, 15
@@ -65,12 +80,16 @@ def main():
                 f=torch.empty(T, N, device="cuda"))
     fr, fl, tm = torch.zeros(P, N, device="cuda"), torch.zeros(N, dtype=torch.int32, device="cuda"), torch.zeros(1, dtype=torch.int32, device="cuda")
     sync = GradSync(dist)
+    ac.updater.attach_exchange(lambda t: dist.all_reduce(t))  # what ac.train.main does under torchrun
     for r in range(3):
         h.ac_collect(cfg2, ac.spec, ac.actor_params, r, T, False, bufs["o"], bufs["a"], bufs["r"], bufs["d"], bufs["f"], fr, fl, tm)
         ac.update_async(Batch(bufs["o"], bufs["a"], bufs["r"], bufs["d"].float(), bufs["f"], None), r * 200, grad_sync=sync, world=world)
     torch.cuda.synchronize()
     same_on_all_ranks(ac.block, "A2C actor|critic block")
     same_on_all_ranks(ac.target_critic_params, "A2C target critic")
+    same_on_all_ranks(ac.updater.ret_stats.mean, "A2C return statistics mean")
+    same_on_all_ranks(ac.updater.ret_stats.var, "A2C return statistics var")
+    assert abs(ac.updater.ret_stats.count - (1e-4 + 3 * world * T * N)) < 1e-6
     dist.barrier()
     if rank == 0:
         print("TWO_RANK_OK")
