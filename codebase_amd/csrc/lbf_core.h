@@ -287,7 +287,16 @@ struct LbfObs {
 
 template <int P, int F>
 MARL_HD void lbf_observe(const LbfParams& q, const LbfState<P, F>& s, int p, LbfObs<P, F>& o) {
-    const int cr = s.pr[p], cc = s.pc[p];
+    // `p` is a run-time value in the agent-per-wave collectors: s.pr[p] would be a dynamically indexed private array, i.e. the whole
+    // state mirrored in scratch memory; a select chain over compile-time indices keeps it in registers (and folds when p is constant)
+    int cr = 0, cc = 0, cl = 0;
+#pragma unroll
+    for (int a = 0; a < P; ++a) {
+        const bool me = a == p;
+        cr = me ? s.pr[a] : cr;
+        cc = me ? s.pc[a] : cc;
+        cl = me ? s.pl[a] : cl;
+    }
     const int offr = imin(q.sight, cr) - cr, offc = imin(q.sight, cc) - cc;
 #pragma unroll
     for (int i = 0; i < F + P; ++i) { o.v[3 * i] = -1.f; o.v[3 * i + 1] = -1.f; o.v[3 * i + 2] = 0.f; }
@@ -307,7 +316,7 @@ MARL_HD void lbf_observe(const LbfParams& q, const LbfState<P, F>& s, int p, Lbf
         n += vis ? 1 : 0;
     }
     // self first
-    o.v[3 * F] = (float)(cr + offr); o.v[3 * F + 1] = (float)(cc + offc); o.v[3 * F + 2] = (float)s.pl[p];
+    o.v[3 * F] = (float)(cr + offr); o.v[3 * F + 1] = (float)(cc + offc); o.v[3 * F + 2] = (float)cl;
     int m = 1;
 #pragma unroll
     for (int a = 0; a < P; ++a) {

@@ -325,13 +325,24 @@ MARL_HD void rw_step(const RwParams& q, RwState<P>& s, const RwGrid& grid, const
     done = (q.max_inactivity_steps > 0 && s.inactive >= q.max_inactivity_steps) || (q.max_steps > 0 && s.steps >= q.max_steps);
 }
 
+// arr[p] for a RUN-TIME agent index (the agent-per-wave collectors): a select chain over compile-time indices - a dynamically
+// indexed private array would move the whole agent state into scratch memory; folds to arr[p] when p is a constant
+template <int P>
+MARL_HD int rw_pick(const int (&arr)[P], int p) {
+    int v = 0;
+#pragma unroll
+    for (int k = 0; k < P; ++k) v = k == p ? arr[k] : v;
+    return v;
+}
+
 // agent p's 3x3 sensor window, one code per cell (row-major): bit0 agent present, bits1-2 its direction, bit3 shelf,
 // bit4 shelf requested; cells off the grid read as empty (np.pad with zeros)
 template <int P>
 MARL_HD void rw_window(const RwParams& q, const RwState<P>& s, const RwGrid& grid, int p, int (&code)[9]) {
+    const int px = rw_pick<P>(s.ax, p), py = rw_pick<P>(s.ay, p);
 #pragma unroll
     for (int c = 0; c < 9; ++c) {
-        const int x = s.ax[p] - 1 + c % 3, y = s.ay[p] - 1 + c / 3;
+        const int x = px - 1 + c % 3, y = py - 1 + c / 3;
         int v = 0;
         if (x >= 0 && y >= 0 && x < q.cols && y < q.rows) {
             const int o = rw_agent_at(s, x, y);
@@ -377,7 +388,7 @@ struct RwRequested {
 template <int P>
 MARL_HD uint64_t rw_window_word(const RwParams& q, const RwState<P>& s, const RwGrid& grid, const RwRequested<P>& rq, int p) {
     uint64_t word = 0;
-    const int x0 = s.ax[p] - 1, y0 = s.ay[p] - 1;
+    const int x0 = rw_pick<P>(s.ax, p) - 1, y0 = rw_pick<P>(s.ay, p) - 1;
 #pragma unroll
     for (int o = 0; o < P; ++o) {
         const unsigned dx = (unsigned)(s.ax[o] - x0), dy = (unsigned)(s.ay[o] - y0);
@@ -398,7 +409,8 @@ MARL_HD uint64_t rw_window_word(const RwParams& q, const RwState<P>& s, const Rw
 template <int P>
 MARL_HD float rw_obs_elem_word(const RwParams& q, const RwState<P>& s, int p, uint64_t word, int d) {
     if (d < 8) {
-        const int v = d == 0 ? s.ax[p] : (d == 1 ? s.ay[p] : (d == 2 ? (s.ac[p] != 0) : (d == 7 ? (int)rw_is_highway(q, s.ax[p], s.ay[p]) : (s.ad[p] == d - 3))));
+        const int ax = rw_pick<P>(s.ax, p), ay = rw_pick<P>(s.ay, p);
+        const int v = d == 0 ? ax : (d == 1 ? ay : (d == 2 ? (rw_pick<P>(s.ac, p) != 0) : (d == 7 ? (int)rw_is_highway(q, ax, ay) : (rw_pick<P>(s.ad, p) == d - 3))));
         return (float)v;
     }
     const int e = d - 8, c = (e * 37) >> 8, f = e - 7 * c;  // e / 7 and e % 7 for e < 63
@@ -416,12 +428,13 @@ MARL_HD float rw_obs_elem_word(const RwParams& q, const RwState<P>& s, int p, ui
 template <int P>
 MARL_HD float rw_obs_elem(const RwParams& q, const RwState<P>& s, int p, const int (&code)[9], int d) {
     if (d < 8) {
+        const int ax = rw_pick<P>(s.ax, p), ay = rw_pick<P>(s.ay, p);
         switch (d) {
-            case 0: return (float)s.ax[p];
-            case 1: return (float)s.ay[p];
-            case 2: return s.ac[p] != 0 ? 1.f : 0.f;
-            case 7: return rw_is_highway(q, s.ax[p], s.ay[p]) ? 1.f : 0.f;
-            default: return s.ad[p] == d - 3 ? 1.f : 0.f;
+            case 0: return (float)ax;
+            case 1: return (float)ay;
+            case 2: return rw_pick<P>(s.ac, p) != 0 ? 1.f : 0.f;
+            case 7: return rw_is_highway(q, ax, ay) ? 1.f : 0.f;
+            default: return rw_pick<P>(s.ad, p) == d - 3 ? 1.f : 0.f;
         }
     }
     const int c = (d - 8) / 7, f = (d - 8) % 7;
