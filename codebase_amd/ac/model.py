@@ -20,7 +20,8 @@ import numpy as np
 import torch
 
 from .. import hip as _hip
-from ..dqn.model import _fc, _gru_layout, block_views, compiled_width, init_flat_gru_params, is_wide, pad_blocks, sharing_indices
+from ..dqn.model import (_fc, block_views, compiled_width, gru_block_views, init_flat_gru_params, is_wide, pad_blocks, pad_gru_blocks,
+                         recurrent_width, sharing_indices)
 from ..spaces import flatdim
 
 
@@ -50,11 +51,14 @@ class A2CNetwork:
         if bool(_get(critic, "use_rnn", False)) != self.recurrent:
             raise NotImplementedError("actor.use_rnn != critic.use_rnn: the recurrent step is built for recurrent actors AND critics")
         ha, hc = [int(h) for h in _get(actor, "layers")], [int(h) for h in _get(critic, "layers")]
-        if self.recurrent and (ha != hc or ha not in ([64, 64], [128, 128])):
-            raise NotImplementedError(f"use_rnn with layers actor={ha} critic={hc}: the recurrent kernels are built for [64, 64] / [128, 128]")
-        # any two-layer widths, actor and critic independently: zero-padded to one kernel width (dqn/model.py pad_blocks; > 128: the GEMM path)
-        Hk = max(compiled_width(ha), compiled_width(hc))
-        wide = is_wide(ha) or is_wide(hc)
+        # any two-layer widths, actor and critic independently: zero-padded to one kernel width (dqn/model.py pad_blocks; > 128: the GEMM path);
+        # recurrent networks likewise ([h, h] with h <= 128, actor and critic each padded onto the 64 / 128 recurrent kernels)
+        if self.recurrent:
+            Hk = max(recurrent_width(ha)[1], recurrent_width(hc)[1])
+            wide = False
+        else:
+            Hk = max(compiled_width(ha), compiled_width(hc))
+            wide = is_wide(ha) or is_wide(hc)
         if len(ha) != len(hc):
             raise NotImplementedError(f"layers actor={ha} critic={hc}: the same number of hidden layers for actor and critic")
         if wide:
@@ -86,6 +90,8 @@ class A2CNetwork:
         if self.recurrent:  # RNNNetwork inits (utils/models.py:83-94); init_flat_gru_params draws one set per call
             a0 = init_flat_gru_params(obs_dims, ha[0], act_dims, _get(actor, "use_orthogonal_init", True), sets=1)[0]
             c0 = init_flat_gru_params(cdims, hc[0], [1] * K, _get(critic, "use_orthogonal_init", True), sets=2)[0]  # critic, then the target's draws
+            a0 = pad_gru_blocks(a0, obs_dims[0], ha[0], act_dims[0], Hk)
+            c0 = pad_gru_blocks(c0, cdims[0], hc[0], 1, Hk)
         else:
             a0 = _init_blocks(obs_dims, ha, act_dims, _get(actor, "use_orthogonal_init", True))
             c0 = _init_blocks(cdims, hc, [1] * K, _get(critic, "use_orthogonal_init", True))
@@ -213,30 +219,29 @@ class A2CNetwork:
         S, P = self.spec, self.spec.n_blocks
         group = "independent" if self.sharing is None else "networks"
         out = OrderedDict()
+        self._shapes = {}  # recurrent networks: key -> the reference tensor's shape
         for prefix, block, A in (("actor", self.actor_params, S.n_actions), ("critic", self.critic_params, 1),
                                  ("target_critic", self.target_critic_params, 1)):
             for i in range(P):
-                o = 0
                 cin = S.n_agents * S.obs_dim if (self.centralised_critic and prefix != "actor") else S.obs_dim
                 if not self.recurrent:  # the live tensors inside the (possibly zero-padded) blocks
                     for name, view in block_views(block[i], cin, self.live_hidden[prefix], A, S.hidden):
                         out[f"{prefix}.{group}.{i}.{name}"] = view
                     continue
-                for name, shape in _gru_layout(cin, S.hidden, A):
-                    n = int(np.prod(shape))
-                    out[f"{prefix}.{group}.{i}.{name}"] = block[i, o:o + n].view(shape)
-                    o += n
+                for name, view, shape in gru_block_views(block[i], cin, self.live_hidden[prefix][0], A, S.hidden):
+                    out[f"{prefix}.{group}.{i}.{name}"] = view  # gate matrices: (3, h, h) views of the padded block
+                    self._shapes[f"{prefix}.{group}.{i}.{name}"] = shape
         return out
 
     def parameters(self):
         return list(self._views().values())
 
     def state_dict(self):
-        return OrderedDict((k, v.detach().clone()) for k, v in self._views().items())
+        return OrderedDict((k, v.detach().clone().reshape(self._shapes.get(k, v.shape))) for k, v in self._views().items())
 
     def load_state_dict(self, sd):
         for k, view in self._views().items():
-            view.copy_(sd[k].to(self.device))
+            view.copy_(sd[k].to(self.device).reshape(view.shape))
 
     def to(self, device):
         return self

@@ -175,8 +175,8 @@ inline AgentMap agent_map(const marlhip_net_shape* s) {
 // any_depth: the caller runs the GEMM path (1 .. 4 hidden layers); every fused kernel is built for two
 inline int agent_map_validate(const marlhip_net_shape* s, bool any_depth = false) {
     MARL_REQUIRE(s->n_agents >= 1 && s->n_agents <= 16, "net shape: %d agents (1..16 supported)", s->n_agents);
-    MARL_REQUIRE(s->n_hidden == 0 || s->n_hidden == 2 || (any_depth && s->n_hidden >= 1 && s->n_hidden <= 4),
-                 "net shape: %d hidden layers (the fused kernels implement 2; 1..4 run on the GEMM path, marlhip_wide_*)", s->n_hidden);
+    MARL_REQUIRE(s->n_hidden == 0 || s->n_hidden == 2 || (any_depth && s->n_hidden >= 1 && s->n_hidden <= 16),
+                 "net shape: %d hidden layers (the fused kernels implement 2; 1..16 run on the GEMM path, marlhip_wide_*)", s->n_hidden);
     if (s->n_networks > 0) {
         MARL_REQUIRE(s->n_networks <= s->n_agents, "net shape: %d networks for %d agents", s->n_networks, s->n_agents);
         for (int i = 0; i < s->n_agents; ++i)

@@ -985,7 +985,18 @@ __device__ __forceinline__ void adam_pack_body(int i, int n, int nsq, float* __r
             // data-parallel form (marlhip_idqn_update_n_dist): the gradient was summed over the ranks AFTER the reduce launch, so no
             // partial sums exist - every block takes the norm of the whole exchanged, scaled gradient itself (n floats from L2; fixed
             // order, so every block and every rank forms the same clip coefficient)
-            for (int j = threadIdx.x; j < n; j += 256) {
+            // (16-byte loads, all of a thread's requests independent: the 13 us of the scalar loop - 87 dependent-looking round trips
+            // per thread, measured on the forced-dist profile - become ~2)
+            const int n4 = n >> 2;
+            const f4* g4 = reinterpret_cast<const f4*>(grad);
+            f4 part = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+            for (int j = threadIdx.x; j < n4; j += 256) {
+                const f4 gj = g4[j] * a.grad_scale;
+                part += gj * gj;
+            }
+            ss = (part[0] + part[1]) + (part[2] + part[3]);
+            for (int j = 4 * n4 + threadIdx.x; j < n; j += 256) {
                 const float gj = grad[j] * a.grad_scale;
                 ss += gj * gj;
             }

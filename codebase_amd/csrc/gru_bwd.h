@@ -10,11 +10,10 @@
 //                        transposed through LDS tiles as in the feed-forward kernels; one partial record per workgroup,
 //                        summed in fixed order by dqn_reduce_kernel.
 #pragma once
-// MARLHIP_GRU_WGRAD_FLAT: the record loads of gru_wgrad_kernel's per-gate roles (hidden 128) through one wave-uniform pointer - see the
-// note at the loads.  Found by reading the ISA after the round's GPU time was spent: 0 ships the form every test and profile of the
-// round ran on; build with -DMARLHIP_GRU_WGRAD_FLAT=1 (identical arithmetic, the loads only) to measure it.
-#ifndef MARLHIP_GRU_WGRAD_FLAT
-#define MARLHIP_GRU_WGRAD_FLAT 0
+// MARLHIP_GRU_WGRAD_PREFETCH: request the next item's record arrays of gru_wgrad_kernel's per-gate roles (hidden 128) right behind the
+// barrier that publishes the current item's tiles, so that they arrive under the item's 128 MFMAs (32 more registers per lane).
+#ifndef MARLHIP_GRU_WGRAD_PREFETCH
+#define MARLHIP_GRU_WGRAD_PREFETCH 0
 #endif
 #include "td_rows.h"
 #include "dqn_update_kernels.h"
@@ -446,11 +445,10 @@ __global__ __launch_bounds__(256) void gru_wgrad_kernel(int steps, int B, const 
     }
     if (role < 3) {
         // ---- gate `role`: dW_ih[gate rows][my columns] += dgi^T x1, dW_hh[...] += dgh^T h_prev
-        // MARLHIP_GRU_WGRAD_FLAT (see the top of this file): ONE wave-uniform source pointer per item and eight unconditional loads.
-        // The per-tile `if (wave == 0) ... else if ...` form below it compiles to a branch around every load with `s_waitcnt vmcnt(0)`
-        // in front of the next one - eight dependent memory round trips per item (~3.3 of the ~5 us an item takes at hidden 128,
-        // where one workgroup per CU has nothing else to run meanwhile; 1054 us for 267 us of MFMAs) - and that, not the load latency
-        // itself, is also why requesting the next item's arrays early made it slower (1133 us: sixteen serialised round trips).
+        // The record loads go through ONE wave-uniform source pointer per item as eight unconditional loads.  The per-tile
+        // `if (wave == 0) ... else if ...` form of rounds 1-2 compiled to a branch around every load with `s_waitcnt vmcnt(0)` in front
+        // of the next one - eight dependent memory round trips per item - and ran hidden-128 recurrent IDQN at 1.19 M env-steps/s
+        // against 1.41 M with this form (gru_wgrad 1054 -> ~640 us per update; profiles/r03_flatload_ab.md).
         const int nt0 = wave * MTN;
         f4 dWa[MT][MTN], dWb[MT][MTN];
 #pragma unroll
@@ -458,31 +456,38 @@ __global__ __launch_bounds__(256) void gru_wgrad_kernel(int steps, int B, const 
 #pragma unroll
             for (int b = 0; b < MTN; ++b) { dWa[a][b] = zero4; dWb[a][b] = zero4; }
         const int gi_arr = role, gh_arr = role == 2 ? 3 : role;  // rec2 arrays: dr, dz, dn, r * dn
-        for (int item = blockIdx.x; item < total; item += gridDim.x) {
+        // the four waves transpose one array each into the shared tiles ([unit][16 rows]): wave 0 dgi, 1 dgh, 2 x1, 3 h_{t-1}
+        auto fetch = [&](int item, f4 (&v)[MT]) {
             const int t = item / nblk, blk = item - t * nblk;
             const f4* R = reinterpret_cast<const f4*>(rec + (((size_t)p * steps + t) * nblk + blk) * S::REC);
             const f4* Rp = reinterpret_cast<const f4*>(rec + (((size_t)p * steps + (t > 0 ? t - 1 : 0)) * nblk + blk) * S::REC);
             const f4* R2 = reinterpret_cast<const f4*>(rec2 + (((size_t)p * steps + t) * nblk + blk) * Bk::REC2);
-            // the four waves transpose one array each into the shared tiles ([unit][16 rows])
-            f4 v[MT];
-#if MARLHIP_GRU_WGRAD_FLAT
             const f4* src = wave == 0 ? R2 + gi_arr * MT * 64 : (wave == 1 ? R2 + gh_arr * MT * 64 : (wave == 2 ? R : Rp + 4 * MT * 64));
             const bool none = wave == 3 && t == 0;  // h_{-1} = 0 (the row read instead is step 0's own: a valid address)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) v[mt] = src[mt * 64 + lane];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) v[mt] = none ? zero4 : v[mt];
-#else
+        };
+#if MARLHIP_GRU_WGRAD_PREFETCH
+        f4 vn[MT];
+#endif
+        for (int item = blockIdx.x; item < total; item += gridDim.x) {
+            f4 v[MT];
+#if MARLHIP_GRU_WGRAD_PREFETCH
+            if (item == (int)blockIdx.x) fetch(item, v);
+            else {
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                if (wave == 0) v[mt] = R2[(gi_arr * MT + mt) * 64 + lane];
-                else if (wave == 1) v[mt] = R2[(gh_arr * MT + mt) * 64 + lane];
-                else if (wave == 2) v[mt] = R[(0 * MT + mt) * 64 + lane];                      // x1
-                else v[mt] = t > 0 ? Rp[(4 * MT + mt) * 64 + lane] : zero4;                    // h_{t-1}
+                for (int mt = 0; mt < MT; ++mt) v[mt] = vn[mt];
             }
+#else
+            fetch(item, v);
 #endif
             tile_write<MT>(wave == 0 ? T0 : (wave == 1 ? T1 : (wave == 2 ? T2 : T3)), v, g, j);
             __syncthreads();
+#if MARLHIP_GRU_WGRAD_PREFETCH
+            if (item + (int)gridDim.x < total) fetch(item + (int)gridDim.x, vn);  // wave-uniform; lands under this item's MFMAs
+#endif
             f4 bX[MTN], bH[MTN];
 #pragma unroll
             for (int nt = 0; nt < MTN; ++nt) {

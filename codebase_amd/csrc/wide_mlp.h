@@ -20,23 +20,11 @@
 
 namespace marl {
 
-// MARLHIP_WIDE_FLATLOAD: operand fetches of the two GEMM kernels as UNCONDITIONAL loads from clamped (always valid) addresses, the
-// bounds / ones-column cases applied to the loaded value.  The `in range ? A[...] : 0` form compiles to a branch around every load with
-// `s_waitcnt vmcnt(0)` in front of the next (scripts/isa_scan.py: 24 of a k-slice's 48 loads in one dependent chain in the 64 x 64
-// kernel, 102 of 160 in the 128 x 128 one).  Same values, same arithmetic.  Found by reading the ISA after the round's GPU time was
-// spent, so 0 ships the form every test and profile of the round ran on; -DMARLHIP_WIDE_FLATLOAD=1 is the first thing to measure next.
-#ifndef MARLHIP_WIDE_FLATLOAD
-#define MARLHIP_WIDE_FLATLOAD 0
-#endif
-
-// element (row, k) of an operand stored with strides (s_r, s_k): 0 outside [0, nrows) x [.., kend), 1 in the ones column, else P[...];
-// the load itself is unconditional (row 0 / the last k stand in where there is nothing to read; a ones column is never the only one)
-__device__ __forceinline__ float gemm_fetch(const float* __restrict__ P, int64_t s_r, int64_t s_k, int row, int nrows, int k, int kend, int ones) {
-    const bool inside = row < nrows && k < kend, one = row == ones;
-    const int rs = (row < nrows && !one) ? row : 0, ks = k < kend ? k : kend - 1;
-    const float v = P[(int64_t)rs * s_r + (int64_t)ks * s_k];
-    return inside ? (one ? 1.f : v) : 0.f;
-}
+// (Round 3: a form with UNCONDITIONAL operand loads from clamped addresses - the `in range ? A[...] : 0` fetches compile to a branch around
+// every load, 24 - 102 loads in one dependent chain per k-slice (profiles/r02_isa_scan.txt) - was measured and taken out again: it is 8 - 11 %
+// SLOWER on every GEMM-path row (MAA2C 15x15-8p 6.27 -> 5.73 M env-steps/s, MAPPO rware 4.83 -> 4.31 M, IDQN 256-256 0.725 -> 0.681 M;
+// profiles/r03_flatload_ab.md): the clamped form issues every load of the padded tile, the branchy one skips the out-of-range ones, and
+// these GEMMs are not bound by load latency.)
 
 struct GemmOp {
     const float* A; int64_t a_m, a_k;      // A(m, k) = A[m * a_m + k * a_k]
@@ -64,16 +52,6 @@ __global__ __launch_bounds__(256) void wide_gemm_kernel(const GemmOp g) {
     for (int nt = 0; nt < 4; ++nt) acc[nt] = f4{0.f, 0.f, 0.f, 0.f};
     float ra[4], rb[4];
     auto load = [&](int k0) {
-#if MARLHIP_WIDE_FLATLOAD
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            ra[e] = A_KC ? gemm_fetch(g.A, g.a_m, g.a_k, m0 + (tid & 63), g.M, k0 + 4 * (tid >> 6) + e, kend, -1)
-                         : gemm_fetch(g.A, g.a_m, g.a_k, m0 + 4 * (tid & 15) + e, g.M, k0 + (tid >> 4), kend, -1);
-            rb[e] = B_KC ? gemm_fetch(g.B, g.b_n, g.b_k, n0 + (tid & 63), g.N, k0 + 4 * (tid >> 6) + e, kend, g.b_ones)
-                         : gemm_fetch(g.B, g.b_n, g.b_k, n0 + 4 * (tid & 15) + e, g.N, k0 + (tid >> 4), kend, g.b_ones);
-        }
-        return;
-#endif
         if (A_KC) {  // thread: one m, four consecutive k
             const int m = m0 + (tid & 63), kq = k0 + 4 * (tid >> 6);
 #pragma unroll
@@ -118,47 +96,6 @@ __global__ __launch_bounds__(256) void wide_gemm_kernel(const GemmOp g) {
         }
     }
     float* C = g.C + (int64_t)blockIdx.z * g.c_split;
-#if MARLHIP_WIDE_FLATLOAD
-    {   // bias / gate values fetched up front from clamped addresses (the epilogue's loads are the same trap as the operands')
-        float bv[4], gt[4][4];
-        const bool with_bias = g.epi == 1 || g.epi == 2;
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            bv[nt] = 0.f;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) gt[nt][r] = 1.f;
-        }
-        if (with_bias) {  // (the condition around the whole group of loads, never around one load)
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) bv[nt] = g.bias[n0 + 16 * nt + i < g.N ? n0 + 16 * nt + i : 0];
-        }
-        if (g.epi == 3) {
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                const int n = n0 + 16 * nt + i, ns = n < g.N ? n : 0;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int m = m0 + 16 * wave + 4 * q + r, ms = m < g.M ? m : 0;
-                    gt[nt][r] = g.gate[(int64_t)ms * g.gate_m + ns];
-                }
-            }
-        }
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            const int n = n0 + 16 * nt + i;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m0 + 16 * wave + 4 * q + r;
-                float v = acc[nt][r];
-                if (with_bias) v += bv[nt];
-                if (g.epi == 2) v = fmaxf(v, 0.f);
-                if (g.epi == 3) v = gt[nt][r] > 0.f ? v : 0.f;
-                if (m < g.M && n < g.N) C[(int64_t)m * g.c_m + n] = v;
-            }
-        }
-        return;
-    }
-#endif
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
         const int n = n0 + 16 * nt + i;
@@ -195,16 +132,6 @@ __global__ __launch_bounds__(256) void wide_gemm128_kernel(const GemmOp g) {
         for (int b = 0; b < 4; ++b) acc[a][b] = f4{0.f, 0.f, 0.f, 0.f};
     float ra[8], rb[8];
     auto load = [&](int k0) {
-#if MARLHIP_WIDE_FLATLOAD
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            ra[e] = A_KC ? gemm_fetch(g.A, g.a_m, g.a_k, m0 + (tid & 127), g.M, k0 + 8 * (tid >> 7) + e, kend, -1)
-                         : gemm_fetch(g.A, g.a_m, g.a_k, m0 + 8 * (tid & 15) + e, g.M, k0 + (tid >> 4), kend, -1);
-            rb[e] = B_KC ? gemm_fetch(g.B, g.b_n, g.b_k, n0 + (tid & 127), g.N, k0 + 8 * (tid >> 7) + e, kend, g.b_ones)
-                         : gemm_fetch(g.B, g.b_n, g.b_k, n0 + 8 * (tid & 15) + e, g.N, k0 + (tid >> 4), kend, g.b_ones);
-        }
-        return;
-#endif
         if (A_KC) {  // thread: one row, eight consecutive k
             const int m = m0 + (tid & 127), kq = k0 + 8 * (tid >> 7);
 #pragma unroll
@@ -256,51 +183,6 @@ __global__ __launch_bounds__(256) void wide_gemm128_kernel(const GemmOp g) {
                 for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = MARL_MFMA(a[mt][s2], b[nt][s2], acc[mt][nt]);
     }
     float* C = g.C + (int64_t)blockIdx.z * g.c_split;
-#if MARLHIP_WIDE_FLATLOAD
-    {
-        float bv[4];
-        const bool with_bias = g.epi == 1 || g.epi == 2;
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) bv[nt] = 0.f;
-        if (with_bias) {  // (the condition around the whole group of loads, never around one load)
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) bv[nt] = g.bias[n0 + 64 * wn + 16 * nt + i < g.N ? n0 + 64 * wn + 16 * nt + i : 0];
-        }
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {  // one row tile at a time: 16 gate values in flight
-            float gt[4][4];
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) gt[nt][r] = 1.f;
-            if (g.epi == 3) {
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
-                    const int n = n0 + 64 * wn + 16 * nt + i, ns = n < g.N ? n : 0;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int m = m0 + 64 * wm + 16 * mt + 4 * q + r, ms = m < g.M ? m : 0;
-                        gt[nt][r] = g.gate[(int64_t)ms * g.gate_m + ns];
-                    }
-                }
-            }
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                const int n = n0 + 64 * wn + 16 * nt + i;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int m = m0 + 64 * wm + 16 * mt + 4 * q + r;
-                    float v = acc[mt][nt][r];
-                    if (with_bias) v += bv[nt];
-                    if (g.epi == 2) v = fmaxf(v, 0.f);
-                    if (g.epi == 3) v = gt[nt][r] > 0.f ? v : 0.f;
-                    if (m < g.M && n < g.N) C[(int64_t)m * g.c_m + n] = v;
-                }
-            }
-        }
-        return;
-    }
-#endif
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -393,7 +275,7 @@ static __global__ __launch_bounds__(256) void wide_gather_kernel(const float* __
 // unequal widths are zero-padded to H by the caller), A outputs; parameters in FCNetwork's parameters() order.
 // Layers are numbered 1 .. L (hidden) and L + 1 (output).
 struct WideNet {
-    static constexpr int MAXL = 4;
+    static constexpr int MAXL = 16;  // == marlhip_net_shape.n_hidden's upper bound (common.h: net_shape_validate)
     int D, H, A;
     int L = 2;
     int n_in(int k) const { return k == 1 ? D : H; }

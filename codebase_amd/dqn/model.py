@@ -103,6 +103,59 @@ def init_flat_gru_params(obs_dims, hidden, act_dims, use_orthogonal_init=True, s
     return blocks[0], blocks[0].clone()
 
 
+# ---- recurrent networks of widths other than the compiled 64 / 128 ------------------------------------------------------------
+# RNNNetwork(dims=[D, h, h, A]) (utils/models.py:51-116) = Linear(D, h) - ReLU - one-layer GRU(h, h) - Linear(h, A) for ANY h.  A width
+# h <= 128 runs EXACTLY on the kernel width Hk in {64, 128} by zero padding, like the feed-forward lists above: a padded unit has zero
+# first-layer / gate weights and biases, so r = z = 1/2, n = tanh(0) = 0 and h' = (1 - z) n + z h = h / 2 = 0 from the zero initial
+# state on; every gradient into the padding is a product with one of those zeros (zero columns of W3 / W_hh keep dL/dh of a padded unit
+# at 0), and Adam maps zero gradient + zero moments to a zero step.  The gate matrices are [3 Hk][Hk] with one [Hk][Hk] block per gate
+# (r, z, n): the live part is [:, :h, :h] of the (3, Hk, Hk) view.  Longer lists (multi-layer GRUs) and h > 128 raise.
+def recurrent_width(hidden):
+    """`layers` of a use_rnn network -> (h, Hk): the live width and the kernel width it is padded to, or raise"""
+    if len(hidden) != 2 or hidden[0] != hidden[1]:
+        raise NotImplementedError(f"use_rnn with layers={list(hidden)}: one GRU layer (layers = [h, h]); RNNNetwork itself asserts equal sizes "
+                                  "(utils/models.py:79-81) and stacks len(layers) - 1 GRU layers")
+    h = int(hidden[0])
+    if not 1 <= h <= 128:
+        raise NotImplementedError(f"use_rnn with layers={list(hidden)}: recurrent widths up to 128 (zero-padded onto the 64 / 128 kernels)")
+    return h, (64 if h <= 64 else 128)
+
+
+def gru_block_views(row, D, h, A, H):
+    """(name, live view, reference shape) of one flat recurrent block laid out for kernel width H (H == h: the unpadded layout), in
+    RNNNetwork's parameters() order (utils/models.py:83-92)"""
+    o, out = 0, []
+
+    def take(n):
+        nonlocal o
+        v = row[o:o + n]
+        o += n
+        return v
+
+    out.append(("first_layer.weight", take(H * D).view(H, D)[:h], (h, D)))
+    out.append(("first_layer.bias", take(H)[:h], (h,)))
+    out.append(("rnn.weight_ih_l0", take(3 * H * H).view(3, H, H)[:, :h, :h], (3 * h, h)))
+    out.append(("rnn.weight_hh_l0", take(3 * H * H).view(3, H, H)[:, :h, :h], (3 * h, h)))
+    out.append(("rnn.bias_ih_l0", take(3 * H).view(3, H)[:, :h], (3 * h,)))
+    out.append(("rnn.bias_hh_l0", take(3 * H).view(3, H)[:, :h], (3 * h,)))
+    out.append(("final_layer.weight", take(A * H).view(A, H)[:, :h], (A, h)))
+    out.append(("final_layer.bias", take(A), (A,)))
+    assert o == row.numel(), (o, row.numel())
+    return out
+
+
+def pad_gru_blocks(flat, D, h, A, H):
+    """[K][n(h)] recurrent parameter blocks -> [K][n(H)] zero-padded blocks"""
+    if h == H:
+        return flat
+    n = H * D + H + 6 * H * H + 6 * H + A * H + A
+    out = torch.zeros(flat.shape[0], n, dtype=flat.dtype)
+    for k in range(flat.shape[0]):
+        for (_, dst, _), (_, src, _) in zip(gru_block_views(out[k], D, h, A, H), gru_block_views(flat[k], D, h, A, h)):
+            dst.copy_(src)
+    return out
+
+
 def _tensor_layout(D, H, A):
     return [("network.0.weight", (H, D)), ("network.0.bias", (H,)), ("network.2.weight", (H, H)),
             ("network.2.bias", (H,)), ("network.4.weight", (A, H)), ("network.4.bias", (A,))]
@@ -117,14 +170,14 @@ def _tensor_layout(D, H, A):
 # computes (utils/models.py:34-48), and state_dict exposes the live tensors in the reference's shapes.
 def compiled_width(hidden):
     """hidden layer list -> the width the kernels run it at (<= 128 with two layers: a fused kernel; otherwise the GEMM path), or raise"""
-    if not 1 <= len(hidden) <= 4:
-        raise NotImplementedError(f"layers={list(hidden)}: one to four hidden layers")
+    if not 1 <= len(hidden) <= 16:  # WideNet::MAXL (csrc/wide_mlp.h); FCNetwork itself takes any list (utils/models.py:14-48)
+        raise NotImplementedError(f"layers={list(hidden)}: 1 to 16 hidden layers")
     h = max(hidden)
     if min(hidden) < 1 or h > 1024:
         raise NotImplementedError(f"layers={list(hidden)}: hidden widths 1..1024")
     if len(hidden) == 2 and h <= 128:
         return 64 if h <= 64 else 128
-    return max((h + 15) // 16 * 16, 144 if len(hidden) == 2 else 16)  # the GEMM path (NetSpec.wide): any width, any of 1..4 layers
+    return max((h + 15) // 16 * 16, 144 if len(hidden) == 2 else 16)  # the GEMM path (NetSpec.wide): any width, any of 1..16 layers
 
 
 def is_wide(hidden):
@@ -166,10 +219,8 @@ class QNetwork:
         obs_dims = [flatdim(o) for o in obs_space]
         act_dims = [flatdim(a) for a in action_space]
         self.recurrent = bool(use_rnn)
-        if use_rnn and hidden not in ([64, 64], [128, 128]):
-            raise NotImplementedError(f"use_rnn with layers={hidden}: the recurrent kernels are built for layers [64, 64] / [128, 128]")
         self.live_hidden = tuple(hidden)
-        Hk = compiled_width(hidden)  # the width the kernels run at (the layers zero-padded to it, see pad_blocks)
+        Hk = recurrent_width(hidden)[1] if use_rnn else compiled_width(hidden)  # the width the kernels run at (the layers zero-padded to it, see pad_blocks / pad_gru_blocks)
         hidden_k = [Hk] * len(hidden)
         if len(set(obs_dims)) != 1 or len(set(act_dims)) != 1:
             raise NotImplementedError("agents with different observation / action sizes")
@@ -183,10 +234,12 @@ class QNetwork:
         self.n_agents = len(obs_dims)
         self.device = torch.device(device)
         self.sharing = sharing_indices(parameter_sharing, self.n_agents)
-        self.spec = _hip.NetSpec(self.n_agents, obs_dims[0], hidden_k[0], act_dims[0], self.sharing, wide=is_wide(hidden), n_hidden=len(hidden))
+        self.spec = _hip.NetSpec(self.n_agents, obs_dims[0], hidden_k[0], act_dims[0], self.sharing, wide=is_wide(hidden) and not use_rnn, n_hidden=len(hidden))
         if self.recurrent:  # RNNNetwork (utils/models.py:51-116): Linear -> ReLU -> GRU -> Linear
             self.nparams = _hip.gru_nparams(self.spec)
-            critic, target = init_flat_gru_params(obs_dims, hidden[0], act_dims, use_orthogonal_init, self.sharing)
+            critic, target = init_flat_gru_params(obs_dims, hidden[0], act_dims, use_orthogonal_init, self.sharing)  # the reference's draws at the true width
+            critic = pad_gru_blocks(critic, obs_dims[0], hidden[0], act_dims[0], Hk)
+            target = critic.clone()
         else:
             self.nparams = self.spec.nparams()
             critic, target = init_flat_params(obs_dims, hidden, act_dims, use_orthogonal_init, self.sharing)  # the reference's RNG draws
@@ -328,28 +381,34 @@ class QNetwork:
                 for name, view in block_views(block[i], S.obs_dim, self.live_hidden, S.n_actions, S.hidden):
                     out[f"{prefix}.{group}.{i}.{name}"] = view
             return out
-        layout = _gru_layout(S.obs_dim, S.hidden, S.n_actions)
-        for i in range(S.n_blocks):
-            o = 0
-            for name, shape in layout:
-                n = int(torch.tensor(shape).prod())
-                out[f"{prefix}.{group}.{i}.{name}"] = block[i, o:o + n].view(shape)
-                o += n
+        for i in range(S.n_blocks):  # live tensors of the (possibly zero-padded) recurrent blocks; gate matrices as (3, h, h) views
+            for name, view, _ in gru_block_views(block[i], S.obs_dim, self.live_hidden[0], S.n_actions, S.hidden):
+                out[f"{prefix}.{group}.{i}.{name}"] = view
         return out
+
+    def _ref_shapes(self, prefix):
+        """state_dict key -> the reference tensor's shape (the recurrent gate matrices are kept as (3, h, h) views of the padded block)"""
+        S = self.spec
+        if not self.recurrent:
+            return {}
+        group = "independent" if self.sharing is None else "networks"
+        return {f"{prefix}.{group}.{i}.{name}": shape for i in range(S.n_blocks)
+                for name, _, shape in gru_block_views(self.params[i], S.obs_dim, self.live_hidden[0], S.n_actions, S.hidden)}
 
     def parameters(self):
         return list(self._views(self.params, "critic").values())
 
     def state_dict(self):
         sd = OrderedDict()
+        shapes = {**self._ref_shapes("critic"), **self._ref_shapes("target")}
         for k, v in list(self._views(self.params, "critic").items()) + list(self._views(self.target_params, "target").items()):
-            sd[k] = v.detach().clone()
+            sd[k] = v.detach().clone().reshape(shapes.get(k, v.shape))
         return sd
 
     def load_state_dict(self, sd):
         for block, prefix in ((self.params, "critic"), (self.target_params, "target")):
             for k, view in self._views(block, prefix).items():
-                view.copy_(sd[k].to(self.device))
+                view.copy_(sd[k].to(self.device).reshape(view.shape))
 
     def to(self, device):
         return self

@@ -184,7 +184,7 @@ class NetSpec:
     n_actions: int
     sharing: tuple = None  # agent -> network index (parameter sharing / SePS); None = independent networks
     wide: bool = False     # no fused kernels for this shape (hidden > 128, ...): the GEMM path (marlhip_wide_*, csrc/wide_mlp.h)
-    n_hidden: int = 2      # hidden layers (the fused kernels: 2; 1..4 on the GEMM path)
+    n_hidden: int = 2      # hidden layers (the fused kernels: 2; 1..16 on the GEMM path)
 
     def c(self):
         s = NetShape(self.n_agents, self.obs_dim, self.hidden, self.n_actions)

@@ -163,7 +163,7 @@ typedef struct marlhip_net_shape {
      * `params` / `target` / `grad` argument is [n_networks][nparams] and a network's gradient is the sum over its agents. */
     int32_t n_networks;
     int32_t net_of[16];
-    int32_t n_hidden; /* hidden layers: 0 = 2.  Every fused kernel implements two; 1..4 layers of width `hidden` run on the GEMM path
+    int32_t n_hidden; /* hidden layers: 0 = 2.  Every fused kernel implements two; 1..16 layers of width `hidden` run on the GEMM path
                        * (marlhip_wide_*, and the actor-critic entry points, which route such shapes there) */
 } marlhip_net_shape;
 
@@ -433,7 +433,7 @@ int marlhip_sample_from_logits(int32_t n_agents, int32_t n_envs, int32_t n_actio
  * Networks without a fused kernel: two hidden layers of ANY width (FCNetwork takes any list, marlbase/utils/models.py:14-48;
  * hidden > 128 - e.g. layers [256, 256] - or an observation / action width outside the compiled lists).  The three layers run as
  * f32 MFMA GEMMs over all rows with the activations in HBM (csrc/wide_mlp.h): slower than the fused kernels, any size.  Parameters
- * in FCNetwork's parameters() order per block; net shape as everywhere (hidden = the width of all n_hidden layers, 1..4 of them;
+ * in FCNetwork's parameters() order per block; net shape as everywhere (hidden = the width of all n_hidden layers, 1..16 of them;
  * unequal widths are zero-padded by the caller, which is exact).  marlhip_wide_forward serves QNetwork.act / get_value and the modular collectors
  * (-> marlhip_act_from_q / marlhip_sample_from_logits); marlhip_wide_dqn_loss_grad is marlhip_dqn_loss_grad for such networks
  * (mode 0 IDQN, 1 VDN; same batch, outputs and 1 / sum(filled) normalisation; marlhip_dqn_clip_adam applies it).  The actor-critic

@@ -417,3 +417,64 @@ def test_recurrent_networks_with_observe_id_and_sharing_end_to_end(tmp_path, mon
         df = run.main([f"+algorithm={algo}", f"env.name={NAME}", "env.time_limit=25", "env.parallel_envs=64", "env.observe_id=True", "seed=1",
                        "algorithm.total_steps=30000", "algorithm.eval_interval=10000"] + extra)
         assert df.shape[0] >= 2 and np.isfinite(df["loss"]).all() and np.isfinite(df["mean_episode_returns"]).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("h,mode,P,D", [(40, "idqn", 2, 15), (96, "vdn", 3, 18), (100, "idqn", 2, 15), (17, "idqn", 4, 27)])
+def test_recurrent_networks_of_other_widths_match_the_port_at_the_true_width(h, mode, P, D):
+    """`use_rnn` with layers [h, h], h not 64 / 128 (RNNNetwork builds any width, utils/models.py:51-116): zero-padded onto the
+    recurrent kernels (dqn/model.py: recurrent_width, pad_gru_blocks).  The driver class against oracle/gru_port at the TRUE width:
+    loss, the live parts of the parameters after 3 updates, the padding still exactly zero, state_dict in the reference's shapes."""
+    from codebase_amd import hip as hh
+    from codebase_amd.dqn import model as M
+    from oracle import dqn_port as dp
+    from tests.test_gpu_layers import spaces
+
+    A, T, B = 6, 9, 24
+    cfg = dict(optimizer="Adam", lr=3e-4, gamma=0.99, grad_clip=1.0, double_q=True, standardise_returns=False, target_update_interval_or_tau=2)
+    torch.manual_seed(11)
+    cls = M.VDNetwork if mode == "vdn" else M.QNetwork
+    obs_space, act_space = spaces(P, D, A)
+    net = cls(obs_space, act_space, cfg, [h, h], False, True, True, "cuda")
+    Hk = net.spec.hidden
+    assert Hk == (64 if h <= 64 else 128) and net.recurrent and not net.spec.wide
+    sd = net.state_dict()
+    assert sd["critic.independent.0.rnn.weight_ih_l0"].shape == (3 * h, h) and sd["critic.independent.1.first_layer.weight"].shape == (h, D)
+    live0 = torch.stack([torch.cat([sd[f"critic.independent.{p}.{n}"].reshape(-1).cpu() for n in gp.NAMES]) for p in range(P)])
+    assert live0.shape == (P, gp.nparams(D, h, A))
+    pad_mask = torch.ones_like(net.params, dtype=torch.bool)
+    for p in range(P):
+        for _, view, _ in M.gru_block_views(pad_mask[p], D, h, A, Hk):
+            view.fill_(False)
+    assert int(pad_mask.sum()) > 0 and float(net.params[pad_mask].abs().max()) == 0.0
+    # the port at the true width, driven by dqn_port.Learner through the recurrent network hooks
+    ref_params, ref_target = live0.clone(), live0.clone()
+    opt_tensors = [torch.nn.Parameter(ref_params[p].clone()) for p in range(P)]
+    opt = torch.optim.Adam(opt_tensors, lr=3e-4)
+    updates = last = 0
+    for i in range(3):
+        batch = dp.synthetic_batch(P, T, B, D, A, seed=40 + i)
+        batch["obss"] = batch["obss"] * 0.25
+        if mode == "vdn":
+            batch["rewards"][1:] = batch["rewards"][0]
+        loss_ref = gp.compute_loss(torch.stack(list(opt_tensors)), ref_target, batch, 0.99, True, D, h, A, mode=mode)
+        opt.zero_grad()
+        loss_ref.backward()
+        torch.nn.utils.clip_grad_norm_(opt_tensors, 1.0)
+        opt.step()
+        updates += 1
+        if updates - last >= 2:
+            ref_target = torch.stack([t.detach().clone() for t in opt_tensors])
+            last = updates
+        hb = hh.Batch(*(batch[k] for k in ("obss", "actions", "rewards", "dones", "filled")), None)
+        got = net.update(hb)["loss"]
+        assert abs(got - loss_ref.item()) <= 5e-5 * max(abs(loss_ref.item()), 1e-3), (i, got, loss_ref.item())
+    sd = net.state_dict()
+    for prefix, ref in (("critic", torch.stack([t.detach() for t in opt_tensors])), ("target", ref_target)):
+        live = torch.stack([torch.cat([sd[f"{prefix}.independent.{p}.{n}"].reshape(-1).cpu() for n in gp.NAMES]) for p in range(P)])
+        np.testing.assert_allclose(live.numpy(), ref.numpy(), rtol=0, atol=5e-6, err_msg=prefix)
+    assert float(net.params[pad_mask].abs().max()) == 0.0 and float(net.updater.exp_avg[pad_mask].abs().max()) == 0.0  # the padding never moves
+    with pytest.raises(NotImplementedError):
+        M.QNetwork(obs_space, act_space, cfg, [64, 64, 64], False, True, True, "cuda")  # a two-layer GRU
+    with pytest.raises(NotImplementedError):
+        M.QNetwork(obs_space, act_space, cfg, [256, 256], False, True, True, "cuda")

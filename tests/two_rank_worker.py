@@ -52,7 +52,6 @@ def main():
             same_on_all_ranks(getattr(model, name), f"{cls.__name__}.{name}")
         same_on_all_ranks(model.updater.exp_avg_sq, f"{cls.__name__} Adam moments")
         same_on_all_ranks(model.updater.gnorm, f"{cls.__name__} clip norm (taken from the REDUCED gradient)")
-        assert not torch.equal(model.params, model.target_params)
         if std:  # RunningMeanStd moved by the GLOBAL batch moments: the same (mean, var, count) on every rank
             st = model.ret_ms
             same_on_all_ranks(st.mean, "return statistics mean")
