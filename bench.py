@@ -60,6 +60,9 @@ def parse():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N > 1: weak = --envs envs and an update batch of B episodes PER GPU (effective batch G*B); strong = --envs envs and B "
                          "episodes in TOTAL, split evenly over the GPUs (the 1-GPU job's global batch and env count)")
+    ap.add_argument("--split16", action="store_true",
+                    help="idqn, hidden 64: the OPT-IN split-fp16 learner (products from fp16 halves on the double-rate MFMA, fp32 accumulate; "
+                         "marlhip_idqn_update_n_split16) - a deviation from the exact-f32 default, reported as its own row")
     ap.add_argument("--no-modes", action="store_true", help="skip the secondary rows (`modes`: env-only, reference cadence, hidden 128) the default line carries")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -397,7 +400,7 @@ def main():
     out = bench_dqn(args, rank, world, dist, args.steps, args.warmup)
     if rank == 0:
         default_line = (args.algo == "idqn" and args.cadence == "ratio" and args.hidden == 64 and not args.rnn and args.env_name == ENV_NAME
-                        and not args.update_batch and not args.updates_per_round)
+                        and not args.update_batch and not args.updates_per_round and not args.split16)
         if world == 1 and default_line and not args.no_modes:
             out["modes"] = secondary_modes(args)
         if world == 1 and not args.no_cpu_baseline:
@@ -418,13 +421,14 @@ def secondary_modes(args):
     rows = {}
     for name, over, steps, warmup in (("env-only", dict(cadence="env-only"), 20, 3),
                                       ("cadence=reference", dict(cadence="reference"), 3, 1),
-                                      ("hidden=128 (reference default net), cadence=ratio", dict(hidden=128), 5, 2)):
+                                      ("hidden=128 (reference default net), cadence=ratio", dict(hidden=128), 5, 2),
+                                      ("split16 OPT-IN learner (fp16 hi/lo products, fp32 accumulate; NOT the default), cadence=ratio", dict(split16=True), 10, 3)):
         a = copy.copy(args)
         for k, v in over.items():
             setattr(a, k, v)
         r = bench_dqn(a, 0, 1, None, steps, warmup)
         rf = r.get("roofline") or {}
-        rows[name] = {"value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"], "steps": steps, "warmup": warmup,
+        rows[name] = {"value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"], "steps": steps, "warmup": warmup, "dtype": r["dtype"],
                       "updates_per_round": r["config"]["updates_per_round"], "update_batch_episodes": r["config"]["update_batch_episodes"],
                       "lr": r["config"]["lr"], "target_update_interval_or_tau": r["config"]["target_update_interval_or_tau"],
                       "roofline": {k: rf.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_us")}}
@@ -468,6 +472,8 @@ def bench_dqn(args, rank, world, dist, steps, warmup):
         # batched gradient steps want a larger step and a faster target (profiles/r02_learning_parity.md: with the reference's lr /
         # target interval the batched cadence barely learns); U = 32: lr 3e-3 + Polyak 0.1; U >= 128: lr 1e-3 + hard copy every 50 updates
         hyper.update(dict(lr=3e-3, target_update_interval_or_tau=0.1) if U < 128 else dict(lr=1e-3, target_update_interval_or_tau=50))
+    if getattr(args, "split16", False):
+        hyper["split16"] = True
     from codebase_amd.dqn.model import QMixNetwork, VDNetwork
 
     if args.algo == "qmix":  # marlbase/configs/algorithm/qmix.yaml:14-17
@@ -529,7 +535,7 @@ def bench_dqn(args, rank, world, dist, steps, warmup):
         ach = flops / avg_s / 1e12
         key = f"{args.algo}:{args.env_name}:N{N}:H{H}:B{B}:T{T}:rnn{int(bool(args.rnn))}"
         traffic, tsrc = traffic_from_profile(key)
-        kname = ("gru_seq_fwd2 + gru_td + gru_seq_bwd + gru_wgrad" if args.rnn else
+        kname = "dqn_lossgrad_h16_kernel (split-fp16 products, fp32 accumulate)" if getattr(args, "split16", False) else ("gru_seq_fwd2 + gru_td + gru_seq_bwd + gru_wgrad" if args.rnn else
                  ("dqn_lossgrad_kernel" if H <= 64 and D <= 48 else "tp_fwd_kernel + tp_mix_kernel + tp_bwd_kernel")) + (" + qmix mixer stage" if args.algo == "qmix" else "")
         roofline = {"kernel": kname, "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": tsrc, "flops_per_launch": flops,
@@ -560,7 +566,7 @@ def bench_dqn(args, rank, world, dist, steps, warmup):
         "higher_is_better": True,
         "scaling": args.scaling,
         "vs_baseline": None,
-        "dtype": "f32" if not (args.algo == "qmix" and args.mixer_fp16) else "f32 (mixer first layers: fp16 inputs on MFMA, fp32 accumulate - opt-in)",
+        "dtype": "f32 via fp16 hi/lo split (2^-21 per product), fp32 accumulate - OPT-IN, not the default" if getattr(args, "split16", False) else "f32" if not (args.algo == "qmix" and args.mixer_fp16) else "f32 (mixer first layers: fp16 inputs on MFMA, fp32 accumulate - opt-in)",
         "data": "synthetic (Philox-seeded env layouts, orthogonal-init weights)",
         "config": {
             "workload": f"{args.algo.upper()} on {args.env_name.split(':')[-1].replace('-v3', '')}, {N} batched HIP envs per GPU, "

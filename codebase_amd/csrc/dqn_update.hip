@@ -6,6 +6,7 @@ using namespace marl;
 
 // the kernel instantiations live in dqn_update_h64.hip / _h64_oid / _h128 / _h128_oid (dqn_update_part.h)
 namespace marl {
+int64_t h16_pack_floats(int D, int H);  // dqn_update_h16.hip
 #define MARL_PART_DECL(name)                                                                                                      \
     int name(const marlhip_net_shape*, const float*, const float*, const marlhip_batch*, const ReplaySrc*, float, int32_t, int32_t, \
              void*, int64_t, float*, float*, hipStream_t, const QmixCtx*, const RetStats*, bool*);
@@ -71,6 +72,10 @@ extern "C" int64_t marlhip_dqn_workspace_bytes(const marlhip_net_shape* s, int32
 #define X(d, h, a) if (s->obs_dim == d && s->hidden == h && s->n_actions == a) pack = 2 * MlpShape<d, h, a>::NFWD + MlpShape<d, h, a>::NBWD;
     MARL_NET_SHAPES(X)
 #undef X
+    {   // the opt-in split-fp16 learner (dqn_update_h16.hip) keeps its packs in the same region: reserve the larger of the two
+        const int64_t h16 = h16_pack_floats(s->obs_dim, s->hidden);
+        if (!tp && h16 > pack) pack = h16;
+    }
     const int64_t base = ws_layout(s->n_agents, pl.nwg, np + 2, (int)pack, max_len, batch).total;
     if (!tp) return base;
     return ((base + 15) & ~(int64_t)15) + tp_h2_floats(s->n_agents, max_len, batch, s->hidden) * (int64_t)sizeof(float);  // pass F -> pass B activations

@@ -254,7 +254,8 @@ class QNetwork:
         self.target_update_interval_or_tau = get("target_update_interval_or_tau", 200)
         self.updater = (_hip.GruUpdater if self.recurrent else _hip.WideDqnUpdater if self.spec.wide else _hip.DqnUpdater)(self.spec, self.params, self.target_params, lr=float(get("lr", 3e-4)),
                                        gamma=self.gamma, grad_clip=self.grad_clip, double_q=self.double_q,
-                                       standardise_returns=self.standardise_returns, optimizer=self.optimizer)
+                                       standardise_returns=self.standardise_returns, optimizer=self.optimizer,
+                                       **({"split16": True} if get("split16", False) else {}))  # `split16`: not a reference key - the opt-in split-fp16 learner (hip.DqnUpdater)
         self.updates = 0
         self.last_target_update = 0
         self.mode = 0  # IDQN

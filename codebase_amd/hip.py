@@ -394,9 +394,14 @@ class DqnUpdater:
     """K5-K8: loss + gradient, clip, Adam, target update over flat per-agent parameter blocks."""
 
     def __init__(self, spec: NetSpec, params, target, lr=3e-4, betas=(0.9, 0.999), eps=1e-8, gamma=0.99, grad_clip=1.0,
-                 double_q=True, standardise_returns=False, optimizer="Adam"):
+                 double_q=True, standardise_returns=False, optimizer="Adam", split16=False):
         _require_gpu()
         self.optimizer = optimizer_id(optimizer)
+        # OPT-IN deviation from the exact-f32 kernels (include/marlhip.h, marlhip_*_split16): products from fp16 halves on the double-rate
+        # matrix pipe, fp32 accumulate.  IDQN (mode 0) only; everything else keeps the f32 entry points.
+        self.split16 = bool(split16)
+        if self.split16 and (standardise_returns or self.optimizer != 0 or spec.wide or spec.hidden != 64 or spec.obs_dim > 32):
+            raise NotImplementedError("split16: the opt-in split-fp16 learner covers IDQN with Adam, layers [64, 64], observation width <= 32")
         self.spec, self.params, self.target = spec, params, target
         self.ret_stats = RunningReturnStats(spec.n_agents, params.device) if standardise_returns else None
         self.lr, self.betas, self.eps, self.gamma = lr, betas, eps, gamma
@@ -448,6 +453,13 @@ class DqnUpdater:
                                                 float(self.gamma), self.double_q, int(mode), ctypes.byref(st), _ptr(ws), ws.numel(),
                                                 _ptr(self.grad), _ptr(self.loss), _stream()), "dqn_loss_grad_std")
             return self.loss, self.grad
+        if self.split16:
+            if mode != 0:
+                raise NotImplementedError("split16: IDQN (mode 0) only")
+            check(lib.marlhip_dqn_loss_grad_split16(ctypes.byref(s), _ptr(self.params), _ptr(self.target), ctypes.byref(bs), float(self.gamma),
+                                                    self.double_q, _ptr(ws), ws.numel(), _ptr(self.grad), _ptr(self.loss), _stream()),
+                  "dqn_loss_grad_split16")
+            return self.loss, self.grad
         check(lib.marlhip_dqn_loss_grad(ctypes.byref(s), _ptr(self.params), _ptr(self.target), ctypes.byref(bs), float(self.gamma),
                                         self.double_q, int(mode), _ptr(ws), ws.numel(), _ptr(self.grad), _ptr(self.loss), _stream()),
               "dqn_loss_grad")
@@ -455,6 +467,8 @@ class DqnUpdater:
 
     def loss_grad_replay(self, replay, batch_size, length=None, idx=None, seed=0, counter=0, idx_out=None, mode=0):
         """Sampling fused into the loss/grad kernel: rows are gathered from the replay in-kernel (no Batch)."""
+        if self.split16:  # the split-fp16 gather lives in the n-updates call (FusedLearner); a single step materialises the Batch
+            return self.loss_grad(replay.sample(batch_size, length=length, idx=idx, seed=seed, counter=counter), mode=mode)
         ws = self._workspace(replay.T, batch_size)
         s = self.spec.c()
         if self.ret_stats is not None:
@@ -741,7 +755,13 @@ class FusedLearner:
         step = ctypes.c_int64(self.up.step)
         upd = ctypes.c_int64(int(updates))
         last = ctypes.c_int64(int(last_target_update))
-        if grad_sync is None:
+        if self.up.split16:
+            if grad_sync is not None or self.c.mode != 0:
+                raise NotImplementedError("split16: the opt-in learner is single-process IDQN")
+            check(lib.marlhip_idqn_update_n_split16(ctypes.byref(self.c), int(n_updates), int(length), int(seed) & (2**64 - 1),
+                                                    int(counter0) & 0xFFFFFFFF, ctypes.byref(step), ctypes.byref(upd), ctypes.byref(last),
+                                                    _stream()), "idqn_update_n_split16")
+        elif grad_sync is None:
             check(lib.marlhip_idqn_update_n(ctypes.byref(self.c), int(n_updates), int(length), int(seed) & (2**64 - 1),
                                             int(counter0) & 0xFFFFFFFF, ctypes.byref(step), ctypes.byref(upd), ctypes.byref(last),
                                             _stream()), "idqn_update_n")

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MARLHIP_VERSION 208
+#define MARLHIP_VERSION 209
 
 int marlhip_version(void);
 const char* marlhip_last_error(void);
@@ -584,6 +584,20 @@ typedef int (*marlhip_exchange_fn)(void* ctx, float* grad, int64_t count, void* 
 int marlhip_idqn_update_n_dist(const marlhip_idqn_learner* L, int32_t n_updates, int32_t length, uint64_t seed,
                                uint32_t counter0, int64_t* adam_step, int64_t* updates, int64_t* last_target_update,
                                marlhip_exchange_fn exchange, void* exchange_ctx, int32_t world, void* stream);
+
+/* OPT-IN, a deviation from the exact-f32 default (C-ABI 209): the same loss / gradient (marlhip_dqn_loss_grad, mode 0) and the same
+ * n-updates loop (marlhip_idqn_update_n) with every f32 product formed from fp16 halves on the double-rate matrix pipe
+ * (v_mfma_f32_16x16x32_f16, fp32 accumulate): x = xh + 2^-11 xl, three MFMAs per product group, relative error ~2^-21 per product
+ * (csrc/dqn_update_h16.h).  Same arguments, workspace (marlhip_dqn_workspace_bytes) and record / reduce / clip / Adam arithmetic;
+ * IDQN only, two hidden layers of 64, observation width <= 32, no action masks; anything else returns an error.  Never selected
+ * by default: the reference's goldens gate it at the default tolerances (tests/test_gpu_split16.py), bench.py reports it as its own
+ * row (--split16).  |values| >= 65504 overflow fp16 (far outside what this path sees) and show up as inf / nan in the loss. */
+int marlhip_dqn_loss_grad_split16(const marlhip_net_shape* s, const float* params, const float* target_params,
+                                  const marlhip_batch* batch, float gamma, int32_t double_q, void* workspace,
+                                  int64_t workspace_bytes, float* grad, float* loss, void* stream);
+int marlhip_idqn_update_n_split16(const marlhip_idqn_learner* L, int32_t n_updates, int32_t length, uint64_t seed,
+                                  uint32_t counter0, int64_t* adam_step, int64_t* updates, int64_t* last_target_update,
+                                  void* stream);
 
 /* cfg.standardise_returns (QNetwork._compute_loss, model.py:146-158; RunningMeanStd, marlbase/utils/standardise_stream.py):
  * device-resident running statistics, one (mean, var) pair per agent and the shared count (initialise mean 0, var 1,

@@ -155,7 +155,7 @@ def test_recurrent_qnetwork_interface_matches_reference(name, mode):
     np.testing.assert_allclose(losses, g["losses"], rtol=5e-5)
     np.testing.assert_allclose(net.params.cpu().numpy(), g["params2"], rtol=0, atol=5e-6)
     with pytest.raises(NotImplementedError):
-        QNetwork(Tuple([Box(-1, 8, (D,))] * P), Tuple([Discrete(A)] * P), hyper, [32, 32], False, True, True, "cuda")
+        QNetwork(Tuple([Box(-1, 8, (D,))] * P), Tuple([Discrete(A)] * P), hyper, [32, 32, 32], False, True, True, "cuda")  # a two-layer GRU
     wide = QNetwork(Tuple([Box(-1, 8, (D,))] * P), Tuple([Discrete(A)] * P), hyper, [128, 128], False, True, True, "cuda")  # reference default
     assert wide.state_dict()["critic.independent.0.rnn.weight_ih_l0"].shape == (384, 128)
     acts, hid = wide.act([o for o in g["act_obs"][0]], wide.init_hiddens(1), 0.0)
