@@ -178,15 +178,18 @@ def traffic_from_profile(key):
     """HBM bytes per launch of the named workload's dominant kernel from the committed rocprofv3 PMC passes (bench.py cannot run
     rocprofv3 on itself): profiles/r02_pmc_traffic.json records the git head and the exact workload it was taken on; anything
     else gets null."""
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
-        ent = pmc["workloads"].get(key)
-        if ent is None:
-            return None, None
-        return ent["traffic_bytes"], {"file": "profiles/r02_pmc_traffic.json", "head": pmc.get("head"), "kernel": ent.get("kernel"),
-                                      "algorithmic_bytes": ent.get("algorithmic_bytes")}
-    except (OSError, KeyError, ValueError):
-        return None, None
+    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):  # the newest profile that holds this exact workload
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
+            ent = pmc["workloads"].get(key)
+            if ent is None:
+                continue
+            return ent["traffic_bytes"], {"file": "profiles/" + name, "head": pmc.get("head"), "kernel": ent.get("kernel"),
+                                          "algorithmic_bytes": ent.get("algorithmic_bytes"),
+                                          "note": "rocprofv3 PMC passes of this workload at the recorded git head (bench.py cannot profile itself)"}
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
 
 
 def _ranks_field(world, dist, args):
@@ -533,7 +536,7 @@ def bench_dqn(args, rank, world, dist, steps, warmup):
         flops, parts = dqn_update_flops(args.algo, bool(args.rnn), P, D, A, H, T, B)
         avg_s = lg["avg_us"] * 1e-6
         ach = flops / avg_s / 1e12
-        key = f"{args.algo}:{args.env_name}:N{N}:H{H}:B{B}:T{T}:rnn{int(bool(args.rnn))}"
+        key = f"{args.algo}:{args.env_name}:N{N}:H{H}:B{B}:T{T}:rnn{int(bool(args.rnn))}" + (":split16" if getattr(args, "split16", False) else "")
         traffic, tsrc = traffic_from_profile(key)
         kname = "dqn_lossgrad_h16_kernel (split-fp16 products, fp32 accumulate)" if getattr(args, "split16", False) else ("gru_seq_fwd2 + gru_td + gru_seq_bwd + gru_wgrad" if args.rnn else
                  ("dqn_lossgrad_kernel" if H <= 64 and D <= 48 else "tp_fwd_kernel + tp_mix_kernel + tp_bwd_kernel")) + (" + qmix mixer stage" if args.algo == "qmix" else "")

@@ -279,6 +279,8 @@ __global__ __launch_bounds__(256, 1) void dqn_lossgrad_h16_kernel(const float* _
         }
 #pragma unroll
         for (int n = 0; n < NN; ++n) q[n] = qm[n] + qc[n] * H16_UNSCALE;
+        // (Scheduling hints for this block - iglp_opt(0 / 1), sched_group_barrier patterns of 1 MFMA : 1 LDS read : 5 VALU and 2 : 2 : 8 -
+        // measured 88.3 / 98.2 / 90.6 / 89.6 us against 88.0 us without, gpurun r3E: none kept.)
     };
 
     struct Rows {

@@ -9,7 +9,8 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "gpurun_out", "prof2")
+SRC = os.path.join(ROOT, "gpurun_out", sys.argv[1] if len(sys.argv) > 1 else "prof2")  # python scripts/profiles_post.py prof3 r03
+PFX = sys.argv[2] if len(sys.argv) > 2 else "r02"
 DST = os.path.join(ROOT, "profiles")
 
 
@@ -34,63 +35,74 @@ def short(name):
 
 
 def main():
-    head = open(os.path.join(ROOT, "scripts", "_bin", "head.txt")).read().strip() if os.path.exists(os.path.join(ROOT, "scripts", "_bin", "head.txt")) else None
-    for tag, out in (("stats", "r02_bench_ratio_kernel_stats.csv"), ("stats_h128", "r02_bench_ratio_H128_kernel_stats.csv"),
-                     ("stats_hbm", "r02_hbm_ubench_kernel_stats.csv"), ("stats_gru64", "r02_gru_H64_kernel_stats.csv"),
-                     ("stats_rware_ia2c", "r02_rware_ia2c_tiny4ag_H128_kernel_stats.csv"),
-                     ("stats_qmix8p", "r02_qmix_15x15_8p5f_H128_kernel_stats.csv")):
+    hp = os.path.join(SRC, "head.txt") if os.path.exists(os.path.join(SRC, "head.txt")) else os.path.join(ROOT, "scripts", "_bin", "head.txt")
+    head = open(hp).read().strip() if os.path.exists(hp) else None
+    for tag, out in (("stats", PFX + "_bench_ratio_kernel_stats.csv"), ("stats_h128", PFX + "_bench_ratio_H128_kernel_stats.csv"),
+                     ("stats_hbm", PFX + "_hbm_ubench_kernel_stats.csv"), ("stats_gru64", PFX + "_gru_H64_kernel_stats.csv"),
+                     ("stats_rware_ia2c", PFX + "_rware_ia2c_tiny4ag_H128_kernel_stats.csv"),
+                     ("stats_qmix8p", PFX + "_qmix_15x15_8p5f_H128_kernel_stats.csv")):
         f = first(f"{tag}/**/*_kernel_stats.csv")
         if f:
             shutil.copy(f, os.path.join(DST, out))
     if os.path.exists(os.path.join(SRC, "matrix.jsonl")):
-        shutil.copy(os.path.join(SRC, "matrix.jsonl"), os.path.join(DST, "r02_bench_matrix.jsonl"))
-    with open(os.path.join(DST, "r02_mfma_valu_ubench.txt"), "w") as o:
-        for f in ("mfma_ubench.txt", "mfma_ubench2.txt", "mfma_ubench3.txt", "mfma_ubench4.txt"):
-            p = os.path.join(SRC, f)
-            if os.path.exists(p):
-                o.write(f"==== scripts/{f.replace('.txt', '.hip')} (MI355X, one wave per SIMD unless stated, 256 workgroups x 256 threads) ====\n{open(p).read()}\n")
-        o.write("-> mfma_ubench4 (read its TFLOP/s column): a second / fourth wave on the SIMD recovers only ~10-13 % (69 -> 76 -> 78 TFLOP/s at 4 VALU\n"
-                "   per MFMA): the VALU work occupies the pipe the f32 MFMA runs on (about 7 cycles per v_fma even when another wave's MFMAs are\n"
-                "   ready), it is not an in-order-issue stall of one wave.  Restructuring the learner for 2 waves per SIMD (it needs 444 of 512\n"
-                "   registers today) would not pay.\n")
+        shutil.copy(os.path.join(SRC, "matrix.jsonl"), os.path.join(DST, PFX + "_bench_matrix.jsonl"))
+    if os.path.exists(os.path.join(SRC, "mfma_ubench.txt")):
+        with open(os.path.join(DST, PFX + "_mfma_valu_ubench.txt"), "w") as o:
+            for f in ("mfma_ubench.txt", "mfma_ubench2.txt", "mfma_ubench3.txt", "mfma_ubench4.txt"):
+                p = os.path.join(SRC, f)
+                if os.path.exists(p):
+                    o.write(f"==== scripts/{f.replace('.txt', '.hip')} (MI355X, one wave per SIMD unless stated, 256 workgroups x 256 threads) ====\n{open(p).read()}\n")
+            o.write("-> mfma_ubench4 (read its TFLOP/s column): a second / fourth wave on the SIMD recovers only ~10-13 % (69 -> 76 -> 78 TFLOP/s at 4 VALU\n"
+                    "   per MFMA): the VALU work occupies the pipe the f32 MFMA runs on (about 7 cycles per v_fma even when another wave's MFMAs are\n"
+                    "   ready), it is not an in-order-issue stall of one wave.  Restructuring the learner for 2 waves per SIMD (it needs 444 of 512\n"
+                    "   registers today) would not pay.\n")
     if os.path.exists(os.path.join(SRC, "hbm_ubench.txt")):
-        shutil.copy(os.path.join(SRC, "hbm_ubench.txt"), os.path.join(DST, "r02_hbm_ubench.txt"))
-    # ---- HBM traffic of the learner kernel (two TCC passes; FETCH_SIZE doubled per MI355X_MICROARCH.md "HBM")
-    fe, wr, tcc = counters("FETCH_SIZE"), counters("WRITE_SIZE"), counters("TCC")
-    kernels = {}
-    for k in sorted(set(fe) | set(wr)):
-        if "marl::" not in k:
-            continue
-        f = fe[k].get("FETCH_SIZE", [])
-        w = wr[k].get("WRITE_SIZE", [])
-        ent = {"launches_profiled": max(len(f), len(w))}
-        if f:
-            ent["FETCH_SIZE_KiB_per_launch"] = sum(f) / len(f)
-            ent["hbm_read_bytes_corrected"] = 2.0 * 1024.0 * sum(f) / len(f)
-        if w:
-            ent["WRITE_SIZE_KiB_per_launch"] = sum(w) / len(w)
-            ent["hbm_write_bytes"] = 1024.0 * sum(w) / len(w)
-        if f and w:
-            ent["traffic_bytes"] = ent["hbm_read_bytes_corrected"] + ent["hbm_write_bytes"]
-        if k in tcc:
-            h, m = tcc[k].get("TCC_HIT_sum", []), tcc[k].get("TCC_MISS_sum", [])
-            if h and m:
-                ent["l2_hit_rate"] = sum(h) / max(1.0, sum(h) + sum(m))
-        kernels[short(k)] = ent
+        shutil.copy(os.path.join(SRC, "hbm_ubench.txt"), os.path.join(DST, PFX + "_hbm_ubench.txt"))
+    # ---- HBM traffic of the learner kernels (two TCC passes per workload; FETCH_SIZE doubled per MI355X_MICROARCH.md "HBM")
     P, D, T, B = 2, 15, 25, 4096
     alg_read = B * (4 * P * D * (T + 1) + P * T * 5 + (T + 1) + T)
-    lg = next((v for k, v in kernels.items() if k.startswith("dqn_lossgrad_kernel")), None)
     out = {"source": "rocprofv3 --kernel-trace --pmc <FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum> -- python bench.py --steps 4 --warmup 1 "
-                     "--no-cpu-baseline --no-kernel-timing (one counter set per run, scripts/collect_profiles.sh), MI355X, round 2",
+                     "--no-cpu-baseline --no-modes --no-kernel-timing [--hidden 128 | --split16] (one counter set per run), MI355X, " + PFX,
            "head": head,
            "units": "FETCH_SIZE / WRITE_SIZE are reported in KiB; read bytes = 2 x FETCH_SIZE (MI355X_MICROARCH.md, HBM: gfx950 tallies 128-B "
                     "read requests at 64 B), write bytes = WRITE_SIZE (the reduce kernel's known 5.7 MB record read calibrates the read side)",
-           "kernels": kernels, "workloads": {}}
-    if lg and "traffic_bytes" in lg:
-        out["workloads"]["idqn:lbforaging:Foraging-8x8-2p-3f-v3:N4096:H64:B4096:T25:rnn0"] = {
-            "kernel": "dqn_lossgrad_kernel<MlpShape<15, 64, 6>, 4, true, 0>", "traffic_bytes": lg["traffic_bytes"],
-            "algorithmic_bytes": {"replay_read": alg_read, "partial_records_write": 256 * (5574 + 2) * 4}}
-    json.dump(out, open(os.path.join(DST, "r02_pmc_traffic.json"), "w"), indent=1)
+           "kernels": {}, "workloads": {}}
+    for sfx, key, match, alg in (
+            ("", "idqn:lbforaging:Foraging-8x8-2p-3f-v3:N4096:H64:B4096:T25:rnn0", ("dqn_lossgrad_kernel",),
+             {"replay_read": alg_read, "partial_records_write": 256 * (5574 + 2) * 4}),
+            ("_h128", "idqn:lbforaging:Foraging-8x8-2p-3f-v3:N4096:H128:B4096:T25:rnn0", ("tp_fwd_kernel", "tp_mix_kernel", "tp_bwd_kernel"),
+             {"replay_read_two_passes": 2 * alg_read, "h2_activations_write_plus_read": 2 * P * T * B * 128 * 4, "partial_records_write": 256 * (19334 + 2) * 4}),
+            ("_s16", "idqn:lbforaging:Foraging-8x8-2p-3f-v3:N4096:H64:B4096:T25:rnn0:split16", ("dqn_lossgrad_h16_kernel",),
+             {"replay_read": alg_read, "partial_records_write": 256 * (5574 + 2) * 4})):
+        fe, wr, tcc = counters("FETCH_SIZE" + sfx), counters("WRITE_SIZE" + sfx), counters("TCC" + sfx)
+        kernels = {}
+        for k in sorted(set(fe) | set(wr)):
+            if "marl::" not in k:
+                continue
+            f = fe[k].get("FETCH_SIZE", [])
+            w = wr[k].get("WRITE_SIZE", [])
+            ent = {"launches_profiled": max(len(f), len(w))}
+            if f:
+                ent["FETCH_SIZE_KiB_per_launch"] = sum(f) / len(f)
+                ent["hbm_read_bytes_corrected"] = 2.0 * 1024.0 * sum(f) / len(f)
+            if w:
+                ent["WRITE_SIZE_KiB_per_launch"] = sum(w) / len(w)
+                ent["hbm_write_bytes"] = 1024.0 * sum(w) / len(w)
+            if f and w:
+                ent["traffic_bytes"] = ent["hbm_read_bytes_corrected"] + ent["hbm_write_bytes"]
+            if k in tcc:
+                h, m = tcc[k].get("TCC_HIT_sum", []), tcc[k].get("TCC_MISS_sum", [])
+                if h and m:
+                    ent["l2_hit_rate"] = sum(h) / max(1.0, sum(h) + sum(m))
+            kernels[short(k)] = ent
+        if not kernels:
+            continue
+        out["kernels"]["default" if not sfx else sfx[1:]] = kernels
+        parts = [v for k, v in kernels.items() if any(k.startswith(mm) for mm in match) and "traffic_bytes" in v]
+        if parts:
+            out["workloads"][key] = {"kernel": " + ".join(k for k in kernels if any(k.startswith(mm) for mm in match)),
+                                     "traffic_bytes": sum(v["traffic_bytes"] for v in parts), "algorithmic_bytes": alg}
+    json.dump(out, open(os.path.join(DST, PFX + "_pmc_traffic.json"), "w"), indent=1)
     # ---- SQ counters
     sq, inst = counters("SQ"), counters("INST")
     rows = []
@@ -110,15 +122,15 @@ def main():
         else:
             row.append("-")
         rows.append(row)
-    with open(os.path.join(DST, "r02_sq_pmc_summary.md"), "w") as o:
-        o.write("# SQ counters of the round-2 kernels (rocprofv3 --pmc, MI355X; scripts/collect_profiles.sh)\n\n"
+    with open(os.path.join(DST, PFX + "_sq_pmc_summary.md"), "w") as o:
+        o.write("# SQ counters (rocprofv3 --pmc, MI355X; " + PFX + ")\n\n"
                 f"git head of the profiled tree: `{head}`.  Fractions are of SQ_WAVE_CYCLES (quad-cycles); `mfma_busy` = SQ_VALU_MFMA_BUSY_CYCLES / (4 x "
                 "SQ_WAVE_CYCLES).  Instruction counts are per launch (all waves): VALU / MFMA / LDS / SALU / VMEM_RD.\n\n"
                 "| kernel | launches | wave quad-cycles / launch | WAIT_ANY | WAIT_INST_ANY | ACTIVE_INST_ANY | WAIT_INST_LDS | mfma_busy | LDS bank-conflict / LDS active | instructions per launch |\n"
                 "|---|---|---|---|---|---|---|---|---|---|\n")
         for r in sorted(rows, key=lambda r: -float(r[2])):
             o.write("| " + " | ".join(str(x) for x in r) + " |\n")
-    print("profiles written:", sorted(f for f in os.listdir(DST) if f.startswith("r02_")))
+    print("profiles written:", sorted(f for f in os.listdir(DST) if f.startswith(PFX + "_")))
 
 
 if __name__ == "__main__":
