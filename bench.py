@@ -544,6 +544,11 @@ def bench_dqn(args, rank, world, dist, steps, warmup):
                     "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": tsrc, "flops_per_launch": flops,
                     "flops_parts": parts, "avg_launch_us": lg["avg_us"],
                     "dominant_stage_by_time": "loss/grad" if not col or lg["total_ms"] >= col["total_ms"] else "idqn_collect_kernel"}
+        if getattr(args, "split16", False):
+            # the same ALGORITHMIC f32 FLOPs over the f32 MFMA peak (comparable with the default row); on the pipe it really runs on it
+            # issues 3 fp16 products per f32 product against the 2.5 PFLOP/s dense fp16 peak
+            roofline["note"] = "frac = algorithmic f32 FLOP/s over the f32-input MFMA peak (f32-equivalent, comparable with the default kernel's)"
+            roofline["fp16_pipe"] = {"issued_flops_per_launch": 3.0 * flops, "peak_TFLOPs": 2516.6, "frac": 3.0 * ach / 2516.6}
         if col and col["total_ms"] > lg["total_ms"]:
             cf = (gru_fwd_flops if args.rnn else mlp_fwd_flops)(D, H, A) * P * (env_steps / steps)
             roofline["collector"] = {"kernel": "idqn_collect_kernel", "bound": "mfma (latency-bound in practice)", "flops_per_launch": cf,
