@@ -177,7 +177,7 @@ int launch_backward_rows(int P, const AgentMap& am, const float* params, const m
         TpMix mix = {};
         mix.lrow = lrow;
         mix.dout = dout;
-        const size_t ldsB = (size_t)(NB * NT * 256 + NB * S::H * 16 + NB * NT * 256 + W * 256 * (1 + 3 * TPW)) * sizeof(float);
+        const size_t ldsB = (size_t)tp_bwd_lds_floats<S, W, TPW, NB, false>() * sizeof(float);
         static LdsAttr attr_set;
         if (attr_set.need()) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tp_bwd_kernel<S, W, TPW, false, NB, true>),

@@ -1171,8 +1171,9 @@ int launch_lossgrad_tp(const marlhip_net_shape* s, const float* params, const fl
     TpMix mix;
     mix.chosen = mixf; mix.tqsel = mixf + P * tb; mix.rew = mixf + 2 * P * tb; mix.dq = mixf + 3 * P * tb;
     mix.dn = mixf + 4 * P * tb; mix.fl = mix.dn + tb; mix.lrow = mix.fl + tb;
-    const size_t ldsF = (size_t)(2 * NBF * NT + 2 * NBF * W) * 256 * sizeof(float);
-    const size_t ldsB = (size_t)(NB * NT * 256 + NB * S::H * 16 + NB * NT * 256 + W * 256 * (1 + 3 * TPW)) * sizeof(float);
+    const size_t ldsF = 2 * (size_t)(2 * NBF * NT + 2 * NBF * W) * 256 * sizeof(float);  // two alternating sets (dqn_update_tp.h)
+    const size_t ldsB = (size_t)tp_bwd_lds_floats<S, W, TPW, NB, true>() * sizeof(float);
+    static_assert(2 * (2 * NBF * NT + 2 * NBF * W) * 256 * 4 <= 160 * 1024 && tp_bwd_lds_floats<S, W, TPW, NB, true>() * 4 <= 160 * 1024, "tensor-parallel passes: LDS");
     static LdsAttr attr_set;
     if (attr_set.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tp_fwd_kernel<S, W, TPW, REPLAY, NBF>),

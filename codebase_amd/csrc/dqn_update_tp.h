@@ -195,10 +195,10 @@ __global__ __launch_bounds__(64 * W, 1) void tp_fwd_kernel(const float* __restri
                                                            f4* __restrict__ h2_out) {
     constexpr int NT = W * TPW, A = S::A;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    f4* Hc = reinterpret_cast<f4*>(lds);
-    f4* Ht = Hc + NB * NT * 64;
-    f4* Qp = Ht + NB * NT * 64;
-    f4* Tp = Qp + NB * W * 64;
+    // TWO sets of the exchange regions, alternating with the time step: the next step writes the other set, so the barrier that used to
+    // protect this step's regions from the next step's writes is gone (two barriers per step instead of three; a set is rewritten two
+    // steps later, behind both barriers of the step in between)
+    constexpr int SETF = (2 * NB * NT + 2 * NB * W) * 64;  // f4 per set
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, j = lane & 15;
     const int p = blockIdx.y, P = gridDim.y;
     const int T = bt.max_len, B = bt.batch;
@@ -259,6 +259,10 @@ __global__ __launch_bounds__(64 * W, 1) void tp_fwd_kernel(const float* __restri
                 tp_mask_rows<S, REPLAY, false>(cur[nb], (set * NB + nb) * 16, B, g, j);
             }
             const bool need_t = t > t0;  // the target value of this step feeds transition t-1
+            f4* Hc = reinterpret_cast<f4*>(lds) + (t & 1) * SETF;
+            f4* Ht = Hc + NB * NT * 64;
+            f4* Qp = Ht + NB * NT * 64;
+            f4* Tp = Qp + NB * W * 64;
             // ---- layer 1 of my tiles, dumped for everybody
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb)
@@ -305,10 +309,12 @@ __global__ __launch_bounds__(64 * W, 1) void tp_fwd_kernel(const float* __restri
                 Tp[(nb * W + wave) * 64 + lane] = tq;
             }
             __syncthreads();
-            // ---- wave 0 finishes Q (partials summed in wave order) and publishes the mixer inputs
-            if (wave == 0) {
+            // ---- wave nb finishes the Q of row block nb (partials summed in wave order) and publishes the mixer inputs (one wave per block:
+            // the blocks' epilogues run side by side instead of one after the other on wave 0)
+            {
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
+                    if (wave != nb % W) continue;
                     const int b0 = (set * NB + nb) * 16;
                     const bool rowok = (b0 + j) < B;
                     const int bj = rowok ? b0 + j : B - 1;
@@ -342,11 +348,18 @@ __global__ __launch_bounds__(64 * W, 1) void tp_fwd_kernel(const float* __restri
                     }
                 }
             }
-            __syncthreads();  // LDS slots are rewritten by the next step
+            // (no barrier: the next step works on the other LDS set)
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) cur[nb] = nxt[nb];
         }
+        __syncthreads();  // the next task may start on either set
     }
+}
+
+// dynamic LDS of tp_bwd_kernel in floats: Hc | [HcT | G2] | per-wave tiles | (STORED) a second [HcT | G2] set
+template <class S, int W, int TPW, int NB, bool STORED>
+constexpr int tp_bwd_lds_floats() {
+    return NB * W * TPW * 256 + (STORED ? 2 : 1) * (NB * S::H * 16 + NB * W * TPW * 256) + W * 256 * NB * (1 + 3 * TPW);
 }
 
 // mixers: dq_p[t][b] = dL/dchosen_p (unnormalised), lrow[t][b] = per-row loss (dqn/model.py:152,160-163 / 254-269)
@@ -386,17 +399,19 @@ template <class S, int W, int TPW, bool REPLAY, int NB, bool FULL = false, bool 
 __global__ __launch_bounds__(64 * W, 1) void tp_bwd_kernel(const float* __restrict__ params, AgentMap am, marlhip_batch bt, ReplaySrc rs, TpMix mix,
                                                            int n_chunks, float* __restrict__ partials, const f4* __restrict__ h2_in = nullptr) {
     constexpr int NT = W * TPW, A = S::A, D = S::D, H = S::H, NT1 = S::DP / 16;
-    constexpr int PRIV = 256 * (1 + 3 * TPW);
+    constexpr int PRIV = 256 * NB * (1 + 3 * TPW);  // per wave: PQ[NB] | PH2[NB][TPW] | P2[NB][TPW] | P1[NB][TPW] tiles of 256 floats
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    // STORED: [HcT | G2] exist TWICE (behind the per-wave regions) and alternate with the time step, so the barrier that protected them from
+    // the next step's writes is gone: one barrier per step.  The recomputing form keeps the single set and its barriers.
     f4* Hc = reinterpret_cast<f4*>(lds);
-    float* HcT = lds + NB * NT * 256;
-    f4* G2 = reinterpret_cast<f4*>(HcT + NB * H * 16);
-    float* priv = HcT + NB * H * 16 + NB * NT * 256;
+    float* HcT0 = lds + NB * NT * 256;
+    float* priv = HcT0 + NB * H * 16 + NB * NT * 256;
+    float* set1 = priv + W * 256 * NB * (1 + 3 * TPW);  // second [HcT | G2] set (STORED only; tp_bwd_lds_floats)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, j = lane & 15;
     float* PQ = priv + wave * PRIV;
-    float* P2 = PQ + 256;
-    float* PH2 = P2 + 256 * TPW;
-    float* P1 = PH2 + 256 * TPW;
+    float* P2 = PQ + 256 * NB;
+    float* PH2 = P2 + 256 * NB * TPW;
+    float* P1 = PH2 + 256 * NB * TPW;
     const int p = blockIdx.y, P = gridDim.y;
     const int T = bt.max_len, B = bt.batch;
 
@@ -472,6 +487,8 @@ __global__ __launch_bounds__(64 * W, 1) void tp_bwd_kernel(const float* __restri
                 }
                 tp_mask_rows<S, REPLAY, true>(cur[nb], (set * NB + nb) * 16, B, g, j);
             }
+            float* HcT = (STORED && (t & 1)) ? set1 : HcT0;
+            f4* G2 = reinterpret_cast<f4*>(HcT + NB * H * 16);
             // ---- layer 1 of my tiles: C-layout dump (layer-2 operand) + [h][row] tile (dW2 operand)
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb)
@@ -488,6 +505,112 @@ __global__ __launch_bounds__(64 * W, 1) void tp_bwd_kernel(const float* __restri
                     for (int r = 0; r < 4; ++r) HcT[(nb * H + 16 * tau + 4 * g + r) * 16 + j] = acc[r];
                 }
             if constexpr (!STORED) __syncthreads();  // (STORED: nothing of another wave is read before the barrier behind dH2)
+            if constexpr (STORED) {
+                // The two phases in BATCHED form: every private tile of the step (per row block nb and owned hidden tile u) has its own LDS
+                // slot, so all of a phase's tile writes go out together, ONE wave fence later all reads come back together, and the
+                // (nb, u) MFMA chains are interleaved instead of each waiting out its own LDS round trips (12 fences per step before).
+                // Per accumulator the order of products is unchanged (nb ascending, k ascending): bitwise the same gradient.
+                f4 dQ[NB][1], d2[NB][TPW];
+                wave_lds_fence();  // the previous step's reads of these slots have retired
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const int a_sel = cur[nb].a_sel;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dQ[nb][0][r] = FULL ? cur[nb].dqv[r] : ((4 * g + r == a_sel) ? cur[nb].dq : 0.f);
+                    if (wave == 0) {
+                        db3 += dQ[nb][0];
+                        if (g == 0 && p == 0) { loss_acc += cur[nb].lr; nfill_acc += cur[nb].fl; }
+                    }
+                    tile_write<1>(PQ + 256 * nb, dQ[nb], g, j);
+#pragma unroll
+                    for (int u = 0; u < TPW; ++u) {
+                        f4 hh[1] = {h2c[nb][u]};
+                        tile_write<1>(PH2 + 256 * (nb * TPW + u), hh, g, j);
+                        d2[nb][u] = zero4;
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                        for (int u = 0; u < TPW; ++u) d2[nb][u] = MARL_MFMA(t3[u][r], dQ[nb][0][r], d2[nb][u]);
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                    for (int u = 0; u < TPW; ++u) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) d2[nb][u][r] = h2c[nb][u][r] > 0.f ? d2[nb][u][r] : 0.f;
+                        db2[u] += d2[nb][u];
+                        G2[(nb * NT + wave * TPW + u) * 64 + lane] = d2[nb][u];
+                    }
+                wave_lds_fence();
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const f4 aQ = tile_read(PQ + 256 * nb, 0, g, j);
+                    f4 bH2[TPW];
+#pragma unroll
+                    for (int u = 0; u < TPW; ++u) bH2[u] = tile_read(PH2 + 256 * (nb * TPW + u), 0, g, j);
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                        for (int u = 0; u < TPW; ++u) dW3[u] = MARL_MFMA(aQ[ks], bH2[u][ks], dW3[u]);
+                }
+                __syncthreads();
+                // ---- dH1 = W2^T dH2 (mask): NB x TPW independent chains, k ascending in each
+                f4 d1[NB][TPW];
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                    for (int u = 0; u < TPW; ++u) d1[nb][u] = zero4;
+#pragma unroll
+                for (int kap = 0; kap < NT; ++kap) {
+                    f4 gk[NB];
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) gk[nb] = G2[(nb * NT + kap) * 64 + lane];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                            for (int u = 0; u < TPW; ++u) d1[nb][u] = MARL_MFMA(t2[u][kap][r], gk[nb][r], d1[nb][u]);
+                }
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                    for (int u = 0; u < TPW; ++u) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) d1[nb][u][r] = h1[nb][u][r] > 0.f ? d1[nb][u][r] : 0.f;
+                        db1[u] += d1[nb][u];
+                        f4 own[1] = {G2[(nb * NT + wave * TPW + u) * 64 + lane]}, mine[1] = {d1[nb][u]};
+                        tile_write<1>(P2 + 256 * (nb * TPW + u), own, g, j);   // transposed A operands: my dH2 tile (from its C dump) ...
+                        tile_write<1>(P1 + 256 * (nb * TPW + u), mine, g, j);  // ... and my dH1 tile
+                    }
+                wave_lds_fence();
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    f4 aG2[TPW], aG1[TPW];
+#pragma unroll
+                    for (int u = 0; u < TPW; ++u) {
+                        aG2[u] = tile_read(P2 + 256 * (nb * TPW + u), 0, g, j);
+                        aG1[u] = tile_read(P1 + 256 * (nb * TPW + u), 0, g, j);
+                    }
+#pragma unroll
+                    for (int nu = 0; nu < NT; ++nu) {
+                        const f4 bH1 = tile_read(HcT + nb * H * 16, nu, g, j);
+#pragma unroll
+                        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                            for (int u = 0; u < TPW; ++u) dW2[u][nu] = MARL_MFMA(aG2[u][ks], bH1[ks], dW2[u][nu]);
+                    }
+#pragma unroll
+                    for (int nt = 0; nt < NT1; ++nt)
+#pragma unroll
+                        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                            for (int u = 0; u < TPW; ++u) dW1[u][nt] = MARL_MFMA(aG1[u][ks], cur[nb].bx[nt][ks], dW1[u][nt]);
+                }
+            } else {
             // ---- layer 2, dH2 = W3^T dQ (mask), dW3, dumps of dH2
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
@@ -573,7 +696,8 @@ __global__ __launch_bounds__(64 * W, 1) void tp_bwd_kernel(const float* __restri
                         for (int ks = 0; ks < 4; ++ks) dW1[u][nt] = MARL_MFMA(aG1[ks], cur[nb].bx[nt][ks], dW1[u][nt]);
                 }
             }
-            __syncthreads();  // Hc / HcT / G2 are rewritten by the next step
+            __syncthreads();  // Hc / HcT / G2 are rewritten by the next step (STORED: the next step uses the other set, no barrier)
+            }  // !STORED
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
                 cur[nb] = nxt[nb];
@@ -583,6 +707,7 @@ __global__ __launch_bounds__(64 * W, 1) void tp_bwd_kernel(const float* __restri
                 }
             }
         }
+        if constexpr (STORED) __syncthreads();  // the next task may start on either set
     }
 
     // ---- every wave owns disjoint slices of the gradient: straight to the workgroup's partial record
