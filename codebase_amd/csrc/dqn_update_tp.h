@@ -263,50 +263,80 @@ __global__ __launch_bounds__(64 * W, 1) void tp_fwd_kernel(const float* __restri
             f4* Ht = Hc + NB * NT * 64;
             f4* Qp = Ht + NB * NT * 64;
             f4* Tp = Qp + NB * W * 64;
-            // ---- layer 1 of my tiles, dumped for everybody
+            // ---- layer 1 of my tiles, dumped for everybody (the 2 NB TPW chains advance together)
+            {
+                f4 a1c[NB][TPW], a1t[NB][TPW];
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
+                for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-                for (int u = 0; u < TPW; ++u) {
-                    f4 acc = cw[u].b1s, acct = tw[u].b1s;
+                    for (int u = 0; u < TPW; ++u) { a1c[nb][u] = cw[u].b1s; a1t[nb][u] = tw[u].b1s; }
 #pragma unroll
-                    for (int ks = 0; ks < S::KS1; ++ks) {
-                        acc = MARL_MFMA(cw[u].a1[ks], cur[nb].x[ks], acc);
-                        acct = MARL_MFMA(tw[u].a1[ks], cur[nb].x[ks], acct);
-                    }
-                    Hc[(nb * NT + wave * TPW + u) * 64 + lane] = relu4(acc);
-                    Ht[(nb * NT + wave * TPW + u) * 64 + lane] = relu4(acct);
-                }
-            __syncthreads();
-            // ---- layer 2 of my tiles + my split-K share of layer 3
+                for (int ks = 0; ks < S::KS1; ++ks)
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                f4 q = cb3, tq = tb3;
+                    for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-                for (int u = 0; u < TPW; ++u) {
-                    f4 acc = cw[u].b2s, acct = tw[u].b2s;
-#pragma unroll
-                    for (int kap = 0; kap < NT; ++kap) {
-                        const f4 hk = Hc[(nb * NT + kap) * 64 + lane];
-                        const f4 gk = Ht[(nb * NT + kap) * 64 + lane];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            acc = MARL_MFMA(cw[u].a2[kap][r], hk[r], acc);
-                            acct = MARL_MFMA(tw[u].a2[kap][r], gk[r], acct);
+                        for (int u = 0; u < TPW; ++u) {
+                            a1c[nb][u] = MARL_MFMA(cw[u].a1[ks], cur[nb].x[ks], a1c[nb][u]);
+                            a1t[nb][u] = MARL_MFMA(tw[u].a1[ks], cur[nb].x[ks], a1t[nb][u]);
                         }
-                    }
-                    acc = relu4(acc);
-                    acct = relu4(acct);
-                    if (h2_out != nullptr && t < t1)  // a transition row of this chunk (t1 itself only bootstraps here)
-                        h2_out[((((size_t)p * T + t) * tp_h2_blocks(B) + (set * NB + nb)) * NT + wave * TPW + u) * 64 + lane] = acc;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        q = MARL_MFMA(ca3[u][r], acc[r], q);
-                        tq = MARL_MFMA(ta3[u][r], acct[r], tq);
+                for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                    for (int u = 0; u < TPW; ++u) {
+                        Hc[(nb * NT + wave * TPW + u) * 64 + lane] = relu4(a1c[nb][u]);
+                        Ht[(nb * NT + wave * TPW + u) * 64 + lane] = relu4(a1t[nb][u]);
+                    }
+            }
+            __syncthreads();
+            // ---- layer 2 of my tiles + my split-K share of layer 3.  The (row block, owned tile, network) chains - 2 NB TPW of them - advance
+            // together, k ascending in each (bitwise the order of the one-chain-at-a-time form): no MFMA waits for its own predecessor
+            {
+                f4 acc[NB][TPW], acct[NB][TPW];
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                    for (int u = 0; u < TPW; ++u) { acc[nb][u] = cw[u].b2s; acct[nb][u] = tw[u].b2s; }
+#pragma unroll
+                for (int kap = 0; kap < NT; ++kap) {
+                    f4 hk[NB], gk[NB];
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) { hk[nb] = Hc[(nb * NT + kap) * 64 + lane]; gk[nb] = Ht[(nb * NT + kap) * 64 + lane]; }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                            for (int u = 0; u < TPW; ++u) {
+                                acc[nb][u] = MARL_MFMA(cw[u].a2[kap][r], hk[nb][r], acc[nb][u]);
+                                acct[nb][u] = MARL_MFMA(tw[u].a2[kap][r], gk[nb][r], acct[nb][u]);
+                            }
+                }
+                f4 q[NB], tq[NB];
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    q[nb] = cb3; tq[nb] = tb3;
+#pragma unroll
+                    for (int u = 0; u < TPW; ++u) {
+                        acc[nb][u] = relu4(acc[nb][u]);
+                        acct[nb][u] = relu4(acct[nb][u]);
+                        if (h2_out != nullptr && t < t1)  // a transition row of this chunk (t1 itself only bootstraps here)
+                            h2_out[((((size_t)p * T + t) * tp_h2_blocks(B) + (set * NB + nb)) * NT + wave * TPW + u) * 64 + lane] = acc[nb][u];
                     }
                 }
-                Qp[(nb * W + wave) * 64 + lane] = q;
-                Tp[(nb * W + wave) * 64 + lane] = tq;
+#pragma unroll
+                for (int u = 0; u < TPW; ++u)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) {
+                            q[nb] = MARL_MFMA(ca3[u][r], acc[nb][u][r], q[nb]);
+                            tq[nb] = MARL_MFMA(ta3[u][r], acct[nb][u][r], tq[nb]);
+                        }
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    Qp[(nb * W + wave) * 64 + lane] = q[nb];
+                    Tp[(nb * W + wave) * 64 + lane] = tq[nb];
+                }
             }
             __syncthreads();
             // ---- wave nb finishes the Q of row block nb (partials summed in wave order) and publishes the mixer inputs (one wave per block:
