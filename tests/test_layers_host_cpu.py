@@ -21,7 +21,8 @@ def test_which_kernel_family_a_layer_list_runs_on():
     assert M.compiled_width([64]) == 64 and M.compiled_width([100, 50, 30, 20]) == 112 and M.compiled_width([8, 8, 8]) == 16
     for hidden in ([256, 256], [129, 5], [64], [64, 64, 64], [100, 50, 30, 20]):
         assert M.is_wide(hidden)
-    for hidden in ([], [64] * 5, [2048, 2048], [0, 64], [1025]):
+    assert M.compiled_width([64] * 5) == 64 and M.is_wide([64] * 5) and M.recurrent_width([40, 40]) == (40, 64) and M.recurrent_width([100, 100]) == (100, 128)
+    for hidden in ([], [64] * 17, [2048, 2048], [0, 64], [1025]):
         with pytest.raises(NotImplementedError):
             M.compiled_width(hidden)
 
