@@ -37,11 +37,21 @@ int64_t forward_scratch_bytes(int P, int n_rows) {
     else return (int64_t)P * S::NFWD * 4 + 16;
 }
 
-// ---- forward rows ------------------------------------------------------------------------------------------
+// shapes whose backward-rows pass is the tensor-parallel kernel (hidden 128, wide rows): their forward-rows pass can leave the second
+// hidden layer for it (dqn_update_tp.h, tp_bwd_kernel<STORED>), so that the backward pass does not recompute layer 2
 template <class S>
+constexpr bool tp_mlp_shape() {
+    if constexpr (IsGru<S>::value || IsWide<S>::value) return false;
+    else return use_tp<S>();
+}
+
+// ---- forward rows ------------------------------------------------------------------------------------------
+// H2: also store the second hidden layer of every row block in the layout tp_bwd_kernel<STORED> reads (rows = t * B + b, B % 16 == 0:
+// row block bk = (t, b0 / 16)): h2_out[(((p T + t) tp_h2_blocks(B) + blk) MT + tile) 64 + lane]
+template <class S, bool H2 = false>
 __global__ __launch_bounds__(256) void mlp_rows_fwd_kernel(const float* __restrict__ packs /* pre-packed [P][NFWD] */, const float* __restrict__ obs,
                                                            size_t agent_stride, size_t row_stride, int n_rows,
-                                                           float* __restrict__ out) {
+                                                           float* __restrict__ out, f4* __restrict__ h2_out = nullptr, int T = 0, int B = 0) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, j = lane & 15;
     const int p = blockIdx.y;
@@ -65,7 +75,23 @@ __global__ __launch_bounds__(256) void mlp_rows_fwd_kernel(const float* __restri
             }
         }
         f4 q[2];
-        mlp_forward_p2<S>(lds, lane, x, q);
+        if constexpr (H2) {
+            f4 h2[2][S::MT];
+            mlp_forward_p2<S, true>(lds, lane, x, q, h2);
+            const int bpt = B >> 4;  // row blocks per time step
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int bk = 2 * pr + h;
+                if (bk < nblk) {
+                    const int t = bk / bpt, blk = bk - t * bpt;
+                    f4* dst = h2_out + ((((size_t)p * T + t) * tp_h2_blocks(B) + blk) * S::MT) * 64 + lane;
+#pragma unroll
+                    for (int mt = 0; mt < S::MT; ++mt) dst[mt * 64] = h2[h][mt];
+                }
+            }
+        } else {
+            mlp_forward_p2<S>(lds, lane, x, q);
+        }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             if (row[h] < n_rows) {
@@ -109,7 +135,6 @@ int launch_forward_rows(int P, const AgentMap& am, const float* params, const ma
         }
         return 0;
     } else {
-    (void)rec;
     const int T = bt->max_len, B = bt->batch;
     const size_t as = bt->obs_agent_stride > 0 ? (size_t)bt->obs_agent_stride : (bt->obs_agent_stride < 0 ? 0 : (size_t)(T + 1) * B * S::D);
     const size_t rs = bt->obs_row_stride ? (size_t)bt->obs_row_stride : (size_t)S::D;
@@ -127,6 +152,19 @@ int launch_forward_rows(int P, const AgentMap& am, const float* params, const ma
     if (gx > cap) gx = cap;
     float* packs = nullptr;
     if (launch_fwd_pack<S>(P, am, params, &packs, st) != 0) return -1;
+    if constexpr (use_tp<S>()) {
+        if (rec != nullptr) {  // leave h2 for tp_bwd_kernel<STORED> (the caller checked n_rows == T * B and B % 16 == 0)
+            static LdsAttr attr_h2;
+            if (attr_h2.need()) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_rows_fwd_kernel<S, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
+                attr_h2.done();
+            }
+            hipLaunchKernelGGL((mlp_rows_fwd_kernel<S, true>), dim3(gx, P), dim3(256), LDSB, st, (const float*)packs, bt->obss, as, rs, n_rows, out,
+                               reinterpret_cast<f4*>(rec), T, B);
+            MARL_CHECK_LAUNCH("mlp_rows_fwd_kernel<H2>");
+            return 0;
+        }
+    }
     hipLaunchKernelGGL((mlp_rows_fwd_kernel<S>), dim3(gx, P), dim3(256), LDSB, st, (const float*)packs, bt->obss, as, rs, n_rows, out);
     MARL_CHECK_LAUNCH("mlp_rows_fwd_kernel");
     return 0;
@@ -165,7 +203,6 @@ int launch_backward_rows(int P, const AgentMap& am, const float* params, const m
         const int64_t rs = bt->obs_row_stride ? bt->obs_row_stride : s.D;
         return wide_backward_rows(s, P, am, params, bt->obss, as, rs, T * B, bt->filled, dout, (int64_t)T * B * s.A, lrow, ws, grad, loss, st);
     } else {
-    (void)rec;
     const int T = bt->max_len, B = bt->batch;
     MARL_REQUIRE(ws_bytes >= backward_ws_bytes<S>(P, T, B), "ac backward: workspace %lld too small", (long long)ws_bytes);
     ReplaySrc none = {};
@@ -178,14 +215,23 @@ int launch_backward_rows(int P, const AgentMap& am, const float* params, const m
         mix.lrow = lrow;
         mix.dout = dout;
         const size_t ldsB = (size_t)tp_bwd_lds_floats<S, W, TPW, NB, false>() * sizeof(float);
+        const size_t ldsS = (size_t)tp_bwd_lds_floats<S, W, TPW, NB, true>() * sizeof(float);
+        static_assert(tp_bwd_lds_floats<S, W, TPW, NB, true>() * 4 <= 160 * 1024, "tp_bwd_kernel<STORED>: LDS");
         static LdsAttr attr_set;
         if (attr_set.need()) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tp_bwd_kernel<S, W, TPW, false, NB, true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsB);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tp_bwd_kernel<S, W, TPW, false, NB, true, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsS);
             attr_set.done();
         }
-        hipLaunchKernelGGL((tp_bwd_kernel<S, W, TPW, false, NB, true>), dim3(pl.nwg, P), dim3(64 * W), ldsB, st, params, am, *bt, none, mix,
-                           pl.n_chunks, (float*)ws);
+        if (rec != nullptr) {  // the forward-rows pass of this step left the second hidden layer: no layer-2 recompute (dqn_update_tp.h)
+            hipLaunchKernelGGL((tp_bwd_kernel<S, W, TPW, false, NB, true, true>), dim3(pl.nwg, P), dim3(64 * W), ldsS, st, params, am, *bt, none, mix,
+                               pl.n_chunks, (float*)ws, reinterpret_cast<const f4*>(rec));
+        } else {
+            hipLaunchKernelGGL((tp_bwd_kernel<S, W, TPW, false, NB, true>), dim3(pl.nwg, P), dim3(64 * W), ldsB, st, params, am, *bt, none, mix,
+                               pl.n_chunks, (float*)ws);
+        }
         MARL_CHECK_LAUNCH("tp_bwd_kernel<FULL>");
     } else {
         using L = UpdLds<S>;
@@ -440,7 +486,9 @@ AcWs ac_ws_layout(int P, int T, int B) {
     w.packs = take(w.packs_bytes / 4 + 1);
     w.rec_a = w.rec_c = o;  // recurrent networks: the activation records of this step's actor / critic forward passes
     if constexpr (IsGru<SA>::value) w.rec_a = take(gru_rec_floats<SA>(P, T, B));
+    else if constexpr (tp_mlp_shape<SA>()) w.rec_a = take(tp_h2_floats(P, T, B, SA::H));  // second hidden layer of the actors' rows for their backward pass
     if constexpr (IsGru<SC>::value) w.rec_c = take(gru_rec_floats<SC>(P, T, B));
+    else if constexpr (tp_mlp_shape<SC>()) w.rec_c = take(tp_h2_floats(P, T, B, SC::H));
     w.bwd = o;
     const int64_t ba = backward_ws_bytes<SA>(P, T, B), bc = backward_ws_bytes<SC>(P, T, B);
     // recurrent networks: the two backward passes run side by side (side_stream) and need a workspace each
@@ -478,8 +526,8 @@ int ac_step_t(int P, const AgentMap& am, const float* actor, const float* critic
     a.standardise = std_on ? 1 : 0;
     int rc;
     timing_begin(TIMER_LOSSGRAD, st);
-    float* rec_a = IsGru<SA>::value && mode != 1 ? f(wl.rec_a) : nullptr;
-    float* rec_c = IsGru<SC>::value ? f(wl.rec_c) : nullptr;
+    float* rec_a = (IsGru<SA>::value || (tp_mlp_shape<SA>() && B % 16 == 0)) && mode != 1 ? f(wl.rec_a) : nullptr;
+    float* rec_c = (IsGru<SC>::value || (tp_mlp_shape<SC>() && B % 16 == 0 && mode != 1)) ? f(wl.rec_c) : nullptr;
     bool v_done = false;
     // PPO's passes with recurrent networks (prepare: target critics + actors; epochs: actors + critics): the critics' sequence pass
     // goes to the side stream next to the actors' (each fills half of the SIMDs), with its packs in the critics' backward workspace

@@ -406,8 +406,8 @@ __device__ __forceinline__ void mlp_forward_g(const float* __restrict__ gpack, i
 // One network on TWO 16-row blocks at once: every A operand fetched from LDS feeds two MFMAs, which halves the LDS
 // operand traffic per flop (at hidden 128 a single-block forward reads 327 KB of operands per 320 MFMAs - the LDS port
 // and the matrix pipe then run at the same rate).  Same pipelining and per-output summation order as mlp_forward_p.
-template <class S>
-__device__ __forceinline__ void mlp_forward_p2(const float* lds, int lane, const float (&x)[2][S::KS1], f4 (&q)[2]) {
+template <class S, bool WANT_H2 = false>
+__device__ __forceinline__ void mlp_forward_p2(const float* lds, int lane, const float (&x)[2][S::KS1], f4 (&q)[2], f4 (*h2_out)[S::MT] = nullptr) {
     constexpr int MT = S::MT, N1 = S::KS1 / 4;
     const int g = lane >> 4;
     const f4* A1 = reinterpret_cast<const f4*>(lds + S::pA1);
@@ -469,6 +469,10 @@ __device__ __forceinline__ void mlp_forward_p2(const float* lds, int lane, const
     constexpr int c3 = (N1 + MT) & 1;
     q[0] = o3;
     q[1] = o3;
+    if constexpr (WANT_H2) {  // the second hidden layer (post-relu, C layout) for a backward pass that does not want to recompute it
+#pragma unroll
+        for (int k1 = 0; k1 < MT; ++k1) { h2_out[0][k1] = relu4(acc[0][k1]); h2_out[1][k1] = relu4(acc[1][k1]); }
+    }
 #pragma unroll
     for (int k1 = 0; k1 < MT; ++k1)
 #pragma unroll
