@@ -6,16 +6,16 @@
 //   delta = y - (r_0 + gamma y' (1 - done)),  dq_p = dL/dchosen_p,  gradient of the mixer parameters
 //
 // with s = the concatenation of all agents' observations (model.py:389,412; state_dim = P*D, model.py:360).
-// One row = one (t, b) pair, R = T*B rows.  Four kernels, every GEMM on v_mfma_f32_16x16x4_f32 (exact f32):
-//   qmix_l1_kernel    Y1[R][192] = act(S W1cat^T + bias): the four state-fed first layers in ONE GEMM
-//                     (features [0,32) hyper_w_1.0 +ReLU | [32,64) hyper_w_final.0 +ReLU | [64,128) hyper_b_1 |
-//                     [128,192) V.0 +ReLU).  Weights stream through LDS in 64-column K chunks, 32 rows per wave.
-//   qmix_mix_kernel   per 16-row block, wave-independent: w1 = |hyper_w_1.2 h1 + c|, z = sum_p q_p w1_p + b1,
-//                     hidden = elu(z), wf = |hyper_w_final.2 hf + c|, y = hidden.wf + V.2 hv + c.  The online
-//                     instance continues with the TD error and the backward down to the first-layer
-//                     pre-activations; it writes dq_p and the operands of the weight-gradient GEMMs.
-//   qmix_wgrad1/2_kernel split-K (over rows) weight-gradient GEMMs; 8 waves own disjoint accumulator tiles, no LDS,
-//                     next block's operands prefetched.
+// One row = one (t, b) pair, R = T*B rows.  Three launches, every GEMM on v_mfma_f32_16x16x4_f32 (exact f32):
+//   qmix_net_kernel<target>  per 16-row block and wave: Y1 = act(S W1cat^T + bias), the four state-fed first layers in ONE GEMM
+//                     (features [0,32) hyper_w_1.0 +ReLU | [32,64) hyper_w_final.0 +ReLU | [64,128) hyper_b_1 | [128,192) V.0 +ReLU;
+//                     weights stream through an LDS window in 64-column K chunks), kept in registers and fed straight into the mixing
+//                     network: w1 = |hyper_w_1.2 h1 + c|, z = sum_p q_p w1_p + b1, hidden = elu(z), wf = |hyper_w_final.2 hf + c|,
+//                     y = hidden.wf + V.2 hv + c.  The [T*B][192] first-layer activations never exist in memory.
+//   qmix_net_kernel<online>  the same, then the TD error and the backward down to the first-layer pre-activations; it writes dq_p and
+//                     the operands of the weight-gradient GEMMs.
+//   qmix_wgrad_kernel split-K (over rows) weight-gradient GEMMs, both groups (first layers | mixing network) side by side in one
+//                     launch; 8 waves own disjoint accumulator tiles, no LDS, next block's operands prefetched.
 //   qmix_reduce_kernel sums the per-workgroup records in fixed order and applies 1/sum(filled).
 // hypernet_layers == 2, embed_dim 64, hypernet_embed 32 (configs/algorithm/qmix.yaml:14-17) are compiled in.
 // d|x|/dx at exactly 0 is taken as -1 (torch: 0): a pre-activation that is exactly 0.0f does not occur with
@@ -24,6 +24,12 @@
 
 #ifndef MARL_QMIX_L1_NB
 #define MARL_QMIX_L1_NB 1  // row blocks per wave and step in qmix_l1_kernel (register blocking vs resident workgroups per CU)
+#endif
+#ifndef MARL_QMIX_FUSE_NCH
+// Shapes with at most this many 64-column K chunks of first-layer weights take the fused per-instance kernel, the rest the split form.
+// Measured (profiles/r03_qmix_mixer_ab.md): fused wins with 1-3 chunks (2p 8x8: 110 vs 162 us for both instances, 4p 15x15: 465 vs 535,
+// rware 2ag: 1009 vs 1237); with 5 chunks and 8 agents the fused online instance spills (150 KB of mixing pack leave it one wave per SIMD).
+#define MARL_QMIX_FUSE_NCH 3
 #endif
 
 namespace marl {
@@ -147,7 +153,7 @@ __device__ __forceinline__ size_t qmix_state_off(int k, size_t ps) {  // k < SD
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// first layers: Y1[row][192]
+// split form (shapes whose first-layer weights stream through LDS in many K chunks, MARL_QMIX_FUSE_NCH): first layers Y1[row][192]
 // ---------------------------------------------------------------------------------------------------------
 // HALF: the A operands come as fp16 (packh: h4 per entry) and the states are rounded to fp16 on the way in (LBF / warehouse observations
 // are small integers: exact); one v_mfma_f32_16x16x16_f16 per (k-group, tile) instead of four f32 MFMAs, fp32 accumulation, fp32 bias.
@@ -243,8 +249,9 @@ __global__ __launch_bounds__(256) void qmix_l1_kernel(const float* __restrict__ 
     }
 }
 
+
 // ---------------------------------------------------------------------------------------------------------
-// mixing network on one 16-row block per wave
+// one mixer instance on one 16-row block per wave: first layers -> mixing network (-> TD error and backward)
 // ---------------------------------------------------------------------------------------------------------
 struct QmixIo {
     const float* chosen;  // [P][R]
@@ -261,11 +268,14 @@ struct QmixIo {
 // backward operands, written by the online instance (Rp = rows padded to whole blocks, nblk = Rp/16):
 //   G1T [nblk][192][16]  d(pre-activation) of the first layers, feature-major inside a block (an MFMA A tile)
 //   DW1T[nblk][E*P][16]  d(pre-abs w1),  DWFT[nblk][64][16]  d(pre-abs w_final),  DY[Rp]  dL/dy
+//   HB  [Rp][192]        the online first-layer activations the weight gradients multiply with: columns [0,32) h1, [32,64) hf,
+//                        [128,192) hv (columns [64,128), hyper_b_1's output, are not needed again and not written)
 struct QmixBwd {
     float* G1T;
     float* DW1T;
     float* DWFT;
     float* DY;
+    float* HB;
 };
 
 template <int N>
@@ -276,28 +286,295 @@ __device__ __forceinline__ void qmix_store_tiles(float* dst, const f4 (&v)[N], i
         for (int r = 0; r < 4; ++r) dst[(16 * mt + 4 * g + r) * 16 + j] = v[mt][r];
 }
 
+// The backward transposes of hyper_w_1.2 / hyper_w_final.2 (T1 | TF, online instance) stay in L2 instead of LDS when the forward pack, they
+// and the first-layer window do not fit the 160 KB together (8 agents: 150 KB of mixing pack alone).
+template <class Q>
+constexpr int qmix_l1_window_floats(bool half) { return (Q::NCH == 1 ? Q::KS4 : 4) * Q::MT1 * 256 / (half ? 2 : 1); }
+template <class Q>
+constexpr bool qmix_t1_global(bool half) { return (Q::NMIX + qmix_l1_window_floats<Q>(half)) * 4 > 160 * 1024; }
 template <class Q, bool ONLINE>
-__global__ __launch_bounds__(256, 1) void qmix_mix_kernel(const float* __restrict__ pack, const float* __restrict__ Y1, QmixIo io, int R,
-                                                          float gamma, QmixBwd bw) {
-    constexpr int P = Q::P, W1T = Q::W1T, NPK = ONLINE ? Q::NMIX : Q::NMIX_FWD;
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, j = lane & 15;
-    {
-        f4* l4 = reinterpret_cast<f4*>(lds);
-        const f4* p4 = reinterpret_cast<const f4*>(pack);
-        copy_f4_to_lds(p4, l4, NPK / 4, tid, 256);
-        __syncthreads();
-    }
+constexpr int qmix_net_lds_floats(bool half) {
+    return ((ONLINE && !qmix_t1_global<Q>(half)) ? Q::NMIX : Q::NMIX_FWD) + qmix_l1_window_floats<Q>(half);
+}
+
+// The mixing network (and, ONLINE, the TD error and the backward) of one 16-row block on one wave, from the first-layer activations in the
+// MFMA's C layout (feature 4g+r of tile k, row j).  lds: the staged mixing pack; TG: T1 | TF are read from the pack in global memory.
+// HB: write the activations the weight gradients need (the fused kernel; the split form has all of Y1 in memory already).
+template <class Q, bool ONLINE, bool TG, bool HB>
+__device__ __forceinline__ void qmix_mix_block(const float* lds, const float* __restrict__ packMix, const f4 (&h1)[2], const f4 (&hf)[2], f4 (&z)[4],
+                                               const f4 (&hv)[4], const QmixIo& io, int R, float gamma, const QmixBwd& bw, int blk, int lane) {
+    constexpr int P = Q::P, W1T = Q::W1T;
+    const int g = lane >> 4, j = lane & 15;
+    const int row = blk * 16 + j;
+    const bool ok = row < R;
+    const int rc = ok ? row : R - 1;
     const f4* P1 = reinterpret_cast<const f4*>(lds + Q::mP1);
     const f4* PF = reinterpret_cast<const f4*>(lds + Q::mPF);
-    const f4* T1 = reinterpret_cast<const f4*>(lds + Q::mT1);
-    const f4* TF = reinterpret_cast<const f4*>(lds + Q::mTF);
-    const int nblk = (R + 15) / 16;
-    for (int blk = blockIdx.x * 4 + wave; blk < nblk; blk += gridDim.x * 4) {
+    auto t1_at = [&](int idx) -> f4 {  // T1 | TF entry (TF starts at (mTF - mT1) / 4)
+        if constexpr (TG) return reinterpret_cast<const f4*>(packMix + Q::mT1)[idx];
+        else return reinterpret_cast<const f4*>(lds + Q::mT1)[idx];
+    };
+    float q[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) q[p] = (ONLINE ? io.chosen : io.tqsel)[(size_t)p * R + rc];
+    // w1 pre-abs = hyper_w_1.2 h1 + c1 ; z += q_p |w1_p|, agent by agent (the target instance keeps no w1 tiles)
+    f4 w1[ONLINE ? W1T : 4];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+#pragma unroll
+        for (int et = 0; et < 4; ++et) {
+            const int mt2 = 4 * p + et;
+            f4 a2 = *reinterpret_cast<const f4*>(lds + Q::mc1 + 16 * mt2 + 4 * g);
+#pragma unroll
+            for (int k1 = 0; k1 < 2; ++k1) {
+                const f4 a = P1[(mt2 * 2 + k1) * 64 + lane];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) a2 = MARL_MFMA(a[r], h1[k1][r], a2);
+            }
+            w1[ONLINE ? mt2 : et] = a2;
+        }
+#pragma unroll
+        for (int et = 0; et < 4; ++et)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) z[et][r] = fmaf(q[p], fabsf(w1[ONLINE ? 4 * p + et : et][r]), z[et][r]);
+        if (!ONLINE) __builtin_amdgcn_sched_barrier(0);  // keep the agents' tile groups from being interleaved (register pressure)
+    }
+    f4 ez[4], hid[4], wfp[4];
+#pragma unroll
+    for (int et = 0; et < 4; ++et)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            ez[et][r] = expf(fminf(z[et][r], 0.f));
+            hid[et][r] = z[et][r] > 0.f ? z[et][r] : ez[et][r] - 1.f;
+        }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        f4 a2 = *reinterpret_cast<const f4*>(lds + Q::mcf + 16 * mt + 4 * g);
+#pragma unroll
+        for (int k1 = 0; k1 < 2; ++k1) {
+            const f4 a = PF[(mt * 2 + k1) * 64 + lane];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a2 = MARL_MFMA(a[r], hf[k1][r], a2);
+        }
+        wfp[mt] = a2;
+    }
+    f4 bv[4];
+    float yp = 0.f;
+#pragma unroll
+    for (int et = 0; et < 4; ++et) {
+        bv[et] = *reinterpret_cast<const f4*>(lds + Q::mbv + 16 * et + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            yp = fmaf(hid[et][r], fabsf(wfp[et][r]), yp);
+            yp = fmaf(hv[et][r], bv[et][r], yp);
+        }
+    }
+    yp += __shfl_xor(yp, 16);
+    yp += __shfl_xor(yp, 32);
+    const float y = yp + lds[Q::mcv];
+    if constexpr (!ONLINE) {
+        if (g == 0 && ok) io.ytgt[row] = y;
+    } else {
+    // ---- TD error and backward (model.py:419-427)
+    const float fl = ok ? io.fl[rc] : 0.f;
+    const float delta = y - (io.ytgt_is_return ? io.ytgt[rc] : io.r0[rc] + gamma * io.ytgt[rc] * (1.f - io.dn[rc]));
+    const float dy = 2.f * fl * delta;
+    if (g == 0) {
+        bw.DY[blk * 16 + j] = dy;
+        if (ok) io.lrow[row] = fl * delta * delta;
+    }
+    {  // the activations the weight-gradient GEMMs multiply with (rows past R: finite values next to zero gradients)
+        float* hb = bw.HB + (size_t)(blk * 16 + j) * Q::NF1 + 4 * g;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            *reinterpret_cast<f4*>(hb + 16 * k) = h1[k];
+            *reinterpret_cast<f4*>(hb + 32 + 16 * k) = hf[k];
+        }
+#pragma unroll
+        for (int et = 0; et < 4; ++et) *reinterpret_cast<f4*>(hb + 128 + 16 * et) = hv[et];
+    }
+    f4 dz[4], dwf[4], dhv[4];
+#pragma unroll
+    for (int et = 0; et < 4; ++et)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float dhid = dy * fabsf(wfp[et][r]);
+            dwf[et][r] = wfp[et][r] > 0.f ? dy * hid[et][r] : -(dy * hid[et][r]);
+            dz[et][r] = z[et][r] > 0.f ? dhid : dhid * ez[et][r];
+            dhv[et][r] = hv[et][r] > 0.f ? dy * bv[et][r] : 0.f;
+        }
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        float s = 0.f;
+#pragma unroll
+        for (int et = 0; et < 4; ++et)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float w = w1[4 * p + et][r];
+                s = fmaf(dz[et][r], fabsf(w), s);
+                const float dwp = dz[et][r] * q[p];
+                w1[4 * p + et][r] = w > 0.f ? dwp : -dwp;  // w1 now holds d(pre-abs w1)
+            }
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        if (g == 0 && ok) io.dq[(size_t)p * R + row] = s;
+    }
+    qmix_store_tiles<W1T>(bw.DW1T + (size_t)blk * (Q::E * P * 16), w1, g, j);
+    qmix_store_tiles<4>(bw.DWFT + (size_t)blk * (Q::E * 16), dwf, g, j);
+    f4 dh[4];  // [dh1 (2 tiles) | dhf (2 tiles)]
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        f4 a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < W1T; ++kt) {
+            const f4 a = t1_at((m * W1T + kt) * 64 + lane);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a1 = MARL_MFMA(a[r], w1[kt][r], a1);
+        }
+        f4 af = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            const f4 a = t1_at((Q::mTF - Q::mT1) / 4 + (m * 4 + kt) * 64 + lane);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) af = MARL_MFMA(a[r], dwf[kt][r], af);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            dh[m][r] = h1[m][r] > 0.f ? a1[r] : 0.f;
+            dh[2 + m][r] = hf[m][r] > 0.f ? af[r] : 0.f;
+        }
+    }
+    float* g1 = bw.G1T + (size_t)blk * (Q::NF1 * 16);
+    qmix_store_tiles<4>(g1, dh, g, j);
+    qmix_store_tiles<4>(g1 + 64 * 16, dz, g, j);
+    qmix_store_tiles<4>(g1 + 128 * 16, dhv, g, j);
+    }
+}
+
+// HALF: the first-layer A operands come as fp16 (packh: h4 per entry) and the states are rounded to fp16 on the way in (LBF / warehouse
+// observations are small integers: exact); one v_mfma_f32_16x16x16_f16 per (k-group, tile) instead of four f32 MFMAs, fp32 accumulation,
+// fp32 bias.
+//
+// Per workgroup step the four waves take four consecutive row blocks.  Phase 1 (all waves in step: the weights stream through one LDS
+// window in 64-column K chunks when they do not fit at once): acc[12] = the 192 first-layer features of the wave's 16 rows, in the MFMA's C
+// layout - exactly the operand layout of phase 2, so Y1 never exists in memory.  Phase 2 (wave-independent): w1 = |hyper_w_1.2 h1 + c|,
+// z = sum_p q_p w1_p + b1, hidden = elu(z), wf = |hyper_w_final.2 hf + c|, y = hidden.wf + V.2 hv + c; the online instance goes on with the
+// TD error and the backward down to the first-layer pre-activations and writes dq_p and the operands of the weight-gradient GEMMs.
+template <class Q, bool REPLAY, bool ONLINE, bool HALF = false>
+__global__ __launch_bounds__(256, ONLINE ? 1 : 2) void qmix_net_kernel(const float* __restrict__ packL1, const h4* __restrict__ packh,
+                                                                       const float* __restrict__ packMix, QmixRows<Q, REPLAY> src, QmixIo io,
+                                                                       int R, float gamma, QmixBwd bw) {
+    constexpr int MT1 = Q::MT1, KS4 = Q::KS4, NCH = Q::NCH, SD = Q::SD;
+    constexpr bool TG = ONLINE && qmix_t1_global<Q>(HALF);
+    constexpr int NPK = (ONLINE && !TG) ? Q::NMIX : Q::NMIX_FWD;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* win = lds + NPK;  // first-layer window
+    f4* win4 = reinterpret_cast<f4*>(win);
+    h4* winh = reinterpret_cast<h4*>(win);
+    const f4* pack4 = reinterpret_cast<const f4*>(packL1);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, j = lane & 15;
+    // window refill: chunk c = n4(c) * MT1 * 64 entries of 16 bytes (8 with HALF: two per f4).  With several chunks the NEXT chunk's loads are
+    // issued before the current chunk's MFMAs and land in registers; they go to the window behind a barrier after the MFMAs (the window
+    // always holds the chunk the next MFMA group needs: chunk 0 again at the end of a step, phase 2 does not touch it).
+    constexpr int WIN4 = qmix_l1_window_floats<Q>(HALF) / 4, PRE = (WIN4 + 255) / 256;
+    auto chunk_n4 = [](int c) { return ((KS4 - 4 * c) < 4 ? (KS4 - 4 * c) : 4) * MT1 * 64 / (HALF ? 2 : 1); };
+    auto chunk_src = [&](int c) -> const f4* {
+        return HALF ? reinterpret_cast<const f4*>(packh + c * 4 * MT1 * 64) : pack4 + c * 4 * MT1 * 64;
+    };
+    copy_f4_to_lds(reinterpret_cast<const f4*>(packMix), reinterpret_cast<f4*>(lds), NPK / 4, tid, 256);
+    copy_f4_to_lds(chunk_src(0), win4, chunk_n4(0), tid, 256);
+    __syncthreads();
+    const size_t ps = src.pstride();
+    const int nblk = (R + 15) / 16, ngroups = (nblk + 3) / 4;
+    for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        const int blk = grp * 4 + wave;
         const int row = blk * 16 + j;
         const bool ok = row < R;
         const int rc = ok ? row : R - 1;
-        const float* y1 = Y1 + (size_t)rc * Q::NF1 + 4 * g;
+        // ---- phase 1: first layers
+        f4 acc[MT1];
+        {
+            const float* rb = src.base(rc, ONLINE ? 0 : 1);
+#pragma unroll
+            for (int mt = 0; mt < MT1; ++mt) acc[mt] = *reinterpret_cast<const f4*>(packL1 + Q::pL1b + 16 * mt + 4 * g);
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                constexpr int full = 4;
+                const int n4 = (KS4 - 4 * c) < full ? (KS4 - 4 * c) : full;
+                f4 pre[NCH > 1 ? PRE : 1];
+                const int cn = c + 1 < NCH ? c + 1 : 0;
+                if (NCH > 1) {
+                    const f4* nsrc = chunk_src(cn);
+#pragma unroll
+                    for (int u = 0; u < PRE; ++u)
+                        if (tid + 256 * u < chunk_n4(cn)) pre[u] = nsrc[tid + 256 * u];
+                }
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    if (q4 < n4) {
+                        float x[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int k = 16 * (4 * c + q4) + 4 * e + g;
+                            const float v = rb[qmix_state_off<Q>(k < SD ? k : SD - 1, ps)];
+                            x[e] = k < SD ? v : 0.f;
+                        }
+                        if constexpr (HALF) {
+                            h4 xh;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) xh[e] = (_Float16)x[e];
+#pragma unroll
+                            for (int mt = 0; mt < MT1; ++mt)
+                                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x16f16(winh[(q4 * MT1 + mt) * 64 + lane], xh, acc[mt], 0, 0, 0);
+                        } else {
+#pragma unroll
+                            for (int mt = 0; mt < MT1; ++mt) {
+                                const f4 a = win4[(q4 * MT1 + mt) * 64 + lane];
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) acc[mt] = MARL_MFMA(a[e], x[e], acc[mt]);
+                            }
+                        }
+                    }
+                }
+                if (NCH > 1) {
+                    __syncthreads();  // every wave is done with the window
+#pragma unroll
+                    for (int u = 0; u < PRE; ++u)
+                        if (tid + 256 * u < chunk_n4(cn)) win4[tid + 256 * u] = pre[u];
+                    __syncthreads();
+                }
+            }
+        }
+        if (blk >= nblk) continue;  // (wave-uniform; all barriers are in phase 1)
+        // ---- phase 2: mixing network.  acc tiles: [0,2) hyper_w_1.0 | [2,4) hyper_w_final.0 | [4,8) hyper_b_1 | [8,12) V.0
+        f4 h1[2], hf[2], z[4], hv[4];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            h1[k] = relu4(acc[k]);
+            hf[k] = relu4(acc[2 + k]);
+        }
+#pragma unroll
+        for (int et = 0; et < 4; ++et) {
+            z[et] = acc[4 + et];
+            hv[et] = relu4(acc[8 + et]);
+        }
+        qmix_mix_block<Q, ONLINE, TG, true>(lds, packMix, h1, hf, z, hv, io, R, gamma, bw, blk, lane);
+    }
+}
+
+// split form: the mixing network of one 16-row block per wave from Y1 in memory
+template <class Q, bool ONLINE>
+__global__ __launch_bounds__(256, 1) void qmix_mix_kernel(const float* __restrict__ pack, const float* __restrict__ Y1, QmixIo io, int R,
+                                                          float gamma, QmixBwd bw) {
+    constexpr int NPK = ONLINE ? Q::NMIX : Q::NMIX_FWD;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, j = lane & 15;
+    copy_f4_to_lds(reinterpret_cast<const f4*>(pack), reinterpret_cast<f4*>(lds), NPK / 4, tid, 256);
+    __syncthreads();
+    const int nblk = (R + 15) / 16;
+    for (int blk = blockIdx.x * 4 + wave; blk < nblk; blk += gridDim.x * 4) {
+        const int row = blk * 16 + j;
+        const float* y1 = Y1 + (size_t)(row < R ? row : R - 1) * Q::NF1 + 4 * g;
         f4 h1[2], hf[2], z[4], hv[4];
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
@@ -309,131 +586,7 @@ __global__ __launch_bounds__(256, 1) void qmix_mix_kernel(const float* __restric
             z[et] = *reinterpret_cast<const f4*>(y1 + 64 + 16 * et);
             hv[et] = *reinterpret_cast<const f4*>(y1 + 128 + 16 * et);
         }
-        float q[P];
-#pragma unroll
-        for (int p = 0; p < P; ++p) q[p] = (ONLINE ? io.chosen : io.tqsel)[(size_t)p * R + rc];
-        // w1 pre-abs = hyper_w_1.2 h1 + c1 ; z += q_p |w1_p|, agent by agent (the target instance keeps no w1 tiles)
-        f4 w1[ONLINE ? W1T : 4];
-#pragma unroll
-        for (int p = 0; p < P; ++p) {
-#pragma unroll
-            for (int et = 0; et < 4; ++et) {
-                const int mt2 = 4 * p + et;
-                f4 acc = *reinterpret_cast<const f4*>(lds + Q::mc1 + 16 * mt2 + 4 * g);
-#pragma unroll
-                for (int k1 = 0; k1 < 2; ++k1) {
-                    const f4 a = P1[(mt2 * 2 + k1) * 64 + lane];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc = MARL_MFMA(a[r], h1[k1][r], acc);
-                }
-                w1[ONLINE ? mt2 : et] = acc;
-            }
-#pragma unroll
-            for (int et = 0; et < 4; ++et)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) z[et][r] = fmaf(q[p], fabsf(w1[ONLINE ? 4 * p + et : et][r]), z[et][r]);
-            if (!ONLINE) __builtin_amdgcn_sched_barrier(0);  // keep the agents' tile groups from being interleaved (register pressure)
-        }
-        f4 ez[4], hid[4], wfp[4];
-#pragma unroll
-        for (int et = 0; et < 4; ++et)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                ez[et][r] = expf(fminf(z[et][r], 0.f));
-                hid[et][r] = z[et][r] > 0.f ? z[et][r] : ez[et][r] - 1.f;
-            }
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            f4 acc = *reinterpret_cast<const f4*>(lds + Q::mcf + 16 * mt + 4 * g);
-#pragma unroll
-            for (int k1 = 0; k1 < 2; ++k1) {
-                const f4 a = PF[(mt * 2 + k1) * 64 + lane];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc = MARL_MFMA(a[r], hf[k1][r], acc);
-            }
-            wfp[mt] = acc;
-        }
-        f4 bv[4];
-        float yp = 0.f;
-#pragma unroll
-        for (int et = 0; et < 4; ++et) {
-            bv[et] = *reinterpret_cast<const f4*>(lds + Q::mbv + 16 * et + 4 * g);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                yp = fmaf(hid[et][r], fabsf(wfp[et][r]), yp);
-                yp = fmaf(hv[et][r], bv[et][r], yp);
-            }
-        }
-        yp += __shfl_xor(yp, 16);
-        yp += __shfl_xor(yp, 32);
-        const float y = yp + lds[Q::mcv];
-        if constexpr (!ONLINE) {
-            if (g == 0 && ok) io.ytgt[row] = y;
-        } else {
-        // ---- TD error and backward (model.py:419-427)
-        const float fl = ok ? io.fl[rc] : 0.f;
-        const float delta = y - (io.ytgt_is_return ? io.ytgt[rc] : io.r0[rc] + gamma * io.ytgt[rc] * (1.f - io.dn[rc]));
-        const float dy = 2.f * fl * delta;
-        if (g == 0) {
-            bw.DY[blk * 16 + j] = dy;
-            if (ok) io.lrow[row] = fl * delta * delta;
-        }
-        f4 dz[4], dwf[4], dhv[4];
-#pragma unroll
-        for (int et = 0; et < 4; ++et)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float dhid = dy * fabsf(wfp[et][r]);
-                dwf[et][r] = wfp[et][r] > 0.f ? dy * hid[et][r] : -(dy * hid[et][r]);
-                dz[et][r] = z[et][r] > 0.f ? dhid : dhid * ez[et][r];
-                dhv[et][r] = hv[et][r] > 0.f ? dy * bv[et][r] : 0.f;
-            }
-#pragma unroll
-        for (int p = 0; p < P; ++p) {
-            float s = 0.f;
-#pragma unroll
-            for (int et = 0; et < 4; ++et)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float w = w1[4 * p + et][r];
-                    s = fmaf(dz[et][r], fabsf(w), s);
-                    const float dwp = dz[et][r] * q[p];
-                    w1[4 * p + et][r] = w > 0.f ? dwp : -dwp;  // w1 now holds d(pre-abs w1)
-                }
-            s += __shfl_xor(s, 16);
-            s += __shfl_xor(s, 32);
-            if (g == 0 && ok) io.dq[(size_t)p * R + row] = s;
-        }
-        qmix_store_tiles<W1T>(bw.DW1T + (size_t)blk * (Q::E * P * 16), w1, g, j);
-        qmix_store_tiles<4>(bw.DWFT + (size_t)blk * (Q::E * 16), dwf, g, j);
-        f4 dh[4];  // [dh1 (2 tiles) | dhf (2 tiles)]
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            f4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kt = 0; kt < W1T; ++kt) {
-                const f4 a = T1[(m * W1T + kt) * 64 + lane];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc = MARL_MFMA(a[r], w1[kt][r], acc);
-            }
-            f4 accf = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt) {
-                const f4 a = TF[(m * 4 + kt) * 64 + lane];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) accf = MARL_MFMA(a[r], dwf[kt][r], accf);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                dh[m][r] = h1[m][r] > 0.f ? acc[r] : 0.f;
-                dh[2 + m][r] = hf[m][r] > 0.f ? accf[r] : 0.f;
-            }
-        }
-        float* g1 = bw.G1T + (size_t)blk * (Q::NF1 * 16);
-        qmix_store_tiles<4>(g1, dh, g, j);
-        qmix_store_tiles<4>(g1 + 64 * 16, dz, g, j);
-        qmix_store_tiles<4>(g1 + 128 * 16, dhv, g, j);
-        }
+        qmix_mix_block<Q, ONLINE, false, false>(lds, pack, h1, hf, z, hv, io, R, gamma, bw, blk, lane);
     }
 }
 
@@ -446,7 +599,7 @@ __global__ __launch_bounds__(256, 1) void qmix_mix_kernel(const float* __restric
 // and block).  Both kernels write disjoint entries of the same per-workgroup record.
 // ---------------------------------------------------------------------------------------------------------
 template <class Q, bool REPLAY>
-__global__ __launch_bounds__(512, 1) void qmix_wgrad1_kernel(QmixRows<Q, REPLAY> src, QmixBwd bw, int R, float* __restrict__ partials) {
+__device__ __forceinline__ void qmix_wgrad1_body(const QmixRows<Q, REPLAY>& src, const QmixBwd& bw, int R, float* __restrict__ partials, int bid, int nwg) {
     constexpr int SD = Q::SD, NTS = Q::KS4, NF1 = Q::NF1;
     constexpr int MG = NTS >= 4 ? 2 : 4, NG = 8 / MG, MPW = Q::MT1 / MG, NPW = (NTS + NG - 1) / NG;
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, g = lane >> 4, j = lane & 15;
@@ -486,8 +639,8 @@ __global__ __launch_bounds__(512, 1) void qmix_wgrad1_kernel(QmixRows<Q, REPLAY>
         }
     };
     const int nblk = (R + 15) / 16;
-    const int per = (nblk + gridDim.x - 1) / gridDim.x;
-    const int bA = blockIdx.x * per, bB = (bA + per) < nblk ? bA + per : nblk;
+    const int per = (nblk + nwg - 1) / nwg;
+    const int bA = bid * per, bB = (bA + per) < nblk ? bA + per : nblk;
     Ops cur, nxt;
     if (bA < bB) load(bA, cur);
     for (int blk = bA; blk < bB; ++blk) {
@@ -503,7 +656,7 @@ __global__ __launch_bounds__(512, 1) void qmix_wgrad1_kernel(QmixRows<Q, REPLAY>
                 for (int e = 0; e < 4; ++e) accW[m][n] = MARL_MFMA(cur.a[m][e], sval[n] ? cur.b[n][e] : 0.f, accW[m][n]);
         cur = nxt;
     }
-    float* rec = partials + (size_t)blockIdx.x * Q::NPARAM;
+    float* rec = partials + (size_t)bid * Q::NPARAM;
 #pragma unroll
     for (int m = 0; m < MPW; ++m) {
         const int mt = mg * MPW + m;
@@ -525,7 +678,8 @@ __global__ __launch_bounds__(512, 1) void qmix_wgrad1_kernel(QmixRows<Q, REPLAY>
 }
 
 template <class Q>
-__global__ __launch_bounds__(512, 1) void qmix_wgrad2_kernel(const float* __restrict__ Y1, QmixBwd bw, int R, float* __restrict__ partials) {
+__device__ __forceinline__ void qmix_wgrad2_body(const QmixBwd& bw, int R, float* __restrict__ partials, int bid, int nwg) {
+    const float* __restrict__ Y1 = bw.HB;
     constexpr int P = Q::P, W1T = Q::W1T, NF1 = Q::NF1, M2W = (W1T + 7) / 8;
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, g = lane >> 4, j = lane & 15;
     const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -563,8 +717,8 @@ __global__ __launch_bounds__(512, 1) void qmix_wgrad2_kernel(const float* __rest
         }
     };
     const int nblk = (R + 15) / 16;
-    const int per = (nblk + gridDim.x - 1) / gridDim.x;
-    const int bA = blockIdx.x * per, bB = (bA + per) < nblk ? bA + per : nblk;
+    const int per = (nblk + nwg - 1) / nwg;
+    const int bA = bid * per, bB = (bA + per) < nblk ? bA + per : nblk;
     Ops cur, nxt;
     if (bA < bB) load(bA, cur);
     for (int blk = bA; blk < bB; ++blk) {
@@ -590,7 +744,7 @@ __global__ __launch_bounds__(512, 1) void qmix_wgrad2_kernel(const float* __rest
         }
         cur = nxt;
     }
-    float* rec = partials + (size_t)blockIdx.x * Q::NPARAM;
+    float* rec = partials + (size_t)bid * Q::NPARAM;
 #pragma unroll
     for (int m = 0; m < M2W; ++m) {
         const int mt2 = w + 8 * m;
@@ -628,6 +782,16 @@ __global__ __launch_bounds__(512, 1) void qmix_wgrad2_kernel(const float* __rest
     }
 }
 
+// both weight-gradient GEMM groups in one launch: workgroups [0, nwg) take the first-layer gradients, [nwg, 2 nwg) the mixing-network ones;
+// workgroup b of either group writes its (disjoint) entries of record b.  Each group alone is latency-bound on its operand stream and leaves
+// most of the chip idle; side by side they overlap.
+template <class Q, bool REPLAY>
+__global__ __launch_bounds__(512, 1) void qmix_wgrad_kernel(QmixRows<Q, REPLAY> src, QmixBwd bw, int R, float* __restrict__ partials) {
+    const int nwg = gridDim.x >> 1;
+    if ((int)blockIdx.x < nwg) qmix_wgrad1_body<Q, REPLAY>(src, bw, R, partials, blockIdx.x, nwg);
+    else qmix_wgrad2_body<Q>(bw, R, partials, blockIdx.x - nwg, nwg);
+}
+
 // mixer_grad[i] = (sum over records, fixed order) / n_filled ; n_filled = nf[1] as written by dqn_reduce_kernel
 static __global__ __launch_bounds__(256) void qmix_reduce_kernel(const float* __restrict__ partials, int nwg, int nparam,
                                                           const float* __restrict__ loss_nf, float* __restrict__ grad) {
@@ -662,7 +826,7 @@ struct QmixCtx {  // what marlhip_qmix_loss_grad adds to the agent-network call
 };
 
 struct QmixWs {
-    int64_t packs, y1o, y1t, dw1, dwf, dy, ytgt, idx, partials, total;  // byte offsets
+    int64_t packs, hb, g1t, dw1, dwf, dy, ytgt, idx, partials, total;  // byte offsets
     int nwg3;
 };
 
@@ -672,9 +836,9 @@ inline QmixWs qmix_ws_layout(int T, int B) {
     QmixWs w;
     auto al = [](int64_t x) { return (x + 255) & ~(int64_t)255; };
     w.packs = 0;
-    w.y1o = al(w.packs + (int64_t)Q::NPACK_ALL * 4);
-    w.y1t = al(w.y1o + Rp * Q::NF1 * 4);  // target first layers, then (dead) reused as G1T
-    w.dw1 = al(w.y1t + Rp * Q::NF1 * 4);
+    w.hb = al(w.packs + (int64_t)Q::NPACK_ALL * 4);  // QmixBwd::HB
+    w.g1t = al(w.hb + Rp * Q::NF1 * 4);              // QmixBwd::G1T
+    w.dw1 = al(w.g1t + Rp * Q::NF1 * 4);
     w.dwf = al(w.dw1 + Rp * Q::E * Q::P * 4);
     w.dy = al(w.dwf + Rp * Q::E * 4);
     w.ytgt = al(w.dy + Rp * 4);
@@ -696,10 +860,8 @@ int qmix_launch_mix(const QmixCtx& qx, const marlhip_batch* bt, const ReplaySrc&
     MARL_REQUIRE(qx.ws_bytes >= wl.total, "qmix_loss_grad: mixer workspace %lld < %lld bytes", (long long)qx.ws_bytes, (long long)wl.total);
     char* base = static_cast<char*>(qx.ws);
     float* packs = reinterpret_cast<float*>(base + wl.packs);
-    float* y1o = reinterpret_cast<float*>(base + wl.y1o);
-    float* y1t = reinterpret_cast<float*>(base + wl.y1t);
     QmixBwd bw;
-    bw.G1T = y1t;
+    bw.G1T = reinterpret_cast<float*>(base + wl.g1t);
     bw.DW1T = reinterpret_cast<float*>(base + wl.dw1);
     bw.DWFT = reinterpret_cast<float*>(base + wl.dwf);
     bw.DY = reinterpret_cast<float*>(base + wl.dy);
@@ -712,46 +874,75 @@ int qmix_launch_mix(const QmixCtx& qx, const marlhip_batch* bt, const ReplaySrc&
         hipLaunchKernelGGL(qmix_draw_kernel, dim3((B + 255) / 256), dim3(256), 0, st, rsrc, B, idxbuf);
         src.rs.idx = idxbuf;
     }
-    constexpr int CH = (Q::NCH == 1 ? Q::KS4 : 4) * Q::MT1 * 256 * (int)sizeof(float);
-    constexpr int LM_ON = Q::NMIX * (int)sizeof(float), LM_TG = Q::NMIX_FWD * (int)sizeof(float);
-    static LdsAttr attr_set;
-    if (attr_set.need()) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qmix_l1_kernel<Q, REPLAY>), hipFuncAttributeMaxDynamicSharedMemorySize, CH);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qmix_l1_kernel<Q, REPLAY, true>), hipFuncAttributeMaxDynamicSharedMemorySize, CH);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qmix_mix_kernel<Q, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LM_ON);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qmix_mix_kernel<Q, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LM_TG);
-        attr_set.done();
-    }
+    bw.HB = reinterpret_cast<float*>(base + wl.hb);
     hipLaunchKernelGGL((qmix_pack_kernel<Q>), dim3((Q::NPACK + 255) / 256), dim3(256), 0, st, qx.mixer, qx.tmixer, packs);
     const h4* packh = reinterpret_cast<const h4*>(packs + Q::NPACK);  // [online | target], Q::KS4 * Q::MT1 * 64 entries each
     if (qx.l1_fp16)
         hipLaunchKernelGGL((qmix_pack_half_kernel<Q>), dim3((2 * Q::KS4 * Q::MT1 * 64 + 255) / 256), dim3(256), 0, st, qx.mixer, qx.tmixer, packs);
-    const int ngroups = (R + 64 * MARL_QMIX_L1_NB - 1) / (64 * MARL_QMIX_L1_NB), nblk = (R + 15) / 16;
-    const int g1 = ngroups < 768 ? ngroups : 768;
-    const int g2 = (nblk + 3) / 4 < 256 ? (nblk + 3) / 4 : 256;
-    timing_begin(TIMER_QMIX, st);
-    if (qx.l1_fp16)
-        hipLaunchKernelGGL((qmix_l1_kernel<Q, REPLAY, true>), dim3(g1), dim3(256), CH / 2, st, (const float*)(packs + Q::NL1), src, 1, R, y1t,
-                           packh + Q::KS4 * Q::MT1 * 64);
-    else
-        hipLaunchKernelGGL((qmix_l1_kernel<Q, REPLAY>), dim3(g1), dim3(256), CH, st, (const float*)(packs + Q::NL1), src, 1, R, y1t, (const h4*)nullptr);
-    hipLaunchKernelGGL((qmix_mix_kernel<Q, false>), dim3(g2), dim3(256), LM_TG, st, (const float*)(packs + 2 * Q::NL1 + Q::NMIX),
-                       (const float*)y1t, io2, R, gamma, bw);
-    if (qx.rst != nullptr) {  // QMixNetwork with standardise_returns: the target mixer's output becomes the standardised return
+    const int nblk = (R + 15) / 16;
+    const float* l1o = packs, *l1t = packs + Q::NL1, *mxo = packs + 2 * Q::NL1, *mxt = packs + 2 * Q::NL1 + Q::NMIX;
+    const h4* packh_t = packh + Q::KS4 * Q::MT1 * 64;
+    auto standardise = [&]() -> int {  // QMixNetwork with standardise_returns: the target mixer's output becomes the standardised return
+        if (qx.rst == nullptr) return 0;
         const int rc = launch_colstd(T, B, gamma, *qx.rst, io2.ytgt, 1, 0, io2.r0, io2.dn, io2.ytgt, st);
-        if (rc != 0) return rc;
         io2.ytgt_is_return = 1;
+        return rc;
+    };
+    timing_begin(TIMER_QMIX, st);
+    if constexpr (Q::NCH <= MARL_QMIX_FUSE_NCH) {
+        // fused form: one launch per mixer instance, the first-layer activations stay in registers
+        constexpr int L_ON = qmix_net_lds_floats<Q, true>(false) * 4, L_TG = qmix_net_lds_floats<Q, false>(false) * 4;
+        constexpr int L_ONH = qmix_net_lds_floats<Q, true>(true) * 4, L_TGH = qmix_net_lds_floats<Q, false>(true) * 4;
+        static_assert(L_ON <= 160 * 1024 && L_TG <= 160 * 1024, "qmix_net_kernel: LDS");
+        static LdsAttr attr_set;
+        if (attr_set.need()) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qmix_net_kernel<Q, REPLAY, true>), hipFuncAttributeMaxDynamicSharedMemorySize, L_ON);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qmix_net_kernel<Q, REPLAY, false>), hipFuncAttributeMaxDynamicSharedMemorySize, L_TG);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qmix_net_kernel<Q, REPLAY, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, L_ONH);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qmix_net_kernel<Q, REPLAY, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, L_TGH);
+            attr_set.done();
+        }
+        // resident workgroups: one per CU for the online instance (registers), as many as the LDS allows (at most 2) for the target's
+        const int ngroups = (nblk + 3) / 4, per_cu_t = 2 * L_TG <= 160 * 1024 ? 2 : 1;
+        const int g_t = ngroups < 256 * per_cu_t ? ngroups : 256 * per_cu_t, g_o = ngroups < 256 ? ngroups : 256;
+        if (qx.l1_fp16)
+            hipLaunchKernelGGL((qmix_net_kernel<Q, REPLAY, false, true>), dim3(g_t), dim3(256), L_TGH, st, l1t, packh_t, mxt, src, io2, R, gamma, bw);
+        else
+            hipLaunchKernelGGL((qmix_net_kernel<Q, REPLAY, false>), dim3(g_t), dim3(256), L_TG, st, l1t, (const h4*)nullptr, mxt, src, io2, R, gamma, bw);
+        if (standardise() != 0) return -1;
+        if (qx.l1_fp16)
+            hipLaunchKernelGGL((qmix_net_kernel<Q, REPLAY, true, true>), dim3(g_o), dim3(256), L_ONH, st, l1o, packh, mxo, src, io2, R, gamma, bw);
+        else
+            hipLaunchKernelGGL((qmix_net_kernel<Q, REPLAY, true>), dim3(g_o), dim3(256), L_ON, st, l1o, (const h4*)nullptr, mxo, src, io2, R, gamma, bw);
+    } else {
+        // split form: Y1 of either instance through memory (target: the G1T buffer, dead until the online backward; online: HB, all 192 columns)
+        constexpr int CH = 4 * Q::MT1 * 256 * (int)sizeof(float);
+        constexpr int LM_ON = Q::NMIX * (int)sizeof(float), LM_TG = Q::NMIX_FWD * (int)sizeof(float);
+        static LdsAttr attr_set;
+        if (attr_set.need()) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qmix_l1_kernel<Q, REPLAY>), hipFuncAttributeMaxDynamicSharedMemorySize, CH);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qmix_l1_kernel<Q, REPLAY, true>), hipFuncAttributeMaxDynamicSharedMemorySize, CH);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qmix_mix_kernel<Q, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LM_ON);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qmix_mix_kernel<Q, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LM_TG);
+            attr_set.done();
+        }
+        const int ngroups = (R + 64 * MARL_QMIX_L1_NB - 1) / (64 * MARL_QMIX_L1_NB);
+        const int g1 = ngroups < 768 ? ngroups : 768;
+        const int g2 = (nblk + 3) / 4 < 256 ? (nblk + 3) / 4 : 256;
+        float* y1t = bw.G1T, *y1o = bw.HB;
+        if (qx.l1_fp16)
+            hipLaunchKernelGGL((qmix_l1_kernel<Q, REPLAY, true>), dim3(g1), dim3(256), CH / 2, st, l1t, src, 1, R, y1t, packh_t);
+        else
+            hipLaunchKernelGGL((qmix_l1_kernel<Q, REPLAY>), dim3(g1), dim3(256), CH, st, l1t, src, 1, R, y1t, (const h4*)nullptr);
+        hipLaunchKernelGGL((qmix_mix_kernel<Q, false>), dim3(g2), dim3(256), LM_TG, st, mxt, (const float*)y1t, io2, R, gamma, bw);
+        if (standardise() != 0) return -1;
+        if (qx.l1_fp16)
+            hipLaunchKernelGGL((qmix_l1_kernel<Q, REPLAY, true>), dim3(g1), dim3(256), CH / 2, st, l1o, src, 0, R, y1o, packh);
+        else
+            hipLaunchKernelGGL((qmix_l1_kernel<Q, REPLAY>), dim3(g1), dim3(256), CH, st, l1o, src, 0, R, y1o, (const h4*)nullptr);
+        hipLaunchKernelGGL((qmix_mix_kernel<Q, true>), dim3(g2), dim3(256), LM_ON, st, mxo, (const float*)y1o, io2, R, gamma, bw);
     }
-    if (qx.l1_fp16)
-        hipLaunchKernelGGL((qmix_l1_kernel<Q, REPLAY, true>), dim3(g1), dim3(256), CH / 2, st, (const float*)packs, src, 0, R, y1o, packh);
-    else
-        hipLaunchKernelGGL((qmix_l1_kernel<Q, REPLAY>), dim3(g1), dim3(256), CH, st, (const float*)packs, src, 0, R, y1o, (const h4*)nullptr);
-    hipLaunchKernelGGL((qmix_mix_kernel<Q, true>), dim3(g2), dim3(256), LM_ON, st, (const float*)(packs + 2 * Q::NL1), (const float*)y1o,
-                       io2, R, gamma, bw);
-    hipLaunchKernelGGL((qmix_wgrad1_kernel<Q, REPLAY>), dim3(wl.nwg3), dim3(512), 0, st, src, bw, R,
-                       reinterpret_cast<float*>(base + wl.partials));
-    hipLaunchKernelGGL((qmix_wgrad2_kernel<Q>), dim3(wl.nwg3), dim3(512), 0, st, (const float*)y1o, bw, R,
-                       reinterpret_cast<float*>(base + wl.partials));
+    hipLaunchKernelGGL((qmix_wgrad_kernel<Q, REPLAY>), dim3(2 * wl.nwg3), dim3(512), 0, st, src, bw, R, reinterpret_cast<float*>(base + wl.partials));
     timing_end(TIMER_QMIX, st);
     MARL_CHECK_LAUNCH("qmix mixer stage");
     return 0;
