@@ -22,6 +22,9 @@
 // non-degenerate parameters.
 #pragma once
 
+#ifndef MARL_QMIX_WG
+#define MARL_QMIX_WG 1  // weight gradients inside the online instance's kernel where the operand tiles fit the LDS (qmix_wg_round)
+#endif
 #ifndef MARL_QMIX_L1_NB
 #define MARL_QMIX_L1_NB 1  // row blocks per wave and step in qmix_l1_kernel (register blocking vs resident workgroups per CU)
 #endif
@@ -299,10 +302,20 @@ constexpr int qmix_net_lds_floats(bool half) {
 
 // The mixing network (and, ONLINE, the TD error and the backward) of one 16-row block on one wave, from the first-layer activations in the
 // MFMA's C layout (feature 4g+r of tile k, row j).  lds: the staged mixing pack; TG: T1 | TF are read from the pack in global memory.
-// HB: write the activations the weight gradients need (the fused kernel; the split form has all of Y1 in memory already).
-template <class Q, bool ONLINE, bool TG, bool HB>
+// OUT (online): where the operands of the weight-gradient GEMMs go - 0: G1T / DW1T / DWFT / DY in memory (split form: Y1 is there already),
+// 1: the same plus HB, the activations they multiply with (fused form), 2: nowhere, they stay in registers (*out) for the in-kernel
+// weight gradients.
+template <class Q>
+struct QmixTiles {
+    f4 g1[12];        // d(pre-activation) of the first layers: [dh1 (2) | dhf (2) | dz (4) | dhv (4)]
+    f4 dw1[Q::W1T];   // d(pre-abs w1)
+    f4 dwf[4];        // d(pre-abs w_final)
+    float dy;         // dL/dy of row j
+};
+template <class Q, bool ONLINE, bool TG, int OUT>
 __device__ __forceinline__ void qmix_mix_block(const float* lds, const float* __restrict__ packMix, const f4 (&h1)[2], const f4 (&hf)[2], f4 (&z)[4],
-                                               const f4 (&hv)[4], const QmixIo& io, int R, float gamma, const QmixBwd& bw, int blk, int lane) {
+                                               const f4 (&hv)[4], const QmixIo& io, int R, float gamma, const QmixBwd& bw, int blk, int lane,
+                                               QmixTiles<Q>* out = nullptr) {
     constexpr int P = Q::P, W1T = Q::W1T;
     const int g = lane >> 4, j = lane & 15;
     const int row = blk * 16 + j;
@@ -380,10 +393,10 @@ __device__ __forceinline__ void qmix_mix_block(const float* lds, const float* __
     const float delta = y - (io.ytgt_is_return ? io.ytgt[rc] : io.r0[rc] + gamma * io.ytgt[rc] * (1.f - io.dn[rc]));
     const float dy = 2.f * fl * delta;
     if (g == 0) {
-        bw.DY[blk * 16 + j] = dy;
+        if constexpr (OUT != 2) bw.DY[blk * 16 + j] = dy;
         if (ok) io.lrow[row] = fl * delta * delta;
     }
-    {  // the activations the weight-gradient GEMMs multiply with (rows past R: finite values next to zero gradients)
+    if constexpr (OUT == 1) {  // the activations the weight-gradient GEMMs multiply with (rows past R: finite values next to zero gradients)
         float* hb = bw.HB + (size_t)(blk * 16 + j) * Q::NF1 + 4 * g;
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
@@ -419,8 +432,10 @@ __device__ __forceinline__ void qmix_mix_block(const float* lds, const float* __
         s += __shfl_xor(s, 32);
         if (g == 0 && ok) io.dq[(size_t)p * R + row] = s;
     }
-    qmix_store_tiles<W1T>(bw.DW1T + (size_t)blk * (Q::E * P * 16), w1, g, j);
-    qmix_store_tiles<4>(bw.DWFT + (size_t)blk * (Q::E * 16), dwf, g, j);
+    if constexpr (OUT != 2) {
+        qmix_store_tiles<W1T>(bw.DW1T + (size_t)blk * (Q::E * P * 16), w1, g, j);
+        qmix_store_tiles<4>(bw.DWFT + (size_t)blk * (Q::E * 16), dwf, g, j);
+    }
     f4 dh[4];  // [dh1 (2 tiles) | dhf (2 tiles)]
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
@@ -444,11 +459,41 @@ __device__ __forceinline__ void qmix_mix_block(const float* lds, const float* __
             dh[2 + m][r] = hf[m][r] > 0.f ? af[r] : 0.f;
         }
     }
-    float* g1 = bw.G1T + (size_t)blk * (Q::NF1 * 16);
-    qmix_store_tiles<4>(g1, dh, g, j);
-    qmix_store_tiles<4>(g1 + 64 * 16, dz, g, j);
-    qmix_store_tiles<4>(g1 + 128 * 16, dhv, g, j);
+    if constexpr (OUT == 2) {
+        out->dy = dy;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            out->g1[k] = dh[k];
+            out->g1[4 + k] = dz[k];
+            out->g1[8 + k] = dhv[k];
+            out->dwf[k] = dwf[k];
+        }
+#pragma unroll
+        for (int k = 0; k < W1T; ++k) out->dw1[k] = w1[k];
+    } else {
+        float* g1 = bw.G1T + (size_t)blk * (Q::NF1 * 16);
+        qmix_store_tiles<4>(g1, dh, g, j);
+        qmix_store_tiles<4>(g1 + 64 * 16, dz, g, j);
+        qmix_store_tiles<4>(g1 + 128 * 16, dhv, g, j);
     }
+    }
+}
+
+// In-kernel weight gradients (WG, online instance): per row block the operands of the three weight-gradient GEMMs are
+// OPT = 20 + W1T tiles of 16 x 16 floats: [G1 (12) | dw1 (W1T) | dwf (4) | h1 (2) | hf (2)], feature-major (an MFMA A operand; the
+// activations are read the same way as B operands).  They go through an LDS region of RB block slots behind the packs, RB = as many as
+// fit (4, 2 or 1; 0: the shape keeps qmix_wgrad_kernel): the four waves of a workgroup step publish their blocks in 4 / RB rounds and, per
+// round, every wave accumulates ITS accumulator tiles (a quarter of dW1cat, dB1, dBf) over the published blocks - G1T / DW1T / DWFT / HB
+// (34-38 KB per row block, written and read back) never exist in memory.
+template <class Q>
+constexpr int qmix_op_tiles() { return 20 + Q::W1T; }
+template <class Q>
+constexpr int qmix_wg_round(bool half) {
+    // (one K chunk only: with the chunk prefetch registers on top, the 3-agent 24/27-wide and the warehouse shapes spill 0.1-0.6 KB per lane)
+    if (Q::NCH > 1 || qmix_t1_global<Q>(half) || MARL_QMIX_WG == 0) return 0;
+    for (int rb = 4; rb >= 1; rb >>= 1)
+        if ((Q::NMIX + qmix_l1_window_floats<Q>(half) + rb * qmix_op_tiles<Q>() * 256) * 4 <= 160 * 1024) return rb;
+    return 0;
 }
 
 // HALF: the first-layer A operands come as fp16 (packh: h4 per entry) and the states are rounded to fp16 on the way in (LBF / warehouse
@@ -460,10 +505,11 @@ __device__ __forceinline__ void qmix_mix_block(const float* lds, const float* __
 // layout - exactly the operand layout of phase 2, so Y1 never exists in memory.  Phase 2 (wave-independent): w1 = |hyper_w_1.2 h1 + c|,
 // z = sum_p q_p w1_p + b1, hidden = elu(z), wf = |hyper_w_final.2 hf + c|, y = hidden.wf + V.2 hv + c; the online instance goes on with the
 // TD error and the backward down to the first-layer pre-activations and writes dq_p and the operands of the weight-gradient GEMMs.
-template <class Q, bool REPLAY, bool ONLINE, bool HALF = false>
-__global__ __launch_bounds__(256, ONLINE ? 1 : 2) void qmix_net_kernel(const float* __restrict__ packL1, const h4* __restrict__ packh,
+template <class Q, bool REPLAY, bool ONLINE, bool HALF = false, bool WG = false>
+__global__ __launch_bounds__(256, (ONLINE || qmix_net_lds_floats<Q, false>(HALF) * 8 > 160 * 1024) ? 1 : 2) void qmix_net_kernel(const float* __restrict__ packL1, const h4* __restrict__ packh,
                                                                        const float* __restrict__ packMix, QmixRows<Q, REPLAY> src, QmixIo io,
-                                                                       int R, float gamma, QmixBwd bw) {
+                                                                       int R, float gamma, QmixBwd bw, float* __restrict__ partials = nullptr) {
+    static_assert(!WG || ONLINE, "weight gradients belong to the online instance");
     constexpr int MT1 = Q::MT1, KS4 = Q::KS4, NCH = Q::NCH, SD = Q::SD;
     constexpr bool TG = ONLINE && qmix_t1_global<Q>(HALF);
     constexpr int NPK = (ONLINE && !TG) ? Q::NMIX : Q::NMIX_FWD;
@@ -486,6 +532,36 @@ __global__ __launch_bounds__(256, ONLINE ? 1 : 2) void qmix_net_kernel(const flo
     __syncthreads();
     const size_t ps = src.pstride();
     const int nblk = (R + 15) / 16, ngroups = (nblk + 3) / 4;
+    // ---- in-kernel weight gradients: this wave's accumulator tiles
+    constexpr int W1T = Q::W1T, OPT = qmix_op_tiles<Q>(), RB = WG ? qmix_wg_round<Q>(HALF) : 1, NR = 4 / (RB > 0 ? RB : 1);
+    constexpr int NG = KS4 >= 4 ? 4 : (KS4 >= 2 ? 2 : 1), MG = 4 / NG, MPW = MT1 / MG, NPW = (KS4 + NG - 1) / NG, M2W = W1T / 4;
+    constexpr int tG1 = 0, tW1 = 12, tWF = 12 + W1T, tH1 = 16 + W1T, tHF = 18 + W1T;  // tile offsets inside a block slot
+    float* OP = win + qmix_l1_window_floats<Q>(HALF);
+    const int mg = wave % MG, ng = wave / MG;
+    const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f4 accW[WG ? MPW : 1][WG ? NPW : 1], accB1[WG ? M2W : 1][2], accBf[2], dbv_acc[4];
+    float cs1[WG ? MPW : 1], csc1[WG ? M2W : 1], cscf = 0.f, dcv_acc = 0.f;
+    unsigned soff[WG ? NPW : 1];
+    bool sval[WG ? NPW : 1];
+    if constexpr (WG) {
+#pragma unroll
+        for (int m = 0; m < MPW; ++m) {
+            cs1[m] = 0.f;
+#pragma unroll
+            for (int n = 0; n < NPW; ++n) accW[m][n] = zero4;
+        }
+#pragma unroll
+        for (int m = 0; m < M2W; ++m) { csc1[m] = 0.f; accB1[m][0] = zero4; accB1[m][1] = zero4; }
+        accBf[0] = zero4; accBf[1] = zero4;
+#pragma unroll
+        for (int et = 0; et < 4; ++et) dbv_acc[et] = zero4;
+#pragma unroll
+        for (int n = 0; n < NPW; ++n) {  // state column of this lane in each owned N tile of dW1cat
+            const int k = 16 * (ng + n * NG) + j;
+            sval[n] = (ng + n * NG) < KS4 && k < SD;
+            soff[n] = (unsigned)qmix_state_off<Q>(k < SD ? k : SD - 1, ps);
+        }
+    }
     for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
         const int blk = grp * 4 + wave;
         const int row = blk * 16 + j;
@@ -545,7 +621,8 @@ __global__ __launch_bounds__(256, ONLINE ? 1 : 2) void qmix_net_kernel(const flo
                 }
             }
         }
-        if (blk >= nblk) continue;  // (wave-uniform; all barriers are in phase 1)
+        const bool active = blk < nblk;  // (wave-uniform)
+        if (!WG && !active) continue;     // (all barriers of this form are in phase 1)
         // ---- phase 2: mixing network.  acc tiles: [0,2) hyper_w_1.0 | [2,4) hyper_w_final.0 | [4,8) hyper_b_1 | [8,12) V.0
         f4 h1[2], hf[2], z[4], hv[4];
 #pragma unroll
@@ -558,7 +635,139 @@ __global__ __launch_bounds__(256, ONLINE ? 1 : 2) void qmix_net_kernel(const flo
             z[et] = acc[4 + et];
             hv[et] = relu4(acc[8 + et]);
         }
-        qmix_mix_block<Q, ONLINE, TG, true>(lds, packMix, h1, hf, z, hv, io, R, gamma, bw, blk, lane);
+        if constexpr (!WG) {
+            qmix_mix_block<Q, ONLINE, TG, 1>(lds, packMix, h1, hf, z, hv, io, R, gamma, bw, blk, lane);
+        } else {
+            QmixTiles<Q> tl;
+            if (active) {
+                qmix_mix_block<Q, true, TG, 2>(lds, packMix, h1, hf, z, hv, io, R, gamma, bw, blk, lane, &tl);
+                if (g == 0) dcv_acc += tl.dy;
+#pragma unroll
+                for (int et = 0; et < 4; ++et)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dbv_acc[et][r] = fmaf(tl.dy, hv[et][r], dbv_acc[et][r]);  // dV.2: per-lane partial, rows folded at the end
+            }
+#pragma unroll
+            for (int rd = 0; rd < NR; ++rd) {
+                if (active && wave / RB == rd) {  // publish my block
+                    float* T = OP + (wave % RB) * (OPT * 256);
+                    tile_write<12>(T + tG1 * 256, tl.g1, g, j);
+                    tile_write<W1T>(T + tW1 * 256, tl.dw1, g, j);
+                    tile_write<4>(T + tWF * 256, tl.dwf, g, j);
+                    tile_write<2>(T + tH1 * 256, h1, g, j);
+                    tile_write<2>(T + tHF * 256, hf, g, j);
+                }
+                // the state rows of the round's blocks as B operands (row 4g+e at k-step e), requested before the barrier
+                float bS[RB][NPW][4];
+#pragma unroll
+                for (int sl = 0; sl < RB; ++sl) {
+                    const int b = grp * 4 + rd * RB + sl;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int rw = b * 16 + 4 * g + e;
+                        const float* rbs = src.base(rw < R ? rw : R - 1, 0);
+#pragma unroll
+                        for (int n = 0; n < NPW; ++n) bS[sl][n][e] = rbs[soff[n]];
+                    }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int sl = 0; sl < RB; ++sl) {
+                    if (grp * 4 + rd * RB + sl < nblk) {
+                        const float* T = OP + sl * (OPT * 256);
+                        f4 a[MPW];
+#pragma unroll
+                        for (int m = 0; m < MPW; ++m) {
+                            a[m] = tile_read(T + tG1 * 256, mg * MPW + m, g, j);
+                            if (ng == 0) cs1[m] += (a[m][0] + a[m][1]) + (a[m][2] + a[m][3]);
+                        }
+#pragma unroll
+                        for (int n = 0; n < NPW; ++n)
+#pragma unroll
+                            for (int m = 0; m < MPW; ++m)
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) accW[m][n] = MARL_MFMA(a[m][e], sval[n] ? bS[sl][n][e] : 0.f, accW[m][n]);
+                        const f4 b1[2] = {tile_read(T + tH1 * 256, 0, g, j), tile_read(T + tH1 * 256, 1, g, j)};
+#pragma unroll
+                        for (int m = 0; m < M2W; ++m) {
+                            const f4 a2 = tile_read(T + tW1 * 256, wave + 4 * m, g, j);
+                            csc1[m] += (a2[0] + a2[1]) + (a2[2] + a2[3]);
+#pragma unroll
+                            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) accB1[m][nt] = MARL_MFMA(a2[e], b1[nt][e], accB1[m][nt]);
+                        }
+                        const f4 a3 = tile_read(T + tWF * 256, wave, g, j);
+                        cscf += (a3[0] + a3[1]) + (a3[2] + a3[3]);
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt) {
+                            const f4 bf = tile_read(T + tHF * 256, nt, g, j);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) accBf[nt] = MARL_MFMA(a3[e], bf[e], accBf[nt]);
+                        }
+                    }
+                }
+                __syncthreads();  // the slots are rewritten by the next round / step
+            }
+        }
+    }
+    if constexpr (WG) {
+        // ---- every wave owns disjoint entries of the workgroup's record (canonical mixer.parameters() offsets)
+        float* rec = partials + (size_t)blockIdx.x * Q::NPARAM;
+#pragma unroll
+        for (int m = 0; m < MPW; ++m) {
+            const int mt = mg * MPW + m;
+#pragma unroll
+            for (int n = 0; n < NPW; ++n) {
+                const int k = 16 * (ng + n * NG) + j;
+                if ((ng + n * NG) < KS4 && k < SD) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) rec[qmix_l1_row<Q>(16 * mt + 4 * g + r) + k] = accW[m][n][r];
+                }
+            }
+            if (ng == 0) {
+                float sm = cs1[m];
+                sm += __shfl_xor(sm, 16);
+                sm += __shfl_xor(sm, 32);
+                if (g == 0) rec[qmix_l1_bias<Q>(16 * mt + j)] = sm;
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < M2W; ++m) {
+            const int mt2 = wave + 4 * m;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rec[Q::oB1 + (16 * mt2 + 4 * g + r) * Q::HE + 16 * nt + j] = accB1[m][nt][r];
+            float sm = csc1[m];
+            sm += __shfl_xor(sm, 16);
+            sm += __shfl_xor(sm, 32);
+            if (g == 0) rec[Q::oc1 + 16 * mt2 + j] = sm;
+        }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) rec[Q::oBf + (16 * wave + 4 * g + r) * Q::HE + 16 * nt + j] = accBf[nt][r];
+        {
+            float sm = cscf;
+            sm += __shfl_xor(sm, 16);
+            sm += __shfl_xor(sm, 32);
+            if (g == 0) rec[Q::ocf + 16 * wave + j] = sm;
+        }
+        // dV.2 weight and bias: rows (lanes j) folded per wave, the four waves' sums through the (now idle) operand region in fixed order
+#pragma unroll
+        for (int et = 0; et < 4; ++et)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = sum16(dbv_acc[et][r]);
+                if (j == 0) OP[wave * 80 + 16 * et + 4 * g + r] = v;
+            }
+        {
+            const float v = sum16(dcv_acc);  // (only the lanes of g == 0 carry it)
+            if (lane == 0) OP[wave * 80 + 64] = v;
+        }
+        __syncthreads();
+        if (tid < 65) rec[(tid < 64 ? Q::obv : Q::ocv - 64) + tid] = (OP[tid] + OP[80 + tid]) + (OP[160 + tid] + OP[240 + tid]);
     }
 }
 
@@ -586,7 +795,7 @@ __global__ __launch_bounds__(256, 1) void qmix_mix_kernel(const float* __restric
             z[et] = *reinterpret_cast<const f4*>(y1 + 64 + 16 * et);
             hv[et] = *reinterpret_cast<const f4*>(y1 + 128 + 16 * et);
         }
-        qmix_mix_block<Q, ONLINE, false, false>(lds, pack, h1, hf, z, hv, io, R, gamma, bw, blk, lane);
+        qmix_mix_block<Q, ONLINE, false, 0>(lds, pack, h1, hf, z, hv, io, R, gamma, bw, blk, lane);
     }
 }
 
@@ -827,7 +1036,8 @@ struct QmixCtx {  // what marlhip_qmix_loss_grad adds to the agent-network call
 
 struct QmixWs {
     int64_t packs, hb, g1t, dw1, dwf, dy, ytgt, idx, partials, total;  // byte offsets
-    int nwg3;
+    int nwg3;  // workgroups per group of qmix_wgrad_kernel
+    int nrec;  // per-workgroup gradient records qmix_reduce_kernel sums (the online instance's grid with in-kernel weight gradients)
 };
 
 template <class Q>
@@ -848,6 +1058,8 @@ inline QmixWs qmix_ws_layout(int T, int B) {
     // light shapes get 3 workgroups per CU; the heavy ones (register-bound, 1 workgroup per CU) one per CU
     const int64_t cap = Q::P <= 4 ? 768 : 256;
     w.nwg3 = (int)(nblk < cap ? nblk : cap);
+    const int64_t ngroups = (nblk + 3) / 4;
+    w.nrec = qmix_wg_round<Q>(false) > 0 ? (int)(ngroups < 256 ? ngroups : 256) : w.nwg3;
     w.total = al(w.partials + (int64_t)w.nwg3 * Q::NPARAM * 4);
     return w;
 }
@@ -891,14 +1103,17 @@ int qmix_launch_mix(const QmixCtx& qx, const marlhip_batch* bt, const ReplaySrc&
     timing_begin(TIMER_QMIX, st);
     if constexpr (Q::NCH <= MARL_QMIX_FUSE_NCH) {
         // fused form: one launch per mixer instance, the first-layer activations stay in registers
-        constexpr int L_ON = qmix_net_lds_floats<Q, true>(false) * 4, L_TG = qmix_net_lds_floats<Q, false>(false) * 4;
-        constexpr int L_ONH = qmix_net_lds_floats<Q, true>(true) * 4, L_TGH = qmix_net_lds_floats<Q, false>(true) * 4;
-        static_assert(L_ON <= 160 * 1024 && L_TG <= 160 * 1024, "qmix_net_kernel: LDS");
+        constexpr bool WG = qmix_wg_round<Q>(false) > 0;  // weight gradients inside the online instance (then also with the smaller fp16 window)
+        constexpr int OPF = qmix_op_tiles<Q>() * 256;
+        constexpr int L_ON = (qmix_net_lds_floats<Q, true>(false) + (WG ? qmix_wg_round<Q>(false) * OPF : 0)) * 4;
+        constexpr int L_ONH = (qmix_net_lds_floats<Q, true>(true) + (WG ? qmix_wg_round<Q>(true) * OPF : 0)) * 4;
+        constexpr int L_TG = qmix_net_lds_floats<Q, false>(false) * 4, L_TGH = qmix_net_lds_floats<Q, false>(true) * 4;
+        static_assert(L_ON <= 160 * 1024 && L_ONH <= 160 * 1024 && L_TG <= 160 * 1024, "qmix_net_kernel: LDS");
         static LdsAttr attr_set;
         if (attr_set.need()) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qmix_net_kernel<Q, REPLAY, true>), hipFuncAttributeMaxDynamicSharedMemorySize, L_ON);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qmix_net_kernel<Q, REPLAY, true, false, WG>), hipFuncAttributeMaxDynamicSharedMemorySize, L_ON);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qmix_net_kernel<Q, REPLAY, false>), hipFuncAttributeMaxDynamicSharedMemorySize, L_TG);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qmix_net_kernel<Q, REPLAY, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, L_ONH);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qmix_net_kernel<Q, REPLAY, true, true, WG>), hipFuncAttributeMaxDynamicSharedMemorySize, L_ONH);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qmix_net_kernel<Q, REPLAY, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, L_TGH);
             attr_set.done();
         }
@@ -910,10 +1125,17 @@ int qmix_launch_mix(const QmixCtx& qx, const marlhip_batch* bt, const ReplaySrc&
         else
             hipLaunchKernelGGL((qmix_net_kernel<Q, REPLAY, false>), dim3(g_t), dim3(256), L_TG, st, l1t, (const h4*)nullptr, mxt, src, io2, R, gamma, bw);
         if (standardise() != 0) return -1;
+        float* recs = reinterpret_cast<float*>(base + wl.partials);
         if (qx.l1_fp16)
-            hipLaunchKernelGGL((qmix_net_kernel<Q, REPLAY, true, true>), dim3(g_o), dim3(256), L_ONH, st, l1o, packh, mxo, src, io2, R, gamma, bw);
+            hipLaunchKernelGGL((qmix_net_kernel<Q, REPLAY, true, true, WG>), dim3(g_o), dim3(256), L_ONH, st, l1o, packh, mxo, src, io2, R, gamma, bw, recs);
         else
-            hipLaunchKernelGGL((qmix_net_kernel<Q, REPLAY, true>), dim3(g_o), dim3(256), L_ON, st, l1o, (const h4*)nullptr, mxo, src, io2, R, gamma, bw);
+            hipLaunchKernelGGL((qmix_net_kernel<Q, REPLAY, true, false, WG>), dim3(g_o), dim3(256), L_ON, st, l1o, (const h4*)nullptr, mxo, src, io2, R, gamma,
+                               bw, recs);
+        if (WG) {  // the records are complete: g_o == wl.nrec of them
+            timing_end(TIMER_QMIX, st);
+            MARL_CHECK_LAUNCH("qmix mixer stage");
+            return 0;
+        }
     } else {
         // split form: Y1 of either instance through memory (target: the G1T buffer, dead until the online backward; online: HB, all 192 columns)
         constexpr int CH = 4 * Q::MT1 * 256 * (int)sizeof(float);
@@ -953,7 +1175,7 @@ template <class Q>
 int qmix_launch_reduce(const QmixCtx& qx, int T, int B, const float* loss, hipStream_t st) {
     const QmixWs wl = qmix_ws_layout<Q>(T, B);
     hipLaunchKernelGGL(qmix_reduce_kernel, dim3((Q::NPARAM + 63) / 64), dim3(256), 0, st,
-                       (const float*)(static_cast<char*>(qx.ws) + wl.partials), wl.nwg3, Q::NPARAM, loss, qx.mgrad);
+                       (const float*)(static_cast<char*>(qx.ws) + wl.partials), wl.nrec, Q::NPARAM, loss, qx.mgrad);
     MARL_CHECK_LAUNCH("qmix_reduce_kernel");
     return 0;
 }
