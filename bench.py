@@ -581,7 +581,7 @@ def bench_dqn(args, rank, world, dist, steps, warmup):
                         + (f"GRU-{H} networks (use_rnn), " if args.rnn else f"2-layer-{H} MLP, ") + f"time_limit {T}",
             "cadence": args.cadence,
             "cadence_note": ("the reference's replay ratio (32 sampled episodes per collected episode), gradient steps batched: U updates of B "
-                             "episodes per round; return-vs-env-steps against the reference cadence: profiles/r02_learning_parity.md")
+                             "episodes per round; return-vs-env-steps against the reference cadence: profiles/r02_learning_parity.md, profiles/r03_learning_parity.md")
             if args.cadence == "ratio" else ("the reference's own cadence: one update of 32 episodes per collected episode, sequentially"
                                              if args.cadence == "reference" else "collection only"),
             "envs_per_gpu": N,
@@ -594,6 +594,8 @@ def bench_dqn(args, rank, world, dist, steps, warmup):
                             + (f"strong scaling: {N * world} envs and a global update batch of {B * world} episodes split over the GPUs)" if strong else
                                f"weak scaling: effective update batch {world} x {B} episodes)")) if world > 1 else "1 GPU",
             "hparams": args.hparams if args.algo == "idqn" and args.cadence == "ratio" else "reference",
+            "learner": "split16 (opt-in: f32 products from fp16 halves)" if getattr(args, "split16", False) else "f32",
+            "mixer_first_layers": ("fp16 (opt-in)" if args.mixer_fp16 else "f32") if args.algo == "qmix" else None,
             "env_steps_timed": env_steps,
         },
         "kernels": timing,
