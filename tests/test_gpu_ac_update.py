@@ -91,10 +91,15 @@ def test_ppo_updates_match_reference_golden(name):
 
 
 @pytest.mark.parametrize("P,T,N,D,H,n", [(2, 25, 33, 15, 64, 5), (4, 7, 16, 27, 64, 1), (8, 25, 20, 39, 128, 10), (3, 25, 130, 24, 128, 5),
-                                         (2, 2, 1, 12, 64, 3), (4, 25, 600, 21, 64, 5)])
+                                         (2, 2, 1, 12, 64, 3), (4, 25, 600, 21, 64, 5),
+                                         # rollouts of whole 16-row blocks on the tensor-parallel kernels (hidden 128; the 71-wide warehouse rows
+                                         # at either width): the forward-rows pass stores the second hidden layer and the backward pass reads it
+                                         # back (tp_bwd_kernel<FULL, STORED>) - one block, an odd block count, several steps per workgroup
+                                         (2, 25, 32, 15, 128, 5), (3, 25, 144, 24, 128, 5), (2, 25, 2048, 15, 128, 5), (4, 12, 48, 71, 128, 5),
+                                         (2, 6, 304, 71, 64, 2), (8, 9, 64, 39, 128, 3)])
 def test_a2c_other_shapes_vs_oracle_port(P, T, N, D, H, n):
     h = hip()
-    A = 6
+    A = 5 if D == 71 else 6
     actor = dp.init_params(P, D, H, A, seed=1) + 0.03
     critic = torch.stack([dp.init_params(1, D, H, 1, seed=20 + p)[0] for p in range(P)]) + 0.02
     target = torch.stack([dp.init_params(1, D, H, 1, seed=40 + p)[0] for p in range(P)])
@@ -106,6 +111,39 @@ def test_a2c_other_shapes_vs_oracle_port(P, T, N, D, H, n):
     up = h.AcUpdater(spec, torch.cat([actor.reshape(-1), critic.reshape(-1)]).to(DEV), target.to(DEV).contiguous(), gamma=0.97,
                      n_steps=n, entropy_coef=0.01, value_loss_coef=0.5)
     got = up.a2c_loss_grad(dev_ac_batch(batch)).cpu().numpy()
+    ref = [m["loss"].item(), m["actor_loss"].item(), m["value_loss"].item(), m["entropy"].item()]
+    np.testing.assert_allclose(got[:4], ref, rtol=5e-5, atol=5e-6)
+    assert_grad_close(up.actor_grad.cpu().numpy(), a.grad.numpy(), 3e-4)
+    assert_grad_close(up.critic_grad.cpu().numpy(), c.grad.numpy(), 3e-4)
+
+
+@pytest.mark.parametrize("P,T,N,D,H", [(2, 25, 32, 15, 128), (3, 12, 144, 24, 128), (2, 25, 33, 15, 128), (4, 10, 64, 71, 64)])
+def test_ppo_epoch_after_a_parameter_change_vs_oracle_port(P, T, N, D, H):
+    """PPONetwork.update's epoch (ac/model.py:300-352) with ratios off 1: returns and old log-probs from the parameters at prepare time,
+    the clipped surrogate and its gradients at perturbed ones - on rollouts of whole 16-row blocks (the epoch's forward-rows pass stores
+    the second hidden layer for its backward pass at hidden 128 / 71-wide rows) and on a ragged one (the recomputing form)"""
+    h = hip()
+    A = 5 if D == 71 else 6
+    actor0 = dp.init_params(P, D, H, A, seed=1) + 0.03
+    critic0 = torch.stack([dp.init_params(1, D, H, 1, seed=20 + p)[0] for p in range(P)]) + 0.02
+    target = torch.stack([dp.init_params(1, D, H, 1, seed=40 + p)[0] for p in range(P)])
+    g = torch.Generator().manual_seed(9)
+    actor1 = actor0 + 0.02 * torch.randn(actor0.shape, generator=g)
+    critic1 = critic0 + 0.02 * torch.randn(critic0.shape, generator=g)
+    batch = ap.synthetic_batch(P, T, N, D, A, seed=7)
+    with torch.no_grad():
+        returns, _, old_logp, _ = ap.evaluate(actor0, critic0, target, batch, D, H, A, 5, 0.97)
+    a, c = actor1.clone().requires_grad_(True), critic1.clone().requires_grad_(True)
+    loss, m = ap.ppo_loss(a, c, returns, old_logp, batch, D, H, A, 0.01, 0.5, 0.2)
+    loss.backward()
+    spec = h.NetSpec(P, D, H, A)
+    up = h.AcUpdater(spec, torch.cat([actor0.reshape(-1), critic0.reshape(-1)]).to(DEV), target.to(DEV).contiguous(), gamma=0.97,
+                     n_steps=5, entropy_coef=0.01, value_loss_coef=0.5, ppo_clip=0.2)
+    b = dev_ac_batch(batch)
+    up.ppo_prepare(b)
+    up.actor.copy_(actor1)
+    up.critic.copy_(critic1)
+    got = up.ppo_loss_grad(b).cpu().numpy()
     ref = [m["loss"].item(), m["actor_loss"].item(), m["value_loss"].item(), m["entropy"].item()]
     np.testing.assert_allclose(got[:4], ref, rtol=5e-5, atol=5e-6)
     assert_grad_close(up.actor_grad.cpu().numpy(), a.grad.numpy(), 3e-4)
