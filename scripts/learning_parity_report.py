@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """profiles/r03_learning_parity.md from profiles/r03_learning/*.jsonl (tests/tools/learning_parity.py writes those: one JSON line per
-evaluation point).  The criterion is coarse on purpose (three and six runs) and the report says pass or fail; its two numbers (0.20,
-one run in three) were written down when the CPU runs stood at 7.2 M of their 18 M steps, i.e. before their later checkpoints existed:
+evaluation point).  The criterion is coarse on purpose (three and six runs) and the report says pass or fail.  Its two numbers (0.20 =
+about the seed-to-seed standard deviation of the return past the take-off, one run in three) were chosen with the curves in view, so it is
+a sanity bound a broken learner would fail, not a pre-registered test:
 
   at every checkpoint from 30 % of the run on, the mean return over the HIP runs lies within `TOL` of the mean over the CPU-oracle
   runs, and at the last common checkpoint the share of runs that left the 0.40 plateau (return >= 0.45) differs by at most one run
@@ -69,7 +70,7 @@ def main():
     left_o = sum(v >= PLATEAU for v in finals[0]) / len(finals[0])
     left_h = sum(v >= PLATEAU for v in finals[1] + finals[2]) / len(finals[1] + finals[2])
     ok = max(diffs) <= TOL and abs(left_o - left_h) <= 1.0 / 3.0 + 1e-9
-    print("\n## Criterion (`scripts/learning_parity_report.py`; thresholds set when the CPU runs were at 40 % of their length)\n")
+    print("\n## Criterion (`scripts/learning_parity_report.py`; thresholds chosen with the curves in view - a sanity bound, not a pre-registered test)\n")
     print("At every checkpoint from 30 %% on, |mean(HIP) - mean(oracle)| <= %.2f: largest difference **%.3f** (at %d %%).  " % (
         TOL, max(diffs), 10 * (3 + diffs.index(max(diffs)))))
     print("Share of runs above the 0.40 plateau (return >= %.2f) at %d %%: oracle %d of %d, HIP %d of %d.  " % (
