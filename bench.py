@@ -70,6 +70,52 @@ def parse():
     return ap.parse_args()
 
 
+def _cpu_all_cores(seconds, hidden, workers, make_env, loop):
+    """`workers` forked copies of `loop` (cpu_baseline hands over oracle/ref_learner.reference_idqn_loop), one thread each; (total env-steps, slowest window in s, copies
+    that reported) or None.  The children never touch the GPU and leave through os._exit (no torch / HIP exit handlers in a fork)."""
+    import select
+
+    pipes, pids = [], []
+    for _ in range(workers):
+        r, w = os.pipe()
+        pid = os.fork()
+        if pid == 0:
+            code = 1
+            try:
+                os.close(r)
+                _, n_steps, _, dt, _ = loop(seconds, hidden, ENV_NAME, 25, make_env)
+                os.write(w, f"{n_steps} {dt}\n".encode())
+                code = 0
+            finally:
+                os._exit(code)
+        os.close(w)
+        pipes.append(r)
+        pids.append(pid)
+    deadline = time.perf_counter() + seconds + 60.0
+    got, open_fds = [], set(pipes)
+    while open_fds and time.perf_counter() < deadline:
+        ready, _, _ = select.select(list(open_fds), [], [], 1.0)
+        for fd in ready:
+            data = os.read(fd, 256)
+            if data:
+                a, b = data.decode().split()
+                got.append((int(a), float(b)))
+            open_fds.discard(fd)
+    for fd in pipes:
+        os.close(fd)
+    for pid in pids:  # exactly the processes started above
+        try:
+            done, _ = os.waitpid(pid, os.WNOHANG)
+            if done == 0:
+                os.kill(pid, 9)
+                os.waitpid(pid, 0)
+        except OSError:
+            pass
+    if not got:
+        return None
+    return sum(a for a, _ in got), max(b for _, b in got), len(got)
+
+
 def cpu_baseline(seconds, hidden):
     """The reference's CPU path on the host cores, reference cadence (1 update of 32 episodes per episode once 32 episodes are
     stored), 1 thread as marlbase/run.py:29, bounded sample, FPS as loggers.py:70.  `kind: "reference"`: the reference's OWN
@@ -84,14 +130,30 @@ def cpu_baseline(seconds, hidden):
     from oracle.lbf import MarlbaseEnv
 
     if ref_learner.available():
-        v, n_steps, n_upd, dt, root = ref_learner.reference_idqn_loop(seconds, hidden, ENV_NAME, 25,
-                                                                       lambda: MarlbaseEnv(ENV_NAME, 25, rng=np.random.default_rng(0)))
-        return {"value": v, "unit": "env-steps/s", "cores": 1, "kind": "reference", "host_cores": os.cpu_count(),
-                "whole_node_estimate": v * (os.cpu_count() or 1),
-                "whole_node_estimate_note": "NOT measured: the 1-thread figure times the host's core count (independent runs, marlbase/run.py:29)",
-                "sample": f"{n_steps} env-steps / {n_upd} updates of the reference's own marlbase.dqn QNetwork + ReplayBuffer + _collect_trajectory "
-                          f"({os.path.relpath(root, ROOT) if root.startswith(ROOT) else root}) on oracle/lbf.py (python LBF env), IDQN {hidden}-{hidden}, "
-                          f"reference cadence, 1 thread, in {dt:.1f} s; host has {os.cpu_count()} cores"}
+        make_env = lambda: MarlbaseEnv(ENV_NAME, 25, rng=np.random.default_rng(0))  # noqa: E731
+        v, n_steps, n_upd, dt, root = ref_learner.reference_idqn_loop(seconds, hidden, ENV_NAME, 25, make_env)
+        where = os.path.relpath(root, ROOT) if root.startswith(ROOT) else root
+        one = {"value": v, "unit": "env-steps/s", "cores": 1, "kind": "reference", "host_cores": os.cpu_count(),
+               "sample": f"{n_steps} env-steps / {n_upd} updates of the reference's own marlbase.dqn QNetwork + ReplayBuffer + _collect_trajectory "
+                         f"({where}) on oracle/lbf.py (python LBF env), IDQN {hidden}-{hidden}, reference cadence, 1 thread, in {dt:.1f} s; "
+                         f"host has {os.cpu_count()} cores"}
+        # the whole host, MEASURED: one independent 1-thread copy of the same loop per core (how marlbase is run on a CPU node: one
+        # process per seed, marlbase/run.py:29), all started together, aggregate = total env-steps / the slowest copy's window
+        try:
+            workers = min(len(os.sched_getaffinity(0)), 256)
+        except AttributeError:
+            workers = min(os.cpu_count() or 1, 256)
+        agg = _cpu_all_cores(0.75 * seconds, hidden, workers, make_env, ref_learner.reference_idqn_loop) if workers > 1 else None
+        if agg is None:
+            one["whole_node_estimate"] = v * (os.cpu_count() or 1)
+            one["whole_node_estimate_note"] = "NOT measured: the 1-thread figure times the host's core count (independent runs, marlbase/run.py:29)"
+            return one
+        total_steps, slowest, n_ok = agg
+        return {"value": total_steps / slowest, "unit": "env-steps/s", "cores": n_ok, "kind": "reference", "host_cores": os.cpu_count(),
+                "one_thread": {"value": v, "sample": one["sample"]},
+                "sample": f"{n_ok} concurrent 1-thread copies (one per host core) of the reference's own marlbase.dqn QNetwork + ReplayBuffer + "
+                          f"_collect_trajectory ({where}) on oracle/lbf.py, IDQN {hidden}-{hidden}, reference cadence: {total_steps} env-steps in "
+                          f"{slowest:.1f} s (the slowest copy's window); one copy alone: {v:.0f} env-steps/s"}
 
     torch.set_num_threads(1)
     P, D, A, T = 2, 15, 6, 25
