@@ -66,6 +66,7 @@ def parse():
     ap.add_argument("--no-modes", action="store_true", help="skip the secondary rows (`modes`: env-only, reference cadence, hidden 128) the default line carries")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-all-cores", type=int, default=0, help=argparse.SUPPRESS)  # internal: the forked all-cores leg of cpu_baseline
     ap.add_argument("--no-kernel-timing", action="store_true")
     return ap.parse_args()
 
@@ -116,7 +117,7 @@ def _cpu_all_cores(seconds, hidden, workers, make_env, loop):
     return sum(a for a, _ in got), max(b for _, b in got), len(got)
 
 
-def cpu_baseline(seconds, hidden):
+def cpu_baseline(seconds, hidden, all_cores_only=0):
     """The reference's CPU path on the host cores, reference cadence (1 update of 32 episodes per episode once 32 episodes are
     stored), 1 thread as marlbase/run.py:29, bounded sample, FPS as loggers.py:70.  `kind: "reference"`: the reference's OWN
     QNetwork / ReplayBuffer / _epsilon_schedule / _collect_trajectory, unmodified, from oracle/_ref (oracle/make_ref.py copies them
@@ -131,6 +132,8 @@ def cpu_baseline(seconds, hidden):
 
     if ref_learner.available():
         make_env = lambda: MarlbaseEnv(ENV_NAME, 25, rng=np.random.default_rng(0))  # noqa: E731
+        if all_cores_only:  # the child process of the all-cores leg below: fork the copies from a process that never touched the GPU
+            return _cpu_all_cores(seconds, hidden, all_cores_only, make_env, ref_learner.reference_idqn_loop)
         v, n_steps, n_upd, dt, root = ref_learner.reference_idqn_loop(seconds, hidden, ENV_NAME, 25, make_env)
         where = os.path.relpath(root, ROOT) if root.startswith(ROOT) else root
         one = {"value": v, "unit": "env-steps/s", "cores": 1, "kind": "reference", "host_cores": os.cpu_count(),
@@ -143,13 +146,31 @@ def cpu_baseline(seconds, hidden):
             workers = min(len(os.sched_getaffinity(0)), 256)
         except AttributeError:
             workers = min(os.cpu_count() or 1, 256)
-        agg = _cpu_all_cores(0.75 * seconds, hidden, workers, make_env, ref_learner.reference_idqn_loop) if workers > 1 else None
+        agg = None
+        if workers > 1:  # in a fresh interpreter without a HIP context (forking this one, with the runtime initialised, is not safe)
+            import subprocess
+            try:
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-all-cores", str(workers), "--cpu-seconds", str(0.75 * seconds),
+                                    "--hidden", str(hidden)], capture_output=True, text=True, timeout=seconds + 180,
+                                   env=dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES=""))
+                lines = [l for l in r.stdout.splitlines() if l.startswith("[")]
+                agg = tuple(json.loads(lines[-1])) if lines else None
+            except (subprocess.SubprocessError, OSError, ValueError):
+                agg = None
         if agg is None:
             one["whole_node_estimate"] = v * (os.cpu_count() or 1)
             one["whole_node_estimate_note"] = "NOT measured: the 1-thread figure times the host's core count (independent runs, marlbase/run.py:29)"
             return one
         total_steps, slowest, n_ok = agg
+        quota = None  # the container's CPU allowance, when the cgroup states one ("max" = none): what the copies actually share
+        for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+            try:
+                quota = open(path).read().strip()
+                break
+            except OSError:
+                pass
         return {"value": total_steps / slowest, "unit": "env-steps/s", "cores": n_ok, "kind": "reference", "host_cores": os.cpu_count(),
+                "cgroup_cpu_quota": quota,
                 "one_thread": {"value": v, "sample": one["sample"]},
                 "sample": f"{n_ok} concurrent 1-thread copies (one per host core) of the reference's own marlbase.dqn QNetwork + ReplayBuffer + "
                           f"_collect_trajectory ({where}) on oracle/lbf.py, IDQN {hidden}-{hidden}, reference cadence: {total_steps} env-steps in "
@@ -410,6 +431,9 @@ def _self_launch(n):
 
 def main():
     args = parse()
+    if args.cpu_all_cores:  # internal: cpu_baseline's all-cores leg in its own interpreter (no GPU use in this process)
+        print(json.dumps(cpu_baseline(args.cpu_seconds, args.hidden, all_cores_only=args.cpu_all_cores)), flush=True)
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         _self_launch(args.gpus)
     import torch
