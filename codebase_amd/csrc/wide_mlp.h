@@ -13,6 +13,7 @@
 // addressed by (row, column) strides, so X^T / W^T never exist in memory; weight gradients split the row dimension over grid.z and a
 // second kernel adds the partial tiles in a fixed order (bitwise reproducible, no atomics) and applies 1 / sum(filled).
 #pragma once
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "common.h"
@@ -37,9 +38,36 @@ struct GemmOp {
     const float* gate; int64_t gate_m;     // epi 3: * (gate[m * gate_m + n] > 0)   (relu mask of the activation the gradient flows into)
     int b_ones;                            // -1: none
     int epi;                               // 0 store, 1 + bias, 2 relu(+ bias), 3 gate
+    bool a_vec, b_vec;                     // 16-byte operand loads are legal (set by wide_gemm from the pointers and strides)
 };
 
-// A_KC / B_KC: the operand is contiguous along k (true) or along m / n (false) - picks the global-load pattern that coalesces
+// Four consecutive elements c .. c + 3 (c a multiple of 4) along an operand's CONTIGUOUS dimension on line `line` (element (line, c) at
+// base[line * ls + c]); elements at or past `lim`, or on a line that is out of range, read as 0; element `ones` (the bias-gradient
+// column, -1: none) reads as 1.  vec (wave-uniform, set by wide_gemm when base, line stride and slice origin are 16-byte aligned): ONE
+// 16-byte load when the four are in range - a wave's 64 lanes then fetch whole 64-byte runs instead of 64 x 4 bytes from 64 different
+// rows per instruction (the scalar form of round 2 was bound by the texture addresser, not by its MFMAs: 0.21 - 0.27 of the f32 peak).
+__device__ __forceinline__ f4 gemm_load4(const float* __restrict__ base, int64_t line, int64_t ls, int c, int lim, bool line_ok, int ones, bool vec) {
+    f4 v = {0.f, 0.f, 0.f, 0.f};
+    if (!line_ok) return v;
+    const float* p = base + line * ls + c;
+    if (vec && c + 3 < lim) {
+        v = *reinterpret_cast<const f4*>(p);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (c + e < lim) v[e] = p[e];
+    }
+    if (ones >= 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (c + e == ones) v[e] = 1.f;
+    }
+    return v;
+}
+
+// A_KC / B_KC: the operand is contiguous along k (true) or along m / n (false) - picks the global-load pattern that coalesces.
+// Thread map of a 16-deep slice: k-contiguous operands - thread t takes row t / 4 and k = 4 (t % 4) .. + 3 (16 lanes cover four rows' 64 bytes);
+// m / n-contiguous ones - thread t takes k = t / 16 and rows 4 (t % 16) .. + 3.
 template <bool A_KC, bool B_KC>
 __global__ __launch_bounds__(256) void wide_gemm_kernel(const GemmOp g) {
     constexpr int LD = 80;
@@ -50,35 +78,27 @@ __global__ __launch_bounds__(256) void wide_gemm_kernel(const GemmOp g) {
     f4 acc[4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) acc[nt] = f4{0.f, 0.f, 0.f, 0.f};
-    float ra[4], rb[4];
+    f4 ra, rb;
     auto load = [&](int k0) {
-        if (A_KC) {  // thread: one m, four consecutive k
-            const int m = m0 + (tid & 63), kq = k0 + 4 * (tid >> 6);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) ra[e] = (m < g.M && kq + e < kend) ? g.A[(int64_t)m * g.a_m + (int64_t)(kq + e) * g.a_k] : 0.f;
-        } else {  // thread: one k, four consecutive m
-            const int k = k0 + (tid >> 4), mm = m0 + 4 * (tid & 15);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) ra[e] = (mm + e < g.M && k < kend) ? g.A[(int64_t)(mm + e) * g.a_m + (int64_t)k * g.a_k] : 0.f;
-        }
+        if (A_KC) ra = gemm_load4(g.A, m0 + (tid >> 2), g.a_m, k0 + 4 * (tid & 3), kend, m0 + (tid >> 2) < g.M, -1, g.a_vec);
+        else ra = gemm_load4(g.A, k0 + (tid >> 4), g.a_k, m0 + 4 * (tid & 15), g.M, k0 + (tid >> 4) < kend, -1, g.a_vec);
         if (B_KC) {
-            const int n = n0 + (tid & 63), kq = k0 + 4 * (tid >> 6);
+            const int n = n0 + (tid >> 2);
+            rb = gemm_load4(g.B, n, g.b_n, k0 + 4 * (tid & 3), kend, n < g.N && n != g.b_ones, -1, g.b_vec);
+            if (n == g.b_ones) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                rb[e] = (n < g.N && kq + e < kend) ? (n == g.b_ones ? 1.f : g.B[(int64_t)(kq + e) * g.b_k + (int64_t)n * g.b_n]) : 0.f;
+                for (int e = 0; e < 4; ++e) rb[e] = k0 + 4 * (tid & 3) + e < kend ? 1.f : 0.f;
+            }
         } else {
-            const int k = k0 + (tid >> 4), nn = n0 + 4 * (tid & 15);
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                rb[e] = (nn + e < g.N && k < kend) ? (nn + e == g.b_ones ? 1.f : g.B[(int64_t)k * g.b_k + (int64_t)(nn + e) * g.b_n]) : 0.f;
+            rb = gemm_load4(g.B, k0 + (tid >> 4), g.b_k, n0 + 4 * (tid & 15), g.b_ones >= 0 ? g.N - 1 : g.N, k0 + (tid >> 4) < kend, g.b_ones, g.b_vec);
         }
     };
     auto store = [&]() {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            if (A_KC) As[(4 * (tid >> 6) + e) * LD + (tid & 63)] = ra[e];
+            if (A_KC) As[(4 * (tid & 3) + e) * LD + (tid >> 2)] = ra[e];
             else As[(tid >> 4) * LD + 4 * (tid & 15) + e] = ra[e];
-            if (B_KC) Bs[(4 * (tid >> 6) + e) * LD + (tid & 63)] = rb[e];
+            if (B_KC) Bs[(4 * (tid & 3) + e) * LD + (tid >> 2)] = rb[e];
             else Bs[(tid >> 4) * LD + 4 * (tid & 15) + e] = rb[e];
         }
     };
@@ -115,8 +135,9 @@ __global__ __launch_bounds__(256) void wide_gemm_kernel(const GemmOp g) {
 
 // The same product on a 128 x 128 tile per workgroup for the large GEMMs (both output dimensions >= 128: hidden layers over all rows,
 // weight gradients of wide layers): wave w owns a 64 x 64 quadrant = 4 x 4 MFMA tiles, so a 16-deep k-slice costs 8 ds_read_b128
-// for 64 MFMAs (the 64 x 64 kernel above: 20 ds_read_b32 for 16).  LDS layout [row][16 + 4] with k PERMUTED inside a row - slot
-// 4 q + s holds k = 4 s + q - so that the four k-steps' operands of a lane (its k-quarter q) are one 16-byte read.
+// for 64 MFMAs (the 64 x 64 kernel above: 20 ds_read_b32 for 16).  LDS layout [row][16 + 4], k in its natural order: lane quarter q
+// takes k = 4 q + s at MFMA step s (the same assignment on both operands), so its four steps' operands are one 16-byte read and the
+// k-contiguous global loads land as 16-byte stores.  Two passes of the thread map above per slice (128 rows).
 template <bool A_KC, bool B_KC>
 __global__ __launch_bounds__(256) void wide_gemm128_kernel(const GemmOp g) {
     constexpr int LD = 20;
@@ -130,37 +151,44 @@ __global__ __launch_bounds__(256) void wide_gemm128_kernel(const GemmOp g) {
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = f4{0.f, 0.f, 0.f, 0.f};
-    float ra[8], rb[8];
+    f4 ra[2], rb[2];
     auto load = [&](int k0) {
-        if (A_KC) {  // thread: one row, eight consecutive k
-            const int m = m0 + (tid & 127), kq = k0 + 8 * (tid >> 7);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) ra[e] = (m < g.M && kq + e < kend) ? g.A[(int64_t)m * g.a_m + (int64_t)(kq + e) * g.a_k] : 0.f;
-        } else {  // thread: one k, eight consecutive rows
-            const int k = k0 + (tid >> 4), mm = m0 + 8 * (tid & 15);
+        for (int h = 0; h < 2; ++h) {
+            if (A_KC) {
+                const int m = m0 + 64 * h + (tid >> 2);
+                ra[h] = gemm_load4(g.A, m, g.a_m, k0 + 4 * (tid & 3), kend, m < g.M, -1, g.a_vec);
+            } else {
+                ra[h] = gemm_load4(g.A, k0 + (tid >> 4), g.a_k, m0 + 64 * h + 4 * (tid & 15), g.M, k0 + (tid >> 4) < kend, -1, g.a_vec);
+            }
+            if (B_KC) {
+                const int n = n0 + 64 * h + (tid >> 2);
+                rb[h] = gemm_load4(g.B, n, g.b_n, k0 + 4 * (tid & 3), kend, n < g.N && n != g.b_ones, -1, g.b_vec);
+                if (n == g.b_ones) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) ra[e] = (mm + e < g.M && k < kend) ? g.A[(int64_t)(mm + e) * g.a_m + (int64_t)k * g.a_k] : 0.f;
-        }
-        if (B_KC) {
-            const int n = n0 + (tid & 127), kq = k0 + 8 * (tid >> 7);
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-                rb[e] = (n < g.N && kq + e < kend) ? (n == g.b_ones ? 1.f : g.B[(int64_t)(kq + e) * g.b_k + (int64_t)n * g.b_n]) : 0.f;
-        } else {
-            const int k = k0 + (tid >> 4), nn = n0 + 8 * (tid & 15);
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-                rb[e] = (nn + e < g.N && k < kend) ? (nn + e == g.b_ones ? 1.f : g.B[(int64_t)k * g.b_k + (int64_t)(nn + e) * g.b_n]) : 0.f;
+                    for (int e = 0; e < 4; ++e) rb[h][e] = k0 + 4 * (tid & 3) + e < kend ? 1.f : 0.f;
+                }
+            } else {
+                rb[h] = gemm_load4(g.B, k0 + (tid >> 4), g.b_k, n0 + 64 * h + 4 * (tid & 15), g.b_ones >= 0 ? g.N - 1 : g.N, k0 + (tid >> 4) < kend,
+                                   g.b_ones, g.b_vec);
+            }
         }
     };
-    auto slot = [](int k) { return 4 * (k & 3) + (k >> 2); };  // k = 4 s + q  ->  4 q + s
     auto store = [&]() {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            if (A_KC) As[(tid & 127) * LD + slot(8 * (tid >> 7) + e)] = ra[e];
-            else As[(8 * (tid & 15) + e) * LD + slot(tid >> 4)] = ra[e];
-            if (B_KC) Bs[(tid & 127) * LD + slot(8 * (tid >> 7) + e)] = rb[e];
-            else Bs[(8 * (tid & 15) + e) * LD + slot(tid >> 4)] = rb[e];
+        for (int h = 0; h < 2; ++h) {
+            if (A_KC) {
+                *reinterpret_cast<f4*>(As + (64 * h + (tid >> 2)) * LD + 4 * (tid & 3)) = ra[h];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) As[(64 * h + 4 * (tid & 15) + e) * LD + (tid >> 4)] = ra[h][e];
+            }
+            if (B_KC) {
+                *reinterpret_cast<f4*>(Bs + (64 * h + (tid >> 2)) * LD + 4 * (tid & 3)) = rb[h];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) Bs[(64 * h + 4 * (tid & 15) + e) * LD + (tid >> 4)] = rb[h][e];
+            }
         }
     };
     if (kbeg < kend) load(kbeg);
@@ -317,7 +345,20 @@ inline WideWs wide_ws(const WideNet& s, int P, int rows, bool backward) {
 }
 
 template <bool A_KC, bool B_KC>
-inline void wide_gemm(const GemmOp& g, int splits, hipStream_t st) {
+inline void wide_gemm(const GemmOp& g0, int splits, hipStream_t st) {
+    GemmOp g = g0;
+    if ((A_KC ? g.a_k : g.a_m) != 1 || (B_KC ? g.b_k : g.b_n) != 1) {  // (a programming error, not a run-time condition)
+        fprintf(stderr, "wide_gemm: operand not unit-stride along its contiguous dimension\n");
+        abort();
+    }
+    {   // 16-byte loads along the contiguous dimension: unit stride there, line stride and base a multiple of 4 floats / 16 bytes, and the
+        // slice origins multiples of 4 (k-contiguous operands start at z * k_chunk; m / n-contiguous ones at multiples of 64 / 128)
+        auto al = [](const float* p, int64_t unit, int64_t line) { return unit == 1 && (line & 3) == 0 && (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+        const bool kc_ok = (g.k_chunk & 3) == 0 || splits == 1;
+        g.a_vec = A_KC ? al(g.A, g.a_k, g.a_m) && kc_ok : al(g.A, g.a_m, g.a_k);
+        g.b_vec = B_KC ? al(g.B, g.b_k, g.b_n) && kc_ok : al(g.B, g.b_n, g.b_k);
+        if (getenv("MARLHIP_WIDE_SCALAR_LOADS") != nullptr) g.a_vec = g.b_vec = false;  // diagnostics: the element-wise loads
+    }
     static const bool small_only = getenv("MARLHIP_WIDE_GEMM64") != nullptr;  // diagnostics: the 64 x 64 kernel for everything
     const int64_t wgs128 = (int64_t)((g.N + 127) / 128) * ((g.M + 127) / 128) * splits;
     if (g.M >= 128 && g.N >= 128 && wgs128 >= 512 && !small_only)  // (a smaller launch fills the chip better with 64 x 64 tiles)
