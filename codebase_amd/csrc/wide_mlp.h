@@ -27,6 +27,13 @@ namespace marl {
 // profiles/r03_flatload_ab.md): the clamped form issues every load of the padded tile, the branchy one skips the out-of-range ones, and
 // these GEMMs are not bound by load latency.)
 
+#ifndef MARL_WIDE_KB
+// k depth of one LDS slice of wide_gemm128_kernel.  Measured (scripts/gpu_runs/r3Q.sh): 32 (128 MFMAs per wave between barrier pairs, 37 KB of
+// LDS, twice the prefetch registers) is 3 - 13 % SLOWER than 16 on every GEMM-path row (MAPPO rware 6.20 -> 5.38 M): the kernels live on
+// resident workgroups per CU, not on barrier count.
+#define MARL_WIDE_KB 16
+#endif
+
 struct GemmOp {
     const float* A; int64_t a_m, a_k;      // A(m, k) = A[m * a_m + k * a_k]
     const float* B; int64_t b_k, b_n;      // B(k, n) = B[k * b_k + n * b_n]; column n == b_ones reads as 1 (bias-gradient column)
@@ -140,7 +147,7 @@ __global__ __launch_bounds__(256) void wide_gemm_kernel(const GemmOp g) {
 // k-contiguous global loads land as 16-byte stores.  Two passes of the thread map above per slice (128 rows).
 template <bool A_KC, bool B_KC>
 __global__ __launch_bounds__(256) void wide_gemm128_kernel(const GemmOp g) {
-    constexpr int LD = 20;
+    constexpr int KB = MARL_WIDE_KB, NS = KB / 16, LD = KB + 4;  // slice depth: NS sub-slices of 16 between two barriers
     __shared__ __attribute__((aligned(16))) float As[128 * LD], Bs[128 * LD];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 15, q = lane >> 4;
     const int wm = wave >> 1, wn = wave & 1;  // the wave's quadrant
@@ -151,64 +158,73 @@ __global__ __launch_bounds__(256) void wide_gemm128_kernel(const GemmOp g) {
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = f4{0.f, 0.f, 0.f, 0.f};
-    f4 ra[2], rb[2];
-    auto load = [&](int k0) {
+    f4 ra[NS][2], rb[NS][2];
+    auto load = [&](int kbase) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            if (A_KC) {
-                const int m = m0 + 64 * h + (tid >> 2);
-                ra[h] = gemm_load4(g.A, m, g.a_m, k0 + 4 * (tid & 3), kend, m < g.M, -1, g.a_vec);
-            } else {
-                ra[h] = gemm_load4(g.A, k0 + (tid >> 4), g.a_k, m0 + 64 * h + 4 * (tid & 15), g.M, k0 + (tid >> 4) < kend, -1, g.a_vec);
-            }
-            if (B_KC) {
-                const int n = n0 + 64 * h + (tid >> 2);
-                rb[h] = gemm_load4(g.B, n, g.b_n, k0 + 4 * (tid & 3), kend, n < g.N && n != g.b_ones, -1, g.b_vec);
-                if (n == g.b_ones) {
+        for (int ss = 0; ss < NS; ++ss) {
+            const int k0 = kbase + 16 * ss;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) rb[h][e] = k0 + 4 * (tid & 3) + e < kend ? 1.f : 0.f;
+            for (int h = 0; h < 2; ++h) {
+                if (A_KC) {
+                    const int m = m0 + 64 * h + (tid >> 2);
+                    ra[ss][h] = gemm_load4(g.A, m, g.a_m, k0 + 4 * (tid & 3), kend, m < g.M, -1, g.a_vec);
+                } else {
+                    ra[ss][h] = gemm_load4(g.A, k0 + (tid >> 4), g.a_k, m0 + 64 * h + 4 * (tid & 15), g.M, k0 + (tid >> 4) < kend, -1, g.a_vec);
                 }
-            } else {
-                rb[h] = gemm_load4(g.B, k0 + (tid >> 4), g.b_k, n0 + 64 * h + 4 * (tid & 15), g.b_ones >= 0 ? g.N - 1 : g.N, k0 + (tid >> 4) < kend,
-                                   g.b_ones, g.b_vec);
+                if (B_KC) {
+                    const int n = n0 + 64 * h + (tid >> 2);
+                    rb[ss][h] = gemm_load4(g.B, n, g.b_n, k0 + 4 * (tid & 3), kend, n < g.N && n != g.b_ones, -1, g.b_vec);
+                    if (n == g.b_ones) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) rb[ss][h][e] = k0 + 4 * (tid & 3) + e < kend ? 1.f : 0.f;
+                    }
+                } else {
+                    rb[ss][h] = gemm_load4(g.B, k0 + (tid >> 4), g.b_k, n0 + 64 * h + 4 * (tid & 15), g.b_ones >= 0 ? g.N - 1 : g.N,
+                                           k0 + (tid >> 4) < kend, g.b_ones, g.b_vec);
+                }
             }
         }
     };
     auto store = [&]() {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            if (A_KC) {
-                *reinterpret_cast<f4*>(As + (64 * h + (tid >> 2)) * LD + 4 * (tid & 3)) = ra[h];
-            } else {
+        for (int ss = 0; ss < NS; ++ss)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) As[(64 * h + 4 * (tid & 15) + e) * LD + (tid >> 4)] = ra[h][e];
-            }
-            if (B_KC) {
-                *reinterpret_cast<f4*>(Bs + (64 * h + (tid >> 2)) * LD + 4 * (tid & 3)) = rb[h];
-            } else {
+            for (int h = 0; h < 2; ++h) {
+                if (A_KC) {
+                    *reinterpret_cast<f4*>(As + (64 * h + (tid >> 2)) * LD + 16 * ss + 4 * (tid & 3)) = ra[ss][h];
+                } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) Bs[(64 * h + 4 * (tid & 15) + e) * LD + (tid >> 4)] = rb[h][e];
+                    for (int e = 0; e < 4; ++e) As[(64 * h + 4 * (tid & 15) + e) * LD + 16 * ss + (tid >> 4)] = ra[ss][h][e];
+                }
+                if (B_KC) {
+                    *reinterpret_cast<f4*>(Bs + (64 * h + (tid >> 2)) * LD + 16 * ss + 4 * (tid & 3)) = rb[ss][h];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) Bs[(64 * h + 4 * (tid & 15) + e) * LD + 16 * ss + (tid >> 4)] = rb[ss][h][e];
+                }
             }
-        }
     };
     if (kbeg < kend) load(kbeg);
-    for (int k0 = kbeg; k0 < kend; k0 += 16) {
+    for (int k0 = kbeg; k0 < kend; k0 += KB) {
         __syncthreads();
         store();
         __syncthreads();
-        if (k0 + 16 < kend) load(k0 + 16);
-        f4 a[4], b[4];
+        if (k0 + KB < kend) load(k0 + KB);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            a[t] = *reinterpret_cast<const f4*>(As + (64 * wm + 16 * t + i) * LD + 4 * q);
-            b[t] = *reinterpret_cast<const f4*>(Bs + (64 * wn + 16 * t + i) * LD + 4 * q);
+        for (int ss = 0; ss < NS; ++ss) {
+            f4 a[4], b[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                a[t] = *reinterpret_cast<const f4*>(As + (64 * wm + 16 * t + i) * LD + 16 * ss + 4 * q);
+                b[t] = *reinterpret_cast<const f4*>(Bs + (64 * wn + 16 * t + i) * LD + 16 * ss + 4 * q);
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = MARL_MFMA(a[mt][s2], b[nt][s2], acc[mt][nt]);
         }
-#pragma unroll
-        for (int s2 = 0; s2 < 4; ++s2)
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = MARL_MFMA(a[mt][s2], b[nt][s2], acc[mt][nt]);
     }
     float* C = g.C + (int64_t)blockIdx.z * g.c_split;
 #pragma unroll
