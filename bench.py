@@ -625,7 +625,7 @@ def bench_dqn(args, rank, world, dist, steps, warmup):
         key = f"{args.algo}:{args.env_name}:N{N}:H{H}:B{B}:T{T}:rnn{int(bool(args.rnn))}" + (":split16" if getattr(args, "split16", False) else "")
         traffic, tsrc = traffic_from_profile(key)
         kname = "dqn_lossgrad_h16_kernel (split-fp16 products, fp32 accumulate)" if getattr(args, "split16", False) else ("gru_seq_fwd2 + gru_td + gru_seq_bwd + gru_wgrad" if args.rnn else
-                 ("dqn_lossgrad_kernel" if H <= 64 and D <= 48 else "tp_fwd_kernel + tp_mix_kernel + tp_bwd_kernel")) + (" + qmix mixer stage" if args.algo == "qmix" else "")
+                 ("dqn_lossgrad_kernel" if H <= 64 else "tp_fwd_kernel + tp_mix_kernel + tp_bwd_kernel")) + (" + qmix mixer stage" if args.algo == "qmix" else "")
         roofline = {"kernel": kname, "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": tsrc, "flops_per_launch": flops,
                     "flops_parts": parts, "avg_launch_us": lg["avg_us"],

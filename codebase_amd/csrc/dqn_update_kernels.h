@@ -68,8 +68,11 @@ struct UpdLds {
     // per wave: [h2 tile, later the dH1 tile][h1 tile][dH2 tile][dQ tile]; the dH1 tile re-uses the h2 tile, whose only reader
     // (the dW3 operands) has retired long before dH1 exists
     static constexpr int per_wave(int ts) { return 3 * ts * S::H + 16 * ts; }
+    // fold regions live at once: one per wave, or two when four copies of the gradient exceed the LDS (the 71-wide warehouse rows: 36 KB
+    // each) - the waves then fold in two rounds (the second pair adds onto the first pair's regions)
+    static constexpr int fold_waves(int waves) { return waves * FOLD * 4 <= 160 * 1024 ? waves : (waves + 1) / 2; }
     static constexpr int total_ts(int waves, int ts) {
-        return (oTiles + waves * per_wave(ts)) > waves * FOLD ? (oTiles + waves * per_wave(ts)) : waves * FOLD;
+        return (oTiles + waves * per_wave(ts)) > fold_waves(waves) * FOLD ? (oTiles + waves * per_wave(ts)) : fold_waves(waves) * FOLD;
     }
     static constexpr int TS = total_ts(4, 24) * 4 <= 160 * 1024 ? 24 : 16;  // padded tiles when they fit next to the packs
     static constexpr int TILE = TS * S::H;
@@ -670,40 +673,45 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dqn_lossgrad_kernel(con
     // accumulators into its own LDS region in parallel (weights at their canonical index, bias / loss
     // partials as [value][16 lanes] strips), one barrier, then all threads sum the regions in a fixed
     // order - no cross-lane shuffles, no serialisation between waves, bitwise reproducible.
+    constexpr int FW = L::fold_waves(WAVES);  // fold regions (WAVES, or WAVES / 2 in two rounds)
     __syncthreads();
-    {
-        float* mine = lds + (size_t)wave * L::FOLD;
-        float* strips = mine + L::STRIP_OFF;  // [(2H + 16) bias rows + 2 loss rows][16]
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
+    for (int round = 0; round < WAVES / FW; ++round) {
+        if (wave / FW == round) {
+            float* mine = lds + (size_t)(wave % FW) * L::FOLD;
+            float* strips = mine + L::STRIP_OFF;  // [(2H + 16) bias rows + 2 loss rows][16]
+            auto put = [&](float& slot, float v) { slot = round == 0 ? v : slot + v; };  // (second round: this lane's own slot of the first round's copy)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int o = 16 * mt + 4 * g + r;
+#pragma unroll
+                    for (int nt = 0; nt < NT1; ++nt) {
+                        const int d = 16 * nt + j;
+                        if (d < D) put(mine[S::oW1 + o * D + d], dW1[mt][nt][r]);
+                    }
+#pragma unroll
+                    for (int nt = 0; nt < MT; ++nt) put(mine[S::oW2 + o * H + 16 * nt + j], dW2[mt][nt][r]);
+                    put(strips[o * 16 + j], DB1_FREE ? (j == D % 16 ? dW1[mt][D / 16][r] : 0.f) : db1[mt][r]);
+                    put(strips[(H + o) * 16 + j], db2[mt][r]);
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int o = 16 * mt + 4 * g + r;
+                const int a = 4 * g + r;
 #pragma unroll
-                for (int nt = 0; nt < NT1; ++nt) {
-                    const int d = 16 * nt + j;
-                    if (d < D) mine[S::oW1 + o * D + d] = dW1[mt][nt][r];
-                }
-#pragma unroll
-                for (int nt = 0; nt < MT; ++nt) mine[S::oW2 + o * H + 16 * nt + j] = dW2[mt][nt][r];
-                strips[o * 16 + j] = DB1_FREE ? (j == D % 16 ? dW1[mt][D / 16][r] : 0.f) : db1[mt][r];
-                strips[(H + o) * 16 + j] = db2[mt][r];
+                for (int nt = 0; nt < MT; ++nt)
+                    if (a < A) put(mine[S::oW3 + a * H + 16 * nt + j], dW3[nt][r]);
+                put(strips[(2 * H + a) * 16 + j], db3[r]);
+            }
+            if (g == 0) {
+                put(strips[(2 * H + 16) * 16 + j], loss_acc);
+                put(strips[(2 * H + 17) * 16 + j], nfill_acc);
             }
         }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int a = 4 * g + r;
-#pragma unroll
-            for (int nt = 0; nt < MT; ++nt)
-                if (a < A) mine[S::oW3 + a * H + 16 * nt + j] = dW3[nt][r];
-            strips[(2 * H + a) * 16 + j] = db3[r];
-        }
-        if (g == 0) {
-            strips[(2 * H + 16) * 16 + j] = loss_acc;
-            strips[(2 * H + 17) * 16 + j] = nfill_acc;
-        }
+        __syncthreads();
     }
-    __syncthreads();
     float* rec = partials + ((size_t)p * gridDim.x + blockIdx.x) * L::REC;
     // plain elements: sum of the four regions in wave order, 16 bytes per thread and step (the bias / loss slots are written by
     // the strip pass below; what this pass leaves there is overwritten)
@@ -711,14 +719,14 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dqn_lossgrad_kernel(con
         for (int i4 = tid; i4 < L::REC / 4; i4 += UPD_BLOCK) {
             f4 acc = reinterpret_cast<const f4*>(lds)[i4];
 #pragma unroll
-            for (int w = 1; w < WAVES; ++w) acc += reinterpret_cast<const f4*>(lds + (size_t)w * L::FOLD)[i4];
+            for (int w = 1; w < FW; ++w) acc += reinterpret_cast<const f4*>(lds + (size_t)w * L::FOLD)[i4];
             reinterpret_cast<f4*>(rec)[i4] = acc;
         }
     } else {
         for (int i = tid; i < L::REC; i += UPD_BLOCK) {
             float acc = lds[i];
 #pragma unroll
-            for (int w = 1; w < WAVES; ++w) acc += lds[(size_t)w * L::FOLD + i];
+            for (int w = 1; w < FW; ++w) acc += lds[(size_t)w * L::FOLD + i];
             rec[i] = acc;
         }
     }
@@ -733,7 +741,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dqn_lossgrad_kernel(con
         if (i < 0) continue;
         float acc = 0.f;
 #pragma unroll
-        for (int w = 0; w < WAVES; ++w) {
+        for (int w = 0; w < FW; ++w) {
             const f4* sp = reinterpret_cast<const f4*>(lds + (size_t)w * L::FOLD + L::STRIP_OFF + sidx * 16);
             float t = 0.f;
 #pragma unroll
