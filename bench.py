@@ -146,6 +146,20 @@ def cpu_baseline(seconds, hidden, all_cores_only=0):
             workers = min(len(os.sched_getaffinity(0)), 256)
         except AttributeError:
             workers = min(os.cpu_count() or 1, 256)
+        quota = None  # the container's CPU allowance when the cgroup states one ("max": none) - more copies than that only time-share
+        for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+            try:
+                quota = open(path).read().strip()
+                break
+            except OSError:
+                pass
+        try:
+            q = quota.split()
+            period = float(q[1]) if len(q) > 1 else float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q[0] not in ("max", "-1"):
+                workers = max(1, min(workers, int(-(-float(q[0]) // period))))
+        except (AttributeError, IndexError, ValueError, OSError):
+            pass
         agg = None
         if workers > 1:  # in a fresh interpreter without a HIP context (forking this one, with the runtime initialised, is not safe)
             import subprocess
@@ -162,17 +176,10 @@ def cpu_baseline(seconds, hidden, all_cores_only=0):
             one["whole_node_estimate_note"] = "NOT measured: the 1-thread figure times the host's core count (independent runs, marlbase/run.py:29)"
             return one
         total_steps, slowest, n_ok = agg
-        quota = None  # the container's CPU allowance, when the cgroup states one ("max" = none): what the copies actually share
-        for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
-            try:
-                quota = open(path).read().strip()
-                break
-            except OSError:
-                pass
         return {"value": total_steps / slowest, "unit": "env-steps/s", "cores": n_ok, "kind": "reference", "host_cores": os.cpu_count(),
                 "cgroup_cpu_quota": quota,
                 "one_thread": {"value": v, "sample": one["sample"]},
-                "sample": f"{n_ok} concurrent 1-thread copies (one per host core) of the reference's own marlbase.dqn QNetwork + ReplayBuffer + "
+                "sample": f"{n_ok} concurrent 1-thread copies (one per CPU this container may use: host cores {os.cpu_count()}, cgroup quota {quota}) of the reference's own marlbase.dqn QNetwork + ReplayBuffer + "
                           f"_collect_trajectory ({where}) on oracle/lbf.py, IDQN {hidden}-{hidden}, reference cadence: {total_steps} env-steps in "
                           f"{slowest:.1f} s (the slowest copy's window); one copy alone: {v:.0f} env-steps/s"}
 
