@@ -1060,7 +1060,10 @@ static __global__ __launch_bounds__(256) void adam_pack_kernel(int n, int nsq, f
 // (Measured and dropped, r02: the same epilogue as ONE launch - reduce, a grid barrier, then Adam + packs in the same workgroups.
 // Through hipLaunchCooperativeKernel the launch itself costs ~30 us (bench 27.1 -> 21.8 M env-steps/s); with a hand-rolled barrier
 // on a plain launch (agent-scope release / acquire around an atomic arrival counter) the L2 write-back + invalidate of the fences
-// costs more than the kernel boundary it replaces (27.1 -> 26.3 M; 0.92 -> 0.75 M at the reference cadence).  Two launches it is.)
+// costs more than the kernel boundary it replaces (27.1 -> 26.3 M; 0.92 -> 0.75 M at the reference cadence).  Two launches it is.
+// r03: for the small updates of the reference cadence (a dozen records per agent) the whole epilogue in ONE 1024-thread workgroup - no grid
+// barrier needed - was tried as well: one CU's worth of loads in flight makes it ~60 us against 9 us for the two launches that spread
+// the same bytes over 130 workgroups (0.92 -> 0.31 M env-steps/s, scripts/gpu_runs/r3U.sh).  Dropped.)
 
 struct UpdPlan {
     int nwg, n_chunks;
