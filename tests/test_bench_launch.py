@@ -52,3 +52,13 @@ def test_bench_gpus_2_runs_two_ranks_on_the_real_kernels(algo):
     line = _json_line(out.stdout)
     assert line["n_gpus"] == 2 and line["rccl_ranks"] == {"world_size": 2, "backend": "gloo"}
     assert line["value"] > 0 and line["scaling"] == "weak"
+
+
+def test_cpu_baseline_all_cores_leg_forks_and_reports():
+    """bench.py --cpu-all-cores N (the internal leg of cpu_baseline that a fresh interpreter runs): N forked 1-thread copies of the
+    reference loop, [total env-steps, slowest window, copies that reported]"""
+    out = subprocess.run([sys.executable, BENCH, "--cpu-all-cores", "2", "--cpu-seconds", "1.0"], cwd=ROOT, env=_env(), capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    got = json.loads([l for l in out.stdout.splitlines() if l.startswith("[")][-1])
+    assert got[2] == 2 and got[0] > 0 and 0.9 <= got[1] <= 30.0
