@@ -77,7 +77,8 @@ extern "C" int64_t marlhip_dqn_workspace_bytes(const marlhip_net_shape* s, int32
         if (!tp && h16 > pack) pack = h16;
     }
     const int64_t base = ws_layout(s->n_agents, pl.nwg, np + 2, (int)pack, max_len, batch).total;
-    if (!tp) return base;
+    if (!tp)  // the two-pass form's stored hidden layers (qsel pass -> bwd pass), whatever mode the caller goes on to use
+        return ((base + 15) & ~(int64_t)15) + lds_h_floats(s->n_agents, max_len, batch, s->hidden) * (int64_t)sizeof(float) + 128;
     return ((base + 15) & ~(int64_t)15) + tp_h2_floats(s->n_agents, max_len, batch, s->hidden) * (int64_t)sizeof(float);  // pass F -> pass B activations
 }
 

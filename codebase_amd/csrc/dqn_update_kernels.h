@@ -172,10 +172,15 @@ struct IntC { static constexpr int value = I; };
 //   C  backward(t)              176 MFMA   | bootstrap value for transition t-1 (argmax / gather on permlane swaps), relu masks
 //                                          | and tile writes of dH2 / dH1 next to dW3 / the first half of dW2
 // The first step of a chunk (t = t1) has no transition (A, B, bootstrap), the last (t = t0) needs no target (A, TD, C).
-template <class S, int WAVES, bool REPLAY, int MODE>
+// STORED (the two-pass form, MODE 1 then MODE 2): the qsel pass leaves the critic's two hidden layers of every transition row (post-relu,
+// MFMA C layout: hst[(((p T + t) ngroups + group) 2 MT + layer MT + tile) 64 + lane], 512 bytes per row at hidden 64) and the bwd pass
+// reads them back one step ahead next to the rows instead of running the critic forward again - 96 of its 272 MFMAs per row block.
+template <class S, int WAVES, bool REPLAY, int MODE, bool STORED = false>
 __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dqn_lossgrad_kernel(const float* __restrict__ packs, marlhip_batch bt, ReplaySrc rs,
                                                                  MixBufs mix, float gamma, int double_q, int n_chunks,
-                                                                 float* __restrict__ partials, unsigned long long* prof) {
+                                                                 float* __restrict__ partials, unsigned long long* prof,
+                                                                 f4* __restrict__ hst = nullptr) {
+    static_assert(!STORED || MODE == 1 || MODE == 2, "stored activations belong to the two-pass form");
     using L = UpdLds<S>;
     constexpr int MT = S::MT, NT1 = S::DP / 16, D = S::D, H = S::H, A = S::A, TS = L::TS, N1 = S::KS1 / 4;
     constexpr int UPD_BLOCK = 64 * WAVES;
@@ -279,6 +284,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dqn_lossgrad_kernel(con
             float dq, lr;      // MODE 2: external dL/dchosen and per-row loss
             float dqv[4];      // MODE 4: external dL/d(output 4g+r)
             float mk[4];       // batch.action_mask of outputs 4g+r at this observation (1 = allowed); all ones without masks
+            f4 hs[(STORED && MODE == 2) ? 2 * S::MT : 1];  // STORED bwd pass: the critic's h1 | h2 tiles of this row block and time step
         };
         // branch-free: every address is clamped in-bounds and loaded unconditionally (a guarded load is
         // an exec-masked branch + a conservative vmcnt(0) at the join); masks are applied at the point of use
@@ -366,6 +372,11 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dqn_lossgrad_kernel(con
             if (MODE == 2) {
                 R.dq = mix.dq[(size_t)p * mix.dq_agent_stride + (size_t)tt * B + bj];
                 R.lr = mix.lrow[(size_t)tt * B + bj];
+                if constexpr (STORED) {
+                    const f4* hp = hst + ((((size_t)p * T + tt) * ngroups + grp) * (2 * MT)) * 64 + lane;
+#pragma unroll
+                    for (int k = 0; k < 2 * MT; ++k) R.hs[k] = hp[k * 64];
+                }
             }
             if (MODE == 4) {
                 const float* drow = mix.dout + (((size_t)p * T + tt) * B + bj) * A;
@@ -403,7 +414,27 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dqn_lossgrad_kernel(con
             MARL_TS(0)
             f4 h1[MT], h2[MT], q, qb, tq = zero4, tqb = zero4;
             // ---- A: critic forward (q arrives as two partial chains, added where it is first used)
-            mlp_forward_f<S>(cpk, chead, lane, cur.x, h1, h2, q, qb, [](int, int) {});
+            if constexpr (STORED && MODE == 2) {  // (the qsel pass ran the identical MFMA chain on these rows; Q is not needed here)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    h1[mt] = cur.hs[mt];
+                    h2[mt] = cur.hs[MT + mt];
+                }
+                q = zero4;
+                qb = zero4;
+            } else {
+                mlp_forward_f<S>(cpk, chead, lane, cur.x, h1, h2, q, qb, [](int, int) {});
+            }
+            if constexpr (STORED && MODE == 1) {
+                if (!FIRST) {  // a transition row (t < T): leave its hidden layers for the bwd pass
+                    f4* hp = hst + ((((size_t)p * T + t) * ngroups + grp) * (2 * MT)) * 64 + lane;
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        hp[mt * 64] = h1[mt];
+                        hp[(MT + mt) * 64] = h2[mt];
+                    }
+                }
+            }
             MARL_TS(1)
             // ---- the critic's epilogue, emitted as fillers of the target forward's MFMA groups (or on its own without one)
             f4 dQ[1] = {zero4};
@@ -1126,6 +1157,14 @@ inline WsLayout ws_layout(int P, int nwg, int rec, int pack, int T, int B) {
     return w;
 }
 
+// LDS-resident learner, two-pass form (VDN / QMIX / standardised IDQN): the qsel pass leaves the critic's two hidden layers of every transition
+// row for the bwd pass - P * T * [row groups of 16] * 2 layers * [H / 16 tiles] * 256 floats behind everything else (+ 128 bytes of slack:
+// the MARLHIP_PROF counters sit at the very end of the caller's workspace)
+inline int64_t lds_h_floats(int P, int T, int B, int H) { return (int64_t)P * T * ((B + 15) / 16) * 2 * (H / 16) * 256 + 32; }
+#ifndef MARL_LDS_STORED
+#define MARL_LDS_STORED 1
+#endif
+
 #ifndef MARL_TP_NBF
 #define MARL_TP_NBF 2  // row blocks per step of the forward pass
 #endif
@@ -1268,8 +1307,17 @@ int launch_lossgrad_src(const marlhip_net_shape* s, const float* params, const f
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dqn_lossgrad_kernel<S, 4, REPLAY, 2>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dqn_lossgrad_kernel<S, 4, REPLAY, 1, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dqn_lossgrad_kernel<S, 4, REPLAY, 2, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         attr_set.done();
     }
+    // two-pass form: room behind the layout for the critic's hidden layers of every transition row (marlhip_dqn_workspace_bytes reserves
+    // it; a caller-sized workspace without it - the actor-critic step's - keeps the recomputing bwd pass)
+    const int64_t hs_off = (wl.total + 15) & ~(int64_t)15;
+    const bool stored = MARL_LDS_STORED && mode != 0 && ws_bytes >= hs_off + lds_h_floats(P, T, B, S::H) * (int64_t)sizeof(float) + 128;
+    f4* hst = stored ? reinterpret_cast<f4*>(static_cast<char*>(ws) + hs_off) : nullptr;
     if (fuse == nullptr || !fuse->packs_valid) {
         hipLaunchKernelGGL((dqn_pack_kernel<S>), dim3((PACK + 255) / 256, P), dim3(256), 0, st, params, tparams, am, packs);
         MARL_CHECK_LAUNCH("dqn_pack_kernel");
@@ -1293,8 +1341,12 @@ int launch_lossgrad_src(const marlhip_net_shape* s, const float* params, const f
         hipLaunchKernelGGL((dqn_lossgrad_kernel<S, 4, REPLAY, 0>), grid, block, lds_bytes, st, (const float*)packs, *bt, src, mix,
                            gamma, double_q, pl.n_chunks, (float*)ws, prof);
     } else {
-        hipLaunchKernelGGL((dqn_lossgrad_kernel<S, 4, REPLAY, 1>), grid, block, lds_bytes, st, (const float*)packs, *bt, src, mix,
-                           gamma, double_q, pl.n_chunks, (float*)ws, prof);
+        if (stored)
+            hipLaunchKernelGGL((dqn_lossgrad_kernel<S, 4, REPLAY, 1, true>), grid, block, lds_bytes, st, (const float*)packs, *bt, src, mix,
+                               gamma, double_q, pl.n_chunks, (float*)ws, prof, hst);
+        else
+            hipLaunchKernelGGL((dqn_lossgrad_kernel<S, 4, REPLAY, 1>), grid, block, lds_bytes, st, (const float*)packs, *bt, src, mix,
+                               gamma, double_q, pl.n_chunks, (float*)ws, prof);
         if (mode == 2) {
             QmixIo io = {mix.chosen, mix.tqsel, mix.r0, mix.dn, mix.fl, mix.dq, mix.lrow, nullptr};
             const int rc = qmix_dispatch_mix<S::D, REPLAY>(P, *qx, bt, src, io, gamma, st);
@@ -1314,8 +1366,12 @@ int launch_lossgrad_src(const marlhip_net_shape* s, const float* params, const f
             hipLaunchKernelGGL(vdn_mix_kernel, dim3((unsigned)((tb + 255) / 256 > 1024 ? 1024 : (tb + 255) / 256)), dim3(256), 0, st,
                                mix, P, T, B, gamma, ret);
         }
-        hipLaunchKernelGGL((dqn_lossgrad_kernel<S, 4, REPLAY, 2>), grid, block, lds_bytes, st, (const float*)packs, *bt, src, mix,
-                           gamma, double_q, pl.n_chunks, (float*)ws, prof);
+        if (stored)
+            hipLaunchKernelGGL((dqn_lossgrad_kernel<S, 4, REPLAY, 2, true>), grid, block, lds_bytes, st, (const float*)packs, *bt, src, mix,
+                               gamma, double_q, pl.n_chunks, (float*)ws, prof, hst);
+        else
+            hipLaunchKernelGGL((dqn_lossgrad_kernel<S, 4, REPLAY, 2>), grid, block, lds_bytes, st, (const float*)packs, *bt, src, mix,
+                               gamma, double_q, pl.n_chunks, (float*)ws, prof);
     }
     timing_end(TIMER_LOSSGRAD, st);
     MARL_CHECK_LAUNCH("dqn_lossgrad_kernel");
