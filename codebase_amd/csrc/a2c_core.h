@@ -44,11 +44,22 @@ constexpr bool tp_mlp_shape() {
     if constexpr (IsGru<S>::value || IsWide<S>::value) return false;
     else return use_tp<S>();
 }
+// every fused MLP shape keeps hidden layers from its forward-rows pass for its backward-rows pass: h2 in the tensor-parallel layout
+// (hidden 128), h1 | h2 in the LDS-resident learner's (hidden 64: dqn_lossgrad_kernel<MODE 4, STORED>)
+template <class S>
+constexpr bool mlp_stored_shape() { return !IsGru<S>::value && !IsWide<S>::value; }
+template <class S>
+inline int64_t mlp_stored_floats(int P, int T, int B) {
+    if constexpr (!mlp_stored_shape<S>()) return 0;
+    else if constexpr (use_tp<S>()) return tp_h2_floats(P, T, B, S::H);
+    else return lds_h_floats(P, T, B, S::H);
+}
 
 // ---- forward rows ------------------------------------------------------------------------------------------
 // H2: also store the second hidden layer of every row block in the layout tp_bwd_kernel<STORED> reads (rows = t * B + b, B % 16 == 0:
 // row block bk = (t, b0 / 16)): h2_out[(((p T + t) tp_h2_blocks(B) + blk) MT + tile) 64 + lane]
-template <class S, bool H2 = false>
+// H2 = 2: the LDS-resident learner's layout instead, both hidden layers: h_out[(((p T + t) (B / 16) + block) 2 MT + layer MT + tile) 64 + lane]
+template <class S, int H2 = 0>
 __global__ __launch_bounds__(256) void mlp_rows_fwd_kernel(const float* __restrict__ packs /* pre-packed [P][NFWD] */, const float* __restrict__ obs,
                                                            size_t agent_stride, size_t row_stride, int n_rows,
                                                            float* __restrict__ out, f4* __restrict__ h2_out = nullptr, int T = 0, int B = 0) {
@@ -75,7 +86,24 @@ __global__ __launch_bounds__(256) void mlp_rows_fwd_kernel(const float* __restri
             }
         }
         f4 q[2];
-        if constexpr (H2) {
+        if constexpr (H2 == 2) {
+            f4 h2[2][S::MT], h1[2][S::MT];
+            mlp_forward_p2<S, true, true>(lds, lane, x, q, h2, h1);
+            const int bpt = B >> 4;  // row blocks per time step
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int bk = 2 * pr + h;
+                if (bk < nblk) {
+                    const int t = bk / bpt, blk = bk - t * bpt;
+                    f4* dst = h2_out + ((((size_t)p * T + t) * bpt + blk) * (2 * S::MT)) * 64 + lane;
+#pragma unroll
+                    for (int mt = 0; mt < S::MT; ++mt) {
+                        dst[mt * 64] = h1[h][mt];
+                        dst[(S::MT + mt) * 64] = h2[h][mt];
+                    }
+                }
+            }
+        } else if constexpr (H2 == 1) {
             f4 h2[2][S::MT];
             mlp_forward_p2<S, true>(lds, lane, x, q, h2);
             const int bpt = B >> 4;  // row blocks per time step
@@ -152,18 +180,17 @@ int launch_forward_rows(int P, const AgentMap& am, const float* params, const ma
     if (gx > cap) gx = cap;
     float* packs = nullptr;
     if (launch_fwd_pack<S>(P, am, params, &packs, st) != 0) return -1;
-    if constexpr (use_tp<S>()) {
-        if (rec != nullptr) {  // leave h2 for tp_bwd_kernel<STORED> (the caller checked n_rows == T * B and B % 16 == 0)
-            static LdsAttr attr_h2;
-            if (attr_h2.need()) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_rows_fwd_kernel<S, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
-                attr_h2.done();
-            }
-            hipLaunchKernelGGL((mlp_rows_fwd_kernel<S, true>), dim3(gx, P), dim3(256), LDSB, st, (const float*)packs, bt->obss, as, rs, n_rows, out,
-                               reinterpret_cast<f4*>(rec), T, B);
-            MARL_CHECK_LAUNCH("mlp_rows_fwd_kernel<H2>");
-            return 0;
+    if (rec != nullptr) {  // leave the hidden layers for the backward-rows pass (the caller checked n_rows == T * B and B % 16 == 0)
+        constexpr int HS = use_tp<S>() ? 1 : 2;  // tp_bwd_kernel<STORED>'s h2 | dqn_lossgrad_kernel<MODE 4, STORED>'s h1 | h2
+        static LdsAttr attr_h2;
+        if (attr_h2.need()) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_rows_fwd_kernel<S, HS>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
+            attr_h2.done();
         }
+        hipLaunchKernelGGL((mlp_rows_fwd_kernel<S, HS>), dim3(gx, P), dim3(256), LDSB, st, (const float*)packs, bt->obss, as, rs, n_rows, out,
+                           reinterpret_cast<f4*>(rec), T, B);
+        MARL_CHECK_LAUNCH("mlp_rows_fwd_kernel<hidden layers kept>");
+        return 0;
     }
     hipLaunchKernelGGL((mlp_rows_fwd_kernel<S>), dim3(gx, P), dim3(256), LDSB, st, (const float*)packs, bt->obss, as, rs, n_rows, out);
     MARL_CHECK_LAUNCH("mlp_rows_fwd_kernel");
@@ -245,14 +272,21 @@ int launch_backward_rows(int P, const AgentMap& am, const float* params, const m
         if (attr_set.need()) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dqn_lossgrad_kernel<S, 4, false, 4>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dqn_lossgrad_kernel<S, 4, false, 4, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
             attr_set.done();
         }
         hipLaunchKernelGGL((dqn_pack_kernel<S>), dim3((PACK + 255) / 256, P), dim3(256), 0, st, params, params, am, packs);
         MixBufs mix = {};
         mix.lrow = lrow;
         mix.dout = dout;
-        hipLaunchKernelGGL((dqn_lossgrad_kernel<S, 4, false, 4>), dim3(pl.nwg, P), dim3(256), lds_bytes, st, (const float*)packs, *bt, none,
-                           mix, 0.f, 0, pl.n_chunks, (float*)ws, (unsigned long long*)nullptr);
+        if (rec != nullptr)  // the forward-rows pass of this step left h1 | h2: no second forward (dqn_lossgrad_kernel<..., STORED>)
+            hipLaunchKernelGGL((dqn_lossgrad_kernel<S, 4, false, 4, true>), dim3(pl.nwg, P), dim3(256), lds_bytes, st, (const float*)packs, *bt, none,
+                               mix, 0.f, 0, pl.n_chunks, (float*)ws, (unsigned long long*)nullptr,
+                               reinterpret_cast<f4*>(const_cast<float*>(rec)));
+        else
+            hipLaunchKernelGGL((dqn_lossgrad_kernel<S, 4, false, 4>), dim3(pl.nwg, P), dim3(256), lds_bytes, st, (const float*)packs, *bt, none,
+                               mix, 0.f, 0, pl.n_chunks, (float*)ws, (unsigned long long*)nullptr);
         MARL_CHECK_LAUNCH("dqn_lossgrad_kernel<MODE 4>");
     }
     const int n = am.nblk * S::NPARAM;
@@ -486,9 +520,9 @@ AcWs ac_ws_layout(int P, int T, int B) {
     w.packs = take(w.packs_bytes / 4 + 1);
     w.rec_a = w.rec_c = o;  // recurrent networks: the activation records of this step's actor / critic forward passes
     if constexpr (IsGru<SA>::value) w.rec_a = take(gru_rec_floats<SA>(P, T, B));
-    else if constexpr (tp_mlp_shape<SA>()) w.rec_a = take(tp_h2_floats(P, T, B, SA::H));  // second hidden layer of the actors' rows for their backward pass
+    else if constexpr (mlp_stored_shape<SA>()) w.rec_a = take(mlp_stored_floats<SA>(P, T, B));  // hidden layers of the actors' rows for their backward pass
     if constexpr (IsGru<SC>::value) w.rec_c = take(gru_rec_floats<SC>(P, T, B));
-    else if constexpr (tp_mlp_shape<SC>()) w.rec_c = take(tp_h2_floats(P, T, B, SC::H));
+    else if constexpr (mlp_stored_shape<SC>()) w.rec_c = take(mlp_stored_floats<SC>(P, T, B));
     w.bwd = o;
     const int64_t ba = backward_ws_bytes<SA>(P, T, B), bc = backward_ws_bytes<SC>(P, T, B);
     // recurrent networks: the two backward passes run side by side (side_stream) and need a workspace each
@@ -526,8 +560,8 @@ int ac_step_t(int P, const AgentMap& am, const float* actor, const float* critic
     a.standardise = std_on ? 1 : 0;
     int rc;
     timing_begin(TIMER_LOSSGRAD, st);
-    float* rec_a = (IsGru<SA>::value || (tp_mlp_shape<SA>() && B % 16 == 0)) && mode != 1 ? f(wl.rec_a) : nullptr;
-    float* rec_c = (IsGru<SC>::value || (tp_mlp_shape<SC>() && B % 16 == 0 && mode != 1)) ? f(wl.rec_c) : nullptr;
+    float* rec_a = (IsGru<SA>::value || (mlp_stored_shape<SA>() && B % 16 == 0)) && mode != 1 ? f(wl.rec_a) : nullptr;
+    float* rec_c = (IsGru<SC>::value || (mlp_stored_shape<SC>() && B % 16 == 0 && mode != 1)) ? f(wl.rec_c) : nullptr;
     bool v_done = false;
     // PPO's passes with recurrent networks (prepare: target critics + actors; epochs: actors + critics): the critics' sequence pass
     // goes to the side stream next to the actors' (each fills half of the SIMDs), with its packs in the critics' backward workspace

@@ -180,7 +180,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dqn_lossgrad_kernel(con
                                                                  MixBufs mix, float gamma, int double_q, int n_chunks,
                                                                  float* __restrict__ partials, unsigned long long* prof,
                                                                  f4* __restrict__ hst = nullptr) {
-    static_assert(!STORED || MODE == 1 || MODE == 2, "stored activations belong to the two-pass form");
+    static_assert(!STORED || MODE == 1 || MODE == 2 || MODE == 4, "stored activations belong to the two-pass forms");
     using L = UpdLds<S>;
     constexpr int MT = S::MT, NT1 = S::DP / 16, D = S::D, H = S::H, A = S::A, TS = L::TS, N1 = S::KS1 / 4;
     constexpr int UPD_BLOCK = 64 * WAVES;
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dqn_lossgrad_kernel(con
             float dq, lr;      // MODE 2: external dL/dchosen and per-row loss
             float dqv[4];      // MODE 4: external dL/d(output 4g+r)
             float mk[4];       // batch.action_mask of outputs 4g+r at this observation (1 = allowed); all ones without masks
-            f4 hs[(STORED && MODE == 2) ? 2 * S::MT : 1];  // STORED bwd pass: the critic's h1 | h2 tiles of this row block and time step
+            f4 hs[(STORED && (MODE == 2 || MODE == 4)) ? 2 * S::MT : 1];  // STORED bwd pass: the network's h1 | h2 tiles of this row block and time step
         };
         // branch-free: every address is clamped in-bounds and loaded unconditionally (a guarded load is
         // an exec-masked branch + a conservative vmcnt(0) at the join); masks are applied at the point of use
@@ -379,6 +379,11 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dqn_lossgrad_kernel(con
                 }
             }
             if (MODE == 4) {
+                if constexpr (STORED) {  // (left by the actor-critic step's forward-rows pass, a2c_core.h)
+                    const f4* hp = hst + ((((size_t)p * T + tt) * ngroups + grp) * (2 * MT)) * 64 + lane;
+#pragma unroll
+                    for (int k = 0; k < 2 * MT; ++k) R.hs[k] = hp[k * 64];
+                }
                 const float* drow = mix.dout + (((size_t)p * T + tt) * B + bj) * A;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) R.dqv[r] = drow[4 * g + r < A ? 4 * g + r : A - 1];
@@ -414,7 +419,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dqn_lossgrad_kernel(con
             MARL_TS(0)
             f4 h1[MT], h2[MT], q, qb, tq = zero4, tqb = zero4;
             // ---- A: critic forward (q arrives as two partial chains, added where it is first used)
-            if constexpr (STORED && MODE == 2) {  // (the qsel pass ran the identical MFMA chain on these rows; Q is not needed here)
+            if constexpr (STORED && (MODE == 2 || MODE == 4)) {  // (an earlier pass ran the forward on these rows; Q is not needed here)
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     h1[mt] = cur.hs[mt];

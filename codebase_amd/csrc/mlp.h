@@ -406,8 +406,9 @@ __device__ __forceinline__ void mlp_forward_g(const float* __restrict__ gpack, i
 // One network on TWO 16-row blocks at once: every A operand fetched from LDS feeds two MFMAs, which halves the LDS
 // operand traffic per flop (at hidden 128 a single-block forward reads 327 KB of operands per 320 MFMAs - the LDS port
 // and the matrix pipe then run at the same rate).  Same pipelining and per-output summation order as mlp_forward_p.
-template <class S, bool WANT_H2 = false>
-__device__ __forceinline__ void mlp_forward_p2(const float* lds, int lane, const float (&x)[2][S::KS1], f4 (&q)[2], f4 (*h2_out)[S::MT] = nullptr) {
+template <class S, bool WANT_H2 = false, bool WANT_H1 = false>
+__device__ __forceinline__ void mlp_forward_p2(const float* lds, int lane, const float (&x)[2][S::KS1], f4 (&q)[2], f4 (*h2_out)[S::MT] = nullptr,
+                                               f4 (*h1_out)[S::MT] = nullptr) {
     constexpr int MT = S::MT, N1 = S::KS1 / 4;
     const int g = lane >> 4;
     const f4* A1 = reinterpret_cast<const f4*>(lds + S::pA1);
@@ -446,6 +447,10 @@ __device__ __forceinline__ void mlp_forward_p2(const float* lds, int lane, const
     for (int mt = 0; mt < MT; ++mt) {
         h1[0][mt] = relu4(acc[0][mt]);
         h1[1][mt] = relu4(acc[1][mt]);
+        if constexpr (WANT_H1) {
+            h1_out[0][mt] = h1[0][mt];
+            h1_out[1][mt] = h1[1][mt];
+        }
         acc[0][mt] = nb[mt];
         acc[1][mt] = nb[mt];
     }

@@ -96,7 +96,9 @@ def test_ppo_updates_match_reference_golden(name):
                                          # at either width): the forward-rows pass stores the second hidden layer and the backward pass reads it
                                          # back (tp_bwd_kernel<FULL, STORED>) - one block, an odd block count, several steps per workgroup
                                          (2, 25, 32, 15, 128, 5), (3, 25, 144, 24, 128, 5), (2, 25, 2048, 15, 128, 5), (4, 12, 48, 71, 128, 5),
-                                         (2, 6, 304, 71, 64, 2), (8, 9, 64, 39, 128, 3)])
+                                         (2, 6, 304, 71, 64, 2), (8, 9, 64, 39, 128, 3),
+                                         # hidden 64 with whole row blocks: the forward-rows pass keeps h1 | h2 for dqn_lossgrad_kernel<MODE 4, STORED>
+                                         (2, 25, 2048, 15, 64, 5), (3, 12, 48, 24, 64, 5), (8, 5, 32, 39, 64, 2)])
 def test_a2c_other_shapes_vs_oracle_port(P, T, N, D, H, n):
     h = hip()
     A = 5 if D == 71 else 6
@@ -117,7 +119,7 @@ def test_a2c_other_shapes_vs_oracle_port(P, T, N, D, H, n):
     assert_grad_close(up.critic_grad.cpu().numpy(), c.grad.numpy(), 3e-4)
 
 
-@pytest.mark.parametrize("P,T,N,D,H", [(2, 25, 32, 15, 128), (3, 12, 144, 24, 128), (2, 25, 33, 15, 128), (4, 10, 64, 71, 64)])
+@pytest.mark.parametrize("P,T,N,D,H", [(2, 25, 32, 15, 128), (3, 12, 144, 24, 128), (2, 25, 33, 15, 128), (4, 10, 64, 71, 64), (2, 25, 256, 15, 64)])
 def test_ppo_epoch_after_a_parameter_change_vs_oracle_port(P, T, N, D, H):
     """PPONetwork.update's epoch (ac/model.py:300-352) with ratios off 1: returns and old log-probs from the parameters at prepare time,
     the clipped surrogate and its gradients at perturbed ones - on rollouts of whole 16-row blocks (the epoch's forward-rows pass stores
