@@ -1142,6 +1142,22 @@ static __global__ __launch_bounds__(256) void vdn_mix_kernel(MixBufs mix, int P,
     }
 }
 
+// the independent learners' "mixer" for the two-pass form (wide first layers, where the single-pass kernel would spill): per agent
+// delta_p = chosen_p - (r_p + gamma tq_p (1 - done)), dq_p = 2 filled delta_p, row loss = filled sum_p delta_p^2 (dqn/model.py:152,160-163)
+static __global__ __launch_bounds__(256) void idqn_mix_kernel(MixBufs mix, int P, int T, int B, float gamma) {
+    const int n = T * B;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const float fl = mix.fl[i], nd = 1.f - mix.dn[i];
+        float l = 0.f;
+        for (int p = 0; p < P; ++p) {
+            const float delta = mix.chosen[(size_t)p * n + i] - (mix.rew_all[(size_t)p * n + i] + gamma * mix.tqsel[(size_t)p * n + i] * nd);
+            mix.dq[(size_t)p * n + i] = 2.f * fl * delta;
+            l += delta * delta;
+        }
+        mix.lrow[i] = fl * l;
+    }
+}
+
 // workspace layout (floats unless noted): [partial records][pad16][packs][mixer buffers (4P+5) T B][pad8][128 B phase counters]
 struct WsLayout {
     int64_t rec_bytes, pack_off, mix_off, total;
@@ -1306,8 +1322,9 @@ int launch_lossgrad_src(const marlhip_net_shape* s, const float* params, const f
     const size_t lds_bytes = (size_t)L::total(4) * sizeof(float);
     static LdsAttr attr_set;
     if (attr_set.need()) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dqn_lossgrad_kernel<S, 4, REPLAY, 0>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if constexpr (S::D <= 48)  // (wider first layers never launch the single-pass kernel: IDQN_TWO_PASS below)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dqn_lossgrad_kernel<S, 4, REPLAY, 0>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dqn_lossgrad_kernel<S, 4, REPLAY, 1>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dqn_lossgrad_kernel<S, 4, REPLAY, 2>),
@@ -1321,7 +1338,11 @@ int launch_lossgrad_src(const marlhip_net_shape* s, const float* params, const f
     // two-pass form: room behind the layout for the critic's hidden layers of every transition row (marlhip_dqn_workspace_bytes reserves
     // it; a caller-sized workspace without it - the actor-critic step's - keeps the recomputing bwd pass)
     const int64_t hs_off = (wl.total + 15) & ~(int64_t)15;
-    const bool stored = MARL_LDS_STORED && mode != 0 && ws_bytes >= hs_off + lds_h_floats(P, T, B, S::H) * (int64_t)sizeof(float) + 128;
+    // independent learners on wide first layers (the 71-wide warehouse rows: the single-pass kernel spills 0.5 KB per lane there - 80 dW1
+    // accumulator registers next to both forwards) take the two-pass form too, with idqn_mix_kernel between the passes
+    constexpr bool IDQN_TWO_PASS = S::D > 48;
+    const bool two_pass = mode != 0 || IDQN_TWO_PASS;
+    const bool stored = MARL_LDS_STORED && two_pass && ws_bytes >= hs_off + lds_h_floats(P, T, B, S::H) * (int64_t)sizeof(float) + 128;
     f4* hst = stored ? reinterpret_cast<f4*>(static_cast<char*>(ws) + hs_off) : nullptr;
     if (fuse == nullptr || !fuse->packs_valid) {
         hipLaunchKernelGGL((dqn_pack_kernel<S>), dim3((PACK + 255) / 256, P), dim3(256), 0, st, params, tparams, am, packs);
@@ -1335,16 +1356,17 @@ int launch_lossgrad_src(const marlhip_net_shape* s, const float* params, const f
     mix.dq = mix.fl + tb; mix.lrow = mix.dq + tb; mix.dq_agent_stride = 0;
     mix.rew_all = nullptr;
     mix.dout = nullptr;
-    if (mode == 2 || mode == 3) {  // QMIX / standardised IDQN: one dq plane per agent
+    if (mode == 2 || mode == 3 || (mode == 0 && IDQN_TWO_PASS)) {  // QMIX / standardised IDQN / two-pass IDQN: one dq plane per agent
         mix.lrow = mix.dq + P * tb;
         mix.dq_agent_stride = (int)tb;
     }
-    if (mode == 3) mix.rew_all = mix.lrow + tb;  // [P][tb]; the statistics' block partials follow it
+    if (mode == 3 || (mode == 0 && IDQN_TWO_PASS)) mix.rew_all = mix.lrow + tb;  // [P][tb]; the statistics' block partials follow it
     const dim3 grid(pl.nwg, P), block(256);
     timing_begin(TIMER_LOSSGRAD, st);
-    if (mode == 0) {
-        hipLaunchKernelGGL((dqn_lossgrad_kernel<S, 4, REPLAY, 0>), grid, block, lds_bytes, st, (const float*)packs, *bt, src, mix,
-                           gamma, double_q, pl.n_chunks, (float*)ws, prof);
+    if (!two_pass) {
+        if constexpr (!IDQN_TWO_PASS)
+            hipLaunchKernelGGL((dqn_lossgrad_kernel<S, 4, REPLAY, 0>), grid, block, lds_bytes, st, (const float*)packs, *bt, src, mix,
+                               gamma, double_q, pl.n_chunks, (float*)ws, prof);
     } else {
         if (stored)
             hipLaunchKernelGGL((dqn_lossgrad_kernel<S, 4, REPLAY, 1, true>), grid, block, lds_bytes, st, (const float*)packs, *bt, src, mix,
@@ -1352,7 +1374,9 @@ int launch_lossgrad_src(const marlhip_net_shape* s, const float* params, const f
         else
             hipLaunchKernelGGL((dqn_lossgrad_kernel<S, 4, REPLAY, 1>), grid, block, lds_bytes, st, (const float*)packs, *bt, src, mix,
                                gamma, double_q, pl.n_chunks, (float*)ws, prof);
-        if (mode == 2) {
+        if (mode == 0) {
+            hipLaunchKernelGGL(idqn_mix_kernel, dim3((unsigned)((tb + 255) / 256 > 1024 ? 1024 : (tb + 255) / 256)), dim3(256), 0, st, mix, P, T, B, gamma);
+        } else if (mode == 2) {
             QmixIo io = {mix.chosen, mix.tqsel, mix.r0, mix.dn, mix.fl, mix.dq, mix.lrow, nullptr};
             const int rc = qmix_dispatch_mix<S::D, REPLAY>(P, *qx, bt, src, io, gamma, st);
             if (rc != 0) return rc;
