@@ -235,7 +235,7 @@ int launch_backward_rows(int P, const AgentMap& am, const float* params, const m
     ReplaySrc none = {};
     int nwg;
     if constexpr (use_tp<S>()) {
-        constexpr int W = 4, TPW = S::H / 64, NB = S::D > 48 ? 1 : 2, NT = W * TPW;  // wide first layers (centralised critics): one row block per step keeps the kernel out of scratch
+        constexpr int W = MARL_TP_W, TPW = S::H / (16 * W), NB = S::D > 48 ? 1 : 2, NT = W * TPW;  // wide first layers (centralised critics): one row block per step keeps the kernel out of scratch
         const UpdPlan pl = upd_plan_tp(P, T, B, NB);
         nwg = pl.nwg;
         TpMix mix = {};

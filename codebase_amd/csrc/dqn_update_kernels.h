@@ -1186,6 +1186,13 @@ inline int64_t lds_h_floats(int P, int T, int B, int H) { return (int64_t)P * T 
 #define MARL_LDS_STORED 1
 #endif
 
+#ifndef MARL_TP_W
+// Waves per workgroup of the tensor-parallel kernels (each owns H / (16 W) hidden tiles).  8 (one tile per wave, two waves per SIMD, <= 256
+// registers) was measured against 4 (scripts/gpu_runs/r3AC.sh): IDQN 128-128 8.21 -> 7.95 M, VDN 15x15-4p 3.79 -> 3.26 M (27 / 39-wide first
+// layers spill 0.1 - 0.4 KB per lane), IA2C 128-128 104.9 -> 107.2 M: twice the barrier participants and exchange traffic cost what the
+// second wave per SIMD hides.  4 stays.
+#define MARL_TP_W 4
+#endif
 #ifndef MARL_TP_NBF
 #define MARL_TP_NBF 2  // row blocks per step of the forward pass
 #endif
@@ -1228,7 +1235,7 @@ template <class S, bool REPLAY>
 int launch_lossgrad_tp(const marlhip_net_shape* s, const float* params, const float* tparams, const marlhip_batch* bt,
                        const ReplaySrc& src, float gamma, int double_q, int mode, void* ws, int64_t ws_bytes, float* grad,
                        float* loss, hipStream_t st, const QmixCtx* qx, const RetStats* rst) {
-    constexpr int W = 4, TPW = S::H / 64, NB = S::D > 48 ? 1 : 2, NBF = MARL_TP_NBF, NT = W * TPW, REC = S::NPARAM + 2;  // wide first layers: one row block per step keeps pass B out of scratch
+    constexpr int W = MARL_TP_W, TPW = S::H / (16 * W), NB = S::D > 48 ? 1 : 2, NBF = MARL_TP_NBF, NT = W * TPW, REC = S::NPARAM + 2;  // wide first layers: one row block per step keeps pass B out of scratch
     const int P = s->n_agents, T = bt->max_len, B = bt->batch;
     const AgentMap am = agent_map(s);
     static_assert(NB <= 2 && NBF <= 2, "tp_h2_blocks counts row blocks in pairs");
