@@ -7,14 +7,14 @@ import os, sys, torch, numpy as np
 os.environ["MARLHIP_PROF"] = "1"
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
 from codebase_amd import hip as h
-from oracle import dqn_port as dp
 def run(B, n):
     P, D, H, A, T = 2, 15, 64, 6, 25
     spec = h.NetSpec(P, D, H, A)
     cap = max(2 * B, 64)
     rb = h.DeviceReplay(cap, P, D, T)
     rb.obs.normal_(); rb.act.random_(0, A); rb.rew.uniform_(); rb.filled.fill_(1); rb.done.zero_()
-    params = dp.init_params(P, D, H, A, seed=1).cuda(); target = params.clone()
+    n = spec.nparams() if callable(spec.nparams) else spec.nparams
+    params = (0.1 * torch.randn(P, n, generator=torch.Generator().manual_seed(1))).cuda(); target = params.clone()
     up = h.DqnUpdater(spec, params, target, lr=3e-4, gamma=0.99, grad_clip=1.0, double_q=True)
     fl = h.FusedLearner(up, rb, B, 200, mode=0)
     upd, last = fl.run(4, cap, 1, 0, 0, 0)
