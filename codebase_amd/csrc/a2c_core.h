@@ -37,13 +37,6 @@ int64_t forward_scratch_bytes(int P, int n_rows) {
     else return (int64_t)P * S::NFWD * 4 + 16;
 }
 
-// shapes whose backward-rows pass is the tensor-parallel kernel (hidden 128, wide rows): their forward-rows pass can leave the second
-// hidden layer for it (dqn_update_tp.h, tp_bwd_kernel<STORED>), so that the backward pass does not recompute layer 2
-template <class S>
-constexpr bool tp_mlp_shape() {
-    if constexpr (IsGru<S>::value || IsWide<S>::value) return false;
-    else return use_tp<S>();
-}
 // every fused MLP shape keeps hidden layers from its forward-rows pass for its backward-rows pass: h2 in the tensor-parallel layout
 // (hidden 128), h1 | h2 in the LDS-resident learner's (hidden 64: dqn_lossgrad_kernel<MODE 4, STORED>)
 template <class S>
