@@ -340,9 +340,13 @@ static int clip_step(const AdamArgs& a, int64_t n, float* params, const float* g
         hipLaunchKernelGGL(adam_fused_kernel, dim3(1), dim3(1024), 0, st, n, params, grad, state1, state2, target_params, a, gnorm_out);
         MARL_CHECK_LAUNCH("adam_fused_kernel");
     } else {
-        hipLaunchKernelGGL(sumsq_kernel, dim3(nblocks), dim3(256), 0, st, grad, n, grad_scale, scratch);
-        MARL_CHECK_LAUNCH("sumsq_kernel");
-        hipLaunchKernelGGL(adam_kernel, dim3(nblocks), dim3(256), 0, st, n, nblocks, params, grad, state1, state2, target_params, a,
+        // the norm is only formed when somebody uses it (QMIX's mixer block and unclipped actor-critic steps do not: one launch less)
+        const bool need_norm = a.max_norm > 0.f || gnorm_out != nullptr;
+        if (need_norm) {
+            hipLaunchKernelGGL(sumsq_kernel, dim3(nblocks), dim3(256), 0, st, grad, n, grad_scale, scratch);
+            MARL_CHECK_LAUNCH("sumsq_kernel");
+        }
+        hipLaunchKernelGGL(adam_kernel, dim3(nblocks), dim3(256), 0, st, n, need_norm ? nblocks : 0, params, grad, state1, state2, target_params, a,
                            (const float*)scratch, gnorm_out);
         MARL_CHECK_LAUNCH("adam_kernel");
     }

@@ -711,7 +711,8 @@ class AcUpdater:
         """clip_grad_norm_(self.parameters(), grad_clip) + optimizer.step() (model.py:227-231): one norm over actor + critic"""
         self.step += 1
         _clip_step(self.optimizer, self.block.numel(), self.block, self.grad, self.exp_avg, self.exp_avg_sq, None, self.step, self.lr, self.betas,
-                   self.eps, self.grad_clip, grad_scale, False, 0.0, self.scratch, self.gnorm, "dqn_clip_step(actor+critic)")
+                   self.eps, self.grad_clip, grad_scale, False, 0.0, self.scratch, self.gnorm if self.grad_clip else None,  # (no clip: no norm launch)
+                   "dqn_clip_step(actor+critic)")
 
 
 def idqn_collect(cfg, spec: NetSpec, params, epsilon, round_idx, replay: DeviceReplay, slot_base, fin_return,
