@@ -259,7 +259,9 @@ typedef struct marlhip_batch {
     const float* action_mask;
 } marlhip_batch;
 
-/* bytes of scratch marlhip_dqn_loss_grad needs for this (shape, T, B) */
+/* bytes of scratch marlhip_dqn_loss_grad needs for this (shape, T, B): partial gradient records, MFMA weight packs, the mixer planes and
+ * the hidden layers one pass leaves for the next (hidden 128: the critic's second layer, 4 H bytes per transition row; hidden 64 two-pass
+ * forms - VDN, QMIX, standardised returns, 71-wide rows: both layers, 512 bytes per row) */
 int64_t marlhip_dqn_workspace_bytes(const marlhip_net_shape* s, int32_t max_len, int32_t batch);
 
 /* loss (scalar, model.py:160-163) and its gradient w.r.t. the critic parameters, both written to
