@@ -12,7 +12,7 @@ using namespace marl;
     X(14, 64, 6) X(17, 64, 6) X(25, 64, 6) X(31, 64, 6) X(47, 64, 6) X(14, 128, 6) X(17, 128, 6) X(25, 128, 6) X(31, 128, 6) X(47, 128, 6) /* env.observe_id */
 
 // (agents, obs dim, hidden) with a compiled recurrent CENTRALISED critic (P * D inputs, critic.centralised: maa2c / mappo with use_rnn)
-#define MARL_GRU_MAC_SHAPES(X) X(2, 12, 64) X(2, 15, 64) X(3, 18, 64) X(4, 21, 64) X(4, 27, 64) X(2, 12, 128) X(2, 15, 128) X(3, 18, 128) X(4, 21, 128) X(4, 27, 128)
+#define MARL_GRU_MAC_SHAPES(X) X(2, 12, 64) X(2, 15, 64) X(3, 18, 64) X(3, 24, 64) X(4, 21, 64) X(4, 27, 64) X(2, 12, 128) X(2, 15, 128) X(3, 18, 128) X(3, 24, 128) X(4, 21, 128) X(4, 27, 128)
 
 static int gru_ac_check(const marlhip_net_shape* s, int centralised = 0) {
     MARL_REQUIRE(s != nullptr, "net shape is NULL");

@@ -478,3 +478,35 @@ def test_recurrent_networks_of_other_widths_match_the_port_at_the_true_width(h, 
         M.QNetwork(obs_space, act_space, cfg, [64, 64, 64], False, True, True, "cuda")  # a two-layer GRU
     with pytest.raises(NotImplementedError):
         M.QNetwork(obs_space, act_space, cfg, [256, 256], False, True, True, "cuda")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("P,T,N,D,H", [(3, 9, 20, 24, 64), (3, 6, 33, 24, 128), (4, 7, 16, 27, 64), (2, 12, 40, 15, 128)])
+def test_recurrent_centralised_critics_other_shapes_vs_port(P, T, N, D, H):
+    """maa2c with use_rnn on the compiled (agents, observation) pairs the goldens do not cover (3 agents x 24: Foraging-10x10-3p-5f):
+    recurrent actors, recurrent critics over the concatenated row - loss pieces and both gradients against the port"""
+    from codebase_amd import hip as h
+    from oracle import ac_update_port as ap
+
+    A = 6
+    g = torch.Generator().manual_seed(3)
+    actor = 0.1 * torch.randn(P, gp.nparams(D, H, A), generator=g)
+    critic = 0.1 * torch.randn(P, gp.nparams(P * D, H, 1), generator=g)
+    target = 0.1 * torch.randn(P, gp.nparams(P * D, H, 1), generator=g)
+    batch = ap.synthetic_batch(P, T, N, D, A, seed=7)
+    with gp.recurrent_ac():
+        a, c = actor.clone().requires_grad_(True), critic.clone().requires_grad_(True)
+        loss, m = ap.a2c_loss(a, c, target, batch, D, H, A, n_steps=5, gamma=0.97, entropy_coef=0.01, value_loss_coef=0.5)
+        loss.backward()
+    spec = h.NetSpec(P, D, H, A)
+    up = h.AcUpdater(spec, torch.cat([actor.reshape(-1), critic.reshape(-1)]).cuda(), target.cuda().contiguous(), gamma=0.97, n_steps=5,
+                     entropy_coef=0.01, value_loss_coef=0.5, recurrent=True, centralised_critic=True)
+    assert up.n_critic == gp.nparams(P * D, H, 1)
+    from collections import namedtuple
+    Batch = namedtuple("Batch", ["obss", "actions", "rewards", "dones", "filled", "action_masks"])
+    b = Batch(*(batch[k].cuda() for k in ("obss", "actions", "rewards", "dones", "filled")), None)
+    got = up.a2c_loss_grad(b).cpu().numpy()
+    ref = [m["loss"].item(), m["actor_loss"].item(), m["value_loss"].item(), m["entropy"].item()]
+    np.testing.assert_allclose(got[:4], ref, rtol=1e-4, atol=1e-5)
+    for gg, rr in ((up.actor_grad, a.grad), (up.critic_grad, c.grad)):
+        np.testing.assert_allclose(gg.cpu().numpy(), rr.numpy(), rtol=3e-4, atol=3e-4 * max(1e-3, float(rr.abs().max())))
