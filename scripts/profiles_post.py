@@ -15,8 +15,8 @@ DST = os.path.join(ROOT, "profiles")
 
 
 def first(pattern):
-    g = glob.glob(os.path.join(SRC, pattern), recursive=True)
-    return g[0] if g else None
+    g = glob.glob(os.path.join(SRC, pattern), recursive=True)  # gpurun_out/ accumulates the files of every collection run: take the newest
+    return max(g, key=os.path.getmtime) if g else None
 
 
 def counters(tag):
