@@ -102,9 +102,17 @@ __device__ __forceinline__ float qmix_mix_pack_elem(const float* __restrict__ w,
     return w[Q::oBf + (16 * kt + 4 * (lane >> 4) + r) * HE + 16 * m + (lane & 15)];
 }
 
+// draw_out (replay form, else null): the blocks behind the pack range draw the episode index of every batch row once per update (the mixer
+// kernels then read it instead of re-running Philox) - in the same launch, the two jobs do not depend on each other
 template <class Q>
 __global__ __launch_bounds__(256) void qmix_pack_kernel(const float* __restrict__ mixer, const float* __restrict__ tmixer,
-                                                        float* __restrict__ packs) {
+                                                        float* __restrict__ packs, ReplaySrc rs, int B, int32_t* __restrict__ draw_out) {
+    constexpr int PACK_BLOCKS = (Q::NPACK + 255) / 256;
+    if ((int)blockIdx.x >= PACK_BLOCKS) {
+        const int b = (blockIdx.x - PACK_BLOCKS) * 256 + threadIdx.x;
+        if (b < B) draw_out[b] = replay_draw(rs, b);
+        return;
+    }
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= Q::NPACK) return;
     float v;
@@ -1017,12 +1025,6 @@ static __global__ __launch_bounds__(256) void qmix_reduce_kernel(const float* __
     if (slice == 0 && i < nparam) grad[i] = ((s_part[0][l64] + s_part[1][l64]) + (s_part[2][l64] + s_part[3][l64])) / loss_nf[1];
 }
 
-// episode index of every batch row, drawn once per update (the mixer kernels then read it instead of re-running Philox)
-static __global__ __launch_bounds__(256) void qmix_draw_kernel(ReplaySrc rs, int B, int32_t* __restrict__ out) {
-    const int b = blockIdx.x * 256 + threadIdx.x;
-    if (b < B) out[b] = replay_draw(rs, b);
-}
-
 // ---- host side ---------------------------------------------------------------------------------------------
 struct QmixCtx {  // what marlhip_qmix_loss_grad adds to the agent-network call
     const float* mixer;
@@ -1081,13 +1083,14 @@ int qmix_launch_mix(const QmixCtx& qx, const marlhip_batch* bt, const ReplaySrc&
     io2.ytgt = reinterpret_cast<float*>(base + wl.ytgt);
     QmixRows<Q, REPLAY> src;
     src.obs = bt->obss; src.rs = rsrc; src.T = T; src.B = B;
-    if (REPLAY && rsrc.idx == nullptr) {
-        int32_t* idxbuf = reinterpret_cast<int32_t*>(base + wl.idx);
-        hipLaunchKernelGGL(qmix_draw_kernel, dim3((B + 255) / 256), dim3(256), 0, st, rsrc, B, idxbuf);
+    int32_t* idxbuf = nullptr;
+    if (REPLAY && rsrc.idx == nullptr) {  // drawn by the pack launch below
+        idxbuf = reinterpret_cast<int32_t*>(base + wl.idx);
         src.rs.idx = idxbuf;
     }
     bw.HB = reinterpret_cast<float*>(base + wl.hb);
-    hipLaunchKernelGGL((qmix_pack_kernel<Q>), dim3((Q::NPACK + 255) / 256), dim3(256), 0, st, qx.mixer, qx.tmixer, packs);
+    hipLaunchKernelGGL((qmix_pack_kernel<Q>), dim3((Q::NPACK + 255) / 256 + (idxbuf != nullptr ? (B + 255) / 256 : 0)), dim3(256), 0, st, qx.mixer,
+                       qx.tmixer, packs, rsrc, B, idxbuf);
     const h4* packh = reinterpret_cast<const h4*>(packs + Q::NPACK);  // [online | target], Q::KS4 * Q::MT1 * 64 entries each
     if (qx.l1_fp16)
         hipLaunchKernelGGL((qmix_pack_half_kernel<Q>), dim3((2 * Q::KS4 * Q::MT1 * 64 + 255) / 256), dim3(256), 0, st, qx.mixer, qx.tmixer, packs);
