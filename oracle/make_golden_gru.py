@@ -9,6 +9,9 @@ update(), and an `act` trace: 6 greedy steps of one env with the hidden states t
   learner_gru_idqn_H64.npz   2 agents x 15 obs, QNetwork, 64-64
   learner_gru_vdn_H64.npz    3 agents x 18 obs, VDNetwork, 64-64
   learner_gru_qmix_H64.npz   2 agents x 15 obs, QMixNetwork (loss, agent + mixer gradients, 2 updates)
+  learner_gru_shared_H64.npz     3 agents x 18 obs, QNetwork, parameter_sharing=True (MultiAgentSharedNetwork, utils/models.py:176-300)
+  learner_gru_seps_vdn_H128.npz  3 agents x 18 obs, VDNetwork, parameter_sharing=[0, 0, 1] (SePS), 128-128
+  learner_gru_std_H64.npz        2 agents x 15 obs, QNetwork, standardise_returns=True (dqn/model.py:147-158): 3 updates on 3 batches
 """
 import contextlib
 import io
@@ -66,6 +69,71 @@ def fixture(ref_model, ref_train, name, cls, P, D, H, B, seed):
     print(name, float(out["loss0"]), out["losses"].tolist(), out["params0"].shape)
 
 
+def shared_fixture(ref_model, ref_train, name, cls, P, D, H, B, sharing, seed):
+    """use_rnn=True on MultiAgentSharedNetwork: blocks [K][n] in `critic.networks` order (K = number of distinct networks), loss,
+    gradient, 2 x update(), state_dict keys.  Same seeds-per-role as `fixture` (seed: init, +1: target noise, +7: batch)."""
+    from .make_golden_sharing import flat_nets
+
+    T, A = 8, 6
+    torch.manual_seed(seed)
+    cfg = Cfg(optimizer="Adam", lr=3e-4, gamma=0.99, grad_clip=1.0, target_update_interval_or_tau=200, double_q=True,
+              standardise_returns=False)
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = cls([Box(D)] * P, [Discrete(A)] * P, cfg, [H, H], sharing, True, True, "cpu")
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for p in net.target.parameters():
+            p.add_(0.05 * torch.randn(p.shape, generator=g))
+    out = dict(P=P, T=T, B=B, D=D, A=A, H=H, sharing=np.array(net.critic.sharing_indices), keys=np.array(list(net.state_dict().keys())),
+               params0=flat_nets(net.critic).numpy(), target0=flat_nets(net.target).numpy())
+    batch = synthetic_batch(P, T, B, D, A, seed=seed + 7)
+    batch["obss"] = batch["obss"] * 0.25
+    if cls is ref_model.VDNetwork:
+        batch["rewards"][1:] = batch["rewards"][0]
+    for k, v in batch.items():
+        out[f"batch_{k}"] = v.numpy()
+    bb = ref_train.Batch(batch["obss"], batch["actions"], batch["rewards"], batch["dones"], batch["filled"], None)
+    loss = net._compute_loss(bb)
+    net.optimizer.zero_grad()
+    loss.backward()
+    out["loss0"] = np.float32(loss.item())
+    out["grad0"] = torch.stack([torch.cat([p.grad.reshape(-1) for p in m.parameters()]) for m in net.critic.networks]).numpy()
+    net.optimizer.zero_grad()
+    out["losses"] = np.array([net.update(bb)["loss"] for _ in range(2)], np.float32)
+    out["params2"] = flat_nets(net.critic).numpy()
+    np.savez_compressed(os.path.join(OUT, name), **out)
+    print(name, "sharing", out["sharing"].tolist(), float(out["loss0"]), out["losses"].tolist(), out["params0"].shape)
+
+
+def std_fixture(ref_model, ref_train, name, P, D, H, B, seed):
+    """QNetwork(use_rnn=True, standardise_returns=True): 3 x update() on 3 batches; losses, parameters and the RunningMeanStd
+    (mean, var, count) after each (the recurrent sibling of make_golden_std.idqn)"""
+    T, A = 8, 6
+    torch.manual_seed(seed)
+    cfg = Cfg(optimizer="Adam", lr=3e-4, gamma=0.99, grad_clip=1.0, target_update_interval_or_tau=200, double_q=True,
+              standardise_returns=True)
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = ref_model.QNetwork([Box(D)] * P, [Discrete(A)] * P, cfg, [H, H], False, True, True, "cpu")
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for p in net.target.parameters():
+            p.add_(0.05 * torch.randn(p.shape, generator=g))
+    out = dict(P=P, T=T, B=B, D=D, A=A, H=H, params0=flat_params(net.critic).numpy(), target0=flat_params(net.target).numpy())
+    losses = []
+    for i in range(3):
+        b = synthetic_batch(P, T, B, D, A, seed=seed + 7 + i)
+        b["obss"] = b["obss"] * 0.25
+        for k, v in b.items():
+            out[f"batch{i}_{k}"] = v.numpy()
+        losses.append(net.update(ref_train.Batch(b["obss"], b["actions"], b["rewards"], b["dones"], b["filled"], None))["loss"])
+        out[f"params{i + 1}"] = flat_params(net.critic).numpy()
+        out[f"ret_mean{i + 1}"], out[f"ret_var{i + 1}"] = net.ret_ms.mean.numpy(), net.ret_ms.var.numpy()
+        out[f"ret_count{i + 1}"] = np.float64(net.ret_ms.count)
+    out["losses"] = np.array(losses, np.float32)
+    np.savez_compressed(os.path.join(OUT, name), **out)
+    print(name, losses, out["ret_mean3"], out["ret_var3"], out["ret_count3"])
+
+
 def qmix_fixture(ref_model, ref_train, name, P, D, H, B, seed):
     """QMixNetwork(use_rnn=True): loss, agent and mixer gradients, 2 updates"""
     from .make_golden_qmix import mixer_flat, mixer_grad
@@ -111,7 +179,6 @@ if __name__ == "__main__":
     fixture(rm, rt, "learner_gru_idqn_H64.npz", rm.QNetwork, P=2, D=15, H=64, B=37, seed=2100)
     fixture(rm, rt, "learner_gru_vdn_H64.npz", rm.VDNetwork, P=3, D=18, H=64, B=21, seed=2200)
     qmix_fixture(rm, rt, "learner_gru_qmix_H64.npz", P=2, D=15, H=64, B=19, seed=2300)
-# learner_gru_shared_H64.npz / learner_gru_seps_vdn_H128.npz (parameter_sharing=True / [0, 0, 1] with use_rnn=True) were produced by the
-# same recipe on MultiAgentSharedNetwork: blocks [K][n] in `critic.networks` order, loss, gradient, 2 updates, state_dict keys.
-# learner_gru_std_H64.npz: QNetwork(use_rnn=True, standardise_returns=True), 3 x update() on 3 batches: losses, parameters and the
-# RunningMeanStd (mean, var, count) after each (same recipe as oracle/make_golden_std.py).
+    shared_fixture(rm, rt, "learner_gru_shared_H64.npz", rm.QNetwork, P=3, D=18, H=64, B=20, sharing=True, seed=2400)
+    shared_fixture(rm, rt, "learner_gru_seps_vdn_H128.npz", rm.VDNetwork, P=3, D=18, H=128, B=17, sharing=[0, 0, 1], seed=2500)
+    std_fixture(rm, rt, "learner_gru_std_H64.npz", P=2, D=15, H=64, B=23, seed=2600)
