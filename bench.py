@@ -53,10 +53,11 @@ def parse():
     ap.add_argument("--algo", default="idqn", choices=["idqn", "vdn", "qmix", "ia2c", "ippo", "maa2c", "mappo"])
     ap.add_argument("--rnn", action="store_true", help="recurrent Q-networks (algorithm.model.use_rnn=True; idqn / vdn, hidden 64)")
     ap.add_argument("--mixer-fp16", action="store_true", help="qmix: the opt-in fp16 first mixer layers (BASELINE config 5; a deviation from the fp32 reference)")
-    ap.add_argument("--hparams", default="tuned", choices=["tuned", "reference"],
-                    help="idqn at --cadence ratio: `tuned` = the optimiser settings under which the batched cadence learns (lr 3e-3 + Polyak 0.1; "
-                         "U >= 128: lr 1e-3 + hard copy every 50; profiles/r02_learning_parity.md), `reference` = idqn.yaml's lr 3e-4 + hard copy "
-                         "every 200 updates.  Same kernels and launch counts either way; named in config.lr / target_update_interval_or_tau")
+    ap.add_argument("--hparams", default="reference", choices=["tuned", "reference"],
+                    help="idqn at --cadence ratio: `reference` (default, the headline line) = idqn.yaml's lr 3e-4 + hard copy every 200 updates; "
+                         "`tuned` = the optimiser settings under which the batched cadence learns fastest (lr 3e-3 + Polyak 0.1; U >= 128: lr 1e-3 + "
+                         "hard copy every 50; profiles/r02_learning_parity.md) - a `modes` row of the default line.  Same loss/grad kernels either "
+                         "way (Polyak adds the target blend to the epilogue); named in config.lr / target_update_interval_or_tau")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N > 1: weak = --envs envs and an update batch of B episodes PER GPU (effective batch G*B); strong = --envs envs and B "
                          "episodes in TOTAL, split evenly over the GPUs (the 1-GPU job's global batch and env count)")
@@ -264,22 +265,46 @@ def ac_update_flops(rnn, P, D, A, H, T, N, central, epochs=1):
     return P * N * (fc * (T + 1) + 3 * fc * T + 3 * fa * T)
 
 
-def traffic_from_profile(key):
+TRAFFIC_SOURCES = {"": ("dqn_update_kernels.h", "mlp.h"), "H128": ("dqn_update_tp.h", "mlp.h"), "split16": ("dqn_update_h16.h", "mlp.h")}
+
+
+def kernel_source_hash(files):
+    """sha256 (16 hex digits) over the named kernel sources under codebase_amd/csrc, in the given order: what a committed PMC profile is
+    keyed by, so that a traffic figure is only quoted for the kernel text it was measured on"""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in files:
+        h.update(f.encode() + b"\0")
+        h.update(open(os.path.join(ROOT, "codebase_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def traffic_from_profile(key, variant=""):
     """HBM bytes per launch of the named workload's dominant kernel from the committed rocprofv3 PMC passes (bench.py cannot run
-    rocprofv3 on itself): profiles/r02_pmc_traffic.json records the git head and the exact workload it was taken on; anything
-    else gets null."""
-    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):  # the newest profile that holds this exact workload
+    rocprofv3 on itself).  Each workload entry of profiles/rNN_pmc_traffic.json carries `source_hash` = kernel_source_hash of the
+    kernel's sources at the profiled head; when the sources in this tree hash differently the figure is NOT quoted: traffic null and
+    the reason in `traffic_source`."""
+    reason = "no committed PMC profile holds this workload"
+    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json"):  # the newest profile that holds this exact workload
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
             ent = pmc["workloads"].get(key)
             if ent is None:
                 continue
+            files = tuple(ent.get("source_files") or TRAFFIC_SOURCES[variant])
+            now = kernel_source_hash(files)
+            if ent.get("source_hash") != now:
+                reason = (f"profiles/{name} was measured on kernel sources {ent.get('source_hash')} ({', '.join(files)} at head {pmc.get('head')}); "
+                          f"this tree's hash is {now}: not quoted")
+                continue
             return ent["traffic_bytes"], {"file": "profiles/" + name, "head": pmc.get("head"), "kernel": ent.get("kernel"),
+                                          "source_files": list(files), "source_hash": now,
                                           "algorithmic_bytes": ent.get("algorithmic_bytes"),
-                                          "note": "rocprofv3 PMC passes of this workload at the recorded git head (bench.py cannot profile itself)"}
+                                          "note": "rocprofv3 PMC passes of this workload; the kernel sources of this tree hash to the profiled ones (bench.py cannot profile itself)"}
         except (OSError, KeyError, ValueError):
             continue
-    return None, None
+    return None, {"reason": reason}
 
 
 def _ranks_field(world, dist, args):
@@ -515,7 +540,8 @@ def secondary_modes(args):
     import copy
 
     rows = {}
-    for name, over, steps, warmup in (("env-only", dict(cadence="env-only"), 20, 3),
+    for name, over, steps, warmup in (("hparams=tuned (lr 3e-3, Polyak 0.1: what the batched cadence learns fastest with), cadence=ratio", dict(hparams="tuned"), 10, 3),
+                                      ("env-only", dict(cadence="env-only"), 20, 3),
                                       ("cadence=reference", dict(cadence="reference"), 3, 1),
                                       ("hidden=128 (reference default net), cadence=ratio", dict(hidden=128), 5, 2),
                                       ("split16 OPT-IN learner (fp16 hi/lo products, fp32 accumulate; NOT the default), cadence=ratio", dict(split16=True), 10, 3)):
@@ -630,7 +656,9 @@ def bench_dqn(args, rank, world, dist, steps, warmup):
         avg_s = lg["avg_us"] * 1e-6
         ach = flops / avg_s / 1e12
         key = f"{args.algo}:{args.env_name}:N{N}:H{H}:B{B}:T{T}:rnn{int(bool(args.rnn))}" + (":split16" if getattr(args, "split16", False) else "")
-        traffic, tsrc = traffic_from_profile(key)
+        traffic, tsrc = traffic_from_profile(key, "split16" if getattr(args, "split16", False) else ("H128" if H > 64 else ""))
+        if args.rnn or args.algo != "idqn":
+            traffic, tsrc = None, {"reason": "no committed PMC profile holds this workload"}
         kname = "dqn_lossgrad_h16_kernel (split-fp16 products, fp32 accumulate)" if getattr(args, "split16", False) else ("gru_seq_fwd2 + gru_td + gru_seq_bwd + gru_wgrad" if args.rnn else
                  ("dqn_lossgrad_kernel" if H <= 64 else "tp_fwd_kernel + tp_mix_kernel + tp_bwd_kernel")) + (" + qmix mixer stage" if args.algo == "qmix" else "")
         roofline = {"kernel": kname, "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",

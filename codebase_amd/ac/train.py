@@ -194,8 +194,18 @@ def main(envs, eval_env, logger, time_limit, **cfg):
         log_now = (step - last_eval) >= g("eval_interval")  # the only consumer of a rollout's infos
         t, batch, infos = _collect_trajectories(envs, model, time_limit, parallel_envs, model.n_agents, device,
                                                 g("use_proper_termination", False), round_idx=updates, want_infos=log_now)
-        if dist is not None and log_now:  # the other ranks' episodes join rank 0's list (returns [P] + length per first episode)
-            rows = torch.tensor([[*map(float, d["episode_returns"]), float(d["episode_length"])] for d in infos[:parallel_envs]],
+        if dist is not None:
+            # the reference's counter (ac/train.py:226) for the whole job, the same number on every rank (it ends the loop).  Exchanged
+            # HERE, where the host has just read `t` and the stream is empty - not behind update_async, where reading it would make the host
+            # wait for the update instead of queueing the next rollout
+            t_job = int(gather_stack(dist, torch.tensor([t * parallel_envs], device=device)).sum().item())
+        if dist is not None and log_now:
+            # the other ranks' FIRST episodes join rank 0's list: one per env, chosen by env id - `infos` is sorted by finish step, so its
+            # head would be the shortest episodes, later ones of fast envs included
+            first = {}
+            for d in infos:
+                first.setdefault(d.env, d)
+            rows = torch.tensor([[*map(float, first[i]["episode_returns"]), float(first[i]["episode_length"])] for i in range(parallel_envs)],
                                 dtype=torch.float32, device=device)
             for r, block in enumerate(gather_stack(dist, rows).cpu().numpy()):
                 if r != rank:
@@ -218,7 +228,6 @@ def main(envs, eval_env, logger, time_limit, **cfg):
         if g("video_interval"):
             raise NotImplementedError("video recording is outside the HIP hot path")
         updates += 1
-        # the reference's counter (ac/train.py:226); N > 1 ranks: the whole job's, the same number on every rank (it ends the loop)
-        step += t * parallel_envs if dist is None else int(gather_stack(dist, torch.tensor([t * parallel_envs], device=device)).sum().item())
+        step += t * parallel_envs if dist is None else t_job
     envs.close()
     return model

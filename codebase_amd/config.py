@@ -118,14 +118,14 @@ def _set(cfg, dotted, value):
     cur[parts[-1]] = value
 
 
-# the one place YAML 1.1 (PyYAML) and YAML 1.2 / OmegaConf disagree on numbers: exponent form WITHOUT a dot (`1e6`, `3e-4`) stays a
-# string in safe_load.  Everything else safe_load already typed - in particular QUOTED scalars ("1", "007", "1e6" written with quotes
+# the one place YAML 1.1 (PyYAML) and YAML 1.2 / OmegaConf disagree on numbers: PyYAML's float needs a dot AND a SIGNED exponent, so
+# `1e6`, `3e-4` (no dot) and `1.5e6`, `.5e3`, `1.e3` (unsigned exponent) stay strings in safe_load.  Everything else safe_load already typed - in particular QUOTED scalars ("1", "007", "1e6" written with quotes
 # lose their quotes in the loaded tree and cannot be told apart here, but quoted digits without an exponent stay strings)
-_YAML11_GAP = re.compile(r"^[-+]?\d+[eE][-+]?\d+$")
+_YAML11_GAP = re.compile(r"^[-+]?(\d+\.?\d*|\.\d+)[eE][-+]?\d+$")
 
 
 def _numbers(x):
-    """PyYAML follows YAML 1.1, where `1e6` / `3e-4` (no dot) are strings; Hydra / OmegaConf read them as floats.
+    """PyYAML follows YAML 1.1, where `1e6` / `3e-4` / `1.5e6` are strings; Hydra / OmegaConf read them as floats.
     Re-type such scalars (recursively) so `algorithm.total_steps=1e6` means what it means to the reference."""
     if isinstance(x, dict):
         return {k: _numbers(v) for k, v in x.items()}

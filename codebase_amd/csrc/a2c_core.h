@@ -157,6 +157,8 @@ int launch_forward_rows(int P, const AgentMap& am, const float* params, const ma
         return 0;
     } else {
     const int T = bt->max_len, B = bt->batch;
+    // the stored-hidden-layer record is [T*B/16 blocks]: a longer row range (the target critic's T*B + B) would write a time step past it
+    MARL_REQUIRE(rec == nullptr || (n_rows == T * B && B % 16 == 0), "forward rows: a hidden-layer record needs n_rows == T*B (%d vs %d x %d) and B %% 16 == 0", n_rows, T, B);
     const size_t as = bt->obs_agent_stride > 0 ? (size_t)bt->obs_agent_stride : (bt->obs_agent_stride < 0 ? 0 : (size_t)(T + 1) * B * S::D);
     const size_t rs = bt->obs_row_stride ? (size_t)bt->obs_row_stride : (size_t)S::D;
     constexpr int LDSB = S::NFWD * (int)sizeof(float);

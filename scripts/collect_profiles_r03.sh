@@ -2,7 +2,7 @@
 # Round-3 evidence, collected on the GPU box (gpurun): PMC traffic (TCC passes) and SQ counters of the default line, the hidden-128 line and
 # the opt-in split16 line, kernel stats of the BASELINE configs, the bench matrix.  Everything lands under gpurun_out/prof3/;
 # `python scripts/profiles_post.py prof3 r03` turns it into the committed files under profiles/.
-O=$GRAFT_REPO_ROOT/gpurun_out/prof3; mkdir -p $O; rm -rf $O/pmc_* $O/stats* $O/matrix.jsonl; cd /tmp; export TMPDIR=/tmp  # (no leftovers of an earlier collection)
+O="${GRAFT_REPO_ROOT:?}/gpurun_out/prof3"; mkdir -p "$O"; rm -rf "$O"/pmc_* "$O"/stats* "$O/matrix.jsonl"; cd /tmp; export TMPDIR=/tmp  # (no leftovers of an earlier collection)
 R=$GRAFT_REPO_ROOT
 cp $R/scripts/_bin/head.txt $O/head.txt 2>/dev/null
 B="python $R/bench.py --no-cpu-baseline --no-modes"

@@ -100,8 +100,13 @@ def main():
         out["kernels"]["default" if not sfx else sfx[1:]] = kernels
         parts = [v for k, v in kernels.items() if any(k.startswith(mm) for mm in match) and "traffic_bytes" in v]
         if parts:
+            sys.path.insert(0, ROOT)
+            import bench  # kernel_source_hash: the key bench.py checks before quoting the figure (run this script on the PROFILED tree)
+
+            files = bench.TRAFFIC_SOURCES["split16" if sfx == "_s16" else ("H128" if sfx == "_h128" else "")]
             out["workloads"][key] = {"kernel": " + ".join(k for k in kernels if any(k.startswith(mm) for mm in match)),
-                                     "traffic_bytes": sum(v["traffic_bytes"] for v in parts), "algorithmic_bytes": alg}
+                                     "traffic_bytes": sum(v["traffic_bytes"] for v in parts), "algorithmic_bytes": alg,
+                                     "source_files": list(files), "source_hash": bench.kernel_source_hash(files)}
     json.dump(out, open(os.path.join(DST, PFX + "_pmc_traffic.json"), "w"), indent=1)
     # ---- SQ counters
     sq, inst = counters("SQ"), counters("INST")

@@ -41,3 +41,7 @@ def test_exponent_literals_are_numbers():
     # only the YAML-1.1 gap is re-typed (exponent form without a dot, which safe_load leaves a string); what safe_load hands over as a
     # string otherwise was QUOTED in the file ("7", "1.5", "007") and stays a string, as it does under OmegaConf
     assert C._numbers({"a": ["1e3", "x1e3", "-2E-2", "7", "1.5", "007", "v3", 7, 1.5]}) == {"a": [1000.0, "x1e3", -0.02, "7", "1.5", "007", "v3", 7, 1.5]}
+    # dotted mantissas with an UNSIGNED exponent are in the same gap (safe_load("1.5e6") == "1.5e6"); ADVICE r3
+    assert C._numbers(["1.5e6", "2.5E5", ".5e3", "1.e3", "+.5e-3", "1.5e", "e3", "1.5e6x"]) == [1.5e6, 2.5e5, 500.0, 1000.0, 0.0005, "1.5e", "e3", "1.5e6x"]
+    cfg = C.compose(["+algorithm=idqn", "env.name=lbforaging:Foraging-8x8-2p-3f-v3", "env.time_limit=25", "algorithm.total_steps=1.5e6", "algorithm.lr=2.5e-4"])
+    assert cfg.algorithm.total_steps == 1.5e6 and isinstance(cfg.algorithm.total_steps, float) and cfg.algorithm.lr == 2.5e-4
