@@ -177,6 +177,8 @@ class Learner:
         self.opt.zero_grad()
         loss.backward()
         gnorm = None
+        per = len(self.tensors) // self.P  # the gradient as _compute_loss leaves it (before clipping), [P][n]: for tests that compare it
+        self.last_grad = torch.stack([torch.cat([t.grad.reshape(-1) for t in self.tensors[p * per:(p + 1) * per]]) for p in range(self.P)]).clone()
         if self.grad_clip:
             gnorm = torch.nn.utils.clip_grad_norm_(self.tensors, self.grad_clip)
         self.opt.step()

@@ -59,7 +59,14 @@ def to_device(h, rb, host):
         t.copy_(host[k])
 
 
-def run_case(mode, P, D, H, A, T, B, cap, lr, tui, n_calls, per_call, params0, target0, seed=1234, grad_clip=1.0, atol=3e-6, split16=False):
+def run_case(mode, P, D, H, A, T, B, cap, lr, tui, n_calls, per_call, params0, target0, seed=1234, grad_clip=1.0, atol=3e-6, split16=False,
+             noise_floor=None):
+    """noise_floor (hidden-128 cases): Adam's first steps are lr * g / (|g| + 1e-8) - for an entry whose gradient is below the f32
+    rounding noise of a 100k-row sum (~3e-8 here) the step is +-lr by the LAST bits of g, which two correct f32 implementations with
+    different summation orders do not share.  With a floor, `atol` binds the entries whose reference gradient stayed >= floor in every
+    update so far (the step then moves by lr * dg / |g| << atol); the others are bounded by the steps taken, at most 0.1 % of all
+    entries may exceed `atol`, and the gradient ITSELF is compared entry by entry (1e-4 of its largest entry) so that nothing hides
+    behind the floor."""
     from codebase_amd import hip as h
 
     spec = h.NetSpec(P, D, H, A)
@@ -73,6 +80,7 @@ def run_case(mode, P, D, H, A, T, B, cap, lr, tui, n_calls, per_call, params0, t
                       target_update_interval_or_tau=tui, mode="vdn" if mode == 1 else "idqn")
     port.target = target0.clone()
     upd = last = counter = 0
+    sure = np.ones(tuple(params0.shape), bool)
     for call in range(n_calls):
         n = per_call[call]
         upd, last = fl.run(n, cap, seed, counter, upd, last)
@@ -80,6 +88,8 @@ def run_case(mode, P, D, H, A, T, B, cap, lr, tui, n_calls, per_call, params0, t
         for u in range(n):
             idx = philox_indices(seed, counter + u, B, cap)
             m = port.update(host_batch(host, idx))
+            if noise_floor is not None:
+                sure &= np.abs(port.last_grad.numpy()) * min(1.0, grad_clip / (m["grad_norm"] + 1e-6)) >= noise_floor
         counter += n
         # the library leaves the indices of its LAST draw: the host restatement of the stream is the one the kernel used
         np.testing.assert_array_equal(rb._outputs(B)[5].cpu().numpy(), idx)
@@ -94,6 +104,13 @@ def run_case(mode, P, D, H, A, T, B, cap, lr, tui, n_calls, per_call, params0, t
                 # ~1e-8 the step is a function of the LAST bits of g, which the split-fp16 products (2^-21) do not share with torch's f32
                 # sums.  Those entries may differ by a fraction of one step; everything else keeps the f32 tolerance.
                 assert (diff > atol).mean() <= 5e-4 and diff.max() <= 2.0 * lr * (call + 1) * max(per_call), (what, call, diff.max(), (diff > atol).sum())
+            elif noise_floor is not None:
+                g_hip, g_ref = up.grad.cpu().numpy(), port.last_grad.numpy()  # the last update's gradient, before clipping
+                assert np.abs(g_hip - g_ref).max() <= 1e-4 * np.abs(g_ref).max(), (what, call, np.abs(g_hip - g_ref).max(), np.abs(g_ref).max())
+                assert diff[sure].max() <= atol, f"{what} after call {call}: max abs difference {diff[sure].max()} on entries with |g| >= {noise_floor}"
+                # (dead units - exact zeros on both sides - sit below the floor too, so the bound is on the entries that DO differ.  Seen on
+                # MI355X: 0 of 38,668 in one run, one entry 2 * lr apart in another - the torch-CPU side's summation order is not fixed either)
+                assert (diff > atol).mean() <= 1e-3 and diff.max() <= 2.0 * lr * counter, (what, call, (diff > atol).sum(), diff.max())
             else:
                 assert diff.max() <= atol, f"{what} after call {call}: max abs difference {diff.max()}"
         assert (upd, last, up.step) == (port.updates, port.last_target_update, port.updates)
@@ -139,3 +156,108 @@ def test_vdn_fused_path_vs_oracle_port(B, lr, tui, atol):
     P, D, H, A, T = 4, 27, 64, 6, 25
     run_case(1, P, D, H, A, T, B=B, cap=2 * B + 32, lr=lr, tui=tui, n_calls=2, per_call=(1, 3),
              params0=_perturbed(P, D, H, A, 5), target0=_perturbed(P, D, H, A, 7), atol=atol)
+
+
+# ---- round 4: the driver-reported rows that had no oracle comparison at their size -----------------------------
+def test_headline_configuration_B4096_reference_hparams_vs_oracle_port():
+    """the default bench line since round 4: idqn.yaml's lr 3e-4 and a hard target copy (interval 2 here so that it happens inside the
+    call; the bench's 200 is the same code with a larger counter) at B = 4096"""
+    P, D, H, A, T = 2, 15, 64, 6, 25
+    run_case(0, P, D, H, A, T, B=4096, cap=8192, lr=3e-4, tui=2, n_calls=2, per_call=(1, 3),
+             params0=_perturbed(P, D, H, A, 1), target0=_perturbed(P, D, H, A, 3), atol=3e-6)
+
+
+def test_hidden128_mode_row_B4096_lr3e3_polyak_vs_oracle_port():
+    """`modes["hidden=128 ..."]`: marlhip_idqn_update_n -> tp_fwd / tp_mix / tp_bwd<STORED> + sumsq + adam_kernel, B = 4096 gathered from
+    the replay, lr 3e-3, Polyak 0.1 (the largest hidden-128 comparison before was B = 1024 on a Batch)"""
+    P, D, H, A, T = 2, 15, 128, 6, 25
+    run_case(0, P, D, H, A, T, B=4096, cap=8192, lr=3e-3, tui=0.1, n_calls=2, per_call=(1, 3),
+             params0=_perturbed(P, D, H, A, 11), target0=_perturbed(P, D, H, A, 13), atol=3e-5, noise_floor=1e-5)
+
+
+def test_hidden128_B4096_reference_hparams_vs_oracle_port():
+    P, D, H, A, T = 2, 15, 128, 6, 25
+    run_case(0, P, D, H, A, T, B=4096, cap=8192, lr=3e-4, tui=2, n_calls=1, per_call=(3,),
+             params0=_perturbed(P, D, H, A, 11), target0=_perturbed(P, D, H, A, 13), atol=3e-6, noise_floor=1e-5)
+
+
+def test_hidden128_golden_configuration_B32_hard_target_copy_vs_oracle_port():
+    g = np.load(os.path.join(G, "learner_H128.npz"))
+    P, D, H, A, T = int(g["P"]), int(g["D"]), 128, int(g["A"]), 25
+    run_case(0, P, D, H, A, T, B=32, cap=96, lr=3e-4, tui=2, n_calls=2, per_call=(3, 2),
+             params0=torch.tensor(g["params0"]), target0=torch.tensor(g["target0"]), atol=3e-6)
+
+
+@pytest.mark.parametrize("H", [64, 128])
+def test_reference_cadence_64_sequential_updates_of_32_vs_oracle_port(H):
+    """`modes["cadence=reference"]`: U sequential updates of 32 episodes inside ONE library call (the bench runs U = 4096 of them; the
+    goldens run 3).  64 updates with a hard copy every 25: every update reads the packs its predecessor's epilogue wrote.  Adam's
+    normalised steps amplify last-bit gradient differences where |g| ~ eps, so the bound is two-part: no entry further apart than ONE
+    of the 64 steps (lr = 3e-4; 64 steps move a parameter by up to 1.9e-2) and 99 % of them within the goldens' 3e-6 (measured on
+    MI355X: hidden 64 max 9.1e-5 / q99 6.9e-7)."""
+    P, D, A, T = 2, 15, 6, 25
+    from codebase_amd import hip as h
+
+    cap, B, lr, tui, U, seed = 512, 32, 3e-4, 25, 64, 77
+    spec = h.NetSpec(P, D, H, A)
+    host = lbf_like_replay(cap, P, D, T, A, seed=seed + 1)
+    rb = h.DeviceReplay(cap, P, D, T)
+    to_device(h, rb, host)
+    p0, t0 = _perturbed(P, D, H, A, 21), _perturbed(P, D, H, A, 23)
+    params, target = p0.clone().to(DEV), t0.clone().to(DEV)
+    up = h.DqnUpdater(spec, params, target, lr=lr, gamma=0.99, grad_clip=1.0, double_q=True)
+    fl = h.FusedLearner(up, rb, B, tui, mode=0)
+    port = dp.Learner(p0.clone(), D, H, A, lr=lr, gamma=0.99, grad_clip=1.0, double_q=True, target_update_interval_or_tau=tui)
+    port.target = t0.clone()
+    upd, last = fl.run(U, cap, seed, 0, 0, 0)
+    torch.cuda.synchronize()
+    for u in range(U):
+        m = port.update(host_batch(host, philox_indices(seed, u, B, cap)))
+    assert (upd, last) == (port.updates, port.last_target_update) == (64, 50)
+    got = up.loss.cpu().numpy()
+    assert abs(got[0] - m["loss"]) <= 1e-4 * abs(m["loss"]), (got, m)   # the 64th loss, after 63 updates on each side
+    for got_t, ref_t, what in ((params, port.flat().detach(), "params"), (target, port.target, "target")):
+        diff = np.abs(got_t.cpu().numpy() - ref_t.numpy())
+        assert diff.max() <= lr and np.quantile(diff, 0.99) <= 3e-6, (what, diff.max(), np.quantile(diff, 0.99))
+
+
+def test_qmix_host_loop_through_the_trainer_B4096_vs_oracle_port():
+    """QMIX 8x8-2p as bench.py --algo qmix runs it: VectorisedIDQN.round = fused collector (4096 cooperative envs) + U x
+    QMixNetwork.update_async (in-library index draw, in-kernel gather, agents + mixer loss/grad, clip over the critic only, one Adam
+    over critic + mixer, hard copy of target and target mixer inside the round).  The right-hand side is oracle/qmix_port.Learner
+    on the batches rebuilt from the host copy of what the collector stored."""
+    from codebase_amd import hip as h
+    from codebase_amd.dqn.model import QMixNetwork
+    from codebase_amd.dqn.train import VectorisedIDQN
+    from codebase_amd.parallel import rank_sample_seed
+    from codebase_amd.utils.envs import _space_pair
+    from oracle import qmix_port as qp
+
+    N, T, H, B, U, seed = 4096, 25, 64, 4096, 3, 5
+    cfg = h.env_config("lbforaging:Foraging-8x8-2p-3f-v3", N, T, seed=seed, cooperative=True)
+    P, (D, A) = cfg.n_agents, h.env_dims(cfg)
+    torch.manual_seed(seed)
+    obs_space, act_space = _space_pair(cfg)
+    hyper = dict(optimizer="Adam", lr=3e-4, gamma=0.99, grad_clip=1.0, double_q=True, standardise_returns=False, target_update_interval_or_tau=2)
+    model = QMixNetwork(obs_space, act_space, hyper, [H, H], False, False, True, dict(embed_dim=64, hypernet_layers=2, hypernet_embed=32), "cuda")
+    p0, t0 = model.params.cpu().clone(), model.target_params.cpu().clone()
+    m0, tm0 = model.mixer_params.cpu().clone(), model.target_mixer_params.cpu().clone()
+    trainer = VectorisedIDQN(cfg, model, N, T, B, U, seed=seed)
+    trainer.round(0.7, train=True)
+    torch.cuda.synchronize()
+    rb = trainer.replay
+    host = dict(obs=rb.obs.cpu(), act=rb.act.cpu(), rew=rb.rew.cpu(), done=rb.done.cpu(), filled=rb.filled.cpu())
+    assert int(host["filled"].sum()) == int(trainer.env_steps.item()) > 20 * N  # the collector's episodes are what is sampled
+    port = qp.Learner(p0, m0, D, H, A, lr=3e-4, gamma=0.99, grad_clip=1.0, double_q=True, target_update_interval_or_tau=2)
+    port.target, port.tmixer = t0.clone(), tm0.clone()
+    for u in range(U):
+        idx = philox_indices(rank_sample_seed(seed, 0), u, B, N)
+        m = port.update(host_batch(host, idx))
+    got = trainer.last_loss.cpu().numpy()
+    assert abs(got[0] - m["loss"]) <= 3e-5 * abs(m["loss"]), (got, m)
+    assert got[1] == float(host["filled"][torch.as_tensor(idx)].sum())
+    assert (model.updates, model.last_target_update) == (port.updates, port.last_target_update) == (3, 2)
+    for got_t, ref_t, what in ((model.params, port.flat().detach(), "params"), (model.target_params, port.target, "target"),
+                               (model.mixer_params, port.mflat().detach(), "mixer"), (model.target_mixer_params, port.tmixer, "target mixer")):
+        diff = np.abs(got_t.cpu().numpy() - ref_t.numpy())
+        assert diff.max() <= 3e-6, f"{what}: max abs difference {diff.max()}"
