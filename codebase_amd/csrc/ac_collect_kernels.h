@@ -26,6 +26,33 @@ int ac_collect_dispatch_oid(const marlhip_lbf_config* cfg, const marlhip_net_sha
 
 constexpr int ACOL_BLOCK = 256;
 
+// MARL_ACOL_PROF=1 (profiling builds only, scripts/build_variants.py): s_memtime at the region boundaries of a rollout step, summed per
+// region over the steps and added by lane 0 of every wave to acol_prof[]: 0 actor forward, 1 Philox + Categorical sample, 2 action swap
+// (barrier), 3 env step, 4 rewards / bookkeeping / auto-reset, 5 observation, 6 batch stores, 7 the whole kernel, 8 waves.
+#ifndef MARL_ACOL_PROF
+#define MARL_ACOL_PROF 0
+#endif
+#if MARL_ACOL_PROF
+static __device__ unsigned long long acol_prof[16];
+#define ACOL_TS_BEGIN unsigned long long ts_ = __builtin_readcyclecounter(), sp_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; const unsigned long long ts0_ = ts_;
+#define ACOL_TS(k)                                                      \
+    {                                                                   \
+        const unsigned long long now_ = __builtin_readcyclecounter();   \
+        sp_[k] += now_ - ts_;                                           \
+        ts_ = now_;                                                     \
+    }
+#define ACOL_TS_END                                                                          \
+    if ((threadIdx.x & 63) == 0) {                                                           \
+        sp_[7] = __builtin_readcyclecounter() - ts0_;                                        \
+        for (int k_ = 0; k_ < 8; ++k_) atomicAdd(&acol_prof[k_], sp_[k_]);                   \
+        atomicAdd(&acol_prof[8], 1ull);                                                      \
+    }
+#else
+#define ACOL_TS_BEGIN
+#define ACOL_TS(k)
+#define ACOL_TS_END
+#endif
+
 
 // softmax inverse-CDF sample for the env of batch row j; logits in C layout (lane (g,j) holds a = 4g+r)
 template <int A>
@@ -127,7 +154,9 @@ __global__ __launch_bounds__(ACOL_BLOCK) void ac_collect_kernel(typename ENV::Pa
 #pragma unroll
     for (int p = 0; p < P; ++p) ep_ret[p] = 0.f;
     int len = 0;
+    ACOL_TS_BEGIN
     for (int t = 0; t < T; ++t) {
+        ACOL_TS(6)
         int act[P], own[K];
 #pragma unroll
         for (int p = 0; p < P; ++p) act[p] = 0;
@@ -153,9 +182,11 @@ __global__ __launch_bounds__(ACOL_BLOCK) void ac_collect_kernel(typename ENV::Pa
                 f4 h1[S::MT], h2[S::MT], logits, unused;
                 if constexpr (FROM_GLOBAL) mlp_forward_g<S>(pack, lane, x[k], logits);
                 else mlp_forward_p<S, false>(pack, pack, lane, x[k], h1, h2, logits, unused, PP::A3REG ? a3[PP::A3REG ? k : 0] : nullptr);
+                ACOL_TS(0)
                 const float u = u01_f32(act_noise_word(q.seed, env_id, 2u * round, (uint32_t)t, 1 + p));
                 own[k] = sample_rows<A>(logits, lane, u);
                 if (NW == 1) act[k] = own[k];
+                ACOL_TS(1)
             }
         }
         if (NW > 1) {  // swap the sampled actions among the waves of the env block (double-buffered: one barrier per step)
@@ -167,11 +198,13 @@ __global__ __launch_bounds__(ACOL_BLOCK) void ac_collect_kernel(typename ENV::Pa
 #pragma unroll
             for (int p = 0; p < P; ++p) act[p] = sa[p * 16 + j];
         }
+        ACOL_TS(2)
         if (running) {
             double raw[P];
             float rw[P];
             bool done;
             ENV::step(q, s, ctx, env_id, 2u * round + gen, act, raw, done);
+            ACOL_TS(3)
             const bool trunc = q.time_limit > 0 && ENV::elapsed(s) >= q.time_limit;
             const bool fin = done || trunc;
             const bool stored_done = proper_term ? done : fin;
@@ -197,10 +230,12 @@ __global__ __launch_bounds__(ACOL_BLOCK) void ac_collect_kernel(typename ENV::Pa
                 ++gen;
                 ENV::reset(q, s, ctx, env_id, 2u * round + gen);
             }
+            ACOL_TS(4)
 #pragma unroll
             for (int k = 0; k < K; ++k) {
                 const int p = aw + k * NW;
                 ENV::template observe<S::KS1, OID>(q, s, ctx, p, g, x[k]);
+                ACOL_TS(5)
                 if (ghost) continue;
 #pragma unroll
                 for (int ks = 0; ks < S::KS1; ++ks)
@@ -242,6 +277,7 @@ __global__ __launch_bounds__(ACOL_BLOCK) void ac_collect_kernel(typename ENV::Pa
             }
         }
     }
+    ACOL_TS_END
     if (valid && running && lead && !ghost) {  // T shorter than the env's limits
 #pragma unroll
         for (int p = 0; p < P; ++p) fin_return[(size_t)p * N + n] = ep_ret[p];

@@ -59,20 +59,36 @@ struct RwEnvT {
         DrawStream req;
         req.init(q.seed, env, episode, STREAM_REQUEST);
         rw_step(q, s, c.grid, act, raw, done, req);
-        c.rq.build(q, s);
+        if (s.inactive == 0) c.rq.build(q, s);  // the queue only changes on a delivery (which zeroes the inactivity counter)
     }
     static __device__ __forceinline__ int elapsed(const State& s) { return s.steps; }
     template <int KS1, bool OID>
     static __device__ __forceinline__ void observe(const Params& q, const State& s, Ctx& c, int p, int g, float (&x)[KS1]) {
-        const uint64_t word = rw_window_word(q, s, c.grid, c.rq, p);
-        constexpr int IDW = OID ? P_ : 0, D = D0 + IDW;
+        if constexpr (OID) {  // with the ObserveID prefix every index shifts by P: the general per-element route
+            const uint64_t word = rw_window_word(q, s, c.grid, c.rq, p);
+            constexpr int IDW = P_, D = D0 + IDW;
 #pragma unroll
-        for (int ks = 0; ks < KS1; ++ks) {
-            const int i = 4 * ks + g;  // the lane's own element of this k-step
-            float v = 0.f;
-            if (i < IDW) v = i == p ? 1.f : 0.f;
-            else if (i < D) v = rw_obs_elem_word(q, s, p, word, i - IDW);
-            x[ks] = v;
+            for (int ks = 0; ks < KS1; ++ks) {
+                const int i = 4 * ks + g;  // the lane's own element of this k-step
+                float v = 0.f;
+                if (i < IDW) v = i == p ? 1.f : 0.f;
+                else if (i < D) v = rw_obs_elem_word(q, s, p, word, i - IDW);
+                x[ks] = v;
+            }
+        } else {
+            // lane g of an env takes elements 4 ks + g: the 8 own features are two select chains, every window feature one bit of the mask
+            const uint64_t bits = rw_obs_bits(q, s, c.grid, c.rq, p);
+            const uint32_t lo = (uint32_t)bits, hi = (uint32_t)(bits >> 32);
+            const int ax = rw_pick<P_>(s.ax, p), ay = rw_pick<P_>(s.ay, p), ad = rw_pick<P_>(s.ad, p);
+            const int carrying = rw_pick<P_>(s.ac, p) != 0 ? 1 : 0, hw = rw_is_highway(q, ax, ay) ? 1 : 0;
+#pragma unroll
+            for (int ks = 0; ks < KS1; ++ks) {
+                int v = 0;
+                if (ks == 0) v = g == 0 ? ax : (g == 1 ? ay : (g == 2 ? carrying : (ad == 0 ? 1 : 0)));
+                else if (ks == 1) v = g == 3 ? hw : (ad == g + 1 ? 1 : 0);
+                else if (4 * ks - 8 < 63) v = (int)((((4 * ks - 8) < 32 ? lo : hi) >> (((4 * ks - 8) & 31) + g)) & 1u);  // 4 ks - 8 is a multiple of 4: + g stays inside the word
+                x[ks] = (float)v;
+            }
         }
     }
 };

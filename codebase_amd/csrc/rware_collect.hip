@@ -92,3 +92,12 @@ extern "C" int marlhip_rware_ac_collect_later_episodes(const marlhip_rware_confi
     return marlhip_rware_ac_collect(&c2, s, actor_params, round, max_len, 0, ret, reinterpret_cast<int64_t*>(meta), ret, reinterpret_cast<uint8_t*>(meta), ret,
                                     ret, meta, meta + 2 * (size_t)n_envs * cap - 1, workspace, workspace_bytes, stream);
 }
+
+#if MARL_ACOL_PROF
+// profiling builds only: read and clear this translation unit's in-kernel region counters (ac_collect_kernels.h)
+extern "C" int marlhip_debug_acol_prof(unsigned long long* out16) {
+    unsigned long long z[16] = {0};
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(marl::acol_prof), sizeof(z)) != hipSuccess) return -1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(marl::acol_prof), z, sizeof(z)) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -162,14 +162,17 @@ MARL_HD void rw_reset(const RwParams& q, RwState<P>& s, const RwGrid& grid, Draw
     s.inactive = 0;
 }
 
-// nibble-packed per-agent tables (P <= 8 here; 0xF = none)
-MARL_HD int rw_nib(uint64_t w, int i) { return (int)((w >> (4 * i)) & 0xF); }
-MARL_HD uint64_t rw_set_nib(uint64_t w, int i, int v) { return (w & ~(0xFull << (4 * i))) | ((uint64_t)(v & 0xF) << (4 * i)); }
+// nibble-packed per-agent tables (P <= 8: eight nibbles = ONE 32-bit word; 0xF = none).  32-bit on purpose: the 64-bit variable
+// shifts of a wider table are multi-pass instructions on the vector ALU, and these run ~100 times per env step.
+MARL_HD int rw_nib(uint32_t w, int i) { return (int)((w >> (4 * i)) & 0xFu); }
+MARL_HD uint32_t rw_set_nib(uint32_t w, int i, int v) { return (w & ~(0xFu << (4 * i))) | ((uint32_t)(v & 0xF) << (4 * i)); }
 
 // committed-agent bit mask from the per-agent "agent on my target cell" table (0xF = free cell, self = stationary) and the
-// target cells; see the header comment and oracle/rware.py resolve_rule
+// target cells; see the header comment and oracle/rware.py resolve_rule.  Written as selects, not branches: per-lane `if`s become
+// exec-mask regions (s_and_saveexec + s_cbranch) whose 64-bit masks overflow the scalar registers (round 4: the step spent most
+// of its time on v_readlane / v_writelane spill traffic and taken branches, not on arithmetic).
 template <int P>
-MARL_HD uint32_t rw_resolve(uint64_t nxt, const int* tcell) {
+MARL_HD uint32_t rw_resolve(uint32_t nxt, const int* tcell) {
     static_assert(P <= 8, "nibble tables sized for <= 8 agents");
     uint32_t committed = 0, in_tree = 0;
 #pragma unroll
@@ -179,21 +182,24 @@ MARL_HD uint32_t rw_resolve(uint64_t nxt, const int* tcell) {
         int j = rw_nib(nxt, i), n = 1;
 #pragma unroll
         for (int it = 0; it < P; ++it) {
-            if (j != 0xF && j != i) { j = rw_nib(nxt, j); ++n; }
+            const bool go = j != 0xF && j != i;
+            const int nj = rw_nib(nxt, go ? j : 0);
+            j = go ? nj : j;
+            n += go ? 1 : 0;
         }
-        if (j == i && n != 2) committed |= 1u << i;
-        if (j == 0xF) in_tree |= 1u << i;
+        committed |= (j == i && n != 2) ? 1u << i : 0u;
+        in_tree |= (j == 0xF) ? 1u << i : 0u;
     }
-    uint64_t height = 0;  // longest chain of feeders behind each agent
+    uint32_t height = 0;  // longest chain of feeders behind each agent
 #pragma unroll
     for (int pass = 0; pass < P - 1; ++pass) {
 #pragma unroll
         for (int i = 0; i < P; ++i) {
             const int t = rw_nib(nxt, i);
-            if (t != 0xF && t != i) {
-                const int h = rw_nib(height, i) + 1, ht = rw_nib(height, t);
-                if (h > ht && h <= P) height = rw_set_nib(height, t, h);
-            }
+            const bool feeds = t != 0xF && t != i;
+            const int tt = feeds ? t : 0;
+            const int h = rw_nib(height, i) + 1, ht = rw_nib(height, tt);
+            height = (feeds && h > ht && h <= P) ? rw_set_nib(height, tt, h) : height;
         }
     }
     // dag_longest_path walked back from the free cell = at every cell the feeder with the longest chain behind it wins
@@ -207,7 +213,7 @@ MARL_HD uint32_t rw_resolve(uint64_t nxt, const int* tcell) {
         for (int o = 0; o < P; ++o) {
             if (o != i) {
                 const int ho = rw_nib(height, o);
-                w = w && !(tcell[o] == tcell[i] && ((in_tree >> o) & 1u) && (ho > hi || (ho == hi && o < i)));
+                w = w & !((tcell[o] == tcell[i]) & (((in_tree >> o) & 1u) != 0) & ((ho > hi) | ((ho == hi) & (o < i))));
             }
         }
         win |= (w ? 1u : 0u) << i;
@@ -218,7 +224,7 @@ MARL_HD uint32_t rw_resolve(uint64_t nxt, const int* tcell) {
 #pragma unroll
     for (int pass = 0; pass < P - 1; ++pass) {
 #pragma unroll
-        for (int i = 0; i < P; ++i) mv |= (((win >> i) & 1u) && ((mv >> rw_nib(nxt, i)) & 1u)) ? 1u << i : 0u;
+        for (int i = 0; i < P; ++i) mv |= (((win >> i) & 1u) & ((mv >> rw_nib(nxt, i)) & 1u)) << i;
     }
     return committed | mv;
 }
@@ -226,31 +232,44 @@ MARL_HD uint32_t rw_resolve(uint64_t nxt, const int* tcell) {
 // Warehouse.step.  rew[] are the env's own per-agent rewards (fp64, as upstream's np.zeros accumulates them); `done` =
 // max_steps / max_inactivity_steps reached.  `req` is the env's replacement-request stream (STREAM_REQUEST); it is
 // positioned at word 8 * step here.
+// Shape of the code (round 4): every grid byte the common path needs - each agent's requested cell and its own cell - is read up
+// front in one batch of independent loads (upstream's TOGGLE too reads the shelf layer as the PREVIOUS step left it: its grid is
+// only recalculated at the end of step()); targets, turns and toggles are selects; the only per-lane branches left are the grid
+// writes of moving carriers and the delivery (rare).
 template <int P>
 MARL_HD void rw_step(const RwParams& q, RwState<P>& s, const RwGrid& grid, const int* act_in, double* rew, bool& done, DrawStream& req) {
-    int act[P], tx[P], ty[P], tcell[P];
-    uint64_t nxt = 0;
+    int act[P], tx[P], ty[P], tcell[P], own[P], g_t[P], g_own[P];
 #pragma unroll
     for (int p = 0; p < P; ++p) {
         int a = act_in[p];
-        if (a < 0 || a > RW_TOGGLE) a = RW_NOOP;
-        int x = s.ax[p], y = s.ay[p];
-        if (a == RW_FORWARD) {
-            if (s.ad[p] == RW_UP) y = y > 0 ? y - 1 : 0;
-            else if (s.ad[p] == RW_DOWN) y = y < q.rows - 1 ? y + 1 : q.rows - 1;
-            else if (s.ad[p] == RW_DLEFT) x = x > 0 ? x - 1 : 0;
-            else x = x < q.cols - 1 ? x + 1 : q.cols - 1;
-        }
-        // a loaded agent cannot enter a cell with a standing shelf (one another agent carries may move away in time)
-        if (s.ac[p] != 0 && (x != s.ax[p] || y != s.ay[p]) && grid.get(y * q.cols + x) != 0) {
-            const int other = rw_agent_at(s, x, y);
-            bool other_loaded = false;
-#pragma unroll
-            for (int o = 0; o < P; ++o) other_loaded = other_loaded || (o == other && s.ac[o] != 0);
-            if (!other_loaded) { a = RW_NOOP; x = s.ax[p]; y = s.ay[p]; }
-        }
-        act[p] = a; tx[p] = x; ty[p] = y; tcell[p] = y * q.cols + x;
+        a = (a < 0 || a > RW_TOGGLE) ? RW_NOOP : a;
+        const int d = s.ad[p], fw = a == RW_FORWARD ? 1 : 0;
+        int x = s.ax[p] + fw * ((d == RW_DRIGHT ? 1 : 0) - (d == RW_DLEFT ? 1 : 0));
+        int y = s.ay[p] + fw * ((d == RW_DOWN ? 1 : 0) - (d == RW_UP ? 1 : 0));
+        x = x < 0 ? 0 : (x > q.cols - 1 ? q.cols - 1 : x);  // Agent.req_location clamps at the walls
+        y = y < 0 ? 0 : (y > q.rows - 1 ? q.rows - 1 : y);
+        act[p] = a; tx[p] = x; ty[p] = y;
+        own[p] = s.ay[p] * q.cols + s.ax[p];
+        tcell[p] = y * q.cols + x;
         rew[p] = 0.0;
+    }
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        g_t[p] = grid.get(tcell[p]);
+        g_own[p] = grid.get(own[p]);
+    }
+    uint32_t nxt = 0;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        // a loaded agent cannot enter a cell with a standing shelf (one another agent carries may move away in time)
+        bool other_loaded = false;
+#pragma unroll
+        for (int o = 0; o < P; ++o) other_loaded = other_loaded | ((s.ax[o] == tx[p]) & (s.ay[o] == ty[p]) & (s.ac[o] != 0));
+        const bool blocked = (s.ac[p] != 0) & (tcell[p] != own[p]) & (g_t[p] != 0) & !other_loaded;
+        act[p] = blocked ? RW_NOOP : act[p];
+        tx[p] = blocked ? s.ax[p] : tx[p];
+        ty[p] = blocked ? s.ay[p] : ty[p];
+        tcell[p] = blocked ? own[p] : tcell[p];
     }
 #pragma unroll
     for (int p = 0; p < P; ++p) {
@@ -259,30 +278,30 @@ MARL_HD void rw_step(const RwParams& q, RwState<P>& s, const RwGrid& grid, const
     }
     const uint32_t committed = rw_resolve<P>(nxt, tcell);
     // moves of loaded agents: clear every vacated cell first, then occupy (trains of carriers)
+    bool carry_move[P];
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-        if (!((committed >> p) & 1u)) act[p] = RW_NOOP;  // only FORWARD requests can fail
-        if (act[p] == RW_FORWARD && s.ac[p] != 0 && tcell[p] != s.ay[p] * q.cols + s.ax[p]) grid.set(s.ay[p] * q.cols + s.ax[p], 0);
+        act[p] = ((committed >> p) & 1u) ? act[p] : RW_NOOP;  // only FORWARD requests can fail
+        carry_move[p] = (act[p] == RW_FORWARD) & (s.ac[p] != 0) & (tcell[p] != own[p]);
+        if (carry_move[p]) grid.set(own[p], 0);
     }
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-        const int a = act[p];
-        if (a == RW_FORWARD) {
-            s.ax[p] = tx[p]; s.ay[p] = ty[p];
-            if (s.ac[p] != 0) grid.set(tcell[p], s.ac[p]);
-        } else if (a == RW_LEFT) {  // clockwise order UP, RIGHT, DOWN, LEFT; LEFT turns against it
-            s.ad[p] = s.ad[p] == RW_UP ? RW_DLEFT : (s.ad[p] == RW_DLEFT ? RW_DOWN : (s.ad[p] == RW_DOWN ? RW_DRIGHT : RW_UP));
-        } else if (a == RW_RIGHT) {
-            s.ad[p] = s.ad[p] == RW_UP ? RW_DRIGHT : (s.ad[p] == RW_DRIGHT ? RW_DOWN : (s.ad[p] == RW_DOWN ? RW_DLEFT : RW_UP));
-        } else if (a == RW_TOGGLE) {
-            if (s.ac[p] == 0) {
-                s.ac[p] = grid.get(s.ay[p] * q.cols + s.ax[p]);
-            } else if (!rw_is_highway(q, s.ax[p], s.ay[p])) {
-                s.ac[p] = 0;
-                if (s.adel[p] && q.reward_type == RW_REWARD_TWO_STAGE) rew[p] += 0.5;
-                s.adel[p] = 0;
-            }
-        }
+        const int a = act[p], d = s.ad[p];
+        const bool fwd = a == RW_FORWARD;
+        if (fwd & (s.ac[p] != 0)) grid.set(tcell[p], s.ac[p]);
+        const int ax0 = s.ax[p], ay0 = s.ay[p];
+        s.ax[p] = fwd ? tx[p] : ax0;
+        s.ay[p] = fwd ? ty[p] : ay0;
+        // clockwise order UP, RIGHT, DOWN, LEFT; LEFT turns against it.  Direction codes: UP 0, DOWN 1, LEFT 2, RIGHT 3
+        const int left = (0x0132 >> (4 * d)) & 3, right = (0x1023 >> (4 * d)) & 3;
+        s.ad[p] = a == RW_LEFT ? left : (a == RW_RIGHT ? right : d);
+        const bool toggle = a == RW_TOGGLE;  // a toggling agent did not move: (ax0, ay0) is its cell, g_own its shelf byte
+        const bool pick = toggle & (s.ac[p] == 0);
+        const bool drop = toggle & (s.ac[p] != 0) & !rw_is_highway(q, ax0, ay0);
+        rew[p] += (drop & (s.adel[p] != 0) & (q.reward_type == RW_REWARD_TWO_STAGE)) ? 0.5 : 0.0;
+        s.adel[p] = drop ? 0 : s.adel[p];
+        s.ac[p] = pick ? g_own[p] : (drop ? 0 : s.ac[p]);
     }
     // deliveries at the two goal cells
     bool delivered = false;
@@ -421,6 +440,56 @@ MARL_HD float rw_obs_elem_word(const RwParams& q, const RwState<P>& s, int p, ui
 }
 
 
+
+// The fused collectors' route (round 4): the 63 window features of agent p as ONE bit mask - bit 7c + f = feature f of window cell
+// c, the order of the flattened observation after its 8 leading entries - so that a lane's element of a k-step is one bit-field
+// extract.  Built from the entities: every cell starts as "no agent, direction one-hot(0)" (bit 7c + 1), an agent inside the window
+// replaces that by (present, one-hot(direction)); the 9 shelf bytes are read UNCONDITIONALLY from clamped coordinates (nine
+// independent loads, one wait - a load under `if (in grid)` is a dependent round trip each) and masked afterwards.
+template <int P>
+MARL_HD uint64_t rw_obs_bits(const RwParams& q, const RwState<P>& s, const RwGrid& grid, const RwRequested<P>& rq, int p) {
+    const int x0 = rw_pick<P>(s.ax, p) - 1, y0 = rw_pick<P>(s.ay, p) - 1;
+    int shelf[9];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) {
+        const int x = x0 + c % 3, y = y0 + c / 3;
+        const int cx = x < 0 ? 0 : (x > q.cols - 1 ? q.cols - 1 : x), cy = y < 0 ? 0 : (y > q.rows - 1 ? q.rows - 1 : y);
+        shelf[c] = grid.get(cy * q.cols + cx);
+    }
+    uint64_t bits = 0;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) bits |= 2ull << (7 * c);
+#pragma unroll
+    for (int o = 0; o < P; ++o) {
+        const unsigned dx = (unsigned)(s.ax[o] - x0), dy = (unsigned)(s.ay[o] - y0);
+        const bool in = (dx < 3u) & (dy < 3u);
+        const int sh = in ? 7 * (int)(dy * 3 + dx) : 0;
+        // clear the default direction bit, then present + one-hot(direction) (direction 0 sets the same bit again)
+        bits = in ? ((bits & ~(2ull << sh)) | ((uint64_t)(1u | (2u << s.ad[o])) << sh)) : bits;
+    }
+    uint32_t lo = 0, hi = 0;  // shelf present (f = 5) and requested (f = 6): bits 7c + 5, 7c + 6 - never straddling bit 32
+#pragma unroll
+    for (int c = 0; c < 9; ++c) {
+        const int x = x0 + c % 3, y = y0 + c / 3;
+        const bool in = (x >= 0) & (y >= 0) & (x < q.cols) & (y < q.rows);
+        const int sf = in ? shelf[c] : 0;
+        const uint32_t two = (sf != 0 ? 1u : 0u) | ((uint32_t)rq.test(sf) << 1);  // shelf ids start at 1: bit 0 of the set is never set
+        if (7 * c + 5 < 32) lo |= two << ((7 * c + 5) & 31);
+        else hi |= two << ((7 * c + 5) & 31);
+    }
+    return bits | (uint64_t)lo | ((uint64_t)hi << 32);
+}
+
+// element d of agent p's observation from the feature mask (d any run-time value in [0, 71))
+template <int P>
+MARL_HD float rw_obs_elem_bits(const RwParams& q, const RwState<P>& s, int p, uint64_t bits, int d) {
+    if (d < 8) {
+        const int ax = rw_pick<P>(s.ax, p), ay = rw_pick<P>(s.ay, p);
+        const int v = d == 0 ? ax : (d == 1 ? ay : (d == 2 ? (rw_pick<P>(s.ac, p) != 0) : (d == 7 ? (int)rw_is_highway(q, ax, ay) : (rw_pick<P>(s.ad, p) == d - 3))));
+        return (float)v;
+    }
+    return (float)((bits >> (d - 8)) & 1ull);
+}
 
 // element d of agent p's flattened observation (Warehouse._make_obs, fast path):
 //   x, y, carrying, one-hot direction[4], on highway, then per window cell: agent present, one-hot direction[4]

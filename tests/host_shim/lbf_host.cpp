@@ -206,7 +206,10 @@ extern "C" int host_rw_obs_word_check(const HostRwCfg* c, const uint8_t* state) 
                 int code[9];                                                                                     \
                 rw_window(q, s, grid, a, code);                                                                  \
                 const uint64_t w = rw_window_word(q, s, grid, rq, a);                                            \
+                const uint64_t bits = rw_obs_bits(q, s, grid, rq, a);                                            \
                 for (int d = 0; d < RW_OBS_DIM; ++d) bad += rw_obs_elem(q, s, a, code, d) != rw_obs_elem_word(q, s, a, w, d); \
+                for (int d = 0; d < RW_OBS_DIM; ++d) bad += rw_obs_elem(q, s, a, code, d) != rw_obs_elem_bits(q, s, a, bits, d); \
+                bad += (bits >> 63) != 0;                                                                        \
             }                                                                                                    \
         }                                                                                                        \
         return bad;                                                                                              \
@@ -218,7 +221,7 @@ extern "C" int host_rw_obs_word_check(const HostRwCfg* c, const uint8_t* state) 
 
 // the movement-conflict rule alone: edges as (start cell, target cell) per agent -> committed-agent bit mask
 extern "C" int host_rw_resolve(int P, const int32_t* start, const int32_t* target) {
-    uint64_t nxt = 0;
+    uint32_t nxt = 0;
     int tc[8];
     for (int p = 0; p < P; ++p) {
         int o = 0xF;
