@@ -91,6 +91,35 @@ __device__ __forceinline__ int sample_rows(const f4& logits, int lane, float u) 
 template <int P>
 constexpr int acol_max_nw() { return P % 4 == 0 ? 4 : (P % 2 == 0 ? 2 : 1); }
 
+// Transposed batch stores (round 4).  A lane holds elements 4 ks + g of ITS env's observation, so a direct store instruction is 64
+// separate 4-byte writes into 16 rows 4 * P * D bytes apart - on the warehouse (D = 71: 18 such instructions per step and wave) the
+// stores were 20 % of a rollout step.  With a [16 envs][D] tile per wave in LDS (the exact image of the 16 consecutive agent-p rows
+// of the batch), lane l then stores elements l, l + 64, ... of the tile: 64 consecutive floats of one or two rows per instruction.
+// The (row, element) of every such store is the same at every step: byte offsets precomputed once, tile reads and writes on
+// immediate offsets.  Used where the rows are wide enough to pay (D >= 32) and the LDS has the room next to resident packs.
+template <int D>
+struct ObsTile {
+    static constexpr int ELEMS = 16 * D, NI = (ELEMS + 63) / 64, BYTES = ELEMS * 4;
+};
+
+template <class ENV, int H, bool OID, int NW>
+constexpr size_t acol_lds_fixed() {  // packs (when they live in LDS) + the env's own bytes: what the kernel used before the tiles
+    constexpr int P = ENV::P, D = ENV::D0 + (OID ? P : 0);
+    using PP = PackPlan<MlpShape<D, H, ENV::A>, P, ENV::LDS_MAX>;
+    return ((NW > 1 && !(PP::RESIDENT || PP::A3REG)) ? 0 : PP::LDS_BYTES) + ENV::LDS_MAX;
+}
+
+template <class ENV, int H, bool OID, int NW>
+constexpr bool acol_tstore() {
+    constexpr int D = ENV::D0 + (OID ? ENV::P : 0);
+    return D >= 32 && acol_lds_fixed<ENV, H, OID, NW>() + 4 * (size_t)ObsTile<D>::BYTES + 4608 <= 160u * 1024u;  // 4608: the static action-swap buffer
+}
+
+__device__ __forceinline__ void wave_lds_fence_acol() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 template <class ENV, int H, bool OID, int NW>
 __global__ __launch_bounds__(ACOL_BLOCK) void ac_collect_kernel(typename ENV::Params q, const float* __restrict__ actor /* pre-packed [P][NFWD] */, uint32_t round, int T,
                                                                 int proper_term, float* __restrict__ b_obs,
@@ -118,6 +147,20 @@ __global__ __launch_bounds__(ACOL_BLOCK) void ac_collect_kernel(typename ENV::Pa
     const int t_first = ghost ? gh.t_start[nn] : 0;
     uint32_t gen = ghost ? 1u : 0u;  // episode generation of the env inside this rollout: reset stream 2 * round + gen
     constexpr int K = P / NW;  // a wave's own agents: p = aw + k * NW, k < K (NW = 1: every agent, p = k)
+    using OT = ObsTile<D>;
+    constexpr bool TSTORE = acol_tstore<ENV, H, OID, NW>();
+    // the wave's tile behind the packs and the env's bytes; fast path only for blocks of 16 envs inside the batch (wave-uniform)
+    float* tile = reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(lds) + (FROM_GLOBAL ? 0 : PP::LDS_BYTES) + ENV::LDS_MAX) + (size_t)wave * OT::ELEMS;
+    const int n0 = (blockIdx.x * (4 / NW) + blk) * 16;
+    const bool tstore = TSTORE && !ghost && n0 + 16 <= N;
+    int t_off[TSTORE ? OT::NI : 1];  // float offset of tile element 64 i + lane inside the block's 16 batch rows (agent 0)
+    if constexpr (TSTORE) {
+#pragma unroll
+        for (int i = 0; i < OT::NI; ++i) {
+            const int idx = 64 * i + lane, e = idx / D;
+            t_off[i] = e * (P * D) + (idx - e * D);
+        }
+    }
     f4 a3[PP::A3REG ? K : 1][S::MT];  // output-layer operands of the wave's agents, when the full packs do not fit the LDS
     if (RESIDENT) {
         for (int p = 0; p < P; ++p)
@@ -136,11 +179,28 @@ __global__ __launch_bounds__(ACOL_BLOCK) void ac_collect_kernel(typename ENV::Pa
     // batch_obs[t][n][p*D + d]
     auto obs_row = [&](int t) { return b_obs + ((size_t)t * N + env_id) * (P * D); };
     float x[K][S::KS1];  // the wave observes, forwards, samples and stores for its own agents
+    // rows t of the block's 16 envs for agent p through the wave's tile: `keep` = this env's row is the observation (else zeros)
+    auto store_rows_t = [&](int t, int p, const float (&xv)[S::KS1], bool keep) {
+        wave_lds_fence_acol();  // the previous use of the tile has been read out
+#pragma unroll
+        for (int ks = 0; ks < S::KS1; ++ks)
+            if (4 * ks < D) {
+                if (4 * ks + 3 < D || 4 * ks + g < D) tile[j * D + 4 * ks + g] = keep ? xv[ks] : 0.f;
+            }
+        wave_lds_fence_acol();
+        float* dst = b_obs + ((size_t)t * N + n0) * (P * D) + p * D;
+#pragma unroll
+        for (int i = 0; i < OT::NI; ++i) {
+            if (64 * i + 63 < OT::ELEMS || 64 * i + lane < OT::ELEMS) dst[t_off[TSTORE ? i : 0]] = tile[64 * i + lane];
+        }
+    };
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const int p = aw + k * NW;
         ENV::template observe<S::KS1, OID>(q, s, ctx, p, g, x[k]);
-        if (valid && !ghost) {
+        if (tstore) {
+            store_rows_t(0, p, x[k], true);
+        } else if (valid && !ghost) {
 #pragma unroll
             for (int ks = 0; ks < S::KS1; ++ks)
                 if (4 * ks + g < D) obs_row(0)[p * D + 4 * ks + g] = x[k][ks];
@@ -199,6 +259,10 @@ __global__ __launch_bounds__(ACOL_BLOCK) void ac_collect_kernel(typename ENV::Pa
             for (int p = 0; p < P; ++p) act[p] = sa[p * 16 + j];
         }
         ACOL_TS(2)
+        const bool ran = running;
+        float rw_own[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) rw_own[k] = 0.f;
         if (running) {
             double raw[P];
             float rw[P];
@@ -236,7 +300,9 @@ __global__ __launch_bounds__(ACOL_BLOCK) void ac_collect_kernel(typename ENV::Pa
                 const int p = aw + k * NW;
                 ENV::template observe<S::KS1, OID>(q, s, ctx, p, g, x[k]);
                 ACOL_TS(5)
+                rw_own[k] = pick_agent<P>(rw, p);
                 if (ghost) continue;
+                if (tstore) continue;  // the rows of all 16 envs of the block go out together below
 #pragma unroll
                 for (int ks = 0; ks < S::KS1; ++ks)
                     if (4 * ks + g < D) obs_row(t + 1)[p * D + 4 * ks + g] = x[k][ks];
@@ -258,7 +324,7 @@ __global__ __launch_bounds__(ACOL_BLOCK) void ac_collect_kernel(typename ENV::Pa
                     atomicMax(t_max, len);
                 }
             }
-        } else if (valid && !ghost) {
+        } else if (valid && !ghost && !tstore) {
             // rows of an env that is no longer running stay zero, as in the reference's freshly allocated batch
 #pragma unroll
             for (int k = 0; k < K; ++k) {
@@ -272,6 +338,21 @@ __global__ __launch_bounds__(ACOL_BLOCK) void ac_collect_kernel(typename ENV::Pa
                 }
             }
             if (lead) {
+                b_done[(size_t)(t + 1) * N + n] = 0;
+                b_filled[(size_t)t * N + n] = 0.f;
+            }
+        }
+        if (tstore) {  // wave-uniform: rows t + 1 of the block's 16 envs (zeros for the envs that were not running), actions, rewards
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const int p = aw + k * NW;
+                store_rows_t(t + 1, p, x[k], ran);
+                if (g == 0) {
+                    b_act[((size_t)t * N + n) * P + p] = ran ? own[k] : 0;
+                    b_rew[((size_t)t * N + n) * P + p] = ran ? rw_own[k] : 0.f;
+                }
+            }
+            if (lead && !ran) {
                 b_done[(size_t)(t + 1) * N + n] = 0;
                 b_filled[(size_t)t * N + n] = 0.f;
             }
@@ -292,8 +373,9 @@ int launch_ac_collect_nw(const typename ENV::Params& q, const float* packs, uint
     constexpr int P = ENV::P, D = ENV::D0 + (OID ? P : 0);
     using S = MlpShape<D, H, ENV::A>;
     using PP = PackPlan<S, P, ENV::LDS_MAX>;
-    // packs read from global memory (NW > 1, not resident): the LDS holds the env's own bytes only
-    const size_t lds_bytes = ((NW > 1 && !(PP::RESIDENT || PP::A3REG)) ? 0 : PP::LDS_BYTES) + ENV::lds_bytes(q);
+    // packs read from global memory (NW > 1, not resident): the LDS holds the env's own bytes only; then the waves' store tiles
+    const size_t lds_bytes = acol_tstore<ENV, H, OID, NW>() ? acol_lds_fixed<ENV, H, OID, NW>() + 4 * (size_t)ObsTile<D>::BYTES
+                                                            : ((NW > 1 && !(PP::RESIDENT || PP::A3REG)) ? 0 : PP::LDS_BYTES) + ENV::lds_bytes(q);
     static LdsAttr attr_set;
     if (attr_set.need(lds_bytes)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ac_collect_kernel<ENV, H, OID, NW>),
