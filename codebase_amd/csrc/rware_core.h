@@ -51,10 +51,15 @@ struct RwGrid {
 };
 
 MARL_HD bool rw_is_highway(const RwParams& q, int x, int y) {
-    const int m = q.column_height + 1;  // y % m == 0 for the at most 6 multiples a validated layout has (rows = m * shelf_rows + 2, shelf_rows <= 5)
-    const bool cross = y == 0 || y == m || y == 2 * m || y == 3 * m || y == 4 * m || y == 5 * m;
-    return x % 3 == 0 || cross || y == q.rows - 1 ||
-           (y > q.rows - (q.column_height + 3) && (x == q.cols / 2 - 1 || x == q.cols / 2));
+    // x % 3 == 0 as one bit of a constant (cols <= 16 in every registered layout; the modulo is a quarter-rate multiply), the cross
+    // aisles y % (column_height + 1) == 0 and the bottom row as one bit of a mask that only depends on the layout (wave-uniform:
+    // scalar registers, hoisted out of the rollout loop): rows = m * shelf_rows + 2 <= 47 with shelf_rows <= 5
+    const int m = q.column_height + 1;
+    const uint64_t rows_hw = 1ull | (1ull << m) | (1ull << (2 * m < 63 ? 2 * m : 63)) | (1ull << (3 * m < 63 ? 3 * m : 63)) |
+                             (1ull << (4 * m < 63 ? 4 * m : 63)) | (1ull << (5 * m < 63 ? 5 * m : 63)) | (1ull << (q.rows - 1));
+    const bool col3 = x < 32 ? ((0x49249249u >> x) & 1u) != 0 : x % 3 == 0;
+    return col3 | (((rows_hw >> y) & 1ull) != 0) |
+           ((y > q.rows - (q.column_height + 3)) & ((x == q.cols / 2 - 1) | (x == q.cols / 2)));
 }
 
 MARL_HD int rw_count_shelves(const RwParams& q) {
@@ -175,13 +180,22 @@ template <int P>
 MARL_HD uint32_t rw_resolve(uint32_t nxt, const int* tcell) {
     static_assert(P <= 8, "nibble tables sized for <= 8 agents");
     uint32_t committed = 0, in_tree = 0;
+    // height[j] = longest chain of feeders behind agent j.  It is only ever read for agents of in-trees (below), where it equals the
+    // longest walk ending at j - so it is gathered on the chain walks themselves: the walk from i reaches its k-th successor after k
+    // moves (upstream's fixed-point passes give the same numbers on in-trees; on cycles they differ, and nobody looks)
+    uint32_t height = 0;
 #pragma unroll
     for (int i = 0; i < P; ++i) {
         // follow the chain from i: back at i = on a cycle, whose length decides (a 2-cycle is a swap: nobody moves);
         // at a free cell = i sits in an in-tree; neither = i feeds a cycle it is not on (and cannot move)
         int j = rw_nib(nxt, i), n = 1;
+        const bool self = j == i;  // stationary: feeds nobody
 #pragma unroll
         for (int it = 0; it < P; ++it) {
+            const bool at_agent = (j != 0xF) & !self & (j != i);
+            const int jj = at_agent ? j : 0;
+            const int hj = rw_nib(height, jj);
+            height = (at_agent & (it + 1 > hj)) ? rw_set_nib(height, jj, it + 1) : height;
             const bool go = j != 0xF && j != i;
             const int nj = rw_nib(nxt, go ? j : 0);
             j = go ? nj : j;
@@ -189,18 +203,6 @@ MARL_HD uint32_t rw_resolve(uint32_t nxt, const int* tcell) {
         }
         committed |= (j == i && n != 2) ? 1u << i : 0u;
         in_tree |= (j == 0xF) ? 1u << i : 0u;
-    }
-    uint32_t height = 0;  // longest chain of feeders behind each agent
-#pragma unroll
-    for (int pass = 0; pass < P - 1; ++pass) {
-#pragma unroll
-        for (int i = 0; i < P; ++i) {
-            const int t = rw_nib(nxt, i);
-            const bool feeds = t != 0xF && t != i;
-            const int tt = feeds ? t : 0;
-            const int h = rw_nib(height, i) + 1, ht = rw_nib(height, tt);
-            height = (feeds && h > ht && h <= P) ? rw_set_nib(height, tt, h) : height;
-        }
     }
     // dag_longest_path walked back from the free cell = at every cell the feeder with the longest chain behind it wins
     // (lowest index on ties), and a winner moves iff its target is free or the agent on it moves
@@ -262,19 +264,16 @@ MARL_HD void rw_step(const RwParams& q, RwState<P>& s, const RwGrid& grid, const
 #pragma unroll
     for (int p = 0; p < P; ++p) {
         // a loaded agent cannot enter a cell with a standing shelf (one another agent carries may move away in time)
-        bool other_loaded = false;
+        const int o = rw_agent_at(s, tx[p], ty[p]);  // the agent on the requested cell (itself when it stays), -1 = nobody
+        int oc = 0;
 #pragma unroll
-        for (int o = 0; o < P; ++o) other_loaded = other_loaded | ((s.ax[o] == tx[p]) & (s.ay[o] == ty[p]) & (s.ac[o] != 0));
-        const bool blocked = (s.ac[p] != 0) & (tcell[p] != own[p]) & (g_t[p] != 0) & !other_loaded;
+        for (int k = 0; k < P; ++k) oc = k == o ? s.ac[k] : oc;
+        const bool blocked = (s.ac[p] != 0) & (tcell[p] != own[p]) & (g_t[p] != 0) & (oc == 0);
         act[p] = blocked ? RW_NOOP : act[p];
         tx[p] = blocked ? s.ax[p] : tx[p];
         ty[p] = blocked ? s.ay[p] : ty[p];
         tcell[p] = blocked ? own[p] : tcell[p];
-    }
-#pragma unroll
-    for (int p = 0; p < P; ++p) {
-        const int o = rw_agent_at(s, tx[p], ty[p]);
-        nxt = rw_set_nib(nxt, p, o < 0 ? 0xF : o);
+        nxt = rw_set_nib(nxt, p, blocked ? p : (o < 0 ? 0xF : o));
     }
     const uint32_t committed = rw_resolve<P>(nxt, tcell);
     // moves of loaded agents: clear every vacated cell first, then occupy (trains of carriers)
