@@ -348,7 +348,7 @@ def bench_ac(args, rank, world, dist):
     t_max = torch.zeros(1, dtype=torch.int32, device=dev)
     steps_dev = torch.zeros((), dtype=torch.int64, device=dev)
     ref_steps = torch.zeros((), dtype=torch.int64, device=dev)
-    sync_grad = GradSync(dist) if dist is not None else None
+    sync_grad = GradSync(dist, max_floats=model.updater.grad.numel()) if dist is not None else None
     state = {"round": 0, "step": 0}
 
     if args.rnn:  # recurrent actors: the rollout runs through the modular entry points (hidden state carried between steps)

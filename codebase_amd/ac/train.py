@@ -183,7 +183,7 @@ def main(envs, eval_env, logger, time_limit, **cfg):
     logger.watch(model)
     sync = None
     if dist is not None:
-        sync = GradSync(dist)
+        sync = GradSync(dist, max_floats=model.updater.grad.numel())  # the in-library peer-to-peer exchange where it can be set up
         dist.broadcast(model.updater.block, 0)  # identical replicas (the seeded init already agrees; this makes it unconditional)
         dist.broadcast(model.updater.target_critic, 0)
         model.updater.attach_exchange(lambda t: dist.all_reduce(t))  # standardise_returns: global batch moments

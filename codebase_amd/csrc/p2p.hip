@@ -1,0 +1,200 @@
+// In-library gradient exchange for the data-parallel learner: a one-shot all-reduce (SUM) over peer-mapped buffers, ONE kernel per
+// update, no host hop, no collective library launch.  SURVEY.md 8(e): the path's only exchange is the flat gradient (44.6 KB at
+// 2 agents x 64-64, 1 MB at most), latency-bound on xGMI - a ring or tree of a collective library pays a launch plus several link
+// latencies per update; with every GPU of the node one xGMI hop away, each rank instead PUBLISHES its gradient in its own memory and
+// READS the other G - 1 directly.
+//
+// Per rank: one uncached (fine-grained) device allocation [flags | slot 0 | slot 1], exported as a hipIpcMemHandle and mapped by
+// every peer (marlhip_p2p_create / _connect; the handles travel through whatever the host side has - torch.distributed's object
+// all-gather in codebase_amd/parallel.py).  marlhip_p2p_allreduce(ctx, grad, n, stream) - which has the marlhip_exchange_fn
+// signature, so marlhip_idqn_update_n_dist takes it directly as its callback - launches one kernel in which block b
+//   1. copies its chunk of `grad` into this rank's slot (epoch parity), fences, and raises this rank's flag of chunk b to the epoch;
+//   2. waits until every peer's flag of chunk b has reached the epoch (system-scope loads; bounded: a peer that never arrives
+//      sets the error word instead of hanging the GPU);
+//   3. sums chunk b over the ranks IN RANK ORDER, from the slots (its own included), into `grad`.
+// Every rank forms the same sums in the same order: replicas stay bitwise identical, as with the collective.  Two slots suffice: a
+// rank can enter update u + 1 (other slot) while a peer still reads its slot of update u, but cannot finish the wait of u + 1 before
+// that peer has entered u + 1 itself, i.e. has left u.  Nothing here exists in the reference (one process, no collective).
+#include <vector>
+
+#include "common.h"
+
+namespace marl {
+
+constexpr int P2P_MAX_WORLD = 16;
+constexpr int P2P_CHUNK = 1024;          // floats per block (256 threads x float4)
+constexpr int P2P_FLAG_BYTES = 1 << 16;  // [2 parities][max chunks] uint32 epochs + error word, padded
+
+struct P2pPeers {
+    const float* slot[P2P_MAX_WORLD];      // peer r's data area (both slots)
+    const uint32_t* flags[P2P_MAX_WORLD];  // peer r's flags
+};
+
+struct P2pState {
+    int rank, world;
+    int64_t max_floats;
+    int max_chunks;
+    void* local;                 // this rank's allocation
+    void* mapped[P2P_MAX_WORLD];  // peers' allocations as mapped here (nullptr for self)
+    P2pPeers peers;
+    uint32_t epoch;
+    bool connected;
+};
+
+__device__ __forceinline__ uint32_t ld_sys(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM); }
+
+// grad: this rank's gradient in, the sum over the ranks out.  flags layout: [parity][chunk], error word at index 2 * max_chunks.
+static __global__ __launch_bounds__(256) void p2p_allreduce_kernel(float* __restrict__ grad, int64_t n, P2pPeers peers, int rank, int world,
+                                                                   int64_t slot_floats, int max_chunks, uint32_t epoch, long long timeout_ticks) {
+    const int b = blockIdx.x, par = (int)(epoch & 1u);
+    const int64_t i0 = (int64_t)b * P2P_CHUNK + 4 * threadIdx.x;
+    float* mine = const_cast<float*>(peers.slot[rank]) + (int64_t)par * slot_floats;
+    uint32_t* my_flags = const_cast<uint32_t*>(peers.flags[rank]);
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (i0 + k < n) {
+            v[k] = grad[i0 + k];
+            __hip_atomic_store(mine + i0 + k, v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(my_flags + par * max_chunks + b, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    // wait for the peers' chunk b (one lane per peer polls; epochs only grow, so ">= epoch" with wrap-safe arithmetic)
+    __shared__ int s_late;
+    if (threadIdx.x == 0) s_late = 0;
+    __syncthreads();
+    if (threadIdx.x < world && threadIdx.x != rank) {
+        const uint32_t* f = peers.flags[threadIdx.x] + par * max_chunks + b;
+        const long long t0 = wall_clock64();
+        while ((int32_t)(ld_sys(f) - epoch) < 0) {
+            if (wall_clock64() - t0 > timeout_ticks) {
+                s_late = 1;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+    }
+    __syncthreads();
+    if (s_late) {  // a peer never published: leave the local gradient, raise the error word (read by marlhip_p2p_status)
+        if (threadIdx.x == 0) __hip_atomic_store(my_flags + 2 * max_chunks, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < world; ++r) {  // rank order on every rank: the same float sums everywhere
+        const float* src = peers.slot[r] + (int64_t)par * slot_floats;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (i0 + k < n) {
+                const float x = r == rank ? v[k] : __hip_atomic_load(src + i0 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                acc[k] = r == 0 ? x : acc[k] + x;
+            }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (i0 + k < n) grad[i0 + k] = acc[k];
+}
+
+}  // namespace marl
+
+using namespace marl;
+
+extern "C" int marlhip_p2p_handle_bytes(void) { return (int)sizeof(hipIpcMemHandle_t); }
+
+// One allocation per rank: [flags (64 KB) | slot 0 | slot 1], uncached so that stores and the system-scope loads of the peers meet in
+// memory, not in a cache.  `handle_out` receives the hipIpcMemHandle (marlhip_p2p_handle_bytes() bytes) to hand to the peers.
+extern "C" int marlhip_p2p_create(int32_t rank, int32_t world, int64_t max_floats, void** state_out, void* handle_out) {
+    MARL_REQUIRE(state_out && handle_out, "p2p_create: NULL pointer");
+    MARL_REQUIRE(world >= 1 && world <= P2P_MAX_WORLD && rank >= 0 && rank < world, "p2p_create: rank %d / world %d (at most %d ranks)", rank, world,
+                 P2P_MAX_WORLD);
+    MARL_REQUIRE(max_floats > 0, "p2p_create: max_floats must be > 0");
+    const int64_t slot = (max_floats + P2P_CHUNK - 1) / P2P_CHUNK * P2P_CHUNK;
+    const int max_chunks = (int)(slot / P2P_CHUNK);
+    MARL_REQUIRE((2 * (int64_t)max_chunks + 1) * 4 <= P2P_FLAG_BYTES, "p2p_create: %lld floats need more chunk flags than the flag area holds", (long long)max_floats);
+    P2pState* st = new P2pState();
+    st->rank = rank; st->world = world; st->max_floats = slot; st->max_chunks = max_chunks; st->epoch = 0; st->connected = false;
+    for (int r = 0; r < P2P_MAX_WORLD; ++r) { st->mapped[r] = nullptr; st->peers.slot[r] = nullptr; st->peers.flags[r] = nullptr; }
+    const size_t bytes = (size_t)P2P_FLAG_BYTES + 2 * (size_t)slot * sizeof(float);
+    hipError_t e = hipExtMallocWithFlags(&st->local, bytes, hipDeviceMallocUncached);
+    if (e != hipSuccess) {
+        set_error("p2p_create: hipExtMallocWithFlags(%zu bytes, uncached): %s", bytes, hipGetErrorString(e));
+        delete st;
+        return -2;
+    }
+    (void)hipMemset(st->local, 0, bytes);
+    e = hipIpcGetMemHandle(reinterpret_cast<hipIpcMemHandle_t*>(handle_out), st->local);
+    if (e != hipSuccess) {
+        set_error("p2p_create: hipIpcGetMemHandle: %s (HSA_ENABLE_IPC_MODE_LEGACY=0 must be exported)", hipGetErrorString(e));
+        (void)hipFree(st->local);
+        delete st;
+        return -2;
+    }
+    *state_out = st;
+    return 0;
+}
+
+// handles: world x marlhip_p2p_handle_bytes() bytes, rank-major (this rank's own entry is ignored).  Every rank calls this after all
+// ranks have created theirs; the peers' allocations are mapped into this process (peer access is enabled on demand).
+extern "C" int marlhip_p2p_connect(void* state, const void* handles) {
+    P2pState* st = static_cast<P2pState*>(state);
+    MARL_REQUIRE(st && handles, "p2p_connect: NULL pointer");
+    const hipIpcMemHandle_t* h = static_cast<const hipIpcMemHandle_t*>(handles);
+    for (int r = 0; r < st->world; ++r) {
+        void* base = st->local;
+        if (r != st->rank) {
+            const hipError_t e = hipIpcOpenMemHandle(&base, h[r], hipIpcMemLazyEnablePeerAccess);
+            if (e != hipSuccess) {
+                set_error("p2p_connect: hipIpcOpenMemHandle of rank %d's buffer: %s", r, hipGetErrorString(e));
+                return -2;
+            }
+            st->mapped[r] = base;
+        }
+        st->peers.flags[r] = reinterpret_cast<const uint32_t*>(base);
+        st->peers.slot[r] = reinterpret_cast<const float*>(static_cast<const char*>(base) + P2P_FLAG_BYTES);
+    }
+    st->connected = true;
+    return 0;
+}
+
+// marlhip_exchange_fn: ctx = the state of marlhip_p2p_create.  Leaves the SUM over the ranks in grad; enqueues one kernel on
+// `stream`, never synchronises.  Every rank must call it the same number of times with the same count (the epoch is the call count).
+extern "C" int marlhip_p2p_allreduce(void* ctx, float* grad, int64_t count, void* stream) {
+    P2pState* st = static_cast<P2pState*>(ctx);
+    MARL_REQUIRE(st && grad, "p2p_allreduce: NULL pointer");
+    MARL_REQUIRE(st->connected, "p2p_allreduce: marlhip_p2p_connect has not run");
+    MARL_REQUIRE(count > 0 && count <= st->max_floats, "p2p_allreduce: %lld floats, the buffers hold %lld", (long long)count, (long long)st->max_floats);
+    st->epoch += 1;
+    const int chunks = (int)((count + P2P_CHUNK - 1) / P2P_CHUNK);
+    static const long long timeout_ticks = [] {  // wall_clock64 counts at 100 MHz; default 5 s, MARLHIP_P2P_TIMEOUT_MS overrides
+        const char* v = getenv("MARLHIP_P2P_TIMEOUT_MS");
+        return (long long)((v ? atof(v) : 5000.0) * 1e5);
+    }();
+    hipLaunchKernelGGL(p2p_allreduce_kernel, dim3(chunks), dim3(256), 0, (hipStream_t)stream, grad, count, st->peers, st->rank, st->world,
+                       st->max_floats, st->max_chunks, st->epoch, timeout_ticks);
+    MARL_CHECK_LAUNCH("p2p_allreduce_kernel");
+    return 0;
+}
+
+// 0 = every exchange so far saw all its peers; 1 = some wait ran into the timeout (the sums of that call are not valid).
+// Synchronises with the device (a 4-byte read of the error word): for tests and end-of-run checks, not for the hot loop.
+extern "C" int marlhip_p2p_status(void* state) {
+    P2pState* st = static_cast<P2pState*>(state);
+    MARL_REQUIRE(st, "p2p_status: NULL pointer");
+    uint32_t err = 0;
+    const hipError_t e = hipMemcpy(&err, static_cast<const uint32_t*>(st->local) + 2 * st->max_chunks, sizeof(err), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) {
+        set_error("p2p_status: %s", hipGetErrorString(e));
+        return -2;
+    }
+    return err ? 1 : 0;
+}
+
+extern "C" int marlhip_p2p_destroy(void* state) {
+    P2pState* st = static_cast<P2pState*>(state);
+    if (st == nullptr) return 0;
+    for (int r = 0; r < st->world; ++r)
+        if (st->mapped[r] != nullptr) (void)hipIpcCloseMemHandle(st->mapped[r]);
+    if (st->local != nullptr) (void)hipFree(st->local);
+    delete st;
+    return 0;
+}

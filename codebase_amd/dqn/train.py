@@ -164,7 +164,8 @@ class VectorisedIDQN:
         from ..parallel import GradSync
 
         if getattr(self, "_sync", None) is None:
-            self._sync = GradSync(self.dist)  # all-reduce(SUM) over RCCL/xGMI; clip+Adam applies 1/world
+            # all-reduce(SUM): the in-library peer-to-peer exchange where it can be set up, else RCCL / gloo; clip+Adam applies 1/world
+            self._sync = GradSync(self.dist, max_floats=grad.numel())
         self._sync(grad)
 
     def _collect_recurrent(self, cfg, epsilon, round_idx, replay, slot_base, fin_return, fin_length):
@@ -218,7 +219,7 @@ class VectorisedIDQN:
                 if self.dist is not None:
                     from ..parallel import GradSync
 
-                    self._sync = GradSync(self.dist)
+                    self._sync = GradSync(self.dist, max_floats=m.updater.grad.numel())
             length = min(self.rounds * self.N, self.capacity)
             m.updates, m.last_target_update = self._fused.run(self.U, length, rank_sample_seed(self.seed, self.rank), self.sample_counter,
                                                               m.updates, m.last_target_update,

@@ -766,6 +766,11 @@ class FusedLearner:
             check(lib.marlhip_idqn_update_n(ctypes.byref(self.c), int(n_updates), int(length), int(seed) & (2**64 - 1),
                                             int(counter0) & 0xFFFFFFFF, ctypes.byref(step), ctypes.byref(upd), ctypes.byref(last),
                                             _stream()), "idqn_update_n")
+        elif getattr(grad_sync, "c_fn", None) is not None:
+            # the in-library exchange (parallel.P2PExchange -> marlhip_p2p_allreduce): a C function pointer, the loop never leaves the library
+            check(lib.marlhip_idqn_update_n_dist(ctypes.byref(self.c), int(n_updates), int(length), int(seed) & (2**64 - 1),
+                                                 int(counter0) & 0xFFFFFFFF, ctypes.byref(step), ctypes.byref(upd), ctypes.byref(last),
+                                                 grad_sync.c_fn, grad_sync.c_ctx, int(world), _stream()), "idqn_update_n_dist")
         else:
             ex = getattr(self, "_exchange", None)
             if ex is None or ex.reduce is not grad_sync:

@@ -63,15 +63,119 @@ def gather_stack(dist, t):
     return out
 
 
-class GradSync:
-    """all-reduce(SUM) of the flat gradient; `scale` is what clip+Adam must multiply by (1/world)."""
+class P2PExchange:
+    """The in-library exchange (csrc/p2p.hip, marlhip_p2p_*): every rank publishes its gradient in an IPC-shared buffer of its own and
+    sums all ranks' buffers in rank order inside ONE kernel - no collective-library launch, no host hop.  `c_fn` / `c_ctx` are what
+    marlhip_idqn_update_n_dist takes as its exchange callback (a C function pointer: the update loop never re-enters Python);
+    calling the object all-reduces a tensor from the host side (one ctypes call).  torch.distributed only carries the 64-byte
+    handles once, at construction.  Build with `try_create`: every rank runs the same sequence of collectives there whatever
+    fails locally, and all ranks end up with the exchange or all without."""
 
-    def __init__(self, dist):
+    def __init__(self, lib, state, handles, rank, world, max_floats):
+        import ctypes
+
+        self.lib, self.state, self._handles = lib, state, handles
+        self.rank, self.world, self.max_floats = rank, world, int(max_floats)
+        self.c_fn = ctypes.cast(lib.marlhip_p2p_allreduce, ctypes.c_void_p)
+        self.c_ctx = self.state
+
+    def __call__(self, t):
+        from ._lib import check
+
+        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() <= self.max_floats
+        check(self.lib.marlhip_p2p_allreduce(self.state, t.data_ptr(), t.numel(), torch.cuda.current_stream().cuda_stream), "p2p_allreduce")
+        return t
+
+    def status(self):
+        """0 = every exchange saw all its peers (synchronises with the device)"""
+        return int(self.lib.marlhip_p2p_status(self.state))
+
+    def close(self):
+        if getattr(self, "state", None):
+            self.lib.marlhip_p2p_destroy(self.state)
+            self.state = None
+
+    @staticmethod
+    def try_create(dist, max_floats):
+        """the exchange, checked against torch.distributed's all-reduce on a test vector - or None (with the reason logged) when the
+        buffers cannot be shared on this system: the caller then keeps the collective"""
+        import ctypes
+        import logging
+
+        from ._lib import last_error, lib
+
+        log = logging.getLogger(__name__)
+        rank, world = dist.get_rank(), dist.get_world_size()
+
+        def everyone(ok):  # the same answer on every rank
+            votes = [None] * world
+            dist.all_gather_object(votes, bool(ok))
+            return all(votes)
+
+        hb = lib.marlhip_p2p_handle_bytes()
+        mine = ctypes.create_string_buffer(hb)
+        state = ctypes.c_void_p()
+        why = None
+        if lib.marlhip_p2p_create(rank, world, int(max_floats), ctypes.byref(state), mine) != 0:
+            why, state = last_error(), ctypes.c_void_p()
+        handles = [None] * world
+        dist.all_gather_object(handles, bytes(mine.raw) if why is None else None)
+        ok = why is None and all(h is not None for h in handles)
+        packed = None
+        if ok:
+            packed = ctypes.create_string_buffer(b"".join(handles), hb * world)
+            if lib.marlhip_p2p_connect(state, packed) != 0:
+                why, ok = last_error(), False
+        if not everyone(ok):
+            if why:
+                log.warning("marlhip p2p exchange not available on rank %d (%s); keeping torch.distributed's all-reduce", rank, why)
+            if state:
+                lib.marlhip_p2p_destroy(state)
+            return None
+        ex = P2PExchange(lib, state, packed, rank, world, max_floats)
+        n = min(int(max_floats), 5000)
+        g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+        x = torch.randn(n, generator=g).cuda()
+        ref = x.clone()
+        dist.all_reduce(ref)
+        good = False
+        try:
+            ex(x)
+            torch.cuda.synchronize()
+            good = ex.status() == 0 and bool(torch.allclose(x, ref, rtol=1e-5, atol=1e-5))
+        except Exception as e:  # noqa: BLE001 - "not available", never a broken run
+            why = str(e)
+        if everyone(good):
+            return ex
+        log.warning("marlhip p2p exchange: self-test failed on some rank (%s); keeping torch.distributed's all-reduce", why or "sum mismatch / peer timeout")
+        ex.close()
+        return None
+
+
+class GradSync:
+    """all-reduce(SUM) of the flat gradient; `scale` is what clip+Adam must multiply by (1/world).
+    max_floats > 0 on GPU ranks: the in-library peer-to-peer exchange (P2PExchange) when it can be set up and passes its self-test
+    (MARLHIP_P2P=0 keeps torch.distributed's collective: backend nccl == RCCL, gloo in the CPU tests)."""
+
+    def __init__(self, dist, max_floats=0):
         self.dist = dist
         self.world = dist.get_world_size() if dist is not None else 1
         self.scale = 1.0 / self.world
+        self.p2p = None
+        if dist is not None and max_floats > 0 and torch.cuda.is_available() and os.environ.get("MARLHIP_P2P", "1") != "0":
+            self.p2p = P2PExchange.try_create(dist, max_floats)
+        # what the library's n-updates loop takes instead of a Python callback (hip.FusedLearner.run)
+        self.c_fn = self.p2p.c_fn if self.p2p is not None else None
+        self.c_ctx = self.p2p.c_ctx if self.p2p is not None else None
 
     def __call__(self, grad):
-        if self.dist is not None:
+        if self.p2p is not None and grad.is_cuda and grad.dtype == torch.float32 and grad.numel() <= self.p2p.max_floats:
+            self.p2p(grad)
+        elif self.dist is not None:
             self.dist.all_reduce(grad)
         return grad
+
+    def check(self):
+        """raises when an in-library exchange ran into its peer timeout (call at log / evaluation points: it synchronises)"""
+        if self.p2p is not None and self.p2p.status() != 0:
+            raise RuntimeError("marlhip p2p exchange: a peer did not publish its gradient in time (MARLHIP_P2P_TIMEOUT_MS); replicas have diverged")

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MARLHIP_VERSION 209
+#define MARLHIP_VERSION 210
 
 int marlhip_version(void);
 const char* marlhip_last_error(void);
@@ -586,6 +586,23 @@ typedef int (*marlhip_exchange_fn)(void* ctx, float* grad, int64_t count, void* 
 int marlhip_idqn_update_n_dist(const marlhip_idqn_learner* L, int32_t n_updates, int32_t length, uint64_t seed,
                                uint32_t counter0, int64_t* adam_step, int64_t* updates, int64_t* last_target_update,
                                marlhip_exchange_fn exchange, void* exchange_ctx, int32_t world, void* stream);
+
+/* In-library gradient exchange (C-ABI 210; csrc/p2p.hip): a one-shot all-reduce (SUM) over peer-mapped buffers, one kernel per
+ * call, no host hop and no collective-library launch - what marlhip_idqn_update_n_dist's `exchange` argument is meant to be given on
+ * a node whose GPUs reach each other directly (xGMI).  marlhip_p2p_allreduce HAS the marlhip_exchange_fn signature (ctx = the state).
+ * Every rank publishes its gradient in its own (uncached, IPC-exported) buffer and sums all ranks' buffers in RANK ORDER: bitwise
+ * identical sums on every rank.  Protocol: every rank calls _create (allocates ITS buffer: the one piece of device memory this
+ * library owns, freed by _destroy), the hipIpcMemHandles (marlhip_p2p_handle_bytes() bytes each) are exchanged by the host side
+ * (torch.distributed in codebase_amd/parallel.py), every rank calls _connect with all of them, then any number of _allreduce calls -
+ * the same sequence of counts on every rank.  A peer that does not arrive within MARLHIP_P2P_TIMEOUT_MS (default 5000) leaves the
+ * local gradient untouched and raises the state's error word, which marlhip_p2p_status reads back (it synchronises: not for the
+ * hot loop).  Nothing like it exists in the reference (one process). */
+int marlhip_p2p_handle_bytes(void);
+int marlhip_p2p_create(int32_t rank, int32_t world, int64_t max_floats, void** state_out, void* handle_out);
+int marlhip_p2p_connect(void* state, const void* handles);
+int marlhip_p2p_allreduce(void* state, float* grad, int64_t count, void* stream);
+int marlhip_p2p_status(void* state);
+int marlhip_p2p_destroy(void* state);
 
 /* OPT-IN, a deviation from the exact-f32 default (C-ABI 209): the same loss / gradient (marlhip_dqn_loss_grad, mode 0) and the same
  * n-updates loop (marlhip_idqn_update_n) with every f32 product formed from fp16 halves on the double-rate matrix pipe

@@ -10,12 +10,19 @@ pytestmark = pytest.mark.gpu
 
 
 def test_two_ranks_stay_bit_identical_idqn_qmix_a2c():
+    """once with the in-library peer-to-peer exchange (marlhip_p2p_allreduce: IPC-shared buffers, the default on GPU ranks) and once
+    with torch.distributed's collective (MARLHIP_P2P=0): replicas identical within each run, and - two ranks, so the rank-ordered sum
+    r0 + r1 is the collective's sum bit for bit - the SAME final parameters in both runs"""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", os.path.join(root, "tests", "two_rank_worker.py")]
-    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0 and "TWO_RANK_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+    digests = {}
+    for p2p, port in (("1", "29533"), ("0", "29535")):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MARLHIP_P2P=p2p, MARLHIP_P2P_TIMEOUT_MS="20000")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", port, os.path.join(root, "tests", "two_rank_worker.py")]
+        out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0 and "TWO_RANK_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+        digests[p2p] = [ln for ln in out.stdout.splitlines() if ln.startswith("TWO_RANK_OK")][-1].split()[1]
+    assert digests["1"] == digests["0"], "the peer-to-peer exchange and the collective left different parameters"
 
 
 def _torchrun(args, extra_env, port, timeout=900):

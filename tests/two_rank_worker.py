@@ -16,6 +16,9 @@ def same_on_all_ranks(t, what):
     assert torch.equal(ref, t.detach().cpu()), f"rank {dist.get_rank()}: {what} diverged"
 
 
+DIGEST = __import__("hashlib").sha256()
+
+
 def main():
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     dist.init_process_group("gloo")
@@ -47,10 +50,13 @@ def main():
             tr.round(0.3)
         torch.cuda.synchronize()
         assert (tr._fused is not None) == (cls is QNetwork and not std), "which cases take the n-updates library call changed"
+        if os.environ.get("MARLHIP_P2P", "1") != "0":  # the gradient went through marlhip_p2p_allreduce (a C pointer inside the library loop, a ctypes call in the host loops)
+            assert tr._sync is not None and tr._sync.p2p is not None and tr._sync.p2p.status() == 0, "p2p exchange missing or timed out"
         assert model.updates == 12 and model.updater.step == 12
         for name in ("params", "target_params"):
             same_on_all_ranks(getattr(model, name), f"{cls.__name__}.{name}")
         same_on_all_ranks(model.updater.exp_avg_sq, f"{cls.__name__} Adam moments")
+        DIGEST.update(model.params.cpu().numpy().tobytes())  # compared between the exchanges by tests/test_gpu_two_ranks.py
         same_on_all_ranks(model.updater.gnorm, f"{cls.__name__} clip norm (taken from the REDUCED gradient)")
         if std:  # RunningMeanStd moved by the GLOBAL batch moments: the same (mean, var, count) on every rank
             st = model.ret_ms
@@ -78,20 +84,23 @@ def main():
                 r=torch.empty(T, N, P, device="cuda"), d=torch.empty(T + 1, N, dtype=torch.uint8, device="cuda"),
                 f=torch.empty(T, N, device="cuda"))
     fr, fl, tm = torch.zeros(P, N, device="cuda"), torch.zeros(N, dtype=torch.int32, device="cuda"), torch.zeros(1, dtype=torch.int32, device="cuda")
-    sync = GradSync(dist)
+    sync = GradSync(dist, max_floats=ac.updater.grad.numel())  # what ac.train.main builds: the in-library exchange when it can be set up
+    assert os.environ.get("MARLHIP_P2P", "1") == "0" or sync.p2p is not None, "the in-library p2p exchange did not come up on two ranks of one GPU"
     ac.updater.attach_exchange(lambda t: dist.all_reduce(t))  # what ac.train.main does under torchrun
     for r in range(3):
         h.ac_collect(cfg2, ac.spec, ac.actor_params, r, T, False, bufs["o"], bufs["a"], bufs["r"], bufs["d"], bufs["f"], fr, fl, tm)
         ac.update_async(Batch(bufs["o"], bufs["a"], bufs["r"], bufs["d"].float(), bufs["f"], None), r * 200, grad_sync=sync, world=world)
     torch.cuda.synchronize()
+    sync.check()
     same_on_all_ranks(ac.block, "A2C actor|critic block")
     same_on_all_ranks(ac.target_critic_params, "A2C target critic")
     same_on_all_ranks(ac.updater.ret_stats.mean, "A2C return statistics mean")
     same_on_all_ranks(ac.updater.ret_stats.var, "A2C return statistics var")
     assert abs(ac.updater.ret_stats.count - (1e-4 + 3 * world * T * N)) < 1e-6
     dist.barrier()
+    DIGEST.update(ac.block.cpu().numpy().tobytes())
     if rank == 0:
-        print("TWO_RANK_OK")
+        print("TWO_RANK_OK", DIGEST.hexdigest())
     dist.destroy_process_group()
 
 
