@@ -20,8 +20,11 @@
 
 #include "common.h"
 #include "mlp.h"
+#include "p2p.h"
 
 namespace marl {
+
+bool p2p_is_builtin(marlhip_exchange_fn fn);  // p2p.hip
 
 
 __device__ __forceinline__ void wave_lds_fence() {
@@ -805,8 +808,17 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dqn_lossgrad_kernel(con
 // grad[p][i] = (sum over the agent's records) / n_filled ; loss = sum of all loss fields / n_filled.
 // n_filled comes from agent 0's records only (every agent sees the same filled mask).
 // sumsq_out (may be null): per-block sum of squares of the block's 64 gradient values, for the clip norm of adam_pack_kernel
+struct ReduceP2p {  // the in-library exchange folded into the reduce launch (marlhip_idqn_update_n_dist with marlhip_p2p_allreduce)
+    P2pPeers peers;
+    int rank, world, max_chunks;
+    int64_t slot_floats;
+    uint32_t epoch;
+    long long timeout_ticks;
+};
+
 __device__ __forceinline__ void dqn_reduce_body(const float* __restrict__ partials, int P, int nwg, int nparam, const AgentMap& am,
-                                                float* __restrict__ grad, float* __restrict__ loss, float* __restrict__ sumsq_out) {
+                                                float* __restrict__ grad, float* __restrict__ loss, float* __restrict__ sumsq_out,
+                                                const ReduceP2p* x = nullptr) {
     __shared__ float s_red[8];
     const int rec = nparam + 2;
     // n_filled (agent 0's records) and the loss sum (all records): strided loads + fixed-order tree
@@ -847,9 +859,15 @@ __device__ __forceinline__ void dqn_reduce_body(const float* __restrict__ partia
     s_part[slice][l64] = acc;
     __syncthreads();
     float gv = 0.f;
-    if (slice == 0 && i < am.nblk * nparam) {
-        gv = ((s_part[0][l64] + s_part[1][l64]) + (s_part[2][l64] + s_part[3][l64])) / nf;
-        grad[i] = gv;
+    if (slice == 0) {
+        const bool in = i < am.nblk * nparam;
+        if (in) gv = ((s_part[0][l64] + s_part[1][l64]) + (s_part[2][l64] + s_part[3][l64])) / nf;
+        if (x != nullptr) {  // wave 0 holds the block's 64 values: publish, wait for the peers' block, sum over the ranks in rank order
+            bool late;
+            gv = p2p_wave_sum(x->peers, x->rank, x->world, x->slot_floats, x->max_chunks, x->epoch, (int)blockIdx.x, (int64_t)i, in, gv,
+                              x->timeout_ticks, late);
+        }
+        if (in) grad[i] = gv;
     }
     if (sumsq_out != nullptr && slice == 0) {  // wave 0 holds the block's 64 values: fixed-order butterfly
         float sq = gv * gv;
@@ -866,6 +884,12 @@ __device__ __forceinline__ void dqn_reduce_body(const float* __restrict__ partia
 static __global__ __launch_bounds__(256) void dqn_reduce_kernel(const float* __restrict__ partials, int P, int nwg, int nparam,
                                                          AgentMap am, float* __restrict__ grad, float* __restrict__ loss) {
     dqn_reduce_body(partials, P, nwg, nparam, am, grad, loss, nullptr);
+}
+
+// reduce + the ranks' exchange in one launch: grad = SUM over the ranks of the mean gradients (clip + Adam then apply 1 / world)
+static __global__ __launch_bounds__(256) void dqn_reduce_p2p_kernel(const float* __restrict__ partials, int P, int nwg, int nparam,
+                                                             AgentMap am, float* __restrict__ grad, float* __restrict__ loss, ReduceP2p x) {
+    dqn_reduce_body(partials, P, nwg, nparam, am, grad, loss, nullptr, &x);
 }
 
 static __global__ __launch_bounds__(256) void dqn_reduce_sq_kernel(const float* __restrict__ partials, int P, int nwg, int nparam,
@@ -1418,11 +1442,21 @@ int launch_lossgrad_src(const marlhip_net_shape* s, const float* params, const f
         if (fuse->exchange != nullptr) {
             // N > 1: reduce -> all-reduce(SUM) of the flat gradient (the caller's RCCL hop) -> Adam, the clip norm taken from the
             // exchanged gradient inside the Adam launch (the clip must use the global post-reduce norm, dqn/model.py:170)
-            hipLaunchKernelGGL(dqn_reduce_kernel, dim3(nsq), dim3(256), 0, st, (const float*)ws, P, pl.nwg, S::NPARAM, am, grad, loss);
-            MARL_CHECK_LAUNCH("dqn_reduce_kernel");
-            const int rc = fuse->exchange(fuse->exchange_ctx, grad, (int64_t)n, (void*)st);
-            MARL_REQUIRE(rc == 0, "idqn_update_n_dist: the gradient exchange callback failed (%d)", rc);
-            nsq = 0;
+            P2pState* ps = p2p_is_builtin(fuse->exchange) ? static_cast<P2pState*>(fuse->exchange_ctx) : nullptr;
+            if (ps != nullptr && ps->connected && n <= ps->max_floats) {
+                // the library's own exchange: folded into the reduce launch (each workgroup publishes its 64 values, waits for the same
+                // workgroup of the peers, sums in rank order) - one launch less per update than reduce -> exchange kernel
+                ps->epoch += 1;
+                ReduceP2p x = {ps->peers, ps->rank, ps->world, ps->max_chunks, ps->max_floats, ps->epoch, p2p_timeout_ticks()};
+                hipLaunchKernelGGL(dqn_reduce_p2p_kernel, dim3(nsq), dim3(256), 0, st, (const float*)ws, P, pl.nwg, S::NPARAM, am, grad, loss, x);
+                MARL_CHECK_LAUNCH("dqn_reduce_p2p_kernel");
+            } else {
+                hipLaunchKernelGGL(dqn_reduce_kernel, dim3(nsq), dim3(256), 0, st, (const float*)ws, P, pl.nwg, S::NPARAM, am, grad, loss);
+                MARL_CHECK_LAUNCH("dqn_reduce_kernel");
+                const int rc = fuse->exchange(fuse->exchange_ctx, grad, (int64_t)n, (void*)st);
+                MARL_REQUIRE(rc == 0, "idqn_update_n_dist: the gradient exchange callback failed (%d)", rc);
+            }
+            nsq = 0;  // the clip norm of the EXCHANGED gradient: taken inside the Adam launch (the same arithmetic for every exchange)
         } else {
             hipLaunchKernelGGL(dqn_reduce_sq_kernel, dim3(nsq), dim3(256), 0, st, (const float*)ws, P, pl.nwg, S::NPARAM, am, grad, loss,
                                fuse->sumsq);

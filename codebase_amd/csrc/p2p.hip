@@ -15,39 +15,17 @@
 // Every rank forms the same sums in the same order: replicas stay bitwise identical, as with the collective.  Two slots suffice: a
 // rank can enter update u + 1 (other slot) while a peer still reads its slot of update u, but cannot finish the wait of u + 1 before
 // that peer has entered u + 1 itself, i.e. has left u.  Nothing here exists in the reference (one process, no collective).
-#include <vector>
-
 #include "common.h"
 
+#include "p2p.h"
+
 namespace marl {
-
-constexpr int P2P_MAX_WORLD = 16;
-constexpr int P2P_CHUNK = 1024;          // floats per block (256 threads x float4)
-constexpr int P2P_FLAG_BYTES = 1 << 16;  // [2 parities][max chunks] uint32 epochs + error word, padded
-
-struct P2pPeers {
-    const float* slot[P2P_MAX_WORLD];      // peer r's data area (both slots)
-    const uint32_t* flags[P2P_MAX_WORLD];  // peer r's flags
-};
-
-struct P2pState {
-    int rank, world;
-    int64_t max_floats;
-    int max_chunks;
-    void* local;                 // this rank's allocation
-    void* mapped[P2P_MAX_WORLD];  // peers' allocations as mapped here (nullptr for self)
-    P2pPeers peers;
-    uint32_t epoch;
-    bool connected;
-};
-
-__device__ __forceinline__ uint32_t ld_sys(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM); }
 
 // grad: this rank's gradient in, the sum over the ranks out.  flags layout: [parity][chunk], error word at index 2 * max_chunks.
 static __global__ __launch_bounds__(256) void p2p_allreduce_kernel(float* __restrict__ grad, int64_t n, P2pPeers peers, int rank, int world,
                                                                    int64_t slot_floats, int max_chunks, uint32_t epoch, long long timeout_ticks) {
-    const int b = blockIdx.x, par = (int)(epoch & 1u);
-    const int64_t i0 = (int64_t)b * P2P_CHUNK + 4 * threadIdx.x;
+    const int b = blockIdx.x * (P2P_CHUNK / 64), par = (int)(epoch & 1u);  // flags are per 64 floats: this block's first one stands for its chunk
+    const int64_t i0 = (int64_t)blockIdx.x * P2P_CHUNK + 4 * threadIdx.x;
     float* mine = const_cast<float*>(peers.slot[rank]) + (int64_t)par * slot_floats;
     uint32_t* my_flags = const_cast<uint32_t*>(peers.flags[rank]);
     float v[4] = {0.f, 0.f, 0.f, 0.f};
@@ -67,7 +45,7 @@ static __global__ __launch_bounds__(256) void p2p_allreduce_kernel(float* __rest
     if (threadIdx.x < world && threadIdx.x != rank) {
         const uint32_t* f = peers.flags[threadIdx.x] + par * max_chunks + b;
         const long long t0 = wall_clock64();
-        while ((int32_t)(ld_sys(f) - epoch) < 0) {
+        while ((int32_t)(p2p_ld_sys(f) - epoch) < 0) {
             if (wall_clock64() - t0 > timeout_ticks) {
                 s_late = 1;
                 break;
@@ -95,13 +73,24 @@ static __global__ __launch_bounds__(256) void p2p_allreduce_kernel(float* __rest
         if (i0 + k < n) grad[i0 + k] = acc[k];
 }
 
+long long p2p_timeout_ticks() {  // wall_clock64 counts at 100 MHz; default 5 s, MARLHIP_P2P_TIMEOUT_MS overrides
+    static const long long t = [] {
+        const char* v = getenv("MARLHIP_P2P_TIMEOUT_MS");
+        return (long long)((v ? atof(v) : 5000.0) * 1e5);
+    }();
+    return t;
+}
+
+// marlhip_idqn_update_n_dist recognises this exchange by its address and folds it into the learner's reduce launch
+bool p2p_is_builtin(marlhip_exchange_fn fn) { return fn == &marlhip_p2p_allreduce; }
+
 }  // namespace marl
 
 using namespace marl;
 
 extern "C" int marlhip_p2p_handle_bytes(void) { return (int)sizeof(hipIpcMemHandle_t); }
 
-// One allocation per rank: [flags (64 KB) | slot 0 | slot 1], uncached so that stores and the system-scope loads of the peers meet in
+// One allocation per rank: [flags | slot 0 | slot 1], uncached so that stores and the system-scope loads of the peers meet in
 // memory, not in a cache.  `handle_out` receives the hipIpcMemHandle (marlhip_p2p_handle_bytes() bytes) to hand to the peers.
 extern "C" int marlhip_p2p_create(int32_t rank, int32_t world, int64_t max_floats, void** state_out, void* handle_out) {
     MARL_REQUIRE(state_out && handle_out, "p2p_create: NULL pointer");
@@ -109,12 +98,13 @@ extern "C" int marlhip_p2p_create(int32_t rank, int32_t world, int64_t max_float
                  P2P_MAX_WORLD);
     MARL_REQUIRE(max_floats > 0, "p2p_create: max_floats must be > 0");
     const int64_t slot = (max_floats + P2P_CHUNK - 1) / P2P_CHUNK * P2P_CHUNK;
-    const int max_chunks = (int)(slot / P2P_CHUNK);
-    MARL_REQUIRE((2 * (int64_t)max_chunks + 1) * 4 <= P2P_FLAG_BYTES, "p2p_create: %lld floats need more chunk flags than the flag area holds", (long long)max_floats);
+    MARL_REQUIRE(slot <= (int64_t)1 << 28, "p2p_create: %lld floats per exchange is beyond what this buffer layout is meant for", (long long)max_floats);
+    const int max_chunks = (int)(slot / 64);  // one flag per 64 floats (the learner's reduce launch exchanges 64 values per workgroup)
     P2pState* st = new P2pState();
     st->rank = rank; st->world = world; st->max_floats = slot; st->max_chunks = max_chunks; st->epoch = 0; st->connected = false;
+    st->flag_bytes = ((size_t)(2 * (int64_t)max_chunks + 1) * 4 + 4095) & ~(size_t)4095;
     for (int r = 0; r < P2P_MAX_WORLD; ++r) { st->mapped[r] = nullptr; st->peers.slot[r] = nullptr; st->peers.flags[r] = nullptr; }
-    const size_t bytes = (size_t)P2P_FLAG_BYTES + 2 * (size_t)slot * sizeof(float);
+    const size_t bytes = st->flag_bytes + 2 * (size_t)slot * sizeof(float);
     hipError_t e = hipExtMallocWithFlags(&st->local, bytes, hipDeviceMallocUncached);
     if (e != hipSuccess) {
         set_error("p2p_create: hipExtMallocWithFlags(%zu bytes, uncached): %s", bytes, hipGetErrorString(e));
@@ -150,7 +140,7 @@ extern "C" int marlhip_p2p_connect(void* state, const void* handles) {
             st->mapped[r] = base;
         }
         st->peers.flags[r] = reinterpret_cast<const uint32_t*>(base);
-        st->peers.slot[r] = reinterpret_cast<const float*>(static_cast<const char*>(base) + P2P_FLAG_BYTES);
+        st->peers.slot[r] = reinterpret_cast<const float*>(static_cast<const char*>(base) + st->flag_bytes);
     }
     st->connected = true;
     return 0;
@@ -165,10 +155,7 @@ extern "C" int marlhip_p2p_allreduce(void* ctx, float* grad, int64_t count, void
     MARL_REQUIRE(count > 0 && count <= st->max_floats, "p2p_allreduce: %lld floats, the buffers hold %lld", (long long)count, (long long)st->max_floats);
     st->epoch += 1;
     const int chunks = (int)((count + P2P_CHUNK - 1) / P2P_CHUNK);
-    static const long long timeout_ticks = [] {  // wall_clock64 counts at 100 MHz; default 5 s, MARLHIP_P2P_TIMEOUT_MS overrides
-        const char* v = getenv("MARLHIP_P2P_TIMEOUT_MS");
-        return (long long)((v ? atof(v) : 5000.0) * 1e5);
-    }();
+    const long long timeout_ticks = p2p_timeout_ticks();
     hipLaunchKernelGGL(p2p_allreduce_kernel, dim3(chunks), dim3(256), 0, (hipStream_t)stream, grad, count, st->peers, st->rank, st->world,
                        st->max_floats, st->max_chunks, st->epoch, timeout_ticks);
     MARL_CHECK_LAUNCH("p2p_allreduce_kernel");
