@@ -130,3 +130,12 @@ extern "C" int marlhip_ac_store_step(int32_t n_envs, int32_t n_agents, int32_t o
     MARL_CHECK_LAUNCH("ac_store_step");
     return 0;
 }
+
+#if MARL_ACOL_PROF
+// profiling builds only: read and clear this translation unit's in-kernel region counters (ac_collect_kernels.h)
+extern "C" int marlhip_debug_acol_prof_lbf(unsigned long long* out16) {
+    unsigned long long z[16] = {0};
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(marl::acol_prof), sizeof(z)) != hipSuccess) return -1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(marl::acol_prof), z, sizeof(z)) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -28,13 +28,14 @@ constexpr int ACOL_BLOCK = 256;
 
 // MARL_ACOL_PROF=1 (profiling builds only, scripts/build_variants.py): s_memtime at the region boundaries of a rollout step, summed per
 // region over the steps and added by lane 0 of every wave to acol_prof[]: 0 actor forward, 1 Philox + Categorical sample, 2 action swap
-// (barrier), 3 env step, 4 rewards / bookkeeping / auto-reset, 5 observation, 6 batch stores, 7 the whole kernel, 8 waves.
+// (barrier), 3 env step, 4 rewards / bookkeeping / auto-reset, 5 observation, 6 batch stores, 7 the whole kernel, 8 waves,
+// 9 pack staging, 10 first reset + observation + row 0.
 #ifndef MARL_ACOL_PROF
 #define MARL_ACOL_PROF 0
 #endif
 #if MARL_ACOL_PROF
 static __device__ unsigned long long acol_prof[16];
-#define ACOL_TS_BEGIN unsigned long long ts_ = __builtin_readcyclecounter(), sp_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; const unsigned long long ts0_ = ts_;
+#define ACOL_TS_BEGIN unsigned long long ts_ = __builtin_readcyclecounter(), sp_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; const unsigned long long ts0_ = ts_;
 #define ACOL_TS(k)                                                      \
     {                                                                   \
         const unsigned long long now_ = __builtin_readcyclecounter();   \
@@ -46,6 +47,8 @@ static __device__ unsigned long long acol_prof[16];
         sp_[7] = __builtin_readcyclecounter() - ts0_;                                        \
         for (int k_ = 0; k_ < 8; ++k_) atomicAdd(&acol_prof[k_], sp_[k_]);                   \
         atomicAdd(&acol_prof[8], 1ull);                                                      \
+        atomicAdd(&acol_prof[9], sp_[9]);                                                    \
+        atomicAdd(&acol_prof[10], sp_[10]);                                                  \
     }
 #else
 #define ACOL_TS_BEGIN
@@ -136,8 +139,10 @@ __global__ __launch_bounds__(ACOL_BLOCK) void ac_collect_kernel(typename ENV::Pa
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ int s_act[NW > 1 ? 2 * 4 * P * 16 : 1];     // [step parity][env block of the workgroup][agent][env]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, j = lane & 15;
-    const int blk = wave / NW, aw = wave % NW;             // env block inside the workgroup, this wave's agent residue
-    const int n = (blockIdx.x * (4 / NW) + blk) * 16 + j;
+    const int blk = wave / NW, aw = wave % NW;
+    const int bpw = (int)blockDim.x / (64 * NW);  // env blocks per workgroup: 4 / NW, or ONE when the launch has fewer waves than the chip has SIMDs             // env block inside the workgroup, this wave's agent residue
+    ACOL_TS_BEGIN
+    const int n = (blockIdx.x * bpw + blk) * 16 + j;
     const int N = q.n_envs;
     typename ENV::Ctx ctx;
     ctx.init(q, reinterpret_cast<uint8_t*>(lds) + (FROM_GLOBAL ? 0 : PP::LDS_BYTES), wave, j);
@@ -151,7 +156,7 @@ __global__ __launch_bounds__(ACOL_BLOCK) void ac_collect_kernel(typename ENV::Pa
     constexpr bool TSTORE = acol_tstore<ENV, H, OID, NW>();
     // the wave's tile behind the packs and the env's bytes; fast path only for blocks of 16 envs inside the batch (wave-uniform)
     float* tile = reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(lds) + (FROM_GLOBAL ? 0 : PP::LDS_BYTES) + ENV::LDS_MAX) + (size_t)wave * OT::ELEMS;
-    const int n0 = (blockIdx.x * (4 / NW) + blk) * 16;
+    const int n0 = (blockIdx.x * bpw + blk) * 16;
     const bool tstore = TSTORE && !ghost && n0 + 16 <= N;
     int t_off[TSTORE ? OT::NI : 1];  // float offset of tile element 64 i + lane inside the block's 16 batch rows (agent 0)
     if constexpr (TSTORE) {
@@ -164,7 +169,7 @@ __global__ __launch_bounds__(ACOL_BLOCK) void ac_collect_kernel(typename ENV::Pa
     f4 a3[PP::A3REG ? K : 1][S::MT];  // output-layer operands of the wave's agents, when the full packs do not fit the LDS
     if (RESIDENT) {
         for (int p = 0; p < P; ++p)
-            stage_packed_prefix<S>(actor + (size_t)p * S::NFWD, lds + (size_t)p * PP::STRIDE, PP::STRIDE, tid, ACOL_BLOCK);
+            stage_packed_prefix<S>(actor + (size_t)p * S::NFWD, lds + (size_t)p * PP::STRIDE, PP::STRIDE, tid, (int)blockDim.x);
         if (PP::A3REG) {
 #pragma unroll
             for (int k = 0; k < K; ++k)
@@ -174,6 +179,7 @@ __global__ __launch_bounds__(ACOL_BLOCK) void ac_collect_kernel(typename ENV::Pa
         }
         __syncthreads();
     }
+    ACOL_TS(9)
     typename ENV::State s;
     ENV::reset(q, s, ctx, env_id, 2u * round + gen);
     // batch_obs[t][n][p*D + d]
@@ -214,7 +220,7 @@ __global__ __launch_bounds__(ACOL_BLOCK) void ac_collect_kernel(typename ENV::Pa
 #pragma unroll
     for (int p = 0; p < P; ++p) ep_ret[p] = 0.f;
     int len = 0;
-    ACOL_TS_BEGIN
+    ACOL_TS(10)
     for (int t = 0; t < T; ++t) {
         ACOL_TS(6)
         int act[P], own[K];
@@ -235,7 +241,7 @@ __global__ __launch_bounds__(ACOL_BLOCK) void ac_collect_kernel(typename ENV::Pa
                     pack = actor + (size_t)p * S::NFWD;
                 } else {
                     __syncthreads();
-                    stage_packed<S>(actor + (size_t)p * S::NFWD, lds, tid, ACOL_BLOCK);
+                    stage_packed<S>(actor + (size_t)p * S::NFWD, lds, tid, (int)blockDim.x);
                     __syncthreads();
                     pack = lds;
                 }
@@ -382,9 +388,12 @@ int launch_ac_collect_nw(const typename ENV::Params& q, const float* packs, uint
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         attr_set.done(lds_bytes);
     }
-    const int per_wg = 64 / NW;  // envs per workgroup
+    // one env block (16 envs, NW waves) per workgroup while the launch has fewer waves than the chip has SIMDs: the per-step action
+    // swap is a workgroup barrier, and with several blocks per workgroup every block waits for the slowest one's step
+    const bool one_block = NW > 1 && (int64_t)((q.n_envs + 15) / 16) * NW <= 1024;
+    const int threads = one_block ? 64 * NW : ACOL_BLOCK, per_wg = 16 * (threads / (64 * NW));  // envs per workgroup
     timing_begin(TIMER_COLLECT, st);
-    hipLaunchKernelGGL((ac_collect_kernel<ENV, H, OID, NW>), dim3((q.n_envs + per_wg - 1) / per_wg), dim3(ACOL_BLOCK), lds_bytes, st, q, packs, round, T,
+    hipLaunchKernelGGL((ac_collect_kernel<ENV, H, OID, NW>), dim3((q.n_envs + per_wg - 1) / per_wg), dim3(threads), lds_bytes, st, q, packs, round, T,
                        proper_term, b_obs, b_act, b_rew, b_done, b_filled, fin_return, fin_length, t_max, ac_ghost_current());
     timing_end(TIMER_COLLECT, st);
     MARL_CHECK_LAUNCH("ac_collect_kernel");

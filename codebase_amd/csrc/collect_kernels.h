@@ -89,7 +89,8 @@ __global__ __launch_bounds__(COL_BLOCK) void idqn_collect_kernel(typename ENV::P
     __shared__ int s_act[NW > 1 ? 2 * 4 * P * 16 : 1];     // [step parity][env block of the workgroup][agent][env]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, j = lane & 15;
     const int blk = wave / NW, aw = wave % NW;
-    const int n = (blockIdx.x * (4 / NW) + blk) * 16 + j;
+    const int bpw = (int)blockDim.x / (64 * NW);  // env blocks per workgroup: 4 / NW, or ONE when the launch has fewer waves than the chip has SIMDs
+    const int n = (blockIdx.x * bpw + blk) * 16 + j;
     const int N = q.n_envs, T = rs.max_len;
     typename ENV::Ctx ctx;
     ctx.init(q, reinterpret_cast<uint8_t*>(lds) + (FROM_GLOBAL ? 0 : PP::LDS_BYTES), wave, j);
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(COL_BLOCK) void idqn_collect_kernel(typename ENV::P
     f4 a3[PP::A3REG ? K : 1][S::MT];  // output-layer operands of the wave's agents, when the full packs do not fit the LDS
     if (RESIDENT) {
         for (int p = 0; p < P; ++p)
-            stage_packed_prefix<S>(packs + (size_t)p * S::NFWD, lds + (size_t)p * PP::STRIDE, PP::STRIDE, tid, COL_BLOCK);
+            stage_packed_prefix<S>(packs + (size_t)p * S::NFWD, lds + (size_t)p * PP::STRIDE, PP::STRIDE, tid, (int)blockDim.x);
         if (PP::A3REG) {
 #pragma unroll
             for (int k = 0; k < K; ++k)
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(COL_BLOCK) void idqn_collect_kernel(typename ENV::P
                 pack = packs + (size_t)p * S::NFWD;
             } else {
                 __syncthreads();
-                stage_packed<S>(packs + (size_t)p * S::NFWD, lds, tid, COL_BLOCK);
+                stage_packed<S>(packs + (size_t)p * S::NFWD, lds, tid, (int)blockDim.x);
                 __syncthreads();
                 pack = lds;
             }
@@ -248,9 +249,12 @@ int launch_collect_nw(const typename ENV::Params& q, const float* packs, float e
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         attr_set.done(lds_bytes);
     }
-    const int per_wg = 64 / NW;
+    // one env block per workgroup while the launch leaves SIMDs empty (see launch_ac_collect_nw): the action swap's barrier then only
+    // joins the NW waves that need each other
+    const bool one_block = NW > 1 && (int64_t)((q.n_envs + 15) / 16) * NW <= 1024;
+    const int threads = one_block ? 64 * NW : COL_BLOCK, per_wg = 16 * (threads / (64 * NW));
     timing_begin(TIMER_COLLECT, st);
-    hipLaunchKernelGGL((idqn_collect_kernel<ENV, H, OID, NW>), dim3((q.n_envs + per_wg - 1) / per_wg), dim3(COL_BLOCK), lds_bytes, st, q, packs, eps, round,
+    hipLaunchKernelGGL((idqn_collect_kernel<ENV, H, OID, NW>), dim3((q.n_envs + per_wg - 1) / per_wg), dim3(threads), lds_bytes, st, q, packs, eps, round,
                        *rs, *rb, slot_base, write_replay, clear_stale, proper_term, fin_return, fin_length);
     timing_end(TIMER_COLLECT, st);
     MARL_CHECK_LAUNCH("idqn_collect_kernel");

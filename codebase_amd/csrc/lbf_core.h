@@ -188,24 +188,24 @@ MARL_HD void lbf_step(const LbfParams& q, LbfState<P, F>& s, const int* act, dou
     for (int p = 0; p < P; ++p) {
         int a = act[p];
         const int r = s.pr[p], c = s.pc[p];
-        // valid set of the current state (_gen_valid_moves at the end of the
-        // previous step); an invalid choice silently becomes NONE
-        bool ok;
-        switch (a) {
-            case ACT_NONE: ok = true; break;
-            case ACT_NORTH: ok = r > 0 && lbf_field(s, r - 1, c) == 0; break;
-            case ACT_SOUTH: ok = r < q.rows - 1 && lbf_field(s, r + 1, c) == 0; break;
-            case ACT_WEST: ok = c > 0 && lbf_field(s, r, c - 1) == 0; break;
-            case ACT_EAST: ok = c < q.cols - 1 && lbf_field(s, r, c + 1) == 0; break;
-            case ACT_LOAD:
-                ok = (lbf_field(s, imax(r - 1, 0), c) + lbf_field(s, imin(r + 1, q.rows - 1), c) +
-                      lbf_field(s, r, imax(c - 1, 0)) + lbf_field(s, r, imin(c + 1, q.cols - 1))) > 0;
-                break;
-            default: ok = false; break;
-        }
-        if (!ok) a = ACT_NONE;
-        tr[p] = r + (a == ACT_SOUTH) - (a == ACT_NORTH);
-        tc[p] = c + (a == ACT_EAST) - (a == ACT_WEST);
+        // valid set of the current state (_gen_valid_moves at the end of the previous step); an invalid choice silently becomes NONE.
+        // Written without a per-action switch (round 4): lanes of a wave hold different actions, so every case of a switch runs, each
+        // with its own field look-ups - one look-up at the requested cell serves the four moves, one pass over the food list LOAD.
+        const int dr = (a == ACT_SOUTH ? 1 : 0) - (a == ACT_NORTH ? 1 : 0), dc = (a == ACT_EAST ? 1 : 0) - (a == ACT_WEST ? 1 : 0);
+        const int nr = r + dr, nc = c + dc;
+        const bool move = (a >= ACT_NORTH) & (a <= ACT_EAST);
+        const bool inside = (nr >= 0) & (nr <= q.rows - 1) & (nc >= 0) & (nc <= q.cols - 1);
+        const bool ok_move = move & inside & (lbf_field(s, nr, nc) == 0);
+        // LOAD: field[max(r-1,0)][c] + field[min(r+1,rows-1)][c] + field[r][max(c-1,0)] + field[r][min(c+1,cols-1)] > 0
+        const int rn = imax(r - 1, 0), rs = imin(r + 1, q.rows - 1), cw = imax(c - 1, 0), ce = imin(c + 1, q.cols - 1);
+        bool near = false;
+#pragma unroll
+        for (int f = 0; f < F; ++f)
+            near = near | ((s.fl[f] > 0) & (((s.fc[f] == c) & ((s.fr[f] == rn) | (s.fr[f] == rs))) | ((s.fr[f] == r) & ((s.fc[f] == cw) | (s.fc[f] == ce)))));
+        const bool ok = (a == ACT_NONE) | ok_move | ((a == ACT_LOAD) & near);
+        a = ok ? a : ACT_NONE;
+        tr[p] = r + (ok_move ? dr : 0);
+        tc[p] = c + (ok_move ? dc : 0);
         load[p] = (a == ACT_LOAD);
         rew[p] = 0.0;
     }
@@ -219,8 +219,10 @@ MARL_HD void lbf_step(const LbfParams& q, LbfState<P, F>& s, const int* act, dou
         sole[p] = (n == 1);
     }
 #pragma unroll
-    for (int p = 0; p < P; ++p)
-        if (sole[p]) { s.pr[p] = tr[p]; s.pc[p] = tc[p]; }
+    for (int p = 0; p < P; ++p) {
+        s.pr[p] = sole[p] ? tr[p] : s.pr[p];
+        s.pc[p] = sole[p] ? tc[p] : s.pc[p];
+    }
 
     // loading, in player order (order-independent on reachable states: the spawn
     // spacing rule leaves no cell adjacent to two foods)

@@ -39,7 +39,7 @@ b_fill = torch.empty(T, N, device=dev)
 fin_ret = torch.zeros(P, N, device=dev)
 fin_len = torch.zeros(N, dtype=torch.int32, device=dev)
 t_max = torch.zeros(1, dtype=torch.int32, device=dev)
-fn = getattr(lib, "marlhip_debug_acol_prof", None)
+fn = getattr(lib, "marlhip_debug_acol_prof" if NAME.startswith("rware") else "marlhip_debug_acol_prof_lbf", None)
 out = (ctypes.c_ulonglong * 16)()
 for r in range(3):
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -50,5 +50,5 @@ for r in range(3):
     print(f"round {r}: {a.elapsed_time(b) * 1e3:.1f} us, t_max {int(t_max.item())}, stored steps {int(b_fill.sum().item())}")
     if fn is not None and fn(out) == 0 and out[8]:
         waves, steps = out[8], int(t_max.item())
-        for k, name in enumerate(REGIONS):
+        for k, name in list(enumerate(REGIONS)) + [(9, "[pack staging]"), (10, "[first reset + observation + row 0]")]:
             print(f"   {name:38s} {out[k] / waves:12.0f} cycles / wave   {out[k] / waves / steps:9.1f} / step   {100.0 * out[k] / out[7]:5.1f} %")
