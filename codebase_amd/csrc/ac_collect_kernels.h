@@ -167,9 +167,9 @@ __global__ __launch_bounds__(ACOL_BLOCK) void ac_collect_kernel(typename ENV::Pa
         }
     }
     f4 a3[PP::A3REG ? K : 1][S::MT];  // output-layer operands of the wave's agents, when the full packs do not fit the LDS
-    if (RESIDENT) {
+    if (RESIDENT) {  // requested here, waited for in front of the first forward pass: the reset below runs under the copy
         for (int p = 0; p < P; ++p)
-            stage_packed_prefix<S>(actor + (size_t)p * S::NFWD, lds + (size_t)p * PP::STRIDE, PP::STRIDE, tid, (int)blockDim.x);
+            stage_packed_async(actor + (size_t)p * S::NFWD, lds + (size_t)p * PP::STRIDE, PP::STRIDE, wave, (int)blockDim.x >> 6, lane);
         if (PP::A3REG) {
 #pragma unroll
             for (int k = 0; k < K; ++k)
@@ -177,7 +177,6 @@ __global__ __launch_bounds__(ACOL_BLOCK) void ac_collect_kernel(typename ENV::Pa
                 for (int mt = 0; mt < S::MT; ++mt)
                     a3[k][mt] = reinterpret_cast<const f4*>(actor + (size_t)(aw + k * NW) * S::NFWD + S::pA3)[mt * 64 + lane];
         }
-        __syncthreads();
     }
     ACOL_TS(9)
     typename ENV::State s;
@@ -220,6 +219,7 @@ __global__ __launch_bounds__(ACOL_BLOCK) void ac_collect_kernel(typename ENV::Pa
 #pragma unroll
     for (int p = 0; p < P; ++p) ep_ret[p] = 0.f;
     int len = 0;
+    if (RESIDENT) stage_async_wait();  // the packs requested at the top have landed, for every wave
     ACOL_TS(10)
     for (int t = 0; t < T; ++t) {
         ACOL_TS(6)

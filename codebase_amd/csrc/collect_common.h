@@ -92,6 +92,27 @@ __device__ __forceinline__ void stage_packed_prefix(const float* __restrict__ pa
     for (int i = tid; i < nfloat / 4; i += nthreads) dst[i] = src[i];
 }
 
+// The same copy WITHOUT passing through registers or waiting: every wave requests its share of the 1 KB pieces with global_load_lds
+// (LDS address = wave-uniform base + 16 * lane, as in gru.h) and goes on - the collectors reset their envs and build the first
+// observation while the packs land; `stage_async_wait` (vmcnt(0) + workgroup barrier) sits in front of the first forward pass.
+__device__ __forceinline__ void stage_packed_async(const float* __restrict__ pack, float* lds, int nfloat, int wave, int nwaves, int lane) {
+    const char* src = reinterpret_cast<const char*>(pack) + 16 * lane;
+    char* dst = reinterpret_cast<char*>(lds);
+    const int bytes = nfloat * 4, full = bytes >> 10;
+    for (int piece = wave; piece < full; piece += nwaves)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 1024 * piece),
+                                         (__attribute__((address_space(3))) void*)(dst + 1024 * piece), 16, 0, 0);
+    const int tail = bytes - (full << 10);  // a multiple of 16: the pack is whole float4s
+    if (tail > 0 && wave == full % nwaves && 16 * lane < tail)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 1024 * full),
+                                         (__attribute__((address_space(3))) void*)(dst + 1024 * full), 16, 0, 0);
+}
+
+__device__ __forceinline__ void stage_async_wait() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
 template <class S>
 int launch_fwd_pack(int P, const AgentMap& am, const float* params, float** packs_out, hipStream_t st) {
     float* packs = collect_pack_scratch((size_t)P * S::NFWD * sizeof(float), st);

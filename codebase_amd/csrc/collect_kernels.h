@@ -100,9 +100,9 @@ __global__ __launch_bounds__(COL_BLOCK) void idqn_collect_kernel(typename ENV::P
 
     constexpr int K = P / NW;  // a wave's own agents: p = aw + k * NW, k < K (NW = 1: every agent, p = k)
     f4 a3[PP::A3REG ? K : 1][S::MT];  // output-layer operands of the wave's agents, when the full packs do not fit the LDS
-    if (RESIDENT) {
+    if (RESIDENT) {  // requested here, waited for in front of the first forward pass: the reset below runs under the copy
         for (int p = 0; p < P; ++p)
-            stage_packed_prefix<S>(packs + (size_t)p * S::NFWD, lds + (size_t)p * PP::STRIDE, PP::STRIDE, tid, (int)blockDim.x);
+            stage_packed_async(packs + (size_t)p * S::NFWD, lds + (size_t)p * PP::STRIDE, PP::STRIDE, wave, (int)blockDim.x >> 6, lane);
         if (PP::A3REG) {
 #pragma unroll
             for (int k = 0; k < K; ++k)
@@ -110,7 +110,6 @@ __global__ __launch_bounds__(COL_BLOCK) void idqn_collect_kernel(typename ENV::P
                 for (int mt = 0; mt < S::MT; ++mt)
                     a3[k][mt] = reinterpret_cast<const f4*>(packs + (size_t)(aw + k * NW) * S::NFWD + S::pA3)[mt * 64 + lane];
         }
-        __syncthreads();
     }
 
     typename ENV::State s;
@@ -140,6 +139,7 @@ __global__ __launch_bounds__(COL_BLOCK) void idqn_collect_kernel(typename ENV::P
 #pragma unroll
     for (int p = 0; p < P; ++p) ep_ret[p] = 0.f;
     int len = 0;
+    if (RESIDENT) stage_async_wait();  // the packs requested at the top have landed, for every wave
 
     for (int t = 0; t < T; ++t) {
         const bool any_alive = __any(alive);

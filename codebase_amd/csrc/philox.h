@@ -30,8 +30,11 @@ MARL_HD uint32_t mulhi32(uint32_t a, uint32_t b) {
 MARL_HD U4 philox4x32_10(U4 c, uint32_t k0, uint32_t k1) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = mulhi32(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
-        const uint32_t hi1 = mulhi32(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+        // both halves of a product from ONE 64-bit multiply (v_mad_u64_u32): the 32-bit integer multiplies are quarter-rate
+        // instructions, and a separate mul_hi + mul_lo pair per product made Philox the largest part of an env reset
+        const uint64_t p0 = (uint64_t)0xD2511F53u * (uint64_t)c.x, p1 = (uint64_t)0xCD9E8D57u * (uint64_t)c.z;
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+        const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
         U4 n;
         n.x = hi1 ^ c.y ^ k0;
         n.y = lo1;
@@ -67,6 +70,9 @@ struct DrawStream {
         blk_no = 0xFFFFFFFFu;
         blk.x = blk.y = blk.z = blk.w = 0;
     }
+    // (Measured and dropped, round 4: generating the first 6 blocks of a reset's stream up front, in lockstep, instead of on demand
+    // inside the lanes' out-of-step rejection loops - env-only 759 -> 754 M env-steps/s: the select chain that picks a word out of 24
+    // registers costs what the on-demand Philox calls do.)
     MARL_HD uint32_t next_u32() {
         const uint32_t b = idx >> 2;
         if (b != blk_no) {
