@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Turn gpurun_out/prof2/ (scripts/collect_profiles.sh, run on the MI355X box) into the committed round-2 evidence under profiles/."""
+"""Turn gpurun_out/prof<N>/ (scripts/collect_profiles*.sh, run on the MI355X box) into the committed evidence under profiles/:
+    python scripts/profiles_post.py prof4 r04"""
 import collections
 import csv
 import glob
@@ -40,7 +41,9 @@ def main():
     for tag, out in (("stats", PFX + "_bench_ratio_kernel_stats.csv"), ("stats_h128", PFX + "_bench_ratio_H128_kernel_stats.csv"),
                      ("stats_hbm", PFX + "_hbm_ubench_kernel_stats.csv"), ("stats_gru64", PFX + "_gru_H64_kernel_stats.csv"),
                      ("stats_rware_ia2c", PFX + "_rware_ia2c_tiny4ag_H128_kernel_stats.csv"),
-                     ("stats_qmix8p", PFX + "_qmix_15x15_8p5f_H128_kernel_stats.csv")):
+                     ("stats_qmix8p", PFX + "_qmix_15x15_8p5f_H128_kernel_stats.csv"),
+                     ("stats_rware_ia2c64", PFX + "_rware_ia2c_tiny4ag_H64_kernel_stats.csv"), ("stats_ia2c64", PFX + "_ia2c_8x8_2p3f_H64_kernel_stats.csv"),
+                     ("stats_envonly", PFX + "_env_only_kernel_stats.csv")):
         f = first(f"{tag}/**/*_kernel_stats.csv")
         if f:
             shutil.copy(f, os.path.join(DST, out))
