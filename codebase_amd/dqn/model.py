@@ -440,11 +440,17 @@ class VDNetwork(QNetwork):
 _MIXER_LAYOUT = ("hyper_w_1.0", "hyper_w_1.2", "hyper_w_final.0", "hyper_w_final.2", "hyper_b_1", "V.0", "V.2")
 
 
+KERNEL_EMBED, KERNEL_HYPER = 64, 32  # the widths csrc/qmix.h is built for (configs/algorithm/qmix.yaml:14-17)
+
+
 def init_flat_mixer(n_agents, state_dim, embed_dim, hypernet_layers, hypernet_embed):
     """Initial mixer AND target-mixer blocks in mixer.parameters() order, consuming torch's global RNG like
     QMixNetwork.__init__ does (mixer, then target mixer, then hard_update; dqn/model.py:283-312, 361-363)."""
     if hypernet_layers != 2:
-        raise NotImplementedError("QMixer with hypernet_layers != 2: the HIP mixer kernels implement configs/algorithm/qmix.yaml")
+        raise NotImplementedError("QMixer with hypernet_layers != 2: the HIP mixer kernels implement configs/algorithm/qmix.yaml's two-layer hypernets")
+    if not (0 < embed_dim <= KERNEL_EMBED and 0 < hypernet_embed <= KERNEL_HYPER):
+        raise NotImplementedError(f"QMixer with embed_dim {embed_dim} / hypernet_embed {hypernet_embed}: the HIP mixer kernels carry widths up to "
+                                  f"{KERNEL_EMBED} / {KERNEL_HYPER} (narrower ones run zero-padded, which is exact)")
 
     def one():
         mods = [nn.Linear(state_dim, hypernet_embed), nn.Linear(hypernet_embed, embed_dim * n_agents),
@@ -455,6 +461,54 @@ def init_flat_mixer(n_agents, state_dim, embed_dim, hypernet_layers, hypernet_em
     mixer, shapes = one()
     one()  # the target mixer's own draw, overwritten by hard_update
     return mixer, mixer.clone(), shapes
+
+
+def mixer_live_views(block, n_agents, state_dim, embed_dim, hypernet_embed):
+    """The reference-sized tensors of a QMixer with (embed_dim, hypernet_embed) <= (64, 32) as strided views INTO a block laid out for the
+    kernels' widths (mixer.parameters() order at 64 / 32).  Everything outside the views is zero and stays zero: a padded embedding unit
+    has w1 = |0| = 0, b1 = 0, hidden = elu(0) = 0, w_final = |0| = 0, a padded hypernet unit relu(0) = 0 with zero outgoing weights -
+    nothing reaches the output, every gradient into the padding is a product with one of those zeros, and Adam leaves an exactly zero
+    gradient's parameter where it is.  [(state_dict name, view, reference shape)]; the view's own shape differs from the reference's only
+    for hyper_w_1.2 ((P, e, h) / (P, e) against (P * e, h) / (P * e,))."""
+    P, SD, E, HE, e, h = n_agents, state_dim, KERNEL_EMBED, KERNEL_HYPER, embed_dim, hypernet_embed
+    out, o = [], 0
+
+    def take(n):
+        nonlocal o
+        t = block[o:o + n]
+        o += n
+        return t
+
+    out.append(("hyper_w_1.0.weight", take(HE * SD).view(HE, SD)[:h], (h, SD)))
+    out.append(("hyper_w_1.0.bias", take(HE)[:h], (h,)))
+    out.append(("hyper_w_1.2.weight", take(E * P * HE).view(P, E, HE)[:, :e, :h], (P * e, h)))
+    out.append(("hyper_w_1.2.bias", take(E * P).view(P, E)[:, :e], (P * e,)))
+    out.append(("hyper_w_final.0.weight", take(HE * SD).view(HE, SD)[:h], (h, SD)))
+    out.append(("hyper_w_final.0.bias", take(HE)[:h], (h,)))
+    out.append(("hyper_w_final.2.weight", take(E * HE).view(E, HE)[:e, :h], (e, h)))
+    out.append(("hyper_w_final.2.bias", take(E)[:e], (e,)))
+    out.append(("hyper_b_1.weight", take(E * SD).view(E, SD)[:e], (e, SD)))
+    out.append(("hyper_b_1.bias", take(E)[:e], (e,)))
+    out.append(("V.0.weight", take(E * SD).view(E, SD)[:e], (e, SD)))
+    out.append(("V.0.bias", take(E)[:e], (e,)))
+    out.append(("V.2.weight", take(E).view(1, E)[:, :e], (1, e)))
+    out.append(("V.2.bias", take(1), (1,)))
+    assert o == block.numel(), (o, block.numel())
+    return out
+
+
+def pad_mixer(live_flat, n_agents, state_dim, embed_dim, hypernet_embed):
+    """a reference-sized flat mixer block (mixer.parameters() order) inside a zeroed kernel-sized one"""
+    P, SD, E, HE = n_agents, state_dim, KERNEL_EMBED, KERNEL_HYPER
+    n = 2 * (HE * SD + HE) + E * P * HE + E * P + E * HE + E + 2 * (E * SD + E) + E + 1
+    block = torch.zeros(n, dtype=live_flat.dtype, device=live_flat.device)
+    o = 0
+    for _, view, shape in mixer_live_views(block, P, SD, embed_dim, hypernet_embed):
+        k = int(np.prod(shape))
+        view.copy_(live_flat[o:o + k].view(view.shape))
+        o += k
+    assert o == live_flat.numel(), (o, live_flat.numel())
+    return block
 
 
 class QMixNetwork(QNetwork):
@@ -473,11 +527,13 @@ class QMixNetwork(QNetwork):
         self.mixer_fp16 = bool(mixing.get("fp16", False))  # opt-in deviation (not a reference key): first mixer layers on the fp16 MFMA
         state_dim = sum(flatdim(o) for o in obs_space)
         mixer, tmixer, self._mixer_shapes = init_flat_mixer(self.n_agents, state_dim, **self.mixing)
-        self.mixer_params = mixer.to(self.device).contiguous()
-        self.target_mixer_params = tmixer.to(self.device).contiguous()
+        self._state_dim = state_dim
+        # blocks laid out for the kernels' widths (64 / 32); narrower mixers sit zero-padded inside them (exact: mixer_live_views)
+        self.mixer_params = pad_mixer(mixer, self.n_agents, state_dim, self.mixing["embed_dim"], self.mixing["hypernet_embed"]).to(self.device).contiguous()
+        self.target_mixer_params = pad_mixer(tmixer, self.n_agents, state_dim, self.mixing["embed_dim"], self.mixing["hypernet_embed"]).to(self.device).contiguous()
         up = self.updater
         self.updater = (_hip.GruQmixUpdater if self.recurrent else _hip.WideQmixUpdater if self.spec.wide else _hip.QmixUpdater)(self.spec, self.params, self.target_params, self.mixer_params, self.target_mixer_params,
-                                        mixing=dict(self.mixing, fp16=self.mixer_fp16), lr=up.lr, gamma=self.gamma, grad_clip=self.grad_clip,
+                                        mixing=dict(embed_dim=KERNEL_EMBED, hypernet_layers=2, hypernet_embed=KERNEL_HYPER, fp16=self.mixer_fp16), lr=up.lr, gamma=self.gamma, grad_clip=self.grad_clip,
                                         double_q=self.double_q, standardise_returns=self.standardise_returns, optimizer=self.optimizer)
         self.mode = 2
 
@@ -497,30 +553,32 @@ class QMixNetwork(QNetwork):
         self.target_mixer_params.copy_(self.mixer_params)
 
     def _mixer_views(self, block, prefix):
-        out, o = OrderedDict(), 0
-        for name, wshape in zip(_MIXER_LAYOUT, self._mixer_shapes):
-            for suffix, shape in (("weight", tuple(wshape)), ("bias", (wshape[0],))):
-                n = int(np.prod(shape))
-                out[f"{prefix}.{name}.{suffix}"] = block[o:o + n].view(shape)
-                o += n
-        assert o == block.numel()
-        return out
+        """state_dict key -> (live strided view into the kernel-sized block, the reference tensor's shape)"""
+        return OrderedDict((f"{prefix}.{name}", (view, shape)) for name, view, shape in
+                           mixer_live_views(block, self.n_agents, self._state_dim, self.mixing["embed_dim"], self.mixing["hypernet_embed"]))
+
+    def mixer_flat(self, block=None):
+        """the mixer in mixer.parameters() order at the CONFIGURED widths (what the reference's optimiser sees)"""
+        block = self.mixer_params if block is None else block
+        return torch.cat([v.reshape(-1) for v, _ in self._mixer_views(block, "mixer").values()])
 
     def parameters(self):
-        return super().parameters() + list(self._mixer_views(self.mixer_params, "mixer").values())
+        return super().parameters() + [v for v, _ in self._mixer_views(self.mixer_params, "mixer").values()]
 
     def state_dict(self):
         sd = super().state_dict()
-        for k, v in list(self._mixer_views(self.mixer_params, "mixer").items()) + \
+        for k, (v, shape) in list(self._mixer_views(self.mixer_params, "mixer").items()) + \
                 list(self._mixer_views(self.target_mixer_params, "target_mixer").items()):
-            sd[k] = v.detach().clone()
+            sd[k] = v.detach().reshape(shape).clone()
         return sd
 
     def load_state_dict(self, sd):
         super().load_state_dict(sd)
         for block, prefix in ((self.mixer_params, "mixer"), (self.target_mixer_params, "target_mixer")):
-            for k, view in self._mixer_views(block, prefix).items():
-                view.copy_(sd[k].to(self.device))
+            for k, (view, shape) in self._mixer_views(block, prefix).items():
+                src = sd[k].to(self.device)
+                assert tuple(src.shape) == tuple(shape), (k, tuple(src.shape), shape)
+                view.copy_(src.reshape(view.shape))
 
     def __repr__(self):
-        return super().__repr__().replace("QNetwork[HIP]", "QMixNetwork[HIP]") + f" + mixer({self.mixer_params.numel()} params)"
+        return super().__repr__().replace("QNetwork[HIP]", "QMixNetwork[HIP]") + f" + mixer({sum(int(np.prod(sh)) for _, sh in self._mixer_views(self.mixer_params, 'mixer').values())} params)"

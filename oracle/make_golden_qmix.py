@@ -7,6 +7,7 @@ Runs only in the build container (needs /root/reference); the vectors travel, th
       gradients of QMixNetwork._compute_loss, then critic / target / mixer / target-mixer after 3 x update()
       (hard target update forced at update 2), Adam moments of the mixer.
   learner_qmix_p4_H64.npz  : 4 agents x 27 obs (15x15-4p-5f shapes), 25 x 24 batch: loss and gradients only.
+  learner_qmix_e24_h16_H64.npz : 3 agents x 18 obs with mixing = {embed_dim 24, hypernet_layers 2, hypernet_embed 16}: loss, gradients, 3 updates.
 """
 import contextlib
 import io
@@ -27,11 +28,11 @@ def mixer_grad(m):
     return torch.cat([p.grad.reshape(-1) for p in m.parameters()])
 
 
-def build(ref_model, P, D, A, H, seed):
+def build(ref_model, P, D, A, H, seed, mixing=None):
     torch.manual_seed(seed)
     cfg = Cfg(optimizer="Adam", lr=3e-4, gamma=0.99, grad_clip=1.0, target_update_interval_or_tau=2, double_q=True,
               standardise_returns=False)
-    mixing = dict(embed_dim=64, hypernet_layers=2, hypernet_embed=32)  # configs/algorithm/qmix.yaml:14-17
+    mixing = mixing or dict(embed_dim=64, hypernet_layers=2, hypernet_embed=32)  # configs/algorithm/qmix.yaml:14-17
     with contextlib.redirect_stdout(io.StringIO()):
         net = ref_model.QMixNetwork([Box(D)] * P, [Discrete(A)] * P, cfg, [H, H], False, False, True, mixing, "cpu")
     g = torch.Generator().manual_seed(seed + 1)
@@ -45,10 +46,10 @@ def build(ref_model, P, D, A, H, seed):
     return net
 
 
-def fixture(ref_model, ref_train, name, P, D, B, seed, updates):
+def fixture(ref_model, ref_train, name, P, D, B, seed, updates, mixing=None):
     T, A, H = 25, 6, 64
-    net = build(ref_model, P, D, A, H, seed)
-    out = dict(P=P, T=T, B=B, D=D, A=A, H=H, E=64, HE=32, params0=flat_params(net.critic).numpy(),
+    net = build(ref_model, P, D, A, H, seed, mixing)
+    out = dict(P=P, T=T, B=B, D=D, A=A, H=H, E=net.mixer.embed_dim, HE=net.mixer.hypernet_embed, params0=flat_params(net.critic).numpy(),
                target0=flat_params(net.target).numpy(), mixer0=mixer_flat(net.mixer).numpy(),
                tmixer0=mixer_flat(net.target_mixer).numpy())
     batches = [synthetic_batch(P, T, B, D, A, seed=seed + 100 + i) for i in range(max(updates, 1))]
@@ -113,3 +114,5 @@ if __name__ == "__main__":
     init_fixture(rm)
     fixture(rm, rt, "learner_qmix_H64.npz", P=2, D=15, B=32, seed=300, updates=3)
     fixture(rm, rt, "learner_qmix_p4_H64.npz", P=4, D=27, B=24, seed=400, updates=0)
+    # a QMixer narrower than qmix.yaml's (QMixer.__init__, dqn/model.py:283-300, takes any widths): runs zero-padded on the 64 / 32 kernels
+    fixture(rm, rt, "learner_qmix_e24_h16_H64.npz", P=3, D=18, B=24, seed=500, updates=3, mixing=dict(embed_dim=24, hypernet_layers=2, hypernet_embed=16))

@@ -8,6 +8,7 @@ import torch
 
 from oracle import dqn_port as dp
 from oracle import qmix_port as qp
+from codebase_amd.hip import Batch
 from tests.test_gpu_parity import DEV, dev_batch, golden_batch, hip, load
 
 pytestmark = pytest.mark.gpu
@@ -98,6 +99,52 @@ def test_qmix_other_shapes_vs_oracle_port(P, T, B, D, H):
     assert abs(loss.cpu().numpy()[0] - ref.item()) <= 3e-5 * abs(ref.item())
     assert_grad_close(grad.cpu().numpy(), pr.grad.numpy(), 3e-4)
     assert_grad_close(up.mixer_grad.cpu().numpy(), mr.grad.numpy(), 3e-4)
+
+
+def test_qmix_narrow_mixer_matches_reference_golden():
+    """mixing = {embed_dim 24, hypernet_layers 2, hypernet_embed 16} (any widths are reference branches: QMixer.__init__, dqn/model.py:283-300)
+    through QMixNetwork: the narrow mixer sits zero-padded inside the 64 / 32 kernels' block (exact, tests/test_mixer_padding_cpu.py);
+    loss, critic and mixer gradients, then 3 x update() with a hard target copy at update 2 against the reference's own QMixNetwork"""
+    from codebase_amd.dqn.model import QMixNetwork
+    from codebase_amd.spaces import Box, Discrete, Tuple
+
+    g = load("learner_qmix_e24_h16_H64.npz")
+    P, D, A, E, HE = int(g["P"]), int(g["D"]), int(g["A"]), int(g["E"]), int(g["HE"])
+    assert (E, HE) == (24, 16)
+    hyper = dict(optimizer="Adam", lr=3e-4, gamma=0.99, grad_clip=1.0, double_q=True, standardise_returns=False, target_update_interval_or_tau=2)
+    net = QMixNetwork(Tuple([Box(-1, 8, (D,)) for _ in range(P)]), Tuple([Discrete(A) for _ in range(P)]), hyper, [64, 64], False, False, True,
+                      dict(embed_dim=E, hypernet_layers=2, hypernet_embed=HE), "cuda")
+    sd = net.state_dict()
+    assert tuple(sd["mixer.hyper_w_1.2.weight"].shape) == (P * E, HE) and tuple(sd["mixer.V.2.weight"].shape) == (1, E)
+    net.params.copy_(torch.tensor(g["params0"]))
+    net.target_params.copy_(torch.tensor(g["target0"]))
+    # the reference's flat blocks -> the live views of the padded blocks
+    for block, flat in ((net.mixer_params, g["mixer0"]), (net.target_mixer_params, g["tmixer0"])):
+        o = 0
+        for view, shape in net._mixer_views(block, "mixer").values():
+            n = int(np.prod(shape))
+            view.copy_(torch.tensor(flat[o:o + n]).reshape(view.shape))
+            o += n
+        assert o == flat.size
+    h = hip()
+    up = net.updater
+    loss, grad = up.loss_grad(dev_batch(h, golden_batch(g, 0)))
+    assert abs(loss.cpu().numpy()[0] - g["loss0"]) <= 1e-5 * abs(g["loss0"])
+    assert_grad_close(grad.cpu().numpy(), g["grad0"])
+    mg = net.mixer_flat(up.mixer_grad).cpu().numpy()
+    assert_grad_close(mg, g["mgrad0"])
+    live = torch.zeros_like(up.mixer_grad)
+    for view, _ in net._mixer_views(live, "mixer").values():
+        view.fill_(1.0)
+    assert float(up.mixer_grad[live == 0].abs().max()) == 0.0   # nothing flows into the padding
+    for i in range(3):
+        b = golden_batch(g, i)
+        lo = net.update(Batch(b["obss"].to(DEV), b["actions"].to(DEV), b["rewards"].to(DEV), b["dones"].to(DEV), b["filled"].to(DEV), None))["loss"]
+        assert abs(lo - g["losses"][i]) <= 2e-5 * abs(g["losses"][i])
+        np.testing.assert_allclose(net.params.cpu().numpy(), g[f"params{i + 1}"], rtol=0, atol=3e-6)
+        np.testing.assert_allclose(net.mixer_flat().cpu().numpy(), g[f"mixer{i + 1}"], rtol=0, atol=3e-6)
+        np.testing.assert_allclose(net.mixer_flat(net.target_mixer_params).cpu().numpy(), g[f"tmixer{i + 1}"], rtol=0, atol=3e-6)
+    assert float(net.mixer_params[live == 0].abs().max()) == 0.0       # the padding is still exactly zero after Adam
 
 
 def test_qmix_rejects_other_mixing_configs():
