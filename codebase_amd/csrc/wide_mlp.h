@@ -27,6 +27,13 @@ namespace marl {
 // profiles/r03_flatload_ab.md): the clamped form issues every load of the padded tile, the branchy one skips the out-of-range ones, and
 // these GEMMs are not bound by load latency.)
 
+// (Round 4: the product WITHOUT LDS and barriers - every wave fetching its 64 x 64 quadrant's operands from global memory straight into
+// MFMA layout (a 16-byte load per tile and slice along k-contiguous operands, four dword loads along m / n-contiguous ones), two or
+// three slices deep - was built as a drop-in for wide_gemm128_kernel and measured 20 - 30 % SLOWER on every GEMM-path row (MAA2C
+// 15x15-8p 7.47 -> 6.31 / 5.79 M env-steps/s at depth 2 / 3, MAPPO rware-tiny-4ag 6.29 -> 4.95 / 4.34 M, IDQN 256-256 0.89 -> 0.71 /
+// 0.61 M; scripts/gpu_runs/r4J.sh): an operand fetch in MFMA layout touches 16 rows x 64 bytes per instruction and every wave repeats
+// its workgroup neighbours' loads, so the texture path, not the matrix pipe, sets the pace.  Staging through LDS stays.)
+
 #ifndef MARL_WIDE_KB
 // k depth of one LDS slice of wide_gemm128_kernel.  Measured (scripts/gpu_runs/r3Q.sh): 32 (128 MFMAs per wave between barrier pairs, 37 KB of
 // LDS, twice the prefetch registers) is 3 - 13 % SLOWER than 16 on every GEMM-path row (MAPPO rware 6.20 -> 5.38 M): the kernels live on
