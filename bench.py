@@ -370,7 +370,7 @@ def bench_ac(args, rank, world, dist):
                      fin_len, t_max)
         b_donef.copy_(b_done)  # batch.dones.float() (ac/model.py:198)
         model.update_async(Batch(b_obs, b_act, b_rew, b_donef, b_fill, None), state["step"], grad_sync=sync_grad, world=world)
-        steps_dev.add_(b_fill.sum().to(torch.int64))
+        steps_dev.add_(fin_len.sum())  # == b_fill.sum(): every env stores exactly its first episode (the collector's contract; checked once below)
         ref_steps.add_(t_max[0].to(torch.int64) * N)
         state["round"] += 1
         state["step"] += T * N  # host-side stand-in for the reference's step counter (target update cadence only)
@@ -383,6 +383,8 @@ def bench_ac(args, rank, world, dist):
     for _ in range(args.warmup):
         one_round()
     sync()
+    if not args.rnn and args.warmup > 0:  # the counter above counts what the batch holds
+        assert int(fin_len.sum().item()) == int(b_fill.sum().item()), "stored transitions != sum of first-episode lengths"
     steps_dev.zero_()
     ref_steps.zero_()
     if not args.no_kernel_timing:
