@@ -307,9 +307,16 @@ def traffic_from_profile(key, variant=""):
     return None, {"reason": reason}
 
 
-def _ranks_field(world, dist, args):
-    """Ranks that took part in the gradient all-reduce, as torch.distributed reports them (and the backend: nccl == RCCL)."""
-    return {"world_size": dist.get_world_size() if dist is not None else 1, "backend": args.backend if dist is not None else None}
+def _ranks_field(world, dist, args, sync=None):
+    """Ranks that took part in the gradient exchange, as torch.distributed reports them (backend: nccl == RCCL), and WHICH exchange
+    carried the gradients: "p2p" = the library's own (csrc/p2p.hip: IPC-shared buffers, rank-ordered sum in the reduce launch),
+    "collective" = torch.distributed's all-reduce.  A p2p exchange that ran into its peer timeout fails the run here."""
+    out = {"world_size": dist.get_world_size() if dist is not None else 1, "backend": args.backend if dist is not None else None}
+    if dist is not None:
+        out["exchange"] = "p2p (in-library)" if getattr(sync, "p2p", None) is not None else "collective (torch.distributed.all_reduce)"
+        if sync is not None:
+            sync.check()
+    return out
 
 
 def bench_ac(args, rank, world, dist):
@@ -431,7 +438,7 @@ def bench_ac(args, rank, world, dist):
                                      "frac": cf / (col["avg_us"] * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS}
     out = {
         "metric": f"env-steps/sec (whole node) {args.algo.upper()} {name}", "value": env_steps / dt, "unit": "env-steps/s",
-        "n_gpus": world, "rccl_ranks": _ranks_field(world, dist, args), "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+        "n_gpus": world, "rccl_ranks": _ranks_field(world, dist, args, sync_grad), "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic (Philox-seeded env layouts, orthogonal-init weights)",
         "config": {"workload": f"{args.algo.upper()} on {name}, {N} batched HIP envs per GPU, actor/critic " + (f"GRU-{H} networks (use_rnn), " if args.rnn else f"2-layer-{H} MLPs, ")
@@ -646,6 +653,7 @@ def bench_dqn(args, rank, world, dist, steps, warmup):
                 timing[kname] = {"launches": n.value, "avg_us": 1e3 * ms.value / n.value, "total_ms": ms.value}
         lib.marlhip_timing_enable(0)
 
+    exchange_sync = getattr(trainer, "_sync", None)
     del trainer, model
     if rank != 0:
         return None
@@ -690,7 +698,7 @@ def bench_dqn(args, rank, world, dist, steps, warmup):
         "value": env_steps / dt,
         "unit": "env-steps/s",
         "n_gpus": world,
-        "rccl_ranks": _ranks_field(world, dist, args),
+        "rccl_ranks": _ranks_field(world, dist, args, exchange_sync),
         "steps": steps,
         "warmup": warmup,
         "ms_per_step": 1e3 * dt / steps,

@@ -41,7 +41,11 @@ __device__ __forceinline__ float p2p_wave_sum(const P2pPeers& peers, int rank, i
     __builtin_amdgcn_wave_barrier();
     if (lane == 0) __hip_atomic_store(my_flags + par * max_chunks + chunk64, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     bool mine_late = false;
-    if (lane < world && lane != rank) {
+    // once an exchange has timed out the run is broken anyway (marlhip_p2p_status reports it): later calls still publish, so that
+    // healthy peers do not wait for this rank, but no longer wait themselves - a dead peer costs ONE timeout, not one per update
+    const bool broken = __hip_atomic_load(my_flags + 2 * max_chunks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+    if (broken) mine_late = true;
+    if (!broken && lane < world && lane != rank) {
         const uint32_t* f = peers.flags[lane] + par * max_chunks + chunk64;
         const long long t0 = wall_clock64();
         while ((int32_t)(p2p_ld_sys(f) - epoch) < 0) {

@@ -42,7 +42,9 @@ static __global__ __launch_bounds__(256) void p2p_allreduce_kernel(float* __rest
     __shared__ int s_late;
     if (threadIdx.x == 0) s_late = 0;
     __syncthreads();
-    if (threadIdx.x < world && threadIdx.x != rank) {
+    const bool broken = __hip_atomic_load(my_flags + 2 * max_chunks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;  // see p2p_wave_sum
+    if (broken && threadIdx.x == 0) s_late = 1;
+    if (!broken && threadIdx.x < world && threadIdx.x != rank) {
         const uint32_t* f = peers.flags[threadIdx.x] + par * max_chunks + b;
         const long long t0 = wall_clock64();
         while ((int32_t)(p2p_ld_sys(f) - epoch) < 0) {
@@ -73,10 +75,10 @@ static __global__ __launch_bounds__(256) void p2p_allreduce_kernel(float* __rest
         if (i0 + k < n) grad[i0 + k] = acc[k];
 }
 
-long long p2p_timeout_ticks() {  // wall_clock64 counts at 100 MHz; default 5 s, MARLHIP_P2P_TIMEOUT_MS overrides
+long long p2p_timeout_ticks() {  // wall_clock64 counts at 100 MHz; default 20 s, MARLHIP_P2P_TIMEOUT_MS overrides
     static const long long t = [] {
         const char* v = getenv("MARLHIP_P2P_TIMEOUT_MS");
-        return (long long)((v ? atof(v) : 5000.0) * 1e5);
+        return (long long)((v ? atof(v) : 20000.0) * 1e5);
     }();
     return t;
 }
