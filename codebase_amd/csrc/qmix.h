@@ -124,6 +124,16 @@ __global__ __launch_bounds__(256) void qmix_pack_kernel(const float* __restrict_
 }
 
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
+typedef short sh4 __attribute__((ext_vector_type(4)));
+// weight-gradient operands of the opt-in low-precision mixer: bf16, not fp16 - per-row gradients have no bound an fp16 exponent could hold
+// (a synthetic batch with raw integer observations reaches 1e5 per row: inf in fp16), and bf16 keeps small-integer states exact
+__device__ __forceinline__ sh4 to_bf16x4(float a, float b, float c, float d) {
+    bf4 v;
+    v[0] = (__bf16)a; v[1] = (__bf16)b; v[2] = (__bf16)c; v[3] = (__bf16)d;
+    return __builtin_bit_cast(sh4, v);
+}
+#define MARL_MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x16bf16_1k((a), (b), (c), 0, 0, 0)
 
 // the first-layer A operands rounded to fp16 (round-to-nearest-even), [online | target] behind the fp32 packs
 template <class Q>
@@ -815,7 +825,10 @@ __global__ __launch_bounds__(256, 1) void qmix_mix_kernel(const float* __restric
 // operands are requested before the current block's MFMAs (the loop is latency-bound otherwise: 24-150 MFMAs per wave
 // and block).  Both kernels write disjoint entries of the same per-workgroup record.
 // ---------------------------------------------------------------------------------------------------------
-template <class Q, bool REPLAY>
+// H16 (the opt-in marlhip_qmix_mixer.l1_fp16, BASELINE config 5's "fp16 mixer on MFMA"): both operands of a block rounded to bf16 (see
+// to_bf16x4) and ONE v_mfma_f32_16x16x16_bf16 per tile pair instead of four f32 MFMAs (the lane's four k values of a block are exactly the
+// 4-element operand), fp32 accumulation; the bias gradients (column sums) stay fp32.
+template <class Q, bool REPLAY, bool H16 = false>
 __device__ __forceinline__ void qmix_wgrad1_body(const QmixRows<Q, REPLAY>& src, const QmixBwd& bw, int R, float* __restrict__ partials, int bid, int nwg) {
     constexpr int SD = Q::SD, NTS = Q::KS4, NF1 = Q::NF1;
     constexpr int MG = NTS >= 4 ? 2 : 4, NG = 8 / MG, MPW = Q::MT1 / MG, NPW = (NTS + NG - 1) / NG;
@@ -865,12 +878,25 @@ __device__ __forceinline__ void qmix_wgrad1_body(const QmixRows<Q, REPLAY>& src,
 #pragma unroll
         for (int m = 0; m < MPW; ++m)
             if (ng == 0) cs1[m] += (cur.a[m][0] + cur.a[m][1]) + (cur.a[m][2] + cur.a[m][3]);
+        if constexpr (H16) {
+            sh4 ah[MPW], bh[NPW];
+#pragma unroll
+            for (int m = 0; m < MPW; ++m) ah[m] = to_bf16x4(cur.a[m][0], cur.a[m][1], cur.a[m][2], cur.a[m][3]);
+#pragma unroll
+            for (int n = 0; n < NPW; ++n)
+                bh[n] = sval[n] ? to_bf16x4(cur.b[n][0], cur.b[n][1], cur.b[n][2], cur.b[n][3]) : to_bf16x4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int n = 0; n < NPW; ++n)
+#pragma unroll
+                for (int m = 0; m < MPW; ++m) accW[m][n] = MARL_MFMA_BF16(ah[m], bh[n], accW[m][n]);
+        } else {
 #pragma unroll
         for (int n = 0; n < NPW; ++n)
 #pragma unroll
             for (int m = 0; m < MPW; ++m)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) accW[m][n] = MARL_MFMA(cur.a[m][e], sval[n] ? cur.b[n][e] : 0.f, accW[m][n]);
+        }
         cur = nxt;
     }
     float* rec = partials + (size_t)bid * Q::NPARAM;
@@ -894,7 +920,7 @@ __device__ __forceinline__ void qmix_wgrad1_body(const QmixRows<Q, REPLAY>& src,
     }
 }
 
-template <class Q>
+template <class Q, bool H16 = false>
 __device__ __forceinline__ void qmix_wgrad2_body(const QmixBwd& bw, int R, float* __restrict__ partials, int bid, int nwg) {
     const float* __restrict__ Y1 = bw.HB;
     constexpr int P = Q::P, W1T = Q::W1T, NF1 = Q::NF1, M2W = (W1T + 7) / 8;
@@ -940,17 +966,33 @@ __device__ __forceinline__ void qmix_wgrad2_body(const QmixBwd& bw, int R, float
     if (bA < bB) load(bA, cur);
     for (int blk = bA; blk < bB; ++blk) {
         load(blk + 1 < bB ? blk + 1 : blk, nxt);
+        sh4 hbh[2], hfh;
+        if constexpr (H16) {
+            hbh[0] = to_bf16x4(cur.hb[0][0], cur.hb[0][1], cur.hb[0][2], cur.hb[0][3]);
+            hbh[1] = to_bf16x4(cur.hb[1][0], cur.hb[1][1], cur.hb[1][2], cur.hb[1][3]);
+            hfh = to_bf16x4(cur.hf[0], cur.hf[1], cur.hf[2], cur.hf[3]);
+        }
 #pragma unroll
         for (int m = 0; m < M2W; ++m) {
             csc1[m] += (cur.a2[m][0] + cur.a2[m][1]) + (cur.a2[m][2] + cur.a2[m][3]);
+            if constexpr (H16) {
+                const sh4 a2h = to_bf16x4(cur.a2[m][0], cur.a2[m][1], cur.a2[m][2], cur.a2[m][3]);
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) accB1[m][nt] = MARL_MFMA_BF16(a2h, hbh[nt], accB1[m][nt]);
+            } else {
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) accB1[m][nt] = MARL_MFMA(cur.a2[m][e], cur.hb[nt][e], accB1[m][nt]);
+            }
         }
         if ((w & 1) == 0) cscf += (cur.a3[0] + cur.a3[1]) + (cur.a3[2] + cur.a3[3]);
+        if constexpr (H16) {
+            accBf = MARL_MFMA_BF16(to_bf16x4(cur.a3[0], cur.a3[1], cur.a3[2], cur.a3[3]), hfh, accBf);
+        } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e) accBf = MARL_MFMA(cur.a3[e], cur.hf[e], accBf);
+        }
         if (w == 7) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -1002,11 +1044,11 @@ __device__ __forceinline__ void qmix_wgrad2_body(const QmixBwd& bw, int R, float
 // both weight-gradient GEMM groups in one launch: workgroups [0, nwg) take the first-layer gradients, [nwg, 2 nwg) the mixing-network ones;
 // workgroup b of either group writes its (disjoint) entries of record b.  Each group alone is latency-bound on its operand stream and leaves
 // most of the chip idle; side by side they overlap.
-template <class Q, bool REPLAY>
+template <class Q, bool REPLAY, bool H16 = false>
 __global__ __launch_bounds__(512, 1) void qmix_wgrad_kernel(QmixRows<Q, REPLAY> src, QmixBwd bw, int R, float* __restrict__ partials) {
     const int nwg = gridDim.x >> 1;
-    if ((int)blockIdx.x < nwg) qmix_wgrad1_body<Q, REPLAY>(src, bw, R, partials, blockIdx.x, nwg);
-    else qmix_wgrad2_body<Q>(bw, R, partials, blockIdx.x - nwg, nwg);
+    if ((int)blockIdx.x < nwg) qmix_wgrad1_body<Q, REPLAY, H16>(src, bw, R, partials, blockIdx.x, nwg);
+    else qmix_wgrad2_body<Q, H16>(bw, R, partials, blockIdx.x - nwg, nwg);
 }
 
 // mixer_grad[i] = (sum over records, fixed order) / n_filled ; n_filled = nf[1] as written by dqn_reduce_kernel
@@ -1167,7 +1209,10 @@ int qmix_launch_mix(const QmixCtx& qx, const marlhip_batch* bt, const ReplaySrc&
             hipLaunchKernelGGL((qmix_l1_kernel<Q, REPLAY>), dim3(g1), dim3(256), CH, st, l1o, src, 0, R, y1o, (const h4*)nullptr);
         hipLaunchKernelGGL((qmix_mix_kernel<Q, true>), dim3(g2), dim3(256), LM_ON, st, mxo, (const float*)y1o, io2, R, gamma, bw);
     }
-    hipLaunchKernelGGL((qmix_wgrad_kernel<Q, REPLAY>), dim3(2 * wl.nwg3), dim3(512), 0, st, src, bw, R, reinterpret_cast<float*>(base + wl.partials));
+    if (qx.l1_fp16)  // the opt-in covers the mixer's weight-gradient products too (round 4)
+        hipLaunchKernelGGL((qmix_wgrad_kernel<Q, REPLAY, true>), dim3(2 * wl.nwg3), dim3(512), 0, st, src, bw, R, reinterpret_cast<float*>(base + wl.partials));
+    else
+        hipLaunchKernelGGL((qmix_wgrad_kernel<Q, REPLAY>), dim3(2 * wl.nwg3), dim3(512), 0, st, src, bw, R, reinterpret_cast<float*>(base + wl.partials));
     timing_end(TIMER_QMIX, st);
     MARL_CHECK_LAUNCH("qmix mixer stage");
     return 0;

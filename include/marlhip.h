@@ -676,8 +676,10 @@ typedef struct marlhip_qmix_mixer {
     const struct marlhip_ret_stats* ret_stats; /* cfg.standardise_returns: per-batch-column statistics (columns = batch), or NULL */
     int32_t l1_fp16; /* opt-in DEVIATION from the reference's fp32 mixer (BASELINE config 5: "fp16 mixer on MFMA"): the state-fed first layers of
                       * both mixers - 2 x state_dim x 192 MACs per row, the mixer stage's largest GEMM - run on v_mfma_f32_16x16x16_f16 with
-                      * weights rounded to fp16 (states are small integers: exact), fp32 accumulation; everything else, the backward pass and
-                      * the master parameters stay fp32.  0 = the reference's arithmetic. */
+                      * weights rounded to fp16 (states are small integers: exact), fp32 accumulation; since C-ABI 210 also the mixer's
+                      * weight-gradient products (operands rounded to bf16 - per-row gradients need fp32's exponent range -, one
+                      * v_mfma_f32_16x16x16_bf16 per tile pair, fp32 accumulation).  The backward pass to the agents, the bias gradients
+                      * and the master parameters stay fp32.  0 = the reference's arithmetic. */
 } marlhip_qmix_mixer;
 
 int marlhip_qmix_nparams(const marlhip_net_shape* s, int32_t embed_dim, int32_t hypernet_layers, int32_t hypernet_embed);
