@@ -91,7 +91,10 @@ class P2PExchange:
         return int(self.lib.marlhip_p2p_status(self.state))
 
     def close(self):
+        """frees this rank's buffer and unmaps the peers': call after a job-wide barrier with the device idle (as for a communicator)"""
         if getattr(self, "state", None):
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
             self.lib.marlhip_p2p_destroy(self.state)
             self.state = None
 

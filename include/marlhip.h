@@ -596,7 +596,9 @@ int marlhip_idqn_update_n_dist(const marlhip_idqn_learner* L, int32_t n_updates,
  * (torch.distributed in codebase_amd/parallel.py), every rank calls _connect with all of them, then any number of _allreduce calls -
  * the same sequence of counts on every rank.  A peer that does not arrive within MARLHIP_P2P_TIMEOUT_MS (default 20000) leaves the
  * local gradient untouched and raises the state's error word, which marlhip_p2p_status reads back (it synchronises: not for the
- * hot loop); once raised, later exchanges publish but no longer wait (one timeout per dead peer, not one per update).  Nothing like it exists in the reference (one process). */
+ * hot loop); once raised, later exchanges publish but no longer wait (one timeout per dead peer, not one per update).  _destroy frees the
+ * buffer: the caller synchronises its stream first (no exchange may be in flight), and the peers must have finished reading - destroy
+ * after a barrier of the job, as a communicator would be.  Nothing like it exists in the reference (one process). */
 int marlhip_p2p_handle_bytes(void);
 int marlhip_p2p_create(int32_t rank, int32_t world, int64_t max_floats, void** state_out, void* handle_out);
 int marlhip_p2p_connect(void* state, const void* handles);
