@@ -84,6 +84,11 @@ class IdqnLearner(ctypes.Structure):
                 ("eps", c_double), ("target_update_interval_or_tau", c_double)]
 
 
+class QmixLearner(ctypes.Structure):
+    _fields_ = [("base", IdqnLearner), ("mixer", QmixMixer), ("mixer_rw", c_void_p), ("target_mixer_rw", c_void_p),
+                ("mixer_exp_avg", c_void_p), ("mixer_exp_avg_sq", c_void_p), ("mixer_scratch", c_void_p), ("optimizer", c_int32)]
+
+
 # every symbol include/marlhip.h declares: name -> (restype, argtypes)
 PROTOTYPES = {
     "marlhip_version": (c_int32, []),
@@ -200,6 +205,8 @@ PROTOTYPES = {
                                         POINTER(c_int64), POINTER(c_int64), c_void_p]),
     "marlhip_idqn_update_n_dist": (c_int32, [POINTER(IdqnLearner), c_int32, c_int32, c_uint64, c_uint32, POINTER(c_int64),
                                              POINTER(c_int64), POINTER(c_int64), c_void_p, c_void_p, c_int32, c_void_p]),
+    "marlhip_qmix_update_n": (c_int32, [POINTER(QmixLearner), c_int32, c_int32, c_uint64, c_uint32, POINTER(c_int64), POINTER(c_int64),
+                                        POINTER(c_int64), c_void_p, c_void_p, c_int32, c_void_p]),
     "marlhip_p2p_handle_bytes": (c_int32, []),
     "marlhip_p2p_create": (c_int32, [c_int32, c_int32, c_int64, POINTER(c_void_p), c_void_p]),
     "marlhip_p2p_connect": (c_int32, [c_void_p, c_void_p]),

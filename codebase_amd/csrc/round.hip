@@ -82,3 +82,52 @@ static int update_n(const marlhip_idqn_learner* L, int32_t n_updates, int32_t le
     }
     return 0;
 }
+
+// QMIX: the same loop around marlhip_qmix_loss_grad_replay and the two optimiser steps QmixUpdater.apply issues (codebase_amd/hip.py) -
+// the per-update host loop of VectorisedIDQN moved behind one call, with the same exchange hook as marlhip_idqn_update_n_dist.
+extern "C" int marlhip_qmix_update_n(const marlhip_qmix_learner* Q, int32_t n_updates, int32_t length, uint64_t seed, uint32_t counter0,
+                                     int64_t* adam_step, int64_t* updates, int64_t* last_target_update, marlhip_exchange_fn exchange,
+                                     void* exchange_ctx, int32_t world, void* stream) {
+    MARL_REQUIRE(Q && adam_step && updates && last_target_update, "qmix_update_n: NULL pointer");
+    const marlhip_idqn_learner* L = &Q->base;
+    MARL_REQUIRE(n_updates >= 0 && L->batch > 0 && world >= 1, "qmix_update_n: bad counts");
+    MARL_REQUIRE(Q->mixer_rw == Q->mixer.mixer && Q->target_mixer_rw == Q->mixer.target_mixer, "qmix_update_n: mixer_rw / target_mixer_rw must alias mixer.mixer / mixer.target_mixer");
+    const int np = marlhip_net_nparams(&L->net);
+    if (np < 0) return -1;
+    const int nm = marlhip_qmix_nparams(&L->net, Q->mixer.embed_dim, Q->mixer.hypernet_layers, Q->mixer.hypernet_embed);
+    if (nm < 0) return -1;
+    const int64_t n_all = (int64_t)(L->net.n_networks > 0 ? L->net.n_networks : L->net.n_agents) * np;
+    MARL_REQUIRE(exchange == nullptr || Q->mixer.mixer_grad == L->grad + n_all, "qmix_update_n: the exchange needs [critic | mixer] gradients in one allocation");
+    const double tui = L->target_update_interval_or_tau;
+    const float scale = exchange != nullptr ? 1.0f / (float)world : 1.0f;
+    for (int u = 0; u < n_updates; ++u) {
+        int rc = marlhip_qmix_loss_grad_replay(&L->net, L->params, L->target, &Q->mixer, &L->rs, &L->rb, nullptr, L->batch, length, seed,
+                                               counter0 + (uint32_t)u, L->idx, L->gamma, L->double_q, L->workspace, L->workspace_bytes, L->grad,
+                                               L->loss, stream);
+        if (rc < 0) return rc;
+        if (exchange != nullptr) {
+            rc = exchange(exchange_ctx, L->grad, n_all + nm, stream);
+            MARL_REQUIRE(rc == 0, "qmix_update_n: the gradient exchange callback failed (%d)", rc);
+        }
+        *updates += 1;
+        *adam_step += 1;
+        const bool hard = tui > 1.0 && (double)(*updates - *last_target_update) >= tui;
+        const float tau = tui < 1.0 ? (float)tui : 0.f;
+        if (Q->optimizer == 0) {
+            rc = marlhip_dqn_clip_adam(n_all, L->params, L->grad, L->exp_avg, L->exp_avg_sq, L->target, *adam_step, L->lr, L->beta1, L->beta2, L->eps,
+                                       L->max_norm, scale, hard ? 1 : 0, tau, L->scratch, L->gnorm, stream);
+            if (rc < 0) return rc;
+            rc = marlhip_dqn_clip_adam(nm, Q->mixer_rw, Q->mixer.mixer_grad, Q->mixer_exp_avg, Q->mixer_exp_avg_sq, Q->target_mixer_rw, *adam_step, L->lr,
+                                       L->beta1, L->beta2, L->eps, 0.f, scale, hard ? 1 : 0, tau, Q->mixer_scratch, nullptr, stream);
+        } else {
+            rc = marlhip_dqn_clip_step(Q->optimizer, n_all, L->params, L->grad, L->exp_avg, L->exp_avg_sq, L->target, *adam_step, L->lr, L->max_norm, scale,
+                                       hard ? 1 : 0, tau, L->scratch, L->gnorm, stream);
+            if (rc < 0) return rc;
+            rc = marlhip_dqn_clip_step(Q->optimizer, nm, Q->mixer_rw, Q->mixer.mixer_grad, Q->mixer_exp_avg, Q->mixer_exp_avg_sq, Q->target_mixer_rw, *adam_step,
+                                       L->lr, 0.f, scale, hard ? 1 : 0, tau, Q->mixer_scratch, nullptr, stream);
+        }
+        if (rc < 0) return rc;
+        if (hard) *last_target_update = *updates;
+    }
+    return 0;
+}

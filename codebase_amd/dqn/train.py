@@ -226,6 +226,21 @@ class VectorisedIDQN:
                                                               grad_sync=self._sync if self.dist is not None else None, world=self.world)
             self.sample_counter += self.U
             self.last_loss = m.updater.loss
+        elif train and m.mode == 2 and type(m.updater) is _hip.QmixUpdater and not _NO_FUSED_LOOP:
+            # QMIX on the fused agent kernels: the U updates (loss/grad with the in-kernel gather, the joint [critic | mixer] gradient exchange,
+            # both optimiser steps, target copies) from ONE library call (marlhip_qmix_update_n) - the same launches as the loop below
+            if self._fused is None:
+                self._fused = _hip.FusedQmixLearner(m.updater, self.replay, self.B, m.target_update_interval_or_tau)
+                if self.dist is not None:
+                    from ..parallel import GradSync
+
+                    self._sync = GradSync(self.dist, max_floats=m.updater.joint_grad.numel())
+            length = min(self.rounds * self.N, self.capacity)
+            m.updates, m.last_target_update = self._fused.run(self.U, length, rank_sample_seed(self.seed, self.rank), self.sample_counter,
+                                                              m.updates, m.last_target_update,
+                                                              grad_sync=self._sync if self.dist is not None else None, world=self.world)
+            self.sample_counter += self.U
+            self.last_loss = m.updater.loss
         elif train:
             length = min(self.rounds * self.N, self.capacity)
             sync = self._grad_sync if self.dist is not None else None

@@ -8,7 +8,7 @@ from dataclasses import dataclass
 import torch
 
 from . import _lib
-from ._lib import (AcConfig, BatchStruct, IdqnLearner, RetStatsStruct, QmixMixer, LbfBuffers, LbfConfig, MarlHipError, RwareConfig, NetShape, ReplayBuffers, ReplayShape, check, lib)
+from ._lib import (AcConfig, BatchStruct, IdqnLearner, QmixLearner, RetStatsStruct, QmixMixer, LbfBuffers, LbfConfig, MarlHipError, RwareConfig, NetShape, ReplayBuffers, ReplayShape, check, lib)
 
 Batch = namedtuple("Batch", ["obss", "actions", "rewards", "dones", "filled", "action_mask"])  # dqn/train.py:14-16
 
@@ -780,6 +780,50 @@ class FusedLearner:
                                                 ex.ptr, None, int(world), _stream())
             ex.check()
             check(rc, "idqn_update_n_dist")
+        self.up.step = step.value
+        return upd.value, last.value
+
+
+class FusedQmixLearner:
+    """n QMIX updates per host call (marlhip_qmix_update_n): the per-update host loop of the trainer - loss/grad with the in-kernel
+    gather, the joint [critic | mixer] gradient exchange, the two optimiser steps, target copies - behind one library call, with the
+    same exchange hook as FusedLearner (a C function pointer for the in-library exchange, a ctypes callback otherwise)."""
+
+    def __init__(self, updater, replay: DeviceReplay, batch, target_update_interval_or_tau):
+        self.up, self.replay, self.B = updater, replay, int(batch)
+        outs = replay._outputs(self.B)
+        ws = updater._workspace(replay.T, self.B)
+        base = IdqnLearner(
+            net=updater.spec.c(), rs=replay.shape, rb=replay.bufs, params=updater.params.data_ptr(),
+            target=updater.target.data_ptr(), exp_avg=updater.exp_avg.data_ptr(), exp_avg_sq=updater.exp_avg_sq.data_ptr(),
+            grad=updater.grad.data_ptr(), loss=updater.loss.data_ptr(), scratch=updater.scratch.data_ptr(),
+            gnorm=updater.gnorm.data_ptr(), workspace=ws.data_ptr(), workspace_bytes=ws.numel(),
+            obss=outs[0].data_ptr(), actions=outs[1].data_ptr(), rewards=outs[2].data_ptr(), dones=outs[3].data_ptr(),
+            filled=outs[4].data_ptr(), idx=outs[5].data_ptr(), batch=self.B, double_q=updater.double_q, mode=2, materialise_batch=0,
+            gamma=float(updater.gamma), max_norm=float(updater.grad_clip), lr=float(updater.lr), beta1=float(updater.betas[0]),
+            beta2=float(updater.betas[1]), eps=float(updater.eps), target_update_interval_or_tau=float(target_update_interval_or_tau))
+        self.c = QmixLearner(base=base, mixer=updater._mx(self.B), mixer_rw=updater.mixer.data_ptr(), target_mixer_rw=updater.target_mixer.data_ptr(),
+                             mixer_exp_avg=updater.mixer_exp_avg.data_ptr(), mixer_exp_avg_sq=updater.mixer_exp_avg_sq.data_ptr(),
+                             mixer_scratch=updater.mixer_scratch.data_ptr(), optimizer=int(updater.optimizer))
+        self._keep = (outs, ws)
+
+    def run(self, n_updates, length, seed, counter0, updates, last_target_update, grad_sync=None, world=1):
+        step = ctypes.c_int64(self.up.step)
+        upd = ctypes.c_int64(int(updates))
+        last = ctypes.c_int64(int(last_target_update))
+        args = (ctypes.byref(self.c), int(n_updates), int(length), int(seed) & (2**64 - 1), int(counter0) & 0xFFFFFFFF, ctypes.byref(step),
+                ctypes.byref(upd), ctypes.byref(last))
+        if grad_sync is None:
+            check(lib.marlhip_qmix_update_n(*args, None, None, 1, _stream()), "qmix_update_n")
+        elif getattr(grad_sync, "c_fn", None) is not None:
+            check(lib.marlhip_qmix_update_n(*args, grad_sync.c_fn, grad_sync.c_ctx, int(world), _stream()), "qmix_update_n")
+        else:
+            ex = getattr(self, "_exchange", None)
+            if ex is None or ex.reduce is not grad_sync:
+                ex = self._exchange = Exchange(self.up.joint_grad, grad_sync)
+            rc = lib.marlhip_qmix_update_n(*args, ex.ptr, None, int(world), _stream())
+            ex.check()
+            check(rc, "qmix_update_n")
         self.up.step = step.value
         return upd.value, last.value
 

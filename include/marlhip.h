@@ -698,6 +698,25 @@ int marlhip_qmix_loss_grad_replay(const marlhip_net_shape* s, const float* param
                                   uint64_t seed, uint32_t counter, int32_t* idx_out, float gamma, int32_t double_q,
                                   void* workspace, int64_t workspace_bytes, float* grad, float* loss, void* stream);
 
+/* The same n-updates loop for QMIX (C-ABI 210): n x (marlhip_qmix_loss_grad_replay -> [exchange of the joint gradient] -> clip + step on
+ * the critic block -> step on the mixer block) with QNetwork.update's bookkeeping, i.e. what QMixNetwork.update + update_target do per
+ * update (marlbase/dqn/model.py:165-185, 429-443: clip_grad_norm_ over the CRITIC parameters only, one optimiser step count for critic
+ * and mixer, hard copy / Polyak of target AND target mixer).  `base` carries the agent side exactly as for marlhip_idqn_update_n (its
+ * workspace sized by marlhip_qmix_workspace_bytes, mode ignored); `mixer.mixer` / `.target_mixer` are written (they alias mixer_rw /
+ * target_mixer_rw).  exchange != NULL (data-parallel): base.grad and mixer.mixer_grad must be ONE allocation [critic | mixer] - the
+ * exchange gets it as one message - and world the number of ranks; NULL: single process.  optimizer as marlhip_dqn_clip_step. */
+typedef struct marlhip_qmix_learner {
+    marlhip_idqn_learner base;
+    marlhip_qmix_mixer mixer;
+    float *mixer_rw, *target_mixer_rw;           /* the same blocks as mixer.mixer / mixer.target_mixer, writable */
+    float *mixer_exp_avg, *mixer_exp_avg_sq;     /* [marlhip_qmix_nparams] each */
+    float* mixer_scratch;                        /* >= ceil(n_mixer / 256) + 1 floats */
+    int32_t optimizer;
+} marlhip_qmix_learner;
+int marlhip_qmix_update_n(const marlhip_qmix_learner* L, int32_t n_updates, int32_t length, uint64_t seed, uint32_t counter0,
+                          int64_t* adam_step, int64_t* updates, int64_t* last_target_update, marlhip_exchange_fn exchange,
+                          void* exchange_ctx, int32_t world, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Measurement aid (bench.py roofline leg): when enabled, the named kernels are bracketed by HIP
  * events on the stream they are launched on.  ids: 0 loss/grad kernel, 1 fused collector,

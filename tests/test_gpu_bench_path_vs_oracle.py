@@ -253,9 +253,10 @@ def test_reference_cadence_64_sequential_updates_of_32_vs_oracle_port(H):
 
 
 def test_qmix_host_loop_through_the_trainer_B4096_vs_oracle_port():
-    """QMIX 8x8-2p as bench.py --algo qmix runs it: VectorisedIDQN.round = fused collector (4096 cooperative envs) + U x
-    QMixNetwork.update_async (in-library index draw, in-kernel gather, agents + mixer loss/grad, clip over the critic only, one Adam
-    over critic + mixer, hard copy of target and target mixer inside the round).  The right-hand side is oracle/qmix_port.Learner
+    """QMIX 8x8-2p as bench.py --algo qmix runs it: VectorisedIDQN.round = fused collector (4096 cooperative envs) + U updates from
+    marlhip_qmix_update_n (round 4; before: U x QMixNetwork.update_async from the host - the same launches: in-library index draw,
+    in-kernel gather, agents + mixer loss/grad, clip over the critic only, one Adam over critic + mixer, hard copy of target and
+    target mixer inside the round).  The right-hand side is oracle/qmix_port.Learner
     on the batches rebuilt from the host copy of what the collector stored."""
     from codebase_amd import hip as h
     from codebase_amd.dqn.model import QMixNetwork

@@ -147,6 +147,36 @@ def test_qmix_narrow_mixer_matches_reference_golden():
     assert float(net.mixer_params[live == 0].abs().max()) == 0.0       # the padding is still exactly zero after Adam
 
 
+def test_qmix_library_loop_equals_the_host_loop_bit_for_bit(monkeypatch):
+    """marlhip_qmix_update_n (the trainer's default since round 4) issues exactly the launches of the per-update host loop
+    (QMixNetwork.update_async x U): two trainers on the same seeds, one forced onto the host loop, must end with the same bytes -
+    critic, target, mixer, target mixer, Adam moments, counters - across a hard target copy inside a round"""
+    from codebase_amd.dqn import train as T
+    from codebase_amd.dqn.model import QMixNetwork
+    from codebase_amd.utils.envs import _space_pair
+
+    h = hip()
+    out = []
+    for host_loop in (False, True):
+        monkeypatch.setattr(T, "_NO_FUSED_LOOP", host_loop)
+        cfg = h.env_config("lbforaging:Foraging-8x8-2p-3f-v3", 256, 25, seed=9, cooperative=True)
+        torch.manual_seed(4)
+        obs_space, act_space = _space_pair(cfg)
+        hyper = dict(optimizer="Adam", lr=3e-4, gamma=0.99, grad_clip=1.0, double_q=True, standardise_returns=False, target_update_interval_or_tau=4)
+        m = QMixNetwork(obs_space, act_space, hyper, [64, 64], False, False, True, dict(embed_dim=64, hypernet_layers=2, hypernet_embed=32), "cuda")
+        tr = T.VectorisedIDQN(cfg, m, 512, 25, 96, 3, seed=2)
+        for _ in range(3):
+            tr.round(0.4)
+        torch.cuda.synchronize()
+        assert (tr._fused is not None) == (not host_loop)
+        out.append((m.updates, m.last_target_update, m.updater.step, [t.cpu().clone() for t in (m.params, m.target_params, m.mixer_params, m.target_mixer_params,
+                                                                                               m.updater.exp_avg_sq, m.updater.mixer_exp_avg, tr.last_loss)]))
+    (ua, la, sa, ta), (ub, lb, sb, tb) = out
+    assert (ua, la, sa) == (ub, lb, sb) == (9, 8, 9)
+    for x, y in zip(ta, tb):
+        assert torch.equal(x, y)
+
+
 def test_qmix_rejects_other_mixing_configs():
     h = hip()
     from codebase_amd._lib import MarlHipError

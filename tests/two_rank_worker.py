@@ -39,7 +39,8 @@ def main():
                  target_update_interval_or_tau=3)
     # (class, extra constructor arguments, hidden width, standardise_returns): hidden-64 IDQN takes the library's n-updates call in its
     # data-parallel form (marlhip_idqn_update_n_dist: reduce -> exchange -> clip + Adam + packs), hidden 128 the same call's generic
-    # loop, QMIX and standardise_returns the per-update host loop
+    # loop, QMIX its own library loop (marlhip_qmix_update_n, the joint [critic | mixer] gradient as one message), standardise_returns the
+    # per-update host loop
     cases = ((QNetwork, (), 64, False), (QNetwork, (), 128, False), (QNetwork, (), 64, True),
              (QMixNetwork, (dict(embed_dim=64, hypernet_layers=2, hypernet_embed=32),), 64, False))
     for cls, extra, hidden, std in cases:
@@ -49,7 +50,7 @@ def main():
         for r in range(3):
             tr.round(0.3)
         torch.cuda.synchronize()
-        assert (tr._fused is not None) == (cls is QNetwork and not std), "which cases take the n-updates library call changed"
+        assert (tr._fused is not None) == (not std), "which cases take an n-updates library call changed"  # IDQN: marlhip_idqn_update_n_dist; QMIX: marlhip_qmix_update_n
         if os.environ.get("MARLHIP_P2P", "1") != "0":  # the gradient went through marlhip_p2p_allreduce (a C pointer inside the library loop, a ctypes call in the host loops)
             assert tr._sync is not None and tr._sync.p2p is not None and tr._sync.p2p.status() == 0, "p2p exchange missing or timed out"
         assert model.updates == 12 and model.updater.step == 12
