@@ -34,6 +34,11 @@ namespace marl {
 // 0.61 M; scripts/gpu_runs/r4J.sh): an operand fetch in MFMA layout touches 16 rows x 64 bytes per instruction and every wave repeats
 // its workgroup neighbours' loads, so the texture path, not the matrix pipe, sets the pace.  Staging through LDS stays.)
 
+#ifndef MARL_WIDE_PF
+// slices of register prefetch in wide_gemm128_kernel.  Measured (scripts/gpu_runs/r4M.sh): 2 (a second register set, the slice stored at the
+// top of iteration k requested two iterations earlier) is within 1 % of 1 on every GEMM-path row - resident workgroups hide the latency
+#define MARL_WIDE_PF 1
+#endif
 #ifndef MARL_WIDE_KB
 // k depth of one LDS slice of wide_gemm128_kernel.  Measured (scripts/gpu_runs/r3Q.sh): 32 (128 MFMAs per wave between barrier pairs, 37 KB of
 // LDS, twice the prefetch registers) is 3 - 13 % SLOWER than 16 on every GEMM-path row (MAPPO rware 6.20 -> 5.38 M): the kernels live on
@@ -130,6 +135,20 @@ __global__ __launch_bounds__(256) void wide_gemm_kernel(const GemmOp g) {
         }
     }
     float* C = g.C + (int64_t)blockIdx.z * g.c_split;
+    // epilogue operands requested together from clamped addresses (see wide_gemm128_kernel): no dependent round trip per element
+    f4 bias4 = {0.f, 0.f, 0.f, 0.f}, gate[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int n = n0 + 16 * nt + i, nc = n < g.N ? n : g.N - 1;
+        if (g.epi == 1 || g.epi == 2) bias4[nt] = g.bias[nc];
+        if (g.epi == 3) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + 16 * wave + 4 * q + r;
+                gate[nt][r] = g.gate[(int64_t)(m < g.M ? m : g.M - 1) * g.gate_m + nc];
+            }
+        }
+    }
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
         const int n = n0 + 16 * nt + i;
@@ -138,9 +157,9 @@ __global__ __launch_bounds__(256) void wide_gemm_kernel(const GemmOp g) {
             const int m = m0 + 16 * wave + 4 * q + r;
             if (m < g.M && n < g.N) {
                 float v = acc[nt][r];
-                if (g.epi == 1 || g.epi == 2) v += g.bias[n];
+                if (g.epi == 1 || g.epi == 2) v += bias4[nt];
                 if (g.epi == 2) v = fmaxf(v, 0.f);
-                if (g.epi == 3) v = g.gate[(int64_t)m * g.gate_m + n] > 0.f ? v : 0.f;
+                if (g.epi == 3) v = gate[nt][r] > 0.f ? v : 0.f;
                 C[(int64_t)m * g.c_m + n] = v;
             }
         }
@@ -165,8 +184,12 @@ __global__ __launch_bounds__(256) void wide_gemm128_kernel(const GemmOp g) {
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = f4{0.f, 0.f, 0.f, 0.f};
-    f4 ra[NS][2], rb[NS][2];
-    auto load = [&](int kbase) {
+    // PF register sets: the slice stored to LDS at the top of iteration k was requested PF iterations earlier (MARL_WIDE_PF above)
+    constexpr int PF = MARL_WIDE_PF;  // slices of prefetch: 2 = two register sets, 1 = one
+    f4 rset[PF][2][NS][2];  // [set][A | B][sub-slice][row half]
+    auto load = [&](int kbase, int set) {
+        f4 (&ra)[NS][2] = rset[set][0];
+        f4 (&rb)[NS][2] = rset[set][1];
 #pragma unroll
         for (int ss = 0; ss < NS; ++ss) {
             const int k0 = kbase + 16 * ss;
@@ -192,7 +215,9 @@ __global__ __launch_bounds__(256) void wide_gemm128_kernel(const GemmOp g) {
             }
         }
     };
-    auto store = [&]() {
+    auto store = [&](int set) {
+        f4 (&ra)[NS][2] = rset[set][0];
+        f4 (&rb)[NS][2] = rset[set][1];
 #pragma unroll
         for (int ss = 0; ss < NS; ++ss)
 #pragma unroll
@@ -211,12 +236,11 @@ __global__ __launch_bounds__(256) void wide_gemm128_kernel(const GemmOp g) {
                 }
             }
     };
-    if (kbeg < kend) load(kbeg);
-    for (int k0 = kbeg; k0 < kend; k0 += KB) {
+    auto slice = [&](int k0, int set) {  // one k-slice: its operands to LDS, the slice two ahead requested, then the MFMAs
         __syncthreads();
-        store();
+        store(set);
         __syncthreads();
-        if (k0 + KB < kend) load(k0 + KB);
+        if (k0 + PF * KB < kend) load(k0 + PF * KB, set);
 #pragma unroll
         for (int ss = 0; ss < NS; ++ss) {
             f4 a[4], b[4];
@@ -232,10 +256,44 @@ __global__ __launch_bounds__(256) void wide_gemm128_kernel(const GemmOp g) {
 #pragma unroll
                     for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = MARL_MFMA(a[mt][s2], b[nt][s2], acc[mt][nt]);
         }
+    };
+    if (kbeg < kend) load(kbeg, 0);
+    if constexpr (PF == 2) {
+        if (kbeg + KB < kend) load(kbeg + KB, 1);
+        for (int k0 = kbeg; k0 < kend; k0 += 2 * KB) {
+            slice(k0, 0);
+            if (k0 + KB < kend) slice(k0 + KB, 1);
+        }
+    } else {
+        for (int k0 = kbeg; k0 < kend; k0 += KB) slice(k0, 0);
     }
     float* C = g.C + (int64_t)blockIdx.z * g.c_split;
+    // epilogue operands up front (round 4): a bias or gate value fetched under the `in range` branch of ITS element is a dependent round
+    // trip per element - 64 per lane, first-touch HBM accesses for the gate - and made the layer-to-layer gradient product an
+    // epilogue-latency kernel (the static scan lists it as a chain of 64 loads).  The lane's 4 bias values and its 64 gate values are
+    // requested in one go from clamped addresses; out-of-range elements are still not stored.
+    float bias4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (g.epi == 1 || g.epi == 2) {
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+        for (int nt = 0; nt < 4; ++nt) {
+            const int n = n0 + 64 * wn + 16 * nt + i;
+            bias4[nt] = g.bias[n < g.N ? n : g.N - 1];
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        f4 gate[4];
+        if (g.epi == 3) {
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const int n = n0 + 64 * wn + 16 * nt + i;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = m0 + 64 * wm + 16 * mt + 4 * q + r;
+                    gate[nt][r] = g.gate[(int64_t)(m < g.M ? m : g.M - 1) * g.gate_m + (n < g.N ? n : g.N - 1)];
+                }
+            }
+        }
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             const int n = n0 + 64 * wn + 16 * nt + i;
@@ -244,13 +302,14 @@ __global__ __launch_bounds__(256) void wide_gemm128_kernel(const GemmOp g) {
                 const int m = m0 + 64 * wm + 16 * mt + 4 * q + r;
                 if (m < g.M && n < g.N) {
                     float v = acc[mt][nt][r];
-                    if (g.epi == 1 || g.epi == 2) v += g.bias[n];
+                    if (g.epi == 1 || g.epi == 2) v += bias4[nt];
                     if (g.epi == 2) v = fmaxf(v, 0.f);
-                    if (g.epi == 3) v = g.gate[(int64_t)m * g.gate_m + n] > 0.f ? v : 0.f;
+                    if (g.epi == 3) v = gate[nt][r] > 0.f ? v : 0.f;
                     C[(int64_t)m * g.c_m + n] = v;
                 }
             }
         }
+    }
 }
 
 // dW[m][n < N - 1] and db[m] (column N - 1) = (sum over the splits, in split order) * inv, inv = 1 / nf[0]
