@@ -4,11 +4,13 @@
 #include "collect_common.h"
 #include "gru_rows.h"
 #include "wide_mlp.h"
+#include "wide_critic.h"
 
 namespace marl {
 
-// A critic whose input is too wide for the fused kernels (wide_mlp.h): hidden width H fixed by the type, the input width set by the
-// entry point for the duration of its call (thread-local: calls on different host threads never meet).
+// A centralised critic whose input is too wide for the register-resident kernels (wide_critic.h: layer 1 streamed through LDS, the three
+// layers fused): hidden width H fixed by the type, the input width set by the entry point for the duration of its call (thread-local:
+// calls on different host threads never meet).
 template <int H_>
 struct WideCritic {
     static constexpr int H = H_, A = 1;
@@ -29,11 +31,16 @@ template <int H>
 struct IsWide<WideCritic<H>> : std::true_type {};
 template <int TAG>
 struct IsWide<WideRt<TAG>> : std::true_type {};
+template <class S>
+struct IsWideCritic : std::false_type {};
+template <int H>
+struct IsWideCritic<WideCritic<H>> : std::true_type {};
 
 // bytes of forward-pack scratch (collect_pack_scratch) a forward-rows launch of shape S over n_rows rows wants
 template <class S>
 int64_t forward_scratch_bytes(int P, int n_rows) {
-    if constexpr (IsWide<S>::value) return wide_ws(S::net(), P, n_rows, false).total + 16;
+    if constexpr (IsWideCritic<S>::value) return wc_pack_bytes(P, S::D, S::H) + 16;
+    else if constexpr (IsWide<S>::value) return wide_ws(S::net(), P, n_rows, false).total + 16;
     else return (int64_t)P * S::NFWD * 4 + 16;
 }
 
@@ -129,6 +136,12 @@ int launch_forward_rows(int P, const AgentMap& am, const float* params, const ma
                         float* rec = nullptr) {
     if constexpr (IsGru<S>::value) {
         return gru_forward_rows<S>(P, am, params, bt, n_rows / bt->batch, out, st, rec);
+    } else if constexpr (IsWideCritic<S>::value) {
+        MARL_REQUIRE(S::D > 0, "wide critic: input width not set");
+        const int64_t as = bt->obs_agent_stride > 0 ? bt->obs_agent_stride : (bt->obs_agent_stride < 0 ? 0 : (int64_t)(bt->max_len + 1) * bt->batch * S::D);
+        const int64_t rs = bt->obs_row_stride ? bt->obs_row_stride : S::D;
+        MARL_REQUIRE(rec == nullptr || n_rows == bt->max_len * bt->batch, "wide critic forward: a hidden-layer record needs n_rows == T*B");
+        return wc_forward_rows<S::H>(P, am, params, S::D, bt->obss, as, rs, n_rows, out, rec, st);
     } else if constexpr (IsWide<S>::value) {
         (void)rec;
         const WideNet s = S::net();
@@ -198,6 +211,8 @@ template <class S>
 int64_t backward_ws_bytes(int P, int T, int B) {
     if constexpr (IsGru<S>::value) {
         return gru_rows_ws<S>(P, T, B, false).total;  // the step's forward passes write the records (AcWs::rec_a / rec_c)
+    } else if constexpr (IsWideCritic<S>::value) {
+        return wc_ws(P, T * B, S::D, S::H).total;
     } else if constexpr (IsWide<S>::value) {
         return wide_ws(S::net(), P, T * B, true).total;
     } else if constexpr (use_tp<S>()) {
@@ -216,6 +231,13 @@ int launch_backward_rows(int P, const AgentMap& am, const float* params, const m
     if constexpr (IsGru<S>::value) {
         MARL_REQUIRE(rec != nullptr, "ac backward: the recurrent networks need the forward record");
         return gru_backward_rows<S>(P, am, params, bt, bt->max_len, dout, lrow, ws, ws_bytes, grad, loss, st, rec);
+    } else if constexpr (IsWideCritic<S>::value) {
+        const int T = bt->max_len, B = bt->batch;
+        MARL_REQUIRE(rec != nullptr, "ac backward: the wide critics need the hidden layers of this step's forward pass");
+        MARL_REQUIRE(ws_bytes >= backward_ws_bytes<S>(P, T, B), "ac backward: workspace %lld too small", (long long)ws_bytes);
+        const int64_t as = bt->obs_agent_stride > 0 ? bt->obs_agent_stride : (bt->obs_agent_stride < 0 ? 0 : (int64_t)(T + 1) * B * S::D);
+        const int64_t rs = bt->obs_row_stride ? bt->obs_row_stride : S::D;
+        return wc_backward_rows<S::H>(P, am, params, S::D, bt->obss, as, rs, T * B, bt->filled, dout, lrow, ws, grad, loss, st, rec);
     } else if constexpr (IsWide<S>::value) {
         (void)rec;
         const WideNet s = S::net();
@@ -518,6 +540,7 @@ AcWs ac_ws_layout(int P, int T, int B) {
     else if constexpr (mlp_stored_shape<SA>()) w.rec_a = take(mlp_stored_floats<SA>(P, T, B));  // hidden layers of the actors' rows for their backward pass
     if constexpr (IsGru<SC>::value) w.rec_c = take(gru_rec_floats<SC>(P, T, B));
     else if constexpr (mlp_stored_shape<SC>()) w.rec_c = take(mlp_stored_floats<SC>(P, T, B));
+    else if constexpr (IsWideCritic<SC>::value) w.rec_c = take(wc_rec_floats(P, (int)TB, SC::H));  // both hidden layers of the critics' rows
     w.bwd = o;
     const int64_t ba = backward_ws_bytes<SA>(P, T, B), bc = backward_ws_bytes<SC>(P, T, B);
     // recurrent networks: the two backward passes run side by side (side_stream) and need a workspace each
@@ -556,7 +579,7 @@ int ac_step_t(int P, const AgentMap& am, const float* actor, const float* critic
     int rc;
     timing_begin(TIMER_LOSSGRAD, st);
     float* rec_a = (IsGru<SA>::value || (mlp_stored_shape<SA>() && B % 16 == 0)) && mode != 1 ? f(wl.rec_a) : nullptr;
-    float* rec_c = (IsGru<SC>::value || (mlp_stored_shape<SC>() && B % 16 == 0 && mode != 1)) ? f(wl.rec_c) : nullptr;
+    float* rec_c = (IsGru<SC>::value || (mlp_stored_shape<SC>() && B % 16 == 0 && mode != 1) || (IsWideCritic<SC>::value && mode != 1)) ? f(wl.rec_c) : nullptr;
     bool v_done = false;
     // PPO's passes with recurrent networks (prepare: target critics + actors; epochs: actors + critics): the critics' sequence pass
     // goes to the side stream next to the actors' (each fills half of the SIMDs), with its packs in the critics' backward workspace
