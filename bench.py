@@ -242,6 +242,13 @@ def qmix_mixer_fwd_flops(P, SD):
     return 2.0 * (192 * SD + 32 * 64 * P + 32 * 64 + 64)
 
 
+def first_layer_dx_flops(D, H):
+    """the one product `backward = 2 x forward` counts that no implementation runs: the gradient w.r.t. a network's INPUT rows
+    (2 D H per row).  Small for the 15-wide LBF rows (18 % of a forward), most of a 312-wide centralised critic's (71 %): the
+    roofline objects carry `frac` by the usual convention (comparable across rounds) and `frac_needed` without this product."""
+    return 2.0 * D * H
+
+
 def dqn_update_flops(algo, rnn, P, D, A, H, T, B):
     """critic forward on T+1 observations, target forward on T (T+1 for recurrent nets: the sequence starts at t = 0), backward =
     2 x forward on the T transitions (T+1 steps of BPTT for recurrent nets); QMIX adds online + target mixer forward and the
@@ -251,7 +258,8 @@ def dqn_update_flops(algo, rnn, P, D, A, H, T, B):
     else:
         agents = mlp_fwd_flops(D, H, A) * P * B * ((T + 1) + T + 2 * T)
     mixer = 4.0 * qmix_mixer_fwd_flops(P, P * D) * T * B if algo == "qmix" else 0.0
-    return agents + mixer, {"agent_networks": agents, "mixer": mixer}
+    unneeded = first_layer_dx_flops(D, H) * P * B * (T + 1 if rnn else T)
+    return agents + mixer, {"agent_networks": agents, "mixer": mixer, "first_layer_input_gradient (counted, never run)": unneeded}
 
 
 def ac_update_flops(rnn, P, D, A, H, T, N, central, epochs=1):
@@ -263,6 +271,12 @@ def ac_update_flops(rnn, P, D, A, H, T, N, central, epochs=1):
     if epochs > 1:  # launch groups under the timer per rollout: 1 prepare + `epochs` epoch steps
         return P * N * ((fc * (T + 1) + fa * T) + epochs * (3 * fc + 3 * fa) * T) / (1 + epochs)
     return P * N * (fc * (T + 1) + 3 * fc * T + 3 * fa * T)
+
+
+def ac_unneeded_flops(P, D, H, T, N, central, epochs=1):
+    """the first-layer input-gradient products inside ac_update_flops (see first_layer_dx_flops), per launch group like it"""
+    dx = (first_layer_dx_flops(D, H) + first_layer_dx_flops(P * D if central else D, H)) * P * N * T
+    return dx * epochs / (1 + epochs) if epochs > 1 else dx
 
 
 TRAFFIC_SOURCES = {"": ("dqn_update_kernels.h", "mlp.h"), "H128": ("dqn_update_tp.h", "mlp.h"), "split16": ("dqn_update_h16.h", "mlp.h")}
@@ -427,9 +441,11 @@ def bench_ac(args, rank, world, dist):
     if upd:
         flops = ac_update_flops(bool(args.rnn), P, D, A, H, T, N, central, epochs=hyper["num_epochs"] if args.algo in ("ippo", "mappo") else 1)
         ach = flops / (upd["avg_us"] * 1e-6) / 1e12
+        needed = flops - ac_unneeded_flops(P, D, H, T, N, central, epochs=hyper["num_epochs"] if args.algo in ("ippo", "mappo") else 1)
         roofline = {"kernel": "ac_update stage (forward rows, elementwise, backward rows)", "bound": "mfma", "achieved": ach,
                     "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
                     "flops_per_launch": flops, "avg_launch_us": upd["avg_us"],
+                    "flops_needed_per_launch": needed, "frac_needed": ach * needed / flops / PEAK_F32_MFMA_TFLOPS,
                     "dominant_stage_by_time": "ac_update" if not col or upd["total_ms"] >= col["total_ms"] else "ac_collect_kernel"}
         if col and col["total_ms"] > upd["total_ms"]:  # the rollout dominates (long episodes, few envs): its acting forward next to it
             cf = (gru_fwd_flops if args.rnn else mlp_fwd_flops)(D, H, A) * P * (env_steps / args.steps)
@@ -674,6 +690,7 @@ def bench_dqn(args, rank, world, dist, steps, warmup):
         roofline = {"kernel": kname, "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": tsrc, "flops_per_launch": flops,
                     "flops_parts": parts, "avg_launch_us": lg["avg_us"],
+                    "frac_needed": ach * (1.0 - parts["first_layer_input_gradient (counted, never run)"] / flops) / PEAK_F32_MFMA_TFLOPS,
                     "dominant_stage_by_time": "loss/grad" if not col or lg["total_ms"] >= col["total_ms"] else "idqn_collect_kernel"}
         if getattr(args, "split16", False):
             # the same ALGORITHMIC f32 FLOPs over the f32 MFMA peak (comparable with the default row); on the pipe it really runs on it

@@ -91,8 +91,10 @@ __device__ __forceinline__ int sample_rows(const f4& logits, int lane, float u) 
 // work, so the copies never diverge.  It buys latency when the launch cannot fill the chip anyway (N / 16 < number of SIMDs): the
 // per-step chain of P forward passes becomes P / NW.  Actor packs that do not fit the LDS are then read straight from global memory
 // (L2) by the wave that needs them - no per-step staging of every agent's pack by the whole workgroup.
-template <int P>
-constexpr int acol_max_nw() { return P % 4 == 0 ? 4 : (P % 2 == 0 ? 2 : 1); }
+// (8 waves per env block: measured and dropped, see col_max_nw in collect_kernels.h)
+template <class ENV>
+constexpr int acol_max_nw() { return ENV::P % 4 == 0 ? 4 : (ENV::P % 2 == 0 ? 2 : 1); }
+constexpr int acol_tiles(int NW) { return NW > 4 ? NW : 4; }  // store tiles of a workgroup: one per wave
 
 // Transposed batch stores (round 4).  A lane holds elements 4 ks + g of ITS env's observation, so a direct store instruction is 64
 // separate 4-byte writes into 16 rows 4 * P * D bytes apart - on the warehouse (D = 71: 18 such instructions per step and wave) the
@@ -115,7 +117,7 @@ constexpr size_t acol_lds_fixed() {  // packs (when they live in LDS) + the env'
 template <class ENV, int H, bool OID, int NW>
 constexpr bool acol_tstore() {
     constexpr int D = ENV::D0 + (OID ? ENV::P : 0);
-    return D >= 32 && acol_lds_fixed<ENV, H, OID, NW>() + 4 * (size_t)ObsTile<D>::BYTES + 4608 <= 160u * 1024u;  // 4608: the static action-swap buffer
+    return D >= 32 && acol_lds_fixed<ENV, H, OID, NW>() + acol_tiles(NW) * (size_t)ObsTile<D>::BYTES + 4608 <= 160u * 1024u;  // 4608: the static action-swap buffer
 }
 
 __device__ __forceinline__ void wave_lds_fence_acol() {
@@ -124,7 +126,7 @@ __device__ __forceinline__ void wave_lds_fence_acol() {
 }
 
 template <class ENV, int H, bool OID, int NW>
-__global__ __launch_bounds__(ACOL_BLOCK) void ac_collect_kernel(typename ENV::Params q, const float* __restrict__ actor /* pre-packed [P][NFWD] */, uint32_t round, int T,
+__global__ __launch_bounds__(NW > 4 ? 64 * NW : ACOL_BLOCK) void ac_collect_kernel(typename ENV::Params q, const float* __restrict__ actor /* pre-packed [P][NFWD] */, uint32_t round, int T,
                                                                 int proper_term, float* __restrict__ b_obs,
                                                                 int64_t* __restrict__ b_act, float* __restrict__ b_rew,
                                                                 uint8_t* __restrict__ b_done, float* __restrict__ b_filled,
@@ -138,7 +140,10 @@ __global__ __launch_bounds__(ACOL_BLOCK) void ac_collect_kernel(typename ENV::Pa
     const bool ghost = gh.env_ids != nullptr;              // second pass (AcGhost): no batch writes, episode records instead
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ int s_act[NW > 1 ? 2 * 4 * P * 16 : 1];     // [step parity][env block of the workgroup][agent][env]
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, j = lane & 15;
+    // (the wave index through readfirstlane: everything derived from it - the agent, its pack's address - is then known to be wave-uniform
+    // and lives in scalar registers; as a per-lane value the 8-agent hidden-128 kernels kept one 64-bit address per pack load in vector
+    // registers, spilled them, and waited out every reload: 85 k cycles per step for two forward passes)
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, g = lane >> 4, j = lane & 15;
     const int blk = wave / NW, aw = wave % NW;
     const int bpw = (int)blockDim.x / (64 * NW);  // env blocks per workgroup: 4 / NW, or ONE when the launch has fewer waves than the chip has SIMDs             // env block inside the workgroup, this wave's agent residue
     ACOL_TS_BEGIN
@@ -380,7 +385,7 @@ int launch_ac_collect_nw(const typename ENV::Params& q, const float* packs, uint
     using S = MlpShape<D, H, ENV::A>;
     using PP = PackPlan<S, P, ENV::LDS_MAX>;
     // packs read from global memory (NW > 1, not resident): the LDS holds the env's own bytes only; then the waves' store tiles
-    const size_t lds_bytes = acol_tstore<ENV, H, OID, NW>() ? acol_lds_fixed<ENV, H, OID, NW>() + 4 * (size_t)ObsTile<D>::BYTES
+    const size_t lds_bytes = acol_tstore<ENV, H, OID, NW>() ? acol_lds_fixed<ENV, H, OID, NW>() + acol_tiles(NW) * (size_t)ObsTile<D>::BYTES
                                                             : ((NW > 1 && !(PP::RESIDENT || PP::A3REG)) ? 0 : PP::LDS_BYTES) + ENV::lds_bytes(q);
     static LdsAttr attr_set;
     if (attr_set.need(lds_bytes)) {
@@ -391,7 +396,7 @@ int launch_ac_collect_nw(const typename ENV::Params& q, const float* packs, uint
     // one env block (16 envs, NW waves) per workgroup while the launch has fewer waves than the chip has SIMDs: the per-step action
     // swap is a workgroup barrier, and with several blocks per workgroup every block waits for the slowest one's step
     const bool one_block = NW > 1 && (int64_t)((q.n_envs + 15) / 16) * NW <= 1024;
-    const int threads = one_block ? 64 * NW : ACOL_BLOCK, per_wg = 16 * (threads / (64 * NW));  // envs per workgroup
+    const int threads = (one_block || NW > 4) ? 64 * NW : ACOL_BLOCK, per_wg = 16 * (threads / (64 * NW));  // envs per workgroup
     timing_begin(TIMER_COLLECT, st);
     hipLaunchKernelGGL((ac_collect_kernel<ENV, H, OID, NW>), dim3((q.n_envs + per_wg - 1) / per_wg), dim3(threads), lds_bytes, st, q, packs, round, T,
                        proper_term, b_obs, b_act, b_rew, b_done, b_filled, fin_return, fin_length, t_max, ac_ghost_current());
@@ -404,7 +409,7 @@ template <class ENV, int H, bool OID>
 int launch_ac_collect(const typename ENV::Params& q, const AgentMap& am, const float* actor, uint32_t round, int T, int proper_term, float* b_obs, int64_t* b_act,
                       float* b_rew, uint8_t* b_done, float* b_filled, float* fin_return, int32_t* fin_length, int32_t* t_max,
                       hipStream_t st) {
-    constexpr int P = ENV::P, D = ENV::D0 + (OID ? P : 0), NWMAX = acol_max_nw<P>();
+    constexpr int P = ENV::P, D = ENV::D0 + (OID ? P : 0), NWMAX = acol_max_nw<ENV>();
     using S = MlpShape<D, H, ENV::A>;
     MARL_REQUIRE(ENV::lds_bytes(q) <= ENV::LDS_MAX, "collector: the env needs %zu bytes of LDS per workgroup, compiled for %zu", ENV::lds_bytes(q),
                  (size_t)ENV::LDS_MAX);

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(COL_BLOCK) void dqn_act_kernel(int P, int N, AgentM
 // NW: waves per block of 16 envs, each running the Q-networks of the agents p = w mod NW on its own copy of the env state (see
 // ac_collect_kernel: the joint action is swapped through LDS once per step, every copy steps with it)
 template <class ENV, int H, bool OID, int NW>
-__global__ __launch_bounds__(COL_BLOCK) void idqn_collect_kernel(typename ENV::Params q, const float* __restrict__ packs, float eps,
+__global__ __launch_bounds__(NW > 4 ? 64 * NW : COL_BLOCK) void idqn_collect_kernel(typename ENV::Params q, const float* __restrict__ packs, float eps,
                                                                  uint32_t round, marlhip_replay_shape rs, marlhip_replay_buffers rb,
                                                                  int slot_base, int write_replay, int clear_stale, int proper_term,
                                                                  float* __restrict__ fin_return, int32_t* __restrict__ fin_length) {
@@ -87,7 +87,10 @@ __global__ __launch_bounds__(COL_BLOCK) void idqn_collect_kernel(typename ENV::P
     constexpr bool FROM_GLOBAL = NW > 1 && !RESIDENT;      // packs too large for the LDS: each wave reads its agents' from L2
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ int s_act[NW > 1 ? 2 * 4 * P * 16 : 1];     // [step parity][env block of the workgroup][agent][env]
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, j = lane & 15;
+    // (the wave index through readfirstlane: everything derived from it - the agent, its pack's address - is then known to be wave-uniform
+    // and lives in scalar registers; as a per-lane value the 8-agent hidden-128 kernels kept one 64-bit address per pack load in vector
+    // registers, spilled them, and waited out every reload: 85 k cycles per step for two forward passes)
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, g = lane >> 4, j = lane & 15;
     const int blk = wave / NW, aw = wave % NW;
     const int bpw = (int)blockDim.x / (64 * NW);  // env blocks per workgroup: 4 / NW, or ONE when the launch has fewer waves than the chip has SIMDs
     const int n = (blockIdx.x * bpw + blk) * 16 + j;
@@ -252,7 +255,7 @@ int launch_collect_nw(const typename ENV::Params& q, const float* packs, float e
     // one env block per workgroup while the launch leaves SIMDs empty (see launch_ac_collect_nw): the action swap's barrier then only
     // joins the NW waves that need each other
     const bool one_block = NW > 1 && (int64_t)((q.n_envs + 15) / 16) * NW <= 1024;
-    const int threads = one_block ? 64 * NW : COL_BLOCK, per_wg = 16 * (threads / (64 * NW));
+    const int threads = (one_block || NW > 4) ? 64 * NW : COL_BLOCK, per_wg = 16 * (threads / (64 * NW));
     timing_begin(TIMER_COLLECT, st);
     hipLaunchKernelGGL((idqn_collect_kernel<ENV, H, OID, NW>), dim3((q.n_envs + per_wg - 1) / per_wg), dim3(threads), lds_bytes, st, q, packs, eps, round,
                        *rs, *rb, slot_base, write_replay, clear_stale, proper_term, fin_return, fin_length);
@@ -261,14 +264,16 @@ int launch_collect_nw(const typename ENV::Params& q, const float* packs, float e
     return 0;
 }
 
-template <int P>
-constexpr int col_max_nw() { return P % 4 == 0 ? 4 : (P % 2 == 0 ? 2 : 1); }
+// (Round 4, measured and dropped: 8 waves per env block for 8 agents in a 512-thread workgroup - the kernels take NW > 4 - is SLOWER, 1.46 ->
+// 1.90 ms per 15x15-8p rollout at hidden 128: eight waves per workgroup halve the register budget per wave and the spills double.)
+template <class ENV>
+constexpr int col_max_nw() { return ENV::P % 4 == 0 ? 4 : (ENV::P % 2 == 0 ? 2 : 1); }
 
 template <class ENV, int H, bool OID>
 int launch_collect(const typename ENV::Params& q, const AgentMap& am, const float* params, float eps, uint32_t round, const marlhip_replay_shape* rs,
                    const marlhip_replay_buffers* rb, int slot_base, int write_replay, int clear_stale, int proper_term,
                    float* fin_return, int32_t* fin_length, hipStream_t st) {
-    constexpr int P = ENV::P, D = ENV::D0 + (OID ? P : 0), NWMAX = col_max_nw<P>();
+    constexpr int P = ENV::P, D = ENV::D0 + (OID ? P : 0), NWMAX = col_max_nw<ENV>();
     using S = MlpShape<D, H, ENV::A>;
     MARL_REQUIRE(ENV::lds_bytes(q) <= ENV::LDS_MAX, "collector: the env needs %zu bytes of LDS per workgroup, compiled for %zu", ENV::lds_bytes(q),
                  (size_t)ENV::LDS_MAX);

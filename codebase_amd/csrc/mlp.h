@@ -344,25 +344,35 @@ __device__ __forceinline__ void marl_static_for(F& f) {
 template <class S>
 __device__ __forceinline__ void mlp_forward_g(const float* __restrict__ gpack, int lane, const float (&x)[S::KS1], f4& q) {
     constexpr int MT = S::MT, N1 = S::KS1 / 4, G = N1 + MT + 1;
-    const int g = lane >> 4;
-    const f4* A1 = reinterpret_cast<const f4*>(gpack + S::pA1);
-    const f4* A2 = reinterpret_cast<const f4*>(gpack + S::pA2);
-    const f4* A3 = reinterpret_cast<const f4*>(gpack + S::pA3);
+    // Addressing (round 4): BUFFER loads - the pack pointer is wave-uniform (the callers derive the agent from a readfirstlane'd wave index)
+    // and becomes a 4-SGPR resource; every operand is then `resource + scalar offset + 16 * lane`: one vector register of lane offsets for
+    // the whole pass.  With 64-bit per-lane pointers (global_load) the ~100 distinct operand addresses of a hidden-128 pass lived in
+    // vector registers - the compiler does not split `uniform base + constant + lane offset` into the scalar-base form beyond the 4 KB
+    // immediate range - and the 8-agent kernels spilled them: every reload waited out the loads in flight (s_waitcnt vmcnt(0) in front
+    // of the dependent load), 85 k cycles per step for two forward passes against 16 k for one.
+    typedef unsigned int u4_t __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gpack), 0, S::NFWD * 4, 0x00020000);
+    const int lo16 = lane * 16, g16 = (lane >> 4) * 16;
+    auto ld16 = [&](int float_off, int voff) -> f4 {
+        const u4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, float_off * 4, 0);
+        return __builtin_bit_cast(f4, v);
+    };
     f4 op[3][MT], acc[MT], nb[MT], h1[MT], h2[MT], o3;
     auto fetch = [&](auto gi_c) {
         constexpr int gi = decltype(gi_c)::value;
         if constexpr (gi < G) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
-                op[gi % 3][mt] = gi < N1 ? A1[(mt * N1 + gi) * 64 + lane] : (gi < N1 + MT ? A2[(mt * MT + (gi - N1)) * 64 + lane] : A3[mt * 64 + lane]);
+                op[gi % 3][mt] = gi < N1 ? ld16(S::pA1 + (mt * N1 + gi) * 256, lo16)
+                                         : (gi < N1 + MT ? ld16(S::pA2 + (mt * MT + (gi - N1)) * 256, lo16) : ld16(S::pA3 + mt * 256, lo16));
         }
     };
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        acc[mt] = *reinterpret_cast<const f4*>(gpack + S::pb1 + 16 * mt + 4 * g);
-        nb[mt] = *reinterpret_cast<const f4*>(gpack + S::pb2 + 16 * mt + 4 * g);
+        acc[mt] = ld16(S::pb1 + 16 * mt, g16);
+        nb[mt] = ld16(S::pb2 + 16 * mt, g16);
     }
-    o3 = *reinterpret_cast<const f4*>(gpack + S::pb3 + 4 * g);
+    o3 = ld16(S::pb3, g16);
     fetch(std::integral_constant<int, 0>{});
     fetch(std::integral_constant<int, 1>{});
     auto step = [&](auto gi_c) {
