@@ -6,10 +6,11 @@
 //                   and of W1 through LDS, as wide_gemm128_kernel does), its relu output left in LDS as the A operand of layer 2 (W2 slices
 //                   streamed the same way), layer 3 a dot product per row.  The target critic writes nothing but the values; the online
 //                   critic also leaves both hidden layers ([P][rows][H], written with full-row stores from the LDS tile) for the backward pass.
-//   wc_bwd_kernel   per 64-row tile: dY2 = dv W3 * (Y2 > 0) elementwise, dY1 = (dY2 W2) * (Y1 > 0) with dY2 as the LDS-resident A operand;
-//                   writes dY2 / dY1 for the weight-gradient products and per-tile column sums (dW3, db3, db2, db1) - no ones column, no
-//                   one-row GEMM for the output layer, no recomputed forward.
-//   wc_wgrad_kernel dW = dY^T Yprev over row ranges: both operands are contiguous ACROSS the reduction index, so the LDS tiles are k-major
+//   wc_bwd_kernel   persistent workgroups over 64-row tiles: dY2 = dv W3 * (Y2 > 0) elementwise, dY1 = (dY2 W2) * (Y1 > 0) with dY2 as the
+//                   LDS-resident A operand, and dW2 += dY2^T Y1 right there (both tiles are in LDS, k-major for that product; the wave's
+//                   64 x 64 quadrant of dW2 stays in registers across the tiles).  Writes dY1 for the first layer's weight-gradient
+//                   product and column sums (dW3, db3, db2, db1) - no ones column, no one-row GEMM for the output layer, no recompute.
+//   wc_wgrad_kernel dW1 = dY1^T X over row ranges: both operands are contiguous ACROSS the reduction index, so the LDS tiles are k-major
 //                   ([16][tile + 16]): 16-byte stores straight from the 16-byte loads, conflict-free 4-byte operand reads (the generic
 //                   kernel transposes with 8-way conflicting scalar stores); every agent in one launch (grid.y).
 // Sums over rows are folded in a fixed order (per-range partials, then ranges in order): bitwise reproducible, no atomics.
@@ -177,129 +178,160 @@ __global__ __launch_bounds__(256) void wc_fwd_kernel(const WcFwdArgs g) {
     }
 }
 
-// per-tile column sums of the backward pass: [dW3 (H) | db3 | db2 (H) | db1 (H)], one record per (tile, row group)
+// column sums of the backward pass, one record per (workgroup, row group): [dW3 (H) | db3 | db2 (H) | db1 (H)]
 __host__ __device__ inline int wc_partn(int H) { return 3 * H + 1; }
 
 struct WcBwdArgs {
     const float* packs;
     AgentMap am;
-    int rows, D;
+    int rows, D, tiles;
     const float* dout;   // [P][rows]: dL/dvalue, already masked by filled
     const float* y1; const float* y2;  // [P][rows][H]
-    float* d1; float* d2;              // [P][rows][H]
-    float* part;         // [P][nslots][wc_partn(H)], nslots = tiles * (256 / H)
-    int nslots;
+    float* d1;           // [P][rows][H]: dL/d(layer-1 pre-activation), the A operand of the first layer's weight-gradient product
+    float* part;         // [P][gridDim.x * (256 / H)][wc_partn(H)]
+    float* w2part;       // [P][gridDim.x][H][H]: the workgroup's share of dW2
 };
 
 template <int H>
 constexpr int wc_bwd_lds_floats() { return H * 20 + 2 * WC_ROWS * (H + 4) + WC_ROWS; }
 
+// Persistent: a workgroup walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... of agent blockIdx.y and keeps dW2 (its wave's 64 x 64
+// quadrant of the H x H matrix; both operands are already in LDS, k-major) and the column sums in registers across them.
 template <int H>
-__global__ __launch_bounds__(256) void wc_bwd_kernel(const WcBwdArgs g) {
+__global__ __launch_bounds__(256, 2) void wc_bwd_kernel(const WcBwdArgs g) {  // two workgroups per compute unit: <= 256 registers
     constexpr int LD = 20, LH = H + 4, NU = H / 32, NH = H / 64, C4 = H / 16, NG = 256 / H, RPG = WC_ROWS / NG;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* Bs = lds;                    // [H][LD]   W2^T slice
-    float* R1 = Bs + H * LD;            // [64][LH]  Y2 tile
-    float* R2 = R1 + WC_ROWS * LH;      // [64][LH]  dY2 tile (A operand), then dY1
+    float* R1 = Bs + H * LD;            // [64][LH]  Y2 tile, then Y1 (B operand of dW2)
+    float* R2 = R1 + WC_ROWS * LH;      // [64][LH]  dY2 tile (A operand of both products), then dY1
     float* dvs = R2 + WC_ROWS * LH;     // [64]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 15, q = lane >> 4, wm = wave >> 1, wn = wave & 1;
-    const int p = blockIdx.y, m0 = blockIdx.x * WC_ROWS;
+    const int p = blockIdx.y;
     const WcPack pk(g.D, H);
     const float* w = g.packs + (int64_t)g.am.net[p] * pk.total();
     const int row = tid >> 2, part = tid & 3, c0 = part * (H / 4);
-    const bool ok = m0 + row < g.rows;
-    const int64_t grow = ((int64_t)p * g.rows + (ok ? m0 + row : g.rows - 1)) * H + c0;
+    const int cn = tid % H, cg = tid / H;
     const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    // ---- a. dY2 = dv W3 * (Y2 > 0), row-wise; Y2 and dY2 to LDS, dY2 to memory
+    f4 dW2[NU][NU];  // rows: layer-2 units (H / 2) wm + 16 t + 4 q + r; columns: layer-1 units (H / 2) wn + 16 u + i
+#pragma unroll
+    for (int t = 0; t < NU; ++t)
+#pragma unroll
+        for (int u = 0; u < NU; ++u) dW2[t][u] = zero4;
+    float s3 = 0.f, s2 = 0.f, s1 = 0.f, sb = 0.f;
     f4 rw[NH];
     auto load2 = [&](int k0) {
 #pragma unroll
         for (int h = 0; h < NH; ++h) rw[h] = *reinterpret_cast<const f4*>(w + pk.oW2T() + (64 * h + row) * H + k0 + 4 * part);
     };
-    f4 y1v[C4];
-    {
-        const float dv = ok ? g.dout[(int64_t)p * g.rows + m0 + row] : 0.f;
-        if (part == 0) dvs[row] = dv;
-        f4 y2v[C4];
+    for (int tile = blockIdx.x; tile < g.tiles; tile += gridDim.x) {
+        const int m0 = tile * WC_ROWS;
+        const bool ok = m0 + row < g.rows;
+        const int64_t grow = ((int64_t)p * g.rows + (ok ? m0 + row : g.rows - 1)) * H + c0;
+        // ---- a. dY2 = dv W3 * (Y2 > 0), row-wise; Y2 and dY2 to LDS
+        f4 y1v[C4];
+        {
+            const float dv = ok ? g.dout[(int64_t)p * g.rows + m0 + row] : 0.f;
+            if (part == 0) dvs[row] = dv;
+            f4 y2v[C4];
 #pragma unroll
-        for (int c = 0; c < C4; ++c) y2v[c] = *reinterpret_cast<const f4*>(g.y2 + grow + 4 * c);
+            for (int c = 0; c < C4; ++c) y2v[c] = *reinterpret_cast<const f4*>(g.y2 + grow + 4 * c);
 #pragma unroll
-        for (int c = 0; c < C4; ++c) y1v[c] = *reinterpret_cast<const f4*>(g.y1 + grow + 4 * c);
-        load2(0);
+            for (int c = 0; c < C4; ++c) y1v[c] = *reinterpret_cast<const f4*>(g.y1 + grow + 4 * c);
+            load2(0);
 #pragma unroll
-        for (int c = 0; c < C4; ++c) {
-            const f4 w3 = *reinterpret_cast<const f4*>(w + pk.oW3() + c0 + 4 * c);
-            f4 y = ok ? y2v[c] : zero4, d;
+            for (int c = 0; c < C4; ++c) {
+                const f4 w3 = *reinterpret_cast<const f4*>(w + pk.oW3() + c0 + 4 * c);
+                f4 y = ok ? y2v[c] : zero4, d;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) d[e] = y[e] > 0.f ? dv * w3[e] : 0.f;
-            *reinterpret_cast<f4*>(R1 + row * LH + c0 + 4 * c) = y;
-            *reinterpret_cast<f4*>(R2 + row * LH + c0 + 4 * c) = d;
-            if (ok) *reinterpret_cast<f4*>(g.d2 + grow + 4 * c) = d;
+                for (int e = 0; e < 4; ++e) d[e] = y[e] > 0.f ? dv * w3[e] : 0.f;
+                *reinterpret_cast<f4*>(R1 + row * LH + c0 + 4 * c) = y;
+                *reinterpret_cast<f4*>(R2 + row * LH + c0 + 4 * c) = d;
+                if (!ok) y1v[c] = zero4;
+            }
         }
-    }
-    __syncthreads();
-    // ---- b. column sums over this group's rows, in row order: dW3 = sum dv Y2, db2 = sum dY2, db3 = sum dv
-    const int cn = tid % H, cg = tid / H;
-    float* rec = g.part + ((int64_t)p * g.nslots + (int64_t)blockIdx.x * NG + cg) * wc_partn(H);
-    {
-        float s3 = 0.f, s2 = 0.f, sb = 0.f;
+        __syncthreads();
+        // ---- b. column sums over this group's rows, in row order: dW3 = sum dv Y2, db2 = sum dY2, db3 = sum dv
         for (int m = cg * RPG; m < (cg + 1) * RPG; ++m) {
             const float dv = dvs[m];
             s3 += dv * R1[m * LH + cn];
             s2 += R2[m * LH + cn];
             sb += dv;
         }
-        rec[cn] = s3;
-        rec[H + 1 + cn] = s2;
-        if (cn == 0) rec[H] = sb;
-    }
-    // ---- c. dY1 (before the gate) = dY2 (LDS) x W2: B operand W2^T[k_out][n], slices of 16 n
-    f4 acc[2][NU];
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int u = 0; u < NU; ++u) acc[t][u] = zero4;
-    for (int k0 = 0; k0 < H; k0 += 16) {
-        if (k0 > 0) __syncthreads();  // slice k0 - 16 has been multiplied
-#pragma unroll
-        for (int h = 0; h < NH; ++h) *reinterpret_cast<f4*>(Bs + (64 * h + row) * LD + 4 * part) = rw[h];
-        __syncthreads();
-        if (k0 + 16 < H) load2(k0 + 16);
-        f4 a[2], b[NU];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) a[t] = *reinterpret_cast<const f4*>(R2 + (32 * wm + 16 * t + i) * LH + k0 + 4 * q);
-#pragma unroll
-        for (int u = 0; u < NU; ++u) b[u] = *reinterpret_cast<const f4*>(Bs + ((H / 2) * wn + 16 * u + i) * LD + 4 * q);
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int u = 0; u < NU; ++u) acc[t][u] = MARL_MFMA(a[t][s], b[u][s], acc[t][u]);
-    }
-    __syncthreads();  // every wave has read dY2 (and finished the column sums of step b)
-    // ---- d. through the LDS tile back to rows: gate with Y1 (held since step a), store, column sums for db1
-#pragma unroll
-    for (int u = 0; u < NU; ++u)
+        // ---- c. dY1 (before the gate) = dY2 (LDS) x W2: B operand W2^T[k_out][n], slices of 16 n
+        f4 acc[2][NU];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) R2[(32 * wm + 16 * t + 4 * q + r) * LH + (H / 2) * wn + 16 * u + i] = acc[t][u][r];
-    __syncthreads();
+            for (int u = 0; u < NU; ++u) acc[t][u] = zero4;
+        for (int k0 = 0; k0 < H; k0 += 16) {
+            if (k0 > 0) __syncthreads();  // slice k0 - 16 has been multiplied (and, at k0 = 16, every wave is past step b: Y2 is no longer needed)
 #pragma unroll
-    for (int c = 0; c < C4; ++c) {
-        f4 d = *reinterpret_cast<const f4*>(R2 + row * LH + c0 + 4 * c);
+            for (int h = 0; h < NH; ++h) *reinterpret_cast<f4*>(Bs + (64 * h + row) * LD + 4 * part) = rw[h];
+            if (k0 == 16) {  // Y1 takes Y2's place: the B operand of dW2 below (rows past the batch are zeros)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) d[e] = (ok && y1v[c][e] > 0.f) ? d[e] : 0.f;
-        *reinterpret_cast<f4*>(R2 + row * LH + c0 + 4 * c) = d;
-        if (ok) *reinterpret_cast<f4*>(g.d1 + grow + 4 * c) = d;
-    }
-    __syncthreads();
-    {
-        float s1 = 0.f;
+                for (int c = 0; c < C4; ++c) *reinterpret_cast<f4*>(R1 + row * LH + c0 + 4 * c) = y1v[c];
+            }
+            __syncthreads();
+            if (k0 + 16 < H) load2(k0 + 16);
+            f4 a[2], b[NU];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) a[t] = *reinterpret_cast<const f4*>(R2 + (32 * wm + 16 * t + i) * LH + k0 + 4 * q);
+#pragma unroll
+            for (int u = 0; u < NU; ++u) b[u] = *reinterpret_cast<const f4*>(Bs + ((H / 2) * wn + 16 * u + i) * LD + 4 * q);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int u = 0; u < NU; ++u) acc[t][u] = MARL_MFMA(a[t][s], b[u][s], acc[t][u]);
+        }
+        // ---- dW2 += dY2^T Y1 over the tile's 64 rows: both tiles are k-major for this product (row = reduction index)
+#pragma unroll 2
+        for (int s = 0; s < WC_ROWS / 4; ++s) {
+            float a2[NU], b2[NU];
+#pragma unroll
+            for (int t = 0; t < NU; ++t) a2[t] = R2[(4 * s + q) * LH + (H / 2) * wm + 16 * t + i];
+#pragma unroll
+            for (int u = 0; u < NU; ++u) b2[u] = R1[(4 * s + q) * LH + (H / 2) * wn + 16 * u + i];
+#pragma unroll
+            for (int t = 0; t < NU; ++t)
+#pragma unroll
+                for (int u = 0; u < NU; ++u) dW2[t][u] = MARL_MFMA(a2[t], b2[u], dW2[t][u]);
+        }
+        __syncthreads();  // every wave has read dY2
+        // ---- d. through the LDS tile back to rows: gate with Y1 (its LDS tile), store, column sums for db1
+#pragma unroll
+        for (int u = 0; u < NU; ++u)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) R2[(32 * wm + 16 * t + 4 * q + r) * LH + (H / 2) * wn + 16 * u + i] = acc[t][u][r];
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < C4; ++c) {
+            f4 d = *reinterpret_cast<const f4*>(R2 + row * LH + c0 + 4 * c);
+            const f4 y1g = *reinterpret_cast<const f4*>(R1 + row * LH + c0 + 4 * c);  // Y1 is still in its tile (rows past the batch: zeros)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) d[e] = y1g[e] > 0.f ? d[e] : 0.f;
+            *reinterpret_cast<f4*>(R2 + row * LH + c0 + 4 * c) = d;
+            if (ok) *reinterpret_cast<f4*>(g.d1 + grow + 4 * c) = d;
+        }
+        __syncthreads();
         for (int m = cg * RPG; m < (cg + 1) * RPG; ++m) s1 += R2[m * LH + cn];
-        rec[2 * H + 1 + cn] = s1;
+        __syncthreads();  // the next tile rewrites both LDS tiles
     }
+    float* rec = g.part + ((int64_t)p * gridDim.x * NG + (int64_t)blockIdx.x * NG + cg) * wc_partn(H);
+    rec[cn] = s3;
+    rec[H + 1 + cn] = s2;
+    rec[2 * H + 1 + cn] = s1;
+    if (cn == 0) rec[H] = sb;
+    float* C = g.w2part + ((int64_t)p * gridDim.x + blockIdx.x) * H * H;
+#pragma unroll
+    for (int t = 0; t < NU; ++t)
+#pragma unroll
+        for (int u = 0; u < NU; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) C[((H / 2) * wm + 16 * t + 4 * q + r) * H + (H / 2) * wn + 16 * u + i] = dW2[t][u][r];
 }
 
 // column partials -> gradient entries: stage A adds groups of 64 records, stage B the groups, both in index order; / nf
@@ -410,19 +442,24 @@ inline int wc_tiles(int rows) { return (rows + WC_ROWS - 1) / WC_ROWS; }
 inline int64_t wc_pack_bytes(int nblk, int D, int H) { return ((int64_t)nblk * WcPack(D, H).total() * 4 + 255) & ~(int64_t)255; }
 
 struct WcWs {
-    int64_t packs, d1, d2, part, g1, wpart, gp, nf, total;
+    int64_t packs, d1, part, g1, w2part, wpart, gp, nf, total;
 };
+// workgroups of wc_bwd_kernel per agent: two per compute unit over all agents (its LDS lets two be resident)
+inline int wc_bwd_wgs(int P, int rows) {
+    const int g = 512 / (P > 0 ? P : 1), t = wc_tiles(rows);
+    return g < 1 ? 1 : (g > t ? t : g);
+}
 inline WcWs wc_ws(int P, int rows, int D, int H) {
     WcWs w = {};
     int64_t o = 0;
     auto take = [&](int64_t nfloat) { const int64_t at = o; o = (o + nfloat * 4 + 255) & ~(int64_t)255; return at; };
-    const int nslots = wc_tiles(rows) * (256 / H), ngroups = (nslots + WC_FOLD_GROUP - 1) / WC_FOLD_GROUP;
+    const int nwg = wc_bwd_wgs(P, rows), nslots = nwg * (256 / H), ngroups = (nslots + WC_FOLD_GROUP - 1) / WC_FOLD_GROUP;
     w.packs = take((int64_t)P * WcPack(D, H).total());
     w.d1 = take((int64_t)P * rows * H);
-    w.d2 = take((int64_t)P * rows * H);
     w.part = take((int64_t)P * nslots * wc_partn(H));
     w.g1 = take((int64_t)P * ngroups * wc_partn(H));
-    w.wpart = take((int64_t)P * wide_splits(rows) * H * (D > H ? D : H));
+    w.w2part = take((int64_t)P * nwg * H * H);
+    w.wpart = take((int64_t)P * wide_splits(rows) * H * D);
     w.gp = take((int64_t)P * WideNet{D, H, 1, 2}.nparam());
     w.nf = take(4 + 2 * WIDE_COUNT_MAX_WG);
     w.total = o;
@@ -468,17 +505,19 @@ int wc_backward_rows(int P, const AgentMap& am, const float* params, int D, cons
     const int64_t nparam = net.nparam();
     wide_count(filled, lrow, rows, nf + 4, nf, st);
     hipLaunchKernelGGL(wc_pack_kernel, dim3((pk.total() + 255) / 256, am.nblk), dim3(256), 0, st, params, nparam, pk, packs);
-    const int tiles = wc_tiles(rows), nslots = tiles * (256 / H), ngroups = (nslots + WC_FOLD_GROUP - 1) / WC_FOLD_GROUP, partn = wc_partn(H);
+    const int nwg = wc_bwd_wgs(P, rows), nslots = nwg * (256 / H), ngroups = (nslots + WC_FOLD_GROUP - 1) / WC_FOLD_GROUP, partn = wc_partn(H);
     WcBwdArgs b = {};
-    b.packs = packs; b.am = am; b.rows = rows; b.D = D; b.dout = dout; b.y1 = rec; b.y2 = rec + (int64_t)P * rows * H;
-    b.d1 = f(w.d1); b.d2 = f(w.d2); b.part = f(w.part); b.nslots = nslots;
+    b.packs = packs; b.am = am; b.rows = rows; b.D = D; b.tiles = wc_tiles(rows); b.dout = dout; b.y1 = rec; b.y2 = rec + (int64_t)P * rows * H;
+    b.d1 = f(w.d1); b.part = f(w.part); b.w2part = f(w.w2part);
     constexpr int LDSB = wc_bwd_lds_floats<H>() * (int)sizeof(float);
     static LdsAttr attr_set;
     if (attr_set.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wc_bwd_kernel<H>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
         attr_set.done();
     }
-    hipLaunchKernelGGL((wc_bwd_kernel<H>), dim3(tiles, P), dim3(256), LDSB, st, b);
+    hipLaunchKernelGGL((wc_bwd_kernel<H>), dim3(nwg, P), dim3(256), LDSB, st, b);
+    hipLaunchKernelGGL(wc_fold_w_kernel, dim3((H * H + 255) / 256, P), dim3(256), 0, st, (const float*)b.w2part, nwg, H * H, (const float*)nf + 1, gp, nparam,
+                       (int)net.oW(2));
     hipLaunchKernelGGL(wc_fold_cols_a_kernel, dim3((partn + 255) / 256, ngroups, P), dim3(256), 0, st, (const float*)b.part, nslots, partn, f(w.g1));
     hipLaunchKernelGGL(wc_fold_cols_b_kernel, dim3((partn + 255) / 256, P), dim3(256), 0, st, (const float*)f(w.g1), ngroups, H, (const float*)nf + 1, gp,
                        nparam, (int)net.oW(3), (int)net.ob(3), (int)net.ob(2), (int)net.ob(1));
@@ -491,7 +530,6 @@ int wc_backward_rows(int P, const AgentMap& am, const float* params, int D, cons
         hipLaunchKernelGGL(wc_fold_w_kernel, dim3((H * N + 255) / 256, P), dim3(256), 0, st, (const float*)a.part, splits, H * N, (const float*)nf + 1, gp,
                            nparam, ow);
     };
-    wgrad(b.d2, b.y1, (int64_t)rows * H, H, H, (int)net.oW(2), true);
     wgrad(b.d1, obs, as, rs, D, (int)net.oW(1), wc_rows_vec(obs, as, rs));
     const int n = am.nblk * (int)nparam;
     hipLaunchKernelGGL(wide_gather_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)gp, P, (int)nparam, am, grad);
