@@ -437,6 +437,14 @@ static __global__ __launch_bounds__(256) void wc_fold_w_kernel(const float* __re
     gp[(int64_t)p * nparam + ow + idx] = acc / nf[0];
 }
 
+// row ranges of wc_wgrad_kernel: about 2048 workgroups in all (two full rounds of the ~1024 that are resident at once: a launch of 1.2
+// rounds runs as long as one of 2), every range at least 256 rows, at most 256 ranges
+inline int wc_wgrad_splits(int P, int rows, int D) {
+    const int per = ((D + 127) / 128) * (P > 0 ? P : 1);
+    int s = (2048 + per - 1) / per;
+    if (s > rows / 256) s = rows / 256;
+    return s < 1 ? 1 : (s > 256 ? 256 : s);
+}
 inline int64_t wc_rec_floats(int P, int rows, int H) { return 2 * (int64_t)P * rows * H; }
 inline int wc_tiles(int rows) { return (rows + WC_ROWS - 1) / WC_ROWS; }
 inline int64_t wc_pack_bytes(int nblk, int D, int H) { return ((int64_t)nblk * WcPack(D, H).total() * 4 + 255) & ~(int64_t)255; }
@@ -459,7 +467,7 @@ inline WcWs wc_ws(int P, int rows, int D, int H) {
     w.part = take((int64_t)P * nslots * wc_partn(H));
     w.g1 = take((int64_t)P * ngroups * wc_partn(H));
     w.w2part = take((int64_t)P * nwg * H * H);
-    w.wpart = take((int64_t)P * wide_splits(rows) * H * D);
+    w.wpart = take((int64_t)P * wc_wgrad_splits(P, rows, D) * H * D);
     w.gp = take((int64_t)P * WideNet{D, H, 1, 2}.nparam());
     w.nf = take(4 + 2 * WIDE_COUNT_MAX_WG);
     w.total = o;
@@ -521,7 +529,7 @@ int wc_backward_rows(int P, const AgentMap& am, const float* params, int D, cons
     hipLaunchKernelGGL(wc_fold_cols_a_kernel, dim3((partn + 255) / 256, ngroups, P), dim3(256), 0, st, (const float*)b.part, nslots, partn, f(w.g1));
     hipLaunchKernelGGL(wc_fold_cols_b_kernel, dim3((partn + 255) / 256, P), dim3(256), 0, st, (const float*)f(w.g1), ngroups, H, (const float*)nf + 1, gp,
                        nparam, (int)net.oW(3), (int)net.ob(3), (int)net.ob(2), (int)net.ob(1));
-    const int splits = wide_splits(rows), chunk = (((rows + splits - 1) / splits) + 15) & ~15;
+    const int splits = wc_wgrad_splits(P, rows, D), chunk = (((rows + splits - 1) / splits) + 15) & ~15;
     auto wgrad = [&](const float* dy, const float* yp, int64_t yp_as, int64_t yp_rs, int N, int ow, bool vec) {
         WcWgradArgs a = {};
         a.dy = dy; a.dy_as = (int64_t)rows * H; a.yp = yp; a.yp_as = yp_as; a.yp_rs = yp_rs; a.rows = rows; a.N = N; a.k_chunk = chunk; a.vec = vec;

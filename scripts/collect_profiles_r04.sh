@@ -19,6 +19,8 @@ timeout 300 rocprofv3 --kernel-trace --stats -d $O/stats_rware_ia2c64 --output-f
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/stats_ia2c64 --output-format csv -- $B --steps 50 --warmup 5 --algo ia2c > $O/stats_ia2c64.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/stats_envonly --output-format csv -- $B --steps 50 --warmup 5 --cadence env-only > $O/stats_envonly.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/stats_qmix2p --output-format csv -- $B --steps 10 --warmup 2 --algo qmix > $O/stats_qmix2p.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/stats_maa2c8p --output-format csv -- $B --steps 3 --warmup 1 --algo maa2c --env-name lbforaging:Foraging-15x15-8p-5f-v3 --envs 4096 --hidden 128 > $O/stats_maa2c8p.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/stats_mappo_rware --output-format csv -- $B --steps 2 --warmup 1 --algo mappo --env-name rware:rware-tiny-4ag-v2 --time-limit 500 --envs 2048 --hidden 128 > $O/stats_mappo_rware.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/stats_qmix8p --output-format csv -- $B --steps 2 --warmup 1 --algo qmix --env-name lbforaging:Foraging-15x15-8p-5f-v3 --envs 8192 --hidden 128 > $O/stats_qmix8p.log 2>&1
 cd $R
 : > $O/matrix.jsonl
@@ -47,6 +49,8 @@ run --steps 5 --warmup 1 --algo ia2c --env-name rware:rware-tiny-4ag-v2 --time-l
 run --steps 3 --warmup 1 --algo ia2c --env-name rware:rware-tiny-4ag-v2 --time-limit 500 --envs 16384 --hidden 128
 run --steps 3 --warmup 1 --algo mappo --env-name rware:rware-tiny-4ag-v2 --time-limit 500 --envs 2048 --hidden 128
 run --steps 3 --warmup 1 --algo maa2c --env-name lbforaging:Foraging-15x15-8p-5f-v3 --envs 4096 --hidden 128
+run --steps 3 --warmup 1 --algo maa2c --env-name lbforaging:Foraging-15x15-8p-5f-v3 --envs 4096 --hidden 64
+run --steps 5 --warmup 1 --algo ia2c --env-name lbforaging:Foraging-15x15-8p-5f-v3 --envs 4096 --hidden 128
 run --steps 5 --warmup 1 --algo ia2c --env-name rware:rware-tiny-4ag-v2 --time-limit 500 --envs 2048 --hidden 64
 run --steps 3 --warmup 1 --algo idqn --env-name rware:rware-tiny-4ag-v2 --time-limit 500 --envs 2048 --hidden 64
 run --steps 3 --warmup 1 --algo qmix --env-name rware:rware-tiny-4ag-v2 --time-limit 500 --envs 2048 --hidden 64

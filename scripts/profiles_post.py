@@ -42,6 +42,7 @@ def main():
                      ("stats_hbm", PFX + "_hbm_ubench_kernel_stats.csv"), ("stats_gru64", PFX + "_gru_H64_kernel_stats.csv"),
                      ("stats_rware_ia2c", PFX + "_rware_ia2c_tiny4ag_H128_kernel_stats.csv"),
                      ("stats_qmix8p", PFX + "_qmix_15x15_8p5f_H128_kernel_stats.csv"),
+                     ("stats_maa2c8p", PFX + "_maa2c_15x15_8p5f_H128_kernel_stats.csv"), ("stats_mappo_rware", PFX + "_mappo_rware_tiny4ag_H128_kernel_stats.csv"),
                      ("stats_rware_ia2c64", PFX + "_rware_ia2c_tiny4ag_H64_kernel_stats.csv"), ("stats_ia2c64", PFX + "_ia2c_8x8_2p3f_H64_kernel_stats.csv"),
                      ("stats_envonly", PFX + "_env_only_kernel_stats.csv")):
         f = first(f"{tag}/**/*_kernel_stats.csv")

@@ -235,10 +235,14 @@ def test_centralised_critic_algorithms_end_to_end(tmp_path, monkeypatch):
 
 
 @pytest.mark.parametrize("P,T,N,D,H,A,n", [(8, 25, 20, 39, 128, 6, 5), (8, 9, 70, 39, 64, 6, 3), (4, 12, 33, 71, 128, 5, 5), (2, 6, 300, 71, 64, 5, 2),
-                                           (5, 7, 130, 27, 64, 6, 5)])
+                                           (5, 7, 130, 27, 64, 6, 5),
+                                           # more 64-row tiles than the persistent backward kernel has workgroups (512 / P per agent): every
+                                           # workgroup accumulates dW2 and its column sums over several tiles
+                                           (8, 10, 1000, 39, 128, 6, 5), (4, 40, 520, 71, 64, 5, 3)])
 def test_wide_centralised_critics_vs_oracle_port(P, T, N, D, H, A, n):
-    """centralised critics the fused kernels do not cover (8 LBF agents: 312 inputs; the warehouse: 71 per agent; 5 agents): the GEMM
-    path of csrc/wide_mlp.h - loss pieces, actor and critic gradients vs the port, and the value rows through marlhip_ac_forward_rows"""
+    """centralised critics the register-resident kernels do not cover (8 LBF agents: 312 inputs; the warehouse: 71 per agent; 5 agents:
+    135-wide rows that are not 16-byte aligned): csrc/wide_critic.h (layer 1 streamed through LDS, the three layers fused, hidden layers
+    kept for the backward pass) - loss pieces, actor and critic gradients vs the port, and the value rows through marlhip_ac_forward_rows"""
     h = hip()
     actor = dp.init_params(P, D, H, A, seed=1) + 0.03
     critic = torch.stack([dp.init_params(1, P * D, H, 1, seed=20 + p)[0] for p in range(P)]) + 0.02
