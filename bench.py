@@ -369,6 +369,11 @@ def bench_ac(args, rank, world, dist):
     t_max = torch.zeros(1, dtype=torch.int32, device=dev)
     steps_dev = torch.zeros((), dtype=torch.int64, device=dev)
     ref_steps = torch.zeros((), dtype=torch.int64, device=dev)
+    # the feed-forward rounds count with ONE small elementwise launch each (per-env first-episode lengths and the round's longest episode
+    # added into accumulators, reduced once behind the timed region): a per-round reduction to a scalar is bench bookkeeping that cost
+    # 17 + 10 us of a 460 us IA2C round
+    len_acc = torch.zeros(N, dtype=torch.int64, device=dev)
+    tmax_acc = torch.zeros(1, dtype=torch.int64, device=dev)
     sync_grad = GradSync(dist, max_floats=model.updater.grad.numel()) if dist is not None else None
     state = {"round": 0, "step": 0}
 
@@ -391,8 +396,8 @@ def bench_ac(args, rank, world, dist):
                      fin_len, t_max)
         b_donef.copy_(b_done)  # batch.dones.float() (ac/model.py:198)
         model.update_async(Batch(b_obs, b_act, b_rew, b_donef, b_fill, None), state["step"], grad_sync=sync_grad, world=world)
-        steps_dev.add_(fin_len.sum())  # == b_fill.sum(): every env stores exactly its first episode (the collector's contract; checked once below)
-        ref_steps.add_(t_max[0].to(torch.int64) * N)
+        len_acc.add_(fin_len)  # sum == b_fill.sum(): every env stores exactly its first episode (the collector's contract; checked once below)
+        tmax_acc.add_(t_max)
         state["round"] += 1
         state["step"] += T * N  # host-side stand-in for the reference's step counter (target update cadence only)
 
@@ -408,6 +413,8 @@ def bench_ac(args, rank, world, dist):
         assert int(fin_len.sum().item()) == int(b_fill.sum().item()), "stored transitions != sum of first-episode lengths"
     steps_dev.zero_()
     ref_steps.zero_()
+    len_acc.zero_()
+    tmax_acc.zero_()
     if not args.no_kernel_timing:
         lib.marlhip_timing_enable(1)
     t0 = time.perf_counter()
@@ -415,6 +422,9 @@ def bench_ac(args, rank, world, dist):
         one_round()
     sync()
     dt = time.perf_counter() - t0
+    if not args.rnn:
+        steps_dev.add_(len_acc.sum())
+        ref_steps.add_(tmax_acc[0] * N)
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

@@ -39,6 +39,9 @@ namespace marl {
 // top of iteration k requested two iterations earlier) is within 1 % of 1 on every GEMM-path row - resident workgroups hide the latency
 #define MARL_WIDE_PF 1
 #endif
+#ifndef MARL_WIDE_KM
+#define MARL_WIDE_KM 1  // k-major LDS tiles for the weight-gradient products of wide_gemm128_kernel (0: the transposing row-major form, for A/B runs)
+#endif
 #ifndef MARL_WIDE_KB
 // k depth of one LDS slice of wide_gemm128_kernel.  Measured (scripts/gpu_runs/r3Q.sh): 32 (128 MFMAs per wave between barrier pairs, 37 KB of
 // LDS, twice the prefetch registers) is 3 - 13 % SLOWER than 16 on every GEMM-path row (MAPPO rware 6.20 -> 5.38 M): the kernels live on
@@ -215,6 +218,13 @@ __global__ __launch_bounds__(256) void wide_gemm128_kernel(const GemmOp g) {
             }
         }
     };
+    // weight-gradient products (neither operand k-contiguous: both are contiguous ACROSS the reduction index) keep their LDS tiles K-MAJOR
+    // (round 4, from wide_critic.h's wc_wgrad_kernel): [k][128 + 16] - the 16-byte global loads land as 16-byte LDS stores and an MFMA
+    // operand is a conflict-free 4-byte read (lane quarter q takes k = 4 s + q at step s: rows 144 floats apart fall 16 banks apart).
+    // The row-major form transposed with four scalar stores per load, 8 lanes to a bank.
+    constexpr bool KM = MARL_WIDE_KM && !A_KC && !B_KC;
+    constexpr int LDK = 128 + 16;
+    static_assert(!KM || KB * LDK <= 128 * LD, "k-major tiles fit the row-major arrays");
     auto store = [&](int set) {
         f4 (&ra)[NS][2] = rset[set][0];
         f4 (&rb)[NS][2] = rset[set][1];
@@ -222,6 +232,11 @@ __global__ __launch_bounds__(256) void wide_gemm128_kernel(const GemmOp g) {
         for (int ss = 0; ss < NS; ++ss)
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
+                if constexpr (KM) {
+                    *reinterpret_cast<f4*>(As + (16 * ss + (tid >> 4)) * LDK + 64 * h + 4 * (tid & 15)) = ra[ss][h];
+                    *reinterpret_cast<f4*>(Bs + (16 * ss + (tid >> 4)) * LDK + 64 * h + 4 * (tid & 15)) = rb[ss][h];
+                    continue;
+                }
                 if (A_KC) {
                     *reinterpret_cast<f4*>(As + (64 * h + (tid >> 2)) * LD + 16 * ss + 4 * (tid & 3)) = ra[ss][h];
                 } else {
@@ -243,6 +258,22 @@ __global__ __launch_bounds__(256) void wide_gemm128_kernel(const GemmOp g) {
         if (k0 + PF * KB < kend) load(k0 + PF * KB, set);
 #pragma unroll
         for (int ss = 0; ss < NS; ++ss) {
+            if constexpr (KM) {
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2) {
+                    float ak[4], bk[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        ak[t] = As[(16 * ss + 4 * s2 + q) * LDK + 64 * wm + 16 * t + i];
+                        bk[t] = Bs[(16 * ss + 4 * s2 + q) * LDK + 64 * wn + 16 * t + i];
+                    }
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = MARL_MFMA(ak[mt], bk[nt], acc[mt][nt]);
+                }
+                continue;
+            }
             f4 a[4], b[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
