@@ -29,6 +29,8 @@ def main():
         else:
             cad = "one update per rollout"
         roof = "%.3f of %s %s (%s, %.0f µs per launch group)" % (r.get("frac") or 0, r.get("peak"), r.get("unit"), r.get("kernel"), r.get("avg_launch_us") or 0)
+        if r.get("frac_needed"):
+            roof = roof.replace(" of ", " (%.3f needed) of " % r["frac_needed"], 1)
         print("| %s | %s | %.2f M | %.2f | %s |" % (w, cad, d["value"] / 1e6, d["ms_per_step"], roof))
 
 
