@@ -125,8 +125,9 @@ __device__ __forceinline__ void wave_lds_fence_acol() {
     __builtin_amdgcn_wave_barrier();
 }
 
-template <class ENV, int H, bool OID, int NW>
-__global__ __launch_bounds__(NW > 4 ? 64 * NW : ACOL_BLOCK) void ac_collect_kernel(typename ENV::Params q, const float* __restrict__ actor /* pre-packed [P][NFWD] */, uint32_t round, int T,
+// HS = 2: two waves per agent (mlp_forward_h2; see idqn_collect_kernel) - NW * HS waves per env block, one block per workgroup
+template <class ENV, int H, bool OID, int NW, int HS = 1>
+__global__ __launch_bounds__(NW * HS > 4 ? 64 * NW * HS : ACOL_BLOCK) void ac_collect_kernel(typename ENV::Params q, const float* __restrict__ actor /* pre-packed [P][NFWD] */, uint32_t round, int T,
                                                                 int proper_term, float* __restrict__ b_obs,
                                                                 int64_t* __restrict__ b_act, float* __restrict__ b_rew,
                                                                 uint8_t* __restrict__ b_done, float* __restrict__ b_filled,
@@ -144,8 +145,11 @@ __global__ __launch_bounds__(NW > 4 ? 64 * NW : ACOL_BLOCK) void ac_collect_kern
     // and lives in scalar registers; as a per-lane value the 8-agent hidden-128 kernels kept one 64-bit address per pack load in vector
     // registers, spilled them, and waited out every reload: 85 k cycles per step for two forward passes)
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, g = lane >> 4, j = lane & 15;
-    const int blk = wave / NW, aw = wave % NW;
-    const int bpw = (int)blockDim.x / (64 * NW);  // env blocks per workgroup: 4 / NW, or ONE when the launch has fewer waves than the chip has SIMDs             // env block inside the workgroup, this wave's agent residue
+    constexpr int WPB = NW * HS;  // waves per env block
+    const int blk = wave / WPB, aw = (wave % WPB) % NW, half = (wave % WPB) / NW;
+    const bool storer = half == 0;  // HS = 2: the half-0 wave of an agent writes its rows (the half-1 wave samples)
+    __shared__ f4 s_xh[HS > 1 ? NW * 2 * (MlpShape<ENV::D0 + (OID ? ENV::P : 0), H, ENV::A>::MT / 2) * 64 : 1], s_xq[HS > 1 ? NW * 64 : 1];
+    const int bpw = (int)blockDim.x / (64 * WPB);  // env blocks per workgroup: 4 / NW, or ONE when the launch has fewer waves than the chip has SIMDs             // env block inside the workgroup, this wave's agent residue
     ACOL_TS_BEGIN
     const int n = (blockIdx.x * bpw + blk) * 16 + j;
     const int N = q.n_envs;
@@ -162,7 +166,7 @@ __global__ __launch_bounds__(NW > 4 ? 64 * NW : ACOL_BLOCK) void ac_collect_kern
     // the wave's tile behind the packs and the env's bytes; fast path only for blocks of 16 envs inside the batch (wave-uniform)
     float* tile = reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(lds) + (FROM_GLOBAL ? 0 : PP::LDS_BYTES) + ENV::LDS_MAX) + (size_t)wave * OT::ELEMS;
     const int n0 = (blockIdx.x * bpw + blk) * 16;
-    const bool tstore = TSTORE && !ghost && n0 + 16 <= N;
+    const bool tstore = TSTORE && !ghost && n0 + 16 <= N && storer;
     int t_off[TSTORE ? OT::NI : 1];  // float offset of tile element 64 i + lane inside the block's 16 batch rows (agent 0)
     if constexpr (TSTORE) {
 #pragma unroll
@@ -210,13 +214,13 @@ __global__ __launch_bounds__(NW > 4 ? 64 * NW : ACOL_BLOCK) void ac_collect_kern
         ENV::template observe<S::KS1, OID>(q, s, ctx, p, g, x[k]);
         if (tstore) {
             store_rows_t(0, p, x[k], true);
-        } else if (valid && !ghost) {
+        } else if (valid && !ghost && storer) {
 #pragma unroll
             for (int ks = 0; ks < S::KS1; ++ks)
                 if (4 * ks + g < D) obs_row(0)[p * D + 4 * ks + g] = x[k][ks];
         }
     }
-    const bool lead = g == 0 && aw == 0;  // the lane that writes an env's per-env records
+    const bool lead = g == 0 && aw == 0 && half == 0;  // the lane that writes an env's per-env records
     if (valid && lead && !ghost) b_done[env_id] = 0;
     bool running = valid && !ghost;
     int n_rec = 0;  // second pass: episodes recorded for this env
@@ -251,23 +255,28 @@ __global__ __launch_bounds__(NW > 4 ? 64 * NW : ACOL_BLOCK) void ac_collect_kern
                     pack = lds;
                 }
                 f4 h1[S::MT], h2[S::MT], logits, unused;
-                if constexpr (FROM_GLOBAL) mlp_forward_g<S>(pack, lane, x[k], logits);
+                if constexpr (HS == 2) mlp_forward_h2<S>(pack, lane, x[k], half, s_xh + aw * (2 * (S::MT / 2) * 64), s_xq + aw * 64, logits);  // (half 1 only)
+                else if constexpr (FROM_GLOBAL) mlp_forward_g<S>(pack, lane, x[k], logits);
                 else mlp_forward_p<S, false>(pack, pack, lane, x[k], h1, h2, logits, unused, PP::A3REG ? a3[PP::A3REG ? k : 0] : nullptr);
                 ACOL_TS(0)
                 const float u = u01_f32(act_noise_word(q.seed, env_id, 2u * round, (uint32_t)t, 1 + p));
                 own[k] = sample_rows<A>(logits, lane, u);
-                if (NW == 1) act[k] = own[k];
+                if (WPB == 1) act[k] = own[k];
                 ACOL_TS(1)
             }
         }
-        if (NW > 1) {  // swap the sampled actions among the waves of the env block (double-buffered: one barrier per step)
+        if (WPB > 1) {  // swap the sampled actions among the waves of the env block (double-buffered: one barrier per step)
             int* sa = s_act + (((t & 1) * 4 + blk) * P) * 16;
 #pragma unroll
             for (int k = 0; k < K; ++k)
-                if (g == 0) sa[(aw + k * NW) * 16 + j] = own[k];
+                if (g == 0 && half == HS - 1) sa[(aw + k * NW) * 16 + j] = own[k];
             __syncthreads();
 #pragma unroll
             for (int p = 0; p < P; ++p) act[p] = sa[p * 16 + j];
+            if (HS > 1) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) own[k] = pick_agent<P>(act, aw + k * NW);  // the half-0 wave stores it
+            }
         }
         ACOL_TS(2)
         const bool ran = running;
@@ -312,7 +321,7 @@ __global__ __launch_bounds__(NW > 4 ? 64 * NW : ACOL_BLOCK) void ac_collect_kern
                 ENV::template observe<S::KS1, OID>(q, s, ctx, p, g, x[k]);
                 ACOL_TS(5)
                 rw_own[k] = pick_agent<P>(rw, p);
-                if (ghost) continue;
+                if (ghost || !storer) continue;
                 if (tstore) continue;  // the rows of all 16 envs of the block go out together below
 #pragma unroll
                 for (int ks = 0; ks < S::KS1; ++ks)
@@ -335,7 +344,7 @@ __global__ __launch_bounds__(NW > 4 ? 64 * NW : ACOL_BLOCK) void ac_collect_kern
                     atomicMax(t_max, len);
                 }
             }
-        } else if (valid && !ghost && !tstore) {
+        } else if (valid && !ghost && !tstore && storer) {
             // rows of an env that is no longer running stay zero, as in the reference's freshly allocated batch
 #pragma unroll
             for (int k = 0; k < K; ++k) {
@@ -378,7 +387,7 @@ __global__ __launch_bounds__(NW > 4 ? 64 * NW : ACOL_BLOCK) void ac_collect_kern
     }
 }
 
-template <class ENV, int H, bool OID, int NW>
+template <class ENV, int H, bool OID, int NW, int HS = 1>
 int launch_ac_collect_nw(const typename ENV::Params& q, const float* packs, uint32_t round, int T, int proper_term, float* b_obs, int64_t* b_act,
                          float* b_rew, uint8_t* b_done, float* b_filled, float* fin_return, int32_t* fin_length, int32_t* t_max, hipStream_t st) {
     constexpr int P = ENV::P, D = ENV::D0 + (OID ? P : 0);
@@ -389,16 +398,16 @@ int launch_ac_collect_nw(const typename ENV::Params& q, const float* packs, uint
                                                             : ((NW > 1 && !(PP::RESIDENT || PP::A3REG)) ? 0 : PP::LDS_BYTES) + ENV::lds_bytes(q);
     static LdsAttr attr_set;
     if (attr_set.need(lds_bytes)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ac_collect_kernel<ENV, H, OID, NW>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ac_collect_kernel<ENV, H, OID, NW, HS>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         attr_set.done(lds_bytes);
     }
     // one env block (16 envs, NW waves) per workgroup while the launch has fewer waves than the chip has SIMDs: the per-step action
     // swap is a workgroup barrier, and with several blocks per workgroup every block waits for the slowest one's step
-    const bool one_block = NW > 1 && (int64_t)((q.n_envs + 15) / 16) * NW <= 1024;
-    const int threads = (one_block || NW > 4) ? 64 * NW : ACOL_BLOCK, per_wg = 16 * (threads / (64 * NW));  // envs per workgroup
+    const bool one_block = HS > 1 || (NW > 1 && (int64_t)((q.n_envs + 15) / 16) * NW <= 1024);
+    const int threads = (one_block || NW * HS > 4) ? 64 * NW * HS : ACOL_BLOCK, per_wg = 16 * (threads / (64 * NW * HS));  // envs per workgroup
     timing_begin(TIMER_COLLECT, st);
-    hipLaunchKernelGGL((ac_collect_kernel<ENV, H, OID, NW>), dim3((q.n_envs + per_wg - 1) / per_wg), dim3(threads), lds_bytes, st, q, packs, round, T,
+    hipLaunchKernelGGL((ac_collect_kernel<ENV, H, OID, NW, HS>), dim3((q.n_envs + per_wg - 1) / per_wg), dim3(threads), lds_bytes, st, q, packs, round, T,
                        proper_term, b_obs, b_act, b_rew, b_done, b_filled, fin_return, fin_length, t_max, ac_ghost_current());
     timing_end(TIMER_COLLECT, st);
     MARL_CHECK_LAUNCH("ac_collect_kernel");
@@ -422,6 +431,11 @@ int launch_ac_collect(const typename ENV::Params& q, const AgentMap& am, const f
     const bool split = NWMAX > 1 && q.reward_stats == nullptr && (forced ? forced > 1 : q.n_envs <= 8192);  // measured: ahead up to 8192 envs (2 and 4 agents), behind from 16384
 #define MARL_ACOL_LAUNCH_ARGS q, (const float*)packs, round, T, proper_term, b_obs, b_act, b_rew, b_done, b_filled, fin_return, fin_length, t_max, st
     if constexpr (NWMAX > 1) {
+        // two waves per agent while even agent-per-wave leaves half of the SIMDs idle (see launch_collect); MARLHIP_ACOL_HS=1 turns it off
+        if constexpr (P == 2 && PackPlan<S, P, ENV::LDS_MAX>::RESIDENT && S::MT % 2 == 0 && !acol_tstore<ENV, H, OID, NWMAX>()) {
+            static const bool hs_off = getenv("MARLHIP_ACOL_HS") != nullptr && atoi(getenv("MARLHIP_ACOL_HS")) == 1;
+            if (split && !hs_off && (int64_t)((q.n_envs + 15) / 16) * NWMAX * 2 <= 1024) return launch_ac_collect_nw<ENV, H, OID, NWMAX, 2>(MARL_ACOL_LAUNCH_ARGS);
+        }
         if (split) return launch_ac_collect_nw<ENV, H, OID, NWMAX>(MARL_ACOL_LAUNCH_ARGS);
     }
     return launch_ac_collect_nw<ENV, H, OID, 1>(MARL_ACOL_LAUNCH_ARGS);

@@ -75,8 +75,11 @@ __global__ __launch_bounds__(COL_BLOCK) void dqn_act_kernel(int P, int N, AgentM
 
 // NW: waves per block of 16 envs, each running the Q-networks of the agents p = w mod NW on its own copy of the env state (see
 // ac_collect_kernel: the joint action is swapped through LDS once per step, every copy steps with it)
-template <class ENV, int H, bool OID, int NW>
-__global__ __launch_bounds__(NW > 4 ? 64 * NW : COL_BLOCK) void idqn_collect_kernel(typename ENV::Params q, const float* __restrict__ packs, float eps,
+// HS = 2 (round 4): every agent's forward pass on TWO waves (mlp_forward_h2), i.e. NW * HS waves per env block, for launches that would
+// otherwise leave half of the SIMDs idle (4096 envs x 2 agents); the half-1 wave ends up with the Q values and publishes the action, the
+// half-0 waves of the block write its records.  One env block per workgroup (the forward pass has workgroup barriers inside).
+template <class ENV, int H, bool OID, int NW, int HS = 1>
+__global__ __launch_bounds__(NW * HS > 4 ? 64 * NW * HS : COL_BLOCK) void idqn_collect_kernel(typename ENV::Params q, const float* __restrict__ packs, float eps,
                                                                  uint32_t round, marlhip_replay_shape rs, marlhip_replay_buffers rb,
                                                                  int slot_base, int write_replay, int clear_stale, int proper_term,
                                                                  float* __restrict__ fin_return, int32_t* __restrict__ fin_length) {
@@ -91,13 +94,15 @@ __global__ __launch_bounds__(NW > 4 ? 64 * NW : COL_BLOCK) void idqn_collect_ker
     // and lives in scalar registers; as a per-lane value the 8-agent hidden-128 kernels kept one 64-bit address per pack load in vector
     // registers, spilled them, and waited out every reload: 85 k cycles per step for two forward passes)
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, g = lane >> 4, j = lane & 15;
-    const int blk = wave / NW, aw = wave % NW;
-    const int bpw = (int)blockDim.x / (64 * NW);  // env blocks per workgroup: 4 / NW, or ONE when the launch has fewer waves than the chip has SIMDs
+    constexpr int WPB = NW * HS;  // waves per env block
+    const int blk = wave / WPB, aw = (wave % WPB) % NW, half = (wave % WPB) / NW;
+    const int bpw = (int)blockDim.x / (64 * WPB);  // env blocks per workgroup: 4 / WPB, or ONE when the launch has fewer waves than the chip has SIMDs
     const int n = (blockIdx.x * bpw + blk) * 16 + j;
     const int N = q.n_envs, T = rs.max_len;
     typename ENV::Ctx ctx;
     ctx.init(q, reinterpret_cast<uint8_t*>(lds) + (FROM_GLOBAL ? 0 : PP::LDS_BYTES), wave, j);
-    const bool lead = g == 0 && aw == 0;  // the lane that writes an env's per-env records
+    const bool lead = g == 0 && aw == 0 && half == 0;  // the lane that writes an env's per-env records
+    __shared__ f4 s_xh[HS > 1 ? NW * 2 * (S::MT / 2) * 64 : 1], s_xq[HS > 1 ? NW * 64 : 1];  // mlp_forward_h2's exchange (one env block per workgroup)
     const bool valid = n < N;
     const uint32_t env_id = (uint32_t)(valid ? n : N - 1);
 
@@ -123,7 +128,7 @@ __global__ __launch_bounds__(NW > 4 ? 64 * NW : COL_BLOCK) void idqn_collect_ker
     float* rr = rb.rew + (size_t)slot * P * T;
     uint8_t* rd = rb.done + (size_t)slot * (T + 1);
     uint8_t* rf = rb.filled + (size_t)slot * T;
-    const bool wr = valid && write_replay;
+    const bool wr = valid && write_replay && half == 0;  // (HS = 2: the half-0 wave of an agent writes its rows)
 
     float x[K][S::KS1];  // the wave observes, forwards and stores for its own agents
 #pragma unroll
@@ -146,7 +151,7 @@ __global__ __launch_bounds__(NW > 4 ? 64 * NW : COL_BLOCK) void idqn_collect_ker
 
     for (int t = 0; t < T; ++t) {
         const bool any_alive = __any(alive);
-        if (RESIDENT && NW == 1) {
+        if (RESIDENT && WPB == 1) {
             if (!any_alive) break;  // wave-uniform: all 16 envs of this wave are finished (NW > 1: the barrier below keeps every wave looping)
         }
         int act[P], own[K];
@@ -160,7 +165,7 @@ __global__ __launch_bounds__(NW > 4 ? 64 * NW : COL_BLOCK) void idqn_collect_ker
         for (int k = 0; k < K; ++k) {
             const int p = aw + k * NW;
             own[k] = 0;
-            if (NW > 1 && !any_alive) continue;
+            if (WPB > 1 && !any_alive) continue;  // (uniform over the env block; HS = 2: over the workgroup, which is one block)
             const float* pack;
             if (RESIDENT) {
                 pack = lds + (size_t)p * PP::STRIDE;
@@ -173,20 +178,25 @@ __global__ __launch_bounds__(NW > 4 ? 64 * NW : COL_BLOCK) void idqn_collect_ker
                 pack = lds;
             }
             f4 h1[S::MT], h2[S::MT], qv, unused;
-            if constexpr (FROM_GLOBAL) mlp_forward_g<S>(pack, lane, x[k], qv);
+            if constexpr (HS == 2) mlp_forward_h2<S>(pack, lane, x[k], half, s_xh + aw * (2 * (S::MT / 2) * 64), s_xq + aw * 64, qv);  // (qv: half 1 only)
+            else if constexpr (FROM_GLOBAL) mlp_forward_g<S>(pack, lane, x[k], qv);
             else mlp_forward_p<S, false>(pack, pack, lane, x[k], h1, h2, qv, unused, PP::A3REG ? a3[PP::A3REG ? k : 0] : nullptr);
             const int greedy = argmax_rows<A>(qv, lane);
             own[k] = explore ? pick_agent<P>(rnd, p) : greedy;
-            if (NW == 1) act[k] = own[k];
+            if (WPB == 1) act[k] = own[k];
         }
-        if (NW > 1) {  // swap the chosen actions among the waves of the env block (double-buffered: one barrier per step)
+        if (WPB > 1) {  // swap the chosen actions among the waves of the env block (double-buffered: one barrier per step)
             int* sa = s_act + (((t & 1) * 4 + blk) * P) * 16;
 #pragma unroll
             for (int k = 0; k < K; ++k)
-                if (g == 0) sa[(aw + k * NW) * 16 + j] = own[k];
+                if (g == 0 && half == HS - 1) sa[(aw + k * NW) * 16 + j] = own[k];
             __syncthreads();
 #pragma unroll
             for (int p = 0; p < P; ++p) act[p] = sa[p * 16 + j];
+            if (HS > 1) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) own[k] = pick_agent<P>(act, aw + k * NW);  // the half-0 wave stores it
+            }
         }
         if (alive) {
             double raw[P];
@@ -238,7 +248,7 @@ __global__ __launch_bounds__(NW > 4 ? 64 * NW : COL_BLOCK) void idqn_collect_ker
     }
 }
 
-template <class ENV, int H, bool OID, int NW>
+template <class ENV, int H, bool OID, int NW, int HS = 1>
 int launch_collect_nw(const typename ENV::Params& q, const float* packs, float eps, uint32_t round, const marlhip_replay_shape* rs,
                       const marlhip_replay_buffers* rb, int slot_base, int write_replay, int clear_stale, int proper_term, float* fin_return,
                       int32_t* fin_length, hipStream_t st) {
@@ -248,16 +258,16 @@ int launch_collect_nw(const typename ENV::Params& q, const float* packs, float e
     const size_t lds_bytes = ((NW > 1 && !(PP::RESIDENT || PP::A3REG)) ? 0 : PP::LDS_BYTES) + ENV::lds_bytes(q);
     static LdsAttr attr_set;
     if (attr_set.need(lds_bytes)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&idqn_collect_kernel<ENV, H, OID, NW>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&idqn_collect_kernel<ENV, H, OID, NW, HS>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         attr_set.done(lds_bytes);
     }
     // one env block per workgroup while the launch leaves SIMDs empty (see launch_ac_collect_nw): the action swap's barrier then only
     // joins the NW waves that need each other
-    const bool one_block = NW > 1 && (int64_t)((q.n_envs + 15) / 16) * NW <= 1024;
-    const int threads = (one_block || NW > 4) ? 64 * NW : COL_BLOCK, per_wg = 16 * (threads / (64 * NW));
+    const bool one_block = HS > 1 || (NW > 1 && (int64_t)((q.n_envs + 15) / 16) * NW <= 1024);
+    const int threads = (one_block || NW * HS > 4) ? 64 * NW * HS : COL_BLOCK, per_wg = 16 * (threads / (64 * NW * HS));
     timing_begin(TIMER_COLLECT, st);
-    hipLaunchKernelGGL((idqn_collect_kernel<ENV, H, OID, NW>), dim3((q.n_envs + per_wg - 1) / per_wg), dim3(threads), lds_bytes, st, q, packs, eps, round,
+    hipLaunchKernelGGL((idqn_collect_kernel<ENV, H, OID, NW, HS>), dim3((q.n_envs + per_wg - 1) / per_wg), dim3(threads), lds_bytes, st, q, packs, eps, round,
                        *rs, *rb, slot_base, write_replay, clear_stale, proper_term, fin_return, fin_length);
     timing_end(TIMER_COLLECT, st);
     MARL_CHECK_LAUNCH("idqn_collect_kernel");
@@ -285,6 +295,12 @@ int launch_collect(const typename ENV::Params& q, const AgentMap& am, const floa
     const bool split = NWMAX > 1 && q.reward_stats == nullptr && (forced ? forced > 1 : q.n_envs <= 8192);  // measured: ahead up to 8192 envs (2 and 4 agents), behind from 16384
 #define MARL_COL_LAUNCH_ARGS q, (const float*)packs, eps, round, rs, rb, slot_base, write_replay, clear_stale, proper_term, fin_return, fin_length, st
     if constexpr (NWMAX > 1) {
+        // two waves per agent while even agent-per-wave leaves half of the SIMDs idle (2 agents with LDS-resident packs, <= 4096 envs);
+        // MARLHIP_COL_HS=1 keeps one wave per agent
+        if constexpr (P == 2 && PackPlan<S, P, ENV::LDS_MAX>::RESIDENT && S::MT % 2 == 0) {
+            static const bool hs_off = getenv("MARLHIP_COL_HS") != nullptr && atoi(getenv("MARLHIP_COL_HS")) == 1;
+            if (split && !hs_off && (int64_t)((q.n_envs + 15) / 16) * NWMAX * 2 <= 1024) return launch_collect_nw<ENV, H, OID, NWMAX, 2>(MARL_COL_LAUNCH_ARGS);
+        }
         if (split) return launch_collect_nw<ENV, H, OID, NWMAX>(MARL_COL_LAUNCH_ARGS);
     }
     return launch_collect_nw<ENV, H, OID, 1>(MARL_COL_LAUNCH_ARGS);

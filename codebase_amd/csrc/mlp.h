@@ -329,6 +329,80 @@ __device__ __forceinline__ void mlp_forward_p(const float* ldsA, const float* ld
     if (DUAL) qB = o3B;
 }
 
+// One network on TWO waves (round 4: the collectors on launches that would leave half of the SIMDs idle - 4096 envs x 2 agents are 512
+// one-agent waves).  Wave `half` owns hidden tiles [half MT/2, (half + 1) MT/2) of layers 1 and 2 (every output tile is accumulated by one
+// wave in mlp_forward_p's k order); the relu'd layer-1 tiles cross through LDS (xh: [2][MT/2][64] f4 per network); layer 3 is ONE chain
+// in mlp_forward_p's order - half 0 starts from the bias with k1 < MT/2, hands the partial sum over (xq: [64] f4), half 1 finishes it.
+// The result (valid in the half-1 wave only) has the bits of the one-wave forward.  Two workgroup barriers: every wave of the workgroup
+// must make the call.
+template <class S>
+__device__ __forceinline__ void mlp_forward_h2(const float* lds, int lane, const float (&x)[S::KS1], int half, f4* xh, f4* xq, f4& q) {
+    constexpr int MT = S::MT, MH = MT / 2, N1 = S::KS1 / 4;
+    static_assert(MT % 2 == 0, "two waves split the hidden tiles evenly");
+    const int g = lane >> 4, t0 = half * MH;
+    const f4* A1 = reinterpret_cast<const f4*>(lds + S::pA1);
+    const f4* A2 = reinterpret_cast<const f4*>(lds + S::pA2);
+    const f4* A3 = reinterpret_cast<const f4*>(lds + S::pA3);
+    f4 acc[MH], h1[MT], h2[MH];
+#pragma unroll
+    for (int m = 0; m < MH; ++m) acc[m] = *reinterpret_cast<const f4*>(lds + S::pb1 + 16 * (t0 + m) + 4 * g);
+#pragma unroll
+    for (int s = 0; s < N1; ++s) {
+        f4 op[MH];
+#pragma unroll
+        for (int m = 0; m < MH; ++m) op[m] = A1[((t0 + m) * N1 + s) * 64 + lane];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int m = 0; m < MH; ++m) acc[m] = MARL_MFMA(op[m][e], x[4 * s + e], acc[m]);
+    }
+#pragma unroll
+    for (int m = 0; m < MH; ++m) {
+        acc[m] = relu4(acc[m]);
+        xh[(half * MH + m) * 64 + lane] = acc[m];
+    }
+    __syncthreads();
+    f4 other[MH];
+#pragma unroll
+    for (int m = 0; m < MH; ++m) other[m] = xh[((1 - half) * MH + m) * 64 + lane];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) h1[mt] = (mt / MH == half) ? acc[mt % MH] : other[mt % MH];  // (compile-time register indices, run-time select)
+#pragma unroll
+    for (int m = 0; m < MH; ++m) acc[m] = *reinterpret_cast<const f4*>(lds + S::pb2 + 16 * (t0 + m) + 4 * g);
+#pragma unroll
+    for (int k1 = 0; k1 < MT; ++k1) {
+        f4 op[MH];
+#pragma unroll
+        for (int m = 0; m < MH; ++m) op[m] = A2[((t0 + m) * MT + k1) * 64 + lane];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int m = 0; m < MH; ++m) acc[m] = MARL_MFMA(op[m][r], h1[k1][r], acc[m]);
+    }
+#pragma unroll
+    for (int m = 0; m < MH; ++m) h2[m] = relu4(acc[m]);
+    f4 op3[MH];
+#pragma unroll
+    for (int m = 0; m < MH; ++m) op3[m] = A3[(t0 + m) * 64 + lane];
+    f4 o3 = *reinterpret_cast<const f4*>(lds + S::pb3 + 4 * g);
+    if (half == 0) {
+#pragma unroll
+        for (int m = 0; m < MH; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o3 = MARL_MFMA(op3[m][r], h2[m][r], o3);
+        xq[lane] = o3;
+    }
+    __syncthreads();
+    if (half == 1) {
+        o3 = xq[lane];
+#pragma unroll
+        for (int m = 0; m < MH; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o3 = MARL_MFMA(op3[m][r], h2[m][r], o3);
+    }
+    q = o3;
+}
+
 template <int I, int N, class F>
 __device__ __forceinline__ void marl_static_for(F& f) {
     if constexpr (I < N) {

@@ -1,7 +1,9 @@
-"""The fused collectors come in two wave organisations (csrc/collect_kernels.h, csrc/ac_collect_kernels.h): one wave per block of 16
-envs running every agent's network in turn, or NW waves per block, each with its own copy of the env state and a share of the
-agents (chosen up to 8192 envs).  Both must write the same bytes.  The choice is read once per process (MARLHIP_COL_NW /
-MARLHIP_ACOL_NW), so each variant runs in its own interpreter and reports digests of everything it wrote."""
+"""The fused collectors come in three wave organisations (csrc/collect_kernels.h, csrc/ac_collect_kernels.h): one wave per block of 16
+envs running every agent's network in turn; NW waves per block, each with its own copy of the env state and a share of the
+agents (chosen up to 8192 envs); and, for 2 agents with LDS-resident packs on launches that would still leave SIMDs idle, TWO waves per
+agent (mlp_forward_h2: hidden tiles split, layer 3 one chain handed from wave to wave).  All must write the same bytes.  The choice is
+read once per process (MARLHIP_COL_NW / MARLHIP_ACOL_NW, MARLHIP_COL_HS / MARLHIP_ACOL_HS), so each variant runs in its own interpreter
+and reports digests of everything it wrote."""
 import hashlib
 import json
 import os
@@ -51,8 +53,12 @@ print("DIGESTS " + json.dumps(out))
 """
 
 
-def run_variant(nw):
+def run_variant(nw, hs=None):
     env = dict(os.environ)
+    for k in ("MARLHIP_COL_HS", "MARLHIP_ACOL_HS"):
+        env.pop(k, None)
+        if hs:
+            env[k] = str(hs)
     if nw:
         env["MARLHIP_COL_NW"] = env["MARLHIP_ACOL_NW"] = str(nw)
     else:
@@ -65,7 +71,8 @@ def run_variant(nw):
 
 
 def test_one_wave_and_agent_per_wave_collectors_write_the_same_bytes():
-    one, split = run_variant(1), run_variant(0)  # 0: the default choice (agent-per-wave at these env counts)
-    assert one.keys() == split.keys() and len(one) == 8
+    # 0: the default choice (agent-per-wave at these env counts; two waves per agent for the 2-agent 64-wide LBF case); hs=1: never two per agent
+    one, split, split1 = run_variant(1), run_variant(0), run_variant(0, hs=1)
+    assert one.keys() == split.keys() == split1.keys() and len(one) == 8
     for k in one:
-        assert one[k] == split[k], k
+        assert one[k] == split[k] == split1[k], k
