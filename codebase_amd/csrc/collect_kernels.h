@@ -295,7 +295,12 @@ int launch_collect(const typename ENV::Params& q, const AgentMap& am, const floa
     const bool split = NWMAX > 1 && q.reward_stats == nullptr && (forced ? forced > 1 : q.n_envs <= 8192);  // measured: ahead up to 8192 envs (2 and 4 agents), behind from 16384
 #define MARL_COL_LAUNCH_ARGS q, (const float*)packs, eps, round, rs, rb, slot_base, write_replay, clear_stale, proper_term, fin_return, fin_length, st
     if constexpr (NWMAX > 1) {
-        // two waves per agent while even agent-per-wave leaves half of the SIMDs idle (2 agents with LDS-resident packs, <= 4096 envs);
+        // two waves per agent while even agent-per-wave leaves half of the SIMDs idle (2 agents with LDS-resident packs, <= 4096 envs).
+        // Measured and NOT extended (scripts/gpu_runs/r4W.sh, r4X.sh): 4 agents x 2 waves in a 512-thread workgroup fit 256 registers but
+        // are 8 - 15 % SLOWER (warehouse rollout 6.9 -> 7.5 ms at hidden 128) - the unit's four matrix pipes are already busy with four
+        // one-agent waves, a second wave per SIMD only adds the exchange; 2 agents with packs read from L2 (hidden 128): +-0, and so is a
+        // fourth / fifth operand group in flight in mlp_forward_g - that pass is bound by the L2 bandwidth of 256 units each re-reading
+        // its agents' packs every step (~8 TB/s in aggregate), not by its MFMAs or its load latency;
         // MARLHIP_COL_HS=1 keeps one wave per agent
         if constexpr (P == 2 && PackPlan<S, P, ENV::LDS_MAX>::RESIDENT && S::MT % 2 == 0) {
             static const bool hs_off = getenv("MARLHIP_COL_HS") != nullptr && atoi(getenv("MARLHIP_COL_HS")) == 1;
