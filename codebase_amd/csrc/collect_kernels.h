@@ -300,7 +300,9 @@ int launch_collect(const typename ENV::Params& q, const AgentMap& am, const floa
         // are 8 - 15 % SLOWER (warehouse rollout 6.9 -> 7.5 ms at hidden 128) - the unit's four matrix pipes are already busy with four
         // one-agent waves, a second wave per SIMD only adds the exchange; 2 agents with packs read from L2 (hidden 128): +-0, and so is a
         // fourth / fifth operand group in flight in mlp_forward_g - that pass is bound by the L2 bandwidth of 256 units each re-reading
-        // its agents' packs every step (~8 TB/s in aggregate), not by its MFMAs or its load latency;
+        // its agents' packs every step, not by its MFMAs or its load latency (spreading the units over 1 / 4 / 8 identical pack sets: +-0
+        // too, r4Y.sh); 2 agents at hidden 128 (the output layer's operands in registers, 150 KB of packs in LDS) leave no room for the
+        // 16 KB of exchange tiles;
         // MARLHIP_COL_HS=1 keeps one wave per agent
         if constexpr (P == 2 && PackPlan<S, P, ENV::LDS_MAX>::RESIDENT && S::MT % 2 == 0) {
             static const bool hs_off = getenv("MARLHIP_COL_HS") != nullptr && atoi(getenv("MARLHIP_COL_HS")) == 1;
