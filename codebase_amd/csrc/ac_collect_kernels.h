@@ -148,7 +148,8 @@ __global__ __launch_bounds__(NW * HS > 4 ? 64 * NW * HS : ACOL_BLOCK) void ac_co
     constexpr int WPB = NW * HS;  // waves per env block
     const int blk = wave / WPB, aw = (wave % WPB) % NW, half = (wave % WPB) / NW;
     const bool storer = half == 0;  // HS = 2: the half-0 wave of an agent writes its rows (the half-1 wave samples)
-    __shared__ f4 s_xh[HS > 1 ? NW * 2 * (MlpShape<ENV::D0 + (OID ? ENV::P : 0), H, ENV::A>::MT / 2) * 64 : 1], s_xq[HS > 1 ? NW * 64 : 1];
+    constexpr int XR = PP::A3REG ? 2 : 1, XT = S::MT / 2 / XR;  // exchange rounds of mlp_forward_h2 and tiles per round
+    __shared__ f4 s_xh[HS > 1 ? NW * 2 * XT * 64 : 1], s_xq[HS > 1 ? NW * 64 : 1];
     const int bpw = (int)blockDim.x / (64 * WPB);  // env blocks per workgroup: 4 / NW, or ONE when the launch has fewer waves than the chip has SIMDs             // env block inside the workgroup, this wave's agent residue
     ACOL_TS_BEGIN
     const int n = (blockIdx.x * bpw + blk) * 16 + j;
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(NW * HS > 4 ? 64 * NW * HS : ACOL_BLOCK) void ac_co
             for (int k = 0; k < K; ++k)
 #pragma unroll
                 for (int mt = 0; mt < S::MT; ++mt)
-                    a3[k][mt] = reinterpret_cast<const f4*>(actor + (size_t)(aw + k * NW) * S::NFWD + S::pA3)[mt * 64 + lane];
+                    a3[k][mt] = reinterpret_cast<const f4*>(actor + (size_t)(aw + k * NW) * S::NFWD + S::pA3)[((HS == 2 && mt < S::MT / 2 ? half * (S::MT / 2) : 0) + mt) * 64 + lane];  // HS = 2: entries [0, MT/2) hold the half's own tiles
         }
     }
     ACOL_TS(9)
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(NW * HS > 4 ? 64 * NW * HS : ACOL_BLOCK) void ac_co
                     pack = lds;
                 }
                 f4 h1[S::MT], h2[S::MT], logits, unused;
-                if constexpr (HS == 2) mlp_forward_h2<S>(pack, lane, x[k], half, s_xh + aw * (2 * (S::MT / 2) * 64), s_xq + aw * 64, logits);  // (half 1 only)
+                if constexpr (HS == 2) mlp_forward_h2<S, XR>(pack, lane, x[k], half, s_xh + aw * (2 * XT * 64), s_xq + aw * 64, logits, PP::A3REG ? a3[PP::A3REG ? k : 0] : nullptr);  // (half 1 only)
                 else if constexpr (FROM_GLOBAL) mlp_forward_g<S>(pack, lane, x[k], logits);
                 else mlp_forward_p<S, false>(pack, pack, lane, x[k], h1, h2, logits, unused, PP::A3REG ? a3[PP::A3REG ? k : 0] : nullptr);
                 ACOL_TS(0)
@@ -432,7 +433,7 @@ int launch_ac_collect(const typename ENV::Params& q, const AgentMap& am, const f
 #define MARL_ACOL_LAUNCH_ARGS q, (const float*)packs, round, T, proper_term, b_obs, b_act, b_rew, b_done, b_filled, fin_return, fin_length, t_max, st
     if constexpr (NWMAX > 1) {
         // two waves per agent while even agent-per-wave leaves half of the SIMDs idle (see launch_collect); MARLHIP_ACOL_HS=1 turns it off
-        if constexpr (P == 2 && PackPlan<S, P, ENV::LDS_MAX>::RESIDENT && S::MT % 2 == 0 && !acol_tstore<ENV, H, OID, NWMAX>()) {
+        if constexpr (P == 2 && (PackPlan<S, P, ENV::LDS_MAX>::RESIDENT || PackPlan<S, P, ENV::LDS_MAX>::A3REG) && S::MT % 4 == 0 && !acol_tstore<ENV, H, OID, NWMAX>()) {
             static const bool hs_off = getenv("MARLHIP_ACOL_HS") != nullptr && atoi(getenv("MARLHIP_ACOL_HS")) == 1;
             if (split && !hs_off && (int64_t)((q.n_envs + 15) / 16) * NWMAX * 2 <= 1024) return launch_ac_collect_nw<ENV, H, OID, NWMAX, 2>(MARL_ACOL_LAUNCH_ARGS);
         }

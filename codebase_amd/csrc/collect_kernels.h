@@ -102,7 +102,8 @@ __global__ __launch_bounds__(NW * HS > 4 ? 64 * NW * HS : COL_BLOCK) void idqn_c
     typename ENV::Ctx ctx;
     ctx.init(q, reinterpret_cast<uint8_t*>(lds) + (FROM_GLOBAL ? 0 : PP::LDS_BYTES), wave, j);
     const bool lead = g == 0 && aw == 0 && half == 0;  // the lane that writes an env's per-env records
-    __shared__ f4 s_xh[HS > 1 ? NW * 2 * (S::MT / 2) * 64 : 1], s_xq[HS > 1 ? NW * 64 : 1];  // mlp_forward_h2's exchange (one env block per workgroup)
+    constexpr int XR = PP::A3REG ? 2 : 1, XT = S::MT / 2 / XR;  // exchange rounds of mlp_forward_h2 and tiles per round (hidden 128: 10 KB of LDS left next to the packs)
+    __shared__ f4 s_xh[HS > 1 ? NW * 2 * XT * 64 : 1], s_xq[HS > 1 ? NW * 64 : 1];  // mlp_forward_h2's exchange (one env block per workgroup)
     const bool valid = n < N;
     const uint32_t env_id = (uint32_t)(valid ? n : N - 1);
 
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(NW * HS > 4 ? 64 * NW * HS : COL_BLOCK) void idqn_c
             for (int k = 0; k < K; ++k)
 #pragma unroll
                 for (int mt = 0; mt < S::MT; ++mt)
-                    a3[k][mt] = reinterpret_cast<const f4*>(packs + (size_t)(aw + k * NW) * S::NFWD + S::pA3)[mt * 64 + lane];
+                    a3[k][mt] = reinterpret_cast<const f4*>(packs + (size_t)(aw + k * NW) * S::NFWD + S::pA3)[((HS == 2 && mt < S::MT / 2 ? half * (S::MT / 2) : 0) + mt) * 64 + lane];  // HS = 2: entries [0, MT/2) hold the half's own tiles
         }
     }
 
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(NW * HS > 4 ? 64 * NW * HS : COL_BLOCK) void idqn_c
                 pack = lds;
             }
             f4 h1[S::MT], h2[S::MT], qv, unused;
-            if constexpr (HS == 2) mlp_forward_h2<S>(pack, lane, x[k], half, s_xh + aw * (2 * (S::MT / 2) * 64), s_xq + aw * 64, qv);  // (qv: half 1 only)
+            if constexpr (HS == 2) mlp_forward_h2<S, XR>(pack, lane, x[k], half, s_xh + aw * (2 * XT * 64), s_xq + aw * 64, qv, PP::A3REG ? a3[PP::A3REG ? k : 0] : nullptr);  // (qv: half 1 only)
             else if constexpr (FROM_GLOBAL) mlp_forward_g<S>(pack, lane, x[k], qv);
             else mlp_forward_p<S, false>(pack, pack, lane, x[k], h1, h2, qv, unused, PP::A3REG ? a3[PP::A3REG ? k : 0] : nullptr);
             const int greedy = argmax_rows<A>(qv, lane);
@@ -301,10 +302,10 @@ int launch_collect(const typename ENV::Params& q, const AgentMap& am, const floa
         // one-agent waves, a second wave per SIMD only adds the exchange; 2 agents with packs read from L2 (hidden 128): +-0, and so is a
         // fourth / fifth operand group in flight in mlp_forward_g - that pass is bound by the L2 bandwidth of 256 units each re-reading
         // its agents' packs every step, not by its MFMAs or its load latency (spreading the units over 1 / 4 / 8 identical pack sets: +-0
-        // too, r4Y.sh); 2 agents at hidden 128 (the output layer's operands in registers, 150 KB of packs in LDS) leave no room for the
-        // 16 KB of exchange tiles;
+        // too, r4Y.sh).  2 agents at hidden 128 (the output layer's operands in registers, 146 KB of packs in LDS) do take the form, with the
+        // exchange in two rounds of 8 KB: rollout 226 -> 185 us;
         // MARLHIP_COL_HS=1 keeps one wave per agent
-        if constexpr (P == 2 && PackPlan<S, P, ENV::LDS_MAX>::RESIDENT && S::MT % 2 == 0) {
+        if constexpr (P == 2 && (PackPlan<S, P, ENV::LDS_MAX>::RESIDENT || PackPlan<S, P, ENV::LDS_MAX>::A3REG) && S::MT % 4 == 0) {
             static const bool hs_off = getenv("MARLHIP_COL_HS") != nullptr && atoi(getenv("MARLHIP_COL_HS")) == 1;
             if (split && !hs_off && (int64_t)((q.n_envs + 15) / 16) * NWMAX * 2 <= 1024) return launch_collect_nw<ENV, H, OID, NWMAX, 2>(MARL_COL_LAUNCH_ARGS);
         }

@@ -335,10 +335,13 @@ __device__ __forceinline__ void mlp_forward_p(const float* ldsA, const float* ld
 // in mlp_forward_p's order - half 0 starts from the bias with k1 < MT/2, hands the partial sum over (xq: [64] f4), half 1 finishes it.
 // The result (valid in the half-1 wave only) has the bits of the one-wave forward.  Two workgroup barriers: every wave of the workgroup
 // must make the call.
-template <class S>
-__device__ __forceinline__ void mlp_forward_h2(const float* lds, int lane, const float (&x)[S::KS1], int half, f4* xh, f4* xq, f4& q) {
-    constexpr int MT = S::MT, MH = MT / 2, N1 = S::KS1 / 4;
-    static_assert(MT % 2 == 0, "two waves split the hidden tiles evenly");
+// XR: the layer-1 tiles cross in XR rounds through an xh of [2][MT / 2 / XR][64] f4 (hidden 128 with the output layer's operands in registers
+// leaves 10 KB of LDS next to the packs: two rounds of 2 tiles); a3r: the half's MT/2 layer-3 operand tiles when the pack in LDS is the
+// NFWD_NOA3 prefix.
+template <class S, int XR = 1>
+__device__ __forceinline__ void mlp_forward_h2(const float* lds, int lane, const float (&x)[S::KS1], int half, f4* xh, f4* xq, f4& q, const f4* a3r = nullptr) {
+    constexpr int MT = S::MT, MH = MT / 2, N1 = S::KS1 / 4, MX = MH / XR;
+    static_assert(MT % 2 == 0 && MH % XR == 0, "two waves split the hidden tiles evenly");
     const int g = lane >> 4, t0 = half * MH;
     const f4* A1 = reinterpret_cast<const f4*>(lds + S::pA1);
     const f4* A2 = reinterpret_cast<const f4*>(lds + S::pA2);
@@ -356,15 +359,18 @@ __device__ __forceinline__ void mlp_forward_h2(const float* lds, int lane, const
 #pragma unroll
             for (int m = 0; m < MH; ++m) acc[m] = MARL_MFMA(op[m][e], x[4 * s + e], acc[m]);
     }
-#pragma unroll
-    for (int m = 0; m < MH; ++m) {
-        acc[m] = relu4(acc[m]);
-        xh[(half * MH + m) * 64 + lane] = acc[m];
-    }
-    __syncthreads();
     f4 other[MH];
 #pragma unroll
-    for (int m = 0; m < MH; ++m) other[m] = xh[((1 - half) * MH + m) * 64 + lane];
+    for (int m = 0; m < MH; ++m) acc[m] = relu4(acc[m]);
+#pragma unroll
+    for (int xr = 0; xr < XR; ++xr) {
+        if (xr > 0) __syncthreads();  // the previous round has been read
+#pragma unroll
+        for (int m = 0; m < MX; ++m) xh[(half * MX + m) * 64 + lane] = acc[xr * MX + m];
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < MX; ++m) other[xr * MX + m] = xh[((1 - half) * MX + m) * 64 + lane];
+    }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) h1[mt] = (mt / MH == half) ? acc[mt % MH] : other[mt % MH];  // (compile-time register indices, run-time select)
 #pragma unroll
@@ -383,7 +389,7 @@ __device__ __forceinline__ void mlp_forward_h2(const float* lds, int lane, const
     for (int m = 0; m < MH; ++m) h2[m] = relu4(acc[m]);
     f4 op3[MH];
 #pragma unroll
-    for (int m = 0; m < MH; ++m) op3[m] = A3[(t0 + m) * 64 + lane];
+    for (int m = 0; m < MH; ++m) op3[m] = a3r != nullptr ? a3r[m] : A3[(t0 + m) * 64 + lane];
     f4 o3 = *reinterpret_cast<const f4*>(lds + S::pb3 + 4 * g);
     if (half == 0) {
 #pragma unroll

@@ -31,7 +31,8 @@ def dig(*ts):
     return m.hexdigest()
 
 out = {}
-for name, T, N, H in (("lbforaging:Foraging-8x8-2p-3f-v3", 25, 200, 64), ("lbforaging:Foraging-15x15-4p-5f-v3", 25, 72, 128),
+for name, T, N, H in (("lbforaging:Foraging-8x8-2p-3f-v3", 25, 200, 64), ("lbforaging:Foraging-8x8-2p-3f-v3", 25, 136, 128),
+                      ("lbforaging:Foraging-15x15-4p-5f-v3", 25, 72, 128),
                       ("rware:rware-tiny-4ag-v2", 40, 100, 128), ("rware:rware-tiny-2ag-v2", 40, 100, 64)):
     torch.manual_seed(3)
     # IDQN collector: replay contents + episode statistics
@@ -43,12 +44,12 @@ for name, T, N, H in (("lbforaging:Foraging-8x8-2p-3f-v3", 25, 200, 64), ("lbfor
     fr = torch.zeros(q.n_agents, N, device="cuda"); fl = torch.zeros(N, dtype=torch.int32, device="cuda")
     for rnd in range(2):
         h.idqn_collect(cfg, q.spec, q.params, 0.3, rnd, rep, rnd * N, fr, fl, write_replay=True, clear_stale=True)
-    out["idqn:" + name] = dig(rep.obs, rep.act, rep.rew, rep.done, rep.filled, fr, fl)
+    out["idqn:%%d:" %% H + name] = dig(rep.obs, rep.act, rep.rew, rep.done, rep.filled, fr, fl)
     # actor-critic collector: the rollout batch + statistics
     envs = make_env(seed=5, name=name, time_limit=T, parallel_envs=N)
     actors = ActorNetworks(envs.single_observation_space, envs.single_action_space, [H, H])
     t, batch, infos = _collect_trajectories(envs, actors, T, N, q.n_agents, "cuda", False, round_idx=1)
-    out["ac:" + name] = dig(batch.obss, batch.actions, batch.rewards, batch.dones.to(torch.uint8), batch.filled) + ":%%d" %% t
+    out["ac:%%d:" %% H + name] = dig(batch.obss, batch.actions, batch.rewards, batch.dones.to(torch.uint8), batch.filled) + ":%%d" %% t
 print("DIGESTS " + json.dumps(out))
 """
 
@@ -71,8 +72,8 @@ def run_variant(nw, hs=None):
 
 
 def test_one_wave_and_agent_per_wave_collectors_write_the_same_bytes():
-    # 0: the default choice (agent-per-wave at these env counts; two waves per agent for the 2-agent 64-wide LBF case); hs=1: never two per agent
+    # 0: the default choice (agent-per-wave at these env counts; two waves per agent for the 2-agent LBF cases, hidden 64 and 128); hs=1: never two per agent
     one, split, split1 = run_variant(1), run_variant(0), run_variant(0, hs=1)
-    assert one.keys() == split.keys() == split1.keys() and len(one) == 8
+    assert one.keys() == split.keys() == split1.keys() and len(one) == 10
     for k in one:
         assert one[k] == split[k] == split1[k], k
