@@ -6,6 +6,11 @@
 #include "wide_mlp.h"
 #include "wide_critic.h"
 
+#ifndef MARL_TP_NB1_D
+#define MARL_TP_NB1_D 48  // observation rows wider than this walk ONE row block per step in tp_bwd_kernel (register budget; re-measured in round 4 on the
+                         // 71-wide warehouse rows: two blocks spill 42 - 102 registers and the IA2C update goes 18.0 -> 19.0 ms, scripts/gpu_runs/r4AA.sh)
+#endif
+
 namespace marl {
 
 // A centralised critic whose input is too wide for the register-resident kernels (wide_critic.h: layer 1 streamed through LDS, the three
@@ -216,7 +221,7 @@ int64_t backward_ws_bytes(int P, int T, int B) {
     } else if constexpr (IsWide<S>::value) {
         return wide_ws(S::net(), P, T * B, true).total;
     } else if constexpr (use_tp<S>()) {
-        const UpdPlan pl = upd_plan_tp(P, T, B, S::D > 48 ? 1 : 2);
+        const UpdPlan pl = upd_plan_tp(P, T, B, S::D > MARL_TP_NB1_D ? 1 : 2);
         return ws_layout(P, pl.nwg, S::NPARAM + 2, 0, T, B).total;
     } else {
         const UpdPlan pl = upd_plan(P, T, B);
@@ -252,7 +257,7 @@ int launch_backward_rows(int P, const AgentMap& am, const float* params, const m
     ReplaySrc none = {};
     int nwg;
     if constexpr (use_tp<S>()) {
-        constexpr int W = MARL_TP_W, TPW = S::H / (16 * W), NB = S::D > 48 ? 1 : 2, NT = W * TPW;  // wide first layers (centralised critics): one row block per step keeps the kernel out of scratch
+        constexpr int W = MARL_TP_W, TPW = S::H / (16 * W), NB = S::D > MARL_TP_NB1_D ? 1 : 2, NT = W * TPW;  // wide first layers (centralised critics): one row block per step keeps the kernel out of scratch
         const UpdPlan pl = upd_plan_tp(P, T, B, NB);
         nwg = pl.nwg;
         TpMix mix = {};
