@@ -265,3 +265,28 @@ def test_wide_centralised_critics_vs_oracle_port(P, T, N, D, H, A, n):
     v = h.ac_forward_rows(spec, up.target_critic, batch["obss"].to(DEV), D, P * D, rows, value_net=2).cpu()
     want = ap.values(target, batch["obss"], D, H).reshape(rows, P).T
     np.testing.assert_allclose(v.reshape(P, rows).numpy(), want.detach().numpy(), rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("P,T,N,D,H,A,sharing", [(8, 10, 100, 39, 128, 6, (0,) * 8), (4, 9, 150, 71, 64, 5, (0, 0, 1, 1))])
+def test_wide_centralised_critics_with_shared_networks_vs_oracle_port(P, T, N, D, H, A, sharing):
+    """parameter_sharing True / a SePS index list next to critic.centralised (ac/model.py:62-66 builds the shared MultiAgentFCNetwork over the
+    concatenated observations): csrc/wide_critic.h reads network net_of[p] for agent p and the per-agent gradients of a network are added in
+    agent order - against the port run on the EXPANDED per-agent parameters (autograd sums the shared blocks)"""
+    h = hip()
+    nb = max(sharing) + 1
+    actor = dp.init_params(nb, D, H, A, seed=3) + 0.03
+    critic = torch.stack([dp.init_params(1, P * D, H, 1, seed=60 + k)[0] for k in range(nb)]) + 0.02
+    target = torch.stack([dp.init_params(1, P * D, H, 1, seed=80 + k)[0] for k in range(nb)])
+    batch = ap.synthetic_batch(P, T, N, D, A, seed=9)
+    a, c = actor.clone().requires_grad_(True), critic.clone().requires_grad_(True)
+    idx = torch.tensor(sharing)
+    loss, m = ap.a2c_loss(a[idx], c[idx], target[idx], batch, D, H, A, n_steps=5, gamma=0.97, entropy_coef=0.01, value_loss_coef=0.5)
+    loss.backward()
+    spec = h.NetSpec(P, D, H, A, sharing=tuple(sharing))
+    up = h.AcUpdater(spec, torch.cat([actor.reshape(-1), critic.reshape(-1)]).to(DEV), target.to(DEV).contiguous(), gamma=0.97,
+                     n_steps=5, entropy_coef=0.01, value_loss_coef=0.5, centralised_critic=True)
+    got = up.a2c_loss_grad(dev_ac_batch(batch)).cpu().numpy()
+    ref = [m["loss"].item(), m["actor_loss"].item(), m["value_loss"].item(), m["entropy"].item()]
+    np.testing.assert_allclose(got[:4], ref, rtol=5e-5, atol=5e-6)
+    assert_grad_close(up.actor_grad.cpu().numpy(), a.grad.numpy(), 3e-4)
+    assert_grad_close(up.critic_grad.cpu().numpy(), c.grad.numpy(), 3e-4)
