@@ -165,6 +165,15 @@ extern "C" int marlhip_ac_forward_rows(const marlhip_net_shape* s, int32_t value
         MARL_MAC_SHAPES(X)
 #undef X
     }
+    if (value_net == 2 && ac_compiled(s)) {  // wide centralised critics: the fused kernels of wide_critic.h (the values the learner step sees, bit for bit)
+#define X(d, h, a)                                                                                                           \
+    if (s->obs_dim == d && s->hidden == h && s->n_actions == a) {                                                             \
+        WideCritic<h>::D = s->n_agents * d;                                                                                   \
+        return launch_forward_rows<WideCritic<h>>(s->n_agents, agent_map(s), params, &bt, n_rows, out, (hipStream_t)stream);  \
+    }
+        MARL_AC_SHAPES(X)
+#undef X
+    }
     if (value_net == 2 || !ac_compiled(s)) {  // the GEMM path: any input / hidden width
         WideRt<1>::set(value_net == 2 ? s->n_agents * s->obs_dim : s->obs_dim, s->hidden, value_net ? 1 : s->n_actions, s->n_hidden > 0 ? s->n_hidden : 2);
         return launch_forward_rows<WideRt<1>>(s->n_agents, agent_map(s), params, &bt, n_rows, out, (hipStream_t)stream);
