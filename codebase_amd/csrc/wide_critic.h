@@ -197,6 +197,8 @@ constexpr int wc_bwd_lds_floats() { return H * 20 + 2 * WC_ROWS * (H + 4) + WC_R
 
 // Persistent: a workgroup walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... of agent blockIdx.y and keeps dW2 (its wave's 64 x 64
 // quadrant of the H x H matrix; both operands are already in LDS, k-major) and the column sums in registers across them.
+// (Measured and dropped, scripts/gpu_runs/r4AB.sh: W2^T RESIDENT in LDS - one workgroup per unit, 7 barriers per tile instead of 21, the next
+// tile's rows requested into registers under the current tile's products - 774 us against this form's 760 us on the 15x15-8p batch.)
 template <int H>
 __global__ __launch_bounds__(256, 2) void wc_bwd_kernel(const WcBwdArgs g) {  // two workgroups per compute unit: <= 256 registers
     constexpr int LD = 20, LH = H + 4, NU = H / 32, NH = H / 64, C4 = H / 16, NG = 256 / H, RPG = WC_ROWS / NG;
