@@ -369,10 +369,13 @@ struct WcWgradArgs {
 };
 
 // C[m][n] = sum_k dy[k][m] yp[k][n] over rows k of split z; grid (N blocks of 128, P, splits)
+#ifndef MARL_WC_WGRAD_KS
+#define MARL_WC_WGRAD_KS 16  // rows per LDS slice of wc_wgrad_kernel (two barriers per slice; 32 measured: +-0, scripts/gpu_runs/r4AC.sh)
+#endif
 template <int H>
 __global__ __launch_bounds__(256) void wc_wgrad_kernel(const WcWgradArgs g) {
-    constexpr int LDA = H + 16, LDB = 128 + 16, TM = H / 32, NH = H / 64;
-    __shared__ __attribute__((aligned(16))) float As[16 * LDA], Bs[16 * LDB];
+    constexpr int LDA = H + 16, LDB = 128 + 16, TM = H / 32, NH = H / 64, KS = MARL_WC_WGRAD_KS, NS = KS / 16;
+    __shared__ __attribute__((aligned(16))) float As[KS * LDA], Bs[KS * LDB];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 15, q = lane >> 4, wm = wave >> 1, wn = wave & 1;
     const int p = blockIdx.y, z = blockIdx.z, n0 = blockIdx.x * 128;
     const int kbeg = z * g.k_chunk, kend = min(g.rows, kbeg + g.k_chunk);
@@ -385,26 +388,32 @@ __global__ __launch_bounds__(256) void wc_wgrad_kernel(const WcWgradArgs g) {
     for (int t = 0; t < TM; ++t)
 #pragma unroll
         for (int u = 0; u < 4; ++u) acc[t][u] = zero4;
-    f4 ra[NH], rb[2];
+    f4 ra[NS][NH], rb[NS][2];
     auto load = [&](int k0) {
-        const int k = k0 + ka;
-        const bool ok = k < kend;
 #pragma unroll
-        for (int h = 0; h < NH; ++h) ra[h] = ok ? *reinterpret_cast<const f4*>(dy + (int64_t)k * H + 64 * h + c) : zero4;
+        for (int ss = 0; ss < NS; ++ss) {
+            const int k = k0 + 16 * ss + ka;
+            const bool ok = k < kend;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) rb[h] = gemm_load4(yp, k, g.yp_rs, n0 + 64 * h + c, g.N, ok, -1, g.vec);
+            for (int h = 0; h < NH; ++h) ra[ss][h] = ok ? *reinterpret_cast<const f4*>(dy + (int64_t)k * H + 64 * h + c) : zero4;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) rb[ss][h] = gemm_load4(yp, k, g.yp_rs, n0 + 64 * h + c, g.N, ok, -1, g.vec);
+        }
     };
     if (kbeg < kend) load(kbeg);
-    for (int k0 = kbeg; k0 < kend; k0 += 16) {
+    for (int k0 = kbeg; k0 < kend; k0 += KS) {
         __syncthreads();
 #pragma unroll
-        for (int h = 0; h < NH; ++h) *reinterpret_cast<f4*>(As + ka * LDA + 64 * h + c) = ra[h];
+        for (int ss = 0; ss < NS; ++ss) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) *reinterpret_cast<f4*>(Bs + ka * LDB + 64 * h + c) = rb[h];
+            for (int h = 0; h < NH; ++h) *reinterpret_cast<f4*>(As + (16 * ss + ka) * LDA + 64 * h + c) = ra[ss][h];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) *reinterpret_cast<f4*>(Bs + (16 * ss + ka) * LDB + 64 * h + c) = rb[ss][h];
+        }
         __syncthreads();
-        if (k0 + 16 < kend) load(k0 + 16);
+        if (k0 + KS < kend) load(k0 + KS);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+        for (int s = 0; s < KS / 4; ++s) {
             float a[TM], b[4];
 #pragma unroll
             for (int t = 0; t < TM; ++t) a[t] = As[(4 * s + q) * LDA + (H / 2) * wm + 16 * t + i];
