@@ -576,7 +576,7 @@ def secondary_modes(args):
 
     rows = {}
     for name, over, steps, warmup in (("hparams=tuned (lr 3e-3, Polyak 0.1: what the batched cadence learns fastest with), cadence=ratio", dict(hparams="tuned"), 10, 3),
-                                      ("env-only", dict(cadence="env-only"), 20, 3),
+                                      ("env-only", dict(cadence="env-only"), 100, 5),
                                       ("cadence=reference", dict(cadence="reference"), 3, 1),
                                       ("hidden=128 (reference default net), cadence=ratio", dict(hidden=128), 5, 2),
                                       ("split16 OPT-IN learner (fp16 hi/lo products, fp32 accumulate; NOT the default), cadence=ratio", dict(split16=True), 10, 3)):
