@@ -11,6 +11,10 @@
                          // 71-wide warehouse rows: two blocks spill 42 - 102 registers and the IA2C update goes 18.0 -> 19.0 ms, scripts/gpu_runs/r4AA.sh)
 #endif
 
+#ifndef MARL_TP_NB1S_D
+#define MARL_TP_NB1S_D 80  // the same threshold for the form that reads both hidden layers back (no layer-1 registers)
+#endif
+
 namespace marl {
 
 // A centralised critic whose input is too wide for the register-resident kernels (wide_critic.h: layer 1 streamed through LDS, the three
@@ -56,7 +60,7 @@ constexpr bool mlp_stored_shape() { return !IsGru<S>::value && !IsWide<S>::value
 template <class S>
 inline int64_t mlp_stored_floats(int P, int T, int B) {
     if constexpr (!mlp_stored_shape<S>()) return 0;
-    else if constexpr (use_tp<S>()) return tp_h2_floats(P, T, B, S::H);
+    else if constexpr (use_tp<S>()) return 2 * tp_h2_floats(P, T, B, S::H);  // h2 | h1, both in tp_bwd_kernel's layout
     else return lds_h_floats(P, T, B, S::H);
 }
 
@@ -109,9 +113,10 @@ __global__ __launch_bounds__(256) void mlp_rows_fwd_kernel(const float* __restri
                 }
             }
         } else if constexpr (H2 == 1) {
-            f4 h2[2][S::MT];
-            mlp_forward_p2<S, true>(lds, lane, x, q, h2);
+            f4 h2[2][S::MT], h1[2][S::MT];
+            mlp_forward_p2<S, true, true>(lds, lane, x, q, h2, h1);
             const int bpt = B >> 4;  // row blocks per time step
+            const size_t h1_off = (size_t)gridDim.y * T * tp_h2_blocks(B) * S::MT * 64;  // f4 units: the h1 record sits behind the h2 record
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int bk = 2 * pr + h;
@@ -119,7 +124,10 @@ __global__ __launch_bounds__(256) void mlp_rows_fwd_kernel(const float* __restri
                     const int t = bk / bpt, blk = bk - t * bpt;
                     f4* dst = h2_out + ((((size_t)p * T + t) * tp_h2_blocks(B) + blk) * S::MT) * 64 + lane;
 #pragma unroll
-                    for (int mt = 0; mt < S::MT; ++mt) dst[mt * 64] = h2[h][mt];
+                    for (int mt = 0; mt < S::MT; ++mt) {
+                        dst[mt * 64] = h2[h][mt];
+                        dst[h1_off + mt * 64] = h1[h][mt];
+                    }
                 }
             }
         } else {
@@ -131,6 +139,23 @@ __global__ __launch_bounds__(256) void mlp_rows_fwd_kernel(const float* __restri
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     if (4 * g + r < S::A) out[((size_t)p * n_rows + row[h]) * S::A + 4 * g + r] = q[h][r];
+            }
+        }
+    }
+    if constexpr (H2 == 1) {
+        // tp_bwd_kernel walks row blocks in PAIRS: with an odd number of blocks per time step the pair's second slot holds no rows - its
+        // gradients are masked, but 0 x (whatever the workspace held) must stay 0: the slot is zero-filled (both records)
+        const int bpt = B >> 4;
+        if ((bpt & 1) && tp_h2_blocks(B) > bpt) {
+            const size_t h1_off = (size_t)gridDim.y * T * tp_h2_blocks(B) * S::MT * 64;
+            const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
+            for (int t = blockIdx.x * 4 + wave; t < T; t += gridDim.x * 4) {
+                f4* dst = h2_out + ((((size_t)p * T + t) * tp_h2_blocks(B) + bpt) * S::MT) * 64 + lane;
+#pragma unroll
+                for (int mt = 0; mt < S::MT; ++mt) {
+                    dst[mt * 64] = zero4;
+                    dst[h1_off + mt * 64] = zero4;
+                }
             }
         }
     }
@@ -221,8 +246,8 @@ int64_t backward_ws_bytes(int P, int T, int B) {
     } else if constexpr (IsWide<S>::value) {
         return wide_ws(S::net(), P, T * B, true).total;
     } else if constexpr (use_tp<S>()) {
-        const UpdPlan pl = upd_plan_tp(P, T, B, S::D > MARL_TP_NB1_D ? 1 : 2);
-        return ws_layout(P, pl.nwg, S::NPARAM + 2, 0, T, B).total;
+        const UpdPlan a = upd_plan_tp(P, T, B, S::D > MARL_TP_NB1_D ? 1 : 2), b = upd_plan_tp(P, T, B, S::D > MARL_TP_NB1S_D ? 1 : 2);  // either form of the pass
+        return ws_layout(P, a.nwg > b.nwg ? a.nwg : b.nwg, S::NPARAM + 2, 0, T, B).total;
     } else {
         const UpdPlan pl = upd_plan(P, T, B);
         return ws_layout(P, pl.nwg, UpdLds<S>::REC, 2 * S::NFWD + S::NBWD, T, B).total;
@@ -257,28 +282,33 @@ int launch_backward_rows(int P, const AgentMap& am, const float* params, const m
     ReplaySrc none = {};
     int nwg;
     if constexpr (use_tp<S>()) {
-        constexpr int W = MARL_TP_W, TPW = S::H / (16 * W), NB = S::D > MARL_TP_NB1_D ? 1 : 2, NT = W * TPW;  // wide first layers (centralised critics): one row block per step keeps the kernel out of scratch
-        const UpdPlan pl = upd_plan_tp(P, T, B, NB);
-        nwg = pl.nwg;
+        // row blocks per step: the recomputing form keeps the layer-1 weights and both copies of the rows in registers and walks ONE block
+        // per step on rows wider than 48 (two spill); with both hidden layers read back (STORED1) those registers are free and two blocks
+        // fit up to 80-wide rows (the 71-wide warehouse rows: 503 registers, no scratch)
+        constexpr int W = MARL_TP_W, TPW = S::H / (16 * W), NBR = S::D > MARL_TP_NB1_D ? 1 : 2, NBS = S::D > MARL_TP_NB1S_D ? 1 : 2;
         TpMix mix = {};
         mix.lrow = lrow;
         mix.dout = dout;
-        const size_t ldsB = (size_t)tp_bwd_lds_floats<S, W, TPW, NB, false>() * sizeof(float);
-        const size_t ldsS = (size_t)tp_bwd_lds_floats<S, W, TPW, NB, true>() * sizeof(float);
-        static_assert(tp_bwd_lds_floats<S, W, TPW, NB, true>() * 4 <= 160 * 1024, "tp_bwd_kernel<STORED>: LDS");
+        const size_t ldsB = (size_t)tp_bwd_lds_floats<S, W, TPW, NBR, false>() * sizeof(float);
+        const size_t ldsS = (size_t)tp_bwd_lds_floats<S, W, TPW, NBS, true>() * sizeof(float);
+        static_assert(tp_bwd_lds_floats<S, W, TPW, NBS, true>() * 4 <= 160 * 1024, "tp_bwd_kernel<STORED>: LDS");
         static LdsAttr attr_set;
         if (attr_set.need()) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tp_bwd_kernel<S, W, TPW, false, NB, true>),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tp_bwd_kernel<S, W, TPW, false, NBR, true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsB);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tp_bwd_kernel<S, W, TPW, false, NB, true, true>),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tp_bwd_kernel<S, W, TPW, false, NBS, true, true, true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsS);
             attr_set.done();
         }
-        if (rec != nullptr) {  // the forward-rows pass of this step left the second hidden layer: no layer-2 recompute (dqn_update_tp.h)
-            hipLaunchKernelGGL((tp_bwd_kernel<S, W, TPW, false, NB, true, true>), dim3(pl.nwg, P), dim3(64 * W), ldsS, st, params, am, *bt, none, mix,
-                               pl.n_chunks, (float*)ws, reinterpret_cast<const f4*>(rec));
+        if (rec != nullptr) {  // both hidden layers come back from the forward-rows pass of this step: h2 | h1 (mlp_rows_fwd_kernel<S, 1>)
+            const UpdPlan pl = upd_plan_tp(P, T, B, NBS);
+            nwg = pl.nwg;
+            hipLaunchKernelGGL((tp_bwd_kernel<S, W, TPW, false, NBS, true, true, true>), dim3(pl.nwg, P), dim3(64 * W), ldsS, st, params, am, *bt, none, mix,
+                               pl.n_chunks, (float*)ws, reinterpret_cast<const f4*>(rec), reinterpret_cast<const f4*>(rec) + tp_h2_floats(P, T, B, S::H) / 4);
         } else {
-            hipLaunchKernelGGL((tp_bwd_kernel<S, W, TPW, false, NB, true>), dim3(pl.nwg, P), dim3(64 * W), ldsB, st, params, am, *bt, none, mix,
+            const UpdPlan pl = upd_plan_tp(P, T, B, NBR);
+            nwg = pl.nwg;
+            hipLaunchKernelGGL((tp_bwd_kernel<S, W, TPW, false, NBR, true>), dim3(pl.nwg, P), dim3(64 * W), ldsB, st, params, am, *bt, none, mix,
                                pl.n_chunks, (float*)ws);
         }
         MARL_CHECK_LAUNCH("tp_bwd_kernel<FULL>");

@@ -77,7 +77,8 @@ struct TpSrc {  // everything load_rows needs, per block
     size_t obs_rs;  // row stride of obs_p (D in the dqn/train.py Batch)
 };
 
-template <class S, bool REPLAY, bool BWD, bool FULL = false>
+// NOX: the rows' MFMA-A-side copy x is not needed (pass B with BOTH hidden layers read back: no layer-1 recompute)
+template <class S, bool REPLAY, bool BWD, bool FULL = false, bool NOX = false>
 __device__ __forceinline__ void tp_load_rows(const TpSrc<S, REPLAY>& s, const TpMix& mix, int t, int b0, int g, int j, int ej,
                                              const int (&eg)[4], TpRows<S, REPLAY>& R) {
     constexpr int D = S::D, NT1 = S::DP / 16;
@@ -106,10 +107,12 @@ __device__ __forceinline__ void tp_load_rows(const TpSrc<S, REPLAY>& s, const Tp
         R.fl = s.rs.rb.filled[(size_t)ej * T + tt] ? 1.f : 0.f;
     } else {
         const float* xrow = s.obs_p + ((size_t)t * B + bj) * s.obs_rs;
+        if (!NOX) {
 #pragma unroll
-        for (int ks = 0; ks < S::KS1; ++ks) {
-            const int d = 4 * ks + g;
-            R.x[ks] = xrow[d < D ? d : D - 1];
+            for (int ks = 0; ks < S::KS1; ++ks) {
+                const int d = 4 * ks + g;
+                R.x[ks] = xrow[d < D ? d : D - 1];
+            }
         }
         if (BWD) {
 #pragma unroll
@@ -144,12 +147,14 @@ __device__ __forceinline__ void tp_load_rows(const TpSrc<S, REPLAY>& s, const Tp
     }
 }
 
-template <class S, bool REPLAY, bool BWD>
+template <class S, bool REPLAY, bool BWD, bool NOX = false>
 __device__ __forceinline__ void tp_mask_rows(TpRows<S, REPLAY>& R, int b0, int B, int g, int j) {
     constexpr int D = S::D, NT1 = S::DP / 16;
     const bool rowok = (b0 + j) < B;
+    if (!NOX) {
 #pragma unroll
-    for (int ks = 0; ks < S::KS1; ++ks) R.x[ks] = (4 * ks + g < D && rowok) ? R.x[ks] : 0.f;
+        for (int ks = 0; ks < S::KS1; ++ks) R.x[ks] = (4 * ks + g < D && rowok) ? R.x[ks] : 0.f;
+    }
     if (BWD) {
 #pragma unroll
         for (int nt = 0; nt < NT1; ++nt)
@@ -425,9 +430,13 @@ static __global__ __launch_bounds__(256) void tp_mix_kernel(TpMix mix, int P, in
 // STORED: layer 2 is not recomputed - the wave reads ITS h2 tiles of the row block back from pass F's h2_out (one step ahead, next
 // to the rows), so the C-layout dump of h1 and the barrier behind it go away too: layer 1 -> [dH2, dW3 from the stored h2] ->
 // barrier -> [dH1, dW2, dW1] -> barrier.  Same arithmetic per element as the recomputing form (pass F ran the identical MFMA chain).
-template <class S, int W, int TPW, bool REPLAY, int NB, bool FULL = false, bool STORED = false>
+// STORED1 (with STORED; round 4, the actor-critic step): layer 1 is not recomputed either - the wave reads ITS h1 tiles of the row block from
+// the forward-rows pass (h1_in, the layout of h2_in): no layer-1 weights, no A-side copy of the rows in registers, 2 KS1 fewer MFMAs per block.
+template <class S, int W, int TPW, bool REPLAY, int NB, bool FULL = false, bool STORED = false, bool STORED1 = false>
 __global__ __launch_bounds__(64 * W, 1) void tp_bwd_kernel(const float* __restrict__ params, AgentMap am, marlhip_batch bt, ReplaySrc rs, TpMix mix,
-                                                           int n_chunks, float* __restrict__ partials, const f4* __restrict__ h2_in = nullptr) {
+                                                           int n_chunks, float* __restrict__ partials, const f4* __restrict__ h2_in = nullptr,
+                                                           const f4* __restrict__ h1_in = nullptr) {
+    static_assert(!STORED1 || STORED, "the stored first layer comes with the stored second");
     constexpr int NT = W * TPW, A = S::A, D = S::D, H = S::H, NT1 = S::DP / 16;
     constexpr int PRIV = 256 * NB * (1 + 3 * TPW);  // per wave: PQ[NB] | PH2[NB][TPW] | P2[NB][TPW] | P1[NB][TPW] tiles of 256 floats
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -492,30 +501,41 @@ __global__ __launch_bounds__(64 * W, 1) void tp_bwd_kernel(const float* __restri
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) tp_episode_ids<REPLAY>(rs, (set * NB + nb) * 16, B, g, j, ej[nb], eg[nb]);
         TpRows<S, REPLAY> cur[NB];
-        f4 h2c[STORED ? NB : 1][TPW];
+        f4 h2c[STORED ? NB : 1][TPW], h1c[STORED1 ? NB : 1][TPW];
         auto h2_at = [&](int t, int nb, int u) -> f4 {
             return h2_in[((((size_t)p * T + t) * tp_h2_blocks(B) + (set * NB + nb)) * NT + wave * TPW + u) * 64 + lane];
         };
+        auto h1_at = [&](int t, int nb, int u) -> f4 {
+            return h1_in[((((size_t)p * T + t) * tp_h2_blocks(B) + (set * NB + nb)) * NT + wave * TPW + u) * 64 + lane];
+        };
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
-            tp_load_rows<S, REPLAY, true, FULL>(src, mix, t1 - 1, (set * NB + nb) * 16, g, j, ej[nb], eg[nb], cur[nb]);
+            tp_load_rows<S, REPLAY, true, FULL, STORED1>(src, mix, t1 - 1, (set * NB + nb) * 16, g, j, ej[nb], eg[nb], cur[nb]);
             if constexpr (STORED) {
 #pragma unroll
                 for (int u = 0; u < TPW; ++u) h2c[nb][u] = h2_at(t1 - 1, nb, u);
             }
+            if constexpr (STORED1) {
+#pragma unroll
+                for (int u = 0; u < TPW; ++u) h1c[nb][u] = h1_at(t1 - 1, nb, u);
+            }
         }
         for (int t = t1 - 1; t >= t0; --t) {
             TpRows<S, REPLAY> nxt[NB];
-            f4 h2n[STORED ? NB : 1][TPW];
+            f4 h2n[STORED ? NB : 1][TPW], h1n[STORED1 ? NB : 1][TPW];
             f4 h1[NB][TPW];
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
-                tp_load_rows<S, REPLAY, true, FULL>(src, mix, t > t0 ? t - 1 : t0, (set * NB + nb) * 16, g, j, ej[nb], eg[nb], nxt[nb]);
+                tp_load_rows<S, REPLAY, true, FULL, STORED1>(src, mix, t > t0 ? t - 1 : t0, (set * NB + nb) * 16, g, j, ej[nb], eg[nb], nxt[nb]);
                 if constexpr (STORED) {
 #pragma unroll
                     for (int u = 0; u < TPW; ++u) h2n[nb][u] = h2_at(t > t0 ? t - 1 : t0, nb, u);
                 }
-                tp_mask_rows<S, REPLAY, true>(cur[nb], (set * NB + nb) * 16, B, g, j);
+                if constexpr (STORED1) {
+#pragma unroll
+                    for (int u = 0; u < TPW; ++u) h1n[nb][u] = h1_at(t > t0 ? t - 1 : t0, nb, u);
+                }
+                tp_mask_rows<S, REPLAY, true, STORED1>(cur[nb], (set * NB + nb) * 16, B, g, j);
             }
             float* HcT = (STORED && (t & 1)) ? set1 : HcT0;
             f4* G2 = reinterpret_cast<f4*>(HcT + NB * H * 16);
@@ -524,10 +544,15 @@ __global__ __launch_bounds__(64 * W, 1) void tp_bwd_kernel(const float* __restri
             for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
                 for (int u = 0; u < TPW; ++u) {
-                    f4 acc = cw[u].b1s;
+                    f4 acc;
+                    if constexpr (STORED1) {
+                        acc = h1c[nb][u];  // relu'd by the forward-rows pass (a padding row block holds the finite values of zero rows)
+                    } else {
+                        acc = cw[u].b1s;
 #pragma unroll
-                    for (int ks = 0; ks < S::KS1; ++ks) acc = MARL_MFMA(cw[u].a1[ks], cur[nb].x[ks], acc);
-                    acc = relu4(acc);
+                        for (int ks = 0; ks < S::KS1; ++ks) acc = MARL_MFMA(cw[u].a1[ks], cur[nb].x[ks], acc);
+                        acc = relu4(acc);
+                    }
                     h1[nb][u] = acc;
                     const int tau = wave * TPW + u;
                     if constexpr (!STORED) Hc[(nb * NT + tau) * 64 + lane] = acc;
@@ -734,6 +759,10 @@ __global__ __launch_bounds__(64 * W, 1) void tp_bwd_kernel(const float* __restri
                 if constexpr (STORED) {
 #pragma unroll
                     for (int u = 0; u < TPW; ++u) h2c[nb][u] = h2n[nb][u];
+                }
+                if constexpr (STORED1) {
+#pragma unroll
+                    for (int u = 0; u < TPW; ++u) h1c[nb][u] = h1n[nb][u];
                 }
             }
         }
