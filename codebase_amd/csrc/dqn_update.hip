@@ -66,7 +66,7 @@ extern "C" int64_t marlhip_dqn_workspace_bytes(const marlhip_net_shape* s, int32
 #define X(d, h, a) if (s->obs_dim == d && s->hidden == h && s->n_actions == a) tp = use_tp<MlpShape<d, h, a>>();
     MARL_NET_SHAPES(X)
 #undef X
-    const UpdPlan pl = tp ? upd_plan_tp(s->n_agents, max_len, batch, s->obs_dim > 48 ? 1 : 2) : upd_plan(s->n_agents, max_len, batch);
+    const UpdPlan pl = tp ? upd_plan_tp(s->n_agents, max_len, batch, s->obs_dim > MARL_TP_NB1S_D ? 1 : 2) : upd_plan(s->n_agents, max_len, batch);
     // partial records + 16 B alignment slack + weight packs (<= 4 x nparams-padded floats per agent; see launch_lossgrad)
     int64_t pack = -1;
 #define X(d, h, a) if (s->obs_dim == d && s->hidden == h && s->n_actions == a) pack = 2 * MlpShape<d, h, a>::NFWD + MlpShape<d, h, a>::NBWD;
@@ -79,7 +79,7 @@ extern "C" int64_t marlhip_dqn_workspace_bytes(const marlhip_net_shape* s, int32
     const int64_t base = ws_layout(s->n_agents, pl.nwg, np + 2, (int)pack, max_len, batch).total;
     if (!tp)  // the two-pass form's stored hidden layers (qsel pass -> bwd pass), whatever mode the caller goes on to use
         return ((base + 15) & ~(int64_t)15) + lds_h_floats(s->n_agents, max_len, batch, s->hidden) * (int64_t)sizeof(float) + 128;
-    return ((base + 15) & ~(int64_t)15) + tp_h2_floats(s->n_agents, max_len, batch, s->hidden) * (int64_t)sizeof(float);  // pass F -> pass B activations
+    return ((base + 15) & ~(int64_t)15) + 2 * tp_h2_floats(s->n_agents, max_len, batch, s->hidden) * (int64_t)sizeof(float);  // pass F -> pass B activations (h2 | h1)
 }
 
 static int lossgrad_dispatch(const marlhip_net_shape* s, const float* params, const float* target_params, const marlhip_batch* bt,

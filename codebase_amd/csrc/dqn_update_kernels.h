@@ -1189,6 +1189,9 @@ struct WsLayout {
 
 // tensor-parallel learner (hidden 128, wide rows): pass F leaves the critic's second hidden layer of every transition row for pass B
 // (dqn_update_tp.h, h2_out): P * T * [row blocks of 16, counted in pairs] * 16 * H floats behind everything else
+#ifndef MARL_TP_NB1S_D
+#define MARL_TP_NB1S_D 80  // rows wider than this walk one row block per step in the pass that reads both hidden layers back
+#endif
 inline int64_t tp_h2_floats(int P, int T, int B, int H) { return (int64_t)P * T * (((B + 31) / 32) * 2) * 16 * H; }  // == tp_h2_blocks(B) row blocks
 
 inline WsLayout ws_layout(int P, int nwg, int rec, int pack, int T, int B) {
@@ -1259,13 +1262,15 @@ template <class S, bool REPLAY>
 int launch_lossgrad_tp(const marlhip_net_shape* s, const float* params, const float* tparams, const marlhip_batch* bt,
                        const ReplaySrc& src, float gamma, int double_q, int mode, void* ws, int64_t ws_bytes, float* grad,
                        float* loss, hipStream_t st, const QmixCtx* qx, const RetStats* rst) {
-    constexpr int W = MARL_TP_W, TPW = S::H / (16 * W), NB = S::D > 48 ? 1 : 2, NBF = MARL_TP_NBF, NT = W * TPW, REC = S::NPARAM + 2;  // wide first layers: one row block per step keeps pass B out of scratch
+    // pass B reads BOTH hidden layers back from pass F (round 4: STORED1 - no layer-1 weights / row copies in registers), so it walks two row
+    // blocks per step up to 80-wide rows (the recomputing form: 48)
+    constexpr int W = MARL_TP_W, TPW = S::H / (16 * W), NB = S::D > MARL_TP_NB1S_D ? 1 : 2, NBF = MARL_TP_NBF, NT = W * TPW, REC = S::NPARAM + 2;
     const int P = s->n_agents, T = bt->max_len, B = bt->batch;
     const AgentMap am = agent_map(s);
     static_assert(NB <= 2 && NBF <= 2, "tp_h2_blocks counts row blocks in pairs");
     const UpdPlan pl = upd_plan_tp(P, T, B, NB), plF = upd_plan_tp(P, T, B, NBF);
     const WsLayout wl = ws_layout(P, pl.nwg, REC, 0, T, B);
-    const int64_t h2_off = (wl.total + 15) & ~(int64_t)15, need = h2_off + tp_h2_floats(P, T, B, S::H) * (int64_t)sizeof(float);
+    const int64_t h2_off = (wl.total + 15) & ~(int64_t)15, need = h2_off + 2 * tp_h2_floats(P, T, B, S::H) * (int64_t)sizeof(float);  // h2 | h1 records
     MARL_REQUIRE(ws_bytes >= need, "dqn_loss_grad: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)need);
     f4* h2buf = reinterpret_cast<f4*>(static_cast<char*>(ws) + h2_off);
     float* mixf = reinterpret_cast<float*>(static_cast<char*>(ws) + wl.mix_off);
@@ -1280,7 +1285,7 @@ int launch_lossgrad_tp(const marlhip_net_shape* s, const float* params, const fl
     if (attr_set.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tp_fwd_kernel<S, W, TPW, REPLAY, NBF>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsF);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tp_bwd_kernel<S, W, TPW, REPLAY, NB, false, true>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tp_bwd_kernel<S, W, TPW, REPLAY, NB, false, true, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsB);
         attr_set.done();
     }
@@ -1307,8 +1312,8 @@ int launch_lossgrad_tp(const marlhip_net_shape* s, const float* params, const fl
         hipLaunchKernelGGL(tp_mix_kernel, dim3((unsigned)((tb + 255) / 256 > 1024 ? 1024 : (tb + 255) / 256)), dim3(256), 0, st, mix, P,
                            T, B, gamma, mode == 1 ? 1 : 0, ret);
     }
-    hipLaunchKernelGGL((tp_bwd_kernel<S, W, TPW, REPLAY, NB, false, true>), grid, block, ldsB, st, params, am, *bt, src, mix, pl.n_chunks,
-                       (float*)ws, (const f4*)h2buf);
+    hipLaunchKernelGGL((tp_bwd_kernel<S, W, TPW, REPLAY, NB, false, true, true>), grid, block, ldsB, st, params, am, *bt, src, mix, pl.n_chunks,
+                       (float*)ws, (const f4*)h2buf, (const f4*)h2buf + tp_h2_floats(P, T, B, S::H) / 4);
     timing_end(TIMER_LOSSGRAD, st);
     MARL_CHECK_LAUNCH("tp_lossgrad");
     const int n = am.nblk * S::NPARAM;

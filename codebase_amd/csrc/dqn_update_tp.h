@@ -87,10 +87,12 @@ __device__ __forceinline__ void tp_load_rows(const TpSrc<S, REPLAY>& s, const Tp
     const int tt = t < T ? t : T - 1;
     if (REPLAY) {
         const float* xrow = s.rs.rb.obs + (((size_t)ej * s.P + p) * (T + 1) + t) * D;
+        if (!NOX) {
 #pragma unroll
-        for (int ks = 0; ks < S::KS1; ++ks) {
-            const int d = 4 * ks + g;
-            R.x[ks] = xrow[d < D ? d : D - 1];
+            for (int ks = 0; ks < S::KS1; ++ks) {
+                const int d = 4 * ks + g;
+                R.x[ks] = xrow[d < D ? d : D - 1];
+            }
         }
         if (BWD) {
 #pragma unroll
@@ -288,8 +290,11 @@ __global__ __launch_bounds__(64 * W, 1) void tp_fwd_kernel(const float* __restri
                 for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
                     for (int u = 0; u < TPW; ++u) {
-                        Hc[(nb * NT + wave * TPW + u) * 64 + lane] = relu4(a1c[nb][u]);
+                        const f4 h1c = relu4(a1c[nb][u]);
+                        Hc[(nb * NT + wave * TPW + u) * 64 + lane] = h1c;
                         Ht[(nb * NT + wave * TPW + u) * 64 + lane] = relu4(a1t[nb][u]);
+                        if (h2_out != nullptr && t < t1)  // the critic's first hidden layer too (behind the h2 record, same layout): pass B recomputes nothing
+                            h2_out[(size_t)P * T * tp_h2_blocks(B) * NT * 64 + ((((size_t)p * T + t) * tp_h2_blocks(B) + (set * NB + nb)) * NT + wave * TPW + u) * 64 + lane] = h1c;
                     }
             }
             __syncthreads();
