@@ -39,3 +39,20 @@ def test_headline_defaults_are_the_reference_config(monkeypatch):
     monkeypatch.setattr(sys, "argv", ["bench.py"])
     a = bench.parse()
     assert a.hparams == "reference" and a.hidden == 64 and a.envs == 4096 and a.cadence == "ratio" and a.gpus == 1
+
+
+def test_needed_flops_leave_out_exactly_the_first_layer_input_gradient():
+    """`roofline.frac_needed` = `frac` without the products `backward = 2 x forward` counts and nothing runs (the gradient w.r.t. a
+    network's input rows): 2 D H per row and backward pass, for the actor and the (centralised) critic"""
+    import bench
+
+    P, D, A, H, T, N = 8, 39, 6, 128, 25, 4096
+    flops, parts = bench.dqn_update_flops("idqn", False, 2, 15, 6, 64, 25, 4096)
+    assert parts["first_layer_input_gradient (counted, never run)"] == 2.0 * 15 * 64 * 2 * 4096 * 25
+    assert 0.04 < parts["first_layer_input_gradient (counted, never run)"] / flops < 0.05  # 15-wide rows: a small share
+    full = bench.ac_update_flops(False, P, D, A, H, T, N, True)
+    dx = bench.ac_unneeded_flops(P, D, H, T, N, True)
+    assert dx == (2.0 * D * H + 2.0 * P * D * H) * P * N * T
+    assert 0.14 < dx / full < 0.17  # 312-wide centralised critics: the share that makes the two fractions differ visibly
+    # PPO: per launch group (1 prepare + E epochs), only the E epoch groups run a backward pass
+    assert bench.ac_unneeded_flops(P, D, H, T, N, True, epochs=4) == dx * 4 / 5
