@@ -211,6 +211,7 @@ PROTOTYPES = {
     "marlhip_p2p_create": (c_int32, [c_int32, c_int32, c_int64, POINTER(c_void_p), c_void_p]),
     "marlhip_p2p_connect": (c_int32, [c_void_p, c_void_p]),
     "marlhip_p2p_allreduce": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "marlhip_p2p_allreduce_wave64": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
     "marlhip_p2p_status": (c_int32, [c_void_p]),
     "marlhip_p2p_destroy": (c_int32, [c_void_p]),
     "marlhip_dqn_loss_grad_split16": (c_int32, [POINTER(NetShape), c_void_p, c_void_p, POINTER(BatchStruct), c_float, c_int32, c_void_p, c_int64,

@@ -217,10 +217,14 @@ def main(envs, eval_env, logger, time_limit, **cfg):
         m = model.update_async(batch, step, grad_sync=sync, world=world)
         infos.append(model._metrics(m) if log_now else m)
         if log_now:
+            if sync is not None:
+                sync.check()  # every rank (`step` is the job's): a timed-out in-library exchange stops the run here, on all of them
             if rank == 0:
                 _log_progress(infos, step, updates, logger)
             last_eval = step
         if g("save_interval") and (step - last_save) >= g("save_interval"):
+            if sync is not None:
+                sync.check()  # never save replicas that have diverged
             if rank == 0:
                 Path("checkpoints").mkdir(exist_ok=True)
                 torch.save(model.state_dict(), f"checkpoints/model_s{step}.pt")
@@ -229,5 +233,7 @@ def main(envs, eval_env, logger, time_limit, **cfg):
             raise NotImplementedError("video recording is outside the HIP hot path")
         updates += 1
         step += t * parallel_envs if dist is None else t_job
+    if sync is not None:
+        sync.close()  # final check on every rank, then the exchange is freed behind a job-wide barrier
     envs.close()
     return model

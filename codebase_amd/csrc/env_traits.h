@@ -58,8 +58,7 @@ struct RwEnvT {
                                                 bool& done) {
         DrawStream req;
         req.init(q.seed, env, episode, STREAM_REQUEST);
-        rw_step(q, s, c.grid, act, raw, done, req);
-        if (s.inactive == 0) c.rq.build(q, s);  // the queue only changes on a delivery (which zeroes the inactivity counter)
+        if (rw_step(q, s, c.grid, act, raw, done, req)) c.rq.build(q, s);  // the queue only changes on a delivery
     }
     static __device__ __forceinline__ int elapsed(const State& s) { return s.steps; }
     template <int KS1, bool OID>

@@ -75,10 +75,34 @@ static __global__ __launch_bounds__(256) void p2p_allreduce_kernel(float* __rest
         if (i0 + k < n) grad[i0 + k] = acc[k];
 }
 
-long long p2p_timeout_ticks() {  // wall_clock64 counts at 100 MHz; default 20 s, MARLHIP_P2P_TIMEOUT_MS overrides
+// The exchange in the launch geometry of the learner's fused reduce (dqn_reduce_p2p_kernel): one 256-thread workgroup per 64 values, its
+// wave 0 runs p2p_wave_sum, the other waves leave at once.  marlhip_p2p_allreduce_wave64: what the set-up's self-test runs at the real
+// gradient size, so that the flags-per-64-floats protocol and the residency pattern of the fused launch (count / 64 workgroups, each
+// spinning on its peer's same-index workgroup) have crossed the links before a training run depends on them.
+static __global__ __launch_bounds__(256) void p2p_allreduce_wave64_kernel(float* __restrict__ grad, int64_t n, P2pPeers peers, int rank, int world,
+                                                                          int64_t slot_floats, int max_chunks, uint32_t epoch, long long timeout_ticks) {
+    if (threadIdx.x >= 64) return;
+    const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const bool in = i < n;
+    bool late;
+    const float v = in ? grad[i] : 0.f;
+    const float s = p2p_wave_sum(peers, rank, world, slot_floats, max_chunks, epoch, (int)blockIdx.x, i, in, v, timeout_ticks, late);
+    if (in) grad[i] = s;
+}
+
+// wall_clock64 counts at 100 MHz.  The wait is bounded so that a dead peer cannot hang the GPU; the bound is DIAGNOSTIC (a collective
+// library would block for ever): 5 minutes by default, MARLHIP_P2P_TIMEOUT_MS overrides; a malformed or non-positive value keeps the default.
+long long p2p_timeout_ticks() {
     static const long long t = [] {
+        double ms = 300000.0;
         const char* v = getenv("MARLHIP_P2P_TIMEOUT_MS");
-        return (long long)((v ? atof(v) : 20000.0) * 1e5);
+        if (v != nullptr && *v) {
+            char* end = nullptr;
+            const double x = strtod(v, &end);
+            if (end != v && x > 0.0 && x < 8.64e7) ms = x;
+            else fprintf(stderr, "[marlhip] MARLHIP_P2P_TIMEOUT_MS=\"%s\" is not a positive number of milliseconds; keeping %.0f ms\n", v, ms);
+        }
+        return (long long)(ms * 1e5);
     }();
     return t;
 }
@@ -113,7 +137,16 @@ extern "C" int marlhip_p2p_create(int32_t rank, int32_t world, int64_t max_float
         delete st;
         return -2;
     }
-    (void)hipMemset(st->local, 0, bytes);
+    // flags, error word and slots must read zero before any peer can see them: the memset runs on the null stream, the exchanges on the
+    // caller's (possibly non-blocking) stream, so wait for it here - before the handle leaves this process
+    e = hipMemset(st->local, 0, bytes);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) {
+        set_error("p2p_create: zeroing the exchange buffer: %s", hipGetErrorString(e));
+        (void)hipFree(st->local);
+        delete st;
+        return -2;
+    }
     e = hipIpcGetMemHandle(reinterpret_cast<hipIpcMemHandle_t*>(handle_out), st->local);
     if (e != hipSuccess) {
         set_error("p2p_create: hipIpcGetMemHandle: %s (HSA_ENABLE_IPC_MODE_LEGACY=0 must be exported)", hipGetErrorString(e));
@@ -161,6 +194,20 @@ extern "C" int marlhip_p2p_allreduce(void* ctx, float* grad, int64_t count, void
     hipLaunchKernelGGL(p2p_allreduce_kernel, dim3(chunks), dim3(256), 0, (hipStream_t)stream, grad, count, st->peers, st->rank, st->world,
                        st->max_floats, st->max_chunks, st->epoch, timeout_ticks);
     MARL_CHECK_LAUNCH("p2p_allreduce_kernel");
+    return 0;
+}
+
+// The same exchange, launched as the learner's fused reduce launches it (one workgroup per 64 values; see the kernel).  Shares the epoch
+// counter with marlhip_p2p_allreduce: every rank must issue the same sequence of calls of either kind.
+extern "C" int marlhip_p2p_allreduce_wave64(void* ctx, float* grad, int64_t count, void* stream) {
+    P2pState* st = static_cast<P2pState*>(ctx);
+    MARL_REQUIRE(st && grad, "p2p_allreduce_wave64: NULL pointer");
+    MARL_REQUIRE(st->connected, "p2p_allreduce_wave64: marlhip_p2p_connect has not run");
+    MARL_REQUIRE(count > 0 && count <= st->max_floats, "p2p_allreduce_wave64: %lld floats, the buffers hold %lld", (long long)count, (long long)st->max_floats);
+    st->epoch += 1;
+    hipLaunchKernelGGL(p2p_allreduce_wave64_kernel, dim3((unsigned)((count + 63) / 64)), dim3(256), 0, (hipStream_t)stream, grad, count, st->peers,
+                       st->rank, st->world, st->max_floats, st->max_chunks, st->epoch, p2p_timeout_ticks());
+    MARL_CHECK_LAUNCH("p2p_allreduce_wave64_kernel");
     return 0;
 }
 

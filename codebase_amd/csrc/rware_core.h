@@ -238,8 +238,10 @@ MARL_HD uint32_t rw_resolve(uint32_t nxt, const int* tcell) {
 // front in one batch of independent loads (upstream's TOGGLE too reads the shelf layer as the PREVIOUS step left it: its grid is
 // only recalculated at the end of step()); targets, turns and toggles are selects; the only per-lane branches left are the grid
 // writes of moving carriers and the delivery (rare).
+// Returns whether a shelf was delivered in this step - the one event that changes the request queue (callers that cache something
+// derived from the queue, env_traits.h's request bit set, rebuild it on exactly that).
 template <int P>
-MARL_HD void rw_step(const RwParams& q, RwState<P>& s, const RwGrid& grid, const int* act_in, double* rew, bool& done, DrawStream& req) {
+MARL_HD bool rw_step(const RwParams& q, RwState<P>& s, const RwGrid& grid, const int* act_in, double* rew, bool& done, DrawStream& req) {
     int act[P], tx[P], ty[P], tcell[P], own[P], g_t[P], g_own[P];
 #pragma unroll
     for (int p = 0; p < P; ++p) {
@@ -341,6 +343,7 @@ MARL_HD void rw_step(const RwParams& q, RwState<P>& s, const RwGrid& grid, const
     s.inactive = delivered ? 0 : s.inactive + 1;
     s.steps += 1;
     done = (q.max_inactivity_steps > 0 && s.inactive >= q.max_inactivity_steps) || (q.max_steps > 0 && s.steps >= q.max_steps);
+    return delivered;
 }
 
 // arr[p] for a RUN-TIME agent index (the agent-per-wave collectors): a select chain over compile-time indices - a dynamically

@@ -359,6 +359,8 @@ def main(env, eval_env, logger, time_limit, **cfg):
             else:
                 metrics = {}
         if g("eval_interval") and (step - last_eval) >= g("eval_interval"):
+            if vectorised and getattr(trainer, "_sync", None) is not None:
+                trainer._sync.check()  # every rank (`step` is the job's): a timed-out in-library exchange stops the run here, on all of them
             if vectorised:
                 infos = trainer.evaluate(g("eval_episodes"), g("eps_evaluation"), round_idx=trainer.rounds)
             else:
@@ -372,9 +374,13 @@ def main(env, eval_env, logger, time_limit, **cfg):
         if g("video_interval"):
             raise NotImplementedError("video recording is outside the HIP hot path")
         if g("save_interval") and (step - last_save) >= g("save_interval"):
+            if vectorised and getattr(trainer, "_sync", None) is not None:
+                trainer._sync.check()  # never save replicas that have diverged
             if rank == 0:
                 Path("checkpoints").mkdir(exist_ok=True)
                 torch.save(model.state_dict(), f"checkpoints/model_s{step}.pt")
             last_save = step
+    if vectorised and getattr(trainer, "_sync", None) is not None:
+        trainer._sync.close()  # final check on every rank, then the exchange is freed behind a job-wide barrier
     env.close()
     return model

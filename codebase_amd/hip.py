@@ -802,10 +802,14 @@ class FusedQmixLearner:
             filled=outs[4].data_ptr(), idx=outs[5].data_ptr(), batch=self.B, double_q=updater.double_q, mode=2, materialise_batch=0,
             gamma=float(updater.gamma), max_norm=float(updater.grad_clip), lr=float(updater.lr), beta1=float(updater.betas[0]),
             beta2=float(updater.betas[1]), eps=float(updater.eps), target_update_interval_or_tau=float(target_update_interval_or_tau))
-        self.c = QmixLearner(base=base, mixer=updater._mx(self.B), mixer_rw=updater.mixer.data_ptr(), target_mixer_rw=updater.target_mixer.data_ptr(),
+        mx = updater._mx(self.B)
+        # the mixer struct is copied BY VALUE below; with standardise_returns its ret_stats field points at the ctypes struct _mx() built
+        # for this call (updater._st_c, replaced by any later _mx()) and at the statistics tensors behind it: hold both for the C loop
+        st_c = getattr(updater, "_st_c", None) if updater.ret_stats is not None else None
+        self.c = QmixLearner(base=base, mixer=mx, mixer_rw=updater.mixer.data_ptr(), target_mixer_rw=updater.target_mixer.data_ptr(),
                              mixer_exp_avg=updater.mixer_exp_avg.data_ptr(), mixer_exp_avg_sq=updater.mixer_exp_avg_sq.data_ptr(),
                              mixer_scratch=updater.mixer_scratch.data_ptr(), optimizer=int(updater.optimizer))
-        self._keep = (outs, ws)
+        self._keep = (outs, ws, mx, st_c, updater.ret_stats, getattr(updater, "_stats", None))
 
     def run(self, n_updates, length, seed, counter0, updates, last_target_update, grad_sync=None, world=1):
         step = ctypes.c_int64(self.up.step)

@@ -136,23 +136,44 @@ class P2PExchange:
                 lib.marlhip_p2p_destroy(state)
             return None
         ex = P2PExchange(lib, state, packed, rank, world, max_floats)
-        n = min(int(max_floats), 5000)
+        # Self-test against torch.distributed's all-reduce, at the REAL gradient size and through BOTH launch geometries: the stand-alone
+        # kernel (1024 floats per workgroup) and the one the learner's fused reduce uses (marlhip_p2p_allreduce_wave64: a workgroup and a
+        # flag per 64 floats, i.e. max_floats / 64 workgroups each spinning on its peer's same-index workgroup).  Several exchanges in a
+        # row, so both slots / flag parities and the "peer still reads my previous slot" window are exercised on the links themselves.
+        n = int(max_floats)
         g = torch.Generator(device="cpu").manual_seed(1234 + rank)
-        x = torch.randn(n, generator=g).cuda()
-        ref = x.clone()
-        dist.all_reduce(ref)
-        good = False
+        good = True
         try:
-            ex(x)
-            torch.cuda.synchronize()
-            good = ex.status() == 0 and bool(torch.allclose(x, ref, rtol=1e-5, atol=1e-5))
+            for k in range(6):
+                x = torch.randn(n, generator=g).cuda()
+                ref = x.clone()
+                dist.all_reduce(ref)
+                fn = lib.marlhip_p2p_allreduce_wave64 if k & 1 else lib.marlhip_p2p_allreduce
+                rc = fn(ex.state, x.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
+                torch.cuda.synchronize()
+                # (rank-ordered float sums: identical on every rank, and equal to the collective's up to its own summation order)
+                good = good and rc == 0 and ex.status() == 0 and bool(torch.allclose(x, ref, rtol=1e-5, atol=1e-5))
         except Exception as e:  # noqa: BLE001 - "not available", never a broken run
-            why = str(e)
+            why, good = str(e), False
         if everyone(good):
             return ex
         log.warning("marlhip p2p exchange: self-test failed on some rank (%s); keeping torch.distributed's all-reduce", why or "sum mismatch / peer timeout")
         ex.close()
         return None
+
+
+def _shares_a_device(dist):
+    """True when two ranks of the job run on the same physical GPU (uuid / PCI bus id gathered over the ranks).  The in-library exchange
+    spin-waits for the peer's same-index workgroup: with two ranks time-sharing one device a spinning launch can keep the peer's off
+    the chip until the timeout, so such jobs keep the collective unless MARLHIP_P2P_SHARED_DEVICE=1 (the one-GPU test boxes)."""
+    try:
+        pr = torch.cuda.get_device_properties(torch.cuda.current_device())
+        me = str(getattr(pr, "uuid", None) or getattr(pr, "pci_bus_id", None) or torch.cuda.current_device())
+    except Exception:  # noqa: BLE001
+        me = str(torch.cuda.current_device())
+    ids = [None] * dist.get_world_size()
+    dist.all_gather_object(ids, me)
+    return len(set(ids)) < len(ids)
 
 
 class GradSync:
@@ -166,7 +187,13 @@ class GradSync:
         self.scale = 1.0 / self.world
         self.p2p = None
         if dist is not None and max_floats > 0 and torch.cuda.is_available() and os.environ.get("MARLHIP_P2P", "1") != "0":
-            self.p2p = P2PExchange.try_create(dist, max_floats)
+            if _shares_a_device(dist) and os.environ.get("MARLHIP_P2P_SHARED_DEVICE", "0") != "1":
+                import logging
+
+                logging.getLogger(__name__).warning("marlhip p2p exchange: two ranks share a GPU; keeping torch.distributed's all-reduce "
+                                                    "(MARLHIP_P2P_SHARED_DEVICE=1 overrides)")
+            else:
+                self.p2p = P2PExchange.try_create(dist, max_floats)
         # what the library's n-updates loop takes instead of a Python callback (hip.FusedLearner.run)
         self.c_fn = self.p2p.c_fn if self.p2p is not None else None
         self.c_ctx = self.p2p.c_ctx if self.p2p is not None else None
@@ -179,6 +206,28 @@ class GradSync:
         return grad
 
     def check(self):
-        """raises when an in-library exchange ran into its peer timeout (call at log / evaluation points: it synchronises)"""
-        if self.p2p is not None and self.p2p.status() != 0:
+        """raises ON EVERY RANK when an in-library exchange ran into its peer timeout on any of them (one small collective + a 4-byte
+        device read: for log / evaluation / save points and the end of a run, not for the update loop)"""
+        if self.p2p is None:
+            return
+        bad = self.p2p.status() != 0
+        if self.dist is not None and self.world > 1:
+            votes = [None] * self.world
+            self.dist.all_gather_object(votes, bool(bad))
+            bad = any(votes)
+        if bad:
             raise RuntimeError("marlhip p2p exchange: a peer did not publish its gradient in time (MARLHIP_P2P_TIMEOUT_MS); replicas have diverged")
+
+    def close(self):
+        """end of a run: verify, then free the exchange behind a job-wide barrier (no peer may still be reading this rank's buffer)"""
+        if self.p2p is None:
+            return
+        try:
+            self.check()
+        finally:
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+            if self.dist is not None and self.world > 1:
+                self.dist.barrier()
+            self.p2p.close()
+            self.p2p = self.c_fn = self.c_ctx = None

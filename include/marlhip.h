@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MARLHIP_VERSION 210
+#define MARLHIP_VERSION 211
 
 int marlhip_version(void);
 const char* marlhip_last_error(void);
@@ -594,7 +594,8 @@ int marlhip_idqn_update_n_dist(const marlhip_idqn_learner* L, int32_t n_updates,
  * identical sums on every rank.  Protocol: every rank calls _create (allocates ITS buffer: the one piece of device memory this
  * library owns, freed by _destroy), the hipIpcMemHandles (marlhip_p2p_handle_bytes() bytes each) are exchanged by the host side
  * (torch.distributed in codebase_amd/parallel.py), every rank calls _connect with all of them, then any number of _allreduce calls -
- * the same sequence of counts on every rank.  A peer that does not arrive within MARLHIP_P2P_TIMEOUT_MS (default 20000) leaves the
+ * the same sequence of counts on every rank.  A peer that does not arrive within MARLHIP_P2P_TIMEOUT_MS (default 300000: diagnostic
+ * only, a collective library would block; a malformed or non-positive value keeps the default) leaves the
  * local gradient untouched and raises the state's error word, which marlhip_p2p_status reads back (it synchronises: not for the
  * hot loop); once raised, later exchanges publish but no longer wait (one timeout per dead peer, not one per update).  _destroy frees the
  * buffer: the caller synchronises its stream first (no exchange may be in flight), and the peers must have finished reading - destroy
@@ -603,6 +604,10 @@ int marlhip_p2p_handle_bytes(void);
 int marlhip_p2p_create(int32_t rank, int32_t world, int64_t max_floats, void** state_out, void* handle_out);
 int marlhip_p2p_connect(void* state, const void* handles);
 int marlhip_p2p_allreduce(void* state, float* grad, int64_t count, void* stream);
+/* C-ABI 211: the same exchange in the launch geometry marlhip_idqn_update_n_dist's fused reduce uses (one workgroup per 64 values, a
+ * flag per 64 floats) - for the set-up's self-test at the real gradient size (codebase_amd/parallel.py); shares the epoch counter
+ * with marlhip_p2p_allreduce, so every rank issues the same sequence of calls of either kind. */
+int marlhip_p2p_allreduce_wave64(void* state, float* grad, int64_t count, void* stream);
 int marlhip_p2p_status(void* state);
 int marlhip_p2p_destroy(void* state);
 

@@ -171,11 +171,23 @@ class Learner:
         per = len(self.tensors) // self.P
         return torch.stack([torch.cat([t.reshape(-1) for t in self.tensors[p * per:(p + 1) * per]]) for p in range(self.P)])
 
-    def update(self, batch):
-        loss = compute_loss(self.flat(), self.target, batch, self.gamma, self.double_q, self.D, self.H, self.A, self.mode,
-                            self.sharing, self.ret_ms)
+    def update(self, batch, chunks=1):
+        """chunks > 1 (the at-size tests: bounded memory in float64): the loss is a filled-weighted mean over batch columns, so the
+        gradient is the sum over column chunks of (chunk loss) x (chunk's filled / total filled) - the same number, accumulated in .grad"""
         self.opt.zero_grad()
-        loss.backward()
+        if chunks > 1:
+            assert self.ret_ms is None, "column chunks and standardise_returns (batch-wide statistics) do not combine"
+            total, loss = batch["filled"].sum(), 0.0
+            for cols in torch.arange(batch["filled"].shape[1]).chunk(chunks):
+                sub = column_chunk(batch, cols)
+                part = compute_loss(self.flat(), self.target, sub, self.gamma, self.double_q, self.D, self.H, self.A, self.mode,
+                                    self.sharing, None) * (sub["filled"].sum() / total)
+                part.backward()
+                loss = loss + part.detach()
+        else:
+            loss = compute_loss(self.flat(), self.target, batch, self.gamma, self.double_q, self.D, self.H, self.A, self.mode,
+                                self.sharing, self.ret_ms)
+            loss.backward()
         gnorm = None
         per = len(self.tensors) // self.P  # the gradient as _compute_loss leaves it (before clipping), [P][n]: for tests that compare it
         self.last_grad = torch.stack([torch.cat([t.grad.reshape(-1) for t in self.tensors[p * per:(p + 1) * per]]) for p in range(self.P)]).clone()
@@ -189,6 +201,11 @@ class Learner:
         elif self.tui < 1.0:
             self.target = (1 - self.tui) * self.target + self.tui * self.flat().detach()
         return {"loss": loss.item(), "grad_norm": None if gnorm is None else float(gnorm)}
+
+
+def column_chunk(batch, cols):
+    """the Batch restricted to the batch columns `cols` (obss / actions / rewards [P, T(+1), B, ...], dones / filled [T(+1), B])"""
+    return {k: (v[:, :, cols] if k in ("obss", "actions", "rewards", "action_mask") else v[:, cols]) for k, v in batch.items()}
 
 
 class ReplayBuffer:

@@ -113,11 +113,24 @@ class Learner:
     def mflat(self):
         return torch.cat([t.reshape(-1) for t in self.mtensors])
 
-    def update(self, batch):
-        loss = compute_loss(self.flat(), self.target, self.mflat(), self.tmixer, batch, self.gamma, self.double_q,
-                            self.D, self.H, self.A, self.E, self.HE)
+    def update(self, batch, chunks=1):
+        """chunks > 1: the gradient accumulated over column chunks of the batch (dqn_port.Learner.update: bounded memory at size)"""
         self.opt.zero_grad()
-        loss.backward()
+        if chunks > 1:
+            total, loss = batch["filled"].sum(), 0.0
+            for cols in torch.arange(batch["filled"].shape[1]).chunk(chunks):
+                sub = dp.column_chunk(batch, cols)
+                part = compute_loss(self.flat(), self.target, self.mflat(), self.tmixer, sub, self.gamma, self.double_q,
+                                    self.D, self.H, self.A, self.E, self.HE) * (sub["filled"].sum() / total)
+                part.backward()
+                loss = loss + part.detach()
+        else:
+            loss = compute_loss(self.flat(), self.target, self.mflat(), self.tmixer, batch, self.gamma, self.double_q,
+                                self.D, self.H, self.A, self.E, self.HE)
+            loss.backward()
+        per = len(self.tensors) // self.P  # the gradients as _compute_loss leaves them (before clipping): for tests that compare them
+        self.last_grad = torch.stack([torch.cat([t.grad.reshape(-1) for t in self.tensors[p * per:(p + 1) * per]]) for p in range(self.P)]).clone()
+        self.last_mixer_grad = torch.cat([t.grad.reshape(-1) for t in self.mtensors]).clone()
         if self.grad_clip:
             torch.nn.utils.clip_grad_norm_(self.tensors, self.grad_clip)
         self.opt.step()

@@ -1,0 +1,213 @@
+"""BASELINE.json configs 3, 4 and 5 (and the wide centralised critics) against the ORACLE at the per-GPU size `bench.py` runs them at
+(VERDICT r4 item 1).  Round 4 rewrote exactly these paths - the stored-hidden-layer passes (`tp_bwd_kernel<STORED1>`, two row blocks per
+step), the split-form mixer at 8 agents, the branch-free warehouse step, buffer-load packs, `wide_critic.h` - and their largest oracle
+comparison was 1/100 of the row count the bench matrix reports.  The right-hand side is the float64 evaluation of the ports (pinned to
+the reference's goldens by the CPU suite), accumulated over column chunks of the batch (oracle/dqn_port.Learner.update(chunks=...): the
+loss is a filled-weighted mean, so the gradient is the sum over chunks - bounded memory at 200k - 1M rows per agent).
+
+Bounds: those of tests/test_gpu_bench_path_vs_oracle.run_case (its docstring has the ReLU-kink / Double-Q-tie argument): loss 1e-5 (3e-5
+through the 8-agent mixer), every gradient entry within 3e-4 of the largest, every parameter within atol + 2 lr n min(1, floor max|g| / |g|)
+after n updates and 95 % of them inside plain atol.  Env transitions replayed through the oracle are bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from tests.test_gpu_bench_path_vs_oracle import _perturbed, host_batch, philox_indices, run_case
+
+DEV = "cuda"
+
+
+def _f64(batch):
+    return {k: (v.double() if v.is_floating_point() else v) for k, v in batch.items()}
+
+
+def assert_entries_at_size(got, ref, lr, n_updates, gmin, what, atol=3e-6, noise_floor=2e-5, bulk=0.05):
+    """per entry: atol where the gradient was above the f32 noise of the row sum in every update, up to a whole +-lr per update where the
+    gradient itself was at the floor (Adam's first steps are lr g / (|g| + eps)); the bulk inside plain atol"""
+    diff = np.abs(np.asarray(got, np.float64) - np.asarray(ref, np.float64))
+    allowed = atol + 2.0 * lr * n_updates * np.minimum(1.0, noise_floor / np.maximum(gmin, 1e-30))
+    worst = int(np.argmax(diff - allowed))
+    assert (diff <= allowed).all(), (what, float(diff.flat[worst]), float(allowed.flat[worst]), float(gmin.flat[worst]))
+    assert (diff > atol).mean() <= bulk, (what, int((diff > atol).sum()), diff.size)
+
+
+def assert_grad_at_size(got, ref, what, rel=3e-4):
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    assert np.abs(got - ref).max() <= rel * np.abs(ref).max(), (what, float(np.abs(got - ref).max()), float(np.abs(ref).max()))
+
+
+# ---- config 3: VDN on Foraging-15x15-4p-5f, 8192 envs, 128-128 ------------------------------------------------------------------------
+def test_config3_vdn_15x15_4p5f_H128_B8192_vs_oracle_port():
+    """marlhip_idqn_update_n, mode 1, at the bench row's shape: 4 agents x 27-wide rows, hidden 128 (tp_fwd<STORED1> -> vdn mixer -> tp_bwd
+    reading both hidden layers back), B = 8192 = 204,800 transition rows per agent, idqn.yaml's lr 3e-4 and a hard target copy inside
+    the call (interval 2: updates 2 of the 1 + 2)"""
+    P, D, H, A, T = 4, 27, 128, 6, 25
+    run_case(1, P, D, H, A, T, B=8192, cap=2 * 8192 + 32, lr=3e-4, tui=2, n_calls=2, per_call=(1, 2),
+             params0=_perturbed(P, D, H, A, 31), target0=_perturbed(P, D, H, A, 33), atol=3e-6, noise_floor=2e-5, chunks=4)
+
+
+# ---- config 5: QMIX on Foraging-15x15-8p-5f, 8192 envs per GPU, 128-128, fp32 mixer -------------------------------------------------
+def test_config5_qmix_15x15_8p5f_H128_B8192_through_the_trainer_vs_oracle_port():
+    """bench.py --algo qmix --env-name lbforaging:Foraging-15x15-8p-5f-v3 --envs 8192 --hidden 128 as it runs: VectorisedIDQN.round =
+    the 8-agent fused collector + marlhip_qmix_update_n (in-library index draw, tp_fwd / split-form mixer (qmix_l1 x2, qmix_mix x2,
+    qmix_wgrad, reduce) / tp_bwd<STORED1>, clip over the critic, one Adam over critic + mixer, hard copies of target and target mixer
+    inside the call) against oracle/qmix_port.Learner in float64 on the episodes the collector stored."""
+    from codebase_amd import hip as h
+    from codebase_amd.dqn.model import QMixNetwork
+    from codebase_amd.dqn.train import VectorisedIDQN
+    from codebase_amd.parallel import rank_sample_seed
+    from codebase_amd.utils.envs import _space_pair
+    from oracle import qmix_port as qp
+
+    N, T, H, B, U, seed, lr = 8192, 25, 128, 8192, 3, 9, 3e-4
+    cfg = h.env_config("lbforaging:Foraging-15x15-8p-5f-v3", N, T, seed=seed, cooperative=True)
+    P, (D, A) = cfg.n_agents, h.env_dims(cfg)
+    assert (P, D, A) == (8, 39, 6)
+    torch.manual_seed(seed)
+    obs_space, act_space = _space_pair(cfg)
+    hyper = dict(optimizer="Adam", lr=lr, gamma=0.99, grad_clip=1.0, double_q=True, standardise_returns=False, target_update_interval_or_tau=2)
+    model = QMixNetwork(obs_space, act_space, hyper, [H, H], False, False, True, dict(embed_dim=64, hypernet_layers=2, hypernet_embed=32), "cuda")
+    # thread-independent instances (run_case's docstring): He-scaled Gaussians instead of the QR-based orthogonal init
+    model.params.copy_(_perturbed(P, D, H, A, 41))
+    model.target_params.copy_(_perturbed(P, D, H, A, 43))
+    p0, t0 = model.params.cpu().clone(), model.target_params.cpu().clone()
+    m0, tm0 = model.mixer_params.cpu().clone(), model.target_mixer_params.cpu().clone()
+    trainer = VectorisedIDQN(cfg, model, N, T, B, U, seed=seed)
+    trainer.round(0.7, train=True)
+    torch.cuda.synchronize()
+    assert type(trainer._fused).__name__ == "FusedQmixLearner"
+    rb = trainer.replay
+    host = dict(obs=rb.obs.cpu(), act=rb.act.cpu(), rew=rb.rew.cpu(), done=rb.done.cpu(), filled=rb.filled.cpu())
+    assert int(host["filled"].sum()) == int(trainer.env_steps.item()) > 20 * N
+    port = qp.Learner(p0.double(), m0.double(), D, H, A, lr=lr, gamma=0.99, grad_clip=1.0, double_q=True, target_update_interval_or_tau=2)
+    port.target, port.tmixer = t0.double(), tm0.double()
+    gmin, gmin_m = np.full(tuple(p0.shape), np.inf), np.full(tuple(m0.shape), np.inf)
+    for u in range(U):
+        idx = philox_indices(rank_sample_seed(seed, 0), u, B, N)
+        m = port.update(_f64(host_batch(host, idx)), chunks=16)
+        ga, gm = np.abs(port.last_grad.numpy()), np.abs(port.last_mixer_grad.numpy())
+        gmin, gmin_m = np.minimum(gmin, ga / ga.max()), np.minimum(gmin_m, gm / gm.max())
+    got = trainer.last_loss.cpu().numpy()
+    assert abs(got[0] - m["loss"]) <= 3e-5 * abs(m["loss"]), (got, m)
+    assert got[1] == float(host["filled"][torch.as_tensor(idx)].sum())
+    assert (model.updates, model.last_target_update) == (port.updates, port.last_target_update) == (3, 2)
+    assert_grad_at_size(model.updater.grad.cpu().numpy(), port.last_grad.numpy(), "critic gradient of the last update")
+    assert_grad_at_size(model.updater.mixer_grad.cpu().numpy(), port.last_mixer_grad.numpy(), "mixer gradient of the last update")
+    for got_t, ref_t, gm, what in ((model.params, port.flat().detach(), gmin, "params"), (model.target_params, port.target, gmin, "target"),
+                                   (model.mixer_params, port.mflat().detach(), gmin_m, "mixer"),
+                                   (model.target_mixer_params, port.tmixer, gmin_m, "target mixer")):
+        assert_entries_at_size(got_t.cpu().numpy(), ref_t.numpy(), lr, U, gm, what)
+
+
+# ---- config 4: IA2C on rware-tiny-4ag, 2048 envs per GPU x 500 steps, 128-128 ------------------------------------------------------------
+def _collect_ac(h, name, N, T, H, seed, rnd, central=False, scale=1.0):
+    from codebase_amd.ac.model import A2CNetwork
+    from codebase_amd.utils.envs import _space_pair
+
+    cfg = h.env_config(name, N, T, seed=seed)
+    P, (D, A) = cfg.n_agents, h.env_dims(cfg)
+    torch.manual_seed(seed)
+    obs_space, act_space = _space_pair(cfg)
+    hyper = dict(optimizer="Adam", lr=3e-4, gamma=0.99, grad_clip=False, n_steps=5, entropy_coef=0.001, value_loss_coef=0.5,
+                 standardise_returns=False, target_update_interval_or_tau=200)  # ia2c.yaml / maa2c.yaml
+    net = dict(layers=[H, H], parameter_sharing=False, use_orthogonal_init=True, use_rnn=False)
+    model = A2CNetwork(obs_space, act_space, hyper, net, dict(net, centralised=central), "cuda")
+    # thread-independent instances: the actors He-scaled (scaled up so that the policy is not uniform), critics / targets likewise
+    model.actor_params.copy_(_perturbed(P, D, H, A, seed + 1) * scale)
+    dc = P * D if central else D
+    model.critic_params.copy_(_perturbed(P, dc, H, 1, seed + 2))
+    model.target_critic_params.copy_(_perturbed(P, dc, H, 1, seed + 3))
+    dev = model.device
+    b = dict(obss=torch.empty(T + 1, N, P * D, device=dev), actions=torch.empty(T, N, P, dtype=torch.int64, device=dev),
+             rewards=torch.empty(T, N, P, device=dev), dones=torch.empty(T + 1, N, dtype=torch.uint8, device=dev),
+             filled=torch.empty(T, N, device=dev))
+    fin_ret = torch.zeros(P, N, device=dev)
+    fin_len = torch.zeros(N, dtype=torch.int32, device=dev)
+    t_max = torch.zeros(1, dtype=torch.int32, device=dev)
+    h.ac_collect(cfg, model.spec, model.actor_params, rnd, T, False, b["obss"], b["actions"], b["rewards"], b["dones"], b["filled"], fin_ret,
+                 fin_len, t_max)
+    torch.cuda.synchronize()
+    return cfg, model, b, fin_len, (P, D, A)
+
+
+def _a2c_step_vs_port(model, b, P, D, H, A, central, env_chunks, loss_rtol=5e-5):
+    """one A2CNetwork.update on the device against oracle/ac_update_port in float64: loss parts, gradients, parameters after the step"""
+    from codebase_amd.ac.train import Batch
+    from oracle import ac_update_port as ap
+
+    a0, c0, t0 = (x.cpu().clone().double() for x in (model.actor_params, model.critic_params, model.target_critic_params))
+    batch = Batch(b["obss"], b["actions"], b["rewards"], b["dones"].float(), b["filled"], None)
+    up = model.updater
+    got = up.a2c_loss_grad(batch).cpu().numpy().astype(np.float64)
+    ga, gc = up.actor_grad.cpu().numpy().copy(), up.critic_grad.cpu().numpy().copy()
+    up.apply()
+    torch.cuda.synchronize()
+    host = {k: v.cpu() for k, v in b.items()}
+    host["dones"] = host["dones"].bool()
+    lr = ap.Learner(a0, c0, D, H, A, lr=3e-4, gamma=0.99, n_steps=5, entropy_coef=0.001, value_loss_coef=0.5, grad_clip=False,
+                    target_update_interval_or_tau=200)
+    lr.target = t0
+    total = host["filled"].double().sum()
+    acc = dict(loss=0.0, actor_loss=0.0, value_loss=0.0, entropy=0.0)
+    lr.opt.zero_grad()
+    for cols in torch.arange(host["filled"].shape[1]).chunk(env_chunks):  # the losses are filled-weighted means over (t, env): additive over env chunks
+        sub = {k: v[:, cols] for k, v in host.items()}
+        sub = {k: (v.double() if v.is_floating_point() else v) for k, v in sub.items()}
+        w = sub["filled"].sum() / total
+        loss, m = ap.a2c_loss(lr.actor(), lr.critic(), lr.target, sub, D, H, A, n_steps=5, gamma=0.99, entropy_coef=0.001, value_loss_coef=0.5)
+        (loss * w).backward()
+        for k in acc:
+            acc[k] += float(m[k]) * float(w)
+    ref = np.array([acc["loss"], acc["actor_loss"], acc["value_loss"], acc["entropy"]])
+    np.testing.assert_allclose(got[:4], ref, rtol=loss_rtol, atol=5e-6)
+    assert got[4] == float(total)
+    per_a, per_c = len(lr.at) // P, len(lr.ct) // P
+    ra = torch.stack([torch.cat([t.grad.reshape(-1) for t in lr.at[p * per_a:(p + 1) * per_a]]) for p in range(P)]).numpy()
+    rc = torch.stack([torch.cat([t.grad.reshape(-1) for t in lr.ct[p * per_c:(p + 1) * per_c]]) for p in range(P)]).numpy()
+    assert_grad_at_size(ga, ra, "actor gradient")
+    assert_grad_at_size(gc, rc, "critic gradient")
+    lr.opt.step()
+    for got_t, ref_t, g, what in ((model.actor_params, lr.actor().detach(), ra, "actor"), (model.critic_params, lr.critic().detach(), rc, "critic")):
+        gm = np.abs(g) / np.abs(g).max()
+        assert_entries_at_size(got_t.cpu().numpy(), ref_t.numpy(), 3e-4, 1, gm, what)
+
+
+def test_config4_ia2c_rware_tiny4ag_2048_envs_x_500_steps_H128_vs_oracle():
+    """bench.py --algo ia2c --env-name rware:rware-tiny-4ag-v2 --envs 2048 --time-limit 500 --hidden 128: the agent-per-wave warehouse
+    collector (branch-free rw_step, buffer-load packs, LDS observation tiles) for 1.02 M env-steps, 64 of the 2048 envs' stored
+    trajectories replayed through oracle/rware.py bit for bit; then one A2C step on that rollout (mlp_rows_fwd<S, 1> leaving h1 | h2
+    = 4.2 GB of records, tp_bwd_kernel<FULL, STORED1> with two row blocks per step) against the port in float64."""
+    from codebase_amd import hip as h
+    from oracle.lbf import MarlbaseEnv
+    from oracle.philox import DrawStream
+
+    name, N, T, H, seed, rnd = "rware:rware-tiny-4ag-v2", 2048, 500, 128, 21, 3
+    cfg, model, b, fin_len, (P, D, A) = _collect_ac(h, name, N, T, H, seed, rnd, scale=3.0)
+    assert (P, D, A) == (4, 71, 5)
+    obs, act, rew, done, fill = (b[k].cpu().numpy() for k in ("obss", "actions", "rewards", "dones", "filled"))
+    assert fill.sum() == N * T and (fin_len.cpu().numpy() == T).all()  # the warehouse never ends before its 500-step limit
+    assert len(np.unique(act)) == A and (rew > 0).sum() >= 0
+    for n in range(7, N, 32):  # 64 envs spread over the workgroups
+        e = MarlbaseEnv(name, T)
+        o, _ = e.reset(DrawStream(seed, n, 2 * rnd))  # the collector's first episode of call `rnd` (oracle/ac_port.collect_trajectories)
+        np.testing.assert_array_equal(np.concatenate(o), obs[0, n])
+        for t in range(T):
+            o, r, d, tr, _ = e.step([int(a) for a in act[t, n]])
+            np.testing.assert_array_equal(np.concatenate(o), obs[t + 1, n], err_msg=f"env {n} step {t}")
+            np.testing.assert_array_equal(np.array(r, dtype=np.float32), rew[t, n])
+            assert bool(done[t + 1, n]) == bool(d or tr)
+    _a2c_step_vs_port(model, b, P, D, H, A, central=False, env_chunks=32)
+
+
+def test_maa2c_15x15_8p5f_4096_envs_H128_wide_critics_vs_oracle():
+    """bench.py --algo maa2c --env-name lbforaging:Foraging-15x15-8p-5f-v3 --envs 4096 --hidden 128: the 8-agent collector and the
+    312-input centralised critics on csrc/wide_critic.h (wc_fwd / wc_bwd / wc_wgrad) at 102,400 rows x 8 critics"""
+    from codebase_amd import hip as h
+
+    name, N, T, H, seed, rnd = "lbforaging:Foraging-15x15-8p-5f-v3", 4096, 25, 128, 23, 1
+    cfg, model, b, fin_len, (P, D, A) = _collect_ac(h, name, N, T, H, seed, rnd, central=True, scale=2.0)
+    assert (P, D, A) == (8, 39, 6)
+    assert float(b["filled"].sum().item()) == float(fin_len.sum().item()) > 20 * N
+    _a2c_step_vs_port(model, b, P, D, H, A, central=True, env_chunks=8)

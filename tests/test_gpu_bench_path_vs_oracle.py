@@ -62,7 +62,7 @@ def to_device(h, rb, host):
 
 
 def run_case(mode, P, D, H, A, T, B, cap, lr, tui, n_calls, per_call, params0, target0, seed=1234, grad_clip=1.0, atol=3e-6, split16=False,
-             noise_floor=None):
+             noise_floor=None, chunks=1):
     """noise_floor (the B = 4096 cases).  The loss is only piecewise smooth: a ReLU pre-activation within f32 rounding of zero, or two
     online Q-values of a row within rounding of each other (the Double-Q bootstrap action), fall on different sides in two correct
     implementations, and the gradient then differs by that one row's term.  With 200k rows x 128 units per update this is not a
@@ -101,7 +101,7 @@ def run_case(mode, P, D, H, A, T, B, cap, lr, tui, n_calls, per_call, params0, t
         for u in range(n):
             idx = philox_indices(seed, counter + u, B, cap)
             hb = host_batch(host, idx)
-            m = port.update({k: (v.double() if f64 and v.is_floating_point() else v) for k, v in hb.items()})
+            m = port.update({k: (v.double() if f64 and v.is_floating_point() else v) for k, v in hb.items()}, chunks=chunks)
             if noise_floor is not None:
                 ga = np.abs(port.last_grad.numpy())
                 gmin = np.minimum(gmin, ga / ga.max())  # relative to the update's largest entry

@@ -16,7 +16,8 @@ def test_two_ranks_stay_bit_identical_idqn_qmix_a2c():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     digests = {}
     for p2p, port in (("1", "29533"), ("0", "29535")):
-        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MARLHIP_P2P=p2p, MARLHIP_P2P_TIMEOUT_MS="20000")
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MARLHIP_P2P=p2p, MARLHIP_P2P_TIMEOUT_MS="20000",
+                   MARLHIP_P2P_SHARED_DEVICE="1")  # two ranks on this box's one GPU: the exchange is refused there unless asked for
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                "--master-port", port, os.path.join(root, "tests", "two_rank_worker.py")]
         out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
@@ -42,5 +43,5 @@ def test_drop_in_entry_point_shards_under_torchrun(tmp_path, algo, extra):
     GPU over gloo.  tests/two_rank_entry.py wraps run.main and checks on every rank: replicas bit-identical at the end, the shards
     different, rank 0 alone wrote results.csv with whole-job step counts."""
     out = _torchrun([os.path.join(os.path.dirname(os.path.abspath(__file__)), "two_rank_entry.py"), str(tmp_path), f"+algorithm={algo}"] + extra,
-                    dict(MARLHIP_DIST_BACKEND="gloo", MARLHIP_ONE_DEVICE="1"), 29541)
+                    dict(MARLHIP_DIST_BACKEND="gloo", MARLHIP_ONE_DEVICE="1", MARLHIP_P2P_SHARED_DEVICE="1", MARLHIP_P2P_TIMEOUT_MS="20000"), 29541)
     assert out.returncode == 0 and "ENTRY_OK" in out.stdout, out.stdout[-3000:] + out.stderr[-5000:]
