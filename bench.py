@@ -324,16 +324,15 @@ def traffic_from_profile(key, variant=""):
 def _ranks_field(world, dist, args, sync=None):
     """Ranks that took part in the gradient exchange, as torch.distributed reports them (backend: nccl == RCCL), and WHICH exchange
     carried the gradients: "p2p" = the library's own (csrc/p2p.hip: IPC-shared buffers, rank-ordered sum in the reduce launch),
-    "collective" = torch.distributed's all-reduce.  A p2p exchange that ran into its peer timeout fails the run here."""
+    "collective" = torch.distributed's all-reduce.  (A p2p exchange that ran into its peer timeout fails the run before this point:
+    GradSync.check() on every rank, right behind the timed region.)"""
     out = {"world_size": dist.get_world_size() if dist is not None else 1, "backend": args.backend if dist is not None else None}
     if dist is not None:
         out["exchange"] = "p2p (in-library)" if getattr(sync, "p2p", None) is not None else "collective (torch.distributed.all_reduce)"
-        if sync is not None:
-            sync.check()
     return out
 
 
-def bench_ac(args, rank, world, dist):
+def bench_ac(args, rank, world, dist, steps=None, warmup=None):
     """IA2C / IPPO (marlbase/ac): one step = one rollout of every env (fused collector, 1 launch) + one update
     (A2C) or num_epochs updates (PPO) on that rollout.  env-steps = transitions actually stored (sum of `filled`);
     the reference's own counter advances by t_max * parallel_envs per rollout (ac/train.py:226) - reported next to it."""
@@ -347,6 +346,8 @@ def bench_ac(args, rank, world, dist):
     from codebase_amd.utils.envs import _space_pair
 
     N, T, H = args.envs, args.time_limit, args.hidden
+    n_steps_timed = args.steps if steps is None else steps
+    n_warmup = args.warmup if warmup is None else warmup
     cfg = h.env_config(args.env_name, N, T, seed=rank_env_seed(args.seed, rank))
     P, (D, A) = cfg.n_agents, h.env_dims(cfg)
     torch.manual_seed(args.seed)
@@ -406,10 +407,10 @@ def bench_ac(args, rank, world, dist):
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(n_warmup):
         one_round()
     sync()
-    if not args.rnn and args.warmup > 0:  # the counter above counts what the batch holds
+    if not args.rnn and n_warmup > 0:  # the counter above counts what the batch holds
         assert int(fin_len.sum().item()) == int(b_fill.sum().item()), "stored transitions != sum of first-episode lengths"
     steps_dev.zero_()
     ref_steps.zero_()
@@ -418,7 +419,7 @@ def bench_ac(args, rank, world, dist):
     if not args.no_kernel_timing:
         lib.marlhip_timing_enable(1)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(n_steps_timed):
         one_round()
     sync()
     dt = time.perf_counter() - t0
@@ -440,10 +441,10 @@ def bench_ac(args, rank, world, dist):
             if n.value:
                 timing[kname] = {"launches": n.value, "avg_us": 1e3 * ms.value / n.value, "total_ms": ms.value}
         lib.marlhip_timing_enable(0)
+    if sync_grad is not None:
+        sync_grad.check()
     if rank != 0:
-        if dist is not None:
-            dist.destroy_process_group()
-        return
+        return None
     name = args.env_name.split(":")[-1].replace("-v3", "").replace("-v2", "")
     roofline = None
     upd = timing.get("ac_update (fwd rows x3, elementwise, bwd rows x2)")
@@ -458,24 +459,25 @@ def bench_ac(args, rank, world, dist):
                     "flops_needed_per_launch": needed, "frac_needed": ach * needed / flops / PEAK_F32_MFMA_TFLOPS,
                     "dominant_stage_by_time": "ac_update" if not col or upd["total_ms"] >= col["total_ms"] else "ac_collect_kernel"}
         if col and col["total_ms"] > upd["total_ms"]:  # the rollout dominates (long episodes, few envs): its acting forward next to it
-            cf = (gru_fwd_flops if args.rnn else mlp_fwd_flops)(D, H, A) * P * (env_steps / args.steps)
+            cf = (gru_fwd_flops if args.rnn else mlp_fwd_flops)(D, H, A) * P * (env_steps / n_steps_timed)
             roofline["collector"] = {"kernel": "ac_collect_kernel", "bound": "mfma (latency-bound in practice: one wave per 16 envs walks the episode)",
                                      "flops_per_launch": cf, "avg_launch_us": col["avg_us"],
                                      "frac": cf / (col["avg_us"] * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS}
     out = {
         "metric": f"env-steps/sec (whole node) {args.algo.upper()} {name}", "value": env_steps / dt, "unit": "env-steps/s",
-        "n_gpus": world, "rccl_ranks": _ranks_field(world, dist, args, sync_grad), "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+        "n_gpus": world, "rccl_ranks": _ranks_field(world, dist, args, sync_grad), "steps": n_steps_timed, "warmup": n_warmup, "ms_per_step": 1e3 * dt / n_steps_timed,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic (Philox-seeded env layouts, orthogonal-init weights)",
         "config": {"workload": f"{args.algo.upper()} on {name}, {N} batched HIP envs per GPU, actor/critic " + (f"GRU-{H} networks (use_rnn), " if args.rnn else f"2-layer-{H} MLPs, ")
                                + f"time_limit {T}, one update per rollout", "envs_per_gpu": N, "env_steps_timed": env_steps,
+                   # the batch stores every env's FIRST episode of a rollout: stored transitions / (rollouts x envs x ranks)
+                   "mean_episode_length": env_steps / max(n_steps_timed * N * world, 1),
+                   "policy_regime": "untrained actors (orthogonal init, a few Adam steps of warm-up): episodes run to the time limit unless the env ends them",
                    "reference_step_counter": int(ref_steps.item()),
                    "parallelism": f"dp{world} (envs sharded per GPU, RCCL grad all-reduce per update)" if world > 1 else "1 GPU"},
         "kernels": timing, "roofline": roofline,
     }
-    print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+    return out
 
 
 def _self_launch(n):
@@ -551,7 +553,12 @@ def main():
     args.backend = backend
 
     if args.algo in ("ia2c", "ippo", "maa2c", "mappo"):
-        return bench_ac(args, rank, world, dist)
+        out = bench_ac(args, rank, world, dist)
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
 
     out = bench_dqn(args, rank, world, dist, args.steps, args.warmup)
     if rank == 0:
@@ -569,26 +576,59 @@ def main():
 def secondary_modes(args):
     """BASELINE.md 3.5's other modes and the reference-default network, timed by the same process right after the headline region so
     that the driver's bench line witnesses them too: env-only (collector alone), cadence=reference (the reference's one update of 32
-    episodes per collected episode, sequentially) and the headline cadence with the reference's default 128-128 networks
-    (configs/algorithm/idqn.yaml:8-10).  Short regions (tens to hundreds of ms); `value`, `config` and `roofline` of the line are
-    untouched."""
+    episodes per collected episode, sequentially), the headline cadence with the reference's default 128-128 networks
+    (configs/algorithm/idqn.yaml:8-10), a trained-policy row (short episodes) and BASELINE.json's configs 3 - 5 at their per-GPU shard.
+    Short regions (tens to hundreds of ms; the trained-policy row trains ~5 s first); `value`, `config` and `roofline` of the line are untouched."""
     import copy
 
     rows = {}
+
+    def row(r, steps, warmup):
+        rf, c = r.get("roofline") or {}, r["config"]
+        return {"value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"], "steps": steps, "warmup": warmup, "dtype": r["dtype"],
+                "workload": c["workload"], "updates_per_round": c.get("updates_per_round"), "update_batch_episodes": c.get("update_batch_episodes"),
+                "lr": c.get("lr"), "target_update_interval_or_tau": c.get("target_update_interval_or_tau"),
+                "mean_episode_length": c.get("mean_episode_length"), "mean_episode_return_last_round": c.get("mean_episode_return_last_round"),
+                "epsilon_timed_rounds": c.get("epsilon_timed_rounds"),
+                "roofline": {k: rf.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "frac_needed", "avg_launch_us")}}
+
     for name, over, steps, warmup in (("hparams=tuned (lr 3e-3, Polyak 0.1: what the batched cadence learns fastest with), cadence=ratio", dict(hparams="tuned"), 10, 3),
                                       ("env-only", dict(cadence="env-only"), 100, 5),
                                       ("cadence=reference", dict(cadence="reference"), 3, 1),
                                       ("hidden=128 (reference default net), cadence=ratio", dict(hidden=128), 5, 2),
-                                      ("split16 OPT-IN learner (fp16 hi/lo products, fp32 accumulate; NOT the default), cadence=ratio", dict(split16=True), 10, 3)):
+                                      ("split16 OPT-IN learner (fp16 hi/lo products, fp32 accumulate; NOT the default), cadence=ratio", dict(split16=True), 10, 3),
+                                      # how env-steps/s moves with the episode length (VERDICT r4 weak 10): the same loop after ~5 s of training with the
+                                      # tuned optimiser settings, timed at epsilon 0.05 - episodes end when the food is gone, update cost per sampled
+                                      # episode stays what it was
+                                      ("trained policy (hparams=tuned, 1500 rounds of training first, epsilon 0.05): short episodes, cadence=ratio",
+                                       dict(hparams="tuned", pretrain_rounds=1500, eps_fixed=0.05,
+                                            regime_note="after 1500 untimed training rounds (epsilon 1 -> 0.05), timed at epsilon 0.05"), 20, 2)):
         a = copy.copy(args)
         for k, v in over.items():
             setattr(a, k, v)
-        r = bench_dqn(a, 0, 1, None, steps, warmup)
-        rf = r.get("roofline") or {}
-        rows[name] = {"value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"], "steps": steps, "warmup": warmup, "dtype": r["dtype"],
-                      "updates_per_round": r["config"]["updates_per_round"], "update_batch_episodes": r["config"]["update_batch_episodes"],
-                      "lr": r["config"]["lr"], "target_update_interval_or_tau": r["config"]["target_update_interval_or_tau"],
-                      "roofline": {k: rf.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_us")}}
+        rows[name] = row(bench_dqn(a, 0, 1, None, steps, warmup), steps, warmup)
+    # BASELINE.json configs 3 - 5 at their per-GPU shard (configs 4 and 5 are quoted on 8 GPUs: 16384 / 8 and 65536 / 8 envs), so that the
+    # driver's line witnesses them; config 3 names no width: both the headline's 64 and the reference default 128
+    for name, over, steps, warmup in (
+            ("BASELINE config 3: VDN Foraging-15x15-4p-5f, 8192 envs, 64-64", dict(algo="vdn", env_name="lbforaging:Foraging-15x15-4p-5f-v3", envs=8192, hidden=64), 3, 1),
+            ("BASELINE config 3: VDN Foraging-15x15-4p-5f, 8192 envs, 128-128", dict(algo="vdn", env_name="lbforaging:Foraging-15x15-4p-5f-v3", envs=8192, hidden=128), 2, 1),
+            ("BASELINE config 4 (per-GPU shard): IA2C rware-tiny-4ag, 2048 envs, 128-128", dict(algo="ia2c", env_name="rware:rware-tiny-4ag-v2", envs=2048, hidden=128, time_limit=500), 3, 1),
+            ("BASELINE config 5 (per-GPU shard): QMIX Foraging-15x15-8p-5f, 8192 envs, 128-128, fp32 mixer", dict(algo="qmix", env_name="lbforaging:Foraging-15x15-8p-5f-v3", envs=8192, hidden=128), 2, 1),
+            ("BASELINE config 5 (per-GPU shard): QMIX Foraging-15x15-8p-5f, 8192 envs, 128-128, OPT-IN fp16 first mixer layers", dict(algo="qmix", env_name="lbforaging:Foraging-15x15-8p-5f-v3", envs=8192, hidden=128, mixer_fp16=True), 2, 1)):
+        a = copy.copy(args)
+        for k, v in over.items():
+            setattr(a, k, v)
+        try:
+            r = bench_ac(a, 0, 1, None, steps, warmup) if a.algo == "ia2c" else bench_dqn(a, 0, 1, None, steps, warmup)
+            rows[name] = row(r, steps, warmup)
+        except Exception as e:  # noqa: BLE001 - a secondary row never takes the headline down
+            rows[name] = {"error": f"{type(e).__name__}: {e}"}
+        import gc
+
+        import torch
+
+        gc.collect()
+        torch.cuda.empty_cache()  # the 8-agent workspaces are GBs: hand them back before the next row
     return rows
 
 
@@ -642,16 +682,24 @@ def bench_dqn(args, rank, world, dist, steps, warmup):
     trainer = VectorisedIDQN(cfg, model, cap, T, B, U, seed=args.seed, dist=dist)
     eps_sched = _epsilon_schedule("linear", 0.5, 1.0, 0.05, 6.5, 100_000_000)
     steps_dev = trainer.env_steps
+    # `modes` row "trained policy": `pretrain_rounds` untimed rounds of the same loop with epsilon annealed 1 -> eps_fixed over their first
+    # 60 %, then the warm-up and the timed rounds at eps_fixed (secondary_modes sets both; the default line has neither)
+    pre, eps_fixed = int(getattr(args, "pretrain_rounds", 0) or 0), getattr(args, "eps_fixed", None)
+
+    def eps_at(rnd):
+        if pre:
+            return max(eps_fixed, 1.0 - (1.0 - eps_fixed) * rnd / (0.6 * pre))
+        return eps_sched(rnd * N * T)
 
     def one_round():
-        trainer.round(eps_sched(trainer.rounds * N * T), train=U > 0)
+        trainer.round(eps_at(trainer.rounds), train=U > 0)
 
     def sync():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(warmup):
+    for _ in range(pre + warmup):
         one_round()
     sync()
     steps_dev.zero_()
@@ -668,6 +716,7 @@ def bench_dqn(args, rank, world, dist, steps, warmup):
         dt = float(tt[0])
         dist.all_reduce(steps_dev)
     env_steps = int(steps_dev.item())
+    mean_return = float(trainer.fin_return.sum(0).mean().item())  # the last round's episodes, summed over the agents (this rank's)
 
     timing = {}
     if not args.no_kernel_timing:
@@ -680,6 +729,10 @@ def bench_dqn(args, rank, world, dist, steps, warmup):
         lib.marlhip_timing_enable(0)
 
     exchange_sync = getattr(trainer, "_sync", None)
+    if exchange_sync is not None:
+        exchange_sync.check()  # every rank: a timed-out in-library exchange fails the run on all of them
+    mean_len = env_steps / max(steps * N * world, 1)  # every round stores N episodes per rank
+    eps_timed = (eps_at(trainer.rounds - steps), eps_at(trainer.rounds - 1))
     del trainer, model
     if rank != 0:
         return None
@@ -755,6 +808,13 @@ def bench_dqn(args, rank, world, dist, steps, warmup):
             "learner": "split16 (opt-in: f32 products from fp16 halves)" if getattr(args, "split16", False) else "f32",
             "mixer_first_layers": ("fp16 (opt-in)" if args.mixer_fp16 else "f32") if args.algo == "qmix" else None,
             "env_steps_timed": env_steps,
+            # update cost is per SAMPLED episode (padding rows are computed), collection cost per step: env-steps/s moves with the episode
+            # length the policy produces.  The timed rounds run at the epsilon below (a fresh run's schedule: close to 1, random policy,
+            # every episode runs to the time limit unless the env ends it) - `modes` carries a trained-policy row next to it
+            "mean_episode_length": mean_len,
+            "mean_episode_return_last_round": mean_return,
+            "epsilon_timed_rounds": {"first": eps_timed[0], "last": eps_timed[1]},
+            "policy_regime": getattr(args, "regime_note", "fresh run: epsilon-greedy near epsilon = 1 on orthogonal-init networks"),
         },
         "kernels": timing,
         "roofline": roofline,
