@@ -159,7 +159,7 @@ def _a2c_step_vs_port(model, b, P, D, H, A, central, env_chunks, loss_rtol=5e-5)
         loss, m = ap.a2c_loss(lr.actor(), lr.critic(), lr.target, sub, D, H, A, n_steps=5, gamma=0.99, entropy_coef=0.001, value_loss_coef=0.5)
         (loss * w).backward()
         for k in acc:
-            acc[k] += float(m[k]) * float(w)
+            acc[k] += float(m[k].detach()) * float(w)
     ref = np.array([acc["loss"], acc["actor_loss"], acc["value_loss"], acc["entropy"]])
     np.testing.assert_allclose(got[:4], ref, rtol=loss_rtol, atol=5e-6)
     assert got[4] == float(total)
@@ -195,6 +195,9 @@ def test_config4_ia2c_rware_tiny4ag_2048_envs_x_500_steps_H128_vs_oracle():
         np.testing.assert_array_equal(np.concatenate(o), obs[0, n])
         for t in range(T):
             o, r, d, tr, _ = e.step([int(a) for a in act[t, n]])
+            if d or tr:  # the vector env auto-resets: the stored row is the NEXT episode's first observation (utils/envs.py:11-65, ac/train.py:80-92)
+                assert t == T - 1
+                o, _ = e.reset(DrawStream(seed, n, 2 * rnd + 1))
             np.testing.assert_array_equal(np.concatenate(o), obs[t + 1, n], err_msg=f"env {n} step {t}")
             np.testing.assert_array_equal(np.array(r, dtype=np.float32), rew[t, n])
             assert bool(done[t + 1, n]) == bool(d or tr)
