@@ -123,11 +123,13 @@ PROTOTYPES = {
     "marlhip_gru_loss_grad_std": (c_int32, [POINTER(NetShape), c_void_p, c_void_p, POINTER(BatchStruct), c_float, c_int32, POINTER(RetStatsStruct),
                                             c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "marlhip_gru_qmix_workspace_bytes": (c_int64, [POINTER(NetShape), c_int32, c_int32]),
+    "marlhip_gru_qmix_workspace_bytes_mx": (c_int64, [POINTER(NetShape), POINTER(QmixMixer), c_int32, c_int32]),
     "marlhip_gru_qmix_loss_grad": (c_int32, [POINTER(NetShape), c_void_p, c_void_p, POINTER(QmixMixer), POINTER(BatchStruct), c_float, c_int32,
                                              c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "marlhip_wide_qmix_loss_grad": (c_int32, [POINTER(NetShape), c_void_p, c_void_p, POINTER(QmixMixer), POINTER(BatchStruct), c_float, c_int32,
                                              c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "marlhip_wide_qmix_workspace_bytes": (c_int64, [POINTER(NetShape), c_int32, c_int32]),
+    "marlhip_wide_qmix_workspace_bytes_mx": (c_int64, [POINTER(NetShape), POINTER(QmixMixer), c_int32, c_int32]),
     "marlhip_gru_ac_critic_nparams": (c_int32, [POINTER(NetShape), c_int32]),
     "marlhip_gru_ac_workspace_bytes": (c_int64, [POINTER(NetShape), c_int32, c_int32, c_int32]),
     "marlhip_gru_a2c_loss_grad": (c_int32, [POINTER(NetShape), c_void_p, c_void_p, c_void_p, POINTER(BatchStruct), POINTER(AcConfig),
@@ -174,6 +176,7 @@ PROTOTYPES = {
                                                    c_void_p]),
     "marlhip_qmix_nparams": (c_int32, [POINTER(NetShape), c_int32, c_int32, c_int32]),
     "marlhip_qmix_workspace_bytes": (c_int64, [POINTER(NetShape), c_int32, c_int32]),
+    "marlhip_qmix_workspace_bytes_mx": (c_int64, [POINTER(NetShape), POINTER(QmixMixer), c_int32, c_int32]),
     "marlhip_qmix_loss_grad": (c_int32, [POINTER(NetShape), c_void_p, c_void_p, POINTER(QmixMixer), POINTER(BatchStruct), c_float,
                                          c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "marlhip_qmix_loss_grad_replay": (c_int32, [POINTER(NetShape), c_void_p, c_void_p, POINTER(QmixMixer), POINTER(ReplayShape),

@@ -32,6 +32,8 @@ MARL_PART_FUSED_DECL(lossgrad_part_h64_oid_fused)
 // QMIX mixer stage for callers that ran the agent networks themselves (gru.hip): phase 0 = mix, phase 1 = mixer-gradient reduce
 int qmix_mix_stage(const marlhip_net_shape* s, const QmixCtx* qx, const marlhip_batch* bt, const QmixIo* io, float gamma, int phase,
                    const float* loss, hipStream_t stream) {
+    if (qx->generic)
+        return phase == 0 ? qmix_gen_mix(*qx, qx->gen, bt, nullptr, *io, gamma, stream) : qmix_gen_reduce(*qx, qx->gen, bt->max_len, bt->batch, loss, stream);
     bool found = false;
     for (auto part : {&lossgrad_part_h64_mix, &lossgrad_part_h64_oid_mix, &lossgrad_part_rware_mix}) {
         const int rc = part(s, qx, bt, io, gamma, phase, loss, stream, &found);
@@ -41,13 +43,37 @@ int qmix_mix_stage(const marlhip_net_shape* s, const QmixCtx* qx, const marlhip_
     return -1;
 }
 
-int64_t qmix_mixer_ws_bytes(const marlhip_net_shape* s, int32_t max_len, int32_t batch) {
-#define X(p, d) if (s->n_agents == p && s->obs_dim == d) return qmix_ws_layout<QmixShape<p, d>>(max_len, batch).total;
+// which mixer stage a (shape, mixing) pair runs on: 0 = the compiled kernels of qmix.h ({64, 2, 32} on the (agents, obs) pairs of
+// MARL_QMIX_SHAPES), 1 = the generic stage of qmix_gen.h (everything else QMixer.__init__ accepts), -1 = not a QMixer.
+// MARLHIP_QMIX_GENERIC=1 (diagnostics / tests) sends the compiled configurations through the generic stage too.
+int qmix_kind(const marlhip_net_shape* s, int embed_dim, int hypernet_layers, int hypernet_embed, QmixGenDims* dims) {
+    static const bool force = getenv("MARLHIP_QMIX_GENERIC") != nullptr;
+    const QmixGenDims d = {s->n_agents, s->obs_dim, embed_dim, hypernet_embed, hypernet_layers};
+    if (dims != nullptr) *dims = d;
+    if (!force && embed_dim == 64 && hypernet_layers == 2 && hypernet_embed == 32) {
+#define X(p, dd) if (s->n_agents == p && s->obs_dim == dd) return 0;
+        MARL_QMIX_SHAPES(X)
+#undef X
+    }
+    return qmix_gen_check(d) != 0 ? -1 : 1;
+}
+
+void qmix_ctx_mixing(QmixCtx& qx, const marlhip_net_shape* s, const marlhip_qmix_mixer* mx) {
+    qx.generic = qmix_kind(s, mx->embed_dim, mx->hypernet_layers, mx->hypernet_embed, &qx.gen) == 1;
+}
+
+int64_t qmix_mixer_ws_bytes_mx(const marlhip_net_shape* s, int embed_dim, int hypernet_layers, int hypernet_embed, int32_t max_len, int32_t batch) {
+    QmixGenDims d;
+    const int kind = qmix_kind(s, embed_dim, hypernet_layers, hypernet_embed, &d);
+    if (kind < 0) return -1;
+    if (kind == 1) return qmix_gen_ws_bytes(d, max_len, batch);
+#define X(p, dd) if (s->n_agents == p && s->obs_dim == dd) return qmix_ws_layout<QmixShape<p, dd>>(max_len, batch).total;
     MARL_QMIX_SHAPES(X)
 #undef X
-    set_error("no QMIX mixer kernel for %d agents x %d observations", s->n_agents, s->obs_dim);
     return -1;
 }
+
+int64_t qmix_mixer_ws_bytes(const marlhip_net_shape* s, int32_t max_len, int32_t batch) { return qmix_mixer_ws_bytes_mx(s, 64, 2, 32, max_len, batch); }
 }  // namespace marl
 
 extern "C" int marlhip_net_nparams(const marlhip_net_shape* s) {
@@ -175,21 +201,13 @@ extern "C" int marlhip_dqn_loss_grad_std_replay(const marlhip_net_shape* s, cons
 }
 
 // ---- QMIX (QMixNetwork, marlbase/dqn/model.py:334-443) ------------------------------------------------------
-static int qmix_check(const marlhip_net_shape* s, int32_t embed_dim, int32_t hypernet_layers, int32_t hypernet_embed) {
-    MARL_REQUIRE(s != nullptr, "net shape is NULL");
-    MARL_REQUIRE(embed_dim == 64 && hypernet_layers == 2 && hypernet_embed == 32,
-                 "qmix: only mixing = {embed_dim 64, hypernet_layers 2, hypernet_embed 32} (configs/algorithm/qmix.yaml) is compiled, "
-                 "got {%d, %d, %d}", embed_dim, hypernet_layers, hypernet_embed);
-#define X(p, d) if (s->n_agents == p && s->obs_dim == d) return 0;
-    MARL_QMIX_SHAPES(X)
-#undef X
-    set_error("no QMIX mixer kernel for %d agents x %d observations (add it to MARL_QMIX_SHAPES)", s->n_agents, s->obs_dim);
-    return -1;
-}
-
 extern "C" int marlhip_qmix_nparams(const marlhip_net_shape* s, int32_t embed_dim, int32_t hypernet_layers, int32_t hypernet_embed) {
-    if (qmix_check(s, embed_dim, hypernet_layers, hypernet_embed) != 0) return -1;
-#define X(p, d) if (s->n_agents == p && s->obs_dim == d) return QmixShape<p, d>::NPARAM;
+    MARL_REQUIRE(s != nullptr, "net shape is NULL");
+    QmixGenDims d;
+    const int kind = qmix_kind(s, embed_dim, hypernet_layers, hypernet_embed, &d);
+    if (kind < 0) return -1;
+    if (kind == 1) return (int)qmix_gen_nparams(d);  // (for {64, 2, 32} the same number as QmixShape::NPARAM: the same canonical order)
+#define X(p, dd) if (s->n_agents == p && s->obs_dim == dd) return QmixShape<p, dd>::NPARAM;
     MARL_QMIX_SHAPES(X)
 #undef X
     return -1;
@@ -200,21 +218,23 @@ static int64_t qmix_agent_ws(const marlhip_net_shape* s, int32_t max_len, int32_
     return a < 0 ? a : ((a + 255) & ~(int64_t)255);
 }
 
+extern "C" int64_t marlhip_qmix_workspace_bytes_mx(const marlhip_net_shape* s, const marlhip_qmix_mixer* mx, int32_t max_len, int32_t batch) {
+    MARL_REQUIRE(s != nullptr && mx != nullptr, "qmix_workspace_bytes: NULL pointer");
+    const int64_t a = qmix_agent_ws(s, max_len, batch), m = a < 0 ? -1 : qmix_mixer_ws_bytes_mx(s, mx->embed_dim, mx->hypernet_layers, mx->hypernet_embed, max_len, batch);
+    return (a < 0 || m < 0) ? -1 : a + m;
+}
+
 extern "C" int64_t marlhip_qmix_workspace_bytes(const marlhip_net_shape* s, int32_t max_len, int32_t batch) {
-    if (qmix_check(s, 64, 2, 32) != 0) return -1;
-    const int64_t a = qmix_agent_ws(s, max_len, batch);
-    if (a < 0) return -1;
-#define X(p, d) if (s->n_agents == p && s->obs_dim == d) return a + qmix_ws_layout<QmixShape<p, d>>(max_len, batch).total;
-    MARL_QMIX_SHAPES(X)
-#undef X
-    return -1;
+    MARL_REQUIRE(s != nullptr, "net shape is NULL");
+    const int64_t a = qmix_agent_ws(s, max_len, batch), m = a < 0 ? -1 : qmix_mixer_ws_bytes(s, max_len, batch);
+    return (a < 0 || m < 0) ? -1 : a + m;
 }
 
 static int qmix_call(const marlhip_net_shape* s, const float* params, const float* target_params, const marlhip_qmix_mixer* mx,
                      const marlhip_batch* bt, const ReplaySrc* rsrc, float gamma, int32_t double_q, void* workspace,
                      int64_t workspace_bytes, float* grad, float* loss, void* stream) {
     MARL_REQUIRE(mx && mx->mixer && mx->target_mixer && mx->mixer_grad, "qmix_loss_grad: NULL mixer pointer");
-    if (qmix_check(s, mx->embed_dim, mx->hypernet_layers, mx->hypernet_embed) != 0) return -1;
+    if (qmix_kind(s, mx->embed_dim, mx->hypernet_layers, mx->hypernet_embed, nullptr) < 0) return -1;
     const int64_t a = qmix_agent_ws(s, bt->max_len, bt->batch);
     MARL_REQUIRE(a >= 0 && workspace_bytes > a, "qmix_loss_grad: workspace %lld too small", (long long)workspace_bytes);
     QmixCtx qx;
@@ -222,6 +242,7 @@ static int qmix_call(const marlhip_net_shape* s, const float* params, const floa
     qx.ws = static_cast<char*>(workspace) + a;
     qx.ws_bytes = workspace_bytes - a;
     qx.l1_fp16 = mx->l1_fp16 != 0;
+    qmix_ctx_mixing(qx, s, mx);
     RetStats rst;
     if (mx->ret_stats != nullptr) {  // QMixNetwork with standardise_returns: per-batch-column statistics (model.py:415-422)
         const marlhip_ret_stats* st = mx->ret_stats;

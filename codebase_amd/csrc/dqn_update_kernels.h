@@ -991,6 +991,7 @@ static __global__ __launch_bounds__(256) void adam_kernel(int64_t n, int nblocks
 
 #include "ret_stats.h"
 #include "dqn_update_tp.h"
+#include "qmix_gen.h"
 #include "qmix.h"
 
 namespace marl {
@@ -1240,6 +1241,7 @@ inline UpdPlan upd_plan_tp(int P, int T, int B, int NB) {  // one workgroup per 
 template <int D, bool REPLAY>
 int qmix_dispatch_mix(int P, const QmixCtx& qx, const marlhip_batch* bt, const ReplaySrc& src, const QmixIo& io, float gamma,
                       hipStream_t st) {
+    if (qx.generic) return qmix_gen_mix(qx, qx.gen, bt, REPLAY ? &src : nullptr, io, gamma, st);
 #define X(p, d) \
     if constexpr (D == d) { if (P == p) return qmix_launch_mix<QmixShape<p, d>, REPLAY>(qx, bt, src, io, gamma, st); }
     MARL_QMIX_SHAPES(X)
@@ -1250,6 +1252,7 @@ int qmix_dispatch_mix(int P, const QmixCtx& qx, const marlhip_batch* bt, const R
 
 template <int D>
 int qmix_dispatch_reduce(int P, const QmixCtx& qx, int T, int B, const float* loss, hipStream_t st) {
+    if (qx.generic) return qmix_gen_reduce(qx, qx.gen, T, B, loss, st);
 #define X(p, d) \
     if constexpr (D == d) { if (P == p) return qmix_launch_reduce<QmixShape<p, d>>(qx, T, B, loss, st); }
     MARL_QMIX_SHAPES(X)

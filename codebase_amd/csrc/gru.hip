@@ -232,6 +232,8 @@ namespace marl {
 int qmix_mix_stage(const marlhip_net_shape* s, const QmixCtx* qx, const marlhip_batch* bt, const QmixIo* io, float gamma, int phase,
                    const float* loss, hipStream_t stream);
 int64_t qmix_mixer_ws_bytes(const marlhip_net_shape* s, int32_t max_len, int32_t batch);
+int64_t qmix_mixer_ws_bytes_mx(const marlhip_net_shape* s, int embed_dim, int hypernet_layers, int hypernet_embed, int32_t max_len, int32_t batch);
+void qmix_ctx_mixing(QmixCtx& qx, const marlhip_net_shape* s, const marlhip_qmix_mixer* mx);
 }
 
 namespace {
@@ -243,7 +245,7 @@ int gru_qmix_loss_grad(const marlhip_net_shape* s, const float* params, const fl
     const int64_t R = (int64_t)T * B;
     const GruWs wl = gru_ws_layout<S>(P, T, B);
     const int64_t extra = ((3 * P + 3) * R * 4 + 255) / 256 * 256;  // chosen, tqsel, dqm [P][R]; r0, dn, fl [R]
-    const int64_t mixws = qmix_mixer_ws_bytes(s, T, B);
+    const int64_t mixws = qmix_mixer_ws_bytes_mx(s, mx->embed_dim, mx->hypernet_layers, mx->hypernet_embed, T, B);
     if (mixws < 0) return -1;
     MARL_REQUIRE(ws_bytes >= wl.total + extra + mixws, "gru_qmix_loss_grad: workspace %lld < %lld bytes", (long long)ws_bytes,
                  (long long)(wl.total + extra + mixws));
@@ -259,6 +261,7 @@ int gru_qmix_loss_grad(const marlhip_net_shape* s, const float* params, const fl
     qx.mixer = mx->mixer; qx.tmixer = mx->target_mixer; qx.mgrad = mx->mixer_grad;
     qx.ws = base + wl.total + extra; qx.ws_bytes = mixws;
     qx.l1_fp16 = mx->l1_fp16 != 0;
+    qmix_ctx_mixing(qx, s, mx);
     RetStats rst;
     if (mx->ret_stats != nullptr) {  // standardise_returns: the mixer stage standardises the target mixer's output per batch column
         const marlhip_ret_stats* stt = mx->ret_stats;
@@ -311,13 +314,20 @@ extern "C" int64_t marlhip_gru_qmix_workspace_bytes(const marlhip_net_shape* s, 
     return a + (((int64_t)(3 * s->n_agents + 3) * max_len * batch * 4 + 255) / 256 * 256) + m;
 }
 
+extern "C" int64_t marlhip_gru_qmix_workspace_bytes_mx(const marlhip_net_shape* s, const marlhip_qmix_mixer* mx, int32_t max_len, int32_t batch) {
+    MARL_REQUIRE(mx != nullptr, "gru_qmix_workspace_bytes: NULL mixer");
+    const int64_t a = marlhip_gru_workspace_bytes(s, max_len, batch),
+                  m = a < 0 ? -1 : qmix_mixer_ws_bytes_mx(s, mx->embed_dim, mx->hypernet_layers, mx->hypernet_embed, max_len, batch);
+    if (a < 0 || m < 0) return -1;
+    return a + (((int64_t)(3 * s->n_agents + 3) * max_len * batch * 4 + 255) / 256 * 256) + m;
+}
+
 extern "C" int marlhip_gru_qmix_loss_grad(const marlhip_net_shape* s, const float* params, const float* target_params, const marlhip_qmix_mixer* mixer,
                                           const marlhip_batch* batch, float gamma, int32_t double_q, void* workspace, int64_t workspace_bytes,
                                           float* grad, float* loss, void* stream) {
     if (gru_check(s) != 0) return -1;
     MARL_REQUIRE(params && target_params && mixer && mixer->mixer && mixer->target_mixer && mixer->mixer_grad && batch && workspace && grad && loss,
                  "gru_qmix_loss_grad: NULL pointer");
-    MARL_REQUIRE(mixer->embed_dim == 64 && mixer->hypernet_layers == 2 && mixer->hypernet_embed == 32, "gru_qmix_loss_grad: mixing = {64, 2, 32} only");
     MARL_REQUIRE(batch->obs_agent_stride == 0 && batch->obs_row_stride == 0, "gru_qmix_loss_grad: the dqn/train.py Batch layout only");
 #define X(d, h, a)                                               \
     if (s->obs_dim == d && s->hidden == h && s->n_actions == a)  \

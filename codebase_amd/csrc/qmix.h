@@ -1076,6 +1076,8 @@ struct QmixCtx {  // what marlhip_qmix_loss_grad adds to the agent-network call
     int64_t ws_bytes;
     const RetStats* rst = nullptr;  // standardise_returns: per-batch-column statistics (ret_stats.h), or null
     bool l1_fp16 = false;           // marlhip_qmix_mixer.l1_fp16: first layers of both mixers on the fp16 MFMA
+    bool generic = false;           // the mixer of qmix_gen.h (hypernet_layers 1, widths beyond 64 / 32, (agents, obs) pairs without a compiled kernel)
+    QmixGenDims gen = {};
 };
 
 struct QmixWs {

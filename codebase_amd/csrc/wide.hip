@@ -159,6 +159,8 @@ namespace marl {
 int qmix_mix_stage(const marlhip_net_shape* s, const QmixCtx* qx, const marlhip_batch* bt, const QmixIo* io, float gamma, int phase,
                    const float* loss, hipStream_t stream);
 int64_t qmix_mixer_ws_bytes(const marlhip_net_shape* s, int32_t max_len, int32_t batch);
+int64_t qmix_mixer_ws_bytes_mx(const marlhip_net_shape* s, int embed_dim, int hypernet_layers, int hypernet_embed, int32_t max_len, int32_t batch);
+void qmix_ctx_mixing(QmixCtx& qx, const marlhip_net_shape* s, const marlhip_qmix_mixer* mx);
 }
 
 static int64_t wide_qmix_extra(const marlhip_net_shape* s, int T, int B) { return ((int64_t)(3 * s->n_agents + 3) * T * B * 4 + 255) / 256 * 256; }
@@ -169,20 +171,27 @@ extern "C" int64_t marlhip_wide_qmix_workspace_bytes(const marlhip_net_shape* s,
     return a + wide_qmix_extra(s, max_len, batch) + m;
 }
 
+extern "C" int64_t marlhip_wide_qmix_workspace_bytes_mx(const marlhip_net_shape* s, const marlhip_qmix_mixer* mx, int32_t max_len, int32_t batch) {
+    MARL_REQUIRE(mx != nullptr, "wide_qmix_workspace_bytes: NULL mixer");
+    const int64_t a = marlhip_wide_dqn_workspace_bytes(s, max_len, batch),
+                  m = a < 0 ? -1 : qmix_mixer_ws_bytes_mx(s, mx->embed_dim, mx->hypernet_layers, mx->hypernet_embed, max_len, batch);
+    if (a < 0 || m < 0) return -1;
+    return a + wide_qmix_extra(s, max_len, batch) + m;
+}
+
 extern "C" int marlhip_wide_qmix_loss_grad(const marlhip_net_shape* s, const float* params, const float* target_params, const marlhip_qmix_mixer* mx,
                                            const marlhip_batch* bt, float gamma, int32_t double_q, void* workspace, int64_t workspace_bytes,
                                            float* grad, float* loss, void* stream) {
     MARL_REQUIRE(s && params && target_params && mx && mx->mixer && mx->target_mixer && mx->mixer_grad && bt && workspace && grad && loss,
                  "wide_qmix_loss_grad: NULL pointer");
     if (wide_check(s, s->n_actions) != 0) return -1;
-    MARL_REQUIRE(mx->embed_dim == 64 && mx->hypernet_layers == 2 && mx->hypernet_embed == 32, "wide_qmix_loss_grad: mixing = {64, 2, 32} only");
     MARL_REQUIRE(bt->obss && bt->actions && bt->rewards && bt->dones && bt->filled && bt->max_len > 0 && bt->batch > 0, "wide_qmix_loss_grad: bad batch");
     MARL_REQUIRE(bt->obs_agent_stride == 0 && bt->obs_row_stride == 0, "wide_qmix_loss_grad: the dqn/train.py Batch layout only");
     const int P = s->n_agents, T = bt->max_len, B = bt->batch, A = s->n_actions, D = s->obs_dim;
     const int64_t R = (int64_t)T * B;
     const WideNet net = wide_net(s, A);
     const WideDqnWs wl = wide_dqn_ws(net, P, T, B);
-    const int64_t extra = wide_qmix_extra(s, T, B), mixws = qmix_mixer_ws_bytes(s, T, B);
+    const int64_t extra = wide_qmix_extra(s, T, B), mixws = qmix_mixer_ws_bytes_mx(s, mx->embed_dim, mx->hypernet_layers, mx->hypernet_embed, T, B);
     if (mixws < 0) return -1;
     MARL_REQUIRE(workspace_bytes >= wl.total + extra + mixws, "wide_qmix_loss_grad: workspace %lld < %lld bytes", (long long)workspace_bytes,
                  (long long)(wl.total + extra + mixws));
@@ -199,6 +208,7 @@ extern "C" int marlhip_wide_qmix_loss_grad(const marlhip_net_shape* s, const flo
     qx.mixer = mx->mixer; qx.tmixer = mx->target_mixer; qx.mgrad = mx->mixer_grad;
     qx.ws = base + wl.total + extra; qx.ws_bytes = mixws;
     qx.l1_fp16 = mx->l1_fp16 != 0;
+    qmix_ctx_mixing(qx, s, mx);
     RetStats rst;
     if (mx->ret_stats != nullptr) {  // standardise_returns: the mixer stage standardises the target mixer's output per batch column
         const marlhip_ret_stats* stt = mx->ret_stats;

@@ -443,24 +443,51 @@ _MIXER_LAYOUT = ("hyper_w_1.0", "hyper_w_1.2", "hyper_w_final.0", "hyper_w_final
 KERNEL_EMBED, KERNEL_HYPER = 64, 32  # the widths csrc/qmix.h is built for (configs/algorithm/qmix.yaml:14-17)
 
 
+def mixer_is_padded(embed_dim, hypernet_layers, hypernet_embed):
+    """two-layer hypernets no wider than csrc/qmix.h's fused kernels: the block is laid out at 64 / 32 and the mixer sits zero-padded in it
+    (exact: mixer_live_views).  Everything else QMixer.__init__ builds (dqn/model.py:283-301: `hypernet_layers` 1, wider embeddings /
+    hypernets) keeps its own sizes and runs on the generic mixer stage (csrc/qmix_gen.hip)."""
+    return hypernet_layers == 2 and 0 < embed_dim <= KERNEL_EMBED and 0 < hypernet_embed <= KERNEL_HYPER
+
+
+def _mixer_modules(n_agents, state_dim, embed_dim, hypernet_layers, hypernet_embed):
+    """(state_dict name, (out, in)) of the QMixer's Linear layers in mixer.parameters() order (dqn/model.py:283-311)"""
+    P, SD, E, HE = n_agents, state_dim, embed_dim, hypernet_embed
+    if hypernet_layers == 1:
+        hyper = [("hyper_w_1", (E * P, SD)), ("hyper_w_final", (E, SD))]
+    elif hypernet_layers == 2:
+        hyper = [("hyper_w_1.0", (HE, SD)), ("hyper_w_1.2", (E * P, HE)), ("hyper_w_final.0", (HE, SD)), ("hyper_w_final.2", (E, HE))]
+    else:
+        raise Exception("Error setting number of hypernet layers (please set `hypernet_layers=1` or `hypernet_layers=2`).")  # dqn/model.py:298-301
+    return hyper + [("hyper_b_1", (E, SD)), ("V.0", (E, SD)), ("V.2", (1, E))]
+
+
 def init_flat_mixer(n_agents, state_dim, embed_dim, hypernet_layers, hypernet_embed):
     """Initial mixer AND target-mixer blocks in mixer.parameters() order, consuming torch's global RNG like
     QMixNetwork.__init__ does (mixer, then target mixer, then hard_update; dqn/model.py:283-312, 361-363)."""
-    if hypernet_layers != 2:
-        raise NotImplementedError("QMixer with hypernet_layers != 2: the HIP mixer kernels implement configs/algorithm/qmix.yaml's two-layer hypernets")
-    if not (0 < embed_dim <= KERNEL_EMBED and 0 < hypernet_embed <= KERNEL_HYPER):
-        raise NotImplementedError(f"QMixer with embed_dim {embed_dim} / hypernet_embed {hypernet_embed}: the HIP mixer kernels carry widths up to "
-                                  f"{KERNEL_EMBED} / {KERNEL_HYPER} (narrower ones run zero-padded, which is exact)")
+    if not (0 < embed_dim <= 1024 and (hypernet_layers == 1 or 0 < hypernet_embed <= 1024)):
+        raise NotImplementedError(f"QMixer with embed_dim {embed_dim} / hypernet_embed {hypernet_embed}: widths up to 1024")
+    layout = _mixer_modules(n_agents, state_dim, embed_dim, hypernet_layers, hypernet_embed)
 
     def one():
-        mods = [nn.Linear(state_dim, hypernet_embed), nn.Linear(hypernet_embed, embed_dim * n_agents),
-                nn.Linear(state_dim, hypernet_embed), nn.Linear(hypernet_embed, embed_dim),
-                nn.Linear(state_dim, embed_dim), nn.Linear(state_dim, embed_dim), nn.Linear(embed_dim, 1)]
+        mods = [nn.Linear(i, o) for _, (o, i) in layout]
         return torch.cat([t.detach().reshape(-1) for m in mods for t in (m.weight, m.bias)]), [m.weight.shape for m in mods]
 
     mixer, shapes = one()
     one()  # the target mixer's own draw, overwritten by hard_update
     return mixer, mixer.clone(), shapes
+
+
+def mixer_plain_views(block, n_agents, state_dim, embed_dim, hypernet_layers, hypernet_embed):
+    """[(state_dict name, view, reference shape)] of a QMixer stored at its own sizes (the generic mixer stage): plain slices"""
+    out, o = [], 0
+    for name, (n_out, n_in) in _mixer_modules(n_agents, state_dim, embed_dim, hypernet_layers, hypernet_embed):
+        out.append((f"{name}.weight", block[o:o + n_out * n_in].view(n_out, n_in), (n_out, n_in)))
+        o += n_out * n_in
+        out.append((f"{name}.bias", block[o:o + n_out], (n_out,)))
+        o += n_out
+    assert o == block.numel(), (o, block.numel())
+    return out
 
 
 def mixer_live_views(block, n_agents, state_dim, embed_dim, hypernet_embed):
@@ -528,12 +555,21 @@ class QMixNetwork(QNetwork):
         state_dim = sum(flatdim(o) for o in obs_space)
         mixer, tmixer, self._mixer_shapes = init_flat_mixer(self.n_agents, state_dim, **self.mixing)
         self._state_dim = state_dim
-        # blocks laid out for the kernels' widths (64 / 32); narrower mixers sit zero-padded inside them (exact: mixer_live_views)
-        self.mixer_params = pad_mixer(mixer, self.n_agents, state_dim, self.mixing["embed_dim"], self.mixing["hypernet_embed"]).to(self.device).contiguous()
-        self.target_mixer_params = pad_mixer(tmixer, self.n_agents, state_dim, self.mixing["embed_dim"], self.mixing["hypernet_embed"]).to(self.device).contiguous()
+        self._mixer_padded = mixer_is_padded(**self.mixing)
+        if self._mixer_padded:
+            # blocks laid out for the fused kernels' widths (64 / 32); narrower mixers sit zero-padded inside them (exact: mixer_live_views)
+            self.mixer_params = pad_mixer(mixer, self.n_agents, state_dim, self.mixing["embed_dim"], self.mixing["hypernet_embed"]).to(self.device).contiguous()
+            self.target_mixer_params = pad_mixer(tmixer, self.n_agents, state_dim, self.mixing["embed_dim"], self.mixing["hypernet_embed"]).to(self.device).contiguous()
+            kernel_mixing = dict(embed_dim=KERNEL_EMBED, hypernet_layers=2, hypernet_embed=KERNEL_HYPER, fp16=self.mixer_fp16)
+        else:
+            # hypernet_layers 1, or wider than the fused kernels: the block at its own sizes, on the generic mixer stage (csrc/qmix_gen.hip)
+            if self.mixer_fp16:
+                raise NotImplementedError("mixing.fp16 (opt-in) exists for two-layer hypernets up to embed_dim 64 / hypernet_embed 32")
+            self.mixer_params, self.target_mixer_params = mixer.to(self.device).contiguous(), tmixer.to(self.device).contiguous()
+            kernel_mixing = dict(self.mixing)
         up = self.updater
         self.updater = (_hip.GruQmixUpdater if self.recurrent else _hip.WideQmixUpdater if self.spec.wide else _hip.QmixUpdater)(self.spec, self.params, self.target_params, self.mixer_params, self.target_mixer_params,
-                                        mixing=dict(embed_dim=KERNEL_EMBED, hypernet_layers=2, hypernet_embed=KERNEL_HYPER, fp16=self.mixer_fp16), lr=up.lr, gamma=self.gamma, grad_clip=self.grad_clip,
+                                        mixing=kernel_mixing, lr=up.lr, gamma=self.gamma, grad_clip=self.grad_clip,
                                         double_q=self.double_q, standardise_returns=self.standardise_returns, optimizer=self.optimizer)
         self.mode = 2
 
@@ -554,6 +590,9 @@ class QMixNetwork(QNetwork):
 
     def _mixer_views(self, block, prefix):
         """state_dict key -> (live strided view into the kernel-sized block, the reference tensor's shape)"""
+        if not self._mixer_padded:
+            return OrderedDict((f"{prefix}.{name}", (view, shape)) for name, view, shape in
+                               mixer_plain_views(block, self.n_agents, self._state_dim, **self.mixing))
         return OrderedDict((f"{prefix}.{name}", (view, shape)) for name, view, shape in
                            mixer_live_views(block, self.n_agents, self._state_dim, self.mixing["embed_dim"], self.mixing["hypernet_embed"]))
 

@@ -554,9 +554,13 @@ class QmixUpdater(DqnUpdater):
         key = (T, B)
         if key not in self._ws:
             s = self.spec.c()
-            n = check(lib.marlhip_qmix_workspace_bytes(ctypes.byref(s), T, B), "qmix_workspace_bytes")
+            n = check(lib.marlhip_qmix_workspace_bytes_mx(ctypes.byref(s), ctypes.byref(self._mx_dims()), T, B), "qmix_workspace_bytes")
             self._ws[key] = torch.empty(max(int(n), 4), dtype=torch.uint8, device=self.params.device)
         return self._ws[key]
+
+    def _mx_dims(self):
+        """the mixing configuration alone (what the *_workspace_bytes_mx queries read)"""
+        return QmixMixer(None, None, None, *self.mixing)
 
     def _mx(self, B=None):
         mx = QmixMixer(self.mixer.data_ptr(), self.target_mixer.data_ptr(), self.mixer_grad.data_ptr(), *self.mixing)
@@ -956,7 +960,7 @@ class GruQmixUpdater(QmixUpdater):
         key = ("gru", T, B)
         if key not in self._ws:
             s = self.spec.c()
-            n = check(lib.marlhip_gru_qmix_workspace_bytes(ctypes.byref(s), T, B), "gru_qmix_workspace_bytes")
+            n = check(lib.marlhip_gru_qmix_workspace_bytes_mx(ctypes.byref(s), ctypes.byref(self._mx_dims()), T, B), "gru_qmix_workspace_bytes")
             self._ws.clear()
             self._ws[key] = torch.empty(int(n), dtype=torch.uint8, device=self.params.device)
         return self._ws[key]
@@ -983,7 +987,7 @@ class WideQmixUpdater(QmixUpdater):
         key = ("wide", T, B)
         if key not in self._ws:
             s = self.spec.c()
-            n = check(lib.marlhip_wide_qmix_workspace_bytes(ctypes.byref(s), T, B), "wide_qmix_workspace_bytes")
+            n = check(lib.marlhip_wide_qmix_workspace_bytes_mx(ctypes.byref(s), ctypes.byref(self._mx_dims()), T, B), "wide_qmix_workspace_bytes")
             self._ws.clear()
             self._ws[key] = torch.empty(int(n), dtype=torch.uint8, device=self.params.device)
         return self._ws[key]

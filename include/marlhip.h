@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MARLHIP_VERSION 211
+#define MARLHIP_VERSION 212
 
 int marlhip_version(void);
 const char* marlhip_last_error(void);
@@ -396,13 +396,16 @@ int marlhip_gru_loss_grad_std(const marlhip_net_shape* s, const float* params, c
  * of marlhip_qmix_loss_grad (same kernels, same mixer block layout) between them.  grad: agents' blocks; mixer->mixer_grad: the
  * mixer's; loss[2] as everywhere. */
 int64_t marlhip_gru_qmix_workspace_bytes(const marlhip_net_shape* s, int32_t max_len, int32_t batch);
+/* C-ABI 212: for the mixing configuration in mixer->{embed_dim, hypernet_layers, hypernet_embed} (marlhip_qmix_workspace_bytes_mx) */
+int64_t marlhip_gru_qmix_workspace_bytes_mx(const marlhip_net_shape* s, const struct marlhip_qmix_mixer* mixer, int32_t max_len, int32_t batch);
 int marlhip_gru_qmix_loss_grad(const marlhip_net_shape* s, const float* params, const float* target_params,
                                const struct marlhip_qmix_mixer* mixer, const marlhip_batch* batch, float gamma, int32_t double_q,
                                void* workspace, int64_t workspace_bytes, float* grad, float* loss /* [2] */, void* stream);
 /* marlhip_qmix_loss_grad with agent networks on the GEMM path (marlhip_wide_*: layers wider than 128 or not two deep); the mixer stage is
  * the same one, mixer->ret_stats (columns = batch) included */
 int64_t marlhip_wide_qmix_workspace_bytes(const marlhip_net_shape* s, int32_t max_len, int32_t batch);
-int marlhip_wide_qmix_loss_grad(const marlhip_net_shape* s, const float* params, const float* target_params, const marlhip_qmix_mixer* mixer,
+int64_t marlhip_wide_qmix_workspace_bytes_mx(const marlhip_net_shape* s, const struct marlhip_qmix_mixer* mixer, int32_t max_len, int32_t batch);
+int marlhip_wide_qmix_loss_grad(const marlhip_net_shape* s, const float* params, const float* target_params, const struct marlhip_qmix_mixer* mixer,
                                 const marlhip_batch* batch, float gamma, int32_t double_q, void* workspace, int64_t workspace_bytes,
                                 float* grad, float* loss, void* stream);
 
@@ -670,8 +673,12 @@ int marlhip_dqn_loss_grad_std_replay(const marlhip_net_shape* s, const float* pa
  * observations (model.py:389,412), reward of agent 0 (model.py:379), Double-Q bootstrap mixed by the TARGET
  * mixer on obs[1:].  Runs as agent-forward -> mixer stage (4 MFMA kernels) -> agent-backward.
  * Flat mixer block = mixer.parameters() order: hyper_w_1.{0,2}.{weight,bias}, hyper_w_final.{0,2}.{weight,bias},
- * hyper_b_1.{weight,bias}, V.{0,2}.{weight,bias} (model.py:283-312).  Compiled for mixing = {embed_dim 64,
- * hypernet_layers 2, hypernet_embed 32} (configs/algorithm/qmix.yaml:14-17); anything else is an error.
+ * hyper_b_1.{weight,bias}, V.{0,2}.{weight,bias} (model.py:283-312).  mixing = {embed_dim 64, hypernet_layers 2, hypernet_embed 32}
+ * (configs/algorithm/qmix.yaml:14-17) on the (agents, observation) pairs of the supported envs runs on the fused MFMA kernels of
+ * csrc/qmix.h; since C-ABI 212 every other QMixer the reference builds (model.py:283-301: hypernet_layers 1 - hyper_w_1 / hyper_w_final
+ * are then ONE Linear each, `hyper_w_1.{weight,bias}`, `hyper_w_final.{weight,bias}` - or 2, any embed_dim / hypernet_embed up to 1024,
+ * any (agents <= 16, observation) pair) runs on the generic stage of csrc/qmix_gen.hip: the hypernet layers as f32 MFMA GEMMs over all
+ * rows, the mixing network one wave per row, split-K weight gradients folded in fixed order.  Workspace: the *_workspace_bytes_mx queries.
  * QNetwork.update clips the CRITIC gradient only (model.py:169-170): call marlhip_dqn_clip_adam on the critic block
  * with max_norm and on the mixer block with max_norm = 0 (same step count; one torch Adam over both lists).
  * ---------------------------------------------------------------------------------------- */
@@ -690,8 +697,10 @@ typedef struct marlhip_qmix_mixer {
 } marlhip_qmix_mixer;
 
 int marlhip_qmix_nparams(const marlhip_net_shape* s, int32_t embed_dim, int32_t hypernet_layers, int32_t hypernet_embed);
-/* scratch for marlhip_qmix_loss_grad: the agent-network workspace + first-layer activations and backward operands */
+/* scratch for marlhip_qmix_loss_grad: the agent-network workspace + first-layer activations and backward operands (mixing = {64, 2, 32}) */
 int64_t marlhip_qmix_workspace_bytes(const marlhip_net_shape* s, int32_t max_len, int32_t batch);
+/* C-ABI 212: the same for the mixing configuration in mixer->{embed_dim, hypernet_layers, hypernet_embed} (only those three fields are read) */
+int64_t marlhip_qmix_workspace_bytes_mx(const marlhip_net_shape* s, const marlhip_qmix_mixer* mixer, int32_t max_len, int32_t batch);
 /* grad[P][nparams], mixer->mixer_grad, loss[0] = value, loss[1] = sum(filled) */
 int marlhip_qmix_loss_grad(const marlhip_net_shape* s, const float* params, const float* target_params,
                            const marlhip_qmix_mixer* mixer, const marlhip_batch* batch, float gamma, int32_t double_q,

@@ -8,6 +8,9 @@ Runs only in the build container (needs /root/reference); the vectors travel, th
       (hard target update forced at update 2), Adam moments of the mixer.
   learner_qmix_p4_H64.npz  : 4 agents x 27 obs (15x15-4p-5f shapes), 25 x 24 batch: loss and gradients only.
   learner_qmix_e24_h16_H64.npz : 3 agents x 18 obs with mixing = {embed_dim 24, hypernet_layers 2, hypernet_embed 16}: loss, gradients, 3 updates.
+  learner_qmix_L1_H64.npz      : 2 agents x 15 obs with mixing = {64, hypernet_layers 1, 32} (QMixer.__init__'s one-Linear hypernets, model.py:283-285).
+  learner_qmix_L1_e40_p3_H64.npz : 3 agents x 18 obs with mixing = {40, 1, 7}; learner_qmix_e96_h48_H64.npz: 2 agents x 15 obs with {96, 2, 48}
+      (wider than the fused kernels); all three: loss, gradients, 3 updates - they run on the generic mixer stage (csrc/qmix_gen.hip).
 """
 import contextlib
 import io
@@ -49,7 +52,8 @@ def build(ref_model, P, D, A, H, seed, mixing=None):
 def fixture(ref_model, ref_train, name, P, D, B, seed, updates, mixing=None):
     T, A, H = 25, 6, 64
     net = build(ref_model, P, D, A, H, seed, mixing)
-    out = dict(P=P, T=T, B=B, D=D, A=A, H=H, E=net.mixer.embed_dim, HE=net.mixer.hypernet_embed, params0=flat_params(net.critic).numpy(),
+    out = dict(P=P, T=T, B=B, D=D, A=A, H=H, E=net.mixer.embed_dim, HE=net.mixer.hypernet_embed, L=net.mixer.hypernet_layers,
+               mixer_keys=np.array([k for k in net.mixer.state_dict().keys()]), params0=flat_params(net.critic).numpy(),
                target0=flat_params(net.target).numpy(), mixer0=mixer_flat(net.mixer).numpy(),
                tmixer0=mixer_flat(net.target_mixer).numpy())
     batches = [synthetic_batch(P, T, B, D, A, seed=seed + 100 + i) for i in range(max(updates, 1))]
@@ -116,3 +120,7 @@ if __name__ == "__main__":
     fixture(rm, rt, "learner_qmix_p4_H64.npz", P=4, D=27, B=24, seed=400, updates=0)
     # a QMixer narrower than qmix.yaml's (QMixer.__init__, dqn/model.py:283-300, takes any widths): runs zero-padded on the 64 / 32 kernels
     fixture(rm, rt, "learner_qmix_e24_h16_H64.npz", P=3, D=18, B=24, seed=500, updates=3, mixing=dict(embed_dim=24, hypernet_layers=2, hypernet_embed=16))
+    # the QMixer configurations outside the fused kernels (generic mixer stage): one-Linear hypernets, and widths beyond 64 / 32
+    fixture(rm, rt, "learner_qmix_L1_H64.npz", P=2, D=15, B=32, seed=600, updates=3, mixing=dict(embed_dim=64, hypernet_layers=1, hypernet_embed=32))
+    fixture(rm, rt, "learner_qmix_L1_e40_p3_H64.npz", P=3, D=18, B=24, seed=700, updates=3, mixing=dict(embed_dim=40, hypernet_layers=1, hypernet_embed=7))
+    fixture(rm, rt, "learner_qmix_e96_h48_H64.npz", P=2, D=15, B=32, seed=800, updates=3, mixing=dict(embed_dim=96, hypernet_layers=2, hypernet_embed=48))

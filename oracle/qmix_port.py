@@ -22,13 +22,16 @@ import torch.nn.functional as F
 from . import dqn_port as dp
 
 
-def mixer_shapes(P, SD, E=64, HE=32):
+def mixer_shapes(P, SD, E=64, HE=32, L=2):
+    """L = hypernet_layers (model.py:283-301): 1 -> hyper_w_1 / hyper_w_final are one Linear each on the state"""
+    if L == 1:
+        return [(E * P, SD), (E * P,), (E, SD), (E,), (E, SD), (E,), (E, SD), (E,), (1, E), (1,)]
     return [(HE, SD), (HE,), (E * P, HE), (E * P,), (HE, SD), (HE,), (E, HE), (E,), (E, SD), (E,), (E, SD), (E,), (1, E), (1,)]
 
 
-def mixer_nparams(P, SD, E=64, HE=32):
+def mixer_nparams(P, SD, E=64, HE=32, L=2):
     n = 0
-    for s in mixer_shapes(P, SD, E, HE):
+    for s in mixer_shapes(P, SD, E, HE, L):
         k = 1
         for d in s:
             k *= d
@@ -36,9 +39,9 @@ def mixer_nparams(P, SD, E=64, HE=32):
     return n
 
 
-def mixer_split(flat, P, SD, E=64, HE=32):
+def mixer_split(flat, P, SD, E=64, HE=32, L=2):
     out, o = [], 0
-    for s in mixer_shapes(P, SD, E, HE):
+    for s in mixer_shapes(P, SD, E, HE, L):
         k = 1
         for d in s:
             k *= d
@@ -47,36 +50,45 @@ def mixer_split(flat, P, SD, E=64, HE=32):
     return out
 
 
-def mixer_init(P, SD, E=64, HE=32, seed=0):
+def mixer_init(P, SD, E=64, HE=32, seed=0, L=2):
     """torch default nn.Linear init, modules built in QMixer.__init__'s order (model.py:283-312)."""
     torch.manual_seed(seed)
-    mods = [torch.nn.Linear(SD, HE), torch.nn.Linear(HE, E * P), torch.nn.Linear(SD, HE), torch.nn.Linear(HE, E),
-            torch.nn.Linear(SD, E), torch.nn.Linear(SD, E), torch.nn.Linear(E, 1)]
+    if L == 1:
+        mods = [torch.nn.Linear(SD, E * P), torch.nn.Linear(SD, E)]
+    else:
+        mods = [torch.nn.Linear(SD, HE), torch.nn.Linear(HE, E * P), torch.nn.Linear(SD, HE), torch.nn.Linear(HE, E)]
+    mods += [torch.nn.Linear(SD, E), torch.nn.Linear(SD, E), torch.nn.Linear(E, 1)]
     return torch.cat([p.detach().reshape(-1) for m in mods for p in m.parameters()])
 
 
-def mixer_forward(flat, agent_qs, states, P, E=64, HE=32):
+def mixer_forward(flat, agent_qs, states, P, E=64, HE=32, L=2):
     """QMixer.forward: agent_qs [P,T,B], states [T,B,SD] -> [T,B]."""
     T, B = agent_qs.shape[1:]
     SD = states.shape[-1]
-    A1, a1, B1, c1, Af, af, Bf, cf, Bb, cb, Av, av, bv, cv = mixer_split(flat, P, SD, E, HE)
     qs = agent_qs.permute(1, 2, 0).reshape(T * B, 1, P)
     s = states.reshape(-1, SD)
-    w1 = torch.abs(F.linear(torch.relu(F.linear(s, A1, a1)), B1, c1)).view(-1, P, E)
+    if L == 1:
+        W1, w1b, Wf, wfb, Bb, cb, Av, av, bv, cv = mixer_split(flat, P, SD, E, HE, 1)
+        w1 = torch.abs(F.linear(s, W1, w1b)).view(-1, P, E)
+        wf_pre = F.linear(s, Wf, wfb)
+    else:
+        A1, a1, B1, c1, Af, af, Bf, cf, Bb, cb, Av, av, bv, cv = mixer_split(flat, P, SD, E, HE)
+        w1 = torch.abs(F.linear(torch.relu(F.linear(s, A1, a1)), B1, c1)).view(-1, P, E)
+        wf_pre = F.linear(torch.relu(F.linear(s, Af, af)), Bf, cf)
     b1 = F.linear(s, Bb, cb).view(-1, 1, E)
     hidden = F.elu(torch.bmm(qs, w1) + b1)
-    wf = torch.abs(F.linear(torch.relu(F.linear(s, Af, af)), Bf, cf)).view(-1, E, 1)
+    wf = torch.abs(wf_pre).view(-1, E, 1)
     v = F.linear(torch.relu(F.linear(s, Av, av)), bv, cv).view(-1, 1, 1)
     return (torch.bmm(hidden, wf) + v).view(T, B)
 
 
-def compute_loss(params, tparams, mixer, tmixer, batch, gamma, double_q, D, H, A, E=64, HE=32):
+def compute_loss(params, tparams, mixer, tmixer, batch, gamma, double_q, D, H, A, E=64, HE=32, L=2):
     """QMixNetwork._compute_loss (model.py:374-427), standardise_returns False."""
     obss, actions = batch["obss"], batch["actions"].unsqueeze(-1)
     rewards, dones, filled = batch["rewards"][0], batch["dones"][1:], batch["filled"]
     P = obss.shape[0]
     q = dp.q_values(params, obss, D, H, A)
-    chosen = mixer_forward(mixer, q[:, :-1].gather(-1, actions).squeeze(-1), torch.concat(list(obss[:, :-1]), dim=-1), P, E, HE)
+    chosen = mixer_forward(mixer, q[:, :-1].gather(-1, actions).squeeze(-1), torch.concat(list(obss[:, :-1]), dim=-1), P, E, HE, L)
     with torch.no_grad():
         tq = dp.q_values(tparams, obss, D, H, A)[:, 1:]
         if double_q:
@@ -84,7 +96,7 @@ def compute_loss(params, tparams, mixer, tmixer, batch, gamma, double_q, D, H, A
             target_qs = tq.gather(-1, a_prime.unsqueeze(-1)).squeeze(-1)
         else:
             target_qs, _ = tq.max(dim=-1)
-        target_tot = mixer_forward(tmixer, target_qs, torch.concat(list(obss[:, 1:]), dim=-1), P, E, HE)
+        target_tot = mixer_forward(tmixer, target_qs, torch.concat(list(obss[:, 1:]), dim=-1), P, E, HE, L)
     returns = rewards + gamma * target_tot * (1 - dones)
     loss = F.mse_loss(chosen, returns.detach(), reduction="none")
     return (loss * filled).sum() / filled.sum()
@@ -94,12 +106,12 @@ class Learner:
     """QMixNetwork.update: one Adam over critic + mixer tensors, clip over the critic tensors only."""
 
     def __init__(self, params, mixer, D, H, A, E=64, HE=32, lr=3e-4, gamma=0.99, grad_clip=1.0, double_q=True,
-                 target_update_interval_or_tau=200):
-        self.D, self.H, self.A, self.E, self.HE = D, H, A, E, HE
+                 target_update_interval_or_tau=200, L=2):
+        self.D, self.H, self.A, self.E, self.HE, self.L = D, H, A, E, HE, L
         self.P = P = params.shape[0]
         self.SD = P * D
         self.tensors = [torch.nn.Parameter(t.clone()) for p in range(P) for t in dp.split(params[p], D, H, A)]
-        self.mtensors = [torch.nn.Parameter(t.clone()) for t in mixer_split(mixer, P, self.SD, E, HE)]
+        self.mtensors = [torch.nn.Parameter(t.clone()) for t in mixer_split(mixer, P, self.SD, E, HE, L)]
         self.target, self.tmixer = params.clone(), mixer.clone()
         self.opt = torch.optim.Adam(self.tensors + self.mtensors, lr=lr)
         self.gamma, self.grad_clip, self.double_q = gamma, grad_clip, double_q
@@ -121,12 +133,12 @@ class Learner:
             for cols in torch.arange(batch["filled"].shape[1]).chunk(chunks):
                 sub = dp.column_chunk(batch, cols)
                 part = compute_loss(self.flat(), self.target, self.mflat(), self.tmixer, sub, self.gamma, self.double_q,
-                                    self.D, self.H, self.A, self.E, self.HE) * (sub["filled"].sum() / total)
+                                    self.D, self.H, self.A, self.E, self.HE, self.L) * (sub["filled"].sum() / total)
                 part.backward()
                 loss = loss + part.detach()
         else:
             loss = compute_loss(self.flat(), self.target, self.mflat(), self.tmixer, batch, self.gamma, self.double_q,
-                                self.D, self.H, self.A, self.E, self.HE)
+                                self.D, self.H, self.A, self.E, self.HE, self.L)
             loss.backward()
         per = len(self.tensors) // self.P  # the gradients as _compute_loss leaves them (before clipping): for tests that compare them
         self.last_grad = torch.stack([torch.cat([t.grad.reshape(-1) for t in self.tensors[p * per:(p + 1) * per]]) for p in range(self.P)]).clone()

@@ -177,7 +177,8 @@ def test_qmix_library_loop_equals_the_host_loop_bit_for_bit(monkeypatch):
         assert torch.equal(x, y)
 
 
-def test_qmix_rejects_other_mixing_configs():
+def test_qmix_rejects_what_the_reference_rejects():
+    """QMixer.__init__ (dqn/model.py:298-301) raises for hypernet_layers outside {1, 2}; a mixer block of the wrong size is refused before any launch"""
     h = hip()
     from codebase_amd._lib import MarlHipError
 
@@ -185,7 +186,101 @@ def test_qmix_rejects_other_mixing_configs():
     z = torch.zeros(10, device=DEV)
     with pytest.raises(MarlHipError):
         h.QmixUpdater(spec, dp.init_params(2, 15, 64, 6).to(DEV), dp.init_params(2, 15, 64, 6).to(DEV), z, z,
+                      mixing=dict(embed_dim=32, hypernet_layers=3, hypernet_embed=64))
+    with pytest.raises(ValueError):
+        h.QmixUpdater(spec, dp.init_params(2, 15, 64, 6).to(DEV), dp.init_params(2, 15, 64, 6).to(DEV), z, z,
                       mixing=dict(embed_dim=32, hypernet_layers=1, hypernet_embed=64))
+
+
+# ---- round 5: the QMixer configurations outside the fused kernels, on the generic mixer stage (csrc/qmix_gen.hip) ---------------------------
+@pytest.mark.parametrize("name", ["learner_qmix_L1_H64.npz", "learner_qmix_L1_e40_p3_H64.npz", "learner_qmix_e96_h48_H64.npz"])
+def test_generic_mixer_matches_reference_goldens(name):
+    """hypernet_layers = 1 (one Linear per hypernet, dqn/model.py:283-285) and mixers wider than 64 / 32 through QMixNetwork: state_dict keys
+    and shapes of the reference's QMixer, loss, critic and mixer gradients, then 3 x update() with a hard copy at update 2 - all against
+    the reference's own QMixNetwork"""
+    from codebase_amd.dqn.model import QMixNetwork
+    from codebase_amd.spaces import Box, Discrete, Tuple
+
+    g = load(name)
+    P, D, A, E, HE, L = (int(g[k]) for k in ("P", "D", "A", "E", "HE", "L"))
+    hyper = dict(optimizer="Adam", lr=3e-4, gamma=0.99, grad_clip=1.0, double_q=True, standardise_returns=False, target_update_interval_or_tau=2)
+    net = QMixNetwork(Tuple([Box(-1, 8, (D,)) for _ in range(P)]), Tuple([Discrete(A) for _ in range(P)]), hyper, [64, 64], False, False, True,
+                      dict(embed_dim=E, hypernet_layers=L, hypernet_embed=HE), "cuda")
+    sd = net.state_dict()
+    assert [k for k in sd if k.startswith("mixer.")] == ["mixer." + k for k in g["mixer_keys"]]
+    assert net.mixer_params.numel() == g["mixer0"].size == qp.mixer_nparams(P, P * D, E, HE, L)
+    net.params.copy_(torch.tensor(g["params0"]))
+    net.target_params.copy_(torch.tensor(g["target0"]))
+    net.mixer_params.copy_(torch.tensor(g["mixer0"]))
+    net.target_mixer_params.copy_(torch.tensor(g["tmixer0"]))
+    h = hip()
+    up = net.updater
+    loss, grad = up.loss_grad(dev_batch(h, golden_batch(g, 0)))
+    assert abs(loss.cpu().numpy()[0] - g["loss0"]) <= 1e-5 * abs(g["loss0"])
+    assert_grad_close(grad.cpu().numpy(), g["grad0"])
+    assert_grad_close(up.mixer_grad.cpu().numpy(), g["mgrad0"])
+    for i in range(3):
+        b = golden_batch(g, i)
+        lo = net.update(Batch(b["obss"].to(DEV), b["actions"].to(DEV), b["rewards"].to(DEV), b["dones"].to(DEV), b["filled"].to(DEV), None))["loss"]
+        assert abs(lo - g["losses"][i]) <= 2e-5 * abs(g["losses"][i])
+        np.testing.assert_allclose(net.params.cpu().numpy(), g[f"params{i + 1}"], rtol=0, atol=3e-6)
+        np.testing.assert_allclose(net.mixer_params.cpu().numpy(), g[f"mixer{i + 1}"], rtol=0, atol=3e-6)
+        np.testing.assert_allclose(net.target_mixer_params.cpu().numpy(), g[f"tmixer{i + 1}"], rtol=0, atol=3e-6)
+    np.testing.assert_allclose(up.mixer_exp_avg.cpu().numpy(), g["mixer_exp_avg"], rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("P,T,B,D,H,E,HE,L,kind", [(8, 6, 70, 39, 128, 64, 32, 1, "fused"), (4, 25, 33, 27, 64, 128, 64, 2, "fused"), (2, 9, 130, 15, 64, 200, 5, 1, "fused"),
+                                                   (5, 7, 21, 11, 64, 64, 32, 2, "wide"),   # an (agents, obs) pair with no compiled mixer: the generic stage at qmix.yaml's widths
+                                                   (3, 8, 19, 18, 96, 48, 32, 1, "wide")])
+def test_generic_mixer_other_shapes_vs_oracle_port(P, T, B, D, H, E, HE, L, kind):
+    """8 agents, embeddings wider than a wave, ragged rows; around the fused agent kernels (also gathered in-kernel from the replay) and
+    around agent networks on the GEMM path"""
+    h = hip()
+    A = 6
+    hid = H if kind == "fused" else (H, H)
+    spec = h.NetSpec(P, D, H, A) if kind == "fused" else h.NetSpec(P, D, H, A, wide=True, n_hidden=2)
+    params = dp.init_params(P, D, hid, A, seed=1) + 0.05
+    target = dp.init_params(P, D, hid, A, seed=3)
+    mixer, tmixer = qp.mixer_init(P, P * D, E, HE, seed=11, L=L), qp.mixer_init(P, P * D, E, HE, seed=12, L=L)
+    batch = dp.synthetic_batch(P, T, B, D, A, seed=5)
+    batch["rewards"][1:] = batch["rewards"][0]
+    batch["obss"] = batch["obss"] * 0.25
+    pr, mr = params.clone().requires_grad_(True), mixer.clone().requires_grad_(True)
+    ref = qp.compute_loss(pr, target, mr, tmixer, batch, 0.99, True, D, hid, A, E, HE, L)
+    ref.backward()
+    cls = h.QmixUpdater if kind == "fused" else h.WideQmixUpdater
+    up = cls(spec, params.to(DEV), target.to(DEV), mixer.to(DEV), tmixer.to(DEV), mixing=dict(embed_dim=E, hypernet_layers=L, hypernet_embed=HE))
+    loss, grad = up.loss_grad(dev_batch(h, batch))
+    assert abs(loss.cpu().numpy()[0] - ref.item()) <= 3e-5 * abs(ref.item())
+    assert_grad_close(grad.cpu().numpy(), pr.grad.numpy(), 3e-4)
+    assert_grad_close(up.mixer_grad.cpu().numpy(), mr.grad.numpy(), 3e-4)
+    if kind == "fused":  # the same numbers with the rows gathered from a replay holding the episodes in another order
+        perm = torch.randperm(B, generator=torch.Generator().manual_seed(1))
+        rb = h.DeviceReplay(B, P, D, T)
+        inv = torch.argsort(perm)
+        rb.obs.copy_(batch["obss"].permute(2, 0, 1, 3)[inv])
+        rb.act.copy_(batch["actions"].permute(2, 0, 1).to(torch.uint8)[inv])
+        rb.rew.copy_(batch["rewards"].permute(2, 0, 1)[inv])
+        rb.done.copy_(batch["dones"].t().to(torch.uint8)[inv])
+        rb.filled.copy_(batch["filled"].t().to(torch.uint8)[inv])
+        l1, g1, m1 = loss.clone(), grad.clone(), up.mixer_grad.clone()
+        up.mixer_grad.zero_()
+        l2, g2 = up.loss_grad_replay(rb, B, idx=perm.to(torch.int32).to(DEV))
+        assert torch.equal(l1, l2) and torch.equal(g1, g2) and torch.equal(m1, up.mixer_grad)
+
+
+def test_generic_mixer_reproduces_the_compiled_configurations_goldens():
+    """MARLHIP_QMIX_GENERIC=1 sends mixing = {64, 2, 32} on the compiled shapes through the generic stage too: the reference's goldens and the
+    port comparisons of this file must hold for it unchanged (a fresh interpreter: the switch is read once per process)"""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_qmix.py"), "-q", "-x", "-m", "gpu", "-k",
+                          "loss_and_grads_match_reference_golden or update_sequence_matches_reference_golden or narrow_mixer or (other_shapes_vs_oracle_port and not generic)"],
+                         cwd=root, env=dict(os.environ, MARLHIP_QMIX_GENERIC="1"), capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
 
 
 @pytest.mark.parametrize("P,T,B,D,H,L", [(2, 25, 33, 15, 256, 2), (4, 9, 50, 27, 160, 2), (2, 12, 40, 15, 64, 3), (3, 7, 21, 18, 96, 1)])
