@@ -65,7 +65,8 @@ class AcConfig(ctypes.Structure):
     _fields_ = [("n_steps", c_int32), ("entropy_coef", c_float), ("value_loss_coef", c_float), ("ppo_clip", c_float),
                 ("gamma", c_double), ("ret_mean", c_void_p), ("ret_var", c_void_p), ("ret_count", c_void_p),
                 ("centralised_critic", c_int32), ("side_stream", c_void_p),
-                ("ret_exchange", c_void_p), ("ret_exchange_ctx", c_void_p), ("ret_moments", c_void_p)]
+                ("ret_exchange", c_void_p), ("ret_exchange_ctx", c_void_p), ("ret_moments", c_void_p),
+                ("critic_n_networks", c_int32), ("critic_net_of", c_int32 * 16)]
 
 
 class RetStatsStruct(ctypes.Structure):

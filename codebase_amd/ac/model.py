@@ -44,9 +44,9 @@ class A2CNetwork:
         obs_dims = [flatdim(o) for o in obs_space]
         act_dims = [flatdim(a) for a in action_space]
         self.n_agents = P = len(obs_dims)
+        # actor.parameter_sharing and critic.parameter_sharing are separate settings (ac/model.py:45-97): two agent -> network maps
         self.sharing = sharing_indices(_get(actor, "parameter_sharing", False), P)
-        if sharing_indices(_get(critic, "parameter_sharing", False), P) != self.sharing:
-            raise NotImplementedError("actor.parameter_sharing != critic.parameter_sharing: one agent -> network map serves both")
+        self.critic_sharing = sharing_indices(_get(critic, "parameter_sharing", False), P)
         self.recurrent = bool(_get(actor, "use_rnn", False))
         if bool(_get(critic, "use_rnn", False)) != self.recurrent:
             raise NotImplementedError("actor.use_rnn != critic.use_rnn: the recurrent step is built for recurrent actors AND critics")
@@ -81,12 +81,17 @@ class A2CNetwork:
         self.standardise_returns = bool(_get(cfg, "standardise_returns", False))
         self.centralised_critic = bool(_get(critic, "centralised", False))  # MAA2C / MAPPO (model.py:62-66)
         self.spec = _hip.NetSpec(P, obs_dims[0], Hk, act_dims[0], self.sharing, wide=wide, n_hidden=len(ha))  # wide: actors and critics on the GEMM path
+        # the critics' view of the same shape under THEIR agent -> network map (get_value's forward rows, state_dict keys)
+        self.critic_spec = _hip.NetSpec(P, obs_dims[0], Hk, act_dims[0], self.critic_sharing, wide=wide, n_hidden=len(ha))
+        cdims = [self.n_agents * self.spec.obs_dim] * P if self.centralised_critic else list(obs_dims)  # critic_obs_shape (model.py:63-65)
         if self.sharing is not None:  # one network per distinct index, in order of first appearance (utils/models.py:209-240)
             first = [self.sharing.index(k) for k in range(max(self.sharing) + 1)]
             obs_dims, act_dims = [obs_dims[i] for i in first], [act_dims[i] for i in first]
-        K = self.spec.n_blocks
+        if self.critic_sharing is not None:
+            first = [self.critic_sharing.index(k) for k in range(max(self.critic_sharing) + 1)]
+            cdims = [cdims[i] for i in first]
+        K = self.critic_spec.n_blocks  # critic networks (the actors' count is len(obs_dims) = self.spec.n_blocks)
         # torch RNG consumption in the reference's order: actor nets, critic nets, target-critic nets (model.py:44-107)
-        cdims = [self.n_agents * self.spec.obs_dim] * K if self.centralised_critic else obs_dims  # critic_obs_shape (model.py:63-65)
         if self.recurrent:  # RNNNetwork inits (utils/models.py:83-94); init_flat_gru_params draws one set per call
             a0 = init_flat_gru_params(obs_dims, ha[0], act_dims, _get(actor, "use_orthogonal_init", True), sets=1)[0]
             c0 = init_flat_gru_params(cdims, hc[0], [1] * K, _get(critic, "use_orthogonal_init", True), sets=2)[0]  # critic, then the target's draws
@@ -104,7 +109,8 @@ class A2CNetwork:
                                       gamma=self.gamma, n_steps=self.n_steps, entropy_coef=self.entropy_coef,
                                       value_loss_coef=self.value_loss_coef, grad_clip=self.grad_clip,
                                       ppo_clip=float(_get(cfg, "ppo_clip", 0.2)), standardise_returns=self.standardise_returns,
-                                      centralised_critic=self.centralised_critic, recurrent=self.recurrent, optimizer=self.optimizer)
+                                      centralised_critic=self.centralised_critic, recurrent=self.recurrent, optimizer=self.optimizer,
+                                      critic_sharing=self.critic_sharing)
         self.ret_ms = self.updater.ret_stats
         self.actor_params, self.critic_params = self.updater.actor, self.updater.critic
 
@@ -127,7 +133,7 @@ class A2CNetwork:
         P, S, N, D = x.shape
         x = x.contiguous()
         h_in = None if hiddens is None or hiddens[0] is None else torch.stack([h.reshape(N, -1) for h in hiddens]).to(self.device).contiguous()
-        out, h = _hip.gru_ac_forward(self.spec, block, x, S * N * D, D, S, N, value_net=value_net, h_in=h_in, want_h=True)
+        out, h = _hip.gru_ac_forward(self.critic_spec if value_net else self.spec, block, x, S * N * D, D, S, N, value_net=value_net, h_in=h_in, want_h=True)
         return out, [h[p].reshape(1, N, -1) for p in range(P)]
 
     def forward(self, inputs, rnn_hxs, masks):
@@ -167,7 +173,7 @@ class A2CNetwork:
             x = (x.unsqueeze(0) if one else x).contiguous()  # [S][N][P*D]
             S_, N = x.shape[0], x.shape[1]
             h_in = None if critic_hiddens is None or critic_hiddens[0] is None else torch.stack([h.reshape(N, -1) for h in critic_hiddens]).to(self.device).contiguous()
-            out, h = _hip.gru_ac_forward(self.spec, blk, x, 0, x.shape[-1], S_, N, value_net=2, h_in=h_in, want_h=True)
+            out, h = _hip.gru_ac_forward(self.critic_spec, blk, x, 0, x.shape[-1], S_, N, value_net=2, h_in=h_in, want_h=True)
             out = out[..., 0]
             return (out[:, 0] if one else out).movedim(0, -1).contiguous(), [h[p].reshape(1, N, -1) for p in range(self.n_agents)]
         if self.recurrent:
@@ -179,11 +185,11 @@ class A2CNetwork:
             x = torch.cat([torch.as_tensor(i, dtype=torch.float32).to(self.device) for i in inputs], dim=-1)
             lead = x.shape[:-1]
             x = x.reshape(-1, x.shape[-1]).contiguous()
-            out = _hip.ac_forward_rows(self.spec, blk, x, 0, x.shape[1], x.shape[0], value_net=2)
+            out = _hip.ac_forward_rows(self.critic_spec, blk, x, 0, x.shape[1], x.shape[0], value_net=2)
             return out.reshape(self.n_agents, *lead).movedim(0, -1).contiguous(), critic_hiddens
         x, lead = self._rows(inputs)
         n, D = x.shape[1], x.shape[2]
-        out = _hip.ac_forward_rows(self.spec, blk, x, n * D, D, n, value_net=True)
+        out = _hip.ac_forward_rows(self.critic_spec, blk, x, n * D, D, n, value_net=True)
         return out.reshape(self.n_agents, *lead).movedim(0, -1).contiguous(), critic_hiddens
 
     def soft_update(self, t):
@@ -216,13 +222,15 @@ class A2CNetwork:
 
     # ---- torch-module-like surface ---------------------------------------------------------------
     def _views(self):
-        S, P = self.spec, self.spec.n_blocks
-        group = "independent" if self.sharing is None else "networks"
+        S = self.spec
         out = OrderedDict()
         self._shapes = {}  # recurrent networks: key -> the reference tensor's shape
         for prefix, block, A in (("actor", self.actor_params, S.n_actions), ("critic", self.critic_params, 1),
                                  ("target_critic", self.target_critic_params, 1)):
-            for i in range(P):
+            # MultiAgentIndependentNetwork.independent / MultiAgentSharedNetwork.networks, each family by its own parameter_sharing
+            sharing = self.sharing if prefix == "actor" else self.critic_sharing
+            group = "independent" if sharing is None else "networks"
+            for i in range(block.shape[0]):
                 cin = S.n_agents * S.obs_dim if (self.centralised_critic and prefix != "actor") else S.obs_dim
                 if not self.recurrent:  # the live tensors inside the (possibly zero-padded) blocks
                     for name, view in block_views(block[i], cin, self.live_hidden[prefix], A, S.hidden):

@@ -590,6 +590,17 @@ int ac_step_t(int P, const AgentMap& am, const float* actor, const float* critic
               int mode, void* ws, int64_t ws_bytes, float* actor_grad, float* critic_grad, float* metrics, hipStream_t st) {
     const int D = SA::D, A = SA::A, DC = SC::D;  // (run-time values for the wide networks)
     const int T = bt->max_len, B = bt->batch, TB = T * B;
+    // critic.parameter_sharing is its own setting (ac/model.py:68-97): the critics and target critics follow marlhip_ac_config's map when it is given
+    AgentMap amc = am;
+    if (c->critic_n_networks > 0) {
+        MARL_REQUIRE(c->critic_n_networks <= P, "ac_loss_grad: %d critic networks for %d agents", c->critic_n_networks, P);
+        amc.nblk = c->critic_n_networks;
+        for (int i = 0; i < 16; ++i) {
+            const int k = i < P ? c->critic_net_of[i] : 0;
+            MARL_REQUIRE(k >= 0 && k < c->critic_n_networks, "ac_loss_grad: critic_net_of[%d] = %d out of range", i, k);
+            amc.net[i] = (int8_t)k;
+        }
+    }
     marlhip_batch btc = *bt;  // the critics' view of the batch
     if (DC != D) btc.obs_agent_stride = -1;
     const marlhip_batch* bc = &btc;
@@ -624,7 +635,7 @@ int ac_step_t(int P, const AgentMap& am, const float* actor, const float* critic
             if (!side.ok()) return -2;
             float* pk = reinterpret_cast<float*>(base + wl.bwd_c + gru_rows_ws<SC>(P, T, B, false).packF);
             side.do_fork();
-            return gru_forward_rows<SC>(P, am, prm, bc, steps, out, side.s, rec, pk);
+            return gru_forward_rows<SC>(P, amc, prm, bc, steps, out, side.s, rec, pk);
         } else {
             (void)prm; (void)steps; (void)out; (void)rec;
             return -2;
@@ -632,16 +643,16 @@ int ac_step_t(int P, const AgentMap& am, const float* actor, const float* critic
     };
     if (mode == 1) {
         rc = side_forward(target, T + 1, f(wl.vnext), nullptr);
-        if (rc == -2) rc = launch_forward_rows<SC>(P, am, target, bc, TB + B, f(wl.vnext), st);
+        if (rc == -2) rc = launch_forward_rows<SC>(P, amc, target, bc, TB + B, f(wl.vnext), st);
         if (rc != 0) return rc;
     } else if (mode != 2) {  // target-critic values of all T+1 observations (model.py:190-193); PPO reuses the returns across epochs
         if constexpr (IsGru<SC>::value) {  // recurrent critics: the critics' own pass rides in the same launch (each fills half the chip)
-            rc = gru_forward_rows_pair<SC>(P, am, critic, target, bc, T, T + 1, f(wl.v), f(wl.vnext), st, rec_c);
+            rc = gru_forward_rows_pair<SC>(P, amc, critic, target, bc, T, T + 1, f(wl.v), f(wl.vnext), st, rec_c);
             if (rc != 0) return rc;
             v_done = true;
         }
         if (!v_done) {
-            rc = launch_forward_rows<SC>(P, am, target, bc, TB + B, f(wl.vnext), st);
+            rc = launch_forward_rows<SC>(P, amc, target, bc, TB + B, f(wl.vnext), st);
             if (rc != 0) return rc;
         }
     }
@@ -653,7 +664,7 @@ int ac_step_t(int P, const AgentMap& am, const float* actor, const float* critic
     }
     if (mode != 1 && !v_done) {  // (forked before the actors' pass is queued, or there is nothing to overlap with)
         rc = side_forward(critic, T, f(wl.v), rec_c);
-        if (rc == -2) rc = launch_forward_rows<SC>(P, am, critic, bc, TB, f(wl.v), st, rec_c);
+        if (rc == -2) rc = launch_forward_rows<SC>(P, amc, critic, bc, TB, f(wl.v), st, rec_c);
         if (rc != 0) return rc;
     }
     rc = launch_forward_rows<SA>(P, am, actor, bt, TB, f(wl.logits), st, rec_a);
@@ -672,7 +683,7 @@ int ac_step_t(int P, const AgentMap& am, const float* actor, const float* critic
         side.do_fork();
         st_c = side.s;
     }
-    rc = launch_backward_rows<SC>(P, am, critic, bc, w.dv, w.lrow_v, base + wl.bwd_c, ws_bytes - wl.bwd_c, critic_grad, scratch + 2, st_c, rec_c);
+    rc = launch_backward_rows<SC>(P, amc, critic, bc, w.dv, w.lrow_v, base + wl.bwd_c, ws_bytes - wl.bwd_c, critic_grad, scratch + 2, st_c, rec_c);
     const int rc_a = launch_backward_rows<SA>(P, am, actor, bt, w.dlogits, w.lrow_a, base + wl.bwd, wl.bwd_c != wl.bwd ? wl.bwd_c - wl.bwd : ws_bytes - wl.bwd,
                                               actor_grad, scratch, st, rec_a);
     side.do_join();

@@ -820,7 +820,25 @@ __device__ __forceinline__ void dqn_reduce_body(const float* __restrict__ partia
                                                 float* __restrict__ grad, float* __restrict__ loss, float* __restrict__ sumsq_out,
                                                 const ReduceP2p* x = nullptr) {
     __shared__ float s_red[8];
+    __shared__ float s_part[4][64];
     const int rec = nparam + 2;
+    // 64 parameters per block, the record range split over the 4 waves (4x the loads in flight and 4x
+    // the blocks of a thread-per-parameter loop); fixed summation order: slice-local in w order, then
+    // (s0 + s1) + (s2 + s3).  Requested FIRST: these loads do not depend on n_filled, and at the reference's cadence (a dozen records per
+    // agent) the launch is two dependent round trips to L2 if the n_filled reduction and its barrier sit in front of them (round 5)
+    const int l64 = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + l64;
+    float acc = 0.f;
+    // grad is [am.nblk][nparam]: a shared network's gradient is the sum over its agents, in agent order
+    if (i < am.nblk * nparam) {
+        const int blk = i / nparam, k = i - blk * nparam;
+        for (int p = 0; p < P; ++p) {
+            if (am.net[p] != blk) continue;
+            const float* src = partials + (size_t)p * nwg * rec + k;
+#pragma unroll 8
+            for (int w = slice; w < nwg; w += 4) acc += src[(size_t)w * rec];
+        }
+    }
     // n_filled (agent 0's records) and the loss sum (all records): strided loads + fixed-order tree
     float nf = 0.f, ls = 0.f;
     for (int w = threadIdx.x; w < P * nwg; w += 256) {
@@ -836,28 +854,10 @@ __device__ __forceinline__ void dqn_reduce_body(const float* __restrict__ partia
         s_red[threadIdx.x >> 6] = nf;
         s_red[4 + (threadIdx.x >> 6)] = ls;
     }
+    s_part[slice][l64] = acc;
     __syncthreads();
     nf = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
     ls = (s_red[4] + s_red[5]) + (s_red[6] + s_red[7]);
-    // 64 parameters per block, the record range split over the 4 waves (4x the loads in flight and 4x
-    // the blocks of a thread-per-parameter loop); fixed summation order: slice-local in w order, then
-    // (s0 + s1) + (s2 + s3)
-    __shared__ float s_part[4][64];
-    const int l64 = threadIdx.x & 63, slice = threadIdx.x >> 6;
-    const int i = blockIdx.x * 64 + l64;
-    float acc = 0.f;
-    // grad is [am.nblk][nparam]: a shared network's gradient is the sum over its agents, in agent order
-    if (i < am.nblk * nparam) {
-        const int blk = i / nparam, k = i - blk * nparam;
-        for (int p = 0; p < P; ++p) {
-            if (am.net[p] != blk) continue;
-            const float* src = partials + (size_t)p * nwg * rec + k;
-#pragma unroll 8
-            for (int w = slice; w < nwg; w += 4) acc += src[(size_t)w * rec];
-        }
-    }
-    s_part[slice][l64] = acc;
-    __syncthreads();
     float gv = 0.f;
     if (slice == 0) {
         const bool in = i < am.nblk * nparam;
@@ -1046,6 +1046,12 @@ __device__ __forceinline__ void adam_pack_body(int i, int n, int nsq, float* __r
     constexpr int TOT = 2 * S::NFWD + S::NBWD;
     __shared__ float s_coef;
     __shared__ float s_red[4];
+    // this thread's operands, requested BEFORE the clip-norm reduction and its barriers: they do not depend on the coefficient (round 5:
+    // one round trip to L2 per launch instead of two at the reference's cadence, where the launch is nothing but latency)
+    const bool mine = i >= 0 && i < n;
+    const float g_raw = mine ? grad[i] : 0.f, m_old = mine ? m[i] : 0.f, v_old = mine ? v[i] : 0.f, p_old = mine ? params[i] : 0.f;
+    const bool tgt = a.hard_update || a.tau > 0.f;
+    const float t_old = (mine && tgt && !a.hard_update) ? target[i] : 0.f;
     {
         float ss = 0.f;
         if (nsq > 0) {
@@ -1081,21 +1087,20 @@ __device__ __forceinline__ void adam_pack_body(int i, int n, int nsq, float* __r
         if (gnorm_out != nullptr && blockIdx.x == 0) gnorm_out[0] = total;
     }
     __syncthreads();
-    if (i < 0 || i >= n) return;
-    const float gv = (grad[i] * a.grad_scale) * s_coef;
-    float mi = m[i], vi = v[i];
+    if (!mine) return;
+    const float gv = (g_raw * a.grad_scale) * s_coef;
+    float mi = m_old, vi = v_old;
     mi = mi + a.w1 * (gv - mi);
     vi = vi * a.beta2 + a.w2 * gv * gv;
     const float denom = sqrtf(vi) / a.bc2_sqrt + a.eps;
-    float pi = params[i];
+    float pi = p_old;
     pi = pi + (-a.lr_step) * (mi / denom);
     m[i] = mi;
     v[i] = vi;
     params[i] = pi;
     float ti = 0.f;
-    const bool tgt = a.hard_update || a.tau > 0.f;
     if (tgt) {
-        ti = a.hard_update ? pi : (1.f - a.tau) * target[i] + a.tau * pi;
+        ti = a.hard_update ? pi : (1.f - a.tau) * t_old + a.tau * pi;
         target[i] = ti;
     }
     const int blk = i / S::NPARAM, k = i - blk * S::NPARAM;

@@ -615,7 +615,9 @@ class AcUpdater:
 
     def __init__(self, spec: NetSpec, block, target_critic, lr=3e-4, betas=(0.9, 0.999), eps=1e-8, gamma=0.99, n_steps=5,
                  entropy_coef=0.001, value_loss_coef=0.5, grad_clip=False, ppo_clip=0.2, standardise_returns=False,
-                 centralised_critic=False, recurrent=False, optimizer="Adam"):
+                 centralised_critic=False, recurrent=False, optimizer="Adam", critic_sharing="actor"):
+        """critic_sharing: the critics' agent -> network map when critic.parameter_sharing differs from actor.parameter_sharing
+        (ac/model.py:45-97): "actor" (default) = spec.sharing for both, None = one critic per agent, or a tuple of network indices"""
         _require_gpu()
         self.optimizer = optimizer_id(optimizer)
         self.recurrent = bool(recurrent)  # use_rnn actors and critics: the marlhip_gru_* entry points, recurrent block layout
@@ -632,14 +634,19 @@ class AcUpdater:
             self.n_actor = spec.nparams()
             self.n_critic = check(lib.marlhip_ac_critic_nparams(ctypes.byref(s), self.centralised), "ac_critic_nparams")
         P = spec.n_blocks
-        if block.numel() != P * (self.n_actor + self.n_critic) or target_critic.numel() != P * self.n_critic:
+        if isinstance(critic_sharing, str):
+            self.critic_sharing = spec.sharing
+        else:
+            self.critic_sharing = None if critic_sharing is None else tuple(int(k) for k in critic_sharing)
+        Kc = spec.n_agents if self.critic_sharing is None else max(self.critic_sharing) + 1
+        if block.numel() != P * self.n_actor + Kc * self.n_critic or target_critic.numel() != Kc * self.n_critic:
             raise ValueError("actor-critic parameter block has the wrong size for this shape")
         self.block, self.target_critic = block, target_critic
         self.actor = block[:P * self.n_actor].view(P, self.n_actor)
-        self.critic = block[P * self.n_actor:].view(P, self.n_critic)
+        self.critic = block[P * self.n_actor:].view(Kc, self.n_critic)
         self.grad = torch.zeros_like(block)
         self.actor_grad = self.grad[:P * self.n_actor].view(P, self.n_actor)
-        self.critic_grad = self.grad[P * self.n_actor:].view(P, self.n_critic)
+        self.critic_grad = self.grad[P * self.n_actor:].view(Kc, self.n_critic)
         self.exp_avg, self.exp_avg_sq = torch.zeros_like(block), torch.zeros_like(block)
         self.scratch = torch.zeros((block.numel() + 255) // 256 + 1, dtype=torch.float32, device=block.device)
         self.gnorm = torch.zeros(1, dtype=torch.float32, device=block.device)
@@ -648,6 +655,13 @@ class AcUpdater:
         self.cfg = AcConfig(int(n_steps), float(entropy_coef), float(value_loss_coef), float(ppo_clip), float(gamma),
                             rs.mean.data_ptr() if rs else None, rs.var.data_ptr() if rs else None,
                             rs.count_t.data_ptr() if rs else None, self.centralised, None)
+        if self.critic_sharing != spec.sharing:  # two agent -> network maps: the critics' rides in the config
+            cmap = self.critic_sharing if self.critic_sharing is not None else tuple(range(spec.n_agents))
+            if len(cmap) != spec.n_agents or spec.n_agents > 16:
+                raise ValueError("critic sharing indices: one per agent, at most 16 agents")
+            self.cfg.critic_n_networks = max(cmap) + 1
+            for i, k in enumerate(cmap):
+                self.cfg.critic_net_of[i] = int(k)
         if self.recurrent:
             # recurrent actors + critics: the critics' sequence passes overlap the actors' on this second stream (joined inside the call)
             self._side = torch.cuda.Stream(device=block.device)

@@ -518,6 +518,11 @@ typedef struct marlhip_ac_config {
     int (*ret_exchange)(void* ctx, double* buf, int64_t count, void* stream);
     void* ret_exchange_ctx;
     double* ret_moments;        /* [2P + 1] device scratch */
+    /* C-ABI 212: critic.parameter_sharing different from actor.parameter_sharing (ac/model.py:45-97 builds the two families from their own
+     * settings).  critic_n_networks > 0: the critics (and target critics) use THIS agent -> network map - critic / target_critic / critic_grad
+     * are then [critic_n_networks][n] blocks - while the actors keep marlhip_net_shape's; 0: one map for both (the default). */
+    int32_t critic_n_networks;
+    int32_t critic_net_of[16];
 } marlhip_ac_config;
 
 int marlhip_ac_critic_nparams(const marlhip_net_shape* s, int32_t centralised); /* per critic block */

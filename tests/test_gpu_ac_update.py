@@ -290,3 +290,40 @@ def test_wide_centralised_critics_with_shared_networks_vs_oracle_port(P, T, N, D
     np.testing.assert_allclose(got[:4], ref, rtol=5e-5, atol=5e-6)
     assert_grad_close(up.actor_grad.cpu().numpy(), a.grad.numpy(), 3e-4)
     assert_grad_close(up.critic_grad.cpu().numpy(), c.grad.numpy(), 3e-4)
+
+
+# ---- round 5: actor.parameter_sharing != critic.parameter_sharing (ac/model.py:45-97: two agent -> network maps) -------------------------
+@pytest.mark.parametrize("name,cls_name", [("learner_a2c_mixed_sharing_H64.npz", "A2CNetwork"), ("learner_ppo_mixed_sharing_p3_H64.npz", "PPONetwork")])
+def test_actor_and_critic_with_their_own_parameter_sharing_match_reference_golden(name, cls_name):
+    """one shared actor next to independent critics (A2C), SePS actors [0, 0, 1] next to ONE shared centralised critic (PPO): the reference's
+    state_dict keys (`actor.networks.*` beside `critic.independent.*` and the other way round), metrics and blocks of 3 x update() with
+    clipping over actor AND critic and the step-keyed target copy"""
+    from codebase_amd.ac import model as acm
+    from codebase_amd.spaces import Box, Discrete, Tuple
+
+    g = load(name)
+    P, D, H, A = int(g["P"]), int(g["D"]), int(g["H"]), int(g["A"])
+    a_sh = True if (int(g["actor_is_shared"]) and len(set(g["actor_sharing"].tolist())) == 1) else ([int(i) for i in g["actor_sharing"]] if int(g["actor_is_shared"]) else False)
+    c_sh = True if (int(g["critic_is_shared"]) and len(set(g["critic_sharing"].tolist())) == 1) else ([int(i) for i in g["critic_sharing"]] if int(g["critic_is_shared"]) else False)
+    cfg = dict(optimizer="Adam", lr=3e-4, gamma=0.99, grad_clip=float(g["grad_clip"]), n_steps=5, entropy_coef=0.001, value_loss_coef=0.5,
+               standardise_returns=False, target_update_interval_or_tau=200, num_epochs=4, ppo_clip=0.2)
+    base = dict(layers=[H, H], use_orthogonal_init=True, use_rnn=False)
+    net = getattr(acm, cls_name)(Tuple([Box(-1, 8, (D,)) for _ in range(P)]), Tuple([Discrete(A) for _ in range(P)]), cfg,
+                                dict(base, parameter_sharing=a_sh), dict(base, parameter_sharing=c_sh, centralised=bool(int(g["centralised"]))), "cuda")
+    assert list(net.state_dict().keys()) == [str(k) for k in g["keys"]]
+    assert tuple(net.actor_params.shape) == g["actor0"].shape and tuple(net.critic_params.shape) == g["critic0"].shape
+    net.actor_params.copy_(torch.tensor(g["actor0"]))
+    net.critic_params.copy_(torch.tensor(g["critic0"]))
+    net.target_critic_params.copy_(torch.tensor(g["target0"]))
+    # A2CNetwork.get_value through the critics' own map
+    b0 = golden_ac_batch(g, 0)
+    for i in range(3):
+        b = dev_ac_batch(golden_ac_batch(g, i))
+        m = net.update(b, int(g["steps"][i]))
+        np.testing.assert_allclose([m["loss"], m["actor_loss"], m["value_loss"], m["entropy"]], g["metrics"][i], rtol=5e-5, atol=5e-6)
+        np.testing.assert_allclose(net.actor_params.cpu().numpy(), g[f"actor{i + 1}"], rtol=0, atol=5e-6)
+        np.testing.assert_allclose(net.critic_params.cpu().numpy(), g[f"critic{i + 1}"], rtol=0, atol=5e-6)
+        np.testing.assert_allclose(net.target_critic_params.cpu().numpy(), g[f"target{i + 1}"], rtol=0, atol=5e-6)
+    obs = [b0["obss"][0, :, p * D:(p + 1) * D].to(DEV) for p in range(P)]
+    v, _ = net.get_value(obs, net.init_critic_hiddens(obs[0].shape[0]))
+    assert tuple(v.shape) == (obs[0].shape[0], P)
