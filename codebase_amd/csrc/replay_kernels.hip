@@ -9,30 +9,48 @@
 
 namespace marl {
 
-// grid (ceil(N * D / 256), P): one thread per observation element of one agent, 32-bit index arithmetic (the element-linear form
-// with three 64-bit divisions per element was ALU-bound: 0.9 TB/s at 2^20 envs).  Reads are coalesced; the writes are the replay's
-// D-float rows ((T + 1) * D floats apart per agent), i.e. partial lines by layout.
+// grid (ceil(N * D / (256 * ADD_ITEMS)), P): a thread takes ADD_ITEMS observation elements of one agent, one per block-wide stride (a wave's
+// 64 lanes stay on 64 consecutive elements = 4.3 rows: coalesced reads, whole-row stores), 32-bit index arithmetic.  The writes are the
+// replay's D-float rows ((T + 1) * D floats apart per agent): partial lines by layout.  Round 5: with ONE 4-byte element per thread the
+// kernel was bound by bytes in flight, not by HBM - a full chip of resident threads holds 2 MB of payload against ~1.5 us of dependent
+// slot / step -> address -> store latency (0.93 TB/s of algorithmic bytes at 2^20 envs while the memory-side counters read 2 TB/s of
+// sector traffic: profiles/r05_hbm_ubench_pmc.md); every thread now requests all its index words and elements before its first store.
+constexpr int ADD_ITEMS = 4;
 __global__ __launch_bounds__(256) void replay_add_kernel(marlhip_replay_shape rs, marlhip_replay_buffers rb,
                                                          const int32_t* __restrict__ slot, const int32_t* __restrict__ tt,
                                                          const uint8_t* __restrict__ active, const float* __restrict__ obs,
                                                          const int32_t* __restrict__ actions, const float* __restrict__ rewards,
                                                          const uint8_t* __restrict__ done, int N, int init_only) {
-    const int P = rs.n_agents, D = rs.obs_dim, T = rs.max_len;
-    const uint32_t nd = blockIdx.x * 256u + threadIdx.x;
-    if (nd >= (uint32_t)N * (uint32_t)D) return;
-    const int n = (int)(nd / (uint32_t)D), d = (int)(nd - (uint32_t)n * (uint32_t)D), p = blockIdx.y;
-    if (active != nullptr && !active[n]) return;
-    const int row = init_only ? 0 : tt[n] + 1;
-    if (row > T) return;  // reference asserts t < max_episode_length (train.py:74)
-    const size_t sp = (size_t)slot[n] * P + p;
-    rb.obs[(sp * (T + 1) + row) * D + d] = obs[(size_t)p * N * D + nd];
-    if (d == 0 && !init_only) {
-        const int t = tt[n];
-        rb.act[sp * T + t] = (uint8_t)actions[(size_t)p * N + n];
-        rb.rew[sp * T + t] = rewards[(size_t)p * N + n];
-        if (p == 0) {
-            rb.done[(size_t)slot[n] * (T + 1) + t + 1] = done[n] ? 1 : 0;
-            rb.filled[(size_t)slot[n] * T + t] = 1;
+    const int P = rs.n_agents, D = rs.obs_dim, T = rs.max_len, p = blockIdx.y;
+    const uint32_t total = (uint32_t)N * (uint32_t)D, stride = gridDim.x * 256u;
+    uint32_t nd[ADD_ITEMS];
+    int n[ADD_ITEMS], sl[ADD_ITEMS], t[ADD_ITEMS];
+    float v[ADD_ITEMS];
+    bool ok[ADD_ITEMS];
+#pragma unroll
+    for (int k = 0; k < ADD_ITEMS; ++k) {  // every request of the thread first (clamped addresses, masks applied at the stores)
+        nd[k] = blockIdx.x * 256u + threadIdx.x + (uint32_t)k * stride;
+        const uint32_t c = nd[k] < total ? nd[k] : total - 1;
+        n[k] = (int)(c / (uint32_t)D);
+        sl[k] = slot[n[k]];
+        t[k] = init_only ? -1 : tt[n[k]];
+        ok[k] = nd[k] < total && (active == nullptr || active[n[k]] != 0);
+        v[k] = obs[(size_t)p * N * D + c];
+    }
+#pragma unroll
+    for (int k = 0; k < ADD_ITEMS; ++k) {
+        const int row = t[k] + 1;
+        if (!ok[k] || row > T) continue;  // reference asserts t < max_episode_length (train.py:74)
+        const int d = (int)(nd[k] - (uint32_t)n[k] * (uint32_t)D);
+        const size_t sp = (size_t)sl[k] * P + p;
+        rb.obs[(sp * (T + 1) + row) * D + d] = v[k];
+        if (d == 0 && !init_only) {
+            rb.act[sp * T + t[k]] = (uint8_t)actions[(size_t)p * N + n[k]];
+            rb.rew[sp * T + t[k]] = rewards[(size_t)p * N + n[k]];
+            if (p == 0) {
+                rb.done[(size_t)sl[k] * (T + 1) + t[k] + 1] = done[n[k]] ? 1 : 0;
+                rb.filled[(size_t)sl[k] * T + t[k]] = 1;
+            }
         }
     }
 }
@@ -256,7 +274,7 @@ extern "C" int marlhip_replay_init_episode(const marlhip_replay_shape* rs, const
     if (check_replay(rs, rb) != 0) return -1;
     MARL_REQUIRE(slot && obs && n_envs > 0, "replay_init_episode: NULL pointer");
     MARL_REQUIRE((int64_t)n_envs * rs->obs_dim < ((int64_t)1 << 31), "replay_init_episode: n_envs * obs_dim must stay below 2^31");
-    hipLaunchKernelGGL(replay_add_kernel, dim3((unsigned)(((int64_t)n_envs * rs->obs_dim + 255) / 256), rs->n_agents), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(replay_add_kernel, dim3((unsigned)(((int64_t)n_envs * rs->obs_dim + 256 * ADD_ITEMS - 1) / (256 * ADD_ITEMS)), rs->n_agents), dim3(256), 0, (hipStream_t)stream,
                        *rs, *rb, slot, (const int32_t*)nullptr, active, obs, (const int32_t*)nullptr, (const float*)nullptr,
                        (const uint8_t*)nullptr, n_envs, 1);
     MARL_CHECK_LAUNCH("replay_init_episode");
@@ -269,7 +287,7 @@ extern "C" int marlhip_replay_add(const marlhip_replay_shape* rs, const marlhip_
     if (check_replay(rs, rb) != 0) return -1;
     MARL_REQUIRE(slot && t && obs && actions && rewards && done && n_envs > 0, "replay_add: NULL pointer");
     MARL_REQUIRE((int64_t)n_envs * rs->obs_dim < ((int64_t)1 << 31), "replay_add: n_envs * obs_dim must stay below 2^31");
-    hipLaunchKernelGGL(replay_add_kernel, dim3((unsigned)(((int64_t)n_envs * rs->obs_dim + 255) / 256), rs->n_agents), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(replay_add_kernel, dim3((unsigned)(((int64_t)n_envs * rs->obs_dim + 256 * ADD_ITEMS - 1) / (256 * ADD_ITEMS)), rs->n_agents), dim3(256), 0, (hipStream_t)stream,
                        *rs, *rb, slot, t, active, obs, actions, rewards, done, n_envs, 0);
     MARL_CHECK_LAUNCH("replay_add");
     return 0;
@@ -283,19 +301,35 @@ __global__ __launch_bounds__(256) void replay_add_step_kernel(marlhip_replay_sha
                                                               int proper_term, const uint8_t* __restrict__ alive, const float* __restrict__ obs,
                                                               const int32_t* __restrict__ actions, const float* __restrict__ rewards,
                                                               const uint8_t* __restrict__ done, const uint8_t* __restrict__ trunc, int N) {
-    const int P = rs.n_agents, D = rs.obs_dim, T = rs.max_len;
-    const uint32_t nd = blockIdx.x * 256u + threadIdx.x;
-    if (nd >= (uint32_t)N * (uint32_t)D) return;
-    const int n = (int)(nd / (uint32_t)D), d = (int)(nd - (uint32_t)n * (uint32_t)D), p = blockIdx.y;
-    if (!alive[n] || t + 1 > T) return;
-    const size_t sp = (size_t)slot[n] * P + p;
-    rb.obs[(sp * (T + 1) + t + 1) * D + d] = obs[(size_t)p * N * D + nd];
-    if (d == 0) {
-        rb.act[sp * T + t] = (uint8_t)actions[(size_t)p * N + n];
-        rb.rew[sp * T + t] = rewards[(size_t)p * N + n];
-        if (p == 0) {
-            rb.done[(size_t)slot[n] * (T + 1) + t + 1] = (proper_term ? done[n] != 0 : (done[n] | trunc[n]) != 0) ? 1 : 0;
-            rb.filled[(size_t)slot[n] * T + t] = 1;
+    const int P = rs.n_agents, D = rs.obs_dim, T = rs.max_len, p = blockIdx.y;
+    if (t + 1 > T) return;
+    const uint32_t total = (uint32_t)N * (uint32_t)D, stride = gridDim.x * 256u;
+    uint32_t nd[ADD_ITEMS];
+    int n[ADD_ITEMS], sl[ADD_ITEMS];
+    float v[ADD_ITEMS];
+    bool ok[ADD_ITEMS];
+#pragma unroll
+    for (int k = 0; k < ADD_ITEMS; ++k) {  // (as replay_add_kernel: all requests before the first store)
+        nd[k] = blockIdx.x * 256u + threadIdx.x + (uint32_t)k * stride;
+        const uint32_t c = nd[k] < total ? nd[k] : total - 1;
+        n[k] = (int)(c / (uint32_t)D);
+        sl[k] = slot[n[k]];
+        ok[k] = nd[k] < total && alive[n[k]] != 0;
+        v[k] = obs[(size_t)p * N * D + c];
+    }
+#pragma unroll
+    for (int k = 0; k < ADD_ITEMS; ++k) {
+        if (!ok[k]) continue;
+        const int d = (int)(nd[k] - (uint32_t)n[k] * (uint32_t)D);
+        const size_t sp = (size_t)sl[k] * P + p;
+        rb.obs[(sp * (T + 1) + t + 1) * D + d] = v[k];
+        if (d == 0) {
+            rb.act[sp * T + t] = (uint8_t)actions[(size_t)p * N + n[k]];
+            rb.rew[sp * T + t] = rewards[(size_t)p * N + n[k]];
+            if (p == 0) {
+                rb.done[(size_t)sl[k] * (T + 1) + t + 1] = (proper_term ? done[n[k]] != 0 : (done[n[k]] | trunc[n[k]]) != 0) ? 1 : 0;
+                rb.filled[(size_t)sl[k] * T + t] = 1;
+            }
         }
     }
 }
@@ -311,7 +345,7 @@ extern "C" int marlhip_replay_add_step(const marlhip_replay_shape* rs, const mar
     if (check_replay(rs, rb) != 0) return -1;
     MARL_REQUIRE(slot && alive && obs && actions && rewards && done && truncated && n_envs > 0 && t >= 0, "replay_add_step: bad argument");
     MARL_REQUIRE((int64_t)n_envs * rs->obs_dim < ((int64_t)1 << 31), "replay_add_step: n_envs * obs_dim must stay below 2^31");
-    hipLaunchKernelGGL(replay_add_step_kernel, dim3((unsigned)(((int64_t)n_envs * rs->obs_dim + 255) / 256), rs->n_agents), dim3(256), 0,
+    hipLaunchKernelGGL(replay_add_step_kernel, dim3((unsigned)(((int64_t)n_envs * rs->obs_dim + 256 * ADD_ITEMS - 1) / (256 * ADD_ITEMS)), rs->n_agents), dim3(256), 0,
                        (hipStream_t)stream, *rs, *rb, slot, t, use_proper_termination, (const uint8_t*)alive, obs, actions, rewards, done, truncated, n_envs);
     hipLaunchKernelGGL(clear_alive_kernel, dim3((n_envs + 255) / 256), dim3(256), 0, (hipStream_t)stream, n_envs, alive, done, truncated);
     MARL_CHECK_LAUNCH("replay_add_step");

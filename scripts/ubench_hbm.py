@@ -74,4 +74,10 @@ dt = timed(lambda: rb.add(slot, tt, env.obs, acts, rew, done), 10)
 per = 4 * P * D + 4 * P * D + 4 * P + P + 4 * P + 4 * P + 1 + 1 + 1 + 8  # read obs/act/rew/done/slot/t, write rows
 out["replay_add_kernel"] = dict(n_envs=N, bytes_per_env_step=per, us=dt * 1e6, achieved_GBs=per * N / dt / 1e9,
                                 frac_of_8TBs=per * N / dt / 1e9 / PEAK)
+# what the collectors do: N consecutive slots of the ring (rows of consecutive envs a whole episode record apart, in order)
+slot_seq = ((torch.arange(N, device="cuda") + 12345) % CAP).to(torch.int32)
+tt_same = torch.full((N,), 7, dtype=torch.int32, device="cuda")
+dt = timed(lambda: rb.add(slot_seq, tt_same, env.obs, acts, rew, done), 10)
+out["replay_add_kernel_consecutive_slots"] = dict(n_envs=N, bytes_per_env_step=per, us=dt * 1e6, achieved_GBs=per * N / dt / 1e9,
+                                                  frac_of_8TBs=per * N / dt / 1e9 / PEAK)
 print(json.dumps(out))

@@ -46,7 +46,7 @@ def test_gpus_flag_under_torchrun_and_mismatch_dryrun():
 def test_bench_gpus_2_runs_two_ranks_on_the_real_kernels(algo):
     """Two ranks share cuda:0 over gloo (the RCCL path differs only in the backend string): the JSON line must say 2."""
     out = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "2", "--warmup", "1", "--envs", "256", "--algo", algo,
-                          "--no-cpu-baseline"], cwd=ROOT, env=_env(MARLHIP_BENCH_BACKEND="gloo", MARLHIP_BENCH_ONE_DEVICE="1"),
+                          "--no-cpu-baseline"], cwd=ROOT, env=_env(MARLHIP_BENCH_BACKEND="gloo", MARLHIP_BENCH_ONE_DEVICE="1", MARLHIP_P2P_SHARED_DEVICE="1"),
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     line = _json_line(out.stdout)
