@@ -300,7 +300,7 @@ def traffic_from_profile(key, variant=""):
     kernel's sources at the profiled head; when the sources in this tree hash differently the figure is NOT quoted: traffic null and
     the reason in `traffic_source`."""
     reason = "no committed PMC profile holds this workload"
-    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json"):  # the newest profile that holds this exact workload
+    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json"):  # the newest profile that holds this exact workload
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
             ent = pmc["workloads"].get(key)

@@ -1,7 +1,7 @@
 # round 5, call B: the whole GPU suite on the tree with the generic QMIX mixer stage, the critics' own sharing map, the reordered reduce / Adam
 # loads; the reference-cadence row before/after; the HBM micro-benchmarks under the traffic counters (WRITE_SIZE / FETCH_SIZE per kernel)
 O=$GRAFT_REPO_ROOT/gpurun_out/r5B; mkdir -p $O; R=$GRAFT_REPO_ROOT; cd $R
-( time timeout 1500 python -m pytest tests -m gpu -x -q --durations=15 ) 2>&1 | tail -45 | tee $O/pytest_gpu.log
+( time timeout 1500 python -m pytest tests -m gpu -q --maxfail=8 --durations=12 ) 2>&1 | tail -120 | tee $O/pytest_gpu.log
 B="python $R/bench.py --no-cpu-baseline --no-modes"
 for a in "--cadence reference --steps 3 --warmup 1" "--steps 40 --warmup 5" "--cadence reference --steps 3 --warmup 1 --hidden 128"; do
   timeout 300 $B $a 2>/dev/null | grep '^{' | python -c "
@@ -9,6 +9,9 @@ import sys,json
 for l in sys.stdin:
     d=json.loads(l);print('$a','->',round(d['value']/1e6,3),'M', round(d['ms_per_step'],3),'ms', {k[:14]:round(v['avg_us'],2) for k,v in d['kernels'].items()})"
 done 2>&1 | tee $O/rows.txt
+timeout 300 python $R/scripts/ubench_hbm.py 2>/dev/null | python -c "
+import sys,json
+for k,v in json.loads(sys.stdin.read()).items(): print('UBENCH',k,round(v['us'],1),'us',round(v['achieved_GBs']),'GB/s',round(v['frac_of_8TBs'],3))" | tee $O/ubench.txt
 cd /tmp; export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/stats_ref --output-format csv -- $B --cadence reference --steps 2 --warmup 1 --no-kernel-timing > $O/stats_ref.log 2>&1
 # where do the fills / copies of the forced one-rank data-parallel profile come from?  HIP API statistics of the same run

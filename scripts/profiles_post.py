@@ -35,6 +35,34 @@ def short(name):
     return n.split("(")[0]
 
 
+def hbm_pmc_table():
+    """profiles/rNN_hbm_ubench_pmc.md: scripts/ubench_hbm.py under the memory-side counters - sector traffic per launch of the HBM-side API
+    kernels next to their algorithmic bytes (WRITE_SIZE in KiB as reported; FETCH_SIZE doubled, MI355X_MICROARCH.md "HBM")"""
+    wr, fe = counters("hbm_WRITE_SIZE"), counters("hbm_FETCH_SIZE")
+    if not wr and not fe:
+        return
+    timed = {}
+    try:
+        timed = json.load(open(os.path.join(SRC, "hbm_ubench.txt")))
+    except (OSError, ValueError):
+        pass
+    with open(os.path.join(DST, PFX + "_hbm_ubench_pmc.md"), "w") as o:
+        o.write("# HBM-side API kernels under the memory-side counters (rocprofv3 --pmc WRITE_SIZE | FETCH_SIZE -- python scripts/ubench_hbm.py; " + PFX + ")\n\n"
+                "Per launch, mean over the launches of the run (several problem sizes share a kernel name: the max column is the largest one).  "
+                "read MB = 2 x FETCH_SIZE KiB (gfx950 tallies 128-B read requests at 64 B), write MB = WRITE_SIZE KiB.\n\n"
+                "| kernel | launches | write MB mean / max | read MB mean / max |\n|---|---|---|---|\n")
+        for k in sorted(set(wr) | set(fe)):
+            if "marl::" not in k:
+                continue
+            w, f = wr.get(k, {}).get("WRITE_SIZE", []), fe.get(k, {}).get("FETCH_SIZE", [])
+            o.write(f"| {short(k)[:60]} | {max(len(w), len(f))} | " + (f"{sum(w) / len(w) * 1.024e-3:.1f} / {max(w) * 1.024e-3:.1f}" if w else "-") + " | "
+                    + (f"{2 * sum(f) / len(f) * 1.024e-3:.1f} / {2 * max(f) * 1.024e-3:.1f}" if f else "-") + " |\n")
+        if timed:
+            o.write("\nTimed run of the same script (algorithmic bytes / measured time):\n\n| row | us | achieved GB/s | of 8 TB/s |\n|---|---|---|---|\n")
+            for k, v in timed.items():
+                o.write(f"| {k} | {v.get('us', 0):.1f} | {v.get('achieved_GBs', 0):.0f} | {v.get('frac_of_8TBs', 0):.3f} |\n")
+
+
 def main():
     hp = os.path.join(SRC, "head.txt") if os.path.exists(os.path.join(SRC, "head.txt")) else os.path.join(ROOT, "scripts", "_bin", "head.txt")
     head = open(hp).read().strip() if os.path.exists(hp) else None
@@ -44,7 +72,8 @@ def main():
                      ("stats_qmix8p", PFX + "_qmix_15x15_8p5f_H128_kernel_stats.csv"),
                      ("stats_maa2c8p", PFX + "_maa2c_15x15_8p5f_H128_kernel_stats.csv"), ("stats_mappo_rware", PFX + "_mappo_rware_tiny4ag_H128_kernel_stats.csv"),
                      ("stats_rware_ia2c64", PFX + "_rware_ia2c_tiny4ag_H64_kernel_stats.csv"), ("stats_ia2c64", PFX + "_ia2c_8x8_2p3f_H64_kernel_stats.csv"),
-                     ("stats_envonly", PFX + "_env_only_kernel_stats.csv")):
+                     ("stats_envonly", PFX + "_env_only_kernel_stats.csv"), ("stats_forcedist", PFX + "_forcedist_1rank_kernel_stats.csv"),
+                     ("stats_reference", PFX + "_reference_cadence_kernel_stats.csv"), ("stats_vdn4p", PFX + "_vdn_15x15_4p5f_H128_kernel_stats.csv")):
         f = first(f"{tag}/**/*_kernel_stats.csv")
         if f:
             shutil.copy(f, os.path.join(DST, out))
@@ -62,6 +91,10 @@ def main():
                     "   registers today) would not pay.\n")
     if os.path.exists(os.path.join(SRC, "hbm_ubench.txt")):
         shutil.copy(os.path.join(SRC, "hbm_ubench.txt"), os.path.join(DST, PFX + "_hbm_ubench.txt"))
+    for name in ("bench_default_line.json", "forcedist_line.json"):
+        if os.path.exists(os.path.join(SRC, name)) and os.path.getsize(os.path.join(SRC, name)) > 0:
+            shutil.copy(os.path.join(SRC, name), os.path.join(DST, PFX + "_" + name))
+    hbm_pmc_table()
     # ---- HBM traffic of the learner kernels (two TCC passes per workload; FETCH_SIZE doubled per MI355X_MICROARCH.md "HBM")
     P, D, T, B = 2, 15, 25, 4096
     alg_read = B * (4 * P * D * (T + 1) + P * T * 5 + (T + 1) + T)

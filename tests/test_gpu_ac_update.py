@@ -311,19 +311,35 @@ def test_actor_and_critic_with_their_own_parameter_sharing_match_reference_golde
     net = getattr(acm, cls_name)(Tuple([Box(-1, 8, (D,)) for _ in range(P)]), Tuple([Discrete(A) for _ in range(P)]), cfg,
                                 dict(base, parameter_sharing=a_sh), dict(base, parameter_sharing=c_sh, centralised=bool(int(g["centralised"]))), "cuda")
     assert list(net.state_dict().keys()) == [str(k) for k in g["keys"]]
-    assert tuple(net.actor_params.shape) == g["actor0"].shape and tuple(net.critic_params.shape) == g["critic0"].shape
-    net.actor_params.copy_(torch.tensor(g["actor0"]))
-    net.critic_params.copy_(torch.tensor(g["critic0"]))
-    net.target_critic_params.copy_(torch.tensor(g["target0"]))
+    assert net.actor_params.shape[0] == g["actor0"].shape[0] and net.critic_params.shape[0] == g["critic0"].shape[0]
+
+    # the reference's flat [K][n] blocks <-> the live tensors (views into blocks that may be zero-padded to a wider kernel: the 3-agent
+    # centralised critic runs at width 128), family by family in parameters() order
+    def family(prefix):
+        return [v for k, v in net._views().items() if k.startswith(prefix + ".")]
+
+    def put(prefix, flat):
+        o, flat = 0, torch.tensor(flat).reshape(-1)
+        for v in family(prefix):
+            v.copy_(flat[o:o + v.numel()].reshape(v.shape))
+            o += v.numel()
+        assert o == flat.numel(), (prefix, o, flat.numel())
+
+    def get(prefix):
+        return torch.cat([v.detach().reshape(-1) for v in family(prefix)]).cpu().numpy()
+
+    put("actor", g["actor0"])
+    put("critic", g["critic0"])
+    put("target_critic", g["target0"])
     # A2CNetwork.get_value through the critics' own map
     b0 = golden_ac_batch(g, 0)
     for i in range(3):
         b = dev_ac_batch(golden_ac_batch(g, i))
         m = net.update(b, int(g["steps"][i]))
         np.testing.assert_allclose([m["loss"], m["actor_loss"], m["value_loss"], m["entropy"]], g["metrics"][i], rtol=5e-5, atol=5e-6)
-        np.testing.assert_allclose(net.actor_params.cpu().numpy(), g[f"actor{i + 1}"], rtol=0, atol=5e-6)
-        np.testing.assert_allclose(net.critic_params.cpu().numpy(), g[f"critic{i + 1}"], rtol=0, atol=5e-6)
-        np.testing.assert_allclose(net.target_critic_params.cpu().numpy(), g[f"target{i + 1}"], rtol=0, atol=5e-6)
+        np.testing.assert_allclose(get("actor"), g[f"actor{i + 1}"].reshape(-1), rtol=0, atol=5e-6)
+        np.testing.assert_allclose(get("critic"), g[f"critic{i + 1}"].reshape(-1), rtol=0, atol=5e-6)
+        np.testing.assert_allclose(get("target_critic"), g[f"target{i + 1}"].reshape(-1), rtol=0, atol=5e-6)
     obs = [b0["obss"][0, :, p * D:(p + 1) * D].to(DEV) for p in range(P)]
     v, _ = net.get_value(obs, net.init_critic_hiddens(obs[0].shape[0]))
     assert tuple(v.shape) == (obs[0].shape[0], P)
