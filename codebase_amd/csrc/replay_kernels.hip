@@ -10,11 +10,14 @@
 namespace marl {
 
 // grid (ceil(N * D / (256 * ADD_ITEMS)), P): a thread takes ADD_ITEMS observation elements of one agent, one per block-wide stride (a wave's
-// 64 lanes stay on 64 consecutive elements = 4.3 rows: coalesced reads, whole-row stores), 32-bit index arithmetic.  The writes are the
-// replay's D-float rows ((T + 1) * D floats apart per agent): partial lines by layout.  Round 5: with ONE 4-byte element per thread the
-// kernel was bound by bytes in flight, not by HBM - a full chip of resident threads holds 2 MB of payload against ~1.5 us of dependent
-// slot / step -> address -> store latency (0.93 TB/s of algorithmic bytes at 2^20 envs while the memory-side counters read 2 TB/s of
-// sector traffic: profiles/r05_hbm_ubench_pmc.md); every thread now requests all its index words and elements before its first store.
+// 64 lanes stay on 64 consecutive elements = 4.3 rows: coalesced reads, whole-row stores), 32-bit index arithmetic, every request of the
+// thread in front of its first store.  The writes are the replay's D-float rows ((T + 1) * D floats apart per agent): partial lines by
+// LAYOUT - the replay is episode-major for the sampler's and the learner's sake, so one time step of N envs is 2 N scattered 60-byte rows
+// plus their 1- to 4-byte side records.  Round 5, under the memory-side counters (profiles/r05_hbm_ubench_pmc.md): 390 MB of write requests
+// per launch for 138 MB of algorithmic writes = ~6 M partial-sector requests in ~300 us - 20 G requests/s, each to a DRAM page of its own.
+// That request rate, not bytes (2 TB/s at the memory side) and not bytes in flight (four elements per thread instead of one: 312 -> 306 us),
+// is the ceiling of this kernel: 0.95 TB/s of algorithmic bytes.  The fused collectors, which carry the env-steps/s metric, write whole
+// episodes from registers and never come here.
 constexpr int ADD_ITEMS = 4;
 __global__ __launch_bounds__(256) void replay_add_kernel(marlhip_replay_shape rs, marlhip_replay_buffers rb,
                                                          const int32_t* __restrict__ slot, const int32_t* __restrict__ tt,
