@@ -333,7 +333,6 @@ int idqn_update_n_fused(const marlhip_idqn_learner* L, int32_t n_updates, int32_
         bool found = false;
         int rc = 0;
         fuse.sumsq = L->scratch;  // clip-norm partials: ceil(n / 64) floats (marlhip_idqn_learner.scratch)
-        fuse.last = u == n_updates - 1 ? 1 : 0;  // the call's last optimiser step is a launch of its own; earlier ones ride in the next learner launch
         for (auto part : {&lossgrad_part_h64_fused, &lossgrad_part_h64_oid_fused}) {
             rc = part(&L->net, L->params, L->target, &bt, L->materialise_batch ? nullptr : &src, L->gamma, L->double_q, L->mode,
                       L->workspace, L->workspace_bytes, L->grad, L->loss, (hipStream_t)stream, &fuse, &found);

@@ -106,61 +106,6 @@ __global__ __launch_bounds__(256) void dqn_pack_kernel(const float* __restrict__
     packs[(size_t)p * TOT + idx] = v;
 }
 
-struct AdamArgs {
-    float lr_step;    // fp32(lr / (1 - beta1^step))
-    float bc2_sqrt;   // fp32(sqrt(1 - beta2^step))
-    float w1;         // fp32(1 - beta1): lerp weight
-    float beta2, w2;  // beta2, fp32(1 - beta2)
-    float eps, max_norm, grad_scale, tau;
-    int hard_update;
-    // getattr(optim, cfg.optimizer)(params, lr=cfg.lr) (dqn/model.py:66-71, ac/model.py:103-105) with torch's default hyper-parameters:
-    // 0 Adam, 1 SGD (p += -lr g), 2 RMSprop (alpha 0.99, not centred, no momentum), 3 AdamW (decoupled weight decay 1e-2, then Adam)
-    int opt = 0;
-    float neg_lr = 0.f;   // fp32(-lr)                     (SGD, RMSprop)
-    float alpha = 0.f;    // RMSprop smoothing, w2 = fp32(1 - alpha)
-    float decay = 1.f;    // AdamW: fp32(1 - lr * weight_decay)
-};
-
-// one parameter's step; m / v are the optimiser's two state slots (Adam: exp_avg / exp_avg_sq; RMSprop: v = square_avg)
-__device__ __forceinline__ void opt_step(const AdamArgs& a, float gv, float& mi, float& vi, float& pi) {
-    if (a.opt == 1) {  // torch.optim.SGD: param.add_(grad, alpha=-lr)
-        pi = pi + a.neg_lr * gv;
-        return;
-    }
-    if (a.opt == 2) {  // torch.optim.RMSprop: square_avg.mul_(alpha).addcmul_(g, g, value=1 - alpha); avg = sqrt + eps; addcdiv_(g, avg, -lr)
-        vi = vi * a.alpha + (a.w2 * gv) * gv;
-        const float avg = sqrtf(vi) + a.eps;
-        pi = pi + a.neg_lr * (gv / avg);
-        return;
-    }
-    if (a.opt == 3) pi = pi * a.decay;  // torch.optim.AdamW: param.mul_(1 - lr * weight_decay) first
-    // torch.optim.Adam (single-tensor): lerp_, mul_/addcmul_, sqrt/div/add_, addcdiv_
-    mi = mi + a.w1 * (gv - mi);
-    vi = vi * a.beta2 + a.w2 * gv * gv;
-    const float denom = sqrtf(vi) / a.bc2_sqrt + a.eps;
-    pi = pi + (-a.lr_step) * (mi / denom);
-}
-
-// The optimiser step of the PREVIOUS update inside this launch's prologue (marlhip_idqn_update_n, round 5): every workgroup of agent p
-// forms the clip coefficient from the reduce launch's partial sums and the Adam step of p's whole block itself - redundantly, from state
-// that nobody overwrites while it is read (the state ping-pongs between two buffers: in = after update u - 1, out = after update u,
-// written by ONE workgroup per network) - and writes the new values straight into its LDS packs.  What that buys: the clip + Adam +
-// packs launch and the 70 KB pack staging of every update but the last of a call; what it costs: NPARAM / 256 parameters per thread of
-// arithmetic per workgroup.  The arithmetic is adam_pack_body's, instruction for instruction: results are bitwise those of the
-// three-launch form.  Hard target copies only (a Polyak target would need its own ping-pong; those runs keep the three launches).
-struct UpdPro {
-    AdamArgs a;
-    const float* grad;    // [nblk][NPARAM] mean gradient of the previous update (reduce launch)
-    const float* sumsq;   // its clip-norm partials
-    int nsq;
-    const float *p_in, *m_in, *v_in;  // parameters / moments before the step
-    float *p_out, *m_out, *v_out;     // after it
-    float* target_rw;     // canonical target block (hard copy)
-    float* packs_rw;      // global pack images: the target section is kept current on hard copies
-    float* gnorm_out;
-    AgentMap am;
-};
-
 // where the rows come from: a materialised Batch in the reference layout (marlhip_dqn_loss_grad), or the
 // episode-major replay itself, gathered in-kernel through sampled episode indices
 // (marlhip_dqn_loss_grad_replay: no sample kernel, no Batch round trip through HBM)
@@ -233,13 +178,12 @@ struct IntC { static constexpr int value = I; };
 // STORED (the two-pass form, MODE 1 then MODE 2): the qsel pass leaves the critic's two hidden layers of every transition row (post-relu,
 // MFMA C layout: hst[(((p T + t) ngroups + group) 2 MT + layer MT + tile) 64 + lane], 512 bytes per row at hidden 64) and the bwd pass
 // reads them back one step ahead next to the rows instead of running the critic forward again - 96 of its 272 MFMAs per row block.
-template <class S, int WAVES, bool REPLAY, int MODE, bool STORED = false, bool PRO = false>
+template <class S, int WAVES, bool REPLAY, int MODE, bool STORED = false>
 __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dqn_lossgrad_kernel(const float* __restrict__ packs, marlhip_batch bt, ReplaySrc rs,
                                                                  MixBufs mix, float gamma, int double_q, int n_chunks,
                                                                  float* __restrict__ partials, unsigned long long* prof,
-                                                                 f4* __restrict__ hst = nullptr, UpdPro pro = UpdPro()) {
+                                                                 f4* __restrict__ hst = nullptr) {
     static_assert(!STORED || MODE == 1 || MODE == 2 || MODE == 4, "stored activations belong to the two-pass forms");
-    static_assert(!PRO || MODE == 0, "the optimiser prologue belongs to the single-pass independent learner");
     using L = UpdLds<S>;
     constexpr int MT = S::MT, NT1 = S::DP / 16, D = S::D, H = S::H, A = S::A, TS = L::TS, N1 = S::KS1 / 4;
     constexpr int UPD_BLOCK = 64 * WAVES;
@@ -252,78 +196,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dqn_lossgrad_kernel(con
     const int T = bt.max_len, B = bt.batch;
     const unsigned long long t_begin = prof ? __builtin_readcyclecounter() : 0;
 
-    if constexpr (PRO) {
-        // ---- clip + Adam of the previous update for this agent's network, then the packs from the new values (see UpdPro)
-        constexpr int TOT = 2 * S::NFWD + S::NBWD, NK = (S::NPARAM + UPD_BLOCK - 1) / UPD_BLOCK;
-        const AdamArgs& a = pro.a;
-        const int blk = pro.am.net[p];
-        int first = 0;  // the first agent of this network: its workgroup 0 writes the state back
-#pragma unroll
-        for (int q = 15; q >= 0; --q) first = (q < (int)gridDim.y && pro.am.net[q] == blk) ? q : first;
-        const bool writer = blockIdx.x == 0 && p == first;
-        // every request in front of the norm's barriers: the block's operands, the partial sums, the target pack
-        float gk[NK], mk[NK], vk[NK], pk[NK];
-#pragma unroll
-        for (int k = 0; k < NK; ++k) {
-            const int kk = tid + k * UPD_BLOCK, i = blk * S::NPARAM + (kk < S::NPARAM ? kk : S::NPARAM - 1);
-            gk[k] = pro.grad[i]; mk[k] = pro.m_in[i]; vk[k] = pro.v_in[i]; pk[k] = pro.p_in[i];
-        }
-        float ss = 0.f;
-        for (int b = tid; b < pro.nsq; b += UPD_BLOCK) ss += pro.sumsq[b];
-        // the packs' zero padding (k-steps beyond D, outputs beyond A) has no parameter: clear the regions the new values are scattered into
-        // (ordered in front of the scatter by the norm's barriers); the target pack is unchanged unless this step is a hard copy: from the
-        // global image
-        {
-            const f4 z4 = {0.f, 0.f, 0.f, 0.f};
-            f4* l4 = reinterpret_cast<f4*>(lds);
-            for (int i4 = tid; i4 < S::NFWD / 4; i4 += UPD_BLOCK) l4[L::oC / 4 + i4] = z4;
-            for (int i4 = tid; i4 < S::NBWD / 4; i4 += UPD_BLOCK) l4[L::oB / 4 + i4] = z4;
-            if (a.hard_update) {
-                for (int i4 = tid; i4 < S::NFWD / 4; i4 += UPD_BLOCK) l4[L::oT / 4 + i4] = z4;
-            } else {
-                copy_f4_to_lds(reinterpret_cast<const f4*>(packs + (size_t)p * TOT + S::NFWD), reinterpret_cast<f4*>(lds + L::oT), S::NFWD / 4, tid, UPD_BLOCK);
-            }
-        }
-        static_assert(S::NFWD % 4 == 0 && S::NBWD % 4 == 0 && L::oC % 4 == 0 && L::oT % 4 == 0 && L::oB % 4 == 0, "pack regions are whole float4s");
-        float* s_red = lds + L::oTiles;  // (the tiles are not in use yet)
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) ss += __shfl_xor(ss, off);
-        if (lane == 0) s_red[wave] = ss;
-        __syncthreads();
-        if (tid == 0) {
-            const float total = sqrtf((s_red[0] + s_red[1]) + (s_red[2] + s_red[3]));
-            s_red[4] = a.max_norm > 0.f ? fminf(a.max_norm / (total + 1e-6f), 1.f) : 1.f;
-            if (pro.gnorm_out != nullptr && blockIdx.x == 0 && p == 0) pro.gnorm_out[0] = total;
-        }
-        __syncthreads();
-        const float coef = s_red[4];
-#pragma unroll
-        for (int k = 0; k < NK; ++k) {
-            const int kk = tid + k * UPD_BLOCK;
-            if (kk >= S::NPARAM) continue;
-            const float gv = (gk[k] * a.grad_scale) * coef;
-            float mi = mk[k], vi = vk[k];
-            mi = mi + a.w1 * (gv - mi);
-            vi = vi * a.beta2 + a.w2 * gv * gv;
-            const float denom = sqrtf(vi) / a.bc2_sqrt + a.eps;
-            float pi = pk[k];
-            pi = pi + (-a.lr_step) * (mi / denom);
-            int fwd, bwd;
-            mlp_param_to_pack<S>(kk, fwd, bwd);
-            lds[L::oC + fwd] = pi;
-            if (bwd >= 0) lds[L::oB + bwd] = pi;
-            if (a.hard_update) lds[L::oT + fwd] = pi;
-            if (writer) {
-                const int i = blk * S::NPARAM + kk;
-                pro.p_out[i] = pi; pro.m_out[i] = mi; pro.v_out[i] = vi;
-                if (a.hard_update) {
-                    pro.target_rw[i] = pi;
-                    for (int q = 0; q < (int)gridDim.y; ++q)
-                        if (pro.am.net[q] == blk) pro.packs_rw[(size_t)q * TOT + S::NFWD + fwd] = pi;
-                }
-            }
-        }
-    } else {   // the three packs were laid out by dqn_pack_kernel exactly as LDS wants them: 16-byte linear copy
+    {   // the three packs were laid out by dqn_pack_kernel exactly as LDS wants them: 16-byte linear copy
         constexpr int TOT4 = (2 * S::NFWD + S::NBWD) / 4;
         const f4* src = reinterpret_cast<const f4*>(packs + (size_t)p * (2 * S::NFWD + S::NBWD));
         f4* dst = reinterpret_cast<f4*>(lds);
@@ -1042,6 +915,41 @@ static __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restri
     if (threadIdx.x == 0) scratch[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+struct AdamArgs {
+    float lr_step;    // fp32(lr / (1 - beta1^step))
+    float bc2_sqrt;   // fp32(sqrt(1 - beta2^step))
+    float w1;         // fp32(1 - beta1): lerp weight
+    float beta2, w2;  // beta2, fp32(1 - beta2)
+    float eps, max_norm, grad_scale, tau;
+    int hard_update;
+    // getattr(optim, cfg.optimizer)(params, lr=cfg.lr) (dqn/model.py:66-71, ac/model.py:103-105) with torch's default hyper-parameters:
+    // 0 Adam, 1 SGD (p += -lr g), 2 RMSprop (alpha 0.99, not centred, no momentum), 3 AdamW (decoupled weight decay 1e-2, then Adam)
+    int opt = 0;
+    float neg_lr = 0.f;   // fp32(-lr)                     (SGD, RMSprop)
+    float alpha = 0.f;    // RMSprop smoothing, w2 = fp32(1 - alpha)
+    float decay = 1.f;    // AdamW: fp32(1 - lr * weight_decay)
+};
+
+// one parameter's step; m / v are the optimiser's two state slots (Adam: exp_avg / exp_avg_sq; RMSprop: v = square_avg)
+__device__ __forceinline__ void opt_step(const AdamArgs& a, float gv, float& mi, float& vi, float& pi) {
+    if (a.opt == 1) {  // torch.optim.SGD: param.add_(grad, alpha=-lr)
+        pi = pi + a.neg_lr * gv;
+        return;
+    }
+    if (a.opt == 2) {  // torch.optim.RMSprop: square_avg.mul_(alpha).addcmul_(g, g, value=1 - alpha); avg = sqrt + eps; addcdiv_(g, avg, -lr)
+        vi = vi * a.alpha + (a.w2 * gv) * gv;
+        const float avg = sqrtf(vi) + a.eps;
+        pi = pi + a.neg_lr * (gv / avg);
+        return;
+    }
+    if (a.opt == 3) pi = pi * a.decay;  // torch.optim.AdamW: param.mul_(1 - lr * weight_decay) first
+    // torch.optim.Adam (single-tensor): lerp_, mul_/addcmul_, sqrt/div/add_, addcdiv_
+    mi = mi + a.w1 * (gv - mi);
+    vi = vi * a.beta2 + a.w2 * gv * gv;
+    const float denom = sqrtf(vi) / a.bc2_sqrt + a.eps;
+    pi = pi + (-a.lr_step) * (mi / denom);
+}
+
 static __global__ __launch_bounds__(256) void adam_kernel(int64_t n, int nblocks, float* __restrict__ params,
                                                    const float* __restrict__ grad, float* __restrict__ m,
                                                    float* __restrict__ v, float* __restrict__ target, AdamArgs a,
@@ -1131,21 +1039,17 @@ static __global__ __launch_bounds__(1024) void adam_fused_kernel(int64_t n, floa
 // loss/grad launch stages (marlhip_idqn_update_n keeps the packs alive between updates, so dqn_pack_kernel runs once per call
 // instead of once per update).  sumsq: per-block partials of dqn_reduce_sq_kernel (nsq of them).
 template <class S>
-__device__ __forceinline__ void adam_pack_body(int i, int n, int nsq, float* params, const float* grad,
-                                               float* m, float* v, float* __restrict__ target,
+__device__ __forceinline__ void adam_pack_body(int i, int n, int nsq, float* __restrict__ params, const float* grad,
+                                               float* __restrict__ m, float* __restrict__ v, float* __restrict__ target,
                                                const AdamArgs& a, const float* sumsq, float* __restrict__ gnorm_out,
-                                               const AgentMap& am, int P, float* __restrict__ packs, const float* p_in = nullptr,
-                                               const float* m_in = nullptr, const float* v_in = nullptr) {
-    // p_in / m_in / v_in: the state before the step when it does not live in params / m / v (the last update of a marlhip_idqn_update_n call
-    // whose earlier steps ran in the learner launches' prologues: UpdPro's ping-pong buffers); null: in place
-    if (p_in == nullptr) { p_in = params; m_in = m; v_in = v; }
+                                               const AgentMap& am, int P, float* __restrict__ packs) {
     constexpr int TOT = 2 * S::NFWD + S::NBWD;
     __shared__ float s_coef;
     __shared__ float s_red[4];
     // this thread's operands, requested BEFORE the clip-norm reduction and its barriers: they do not depend on the coefficient (round 5:
     // one round trip to L2 per launch instead of two at the reference's cadence, where the launch is nothing but latency)
     const bool mine = i >= 0 && i < n;
-    const float g_raw = mine ? grad[i] : 0.f, m_old = mine ? m_in[i] : 0.f, v_old = mine ? v_in[i] : 0.f, p_old = mine ? p_in[i] : 0.f;
+    const float g_raw = mine ? grad[i] : 0.f, m_old = mine ? m[i] : 0.f, v_old = mine ? v[i] : 0.f, p_old = mine ? params[i] : 0.f;
     const bool tgt = a.hard_update || a.tau > 0.f;
     const float t_old = (mine && tgt && !a.hard_update) ? target[i] : 0.f;
     {
@@ -1215,9 +1119,8 @@ template <class S>
 static __global__ __launch_bounds__(256) void adam_pack_kernel(int n, int nsq, float* __restrict__ params, const float* __restrict__ grad,
                                                         float* __restrict__ m, float* __restrict__ v, float* __restrict__ target,
                                                         AdamArgs a, const float* __restrict__ sumsq, float* __restrict__ gnorm_out,
-                                                        AgentMap am, int P, float* __restrict__ packs, const float* p_in = nullptr,
-                                                        const float* m_in = nullptr, const float* v_in = nullptr) {
-    adam_pack_body<S>(blockIdx.x * 256 + threadIdx.x, n, nsq, params, grad, m, v, target, a, sumsq, gnorm_out, am, P, packs, p_in, m_in, v_in);
+                                                        AgentMap am, int P, float* __restrict__ packs) {
+    adam_pack_body<S>(blockIdx.x * 256 + threadIdx.x, n, nsq, params, grad, m, v, target, a, sumsq, gnorm_out, am, P, packs);
 }
 
 // (Measured and dropped, r02: the same epilogue as ONE launch - reduce, a grid barrier, then Adam + packs in the same workgroups.
@@ -1226,7 +1129,13 @@ static __global__ __launch_bounds__(256) void adam_pack_kernel(int n, int nsq, f
 // costs more than the kernel boundary it replaces (27.1 -> 26.3 M; 0.92 -> 0.75 M at the reference cadence).  Two launches it is.
 // r03: for the small updates of the reference cadence (a dozen records per agent) the whole epilogue in ONE 1024-thread workgroup - no grid
 // barrier needed - was tried as well: one CU's worth of loads in flight makes it ~60 us against 9 us for the two launches that spread
-// the same bytes over 130 workgroups (0.92 -> 0.31 M env-steps/s, scripts/gpu_runs/r3U.sh).  Dropped.)
+// the same bytes over 130 workgroups (0.92 -> 0.31 M env-steps/s, scripts/gpu_runs/r3U.sh).  Dropped.
+// r05: the step inside the NEXT learner launch's prologue - every workgroup steps its agent's whole block itself (ping-pong state, the
+// new values scattered straight into its LDS packs: no Adam launch, no pack staging; bitwise the three-launch results, commit 6f18cb7,
+// scripts/gpu_runs/r5C.sh).  22 parameters per thread x ~150 VALU instructions (three IEEE divisions / roots and the pack index math each)
+// at one wave per SIMD is 8.3 us of serial instruction issue against the 4.9 us launch + 1.7 us staging it removes: the learner launch
+// went 19.7 -> 26.3 us at the reference cadence (0.864 -> 0.782 M env-steps/s) and 98.3 -> 106.0 us at the headline (27.8 -> 26.8 M).
+// Dropped: an optimiser step spread over 88 workgroups beats the same step repeated in each of 26.)
 
 struct UpdPlan {
     int nwg, n_chunks;
@@ -1439,11 +1348,6 @@ struct UpdFuse {
     // the ranks in `grad`, ordered on the stream; adam.grad_scale = 1 / world.  nullptr: single GPU.
     marlhip_exchange_fn exchange = nullptr;
     void* exchange_ctx = nullptr;
-    // the optimiser step inside the NEXT learner launch's prologue (UpdPro): `last` (in) = this is the final update of the call, its step runs
-    // as a launch; pending / pend_adam / cur (state between the updates of one call): a step is owed, its arguments, and which buffer
-    // holds the current parameters and moments (0: the caller's blocks, 1: the workspace's ping-pong copy)
-    int last = 1, pending = 0, cur = 0;
-    AdamArgs pend_adam;
 };
 
 template <class S, bool REPLAY>
@@ -1509,43 +1413,10 @@ int launch_lossgrad_src(const marlhip_net_shape* s, const float* params, const f
     if (mode == 3 || (mode == 0 && IDQN_TWO_PASS)) mix.rew_all = mix.lrow + tb;  // [P][tb]; the statistics' block partials follow it
     const dim3 grid(pl.nwg, P), block(256);
     timing_begin(TIMER_LOSSGRAD, st);
-    // marlhip_idqn_update_n, independent learners, single GPU, hard (or no) target copies: the optimiser step of update u runs in the
-    // prologue of update u + 1's learner launch (UpdPro) - two launches per update instead of three; the call's last step is a launch
-    constexpr bool CAN_PRO = REPLAY && !IDQN_TWO_PASS;
-    const int n_all = am.nblk * S::NPARAM;
-    const int64_t pro_off = (hs_off + 255) & ~(int64_t)255;  // parameters | exp_avg | exp_avg_sq, behind the layout (the two-pass forms' record region)
-    const bool no_pro = getenv("MARLHIP_NO_PROLOGUE_ADAM") != nullptr;  // diagnostics / A-B runs and tests: the three-launch form (read per update: a call may toggle it)
-    const bool pro_ok = CAN_PRO && !no_pro && fuse != nullptr && mode == 0 && fuse->exchange == nullptr && fuse->adam.tau == 0.f && prof == nullptr &&
-                        ws_bytes >= pro_off + (int64_t)3 * n_all * (int64_t)sizeof(float) + 128;
-    float* pro_buf = reinterpret_cast<float*>(static_cast<char*>(ws) + pro_off);
-    bool ran_pro = false;
     if (!two_pass) {
-        if constexpr (CAN_PRO) {
-            if (fuse != nullptr && fuse->pending) {
-                static LdsAttr attr_pro;
-                if (attr_pro.need()) {
-                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dqn_lossgrad_kernel<S, 4, REPLAY, 0, false, true>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-                    attr_pro.done();
-                }
-                UpdPro pro;
-                pro.a = fuse->pend_adam; pro.grad = grad; pro.sumsq = fuse->sumsq; pro.nsq = (n_all + 63) / 64;
-                const bool in_ws = fuse->cur == 1;  // where the state before this step lives
-                pro.p_in = in_ws ? pro_buf : fuse->params_rw; pro.m_in = in_ws ? pro_buf + n_all : fuse->exp_avg; pro.v_in = in_ws ? pro_buf + 2 * n_all : fuse->exp_avg_sq;
-                pro.p_out = in_ws ? fuse->params_rw : pro_buf; pro.m_out = in_ws ? fuse->exp_avg : pro_buf + n_all; pro.v_out = in_ws ? fuse->exp_avg_sq : pro_buf + 2 * n_all;
-                pro.target_rw = fuse->target_rw; pro.packs_rw = packs; pro.gnorm_out = fuse->gnorm; pro.am = am;
-                hipLaunchKernelGGL((dqn_lossgrad_kernel<S, 4, REPLAY, 0, false, true>), grid, block, lds_bytes, st, (const float*)packs, *bt, src, mix,
-                                   gamma, double_q, pl.n_chunks, (float*)ws, prof, (f4*)nullptr, pro);
-                fuse->cur ^= 1;
-                fuse->pending = 0;
-                ran_pro = true;
-            }
-        }
-        if constexpr (!IDQN_TWO_PASS) {
-            if (!ran_pro)
-                hipLaunchKernelGGL((dqn_lossgrad_kernel<S, 4, REPLAY, 0>), grid, block, lds_bytes, st, (const float*)packs, *bt, src, mix,
-                                   gamma, double_q, pl.n_chunks, (float*)ws, prof);
-        }
+        if constexpr (!IDQN_TWO_PASS)
+            hipLaunchKernelGGL((dqn_lossgrad_kernel<S, 4, REPLAY, 0>), grid, block, lds_bytes, st, (const float*)packs, *bt, src, mix,
+                               gamma, double_q, pl.n_chunks, (float*)ws, prof);
     } else {
         if (stored)
             hipLaunchKernelGGL((dqn_lossgrad_kernel<S, 4, REPLAY, 1, true>), grid, block, lds_bytes, st, (const float*)packs, *bt, src, mix,
@@ -1610,20 +1481,9 @@ int launch_lossgrad_src(const marlhip_net_shape* s, const float* params, const f
                                fuse->sumsq);
             MARL_CHECK_LAUNCH("dqn_reduce_sq_kernel");
         }
-        if (pro_ok && !fuse->last) {  // this update's step rides in the next learner launch
-            fuse->pending = 1;
-            fuse->pend_adam = fuse->adam;
-            fuse->packs_valid = 1;  // (the next launch builds its own packs; the global image is rewritten by the call's last step)
-            return 0;
-        }
-        {
-            const bool in_ws = fuse->cur == 1;  // earlier steps of this call left the state in the workspace copy: read it there, write the caller's blocks
-            hipLaunchKernelGGL((adam_pack_kernel<S>), dim3((n + 255) / 256), dim3(256), 0, st, n, nsq, fuse->params_rw, (const float*)grad,
-                               fuse->exp_avg, fuse->exp_avg_sq, fuse->target_rw, fuse->adam, (const float*)fuse->sumsq, fuse->gnorm, am, P,
-                               packs, in_ws ? (const float*)pro_buf : (const float*)nullptr, in_ws ? (const float*)(pro_buf + n_all) : (const float*)nullptr,
-                               in_ws ? (const float*)(pro_buf + 2 * n_all) : (const float*)nullptr);
-            fuse->cur = 0;
-        }
+        hipLaunchKernelGGL((adam_pack_kernel<S>), dim3((n + 255) / 256), dim3(256), 0, st, n, nsq, fuse->params_rw, (const float*)grad,
+                           fuse->exp_avg, fuse->exp_avg_sq, fuse->target_rw, fuse->adam, (const float*)fuse->sumsq, fuse->gnorm, am, P,
+                           packs);
         MARL_CHECK_LAUNCH("adam_pack_kernel");
         fuse->packs_valid = 1;
         return 0;

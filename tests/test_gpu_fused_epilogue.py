@@ -67,31 +67,6 @@ def test_fused_epilogue_matches_generic_loop(mode, D, sharing, tui):
         assert not torch.equal(a["target"], a["params"])
 
 
-@pytest.mark.parametrize("D,sharing,tui,n_updates,B", [(15, None, 3, 5, 96), (15, None, 200, 4, 32), (17, [0, 0], 2, 7, 40), (27, None, 3, 6, 4096)])
-def test_optimiser_step_in_the_learner_prologue_is_bitwise_the_three_launch_form(D, sharing, tui, n_updates, B):
-    """round 5: inside a marlhip_idqn_update_n call the clip + Adam (+ hard target copy) of update u runs in the prologue of update u + 1's
-    learner launch (UpdPro: every workgroup steps its agent's block itself, the state ping-pongs between the caller's blocks and a workspace
-    copy); MARLHIP_NO_PROLOGUE_ADAM=1 keeps the launch.  Same arithmetic, same summation orders: every output must be bit-identical - odd and
-    even update counts (where the state lives when the call's last step runs), hard copies inside the prologue, a shared network, the
-    reference's batch of 32 and the bench's 4096."""
-    from codebase_amd import hip as h
-
-    P = 4 if D == 27 else 2
-    spec = h.NetSpec(P, D, 64, 6, None if sharing is None else tuple(sharing))
-    out = []
-    for no_pro in (False, True):
-        if no_pro:
-            os.environ["MARLHIP_NO_PROLOGUE_ADAM"] = "1"
-        try:
-            out.append(_run(h, spec, 0, True, tui, n_updates, B=B, cap=max(300, 2 * B)))
-        finally:
-            os.environ.pop("MARLHIP_NO_PROLOGUE_ADAM", None)
-    a, b = out
-    assert (a["upd"], a["last"], a["step"]) == (b["upd"], b["last"], b["step"]) and a["upd"] == 2 * n_updates
-    for k in ("params", "target", "m", "v", "loss", "gnorm"):
-        assert torch.equal(a[k], b[k]), k
-
-
 def test_replay_gather_above_2gb_takes_the_64bit_path_and_matches_the_buffer_path():
     """The learner gathers its rows through buffer descriptors (32-bit offsets) while every replay array is below 2 GB and through
     64-bit global loads above: the same 512 episodes placed in a 2.2 GB replay (704,512 episodes x 3,120 B of observations) and in
