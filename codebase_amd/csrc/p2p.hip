@@ -92,19 +92,21 @@ static __global__ __launch_bounds__(256) void p2p_allreduce_wave64_kernel(float*
 
 // wall_clock64 counts at 100 MHz.  The wait is bounded so that a dead peer cannot hang the GPU; the bound is DIAGNOSTIC (a collective
 // library would block for ever): 5 minutes by default, MARLHIP_P2P_TIMEOUT_MS overrides; a malformed or non-positive value keeps the default.
-long long p2p_timeout_ticks() {
-    static const long long t = [] {
-        double ms = 300000.0;
-        const char* v = getenv("MARLHIP_P2P_TIMEOUT_MS");
-        if (v != nullptr && *v) {
-            char* end = nullptr;
-            const double x = strtod(v, &end);
-            if (end != v && x > 0.0 && x < 8.64e7) ms = x;
-            else fprintf(stderr, "[marlhip] MARLHIP_P2P_TIMEOUT_MS=\"%s\" is not a positive number of milliseconds; keeping %.0f ms\n", v, ms);
+long long p2p_timeout_ticks() {  // read per exchange (a getenv, ~0.1 us next to a launch): the set-up's self-test runs under a short bound of its own
+    double ms = 300000.0;
+    const char* v = getenv("MARLHIP_P2P_TIMEOUT_MS");
+    if (v != nullptr && *v) {
+        char* end = nullptr;
+        const double x = strtod(v, &end);
+        if (end != v && x > 0.0 && x < 8.64e7) {
+            ms = x;
+        } else {
+            static bool warned = false;
+            if (!warned) fprintf(stderr, "[marlhip] MARLHIP_P2P_TIMEOUT_MS=\"%s\" is not a positive number of milliseconds; keeping %.0f ms\n", v, ms);
+            warned = true;
         }
-        return (long long)(ms * 1e5);
-    }();
-    return t;
+    }
+    return (long long)(ms * 1e5);
 }
 
 // marlhip_idqn_update_n_dist recognises this exchange by its address and folds it into the learner's reduce launch

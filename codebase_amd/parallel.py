@@ -143,6 +143,10 @@ class P2PExchange:
         n = int(max_floats)
         g = torch.Generator(device="cpu").manual_seed(1234 + rank)
         good = True
+        # the self-test waits at most MARLHIP_P2P_SELFTEST_TIMEOUT_MS (default 5 s) for a peer: a link that does not carry the flags must cost
+        # the set-up seconds, not the training run's diagnostic bound (minutes) per exchange
+        keep = os.environ.get("MARLHIP_P2P_TIMEOUT_MS")
+        os.environ["MARLHIP_P2P_TIMEOUT_MS"] = os.environ.get("MARLHIP_P2P_SELFTEST_TIMEOUT_MS", "5000")
         try:
             for k in range(6):
                 x = torch.randn(n, generator=g).cuda()
@@ -155,6 +159,11 @@ class P2PExchange:
                 good = good and rc == 0 and ex.status() == 0 and bool(torch.allclose(x, ref, rtol=1e-5, atol=1e-5))
         except Exception as e:  # noqa: BLE001 - "not available", never a broken run
             why, good = str(e), False
+        finally:
+            if keep is None:
+                os.environ.pop("MARLHIP_P2P_TIMEOUT_MS", None)
+            else:
+                os.environ["MARLHIP_P2P_TIMEOUT_MS"] = keep
         if everyone(good):
             return ex
         log.warning("marlhip p2p exchange: self-test failed on some rank (%s); keeping torch.distributed's all-reduce", why or "sum mismatch / peer timeout")

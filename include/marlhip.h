@@ -603,7 +603,8 @@ int marlhip_idqn_update_n_dist(const marlhip_idqn_learner* L, int32_t n_updates,
  * library owns, freed by _destroy), the hipIpcMemHandles (marlhip_p2p_handle_bytes() bytes each) are exchanged by the host side
  * (torch.distributed in codebase_amd/parallel.py), every rank calls _connect with all of them, then any number of _allreduce calls -
  * the same sequence of counts on every rank.  A peer that does not arrive within MARLHIP_P2P_TIMEOUT_MS (default 300000: diagnostic
- * only, a collective library would block; a malformed or non-positive value keeps the default) leaves the
+ * only, a collective library would block; a malformed or non-positive value keeps the default; read at every exchange, so the host side
+ * can run its set-up self-test under a short bound of its own) leaves the
  * local gradient untouched and raises the state's error word, which marlhip_p2p_status reads back (it synchronises: not for the
  * hot loop); once raised, later exchanges publish but no longer wait (one timeout per dead peer, not one per update).  _destroy frees the
  * buffer: the caller synchronises its stream first (no exchange may be in flight), and the peers must have finished reading - destroy
