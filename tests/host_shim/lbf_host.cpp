@@ -2,6 +2,8 @@
 // that the HIP kernels inline can be checked against oracle/lbf.py on a machine with no GPU.
 #include <stdint.h>
 #include <string.h>
+#include <vector>
+#include <string.h>
 
 #include "../../codebase_amd/csrc/lbf_core.h"
 
@@ -183,6 +185,48 @@ extern "C" int host_rw_step(const HostRwCfg* c, uint8_t* state, const uint32_t* 
                             uint8_t* done, uint8_t* trunc) {
     const RwParams q = rw_conv(c);
 #define X(p) if (c->n_agents == p) { rw_run_step<p>(q, state, episode, actions, obs, rew, done, trunc); return 0; }
+    X(2) X(4) X(8)
+#undef X
+    return -1;
+}
+
+// The fused collectors keep the request queue as a bit set (RwRequested) ACROSS steps and rebuild it only when rw_step reports a delivery
+// (env_traits.h RwEnvT::step).  rq_io [n_envs][4]: the carried words, in: as left by the previous call (build_only != 0: just build them
+// from the state, as RwEnvT::reset does); returns the number of envs whose carried set differs from a fresh build after the step.
+extern "C" int host_rw_step_carried_rq(const HostRwCfg* c, const uint8_t* state_before, const uint8_t* state_after, const uint32_t* episode,
+                                       const int32_t* actions, uint64_t* rq_io, int build_only) {
+    const RwParams q = rw_conv(c);
+    int bad = 0;
+#define X(p)                                                                                                          \
+    if (c->n_agents == p) {                                                                                           \
+        const int stride = rw_state_stride(p, q.rows, q.cols), cells = q.rows * q.cols;                               \
+        for (int n = 0; n < q.n_envs; ++n) {                                                                          \
+            RwState<p> s;                                                                                             \
+            std::vector<uint8_t> rec(state_before + (size_t)n * stride, state_before + (size_t)(n + 1) * stride);     \
+            const RwGrid grid{rec.data(), 1};                                                                         \
+            rw_load(rec.data(), cells, s);                                                                            \
+            RwRequested<p> rq;                                                                                        \
+            if (build_only) {                                                                                         \
+                rq.build(q, s);                                                                                       \
+            } else {                                                                                                  \
+                for (int k = 0; k < 4; ++k) rq.w[k] = rq_io[(size_t)n * 4 + k];                                       \
+                int a[p];                                                                                             \
+                double raw[p];                                                                                        \
+                bool d = false;                                                                                       \
+                for (int i = 0; i < p; ++i) a[i] = actions[(size_t)i * q.n_envs + n];                                 \
+                DrawStream req;                                                                                       \
+                req.init(q.seed, (uint32_t)n, episode[n], STREAM_REQUEST);                                            \
+                if (rw_step(q, s, grid, a, raw, d, req)) rq.build(q, s);                                              \
+                rw_store(rec.data(), cells, s);                                                                       \
+                bad += memcmp(rec.data(), state_after + (size_t)n * stride, stride) != 0; /* the same step as host_rw_step took */ \
+                RwRequested<p> fresh;                                                                                 \
+                fresh.build(q, s);                                                                                    \
+                bad += memcmp(fresh.w, rq.w, sizeof(rq.w)) != 0;                                                      \
+            }                                                                                                         \
+            for (int k = 0; k < 4; ++k) rq_io[(size_t)n * 4 + k] = rq.w[k];                                           \
+        }                                                                                                             \
+        return bad;                                                                                                   \
+    }
     X(2) X(4) X(8)
 #undef X
     return -1;

@@ -319,6 +319,10 @@ def test_core_matches_oracle(name, over, coop):
                 sh.x, sh.y = a.x, a.y
                 w._recalc_grid()
                 state[n] = pack_state(w, P)
+        # the collectors carry the request queue as a bit set across steps and rebuild it only when rw_step reports a delivery:
+        # the carried set against a fresh build after EVERY step, on a copy of the same states
+        rq = np.zeros((N, 4), np.uint64)
+        assert lib.host_rw_step_carried_rq(ctypes.byref(hc), ptr(state), ptr(state), ptr(epi), None, ptr(rq), 1) == 0
         for t in range(T):
             acts = rng.choice(5, size=(P, N), p=[0.1, 0.5, 0.1, 0.1, 0.2]).astype(np.int32)
             if episode == 1 and t == 0:
@@ -326,7 +330,9 @@ def test_core_matches_oracle(name, over, coop):
             rew = np.zeros((P, N), np.float32)
             done = np.zeros(N, np.uint8)
             trunc = np.zeros(N, np.uint8)
+            before = state.copy()
             assert lib.host_rw_step(ctypes.byref(hc), ptr(state), ptr(epi), ptr(acts), ptr(obs), ptr(rew), ptr(done), ptr(trunc)) == 0
+            assert lib.host_rw_step_carried_rq(ctypes.byref(hc), ptr(before), ptr(state), ptr(epi), ptr(acts), ptr(rq), 0) == 0, f"stale request bits at step {t}"
             for n, e in enumerate(envs):
                 o, r, d, tr, _ = e.step([int(a) for a in acts[:, n]])
                 np.testing.assert_array_equal(pack_state(e.env, P), state[n], err_msg=f"env {n} step {t}")
