@@ -828,8 +828,26 @@ __global__ __launch_bounds__(256, 1) void qmix_mix_kernel(const float* __restric
 // H16 (the opt-in marlhip_qmix_mixer.l1_fp16, BASELINE config 5's "fp16 mixer on MFMA"): both operands of a block rounded to bf16 (see
 // to_bf16x4) and ONE v_mfma_f32_16x16x16_bf16 per tile pair instead of four f32 MFMAs (the lane's four k values of a block are exactly the
 // 4-element operand), fp32 accumulation; the bias gradients (column sums) stay fp32.
+// Round 5: the first group's operands go through LDS.  Until then every wave fetched its own B operand - 20 dword loads per block, each
+// touching 16 rows x 16 bytes, behind a per-lane episode-index load, with ONE block of prefetch because accumulators (120) and two operand
+// sets (88) left no registers for a second - and ran at mfma_busy 0.26 (profiles/r05_qmix8p_sq_counters.md).  Now the WORKGROUP stages a
+// block once: the state tile column-major (TS[col][16 rows]: a lane's four k values of a column are one ds_read_b128, and the two m-groups
+// that read the same states from L2 separately share it) and the G1T tile as it lies in memory; a thread carries 10 + 8 staged values of the
+// NEXT block in registers while the current one is multiplied out of the other LDS buffer - one barrier per block.  Same products in the same
+// order per accumulator: results are bitwise those of the register form.
+template <class Q>
+struct QmixWg1Lds {
+    static constexpr int SDP = Q::KS4 * 16;                  // state columns padded to whole tiles
+    static constexpr int TS = SDP * 16, TA = Q::NF1 * 16;    // floats per buffer
+    static constexpr int FLOATS = 2 * (TS + TA);
+    static constexpr int NST = (SDP + 31) / 32;              // state elements a thread stages per block (512 threads: 16 rows x 32 columns a pass)
+    static constexpr int NA4 = (TA / 4 + 511) / 512;         // float4s of the G1T tile per thread
+};
+
 template <class Q, bool REPLAY, bool H16 = false>
-__device__ __forceinline__ void qmix_wgrad1_body(const QmixRows<Q, REPLAY>& src, const QmixBwd& bw, int R, float* __restrict__ partials, int bid, int nwg) {
+__device__ __forceinline__ void qmix_wgrad1_body(const QmixRows<Q, REPLAY>& src, const QmixBwd& bw, int R, float* __restrict__ partials, int bid, int nwg,
+                                                 float* lds) {
+    using LW = QmixWg1Lds<Q>;
     constexpr int SD = Q::SD, NTS = Q::KS4, NF1 = Q::NF1;
     constexpr int MG = NTS >= 4 ? 2 : 4, NG = 8 / MG, MPW = Q::MT1 / MG, NPW = (NTS + NG - 1) / NG;
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, g = lane >> 4, j = lane & 15;
@@ -844,60 +862,83 @@ __device__ __forceinline__ void qmix_wgrad1_body(const QmixRows<Q, REPLAY>& src,
 #pragma unroll
         for (int n = 0; n < NPW; ++n) accW[m][n] = zero4;
     }
-    unsigned soff[NPW];  // state column of this lane in each owned N tile (element offset inside a state row group)
-    bool sval[NPW];
+    // staging role of this thread: row sr of the block, columns sc + 32 i
+    const int sr = tid & 15, sc = tid >> 4;
+    unsigned soff[LW::NST];
 #pragma unroll
-    for (int n = 0; n < NPW; ++n) {
-        const int k = 16 * (ng + n * NG) + j;
-        sval[n] = (ng + n * NG) < NTS && k < SD;
-        soff[n] = (unsigned)qmix_state_off<Q>(k < SD ? k : SD - 1, ps);
+    for (int i = 0; i < LW::NST; ++i) {
+        const int c = sc + 32 * i;
+        soff[i] = (unsigned)qmix_state_off<Q>(c < SD ? c : SD - 1, ps);  // (columns past SD: a valid element; they only reach accumulator columns that are never written)
     }
-    struct Ops {
-        f4 a[MPW];
-        float b[NPW][4];
-    };
-    auto load = [&](int blk, Ops& o) {
-#pragma unroll
-        for (int m = 0; m < MPW; ++m)
-            o.a[m] = *reinterpret_cast<const f4*>(bw.G1T + (size_t)blk * (NF1 * 16) + (16 * (mg * MPW + m) + j) * 16 + 4 * g);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int row = blk * 16 + 4 * g + e;
-            const float* rb = src.base(row < R ? row : R - 1, 0);
-#pragma unroll
-            for (int n = 0; n < NPW; ++n) o.b[n][e] = rb[soff[n]];
-        }
-    };
     const int nblk = (R + 15) / 16;
     const int per = (nblk + nwg - 1) / nwg;
     const int bA = bid * per, bB = (bA + per) < nblk ? bA + per : nblk;
-    Ops cur, nxt;
-    if (bA < bB) load(bA, cur);
-    for (int blk = bA; blk < bB; ++blk) {
-        load(blk + 1 < bB ? blk + 1 : blk, nxt);
+    float sv[LW::NST];
+    f4 av[LW::NA4];
+    auto request = [&](int blk) {  // this thread's share of block blk into registers
+        const int row = blk * 16 + sr;
+        const float* rb = src.base(row < R ? row : R - 1, 0);
+#pragma unroll
+        for (int i = 0; i < LW::NST; ++i) sv[i] = rb[soff[i]];
+        const f4* ga = reinterpret_cast<const f4*>(bw.G1T + (size_t)blk * (NF1 * 16));
+#pragma unroll
+        for (int i = 0; i < LW::NA4; ++i) av[i] = (tid + 512 * i) < LW::TA / 4 ? ga[tid + 512 * i] : zero4;
+    };
+    auto publish = [&](int buf) {  // registers -> LDS buffer `buf`
+        float* ts = lds + buf * (LW::TS + LW::TA);
+        f4* ta = reinterpret_cast<f4*>(ts + LW::TS);
+#pragma unroll
+        for (int i = 0; i < LW::NST; ++i)
+            if (sc + 32 * i < LW::SDP) ts[(sc + 32 * i) * 16 + sr] = sv[i];
+#pragma unroll
+        for (int i = 0; i < LW::NA4; ++i)
+            if ((tid + 512 * i) < LW::TA / 4) ta[tid + 512 * i] = av[i];
+    };
+    auto mac = [&](int buf) {
+        const float* ts = lds + buf * (LW::TS + LW::TA);
+        const float* ta = ts + LW::TS;
+        f4 a[MPW], b[NPW];
+#pragma unroll
+        for (int m = 0; m < MPW; ++m) a[m] = *reinterpret_cast<const f4*>(ta + (16 * (mg * MPW + m) + j) * 16 + 4 * g);
+#pragma unroll
+        for (int n = 0; n < NPW; ++n) {
+            const int tile = ng + n * NG;
+            b[n] = *reinterpret_cast<const f4*>(ts + (16 * (tile < NTS ? tile : NTS - 1) + j) * 16 + 4 * g);
+        }
 #pragma unroll
         for (int m = 0; m < MPW; ++m)
-            if (ng == 0) cs1[m] += (cur.a[m][0] + cur.a[m][1]) + (cur.a[m][2] + cur.a[m][3]);
+            if (ng == 0) cs1[m] += (a[m][0] + a[m][1]) + (a[m][2] + a[m][3]);
         if constexpr (H16) {
             sh4 ah[MPW], bh[NPW];
 #pragma unroll
-            for (int m = 0; m < MPW; ++m) ah[m] = to_bf16x4(cur.a[m][0], cur.a[m][1], cur.a[m][2], cur.a[m][3]);
+            for (int m = 0; m < MPW; ++m) ah[m] = to_bf16x4(a[m][0], a[m][1], a[m][2], a[m][3]);
 #pragma unroll
-            for (int n = 0; n < NPW; ++n)
-                bh[n] = sval[n] ? to_bf16x4(cur.b[n][0], cur.b[n][1], cur.b[n][2], cur.b[n][3]) : to_bf16x4(0.f, 0.f, 0.f, 0.f);
+            for (int n = 0; n < NPW; ++n) bh[n] = to_bf16x4(b[n][0], b[n][1], b[n][2], b[n][3]);
 #pragma unroll
             for (int n = 0; n < NPW; ++n)
 #pragma unroll
                 for (int m = 0; m < MPW; ++m) accW[m][n] = MARL_MFMA_BF16(ah[m], bh[n], accW[m][n]);
         } else {
 #pragma unroll
-        for (int n = 0; n < NPW; ++n)
+            for (int n = 0; n < NPW; ++n)
 #pragma unroll
-            for (int m = 0; m < MPW; ++m)
+                for (int m = 0; m < MPW; ++m)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) accW[m][n] = MARL_MFMA(cur.a[m][e], sval[n] ? cur.b[n][e] : 0.f, accW[m][n]);
+                    for (int e = 0; e < 4; ++e) accW[m][n] = MARL_MFMA(a[m][e], b[n][e], accW[m][n]);
         }
-        cur = nxt;
+    };
+    if (bA < bB) {
+        request(bA);
+        publish(0);
+        if (bA + 1 < bB) request(bA + 1);
+        __syncthreads();
+        for (int blk = bA; blk < bB; ++blk) {
+            const int buf = (blk - bA) & 1;
+            if (blk + 1 < bB) publish(buf ^ 1);      // block blk + 1 (requested one block ago); its buffer was last read two blocks ago, behind a barrier
+            if (blk + 2 < bB) request(blk + 2);
+            mac(buf);
+            __syncthreads();
+        }
     }
     float* rec = partials + (size_t)bid * Q::NPARAM;
 #pragma unroll
@@ -1045,9 +1086,12 @@ __device__ __forceinline__ void qmix_wgrad2_body(const QmixBwd& bw, int R, float
 // workgroup b of either group writes its (disjoint) entries of record b.  Each group alone is latency-bound on its operand stream and leaves
 // most of the chip idle; side by side they overlap.
 template <class Q, bool REPLAY, bool H16 = false>
-__global__ __launch_bounds__(512, 1) void qmix_wgrad_kernel(QmixRows<Q, REPLAY> src, QmixBwd bw, int R, float* __restrict__ partials) {
+__global__ __launch_bounds__(512, 1) void qmix_wgrad_kernel(QmixRows<Q, REPLAY> src, QmixBwd bw, int R, float* __restrict__ partials, int only = 0) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // QmixWg1Lds<Q>::FLOATS (the first group's operand tiles)
     const int nwg = gridDim.x >> 1;
-    if ((int)blockIdx.x < nwg) qmix_wgrad1_body<Q, REPLAY, H16>(src, bw, R, partials, blockIdx.x, nwg);
+    if (only == 1 && (int)blockIdx.x >= nwg) return;  // (diagnostics, MARLHIP_QMIX_WG_ONLY: time one group alone; the gradient is then incomplete)
+    if (only == 2 && (int)blockIdx.x < nwg) return;
+    if ((int)blockIdx.x < nwg) qmix_wgrad1_body<Q, REPLAY, H16>(src, bw, R, partials, blockIdx.x, nwg, lds);
     else qmix_wgrad2_body<Q, H16>(bw, R, partials, blockIdx.x - nwg, nwg);
 }
 
@@ -1211,10 +1255,19 @@ int qmix_launch_mix(const QmixCtx& qx, const marlhip_batch* bt, const ReplaySrc&
             hipLaunchKernelGGL((qmix_l1_kernel<Q, REPLAY>), dim3(g1), dim3(256), CH, st, l1o, src, 0, R, y1o, (const h4*)nullptr);
         hipLaunchKernelGGL((qmix_mix_kernel<Q, true>), dim3(g2), dim3(256), LM_ON, st, mxo, (const float*)y1o, io2, R, gamma, bw);
     }
+    constexpr int LW_BYTES = QmixWg1Lds<Q>::FLOATS * (int)sizeof(float);
+    static_assert(LW_BYTES <= 160 * 1024, "qmix_wgrad_kernel: LDS");
+    static LdsAttr attr_wg;
+    if (attr_wg.need()) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qmix_wgrad_kernel<Q, REPLAY, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LW_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qmix_wgrad_kernel<Q, REPLAY>), hipFuncAttributeMaxDynamicSharedMemorySize, LW_BYTES);
+        attr_wg.done();
+    }
     if (qx.l1_fp16)  // the opt-in covers the mixer's weight-gradient products too (round 4)
-        hipLaunchKernelGGL((qmix_wgrad_kernel<Q, REPLAY, true>), dim3(2 * wl.nwg3), dim3(512), 0, st, src, bw, R, reinterpret_cast<float*>(base + wl.partials));
+        hipLaunchKernelGGL((qmix_wgrad_kernel<Q, REPLAY, true>), dim3(2 * wl.nwg3), dim3(512), LW_BYTES, st, src, bw, R, reinterpret_cast<float*>(base + wl.partials));
     else
-        hipLaunchKernelGGL((qmix_wgrad_kernel<Q, REPLAY>), dim3(2 * wl.nwg3), dim3(512), 0, st, src, bw, R, reinterpret_cast<float*>(base + wl.partials));
+        hipLaunchKernelGGL((qmix_wgrad_kernel<Q, REPLAY>), dim3(2 * wl.nwg3), dim3(512), LW_BYTES, st, src, bw, R, reinterpret_cast<float*>(base + wl.partials),
+                           getenv("MARLHIP_QMIX_WG_ONLY") ? atoi(getenv("MARLHIP_QMIX_WG_ONLY")) : 0);
     timing_end(TIMER_QMIX, st);
     MARL_CHECK_LAUNCH("qmix mixer stage");
     return 0;
