@@ -681,7 +681,6 @@ def bench_dqn(args, rank, world, dist, steps, warmup):
     cap = args.replay_rounds * N
     trainer = VectorisedIDQN(cfg, model, cap, T, B, U, seed=args.seed, dist=dist)
     eps_sched = _epsilon_schedule("linear", 0.5, 1.0, 0.05, 6.5, 100_000_000)
-    steps_dev = trainer.env_steps
     # `modes` row "trained policy": `pretrain_rounds` untimed rounds of the same loop with epsilon annealed 1 -> eps_fixed over their first
     # 60 %, then the warm-up and the timed rounds at eps_fixed (secondary_modes sets both; the default line has neither)
     pre, eps_fixed = int(getattr(args, "pretrain_rounds", 0) or 0), getattr(args, "eps_fixed", None)
@@ -702,7 +701,7 @@ def bench_dqn(args, rank, world, dist, steps, warmup):
     for _ in range(pre + warmup):
         one_round()
     sync()
-    steps_dev.zero_()
+    trainer.reset_env_steps()
     if not args.no_kernel_timing:
         lib.marlhip_timing_enable(1)
     t0 = time.perf_counter()
@@ -714,6 +713,8 @@ def bench_dqn(args, rank, world, dist, steps, warmup):
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt[0])
+    steps_dev = trainer.env_steps
+    if dist is not None:
         dist.all_reduce(steps_dev)
     env_steps = int(steps_dev.item())
     mean_return = float(trainer.fin_return.sum(0).mean().item())  # the last round's episodes, summed over the agents (this rank's)

@@ -149,7 +149,9 @@ class VectorisedIDQN:
         dev = model.device
         self.fin_return = torch.zeros(model.n_agents, self.N, device=dev)
         self.fin_length = torch.zeros(self.N, dtype=torch.int32, device=dev)
-        self.env_steps = torch.zeros((), dtype=torch.int64, device=dev)  # counted on the device
+        # env-steps counted on the device: ONE elementwise launch per round (per-env episode lengths added into an accumulator), reduced
+        # when somebody reads `env_steps` - a sum + add + conversion per round made the collector-only loop host-bound on a busy host
+        self._len_acc = torch.zeros(self.N, dtype=torch.int64, device=dev)
         self.rounds = 0
         self.sample_counter = 0
         self.last_loss = None
@@ -159,6 +161,14 @@ class VectorisedIDQN:
             # per-agent RunningMeanStd: batch moments summed over the ranks before the running update (standardise_stream.py:15-20 on the
             # global batch); VDN / QMIX keep one (mean, var) per batch column - a rank's columns are its own part of the global batch
             model.updater.ret_stats.attach_exchange(lambda t: dist.all_reduce(t))
+
+    @property
+    def env_steps(self):
+        """0-dim int64 device tensor: transitions collected since construction (or the last reset_env_steps)"""
+        return self._len_acc.sum()
+
+    def reset_env_steps(self):
+        self._len_acc.zero_()
 
     def _grad_sync(self, grad):
         from ..parallel import GradSync
@@ -210,7 +220,7 @@ class VectorisedIDQN:
             _hip.idqn_collect(self.cfg, m.spec, m.params, epsilon, self.rounds, self.replay, slot_base, self.fin_return,
                               self.fin_length, write_replay=True, clear_stale=self.clear_stale,
                               use_proper_termination=self.proper)
-        self.env_steps += self.fin_length.sum()
+        self._len_acc.add_(self.fin_length)
         self.rounds += 1
         if train and self.U > 0 and m.mode != 2 and not m.standardise_returns and not _NO_FUSED_LOOP and not getattr(m, "recurrent", False) and not m.spec.wide and m.updater.optimizer == 0:  # the n-updates library call has no mixer / no return statistics (those loop here)
             # one library call for all U updates; with N > 1 ranks its data-parallel form: the gradient all-reduce is the only host hop
