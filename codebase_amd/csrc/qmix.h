@@ -178,94 +178,105 @@ __device__ __forceinline__ size_t qmix_state_off(int k, size_t ps) {  // k < SD
 // ---------------------------------------------------------------------------------------------------------
 // HALF: the A operands come as fp16 (packh: h4 per entry) and the states are rounded to fp16 on the way in (LBF / warehouse observations
 // are small integers: exact); one v_mfma_f32_16x16x16_f16 per (k-group, tile) instead of four f32 MFMAs, fp32 accumulation, fp32 bias.
+// Round 5: the B operand (state rows) goes through LDS with the weights.  Until then every wave fetched it with 80 dword loads per block, each
+// touching 16 rows x 16 bytes - 47 % of the kernel's wave cycles waiting on memory, the L2 missing on 46 % of its requests (rows re-fetched
+// sector by sector, profiles/r05_qmix8p_sq_counters.md).  Now the chunk staging that brings 64 weight columns into LDS also brings the
+// workgroup's 64 rows x the same 64 state columns: every load instruction is 64 consecutive columns of one row, every row sector is fetched
+// once, and a lane's four k values of a group are one ds_read_b128 out of a [k-group][g][row][e] tile (g-stride padded to 68 floats: the
+// transposing writes spread over the banks).  A operand, pack layout and the order of products per accumulator are unchanged: bitwise the
+// results of the direct-load form.
+template <class Q>
+struct QmixL1Lds {
+    static constexpr int WCH = 4 * Q::MT1 * 256;          // floats of one weight chunk (64 columns x 192 features)
+    static constexpr int GS = 68;                         // floats per (k-group, g) slab of a wave's state tile: 16 rows x 4 e + 4 pad
+    static constexpr int STILE = 4 * 4 * GS;              // one wave's tile: 4 k-groups x 4 g
+    static constexpr int FLOATS = WCH + 4 * STILE;
+};
+
 template <class Q, bool REPLAY, bool HALF = false>
-__global__ __launch_bounds__(256) void qmix_l1_kernel(const float* __restrict__ pack, QmixRows<Q, REPLAY> src, int toff, int R,
+__global__ __launch_bounds__(256, 2) void qmix_l1_kernel(const float* __restrict__ pack, QmixRows<Q, REPLAY> src, int toff, int R,
                                                       float* __restrict__ Y1, const h4* __restrict__ packh = nullptr) {
-    constexpr int NB = MARL_QMIX_L1_NB, MT1 = Q::MT1, KS4 = Q::KS4, NCH = Q::NCH, SD = Q::SD;
+    using LL = QmixL1Lds<Q>;
+    constexpr int MT1 = Q::MT1, KS4 = Q::KS4, NCH = Q::NCH, SD = Q::SD;
+    static_assert(MARL_QMIX_L1_NB == 1, "the LDS-staged state tile is one row block per wave");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     f4* lds4 = reinterpret_cast<f4*>(lds);
     h4* ldsh = reinterpret_cast<h4*>(lds);
+    float* stile = lds + LL::WCH;  // (the fp16 form's weight chunk takes half of the weight region; the state tiles stay where they are)
     const f4* pack4 = reinterpret_cast<const f4*>(pack);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, j = lane & 15;
-    const int ngroups = (R + 64 * NB - 1) / (64 * NB);
+    const int ngroups = (R + 63) / 64;
     const size_t ps = src.pstride();
-    if (NCH == 1) {
-        if (HALF) copy_f4_to_lds(reinterpret_cast<const f4*>(packh), lds4, KS4 * MT1 * 64 / 2, tid, 256);  // 8-byte entries, copied 16 bytes at a time
-        else copy_f4_to_lds(pack4, lds4, KS4 * MT1 * 64, tid, 256);
-        __syncthreads();
-    }
+    // staging role: column (tid & 63) of the chunk, rows (tid >> 6) + 4 i of the workgroup's 64; where the element lands: its row's wave tile,
+    // slab (k-group, g) = (column / 16, column % 4), slot (row % 16) * 4 + (column % 16) / 4
+    const int scol = tid & 63, srow0 = tid >> 6;
+    const int sdst = ((scol >> 4) * 4 + (scol & 3)) * LL::GS + ((scol & 15) >> 2);
     for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
-        const float* rb[NB];
-        int row[NB];
+        const int row = (grp * 4 + wave) * 16 + j;
+        const float* rbs[16];  // the 16 rows this thread stages, for all chunks of the group
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            row[nb] = ((grp * 4 + wave) * NB + nb) * 16 + j;
-            rb[nb] = src.base(row[nb] < R ? row[nb] : R - 1, toff);
+        for (int i = 0; i < 16; ++i) {
+            const int r = grp * 64 + srow0 + 4 * i;
+            rbs[i] = src.base(r < R ? r : R - 1, toff);
         }
-        f4 acc[NB][MT1];
+        f4 acc[MT1];
 #pragma unroll
-        for (int mt = 0; mt < MT1; ++mt) {
-            const f4 b = *reinterpret_cast<const f4*>(pack + Q::pL1b + 16 * mt + 4 * g);
+        for (int mt = 0; mt < MT1; ++mt) acc[mt] = *reinterpret_cast<const f4*>(pack + Q::pL1b + 16 * mt + 4 * g);
+        // chunk c + 1's state column rides in registers while chunk c is multiplied (requested right behind the barrier that publishes chunk c;
+        // the weight share as well was measured to spill: 48 more registers next to 48 accumulators and the 16 row pointers)
+        float sv[16];
+        bool kin = false;
+        auto request = [&](int c) {
+            const int k = 64 * c + scol;  // this thread's state column of the chunk (clamped: columns past SD are staged as zeros)
+            kin = k < SD;
+            const size_t off = qmix_state_off<Q>(kin ? k : SD - 1, ps);
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) acc[nb][mt] = b;
-        }
+            for (int i = 0; i < 16; ++i) sv[i] = rbs[i][off];
+        };
+        request(0);
+#pragma unroll 1
+        for (int c = 0; c < NCH; ++c) {  // (not unrolled: five copies of the prefetch with their own operand sets spill 750 B per lane)
+            const int n4 = (KS4 - 4 * c) < 4 ? (KS4 - 4 * c) : 4;
+            __syncthreads();  // the previous chunk's readers are done
+            if (HALF) copy_f4_to_lds(reinterpret_cast<const f4*>(packh + c * 4 * MT1 * 64), lds4, n4 * MT1 * 64 / 2, tid, 256);
+            else copy_f4_to_lds(pack4 + c * 4 * MT1 * 64, lds4, n4 * MT1 * 64, tid, 256);
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            constexpr int full = 4;
-            const int n4 = (KS4 - 4 * c) < full ? (KS4 - 4 * c) : full;
-            if (NCH > 1) {
-                __syncthreads();
-                if (HALF) copy_f4_to_lds(reinterpret_cast<const f4*>(packh + c * 4 * MT1 * 64), lds4, n4 * MT1 * 64 / 2, tid, 256);
-                else copy_f4_to_lds(pack4 + c * 4 * MT1 * 64, lds4, n4 * MT1 * 64, tid, 256);
-                __syncthreads();
+            for (int i = 0; i < 16; ++i) {
+                const int rl = srow0 + 4 * i;  // row inside the workgroup's 64: wave rl / 16, row rl % 16 of its tile
+                stile[(rl >> 4) * LL::STILE + sdst + (rl & 15) * 4] = kin ? sv[i] : 0.f;
             }
+            __syncthreads();
+            if (c + 1 < NCH) request(c + 1);
+            const float* mine = stile + wave * LL::STILE + g * LL::GS + j * 4;
 #pragma unroll
             for (int q4 = 0; q4 < 4; ++q4) {
                 if (q4 < n4) {
-                    float x[NB][4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int k = 16 * (4 * c + q4) + 4 * e + g;
-                        const size_t off = qmix_state_off<Q>(k < SD ? k : SD - 1, ps);
-#pragma unroll
-                        for (int nb = 0; nb < NB; ++nb) {
-                            const float v = rb[nb][off];
-                            x[nb][e] = k < SD ? v : 0.f;
-                        }
-                    }
+                    const f4 x = *reinterpret_cast<const f4*>(mine + q4 * 4 * LL::GS);  // x[e] = state[row j][16 (4 c + q4) + 4 e + g]
                     if constexpr (HALF) {
-                        h4 xh[NB];
+                        h4 xh;
 #pragma unroll
-                        for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) xh[nb][e] = (_Float16)x[nb][e];
+                        for (int e = 0; e < 4; ++e) xh[e] = (_Float16)x[e];
 #pragma unroll
                         for (int mt = 0; mt < MT1; ++mt) {
                             const h4 a = ldsh[(q4 * MT1 + mt) * 64 + lane];
-#pragma unroll
-                            for (int nb = 0; nb < NB; ++nb) acc[nb][mt] = __builtin_amdgcn_mfma_f32_16x16x16f16(a, xh[nb], acc[nb][mt], 0, 0, 0);
+                            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x16f16(a, xh, acc[mt], 0, 0, 0);
                         }
                     } else {
 #pragma unroll
                         for (int mt = 0; mt < MT1; ++mt) {
                             const f4 a = lds4[(q4 * MT1 + mt) * 64 + lane];
 #pragma unroll
-                            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                                for (int nb = 0; nb < NB; ++nb) acc[nb][mt] = MARL_MFMA(a[e], x[nb][e], acc[nb][mt]);
+                            for (int e = 0; e < 4; ++e) acc[mt] = MARL_MFMA(a[e], x[e], acc[mt]);
                         }
                     }
                 }
             }
         }
+        if (row < R) {
+            float* y = Y1 + (size_t)row * Q::NF1 + 4 * g;
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            if (row[nb] < R) {
-                float* y = Y1 + (size_t)row[nb] * Q::NF1 + 4 * g;
-#pragma unroll
-                for (int mt = 0; mt < MT1; ++mt)
-                    *reinterpret_cast<f4*>(y + 16 * mt) = (mt < 4 || mt >= 8) ? relu4(acc[nb][mt]) : acc[nb][mt];
-            }
+            for (int mt = 0; mt < MT1; ++mt)
+                *reinterpret_cast<f4*>(y + 16 * mt) = (mt < 4 || mt >= 8) ? relu4(acc[mt]) : acc[mt];
         }
     }
 }
@@ -1229,7 +1240,7 @@ int qmix_launch_mix(const QmixCtx& qx, const marlhip_batch* bt, const ReplaySrc&
         }
     } else {
         // split form: Y1 of either instance through memory (target: the G1T buffer, dead until the online backward; online: HB, all 192 columns)
-        constexpr int CH = 4 * Q::MT1 * 256 * (int)sizeof(float);
+        constexpr int CH = QmixL1Lds<Q>::FLOATS * (int)sizeof(float);  // weight chunk + the four waves' state tiles
         constexpr int LM_ON = Q::NMIX * (int)sizeof(float), LM_TG = Q::NMIX_FWD * (int)sizeof(float);
         static LdsAttr attr_set;
         if (attr_set.need()) {
@@ -1240,17 +1251,19 @@ int qmix_launch_mix(const QmixCtx& qx, const marlhip_batch* bt, const ReplaySrc&
             attr_set.done();
         }
         const int ngroups = (R + 64 * MARL_QMIX_L1_NB - 1) / (64 * MARL_QMIX_L1_NB);
-        const int g1 = ngroups < 768 ? ngroups : 768;
+        // two workgroups of the first-layer kernel fit a CU (65 KB of LDS, <= 256 registers): 512 resident ones walk the groups - a third per CU
+        // would only start when the first have finished (768 of them left half the chip idle for a third of the launch)
+        const int g1 = ngroups < 512 ? ngroups : 512;
         const int g2 = (nblk + 3) / 4 < 256 ? (nblk + 3) / 4 : 256;
         float* y1t = bw.G1T, *y1o = bw.HB;
         if (qx.l1_fp16)
-            hipLaunchKernelGGL((qmix_l1_kernel<Q, REPLAY, true>), dim3(g1), dim3(256), CH / 2, st, l1t, src, 1, R, y1t, packh_t);
+            hipLaunchKernelGGL((qmix_l1_kernel<Q, REPLAY, true>), dim3(g1), dim3(256), CH, st, l1t, src, 1, R, y1t, packh_t);
         else
             hipLaunchKernelGGL((qmix_l1_kernel<Q, REPLAY>), dim3(g1), dim3(256), CH, st, l1t, src, 1, R, y1t, (const h4*)nullptr);
         hipLaunchKernelGGL((qmix_mix_kernel<Q, false>), dim3(g2), dim3(256), LM_TG, st, mxt, (const float*)y1t, io2, R, gamma, bw);
         if (standardise() != 0) return -1;
         if (qx.l1_fp16)
-            hipLaunchKernelGGL((qmix_l1_kernel<Q, REPLAY, true>), dim3(g1), dim3(256), CH / 2, st, l1o, src, 0, R, y1o, packh);
+            hipLaunchKernelGGL((qmix_l1_kernel<Q, REPLAY, true>), dim3(g1), dim3(256), CH, st, l1o, src, 0, R, y1o, packh);
         else
             hipLaunchKernelGGL((qmix_l1_kernel<Q, REPLAY>), dim3(g1), dim3(256), CH, st, l1o, src, 0, R, y1o, (const h4*)nullptr);
         hipLaunchKernelGGL((qmix_mix_kernel<Q, true>), dim3(g2), dim3(256), LM_ON, st, mxo, (const float*)y1o, io2, R, gamma, bw);
