@@ -810,21 +810,31 @@ __global__ __launch_bounds__(256, 1) void qmix_mix_kernel(const float* __restric
     copy_f4_to_lds(reinterpret_cast<const f4*>(pack), reinterpret_cast<f4*>(lds), NPK / 4, tid, 256);
     __syncthreads();
     const int nblk = (R + 15) / 16;
-    for (int blk = blockIdx.x * 4 + wave; blk < nblk; blk += gridDim.x * 4) {
+    // the NEXT block's first-layer rows are requested before the current block's mixing network runs (round 5: one wave per SIMD here - the
+    // 150 KB of mixing pack - so nothing else covers the 12 row loads at the top of a block)
+    struct Rows { f4 h1[2], hf[2], z[4], hv[4]; };
+    auto request = [&](int blk, Rows& r) {
         const int row = blk * 16 + j;
         const float* y1 = Y1 + (size_t)(row < R ? row : R - 1) * Q::NF1 + 4 * g;
-        f4 h1[2], hf[2], z[4], hv[4];
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            h1[k] = *reinterpret_cast<const f4*>(y1 + 16 * k);
-            hf[k] = *reinterpret_cast<const f4*>(y1 + 32 + 16 * k);
+            r.h1[k] = *reinterpret_cast<const f4*>(y1 + 16 * k);
+            r.hf[k] = *reinterpret_cast<const f4*>(y1 + 32 + 16 * k);
         }
 #pragma unroll
         for (int et = 0; et < 4; ++et) {
-            z[et] = *reinterpret_cast<const f4*>(y1 + 64 + 16 * et);
-            hv[et] = *reinterpret_cast<const f4*>(y1 + 128 + 16 * et);
+            r.z[et] = *reinterpret_cast<const f4*>(y1 + 64 + 16 * et);
+            r.hv[et] = *reinterpret_cast<const f4*>(y1 + 128 + 16 * et);
         }
-        qmix_mix_block<Q, ONLINE, false, 0>(lds, pack, h1, hf, z, hv, io, R, gamma, bw, blk, lane);
+    };
+    const int stride = gridDim.x * 4;
+    int blk = blockIdx.x * 4 + wave;
+    Rows cur, nxt;
+    if (blk < nblk) request(blk, cur);
+    for (; blk < nblk; blk += stride) {
+        request(blk + stride < nblk ? blk + stride : blk, nxt);
+        qmix_mix_block<Q, ONLINE, false, 0>(lds, pack, cur.h1, cur.hf, cur.z, cur.hv, io, R, gamma, bw, blk, lane);
+        cur = nxt;
     }
 }
 
