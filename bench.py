@@ -262,15 +262,17 @@ def dqn_update_flops(algo, rnn, P, D, A, H, T, B):
     return agents + mixer, {"agent_networks": agents, "mixer": mixer, "first_layer_input_gradient (counted, never run)": unneeded}
 
 
-def ac_update_flops(rnn, P, D, A, H, T, N, central, epochs=1):
+def ac_update_flops(rnn, P, D, A, H, T, N, central, epochs=1, actor_forward_kept=False):
     """target-critic forward on T+1 rows, critic and actor forward + backward (3 x forward) on T rows; recurrent nets walk
     T+1 / T steps the same way.  PPO (`epochs` > 1): the prepare pass (target critic + old log-probs = one actor forward) once,
-    then critic + actor forward / backward per epoch - the timer brackets one launch group, so this returns the per-call mean."""
+    then critic + actor forward / backward per epoch - the timer brackets one launch group, so this returns the per-call mean.
+    actor_forward_kept (A2C on the fused collectors): the rollout left the actors' logits and hidden layers for the step
+    (marlhip_*_ac_collect_keep), which then runs the actors' backward only - the stage under the timer does 2 x, not 3 x, their forward."""
     f = gru_fwd_flops if rnn else mlp_fwd_flops
     fa, fc = f(D, H, A), f(P * D if central else D, H, 1)
     if epochs > 1:  # launch groups under the timer per rollout: 1 prepare + `epochs` epoch steps
         return P * N * ((fc * (T + 1) + fa * T) + epochs * (3 * fc + 3 * fa) * T) / (1 + epochs)
-    return P * N * (fc * (T + 1) + 3 * fc * T + 3 * fa * T)
+    return P * N * (fc * (T + 1) + 3 * fc * T + (2 if actor_forward_kept else 3) * fa * T)
 
 
 def ac_unneeded_flops(P, D, H, T, N, central, epochs=1):
@@ -394,7 +396,7 @@ def bench_ac(args, rank, world, dist, steps=None, warmup=None):
             state["step"] += T * N
             return
         h.ac_collect(cfg, model.spec, model.actor_params, state["round"], T, False, b_obs, b_act, b_rew, b_done, b_fill, fin_ret,
-                     fin_len, t_max)
+                     fin_len, t_max, keep_for=model.updater if getattr(model, "keeps_actor_forward", False) else None)
         b_donef.copy_(b_done)  # batch.dones.float() (ac/model.py:198)
         model.update_async(Batch(b_obs, b_act, b_rew, b_donef, b_fill, None), state["step"], grad_sync=sync_grad, world=world)
         len_acc.add_(fin_len)  # sum == b_fill.sum(): every env stores exactly its first episode (the collector's contract; checked once below)
@@ -450,10 +452,13 @@ def bench_ac(args, rank, world, dist, steps=None, warmup=None):
     upd = timing.get("ac_update (fwd rows x3, elementwise, bwd rows x2)")
     col = timing.get("ac_collect_kernel")
     if upd:
-        flops = ac_update_flops(bool(args.rnn), P, D, A, H, T, N, central, epochs=hyper["num_epochs"] if args.algo in ("ippo", "mappo") else 1)
+        kept = bool(getattr(model.updater, "last_step_used_kept_forward", False))  # A2C: the collector left the actors' forward pass for the step
+        flops = ac_update_flops(bool(args.rnn), P, D, A, H, T, N, central, epochs=hyper["num_epochs"] if args.algo in ("ippo", "mappo") else 1,
+                                actor_forward_kept=kept)
         ach = flops / (upd["avg_us"] * 1e-6) / 1e12
         needed = flops - ac_unneeded_flops(P, D, H, T, N, central, epochs=hyper["num_epochs"] if args.algo in ("ippo", "mappo") else 1)
-        roofline = {"kernel": "ac_update stage (forward rows, elementwise, backward rows)", "bound": "mfma", "achieved": ach,
+        roofline = {"kernel": "ac_update stage (forward rows, elementwise, backward rows)" + ("; the actors' forward pass is the collector's own, kept for the step" if kept else ""),
+                    "actor_forward_kept": kept, "bound": "mfma", "achieved": ach,
                     "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
                     "flops_per_launch": flops, "avg_launch_us": upd["avg_us"],
                     "flops_needed_per_launch": needed, "frac_needed": ach * needed / flops / PEAK_F32_MFMA_TFLOPS,

@@ -66,7 +66,7 @@ class AcConfig(ctypes.Structure):
                 ("gamma", c_double), ("ret_mean", c_void_p), ("ret_var", c_void_p), ("ret_count", c_void_p),
                 ("centralised_critic", c_int32), ("side_stream", c_void_p),
                 ("ret_exchange", c_void_p), ("ret_exchange_ctx", c_void_p), ("ret_moments", c_void_p),
-                ("critic_n_networks", c_int32), ("critic_net_of", c_int32 * 16)]
+                ("critic_n_networks", c_int32), ("critic_net_of", c_int32 * 16), ("actor_forward_kept", c_int32)]
 
 
 class RetStatsStruct(ctypes.Structure):
@@ -200,6 +200,12 @@ PROTOTYPES = {
                                         c_int32, c_float, c_void_p, c_void_p, c_void_p]),
     "marlhip_ac_collect": (c_int32, [POINTER(LbfConfig), POINTER(NetShape), c_void_p, c_uint32, c_int32, c_int32, c_void_p,
                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "marlhip_ac_collect_keep": (c_int32, [POINTER(LbfConfig), POINTER(NetShape), c_void_p, c_uint32, c_int32, c_int32, c_void_p,
+                                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p,
+                                          c_int64, c_void_p]),
+    "marlhip_rware_ac_collect_keep": (c_int32, [POINTER(RwareConfig), POINTER(NetShape), c_void_p, c_uint32, c_int32, c_int32, c_void_p,
+                                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32,
+                                                c_void_p, c_int64, c_void_p]),
     "marlhip_ac_store_step": (c_int32, [c_int32, c_int32, c_int32, c_int32, c_int32] + [c_void_p] * 16 + [c_int32, c_void_p, c_void_p, c_void_p]),
     "marlhip_ac_collect_later_episodes": (c_int32, [c_void_p, POINTER(NetShape), c_void_p, c_uint32, c_int32, c_void_p, c_void_p, c_int32, c_int32,
                                                     c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),

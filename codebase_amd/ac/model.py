@@ -202,6 +202,10 @@ class A2CNetwork:
         elif tui < 1.0:
             self.soft_update(tui)
 
+    # one update per rollout, on the parameters the rollout was sampled with (model.py:189-246): the fused collector leaves the actors'
+    # logits and hidden layers of every batch row for the step (hip.ac_collect(keep_for=updater)) instead of the step recomputing them
+    keeps_actor_forward = True
+
     def update_async(self, batch, step, grad_sync=None, world=1):
         """loss/grad -> [grad_sync(grad)] -> clip+Adam -> target update; returns the device metrics tensor
         (loss, actor_loss, value_loss, entropy, sum(filled)) without synchronising."""
@@ -263,6 +267,8 @@ class A2CNetwork:
 
 class PPONetwork(A2CNetwork):
     """marlbase/ac/model.py:249-352: returns and old log-probs once per batch, then num_epochs clipped-surrogate steps."""
+
+    keeps_actor_forward = False  # the epochs move the parameters: only A2C's single step sees the collector's own forward pass
 
     def __init__(self, obs_space, action_space, cfg, actor, critic, device="cuda"):
         super().__init__(obs_space, action_space, cfg, actor, critic, device)

@@ -119,8 +119,10 @@ def _collect_trajectories(envs, model, max_ep_length, parallel_envs, n_agents, d
     if getattr(model, "recurrent", False) or model.spec.wide:  # no fused collector for these: the modular loop
         t, batch, fin_ret, fin_len, later = _collect_trajectories_recurrent(envs, model, T, use_proper_termination, round_idx)
     else:
+        # A2C: the update that follows runs on these parameters, so the collector leaves the actors' forward pass for it (hip.ac_collect)
+        keep_for = getattr(model, "updater", None) if getattr(model, "keeps_actor_forward", False) else None
         _hip.ac_collect(cfg, model.spec, model.actor_params, round_idx, T, use_proper_termination, b_obs, b_act, b_rew, b_done,
-                        b_fill, fin_ret, fin_len, t_max)
+                        b_fill, fin_ret, fin_len, t_max, keep_for=keep_for)
         t = int(t_max.item())
         batch = Batch(b_obs, b_act, b_rew, b_done.bool(), b_fill, None)
         second = (want_infos or bool(getattr(cfg, "reward_stats", None))) and not _FIRST_EPISODES_ONLY

@@ -187,6 +187,74 @@ extern "C" int marlhip_ac_forward_rows(const marlhip_net_shape* s, int32_t value
     return -1;
 }
 
+// ---- the rollout that keeps the actors' forward pass for the step (AcKeep, common.h; ac_keep_layout, a2c_core.h) -------------------
+namespace {
+template <class T>
+struct ShapeTag {
+    using type = T;
+};
+
+// f(actor shape, critic shape) for the shapes with FUSED actors - ac_call's dispatch for them
+template <class F>
+int ac_fused_actor_dispatch(const marlhip_net_shape* s, int centralised, F&& f) {
+    MARL_REQUIRE(ac_compiled(s), "ac_collect_keep: actors D=%d H=%d A=%d run on the GEMM path, which has no fused collector", s->obs_dim, s->hidden,
+                 s->n_actions);
+    if (centralised) {
+        if (mac_compiled(s)) {
+#define X(p, d, h) if (s->n_agents == p && s->obs_dim == d && s->hidden == h) return f(ShapeTag<MlpShape<d, h, 6>>{}, ShapeTag<MlpShape<p * d, h, 1>>{});
+            MARL_MAC_SHAPES(X)
+#undef X
+        }
+#define X(d, h, a)                                                                   \
+    if (s->obs_dim == d && s->hidden == h && s->n_actions == a) {                    \
+        WideCritic<h>::D = s->n_agents * d;                                          \
+        return f(ShapeTag<MlpShape<d, h, a>>{}, ShapeTag<WideCritic<h>>{});          \
+    }
+        MARL_AC_SHAPES(X)
+#undef X
+    }
+#define X(d, h, a) if (s->obs_dim == d && s->hidden == h && s->n_actions == a) return f(ShapeTag<MlpShape<d, h, a>>{}, ShapeTag<MlpShape<d, h, 1>>{});
+    MARL_AC_SHAPES(X)
+#undef X
+    set_error("ac_collect_keep: no fused actor shape D=%d H=%d A=%d", s->obs_dim, s->hidden, s->n_actions);
+    return -1;
+}
+
+int ac_keep_for(const marlhip_net_shape* s, int centralised, int T, int B, void* ws, int64_t ws_bytes, AcKeep* k, hipStream_t st) {
+    MARL_REQUIRE(ws != nullptr, "ac_collect_keep: NULL learner workspace");
+    if (ac_check(s, centralised) != 0) return -1;
+    return ac_fused_actor_dispatch(s, centralised, [&](auto sa, auto sc) {
+        return ac_keep_layout<typename decltype(sa)::type, typename decltype(sc)::type>(s->n_agents, T, B, ws, ws_bytes, k, st);
+    });
+}
+}  // namespace
+
+extern "C" int marlhip_ac_collect_keep(const marlhip_lbf_config* cfg, const marlhip_net_shape* s, const float* actor_params, uint32_t round,
+                                       int32_t max_len, int32_t use_proper_termination, float* batch_obs, int64_t* batch_act, float* batch_rew,
+                                       uint8_t* batch_done, float* batch_filled, float* fin_return, int32_t* fin_length, int32_t* t_max,
+                                       void* workspace, int64_t workspace_bytes, int32_t centralised, void* learner_workspace,
+                                       int64_t learner_workspace_bytes, void* stream) {
+    MARL_REQUIRE(cfg != nullptr, "ac_collect_keep: NULL config");
+    AcKeep k = {};
+    if (ac_keep_for(s, centralised, max_len, cfg->n_envs, learner_workspace, learner_workspace_bytes, &k, (hipStream_t)stream) != 0) return -1;
+    AcKeepScope scope(k);
+    return marlhip_ac_collect(cfg, s, actor_params, round, max_len, use_proper_termination, batch_obs, batch_act, batch_rew, batch_done, batch_filled,
+                              fin_return, fin_length, t_max, workspace, workspace_bytes, stream);
+}
+
+extern "C" int marlhip_rware_ac_collect_keep(const marlhip_rware_config* cfg, const marlhip_net_shape* s, const float* actor_params, uint32_t round,
+                                             int32_t max_len, int32_t use_proper_termination, float* batch_obs, int64_t* batch_act, float* batch_rew,
+                                             uint8_t* batch_done, float* batch_filled, float* fin_return, int32_t* fin_length, int32_t* t_max,
+                                             void* workspace, int64_t workspace_bytes, int32_t centralised, void* learner_workspace,
+                                             int64_t learner_workspace_bytes, void* stream) {
+    MARL_REQUIRE(cfg != nullptr, "rware_ac_collect_keep: NULL config");
+    AcKeep k = {};
+    if (ac_keep_for(s, centralised, max_len, cfg->n_envs, learner_workspace, learner_workspace_bytes, &k, (hipStream_t)stream) != 0) return -1;
+    AcKeepScope scope(k);
+    return marlhip_rware_ac_collect(cfg, s, actor_params, round, max_len, use_proper_termination, batch_obs, batch_act, batch_rew, batch_done,
+                                    batch_filled, fin_return, fin_length, t_max, workspace, workspace_bytes, stream);
+}
+
 extern "C" int marlhip_a2c_loss_grad(const marlhip_net_shape* s, const float* actor, const float* critic, const float* target_critic,
                                      const marlhip_batch* batch, const marlhip_ac_config* cfg, void* workspace, int64_t workspace_bytes,
                                      float* actor_grad, float* critic_grad, float* metrics, void* stream) {

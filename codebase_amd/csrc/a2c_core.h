@@ -584,6 +584,56 @@ AcWs ac_ws_layout(int P, int T, int B) {
     return w;
 }
 
+// ---- the actors' forward pass kept by the rollout (AcKeep, common.h) ----------------------------------------------------------
+// tp_bwd_kernel walks row blocks in pairs: the empty second slot of an odd count per time step is zero-filled, as mlp_rows_fwd_kernel<S, 1>
+// does for its own record
+static __global__ __launch_bounds__(64) void ac_keep_pad_kernel(AcKeep k, int P, int MT) {
+    const int lane = threadIdx.x, t = blockIdx.x, p = blockIdx.y;
+    f4* hid = reinterpret_cast<f4*>(k.hid);
+    const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const size_t slot = ((((size_t)p * k.T + t) * k.bpt + (k.B >> 4)) * k.stride) * 64 + lane;
+    for (int mt = 0; mt < MT; ++mt) {
+        hid[k.off_h1 + slot + mt * 64] = zero4;
+        hid[k.off_h2 + slot + mt * 64] = zero4;
+    }
+}
+
+// where a rollout of (T, B) leaves the actors' logits and hidden layers inside the learner step's workspace: AcWs::logits / AcWs::rec_a in the
+// layout launch_backward_rows<SA> reads (the record mlp_rows_fwd_kernel<SA, HS> would write)
+template <class SA, class SC>
+int ac_keep_layout(int P, int T, int B, void* ws, int64_t ws_bytes, AcKeep* k, hipStream_t st) {
+    if constexpr (!mlp_stored_shape<SA>()) {
+        set_error("ac_collect_keep: the actors of this shape keep no forward pass (recurrent / GEMM-path networks)");
+        return -1;
+    } else {
+        MARL_REQUIRE(T > 0 && B > 0 && B % 16 == 0, "ac_collect_keep: the hidden-layer record is laid out in blocks of 16 envs (%d envs)", B);
+        const AcWs wl = ac_ws_layout<SA, SC>(P, T, B);
+        MARL_REQUIRE(ws_bytes >= wl.total, "ac_collect_keep: learner workspace %lld < %lld bytes (marlhip_ac_workspace_bytes)", (long long)ws_bytes,
+                     (long long)wl.total);
+        char* base = static_cast<char*>(ws);
+        k->logits = reinterpret_cast<float*>(base + wl.logits);
+        k->hid = reinterpret_cast<float*>(base + wl.rec_a);
+        k->T = T;
+        k->B = B;
+        if constexpr (use_tp<SA>()) {  // h2 record | h1 record (mlp_rows_fwd_kernel<S, 1>)
+            k->bpt = tp_h2_blocks(B);
+            k->stride = SA::MT;
+            k->off_h2 = 0;
+            k->off_h1 = (int64_t)P * T * k->bpt * SA::MT * 64;
+            if (((B >> 4) & 1) && k->bpt > (B >> 4)) {
+                hipLaunchKernelGGL(ac_keep_pad_kernel, dim3(T, P), dim3(64), 0, st, *k, P, (int)SA::MT);
+                MARL_CHECK_LAUNCH("ac_keep_pad_kernel");
+            }
+        } else {  // h1 | h2 inside a row block's slot (mlp_rows_fwd_kernel<S, 2>)
+            k->bpt = B >> 4;
+            k->stride = 2 * SA::MT;
+            k->off_h1 = 0;
+            k->off_h2 = SA::MT * 64;
+        }
+        return 0;
+    }
+}
+
 // SA / SC: the actors' and critics' shapes (MlpShape, or GruShape for recurrent networks)
 template <class SA, class SC>
 int ac_step_t(int P, const AgentMap& am, const float* actor, const float* critic, const float* target, const marlhip_batch* bt, const marlhip_ac_config* c,
@@ -667,8 +717,15 @@ int ac_step_t(int P, const AgentMap& am, const float* actor, const float* critic
         if (rc == -2) rc = launch_forward_rows<SC>(P, amc, critic, bc, TB, f(wl.v), st, rec_c);
         if (rc != 0) return rc;
     }
-    rc = launch_forward_rows<SA>(P, am, actor, bt, TB, f(wl.logits), st, rec_a);
-    if (rc != 0) return rc;
+    if (c->actor_forward_kept != 0) {
+        // the rollout's collector left the logits and the hidden-layer record of exactly these rows (marlhip_*_ac_collect_keep on this
+        // workspace, the same actor parameters): A2C's one update per rollout needs no second pass
+        MARL_REQUIRE(mode == 0 && rec_a != nullptr && mlp_stored_shape<SA>(),
+                     "ac_loss_grad: actor_forward_kept goes with marlhip_a2c_loss_grad on fused feed-forward actors and whole blocks of 16 envs");
+    } else {
+        rc = launch_forward_rows<SA>(P, am, actor, bt, TB, f(wl.logits), st, rec_a);
+        if (rc != 0) return rc;
+    }
     side.do_join();  // before the elementwise stage
     hipLaunchKernelGGL(ac_elem_kernel, dim3((TB + 255) / 256), dim3(256), 0, st, a, *bt, w);
     MARL_CHECK_LAUNCH("ac_elem_kernel");

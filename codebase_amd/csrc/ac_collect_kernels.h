@@ -15,6 +15,7 @@
 #pragma once
 #include "collect_common.h"
 #include "env_traits.h"
+#include "mlp_keep.h"
 
 namespace marl {
 
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(NW * HS > 4 ? 64 * NW * HS : ACOL_BLOCK) void ac_co
                                                                 int64_t* __restrict__ b_act, float* __restrict__ b_rew,
                                                                 uint8_t* __restrict__ b_done, float* __restrict__ b_filled,
                                                                 float* __restrict__ fin_return, int32_t* __restrict__ fin_length,
-                                                                int32_t* __restrict__ t_max, AcGhost gh) {
+                                                                int32_t* __restrict__ t_max, AcGhost gh, AcKeep kp) {
     constexpr int P = ENV::P, D = ENV::D0 + (OID ? P : 0), A = ENV::A;
     using S = MlpShape<D, H, A>;
     using PP = PackPlan<S, P, ENV::LDS_MAX>;
@@ -168,6 +169,11 @@ __global__ __launch_bounds__(NW * HS > 4 ? 64 * NW * HS : ACOL_BLOCK) void ac_co
     float* tile = reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(lds) + (FROM_GLOBAL ? 0 : PP::LDS_BYTES) + ENV::LDS_MAX) + (size_t)wave * OT::ELEMS;
     const int n0 = (blockIdx.x * bpw + blk) * 16;
     const bool tstore = TSTORE && !ghost && n0 + 16 <= N && storer;
+    // AcKeep (common.h): the wave leaves the logits and both hidden layers of its agents' rows where the learner step reads them (whole env
+    // blocks of the batch only - the launcher checked B == n_envs and B % 16 == 0); wave-uniform
+    const bool keep = kp.hid != nullptr && !ghost && n0 + 16 <= N;
+    f4* const kp_hid = reinterpret_cast<f4*>(kp.hid);
+    auto keep_slot = [&](int t, int p) { return ((((size_t)p * kp.T + t) * kp.bpt + (n0 >> 4)) * kp.stride) * 64 + lane; };
     int t_off[TSTORE ? OT::NI : 1];  // float offset of tile element 64 i + lane inside the block's 16 batch rows (agent 0)
     if constexpr (TSTORE) {
 #pragma unroll
@@ -256,14 +262,53 @@ __global__ __launch_bounds__(NW * HS > 4 ? 64 * NW * HS : ACOL_BLOCK) void ac_co
                     pack = lds;
                 }
                 f4 h1[S::MT], h2[S::MT], logits, unused;
-                if constexpr (HS == 2) mlp_forward_h2<S, XR>(pack, lane, x[k], half, s_xh + aw * (2 * XT * 64), s_xq + aw * 64, logits, PP::A3REG ? a3[PP::A3REG ? k : 0] : nullptr);  // (half 1 only)
-                else if constexpr (FROM_GLOBAL) mlp_forward_g<S>(pack, lane, x[k], logits);
-                else mlp_forward_p<S, false>(pack, pack, lane, x[k], h1, h2, logits, unused, PP::A3REG ? a3[PP::A3REG ? k : 0] : nullptr);
+                f4* const d1 = keep ? kp_hid + kp.off_h1 + keep_slot(t, p) : nullptr;
+                f4* const d2 = keep ? kp_hid + kp.off_h2 + keep_slot(t, p) : nullptr;
+                if constexpr (HS == 2) {
+                    mlp_forward_h2_keep<S, XR>(pack, lane, x[k], half, s_xh + aw * (2 * XT * 64), s_xq + aw * 64, logits, PP::A3REG ? a3[PP::A3REG ? k : 0] : nullptr, d1, d2);  // (logits: half 1 only)
+                } else if constexpr (FROM_GLOBAL) {
+                    mlp_forward_g_keep<S>(pack, lane, x[k], logits, d1, d2);
+                } else {
+                    mlp_forward_p<S, false>(pack, pack, lane, x[k], h1, h2, logits, unused, PP::A3REG ? a3[PP::A3REG ? k : 0] : nullptr);
+                    if (keep) {
+#pragma unroll
+                        for (int mt = 0; mt < S::MT; ++mt) {
+                            d1[mt * 64] = h1[mt];
+                            d2[mt * 64] = h2[mt];
+                        }
+                    }
+                }
+                if (keep && half == HS - 1) {  // mlp_rows_fwd_kernel's `out`: lane (g, j) holds outputs 4 g + r of env j
+                    float* lo = kp.logits + (((size_t)p * kp.T + t) * kp.B + n) * A + 4 * g;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (4 * g + r < A) lo[r] = logits[r];
+                }
                 ACOL_TS(0)
                 const float u = u01_f32(act_noise_word(q.seed, env_id, 2u * round, (uint32_t)t, 1 + p));
                 own[k] = sample_rows<A>(logits, lane, u);
                 if (WPB == 1) act[k] = own[k];
                 ACOL_TS(1)
+            }
+        } else if (keep) {  // no env of the block is running any more: the rows stay in the batch (filled = 0) and their gradients are
+            // masked, but 0 x (whatever the record held) must be 0
+            const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const int p = aw + k * NW;
+                f4* const d1 = kp_hid + kp.off_h1 + keep_slot(t, p);
+                f4* const d2 = kp_hid + kp.off_h2 + keep_slot(t, p);
+#pragma unroll
+                for (int m = 0; m < S::MT / HS; ++m) {
+                    d1[(half * (S::MT / HS) + m) * 64] = zero4;
+                    d2[(half * (S::MT / HS) + m) * 64] = zero4;
+                }
+                if (half == HS - 1) {
+                    float* lo = kp.logits + (((size_t)p * kp.T + t) * kp.B + n) * A + 4 * g;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (4 * g + r < A) lo[r] = 0.f;
+                }
             }
         }
         if (WPB > 1) {  // swap the sampled actions among the waves of the env block (double-buffered: one barrier per step)
@@ -407,9 +452,18 @@ int launch_ac_collect_nw(const typename ENV::Params& q, const float* packs, uint
     // swap is a workgroup barrier, and with several blocks per workgroup every block waits for the slowest one's step
     const bool one_block = HS > 1 || (NW > 1 && (int64_t)((q.n_envs + 15) / 16) * NW <= 1024);
     const int threads = (one_block || NW * HS > 4) ? 64 * NW * HS : ACOL_BLOCK, per_wg = 16 * (threads / (64 * NW * HS));  // envs per workgroup
+    // the actors' forward pass kept for the learner step (AcKeep): first passes over the whole batch only, and the record is laid out for
+    // this rollout's (T, B)
+    AcKeep keep_here = ac_keep_current();
+    if (keep_here.hid != nullptr) {
+        MARL_REQUIRE(ac_ghost_current().env_ids == nullptr, "ac_collect: the second pass of a rollout keeps no forward pass");
+        MARL_REQUIRE(keep_here.T == T && keep_here.B == q.n_envs && q.n_envs % 16 == 0,
+                     "ac_collect: the kept forward pass is laid out for %d x %d rows, the rollout has %d x %d (envs in whole blocks of 16)",
+                     keep_here.T, keep_here.B, T, q.n_envs);
+    }
     timing_begin(TIMER_COLLECT, st);
     hipLaunchKernelGGL((ac_collect_kernel<ENV, H, OID, NW, HS>), dim3((q.n_envs + per_wg - 1) / per_wg), dim3(threads), lds_bytes, st, q, packs, round, T,
-                       proper_term, b_obs, b_act, b_rew, b_done, b_filled, fin_return, fin_length, t_max, ac_ghost_current());
+                       proper_term, b_obs, b_act, b_rew, b_done, b_filled, fin_return, fin_length, t_max, ac_ghost_current(), keep_here);
     timing_end(TIMER_COLLECT, st);
     MARL_CHECK_LAUNCH("ac_collect_kernel");
     return 0;

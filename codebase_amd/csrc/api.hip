@@ -54,6 +54,10 @@ static thread_local AcGhost g_ac_ghost = {};
 const AcGhost& ac_ghost_current() { return g_ac_ghost; }
 void ac_ghost_bind(const AcGhost* g) { g_ac_ghost = g != nullptr ? *g : AcGhost{}; }
 
+static thread_local AcKeep g_ac_keep = {};
+const AcKeep& ac_keep_current() { return g_ac_keep; }
+void ac_keep_bind(const AcKeep* k) { g_ac_keep = k != nullptr ? *k : AcKeep{}; }
+
 int64_t scratch_avail() {  // bytes collect_pack_scratch can hand out in this call
     if (g_scratch_base == nullptr) return 0;
     char* b = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(g_scratch_base) + 15) & ~(uintptr_t)15);

@@ -54,6 +54,27 @@ struct AcGhostScope {
     AcGhostScope& operator=(const AcGhostScope&) = delete;
 };
 
+// The actors' forward pass kept by the rollout (round 5).  A2C updates once per rollout, on the parameters the rollout was sampled with
+// (ac/train.py:203-212 -> ac/model.py:189-246): the logits and both hidden layers the learner step computes for every batch row
+// (mlp_rows_fwd_kernel<S, HS> over T*B rows per agent) are the values the collector had in registers when it sampled that row's action -
+// the same packs, the same operand order, bit for bit.  With a record bound, the fused collector writes them where the learner step
+// reads them (AcWs::logits, AcWs::rec_a) and marlhip_ac_config.actor_forward_kept skips the pass.  hid == NULL: nothing is kept.
+struct AcKeep {
+    float* logits;           // [P][T*B][A], row = t * B + env
+    float* hid;              // 16-byte tiles [64 lanes] in the MFMA C layout: tile index ((p T + t) bpt + env / 16) stride + tile of the layer
+    int T, B, bpt, stride;   // bpt row-block slots per time step, `stride` tiles per slot
+    int64_t off_h1, off_h2;  // tile offsets of the layers' tile 0 (hidden 128: the h1 record behind the h2 record, tp_bwd_kernel<STORED1>;
+                             // hidden 64: h1 | h2 inside a slot, dqn_lossgrad_kernel<MODE 4, STORED>)
+};
+const AcKeep& ac_keep_current();  // the calling host thread's binding (api.hip)
+void ac_keep_bind(const AcKeep* k);
+struct AcKeepScope {
+    explicit AcKeepScope(const AcKeep& k) { ac_keep_bind(&k); }
+    ~AcKeepScope() { ac_keep_bind(nullptr); }
+    AcKeepScope(const AcKeepScope&) = delete;
+    AcKeepScope& operator=(const AcKeepScope&) = delete;
+};
+
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: one slot per device ordinal, raised monotonically (a racing second
 // call sets the same value)
 struct LdsAttr {

@@ -7,10 +7,16 @@ from dataclasses import dataclass
 
 import torch
 
+import os
+
 from . import _lib
 from ._lib import (AcConfig, BatchStruct, IdqnLearner, QmixLearner, RetStatsStruct, QmixMixer, LbfBuffers, LbfConfig, MarlHipError, RwareConfig, NetShape, ReplayBuffers, ReplayShape, check, lib)
 
 Batch = namedtuple("Batch", ["obss", "actions", "rewards", "dones", "filled", "action_mask"])  # dqn/train.py:14-16
+
+
+# MARLHIP_AC_NO_KEEP=1: A2C's step always runs the actors' forward pass itself (diagnostics; the collector then keeps nothing)
+_NO_KEEP = bool(os.environ.get("MARLHIP_AC_NO_KEEP"))
 
 
 def _require_gpu():
@@ -670,6 +676,13 @@ class AcUpdater:
         self.grad_clip = float(grad_clip) if grad_clip else 0.0
         self.step = 0
         self._ws = {}
+        self._kept = None  # (T, B, batch obs pointer) of the rollout whose actor forward pass sits in the workspace (ac_collect(keep_for=self))
+
+    # ---- the actors' forward pass kept by the rollout (marlhip_*_ac_collect_keep; include/marlhip.h) ------------------------------
+    def can_keep(self, n_envs, actor_params):
+        """fused feed-forward actors, envs in whole blocks of 16, and the rollout sampled with THIS updater's actor block"""
+        return (not self.recurrent and not self.spec.wide and n_envs % 16 == 0 and not _NO_KEEP
+                and actor_params.data_ptr() == self.actor.data_ptr())
 
     def attach_exchange(self, reduce):
         """data-parallel training with standardise_returns: batch moments summed over the ranks (marlhip_ac_config.ret_exchange)"""
@@ -703,12 +716,21 @@ class AcUpdater:
                          D, P * D, 1, P, _mask_ptr(masks, (T + 1, N, P, self.spec.n_actions)))
         return bs, keep, T, N
 
-    def a2c_loss_grad(self, batch):
+    def a2c_loss_grad(self, batch, kept=True):
+        """kept: let the step read the actors' logits and hidden layers the collector left (ac_collect(keep_for=self)) instead of running the
+        pass again - taken only when the batch is that rollout's (same T x N, same observation tensor) and the parameters have not moved
+        since (apply() voids the record); False: always recompute."""
         bs, keep, T, N = self._batch(batch)
         ws, s = self._workspace(T, N), self.spec.c()
-        check(self._fn[0](ctypes.byref(s), _ptr(self.actor), _ptr(self.critic), _ptr(self.target_critic),
-                                        ctypes.byref(bs), ctypes.byref(self.cfg), _ptr(ws), ws.numel(), _ptr(self.actor_grad),
-                                        _ptr(self.critic_grad), _ptr(self.metrics), _stream()), "a2c_loss_grad")
+        use = bool(kept) and self._kept is not None and self._kept == (T, N, keep[0].data_ptr()) and not bs.action_mask
+        self.cfg.actor_forward_kept = int(use)
+        try:
+            check(self._fn[0](ctypes.byref(s), _ptr(self.actor), _ptr(self.critic), _ptr(self.target_critic),
+                                            ctypes.byref(bs), ctypes.byref(self.cfg), _ptr(ws), ws.numel(), _ptr(self.actor_grad),
+                                            _ptr(self.critic_grad), _ptr(self.metrics), _stream()), "a2c_loss_grad")
+        finally:
+            self.cfg.actor_forward_kept = 0
+        self.last_step_used_kept_forward = bool(use)
         return self.metrics
 
     def ppo_prepare(self, batch):
@@ -728,6 +750,7 @@ class AcUpdater:
     def apply(self, grad_scale=1.0):
         """clip_grad_norm_(self.parameters(), grad_clip) + optimizer.step() (model.py:227-231): one norm over actor + critic"""
         self.step += 1
+        self._kept = None  # the parameters move: a kept forward pass is no longer this network's
         _clip_step(self.optimizer, self.block.numel(), self.block, self.grad, self.exp_avg, self.exp_avg_sq, None, self.step, self.lr, self.betas,
                    self.eps, self.grad_clip, grad_scale, False, 0.0, self.scratch, self.gnorm if self.grad_clip else None,  # (no clip: no norm launch)
                    "dqn_clip_step(actor+critic)")
@@ -851,15 +874,26 @@ class FusedQmixLearner:
 
 
 def ac_collect(cfg, spec: NetSpec, actor_params, round_idx, max_len, use_proper_termination, b_obs, b_act, b_rew,
-               b_done, b_filled, fin_return, fin_length, t_max):
-    """Fused actor-critic rollout collector (marlbase/ac/train.py:24-119): one launch = one collection call."""
+               b_done, b_filled, fin_return, fin_length, t_max, keep_for=None):
+    """Fused actor-critic rollout collector (marlbase/ac/train.py:24-119): one launch = one collection call.
+    keep_for: the AcUpdater whose A2C step will run on this rollout - when the rollout is sampled with ITS actor block, the collector leaves
+    the actors' logits and hidden layers in the updater's workspace (marlhip_*_ac_collect_keep) and `a2c_loss_grad` on these batch tensors
+    reads them instead of running the pass again (AcUpdater.can_keep says for which shapes).  Returns True when the pass was kept."""
     _require_gpu()
     s = spec.c()
+    args = (ctypes.byref(cfg), ctypes.byref(s), _ptr(actor_params), int(round_idx) & 0xFFFFFFFF, int(max_len),
+            int(bool(use_proper_termination)), _ptr(b_obs), _ptr(b_act), _ptr(b_rew), _ptr(b_done),
+            _ptr(b_filled), _ptr(fin_return), _ptr(fin_length), _ptr(t_max), *_fwd_ws(spec, actor_params.device))
+    if keep_for is not None and keep_for.can_keep(cfg.n_envs, actor_params):
+        ws = keep_for._workspace(int(max_len), int(cfg.n_envs))
+        fn = lib.marlhip_rware_ac_collect_keep if is_rware(cfg) else lib.marlhip_ac_collect_keep
+        keep_for._kept = None
+        check(fn(*args, keep_for.centralised, _ptr(ws), ws.numel(), _stream()), "ac_collect_keep")
+        keep_for._kept = (int(max_len), int(cfg.n_envs), b_obs.data_ptr())
+        return True
     fn = lib.marlhip_rware_ac_collect if is_rware(cfg) else lib.marlhip_ac_collect
-    check(fn(ctypes.byref(cfg), ctypes.byref(s), _ptr(actor_params), int(round_idx) & 0xFFFFFFFF, int(max_len),
-                                 int(bool(use_proper_termination)), _ptr(b_obs), _ptr(b_act), _ptr(b_rew), _ptr(b_done),
-                                 _ptr(b_filled), _ptr(fin_return), _ptr(fin_length), _ptr(t_max), *_fwd_ws(spec, actor_params.device),
-                                 _stream()), "ac_collect")
+    check(fn(*args, _stream()), "ac_collect")
+    return False
 
 
 def ac_store_step(env, t, proper, running, acts, b_obs, b_act, b_rew, b_done, b_fill, fin_ret, fin_len, later=None):

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MARLHIP_VERSION 212
+#define MARLHIP_VERSION 213
 
 int marlhip_version(void);
 const char* marlhip_last_error(void);
@@ -523,6 +523,10 @@ typedef struct marlhip_ac_config {
      * are then [critic_n_networks][n] blocks - while the actors keep marlhip_net_shape's; 0: one map for both (the default). */
     int32_t critic_n_networks;
     int32_t critic_net_of[16];
+    /* C-ABI 213, marlhip_a2c_loss_grad only: the rollout was collected by marlhip_ac_collect_keep / marlhip_rware_ac_collect_keep into THIS
+     * call's workspace with THESE actor parameters - the actors' logits and hidden layers of every batch row are already there and the
+     * step does not compute them again.  0 (default): the step runs the actors' forward pass itself. */
+    int32_t actor_forward_kept;
 } marlhip_ac_config;
 
 int marlhip_ac_critic_nparams(const marlhip_net_shape* s, int32_t centralised); /* per critic block */
@@ -536,6 +540,23 @@ int marlhip_ac_forward_rows(const marlhip_net_shape* s, int32_t value_net, const
 int marlhip_a2c_loss_grad(const marlhip_net_shape* s, const float* actor, const float* critic, const float* target_critic,
                           const marlhip_batch* batch, const marlhip_ac_config* cfg, void* workspace, int64_t workspace_bytes,
                           float* actor_grad, float* critic_grad, float* metrics, void* stream);
+/* marlhip_ac_collect / marlhip_rware_ac_collect that also KEEP the actors' forward pass for the learner step (C-ABI 213).  A2C updates once
+ * per rollout on the parameters the rollout was sampled with (ac/train.py:203-212, ac/model.py:189-246), so the logits and hidden layers
+ * A2CNetwork.update recomputes for every batch row (model.py:206-213) are the values the collector held when it sampled that row's action:
+ * the same packs and operand order, the same bits.  The collector writes them into `learner_workspace` (the marlhip_a2c_loss_grad
+ * workspace for max_len x n_envs rows, >= marlhip_ac_workspace_bytes(s, centralised, max_len, n_envs)) where the step reads them; the
+ * following marlhip_a2c_loss_grad on that workspace sets marlhip_ac_config.actor_forward_kept.  Fused feed-forward actors and n_envs % 16
+ * == 0 only (an error otherwise); rows of envs whose episode is over hold zeros (their gradients are masked by `filled`). */
+int marlhip_ac_collect_keep(const marlhip_lbf_config* cfg, const marlhip_net_shape* s, const float* actor_params, uint32_t round,
+                            int32_t max_len, int32_t use_proper_termination, float* batch_obs, int64_t* batch_act, float* batch_rew,
+                            uint8_t* batch_done, float* batch_filled, float* fin_return, int32_t* fin_length, int32_t* t_max,
+                            void* workspace, int64_t workspace_bytes, int32_t centralised, void* learner_workspace,
+                            int64_t learner_workspace_bytes, void* stream);
+int marlhip_rware_ac_collect_keep(const marlhip_rware_config* cfg, const marlhip_net_shape* s, const float* actor_params, uint32_t round,
+                                  int32_t max_len, int32_t use_proper_termination, float* batch_obs, int64_t* batch_act, float* batch_rew,
+                                  uint8_t* batch_done, float* batch_filled, float* fin_return, int32_t* fin_length, int32_t* t_max,
+                                  void* workspace, int64_t workspace_bytes, int32_t centralised, void* learner_workspace,
+                                  int64_t learner_workspace_bytes, void* stream);
 /* PPONetwork.update: marlhip_ppo_prepare once per batch (returns + old log-probs, kept in the workspace: model.py:266-293),
  * then per epoch marlhip_ppo_loss_grad + marlhip_dqn_clip_adam (model.py:296-335). */
 int marlhip_ppo_prepare(const marlhip_net_shape* s, const float* actor, const float* critic, const float* target_critic,

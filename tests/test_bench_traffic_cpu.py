@@ -56,3 +56,5 @@ def test_needed_flops_leave_out_exactly_the_first_layer_input_gradient():
     assert 0.14 < dx / full < 0.17  # 312-wide centralised critics: the share that makes the two fractions differ visibly
     # PPO: per launch group (1 prepare + E epochs), only the E epoch groups run a backward pass
     assert bench.ac_unneeded_flops(P, D, H, T, N, True, epochs=4) == dx * 4 / 5
+    # A2C on a rollout whose collector kept the actors' forward pass: the step runs one actor forward less (T rows per agent and env)
+    assert full - bench.ac_update_flops(False, P, D, A, H, T, N, True, actor_forward_kept=True) == bench.mlp_fwd_flops(D, H, A) * P * N * T
