@@ -267,12 +267,14 @@ def ac_update_flops(rnn, P, D, A, H, T, N, central, epochs=1, actor_forward_kept
     T+1 / T steps the same way.  PPO (`epochs` > 1): the prepare pass (target critic + old log-probs = one actor forward) once,
     then critic + actor forward / backward per epoch - the timer brackets one launch group, so this returns the per-call mean.
     actor_forward_kept (A2C on the fused collectors): the rollout left the actors' logits and hidden layers for the step
-    (marlhip_*_ac_collect_keep), which then runs the actors' backward only - the stage under the timer does 2 x, not 3 x, their forward."""
+    (marlhip_*_ac_collect_keep), which then runs the actors' backward only - the stage under the timer does 2 x, not 3 x, their forward;
+    PPO: the prepare pass and the first epoch read it (the later epochs run on moved parameters)."""
     f = gru_fwd_flops if rnn else mlp_fwd_flops
     fa, fc = f(D, H, A), f(P * D if central else D, H, 1)
-    if epochs > 1:  # launch groups under the timer per rollout: 1 prepare + `epochs` epoch steps
-        return P * N * ((fc * (T + 1) + fa * T) + epochs * (3 * fc + 3 * fa) * T) / (1 + epochs)
-    return P * N * (fc * (T + 1) + 3 * fc * T + (2 if actor_forward_kept else 3) * fa * T)
+    k = 1 if actor_forward_kept else 0
+    if epochs > 1:  # launch groups under the timer per rollout: 1 prepare + `epochs` epoch steps (kept: neither the prepare pass nor the first epoch runs the actors' forward)
+        return P * N * ((fc * (T + 1) + (1 - k) * fa * T) + (epochs * (3 * fc + 3 * fa) - k * fa) * T) / (1 + epochs)
+    return P * N * (fc * (T + 1) + 3 * fc * T + (3 - k) * fa * T)
 
 
 def ac_unneeded_flops(P, D, H, T, N, central, epochs=1):
@@ -395,8 +397,8 @@ def bench_ac(args, rank, world, dist, steps=None, warmup=None):
             state["round"] += 1
             state["step"] += T * N
             return
-        h.ac_collect(cfg, model.spec, model.actor_params, state["round"], T, False, b_obs, b_act, b_rew, b_done, b_fill, fin_ret,
-                     fin_len, t_max, keep_for=model.updater if getattr(model, "keeps_actor_forward", False) else None)
+        state["kept"] = h.ac_collect(cfg, model.spec, model.actor_params, state["round"], T, False, b_obs, b_act, b_rew, b_done, b_fill, fin_ret,
+                                     fin_len, t_max, keep_for=model.updater if getattr(model, "keeps_actor_forward", False) else None)
         b_donef.copy_(b_done)  # batch.dones.float() (ac/model.py:198)
         model.update_async(Batch(b_obs, b_act, b_rew, b_donef, b_fill, None), state["step"], grad_sync=sync_grad, world=world)
         len_acc.add_(fin_len)  # sum == b_fill.sum(): every env stores exactly its first episode (the collector's contract; checked once below)
@@ -452,7 +454,7 @@ def bench_ac(args, rank, world, dist, steps=None, warmup=None):
     upd = timing.get("ac_update (fwd rows x3, elementwise, bwd rows x2)")
     col = timing.get("ac_collect_kernel")
     if upd:
-        kept = bool(getattr(model.updater, "last_step_used_kept_forward", False))  # A2C: the collector left the actors' forward pass for the step
+        kept = bool(state.get("kept", False))  # the collector left the actors' forward pass for the step (hip.ac_collect(keep_for=...))
         flops = ac_update_flops(bool(args.rnn), P, D, A, H, T, N, central, epochs=hyper["num_epochs"] if args.algo in ("ippo", "mappo") else 1,
                                 actor_forward_kept=kept)
         ach = flops / (upd["avg_us"] * 1e-6) / 1e12

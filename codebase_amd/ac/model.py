@@ -268,7 +268,8 @@ class A2CNetwork:
 class PPONetwork(A2CNetwork):
     """marlbase/ac/model.py:249-352: returns and old log-probs once per batch, then num_epochs clipped-surrogate steps."""
 
-    keeps_actor_forward = False  # the epochs move the parameters: only A2C's single step sees the collector's own forward pass
+    # the old log-probs (model.py:266-293) and the first epoch run on the parameters the rollout was sampled with: both read the collector's
+    # forward pass; the first apply() voids it and epochs 2.. run the pass themselves
 
     def __init__(self, obs_space, action_space, cfg, actor, critic, device="cuda"):
         super().__init__(obs_space, action_space, cfg, actor, critic, device)

@@ -720,8 +720,9 @@ int ac_step_t(int P, const AgentMap& am, const float* actor, const float* critic
     if (c->actor_forward_kept != 0) {
         // the rollout's collector left the logits and the hidden-layer record of exactly these rows (marlhip_*_ac_collect_keep on this
         // workspace, the same actor parameters): A2C's one update per rollout needs no second pass
-        MARL_REQUIRE(mode == 0 && rec_a != nullptr && mlp_stored_shape<SA>(),
-                     "ac_loss_grad: actor_forward_kept goes with marlhip_a2c_loss_grad on fused feed-forward actors and whole blocks of 16 envs");
+        // (PPO: marlhip_ppo_prepare's old log-probs, and the FIRST epoch's step - the parameters have not moved yet)
+        MARL_REQUIRE((mode == 1 || rec_a != nullptr) && mlp_stored_shape<SA>() && bt->batch % 16 == 0,
+                     "ac_loss_grad: actor_forward_kept goes with fused feed-forward actors and whole blocks of 16 envs");
     } else {
         rc = launch_forward_rows<SA>(P, am, actor, bt, TB, f(wl.logits), st, rec_a);
         if (rc != 0) return rc;

@@ -722,29 +722,46 @@ class AcUpdater:
         since (apply() voids the record); False: always recompute."""
         bs, keep, T, N = self._batch(batch)
         ws, s = self._workspace(T, N), self.spec.c()
-        use = bool(kept) and self._kept is not None and self._kept == (T, N, keep[0].data_ptr()) and not bs.action_mask
-        self.cfg.actor_forward_kept = int(use)
-        try:
+        with self._kept_scope(kept, bs, keep, T, N):
             check(self._fn[0](ctypes.byref(s), _ptr(self.actor), _ptr(self.critic), _ptr(self.target_critic),
                                             ctypes.byref(bs), ctypes.byref(self.cfg), _ptr(ws), ws.numel(), _ptr(self.actor_grad),
                                             _ptr(self.critic_grad), _ptr(self.metrics), _stream()), "a2c_loss_grad")
-        finally:
-            self.cfg.actor_forward_kept = 0
-        self.last_step_used_kept_forward = bool(use)
         return self.metrics
 
-    def ppo_prepare(self, batch):
-        bs, keep, T, N = self._batch(batch)
-        ws, s = self._workspace(T, N), self.spec.c()
-        check(self._fn[1](ctypes.byref(s), _ptr(self.actor), _ptr(self.critic), _ptr(self.target_critic),
-                                      ctypes.byref(bs), ctypes.byref(self.cfg), _ptr(ws), ws.numel(), _stream()), "ppo_prepare")
+    def _kept_scope(self, kept, bs, keep, T, N):
+        """marlhip_ac_config.actor_forward_kept for ONE library call: set when the batch is the kept rollout's and the parameters are still
+        the ones it was sampled with; `last_step_used_kept_forward` says what the call did"""
+        use = bool(kept) and self._kept is not None and self._kept == (T, N, keep[0].data_ptr()) and not bs.action_mask
+        up = self
 
-    def ppo_loss_grad(self, batch):
+        class _Scope:
+            def __enter__(self):
+                up.cfg.actor_forward_kept = int(use)
+                up.last_step_used_kept_forward = bool(use)
+
+            def __exit__(self, *exc):
+                up.cfg.actor_forward_kept = 0
+                return False
+
+        return _Scope()
+
+    def ppo_prepare(self, batch, kept=True):
+        """kept: as a2c_loss_grad's - the old log-probs come from the logits the collector sampled the actions with (the same bits)"""
         bs, keep, T, N = self._batch(batch)
         ws, s = self._workspace(T, N), self.spec.c()
-        check(self._fn[2](ctypes.byref(s), _ptr(self.actor), _ptr(self.critic), ctypes.byref(bs), ctypes.byref(self.cfg),
-                                        _ptr(ws), ws.numel(), _ptr(self.actor_grad), _ptr(self.critic_grad), _ptr(self.metrics),
-                                        _stream()), "ppo_loss_grad")
+        with self._kept_scope(kept, bs, keep, T, N):
+            check(self._fn[1](ctypes.byref(s), _ptr(self.actor), _ptr(self.critic), _ptr(self.target_critic),
+                                          ctypes.byref(bs), ctypes.byref(self.cfg), _ptr(ws), ws.numel(), _stream()), "ppo_prepare")
+
+    def ppo_loss_grad(self, batch, kept=True):
+        """kept: the FIRST epoch of a rollout runs on the parameters it was sampled with - its actor forward pass is the collector's; apply()
+        voids the record, the later epochs run the pass themselves"""
+        bs, keep, T, N = self._batch(batch)
+        ws, s = self._workspace(T, N), self.spec.c()
+        with self._kept_scope(kept, bs, keep, T, N):
+            check(self._fn[2](ctypes.byref(s), _ptr(self.actor), _ptr(self.critic), ctypes.byref(bs), ctypes.byref(self.cfg),
+                                            _ptr(ws), ws.numel(), _ptr(self.actor_grad), _ptr(self.critic_grad), _ptr(self.metrics),
+                                            _stream()), "ppo_loss_grad")
         return self.metrics
 
     def apply(self, grad_scale=1.0):

@@ -523,9 +523,10 @@ typedef struct marlhip_ac_config {
      * are then [critic_n_networks][n] blocks - while the actors keep marlhip_net_shape's; 0: one map for both (the default). */
     int32_t critic_n_networks;
     int32_t critic_net_of[16];
-    /* C-ABI 213, marlhip_a2c_loss_grad only: the rollout was collected by marlhip_ac_collect_keep / marlhip_rware_ac_collect_keep into THIS
-     * call's workspace with THESE actor parameters - the actors' logits and hidden layers of every batch row are already there and the
-     * step does not compute them again.  0 (default): the step runs the actors' forward pass itself. */
+    /* C-ABI 213: the rollout was collected by marlhip_ac_collect_keep / marlhip_rware_ac_collect_keep into THIS call's workspace with THESE
+     * actor parameters - the actors' logits and hidden layers of every batch row are already there and the call does not compute them
+     * again.  For marlhip_a2c_loss_grad; for marlhip_ppo_prepare (the old log-probs) and the FIRST marlhip_ppo_loss_grad of a rollout
+     * (the later epochs run on moved parameters).  0 (default): the call runs the actors' forward pass itself. */
     int32_t actor_forward_kept;
 } marlhip_ac_config;
 
@@ -545,7 +546,8 @@ int marlhip_a2c_loss_grad(const marlhip_net_shape* s, const float* actor, const 
  * A2CNetwork.update recomputes for every batch row (model.py:206-213) are the values the collector held when it sampled that row's action:
  * the same packs and operand order, the same bits.  The collector writes them into `learner_workspace` (the marlhip_a2c_loss_grad
  * workspace for max_len x n_envs rows, >= marlhip_ac_workspace_bytes(s, centralised, max_len, n_envs)) where the step reads them; the
- * following marlhip_a2c_loss_grad on that workspace sets marlhip_ac_config.actor_forward_kept.  Fused feed-forward actors and n_envs % 16
+ * following marlhip_a2c_loss_grad (or marlhip_ppo_prepare + first marlhip_ppo_loss_grad) on that workspace sets
+ * marlhip_ac_config.actor_forward_kept.  Fused feed-forward actors and n_envs % 16
  * == 0 only (an error otherwise); rows of envs whose episode is over hold zeros (their gradients are masked by `filled`). */
 int marlhip_ac_collect_keep(const marlhip_lbf_config* cfg, const marlhip_net_shape* s, const float* actor_params, uint32_t round,
                             int32_t max_len, int32_t use_proper_termination, float* batch_obs, int64_t* batch_act, float* batch_rew,

@@ -150,9 +150,9 @@ def test_config5_qmix_15x15_8p5f_H128_B8192_through_the_trainer_vs_oracle_port()
 
 
 # ---- config 4: IA2C on rware-tiny-4ag, 2048 envs per GPU x 500 steps, 128-128 ------------------------------------------------------------
-def _collect_ac(h, name, N, T, H, seed, rnd, central=False, scale=1.0, keep=True, max_len=None):
+def _collect_ac(h, name, N, T, H, seed, rnd, central=False, scale=1.0, keep=True, max_len=None, ppo=False):
     """keep: the collector leaves the actors' forward pass for the A2C step, as ac/train.py's rollouts do (hip.ac_collect(keep_for=updater))"""
-    from codebase_amd.ac.model import A2CNetwork
+    from codebase_amd.ac.model import A2CNetwork, PPONetwork
     from codebase_amd.utils.envs import _space_pair
 
     cfg = h.env_config(name, N, T, seed=seed)
@@ -162,7 +162,9 @@ def _collect_ac(h, name, N, T, H, seed, rnd, central=False, scale=1.0, keep=True
     hyper = dict(optimizer="Adam", lr=3e-4, gamma=0.99, grad_clip=False, n_steps=5, entropy_coef=0.001, value_loss_coef=0.5,
                  standardise_returns=False, target_update_interval_or_tau=200)  # ia2c.yaml / maa2c.yaml
     net = dict(layers=[H, H], parameter_sharing=False, use_orthogonal_init=True, use_rnn=False)
-    model = A2CNetwork(obs_space, act_space, hyper, net, dict(net, centralised=central), "cuda")
+    if ppo:
+        hyper.update(num_epochs=4, ppo_clip=0.2, grad_clip=0.5, target_update_interval_or_tau=0.01)  # ippo.yaml / mappo.yaml
+    model = (PPONetwork if ppo else A2CNetwork)(obs_space, act_space, hyper, net, dict(net, centralised=central), "cuda")
     # thread-independent instances: the actors He-scaled (scaled up so that the policy is not uniform), critics / targets likewise
     model.actor_params.copy_(_perturbed(P, D, H, A, seed + 1) * scale)
     dc = P * D if central else D
