@@ -262,24 +262,26 @@ def dqn_update_flops(algo, rnn, P, D, A, H, T, B):
     return agents + mixer, {"agent_networks": agents, "mixer": mixer, "first_layer_input_gradient (counted, never run)": unneeded}
 
 
-def ac_update_flops(rnn, P, D, A, H, T, N, central, epochs=1, actor_forward_kept=False):
+def ac_update_flops(rnn, P, D, A, H, T, N, central, epochs=1, actor_forward_kept=False, critic_backward_deferred=False):
     """target-critic forward on T+1 rows, critic and actor forward + backward (3 x forward) on T rows; recurrent nets walk
     T+1 / T steps the same way.  PPO (`epochs` > 1): the prepare pass (target critic + old log-probs = one actor forward) once,
     then critic + actor forward / backward per epoch - the timer brackets one launch group, so this returns the per-call mean.
     actor_forward_kept (A2C on the fused collectors): the rollout left the actors' logits and hidden layers for the step
     (marlhip_*_ac_collect_keep), which then runs the actors' backward only - the stage under the timer does 2 x, not 3 x, their forward;
-    PPO: the prepare pass and the first epoch read it (the later epochs run on moved parameters)."""
+    PPO: the prepare pass and the first epoch read it (the later epochs run on moved parameters).
+    critic_backward_deferred (A2C, one process, no joint clip): the critics' backward pass runs on a stream of its own next to the following
+    rollout (update_async(overlap=True)) - it is not inside the timed launch group, so its 2 x forward is not counted for it either."""
     f = gru_fwd_flops if rnn else mlp_fwd_flops
     fa, fc = f(D, H, A), f(P * D if central else D, H, 1)
     k = 1 if actor_forward_kept else 0
     if epochs > 1:  # launch groups under the timer per rollout: 1 prepare + `epochs` epoch steps (kept: neither the prepare pass nor the first epoch runs the actors' forward)
         return P * N * ((fc * (T + 1) + (1 - k) * fa * T) + (epochs * (3 * fc + 3 * fa) - k * fa) * T) / (1 + epochs)
-    return P * N * (fc * (T + 1) + 3 * fc * T + (3 - k) * fa * T)
+    return P * N * (fc * (T + 1) + (1 if critic_backward_deferred else 3) * fc * T + (3 - k) * fa * T)
 
 
-def ac_unneeded_flops(P, D, H, T, N, central, epochs=1):
+def ac_unneeded_flops(P, D, H, T, N, central, epochs=1, critic_backward_deferred=False):
     """the first-layer input-gradient products inside ac_update_flops (see first_layer_dx_flops), per launch group like it"""
-    dx = (first_layer_dx_flops(D, H) + first_layer_dx_flops(P * D if central else D, H)) * P * N * T
+    dx = (first_layer_dx_flops(D, H) + (0.0 if critic_backward_deferred else first_layer_dx_flops(P * D if central else D, H))) * P * N * T
     return dx * epochs / (1 + epochs) if epochs > 1 else dx
 
 
@@ -363,12 +365,12 @@ def bench_ac(args, rank, world, dist, steps=None, warmup=None):
     model = (PPONetwork if args.algo in ("ippo", "mappo") else A2CNetwork)(obs_space, act_space, hyper, net,
                                                                            dict(net, centralised=central), "cuda")
     dev = model.device
-    b_obs = torch.empty(T + 1, N, P * D, device=dev)
-    b_act = torch.empty(T, N, P, dtype=torch.int64, device=dev)
-    b_rew = torch.empty(T, N, P, device=dev)
-    b_done = torch.empty(T + 1, N, dtype=torch.uint8, device=dev)
-    b_donef = torch.empty(T + 1, N, device=dev)
-    b_fill = torch.empty(T, N, device=dev)
+    # two sets of batch tensors, used in turn: A2C's critics finish their half of update r (backward pass, step, target update) on a stream
+    # of their own while rollout r + 1 is being written (update_async(overlap=True)) - the drivers allocate a fresh batch per rollout
+    # (ac/train.py:36-49), the bench keeps its two
+    bufs = [dict(obs=torch.empty(T + 1, N, P * D, device=dev), act=torch.empty(T, N, P, dtype=torch.int64, device=dev),
+                 rew=torch.empty(T, N, P, device=dev), done=torch.empty(T + 1, N, dtype=torch.uint8, device=dev),
+                 donef=torch.empty(T + 1, N, device=dev), fill=torch.empty(T, N, device=dev)) for _ in range(2)]
     fin_ret = torch.zeros(P, N, device=dev)
     fin_len = torch.zeros(N, dtype=torch.int32, device=dev)
     t_max = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -388,7 +390,15 @@ def bench_ac(args, rank, world, dist, steps=None, warmup=None):
 
         vec = HipForagingVecEnv(cfg)
 
+    # a stream of the bench's own: the critics' half of an A2C update can only run next to the following rollout when the caller is not on
+    # the default stream (AcUpdater.can_defer)
+    own_stream = torch.cuda.Stream(device=dev)
+
     def one_round():
+        with torch.cuda.stream(own_stream):
+            _one_round()
+
+    def _one_round():
         if args.rnn:
             tmax, batch, _, _, _ = _collect_trajectories_recurrent(vec, model, T, False, state["round"])
             model.update_async(batch._replace(dones=batch.dones.float()), state["step"], grad_sync=sync_grad, world=world)
@@ -397,10 +407,12 @@ def bench_ac(args, rank, world, dist, steps=None, warmup=None):
             state["round"] += 1
             state["step"] += T * N
             return
-        state["kept"] = h.ac_collect(cfg, model.spec, model.actor_params, state["round"], T, False, b_obs, b_act, b_rew, b_done, b_fill, fin_ret,
-                                     fin_len, t_max, keep_for=model.updater if getattr(model, "keeps_actor_forward", False) else None)
-        b_donef.copy_(b_done)  # batch.dones.float() (ac/model.py:198)
-        model.update_async(Batch(b_obs, b_act, b_rew, b_donef, b_fill, None), state["step"], grad_sync=sync_grad, world=world)
+        b = bufs[state["round"] & 1]
+        state["kept"] = h.ac_collect(cfg, model.spec, model.actor_params, state["round"], T, False, b["obs"], b["act"], b["rew"], b["done"], b["fill"],
+                                     fin_ret, fin_len, t_max, keep_for=model.updater if getattr(model, "keeps_actor_forward", False) else None)
+        b["donef"].copy_(b["done"])  # batch.dones.float() (ac/model.py:198)
+        model.update_async(Batch(b["obs"], b["act"], b["rew"], b["donef"], b["fill"], None), state["step"], grad_sync=sync_grad, world=world, overlap=True)
+        state["deferred"] = model.updater._critic_event is not None
         len_acc.add_(fin_len)  # sum == b_fill.sum(): every env stores exactly its first episode (the collector's contract; checked once below)
         tmax_acc.add_(t_max)
         state["round"] += 1
@@ -415,7 +427,7 @@ def bench_ac(args, rank, world, dist, steps=None, warmup=None):
         one_round()
     sync()
     if not args.rnn and n_warmup > 0:  # the counter above counts what the batch holds
-        assert int(fin_len.sum().item()) == int(b_fill.sum().item()), "stored transitions != sum of first-episode lengths"
+        assert int(fin_len.sum().item()) == int(bufs[(state["round"] - 1) & 1]["fill"].sum().item()), "stored transitions != sum of first-episode lengths"
     steps_dev.zero_()
     ref_steps.zero_()
     len_acc.zero_()
@@ -455,12 +467,14 @@ def bench_ac(args, rank, world, dist, steps=None, warmup=None):
     col = timing.get("ac_collect_kernel")
     if upd:
         kept = bool(state.get("kept", False))  # the collector left the actors' forward pass for the step (hip.ac_collect(keep_for=...))
+        deferred = bool(state.get("deferred", False))  # the critics' backward pass ran next to the following rollout, outside the timed launch group
         flops = ac_update_flops(bool(args.rnn), P, D, A, H, T, N, central, epochs=hyper["num_epochs"] if args.algo in ("ippo", "mappo") else 1,
-                                actor_forward_kept=kept)
+                                actor_forward_kept=kept, critic_backward_deferred=deferred)
         ach = flops / (upd["avg_us"] * 1e-6) / 1e12
-        needed = flops - ac_unneeded_flops(P, D, H, T, N, central, epochs=hyper["num_epochs"] if args.algo in ("ippo", "mappo") else 1)
+        needed = flops - ac_unneeded_flops(P, D, H, T, N, central, epochs=hyper["num_epochs"] if args.algo in ("ippo", "mappo") else 1,
+                                           critic_backward_deferred=deferred)
         roofline = {"kernel": "ac_update stage (forward rows, elementwise, backward rows)" + ("; the actors' forward pass is the collector's own, kept for the step" if kept else ""),
-                    "actor_forward_kept": kept, "bound": "mfma", "achieved": ach,
+                    "actor_forward_kept": kept, "critic_backward_overlaps_next_rollout": deferred, "bound": "mfma", "achieved": ach,
                     "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
                     "flops_per_launch": flops, "avg_launch_us": upd["avg_us"],
                     "flops_needed_per_launch": needed, "frac_needed": ach * needed / flops / PEAK_F32_MFMA_TFLOPS,

@@ -66,7 +66,8 @@ class AcConfig(ctypes.Structure):
                 ("gamma", c_double), ("ret_mean", c_void_p), ("ret_var", c_void_p), ("ret_count", c_void_p),
                 ("centralised_critic", c_int32), ("side_stream", c_void_p),
                 ("ret_exchange", c_void_p), ("ret_exchange_ctx", c_void_p), ("ret_moments", c_void_p),
-                ("critic_n_networks", c_int32), ("critic_net_of", c_int32 * 16), ("actor_forward_kept", c_int32)]
+                ("critic_n_networks", c_int32), ("critic_net_of", c_int32 * 16), ("actor_forward_kept", c_int32),
+                ("defer_critic_backward", c_int32)]
 
 
 class RetStatsStruct(ctypes.Structure):
@@ -200,6 +201,8 @@ PROTOTYPES = {
                                         c_int32, c_float, c_void_p, c_void_p, c_void_p]),
     "marlhip_ac_collect": (c_int32, [POINTER(LbfConfig), POINTER(NetShape), c_void_p, c_uint32, c_int32, c_int32, c_void_p,
                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "marlhip_stream_create_cu_share": (c_int32, [c_int32, c_int32, POINTER(c_void_p)]),
+    "marlhip_stream_destroy": (c_int32, [c_void_p]),
     "marlhip_ac_collect_keep": (c_int32, [POINTER(LbfConfig), POINTER(NetShape), c_void_p, c_uint32, c_int32, c_int32, c_void_p,
                                           c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p,
                                           c_int64, c_void_p]),

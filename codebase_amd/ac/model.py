@@ -103,16 +103,34 @@ class A2CNetwork:
             _init_blocks(cdims, hc, [1] * K, _get(critic, "use_orthogonal_init", True))  # target: drawn, then overwritten (soft_update(1.0))
             a0 = pad_blocks(a0, obs_dims[0], ha, act_dims[0], Hk)
             c0 = pad_blocks(c0, cdims[0], hc, 1, Hk)
-        self.block = torch.cat([a0.reshape(-1), c0.reshape(-1)]).to(self.device).contiguous()
-        self.target_critic_params = c0.clone().to(self.device).contiguous()
-        self.updater = _hip.AcUpdater(self.spec, self.block, self.target_critic_params, lr=float(_get(cfg, "lr", 3e-4)),
+        self._block = torch.cat([a0.reshape(-1), c0.reshape(-1)]).to(self.device).contiguous()
+        self._target_critic_params = c0.clone().to(self.device).contiguous()
+        self.updater = _hip.AcUpdater(self.spec, self._block, self._target_critic_params, lr=float(_get(cfg, "lr", 3e-4)),
                                       gamma=self.gamma, n_steps=self.n_steps, entropy_coef=self.entropy_coef,
                                       value_loss_coef=self.value_loss_coef, grad_clip=self.grad_clip,
                                       ppo_clip=float(_get(cfg, "ppo_clip", 0.2)), standardise_returns=self.standardise_returns,
                                       centralised_critic=self.centralised_critic, recurrent=self.recurrent, optimizer=self.optimizer,
                                       critic_sharing=self.critic_sharing)
         self.ret_ms = self.updater.ret_stats
-        self.actor_params, self.critic_params = self.updater.actor, self.updater.critic
+        self.actor_params = self.updater.actor
+
+    # The critics' blocks (and the joint block) may still be written by the deferred half of the last update (update_async(overlap=True):
+    # their backward pass, step and target update run on a stream of their own next to the following rollout): every access through the
+    # model first orders the current stream behind that work (AcUpdater.sync_critic; nothing to wait for otherwise).
+    @property
+    def block(self):
+        self.updater.sync_critic()
+        return self._block
+
+    @property
+    def critic_params(self):
+        self.updater.sync_critic()
+        return self.updater.critic
+
+    @property
+    def target_critic_params(self):
+        self.updater.sync_critic()
+        return self._target_critic_params
 
     # ---- reference interface ---------------------------------------------------------------
     def init_critic_hiddens(self, batch_size, target=False):
@@ -193,7 +211,8 @@ class A2CNetwork:
         return out.reshape(self.n_agents, *lead).movedim(0, -1).contiguous(), critic_hiddens
 
     def soft_update(self, t):
-        self.target_critic_params.mul_(1 - t).add_(self.critic_params, alpha=t)
+        # (the raw tensors: inside update_async this runs on the critics' own stream, behind their step)
+        self._target_critic_params.mul_(1 - t).add_(self.updater.critic, alpha=t)
 
     def _target_update(self, step):
         tui = self.target_update_interval_or_tau
@@ -206,14 +225,21 @@ class A2CNetwork:
     # logits and hidden layers of every batch row for the step (hip.ac_collect(keep_for=updater)) instead of the step recomputing them
     keeps_actor_forward = True
 
-    def update_async(self, batch, step, grad_sync=None, world=1):
+    def update_async(self, batch, step, grad_sync=None, world=1, overlap=False):
         """loss/grad -> [grad_sync(grad)] -> clip+Adam -> target update; returns the device metrics tensor
-        (loss, actor_loss, value_loss, entropy, sum(filled)) without synchronising."""
-        m = self.updater.a2c_loss_grad(batch)
+        (loss, actor_loss, value_loss, entropy, sum(filled)) without synchronising.
+        overlap (the drivers' rollout -> update loops; one process): without a joint clip (ia2c.yaml / maa2c.yaml: grad_clip False) the
+        next rollout needs only the ACTORS' step, so the critics' backward pass, their step and their target update run on a stream of
+        their own next to it (AcUpdater.a2c_loss_grad(defer_critic=True)) - the same launches on the same data, the same bits.  The caller
+        must leave the batch tensors alone until the next update (or model access) has waited for that stream."""
+        up = self.updater
+        m = up.a2c_loss_grad(batch, defer_critic=overlap if grad_sync is None else False)  # (overlap="force": wherever it is possible, not only where it pays)
         if grad_sync is not None:
-            grad_sync(self.updater.grad)
-        self.updater.apply(grad_scale=1.0 / world)
-        self._target_update(step)
+            grad_sync(up.grad)
+        up.apply(grad_scale=1.0 / world)
+        with up.critic_stream():
+            self._target_update(step)
+        up.finish_critic()
         return m
 
     @staticmethod
@@ -276,7 +302,8 @@ class PPONetwork(A2CNetwork):
         self.num_epochs = int(_get(cfg, "num_epochs", 4))
         self.ppo_clip = float(_get(cfg, "ppo_clip", 0.2))
 
-    def update_async(self, batch, step, grad_sync=None, world=1):
+    def update_async(self, batch, step, grad_sync=None, world=1, overlap=False):
+        """overlap: accepted for the drivers' uniform call; every epoch's forward passes need both networks, nothing is deferred"""
         up = self.updater
         up.ppo_prepare(batch)
         acc = torch.zeros(5, device=self.device)

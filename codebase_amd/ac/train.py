@@ -192,6 +192,9 @@ def main(envs, eval_env, logger, time_limit, **cfg):
     parallel_envs = envs.observation_space[0].shape[0]
     device = g("model.device", "cuda")
     step = updates = last_eval = last_save = 0
+    # the loop runs on a stream of its own: A2C's critics finish their half of an update next to the following rollout, on a stream that
+    # owns half of the compute units, and a stream of that kind synchronises implicitly with the DEFAULT stream (AcUpdater.can_defer)
+    torch.cuda.set_stream(torch.cuda.Stream(device=model.device))
     while step < g("total_steps") + 1:
         log_now = (step - last_eval) >= g("eval_interval")  # the only consumer of a rollout's infos
         t, batch, infos = _collect_trajectories(envs, model, time_limit, parallel_envs, model.n_agents, device,
@@ -216,7 +219,9 @@ def main(envs, eval_env, logger, time_limit, **cfg):
                         for p in range(model.n_agents):
                             d[f"agent{p}/episode_returns"] = row[p]
                         infos.append(d)
-        m = model.update_async(batch, step, grad_sync=sync, world=world)
+        # overlap: one process, no joint clip -> the critics' half of the update runs next to the following rollout (A2CNetwork.update_async);
+        # every rollout has its own batch tensors here, and reading `t` above has already waited for the rollout
+        m = model.update_async(batch, step, grad_sync=sync, world=world, overlap=True)
         infos.append(model._metrics(m) if log_now else m)
         if log_now:
             if sync is not None:

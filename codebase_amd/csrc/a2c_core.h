@@ -736,6 +736,29 @@ int ac_step_t(int P, const AgentMap& am, const float* actor, const float* critic
         return 0;
     }
     float* scratch = f(wl.scratch);
+    if (c->defer_critic_backward != 0) {
+        // The critics' backward pass leaves the call's stream (marlhip_ac_config.defer_critic_backward): without a joint gradient clip the
+        // optimiser step is elementwise, so the ACTORS' step - all the next rollout needs - does not wait for the critics' gradient.  The
+        // actors' pass goes first (the two passes share the backward workspace), the critics' is enqueued on side_stream behind it and is
+        // NOT joined: the caller steps the critics there and orders the next call on this workspace behind that (an event of its own).
+        if constexpr (IsGru<SA>::value || IsGru<SC>::value) {
+            set_error("ac_loss_grad: defer_critic_backward is for feed-forward networks (the recurrent passes already share the chip)");
+            return -1;
+        } else {
+            MARL_REQUIRE(mode == 0 && c->side_stream != nullptr && c->side_stream != (void*)st,
+                         "ac_loss_grad: defer_critic_backward goes with marlhip_a2c_loss_grad and a side_stream other than the call's");
+            const int rc_a = launch_backward_rows<SA>(P, am, actor, bt, w.dlogits, w.lrow_a, base + wl.bwd, ws_bytes - wl.bwd, actor_grad, scratch, st, rec_a);
+            if (rc_a != 0) return rc_a;
+            hipEvent_t ev;
+            MARL_REQUIRE(hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess, "ac_loss_grad: hipEventCreate failed");
+            const bool ok = hipEventRecord(ev, st) == hipSuccess && hipStreamWaitEvent((hipStream_t)c->side_stream, ev, 0) == hipSuccess;
+            (void)hipEventDestroy(ev);  // (released once it has completed)
+            MARL_REQUIRE(ok, "ac_loss_grad: could not order the critics' backward pass behind the actors'");
+            rc = launch_backward_rows<SC>(P, amc, critic, bc, w.dv, w.lrow_v, base + wl.bwd, ws_bytes - wl.bwd, critic_grad, scratch + 2,
+                                          (hipStream_t)c->side_stream, rec_c);
+            if (rc != 0) return rc;
+        }
+    } else {
     hipStream_t st_c = st;
     if (wl.bwd_c != wl.bwd && side.ok()) {  // fork: the critics' backward on the side stream, behind everything queued so far
         side.do_fork();
@@ -746,6 +769,7 @@ int ac_step_t(int P, const AgentMap& am, const float* actor, const float* critic
                                               actor_grad, scratch, st, rec_a);
     side.do_join();
     if (rc != 0 || rc_a != 0) return rc != 0 ? rc : rc_a;
+    }
     hipLaunchKernelGGL(ac_metrics_kernel, dim3(1), dim3(1024), 0, st, (TB + 255) / 256, c->value_loss_coef, (const float*)w.partial,
                        metrics);
     timing_end(TIMER_LOSSGRAD, st);

@@ -99,6 +99,37 @@ extern "C" int64_t marlhip_forward_workspace_bytes(const marlhip_net_shape* s) {
     return 2 * P * (mlp > gru ? mlp : gru) * 4 + 256;
 }
 
+extern "C" int marlhip_stream_create_cu_share(int32_t percent, int32_t pattern, void** stream_out) {
+    using namespace marl;
+    MARL_REQUIRE(stream_out != nullptr && percent >= 1 && percent <= 100 && (pattern == 0 || pattern == 1),
+                 "stream_create_cu_share: percent %d (1..100), pattern %d (0 / 1)", percent, pattern);
+    int dev = 0, cus = 0;
+    MARL_REQUIRE(hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0,
+                 "stream_create_cu_share: no device");
+    const int want = (cus * percent + 99) / 100;
+    uint32_t mask[32] = {0};
+    MARL_REQUIRE(cus <= 32 * 32, "stream_create_cu_share: %d compute units", cus);
+    int set = 0;
+    for (int i = 0; i < cus && set < want; ++i) {
+        const bool take = pattern == 0 || (i & 1) == 0 || want > (cus + 1) / 2;  // every other unit first; above one half every unit is a candidate
+        if (take) {
+            mask[i >> 5] |= 1u << (i & 31);
+            ++set;
+        }
+    }
+    hipStream_t st = nullptr;
+    MARL_REQUIRE(hipExtStreamCreateWithCUMask(&st, (uint32_t)((cus + 31) / 32), mask) == hipSuccess, "stream_create_cu_share: hipExtStreamCreateWithCUMask failed");
+    *stream_out = st;
+    return 0;
+}
+
+extern "C" int marlhip_stream_destroy(void* stream) {
+    using namespace marl;
+    MARL_REQUIRE(stream != nullptr, "stream_destroy: NULL stream");
+    MARL_REQUIRE(hipStreamDestroy((hipStream_t)stream) == hipSuccess, "stream_destroy: hipStreamDestroy failed");
+    return 0;
+}
+
 extern "C" int marlhip_timing_enable(int on) {
     marl::g_timing = on != 0;
     for (int i = 0; i < marl::TIMER_COUNT; ++i) { marl::g_timers[i].n = 0; marl::g_timers[i].open = false; }

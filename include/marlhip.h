@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MARLHIP_VERSION 213
+#define MARLHIP_VERSION 214
 
 int marlhip_version(void);
 const char* marlhip_last_error(void);
@@ -528,6 +528,12 @@ typedef struct marlhip_ac_config {
      * again.  For marlhip_a2c_loss_grad; for marlhip_ppo_prepare (the old log-probs) and the FIRST marlhip_ppo_loss_grad of a rollout
      * (the later epochs run on moved parameters).  0 (default): the call runs the actors' forward pass itself. */
     int32_t actor_forward_kept;
+    /* C-ABI 214, marlhip_a2c_loss_grad with feed-forward networks: the critics' backward pass is enqueued on `side_stream` (required, not the
+     * call's stream) behind the actors' and is NOT joined before the call returns.  Without a joint gradient clip (ia2c.yaml / maa2c.yaml:
+     * grad_clip False) the optimiser step is elementwise, so the caller can step the ACTOR block on the call's stream and start the next
+     * rollout while the critics' gradient, their step and their target update run on side_stream; the next call on this workspace (and any
+     * reader of the critic blocks) must be ordered behind that work by the caller.  0 (default): both passes on the call's stream. */
+    int32_t defer_critic_backward;
 } marlhip_ac_config;
 
 int marlhip_ac_critic_nparams(const marlhip_net_shape* s, int32_t centralised); /* per critic block */
@@ -549,6 +555,13 @@ int marlhip_a2c_loss_grad(const marlhip_net_shape* s, const float* actor, const 
  * following marlhip_a2c_loss_grad (or marlhip_ppo_prepare + first marlhip_ppo_loss_grad) on that workspace sets
  * marlhip_ac_config.actor_forward_kept.  Fused feed-forward actors and n_envs % 16
  * == 0 only (an error otherwise); rows of envs whose episode is over hold zeros (their gradients are masked by `filled`). */
+/* A stream restricted to a share of the device's compute units (hipExtStreamCreateWithCUMask; C-ABI 214), for work that is meant to run NEXT
+ * TO another kernel rather than in front of it: a kernel whose grid fills the chip holds every compute unit until it retires, so the
+ * critics' backward pass of marlhip_ac_config.defer_critic_backward on an ordinary stream delays the following rollout by its whole length;
+ * on a stream that owns `percent` of the units it leaves the rest to the rollout (same grid, same summation order, same bits).
+ * pattern 0: the lowest-numbered units of the mask, 1: every other unit.  marlhip_stream_destroy releases the stream. */
+int marlhip_stream_create_cu_share(int32_t percent /* 1..100 */, int32_t pattern, void** stream_out);
+int marlhip_stream_destroy(void* stream);
 int marlhip_ac_collect_keep(const marlhip_lbf_config* cfg, const marlhip_net_shape* s, const float* actor_params, uint32_t round,
                             int32_t max_len, int32_t use_proper_termination, float* batch_obs, int64_t* batch_act, float* batch_rew,
                             uint8_t* batch_done, float* batch_filled, float* fin_return, int32_t* fin_length, int32_t* t_max,

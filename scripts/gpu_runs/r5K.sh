@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 5, run K: evidence refresh after the kept forward pass (C-ABI 213) - kernel stats of the actor-critic rows, their bench lines, the
+# round 5, run K: evidence refresh after the kept forward pass and the critics' half-chip stream (C-ABI 213 / 214) - kernel stats of the actor-critic rows, their bench lines, the
 # default line (its `modes` carry BASELINE config 4), then the whole GPU suite on this tree.  `python scripts/profiles_merge_ac.py prof5k r05`
 # merges the result into profiles/.
 O="${GRAFT_REPO_ROOT:?}/gpurun_out/prof5k"; mkdir -p "$O"; rm -rf "$O"/stats* "$O/matrix_ac.jsonl"; cd /tmp; export TMPDIR=/tmp
@@ -18,7 +18,10 @@ run --steps 5 --warmup 1 --algo ia2c --env-name rware:rware-tiny-4ag-v2 --time-l
 run --steps 3 --warmup 1 --algo maa2c --env-name lbforaging:Foraging-15x15-8p-5f-v3 --envs 4096 --hidden 128
 run --steps 3 --warmup 1 --algo mappo --env-name rware:rware-tiny-4ag-v2 --time-limit 500 --envs 2048 --hidden 128
 run --steps 40 --warmup 5 --algo ippo
-MARLHIP_AC_NO_KEEP=1 run --steps 5 --warmup 1 --algo ia2c --env-name rware:rware-tiny-4ag-v2 --time-limit 500 --envs 2048 --hidden 128
+MARLHIP_AC_NO_OVERLAP=1 run --steps 5 --warmup 1 --algo ia2c --env-name rware:rware-tiny-4ag-v2 --time-limit 500 --envs 2048 --hidden 128
+MARLHIP_AC_NO_OVERLAP=1 MARLHIP_AC_NO_KEEP=1 run --steps 5 --warmup 1 --algo ia2c --env-name rware:rware-tiny-4ag-v2 --time-limit 500 --envs 2048 --hidden 128
+run --steps 5 --warmup 1 --algo ia2c --env-name rware:rware-tiny-4ag-v2 --time-limit 500 --envs 2048 --hidden 64
+run --steps 60 --warmup 5 --algo ia2c --envs 2048 --hidden 128
 wc -l $O/matrix_ac.jsonl
 ( timeout 600 python $R/bench.py > $O/bench_default_line.json 2> $O/bench_default_line.err )
 find $O -name "*.db" -delete; find $O -name "*kernel_trace.csv" -size +3M -delete; du -sh $O

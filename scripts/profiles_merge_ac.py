@@ -15,7 +15,8 @@ DST = os.path.join(ROOT, "profiles")
 
 def key(d):
     c = d.get("config", {})
-    return (d.get("metric"), c.get("workload"), d.get("dtype"), bool((d.get("roofline") or {}).get("actor_forward_kept", True)))
+    r = d.get("roofline") or {}
+    return (d.get("metric"), c.get("workload"), d.get("dtype"), bool(r.get("actor_forward_kept", True)), c.get("note"))
 
 
 for tag, out in (("stats_rware_ia2c", "_rware_ia2c_tiny4ag_H128_kernel_stats.csv"), ("stats_maa2c8p", "_maa2c_15x15_8p5f_H128_kernel_stats.csv"),
@@ -28,8 +29,12 @@ mp = os.path.join(DST, PFX + "_bench_matrix.jsonl")
 rows = [json.loads(l) for l in open(mp) if l.strip()]
 new = [json.loads(l) for l in open(os.path.join(SRC, "matrix_ac.jsonl")) if l.strip()]
 for d in new:
-    if not (d.get("roofline") or {}).get("actor_forward_kept", True):
-        d["config"]["note"] = "MARLHIP_AC_NO_KEEP=1: the step runs the actors' forward pass itself (the A/B row of the kept pass)"
+    r = d.get("roofline") or {}
+    n_envs = d["config"].get("envs_per_gpu", 0)
+    if not r.get("actor_forward_kept", True):
+        d["config"]["note"] = "MARLHIP_AC_NO_KEEP=1 MARLHIP_AC_NO_OVERLAP=1: the step runs the actors' forward pass itself, on one stream (the A/B row)"
+    elif "rware" in d["metric"] and "IA2C" in d["metric"] and n_envs <= 2048 and not r.get("critic_backward_overlaps_next_rollout", False):
+        d["config"]["note"] = "MARLHIP_AC_NO_OVERLAP=1: the critics' backward pass stays on the caller's stream (the A/B row of the half-chip stream)"
     for i, r in enumerate(rows):
         if key(r) == key(d):
             rows[i] = d

@@ -130,3 +130,71 @@ def test_keep_refusals():
     rc = lib.marlhip_ac_collect_keep(ctypes.byref(cfg), ctypes.byref(s), model.actor_params.data_ptr(), 0, 25, 0, *(t.data_ptr() for t in bufs), *fws, 0,
                                      ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream)
     assert rc != 0 and b"16" in lib.marlhip_last_error()
+
+
+# ---- the critics' half of an A2C update next to the following rollout (marlhip_ac_config.defer_critic_backward) --------------------------
+def _rounds(h, name, N, T, H, central, overlap, tui, rounds=4):
+    """rollout -> A2CNetwork.update_async x rounds, a fresh batch per rollout as ac/train.py allocates them"""
+    from codebase_amd.ac.train import Batch
+
+    cfg, model, b, _, (P, D, A) = _collect_ac(h, name, N, T, H, 13, 0, central=central, scale=1.5, keep=True)
+    model.target_update_interval_or_tau = tui
+    dev, ms, deferred = model.device, [], []
+    torch.cuda.synchronize()
+    with torch.cuda.stream(torch.cuda.Stream(device=dev)):  # (the critics only leave a caller that is not on the default stream)
+        out = _rounds_body(h, cfg, model, b, N, T, P, D, rounds, overlap, ms, deferred)
+    torch.cuda.synchronize()
+    return out, deferred, model
+
+
+def _rounds_body(h, cfg, model, b, N, T, P, D, rounds, overlap, ms, deferred):
+    from codebase_amd.ac.train import Batch
+
+    dev = model.device
+    for r in range(rounds):
+        if r > 0:
+            b = dict(obss=torch.empty(T + 1, N, P * D, device=dev), actions=torch.empty(T, N, P, dtype=torch.int64, device=dev),
+                     rewards=torch.empty(T, N, P, device=dev), dones=torch.empty(T + 1, N, dtype=torch.uint8, device=dev),
+                     filled=torch.empty(T, N, device=dev))
+            fr, fl, tm = torch.zeros(P, N, device=dev), torch.zeros(N, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int32, device=dev)
+            assert h.ac_collect(cfg, model.spec, model.actor_params, r, T, False, b["obss"], b["actions"], b["rewards"], b["dones"], b["filled"], fr, fl, tm,
+                                keep_for=model.updater)
+        batch = Batch(b["obss"], b["actions"], b["rewards"], b["dones"].float(), b["filled"], None)
+        ms.append(model.update_async(batch, step=200 * r, overlap=overlap).clone())
+        deferred.append(model.updater._critic_event is not None)
+    return (torch.stack(ms), model.block.clone(), model.target_critic_params.clone(), model.updater.exp_avg.clone(), model.updater.exp_avg_sq.clone())
+
+
+@pytest.mark.parametrize("name,N,T,H,central,tui,overlap,expect", [
+    ("rware:rware-tiny-4ag-v2", 256, 60, 128, False, 200, True, True),             # BASELINE config 4's kernels: the rollout leaves most of the chip to the critics
+    ("rware:rware-tiny-2ag-v2", 512, 40, 64, False, 0.01, True, True),             # Polyak target on the critics' stream
+    ("lbforaging:Foraging-8x8-2p-3f-v3", 2048, 25, 64, False, 400, True, True),    # two waves per agent: 128 workgroups of 4 waves
+    ("lbforaging:Foraging-8x8-2p-3f-v3", 4096, 25, 64, False, 400, True, False),   # a rollout that fills the chip: nothing is deferred
+    ("lbforaging:Foraging-8x8-2p-3f-v3", 1024, 25, 128, True, 200, True, True),    # fused centralised critics, 30 inputs: about an actor row's cost
+    ("lbforaging:Foraging-15x15-8p-5f-v3", 512, 25, 128, True, 0.05, True, False),  # 312-input critics: their half-speed backward pass would outlast the rollout
+    ("lbforaging:Foraging-15x15-8p-5f-v3", 512, 25, 128, True, 0.05, "force", True),  # ... the same on request (wc_* kernels on the critics' stream)
+    ("lbforaging:Foraging-8x8-2p-3f-v3", 4096, 25, 128, False, 200, "force", True),
+])
+def test_update_with_the_critics_half_overlapping_the_next_rollout_has_the_bits_of_the_sequential_one(name, N, T, H, central, tui, overlap, expect):
+    """A2CNetwork.update_async(overlap=True): actors' backward + step on the caller's stream, critics' backward + step + target update on a
+    stream of their own while the next rollout runs; four rollout -> update rounds end with the same joint parameter block, target critics,
+    Adam moments and per-update metrics as the one-stream update (the launches and their inputs are the same; only their placement moved)"""
+    from codebase_amd import hip as h
+
+    (m1, p1, t1, a1, v1), d1, _ = _rounds(h, name, N, T, H, central, overlap, tui)
+    (m2, p2, t2, a2, v2), d2, _ = _rounds(h, name, N, T, H, central, False, tui)
+    # the critics leave the caller's stream where AcUpdater.can_defer says it pays (or on request)
+    assert d1 == [expect] * len(d1) and not any(d2)
+    assert torch.equal(m1, m2) and torch.equal(p1, p2) and torch.equal(t1, t2) and torch.equal(a1, a2) and torch.equal(v1, v2)
+    assert float(v1[-64:].abs().max()) > 0  # (the critics' slice did step)
+
+
+def test_a_joint_gradient_clip_keeps_the_update_on_one_stream():
+    from codebase_amd import hip as h
+
+    name, N, T, H = "lbforaging:Foraging-8x8-2p-3f-v3", 256, 25, 64
+    _, model, b, _, _ = _collect_ac(h, name, N, T, H, 4, 0, keep=True)
+    from codebase_amd.ac.train import Batch
+    model.updater.grad_clip = 0.5  # clip_grad_norm_ over actor AND critic (ac/model.py:227-229): the actors' step needs the critics' gradient
+    model.update_async(Batch(b["obss"], b["actions"], b["rewards"], b["dones"].float(), b["filled"], None), step=0, overlap=True)
+    assert model.updater._critic_event is None and model.updater._critic_pending is None
