@@ -633,7 +633,7 @@ def secondary_modes(args):
     for name, over, steps, warmup in (
             ("BASELINE config 3: VDN Foraging-15x15-4p-5f, 8192 envs, 64-64", dict(algo="vdn", env_name="lbforaging:Foraging-15x15-4p-5f-v3", envs=8192, hidden=64), 3, 1),
             ("BASELINE config 3: VDN Foraging-15x15-4p-5f, 8192 envs, 128-128", dict(algo="vdn", env_name="lbforaging:Foraging-15x15-4p-5f-v3", envs=8192, hidden=128), 2, 1),
-            ("BASELINE config 4 (per-GPU shard): IA2C rware-tiny-4ag, 2048 envs, 128-128", dict(algo="ia2c", env_name="rware:rware-tiny-4ag-v2", envs=2048, hidden=128, time_limit=500), 3, 1),
+            ("BASELINE config 4 (per-GPU shard): IA2C rware-tiny-4ag, 2048 envs, 128-128", dict(algo="ia2c", env_name="rware:rware-tiny-4ag-v2", envs=2048, hidden=128, time_limit=500), 16, 2),  # (16 rounds: the last update's critics finish inside the timed region, beside no rollout - 7 ms over the K rounds)
             ("BASELINE config 5 (per-GPU shard): QMIX Foraging-15x15-8p-5f, 8192 envs, 128-128, fp32 mixer", dict(algo="qmix", env_name="lbforaging:Foraging-15x15-8p-5f-v3", envs=8192, hidden=128), 2, 1),
             ("BASELINE config 5 (per-GPU shard): QMIX Foraging-15x15-8p-5f, 8192 envs, 128-128, OPT-IN fp16 first mixer layers", dict(algo="qmix", env_name="lbforaging:Foraging-15x15-8p-5f-v3", envs=8192, hidden=128, mixer_fp16=True), 2, 1)):
         a = copy.copy(args)
