@@ -38,7 +38,7 @@ run --steps 4 --warmup 1 --algo qmix --env-name lbforaging:Foraging-15x15-8p-5f-
 run --steps 4 --warmup 1 --algo qmix --env-name lbforaging:Foraging-15x15-8p-5f-v3 --envs 8192 --hidden 128 --mixer-fp16
 run --steps 100 --warmup 5 --algo ia2c
 run --steps 100 --warmup 5 --algo ia2c --hidden 128
-run --steps 5 --warmup 1 --algo ia2c --env-name rware:rware-tiny-4ag-v2 --time-limit 500 --envs 2048 --hidden 128
+run --steps 20 --warmup 2 --algo ia2c --env-name rware:rware-tiny-4ag-v2 --time-limit 500 --envs 2048 --hidden 128  # (20 rounds: the last update's critics finish inside the timed region; scripts/gpu_runs/r5K.sh / r5P.sh hold the A/B rows)
 run --steps 3 --warmup 1 --algo maa2c --env-name lbforaging:Foraging-15x15-8p-5f-v3 --envs 4096 --hidden 128
 run --steps 3 --warmup 1 --algo mappo --env-name rware:rware-tiny-4ag-v2 --time-limit 500 --envs 2048 --hidden 128
 run --steps 10 --warmup 2 --rnn
