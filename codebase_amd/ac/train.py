@@ -194,7 +194,9 @@ def main(envs, eval_env, logger, time_limit, **cfg):
     step = updates = last_eval = last_save = 0
     # the loop runs on a stream of its own: A2C's critics finish their half of an update next to the following rollout, on a stream that
     # owns half of the compute units, and a stream of that kind synchronises implicitly with the DEFAULT stream (AcUpdater.can_defer)
+    caller_stream = torch.cuda.current_stream(model.device)
     torch.cuda.set_stream(torch.cuda.Stream(device=model.device))
+    torch.cuda.current_stream(model.device).wait_stream(caller_stream)  # (the model was built on the caller's stream)
     while step < g("total_steps") + 1:
         log_now = (step - last_eval) >= g("eval_interval")  # the only consumer of a rollout's infos
         t, batch, infos = _collect_trajectories(envs, model, time_limit, parallel_envs, model.n_agents, device,
@@ -242,5 +244,9 @@ def main(envs, eval_env, logger, time_limit, **cfg):
         step += t * parallel_envs if dist is None else t_job
     if sync is not None:
         sync.close()  # final check on every rank, then the exchange is freed behind a job-wide barrier
+    # back on the caller's stream, behind everything the loop queued (the critics' deferred half included)
+    model.updater.sync_critic()
+    caller_stream.wait_stream(torch.cuda.current_stream(model.device))
+    torch.cuda.set_stream(caller_stream)
     envs.close()
     return model
