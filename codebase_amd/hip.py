@@ -762,14 +762,14 @@ class AcUpdater:
         if self._critic_pending is not None:
             self.finish_critic()
         if self._critic_event is not None:
-            torch.cuda.current_stream().wait_event(self._critic_event)
+            torch.cuda.current_stream(self.block.device).wait_event(self._critic_event)
             self._critic_event = None
             self._inflight = None
 
     def critic_stream(self):
         """context manager: torch ops on the critics' blocks that belong behind the deferred step (the target update); the current stream
         when nothing is deferred"""
-        return torch.cuda.stream(self._critic_stream if self._critic_pending is not None else torch.cuda.current_stream())
+        return torch.cuda.stream(self._critic_stream if self._critic_pending is not None else torch.cuda.current_stream(self.block.device))
 
     def finish_critic(self):
         """after the critics' step and target update have been queued: mark the point later readers wait for"""
