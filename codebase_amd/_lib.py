@@ -67,7 +67,7 @@ class AcConfig(ctypes.Structure):
                 ("centralised_critic", c_int32), ("side_stream", c_void_p),
                 ("ret_exchange", c_void_p), ("ret_exchange_ctx", c_void_p), ("ret_moments", c_void_p),
                 ("critic_n_networks", c_int32), ("critic_net_of", c_int32 * 16), ("actor_forward_kept", c_int32),
-                ("defer_critic_backward", c_int32)]
+                ("defer_critic_backward", c_int32), ("critic_n_hidden", c_int32)]
 
 
 class RetStatsStruct(ctypes.Structure):
@@ -186,6 +186,7 @@ PROTOTYPES = {
                                                 c_float, c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "marlhip_ac_critic_nparams": (c_int32, [POINTER(NetShape), c_int32]),
     "marlhip_ac_workspace_bytes": (c_int64, [POINTER(NetShape), c_int32, c_int32, c_int32]),
+    "marlhip_ac_workspace_bytes_lc": (c_int64, [POINTER(NetShape), c_int32, c_int32, c_int32, c_int32]),
     "marlhip_ac_forward_rows": (c_int32, [POINTER(NetShape), c_int32, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_void_p,
                                           c_void_p, c_int64, c_void_p]),
     "marlhip_a2c_loss_grad": (c_int32, [POINTER(NetShape), c_void_p, c_void_p, c_void_p, POINTER(BatchStruct), POINTER(AcConfig),

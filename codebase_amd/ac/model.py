@@ -59,10 +59,13 @@ class A2CNetwork:
         else:
             Hk = max(compiled_width(ha), compiled_width(hc))
             wide = is_wide(ha) or is_wide(hc)
-        if len(ha) != len(hc):
-            raise NotImplementedError(f"layers actor={ha} critic={hc}: the same number of hidden layers for actor and critic")
+        if self.recurrent and len(ha) != len(hc):
+            raise NotImplementedError(f"use_rnn with layers actor={ha} critic={hc}: one GRU layer each ([h, h])")
+        # actor and critic are built from their own `layers` lists (ac/model.py:45-97): with different DEPTHS both run on the GEMM path,
+        # the critics with their own layer count (marlhip_ac_config.critic_n_hidden)
+        wide = wide or len(ha) != len(hc)
         if wide:
-            Hk = max(Hk, 144 if len(ha) == 2 else 16)
+            Hk = max(Hk, 144 if 2 in (len(ha), len(hc)) else 16)  # (a width no fused two-layer kernel exists for)
         if bool(_get(critic, "centralised", False)) and not self.recurrent and not wide and (P, obs_dims[0]) in _FUSED_CENTRALISED_128:
             Hk = 128  # fused centralised-critic kernels for 3 / 4 agents exist at width 128 only (a2c.hip MARL_MAC_SHAPES); every other
             #           (agents, observation width) runs the critics on the wide path (csrc/wide_mlp.h) at the compiled width of the layers
@@ -82,7 +85,7 @@ class A2CNetwork:
         self.centralised_critic = bool(_get(critic, "centralised", False))  # MAA2C / MAPPO (model.py:62-66)
         self.spec = _hip.NetSpec(P, obs_dims[0], Hk, act_dims[0], self.sharing, wide=wide, n_hidden=len(ha))  # wide: actors and critics on the GEMM path
         # the critics' view of the same shape under THEIR agent -> network map (get_value's forward rows, state_dict keys)
-        self.critic_spec = _hip.NetSpec(P, obs_dims[0], Hk, act_dims[0], self.critic_sharing, wide=wide, n_hidden=len(ha))
+        self.critic_spec = _hip.NetSpec(P, obs_dims[0], Hk, act_dims[0], self.critic_sharing, wide=wide, n_hidden=len(hc))
         cdims = [self.n_agents * self.spec.obs_dim] * P if self.centralised_critic else list(obs_dims)  # critic_obs_shape (model.py:63-65)
         if self.sharing is not None:  # one network per distinct index, in order of first appearance (utils/models.py:209-240)
             first = [self.sharing.index(k) for k in range(max(self.sharing) + 1)]
@@ -110,7 +113,7 @@ class A2CNetwork:
                                       value_loss_coef=self.value_loss_coef, grad_clip=self.grad_clip,
                                       ppo_clip=float(_get(cfg, "ppo_clip", 0.2)), standardise_returns=self.standardise_returns,
                                       centralised_critic=self.centralised_critic, recurrent=self.recurrent, optimizer=self.optimizer,
-                                      critic_sharing=self.critic_sharing)
+                                      critic_sharing=self.critic_sharing, critic_n_hidden=len(hc))
         self.ret_ms = self.updater.ret_stats
         self.actor_params = self.updater.actor
 

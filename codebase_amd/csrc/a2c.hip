@@ -56,10 +56,12 @@ static int ac_check(const marlhip_net_shape* s, int centralised = 0) {
 }
 
 // the run-time shapes of the all-GEMM step: actor D -> H -> H -> A, critic (P * D or D) -> H -> H -> 1
-static void wide_set(const marlhip_net_shape* s, int centralised) {
+// critic_L > 0: the critics' own number of hidden layers (marlhip_ac_config.critic_n_hidden: ac/model.py:45-97 builds actor and critic from
+// their own `layers` lists), else the shape's
+static void wide_set(const marlhip_net_shape* s, int centralised, int critic_L = 0) {
     const int L = s->n_hidden > 0 ? s->n_hidden : 2;
     WideRt<0>::set(s->obs_dim, s->hidden, s->n_actions, L);
-    WideRt<1>::set(centralised ? s->n_agents * s->obs_dim : s->obs_dim, s->hidden, 1, L);
+    WideRt<1>::set(centralised ? s->n_agents * s->obs_dim : s->obs_dim, s->hidden, 1, critic_L > 0 ? critic_L : L);
 }
 
 extern "C" int marlhip_ac_critic_nparams(const marlhip_net_shape* s, int32_t centralised) {
@@ -75,6 +77,18 @@ extern "C" int marlhip_ac_critic_nparams(const marlhip_net_shape* s, int32_t cen
     MARL_AC_SHAPES(X)
 #undef X
     return -1;
+}
+
+extern "C" int64_t marlhip_ac_workspace_bytes_lc(const marlhip_net_shape* s, int32_t centralised, int32_t critic_n_hidden, int32_t max_len,
+                                                  int32_t batch) {
+    if (critic_n_hidden <= 0 || critic_n_hidden == (s != nullptr && s->n_hidden > 0 ? s->n_hidden : 2))
+        return marlhip_ac_workspace_bytes(s, centralised, max_len, batch);
+    if (ac_check(s, centralised) != 0) return -1;
+    MARL_REQUIRE(critic_n_hidden <= 16, "ac_workspace_bytes: %d hidden layers for the critics (1..16)", critic_n_hidden);
+    MARL_REQUIRE(!ac_compiled(s), "ac_workspace_bytes: critics of another depth than the actors run on the GEMM path - give the shape a width without "
+                                  "fused kernels (hidden > 128)");
+    wide_set(s, centralised, critic_n_hidden);
+    return ac_ws_layout<WideRt<0>, WideRt<1>>(s->n_agents, max_len, batch).total;
 }
 
 extern "C" int64_t marlhip_ac_workspace_bytes(const marlhip_net_shape* s, int32_t centralised, int32_t max_len, int32_t batch) {
@@ -122,9 +136,12 @@ static int ac_call(const marlhip_net_shape* s, const float* actor, const float* 
     if (!ac_compiled(s)) {  // both networks on the GEMM path
         MARL_REQUIRE(!c->centralised_critic || (bt->obs_row_stride == (int64_t)s->n_agents * s->obs_dim && bt->obs_agent_stride == s->obs_dim),
                      "ac_loss_grad: a centralised critic needs the ac/train.py Batch layout (agents concatenated in a row)");
-        wide_set(s, c->centralised_critic);
+        MARL_REQUIRE(c->critic_n_hidden >= 0 && c->critic_n_hidden <= 16, "ac_loss_grad: critic_n_hidden %d outside [0, 16]", c->critic_n_hidden);
+        wide_set(s, c->centralised_critic, c->critic_n_hidden);
         return ac_step_t<WideRt<0>, WideRt<1>>(MARL_AC_ARGS);
     }
+    MARL_REQUIRE(c->critic_n_hidden == 0 || c->critic_n_hidden == 2, "ac_loss_grad: critics with %d hidden layers next to fused two-layer actors - the "
+                 "GEMM path takes both networks (give the shape a width without fused kernels)", c->critic_n_hidden);
     if (c->centralised_critic) {
         MARL_REQUIRE(bt->obs_row_stride == (int64_t)s->n_agents * s->obs_dim && bt->obs_agent_stride == s->obs_dim,
                      "ac_loss_grad: a centralised critic needs the ac/train.py Batch layout (agents concatenated in a row)");

@@ -659,9 +659,10 @@ class AcUpdater:
 
     def __init__(self, spec: NetSpec, block, target_critic, lr=3e-4, betas=(0.9, 0.999), eps=1e-8, gamma=0.99, n_steps=5,
                  entropy_coef=0.001, value_loss_coef=0.5, grad_clip=False, ppo_clip=0.2, standardise_returns=False,
-                 centralised_critic=False, recurrent=False, optimizer="Adam", critic_sharing="actor"):
+                 centralised_critic=False, recurrent=False, optimizer="Adam", critic_sharing="actor", critic_n_hidden=None):
         """critic_sharing: the critics' agent -> network map when critic.parameter_sharing differs from actor.parameter_sharing
-        (ac/model.py:45-97): "actor" (default) = spec.sharing for both, None = one critic per agent, or a tuple of network indices"""
+        (ac/model.py:45-97): "actor" (default) = spec.sharing for both, None = one critic per agent, or a tuple of network indices.
+        critic_n_hidden: the critics' number of hidden layers when critic.layers is of another length than actor.layers (GEMM-path shapes)"""
         _require_gpu()
         self.optimizer = optimizer_id(optimizer)
         self.recurrent = bool(recurrent)  # use_rnn actors and critics: the marlhip_gru_* entry points, recurrent block layout
@@ -676,7 +677,13 @@ class AcUpdater:
             self.n_critic = check(lib.marlhip_gru_ac_critic_nparams(ctypes.byref(s), int(bool(centralised_critic))), "gru_ac_critic_nparams")
         else:
             self.n_actor = spec.nparams()
-            self.n_critic = check(lib.marlhip_ac_critic_nparams(ctypes.byref(s), self.centralised), "ac_critic_nparams")
+            sc = spec.c()
+            self.critic_n_hidden = 0
+            if critic_n_hidden is not None and int(critic_n_hidden) != int(spec.n_hidden):
+                if not spec.wide:
+                    raise ValueError("critics of another depth than the actors: the shape must be a GEMM-path one (NetSpec.wide)")
+                self.critic_n_hidden = sc.n_hidden = int(critic_n_hidden)
+            self.n_critic = check(lib.marlhip_ac_critic_nparams(ctypes.byref(sc), self.centralised), "ac_critic_nparams")
         P = spec.n_blocks
         if isinstance(critic_sharing, str):
             self.critic_sharing = spec.sharing
@@ -699,6 +706,7 @@ class AcUpdater:
         self.cfg = AcConfig(int(n_steps), float(entropy_coef), float(value_loss_coef), float(ppo_clip), float(gamma),
                             rs.mean.data_ptr() if rs else None, rs.var.data_ptr() if rs else None,
                             rs.count_t.data_ptr() if rs else None, self.centralised, None)
+        self.cfg.critic_n_hidden = getattr(self, "critic_n_hidden", 0)
         if self.critic_sharing != spec.sharing:  # two agent -> network maps: the critics' rides in the config
             cmap = self.critic_sharing if self.critic_sharing is not None else tuple(range(spec.n_agents))
             if len(cmap) != spec.n_agents or spec.n_agents > 16:
@@ -791,7 +799,7 @@ class AcUpdater:
             if self.recurrent:
                 n = check(lib.marlhip_gru_ac_workspace_bytes(ctypes.byref(s), self.centralised, T, B), "gru_ac_workspace_bytes")
             else:
-                n = check(lib.marlhip_ac_workspace_bytes(ctypes.byref(s), self.centralised, T, B), "ac_workspace_bytes")
+                n = check(lib.marlhip_ac_workspace_bytes_lc(ctypes.byref(s), self.centralised, self.critic_n_hidden, T, B), "ac_workspace_bytes")
             self._ws[(T, B)] = torch.empty(int(n), dtype=torch.uint8, device=self.block.device)
         return self._ws[(T, B)]
 

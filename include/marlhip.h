@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MARLHIP_VERSION 214
+#define MARLHIP_VERSION 215
 
 int marlhip_version(void);
 const char* marlhip_last_error(void);
@@ -534,10 +534,17 @@ typedef struct marlhip_ac_config {
      * rollout while the critics' gradient, their step and their target update run on side_stream; the next call on this workspace (and any
      * reader of the critic blocks) must be ordered behind that work by the caller.  0 (default): both passes on the call's stream. */
     int32_t defer_critic_backward;
+    /* C-ABI 215: the critics' number of hidden layers when it differs from the actors' (marlhip_net_shape.n_hidden) - ac/model.py:45-97
+     * builds the two families from their own `layers` lists.  GEMM-path shapes only (both networks then run there, zero-padded to the
+     * shape's width); critic / target_critic blocks are WideNet blocks of that depth (marlhip_ac_critic_nparams on a shape copy whose
+     * n_hidden is the critics'), the workspace comes from marlhip_ac_workspace_bytes_lc.  0 (default): as the actors. */
+    int32_t critic_n_hidden;
 } marlhip_ac_config;
 
 int marlhip_ac_critic_nparams(const marlhip_net_shape* s, int32_t centralised); /* per critic block */
 int64_t marlhip_ac_workspace_bytes(const marlhip_net_shape* s, int32_t centralised, int32_t max_len, int32_t batch);
+int64_t marlhip_ac_workspace_bytes_lc(const marlhip_net_shape* s, int32_t centralised, int32_t critic_n_hidden /* marlhip_ac_config's */,
+                                      int32_t max_len, int32_t batch);
 /* A2CNetwork.get_value / the actor forward of A2CNetwork.act (model.py:147-163) on arbitrary rows:
  * out[p][row][:] = MLP_p(obs + p * agent_stride + row * row_stride); value_net 1: the one-output critic shape; value_net 2:
  * the centralised critic (P*D inputs, agent_stride 0: rows are the concatenated observations). */

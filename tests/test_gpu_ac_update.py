@@ -343,3 +343,59 @@ def test_actor_and_critic_with_their_own_parameter_sharing_match_reference_golde
     obs = [b0["obss"][0, :, p * D:(p + 1) * D].to(DEV) for p in range(P)]
     v, _ = net.get_value(obs, net.init_critic_hiddens(obs[0].shape[0]))
     assert tuple(v.shape) == (obs[0].shape[0], P)
+
+
+# ---- round 5: actor.layers and critic.layers of different LENGTHS (ac/model.py:45-97: each family from its own list) ---------------------
+@pytest.mark.parametrize("name,cls_name", [("learner_a2c_depths.npz", "A2CNetwork"), ("learner_ppo_depths_p3.npz", "PPONetwork")])
+def test_actor_and_critic_of_different_depths_match_reference_golden(name, cls_name):
+    """two-layer actors next to three-layer critics (A2C: [64, 64] | [48, 64, 32]) and the other way round (PPO, centralised, one shared
+    critic: [32, 48, 40] | [64, 64]): both families on the GEMM path, the critics with their own layer count
+    (marlhip_ac_config.critic_n_hidden) - state_dict keys and shapes, metrics and every block of 3 x update() against the reference's"""
+    from codebase_amd.ac import model as acm
+    from codebase_amd.spaces import Box, Discrete, Tuple
+
+    g = load(name)
+    P, D, A = int(g["P"]), int(g["D"]), int(g["A"])
+    la, lc = [int(h) for h in g["actor_layers"]], [int(h) for h in g["critic_layers"]]
+    assert len(la) != len(lc)
+    c_sh = bool(int(g["critic_is_shared"]))
+    cfg = dict(optimizer="Adam", lr=3e-4, gamma=0.99, grad_clip=float(g["grad_clip"]), n_steps=5, entropy_coef=0.001, value_loss_coef=0.5,
+               standardise_returns=False, target_update_interval_or_tau=200, num_epochs=4, ppo_clip=0.2)
+    base = dict(use_orthogonal_init=True, use_rnn=False)
+    net = getattr(acm, cls_name)(Tuple([Box(-1, 8, (D,)) for _ in range(P)]), Tuple([Discrete(A) for _ in range(P)]), cfg,
+                                dict(base, layers=la, parameter_sharing=False), dict(base, layers=lc, parameter_sharing=c_sh, centralised=bool(int(g["centralised"]))), "cuda")
+    sd = net.state_dict()
+    assert list(sd.keys()) == [str(k) for k in g["keys"]]
+    assert net.spec.wide and net.spec.n_hidden == len(la) and net.critic_spec.n_hidden == len(lc) and net.updater.cfg.critic_n_hidden == len(lc)
+    cin = P * D if int(g["centralised"]) else D
+    grp = "networks" if c_sh else "independent"
+    assert tuple(sd[f"critic.{grp}.0.network.0.weight"].shape) == (lc[0], cin) and tuple(sd[f"critic.{grp}.0.network.{2 * len(lc)}.weight"].shape) == (1, lc[-1])
+    assert tuple(sd["actor.independent.0.network.2.weight"].shape) == (la[1], la[0])
+
+    def family(prefix):
+        return [v for k, v in net._views().items() if k.startswith(prefix + ".")]
+
+    def put(prefix, flat):
+        o, flat = 0, torch.tensor(flat).reshape(-1)
+        for v in family(prefix):
+            v.copy_(flat[o:o + v.numel()].reshape(v.shape))
+            o += v.numel()
+        assert o == flat.numel(), (prefix, o, flat.numel())
+
+    def get(prefix):
+        return torch.cat([v.detach().reshape(-1) for v in family(prefix)]).cpu().numpy()
+
+    put("actor", g["actor0"])
+    put("critic", g["critic0"])
+    put("target_critic", g["target0"])
+    for i in range(3):
+        b = dev_ac_batch(golden_ac_batch(g, i))
+        m = net.update(b, int(g["steps"][i]))
+        np.testing.assert_allclose([m["loss"], m["actor_loss"], m["value_loss"], m["entropy"]], g["metrics"][i], rtol=5e-5, atol=5e-6)
+        np.testing.assert_allclose(get("actor"), g[f"actor{i + 1}"].reshape(-1), rtol=0, atol=5e-6)
+        np.testing.assert_allclose(get("critic"), g[f"critic{i + 1}"].reshape(-1), rtol=0, atol=5e-6)
+        np.testing.assert_allclose(get("target_critic"), g[f"target{i + 1}"].reshape(-1), rtol=0, atol=5e-6)
+    b0 = golden_ac_batch(g, 0)
+    obs = [b0["obss"][0, :, p * D:(p + 1) * D].to(DEV) for p in range(P)]
+    v, _ = net.get_value(obs, net.init_critic_hiddens(obs[0].shape[0]))
+    assert tuple(v.shape) == (obs[0].shape[0], P) and bool(torch.isfinite(v).all())
