@@ -64,11 +64,13 @@ def _masked(lg, batch):
     return [l * m[:-1, :, p] + (1 - m[:-1, :, p]) * -1e8 for p, l in enumerate(lg)]
 
 
-def evaluate(actor, critic, target, batch, D, H, A, n_steps, gamma, ret_ms=None):
+def evaluate(actor, critic, target, batch, D, H, A, n_steps, gamma, ret_ms=None, Hc=None):
+    """Hc: the critics' own `layers` list when it differs from the actors' H (ac/model.py:45-97 builds each family from its own)"""
+    Hc = H if Hc is None else Hc
     obss, actions = batch["obss"], batch["actions"]
     P = actor.shape[0]
     with torch.no_grad():
-        next_value = values(target, obss, D, H)
+        next_value = values(target, obss, D, Hc)
     if ret_ms is not None:  # standardise_returns (model.py:195-196)
         next_value = next_value * torch.sqrt(ret_ms.var) + ret_ms.mean
     done = batch["dones"].float().unsqueeze(-1).repeat(1, 1, P)
@@ -76,7 +78,7 @@ def evaluate(actor, critic, target, batch, D, H, A, n_steps, gamma, ret_ms=None)
     if ret_ms is not None:  # model.py:202-204
         ret_ms.update(returns)
         returns = (returns - ret_ms.mean) / torch.sqrt(ret_ms.var)
-    v = values(critic, obss[:-1], D, H)
+    v = values(critic, obss[:-1], D, Hc)
     lg = _masked(logits(actor, obss[:-1], D, H, A), batch)
     dists = [torch.distributions.Categorical(logits=l) for l in lg]
     logp = torch.stack([d.log_prob(actions[..., p]) for p, d in enumerate(dists)], dim=-1)
@@ -84,8 +86,8 @@ def evaluate(actor, critic, target, batch, D, H, A, n_steps, gamma, ret_ms=None)
     return returns, v, logp, ent
 
 
-def a2c_loss(actor, critic, target, batch, D, H, A, n_steps=5, gamma=0.99, entropy_coef=0.001, value_loss_coef=0.5, ret_ms=None):
-    returns, v, logp, ent = evaluate(actor, critic, target, batch, D, H, A, n_steps, gamma, ret_ms)
+def a2c_loss(actor, critic, target, batch, D, H, A, n_steps=5, gamma=0.99, entropy_coef=0.001, value_loss_coef=0.5, ret_ms=None, Hc=None):
+    returns, v, logp, ent = evaluate(actor, critic, target, batch, D, H, A, n_steps, gamma, ret_ms, Hc)
     filled = batch["filled"]
     adv = returns - v
     actor_loss = -(logp * adv.detach()).sum(-1) - entropy_coef * ent
@@ -95,9 +97,9 @@ def a2c_loss(actor, critic, target, batch, D, H, A, n_steps=5, gamma=0.99, entro
     return loss, {"loss": loss, "actor_loss": actor_loss, "value_loss": value_loss, "entropy": (ent * filled).sum() / filled.sum()}
 
 
-def ppo_loss(actor, critic, returns, old_logp, batch, D, H, A, entropy_coef, value_loss_coef, ppo_clip):
+def ppo_loss(actor, critic, returns, old_logp, batch, D, H, A, entropy_coef, value_loss_coef, ppo_clip, Hc=None):
     obss, actions, filled = batch["obss"], batch["actions"], batch["filled"]
-    v = values(critic, obss[:-1], D, H)
+    v = values(critic, obss[:-1], D, H if Hc is None else Hc)
     lg = _masked(logits(actor, obss[:-1], D, H, A), batch)
     dists = [torch.distributions.Categorical(logits=l) for l in lg]
     logp = torch.stack([d.log_prob(actions[..., p]) for p, d in enumerate(dists)], dim=-1)
@@ -116,12 +118,13 @@ class Learner:
     """A2CNetwork / PPONetwork update: one Adam over actor + critic tensors in parameters() order."""
 
     def __init__(self, actor, critic, D, H, A, lr=3e-4, gamma=0.99, n_steps=5, entropy_coef=0.001, value_loss_coef=0.5,
-                 grad_clip=False, target_update_interval_or_tau=200, num_epochs=0, ppo_clip=0.2, standardise_returns=False):
+                 grad_clip=False, target_update_interval_or_tau=200, num_epochs=0, ppo_clip=0.2, standardise_returns=False, Hc=None):
         self.ret_ms = dp.RunningMeanStd((actor.shape[0],)) if standardise_returns else None
         self.D, self.H, self.A, self.P = D, H, A, actor.shape[0]
+        self.Hc = Hc = H if Hc is None else Hc  # the critics' own layer list (actor.layers != critic.layers)
         self.at = [torch.nn.Parameter(t.clone()) for p in range(self.P) for t in dp.split(actor[p], D, H, A)]
-        dc = self.P * D if critic.shape[1] == dp.nparams(self.P * D, H, 1) and self.P > 1 else D  # centralised critic
-        self.ct = [torch.nn.Parameter(t.clone()) for p in range(self.P) for t in dp.split(critic[p], dc, H, 1)]
+        dc = self.P * D if critic.shape[1] == dp.nparams(self.P * D, Hc, 1) and self.P > 1 else D  # centralised critic
+        self.ct = [torch.nn.Parameter(t.clone()) for p in range(self.P) for t in dp.split(critic[p], dc, Hc, 1)]
         self.target = critic.clone()
         self.opt = torch.optim.Adam(self.at + self.ct, lr=lr)
         self.gamma, self.n_steps, self.ec, self.vc = gamma, n_steps, entropy_coef, value_loss_coef
@@ -148,16 +151,16 @@ class Learner:
         D, H, A = self.D, self.H, self.A
         if self.num_epochs == 0:
             loss, m = a2c_loss(self.actor(), self.critic(), self.target, batch, D, H, A, self.n_steps, self.gamma, self.ec, self.vc,
-                               self.ret_ms)
+                               self.ret_ms, self.Hc)
             self._step(loss)
             metrics = {k: v.item() for k, v in m.items()}
         else:
             with torch.no_grad():
                 returns, _, old_logp, _ = evaluate(self.actor(), self.critic(), self.target, batch, D, H, A, self.n_steps, self.gamma,
-                                                   self.ret_ms)
+                                                   self.ret_ms, self.Hc)
             acc = {}
             for _ in range(self.num_epochs):
-                loss, m = ppo_loss(self.actor(), self.critic(), returns, old_logp, batch, D, H, A, self.ec, self.vc, self.ppo_clip)
+                loss, m = ppo_loss(self.actor(), self.critic(), returns, old_logp, batch, D, H, A, self.ec, self.vc, self.ppo_clip, self.Hc)
                 self._step(loss)
                 for k, v in m.items():
                     acc.setdefault(k, []).append(v.item())

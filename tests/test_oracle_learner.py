@@ -166,6 +166,25 @@ def test_actor_critic_update_matches_reference(name):
         np.testing.assert_allclose(lr.target.numpy(), g[f"target{i + 1}"], rtol=0, atol=2e-6)
 
 
+def test_actor_critic_port_with_different_depths_matches_reference():
+    """actor.layers [64, 64] next to critic.layers [48, 64, 32] (marlbase/ac/model.py:45-97: each family from its own list): the port with the
+    critics' own layer list (Hc) against the reference's A2CNetwork - metrics and every block after 3 clipped updates"""
+    from oracle import ac_update_port as ap
+
+    g = load("learner_a2c_depths.npz")
+    D, A = int(g["D"]), int(g["A"])
+    H, Hc = tuple(int(h) for h in g["actor_layers"]), tuple(int(h) for h in g["critic_layers"])
+    assert len(H) != len(Hc) and g["critic0"].shape[1] == dp.nparams(D, Hc, 1) and g["actor0"].shape[1] == dp.nparams(D, H, A)
+    lr = ap.Learner(torch.tensor(g["actor0"]), torch.tensor(g["critic0"]), D, H, A, grad_clip=float(g["grad_clip"]), Hc=Hc)
+    lr.target = torch.tensor(g["target0"])
+    for i in range(3):
+        m = lr.update(ac_batch_of(g, i), int(g["steps"][i]))
+        np.testing.assert_allclose([m["loss"], m["actor_loss"], m["value_loss"], m["entropy"]], g["metrics"][i], rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(lr.actor().detach().numpy(), g[f"actor{i + 1}"], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(lr.critic().detach().numpy(), g[f"critic{i + 1}"], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(lr.target.numpy(), g[f"target{i + 1}"], rtol=0, atol=2e-6)
+
+
 @pytest.mark.parametrize("name,mode", [("learner_shared_H64.npz", "idqn"), ("learner_shared_seps_H64.npz", "vdn")])
 def test_parameter_sharing_matches_reference(name, mode):
     """MultiAgentSharedNetwork (utils/models.py:176-300): agents mapped onto K shared networks, gradients tied"""
