@@ -69,6 +69,14 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--cpu-all-cores", type=int, default=0, help=argparse.SUPPRESS)  # internal: the forked all-cores leg of cpu_baseline
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--pretrain-rounds", type=int, default=0,
+                    help="idqn / vdn / qmix: this many UNTIMED training rounds first (epsilon annealed 1 -> --eps-fixed over their first 60 %%), then the "
+                         "warm-up and timed rounds at --eps-fixed: the trained-policy rows of `modes` (short episodes)")
+    ap.add_argument("--eps-fixed", type=float, default=None)
+    ap.add_argument("--clear-stale", action="store_true",
+                    help="idqn / vdn / qmix: the collector zeroes the `filled` tail of a replay slot it reuses (marlhip_idqn_collect clear_stale) - a "
+                         "DEVIATION from the reference's ReplayBuffer, which never resets `filled` (dqn/train.py:65-89: once the ring has wrapped, the rows "
+                         "behind a shorter episode's end are the previous occupant's, still filled = True, and are trained on)")
     return ap.parse_args()
 
 
@@ -335,6 +343,8 @@ def _ranks_field(world, dist, args, sync=None):
     out = {"world_size": dist.get_world_size() if dist is not None else 1, "backend": args.backend if dist is not None else None}
     if dist is not None:
         out["exchange"] = "p2p (in-library)" if getattr(sync, "p2p", None) is not None else "collective (torch.distributed.all_reduce)"
+        if hasattr(sync, "describe"):
+            out.update(sync.describe())
     return out
 
 
@@ -381,7 +391,10 @@ def bench_ac(args, rank, world, dist, steps=None, warmup=None):
     # 17 + 10 us of a 460 us IA2C round
     len_acc = torch.zeros(N, dtype=torch.int64, device=dev)
     tmax_acc = torch.zeros(1, dtype=torch.int64, device=dev)
-    sync_grad = GradSync(dist, max_floats=model.updater.grad.numel()) if dist is not None else None
+    # N > 1: the joint gradient on one lane, and a second lane for the critics' slice when their half of the update runs beside the next
+    # rollout (A2CNetwork.update_async(overlap=True); PPO defers nothing)
+    sync_grad = GradSync(dist, max_floats=model.updater.grad.numel(),
+                         side_floats=model.updater.critic_grad.numel() if hasattr(model, "attach_grad_sync") and args.algo in ("ia2c", "maa2c") else 0) if dist is not None else None
     state = {"round": 0, "step": 0}
 
     if args.rnn:  # recurrent actors: the rollout runs through the modular entry points (hidden state carried between steps)
@@ -423,6 +436,9 @@ def bench_ac(args, rank, world, dist, steps=None, warmup=None):
             dist.barrier()
         torch.cuda.synchronize()
 
+    if sync_grad is not None and hasattr(model, "attach_grad_sync"):
+        with torch.cuda.stream(own_stream):
+            state["split_exchange"] = model.attach_grad_sync(sync_grad)  # a vote over the ranks: all defer or none
     for _ in range(n_warmup):
         one_round()
     sync()
@@ -457,8 +473,20 @@ def bench_ac(args, rank, world, dist, steps=None, warmup=None):
             if n.value:
                 timing[kname] = {"launches": n.value, "avg_us": 1e3 * ms.value / n.value, "total_ms": ms.value}
         lib.marlhip_timing_enable(0)
+    exchange = None
     if sync_grad is not None:
         sync_grad.check()
+        exchange = sync_grad.describe()
+        exchange["critics_slice_on_their_own_lane"] = bool(state.get("split_exchange", False))
+    digest = None
+    if getattr(args, "want_digest", False):
+        import hashlib
+
+        model.updater.sync_critic()
+        torch.cuda.synchronize()
+        digest = hashlib.sha256(model.updater.block.cpu().numpy().tobytes()).hexdigest()[:16]
+    if sync_grad is not None:
+        sync_grad.close()
     if rank != 0:
         return None
     name = args.env_name.split(":")[-1].replace("-v3", "").replace("-v2", "")
@@ -479,6 +507,17 @@ def bench_ac(args, rank, world, dist, steps=None, warmup=None):
                     "flops_per_launch": flops, "avg_launch_us": upd["avg_us"],
                     "flops_needed_per_launch": needed, "frac_needed": ach * needed / flops / PEAK_F32_MFMA_TFLOPS,
                     "dominant_stage_by_time": "ac_update" if not col or upd["total_ms"] >= col["total_ms"] else "ac_collect_kernel"}
+        if deferred:
+            roofline["side_stream"] = h.side_stream_description(dev)
+        # the whole round against its wall time - every product the round runs, wherever it runs: the rollout's acting forward pass, the
+        # update stage above AND the critics' deferred backward pass (which the stage's own `frac` leaves out of both FLOPs and time)
+        epochs = hyper["num_epochs"] if args.algo in ("ippo", "mappo") else 1
+        f_all = (ac_update_flops(bool(args.rnn), P, D, A, H, T, N, central, epochs=epochs, actor_forward_kept=kept) * (1 + epochs if epochs > 1 else 1)
+                 + (gru_fwd_flops if args.rnn else mlp_fwd_flops)(D, H, A) * P * (env_steps / max(n_steps_timed * world, 1)))
+        round_s = dt / n_steps_timed
+        roofline["whole_round"] = {"flops_per_round_per_gpu": f_all, "round_ms": 1e3 * round_s,
+                                   "frac": f_all / round_s / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                                   "note": "rollout forward + update stage + the critics' backward pass (deferred or not) over the round's wall time"}
         if col and col["total_ms"] > upd["total_ms"]:  # the rollout dominates (long episodes, few envs): its acting forward next to it
             cf = (gru_fwd_flops if args.rnn else mlp_fwd_flops)(D, H, A) * P * (env_steps / n_steps_timed)
             roofline["collector"] = {"kernel": "ac_collect_kernel", "bound": "mfma (latency-bound in practice: one wave per 16 envs walks the episode)",
@@ -498,6 +537,10 @@ def bench_ac(args, rank, world, dist, steps=None, warmup=None):
                    "parallelism": f"dp{world} (envs sharded per GPU, RCCL grad all-reduce per update)" if world > 1 else "1 GPU"},
         "kernels": timing, "roofline": roofline,
     }
+    if exchange is not None:
+        out["rccl_ranks"].update(exchange)
+    if digest is not None:
+        out["params_sha16_rank0"] = digest
     return out
 
 
@@ -581,10 +624,18 @@ def main():
             dist.destroy_process_group()
         return
 
+    default_line = (args.algo == "idqn" and args.cadence == "ratio" and args.hidden == 64 and not args.rnn and args.env_name == ENV_NAME
+                    and not args.update_batch and not args.updates_per_round and not args.split16 and not args.pretrain_rounds)
+    multi = world > 1 and default_line and not args.no_modes  # the first multi-GPU run describes itself
+    if multi:
+        args.want_digest = True
     out = bench_dqn(args, rank, world, dist, args.steps, args.warmup)
+    if multi:
+        rows = multi_gpu_rows(args, rank, world, dist, out)
+        if rank == 0:
+            out["rccl_ranks"]["exchange_rows"] = rows["exchange_rows"]
+            out["modes"] = rows["modes"]
     if rank == 0:
-        default_line = (args.algo == "idqn" and args.cadence == "ratio" and args.hidden == 64 and not args.rnn and args.env_name == ENV_NAME
-                        and not args.update_batch and not args.updates_per_round and not args.split16)
         if world == 1 and default_line and not args.no_modes:
             out["modes"] = secondary_modes(args)
         if world == 1 and not args.no_cpu_baseline:
@@ -592,6 +643,66 @@ def main():
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def multi_gpu_rows(args, rank, world, dist, headline):
+    """N > 1 only, every rank runs the same sequence: (i) the headline workload a second time in the same process group with the OTHER
+    exchange (MARLHIP_P2P=0: torch.distributed's all-reduce, RCCL under backend nccl), so that one line carries both - value, the
+    per-update exchange time from the library's timers (id 5), what carried the gradients and why; for two ranks the rank-ordered
+    sum IS the collective's sum, so the two rows' final parameters must hash the same; (ii) BASELINE configs 4 and 5 at their
+    per-GPU shard (2048 / 8192 envs per rank) with their own exchanges (config 4: the critics' slice on the second lane)."""
+    import copy
+    import gc
+
+    import torch
+
+    def summary(r):
+        k = (r.get("kernels") or {})
+        ex = next((v for n, v in k.items() if n.startswith("gradient_exchange")), None)
+        rr = r["rccl_ranks"]
+        return {"value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"], "steps": r["steps"], "warmup": r["warmup"],
+                "exchange": rr.get("exchange"), "self_test": rr.get("self_test"), "fallback_reason": rr.get("fallback_reason"),
+                "per_update_exchange_us": ex["avg_us"] if ex else None, "exchanges_timed": ex["launches"] if ex else None,
+                "params_sha16_rank0": r.get("params_sha16_rank0")}
+
+    rows = {"exchange_rows": {}, "modes": {}}
+    if rank == 0:
+        rows["exchange_rows"]["default (MARLHIP_P2P unset): " + headline["rccl_ranks"].get("exchange", "?")] = summary(headline)
+    keep = os.environ.get("MARLHIP_P2P")
+    os.environ["MARLHIP_P2P"] = "0"
+    try:
+        a = copy.copy(args)
+        r = bench_dqn(a, rank, world, dist, args.steps, args.warmup)
+        if rank == 0:
+            rows["exchange_rows"]["MARLHIP_P2P=0: " + r["rccl_ranks"].get("exchange", "?")] = summary(r)
+    finally:
+        if keep is None:
+            os.environ.pop("MARLHIP_P2P", None)
+        else:
+            os.environ["MARLHIP_P2P"] = keep
+    if rank == 0:
+        shas = [v["params_sha16_rank0"] for v in rows["exchange_rows"].values()]
+        rows["exchange_rows"]["same_final_parameters"] = len(set(shas)) == 1 if world == 2 else None  # (N > 2: the collective's summation order is its own)
+    for name, over, steps, warmup in (
+            ("BASELINE config 4 (per-GPU shard): IA2C rware-tiny-4ag, 2048 envs per rank, 128-128", dict(algo="ia2c", env_name="rware:rware-tiny-4ag-v2", envs=2048, hidden=128, time_limit=500), 16, 2),
+            ("BASELINE config 5 (per-GPU shard): QMIX Foraging-15x15-8p-5f, 8192 envs per rank, 128-128, fp32 mixer", dict(algo="qmix", env_name="lbforaging:Foraging-15x15-8p-5f-v3", envs=8192, hidden=128), 2, 1)):
+        a = copy.copy(args)
+        for k, v in over.items():
+            setattr(a, k, v)
+        if os.environ.get("MARLHIP_BENCH_SMALL_ROWS"):  # the one-device plumbing test: the same rows at a size two ranks sharing a GPU finish in seconds
+            a.envs, a.time_limit = (256, 60) if a.algo == "ia2c" else (256, 25)
+            steps, warmup = 3, 1
+        r = bench_ac(a, rank, world, dist, steps, warmup) if a.algo == "ia2c" else bench_dqn(a, rank, world, dist, steps, warmup)
+        if rank == 0:
+            rf = r.get("roofline") or {}
+            row = summary(r)
+            row.update({"workload": r["config"]["workload"], "critic_backward_overlaps_next_rollout": rf.get("critic_backward_overlaps_next_rollout"),
+                        "critics_slice_on_their_own_lane": r["rccl_ranks"].get("critics_slice_on_their_own_lane"),
+                        "roofline": {k: rf.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_us", "whole_round")}})
+            rows["modes"][name] = row
+        gc.collect()
+        torch.cuda.empty_cache()
+    return rows
 
 
 def secondary_modes(args):
@@ -700,11 +811,13 @@ def bench_dqn(args, rank, world, dist, steps, warmup):
     else:
         model = (VDNetwork if args.algo == "vdn" else QNetwork)(obs_space, act_space, hyper, [H, H], False, bool(args.rnn), True, "cuda")
     cap = args.replay_rounds * N
-    trainer = VectorisedIDQN(cfg, model, cap, T, B, U, seed=args.seed, dist=dist)
+    trainer = VectorisedIDQN(cfg, model, cap, T, B, U, seed=args.seed, dist=dist, clear_stale=bool(getattr(args, "clear_stale", False)))
     eps_sched = _epsilon_schedule("linear", 0.5, 1.0, 0.05, 6.5, 100_000_000)
     # `modes` row "trained policy": `pretrain_rounds` untimed rounds of the same loop with epsilon annealed 1 -> eps_fixed over their first
     # 60 %, then the warm-up and the timed rounds at eps_fixed (secondary_modes sets both; the default line has neither)
     pre, eps_fixed = int(getattr(args, "pretrain_rounds", 0) or 0), getattr(args, "eps_fixed", None)
+    if pre and eps_fixed is None:
+        eps_fixed = 0.05
 
     def eps_at(rnd):
         if pre:
@@ -739,11 +852,14 @@ def bench_dqn(args, rank, world, dist, steps, warmup):
         dist.all_reduce(steps_dev)
     env_steps = int(steps_dev.item())
     mean_return = float(trainer.fin_return.sum(0).mean().item())  # the last round's episodes, summed over the agents (this rank's)
+    # rows the learner must compute per sampled episode = sum(filled) of the last update / B: the episode's own transitions PLUS, once the ring
+    # has wrapped, the stale tail of the slot's longer previous occupants (the reference never resets `filled`: dqn/train.py:65-89)
+    sampled_rows = float(trainer.last_loss[1].item()) / B if (U and trainer.last_loss is not None) else None
 
     timing = {}
     if not args.no_kernel_timing:
         for kid, kname in ((0, "dqn_lossgrad_kernel"), (1, "idqn_collect_kernel"), (2, "replay_sample_kernel"),
-                           (4, "qmix_mixer_stage")):
+                           (4, "qmix_mixer_stage"), (5, "gradient_exchange (reduce launch with the in-library exchange inside, or the exchange call)")):
             n, ms = ctypes.c_int64(0), ctypes.c_double(0.0)
             lib.marlhip_timing_read(kid, ctypes.byref(n), ctypes.byref(ms))
             if n.value:
@@ -751,8 +867,16 @@ def bench_dqn(args, rank, world, dist, steps, warmup):
         lib.marlhip_timing_enable(0)
 
     exchange_sync = getattr(trainer, "_sync", None)
+    ranks_field = _ranks_field(world, dist, args, exchange_sync)
+    digest = None
+    if getattr(args, "want_digest", False):
+        import hashlib
+
+        torch.cuda.synchronize()
+        digest = hashlib.sha256(model.params.cpu().numpy().tobytes()).hexdigest()[:16]
     if exchange_sync is not None:
         exchange_sync.check()  # every rank: a timed-out in-library exchange fails the run on all of them
+        exchange_sync.close()  # (freed behind a job-wide barrier: the next row of a multi-row run sets up its own)
     mean_len = env_steps / max(steps * N * world, 1)  # every round stores N episodes per rank
     eps_timed = (eps_at(trainer.rounds - steps), eps_at(trainer.rounds - 1))
     del trainer, model
@@ -800,7 +924,7 @@ def bench_dqn(args, rank, world, dist, steps, warmup):
         "value": env_steps / dt,
         "unit": "env-steps/s",
         "n_gpus": world,
-        "rccl_ranks": _ranks_field(world, dist, args, exchange_sync),
+        "rccl_ranks": ranks_field,
         "steps": steps,
         "warmup": warmup,
         "ms_per_step": 1e3 * dt / steps,
@@ -834,6 +958,8 @@ def bench_dqn(args, rank, world, dist, steps, warmup):
             # length the policy produces.  The timed rounds run at the epsilon below (a fresh run's schedule: close to 1, random policy,
             # every episode runs to the time limit unless the env ends it) - `modes` carries a trained-policy row next to it
             "mean_episode_length": mean_len,
+            "mean_filled_rows_per_sampled_episode": sampled_rows,
+            "replay_clear_stale": bool(getattr(args, "clear_stale", False)),
             "mean_episode_return_last_round": mean_return,
             "epsilon_timed_rounds": {"first": eps_timed[0], "last": eps_timed[1]},
             "policy_regime": getattr(args, "regime_note", "fresh run: epsilon-greedy near epsilon = 1 on orthogonal-init networks"),
@@ -841,6 +967,8 @@ def bench_dqn(args, rank, world, dist, steps, warmup):
         "kernels": timing,
         "roofline": roofline,
     }
+    if digest is not None:
+        out["params_sha16_rank0"] = digest
     return out
 
 

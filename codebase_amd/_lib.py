@@ -217,6 +217,8 @@ PROTOTYPES = {
                                                           c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "marlhip_idqn_update_n": (c_int32, [POINTER(IdqnLearner), c_int32, c_int32, c_uint64, c_uint32, POINTER(c_int64),
                                         POINTER(c_int64), POINTER(c_int64), c_void_p]),
+    "marlhip_update_plan": (c_int32, [POINTER(ReplayShape), POINTER(ReplayBuffers), c_int32, c_int32, c_int32, c_uint64, c_uint32, c_int32, c_void_p,
+                                      c_int64, c_void_p, c_void_p, c_void_p]),
     "marlhip_idqn_update_n_dist": (c_int32, [POINTER(IdqnLearner), c_int32, c_int32, c_uint64, c_uint32, POINTER(c_int64),
                                              POINTER(c_int64), POINTER(c_int64), c_void_p, c_void_p, c_int32, c_void_p]),
     "marlhip_qmix_update_n": (c_int32, [POINTER(QmixLearner), c_int32, c_int32, c_uint64, c_uint32, POINTER(c_int64), POINTER(c_int64),

@@ -228,17 +228,43 @@ class A2CNetwork:
     # logits and hidden layers of every batch row for the step (hip.ac_collect(keep_for=updater)) instead of the step recomputing them
     keeps_actor_forward = True
 
+    def attach_grad_sync(self, grad_sync):
+        """data-parallel set-up (every rank, once, before the first update): whether the critics' half of an update may leave the caller's
+        stream beside a gradient exchange.  It may when the exchange has a second lane (GradSync(side_floats=...)) and EVERY rank can
+        create the compute-unit-masked stream - a vote, so that all ranks issue the same sequence of exchanges on the same lanes."""
+        ok = getattr(grad_sync, "side", None) is not None and self.updater.probe_defer()
+        dist = getattr(grad_sync, "dist", None)
+        if dist is not None and grad_sync.world > 1:
+            votes = [None] * grad_sync.world
+            dist.all_gather_object(votes, bool(ok))
+            ok = all(votes)
+        self._split_exchange = bool(ok)
+        return self._split_exchange
+
+    _split_exchange = False
+
     def update_async(self, batch, step, grad_sync=None, world=1, overlap=False):
         """loss/grad -> [grad_sync(grad)] -> clip+Adam -> target update; returns the device metrics tensor
         (loss, actor_loss, value_loss, entropy, sum(filled)) without synchronising.
-        overlap (the drivers' rollout -> update loops; one process): without a joint clip (ia2c.yaml / maa2c.yaml: grad_clip False) the
+        overlap (the drivers' rollout -> update loops): without a joint clip (ia2c.yaml / maa2c.yaml: grad_clip False) the
         next rollout needs only the ACTORS' step, so the critics' backward pass, their step and their target update run on a stream of
         their own next to it (AcUpdater.a2c_loss_grad(defer_critic=True)) - the same launches on the same data, the same bits.  The caller
-        must leave the batch tensors alone until the next update (or model access) has waited for that stream."""
+        must leave the batch tensors alone until the next update (or model access) has waited for that stream.
+        Beside a gradient exchange the optimiser step is still elementwise, so the exchange splits with it: the actors' slice is reduced and
+        stepped on the caller's stream, the critics' slice on their stream behind the deferred backward pass, through the exchange's second
+        lane (attach_grad_sync; without one, or when some rank has no masked stream, the whole update stays on the caller's stream)."""
         up = self.updater
-        m = up.a2c_loss_grad(batch, defer_critic=overlap if grad_sync is None else False)  # (overlap="force": wherever it is possible, not only where it pays)
+        if grad_sync is not None and not self._split_exchange:
+            overlap = False
+        m = up.a2c_loss_grad(batch, defer_critic=overlap)  # (overlap="force": wherever it is possible, not only where it pays)
         if grad_sync is not None:
-            grad_sync(up.grad)
+            if up._critic_pending is not None:
+                na = up.actor.numel()
+                grad_sync(up.grad[:na])
+                with torch.cuda.stream(up._critic_stream):
+                    grad_sync.side(up.grad[na:])
+            else:
+                grad_sync(up.grad)
         up.apply(grad_scale=1.0 / world)
         with up.critic_stream():
             self._target_update(step)
@@ -281,6 +307,7 @@ class A2CNetwork:
         return OrderedDict((k, v.detach().clone().reshape(self._shapes.get(k, v.shape))) for k, v in self._views().items())
 
     def load_state_dict(self, sd):
+        self.updater._kept = None  # the actors move: a forward pass kept by an earlier rollout is no longer this network's
         for k, view in self._views().items():
             view.copy_(sd[k].to(self.device).reshape(view.shape))
 

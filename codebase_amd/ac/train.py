@@ -185,7 +185,9 @@ def main(envs, eval_env, logger, time_limit, **cfg):
     logger.watch(model)
     sync = None
     if dist is not None:
-        sync = GradSync(dist, max_floats=model.updater.grad.numel())  # the in-library peer-to-peer exchange where it can be set up
+        # the in-library peer-to-peer exchange where it can be set up; a second lane for the critics' slice, reduced on their own stream
+        # when their half of an update runs next to the following rollout (A2CNetwork.update_async)
+        sync = GradSync(dist, max_floats=model.updater.grad.numel(), side_floats=model.updater.critic_grad.numel())
         dist.broadcast(model.updater.block, 0)  # identical replicas (the seeded init already agrees; this makes it unconditional)
         dist.broadcast(model.updater.target_critic, 0)
         model.updater.attach_exchange(lambda t: dist.all_reduce(t))  # standardise_returns: global batch moments
@@ -195,58 +197,73 @@ def main(envs, eval_env, logger, time_limit, **cfg):
     # the loop runs on a stream of its own: A2C's critics finish their half of an update next to the following rollout, on a stream that
     # owns half of the compute units, and a stream of that kind synchronises implicitly with the DEFAULT stream (AcUpdater.can_defer)
     caller_stream = torch.cuda.current_stream(model.device)
-    torch.cuda.set_stream(torch.cuda.Stream(device=model.device))
-    torch.cuda.current_stream(model.device).wait_stream(caller_stream)  # (the model was built on the caller's stream)
-    while step < g("total_steps") + 1:
-        log_now = (step - last_eval) >= g("eval_interval")  # the only consumer of a rollout's infos
-        t, batch, infos = _collect_trajectories(envs, model, time_limit, parallel_envs, model.n_agents, device,
-                                                g("use_proper_termination", False), round_idx=updates, want_infos=log_now)
-        if dist is not None:
-            # the reference's counter (ac/train.py:226) for the whole job, the same number on every rank (it ends the loop).  Exchanged
-            # HERE, where the host has just read `t` and the stream is empty - not behind update_async, where reading it would make the host
-            # wait for the update instead of queueing the next rollout
-            t_job = int(gather_stack(dist, torch.tensor([t * parallel_envs], device=device)).sum().item())
-        if dist is not None and log_now:
-            # the other ranks' FIRST episodes join rank 0's list: one per env, chosen by env id - `infos` is sorted by finish step, so its
-            # head would be the shortest episodes, later ones of fast envs included
-            first = {}
-            for d in infos:
-                first.setdefault(d.env, d)
-            rows = torch.tensor([[*map(float, first[i]["episode_returns"]), float(first[i]["episode_length"])] for i in range(parallel_envs)],
-                                dtype=torch.float32, device=device)
-            for r, block in enumerate(gather_stack(dist, rows).cpu().numpy()):
-                if r != rank:
-                    for row in block:
-                        d = EpisodeInfo({"episode_returns": row[:-1].copy(), "episode_length": int(row[-1])})
-                        for p in range(model.n_agents):
-                            d[f"agent{p}/episode_returns"] = row[p]
-                        infos.append(d)
-        # overlap: one process, no joint clip -> the critics' half of the update runs next to the following rollout (A2CNetwork.update_async);
-        # every rollout has its own batch tensors here, and reading `t` above has already waited for the rollout
-        m = model.update_async(batch, step, grad_sync=sync, world=world, overlap=True)
-        infos.append(model._metrics(m) if log_now else m)
-        if log_now:
-            if sync is not None:
-                sync.check()  # every rank (`step` is the job's): a timed-out in-library exchange stops the run here, on all of them
-            if rank == 0:
-                _log_progress(infos, step, updates, logger)
-            last_eval = step
-        if g("save_interval") and (step - last_save) >= g("save_interval"):
-            if sync is not None:
-                sync.check()  # never save replicas that have diverged
-            if rank == 0:
-                Path("checkpoints").mkdir(exist_ok=True)
-                torch.save(model.state_dict(), f"checkpoints/model_s{step}.pt")
-            last_save = step
-        if g("video_interval"):
-            raise NotImplementedError("video recording is outside the HIP hot path")
-        updates += 1
-        step += t * parallel_envs if dist is None else t_job
-    if sync is not None:
-        sync.close()  # final check on every rank, then the exchange is freed behind a job-wide barrier
-    # back on the caller's stream, behind everything the loop queued (the critics' deferred half included)
-    model.updater.sync_critic()
-    caller_stream.wait_stream(torch.cuda.current_stream(model.device))
-    torch.cuda.set_stream(caller_stream)
+    loop_stream = torch.cuda.Stream(device=model.device)
+    loop_stream.wait_stream(caller_stream)  # (the model was built on the caller's stream)
+    torch.cuda.set_stream(loop_stream)
+    finished = False
+    try:
+        if sync is not None and hasattr(model, "attach_grad_sync"):
+            model.attach_grad_sync(sync)  # (a vote over the ranks, on the loop's stream: what can_defer looks at)
+        while step < g("total_steps") + 1:
+            log_now = (step - last_eval) >= g("eval_interval")  # the only consumer of a rollout's infos
+            t, batch, infos = _collect_trajectories(envs, model, time_limit, parallel_envs, model.n_agents, device,
+                                                    g("use_proper_termination", False), round_idx=updates, want_infos=log_now)
+            if dist is not None:
+                # the reference's counter (ac/train.py:226) for the whole job, the same number on every rank (it ends the loop).  Exchanged
+                # HERE, where the host has just read `t` and the stream is empty - not behind update_async, where reading it would make the host
+                # wait for the update instead of queueing the next rollout
+                t_job = int(gather_stack(dist, torch.tensor([t * parallel_envs], device=device)).sum().item())
+            if dist is not None and log_now:
+                # the other ranks' FIRST episodes join rank 0's list: one per env, chosen by env id - `infos` is sorted by finish step, so its
+                # head would be the shortest episodes, later ones of fast envs included
+                first = {}
+                for d in infos:
+                    first.setdefault(d.env, d)
+                rows = torch.tensor([[*map(float, first[i]["episode_returns"]), float(first[i]["episode_length"])] for i in range(parallel_envs)],
+                                    dtype=torch.float32, device=device)
+                for r, block in enumerate(gather_stack(dist, rows).cpu().numpy()):
+                    if r != rank:
+                        for row in block:
+                            d = EpisodeInfo({"episode_returns": row[:-1].copy(), "episode_length": int(row[-1])})
+                            for p in range(model.n_agents):
+                                d[f"agent{p}/episode_returns"] = row[p]
+                            infos.append(d)
+            # overlap: no joint clip -> the critics' half of the update runs next to the following rollout (A2CNetwork.update_async; beside a
+            # gradient exchange through the exchange's second lane); every rollout has its own batch tensors here, and reading `t` above has
+            # already waited for the rollout
+            m = model.update_async(batch, step, grad_sync=sync, world=world, overlap=True)
+            infos.append(model._metrics(m) if log_now else m)
+            if log_now:
+                if sync is not None:
+                    sync.check()  # every rank (`step` is the job's): a timed-out in-library exchange stops the run here, on all of them
+                if rank == 0:
+                    _log_progress(infos, step, updates, logger)
+                last_eval = step
+            if g("save_interval") and (step - last_save) >= g("save_interval"):
+                if sync is not None:
+                    sync.check()  # never save replicas that have diverged
+                if rank == 0:
+                    Path("checkpoints").mkdir(exist_ok=True)
+                    torch.save(model.state_dict(), f"checkpoints/model_s{step}.pt")
+                last_save = step
+            if g("video_interval"):
+                raise NotImplementedError("video recording is outside the HIP hot path")
+            updates += 1
+            step += t * parallel_envs if dist is None else t_job
+        if sync is not None:
+            sync.check()  # the final check on every rank (a raise here still takes the finally below)
+        finished = True
+    finally:
+        # back on the caller's stream, behind everything the loop queued (the critics' deferred half included) - also when the loop raised
+        # (sync.check(), a NotImplementedError, KeyboardInterrupt): the caller must not be left on a private stream with the critics'
+        # work unordered against it
+        try:
+            if hasattr(model, "updater"):
+                model.updater.sync_critic()
+            caller_stream.wait_stream(loop_stream)
+        finally:
+            torch.cuda.set_stream(caller_stream)
+            if sync is not None and finished:
+                sync.close()  # the exchange is freed behind a job-wide barrier (not on the error path: a peer may never reach it)
     envs.close()
     return model

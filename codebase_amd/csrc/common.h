@@ -13,7 +13,9 @@ namespace marl {
 void set_error(const char* fmt, ...);
 
 // optional per-kernel HIP-event timing (bench.py's roofline leg): off by default
-enum { TIMER_LOSSGRAD = 0, TIMER_COLLECT = 1, TIMER_SAMPLE = 2, TIMER_ENVSTEP = 3, TIMER_QMIX = 4, TIMER_COUNT = 5 };
+enum { TIMER_LOSSGRAD = 0, TIMER_COLLECT = 1, TIMER_SAMPLE = 2, TIMER_ENVSTEP = 3, TIMER_QMIX = 4,
+       TIMER_EXCHANGE = 5,  // data-parallel updates: the reduce launch with the in-library exchange inside, or reduce + the exchange callback
+       TIMER_COUNT = 6 };
 void timing_begin(int id, hipStream_t st);
 void timing_end(int id, hipStream_t st);
 

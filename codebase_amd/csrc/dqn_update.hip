@@ -319,7 +319,10 @@ int idqn_update_n_fused(const marlhip_idqn_learner* L, int32_t n_updates, int32_
     fuse.exchange = exchange;
     fuse.exchange_ctx = exchange_ctx;
     const float grad_scale = exchange != nullptr ? 1.0f / (float)world : 1.0f;
+    // filled-aware task plans for the single-pass learner (update_plan.h); MARLHIP_NO_PLAN=1: every tile walks all T steps (diagnostics, A/B rows)
+    fuse.plan_enabled = (L->mode == 0 && !L->materialise_batch && getenv("MARLHIP_NO_PLAN") == nullptr) ? 1 : 0;
     for (int u = 0; u < n_updates; ++u) {
+        fuse.updates_left = n_updates - u;
         const bool hard = tui > 1.0 && (double)(*updates + 1 - *last_target_update) >= tui;
         const float tau = tui < 1.0 ? (float)tui : 0.f;
         fuse.adam = adam_args(*adam_step + 1, L->lr, L->beta1, L->beta2, L->eps, L->max_norm, grad_scale, hard ? 1 : 0, tau);
@@ -352,6 +355,33 @@ int idqn_update_n_fused(const marlhip_idqn_learner* L, int32_t n_updates, int32_
     return 0;
 }
 }  // namespace marl
+
+// The filled-aware task plans marlhip_idqn_update_n builds for its single-pass learner, for inspection (tests, tools): plan_out receives
+// n_updates x dims[1] int32 - per update [4 header: slots, chunk length, longest episode, stored transitions][batch episode indices,
+// longest first (stable)][slots x waves tasks: tile << 16 | t0 << 8 | t1, 0 = none] - exactly what the learner kernel reads.
+extern "C" int marlhip_update_plan(const marlhip_replay_shape* rs, const marlhip_replay_buffers* rb, int32_t n_agents, int32_t batch, int32_t length,
+                                   uint64_t seed, uint32_t counter0, int32_t n_updates, int32_t* plan_out, int64_t plan_out_ints, int32_t* idx_out,
+                                   int32_t* dims_out, void* stream) {
+    MARL_REQUIRE(rs && rb && dims_out, "update_plan: NULL pointer");
+    MARL_REQUIRE(n_agents >= 1 && batch >= 1 && length >= 1 && length <= rs->capacity && n_updates >= 0, "update_plan: bad counts");
+    const UpdPlan pl = upd_plan(n_agents, rs->max_len, batch);
+    const PlanDims d = plan_dims(n_agents, rs->max_len, batch, pl.nwg, UPD_WAVES, pl.n_chunks);
+    dims_out[0] = d.planned; dims_out[1] = d.stride; dims_out[2] = PLAN_HDR; dims_out[3] = d.waves; dims_out[4] = d.cap_slots;
+    dims_out[5] = d.nc_static; dims_out[6] = d.ngroups; dims_out[7] = d.T;
+    if (plan_out == nullptr || n_updates == 0) return 0;
+    MARL_REQUIRE(d.planned, "update_plan: this (batch, max_len) is outside the planner's limits (the learner runs its static plan)");
+    MARL_REQUIRE(plan_out_ints >= (int64_t)n_updates * d.stride, "update_plan: plan_out holds %lld int32, %lld needed", (long long)plan_out_ints,
+                 (long long)n_updates * d.stride);
+    static LdsAttr attr;
+    if (attr.need()) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&update_plan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        attr.done();
+    }
+    hipLaunchKernelGGL(update_plan_kernel, dim3(n_updates), dim3(PLAN_THREADS), plan_lds_bytes(d), (hipStream_t)stream, *rb, seed, counter0, length, d,
+                       plan_out, idx_out, n_updates - 1);
+    MARL_CHECK_LAUNCH("update_plan_kernel");
+    return 0;
+}
 
 static int clip_step(const AdamArgs& a, int64_t n, float* params, const float* grad, float* state1, float* state2, float* target_params,
                      float grad_scale, float* scratch, float* gnorm_out, hipStream_t st) {

@@ -25,6 +25,9 @@
 namespace marl {
 
 bool p2p_is_builtin(marlhip_exchange_fn fn);  // p2p.hip
+}
+#include "update_plan.h"
+namespace marl {
 
 
 __device__ __forceinline__ void wave_lds_fence() {
@@ -117,6 +120,8 @@ struct ReplaySrc {
     uint32_t counter;
     int length;
     int capacity;  // episodes in the replay: when every array is < 2 GB the kernel addresses it through buffer descriptors (32-bit offsets)
+    // filled-aware plan of this update (update_plan.h; nullptr: the static plan): [header][B episode indices, longest first][slot][wave] tasks
+    const int32_t* plan = nullptr;
 };
 
 __device__ __forceinline__ int replay_draw(const ReplaySrc& r, int b) {
@@ -256,9 +261,23 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dqn_lossgrad_kernel(con
     const unsigned long long t_loop_begin = prof ? __builtin_readcyclecounter() : 0;
     const int ngroups = (B + 15) >> 4;
     const int ntasks = ngroups * n_chunks;
-    for (int task = blockIdx.x * WAVES + wave; task < ntasks; task += gridDim.x * WAVES) {
-        const int grp = task / n_chunks, c = task - grp * n_chunks;
-        const int t0 = (c * T) / n_chunks, t1 = ((c + 1) * T) / n_chunks;
+    // tasks of this wave: computed (the static plan: every tile walks all T steps in n_chunks chunks) or read from the update's
+    // filled-aware table (update_plan.h: a tile walks only the steps its longest episode has, in chunks sized to balance the waves)
+    const int waves_all = gridDim.x * WAVES, wave_id = __builtin_amdgcn_readfirstlane(blockIdx.x * WAVES + wave);
+    const int32_t* ptab = (REPLAY && MODE == 0) ? rs.plan : nullptr;
+    const int nslots = ptab != nullptr ? ptab[0] : (ntasks + waves_all - 1) / waves_all;
+    for (int slot = 0; slot < nslots; ++slot) {
+        int grp, c = 1, t0, t1;
+        if (ptab != nullptr) {
+            const int e = ptab[PLAN_HDR + B + slot * waves_all + wave_id];
+            grp = e >> 16; t0 = (e >> 8) & 255; t1 = e & 255;
+        } else {
+            const int task = slot * waves_all + wave_id;
+            if (task >= ntasks) break;
+            grp = task / n_chunks;
+            c = task - grp * n_chunks;
+            t0 = (c * T) / n_chunks; t1 = ((c + 1) * T) / n_chunks;
+        }
         if (t1 <= t0) continue;
         const int b0 = grp * 16;
         const bool rowok = (b0 + j) < B;
@@ -1348,6 +1367,9 @@ struct UpdFuse {
     // the ranks in `grad`, ordered on the stream; adam.grad_scale = 1 / world.  nullptr: single GPU.
     marlhip_exchange_fn exchange = nullptr;
     void* exchange_ctx = nullptr;
+    // filled-aware task plans (update_plan.h): one planning launch covers as many of the call's remaining updates as the idle mixer planes
+    // of the workspace hold; the caller sets plan_enabled and, before every update, updates_left (this one included)
+    int plan_enabled = 0, updates_left = 0, plan_left = 0, plan_pos = 0;
 };
 
 template <class S, bool REPLAY>
@@ -1412,10 +1434,41 @@ int launch_lossgrad_src(const marlhip_net_shape* s, const float* params, const f
     }
     if (mode == 3 || (mode == 0 && IDQN_TWO_PASS)) mix.rew_all = mix.lrow + tb;  // [P][tb]; the statistics' block partials follow it
     const dim3 grid(pl.nwg, P), block(256);
+    ReplaySrc psrc = src;
+    if constexpr (REPLAY && !IDQN_TWO_PASS) {
+        // the single-pass learner leaves the mixer planes of the workspace idle: they hold the filled-aware plans of the next K updates
+        if (fuse != nullptr && fuse->plan_enabled && !two_pass && src.idx == nullptr) {
+            const PlanDims pd = plan_dims(P, T, B, pl.nwg, UPD_WAVES, pl.n_chunks);
+            const int64_t region = (int64_t)(4 * P + 5) * T * B * (int64_t)sizeof(float);
+            const int K = pd.planned ? (int)(region / ((int64_t)pd.stride * 4) > 4096 ? 4096 : region / ((int64_t)pd.stride * 4)) : 0;
+            if (K >= 1) {
+                int32_t* pbase = reinterpret_cast<int32_t*>(mixf);
+                if (fuse->plan_left == 0) {
+                    const int n = fuse->updates_left < K ? (fuse->updates_left > 0 ? fuse->updates_left : 1) : K;
+                    const size_t plds = plan_lds_bytes(pd);
+                    static LdsAttr plan_attr;
+                    if (plan_attr.need()) {
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&update_plan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+                        plan_attr.done();
+                    }
+                    hipLaunchKernelGGL(update_plan_kernel, dim3(n), dim3(PLAN_THREADS), plds, st, src.rb, src.seed, src.counter, src.length, pd, pbase,
+                                       src.idx_out, fuse->updates_left <= n ? fuse->updates_left - 1 : -1);
+                    MARL_CHECK_LAUNCH("update_plan_kernel");
+                    fuse->plan_left = n;
+                    fuse->plan_pos = 0;
+                }
+                psrc.plan = pbase + (size_t)fuse->plan_pos * pd.stride;
+                psrc.idx = psrc.plan + PLAN_HDR;
+                psrc.idx_out = nullptr;  // (the planning launch recorded the draws, in draw order)
+                fuse->plan_pos += 1;
+                fuse->plan_left -= 1;
+            }
+        }
+    }
     timing_begin(TIMER_LOSSGRAD, st);
     if (!two_pass) {
         if constexpr (!IDQN_TWO_PASS)
-            hipLaunchKernelGGL((dqn_lossgrad_kernel<S, 4, REPLAY, 0>), grid, block, lds_bytes, st, (const float*)packs, *bt, src, mix,
+            hipLaunchKernelGGL((dqn_lossgrad_kernel<S, 4, REPLAY, 0>), grid, block, lds_bytes, st, (const float*)packs, *bt, psrc, mix,
                                gamma, double_q, pl.n_chunks, (float*)ws, prof);
     } else {
         if (stored)
@@ -1462,6 +1515,7 @@ int launch_lossgrad_src(const marlhip_net_shape* s, const float* params, const f
             // N > 1: reduce -> all-reduce(SUM) of the flat gradient (the caller's RCCL hop) -> Adam, the clip norm taken from the
             // exchanged gradient inside the Adam launch (the clip must use the global post-reduce norm, dqn/model.py:170)
             P2pState* ps = p2p_is_builtin(fuse->exchange) ? static_cast<P2pState*>(fuse->exchange_ctx) : nullptr;
+            timing_begin(TIMER_EXCHANGE, st);
             if (ps != nullptr && ps->connected && n <= ps->max_floats) {
                 // the library's own exchange: folded into the reduce launch (each workgroup publishes its 64 values, waits for the same
                 // workgroup of the peers, sums in rank order) - one launch less per update than reduce -> exchange kernel
@@ -1475,6 +1529,7 @@ int launch_lossgrad_src(const marlhip_net_shape* s, const float* params, const f
                 const int rc = fuse->exchange(fuse->exchange_ctx, grad, (int64_t)n, (void*)st);
                 MARL_REQUIRE(rc == 0, "idqn_update_n_dist: the gradient exchange callback failed (%d)", rc);
             }
+            timing_end(TIMER_EXCHANGE, st);
             nsq = 0;  // the clip norm of the EXCHANGED gradient: taken inside the Adam launch (the same arithmetic for every exchange)
         } else {
             hipLaunchKernelGGL(dqn_reduce_sq_kernel, dim3(nsq), dim3(256), 0, st, (const float*)ws, P, pl.nwg, S::NPARAM, am, grad, loss,

@@ -67,7 +67,9 @@ static int update_n(const marlhip_idqn_learner* L, int32_t n_updates, int32_t le
         if (rc < 0) return rc;
         const int64_t n_all = (int64_t)(L->net.n_networks > 0 ? L->net.n_networks : L->net.n_agents) * np;
         if (exchange != nullptr) {
+            marl::timing_begin(marl::TIMER_EXCHANGE, (hipStream_t)stream);
             rc = exchange(exchange_ctx, L->grad, n_all, stream);
+            marl::timing_end(marl::TIMER_EXCHANGE, (hipStream_t)stream);
             MARL_REQUIRE(rc == 0, "idqn_update_n_dist: the gradient exchange callback failed (%d)", rc);
         }
         *updates += 1;
@@ -106,7 +108,9 @@ extern "C" int marlhip_qmix_update_n(const marlhip_qmix_learner* Q, int32_t n_up
                                                L->loss, stream);
         if (rc < 0) return rc;
         if (exchange != nullptr) {
+            marl::timing_begin(marl::TIMER_EXCHANGE, (hipStream_t)stream);
             rc = exchange(exchange_ctx, L->grad, n_all + nm, stream);
+            marl::timing_end(marl::TIMER_EXCHANGE, (hipStream_t)stream);
             MARL_REQUIRE(rc == 0, "qmix_update_n: the gradient exchange callback failed (%d)", rc);
         }
         *updates += 1;

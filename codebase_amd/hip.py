@@ -41,6 +41,13 @@ def _half_chip_stream(device):
     return _HALF_CHIP_STREAMS[key][0]
 
 
+def side_stream_description(device=None):
+    """what the critics' stream owns, for bench lines (the mask's meaning is device-specific: include/marlhip.h)"""
+    cus = torch.cuda.get_device_properties(device if device is not None else torch.cuda.current_device()).multi_processor_count
+    return {"api": "hipExtStreamCreateWithCUMask", "percent": 50, "pattern": _SIDE_PATTERN, "compute_units": cus, "mask_bits_set": (cus * 50 + 99) // 100,
+            "mask": ("the lowest-numbered mask bits" if _SIDE_PATTERN == 0 else "every other mask bit") + " (MARLHIP_SIDE_PATTERN; bit -> physical unit is the runtime's order)"}
+
+
 def _destroy_half_chip_streams():
     for key, (stream, h) in list(_HALF_CHIP_STREAMS.items()):
         try:
@@ -722,10 +729,11 @@ class AcUpdater:
         self.grad_clip = float(grad_clip) if grad_clip else 0.0
         self.step = 0
         self._ws = {}
-        self._kept = None  # (T, B, batch obs pointer) of the rollout whose actor forward pass sits in the workspace (ac_collect(keep_for=self))
+        self._kept = None  # (T, B, batch obs pointer, rollout generation) of the rollout whose actor forward pass sits in the workspace (ac_collect(keep_for=self))
         # the critics' half of an update on a stream of its own (a2c_loss_grad(defer_critic=True)): the stream, the batch tensors its
         # backward pass still reads, and the event everything that touches the critic blocks next waits for
         self._critic_stream = None
+        self._no_defer = False  # set when the device refuses a compute-unit-masked stream (_side_stream)
         self._critic_pending = None
         self._critic_event = None
         self._inflight = None
@@ -744,7 +752,7 @@ class AcUpdater:
         half idle (one workgroup per block of 16 envs: at most CUs / 2 blocks) and the critics' backward pass at half speed is not longer
         than the rollout (measured on the warehouse, 2048 envs x 500 steps, 128-128: independent critics 3.7 ms against a 7.3 ms rollout,
         52.2 -> 59.8 M env-steps/s; the 284-input centralised critics 7 ms, 38.1 -> 31.1 M: a critic row may cost 1.5 x an actor row)."""
-        if self.recurrent or self.grad_clip or _NO_OVERLAP:
+        if self.recurrent or self.grad_clip or _NO_OVERLAP or self._no_defer:
             return False
         if n_envs is None:
             return True
@@ -761,9 +769,24 @@ class AcUpdater:
         return not S.wide and (int(n_envs) + 15) // 16 <= cus // 2 and row(dc, 1) <= 1.5 * row(S.obs_dim, S.n_actions)
 
     def _side_stream(self):
-        if self._critic_stream is None:
-            self._critic_stream = _half_chip_stream(self.block.device)
+        """the stream that owns half of the compute units, or None when the runtime refuses one (a virtualised / partitioned device, an
+        older runtime: hipExtStreamCreateWithCUMask fails) - remembered, warned about once, and the update then stays on the caller's
+        stream (the same launches, the same bits)"""
+        if self._critic_stream is None and not self._no_defer:
+            try:
+                self._critic_stream = _half_chip_stream(self.block.device)
+            except Exception as e:  # noqa: BLE001 - MarlHipError from check(), or whatever torch raises wrapping the handle
+                import logging
+
+                logging.getLogger(__name__).warning("marlhip: no compute-unit-masked stream on this device (%s); the critics' half of an A2C "
+                                                    "update stays on the caller's stream", e)
+                self._no_defer = True
         return self._critic_stream
+
+    def probe_defer(self):
+        """True when the critics' half of an update could run on a stream of its own here (hard conditions of can_defer + the stream
+        exists).  Data-parallel jobs vote over this at set-up (A2CNetwork.attach_grad_sync): every rank defers or none does."""
+        return self.can_defer() and self._side_stream() is not None
 
     def sync_critic(self):
         """order the current stream behind the critics' deferred work (no-op when none is in flight) and release the batch it read"""
@@ -830,9 +853,9 @@ class AcUpdater:
         self.sync_critic()
         bs, keep, T, N = self._batch(batch)
         ws, s = self._workspace(T, N), self.spec.c()
-        defer = bool(defer_critic) and self.can_defer(N, force=defer_critic == "force")
+        defer = bool(defer_critic) and self.can_defer(N, force=defer_critic == "force") and self._side_stream() is not None
         if defer:
-            self.cfg.side_stream = self._side_stream().cuda_stream
+            self.cfg.side_stream = self._critic_stream.cuda_stream
             self.cfg.defer_critic_backward = 1
         try:
             with self._kept_scope(kept, bs, keep, T, N):
@@ -850,7 +873,8 @@ class AcUpdater:
     def _kept_scope(self, kept, bs, keep, T, N):
         """marlhip_ac_config.actor_forward_kept for ONE library call: set when the batch is the kept rollout's and the parameters are still
         the ones it was sampled with; `last_step_used_kept_forward` says what the call did"""
-        use = bool(kept) and self._kept is not None and self._kept == (T, N, keep[0].data_ptr()) and not bs.action_mask
+        use = (bool(kept) and self._kept is not None and self._kept == (T, N, keep[0].data_ptr(), _ROLLOUT_GEN.get(keep[0].data_ptr()))
+               and not bs.action_mask)
         up = self
 
         class _Scope:
@@ -1022,6 +1046,10 @@ class FusedQmixLearner:
         return upd.value, last.value
 
 
+_ROLLOUT_GEN = {}  # batch observation tensor (device pointer) -> serial number of the last rollout written into it (ac_collect)
+_ROLLOUT_COUNTER = __import__("itertools").count(1)
+
+
 def ac_collect(cfg, spec: NetSpec, actor_params, round_idx, max_len, use_proper_termination, b_obs, b_act, b_rew,
                b_done, b_filled, fin_return, fin_length, t_max, keep_for=None):
     """Fused actor-critic rollout collector (marlbase/ac/train.py:24-119): one launch = one collection call.
@@ -1030,6 +1058,12 @@ def ac_collect(cfg, spec: NetSpec, actor_params, round_idx, max_len, use_proper_
     reads them instead of running the pass again (AcUpdater.can_keep says for which shapes).  Returns True when the pass was kept."""
     _require_gpu()
     s = spec.c()
+    # every rollout written into these batch tensors gets a new generation number: a kept record only matches the LAST rollout that wrote
+    # them, whoever collected it (another updater, keep_for=None, another actor block - ADVICE r5)
+    gen = _ROLLOUT_GEN[b_obs.data_ptr()] = next(_ROLLOUT_COUNTER)
+    if len(_ROLLOUT_GEN) > 4096:  # (fresh batch tensors per rollout reuse the allocator's blocks; this only bounds a pathological caller)
+        _ROLLOUT_GEN.clear()
+        _ROLLOUT_GEN[b_obs.data_ptr()] = gen
     args = (ctypes.byref(cfg), ctypes.byref(s), _ptr(actor_params), int(round_idx) & 0xFFFFFFFF, int(max_len),
             int(bool(use_proper_termination)), _ptr(b_obs), _ptr(b_act), _ptr(b_rew), _ptr(b_done),
             _ptr(b_filled), _ptr(fin_return), _ptr(fin_length), _ptr(t_max), *_fwd_ws(spec, actor_params.device))
@@ -1038,8 +1072,10 @@ def ac_collect(cfg, spec: NetSpec, actor_params, round_idx, max_len, use_proper_
         fn = lib.marlhip_rware_ac_collect_keep if is_rware(cfg) else lib.marlhip_ac_collect_keep
         keep_for._kept = None
         check(fn(*args, keep_for.centralised, _ptr(ws), ws.numel(), _stream()), "ac_collect_keep")
-        keep_for._kept = (int(max_len), int(cfg.n_envs), b_obs.data_ptr())
+        keep_for._kept = (int(max_len), int(cfg.n_envs), b_obs.data_ptr(), gen)
         return True
+    if keep_for is not None:
+        keep_for._kept = None  # this rollout leaves no record: one of an earlier rollout into the same batch tensors must not match it
     fn = lib.marlhip_rware_ac_collect if is_rware(cfg) else lib.marlhip_ac_collect
     check(fn(*args, _stream()), "ac_collect")
     return False

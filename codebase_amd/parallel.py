@@ -147,18 +147,32 @@ class P2PExchange:
         # the set-up seconds, not the training run's diagnostic bound (minutes) per exchange
         keep = os.environ.get("MARLHIP_P2P_TIMEOUT_MS")
         os.environ["MARLHIP_P2P_TIMEOUT_MS"] = os.environ.get("MARLHIP_P2P_SELFTEST_TIMEOUT_MS", "5000")
+        # (the try sits INSIDE the loop body: a rank that fails locally - out of memory at the real gradient size, a device fault - still
+        # issues the same six all_reduces as its peers, so the collective sequences match and the vote below is reached - ADVICE r5)
         try:
             for k in range(6):
-                x = torch.randn(n, generator=g).cuda()
-                ref = x.clone()
+                ref = None
+                try:
+                    x = torch.randn(n, generator=g).cuda()
+                    ref = x.clone()
+                except Exception as e:  # noqa: BLE001
+                    why, good = str(e), False
+                if ref is None:
+                    try:
+                        ref = torch.zeros(n, device="cuda")
+                    except Exception:  # noqa: BLE001 - still take part in the collective, on the host if the device refuses
+                        ref = torch.zeros(n)
                 dist.all_reduce(ref)
-                fn = lib.marlhip_p2p_allreduce_wave64 if k & 1 else lib.marlhip_p2p_allreduce
-                rc = fn(ex.state, x.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
-                torch.cuda.synchronize()
-                # (rank-ordered float sums: identical on every rank, and equal to the collective's up to its own summation order)
-                good = good and rc == 0 and ex.status() == 0 and bool(torch.allclose(x, ref, rtol=1e-5, atol=1e-5))
-        except Exception as e:  # noqa: BLE001 - "not available", never a broken run
-            why, good = str(e), False
+                if not good:
+                    continue
+                try:
+                    fn = lib.marlhip_p2p_allreduce_wave64 if k & 1 else lib.marlhip_p2p_allreduce
+                    rc = fn(ex.state, x.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
+                    torch.cuda.synchronize()
+                    # (rank-ordered float sums: identical on every rank, and equal to the collective's up to its own summation order)
+                    good = good and rc == 0 and ex.status() == 0 and bool(torch.allclose(x, ref, rtol=1e-5, atol=1e-5))
+                except Exception as e:  # noqa: BLE001 - "not available", never a broken run
+                    why, good = str(e), False
         finally:
             if keep is None:
                 os.environ.pop("MARLHIP_P2P_TIMEOUT_MS", None)
@@ -188,35 +202,57 @@ def _shares_a_device(dist):
 class GradSync:
     """all-reduce(SUM) of the flat gradient; `scale` is what clip+Adam must multiply by (1/world).
     max_floats > 0 on GPU ranks: the in-library peer-to-peer exchange (P2PExchange) when it can be set up and passes its self-test
-    (MARLHIP_P2P=0 keeps torch.distributed's collective: backend nccl == RCCL, gloo in the CPU tests)."""
+    (MARLHIP_P2P=0 keeps torch.distributed's collective: backend nccl == RCCL, gloo in the CPU tests).
+    side_floats > 0: a SECOND, independent exchange lane (`.side`, itself a GradSync) for a slice of the gradient that is reduced on
+    another stream while this one is in use - the critics' slice of an actor-critic update whose backward pass runs next to the following
+    rollout (A2CNetwork.update_async(overlap=True)).  It owns its own IPC buffers / flags and its own process group (communicator), so
+    the two lanes never order against each other; every rank must construct it (a collective set-up like this one's)."""
 
-    def __init__(self, dist, max_floats=0):
+    def __init__(self, dist, max_floats=0, side_floats=0, _group=None):
         self.dist = dist
+        self.group = _group
         self.world = dist.get_world_size() if dist is not None else 1
         self.scale = 1.0 / self.world
         self.p2p = None
-        if dist is not None and max_floats > 0 and torch.cuda.is_available() and os.environ.get("MARLHIP_P2P", "1") != "0":
-            if _shares_a_device(dist) and os.environ.get("MARLHIP_P2P_SHARED_DEVICE", "0") != "1":
+        self.fallback_reason = None  # why the collective carries the gradients although the in-library exchange was wanted
+        if dist is not None and max_floats > 0 and torch.cuda.is_available():
+            if os.environ.get("MARLHIP_P2P", "1") == "0":
+                self.fallback_reason = "MARLHIP_P2P=0"
+            elif _shares_a_device(dist) and os.environ.get("MARLHIP_P2P_SHARED_DEVICE", "0") != "1":
                 import logging
 
                 logging.getLogger(__name__).warning("marlhip p2p exchange: two ranks share a GPU; keeping torch.distributed's all-reduce "
                                                     "(MARLHIP_P2P_SHARED_DEVICE=1 overrides)")
+                self.fallback_reason = "two ranks share a GPU"
             else:
                 self.p2p = P2PExchange.try_create(dist, max_floats)
+                if self.p2p is None:
+                    self.fallback_reason = "set-up or self-test failed on some rank (see the log)"
         # what the library's n-updates loop takes instead of a Python callback (hip.FusedLearner.run)
         self.c_fn = self.p2p.c_fn if self.p2p is not None else None
         self.c_ctx = self.p2p.c_ctx if self.p2p is not None else None
+        self.side = None
+        if dist is not None and side_floats > 0:
+            self.side = GradSync(dist, max_floats=side_floats, _group=dist.new_group())
+
+    def describe(self):
+        """what carried the gradients, for logs and bench lines"""
+        return {"exchange": "p2p (in-library)" if self.p2p is not None else "collective (torch.distributed.all_reduce)",
+                "self_test": "passed" if self.p2p is not None else None, "fallback_reason": self.fallback_reason,
+                "side_lane": self.side.describe() if self.side is not None else None}
 
     def __call__(self, grad):
         if self.p2p is not None and grad.is_cuda and grad.dtype == torch.float32 and grad.numel() <= self.p2p.max_floats:
             self.p2p(grad)
         elif self.dist is not None:
-            self.dist.all_reduce(grad)
+            self.dist.all_reduce(grad, group=self.group)
         return grad
 
     def check(self):
         """raises ON EVERY RANK when an in-library exchange ran into its peer timeout on any of them (one small collective + a 4-byte
         device read: for log / evaluation / save points and the end of a run, not for the update loop)"""
+        if self.side is not None:
+            self.side.check()
         if self.p2p is None:
             return
         bad = self.p2p.status() != 0
@@ -229,6 +265,9 @@ class GradSync:
 
     def close(self):
         """end of a run: verify, then free the exchange behind a job-wide barrier (no peer may still be reading this rank's buffer)"""
+        if self.side is not None:
+            self.side.close()
+            self.side = None
         if self.p2p is None:
             return
         try:

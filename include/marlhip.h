@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MARLHIP_VERSION 215
+#define MARLHIP_VERSION 216
 
 int marlhip_version(void);
 const char* marlhip_last_error(void);
@@ -566,7 +566,11 @@ int marlhip_a2c_loss_grad(const marlhip_net_shape* s, const float* actor, const 
  * TO another kernel rather than in front of it: a kernel whose grid fills the chip holds every compute unit until it retires, so the
  * critics' backward pass of marlhip_ac_config.defer_critic_backward on an ordinary stream delays the following rollout by its whole length;
  * on a stream that owns `percent` of the units it leaves the rest to the rollout (same grid, same summation order, same bits).
- * pattern 0: the lowest-numbered units of the mask, 1: every other unit.  marlhip_stream_destroy releases the stream. */
+ * pattern 0: the lowest-numbered bits of the runtime's compute-unit mask, 1: every other bit.  WHICH physical units a mask bit names is
+ * device-specific: on multi-XCD parts (MI355X: 8 XCDs x 32 units) the runtime's bit order interleaves shader engines and XCDs, so "the
+ * lowest half" may be whole XCDs or an uneven share per shader engine - that moves the measured overlap gain, never a result.  Callers
+ * that report timings under such a stream should record (percent, pattern, unit count) next to them (bench.py: `side_stream`).
+ * marlhip_stream_destroy releases the stream. */
 int marlhip_stream_create_cu_share(int32_t percent /* 1..100 */, int32_t pattern, void** stream_out);
 int marlhip_stream_destroy(void* stream);
 int marlhip_ac_collect_keep(const marlhip_lbf_config* cfg, const marlhip_net_shape* s, const float* actor_params, uint32_t round,
@@ -623,6 +627,22 @@ typedef struct marlhip_idqn_learner {
 int marlhip_idqn_update_n(const marlhip_idqn_learner* L, int32_t n_updates, int32_t length, uint64_t seed,
                           uint32_t counter0, int64_t* adam_step, int64_t* updates, int64_t* last_target_update,
                           void* stream);
+
+/* Filled-aware learner updates (C-ABI 216).  The loss is a filled-weighted sum (dqn/model.py:160-163): the rows behind an episode's last
+ * transition contribute exactly zero to it and to every gradient entry.  For the single-pass hidden-64 IDQN learner marlhip_idqn_update_n
+ * therefore plans the walk before its update loop (one launch for all n updates; csrc/update_plan.h): the batch's episode draws - the
+ * same Philox stream as marlhip_replay_sample - are ordered by stored length, longest first (a stable sort: a batch of full-length
+ * episodes keeps its draw order and the update its bits), a 16-episode tile walks only the steps its longest episode has, in chunks
+ * sized so that the launch's waves get the same number of steps.  Any permutation of the batch is the same update up to summation
+ * order (deterministic).  marlhip_idqn_learner.idx still receives the LAST update's draws in draw order.  Limits: 256 <= batch <= 8192,
+ * max_len <= 255 (otherwise, and with MARLHIP_NO_PLAN=1 in the environment, every tile walks all max_len steps as before).
+ * marlhip_update_plan exposes the plans for inspection: dims_out[8] = {planned, int32 per update, header ints, waves per agent, table
+ * rows, chunks per tile of the static plan, tiles, max_len}; plan_out (may be NULL: dims only) receives n_updates plans of dims_out[1]
+ * int32 each - [slots, chunk length, longest episode, stored transitions][batch episode indices, longest first][slots x waves tasks:
+ * tile << 16 | t0 << 8 | t1; 0 = none] - and idx_out (may be NULL) the last update's draws in draw order. */
+int marlhip_update_plan(const marlhip_replay_shape* rs, const marlhip_replay_buffers* rb, int32_t n_agents, int32_t batch, int32_t length,
+                        uint64_t seed, uint32_t counter0, int32_t n_updates, int32_t* plan_out, int64_t plan_out_ints, int32_t* idx_out,
+                        int32_t* dims_out, void* stream);
 
 /* Data-parallel form of marlhip_idqn_update_n (C-ABI 208; SURVEY.md 8e - the reference is one process and has no counterpart): one
  * process per GPU, envs and replay sharded, weights replicated, and per update ONE exchange of the flat gradient.  After the
@@ -783,7 +803,8 @@ int marlhip_qmix_update_n(const marlhip_qmix_learner* L, int32_t n_updates, int3
 /* ------------------------------------------------------------------------------------------
  * Measurement aid (bench.py roofline leg): when enabled, the named kernels are bracketed by HIP
  * events on the stream they are launched on.  ids: 0 loss/grad kernel, 1 fused collector,
- * 2 replay sample gather, 3 env step, 4 QMIX mixer stage.  marlhip_timing_read waits for the recorded events,
+ * 2 replay sample gather, 3 env step, 4 QMIX mixer stage, 5 the gradient exchange of the data-parallel update loops (the reduce launch
+ * with the in-library exchange inside, or the exchange callback).  marlhip_timing_read waits for the recorded events,
  * returns launches and summed milliseconds, and clears the slot.
  * ---------------------------------------------------------------------------------------- */
 int marlhip_timing_enable(int32_t on);

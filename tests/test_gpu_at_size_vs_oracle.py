@@ -31,6 +31,7 @@ def assert_entries_at_size(got, ref, lr, n_updates, gmin, what, atol=3e-6, noise
     diff = np.abs(np.asarray(got, np.float64) - np.asarray(ref, np.float64))
     allowed = atol + 2.0 * lr * n_updates * np.minimum(1.0, noise_floor / np.maximum(gmin, 1e-30))
     worst = int(np.argmax(diff - allowed))
+    print(f"[at-size] {what}: largest entry deviation {diff.max():.3e} (lr {lr:g} x {n_updates} updates), {(diff > atol).mean():.2%} of the entries beyond atol {atol:g}")
     assert (diff <= allowed).all(), (what, float(diff.flat[worst]), float(allowed.flat[worst]), float(gmin.flat[worst]))
     assert (diff > atol).mean() <= bulk, (what, int((diff > atol).sum()), diff.size)
 
@@ -60,6 +61,10 @@ def replay_lbf_through_oracle(name, host, fin_length, fin_return, seed, rnd, T, 
 
 def assert_grad_at_size(got, ref, what, rel=3e-4):
     got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    dev = np.abs(got - ref) / np.abs(ref).max()
+    top = np.argsort(dev.reshape(-1))[-4:][::-1]
+    print(f"[at-size] {what}: largest entry deviation {dev.max():.3e} of the largest entry (bound {rel:.0e}); {(dev > rel).sum()} of {dev.size} entries beyond it; "
+          f"largest at {[tuple(int(x) for x in np.unravel_index(i, dev.shape)) for i in top]} = {[float(f'{dev.reshape(-1)[i]:.2e}') for i in top]}")
     assert np.abs(got - ref).max() <= rel * np.abs(ref).max(), (what, float(np.abs(got - ref).max()), float(np.abs(ref).max()))
 
 
@@ -138,6 +143,7 @@ def test_config5_qmix_15x15_8p5f_H128_B8192_through_the_trainer_vs_oracle_port()
         ga, gm = np.abs(port.last_grad.numpy()), np.abs(port.last_mixer_grad.numpy())
         gmin, gmin_m = np.minimum(gmin, ga / ga.max()), np.minimum(gmin_m, gm / gm.max())
     got = trainer.last_loss.cpu().numpy()
+    print(f"[at-size] config 5 QMIX loss: observed relative deviation from the float64 port {abs(got[0] - m['loss']) / abs(m['loss']):.3e} (bound 3e-5; north_star 1e-5)")
     assert abs(got[0] - m["loss"]) <= 3e-5 * abs(m["loss"]), (got, m)
     assert got[1] == float(host["filled"][torch.as_tensor(idx)].sum())
     assert (model.updates, model.last_target_update) == (port.updates, port.last_target_update) == (3, 2)
@@ -185,6 +191,31 @@ def _collect_ac(h, name, N, T, H, seed, rnd, central=False, scale=1.0, keep=True
     return cfg, model, b, fin_len, (P, D, A)
 
 
+def _port_a2c_loss_backward(lr, host, D, H, A, env_chunks):
+    """one A2C loss + backward of oracle/ac_update_port.Learner `lr` in float64 on the host batch, accumulated over env chunks (the losses
+    are filled-weighted means over (t, env): additive over env chunks); leaves the gradients in lr's tensors, returns
+    ([loss, actor_loss, value_loss, entropy], sum(filled), actor gradient [P][n], critic gradient [P][n])"""
+    from oracle import ac_update_port as ap
+
+    P = lr.P
+    total = host["filled"].double().sum()
+    acc = dict(loss=0.0, actor_loss=0.0, value_loss=0.0, entropy=0.0)
+    lr.opt.zero_grad()
+    for cols in torch.arange(host["filled"].shape[1]).chunk(env_chunks):
+        sub = {k: v[:, cols] for k, v in host.items()}
+        sub = {k: (v.double() if v.is_floating_point() else v) for k, v in sub.items()}
+        w = sub["filled"].sum() / total
+        loss, m = ap.a2c_loss(lr.actor(), lr.critic(), lr.target, sub, D, H, A, n_steps=5, gamma=0.99, entropy_coef=0.001, value_loss_coef=0.5)
+        (loss * w).backward()
+        for k in acc:
+            acc[k] += float(m[k].detach()) * float(w)
+    ref = np.array([acc["loss"], acc["actor_loss"], acc["value_loss"], acc["entropy"]])
+    per_a, per_c = len(lr.at) // P, len(lr.ct) // P
+    ra = torch.stack([torch.cat([t.grad.reshape(-1) for t in lr.at[p * per_a:(p + 1) * per_a]]) for p in range(P)]).numpy()
+    rc = torch.stack([torch.cat([t.grad.reshape(-1) for t in lr.ct[p * per_c:(p + 1) * per_c]]) for p in range(P)]).numpy()
+    return ref, float(total), ra, rc
+
+
 def _a2c_step_vs_port(model, b, P, D, H, A, central, env_chunks, loss_rtol=5e-5):
     """one A2CNetwork.update on the device against oracle/ac_update_port in float64: loss parts, gradients, parameters after the step"""
     from codebase_amd.ac.train import Batch
@@ -204,23 +235,10 @@ def _a2c_step_vs_port(model, b, P, D, H, A, central, env_chunks, loss_rtol=5e-5)
     lr = ap.Learner(a0, c0, D, H, A, lr=3e-4, gamma=0.99, n_steps=5, entropy_coef=0.001, value_loss_coef=0.5, grad_clip=False,
                     target_update_interval_or_tau=200)
     lr.target = t0
-    total = host["filled"].double().sum()
-    acc = dict(loss=0.0, actor_loss=0.0, value_loss=0.0, entropy=0.0)
-    lr.opt.zero_grad()
-    for cols in torch.arange(host["filled"].shape[1]).chunk(env_chunks):  # the losses are filled-weighted means over (t, env): additive over env chunks
-        sub = {k: v[:, cols] for k, v in host.items()}
-        sub = {k: (v.double() if v.is_floating_point() else v) for k, v in sub.items()}
-        w = sub["filled"].sum() / total
-        loss, m = ap.a2c_loss(lr.actor(), lr.critic(), lr.target, sub, D, H, A, n_steps=5, gamma=0.99, entropy_coef=0.001, value_loss_coef=0.5)
-        (loss * w).backward()
-        for k in acc:
-            acc[k] += float(m[k].detach()) * float(w)
-    ref = np.array([acc["loss"], acc["actor_loss"], acc["value_loss"], acc["entropy"]])
+    ref, total, ra, rc = _port_a2c_loss_backward(lr, host, D, H, A, env_chunks)
     np.testing.assert_allclose(got[:4], ref, rtol=loss_rtol, atol=5e-6)
-    assert got[4] == float(total)
-    per_a, per_c = len(lr.at) // P, len(lr.ct) // P
-    ra = torch.stack([torch.cat([t.grad.reshape(-1) for t in lr.at[p * per_a:(p + 1) * per_a]]) for p in range(P)]).numpy()
-    rc = torch.stack([torch.cat([t.grad.reshape(-1) for t in lr.ct[p * per_c:(p + 1) * per_c]]) for p in range(P)]).numpy()
+    print(f"[at-size] A2C loss parts, observed relative deviation from the float64 port: {np.abs(got[:4] - ref) / np.maximum(np.abs(ref), 1e-30)}")
+    assert got[4] == total
     assert_grad_at_size(ga, ra, "actor gradient")
     assert_grad_at_size(gc, rc, "critic gradient")
     lr.opt.step()
@@ -269,3 +287,114 @@ def test_maa2c_15x15_8p5f_4096_envs_H128_wide_critics_vs_oracle():
     assert (P, D, A) == (8, 39, 6)
     assert float(b["filled"].sum().item()) == float(fin_len.sum().item()) > 20 * N
     _a2c_step_vs_port(model, b, P, D, H, A, central=True, env_chunks=8)
+
+
+def test_config4_two_rounds_through_update_async_overlap_exactly_as_bench_drives_them():
+    """the config-4 bench row does not call a2c_loss_grad + apply - it runs `A2CNetwork.update_async(overlap=True)` on a
+    stream of its own with two alternating batch sets (bench.py bench_ac._one_round): the rollout leaves the actors' forward pass, the
+    actors' backward + step run on the caller's stream, the critics' backward pass, step and hard target copy on the half-chip stream
+    beside the NEXT rollout.  Two such rounds at rware-tiny-4ag 2048 x 500, 128-128; EACH round's update is then compared with
+    oracle/ac_update_port in float64 started from the state the device itself had before that round (actor and critic blocks, target
+    critics, both Adam moments, the step count - snapshotted on the streams that own them, so the overlap is left as the bench has it):
+    loss parts, actor and critic gradients, blocks / targets / moments after the step.  (One port trajectory over both rounds is not a
+    sharper statement: Adam's first step is +-lr whatever a gradient entry's size, so the entries whose gradient is at the f32 noise floor
+    differ by 2 lr after round 1 in any two correct implementations, and round 2's near-deterministic policy turns that into 2e-4 of its
+    entropy - measured on the first draft of this test.)"""
+    from codebase_amd import hip as h
+    from codebase_amd.ac.model import A2CNetwork
+    from codebase_amd.ac.train import Batch
+    from codebase_amd.utils.envs import _space_pair
+    from oracle import ac_update_port as ap
+    from oracle import dqn_port as dp
+
+    import os
+
+    name, N, T, H, seed, rounds = "rware:rware-tiny-4ag-v2", 2048, 500, 128, int(os.environ.get("MARLHIP_TEST_SEED", 27)), 2
+    cfg = h.env_config(name, N, T, seed=seed)
+    P, (D, A) = cfg.n_agents, h.env_dims(cfg)
+    torch.manual_seed(seed)
+    obs_space, act_space = _space_pair(cfg)
+    hyper = dict(optimizer="Adam", lr=3e-4, gamma=0.99, grad_clip=False, n_steps=5, entropy_coef=0.001, value_loss_coef=0.5,
+                 standardise_returns=False, target_update_interval_or_tau=200)  # ia2c.yaml, as bench_ac builds it
+    net = dict(layers=[H, H], parameter_sharing=False, use_orthogonal_init=True, use_rnn=False)
+    model = A2CNetwork(obs_space, act_space, hyper, net, dict(net, centralised=False), "cuda")
+    model.actor_params.copy_(_perturbed(P, D, H, A, seed + 1) * 3.0)
+    model.critic_params.copy_(_perturbed(P, D, H, 1, seed + 2))
+    model.target_critic_params.copy_(_perturbed(P, D, H, 1, seed + 3))
+    up = model.updater
+    na = up.actor.numel()
+    dev = model.device
+    bufs = [dict(obs=torch.empty(T + 1, N, P * D, device=dev), act=torch.empty(T, N, P, dtype=torch.int64, device=dev),
+                 rew=torch.empty(T, N, P, device=dev), done=torch.empty(T + 1, N, dtype=torch.uint8, device=dev),
+                 donef=torch.empty(T + 1, N, device=dev), fill=torch.empty(T, N, device=dev)) for _ in range(2)]
+    fin_ret, fin_len = torch.zeros(P, N, device=dev), torch.zeros(N, dtype=torch.int32, device=dev)
+    t_max = torch.zeros(1, dtype=torch.int32, device=dev)
+
+    def snap_actor():  # (on the caller's stream: behind the actors' step)
+        return dict(a=up.actor.clone(), ma=up.exp_avg[:na].clone(), va=up.exp_avg_sq[:na].clone(), ga=up.actor_grad.clone())
+
+    def snap_critic():  # (on whatever stream owns the critics' half right now)
+        return dict(c=up.critic.clone(), t=up.target_critic.clone(), mc=up.exp_avg[na:].clone(), vc=up.exp_avg_sq[na:].clone(), gc=up.critic_grad.clone())
+
+    states = [dict(snap_actor(), **snap_critic())]
+    torch.cuda.synchronize()
+    own, ms, kept, deferred, step = torch.cuda.Stream(device=dev), [], [], [], 0
+    with torch.cuda.stream(own):  # bench_ac.one_round
+        for r in range(rounds):
+            b = bufs[r & 1]
+            kept.append(h.ac_collect(cfg, model.spec, model.actor_params, r, T, False, b["obs"], b["act"], b["rew"], b["done"], b["fill"], fin_ret, fin_len,
+                                     t_max, keep_for=model.updater))
+            b["donef"].copy_(b["done"])
+            ms.append(model.update_async(Batch(b["obs"], b["act"], b["rew"], b["donef"], b["fill"], None), step, overlap=True).clone())
+            deferred.append(up._critic_event is not None)
+            st = snap_actor()
+            with torch.cuda.stream(up._critic_stream if up._critic_event is not None else own):  # behind the critics' step and target copy, beside the next rollout
+                st.update(snap_critic())
+            states.append(st)
+            step += T * N
+    torch.cuda.synchronize()
+    assert kept == [True] * rounds and deferred == [True] * rounds, (kept, deferred)  # the path the 62 M row runs, not its fallback
+    assert not torch.equal(states[0]["c"], states[1]["c"]) and not torch.equal(states[1]["c"], states[2]["c"])  # (the critics did step, both rounds)
+    assert torch.equal(states[1]["t"], states[1]["c"]) and torch.equal(states[2]["t"], states[2]["c"])          # hard copies at step 0 and 1,024,000
+
+    def blocks(flat, n_out):
+        return flat.reshape(P, -1).cpu().double()
+
+    step = 0
+    for r in range(rounds):
+        s0, s1 = states[r], states[r + 1]
+        a0, c0 = blocks(s0["a"], A), blocks(s0["c"], 1)
+        lr = ap.Learner(a0, c0, D, H, A, lr=3e-4, gamma=0.99, n_steps=5, entropy_coef=0.001, value_loss_coef=0.5, grad_clip=False,
+                        target_update_interval_or_tau=200)
+        lr.target = blocks(s0["t"], 1)
+        if r > 0:  # Adam's state as the device had it before this round
+            for tensors, m, v, n_out in ((lr.at, s0["ma"], s0["va"], A), (lr.ct, s0["mc"], s0["vc"], 1)):
+                per = len(tensors) // P
+                mb, vb = blocks(m, n_out), blocks(v, n_out)
+                for p in range(P):
+                    for tens, mm, vv in zip(tensors[p * per:(p + 1) * per], dp.split(mb[p], D, H, n_out), dp.split(vb[p], D, H, n_out)):
+                        lr.opt.state[tens] = dict(step=torch.tensor(float(r)), exp_avg=mm.clone(), exp_avg_sq=vv.clone())
+        b = bufs[r & 1]
+        host = dict(obss=b["obs"].cpu(), actions=b["act"].cpu(), rewards=b["rew"].cpu(), dones=b["done"].cpu().bool(), filled=b["fill"].cpu())
+        assert float(host["filled"].sum()) == N * T
+        ref, total, ra, rc = _port_a2c_loss_backward(lr, host, D, H, A, env_chunks=32)
+        got = ms[r].cpu().numpy().astype(np.float64)
+        print(f"[at-size] config 4 round {r}: loss parts deviate {np.abs(got[:4] - ref) / np.maximum(np.abs(ref), 1e-30)} (relative) from the float64 port")
+        np.testing.assert_allclose(got[:4], ref, rtol=5e-5, atol=5e-6)
+        assert got[4] == total
+        assert_grad_at_size(s1["ga"].cpu().numpy(), ra, f"round {r}: actor gradient")
+        assert_grad_at_size(s1["gc"].cpu().numpy(), rc, f"round {r}: critic gradient (deferred backward pass)")
+        lr.opt.step()
+        if step % 200 == 0:  # model.py:233-239
+            lr.target = lr.critic().detach().clone()
+        step += T * N
+        gma, gmc = np.abs(ra) / np.abs(ra).max(), np.abs(rc) / np.abs(rc).max()
+        for got_t, ref_t, gm, what in ((s1["a"], lr.actor().detach(), gma, "actor"), (s1["c"], lr.critic().detach(), gmc, "critic"),
+                                       (s1["t"], lr.target, gmc, "target critic")):
+            assert_entries_at_size(blocks(got_t, 0).numpy(), ref_t.numpy(), 3e-4, 1, gm, f"round {r}: {what} after the overlapped update")
+        for key, ka, kc in (("exp_avg", "ma", "mc"), ("exp_avg_sq", "va", "vc")):
+            ref_a = torch.stack([torch.cat([lr.opt.state[t][key].reshape(-1) for t in lr.at[p * (len(lr.at) // P):(p + 1) * (len(lr.at) // P)]]) for p in range(P)]).numpy()
+            ref_c = torch.stack([torch.cat([lr.opt.state[t][key].reshape(-1) for t in lr.ct[p * (len(lr.ct) // P):(p + 1) * (len(lr.ct) // P)]]) for p in range(P)]).numpy()
+            rel = 3e-4 if key == "exp_avg" else 6e-4  # (a squared gradient doubles the relative deviation)
+            assert_grad_at_size(blocks(s1[ka], 0).numpy(), ref_a, f"round {r}: actor {key}", rel=rel)
+            assert_grad_at_size(blocks(s1[kc], 0).numpy(), ref_c, f"round {r}: critic {key}", rel=rel)

@@ -100,6 +100,51 @@ def main():
     assert abs(ac.updater.ret_stats.count - (1e-4 + 3 * world * T * N)) < 1e-6
     dist.barrier()
     DIGEST.update(ac.block.cpu().numpy().tobytes())
+    sync.close()
+    # ia2c.yaml's own setting (no joint clip): the critics' half of every update on their own stream NEXT TO a gradient exchange - the
+    # actors' slice reduced and stepped on the caller's stream, the critics' slice through the exchange's second lane on theirs
+    # (A2CNetwork.update_async(overlap=True) after attach_grad_sync) - against the same three rounds with everything on one stream and
+    # ONE exchange of the joint block: the same bits.  BASELINE config 4's kernels (rware-tiny-4ag, 128-128).
+    Nw, Tw = 256, 60
+    cfg3 = h.env_config("rware:rware-tiny-4ag-v2", Nw, Tw, seed=rank_env_seed(11, rank))
+    o3, a3 = _space_pair(cfg3)
+    Pw, (Dw, Aw) = cfg3.n_agents, h.env_dims(cfg3)
+    net3 = dict(layers=[128, 128], parameter_sharing=False, use_orthogonal_init=True, use_rnn=False)
+    hyp3 = dict(optimizer="Adam", lr=3e-4, gamma=0.99, grad_clip=False, n_steps=5, entropy_coef=0.001, value_loss_coef=0.5,
+                standardise_returns=False, target_update_interval_or_tau=200)
+    ends = {}
+    for overlap in (True, False):
+        torch.manual_seed(2)
+        m3 = A2CNetwork(o3, a3, hyp3, net3, dict(net3, centralised=False), "cuda")
+        s3 = GradSync(dist, max_floats=m3.updater.grad.numel(), side_floats=m3.updater.critic_grad.numel() if overlap else 0)
+        sets = [dict(o=torch.empty(Tw + 1, Nw, Pw * Dw, device="cuda"), a=torch.empty(Tw, Nw, Pw, dtype=torch.int64, device="cuda"),
+                     r=torch.empty(Tw, Nw, Pw, device="cuda"), d=torch.empty(Tw + 1, Nw, dtype=torch.uint8, device="cuda"),
+                     df=torch.empty(Tw + 1, Nw, device="cuda"), f=torch.empty(Tw, Nw, device="cuda")) for _ in range(2)]
+        fr3, fl3 = torch.zeros(Pw, Nw, device="cuda"), torch.zeros(Nw, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        deferred = []
+        with torch.cuda.stream(torch.cuda.Stream(device="cuda")):  # (nothing leaves a caller that is on the default stream)
+            assert m3.attach_grad_sync(s3) == overlap
+            for r in range(4):  # two alternating batch sets, as bench.py keeps them: round r + 2 rewrites the set round r's critics read
+                b = sets[r & 1]
+                h.ac_collect(cfg3, m3.spec, m3.actor_params, r, Tw, False, b["o"], b["a"], b["r"], b["d"], b["f"], fr3, fl3, tm, keep_for=m3.updater)
+                b["df"].copy_(b["d"])
+                m3.update_async(Batch(b["o"], b["a"], b["r"], b["df"], b["f"], None), r * Tw * Nw, grad_sync=s3, world=world, overlap=overlap)
+                deferred.append(m3.updater._critic_event is not None)
+        torch.cuda.synchronize()
+        assert deferred == [overlap] * 4, deferred
+        if overlap and os.environ.get("MARLHIP_P2P", "1") != "0":
+            assert s3.p2p is not None and s3.side.p2p is not None and s3.p2p.status() == 0 and s3.side.p2p.status() == 0, "a p2p lane is missing or timed out"
+        s3.check()
+        for what, t in (("block", m3.block), ("target critic", m3.target_critic_params), ("exp_avg", m3.updater.exp_avg), ("exp_avg_sq", m3.updater.exp_avg_sq)):
+            same_on_all_ranks(t, f"A2C (overlap={overlap}) {what}")
+        ends[overlap] = [t.clone() for t in (m3.block, m3.target_critic_params, m3.updater.exp_avg, m3.updater.exp_avg_sq)]
+        s3.close()
+    for x, y in zip(ends[True], ends[False]):
+        assert torch.equal(x, y), "the split exchange beside the deferred critics left other bits than the one-stream update"
+    assert float(ends[True][3][-64:].abs().max()) > 0
+    DIGEST.update(ends[True][0].cpu().numpy().tobytes())
+    dist.barrier()
     if rank == 0:
         print("TWO_RANK_OK", DIGEST.hexdigest())
     dist.destroy_process_group()
