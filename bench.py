@@ -314,7 +314,7 @@ def traffic_from_profile(key, variant=""):
     kernel's sources at the profiled head; when the sources in this tree hash differently the figure is NOT quoted: traffic null and
     the reason in `traffic_source`."""
     reason = "no committed PMC profile holds this workload"
-    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json"):  # the newest profile that holds this exact workload
+    for name in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json"):  # the newest profile that holds this exact workload
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
             ent = pmc["workloads"].get(key)
@@ -722,7 +722,9 @@ def secondary_modes(args):
                 "lr": c.get("lr"), "target_update_interval_or_tau": c.get("target_update_interval_or_tau"),
                 "mean_episode_length": c.get("mean_episode_length"), "mean_episode_return_last_round": c.get("mean_episode_return_last_round"),
                 "epsilon_timed_rounds": c.get("epsilon_timed_rounds"),
-                "roofline": {k: rf.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "frac_needed", "avg_launch_us")}}
+                "mean_filled_rows_per_sampled_episode": c.get("mean_filled_rows_per_sampled_episode"), "replay_clear_stale": c.get("replay_clear_stale"),
+                "roofline": dict({k: rf.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "frac_needed", "avg_launch_us", "traffic", "whole_round")},
+                                 traffic_source=(rf.get("traffic_source") or {}).get("file") or (rf.get("traffic_source") or {}).get("reason"))}
 
     for name, over, steps, warmup in (("hparams=tuned (lr 3e-3, Polyak 0.1: what the batched cadence learns fastest with), cadence=ratio", dict(hparams="tuned"), 10, 3),
                                       ("env-only", dict(cadence="env-only"), 100, 5),
@@ -734,7 +736,15 @@ def secondary_modes(args):
                                       # episode stays what it was
                                       ("trained policy (hparams=tuned, 1500 rounds of training first, epsilon 0.05): short episodes, cadence=ratio",
                                        dict(hparams="tuned", pretrain_rounds=1500, eps_fixed=0.05,
-                                            regime_note="after 1500 untimed training rounds (epsilon 1 -> 0.05), timed at epsilon 0.05"), 20, 2)):
+                                            regime_note="after 1500 untimed training rounds (epsilon 1 -> 0.05), timed at epsilon 0.05"), 20, 2),
+                                      # round 6: WHY the row above pays for 25 rows per sampled episode - the reference's
+                                      # ReplayBuffer never resets `filled` (dqn/train.py:65-89), so once the ring has wrapped a slot's rows behind a
+                                      # shorter episode's end are its previous occupant's, still filled = True, and the reference trains on them
+                                      # (`mean_filled_rows_per_sampled_episode` = 25.0 there).  With clear_stale (an opt-in DEVIATION: the collector zeroes
+                                      # the tail of a slot it reuses) the filled-aware plan (csrc/update_plan.h) walks only what an episode stored
+                                      ("trained policy as above, replay with clear_stale (OPT-IN deviation from the reference's ReplayBuffer: no stale filled tails), filled-aware update plans",
+                                       dict(hparams="tuned", pretrain_rounds=1500, eps_fixed=0.05, clear_stale=True,
+                                            regime_note="after 1500 untimed training rounds (epsilon 1 -> 0.05), timed at epsilon 0.05; replay slots cleared on reuse"), 20, 2)):
         a = copy.copy(args)
         for k, v in over.items():
             setattr(a, k, v)
@@ -892,8 +902,6 @@ def bench_dqn(args, rank, world, dist, steps, warmup):
         ach = flops / avg_s / 1e12
         key = f"{args.algo}:{args.env_name}:N{N}:H{H}:B{B}:T{T}:rnn{int(bool(args.rnn))}" + (":split16" if getattr(args, "split16", False) else "")
         traffic, tsrc = traffic_from_profile(key, "split16" if getattr(args, "split16", False) else ("H128" if H > 64 else ""))
-        if args.rnn or args.algo != "idqn":
-            traffic, tsrc = None, {"reason": "no committed PMC profile holds this workload"}
         kname = "dqn_lossgrad_h16_kernel (split-fp16 products, fp32 accumulate)" if getattr(args, "split16", False) else ("gru_seq_fwd2 + gru_td + gru_seq_bwd + gru_wgrad" if args.rnn else
                  ("dqn_lossgrad_kernel" if H <= 64 else "tp_fwd_kernel + tp_mix_kernel + tp_bwd_kernel")) + (" + qmix mixer stage" if args.algo == "qmix" else "")
         roofline = {"kernel": kname, "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -951,6 +959,13 @@ def bench_dqn(args, rank, world, dist, steps, warmup):
                             + (f"strong scaling: {N * world} envs and a global update batch of {B * world} episodes split over the GPUs)" if strong else
                                f"weak scaling: effective update batch {world} x {B} episodes)")) if world > 1 else "1 GPU",
             "hparams": args.hparams if args.algo == "idqn" and args.cadence == "ratio" else "reference",
+            #  idqn.yaml's lr 3e-4 / hard copy every 200 updates are tuned for the reference's one update per collected
+            # episode; at the batched cadence they barely move the return inside a bench run (`mean_episode_return_last_round` = random play).
+            # The `tuned` row of `modes` runs the same kernels at the same throughput and learns (0.84 after 1.2e8 env-steps:
+            # profiles/r03_learning_parity.md); cadence=reference is the row whose learning curve matches the reference's per env-step
+            "learns_at_these_hparams": (("yes (profiles/r03_learning_parity.md)" if args.hparams == "tuned" else
+                                         "barely at this cadence - see the `tuned` row of `modes` (same kernels, same throughput)")
+                                        if args.algo == "idqn" and args.cadence == "ratio" else None),
             "learner": "split16 (opt-in: f32 products from fp16 halves)" if getattr(args, "split16", False) else "f32",
             "mixer_first_layers": ("fp16 (opt-in)" if args.mixer_fp16 else "f32") if args.algo == "qmix" else None,
             "env_steps_timed": env_steps,

@@ -14,6 +14,88 @@
 
 namespace marl {
 
+// relu as ONE v_max_f32 per element (round 6).  fmaxf(v, 0) lowers to a canonicalising v_max(v, v) + v_max(v, 0): two VALU instructions per
+// element on top of the v_accvgpr_read that brings an accumulator of the builtin (AGPR-destination) MFMA form into a VGPR - 128 of the 514
+// VALU instructions of a tp_fwd step (static count, 15-wide rows) next to 320 MFMAs.  The operand reaches the asm through that compiler-
+// inserted, hazard-aware read, so no manual wait states are needed here (unlike relu4_settled, whose inputs are VGPR-form MFMA results).
+// Equal to fmaxf(v, 0) for every non-NaN input.
+__device__ __forceinline__ f4 relu4_one(f4 v) {
+    f4 o;
+    asm("v_max_f32 %0, 0, %1" : "=v"(o.x) : "v"(v.x));
+    asm("v_max_f32 %0, 0, %1" : "=v"(o.y) : "v"(v.y));
+    asm("v_max_f32 %0, 0, %1" : "=v"(o.z) : "v"(v.z));
+    asm("v_max_f32 %0, 0, %1" : "=v"(o.w) : "v"(v.w));
+    return o;
+}
+
+// ---- round 6: the forward pass's hidden-layer chains with VGPR accumulators and the weights named as AGPR operands -------------------------
+// hipcc gives every MFMA of a > 256-register kernel an AGPR destination, so each pre-activation a relu touches costs a v_accvgpr_read
+// (+ the two-instruction fmaxf): 192 of tp_fwd's 514 VALU instructions per step.  Written as inline asm the register classes are ours:
+// accumulators in VGPRs (the relu reads them directly: one v_max each), the wave's resident weights as "a" operands (the compiler keeps
+// them in AGPRs for the whole kernel), activations "v".  The FIRST k-step of a chain takes its C operand from the bias registers (D != C is
+// legal), so no accumulator is ever initialised by VALU moves.  Order per accumulator: k ascending, as in the builtin form - the same bits.
+// Hazards the compiler does not see inside asm: `s_nop 1` in front of a group (an operand written just before), tp_settle8 (12 states)
+// between the last MFMA of the chains and the first VALU reader.
+// MEASURED (round 6, scripts/gpu_runs/r6F.sh, B = 4096, 15-wide rows): the static VALU count of a tp_fwd step goes 514 -> 383 (no
+// v_accvgpr_read left in the loop, 64 v_max instead of 128 + 64 reads, no spills: 203 VGPRs + 106 AGPRs) and the kernel goes 180.7 -> 187.4 us
+// on a box whose untouched tp_bwd ran its usual 175 us.  The pass is not VALU-issue-bound (WAIT_INST_ANY 0.69: four waves, one per SIMD,
+// meeting at two barriers per step around LDS exchanges) - the H64 kernel's price list (7 cycles per VALU next to an MFMA) does not carry
+// over to a kernel that waits at barriers anyway, and the volatile asm groups take scheduling freedom from the compiler (operand reads can
+// no longer sit between the MFMAs of a group).  OFF by default; kept as the record of the experiment (bitwise the builtin form's results:
+// the goldens and the at-size tests pass with it on).
+#ifndef MARL_TP_VGPR
+#define MARL_TP_VGPR 0
+#endif
+#define MARL_TP_M8(D0, D1, D2, D3, D4, D5, D6, D7, C0, C1, C2, C3, C4, C5, C6, C7)                      \
+    "s_nop 1\n\t"                                                                                      \
+    "v_mfma_f32_16x16x4_f32 " D0 ", %[wc0], %[bc0], " C0 "\n\t"                                          \
+    "v_mfma_f32_16x16x4_f32 " D4 ", %[wt0], %[bt0], " C4 "\n\t"                                          \
+    "v_mfma_f32_16x16x4_f32 " D1 ", %[wc1], %[bc0], " C1 "\n\t"                                          \
+    "v_mfma_f32_16x16x4_f32 " D5 ", %[wt1], %[bt0], " C5 "\n\t"                                          \
+    "v_mfma_f32_16x16x4_f32 " D2 ", %[wc0], %[bc1], " C2 "\n\t"                                          \
+    "v_mfma_f32_16x16x4_f32 " D6 ", %[wt0], %[bt1], " C6 "\n\t"                                          \
+    "v_mfma_f32_16x16x4_f32 " D3 ", %[wc1], %[bc1], " C3 "\n\t"                                          \
+    "v_mfma_f32_16x16x4_f32 " D7 ", %[wt1], %[bt1], " C7 "\n\t"
+// ac[nb][u] / at[nb][u] (critic / target) += w{c,t}[u] x b{c,t}[nb]: 8 MFMAs on 8 chains, issue order (nb, u, net) as the builtin loop
+__device__ __forceinline__ void tp_mfma8(f4 (&ac)[2][2], f4 (&at)[2][2], float wc0, float wc1, float wt0, float wt1, float bc0, float bc1, float bt0,
+                                         float bt1) {
+    asm volatile(MARL_TP_M8("%0", "%1", "%2", "%3", "%4", "%5", "%6", "%7", "%0", "%1", "%2", "%3", "%4", "%5", "%6", "%7")
+                 : "+v"(ac[0][0]), "+v"(ac[0][1]), "+v"(ac[1][0]), "+v"(ac[1][1]), "+v"(at[0][0]), "+v"(at[0][1]), "+v"(at[1][0]), "+v"(at[1][1])
+                 : [wc0] "a"(wc0), [wc1] "a"(wc1), [wt0] "a"(wt0), [wt1] "a"(wt1), [bc0] "v"(bc0), [bc1] "v"(bc1), [bt0] "v"(bt0), [bt1] "v"(bt1));
+}
+// the first k-step: D = A B + bias (cb[u] / tb[u], the wave's resident bias rows in accumulator layout)
+__device__ __forceinline__ void tp_mfma8_first(f4 (&ac)[2][2], f4 (&at)[2][2], const f4& cb0, const f4& cb1, const f4& tb0, const f4& tb1, float wc0,
+                                               float wc1, float wt0, float wt1, float bc0, float bc1, float bt0, float bt1) {
+    asm volatile(MARL_TP_M8("%0", "%1", "%2", "%3", "%4", "%5", "%6", "%7", "%8", "%9", "%8", "%9", "%10", "%11", "%10", "%11")
+                 : "=&v"(ac[0][0]), "=&v"(ac[0][1]), "=&v"(ac[1][0]), "=&v"(ac[1][1]), "=&v"(at[0][0]), "=&v"(at[0][1]), "=&v"(at[1][0]), "=&v"(at[1][1])
+                 : "v"(cb0), "v"(cb1), "v"(tb0), "v"(tb1), [wc0] "a"(wc0), [wc1] "a"(wc1), [wt0] "a"(wt0), [wt1] "a"(wt1), [bc0] "v"(bc0), [bc1] "v"(bc1),
+                   [bt0] "v"(bt0), [bt1] "v"(bt1));
+}
+// pass B's two chains whose results the VALU masks next (dH2 = W3^T dQ, dH1 = W2^T dH2): d[nb][u] += w[u] x b[nb], 4 MFMAs on 4 chains in the
+// builtin loop's order (nb, u); the first k-step starts from the inline constant 0 instead of VALU-zeroed accumulators
+__device__ __forceinline__ void tp_mfma4(f4 (&d)[2][2], float w0, float w1, float b0, float b1) {
+    asm volatile("s_nop 1\n\t"
+                 "v_mfma_f32_16x16x4_f32 %0, %4, %6, %0\n\t"
+                 "v_mfma_f32_16x16x4_f32 %1, %5, %6, %1\n\t"
+                 "v_mfma_f32_16x16x4_f32 %2, %4, %7, %2\n\t"
+                 "v_mfma_f32_16x16x4_f32 %3, %5, %7, %3\n\t"
+                 : "+v"(d[0][0]), "+v"(d[0][1]), "+v"(d[1][0]), "+v"(d[1][1])
+                 : "a"(w0), "a"(w1), "v"(b0), "v"(b1));
+}
+__device__ __forceinline__ void tp_mfma4_zero(f4 (&d)[2][2], float w0, float w1, float b0, float b1) {
+    asm volatile("s_nop 1\n\t"
+                 "v_mfma_f32_16x16x4_f32 %0, %4, %6, 0\n\t"
+                 "v_mfma_f32_16x16x4_f32 %1, %5, %6, 0\n\t"
+                 "v_mfma_f32_16x16x4_f32 %2, %4, %7, 0\n\t"
+                 "v_mfma_f32_16x16x4_f32 %3, %5, %7, 0\n\t"
+                 : "=&v"(d[0][0]), "=&v"(d[0][1]), "=&v"(d[1][0]), "=&v"(d[1][1])
+                 : "a"(w0), "a"(w1), "v"(b0), "v"(b1));
+}
+__device__ __forceinline__ void tp_settle4(f4 (&d)[2][2]) { asm volatile("s_nop 11" : "+v"(d[0][0]), "+v"(d[0][1]), "+v"(d[1][0]), "+v"(d[1][1])); }
+__device__ __forceinline__ void tp_settle8(f4 (&ac)[2][2], f4 (&at)[2][2]) {
+    asm volatile("s_nop 11" : "+v"(ac[0][0]), "+v"(ac[0][1]), "+v"(ac[1][0]), "+v"(ac[1][1]), "+v"(at[0][0]), "+v"(at[0][1]), "+v"(at[1][0]), "+v"(at[1][1]));
+}
+
 struct TpMix {
     float* chosen;  // [P][T][B]
     float* tqsel;   // [P][T][B]
@@ -273,26 +355,36 @@ __global__ __launch_bounds__(64 * W, 1) void tp_fwd_kernel(const float* __restri
             // ---- layer 1 of my tiles, dumped for everybody (the 2 NB TPW chains advance together)
             {
                 f4 a1c[NB][TPW], a1t[NB][TPW];
+                constexpr bool VG = MARL_TP_VGPR && NB == 2 && TPW == 2;
+                if constexpr (VG) {
+                    tp_mfma8_first(a1c, a1t, cw[0].b1s, cw[1].b1s, tw[0].b1s, tw[1].b1s, cw[0].a1[0], cw[1].a1[0], tw[0].a1[0], tw[1].a1[0], cur[0].x[0],
+                                   cur[1].x[0], cur[0].x[0], cur[1].x[0]);
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-                    for (int u = 0; u < TPW; ++u) { a1c[nb][u] = cw[u].b1s; a1t[nb][u] = tw[u].b1s; }
-#pragma unroll
-                for (int ks = 0; ks < S::KS1; ++ks)
+                    for (int ks = 1; ks < S::KS1; ++ks)
+                        tp_mfma8(a1c, a1t, cw[0].a1[ks], cw[1].a1[ks], tw[0].a1[ks], tw[1].a1[ks], cur[0].x[ks], cur[1].x[ks], cur[0].x[ks], cur[1].x[ks]);
+                    tp_settle8(a1c, a1t);
+                } else {
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-                        for (int u = 0; u < TPW; ++u) {
-                            a1c[nb][u] = MARL_MFMA(cw[u].a1[ks], cur[nb].x[ks], a1c[nb][u]);
-                            a1t[nb][u] = MARL_MFMA(tw[u].a1[ks], cur[nb].x[ks], a1t[nb][u]);
-                        }
+                        for (int u = 0; u < TPW; ++u) { a1c[nb][u] = cw[u].b1s; a1t[nb][u] = tw[u].b1s; }
+#pragma unroll
+                    for (int ks = 0; ks < S::KS1; ++ks)
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                            for (int u = 0; u < TPW; ++u) {
+                                a1c[nb][u] = MARL_MFMA(cw[u].a1[ks], cur[nb].x[ks], a1c[nb][u]);
+                                a1t[nb][u] = MARL_MFMA(tw[u].a1[ks], cur[nb].x[ks], a1t[nb][u]);
+                            }
+                }
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
                     for (int u = 0; u < TPW; ++u) {
-                        const f4 h1c = relu4(a1c[nb][u]);
+                        const f4 h1c = VG ? relu4_settled(a1c[nb][u]) : relu4_one(a1c[nb][u]);
                         Hc[(nb * NT + wave * TPW + u) * 64 + lane] = h1c;
-                        Ht[(nb * NT + wave * TPW + u) * 64 + lane] = relu4(a1t[nb][u]);
+                        Ht[(nb * NT + wave * TPW + u) * 64 + lane] = VG ? relu4_settled(a1t[nb][u]) : relu4_one(a1t[nb][u]);
                         if (h2_out != nullptr && t < t1)  // the critic's first hidden layer too (behind the h2 record, same layout): pass B recomputes nothing
                             h2_out[(size_t)P * T * tp_h2_blocks(B) * NT * 64 + ((((size_t)p * T + t) * tp_h2_blocks(B) + (set * NB + nb)) * NT + wave * TPW + u) * 64 + lane] = h1c;
                     }
@@ -302,33 +394,47 @@ __global__ __launch_bounds__(64 * W, 1) void tp_fwd_kernel(const float* __restri
             // together, k ascending in each (bitwise the order of the one-chain-at-a-time form): no MFMA waits for its own predecessor
             {
                 f4 acc[NB][TPW], acct[NB][TPW];
+                constexpr bool VG = MARL_TP_VGPR && NB == 2 && TPW == 2;
+                if constexpr (!VG) {
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb)
+                    for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-                    for (int u = 0; u < TPW; ++u) { acc[nb][u] = cw[u].b2s; acct[nb][u] = tw[u].b2s; }
+                        for (int u = 0; u < TPW; ++u) { acc[nb][u] = cw[u].b2s; acct[nb][u] = tw[u].b2s; }
+                }
 #pragma unroll
                 for (int kap = 0; kap < NT; ++kap) {
                     f4 hk[NB], gk[NB];
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb) { hk[nb] = Hc[(nb * NT + kap) * 64 + lane]; gk[nb] = Ht[(nb * NT + kap) * 64 + lane]; }
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
+                    for (int r = 0; r < 4; ++r) {
+                        if constexpr (VG) {
+                            if (kap == 0 && r == 0)
+                                tp_mfma8_first(acc, acct, cw[0].b2s, cw[1].b2s, tw[0].b2s, tw[1].b2s, cw[0].a2[0][0], cw[1].a2[0][0], tw[0].a2[0][0],
+                                               tw[1].a2[0][0], hk[0][0], hk[1][0], gk[0][0], gk[1][0]);
+                            else
+                                tp_mfma8(acc, acct, cw[0].a2[kap][r], cw[1].a2[kap][r], tw[0].a2[kap][r], tw[1].a2[kap][r], hk[0][r], hk[1][r], gk[0][r],
+                                         gk[1][r]);
+                        } else {
 #pragma unroll
-                        for (int nb = 0; nb < NB; ++nb)
+                            for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-                            for (int u = 0; u < TPW; ++u) {
-                                acc[nb][u] = MARL_MFMA(cw[u].a2[kap][r], hk[nb][r], acc[nb][u]);
-                                acct[nb][u] = MARL_MFMA(tw[u].a2[kap][r], gk[nb][r], acct[nb][u]);
-                            }
+                                for (int u = 0; u < TPW; ++u) {
+                                    acc[nb][u] = MARL_MFMA(cw[u].a2[kap][r], hk[nb][r], acc[nb][u]);
+                                    acct[nb][u] = MARL_MFMA(tw[u].a2[kap][r], gk[nb][r], acct[nb][u]);
+                                }
+                        }
+                    }
                 }
+                if constexpr (VG) tp_settle8(acc, acct);
                 f4 q[NB], tq[NB];
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
                     q[nb] = cb3; tq[nb] = tb3;
 #pragma unroll
                     for (int u = 0; u < TPW; ++u) {
-                        acc[nb][u] = relu4(acc[nb][u]);
-                        acct[nb][u] = relu4(acct[nb][u]);
+                        acc[nb][u] = VG ? relu4_settled(acc[nb][u]) : relu4_one(acc[nb][u]);
+                        acct[nb][u] = VG ? relu4_settled(acct[nb][u]) : relu4_one(acct[nb][u]);
                         if (h2_out != nullptr && t < t1)  // a transition row of this chunk (t1 itself only bootstraps here)
                             h2_out[((((size_t)p * T + t) * tp_h2_blocks(B) + (set * NB + nb)) * NT + wave * TPW + u) * 64 + lane] = acc[nb][u];
                     }
@@ -556,7 +662,7 @@ __global__ __launch_bounds__(64 * W, 1) void tp_bwd_kernel(const float* __restri
                         acc = cw[u].b1s;
 #pragma unroll
                         for (int ks = 0; ks < S::KS1; ++ks) acc = MARL_MFMA(cw[u].a1[ks], cur[nb].x[ks], acc);
-                        acc = relu4(acc);
+                        acc = relu4_one(acc);
                     }
                     h1[nb][u] = acc;
                     const int tau = wave * TPW + u;
@@ -586,15 +692,22 @@ __global__ __launch_bounds__(64 * W, 1) void tp_bwd_kernel(const float* __restri
                     for (int u = 0; u < TPW; ++u) {
                         f4 hh[1] = {h2c[nb][u]};
                         tile_write<1>(PH2 + 256 * (nb * TPW + u), hh, g, j);
-                        d2[nb][u] = zero4;
+                        if constexpr (!(MARL_TP_VGPR && NB == 2 && TPW == 2)) d2[nb][u] = zero4;
                     }
                 }
+                if constexpr (MARL_TP_VGPR && NB == 2 && TPW == 2) {
+                    tp_mfma4_zero(d2, t3[0][0], t3[1][0], dQ[0][0][0], dQ[1][0][0]);
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
+                    for (int r = 1; r < 4; ++r) tp_mfma4(d2, t3[0][r], t3[1][r], dQ[0][0][r], dQ[1][0][r]);
+                    tp_settle4(d2);
+                } else {
 #pragma unroll
-                    for (int nb = 0; nb < NB; ++nb)
+                    for (int r = 0; r < 4; ++r)
 #pragma unroll
-                        for (int u = 0; u < TPW; ++u) d2[nb][u] = MARL_MFMA(t3[u][r], dQ[nb][0][r], d2[nb][u]);
+                        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                            for (int u = 0; u < TPW; ++u) d2[nb][u] = MARL_MFMA(t3[u][r], dQ[nb][0][r], d2[nb][u]);
+                }
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
@@ -619,22 +732,32 @@ __global__ __launch_bounds__(64 * W, 1) void tp_bwd_kernel(const float* __restri
                 __syncthreads();
                 // ---- dH1 = W2^T dH2 (mask): NB x TPW independent chains, k ascending in each
                 f4 d1[NB][TPW];
+                constexpr bool VGB = MARL_TP_VGPR && NB == 2 && TPW == 2;
+                if constexpr (!VGB) {
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb)
+                    for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-                    for (int u = 0; u < TPW; ++u) d1[nb][u] = zero4;
+                        for (int u = 0; u < TPW; ++u) d1[nb][u] = zero4;
+                }
 #pragma unroll
                 for (int kap = 0; kap < NT; ++kap) {
                     f4 gk[NB];
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb) gk[nb] = G2[(nb * NT + kap) * 64 + lane];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
+                    for (int r = 0; r < 4; ++r) {
+                        if constexpr (VGB) {
+                            if (kap == 0 && r == 0) tp_mfma4_zero(d1, t2[0][0][0], t2[1][0][0], gk[0][0], gk[1][0]);
+                            else tp_mfma4(d1, t2[0][kap][r], t2[1][kap][r], gk[0][r], gk[1][r]);
+                        } else {
 #pragma unroll
-                        for (int nb = 0; nb < NB; ++nb)
+                            for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-                            for (int u = 0; u < TPW; ++u) d1[nb][u] = MARL_MFMA(t2[u][kap][r], gk[nb][r], d1[nb][u]);
+                                for (int u = 0; u < TPW; ++u) d1[nb][u] = MARL_MFMA(t2[u][kap][r], gk[nb][r], d1[nb][u]);
+                        }
+                    }
                 }
+                if constexpr (VGB) tp_settle4(d1);
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
@@ -697,7 +820,7 @@ __global__ __launch_bounds__(64 * W, 1) void tp_bwd_kernel(const float* __restri
 #pragma unroll
                             for (int r = 0; r < 4; ++r) acc = MARL_MFMA(cw[u].a2[kap][r], hk[r], acc);
                         }
-                        h2[0] = relu4(acc);
+                        h2[0] = relu4_one(acc);
                     }
                     f4 d2[1];
                     d2[0] = zero4;

@@ -68,7 +68,9 @@ static __global__ __launch_bounds__(PLAN_THREADS) void update_plan_kernel(marlhi
     const int u = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     int32_t* out = plan + (size_t)u * d.stride;
     for (int i = tid; i < segs * nb + 2 * nb; i += PLAN_THREADS) s_cnt[i] = 0;  // (s_cnt, s_base, s_S are contiguous)
+    if (tid == 0) { s_misc[0] = T; s_misc[3] = 0; }
     __syncthreads();
+    int my_min = T, my_total = 0;
     // ---- 1. draws + lengths; per 64-element segment: rank among the equal lengths to the left, count per length
     for (int i0 = 0; i0 < B; i0 += PLAN_THREADS) {
         const int i = i0 + tid;
@@ -84,6 +86,8 @@ static __global__ __launch_bounds__(PLAN_THREADS) void update_plan_kernel(marlhi
             for (int t = 0; t < T; ++t) len += f[t] ? 1 : 0;  // (a prefix mask: the count is the length; independent loads)
             s_idx[i] = e;
             s_len[i] = (uint8_t)len;
+            my_min = len < my_min ? len : my_min;
+            my_total += len;
             if (idx_out != nullptr && u == idx_out_update) idx_out[i] = e;
         }
         const int bin = in ? T - len : -1;  // longest first
@@ -103,7 +107,38 @@ static __global__ __launch_bounds__(PLAN_THREADS) void update_plan_kernel(marlhi
         }
         if (in) s_sorted[i] = rank;  // (parked until the bases exist)
     }
+    for (int off = 32; off >= 1; off >>= 1) {
+        const int o = __shfl_xor(my_min, off);
+        my_min = o < my_min ? o : my_min;
+        my_total += __shfl_xor(my_total, off);
+    }
+    if (lane == 0) {
+        atomicMin(&s_misc[0], my_min);
+        atomicAdd(&s_misc[3], my_total);
+    }
     __syncthreads();
+    const int W = d.waves;
+    if (s_misc[0] >= T) {
+        // every drawn episode runs to the time limit (a fresh run's regime, the headline's): nothing to order, nothing to skip - the draws
+        // in draw order and the static plan, entry for entry (what the sort and the balanced table below would produce as well)
+        for (int i = tid; i < B; i += PLAN_THREADS) out[PLAN_HDR + i] = s_idx[i];
+        const int nc = d.nc_static, ntasks = d.ngroups * nc;
+        for (int i = tid; i < d.cap_slots * W; i += PLAN_THREADS) {
+            int e = 0;
+            if (i < ntasks) {
+                const int grp = i / nc, ch = i - grp * nc;
+                e = plan_task(grp, (ch * T) / nc, ((ch + 1) * T) / nc);  // slot = task / W, wave = task % W: the static loop's own assignment
+            }
+            out[PLAN_HDR + B + i] = e;
+        }
+        if (tid == 0) {
+            out[0] = (ntasks + W - 1) / W;
+            out[1] = T;
+            out[2] = T;
+            out[3] = s_misc[3];
+        }
+        return;
+    }
     // ---- 2. exclusive prefix over the segments inside each bin, then over the bins
     if (tid < nb) {
         int run = 0;
@@ -147,19 +182,18 @@ static __global__ __launch_bounds__(PLAN_THREADS) void update_plan_kernel(marlhi
     __syncthreads();
     for (int i = tid; i < B; i += PLAN_THREADS) out[PLAN_HDR + i] = s_sorted[i];
     // ---- 4. tile lengths (sorted longest first: a tile's first episode is its longest) and the chunk length
-    int total = 0;
-    for (int k = tid; k < d.ngroups; k += PLAN_THREADS) {
-        const int L = (int)s_slen[16 * k];
-        s_tile[k] = L;
-        for (int c = 1; c <= T; ++c) atomicAdd(&s_S[c], (L + c - 1) / c);
+    for (int k0 = 0; k0 < d.ngroups; k0 += PLAN_THREADS) {
+        const int k = k0 + tid;
+        const int L = k < d.ngroups ? (int)s_slen[16 * k] : 0;
+        if (k < d.ngroups) s_tile[k] = L;
+        if (__ballot(k < d.ngroups) == 0ull) continue;
+        for (int c = 1; c <= T; ++c) {  // tasks needed with chunk length c: summed per wave, one atomic per wave and c
+            int v = (L + c - 1) / c;
+            for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+            if (lane == 0) atomicAdd(&s_S[c], v);
+        }
     }
-    for (int i = tid; i < B; i += PLAN_THREADS) total += (int)s_len[i];
-    for (int off = 32; off >= 1; off >>= 1) total += __shfl_xor(total, off);
-    if (tid == 0) s_misc[3] = 0;
     __syncthreads();
-    if (lane == 0) atomicAdd(&s_misc[3], total);
-    __syncthreads();
-    const int W = d.waves;
     if (tid == 0) {
         const int Lmax = s_tile[0], Lmin = s_tile[d.ngroups - 1];
         const bool full = Lmin >= T;  // every tile walks all T steps: the static plan, bit for bit

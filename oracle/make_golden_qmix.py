@@ -11,6 +11,8 @@ Runs only in the build container (needs /root/reference); the vectors travel, th
   learner_qmix_L1_H64.npz      : 2 agents x 15 obs with mixing = {64, hypernet_layers 1, 32} (QMixer.__init__'s one-Linear hypernets, model.py:283-285).
   learner_qmix_L1_e40_p3_H64.npz : 3 agents x 18 obs with mixing = {40, 1, 7}; learner_qmix_e96_h48_H64.npz: 2 agents x 15 obs with {96, 2, 48}
       (wider than the fused kernels); all three: loss, gradients, 3 updates - they run on the generic mixer stage (csrc/qmix_gen.hip).
+  learner_qmix_layers136.npz   : 2 agents x 15 obs, AGENT networks with layers = [136, 136] (wider than the fused agent kernels: the GEMM path,
+      marlhip_wide_qmix_loss_grad) around qmix.yaml's mixer: loss, gradients, 2 updates (hard copy at update 2).
 """
 import contextlib
 import io
@@ -31,13 +33,13 @@ def mixer_grad(m):
     return torch.cat([p.grad.reshape(-1) for p in m.parameters()])
 
 
-def build(ref_model, P, D, A, H, seed, mixing=None):
+def build(ref_model, P, D, A, H, seed, mixing=None, layers=None):
     torch.manual_seed(seed)
     cfg = Cfg(optimizer="Adam", lr=3e-4, gamma=0.99, grad_clip=1.0, target_update_interval_or_tau=2, double_q=True,
               standardise_returns=False)
     mixing = mixing or dict(embed_dim=64, hypernet_layers=2, hypernet_embed=32)  # configs/algorithm/qmix.yaml:14-17
     with contextlib.redirect_stdout(io.StringIO()):
-        net = ref_model.QMixNetwork([Box(D)] * P, [Discrete(A)] * P, cfg, [H, H], False, False, True, mixing, "cpu")
+        net = ref_model.QMixNetwork([Box(D)] * P, [Discrete(A)] * P, cfg, list(layers) if layers else [H, H], False, False, True, mixing, "cpu")
     g = torch.Generator().manual_seed(seed + 1)
     with torch.no_grad():  # critic != target, mixer != target mixer, biases non-zero
         for p in net.critic.parameters():
@@ -49,10 +51,10 @@ def build(ref_model, P, D, A, H, seed, mixing=None):
     return net
 
 
-def fixture(ref_model, ref_train, name, P, D, B, seed, updates, mixing=None):
+def fixture(ref_model, ref_train, name, P, D, B, seed, updates, mixing=None, layers=None):
     T, A, H = 25, 6, 64
-    net = build(ref_model, P, D, A, H, seed, mixing)
-    out = dict(P=P, T=T, B=B, D=D, A=A, H=H, E=net.mixer.embed_dim, HE=net.mixer.hypernet_embed, L=net.mixer.hypernet_layers,
+    net = build(ref_model, P, D, A, H, seed, mixing, layers)
+    out = dict(P=P, T=T, B=B, D=D, A=A, H=H, layers=np.array(layers if layers else [H, H]), E=net.mixer.embed_dim, HE=net.mixer.hypernet_embed, L=net.mixer.hypernet_layers,
                mixer_keys=np.array([k for k in net.mixer.state_dict().keys()]), params0=flat_params(net.critic).numpy(),
                target0=flat_params(net.target).numpy(), mixer0=mixer_flat(net.mixer).numpy(),
                tmixer0=mixer_flat(net.target_mixer).numpy())
@@ -124,3 +126,5 @@ if __name__ == "__main__":
     fixture(rm, rt, "learner_qmix_L1_H64.npz", P=2, D=15, B=32, seed=600, updates=3, mixing=dict(embed_dim=64, hypernet_layers=1, hypernet_embed=32))
     fixture(rm, rt, "learner_qmix_L1_e40_p3_H64.npz", P=3, D=18, B=24, seed=700, updates=3, mixing=dict(embed_dim=40, hypernet_layers=1, hypernet_embed=7))
     fixture(rm, rt, "learner_qmix_e96_h48_H64.npz", P=2, D=15, B=32, seed=800, updates=3, mixing=dict(embed_dim=96, hypernet_layers=2, hypernet_embed=48))
+    # QMIX around agent networks wider than the fused kernels (QMixNetwork takes any `layers`, dqn/model.py:334-372)
+    fixture(rm, rt, "learner_qmix_layers136.npz", P=2, D=15, B=32, seed=900, updates=2, layers=[136, 136])
