@@ -501,9 +501,10 @@ def bench_ac(args, rank, world, dist, steps=None, warmup=None):
         ach = flops / (upd["avg_us"] * 1e-6) / 1e12
         needed = flops - ac_unneeded_flops(P, D, H, T, N, central, epochs=hyper["num_epochs"] if args.algo in ("ippo", "mappo") else 1,
                                            critic_backward_deferred=deferred)
+        traffic, tsrc = traffic_from_profile(f"{args.algo}:{args.env_name}:N{N}:H{H}:T{T}")  # (whole update stage incl. the critics' backward pass, per rollout)
         roofline = {"kernel": "ac_update stage (forward rows, elementwise, backward rows)" + ("; the actors' forward pass is the collector's own, kept for the step" if kept else ""),
                     "actor_forward_kept": kept, "critic_backward_overlaps_next_rollout": deferred, "bound": "mfma", "achieved": ach,
-                    "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                    "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": tsrc,
                     "flops_per_launch": flops, "avg_launch_us": upd["avg_us"],
                     "flops_needed_per_launch": needed, "frac_needed": ach * needed / flops / PEAK_F32_MFMA_TFLOPS,
                     "dominant_stage_by_time": "ac_update" if not col or upd["total_ms"] >= col["total_ms"] else "ac_collect_kernel"}

@@ -246,7 +246,7 @@ int64_t backward_ws_bytes(int P, int T, int B) {
     } else if constexpr (IsWide<S>::value) {
         return wide_ws(S::net(), P, T * B, true).total;
     } else if constexpr (use_tp<S>()) {
-        const UpdPlan a = upd_plan_tp(P, T, B, S::D > MARL_TP_NB1_D ? 1 : 2), b = upd_plan_tp(P, T, B, S::D > MARL_TP_NB1S_D ? 1 : 2);  // either form of the pass
+        const UpdPlan a = upd_plan_tp(P, T, B, S::D > MARL_TP_NB1_D ? 1 : 2), b = upd_plan_tp(P, T, B, S::D > MARL_TP_NB1S_D ? 1 : 2, MARL_TP_BWD_OCC);  // either form of the pass
         return ws_layout(P, a.nwg > b.nwg ? a.nwg : b.nwg, S::NPARAM + 2, 0, T, B).total;
     } else {
         const UpdPlan pl = upd_plan(P, T, B);
@@ -301,7 +301,7 @@ int launch_backward_rows(int P, const AgentMap& am, const float* params, const m
             attr_set.done();
         }
         if (rec != nullptr) {  // both hidden layers come back from the forward-rows pass of this step: h2 | h1 (mlp_rows_fwd_kernel<S, 1>)
-            const UpdPlan pl = upd_plan_tp(P, T, B, NBS);
+            const UpdPlan pl = upd_plan_tp(P, T, B, NBS, MARL_TP_BWD_OCC);
             nwg = pl.nwg;
             hipLaunchKernelGGL((tp_bwd_kernel<S, W, TPW, false, NBS, true, true, true>), dim3(pl.nwg, P), dim3(64 * W), ldsS, st, params, am, *bt, none, mix,
                                pl.n_chunks, (float*)ws, reinterpret_cast<const f4*>(rec), reinterpret_cast<const f4*>(rec) + tp_h2_floats(P, T, B, S::H) / 4);

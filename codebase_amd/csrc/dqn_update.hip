@@ -92,7 +92,7 @@ extern "C" int64_t marlhip_dqn_workspace_bytes(const marlhip_net_shape* s, int32
 #define X(d, h, a) if (s->obs_dim == d && s->hidden == h && s->n_actions == a) tp = use_tp<MlpShape<d, h, a>>();
     MARL_NET_SHAPES(X)
 #undef X
-    const UpdPlan pl = tp ? upd_plan_tp(s->n_agents, max_len, batch, s->obs_dim > MARL_TP_NB1S_D ? 1 : 2) : upd_plan(s->n_agents, max_len, batch);
+    const UpdPlan pl = tp ? upd_plan_tp(s->n_agents, max_len, batch, s->obs_dim > MARL_TP_NB1S_D ? 1 : 2, MARL_TP_BWD_OCC) : upd_plan(s->n_agents, max_len, batch);
     // partial records + 16 B alignment slack + weight packs (<= 4 x nparams-padded floats per agent; see launch_lossgrad)
     int64_t pack = -1;
 #define X(d, h, a) if (s->obs_dim == d && s->hidden == h && s->n_actions == a) pack = 2 * MlpShape<d, h, a>::NFWD + MlpShape<d, h, a>::NBWD;

@@ -1255,9 +1255,9 @@ inline int64_t lds_h_floats(int P, int T, int B, int H) { return (int64_t)P * T 
 #define MARL_TP_NBF 2  // row blocks per step of the forward pass
 #endif
 // hidden 128: tensor-parallel passes (dqn_update_tp.h) - pass F, mixer, pass B, reduce
-inline UpdPlan upd_plan_tp(int P, int T, int B, int NB) {  // one workgroup per CU, tasks = (block set, time chunk)
+inline UpdPlan upd_plan_tp(int P, int T, int B, int NB, int occ = 1) {  // `occ` workgroups per CU, tasks = (block set, time chunk)
     const int nsets = (B + 16 * NB - 1) / (16 * NB);
-    const int want = 256 / P > 1 ? 256 / P : 1;
+    const int want = occ * 256 / P > 1 ? occ * 256 / P : 1;
     int nc = (want + nsets - 1) / nsets;
     if (nc < 1) nc = 1;
     if (nc > T) nc = T;
@@ -1301,7 +1301,7 @@ int launch_lossgrad_tp(const marlhip_net_shape* s, const float* params, const fl
     const int P = s->n_agents, T = bt->max_len, B = bt->batch;
     const AgentMap am = agent_map(s);
     static_assert(NB <= 2 && NBF <= 2, "tp_h2_blocks counts row blocks in pairs");
-    const UpdPlan pl = upd_plan_tp(P, T, B, NB), plF = upd_plan_tp(P, T, B, NBF);
+    const UpdPlan pl = upd_plan_tp(P, T, B, NB, MARL_TP_BWD_OCC), plF = upd_plan_tp(P, T, B, NBF);
     const WsLayout wl = ws_layout(P, pl.nwg, REC, 0, T, B);
     const int64_t h2_off = (wl.total + 15) & ~(int64_t)15, need = h2_off + 2 * tp_h2_floats(P, T, B, S::H) * (int64_t)sizeof(float);  // h2 | h1 records
     MARL_REQUIRE(ws_bytes >= need, "dqn_loss_grad: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)need);

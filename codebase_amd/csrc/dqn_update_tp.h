@@ -46,6 +46,14 @@ __device__ __forceinline__ f4 relu4_one(f4 v) {
 #ifndef MARL_TP_VGPR
 #define MARL_TP_VGPR 0
 #endif
+// workgroups of pass B per compute unit.  MEASURED (round 6, scripts/gpu_runs/r6G.sh): 2 (launch_bounds(256, 2): 256 registers, 31 spilled,
+// with -DMARL_TP_NB1S_D=0 = one row block per step so that two workgroups' LDS fit) - a second wave per SIMD to hide the barrier / exchange
+// latency - runs tp_bwd at 180.7 us against 175 (IDQN 128-128), VDN 15x15-4p 3.96 -> 3.57 M, and the actor-critic FULL form spills badly
+// (config 4: 62 -> 33 M).  The matrix pipe is shared by the SIMD's waves and the pass holds its weights in registers: halving the register
+// budget costs more than the overlap returns.  1 it stays.
+#ifndef MARL_TP_BWD_OCC
+#define MARL_TP_BWD_OCC 1
+#endif
 #define MARL_TP_M8(D0, D1, D2, D3, D4, D5, D6, D7, C0, C1, C2, C3, C4, C5, C6, C7)                      \
     "s_nop 1\n\t"                                                                                      \
     "v_mfma_f32_16x16x4_f32 " D0 ", %[wc0], %[bc0], " C0 "\n\t"                                          \
@@ -544,7 +552,7 @@ static __global__ __launch_bounds__(256) void tp_mix_kernel(TpMix mix, int P, in
 // STORED1 (with STORED; round 4, the actor-critic step): layer 1 is not recomputed either - the wave reads ITS h1 tiles of the row block from
 // the forward-rows pass (h1_in, the layout of h2_in): no layer-1 weights, no A-side copy of the rows in registers, 2 KS1 fewer MFMAs per block.
 template <class S, int W, int TPW, bool REPLAY, int NB, bool FULL = false, bool STORED = false, bool STORED1 = false>
-__global__ __launch_bounds__(64 * W, 1) void tp_bwd_kernel(const float* __restrict__ params, AgentMap am, marlhip_batch bt, ReplaySrc rs, TpMix mix,
+__global__ __launch_bounds__(64 * W, MARL_TP_BWD_OCC) void tp_bwd_kernel(const float* __restrict__ params, AgentMap am, marlhip_batch bt, ReplaySrc rs, TpMix mix,
                                                            int n_chunks, float* __restrict__ partials, const f4* __restrict__ h2_in = nullptr,
                                                            const f4* __restrict__ h1_in = nullptr) {
     static_assert(!STORED1 || STORED, "the stored first layer comes with the stored second");

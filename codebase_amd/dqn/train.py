@@ -170,6 +170,21 @@ class VectorisedIDQN:
     def reset_env_steps(self):
         self._len_acc.zero_()
 
+    def job_steps_last_round(self):
+        """env-steps the WHOLE JOB collected in the last round (int; one host read).  N > 1 ranks: the per-rank count of the round (<= N T:
+        exact in a float) crosses the ranks through the SAME exchange as the gradients - the in-library peer-to-peer kernel where it is
+        set up (one 1-workgroup launch; no collective-library launch, no second communicator), torch.distributed's all-reduce otherwise -
+        so a round's only inter-rank traffic is of one kind."""
+        t = self.fin_length.sum().to(torch.float32).reshape(1)
+        if self.dist is not None:
+            if self._sync is None:
+                from ..parallel import GradSync
+
+                g = self.model.updater
+                self._sync = GradSync(self.dist, max_floats=getattr(g, "joint_grad", g.grad).numel())
+            self._sync(t)
+        return int(round(float(t.item())))
+
     def _grad_sync(self, grad):
         from ..parallel import GradSync
 
@@ -226,7 +241,7 @@ class VectorisedIDQN:
             # one library call for all U updates; with N > 1 ranks its data-parallel form: the gradient all-reduce is the only host hop
             if self._fused is None:
                 self._fused = _hip.FusedLearner(m.updater, self.replay, self.B, m.target_update_interval_or_tau, mode=m.mode)
-                if self.dist is not None:
+                if self.dist is not None and self._sync is None:
                     from ..parallel import GradSync
 
                     self._sync = GradSync(self.dist, max_floats=m.updater.grad.numel())
@@ -241,7 +256,7 @@ class VectorisedIDQN:
             # both optimiser steps, target copies) from ONE library call (marlhip_qmix_update_n) - the same launches as the loop below
             if self._fused is None:
                 self._fused = _hip.FusedQmixLearner(m.updater, self.replay, self.B, m.target_update_interval_or_tau)
-                if self.dist is not None:
+                if self.dist is not None and self._sync is None:
                     from ..parallel import GradSync
 
                     self._sync = GradSync(self.dist, max_floats=m.updater.joint_grad.numel())
@@ -356,7 +371,7 @@ def main(env, eval_env, logger, time_limit, **cfg):
             trainer.round(eps_sched(step), train=train)
             # one host sync per round (N episodes); N > 1 ranks: the whole job's env-steps, the same number on every rank - it drives
             # the epsilon schedule, the training start and the loop's end, so all ranks issue the same collectives
-            step = int(all_sum(dist, trainer.env_steps.clone()).item())
+            step += trainer.job_steps_last_round()
             if train:
                 updates += trainer.U
                 metrics = {"loss": float(trainer.last_loss[0].item())}

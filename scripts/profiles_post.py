@@ -91,7 +91,7 @@ def main():
                     "   registers today) would not pay.\n")
     if os.path.exists(os.path.join(SRC, "hbm_ubench.txt")):
         shutil.copy(os.path.join(SRC, "hbm_ubench.txt"), os.path.join(DST, PFX + "_hbm_ubench.txt"))
-    for name in ("bench_default_line.json", "forcedist_line.json"):
+    for name in ("bench_default_line.json", "forcedist_line.json", "episode_lengths.json", "episode_lengths_clear_stale.json"):
         if os.path.exists(os.path.join(SRC, name)) and os.path.getsize(os.path.join(SRC, name)) > 0:
             shutil.copy(os.path.join(SRC, name), os.path.join(DST, PFX + "_" + name))
     hbm_pmc_table()
@@ -104,13 +104,33 @@ def main():
            "units": "FETCH_SIZE / WRITE_SIZE are reported in KiB; read bytes = 2 x FETCH_SIZE (MI355X_MICROARCH.md, HBM: gfx950 tallies 128-B "
                     "read requests at 64 B), write bytes = WRITE_SIZE (the reduce kernel's known 5.7 MB record read calibrates the read side)",
            "kernels": {}, "workloads": {}}
-    for sfx, key, match, alg in (
+    def replay_bytes(p_, d_, b_):  # one sampled episode = 4 P D (T + 1) + P T 5 + (T + 1) + T bytes
+        return b_ * (4 * p_ * d_ * (T + 1) + p_ * T * 5 + (T + 1) + T)
+
+    # round 6: every `modes` row of the default line that a PMC pass was collected for; `files` = the kernel sources the
+    # figure is keyed to (bench.traffic_from_profile refuses to quote it when they hash differently)
+    extra = (
+        ("_vdn64", "vdn:lbforaging:Foraging-15x15-4p-5f-v3:N8192:H64:B8192:T25:rnn0", ("dqn_lossgrad_kernel", "vdn_mix_kernel"),
+         {"replay_read_two_passes": 2 * replay_bytes(4, 27, 8192), "hidden_layers_write_plus_read": 2 * 4 * T * 8192 * 2 * 64 * 4,
+          "mixer_planes": 13 * T * 8192 * 4}, ("dqn_update_kernels.h", "mlp.h")),
+        ("_vdn128", "vdn:lbforaging:Foraging-15x15-4p-5f-v3:N8192:H128:B8192:T25:rnn0", ("tp_fwd_kernel", "tp_mix_kernel", "tp_bwd_kernel"),
+         {"replay_read_two_passes": 2 * replay_bytes(4, 27, 8192), "h1_h2_activations_write_plus_read": 2 * 2 * 4 * T * 8192 * 128 * 4},
+         ("dqn_update_tp.h", "mlp.h")),
+        ("_qmix8p", "qmix:lbforaging:Foraging-15x15-8p-5f-v3:N8192:H128:B8192:T25:rnn0", ("tp_fwd_kernel", "tp_bwd_kernel", "qmix_"),
+         {"replay_read_two_passes": 2 * replay_bytes(8, 39, 8192), "h1_h2_activations_write_plus_read": 2 * 2 * 8 * T * 8192 * 128 * 4,
+          "mixer_state_rows_read (online + target + weight gradient)": 3 * T * 8192 * 8 * 39 * 4}, ("dqn_update_tp.h", "mlp.h", "qmix.h")),
+        ("_ia2c_rware", "ia2c:rware:rware-tiny-4ag-v2:N2048:H128:T500", ("mlp_rows_fwd_kernel", "a2c_", "tp_bwd_kernel", "ac_"),
+         {"rollout_rows_read (critic, target critic, actor backward)": 3 * 4 * 500 * 2048 * 71 * 4,
+          "h1_h2_records_write_plus_read (critics; the actors' are the collector's)": 2 * 2 * 4 * 500 * 2048 * 128 * 4}, ("a2c_core.h", "dqn_update_tp.h", "mlp.h", "mlp_keep.h")))
+    for row in (
             ("", "idqn:lbforaging:Foraging-8x8-2p-3f-v3:N4096:H64:B4096:T25:rnn0", ("dqn_lossgrad_kernel",),
              {"replay_read": alg_read, "partial_records_write": 256 * (5574 + 2) * 4}),
             ("_h128", "idqn:lbforaging:Foraging-8x8-2p-3f-v3:N4096:H128:B4096:T25:rnn0", ("tp_fwd_kernel", "tp_mix_kernel", "tp_bwd_kernel"),
              {"replay_read_two_passes": 2 * alg_read, "h2_activations_write_plus_read": 2 * P * T * B * 128 * 4, "partial_records_write": 256 * (19334 + 2) * 4}),
             ("_s16", "idqn:lbforaging:Foraging-8x8-2p-3f-v3:N4096:H64:B4096:T25:rnn0:split16", ("dqn_lossgrad_h16_kernel",),
-             {"replay_read": alg_read, "partial_records_write": 256 * (5574 + 2) * 4})):
+             {"replay_read": alg_read, "partial_records_write": 256 * (5574 + 2) * 4})) + extra:
+        sfx, key, match, alg = row[:4]
+        files_override = row[4] if len(row) > 4 else None
         fe, wr, tcc = counters("FETCH_SIZE" + sfx), counters("WRITE_SIZE" + sfx), counters("TCC" + sfx)
         kernels = {}
         for k in sorted(set(fe) | set(wr)):
@@ -140,9 +160,13 @@ def main():
             sys.path.insert(0, ROOT)
             import bench  # kernel_source_hash: the key bench.py checks before quoting the figure (run this script on the PROFILED tree)
 
-            files = bench.TRAFFIC_SOURCES["split16" if sfx == "_s16" else ("H128" if sfx == "_h128" else "")]
+            files = files_override or bench.TRAFFIC_SOURCES["split16" if sfx == "_s16" else ("H128" if sfx == "_h128" else "")]
+            # per UPDATE (= per launch of the group bench.py's timer brackets): a kernel launched k times per update counts k times - the
+            # matched kernel with the fewest launches in the run is the once-per-update one
+            n_upd = max(1, min(v["launches_profiled"] for v in parts))
             out["workloads"][key] = {"kernel": " + ".join(k for k in kernels if any(k.startswith(mm) for mm in match)),
-                                     "traffic_bytes": sum(v["traffic_bytes"] for v in parts), "algorithmic_bytes": alg,
+                                     "traffic_bytes": sum(v["traffic_bytes"] * v["launches_profiled"] for v in parts) / n_upd,
+                                     "updates_profiled": n_upd, "algorithmic_bytes": alg,
                                      "source_files": list(files), "source_hash": bench.kernel_source_hash(files)}
     json.dump(out, open(os.path.join(DST, PFX + "_pmc_traffic.json"), "w"), indent=1)
     # ---- SQ counters
