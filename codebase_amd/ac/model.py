@@ -12,7 +12,8 @@ Storage: ONE flat fp32 block [actor agents | critic agents] (so that clip_grad_n
 single fused launch) plus the target-critic block; state_dict tensors are slices.
 Built: independent or shared (parameter_sharing True / SePS index list, the same for actor and critic) actors and
 critics (IA2C / IPPO) and centralised critics (MAA2C / MAPPO: fused kernels up to 4 LBF agents, GEMM path beyond), two hidden layers of any widths <= 128
-(zero-padded to the compiled 64 / 128, exact), recurrent actors / critics (`use_rnn`, widths 64 / 128), `action_mask`.
+(zero-padded to the compiled 64 / 128, exact), recurrent actors / critics (`use_rnn`, widths 64 / 128; `actor.use_rnn` and `critic.use_rnn`
+may differ: csrc/mixed_ac.hip), `action_mask`.
 """
 from collections import OrderedDict
 
@@ -47,14 +48,23 @@ class A2CNetwork:
         # actor.parameter_sharing and critic.parameter_sharing are separate settings (ac/model.py:45-97): two agent -> network maps
         self.sharing = sharing_indices(_get(actor, "parameter_sharing", False), P)
         self.critic_sharing = sharing_indices(_get(critic, "parameter_sharing", False), P)
-        self.recurrent = bool(_get(actor, "use_rnn", False))
-        if bool(_get(critic, "use_rnn", False)) != self.recurrent:
-            raise NotImplementedError("actor.use_rnn != critic.use_rnn: the recurrent step is built for recurrent actors AND critics")
+        # actor.use_rnn and critic.use_rnn are separate settings (ac/model.py:45-97 passes each to its own MultiAgent*Network): both recurrent
+        # (marlhip_gru_*), neither (marlhip_a2c_* / ppo_*), or one of them (marlhip_mixed_*: csrc/mixed_ac.hip)
+        self.actor_recurrent = bool(_get(actor, "use_rnn", False))
+        self.critic_recurrent = bool(_get(critic, "use_rnn", False))
+        self.recurrent = self.actor_recurrent and self.critic_recurrent
+        self.mixed_rnn = None if self.actor_recurrent == self.critic_recurrent else ("actor" if self.actor_recurrent else "critic")
         ha, hc = [int(h) for h in _get(actor, "layers")], [int(h) for h in _get(critic, "layers")]
         # any two-layer widths, actor and critic independently: zero-padded to one kernel width (dqn/model.py pad_blocks; > 128: the GEMM path);
         # recurrent networks likewise ([h, h] with h <= 128, actor and critic each padded onto the 64 / 128 recurrent kernels)
         if self.recurrent:
             Hk = max(recurrent_width(ha)[1], recurrent_width(hc)[1])
+            wide = False
+        elif self.mixed_rnn:
+            if is_wide(hc if self.actor_recurrent else ha) or len(ha) != len(hc) or bool(_get(critic, "centralised", False)):
+                raise NotImplementedError(f"actor.use_rnn != critic.use_rnn with layers actor={ha} critic={hc}: the feed-forward family must be two "
+                                          "layers of at most 128 units next to the [h, h] recurrent one, and the critics independent")
+            Hk = max(recurrent_width(ha)[1] if self.actor_recurrent else compiled_width(ha), recurrent_width(hc)[1] if self.critic_recurrent else compiled_width(hc))
             wide = False
         else:
             Hk = max(compiled_width(ha), compiled_width(hc))
@@ -95,16 +105,18 @@ class A2CNetwork:
             cdims = [cdims[i] for i in first]
         K = self.critic_spec.n_blocks  # critic networks (the actors' count is len(obs_dims) = self.spec.n_blocks)
         # torch RNG consumption in the reference's order: actor nets, critic nets, target-critic nets (model.py:44-107)
-        if self.recurrent:  # RNNNetwork inits (utils/models.py:83-94); init_flat_gru_params draws one set per call
+        if self.actor_recurrent:  # RNNNetwork inits (utils/models.py:83-94); init_flat_gru_params draws one set per call
             a0 = init_flat_gru_params(obs_dims, ha[0], act_dims, _get(actor, "use_orthogonal_init", True), sets=1)[0]
-            c0 = init_flat_gru_params(cdims, hc[0], [1] * K, _get(critic, "use_orthogonal_init", True), sets=2)[0]  # critic, then the target's draws
             a0 = pad_gru_blocks(a0, obs_dims[0], ha[0], act_dims[0], Hk)
-            c0 = pad_gru_blocks(c0, cdims[0], hc[0], 1, Hk)
         else:
             a0 = _init_blocks(obs_dims, ha, act_dims, _get(actor, "use_orthogonal_init", True))
+            a0 = pad_blocks(a0, obs_dims[0], ha, act_dims[0], Hk)
+        if self.critic_recurrent:
+            c0 = init_flat_gru_params(cdims, hc[0], [1] * K, _get(critic, "use_orthogonal_init", True), sets=2)[0]  # critic, then the target's draws
+            c0 = pad_gru_blocks(c0, cdims[0], hc[0], 1, Hk)
+        else:
             c0 = _init_blocks(cdims, hc, [1] * K, _get(critic, "use_orthogonal_init", True))
             _init_blocks(cdims, hc, [1] * K, _get(critic, "use_orthogonal_init", True))  # target: drawn, then overwritten (soft_update(1.0))
-            a0 = pad_blocks(a0, obs_dims[0], ha, act_dims[0], Hk)
             c0 = pad_blocks(c0, cdims[0], hc, 1, Hk)
         self._block = torch.cat([a0.reshape(-1), c0.reshape(-1)]).to(self.device).contiguous()
         self._target_critic_params = c0.clone().to(self.device).contiguous()
@@ -113,7 +125,7 @@ class A2CNetwork:
                                       value_loss_coef=self.value_loss_coef, grad_clip=self.grad_clip,
                                       ppo_clip=float(_get(cfg, "ppo_clip", 0.2)), standardise_returns=self.standardise_returns,
                                       centralised_critic=self.centralised_critic, recurrent=self.recurrent, optimizer=self.optimizer,
-                                      critic_sharing=self.critic_sharing, critic_n_hidden=len(hc))
+                                      critic_sharing=self.critic_sharing, critic_n_hidden=None if self.mixed_rnn else len(hc), mixed_rnn=self.mixed_rnn)
         self.ret_ms = self.updater.ret_stats
         self.actor_params = self.updater.actor
 
@@ -137,12 +149,12 @@ class A2CNetwork:
 
     # ---- reference interface ---------------------------------------------------------------
     def init_critic_hiddens(self, batch_size, target=False):
-        if self.recurrent:
+        if self.critic_recurrent:
             return [torch.zeros(1, batch_size, self.spec.hidden, device=self.device) for _ in range(self.n_agents)]
         return [None] * self.n_agents
 
     def init_actor_hiddens(self, batch_size):
-        if self.recurrent:
+        if self.actor_recurrent:
             return [torch.zeros(1, batch_size, self.spec.hidden, device=self.device) for _ in range(self.n_agents)]
         return [None] * self.n_agents
 
@@ -174,7 +186,7 @@ class A2CNetwork:
 
     def act(self, inputs, actor_hiddens, action_mask=None):
         """model.py:147-153: Categorical(logits).sample() per agent; returns ([P, N, 1] int64, hiddens)"""
-        if self.recurrent:
+        if self.actor_recurrent:
             out, actor_hiddens = self._seq(self.actor_params, inputs, actor_hiddens, False)
             lg = out[:, 0]
         else:
@@ -197,7 +209,7 @@ class A2CNetwork:
             out, h = _hip.gru_ac_forward(self.critic_spec, blk, x, 0, x.shape[-1], S_, N, value_net=2, h_in=h_in, want_h=True)
             out = out[..., 0]
             return (out[:, 0] if one else out).movedim(0, -1).contiguous(), [h[p].reshape(1, N, -1) for p in range(self.n_agents)]
-        if self.recurrent:
+        if self.critic_recurrent:
             out, critic_hiddens = self._seq(blk, inputs, critic_hiddens, True)
             out = out[..., 0]  # [P][S][N]
             lead_one = torch.as_tensor(inputs[0]).dim() == 2
@@ -226,7 +238,9 @@ class A2CNetwork:
 
     # one update per rollout, on the parameters the rollout was sampled with (model.py:189-246): the fused collector leaves the actors'
     # logits and hidden layers of every batch row for the step (hip.ac_collect(keep_for=updater)) instead of the step recomputing them
-    keeps_actor_forward = True
+    @property
+    def keeps_actor_forward(self):
+        return not (self.actor_recurrent or self.critic_recurrent)
 
     def attach_grad_sync(self, grad_sync):
         """data-parallel set-up (every rank, once, before the first update): whether the critics' half of an update may leave the caller's
@@ -291,7 +305,7 @@ class A2CNetwork:
             group = "independent" if sharing is None else "networks"
             for i in range(block.shape[0]):
                 cin = S.n_agents * S.obs_dim if (self.centralised_critic and prefix != "actor") else S.obs_dim
-                if not self.recurrent:  # the live tensors inside the (possibly zero-padded) blocks
+                if not (self.actor_recurrent if prefix == "actor" else self.critic_recurrent):  # the live tensors inside the (possibly zero-padded) blocks
                     for name, view in block_views(block[i], cin, self.live_hidden[prefix], A, S.hidden):
                         out[f"{prefix}.{group}.{i}.{name}"] = view
                     continue

@@ -74,7 +74,7 @@ def _collect_trajectories_recurrent(envs, model, T, use_proper_termination, roun
     later_dev = (torch.zeros(1, dtype=torch.int32, device=dev), torch.zeros(cap, P, device=dev), torch.zeros(cap, 3, dtype=torch.int32, device=dev))
     hid, t = None, 0
     while t < T:
-        if getattr(model, "recurrent", False):
+        if getattr(model, "actor_recurrent", getattr(model, "recurrent", False)):  # (the hidden state carried between the steps is the ACTORS')
             logits, hid = _hip.gru_ac_forward(model.spec, model.actor_params, obs, N * D, D, 1, N, h_in=hid, want_h=True)
             logits = logits[:, 0]
         else:  # feed-forward actors without a fused collector (layers wider than 128): the GEMM path's logits, no state
@@ -116,7 +116,7 @@ def _collect_trajectories(envs, model, max_ep_length, parallel_envs, n_agents, d
     fin_len = torch.zeros(N, dtype=torch.int32, device=dev)
     t_max = torch.zeros(1, dtype=torch.int32, device=dev)
     later = []  # (finishing step, env, returns [P], length) of episodes that ended after an env's first one (ac/train.py:101-110)
-    if getattr(model, "recurrent", False) or model.spec.wide:  # no fused collector for these: the modular loop
+    if getattr(model, "actor_recurrent", getattr(model, "recurrent", False)) or model.spec.wide:  # no fused collector for these: the modular loop
         t, batch, fin_ret, fin_len, later = _collect_trajectories_recurrent(envs, model, T, use_proper_termination, round_idx)
     else:
         # A2C: the update that follows runs on these parameters, so the collector leaves the actors' forward pass for it (hip.ac_collect)

@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(CSRC, "libmarlhip.so")
-SOURCES = ["api.hip", "lbf_kernels.hip", "replay_kernels.hip", "collect.hip", "collect_oid.hip", "dqn_update.hip", "dqn_update_h64.hip", "dqn_update_h64_oid.hip", "dqn_update_h128.hip", "dqn_update_h128_oid.hip", "dqn_update_rware.hip", "dqn_update_h16.hip", "round.hip", "p2p.hip", "rware_kernels.hip", "rware_collect.hip", "rware_collect_big.hip", "rware_collect_p8.hip", "ac_collect.hip", "ac_collect_oid.hip", "a2c.hip", "gru.hip", "gru_ac.hip", "wide.hip", "qmix_gen.hip"]
+SOURCES = ["api.hip", "lbf_kernels.hip", "replay_kernels.hip", "collect.hip", "collect_oid.hip", "dqn_update.hip", "dqn_update_h64.hip", "dqn_update_h64_oid.hip", "dqn_update_h128.hip", "dqn_update_h128_oid.hip", "dqn_update_rware.hip", "dqn_update_h16.hip", "round.hip", "p2p.hip", "rware_kernels.hip", "rware_collect.hip", "rware_collect_big.hip", "rware_collect_p8.hip", "ac_collect.hip", "ac_collect_oid.hip", "a2c.hip", "gru.hip", "gru_ac.hip", "mixed_ac.hip", "wide.hip", "qmix_gen.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 
 

@@ -666,15 +666,26 @@ class AcUpdater:
 
     def __init__(self, spec: NetSpec, block, target_critic, lr=3e-4, betas=(0.9, 0.999), eps=1e-8, gamma=0.99, n_steps=5,
                  entropy_coef=0.001, value_loss_coef=0.5, grad_clip=False, ppo_clip=0.2, standardise_returns=False,
-                 centralised_critic=False, recurrent=False, optimizer="Adam", critic_sharing="actor", critic_n_hidden=None):
-        """critic_sharing: the critics' agent -> network map when critic.parameter_sharing differs from actor.parameter_sharing
+                 centralised_critic=False, recurrent=False, optimizer="Adam", critic_sharing="actor", critic_n_hidden=None, mixed_rnn=None):
+        """mixed_rnn: actor.use_rnn != critic.use_rnn (ac/model.py:45-97 builds the families from their own flags): "actor" = recurrent actors
+        next to feed-forward critics, "critic" = the reverse (marlhip_mixed_*; `recurrent` must then be False).
+        critic_sharing: the critics' agent -> network map when critic.parameter_sharing differs from actor.parameter_sharing
         (ac/model.py:45-97): "actor" (default) = spec.sharing for both, None = one critic per agent, or a tuple of network indices.
         critic_n_hidden: the critics' number of hidden layers when critic.layers is of another length than actor.layers (GEMM-path shapes)"""
         _require_gpu()
         self.optimizer = optimizer_id(optimizer)
         self.recurrent = bool(recurrent)  # use_rnn actors and critics: the marlhip_gru_* entry points, recurrent block layout
-        self._fn = ((lib.marlhip_gru_a2c_loss_grad, lib.marlhip_gru_ppo_prepare, lib.marlhip_gru_ppo_loss_grad) if self.recurrent else
-                    (lib.marlhip_a2c_loss_grad, lib.marlhip_ppo_prepare, lib.marlhip_ppo_loss_grad))
+        if mixed_rnn not in (None, "actor", "critic") or (mixed_rnn and (recurrent or centralised_critic or spec.wide)):
+            raise ValueError("mixed_rnn: 'actor' or 'critic', with independent fused-width critics and recurrent=False")
+        self.mixed_rnn = mixed_rnn
+        self.any_recurrent = self.recurrent or mixed_rnn is not None  # (no kept forward pass, no deferred critics, no CU-share stream)
+        if mixed_rnn:
+            arnn = int(mixed_rnn == "actor")
+            self._fn = tuple((lambda s_, *a, _f=f: _f(s_, arnn, *a)) for f in (lib.marlhip_mixed_a2c_loss_grad, lib.marlhip_mixed_ppo_prepare,
+                                                                              lib.marlhip_mixed_ppo_loss_grad))
+        else:
+            self._fn = ((lib.marlhip_gru_a2c_loss_grad, lib.marlhip_gru_ppo_prepare, lib.marlhip_gru_ppo_loss_grad) if self.recurrent else
+                        (lib.marlhip_a2c_loss_grad, lib.marlhip_ppo_prepare, lib.marlhip_ppo_loss_grad))
         self.centralised = int(bool(centralised_critic))
         self.ret_stats = RunningReturnStats(spec.n_agents, block.device) if standardise_returns else None
         s = spec.c()
@@ -682,6 +693,11 @@ class AcUpdater:
         if self.recurrent:
             self.n_actor = check(lib.marlhip_gru_nparams(ctypes.byref(s)), "gru_nparams")
             self.n_critic = check(lib.marlhip_gru_ac_critic_nparams(ctypes.byref(s), int(bool(centralised_critic))), "gru_ac_critic_nparams")
+        elif mixed_rnn:  # each block in its own family's layout
+            self.critic_n_hidden = 0
+            self.n_actor = check(lib.marlhip_gru_nparams(ctypes.byref(s)), "gru_nparams") if mixed_rnn == "actor" else spec.nparams()
+            self.n_critic = (check(lib.marlhip_ac_critic_nparams(ctypes.byref(s), 0), "ac_critic_nparams") if mixed_rnn == "actor" else
+                             check(lib.marlhip_gru_ac_critic_nparams(ctypes.byref(s), 0), "gru_ac_critic_nparams"))
         else:
             self.n_actor = spec.nparams()
             sc = spec.c()
@@ -741,7 +757,7 @@ class AcUpdater:
     # ---- the actors' forward pass kept by the rollout (marlhip_*_ac_collect_keep; include/marlhip.h) ------------------------------
     def can_keep(self, n_envs, actor_params):
         """fused feed-forward actors, envs in whole blocks of 16, and the rollout sampled with THIS updater's actor block"""
-        return (not self.recurrent and not self.spec.wide and n_envs % 16 == 0 and not _NO_KEEP
+        return (not self.any_recurrent and not self.spec.wide and n_envs % 16 == 0 and not _NO_KEEP
                 and actor_params.data_ptr() == self.actor.data_ptr())
 
     # ---- the critics' half of an A2C update next to the following rollout (marlhip_ac_config.defer_critic_backward) -----------------
@@ -752,7 +768,7 @@ class AcUpdater:
         half idle (one workgroup per block of 16 envs: at most CUs / 2 blocks) and the critics' backward pass at half speed is not longer
         than the rollout (measured on the warehouse, 2048 envs x 500 steps, 128-128: independent critics 3.7 ms against a 7.3 ms rollout,
         52.2 -> 59.8 M env-steps/s; the 284-input centralised critics 7 ms, 38.1 -> 31.1 M: a critic row may cost 1.5 x an actor row)."""
-        if self.recurrent or self.grad_clip or _NO_OVERLAP or self._no_defer:
+        if self.any_recurrent or self.grad_clip or _NO_OVERLAP or self._no_defer:
             return False
         if n_envs is None:
             return True
@@ -819,7 +835,9 @@ class AcUpdater:
     def _workspace(self, T, B):
         if (T, B) not in self._ws:
             s = self.spec.c()
-            if self.recurrent:
+            if self.mixed_rnn:
+                n = check(lib.marlhip_mixed_ac_workspace_bytes(ctypes.byref(s), int(self.mixed_rnn == "actor"), T, B), "mixed_ac_workspace_bytes")
+            elif self.recurrent:
                 n = check(lib.marlhip_gru_ac_workspace_bytes(ctypes.byref(s), self.centralised, T, B), "gru_ac_workspace_bytes")
             else:
                 n = check(lib.marlhip_ac_workspace_bytes_lc(ctypes.byref(s), self.centralised, self.critic_n_hidden, T, B), "ac_workspace_bytes")

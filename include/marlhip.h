@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MARLHIP_VERSION 216
+#define MARLHIP_VERSION 217
 
 int marlhip_version(void);
 const char* marlhip_last_error(void);
@@ -428,6 +428,24 @@ int marlhip_gru_ppo_loss_grad(const marlhip_net_shape* s, const float* actor, co
 int marlhip_gru_ac_forward(const marlhip_net_shape* s, int32_t value_net, const float* params, const float* obs, int64_t agent_stride,
                            int64_t row_stride, int32_t steps, int32_t batch, const float* h_in, float* h_out, float* out, void* workspace,
                            int64_t workspace_bytes /* >= marlhip_forward_workspace_bytes(s) */, void* stream);
+
+/* actor.use_rnn != critic.use_rnn (C-ABI 217).  The reference builds the two families from their own flags (marlbase/ac/model.py:45-97), so a
+ * recurrent actor next to feed-forward critics - or the reverse - is a configuration A2CNetwork / PPONetwork accept.  Same contracts as
+ * marlhip_a2c_loss_grad / marlhip_ppo_prepare / marlhip_ppo_loss_grad with each block in ITS family's layout: actor_rnn != 0 - recurrent actors
+ * (marlhip_gru_nparams) + feed-forward critics (marlhip_ac_critic_nparams(s, 0)); actor_rnn == 0 - feed-forward actors (marlhip_net_nparams) +
+ * recurrent critics (marlhip_gru_ac_critic_nparams(s, 0)).  Independent critics; LBF observation widths (csrc/mixed_ac.hip: MARL_MIXED_AC_SHAPES);
+ * cfg->actor_forward_kept / defer_critic_backward must be 0.  Forward passes for acting / values: the family's own marlhip_gru_ac_forward or
+ * marlhip_ac_forward_rows. */
+int64_t marlhip_mixed_ac_workspace_bytes(const marlhip_net_shape* s, int32_t actor_rnn, int32_t max_len, int32_t batch);
+int marlhip_mixed_a2c_loss_grad(const marlhip_net_shape* s, int32_t actor_rnn, const float* actor, const float* critic, const float* target_critic,
+                                const marlhip_batch* batch, const struct marlhip_ac_config* cfg, void* workspace, int64_t workspace_bytes,
+                                float* actor_grad, float* critic_grad, float* metrics /* [5] */, void* stream);
+int marlhip_mixed_ppo_prepare(const marlhip_net_shape* s, int32_t actor_rnn, const float* actor, const float* critic, const float* target_critic,
+                              const marlhip_batch* batch, const struct marlhip_ac_config* cfg, void* workspace, int64_t workspace_bytes,
+                              void* stream);
+int marlhip_mixed_ppo_loss_grad(const marlhip_net_shape* s, int32_t actor_rnn, const float* actor, const float* critic, const marlhip_batch* batch,
+                                const struct marlhip_ac_config* cfg, void* workspace, int64_t workspace_bytes, float* actor_grad,
+                                float* critic_grad, float* metrics /* [5] */, void* stream);
 
 /* Categorical(logits=logits[p][n]).sample() for every (agent, env) (ac/model.py:147-153), drawn as the fused rollout collector draws
  * it: inverse CDF of the fp32 softmax with the Philox uniform of (env n, episode[n], step t, word 1 + p).  actions: i64 [P][N]. */

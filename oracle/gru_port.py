@@ -101,3 +101,21 @@ def recurrent_ac():
         yield
     finally:
         dp.mlp, dp.split, dp.nparams = saved
+
+
+@contextlib.contextmanager
+def mixed_ac():
+    """oracle.ac_update_port with actor.use_rnn != critic.use_rnn (ac/model.py:45-97: each family built from its own flag): the hooks look at
+    the block they are given - a block of the recurrent layout's size runs the sequence forward from zero hidden states, any other the
+    feed-forward network (the two layouts have different sizes for every (D, H, A))"""
+    saved = dp.mlp, dp.split, dp.nparams
+
+    def is_gru(block, D, H, A):
+        return block.numel() == nparams(D, H, A)
+
+    dp.mlp = lambda block, x, D, H, A: sequence(block, x, D, H, A)[0] if is_gru(block, D, H, A) else saved[0](block, x, D, H, A)
+    dp.split = lambda block, D, H, A: split(block, D, H, A) if is_gru(block, D, H, A) else saved[1](block, D, H, A)
+    try:
+        yield
+    finally:
+        dp.mlp, dp.split, dp.nparams = saved

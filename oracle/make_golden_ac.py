@@ -30,8 +30,12 @@ def build(cls, P, D, A, H, seed, **over):
     centralised = bool(over.pop("centralised", False)) if "centralised" in over else False
     cfg.pop("centralised", None)
     net_cfg = dict(layers=[H, H], parameter_sharing=False, use_orthogonal_init=True, use_rnn=bool(cfg.pop("use_rnn", False)))
+    # actor.use_rnn / critic.use_rnn set separately (ac/model.py:45-97 passes each flag to its own family)
+    actor_rnn, critic_rnn = cfg.pop("actor_rnn", None), cfg.pop("critic_rnn", None)
+    a_cfg = dict(net_cfg, use_rnn=net_cfg["use_rnn"] if actor_rnn is None else bool(actor_rnn))
+    c_cfg = dict(net_cfg, use_rnn=net_cfg["use_rnn"] if critic_rnn is None else bool(critic_rnn), centralised=centralised)
     with contextlib.redirect_stdout(io.StringIO()):
-        net = cls([Box(D)] * P, [Discrete(A)] * P, cfg, Cfg(net_cfg), Cfg(dict(net_cfg, centralised=centralised)), "cpu")
+        net = cls([Box(D)] * P, [Discrete(A)] * P, cfg, Cfg(a_cfg), Cfg(c_cfg), "cpu")
     g = torch.Generator().manual_seed(seed + 1)
     with torch.no_grad():  # non-zero biases, target != critic
         for p in list(net.actor.parameters()) + list(net.critic.parameters()):
@@ -44,7 +48,9 @@ def build(cls, P, D, A, H, seed, **over):
 def fixture(ref_ac_model, ref_ac_train, name, cls, P, D, H, N, seed, masked=False, **over):
     T, A = 25, 6
     net, cfg = build(cls, P, D, A, H, seed, **over)
-    out = dict(P=P, T=T, N=N, D=D, A=A, H=H, n_steps=cfg.n_steps, gamma=cfg.gamma, entropy_coef=cfg.entropy_coef,
+    out = dict(P=P, T=T, N=N, D=D, A=A, H=H, actor_rnn=int(bool(over.get("actor_rnn", over.get("use_rnn", False)))),
+               critic_rnn=int(bool(over.get("critic_rnn", over.get("use_rnn", False)))), state_dict_keys=np.array(list(net.state_dict().keys())),
+               n_steps=cfg.n_steps, gamma=cfg.gamma, entropy_coef=cfg.entropy_coef,
                value_loss_coef=cfg.value_loss_coef, grad_clip=float(cfg.grad_clip or 0.0), num_epochs=cfg.num_epochs,
                ppo_clip=cfg.ppo_clip, actor0=flat_params(net.actor).numpy(), critic0=flat_params(net.critic).numpy(),
                target0=flat_params(net.target_critic).numpy())
@@ -58,7 +64,7 @@ def fixture(ref_ac_model, ref_ac_train, name, cls, P, D, H, N, seed, masked=Fals
             m[:-1].scatter_(-1, b["actions"].unsqueeze(-1), 1.0)
             b["action_masks"] = m
     mk = lambda b: ref_ac_train.Batch(b["obss"], b["actions"], b["rewards"], b["dones"], b["filled"], b.get("action_masks"))  # noqa: E731
-    if cls is ref_ac_model.A2CNetwork and not over.get("use_rnn"):  # gradient of the first update, via a throw-away copy stepped with lr = 0
+    if cls is ref_ac_model.A2CNetwork and not over.get("use_rnn") and not over.get("actor_rnn") and not over.get("critic_rnn"):  # gradient of the first update, via a throw-away copy stepped with lr = 0
         probe, _ = build(cls, P, D, A, H, seed, **dict(over, lr=0.0, grad_clip=False))  # noqa
         probe.update(mk(batches[0]), 1)
         out["actor_grad0"] = torch.stack([torch.cat([p.grad.reshape(-1) for p in m.parameters()]) for m in probe.actor.independent]).numpy()
@@ -106,3 +112,6 @@ if __name__ == "__main__":
     fixture(ram, rat, "learner_ppo_gru_H128.npz", ram.PPONetwork, P=2, D=15, H=128, N=10, seed=1600, use_rnn=True)
     fixture(ram, rat, "learner_maa2c_gru_H64.npz", ram.A2CNetwork, P=2, D=15, H=64, N=11, seed=1700, use_rnn=True, centralised=True)
     fixture(ram, rat, "learner_mappo_gru_p3_H64.npz", ram.PPONetwork, P=3, D=18, H=64, N=9, seed=1800, use_rnn=True, centralised=True)
+    # actor.use_rnn != critic.use_rnn (round 6): recurrent actors next to feed-forward critics, and the reverse
+    fixture(ram, rat, "learner_a2c_rnn_actor_ff_critic_H64.npz", ram.A2CNetwork, P=2, D=15, H=64, N=12, seed=1900, actor_rnn=True, critic_rnn=False)
+    fixture(ram, rat, "learner_ppo_ff_actor_rnn_critic_H64.npz", ram.PPONetwork, P=2, D=15, H=64, N=10, seed=2000, actor_rnn=False, critic_rnn=True)

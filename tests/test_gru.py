@@ -308,6 +308,88 @@ def test_hip_recurrent_actor_critic_matches_reference(name):
             assert diff.max() <= 5e-5 and (diff > 5e-6).mean() <= 1e-4, (diff.max(), (diff > 5e-6).sum())
 
 
+# ---- actor.use_rnn != critic.use_rnn (ac/model.py:45-97 builds each family from its own flag; csrc/mixed_ac.hip) ----------------------------
+AC_MIXED = [("learner_a2c_rnn_actor_ff_critic_H64.npz", "actor"), ("learner_ppo_ff_actor_rnn_critic_H64.npz", "critic")]
+
+
+@pytest.mark.parametrize("name,which", AC_MIXED)
+def test_ac_oracle_port_with_one_recurrent_family_matches_reference(name, which):
+    from oracle import ac_update_port as ap
+
+    g = dict(np.load(os.path.join(G, name)))
+    assert (int(g["actor_rnn"]), int(g["critic_rnn"])) == ((1, 0) if which == "actor" else (0, 1))
+    D, H, A = int(g["D"]), int(g["H"]), int(g["A"])
+    with gp.mixed_ac():
+        lr = ap.Learner(torch.tensor(g["actor0"]), torch.tensor(g["critic0"]), D, H, A, gamma=float(g["gamma"]), n_steps=int(g["n_steps"]),
+                        entropy_coef=float(g["entropy_coef"]), value_loss_coef=float(g["value_loss_coef"]),
+                        num_epochs=int(g["num_epochs"]) if "ppo" in name else 0, ppo_clip=float(g["ppo_clip"]))
+        lr.target = torch.tensor(g["target0"])
+        for i in range(3):
+            m = lr.update(_ac_batch(g, i), int(g["steps"][i]))
+            np.testing.assert_allclose([m["loss"], m["actor_loss"], m["value_loss"], m["entropy"]], g["metrics"][i], rtol=2e-5, atol=2e-6)
+            np.testing.assert_allclose(lr.actor().detach().numpy(), g[f"actor{i + 1}"], rtol=0, atol=3e-6)
+            np.testing.assert_allclose(lr.critic().detach().numpy(), g[f"critic{i + 1}"], rtol=0, atol=3e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,which", AC_MIXED)
+def test_hip_actor_critic_with_one_recurrent_family_matches_reference(name, which):
+    """marlhip_mixed_a2c_loss_grad / marlhip_mixed_ppo_* through A2CNetwork / PPONetwork built with actor.use_rnn != critic.use_rnn: the
+    reference's state_dict keys (recurrent names on one family, network.N on the other), metrics and both blocks after 3 updates"""
+    from collections import namedtuple
+
+    from codebase_amd.ac.model import A2CNetwork, PPONetwork
+    from codebase_amd.spaces import Box, Discrete, Tuple
+
+    Batch = namedtuple("Batch", ["obss", "actions", "rewards", "dones", "filled", "action_masks"])
+    g = dict(np.load(os.path.join(G, name)))
+    P, D, H, A = int(g["P"]), int(g["D"]), int(g["H"]), int(g["A"])
+    ppo = "ppo" in name
+    cfg = dict(optimizer="Adam", lr=3e-4, gamma=float(g["gamma"]), grad_clip=False, n_steps=int(g["n_steps"]), entropy_coef=float(g["entropy_coef"]),
+               value_loss_coef=float(g["value_loss_coef"]), standardise_returns=False, target_update_interval_or_tau=200,
+               num_epochs=int(g["num_epochs"]), ppo_clip=float(g["ppo_clip"]))
+    net_cfg = dict(layers=[H, H], parameter_sharing=False, use_orthogonal_init=True)
+    net = (PPONetwork if ppo else A2CNetwork)(Tuple([Box(-1, 8, (D,))] * P), Tuple([Discrete(A)] * P), cfg, dict(net_cfg, use_rnn=which == "actor"),
+                                             dict(net_cfg, use_rnn=which == "critic", centralised=False), "cuda")
+    assert net.updater.mixed_rnn == which and not net.keeps_actor_forward
+    sd = net.state_dict()
+    assert list(sd.keys()) == [str(k) for k in g["state_dict_keys"]]
+    rec, ff = ("actor", "critic") if which == "actor" else ("critic", "actor")
+    assert f"{rec}.independent.0.rnn.weight_hh_l0" in sd and f"{ff}.independent.1.network.2.weight" in sd
+    assert net.actor_params.shape == g["actor0"].shape and net.critic_params.shape == g["critic0"].shape
+    net.actor_params.copy_(torch.tensor(g["actor0"]))
+    net.critic_params.copy_(torch.tensor(g["critic0"]))
+    net.target_critic_params.copy_(torch.tensor(g["target0"]))
+    # reference-shaped acting / values with the hidden state of the recurrent family only
+    obs = [torch.rand(5, D) for _ in range(P)]
+    acts, hid = net.act(obs, net.init_actor_hiddens(5))
+    v, ch = net.get_value(obs, net.init_critic_hiddens(5))
+    assert acts.shape == (P, 5, 1) and v.shape == (5, P)
+    assert (hid[0] is not None and hid[0].shape == (1, 5, H)) == (which == "actor") and (ch[0] is not None) == (which == "critic")
+    for i in range(3):
+        b = Batch(*(x.cuda() for x in _ac_batch(g, i).values()), None)
+        m = net.update(b._replace(dones=b.dones.float()), int(g["steps"][i]))
+        np.testing.assert_allclose([m["loss"], m["actor_loss"], m["value_loss"], m["entropy"]], g["metrics"][i], rtol=1e-4, atol=1e-5)
+        for got, want in ((net.actor_params, g[f"actor{i + 1}"]), (net.critic_params, g[f"critic{i + 1}"]), (net.target_critic_params, g[f"target{i + 1}"])):
+            diff = np.abs(got.cpu().numpy() - want)
+            assert diff.max() <= 5e-5 and (diff > 5e-6).mean() <= 1e-4, (i, diff.max(), (diff > 5e-6).sum())
+
+
+@pytest.mark.gpu
+def test_ia2c_with_recurrent_actors_and_feed_forward_critics_end_to_end(tmp_path, monkeypatch):
+    """+algorithm=ia2c algorithm.model.actor.use_rnn=True algorithm.model.critic.use_rnn=False (and the reverse, whose rollout is the fused
+    collector's) through run.main"""
+    from codebase_amd import run
+
+    NAME = "lbforaging:Foraging-8x8-2p-3f-v3"
+    for a_rnn, c_rnn in ((True, False), (False, True)):
+        monkeypatch.setenv("MARLHIP_RUN_DIR", str(tmp_path / f"a{int(a_rnn)}c{int(c_rnn)}"))
+        df = run.main(["+algorithm=ia2c", f"env.name={NAME}", "env.time_limit=25", "env.parallel_envs=128", "algorithm.model.actor.layers=[64,64]",
+                       "algorithm.model.critic.layers=[64,64]", f"algorithm.model.actor.use_rnn={a_rnn}", f"algorithm.model.critic.use_rnn={c_rnn}",
+                       "seed=1", "algorithm.total_steps=40000", "algorithm.eval_interval=15000"])
+        assert df.shape[0] >= 2 and np.isfinite(df["loss"]).all() and np.isfinite(df["mean_episode_returns"]).all()
+
+
 @pytest.mark.gpu
 def test_recurrent_ia2c_and_ippo_end_to_end(tmp_path, monkeypatch):
     """+algorithm=ia2c / ippo with use_rnn for actor and critic: recurrent rollout collection (hidden state carried on the device,
