@@ -82,8 +82,16 @@ static __global__ __launch_bounds__(PLAN_THREADS) void update_plan_kernel(marlhi
             const U4 o = philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
             const int s = i & 3;
             e = (int)bounded_nr(s == 0 ? o.x : (s == 1 ? o.y : (s == 2 ? o.z : o.w)), (uint32_t)length);
+            // the episode's `filled` bytes are 0 / 1 (a prefix mask: their count is the stored length): eight at a time through unaligned
+            // 64-bit loads (an episode's row starts at e * T bytes: any alignment) + the tail bytes - 4 loads instead of 25 at T = 25
             const uint8_t* f = rb.filled + (size_t)e * T;
-            for (int t = 0; t < T; ++t) len += f[t] ? 1 : 0;  // (a prefix mask: the count is the length; independent loads)
+            typedef unsigned long long __attribute__((aligned(1))) u64_unaligned;
+            int t = 0;
+            for (; t + 8 <= T; t += 8) {  // non-zero bytes of the word (any non-zero value counts, as in the learner kernel's own test)
+                const unsigned long long w = *reinterpret_cast<const u64_unaligned*>(f + t);
+                len += __popcll((((w & 0x7F7F7F7F7F7F7F7Full) + 0x7F7F7F7F7F7F7F7Full) | w) & 0x8080808080808080ull);
+            }
+            for (; t < T; ++t) len += f[t] ? 1 : 0;
             s_idx[i] = e;
             s_len[i] = (uint8_t)len;
             my_min = len < my_min ? len : my_min;

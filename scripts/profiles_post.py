@@ -119,9 +119,11 @@ def main():
         ("_qmix8p", "qmix:lbforaging:Foraging-15x15-8p-5f-v3:N8192:H128:B8192:T25:rnn0", ("tp_fwd_kernel", "tp_bwd_kernel", "qmix_"),
          {"replay_read_two_passes": 2 * replay_bytes(8, 39, 8192), "h1_h2_activations_write_plus_read": 2 * 2 * 8 * T * 8192 * 128 * 4,
           "mixer_state_rows_read (online + target + weight gradient)": 3 * T * 8192 * 8 * 39 * 4}, ("dqn_update_tp.h", "mlp.h", "qmix.h")),
-        ("_ia2c_rware", "ia2c:rware:rware-tiny-4ag-v2:N2048:H128:T500", ("mlp_rows_fwd_kernel", "a2c_", "tp_bwd_kernel", "ac_"),
+        ("_ia2c_rware", "ia2c:rware:rware-tiny-4ag-v2:N2048:H128:T500", ("mlp_rows_fwd_kernel", "ac_elem_kernel", "ac_metrics_kernel", "tp_bwd_kernel", "dqn_reduce_kernel"),  # (the update stage: not the collector)
          {"rollout_rows_read (critic, target critic, actor backward)": 3 * 4 * 500 * 2048 * 71 * 4,
-          "h1_h2_records_write_plus_read (critics; the actors' are the collector's)": 2 * 2 * 4 * 500 * 2048 * 128 * 4}, ("a2c_core.h", "dqn_update_tp.h", "mlp.h", "mlp_keep.h")))
+          "h1_h2_records_write_plus_read (critics)": 2 * 2 * 4 * 500 * 2048 * 128 * 4,
+          "h1_h2_records_read (actors: written by the collector, outside this stage)": 2 * 4 * 500 * 2048 * 128 * 4,
+          "logits_values_gradients_planes": 4 * 500 * 2048 * (5 + 5 + 1 + 1 + 1 + 1) * 4}, ("a2c_core.h", "dqn_update_tp.h", "mlp.h", "mlp_keep.h")))
     for row in (
             ("", "idqn:lbforaging:Foraging-8x8-2p-3f-v3:N4096:H64:B4096:T25:rnn0", ("dqn_lossgrad_kernel",),
              {"replay_read": alg_read, "partial_records_write": 256 * (5574 + 2) * 4}),

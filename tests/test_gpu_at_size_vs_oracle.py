@@ -5,8 +5,8 @@ comparison was 1/100 of the row count the bench matrix reports.  The right-hand 
 the reference's goldens by the CPU suite), accumulated over column chunks of the batch (oracle/dqn_port.Learner.update(chunks=...): the
 loss is a filled-weighted mean, so the gradient is the sum over chunks - bounded memory at 200k - 1M rows per agent).
 
-Bounds: those of tests/test_gpu_bench_path_vs_oracle.run_case (its docstring has the ReLU-kink / Double-Q-tie argument): loss 1e-5 (3e-5
-through the 8-agent mixer), every gradient entry within 3e-4 of the largest, every parameter within atol + 2 lr n min(1, floor max|g| / |g|)
+Bounds: those of tests/test_gpu_bench_path_vs_oracle.run_case (its docstring has the ReLU-kink / Double-Q-tie argument): loss 1e-5 (also
+through the 8-agent mixer since round 6: observed 8.5e-7), every gradient entry within 3e-4 of the largest, every parameter within atol + 2 lr n min(1, floor max|g| / |g|)
 after n updates and 95 % of them inside plain atol.  Env transitions replayed through the oracle are bit-exact."""
 import numpy as np
 import pytest
@@ -143,8 +143,9 @@ def test_config5_qmix_15x15_8p5f_H128_B8192_through_the_trainer_vs_oracle_port()
         ga, gm = np.abs(port.last_grad.numpy()), np.abs(port.last_mixer_grad.numpy())
         gmin, gmin_m = np.minimum(gmin, ga / ga.max()), np.minimum(gmin_m, gm / gm.max())
     got = trainer.last_loss.cpu().numpy()
-    print(f"[at-size] config 5 QMIX loss: observed relative deviation from the float64 port {abs(got[0] - m['loss']) / abs(m['loss']):.3e} (bound 3e-5; north_star 1e-5)")
-    assert abs(got[0] - m["loss"]) <= 3e-5 * abs(m["loss"]), (got, m)
+    # round 6: the bound is north_star's 1e-5 (it was 3e-5 while the observed value went unrecorded; observed on the full-suite run: 8.5e-7)
+    print(f"[at-size] config 5 QMIX loss: observed relative deviation from the float64 port {abs(got[0] - m['loss']) / abs(m['loss']):.3e} (bound 1e-5 = north_star's)")
+    assert abs(got[0] - m["loss"]) <= 1e-5 * abs(m["loss"]), (got, m)
     assert got[1] == float(host["filled"][torch.as_tensor(idx)].sum())
     assert (model.updates, model.last_target_update) == (port.updates, port.last_target_update) == (3, 2)
     assert_grad_at_size(model.updater.grad.cpu().numpy(), port.last_grad.numpy(), "critic gradient of the last update")
