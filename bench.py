@@ -669,6 +669,8 @@ def multi_gpu_rows(args, rank, world, dist, headline):
     rows = {"exchange_rows": {}, "modes": {}}
     if rank == 0:
         rows["exchange_rows"]["default (MARLHIP_P2P unset): " + headline["rccl_ranks"].get("exchange", "?")] = summary(headline)
+    if os.environ.get("MARLHIP_BENCH_EXTRAS", "1") == "0":  # the headline alone (a driver that wants the shortest possible N > 1 run)
+        return rows
     keep = os.environ.get("MARLHIP_P2P")
     os.environ["MARLHIP_P2P"] = "0"
     try:
@@ -676,14 +678,17 @@ def multi_gpu_rows(args, rank, world, dist, headline):
         r = bench_dqn(a, rank, world, dist, args.steps, args.warmup)
         if rank == 0:
             rows["exchange_rows"]["MARLHIP_P2P=0: " + r["rccl_ranks"].get("exchange", "?")] = summary(r)
+    except Exception as e:  # noqa: BLE001 - a secondary row never takes the headline down (an error every rank raises alike; a rank-local one cannot be caught here)
+        if rank == 0:
+            rows["exchange_rows"]["MARLHIP_P2P=0: error"] = {"error": f"{type(e).__name__}: {e}"}
     finally:
         if keep is None:
             os.environ.pop("MARLHIP_P2P", None)
         else:
             os.environ["MARLHIP_P2P"] = keep
     if rank == 0:
-        shas = [v["params_sha16_rank0"] for v in rows["exchange_rows"].values()]
-        rows["exchange_rows"]["same_final_parameters"] = len(set(shas)) == 1 if world == 2 else None  # (N > 2: the collective's summation order is its own)
+        shas = [v.get("params_sha16_rank0") for v in rows["exchange_rows"].values()]
+        rows["exchange_rows"]["same_final_parameters"] = (len(set(shas)) == 1 and None not in shas) if world == 2 else None  # (N > 2: the collective's summation order is its own)
     for name, over, steps, warmup in (
             ("BASELINE config 4 (per-GPU shard): IA2C rware-tiny-4ag, 2048 envs per rank, 128-128", dict(algo="ia2c", env_name="rware:rware-tiny-4ag-v2", envs=2048, hidden=128, time_limit=500), 16, 2),
             ("BASELINE config 5 (per-GPU shard): QMIX Foraging-15x15-8p-5f, 8192 envs per rank, 128-128, fp32 mixer", dict(algo="qmix", env_name="lbforaging:Foraging-15x15-8p-5f-v3", envs=8192, hidden=128), 2, 1)):
@@ -693,7 +698,14 @@ def multi_gpu_rows(args, rank, world, dist, headline):
         if os.environ.get("MARLHIP_BENCH_SMALL_ROWS"):  # the one-device plumbing test: the same rows at a size two ranks sharing a GPU finish in seconds
             a.envs, a.time_limit = (256, 60) if a.algo == "ia2c" else (256, 25)
             steps, warmup = 3, 1
-        r = bench_ac(a, rank, world, dist, steps, warmup) if a.algo == "ia2c" else bench_dqn(a, rank, world, dist, steps, warmup)
+        try:
+            r = bench_ac(a, rank, world, dist, steps, warmup) if a.algo == "ia2c" else bench_dqn(a, rank, world, dist, steps, warmup)
+        except Exception as e:  # noqa: BLE001
+            if rank == 0:
+                rows["modes"][name] = {"error": f"{type(e).__name__}: {e}"}
+            gc.collect()
+            torch.cuda.empty_cache()
+            continue
         if rank == 0:
             rf = r.get("roofline") or {}
             row = summary(r)

@@ -8,8 +8,10 @@
 
 using namespace marl;
 
-// (obs dim, hidden, actions): LBF widths at hidden 64, the headline's and the 15x15 boards' at hidden 128
-#define MARL_MIXED_AC_SHAPES(X) X(12, 64, 6) X(15, 64, 6) X(18, 64, 6) X(21, 64, 6) X(27, 64, 6) X(15, 128, 6) X(27, 128, 6)
+// (obs dim, hidden, actions): the LBF widths and the warehouse at hidden 64 and 128 (gru_ac.hip's list without the observe_id widths)
+#define MARL_MIXED_AC_SHAPES(X) \
+    X(12, 64, 6) X(15, 64, 6) X(18, 64, 6) X(21, 64, 6) X(24, 64, 6) X(27, 64, 6) X(39, 64, 6) X(12, 128, 6) X(15, 128, 6) X(18, 128, 6) X(21, 128, 6) \
+    X(24, 128, 6) X(27, 128, 6) X(39, 128, 6) X(71, 64, 5) X(71, 128, 5) /* rware */
 
 static int mixed_check(const marlhip_net_shape* s) {
     MARL_REQUIRE(s != nullptr, "net shape is NULL");
