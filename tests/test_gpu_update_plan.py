@@ -161,3 +161,20 @@ def test_planned_updates_are_faster_on_a_ragged_replay():
         us[planned] = 1e3 * ms.value / n.value
     print(f"[plan] loss/grad launch, B = 4096, mean episode length 13: planned {us[True]:.1f} us, static {us[False]:.1f} us")
     assert us[True] < 0.8 * us[False], us
+
+
+def test_more_updates_than_one_planning_launch_holds():
+    """B = 256 leaves room for ~100 plans in the workspace's idle mixer planes: a call of 260 updates plans in three launches (the counter of
+    each chunk continues the stream, the last chunk records the last update's draws) - same parameters as the unplanned call up to summation
+    order, the recorded draws those of update 259"""
+    from codebase_amd import hip as h
+
+    P, D, H, A, T, B, cap, n = 2, 15, 64, 6, 25, 256, 2000, 260
+    host = lbf_like_replay(cap, P, D, T, A, seed=31)
+    a = _run(h, host, P, D, H, A, T, B, cap, n, planned=True, lr=1e-4)
+    b = _run(h, host, P, D, H, A, T, B, cap, n, planned=False, lr=1e-4)
+    np.testing.assert_array_equal(a[5].numpy(), philox_indices(4321, 11 + n - 1, B, cap))
+    assert torch.equal(a[5], b[5]) and float(a[3][1]) == float(b[3][1])
+    # 260 Adam steps amplify last-bit differences of the gradients (lr g / (sqrt(v) + eps)); the trajectories stay together to a few lr
+    assert float((a[0] - b[0]).abs().max()) <= 20 * 1e-4 and float((a[0] - b[0]).abs().mean()) <= 1e-5
+    assert abs(float(a[3][0]) - float(b[3][0])) <= 1e-3 * abs(float(b[3][0]))

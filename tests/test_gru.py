@@ -388,6 +388,12 @@ def test_ia2c_with_recurrent_actors_and_feed_forward_critics_end_to_end(tmp_path
                        "algorithm.model.critic.layers=[64,64]", f"algorithm.model.actor.use_rnn={a_rnn}", f"algorithm.model.critic.use_rnn={c_rnn}",
                        "seed=1", "algorithm.total_steps=40000", "algorithm.eval_interval=15000"])
         assert df.shape[0] >= 2 and np.isfinite(df["loss"]).all() and np.isfinite(df["mean_episode_returns"]).all()
+    # the warehouse's 71-wide rows, 128-128, PPO: recurrent critics next to feed-forward actors
+    monkeypatch.setenv("MARLHIP_RUN_DIR", str(tmp_path / "rware"))
+    df = run.main(["+algorithm=ippo", "env.name=rware:rware-tiny-2ag-v2", "env.time_limit=50", "env.parallel_envs=64", "algorithm.model.actor.layers=[128,128]",
+                   "algorithm.model.critic.layers=[128,128]", "algorithm.model.actor.use_rnn=False", "algorithm.model.critic.use_rnn=True", "seed=2",
+                   "algorithm.total_steps=20000", "algorithm.eval_interval=8000"])
+    assert df.shape[0] >= 2 and np.isfinite(df["loss"]).all()
 
 
 @pytest.mark.gpu
