@@ -46,6 +46,29 @@ __device__ __forceinline__ f4 relu4_one(f4 v) {
 #ifndef MARL_TP_VGPR
 #define MARL_TP_VGPR 0
 #endif
+// MARL_TP_PROF=1 (profiling builds only): s_memtime at the phase boundaries of a pass-F step, averaged per wave and printed by one workgroup at
+// the end of the launch - rows + layer 1 | first barrier | layer 2 | relu + stores + layer 3 | second barrier | epilogue.  What it showed on the
+// round-5 form (scripts/gpu_runs/r6M.sh, 15-wide rows, cycles per step): 2.7 k | 0.1 k (waves 2, 3: 2.0 k) | 7.35 k | 2.75 k | 0.1 k | 2.3 k on the two
+// epilogue waves (0.3 k on the others): 256 of the step's 320 MFMAs sit in the 7.35 k, and the one-wave epilogue - a latency chain of LDS
+// reads, sums, permlane argmax and scattered stores - was 2.3 k of exposed time every step, which the other waves spent at the next barrier.
+#ifndef MARL_TP_PROF
+#define MARL_TP_PROF 0
+#endif
+// MARL_TP_DEFER_EPI=1 (experiment, round 6; OFF): the epilogue of step t runs in step t - 1's iteration, behind its first barrier and in the
+// same scheduling region as its layer-2 MFMAs (the Q partials sit in the LDS set of step t's parity, which nothing writes before step t - 2),
+// so that the latency chain hides under matrix work.  Same sums, same order, same bits (goldens and the config-3 at-size test pass with it on).
+// MEASURED (scripts/gpu_runs/r6N.sh, both variants of one tree on one box): loss/grad group 358.3 -> 367.4 us.  The phase counters say why: the
+// layer-2 region absorbs the epilogue for 1.35 k instead of 2.3 k on its two waves (the other two now wait 1.2 k at the SECOND barrier), but
+// the rows + layer-1 region grows 2.7 k -> 3.9 k on all four - the epilogue's scattered stores sit in front of the next step's row loads in
+// the in-order memory counter.  Splitting the epilogue over two waves per row block (r6K.sh) changed nothing either: it is a latency
+// chain, not work.
+#ifndef MARL_TP_DEFER_EPI
+#define MARL_TP_DEFER_EPI 0
+#endif
+struct TpPend {  // what the epilogue of a step needs from its rows
+    int a_sel;
+    float rw, dn, fl, mk[4];
+};
 // workgroups of pass B per compute unit.  MEASURED (round 6, scripts/gpu_runs/r6G.sh): 2 (launch_bounds(256, 2): 256 registers, 31 spilled,
 // with -DMARL_TP_NB1S_D=0 = one row block per step so that two workgroups' LDS fit) - a second wave per SIMD to hide the barrier / exchange
 // latency - runs tp_bwd at 180.7 us against 175 (IDQN 128-128), VDN 15x15-4p 3.96 -> 3.57 M, and the actor-critic FULL form spills badly
@@ -333,6 +356,9 @@ __global__ __launch_bounds__(64 * W, 1) void tp_fwd_kernel(const float* __restri
 
     const int nsets = (B + 16 * NB - 1) / (16 * NB);
     const int ntasks = nsets * n_chunks;
+#if MARL_TP_PROF
+    unsigned long long tp_sp[7] = {0, 0, 0, 0, 0, 0, 0};
+#endif
     for (int task = blockIdx.x; task < ntasks; task += gridDim.x) {
         const int set = task / n_chunks, c = task - set * n_chunks;
         const int t0 = (c * T) / n_chunks, t1 = ((c + 1) * T) / n_chunks;
@@ -348,18 +374,71 @@ __global__ __launch_bounds__(64 * W, 1) void tp_fwd_kernel(const float* __restri
         TpRows<S, REPLAY> cur[NB];
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) tp_load_rows<S, REPLAY, false>(src, mix, t1, (set * NB + nb) * 16, g, j, ej[nb], eg[nb], cur[nb]);
+        // the epilogue of step `tt` on the Q partials of its LDS set: the block's wave finishes Q (partials summed in wave order), publishes the
+        // mixer inputs of transition tt and the bootstrap value of transition tt - 1
+        TpPend pend[NB];
+        int pend_t = -1;
+        auto epilogue = [&](int tt, const TpPend (&pr)[NB]) {
+            const f4* Qe = reinterpret_cast<const f4*>(lds) + (tt & 1) * SETF + 2 * NB * NT * 64;
+            const f4* Te = Qe + NB * W * 64;
+            const bool need_tt = tt > t0;  // the target value of this step feeds transition tt - 1
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                if (wave != nb % W) continue;
+                const int b0 = (set * NB + nb) * 16;
+                const bool rowok = (b0 + j) < B;
+                const int bj = rowok ? b0 + j : B - 1;
+                f4 q = Qe[(nb * W + 0) * 64 + lane], tq = Te[(nb * W + 0) * 64 + lane];
+#pragma unroll
+                for (int w2 = 1; w2 < W; ++w2) {
+                    q += Qe[(nb * W + w2) * 64 + lane];
+                    tq += Te[(nb * W + w2) * 64 + lane];
+                }
+                if (tt < t1) {
+                    const float ch = gather_rows_pl<A>(q, lane, pr[nb].a_sel);
+                    if (g == 0 && rowok) {
+                        mix.chosen[((size_t)p * T + tt) * B + bj] = ch;
+                        mix.rew[((size_t)p * T + tt) * B + bj] = pr[nb].rw;
+                        if (p == 0) {
+                            mix.dn[(size_t)tt * B + bj] = pr[nb].dn;
+                            mix.fl[(size_t)tt * B + bj] = pr[nb].fl;
+                        }
+                    }
+                }
+                if (need_tt) {
+                    if (!REPLAY && src.mask_p != nullptr) {  // dqn/model.py:136-142
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            if (pr[nb].mk[r] == 0.f) { q[r] = -1e8f; tq[r] = -1e8f; }
+                        }
+                    }
+                    const int a_p = double_q ? argmax_rows_pl<A>(q, lane) : argmax_rows_pl<A>(tq, lane);
+                    const float tv = gather_rows_pl<A>(tq, lane, a_p);
+                    if (g == 0 && rowok) mix.tqsel[((size_t)p * T + (tt - 1)) * B + bj] = tv;
+                }
+            }
+        };
+#if MARL_TP_PROF
+#define MARL_TPP(k) { const unsigned long long now_ = __builtin_readcyclecounter(); tp_sp[k] += now_ - tp_c; tp_c = now_; }
+#else
+#define MARL_TPP(k)
+#endif
         for (int t = t1; t >= t0; --t) {
             TpRows<S, REPLAY> nxt[NB];
+#if MARL_TP_PROF
+            unsigned long long tp_c = __builtin_readcyclecounter();
+            tp_sp[6] += 1;
+#endif
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
                 tp_load_rows<S, REPLAY, false>(src, mix, t > t0 ? t - 1 : t0, (set * NB + nb) * 16, g, j, ej[nb], eg[nb], nxt[nb]);
                 tp_mask_rows<S, REPLAY, false>(cur[nb], (set * NB + nb) * 16, B, g, j);
             }
-            const bool need_t = t > t0;  // the target value of this step feeds transition t-1
             f4* Hc = reinterpret_cast<f4*>(lds) + (t & 1) * SETF;
             f4* Ht = Hc + NB * NT * 64;
             f4* Qp = Ht + NB * NT * 64;
             f4* Tp = Qp + NB * W * 64;
+            const bool st_rec = h2_out != nullptr && t < t1;  // a transition row of this chunk leaves its hidden layers for pass B (t1 itself only bootstraps here)
             // ---- layer 1 of my tiles, dumped for everybody (the 2 NB TPW chains advance together)
             {
                 f4 a1c[NB][TPW], a1t[NB][TPW];
@@ -393,11 +472,14 @@ __global__ __launch_bounds__(64 * W, 1) void tp_fwd_kernel(const float* __restri
                         const f4 h1c = VG ? relu4_settled(a1c[nb][u]) : relu4_one(a1c[nb][u]);
                         Hc[(nb * NT + wave * TPW + u) * 64 + lane] = h1c;
                         Ht[(nb * NT + wave * TPW + u) * 64 + lane] = VG ? relu4_settled(a1t[nb][u]) : relu4_one(a1t[nb][u]);
-                        if (h2_out != nullptr && t < t1)  // the critic's first hidden layer too (behind the h2 record, same layout): pass B recomputes nothing
+                        if (st_rec)  // the critic's first hidden layer too (behind the h2 record, same layout): pass B recomputes nothing
                             h2_out[(size_t)P * T * tp_h2_blocks(B) * NT * 64 + ((((size_t)p * T + t) * tp_h2_blocks(B) + (set * NB + nb)) * NT + wave * TPW + u) * 64 + lane] = h1c;
                     }
             }
+            MARL_TPP(0)
             __syncthreads();
+            MARL_TPP(1)
+            if (MARL_TP_DEFER_EPI && pend_t >= 0) epilogue(pend_t, pend);  // (no scheduling barrier towards the MFMAs below)
             // ---- layer 2 of my tiles + my split-K share of layer 3.  The (row block, owned tile, network) chains - 2 NB TPW of them - advance
             // together, k ascending in each (bitwise the order of the one-chain-at-a-time form): no MFMA waits for its own predecessor
             {
@@ -435,6 +517,7 @@ __global__ __launch_bounds__(64 * W, 1) void tp_fwd_kernel(const float* __restri
                     }
                 }
                 if constexpr (VG) tp_settle8(acc, acct);
+                MARL_TPP(2)
                 f4 q[NB], tq[NB];
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
@@ -443,7 +526,7 @@ __global__ __launch_bounds__(64 * W, 1) void tp_fwd_kernel(const float* __restri
                     for (int u = 0; u < TPW; ++u) {
                         acc[nb][u] = VG ? relu4_settled(acc[nb][u]) : relu4_one(acc[nb][u]);
                         acct[nb][u] = VG ? relu4_settled(acct[nb][u]) : relu4_one(acct[nb][u]);
-                        if (h2_out != nullptr && t < t1)  // a transition row of this chunk (t1 itself only bootstraps here)
+                        if (st_rec)
                             h2_out[((((size_t)p * T + t) * tp_h2_blocks(B) + (set * NB + nb)) * NT + wave * TPW + u) * 64 + lane] = acc[nb][u];
                     }
                 }
@@ -462,52 +545,35 @@ __global__ __launch_bounds__(64 * W, 1) void tp_fwd_kernel(const float* __restri
                     Tp[(nb * W + wave) * 64 + lane] = tq[nb];
                 }
             }
+            MARL_TPP(3)
             __syncthreads();
-            // ---- wave nb finishes the Q of row block nb (partials summed in wave order) and publishes the mixer inputs (one wave per block:
-            // the blocks' epilogues run side by side instead of one after the other on wave 0)
-            {
+            MARL_TPP(4)
+            // ---- the step's epilogue: deferred into the next iteration (MARL_TP_DEFER_EPI), or here
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) {
-                    if (wave != nb % W) continue;
-                    const int b0 = (set * NB + nb) * 16;
-                    const bool rowok = (b0 + j) < B;
-                    const int bj = rowok ? b0 + j : B - 1;
-                    f4 q = Qp[(nb * W + 0) * 64 + lane], tq = Tp[(nb * W + 0) * 64 + lane];
+            for (int nb = 0; nb < NB; ++nb) {
+                pend[nb].a_sel = cur[nb].a_sel; pend[nb].rw = cur[nb].rw; pend[nb].dn = cur[nb].dn; pend[nb].fl = cur[nb].fl;
 #pragma unroll
-                    for (int w2 = 1; w2 < W; ++w2) {
-                        q += Qp[(nb * W + w2) * 64 + lane];
-                        tq += Tp[(nb * W + w2) * 64 + lane];
-                    }
-                    if (t < t1) {
-                        const float ch = gather_rows_pl<A>(q, lane, cur[nb].a_sel);
-                        if (g == 0 && rowok) {
-                            mix.chosen[((size_t)p * T + t) * B + bj] = ch;
-                            mix.rew[((size_t)p * T + t) * B + bj] = cur[nb].rw;
-                            if (p == 0) {
-                                mix.dn[(size_t)t * B + bj] = cur[nb].dn;
-                                mix.fl[(size_t)t * B + bj] = cur[nb].fl;
-                            }
-                        }
-                    }
-                    if (need_t) {
-                        if (!REPLAY && src.mask_p != nullptr) {  // dqn/model.py:136-142
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                if (cur[nb].mk[r] == 0.f) { q[r] = -1e8f; tq[r] = -1e8f; }
-                            }
-                        }
-                        const int a_p = double_q ? argmax_rows_pl<A>(q, lane) : argmax_rows_pl<A>(tq, lane);
-                        const float tv = gather_rows_pl<A>(tq, lane, a_p);
-                        if (g == 0 && rowok) mix.tqsel[((size_t)p * T + (t - 1)) * B + bj] = tv;
-                    }
-                }
+                for (int r = 0; r < 4; ++r) pend[nb].mk[r] = cur[nb].mk[r];
+            }
+            if (MARL_TP_DEFER_EPI) {
+                pend_t = t;
+            } else {
+                epilogue(t, pend);
             }
             // (no barrier: the next step works on the other LDS set)
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) cur[nb] = nxt[nb];
+            MARL_TPP(5)
         }
+        if (MARL_TP_DEFER_EPI && pend_t >= 0) epilogue(pend_t, pend);  // the chunk's last step
         __syncthreads();  // the next task may start on either set
     }
+#if MARL_TP_PROF
+    if (blockIdx.x == 7 && blockIdx.y == 0 && lane == 0 && tp_sp[6] > 0)
+        printf("TPPROF wave %d steps %llu: rows+L1 %llu | barrier1 %llu | (epilogue+)L2 %llu | relu+store+L3 %llu | barrier2 %llu | tail %llu (cycles per step)\n", wave,
+               tp_sp[6], tp_sp[0] / tp_sp[6], tp_sp[1] / tp_sp[6], tp_sp[2] / tp_sp[6], tp_sp[3] / tp_sp[6], tp_sp[4] / tp_sp[6], tp_sp[5] / tp_sp[6]);
+#endif
+#undef MARL_TPP
 }
 
 // dynamic LDS of tp_bwd_kernel in floats: Hc | [HcT | G2] | per-wave tiles | (STORED) a second [HcT | G2] set

@@ -86,6 +86,48 @@ def test_env_reset_step_bit_exact_vs_oracle(name, coop):
         assert not alive.any()  # time_limit 25 ends every episode
 
 
+@pytest.mark.parametrize("name,coop,N", [("lbforaging:Foraging-8x8-2p-3f-v3", False, 2048), ("lbforaging:Foraging-15x15-4p-5f-v3", True, 1024)])
+def test_env_hundred_thousand_transitions_vs_the_python_oracle(name, coop, N):
+    """the INDEPENDENT comparison at scale (the million-transition test below runs the kernels against a g++ build of
+    their own header): every env of a bench-sized batch, two episodes each, stepped next to its own oracle/lbf.py instance - state bytes,
+    observations, rewards, done / truncated flags, episode statistics, ~100k / ~50k transitions per case"""
+    env, cfg = make_env(name, N, seed=1234, coop=coop)
+    P = env.P
+    rng = np.random.default_rng(11)
+    total = 0
+    for episode in range(2):
+        obs = env.reset().cpu().numpy()
+        state = env.state.cpu().numpy()
+        orc = [oracle_env(name, cfg) for _ in range(N)]
+        o0 = [e.reset(DrawStream(cfg["seed"], n, episode))[0] for n, e in enumerate(orc)]
+        np.testing.assert_array_equal(np.stack([pack_state(e.env) for e in orc]), state)
+        np.testing.assert_array_equal(np.stack([np.stack(o) for o in o0]).transpose(1, 0, 2), obs)
+        alive = np.ones(N, bool)
+        for t in range(25):
+            acts = rng.integers(0, 6, size=(P, N)).astype(np.int32)
+            o_d, r_d, d_d, tr_d = (x.cpu().numpy() for x in env.step(torch.tensor(acts, device=DEV), active=torch.tensor(alive.astype(np.uint8), device=DEV)))
+            state = env.state.cpu().numpy()
+            finr, finl = env.fin_return.cpu().numpy(), env.fin_length.cpu().numpy()
+            idx = np.nonzero(alive)[0]
+            assert not d_d[~alive].any() and not tr_d[~alive].any() and not r_d[:, ~alive].any()
+            outs = [orc[n].step([int(a) for a in acts[:, n]]) for n in idx]
+            np.testing.assert_array_equal(np.stack([pack_state(orc[n].env) for n in idx]), state[idx])
+            np.testing.assert_array_equal(np.stack([np.stack(o[0]) for o in outs]).transpose(1, 0, 2), o_d[:, idx])
+            np.testing.assert_array_equal(np.array([o[1] for o in outs], dtype=np.float32).T, r_d[:, idx])
+            np.testing.assert_array_equal(np.array([o[2] for o in outs]), d_d[idx].astype(bool))
+            np.testing.assert_array_equal(np.array([o[3] for o in outs]), tr_d[idx].astype(bool))
+            total += len(idx)
+            for n, o in zip(idx, outs):
+                if o[2] or o[3]:
+                    alive[n] = False
+                    np.testing.assert_array_equal(o[4]["episode_returns"].astype(np.float32), finr[:, n])
+                    assert o[4]["episode_length"] == finl[n]
+            if not alive.any():
+                break
+        assert not alive.any()
+    assert total > 40 * N
+
+
 def test_env_million_transitions_vs_host_core():
     """>= 1e6 (state, joint action) pairs: the kernels against a g++ build of the same env core
     (which tests/test_lbf_core_host.py pins to the oracle), plus size-independent invariants."""
