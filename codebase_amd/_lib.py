@@ -116,6 +116,7 @@ PROTOTYPES = {
                                            c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                            c_void_p]),
     "marlhip_gru_nparams": (c_int32, [POINTER(NetShape)]),
+    "marlhip_gru_forward_workspace_bytes": (c_int64, [POINTER(NetShape), c_int32, c_int32]),
     "marlhip_gru_record_floats": (c_int64, [POINTER(NetShape), c_int32, c_int32]),
     "marlhip_gru_forward": (c_int32, [POINTER(NetShape), c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_void_p, c_int64, c_void_p]),

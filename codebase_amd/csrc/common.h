@@ -186,12 +186,15 @@ inline int rw_validate(const marlhip_rware_config* c) {
 struct AgentMap {
     int nblk;         // number of parameter blocks (networks)
     int8_t net[16];
+    int8_t depth;     // recurrent networks: stacked GRU layers, len(layers) - 1 (gru_stack.h); unused by the feed-forward kernels
 };
 
 inline AgentMap agent_map(const marlhip_net_shape* s) {
     AgentMap m;
     m.nblk = s->n_networks > 0 ? s->n_networks : s->n_agents;
     for (int i = 0; i < 16; ++i) m.net[i] = (int8_t)(s->n_networks > 0 ? (i < s->n_agents ? s->net_of[i] : 0) : i);
+    const int depth = (s->n_hidden > 0 ? s->n_hidden : 2) - 1;
+    m.depth = (int8_t)(depth < 1 ? 1 : (depth > 16 ? 16 : depth));
     return m;
 }
 

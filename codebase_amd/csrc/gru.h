@@ -28,6 +28,12 @@ struct GruShape {
     static constexpr int oW1 = 0, ob1 = oW1 + H_ * D_, oWih = ob1 + H_, oWhh = oWih + 3 * H_ * H_, obih = oWhh + 3 * H_ * H_,
                          obhh = obih + 3 * H_, oW3 = obhh + 3 * H_, ob3 = oW3 + A_ * H_;
     static constexpr int NPARAM = ob3 + A_;
+    // stacked recurrent layers (`layers = [h] * (L + 1)`: nn.GRU(num_layers = L), marlbase/utils/models.py:74-90): parameters() lists layer
+    // l's (weight_ih, weight_hh, bias_ih, bias_hh) behind layer l - 1's, the final layer last.  Every layer runs these same kernels as a
+    // one-layer network whose block starts l * LAYER floats into the agent's: its gate matrices and biases then sit at oWih .. obhh, the
+    // first layer's W1 at oW1 (l = 0) and the final layer at oW3 (l = L - 1); the parts a layer does not own are packed (in bounds) and unused.
+    static constexpr int LAYER = 6 * H_ * H_ + 6 * H_;
+    static constexpr int nparam(int layers) { return NPARAM + (layers - 1) * LAYER; }
     // forward pack: A1[MT][KS1/4][64][4] | Gi[3][MT][MT][64][4] | Gh[3][MT][MT][64][4] | A3[MT][64][4] | b1[H] | bih[3H] | bhh[3H] | b3[16]
     static constexpr int pA1 = 0, pGi = pA1 + MT * KS1 * 64, pGh = pGi + 3 * MT * MT * 256, pA3 = pGh + 3 * MT * MT * 256,
                          pb1 = pA3 + MT * 256, pbih = pb1 + H_, pbhh = pbih + 3 * H_, pb3 = pbhh + 3 * H_;
@@ -79,9 +85,10 @@ __device__ __forceinline__ float gru_fwd_pack_elem(const float* __restrict__ w, 
 }
 
 template <class S>
-__global__ __launch_bounds__(256) void gru_pack_kernel(const float* __restrict__ params, AgentMap am, float* __restrict__ packs) {
+__global__ __launch_bounds__(256) void gru_pack_kernel(const float* __restrict__ params, AgentMap am, float* __restrict__ packs, int block_floats = S::NPARAM,
+                                                       int layer_off = 0) {
     const int p = blockIdx.y, idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx < S::NFWD) packs[(size_t)p * S::NFWD + idx] = gru_fwd_pack_elem<S>(params + (size_t)am.net[p] * S::NPARAM, idx);
+    if (idx < S::NFWD) packs[(size_t)p * S::NFWD + idx] = gru_fwd_pack_elem<S>(params + (size_t)am.net[p] * block_floats + layer_off, idx);
 }
 
 // Gate nonlinearities on the hardware transcendental units: v_exp_f32 (2^x) and v_rcp_f32, 1 ulp each - 5 / 6 VALU instructions per
@@ -126,10 +133,12 @@ __device__ __forceinline__ void gru_gate(const f4* G /* [MT][MT][64] chunk */, c
 // obs: row (t, b) of agent p at obs + p * obs_as + (t * B + b) * obs_rs (dqn/train.py Batch [P][S][B][D]: as = S*B*D, rs = D; the
 // ac/train.py Batch [S][B][P*D]: as = D, rs = P*D); q: [P][S][B][A], h_in / h_out: [P][B][H] or NULL,
 // rec: [P][S][nblk][REC] or NULL (nblk = ceil(B / 16))
+// x_in (stacked layers, layer l >= 1): the record of the layer below - this layer's input x1[t] is that layer's h[t] (no first linear
+// layer, no ReLU); q_out NULL: no final layer (every layer but the last)
 template <class S>
 __device__ __forceinline__ void gru_seq_fwd_body(const float* __restrict__ packs, const float* __restrict__ obs, size_t obs_as, size_t obs_rs,
                                                  int steps, int B, const float* __restrict__ h_in, float* __restrict__ h_out,
-                                                 float* __restrict__ q_out, float* __restrict__ rec) {
+                                                 float* __restrict__ q_out, float* __restrict__ rec, const float* __restrict__ x_in = nullptr) {
     constexpr int MT = S::MT, D = S::D, H = S::H, A = S::A;
     constexpr bool STREAM = S::STREAM;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -203,6 +212,12 @@ __device__ __forceinline__ void gru_seq_fwd_body(const float* __restrict__ packs
         t_now = t;
         asm volatile("" ::: "memory");  // the packs never change, so the compiler would hoist every weight read out of the time
                                         // loop (and spill ~1 KB per lane): re-read them from LDS each step
+        f4 x1[MT];
+        if (x_in != nullptr) {
+            const f4* Rb = reinterpret_cast<const f4*>(x_in + (((size_t)p * steps + t) * nblk + (active ? blk : nblk - 1)) * S::REC);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) x1[mt] = Rb[(4 * MT + mt) * 64 + lane];
+        } else {
         const float* xrow = obs + (size_t)p * obs_as + ((size_t)t * B + bj) * obs_rs;  // row (t, b) of agent p
         float x[S::KS1];
 #pragma unroll
@@ -211,7 +226,6 @@ __device__ __forceinline__ void gru_seq_fwd_body(const float* __restrict__ packs
             x[ks] = (d < D && rowok) ? xrow[d < D ? d : D - 1] : 0.f;
         }
         // x1 = relu(W1 x + b1)
-        f4 x1[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) x1[mt] = *reinterpret_cast<const f4*>(lb1 + 16 * mt + 4 * g);
 #pragma unroll
@@ -226,6 +240,7 @@ __device__ __forceinline__ void gru_seq_fwd_body(const float* __restrict__ packs
         }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) x1[mt] = relu4(x1[mt]);
+        }
         // gates (torch.nn.GRU): r, z, n
         f4 gi[MT], gh[MT], rg[MT], zg[MT], ng[MT], ghn[MT];
         gru_gate<S>(gate_chunk(0, 0), lbih + 0 * H, lane, x1, gi);
@@ -255,6 +270,7 @@ __device__ __forceinline__ void gru_seq_fwd_body(const float* __restrict__ packs
                 R[(5 * MT + mt) * 64 + lane] = ghn[mt];
             }
         }
+        if (q_out == nullptr) continue;  // (uniform: a layer below the last)
         // q = W3 h + b3
         f4 q = *reinterpret_cast<const f4*>(lb3 + 4 * g);
 #pragma unroll
@@ -279,8 +295,9 @@ __device__ __forceinline__ void gru_seq_fwd_body(const float* __restrict__ packs
 template <class S>
 __global__ __launch_bounds__(256) void gru_seq_fwd_kernel(const float* __restrict__ packs, const float* __restrict__ obs, size_t obs_as,
                                                           size_t obs_rs, int steps, int B, const float* __restrict__ h_in,
-                                                          float* __restrict__ h_out, float* __restrict__ q_out, float* __restrict__ rec) {
-    gru_seq_fwd_body<S>(packs, obs, obs_as, obs_rs, steps, B, h_in, h_out, q_out, rec);
+                                                          float* __restrict__ h_out, float* __restrict__ q_out, float* __restrict__ rec,
+                                                          const float* __restrict__ x_in = nullptr) {
+    gru_seq_fwd_body<S>(packs, obs, obs_as, obs_rs, steps, B, h_in, h_out, q_out, rec, x_in);
 }
 
 // Two independent passes over the same observations in one launch (blockIdx.z): the online networks (with the activation record) and
@@ -289,10 +306,13 @@ __global__ __launch_bounds__(256) void gru_seq_fwd_kernel(const float* __restric
 template <class S>
 __global__ __launch_bounds__(256) void gru_seq_fwd2_kernel(const float* __restrict__ packs, const float* __restrict__ packs2,
                                                            const float* __restrict__ obs, size_t obs_as, size_t obs_rs, int steps, int steps2, int B,
-                                                           float* __restrict__ q_out, float* __restrict__ q_out2, float* __restrict__ rec) {
+                                                           float* __restrict__ q_out, float* __restrict__ q_out2, float* __restrict__ rec,
+                                                           float* __restrict__ rec_second = nullptr, const float* __restrict__ x_in = nullptr,
+                                                           const float* __restrict__ x_in2 = nullptr) {
+    // rec_second / x_in / x_in2: stacked layers - the second pass keeps a record too where a layer above reads its h[t] from it
     const bool second = blockIdx.z == 1;
     gru_seq_fwd_body<S>(second ? packs2 : packs, obs, obs_as, obs_rs, second ? steps2 : steps, B, nullptr, nullptr, second ? q_out2 : q_out,
-                        second ? nullptr : rec);
+                        second ? rec_second : rec, second ? x_in2 : x_in);
 }
 
 }  // namespace marl

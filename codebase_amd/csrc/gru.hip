@@ -1,5 +1,5 @@
 // extern "C" entry points of the recurrent (use_rnn) Q-network path; kernels in gru.h / gru_bwd.h
-#include "gru_bwd.h"
+#include "gru_stack.h"
 #include "collect_common.h"
 
 using namespace marl;
@@ -13,7 +13,9 @@ using namespace marl;
 
 static int gru_check(const marlhip_net_shape* s) {
     MARL_REQUIRE(s != nullptr, "net shape is NULL");
-    if (agent_map_validate(s) != 0) return -1;
+    if (agent_map_validate(s, true) != 0) return -1;
+    MARL_REQUIRE(gru_depth(s) >= 1 && gru_depth(s) <= GRU_MAX_LAYERS, "recurrent networks: n_hidden %d = %d stacked GRU layers (1..%d: layers = [h] * 2 .. [h] * %d)",
+                 s->n_hidden, gru_depth(s), GRU_MAX_LAYERS, GRU_MAX_LAYERS + 1);
 #define X(d, h, a) if (s->obs_dim == d && s->hidden == h && s->n_actions == a) return 0;
     MARL_GRU_SHAPES(X)
 #undef X
@@ -23,7 +25,7 @@ static int gru_check(const marlhip_net_shape* s) {
 
 extern "C" int marlhip_gru_nparams(const marlhip_net_shape* s) {
     if (gru_check(s) != 0) return -1;
-#define X(d, h, a) if (s->obs_dim == d && s->hidden == h && s->n_actions == a) return GruShape<d, h, a>::NPARAM;
+#define X(d, h, a) if (s->obs_dim == d && s->hidden == h && s->n_actions == a) return GruShape<d, h, a>::nparam(gru_depth(s));
     MARL_GRU_SHAPES(X)
 #undef X
     return -1;
@@ -31,16 +33,23 @@ extern "C" int marlhip_gru_nparams(const marlhip_net_shape* s) {
 
 extern "C" int64_t marlhip_gru_record_floats(const marlhip_net_shape* s, int32_t steps, int32_t batch) {
     if (gru_check(s) != 0) return -1;
-    return (int64_t)s->n_agents * steps * ((batch + 15) / 16) * (s->hidden == 64 ? GruShape<15, 64, 6>::REC : GruShape<15, 128, 6>::REC);  // REC depends on H only
+    return (int64_t)gru_depth(s) * s->n_agents * steps * ((batch + 15) / 16) * (s->hidden == 64 ? GruShape<15, 64, 6>::REC : GruShape<15, 128, 6>::REC);  // REC depends on H only
 }
+
+// floats of scratch behind the packs: the chain records of a stack (layers 0 .. L-2) when the caller keeps no record of its own
+template <class S>
+static int64_t gru_forward_chain_floats(int P, int L, int steps, int B) { return L > 1 ? (L - 1) * gru_layer_rec<S>(P, steps, B) : 0; }
 
 template <class S>
 static int gru_forward(const marlhip_net_shape* s, const float* params, const float* obs, int steps, int B, const float* h_in, float* h_out,
                        float* q_out, float* rec, hipStream_t st) {
-    const int P = s->n_agents;
-    float* packs = collect_pack_scratch((size_t)P * S::NFWD * sizeof(float), st);
+    const int P = s->n_agents, L = gru_depth(s);
+    const size_t pack_bytes = ((size_t)L * P * S::NFWD * sizeof(float) + 255) & ~(size_t)255;
+    const size_t chain_bytes = rec != nullptr ? 0 : (size_t)gru_forward_chain_floats<S>(P, L, steps, B) * sizeof(float);
+    float* packs = collect_pack_scratch(pack_bytes + chain_bytes, st);
     if (packs == nullptr) return -1;  // error text set by collect_pack_scratch
-    hipLaunchKernelGGL((gru_pack_kernel<S>), dim3((S::NFWD + 255) / 256, P), dim3(256), 0, st, params, agent_map(s), packs);
+    float* chain = rec != nullptr ? rec : (chain_bytes ? reinterpret_cast<float*>(reinterpret_cast<char*>(packs) + pack_bytes) : nullptr);
+    gru_pack_fwd_layers<S>(P, L, params, agent_map(s), packs, st);
     MARL_CHECK_LAUNCH("gru_pack_kernel");
     const size_t lds = (size_t)S::LDS_FLOATS * sizeof(float);
     static LdsAttr attr;
@@ -48,10 +57,23 @@ static int gru_forward(const marlhip_net_shape* s, const float* params, const fl
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_seq_fwd_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr.done();
     }
-    hipLaunchKernelGGL((gru_seq_fwd_kernel<S>), dim3((B + 63) / 64, P), dim3(256), lds, st, (const float*)packs, obs, (size_t)steps * B * S::D,
-                       (size_t)S::D, steps, B, h_in, h_out, q_out, rec);
+    gru_fwd_layers<S>(P, L, packs, obs, (size_t)steps * B * S::D, (size_t)S::D, steps, B, h_in, h_out, q_out, chain, rec != nullptr, st);
     MARL_CHECK_LAUNCH("gru_seq_fwd_kernel");
     return 0;
+}
+
+extern "C" int64_t marlhip_gru_forward_workspace_bytes(const marlhip_net_shape* s, int32_t steps, int32_t batch) {
+    if (s == nullptr || steps < 1 || batch < 1) {
+        set_error("gru_forward_workspace_bytes: bad argument");
+        return -1;
+    }
+    if (agent_map_validate(s, true) != 0) return -1;
+    const int L = gru_depth(s);
+    MARL_REQUIRE(L >= 1 && L <= GRU_MAX_LAYERS, "gru_forward_workspace_bytes: %d stacked GRU layers (1..%d)", L, GRU_MAX_LAYERS);
+    const int64_t packs = marlhip_forward_workspace_bytes(s);  // one layer's packs (two sets, own or concatenated observations)
+    if (packs < 0) return -1;
+    const int64_t rec = s->hidden <= 64 ? GruShape<15, 64, 6>::REC : GruShape<15, 128, 6>::REC;  // REC depends on H only
+    return L * packs + (int64_t)(L - 1) * s->n_agents * steps * ((batch + 15) / 16) * rec * 4 + 1024;
 }
 
 extern "C" int marlhip_gru_forward(const marlhip_net_shape* s, const float* params, const float* obs, int32_t steps, int32_t batch,
@@ -70,12 +92,12 @@ extern "C" int marlhip_gru_forward(const marlhip_net_shape* s, const float* para
 // ---- learner step: QNetwork._compute_loss / VDNetwork._compute_loss + backward with recurrent networks ----------------------
 namespace {
 struct GruWs {
-    int64_t q, tq, dq, lrow, rec, rec2, partials, packC, packT, packB, total;
+    int64_t q, tq, dq, lrow, rec, recT, rec2, partials, packC, packT, packB, total;
     int nwg;
 };
 
 template <class S>
-GruWs gru_ws_layout(int P, int T, int B) {
+GruWs gru_ws_layout(int P, int T, int B, int L) {
     const int64_t steps = T + 1, nblk = (B + 15) / 16;
     GruWs w;
     int64_t off = 0;
@@ -84,15 +106,16 @@ GruWs gru_ws_layout(int P, int T, int B) {
     w.tq = take(P * steps * B * S::A);
     w.dq = take(P * steps * B * S::A);
     w.lrow = take((int64_t)T * B);
-    w.rec = take(P * steps * nblk * S::REC);
-    w.rec2 = take(P * steps * nblk * GruBwd<S>::REC2);
+    w.rec = take(L * P * steps * nblk * S::REC);
+    w.recT = take((L - 1) * P * steps * nblk * S::REC);  // the target networks' chain through a stack
+    w.rec2 = take(L * P * steps * nblk * GruBwd<S>::REC2);
     const int64_t items = steps * nblk;
     const int cap = 256 / P > 1 ? 256 / P : 1;
     w.nwg = (int)(items < cap ? items : cap);
-    w.partials = take((int64_t)P * w.nwg * (S::NPARAM + 2));
-    w.packC = take((int64_t)P * S::NFWD);
-    w.packT = take((int64_t)P * S::NFWD);
-    w.packB = take((int64_t)P * GruBwd<S>::NBWD);
+    w.partials = take((int64_t)P * w.nwg * (S::nparam(L) + 2));
+    w.packC = take((int64_t)L * P * S::NFWD);
+    w.packT = take((int64_t)L * P * S::NFWD);
+    w.packB = take((int64_t)L * P * GruBwd<S>::NBWD);
     w.total = off;
     return w;
 }
@@ -101,15 +124,15 @@ template <class S>
 int gru_loss_grad(const marlhip_net_shape* s, const float* params, const float* target, const marlhip_batch* bt, float gamma, int double_q,
                   int mode, void* ws, int64_t ws_bytes, float* grad, float* loss, hipStream_t st, const RetStats* rst = nullptr) {
     using Bk = GruBwd<S>;
-    const int P = s->n_agents, T = bt->max_len, B = bt->batch, steps = T + 1;
-    const GruWs wl = gru_ws_layout<S>(P, T, B);
+    const int P = s->n_agents, T = bt->max_len, B = bt->batch, steps = T + 1, L = gru_depth(s);
+    const GruWs wl = gru_ws_layout<S>(P, T, B, L);
     MARL_REQUIRE(ws_bytes >= wl.total, "gru_loss_grad: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)wl.total);
     char* base = static_cast<char*>(ws);
     auto f = [&](int64_t o) { return reinterpret_cast<float*>(base + o); };
     const AgentMap am = agent_map(s);
-    hipLaunchKernelGGL((gru_pack_kernel<S>), dim3((S::NFWD + 255) / 256, P), dim3(256), 0, st, params, am, f(wl.packC));
-    hipLaunchKernelGGL((gru_pack_kernel<S>), dim3((S::NFWD + 255) / 256, P), dim3(256), 0, st, target, am, f(wl.packT));
-    hipLaunchKernelGGL((gru_bwd_pack_kernel<S>), dim3((Bk::NBWD + 255) / 256, P), dim3(256), 0, st, params, am, f(wl.packB));
+    gru_pack_fwd_layers<S>(P, L, params, am, f(wl.packC), st);
+    gru_pack_fwd_layers<S>(P, L, target, am, f(wl.packT), st);
+    gru_pack_bwd_layers<S>(P, L, params, am, f(wl.packB), st);
     MARL_CHECK_LAUNCH("gru pack kernels");
     const size_t ldsF = (size_t)S::LDS_FLOATS * sizeof(float), ldsB = (size_t)Bk::LDS_FLOATS * sizeof(float);
     const size_t ldsW = gru_wgrad_lds_bytes<S>();
@@ -122,8 +145,7 @@ int gru_loss_grad(const marlhip_net_shape* s, const float* params, const float* 
     }
     const dim3 gridS((B + 63) / 64, P);
     timing_begin(TIMER_LOSSGRAD, st);
-    hipLaunchKernelGGL((gru_seq_fwd2_kernel<S>), dim3(gridS.x, gridS.y, 2), dim3(256), ldsF, st, (const float*)f(wl.packC), (const float*)f(wl.packT), bt->obss,
-                       (size_t)steps * B * S::D, (size_t)S::D, steps, steps, B, f(wl.q), f(wl.tq), f(wl.rec));
+    gru_fwd2_layers<S>(P, L, f(wl.packC), f(wl.packT), bt->obss, (size_t)steps * B * S::D, (size_t)S::D, steps, steps, B, f(wl.q), f(wl.tq), f(wl.rec), f(wl.recT), st);
     MARL_CHECK_LAUNCH("gru_seq_fwd_kernel");
     (void)hipMemsetAsync(f(wl.dq), 0, (size_t)P * steps * B * S::A * sizeof(float), st);
     if (rst != nullptr) {
@@ -161,13 +183,13 @@ int gru_loss_grad(const marlhip_net_shape* s, const float* params, const float* 
                            gamma, double_q, mode == 1 ? 1 : 0, f(wl.dq), f(wl.lrow));
     }
     MARL_CHECK_LAUNCH("gru_td_kernel");
-    gru_launch_seq_bwd<S>(P, B, (const float*)f(wl.packB), steps, (const float*)f(wl.rec), (const float*)f(wl.dq), f(wl.rec2), st);
+    gru_bwd_layers<S>(P, L, f(wl.packB), steps, B, f(wl.rec), f(wl.dq), f(wl.rec2), st, true);
     MARL_CHECK_LAUNCH("gru_seq_bwd_kernel");
-    hipLaunchKernelGGL((gru_wgrad_kernel<S>), dim3(wl.nwg, P, gru_wgrad_roles<S>()), dim3(256), ldsW, st, steps, B, bt->obss, (size_t)steps * B * S::D, (size_t)S::D, (const float*)f(wl.rec), (const float*)f(wl.rec2),
-                       (const float*)f(wl.dq), (const float*)f(wl.lrow), bt->filled, T, f(wl.partials));
+    gru_wgrad_layers<S>(P, L, wl.nwg, steps, B, bt->obss, (size_t)steps * B * S::D, (size_t)S::D, f(wl.rec), f(wl.rec2), f(wl.dq), f(wl.lrow), bt->filled, T,
+                        f(wl.partials), st);
     MARL_CHECK_LAUNCH("gru_wgrad_kernel");
-    const int n = am.nblk * S::NPARAM;  // one gradient block per NETWORK: a shared network's agents are summed by the reduce
-    hipLaunchKernelGGL(dqn_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, st, (const float*)f(wl.partials), P, wl.nwg, S::NPARAM, am, grad, loss);
+    const int n = am.nblk * S::nparam(L);  // one gradient block per NETWORK: a shared network's agents are summed by the reduce
+    hipLaunchKernelGGL(dqn_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, st, (const float*)f(wl.partials), P, wl.nwg, S::nparam(L), am, grad, loss);
     timing_end(TIMER_LOSSGRAD, st);
     MARL_CHECK_LAUNCH("dqn_reduce_kernel");
     return 0;
@@ -176,7 +198,7 @@ int gru_loss_grad(const marlhip_net_shape* s, const float* params, const float* 
 
 extern "C" int64_t marlhip_gru_workspace_bytes(const marlhip_net_shape* s, int32_t max_len, int32_t batch) {
     if (gru_check(s) != 0) return -1;
-#define X(d, h, a) if (s->obs_dim == d && s->hidden == h && s->n_actions == a) return gru_ws_layout<GruShape<d, h, a>>(s->n_agents, max_len, batch).total;
+#define X(d, h, a) if (s->obs_dim == d && s->hidden == h && s->n_actions == a) return gru_ws_layout<GruShape<d, h, a>>(s->n_agents, max_len, batch, gru_depth(s)).total;
     MARL_GRU_SHAPES(X)
 #undef X
     return -1;
@@ -241,9 +263,9 @@ template <class S>
 int gru_qmix_loss_grad(const marlhip_net_shape* s, const float* params, const float* target, const marlhip_qmix_mixer* mx, const marlhip_batch* bt,
                        float gamma, int double_q, void* ws, int64_t ws_bytes, float* grad, float* loss, hipStream_t st) {
     using Bk = GruBwd<S>;
-    const int P = s->n_agents, T = bt->max_len, B = bt->batch, steps = T + 1;
+    const int P = s->n_agents, T = bt->max_len, B = bt->batch, steps = T + 1, L = gru_depth(s);
     const int64_t R = (int64_t)T * B;
-    const GruWs wl = gru_ws_layout<S>(P, T, B);
+    const GruWs wl = gru_ws_layout<S>(P, T, B, L);
     const int64_t extra = ((3 * P + 3) * R * 4 + 255) / 256 * 256;  // chosen, tqsel, dqm [P][R]; r0, dn, fl [R]
     const int64_t mixws = qmix_mixer_ws_bytes_mx(s, mx->embed_dim, mx->hypernet_layers, mx->hypernet_embed, T, B);
     if (mixws < 0) return -1;
@@ -271,9 +293,9 @@ int gru_qmix_loss_grad(const marlhip_net_shape* s, const float* params, const fl
         qx.rst = &rst;
     }
     const AgentMap am = agent_map(s);
-    hipLaunchKernelGGL((gru_pack_kernel<S>), dim3((S::NFWD + 255) / 256, P), dim3(256), 0, st, params, am, f(wl.packC));
-    hipLaunchKernelGGL((gru_pack_kernel<S>), dim3((S::NFWD + 255) / 256, P), dim3(256), 0, st, target, am, f(wl.packT));
-    hipLaunchKernelGGL((gru_bwd_pack_kernel<S>), dim3((Bk::NBWD + 255) / 256, P), dim3(256), 0, st, params, am, f(wl.packB));
+    gru_pack_fwd_layers<S>(P, L, params, am, f(wl.packC), st);
+    gru_pack_fwd_layers<S>(P, L, target, am, f(wl.packT), st);
+    gru_pack_bwd_layers<S>(P, L, params, am, f(wl.packB), st);
     MARL_CHECK_LAUNCH("gru pack kernels");
     const size_t ldsF = (size_t)S::LDS_FLOATS * sizeof(float), ldsB = (size_t)Bk::LDS_FLOATS * sizeof(float);
     const size_t ldsW = gru_wgrad_lds_bytes<S>();
@@ -286,8 +308,7 @@ int gru_qmix_loss_grad(const marlhip_net_shape* s, const float* params, const fl
     }
     const dim3 gridS((B + 63) / 64, P), gridR((unsigned)((R + 255) / 256));
     timing_begin(TIMER_LOSSGRAD, st);
-    hipLaunchKernelGGL((gru_seq_fwd2_kernel<S>), dim3(gridS.x, gridS.y, 2), dim3(256), ldsF, st, (const float*)f(wl.packC), (const float*)f(wl.packT), bt->obss,
-                       (size_t)steps * B * S::D, (size_t)S::D, steps, steps, B, f(wl.q), f(wl.tq), f(wl.rec));
+    gru_fwd2_layers<S>(P, L, f(wl.packC), f(wl.packT), bt->obss, (size_t)steps * B * S::D, (size_t)S::D, steps, steps, B, f(wl.q), f(wl.tq), f(wl.rec), f(wl.recT), st);
     hipLaunchKernelGGL(gru_qsel_kernel, gridR, dim3(256), 0, st, P, T, B, S::A, (const float*)f(wl.q), (const float*)f(wl.tq), *bt, double_q, chosen,
                        tqsel, r0, dn, fl);
     MARL_CHECK_LAUNCH("gru forward / qsel");
@@ -296,12 +317,12 @@ int gru_qmix_loss_grad(const marlhip_net_shape* s, const float* params, const fl
     if (rc != 0) return rc;
     (void)hipMemsetAsync(f(wl.dq), 0, (size_t)P * steps * B * S::A * sizeof(float), st);
     hipLaunchKernelGGL(gru_expand_dq_kernel, gridR, dim3(256), 0, st, P, T, B, S::A, (const float*)dqm, *bt, f(wl.dq));
-    gru_launch_seq_bwd<S>(P, B, (const float*)f(wl.packB), steps, (const float*)f(wl.rec), (const float*)f(wl.dq), f(wl.rec2), st);
-    hipLaunchKernelGGL((gru_wgrad_kernel<S>), dim3(wl.nwg, P, gru_wgrad_roles<S>()), dim3(256), ldsW, st, steps, B, bt->obss, (size_t)steps * B * S::D, (size_t)S::D, (const float*)f(wl.rec), (const float*)f(wl.rec2),
-                       (const float*)f(wl.dq), (const float*)f(wl.lrow), bt->filled, T, f(wl.partials));
+    gru_bwd_layers<S>(P, L, f(wl.packB), steps, B, f(wl.rec), f(wl.dq), f(wl.rec2), st, true);
+    gru_wgrad_layers<S>(P, L, wl.nwg, steps, B, bt->obss, (size_t)steps * B * S::D, (size_t)S::D, f(wl.rec), f(wl.rec2), f(wl.dq), f(wl.lrow), bt->filled, T,
+                        f(wl.partials), st);
     MARL_CHECK_LAUNCH("gru backward");
-    const int n = am.nblk * S::NPARAM;  // one gradient block per NETWORK: a shared network's agents are summed by the reduce
-    hipLaunchKernelGGL(dqn_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, st, (const float*)f(wl.partials), P, wl.nwg, S::NPARAM, am, grad, loss);
+    const int n = am.nblk * S::nparam(L);  // one gradient block per NETWORK: a shared network's agents are summed by the reduce
+    hipLaunchKernelGGL(dqn_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, st, (const float*)f(wl.partials), P, wl.nwg, S::nparam(L), am, grad, loss);
     timing_end(TIMER_LOSSGRAD, st);
     MARL_CHECK_LAUNCH("dqn_reduce_kernel");
     return qmix_mix_stage(s, &qx, bt, &io, gamma, 1, loss, st);

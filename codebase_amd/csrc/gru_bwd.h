@@ -45,9 +45,10 @@ __device__ __forceinline__ float gru_bwd_pack_elem(const float* __restrict__ w, 
 }
 
 template <class S>
-__global__ __launch_bounds__(256) void gru_bwd_pack_kernel(const float* __restrict__ params, AgentMap am, float* __restrict__ packs) {
+__global__ __launch_bounds__(256) void gru_bwd_pack_kernel(const float* __restrict__ params, AgentMap am, float* __restrict__ packs,
+                                                           int block_floats = S::NPARAM, int layer_off = 0) {
     const int p = blockIdx.y, idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx < GruBwd<S>::NBWD) packs[(size_t)p * GruBwd<S>::NBWD + idx] = gru_bwd_pack_elem<S>(params + (size_t)am.net[p] * S::NPARAM, idx);
+    if (idx < GruBwd<S>::NBWD) packs[(size_t)p * GruBwd<S>::NBWD + idx] = gru_bwd_pack_elem<S>(params + (size_t)am.net[p] * block_floats + layer_off, idx);
 }
 
 // transposed product: out[mt1] += sum_{gate-unit tiles mt2, r} T[gate][mt1][mt2][lane][r] * dg[mt2][r]
@@ -67,9 +68,12 @@ __device__ __forceinline__ void gru_tgate(const f4* Tm /* [MT][MT][64] chunk */,
 }
 
 // rec: forward record [P][S][nblk][REC]; dq: [P][S][B][A]; rec2: [P][S][nblk][REC2]
+// Stacked layers: dh_above = the backward record of the layer above - dL/dh[t] of this layer is that layer's dx1[t] instead of W3^T dq[t];
+// inner (layer >= 1): this layer's input is the hidden state below, not a ReLU output - dx1 is not masked
 template <class S>
 __global__ __launch_bounds__(256) void gru_seq_bwd_kernel(const float* __restrict__ packs, int steps, int B, const float* __restrict__ rec,
-                                                          const float* __restrict__ dq, float* __restrict__ rec2) {
+                                                          const float* __restrict__ dq, float* __restrict__ rec2,
+                                                          const float* __restrict__ dh_above = nullptr, int inner = 0) {
     using Bk = GruBwd<S>;
     constexpr int MT = S::MT, A = S::A;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -115,6 +119,12 @@ __global__ __launch_bounds__(256) void gru_seq_bwd_kernel(const float* __restric
             ghn[mt] = R[(5 * MT + mt) * 64 + lane];
             hp[mt] = t > 0 ? Rp[(4 * MT + mt) * 64 + lane] : zero4;
         }
+        f4 dh[MT];
+        if (dh_above != nullptr) {  // dh = carried + the layer above's dx1
+            const f4* Ra = reinterpret_cast<const f4*>(dh_above + (((size_t)p * steps + t) * nblk + blk) * Bk::REC2);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) dh[mt] = carry[mt] + Ra[(4 * MT + mt) * 64 + lane];
+        } else {
         f4 dQ;
         {
             const float* drow = dq + (((size_t)p * steps + t) * B + bj) * A;
@@ -122,13 +132,13 @@ __global__ __launch_bounds__(256) void gru_seq_bwd_kernel(const float* __restric
             for (int r = 0; r < 4; ++r) dQ[r] = (rowok && 4 * g + r < A) ? drow[4 * g + r < A ? 4 * g + r : A - 1] : 0.f;
         }
         // dh = carried + W3^T dq
-        f4 dh[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             dh[mt] = carry[mt];
             const f4 a = T3[mt * 64 + lane];
 #pragma unroll
             for (int r = 0; r < 4; ++r) dh[mt] = MARL_MFMA(a[r], dQ[r], dh[mt]);
+        }
         }
         // gate derivatives (h' = (1 - z) n + z h;  n = tanh(gi_n + r ghn);  r, z = sigmoid(...))
         f4 dr[MT], dz[MT], dng[MT], drn[MT];
@@ -154,7 +164,7 @@ __global__ __launch_bounds__(256) void gru_seq_bwd_kernel(const float* __restric
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) dx1[mt][r] = x1[mt][r] > 0.f ? dx1[mt][r] : 0.f;
+            for (int r = 0; r < 4; ++r) dx1[mt][r] = (inner || x1[mt][r] > 0.f) ? dx1[mt][r] : 0.f;
             R2[(0 * MT + mt) * 64 + lane] = dr[mt];
             R2[(1 * MT + mt) * 64 + lane] = dz[mt];
             R2[(2 * MT + mt) * 64 + lane] = dng[mt];
@@ -180,7 +190,8 @@ constexpr size_t gru_bwd_lds_bytes() {
 
 template <class S>
 __global__ __launch_bounds__(256) void gru_seq_bwd2_kernel(const float* __restrict__ packs, int steps, int B, const float* __restrict__ rec,
-                                                           const float* __restrict__ dq, float* __restrict__ rec2) {
+                                                           const float* __restrict__ dq, float* __restrict__ rec2,
+                                                           const float* __restrict__ dh_above = nullptr, int inner = 0) {
     using Bk = GruBwd<S>;
     constexpr int MT = S::MT, MH = MT / 2, A = S::A;
     constexpr bool STREAM = Bk::STREAM;
@@ -241,8 +252,11 @@ __global__ __launch_bounds__(256) void gru_seq_bwd2_kernel(const float* __restri
             ghn[u] = R[(5 * MT + mt) * 64 + lane];
             hp[u] = t > 0 ? Rp[(4 * MT + mt) * 64 + lane] : zero4;
         }
-        f4 dQ;
-        {
+        f4 dQ = zero4;
+        const f4* Ra = nullptr;
+        if (dh_above != nullptr) {
+            Ra = reinterpret_cast<const f4*>(dh_above + (((size_t)p * steps + t) * nblk + blk) * Bk::REC2);
+        } else {
             const float* drow = dq + (((size_t)p * steps + t) * B + bj) * A;
 #pragma unroll
             for (int r = 0; r < 4; ++r) dQ[r] = (rowok && 4 * g + r < A) ? drow[4 * g + r < A ? 4 * g + r : A - 1] : 0.f;
@@ -250,10 +264,14 @@ __global__ __launch_bounds__(256) void gru_seq_bwd2_kernel(const float* __restri
         f4 dr[MH], dz[MH], dng[MH], drn[MH];
 #pragma unroll
         for (int u = 0; u < MH; ++u) {
-            f4 dh = carry[u];  // dh = carried + W3^T dq
+            f4 dh = carry[u];  // dh = carried + W3^T dq (or + the layer above's dx1)
+            if (Ra != nullptr) {
+                dh += Ra[(4 * MT + m0 + u) * 64 + lane];
+            } else {
             const f4 a = T3[(m0 + u) * 64 + lane];
 #pragma unroll
             for (int r = 0; r < 4; ++r) dh = MARL_MFMA(a[r], dQ[r], dh);
+            }
             dng[u] = dh * (1.f - zg[u]) * (1.f - ng[u] * ng[u]);
             dz[u] = dh * (hp[u] - ng[u]) * zg[u] * (1.f - zg[u]);
             drn[u] = dng[u] * rg[u];
@@ -289,7 +307,7 @@ __global__ __launch_bounds__(256) void gru_seq_bwd2_kernel(const float* __restri
         for (int u = 0; u < MH; ++u) {
             const int mt = m0 + u;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) dx1[u][r] = x1[u][r] > 0.f ? dx1[u][r] : 0.f;
+            for (int r = 0; r < 4; ++r) dx1[u][r] = (inner || x1[u][r] > 0.f) ? dx1[u][r] : 0.f;
             R2[(0 * MT + mt) * 64 + lane] = dr[u];
             R2[(1 * MT + mt) * 64 + lane] = dz[u];
             R2[(2 * MT + mt) * 64 + lane] = dng[u];
@@ -304,7 +322,8 @@ __global__ __launch_bounds__(256) void gru_seq_bwd2_kernel(const float* __restri
 // matrices the pair of one-wave launches already fills the CUs and the two-wave form only adds staging - measured 7.54 vs 7.69 ms
 // per recurrent IA2C GRU-128 round; alone, the hidden-128 walk goes 1045 -> 650 us).
 template <class S>
-void gru_launch_seq_bwd(int P, int B, const float* packB, int steps, const float* rec, const float* dq, float* rec2, hipStream_t st, bool alone = true) {
+void gru_launch_seq_bwd(int P, int B, const float* packB, int steps, const float* rec, const float* dq, float* rec2, hipStream_t st, bool alone = true,
+                        const float* dh_above = nullptr, int inner = 0) {
     static const bool one_wave = getenv("MARLHIP_GRU_BWD_ONE_WAVE") != nullptr;
     if constexpr (GruBwdSplit<S>::value) {
         if (!one_wave && (alone || !GruBwd<S>::STREAM)) {
@@ -314,11 +333,11 @@ void gru_launch_seq_bwd(int P, int B, const float* packB, int steps, const float
                                           (int)gru_bwd_lds_bytes<S>());
                 attr.done();
             }
-            hipLaunchKernelGGL((gru_seq_bwd2_kernel<S>), dim3((B + 31) / 32, P), dim3(256), gru_bwd_lds_bytes<S>(), st, packB, steps, B, rec, dq, rec2);
+            hipLaunchKernelGGL((gru_seq_bwd2_kernel<S>), dim3((B + 31) / 32, P), dim3(256), gru_bwd_lds_bytes<S>(), st, packB, steps, B, rec, dq, rec2, dh_above, inner);
             return;
         }
     }
-    hipLaunchKernelGGL((gru_seq_bwd_kernel<S>), dim3((B + 63) / 64, P), dim3(256), GruBwd<S>::LDS_FLOATS * sizeof(float), st, packB, steps, B, rec, dq, rec2);
+    hipLaunchKernelGGL((gru_seq_bwd_kernel<S>), dim3((B + 63) / 64, P), dim3(256), GruBwd<S>::LDS_FLOATS * sizeof(float), st, packB, steps, B, rec, dq, rec2, dh_above, inner);
 }
 
 // hidden 64 (four unit tiles): the three gate roles below are one workgroup role (the FUSED branch of the kernel); launches use
@@ -341,7 +360,10 @@ __global__ __launch_bounds__(256) void gru_wgrad_kernel(int steps, int B, const 
                                                         const float* __restrict__ rec,
                                                         const float* __restrict__ rec2, const float* __restrict__ dq,
                                                         const float* __restrict__ lrow, const float* __restrict__ filled, int loss_steps,
-                                                        float* __restrict__ partials) {
+                                                        float* __restrict__ partials, int rec_floats = S::NPARAM + 2, int layer_off = 0,
+                                                        int parts = 3) {
+    // Stacked layers: rec_floats = the whole block's partial record (S::nparam(L) + 2), layer_off = l * S::LAYER (this layer's gate
+    // gradients land at the block's oWih + layer_off ...), parts: bit 0 - this is layer 0 (dW1, db1), bit 1 - the last layer (dW3, db3, loss)
     using Bk = GruBwd<S>;
     constexpr int MT = S::MT, H = S::H, D = S::D, A = S::A, NT1 = S::DP / 16, TILE = 16 * H, MTN = MT / 4;
     extern __shared__ __attribute__((aligned(16))) float tiles[];  // 4 * TILE + 256 floats
@@ -355,7 +377,7 @@ __global__ __launch_bounds__(256) void gru_wgrad_kernel(int steps, int B, const 
     const int p = blockIdx.y, role = FUSED ? (blockIdx.z == 0 ? 0 : 3) : (int)blockIdx.z;
     const int nblk = (B + 15) >> 4, T = loss_steps;  // lrow / filled have loss_steps rows (DQN: steps - 1; actor-critic: steps)
     const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    float* recd = partials + ((size_t)p * gridDim.x + blockIdx.x) * (S::NPARAM + 2);
+    float* recd = partials + ((size_t)p * gridDim.x + blockIdx.x) * rec_floats + layer_off;
     const int total = steps * nblk;
     if constexpr (FUSED) {
         if (role == 0) {
@@ -502,6 +524,7 @@ __global__ __launch_bounds__(256) void gru_wgrad_kernel(int steps, int B, const 
         return;
     }
     // ---- role 3: the small parts, one per wave (no cross-wave traffic: per-wave tiles)
+    if ((wave == 0 && !(parts & 1)) || (wave == 1 && !(parts & 2))) return;
     float* TA = wave == 0 ? T0 : T1;  // wave 0: dx1 tile; wave 1: h tile (+ TQ)
     f4 acc1[MT][NT1], acc3[MT], sa[MT], sb[MT], sc[MT], db3 = zero4;
 #pragma unroll

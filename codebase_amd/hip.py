@@ -22,6 +22,9 @@ _NO_KEEP = bool(os.environ.get("MARLHIP_AC_NO_KEEP"))
 _NO_OVERLAP = bool(os.environ.get("MARLHIP_AC_NO_OVERLAP"))
 _FORCE_OVERLAP = bool(os.environ.get("MARLHIP_AC_FORCE_OVERLAP"))
 _SIDE_PATTERN = int(os.environ.get("MARLHIP_SIDE_PATTERN", "0"))
+# MARLHIP_SIDE_SHARE=1..100: the percentage of the compute units the critics' stream owns (50; the two-ranks-on-one-device test rigs set 100:
+# see tests/test_gpu_two_ranks.py)
+_SIDE_SHARE = min(100, max(1, int(os.environ.get("MARLHIP_SIDE_SHARE", "50"))))
 
 
 # streams that own a share of the compute units (marlhip_stream_create_cu_share): one per device, shared by the updaters of the process and
@@ -36,7 +39,7 @@ def _half_chip_stream(device):
     if key not in _HALF_CHIP_STREAMS:
         h = ctypes.c_void_p()
         with torch.cuda.device(key):
-            check(lib.marlhip_stream_create_cu_share(50, _SIDE_PATTERN, ctypes.byref(h)), "stream_create_cu_share")
+            check(lib.marlhip_stream_create_cu_share(_SIDE_SHARE, _SIDE_PATTERN, ctypes.byref(h)), "stream_create_cu_share")
         _HALF_CHIP_STREAMS[key] = (torch.cuda.ExternalStream(h.value, device=torch.device("cuda", key)), h)
     return _HALF_CHIP_STREAMS[key][0]
 
@@ -44,7 +47,7 @@ def _half_chip_stream(device):
 def side_stream_description(device=None):
     """what the critics' stream owns, for bench lines (the mask's meaning is device-specific: include/marlhip.h)"""
     cus = torch.cuda.get_device_properties(device if device is not None else torch.cuda.current_device()).multi_processor_count
-    return {"api": "hipExtStreamCreateWithCUMask", "percent": 50, "pattern": _SIDE_PATTERN, "compute_units": cus, "mask_bits_set": (cus * 50 + 99) // 100,
+    return {"api": "hipExtStreamCreateWithCUMask", "percent": _SIDE_SHARE, "pattern": _SIDE_PATTERN, "compute_units": cus, "mask_bits_set": (cus * _SIDE_SHARE + 99) // 100,
             "mask": ("the lowest-numbered mask bits" if _SIDE_PATTERN == 0 else "every other mask bit") + " (MARLHIP_SIDE_PATTERN; bit -> physical unit is the runtime's order)"}
 
 

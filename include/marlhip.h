@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MARLHIP_VERSION 217
+#define MARLHIP_VERSION 218
 
 int marlhip_version(void);
 const char* marlhip_last_error(void);
@@ -373,6 +373,14 @@ int marlhip_ac_store_step(int32_t n_envs, int32_t n_agents, int32_t obs_dim, int
  * learner's.  record (NULL or marlhip_gru_record_floats floats) receives the per-step activations the backward pass reads.
  * ---------------------------------------------------------------------------------------- */
 int marlhip_gru_nparams(const marlhip_net_shape* s); /* per agent block; <0 if the shape has no recurrent kernel */
+/* C-ABI 218 - stacked recurrent layers (RNNNetwork: nn.GRU(num_layers = len(layers) - 1), marlbase/utils/models.py:74-90): every
+ * marlhip_gru_* entry point reads the depth from marlhip_net_shape.n_hidden = len(layers) (0 = 2 = one GRU layer; 2..5 -> 1..4 layers of
+ * width `hidden`).  The block is RNNNetwork's parameters() order: first_layer, then (weight_ih, weight_hh, bias_ih, bias_hh) of layer 0, 1,
+ * ..., then final_layer.  Hidden states across calls (h_in / h_out) are [L][P][B][H] - nn.GRU's (num_layers, batch, hidden) per agent;
+ * records are L times marlhip_gru_record_floats' one-layer size (the function returns the stack's).  The forward-only entry points
+ * (marlhip_gru_forward, marlhip_gru_ac_forward) chain the layers through scratch behind the weight packs: their `workspace` holds
+ * marlhip_gru_forward_workspace_bytes(s, steps, batch) bytes (for one layer: marlhip_forward_workspace_bytes(s) suffices, as before). */
+int64_t marlhip_gru_forward_workspace_bytes(const marlhip_net_shape* s, int32_t steps, int32_t batch);
 int64_t marlhip_gru_record_floats(const marlhip_net_shape* s, int32_t steps, int32_t batch);
 int marlhip_gru_forward(const marlhip_net_shape* s, const float* params /* [P][nparams] */, const float* obs, int32_t steps,
                         int32_t batch, const float* h_in, float* h_out, float* q_out /* [P][steps][B][A] */, float* record,

@@ -45,10 +45,16 @@ def test_gpus_flag_under_torchrun_and_mismatch_dryrun():
 @pytest.mark.parametrize("algo", ["idqn", "ia2c"])
 def test_bench_gpus_2_runs_two_ranks_on_the_real_kernels(algo):
     """Two ranks share cuda:0 over gloo (the RCCL path differs only in the backend string): the JSON line must say 2."""
-    out = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "2", "--warmup", "1", "--envs", "256", "--algo", algo,
-                          "--no-cpu-baseline"], cwd=ROOT, env=_env(MARLHIP_BENCH_BACKEND="gloo", MARLHIP_BENCH_ONE_DEVICE="1", MARLHIP_P2P_SHARED_DEVICE="1",
-                                                                   MARLHIP_BENCH_SMALL_ROWS="1", MARLHIP_P2P_TIMEOUT_MS="20000"),
-                         capture_output=True, text=True, timeout=900)
+    def run():
+        return subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "2", "--warmup", "1", "--envs", "256", "--algo", algo, "--no-cpu-baseline"],
+                              cwd=ROOT, env=_env(MARLHIP_BENCH_BACKEND="gloo", MARLHIP_BENCH_ONE_DEVICE="1", MARLHIP_P2P_SHARED_DEVICE="1",
+                                                 MARLHIP_BENCH_SMALL_ROWS="1", MARLHIP_P2P_TIMEOUT_MS="20000"), capture_output=True, text=True, timeout=900)
+
+    out = run()
+    if "did not publish its gradient in time" in out.stdout + out.stderr:
+        # the one-device rig's rare lane timeout (tests/test_gpu_two_ranks.py has the numbers): the run says so itself - once more
+        print("[bench --gpus 2] a lane of the in-library exchange timed out on the shared device; second attempt")
+        out = run()
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     line = _json_line(out.stdout)
     rr = line["rccl_ranks"]

@@ -2,6 +2,7 @@
 Each rank owns its env / replay shard (different Philox keys), gradients are all-reduced every update; after a few
 rounds every rank must hold bit-identical parameters, optimiser moments and targets - for IDQN, QMIX and IA2C."""
 import os
+import time
 import sys
 
 import torch
@@ -122,11 +123,12 @@ def main():
                      df=torch.empty(Tw + 1, Nw, device="cuda"), f=torch.empty(Tw, Nw, device="cuda")) for _ in range(2)]
         fr3, fl3 = torch.zeros(Pw, Nw, device="cuda"), torch.zeros(Nw, dtype=torch.int32, device="cuda")
         torch.cuda.synchronize()
-        deferred = []
+        deferred, stamps, t_start = [], [], time.time()
         with torch.cuda.stream(torch.cuda.Stream(device="cuda")):  # (nothing leaves a caller that is on the default stream)
             assert m3.attach_grad_sync(s3) == overlap
             for r in range(4):  # two alternating batch sets, as bench.py keeps them: round r + 2 rewrites the set round r's critics read
                 b = sets[r & 1]
+                stamps.append(round(time.time() - t_start, 2))
                 h.ac_collect(cfg3, m3.spec, m3.actor_params, r, Tw, False, b["o"], b["a"], b["r"], b["d"], b["f"], fr3, fl3, tm, keep_for=m3.updater)
                 b["df"].copy_(b["d"])
                 m3.update_async(Batch(b["o"], b["a"], b["r"], b["df"], b["f"], None), r * Tw * Nw, grad_sync=s3, world=world, overlap=overlap)
@@ -134,7 +136,8 @@ def main():
         torch.cuda.synchronize()
         assert deferred == [overlap] * 4, deferred
         if overlap and os.environ.get("MARLHIP_P2P", "1") != "0":
-            assert s3.p2p is not None and s3.side.p2p is not None and s3.p2p.status() == 0 and s3.side.p2p.status() == 0, "a p2p lane is missing or timed out"
+            lanes = dict(main=None if s3.p2p is None else s3.p2p.status(), side=None if s3.side is None or s3.side.p2p is None else s3.side.p2p.status())
+            assert lanes == dict(main=0, side=0), f"rank {rank}: a p2p lane is missing (None) or ran into its peer timeout (1): {lanes}; round starts {stamps}"
         s3.check()
         for what, t in (("block", m3.block), ("target critic", m3.target_critic_params), ("exp_avg", m3.updater.exp_avg), ("exp_avg_sq", m3.updater.exp_avg_sq)):
             same_on_all_ranks(t, f"A2C (overlap={overlap}) {what}")
