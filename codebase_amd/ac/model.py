@@ -70,7 +70,10 @@ class A2CNetwork:
             Hk = max(compiled_width(ha), compiled_width(hc))
             wide = is_wide(ha) or is_wide(hc)
         if self.recurrent and len(ha) != len(hc):
-            raise NotImplementedError(f"use_rnn with layers actor={ha} critic={hc}: one GRU layer each ([h, h])")
+            raise NotImplementedError(f"use_rnn with layers actor={ha} critic={hc}: the two families at one depth (the same number of stacked GRU layers)")
+        if (self.recurrent or self.mixed_rnn) and (len(ha) != 2 or len(hc) != 2):
+            raise NotImplementedError(f"use_rnn with layers actor={ha} critic={hc}: stacked GRU layers exist for the DQN family (dqn/model.py); "
+                                      "the actor-critic learners run one GRU layer ([h, h])")
         # actor and critic are built from their own `layers` lists (ac/model.py:45-97): with different DEPTHS both run on the GEMM path,
         # the critics with their own layer count (marlhip_ac_config.critic_n_hidden)
         wide = wide or len(ha) != len(hc)

@@ -73,13 +73,15 @@ def init_flat_params(obs_dims, hidden_dims, act_dims, use_orthogonal_init=True, 
     return critic, critic.clone()  # hard_update (dqn/model.py:60)
 
 
-def _gru_layout(D, H, A):
-    """RNNNetwork's parameters() order (utils/models.py:83-92)"""
-    return [("first_layer.weight", (H, D)), ("first_layer.bias", (H,)), ("rnn.weight_ih_l0", (3 * H, H)), ("rnn.weight_hh_l0", (3 * H, H)),
-            ("rnn.bias_ih_l0", (3 * H,)), ("rnn.bias_hh_l0", (3 * H,)), ("final_layer.weight", (A, H)), ("final_layer.bias", (A,))]
+def _gru_layout(D, H, A, L=1):
+    """RNNNetwork's parameters() order (utils/models.py:83-92): nn.GRU lists layer l's four tensors behind layer l - 1's"""
+    out = [("first_layer.weight", (H, D)), ("first_layer.bias", (H,))]
+    for l in range(L):
+        out += [(f"rnn.weight_ih_l{l}", (3 * H, H)), (f"rnn.weight_hh_l{l}", (3 * H, H)), (f"rnn.bias_ih_l{l}", (3 * H,)), (f"rnn.bias_hh_l{l}", (3 * H,))]
+    return out + [("final_layer.weight", (A, H)), ("final_layer.bias", (A,))]
 
 
-def init_flat_gru_params(obs_dims, hidden, act_dims, use_orthogonal_init=True, sharing=None, sets=2):
+def init_flat_gru_params(obs_dims, hidden, act_dims, use_orthogonal_init=True, sharing=None, sets=2, num_layers=1):
     """Initial critic / target blocks of recurrent networks, consuming torch's global RNG like RNNNetwork.__init__ does
     (utils/models.py:83-94: nn.Linear and nn.GRU default inits, orthogonal gain sqrt(2) + zero bias on the output layer only),
     critic nets first, then target nets, then hard_update (dqn/model.py:36-41,60); with parameter sharing one network per distinct
@@ -92,13 +94,12 @@ def init_flat_gru_params(obs_dims, hidden, act_dims, use_orthogonal_init=True, s
         per_agent = []
         for d, a in zip(obs_dims, act_dims):
             first = nn.Linear(d, hidden)
-            rnn = nn.GRU(input_size=hidden, hidden_size=hidden, num_layers=1, batch_first=False)
+            rnn = nn.GRU(input_size=hidden, hidden_size=hidden, num_layers=num_layers, batch_first=False)
             final = nn.Linear(hidden, a)
             if use_orthogonal_init:
                 nn.init.orthogonal_(final.weight.data, gain=np.sqrt(2))
                 nn.init.constant_(final.bias.data, 0)
-            per_agent.append(torch.cat([t.detach().reshape(-1) for t in (first.weight, first.bias, rnn.weight_ih_l0, rnn.weight_hh_l0,
-                                                                         rnn.bias_ih_l0, rnn.bias_hh_l0, final.weight, final.bias)]))
+            per_agent.append(torch.cat([t.detach().reshape(-1) for t in [first.weight, first.bias] + list(rnn.parameters()) + [final.weight, final.bias]]))
         blocks.append(torch.stack(per_agent))
     return blocks[0], blocks[0].clone()
 
@@ -109,21 +110,33 @@ def init_flat_gru_params(obs_dims, hidden, act_dims, use_orthogonal_init=True, s
 # first-layer / gate weights and biases, so r = z = 1/2, n = tanh(0) = 0 and h' = (1 - z) n + z h = h / 2 = 0 from the zero initial
 # state on; every gradient into the padding is a product with one of those zeros (zero columns of W3 / W_hh keep dL/dh of a padded unit
 # at 0), and Adam maps zero gradient + zero moments to a zero step.  The gate matrices are [3 Hk][Hk] with one [Hk][Hk] block per gate
-# (r, z, n): the live part is [:, :h, :h] of the (3, Hk, Hk) view.  Longer lists (multi-layer GRUs) and h > 128 raise.
+# (r, z, n): the live part is [:, :h, :h] of the (3, Hk, Hk) view.  Longer lists [h] * (L + 1) stack L GRU layers (csrc/gru_stack.h; a padded
+# unit of layer l feeds zeros into layer l + 1, whose padded input columns are zero as well); h > 128 raises.
+MAX_GRU_LAYERS = 4  # csrc/gru_stack.h: GRU_MAX_LAYERS
+
+
 def recurrent_width(hidden):
-    """`layers` of a use_rnn network -> (h, Hk): the live width and the kernel width it is padded to, or raise"""
-    if len(hidden) != 2 or hidden[0] != hidden[1]:
-        raise NotImplementedError(f"use_rnn with layers={list(hidden)}: one GRU layer (layers = [h, h]); RNNNetwork itself asserts equal sizes "
-                                  "(utils/models.py:79-81) and stacks len(layers) - 1 GRU layers")
+    """`layers` of a use_rnn network -> (h, Hk): the live width and the kernel width it is padded to, or raise.  len(layers) - 1 GRU
+    layers (recurrent_depth): RNNNetwork asserts equal sizes (utils/models.py:79-81) and builds nn.GRU(num_layers=len(layers) - 1)"""
+    if len(hidden) < 2 or len(set(hidden)) != 1:
+        raise NotImplementedError(f"use_rnn with layers={list(hidden)}: at least two equal sizes (RNNNetwork itself asserts equal sizes, "
+                                  "utils/models.py:79-81; a single size would be nn.GRU(num_layers=0), which torch rejects)")
+    if len(hidden) - 1 > MAX_GRU_LAYERS:
+        raise NotImplementedError(f"use_rnn with layers={list(hidden)}: up to {MAX_GRU_LAYERS} stacked GRU layers (layers = [h] * 2 .. [h] * {MAX_GRU_LAYERS + 1})")
     h = int(hidden[0])
     if not 1 <= h <= 128:
         raise NotImplementedError(f"use_rnn with layers={list(hidden)}: recurrent widths up to 128 (zero-padded onto the 64 / 128 kernels)")
     return h, (64 if h <= 64 else 128)
 
 
-def gru_block_views(row, D, h, A, H):
+def recurrent_depth(hidden):
+    """number of stacked GRU layers of a use_rnn network: len(layers) - 1 (utils/models.py:77)"""
+    return len(hidden) - 1
+
+
+def gru_block_views(row, D, h, A, H, L=1):
     """(name, live view, reference shape) of one flat recurrent block laid out for kernel width H (H == h: the unpadded layout), in
-    RNNNetwork's parameters() order (utils/models.py:83-92)"""
+    RNNNetwork's parameters() order (utils/models.py:83-92); L stacked GRU layers"""
     o, out = 0, []
 
     def take(n):
@@ -134,24 +147,25 @@ def gru_block_views(row, D, h, A, H):
 
     out.append(("first_layer.weight", take(H * D).view(H, D)[:h], (h, D)))
     out.append(("first_layer.bias", take(H)[:h], (h,)))
-    out.append(("rnn.weight_ih_l0", take(3 * H * H).view(3, H, H)[:, :h, :h], (3 * h, h)))
-    out.append(("rnn.weight_hh_l0", take(3 * H * H).view(3, H, H)[:, :h, :h], (3 * h, h)))
-    out.append(("rnn.bias_ih_l0", take(3 * H).view(3, H)[:, :h], (3 * h,)))
-    out.append(("rnn.bias_hh_l0", take(3 * H).view(3, H)[:, :h], (3 * h,)))
+    for l in range(L):
+        out.append((f"rnn.weight_ih_l{l}", take(3 * H * H).view(3, H, H)[:, :h, :h], (3 * h, h)))
+        out.append((f"rnn.weight_hh_l{l}", take(3 * H * H).view(3, H, H)[:, :h, :h], (3 * h, h)))
+        out.append((f"rnn.bias_ih_l{l}", take(3 * H).view(3, H)[:, :h], (3 * h,)))
+        out.append((f"rnn.bias_hh_l{l}", take(3 * H).view(3, H)[:, :h], (3 * h,)))
     out.append(("final_layer.weight", take(A * H).view(A, H)[:, :h], (A, h)))
     out.append(("final_layer.bias", take(A), (A,)))
     assert o == row.numel(), (o, row.numel())
     return out
 
 
-def pad_gru_blocks(flat, D, h, A, H):
+def pad_gru_blocks(flat, D, h, A, H, L=1):
     """[K][n(h)] recurrent parameter blocks -> [K][n(H)] zero-padded blocks"""
     if h == H:
         return flat
-    n = H * D + H + 6 * H * H + 6 * H + A * H + A
+    n = H * D + H + L * (6 * H * H + 6 * H) + A * H + A
     out = torch.zeros(flat.shape[0], n, dtype=flat.dtype)
     for k in range(flat.shape[0]):
-        for (_, dst, _), (_, src, _) in zip(gru_block_views(out[k], D, h, A, H), gru_block_views(flat[k], D, h, A, h)):
+        for (_, dst, _), (_, src, _) in zip(gru_block_views(out[k], D, h, A, H, L), gru_block_views(flat[k], D, h, A, h, L)):
             dst.copy_(src)
     return out
 
@@ -237,8 +251,9 @@ class QNetwork:
         self.spec = _hip.NetSpec(self.n_agents, obs_dims[0], hidden_k[0], act_dims[0], self.sharing, wide=is_wide(hidden) and not use_rnn, n_hidden=len(hidden))
         if self.recurrent:  # RNNNetwork (utils/models.py:51-116): Linear -> ReLU -> GRU -> Linear
             self.nparams = _hip.gru_nparams(self.spec)
-            critic, target = init_flat_gru_params(obs_dims, hidden[0], act_dims, use_orthogonal_init, self.sharing)  # the reference's draws at the true width
-            critic = pad_gru_blocks(critic, obs_dims[0], hidden[0], act_dims[0], Hk)
+            self.rnn_layers = recurrent_depth(hidden)
+            critic, target = init_flat_gru_params(obs_dims, hidden[0], act_dims, use_orthogonal_init, self.sharing, num_layers=self.rnn_layers)  # the reference's draws at the true width
+            critic = pad_gru_blocks(critic, obs_dims[0], hidden[0], act_dims[0], Hk, self.rnn_layers)
             target = critic.clone()
         else:
             self.nparams = self.spec.nparams()
@@ -275,12 +290,12 @@ class QNetwork:
 
     def init_hiddens(self, batch_size):
         if self.recurrent:  # RNNNetwork.init_hiddens (utils/models.py:96-102): [num_layers, batch, H] zeros per agent
-            return [torch.zeros(1, batch_size, self.spec.hidden, device=self.device) for _ in range(self.n_agents)]
+            return [torch.zeros(self.rnn_layers, batch_size, self.spec.hidden, device=self.device) for _ in range(self.n_agents)]
         return [None] * self.n_agents
 
     def q_values(self, obs, hiddens=None):
         """obs f32 [P][N][D] on the device -> Q [P][N][A] (critic forward, K2); recurrent networks also take / return the hidden
-        state [P][N][H]: (Q, hiddens)"""
+        state [P][N][H] ([L][P][N][H] for L > 1 stacked GRU layers): (Q, hiddens)"""
         if self.recurrent:
             q, h = _hip.gru_forward(self.spec, self.params, obs.unsqueeze(1).contiguous(), h_in=hiddens, want_h=True)
             return q[:, 0], h
@@ -297,9 +312,10 @@ class QNetwork:
         if self.recurrent:  # the networks run even on a random step: the hidden state advances (model.py:99)
             for p, o in enumerate(inputs):
                 self._obs1[p, 0].copy_(torch.as_tensor(o, dtype=torch.float32))
-            h_in = None if hiddens is None or hiddens[0] is None else torch.stack([h.reshape(1, -1) for h in hiddens]).to(self.device).contiguous()
-            q, h = self.q_values(self._obs1, h_in)
-            hiddens = [h[p].reshape(1, 1, -1) for p in range(self.n_agents)]
+            L = self.rnn_layers  # per agent [num_layers, 1, H] (utils/models.py:96-102) <-> the kernels' [P][1][H] ([L][P][1][H] for a stack)
+            h_in = None if hiddens is None or hiddens[0] is None else torch.stack([h.reshape(L, 1, -1) for h in hiddens], dim=1).to(self.device).contiguous()
+            q, h = self.q_values(self._obs1, h_in if h_in is None or L > 1 else h_in[0])
+            hiddens = [(h[:, p] if L > 1 else h[p]).reshape(L, 1, -1) for p in range(self.n_agents)]
             if epsilon > random.random():
                 if action_masks is not None:
                     return [random.choice([i for i, m in enumerate(mask) if m == 1]) for mask in action_masks], hiddens
@@ -383,7 +399,7 @@ class QNetwork:
                     out[f"{prefix}.{group}.{i}.{name}"] = view
             return out
         for i in range(S.n_blocks):  # live tensors of the (possibly zero-padded) recurrent blocks; gate matrices as (3, h, h) views
-            for name, view, _ in gru_block_views(block[i], S.obs_dim, self.live_hidden[0], S.n_actions, S.hidden):
+            for name, view, _ in gru_block_views(block[i], S.obs_dim, self.live_hidden[0], S.n_actions, S.hidden, self.rnn_layers):
                 out[f"{prefix}.{group}.{i}.{name}"] = view
         return out
 
@@ -394,7 +410,7 @@ class QNetwork:
             return {}
         group = "independent" if self.sharing is None else "networks"
         return {f"{prefix}.{group}.{i}.{name}": shape for i in range(S.n_blocks)
-                for name, _, shape in gru_block_views(self.params[i], S.obs_dim, self.live_hidden[0], S.n_actions, S.hidden)}
+                for name, _, shape in gru_block_views(self.params[i], S.obs_dim, self.live_hidden[0], S.n_actions, S.hidden, self.rnn_layers)}
 
     def parameters(self):
         return list(self._views(self.params, "critic").values())

@@ -1128,17 +1128,36 @@ def ac_collect_later_episodes(cfg, spec: NetSpec, actor_params, round_idx, max_l
     return ret, meta, cnt
 
 
+def _gru_fwd_ws(spec, steps, batch, device):
+    """(pointer, bytes) for marlhip_gru_forward / marlhip_gru_ac_forward: one layer -> the shared pack workspace (_fwd_ws); a stack of GRU layers
+    chains them through scratch behind the packs (marlhip_gru_forward_workspace_bytes), one buffer per (shape, depth, steps, batch, stream)"""
+    if int(spec.n_hidden) <= 2:
+        return _fwd_ws(spec, device)
+    key = ("gru", spec.n_agents, spec.obs_dim, spec.hidden, int(spec.n_hidden), int(steps), int(batch), torch.device(device).index, torch.cuda.current_stream().cuda_stream)
+    ws = _FWD_WS.get(key)
+    if ws is None:
+        s = spec.c()
+        n = check(lib.marlhip_gru_forward_workspace_bytes(ctypes.byref(s), int(steps), int(batch)), "gru_forward_workspace_bytes")
+        ws = _FWD_WS[key] = torch.empty(n, dtype=torch.uint8, device=device)
+    return ctypes.c_void_p(ws.data_ptr()), ws.numel()
+
+
 def gru_forward(spec: NetSpec, params, obs, h_in=None, want_h=False, record=None):
     """recurrent Q-networks (use_rnn): obs f32 [P][S][B][D] on the device -> q [P][S][B][A] (and the final hidden state
-    [P][B][H] when want_h); h_in [P][B][H] or None (zeros).  `record`: float tensor of marlhip_gru_record_floats for BPTT."""
+    [P][B][H] when want_h); h_in [P][B][H] or None (zeros).  L = spec.n_hidden - 1 > 1 stacked GRU layers: hidden states [L][P][B][H].
+    `record`: float tensor of marlhip_gru_record_floats for BPTT."""
     _require_gpu()
     P, S, B, D = obs.shape
+    L = max(int(spec.n_hidden), 2) - 1
     assert obs.is_contiguous() and obs.dtype == torch.float32 and D == spec.obs_dim and P == spec.n_agents
+    hshape = (P, B, spec.hidden) if L == 1 else (L, P, B, spec.hidden)
+    if h_in is not None:
+        assert tuple(h_in.shape) == hshape and h_in.is_contiguous() and h_in.dtype == torch.float32, (tuple(h_in.shape), hshape)
     q = torch.empty(P, S, B, spec.n_actions, device=obs.device)
-    h_out = torch.empty(P, B, spec.hidden, device=obs.device) if want_h else None
+    h_out = torch.empty(*hshape, device=obs.device) if want_h else None
     s = spec.c()
     check(lib.marlhip_gru_forward(ctypes.byref(s), _ptr(params), _ptr(obs), S, B, _ptr(h_in), _ptr(h_out), _ptr(q), _ptr(record),
-                                  *_fwd_ws(spec, params.device), _stream()), "gru_forward")
+                                  *_gru_fwd_ws(spec, S, B, params.device), _stream()), "gru_forward")
     return (q, h_out) if want_h else q
 
 

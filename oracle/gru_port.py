@@ -1,7 +1,7 @@
 """TEST INFRASTRUCTURE ONLY - CPU restatement of the reference's recurrent Q-network (`use_rnn: True`).
 
-Follows marlbase/utils/models.py:51-116 (RNNNetwork: Linear(D, H) -> ReLU -> one-layer nn.GRU(H, H) -> Linear(H, A); with
-`layers: [H, H]` the GRU has len(layers) - 1 = 1 layer) and the way the DQN family drives it:
+Follows marlbase/utils/models.py:51-116 (RNNNetwork: Linear(D, H) -> ReLU -> nn.GRU(H, H, num_layers = len(layers) - 1) -> Linear(H, A);
+`layers: [H, H]` is one GRU layer, [H] * (L + 1) stacks L: the port reads L off the block's size) and the way the DQN family drives it:
   QNetwork.act            dqn/model.py:94-116   one step, hidden state [1, 1, H] per agent carried by the caller
   QNetwork._compute_loss  dqn/model.py:118-163  whole [T+1, B] sequences from a zero hidden state (`hiddens=None`)
 torch.nn.GRU's cell (gate order r, z, n in weight_ih_l0 / weight_hh_l0):
@@ -10,25 +10,43 @@ torch.nn.GRU's cell (gate order r, z, n in weight_ih_l0 / weight_hh_l0):
 Parameters of one agent = one flat fp32 block in parameters() order:
   first_layer.weight [H, D] | first_layer.bias [H] | rnn.weight_ih_l0 [3H, H] | rnn.weight_hh_l0 [3H, H] |
   rnn.bias_ih_l0 [3H] | rnn.bias_hh_l0 [3H] | final_layer.weight [A, H] | final_layer.bias [A]
-PINNED by tests/golden/learner_gru_*.npz (oracle/make_golden_gru.py runs the reference's own QNetwork(use_rnn=True)).
+  ... then rnn.*_l1, rnn.*_l2, ... for a stack, final_layer last.
+PINNED by tests/golden/learner_gru_*.npz (oracle/make_golden_gru.py runs the reference's own QNetwork(use_rnn=True), incl. layers [64] * 3).
 """
 import numpy as np
 import torch
 
 from . import dqn_port as dp
 
-SHAPES = lambda D, H, A: ((H, D), (H,), (3 * H, H), (3 * H, H), (3 * H,), (3 * H,), (A, H), (A,))  # noqa: E731
+def SHAPES(D, H, A, L=1):
+    """RNNNetwork's parameters() order; nn.GRU(num_layers=L) lists layer l's four tensors behind layer l - 1's (utils/models.py:83-92)"""
+    return ((H, D), (H,)) + ((3 * H, H), (3 * H, H), (3 * H,), (3 * H,)) * L + ((A, H), (A,))
+
+
 NAMES = ("first_layer.weight", "first_layer.bias", "rnn.weight_ih_l0", "rnn.weight_hh_l0", "rnn.bias_ih_l0", "rnn.bias_hh_l0",
          "final_layer.weight", "final_layer.bias")
 
 
-def nparams(D, H, A):
-    return sum(int(np.prod(s)) for s in SHAPES(D, H, A))
+def names(L=1):
+    return (("first_layer.weight", "first_layer.bias") + tuple(f"rnn.{n}_l{l}" for l in range(L) for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"))
+            + ("final_layer.weight", "final_layer.bias"))
+
+
+def nparams(D, H, A, L=1):
+    return sum(int(np.prod(s)) for s in SHAPES(D, H, A, L))
+
+
+def depth(block, D, H, A):
+    """stacked GRU layers of a flat block: `layers = [H] * (L + 1)` -> nn.GRU(num_layers=L) (utils/models.py:74-90)"""
+    extra = block.numel() - nparams(D, H, A)
+    per = 6 * H * H + 6 * H
+    assert extra >= 0 and extra % per == 0, (block.numel(), D, H, A)
+    return 1 + extra // per
 
 
 def split(block, D, H, A):
     out, o = [], 0
-    for s in SHAPES(D, H, A):
+    for s in SHAPES(D, H, A, depth(block, D, H, A)):
         n = int(np.prod(s))
         out.append(block[o:o + n].reshape(s))
         o += n
@@ -36,23 +54,31 @@ def split(block, D, H, A):
 
 
 def cell(parts, x, h):
-    """one step: x [..., D], h [..., H] -> (q [..., A], h' [..., H])"""
-    W1, b1, Wih, Whh, bih, bhh, W3, b3 = parts
+    """one step: x [..., D], h [..., H] ([L, ..., H] for L > 1 stacked layers) -> (q [..., A], h' like h).  Layer l's input is layer
+    l - 1's new hidden state (torch.nn.GRU; no dropout: RNNNetwork passes none)"""
+    L = (len(parts) - 4) // 4
+    W1, b1, W3, b3 = parts[0], parts[1], parts[-2], parts[-1]
     H = h.shape[-1]
-    x1 = torch.relu(torch.nn.functional.linear(x, W1, b1))
-    gi = torch.nn.functional.linear(x1, Wih, bih)
-    gh = torch.nn.functional.linear(h, Whh, bhh)
-    r = torch.sigmoid(gi[..., :H] + gh[..., :H])
-    z = torch.sigmoid(gi[..., H:2 * H] + gh[..., H:2 * H])
-    n = torch.tanh(gi[..., 2 * H:] + r * gh[..., 2 * H:])
-    hn = (1 - z) * n + z * h
-    return torch.nn.functional.linear(hn, W3, b3), hn
+    inp = torch.relu(torch.nn.functional.linear(x, W1, b1))
+    hs = []
+    for l in range(L):
+        Wih, Whh, bih, bhh = parts[2 + 4 * l:6 + 4 * l]
+        hl = h[l] if L > 1 else h
+        gi = torch.nn.functional.linear(inp, Wih, bih)
+        gh = torch.nn.functional.linear(hl, Whh, bhh)
+        r = torch.sigmoid(gi[..., :H] + gh[..., :H])
+        z = torch.sigmoid(gi[..., H:2 * H] + gh[..., H:2 * H])
+        n = torch.tanh(gi[..., 2 * H:] + r * gh[..., 2 * H:])
+        inp = (1 - z) * n + z * hl
+        hs.append(inp)
+    return torch.nn.functional.linear(inp, W3, b3), (torch.stack(hs) if L > 1 else hs[0])
 
 
 def sequence(block, obss, D, H, A, h0=None):
-    """obss [S, B, D] -> (q [S, B, A], h_S [B, H]) from h0 (zeros when None), one step after the other"""
+    """obss [S, B, D] -> (q [S, B, A], h_S [B, H] or [L, B, H]) from h0 (zeros when None), one step after the other"""
     parts = split(block, D, H, A)
-    h = torch.zeros(obss.shape[1], H) if h0 is None else h0
+    L = (len(parts) - 4) // 4
+    h = (torch.zeros(obss.shape[1], H, dtype=obss.dtype) if L == 1 else torch.zeros(L, obss.shape[1], H, dtype=obss.dtype)) if h0 is None else h0
     qs = []
     for t in range(obss.shape[0]):
         q, h = cell(parts, obss[t], h)

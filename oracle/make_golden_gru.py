@@ -12,6 +12,10 @@ update(), and an `act` trace: 6 greedy steps of one env with the hidden states t
   learner_gru_shared_H64.npz     3 agents x 18 obs, QNetwork, parameter_sharing=True (MultiAgentSharedNetwork, utils/models.py:176-300)
   learner_gru_seps_vdn_H128.npz  3 agents x 18 obs, VDNetwork, parameter_sharing=[0, 0, 1] (SePS), 128-128
   learner_gru_std_H64.npz        2 agents x 15 obs, QNetwork, standardise_returns=True (dqn/model.py:147-158): 3 updates on 3 batches
+  learner_gru_idqn_L2_H64.npz    2 agents x 15 obs, QNetwork, layers [64] * 3: nn.GRU(num_layers=2) (utils/models.py:74-90)
+  learner_gru_vdn_L3_h40.npz     3 agents x 18 obs, VDNetwork, layers [40] * 4: three stacked layers at a width the kernels pad
+  learner_gru_idqn_L2_h72.npz    2 agents x 15 obs, QNetwork, layers [72] * 3 (runs on the 128-wide kernels)
+  learner_gru_qmix_L2_H64.npz    2 agents x 15 obs, QMixNetwork, layers [64] * 3
 """
 import contextlib
 import io
@@ -24,19 +28,22 @@ from .dqn_port import synthetic_batch
 from .make_golden import OUT, Box, Cfg, Discrete, flat_params, import_reference
 
 
-def fixture(ref_model, ref_train, name, cls, P, D, H, B, seed):
+def fixture(ref_model, ref_train, name, cls, P, D, H, B, seed, layers=None):
     T, A = 10, 6
+    layers = [H, H] if layers is None else list(layers)  # [H] * (L + 1): nn.GRU(num_layers=L) (utils/models.py:74-90)
     torch.manual_seed(seed)
     cfg = Cfg(optimizer="Adam", lr=3e-4, gamma=0.99, grad_clip=1.0, target_update_interval_or_tau=200, double_q=True,
               standardise_returns=False)
     with contextlib.redirect_stdout(io.StringIO()):
-        net = cls([Box(D)] * P, [Discrete(A)] * P, cfg, [H, H], False, True, True, "cpu")
+        net = cls([Box(D)] * P, [Discrete(A)] * P, cfg, layers, False, True, True, "cpu")
     g = torch.Generator().manual_seed(seed + 1)
     with torch.no_grad():
         for p in net.target.parameters():
             p.add_(0.05 * torch.randn(p.shape, generator=g))
     out = dict(P=P, T=T, B=B, D=D, A=A, H=H, keys=np.array(list(net.state_dict().keys())),
                params0=flat_params(net.critic).numpy(), target0=flat_params(net.target).numpy())
+    if len(layers) != 2:
+        out["layers"] = np.array(layers)
     batch = synthetic_batch(P, T, B, D, A, seed=seed + 7)
     batch["obss"] = batch["obss"] * 0.25
     if cls is ref_model.VDNetwork:
@@ -134,7 +141,7 @@ def std_fixture(ref_model, ref_train, name, P, D, H, B, seed):
     print(name, losses, out["ret_mean3"], out["ret_var3"], out["ret_count3"])
 
 
-def qmix_fixture(ref_model, ref_train, name, P, D, H, B, seed):
+def qmix_fixture(ref_model, ref_train, name, P, D, H, B, seed, layers=None):
     """QMixNetwork(use_rnn=True): loss, agent and mixer gradients, 2 updates"""
     from .make_golden_qmix import mixer_flat, mixer_grad
 
@@ -144,13 +151,15 @@ def qmix_fixture(ref_model, ref_train, name, P, D, H, B, seed):
               standardise_returns=False)
     mixing = dict(embed_dim=64, hypernet_layers=2, hypernet_embed=32)
     with contextlib.redirect_stdout(io.StringIO()):
-        net = ref_model.QMixNetwork([Box(D)] * P, [Discrete(A)] * P, cfg, [H, H], False, True, True, mixing, "cpu")
+        net = ref_model.QMixNetwork([Box(D)] * P, [Discrete(A)] * P, cfg, [H, H] if layers is None else list(layers), False, True, True, mixing, "cpu")
     g = torch.Generator().manual_seed(seed + 1)
     with torch.no_grad():
         for p in list(net.target.parameters()) + list(net.target_mixer.parameters()):
             p.add_(0.04 * torch.randn(p.shape, generator=g))
     out = dict(P=P, T=T, B=B, D=D, A=A, H=H, params0=flat_params(net.critic).numpy(), target0=flat_params(net.target).numpy(),
                mixer0=mixer_flat(net.mixer).numpy(), tmixer0=mixer_flat(net.target_mixer).numpy(), keys=np.array(list(net.state_dict().keys())))
+    if layers is not None:
+        out["layers"] = np.array(layers)
     batch = synthetic_batch(P, T, B, D, A, seed=seed + 7)
     batch["obss"] = batch["obss"] * 0.25
     batch["rewards"][1:] = batch["rewards"][0]
@@ -170,11 +179,25 @@ def qmix_fixture(ref_model, ref_train, name, P, D, H, B, seed):
     print(name, float(out["loss0"]), out["losses"].tolist())
 
 
+def stacked(rm, rt):
+    """round 6: len(layers) - 1 > 1 stacked GRU layers (utils/models.py:74-90), the reference's own classes"""
+    fixture(rm, rt, "learner_gru_idqn_L2_H64.npz", rm.QNetwork, P=2, D=15, H=64, B=37, seed=2700, layers=[64, 64, 64])
+    fixture(rm, rt, "learner_gru_vdn_L3_h40.npz", rm.VDNetwork, P=3, D=18, H=40, B=21, seed=2800, layers=[40, 40, 40, 40])  # padded onto the 64 kernels
+    fixture(rm, rt, "learner_gru_idqn_L2_h72.npz", rm.QNetwork, P=2, D=15, H=72, B=18, seed=2900, layers=[72, 72, 72])  # padded onto the 128 kernels
+    qmix_fixture(rm, rt, "learner_gru_qmix_L2_H64.npz", P=2, D=15, H=64, B=19, seed=3000, layers=[64, 64, 64])
+
+
 if __name__ == "__main__":
+    import sys
+
     torch.set_num_threads(1)
     import_reference()
     from marlbase.dqn import model as rm
     from marlbase.dqn import train as rt
+
+    if "--stacked-only" in sys.argv:
+        stacked(rm, rt)
+        sys.exit(0)
 
     fixture(rm, rt, "learner_gru_idqn_H64.npz", rm.QNetwork, P=2, D=15, H=64, B=37, seed=2100)
     fixture(rm, rt, "learner_gru_vdn_H64.npz", rm.VDNetwork, P=3, D=18, H=64, B=21, seed=2200)
@@ -182,3 +205,4 @@ if __name__ == "__main__":
     shared_fixture(rm, rt, "learner_gru_shared_H64.npz", rm.QNetwork, P=3, D=18, H=64, B=20, sharing=True, seed=2400)
     shared_fixture(rm, rt, "learner_gru_seps_vdn_H128.npz", rm.VDNetwork, P=3, D=18, H=128, B=17, sharing=[0, 0, 1], seed=2500)
     std_fixture(rm, rt, "learner_gru_std_H64.npz", P=2, D=15, H=64, B=23, seed=2600)
+    stacked(rm, rt)

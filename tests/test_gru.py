@@ -155,7 +155,7 @@ def test_recurrent_qnetwork_interface_matches_reference(name, mode):
     np.testing.assert_allclose(losses, g["losses"], rtol=5e-5)
     np.testing.assert_allclose(net.params.cpu().numpy(), g["params2"], rtol=0, atol=5e-6)
     with pytest.raises(NotImplementedError):
-        QNetwork(Tuple([Box(-1, 8, (D,))] * P), Tuple([Discrete(A)] * P), hyper, [32, 32, 32], False, True, True, "cuda")  # a two-layer GRU
+        QNetwork(Tuple([Box(-1, 8, (D,))] * P), Tuple([Discrete(A)] * P), hyper, [32] * 6, False, True, True, "cuda")  # five stacked GRU layers (up to four: tests/test_gru_stacked.py)
     wide = QNetwork(Tuple([Box(-1, 8, (D,))] * P), Tuple([Discrete(A)] * P), hyper, [128, 128], False, True, True, "cuda")  # reference default
     assert wide.state_dict()["critic.independent.0.rnn.weight_ih_l0"].shape == (384, 128)
     acts, hid = wide.act([o for o in g["act_obs"][0]], wide.init_hiddens(1), 0.0)
@@ -563,7 +563,7 @@ def test_recurrent_networks_of_other_widths_match_the_port_at_the_true_width(h, 
         np.testing.assert_allclose(live.numpy(), ref.numpy(), rtol=0, atol=5e-6, err_msg=prefix)
     assert float(net.params[pad_mask].abs().max()) == 0.0 and float(net.updater.exp_avg[pad_mask].abs().max()) == 0.0  # the padding never moves
     with pytest.raises(NotImplementedError):
-        M.QNetwork(obs_space, act_space, cfg, [64, 64, 64], False, True, True, "cuda")  # a two-layer GRU
+        M.QNetwork(obs_space, act_space, cfg, [64] * 6, False, True, True, "cuda")  # five stacked GRU layers (tests/test_gru_stacked.py: up to four)
     with pytest.raises(NotImplementedError):
         M.QNetwork(obs_space, act_space, cfg, [256, 256], False, True, True, "cuda")
 
