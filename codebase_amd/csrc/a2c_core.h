@@ -46,10 +46,12 @@ template <int H>
 struct IsWideCritic<WideCritic<H>> : std::true_type {};
 
 // bytes of forward-pack scratch (collect_pack_scratch) a forward-rows launch of shape S over n_rows rows wants
+// (B, L: recurrent stacks - L pack sets and the chain records of a pass that keeps none, gru_rows.h)
 template <class S>
-int64_t forward_scratch_bytes(int P, int n_rows) {
+int64_t forward_scratch_bytes(int P, int n_rows, int B = 0, int L = 1) {
     if constexpr (IsWideCritic<S>::value) return wc_pack_bytes(P, S::D, S::H) + 16;
     else if constexpr (IsWide<S>::value) return wide_ws(S::net(), P, n_rows, false).total + 16;
+    else if constexpr (IsGru<S>::value) return gru_forward_scratch_bytes<S>(P, n_rows / (B > 0 ? B : 1), B, L);
     else return (int64_t)P * S::NFWD * 4 + 16;
 }
 
@@ -238,9 +240,9 @@ int launch_forward_rows(int P, const AgentMap& am, const float* params, const ma
 
 // ---- backward rows -----------------------------------------------------------------------------------------
 template <class S>
-int64_t backward_ws_bytes(int P, int T, int B) {
+int64_t backward_ws_bytes(int P, int T, int B, int L = 1) {
     if constexpr (IsGru<S>::value) {
-        return gru_rows_ws<S>(P, T, B, false).total;  // the step's forward passes write the records (AcWs::rec_a / rec_c)
+        return gru_rows_ws<S>(P, T, B, false, L).total;  // the step's forward passes write the records (AcWs::rec_a / rec_c)
     } else if constexpr (IsWideCritic<S>::value) {
         return wc_ws(P, T * B, S::D, S::H).total;
     } else if constexpr (IsWide<S>::value) {
@@ -546,7 +548,7 @@ struct AcWs {
 };
 
 template <class SA, class SC>
-AcWs ac_ws_layout(int P, int T, int B) {
+AcWs ac_ws_layout(int P, int T, int B, int L = 1) {  // L: stacked GRU layers of the recurrent families (AgentMap::depth)
     const int64_t TB = (int64_t)T * B;
     AcWs w;
     int64_t o = 0;
@@ -566,18 +568,18 @@ AcWs ac_ws_layout(int P, int T, int B) {
     w.scratch = take(8);
     // weight packs of the forward-rows launches (two networks at once for the paired recurrent pass): collect_pack_scratch's region
     {
-        const int64_t fa = forward_scratch_bytes<SA>(P, (int)(TB + B)), fc = forward_scratch_bytes<SC>(P, (int)(TB + B));
+        const int64_t fa = forward_scratch_bytes<SA>(P, (int)(TB + B), B, L), fc = forward_scratch_bytes<SC>(P, (int)(TB + B), B, L);
         w.packs_bytes = 2 * (fa > fc ? fa : fc);
     }
     w.packs = take(w.packs_bytes / 4 + 1);
     w.rec_a = w.rec_c = o;  // recurrent networks: the activation records of this step's actor / critic forward passes
-    if constexpr (IsGru<SA>::value) w.rec_a = take(gru_rec_floats<SA>(P, T, B));
+    if constexpr (IsGru<SA>::value) w.rec_a = take(gru_rec_floats<SA>(P, T, B, L));
     else if constexpr (mlp_stored_shape<SA>()) w.rec_a = take(mlp_stored_floats<SA>(P, T, B));  // hidden layers of the actors' rows for their backward pass
-    if constexpr (IsGru<SC>::value) w.rec_c = take(gru_rec_floats<SC>(P, T, B));
+    if constexpr (IsGru<SC>::value) w.rec_c = take(gru_rec_floats<SC>(P, T, B, L));
     else if constexpr (mlp_stored_shape<SC>()) w.rec_c = take(mlp_stored_floats<SC>(P, T, B));
     else if constexpr (IsWideCritic<SC>::value) w.rec_c = take(wc_rec_floats(P, (int)TB, SC::H));  // both hidden layers of the critics' rows
     w.bwd = o;
-    const int64_t ba = backward_ws_bytes<SA>(P, T, B), bc = backward_ws_bytes<SC>(P, T, B);
+    const int64_t ba = backward_ws_bytes<SA>(P, T, B, L), bc = backward_ws_bytes<SC>(P, T, B, L);
     // recurrent networks: the two backward passes run side by side (side_stream) and need a workspace each
     w.bwd_c = IsGru<SA>::value && IsGru<SC>::value ? o + ((ba + 255) & ~(int64_t)255) : o;
     w.total = w.bwd_c != o ? w.bwd_c + bc : o + (ba > bc ? ba : bc);
@@ -654,7 +656,7 @@ int ac_step_t(int P, const AgentMap& am, const float* actor, const float* critic
     marlhip_batch btc = *bt;  // the critics' view of the batch
     if (DC != D) btc.obs_agent_stride = -1;
     const marlhip_batch* bc = &btc;
-    const AcWs wl = ac_ws_layout<SA, SC>(P, T, B);
+    const AcWs wl = ac_ws_layout<SA, SC>(P, T, B, (IsGru<SA>::value || IsGru<SC>::value) ? am.depth : 1);
     MARL_REQUIRE(ws_bytes >= wl.total, "ac_loss_grad: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)wl.total);
     char* base = static_cast<char*>(ws);
     ScratchScope pack_scope(base + wl.packs, wl.packs_bytes);
@@ -683,9 +685,10 @@ int ac_step_t(int P, const AgentMap& am, const float* actor, const float* critic
     auto side_forward = [&](const float* prm, int steps, float* out, float* rec) -> int {  // -2: not available
         if constexpr (IsGru<SA>::value && IsGru<SC>::value) {
             if (!side.ok()) return -2;
-            float* pk = reinterpret_cast<float*>(base + wl.bwd_c + gru_rows_ws<SC>(P, T, B, false).packF);
+            float* pk = reinterpret_cast<float*>(base + wl.bwd_c + gru_rows_ws<SC>(P, T, B, false, amc.depth).packF);
             side.do_fork();
-            return gru_forward_rows<SC>(P, amc, prm, bc, steps, out, side.s, rec, pk);
+            // (a stack's record-less pass - marlhip_gru_ppo_prepare's target critics - chains its layers through the critics' record space)
+            return gru_forward_rows<SC>(P, amc, prm, bc, steps, out, side.s, rec, pk, rec == nullptr ? reinterpret_cast<float*>(base + wl.rec_c) : nullptr);
         } else {
             (void)prm; (void)steps; (void)out; (void)rec;
             return -2;

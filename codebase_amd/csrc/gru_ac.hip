@@ -16,7 +16,9 @@ using namespace marl;
 
 static int gru_ac_check(const marlhip_net_shape* s, int centralised = 0) {
     MARL_REQUIRE(s != nullptr, "net shape is NULL");
-    if (agent_map_validate(s) != 0) return -1;
+    if (agent_map_validate(s, true) != 0) return -1;
+    MARL_REQUIRE(gru_depth(s) >= 1 && gru_depth(s) <= GRU_MAX_LAYERS, "recurrent networks: n_hidden %d = %d stacked GRU layers (1..%d)", s->n_hidden,
+                 gru_depth(s), GRU_MAX_LAYERS);
     if (centralised) {
 #define X(p, d, h) if (s->n_agents == p && s->obs_dim == d && s->hidden == h && s->n_actions == 6) return 0;
         MARL_GRU_MAC_SHAPES(X)
@@ -35,11 +37,11 @@ static int gru_ac_check(const marlhip_net_shape* s, int centralised = 0) {
 extern "C" int marlhip_gru_ac_critic_nparams(const marlhip_net_shape* s, int32_t centralised) {
     if (gru_ac_check(s, centralised) != 0) return -1;
     if (centralised) {
-#define X(p, d, h) if (s->n_agents == p && s->obs_dim == d && s->hidden == h) return GruShape<p * d, h, 1>::NPARAM;
+#define X(p, d, h) if (s->n_agents == p && s->obs_dim == d && s->hidden == h) return GruShape<p * d, h, 1>::nparam(gru_depth(s));
         MARL_GRU_MAC_SHAPES(X)
 #undef X
     }
-#define X(d, h, a) if (s->obs_dim == d && s->hidden == h && s->n_actions == a) return GruShape<d, h, 1>::NPARAM;
+#define X(d, h, a) if (s->obs_dim == d && s->hidden == h && s->n_actions == a) return GruShape<d, h, 1>::nparam(gru_depth(s));
     MARL_GRU_AC_SHAPES(X)
 #undef X
     return -1;
@@ -49,12 +51,12 @@ extern "C" int64_t marlhip_gru_ac_workspace_bytes(const marlhip_net_shape* s, in
     if (gru_ac_check(s, centralised) != 0) return -1;
     if (centralised) {
 #define X(p, d, h) \
-    if (s->n_agents == p && s->obs_dim == d && s->hidden == h) return ac_ws_layout<GruShape<d, h, 6>, GruShape<p * d, h, 1>>(s->n_agents, max_len, batch).total;
+    if (s->n_agents == p && s->obs_dim == d && s->hidden == h) return ac_ws_layout<GruShape<d, h, 6>, GruShape<p * d, h, 1>>(s->n_agents, max_len, batch, gru_depth(s)).total;
         MARL_GRU_MAC_SHAPES(X)
 #undef X
     }
 #define X(d, h, a) \
-    if (s->obs_dim == d && s->hidden == h && s->n_actions == a) return ac_ws_layout<GruShape<d, h, a>, GruShape<d, h, 1>>(s->n_agents, max_len, batch).total;
+    if (s->obs_dim == d && s->hidden == h && s->n_actions == a) return ac_ws_layout<GruShape<d, h, a>, GruShape<d, h, 1>>(s->n_agents, max_len, batch, gru_depth(s)).total;
     MARL_GRU_AC_SHAPES(X)
 #undef X
     return -1;
@@ -118,12 +120,15 @@ extern "C" int marlhip_gru_ac_forward(const marlhip_net_shape* s, int32_t value_
     const int P = s->n_agents;
     auto run = [&](auto shape) -> int {
         using S = decltype(shape);
-        float* packs = collect_pack_scratch((size_t)P * S::NFWD * sizeof(float), st);
+        const int L = gru_depth(s);  // h_in / h_out: [L][P][batch][H]
+        const size_t pack_bytes = ((size_t)L * P * S::NFWD * sizeof(float) + 255) & ~(size_t)255;
+        const size_t chain_bytes = L > 1 ? (size_t)(L - 1) * gru_layer_rec<S>(P, steps, batch) * sizeof(float) : 0;
+        float* packs = collect_pack_scratch(pack_bytes + chain_bytes, st);  // (marlhip_gru_forward_workspace_bytes)
         if (packs == nullptr) return -1;  // error text set by collect_pack_scratch
         gru_set_attrs<S>();
-        hipLaunchKernelGGL((gru_pack_kernel<S>), dim3((S::NFWD + 255) / 256, P), dim3(256), 0, st, params, agent_map(s), packs);
-        hipLaunchKernelGGL((gru_seq_fwd_kernel<S>), dim3((batch + 63) / 64, P), dim3(256), S::LDS_FLOATS * sizeof(float), st, (const float*)packs, obs,
-                           (size_t)agent_stride, (size_t)row_stride, steps, batch, h_in, h_out, out, (float*)nullptr);
+        gru_pack_fwd_layers<S>(P, L, params, agent_map(s), packs, st);
+        gru_fwd_layers<S>(P, L, packs, obs, (size_t)agent_stride, (size_t)row_stride, steps, batch, h_in, h_out, out,
+                          chain_bytes ? reinterpret_cast<float*>(reinterpret_cast<char*>(packs) + pack_bytes) : (float*)nullptr, false, st);
         MARL_CHECK_LAUNCH("gru_seq_fwd_kernel (ac forward)");
         return 0;
     };

@@ -1282,14 +1282,18 @@ class WideQmixUpdater(QmixUpdater):
 
 def gru_ac_forward(spec: NetSpec, params, obs, agent_stride, row_stride, steps, batch, value_net=False, h_in=None, want_h=False):
     """sequence forward of recurrent actors (logits [P][steps][B][A]) or critics (values [P][steps][B][1]); rows of agent p at
-    obs + p * agent_stride + (t * B + b) * row_stride; hidden state [P][B][H] in / out"""
+    obs + p * agent_stride + (t * B + b) * row_stride; hidden state [P][B][H] in / out ([L][P][B][H] for L = spec.n_hidden - 1 > 1 stacked layers)"""
     _require_gpu()
     P = spec.n_agents
+    L = max(int(spec.n_hidden), 2) - 1
+    hshape = (P, batch, spec.hidden) if L == 1 else (L, P, batch, spec.hidden)
+    if h_in is not None:
+        assert tuple(h_in.shape) == hshape and h_in.is_contiguous() and h_in.dtype == torch.float32, (tuple(h_in.shape), hshape)
     out = torch.empty(P, steps, batch, 1 if value_net else spec.n_actions, device=params.device)
-    h_out = torch.empty(P, batch, spec.hidden, device=params.device) if want_h else None
+    h_out = torch.empty(*hshape, device=params.device) if want_h else None
     s = spec.c()
     check(lib.marlhip_gru_ac_forward(ctypes.byref(s), int(value_net), _ptr(params), _ptr(obs), int(agent_stride), int(row_stride), int(steps),
-                                     int(batch), _ptr(h_in), _ptr(h_out), _ptr(out), *_fwd_ws(spec, params.device), _stream()), "gru_ac_forward")
+                                     int(batch), _ptr(h_in), _ptr(h_out), _ptr(out), *_gru_fwd_ws(spec, steps, batch, params.device), _stream()), "gru_ac_forward")
     return (out, h_out) if want_h else out
 
 

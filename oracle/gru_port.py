@@ -117,12 +117,12 @@ import contextlib
 
 
 @contextlib.contextmanager
-def recurrent_ac():
+def recurrent_ac(L=1):
     """oracle.ac_update_port with recurrent actors and critics (ac/model.py:189-352 with use_rnn): its mlp / split / nparams hooks
-    become the sequence forward and the recurrent block layout for the duration of the `with` block"""
+    become the sequence forward and the recurrent block layout for the duration of the `with` block; L stacked GRU layers in both families"""
     saved = dp.mlp, dp.split, dp.nparams
     dp.mlp = lambda block, x, D, H, A: sequence(block, x, D, H, A)[0]  # x [S, N, D] from zero hidden states
-    dp.split, dp.nparams = split, nparams
+    dp.split, dp.nparams = split, (lambda D, H, A: nparams(D, H, A, L))
     try:
         yield
     finally:

@@ -29,7 +29,7 @@ def build(cls, P, D, A, H, seed, **over):
     cfg.update(over)
     centralised = bool(over.pop("centralised", False)) if "centralised" in over else False
     cfg.pop("centralised", None)
-    net_cfg = dict(layers=[H, H], parameter_sharing=False, use_orthogonal_init=True, use_rnn=bool(cfg.pop("use_rnn", False)))
+    net_cfg = dict(layers=list(cfg.pop("layers", [H, H])), parameter_sharing=False, use_orthogonal_init=True, use_rnn=bool(cfg.pop("use_rnn", False)))
     # actor.use_rnn / critic.use_rnn set separately (ac/model.py:45-97 passes each flag to its own family)
     actor_rnn, critic_rnn = cfg.pop("actor_rnn", None), cfg.pop("critic_rnn", None)
     a_cfg = dict(net_cfg, use_rnn=net_cfg["use_rnn"] if actor_rnn is None else bool(actor_rnn))
@@ -54,6 +54,8 @@ def fixture(ref_ac_model, ref_ac_train, name, cls, P, D, H, N, seed, masked=Fals
                value_loss_coef=cfg.value_loss_coef, grad_clip=float(cfg.grad_clip or 0.0), num_epochs=cfg.num_epochs,
                ppo_clip=cfg.ppo_clip, actor0=flat_params(net.actor).numpy(), critic0=flat_params(net.critic).numpy(),
                target0=flat_params(net.target_critic).numpy())
+    if "layers" in over:
+        out["layers"] = np.array(over["layers"])
     steps = [0, 250, 400]
     batches = [synthetic_batch(P, T, N, D, A, seed=seed + 100 + i) for i in range(3)]
     if masked:  # batch.action_masks [T+1][N][P][A] (ac/train.py:53-63): random, never empty, the taken action allowed
@@ -92,11 +94,23 @@ def fixture(ref_ac_model, ref_ac_train, name, cls, P, D, H, N, seed, masked=Fals
     print(name, "metrics", np.array(metrics).round(5).tolist())
 
 
+def stacked(ram, rat):
+    """round 6: use_rnn with layers [h] * (L + 1) - nn.GRU(num_layers=L) in both families (utils/models.py:74-90)"""
+    fixture(ram, rat, "learner_a2c_gru_L2_h24.npz", ram.A2CNetwork, P=2, D=15, H=24, N=12, seed=2100, use_rnn=True, layers=[24, 24, 24])
+    fixture(ram, rat, "learner_mappo_gru_L3_p3_h40.npz", ram.PPONetwork, P=3, D=18, H=40, N=9, seed=2200, use_rnn=True, centralised=True, layers=[40, 40, 40, 40])
+
+
 if __name__ == "__main__":
+    import sys
+
     torch.set_num_threads(1)
     import_reference()
     from marlbase.ac import model as ram
     from marlbase.ac import train as rat
+
+    if "--stacked-only" in sys.argv:
+        stacked(ram, rat)
+        sys.exit(0)
 
     fixture(ram, rat, "learner_a2c_H64.npz", ram.A2CNetwork, P=2, D=15, H=64, N=12, seed=500)
     fixture(ram, rat, "learner_a2c_clip_H128.npz", ram.A2CNetwork, P=3, D=18, H=128, N=9, seed=600, grad_clip=0.5, n_steps=3)
@@ -115,3 +129,4 @@ if __name__ == "__main__":
     # actor.use_rnn != critic.use_rnn (round 6): recurrent actors next to feed-forward critics, and the reverse
     fixture(ram, rat, "learner_a2c_rnn_actor_ff_critic_H64.npz", ram.A2CNetwork, P=2, D=15, H=64, N=12, seed=1900, actor_rnn=True, critic_rnn=False)
     fixture(ram, rat, "learner_ppo_ff_actor_rnn_critic_H64.npz", ram.PPONetwork, P=2, D=15, H=64, N=10, seed=2000, actor_rnn=False, critic_rnn=True)
+    stacked(ram, rat)

@@ -111,7 +111,7 @@ def test_layer_lists_the_kernels_do_not_cover_raise():
     for layers in ([], [64] * 17, [2048, 2048], [0, 64]):
         with pytest.raises(NotImplementedError):
             QNetwork(obs_space, act_space, hyper, layers, False, False, True, DEV)
-    for layers in ([32, 48], [64, 64, 64], [192, 192]):  # recurrent: one GRU layer ([h, h]), h <= 128
+    for layers in ([32, 48], [64] * 6, [64], [192, 192]):  # recurrent: equal sizes (RNNNetwork asserts it), one to four stacked GRU layers, h <= 128
         with pytest.raises(NotImplementedError):
             QNetwork(obs_space, act_space, hyper, layers, False, True, True, DEV)
 

@@ -225,3 +225,148 @@ def test_stacked_recurrent_idqn_trains_through_the_entry_point(tmp_path, monkeyp
     df = run.main(["+algorithm=idqn", "env.name=lbforaging:Foraging-8x8-2p-3f-v3", "env.time_limit=25", "env.parallel_envs=64", "seed=1",
                    "algorithm.total_steps=30000", "algorithm.eval_interval=10000", "algorithm.model.use_rnn=True", "algorithm.model.layers=[64,64,64]"])
     assert df.shape[0] >= 2 and np.isfinite(df["loss"]).all() and np.isfinite(df["mean_episode_returns"]).all()
+
+
+# ---- actor-critic learners: both families recurrent at one depth (ac/model.py:45-97 with use_rnn and layers [h] * (L + 1)) ---------------
+AC_FILES = [("learner_a2c_gru_L2_h24.npz", 2), ("learner_mappo_gru_L3_p3_h40.npz", 3)]
+
+
+def _ac_batch(g, i):
+    return {k: torch.tensor(g[f"batch{i}_{k}"]) for k in ("obss", "actions", "rewards", "dones", "filled")}
+
+
+@pytest.mark.parametrize("name,L", AC_FILES)
+def test_ac_oracle_port_with_stacked_recurrent_networks_matches_reference(name, L):
+    from oracle import ac_update_port as ap
+
+    g = dict(np.load(os.path.join(G, name)))
+    D, H, A = int(g["D"]), int(g["H"]), int(g["A"])
+    assert list(g["layers"]) == [H] * (L + 1) and g["actor0"].shape[1] == gp.nparams(D, H, A, L)
+    with gp.recurrent_ac(L):
+        lr = ap.Learner(torch.tensor(g["actor0"]), torch.tensor(g["critic0"]), D, H, A, gamma=float(g["gamma"]), n_steps=int(g["n_steps"]),
+                        entropy_coef=float(g["entropy_coef"]), value_loss_coef=float(g["value_loss_coef"]),
+                        num_epochs=int(g["num_epochs"]) if "ppo" in name else 0, ppo_clip=float(g["ppo_clip"]))
+        lr.target = torch.tensor(g["target0"])
+        for i in range(3):
+            m = lr.update(_ac_batch(g, i), int(g["steps"][i]))
+            np.testing.assert_allclose([m["loss"], m["actor_loss"], m["value_loss"], m["entropy"]], g["metrics"][i], rtol=2e-5, atol=2e-6)
+            np.testing.assert_allclose(lr.actor().detach().numpy(), g[f"actor{i + 1}"], rtol=0, atol=3e-6)
+            np.testing.assert_allclose(lr.critic().detach().numpy(), g[f"critic{i + 1}"], rtol=0, atol=3e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,L", AC_FILES)
+def test_hip_stacked_recurrent_actor_critic_matches_reference(name, L):
+    """A2CNetwork / PPONetwork (centralised critics in the second) built with use_rnn and L + 1 layer sizes: the reference's state_dict
+    keys and shapes, acting / values with [num_layers, N, h]-shaped hidden states, metrics and the live parts of all three blocks after 3
+    updates (the blocks are zero-padded onto the 64-wide kernels: the padding stays exactly zero)"""
+    from collections import namedtuple
+
+    from codebase_amd.ac.model import A2CNetwork, PPONetwork
+    from codebase_amd.dqn import model as M
+    from codebase_amd.spaces import Box, Discrete, Tuple
+
+    Batch = namedtuple("Batch", ["obss", "actions", "rewards", "dones", "filled", "action_masks"])
+    g = dict(np.load(os.path.join(G, name)))
+    P, D, H, A = int(g["P"]), int(g["D"]), int(g["H"]), int(g["A"])
+    ppo, cen = "ppo" in name, "mappo" in name or "maa2c" in name
+    cfg = dict(optimizer="Adam", lr=3e-4, gamma=float(g["gamma"]), grad_clip=False, n_steps=int(g["n_steps"]), entropy_coef=float(g["entropy_coef"]),
+               value_loss_coef=float(g["value_loss_coef"]), standardise_returns=False, target_update_interval_or_tau=200,
+               num_epochs=int(g["num_epochs"]), ppo_clip=float(g["ppo_clip"]))
+    net_cfg = dict(layers=[H] * (L + 1), parameter_sharing=False, use_orthogonal_init=True, use_rnn=True)
+    net = (PPONetwork if ppo else A2CNetwork)(Tuple([Box(-1, 8, (D,))] * P), Tuple([Discrete(A)] * P), cfg, dict(net_cfg), dict(net_cfg, centralised=cen), "cuda")
+    Hk = net.spec.hidden
+    assert net.recurrent and net.rnn_layers == L and Hk == 64 and net.spec.n_hidden == L + 1
+    sd = net.state_dict()
+    assert list(sd.keys()) == [str(k) for k in g["state_dict_keys"]]
+    assert sd[f"actor.independent.0.rnn.weight_hh_l{L - 1}"].shape == (3 * H, H) and sd[f"critic.independent.1.rnn.bias_ih_l{L - 1}"].shape == (3 * H,)
+    dc = P * D if cen else D
+    net.actor_params.copy_(M.pad_gru_blocks(torch.tensor(g["actor0"]), D, H, A, Hk, L))
+    net.critic_params.copy_(M.pad_gru_blocks(torch.tensor(g["critic0"]), dc, H, 1, Hk, L))
+    net.target_critic_params.copy_(M.pad_gru_blocks(torch.tensor(g["target0"]), dc, H, 1, Hk, L))
+    # acting / values one step at a time == the port's sequence (zero initial hidden states), hidden states in the reference's shape
+    obs = torch.tensor(g["batch0_obss"][:4])  # [4][N][P*D]
+    N = obs.shape[1]
+    ah, ch = net.init_actor_hiddens(N), net.init_critic_hiddens(N)
+    assert ah[0].shape == (L, N, Hk) and ch[0].shape == (L, N, Hk)
+    vals = []
+    for t in range(4):
+        per_agent = [obs[t, :, p * D:(p + 1) * D] for p in range(P)]
+        acts, ah = net.act(per_agent, ah)
+        v, ch = net.get_value(per_agent, ch)
+        assert acts.shape == (P, N, 1) and v.shape == (N, P) and ah[1].shape == (L, N, Hk)
+        vals.append(v.cpu())
+    for p in range(P):
+        x = obs[:4] if cen else obs[:4, :, p * D:(p + 1) * D]
+        want, hT = gp.sequence(torch.tensor(g["critic0"][p]), x, dc, H, 1)
+        np.testing.assert_allclose(torch.stack(vals)[:, :, p].numpy(), want[..., 0].numpy(), rtol=0, atol=5e-6)
+        np.testing.assert_allclose(ch[p][:, :, :H].cpu().numpy(), hT.numpy(), rtol=0, atol=5e-6)
+        assert float(ch[p][:, :, H:].abs().max()) == 0.0
+    for i in range(3):
+        b = Batch(*(x.cuda() for x in _ac_batch(g, i).values()), None)
+        m = net.update(b._replace(dones=b.dones.float()), int(g["steps"][i]))
+        np.testing.assert_allclose([m["loss"], m["actor_loss"], m["value_loss"], m["entropy"]], g["metrics"][i], rtol=1e-4, atol=1e-5)
+        for got, want, d, a in ((net.actor_params, g[f"actor{i + 1}"], D, A), (net.critic_params, g[f"critic{i + 1}"], dc, 1),
+                                (net.target_critic_params, g[f"target{i + 1}"], dc, 1)):
+            diff = np.abs(_live(M, got.cpu(), d, H, a, Hk, L).numpy() - want)
+            assert diff.max() <= 5e-5 and (diff > 5e-6).mean() <= 1e-4, (i, diff.max(), (diff > 5e-6).sum())
+    pad = torch.ones_like(net.actor_params, dtype=torch.bool)
+    for p in range(P):
+        for _, view, _ in M.gru_block_views(pad[p], D, H, A, Hk, L):
+            view.fill_(False)
+    assert int(pad.sum()) > 0 and float(net.actor_params[pad].abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("P,T,N,D,H,L,cen,ppo", [(2, 9, 20, 15, 64, 2, False, False), (3, 6, 33, 18, 128, 2, True, True), (4, 7, 16, 27, 64, 4, True, False),
+                                                  (2, 5, 40, 71, 128, 3, False, True)])
+def test_hip_stacked_recurrent_actor_critic_other_shapes_vs_port(P, T, N, D, H, L, cen, ppo):
+    """exact kernel widths (64: LDS-resident, 128: streamed gate matrices), depths up to 4, independent and centralised critics, A2C and PPO:
+    metrics and both gradients of one step against the port"""
+    from collections import namedtuple
+
+    from codebase_amd import hip as h
+    from oracle import ac_update_port as ap
+
+    Batch = namedtuple("Batch", ["obss", "actions", "rewards", "dones", "filled", "action_masks"])
+    A = 5 if D == 71 else 6
+    gen = torch.Generator().manual_seed(31 * L + P)
+    dc = P * D if cen else D
+    actor = 0.1 * torch.randn(P, gp.nparams(D, H, A, L), generator=gen)
+    critic = 0.1 * torch.randn(P, gp.nparams(dc, H, 1, L), generator=gen)
+    target = critic + 0.05 * torch.randn(P, gp.nparams(dc, H, 1, L), generator=gen)
+    batch = ap.synthetic_batch(P, T, N, D, A, seed=5 + L)
+    with gp.recurrent_ac(L):
+        lr = ap.Learner(actor, critic, D, H, A, gamma=0.99, n_steps=5, entropy_coef=0.001, value_loss_coef=0.5, num_epochs=1 if ppo else 0, ppo_clip=0.2)
+        lr.target = target.clone()
+        m_ref = lr.update(batch, 1)
+    spec = h.NetSpec(P, D, H, A, n_hidden=L + 1)
+    block = torch.cat([actor.reshape(-1), critic.reshape(-1)]).cuda()
+    up = h.AcUpdater(spec, block, target.cuda().contiguous(), lr=3e-4, gamma=0.99, n_steps=5, entropy_coef=0.001, value_loss_coef=0.5, grad_clip=False,
+                     ppo_clip=0.2, recurrent=True, centralised_critic=cen)
+    assert up.n_actor == actor.shape[1] and up.n_critic == critic.shape[1]
+    b = Batch(*(batch[k].cuda() for k in ("obss", "actions", "rewards", "dones", "filled")), None)
+    if ppo:
+        up.ppo_prepare(b)
+        m = up.ppo_loss_grad(b).cpu().numpy()[:4]
+    else:
+        m = up.a2c_loss_grad(b).cpu().numpy()[:4]
+    np.testing.assert_allclose(m, [m_ref["loss"], m_ref["actor_loss"], m_ref["value_loss"], m_ref["entropy"]], rtol=1e-4, atol=1e-5)
+    up.apply()
+    for got, want in ((up.block[:P * up.n_actor], lr.actor().detach()), (up.block[P * up.n_actor:], lr.critic().detach())):
+        diff = np.abs(got.cpu().numpy().reshape(P, -1) - want.numpy())
+        assert diff.max() <= 3.1e-4 and (diff > 5e-6).mean() <= 2e-3, (diff.max(), (diff > 5e-6).mean())  # one Adam step: |step| <= lr
+
+
+@pytest.mark.gpu
+def test_stacked_recurrent_ia2c_and_ippo_end_to_end(tmp_path, monkeypatch):
+    """`+algorithm=ia2c|ippo` with actor / critic use_rnn and layers [64,64,64] through codebase_amd.run (the modular rollout carries the
+    actors' [L][P][N][H] between the steps)"""
+    from codebase_amd import run
+
+    for algo in ("ia2c", "ippo"):
+        monkeypatch.setenv("MARLHIP_RUN_DIR", str(tmp_path / algo))
+        df = run.main([f"+algorithm={algo}", "env.name=lbforaging:Foraging-8x8-2p-3f-v3", "env.time_limit=25", "env.parallel_envs=64", "seed=1",
+                       "algorithm.model.actor.layers=[64,64,64]", "algorithm.model.critic.layers=[64,64,64]", "algorithm.model.actor.use_rnn=True",
+                       "algorithm.model.critic.use_rnn=True", "algorithm.total_steps=30000", "algorithm.eval_interval=10000"])
+        assert df.shape[0] >= 2 and np.isfinite(df["loss"]).all() and np.isfinite(df["mean_episode_returns"]).all()
