@@ -379,7 +379,9 @@ int marlhip_gru_nparams(const marlhip_net_shape* s); /* per agent block; <0 if t
  * ..., then final_layer.  Hidden states across calls (h_in / h_out) are [L][P][B][H] - nn.GRU's (num_layers, batch, hidden) per agent;
  * records are L times marlhip_gru_record_floats' one-layer size (the function returns the stack's).  The forward-only entry points
  * (marlhip_gru_forward, marlhip_gru_ac_forward) chain the layers through scratch behind the weight packs: their `workspace` holds
- * marlhip_gru_forward_workspace_bytes(s, steps, batch) bytes (for one layer: marlhip_forward_workspace_bytes(s) suffices, as before). */
+ * marlhip_gru_forward_workspace_bytes(s, steps, batch) bytes (for one layer: marlhip_forward_workspace_bytes(s) suffices, as before).
+ * marlhip_gru_a2c_loss_grad / marlhip_gru_ppo_*: actors and critics at ONE depth (the reference takes a `layers` list per family; two
+ * recurrent families of different depths, and a stack next to a feed-forward family - marlhip_mixed_* - are not built: the host raises). */
 int64_t marlhip_gru_forward_workspace_bytes(const marlhip_net_shape* s, int32_t steps, int32_t batch);
 int64_t marlhip_gru_record_floats(const marlhip_net_shape* s, int32_t steps, int32_t batch);
 int marlhip_gru_forward(const marlhip_net_shape* s, const float* params /* [P][nparams] */, const float* obs, int32_t steps,
