@@ -100,8 +100,8 @@ def test_qnetwork_interface_state_dict_and_act():
     sd2 = {k: v + 1.0 for k, v in sd.items()}
     m.load_state_dict(sd2)
     assert torch.equal(m.state_dict()["target.independent.1.network.4.bias"], sd2["target.independent.1.network.4.bias"])
-    with pytest.raises(NotImplementedError):  # recurrent networks: one GRU layer of width <= 128 (other widths zero-padded, tests/test_gru.py)
-        QNetwork(obs_space, act_space, hyper, [32, 32, 32], False, True, True, "cuda")
+    with pytest.raises(NotImplementedError):  # recurrent networks: one to four stacked GRU layers of width <= 128 (tests/test_gru.py, test_gru_stacked.py)
+        QNetwork(obs_space, act_space, hyper, [32] * 6, False, True, True, "cuda")
     shared = QNetwork(obs_space, act_space, hyper, [64, 64], True, False, True, "cuda")  # parameter_sharing=True
     assert shared.params.shape[0] == 1 and "critic.networks.0.network.0.weight" in shared.state_dict()
 
