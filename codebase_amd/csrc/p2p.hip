@@ -22,57 +22,67 @@
 namespace marl {
 
 // grad: this rank's gradient in, the sum over the ranks out.  flags layout: [parity][chunk], error word at index 2 * max_chunks.
+// A workgroup takes the chunks blockIdx.x, blockIdx.x + gridDim.x, ...: it PUBLISHES all of them first, then waits for and sums one after
+// the other - so at most gridDim.x workgroups ever sit spinning on a peer (marlhip_p2p_allreduce caps the grid: P2P_MAX_WGS).  With one
+// workgroup per chunk a 1 MB gradient put a spinning workgroup on every compute unit; on a device shared by two ranks (the test rigs) the
+// peer's learner kernels - one workgroup per CU, the whole register file - then could not start anywhere, and the exchange they precede
+// never arrived: both ranks ran into the timeout (gpurun r6W: 4 of 7 runs on one box).  Every element is still summed in rank order from
+// the same published values: the same bits as before.
 static __global__ __launch_bounds__(256) void p2p_allreduce_kernel(float* __restrict__ grad, int64_t n, P2pPeers peers, int rank, int world,
-                                                                   int64_t slot_floats, int max_chunks, uint32_t epoch, long long timeout_ticks) {
-    const int b = blockIdx.x * (P2P_CHUNK / 64), par = (int)(epoch & 1u);  // flags are per 64 floats: this block's first one stands for its chunk
-    const int64_t i0 = (int64_t)blockIdx.x * P2P_CHUNK + 4 * threadIdx.x;
+                                                                   int64_t slot_floats, int max_chunks, uint32_t epoch, long long timeout_ticks,
+                                                                   int chunks) {
+    const int par = (int)(epoch & 1u);
     float* mine = const_cast<float*>(peers.slot[rank]) + (int64_t)par * slot_floats;
     uint32_t* my_flags = const_cast<uint32_t*>(peers.flags[rank]);
-    float v[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-        if (i0 + k < n) {
-            v[k] = grad[i0 + k];
-            __hip_atomic_store(mine + i0 + k, v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    __threadfence_system();
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(my_flags + par * max_chunks + b, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    // wait for the peers' chunk b (one lane per peer polls; epochs only grow, so ">= epoch" with wrap-safe arithmetic)
-    __shared__ int s_late;
-    if (threadIdx.x == 0) s_late = 0;
-    __syncthreads();
-    const bool broken = __hip_atomic_load(my_flags + 2 * max_chunks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;  // see p2p_wave_sum
-    if (broken && threadIdx.x == 0) s_late = 1;
-    if (!broken && threadIdx.x < world && threadIdx.x != rank) {
-        const uint32_t* f = peers.flags[threadIdx.x] + par * max_chunks + b;
-        const long long t0 = wall_clock64();
-        while ((int32_t)(p2p_ld_sys(f) - epoch) < 0) {
-            if (wall_clock64() - t0 > timeout_ticks) {
-                s_late = 1;
-                break;
-            }
-            __builtin_amdgcn_s_sleep(2);
-        }
-    }
-    __syncthreads();
-    if (s_late) {  // a peer never published: leave the local gradient, raise the error word (read by marlhip_p2p_status)
-        if (threadIdx.x == 0) __hip_atomic_store(my_flags + 2 * max_chunks, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        return;
-    }
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int r = 0; r < world; ++r) {  // rank order on every rank: the same float sums everywhere
-        const float* src = peers.slot[r] + (int64_t)par * slot_floats;
+    for (int c = blockIdx.x; c < chunks; c += gridDim.x) {  // publish
+        const int64_t i0 = (int64_t)c * P2P_CHUNK + 4 * threadIdx.x;
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-            if (i0 + k < n) {
-                const float x = r == rank ? v[k] : __hip_atomic_load(src + i0 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                acc[k] = r == 0 ? x : acc[k] + x;
-            }
+            if (i0 + k < n) __hip_atomic_store(mine + i0 + k, grad[i0 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __threadfence_system();
+        __syncthreads();
+        // flags are per 64 floats: this chunk's first one stands for it
+        if (threadIdx.x == 0) __hip_atomic_store(my_flags + par * max_chunks + c * (P2P_CHUNK / 64), epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+    __shared__ int s_late;
+    for (int c = blockIdx.x; c < chunks; c += gridDim.x) {  // wait for the peers' chunk c (one lane per peer polls; epochs only grow), sum
+        const int b = c * (P2P_CHUNK / 64);
+        const int64_t i0 = (int64_t)c * P2P_CHUNK + 4 * threadIdx.x;
+        if (threadIdx.x == 0) s_late = 0;
+        __syncthreads();
+        const bool broken = __hip_atomic_load(my_flags + 2 * max_chunks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;  // see p2p_wave_sum
+        if (broken && threadIdx.x == 0) s_late = 1;
+        if (!broken && threadIdx.x < world && threadIdx.x != rank) {
+            const uint32_t* f = peers.flags[threadIdx.x] + par * max_chunks + b;
+            const long long t0 = wall_clock64();
+            while ((int32_t)(p2p_ld_sys(f) - epoch) < 0) {
+                if (wall_clock64() - t0 > timeout_ticks) {
+                    s_late = 1;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+        __syncthreads();
+        if (s_late) {  // a peer never published: leave the local gradient, raise the error word (read by marlhip_p2p_status)
+            if (threadIdx.x == 0) __hip_atomic_store(my_flags + 2 * max_chunks, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            return;
+        }
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < world; ++r) {  // rank order on every rank: the same float sums everywhere
+            const float* src = peers.slot[r] + (int64_t)par * slot_floats;
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-        if (i0 + k < n) grad[i0 + k] = acc[k];
+            for (int k = 0; k < 4; ++k)
+                if (i0 + k < n) {
+                    const float x = r == rank ? grad[i0 + k] : __hip_atomic_load(src + i0 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    acc[k] = r == 0 ? x : acc[k] + x;
+                }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (i0 + k < n) grad[i0 + k] = acc[k];
+        __syncthreads();  // s_late is reset for the next chunk
+    }
 }
 
 // The exchange in the launch geometry of the learner's fused reduce (dqn_reduce_p2p_kernel): one 256-thread workgroup per 64 values, its
@@ -193,8 +203,15 @@ extern "C" int marlhip_p2p_allreduce(void* ctx, float* grad, int64_t count, void
     st->epoch += 1;
     const int chunks = (int)((count + P2P_CHUNK - 1) / P2P_CHUNK);
     const long long timeout_ticks = p2p_timeout_ticks();
-    hipLaunchKernelGGL(p2p_allreduce_kernel, dim3(chunks), dim3(256), 0, (hipStream_t)stream, grad, count, st->peers, st->rank, st->world,
-                       st->max_floats, st->max_chunks, st->epoch, timeout_ticks);
+    // at most P2P_MAX_WGS workgroups wait on a peer at a time (see the kernel); MARLHIP_P2P_MAX_WGS overrides (diagnostics: a large value
+    // restores one workgroup per chunk)
+    int cap = 32;
+    if (const char* v = getenv("MARLHIP_P2P_MAX_WGS")) {
+        const int x = atoi(v);
+        if (x >= 1) cap = x;
+    }
+    hipLaunchKernelGGL(p2p_allreduce_kernel, dim3(chunks < cap ? chunks : cap), dim3(256), 0, (hipStream_t)stream, grad, count, st->peers, st->rank, st->world,
+                       st->max_floats, st->max_chunks, st->epoch, timeout_ticks, chunks);
     MARL_CHECK_LAUNCH("p2p_allreduce_kernel");
     return 0;
 }

@@ -22,9 +22,10 @@ def test_two_ranks_stay_bit_identical_idqn_qmix_a2c():
                "--master-port", port, os.path.join(root, "tests", "two_rank_worker.py")]
         out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
         if p2p == "1" and out.returncode != 0 and "ran into its peer timeout" in out.stderr:
-            # Two processes time-sharing ONE device (this rig only; a job's ranks own a GPU each): in 2 of 49 runs of round 6 (gpurun r6P, r6Q;
-            # 0 of 32 in r6R) a wait of the exchange's SECOND lane never saw its peer's flag within the 20 s bound - not root-caused
-            # (DESIGN 0.4 item 1).  The worker asserts the lanes' status itself, so a timeout can never pass as a result: run it once more.
+            # Two processes time-sharing ONE device (this rig only; a job's ranks own a GPU each): until marlhip_p2p_allreduce capped its
+            # grid, ~100 spinning workgroups of the early rank could leave the late rank's 128-wide learner kernels (a SIMD's whole register
+            # file each) no compute unit to start on - 9 of 80 runs ran into the 20 s bound; 0 of 128 since (gpurun
+            # r6W - r6Y).  The worker asserts the lanes' status itself, so a timeout can never pass as a result; kept: one more attempt.
             print("[two ranks] a lane of the in-library exchange timed out on the shared device; second attempt\n" + out.stderr[-1500:])
             out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
         assert out.returncode == 0 and "TWO_RANK_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]

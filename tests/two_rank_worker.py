@@ -124,6 +124,10 @@ def main():
         fr3, fl3 = torch.zeros(Pw, Nw, device="cuda"), torch.zeros(Nw, dtype=torch.int32, device="cuda")
         torch.cuda.synchronize()
         deferred, stamps, t_start = [], [], time.time()
+        if os.environ.get("MARLHIP_TWO_RANK_DIAG"):  # where is this rank's host when a lane's wait runs into its bound (scripts/gpu_runs/r6W.sh)
+            import faulthandler
+
+            faulthandler.dump_traceback_later(8, exit=False)
         with torch.cuda.stream(torch.cuda.Stream(device="cuda")):  # (nothing leaves a caller that is on the default stream)
             assert m3.attach_grad_sync(s3) == overlap
             for r in range(4):  # two alternating batch sets, as bench.py keeps them: round r + 2 rewrites the set round r's critics read
@@ -133,7 +137,12 @@ def main():
                 b["df"].copy_(b["d"])
                 m3.update_async(Batch(b["o"], b["a"], b["r"], b["df"], b["f"], None), r * Tw * Nw, grad_sync=s3, world=world, overlap=overlap)
                 deferred.append(m3.updater._critic_event is not None)
+        stamps.append(("enqueued", round(time.time() - t_start, 2)))
         torch.cuda.synchronize()
+        stamps.append(("drained", round(time.time() - t_start, 2)))
+        if os.environ.get("MARLHIP_TWO_RANK_DIAG"):
+            faulthandler.cancel_dump_traceback_later()
+            print(f"[diag] rank {rank} overlap={overlap} stamps {stamps}", file=sys.stderr, flush=True)
         assert deferred == [overlap] * 4, deferred
         if overlap and os.environ.get("MARLHIP_P2P", "1") != "0":
             lanes = dict(main=None if s3.p2p is None else s3.p2p.status(), side=None if s3.side is None or s3.side.p2p is None else s3.side.p2p.status())
