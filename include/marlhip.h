@@ -703,6 +703,8 @@ int marlhip_idqn_update_n_dist(const marlhip_idqn_learner* L, int32_t n_updates,
 int marlhip_p2p_handle_bytes(void);
 int marlhip_p2p_create(int32_t rank, int32_t world, int64_t max_floats, void** state_out, void* handle_out);
 int marlhip_p2p_connect(void* state, const void* handles);
+/* (the launch holds at most 32 workgroups - MARLHIP_P2P_MAX_WGS overrides -, each publishing all of its 1024-float chunks before it waits
+ * for the first: the number of compute units that can hold a waiting workgroup is bounded whatever the gradient's size) */
 int marlhip_p2p_allreduce(void* state, float* grad, int64_t count, void* stream);
 /* C-ABI 211: the same exchange in the launch geometry marlhip_idqn_update_n_dist's fused reduce uses (one workgroup per 64 values, a
  * flag per 64 floats) - for the set-up's self-test at the real gradient size (codebase_amd/parallel.py); shares the epoch counter
