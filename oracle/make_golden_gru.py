@@ -76,7 +76,7 @@ def fixture(ref_model, ref_train, name, cls, P, D, H, B, seed, layers=None):
     print(name, float(out["loss0"]), out["losses"].tolist(), out["params0"].shape)
 
 
-def shared_fixture(ref_model, ref_train, name, cls, P, D, H, B, sharing, seed):
+def shared_fixture(ref_model, ref_train, name, cls, P, D, H, B, sharing, seed, layers=None):
     """use_rnn=True on MultiAgentSharedNetwork: blocks [K][n] in `critic.networks` order (K = number of distinct networks), loss,
     gradient, 2 x update(), state_dict keys.  Same seeds-per-role as `fixture` (seed: init, +1: target noise, +7: batch)."""
     from .make_golden_sharing import flat_nets
@@ -86,13 +86,15 @@ def shared_fixture(ref_model, ref_train, name, cls, P, D, H, B, sharing, seed):
     cfg = Cfg(optimizer="Adam", lr=3e-4, gamma=0.99, grad_clip=1.0, target_update_interval_or_tau=200, double_q=True,
               standardise_returns=False)
     with contextlib.redirect_stdout(io.StringIO()):
-        net = cls([Box(D)] * P, [Discrete(A)] * P, cfg, [H, H], sharing, True, True, "cpu")
+        net = cls([Box(D)] * P, [Discrete(A)] * P, cfg, [H, H] if layers is None else list(layers), sharing, True, True, "cpu")
     g = torch.Generator().manual_seed(seed + 1)
     with torch.no_grad():
         for p in net.target.parameters():
             p.add_(0.05 * torch.randn(p.shape, generator=g))
     out = dict(P=P, T=T, B=B, D=D, A=A, H=H, sharing=np.array(net.critic.sharing_indices), keys=np.array(list(net.state_dict().keys())),
                params0=flat_nets(net.critic).numpy(), target0=flat_nets(net.target).numpy())
+    if layers is not None:
+        out["layers"] = np.array(layers)
     batch = synthetic_batch(P, T, B, D, A, seed=seed + 7)
     batch["obss"] = batch["obss"] * 0.25
     if cls is ref_model.VDNetwork:
@@ -112,7 +114,7 @@ def shared_fixture(ref_model, ref_train, name, cls, P, D, H, B, sharing, seed):
     print(name, "sharing", out["sharing"].tolist(), float(out["loss0"]), out["losses"].tolist(), out["params0"].shape)
 
 
-def std_fixture(ref_model, ref_train, name, P, D, H, B, seed):
+def std_fixture(ref_model, ref_train, name, P, D, H, B, seed, layers=None):
     """QNetwork(use_rnn=True, standardise_returns=True): 3 x update() on 3 batches; losses, parameters and the RunningMeanStd
     (mean, var, count) after each (the recurrent sibling of make_golden_std.idqn)"""
     T, A = 8, 6
@@ -120,12 +122,14 @@ def std_fixture(ref_model, ref_train, name, P, D, H, B, seed):
     cfg = Cfg(optimizer="Adam", lr=3e-4, gamma=0.99, grad_clip=1.0, target_update_interval_or_tau=200, double_q=True,
               standardise_returns=True)
     with contextlib.redirect_stdout(io.StringIO()):
-        net = ref_model.QNetwork([Box(D)] * P, [Discrete(A)] * P, cfg, [H, H], False, True, True, "cpu")
+        net = ref_model.QNetwork([Box(D)] * P, [Discrete(A)] * P, cfg, [H, H] if layers is None else list(layers), False, True, True, "cpu")
     g = torch.Generator().manual_seed(seed + 1)
     with torch.no_grad():
         for p in net.target.parameters():
             p.add_(0.05 * torch.randn(p.shape, generator=g))
     out = dict(P=P, T=T, B=B, D=D, A=A, H=H, params0=flat_params(net.critic).numpy(), target0=flat_params(net.target).numpy())
+    if layers is not None:
+        out["layers"] = np.array(layers)
     losses = []
     for i in range(3):
         b = synthetic_batch(P, T, B, D, A, seed=seed + 7 + i)
@@ -185,6 +189,9 @@ def stacked(rm, rt):
     fixture(rm, rt, "learner_gru_vdn_L3_h40.npz", rm.VDNetwork, P=3, D=18, H=40, B=21, seed=2800, layers=[40, 40, 40, 40])  # padded onto the 64 kernels
     fixture(rm, rt, "learner_gru_idqn_L2_h72.npz", rm.QNetwork, P=2, D=15, H=72, B=18, seed=2900, layers=[72, 72, 72])  # padded onto the 128 kernels
     qmix_fixture(rm, rt, "learner_gru_qmix_L2_H64.npz", P=2, D=15, H=64, B=19, seed=3000, layers=[64, 64, 64])
+    # a stack under parameter sharing (SePS: agents 0, 1 share a network) and with standardise_returns
+    shared_fixture(rm, rt, "learner_gru_seps_vdn_L2_h24.npz", rm.VDNetwork, P=3, D=18, H=24, B=17, sharing=[0, 0, 1], seed=3100, layers=[24, 24, 24])
+    std_fixture(rm, rt, "learner_gru_std_L2_h24.npz", P=2, D=15, H=24, B=23, seed=3200, layers=[24, 24, 24])
 
 
 if __name__ == "__main__":

@@ -370,3 +370,68 @@ def test_stacked_recurrent_ia2c_and_ippo_end_to_end(tmp_path, monkeypatch):
                        "algorithm.model.actor.layers=[64,64,64]", "algorithm.model.critic.layers=[64,64,64]", "algorithm.model.actor.use_rnn=True",
                        "algorithm.model.critic.use_rnn=True", "algorithm.total_steps=30000", "algorithm.eval_interval=10000"])
         assert df.shape[0] >= 2 and np.isfinite(df["loss"]).all() and np.isfinite(df["mean_episode_returns"]).all()
+
+
+# ---- a stack together with parameter sharing / standardise_returns (the reference's own classes again) ------------------------------------
+@pytest.mark.gpu
+def test_stacked_recurrent_vdn_with_seps_sharing_matches_reference():
+    """VDNetwork(use_rnn, layers [24] * 3, parameter_sharing=[0, 0, 1]): two networks for three agents, each agent with its own hidden
+    state through the network of its group; the shared network's gradient is the sum over its agents (MultiAgentSharedNetwork)"""
+    from codebase_amd import hip as h
+    from codebase_amd.dqn import model as M
+    from codebase_amd.spaces import Box, Discrete, Tuple
+
+    g, batch = load("learner_gru_seps_vdn_L2_h24.npz")
+    P, D, H, A, L = int(g["P"]), int(g["D"]), int(g["H"]), int(g["A"]), 2
+    sharing = [int(x) for x in g["sharing"]]
+    hyper = dict(optimizer="Adam", lr=3e-4, gamma=0.99, grad_clip=1.0, double_q=True, standardise_returns=False, target_update_interval_or_tau=200)
+    net = M.VDNetwork(Tuple([Box(-1, 8, (D,))] * P), Tuple([Discrete(A)] * P), hyper, [H] * (L + 1), sharing, True, True, "cuda")
+    Hk = net.spec.hidden
+    assert list(net.state_dict().keys()) == list(g["keys"]) and net.params.shape[0] == g["params0"].shape[0] == 2
+    net.params.copy_(M.pad_gru_blocks(torch.tensor(g["params0"]), D, H, A, Hk, L))
+    net.target_params.copy_(M.pad_gru_blocks(torch.tensor(g["target0"]), D, H, A, Hk, L))
+    hb = h.Batch(*(batch[k].cuda().contiguous() for k in ("obss", "actions", "rewards", "dones", "filled")), None)
+    loss, grad = net.updater.loss_grad(hb, mode=net.mode)
+    assert abs(loss.cpu().numpy()[0] - g["loss0"]) <= 3e-5 * abs(g["loss0"])
+    np.testing.assert_allclose(_live(M, grad.cpu(), D, H, A, Hk, L).numpy(), g["grad0"], rtol=3e-4, atol=3e-5 * max(1e-2, np.abs(g["grad0"]).max()))
+    b = h.Batch(*(batch[k] for k in ("obss", "actions", "rewards", "dones", "filled")), None)
+    np.testing.assert_allclose([net.update(b)["loss"] for _ in range(2)], g["losses"], rtol=5e-5)
+    np.testing.assert_allclose(_live(M, net.params.cpu(), D, H, A, Hk, L).numpy(), g["params2"], rtol=0, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_stacked_recurrent_idqn_with_standardise_returns_matches_reference():
+    """QNetwork(use_rnn, layers [24] * 3, standardise_returns=True): 3 updates on 3 batches - losses, running statistics, parameters"""
+    from codebase_amd import hip as h
+    from codebase_amd.dqn import model as M
+    from codebase_amd.spaces import Box, Discrete, Tuple
+
+    g = dict(np.load(os.path.join(G, "learner_gru_std_L2_h24.npz")))
+    P, D, H, A, L = int(g["P"]), int(g["D"]), int(g["H"]), int(g["A"]), 2
+    hyper = dict(optimizer="Adam", lr=3e-4, gamma=0.99, grad_clip=1.0, double_q=True, standardise_returns=True, target_update_interval_or_tau=200)
+    net = M.QNetwork(Tuple([Box(-1, 8, (D,))] * P), Tuple([Discrete(A)] * P), hyper, [H] * (L + 1), False, True, True, "cuda")
+    Hk = net.spec.hidden
+    net.params.copy_(M.pad_gru_blocks(torch.tensor(g["params0"]), D, H, A, Hk, L))
+    net.target_params.copy_(M.pad_gru_blocks(torch.tensor(g["target0"]), D, H, A, Hk, L))
+    for i in range(3):
+        b = h.Batch(*(torch.tensor(g[f"batch{i}_{k}"]) for k in ("obss", "actions", "rewards", "dones", "filled")), None)
+        loss = net.update(b)["loss"]
+        assert abs(loss - g["losses"][i]) <= 5e-5 * abs(g["losses"][i])
+        np.testing.assert_allclose(net.ret_ms.mean.cpu().numpy(), g[f"ret_mean{i + 1}"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(net.ret_ms.var.cpu().numpy(), g[f"ret_var{i + 1}"], rtol=1e-5, atol=1e-6)
+        assert abs(net.ret_ms.count - float(g[f"ret_count{i + 1}"])) < 1e-6
+        np.testing.assert_allclose(_live(M, net.params.cpu(), D, H, A, Hk, L).numpy(), g[f"params{i + 1}"], rtol=0, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_stacked_recurrent_actor_critic_with_sharing_vs_port_free_run(tmp_path, monkeypatch):
+    """ia2c with both families recurrent, three layer sizes and parameter sharing in both, through codebase_amd.run on the warehouse's
+    71-wide rows (the recurrent centralised / shared maps travel through the same AgentMap that now carries the depth)"""
+    from codebase_amd import run
+
+    monkeypatch.setenv("MARLHIP_RUN_DIR", str(tmp_path))
+    df = run.main(["+algorithm=ia2c", "env.name=rware:rware-tiny-2ag-v2", "env.time_limit=40", "env.parallel_envs=64", "seed=1",
+                   "algorithm.model.actor.layers=[64,64,64]", "algorithm.model.critic.layers=[64,64,64]", "algorithm.model.actor.use_rnn=True",
+                   "algorithm.model.critic.use_rnn=True", "algorithm.model.actor.parameter_sharing=True", "algorithm.model.critic.parameter_sharing=True",
+                   "algorithm.total_steps=30000", "algorithm.eval_interval=10000"])
+    assert df.shape[0] >= 2 and np.isfinite(df["loss"]).all() and np.isfinite(df["mean_episode_returns"]).all()
