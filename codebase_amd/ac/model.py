@@ -69,15 +69,15 @@ class A2CNetwork:
         else:
             Hk = max(compiled_width(ha), compiled_width(hc))
             wide = is_wide(ha) or is_wide(hc)
-        if self.recurrent and len(ha) != len(hc):
-            raise NotImplementedError(f"use_rnn with layers actor={ha} critic={hc}: the two families at one depth (the same number of stacked GRU layers)")
         if self.mixed_rnn and (len(ha) != 2 or len(hc) != 2):
             raise NotImplementedError(f"actor.use_rnn != critic.use_rnn with layers actor={ha} critic={hc}: one GRU layer ([h, h]) next to two feed-forward "
                                       "layers; stacked GRU layers run where both families are recurrent")
-        self.rnn_layers = recurrent_depth(ha) if self.recurrent else 1  # stacked GRU layers, both families (csrc/gru_stack.h)
+        # stacked GRU layers per family (csrc/gru_stack.h): each from its own `layers` list; a recurrent family next to a feed-forward one has one
+        self.rnn_layers = {"actor": recurrent_depth(ha) if self.recurrent else 1, "critic": recurrent_depth(hc) if self.recurrent else 1}
+        self.rnn_layers["target_critic"] = self.rnn_layers["critic"]
         # actor and critic are built from their own `layers` lists (ac/model.py:45-97): with different DEPTHS both run on the GEMM path,
         # the critics with their own layer count (marlhip_ac_config.critic_n_hidden)
-        wide = wide or len(ha) != len(hc)
+        wide = wide or (len(ha) != len(hc) and not self.recurrent)  # (recurrent families of two depths stay on the sequence kernels)
         if wide:
             Hk = max(Hk, 144 if 2 in (len(ha), len(hc)) else 16)  # (a width no fused two-layer kernel exists for)
         if bool(_get(critic, "centralised", False)) and not self.recurrent and not wide and (P, obs_dims[0]) in _FUSED_CENTRALISED_128:
@@ -110,14 +110,14 @@ class A2CNetwork:
         K = self.critic_spec.n_blocks  # critic networks (the actors' count is len(obs_dims) = self.spec.n_blocks)
         # torch RNG consumption in the reference's order: actor nets, critic nets, target-critic nets (model.py:44-107)
         if self.actor_recurrent:  # RNNNetwork inits (utils/models.py:83-94); init_flat_gru_params draws one set per call
-            a0 = init_flat_gru_params(obs_dims, ha[0], act_dims, _get(actor, "use_orthogonal_init", True), sets=1, num_layers=self.rnn_layers)[0]
-            a0 = pad_gru_blocks(a0, obs_dims[0], ha[0], act_dims[0], Hk, self.rnn_layers)
+            a0 = init_flat_gru_params(obs_dims, ha[0], act_dims, _get(actor, "use_orthogonal_init", True), sets=1, num_layers=self.rnn_layers["actor"])[0]
+            a0 = pad_gru_blocks(a0, obs_dims[0], ha[0], act_dims[0], Hk, self.rnn_layers["actor"])
         else:
             a0 = _init_blocks(obs_dims, ha, act_dims, _get(actor, "use_orthogonal_init", True))
             a0 = pad_blocks(a0, obs_dims[0], ha, act_dims[0], Hk)
         if self.critic_recurrent:
-            c0 = init_flat_gru_params(cdims, hc[0], [1] * K, _get(critic, "use_orthogonal_init", True), sets=2, num_layers=self.rnn_layers)[0]  # critic, then the target's draws
-            c0 = pad_gru_blocks(c0, cdims[0], hc[0], 1, Hk, self.rnn_layers)
+            c0 = init_flat_gru_params(cdims, hc[0], [1] * K, _get(critic, "use_orthogonal_init", True), sets=2, num_layers=self.rnn_layers["critic"])[0]  # critic, then the target's draws
+            c0 = pad_gru_blocks(c0, cdims[0], hc[0], 1, Hk, self.rnn_layers["critic"])
         else:
             c0 = _init_blocks(cdims, hc, [1] * K, _get(critic, "use_orthogonal_init", True))
             _init_blocks(cdims, hc, [1] * K, _get(critic, "use_orthogonal_init", True))  # target: drawn, then overwritten (soft_update(1.0))
@@ -154,24 +154,22 @@ class A2CNetwork:
     # ---- reference interface ---------------------------------------------------------------
     def init_critic_hiddens(self, batch_size, target=False):
         if self.critic_recurrent:  # RNNNetwork.init_hiddens (utils/models.py:96-102): [num_layers, batch, H] zeros per agent
-            return [torch.zeros(self.rnn_layers, batch_size, self.spec.hidden, device=self.device) for _ in range(self.n_agents)]
+            return [torch.zeros(self.rnn_layers["critic"], batch_size, self.spec.hidden, device=self.device) for _ in range(self.n_agents)]
         return [None] * self.n_agents
 
     def init_actor_hiddens(self, batch_size):
         if self.actor_recurrent:
-            return [torch.zeros(self.rnn_layers, batch_size, self.spec.hidden, device=self.device) for _ in range(self.n_agents)]
+            return [torch.zeros(self.rnn_layers["actor"], batch_size, self.spec.hidden, device=self.device) for _ in range(self.n_agents)]
         return [None] * self.n_agents
 
-    def _h_pack(self, hiddens, N):
+    def _h_pack(self, hiddens, N, L):
         """the reference's per-agent [num_layers, N, H] list -> the kernels' [P][N][H] ([L][P][N][H] for a stack), or None"""
         if hiddens is None or hiddens[0] is None:
             return None
-        L = self.rnn_layers
         h = torch.stack([x.reshape(L, N, -1) for x in hiddens], dim=1).to(self.device)
         return (h[0] if L == 1 else h).contiguous()
 
-    def _h_unpack(self, h, N):
-        L = self.rnn_layers
+    def _h_unpack(self, h, N, L):
         return [(h[p] if L == 1 else h[:, p]).reshape(L, N, -1) for p in range(self.n_agents)]
 
     def _seq(self, block, inputs, hiddens, value_net):
@@ -181,8 +179,9 @@ class A2CNetwork:
             x = x.unsqueeze(1)
         P, S, N, D = x.shape
         x = x.contiguous()
-        out, h = _hip.gru_ac_forward(self.critic_spec if value_net else self.spec, block, x, S * N * D, D, S, N, value_net=value_net, h_in=self._h_pack(hiddens, N), want_h=True)
-        return out, self._h_unpack(h, N)
+        L = self.rnn_layers["critic" if value_net else "actor"]
+        out, h = _hip.gru_ac_forward(self.critic_spec if value_net else self.spec, block, x, S * N * D, D, S, N, value_net=value_net, h_in=self._h_pack(hiddens, N, L), want_h=True)
+        return out, self._h_unpack(h, N, L)
 
     def forward(self, inputs, rnn_hxs, masks):
         raise NotImplementedError("Forward not implemented. Use act, get_value, get_target_value or evaluate_actions instead.")
@@ -220,9 +219,10 @@ class A2CNetwork:
             one = x.dim() == 2
             x = (x.unsqueeze(0) if one else x).contiguous()  # [S][N][P*D]
             S_, N = x.shape[0], x.shape[1]
-            out, h = _hip.gru_ac_forward(self.critic_spec, blk, x, 0, x.shape[-1], S_, N, value_net=2, h_in=self._h_pack(critic_hiddens, N), want_h=True)
+            Lc = self.rnn_layers["critic"]
+            out, h = _hip.gru_ac_forward(self.critic_spec, blk, x, 0, x.shape[-1], S_, N, value_net=2, h_in=self._h_pack(critic_hiddens, N, Lc), want_h=True)
             out = out[..., 0]
-            return (out[:, 0] if one else out).movedim(0, -1).contiguous(), self._h_unpack(h, N)
+            return (out[:, 0] if one else out).movedim(0, -1).contiguous(), self._h_unpack(h, N, Lc)
         if self.critic_recurrent:
             out, critic_hiddens = self._seq(blk, inputs, critic_hiddens, True)
             out = out[..., 0]  # [P][S][N]
@@ -323,7 +323,7 @@ class A2CNetwork:
                     for name, view in block_views(block[i], cin, self.live_hidden[prefix], A, S.hidden):
                         out[f"{prefix}.{group}.{i}.{name}"] = view
                     continue
-                for name, view, shape in gru_block_views(block[i], cin, self.live_hidden[prefix][0], A, S.hidden, self.rnn_layers):
+                for name, view, shape in gru_block_views(block[i], cin, self.live_hidden[prefix][0], A, S.hidden, self.rnn_layers[prefix]):
                     out[f"{prefix}.{group}.{i}.{name}"] = view  # gate matrices: (3, h, h) views of the padded block
                     self._shapes[f"{prefix}.{group}.{i}.{name}"] = shape
         return out

@@ -548,7 +548,8 @@ struct AcWs {
 };
 
 template <class SA, class SC>
-AcWs ac_ws_layout(int P, int T, int B, int L = 1) {  // L: stacked GRU layers of the recurrent families (AgentMap::depth)
+AcWs ac_ws_layout(int P, int T, int B, int L = 1, int Lc_ = 0) {  // L / Lc: stacked GRU layers of recurrent actors / critics (AgentMap::depth; Lc 0 = L)
+    const int Lc = Lc_ > 0 ? Lc_ : L;
     const int64_t TB = (int64_t)T * B;
     AcWs w;
     int64_t o = 0;
@@ -568,18 +569,18 @@ AcWs ac_ws_layout(int P, int T, int B, int L = 1) {  // L: stacked GRU layers of
     w.scratch = take(8);
     // weight packs of the forward-rows launches (two networks at once for the paired recurrent pass): collect_pack_scratch's region
     {
-        const int64_t fa = forward_scratch_bytes<SA>(P, (int)(TB + B), B, L), fc = forward_scratch_bytes<SC>(P, (int)(TB + B), B, L);
+        const int64_t fa = forward_scratch_bytes<SA>(P, (int)(TB + B), B, L), fc = forward_scratch_bytes<SC>(P, (int)(TB + B), B, Lc);
         w.packs_bytes = 2 * (fa > fc ? fa : fc);
     }
     w.packs = take(w.packs_bytes / 4 + 1);
     w.rec_a = w.rec_c = o;  // recurrent networks: the activation records of this step's actor / critic forward passes
     if constexpr (IsGru<SA>::value) w.rec_a = take(gru_rec_floats<SA>(P, T, B, L));
     else if constexpr (mlp_stored_shape<SA>()) w.rec_a = take(mlp_stored_floats<SA>(P, T, B));  // hidden layers of the actors' rows for their backward pass
-    if constexpr (IsGru<SC>::value) w.rec_c = take(gru_rec_floats<SC>(P, T, B, L));
+    if constexpr (IsGru<SC>::value) w.rec_c = take(gru_rec_floats<SC>(P, T, B, Lc));
     else if constexpr (mlp_stored_shape<SC>()) w.rec_c = take(mlp_stored_floats<SC>(P, T, B));
     else if constexpr (IsWideCritic<SC>::value) w.rec_c = take(wc_rec_floats(P, (int)TB, SC::H));  // both hidden layers of the critics' rows
     w.bwd = o;
-    const int64_t ba = backward_ws_bytes<SA>(P, T, B, L), bc = backward_ws_bytes<SC>(P, T, B, L);
+    const int64_t ba = backward_ws_bytes<SA>(P, T, B, L), bc = backward_ws_bytes<SC>(P, T, B, Lc);
     // recurrent networks: the two backward passes run side by side (side_stream) and need a workspace each
     w.bwd_c = IsGru<SA>::value && IsGru<SC>::value ? o + ((ba + 255) & ~(int64_t)255) : o;
     w.total = w.bwd_c != o ? w.bwd_c + bc : o + (ba > bc ? ba : bc);
@@ -656,7 +657,11 @@ int ac_step_t(int P, const AgentMap& am, const float* actor, const float* critic
     marlhip_batch btc = *bt;  // the critics' view of the batch
     if (DC != D) btc.obs_agent_stride = -1;
     const marlhip_batch* bc = &btc;
-    const AcWs wl = ac_ws_layout<SA, SC>(P, T, B, (IsGru<SA>::value || IsGru<SC>::value) ? am.depth : 1);
+    if constexpr (IsGru<SC>::value) {  // recurrent critics of their own depth (marlhip_ac_config.critic_n_hidden = len(critic.layers); 0: as the actors)
+        if (c->critic_n_hidden > 0) amc.depth = (int8_t)(c->critic_n_hidden - 1);
+    }
+    const bool any_gru = IsGru<SA>::value || IsGru<SC>::value;
+    const AcWs wl = ac_ws_layout<SA, SC>(P, T, B, any_gru ? am.depth : 1, any_gru ? amc.depth : 0);
     MARL_REQUIRE(ws_bytes >= wl.total, "ac_loss_grad: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)wl.total);
     char* base = static_cast<char*>(ws);
     ScratchScope pack_scope(base + wl.packs, wl.packs_bytes);

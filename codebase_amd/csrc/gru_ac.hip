@@ -47,19 +47,28 @@ extern "C" int marlhip_gru_ac_critic_nparams(const marlhip_net_shape* s, int32_t
     return -1;
 }
 
-extern "C" int64_t marlhip_gru_ac_workspace_bytes(const marlhip_net_shape* s, int32_t centralised, int32_t max_len, int32_t batch) {
+static int gru_critic_depth(const marlhip_net_shape* s, int critic_n_hidden) { return critic_n_hidden > 0 ? critic_n_hidden - 1 : gru_depth(s); }
+
+extern "C" int64_t marlhip_gru_ac_workspace_bytes_lc(const marlhip_net_shape* s, int32_t centralised, int32_t critic_n_hidden, int32_t max_len, int32_t batch) {
     if (gru_ac_check(s, centralised) != 0) return -1;
+    MARL_REQUIRE(critic_n_hidden == 0 || (critic_n_hidden >= 2 && critic_n_hidden <= GRU_MAX_LAYERS + 1), "gru_ac_workspace_bytes: critic_n_hidden %d (0, 2..%d)",
+                 critic_n_hidden, GRU_MAX_LAYERS + 1);
+    const int Lc = gru_critic_depth(s, critic_n_hidden);
     if (centralised) {
 #define X(p, d, h) \
-    if (s->n_agents == p && s->obs_dim == d && s->hidden == h) return ac_ws_layout<GruShape<d, h, 6>, GruShape<p * d, h, 1>>(s->n_agents, max_len, batch, gru_depth(s)).total;
+    if (s->n_agents == p && s->obs_dim == d && s->hidden == h) return ac_ws_layout<GruShape<d, h, 6>, GruShape<p * d, h, 1>>(s->n_agents, max_len, batch, gru_depth(s), Lc).total;
         MARL_GRU_MAC_SHAPES(X)
 #undef X
     }
 #define X(d, h, a) \
-    if (s->obs_dim == d && s->hidden == h && s->n_actions == a) return ac_ws_layout<GruShape<d, h, a>, GruShape<d, h, 1>>(s->n_agents, max_len, batch, gru_depth(s)).total;
+    if (s->obs_dim == d && s->hidden == h && s->n_actions == a) return ac_ws_layout<GruShape<d, h, a>, GruShape<d, h, 1>>(s->n_agents, max_len, batch, gru_depth(s), Lc).total;
     MARL_GRU_AC_SHAPES(X)
 #undef X
     return -1;
+}
+
+extern "C" int64_t marlhip_gru_ac_workspace_bytes(const marlhip_net_shape* s, int32_t centralised, int32_t max_len, int32_t batch) {
+    return marlhip_gru_ac_workspace_bytes_lc(s, centralised, 0, max_len, batch);
 }
 
 static int gru_ac_call(const marlhip_net_shape* s, const float* actor, const float* critic, const float* target, const marlhip_batch* bt,
@@ -72,6 +81,8 @@ static int gru_ac_call(const marlhip_net_shape* s, const float* actor, const flo
     MARL_REQUIRE(mode == 2 || target != nullptr, "gru_ac_loss_grad: NULL target critic");
     MARL_REQUIRE(bt->obss && bt->actions && bt->rewards && bt->dones && bt->filled, "gru_ac_loss_grad: NULL batch field");
     MARL_REQUIRE(c->n_steps >= 1 && c->n_steps <= 16, "gru_ac_loss_grad: n_steps %d (1..16)", c->n_steps);
+    MARL_REQUIRE(c->critic_n_hidden == 0 || (c->critic_n_hidden >= 2 && c->critic_n_hidden <= GRU_MAX_LAYERS + 1),
+                 "gru_ac_loss_grad: critic_n_hidden %d (0 = as the actors; 2..%d = 1..%d stacked GRU layers)", c->critic_n_hidden, GRU_MAX_LAYERS + 1, GRU_MAX_LAYERS);
     if (c->centralised_critic) {
         MARL_REQUIRE(bt->obs_agent_stride == s->obs_dim && bt->obs_row_stride == (int64_t)s->n_agents * s->obs_dim,
                      "gru_ac_loss_grad: a centralised critic needs the ac/train.py Batch layout (agents concatenated in a row)");

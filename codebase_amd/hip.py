@@ -695,7 +695,11 @@ class AcUpdater:
         self.spec = spec
         if self.recurrent:
             self.n_actor = check(lib.marlhip_gru_nparams(ctypes.byref(s)), "gru_nparams")
-            self.n_critic = check(lib.marlhip_gru_ac_critic_nparams(ctypes.byref(s), int(bool(centralised_critic))), "gru_ac_critic_nparams")
+            sc = spec.c()  # the critics' own number of stacked GRU layers (critic.layers is its own list: ac/model.py:45-97)
+            self.critic_n_hidden = 0
+            if critic_n_hidden is not None and int(critic_n_hidden) != int(spec.n_hidden):
+                self.critic_n_hidden = sc.n_hidden = int(critic_n_hidden)
+            self.n_critic = check(lib.marlhip_gru_ac_critic_nparams(ctypes.byref(sc), int(bool(centralised_critic))), "gru_ac_critic_nparams")
         elif mixed_rnn:  # each block in its own family's layout
             self.critic_n_hidden = 0
             self.n_actor = check(lib.marlhip_gru_nparams(ctypes.byref(s)), "gru_nparams") if mixed_rnn == "actor" else spec.nparams()
@@ -841,7 +845,7 @@ class AcUpdater:
             if self.mixed_rnn:
                 n = check(lib.marlhip_mixed_ac_workspace_bytes(ctypes.byref(s), int(self.mixed_rnn == "actor"), T, B), "mixed_ac_workspace_bytes")
             elif self.recurrent:
-                n = check(lib.marlhip_gru_ac_workspace_bytes(ctypes.byref(s), self.centralised, T, B), "gru_ac_workspace_bytes")
+                n = check(lib.marlhip_gru_ac_workspace_bytes_lc(ctypes.byref(s), self.centralised, self.critic_n_hidden, T, B), "gru_ac_workspace_bytes")
             else:
                 n = check(lib.marlhip_ac_workspace_bytes_lc(ctypes.byref(s), self.centralised, self.critic_n_hidden, T, B), "ac_workspace_bytes")
             self._ws[(T, B)] = torch.empty(int(n), dtype=torch.uint8, device=self.block.device)

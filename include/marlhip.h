@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MARLHIP_VERSION 218
+#define MARLHIP_VERSION 219
 
 int marlhip_version(void);
 const char* marlhip_last_error(void);
@@ -380,8 +380,8 @@ int marlhip_gru_nparams(const marlhip_net_shape* s); /* per agent block; <0 if t
  * records are L times marlhip_gru_record_floats' one-layer size (the function returns the stack's).  The forward-only entry points
  * (marlhip_gru_forward, marlhip_gru_ac_forward) chain the layers through scratch behind the weight packs: their `workspace` holds
  * marlhip_gru_forward_workspace_bytes(s, steps, batch) bytes (for one layer: marlhip_forward_workspace_bytes(s) suffices, as before).
- * marlhip_gru_a2c_loss_grad / marlhip_gru_ppo_*: actors and critics at ONE depth (the reference takes a `layers` list per family; two
- * recurrent families of different depths, and a stack next to a feed-forward family - marlhip_mixed_* - are not built: the host raises). */
+ * marlhip_gru_a2c_loss_grad / marlhip_gru_ppo_*: the critics' depth from marlhip_ac_config.critic_n_hidden when it differs (C-ABI 219); a
+ * stack next to a feed-forward family - marlhip_mixed_* - is not built: the host raises. */
 int64_t marlhip_gru_forward_workspace_bytes(const marlhip_net_shape* s, int32_t steps, int32_t batch);
 int64_t marlhip_gru_record_floats(const marlhip_net_shape* s, int32_t steps, int32_t batch);
 int marlhip_gru_forward(const marlhip_net_shape* s, const float* params /* [P][nparams] */, const float* obs, int32_t steps,
@@ -426,6 +426,10 @@ int marlhip_wide_qmix_loss_grad(const marlhip_net_shape* s, const float* params,
  * the actors (value_net = 0), critics (1) or centralised critics (2, agent_stride 0) with the hidden state carried by the caller (A2CNetwork.act / get_value). */
 int marlhip_gru_ac_critic_nparams(const marlhip_net_shape* s, int32_t centralised);
 int64_t marlhip_gru_ac_workspace_bytes(const marlhip_net_shape* s, int32_t centralised, int32_t max_len, int32_t batch);
+/* C-ABI 219: recurrent critics of another depth than the recurrent actors (actor.layers / critic.layers are separate lists: marlbase/ac/model.py:45-97).
+ * s->n_hidden = len(actor.layers); marlhip_ac_config.critic_n_hidden = len(critic.layers) (0: as the actors; 2..5), the critic blocks in
+ * marlhip_gru_ac_critic_nparams of a shape whose n_hidden is the critics', marlhip_gru_ac_forward(value_net != 0) with that shape too. */
+int64_t marlhip_gru_ac_workspace_bytes_lc(const marlhip_net_shape* s, int32_t centralised, int32_t critic_n_hidden, int32_t max_len, int32_t batch);
 int marlhip_gru_a2c_loss_grad(const marlhip_net_shape* s, const float* actor, const float* critic, const float* target_critic,
                               const marlhip_batch* batch, const struct marlhip_ac_config* cfg, void* workspace, int64_t workspace_bytes,
                               float* actor_grad, float* critic_grad, float* metrics /* [5] */, void* stream);

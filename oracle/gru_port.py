@@ -117,12 +117,14 @@ import contextlib
 
 
 @contextlib.contextmanager
-def recurrent_ac(L=1):
+def recurrent_ac(L=1, Lc=None):
     """oracle.ac_update_port with recurrent actors and critics (ac/model.py:189-352 with use_rnn): its mlp / split / nparams hooks
-    become the sequence forward and the recurrent block layout for the duration of the `with` block; L stacked GRU layers in both families"""
+    become the sequence forward and the recurrent block layout for the duration of the `with` block; L stacked GRU layers in the actors,
+    Lc (default L) in the critics (the one-output networks: each family is built from its own `layers` list, ac/model.py:45-97)"""
     saved = dp.mlp, dp.split, dp.nparams
+    Lc = L if Lc is None else Lc
     dp.mlp = lambda block, x, D, H, A: sequence(block, x, D, H, A)[0]  # x [S, N, D] from zero hidden states
-    dp.split, dp.nparams = split, (lambda D, H, A: nparams(D, H, A, L))
+    dp.split, dp.nparams = split, (lambda D, H, A: nparams(D, H, A, Lc if A == 1 else L))
     try:
         yield
     finally:

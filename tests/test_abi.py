@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(_lib.lib, s), f"{s} declared in marlhip.h but not exported"
     assert sorted(_lib.PROTOTYPES) == syms, "ctypes prototypes and header disagree"
-    assert _lib.lib.marlhip_version() == 218
+    assert _lib.lib.marlhip_version() == 219
 
 
 def test_validation_errors_are_loud_and_need_no_gpu():

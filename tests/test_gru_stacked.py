@@ -229,6 +229,7 @@ def test_stacked_recurrent_idqn_trains_through_the_entry_point(tmp_path, monkeyp
 
 # ---- actor-critic learners: both families recurrent at one depth (ac/model.py:45-97 with use_rnn and layers [h] * (L + 1)) ---------------
 AC_FILES = [("learner_a2c_gru_L2_h24.npz", 2), ("learner_mappo_gru_L3_p3_h40.npz", 3)]
+AC_TWO_DEPTHS = "learner_a2c_gru_L1_L3_h24.npz"  # actor.layers [24, 24], critic.layers [24] * 4: each family from its own list (ac/model.py:45-97)
 
 
 def _ac_batch(g, i):
@@ -276,7 +277,7 @@ def test_hip_stacked_recurrent_actor_critic_matches_reference(name, L):
     net_cfg = dict(layers=[H] * (L + 1), parameter_sharing=False, use_orthogonal_init=True, use_rnn=True)
     net = (PPONetwork if ppo else A2CNetwork)(Tuple([Box(-1, 8, (D,))] * P), Tuple([Discrete(A)] * P), cfg, dict(net_cfg), dict(net_cfg, centralised=cen), "cuda")
     Hk = net.spec.hidden
-    assert net.recurrent and net.rnn_layers == L and Hk == 64 and net.spec.n_hidden == L + 1
+    assert net.recurrent and net.rnn_layers == {"actor": L, "critic": L, "target_critic": L} and Hk == 64 and net.spec.n_hidden == L + 1
     sd = net.state_dict()
     assert list(sd.keys()) == [str(k) for k in g["state_dict_keys"]]
     assert sd[f"actor.independent.0.rnn.weight_hh_l{L - 1}"].shape == (3 * H, H) and sd[f"critic.independent.1.rnn.bias_ih_l{L - 1}"].shape == (3 * H,)
@@ -435,3 +436,61 @@ def test_stacked_recurrent_actor_critic_with_sharing_vs_port_free_run(tmp_path, 
                    "algorithm.model.critic.use_rnn=True", "algorithm.model.actor.parameter_sharing=True", "algorithm.model.critic.parameter_sharing=True",
                    "algorithm.total_steps=30000", "algorithm.eval_interval=10000"])
     assert df.shape[0] >= 2 and np.isfinite(df["loss"]).all() and np.isfinite(df["mean_episode_returns"]).all()
+
+
+def test_ac_oracle_port_with_recurrent_families_of_two_depths_matches_reference():
+    from oracle import ac_update_port as ap
+
+    g = dict(np.load(os.path.join(G, AC_TWO_DEPTHS)))
+    D, H, A = int(g["D"]), int(g["H"]), int(g["A"])
+    La, Lc = len(g["layers"]) - 1, len(g["critic_layers"]) - 1
+    assert (La, Lc) == (1, 3) and g["actor0"].shape[1] == gp.nparams(D, H, A, La) and g["critic0"].shape[1] == gp.nparams(D, H, 1, Lc)
+    with gp.recurrent_ac(La, Lc):
+        lr = ap.Learner(torch.tensor(g["actor0"]), torch.tensor(g["critic0"]), D, H, A, gamma=float(g["gamma"]), n_steps=int(g["n_steps"]),
+                        entropy_coef=float(g["entropy_coef"]), value_loss_coef=float(g["value_loss_coef"]), num_epochs=0, ppo_clip=float(g["ppo_clip"]))
+        lr.target = torch.tensor(g["target0"])
+        for i in range(3):
+            m = lr.update(_ac_batch(g, i), int(g["steps"][i]))
+            np.testing.assert_allclose([m["loss"], m["actor_loss"], m["value_loss"], m["entropy"]], g["metrics"][i], rtol=2e-5, atol=2e-6)
+            np.testing.assert_allclose(lr.actor().detach().numpy(), g[f"actor{i + 1}"], rtol=0, atol=3e-6)
+            np.testing.assert_allclose(lr.critic().detach().numpy(), g[f"critic{i + 1}"], rtol=0, atol=3e-6)
+
+
+@pytest.mark.gpu
+def test_hip_recurrent_families_of_two_depths_match_reference():
+    """A2CNetwork with actor.layers [24, 24] and critic.layers [24] * 4, both use_rnn (C-ABI 219: marlhip_ac_config.critic_n_hidden carries the
+    critics' depth into the recurrent step): state_dict keys, hidden-state shapes per family, metrics and all three blocks after 3 updates"""
+    from collections import namedtuple
+
+    from codebase_amd.ac.model import A2CNetwork
+    from codebase_amd.dqn import model as M
+    from codebase_amd.spaces import Box, Discrete, Tuple
+
+    Batch = namedtuple("Batch", ["obss", "actions", "rewards", "dones", "filled", "action_masks"])
+    g = dict(np.load(os.path.join(G, AC_TWO_DEPTHS)))
+    P, D, H, A = int(g["P"]), int(g["D"]), int(g["H"]), int(g["A"])
+    la, lc = [int(x) for x in g["layers"]], [int(x) for x in g["critic_layers"]]
+    La, Lc = len(la) - 1, len(lc) - 1
+    cfg = dict(optimizer="Adam", lr=3e-4, gamma=float(g["gamma"]), grad_clip=False, n_steps=int(g["n_steps"]), entropy_coef=float(g["entropy_coef"]),
+               value_loss_coef=float(g["value_loss_coef"]), standardise_returns=False, target_update_interval_or_tau=200)
+    base = dict(parameter_sharing=False, use_orthogonal_init=True, use_rnn=True)
+    net = A2CNetwork(Tuple([Box(-1, 8, (D,))] * P), Tuple([Discrete(A)] * P), cfg, dict(base, layers=la), dict(base, layers=lc, centralised=False), "cuda")
+    Hk = net.spec.hidden
+    assert net.recurrent and net.rnn_layers["actor"] == La and net.rnn_layers["critic"] == Lc and not net.spec.wide
+    assert list(net.state_dict().keys()) == [str(k) for k in g["state_dict_keys"]]
+    assert net.init_actor_hiddens(7)[0].shape == (La, 7, Hk) and net.init_critic_hiddens(7)[1].shape == (Lc, 7, Hk)
+    net.actor_params.copy_(M.pad_gru_blocks(torch.tensor(g["actor0"]), D, H, A, Hk, La))
+    net.critic_params.copy_(M.pad_gru_blocks(torch.tensor(g["critic0"]), D, H, 1, Hk, Lc))
+    net.target_critic_params.copy_(M.pad_gru_blocks(torch.tensor(g["target0"]), D, H, 1, Hk, Lc))
+    obs = [torch.rand(7, D) for _ in range(P)]
+    acts, ah = net.act(obs, net.init_actor_hiddens(7))
+    v, ch = net.get_value(obs, net.init_critic_hiddens(7))
+    assert acts.shape == (P, 7, 1) and v.shape == (7, P) and ah[0].shape == (La, 7, Hk) and ch[0].shape == (Lc, 7, Hk)
+    for i in range(3):
+        b = Batch(*(x.cuda() for x in _ac_batch(g, i).values()), None)
+        m = net.update(b._replace(dones=b.dones.float()), int(g["steps"][i]))
+        np.testing.assert_allclose([m["loss"], m["actor_loss"], m["value_loss"], m["entropy"]], g["metrics"][i], rtol=1e-4, atol=1e-5)
+        for got, want, a, L in ((net.actor_params, g[f"actor{i + 1}"], A, La), (net.critic_params, g[f"critic{i + 1}"], 1, Lc),
+                                (net.target_critic_params, g[f"target{i + 1}"], 1, Lc)):
+            diff = np.abs(_live(M, got.cpu(), D, H, a, Hk, L).numpy() - want)
+            assert diff.max() <= 5e-5 and (diff > 5e-6).mean() <= 1e-4, (i, diff.max(), (diff > 5e-6).sum())
