@@ -194,6 +194,7 @@ PROTOTYPES = {
     "marlhip_a2c_loss_grad": (c_int32, [POINTER(NetShape), c_void_p, c_void_p, c_void_p, POINTER(BatchStruct), POINTER(AcConfig),
                                         c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "marlhip_mixed_ac_workspace_bytes": (c_int64, [POINTER(NetShape), c_int32, c_int32, c_int32]),
+    "marlhip_mixed_ac_workspace_bytes_lc": (c_int64, [POINTER(NetShape), c_int32, c_int32, c_int32, c_int32]),
     "marlhip_mixed_a2c_loss_grad": (c_int32, [POINTER(NetShape), c_int32, c_void_p, c_void_p, c_void_p, POINTER(BatchStruct), POINTER(AcConfig),
                                               c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "marlhip_mixed_ppo_prepare": (c_int32, [POINTER(NetShape), c_int32, c_void_p, c_void_p, c_void_p, POINTER(BatchStruct), POINTER(AcConfig),

@@ -61,23 +61,20 @@ class A2CNetwork:
             Hk = max(recurrent_width(ha)[1], recurrent_width(hc)[1])
             wide = False
         elif self.mixed_rnn:
-            if is_wide(hc if self.actor_recurrent else ha) or len(ha) != len(hc) or bool(_get(critic, "centralised", False)):
+            if is_wide(hc if self.actor_recurrent else ha) or bool(_get(critic, "centralised", False)):  # (is_wide: any list but two sizes <= 128)
                 raise NotImplementedError(f"actor.use_rnn != critic.use_rnn with layers actor={ha} critic={hc}: the feed-forward family must be two "
-                                          "layers of at most 128 units next to the [h, h] recurrent one, and the critics independent")
+                                          "layers of at most 128 units next to the recurrent one ([h] * 2 .. [h] * 5), and the critics independent")
             Hk = max(recurrent_width(ha)[1] if self.actor_recurrent else compiled_width(ha), recurrent_width(hc)[1] if self.critic_recurrent else compiled_width(hc))
             wide = False
         else:
             Hk = max(compiled_width(ha), compiled_width(hc))
             wide = is_wide(ha) or is_wide(hc)
-        if self.mixed_rnn and (len(ha) != 2 or len(hc) != 2):
-            raise NotImplementedError(f"actor.use_rnn != critic.use_rnn with layers actor={ha} critic={hc}: one GRU layer ([h, h]) next to two feed-forward "
-                                      "layers; stacked GRU layers run where both families are recurrent")
         # stacked GRU layers per family (csrc/gru_stack.h): each from its own `layers` list; a recurrent family next to a feed-forward one has one
-        self.rnn_layers = {"actor": recurrent_depth(ha) if self.recurrent else 1, "critic": recurrent_depth(hc) if self.recurrent else 1}
+        self.rnn_layers = {"actor": recurrent_depth(ha) if self.actor_recurrent else 1, "critic": recurrent_depth(hc) if self.critic_recurrent else 1}
         self.rnn_layers["target_critic"] = self.rnn_layers["critic"]
         # actor and critic are built from their own `layers` lists (ac/model.py:45-97): with different DEPTHS both run on the GEMM path,
         # the critics with their own layer count (marlhip_ac_config.critic_n_hidden)
-        wide = wide or (len(ha) != len(hc) and not self.recurrent)  # (recurrent families of two depths stay on the sequence kernels)
+        wide = wide or (len(ha) != len(hc) and not self.recurrent and not self.mixed_rnn)  # (a recurrent family's depth is its own: the sequence kernels)
         if wide:
             Hk = max(Hk, 144 if 2 in (len(ha), len(hc)) else 16)  # (a width no fused two-layer kernel exists for)
         if bool(_get(critic, "centralised", False)) and not self.recurrent and not wide and (P, obs_dims[0]) in _FUSED_CENTRALISED_128:
@@ -129,7 +126,7 @@ class A2CNetwork:
                                       value_loss_coef=self.value_loss_coef, grad_clip=self.grad_clip,
                                       ppo_clip=float(_get(cfg, "ppo_clip", 0.2)), standardise_returns=self.standardise_returns,
                                       centralised_critic=self.centralised_critic, recurrent=self.recurrent, optimizer=self.optimizer,
-                                      critic_sharing=self.critic_sharing, critic_n_hidden=None if self.mixed_rnn else len(hc), mixed_rnn=self.mixed_rnn)
+                                      critic_sharing=self.critic_sharing, critic_n_hidden=None if self.mixed_rnn == "actor" else len(hc), mixed_rnn=self.mixed_rnn)
         self.ret_ms = self.updater.ret_stats
         self.actor_params = self.updater.actor
 

@@ -700,11 +700,19 @@ class AcUpdater:
             if critic_n_hidden is not None and int(critic_n_hidden) != int(spec.n_hidden):
                 self.critic_n_hidden = sc.n_hidden = int(critic_n_hidden)
             self.n_critic = check(lib.marlhip_gru_ac_critic_nparams(ctypes.byref(sc), int(bool(centralised_critic))), "gru_ac_critic_nparams")
-        elif mixed_rnn:  # each block in its own family's layout
+        elif mixed_rnn:  # each block in its own family's layout; the recurrent family may be a stack (its own depth), the other has two layers
             self.critic_n_hidden = 0
-            self.n_actor = check(lib.marlhip_gru_nparams(ctypes.byref(s)), "gru_nparams") if mixed_rnn == "actor" else spec.nparams()
-            self.n_critic = (check(lib.marlhip_ac_critic_nparams(ctypes.byref(s), 0), "ac_critic_nparams") if mixed_rnn == "actor" else
-                             check(lib.marlhip_gru_ac_critic_nparams(ctypes.byref(s), 0), "gru_ac_critic_nparams"))
+            if mixed_rnn == "actor":  # spec.n_hidden = len(actor.layers)
+                two = spec.c()
+                two.n_hidden = 2
+                self.n_actor = check(lib.marlhip_gru_nparams(ctypes.byref(s)), "gru_nparams")
+                self.n_critic = check(lib.marlhip_ac_critic_nparams(ctypes.byref(two), 0), "ac_critic_nparams")
+            else:  # spec.n_hidden = 2 (the actors'); critic_n_hidden = len(critic.layers)
+                sc = spec.c()
+                if critic_n_hidden is not None and int(critic_n_hidden) != 2:
+                    self.critic_n_hidden = sc.n_hidden = int(critic_n_hidden)
+                self.n_actor = spec.nparams()
+                self.n_critic = check(lib.marlhip_gru_ac_critic_nparams(ctypes.byref(sc), 0), "gru_ac_critic_nparams")
         else:
             self.n_actor = spec.nparams()
             sc = spec.c()
@@ -843,7 +851,7 @@ class AcUpdater:
         if (T, B) not in self._ws:
             s = self.spec.c()
             if self.mixed_rnn:
-                n = check(lib.marlhip_mixed_ac_workspace_bytes(ctypes.byref(s), int(self.mixed_rnn == "actor"), T, B), "mixed_ac_workspace_bytes")
+                n = check(lib.marlhip_mixed_ac_workspace_bytes_lc(ctypes.byref(s), int(self.mixed_rnn == "actor"), self.critic_n_hidden, T, B), "mixed_ac_workspace_bytes")
             elif self.recurrent:
                 n = check(lib.marlhip_gru_ac_workspace_bytes_lc(ctypes.byref(s), self.centralised, self.critic_n_hidden, T, B), "gru_ac_workspace_bytes")
             else:

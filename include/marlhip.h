@@ -380,8 +380,8 @@ int marlhip_gru_nparams(const marlhip_net_shape* s); /* per agent block; <0 if t
  * records are L times marlhip_gru_record_floats' one-layer size (the function returns the stack's).  The forward-only entry points
  * (marlhip_gru_forward, marlhip_gru_ac_forward) chain the layers through scratch behind the weight packs: their `workspace` holds
  * marlhip_gru_forward_workspace_bytes(s, steps, batch) bytes (for one layer: marlhip_forward_workspace_bytes(s) suffices, as before).
- * marlhip_gru_a2c_loss_grad / marlhip_gru_ppo_*: the critics' depth from marlhip_ac_config.critic_n_hidden when it differs (C-ABI 219); a
- * stack next to a feed-forward family - marlhip_mixed_* - is not built: the host raises. */
+ * marlhip_gru_a2c_loss_grad / marlhip_gru_ppo_*: the critics' depth from marlhip_ac_config.critic_n_hidden when it differs (C-ABI 219);
+ * marlhip_mixed_*: the recurrent family's depth as documented there. */
 int64_t marlhip_gru_forward_workspace_bytes(const marlhip_net_shape* s, int32_t steps, int32_t batch);
 int64_t marlhip_gru_record_floats(const marlhip_net_shape* s, int32_t steps, int32_t batch);
 int marlhip_gru_forward(const marlhip_net_shape* s, const float* params /* [P][nparams] */, const float* obs, int32_t steps,
@@ -451,6 +451,10 @@ int marlhip_gru_ac_forward(const marlhip_net_shape* s, int32_t value_net, const 
  * cfg->actor_forward_kept / defer_critic_backward must be 0.  Forward passes for acting / values: the family's own marlhip_gru_ac_forward or
  * marlhip_ac_forward_rows. */
 int64_t marlhip_mixed_ac_workspace_bytes(const marlhip_net_shape* s, int32_t actor_rnn, int32_t max_len, int32_t batch);
+/* C-ABI 219: the recurrent family as a stack of GRU layers - recurrent actors: s->n_hidden = len(actor.layers) (2..5; the critics' two layers
+ * stay implied, cfg->critic_n_hidden 0 or 2); recurrent critics: cfg->critic_n_hidden = len(critic.layers) (s->n_hidden = the actors' 2) and
+ * the workspace from this query */
+int64_t marlhip_mixed_ac_workspace_bytes_lc(const marlhip_net_shape* s, int32_t actor_rnn, int32_t critic_n_hidden, int32_t max_len, int32_t batch);
 int marlhip_mixed_a2c_loss_grad(const marlhip_net_shape* s, int32_t actor_rnn, const float* actor, const float* critic, const float* target_critic,
                                 const marlhip_batch* batch, const struct marlhip_ac_config* cfg, void* workspace, int64_t workspace_bytes,
                                 float* actor_grad, float* critic_grad, float* metrics /* [5] */, void* stream);

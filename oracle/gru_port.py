@@ -138,8 +138,8 @@ def mixed_ac():
     feed-forward network (the two layouts have different sizes for every (D, H, A))"""
     saved = dp.mlp, dp.split, dp.nparams
 
-    def is_gru(block, D, H, A):
-        return block.numel() == nparams(D, H, A)
+    def is_gru(block, D, H, A):  # (a stack of L layers has L (6 H^2 + 6 H) gate parameters where the feed-forward net has H^2 + H: never equal)
+        return any(block.numel() == nparams(D, H, A, L) for L in range(1, 9))
 
     dp.mlp = lambda block, x, D, H, A: sequence(block, x, D, H, A)[0] if is_gru(block, D, H, A) else saved[0](block, x, D, H, A)
     dp.split = lambda block, D, H, A: split(block, D, H, A) if is_gru(block, D, H, A) else saved[1](block, D, H, A)

@@ -33,6 +33,8 @@ def build(cls, P, D, A, H, seed, **over):
     # actor.use_rnn / critic.use_rnn set separately (ac/model.py:45-97 passes each flag to its own family)
     actor_rnn, critic_rnn = cfg.pop("actor_rnn", None), cfg.pop("critic_rnn", None)
     a_cfg = dict(net_cfg, use_rnn=net_cfg["use_rnn"] if actor_rnn is None else bool(actor_rnn))
+    if "actor_layers" in cfg:
+        a_cfg["layers"] = list(cfg.pop("actor_layers"))
     c_cfg = dict(net_cfg, use_rnn=net_cfg["use_rnn"] if critic_rnn is None else bool(critic_rnn), centralised=centralised)
     if "critic_layers" in cfg:  # critic.layers is its own list (ac/model.py:45-97)
         c_cfg["layers"] = list(cfg.pop("critic_layers"))
@@ -60,6 +62,8 @@ def fixture(ref_ac_model, ref_ac_train, name, cls, P, D, H, N, seed, masked=Fals
         out["layers"] = np.array(over["layers"])
     if "critic_layers" in over:
         out["critic_layers"] = np.array(over["critic_layers"])
+    if "actor_layers" in over:
+        out["actor_layers"] = np.array(over["actor_layers"])
     steps = [0, 250, 400]
     batches = [synthetic_batch(P, T, N, D, A, seed=seed + 100 + i) for i in range(3)]
     if masked:  # batch.action_masks [T+1][N][P][A] (ac/train.py:53-63): random, never empty, the taken action allowed
@@ -104,6 +108,11 @@ def stacked(ram, rat):
     fixture(ram, rat, "learner_mappo_gru_L3_p3_h40.npz", ram.PPONetwork, P=3, D=18, H=40, N=9, seed=2200, use_rnn=True, centralised=True, layers=[40, 40, 40, 40])
     # recurrent families of two depths: actor.layers [24, 24] (one GRU layer), critic.layers [24] * 4 (three)
     fixture(ram, rat, "learner_a2c_gru_L1_L3_h24.npz", ram.A2CNetwork, P=2, D=15, H=24, N=10, seed=2300, use_rnn=True, layers=[24, 24], critic_layers=[24, 24, 24, 24])
+    # a stack next to a feed-forward family: recurrent actors [24] * 3 + feed-forward critics [24, 24]; feed-forward actors + recurrent critics [24] * 3
+    fixture(ram, rat, "learner_a2c_rnn_actor_L2_ff_critic_h24.npz", ram.A2CNetwork, P=2, D=15, H=24, N=10, seed=2400, actor_rnn=True, critic_rnn=False,
+            actor_layers=[24, 24, 24])
+    fixture(ram, rat, "learner_ppo_ff_actor_rnn_critic_L2_h24.npz", ram.PPONetwork, P=2, D=15, H=24, N=10, seed=2500, actor_rnn=False, critic_rnn=True,
+            critic_layers=[24, 24, 24])
 
 
 if __name__ == "__main__":

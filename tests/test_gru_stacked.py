@@ -494,3 +494,80 @@ def test_hip_recurrent_families_of_two_depths_match_reference():
                                 (net.target_critic_params, g[f"target{i + 1}"], 1, Lc)):
             diff = np.abs(_live(M, got.cpu(), D, H, a, Hk, L).numpy() - want)
             assert diff.max() <= 5e-5 and (diff > 5e-6).mean() <= 1e-4, (i, diff.max(), (diff > 5e-6).sum())
+
+
+# ---- a stack next to a feed-forward family (actor.use_rnn != critic.use_rnn with three layer sizes on the recurrent side) ---------------------
+AC_MIXED_STACK = [("learner_a2c_rnn_actor_L2_ff_critic_h24.npz", "actor"), ("learner_ppo_ff_actor_rnn_critic_L2_h24.npz", "critic")]
+
+
+@pytest.mark.parametrize("name,which", AC_MIXED_STACK)
+def test_ac_oracle_port_with_one_stacked_recurrent_family_matches_reference(name, which):
+    from oracle import ac_update_port as ap
+
+    g = dict(np.load(os.path.join(G, name)))
+    D, H, A = int(g["D"]), int(g["H"]), int(g["A"])
+    rec = g["actor0"] if which == "actor" else g["critic0"]
+    assert rec.shape[1] == gp.nparams(D, H, A if which == "actor" else 1, 2)
+    with gp.mixed_ac():
+        lr = ap.Learner(torch.tensor(g["actor0"]), torch.tensor(g["critic0"]), D, H, A, gamma=float(g["gamma"]), n_steps=int(g["n_steps"]),
+                        entropy_coef=float(g["entropy_coef"]), value_loss_coef=float(g["value_loss_coef"]),
+                        num_epochs=int(g["num_epochs"]) if "ppo" in name else 0, ppo_clip=float(g["ppo_clip"]))
+        lr.target = torch.tensor(g["target0"])
+        for i in range(3):
+            m = lr.update(_ac_batch(g, i), int(g["steps"][i]))
+            np.testing.assert_allclose([m["loss"], m["actor_loss"], m["value_loss"], m["entropy"]], g["metrics"][i], rtol=2e-5, atol=2e-6)
+            np.testing.assert_allclose(lr.actor().detach().numpy(), g[f"actor{i + 1}"], rtol=0, atol=3e-6)
+            np.testing.assert_allclose(lr.critic().detach().numpy(), g[f"critic{i + 1}"], rtol=0, atol=3e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,which", AC_MIXED_STACK)
+def test_hip_one_stacked_recurrent_family_next_to_a_feed_forward_one_matches_reference(name, which):
+    """marlhip_mixed_* with the recurrent family as a stack (C-ABI 219): recurrent actors [24] * 3 + feed-forward critics [24, 24] (A2CNetwork),
+    feed-forward actors [24, 24] + recurrent critics [24] * 3 (PPONetwork) - state_dict keys, metrics, the live parts of all blocks"""
+    from collections import namedtuple
+
+    from codebase_amd.ac.model import A2CNetwork, PPONetwork
+    from codebase_amd.dqn import model as M
+    from codebase_amd.spaces import Box, Discrete, Tuple
+
+    Batch = namedtuple("Batch", ["obss", "actions", "rewards", "dones", "filled", "action_masks"])
+    g = dict(np.load(os.path.join(G, name)))
+    P, D, H, A, L = int(g["P"]), int(g["D"]), int(g["H"]), int(g["A"]), 2
+    ppo = "ppo" in name
+    cfg = dict(optimizer="Adam", lr=3e-4, gamma=float(g["gamma"]), grad_clip=False, n_steps=int(g["n_steps"]), entropy_coef=float(g["entropy_coef"]),
+               value_loss_coef=float(g["value_loss_coef"]), standardise_returns=False, target_update_interval_or_tau=200,
+               num_epochs=int(g["num_epochs"]), ppo_clip=float(g["ppo_clip"]))
+    base = dict(parameter_sharing=False, use_orthogonal_init=True)
+    la = [H] * (L + 1) if which == "actor" else [H, H]
+    lc = [H] * (L + 1) if which == "critic" else [H, H]
+    net = (PPONetwork if ppo else A2CNetwork)(Tuple([Box(-1, 8, (D,))] * P), Tuple([Discrete(A)] * P), cfg, dict(base, layers=la, use_rnn=which == "actor"),
+                                             dict(base, layers=lc, use_rnn=which == "critic", centralised=False), "cuda")
+    Hk = net.spec.hidden
+    assert net.updater.mixed_rnn == which and net.rnn_layers[which] == L and net.rnn_layers["critic" if which == "actor" else "actor"] == 1
+    assert list(net.state_dict().keys()) == [str(k) for k in g["state_dict_keys"]]
+
+    def put(dst, src, d, a, recurrent):
+        dst.copy_(M.pad_gru_blocks(torch.tensor(src), d, H, a, Hk, L) if recurrent else M.pad_blocks(torch.tensor(src), d, [H, H], a, Hk))
+
+    def live(blocks, d, a, recurrent):
+        if recurrent:
+            return _live(M, blocks.cpu(), d, H, a, Hk, L).numpy()
+        return torch.stack([torch.cat([v.reshape(-1) for _, v in M.block_views(blocks[p].cpu(), d, (H, H), a, Hk)]) for p in range(P)]).numpy()
+
+    put(net.actor_params, g["actor0"], D, A, which == "actor")
+    put(net.critic_params, g["critic0"], D, 1, which == "critic")
+    put(net.target_critic_params, g["target0"], D, 1, which == "critic")
+    obs = [torch.rand(5, D) for _ in range(P)]
+    acts, hid = net.act(obs, net.init_actor_hiddens(5))
+    v, ch = net.get_value(obs, net.init_critic_hiddens(5))
+    assert acts.shape == (P, 5, 1) and v.shape == (5, P)
+    assert (hid[0] is not None and hid[0].shape == (L, 5, Hk)) == (which == "actor") and (ch[0] is not None and ch[0].shape == (L, 5, Hk)) == (which == "critic")
+    for i in range(3):
+        b = Batch(*(x.cuda() for x in _ac_batch(g, i).values()), None)
+        m = net.update(b._replace(dones=b.dones.float()), int(g["steps"][i]))
+        np.testing.assert_allclose([m["loss"], m["actor_loss"], m["value_loss"], m["entropy"]], g["metrics"][i], rtol=1e-4, atol=1e-5)
+        for got, want, a, rec in ((net.actor_params, g[f"actor{i + 1}"], A, which == "actor"), (net.critic_params, g[f"critic{i + 1}"], 1, which == "critic"),
+                                  (net.target_critic_params, g[f"target{i + 1}"], 1, which == "critic")):
+            diff = np.abs(live(got, D, a, rec) - want)
+            assert diff.max() <= 5e-5 and (diff > 5e-6).mean() <= 1e-4, (i, diff.max(), (diff > 5e-6).sum())
