@@ -13,7 +13,8 @@ single fused launch) plus the target-critic block; state_dict tensors are slices
 Built: independent or shared (parameter_sharing True / SePS index list, the same for actor and critic) actors and
 critics (IA2C / IPPO) and centralised critics (MAA2C / MAPPO: fused kernels up to 4 LBF agents, GEMM path beyond), two hidden layers of any widths <= 128
 (zero-padded to the compiled 64 / 128, exact), recurrent actors / critics (`use_rnn`, widths 64 / 128; `actor.use_rnn` and `critic.use_rnn`
-may differ: csrc/mixed_ac.hip), `action_mask`.
+may differ: csrc/mixed_ac.hip; stacked GRU layers: csrc/gru_stack.h), `action_mask`, agents of different observation / action sizes
+(independent feed-forward networks: zero-padded to the widest, the missing actions masked).
 """
 from collections import OrderedDict
 
@@ -35,6 +36,26 @@ def _get(cfg, k, d=None):
 def _init_blocks(obs_dims, hidden, out_dims, orth):
     return torch.stack([torch.cat([t.detach().reshape(-1) for lin in _fc([d] + list(hidden) + [a], orth) for t in (lin.weight, lin.bias)])
                         for d, a in zip(obs_dims, out_dims)])
+
+
+def _init_blocks_io_padded(obs_dims, hidden, out_dims, orth, D, A):
+    """_init_blocks for agents whose observation / action sizes differ (MultiAgentIndependentNetwork builds each agent's network from its own
+    sizes, utils/models.py:133-155; the same torch RNG draws): every block laid out for D = max(obs_dims) inputs and A = max(out_dims)
+    outputs - zero input columns behind an agent's own, zero output rows / biases behind its own"""
+    rows = []
+    for d, a in zip(obs_dims, out_dims):
+        lins = _fc([d] + list(hidden) + [a], orth)
+        parts = []
+        for k, lin in enumerate(lins):
+            w, b = lin.weight.detach(), lin.bias.detach()
+            if k == 0 and d < D:
+                w = torch.cat([w, torch.zeros(w.shape[0], D - d)], dim=1)
+            if k == len(lins) - 1 and a < A:
+                w = torch.cat([w, torch.zeros(A - a, w.shape[1])], dim=0)
+                b = torch.cat([b, torch.zeros(A - a)])
+            parts += [w.reshape(-1), b]
+        rows.append(torch.cat(parts))
+    return torch.stack(rows)
 
 
 _FUSED_CENTRALISED_128 = {(3, 18), (3, 24), (4, 21), (4, 27)}
@@ -81,8 +102,18 @@ class A2CNetwork:
             Hk = 128  # fused centralised-critic kernels for 3 / 4 agents exist at width 128 only (a2c.hip MARL_MAC_SHAPES); every other
             #           (agents, observation width) runs the critics on the wide path (csrc/wide_mlp.h) at the compiled width of the layers
         self.live_hidden = {"actor": tuple(ha), "critic": tuple(hc), "target_critic": tuple(hc)}
-        if len(set(obs_dims)) != 1 or len(set(act_dims)) != 1:
-            raise NotImplementedError("agents with different observation / action sizes")
+        # Agents with different observation / action sizes (utils/models.py:133-155; A2CNetwork splits the concatenated row by the agents' own
+        # sizes and builds one Categorical per agent, ac/model.py:115-145 - the DQN family cannot: its learner stacks the agents' values,
+        # dqn/model.py:128).  They run on the kernels of (max D, max A): an agent's block has zero input columns / output rows behind its
+        # own, its rows are zero-padded, and the actions it does not have are masked exactly as batch.action_masks masks (logit -1e8: probability
+        # exactly 0, no entropy, no gradient) - the padding stays zero.
+        self.obs_dims, self.act_dims = list(obs_dims), list(act_dims)
+        self.hetero = len(set(obs_dims)) != 1 or len(set(act_dims)) != 1
+        if self.hetero and (self.recurrent or self.mixed_rnn or wide or self.sharing is not None or self.critic_sharing is not None
+                            or bool(_get(critic, "centralised", False))):
+            raise NotImplementedError("agents with different observation / action sizes: independent feed-forward actors and critics of two layers "
+                                      "<= 128 (no parameter sharing, no centralised critic, no use_rnn)")
+        D_all, A_all = max(obs_dims), max(act_dims)
         if str(device) == "cpu":
             raise _hip.MarlHipError("codebase_amd.ac.model.A2CNetwork runs on the GPU only: set algorithm.model.device=cuda")
         self.optimizer = _get(cfg, "optimizer", "Adam")  # getattr(optim, cfg.optimizer) (ac/model.py:103-105): Adam, SGD, RMSprop, AdamW
@@ -94,9 +125,9 @@ class A2CNetwork:
         self.target_update_interval_or_tau = _get(cfg, "target_update_interval_or_tau", 200)
         self.standardise_returns = bool(_get(cfg, "standardise_returns", False))
         self.centralised_critic = bool(_get(critic, "centralised", False))  # MAA2C / MAPPO (model.py:62-66)
-        self.spec = _hip.NetSpec(P, obs_dims[0], Hk, act_dims[0], self.sharing, wide=wide, n_hidden=len(ha))  # wide: actors and critics on the GEMM path
+        self.spec = _hip.NetSpec(P, D_all, Hk, A_all, self.sharing, wide=wide, n_hidden=len(ha))  # wide: actors and critics on the GEMM path
         # the critics' view of the same shape under THEIR agent -> network map (get_value's forward rows, state_dict keys)
-        self.critic_spec = _hip.NetSpec(P, obs_dims[0], Hk, act_dims[0], self.critic_sharing, wide=wide, n_hidden=len(hc))
+        self.critic_spec = _hip.NetSpec(P, D_all, Hk, A_all, self.critic_sharing, wide=wide, n_hidden=len(hc))
         cdims = [self.n_agents * self.spec.obs_dim] * P if self.centralised_critic else list(obs_dims)  # critic_obs_shape (model.py:63-65)
         if self.sharing is not None:  # one network per distinct index, in order of first appearance (utils/models.py:209-240)
             first = [self.sharing.index(k) for k in range(max(self.sharing) + 1)]
@@ -109,12 +140,19 @@ class A2CNetwork:
         if self.actor_recurrent:  # RNNNetwork inits (utils/models.py:83-94); init_flat_gru_params draws one set per call
             a0 = init_flat_gru_params(obs_dims, ha[0], act_dims, _get(actor, "use_orthogonal_init", True), sets=1, num_layers=self.rnn_layers["actor"])[0]
             a0 = pad_gru_blocks(a0, obs_dims[0], ha[0], act_dims[0], Hk, self.rnn_layers["actor"])
+        elif self.hetero:
+            a0 = _init_blocks_io_padded(obs_dims, ha, act_dims, _get(actor, "use_orthogonal_init", True), D_all, A_all)
+            a0 = pad_blocks(a0, D_all, ha, A_all, Hk)
         else:
             a0 = _init_blocks(obs_dims, ha, act_dims, _get(actor, "use_orthogonal_init", True))
             a0 = pad_blocks(a0, obs_dims[0], ha, act_dims[0], Hk)
         if self.critic_recurrent:
             c0 = init_flat_gru_params(cdims, hc[0], [1] * K, _get(critic, "use_orthogonal_init", True), sets=2, num_layers=self.rnn_layers["critic"])[0]  # critic, then the target's draws
             c0 = pad_gru_blocks(c0, cdims[0], hc[0], 1, Hk, self.rnn_layers["critic"])
+        elif self.hetero:
+            c0 = _init_blocks_io_padded(cdims, hc, [1] * K, _get(critic, "use_orthogonal_init", True), D_all, 1)
+            _init_blocks_io_padded(cdims, hc, [1] * K, _get(critic, "use_orthogonal_init", True), D_all, 1)  # target: drawn, then overwritten
+            c0 = pad_blocks(c0, D_all, hc, 1, Hk)
         else:
             c0 = _init_blocks(cdims, hc, [1] * K, _get(critic, "use_orthogonal_init", True))
             _init_blocks(cdims, hc, [1] * K, _get(critic, "use_orthogonal_init", True))  # target: drawn, then overwritten (soft_update(1.0))
@@ -183,8 +221,40 @@ class A2CNetwork:
     def forward(self, inputs, rnn_hxs, masks):
         raise NotImplementedError("Forward not implemented. Use act, get_value, get_target_value or evaluate_actions instead.")
 
+    # ---- agents of different sizes (self.hetero): rows zero-padded to the widest, missing actions masked ------------------------------------
+    def _pad_obs(self, t, d):
+        t = torch.as_tensor(t, dtype=torch.float32)
+        D = self.spec.obs_dim
+        return t if d == D else torch.cat([t, t.new_zeros(*t.shape[:-1], D - d)], dim=-1)
+
+    def _own_actions(self, device):
+        """[P][A] f32: 1 where agent p has the action"""
+        m = getattr(self, "_own_actions_mask", None)
+        if m is None or m.device != torch.device(device):
+            m = self._own_actions_mask = (torch.arange(self.spec.n_actions)[None, :] < torch.tensor(self.act_dims)[:, None]).float().to(device)
+        return m
+
+    def _hetero_batch(self, batch):
+        """the reference's Batch for agents of different sizes (obss [T+1, N, sum d_p]; ac/train.py:120-168) -> the kernels' layout
+        (obss [T+1, N, P * D], zero columns behind each agent's own) with the actions an agent does not have masked in action_masks"""
+        dev = self.device
+        obss = batch.obss.to(dev)
+        D, P = self.spec.obs_dim, self.n_agents
+        idx = getattr(self, "_obs_cols", None)
+        if idx is None:
+            idx = self._obs_cols = torch.cat([p * D + torch.arange(d) for p, d in enumerate(self.obs_dims)]).to(dev)
+        wide_obs = obss.new_zeros(*obss.shape[:-1], P * D)
+        wide_obs.index_copy_(-1, idx, obss)
+        own = self._own_actions(dev)  # [P][A]
+        masks = getattr(batch, "action_masks", None)
+        T1, N = obss.shape[0], obss.shape[1]
+        masks = own.expand(T1, N, P, -1).contiguous() if masks is None else (masks.to(dev).float() * own).contiguous()
+        return batch._replace(obss=wide_obs, action_masks=masks)
+
     def _rows(self, inputs):
         """list of P tensors [..., D] -> contiguous [P][n][D] on the device"""
+        if self.hetero:
+            inputs = [self._pad_obs(i, d) for i, d in zip(inputs, self.obs_dims)]
         x = torch.stack([torch.as_tensor(i, dtype=torch.float32) for i in inputs]).to(self.device)
         lead = x.shape[1:-1]
         return x.reshape(self.n_agents, -1, x.shape[-1]).contiguous(), lead
@@ -202,6 +272,13 @@ class A2CNetwork:
             lg = out[:, 0]
         else:
             lg = self.logits(inputs)
+        if self.hetero:  # an agent's logits are its first act_dims[p]: the rest never get sampled
+            own = self._own_actions(lg.device).reshape(self.n_agents, *([1] * (lg.dim() - 2)), -1)
+            if action_mask is not None:  # (given per agent at ITS size)
+                action_mask = [torch.cat([torch.as_tensor(x, dtype=torch.float32), torch.zeros(*np.shape(x)[:-1], self.spec.n_actions - a)], dim=-1)
+                               for x, a in zip(action_mask, self.act_dims)]
+            else:
+                lg = lg * own + (1 - own) * -1e8
         if action_mask is not None:  # get_dist (model.py:135-145): one mask per agent, shaped like that agent's logits
             m = torch.stack([torch.as_tensor(x, dtype=torch.float32) for x in action_mask]).to(lg.device).reshape(lg.shape)
             lg = lg * m + (1 - m) * -1e8
@@ -279,6 +356,8 @@ class A2CNetwork:
         stepped on the caller's stream, the critics' slice on their stream behind the deferred backward pass, through the exchange's second
         lane (attach_grad_sync; without one, or when some rank has no masked stream, the whole update stays on the caller's stream)."""
         up = self.updater
+        if self.hetero:
+            batch = self._hetero_batch(batch)
         if grad_sync is not None and not self._split_exchange:
             overlap = False
         m = up.a2c_loss_grad(batch, defer_critic=overlap)  # (overlap="force": wherever it is possible, not only where it pays)
@@ -317,7 +396,13 @@ class A2CNetwork:
             for i in range(block.shape[0]):
                 cin = S.n_agents * S.obs_dim if (self.centralised_critic and prefix != "actor") else S.obs_dim
                 if not (self.actor_recurrent if prefix == "actor" else self.critic_recurrent):  # the live tensors inside the (possibly zero-padded) blocks
+                    last = 2 * len(self.live_hidden[prefix])  # network.{last}: the output layer
                     for name, view in block_views(block[i], cin, self.live_hidden[prefix], A, S.hidden):
+                        if self.hetero:  # the agent's own input columns / output rows of the (max D, max A) layout
+                            if name == "network.0.weight":
+                                view = view[:, :self.obs_dims[i]]
+                            elif prefix == "actor" and name.startswith(f"network.{last}."):
+                                view = view[:self.act_dims[i]]
                         out[f"{prefix}.{group}.{i}.{name}"] = view
                     continue
                 for name, view, shape in gru_block_views(block[i], cin, self.live_hidden[prefix][0], A, S.hidden, self.rnn_layers[prefix]):
@@ -360,6 +445,8 @@ class PPONetwork(A2CNetwork):
     def update_async(self, batch, step, grad_sync=None, world=1, overlap=False):
         """overlap: accepted for the drivers' uniform call; every epoch's forward passes need both networks, nothing is deferred"""
         up = self.updater
+        if self.hetero:
+            batch = self._hetero_batch(batch)
         up.ppo_prepare(batch)
         acc = torch.zeros(5, device=self.device)
         for _ in range(self.num_epochs):

@@ -237,7 +237,10 @@ class QNetwork:
         Hk = recurrent_width(hidden)[1] if use_rnn else compiled_width(hidden)  # the width the kernels run at (the layers zero-padded to it, see pad_blocks / pad_gru_blocks)
         hidden_k = [Hk] * len(hidden)
         if len(set(obs_dims)) != 1 or len(set(act_dims)) != 1:
-            raise NotImplementedError("agents with different observation / action sizes")
+            # (the reference's own learner cannot train such agents either: ReplayBuffer.sample stacks the agents' observation arrays,
+            # dqn/train.py:98, and _compute_loss stacks their value tensors, dqn/model.py:128; the actor-critic classes take them)
+            raise NotImplementedError("agents with different observation / action sizes: the DQN learners stack the agents' tensors (as the "
+                                      "reference's do, dqn/model.py:128); codebase_amd.ac.model takes such agents")
         if str(device) == "cpu":
             raise _hip.MarlHipError("codebase_amd.dqn.model.QNetwork runs on the GPU only: set algorithm.model.device=cuda")
         get = (lambda k, d=None: cfg[k] if k in cfg else d) if isinstance(cfg, dict) else (lambda k, d=None: getattr(cfg, k, d))

@@ -102,6 +102,52 @@ def fixture(ref_ac_model, ref_ac_train, name, cls, P, D, H, N, seed, masked=Fals
     print(name, "metrics", np.array(metrics).round(5).tolist())
 
 
+def hetero_fixture(ref_ac_model, ref_ac_train, name, cls, obs_dims, act_dims, H, N, seed, **over):
+    """agents with different observation / action sizes (MultiAgentIndependentNetwork builds each agent's network from its own sizes,
+    utils/models.py:133-155; A2CNetwork splits the concatenated observation row by them, ac/model.py:115): the state_dict before and after
+    each of 3 updates (tensor by tensor: the agents' blocks have different sizes), metrics, the batches in the reference's layout
+    (obss [T+1, N, sum d_p]; actions of agent p below act_dims[p])"""
+    T, P = 25, len(obs_dims)
+    torch.manual_seed(seed)
+    cfg = Cfg(optimizer="Adam", lr=3e-4, gamma=0.99, grad_clip=False, n_steps=5, entropy_coef=0.001, value_loss_coef=0.5,
+              standardise_returns=False, target_update_interval_or_tau=200, num_epochs=4, ppo_clip=0.2)
+    cfg.update(over)
+    net_cfg = dict(layers=[H, H], parameter_sharing=False, use_orthogonal_init=True, use_rnn=False)
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = cls([Box(d) for d in obs_dims], [Discrete(a) for a in act_dims], cfg, Cfg(net_cfg), Cfg(dict(net_cfg, centralised=False)), "cpu")
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for p in list(net.actor.parameters()) + list(net.critic.parameters()):
+            p.add_(0.05 * torch.randn(p.shape, generator=g))
+        for p in net.target_critic.parameters():
+            p.add_(0.08 * torch.randn(p.shape, generator=g))
+    out = dict(P=P, T=T, N=N, H=H, obs_dims=np.array(obs_dims), act_dims=np.array(act_dims), state_dict_keys=np.array(list(net.state_dict().keys())),
+               n_steps=cfg.n_steps, gamma=cfg.gamma, entropy_coef=cfg.entropy_coef, value_loss_coef=cfg.value_loss_coef, num_epochs=cfg.num_epochs,
+               ppo_clip=cfg.ppo_clip)
+    for k, v in net.state_dict().items():
+        out[f"sd0/{k}"] = v.detach().numpy().copy()
+    Dm, Am = max(obs_dims), max(act_dims)
+    steps, metrics = [0, 250, 400], []
+    for i, st in enumerate(steps):
+        b = synthetic_batch(P, T, N, Dm, Am, seed=seed + 100 + i)  # the homogeneous generator at the widest sizes, cut down per agent
+        obss = torch.cat([b["obss"][..., p * Dm:p * Dm + d] for p, d in enumerate(obs_dims)], dim=-1)
+        acts = torch.stack([b["actions"][..., p] % a for p, a in enumerate(act_dims)], dim=-1)
+        m = net.update(ref_ac_train.Batch(obss, acts, b["rewards"], b["dones"], b["filled"], None), st)
+        metrics.append([m["loss"], m["actor_loss"], m["value_loss"], m["entropy"]])
+        for k, v in (("obss", obss), ("actions", acts), ("rewards", b["rewards"]), ("dones", b["dones"]), ("filled", b["filled"])):
+            out[f"batch{i}_{k}"] = v.numpy()
+        for k, v in net.state_dict().items():
+            out[f"sd{i + 1}/{k}"] = v.detach().numpy().copy()
+    out["metrics"], out["steps"] = np.array(metrics, np.float64), np.array(steps)
+    np.savez_compressed(os.path.join(OUT, name), **out)
+    print(name, "metrics", np.array(metrics).round(5).tolist())
+
+
+def hetero(ram, rat):
+    hetero_fixture(ram, rat, "learner_a2c_hetero_H64.npz", ram.A2CNetwork, obs_dims=[15, 18], act_dims=[6, 5], H=64, N=12, seed=2600)
+    hetero_fixture(ram, rat, "learner_ppo_hetero_h48.npz", ram.PPONetwork, obs_dims=[12, 18, 15], act_dims=[4, 6, 6], H=48, N=9, seed=2700)
+
+
 def stacked(ram, rat):
     """round 6: use_rnn with layers [h] * (L + 1) - nn.GRU(num_layers=L) in both families (utils/models.py:74-90)"""
     fixture(ram, rat, "learner_a2c_gru_L2_h24.npz", ram.A2CNetwork, P=2, D=15, H=24, N=12, seed=2100, use_rnn=True, layers=[24, 24, 24])
@@ -126,6 +172,9 @@ if __name__ == "__main__":
     if "--stacked-only" in sys.argv:
         stacked(ram, rat)
         sys.exit(0)
+    if "--hetero-only" in sys.argv:
+        hetero(ram, rat)
+        sys.exit(0)
 
     fixture(ram, rat, "learner_a2c_H64.npz", ram.A2CNetwork, P=2, D=15, H=64, N=12, seed=500)
     fixture(ram, rat, "learner_a2c_clip_H128.npz", ram.A2CNetwork, P=3, D=18, H=128, N=9, seed=600, grad_clip=0.5, n_steps=3)
@@ -145,3 +194,4 @@ if __name__ == "__main__":
     fixture(ram, rat, "learner_a2c_rnn_actor_ff_critic_H64.npz", ram.A2CNetwork, P=2, D=15, H=64, N=12, seed=1900, actor_rnn=True, critic_rnn=False)
     fixture(ram, rat, "learner_ppo_ff_actor_rnn_critic_H64.npz", ram.PPONetwork, P=2, D=15, H=64, N=10, seed=2000, actor_rnn=False, critic_rnn=True)
     stacked(ram, rat)
+    hetero(ram, rat)
