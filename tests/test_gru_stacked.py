@@ -571,3 +571,34 @@ def test_hip_one_stacked_recurrent_family_next_to_a_feed_forward_one_matches_ref
                                   (net.target_critic_params, g[f"target{i + 1}"], 1, which == "critic")):
             diff = np.abs(live(got, D, a, rec) - want)
             assert diff.max() <= 5e-5 and (diff > 5e-6).mean() <= 1e-4, (i, diff.max(), (diff > 5e-6).sum())
+
+
+# ---- at the bench batch: a stack against the float64 port ---------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("H,L,mode", [(128, 2, "idqn"), (64, 3, "vdn")])
+def test_stack_at_the_bench_batch_vs_float64_port(H, L, mode):
+    """B = 4096 sequences x 26 steps x 2 agents (the headline's batch, 212,992 rows through every layer), reference-default width 128 with two
+    stacked layers and width 64 with three: loss within north_star's 1e-5 of the float64 port, every gradient entry within 3e-4 of the
+    largest (tests/test_gpu_at_size_vs_oracle.py's bound for the feed-forward learners at this size)"""
+    from codebase_amd import hip as h
+    from oracle import dqn_port as dp
+    from tests.test_gpu_at_size_vs_oracle import assert_grad_at_size
+
+    P, D, A, T, B = 2, 15, 6, 25, 4096
+    gen = torch.Generator().manual_seed(900 + L)
+    params = 0.12 * torch.randn(P, gp.nparams(D, H, A, L), generator=gen)
+    target = params + 0.05 * torch.randn(P, gp.nparams(D, H, A, L), generator=gen)
+    batch = dp.synthetic_batch(P, T, B, D, A, seed=70 + L)
+    batch["obss"] = batch["obss"] * 0.25
+    if mode == "vdn":
+        batch["rewards"][1:] = batch["rewards"][0]
+    pr = params.double().requires_grad_(True)
+    ref = gp.compute_loss(pr, target.double(), {k: (v.double() if v.is_floating_point() else v) for k, v in batch.items()}, 0.99, True, D, H, A, mode=mode)
+    ref.backward()
+    spec = h.NetSpec(P, D, H, A, n_hidden=L + 1)
+    hb = h.Batch(*(batch[k].cuda().contiguous() for k in ("obss", "actions", "rewards", "dones", "filled")), None)
+    loss, grad = h.gru_loss_grad(spec, params.cuda(), target.cuda(), hb, mode=1 if mode == "vdn" else 0)
+    rel = abs(float(loss.cpu()[0]) - ref.item()) / abs(ref.item())
+    print(f"[at-size] stacked GRU {mode} H{H} L{L} B{B}: loss {float(loss.cpu()[0]):.7f} vs float64 {ref.item():.7f} (relative {rel:.2e})")
+    assert rel <= 1e-5
+    assert_grad_at_size(grad.cpu().numpy(), pr.grad.numpy(), f"stacked GRU {mode} H{H} L{L} gradient")
