@@ -79,6 +79,8 @@ def main():
             shutil.copy(f, os.path.join(DST, out))
     if os.path.exists(os.path.join(SRC, "matrix.jsonl")):
         shutil.copy(os.path.join(SRC, "matrix.jsonl"), os.path.join(DST, PFX + "_bench_matrix.jsonl"))
+    if os.path.exists(os.path.join(SRC, "matrix_h64.jsonl")):  # every BASELINE-config row after the reduce kernel's record loop changed
+        shutil.copy(os.path.join(SRC, "matrix_h64.jsonl"), os.path.join(DST, PFX + "_bench_rows_final_tree.jsonl"))
     if os.path.exists(os.path.join(SRC, "matrix_ia2c.jsonl")):  # the actor-critic rows again on the tree that carries stacked GRU layers
         shutil.copy(os.path.join(SRC, "matrix_ia2c.jsonl"), os.path.join(DST, PFX + "_bench_matrix_ac_rows_final_tree.jsonl"))
     if os.path.exists(os.path.join(SRC, "mfma_ubench.txt")):
@@ -172,8 +174,8 @@ def main():
                                      "traffic_bytes": sum(v["traffic_bytes"] * v["launches_profiled"] for v in parts) / n_upd,
                                      "updates_profiled": n_upd, "algorithmic_bytes": alg,
                                      "source_files": list(files), "source_hash": bench.kernel_source_hash(files)}
-            hp2 = os.path.join(SRC, f"head{sfx}.txt")  # a workload profiled again later than the rest (scripts/collect_profiles_r06_ia2c.sh)
-            if sfx and os.path.exists(hp2):
+            hp2 = os.path.join(SRC, f"head{sfx or '_default'}.txt")  # a workload profiled again later than the rest (scripts/collect_profiles_r06_*.sh)
+            if os.path.exists(hp2):
                 out["workloads"][key]["head"] = open(hp2).read().strip()
     json.dump(out, open(os.path.join(DST, PFX + "_pmc_traffic.json"), "w"), indent=1)
     # ---- SQ counters
